@@ -1,0 +1,517 @@
+"""Generate tests/golden/*.npz by driving the UNMODIFIED reference (dev container only).
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+The reference has no tests or known-answer vectors of its own, so
+these fixtures are the pin for the oracle (and, through it, for the HIP kernels).  Each
+fixture stores the host-RNG draws the reference consumed (replay indices, REDQ subsets,
+normal draws) and the reference's outputs; the big inputs (buffers, weights) are rebuilt
+from numpy seeds by ``tests/synth.py`` + ``oracle/ssac_oracle.py::make_mlp``.
+
+While generating, the oracle is run on the same inputs and the maximum deviation from the
+reference is printed (and asserted), i.e. this script is also the oracle-vs-reference check.
+"""
+import copy
+import math
+import os
+import random
+import sys
+import types
+from itertools import chain
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import ref_harness  # noqa: E402
+import ssac_oracle as orc  # noqa: E402
+import synth  # noqa: E402
+
+ref = ref_harness.import_reference()
+rl = ref.learning
+rlu = ref.learning_utils
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(4)
+
+
+class RefIdentityEncoder(ref.nets.Encoder):
+    """Same role as experiments/gym/train_gym.py:18-28 (built here; scripts need gym)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self._dim = dim
+
+    @property
+    def embedding_dim(self):
+        return self._dim
+
+    def forward(self, obs_dict):
+        return obs_dict["obs"]
+
+
+def load_linear(lin, w, b):
+    lin.weight.data.copy_(w)
+    lin.bias.data.copy_(b)
+
+
+def load_mlp(mod, p, names):
+    for (wk, bk), name in zip((("w1", "b1"), ("w2", "b2"), ("w3", "b3")), names):
+        load_linear(getattr(mod, name), p[wk], p[bk])
+
+
+def build_pair(cfg):
+    """(reference agent, oracle agent) holding identical seeded weights."""
+    oa = orc.AgentOracle(state_dim=cfg["obs"], act_dim=cfg["act"], hidden=cfg["hidden"],
+                         num_critics=cfg["N"], ensemble_size=cfg["E"], discrete=cfg["discrete"],
+                         actor_kind=cfg["actor"], log_std_low=cfg["lo"], log_std_high=cfg["hi"],
+                         popart=cfg["popart"], seed=cfg["seed"])
+    actor_cls = {"stochastic": ref.nets.mlps.ContinuousStochasticActor,
+                 "deterministic": ref.nets.mlps.ContinuousDeterministicActor,
+                 "discrete": ref.nets.mlps.DiscreteActor}[cfg["actor"]]
+    critic_cls = ref.nets.mlps.DiscreteCritic if cfg["discrete"] else ref.nets.mlps.ContinuousCritic
+    ra = ref.Agent(act_space_size=cfg["act"], encoder=RefIdentityEncoder(cfg["obs"]),
+                   actor_network_cls=actor_cls, critic_network_cls=critic_cls,
+                   discrete=cfg["discrete"], ensemble_size=cfg["E"], num_critics=cfg["N"],
+                   ucb_bonus=0.0, hidden_size=cfg["hidden"], auto_rescale_targets=cfg["popart"],
+                   log_std_low=cfg["lo"], log_std_high=cfg["hi"])
+    last = {"stochastic": "fc3", "deterministic": "out", "discrete": "act_p"}[cfg["actor"]]
+    for i in range(cfg["E"]):
+        load_mlp(ra.actors[i], oa.actors[i], ("fc1", "fc2", last))
+        for j in range(cfg["N"]):
+            load_mlp(ra.critics[i].nets[j], oa.critics[i][j], ("fc1", "fc2", "out"))
+        if cfg["popart"]:
+            ms = cfg.get("popart_min_steps", 1000)
+            ra.popart[i].min_steps = ms
+            oa.popart[i].min_steps = ms
+    ra.to(ref.device)
+    ra.train()
+    return ra, oa
+
+
+def ref_params(ra, cfg):
+    """flat list in the oracle's order (critics, then actors)."""
+    crit = [p for i in range(cfg["E"]) for j in range(cfg["N"])
+            for p in ra.critics[i].nets[j].parameters()]
+    act = [p for i in range(cfg["E"]) for p in ra.actors[i].parameters()]
+    return crit, act
+
+
+def maxdiff(a_list, b_list):
+    return max(float((a.detach() - b.detach()).abs().max()) for a, b in zip(a_list, b_list))
+
+
+def run_case(name, cfg):
+    print(f"== {name}")
+    torch.manual_seed(cfg["seed"])
+    np.random.seed(cfg["seed"])
+    random.seed(cfg["seed"])
+    B, E, N = cfg["B"], cfg["E"], cfg["N"]
+    s, a, r, s1, d = synth.synth_transitions(cfg["rows"], cfg["obs"], cfg["act"], cfg["discrete"],
+                                            seed=cfg["seed"] + 100, n_actions=cfg["act"])
+    rbuf = ref.replay.ReplayBuffer(cfg["cap"])
+    rbuf.load_experience(s, a, r, s1, d)
+    obuf = orc.ReplayOracle(cfg["cap"])
+    obuf.load_experience(s, a, r, s1, d)
+
+    ra, oa = build_pair(cfg)
+    rt = copy.deepcopy(ra)
+    oa.requires_grad_(True)
+    ot = oa.clone()
+
+    # optimizers exactly as main.py:188-239
+    r_copt = torch.optim.Adam(chain(*(c.parameters() for c in ra.critics)), lr=cfg["lr"],
+                              weight_decay=0, betas=(0.9, 0.999))
+    r_aopt = torch.optim.Adam(chain(*(ac.parameters() for ac in ra.actors)), lr=cfg["lr"],
+                              weight_decay=0, betas=(0.9, 0.999))
+    r_eopt = torch.optim.Adam(ra.encoder.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    init_alpha = max(cfg["init_alpha"], 1e-15)
+    r_las, r_lopts, o_las, o_lopts = [], [], [], []
+    for _ in range(E):
+        la = torch.Tensor([math.log(init_alpha)]).to(ref.device)
+        la.requires_grad = True
+        r_las.append(la)
+        r_lopts.append(torch.optim.Adam([la], lr=cfg["alpha_lr"], betas=(0.5, 0.999)))
+        ola = torch.tensor([math.log(init_alpha)], requires_grad=True)
+        o_las.append(ola)
+        o_lopts.append(orc.AdamOracle([ola], lr=cfg["alpha_lr"], betas=(0.5, 0.999)))
+    o_copt = orc.AdamOracle(oa.critic_params(), lr=cfg["lr"])
+    o_aopt = orc.AdamOracle(oa.actor_params(), lr=cfg["lr"])
+    o_eopt = orc.AdamOracle([], lr=1e-4)
+    target_entropy = (-math.log(1.0 / cfg["act"]) * 0.98) if cfg["discrete"] else -float(cfg["act"])
+
+    r_aug = ref.augmentations.AugmentationSequence([ref.augmentations.IdentityAug(B)])
+    o_aug = orc.AugOracle("identity", B)
+    if cfg["noise"]:
+        space = types.SimpleNamespace(low=-np.ones(cfg["act"], np.float32),
+                                      high=np.ones(cfg["act"], np.float32))
+        rproc = rlu.GaussianExplorationNoise(space, start_scale=cfg["noise"]["scale"],
+                                             final_scale=cfg["noise"]["scale"] * 0.1,
+                                             steps_annealed=1000)
+        nscale, nclip = cfg["noise"]["scale"], cfg["noise"]["clip"]
+    else:
+        rproc, nscale, nclip = None, None, None
+
+    # capture the reference's TD targets without touching its source
+    captured = []
+    orig_td = rlu.compute_td_targets
+
+    def td_spy(*args, **kw):
+        out = orig_td(*args, **kw)
+        captured.append(out[0].detach().clone())
+        return out
+    rlu.compute_td_targets = td_spy
+
+    stochastic = (cfg["actor"] == "stochastic")
+    rec = {}
+    worst = 0.0
+    upd = 0
+    for cyc in range(cfg["cycles"]):
+        for k in range(cfg["utd"]):
+            # replicate the host draws the reference is about to make, then rewind
+            st, pst = torch.get_rng_state(), random.getstate()
+            idxs, epss, noises, subsets = [], [], [], []
+            for i in range(E):
+                idxs.append(torch.randint(len(rbuf), (B,)).numpy())
+                if stochastic:
+                    epss.append(torch.randn(B, cfg["act"]))
+                if cfg["noise"]:
+                    noises.append(torch.randn(B, cfg["act"]))
+                subsets.append(random.sample(range(N), k=cfg["n"]))
+            torch.set_rng_state(st)
+            random.setstate(pst)
+
+            captured.clear()
+            rlogs, rdicts = rl.critic_update(
+                buffer=rbuf, agent=ra, target_agent=rt, critic_optimizer=r_copt,
+                encoder_optimizer=r_eopt, log_alphas=r_las, batch_size=B, gamma=cfg["gamma"],
+                critic_clip=cfg["clip"], encoder_clip=cfg["clip"],
+                target_critic_ensemble_n=cfg["n"], weighted_bellman_temp=cfg["temp"],
+                weight_type=cfg["weight_type"], pop=cfg["pop"], augmenter=r_aug, encoder_lambda=0,
+                aug_mix=0.0, discrete=cfg["discrete"], random_process=rproc, noise_clip=nclip,
+                per=False, update_priorities=False, dr3_coeff=0.0)
+            ologs, odicts = orc.critic_update(
+                obuf, oa, ot, o_copt, o_eopt, o_las, B, cfg["gamma"], cfg["clip"], cfg["clip"],
+                cfg["n"], cfg["temp"], cfg["weight_type"], cfg["pop"], o_aug, aug_mix=0.0,
+                noise_scale=nscale, noise_clip=nclip, idx_list=idxs,
+                eps_list=epss if stochastic else None,
+                noise_list=noises if cfg["noise"] else None, subset_list=subsets)
+            for i in range(E):
+                assert np.array_equal(rdicts[i]["priority_idxs"], idxs[i]), "index stream mismatch"
+                dtd = float((captured[i] - odicts[i]["td_target"]).abs().max())
+                worst = max(worst, dtd)
+                rec[f"u{upd}_idx{i}"] = idxs[i]
+                rec[f"u{upd}_subset{i}"] = np.array(subsets[i], np.int64)
+                if stochastic:
+                    rec[f"u{upd}_eps{i}"] = epss[i].numpy()
+                if cfg["noise"]:
+                    rec[f"u{upd}_noise{i}"] = noises[i].numpy()
+                rec[f"u{upd}_td{i}"] = captured[i].numpy()
+            for key, val in rlogs.items():
+                if key.startswith("gradients/"):
+                    continue
+                v = float(val)
+                rec[f"u{upd}_log:{key}"] = np.float64(v)
+                dv = abs(v - float(ologs[key]))
+                assert dv <= 2e-4 * max(1.0, abs(v)), (key, v, ologs[key])
+            if cfg["popart"]:
+                for i in range(E):
+                    pr, po = ra.popart[i], oa.popart[i]
+                    stt = np.array([float(pr.mu), float(pr.nu), float(pr.w), float(pr.b),
+                                    float(pr.sigma), pr._t], np.float64)
+                    rec[f"u{upd}_popart{i}"] = stt
+                    ost = po.state()
+                    assert abs(ost["mu"] - stt[0]) < 1e-6 and abs(ost["w"] - stt[2]) < 1e-5
+            # polyak (main.py:409-414)
+            if (k + cyc) % cfg["target_delay"] == 0:
+                for ac, tc in zip(ra.critics, rt.critics):
+                    rlu.soft_update(tc, ac, cfg["tau"])
+                orc.soft_update(ot.critic_params(), oa.critic_params(), cfg["tau"])
+                rec[f"u{upd}_polyak"] = np.int64(1)
+            else:
+                rec[f"u{upd}_polyak"] = np.int64(0)
+            upd += 1
+
+        # online actor update on the last critic batch (main.py:489-511)
+        st = torch.get_rng_state()
+        aeps, anoise = [], []
+        for i in range(E):
+            if not cfg["discrete"]:
+                aeps.append(torch.randn(B, cfg["act"]))
+            if cfg["noise"]:
+                anoise.append(torch.randn(B, cfg["act"]))
+        torch.set_rng_state(st)
+        ralogs = rl.online_actor_update(
+            buffer=rbuf, agent=ra, pop=cfg["pop"], actor_optimizer=r_aopt, log_alphas=r_las,
+            batch_size=B, aug_mix=0.0, clip=cfg["clip"], augmenter=r_aug, per=False,
+            discrete=cfg["discrete"], random_process=rproc, noise_clip=nclip,
+            premade_replay_dicts=rdicts, use_baseline=False)
+        oalogs = orc.online_actor_update(oa, o_aopt, o_las, odicts, cfg["pop"], cfg["clip"],
+                                         eps_list=aeps if aeps else None, noise_scale=nscale,
+                                         noise_clip=nclip, noise_list=anoise if anoise else None)
+        for i in range(E):
+            if aeps:
+                rec[f"a{cyc}_eps{i}"] = aeps[i].numpy()
+            if anoise:
+                rec[f"a{cyc}_noise{i}"] = anoise[i].numpy()
+        v = float(ralogs["losses/actor_pg_loss"])
+        rec[f"a{cyc}_log:losses/actor_pg_loss"] = np.float64(v)
+        assert abs(v - oalogs["losses/actor_pg_loss"]) <= 2e-4 * max(1.0, abs(v)), (v, oalogs)
+
+        if cfg["init_alpha"] > 0 and cfg["alpha_lr"] > 0:
+            st = torch.get_rng_state()
+            leps = []
+            for i in range(E):
+                if stochastic:
+                    leps.append(torch.randn(B, cfg["act"]))
+            torch.set_rng_state(st)
+            rllogs = rl.alpha_update(buffer=rbuf, agent=ra, optimizers=r_lopts, batch_size=B,
+                                     log_alphas=r_las, augmenter=r_aug, aug_mix=0.0,
+                                     target_entropy=target_entropy, premade_replay_dicts=rdicts,
+                                     discrete=cfg["discrete"])
+            ollogs = orc.alpha_update(oa, o_lopts, o_las, odicts, target_entropy,
+                                      eps_list=leps if leps else None)
+            for i in range(E):
+                if leps:
+                    rec[f"l{cyc}_eps{i}"] = leps[i].numpy()
+            for key, val in rllogs.items():
+                rec[f"l{cyc}_log:{key}"] = np.float64(val)
+                assert abs(val - ollogs[key]) <= 2e-4 * max(1.0, abs(val)), (key, val, ollogs[key])
+
+    rlu.compute_td_targets = orig_td
+    rc, rac = ref_params(ra, cfg)
+    rtc, _ = ref_params(rt, cfg)
+    dpar = max(maxdiff(rc, oa.critic_params()), maxdiff(rac, oa.actor_params()),
+               maxdiff(rtc, ot.critic_params()))
+    dla = max(abs(float(x) - float(y)) for x, y in zip(r_las, o_las))
+    print(f"   td max|diff| {worst:.3e}   params max|diff| {dpar:.3e}   log_alpha diff {dla:.3e}")
+    assert worst < 5e-4 and dpar < 5e-5 and dla < 1e-6
+
+    small = sum(p.numel() for p in rc) < 40000
+    for tag, plist in (("critic", rc), ("actor", rac), ("target_critic", rtc)):
+        if small:
+            rec[f"final_{tag}"] = np.concatenate([p.detach().numpy().ravel() for p in plist])
+        else:
+            vals = []
+            for p in plist:
+                flat = p.detach().numpy().ravel()
+                vals.append(flat[synth.fingerprint_indices(flat.size)])
+            rec[f"finalfp_{tag}"] = np.concatenate(vals)
+    # Adam moments of the critic optimizer (exp_avg / exp_avg_sq), fingerprinted
+    ms, vs = [], []
+    for p in rc:
+        stt = r_copt.state[p]
+        fi = synth.fingerprint_indices(p.numel())
+        ms.append(stt["exp_avg"].numpy().ravel()[fi])
+        vs.append(stt["exp_avg_sq"].numpy().ravel()[fi])
+    rec["finalfp_critic_m"] = np.concatenate(ms)
+    rec["finalfp_critic_v"] = np.concatenate(vs)
+    rec["final_log_alpha"] = np.array([float(x) for x in r_las], np.float64)
+    rec["n_updates"] = np.int64(upd)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
+
+
+def gen_indices():
+    print("== replay_indices")
+    rec = {}
+    for seed in (0, 7, 123):
+        for n in (1000, 100_000, 1_000_000):
+            torch.manual_seed(seed)
+            draws = np.stack([torch.randint(n, (512,)).numpy() for _ in range(3)])
+            rec[f"s{seed}_n{n}"] = draws
+            mine = orc.randint_from_raw32(orc.MT19937(seed).raw32(3 * 512), 0, n).reshape(3, 512)
+            assert np.array_equal(draws, mine), (seed, n)
+    # the buffer gather itself: reference storage vs oracle storage on wrapped pushes
+    s, a, r, s1, d = synth.synth_transitions(700, 5, 2, seed=3)
+    rb = ref.replay.ReplayBuffer(512)
+    ob = orc.ReplayOracle(512)
+    for lo in range(0, 700, 100):
+        sl = slice(lo, lo + 100)
+        rb.push({"obs": s["obs"][sl]}, a[sl], r[sl, None], {"obs": s1["obs"][sl]}, d[sl, None])
+        ob.push({"obs": s["obs"][sl]}, a[sl], r[sl, None], {"obs": s1["obs"][sl]}, d[sl, None])
+    torch.manual_seed(5)
+    (ro, ra_, rr, ro1, rd), ridx = rb.sample_uniform(64)
+    oo, oa_, or_, oo1, od = ob.gather(ridx)
+    assert torch.equal(ro["obs"].float(), oo["obs"]) and torch.equal(ra_, oa_)
+    assert torch.equal(rr, or_) and torch.equal(rd.float(), od) and len(rb) == len(ob) == 512
+    rec["wrap_idx"] = ridx
+    rec["wrap_obs"] = ro["obs"].numpy()
+    rec["wrap_next_obs"] = ro1["obs"].numpy()
+    rec["wrap_act"] = ra_.numpy()
+    rec["wrap_rew"] = rr.numpy()
+    rec["wrap_done"] = rd.numpy()
+    np.savez_compressed(os.path.join(OUT, "replay_indices.npz"), **rec)
+
+
+def gen_popart():
+    print("== popart")
+    rec = {}
+    rng = np.random.RandomState(5)
+    rp = ref.popart.PopArtLayer(beta=1e-2, min_steps=3)
+    op = orc.PopArtOracle(beta=1e-2, min_steps=3)
+    states, outs = [], []
+    for t in range(10):
+        v = torch.from_numpy((rng.standard_normal((64, 1)) * (1.0 + t) + 0.5 * t).astype(np.float32))
+        rec[f"v{t}"] = v.numpy()
+        rp.update_stats(v)
+        op.update_stats(v)
+        states.append([float(rp.mu), float(rp.nu), float(rp.w), float(rp.b), float(rp.sigma),
+                       rp._t, float(rp._stable)])
+        x = torch.linspace(-2, 2, 9).unsqueeze(1)
+        outs.append(torch.cat([rp(x), rp(x, normalized=False), rp.normalize_values(x)], 1).numpy())
+        o = op.state()
+        assert abs(o["mu"] - states[-1][0]) < 1e-6 and abs(o["b"] - states[-1][3]) < 1e-5
+        assert float(op.stable) == states[-1][6]
+    rec["states"] = np.array(states, np.float64)
+    rec["outs"] = np.stack(outs)
+    np.savez_compressed(os.path.join(OUT, "popart.npz"), **rec)
+
+
+def gen_aug():
+    print("== augmentations")
+    rec = {}
+    rng = np.random.RandomState(9)
+    B, C, H = 6, 3, 24
+    x0 = torch.from_numpy(rng.randint(0, 256, (B, C, H, H)).astype(np.float32))
+    x1 = torch.from_numpy(rng.randint(0, 256, (B, C, H, H)).astype(np.float32))
+    rec["x0"], rec["x1"] = x0.numpy(), x1.numpy()
+    # Drqv2: one shift draw shared by s and s'
+    torch.manual_seed(21)
+    seq = ref.augmentations.AugmentationSequence([ref.augmentations.Drqv2Aug(B)])
+    y0, y1 = seq({"obs": x0}, {"obs": x1})
+    shift = seq.aug_list[0].shift.clone()
+    rec["v2_shift"] = shift.numpy()
+    rec["v2_y0"], rec["v2_y1"] = y0["obs"].numpy(), y1["obs"].numpy()
+    torch.manual_seed(21)
+    oaug = orc.AugOracle("drqv2", B)
+    z0, z1 = oaug({"obs": x0}, {"obs": x1})
+    assert torch.equal(oaug.last, shift)
+    dv2 = max(float((z0["obs"] - y0["obs"]).abs().max()), float((z1["obs"] - y1["obs"]).abs().max()))
+    print(f"   drqv2 oracle vs reference max|diff| = {dv2:.3e} (0-255 scale)")
+    assert dv2 < 2e-3
+    # DrQ v1 without noise: exact integer crop of the reflection-padded image
+    torch.manual_seed(22)
+    seq = ref.augmentations.AugmentationSequence([ref.augmentations.DrqNoNoiseAug(B)])
+    y0, y1 = seq({"obs": x0}, {"obs": x1})
+    rec["v1_w1"], rec["v1_h1"] = seq.aug_list[0].w1.numpy(), seq.aug_list[0].h1.numpy()
+    rec["v1_y0"], rec["v1_y1"] = y0["obs"].numpy(), y1["obs"].numpy()
+    torch.manual_seed(22)
+    oaug = orc.AugOracle("drq_nonoise", B)
+    z0, z1 = oaug({"obs": x0}, {"obs": x1})
+    assert torch.equal(z0["obs"], y0["obs"]) and torch.equal(z1["obs"], y1["obs"])
+    # DrQ v1 with N(0,1) noise (noise drawn after the crop, s first then s')
+    torch.manual_seed(23)
+    seq = ref.augmentations.AugmentationSequence([ref.augmentations.DrqAug(B)])
+    st_after_ctor = None
+    y0, y1 = seq({"obs": x0}, {"obs": x1})
+    torch.manual_seed(23)
+    oaug = orc.AugOracle("drq", B)
+    z0, z1 = oaug({"obs": x0}, {"obs": x1})
+    dn = max(float((z0["obs"] - y0["obs"]).abs().max()), float((z1["obs"] - y1["obs"]).abs().max()))
+    print(f"   drq(noise) oracle vs reference max|diff| = {dn:.3e}")
+    assert dn < 1e-5
+    rec["v1n_y0"], rec["v1n_y1"] = y0["obs"].numpy(), y1["obs"].numpy()
+    rec["v1n_w1"], rec["v1n_h1"] = seq.aug_list[0].w1.numpy(), seq.aug_list[0].h1.numpy()
+    # the noise tensors themselves (so a device path can be checked with explicit noise)
+    torch.manual_seed(23)
+    orc.drq_draw_offsets(B)
+    orc.drq_draw_offsets(B)
+    rec["v1n_noise0"] = torch.randn(B, C, H, H).numpy()
+    rec["v1n_noise1"] = torch.randn(B, C, H, H).numpy()
+    # aug_mix row mixing through sample_move_and_augment (learning_utils.py:200-206)
+    np.savez_compressed(os.path.join(OUT, "augmentations.npz"), **rec)
+
+
+def gen_nets():
+    print("== nets")
+    rec = {}
+    rng = np.random.RandomState(31)
+    # ensemble-Q known answers at the metric shape
+    N, B, obs, act, Hd = 10, 512, 17, 6, 256
+    crit = [orc.make_mlp(rng, obs + act, Hd, 1) for _ in range(N)]
+    s = torch.from_numpy(rng.standard_normal((B, obs)).astype(np.float32))
+    a = torch.from_numpy(rng.uniform(-1, 1, (B, act)).astype(np.float32))
+    mods = []
+    for p in crit:
+        m = ref.nets.mlps.ContinuousCritic(obs, act, Hd)
+        load_mlp(m, p, ("fc1", "fc2", "out"))
+        mods.append(m)
+    with torch.no_grad():
+        q_ref = torch.stack([m(s, a) for m in mods], 0).squeeze(-1)
+        q_orc = torch.stack([orc.critic_q(p, s, a) for p in crit], 0).squeeze(-1)
+    assert float((q_ref - q_orc).abs().max()) < 1e-5
+    rec["ensq_q"] = q_ref.numpy()
+    rec["ensq_seed"] = np.int64(31)
+    # tanh-normal sample / log-prob
+    for tag, lo, hi in (("redq", -5.0, 2.0), ("default", -10.0, 2.0)):
+        out = torch.from_numpy((rng.standard_normal((64, 12)) * 1.5).astype(np.float32))
+        eps = torch.from_numpy(rng.standard_normal((64, 6)).astype(np.float32))
+        dist = ref.nets.distributions.create_tanh_normal(out, lo, hi)
+        u = dist.loc + dist.scale * eps
+        a_ref = dist.transforms[0](u)  # fills the transform cache like sample()/rsample()
+        lp_ref = dist.log_prob(a_ref).sum(-1, keepdim=True)
+        a_o, lp_o = orc.tanh_normal_sample(out, lo, hi, eps)
+        assert float((a_ref - a_o).abs().max()) < 1e-6 and float((lp_ref - lp_o).abs().max()) < 2e-4
+        rec[f"tn_{tag}_out"], rec[f"tn_{tag}_eps"] = out.numpy(), eps.numpy()
+        rec[f"tn_{tag}_a"], rec[f"tn_{tag}_logp"] = a_ref.numpy(), lp_ref.numpy()
+    # pixel encoders (forward)
+    for kind, ch, emb in (("big", 9, 50), ("small", 4, 128)):
+        p = orc.make_conv_encoder(np.random.RandomState(40 + ch), kind, ch, emb)
+        cls = ref.nets.cnns.BigPixelEncoder if kind == "big" else ref.nets.cnns.SmallPixelEncoder
+        m = cls((ch, 84, 84), emb)
+        names = ["conv1", "conv2", "conv3", "conv4"] if kind == "big" else ["conv1", "conv2", "conv3"]
+        for i, nm in enumerate(names, 1):
+            load_linear(getattr(m, nm), p[f"c{i}w"], p[f"c{i}b"])
+        load_linear(m.fc, p["fcw"], p["fcb"])
+        if kind == "big":
+            load_linear(m.ln, p["lnw"], p["lnb"])
+        x = torch.from_numpy(np.random.RandomState(50 + ch).randint(0, 256, (3, ch, 84, 84)).astype(np.float32))
+        with torch.no_grad():
+            y_ref = m(x)
+            y_orc = orc.encode({"kind": kind, "key": "obs", "p": p}, {"obs": x})
+        assert float((y_ref - y_orc).abs().max()) < 1e-5
+        rec[f"enc_{kind}_y"] = y_ref.numpy()
+    np.savez_compressed(os.path.join(OUT, "nets.npz"), **rec)
+
+
+def gen_per():
+    print("== per (prioritised replay sample path, SURVEY 8(f) rank 1)")
+    rec = {}
+    s, a, r, s1, d = synth.synth_transitions(300, 4, 2, seed=8)
+    rb = ref.replay.ReplayBuffer(400, alpha=0.6, beta=1.0)
+    rb.load_experience(s, a, r, s1, d)
+    per = orc.PerOracle(400, 0.6, 1.0)
+    per.push_rows(np.arange(300))
+    np.random.seed(77)
+    st = np.random.get_state()
+    _, w0, i0 = rb.sample(32)
+    np.random.set_state(st)
+    oi0, ow0 = per.sample(300, 32)
+    assert np.array_equal(i0, oi0) and np.allclose(w0.numpy(), ow0)
+    pr = np.random.RandomState(3).uniform(0.1, 4.0, 32)
+    rb.update_priorities(i0, pr)
+    per.update(i0, pr)
+    st = np.random.get_state()
+    _, w1, i1 = rb.sample(32)
+    np.random.set_state(st)
+    oi1, ow1 = per.sample(300, 32)
+    assert np.array_equal(i1, oi1) and np.allclose(w1.numpy(), ow1, rtol=1e-12)
+    rec.update(i0=i0, w0=w0.numpy(), prios=pr, i1=i1, w1=w1.numpy(), np_seed=np.int64(77))
+    np.savez_compressed(os.path.join(OUT, "per.npz"), **rec)
+
+
+if __name__ == "__main__":
+    only = set(sys.argv[1:])
+    units = {"indices": gen_indices, "popart": gen_popart, "aug": gen_aug, "nets": gen_nets,
+             "per": gen_per}
+    for nm, fn in units.items():
+        if not only or nm in only:
+            fn()
+    for name, cfg in synth.CASES.items():
+        if not only or name in only:
+            run_case(name, cfg)
+    print("golden fixtures written to", OUT)

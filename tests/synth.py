@@ -1,0 +1,80 @@
+"""Seeded synthetic inputs shared by the golden generator, the parity tests and bench.py.
+
+Everything is derived from numpy ``RandomState`` seeds so the fixtures under
+``tests/golden`` only need to store the reference's *outputs* (plus the host-RNG
+draws that the reference consumed), never the 100k-row buffers or the weights.
+"""
+import numpy as np
+
+# name -> configuration of one parity case.  Values follow SURVEY.md Appendix C.
+CASES = {
+    # small REDQ: full post-update parameter dump is stored
+    "redq_small": dict(obs=17, act=6, hidden=64, N=4, n=2, E=1, B=128, rows=2000, cap=4096,
+                       lo=-5.0, hi=2.0, popart=False, pop=False, discrete=False,
+                       actor="stochastic", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                       clip=None, tau=0.005, weight_type=None, temp=None, noise=None,
+                       cycles=2, utd=3, target_delay=2, seed=11),
+    # the metric shape (BASELINE.json): obs 17 / act 6 / B 512 / N 10 / n 2 / H 256
+    "redq_M": dict(obs=17, act=6, hidden=256, N=10, n=2, E=1, B=512, rows=5000, cap=8192,
+                   lo=-5.0, hi=2.0, popart=False, pop=False, discrete=False,
+                   actor="stochastic", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                   clip=None, tau=0.005, weight_type=None, temp=None, noise=None,
+                   cycles=2, utd=2, target_delay=2, seed=12),
+    # PopArt + pop + gradient clipping on a SAC shape (Agent defaults: ART on, lo=-10)
+    "sac_popart": dict(obs=11, act=3, hidden=64, N=2, n=2, E=1, B=64, rows=1000, cap=1024,
+                       lo=-10.0, hi=2.0, popart=True, pop=True, discrete=False,
+                       actor="stochastic", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                       clip=40.0, tau=0.005, weight_type=None, temp=None, noise=None,
+                       cycles=2, utd=2, target_delay=1, seed=13, popart_min_steps=2),
+    # SAC-Discrete with vector observations (experiments/gym/sac_discrete.gin shape)
+    "sac_discrete": dict(obs=8, act=4, hidden=64, N=2, n=2, E=1, B=64, rows=1000, cap=1024,
+                         lo=-10.0, hi=2.0, popart=False, pop=False, discrete=True,
+                         actor="discrete", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                         clip=40.0, tau=0.005, weight_type=None, temp=None, noise=None,
+                         cycles=2, utd=2, target_delay=2, seed=14),
+    # TD3/DrQv2-style: deterministic actor + Gaussian exploration process inside the updates
+    "td3_noise": dict(obs=9, act=4, hidden=64, N=2, n=2, E=1, B=64, rows=1000, cap=1024,
+                      lo=-10.0, hi=2.0, popart=False, pop=False, discrete=False,
+                      actor="deterministic", gamma=0.99 ** 3, lr=1e-4, alpha_lr=0.0,
+                      init_alpha=0.0, clip=None, tau=0.01, weight_type=None, temp=None,
+                      noise=dict(scale=0.7, clip=0.3), cycles=2, utd=1, target_delay=1, seed=15),
+    # SUNRISE: 3 members x 2 critics, sigmoid backup weights
+    "sunrise": dict(obs=11, act=3, hidden=64, N=2, n=2, E=3, B=64, rows=1000, cap=1024,
+                    lo=-5.0, hi=2.0, popart=False, pop=False, discrete=False,
+                    actor="stochastic", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                    clip=None, tau=0.005, weight_type="sunrise", temp=20.0, noise=None,
+                    cycles=1, utd=2, target_delay=2, seed=16),
+}
+
+
+def synth_transitions(rows, obs_dim, act_dim, discrete=False, seed=1, n_actions=None):
+    """obs,next_obs ~ N(0,1); act ~ U(-1,1); rew ~ N(0,1); done ~ Bern(0.01)."""
+    rng = np.random.RandomState(seed)
+    s = rng.standard_normal((rows, obs_dim)).astype(np.float32)
+    s1 = rng.standard_normal((rows, obs_dim)).astype(np.float32)
+    if discrete:
+        a = rng.randint(0, n_actions, size=(rows, 1)).astype(np.float32)
+    else:
+        a = rng.uniform(-1.0, 1.0, size=(rows, act_dim)).astype(np.float32)
+    r = rng.standard_normal((rows,)).astype(np.float32)
+    d = (rng.uniform(size=(rows,)) < 0.01)
+    return {"obs": s}, a, r, {"obs": s1}, d
+
+
+def synth_pixel_transitions(rows, channels, hw, n_actions=None, act_dim=None, seed=1):
+    rng = np.random.RandomState(seed)
+    s = rng.randint(0, 256, size=(rows, channels, hw, hw)).astype(np.uint8)
+    s1 = rng.randint(0, 256, size=(rows, channels, hw, hw)).astype(np.uint8)
+    if n_actions is not None:
+        a = rng.randint(0, n_actions, size=(rows, 1)).astype(np.float32)
+    else:
+        a = rng.uniform(-1.0, 1.0, size=(rows, act_dim)).astype(np.float32)
+    r = rng.standard_normal((rows,)).astype(np.float32)
+    d = (rng.uniform(size=(rows,)) < 0.01)
+    return {"obs": s}, a, r, {"obs": s1}, d
+
+
+def fingerprint_indices(numel, k=48, seed=1234):
+    """Deterministic sample positions used to fingerprint big tensors in fixtures."""
+    rng = np.random.RandomState(seed + numel % 9973)
+    return rng.randint(0, numel, size=min(k, numel))

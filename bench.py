@@ -1,0 +1,210 @@
+"""Headline benchmark: gradient updates/sec of the REDQ critic update (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = one ``learning.critic_update`` call on a synthetic replay batch (obs 17, act 6,
+batch 512, N=10 critics, n=2 target subset, hidden 256, fp32 -- the shape the metric is
+quoted on) followed, every ``target_delay``=2 updates, by the Polyak update of the target
+critics, exactly as the reference's UTD loop does (main.py:379-414).  The replay buffer
+(100k transitions) is resident in HBM before the timed region starts; the per-update host
+work that remains (index draw from the torch CPU generator, REDQ subset draw, a 4 KB index
+upload) is part of the path and is inside the timed region.
+
+For N > 1 (launched by torch.distributed.run, one rank per GPU) the critic ensemble is
+sharded across ranks (super_sac_amd.parallel): one MIN all-reduce of the (B,) partial
+min-Q per update over RCCL; total work is fixed, so scaling is "strong".
+
+Prints ONE JSON line (rank 0) with `roofline` for the ensemble-Q GEMM and `cpu_baseline`
+(the CPU oracle -- a port of the reference's update -- timed on this host's cores).
+"""
+import argparse
+import copy
+import json
+import math
+import os
+import sys
+import time
+from itertools import chain
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+OBS, ACT, BATCH, NCRIT, NSUB, HID = 17, 6, 512, 10, 2, 256
+ROWS, CAP = 100_000, 1_000_000
+GAMMA, LR, TAU, TARGET_DELAY = 0.99, 3e-4, 0.005, 2
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def synth_data():
+    import synth
+    return synth.synth_transitions(ROWS, OBS, ACT, seed=1)
+
+
+def build_engine(device, n_local, shard=None):
+    import super_sac_amd as ssa
+    torch.manual_seed(0)
+    np.random.seed(0)
+    import random
+    random.seed(0)
+    agent = ssa.Agent(act_space_size=ACT, encoder=ssa.nets.IdentityEncoder(OBS),
+                      actor_network_cls=ssa.nets.ContinuousStochasticActor,
+                      critic_network_cls=ssa.nets.ContinuousCritic, discrete=False, ensemble_size=1,
+                      num_critics=n_local, ucb_bonus=0.0, hidden_size=HID, auto_rescale_targets=False,
+                      log_std_low=-5.0, log_std_high=2.0)
+    agent.to(device)
+    agent.train()
+    target = copy.deepcopy(agent)
+    buf = ssa.replay.ReplayBuffer(CAP, device=device)
+    buf.load_experience(*synth_data())
+    copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=LR, betas=(0.9, 0.999))
+    eopt = torch.optim.Adam(agent.encoder.parameters(), lr=1e-4)
+    la = torch.Tensor([math.log(0.1)]).to(device)
+    la.requires_grad = True
+    aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(BATCH)])
+    if shard is not None:
+        ssa.parallel.install(agent, target, shard)
+    state = {"k": 0}
+
+    def step():
+        ssa.learning.critic_update(
+            buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt, encoder_optimizer=eopt,
+            log_alphas=[la], batch_size=BATCH, gamma=GAMMA, critic_clip=None, encoder_clip=None,
+            target_critic_ensemble_n=NSUB, weighted_bellman_temp=None, weight_type=None, pop=False,
+            augmenter=aug, encoder_lambda=0, aug_mix=0.0, discrete=False, random_process=None,
+            noise_clip=None, per=False, update_priorities=False, dr3_coeff=0.0)
+        if state["k"] % TARGET_DELAY == 0:
+            for ac, tc in zip(agent.critics, target.critics):
+                ssa.learning_utils.soft_update(tc, ac, TAU)
+        state["k"] += 1
+    return step, ssa
+
+
+def cpu_baseline(budget_s=12.0):
+    """The oracle's critic_update (+Polyak) on the host cores: same shape, same 100k-row buffer."""
+    import ssac_oracle as orc
+    torch.manual_seed(0)
+    buf = orc.ReplayOracle(CAP)
+    buf.load_experience(*synth_data())
+    oa = orc.AgentOracle(state_dim=OBS, act_dim=ACT, hidden=HID, num_critics=NCRIT, ensemble_size=1,
+                         log_std_low=-5.0, log_std_high=2.0, seed=0).requires_grad_(True)
+    ot = oa.clone()
+    copt = orc.AdamOracle(oa.critic_params(), lr=LR)
+    eopt = orc.AdamOracle([], lr=1e-4)
+    la = [torch.tensor([math.log(0.1)], requires_grad=True)]
+    aug = orc.AugOracle("identity", BATCH)
+
+    def one(k):
+        orc.critic_update(buf, oa, ot, copt, eopt, la, BATCH, GAMMA, None, None, NSUB, None, None, False, aug)
+        if k % TARGET_DELAY == 0:
+            orc.soft_update(ot.critic_params(), oa.critic_params(), TAU)
+    # pick the thread count that is FASTEST for this workload on this host (tiny GEMMs do not
+    # scale to hundreds of threads; the baseline should be the CPU's best, not its worst)
+    best = (float("inf"), 1)
+    for th in sorted({1, 4, 8, 16, 32, min(64, os.cpu_count() or 1)}):
+        if th > (os.cpu_count() or 1):
+            continue
+        torch.set_num_threads(th)
+        one(0)
+        t1 = time.perf_counter()
+        for k in range(3):
+            one(k)
+        best = min(best, ((time.perf_counter() - t1) / 3, th))
+    threads = best[1]
+    torch.set_num_threads(threads)
+    for k in range(3):
+        one(k)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        one(n)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 2), "unit": "updates/s", "cores": threads, "kind": "port",
+            "sample": f"{n} critic updates (+Polyak every 2nd) of the same workload in {dt:.1f} s, "
+                      f"torch {torch.__version__} CPU, {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    shard = None
+    n_local = NCRIT
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+        from super_sac_amd import parallel
+        shard = parallel.Shard(rank, world, NCRIT)
+        n_local = shard.n_local
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    step, ssa = build_engine(device, n_local, shard)
+    for _ in range(args.warmup):
+        step()
+
+    # ---- timed region: EXACTLY --steps steps between barrier+sync brackets
+    ssa.engine.PROFILE["tag"] = "cu.c0"
+    ssa.engine.PROFILE["events"] = []
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ssa.engine.PROFILE["tag"] = None
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+
+    # ---- roofline of the dominant kernel: ensemble-Q forward, hidden layer (fc2) GEMM.
+    evs = ssa.engine.PROFILE["events"]
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    avg_ms = sum(ms) / len(ms)
+    flops = 2.0 * BATCH * HID * HID * n_local  # algorithmic FLOPs of one launch
+    achieved = flops / (avg_ms * 1e-3) / 1e12
+    roofline = {"kernel": "ens_gemm_kernel<NT,bias+relu> (critic fc2, all local critics, one launch)",
+                "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                "avg_launch_us": round(avg_ms * 1e3, 3), "launches_timed": len(ms),
+                "flops_per_launch": flops, "traffic": None}
+
+    if rank == 0:
+        out = {"metric": "gradient updates/sec (REDQ N=10, batch 512)", "value": round(args.steps / dt, 2),
+               "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * dt / args.steps, 5), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "REDQ critic_update + Polyak/2: obs 17, act 6, batch 512, "
+                                      "N=10 critics (n=2 target subset), hidden 256, replay 100k rows in HBM",
+                          "global_batch": BATCH, "num_critics": NCRIT,
+                          "parallelism": "single GPU" if world == 1 else f"critic-ensemble sharded x{world}"},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,232 @@
+/*
+ * ssac_hip.h -- C ABI of libssac_hip.so, the MI355X (gfx950) update-path kernels.
+ *
+ * The reference (jakegrigsby/super_sac) is pure Python: it has no FFI of its own, so
+ * there is nothing to match symbol-for-symbol.  Each entry point below replaces the
+ * arithmetic of one group of reference call sites (cited per function); the Python
+ * host layer (super_sac_amd/) keeps the reference's function names and signatures
+ * (learning.critic_update, ...) and calls these through ctypes.  INTEGRATION.md shows
+ * the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless the
+ *     parameter name ends in _host.  No torch types, no exceptions.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*).
+ *   - return value: 0 on success, non-zero on error; ssac_last_error() gives the text.
+ *   - all floating point data is fp32 (the reference computes in fp32 throughout).
+ *   - weight tensors use the torch.nn.Linear layout: W is (out, in) row-major.
+ *
+ * Packed ensemble-MLP arena ("ssac_mlp"): `n_nets` identically shaped 3-layer ReLU MLPs
+ * (reference nets/mlps.py:11-41, 78-93, 113-129, 132-149, 170-185), each stored as
+ *   [ W1 (hidden x in) | b1 (hidden) | W2 (hidden x hidden) | b2 (hidden) |
+ *     W3 (out x hidden) | b3 (out) | pad to a multiple of 4 floats ]
+ * with `net_stride` floats between consecutive nets.  Adam moments and Polyak targets
+ * use arenas of the same layout.
+ */
+#ifndef SSAC_HIP_H
+#define SSAC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSAC_ABI_VERSION 1
+#define SSAC_MAX_NETS 64
+
+typedef struct ssac_mlp {
+    float *params;      /* arena base */
+    int64_t net_stride; /* floats between nets */
+    int32_t n_nets;
+    int32_t in_dim, hidden, out_dim;
+} ssac_mlp;
+
+/* Adam hyper-parameters + per-step scalars, resident in DEVICE memory so that a captured
+ * hipGraph can be replayed while the step count advances (ssac_adam_advance). */
+typedef struct ssac_adam_ctl {
+    float lr, beta1, beta2, eps, weight_decay;
+    float step_size;    /* lr / (1 - beta1^t)           (torch.optim.Adam, main.py:188-239) */
+    float bc2_sqrt;     /* sqrt(1 - beta2^t) */
+    float clip_coef;    /* clip_grad_norm_ coefficient, 1.0 when clipping is off */
+    int32_t step;       /* t */
+    int32_t _pad[3];
+    double lr_d, beta1_d, beta2_d; /* the host's exact doubles, used for the bias corrections */
+} ssac_adam_ctl;
+
+/* PopArt layer state (popart.py:8-20), resident in device memory. */
+typedef struct ssac_popart {
+    float mu, nu, w, b;
+    int32_t t, min_steps, stable, _pad;
+    double beta;
+} ssac_popart;
+
+int ssac_abi_version(void);
+const char *ssac_last_error(void);
+
+/* floats per net and the six segment offsets {W1,b1,W2,b2,W3,b3}. */
+int64_t ssac_mlp_layout(int in_dim, int hidden, int out_dim, int64_t offsets[6]);
+
+/* ---- replay sample path: replay.py:66-84 (fancy-index gather) + learning_utils.py:186-197
+ * (.float()).  Gathers `n_rows` rows `idx[i]` from a row-major source of `row_elems`
+ * elements per row into dst (row stride `ld_dst`, starting at column dst_col0).
+ * src_dtype: 0 = fp32, 1 = uint8 (cast to fp32). */
+int ssac_gather_rows(const void *src, int src_dtype, int64_t row_elems, const int64_t *idx,
+                     int n_rows, float *dst, int64_t ld_dst, int64_t dst_col0, void *stream);
+
+/* Whole-transition gather in ONE launch (replay.py:66-84 gathers five arrays separately):
+ *   xsa [i, 0:s_elems]           <- float(s [idx[i]])      (row stride ld_x)
+ *   xsa [i, s_elems:+a_elems]    <- act[idx[i]]
+ *   x1sa[i, 0:s_elems]           <- float(s1[idx[i]])      (row stride ld_x1)
+ *   rew_out[i], done_out[i]      <- rew[idx[i]], float(done[idx[i]])   (done is uint8)
+ * for vector observations (or flattened images without augmentation). */
+int ssac_gather_transition(const void *s, const void *s1, int s_dtype, int64_t s_elems,
+                           const float *act, int64_t a_elems, const float *rew, const uint8_t *done,
+                           const int64_t *idx, int n_rows, float *xsa, int64_t ld_x, float *x1sa,
+                           int64_t ld_x1, float *rew_out, float *done_out, void *stream);
+
+/* ---- one layer of every selected net: Y[e] = act(X[e] W_l[id_e]^T + b_l[id_e])
+ * (mlps.py:33-35,125-129; agent.py:34 runs this once per net in a Python loop).
+ * layer 0/1/2 = fc1/fc2/out.  net_ids: device int32[n_sel] or NULL (=0..n_sel-1).
+ * x_net_stride = 0 shares X across nets.  relu != 0 applies ReLU. */
+int ssac_mlp_layer_fwd(const ssac_mlp *nets, int layer, const int32_t *net_ids, int n_sel,
+                       const float *X, int64_t ldx, int64_t x_net_stride, int n_rows,
+                       float *Y, int64_t ldy, int64_t y_net_stride, int relu, void *stream);
+
+/* ---- backward-data of one layer: dX[e] = (dY[e] W_l[id_e]) (.) [mask[e] > 0]
+ * (what autograd does for loss.backward(), learning.py:121,411).  mask may be NULL. */
+int ssac_mlp_layer_dgrad(const ssac_mlp *nets, int layer, const int32_t *net_ids, int n_sel,
+                         const float *dY, int64_t ldy, int64_t y_net_stride,
+                         const float *mask, int64_t ldmask, int64_t mask_net_stride, int n_rows,
+                         float *dX, int64_t ldx, int64_t x_net_stride, void *stream);
+
+/* ---- backward-weights of one layer fused with the optimizer step:
+ * g_W = dY^T X, g_b = colsum(dY); then either
+ *   (grads == NULL)  Adam in place on params/m/v (torch.optim.Adam.step, learning.py:129-130,416)
+ *                    and, when `target` != NULL, the Polyak update target <- (1-tau) target + tau p
+ *                    (learning_utils.py:160-162) on the freshly updated values, or
+ *   (grads != NULL)  store the gradients into a same-layout arena (for clip_grad_norm_).
+ * sumsq: device float array, one slot per (net, tile) of this launch, receives sum(g^2)
+ * partials (for clip_grad_norm_ / get_grad_norm, learning_utils.py:95-106); layout
+ * sumsq[e * sumsq_net_stride + tile], tile < ssac_wgrad_tiles(nets, layer).  May be NULL. */
+int ssac_wgrad_tiles(const ssac_mlp *nets, int layer);
+int ssac_mlp_layer_wgrad(const ssac_mlp *nets, int layer, const int32_t *net_ids, int n_sel,
+                         const float *X, int64_t ldx, int64_t x_net_stride,
+                         const float *dY, int64_t ldy, int64_t y_net_stride, int n_rows,
+                         float *adam_m, float *adam_v, const ssac_adam_ctl *ctl,
+                         float *grads, float *sumsq, int64_t sumsq_net_stride,
+                         float *target, float tau, void *stream);
+
+/* ---- elementwise Adam over a whole arena from stored gradients (clip path):
+ * g *= ctl->clip_coef first (torch.nn.utils.clip_grad_norm_, learning.py:122-128). */
+int ssac_adam_step(float *params, float *adam_m, float *adam_v, const float *grads, int64_t n,
+                   const ssac_adam_ctl *ctl, void *stream);
+
+/* advance ctl->step by one and refresh step_size / bc2_sqrt (double precision on device). */
+int ssac_adam_advance(ssac_adam_ctl *ctl, void *stream);
+/* clip_coef = min(1, max_norm / (sqrt(sum(sumsq[0..n))) + 1e-6)); max_norm <= 0 -> 1.
+ * Also writes the total norm to *norm_out when not NULL. */
+int ssac_clip_coef(ssac_adam_ctl *ctl, const float *sumsq, int n, float max_norm, float *norm_out,
+                   void *stream);
+
+/* out[g] = sqrt(sum(sumsq[g*group_size .. (g+1)*group_size))): per-net gradient norms for the
+ * "gradients/..." logs (learning_utils.py:95-106); multiplied by scale_by_clip->clip_coef when
+ * given (the reference logs the norm after clip_grad_norm_ rescaled the gradients). */
+int ssac_group_norms(const float *sumsq, int n_groups, int group_size, const ssac_adam_ctl *scale_by_clip,
+                     float *out, void *stream);
+
+/* ---- Polyak / hard update over n floats: learning_utils.py:160-167 */
+int ssac_polyak(float *target, const float *source, int64_t n, float tau, void *stream);
+
+/* ---- tanh-squashed normal head: distributions.py:9-15, 64-104.
+ * out (n_rows x 2A) -> a = tanh(mu + sigma eps) written to act_dst (row stride ld_act, column
+ * offset act_col0) and log pi (n_rows) using the cached pre-tanh value. */
+int ssac_tanh_normal_fwd(const float *out, int64_t ld_out, const float *eps, int n_rows, int act_dim,
+                         float log_std_lo, float log_std_hi, float *act_dst, int64_t ld_act,
+                         int64_t act_col0, float *logp, void *stream);
+
+/* deterministic actor: a = tanh(out) + sample_std*eps (distributions.py:107-114, eps may be NULL),
+ * then optional exploration noise (learning_utils.py:48-59): a += clamp(scale*noise, +-clip),
+ * clamp to [-1+1e-6, 1-1e-6].  noise may be NULL; noise_clip <= 0 disables the clip. */
+int ssac_det_action_fwd(const float *out, int64_t ld_out, const float *eps, float sample_std,
+                        const float *noise, float noise_scale, float noise_clip, int n_rows,
+                        int act_dim, float *act_dst, int64_t ld_act, int64_t act_col0, void *stream);
+
+/* ---- TD target: learning_utils.py:298-354 (+ popart.py:35-59).  One workgroup.
+ * q_t: (n_sel x n_rows x q_dim) target-critic outputs; min over n_sel (agent.py:37-38).
+ * continuous (q_dim == 1): val = minq - exp(log_alpha)*logp  (use_entropy != 0), else val = minq.
+ * discrete  (q_dim  > 1): logits (n_rows x q_dim): val = sum_a pi (minq_a - alpha log pi_a).
+ * popart: device ssac_popart* or NULL; pop != 0 de-normalises.
+ * td <- r + gamma (1-d) val, then PopArt stat update + normalise when popart != NULL.
+ * logs[0..2] = mean(td), unbiased std(td), mean(entropy bonus). */
+int ssac_td_target(const float *q_t, int n_sel, int n_rows, int q_dim, const float *logp_or_logits,
+                   const float *rew, const float *done, const float *log_alpha, int use_entropy,
+                   float gamma, ssac_popart *popart, int pop, float *td, float *logs, void *stream);
+
+/* ---- critic loss gradient: learning.py:90-98,112.
+ * q: (n_nets x n_rows x q_dim).  For q_dim > 1 the taken action column is gathered
+ * (learning.py:92, act holds the index as float).  PopArt (w,b) applied to q when pop.
+ * dq = -2 * weight_b * (td - q') * popart_w / (denom * n_rows); weight may be NULL (=1).
+ * logs[0] += sum over nets of mean(weight*(td-q')^2)/denom   (critic_overall_loss)
+ * logs[1]  = mean(td - q') of the LAST net                   (last_member_critic_td_error) */
+int ssac_critic_loss_bwd(const float *q, int n_nets, int n_rows, int q_dim, const float *act,
+                         int64_t ld_act, const float *td, const float *weight, const ssac_popart *popart,
+                         int pop, float denom, float *dq, float *logs, void *stream);
+
+/* ---- actor loss gradient, continuous: learning.py:392-408.
+ * q (n_nets x n_rows): min over ALL nets (learning.py:402), arg-min routing.
+ * dq[j][b] = -(popart_w) / (n_rows*E) for j = argmin_b else 0;  logs[0] += -mean(minq' - bonus)/E,
+ * bonus = exp(log_alpha)*logp when use_entropy. */
+int ssac_actor_loss_bwd(const float *q, int n_nets, int n_rows, const float *logp,
+                        const float *log_alpha, int use_entropy, const ssac_popart *popart, int pop,
+                        float inv_members, float *dq, float *logs, void *stream);
+
+/* ---- backward of the tanh-normal head: given dL/da summed from the critics' input
+ * gradients dX (n_nets x n_rows x ldx, action columns start at act_col0) and the entropy
+ * term alpha/(n_rows*E) * log pi, produce dL/d(out) (n_rows x 2A). */
+int ssac_tanh_normal_bwd(const float *dX, int n_nets, int64_t ldx, int64_t x_net_stride,
+                         int64_t act_col0, const float *out, int64_t ld_out, const float *eps,
+                         int n_rows, int act_dim, float log_std_lo, float log_std_hi,
+                         const float *log_alpha, int use_entropy, float inv_members, float *d_out,
+                         int64_t ld_dout, void *stream);
+/* deterministic actor: d_out = (sum_j dX_j[:, act cols]) * (1 - tanh(out)^2) (straight-through clamp). */
+int ssac_det_action_bwd(const float *dX, int n_nets, int64_t ldx, int64_t x_net_stride,
+                        int64_t act_col0, const float *out, int64_t ld_out, int n_rows, int act_dim,
+                        float *d_out, int64_t ld_dout, void *stream);
+
+/* ---- SAC-Discrete actor loss gradient: learning.py:382-390,407-408.
+ * logits (n_rows x A); q (n_nets x n_rows x A) elementwise min (agent.py:38), no grad.
+ * loss = -(1/E) mean_b sum_a pi (minq' - alpha log pi);  d_logits written. */
+int ssac_discrete_actor_loss_bwd(const float *logits, const float *q, int n_nets, int n_rows,
+                                 int n_act, const float *log_alpha, const ssac_popart *popart, int pop,
+                                 float inv_members, float *d_logits, float *logs, void *stream);
+
+/* ---- temperature update: learning.py:222-263 (loss uses log_alpha itself).
+ * continuous: logp (n_rows); discrete: logits (n_rows x n_act) -> sum_a pi log pi.
+ * One Adam step (betas from ctl) on the device scalar *log_alpha.
+ * logs[0] = alpha_loss, logs[1] = exp(log_alpha) after the step. */
+int ssac_alpha_update(float *log_alpha, float *adam_m, float *adam_v, ssac_adam_ctl *ctl,
+                      const float *logp_or_logits, int n_rows, int n_act, float target_entropy,
+                      float *logs, void *stream);
+
+/* ---- SUNRISE backup weights: learning_utils.py:372-382.  q (n_members x n_rows) ->
+ * w = sigmoid(-std_unbiased(q) * temp) + 0.5; logs[0..3] = mean,max,min,std(w). */
+int ssac_sunrise_weights(const float *q, int n_members, int n_rows, float temp, float *w, float *logs,
+                         void *stream);
+
+/* ---- DrQ augmentations: augmentations.py:214-263 (Drqv2Aug) and :165-204 (DrqAug).
+ * src: uint8 or fp32 images (n x c x h x h) gathered through idx (may be NULL = identity);
+ * rows >= n_aug are copied un-augmented (aug_mix, learning_utils.py:200-206).
+ * shift: int64 (n x 2) = (x, y) per sample.  mode 0: Drqv2 (replicate pad + fp32 bilinear grid),
+ * mode 1: DrQ v1 (reflection pad + integer crop, optional additive noise, clamp 0..255). */
+int ssac_drq_shift(const void *src, int src_dtype, const int64_t *idx, int n, int c, int h, int pad,
+                   const int64_t *shift, int mode, const float *noise, int n_aug, float *dst,
+                   void *stream);
+
+/* zero a float buffer (log accumulators) */
+int ssac_zero(float *p, int64_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSAC_HIP_H */

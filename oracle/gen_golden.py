@@ -393,6 +393,16 @@ def gen_aug():
     dv2 = max(float((z0["obs"] - y0["obs"]).abs().max()), float((z1["obs"] - y1["obs"]).abs().max()))
     print(f"   drqv2 oracle vs reference max|diff| = {dv2:.3e} (0-255 scale)")
     assert dv2 < 2e-3
+    # production image size (84 -> padded 92): pins the fp32 grid arithmetic at that size
+    bx = torch.from_numpy(np.random.RandomState(10).randint(0, 256, (3, 2, 84, 84)).astype(np.float32))
+    torch.manual_seed(24)
+    seqb = ref.augmentations.AugmentationSequence([ref.augmentations.Drqv2Aug(3)])
+    by = seqb({"obs": bx})
+    rec["big_x"], rec["big_shift"], rec["big_y"] = bx.numpy(), seqb.aug_list[0].shift.numpy(), by["obs"].numpy()
+    bz = orc.drqv2_shift(bx, seqb.aug_list[0].shift)
+    d84 = float((bz - by["obs"]).abs().max())
+    print(f"   drqv2 84x84 oracle vs reference max|diff| = {d84:.3e}")
+    assert d84 < 1e-3  # fp32 summation order of the 4 bilinear taps differs (0-255 scale)
     # DrQ v1 without noise: exact integer crop of the reflection-padded image
     torch.manual_seed(22)
     seq = ref.augmentations.AugmentationSequence([ref.augmentations.DrqNoNoiseAug(B)])

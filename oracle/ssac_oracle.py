@@ -248,7 +248,8 @@ def drqv2_draw_shift(batch_size, pad=4):
 
 
 def _linspace_f32(start, end, steps):
-    # ATen CPU linspace: symmetric two-sided evaluation in the output dtype
+    """ATen linspace in fp32: two-sided, and each element is ONE fused multiply-add
+    (start + step*i contracts to fma on the CPU build and under nvcc alike)."""
     start = np.float32(start)
     end = np.float32(end)
     step = np.float32((end - start) / np.float32(steps - 1))
@@ -256,9 +257,9 @@ def _linspace_f32(start, end, steps):
     half = steps // 2
     for i in range(steps):
         if i < half:
-            out[i] = np.float32(start + np.float32(step * np.float32(i)))
+            out[i] = np.float32(np.float64(start) + np.float64(step) * i)
         else:
-            out[i] = np.float32(end - np.float32(step * np.float32(steps - 1 - i)))
+            out[i] = np.float32(np.float64(end) - np.float64(step) * (steps - 1 - i))
     return out
 
 
@@ -271,8 +272,8 @@ def drqv2_shift(imgs, shift, pad=4):
     hp = h + 2 * pad
     x = imgs.numpy().astype(np.float32)
     padded = np.pad(x, ((0, 0), (0, 0), (pad, pad), (pad, pad)), mode="edge")
-    eps = np.float32(1.0 / hp)
-    ar = _linspace_f32(np.float32(-1.0) + eps, np.float32(1.0) - eps, hp)[:h]
+    # eps = 1.0/(h+2*pad) is a Python double; linspace rounds its end points to fp32
+    ar = _linspace_f32(np.float32(-1.0 + 1.0 / hp), np.float32(1.0 - 1.0 / hp), hp)[:h]
     sh = shift.numpy().reshape(n, 2).astype(np.float32) * np.float32(2.0 / hp)
     out = np.zeros((n, c, h, w), np.float32)
     size = np.float32(hp)

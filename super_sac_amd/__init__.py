@@ -1,0 +1,30 @@
+"""super_sac_amd -- MI355X-native update engine behind the super_sac interface.
+
+Same module / function names as the reference package for the one path it replaces:
+
+    super_sac_amd.Agent                         <- super_sac/agent.py
+    super_sac_amd.learning.critic_update ...    <- super_sac/learning.py
+    super_sac_amd.learning_utils.*              <- super_sac/learning_utils.py
+    super_sac_amd.replay.ReplayBuffer           <- super_sac/replay.py (sample path)
+    super_sac_amd.augmentations.*               <- super_sac/augmentations.py (DrQ family)
+    super_sac_amd.popart.PopArtLayer            <- super_sac/popart.py
+    super_sac_amd.nets.*                        <- super_sac/nets/
+
+All arithmetic runs in hand-written HIP kernels (libssac_hip.so, gfx950); importing the
+package fails if the library has not been built -- there is no fallback path.
+"""
+import torch
+
+device = torch.device("cuda") if torch.cuda.is_available() else "cpu"
+
+from . import _lib  # noqa: E402,F401  (raises ImportError when the HIP library is missing)
+from . import rng  # noqa: E402,F401
+from . import engine  # noqa: E402,F401
+from . import nets  # noqa: E402,F401
+from . import popart  # noqa: E402,F401
+from . import replay  # noqa: E402,F401
+from . import augmentations  # noqa: E402,F401
+from . import agent  # noqa: E402,F401
+from .agent import Agent  # noqa: E402,F401
+from . import learning_utils  # noqa: E402,F401
+from . import learning  # noqa: E402,F401

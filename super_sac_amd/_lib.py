@@ -1,0 +1,90 @@
+"""ctypes binding of libssac_hip.so (the C ABI declared in include/ssac_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  If it is missing the
+import fails with instructions to build it; if a kernel launch fails the call raises
+``RuntimeError(ssac_last_error())``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssac_hip.so")
+
+
+class MlpDesc(C.Structure):
+    """struct ssac_mlp"""
+    _fields_ = [("params", C.c_void_p), ("net_stride", C.c_int64), ("n_nets", C.c_int32),
+                ("in_dim", C.c_int32), ("hidden", C.c_int32), ("out_dim", C.c_int32)]
+
+
+class AdamCtl(C.Structure):
+    """struct ssac_adam_ctl (device resident; this mirror is used to initialise / read it)"""
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("step_size", C.c_float), ("bc2_sqrt", C.c_float),
+                ("clip_coef", C.c_float), ("step", C.c_int32), ("_pad", C.c_int32 * 3),
+                ("lr_d", C.c_double), ("beta1_d", C.c_double), ("beta2_d", C.c_double)]
+
+
+class PopArtState(C.Structure):
+    """struct ssac_popart"""
+    _fields_ = [("mu", C.c_float), ("nu", C.c_float), ("w", C.c_float), ("b", C.c_float),
+                ("t", C.c_int32), ("min_steps", C.c_int32), ("stable", C.c_int32), ("_pad", C.c_int32),
+                ("beta", C.c_double)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_MP = C.POINTER(MlpDesc)
+
+# name -> argtypes; every function returns int status unless listed in _RESTYPES
+SIGNATURES = {
+    "ssac_abi_version": [],
+    "ssac_last_error": [],
+    "ssac_mlp_layout": [_I, _I, _I, C.POINTER(C.c_int64)],
+    "ssac_gather_rows": [_P, _I, _L, _P, _I, _P, _L, _L, _P],
+    "ssac_mlp_layer_fwd": [_MP, _I, _P, _I, _P, _L, _L, _I, _P, _L, _L, _I, _P],
+    "ssac_mlp_layer_dgrad": [_MP, _I, _P, _I, _P, _L, _L, _P, _L, _L, _I, _P, _L, _L, _P],
+    "ssac_wgrad_tiles": [_MP, _I],
+    "ssac_mlp_layer_wgrad": [_MP, _I, _P, _I, _P, _L, _L, _P, _L, _L, _I, _P, _P, _P, _P, _P, _L, _P, _F, _P],
+    "ssac_group_norms": [_P, _I, _I, _P, _P, _P],
+    "ssac_gather_transition": [_P, _P, _I, _L, _P, _L, _P, _P, _P, _I, _P, _L, _P, _L, _P, _P, _P],
+    "ssac_adam_step": [_P, _P, _P, _P, _L, _P, _P],
+    "ssac_adam_advance": [_P, _P],
+    "ssac_clip_coef": [_P, _P, _I, _F, _P, _P],
+    "ssac_polyak": [_P, _P, _L, _F, _P],
+    "ssac_tanh_normal_fwd": [_P, _L, _P, _I, _I, _F, _F, _P, _L, _L, _P, _P],
+    "ssac_det_action_fwd": [_P, _L, _P, _F, _P, _F, _F, _I, _I, _P, _L, _L, _P],
+    "ssac_td_target": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _I, _P, _P, _P],
+    "ssac_critic_loss_bwd": [_P, _I, _I, _I, _P, _L, _P, _P, _P, _I, _F, _P, _P, _P],
+    "ssac_actor_loss_bwd": [_P, _I, _I, _P, _P, _I, _P, _I, _F, _P, _P, _P],
+    "ssac_tanh_normal_bwd": [_P, _I, _L, _L, _L, _P, _L, _P, _I, _I, _F, _F, _P, _I, _F, _P, _L, _P],
+    "ssac_det_action_bwd": [_P, _I, _L, _L, _L, _P, _L, _I, _I, _P, _L, _P],
+    "ssac_discrete_actor_loss_bwd": [_P, _P, _I, _I, _I, _P, _P, _I, _F, _P, _P, _P],
+    "ssac_alpha_update": [_P, _P, _P, _P, _P, _I, _I, _F, _P, _P],
+    "ssac_sunrise_weights": [_P, _I, _I, _F, _P, _P, _P],
+    "ssac_drq_shift": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P],
+    "ssac_zero": [_P, _L, _P],
+}
+_RESTYPES = {"ssac_last_error": C.c_char_p, "ssac_mlp_layout": C.c_int64}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is the only implementation of this package. "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc).")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == ABI mismatch, fail loudly
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    if lib.ssac_abi_version() != 1:
+        raise ImportError("libssac_hip.so ABI version mismatch; rebuild the extension")
+    return lib
+
+
+lib = _load()
+
+
+def check(status):
+    if status != 0:
+        raise RuntimeError("libssac_hip: " + lib.ssac_last_error().decode())

@@ -1,0 +1,818 @@
+// HBM/latency-bound pieces of the update path on gfx950: replay gather, tanh-normal head,
+// TD target (+PopArt), loss gradients, temperature update, Polyak, Adam-from-grads, DrQ shifts.
+//
+// None of this is GEMM-shaped; it is byte/row work, so the rules that matter are coalesced
+// row access and wavefront (64-lane) reductions -- no MFMA here.  Batch-wide statistics
+// (TD-target mean/std for the logs and PopArt, loss means) are produced by single-workgroup
+// kernels so their summation order is fixed and results are run-to-run deterministic.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "ssac_internal.h"
+
+namespace {
+
+constexpr int RED_THREADS = 1024;
+constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
+constexpr float LOG_2 = 0.69314718055994530942f;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide reductions for <=1024 threads; `scratch` is 16 floats of LDS; result broadcast.
+template <int OP>  // 0 sum, 1 max, 2 min
+__device__ float block_reduce(float v, float *scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = OP == 0 ? wave_sum(v) : (OP == 1 ? wave_max(v) : wave_min(v));
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float r = scratch[0];
+    for (int w = 1; w < nw; ++w) r = OP == 0 ? r + scratch[w] : (OP == 1 ? fmaxf(r, scratch[w]) : fminf(r, scratch[w]));
+    return r;
+}
+
+__device__ __forceinline__ float softplus_f(float x) {
+    // F.softplus, beta=1, threshold=20
+    return x > 20.0f ? x : log1pf(expf(x));
+}
+
+__device__ __forceinline__ float popart_sigma(float mu, float nu) {
+    // popart.py:22-23
+    return fminf(fmaxf(sqrtf(nu - mu * mu) + 1e-5f, 1e-4f), 1e6f);
+}
+
+// ------------------------------------------------------------------ replay gather
+template <typename T>
+__global__ void gather_rows_kernel(const T *__restrict__ src, int64_t row_elems,
+                                   const int64_t *__restrict__ idx, int n_rows,
+                                   float *__restrict__ dst, int64_t ld, int64_t col0) {
+    const int64_t total = (int64_t)n_rows * row_elems;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / row_elems, c = i - r * row_elems;
+        dst[r * ld + col0 + c] = (float)src[idx[r] * row_elems + c];
+    }
+}
+
+template <typename T>
+__global__ void gather_transition_kernel(const T *__restrict__ s, const T *__restrict__ s1,
+                                         int64_t s_elems, const float *__restrict__ act,
+                                         int64_t a_elems, const float *__restrict__ rew,
+                                         const uint8_t *__restrict__ done,
+                                         const int64_t *__restrict__ idx, int n_rows,
+                                         float *__restrict__ xsa, int64_t ld_x,
+                                         float *__restrict__ x1sa, int64_t ld_x1,
+                                         float *__restrict__ rew_out, float *__restrict__ done_out) {
+    // one row of work = 2*s_elems + a_elems + 2 elements; consecutive threads walk one row
+    const int64_t per_row = 2 * s_elems + a_elems + 2;
+    const int64_t total = (int64_t)n_rows * per_row;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / per_row;
+        int64_t c = i - r * per_row;
+        const int64_t src = idx[r];
+        if (c < s_elems) {
+            xsa[r * ld_x + c] = (float)s[src * s_elems + c];
+        } else if ((c -= s_elems) < a_elems) {
+            xsa[r * ld_x + s_elems + c] = act[src * a_elems + c];
+        } else if ((c -= a_elems) < s_elems) {
+            x1sa[r * ld_x1 + c] = (float)s1[src * s_elems + c];
+        } else if (c == s_elems) {
+            rew_out[r] = rew[src];
+        } else {
+            done_out[r] = (float)done[src];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ tanh-normal head
+__global__ void tanh_normal_fwd_kernel(const float *__restrict__ out, int64_t ld_out,
+                                       const float *__restrict__ eps, int n_rows, int A, float lo,
+                                       float hi, float *__restrict__ act, int64_t ld_act,
+                                       int64_t col0, float *__restrict__ logp) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_rows) return;
+    float lp = 0.0f;
+    for (int i = 0; i < A; ++i) {
+        const float mu = out[b * ld_out + i];
+        const float raw = out[b * ld_out + A + i];
+        const float log_std = lo + 0.5f * (hi - lo) * (tanhf(raw) + 1.0f);
+        const float sd = expf(log_std);
+        const float u = mu + sd * eps[(int64_t)b * A + i];
+        const float a = tanhf(u);
+        const float dlt = u - mu;
+        const float base = -(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI;
+        const float ladj = 2.0f * (LOG_2 - u - softplus_f(-2.0f * u));
+        lp += base - ladj;
+        act[b * ld_act + col0 + i] = a;
+    }
+    if (logp) logp[b] = lp;
+}
+
+__global__ void tanh_normal_bwd_kernel(const float *__restrict__ dX, int n_nets, int64_t ldx,
+                                       int64_t sX, int64_t col0, const float *__restrict__ out,
+                                       int64_t ld_out, const float *__restrict__ eps, int n_rows,
+                                       int A, float lo, float hi, const float *__restrict__ log_alpha,
+                                       int use_entropy, float inv_members, float *__restrict__ d_out,
+                                       int64_t ld_dout) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_rows) return;
+    const float c = use_entropy ? expf(log_alpha[0]) * inv_members / (float)n_rows : 0.0f;
+    for (int i = 0; i < A; ++i) {
+        float gsum = 0.0f;
+        for (int j = 0; j < n_nets; ++j) gsum += dX[j * sX + b * ldx + col0 + i];
+        const float mu = out[b * ld_out + i];
+        const float raw = out[b * ld_out + A + i];
+        const float t = tanhf(raw);
+        const float log_std = lo + 0.5f * (hi - lo) * (t + 1.0f);
+        const float sd = expf(log_std);
+        const float e = eps[(int64_t)b * A + i];
+        const float a = tanhf(mu + sd * e);
+        const float gu = gsum * (1.0f - a * a);
+        const float d_mu = gu + c * 2.0f * a;
+        const float d_ls = gu * sd * e + c * (-1.0f + 2.0f * a * sd * e);
+        d_out[b * ld_dout + i] = d_mu;
+        d_out[b * ld_dout + A + i] = d_ls * 0.5f * (hi - lo) * (1.0f - t * t);
+    }
+}
+
+__global__ void det_action_fwd_kernel(const float *__restrict__ out, int64_t ld_out,
+                                      const float *__restrict__ eps, float sample_std,
+                                      const float *__restrict__ noise, float scale, float clip,
+                                      int n_rows, int A, float *__restrict__ act, int64_t ld_act,
+                                      int64_t col0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * A) return;
+    const int b = i / A, k = i - b * A;
+    float a = tanhf(out[b * ld_out + k]);
+    if (eps) a = a + sample_std * eps[i];
+    if (noise) {
+        float nz = scale * noise[i];
+        if (clip > 0.0f) nz = fminf(fmaxf(nz, -clip), clip);
+        a = fminf(fmaxf(a + nz, -1.0f + 1e-6f), 1.0f - 1e-6f);
+    }
+    act[b * ld_act + col0 + k] = a;
+}
+
+__global__ void det_action_bwd_kernel(const float *__restrict__ dX, int n_nets, int64_t ldx, int64_t sX,
+                                      int64_t col0, const float *__restrict__ out, int64_t ld_out,
+                                      int n_rows, int A, float *__restrict__ d_out, int64_t ld_dout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * A) return;
+    const int b = i / A, k = i - b * A;
+    float gsum = 0.0f;
+    for (int j = 0; j < n_nets; ++j) gsum += dX[j * sX + b * ldx + col0 + k];
+    const float t = tanhf(out[b * ld_out + k]);
+    d_out[b * ld_dout + k] = gsum * (1.0f - t * t);
+}
+
+// ------------------------------------------------------------------ TD target (+PopArt)
+__global__ __launch_bounds__(RED_THREADS) void td_target_kernel(
+    const float *__restrict__ q_t, int n_sel, int n_rows, int qd, const float *__restrict__ lp,
+    const float *__restrict__ rew, const float *__restrict__ done, const float *__restrict__ log_alpha,
+    int use_entropy, float gamma, ssac_popart *popart, int pop, float *__restrict__ td,
+    float *__restrict__ logs) {
+    __shared__ float scratch[16];
+    const float alpha = (use_entropy || qd > 1) ? expf(log_alpha[0]) : 0.0f;
+    float pmu = 0.f, pnu = 0.f, pw = 1.f, pb = 0.f, psig = 1.f;
+    if (popart) {
+        pmu = popart->mu; pnu = popart->nu; pw = popart->w; pb = popart->b;
+        psig = popart_sigma(pmu, pnu);
+    }
+    float s_td = 0.f, s_td2 = 0.f, s_bonus = 0.f;
+    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+        float val, bonus_acc;
+        if (qd == 1) {
+            float mq = q_t[b];
+            for (int j = 1; j < n_sel; ++j) mq = fminf(mq, q_t[(int64_t)j * n_rows + b]);
+            const float bonus = use_entropy ? alpha * lp[b] : 0.0f;
+            val = mq - bonus;
+            bonus_acc = bonus;
+        } else {
+            // SAC-Discrete: v = sum_a pi_a (minq_a - alpha log pi_a)   (learning_utils.py:322-328)
+            const float *x = lp + (int64_t)b * qd;
+            float mx = x[0];
+            for (int a = 1; a < qd; ++a) mx = fmaxf(mx, x[a]);
+            float se = 0.f;
+            for (int a = 0; a < qd; ++a) se += expf(x[a] - mx);
+            const float lse = mx + logf(se);
+            val = 0.f;
+            bonus_acc = 0.f;
+            for (int a = 0; a < qd; ++a) {
+                const float logpa = x[a] - lse;
+                const float pa = expf(logpa);
+                float mq = q_t[(int64_t)b * qd + a];
+                for (int j = 1; j < n_sel; ++j)
+                    mq = fminf(mq, q_t[((int64_t)j * n_rows + b) * qd + a]);
+                const float bonus = alpha * logpa;
+                val += pa * (mq - bonus);
+                bonus_acc += bonus;
+            }
+            bonus_acc /= (float)qd;  // entropy_bonus.mean() runs over (B, A)
+        }
+        if (popart && pop) val = psig * (pw * val + pb) + pmu;  // popart(val, normalized=False)
+        const float t = rew[b] + gamma * (1.0f - done[b]) * val;
+        td[b] = t;
+        s_td += t;
+        s_td2 += t * t;
+        s_bonus += bonus_acc;
+    }
+    const float inv_n = 1.0f / (float)n_rows;
+    float mean = block_reduce<0>(s_td, scratch) * inv_n;
+    const float mean2 = block_reduce<0>(s_td2, scratch) * inv_n;
+    const float mbonus = block_reduce<0>(s_bonus, scratch) * inv_n;
+    if (popart) {
+        // popart.update_stats (popart.py:35-52), then normalize_values (popart.py:25-26)
+        const int t = popart->t + 1;
+        const double beta = popart->beta;
+        const float beta_t = (float)(beta / (1.0 - pow(1.0 - beta, (double)t)));
+        const float omb = (float)(1.0 - (beta / (1.0 - pow(1.0 - beta, (double)t))));
+        const float nmu = omb * pmu + beta_t * mean;
+        const float nnu = omb * pnu + beta_t * mean2;
+        const float nsig = popart_sigma(nmu, nnu);
+        const bool stable = (t > popart->min_steps) && (((1.0f - psig) / nsig) <= 0.1f);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            popart->t = t;
+            popart->mu = nmu;
+            popart->nu = nnu;
+            popart->stable = stable ? 1 : 0;
+            if (stable) {
+                popart->w = pw * (psig / nsig);
+                popart->b = (psig * pb + pmu - nmu) / nsig;
+            }
+        }
+        float s1 = 0.f;
+        for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+            const float t2 = (td[b] - nmu) / nsig;
+            td[b] = t2;
+            s1 += t2;
+        }
+        mean = block_reduce<0>(s1, scratch) * inv_n;
+    }
+    float sv = 0.f;
+    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+        const float dlt = td[b] - mean;
+        sv += dlt * dlt;
+    }
+    const float var = block_reduce<0>(sv, scratch) / (float)(n_rows > 1 ? n_rows - 1 : 1);
+    if (threadIdx.x == 0 && logs) {
+        logs[0] = mean;
+        logs[1] = sqrtf(var);
+        logs[2] = mbonus;
+    }
+}
+
+// ------------------------------------------------------------------ critic loss gradient
+__global__ __launch_bounds__(RED_THREADS) void critic_loss_bwd_kernel(
+    const float *__restrict__ q, int n_nets, int n_rows, int qd, const float *__restrict__ act,
+    int64_t ld_act, const float *__restrict__ td, const float *__restrict__ weight,
+    const ssac_popart *popart, int pop, float denom, float *__restrict__ dq, float *__restrict__ logs) {
+    __shared__ float scratch[16];
+    const float pw = (popart && pop) ? popart->w : 1.0f;
+    const float pb = (popart && pop) ? popart->b : 0.0f;
+    const float gscale = -2.0f * pw / (denom * (float)n_rows);
+    float s_loss = 0.f, s_err_last = 0.f;
+    const int total = n_nets * n_rows;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const int j = i / n_rows, b = i - j * n_rows;
+        const float w = weight ? weight[b] : 1.0f;
+        float qv;
+        int ai = 0;
+        if (qd == 1) {
+            qv = q[i];
+        } else {
+            ai = (int)act[b * ld_act];  // a.long() (learning.py:92)
+            qv = q[(int64_t)i * qd + ai];
+        }
+        const float err = td[b] - (pw * qv + pb);
+        s_loss += w * err * err;
+        if (j == n_nets - 1) s_err_last += err;
+        if (qd == 1) {
+            dq[i] = gscale * w * err;
+        } else {
+            for (int a = 0; a < qd; ++a) dq[(int64_t)i * qd + a] = (a == ai) ? gscale * w * err : 0.0f;
+        }
+    }
+    const float loss = block_reduce<0>(s_loss, scratch) / (denom * (float)n_rows);
+    const float errm = block_reduce<0>(s_err_last, scratch) / (float)n_rows;
+    if (threadIdx.x == 0 && logs) {
+        logs[0] += loss;
+        logs[1] = errm;
+    }
+}
+
+// ------------------------------------------------------------------ actor loss gradients
+__global__ __launch_bounds__(RED_THREADS) void actor_loss_bwd_kernel(
+    const float *__restrict__ q, int n_nets, int n_rows, const float *__restrict__ logp,
+    const float *__restrict__ log_alpha, int use_entropy, const ssac_popart *popart, int pop,
+    float inv_members, float *__restrict__ dq, float *__restrict__ logs) {
+    __shared__ float scratch[16];
+    const float pw = (popart && pop) ? popart->w : 1.0f;
+    const float pb = (popart && pop) ? popart->b : 0.0f;
+    const float alpha = use_entropy ? expf(log_alpha[0]) : 0.0f;
+    const float gq = -pw * inv_members / (float)n_rows;
+    float s = 0.f;
+    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+        float mq = q[b];
+        int am = 0;
+        for (int j = 1; j < n_nets; ++j) {
+            const float v = q[(int64_t)j * n_rows + b];
+            if (v < mq) { mq = v; am = j; }
+        }
+        for (int j = 0; j < n_nets; ++j) dq[(int64_t)j * n_rows + b] = (j == am) ? gq : 0.0f;
+        const float bonus = use_entropy ? alpha * logp[b] : 0.0f;
+        s += (pw * mq + pb) - bonus;
+    }
+    const float tot = block_reduce<0>(s, scratch);
+    if (threadIdx.x == 0 && logs) logs[0] += -inv_members * tot / (float)n_rows;
+}
+
+__global__ __launch_bounds__(RED_THREADS) void discrete_actor_loss_bwd_kernel(
+    const float *__restrict__ logits, const float *__restrict__ q, int n_nets, int n_rows, int A,
+    const float *__restrict__ log_alpha, const ssac_popart *popart, int pop, float inv_members,
+    float *__restrict__ d_logits, float *__restrict__ logs) {
+    __shared__ float scratch[16];
+    const float pw = (popart && pop) ? popart->w : 1.0f;
+    const float pb = (popart && pop) ? popart->b : 0.0f;
+    const float alpha = expf(log_alpha[0]);
+    const float scale = -inv_members / (float)n_rows;
+    float s = 0.f;
+    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+        const float *x = logits + (int64_t)b * A;
+        float mx = x[0];
+        for (int a = 1; a < A; ++a) mx = fmaxf(mx, x[a]);
+        float se = 0.f;
+        for (int a = 0; a < A; ++a) se += expf(x[a] - mx);
+        const float lse = mx + logf(se);
+        float S = 0.f;
+        for (int a = 0; a < A; ++a) {
+            const float lpa = x[a] - lse, pa = expf(lpa);
+            float mq = q[(int64_t)b * A + a];
+            for (int j = 1; j < n_nets; ++j) mq = fminf(mq, q[((int64_t)j * n_rows + b) * A + a]);
+            S += pa * ((pw * mq + pb) - alpha * lpa);
+        }
+        for (int a = 0; a < A; ++a) {
+            const float lpa = x[a] - lse, pa = expf(lpa);
+            float mq = q[(int64_t)b * A + a];
+            for (int j = 1; j < n_nets; ++j) mq = fminf(mq, q[((int64_t)j * n_rows + b) * A + a]);
+            const float f = (pw * mq + pb) - alpha * lpa;
+            d_logits[(int64_t)b * A + a] = scale * pa * (f - S);
+        }
+        s += S;
+    }
+    const float tot = block_reduce<0>(s, scratch);
+    if (threadIdx.x == 0 && logs) logs[0] += scale * tot;
+}
+
+// ------------------------------------------------------------------ temperature update
+__device__ __forceinline__ void adam_refresh(ssac_adam_ctl *c, int t) {
+    c->step = t;
+    c->step_size = (float)(c->lr_d / (1.0 - pow(c->beta1_d, (double)t)));
+    c->bc2_sqrt = (float)sqrt(1.0 - pow(c->beta2_d, (double)t));
+}
+
+__global__ __launch_bounds__(RED_THREADS) void alpha_update_kernel(
+    float *log_alpha, float *am, float *av, ssac_adam_ctl *ctl, const float *__restrict__ lp,
+    int n_rows, int A, float target_entropy, float *__restrict__ logs) {
+    __shared__ float scratch[16];
+    float s = 0.f;
+    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+        float v;
+        if (A <= 1) {
+            v = lp[b];
+        } else {  // sum_a pi log pi (learning.py:253)
+            const float *x = lp + (int64_t)b * A;
+            float mx = x[0];
+            for (int a = 1; a < A; ++a) mx = fmaxf(mx, x[a]);
+            float se = 0.f;
+            for (int a = 0; a < A; ++a) se += expf(x[a] - mx);
+            const float lse = mx + logf(se);
+            v = 0.f;
+            for (int a = 0; a < A; ++a) v += expf(x[a] - lse) * (x[a] - lse);
+        }
+        s += v + target_entropy;
+    }
+    const float mean = block_reduce<0>(s, scratch) / (float)n_rows;
+    if (threadIdx.x == 0) {
+        const float la = log_alpha[0];
+        const float loss = -(la * mean);
+        const float g = -mean;
+        adam_refresh(ctl, ctl->step + 1);
+        float m = am[0], v = av[0];
+        m = m + (1.0f - ctl->beta1) * (g - m);
+        v = v * ctl->beta2 + (1.0f - ctl->beta2) * g * g;
+        const float denom = sqrtf(v) / ctl->bc2_sqrt + ctl->eps;
+        const float nla = la - ctl->step_size * (m / denom);
+        am[0] = m;
+        av[0] = v;
+        log_alpha[0] = nla;
+        if (logs) {
+            logs[0] = loss;
+            logs[1] = expf(nla);
+        }
+    }
+}
+
+__global__ void adam_advance_kernel(ssac_adam_ctl *ctl) { adam_refresh(ctl, ctl->step + 1); }
+
+__global__ __launch_bounds__(RED_THREADS) void clip_coef_kernel(ssac_adam_ctl *ctl,
+                                                               const float *__restrict__ sumsq, int n,
+                                                               float max_norm, float *norm_out) {
+    __shared__ float scratch[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += sumsq[i];
+    const float tot = sqrtf(block_reduce<0>(s, scratch));
+    if (threadIdx.x == 0) {
+        // clip_grad_norm_: coef = clamp(max_norm / (total + 1e-6), max=1)
+        if (ctl) ctl->clip_coef = max_norm > 0.0f ? fminf(max_norm / (tot + 1e-6f), 1.0f) : 1.0f;
+        if (norm_out) norm_out[0] = tot;
+    }
+}
+
+__global__ void group_norms_kernel(const float *__restrict__ sumsq, int group_size,
+                                   const ssac_adam_ctl *scale, float *out) {
+    __shared__ float scratch[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < group_size; i += blockDim.x) s += sumsq[(int64_t)blockIdx.x * group_size + i];
+    const float tot = block_reduce<0>(s, scratch);
+    if (threadIdx.x == 0) out[blockIdx.x] = sqrtf(tot) * (scale ? scale->clip_coef : 1.0f);
+}
+
+__global__ void adam_step_kernel(float *__restrict__ p, float *__restrict__ am, float *__restrict__ av,
+                                 const float *__restrict__ g, int64_t n, const ssac_adam_ctl *ctl) {
+    const ssac_adam_ctl c = *ctl;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float gr = g[i] * c.clip_coef;
+        const float pv = p[i];
+        if (c.weight_decay != 0.0f) gr = gr + c.weight_decay * pv;
+        float m = am[i], v = av[i];
+        m = m + (1.0f - c.beta1) * (gr - m);
+        v = v * c.beta2 + (1.0f - c.beta2) * gr * gr;
+        const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+        am[i] = m;
+        av[i] = v;
+        p[i] = pv - c.step_size * (m / denom);
+    }
+}
+
+__global__ void polyak_kernel(float *__restrict__ t, const float *__restrict__ s, int64_t n, float tau) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        t[i] = t[i] * (1.0f - tau) + s[i] * tau;
+}
+
+__global__ void zero_kernel(float *p, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = 0.0f;
+}
+
+// ------------------------------------------------------------------ SUNRISE weights
+__global__ __launch_bounds__(RED_THREADS) void sunrise_weights_kernel(const float *__restrict__ q,
+                                                                     int E, int n_rows, float temp,
+                                                                     float *__restrict__ w,
+                                                                     float *__restrict__ logs) {
+    __shared__ float scratch[16];
+    float s = 0.f, mx = -INFINITY, mn = INFINITY;
+    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+        float m = 0.f;
+        for (int k = 0; k < E; ++k) m += q[(int64_t)k * n_rows + b];
+        m /= (float)E;
+        float var = 0.f;
+        for (int k = 0; k < E; ++k) {
+            const float d = q[(int64_t)k * n_rows + b] - m;
+            var += d * d;
+        }
+        const float sd = sqrtf(var / (float)(E - 1));
+        const float wv = 1.0f / (1.0f + expf(sd * temp)) + 0.5f;  // sigmoid(-sd*temp) + 0.5
+        w[b] = wv;
+        s += wv;
+        mx = fmaxf(mx, wv);
+        mn = fminf(mn, wv);
+    }
+    const float mean = block_reduce<0>(s, scratch) / (float)n_rows;
+    mx = block_reduce<1>(mx, scratch);
+    mn = block_reduce<2>(mn, scratch);
+    float sv = 0.f;
+    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+        const float d = w[b] - mean;
+        sv += d * d;
+    }
+    const float var = block_reduce<0>(sv, scratch) / (float)(n_rows > 1 ? n_rows - 1 : 1);
+    if (threadIdx.x == 0 && logs) {
+        logs[0] = mean; logs[1] = mx; logs[2] = mn; logs[3] = sqrtf(var);
+    }
+}
+
+// ------------------------------------------------------------------ DrQ shifts
+// torch.linspace(start, end, steps) element i in fp32 (two-sided evaluation)
+__device__ __forceinline__ float linspace_f32(float start, float end, float step, int steps, int i) {
+    // each element is one fused multiply-add in ATen (CPU build and nvcc contract it alike)
+    return (i < steps / 2) ? __fmaf_rn(step, (float)i, start)
+                           : __fmaf_rn(-step, (float)(steps - 1 - i), end);
+}
+
+template <typename T>
+__global__ void drq_shift_kernel(const T *__restrict__ src, const int64_t *__restrict__ idx, int n, int c,
+                                 int h, int pad, const int64_t *__restrict__ shift, int mode,
+                                 const float *__restrict__ noise, int n_aug, float *__restrict__ dst) {
+    // The sampling grid must round like ATen's separate fp32 ops: HIP's __fmul_rn/__fadd_rn are
+    // plain * and + and would be contracted into FMAs under the default -ffp-contract=fast.
+#pragma clang fp contract(off)
+    const int64_t per_img = (int64_t)c * h * h;
+    const int64_t total = (int64_t)n * per_img;
+    const int hp = h + 2 * pad;
+    // Drqv2Aug.random_crop constants (augmentations.py:242-255)
+    const float start = (float)(-1.0 + 1.0 / (double)hp), end = (float)(1.0 - 1.0 / (double)hp);
+    const float step = __fdiv_rn(__fsub_rn(end, start), (float)(hp - 1));
+    const float sscale = (float)(2.0 / (double)hp);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per_img);
+        const int64_t rem = i - (int64_t)b * per_img;
+        const int ch = (int)(rem / (h * h));
+        const int y = (int)((rem / h) % h), x = (int)(rem % h);
+        const T *img = src + (idx ? idx[b] : (int64_t)b) * per_img + (int64_t)ch * h * h;
+        float v;
+        if (b >= n_aug) {
+            v = (float)img[y * h + x];
+        } else if (mode == 0) {
+            const float gx = __fadd_rn(linspace_f32(start, end, step, hp, x),
+                                       __fmul_rn((float)shift[2 * b + 0], sscale));
+            const float gy = __fadd_rn(linspace_f32(start, end, step, hp, y),
+                                       __fmul_rn((float)shift[2 * b + 1], sscale));
+            // grid_sample un-normalise, align_corners=False: ((g + 1) * size - 1) / 2
+            const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gx, 1.0f), (float)hp), 1.0f), 2.0f);
+            const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gy, 1.0f), (float)hp), 1.0f), 2.0f);
+            const float fx = floorf(ix), fy = floorf(iy);
+            const float wx1 = __fsub_rn(ix, fx), wy1 = __fsub_rn(iy, fy);
+            const float wx0 = __fsub_rn(1.0f, wx1), wy0 = __fsub_rn(1.0f, wy1);
+            const int x0 = (int)fx, y0 = (int)fy;
+            float acc = 0.0f;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int yy = y0 + dy;
+                const float wy = dy ? wy1 : wy0;
+                const bool vy = yy >= 0 && yy < hp;
+                const int sy = min(max(yy - pad, 0), h - 1);  // replicate pad
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int xx = x0 + dx;
+                    const float wx = dx ? wx1 : wx0;
+                    const bool vx = xx >= 0 && xx < hp;
+                    const int sx = min(max(xx - pad, 0), h - 1);
+                    const float wgt = (vy && vx) ? __fmul_rn(wy, wx) : 0.0f;
+                    acc = __fadd_rn(acc, __fmul_rn((float)img[sy * h + sx], wgt));
+                }
+            }
+            v = fminf(fmaxf(acc, 0.0f), 255.0f);
+        } else {
+            // DrqAug: ReflectionPad2d(pad) then crop at (h1, w1) (augmentations.py:188-204)
+            int sy = y + (int)shift[2 * b + 1] - pad, sx = x + (int)shift[2 * b + 0] - pad;
+            sy = sy < 0 ? -sy : (sy >= h ? 2 * (h - 1) - sy : sy);
+            sx = sx < 0 ? -sx : (sx >= h ? 2 * (h - 1) - sx : sx);
+            v = (float)img[sy * h + sx];
+            if (noise) v += noise[i];
+            v = fminf(fmaxf(v, 0.0f), 255.0f);
+        }
+        dst[i] = v;
+    }
+}
+
+inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
+    int64_t g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int ssac_gather_rows(const void *src, int src_dtype, int64_t row_elems, const int64_t *idx,
+                                int n_rows, float *dst, int64_t ld_dst, int64_t dst_col0, void *stream) {
+    if (n_rows <= 0 || row_elems <= 0) return 0;
+    const int64_t total = (int64_t)n_rows * row_elems;
+    if (src_dtype == 0)
+        hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid_for(total)), dim3(256), 0, ST,
+                           (const float *)src, row_elems, idx, n_rows, dst, ld_dst, dst_col0);
+    else if (src_dtype == 1)
+        hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, dim3(grid_for(total)), dim3(256), 0, ST,
+                           (const uint8_t *)src, row_elems, idx, n_rows, dst, ld_dst, dst_col0);
+    else
+        return ssac_fail("ssac_gather_rows: unsupported src_dtype");
+    return ssac_check_launch("gather_rows");
+}
+
+extern "C" int ssac_gather_transition(const void *s, const void *s1, int s_dtype, int64_t s_elems,
+                                      const float *act, int64_t a_elems, const float *rew,
+                                      const uint8_t *done, const int64_t *idx, int n_rows, float *xsa,
+                                      int64_t ld_x, float *x1sa, int64_t ld_x1, float *rew_out,
+                                      float *done_out, void *stream) {
+    if (n_rows <= 0) return 0;
+    const int64_t total = (int64_t)n_rows * (2 * s_elems + a_elems + 2);
+    if (s_dtype == 0)
+        hipLaunchKernelGGL(gather_transition_kernel<float>, dim3(grid_for(total)), dim3(256), 0, ST,
+                           (const float *)s, (const float *)s1, s_elems, act, a_elems, rew, done, idx,
+                           n_rows, xsa, ld_x, x1sa, ld_x1, rew_out, done_out);
+    else if (s_dtype == 1)
+        hipLaunchKernelGGL(gather_transition_kernel<uint8_t>, dim3(grid_for(total)), dim3(256), 0, ST,
+                           (const uint8_t *)s, (const uint8_t *)s1, s_elems, act, a_elems, rew, done,
+                           idx, n_rows, xsa, ld_x, x1sa, ld_x1, rew_out, done_out);
+    else
+        return ssac_fail("ssac_gather_transition: unsupported s_dtype");
+    return ssac_check_launch("gather_transition");
+}
+
+extern "C" int ssac_tanh_normal_fwd(const float *out, int64_t ld_out, const float *eps, int n_rows,
+                                    int act_dim, float lo, float hi, float *act_dst, int64_t ld_act,
+                                    int64_t act_col0, float *logp, void *stream) {
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(tanh_normal_fwd_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ST, out, ld_out,
+                       eps, n_rows, act_dim, lo, hi, act_dst, ld_act, act_col0, logp);
+    return ssac_check_launch("tanh_normal_fwd");
+}
+
+extern "C" int ssac_det_action_fwd(const float *out, int64_t ld_out, const float *eps, float sample_std,
+                                   const float *noise, float noise_scale, float noise_clip, int n_rows,
+                                   int act_dim, float *act_dst, int64_t ld_act, int64_t act_col0,
+                                   void *stream) {
+    if (n_rows <= 0) return 0;
+    const int total = n_rows * act_dim;
+    hipLaunchKernelGGL(det_action_fwd_kernel, dim3((total + 255) / 256), dim3(256), 0, ST, out, ld_out,
+                       eps, sample_std, noise, noise_scale, noise_clip, n_rows, act_dim, act_dst, ld_act,
+                       act_col0);
+    return ssac_check_launch("det_action_fwd");
+}
+
+extern "C" int ssac_td_target(const float *q_t, int n_sel, int n_rows, int q_dim,
+                              const float *logp_or_logits, const float *rew, const float *done,
+                              const float *log_alpha, int use_entropy, float gamma, ssac_popart *popart,
+                              int pop, float *td, float *logs, void *stream) {
+    if (n_sel < 1 || n_rows < 1 || q_dim < 1) return ssac_fail("ssac_td_target: bad sizes");
+    hipLaunchKernelGGL(td_target_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q_t, n_sel, n_rows, q_dim,
+                       logp_or_logits, rew, done, log_alpha, use_entropy, gamma, popart, pop, td, logs);
+    return ssac_check_launch("td_target");
+}
+
+extern "C" int ssac_critic_loss_bwd(const float *q, int n_nets, int n_rows, int q_dim, const float *act,
+                                    int64_t ld_act, const float *td, const float *weight,
+                                    const ssac_popart *popart, int pop, float denom, float *dq,
+                                    float *logs, void *stream) {
+    if (n_nets < 1 || n_rows < 1 || q_dim < 1) return ssac_fail("ssac_critic_loss_bwd: bad sizes");
+    if (q_dim > 1 && !act) return ssac_fail("ssac_critic_loss_bwd: discrete needs actions");
+    hipLaunchKernelGGL(critic_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_nets, n_rows,
+                       q_dim, act, ld_act, td, weight, popart, pop, denom, dq, logs);
+    return ssac_check_launch("critic_loss_bwd");
+}
+
+extern "C" int ssac_actor_loss_bwd(const float *q, int n_nets, int n_rows, const float *logp,
+                                   const float *log_alpha, int use_entropy, const ssac_popart *popart,
+                                   int pop, float inv_members, float *dq, float *logs, void *stream) {
+    if (n_nets < 1 || n_rows < 1) return ssac_fail("ssac_actor_loss_bwd: bad sizes");
+    hipLaunchKernelGGL(actor_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_nets, n_rows, logp,
+                       log_alpha, use_entropy, popart, pop, inv_members, dq, logs);
+    return ssac_check_launch("actor_loss_bwd");
+}
+
+extern "C" int ssac_tanh_normal_bwd(const float *dX, int n_nets, int64_t ldx, int64_t x_net_stride,
+                                    int64_t act_col0, const float *out, int64_t ld_out, const float *eps,
+                                    int n_rows, int act_dim, float lo, float hi, const float *log_alpha,
+                                    int use_entropy, float inv_members, float *d_out, int64_t ld_dout,
+                                    void *stream) {
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(tanh_normal_bwd_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ST, dX, n_nets, ldx,
+                       x_net_stride, act_col0, out, ld_out, eps, n_rows, act_dim, lo, hi, log_alpha,
+                       use_entropy, inv_members, d_out, ld_dout);
+    return ssac_check_launch("tanh_normal_bwd");
+}
+
+extern "C" int ssac_det_action_bwd(const float *dX, int n_nets, int64_t ldx, int64_t x_net_stride,
+                                   int64_t act_col0, const float *out, int64_t ld_out, int n_rows,
+                                   int act_dim, float *d_out, int64_t ld_dout, void *stream) {
+    if (n_rows <= 0) return 0;
+    const int total = n_rows * act_dim;
+    hipLaunchKernelGGL(det_action_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, ST, dX, n_nets, ldx,
+                       x_net_stride, act_col0, out, ld_out, n_rows, act_dim, d_out, ld_dout);
+    return ssac_check_launch("det_action_bwd");
+}
+
+extern "C" int ssac_discrete_actor_loss_bwd(const float *logits, const float *q, int n_nets, int n_rows,
+                                            int n_act, const float *log_alpha, const ssac_popart *popart,
+                                            int pop, float inv_members, float *d_logits, float *logs,
+                                            void *stream) {
+    if (n_nets < 1 || n_rows < 1 || n_act < 2) return ssac_fail("ssac_discrete_actor_loss_bwd: bad sizes");
+    hipLaunchKernelGGL(discrete_actor_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, logits, q,
+                       n_nets, n_rows, n_act, log_alpha, popart, pop, inv_members, d_logits, logs);
+    return ssac_check_launch("discrete_actor_loss_bwd");
+}
+
+extern "C" int ssac_alpha_update(float *log_alpha, float *adam_m, float *adam_v, ssac_adam_ctl *ctl,
+                                 const float *logp_or_logits, int n_rows, int n_act, float target_entropy,
+                                 float *logs, void *stream) {
+    if (n_rows < 1) return ssac_fail("ssac_alpha_update: bad sizes");
+    hipLaunchKernelGGL(alpha_update_kernel, dim3(1), dim3(RED_THREADS), 0, ST, log_alpha, adam_m, adam_v,
+                       ctl, logp_or_logits, n_rows, n_act, target_entropy, logs);
+    return ssac_check_launch("alpha_update");
+}
+
+extern "C" int ssac_adam_advance(ssac_adam_ctl *ctl, void *stream) {
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, ST, ctl);
+    return ssac_check_launch("adam_advance");
+}
+
+extern "C" int ssac_clip_coef(ssac_adam_ctl *ctl, const float *sumsq, int n, float max_norm,
+                              float *norm_out, void *stream) {
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(RED_THREADS), 0, ST, ctl, sumsq, n, max_norm,
+                       norm_out);
+    return ssac_check_launch("clip_coef");
+}
+
+extern "C" int ssac_group_norms(const float *sumsq, int n_groups, int group_size,
+                                const ssac_adam_ctl *scale_by_clip, float *out, void *stream) {
+    if (n_groups <= 0 || group_size <= 0) return 0;
+    hipLaunchKernelGGL(group_norms_kernel, dim3(n_groups), dim3(64), 0, ST, sumsq, group_size,
+                       scale_by_clip, out);
+    return ssac_check_launch("group_norms");
+}
+
+extern "C" int ssac_adam_step(float *params, float *adam_m, float *adam_v, const float *grads, int64_t n,
+                              const ssac_adam_ctl *ctl, void *stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for(n)), dim3(256), 0, ST, params, adam_m, adam_v,
+                       grads, n, ctl);
+    return ssac_check_launch("adam_step");
+}
+
+extern "C" int ssac_polyak(float *target, const float *source, int64_t n, float tau, void *stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(polyak_kernel, dim3(grid_for(n)), dim3(256), 0, ST, target, source, n, tau);
+    return ssac_check_launch("polyak");
+}
+
+extern "C" int ssac_zero(float *p, int64_t n, void *stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(zero_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, n);
+    return ssac_check_launch("zero");
+}
+
+extern "C" int ssac_sunrise_weights(const float *q, int n_members, int n_rows, float temp, float *w,
+                                    float *logs, void *stream) {
+    if (n_members < 2 || n_rows < 1) return ssac_fail("ssac_sunrise_weights: bad sizes");
+    hipLaunchKernelGGL(sunrise_weights_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_members, n_rows,
+                       temp, w, logs);
+    return ssac_check_launch("sunrise_weights");
+}
+
+extern "C" int ssac_drq_shift(const void *src, int src_dtype, const int64_t *idx, int n, int c, int h,
+                              int pad, const int64_t *shift, int mode, const float *noise, int n_aug,
+                              float *dst, void *stream) {
+    if (n <= 0) return 0;
+    if (mode != 0 && mode != 1) return ssac_fail("ssac_drq_shift: bad mode");
+    const int64_t total = (int64_t)n * c * h * h;
+    if (src_dtype == 0)
+        hipLaunchKernelGGL(drq_shift_kernel<float>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST,
+                           (const float *)src, idx, n, c, h, pad, shift, mode, noise, n_aug, dst);
+    else if (src_dtype == 1)
+        hipLaunchKernelGGL(drq_shift_kernel<uint8_t>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST,
+                           (const uint8_t *)src, idx, n, c, h, pad, shift, mode, noise, n_aug, dst);
+    else
+        return ssac_fail("ssac_drq_shift: unsupported src_dtype");
+    return ssac_check_launch("drq_shift");
+}
+
+// ------------------------------------------------------------------ error plumbing
+static thread_local char g_err[256] = "";
+
+int ssac_fail(const char *msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return 1;
+}
+
+int ssac_check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return 2;
+    }
+    return 0;
+}
+
+extern "C" const char *ssac_last_error(void) { return g_err; }
+extern "C" int ssac_abi_version(void) { return SSAC_ABI_VERSION; }

@@ -1,0 +1,283 @@
+"""Host-side plumbing over the C ABI: packed parameter arenas, Adam state, workspace and
+the forward/backward launch sequences of a 3-layer ensemble MLP.
+
+PyTorch is used here for device memory (tensors own the HBM allocations), streams and
+pinned staging only; all arithmetic on the update path happens in libssac_hip.so.
+"""
+import ctypes as C
+import struct
+
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+SEGS = ("w1", "b1", "w2", "b2", "w3", "b3")
+# bench.py's live kernel timing: when PROFILE["tag"] names a forward, its hidden-layer (fc2) launch
+# is bracketed by events recorded on the launch stream.
+PROFILE = {"tag": None, "events": []}
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(t=None):
+    if not torch.cuda.is_available():
+        raise RuntimeError("super_sac_amd runs its update path only on an MI355X/ROCm device; "
+                           "no CPU fallback exists (the CPU oracle under oracle/ is test-only)")
+    if t is not None and not t.is_cuda:
+        raise RuntimeError("expected a device tensor on the update path")
+
+
+def mlp_layout(in_dim, hidden, out_dim):
+    offs = (C.c_int64 * 6)()
+    stride = lib.ssac_mlp_layout(in_dim, hidden, out_dim, offs)
+    return int(stride), [int(o) for o in offs]
+
+
+class Workspace:
+    """Named scratch tensors, allocated once per (name, shape) so the hot loop never allocates."""
+
+    def __init__(self, device):
+        self.device = device
+        self._bufs = {}
+
+    def get(self, name, shape, dtype=torch.float32, zero=False):
+        key = (name, tuple(shape), dtype)
+        buf = self._bufs.get(key)
+        if buf is None:
+            buf = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=self.device)
+            self._bufs[key] = buf
+        return buf
+
+
+class MlpArena:
+    """`n_nets` identically shaped 3-layer MLPs packed as one HBM arena (include/ssac_hip.h).
+
+    ``adopt`` re-points the ``.data`` of existing ``nn.Linear`` parameters at views of the
+    arena, so the torch modules (state_dict / save / load / deepcopy) and the kernels share
+    one copy of the weights."""
+
+    def __init__(self, n_nets, in_dim, hidden, out_dim, device):
+        self.n_nets, self.in_dim, self.hidden, self.out_dim = n_nets, in_dim, hidden, out_dim
+        self.stride, self.offs = mlp_layout(in_dim, hidden, out_dim)
+        self.shapes = [(hidden, in_dim), (hidden,), (hidden, hidden), (hidden,), (out_dim, hidden),
+                       (out_dim,)]
+        self.params = torch.zeros(n_nets * self.stride, dtype=torch.float32, device=device)
+        self.device = device
+
+    def like(self):
+        return torch.zeros_like(self.params)
+
+    def desc(self, tensor=None):
+        t = self.params if tensor is None else tensor
+        return _lib.MlpDesc(t.data_ptr(), self.stride, self.n_nets, self.in_dim, self.hidden,
+                            self.out_dim)
+
+    def view(self, net, seg, tensor=None):
+        t = self.params if tensor is None else tensor
+        k = SEGS.index(seg)
+        o = net * self.stride + self.offs[k]
+        shp = self.shapes[k]
+        n = 1
+        for d in shp:
+            n *= d
+        return t[o:o + n].view(shp)
+
+    def tiles(self, layer):
+        return int(lib.ssac_wgrad_tiles(C.byref(self.desc()), layer))
+
+    # ---- adoption of torch modules -------------------------------------------------------
+    @staticmethod
+    def linear_triples(module):
+        """the three Linear layers of an actor/critic module, in order."""
+        last = [n for n in ("fc3", "out", "act_p") if hasattr(module, n)]
+        assert hasattr(module, "fc1") and hasattr(module, "fc2") and len(last) == 1, \
+            f"{type(module).__name__} is not a 3-layer MLP the engine recognises"
+        return [module.fc1, module.fc2, getattr(module, last[0])]
+
+    def is_bound(self, modules):
+        """cheap per-call validation: every parameter still points at its arena slot."""
+        ptrs = self.__dict__.get("_bound_ptrs")
+        if ptrs is None or len(ptrs[0]) != 6 * len(modules):
+            params, expect = [], []
+            for j, m in enumerate(modules):
+                for k, lin in enumerate(self.linear_triples(m)):
+                    for seg, p in ((SEGS[2 * k], lin.weight), (SEGS[2 * k + 1], lin.bias)):
+                        params.append(p)
+                        expect.append(self.view(j, seg).data_ptr())
+            ptrs = self.__dict__["_bound_ptrs"] = (params, expect)
+        return all(p.data_ptr() == e for p, e in zip(*ptrs))
+
+    @classmethod
+    def adopt(cls, modules, device):
+        l0 = cls.linear_triples(modules[0])
+        in_dim, hidden, out_dim = l0[0].in_features, l0[0].out_features, l0[2].out_features
+        arena = cls(len(modules), in_dim, hidden, out_dim, device)
+        with torch.no_grad():
+            for j, m in enumerate(modules):
+                lins = cls.linear_triples(m)
+                assert (lins[0].in_features, lins[1].in_features, lins[2].out_features) == \
+                    (in_dim, hidden, out_dim), "ensemble members must share one shape"
+                for k, lin in enumerate(lins):
+                    for seg, p in ((SEGS[2 * k], lin.weight), (SEGS[2 * k + 1], lin.bias)):
+                        v = arena.view(j, seg)
+                        v.copy_(p.data.to(device=device, dtype=torch.float32))
+                        p.data = v
+        return arena
+
+
+def bind_arena(owner, key, modules, device):
+    """Arena for `modules`, cached on `owner` and re-validated by pointer each call (a
+    deepcopy or load_state_dict that re-allocates parameters triggers a re-pack)."""
+    cache = owner.__dict__.setdefault("_ssac_arenas", {})
+    arena = cache.get(key)
+    if arena is None or arena.n_nets != len(modules) or not arena.is_bound(modules):
+        arena = MlpArena.adopt(modules, device)
+        cache[key] = arena
+    return arena
+
+
+class DeviceStruct:
+    """A small C struct living in device memory (Adam control block, PopArt state)."""
+
+    def __init__(self, cstruct, device):
+        self.ctype = type(cstruct)
+        self.size = C.sizeof(cstruct)
+        self.dev = torch.zeros(self.size, dtype=torch.uint8, device=device)
+        self.write(cstruct)
+
+    def write(self, cstruct):
+        host = torch.frombuffer(bytearray(bytes(cstruct)), dtype=torch.uint8)
+        self.dev.copy_(host)
+
+    def read(self):
+        raw = bytes(self.dev.cpu().numpy().tobytes())
+        return self.ctype.from_buffer_copy(raw)
+
+    @property
+    def ptr(self):
+        return self.dev.data_ptr()
+
+
+class AdamGroup:
+    """Adam state for one ``torch.optim.Adam`` instance (hyper-parameters are read from its
+    param_groups, exactly the values main.py:188-239 passes).  Moments live in arenas of the
+    same layout as the parameters they belong to."""
+
+    def __init__(self, optimizer, device):
+        g = optimizer.param_groups[0]
+        self.lr, (self.b1, self.b2) = float(g["lr"]), g["betas"]
+        self.eps, self.wd = float(g["eps"]), float(g["weight_decay"])
+        assert not g.get("amsgrad", False), "amsgrad is not supported (the reference never uses it)"
+        ctl = _lib.AdamCtl(self.lr, self.b1, self.b2, self.eps, self.wd, 0.0, 1.0, 1.0, 0,
+                           (C.c_int32 * 3)(0, 0, 0), self.lr, self.b1, self.b2)
+        self.ctl = DeviceStruct(ctl, device)
+        self.moments = {}
+        self.device = device
+
+    def moments_for(self, key, like):
+        mv = self.moments.get(key)
+        if mv is None or mv[0].numel() != like.numel():
+            mv = (torch.zeros_like(like), torch.zeros_like(like))
+            self.moments[key] = mv
+        return mv
+
+    def advance(self):
+        check(lib.ssac_adam_advance(self.ctl.ptr, stream()))
+
+
+def adam_group(optimizer, device):
+    grp = getattr(optimizer, "_ssac_adam", None)
+    if grp is None:
+        grp = AdamGroup(optimizer, device)
+        optimizer._ssac_adam = grp
+    return grp
+
+
+# ------------------------------------------------------------------------------------------
+# launch sequences
+# ------------------------------------------------------------------------------------------
+def mlp_forward(arena, X, ldx, x_net_stride, n_rows, ws, tag, net_ids=None, n_sel=None,
+                params=None):
+    """h1 = relu(fc1 x), h2 = relu(fc2 h1), y = out(h2) for every selected net.
+    Returns (h1, h2, y) with shapes (n_sel, n_rows, H|H|out); all three are kept because the
+    backward pass needs them (they are what autograd would have saved)."""
+    n_sel = arena.n_nets if n_sel is None else n_sel
+    H, O = arena.hidden, arena.out_dim
+    h1 = ws.get(tag + ".h1", (n_sel, n_rows, H))
+    h2 = ws.get(tag + ".h2", (n_sel, n_rows, H))
+    y = ws.get(tag + ".y", (n_sel, n_rows, O))
+    d = arena.desc(params)
+    ids = _ptr(net_ids)
+    st = stream()
+    check(lib.ssac_mlp_layer_fwd(C.byref(d), 0, ids, n_sel, X.data_ptr(), ldx, x_net_stride, n_rows,
+                                 h1.data_ptr(), H, n_rows * H, 1, st))
+    prof = PROFILE["tag"] == tag
+    if prof:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.ssac_mlp_layer_fwd(C.byref(d), 1, ids, n_sel, h1.data_ptr(), H, n_rows * H, n_rows,
+                                 h2.data_ptr(), H, n_rows * H, 1, st))
+    if prof:
+        e1.record()
+        PROFILE["events"].append((e0, e1))
+    check(lib.ssac_mlp_layer_fwd(C.byref(d), 2, ids, n_sel, h2.data_ptr(), H, n_rows * H, n_rows,
+                                 y.data_ptr(), O, n_rows * O, 0, st))
+    return h1, h2, y
+
+
+def mlp_backward(arena, dY, X, ldx, x_net_stride, h1, h2, n_rows, ws, tag, *, adam=None,
+                 adam_key=None, need_dx=False, grads=None, sumsq=None, target=None, tau=0.0,
+                 net_ids=None, n_sel=None, update=True):
+    """Backward of `mlp_forward` given dL/dy.  With `update`, the weight gradients are consumed
+    in-kernel by Adam (or stored to `grads` when clipping needs the global norm first).
+    Returns dX (n_sel, n_rows, in_dim) when `need_dx`."""
+    n_sel = arena.n_nets if n_sel is None else n_sel
+    H, O, I = arena.hidden, arena.out_dim, arena.in_dim
+    d = arena.desc()
+    ids = _ptr(net_ids)
+    st = stream()
+    dz2 = ws.get(tag + ".dz2", (n_sel, n_rows, H))
+    dz1 = ws.get(tag + ".dz1", (n_sel, n_rows, H))
+    check(lib.ssac_mlp_layer_dgrad(C.byref(d), 2, ids, n_sel, dY.data_ptr(), O, n_rows * O,
+                                   h2.data_ptr(), H, n_rows * H, n_rows,
+                                   dz2.data_ptr(), H, n_rows * H, st))
+    check(lib.ssac_mlp_layer_dgrad(C.byref(d), 1, ids, n_sel, dz2.data_ptr(), H, n_rows * H,
+                                   h1.data_ptr(), H, n_rows * H, n_rows,
+                                   dz1.data_ptr(), H, n_rows * H, st))
+    dX = None
+    if need_dx:
+        dX = ws.get(tag + ".dx", (n_sel, n_rows, I))
+        check(lib.ssac_mlp_layer_dgrad(C.byref(d), 0, ids, n_sel, dz1.data_ptr(), H, n_rows * H,
+                                       0, 0, 0, n_rows, dX.data_ptr(), I, n_rows * I, st))
+    if update:
+        m = v = None
+        if grads is None:
+            m, v = adam.moments_for(adam_key, arena.params)
+        tiles = [arena.tiles(l) for l in range(3)]
+        ttot = sum(tiles)
+        srcs = ((2, h2, H, n_rows * H, dY, O, n_rows * O),
+                (1, h1, H, n_rows * H, dz2, H, n_rows * H),
+                (0, X, ldx, x_net_stride, dz1, H, n_rows * H))
+        off = {0: 0, 1: tiles[0], 2: tiles[0] + tiles[1]}
+        for layer, xin, ldi, sxi, dy, ldy, sy in srcs:
+            ss = 0 if sumsq is None else sumsq.data_ptr() + 4 * off[layer]
+            check(lib.ssac_mlp_layer_wgrad(C.byref(d), layer, ids, n_sel, xin.data_ptr(), ldi, sxi,
+                                           dy.data_ptr(), ldy, sy, n_rows, _ptr(m), _ptr(v),
+                                           0 if adam is None else adam.ctl.ptr, _ptr(grads), ss, ttot,
+                                           _ptr(target), float(tau), st))
+    return dX
+
+
+def wgrad_tiles_total(arena):
+    return sum(arena.tiles(l) for l in range(3))
+
+
+def pack_f32(*vals):
+    return struct.pack("%df" % len(vals), *vals)

@@ -1,0 +1,263 @@
+"""The three update functions of the reference's training loop, same names and keyword
+arguments (super_sac/learning.py:18-141 critic_update, :344-421 online_actor_update,
+:222-263 alpha_update; call sites main.py:380-405, :492-510, :529-542).
+
+What changes underneath: the per-critic Python loop + autograd + per-parameter Adam of the
+reference become ensemble-batched HIP launches -- forward of all N critics in three launches,
+hand-derived backward, and weight-gradient GEMMs whose epilogue is the Adam step -- and the
+logs stay on the device until somebody reads them.
+"""
+import ctypes as C
+
+import torch
+
+from . import engine, rng
+from . import learning_utils as lu
+from ._lib import check, lib
+
+
+def _critic_input(bt, ws, tag, s_rep, a, discrete):
+    """(X, ldx, in_dim) for the online critics: [s | a] (continuous) or s (discrete)."""
+    B, S = s_rep.shape
+    if bt is not None and bt.xsa is not None and s_rep.data_ptr() == bt.xsa.data_ptr():
+        return bt.xsa, bt.xsa.stride(0)
+    if discrete:
+        return s_rep, lu._row_stride(s_rep)
+    x = lu._concat_buffer(ws, tag, s_rep, a.shape[1])
+    x[:, S:].copy_(a)
+    return x, x.stride(0)
+
+
+def _clip_and_step(adam, members, clip, slot_norm):
+    """clip_grad_norm_ over ALL listed arenas jointly, then Adam from the stored gradients
+    (learning.py:122-130 / :413-416).  members: list of (arena, key, grads, sumsq)."""
+    st = engine.stream()
+    allss = members[0][3] if len(members) == 1 else torch.cat([m[3] for m in members])
+    check(lib.ssac_clip_coef(adam.ctl.ptr, allss.data_ptr(), allss.numel(), float(clip), 0, st))
+    for arena, key, grads, _ in members:
+        m, v = adam.moments_for(key, arena.params)
+        check(lib.ssac_adam_step(arena.params.data_ptr(), m.data_ptr(), v.data_ptr(), grads.data_ptr(),
+                                 arena.params.numel(), adam.ctl.ptr, st))
+
+
+def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimizer, log_alphas,
+                  batch_size, gamma, critic_clip, encoder_clip, target_critic_ensemble_n,
+                  weighted_bellman_temp, weight_type, pop, augmenter, encoder_lambda, random_process,
+                  noise_clip, aug_mix=0.75, discrete=False, per=False, update_priorities=False,
+                  dr3_coeff=0.0):
+    engine.require_gpu()
+    if encoder_lambda:
+        raise NotImplementedError("encoder invariance loss (SURVEY 8(f) rank 4) is not accelerated")
+    if dr3_coeff > 0:
+        raise NotImplementedError("DR3 regulariser (SURVEY 8(f) rank 4) is not accelerated")
+    if update_priorities:
+        raise NotImplementedError("PER priority refresh (SURVEY 8(f) rank 1) is not accelerated")
+    E = agent.ensemble_size
+    assert E <= lu.MAX_MEMBERS
+    dev = log_alphas[0].device
+    ws = lu.agent_ws(agent, dev)
+    slot = lu.log_block(dev)
+    logs = {}
+    st = engine.stream()
+    adam = engine.adam_group(critic_optimizer, dev)
+    adam.advance()
+    clip_members = []
+    replay_dicts = []
+    member_ss = []
+    for i in range(E):
+        rd = lu.sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter,
+                                        aug_mix=aug_mix, per=per)
+        td, _ = lu.compute_td_targets(logs=logs, replay_dict=rd, agent=agent, target_agent=target_agent,
+                                      ensemble_idx=i, ensemble_n=target_critic_ensemble_n,
+                                      log_alphas=log_alphas, pop=pop, gamma=gamma,
+                                      random_process=random_process, noise_clip=noise_clip,
+                                      discrete=discrete, _slot=slot)
+        bw = lu.compute_backup_weights(logs=logs, replay_dict=rd, agent=agent, target_agent=target_agent,
+                                       weight_type=weight_type, weight_temp=weighted_bellman_temp,
+                                       batch_size=batch_size, discrete=discrete, _slot=slot)
+        o, a, r, o1, d = rd["primary_batch"]
+        B = r.shape[0]
+        s_rep = lu.encode(agent.encoder, o)
+        arena = agent.critics[i].arena(dev)
+        N, qd = arena.n_nets, arena.out_dim
+        X, ldx = _critic_input(rd.get("_ssac"), ws, f"cu.x{i}", s_rep, a, discrete)
+        h1, h2, q = engine.mlp_forward(arena, X, ldx, 0, B, ws, f"cu.c{i}")
+        dq = ws.get(f"cu.dq{i}", (N, B, qd))
+        popart = agent.popart[i]
+        weight_ptr = 0
+        if not isinstance(bw, float):
+            weight_ptr = bw.data_ptr()  # imp_weights is ones(1) on the uniform path
+        check(lib.ssac_critic_loss_bwd(q.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0), td.data_ptr(),
+                                       weight_ptr, popart.ptr if popart else 0,
+                                       1 if (popart and pop) else 0, float(E * N), dq.data_ptr(),
+                                       slot.data_ptr(), st))
+        ttot = engine.wgrad_tiles_total(arena)
+        ss = ws.get(f"cu.ss{i}", (N * ttot,))
+        if critic_clip:
+            grads = ws.get(f"cu.g{i}", (arena.params.numel(),), zero=True)
+            engine.mlp_backward(arena, dq, X, ldx, 0, h1, h2, B, ws, f"cu.c{i}", grads=grads, sumsq=ss)
+            clip_members.append((arena, ("critic", i), grads, ss))
+        else:
+            engine.mlp_backward(arena, dq, X, ldx, 0, h1, h2, B, ws, f"cu.c{i}", adam=adam,
+                                adam_key=("critic", i), sumsq=ss)
+        member_ss.append(ss)
+        rd["td_target"] = td
+        replay_dicts.append(rd)
+    if critic_clip:
+        _clip_and_step(adam, clip_members, critic_clip, None)
+    # encoder: identity encoders carry no trainable tensor on this path (their dummy Linear(1,1)
+    # never receives a gradient, nets/__init__.py:24), so encoder_optimizer.step() is a no-op.
+    logs["losses/last_member_critic_td_error"] = slot[lu.L_TD_ERR]
+    logs["losses/critic_overall_loss"] = slot[lu.L_CRITIC_LOSS]
+    pick = rng.choice(agent.critics)  # same Python-RNG draw as learning.py:135
+    k = next(j for j, c in enumerate(agent.critics) if c is pick)
+    check(lib.ssac_group_norms(member_ss[k].data_ptr(), 1, member_ss[k].numel(),
+                               adam.ctl.ptr if critic_clip else 0, slot[lu.L_CRITIC_GN:].data_ptr(), st))
+    logs["gradients/critic_random_grad"] = slot[lu.L_CRITIC_GN]
+    logs["gradients/encoder_criticloss_grad_norm"] = slot[lu.L_ENC_GN]
+    return logs, replay_dicts
+
+
+def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_size, clip,
+                        random_process, noise_clip, augmenter, aug_mix, premade_replay_dicts=None,
+                        per=False, discrete=False, use_baseline=False):
+    engine.require_gpu()
+    if use_baseline:
+        raise NotImplementedError("advantage baseline (AFBC path, SURVEY 8(f) rank 1)")
+    E = agent.ensemble_size
+    dev = log_alphas[0].device
+    ws = lu.agent_ws(agent, dev)
+    slot = lu.log_block(dev)
+    logs = {}
+    st = engine.stream()
+    adam = engine.adam_group(actor_optimizer, dev)
+    adam.advance()
+    inv_e = 1.0 / len(agent.actors)
+    clip_members, member_ss = [], []
+    for i, ((actor, critic), popart, log_alpha) in enumerate(zip(agent.ensemble, agent.popart, log_alphas)):
+        if premade_replay_dicts is not None:
+            rd = premade_replay_dicts[i]
+        else:
+            rd = lu.sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter,
+                                            aug_mix=aug_mix, per=per)
+        o = rd["primary_batch"][0]
+        s_rep = lu.encode(agent.encoder, o)  # no gradient to the encoder (learning.py:378-380)
+        B, S = s_rep.shape
+        lds = lu._row_stride(s_rep)
+        a_arena = engine.bind_arena(actor, "self", [actor], dev)
+        c_arena = critic.arena(dev)
+        N = c_arena.n_nets
+        ah1, ah2, aout = engine.mlp_forward(a_arena, s_rep, lds, 0, B, ws, f"au.a{i}")
+        kind = lu.actor_kind(actor)
+        pp, dopop = (popart.ptr if popart else 0), (1 if (popart and pop) else 0)
+        if kind == "discrete":
+            A = a_arena.out_dim
+            _, _, q = engine.mlp_forward(c_arena, s_rep, lds, 0, B, ws, f"au.c{i}")
+            d_out = ws.get(f"au.dout{i}", (1, B, A))
+            check(lib.ssac_discrete_actor_loss_bwd(aout.data_ptr(), q.data_ptr(), N, B, A,
+                                                   log_alpha.data_ptr(), pp, dopop, inv_e,
+                                                   d_out.data_ptr(), slot[lu.L_ACTOR_LOSS:].data_ptr(), st))
+        else:
+            A = actor.action_size
+            xpi = lu._concat_buffer(ws, f"au.x{i}", s_rep, A)
+            logp = ws.get(f"au.logp{i}", (B,))
+            eps = rng.draw_normal((B, A), dev)  # a_dist.rsample() (learning.py:392)
+            if kind == "stochastic":
+                if random_process is not None:
+                    raise NotImplementedError("exploration noise on a stochastic actor")
+                check(lib.ssac_tanh_normal_fwd(aout.data_ptr(), 2 * A, eps.data_ptr(), B, A,
+                                               float(actor.log_std_low), float(actor.log_std_high),
+                                               xpi.data_ptr(), S + A, S, logp.data_ptr(), st))
+                use_entropy = 1
+            else:
+                if random_process is None:
+                    raise NotImplementedError("deterministic actor without an exploration process")
+                noise = rng.draw_normal((B, A), dev)
+                check(lib.ssac_det_action_fwd(aout.data_ptr(), A, eps.data_ptr(), 1e-4, noise.data_ptr(),
+                                              float(random_process.current_scale),
+                                              float(noise_clip) if noise_clip is not None else 0.0, B, A,
+                                              xpi.data_ptr(), S + A, S, st))
+                use_entropy = 0
+            ch1, ch2, q = engine.mlp_forward(c_arena, xpi, S + A, 0, B, ws, f"au.c{i}")
+            dq = ws.get(f"au.dq{i}", (N, B, 1))
+            check(lib.ssac_actor_loss_bwd(q.data_ptr(), N, B, logp.data_ptr(), log_alpha.data_ptr(),
+                                          use_entropy, pp, dopop, inv_e, dq.data_ptr(),
+                                          slot[lu.L_ACTOR_LOSS:].data_ptr(), st))
+            # dQ/da through the arg-min critic of every row; critic weights are NOT updated here
+            dX = engine.mlp_backward(c_arena, dq, xpi, S + A, 0, ch1, ch2, B, ws, f"au.c{i}",
+                                     need_dx=True, update=False)
+            d_out = ws.get(f"au.dout{i}", (1, B, a_arena.out_dim))
+            if kind == "stochastic":
+                check(lib.ssac_tanh_normal_bwd(dX.data_ptr(), N, S + A, B * (S + A), S, aout.data_ptr(),
+                                               2 * A, eps.data_ptr(), B, A, float(actor.log_std_low),
+                                               float(actor.log_std_high), log_alpha.data_ptr(), 1, inv_e,
+                                               d_out.data_ptr(), 2 * A, st))
+            else:
+                check(lib.ssac_det_action_bwd(dX.data_ptr(), N, S + A, B * (S + A), S, aout.data_ptr(), A,
+                                              B, A, d_out.data_ptr(), A, st))
+        ttot = engine.wgrad_tiles_total(a_arena)
+        ss = ws.get(f"au.ss{i}", (ttot,))
+        if clip:
+            grads = ws.get(f"au.g{i}", (a_arena.params.numel(),), zero=True)
+            engine.mlp_backward(a_arena, d_out, s_rep, lds, 0, ah1, ah2, B, ws, f"au.a{i}", grads=grads,
+                                sumsq=ss)
+            clip_members.append((a_arena, ("actor", i), grads, ss))
+        else:
+            engine.mlp_backward(a_arena, d_out, s_rep, lds, 0, ah1, ah2, B, ws, f"au.a{i}", adam=adam,
+                                adam_key=("actor", i), sumsq=ss)
+        member_ss.append(ss)
+    if clip:
+        _clip_and_step(adam, clip_members, clip, None)
+    pick = rng.choice(agent.actors)  # learning.py:417-419
+    k = next(j for j, a_ in enumerate(agent.actors) if a_ is pick)
+    check(lib.ssac_group_norms(member_ss[k].data_ptr(), 1, member_ss[k].numel(),
+                               adam.ctl.ptr if clip else 0, slot[lu.L_ACTOR_GN:].data_ptr(), st))
+    logs["gradients/random_actor_online_grad"] = slot[lu.L_ACTOR_GN]
+    logs["losses/actor_pg_loss"] = slot[lu.L_ACTOR_LOSS]
+    return logs
+
+
+def alpha_update(buffer, agent, optimizers, batch_size, log_alphas, augmenter, aug_mix, target_entropy,
+                 premade_replay_dicts, discrete):
+    engine.require_gpu()
+    dev = log_alphas[0].device
+    ws = lu.agent_ws(agent, dev)
+    slot = lu.log_block(dev)
+    logs = {}
+    st = engine.stream()
+    for i in range(agent.ensemble_size):
+        if premade_replay_dicts is not None:
+            rd = premade_replay_dicts[i]
+        else:
+            rd = lu.sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter,
+                                            per=False, aug_mix=aug_mix)
+        o = rd["primary_batch"][0]
+        s_rep = lu.encode(agent.encoder, o)
+        B, S = s_rep.shape
+        actor = agent.actors[i]
+        a_arena = engine.bind_arena(actor, "self", [actor], dev)
+        _, _, aout = engine.mlp_forward(a_arena, s_rep, lu._row_stride(s_rep), 0, B, ws, f"al.a{i}")
+        kind = lu.actor_kind(actor)
+        if kind == "discrete":
+            lp_ptr, n_act = aout.data_ptr(), a_arena.out_dim
+        else:
+            A = actor.action_size
+            logp = ws.get(f"al.logp{i}", (B,))
+            if kind == "stochastic":
+                eps = rng.draw_normal((B, A), dev)  # a_dist.sample() (learning.py:255)
+                scratch = ws.get(f"al.act{i}", (B, A))
+                check(lib.ssac_tanh_normal_fwd(aout.data_ptr(), 2 * A, eps.data_ptr(), B, A,
+                                               float(actor.log_std_low), float(actor.log_std_high),
+                                               scratch.data_ptr(), A, 0, logp.data_ptr(), st))
+            else:
+                import math
+                logp.fill_(A * (-math.log(1e-4) - 0.5 * math.log(2 * math.pi)))
+            lp_ptr, n_act = logp.data_ptr(), 1
+        adam = engine.adam_group(optimizers[i], dev)
+        la = log_alphas[i]
+        m, v = adam.moments_for("log_alpha", la.data)
+        check(lib.ssac_alpha_update(la.data_ptr(), m.data_ptr(), v.data_ptr(), adam.ctl.ptr, lp_ptr, B,
+                                    n_act, float(target_entropy), slot[lu.L_ALPHA0 + 2 * i:].data_ptr(), st))
+        logs[f"losses/alpha_loss_{i}"] = slot[lu.L_ALPHA0 + 2 * i]
+        logs[f"alphas/alpha_{i}"] = slot[lu.L_ALPHA0 + 2 * i + 1]
+    return logs

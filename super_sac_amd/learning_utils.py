@@ -1,0 +1,345 @@
+"""Update helpers with the reference's names and signatures (super_sac/learning_utils.py):
+``sample_move_and_augment`` (:174), ``compute_td_targets`` (:298), ``compute_backup_weights``
+(:357), ``soft_update`` / ``hard_update`` (:160-167), ``GaussianExplorationNoise`` (:18-66).
+
+Every arithmetic step is a kernel of libssac_hip.so; this file only sequences launches and
+keeps the reference's host-RNG order (index draw -> augmentation draw -> action noise ->
+REDQ subset).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import augmentations, engine, nets, rng
+from ._lib import check, lib
+
+LOG_WIDTH = 64
+MAX_MEMBERS = 8
+# slot layout of one update's log block (floats)
+L_CRITIC_LOSS, L_TD_ERR, L_CRITIC_GN, L_ENC_GN = 0, 1, 2, 3
+L_TD0 = 4            # + 3*i : mean, std, entropy bonus of member i
+L_BW = 28            # bellman weights mean, max, min, std
+L_ACTOR_LOSS, L_ACTOR_GN = 32, 33
+L_ALPHA0 = 34        # + 2*i : alpha_loss_i, alpha_i
+
+
+class LogRing:
+    """Ring of device log blocks.  Update functions hand out 0-dim views of a block as log
+    values, so nothing synchronises until the caller reads them (the reference blocks on
+    ``.item()`` several times per update: learning.py:132, learning_utils.py:351-353)."""
+
+    def __init__(self, device, slots=512):
+        self.buf = torch.zeros(slots, LOG_WIDTH, dtype=torch.float32, device=device)
+        self.k = 0
+
+    def next(self):
+        self.k = (self.k + 1) % self.buf.shape[0]
+        blk = self.buf[self.k]
+        check(lib.ssac_zero(blk.data_ptr(), LOG_WIDTH, engine.stream()))
+        return blk
+
+
+_rings = {}
+
+
+def log_block(device):
+    ring = _rings.get(device)
+    if ring is None:
+        ring = _rings[device] = LogRing(device)
+    return ring.next()
+
+
+def agent_ws(agent, device):
+    ws = agent.__dict__.get("_ssac_ws")
+    if ws is None or ws.device != device:
+        ws = agent.__dict__["_ssac_ws"] = engine.Workspace(device)
+    return ws
+
+
+class GaussianExplorationNoise:
+    """learning_utils.py:18-66.  Inside the updates only ``current_scale`` is read; the noise
+    itself is drawn on the device and applied by ``ssac_det_action_fwd``."""
+
+    def __init__(self, action_space, start_scale=1.0, final_scale=0.1, steps_annealed=1000, eps=1e-6):
+        assert start_scale >= final_scale
+        self.action_space = action_space
+        self.start_scale, self.final_scale = start_scale, final_scale
+        self.steps_annealed = steps_annealed
+        self.current_scale = start_scale
+        self._scale_slope = (start_scale - final_scale) / steps_annealed
+        self.eps = eps
+
+    def sample(self, action, clip=None, update_schedule=False):
+        assert isinstance(action, np.ndarray), "device-side noise is applied inside the update kernels"
+        noise = self.current_scale * np.random.randn(*action.shape)
+        if clip is not None:
+            noise = np.clip(noise, -clip, clip)
+        out = np.clip(action + noise, self.action_space.low + self.eps, self.action_space.high - self.eps)
+        if update_schedule:
+            self.current_scale = max(self.current_scale - self._scale_slope, self.final_scale)
+        return out
+
+
+# ------------------------------------------------------------------------------------------
+def _polyak_tensor(t, s, tau):
+    check(lib.ssac_polyak(t.data_ptr(), s.data_ptr(), t.numel(), float(tau), engine.stream()))
+
+
+def soft_update(target, source, tau):
+    """theta_bar <- (1-tau) theta_bar + tau theta over all parameters (learning_utils.py:160-162);
+    one launch over the packed arena when both sides are packed ensembles."""
+    if hasattr(target, "arena") and hasattr(source, "arena"):
+        dev = next(source.parameters()).device
+        ta, sa = target.arena(dev), source.arena(dev)
+        if ta.params.numel() == sa.params.numel():
+            _polyak_tensor(ta.params, sa.params, tau)
+            return
+    for tp, sp in zip(target.parameters(), source.parameters()):
+        if tp.is_cuda and tp.data.is_contiguous() and sp.data.is_contiguous():
+            _polyak_tensor(tp.data, sp.data, tau)
+        else:
+            raise RuntimeError("soft_update expects contiguous device parameters")
+
+
+def hard_update(target, source):
+    soft_update(target, source, 1.0)
+
+
+# ------------------------------------------------------------------------------------------
+class _Batch:
+    """device buffers of one sampled minibatch: xsa = [s | a], x1sa = [s' | (a' written later)]."""
+    __slots__ = ("B", "S", "A", "xsa", "x1sa", "r", "d", "key", "pixel")
+
+
+def sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, per=True):
+    assert len(buffer) >= batch_size
+    if per:
+        raise NotImplementedError("prioritised sampling is not on the accelerated path yet "
+                                  "(the 5 target configs sample uniformly, main.py:401)")
+    idx_cpu, idx = buffer.draw_uniform_indices(batch_size)
+    st = buffer._storage
+    dev = st.device
+    imp_weights = torch.ones(1, device=dev)
+    B = batch_size
+    keys = list(st.s_stack.keys())
+    A = int(np.prod(st.action_stack.shape[1:]))
+    r = torch.empty(B, 1, device=dev)
+    d = torch.empty(B, 1, device=dev)
+    # one randomisation per call, shared by s and s' (augmentations.py:28-29)
+    augmenter.change_randomization_params()
+    bt = _Batch()
+    bt.B, bt.A = B, A
+    vec = len(keys) == 1 and st.s_stack[keys[0]].dim() == 2
+    if vec:
+        key = keys[0]
+        S = st.s_stack[key].shape[1]
+        xsa = torch.empty(B, S + A, device=dev)
+        x1sa = torch.empty(B, S + A, device=dev)
+        src = st.s_stack[key]
+        check(lib.ssac_gather_transition(src.data_ptr(), st.s1_stack[key].data_ptr(),
+                                         1 if src.dtype == torch.uint8 else 0, S,
+                                         st.action_stack.data_ptr(), A, st.reward_stack.data_ptr(),
+                                         st.done_stack.data_ptr(), idx.data_ptr(), B, xsa.data_ptr(),
+                                         S + A, x1sa.data_ptr(), S + A, r.data_ptr(), d.data_ptr(),
+                                         engine.stream()))
+        o, o1, a = {key: xsa[:, :S]}, {key: x1sa[:, :S]}, xsa[:, S:]
+        bt.S, bt.xsa, bt.x1sa, bt.key, bt.pixel = S, xsa, x1sa, key, False
+        assert augmenter.is_identity(), "image augmentations need image observations"
+    else:
+        shift_aug = augmenter.single_shift()
+        k_aug = int(batch_size * aug_mix)
+        o, o1 = {}, {}
+        for key in keys:
+            src, src1 = st.s_stack[key], st.s1_stack[key]
+            if src.dim() == 4 and shift_aug is not None:
+                n, (c, h, w) = B, src.shape[1:]
+                assert h == w
+                for dst_dict, s_arr in ((o, src), (o1, src1)):
+                    out = torch.empty(B, c, h, w, device=dev)
+                    nz = rng.draw_normal((B, c, h, w), dev) if shift_aug.noise else None
+                    shift_aug.apply(s_arr, idx, B, c, h, k_aug, out, nz)
+                    dst_dict[key] = out
+            else:
+                assert augmenter.is_identity(), "unsupported augmentation on the accelerated path"
+                o[key] = st.gather_field(src, idx, B)
+                o1[key] = st.gather_field(src1, idx, B)
+        a = st.gather_field(st.action_stack, idx, B)
+        if a.dim() < 2:
+            a = a.unsqueeze(1)
+        st.gather_field(st.reward_stack, idx, B, dst=r, ld=1)
+        st.gather_field(st.done_stack, idx, B, dst=d, ld=1)
+        bt.S, bt.xsa, bt.x1sa, bt.key, bt.pixel = None, None, None, None, True
+    bt.r, bt.d = r, d
+    return {"primary_batch": (o, a, r, o1, d), "augmented_obs": None, "original_obs": None,
+            "priority_idxs": idx_cpu.numpy(), "imp_weights": imp_weights, "_ssac": bt}
+
+
+# ------------------------------------------------------------------------------------------
+def encode(encoder, obs_dict):
+    """state representation of the batch.  Identity encoders return the (strided) view."""
+    key = getattr(encoder, "ssac_identity_key", None)
+    if key is not None:
+        return obs_dict[key]
+    raise NotImplementedError(f"{type(encoder).__name__}: this encoder has no HIP path yet")
+
+
+def _row_stride(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major (B, F) device tensor"
+    return t.stride(0)
+
+
+def _concat_buffer(ws, tag, s_rep, A):
+    """(B, S+A) buffer whose first S columns hold s_rep (copy is device plumbing)."""
+    B, S = s_rep.shape
+    buf = ws.get(tag, (B, S + A))
+    buf[:, :S].copy_(s_rep)
+    return buf
+
+
+def actor_kind(actor):
+    if isinstance(actor, nets.DiscreteActor) or hasattr(actor, "act_p"):
+        return "discrete"
+    if getattr(actor, "dist_impl", None) == "deterministic":
+        return "deterministic"
+    return "stochastic"
+
+
+def _upload_ids(ws, ids, device, tag):
+    stager = ws.__dict__.setdefault("_stager", None)
+    if stager is None:
+        from .replay import _IndexStager
+        stager = ws.__dict__["_stager"] = _IndexStager(device)
+    return stager.upload(torch.tensor(ids, dtype=torch.int32), tag=tag)
+
+
+def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ensemble_n, log_alphas,
+                       pop, gamma, random_process, noise_clip, discrete=False, _slot=None):
+    o, a, r, o1, d = replay_dict["primary_batch"]
+    i = ensemble_idx
+    dev = r.device
+    ws = agent_ws(agent, dev)
+    slot = _slot if _slot is not None else log_block(dev)
+    actor = agent.actors[i]
+    popart = agent.popart[i]
+    log_alpha = log_alphas[i]
+    B = r.shape[0]
+    kind = actor_kind(actor)
+    st = engine.stream()
+
+    s1_rep = encode(target_agent.encoder, o1)
+    S = s1_rep.shape[1]
+    a_arena = engine.bind_arena(actor, "self", [actor], dev)
+    _, _, aout = engine.mlp_forward(a_arena, s1_rep, _row_stride(s1_rep), 0, B, ws, f"td.a{i}")
+    t_arena = target_agent.critics[i].arena(dev)
+    N = t_arena.n_nets
+    assert 0 < ensemble_n <= N
+    bt = replay_dict.get("_ssac")
+    logp = ws.get(f"td.logp{i}", (B,))
+    use_entropy = 0
+    if kind == "discrete":
+        ids = rng.draw_subset(N, ensemble_n)
+        ids_dev = _upload_ids(ws, ids, dev, "sub")
+        _, _, q1 = engine.mlp_forward(t_arena, s1_rep, _row_stride(s1_rep), 0, B, ws, f"td.c{i}",
+                                      net_ids=ids_dev, n_sel=ensemble_n)
+        lp_ptr, qd = aout.data_ptr(), t_arena.out_dim
+        a_s1 = None
+    else:
+        A = actor.action_size
+        if bt is not None and bt.x1sa is not None and s1_rep.data_ptr() == bt.x1sa.data_ptr():
+            x1 = bt.x1sa
+        else:
+            x1 = _concat_buffer(ws, f"td.x1.{i}", s1_rep, A)
+        if kind == "stochastic":
+            eps = rng.draw_normal((B, A), dev)
+            check(lib.ssac_tanh_normal_fwd(aout.data_ptr(), 2 * A, eps.data_ptr(), B, A,
+                                           float(actor.log_std_low), float(actor.log_std_high),
+                                           x1.data_ptr(), S + A, S, logp.data_ptr(), st))
+            if random_process is not None:
+                raise NotImplementedError("exploration noise on a stochastic actor")
+            use_entropy = 1
+        else:
+            noise = None
+            scale = 0.0
+            if random_process is not None:
+                noise = rng.draw_normal((B, A), dev)
+                scale = float(random_process.current_scale)
+            else:
+                raise NotImplementedError("deterministic actor without an exploration process")
+            check(lib.ssac_det_action_fwd(aout.data_ptr(), A, 0, 0.0, noise.data_ptr(), scale,
+                                          float(noise_clip) if noise_clip is not None else 0.0, B, A,
+                                          x1.data_ptr(), S + A, S, st))
+        ids = rng.draw_subset(N, ensemble_n)
+        ids_dev = _upload_ids(ws, ids, dev, "sub")
+        _, _, q1 = engine.mlp_forward(t_arena, x1, S + A, 0, B, ws, f"td.c{i}", net_ids=ids_dev,
+                                      n_sel=ensemble_n)
+        lp_ptr, qd = logp.data_ptr(), 1
+        a_s1 = x1[:, S:]
+    td = torch.empty(B, 1, device=dev)
+    check(lib.ssac_td_target(q1.data_ptr(), ensemble_n, B, qd, lp_ptr, r.data_ptr(), d.data_ptr(),
+                             log_alpha.data_ptr(), use_entropy, float(gamma),
+                             popart.ptr if popart else 0, 1 if (popart and pop) else 0,
+                             td.data_ptr(), slot[L_TD0 + 3 * i:].data_ptr(), st))
+    logs[f"td_targets/mean_td_target_{i}"] = slot[L_TD0 + 3 * i]
+    logs[f"td_targets/std_td_target_{i}"] = slot[L_TD0 + 3 * i + 1]
+    logs[f"td_targets/entropy_bonus_{i}"] = slot[L_TD0 + 3 * i + 2]
+    replay_dict["_subset"] = ids
+    if kind == "discrete":
+        a_s1 = aout[0]  # logits; the reference returns probs here, only used by dr3
+    return td, (s1_rep, a_s1)
+
+
+def compute_backup_weights(logs, replay_dict, agent, target_agent, weight_type, weight_temp, batch_size,
+                           discrete=False, _slot=None):
+    if weight_type is None or weight_temp is None or agent.ensemble_size == 1:
+        return 1.0
+    if weight_type != "sunrise":
+        raise NotImplementedError("only SUNRISE backup weights are on the accelerated path")
+    if discrete:
+        raise NotImplementedError("SUNRISE weights with discrete actions")
+    o, a, _, o1, _ = replay_dict["primary_batch"]
+    dev = a.device
+    ws = agent_ws(agent, dev)
+    slot = _slot if _slot is not None else log_block(dev)
+    s_rep = encode(target_agent.encoder, o)
+    B, S = s_rep.shape
+    A = a.shape[1]
+    bt = replay_dict.get("_ssac")
+    if bt is not None and bt.xsa is not None and s_rep.data_ptr() == bt.xsa.data_ptr():
+        x = bt.xsa
+    else:
+        x = _concat_buffer(ws, "bw.x", s_rep, A)
+        x[:, S:].copy_(a)
+    E = agent.ensemble_size
+    qmin = ws.get("bw.qmin", (E, B))
+    for k in range(E):
+        ar = target_agent.critics[k].arena(dev)
+        _, _, q = engine.mlp_forward(ar, x, S + A, 0, B, ws, f"bw.c{k}")
+        # min over this member's critics: TD-target kernel's min is reused via torch-free path
+        _min_over_nets(q, ar.n_nets, B, qmin[k])
+    w = torch.empty(B, 1, device=dev)
+    check(lib.ssac_sunrise_weights(qmin.data_ptr(), E, B, float(weight_temp), w.data_ptr(),
+                                   slot[L_BW:].data_ptr(), engine.stream()))
+    for j, nm in enumerate(("mean", "max", "min", "std")):
+        logs[f"bellman_weights/{nm}"] = slot[L_BW + j]
+    return w
+
+
+def _min_over_nets(q, n, B, out):
+    """out[b] = min_j q[j][b] using the TD-target kernel in its plain-min configuration
+    (gamma=1, r=0, d=0, no entropy, no PopArt): td = 0 + 1*(1-0)*min."""
+    dev = q.device
+    z = _zeros(dev, B)
+    check(lib.ssac_td_target(q.data_ptr(), n, B, 1, 0, z.data_ptr(), z.data_ptr(), z.data_ptr(), 0, 1.0,
+                             0, 0, out.data_ptr(), 0, engine.stream()))
+
+
+_zero_cache = {}
+
+
+def _zeros(dev, n):
+    z = _zero_cache.get((dev, n))
+    if z is None:
+        z = _zero_cache[(dev, n)] = torch.zeros(n, device=dev)
+    return z

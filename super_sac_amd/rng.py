@@ -1,0 +1,38 @@
+"""Host random streams of the update path, kept on the SAME generators the reference uses
+so a run that swaps in this engine consumes them identically:
+
+  replay indices, DrQ shifts      torch CPU default generator   (replay.py:122, augmentations.py:227)
+  REDQ target subset, logged net  Python ``random``             (agent.py:29, learning.py:135)
+  action noise eps                generator of the compute device (distributions: Normal.sample)
+
+Parity tests replace these functions to replay the draws recorded in tests/golden.
+"""
+import random
+
+import torch
+
+
+def draw_indices(n, batch_size):
+    return torch.randint(n, (batch_size,))
+
+
+def draw_subset(num_critics, k):
+    return random.sample(range(num_critics), k=k)
+
+
+def choice(seq):
+    return random.choice(seq)
+
+
+def draw_normal(shape, device):
+    return torch.randn(*shape, device=device)
+
+
+def draw_drqv2_shift(batch_size, pad):
+    return torch.randint(0, 2 * pad + 1, size=(batch_size, 1, 1, 2))
+
+
+def draw_drq_offsets(batch_size, pad):
+    w1 = torch.randint(0, pad * 2, (batch_size,))
+    h1 = torch.randint(0, pad * 2, (batch_size,))
+    return w1, h1

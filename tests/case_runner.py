@@ -1,0 +1,324 @@
+"""Replays the multi-step parity cases of tests/golden with either backend:
+
+  * ``run_oracle(name)``  -- the CPU oracle (oracle/ssac_oracle.py); CPU test, no GPU needed
+  * ``run_engine(name)``  -- the HIP engine through super_sac_amd's reference-shaped API
+
+Both consume the host-RNG draws recorded in the fixture (replay indices, REDQ subsets,
+normal draws) and return the same record layout as the fixture, so one comparison routine
+serves oracle-vs-reference, engine-vs-reference and engine-vs-oracle.
+"""
+import copy
+import math
+import os
+import sys
+from itertools import chain
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import ssac_oracle as orc  # noqa: E402
+import synth  # noqa: E402
+
+GOLDEN = os.path.join(HERE, "golden")
+
+
+def load_fixture(name):
+    return dict(np.load(os.path.join(GOLDEN, f"{name}.npz")))
+
+
+def _buffers(cfg):
+    return synth.synth_transitions(cfg["rows"], cfg["obs"], cfg["act"], cfg["discrete"],
+                                   seed=cfg["seed"] + 100, n_actions=cfg["act"])
+
+
+def _oracle_agent(cfg):
+    oa = orc.AgentOracle(state_dim=cfg["obs"], act_dim=cfg["act"], hidden=cfg["hidden"],
+                         num_critics=cfg["N"], ensemble_size=cfg["E"], discrete=cfg["discrete"],
+                         actor_kind=cfg["actor"], log_std_low=cfg["lo"], log_std_high=cfg["hi"],
+                         popart=cfg["popart"], seed=cfg["seed"])
+    if cfg["popart"]:
+        for p in oa.popart:
+            p.min_steps = cfg.get("popart_min_steps", 1000)
+    return oa
+
+
+def _target_entropy(cfg):
+    return (-math.log(1.0 / cfg["act"]) * 0.98) if cfg["discrete"] else -float(cfg["act"])
+
+
+def _flat(params):
+    return np.concatenate([p.detach().cpu().numpy().ravel() for p in params])
+
+
+def _fingerprint(params):
+    vals = []
+    for p in params:
+        flat = p.detach().cpu().numpy().ravel()
+        vals.append(flat[synth.fingerprint_indices(flat.size)])
+    return np.concatenate(vals)
+
+
+# ------------------------------------------------------------------------------------------
+def run_oracle(name):
+    cfg = synth.CASES[name]
+    fx = load_fixture(name)
+    B, E = cfg["B"], cfg["E"]
+    obuf = orc.ReplayOracle(cfg["cap"])
+    obuf.load_experience(*_buffers(cfg))
+    oa = _oracle_agent(cfg).requires_grad_(True)
+    ot = oa.clone()
+    copt = orc.AdamOracle(oa.critic_params(), lr=cfg["lr"])
+    aopt = orc.AdamOracle(oa.actor_params(), lr=cfg["lr"])
+    eopt = orc.AdamOracle([], lr=1e-4)
+    init_alpha = max(cfg["init_alpha"], 1e-15)
+    las = [torch.tensor([math.log(init_alpha)], requires_grad=True) for _ in range(E)]
+    lopts = [orc.AdamOracle([la], lr=cfg["alpha_lr"], betas=(0.5, 0.999)) for la in las]
+    aug = orc.AugOracle("identity", B)
+    nscale = cfg["noise"]["scale"] if cfg["noise"] else None
+    nclip = cfg["noise"]["clip"] if cfg["noise"] else None
+    stochastic = cfg["actor"] == "stochastic"
+    T = lambda key: torch.from_numpy(fx[key])
+    rec, upd = {}, 0
+    dicts = None
+    for cyc in range(cfg["cycles"]):
+        for k in range(cfg["utd"]):
+            logs, dicts = orc.critic_update(
+                obuf, oa, ot, copt, eopt, las, B, cfg["gamma"], cfg["clip"], cfg["clip"], cfg["n"],
+                cfg["temp"], cfg["weight_type"], cfg["pop"], aug, aug_mix=0.0, noise_scale=nscale,
+                noise_clip=nclip, idx_list=[fx[f"u{upd}_idx{i}"] for i in range(E)],
+                eps_list=[T(f"u{upd}_eps{i}") for i in range(E)] if stochastic else None,
+                noise_list=[T(f"u{upd}_noise{i}") for i in range(E)] if cfg["noise"] else None,
+                subset_list=[list(fx[f"u{upd}_subset{i}"]) for i in range(E)])
+            for i in range(E):
+                rec[f"u{upd}_td{i}"] = dicts[i]["td_target"].numpy()
+                if cfg["popart"]:
+                    s = oa.popart[i].state()
+                    rec[f"u{upd}_popart{i}"] = np.array([s["mu"], s["nu"], s["w"], s["b"], s["sigma"], s["t"]])
+            for key, val in logs.items():
+                rec[f"u{upd}_log:{key}"] = np.float64(val)
+            if int(fx[f"u{upd}_polyak"]):
+                orc.soft_update(ot.critic_params(), oa.critic_params(), cfg["tau"])
+            upd += 1
+        have_eps = not cfg["discrete"]
+        alog = orc.online_actor_update(
+            oa, aopt, las, dicts, cfg["pop"], cfg["clip"],
+            eps_list=[T(f"a{cyc}_eps{i}") for i in range(E)] if have_eps else None,
+            noise_scale=nscale, noise_clip=nclip,
+            noise_list=[T(f"a{cyc}_noise{i}") for i in range(E)] if cfg["noise"] else None)
+        rec[f"a{cyc}_log:losses/actor_pg_loss"] = np.float64(alog["losses/actor_pg_loss"])
+        if cfg["init_alpha"] > 0 and cfg["alpha_lr"] > 0:
+            llog = orc.alpha_update(oa, lopts, las, dicts, _target_entropy(cfg),
+                                    eps_list=[T(f"l{cyc}_eps{i}") for i in range(E)] if stochastic else None)
+            for key, val in llog.items():
+                rec[f"l{cyc}_log:{key}"] = np.float64(val)
+    _finalise(rec, fx, oa.critic_params(), oa.actor_params(), ot.critic_params(),
+              copt.m, copt.v, las)
+    return rec
+
+
+def _finalise(rec, fx, crit, act, tcrit, m_list, v_list, las):
+    for tag, plist in (("critic", crit), ("actor", act), ("target_critic", tcrit)):
+        if f"final_{tag}" in fx:
+            rec[f"final_{tag}"] = _flat(plist)
+        else:
+            rec[f"finalfp_{tag}"] = _fingerprint(plist)
+    rec["finalfp_critic_m"] = _fingerprint(m_list)
+    rec["finalfp_critic_v"] = _fingerprint(v_list)
+    rec["final_log_alpha"] = np.array([float(x) for x in las], np.float64)
+
+
+# ------------------------------------------------------------------------------------------
+class DrawPlayer:
+    """Feeds recorded host-RNG draws to super_sac_amd.rng in the order the engine asks."""
+
+    def __init__(self, device):
+        self.device = device
+        self.idx, self.sub, self.normal = [], [], []
+
+    def install(self, rng_mod):
+        self._saved = (rng_mod.draw_indices, rng_mod.draw_subset, rng_mod.draw_normal)
+        rng_mod.draw_indices = lambda n, b: torch.from_numpy(self.idx.pop(0).astype(np.int64))
+        rng_mod.draw_subset = lambda n, k: [int(v) for v in self.sub.pop(0)]
+        rng_mod.draw_normal = lambda shape, device: torch.from_numpy(self.normal.pop(0)).to(self.device)
+        self._mod = rng_mod
+
+    def restore(self):
+        m = self._mod
+        m.draw_indices, m.draw_subset, m.draw_normal = self._saved
+
+
+def build_engine_agent(cfg, device):
+    """super_sac_amd.Agent holding the same seeded weights as the oracle agent."""
+    import super_sac_amd as ssa
+    oa = _oracle_agent(cfg)
+    actor_cls = {"stochastic": ssa.nets.ContinuousStochasticActor,
+                 "deterministic": ssa.nets.ContinuousDeterministicActor,
+                 "discrete": ssa.nets.DiscreteActor}[cfg["actor"]]
+    critic_cls = ssa.nets.DiscreteCritic if cfg["discrete"] else ssa.nets.ContinuousCritic
+    ag = ssa.Agent(act_space_size=cfg["act"], encoder=ssa.nets.IdentityEncoder(cfg["obs"]),
+                   actor_network_cls=actor_cls, critic_network_cls=critic_cls, discrete=cfg["discrete"],
+                   ensemble_size=cfg["E"], num_critics=cfg["N"], ucb_bonus=0.0,
+                   hidden_size=cfg["hidden"], auto_rescale_targets=cfg["popart"],
+                   log_std_low=cfg["lo"], log_std_high=cfg["hi"])
+    head = {"stochastic": "fc3", "deterministic": "out", "discrete": "act_p"}[cfg["actor"]]
+
+    def load(mod, p, names):
+        with torch.no_grad():
+            for (wk, bk), nm in zip((("w1", "b1"), ("w2", "b2"), ("w3", "b3")), names):
+                getattr(mod, nm).weight.copy_(p[wk])
+                getattr(mod, nm).bias.copy_(p[bk])
+    for i in range(cfg["E"]):
+        load(ag.actors[i], oa.actors[i], ("fc1", "fc2", head))
+        for j in range(cfg["N"]):
+            load(ag.critics[i].nets[j], oa.critics[i][j], ("fc1", "fc2", "out"))
+    ag.to(device)
+    if cfg["popart"]:
+        for p in ag.popart:
+            p.min_steps = cfg.get("popart_min_steps", 1000)
+    ag.train()
+    return ag
+
+
+def run_engine(name, device="cuda"):
+    import super_sac_amd as ssa
+    cfg = synth.CASES[name]
+    fx = load_fixture(name)
+    B, E = cfg["B"], cfg["E"]
+    device = torch.device(device)
+    buf = ssa.replay.ReplayBuffer(cfg["cap"], device=device)
+    buf.load_experience(*_buffers(cfg))
+    agent = build_engine_agent(cfg, device)
+    target = copy.deepcopy(agent)
+    copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=cfg["lr"],
+                            weight_decay=0, betas=(0.9, 0.999))
+    aopt = torch.optim.Adam(chain(*(a.parameters() for a in agent.actors)), lr=cfg["lr"],
+                            weight_decay=0, betas=(0.9, 0.999))
+    eopt = torch.optim.Adam(agent.encoder.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    init_alpha = max(cfg["init_alpha"], 1e-15)
+    las, lopts = [], []
+    for _ in range(E):
+        la = torch.Tensor([math.log(init_alpha)]).to(device)
+        la.requires_grad = True
+        las.append(la)
+        lopts.append(torch.optim.Adam([la], lr=cfg["alpha_lr"], betas=(0.5, 0.999)))
+    aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(B)])
+    rproc = None
+    nclip = None
+    if cfg["noise"]:
+        import types
+        space = types.SimpleNamespace(low=-np.ones(cfg["act"], np.float32), high=np.ones(cfg["act"], np.float32))
+        rproc = ssa.learning_utils.GaussianExplorationNoise(space, start_scale=cfg["noise"]["scale"],
+                                                            final_scale=cfg["noise"]["scale"] * 0.1,
+                                                            steps_annealed=1000)
+        nclip = cfg["noise"]["clip"]
+    stochastic = cfg["actor"] == "stochastic"
+    player = DrawPlayer(device)
+    player.install(ssa.rng)
+    rec, upd = {}, 0
+    try:
+        for cyc in range(cfg["cycles"]):
+            for k in range(cfg["utd"]):
+                for i in range(E):
+                    player.idx.append(fx[f"u{upd}_idx{i}"])
+                    if stochastic:
+                        player.normal.append(fx[f"u{upd}_eps{i}"])
+                    if cfg["noise"]:
+                        player.normal.append(fx[f"u{upd}_noise{i}"])
+                    player.sub.append(fx[f"u{upd}_subset{i}"])
+                logs, dicts = ssa.learning.critic_update(
+                    buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt,
+                    encoder_optimizer=eopt, log_alphas=las, batch_size=B, gamma=cfg["gamma"],
+                    critic_clip=cfg["clip"], encoder_clip=cfg["clip"],
+                    target_critic_ensemble_n=cfg["n"], weighted_bellman_temp=cfg["temp"],
+                    weight_type=cfg["weight_type"], pop=cfg["pop"], augmenter=aug, encoder_lambda=0,
+                    aug_mix=0.0, discrete=cfg["discrete"], random_process=rproc, noise_clip=nclip,
+                    per=False, update_priorities=False, dr3_coeff=0.0)
+                for i in range(E):
+                    assert np.array_equal(dicts[i]["priority_idxs"], fx[f"u{upd}_idx{i}"])
+                    rec[f"u{upd}_td{i}"] = dicts[i]["td_target"].cpu().numpy()
+                    if cfg["popart"]:
+                        p = agent.popart[i]._read()
+                        rec[f"u{upd}_popart{i}"] = np.array([p.mu, p.nu, p.w, p.b, agent.popart[i].sigma, p.t])
+                for key, val in logs.items():
+                    rec[f"u{upd}_log:{key}"] = np.float64(float(val))
+                if int(fx[f"u{upd}_polyak"]):
+                    for ac, tc in zip(agent.critics, target.critics):
+                        ssa.learning_utils.soft_update(tc, ac, cfg["tau"])
+                upd += 1
+            for i in range(E):
+                if not cfg["discrete"]:
+                    player.normal.append(fx[f"a{cyc}_eps{i}"])
+                if cfg["noise"]:
+                    player.normal.append(fx[f"a{cyc}_noise{i}"])
+            alog = ssa.learning.online_actor_update(
+                buffer=buf, agent=agent, pop=cfg["pop"], actor_optimizer=aopt, log_alphas=las,
+                batch_size=B, aug_mix=0.0, clip=cfg["clip"], augmenter=aug, per=False,
+                discrete=cfg["discrete"], random_process=rproc, noise_clip=nclip,
+                premade_replay_dicts=dicts, use_baseline=False)
+            rec[f"a{cyc}_log:losses/actor_pg_loss"] = np.float64(float(alog["losses/actor_pg_loss"]))
+            if cfg["init_alpha"] > 0 and cfg["alpha_lr"] > 0:
+                for i in range(E):
+                    if stochastic:
+                        player.normal.append(fx[f"l{cyc}_eps{i}"])
+                llog = ssa.learning.alpha_update(
+                    buffer=buf, agent=agent, optimizers=lopts, batch_size=B, log_alphas=las,
+                    augmenter=aug, aug_mix=0.0, target_entropy=_target_entropy(cfg),
+                    premade_replay_dicts=dicts, discrete=cfg["discrete"])
+                for key, val in llog.items():
+                    rec[f"l{cyc}_log:{key}"] = np.float64(float(val))
+        assert not player.idx and not player.sub and not player.normal, "unconsumed recorded draws"
+    finally:
+        player.restore()
+    crit = [p for i in range(E) for j in range(cfg["N"]) for p in agent.critics[i].nets[j].parameters()]
+    tcrit = [p for i in range(E) for j in range(cfg["N"]) for p in target.critics[i].nets[j].parameters()]
+    act = [p for i in range(E) for p in agent.actors[i].parameters()]
+    grp = copt._ssac_adam
+    m_list, v_list = [], []
+    for i in range(E):
+        ar = agent.critics[i].arena(device)
+        m, v = grp.moments_for(("critic", i), ar.params)
+        for j in range(cfg["N"]):
+            for seg in ("w1", "b1", "w2", "b2", "w3", "b3"):
+                m_list.append(ar.view(j, seg, m))
+                v_list.append(ar.view(j, seg, v))
+    _finalise(rec, fx, crit, act, tcrit, m_list, v_list, las)
+    return rec
+
+
+# ------------------------------------------------------------------------------------------
+def compare(rec, fx, *, td_tol=2e-4, log_rtol=5e-4, par_tol=3e-5, who="backend"):
+    """Assert rec (a backend's record) matches the reference fixture within the stated
+    fp32 tolerances.  Returns the worst deviations for reporting."""
+    worst = {"td": 0.0, "log": 0.0, "param": 0.0}
+    for key, ref in fx.items():
+        if key not in rec:
+            assert not (key.startswith("u") and ("_td" in key or "_log:" in key)) or \
+                "gradients/" in key, f"{who}: missing {key}"
+            continue
+        got = np.asarray(rec[key], dtype=np.float64)
+        ref = np.asarray(ref, dtype=np.float64)
+        if "_td" in key:
+            dv = float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))))
+            worst["td"] = max(worst["td"], dv)
+            assert dv <= td_tol, f"{who}: {key} deviates {dv:.3e} > {td_tol}"
+        elif "_log:" in key:
+            dv = float(abs(got - ref) / max(1.0, abs(ref)))
+            worst["log"] = max(worst["log"], dv)
+            assert dv <= log_rtol, f"{who}: {key} = {got} vs reference {ref}"
+        elif key.startswith("final") and key != "final_log_alpha":
+            scale = 1.0 if not key.endswith("_v") else max(1e-12, float(np.max(np.abs(ref))))
+            dv = float(np.max(np.abs(got - ref)) / scale)
+            tol = par_tol if not key.endswith("_v") else 1e-3
+            worst["param"] = max(worst["param"], dv)
+            assert dv <= tol, f"{who}: {key} deviates {dv:.3e} > {tol}"
+        elif key == "final_log_alpha":
+            assert np.max(np.abs(got - ref)) <= 1e-6, f"{who}: log_alpha {got} vs {ref}"
+        elif "_popart" in key:
+            assert np.allclose(got, ref, rtol=1e-4, atol=1e-5), f"{who}: {key} {got} vs {ref}"
+    return worst

@@ -1,0 +1,531 @@
+"""GPU: every kernel of libssac_hip.so, called through the C ABI, against the CPU oracle
+(oracle/ssac_oracle.py) and the reference-generated fixtures on the same inputs.
+
+Tolerances are fp32 round-off class: the GEMMs use exact-fp32 MFMA (a k-ordered fma chain),
+torch's CPU GEMM sums in a different order, so |diff| <= ~1e-5 * sum|a*b| is expected.
+Index/byte work (gathers, integer crops) must be bit-exact.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import case_runner
+import ssac_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+_KEEP = []
+
+
+def D(t):
+    """device pointer of a host tensor; the device copy is kept alive for the whole test session
+    (a temporary `.to(DEV).data_ptr()` could be recycled by the caching allocator before launch)."""
+    d = t.to(DEV)
+    _KEEP.append(d)
+    if len(_KEEP) > 4096:
+        torch.cuda.synchronize()
+        del _KEEP[:2048]
+    return d.data_ptr()
+
+
+@pytest.fixture(scope="module")
+def ssa():
+    import super_sac_amd
+    return super_sac_amd
+
+
+def _arena_from(ssa, mlps, dev=DEV):
+    """engine.MlpArena filled from a list of oracle MLP dicts."""
+    in_dim, hidden, out = mlps[0]["w1"].shape[1], mlps[0]["w1"].shape[0], mlps[0]["w3"].shape[0]
+    ar = ssa.engine.MlpArena(len(mlps), in_dim, hidden, out, torch.device(dev))
+    for j, p in enumerate(mlps):
+        for seg in ssa.engine.SEGS:
+            ar.view(j, seg).copy_(p[seg])
+    return ar
+
+
+def _close(got, ref, atol, rtol=1e-5, what=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    assert bool((err <= bound).all()), f"{what}: max err {float(err.max()):.3e} (atol {atol})"
+
+
+# --------------------------------------------------------------------- ensemble MLP forward
+@pytest.mark.parametrize("B,in_dim,H,out,N", [(512, 23, 256, 1, 10), (100, 17, 64, 12, 1),
+                                              (77, 393, 96, 1, 3), (1024, 128, 256, 4, 2), (1, 5, 32, 3, 2)])
+def test_mlp_forward_matches_oracle(ssa, B, in_dim, H, out, N):
+    rng = np.random.RandomState(B + in_dim)
+    mlps = [orc.make_mlp(rng, in_dim, H, out) for _ in range(N)]
+    x = torch.from_numpy(rng.standard_normal((B, in_dim)).astype(np.float32))
+    ar = _arena_from(ssa, mlps)
+    ws = ssa.engine.Workspace(torch.device(DEV))
+    xd = x.to(DEV)
+    h1, h2, y = ssa.engine.mlp_forward(ar, xd, in_dim, 0, B, ws, "t")
+    for j, p in enumerate(mlps):
+        yr, h2r = orc.mlp3(p, x)
+        _close(h2[j], h2r, 2e-5, what=f"h2[{j}]")
+        _close(y[j], yr, 5e-5, what=f"y[{j}]")
+
+
+def test_mlp_forward_subset_ids_and_strided_input(ssa):
+    """REDQ subset through net_ids; X is a strided view (the [s|a] buffer read as s only)."""
+    rng = np.random.RandomState(3)
+    mlps = [orc.make_mlp(rng, 17, 64, 2) for _ in range(6)]
+    buf = torch.from_numpy(rng.standard_normal((200, 23)).astype(np.float32)).to(DEV)
+    ar = _arena_from(ssa, mlps)
+    ws = ssa.engine.Workspace(torch.device(DEV))
+    ids = torch.tensor([4, 1, 5], dtype=torch.int32, device=DEV)
+    _, _, y = ssa.engine.mlp_forward(ar, buf, 23, 0, 200, ws, "t", net_ids=ids, n_sel=3)
+    for k, j in enumerate([4, 1, 5]):
+        _close(y[k], orc.mlp3(mlps[j], buf[:, :17].cpu())[0], 5e-5, what=f"net {j}")
+
+
+def test_ensemble_q_known_answers_from_reference(ssa):
+    """tests/golden/nets.npz: Q-values the REFERENCE's ContinuousCritic modules produced."""
+    f = case_runner.load_fixture("nets")
+    rng = np.random.RandomState(int(f["ensq_seed"]))
+    crit = [orc.make_mlp(rng, 23, 256, 1) for _ in range(10)]
+    s = rng.standard_normal((512, 17)).astype(np.float32)
+    a = rng.uniform(-1, 1, (512, 6)).astype(np.float32)
+    x = torch.from_numpy(np.concatenate([s, a], 1)).to(DEV)
+    ar = _arena_from(ssa, crit)
+    _, _, q = ssa.engine.mlp_forward(ar, x, 23, 0, 512, ssa.engine.Workspace(torch.device(DEV)), "t")
+    _close(q[:, :, 0], torch.from_numpy(f["ensq_q"]), 5e-5, what="ensemble Q")
+
+
+# --------------------------------------------------------------------- backward + Adam
+def _autograd_reference(mlps, x, dy):
+    ps = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in mlps]
+    xs = x.clone().requires_grad_(True)
+    tot = 0.0
+    for j, p in enumerate(ps):
+        y, _ = orc.mlp3(p, xs)
+        tot = tot + (y * dy[j]).sum()
+    tot.backward()
+    return ps, xs.grad
+
+
+@pytest.mark.parametrize("B,in_dim,H,out,N", [(512, 23, 256, 1, 4), (96, 17, 64, 12, 1), (130, 40, 96, 5, 3)])
+def test_backward_grads_and_input_grad(ssa, B, in_dim, H, out, N):
+    rng = np.random.RandomState(B)
+    mlps = [orc.make_mlp(rng, in_dim, H, out) for _ in range(N)]
+    x = torch.from_numpy(rng.standard_normal((B, in_dim)).astype(np.float32))
+    dy = torch.from_numpy(rng.standard_normal((N, B, out)).astype(np.float32)) / B
+    ps, gx = _autograd_reference(mlps, x, dy)
+    ar = _arena_from(ssa, mlps)
+    dev = torch.device(DEV)
+    ws = ssa.engine.Workspace(dev)
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    h1, h2, _ = ssa.engine.mlp_forward(ar, xd, in_dim, 0, B, ws, "t")
+    grads = torch.zeros_like(ar.params)
+    ttot = ssa.engine.wgrad_tiles_total(ar)
+    ss = torch.zeros(N * ttot, device=DEV)
+    dX = ssa.engine.mlp_backward(ar, dyd, xd, in_dim, 0, h1, h2, B, ws, "t", grads=grads, sumsq=ss,
+                                 need_dx=True)
+    _close(dX.sum(0), gx, 2e-6, rtol=1e-4, what="dX")
+    for j in range(N):
+        gsq = 0.0
+        for seg in ssa.engine.SEGS:
+            g = ar.view(j, seg, grads)
+            _close(g, ps[j][seg].grad, 3e-6, rtol=1e-4, what=f"grad {seg}[{j}]")
+            gsq += float((ps[j][seg].grad.double() ** 2).sum())
+        got = float(ss[j * ttot:(j + 1) * ttot].sum())
+        assert abs(got - gsq) <= 1e-4 * max(gsq, 1e-12), "sum of squared grads (grad-norm log)"
+
+
+def test_fused_adam_and_polyak_match_torch_adam(ssa):
+    rng = np.random.RandomState(5)
+    B, in_dim, H, out, N = 128, 23, 64, 1, 3
+    mlps = [orc.make_mlp(rng, in_dim, H, out) for _ in range(N)]
+    x = torch.from_numpy(rng.standard_normal((B, in_dim)).astype(np.float32))
+    ar = _arena_from(ssa, mlps)
+    target = ar.params.clone() * 0.5
+    tgt_ref = [{k: v.clone() * 0.5 for k, v in p.items()} for p in mlps]
+    ps = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in mlps]
+    flat = [p[k] for p in ps for k in orc.MLP_KEYS]
+    topt = torch.optim.Adam(flat, lr=3e-4, betas=(0.9, 0.999), weight_decay=1e-3)
+    grp = ssa.engine.AdamGroup(topt, torch.device(DEV))
+    ws = ssa.engine.Workspace(torch.device(DEV))
+    xd = x.to(DEV)
+    for step in range(3):
+        dy = torch.from_numpy(rng.standard_normal((N, B, out)).astype(np.float32)) / B
+        topt.zero_grad()
+        tot = 0.0
+        for j, p in enumerate(ps):
+            tot = tot + (orc.mlp3(p, x)[0] * dy[j]).sum()
+        tot.backward()
+        topt.step()
+        for j in range(N):
+            for k in orc.MLP_KEYS:
+                tgt_ref[j][k] = tgt_ref[j][k] * (1 - 0.01) + ps[j][k].detach() * 0.01
+        h1, h2, _ = ssa.engine.mlp_forward(ar, xd, in_dim, 0, B, ws, "t")
+        grp.advance()
+        ssa.engine.mlp_backward(ar, dy.to(DEV), xd, in_dim, 0, h1, h2, B, ws, "t", adam=grp,
+                                adam_key="k", target=target, tau=0.01)
+    ctl = grp.ctl.read()
+    assert ctl.step == 3
+    assert abs(ctl.step_size - 3e-4 / (1 - 0.9 ** 3)) < 1e-9 and abs(ctl.bc2_sqrt - math.sqrt(1 - 0.999 ** 3)) < 1e-8
+    for j in range(N):
+        for seg in ssa.engine.SEGS:
+            _close(ar.view(j, seg), ps[j][seg], 2e-6, what=f"param {seg}[{j}] after 3 Adam steps")
+            _close(ar.view(j, seg, target), tgt_ref[j][seg], 2e-6, what=f"polyak {seg}[{j}]")
+
+
+def test_clip_path_matches_clip_grad_norm(ssa):
+    rng = np.random.RandomState(6)
+    B, in_dim, H, out, N = 64, 9, 32, 2, 2
+    mlps = [orc.make_mlp(rng, in_dim, H, out, w_scale=3.0) for _ in range(N)]
+    x = torch.from_numpy(rng.standard_normal((B, in_dim)).astype(np.float32))
+    dy = torch.from_numpy(rng.standard_normal((N, B, out)).astype(np.float32))
+    ps, _ = _autograd_reference(mlps, x, dy)
+    flat = [p[k] for p in ps for k in orc.MLP_KEYS]
+    total = orc.clip_grad_norm(flat, 0.5)
+    assert float(total) > 0.5, "test must actually clip"
+    topt = torch.optim.Adam(flat, lr=1e-3)
+    topt.step()
+    ar = _arena_from(ssa, mlps)
+    dev = torch.device(DEV)
+    ws = ssa.engine.Workspace(dev)
+    grp = ssa.engine.AdamGroup(torch.optim.Adam([torch.zeros(1)], lr=1e-3), dev)
+    xd = x.to(DEV)
+    h1, h2, _ = ssa.engine.mlp_forward(ar, xd, in_dim, 0, B, ws, "t")
+    grads = torch.zeros_like(ar.params)
+    ss = torch.zeros(N * ssa.engine.wgrad_tiles_total(ar), device=DEV)
+    grp.advance()
+    ssa.engine.mlp_backward(ar, dy.to(DEV), xd, in_dim, 0, h1, h2, B, ws, "t", grads=grads, sumsq=ss)
+    norm = torch.zeros(1, device=DEV)
+    lib, check = ssa._lib.lib, ssa._lib.check
+    check(lib.ssac_clip_coef(grp.ctl.ptr, ss.data_ptr(), ss.numel(), 0.5, norm.data_ptr(), ssa.engine.stream()))
+    m, v = grp.moments_for("k", ar.params)
+    check(lib.ssac_adam_step(ar.params.data_ptr(), m.data_ptr(), v.data_ptr(), grads.data_ptr(),
+                             ar.params.numel(), grp.ctl.ptr, ssa.engine.stream()))
+    assert abs(float(norm) - float(total)) <= 1e-4 * float(total)
+    for j in range(N):
+        for seg in ssa.engine.SEGS:
+            _close(ar.view(j, seg), ps[j][seg], 2e-6, what=f"clipped Adam {seg}[{j}]")
+
+
+# --------------------------------------------------------------------- replay sample path
+def test_replay_gather_bit_exact_with_wraparound(ssa):
+    import synth
+    f = case_runner.load_fixture("replay_indices")
+    s, a, r, s1, d = synth.synth_transitions(700, 5, 2, seed=3)
+    rb = ssa.replay.ReplayBuffer(512, device=DEV)
+    for lo in range(0, 700, 100):
+        sl = slice(lo, lo + 100)
+        rb.push({"obs": s["obs"][sl]}, a[sl], r[sl, None], {"obs": s1["obs"][sl]}, d[sl, None])
+    assert len(rb) == 512
+    idx = torch.from_numpy(f["wrap_idx"]).to(DEV)
+    o, act, rew, o1, done = rb.gather(idx, len(f["wrap_idx"]))
+    assert np.array_equal(o["obs"].cpu().numpy(), f["wrap_obs"])
+    assert np.array_equal(o1["obs"].cpu().numpy(), f["wrap_next_obs"])
+    assert np.array_equal(act.cpu().numpy(), f["wrap_act"])
+    assert np.array_equal(rew.cpu().numpy(), f["wrap_rew"])
+    assert np.array_equal(done.cpu().numpy(), f["wrap_done"].astype(np.float32))
+
+
+def test_sample_move_and_augment_vector_path(ssa):
+    import synth
+    s, a, r, s1, d = synth.synth_transitions(300, 17, 6, seed=4)
+    rb = ssa.replay.ReplayBuffer(400, device=DEV)
+    rb.load_experience(s, a, r, s1, d)
+    aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(64)])
+    torch.manual_seed(9)
+    rd = ssa.learning_utils.sample_move_and_augment(rb, 64, aug, 0.0, per=False)
+    torch.manual_seed(9)
+    want = torch.randint(300, (64,)).numpy()
+    assert np.array_equal(rd["priority_idxs"], want), "index stream must be torch.randint's, bit for bit"
+    o, act, rew, o1, done = rd["primary_batch"]
+    assert np.array_equal(o["obs"].cpu().numpy(), s["obs"][want])
+    assert np.array_equal(o1["obs"].cpu().numpy(), s1["obs"][want])
+    assert np.array_equal(act.cpu().numpy(), a[want])
+    assert np.array_equal(rew.cpu().numpy()[:, 0], r[want])
+    assert np.array_equal(done.cpu().numpy()[:, 0], d[want].astype(np.float32))
+    assert rb.total_sample_calls == 1
+    with pytest.raises(AssertionError):
+        ssa.learning_utils.sample_move_and_augment(rb, 301, aug, 0.0, per=False)  # lu:175
+
+
+def test_uint8_pixels_gather_and_cast(ssa):
+    import synth
+    s, a, r, s1, d = synth.synth_pixel_transitions(40, 3, 12, act_dim=2, seed=2)
+    rb = ssa.replay.ReplayBuffer(64, device=DEV)
+    rb.load_experience(s, a, r, s1, d)
+    (o, act, rew, o1, done), idx = rb.sample_uniform(16)
+    assert o["obs"].dtype == torch.float32
+    assert np.array_equal(o["obs"].cpu().numpy(), s["obs"][idx].astype(np.float32))
+    assert np.array_equal(o1["obs"].cpu().numpy(), s1["obs"][idx].astype(np.float32))
+
+
+# --------------------------------------------------------------------- tanh-normal head
+@pytest.mark.parametrize("tag,lo,hi", [("redq", -5.0, 2.0), ("default", -10.0, 2.0)])
+def test_tanh_normal_forward_reference_vectors(ssa, tag, lo, hi):
+    f = case_runner.load_fixture("nets")
+    out = torch.from_numpy(f[f"tn_{tag}_out"]).to(DEV)
+    eps = torch.from_numpy(f[f"tn_{tag}_eps"]).to(DEV)
+    act = torch.zeros(64, 10, device=DEV)
+    logp = torch.zeros(64, device=DEV)
+    ssa._lib.check(ssa._lib.lib.ssac_tanh_normal_fwd(out.data_ptr(), 12, eps.data_ptr(), 64, 6, lo, hi,
+                                                     act.data_ptr(), 10, 4, logp.data_ptr(), ssa.engine.stream()))
+    _close(act[:, 4:], torch.from_numpy(f[f"tn_{tag}_a"]), 1e-6, what="a")
+    _close(logp, torch.from_numpy(f[f"tn_{tag}_logp"])[:, 0], 3e-4, rtol=1e-5, what="log pi")
+    assert float(act[:, :4].abs().max()) == 0.0, "columns outside the action slice must be untouched"
+
+
+def test_tanh_normal_backward_matches_autograd(ssa):
+    rng = np.random.RandomState(8)
+    B, A, N, S = 50, 6, 3, 4
+    out = torch.from_numpy((rng.standard_normal((B, 2 * A)) * 1.2).astype(np.float32))
+    eps = torch.from_numpy(rng.standard_normal((B, A)).astype(np.float32))
+    dX = torch.from_numpy(rng.standard_normal((N, B, S + A)).astype(np.float32))
+    log_alpha = torch.tensor([-1.3])
+    inv_e = 0.5
+    o = out.clone().requires_grad_(True)
+    a, lp = orc.tanh_normal_sample(o, -5.0, 2.0, eps)
+    loss = (a * dX[:, :, S:].sum(0)).sum() + (log_alpha.exp() * inv_e / B) * lp.sum()
+    loss.backward()
+    d_out = torch.zeros(B, 2 * A, device=DEV)
+    ssa._lib.check(ssa._lib.lib.ssac_tanh_normal_bwd(
+        D(dX), N, S + A, B * (S + A), S, D(out), 2 * A,
+        D(eps), B, A, -5.0, 2.0, D(log_alpha), 1, inv_e,
+        d_out.data_ptr(), 2 * A, ssa.engine.stream()))
+    _close(d_out, o.grad, 2e-6, rtol=2e-4, what="d_out")
+
+
+# --------------------------------------------------------------------- TD target / PopArt
+def _popart_dev(ssa, po):
+    st = ssa._lib.PopArtState(float(po.mu), float(po.nu), float(po.w), float(po.b), po.t, po.min_steps,
+                              int(po.stable), 0, po.beta)
+    return ssa.engine.DeviceStruct(st, torch.device(DEV))
+
+
+@pytest.mark.parametrize("popart,pop", [(False, False), (True, True), (True, False)])
+def test_td_target_continuous(ssa, popart, pop):
+    rng = np.random.RandomState(11)
+    B, n = 300, 2
+    q = torch.from_numpy(rng.standard_normal((n, B)).astype(np.float32) * 3)
+    logp = torch.from_numpy(rng.standard_normal(B).astype(np.float32) * 2 - 3)
+    r = torch.from_numpy(rng.standard_normal((B, 1)).astype(np.float32))
+    d = torch.from_numpy((rng.uniform(size=(B, 1)) < 0.1).astype(np.float32))
+    la = torch.tensor([math.log(0.1)])
+    po = orc.PopArtOracle(beta=1e-2, min_steps=2) if popart else False
+    pdev = None
+    if popart:  # warm the statistics so the stable/rescale branch is live
+        for t in range(4):
+            po.update_stats(torch.from_numpy(rng.standard_normal((64, 1)).astype(np.float32) * (2 + t)))
+        pdev = _popart_dev(ssa, po)
+    val = q.min(0).values.unsqueeze(1) - la.exp() * logp.unsqueeze(1)
+    if popart and pop:
+        val = po(val, normalized=False)
+    td = r + 0.99 * (1 - d) * val
+    if popart:
+        po.update_stats(td)
+        td = po.normalize(td)
+    td_d = torch.zeros(B, 1, device=DEV)
+    logs = torch.zeros(4, device=DEV)
+    ssa._lib.check(ssa._lib.lib.ssac_td_target(
+        D(q), n, B, 1, D(logp), D(r), D(d),
+        D(la), 1, 0.99, pdev.ptr if pdev else 0, 1 if (popart and pop) else 0,
+        td_d.data_ptr(), logs.data_ptr(), ssa.engine.stream()))
+    _close(td_d, td, 2e-5, rtol=2e-5, what="td")
+    lg = logs.cpu()
+    assert abs(float(lg[0]) - float(td.mean())) < 2e-5 and abs(float(lg[1]) - float(td.std())) < 2e-4
+    assert abs(float(lg[2]) - float((la.exp() * logp).mean())) < 2e-5
+    if popart:
+        got = pdev.read()
+        s = po.state()
+        assert got.t == s["t"] and got.stable == int(po.stable)
+        assert np.allclose([got.mu, got.nu, got.w, got.b], [s["mu"], s["nu"], s["w"], s["b"]], rtol=2e-5, atol=1e-6)
+
+
+def test_td_target_discrete(ssa):
+    rng = np.random.RandomState(12)
+    B, n, A = 200, 2, 5
+    q = torch.from_numpy(rng.standard_normal((n, B, A)).astype(np.float32) * 2)
+    logits = torch.from_numpy(rng.standard_normal((B, A)).astype(np.float32) * 2)
+    r = torch.from_numpy(rng.standard_normal((B, 1)).astype(np.float32))
+    d = torch.from_numpy((rng.uniform(size=(B, 1)) < 0.1).astype(np.float32))
+    la = torch.tensor([math.log(0.2)])
+    logp = torch.log_softmax(logits, -1)
+    bonus = la.exp() * logp
+    val = (logp.exp() * (q.min(0).values - bonus)).sum(-1, keepdim=True)
+    td = r + 0.95 * (1 - d) * val
+    td_d = torch.zeros(B, 1, device=DEV)
+    logs = torch.zeros(4, device=DEV)
+    ssa._lib.check(ssa._lib.lib.ssac_td_target(
+        D(q), n, B, A, D(logits), D(r), D(d),
+        D(la), 0, 0.95, 0, 0, td_d.data_ptr(), logs.data_ptr(), ssa.engine.stream()))
+    _close(td_d, td, 2e-5, rtol=2e-5, what="discrete td")
+    assert abs(float(logs[2]) - float(bonus.mean())) < 2e-5
+
+
+# --------------------------------------------------------------------- loss gradients
+def test_critic_loss_bwd_continuous_and_discrete(ssa):
+    rng = np.random.RandomState(13)
+    lib, check, st = ssa._lib.lib, ssa._lib.check, ssa.engine.stream
+    for qd in (1, 4):
+        N, B = 3, 90
+        q = torch.from_numpy(rng.standard_normal((N, B, qd)).astype(np.float32))
+        td = torch.from_numpy(rng.standard_normal((B, 1)).astype(np.float32))
+        w = torch.from_numpy(rng.uniform(0.5, 1.5, (B, 1)).astype(np.float32))
+        act = torch.from_numpy(rng.randint(0, qd, (B, 1)).astype(np.float32))
+        qq = q.clone().requires_grad_(True)
+        loss = 0.0
+        for j in range(N):
+            qj = qq[j] if qd == 1 else qq[j].gather(-1, act.long())
+            err = td - qj
+            loss = loss + (w * err ** 2).mean()
+        loss = loss / 6.0
+        loss.backward()
+        dq = torch.zeros(N, B, qd, device=DEV)
+        logs = torch.zeros(4, device=DEV)
+        check(lib.ssac_critic_loss_bwd(D(q), N, B, qd, D(act), 1,
+                                       D(td), D(w), 0, 0, 6.0,
+                                       dq.data_ptr(), logs.data_ptr(), st()))
+        _close(dq, qq.grad, 1e-7, rtol=1e-5, what=f"dq qd={qd}")
+        assert abs(float(logs[0]) - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+        assert abs(float(logs[1]) - float(err.mean())) < 1e-5
+
+
+def test_actor_loss_bwd_routes_to_argmin(ssa):
+    rng = np.random.RandomState(14)
+    N, B = 5, 120
+    q = torch.from_numpy(rng.standard_normal((N, B)).astype(np.float32))
+    logp = torch.from_numpy(rng.standard_normal(B).astype(np.float32))
+    la = torch.tensor([-2.0])
+    qq = q.clone().requires_grad_(True)
+    loss = -(qq.min(0).values - la.exp() * logp).mean() * 0.5
+    loss.backward()
+    dq = torch.zeros(N, B, device=DEV)
+    logs = torch.zeros(2, device=DEV)
+    ssa._lib.check(ssa._lib.lib.ssac_actor_loss_bwd(D(q), N, B, D(logp),
+                                                    D(la), 1, 0, 0, 0.5, dq.data_ptr(),
+                                                    logs.data_ptr(), ssa.engine.stream()))
+    _close(dq, qq.grad, 1e-8, what="dq")
+    assert abs(float(logs[0]) - float(loss)) < 1e-5
+
+
+def test_discrete_actor_loss_bwd(ssa):
+    rng = np.random.RandomState(15)
+    N, B, A = 2, 70, 6
+    logits = torch.from_numpy(rng.standard_normal((B, A)).astype(np.float32) * 1.5)
+    q = torch.from_numpy(rng.standard_normal((N, B, A)).astype(np.float32))
+    la = torch.tensor([-1.0])
+    x = logits.clone().requires_grad_(True)
+    p, lp = torch.softmax(x, -1), torch.log_softmax(x, -1)
+    vals = (p * q.min(0).values).sum(-1, keepdim=True)
+    bonus = la.exp() * (p * lp).sum(-1, keepdim=True)
+    loss = -(vals - bonus).mean()
+    loss.backward()
+    dl = torch.zeros(B, A, device=DEV)
+    logs = torch.zeros(2, device=DEV)
+    ssa._lib.check(ssa._lib.lib.ssac_discrete_actor_loss_bwd(
+        D(logits), D(q), N, B, A, D(la), 0, 0, 1.0,
+        dl.data_ptr(), logs.data_ptr(), ssa.engine.stream()))
+    _close(dl, x.grad, 2e-8, rtol=2e-4, what="d_logits")
+    assert abs(float(logs[0]) - float(loss)) < 1e-5
+
+
+def test_alpha_update_three_steps(ssa):
+    rng = np.random.RandomState(16)
+    la_ref = torch.tensor([math.log(0.1)], requires_grad=True)
+    opt = orc.AdamOracle([la_ref], lr=1e-3, betas=(0.5, 0.999))
+    la = torch.tensor([math.log(0.1)], device=DEV)
+    topt = torch.optim.Adam([torch.zeros(1)], lr=1e-3, betas=(0.5, 0.999))
+    grp = ssa.engine.AdamGroup(topt, torch.device(DEV))
+    m, v = grp.moments_for("a", la)
+    logs = torch.zeros(2, device=DEV)
+    for _ in range(3):
+        logp = torch.from_numpy(rng.standard_normal(100).astype(np.float32) - 4)
+        loss = -(la_ref * (logp + (-6.0))).mean()
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        ssa._lib.check(ssa._lib.lib.ssac_alpha_update(la.data_ptr(), m.data_ptr(), v.data_ptr(), grp.ctl.ptr,
+                                                      D(logp), 100, 1, -6.0, logs.data_ptr(),
+                                                      ssa.engine.stream()))
+        assert abs(float(logs[0]) - float(loss)) < 1e-5
+    assert abs(float(la) - float(la_ref)) < 1e-6 and grp.ctl.read().step == 3
+
+
+def test_sunrise_weights(ssa):
+    rng = np.random.RandomState(17)
+    q = torch.from_numpy(rng.standard_normal((5, 64)).astype(np.float32))
+    w_ref = torch.sigmoid(-q.std(0) * 20.0) + 0.5
+    w = torch.zeros(64, 1, device=DEV)
+    logs = torch.zeros(4, device=DEV)
+    ssa._lib.check(ssa._lib.lib.ssac_sunrise_weights(D(q), 5, 64, 20.0, w.data_ptr(),
+                                                     logs.data_ptr(), ssa.engine.stream()))
+    _close(w[:, 0], w_ref, 1e-6, what="sunrise w")
+    assert np.allclose(logs.cpu().numpy(), [w_ref.mean(), w_ref.max(), w_ref.min(), w_ref.std()], atol=1e-5)
+
+
+# --------------------------------------------------------------------- DrQ augmentations
+def test_drqv2_against_reference_fixture(ssa):
+    f = case_runner.load_fixture("augmentations")
+    for xk, yk in (("x0", "v2_y0"), ("x1", "v2_y1")):
+        x = torch.from_numpy(f[xk]).to(DEV)
+        aug = ssa.augmentations.Drqv2Aug(6)
+        aug.shift = torch.from_numpy(f["v2_shift"])
+        aug._upload(aug.shift.reshape(6, 2).to(torch.int64))
+        y = aug(x)
+        # stated tolerance: 1e-3 on the 0..255 scale (fp32 order of the four bilinear taps)
+        assert float((y.cpu() - torch.from_numpy(f[yk])).abs().max()) <= 1e-3
+    x = torch.from_numpy(f["big_x"]).to(DEV)
+    aug = ssa.augmentations.Drqv2Aug(3)
+    aug._upload(torch.from_numpy(f["big_shift"]).reshape(3, 2).to(torch.int64))
+    err = (aug(x).cpu() - torch.from_numpy(f["big_y"])).abs()
+    print("drqv2 84x84: max err", float(err.max()), "pixels off by >1e-4:", float((err > 1e-4).float().mean()))
+    assert float(err.max()) <= 4e-3
+
+
+def test_drq_v1_crop_bit_exact_and_noise(ssa):
+    f = case_runner.load_fixture("augmentations")
+    x = torch.from_numpy(f["x0"]).to(DEV)
+    aug = ssa.augmentations.DrqNoNoiseAug(6)
+    aug._upload(torch.stack([torch.from_numpy(f["v1_w1"]), torch.from_numpy(f["v1_h1"])], 1).to(torch.int64))
+    assert np.array_equal(aug(x).cpu().numpy(), f["v1_y0"]), "integer crop must be bit-exact"
+    out = torch.zeros_like(x)
+    aug2 = ssa.augmentations.DrqAug(6)
+    aug2._upload(torch.stack([torch.from_numpy(f["v1n_w1"]), torch.from_numpy(f["v1n_h1"])], 1).to(torch.int64))
+    aug2.apply(x, None, 6, 3, 24, 6, out, torch.from_numpy(f["v1n_noise0"]).to(DEV))
+    assert np.allclose(out.cpu().numpy(), f["v1n_y0"], atol=1e-5)
+
+
+def test_fused_gather_shift_aug_mix_from_uint8_replay(ssa):
+    """sample_move_and_augment on pixels: uint8 rows -> gather -> shift -> first int(B*mix) rows."""
+    import synth
+    s, a, r, s1, d = synth.synth_pixel_transitions(50, 3, 20, act_dim=2, seed=6)
+    rb = ssa.replay.ReplayBuffer(64, device=DEV)
+    rb.load_experience(s, a, r, s1, d)
+    B = 8
+    torch.manual_seed(31)
+    aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.Drqv2Aug(B)])
+    rd = ssa.learning_utils.sample_move_and_augment(rb, B, aug, 0.5, per=False)
+    torch.manual_seed(31)
+    orc.drqv2_draw_shift(B)                      # constructor draw
+    idx = torch.randint(50, (B,)).numpy()        # index draw comes first (lu:179)
+    shift = orc.drqv2_draw_shift(B)              # then the augmentation draw (lu:201)
+    assert np.array_equal(rd["priority_idxs"], idx)
+    o, _, _, o1, _ = rd["primary_batch"]
+    for got, src in ((o["obs"], s["obs"]), (o1["obs"], s1["obs"])):
+        plain = torch.from_numpy(src[idx].astype(np.float32))
+        shifted = orc.drqv2_shift(plain, shift)
+        want = plain.clone()
+        want[:4] = shifted[:4]
+        assert float((got.cpu() - want).abs().max()) <= 4e-3
+
+
+# --------------------------------------------------------------------- Polyak
+def test_polyak(ssa):
+    t = torch.randn(10_001, device=DEV)
+    s = torch.randn(10_001, device=DEV)
+    want = t.cpu() * (1 - 0.005) + s.cpu() * 0.005
+    ssa._lib.check(ssa._lib.lib.ssac_polyak(t.data_ptr(), s.data_ptr(), t.numel(), 0.005, ssa.engine.stream()))
+    _close(t, want, 1e-7, what="polyak")

@@ -159,7 +159,7 @@ def main():
         step()
 
     # ---- timed region: EXACTLY --steps steps between barrier+sync brackets
-    ssa.engine.PROFILE["tag"] = "cu.c0"
+    ssa.engine.PROFILE["tag"] = "critic_fused"
     ssa.engine.PROFILE["events"] = []
     if dist is not None:
         dist.barrier()
@@ -177,13 +177,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
 
-    # ---- roofline of the dominant kernel: ensemble-Q forward, hidden layer (fc2) GEMM.
+    # ---- roofline of the dominant kernel: the fused critic kernel (forward of all local critics,
+    # loss gradient, backward-data), one launch per update.  Algorithmic FLOPs per launch:
+    # forward 2*B*N*(in*H + H*H + H*out) + backward-data 2*B*N*(out*H + H*H).
     evs = ssa.engine.PROFILE["events"]
     ms = sorted(a.elapsed_time(b) for a, b in evs)
     avg_ms = sum(ms) / len(ms)
-    flops = 2.0 * BATCH * HID * HID * n_local  # algorithmic FLOPs of one launch
+    IN = OBS + ACT
+    flops = 2.0 * BATCH * n_local * (IN * HID + HID * HID + HID) + 2.0 * BATCH * n_local * (HID + HID * HID)
     achieved = flops / (avg_ms * 1e-3) / 1e12
-    roofline = {"kernel": "ens_gemm_kernel<NT,bias+relu> (critic fc2, all local critics, one launch)",
+    roofline = {"kernel": "fused_mlp_kernel<critic>: fc1+fc2+head of all local critics, loss gradient, "
+                          "head backward, fc2 backward-data (one launch per update)",
                 "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                 "avg_launch_us": round(avg_ms * 1e3, 3), "launches_timed": len(ms),

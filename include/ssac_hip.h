@@ -122,6 +122,10 @@ int ssac_mlp_layer_wgrad(const ssac_mlp *nets, int layer, const int32_t *net_ids
 int ssac_adam_step(float *params, float *adam_m, float *adam_v, const float *grads, int64_t n,
                    const ssac_adam_ctl *ctl, void *stream);
 
+/* one launch at the start of an update: zero the n_logs (<= 256) floats of the log block and, when
+ * ctl != NULL, advance the optimizer step like ssac_adam_advance. */
+int ssac_begin_update(float *logs, int n_logs, ssac_adam_ctl *ctl, void *stream);
+
 /* advance ctl->step by one and refresh step_size / bc2_sqrt (double precision on device). */
 int ssac_adam_advance(ssac_adam_ctl *ctl, void *stream);
 /* clip_coef = min(1, max_norm / (sqrt(sum(sumsq[0..n))) + 1e-6)); max_norm <= 0 -> 1.
@@ -222,6 +226,52 @@ int ssac_sunrise_weights(const float *q, int n_members, int n_rows, float temp, 
 int ssac_drq_shift(const void *src, int src_dtype, const int64_t *idx, int n, int c, int h, int pad,
                    const int64_t *shift, int mode, const float *noise, int n_aug, float *dst,
                    void *stream);
+
+/* ==== fused kernels (csrc/ssac_fused.hip): the same arithmetic as the per-layer entry points above,
+ * with the activations of a 32-row tile kept in LDS across fc1 -> fc2 -> head.  Supported when
+ * ssac_fused_supported() (hidden % 32 == 0, hidden <= 256, out_dim <= 16, LDS carve fits 160 KB);
+ * callers fall back to the per-layer entry points otherwise. ==== */
+int ssac_fused_supported(const ssac_mlp *nets);
+/* development aid: when set to a device buffer of >= 16 int64, workgroup (0,0) of every fused launch
+ * records s_memtime() at its phase boundaries there; NULL (default) disables it. */
+int ssac_fused_debug_stamps(long long *dev_buf);
+int ssac_gemm_debug_stamps(long long *dev_buf); /* same for the weight-gradient GEMM launches */
+int ssac_fused_row_tiles(int n_rows);
+
+/* y = MLP(x) for every selected net in ONE launch (agent.py:34 loop + mlps.py:123-129).
+ * H1/H2 (n_sel x n_rows x hidden) are written when not NULL (needed by a later backward). */
+int ssac_mlp3_fwd_fused(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
+                        int64_t ldx, int64_t x_net_stride, int n_rows, float *H1, float *H2, float *Y,
+                        void *stream);
+
+/* actor forward + tanh-normal sample + log pi in ONE launch (mlps.py:32-39, distributions.py:9-15).
+ * out (n_rows x 2A), H1, H2 may be NULL. */
+int ssac_actor_sample_fused(const ssac_mlp *actor, const float *X, int64_t ldx, int n_rows,
+                            const float *eps, float log_std_lo, float log_std_hi, float *act_dst,
+                            int64_t ld_act, int64_t act_col0, float *logp, float *H1, float *H2,
+                            float *out, void *stream);
+
+/* critic forward of ALL nets + loss gradient + backward-data in ONE launch (learning.py:83-98,112,121):
+ * writes H1, H2, Q (n_nets x n_rows x out), DQ, DZ2 = dL/d(pre-activation of fc2), DZ1, and per-(net,
+ * row-tile) partial sums partials[(e*tiles + tile)*2 + {sum w*err^2, sum err}] for ssac_critic_logs. */
+int ssac_critic_fwd_bwd_fused(const ssac_mlp *nets, const float *X, int64_t ldx, int n_rows,
+                              const float *td, const float *weight, const float *act, int64_t ld_act,
+                              const ssac_popart *popart, int pop, float denom, float *H1, float *H2,
+                              float *Q, float *DQ, float *DZ2, float *DZ1, float *partials, void *stream);
+
+/* weight gradient of the head layer (out_dim <= 16) + Adam/Polyak, VALU: dW3 = DQ^T H2, db3 = colsum(DQ).
+ * Same grads/sumsq/target conventions as ssac_mlp_layer_wgrad; sumsq slots: ssac_head_wgrad_tiles(). */
+int ssac_head_wgrad_tiles(const ssac_mlp *nets);
+int ssac_head_wgrad(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *H2,
+                    const float *DQ, int n_rows, float *adam_m, float *adam_v, const ssac_adam_ctl *ctl,
+                    float *grads, float *sumsq, int64_t sumsq_net_stride, float *target, float tau,
+                    void *stream);
+
+/* reduce the fused critic kernel's partials into the log block: logs[0] += loss, logs[1] = mean td
+ * error of the last net, logs[2] = sqrt(sum(sumsq[0..n_sumsq))) (x clip_coef when given). */
+int ssac_critic_logs(const float *partials, int n_nets, int tiles, int n_rows, float denom,
+                     const float *sumsq, int n_sumsq, const ssac_adam_ctl *scale_by_clip, float *logs,
+                     void *stream);
 
 /* zero a float buffer (log accumulators) */
 int ssac_zero(float *p, int64_t n, void *stream);

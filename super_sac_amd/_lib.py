@@ -49,6 +49,7 @@ SIGNATURES = {
     "ssac_gather_transition": [_P, _P, _I, _L, _P, _L, _P, _P, _P, _I, _P, _L, _P, _L, _P, _P, _P],
     "ssac_adam_step": [_P, _P, _P, _P, _L, _P, _P],
     "ssac_adam_advance": [_P, _P],
+    "ssac_begin_update": [_P, _I, _P, _P],
     "ssac_clip_coef": [_P, _P, _I, _F, _P, _P],
     "ssac_polyak": [_P, _P, _L, _F, _P],
     "ssac_tanh_normal_fwd": [_P, _L, _P, _I, _I, _F, _F, _P, _L, _L, _P, _P],
@@ -63,6 +64,16 @@ SIGNATURES = {
     "ssac_sunrise_weights": [_P, _I, _I, _F, _P, _P, _P],
     "ssac_drq_shift": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P],
     "ssac_zero": [_P, _L, _P],
+    "ssac_fused_supported": [_MP],
+    "ssac_fused_debug_stamps": [_P],
+    "ssac_gemm_debug_stamps": [_P],
+    "ssac_fused_row_tiles": [_I],
+    "ssac_mlp3_fwd_fused": [_MP, _P, _I, _P, _L, _L, _I, _P, _P, _P, _P],
+    "ssac_actor_sample_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _P, _P, _P],
+    "ssac_critic_fwd_bwd_fused": [_MP, _P, _L, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ssac_head_wgrad_tiles": [_MP],
+    "ssac_head_wgrad": [_MP, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P, _F, _P],
+    "ssac_critic_logs": [_P, _I, _I, _I, _F, _P, _I, _P, _P, _P],
 }
 _RESTYPES = {"ssac_last_error": C.c_char_p, "ssac_mlp_layout": C.c_int64}
 

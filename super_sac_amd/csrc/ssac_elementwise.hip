@@ -431,6 +431,12 @@ __global__ __launch_bounds__(RED_THREADS) void alpha_update_kernel(
 
 __global__ void adam_advance_kernel(ssac_adam_ctl *ctl) { adam_refresh(ctl, ctl->step + 1); }
 
+// start of an update: clear the log block and advance the optimizer's step in one launch
+__global__ void begin_update_kernel(float *logs, int n, ssac_adam_ctl *ctl) {
+    if ((int)threadIdx.x < n) logs[threadIdx.x] = 0.0f;
+    if (threadIdx.x == 0 && ctl) adam_refresh(ctl, ctl->step + 1);
+}
+
 __global__ __launch_bounds__(RED_THREADS) void clip_coef_kernel(ssac_adam_ctl *ctl,
                                                                const float *__restrict__ sumsq, int n,
                                                                float max_norm, float *norm_out) {
@@ -735,6 +741,12 @@ extern "C" int ssac_alpha_update(float *log_alpha, float *adam_m, float *adam_v,
 extern "C" int ssac_adam_advance(ssac_adam_ctl *ctl, void *stream) {
     hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, ST, ctl);
     return ssac_check_launch("adam_advance");
+}
+
+extern "C" int ssac_begin_update(float *logs, int n_logs, ssac_adam_ctl *ctl, void *stream) {
+    if (n_logs > 256) return ssac_fail("ssac_begin_update: log block too large");
+    hipLaunchKernelGGL(begin_update_kernel, dim3(1), dim3(256), 0, ST, logs, n_logs, ctl);
+    return ssac_check_launch("begin_update");
 }
 
 extern "C" int ssac_clip_coef(ssac_adam_ctl *ctl, const float *sumsq, int n, float max_norm,

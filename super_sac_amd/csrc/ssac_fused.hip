@@ -1,0 +1,738 @@
+// Fused 3-layer ensemble-MLP kernels for gfx950: one launch runs fc1 -> ReLU -> fc2 -> ReLU ->
+// head for a 32-row tile of one net with the activations resident in LDS, and optionally
+// continues with an epilogue that would otherwise be 3-6 more launches:
+//
+//   MODE_PLAIN   store y (and h1/h2 when the caller needs them for a backward pass)
+//   MODE_SAMPLE  tanh-normal policy head: a = tanh(mu + sigma*eps) written into the [s'|a'] batch
+//                buffer and log pi (distributions.py:9-15, 64-104)
+//   MODE_CRITIC  critic loss gradient (learning.py:90-98), head backward, and the backward-data
+//                GEMM of fc2 -- i.e. forward + loss + the whole dL/d(activations) chain.  Only
+//                what the weight-gradient GEMMs need (h1, h2, dz2, dz1, dq) is written to HBM.
+//
+// A workgroup is 512 threads = 8 waves (2 per SIMD, so one wave's LDS/barrier phases hide under
+// the other's MFMAs); wave w owns output columns [32w, 32w+32) of the 32 x H activation tile as one
+// v_mfma_f32_32x32x2_f32 accumulator (exact fp32).  The A operand (x, h1, dz2) is read from LDS
+// with odd row strides (bank = (row + k) % 32, conflict free); weight chunks of 32 k-steps are
+// staged through a 33 KB LDS buffer with the next chunk's global loads in flight during the MFMAs.
+// Constraints (checked by ssac_fused_supported): hidden % 32 == 0, hidden <= 256, out_dim <= 16,
+// and the LDS carve (depends on in_dim) must fit 160 KB; other shapes use the per-layer kernels.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "ssac_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int TM = 32;          // rows per workgroup
+constexpr int NTHR = 512;       // 8 waves
+constexpr int WS_LD = 36;             // K-contiguous staging row stride: 16-byte rows, conflict-free b128
+constexpr int WS_FLOATS = 256 * WS_LD;  // weight staging buffer (>= 32*256 for the row-contiguous image)
+constexpr int APAD = 4;               // activation rows are padded by 4 floats (16-byte aligned rows)
+constexpr int MAX_OUT = 16;
+constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
+constexpr float LOG_2 = 0.69314718055994530942f;
+
+enum { MODE_PLAIN = 0, MODE_SAMPLE = 1, MODE_CRITIC = 2 };
+
+struct FusedArgs {
+    const float *params; int64_t net_stride; int in_dim, hidden, out_dim;
+    int64_t off[6];
+    const int32_t *ids;
+    const float *X; int64_t ldx, sX; int n_rows;
+    float *H1, *H2;              // (n_sel, n_rows, hidden) or null
+    float *Y;                    // (n_sel, n_rows, out) or null
+    // MODE_SAMPLE
+    const float *eps; float lo, hi; float *act_dst; int64_t ld_act, act_col0; float *logp;
+    // MODE_CRITIC
+    const float *td, *weight, *act; int64_t ld_a; const ssac_popart *popart; int pop; float denom;
+    float *DQ, *DZ2, *DZ1; float *partials;  // partials[(e*tiles + tile)*2 + {loss, err}]
+    int vec;  // 16-byte weight loads are legal for this arena
+    long long *dbg;  // optional phase timestamps (s_memtime) of workgroup (0,0), thread 0
+};
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// ---------------------------------------------------------------------------------------------
+// Weight staging.  Two LDS buffers; chunk c+1 is written while chunk c is being multiplied and the
+// global loads of chunk c+2 are in flight, so there is ONE barrier per 32-deep K chunk and the
+// memory instructions of a wave sit between its MFMAs (sched_group_barrier below) instead of in a
+// separate phase.  Per-thread source pointers are computed once and advanced by a uniform step
+// (no 64-bit address arithmetic in the loop).  VEC = 16-byte global loads (needs ldw % 4 == 0,
+// K % 32 == 0, 16-byte aligned base; the host checks); otherwise a guarded scalar path.
+// ---------------------------------------------------------------------------------------------
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// W is (Nout x K), K contiguous.  LDS image Ws[n*WS_LD + k] for n < 256, k < 32.
+template <bool VEC>
+struct KcStage {
+    const float *p[VEC ? 4 : 16];
+    unsigned okmask;
+    int kk;
+    f4 v[4];
+    float s[VEC ? 1 : 16];
+    __device__ __forceinline__ void init(const float *W, int ldw, int Nout, int tid) {
+        okmask = 0;
+        if (VEC) {
+            kk = (tid & 7) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = (tid >> 3) + 64 * q;
+                const bool ok = n < Nout;
+                p[q] = W + (ok ? (int64_t)n * ldw + kk : 0);
+                okmask |= (ok ? 1u : 0u) << q;
+            }
+        } else {
+            kk = tid & 31;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int n = (tid >> 5) + 16 * q;
+                const bool ok = n < Nout;
+                p[q] = W + (ok ? (int64_t)n * ldw + kk : 0);
+                okmask |= (ok ? 1u : 0u) << q;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int K) {
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f4 *>(p[q] + k0);
+        } else {
+            const bool kok = (k0 + kk) < K;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const bool ok = kok && ((okmask >> q) & 1u);
+                const float x = p[q][ok ? k0 : 0];
+                s[q] = ok ? x : 0.0f;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float *__restrict__ Ws, int tid) const {
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool ok = (okmask >> q) & 1u;
+                *reinterpret_cast<f4 *>(Ws + ((tid >> 3) + 64 * q) * WS_LD + kk) =
+                    ok ? v[q] : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) Ws[((tid >> 5) + 16 * q) * WS_LD + kk] = s[q];
+        }
+    }
+};
+
+// W is (K x Ncols), rows contiguous; stage rows [n0, n0+32), columns [0, 256) -> Wt[n*256 + c].
+template <bool VEC>
+struct RcStage {
+    const float *p[VEC ? 4 : 16];
+    bool cok[VEC ? 1 : 1];
+    int c0;
+    f4 v[4];
+    float s[VEC ? 1 : 16];
+    int ldw_, ncols_;
+    __device__ __forceinline__ void init(const float *W, int ldw, int Ncols, int tid) {
+        ldw_ = ldw; ncols_ = Ncols;
+        if (VEC) {
+            c0 = (tid & 63) * 4;
+            cok[0] = c0 < Ncols;  // Ncols % 4 == 0 on this path
+#pragma unroll
+            for (int q = 0; q < 4; ++q) p[q] = W + (cok[0] ? (int64_t)((tid >> 6) + 8 * q) * ldw + c0 : 0);
+        } else {
+            c0 = tid & 255;
+            cok[0] = c0 < Ncols;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) p[q] = W + (cok[0] ? (int64_t)((tid >> 8) + 2 * q) * ldw + c0 : 0);
+        }
+    }
+    // rows n0 + local row; K = number of rows of W
+    __device__ __forceinline__ void load(int n0, int K) {
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool ok = cok[0] && (n0 + (int)(threadIdx.x >> 6) + 8 * q) < K;
+                const f4 x = *reinterpret_cast<const f4 *>(p[q] + (ok ? (int64_t)n0 * ldw_ : 0));
+                v[q] = ok ? x : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const bool ok = cok[0] && (n0 + (int)(threadIdx.x >> 8) + 2 * q) < K;
+                const float x = p[q][ok ? (int64_t)n0 * ldw_ : 0];
+                s[q] = ok ? x : 0.0f;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float *__restrict__ Wt, int tid) const {
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f4 *>(Wt + ((tid >> 6) + 8 * q) * 256 + c0) = v[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) Wt[((tid >> 8) + 2 * q) * 256 + c0] = s[q];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// The K loop.  MFMA step t of a chunk consumes k = 16*lh + t from lane half lh (a permutation of
+// the chunk's 32 k values, identical for A and B), so a lane's 16 operands are CONSECUTIVE floats:
+// four ds_read_b128 per operand per chunk.
+//
+// Software pipeline (vector path), one barrier per chunk, placed in the MIDDLE of the 16 MFMAs:
+//   MFMA 0..7  of chunk c   interleaved with: LDS stores of chunk c+1, global loads of chunk c+2
+//   barrier                 (chunk c+1 visible; everybody has read chunk c-1's buffer long ago)
+//   MFMA 8..15 of chunk c   interleaved with: fragment reads of chunk c+1 into the other register set
+// so the matrix pipe never waits for LDS latency and the barrier skew hides under the first 8 MFMAs
+// that are already in the pipe.  sched_barrier(0) pins the interleave the source order expresses.
+// ---------------------------------------------------------------------------------------------
+#define SSAC_PIN() __builtin_amdgcn_sched_barrier(0)
+
+template <bool NN>
+__device__ __forceinline__ void read_frags(f4 (&a4)[4], f4 (&b4)[4], float (&bs)[16], const float *As,
+                                           int lda, const float *buf, int c, int li, int lh, int col0) {
+    const f4 *ap = reinterpret_cast<const f4 *>(As + li * lda + c * 32 + lh * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a4[q] = ap[q];
+    if (NN) {
+        const float *bp = buf + (lh * 16) * 256 + col0 + li;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) bs[t] = bp[t * 256];
+    } else {
+        const f4 *bp = reinterpret_cast<const f4 *>(buf + (col0 + li) * WS_LD + lh * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b4[q] = bp[q];
+    }
+}
+
+template <bool NN>
+__device__ __forceinline__ float bval(const f4 (&b4)[4], const float (&bs)[16], int t) {
+    return NN ? bs[t] : b4[t >> 2][t & 3];
+}
+
+// one pipelined chunk: consumes (a, b), prefetches the next chunk's fragments into (an, bn)
+template <bool NN, typename Stage>
+__device__ __forceinline__ void pipe_step(f32x16 &acc, Stage &st, int c, int nch, int K,
+                                          const float *As, int lda, float *cur, float *nxt,
+                                          const f4 (&a)[4], const f4 (&b)[4], const float (&bsc)[16],
+                                          f4 (&an)[4], f4 (&bn)[4], float (&bsn)[16], int tid, int li,
+                                          int lh, int col0) {
+    const bool has1 = (c + 1) < nch, has2 = (c + 2) < nch;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t >> 2][t & 3], bval<NN>(b, bsc, t), acc, 0, 0, 0);
+        if (t == 0 && has1) st.store(nxt, tid);
+        if (t == 4 && has2) st.load((c + 2) * 32, K);
+        SSAC_PIN();
+    }
+    __syncthreads();
+    if (has1) {
+        const f4 *ap = reinterpret_cast<const f4 *>(As + li * lda + (c + 1) * 32 + lh * 16);
+        const f4 *bp4 = reinterpret_cast<const f4 *>(nxt + (col0 + li) * WS_LD + lh * 16);
+        const float *bps = nxt + (lh * 16) * 256 + col0 + li;
+#pragma unroll
+        for (int t = 8; t < 16; ++t) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t >> 2][t & 3], bval<NN>(b, bsc, t), acc, 0, 0, 0);
+            const int u = t - 8;
+            if (u < 4) an[u] = ap[u];
+            if (NN) { bsn[2 * u] = bps[(2 * u) * 256]; bsn[2 * u + 1] = bps[(2 * u + 1) * 256]; }
+            else if (u >= 4) bn[u - 4] = bp4[u - 4];
+            SSAC_PIN();
+        }
+    } else {
+#pragma unroll
+        for (int t = 8; t < 16; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t >> 2][t & 3], bval<NN>(b, bsc, t), acc, 0, 0, 0);
+    }
+}
+
+// NN = false: acc += A[32 x K] * W^T, W = (Nout x K) K-contiguous          (forward)
+// NN = true : acc += A[32 x K] * W,   W = (K x Ncols) rows contiguous       (backward-data)
+// Every wave runs the loop (waves whose columns lie beyond the layer width multiply staged zeros),
+// so the loop body is branch-free and the interleave above survives instruction scheduling.
+template <bool VEC, bool NN>
+__device__ __forceinline__ void gemm_tile(f32x16 &acc, const float *__restrict__ As, int lda, int K,
+                                          const float *__restrict__ W, int ldw, int Nw, float *B0,
+                                          float *B1, int tid, int col0) {
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int nch = (K + 31) >> 5;
+    typename std::conditional<NN, RcStage<VEC>, KcStage<VEC>>::type st;
+    st.init(W, ldw, Nw, tid);
+    st.load(0, K);
+    __syncthreads();  // previous users of the staging buffers / writers of As are done
+    st.store(B0, tid);
+    if (nch > 1) st.load(32, K);
+    __syncthreads();
+    f4 a0[4], b0[4], a1[4], b1[4];
+    float s0[16], s1[16];
+    read_frags<NN>(a0, b0, s0, As, lda, B0, 0, li, lh, col0);
+    for (int c = 0; c < nch; c += 2) {
+        pipe_step<NN>(acc, st, c, nch, K, As, lda, B0, B1, a0, b0, s0, a1, b1, s1, tid, li, lh, col0);
+        if (c + 1 < nch)
+            pipe_step<NN>(acc, st, c + 1, nch, K, As, lda, B1, B0, a1, b1, s1, a0, b0, s0, tid, li, lh, col0);
+    }
+    __syncthreads();  // all fragment reads done before the caller reuses As / the staging buffers
+}
+
+#define STAMP(i) do { if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+
+template <int MODE>
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void fused_mlp_kernel(FusedArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = g.hidden, IN = g.in_dim, OUT = g.out_dim;
+    const int KP = (IN + 31) & ~31;
+    const int ldx_s = KP + APAD, ldh = H + APAD;
+    float *xs = smem;                       // [32][KP+4]
+    float *h1s = xs + TM * ldx_s;           // [32][H+4]
+    float *h2s = h1s + TM * ldh;            // [32][H+4]
+    float *Ws = h2s + TM * ldh;             // staging buffer 0
+    float *Ws1 = Ws + WS_FLOATS;            // staging buffer 1
+    float *ys = Ws1 + WS_FLOATS;            // [32][MAX_OUT]
+    float *dqs = ys + TM * MAX_OUT;         // [32][MAX_OUT]
+    float *rowred = dqs + TM * MAX_OUT;     // [64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int e = blockIdx.y, m0 = blockIdx.x * TM;
+    const int net = g.ids ? g.ids[e] : e;
+    const float *P = g.params + (int64_t)net * g.net_stride;
+    const float *X = g.X + (int64_t)e * g.sX;
+    const int col0 = wave * 32;
+    const bool active = col0 < H;
+
+    STAMP(0);
+    // ---- x tile -> LDS, zero padded to KP columns and to 32 rows
+    for (int i = tid; i < TM * KP; i += NTHR) {
+        const int r = i / KP, k = i - r * KP;
+        const bool ok = (m0 + r) < g.n_rows && k < IN;
+        const float v = X[ok ? (int64_t)(m0 + r) * g.ldx + k : 0];
+        xs[r * ldx_s + k] = ok ? v : 0.0f;
+    }
+    // (gemm_tile starts with a barrier)
+
+    STAMP(1);
+    // ---- fc1
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    gemm_tile<false, false>(acc, xs, ldx_s, IN, P + g.off[0], IN, H, Ws, Ws1, tid, col0);
+    STAMP(2);
+    if (active) {
+        const float b = P[g.off[1] + col0 + li];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float v = fmaxf(acc[r] + b, 0.0f);
+            h1s[row * ldh + col0 + li] = v;
+            if (g.H1 && (m0 + row) < g.n_rows)
+                g.H1[((int64_t)e * g.n_rows + m0 + row) * H + col0 + li] = v;
+        }
+    }
+    STAMP(3);
+    // ---- fc2
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    if (g.vec) gemm_tile<true, false>(acc, h1s, ldh, H, P + g.off[2], H, H, Ws, Ws1, tid, col0);
+    else gemm_tile<false, false>(acc, h1s, ldh, H, P + g.off[2], H, H, Ws, Ws1, tid, col0);
+    STAMP(4);
+    if (active) {
+        const float b = P[g.off[3] + col0 + li];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float v = fmaxf(acc[r] + b, 0.0f);
+            h2s[row * ldh + col0 + li] = v;
+            if (g.H2 && (m0 + row) < g.n_rows)
+                g.H2[((int64_t)e * g.n_rows + m0 + row) * H + col0 + li] = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- head weights -> LDS (the staging buffers are free after fc2): every later use of W3
+    //      (head, head backward) then reads LDS instead of chaining global-load latencies
+    STAMP(5);
+    const int ldw3 = H + APAD;
+    float *w3s = Ws;   // [OUT][H+4]
+    float *b3s = Ws1;  // [OUT], then the K-split partial tiles [8][32][16] at Ws1 + 16
+    float *hpart = Ws1 + 16;
+    for (int i = tid; i < OUT * H; i += NTHR) {
+        const int o = i / H, k = i - o * H;
+        w3s[o * ldw3 + k] = P[g.off[4] + i];
+    }
+    if (tid < OUT) b3s[tid] = P[g.off[5] + tid];
+    __syncthreads();
+    STAMP(6);
+    // ---- head on the matrix cores: wave w multiplies the k-slice [32w, 32w+32) of h2 with W3^T
+    //      (rows >= OUT of the 32-wide B tile are zero); the 8 partial tiles are summed through LDS
+    {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        if (col0 < H) {  // col0 = 32*wave doubles as this wave's k-slice start
+            const f4 *ap = reinterpret_cast<const f4 *>(h2s + li * ldh + col0 + lh * 16);
+            const f4 *bp = reinterpret_cast<const f4 *>(w3s + (li < OUT ? li : 0) * ldw3 + col0 + lh * 16);
+            f4 a4[4], b4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a4[q] = ap[q]; b4[q] = bp[q]; }
+            const float keep = li < OUT ? 1.0f : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t >> 2][t & 3], b4[t >> 2][t & 3] * keep, acc, 0, 0, 0);
+        }
+        if (li < MAX_OUT) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                hpart[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * MAX_OUT + li] = acc[r];
+        }
+        __syncthreads();
+        const int row = tid >> 4, o = tid & 15;
+        if (o < OUT) {
+            float v = b3s[o];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) v += hpart[(w * 32 + row) * MAX_OUT + o];
+            ys[row * MAX_OUT + o] = v;
+            if (g.Y && (m0 + row) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + row) * OUT + o] = v;
+        }
+    }
+    STAMP(7);
+    if (MODE == MODE_PLAIN) return;
+    __syncthreads();
+
+    if (MODE == MODE_SAMPLE) {
+        // tanh-normal head: one thread per row (32 rows)
+        if (tid < TM && (m0 + tid) < g.n_rows) {
+            const int b = m0 + tid, A = OUT >> 1;
+            float lp = 0.0f;
+            for (int i = 0; i < A; ++i) {
+                const float mu = ys[tid * MAX_OUT + i], raw = ys[tid * MAX_OUT + A + i];
+                const float log_std = g.lo + 0.5f * (g.hi - g.lo) * (tanhf(raw) + 1.0f);
+                const float sd = expf(log_std);
+                const float u = mu + sd * g.eps[(int64_t)b * A + i];
+                const float a = tanhf(u);
+                const float dlt = u - mu;
+                lp += (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -
+                      2.0f * (LOG_2 - u - softplus_f(-2.0f * u));
+                g.act_dst[b * g.ld_act + g.act_col0 + i] = a;
+            }
+            if (g.logp) g.logp[b] = lp;
+        }
+        return;
+    }
+
+    if (MODE == MODE_CRITIC) {
+        // ---- loss gradient per row (learning.py:90-98, 112)
+        const float pw = (g.popart && g.pop) ? g.popart->w : 1.0f;
+        const float pb = (g.popart && g.pop) ? g.popart->b : 0.0f;
+        const float gscale = -2.0f * pw / (g.denom * (float)g.n_rows);
+        if (tid < TM) {
+            float lossv = 0.0f, errv = 0.0f;
+            const int b = m0 + tid;
+            int ai = 0;
+            float dsel = 0.0f;
+            if (b < g.n_rows) {
+                if (OUT > 1) ai = (int)g.act[b * g.ld_a];
+                const float w = g.weight ? g.weight[b] : 1.0f;
+                const float err = g.td[b] - (pw * ys[tid * MAX_OUT + ai] + pb);
+                lossv = w * err * err;
+                errv = err;
+                dsel = gscale * w * err;
+            }
+            for (int o = 0; o < OUT; ++o) {
+                const float d = (o == ai) ? dsel : 0.0f;
+                dqs[tid * MAX_OUT + o] = d;
+                if (b < g.n_rows) g.DQ[((int64_t)e * g.n_rows + b) * OUT + o] = d;
+            }
+            rowred[tid] = lossv;
+            rowred[32 + tid] = errv;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float sl = 0.0f, se = 0.0f;
+            for (int r = 0; r < TM; ++r) { sl += rowred[r]; se += rowred[32 + r]; }
+            const int64_t pi = ((int64_t)e * gridDim.x + blockIdx.x) * 2;
+            g.partials[pi] = sl;
+            g.partials[pi + 1] = se;
+        }
+        STAMP(8);
+        // ---- head backward: dz2 = (dq W3) (.) [h2 > 0], in place over h2s
+        {
+            // thread -> column k = tid % 256, rows r = (tid >> 8), +2, ...  (H <= 256)
+            const int k = tid & 255;
+            if (k < H) {
+                for (int r = tid >> 8; r < TM; r += 2) {
+                    float gsum = 0.0f;
+                    for (int o = 0; o < OUT; ++o) gsum += dqs[r * MAX_OUT + o] * w3s[o * ldw3 + k];
+                    const float dz = h2s[r * ldh + k] > 0.0f ? gsum : 0.0f;
+                    h2s[r * ldh + k] = dz;
+                    if ((m0 + r) < g.n_rows) g.DZ2[((int64_t)e * g.n_rows + m0 + r) * H + k] = dz;
+                }
+            }
+        }
+        STAMP(9);
+        // ---- backward-data of fc2: dz1 = (dz2 W2) (.) [h1 > 0]   (gemm_nn starts with a barrier)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        if (g.vec) gemm_tile<true, true>(acc, h2s, ldh, H, P + g.off[2], H, H, Ws, Ws1, tid, col0);
+        else gemm_tile<false, true>(acc, h2s, ldh, H, P + g.off[2], H, H, Ws, Ws1, tid, col0);
+        STAMP(10);
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if ((m0 + row) < g.n_rows) {
+                    const float v = h1s[row * ldh + col0 + li] > 0.0f ? acc[r] : 0.0f;
+                    g.DZ1[((int64_t)e * g.n_rows + m0 + row) * H + col0 + li] = v;
+                }
+            }
+        }
+        STAMP(11);
+    }
+}
+
+long long *g_fused_dbg = nullptr;
+
+size_t fused_lds_bytes(int in_dim, int hidden) {
+    const int KP = (in_dim + 31) & ~31;
+    return sizeof(float) * ((size_t)TM * (KP + APAD) + 2 * (size_t)TM * (hidden + APAD) + 2 * WS_FLOATS +
+                            2 * TM * MAX_OUT + 64);
+}
+
+bool fused_ok(const ssac_mlp *n) {
+    return n && n->hidden % 32 == 0 && n->hidden <= 256 && n->out_dim >= 1 && n->out_dim <= MAX_OUT &&
+           n->in_dim >= 1 && fused_lds_bytes(n->in_dim, n->hidden) <= 160 * 1024;
+}
+
+void fill_common(FusedArgs &g, const ssac_mlp *nets, const int32_t *ids, const float *X, int64_t ldx,
+                 int64_t sX, int n_rows) {
+    g.params = nets->params; g.net_stride = nets->net_stride;
+    g.in_dim = nets->in_dim; g.hidden = nets->hidden; g.out_dim = nets->out_dim;
+    ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, g.off);
+    g.ids = ids; g.X = X; g.ldx = ldx; g.sX = sX; g.n_rows = n_rows;
+    // W2 rows are 16-byte aligned when the arena base, the net stride and the W2 offset are
+    g.dbg = g_fused_dbg;
+    g.vec = (((uintptr_t)nets->params & 15) == 0 && (nets->net_stride & 3) == 0 && (g.off[2] & 3) == 0 &&
+             (nets->hidden & 3) == 0) ? 1 : 0;
+}
+
+template <int MODE>
+int launch_fused(const FusedArgs &g, int n_sel, hipStream_t st) {
+    static bool attr_set = false;
+    const size_t lds = fused_lds_bytes(g.in_dim, g.hidden);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)fused_mlp_kernel<MODE>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return ssac_fail("fused_mlp: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    dim3 grid((g.n_rows + TM - 1) / TM, n_sel);
+    hipLaunchKernelGGL((fused_mlp_kernel<MODE>), grid, dim3(NTHR), lds, st, g);
+    return ssac_check_launch("fused_mlp");
+}
+
+// ------------------------------------------------------------------ head weight gradient + Adam
+// dW3[o][k] = sum_m dq[m][o] h2[m][k];  db3[o] = sum_m dq[m][o].  grid (ceil(H/64), n_sel), 256 thr.
+constexpr int HW_GROUPS = 16;  // row groups per workgroup (1024 threads = 64 columns x 16 groups)
+__global__ __launch_bounds__(64 * HW_GROUPS) void head_wgrad_kernel(
+    float *params, int64_t net_stride, int hidden, int out_dim, int64_t off_w, int64_t off_b,
+    const int32_t *ids, const float *__restrict__ H2, const float *__restrict__ DQ, int n_rows,
+    float *am, float *av, const ssac_adam_ctl *ctl, float *grads, float *sumsq, int64_t sumsq_stride,
+    float *target, float tau) {
+    __shared__ float red[HW_GROUPS][64];
+    __shared__ float redb[HW_GROUPS];
+    __shared__ float ssred;
+    const int tid = threadIdx.x, kk = tid & 63, mg = tid >> 6;
+    const int e = blockIdx.y, k = blockIdx.x * 64 + kk;
+    const int net = ids ? ids[e] : e;
+    const int64_t base = (int64_t)net * net_stride;
+    const bool kok = k < hidden;
+    const float *h2 = H2 + (int64_t)e * n_rows * hidden + (kok ? k : 0);
+    const float *dq = DQ + (int64_t)e * n_rows * out_dim;
+    if (tid == 0) ssred = 0.0f;
+    float ss = 0.0f;
+    // one output row o at a time: out_dim is small (1 for continuous critics), rows are the long axis
+    for (int o = 0; o < out_dim; ++o) {
+        float acc = 0.0f, accb = 0.0f;
+        int m = mg;
+        for (; m + 7 * HW_GROUPS < n_rows; m += 8 * HW_GROUPS) {
+            float hv[8], dv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                hv[u] = h2[(int64_t)(m + u * HW_GROUPS) * hidden];
+                dv[u] = dq[(int64_t)(m + u * HW_GROUPS) * out_dim + o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc += dv[u] * hv[u]; accb += dv[u]; }
+        }
+        for (; m < n_rows; m += HW_GROUPS) {
+            const float d = dq[(int64_t)m * out_dim + o];
+            acc += d * h2[(int64_t)m * hidden];
+            accb += d;
+        }
+        __syncthreads();
+        red[mg][kk] = acc;
+        if (kk == 0) redb[mg] = accb;
+        __syncthreads();
+        if (mg == 0) {
+            float gr = 0.0f;
+#pragma unroll
+            for (int q = 0; q < HW_GROUPS; ++q) gr += red[q][kk];
+            const ssac_adam_ctl c = grads ? ssac_adam_ctl{} : *ctl;
+            if (kok) {
+                ss += gr * gr;
+                const int64_t i = base + off_w + (int64_t)o * hidden + k;
+                if (grads) {
+                    grads[i] = gr;
+                } else {
+                    float g2 = gr;
+                    const float p = params[i];
+                    if (c.weight_decay != 0.0f) g2 = g2 + c.weight_decay * p;
+                    float mm = am[i], vv = av[i];
+                    mm = mm + (1.0f - c.beta1) * (g2 - mm);
+                    vv = vv * c.beta2 + (1.0f - c.beta2) * g2 * g2;
+                    const float pn = p - c.step_size * (mm / (sqrtf(vv) / c.bc2_sqrt + c.eps));
+                    am[i] = mm; av[i] = vv; params[i] = pn;
+                    if (target) target[i] = target[i] * (1.0f - tau) + pn * tau;
+                }
+            }
+            if (blockIdx.x == 0 && kk == 0) {  // bias gradient db3[o] = sum_m dq[m][o]
+                float gb = 0.0f;
+#pragma unroll
+                for (int q = 0; q < HW_GROUPS; ++q) gb += redb[q];
+                ss += gb * gb;
+                const int64_t i = base + off_b + o;
+                if (grads) {
+                    grads[i] = gb;
+                } else {
+                    float g2 = gb;
+                    const float p = params[i];
+                    if (c.weight_decay != 0.0f) g2 = g2 + c.weight_decay * p;
+                    float mm = am[i], vv = av[i];
+                    mm = mm + (1.0f - c.beta1) * (g2 - mm);
+                    vv = vv * c.beta2 + (1.0f - c.beta2) * g2 * g2;
+                    const float pn = p - c.step_size * (mm / (sqrtf(vv) / c.bc2_sqrt + c.eps));
+                    am[i] = mm; av[i] = vv; params[i] = pn;
+                    if (target) target[i] = target[i] * (1.0f - tau) + pn * tau;
+                }
+            }
+        }
+    }
+    if (sumsq) {
+        if (mg == 0) {  // wave 0 holds every contribution
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            if (kk == 0) sumsq[(int64_t)e * sumsq_stride + blockIdx.x] = ss;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ log finalisation (1 WG)
+__global__ __launch_bounds__(256) void critic_logs_kernel(const float *__restrict__ partials, int n_nets,
+                                                          int tiles, int n_rows, float denom,
+                                                          const float *__restrict__ sumsq, int n_ss,
+                                                          const ssac_adam_ctl *scale, float *logs) {
+    __shared__ float red[3][4];
+    float sl = 0.f, se = 0.f, ss = 0.f;
+    const int tot = n_nets * tiles;
+    for (int i = threadIdx.x; i < tot; i += blockDim.x) {
+        sl += partials[2 * i];
+        if (i / tiles == n_nets - 1) se += partials[2 * i + 1];
+    }
+    for (int i = threadIdx.x; i < n_ss; i += blockDim.x) ss += sumsq[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sl += __shfl_xor(sl, o, 64); se += __shfl_xor(se, o, 64); ss += __shfl_xor(ss, o, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = sl; red[1][w] = se; red[2][w] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sl = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        se = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        ss = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        logs[0] += sl / (denom * (float)n_rows);   // losses/critic_overall_loss (accumulates over members)
+        logs[1] = se / (float)n_rows;              // losses/last_member_critic_td_error
+        if (sumsq) logs[2] = sqrtf(ss) * (scale ? scale->clip_coef : 1.0f);
+    }
+}
+
+}  // namespace
+
+extern "C" int ssac_fused_debug_stamps(long long *dev_buf) { g_fused_dbg = dev_buf; return 0; }
+extern "C" int ssac_fused_supported(const ssac_mlp *nets) { return fused_ok(nets) ? 1 : 0; }
+
+extern "C" int ssac_mlp3_fwd_fused(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
+                                   int64_t ldx, int64_t x_net_stride, int n_rows, float *H1, float *H2,
+                                   float *Y, void *stream) {
+    if (!fused_ok(nets)) return ssac_fail("ssac_mlp3_fwd_fused: shape not supported by the fused path");
+    if (n_sel < 0 || n_sel > SSAC_MAX_NETS) return ssac_fail("ssac_mlp3_fwd_fused: n_sel out of range");
+    if (n_sel == 0 || n_rows <= 0) return 0;
+    FusedArgs g{};
+    fill_common(g, nets, net_ids, X, ldx, x_net_stride, n_rows);
+    g.H1 = H1; g.H2 = H2; g.Y = Y;
+    return launch_fused<MODE_PLAIN>(g, n_sel, (hipStream_t)stream);
+}
+
+extern "C" int ssac_actor_sample_fused(const ssac_mlp *actor, const float *X, int64_t ldx, int n_rows,
+                                       const float *eps, float log_std_lo, float log_std_hi,
+                                       float *act_dst, int64_t ld_act, int64_t act_col0, float *logp,
+                                       float *H1, float *H2, float *out, void *stream) {
+    if (!fused_ok(actor) || (actor->out_dim & 1))
+        return ssac_fail("ssac_actor_sample_fused: shape not supported by the fused path");
+    if (n_rows <= 0) return 0;
+    FusedArgs g{};
+    fill_common(g, actor, nullptr, X, ldx, 0, n_rows);
+    g.H1 = H1; g.H2 = H2; g.Y = out;
+    g.eps = eps; g.lo = log_std_lo; g.hi = log_std_hi;
+    g.act_dst = act_dst; g.ld_act = ld_act; g.act_col0 = act_col0; g.logp = logp;
+    return launch_fused<MODE_SAMPLE>(g, 1, (hipStream_t)stream);
+}
+
+extern "C" int ssac_critic_fwd_bwd_fused(const ssac_mlp *nets, const float *X, int64_t ldx, int n_rows,
+                                         const float *td, const float *weight, const float *act,
+                                         int64_t ld_act, const ssac_popart *popart, int pop, float denom,
+                                         float *H1, float *H2, float *Q, float *DQ, float *DZ2, float *DZ1,
+                                         float *partials, void *stream) {
+    if (!fused_ok(nets)) return ssac_fail("ssac_critic_fwd_bwd_fused: shape not supported by the fused path");
+    if (!H1 || !H2 || !DQ || !DZ2 || !DZ1 || !partials || !td)
+        return ssac_fail("ssac_critic_fwd_bwd_fused: missing output buffer");
+    if (nets->out_dim > 1 && !act) return ssac_fail("ssac_critic_fwd_bwd_fused: discrete needs actions");
+    if (n_rows <= 0) return 0;
+    FusedArgs g{};
+    fill_common(g, nets, nullptr, X, ldx, 0, n_rows);
+    g.H1 = H1; g.H2 = H2; g.Y = Q;
+    g.td = td; g.weight = weight; g.act = act; g.ld_a = ld_act; g.popart = popart; g.pop = pop;
+    g.denom = denom; g.DQ = DQ; g.DZ2 = DZ2; g.DZ1 = DZ1; g.partials = partials;
+    return launch_fused<MODE_CRITIC>(g, nets->n_nets, (hipStream_t)stream);
+}
+
+extern "C" int ssac_fused_row_tiles(int n_rows) { return (n_rows + TM - 1) / TM; }
+
+extern "C" int ssac_head_wgrad(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *H2,
+                               const float *DQ, int n_rows, float *adam_m, float *adam_v,
+                               const ssac_adam_ctl *ctl, float *grads, float *sumsq,
+                               int64_t sumsq_net_stride, float *target, float tau, void *stream) {
+    if (!nets || nets->out_dim > MAX_OUT) return ssac_fail("ssac_head_wgrad: out_dim too large");
+    if (!grads && (!adam_m || !adam_v || !ctl)) return ssac_fail("ssac_head_wgrad: Adam state missing");
+    if (n_sel <= 0 || n_rows <= 0) return 0;
+    int64_t off[6];
+    ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, off);
+    dim3 grid((nets->hidden + 63) / 64, n_sel);
+    hipLaunchKernelGGL(head_wgrad_kernel, grid, dim3(64 * HW_GROUPS), 0, (hipStream_t)stream, nets->params,
+                       nets->net_stride, nets->hidden, nets->out_dim, off[4], off[5], net_ids, H2, DQ,
+                       n_rows, adam_m, adam_v, ctl, grads, sumsq, sumsq_net_stride, target, tau);
+    return ssac_check_launch("head_wgrad");
+}
+
+extern "C" int ssac_head_wgrad_tiles(const ssac_mlp *nets) { return nets ? (nets->hidden + 63) / 64 : -1; }
+
+extern "C" int ssac_critic_logs(const float *partials, int n_nets, int tiles, int n_rows, float denom,
+                                const float *sumsq, int n_sumsq, const ssac_adam_ctl *scale_by_clip,
+                                float *logs, void *stream) {
+    hipLaunchKernelGGL(critic_logs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n_nets,
+                       tiles, n_rows, denom, sumsq, n_sumsq, scale_by_clip, logs);
+    return ssac_check_launch("critic_logs");
+}

@@ -50,13 +50,16 @@ struct GemmArgs {
     const ssac_adam_ctl *ctl;
     float *sumsq;            // partial sums of g^2: sumsq[e*sumsq_stride + tile] (nullable)
     int64_t sumsq_stride;
+    int vec;                 // bit0: A rows are 16-byte aligned, bit1: B rows (row-contiguous operands)
+    long long *dbg;          // optional s_memtime stamps of workgroup (0,0,0), thread 0
 };
 
 __device__ __forceinline__ int64_t batch_off(const int32_t *ids, int use_ids, int e, int64_t stride) {
     return (int64_t)((use_ids && ids) ? ids[e] : e) * stride;
 }
 
-// ---- global -> register staging (8 floats per thread per operand per chunk) ----
+// ---- global -> register staging (8 floats per thread per operand per chunk), branch-free:
+//      out-of-range lanes read element 0 (always valid) and select 0.
 template <bool KCONTIG>
 __device__ __forceinline__ void load_chunk(float (&r)[8], const float *__restrict__ S, int64_t ld,
                                            int R0, int R, int k0, int K, int tid) {
@@ -67,7 +70,9 @@ __device__ __forceinline__ void load_chunk(float (&r)[8], const float *__restric
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int row = R0 + rr + 8 * p;
-            r[p] = (kok && row < R) ? S[(int64_t)row * ld + k0 + kk] : 0.0f;
+            const bool ok = kok && row < R;
+            const float v = S[ok ? (int64_t)row * ld + k0 + kk : 0];
+            r[p] = ok ? v : 0.0f;
         }
     } else {
         // S is (K x R) row-major: thread -> row = tid&63, k = (tid>>6) + 4p
@@ -76,7 +81,9 @@ __device__ __forceinline__ void load_chunk(float (&r)[8], const float *__restric
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int k = k0 + kk + 4 * p;
-            r[p] = (rok && k < K) ? S[(int64_t)k * ld + R0 + rr] : 0.0f;
+            const bool ok = rok && k < K;
+            const float v = S[ok ? (int64_t)k * ld + R0 + rr : 0];
+            r[p] = ok ? v : 0.0f;
         }
     }
 }
@@ -115,14 +122,56 @@ __device__ __forceinline__ float adam_elem(float p, float g, float &m, float &v,
     return p - c.step_size * (m / denom);
 }
 
-template <bool A_KC, bool B_KC, int EPI>
-__global__ __launch_bounds__(NTHREADS) void ens_gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * TILE_FLOATS + 64];
-    float *As = lds;
-    float *Bs = lds + TILE_FLOATS;
-    float *red = lds + 2 * TILE_FLOATS;  // 64 floats: bias-grad / sumsq scratch
+// KS = number of K-split groups of 4 waves inside the workgroup.  Group kg consumes chunks
+// kg, kg+KS, ... with its own LDS staging; the partial tiles are summed through LDS before the
+// epilogue.  It buys latency hiding (KS waves per SIMD) for launches with few tiles and a long K
+// (weight gradients: K = batch), where most CUs would otherwise run one wave per SIMD.
+#define GSTAMP(i) do { if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
-    const int tid = threadIdx.x;
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// Row-contiguous operand (K x R row-major, e.g. dY and X of the weight-gradient GEMM), 16-byte
+// loads: thread -> 4 consecutive rows r4 = 4*(tid&15), k = (tid>>4) + 16q.  The source pointers
+// are built once and advanced by a uniform stride; the LDS image is Xt[k*64 + r] (b128 stores).
+struct RcVecLoader {
+    const float *p[2];
+    const float *safe;  // always-valid 16-byte aligned address for predicated-off lanes
+    f4 v[2];
+    int kk, r4;
+    bool rok;
+    __device__ __forceinline__ void init(const float *S, int64_t ld, int R0, int R, int kfirst, int tid) {
+        r4 = (tid & 15) * 4;
+        kk = tid >> 4;
+        safe = S;
+        rok = (R0 + r4) < R;  // R % 4 == 0 on this path
+#pragma unroll
+        for (int q = 0; q < 2; ++q) p[q] = S + (rok ? (int64_t)(kfirst + kk + 16 * q) * ld + R0 + r4 : 0);
+    }
+    __device__ __forceinline__ void load(int k0, int K, int64_t adv) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bool ok = rok && (k0 + kk + 16 * q) < K;
+            const f4 x = *reinterpret_cast<const f4 *>(ok ? p[q] : safe);
+            v[q] = ok ? x : (f4){0.f, 0.f, 0.f, 0.f};
+            p[q] += adv;
+        }
+    }
+    __device__ __forceinline__ void store(float *Xt) const {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<f4 *>(Xt + (kk + 16 * q) * LDS_RC + r4) = v[q];
+    }
+};
+
+template <bool A_KC, bool B_KC, int EPI, int KS>
+__global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid_all = threadIdx.x;
+    const int kg = tid_all >> 8, tid = tid_all & 255;
+    // per K-group: two staging buffers (double buffering), each [A tile | B tile]
+    float *buf0 = lds + kg * (4 * TILE_FLOATS);
+    float *buf1 = buf0 + 2 * TILE_FLOATS;
+    float *red = lds + KS * (4 * TILE_FLOATS);  // 64*KS floats: bias-grad / sumsq scratch
+
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -137,83 +186,125 @@ __global__ __launch_bounds__(NTHREADS) void ens_gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 
-    float ra[8], rb[8];
     float bias_acc = 0.0f;  // TN mode, column sums of A (bias gradient), threads < 64 of n-tile 0
     const bool want_bias_grad = (EPI == EPI_ADAM || EPI == EPI_GRAD) && blockIdx.x == 0;
-
     const int nchunks = (g.K + BK - 1) / BK;
-    load_chunk<A_KC>(ra, A, g.lda, m0, g.M, 0, g.K, tid);
-    load_chunk<B_KC>(rb, B, g.ldb, n0, g.N, 0, g.K, tid);
-    for (int c = 0; c < nchunks; ++c) {
-        __syncthreads();  // everyone finished reading the previous chunk
-        store_chunk<A_KC>(ra, As, tid);
-        store_chunk<B_KC>(rb, Bs, tid);
-        __syncthreads();
-        if (c + 1 < nchunks) {
-            load_chunk<A_KC>(ra, A, g.lda, m0, g.M, (c + 1) * BK, g.K, tid);
-            load_chunk<B_KC>(rb, B, g.ldb, n0, g.N, (c + 1) * BK, g.K, tid);
+    const int iters = (nchunks + KS - 1) / KS;
+    constexpr bool TN = !A_KC && !B_KC;
+    // 16-byte loads need 16-byte aligned rows on both operands (checked per launch on the host)
+    const bool vecA = TN && (g.vec & 1), vecB = TN && (g.vec & 2);
+
+    float ra[8], rb[8];
+    RcVecLoader va, vb;
+    if (vecA) va.init(A, g.lda, m0, g.M, kg * BK, tid);
+    if (vecB) vb.init(B, g.ldb, n0, g.N, kg * BK, tid);
+    const int64_t advA = (int64_t)KS * BK * g.lda, advB = (int64_t)KS * BK * g.ldb;
+
+    auto loadA = [&](int k0) { if (vecA) va.load(k0, g.K, advA); else load_chunk<A_KC>(ra, A, g.lda, m0, g.M, k0, g.K, tid); };
+    auto loadB = [&](int k0) { if (vecB) vb.load(k0, g.K, advB); else load_chunk<B_KC>(rb, B, g.ldb, n0, g.N, k0, g.K, tid); };
+    auto storeA = [&](float *d) { if (vecA) va.store(d); else store_chunk<A_KC>(ra, d, tid); };
+    auto storeB = [&](float *d) { if (vecB) vb.store(d); else store_chunk<B_KC>(rb, d, tid); };
+
+    GSTAMP(0);
+    loadA(kg * BK);
+    loadB(kg * BK);
+    storeA(buf0);
+    storeB(buf0 + TILE_FLOATS);
+    if (iters > 1) { loadA((KS + kg) * BK); loadB((KS + kg) * BK); }
+    __syncthreads();
+    GSTAMP(1);
+    for (int it = 0; it < iters; ++it) {
+        float *cur = (it & 1) ? buf1 : buf0;
+        float *nxt = (it & 1) ? buf0 : buf1;
+        const float *As = cur, *Bs = cur + TILE_FLOATS;
+        float fa[BK / 2], fb[BK / 2];
+#pragma unroll
+        for (int t = 0; t < BK / 2; ++t) {
+            fa[t] = frag<A_KC>(As, wm * 32 + li, 2 * t + lh);
+            fb[t] = frag<B_KC>(Bs, wn * 32 + li, 2 * t + lh);
         }
+        if (it + 1 < iters) { storeA(nxt); storeB(nxt + TILE_FLOATS); }
+        if (it + 2 < iters) { const int k0 = ((it + 2) * KS + kg) * BK; loadA(k0); loadB(k0); }
         if (want_bias_grad && tid < 64) {
             // A is staged row-contiguous in the weight-gradient mode: As[k][m]
 #pragma unroll 8
             for (int k = 0; k < BK; ++k) bias_acc += As[k * LDS_RC + tid];
         }
 #pragma unroll
-        for (int t = 0; t < BK / 2; ++t) {
-            const float a = frag<A_KC>(As, wm * 32 + li, 2 * t + lh);
-            const float b = frag<B_KC>(Bs, wn * 32 + li, 2 * t + lh);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
+        for (int t = 0; t < BK / 2; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
+        __syncthreads();
     }
 
-    // ---- epilogue.  C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int gn = n0 + wn * 32 + li;
-    const bool nok = gn < g.N;
-    float ss = 0.0f;
-    ssac_adam_ctl ctl;
-    if (EPI == EPI_ADAM) ctl = *g.ctl;
-    float bias_n = 0.0f;
-    if ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && nok)
-        bias_n = g.bias[batch_off(g.ids, g.idsB, e, g.sBias) + gn];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (!(nok && gm < g.M)) continue;
-        float val = acc[r];
-        const int64_t ci = coff + (int64_t)gm * g.ldc + gn;
-        if (EPI == EPI_STORE) {
-            g.C[ci] = val;
-        } else if (EPI == EPI_BIAS) {
-            g.C[ci] = val + bias_n;
-        } else if (EPI == EPI_BIAS_RELU) {
-            g.C[ci] = fmaxf(val + bias_n, 0.0f);
-        } else if (EPI == EPI_MASK) {
-            const float hm = g.mask[(int64_t)e * g.sMask + (int64_t)gm * g.ldmask + gn];
-            g.C[ci] = hm > 0.0f ? val : 0.0f;
-        } else if (EPI == EPI_GRAD) {
-            g.gw[ci] = val;
-            ss += val * val;
-        } else if (EPI == EPI_ADAM) {
-            ss += val * val;
-            float m = g.am[ci], v = g.av[ci];
-            const float pn = adam_elem(g.C[ci], val, m, v, ctl);
-            g.am[ci] = m;
-            g.av[ci] = v;
-            g.C[ci] = pn;
-            if (g.tw) g.tw[ci] = g.tw[ci] * (1.0f - g.tau) + pn * g.tau;
-        }
-    }
+    GSTAMP(2);
     if (EPI == EPI_ADAM || EPI == EPI_GRAD) {
-        if (want_bias_grad && tid < 64) {
-            const int gm = m0 + tid;
+        // ---- weight-gradient epilogue on ALL threads of the workgroup.  Every K-group parks its
+        // partial 64x64 tile in LDS; element idx = row*64 + col is then finished (partials summed in
+        // a fixed order -> deterministic) by thread idx % (256*KS), so the optimizer's three loads
+        // and three stores per element are spread over 4*KS waves and issued as independent batches
+        // instead of one latency-bound chain per accumulator register.
+        float *mine = lds + kg * (4 * TILE_FLOATS);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            mine[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + wn * 32 + li] = acc[r];
+        if (want_bias_grad && tid < 64) red[kg * 64 + tid] = bias_acc;
+        __syncthreads();
+        GSTAMP(3);
+        constexpr int NT_ALL = NTHREADS * KS;
+        constexpr int PER = (BM * BN) / NT_ALL;  // 16 / KS elements per thread
+        ssac_adam_ctl ctl;
+        if (EPI == EPI_ADAM) ctl = *g.ctl;
+        float gval[PER], pv[PER], mv[PER], vv[PER], tv[PER];
+        int64_t ci[PER];
+        bool ok[PER];
+        float ss = 0.0f;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int idx = tid_all + j * NT_ALL;
+            const int row = idx >> 6, col = idx & 63;
+            float sum = lds[idx];
+#pragma unroll
+            for (int gq = 1; gq < KS; ++gq) sum += lds[gq * (4 * TILE_FLOATS) + idx];
+            gval[j] = sum;
+            ok[j] = (m0 + row) < g.M && (n0 + col) < g.N;
+            ci[j] = coff + (int64_t)(m0 + row) * g.ldc + n0 + col;
+        }
+        if (EPI == EPI_ADAM) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int64_t a = ok[j] ? ci[j] : coff;
+                pv[j] = g.C[a]; mv[j] = g.am[a]; vv[j] = g.av[a];
+                tv[j] = g.tw ? g.tw[a] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if (!ok[j]) continue;
+            ss += gval[j] * gval[j];
+            if (EPI == EPI_GRAD) {
+                g.gw[ci[j]] = gval[j];
+            } else {
+                float m = mv[j], v = vv[j];
+                const float pn = adam_elem(pv[j], gval[j], m, v, ctl);
+                g.am[ci[j]] = m;
+                g.av[ci[j]] = v;
+                g.C[ci[j]] = pn;
+                if (g.tw) g.tw[ci[j]] = tv[j] * (1.0f - g.tau) + pn * g.tau;
+            }
+        }
+        if (want_bias_grad && tid_all < 64) {
+            const int gm = m0 + tid_all;
             if (gm < g.M) {
+                float bsum = red[tid_all];
+#pragma unroll
+                for (int gq = 1; gq < KS; ++gq) bsum += red[gq * 64 + tid_all];
                 const int64_t bi = coff + gm;
-                ss += bias_acc * bias_acc;
+                ss += bsum * bsum;
                 if (EPI == EPI_GRAD) {
-                    g.gb[bi] = bias_acc;
+                    g.gb[bi] = bsum;
                 } else {
                     float m = g.bm[bi], v = g.bv[bi];
-                    const float pn = adam_elem(g.pb[bi], bias_acc, m, v, ctl);
+                    const float pn = adam_elem(g.pb[bi], bsum, m, v, ctl);
                     g.bm[bi] = m;
                     g.bv[bi] = v;
                     g.pb[bi] = pn;
@@ -221,26 +312,96 @@ __global__ __launch_bounds__(NTHREADS) void ens_gemm_kernel(GemmArgs g) {
                 }
             }
         }
+        GSTAMP(4);
         if (g.sumsq) {
             ss = wave_sum(ss);
+            __syncthreads();  // red[] (bias partials) has been consumed
+            if (lane == 0) red[tid_all >> 6] = ss;
             __syncthreads();
-            if (lane == 0) red[wave] = ss;
-            __syncthreads();
-            if (tid == 0) {
-                g.sumsq[(int64_t)e * g.sumsq_stride + blockIdx.y * gridDim.x + blockIdx.x] =
-                    red[0] + red[1] + red[2] + red[3];
+            if (tid_all == 0) {
+                float tot = 0.0f;
+                for (int w = 0; w < 4 * KS; ++w) tot += red[w];
+                g.sumsq[(int64_t)e * g.sumsq_stride + blockIdx.y * gridDim.x + blockIdx.x] = tot;
             }
         }
+        return;
     }
+
+    if (KS > 1) {
+        // sum the K-split partial tiles into group 0 (fixed order -> deterministic)
+        __syncthreads();
+        float *mine = lds + kg * (4 * TILE_FLOATS);  // 64x64 floats fit in one group's staging area
+        if (kg > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                mine[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + wn * 32 + li] = acc[r];
+        }
+        __syncthreads();
+        for (int gq = 1; gq < KS && kg == 0; ++gq) {
+            const float *other = lds + gq * (4 * TILE_FLOATS);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[r] += other[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + wn * 32 + li];
+        }
+    }
+
+    // ---- activation epilogues (group 0 only).  C/D layout of 32x32 MFMA: col = lane&31,
+    //      row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool leader = kg == 0;
+    const int gn = n0 + wn * 32 + li;
+    const bool nok = leader && gn < g.N;
+    float bias_n = 0.0f;
+    if ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && nok)
+        bias_n = g.bias[batch_off(g.ids, g.idsB, e, g.sBias) + gn];
+    float maskv[16];
+    if (EPI == EPI_MASK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const bool in = nok && gm < g.M;
+            maskv[r] = g.mask[in ? (int64_t)e * g.sMask + (int64_t)gm * g.ldmask + gn : 0];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gm = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (!(nok && gm < g.M)) continue;
+        const float val = acc[r];
+        const int64_t ci = coff + (int64_t)gm * g.ldc + gn;
+        if (EPI == EPI_STORE) g.C[ci] = val;
+        else if (EPI == EPI_BIAS) g.C[ci] = val + bias_n;
+        else if (EPI == EPI_BIAS_RELU) g.C[ci] = fmaxf(val + bias_n, 0.0f);
+        else if (EPI == EPI_MASK) g.C[ci] = maskv[r] > 0.0f ? val : 0.0f;
+    }
+}
+
+template <bool A_KC, bool B_KC, int EPI, int KS>
+int launch_ks(const GemmArgs &g, dim3 grid, hipStream_t st) {
+    static bool attr_set = false;
+    const size_t lds = sizeof(float) * (KS * 4 * TILE_FLOATS + 64 * KS);
+    if (!attr_set && lds > 48 * 1024) {
+        if (hipFuncSetAttribute((const void *)ens_gemm_kernel<A_KC, B_KC, EPI, KS>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ssac_fail("ens_gemm: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((ens_gemm_kernel<A_KC, B_KC, EPI, KS>), grid, dim3(NTHREADS * KS), lds, st, g);
+    return ssac_check_launch("ens_gemm");
 }
 
 template <bool A_KC, bool B_KC, int EPI>
 int launch(const GemmArgs &g, int batch, hipStream_t st) {
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
     if (grid.x == 0 || grid.y == 0 || batch == 0) return 0;
-    hipLaunchKernelGGL((ens_gemm_kernel<A_KC, B_KC, EPI>), grid, dim3(NTHREADS), 0, st, g);
-    return ssac_check_launch("ens_gemm");
+    const int tiles = grid.x * grid.y * batch;
+    const int nchunks = (g.K + BK - 1) / BK;
+    // K-split inside the workgroup when the launch cannot fill the chip with tiles alone
+    if (tiles <= 256 && nchunks >= 8) return launch_ks<A_KC, B_KC, EPI, 4>(g, grid, st);
+    if (tiles <= 512 && nchunks >= 4) return launch_ks<A_KC, B_KC, EPI, 2>(g, grid, st);
+    return launch_ks<A_KC, B_KC, EPI, 1>(g, grid, st);
 }
+
+long long *g_gemm_dbg = nullptr;
 
 struct LayerGeom { int64_t off_w, off_b; int rows, cols; };
 
@@ -254,6 +415,8 @@ bool layer_geom(const ssac_mlp *n, int layer, LayerGeom &L) {
 }
 
 }  // namespace
+
+extern "C" int ssac_gemm_debug_stamps(long long *dev_buf) { g_gemm_dbg = dev_buf; return 0; }
 
 extern "C" int64_t ssac_mlp_layout(int in_dim, int hidden, int out_dim, int64_t off[6]) {
     int64_t o = 0;
@@ -324,10 +487,13 @@ extern "C" int ssac_mlp_layer_wgrad(const ssac_mlp *nets, int layer, const int32
     g.C = nets->params + L.off_w; g.ldc = L.cols; g.sC = nets->net_stride; g.idsC = 1;
     g.M = L.rows; g.N = L.cols; g.K = n_rows;
     g.ids = net_ids;
+    g.vec = (((uintptr_t)dY & 15) == 0 && (ldy & 3) == 0 && (y_net_stride & 3) == 0 && (L.rows & 3) == 0 ? 1 : 0) |
+            (((uintptr_t)X & 15) == 0 && (ldx & 3) == 0 && (x_net_stride & 3) == 0 && (L.cols & 3) == 0 ? 2 : 0);
     g.pb = nets->params + L.off_b;
     g.ctl = ctl;
     g.sumsq = sumsq;
     g.sumsq_stride = sumsq_net_stride;
+    g.dbg = g_gemm_dbg;
     g.tau = tau;
     hipStream_t st = (hipStream_t)stream;
     if (grads) {

@@ -16,6 +16,7 @@ SEGS = ("w1", "b1", "w2", "b2", "w3", "b3")
 # bench.py's live kernel timing: when PROFILE["tag"] names a forward, its hidden-layer (fc2) launch
 # is bracketed by events recorded on the launch stream.
 PROFILE = {"tag": None, "events": []}
+USE_FUSED = True  # tests flip this to exercise the per-layer kernels on fused-capable shapes
 
 
 def _ptr(t):
@@ -70,6 +71,8 @@ class MlpArena:
                        (out_dim,)]
         self.params = torch.zeros(n_nets * self.stride, dtype=torch.float32, device=device)
         self.device = device
+        # one-launch fused kernels (csrc/ssac_fused.hip) apply to this shape?
+        self.fused = bool(lib.ssac_fused_supported(C.byref(self.desc()))) and USE_FUSED
 
     def like(self):
         return torch.zeros_like(self.params)
@@ -203,33 +206,82 @@ def adam_group(optimizer, device):
 # ------------------------------------------------------------------------------------------
 # launch sequences
 # ------------------------------------------------------------------------------------------
+def _timed(tag):
+    """context manager recording a (start, end) event pair when bench.py asked for `tag`."""
+    class _T:
+        def __enter__(self_):
+            self_.on = PROFILE["tag"] == tag
+            if self_.on:
+                self_.e0 = torch.cuda.Event(enable_timing=True)
+                self_.e1 = torch.cuda.Event(enable_timing=True)
+                self_.e0.record()
+        def __exit__(self_, *a):
+            if self_.on:
+                self_.e1.record()
+                PROFILE["events"].append((self_.e0, self_.e1))
+    return _T()
+
+
 def mlp_forward(arena, X, ldx, x_net_stride, n_rows, ws, tag, net_ids=None, n_sel=None,
-                params=None):
+                params=None, save=True):
     """h1 = relu(fc1 x), h2 = relu(fc2 h1), y = out(h2) for every selected net.
-    Returns (h1, h2, y) with shapes (n_sel, n_rows, H|H|out); all three are kept because the
-    backward pass needs them (they are what autograd would have saved)."""
+    Returns (h1, h2, y) with shapes (n_sel, n_rows, H|H|out); h1/h2 are what autograd would have
+    saved for the backward pass (None when `save` is False and the fused kernel kept them in LDS)."""
     n_sel = arena.n_nets if n_sel is None else n_sel
     H, O = arena.hidden, arena.out_dim
-    h1 = ws.get(tag + ".h1", (n_sel, n_rows, H))
-    h2 = ws.get(tag + ".h2", (n_sel, n_rows, H))
     y = ws.get(tag + ".y", (n_sel, n_rows, O))
     d = arena.desc(params)
     ids = _ptr(net_ids)
     st = stream()
+    if arena.fused:
+        h1 = ws.get(tag + ".h1", (n_sel, n_rows, H)) if save else None
+        h2 = ws.get(tag + ".h2", (n_sel, n_rows, H)) if save else None
+        check(lib.ssac_mlp3_fwd_fused(C.byref(d), ids, n_sel, X.data_ptr(), ldx, x_net_stride, n_rows,
+                                      _ptr(h1), _ptr(h2), y.data_ptr(), st))
+        return h1, h2, y
+    h1 = ws.get(tag + ".h1", (n_sel, n_rows, H))
+    h2 = ws.get(tag + ".h2", (n_sel, n_rows, H))
     check(lib.ssac_mlp_layer_fwd(C.byref(d), 0, ids, n_sel, X.data_ptr(), ldx, x_net_stride, n_rows,
                                  h1.data_ptr(), H, n_rows * H, 1, st))
-    prof = PROFILE["tag"] == tag
-    if prof:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    check(lib.ssac_mlp_layer_fwd(C.byref(d), 1, ids, n_sel, h1.data_ptr(), H, n_rows * H, n_rows,
-                                 h2.data_ptr(), H, n_rows * H, 1, st))
-    if prof:
-        e1.record()
-        PROFILE["events"].append((e0, e1))
+    with _timed(tag + ".fc2"):
+        check(lib.ssac_mlp_layer_fwd(C.byref(d), 1, ids, n_sel, h1.data_ptr(), H, n_rows * H, n_rows,
+                                     h2.data_ptr(), H, n_rows * H, 1, st))
     check(lib.ssac_mlp_layer_fwd(C.byref(d), 2, ids, n_sel, h2.data_ptr(), H, n_rows * H, n_rows,
                                  y.data_ptr(), O, n_rows * O, 0, st))
     return h1, h2, y
+
+
+def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, adam=None, adam_key=None,
+                 grads=None, sumsq=None, target=None, tau=0.0, net_ids=None, n_sel=None):
+    """the three weight-gradient launches (+Adam/Polyak in their epilogues, or gradient store)."""
+    n_sel = arena.n_nets if n_sel is None else n_sel
+    H, O = arena.hidden, arena.out_dim
+    d = arena.desc()
+    ids = _ptr(net_ids)
+    st = stream()
+    m = v = None
+    if grads is None:
+        m, v = adam.moments_for(adam_key, arena.params)
+    tiles = [arena.tiles(l) for l in range(3)]
+    ttot = sum(tiles)
+    off = {0: 0, 1: tiles[0], 2: tiles[0] + tiles[1]}
+    ctl = 0 if adam is None else adam.ctl.ptr
+
+    def ssp(layer):
+        return 0 if sumsq is None else sumsq.data_ptr() + 4 * off[layer]
+    if O <= 16:
+        check(lib.ssac_head_wgrad(C.byref(d), ids, n_sel, h2.data_ptr(), dY.data_ptr(), n_rows, _ptr(m),
+                                  _ptr(v), ctl, _ptr(grads), ssp(2), ttot, _ptr(target), float(tau), st))
+    else:
+        check(lib.ssac_mlp_layer_wgrad(C.byref(d), 2, ids, n_sel, h2.data_ptr(), H, n_rows * H,
+                                       dY.data_ptr(), O, n_rows * O, n_rows, _ptr(m), _ptr(v), ctl,
+                                       _ptr(grads), ssp(2), ttot, _ptr(target), float(tau), st))
+    check(lib.ssac_mlp_layer_wgrad(C.byref(d), 1, ids, n_sel, h1.data_ptr(), H, n_rows * H,
+                                   dz2.data_ptr(), H, n_rows * H, n_rows, _ptr(m), _ptr(v), ctl,
+                                   _ptr(grads), ssp(1), ttot, _ptr(target), float(tau), st))
+    check(lib.ssac_mlp_layer_wgrad(C.byref(d), 0, ids, n_sel, X.data_ptr(), ldx, x_net_stride,
+                                   dz1.data_ptr(), H, n_rows * H, n_rows, _ptr(m), _ptr(v), ctl,
+                                   _ptr(grads), ssp(0), ttot, _ptr(target), float(tau), st))
 
 
 def mlp_backward(arena, dY, X, ldx, x_net_stride, h1, h2, n_rows, ws, tag, *, adam=None,
@@ -257,21 +309,9 @@ def mlp_backward(arena, dY, X, ldx, x_net_stride, h1, h2, n_rows, ws, tag, *, ad
         check(lib.ssac_mlp_layer_dgrad(C.byref(d), 0, ids, n_sel, dz1.data_ptr(), H, n_rows * H,
                                        0, 0, 0, n_rows, dX.data_ptr(), I, n_rows * I, st))
     if update:
-        m = v = None
-        if grads is None:
-            m, v = adam.moments_for(adam_key, arena.params)
-        tiles = [arena.tiles(l) for l in range(3)]
-        ttot = sum(tiles)
-        srcs = ((2, h2, H, n_rows * H, dY, O, n_rows * O),
-                (1, h1, H, n_rows * H, dz2, H, n_rows * H),
-                (0, X, ldx, x_net_stride, dz1, H, n_rows * H))
-        off = {0: 0, 1: tiles[0], 2: tiles[0] + tiles[1]}
-        for layer, xin, ldi, sxi, dy, ldy, sy in srcs:
-            ss = 0 if sumsq is None else sumsq.data_ptr() + 4 * off[layer]
-            check(lib.ssac_mlp_layer_wgrad(C.byref(d), layer, ids, n_sel, xin.data_ptr(), ldi, sxi,
-                                           dy.data_ptr(), ldy, sy, n_rows, _ptr(m), _ptr(v),
-                                           0 if adam is None else adam.ctl.ptr, _ptr(grads), ss, ttot,
-                                           _ptr(target), float(tau), st))
+        weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, adam=adam,
+                     adam_key=adam_key, grads=grads, sumsq=sumsq, target=target, tau=tau,
+                     net_ids=net_ids, n_sel=n_sel)
     return dX
 
 

@@ -56,14 +56,14 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
     assert E <= lu.MAX_MEMBERS
     dev = log_alphas[0].device
     ws = lu.agent_ws(agent, dev)
-    slot = lu.log_block(dev)
+    adam = engine.adam_group(critic_optimizer, dev)
+    slot = lu.log_block(dev, adam)  # one launch: clear the log block + advance the Adam step
     logs = {}
     st = engine.stream()
-    adam = engine.adam_group(critic_optimizer, dev)
-    adam.advance()
     clip_members = []
     replay_dicts = []
     member_ss = []
+    fused_logs = []
     for i in range(E):
         rd = lu.sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter,
                                         aug_mix=aug_mix, per=per)
@@ -81,25 +81,44 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
         arena = agent.critics[i].arena(dev)
         N, qd = arena.n_nets, arena.out_dim
         X, ldx = _critic_input(rd.get("_ssac"), ws, f"cu.x{i}", s_rep, a, discrete)
-        h1, h2, q = engine.mlp_forward(arena, X, ldx, 0, B, ws, f"cu.c{i}")
-        dq = ws.get(f"cu.dq{i}", (N, B, qd))
         popart = agent.popart[i]
         weight_ptr = 0
         if not isinstance(bw, float):
             weight_ptr = bw.data_ptr()  # imp_weights is ones(1) on the uniform path
-        check(lib.ssac_critic_loss_bwd(q.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0), td.data_ptr(),
-                                       weight_ptr, popart.ptr if popart else 0,
-                                       1 if (popart and pop) else 0, float(E * N), dq.data_ptr(),
-                                       slot.data_ptr(), st))
+        pp, dopop = (popart.ptr if popart else 0), (1 if (popart and pop) else 0)
         ttot = engine.wgrad_tiles_total(arena)
         ss = ws.get(f"cu.ss{i}", (N * ttot,))
-        if critic_clip:
-            grads = ws.get(f"cu.g{i}", (arena.params.numel(),), zero=True)
-            engine.mlp_backward(arena, dq, X, ldx, 0, h1, h2, B, ws, f"cu.c{i}", grads=grads, sumsq=ss)
-            clip_members.append((arena, ("critic", i), grads, ss))
+        dq = ws.get(f"cu.dq{i}", (N, B, qd))
+        tag = f"cu.c{i}"
+        grads = ws.get(f"cu.g{i}", (arena.params.numel(),), zero=True) if critic_clip else None
+        if arena.fused:
+            # forward of all N critics + loss gradient + backward-data: ONE launch
+            H = arena.hidden
+            h1 = ws.get(tag + ".h1", (N, B, H))
+            h2 = ws.get(tag + ".h2", (N, B, H))
+            q = ws.get(tag + ".y", (N, B, qd))
+            dz2 = ws.get(tag + ".dz2", (N, B, H))
+            dz1 = ws.get(tag + ".dz1", (N, B, H))
+            tiles = int(lib.ssac_fused_row_tiles(B))
+            parts = ws.get(tag + ".parts", (N * tiles * 2,))
+            with engine._timed("critic_fused"):
+                check(lib.ssac_critic_fwd_bwd_fused(
+                    C.byref(arena.desc()), X.data_ptr(), ldx, B, td.data_ptr(), weight_ptr, a.data_ptr(),
+                    a.stride(0), pp, dopop, float(E * N), h1.data_ptr(), h2.data_ptr(), q.data_ptr(),
+                    dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), st))
+            engine.weight_grads(arena, X, ldx, 0, h1, h2, dq, dz2, dz1, B, adam=adam,
+                                adam_key=("critic", i), grads=grads, sumsq=ss)
+            fused_logs.append((parts, N, tiles, B))
         else:
-            engine.mlp_backward(arena, dq, X, ldx, 0, h1, h2, B, ws, f"cu.c{i}", adam=adam,
-                                adam_key=("critic", i), sumsq=ss)
+            h1, h2, q = engine.mlp_forward(arena, X, ldx, 0, B, ws, tag)
+            check(lib.ssac_critic_loss_bwd(q.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0),
+                                           td.data_ptr(), weight_ptr, pp, dopop, float(E * N),
+                                           dq.data_ptr(), slot.data_ptr(), st))
+            engine.mlp_backward(arena, dq, X, ldx, 0, h1, h2, B, ws, tag, adam=adam,
+                                adam_key=("critic", i), grads=grads, sumsq=ss)
+            fused_logs.append(None)
+        if critic_clip:
+            clip_members.append((arena, ("critic", i), grads, ss))
         member_ss.append(ss)
         rd["td_target"] = td
         replay_dicts.append(rd)
@@ -111,8 +130,20 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
     logs["losses/critic_overall_loss"] = slot[lu.L_CRITIC_LOSS]
     pick = rng.choice(agent.critics)  # same Python-RNG draw as learning.py:135
     k = next(j for j, c in enumerate(agent.critics) if c is pick)
-    check(lib.ssac_group_norms(member_ss[k].data_ptr(), 1, member_ss[k].numel(),
-                               adam.ctl.ptr if critic_clip else 0, slot[lu.L_CRITIC_GN:].data_ptr(), st))
+    clip_ctl = adam.ctl.ptr if critic_clip else 0
+    done_norm = False
+    for j, fl in enumerate(fused_logs):
+        if fl is None:
+            continue
+        parts, n_, tiles_, b_ = fl
+        want = j == k
+        check(lib.ssac_critic_logs(parts.data_ptr(), n_, tiles_, b_, float(E * n_),
+                                   member_ss[k].data_ptr() if want else 0, member_ss[k].numel() if want else 0,
+                                   clip_ctl, slot.data_ptr(), st))
+        done_norm = done_norm or want
+    if not done_norm:
+        check(lib.ssac_group_norms(member_ss[k].data_ptr(), 1, member_ss[k].numel(), clip_ctl,
+                                   slot[lu.L_CRITIC_GN:].data_ptr(), st))
     logs["gradients/critic_random_grad"] = slot[lu.L_CRITIC_GN]
     logs["gradients/encoder_criticloss_grad_norm"] = slot[lu.L_ENC_GN]
     return logs, replay_dicts
@@ -127,11 +158,10 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
     E = agent.ensemble_size
     dev = log_alphas[0].device
     ws = lu.agent_ws(agent, dev)
-    slot = lu.log_block(dev)
+    adam = engine.adam_group(actor_optimizer, dev)
+    slot = lu.log_block(dev, adam)
     logs = {}
     st = engine.stream()
-    adam = engine.adam_group(actor_optimizer, dev)
-    adam.advance()
     inv_e = 1.0 / len(agent.actors)
     clip_members, member_ss = [], []
     for i, ((actor, critic), popart, log_alpha) in enumerate(zip(agent.ensemble, agent.popart, log_alphas)):

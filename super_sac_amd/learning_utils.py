@@ -34,21 +34,34 @@ class LogRing:
         self.buf = torch.zeros(slots, LOG_WIDTH, dtype=torch.float32, device=device)
         self.k = 0
 
-    def next(self):
+    def next(self, adam=None):
+        """fresh zeroed block; the same launch advances `adam`'s step when given."""
         self.k = (self.k + 1) % self.buf.shape[0]
         blk = self.buf[self.k]
-        check(lib.ssac_zero(blk.data_ptr(), LOG_WIDTH, engine.stream()))
+        check(lib.ssac_begin_update(blk.data_ptr(), LOG_WIDTH, 0 if adam is None else adam.ctl.ptr,
+                                    engine.stream()))
         return blk
 
 
 _rings = {}
 
 
-def log_block(device):
+def log_block(device, adam=None):
     ring = _rings.get(device)
     if ring is None:
         ring = _rings[device] = LogRing(device)
-    return ring.next()
+    return ring.next(adam)
+
+
+_ones = {}
+
+
+def unit_weight(device):
+    """imp_weights of the uniform path: torch.ones(1) (learning_utils.py:180), allocated once."""
+    t = _ones.get(device)
+    if t is None:
+        t = _ones[device] = torch.ones(1, device=device)
+    return t
 
 
 def agent_ws(agent, device):
@@ -121,7 +134,7 @@ def sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, per=True):
     idx_cpu, idx = buffer.draw_uniform_indices(batch_size)
     st = buffer._storage
     dev = st.device
-    imp_weights = torch.ones(1, device=dev)
+    imp_weights = unit_weight(dev)
     B = batch_size
     keys = list(st.s_stack.keys())
     A = int(np.prod(st.action_stack.shape[1:]))
@@ -231,7 +244,10 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
     s1_rep = encode(target_agent.encoder, o1)
     S = s1_rep.shape[1]
     a_arena = engine.bind_arena(actor, "self", [actor], dev)
-    _, _, aout = engine.mlp_forward(a_arena, s1_rep, _row_stride(s1_rep), 0, B, ws, f"td.a{i}")
+    fuse_sample = kind == "stochastic" and a_arena.fused and random_process is None
+    if not fuse_sample:
+        _, _, aout = engine.mlp_forward(a_arena, s1_rep, _row_stride(s1_rep), 0, B, ws, f"td.a{i}",
+                                        save=False)
     t_arena = target_agent.critics[i].arena(dev)
     N = t_arena.n_nets
     assert 0 < ensemble_n <= N
@@ -242,7 +258,7 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
         ids = rng.draw_subset(N, ensemble_n)
         ids_dev = _upload_ids(ws, ids, dev, "sub")
         _, _, q1 = engine.mlp_forward(t_arena, s1_rep, _row_stride(s1_rep), 0, B, ws, f"td.c{i}",
-                                      net_ids=ids_dev, n_sel=ensemble_n)
+                                      net_ids=ids_dev, n_sel=ensemble_n, save=False)
         lp_ptr, qd = aout.data_ptr(), t_arena.out_dim
         a_s1 = None
     else:
@@ -252,12 +268,19 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
         else:
             x1 = _concat_buffer(ws, f"td.x1.{i}", s1_rep, A)
         if kind == "stochastic":
-            eps = rng.draw_normal((B, A), dev)
-            check(lib.ssac_tanh_normal_fwd(aout.data_ptr(), 2 * A, eps.data_ptr(), B, A,
-                                           float(actor.log_std_low), float(actor.log_std_high),
-                                           x1.data_ptr(), S + A, S, logp.data_ptr(), st))
             if random_process is not None:
                 raise NotImplementedError("exploration noise on a stochastic actor")
+            eps = rng.draw_normal((B, A), dev)
+            if fuse_sample:
+                # actor forward + sample + log pi: ONE launch, a' lands in the [s'|a'] buffer
+                check(lib.ssac_actor_sample_fused(C.byref(a_arena.desc()), s1_rep.data_ptr(),
+                                                  _row_stride(s1_rep), B, eps.data_ptr(),
+                                                  float(actor.log_std_low), float(actor.log_std_high),
+                                                  x1.data_ptr(), S + A, S, logp.data_ptr(), 0, 0, 0, st))
+            else:
+                check(lib.ssac_tanh_normal_fwd(aout.data_ptr(), 2 * A, eps.data_ptr(), B, A,
+                                               float(actor.log_std_low), float(actor.log_std_high),
+                                               x1.data_ptr(), S + A, S, logp.data_ptr(), st))
             use_entropy = 1
         else:
             noise = None
@@ -273,7 +296,7 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
         ids = rng.draw_subset(N, ensemble_n)
         ids_dev = _upload_ids(ws, ids, dev, "sub")
         _, _, q1 = engine.mlp_forward(t_arena, x1, S + A, 0, B, ws, f"td.c{i}", net_ids=ids_dev,
-                                      n_sel=ensemble_n)
+                                      n_sel=ensemble_n, save=False)
         lp_ptr, qd = logp.data_ptr(), 1
         a_s1 = x1[:, S:]
     td = torch.empty(B, 1, device=dev)

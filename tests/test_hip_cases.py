@@ -15,11 +15,19 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
 @pytest.mark.parametrize("name", list(synth.CASES))
-def test_engine_matches_reference(name):
-    rec = case_runner.run_engine(name)
+def test_engine_matches_reference(name, fused):
+    """both kernel families: the one-launch fused MLP kernels and the per-layer GEMM path."""
+    import super_sac_amd as ssa
+    old = ssa.engine.USE_FUSED
+    ssa.engine.USE_FUSED = fused
+    try:
+        rec = case_runner.run_engine(name)
+    finally:
+        ssa.engine.USE_FUSED = old
     fx = case_runner.load_fixture(name)
-    worst = case_runner.compare(rec, fx, who=f"hip[{name}]")
+    worst = case_runner.compare(rec, fx, who=f"hip[{name},{'fused' if fused else 'per-layer'}]")
     print(f"{name}: worst deviations vs reference {worst}")
 
 

@@ -99,6 +99,88 @@ def test_ensemble_q_known_answers_from_reference(ssa):
     _close(q[:, :, 0], torch.from_numpy(f["ensq_q"]), 5e-5, what="ensemble Q")
 
 
+@pytest.mark.parametrize("B,in_dim,H,out,N", [(512, 23, 256, 1, 10), (100, 17, 64, 12, 1), (77, 393, 96, 1, 3),
+                                              (33, 128, 256, 4, 2), (1, 5, 32, 3, 2)])
+def test_fused_forward_equals_per_layer_and_oracle(ssa, B, in_dim, H, out, N):
+    rng = np.random.RandomState(B + in_dim + 1)
+    mlps = [orc.make_mlp(rng, in_dim, H, out) for _ in range(N)]
+    x = torch.from_numpy(rng.standard_normal((B, in_dim)).astype(np.float32))
+    ar = _arena_from(ssa, mlps)
+    assert ar.fused, "shape should be eligible for the fused kernels"
+    ws = ssa.engine.Workspace(torch.device(DEV))
+    xd = x.to(DEV)
+    h1, h2, y = ssa.engine.mlp_forward(ar, xd, in_dim, 0, B, ws, "f")
+    ar.fused = False
+    g1, g2, z = ssa.engine.mlp_forward(ar, xd, in_dim, 0, B, ws, "p")
+    _close(h1, g1, 1e-5, what="h1 fused vs per-layer")
+    _close(h2, g2, 2e-5, what="h2 fused vs per-layer")
+    _close(y, z, 5e-5, what="y fused vs per-layer")
+    for j, p in enumerate(mlps):
+        _close(y[j], orc.mlp3(p, x)[0], 5e-5, what=f"y[{j}] vs oracle")
+
+
+def test_fused_actor_sample(ssa):
+    rng = np.random.RandomState(41)
+    B, S, A, H = 200, 17, 6, 256
+    actor = orc.make_mlp(rng, S, H, 2 * A)
+    x1 = torch.from_numpy(rng.standard_normal((B, S + A)).astype(np.float32))
+    eps = torch.from_numpy(rng.standard_normal((B, A)).astype(np.float32))
+    a_ref, lp_ref = orc.tanh_normal_sample(orc.mlp3(actor, x1[:, :S])[0], -5.0, 2.0, eps)
+    ar = _arena_from(ssa, [actor])
+    xd, ed = x1.to(DEV), eps.to(DEV)
+    logp = torch.zeros(B, device=DEV)
+    ssa._lib.check(ssa._lib.lib.ssac_actor_sample_fused(C.byref(ar.desc()), xd.data_ptr(), S + A, B,
+                                                        ed.data_ptr(), -5.0, 2.0, xd.data_ptr(), S + A, S,
+                                                        logp.data_ptr(), 0, 0, 0, ssa.engine.stream()))
+    _close(xd[:, S:], a_ref, 2e-5, what="a'")
+    _close(logp, lp_ref[:, 0], 5e-4, rtol=2e-5, what="log pi")
+    assert torch.equal(xd[:, :S].cpu(), x1[:, :S]), "state columns must be untouched"
+
+
+@pytest.mark.parametrize("qd,B,H,N", [(1, 512, 256, 10), (4, 70, 64, 2)])
+def test_fused_critic_fwd_bwd_matches_autograd(ssa, qd, B, H, N):
+    rng = np.random.RandomState(42 + qd)
+    in_dim = 23 if qd == 1 else 9
+    mlps = [orc.make_mlp(rng, in_dim, H, qd) for _ in range(N)]
+    x = torch.from_numpy(rng.standard_normal((B, in_dim)).astype(np.float32))
+    td = torch.from_numpy(rng.standard_normal((B, 1)).astype(np.float32))
+    w = torch.from_numpy(rng.uniform(0.5, 1.5, (B, 1)).astype(np.float32))
+    act = torch.from_numpy(rng.randint(0, qd, (B, 1)).astype(np.float32))
+    ps = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in mlps]
+    loss = 0.0
+    for p in ps:
+        q = orc.mlp3(p, x)[0]
+        qs = q if qd == 1 else q.gather(-1, act.long())
+        loss = loss + (w * (td - qs) ** 2).mean()
+    loss = loss / N
+    loss.backward()
+    ar = _arena_from(ssa, mlps)
+    dev = torch.device(DEV)
+    ws = ssa.engine.Workspace(dev)
+    xd, tdd, wd, ad = x.to(DEV), td.to(DEV), w.to(DEV), act.to(DEV)
+    h1 = torch.zeros(N, B, H, device=DEV); h2 = torch.zeros_like(h1); dz2 = torch.zeros_like(h1); dz1 = torch.zeros_like(h1)
+    q = torch.zeros(N, B, qd, device=DEV); dq = torch.zeros_like(q)
+    tiles = int(ssa._lib.lib.ssac_fused_row_tiles(B))
+    parts = torch.zeros(N * tiles * 2, device=DEV)
+    ssa._lib.check(ssa._lib.lib.ssac_critic_fwd_bwd_fused(
+        C.byref(ar.desc()), xd.data_ptr(), in_dim, B, tdd.data_ptr(), wd.data_ptr(), ad.data_ptr(), 1, 0, 0,
+        float(N), h1.data_ptr(), h2.data_ptr(), q.data_ptr(), dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(),
+        parts.data_ptr(), ssa.engine.stream()))
+    grads = torch.zeros_like(ar.params)
+    ss = torch.zeros(N * ssa.engine.wgrad_tiles_total(ar), device=DEV)
+    ssa.engine.weight_grads(ar, xd, in_dim, 0, h1, h2, dq, dz2, dz1, B, grads=grads, sumsq=ss)
+    logs = torch.zeros(4, device=DEV)
+    ssa._lib.check(ssa._lib.lib.ssac_critic_logs(parts.data_ptr(), N, tiles, B, float(N), ss.data_ptr(),
+                                                 ss.numel(), 0, logs.data_ptr(), ssa.engine.stream()))
+    assert abs(float(logs[0]) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
+    gsq = 0.0
+    for j in range(N):
+        for seg in ssa.engine.SEGS:
+            _close(ar.view(j, seg, grads), ps[j][seg].grad, 3e-6, rtol=1e-4, what=f"grad {seg}[{j}]")
+            gsq += float((ps[j][seg].grad.double() ** 2).sum())
+    assert abs(float(logs[2]) - math.sqrt(gsq)) <= 1e-4 * math.sqrt(gsq)
+
+
 # --------------------------------------------------------------------- backward + Adam
 def _autograd_reference(mlps, x, dy):
     ps = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in mlps]

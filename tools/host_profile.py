@@ -1,0 +1,31 @@
+"""Where does the host time of one critic_update go?  (run on the GPU box)"""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+
+step, ssa = bench.build_engine(torch.device("cuda", 0), bench.NCRIT)
+for _ in range(100):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(500):
+    step()
+t_host = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t0
+print(f"host enqueue {1e6*t_host/500:.1f} us/step, wall {1e6*t_all/500:.1f} us/step")
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(300):
+    step()
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(28)

@@ -140,6 +140,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)  # (the single-GPU smoke test of the N>1 path runs 2 ranks on 1 device)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
@@ -148,7 +150,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("SSAC_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
         from super_sac_amd import parallel
         shard = parallel.Shard(rank, world, NCRIT)
         n_local = shard.n_local

@@ -180,10 +180,12 @@ int ssac_critic_loss_bwd(const float *q, int n_nets, int n_rows, int q_dim, cons
 /* ---- actor loss gradient, continuous: learning.py:392-408.
  * q (n_nets x n_rows): min over ALL nets (learning.py:402), arg-min routing.
  * dq[j][b] = -(popart_w) / (n_rows*E) for j = argmin_b else 0;  logs[0] += -mean(minq' - bonus)/E,
- * bonus = exp(log_alpha)*logp when use_entropy. */
+ * bonus = exp(log_alpha)*logp when use_entropy.  qmin_global (nullable): when the ensemble is sharded
+ * across ranks, the all-reduced min over ALL critics; the gradient is routed only where the local min
+ * equals it. */
 int ssac_actor_loss_bwd(const float *q, int n_nets, int n_rows, const float *logp,
                         const float *log_alpha, int use_entropy, const ssac_popart *popart, int pop,
-                        float inv_members, float *dq, float *logs, void *stream);
+                        float inv_members, const float *qmin_global, float *dq, float *logs, void *stream);
 
 /* ---- backward of the tanh-normal head: given dL/da summed from the critics' input
  * gradients dX (n_nets x n_rows x ldx, action columns start at act_col0) and the entropy

@@ -28,3 +28,4 @@ from . import agent  # noqa: E402,F401
 from .agent import Agent  # noqa: E402,F401
 from . import learning_utils  # noqa: E402,F401
 from . import learning  # noqa: E402,F401
+from . import parallel  # noqa: E402,F401

@@ -321,7 +321,8 @@ __global__ __launch_bounds__(RED_THREADS) void critic_loss_bwd_kernel(
 __global__ __launch_bounds__(RED_THREADS) void actor_loss_bwd_kernel(
     const float *__restrict__ q, int n_nets, int n_rows, const float *__restrict__ logp,
     const float *__restrict__ log_alpha, int use_entropy, const ssac_popart *popart, int pop,
-    float inv_members, float *__restrict__ dq, float *__restrict__ logs) {
+    float inv_members, const float *__restrict__ qmin_global, float *__restrict__ dq,
+    float *__restrict__ logs) {
     __shared__ float scratch[16];
     const float pw = (popart && pop) ? popart->w : 1.0f;
     const float pb = (popart && pop) ? popart->b : 0.0f;
@@ -334,6 +335,13 @@ __global__ __launch_bounds__(RED_THREADS) void actor_loss_bwd_kernel(
         for (int j = 1; j < n_nets; ++j) {
             const float v = q[(int64_t)j * n_rows + b];
             if (v < mq) { mq = v; am = j; }
+        }
+        if (qmin_global) {
+            // sharded ensemble: the min over ALL critics came from an all-reduce; the gradient is
+            // routed only on the rank whose local min IS the global min
+            const bool mine = mq == qmin_global[b];
+            mq = qmin_global[b];
+            if (!mine) am = -1;
         }
         for (int j = 0; j < n_nets; ++j) dq[(int64_t)j * n_rows + b] = (j == am) ? gq : 0.0f;
         const float bonus = use_entropy ? alpha * logp[b] : 0.0f;
@@ -690,10 +698,11 @@ extern "C" int ssac_critic_loss_bwd(const float *q, int n_nets, int n_rows, int 
 
 extern "C" int ssac_actor_loss_bwd(const float *q, int n_nets, int n_rows, const float *logp,
                                    const float *log_alpha, int use_entropy, const ssac_popart *popart,
-                                   int pop, float inv_members, float *dq, float *logs, void *stream) {
+                                   int pop, float inv_members, const float *qmin_global, float *dq,
+                                   float *logs, void *stream) {
     if (n_nets < 1 || n_rows < 1) return ssac_fail("ssac_actor_loss_bwd: bad sizes");
     hipLaunchKernelGGL(actor_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_nets, n_rows, logp,
-                       log_alpha, use_entropy, popart, pop, inv_members, dq, logs);
+                       log_alpha, use_entropy, popart, pop, inv_members, qmin_global, dq, logs);
     return ssac_check_launch("actor_loss_bwd");
 }
 

@@ -11,7 +11,7 @@ import ctypes as C
 
 import torch
 
-from . import engine, rng
+from . import engine, parallel, rng
 from . import learning_utils as lu
 from ._lib import check, lib
 
@@ -80,6 +80,8 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
         s_rep = lu.encode(agent.encoder, o)
         arena = agent.critics[i].arena(dev)
         N, qd = arena.n_nets, arena.out_dim
+        shard = parallel.shard_of(agent)
+        n_glob = N if shard is None else shard.num_critics  # loss is averaged over the GLOBAL ensemble
         X, ldx = _critic_input(rd.get("_ssac"), ws, f"cu.x{i}", s_rep, a, discrete)
         popart = agent.popart[i]
         weight_ptr = 0
@@ -104,15 +106,15 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
             with engine._timed("critic_fused"):
                 check(lib.ssac_critic_fwd_bwd_fused(
                     C.byref(arena.desc()), X.data_ptr(), ldx, B, td.data_ptr(), weight_ptr, a.data_ptr(),
-                    a.stride(0), pp, dopop, float(E * N), h1.data_ptr(), h2.data_ptr(), q.data_ptr(),
+                    a.stride(0), pp, dopop, float(E * n_glob), h1.data_ptr(), h2.data_ptr(), q.data_ptr(),
                     dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), st))
             engine.weight_grads(arena, X, ldx, 0, h1, h2, dq, dz2, dz1, B, adam=adam,
                                 adam_key=("critic", i), grads=grads, sumsq=ss)
-            fused_logs.append((parts, N, tiles, B))
+            fused_logs.append((parts, N, tiles, B, n_glob))
         else:
             h1, h2, q = engine.mlp_forward(arena, X, ldx, 0, B, ws, tag)
             check(lib.ssac_critic_loss_bwd(q.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0),
-                                           td.data_ptr(), weight_ptr, pp, dopop, float(E * N),
+                                           td.data_ptr(), weight_ptr, pp, dopop, float(E * n_glob),
                                            dq.data_ptr(), slot.data_ptr(), st))
             engine.mlp_backward(arena, dq, X, ldx, 0, h1, h2, B, ws, tag, adam=adam,
                                 adam_key=("critic", i), grads=grads, sumsq=ss)
@@ -135,9 +137,9 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
     for j, fl in enumerate(fused_logs):
         if fl is None:
             continue
-        parts, n_, tiles_, b_ = fl
+        parts, n_, tiles_, b_, ng_ = fl
         want = j == k
-        check(lib.ssac_critic_logs(parts.data_ptr(), n_, tiles_, b_, float(E * n_),
+        check(lib.ssac_critic_logs(parts.data_ptr(), n_, tiles_, b_, float(E * ng_),
                                    member_ss[k].data_ptr() if want else 0, member_ss[k].numel() if want else 0,
                                    clip_ctl, slot.data_ptr(), st))
         done_norm = done_norm or want
@@ -180,9 +182,15 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
         ah1, ah2, aout = engine.mlp_forward(a_arena, s_rep, lds, 0, B, ws, f"au.a{i}")
         kind = lu.actor_kind(actor)
         pp, dopop = (popart.ptr if popart else 0), (1 if (popart and pop) else 0)
+        shard = parallel.shard_of(agent)
         if kind == "discrete":
             A = a_arena.out_dim
-            _, _, q = engine.mlp_forward(c_arena, s_rep, lds, 0, B, ws, f"au.c{i}")
+            _, _, q = engine.mlp_forward(c_arena, s_rep, lds, 0, B, ws, f"au.c{i}", save=False)
+            if shard is not None:  # elementwise min over the local critics, then over the ranks
+                qm = ws.get(f"au.qmin{i}", (1, B, A))
+                lu._min_over_nets(q, N, B * A, qm)
+                parallel.all_reduce_min(qm)
+                q, N = qm, 1
             d_out = ws.get(f"au.dout{i}", (1, B, A))
             check(lib.ssac_discrete_actor_loss_bwd(aout.data_ptr(), q.data_ptr(), N, B, A,
                                                    log_alpha.data_ptr(), pp, dopop, inv_e,
@@ -210,20 +218,32 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
                 use_entropy = 0
             ch1, ch2, q = engine.mlp_forward(c_arena, xpi, S + A, 0, B, ws, f"au.c{i}")
             dq = ws.get(f"au.dq{i}", (N, B, 1))
+            qmin_ptr = 0
+            if shard is not None:  # min over ALL critics: local min, then MIN all-reduce over ranks
+                qmin = ws.get(f"au.qmin{i}", (B,))
+                lu._min_over_nets(q, N, B, qmin)
+                parallel.all_reduce_min(qmin)
+                qmin_ptr = qmin.data_ptr()
             check(lib.ssac_actor_loss_bwd(q.data_ptr(), N, B, logp.data_ptr(), log_alpha.data_ptr(),
-                                          use_entropy, pp, dopop, inv_e, dq.data_ptr(),
+                                          use_entropy, pp, dopop, inv_e, qmin_ptr, dq.data_ptr(),
                                           slot[lu.L_ACTOR_LOSS:].data_ptr(), st))
             # dQ/da through the arg-min critic of every row; critic weights are NOT updated here
             dX = engine.mlp_backward(c_arena, dq, xpi, S + A, 0, ch1, ch2, B, ws, f"au.c{i}",
                                      need_dx=True, update=False)
+            n_dx, ld_dx, s_dx, col_dx = N, S + A, B * (S + A), S
+            if shard is not None:  # SUM all-reduce of the (B x A) action gradient
+                da = ws.get(f"au.da{i}", (1, B, A))
+                torch.sum(dX[:, :, S:], dim=0, out=da[0])
+                parallel.all_reduce_sum(da)
+                dX, n_dx, ld_dx, s_dx, col_dx = da, 1, A, B * A, 0
             d_out = ws.get(f"au.dout{i}", (1, B, a_arena.out_dim))
             if kind == "stochastic":
-                check(lib.ssac_tanh_normal_bwd(dX.data_ptr(), N, S + A, B * (S + A), S, aout.data_ptr(),
+                check(lib.ssac_tanh_normal_bwd(dX.data_ptr(), n_dx, ld_dx, s_dx, col_dx, aout.data_ptr(),
                                                2 * A, eps.data_ptr(), B, A, float(actor.log_std_low),
                                                float(actor.log_std_high), log_alpha.data_ptr(), 1, inv_e,
                                                d_out.data_ptr(), 2 * A, st))
             else:
-                check(lib.ssac_det_action_bwd(dX.data_ptr(), N, S + A, B * (S + A), S, aout.data_ptr(), A,
+                check(lib.ssac_det_action_bwd(dX.data_ptr(), n_dx, ld_dx, s_dx, col_dx, aout.data_ptr(), A,
                                               B, A, d_out.data_ptr(), A, st))
         ttot = engine.wgrad_tiles_total(a_arena)
         ss = ws.get(f"au.ss{i}", (ttot,))

@@ -249,16 +249,16 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
         _, _, aout = engine.mlp_forward(a_arena, s1_rep, _row_stride(s1_rep), 0, B, ws, f"td.a{i}",
                                         save=False)
     t_arena = target_agent.critics[i].arena(dev)
-    N = t_arena.n_nets
+    from . import parallel
+    shard = parallel.shard_of(target_agent)
+    N = t_arena.n_nets if shard is None else shard.num_critics  # the subset is drawn over the GLOBAL ensemble
     assert 0 < ensemble_n <= N
     bt = replay_dict.get("_ssac")
     logp = ws.get(f"td.logp{i}", (B,))
     use_entropy = 0
     if kind == "discrete":
         ids = rng.draw_subset(N, ensemble_n)
-        ids_dev = _upload_ids(ws, ids, dev, "sub")
-        _, _, q1 = engine.mlp_forward(t_arena, s1_rep, _row_stride(s1_rep), 0, B, ws, f"td.c{i}",
-                                      net_ids=ids_dev, n_sel=ensemble_n, save=False)
+        q1, n_q = _subset_q(ws, shard, t_arena, ids, s1_rep, _row_stride(s1_rep), B, dev, f"td.c{i}")
         lp_ptr, qd = aout.data_ptr(), t_arena.out_dim
         a_s1 = None
     else:
@@ -294,13 +294,11 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
                                           float(noise_clip) if noise_clip is not None else 0.0, B, A,
                                           x1.data_ptr(), S + A, S, st))
         ids = rng.draw_subset(N, ensemble_n)
-        ids_dev = _upload_ids(ws, ids, dev, "sub")
-        _, _, q1 = engine.mlp_forward(t_arena, x1, S + A, 0, B, ws, f"td.c{i}", net_ids=ids_dev,
-                                      n_sel=ensemble_n, save=False)
+        q1, n_q = _subset_q(ws, shard, t_arena, ids, x1, S + A, B, dev, f"td.c{i}")
         lp_ptr, qd = logp.data_ptr(), 1
         a_s1 = x1[:, S:]
     td = torch.empty(B, 1, device=dev)
-    check(lib.ssac_td_target(q1.data_ptr(), ensemble_n, B, qd, lp_ptr, r.data_ptr(), d.data_ptr(),
+    check(lib.ssac_td_target(q1.data_ptr(), n_q, B, qd, lp_ptr, r.data_ptr(), d.data_ptr(),
                              log_alpha.data_ptr(), use_entropy, float(gamma),
                              popart.ptr if popart else 0, 1 if (popart and pop) else 0,
                              td.data_ptr(), slot[L_TD0 + 3 * i:].data_ptr(), st))
@@ -311,6 +309,30 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
     if kind == "discrete":
         a_s1 = aout[0]  # logits; the reference returns probs here, only used by dr3
     return td, (s1_rep, a_s1)
+
+
+def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag):
+    """target-critic outputs for the REDQ subset `ids`: (q, n) with q of shape (n, B, out).
+    Sharded: forward of the locally owned subset members, elementwise min, MIN all-reduce of the
+    (B x out) partial (the one real exchange step of the critic update), n = 1."""
+    if shard is None:
+        ids_dev = _upload_ids(ws, ids, dev, "sub")
+        _, _, q1 = engine.mlp_forward(t_arena, X, ldx, 0, B, ws, tag, net_ids=ids_dev, n_sel=len(ids),
+                                      save=False)
+        return q1, len(ids)
+    from . import parallel
+    local = shard.local_subset(ids)
+    O = t_arena.out_dim
+    qpart = ws.get(tag + ".qpart", (1, B, O))
+    if local:
+        ids_dev = _upload_ids(ws, local, dev, f"sub{len(local)}")
+        _, _, q1 = engine.mlp_forward(t_arena, X, ldx, 0, B, ws, tag, net_ids=ids_dev, n_sel=len(local),
+                                      save=False)
+        _min_over_nets(q1, len(local), B * O, qpart)
+    else:
+        qpart.fill_(float("inf"))
+    parallel.all_reduce_min(qpart)
+    return qpart, 1
 
 
 def compute_backup_weights(logs, replay_dict, agent, target_agent, weight_type, weight_temp, batch_size,

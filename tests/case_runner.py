@@ -153,17 +153,20 @@ class DrawPlayer:
         m.draw_indices, m.draw_subset, m.draw_normal = self._saved
 
 
-def build_engine_agent(cfg, device):
-    """super_sac_amd.Agent holding the same seeded weights as the oracle agent."""
+def build_engine_agent(cfg, device, shard=None):
+    """super_sac_amd.Agent holding the same seeded weights as the oracle agent (with `shard`: only
+    the critics [shard.lo, shard.hi) of the global ensemble)."""
     import super_sac_amd as ssa
     oa = _oracle_agent(cfg)
+    lo = 0 if shard is None else shard.lo
+    n_loc = cfg["N"] if shard is None else shard.n_local
     actor_cls = {"stochastic": ssa.nets.ContinuousStochasticActor,
                  "deterministic": ssa.nets.ContinuousDeterministicActor,
                  "discrete": ssa.nets.DiscreteActor}[cfg["actor"]]
     critic_cls = ssa.nets.DiscreteCritic if cfg["discrete"] else ssa.nets.ContinuousCritic
     ag = ssa.Agent(act_space_size=cfg["act"], encoder=ssa.nets.IdentityEncoder(cfg["obs"]),
                    actor_network_cls=actor_cls, critic_network_cls=critic_cls, discrete=cfg["discrete"],
-                   ensemble_size=cfg["E"], num_critics=cfg["N"], ucb_bonus=0.0,
+                   ensemble_size=cfg["E"], num_critics=n_loc, ucb_bonus=0.0,
                    hidden_size=cfg["hidden"], auto_rescale_targets=cfg["popart"],
                    log_std_low=cfg["lo"], log_std_high=cfg["hi"])
     head = {"stochastic": "fc3", "deterministic": "out", "discrete": "act_p"}[cfg["actor"]]
@@ -175,8 +178,8 @@ def build_engine_agent(cfg, device):
                 getattr(mod, nm).bias.copy_(p[bk])
     for i in range(cfg["E"]):
         load(ag.actors[i], oa.actors[i], ("fc1", "fc2", head))
-        for j in range(cfg["N"]):
-            load(ag.critics[i].nets[j], oa.critics[i][j], ("fc1", "fc2", "out"))
+        for j in range(n_loc):
+            load(ag.critics[i].nets[j], oa.critics[i][lo + j], ("fc1", "fc2", "out"))
     ag.to(device)
     if cfg["popart"]:
         for p in ag.popart:
@@ -185,7 +188,9 @@ def build_engine_agent(cfg, device):
     return ag
 
 
-def run_engine(name, device="cuda"):
+def run_engine(name, device="cuda", shard=None):
+    """`shard` (super_sac_amd.parallel.Shard): run as one rank of a critic-sharded job; the record
+    then holds this rank's critics only (see slice_fixture)."""
     import super_sac_amd as ssa
     cfg = synth.CASES[name]
     fx = load_fixture(name)
@@ -193,8 +198,12 @@ def run_engine(name, device="cuda"):
     device = torch.device(device)
     buf = ssa.replay.ReplayBuffer(cfg["cap"], device=device)
     buf.load_experience(*_buffers(cfg))
-    agent = build_engine_agent(cfg, device)
+    agent = build_engine_agent(cfg, device, shard)
     target = copy.deepcopy(agent)
+    if shard is not None:
+        ssa.parallel.install(agent, target, shard)
+        fx = slice_fixture(fx, cfg, shard)
+    NL = agent.num_critics
     copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=cfg["lr"],
                             weight_decay=0, betas=(0.9, 0.999))
     aopt = torch.optim.Adam(chain(*(a.parameters() for a in agent.actors)), lr=cfg["lr"],
@@ -275,20 +284,43 @@ def run_engine(name, device="cuda"):
         assert not player.idx and not player.sub and not player.normal, "unconsumed recorded draws"
     finally:
         player.restore()
-    crit = [p for i in range(E) for j in range(cfg["N"]) for p in agent.critics[i].nets[j].parameters()]
-    tcrit = [p for i in range(E) for j in range(cfg["N"]) for p in target.critics[i].nets[j].parameters()]
+    crit = [p for i in range(E) for j in range(NL) for p in agent.critics[i].nets[j].parameters()]
+    tcrit = [p for i in range(E) for j in range(NL) for p in target.critics[i].nets[j].parameters()]
     act = [p for i in range(E) for p in agent.actors[i].parameters()]
     grp = copt._ssac_adam
     m_list, v_list = [], []
     for i in range(E):
         ar = agent.critics[i].arena(device)
         m, v = grp.moments_for(("critic", i), ar.params)
-        for j in range(cfg["N"]):
+        for j in range(NL):
             for seg in ("w1", "b1", "w2", "b2", "w3", "b3"):
                 m_list.append(ar.view(j, seg, m))
                 v_list.append(ar.view(j, seg, v))
     _finalise(rec, fx, crit, act, tcrit, m_list, v_list, las)
     return rec
+
+
+def slice_fixture(fx, cfg, shard):
+    """the part of a (single-member, full-dump) fixture that rank `shard` can reproduce: its own
+    critics' parameters/moments; TD targets, actor parameters and temperature are global."""
+    assert cfg["E"] == 1 and "final_critic" in fx, "sharded replays use the small full-dump fixtures"
+    out = dict(fx)
+    in_dim = cfg["obs"] if cfg["discrete"] else cfg["obs"] + cfg["act"]
+    out_dim = cfg["act"] if cfg["discrete"] else 1
+    H = cfg["hidden"]
+    per = H * in_dim + H + H * H + H + out_dim * H + out_dim
+    for key in ("final_critic", "final_target_critic"):
+        out[key] = fx[key][shard.lo * per: shard.hi * per]
+    sizes = [H * in_dim, H, H * H, H, out_dim * H, out_dim]
+    fpn = [min(48, n) for n in sizes]
+    perfp = sum(fpn)
+    for key in ("finalfp_critic_m", "finalfp_critic_v"):
+        out[key] = fx[key][shard.lo * perfp: shard.hi * perfp]
+    # the critic-loss / td-error / grad-norm logs are per-rank partial sums in a sharded run
+    for key in list(out):
+        if "_log:losses/critic" in key or "_log:losses/last_member" in key or "_log:gradients/" in key:
+            del out[key]
+    return out
 
 
 # ------------------------------------------------------------------------------------------

@@ -487,7 +487,7 @@ def test_actor_loss_bwd_routes_to_argmin(ssa):
     dq = torch.zeros(N, B, device=DEV)
     logs = torch.zeros(2, device=DEV)
     ssa._lib.check(ssa._lib.lib.ssac_actor_loss_bwd(D(q), N, B, D(logp),
-                                                    D(la), 1, 0, 0, 0.5, dq.data_ptr(),
+                                                    D(la), 1, 0, 0, 0.5, 0, dq.data_ptr(),
                                                     logs.data_ptr(), ssa.engine.stream()))
     _close(dq, qq.grad, 1e-8, what="dq")
     assert abs(float(logs[0]) - float(loss)) < 1e-5

@@ -1,0 +1,126 @@
+"""CPU, world_size 2, gloo: the critic-sharded update (super_sac_amd.parallel) is the same
+computation as the unsharded one.
+
+No GPU here, so the per-shard arithmetic is done by the oracle; what is under test is the
+product's host logic for N > 1 ranks -- the shard ownership map, the "draw the REDQ subset over
+the GLOBAL ensemble, evaluate the locally owned members, MIN all-reduce the partial" protocol
+(+inf when a rank owns none), the global loss denominator -- over a real collective.
+The GPU counterpart (same protocol on the HIP kernels) is tests/test_hip_sharded.py.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _sharded_critic_sequence(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    import case_runner  # noqa: F401  (sets sys.path)
+    import ssac_oracle as orc
+    import synth
+    from super_sac_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    cfg = synth.CASES["redq_small"]
+    fx = case_runner.load_fixture("redq_small")
+    shard = parallel.Shard(rank, world, cfg["N"])
+    full = case_runner._oracle_agent(cfg).requires_grad_(True)
+    target = full.clone()
+    buf = orc.ReplayOracle(cfg["cap"])
+    buf.load_experience(*case_runner._buffers(cfg))
+    mine = [full.critics[0][j] for j in range(shard.lo, shard.hi)]
+    tmine = [target.critics[0][j] for j in range(shard.lo, shard.hi)]
+    opt = orc.AdamOracle([p[k] for p in mine for k in orc.MLP_KEYS], lr=cfg["lr"])
+    la = torch.tensor([np.log(cfg["init_alpha"])], dtype=torch.float32)
+    B = cfg["B"]
+    tds = []
+    for upd in range(int(fx["n_updates"])):
+        o, a, r, o1, d = buf.gather(fx[f"u{upd}_idx0"])
+        ids = [int(v) for v in fx[f"u{upd}_subset0"]]
+        with torch.no_grad():
+            a1, logp = orc.tanh_normal_sample(orc.mlp3(full.actors[0], o1["obs"])[0], cfg["lo"], cfg["hi"],
+                                              torch.from_numpy(fx[f"u{upd}_eps0"]))
+            local = shard.local_subset(ids)
+            if local:
+                part = torch.stack([orc.critic_q(tmine[j], o1["obs"], a1) for j in local], 0).min(0).values
+            else:
+                part = torch.full((B, 1), float("inf"))
+            parallel.all_reduce_min(part)  # the exchange step
+            td = r + cfg["gamma"] * (1.0 - d) * (part - la.exp() * logp)
+        tds.append(td.numpy())
+        loss = 0.0
+        for p in mine:
+            loss = loss + ((td - orc.critic_q(p, o["obs"], a)) ** 2).mean()
+        loss = loss / cfg["N"]  # GLOBAL ensemble size in the denominator (learning.py:112)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if int(fx[f"u{upd}_polyak"]):
+            orc.soft_update([p[k] for p in tmine for k in orc.MLP_KEYS],
+                            [p[k] for p in mine for k in orc.MLP_KEYS], cfg["tau"])
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), td=np.stack(tds),
+             params=np.concatenate([p[k].detach().numpy().ravel() for p in mine for k in orc.MLP_KEYS]),
+             lo=shard.lo, hi=shard.hi)
+    dist.destroy_process_group()
+
+
+def _unsharded_reference():
+    import case_runner
+    import ssac_oracle as orc
+    import synth
+    cfg = synth.CASES["redq_small"]
+    fx = case_runner.load_fixture("redq_small")
+    full = case_runner._oracle_agent(cfg).requires_grad_(True)
+    target = full.clone()
+    buf = orc.ReplayOracle(cfg["cap"])
+    buf.load_experience(*case_runner._buffers(cfg))
+    opt = orc.AdamOracle(full.critic_params(), lr=cfg["lr"])
+    eopt = orc.AdamOracle([], lr=1e-4)
+    la = [torch.tensor([np.log(cfg["init_alpha"])], dtype=torch.float32, requires_grad=True)]
+    aug = orc.AugOracle("identity", cfg["B"])
+    tds = []
+    for upd in range(int(fx["n_updates"])):
+        _, dicts = orc.critic_update(buf, full, target, opt, eopt, la, cfg["B"], cfg["gamma"], None, None,
+                                     cfg["n"], None, None, False, aug, idx_list=[fx[f"u{upd}_idx0"]],
+                                     eps_list=[torch.from_numpy(fx[f"u{upd}_eps0"])],
+                                     subset_list=[[int(v) for v in fx[f"u{upd}_subset0"]]])
+        tds.append(dicts[0]["td_target"].numpy())
+        if int(fx[f"u{upd}_polyak"]):
+            orc.soft_update(target.critic_params(), full.critic_params(), cfg["tau"])
+    return np.stack(tds), [np.concatenate([c[k].detach().numpy().ravel() for k in orc.MLP_KEYS])
+                           for c in full.critics[0]]
+
+
+def test_shard_ownership_map():
+    from super_sac_amd.parallel import Shard
+    for n, w in ((10, 1), (10, 2), (10, 4), (10, 8), (16, 8), (3, 2)):
+        owned = []
+        for r in range(w):
+            s = Shard(r, w, n)
+            owned += list(range(s.lo, s.hi))
+            assert s.n_local >= 1 and set(s.local_subset([s.lo, s.hi - 1])) == {0, s.n_local - 1}
+        assert owned == list(range(n)), "every critic has exactly one owner"
+    s = Shard(1, 2, 4)
+    assert s.local_subset([0, 3]) == [1] and s.local_subset([0, 1]) == []
+    with pytest.raises(AssertionError):
+        Shard(0, 8, 4)
+
+
+def test_sharded_critic_updates_equal_unsharded(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_sharded_critic_sequence, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    td_ref, params_ref = _unsharded_reference()
+    for rank in range(world):
+        got = np.load(tmp_path / f"rank{rank}.npz")
+        assert np.allclose(got["td"], td_ref, atol=1e-6), "TD targets after the MIN all-reduce"
+        want = np.concatenate(params_ref[int(got["lo"]):int(got["hi"])])
+        assert np.max(np.abs(got["params"] - want)) < 1e-6, f"rank {rank}: owned critics diverged"

@@ -275,6 +275,40 @@ int ssac_critic_logs(const float *partials, int n_nets, int tiles, int n_rows, f
                      const float *sumsq, int n_sumsq, const ssac_adam_ctl *scale_by_clip, float *logs,
                      void *stream);
 
+/* ==== pixel encoders (nets/cnns.py:37-103): convolution = im2col + GEMM, activations channels-last ====
+ * ssac_im2col: col[(b,oy,ox)][(c,ky,kx)] = float(src[b,c,oy*s+ky,ox*s+kx]) / div + shift, source addressed by
+ * element strides (so NCHW images and channels-last feature maps both work; src_u8 reads uint8).
+ * The nn.Linear over the flattened NCHW feature map is the same gather with k = the whole map. */
+int ssac_im2col(const void *src, int src_u8, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int B, int C,
+                int Hi, int Wi, int k, int stride, float div, float shift, float *col, void *stream);
+/* adjoint of im2col: dx[b,c,y,x] = sum of the dcol entries that read it, times [mask > 0] when mask != NULL
+ * (ReLU backward of the producing layer), destination / mask addressed by element strides. */
+int ssac_col2im(const float *dcol, float *dx, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                const float *mask, int64_t mb, int64_t mc, int64_t my, int64_t mx, int B, int C, int Hi,
+                int Wi, int k, int stride, void *stream);
+/* Y = act(X W^T + b), X (M x K), W (N x K): F.conv2d on patches / nn.Linear (cnns.py:61-66,98-102). */
+int ssac_linear_fwd(const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, float *Y,
+                    int64_t ldy, int M, int N, int K, int relu, void *stream);
+/* dX (M x N_in) = dY (M x K_out) W (K_out x N_in) */
+int ssac_linear_dgrad(const float *dY, int64_t ldy, const float *W, int64_t ldw, float *dX, int64_t ldx,
+                      int M, int N_in, int K_out, void *stream);
+/* split-K weight gradient: slice z covers rows [z*rows_per_slice, ...): partial_w[z] = dY_z^T X_z
+ * (M_out x N_in), partial_b[z] = colsum(dY_z); reduce with ssac_reduce_slices. */
+int ssac_linear_wgrad_splitk(const float *dY, int64_t ldy, const float *X, int64_t ldx, float *partial_w,
+                             float *partial_b, int M_out, int N_in, int n_rows, int rows_per_slice,
+                             void *stream);
+int ssac_reduce_slices(const float *partial, int slices, int64_t n, float *out, void *stream);
+int ssac_relu_mask(float *dy, const float *y, int64_t n, void *stream);
+/* sum of squares of x as ssac_sumsq_blocks() partials (feed ssac_clip_coef / ssac_group_norms) */
+int ssac_sumsq_blocks(void);
+int ssac_sumsq(const float *x, int64_t n, float *out_partials, void *stream);
+/* LayerNorm(eps 1e-5) + tanh (cnns.py:66-68) and its backward (one workgroup; dy_scratch n_rows*dim). */
+int ssac_ln_tanh_fwd(const float *x, int64_t ldx, const float *gamma, const float *beta, int n_rows, int dim,
+                     float *out, int64_t ldo, float *xhat, float *rstd, void *stream);
+int ssac_ln_tanh_bwd(const float *d_out, int64_t ldd, const float *out, int64_t ldo, const float *xhat,
+                     const float *rstd, const float *gamma, int n_rows, int dim, float *dx, int64_t ldx,
+                     float *dy_scratch, float *dgamma, float *dbeta, void *stream);
+
 /* zero a float buffer (log accumulators) */
 int ssac_zero(float *p, int64_t n, void *stream);
 

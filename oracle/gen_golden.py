@@ -54,6 +54,53 @@ class RefIdentityEncoder(ref.nets.Encoder):
         return obs_dict["obs"]
 
 
+class RefPixelEncoder(ref.nets.Encoder):
+    """Same role as DMCPixelEncoder / AtariEncoder (experiments/dmc/train_dmc_from_pixels.py:15-27,
+    experiments/atari/train_atari.py:9-20); those scripts need gym/dmc2gym, so it is rebuilt here."""
+
+    def __init__(self, conv_block, dim):
+        super().__init__()
+        self.conv_block = conv_block
+        self._dim = dim
+
+    @property
+    def embedding_dim(self):
+        return self._dim
+
+    def forward(self, obs_dict):
+        return self.conv_block(obs_dict["obs"])
+
+
+def build_encoders(cfg):
+    """(reference encoder module, oracle encoder dict) for a case."""
+    px = cfg.get("pixels")
+    if not px:
+        return RefIdentityEncoder(cfg["obs"]), None
+    p = orc.make_conv_encoder(np.random.RandomState(cfg["seed"] + 7), px["kind"], px["channels"], px["emb"])
+    cls = ref.nets.cnns.BigPixelEncoder if px["kind"] == "big" else ref.nets.cnns.SmallPixelEncoder
+    m = cls((px["channels"], px["hw"], px["hw"]), px["emb"])
+    names = ["conv1", "conv2", "conv3", "conv4"] if px["kind"] == "big" else ["conv1", "conv2", "conv3"]
+    for i, nm in enumerate(names, 1):
+        load_linear(getattr(m, nm), p[f"c{i}w"], p[f"c{i}b"])
+    load_linear(m.fc, p["fcw"], p["fcb"])
+    if px["kind"] == "big":
+        load_linear(m.ln, p["lnw"], p["lnb"])
+    return RefPixelEncoder(m, px["emb"]), {"kind": px["kind"], "key": "obs", "p": p}
+
+
+def ref_encoder_params(enc, cfg):
+    """reference encoder tensors in the oracle's dict order (c1w, c1b, ..., fcw, fcb[, lnw, lnb])."""
+    m = enc.conv_block
+    names = ["conv1", "conv2", "conv3", "conv4"] if cfg["pixels"]["kind"] == "big" else ["conv1", "conv2", "conv3"]
+    out = []
+    for nm in names:
+        out += [getattr(m, nm).weight, getattr(m, nm).bias]
+    out += [m.fc.weight, m.fc.bias]
+    if cfg["pixels"]["kind"] == "big":
+        out += [m.ln.weight, m.ln.bias]
+    return out
+
+
 def load_linear(lin, w, b):
     lin.weight.data.copy_(w)
     lin.bias.data.copy_(b)
@@ -66,15 +113,16 @@ def load_mlp(mod, p, names):
 
 def build_pair(cfg):
     """(reference agent, oracle agent) holding identical seeded weights."""
+    r_enc, o_enc = build_encoders(cfg)
     oa = orc.AgentOracle(state_dim=cfg["obs"], act_dim=cfg["act"], hidden=cfg["hidden"],
                          num_critics=cfg["N"], ensemble_size=cfg["E"], discrete=cfg["discrete"],
                          actor_kind=cfg["actor"], log_std_low=cfg["lo"], log_std_high=cfg["hi"],
-                         popart=cfg["popart"], seed=cfg["seed"])
+                         popart=cfg["popart"], encoder=o_enc, seed=cfg["seed"])
     actor_cls = {"stochastic": ref.nets.mlps.ContinuousStochasticActor,
                  "deterministic": ref.nets.mlps.ContinuousDeterministicActor,
                  "discrete": ref.nets.mlps.DiscreteActor}[cfg["actor"]]
     critic_cls = ref.nets.mlps.DiscreteCritic if cfg["discrete"] else ref.nets.mlps.ContinuousCritic
-    ra = ref.Agent(act_space_size=cfg["act"], encoder=RefIdentityEncoder(cfg["obs"]),
+    ra = ref.Agent(act_space_size=cfg["act"], encoder=r_enc,
                    actor_network_cls=actor_cls, critic_network_cls=critic_cls,
                    discrete=cfg["discrete"], ensemble_size=cfg["E"], num_critics=cfg["N"],
                    ucb_bonus=0.0, hidden_size=cfg["hidden"], auto_rescale_targets=cfg["popart"],
@@ -111,8 +159,14 @@ def run_case(name, cfg):
     np.random.seed(cfg["seed"])
     random.seed(cfg["seed"])
     B, E, N = cfg["B"], cfg["E"], cfg["N"]
-    s, a, r, s1, d = synth.synth_transitions(cfg["rows"], cfg["obs"], cfg["act"], cfg["discrete"],
-                                            seed=cfg["seed"] + 100, n_actions=cfg["act"])
+    px = cfg.get("pixels")
+    if px:
+        s, a, r, s1, d = synth.synth_pixel_transitions(cfg["rows"], px["channels"], px["hw"],
+                                                      n_actions=cfg["act"] if cfg["discrete"] else None,
+                                                      act_dim=cfg["act"], seed=cfg["seed"] + 100)
+    else:
+        s, a, r, s1, d = synth.synth_transitions(cfg["rows"], cfg["obs"], cfg["act"], cfg["discrete"],
+                                                seed=cfg["seed"] + 100, n_actions=cfg["act"])
     rbuf = ref.replay.ReplayBuffer(cfg["cap"])
     rbuf.load_experience(s, a, r, s1, d)
     obuf = orc.ReplayOracle(cfg["cap"])
@@ -128,7 +182,8 @@ def run_case(name, cfg):
                               weight_decay=0, betas=(0.9, 0.999))
     r_aopt = torch.optim.Adam(chain(*(ac.parameters() for ac in ra.actors)), lr=cfg["lr"],
                               weight_decay=0, betas=(0.9, 0.999))
-    r_eopt = torch.optim.Adam(ra.encoder.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    enc_lr = px["enc_lr"] if px else 1e-4
+    r_eopt = torch.optim.Adam(ra.encoder.parameters(), lr=enc_lr, betas=(0.9, 0.999))
     init_alpha = max(cfg["init_alpha"], 1e-15)
     r_las, r_lopts, o_las, o_lopts = [], [], [], []
     for _ in range(E):
@@ -141,11 +196,16 @@ def run_case(name, cfg):
         o_lopts.append(orc.AdamOracle([ola], lr=cfg["alpha_lr"], betas=(0.5, 0.999)))
     o_copt = orc.AdamOracle(oa.critic_params(), lr=cfg["lr"])
     o_aopt = orc.AdamOracle(oa.actor_params(), lr=cfg["lr"])
-    o_eopt = orc.AdamOracle([], lr=1e-4)
+    o_eopt = orc.AdamOracle(oa.encoder_params(), lr=enc_lr)
     target_entropy = (-math.log(1.0 / cfg["act"]) * 0.98) if cfg["discrete"] else -float(cfg["act"])
 
-    r_aug = ref.augmentations.AugmentationSequence([ref.augmentations.IdentityAug(B)])
-    o_aug = orc.AugOracle("identity", B)
+    if px and px["aug"] == "drqv2":
+        r_aug = ref.augmentations.AugmentationSequence([ref.augmentations.Drqv2Aug(B)])
+        o_aug = orc.AugOracle("drqv2", B)
+    else:
+        r_aug = ref.augmentations.AugmentationSequence([ref.augmentations.IdentityAug(B)])
+        o_aug = orc.AugOracle("identity", B)
+    aug_mix = px["aug_mix"] if px else 0.0
     if cfg["noise"]:
         space = types.SimpleNamespace(low=-np.ones(cfg["act"], np.float32),
                                       high=np.ones(cfg["act"], np.float32))
@@ -174,9 +234,11 @@ def run_case(name, cfg):
         for k in range(cfg["utd"]):
             # replicate the host draws the reference is about to make, then rewind
             st, pst = torch.get_rng_state(), random.getstate()
-            idxs, epss, noises, subsets = [], [], [], []
+            idxs, epss, noises, subsets, shifts = [], [], [], [], []
             for i in range(E):
                 idxs.append(torch.randint(len(rbuf), (B,)).numpy())
+                if px and px["aug"] == "drqv2":
+                    shifts.append(orc.drqv2_draw_shift(B))
                 if stochastic:
                     epss.append(torch.randn(B, cfg["act"]))
                 if cfg["noise"]:
@@ -192,11 +254,14 @@ def run_case(name, cfg):
                 critic_clip=cfg["clip"], encoder_clip=cfg["clip"],
                 target_critic_ensemble_n=cfg["n"], weighted_bellman_temp=cfg["temp"],
                 weight_type=cfg["weight_type"], pop=cfg["pop"], augmenter=r_aug, encoder_lambda=0,
-                aug_mix=0.0, discrete=cfg["discrete"], random_process=rproc, noise_clip=nclip,
+                aug_mix=aug_mix, discrete=cfg["discrete"], random_process=rproc, noise_clip=nclip,
                 per=False, update_priorities=False, dr3_coeff=0.0)
+            if shifts:
+                assert torch.equal(r_aug.aug_list[0].shift, shifts[-1]), "shift stream mismatch"
+                o_aug.forced = [sh.clone() for sh in shifts]
             ologs, odicts = orc.critic_update(
                 obuf, oa, ot, o_copt, o_eopt, o_las, B, cfg["gamma"], cfg["clip"], cfg["clip"],
-                cfg["n"], cfg["temp"], cfg["weight_type"], cfg["pop"], o_aug, aug_mix=0.0,
+                cfg["n"], cfg["temp"], cfg["weight_type"], cfg["pop"], o_aug, aug_mix=aug_mix,
                 noise_scale=nscale, noise_clip=nclip, idx_list=idxs,
                 eps_list=epss if stochastic else None,
                 noise_list=noises if cfg["noise"] else None, subset_list=subsets)
@@ -206,6 +271,8 @@ def run_case(name, cfg):
                 worst = max(worst, dtd)
                 rec[f"u{upd}_idx{i}"] = idxs[i]
                 rec[f"u{upd}_subset{i}"] = np.array(subsets[i], np.int64)
+                if shifts:
+                    rec[f"u{upd}_shift{i}"] = shifts[i].numpy()
                 if stochastic:
                     rec[f"u{upd}_eps{i}"] = epss[i].numpy()
                 if cfg["noise"]:
@@ -231,6 +298,9 @@ def run_case(name, cfg):
                 for ac, tc in zip(ra.critics, rt.critics):
                     rlu.soft_update(tc, ac, cfg["tau"])
                 orc.soft_update(ot.critic_params(), oa.critic_params(), cfg["tau"])
+                if px:
+                    rlu.soft_update(rt.encoder, ra.encoder, px["enc_tau"])
+                    orc.soft_update(ot.encoder_params(), oa.encoder_params(), px["enc_tau"])
                 rec[f"u{upd}_polyak"] = np.int64(1)
             else:
                 rec[f"u{upd}_polyak"] = np.int64(0)
@@ -291,6 +361,17 @@ def run_case(name, cfg):
     print(f"   td max|diff| {worst:.3e}   params max|diff| {dpar:.3e}   log_alpha diff {dla:.3e}")
     assert worst < 5e-4 and dpar < 5e-5 and dla < 1e-6
 
+    if px:
+        re_, rte_ = ref_encoder_params(ra.encoder, cfg), ref_encoder_params(rt.encoder, cfg)
+        denc = max(maxdiff(re_, oa.encoder_params()), maxdiff(rte_, ot.encoder_params()))
+        print(f"   encoder params max|diff| {denc:.3e}")
+        assert denc < 5e-5
+        for tag, plist in (("encoder", re_), ("target_encoder", rte_)):
+            vals = []
+            for p in plist:
+                flat = p.detach().numpy().ravel()
+                vals.append(flat[synth.fingerprint_indices(flat.size)])
+            rec[f"finalfp_{tag}"] = np.concatenate(vals)
     small = sum(p.numel() for p in rc) < 40000
     for tag, plist in (("critic", rc), ("actor", rac), ("target_critic", rtc)):
         if small:

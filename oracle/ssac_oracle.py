@@ -335,6 +335,7 @@ class AugOracle:
     def __init__(self, kind, batch_size, pad=4):
         self.kind, self.batch_size, self.pad = kind, batch_size, pad
         self.last = None
+        self.forced = None  # list of recorded draws to replay instead of the torch generator
         # the reference constructors draw once at build time (augmentations.py:180,221)
         if kind == "drqv2":
             drqv2_draw_shift(batch_size, pad)
@@ -346,7 +347,7 @@ class AugOracle:
             outs = [{k: v.clone() for k, v in d.items()} for d in obs_dicts]
             return tuple(outs) if len(outs) > 1 else outs[0]
         if self.kind == "drqv2":
-            shift = drqv2_draw_shift(self.batch_size, self.pad)
+            shift = self.forced.pop(0) if self.forced else drqv2_draw_shift(self.batch_size, self.pad)
             self.last = shift
             f = lambda x, nz: drqv2_shift(x, shift, self.pad)
         else:

@@ -64,6 +64,17 @@ SIGNATURES = {
     "ssac_sunrise_weights": [_P, _I, _I, _F, _P, _P, _P],
     "ssac_drq_shift": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P],
     "ssac_zero": [_P, _L, _P],
+    "ssac_im2col": [_P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P],
+    "ssac_col2im": [_P, _P, _L, _L, _L, _L, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P],
+    "ssac_linear_fwd": [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _P],
+    "ssac_linear_dgrad": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P],
+    "ssac_linear_wgrad_splitk": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _P],
+    "ssac_reduce_slices": [_P, _I, _L, _P, _P],
+    "ssac_relu_mask": [_P, _P, _L, _P],
+    "ssac_sumsq_blocks": [],
+    "ssac_sumsq": [_P, _L, _P, _P],
+    "ssac_ln_tanh_fwd": [_P, _L, _P, _P, _I, _I, _P, _L, _P, _P, _P],
+    "ssac_ln_tanh_bwd": [_P, _L, _P, _L, _P, _P, _P, _I, _I, _P, _L, _P, _P, _P, _P],
     "ssac_fused_supported": [_MP],
     "ssac_fused_debug_stamps": [_P],
     "ssac_gemm_debug_stamps": [_P],

@@ -1,0 +1,204 @@
+"""Pixel encoders on the HIP path (reference super_sac/nets/cnns.py:37-103).
+
+``BigPixelEncoder`` (DrQ: conv3x3 s2 + 3x conv3x3 s1, ReLU, fc, LayerNorm, tanh; input x/255-0.5) and
+``SmallPixelEncoder`` (Nature-DQN: conv8 s4, conv4 s2, conv3 s1, ReLU, fc; input x/255) run as
+
+    im2col (normalisation fused) -> exact-fp32 MFMA GEMM with bias+ReLU epilogue      per conv layer
+    im2col with kernel = whole map -> GEMM                                            fc over the NCHW flatten
+    LayerNorm+tanh kernel                                                             (Big only)
+
+with channels-last activations, so each GEMM output is the next layer's input and the
+``nn.Conv2d`` weights are used in place as (out, c*kh*kw) matrices.  The backward pass mirrors it
+(GEMM backward-data -> col2im with the ReLU mask fused; split-K weight-gradient GEMMs reduced in a
+fixed order), leaving the gradients in one flat arena so clip_grad_norm_ and Adam are two launches.
+The module's parameters are re-pointed at a flat arena exactly like the MLP ensembles.
+"""
+import ctypes as C
+
+import torch
+
+from . import engine
+from ._lib import check, lib
+
+ROWS_PER_SLICE = 4096  # split-K granularity of the convolution weight gradients
+
+
+def find_conv_module(encoder):
+    """the BigPixelEncoder/SmallPixelEncoder-shaped module inside an Encoder wrapper
+    (train_dmc_from_pixels.py:15-27 ``conv_block``, train_atari.py:9-20 ``cnn``)."""
+    for m in encoder.modules():
+        if hasattr(m, "conv1") and hasattr(m, "fc"):
+            return m
+    return None
+
+
+class ConvEncoderEngine:
+    def __init__(self, module, device):
+        self.module = module
+        self.device = device
+        convs = [getattr(module, n) for n in ("conv1", "conv2", "conv3", "conv4") if hasattr(module, n)]
+        self.convs = convs
+        self.big = hasattr(module, "ln")
+        self.geom = [(c.in_channels, c.out_channels, c.kernel_size[0], c.stride[0]) for c in convs]
+        self.emb = module.fc.out_features
+        self.div, self.shift = (255.0, -0.5) if self.big else (255.0, 0.0)
+        # ---- flat parameter arena (each tensor starts at a multiple of 4 floats)
+        plist = []
+        for c in convs:
+            plist += [c.weight, c.bias]
+        plist += [module.fc.weight, module.fc.bias]
+        if self.big:
+            plist += [module.ln.weight, module.ln.bias]
+        self.plist = plist
+        offs, o = [], 0
+        for p in plist:
+            offs.append(o)
+            o += (p.numel() + 3) // 4 * 4
+        self.offs, self.numel = offs, o
+        self.flat = torch.zeros(o, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for p, off in zip(plist, offs):
+                v = self.flat[off:off + p.numel()].view(p.shape)
+                v.copy_(p.data.to(device=device, dtype=torch.float32))
+                p.data = v
+        self.grads = torch.zeros_like(self.flat)
+        self.ws = engine.Workspace(device)
+        self.saved = None
+
+    def is_bound(self):
+        return all(p.data_ptr() == self.flat.data_ptr() + 4 * off for p, off in zip(self.plist, self.offs))
+
+    def _seg(self, k, tensor=None):
+        t = self.flat if tensor is None else tensor
+        return t[self.offs[k]:self.offs[k] + self.plist[k].numel()]
+
+    # ------------------------------------------------------------------------------------
+    def forward(self, img, dst, ld_dst, save):
+        """img (B, C, H, W) fp32 on the device; writes the embedding into dst[:, :emb] (row stride
+        ld_dst).  With `save`, keeps what backward() needs."""
+        engine.require_gpu(img)
+        img = img.contiguous()
+        B, Cc, Hh, Ww = img.shape
+        st = engine.stream()
+        src, u8 = img, 0
+        strides = (Cc * Hh * Ww, Hh * Ww, Ww, 1)
+        Hi, Wi, div, shift = Hh, Ww, self.div, self.shift
+        cols, ys, shapes = [], [], []
+        tag = "s" if save else "t"
+        for l, (ci, co, k, s) in enumerate(self.geom):
+            Ho, Wo = (Hi - k) // s + 1, (Wi - k) // s + 1
+            rows, ckk = B * Ho * Wo, ci * k * k
+            col = self.ws.get(f"{tag}.col{l if save else 0}", (rows * ckk,))
+            y = self.ws.get(f"{tag}.y{l if save else l % 2}", (rows * co,))
+            check(lib.ssac_im2col(src.data_ptr(), u8, *strides, B, ci, Hi, Wi, k, s, div, shift,
+                                  col.data_ptr(), st))
+            check(lib.ssac_linear_fwd(col.data_ptr(), ckk, self.convs[l].weight.data_ptr(), ckk,
+                                      self.convs[l].bias.data_ptr(), y.data_ptr(), co, rows, co, ckk, 1, st))
+            cols.append(col); ys.append(y); shapes.append((ci, co, k, s, Hi, Wi, Ho, Wo))
+            src, strides = y, (Ho * Wo * co, 1, Wo * co, co)  # channels-last view of the GEMM output
+            Hi, Wi, div, shift = Ho, Wo, 1.0, 0.0
+        co = self.geom[-1][1]
+        flat_dim = co * Hi * Wi
+        colf = self.ws.get(f"{tag}.colf", (B * flat_dim,))
+        check(lib.ssac_im2col(src.data_ptr(), 0, *strides, B, co, Hi, Wi, Hi, 1, 1.0, 0.0, colf.data_ptr(), st))
+        fc = self.module.fc
+        if self.big:
+            z = self.ws.get(f"{tag}.z", (B, self.emb))
+            check(lib.ssac_linear_fwd(colf.data_ptr(), flat_dim, fc.weight.data_ptr(), flat_dim,
+                                      fc.bias.data_ptr(), z.data_ptr(), self.emb, B, self.emb, flat_dim, 0, st))
+            xhat = self.ws.get(f"{tag}.xhat", (B, self.emb))
+            rstd = self.ws.get(f"{tag}.rstd", (B,))
+            ln = self.module.ln
+            check(lib.ssac_ln_tanh_fwd(z.data_ptr(), self.emb, ln.weight.data_ptr(), ln.bias.data_ptr(), B,
+                                       self.emb, dst.data_ptr(), ld_dst, xhat.data_ptr(), rstd.data_ptr(), st))
+        else:
+            xhat = rstd = None
+            check(lib.ssac_linear_fwd(colf.data_ptr(), flat_dim, fc.weight.data_ptr(), flat_dim,
+                                      fc.bias.data_ptr(), dst.data_ptr(), ld_dst, B, self.emb, flat_dim, 0, st))
+        if save:
+            self.saved = dict(B=B, cols=cols, ys=ys, shapes=shapes, colf=colf, flat_dim=flat_dim,
+                              Hf=Hi, Wf=Wi, xhat=xhat, rstd=rstd, out=dst, ld_out=ld_dst)
+
+    # ------------------------------------------------------------------------------------
+    def backward(self, d_rep):
+        """d_rep (B, emb) contiguous = dL/d(embedding).  Fills self.grads (flat, same layout as the
+        parameters)."""
+        sv = self.saved
+        assert sv is not None, "backward() needs a forward(save=True)"
+        B, st = sv["B"], engine.stream()
+        nconv = len(self.geom)
+        k_fcw, k_fcb = 2 * nconv, 2 * nconv + 1
+        if self.big:
+            dz = self.ws.get("b.dz", (B, self.emb))
+            scratch = self.ws.get("b.lnscratch", (B, self.emb))
+            check(lib.ssac_ln_tanh_bwd(d_rep.data_ptr(), self.emb, sv["out"].data_ptr(), sv["ld_out"],
+                                       sv["xhat"].data_ptr(), sv["rstd"].data_ptr(),
+                                       self.module.ln.weight.data_ptr(), B, self.emb, dz.data_ptr(), self.emb,
+                                       scratch.data_ptr(), self._seg(k_fcb + 1, self.grads).data_ptr(),
+                                       self._seg(k_fcb + 2, self.grads).data_ptr(), st))
+        else:
+            dz = d_rep
+        flat_dim = sv["flat_dim"]
+        # fc: weight gradient (K = B rows, one slice writes straight into the gradient arena)
+        check(lib.ssac_linear_wgrad_splitk(dz.data_ptr(), self.emb, sv["colf"].data_ptr(), flat_dim,
+                                           self._seg(k_fcw, self.grads).data_ptr(),
+                                           self._seg(k_fcb, self.grads).data_ptr(), self.emb, flat_dim, B, B, st))
+        dcolf = self.ws.get("b.dcolf", (B * flat_dim,))
+        check(lib.ssac_linear_dgrad(dz.data_ptr(), self.emb, self.module.fc.weight.data_ptr(), flat_dim,
+                                    dcolf.data_ptr(), flat_dim, B, flat_dim, self.emb, st))
+        ci, co, k, s, Hi, Wi, Ho, Wo = sv["shapes"][-1]
+        dy = self.ws.get(f"b.dy{(nconv - 1) % 2}", (B * Ho * Wo * co,))
+        ylast = sv["ys"][-1]
+        cl = (Ho * Wo * co, 1, Wo * co, co)
+        check(lib.ssac_col2im(dcolf.data_ptr(), dy.data_ptr(), *cl, ylast.data_ptr(), *cl, B, co, Ho, Wo,
+                              sv["Hf"], 1, st))
+        for l in range(nconv - 1, -1, -1):
+            ci, co, k, s, Hi, Wi, Ho, Wo = sv["shapes"][l]
+            rows, ckk = B * Ho * Wo, ci * k * k
+            slices = (rows + ROWS_PER_SLICE - 1) // ROWS_PER_SLICE
+            pw = self.ws.get("b.pw", (slices * co * ckk,))
+            pb = self.ws.get("b.pb", (slices * co,))
+            check(lib.ssac_linear_wgrad_splitk(dy.data_ptr(), co, sv["cols"][l].data_ptr(), ckk, pw.data_ptr(),
+                                               pb.data_ptr(), co, ckk, rows, ROWS_PER_SLICE, st))
+            check(lib.ssac_reduce_slices(pw.data_ptr(), slices, co * ckk,
+                                         self._seg(2 * l, self.grads).data_ptr(), st))
+            check(lib.ssac_reduce_slices(pb.data_ptr(), slices, co, self._seg(2 * l + 1, self.grads).data_ptr(), st))
+            if l == 0:
+                break
+            dcol = self.ws.get("b.dcol", (rows * ckk,))
+            check(lib.ssac_linear_dgrad(dy.data_ptr(), co, self.convs[l].weight.data_ptr(), ckk, dcol.data_ptr(),
+                                        ckk, rows, ckk, co, st))
+            pci, pco, pk, ps, pHi, pWi, pHo, pWo = sv["shapes"][l - 1]
+            dprev = self.ws.get(f"b.dy{(l - 1) % 2}", (B * pHo * pWo * pco,))
+            pcl = (pHo * pWo * pco, 1, pWo * pco, pco)
+            check(lib.ssac_col2im(dcol.data_ptr(), dprev.data_ptr(), *pcl, sv["ys"][l - 1].data_ptr(), *pcl,
+                                  B, ci, Hi, Wi, k, s, st))
+            dy = dprev
+
+    # ------------------------------------------------------------------------------------
+    def optimizer_step(self, optimizer, clip, norm_out=None):
+        """clip_grad_norm_(encoder.parameters(), clip) + encoder_optimizer.step() (learning.py:127-129)."""
+        st = engine.stream()
+        adam = engine.adam_group(optimizer, self.device)
+        adam.advance()
+        nb = int(lib.ssac_sumsq_blocks())
+        ss = self.ws.get("o.ss", (nb,))
+        check(lib.ssac_sumsq(self.grads.data_ptr(), self.numel, ss.data_ptr(), st))
+        check(lib.ssac_clip_coef(adam.ctl.ptr, ss.data_ptr(), nb, float(clip) if clip else 0.0, 0, st))
+        if norm_out is not None:
+            check(lib.ssac_group_norms(ss.data_ptr(), 1, nb, adam.ctl.ptr, norm_out.data_ptr(), st))
+        m, v = adam.moments_for("conv_encoder", self.flat)
+        check(lib.ssac_adam_step(self.flat.data_ptr(), m.data_ptr(), v.data_ptr(), self.grads.data_ptr(),
+                                 self.numel, adam.ctl.ptr, st))
+
+
+def conv_engine(encoder, device):
+    """ConvEncoderEngine of `encoder` (cached on the wrapped conv module; re-packed after a deepcopy)."""
+    mod = find_conv_module(encoder)
+    if mod is None:
+        return None
+    eng = mod.__dict__.get("_ssac_conv")
+    if eng is None or eng.module is not mod or not eng.is_bound() or eng.device != device:
+        eng = ConvEncoderEngine(mod, device)
+        mod.__dict__["_ssac_conv"] = eng
+    return eng

@@ -1,0 +1,249 @@
+// Pixel-encoder pieces (reference nets/cnns.py:37-103) that are not GEMMs: patch gather
+// (im2col) with the input normalisation fused, its adjoint (col2im) with the ReLU mask fused,
+// LayerNorm+tanh forward/backward, slice reduction for the split-K weight gradients.
+//
+// Convolutions run as  im2col -> ens_gemm (exact-fp32 MFMA, bias+ReLU epilogue)  with activations
+// kept channels-last, i.e. the GEMM output (rows = (b, y, x), cols = channel) IS the next layer's
+// input; column order of a patch is (c, ky, kx) = the flattened nn.Conv2d weight, so the weight
+// tensor is used in place.  The final nn.Linear over the NCHW-flattened feature map is the same
+// gather with kernel = the whole map.  These kernels are HBM-bound byte movers: one thread per
+// element, consecutive threads along the contiguous output dimension.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "ssac_internal.h"
+
+namespace {
+
+struct Im2colArgs {
+    const void *src; int src_u8;
+    int64_t sb, sc, sy, sx;   // element strides of the source for (batch, channel, y, x)
+    int B, C, Hi, Wi, k, stride, Ho, Wo;
+    float div, shift;         // value = float(src) / div + shift   (cnns.py:60: obs/255 - 0.5)
+    float *col;               // (B*Ho*Wo, C*k*k)
+};
+
+__global__ void im2col_kernel(Im2colArgs a) {
+    const int64_t ckk = (int64_t)a.C * a.k * a.k;
+    const int64_t total = (int64_t)a.B * a.Ho * a.Wo * ckk;
+    const uint8_t *s8 = (const uint8_t *)a.src;
+    const float *sf = (const float *)a.src;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / ckk;
+        const int col = (int)(i - row * ckk);
+        const int c = col / (a.k * a.k), kr = col - c * a.k * a.k;
+        const int ky = kr / a.k, kx = kr - ky * a.k;
+        const int ox = (int)(row % a.Wo);
+        const int64_t t = row / a.Wo;
+        const int oy = (int)(t % a.Ho), b = (int)(t / a.Ho);
+        const int64_t si = b * a.sb + c * a.sc + (int64_t)(oy * a.stride + ky) * a.sy +
+                           (int64_t)(ox * a.stride + kx) * a.sx;
+        const float v = a.src_u8 ? (float)s8[si] : sf[si];
+        a.col[i] = a.div == 1.0f && a.shift == 0.0f ? v : v / a.div + a.shift;
+    }
+}
+
+struct Col2imArgs {
+    const float *dcol;        // (B*Ho*Wo, C*k*k)
+    float *dx; int64_t sb, sc, sy, sx;   // destination strides
+    const float *mask; int64_t mb, mc, my, mx;  // optional ReLU mask source (same logical shape as dx)
+    int B, C, Hi, Wi, k, stride, Ho, Wo;
+};
+
+__global__ void col2im_kernel(Col2imArgs a) {
+    const int64_t total = (int64_t)a.B * a.C * a.Hi * a.Wi;
+    const int64_t ckk = (int64_t)a.C * a.k * a.k;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        // decode with channel fastest (destination is channels-last in every use)
+        const int c = (int)(i % a.C);
+        int64_t t = i / a.C;
+        const int ix = (int)(t % a.Wi); t /= a.Wi;
+        const int iy = (int)(t % a.Hi);
+        const int b = (int)(t / a.Hi);
+        float acc = 0.0f;
+        for (int ky = 0; ky < a.k; ++ky) {
+            const int ny = iy - ky;
+            if (ny < 0 || ny % a.stride) continue;
+            const int oy = ny / a.stride;
+            if (oy >= a.Ho) continue;
+            for (int kx = 0; kx < a.k; ++kx) {
+                const int nx = ix - kx;
+                if (nx < 0 || nx % a.stride) continue;
+                const int ox = nx / a.stride;
+                if (ox >= a.Wo) continue;
+                acc += a.dcol[((int64_t)(b * a.Ho + oy) * a.Wo + ox) * ckk + (c * a.k + ky) * a.k + kx];
+            }
+        }
+        if (a.mask) {
+            const float m = a.mask[b * a.mb + c * a.mc + (int64_t)iy * a.my + (int64_t)ix * a.mx];
+            acc = m > 0.0f ? acc : 0.0f;
+        }
+        a.dx[b * a.sb + c * a.sc + (int64_t)iy * a.sy + (int64_t)ix * a.sx] = acc;
+    }
+}
+
+// dY (.)= [Y > 0]  (ReLU backward on a contiguous buffer)
+__global__ void relu_mask_kernel(float *__restrict__ dy, const float *__restrict__ y, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        dy[i] = y[i] > 0.0f ? dy[i] : 0.0f;
+}
+
+// out[i] = sum_s partial[s*n + i], fixed order
+__global__ void reduce_slices_kernel(const float *__restrict__ partial, int slices, int64_t n,
+                                     float *__restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int z = 0; z < slices; ++z) s += partial[(int64_t)z * n + i];
+        out[i] = s;
+    }
+}
+
+// per-block partial sums of x^2 (for clip_grad_norm_ over an encoder's gradient arena)
+__global__ void sumsq_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.0f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        s += x[i] * x[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// LayerNorm (eps 1e-5, biased variance) + tanh, one thread per row (cnns.py:66-68)
+__global__ void ln_tanh_fwd_kernel(const float *__restrict__ x, int64_t ldx, const float *__restrict__ gamma,
+                                   const float *__restrict__ beta, int n_rows, int D, float *__restrict__ out,
+                                   int64_t ldo, float *__restrict__ xhat, float *__restrict__ rstd) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_rows) return;
+    const float *xr = x + b * ldx;
+    float mean = 0.0f;
+    for (int j = 0; j < D; ++j) mean += xr[j];
+    mean /= (float)D;
+    float var = 0.0f;
+    for (int j = 0; j < D; ++j) { const float d = xr[j] - mean; var += d * d; }
+    var /= (float)D;
+    const float rs = 1.0f / sqrtf(var + 1e-5f);
+    if (rstd) rstd[b] = rs;
+    for (int j = 0; j < D; ++j) {
+        const float xh = (xr[j] - mean) * rs;
+        if (xhat) xhat[(int64_t)b * D + j] = xh;
+        out[b * ldo + j] = tanhf(xh * gamma[j] + beta[j]);
+    }
+}
+
+// backward: d_out (n_rows x D) wrt tanh output -> dx (pre-LayerNorm), dgamma, dbeta.  One workgroup;
+// thread per row for dx, then per-feature column reductions in a fixed order.
+__global__ __launch_bounds__(1024) void ln_tanh_bwd_kernel(
+    const float *__restrict__ d_out, int64_t ldd, const float *__restrict__ out, int64_t ldo,
+    const float *__restrict__ xhat, const float *__restrict__ rstd, const float *__restrict__ gamma,
+    int n_rows, int D, float *__restrict__ dx, int64_t ldx, float *__restrict__ dy_scratch,
+    float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+        float m1 = 0.0f, m2 = 0.0f;
+        for (int j = 0; j < D; ++j) {
+            const float o = out[b * ldo + j];
+            const float dy = d_out[b * ldd + j] * (1.0f - o * o);
+            dy_scratch[(int64_t)b * D + j] = dy;
+            const float dxh = dy * gamma[j];
+            m1 += dxh;
+            m2 += dxh * xhat[(int64_t)b * D + j];
+        }
+        m1 /= (float)D;
+        m2 /= (float)D;
+        const float rs = rstd[b];
+        for (int j = 0; j < D; ++j) {
+            const float dxh = dy_scratch[(int64_t)b * D + j] * gamma[j];
+            dx[b * ldx + j] = rs * (dxh - m1 - xhat[(int64_t)b * D + j] * m2);
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < D; j += blockDim.x) {
+        float g = 0.0f, bb = 0.0f;
+        for (int b = 0; b < n_rows; ++b) {
+            const float dy = dy_scratch[(int64_t)b * D + j];
+            g += dy * xhat[(int64_t)b * D + j];
+            bb += dy;
+        }
+        dgamma[j] = g;
+        dbeta[j] = bb;
+    }
+}
+
+inline int grid_for(int64_t n, int block = 256, int cap = 16384) {
+    int64_t g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int ssac_im2col(const void *src, int src_u8, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                           int B, int C, int Hi, int Wi, int k, int stride, float div, float shift,
+                           float *col, void *stream) {
+    if (k < 1 || stride < 1 || Hi < k || Wi < k) return ssac_fail("ssac_im2col: bad geometry");
+    Im2colArgs a{src, src_u8, sb, sc, sy, sx, B, C, Hi, Wi, k, stride, (Hi - k) / stride + 1,
+                 (Wi - k) / stride + 1, div, shift, col};
+    const int64_t total = (int64_t)B * a.Ho * a.Wo * C * k * k;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, ST, a);
+    return ssac_check_launch("im2col");
+}
+
+extern "C" int ssac_col2im(const float *dcol, float *dx, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                           const float *mask, int64_t mb, int64_t mc, int64_t my, int64_t mx, int B, int C,
+                           int Hi, int Wi, int k, int stride, void *stream) {
+    if (k < 1 || stride < 1 || Hi < k || Wi < k) return ssac_fail("ssac_col2im: bad geometry");
+    Col2imArgs a{dcol, dx, sb, sc, sy, sx, mask, mb, mc, my, mx, B, C, Hi, Wi, k, stride,
+                 (Hi - k) / stride + 1, (Wi - k) / stride + 1};
+    const int64_t total = (int64_t)B * C * Hi * Wi;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, ST, a);
+    return ssac_check_launch("col2im");
+}
+
+extern "C" int ssac_relu_mask(float *dy, const float *y, int64_t n, void *stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for(n)), dim3(256), 0, ST, dy, y, n);
+    return ssac_check_launch("relu_mask");
+}
+
+extern "C" int ssac_reduce_slices(const float *partial, int slices, int64_t n, float *out, void *stream) {
+    if (n <= 0 || slices <= 0) return 0;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3(grid_for(n)), dim3(256), 0, ST, partial, slices, n, out);
+    return ssac_check_launch("reduce_slices");
+}
+
+extern "C" int ssac_sumsq_blocks(void) { return 256; }
+
+extern "C" int ssac_sumsq(const float *x, int64_t n, float *out_partials, void *stream) {
+    hipLaunchKernelGGL(sumsq_kernel, dim3(256), dim3(256), 0, ST, x, n, out_partials);
+    return ssac_check_launch("sumsq");
+}
+
+extern "C" int ssac_ln_tanh_fwd(const float *x, int64_t ldx, const float *gamma, const float *beta,
+                                int n_rows, int dim, float *out, int64_t ldo, float *xhat, float *rstd,
+                                void *stream) {
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(ln_tanh_fwd_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ST, x, ldx, gamma, beta,
+                       n_rows, dim, out, ldo, xhat, rstd);
+    return ssac_check_launch("ln_tanh_fwd");
+}
+
+extern "C" int ssac_ln_tanh_bwd(const float *d_out, int64_t ldd, const float *out, int64_t ldo,
+                                const float *xhat, const float *rstd, const float *gamma, int n_rows,
+                                int dim, float *dx, int64_t ldx, float *dy_scratch, float *dgamma,
+                                float *dbeta, void *stream) {
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(ln_tanh_bwd_kernel, dim3(1), dim3(1024), 0, ST, d_out, ldd, out, ldo, xhat, rstd,
+                       gamma, n_rows, dim, dx, ldx, dy_scratch, dgamma, dbeta);
+    return ssac_check_launch("ln_tanh_bwd");
+}

@@ -52,6 +52,8 @@ struct GemmArgs {
     int64_t sumsq_stride;
     int vec;                 // bit0: A rows are 16-byte aligned, bit1: B rows (row-contiguous operands)
     long long *dbg;          // optional s_memtime stamps of workgroup (0,0,0), thread 0
+    int Ktot;                // > 0: batch entry e covers k in [e*K, min((e+1)*K, Ktot)) (split-K over blocks)
+    int64_t sGb;             // EPI_GRAD: bias-gradient stride per batch entry (0 = same as sC)
 };
 
 __device__ __forceinline__ int64_t batch_off(const int32_t *ids, int use_ids, int e, int64_t stride) {
@@ -188,7 +190,8 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
 
     float bias_acc = 0.0f;  // TN mode, column sums of A (bias gradient), threads < 64 of n-tile 0
     const bool want_bias_grad = (EPI == EPI_ADAM || EPI == EPI_GRAD) && blockIdx.x == 0;
-    const int nchunks = (g.K + BK - 1) / BK;
+    const int Kloc = g.Ktot > 0 ? max(0, min(g.K, g.Ktot - e * g.K)) : g.K;
+    const int nchunks = (Kloc + BK - 1) / BK;
     const int iters = (nchunks + KS - 1) / KS;
     constexpr bool TN = !A_KC && !B_KC;
     // 16-byte loads need 16-byte aligned rows on both operands (checked per launch on the host)
@@ -200,8 +203,8 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
     if (vecB) vb.init(B, g.ldb, n0, g.N, kg * BK, tid);
     const int64_t advA = (int64_t)KS * BK * g.lda, advB = (int64_t)KS * BK * g.ldb;
 
-    auto loadA = [&](int k0) { if (vecA) va.load(k0, g.K, advA); else load_chunk<A_KC>(ra, A, g.lda, m0, g.M, k0, g.K, tid); };
-    auto loadB = [&](int k0) { if (vecB) vb.load(k0, g.K, advB); else load_chunk<B_KC>(rb, B, g.ldb, n0, g.N, k0, g.K, tid); };
+    auto loadA = [&](int k0) { if (vecA) va.load(k0, Kloc, advA); else load_chunk<A_KC>(ra, A, g.lda, m0, g.M, k0, Kloc, tid); };
+    auto loadB = [&](int k0) { if (vecB) vb.load(k0, Kloc, advB); else load_chunk<B_KC>(rb, B, g.ldb, n0, g.N, k0, Kloc, tid); };
     auto storeA = [&](float *d) { if (vecA) va.store(d); else store_chunk<A_KC>(ra, d, tid); };
     auto storeB = [&](float *d) { if (vecB) vb.store(d); else store_chunk<B_KC>(rb, d, tid); };
 
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
                 float bsum = red[tid_all];
 #pragma unroll
                 for (int gq = 1; gq < KS; ++gq) bsum += red[gq * 64 + tid_all];
-                const int64_t bi = coff + gm;
+                const int64_t bi = (EPI == EPI_GRAD && g.sGb) ? (int64_t)e * g.sGb + gm : coff + gm;
                 ss += bsum * bsum;
                 if (EPI == EPI_GRAD) {
                     g.gb[bi] = bsum;
@@ -504,4 +507,43 @@ extern "C" int ssac_mlp_layer_wgrad(const ssac_mlp *nets, int layer, const int32
     g.bm = adam_m + L.off_b; g.bv = adam_v + L.off_b;
     if (target) { g.tw = target + L.off_w; g.tb = target + L.off_b; }
     return launch<false, false, EPI_ADAM>(g, n_sel, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-problem GEMM entry points for the pixel encoders (convolutions run as im2col + GEMM).
+// ---------------------------------------------------------------------------------------------
+extern "C" int ssac_linear_fwd(const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias,
+                               float *Y, int64_t ldy, int M, int N, int K, int relu, void *stream) {
+    GemmArgs g{};
+    g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy;
+    g.M = M; g.N = N; g.K = K; g.bias = bias;
+    hipStream_t st = (hipStream_t)stream;
+    if (!bias) return ssac_fail("ssac_linear_fwd: bias required");
+    return relu ? launch<true, true, EPI_BIAS_RELU>(g, 1, st) : launch<true, true, EPI_BIAS>(g, 1, st);
+}
+
+extern "C" int ssac_linear_dgrad(const float *dY, int64_t ldy, const float *W, int64_t ldw, float *dX,
+                                 int64_t ldx, int M, int N_in, int K_out, void *stream) {
+    GemmArgs g{};
+    g.A = dY; g.lda = ldy; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = ldx;
+    g.M = M; g.N = N_in; g.K = K_out;
+    return launch<true, false, EPI_STORE>(g, 1, (hipStream_t)stream);
+}
+
+// dW partials: for slice z, partial_w[z] (M_out x N_in) = dY[rows of z]^T X[rows of z],
+// partial_b[z] (M_out) = colsum(dY[rows of z]); rows_per_slice rows each (the last one shorter).
+extern "C" int ssac_linear_wgrad_splitk(const float *dY, int64_t ldy, const float *X, int64_t ldx,
+                                        float *partial_w, float *partial_b, int M_out, int N_in,
+                                        int n_rows, int rows_per_slice, void *stream) {
+    if (rows_per_slice <= 0) return ssac_fail("ssac_linear_wgrad_splitk: bad slice size");
+    const int slices = (n_rows + rows_per_slice - 1) / rows_per_slice;
+    GemmArgs g{};
+    g.A = dY; g.lda = ldy; g.sA = (int64_t)rows_per_slice * ldy;
+    g.B = X; g.ldb = ldx; g.sB = (int64_t)rows_per_slice * ldx;
+    g.C = partial_w; g.ldc = N_in; g.sC = (int64_t)M_out * N_in;
+    g.gw = partial_w; g.gb = partial_b; g.sGb = M_out;
+    g.M = M_out; g.N = N_in; g.K = rows_per_slice; g.Ktot = n_rows;
+    g.vec = (((uintptr_t)dY & 15) == 0 && (ldy & 3) == 0 && (M_out & 3) == 0 ? 1 : 0) |
+            (((uintptr_t)X & 15) == 0 && (ldx & 3) == 0 && (N_in & 3) == 0 ? 2 : 0);
+    return launch<false, false, EPI_GRAD>(g, slices, (hipStream_t)stream);
 }

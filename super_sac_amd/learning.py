@@ -40,6 +40,18 @@ def _clip_and_step(adam, members, clip, slot_norm):
                                  arena.params.numel(), adam.ctl.ptr, st))
 
 
+def _encoder_step(encoder, encoder_optimizer, encoder_clip, dX, emb, ws, slot, dev):
+    """encoder backward from the critics' input gradients + clip + encoder_optimizer.step()
+    (learning.py:121,127-129); logs the (clipped) encoder gradient norm (learning.py:137)."""
+    from . import conv_encoder
+    eng = conv_encoder.conv_engine(encoder, dev)
+    B = dX.shape[1]
+    d_rep = ws.get("cu.drep", (B, emb))
+    torch.sum(dX[:, :, :emb], dim=0, out=d_rep)  # device plumbing: sum of N small slices
+    eng.backward(d_rep)
+    eng.optimizer_step(encoder_optimizer, encoder_clip, norm_out=slot[lu.L_ENC_GN:])
+
+
 def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimizer, log_alphas,
                   batch_size, gamma, critic_clip, encoder_clip, target_critic_ensemble_n,
                   weighted_bellman_temp, weight_type, pop, augmenter, encoder_lambda, random_process,
@@ -77,12 +89,24 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
                                        batch_size=batch_size, discrete=discrete, _slot=slot)
         o, a, r, o1, d = rd["primary_batch"]
         B = r.shape[0]
-        s_rep = lu.encode(agent.encoder, o)
         arena = agent.critics[i].arena(dev)
         N, qd = arena.n_nets, arena.out_dim
+        train_enc = not lu.is_identity(agent.encoder)
+        if train_enc:
+            # online encoder WITH gradient (learning.py:83): embedding goes straight into the critic input
+            assert E == 1, "trainable encoders are supported for ensemble_size == 1"
+            xin = ws.get(f"cu.x{i}", (B, arena.in_dim))
+            s_rep = lu.encode(agent.encoder, o, dst=xin, save=True)
+            if not discrete:
+                xin[:, s_rep.shape[1]:].copy_(a)
+        else:
+            s_rep = lu.encode(agent.encoder, o)
         shard = parallel.shard_of(agent)
         n_glob = N if shard is None else shard.num_critics  # loss is averaged over the GLOBAL ensemble
-        X, ldx = _critic_input(rd.get("_ssac"), ws, f"cu.x{i}", s_rep, a, discrete)
+        if train_enc:
+            X, ldx = xin, xin.stride(0)
+        else:
+            X, ldx = _critic_input(rd.get("_ssac"), ws, f"cu.x{i}", s_rep, a, discrete)
         popart = agent.popart[i]
         weight_ptr = 0
         if not isinstance(bw, float):
@@ -108,6 +132,11 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
                     C.byref(arena.desc()), X.data_ptr(), ldx, B, td.data_ptr(), weight_ptr, a.data_ptr(),
                     a.stride(0), pp, dopop, float(E * n_glob), h1.data_ptr(), h2.data_ptr(), q.data_ptr(),
                     dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), st))
+            if train_enc:  # dL/d(embedding) = sum over critics of dz1 W1[:, :emb], BEFORE W1 is updated
+                dX = ws.get(tag + ".dx", (N, B, arena.in_dim))
+                check(lib.ssac_mlp_layer_dgrad(C.byref(arena.desc()), 0, 0, N, dz1.data_ptr(), H, B * H, 0, 0, 0,
+                                               B, dX.data_ptr(), arena.in_dim, B * arena.in_dim, st))
+                _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, s_rep.shape[1], ws, slot, dev)
             engine.weight_grads(arena, X, ldx, 0, h1, h2, dq, dz2, dz1, B, adam=adam,
                                 adam_key=("critic", i), grads=grads, sumsq=ss)
             fused_logs.append((parts, N, tiles, B, n_glob))
@@ -116,8 +145,15 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
             check(lib.ssac_critic_loss_bwd(q.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0),
                                            td.data_ptr(), weight_ptr, pp, dopop, float(E * n_glob),
                                            dq.data_ptr(), slot.data_ptr(), st))
-            engine.mlp_backward(arena, dq, X, ldx, 0, h1, h2, B, ws, tag, adam=adam,
-                                adam_key=("critic", i), grads=grads, sumsq=ss)
+            if train_enc:
+                dX = engine.mlp_backward(arena, dq, X, ldx, 0, h1, h2, B, ws, tag, need_dx=True, update=False)
+                _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, s_rep.shape[1], ws, slot, dev)
+                dz2, dz1 = ws.get(tag + ".dz2", (N, B, arena.hidden)), ws.get(tag + ".dz1", (N, B, arena.hidden))
+                engine.weight_grads(arena, X, ldx, 0, h1, h2, dq, dz2, dz1, B, adam=adam,
+                                    adam_key=("critic", i), grads=grads, sumsq=ss)
+            else:
+                engine.mlp_backward(arena, dq, X, ldx, 0, h1, h2, B, ws, tag, adam=adam,
+                                    adam_key=("critic", i), grads=grads, sumsq=ss)
             fused_logs.append(None)
         if critic_clip:
             clip_members.append((arena, ("critic", i), grads, ss))

@@ -190,12 +190,25 @@ def sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, per=True):
 
 
 # ------------------------------------------------------------------------------------------
-def encode(encoder, obs_dict):
-    """state representation of the batch.  Identity encoders return the (strided) view."""
+def encode(encoder, obs_dict, dst=None, save=False):
+    """state representation of the batch: identity encoders return the (strided) view; pixel
+    encoders run the HIP conv engine (conv_encoder.py) and write into `dst[:, :emb]` when given."""
     key = getattr(encoder, "ssac_identity_key", None)
     if key is not None:
         return obs_dict[key]
-    raise NotImplementedError(f"{type(encoder).__name__}: this encoder has no HIP path yet")
+    from . import conv_encoder
+    img = obs_dict[getattr(encoder, "ssac_obs_key", "obs")]
+    eng = conv_encoder.conv_engine(encoder, img.device)
+    if eng is None:
+        raise NotImplementedError(f"{type(encoder).__name__}: this encoder has no HIP path")
+    if dst is None:
+        dst = torch.empty(img.shape[0], eng.emb, device=img.device)
+    eng.forward(img, dst, dst.stride(0), save)
+    return dst[:, :eng.emb]
+
+
+def is_identity(encoder):
+    return getattr(encoder, "ssac_identity_key", None) is not None
 
 
 def _row_stride(t):
@@ -241,7 +254,11 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
     kind = actor_kind(actor)
     st = engine.stream()
 
-    s1_rep = encode(target_agent.encoder, o1)
+    x1_pre = None
+    if not is_identity(target_agent.encoder) and kind != "discrete":
+        emb = target_agent.encoder.embedding_dim
+        x1_pre = ws.get(f"td.x1.{i}", (B, emb + actor.action_size))
+    s1_rep = encode(target_agent.encoder, o1, dst=x1_pre)
     S = s1_rep.shape[1]
     a_arena = engine.bind_arena(actor, "self", [actor], dev)
     fuse_sample = kind == "stochastic" and a_arena.fused and random_process is None
@@ -265,6 +282,8 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
         A = actor.action_size
         if bt is not None and bt.x1sa is not None and s1_rep.data_ptr() == bt.x1sa.data_ptr():
             x1 = bt.x1sa
+        elif x1_pre is not None:
+            x1 = x1_pre
         else:
             x1 = _concat_buffer(ws, f"td.x1.{i}", s1_rep, A)
         if kind == "stochastic":

@@ -132,3 +132,73 @@ class IdentityEncoder(Encoder):
 
     def forward(self, obs_dict):
         return obs_dict[self.ssac_identity_key]
+
+
+class _PixelEncoderBase(nn.Module):
+    """parameter container of a convolutional encoder; arithmetic lives in conv_encoder.py"""
+
+    def forward(self, obs):
+        from . import conv_encoder
+        engine.require_gpu(obs)
+        eng = conv_encoder.ConvEncoderEngine(self, obs.device) if "_ssac_conv" not in self.__dict__ \
+            else self.__dict__["_ssac_conv"]
+        self.__dict__["_ssac_conv"] = eng
+        out = torch.empty(obs.shape[0], self.embedding_dim, device=obs.device)
+        eng.forward(obs.float(), out, self.embedding_dim, save=False)
+        return out
+
+
+def _conv_out(n, k, s):
+    return (n - k) // s + 1
+
+
+class BigPixelEncoder(_PixelEncoderBase):
+    """cnns.py:37-69: conv3x3 s2, 3x conv3x3 s1 (32 ch), fc -> LayerNorm -> tanh; input x/255 - 0.5"""
+
+    def __init__(self, obs_shape, out_dim=50):
+        super().__init__()
+        c, h, w = obs_shape
+        self.conv1 = nn.Conv2d(c, 32, kernel_size=3, stride=2)
+        self.conv2 = nn.Conv2d(32, 32, kernel_size=3, stride=1)
+        self.conv3 = nn.Conv2d(32, 32, kernel_size=3, stride=1)
+        self.conv4 = nn.Conv2d(32, 32, kernel_size=3, stride=1)
+        h, w = _conv_out(h, 3, 2), _conv_out(w, 3, 2)
+        for _ in range(3):
+            h, w = _conv_out(h, 3, 1), _conv_out(w, 3, 1)
+        self.fc = nn.Linear(h * w * 32, out_dim)
+        self.ln = nn.LayerNorm(out_dim)
+        self.apply(weight_init)
+        self.embedding_dim = out_dim
+
+
+class SmallPixelEncoder(_PixelEncoderBase):
+    """cnns.py:72-103: conv8 s4 (32), conv4 s2 (64), conv3 s1 (64), fc; input x/255"""
+
+    def __init__(self, obs_shape, out_dim=50):
+        super().__init__()
+        c, h, w = obs_shape
+        self.conv1 = nn.Conv2d(c, 32, kernel_size=8, stride=4)
+        self.conv2 = nn.Conv2d(32, 64, kernel_size=4, stride=2)
+        self.conv3 = nn.Conv2d(64, 64, kernel_size=3, stride=1)
+        for k, s in ((8, 4), (4, 2), (3, 1)):
+            h, w = _conv_out(h, k, s), _conv_out(w, k, s)
+        self.fc = nn.Linear(h * w * 64, out_dim)
+        self.apply(weight_init)
+        self.embedding_dim = out_dim
+
+
+class PixelEncoder(Encoder):
+    """Encoder wrapper in the shape of the reference scripts' DMCPixelEncoder / AtariEncoder
+    (train_dmc_from_pixels.py:15-27, train_atari.py:9-20): obs_dict["obs"] -> conv block."""
+
+    def __init__(self, conv_block, key="obs"):
+        super().__init__()
+        self.conv_block = conv_block
+        self.ssac_obs_key = key
+
+    @property
+    def embedding_dim(self):
+        return self.conv_block.embedding_dim
+
+    def forward(self, obs_dict):
+        return self.conv_block(obs_dict[self.ssac_obs_key])

@@ -33,15 +33,32 @@ def load_fixture(name):
 
 
 def _buffers(cfg):
+    px = cfg.get("pixels")
+    if px:
+        return synth.synth_pixel_transitions(cfg["rows"], px["channels"], px["hw"],
+                                             n_actions=cfg["act"] if cfg["discrete"] else None,
+                                             act_dim=cfg["act"], seed=cfg["seed"] + 100)
     return synth.synth_transitions(cfg["rows"], cfg["obs"], cfg["act"], cfg["discrete"],
                                    seed=cfg["seed"] + 100, n_actions=cfg["act"])
+
+
+ENC_KEYS = {"big": ["c1w", "c1b", "c2w", "c2b", "c3w", "c3b", "c4w", "c4b", "fcw", "fcb", "lnw", "lnb"],
+            "small": ["c1w", "c1b", "c2w", "c2b", "c3w", "c3b", "fcw", "fcb"]}
+
+
+def _oracle_encoder(cfg):
+    px = cfg.get("pixels")
+    if not px:
+        return None
+    p = orc.make_conv_encoder(np.random.RandomState(cfg["seed"] + 7), px["kind"], px["channels"], px["emb"])
+    return {"kind": px["kind"], "key": "obs", "p": p}
 
 
 def _oracle_agent(cfg):
     oa = orc.AgentOracle(state_dim=cfg["obs"], act_dim=cfg["act"], hidden=cfg["hidden"],
                          num_critics=cfg["N"], ensemble_size=cfg["E"], discrete=cfg["discrete"],
                          actor_kind=cfg["actor"], log_std_low=cfg["lo"], log_std_high=cfg["hi"],
-                         popart=cfg["popart"], seed=cfg["seed"])
+                         popart=cfg["popart"], encoder=_oracle_encoder(cfg), seed=cfg["seed"])
     if cfg["popart"]:
         for p in oa.popart:
             p.min_steps = cfg.get("popart_min_steps", 1000)
@@ -75,11 +92,13 @@ def run_oracle(name):
     ot = oa.clone()
     copt = orc.AdamOracle(oa.critic_params(), lr=cfg["lr"])
     aopt = orc.AdamOracle(oa.actor_params(), lr=cfg["lr"])
-    eopt = orc.AdamOracle([], lr=1e-4)
+    px = cfg.get("pixels")
+    eopt = orc.AdamOracle(oa.encoder_params(), lr=px["enc_lr"] if px else 1e-4)
     init_alpha = max(cfg["init_alpha"], 1e-15)
     las = [torch.tensor([math.log(init_alpha)], requires_grad=True) for _ in range(E)]
     lopts = [orc.AdamOracle([la], lr=cfg["alpha_lr"], betas=(0.5, 0.999)) for la in las]
-    aug = orc.AugOracle("identity", B)
+    aug = orc.AugOracle(px["aug"] if px else "identity", B)
+    aug_mix = px["aug_mix"] if px else 0.0
     nscale = cfg["noise"]["scale"] if cfg["noise"] else None
     nclip = cfg["noise"]["clip"] if cfg["noise"] else None
     stochastic = cfg["actor"] == "stochastic"
@@ -88,9 +107,11 @@ def run_oracle(name):
     dicts = None
     for cyc in range(cfg["cycles"]):
         for k in range(cfg["utd"]):
+            if px:
+                aug.forced = [T(f"u{upd}_shift{i}") for i in range(E)]
             logs, dicts = orc.critic_update(
                 obuf, oa, ot, copt, eopt, las, B, cfg["gamma"], cfg["clip"], cfg["clip"], cfg["n"],
-                cfg["temp"], cfg["weight_type"], cfg["pop"], aug, aug_mix=0.0, noise_scale=nscale,
+                cfg["temp"], cfg["weight_type"], cfg["pop"], aug, aug_mix=aug_mix, noise_scale=nscale,
                 noise_clip=nclip, idx_list=[fx[f"u{upd}_idx{i}"] for i in range(E)],
                 eps_list=[T(f"u{upd}_eps{i}") for i in range(E)] if stochastic else None,
                 noise_list=[T(f"u{upd}_noise{i}") for i in range(E)] if cfg["noise"] else None,
@@ -104,6 +125,8 @@ def run_oracle(name):
                 rec[f"u{upd}_log:{key}"] = np.float64(val)
             if int(fx[f"u{upd}_polyak"]):
                 orc.soft_update(ot.critic_params(), oa.critic_params(), cfg["tau"])
+                if px:
+                    orc.soft_update(ot.encoder_params(), oa.encoder_params(), px["enc_tau"])
             upd += 1
         have_eps = not cfg["discrete"]
         alog = orc.online_actor_update(
@@ -119,6 +142,9 @@ def run_oracle(name):
                 rec[f"l{cyc}_log:{key}"] = np.float64(val)
     _finalise(rec, fx, oa.critic_params(), oa.actor_params(), ot.critic_params(),
               copt.m, copt.v, las)
+    if px:
+        rec["finalfp_encoder"] = _fingerprint(oa.encoder_params())
+        rec["finalfp_target_encoder"] = _fingerprint(ot.encoder_params())
     return rec
 
 
@@ -139,10 +165,12 @@ class DrawPlayer:
 
     def __init__(self, device):
         self.device = device
-        self.idx, self.sub, self.normal = [], [], []
+        self.idx, self.sub, self.normal, self.shift = [], [], [], []
 
     def install(self, rng_mod):
         self._saved = (rng_mod.draw_indices, rng_mod.draw_subset, rng_mod.draw_normal)
+        self._saved_shift = rng_mod.draw_drqv2_shift
+        rng_mod.draw_drqv2_shift = lambda b, pad: torch.from_numpy(self.shift.pop(0))
         rng_mod.draw_indices = lambda n, b: torch.from_numpy(self.idx.pop(0).astype(np.int64))
         rng_mod.draw_subset = lambda n, k: [int(v) for v in self.sub.pop(0)]
         rng_mod.draw_normal = lambda shape, device: torch.from_numpy(self.normal.pop(0)).to(self.device)
@@ -151,6 +179,7 @@ class DrawPlayer:
     def restore(self):
         m = self._mod
         m.draw_indices, m.draw_subset, m.draw_normal = self._saved
+        m.draw_drqv2_shift = self._saved_shift
 
 
 def build_engine_agent(cfg, device, shard=None):
@@ -164,7 +193,22 @@ def build_engine_agent(cfg, device, shard=None):
                  "deterministic": ssa.nets.ContinuousDeterministicActor,
                  "discrete": ssa.nets.DiscreteActor}[cfg["actor"]]
     critic_cls = ssa.nets.DiscreteCritic if cfg["discrete"] else ssa.nets.ContinuousCritic
-    ag = ssa.Agent(act_space_size=cfg["act"], encoder=ssa.nets.IdentityEncoder(cfg["obs"]),
+    px = cfg.get("pixels")
+    if px:
+        cls = ssa.nets.BigPixelEncoder if px["kind"] == "big" else ssa.nets.SmallPixelEncoder
+        conv = cls((px["channels"], px["hw"], px["hw"]), px["emb"])
+        ep = _oracle_encoder(cfg)["p"]
+        names = ["conv1", "conv2", "conv3", "conv4"] if px["kind"] == "big" else ["conv1", "conv2", "conv3"]
+        with torch.no_grad():
+            for i_, nm in enumerate(names, 1):
+                getattr(conv, nm).weight.copy_(ep[f"c{i_}w"]); getattr(conv, nm).bias.copy_(ep[f"c{i_}b"])
+            conv.fc.weight.copy_(ep["fcw"]); conv.fc.bias.copy_(ep["fcb"])
+            if px["kind"] == "big":
+                conv.ln.weight.copy_(ep["lnw"]); conv.ln.bias.copy_(ep["lnb"])
+        enc = ssa.nets.PixelEncoder(conv)
+    else:
+        enc = ssa.nets.IdentityEncoder(cfg["obs"])
+    ag = ssa.Agent(act_space_size=cfg["act"], encoder=enc,
                    actor_network_cls=actor_cls, critic_network_cls=critic_cls, discrete=cfg["discrete"],
                    ensemble_size=cfg["E"], num_critics=n_loc, ucb_bonus=0.0,
                    hidden_size=cfg["hidden"], auto_rescale_targets=cfg["popart"],
@@ -208,7 +252,8 @@ def run_engine(name, device="cuda", shard=None):
                             weight_decay=0, betas=(0.9, 0.999))
     aopt = torch.optim.Adam(chain(*(a.parameters() for a in agent.actors)), lr=cfg["lr"],
                             weight_decay=0, betas=(0.9, 0.999))
-    eopt = torch.optim.Adam(agent.encoder.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    px = cfg.get("pixels")
+    eopt = torch.optim.Adam(agent.encoder.parameters(), lr=px["enc_lr"] if px else 1e-4, betas=(0.9, 0.999))
     init_alpha = max(cfg["init_alpha"], 1e-15)
     las, lopts = [], []
     for _ in range(E):
@@ -216,7 +261,11 @@ def run_engine(name, device="cuda", shard=None):
         la.requires_grad = True
         las.append(la)
         lopts.append(torch.optim.Adam([la], lr=cfg["alpha_lr"], betas=(0.5, 0.999)))
-    aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(B)])
+    if px and px["aug"] == "drqv2":
+        aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.Drqv2Aug(B)])
+    else:
+        aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(B)])
+    aug_mix = px["aug_mix"] if px else 0.0
     rproc = None
     nclip = None
     if cfg["noise"]:
@@ -235,6 +284,8 @@ def run_engine(name, device="cuda", shard=None):
             for k in range(cfg["utd"]):
                 for i in range(E):
                     player.idx.append(fx[f"u{upd}_idx{i}"])
+                    if px:
+                        player.shift.append(fx[f"u{upd}_shift{i}"])
                     if stochastic:
                         player.normal.append(fx[f"u{upd}_eps{i}"])
                     if cfg["noise"]:
@@ -246,7 +297,7 @@ def run_engine(name, device="cuda", shard=None):
                     critic_clip=cfg["clip"], encoder_clip=cfg["clip"],
                     target_critic_ensemble_n=cfg["n"], weighted_bellman_temp=cfg["temp"],
                     weight_type=cfg["weight_type"], pop=cfg["pop"], augmenter=aug, encoder_lambda=0,
-                    aug_mix=0.0, discrete=cfg["discrete"], random_process=rproc, noise_clip=nclip,
+                    aug_mix=aug_mix, discrete=cfg["discrete"], random_process=rproc, noise_clip=nclip,
                     per=False, update_priorities=False, dr3_coeff=0.0)
                 for i in range(E):
                     assert np.array_equal(dicts[i]["priority_idxs"], fx[f"u{upd}_idx{i}"])
@@ -259,6 +310,8 @@ def run_engine(name, device="cuda", shard=None):
                 if int(fx[f"u{upd}_polyak"]):
                     for ac, tc in zip(agent.critics, target.critics):
                         ssa.learning_utils.soft_update(tc, ac, cfg["tau"])
+                    if px:
+                        ssa.learning_utils.soft_update(target.encoder, agent.encoder, px["enc_tau"])
                 upd += 1
             for i in range(E):
                 if not cfg["discrete"]:
@@ -267,7 +320,7 @@ def run_engine(name, device="cuda", shard=None):
                     player.normal.append(fx[f"a{cyc}_noise{i}"])
             alog = ssa.learning.online_actor_update(
                 buffer=buf, agent=agent, pop=cfg["pop"], actor_optimizer=aopt, log_alphas=las,
-                batch_size=B, aug_mix=0.0, clip=cfg["clip"], augmenter=aug, per=False,
+                batch_size=B, aug_mix=aug_mix, clip=cfg["clip"], augmenter=aug, per=False,
                 discrete=cfg["discrete"], random_process=rproc, noise_clip=nclip,
                 premade_replay_dicts=dicts, use_baseline=False)
             rec[f"a{cyc}_log:losses/actor_pg_loss"] = np.float64(float(alog["losses/actor_pg_loss"]))
@@ -277,11 +330,12 @@ def run_engine(name, device="cuda", shard=None):
                         player.normal.append(fx[f"l{cyc}_eps{i}"])
                 llog = ssa.learning.alpha_update(
                     buffer=buf, agent=agent, optimizers=lopts, batch_size=B, log_alphas=las,
-                    augmenter=aug, aug_mix=0.0, target_entropy=_target_entropy(cfg),
+                    augmenter=aug, aug_mix=aug_mix, target_entropy=_target_entropy(cfg),
                     premade_replay_dicts=dicts, discrete=cfg["discrete"])
                 for key, val in llog.items():
                     rec[f"l{cyc}_log:{key}"] = np.float64(float(val))
-        assert not player.idx and not player.sub and not player.normal, "unconsumed recorded draws"
+        assert not player.idx and not player.sub and not player.normal and not player.shift, \
+            "unconsumed recorded draws"
     finally:
         player.restore()
     crit = [p for i in range(E) for j in range(NL) for p in agent.critics[i].nets[j].parameters()]
@@ -297,6 +351,19 @@ def run_engine(name, device="cuda", shard=None):
                 m_list.append(ar.view(j, seg, m))
                 v_list.append(ar.view(j, seg, v))
     _finalise(rec, fx, crit, act, tcrit, m_list, v_list, las)
+    if px:
+        def enc_params(enc):
+            conv = enc.conv_block
+            names = ["conv1", "conv2", "conv3", "conv4"] if px["kind"] == "big" else ["conv1", "conv2", "conv3"]
+            out = []
+            for nm in names:
+                out += [getattr(conv, nm).weight, getattr(conv, nm).bias]
+            out += [conv.fc.weight, conv.fc.bias]
+            if px["kind"] == "big":
+                out += [conv.ln.weight, conv.ln.bias]
+            return out
+        rec["finalfp_encoder"] = _fingerprint(enc_params(agent.encoder))
+        rec["finalfp_target_encoder"] = _fingerprint(enc_params(target.encoder))
     return rec
 
 
@@ -324,7 +391,7 @@ def slice_fixture(fx, cfg, shard):
 
 
 # ------------------------------------------------------------------------------------------
-def compare(rec, fx, *, td_tol=2e-4, log_rtol=5e-4, par_tol=3e-5, who="backend"):
+def compare(rec, fx, *, td_tol=2e-4, log_rtol=5e-4, par_tol=3e-5, enc_tol=3e-3, who="backend"):
     """Assert rec (a backend's record) matches the reference fixture within the stated
     fp32 tolerances.  Returns the worst deviations for reporting."""
     worst = {"td": 0.0, "log": 0.0, "param": 0.0}
@@ -343,6 +410,13 @@ def compare(rec, fx, *, td_tol=2e-4, log_rtol=5e-4, par_tol=3e-5, who="backend")
             dv = float(abs(got - ref) / max(1.0, abs(ref)))
             worst["log"] = max(worst["log"], dv)
             assert dv <= log_rtol, f"{who}: {key} = {got} vs reference {ref}"
+        elif "encoder" in key and key.startswith("final"):
+            # Adam moves a weight by ~lr per step whatever the gradient's size, so the few encoder weights
+            # whose gradient is pure round-off (|g| ~ 1e-9) may differ by O(lr): bound the worst element by
+            # 2.5*lr*steps and require the typical element to agree to 1e-6.
+            err = np.abs(got - ref)
+            assert float(np.max(err)) <= enc_tol and float(np.median(err)) <= 1e-6, \
+                f"{who}: {key} max {np.max(err):.3e} median {np.median(err):.3e}"
         elif key.startswith("final") and key != "final_log_alpha":
             scale = 1.0 if not key.endswith("_v") else max(1e-12, float(np.max(np.abs(ref))))
             dv = float(np.max(np.abs(got - ref)) / scale)

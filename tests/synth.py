@@ -44,6 +44,24 @@ CASES = {
                     actor="stochastic", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
                     clip=None, tau=0.005, weight_type="sunrise", temp=20.0, noise=None,
                     cycles=1, utd=2, target_delay=2, seed=16),
+    # DrQv2 on pixels (dmc/drqv2.gin shape): BigPixelEncoder, deterministic actor + exploration
+    # noise, Drqv2Aug with aug_mix 1.0, "no target encoder" (encoder_tau 1.0, target_delay 1), n-step 3
+    "drqv2_pixels": dict(obs=50, act=4, hidden=64, N=2, n=2, E=1, B=8, rows=48, cap=64,
+                         lo=-10.0, hi=2.0, popart=False, pop=False, discrete=False,
+                         actor="deterministic", gamma=0.99 ** 3, lr=1e-4, alpha_lr=0.0, init_alpha=0.0,
+                         clip=None, tau=0.01, weight_type=None, temp=None,
+                         noise=dict(scale=0.5, clip=0.3), cycles=2, utd=1, target_delay=1, seed=17,
+                         pixels=dict(kind="big", channels=9, hw=84, emb=50, enc_lr=1e-4, enc_tau=1.0,
+                                     aug="drqv2", aug_mix=1.0)),
+    # Atari-style SAC-Discrete on pixels (atari/basic_online.gin shape): SmallPixelEncoder, clips 40,
+    # Drqv2Aug with aug_mix 0.9, Polyak'd target encoder
+    "atari_pixels": dict(obs=128, act=6, hidden=64, N=2, n=2, E=1, B=8, rows=48, cap=64,
+                         lo=-10.0, hi=2.0, popart=False, pop=False, discrete=True,
+                         actor="discrete", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                         clip=40.0, tau=0.005, weight_type=None, temp=None, noise=None,
+                         cycles=2, utd=2, target_delay=2, seed=18,
+                         pixels=dict(kind="small", channels=4, hw=84, emb=128, enc_lr=3e-4, enc_tau=0.01,
+                                     aug="drqv2", aug_mix=0.9)),
 }
 
 

@@ -117,6 +117,14 @@ int ssac_mlp_layer_wgrad(const ssac_mlp *nets, int layer, const int32_t *net_ids
                          float *grads, float *sumsq, int64_t sumsq_net_stride,
                          float *target, float tau, void *stream);
 
+/* fc2 AND fc1 weight gradients of every selected net in ONE launch (the small fc1 problem fills the CUs
+ * the fc2 tiles leave idle): H1/DZ2 feed fc2, X/DZ1 feed fc1 (all (n_sel x n_rows x hidden) except X).
+ * sumsq1 / sumsq0 point at the two layers' slots of the per-net sumsq row. */
+int ssac_mlp_wgrad_fc12(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X, int64_t ldx,
+                        int64_t x_net_stride, const float *H1, const float *DZ2, const float *DZ1, int n_rows,
+                        float *adam_m, float *adam_v, const ssac_adam_ctl *ctl, float *grads, float *sumsq1,
+                        float *sumsq0, int64_t sumsq_net_stride, float *target, float tau, void *stream);
+
 /* ---- elementwise Adam over a whole arena from stored gradients (clip path):
  * g *= ctl->clip_coef first (torch.nn.utils.clip_grad_norm_, learning.py:122-128). */
 int ssac_adam_step(float *params, float *adam_m, float *adam_v, const float *grads, int64_t n,

@@ -52,6 +52,7 @@ struct GemmArgs {
     int64_t sumsq_stride;
     int vec;                 // bit0: A rows are 16-byte aligned, bit1: B rows (row-contiguous operands)
     long long *dbg;          // optional s_memtime stamps of workgroup (0,0,0), thread 0
+    int grid_x, grid_y;      // tiles along N and M (filled by the launcher)
     int Ktot;                // > 0: batch entry e covers k in [e*K, min((e+1)*K, Ktot)) (split-K over blocks)
     int64_t sGb;             // EPI_GRAD: bias-gradient stride per batch entry (0 = same as sC)
 };
@@ -128,7 +129,7 @@ __device__ __forceinline__ float adam_elem(float p, float g, float &m, float &v,
 // kg, kg+KS, ... with its own LDS staging; the partial tiles are summed through LDS before the
 // epilogue.  It buys latency hiding (KS waves per SIMD) for launches with few tiles and a long K
 // (weight gradients: K = batch), where most CUs would otherwise run one wave per SIMD.
-#define GSTAMP(i) do { if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define GSTAMP(i) do { if (g.dbg && bx == 0 && by == 0 && bz == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -165,8 +166,7 @@ struct RcVecLoader {
 };
 
 template <bool A_KC, bool B_KC, int EPI, int KS>
-__global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int bx, int by, int bz) {
     const int tid_all = threadIdx.x;
     const int kg = tid_all >> 8, tid = tid_all & 255;
     // per K-group: two staging buffers (double buffering), each [A tile | B tile]
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-    const int e = blockIdx.z;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int e = bz;
+    const int m0 = by * BM, n0 = bx * BN;
 
     const float *A = g.A + batch_off(g.ids, g.idsA, e, g.sA);
     const float *B = g.B + batch_off(g.ids, g.idsB, e, g.sB);
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 
     float bias_acc = 0.0f;  // TN mode, column sums of A (bias gradient), threads < 64 of n-tile 0
-    const bool want_bias_grad = (EPI == EPI_ADAM || EPI == EPI_GRAD) && blockIdx.x == 0;
+    const bool want_bias_grad = (EPI == EPI_ADAM || EPI == EPI_GRAD) && bx == 0;
     const int Kloc = g.Ktot > 0 ? max(0, min(g.K, g.Ktot - e * g.K)) : g.K;
     const int nchunks = (Kloc + BK - 1) / BK;
     const int iters = (nchunks + KS - 1) / KS;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
             if (tid_all == 0) {
                 float tot = 0.0f;
                 for (int w = 0; w < 4 * KS; ++w) tot += red[w];
-                g.sumsq[(int64_t)e * g.sumsq_stride + blockIdx.y * gridDim.x + blockIdx.x] = tot;
+                g.sumsq[(int64_t)e * g.sumsq_stride + by * g.grid_x + bx] = tot;
             }
         }
         return;
@@ -379,6 +379,43 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
 }
 
 template <bool A_KC, bool B_KC, int EPI, int KS>
+__global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Two problems in ONE launch (the fc2 and fc1 weight gradients of an update): workgroups
+// [0, tiles0) work on g0, the rest on g1, so the small problem fills CUs the big one leaves idle.
+struct GemmPair { GemmArgs g0, g1; int tiles0; };
+
+template <bool A_KC, bool B_KC, int EPI, int KS>
+__global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const bool first = (int)blockIdx.x < p.tiles0;
+    const GemmArgs &g = first ? p.g0 : p.g1;
+    const int L = first ? blockIdx.x : blockIdx.x - p.tiles0;
+    const int per = g.grid_x * g.grid_y;
+    const int bz = L / per, rem = L - bz * per;
+    ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % g.grid_x, rem / g.grid_x, bz);
+}
+
+template <bool A_KC, bool B_KC, int EPI, int KS>
+int launch_pair_ks(GemmPair &p, int batch0, int batch1, hipStream_t st) {
+    static bool attr_set = false;
+    const size_t lds = sizeof(float) * (KS * 4 * TILE_FLOATS + 64 * KS);
+    if (!attr_set && lds > 48 * 1024) {
+        if (hipFuncSetAttribute((const void *)ens_gemm_pair_kernel<A_KC, B_KC, EPI, KS>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ssac_fail("ens_gemm_pair: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    p.tiles0 = p.g0.grid_x * p.g0.grid_y * batch0;
+    const int total = p.tiles0 + p.g1.grid_x * p.g1.grid_y * batch1;
+    hipLaunchKernelGGL((ens_gemm_pair_kernel<A_KC, B_KC, EPI, KS>), dim3(total), dim3(NTHREADS * KS), lds, st, p);
+    return ssac_check_launch("ens_gemm_pair");
+}
+
+template <bool A_KC, bool B_KC, int EPI, int KS>
 int launch_ks(const GemmArgs &g, dim3 grid, hipStream_t st) {
     static bool attr_set = false;
     const size_t lds = sizeof(float) * (KS * 4 * TILE_FLOATS + 64 * KS);
@@ -393,9 +430,11 @@ int launch_ks(const GemmArgs &g, dim3 grid, hipStream_t st) {
 }
 
 template <bool A_KC, bool B_KC, int EPI>
-int launch(const GemmArgs &g, int batch, hipStream_t st) {
+int launch(const GemmArgs &g_in, int batch, hipStream_t st) {
+    GemmArgs g = g_in;
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
     if (grid.x == 0 || grid.y == 0 || batch == 0) return 0;
+    g.grid_x = grid.x; g.grid_y = grid.y;
     const int tiles = grid.x * grid.y * batch;
     const int nchunks = (g.K + BK - 1) / BK;
     // K-split inside the workgroup when the launch cannot fill the chip with tiles alone
@@ -472,6 +511,63 @@ extern "C" int ssac_wgrad_tiles(const ssac_mlp *nets, int layer) {
     LayerGeom L;
     if (!nets || !layer_geom(nets, layer, L)) return -1;
     return ((L.rows + BM - 1) / BM) * ((L.cols + BN - 1) / BN);
+}
+
+namespace {
+bool build_wgrad_args(GemmArgs &g, const ssac_mlp *nets, int layer, const int32_t *net_ids,
+                      const float *X, int64_t ldx, int64_t x_net_stride, const float *dY, int64_t ldy,
+                      int64_t y_net_stride, int n_rows, float *adam_m, float *adam_v, const ssac_adam_ctl *ctl,
+                      float *grads, float *sumsq, int64_t sumsq_net_stride, float *target, float tau) {
+    LayerGeom L;
+    if (!nets || !layer_geom(nets, layer, L)) return false;
+    g = GemmArgs{};
+    g.A = dY; g.lda = ldy; g.sA = y_net_stride; g.idsA = 0;
+    g.B = X; g.ldb = ldx; g.sB = x_net_stride; g.idsB = 0;
+    g.C = nets->params + L.off_w; g.ldc = L.cols; g.sC = nets->net_stride; g.idsC = 1;
+    g.M = L.rows; g.N = L.cols; g.K = n_rows;
+    g.grid_x = (g.N + BN - 1) / BN; g.grid_y = (g.M + BM - 1) / BM;
+    g.ids = net_ids;
+    g.vec = (((uintptr_t)dY & 15) == 0 && (ldy & 3) == 0 && (y_net_stride & 3) == 0 && (L.rows & 3) == 0 ? 1 : 0) |
+            (((uintptr_t)X & 15) == 0 && (ldx & 3) == 0 && (x_net_stride & 3) == 0 && (L.cols & 3) == 0 ? 2 : 0);
+    g.pb = nets->params + L.off_b;
+    g.ctl = ctl; g.sumsq = sumsq; g.sumsq_stride = sumsq_net_stride; g.dbg = g_gemm_dbg; g.tau = tau;
+    if (grads) { g.gw = grads + L.off_w; g.gb = grads + L.off_b; }
+    else {
+        g.am = adam_m + L.off_w; g.av = adam_v + L.off_w; g.bm = adam_m + L.off_b; g.bv = adam_v + L.off_b;
+        if (target) { g.tw = target + L.off_w; g.tb = target + L.off_b; }
+    }
+    return true;
+}
+}  // namespace
+
+// fc2 and fc1 weight gradients (+Adam/Polyak or gradient store) of every selected net in ONE launch.
+// sumsq1 / sumsq0: the layers' slots inside the per-net sumsq row (see ssac_mlp_layer_wgrad).
+extern "C" int ssac_mlp_wgrad_fc12(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
+                                   int64_t ldx, int64_t x_net_stride, const float *H1, const float *DZ2,
+                                   const float *DZ1, int n_rows, float *adam_m, float *adam_v,
+                                   const ssac_adam_ctl *ctl, float *grads, float *sumsq1, float *sumsq0,
+                                   int64_t sumsq_net_stride, float *target, float tau, void *stream) {
+    if (n_sel < 0 || n_sel > SSAC_MAX_NETS) return ssac_fail("ssac_mlp_wgrad_fc12: n_sel out of range");
+    if (!grads && (!adam_m || !adam_v || !ctl)) return ssac_fail("ssac_mlp_wgrad_fc12: Adam state missing");
+    if (n_sel == 0 || n_rows <= 0) return 0;
+    const int H = nets->hidden;
+    GemmPair p{};
+    if (!build_wgrad_args(p.g0, nets, 1, net_ids, H1, H, (int64_t)n_rows * H, DZ2, H, (int64_t)n_rows * H, n_rows,
+                          adam_m, adam_v, ctl, grads, sumsq1, sumsq_net_stride, target, tau) ||
+        !build_wgrad_args(p.g1, nets, 0, net_ids, X, ldx, x_net_stride, DZ1, H, (int64_t)n_rows * H, n_rows,
+                          adam_m, adam_v, ctl, grads, sumsq0, sumsq_net_stride, target, tau))
+        return ssac_fail("ssac_mlp_wgrad_fc12: bad arena");
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles = (p.g0.grid_x * p.g0.grid_y + p.g1.grid_x * p.g1.grid_y) * n_sel;
+    const int nchunks = (n_rows + BK - 1) / BK;
+    if (grads) {
+        if (tiles <= 256 && nchunks >= 8) return launch_pair_ks<false, false, EPI_GRAD, 4>(p, n_sel, n_sel, st);
+        if (tiles <= 512 && nchunks >= 4) return launch_pair_ks<false, false, EPI_GRAD, 2>(p, n_sel, n_sel, st);
+        return launch_pair_ks<false, false, EPI_GRAD, 1>(p, n_sel, n_sel, st);
+    }
+    if (tiles <= 256 && nchunks >= 8) return launch_pair_ks<false, false, EPI_ADAM, 4>(p, n_sel, n_sel, st);
+    if (tiles <= 512 && nchunks >= 4) return launch_pair_ks<false, false, EPI_ADAM, 2>(p, n_sel, n_sel, st);
+    return launch_pair_ks<false, false, EPI_ADAM, 1>(p, n_sel, n_sel, st);
 }
 
 extern "C" int ssac_mlp_layer_wgrad(const ssac_mlp *nets, int layer, const int32_t *net_ids, int n_sel,

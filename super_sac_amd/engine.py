@@ -19,6 +19,20 @@ PROFILE = {"tag": None, "events": []}
 USE_FUSED = True  # tests flip this to exercise the per-layer kernels on fused-capable shapes
 
 
+class CaptureCtx:
+    """static device inputs of one captured update (learning.py, graph replay): while CAPTURE is set,
+    the host-RNG draw sites hand out these buffers instead of drawing, so the launch sequence that gets
+    recorded into a HIP graph reads its per-update inputs from fixed addresses."""
+
+    def __init__(self, idx_cpu, idx_dev, ids, ids_dev, normals, logblk):
+        self.idx_cpu, self.idx_dev, self.ids, self.ids_dev = idx_cpu, idx_dev, ids, ids_dev
+        self.normals = list(normals)
+        self.logblk = logblk
+
+
+CAPTURE = None
+
+
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
@@ -276,12 +290,10 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
         check(lib.ssac_mlp_layer_wgrad(C.byref(d), 2, ids, n_sel, h2.data_ptr(), H, n_rows * H,
                                        dY.data_ptr(), O, n_rows * O, n_rows, _ptr(m), _ptr(v), ctl,
                                        _ptr(grads), ssp(2), ttot, _ptr(target), float(tau), st))
-    check(lib.ssac_mlp_layer_wgrad(C.byref(d), 1, ids, n_sel, h1.data_ptr(), H, n_rows * H,
-                                   dz2.data_ptr(), H, n_rows * H, n_rows, _ptr(m), _ptr(v), ctl,
-                                   _ptr(grads), ssp(1), ttot, _ptr(target), float(tau), st))
-    check(lib.ssac_mlp_layer_wgrad(C.byref(d), 0, ids, n_sel, X.data_ptr(), ldx, x_net_stride,
-                                   dz1.data_ptr(), H, n_rows * H, n_rows, _ptr(m), _ptr(v), ctl,
-                                   _ptr(grads), ssp(0), ttot, _ptr(target), float(tau), st))
+    # fc2 and fc1 weight gradients share one launch
+    check(lib.ssac_mlp_wgrad_fc12(C.byref(d), ids, n_sel, X.data_ptr(), ldx, x_net_stride, h1.data_ptr(),
+                                  dz2.data_ptr(), dz1.data_ptr(), n_rows, _ptr(m), _ptr(v), ctl, _ptr(grads),
+                                  ssp(1), ssp(0), ttot, _ptr(target), float(tau), st))
 
 
 def mlp_backward(arena, dY, X, ldx, x_net_stride, h1, h2, n_rows, ws, tag, *, adam=None,

@@ -52,11 +52,102 @@ def _encoder_step(encoder, encoder_optimizer, encoder_clip, dX, emb, ws, slot, d
     eng.optimizer_step(encoder_optimizer, encoder_clip, norm_out=slot[lu.L_ENC_GN:])
 
 
+USE_GRAPHS = True   # replay the critic update's launch sequence as one HIP graph when it is static
+GRAPH_WARMUP = 3    # eager calls before capture (workspace allocation, arena binding, kernel attributes)
+
+
+class _Graphed:
+    def __init__(self):
+        self.calls = 0
+        self.graph = None
+
+
 def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimizer, log_alphas,
                   batch_size, gamma, critic_clip, encoder_clip, target_critic_ensemble_n,
                   weighted_bellman_temp, weight_type, pop, augmenter, encoder_lambda, random_process,
                   noise_clip, aug_mix=0.75, discrete=False, per=False, update_priorities=False,
                   dr3_coeff=0.0):
+    """learning.py:18-141.  When the launch sequence is static (one ensemble member, vector
+    observations, uniform sampling, single rank) it is captured once into a HIP graph and replayed:
+    the host then only draws the indices / REDQ subset / noise, uploads them into fixed-address
+    buffers and issues one graph launch, instead of ~15 kernel launches."""
+    kw = dict(buffer=buffer, agent=agent, target_agent=target_agent, critic_optimizer=critic_optimizer,
+              encoder_optimizer=encoder_optimizer, log_alphas=log_alphas, batch_size=batch_size, gamma=gamma,
+              critic_clip=critic_clip, encoder_clip=encoder_clip,
+              target_critic_ensemble_n=target_critic_ensemble_n, weighted_bellman_temp=weighted_bellman_temp,
+              weight_type=weight_type, pop=pop, augmenter=augmenter, encoder_lambda=encoder_lambda,
+              random_process=random_process, noise_clip=noise_clip, aug_mix=aug_mix, discrete=discrete, per=per,
+              update_priorities=update_priorities, dr3_coeff=dr3_coeff)
+    graphable = (USE_GRAPHS and engine.CAPTURE is None and agent.ensemble_size == 1 and not per
+                 and lu.is_identity(agent.encoder) and parallel.shard_of(agent) is None
+                 and random_process is None and torch.cuda.is_available())
+    if not graphable:
+        return _critic_update_eager(**kw)
+    key = (id(buffer), id(target_agent), id(critic_optimizer), batch_size, float(gamma), critic_clip,
+           target_critic_ensemble_n, bool(pop), bool(discrete), id(log_alphas[0]), engine.USE_FUSED)
+    cache = agent.__dict__.setdefault("_ssac_graphs", {})  # lives and dies with the agent
+    gs = cache.get(key)
+    if gs is None:
+        gs = cache[key] = _Graphed()
+        gs.refs = (buffer, target_agent, critic_optimizer, log_alphas[0])  # pin the ids used in the key
+    gs.calls += 1
+    if gs.calls <= GRAPH_WARMUP or len(buffer) < batch_size:
+        return _critic_update_eager(**kw)
+    return _critic_update_graphed(gs, kw)
+
+
+def _critic_update_graphed(gs, kw):
+    buffer, agent, B = kw["buffer"], kw["agent"], kw["batch_size"]
+    dev = kw["log_alphas"][0].device
+    actor = agent.actors[0]
+    kind = lu.actor_kind(actor)
+    n_sub = kw["target_critic_ensemble_n"]
+    # ---- host draws, in the reference's order: indices -> (augmentation: none here) -> noise -> subset
+    buffer.total_sample_calls += 1
+    idx_cpu = rng.draw_indices(len(buffer), B)
+    eps = rng.draw_normal((B, actor.action_size), dev) if kind == "stochastic" else None
+    ids = rng.draw_subset(agent.num_critics, n_sub)
+    if gs.graph is None:
+        gs.idx_dev = torch.empty(B, dtype=torch.int64, device=dev)
+        gs.ids_dev = torch.empty(n_sub, dtype=torch.int32, device=dev)
+        gs.eps_dev = torch.empty(B, actor.action_size, device=dev) if eps is not None else None
+        gs.logblk = torch.zeros(lu.LOG_WIDTH, device=dev)
+        gs.stager = buffer._stager
+        ctx = engine.CaptureCtx(idx_cpu, gs.idx_dev, ids, gs.ids_dev,
+                                [gs.eps_dev] if eps is not None else [], gs.logblk)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        engine.CAPTURE = ctx
+        try:
+            with torch.cuda.graph(graph):
+                logs, dicts = _critic_update_eager(**kw)
+        finally:
+            engine.CAPTURE = None
+        gs.graph, gs.dicts = graph, dicts
+        base = gs.logblk.data_ptr()
+        gs.log_index = {k: (v.data_ptr() - base) // 4 for k, v in logs.items()}
+    # ---- per-update inputs into the fixed-address buffers, then ONE graph launch
+    gs.idx_dev.copy_(gs.stager.upload(idx_cpu), non_blocking=True)
+    gs.ids_dev.copy_(gs.stager.upload(torch.tensor(ids, dtype=torch.int32), tag="sub"), non_blocking=True)
+    if eps is not None:
+        gs.eps_dev.copy_(eps, non_blocking=True)
+    gs.graph.replay()
+    rng.choice(agent.critics)  # keep the Python RNG stream in step with learning.py:135
+    ring = lu.ring_for(dev)
+    slot = ring.buf[ring.advance()]
+    slot.copy_(gs.logblk, non_blocking=True)
+    logs = {k: slot[i] for k, i in gs.log_index.items()}
+    rd = gs.dicts[0]
+    rd["priority_idxs"] = idx_cpu.numpy()
+    rd["_subset"] = ids
+    return logs, gs.dicts
+
+
+def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_optimizer, log_alphas,
+                         batch_size, gamma, critic_clip, encoder_clip, target_critic_ensemble_n,
+                         weighted_bellman_temp, weight_type, pop, augmenter, encoder_lambda, random_process,
+                         noise_clip, aug_mix=0.75, discrete=False, per=False, update_priorities=False,
+                         dr3_coeff=0.0):
     engine.require_gpu()
     if encoder_lambda:
         raise NotImplementedError("encoder invariance loss (SURVEY 8(f) rank 4) is not accelerated")
@@ -166,7 +257,7 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
     # never receives a gradient, nets/__init__.py:24), so encoder_optimizer.step() is a no-op.
     logs["losses/last_member_critic_td_error"] = slot[lu.L_TD_ERR]
     logs["losses/critic_overall_loss"] = slot[lu.L_CRITIC_LOSS]
-    pick = rng.choice(agent.critics)  # same Python-RNG draw as learning.py:135
+    pick = agent.critics[0] if engine.CAPTURE is not None else rng.choice(agent.critics)  # learning.py:135
     k = next(j for j, c in enumerate(agent.critics) if c is pick)
     clip_ctl = adam.ctl.ptr if critic_clip else 0
     done_norm = False

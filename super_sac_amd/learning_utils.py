@@ -34,6 +34,10 @@ class LogRing:
         self.buf = torch.zeros(slots, LOG_WIDTH, dtype=torch.float32, device=device)
         self.k = 0
 
+    def advance(self):
+        self.k = (self.k + 1) % self.buf.shape[0]
+        return self.k
+
     def next(self, adam=None):
         """fresh zeroed block; the same launch advances `adam`'s step when given."""
         self.k = (self.k + 1) % self.buf.shape[0]
@@ -46,11 +50,33 @@ class LogRing:
 _rings = {}
 
 
+def draw_normal(shape, device):
+    """action-noise draw site (honours an active graph capture)."""
+    if engine.CAPTURE is not None:
+        return engine.CAPTURE.normals.pop(0)
+    return rng.draw_normal(shape, device)
+
+
+def draw_subset(num_critics, k):
+    if engine.CAPTURE is not None:
+        return list(engine.CAPTURE.ids)
+    return rng.draw_subset(num_critics, k)
+
+
 def log_block(device, adam=None):
+    if engine.CAPTURE is not None:
+        blk = engine.CAPTURE.logblk
+        check(lib.ssac_begin_update(blk.data_ptr(), LOG_WIDTH, 0 if adam is None else adam.ctl.ptr,
+                                    engine.stream()))
+        return blk
+    return ring_for(device).next(adam)
+
+
+def ring_for(device):
     ring = _rings.get(device)
     if ring is None:
         ring = _rings[device] = LogRing(device)
-    return ring.next(adam)
+    return ring
 
 
 _ones = {}
@@ -233,6 +259,8 @@ def actor_kind(actor):
 
 
 def _upload_ids(ws, ids, device, tag):
+    if engine.CAPTURE is not None:
+        return engine.CAPTURE.ids_dev
     stager = ws.__dict__.setdefault("_stager", None)
     if stager is None:
         from .replay import _IndexStager
@@ -274,7 +302,7 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
     logp = ws.get(f"td.logp{i}", (B,))
     use_entropy = 0
     if kind == "discrete":
-        ids = rng.draw_subset(N, ensemble_n)
+        ids = draw_subset(N, ensemble_n)
         q1, n_q = _subset_q(ws, shard, t_arena, ids, s1_rep, _row_stride(s1_rep), B, dev, f"td.c{i}")
         lp_ptr, qd = aout.data_ptr(), t_arena.out_dim
         a_s1 = None
@@ -289,7 +317,7 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
         if kind == "stochastic":
             if random_process is not None:
                 raise NotImplementedError("exploration noise on a stochastic actor")
-            eps = rng.draw_normal((B, A), dev)
+            eps = draw_normal((B, A), dev)
             if fuse_sample:
                 # actor forward + sample + log pi: ONE launch, a' lands in the [s'|a'] buffer
                 check(lib.ssac_actor_sample_fused(C.byref(a_arena.desc()), s1_rep.data_ptr(),
@@ -305,14 +333,14 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
             noise = None
             scale = 0.0
             if random_process is not None:
-                noise = rng.draw_normal((B, A), dev)
+                noise = draw_normal((B, A), dev)
                 scale = float(random_process.current_scale)
             else:
                 raise NotImplementedError("deterministic actor without an exploration process")
             check(lib.ssac_det_action_fwd(aout.data_ptr(), A, 0, 0.0, noise.data_ptr(), scale,
                                           float(noise_clip) if noise_clip is not None else 0.0, B, A,
                                           x1.data_ptr(), S + A, S, st))
-        ids = rng.draw_subset(N, ensemble_n)
+        ids = draw_subset(N, ensemble_n)
         q1, n_q = _subset_q(ws, shard, t_arena, ids, x1, S + A, B, dev, f"td.c{i}")
         lp_ptr, qd = logp.data_ptr(), 1
         a_s1 = x1[:, S:]

@@ -49,6 +49,79 @@ class _IndexStager:
         return dev
 
 
+class PrioritySampler:
+    """Proportional prioritised replay index sampler (mirror of replay.py:140-190, 207-353).
+
+    Host-side by design: the draw consumes numpy's GLOBAL generator (replay.py:166) and the trees are
+    float64, so keeping them in numpy makes the index stream and the importance weights bit-identical
+    to the reference; only the gather of the selected rows runs on the device.  Sum and min trees are
+    stored as implicit binary heaps over the next power of two >= capacity (replay.py:147-152)."""
+
+    def __init__(self, capacity, alpha=0.6, beta=1.0):
+        cap = 1
+        while cap < capacity:
+            cap *= 2
+        self.cap, self.alpha, self.beta = cap, alpha, beta
+        self.sum_tree = np.zeros(2 * cap, dtype=np.float64)
+        self.min_tree = np.full(2 * cap, np.inf, dtype=np.float64)
+        self._max_priority = 1.0
+
+    def _assign(self, rows, values):
+        rows = np.atleast_1d(np.asarray(rows, dtype=np.int64))
+        leaves = rows + self.cap
+        self.sum_tree[leaves] = values
+        self.min_tree[leaves] = values
+        nodes = np.unique(leaves >> 1)
+        while nodes.size:
+            self.sum_tree[nodes] = self.sum_tree[2 * nodes] + self.sum_tree[2 * nodes + 1]
+            self.min_tree[nodes] = np.minimum(self.min_tree[2 * nodes], self.min_tree[2 * nodes + 1])
+            if nodes[0] <= 1:
+                break
+            nodes = np.unique(nodes >> 1)
+
+    def push_rows(self, rows, priorities=None):
+        pr = self._max_priority if priorities is None else priorities
+        self._assign(rows, np.asarray(pr, dtype=np.float64) ** self.alpha)
+
+    def update_priorities(self, idxes, priorities, n_filled):
+        priorities = np.asarray(priorities, dtype=np.float64)
+        assert len(idxes) == len(priorities)
+        assert np.min(priorities) > 0
+        assert np.min(idxes) >= 0
+        assert np.max(idxes) < n_filled
+        self._assign(idxes, priorities ** self.alpha)
+        self._max_priority = max(self._max_priority, float(np.max(priorities)))
+
+    def _range_sum(self, start, end_exclusive):
+        return float(self.sum_tree[self.cap + start: self.cap + end_exclusive].sum())
+
+    def descend(self, mass):
+        """largest i with prefix_sum(i) <= mass, for a vector of masses (replay.py:297-336)."""
+        mass = np.array(mass, dtype=np.float64)
+        node = np.ones(len(mass), dtype=np.int64)
+        while True:
+            inner = node < self.cap
+            if not inner.any():
+                break
+            left = np.where(inner, 2 * node, node)
+            lsum = self.sum_tree[left]
+            right = inner & (lsum <= mass)
+            mass = np.where(right, mass - lsum, mass)
+            node = np.where(inner, left + right.astype(np.int64), node)
+        return node - self.cap
+
+    def sample(self, n_filled, batch_size):
+        # the reference sums leaves [0, n_filled-2] (SegmentTree.reduce makes `end` exclusive after -1)
+        total = self._range_sum(0, n_filled - 1)
+        mass = np.random.random(size=batch_size) * total
+        idx = self.descend(mass)
+        p_min = self.min_tree[1] / self.sum_tree[1]
+        max_weight = (p_min * n_filled) ** (-self.beta)
+        p_sample = self.sum_tree[self.cap + idx] / self.sum_tree[1]
+        weights = (p_sample * n_filled) ** (-self.beta) / max_weight
+        return idx, weights
+
+
 class ReplayBufferStorage:
     def __init__(self, size, state_example, act_example, device):
         self.device = device
@@ -109,7 +182,7 @@ class ReplayBuffer:
         self.total_sample_calls = 0
         self.device = torch.device(device) if device is not None else _default_device
         self._stager = None
-        self._per = None
+        self._per = PrioritySampler(size, alpha, beta)
 
     def __len__(self):
         return len(self._storage) if self._storage is not None else 0
@@ -142,6 +215,8 @@ class ReplayBuffer:
     # ---- sample path -----------------------------------------------------------------------
     def draw_uniform_indices(self, batch_size):
         """(cpu int64 tensor, device int64 tensor) of replay.py:122's torch.randint draw."""
+        if engine.CAPTURE is not None:  # graph capture: fixed-address index buffer, no draw
+            return engine.CAPTURE.idx_cpu, engine.CAPTURE.idx_dev
         self.total_sample_calls += 1
         idx = rng.draw_indices(len(self._storage), batch_size)
         return idx, self._stager.upload(idx)
@@ -160,3 +235,13 @@ class ReplayBuffer:
     def sample_uniform(self, batch_size):
         idx, idx_dev = self.draw_uniform_indices(batch_size)
         return self.gather(idx_dev, batch_size), idx.numpy()
+
+    def sample(self, batch_size):
+        """prioritised draw (replay.py:171-177): (batch, float64 importance weights, indices)."""
+        self.total_sample_calls += 1
+        idxes, weights = self._per.sample(len(self._storage), batch_size)
+        idx_dev = self._stager.upload(torch.from_numpy(idxes))
+        return self.gather(idx_dev, batch_size), torch.from_numpy(weights), idxes
+
+    def update_priorities(self, idxes, priorities):
+        self._per.update_priorities(idxes, priorities, len(self._storage))

@@ -50,3 +50,57 @@ def test_grad_norm_log_and_lazy_logs():
     assert rec["u0_log:gradients/critic_random_grad"] > 0
     assert rec["u0_log:gradients/encoder_criticloss_grad_norm"] == 0.0
     assert torch.cuda.is_available()
+
+
+def test_graph_replay_equals_eager_launches():
+    """20 critic updates (+Polyak) with the captured HIP graph vs. plain launches: same parameters."""
+    import copy
+    import math
+    import random
+    from itertools import chain
+
+    import torch
+    import super_sac_amd as ssa
+
+    def run(use_graphs):
+        old = ssa.learning.USE_GRAPHS
+        ssa.learning.USE_GRAPHS = use_graphs
+        try:
+            torch.manual_seed(3); np.random.seed(3); random.seed(3)
+            dev = torch.device("cuda")
+            agent = ssa.Agent(act_space_size=6, encoder=ssa.nets.IdentityEncoder(17),
+                              actor_network_cls=ssa.nets.ContinuousStochasticActor,
+                              critic_network_cls=ssa.nets.ContinuousCritic, ensemble_size=1, num_critics=4,
+                              hidden_size=64, auto_rescale_targets=False, log_std_low=-5.0, log_std_high=2.0)
+            agent.to(dev)
+            target = copy.deepcopy(agent)
+            buf = ssa.replay.ReplayBuffer(4096, device=dev)
+            buf.load_experience(*synth.synth_transitions(2000, 17, 6, seed=5))
+            copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=3e-4)
+            eopt = torch.optim.Adam(agent.encoder.parameters(), lr=1e-4)
+            la = torch.Tensor([math.log(0.1)]).to(dev); la.requires_grad = True
+            aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(128)])
+            last = None
+            for k in range(20):
+                logs, dicts = ssa.learning.critic_update(
+                    buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt, encoder_optimizer=eopt,
+                    log_alphas=[la], batch_size=128, gamma=0.99, critic_clip=None, encoder_clip=None,
+                    target_critic_ensemble_n=2, weighted_bellman_temp=None, weight_type=None, pop=False,
+                    augmenter=aug, encoder_lambda=0, aug_mix=0.0, discrete=False, random_process=None,
+                    noise_clip=None, per=False, update_priorities=False, dr3_coeff=0.0)
+                if k % 2 == 0:
+                    ssa.learning_utils.soft_update(target.critics[0], agent.critics[0], 0.005)
+                last = (float(logs["losses/critic_overall_loss"]), float(logs["td_targets/mean_td_target_0"]),
+                        dicts[0]["priority_idxs"].copy())
+            params = torch.cat([p.detach().flatten() for p in agent.critics[0].parameters()]).cpu().numpy()
+            tparams = torch.cat([p.detach().flatten() for p in target.critics[0].parameters()]).cpu().numpy()
+            return params, tparams, last, buf.total_sample_calls
+        finally:
+            ssa.learning.USE_GRAPHS = old
+
+    pe, te, le, ce = run(False)
+    pg, tg, lg, cg = run(True)
+    assert ce == cg == 20
+    assert np.array_equal(le[2], lg[2]), "replay indices must not depend on the launch mechanism"
+    assert np.array_equal(pe, pg) and np.array_equal(te, tg), "graph replay must be bit-identical to eager launches"
+    assert le[0] == lg[0] and le[1] == lg[1]

@@ -162,3 +162,21 @@ def test_update_cases_match_reference(name):
     rec = case_runner.run_oracle(name)
     worst = case_runner.compare(rec, case_runner.load_fixture(name), who=f"oracle[{name}]")
     assert worst["param"] < 3e-5
+
+
+def test_product_priority_sampler_matches_reference_fixture():
+    """super_sac_amd.replay.PrioritySampler (host trees of the product) against the reference's draws."""
+    from super_sac_amd.replay import PrioritySampler
+    f = fx("per")
+    ps = PrioritySampler(400, 0.6, 1.0)
+    ps.push_rows(np.arange(300))
+    np.random.seed(int(f["np_seed"]))
+    i0, w0 = ps.sample(300, 32)
+    assert np.array_equal(i0, f["i0"]) and np.allclose(w0, f["w0"], rtol=1e-12)
+    ps.update_priorities(i0, f["prios"], 300)
+    i1, w1 = ps.sample(300, 32)
+    assert np.array_equal(i1, f["i1"]) and np.allclose(w1, f["w1"], rtol=1e-12)
+    with pytest.raises(AssertionError):
+        ps.update_priorities(np.array([0, 1]), np.array([1.0, 0.0]), 300)   # priorities must be > 0
+    with pytest.raises(AssertionError):
+        ps.update_priorities(np.array([300]), np.array([1.0]), 300)          # index range (replay.py:187)

@@ -41,6 +41,32 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_side = {}
+
+
+class side_stream:
+    """run the enclosed launches on a second HIP stream, forked from and joined back into the current
+    one (inside a graph capture this becomes a parallel branch): used to overlap small independent
+    kernels with the big GEMM launches instead of queueing them behind."""
+
+    def __init__(self, device):
+        s = _side.get(device)
+        if s is None:
+            s = _side[device] = torch.cuda.Stream(device=device)
+        self.s = s
+
+    def __enter__(self):
+        self.main = torch.cuda.current_stream()
+        self.s.wait_stream(self.main)
+        self.ctx = torch.cuda.stream(self.s)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        self.ctx.__exit__(*a)
+        self.main.wait_stream(self.s)
+
+
 def require_gpu(t=None):
     if not torch.cuda.is_available():
         raise RuntimeError("super_sac_amd runs its update path only on an MI355X/ROCm device; "
@@ -284,8 +310,11 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
     def ssp(layer):
         return 0 if sumsq is None else sumsq.data_ptr() + 4 * off[layer]
     if O <= 16:
-        check(lib.ssac_head_wgrad(C.byref(d), ids, n_sel, h2.data_ptr(), dY.data_ptr(), n_rows, _ptr(m),
-                                  _ptr(v), ctl, _ptr(grads), ssp(2), ttot, _ptr(target), float(tau), st))
+        # the head's weight gradient is an independent VALU kernel: run it beside the GEMM launch below
+        with side_stream(arena.params.device):
+            check(lib.ssac_head_wgrad(C.byref(d), ids, n_sel, h2.data_ptr(), dY.data_ptr(), n_rows, _ptr(m),
+                                      _ptr(v), ctl, _ptr(grads), ssp(2), ttot, _ptr(target), float(tau),
+                                      stream()))
     else:
         check(lib.ssac_mlp_layer_wgrad(C.byref(d), 2, ids, n_sel, h2.data_ptr(), H, n_rows * H,
                                        dY.data_ptr(), O, n_rows * O, n_rows, _ptr(m), _ptr(v), ctl,

@@ -102,19 +102,28 @@ def _critic_update_graphed(gs, kw):
     actor = agent.actors[0]
     kind = lu.actor_kind(actor)
     n_sub = kw["target_critic_ensemble_n"]
+    if gs.graph is None:
+        # one fixed device block holds the per-update inputs: [B int64 indices | n int32 subset ids (padded)]
+        n_pad = (n_sub + 1) // 2 * 2
+        gs.inbuf = torch.zeros(8 * B + 4 * n_pad, dtype=torch.uint8, device=dev)
+        gs.idx_dev = gs.inbuf[:8 * B].view(torch.int64)
+        gs.ids_dev = gs.inbuf[8 * B:].view(torch.int32)[:n_sub]
+        gs.host = torch.zeros(8 * B + 4 * n_pad, dtype=torch.uint8)
+        gs.host_idx = gs.host[:8 * B].view(torch.int64)
+        gs.host_ids = gs.host[8 * B:].view(torch.int32)
+        from .replay import _PinnedRing
+        gs.ring = _PinnedRing(gs.host.numel())
+        gs.eps_dev = torch.empty(B, actor.action_size, device=dev) if kind == "stochastic" else None
+        gs.logblk = torch.zeros(lu.LOG_WIDTH, device=dev)
     # ---- host draws, in the reference's order: indices -> (augmentation: none here) -> noise -> subset
     buffer.total_sample_calls += 1
     idx_cpu = rng.draw_indices(len(buffer), B)
-    eps = rng.draw_normal((B, actor.action_size), dev) if kind == "stochastic" else None
+    if kind == "stochastic":
+        rng.draw_normal_into(gs.eps_dev)  # noise straight into the graph's input buffer
     ids = rng.draw_subset(agent.num_critics, n_sub)
     if gs.graph is None:
-        gs.idx_dev = torch.empty(B, dtype=torch.int64, device=dev)
-        gs.ids_dev = torch.empty(n_sub, dtype=torch.int32, device=dev)
-        gs.eps_dev = torch.empty(B, actor.action_size, device=dev) if eps is not None else None
-        gs.logblk = torch.zeros(lu.LOG_WIDTH, device=dev)
-        gs.stager = buffer._stager
         ctx = engine.CaptureCtx(idx_cpu, gs.idx_dev, ids, gs.ids_dev,
-                                [gs.eps_dev] if eps is not None else [], gs.logblk)
+                                [gs.eps_dev] if gs.eps_dev is not None else [], gs.logblk)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         engine.CAPTURE = ctx
@@ -126,11 +135,11 @@ def _critic_update_graphed(gs, kw):
         gs.graph, gs.dicts = graph, dicts
         base = gs.logblk.data_ptr()
         gs.log_index = {k: (v.data_ptr() - base) // 4 for k, v in logs.items()}
-    # ---- per-update inputs into the fixed-address buffers, then ONE graph launch
-    gs.idx_dev.copy_(gs.stager.upload(idx_cpu), non_blocking=True)
-    gs.ids_dev.copy_(gs.stager.upload(torch.tensor(ids, dtype=torch.int32), tag="sub"), non_blocking=True)
-    if eps is not None:
-        gs.eps_dev.copy_(eps, non_blocking=True)
+    # ---- per-update inputs into the fixed-address buffers (ONE pinned H2D copy), then ONE graph launch
+    gs.host_idx.copy_(idx_cpu)
+    for j, v in enumerate(ids):
+        gs.host_ids[j] = v
+    gs.ring.push(gs.host, gs.inbuf)
     gs.graph.replay()
     rng.choice(agent.critics)  # keep the Python RNG stream in step with learning.py:135
     ring = lu.ring_for(dev)

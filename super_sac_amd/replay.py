@@ -122,6 +122,28 @@ class PrioritySampler:
         return idx, weights
 
 
+class _PinnedRing:
+    """host staging for small per-update inputs: copy through a ring of pinned buffers straight into a
+    FIXED device buffer (graph replay reads it), guarding slot reuse with events."""
+
+    def __init__(self, nbytes, slots=8):
+        self.bufs = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self.events = [None] * slots
+        self.k = 0
+
+    def push(self, host_bytes_tensor, dst_dev_u8):
+        self.k = (self.k + 1) % len(self.bufs)
+        ev = self.events[self.k]
+        if ev is not None:
+            ev.synchronize()
+        buf = self.bufs[self.k]
+        buf[:host_bytes_tensor.numel()].copy_(host_bytes_tensor)
+        dst_dev_u8.copy_(buf[:dst_dev_u8.numel()], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[self.k] = ev
+
+
 class ReplayBufferStorage:
     def __init__(self, size, state_example, act_example, device):
         self.device = device

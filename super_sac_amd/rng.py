@@ -28,6 +28,11 @@ def draw_normal(shape, device):
     return torch.randn(*shape, device=device)
 
 
+def draw_normal_into(dst):
+    """standard-normal draw written in place (same device-generator consumption as torch.randn)."""
+    return dst.normal_()
+
+
 def draw_drqv2_shift(batch_size, pad):
     return torch.randint(0, 2 * pad + 1, size=(batch_size, 1, 1, 2))
 

@@ -171,6 +171,8 @@ class DrawPlayer:
         self._saved = (rng_mod.draw_indices, rng_mod.draw_subset, rng_mod.draw_normal)
         self._saved_shift = rng_mod.draw_drqv2_shift
         rng_mod.draw_drqv2_shift = lambda b, pad: torch.from_numpy(self.shift.pop(0))
+        self._saved_into = rng_mod.draw_normal_into
+        rng_mod.draw_normal_into = lambda dst: dst.copy_(torch.from_numpy(self.normal.pop(0)))
         rng_mod.draw_indices = lambda n, b: torch.from_numpy(self.idx.pop(0).astype(np.int64))
         rng_mod.draw_subset = lambda n, k: [int(v) for v in self.sub.pop(0)]
         rng_mod.draw_normal = lambda shape, device: torch.from_numpy(self.normal.pop(0)).to(self.device)
@@ -180,6 +182,7 @@ class DrawPlayer:
         m = self._mod
         m.draw_indices, m.draw_subset, m.draw_normal = self._saved
         m.draw_drqv2_shift = self._saved_shift
+        m.draw_normal_into = self._saved_into
 
 
 def build_engine_agent(cfg, device, shard=None):

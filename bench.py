@@ -207,7 +207,10 @@ def main():
                 "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                 "avg_launch_us": round(avg_ms * 1e3, 3), "launches_timed": len(ms),
                 "timing": "HIP events around the launch, eager pass right after the timed (graph-replay) region",
-                "flops_per_launch": flops, "traffic": None}
+                "flops_per_launch": flops,
+                # HBM bytes per launch from the PMC passes in profiles/r1_pmc_counters.md (FETCH_SIZE doubled
+                # per the gfx950 note + WRITE_SIZE, KiB -> bytes); not collected live, N=10 single-GPU shape only
+                "traffic": (2 * 12682 + 20525) * 1024 if (world == 1 and n_local == NCRIT) else None}
 
     if rank == 0:
         out = {"metric": "gradient updates/sec (REDQ N=10, batch 512)", "value": round(args.steps / dt, 2),

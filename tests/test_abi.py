@@ -53,3 +53,13 @@ def test_update_path_refuses_to_run_without_a_gpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         engine.require_gpu()
+
+
+def test_install_rebinds_the_reference_seam():
+    import types
+    import super_sac_amd as ssa
+    fake = types.SimpleNamespace(learning=types.SimpleNamespace(), learning_utils=types.SimpleNamespace())
+    ssa.install(fake)
+    assert fake.learning.critic_update is ssa.learning.critic_update
+    assert fake.learning.alpha_update is ssa.learning.alpha_update
+    assert fake.learning_utils.soft_update is ssa.learning_utils.soft_update

@@ -688,3 +688,21 @@ def test_im2col_col2im_are_adjoint(ssa):
     # and im2col equals torch's unfold on the NCHW view
     ref = torch.nn.functional.unfold(x.permute(0, 3, 1, 2).cpu(), k, stride=s).transpose(1, 2).reshape(B * Ho * Ho, -1)
     assert torch.equal(col.cpu(), ref)
+
+
+def test_prioritised_sample_path_on_device(ssa):
+    """ReplayBuffer.sample / update_priorities: host trees (bit-exact with the reference fixture's numpy
+    stream) + device gather of the drawn rows."""
+    import synth
+    f = case_runner.load_fixture("per")
+    s, a, r, s1, d = synth.synth_transitions(300, 4, 2, seed=8)
+    rb = ssa.replay.ReplayBuffer(400, alpha=0.6, beta=1.0, device=DEV)
+    rb.load_experience(s, a, r, s1, d)
+    np.random.seed(int(f["np_seed"]))
+    (o, act, rew, o1, done), w, idx = rb.sample(32)
+    assert np.array_equal(idx, f["i0"]) and np.allclose(w.numpy(), f["w0"], rtol=1e-12)
+    assert np.array_equal(o["obs"].cpu().numpy(), s["obs"][idx]) and np.array_equal(act.cpu().numpy(), a[idx])
+    rb.update_priorities(idx, f["prios"])
+    _, w1, idx1 = rb.sample(32)
+    assert np.array_equal(idx1, f["i1"]) and np.allclose(w1.numpy(), f["w1"], rtol=1e-12)
+    assert rb.total_sample_calls == 2

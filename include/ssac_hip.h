@@ -246,7 +246,10 @@ int ssac_fused_supported(const ssac_mlp *nets);
  * records s_memtime() at its phase boundaries there; NULL (default) disables it. */
 int ssac_fused_debug_stamps(long long *dev_buf);
 int ssac_gemm_debug_stamps(long long *dev_buf); /* same for the weight-gradient GEMM launches */
-int ssac_fused_row_tiles(int n_rows);
+/* row tiles the fused critic launch uses for (n_rows, n_nets): the `partials` buffer holds
+ * n_nets * tiles * 2 floats.  ssac_fused_tile_rows(0|16|32) overrides the automatic 16/32-row choice. */
+int ssac_fused_row_tiles(int n_rows, int n_nets);
+int ssac_fused_tile_rows(int rows);
 
 /* y = MLP(x) for every selected net in ONE launch (agent.py:34 loop + mlps.py:123-129).
  * H1/H2 (n_sel x n_rows x hidden) are written when not NULL (needed by a later backward). */

@@ -180,86 +180,140 @@ struct RcStage {
 };
 
 // ---------------------------------------------------------------------------------------------
-// The K loop.  MFMA step t of a chunk consumes k = 16*lh + t from lane half lh (a permutation of
-// the chunk's 32 k values, identical for A and B), so a lane's 16 operands are CONSECUTIVE floats:
-// four ds_read_b128 per operand per chunk.
-//
-// Software pipeline (vector path), one barrier per chunk, placed in the MIDDLE of the 16 MFMAs:
-//   MFMA 0..7  of chunk c   interleaved with: LDS stores of chunk c+1, global loads of chunk c+2
-//   barrier                 (chunk c+1 visible; everybody has read chunk c-1's buffer long ago)
-//   MFMA 8..15 of chunk c   interleaved with: fragment reads of chunk c+1 into the other register set
-// so the matrix pipe never waits for LDS latency and the barrier skew hides under the first 8 MFMAs
-// that are already in the pipe.  sched_barrier(0) pins the interleave the source order expresses.
+// Row-tile policies.  A workgroup (8 waves) owns TMR rows x 256 columns of an activation tile;
+// wave w owns columns [32w, 32w+32):
+//   Tile<32>: one v_mfma_f32_32x32x2_f32 accumulator (16 regs); MFMA step t of a 32-deep K chunk takes
+//             k = 16*half + t from lane half `half`  -> 16 consecutive floats per lane (4 x ds_read_b128)
+//   Tile<16>: two v_mfma_f32_16x16x4_f32 accumulators (4 regs each, column sub-tiles of 16); step t takes
+//             k = 8*group + t from lane group `group` = lane>>4 -> 8 consecutive floats (2 x ds_read_b128)
+// (a permutation of the chunk's k values, identical for A and B, so the sum is unchanged up to fp32
+// association).  Tile<16> doubles the workgroup count for the same batch -- the actor / target-critic
+// launches use 32 / 64 CUs instead of 16 / 32 and each CU carries half the matrix work -- at the
+// same MFMA rate (both shapes are 64 FLOP/clk/SIMD).
 // ---------------------------------------------------------------------------------------------
-#define SSAC_PIN() __builtin_amdgcn_sched_barrier(0)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <bool NN>
-__device__ __forceinline__ void read_frags(f4 (&a4)[4], f4 (&b4)[4], float (&bs)[16], const float *As,
-                                           int lda, const float *buf, int c, int li, int lh, int col0) {
-    const f4 *ap = reinterpret_cast<const f4 *>(As + li * lda + c * 32 + lh * 16);
+template <int TMR> struct Tile;
+
+template <> struct Tile<32> {
+    typedef f32x16 Acc;
+    struct Frag { f4 a[4]; f4 b[4]; float bs[16]; };
+    static __device__ __forceinline__ void zero(Acc &a) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a4[q] = ap[q];
-    if (NN) {
-        const float *bp = buf + (lh * 16) * 256 + col0 + li;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) bs[t] = bp[t * 256];
-    } else {
-        const f4 *bp = reinterpret_cast<const f4 *>(buf + (col0 + li) * WS_LD + lh * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) b4[q] = bp[q];
+        for (int i = 0; i < 16; ++i) a[i] = 0.0f;
     }
-}
-
-template <bool NN>
-__device__ __forceinline__ float bval(const f4 (&b4)[4], const float (&bs)[16], int t) {
-    return NN ? bs[t] : b4[t >> 2][t & 3];
-}
-
-// one pipelined chunk: consumes (a, b), prefetches the next chunk's fragments into (an, bn)
-template <bool NN, typename Stage>
-__device__ __forceinline__ void pipe_step(f32x16 &acc, Stage &st, int c, int nch, int K,
-                                          const float *As, int lda, float *cur, float *nxt,
-                                          const f4 (&a)[4], const f4 (&b)[4], const float (&bsc)[16],
-                                          f4 (&an)[4], f4 (&bn)[4], float (&bsn)[16], int tid, int li,
-                                          int lh, int col0) {
-    const bool has1 = (c + 1) < nch, has2 = (c + 2) < nch;
+    template <bool NN>
+    static __device__ __forceinline__ void read(Frag &f, const float *As, int lda, const float *buf, int c,
+                                                int lane, int col0) {
+        const int li = lane & 31, lh = lane >> 5;
+        const f4 *ap = reinterpret_cast<const f4 *>(As + li * lda + c * 32 + lh * 16);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t >> 2][t & 3], bval<NN>(b, bsc, t), acc, 0, 0, 0);
-        if (t == 0 && has1) st.store(nxt, tid);
-        if (t == 4 && has2) st.load((c + 2) * 32, K);
-        SSAC_PIN();
-    }
-    __syncthreads();
-    if (has1) {
-        const f4 *ap = reinterpret_cast<const f4 *>(As + li * lda + (c + 1) * 32 + lh * 16);
-        const f4 *bp4 = reinterpret_cast<const f4 *>(nxt + (col0 + li) * WS_LD + lh * 16);
-        const float *bps = nxt + (lh * 16) * 256 + col0 + li;
+        for (int q = 0; q < 4; ++q) f.a[q] = ap[q];
+        if (NN) {
+            const float *bp = buf + (lh * 16) * 256 + col0 + li;
 #pragma unroll
-        for (int t = 8; t < 16; ++t) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t >> 2][t & 3], bval<NN>(b, bsc, t), acc, 0, 0, 0);
-            const int u = t - 8;
-            if (u < 4) an[u] = ap[u];
-            if (NN) { bsn[2 * u] = bps[(2 * u) * 256]; bsn[2 * u + 1] = bps[(2 * u + 1) * 256]; }
-            else if (u >= 4) bn[u - 4] = bp4[u - 4];
-            SSAC_PIN();
+            for (int t = 0; t < 16; ++t) f.bs[t] = bp[t * 256];
+        } else {
+            const f4 *bp = reinterpret_cast<const f4 *>(buf + (col0 + li) * WS_LD + lh * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f.b[q] = bp[q];
         }
-    } else {
-#pragma unroll
-        for (int t = 8; t < 16; ++t)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t >> 2][t & 3], bval<NN>(b, bsc, t), acc, 0, 0, 0);
     }
+    template <bool NN>
+    static __device__ __forceinline__ void mfma_half(Acc &acc, const Frag &f, int half) {
+#pragma unroll
+        for (int t8 = 0; t8 < 8; ++t8) {
+            const int t = half * 8 + t8;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t >> 2][t & 3], NN ? f.bs[t] : f.b[t >> 2][t & 3],
+                                                      acc, 0, 0, 0);
+        }
+    }
+    // f(row, column within the wave's 32, value)
+    template <class F>
+    static __device__ __forceinline__ void foreach(const Acc &acc, int lane, F fn) {
+        const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fn((r & 3) + 8 * (r >> 2) + 4 * lh, li, acc[r]);
+    }
+};
+
+template <> struct Tile<16> {
+    struct Acc { f32x4 v[2]; };
+    struct Frag { f4 a[2]; f4 b[2][2]; float bs[2][8]; };
+    static __device__ __forceinline__ void zero(Acc &a) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a.v[u][i] = 0.0f;
+    }
+    template <bool NN>
+    static __device__ __forceinline__ void read(Frag &f, const float *As, int lda, const float *buf, int c,
+                                                int lane, int col0) {
+        const int li = lane & 15, lg = lane >> 4;
+        const f4 *ap = reinterpret_cast<const f4 *>(As + li * lda + c * 32 + lg * 8);
+        f.a[0] = ap[0]; f.a[1] = ap[1];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (NN) {
+                const float *bp = buf + (lg * 8) * 256 + col0 + 16 * u + li;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) f.bs[u][t] = bp[t * 256];
+            } else {
+                const f4 *bp = reinterpret_cast<const f4 *>(buf + (col0 + 16 * u + li) * WS_LD + lg * 8);
+                f.b[u][0] = bp[0]; f.b[u][1] = bp[1];
+            }
+        }
+    }
+    template <bool NN>
+    static __device__ __forceinline__ void mfma_half(Acc &acc, const Frag &f, int half) {
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const int t = half * 4 + t4;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                acc.v[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[t >> 2][t & 3],
+                                                                NN ? f.bs[u][t] : f.b[u][t >> 2][t & 3],
+                                                                acc.v[u], 0, 0, 0);
+        }
+    }
+    template <class F>
+    static __device__ __forceinline__ void foreach(const Acc &acc, int lane, F fn) {
+        const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fn(4 * lg + r, 16 * u + li, acc.v[u][r]);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// The K loop: one barrier per 32-deep chunk, placed in the MIDDLE of the chunk's MFMAs:
+//   [LDS stores of chunk c+1, global loads of chunk c+2, first half of chunk c's MFMAs]
+//   barrier   (chunk c+1 visible; everybody finished reading chunk c-1's buffer long ago)
+//   [fragment reads of chunk c+1 into the other register set, second half of chunk c's MFMAs]
+// so fragment-read latency hides under MFMAs and the barrier skew under the MFMAs already in the pipe.
+// NN = false: acc += A[TMR x K] * W^T, W = (Nw x K) K-contiguous       (forward)
+// NN = true : acc += A[TMR x K] * W,   W = (K x Nw) rows contiguous    (backward-data)
+// Every wave runs the loop (waves whose columns lie beyond the layer width multiply staged zeros).
+// ---------------------------------------------------------------------------------------------
+template <int TMR, bool NN, typename Stage>
+__device__ __forceinline__ void pipe_step(typename Tile<TMR>::Acc &acc, Stage &st, int c, int nch, int K,
+                                          const float *As, int lda, float *nxt,
+                                          const typename Tile<TMR>::Frag &cur, typename Tile<TMR>::Frag &nf,
+                                          int tid, int col0) {
+    const bool has1 = (c + 1) < nch, has2 = (c + 2) < nch;
+    if (has1) st.store(nxt, tid);
+    if (has2) st.load((c + 2) * 32, K);
+    Tile<TMR>::template mfma_half<NN>(acc, cur, 0);
+    __syncthreads();
+    if (has1) Tile<TMR>::template read<NN>(nf, As, lda, nxt, c + 1, tid & 63, col0);
+    Tile<TMR>::template mfma_half<NN>(acc, cur, 1);
 }
 
-// NN = false: acc += A[32 x K] * W^T, W = (Nout x K) K-contiguous          (forward)
-// NN = true : acc += A[32 x K] * W,   W = (K x Ncols) rows contiguous       (backward-data)
-// Every wave runs the loop (waves whose columns lie beyond the layer width multiply staged zeros),
-// so the loop body is branch-free and the interleave above survives instruction scheduling.
-template <bool VEC, bool NN>
-__device__ __forceinline__ void gemm_tile(f32x16 &acc, const float *__restrict__ As, int lda, int K,
-                                          const float *__restrict__ W, int ldw, int Nw, float *B0,
+template <int TMR, bool VEC, bool NN>
+__device__ __forceinline__ void gemm_tile(typename Tile<TMR>::Acc &acc, const float *__restrict__ As, int lda,
+                                          int K, const float *__restrict__ W, int ldw, int Nw, float *B0,
                                           float *B1, int tid, int col0) {
-    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int nch = (K + 31) >> 5;
     typename std::conditional<NN, RcStage<VEC>, KcStage<VEC>>::type st;
     st.init(W, ldw, Nw, tid);
@@ -268,46 +322,43 @@ __device__ __forceinline__ void gemm_tile(f32x16 &acc, const float *__restrict__
     st.store(B0, tid);
     if (nch > 1) st.load(32, K);
     __syncthreads();
-    f4 a0[4], b0[4], a1[4], b1[4];
-    float s0[16], s1[16];
-    read_frags<NN>(a0, b0, s0, As, lda, B0, 0, li, lh, col0);
+    typename Tile<TMR>::Frag f0, f1;
+    Tile<TMR>::template read<NN>(f0, As, lda, B0, 0, tid & 63, col0);
     for (int c = 0; c < nch; c += 2) {
-        pipe_step<NN>(acc, st, c, nch, K, As, lda, B0, B1, a0, b0, s0, a1, b1, s1, tid, li, lh, col0);
-        if (c + 1 < nch)
-            pipe_step<NN>(acc, st, c + 1, nch, K, As, lda, B1, B0, a1, b1, s1, a0, b0, s0, tid, li, lh, col0);
+        pipe_step<TMR, NN>(acc, st, c, nch, K, As, lda, B1, f0, f1, tid, col0);
+        if (c + 1 < nch) pipe_step<TMR, NN>(acc, st, c + 1, nch, K, As, lda, B0, f1, f0, tid, col0);
     }
     __syncthreads();  // all fragment reads done before the caller reuses As / the staging buffers
 }
 
 #define STAMP(i) do { if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
-template <int MODE>
+template <int MODE, int TMR>
 __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void fused_mlp_kernel(FusedArgs g) {
+    typedef Tile<TMR> T;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = g.hidden, IN = g.in_dim, OUT = g.out_dim;
     const int KP = (IN + 31) & ~31;
     const int ldx_s = KP + APAD, ldh = H + APAD;
-    float *xs = smem;                       // [32][KP+4]
-    float *h1s = xs + TM * ldx_s;           // [32][H+4]
-    float *h2s = h1s + TM * ldh;            // [32][H+4]
-    float *Ws = h2s + TM * ldh;             // staging buffer 0
+    float *xs = smem;                       // [TMR][KP+4]
+    float *h1s = xs + TMR * ldx_s;          // [TMR][H+4]
+    float *h2s = h1s + TMR * ldh;           // [TMR][H+4]
+    float *Ws = h2s + TMR * ldh;            // staging buffer 0
     float *Ws1 = Ws + WS_FLOATS;            // staging buffer 1
-    float *ys = Ws1 + WS_FLOATS;            // [32][MAX_OUT]
-    float *dqs = ys + TM * MAX_OUT;         // [32][MAX_OUT]
-    float *rowred = dqs + TM * MAX_OUT;     // [64]
+    float *ys = Ws1 + WS_FLOATS;            // [TMR][MAX_OUT]
+    float *dqs = ys + TMR * MAX_OUT;        // [TMR][MAX_OUT]
+    float *rowred = dqs + TMR * MAX_OUT;    // [64]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int e = blockIdx.y, m0 = blockIdx.x * TM;
+    const int e = blockIdx.y, m0 = blockIdx.x * TMR;
     const int net = g.ids ? g.ids[e] : e;
     const float *P = g.params + (int64_t)net * g.net_stride;
     const float *X = g.X + (int64_t)e * g.sX;
     const int col0 = wave * 32;
-    const bool active = col0 < H;
 
     STAMP(0);
-    // ---- x tile -> LDS, zero padded to KP columns and to 32 rows
-    for (int i = tid; i < TM * KP; i += NTHR) {
+    // ---- x tile -> LDS, zero padded to KP columns and to TMR rows
+    for (int i = tid; i < TMR * KP; i += NTHR) {
         const int r = i / KP, k = i - r * KP;
         const bool ok = (m0 + r) < g.n_rows && k < IN;
         const float v = X[ok ? (int64_t)(m0 + r) * g.ldx + k : 0];
@@ -317,83 +368,81 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 
     STAMP(1);
     // ---- fc1
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    gemm_tile<false, false>(acc, xs, ldx_s, IN, P + g.off[0], IN, H, Ws, Ws1, tid, col0);
+    typename T::Acc acc;
+    T::zero(acc);
+    gemm_tile<TMR, false, false>(acc, xs, ldx_s, IN, P + g.off[0], IN, H, Ws, Ws1, tid, col0);
     STAMP(2);
-    if (active) {
-        const float b = P[g.off[1] + col0 + li];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float v = fmaxf(acc[r] + b, 0.0f);
-            h1s[row * ldh + col0 + li] = v;
-            if (g.H1 && (m0 + row) < g.n_rows)
-                g.H1[((int64_t)e * g.n_rows + m0 + row) * H + col0 + li] = v;
+    T::foreach(acc, lane, [&](int row, int cw, float val) {
+        const int col = col0 + cw;
+        if (col < H) {
+            const float v = fmaxf(val + P[g.off[1] + col], 0.0f);
+            h1s[row * ldh + col] = v;
+            if (g.H1 && (m0 + row) < g.n_rows) g.H1[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
         }
-    }
+    });
     STAMP(3);
     // ---- fc2
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    if (g.vec) gemm_tile<true, false>(acc, h1s, ldh, H, P + g.off[2], H, H, Ws, Ws1, tid, col0);
-    else gemm_tile<false, false>(acc, h1s, ldh, H, P + g.off[2], H, H, Ws, Ws1, tid, col0);
+    T::zero(acc);
+    if (g.vec) gemm_tile<TMR, true, false>(acc, h1s, ldh, H, P + g.off[2], H, H, Ws, Ws1, tid, col0);
+    else gemm_tile<TMR, false, false>(acc, h1s, ldh, H, P + g.off[2], H, H, Ws, Ws1, tid, col0);
     STAMP(4);
-    if (active) {
-        const float b = P[g.off[3] + col0 + li];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float v = fmaxf(acc[r] + b, 0.0f);
-            h2s[row * ldh + col0 + li] = v;
-            if (g.H2 && (m0 + row) < g.n_rows)
-                g.H2[((int64_t)e * g.n_rows + m0 + row) * H + col0 + li] = v;
+    T::foreach(acc, lane, [&](int row, int cw, float val) {
+        const int col = col0 + cw;
+        if (col < H) {
+            const float v = fmaxf(val + P[g.off[3] + col], 0.0f);
+            h2s[row * ldh + col] = v;
+            if (g.H2 && (m0 + row) < g.n_rows) g.H2[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
         }
-    }
+    });
     __syncthreads();
 
     // ---- head weights -> LDS (the staging buffers are free after fc2): every later use of W3
     //      (head, head backward) then reads LDS instead of chaining global-load latencies
     STAMP(5);
     const int ldw3 = H + APAD;
-    float *w3s = Ws;   // [OUT][H+4]
-    float *b3s = Ws1;  // [OUT], then the K-split partial tiles [8][32][16] at Ws1 + 16
+    float *w3s = Ws;   // [MAX_OUT][H+4], rows >= OUT zero
+    float *b3s = Ws1;  // [OUT], then the K-split partial tiles [8][TMR][16] at Ws1 + 16
     float *hpart = Ws1 + 16;
-    for (int i = tid; i < OUT * H; i += NTHR) {
+    for (int i = tid; i < MAX_OUT * H; i += NTHR) {
         const int o = i / H, k = i - o * H;
-        w3s[o * ldw3 + k] = P[g.off[4] + i];
+        w3s[o * ldw3 + k] = o < OUT ? P[g.off[4] + i] : 0.0f;
     }
     if (tid < OUT) b3s[tid] = P[g.off[5] + tid];
     __syncthreads();
     STAMP(6);
     // ---- head on the matrix cores: wave w multiplies the k-slice [32w, 32w+32) of h2 with W3^T
-    //      (rows >= OUT of the 32-wide B tile are zero); the 8 partial tiles are summed through LDS
+    //      (a 16-wide B tile, rows >= OUT zero); the 8 partial tiles are summed through LDS.
     {
+        f32x4 hacc[TMR / 16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        for (int q = 0; q < TMR / 16; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hacc[q][i] = 0.0f;
+        const int li = lane & 15, lg = lane >> 4;
         if (col0 < H) {  // col0 = 32*wave doubles as this wave's k-slice start
-            const f4 *ap = reinterpret_cast<const f4 *>(h2s + li * ldh + col0 + lh * 16);
-            const f4 *bp = reinterpret_cast<const f4 *>(w3s + (li < OUT ? li : 0) * ldw3 + col0 + lh * 16);
-            f4 a4[4], b4[4];
+            const f4 *bp = reinterpret_cast<const f4 *>(w3s + li * ldw3 + col0 + lg * 8);
+            const f4 b0 = bp[0], b1 = bp[1];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { a4[q] = ap[q]; b4[q] = bp[q]; }
-            const float keep = li < OUT ? 1.0f : 0.0f;
+            for (int q = 0; q < TMR / 16; ++q) {
+                const f4 *ap = reinterpret_cast<const f4 *>(h2s + (16 * q + li) * ldh + col0 + lg * 8);
+                const f4 a0 = ap[0], a1 = ap[1];
 #pragma unroll
-            for (int t = 0; t < 16; ++t)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t >> 2][t & 3], b4[t >> 2][t & 3] * keep, acc, 0, 0, 0);
+                for (int t = 0; t < 8; ++t)
+                    hacc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(t < 4 ? a0[t & 3] : a1[t & 3],
+                                                                   t < 4 ? b0[t & 3] : b1[t & 3], hacc[q], 0, 0, 0);
+            }
         }
-        if (li < MAX_OUT) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                hpart[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * MAX_OUT + li] = acc[r];
-        }
+        for (int q = 0; q < TMR / 16; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                hpart[(wave * TMR + 16 * q + 4 * lg + r) * MAX_OUT + li] = hacc[q][r];
         __syncthreads();
         const int row = tid >> 4, o = tid & 15;
-        if (o < OUT) {
+        if (row < TMR && o < OUT) {
             float v = b3s[o];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) v += hpart[(w * 32 + row) * MAX_OUT + o];
+            for (int w = 0; w < 8; ++w) v += hpart[(w * TMR + row) * MAX_OUT + o];
             ys[row * MAX_OUT + o] = v;
             if (g.Y && (m0 + row) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + row) * OUT + o] = v;
         }
@@ -403,8 +452,8 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     __syncthreads();
 
     if (MODE == MODE_SAMPLE) {
-        // tanh-normal head: one thread per row (32 rows)
-        if (tid < TM && (m0 + tid) < g.n_rows) {
+        // tanh-normal head: one thread per row
+        if (tid < TMR && (m0 + tid) < g.n_rows) {
             const int b = m0 + tid, A = OUT >> 1;
             float lp = 0.0f;
             for (int i = 0; i < A; ++i) {
@@ -428,7 +477,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         const float pw = (g.popart && g.pop) ? g.popart->w : 1.0f;
         const float pb = (g.popart && g.pop) ? g.popart->b : 0.0f;
         const float gscale = -2.0f * pw / (g.denom * (float)g.n_rows);
-        if (tid < TM) {
+        if (tid < TMR) {
             float lossv = 0.0f, errv = 0.0f;
             const int b = m0 + tid;
             int ai = 0;
@@ -452,7 +501,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         __syncthreads();
         if (tid == 0) {
             float sl = 0.0f, se = 0.0f;
-            for (int r = 0; r < TM; ++r) { sl += rowred[r]; se += rowred[32 + r]; }
+            for (int r = 0; r < TMR; ++r) { sl += rowred[r]; se += rowred[32 + r]; }
             const int64_t pi = ((int64_t)e * gridDim.x + blockIdx.x) * 2;
             g.partials[pi] = sl;
             g.partials[pi + 1] = se;
@@ -463,7 +512,7 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             // thread -> column k = tid % 256, rows r = (tid >> 8), +2, ...  (H <= 256)
             const int k = tid & 255;
             if (k < H) {
-                for (int r = tid >> 8; r < TM; r += 2) {
+                for (int r = tid >> 8; r < TMR; r += 2) {
                     float gsum = 0.0f;
                     for (int o = 0; o < OUT; ++o) gsum += dqs[r * MAX_OUT + o] * w3s[o * ldw3 + k];
                     const float dz = h2s[r * ldh + k] > 0.0f ? gsum : 0.0f;
@@ -473,32 +522,38 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             }
         }
         STAMP(9);
-        // ---- backward-data of fc2: dz1 = (dz2 W2) (.) [h1 > 0]   (gemm_nn starts with a barrier)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-        if (g.vec) gemm_tile<true, true>(acc, h2s, ldh, H, P + g.off[2], H, H, Ws, Ws1, tid, col0);
-        else gemm_tile<false, true>(acc, h2s, ldh, H, P + g.off[2], H, H, Ws, Ws1, tid, col0);
+        // ---- backward-data of fc2: dz1 = (dz2 W2) (.) [h1 > 0]   (gemm_tile starts with a barrier)
+        T::zero(acc);
+        if (g.vec) gemm_tile<TMR, true, true>(acc, h2s, ldh, H, P + g.off[2], H, H, Ws, Ws1, tid, col0);
+        else gemm_tile<TMR, false, true>(acc, h2s, ldh, H, P + g.off[2], H, H, Ws, Ws1, tid, col0);
         STAMP(10);
-        if (active) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if ((m0 + row) < g.n_rows) {
-                    const float v = h1s[row * ldh + col0 + li] > 0.0f ? acc[r] : 0.0f;
-                    g.DZ1[((int64_t)e * g.n_rows + m0 + row) * H + col0 + li] = v;
-                }
+        T::foreach(acc, lane, [&](int row, int cw, float val) {
+            const int col = col0 + cw;
+            if (col < H && (m0 + row) < g.n_rows) {
+                const float v = h1s[row * ldh + col] > 0.0f ? val : 0.0f;
+                g.DZ1[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
             }
-        }
+        });
         STAMP(11);
     }
 }
 
 long long *g_fused_dbg = nullptr;
 
-size_t fused_lds_bytes(int in_dim, int hidden) {
+int g_tile_rows = 0;  // 0 = automatic, else 16 or 32 (ssac_fused_tile_rows)
+
+size_t fused_lds_bytes(int in_dim, int hidden, int tm = TM) {
     const int KP = (in_dim + 31) & ~31;
-    return sizeof(float) * ((size_t)TM * (KP + APAD) + 2 * (size_t)TM * (hidden + APAD) + 2 * WS_FLOATS +
-                            2 * TM * MAX_OUT + 64);
+    return sizeof(float) * ((size_t)tm * (KP + APAD) + 2 * (size_t)tm * (hidden + APAD) + 2 * WS_FLOATS +
+                            2 * tm * MAX_OUT + 64);
+}
+
+// 16-row tiles whenever the launch is small enough that they still run in a single round of the 256 CUs
+int pick_tile_rows(int n_rows, int n_sel) {
+    if (g_tile_rows == 16 || g_tile_rows == 32) return g_tile_rows;
+    // one workgroup per CU is resident (LDS): 16-row tiles only while they all fit in one round
+    const int wg16 = ((n_rows + 15) / 16) * n_sel;
+    return wg16 <= 256 ? 16 : 32;
 }
 
 bool fused_ok(const ssac_mlp *n) {
@@ -518,19 +573,25 @@ void fill_common(FusedArgs &g, const ssac_mlp *nets, const int32_t *ids, const f
              (nets->hidden & 3) == 0) ? 1 : 0;
 }
 
-template <int MODE>
-int launch_fused(const FusedArgs &g, int n_sel, hipStream_t st) {
+template <int MODE, int TMR>
+int launch_fused_t(const FusedArgs &g, int n_sel, hipStream_t st) {
     static bool attr_set = false;
-    const size_t lds = fused_lds_bytes(g.in_dim, g.hidden);
+    const size_t lds = fused_lds_bytes(g.in_dim, g.hidden, TMR);
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)fused_mlp_kernel<MODE>,
+        hipError_t e = hipFuncSetAttribute((const void *)fused_mlp_kernel<MODE, TMR>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return ssac_fail("fused_mlp: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
-    dim3 grid((g.n_rows + TM - 1) / TM, n_sel);
-    hipLaunchKernelGGL((fused_mlp_kernel<MODE>), grid, dim3(NTHR), lds, st, g);
+    dim3 grid((g.n_rows + TMR - 1) / TMR, n_sel);
+    hipLaunchKernelGGL((fused_mlp_kernel<MODE, TMR>), grid, dim3(NTHR), lds, st, g);
     return ssac_check_launch("fused_mlp");
+}
+
+template <int MODE>
+int launch_fused(const FusedArgs &g, int n_sel, hipStream_t st) {
+    return pick_tile_rows(g.n_rows, n_sel) == 16 ? launch_fused_t<MODE, 16>(g, n_sel, st)
+                                                 : launch_fused_t<MODE, 32>(g, n_sel, st);
 }
 
 // ------------------------------------------------------------------ head weight gradient + Adam
@@ -709,7 +770,17 @@ extern "C" int ssac_critic_fwd_bwd_fused(const ssac_mlp *nets, const float *X, i
     return launch_fused<MODE_CRITIC>(g, nets->n_nets, (hipStream_t)stream);
 }
 
-extern "C" int ssac_fused_row_tiles(int n_rows) { return (n_rows + TM - 1) / TM; }
+// row tiles the fused critic launch will use for (n_rows, n_nets): sizes the `partials` buffer
+extern "C" int ssac_fused_row_tiles(int n_rows, int n_nets) {
+    const int tm = pick_tile_rows(n_rows, n_nets);
+    return (n_rows + tm - 1) / tm;
+}
+
+extern "C" int ssac_fused_tile_rows(int rows) {
+    if (rows != 0 && rows != 16 && rows != 32) return ssac_fail("ssac_fused_tile_rows: 0 (auto), 16 or 32");
+    g_tile_rows = rows;
+    return 0;
+}
 
 extern "C" int ssac_head_wgrad(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *H2,
                                const float *DQ, int n_rows, float *adam_m, float *adam_v,

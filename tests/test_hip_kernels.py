@@ -99,9 +99,17 @@ def test_ensemble_q_known_answers_from_reference(ssa):
     _close(q[:, :, 0], torch.from_numpy(f["ensq_q"]), 5e-5, what="ensemble Q")
 
 
+@pytest.fixture(params=[16, 32], ids=["tile16", "tile32"])
+def tile_rows(request, ssa):
+    """run the fused kernels with 16-row (16x16x4 MFMA) and 32-row (32x32x2 MFMA) tiles"""
+    ssa._lib.check(ssa._lib.lib.ssac_fused_tile_rows(request.param))
+    yield request.param
+    ssa._lib.check(ssa._lib.lib.ssac_fused_tile_rows(0))
+
+
 @pytest.mark.parametrize("B,in_dim,H,out,N", [(512, 23, 256, 1, 10), (100, 17, 64, 12, 1), (77, 393, 96, 1, 3),
                                               (33, 128, 256, 4, 2), (1, 5, 32, 3, 2)])
-def test_fused_forward_equals_per_layer_and_oracle(ssa, B, in_dim, H, out, N):
+def test_fused_forward_equals_per_layer_and_oracle(ssa, tile_rows, B, in_dim, H, out, N):
     rng = np.random.RandomState(B + in_dim + 1)
     mlps = [orc.make_mlp(rng, in_dim, H, out) for _ in range(N)]
     x = torch.from_numpy(rng.standard_normal((B, in_dim)).astype(np.float32))
@@ -119,7 +127,7 @@ def test_fused_forward_equals_per_layer_and_oracle(ssa, B, in_dim, H, out, N):
         _close(y[j], orc.mlp3(p, x)[0], 5e-5, what=f"y[{j}] vs oracle")
 
 
-def test_fused_actor_sample(ssa):
+def test_fused_actor_sample(ssa, tile_rows):
     rng = np.random.RandomState(41)
     B, S, A, H = 200, 17, 6, 256
     actor = orc.make_mlp(rng, S, H, 2 * A)
@@ -138,7 +146,7 @@ def test_fused_actor_sample(ssa):
 
 
 @pytest.mark.parametrize("qd,B,H,N", [(1, 512, 256, 10), (4, 70, 64, 2)])
-def test_fused_critic_fwd_bwd_matches_autograd(ssa, qd, B, H, N):
+def test_fused_critic_fwd_bwd_matches_autograd(ssa, tile_rows, qd, B, H, N):
     rng = np.random.RandomState(42 + qd)
     in_dim = 23 if qd == 1 else 9
     mlps = [orc.make_mlp(rng, in_dim, H, qd) for _ in range(N)]
@@ -160,7 +168,7 @@ def test_fused_critic_fwd_bwd_matches_autograd(ssa, qd, B, H, N):
     xd, tdd, wd, ad = x.to(DEV), td.to(DEV), w.to(DEV), act.to(DEV)
     h1 = torch.zeros(N, B, H, device=DEV); h2 = torch.zeros_like(h1); dz2 = torch.zeros_like(h1); dz1 = torch.zeros_like(h1)
     q = torch.zeros(N, B, qd, device=DEV); dq = torch.zeros_like(q)
-    tiles = int(ssa._lib.lib.ssac_fused_row_tiles(B))
+    tiles = int(ssa._lib.lib.ssac_fused_row_tiles(B, N))
     parts = torch.zeros(N * tiles * 2, device=DEV)
     ssa._lib.check(ssa._lib.lib.ssac_critic_fwd_bwd_fused(
         C.byref(ar.desc()), xd.data_ptr(), in_dim, B, tdd.data_ptr(), wd.data_ptr(), ad.data_ptr(), 1, 0, 0,

@@ -247,8 +247,9 @@ int ssac_fused_supported(const ssac_mlp *nets);
 int ssac_fused_debug_stamps(long long *dev_buf);
 int ssac_gemm_debug_stamps(long long *dev_buf); /* same for the weight-gradient GEMM launches */
 /* row tiles the fused critic launch uses for (n_rows, n_nets): the `partials` buffer holds
- * n_nets * tiles * 2 floats.  ssac_fused_tile_rows(0|16|32) overrides the automatic 16/32-row choice. */
-int ssac_fused_row_tiles(int n_rows, int n_nets);
+ * n_nets * tiles * 2 floats.  ssac_fused_tile_rows(0|16|17|32) overrides the automatic choice (17 = 16 rows with a
+ * single weight-staging buffer, two workgroups per CU). */
+int ssac_fused_row_tiles(const ssac_mlp *nets, int n_rows, int n_nets);
 int ssac_fused_tile_rows(int rows);
 
 /* y = MLP(x) for every selected net in ONE launch (agent.py:34 loop + mlps.py:123-129).

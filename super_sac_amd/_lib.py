@@ -79,7 +79,7 @@ SIGNATURES = {
     "ssac_fused_supported": [_MP],
     "ssac_fused_debug_stamps": [_P],
     "ssac_gemm_debug_stamps": [_P],
-    "ssac_fused_row_tiles": [_I, _I],
+    "ssac_fused_row_tiles": [_MP, _I, _I],
     "ssac_fused_tile_rows": [_I],
     "ssac_mlp3_fwd_fused": [_MP, _P, _I, _P, _L, _L, _I, _P, _P, _P, _P],
     "ssac_actor_sample_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _P, _P, _P],

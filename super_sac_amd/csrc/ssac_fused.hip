@@ -310,14 +310,29 @@ __device__ __forceinline__ void pipe_step(typename Tile<TMR>::Acc &acc, Stage &s
     Tile<TMR>::template mfma_half<NN>(acc, cur, 1);
 }
 
-template <int TMR, bool VEC, bool NN>
-__device__ __forceinline__ void gemm_tile(typename Tile<TMR>::Acc &acc, const float *__restrict__ As, int lda,
-                                          int K, const float *__restrict__ W, int ldw, int Nw, float *B0,
-                                          float *B1, int tid, int col0) {
+// The caller has already done st.init(...) and st.load(0, K): the first weight chunk's global loads are
+// issued one phase EARLY (before the previous phase's epilogue / staging), so no phase of the kernel
+// starts by waiting a full HBM/L2 round trip.
+template <int TMR, bool NN, bool DBUF, typename Stage>
+__device__ __forceinline__ void gemm_tile(typename Tile<TMR>::Acc &acc, Stage &st, const float *__restrict__ As,
+                                          int lda, int K, float *B0, float *B1, int tid, int col0) {
     const int nch = (K + 31) >> 5;
-    typename std::conditional<NN, RcStage<VEC>, KcStage<VEC>>::type st;
-    st.init(W, ldw, Nw, tid);
-    st.load(0, K);
+    if (!DBUF) {
+        // single staging buffer, two barriers per chunk: half the LDS, so TWO workgroups fit a CU and
+        // each one's barrier / staging phases hide under the other's MFMAs (4 waves per SIMD)
+        typename Tile<TMR>::Frag f;
+        for (int c = 0; c < nch; ++c) {
+            __syncthreads();  // everybody is done with the previous chunk (and with As' writers)
+            st.store(B0, tid);
+            if (c + 1 < nch) st.load((c + 1) * 32, K);
+            __syncthreads();
+            Tile<TMR>::template read<NN>(f, As, lda, B0, c, tid & 63, col0);
+            Tile<TMR>::template mfma_half<NN>(acc, f, 0);
+            Tile<TMR>::template mfma_half<NN>(acc, f, 1);
+        }
+        __syncthreads();
+        return;
+    }
     __syncthreads();  // previous users of the staging buffers / writers of As are done
     st.store(B0, tid);
     if (nch > 1) st.load(32, K);
@@ -333,8 +348,10 @@ __device__ __forceinline__ void gemm_tile(typename Tile<TMR>::Acc &acc, const fl
 
 #define STAMP(i) do { if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
-template <int MODE, int TMR>
-__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) void fused_mlp_kernel(FusedArgs g) {
+// DBUF = false: 2 workgroups per CU (needs <= 128 VGPRs and <= 80 KB of LDS each)
+template <int MODE, int TMR, bool DBUF>
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(DBUF ? 2 : 4, DBUF ? 2 : 4)))
+void fused_mlp_kernel(FusedArgs g) {
     typedef Tile<TMR> T;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = g.hidden, IN = g.in_dim, OUT = g.out_dim;
@@ -344,10 +361,16 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     float *h1s = xs + TMR * ldx_s;          // [TMR][H+4]
     float *h2s = h1s + TMR * ldh;           // [TMR][H+4]
     float *Ws = h2s + TMR * ldh;            // staging buffer 0
-    float *Ws1 = Ws + WS_FLOATS;            // staging buffer 1
-    float *ys = Ws1 + WS_FLOATS;            // [TMR][MAX_OUT]
+    float *Ws1 = Ws + WS_FLOATS;            // staging buffer 1 (DBUF only)
+    float *ys = Ws + (DBUF ? 2 : 1) * WS_FLOATS;  // [TMR][MAX_OUT]
     float *dqs = ys + TMR * MAX_OUT;        // [TMR][MAX_OUT]
     float *rowred = dqs + TMR * MAX_OUT;    // [64]
+    // small operands fetched at kernel start, so later phases never begin with a global round trip:
+    float *b1s = rowred + 64;               // [H]
+    float *b2s = b1s + H;                   // [H]
+    float *b3s = b2s + H;                   // [16]
+    float *w3s = b3s + 16;                  // [OUT][H+4]
+    float *rowin = w3s + OUT * (H + APAD);  // [3][TMR]: td, weight, action index of this tile's rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e = blockIdx.y, m0 = blockIdx.x * TMR;
@@ -357,6 +380,25 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     const int col0 = wave * 32;
 
     STAMP(0);
+    const int ldw3 = H + APAD;
+    // ---- first weight chunk of fc1 in flight before anything else
+    KcStage<false> st1;
+    st1.init(P + g.off[0], IN, H, tid);
+    st1.load(0, IN);
+    // ---- small operands -> LDS (visible after the first barrier inside gemm_tile)
+    for (int i = tid; i < H; i += NTHR) { b1s[i] = P[g.off[1] + i]; b2s[i] = P[g.off[3] + i]; }
+    if (tid < OUT) b3s[tid] = P[g.off[5] + tid];
+    for (int i = tid; i < OUT * H; i += NTHR) {
+        const int o = i / H, k = i - o * H;
+        w3s[o * ldw3 + k] = P[g.off[4] + i];
+    }
+    if (MODE == MODE_CRITIC && tid < TMR) {
+        const int b = m0 + tid;
+        const bool ok = b < g.n_rows;
+        rowin[tid] = ok ? g.td[b] : 0.0f;
+        rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
+        rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
+    }
     // ---- x tile -> LDS, zero padded to KP columns and to TMR rows
     for (int i = tid; i < TMR * KP; i += NTHR) {
         const int r = i / KP, k = i - r * KP;
@@ -370,12 +412,17 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     // ---- fc1
     typename T::Acc acc;
     T::zero(acc);
-    gemm_tile<TMR, false, false>(acc, xs, ldx_s, IN, P + g.off[0], IN, H, Ws, Ws1, tid, col0);
+    gemm_tile<TMR, false, DBUF>(acc, st1, xs, ldx_s, IN, Ws, Ws1, tid, col0);
     STAMP(2);
+    // fc2's first weight chunk is requested before fc1's epilogue
+    KcStage<true> st2v;
+    KcStage<false> st2s;
+    if (g.vec) { st2v.init(P + g.off[2], H, H, tid); st2v.load(0, H); }
+    else { st2s.init(P + g.off[2], H, H, tid); st2s.load(0, H); }
     T::foreach(acc, lane, [&](int row, int cw, float val) {
         const int col = col0 + cw;
         if (col < H) {
-            const float v = fmaxf(val + P[g.off[1] + col], 0.0f);
+            const float v = fmaxf(val + b1s[col], 0.0f);
             h1s[row * ldh + col] = v;
             if (g.H1 && (m0 + row) < g.n_rows) g.H1[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
         }
@@ -383,32 +430,28 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     STAMP(3);
     // ---- fc2
     T::zero(acc);
-    if (g.vec) gemm_tile<TMR, true, false>(acc, h1s, ldh, H, P + g.off[2], H, H, Ws, Ws1, tid, col0);
-    else gemm_tile<TMR, false, false>(acc, h1s, ldh, H, P + g.off[2], H, H, Ws, Ws1, tid, col0);
+    if (g.vec) gemm_tile<TMR, false, DBUF>(acc, st2v, h1s, ldh, H, Ws, Ws1, tid, col0);
+    else gemm_tile<TMR, false, DBUF>(acc, st2s, h1s, ldh, H, Ws, Ws1, tid, col0);
     STAMP(4);
+    // the backward-data phase re-reads W2 (row-contiguous image): request its first chunk now
+    RcStage<true> st3v;
+    RcStage<false> st3s;
+    if (MODE == MODE_CRITIC) {
+        if (g.vec) { st3v.init(P + g.off[2], H, H, tid); st3v.load(0, H); }
+        else { st3s.init(P + g.off[2], H, H, tid); st3s.load(0, H); }
+    }
     T::foreach(acc, lane, [&](int row, int cw, float val) {
         const int col = col0 + cw;
         if (col < H) {
-            const float v = fmaxf(val + P[g.off[3] + col], 0.0f);
+            const float v = fmaxf(val + b2s[col], 0.0f);
             h2s[row * ldh + col] = v;
             if (g.H2 && (m0 + row) < g.n_rows) g.H2[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
         }
     });
     __syncthreads();
 
-    // ---- head weights -> LDS (the staging buffers are free after fc2): every later use of W3
-    //      (head, head backward) then reads LDS instead of chaining global-load latencies
     STAMP(5);
-    const int ldw3 = H + APAD;
-    float *w3s = Ws;   // [MAX_OUT][H+4], rows >= OUT zero
-    float *b3s = Ws1;  // [OUT], then the K-split partial tiles [8][TMR][16] at Ws1 + 16
-    float *hpart = Ws1 + 16;
-    for (int i = tid; i < MAX_OUT * H; i += NTHR) {
-        const int o = i / H, k = i - o * H;
-        w3s[o * ldw3 + k] = o < OUT ? P[g.off[4] + i] : 0.0f;
-    }
-    if (tid < OUT) b3s[tid] = P[g.off[5] + tid];
-    __syncthreads();
+    float *hpart = Ws;  // K-split partial head tiles [8][TMR][16] (the staging buffer is free after fc2)
     STAMP(6);
     // ---- head on the matrix cores: wave w multiplies the k-slice [32w, 32w+32) of h2 with W3^T
     //      (a 16-wide B tile, rows >= OUT zero); the 8 partial tiles are summed through LDS.
@@ -420,8 +463,9 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             for (int i = 0; i < 4; ++i) hacc[q][i] = 0.0f;
         const int li = lane & 15, lg = lane >> 4;
         if (col0 < H) {  // col0 = 32*wave doubles as this wave's k-slice start
-            const f4 *bp = reinterpret_cast<const f4 *>(w3s + li * ldw3 + col0 + lg * 8);
-            const f4 b0 = bp[0], b1 = bp[1];
+            const f4 *bp = reinterpret_cast<const f4 *>(w3s + (li < OUT ? li : 0) * ldw3 + col0 + lg * 8);
+            const float keep = li < OUT ? 1.0f : 0.0f;  // rows >= OUT of the 16-wide B tile are zero
+            const f4 b0 = bp[0] * keep, b1 = bp[1] * keep;
 #pragma unroll
             for (int q = 0; q < TMR / 16; ++q) {
                 const f4 *ap = reinterpret_cast<const f4 *>(h2s + (16 * q + li) * ldh + col0 + lg * 8);
@@ -483,9 +527,9 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             int ai = 0;
             float dsel = 0.0f;
             if (b < g.n_rows) {
-                if (OUT > 1) ai = (int)g.act[b * g.ld_a];
-                const float w = g.weight ? g.weight[b] : 1.0f;
-                const float err = g.td[b] - (pw * ys[tid * MAX_OUT + ai] + pb);
+                if (OUT > 1) ai = (int)rowin[2 * TMR + tid];
+                const float w = rowin[TMR + tid];
+                const float err = rowin[tid] - (pw * ys[tid * MAX_OUT + ai] + pb);
                 lossv = w * err * err;
                 errv = err;
                 dsel = gscale * w * err;
@@ -524,8 +568,8 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         STAMP(9);
         // ---- backward-data of fc2: dz1 = (dz2 W2) (.) [h1 > 0]   (gemm_tile starts with a barrier)
         T::zero(acc);
-        if (g.vec) gemm_tile<TMR, true, true>(acc, h2s, ldh, H, P + g.off[2], H, H, Ws, Ws1, tid, col0);
-        else gemm_tile<TMR, false, true>(acc, h2s, ldh, H, P + g.off[2], H, H, Ws, Ws1, tid, col0);
+        if (g.vec) gemm_tile<TMR, true, DBUF>(acc, st3v, h2s, ldh, H, Ws, Ws1, tid, col0);
+        else gemm_tile<TMR, true, DBUF>(acc, st3s, h2s, ldh, H, Ws, Ws1, tid, col0);
         STAMP(10);
         T::foreach(acc, lane, [&](int row, int cw, float val) {
             const int col = col0 + cw;
@@ -542,23 +586,36 @@ long long *g_fused_dbg = nullptr;
 
 int g_tile_rows = 0;  // 0 = automatic, else 16 or 32 (ssac_fused_tile_rows)
 
-size_t fused_lds_bytes(int in_dim, int hidden, int tm = TM) {
+size_t fused_lds_bytes(int in_dim, int hidden, int out_dim, int tm = TM, bool dbuf = true) {
     const int KP = (in_dim + 31) & ~31;
-    return sizeof(float) * ((size_t)tm * (KP + APAD) + 2 * (size_t)tm * (hidden + APAD) + 2 * WS_FLOATS +
-                            2 * tm * MAX_OUT + 64);
+    return sizeof(float) * ((size_t)tm * (KP + APAD) + 2 * (size_t)tm * (hidden + APAD) +
+                            (dbuf ? 2 : 1) * WS_FLOATS + 2 * tm * MAX_OUT + 64 +
+                            2 * hidden + 16 + (size_t)out_dim * (hidden + APAD) + 3 * tm);
 }
 
 // 16-row tiles whenever the launch is small enough that they still run in a single round of the 256 CUs
-int pick_tile_rows(int n_rows, int n_sel) {
+int pick_tile_rows(const FusedArgs &g, int n_sel) {
+    const int n_rows = g.n_rows;
+    // wide inputs / wide heads with hidden 256 only fit the 160 KB of LDS with 16-row tiles
+    if (fused_lds_bytes(g.in_dim, g.hidden, g.out_dim, 32) > 160 * 1024) return 16;
     if (g_tile_rows == 16 || g_tile_rows == 32) return g_tile_rows;
-    // one workgroup per CU is resident (LDS): 16-row tiles only while they all fit in one round
+    // 16-row tiles while the launch fits the chip in one round: one double-buffered workgroup per CU up to
+    // 256 workgroups, two single-buffered ones per CU up to 512 (variant 17 = "16 rows, single buffer")
     const int wg16 = ((n_rows + 15) / 16) * n_sel;
     return wg16 <= 256 ? 16 : 32;
 }
 
+bool pick_single_buffer(const FusedArgs &g, int n_sel) {
+    if (g_tile_rows == 17) return true;
+    // Measured on MI355X at the metric shape (320 such workgroups): 44.7 us against 40-44 us for the
+    // 32-row double-buffered tiles, so the variant is never chosen automatically; it stays a tested option.
+    (void)g; (void)n_sel;
+    return false;
+}
+
 bool fused_ok(const ssac_mlp *n) {
     return n && n->hidden % 32 == 0 && n->hidden <= 256 && n->out_dim >= 1 && n->out_dim <= MAX_OUT &&
-           n->in_dim >= 1 && fused_lds_bytes(n->in_dim, n->hidden) <= 160 * 1024;
+           n->in_dim >= 1 && fused_lds_bytes(n->in_dim, n->hidden, n->out_dim, 16) <= 160 * 1024;
 }
 
 void fill_common(FusedArgs &g, const ssac_mlp *nets, const int32_t *ids, const float *X, int64_t ldx,
@@ -573,25 +630,26 @@ void fill_common(FusedArgs &g, const ssac_mlp *nets, const int32_t *ids, const f
              (nets->hidden & 3) == 0) ? 1 : 0;
 }
 
-template <int MODE, int TMR>
+template <int MODE, int TMR, bool DBUF>
 int launch_fused_t(const FusedArgs &g, int n_sel, hipStream_t st) {
     static bool attr_set = false;
-    const size_t lds = fused_lds_bytes(g.in_dim, g.hidden, TMR);
+    const size_t lds = fused_lds_bytes(g.in_dim, g.hidden, g.out_dim, TMR, DBUF);
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)fused_mlp_kernel<MODE, TMR>,
+        hipError_t e = hipFuncSetAttribute((const void *)fused_mlp_kernel<MODE, TMR, DBUF>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return ssac_fail("fused_mlp: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
     dim3 grid((g.n_rows + TMR - 1) / TMR, n_sel);
-    hipLaunchKernelGGL((fused_mlp_kernel<MODE, TMR>), grid, dim3(NTHR), lds, st, g);
+    hipLaunchKernelGGL((fused_mlp_kernel<MODE, TMR, DBUF>), grid, dim3(NTHR), lds, st, g);
     return ssac_check_launch("fused_mlp");
 }
 
 template <int MODE>
 int launch_fused(const FusedArgs &g, int n_sel, hipStream_t st) {
-    return pick_tile_rows(g.n_rows, n_sel) == 16 ? launch_fused_t<MODE, 16>(g, n_sel, st)
-                                                 : launch_fused_t<MODE, 32>(g, n_sel, st);
+    if (pick_single_buffer(g, n_sel)) return launch_fused_t<MODE, 16, false>(g, n_sel, st);
+    return pick_tile_rows(g, n_sel) == 16 ? launch_fused_t<MODE, 16, true>(g, n_sel, st)
+                                                 : launch_fused_t<MODE, 32, true>(g, n_sel, st);
 }
 
 // ------------------------------------------------------------------ head weight gradient + Adam
@@ -771,13 +829,16 @@ extern "C" int ssac_critic_fwd_bwd_fused(const ssac_mlp *nets, const float *X, i
 }
 
 // row tiles the fused critic launch will use for (n_rows, n_nets): sizes the `partials` buffer
-extern "C" int ssac_fused_row_tiles(int n_rows, int n_nets) {
-    const int tm = pick_tile_rows(n_rows, n_nets);
+extern "C" int ssac_fused_row_tiles(const ssac_mlp *nets, int n_rows, int n_nets) {
+    FusedArgs g{};
+    g.n_rows = n_rows; g.in_dim = nets->in_dim; g.hidden = nets->hidden; g.out_dim = nets->out_dim;
+    const int tm = pick_single_buffer(g, n_nets) ? 16 : pick_tile_rows(g, n_nets);
     return (n_rows + tm - 1) / tm;
 }
 
 extern "C" int ssac_fused_tile_rows(int rows) {
-    if (rows != 0 && rows != 16 && rows != 32) return ssac_fail("ssac_fused_tile_rows: 0 (auto), 16 or 32");
+    if (rows != 0 && rows != 16 && rows != 17 && rows != 32)
+        return ssac_fail("ssac_fused_tile_rows: 0 (auto), 16, 17 (16 rows, single buffer) or 32");
     g_tile_rows = rows;
     return 0;
 }

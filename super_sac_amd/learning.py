@@ -225,7 +225,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             q = ws.get(tag + ".y", (N, B, qd))
             dz2 = ws.get(tag + ".dz2", (N, B, H))
             dz1 = ws.get(tag + ".dz1", (N, B, H))
-            tiles = int(lib.ssac_fused_row_tiles(B, N))
+            tiles = int(lib.ssac_fused_row_tiles(C.byref(arena.desc()), B, N))
             parts = ws.get(tag + ".parts", (N * tiles * 2,))
             with engine._timed("critic_fused"):
                 check(lib.ssac_critic_fwd_bwd_fused(

@@ -99,7 +99,7 @@ def test_ensemble_q_known_answers_from_reference(ssa):
     _close(q[:, :, 0], torch.from_numpy(f["ensq_q"]), 5e-5, what="ensemble Q")
 
 
-@pytest.fixture(params=[16, 32], ids=["tile16", "tile32"])
+@pytest.fixture(params=[16, 17, 32], ids=["tile16", "tile16-single-buffer", "tile32"])
 def tile_rows(request, ssa):
     """run the fused kernels with 16-row (16x16x4 MFMA) and 32-row (32x32x2 MFMA) tiles"""
     ssa._lib.check(ssa._lib.lib.ssac_fused_tile_rows(request.param))
@@ -168,7 +168,7 @@ def test_fused_critic_fwd_bwd_matches_autograd(ssa, tile_rows, qd, B, H, N):
     xd, tdd, wd, ad = x.to(DEV), td.to(DEV), w.to(DEV), act.to(DEV)
     h1 = torch.zeros(N, B, H, device=DEV); h2 = torch.zeros_like(h1); dz2 = torch.zeros_like(h1); dz1 = torch.zeros_like(h1)
     q = torch.zeros(N, B, qd, device=DEV); dq = torch.zeros_like(q)
-    tiles = int(ssa._lib.lib.ssac_fused_row_tiles(B, N))
+    tiles = int(ssa._lib.lib.ssac_fused_row_tiles(C.byref(ar.desc()), B, N))
     parts = torch.zeros(N * tiles * 2, device=DEV)
     ssa._lib.check(ssa._lib.lib.ssac_critic_fwd_bwd_fused(
         C.byref(ar.desc()), xd.data_ptr(), in_dim, B, tdd.data_ptr(), wd.data_ptr(), ad.data_ptr(), 1, 0, 0,

@@ -38,7 +38,7 @@ ar = ssa.engine.MlpArena(N, in_dim, H, 1, dev)
 x = torch.randn(B, in_dim, device=dev); td = torch.randn(B, 1, device=dev)
 h1 = torch.zeros(N, B, H, device=dev); h2 = torch.zeros_like(h1); dz2 = torch.zeros_like(h1); dz1 = torch.zeros_like(h1)
 q = torch.zeros(N, B, 1, device=dev); dq = torch.zeros_like(q)
-tiles = int(ssa._lib.lib.ssac_fused_row_tiles(B, N)); parts = torch.zeros(N * tiles * 2, device=dev)
+tiles = int(ssa._lib.lib.ssac_fused_row_tiles(C.byref(ar.desc()), B, N)); parts = torch.zeros(N * tiles * 2, device=dev)
 dbg = torch.zeros(16, dtype=torch.int64, device=dev)
 ssa._lib.lib.ssac_fused_debug_stamps(dbg.data_ptr())
 def run():

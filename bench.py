@@ -38,6 +38,7 @@ OBS, ACT, BATCH, NCRIT, NSUB, HID = 17, 6, 512, 10, 2, 256
 ROWS, CAP = 100_000, 1_000_000
 GAMMA, LR, TAU, TARGET_DELAY = 0.99, 3e-4, 0.005, 2
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+TRAFFIC_FWD_BYTES = None  # filled from the PMC passes (profiles/): HBM bytes of one ensemble-Q forward launch
 
 
 def synth_data():
@@ -180,37 +181,55 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
 
-    # ---- roofline of the dominant kernel: the fused critic kernel (forward of all local critics,
-    # loss gradient, backward-data), one launch per update.  Algorithmic FLOPs per launch:
-    # forward 2*B*N*(in*H + H*H + H*out) + backward-data 2*B*N*(out*H + H*H).
-    # The timed region replays the update as ONE HIP graph, inside which a single kernel cannot be bracketed
-    # by events; so the same update is run again right here with plain launches and the fused critic launch
-    # is bracketed by HIP events recorded on its stream (same shapes, same buffers, same kernel binary).
+    # ---- roofline of the dominant kernel: the ensemble-Q kernel = fused forward (fc1+fc2+head, activations in
+    # LDS) of all local critics on the sampled batch, one launch per update.  Algorithmic FLOPs per launch
+    # (SURVEY 8(d)): 2*B*N*(in*H + H*H + H*out).  Its backward half (loss gradient, head backward, fc2
+    # backward-data: 2*B*N*(out*H + H*H) FLOPs) is a second launch of the same kernel template and is reported
+    # beside it.  The timed region replays the update as ONE HIP graph, inside which a single kernel cannot be
+    # bracketed by events; so the same update is run again right here with plain launches and the launches are
+    # bracketed by HIP events recorded on the stream each one is launched on (same shapes, buffers, binary).
     graphs_were_on = ssa.learning.USE_GRAPHS
     ssa.learning.USE_GRAPHS = False
-    ssa.engine.PROFILE["tag"] = "critic_fused"
+    ssa.engine.PROFILE["tag"] = ("critic_fwd", "critic_bwd", "critic_fused")
     ssa.engine.PROFILE["events"] = []
     for _ in range(min(args.steps, 300)):
         step()
     torch.cuda.synchronize()
     ssa.engine.PROFILE["tag"] = None
     ssa.learning.USE_GRAPHS = graphs_were_on
-    evs = ssa.engine.PROFILE["events"]
-    ms = sorted(a.elapsed_time(b) for a, b in evs)
-    avg_ms = sum(ms) / len(ms)
+    by_tag = {}
+    for a, b, tag in ssa.engine.PROFILE["events"]:
+        by_tag.setdefault(tag, []).append(a.elapsed_time(b))
     IN = OBS + ACT
-    flops = 2.0 * BATCH * n_local * (IN * HID + HID * HID + HID) + 2.0 * BATCH * n_local * (HID + HID * HID)
+    f_fwd = 2.0 * BATCH * n_local * (IN * HID + HID * HID + HID)
+    f_bwd = 2.0 * BATCH * n_local * (HID + HID * HID)
+    if "critic_fwd" in by_tag:
+        ms = by_tag["critic_fwd"]
+        flops, kname = f_fwd, ("fused_mlp_kernel<plain>: ensemble-Q forward (fc1+fc2+head) of all local critics, "
+                               "h1/h2/q stored for the backward launches (one launch per update)")
+    else:  # the one-launch forward+backward form (learning.SPLIT_FORWARD off / chip-filling ensembles)
+        ms = by_tag["critic_fused"]
+        flops, kname = f_fwd + f_bwd, ("fused_mlp_kernel<critic>: forward of all local critics + loss gradient + "
+                                       "head backward + fc2 backward-data (one launch per update)")
+    avg_ms = sum(ms) / len(ms)
     achieved = flops / (avg_ms * 1e-3) / 1e12
-    roofline = {"kernel": "fused_mlp_kernel<critic>: fc1+fc2+head of all local critics, loss gradient, "
-                          "head backward, fc2 backward-data (one launch per update)",
+    roofline = {"kernel": kname,
                 "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                 "avg_launch_us": round(avg_ms * 1e3, 3), "launches_timed": len(ms),
-                "timing": "HIP events around the launch, eager pass right after the timed (graph-replay) region",
+                "timing": "HIP events around the launch on its own stream, eager pass right after the timed "
+                          "(graph-replay) region",
                 "flops_per_launch": flops,
-                # HBM bytes per launch from the PMC passes in profiles/r1_pmc_counters.md (FETCH_SIZE doubled
-                # per the gfx950 note + WRITE_SIZE, KiB -> bytes); not collected live, N=10 single-GPU shape only
-                "traffic": (2 * 12682 + 20525) * 1024 if (world == 1 and n_local == NCRIT) else None}
+                # HBM bytes per launch from the PMC passes in profiles/ (FETCH_SIZE doubled per the gfx950 note
+                # + WRITE_SIZE, KiB -> bytes); not collected live, N=10 single-GPU shape only
+                "traffic": TRAFFIC_FWD_BYTES if (world == 1 and n_local == NCRIT and "critic_fwd" in by_tag) else None}
+    if "critic_bwd" in by_tag:
+        mb = by_tag["critic_bwd"]
+        avg_b = sum(mb) / len(mb)
+        roofline["backward_launch"] = {"kernel": "fused_mlp_kernel<critic-bwd>: loss gradient + head backward + "
+                                                 "fc2 backward-data on the saved forward",
+                                       "avg_launch_us": round(avg_b * 1e3, 3), "flops_per_launch": f_bwd,
+                                       "achieved": round(f_bwd / (avg_b * 1e-3) / 1e12, 3)}
 
     if rank == 0:
         out = {"metric": "gradient updates/sec (REDQ N=10, batch 512)", "value": round(args.steps / dt, 2),

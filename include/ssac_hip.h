@@ -61,8 +61,34 @@ typedef struct ssac_popart {
     double beta;
 } ssac_popart;
 
+/* Per-update host inputs of a captured (hipGraph) update, fed WITHOUT a copy node: the host writes replay
+ * indices / REDQ subset ids / the log-ring slot of update k into slot k % n_slots of a pinned host ring;
+ * ssac_begin_update pulls that slot over PCIe into `dst` (fixed device address, read by the captured gather /
+ * target-critic launches) and ssac_critic_logs, the last launch of the update, publishes the log block into
+ * log_ring[dst_words[log_slot_word]] and advances `tick`.  Lives in DEVICE memory. */
+typedef struct ssac_feed {
+    const uint32_t *host_ring;  /* pinned host memory, n_slots x slot_words 4-byte words */
+    uint32_t *dst;              /* device copy of the current slot (slot_words words) */
+    float *log_ring;            /* device ring of log blocks, log_width floats each */
+    int64_t tick;               /* updates consumed so far */
+    int32_t n_slots, slot_words, log_slot_word, log_width;
+} ssac_feed;
+
 int ssac_abi_version(void);
 const char *ssac_last_error(void);
+
+/* ---- launch lists: record the kernel launches of one update (they still execute while being recorded),
+ * then re-issue the whole sequence with ONE call.  Valid while every pointer argument of the recorded
+ * calls stays alive at the same address -- the same contract as a hipGraph capture, which this replaces on
+ * the update path (a hipGraph launch leaves a ~13 us idle tail on the queue on MI355X; a replayed list
+ * does not).  Recording is per host thread; calls issued between begin and end on that thread are
+ * recorded in issue order, whatever stream they were given, and replayed on the one stream passed. */
+typedef struct ssac_launch_list ssac_launch_list;
+int ssac_record_begin(void);
+ssac_launch_list *ssac_record_end(void);          /* NULL (+ ssac_last_error) when no recording is open */
+int ssac_launch_list_size(const ssac_launch_list *list);
+int ssac_replay(ssac_launch_list *list, void *stream);
+void ssac_launch_list_free(ssac_launch_list *list);
 
 /* floats per net and the six segment offsets {W1,b1,W2,b2,W3,b3}. */
 int64_t ssac_mlp_layout(int in_dim, int hidden, int out_dim, int64_t offsets[6]);
@@ -131,8 +157,9 @@ int ssac_adam_step(float *params, float *adam_m, float *adam_v, const float *gra
                    const ssac_adam_ctl *ctl, void *stream);
 
 /* one launch at the start of an update: zero the n_logs (<= 256) floats of the log block and, when
- * ctl != NULL, advance the optimizer step like ssac_adam_advance. */
-int ssac_begin_update(float *logs, int n_logs, ssac_adam_ctl *ctl, void *stream);
+ * ctl != NULL, advance the optimizer step like ssac_adam_advance; when feed != NULL, also pull this
+ * update's host inputs (ssac_feed) into feed->dst. */
+int ssac_begin_update(float *logs, int n_logs, ssac_adam_ctl *ctl, const ssac_feed *feed, void *stream);
 
 /* advance ctl->step by one and refresh step_size / bc2_sqrt (double precision on device). */
 int ssac_adam_advance(ssac_adam_ctl *ctl, void *stream);
@@ -273,6 +300,15 @@ int ssac_critic_fwd_bwd_fused(const ssac_mlp *nets, const float *X, int64_t ldx,
                               const ssac_popart *popart, int pop, float denom, float *H1, float *H2,
                               float *Q, float *DQ, float *DZ2, float *DZ1, float *partials, void *stream);
 
+/* the second half of ssac_critic_fwd_bwd_fused alone: H1, H2, Q come from an earlier ssac_mlp3_fwd_fused
+ * launch over all nets (same layouts); results are bit-identical to the one-launch form.  The forward does
+ * not depend on the TD target, so the host runs it on a second stream beside the actor / target-critic /
+ * TD-target chain (learning_utils.py:298-354) and joins before this launch. */
+int ssac_critic_bwd_fused(const ssac_mlp *nets, int n_rows, const float *td, const float *weight,
+                          const float *act, int64_t ld_act, const ssac_popart *popart, int pop, float denom,
+                          const float *H1, const float *H2, const float *Q, float *DQ, float *DZ2,
+                          float *DZ1, float *partials, void *stream);
+
 /* weight gradient of the head layer (out_dim <= 16) + Adam/Polyak, VALU: dW3 = DQ^T H2, db3 = colsum(DQ).
  * Same grads/sumsq/target conventions as ssac_mlp_layer_wgrad; sumsq slots: ssac_head_wgrad_tiles(). */
 int ssac_head_wgrad_tiles(const ssac_mlp *nets);
@@ -282,10 +318,13 @@ int ssac_head_wgrad(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, con
                     void *stream);
 
 /* reduce the fused critic kernel's partials into the log block: logs[0] += loss, logs[1] = mean td
- * error of the last net, logs[2] = sqrt(sum(sumsq[0..n_sumsq))) (x clip_coef when given). */
+ * error of the last net, logs[2] = sqrt(sum(sumsq[0..n_sumsq))) (x clip_coef when given).  With feed != NULL
+ * the launch also does what ssac_publish_logs does. */
 int ssac_critic_logs(const float *partials, int n_nets, int tiles, int n_rows, float denom,
                      const float *sumsq, int n_sumsq, const ssac_adam_ctl *scale_by_clip, float *logs,
-                     void *stream);
+                     ssac_feed *feed, void *stream);
+/* last launch of a captured update: copy the finished log block to its ring slot and advance feed->tick. */
+int ssac_publish_logs(const float *logs, ssac_feed *feed, void *stream);
 
 /* ==== pixel encoders (nets/cnns.py:37-103): convolution = im2col + GEMM, activations channels-last ====
  * ssac_im2col: col[(b,oy,ox)][(c,ky,kx)] = float(src[b,c,oy*s+ky,ox*s+kx]) / div + shift, source addressed by

@@ -32,6 +32,13 @@ class PopArtState(C.Structure):
                 ("beta", C.c_double)]
 
 
+class Feed(C.Structure):
+    """struct ssac_feed"""
+    _fields_ = [("host_ring", C.c_void_p), ("dst", C.c_void_p), ("log_ring", C.c_void_p),
+                ("tick", C.c_int64), ("n_slots", C.c_int32), ("slot_words", C.c_int32),
+                ("log_slot_word", C.c_int32), ("log_width", C.c_int32)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _MP = C.POINTER(MlpDesc)
 
@@ -40,6 +47,11 @@ SIGNATURES = {
     "ssac_abi_version": [],
     "ssac_last_error": [],
     "ssac_mlp_layout": [_I, _I, _I, C.POINTER(C.c_int64)],
+    "ssac_record_begin": [],
+    "ssac_record_end": [],
+    "ssac_launch_list_size": [_P],
+    "ssac_replay": [_P, _P],
+    "ssac_launch_list_free": [_P],
     "ssac_gather_rows": [_P, _I, _L, _P, _I, _P, _L, _L, _P],
     "ssac_mlp_layer_fwd": [_MP, _I, _P, _I, _P, _L, _L, _I, _P, _L, _L, _I, _P],
     "ssac_mlp_layer_dgrad": [_MP, _I, _P, _I, _P, _L, _L, _P, _L, _L, _I, _P, _L, _L, _P],
@@ -50,7 +62,8 @@ SIGNATURES = {
     "ssac_gather_transition": [_P, _P, _I, _L, _P, _L, _P, _P, _P, _I, _P, _L, _P, _L, _P, _P, _P],
     "ssac_adam_step": [_P, _P, _P, _P, _L, _P, _P],
     "ssac_adam_advance": [_P, _P],
-    "ssac_begin_update": [_P, _I, _P, _P],
+    "ssac_begin_update": [_P, _I, _P, _P, _P],
+    "ssac_publish_logs": [_P, _P, _P],
     "ssac_clip_coef": [_P, _P, _I, _F, _P, _P],
     "ssac_polyak": [_P, _P, _L, _F, _P],
     "ssac_tanh_normal_fwd": [_P, _L, _P, _I, _I, _F, _F, _P, _L, _L, _P, _P],
@@ -84,11 +97,13 @@ SIGNATURES = {
     "ssac_mlp3_fwd_fused": [_MP, _P, _I, _P, _L, _L, _I, _P, _P, _P, _P],
     "ssac_actor_sample_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _P, _P, _P],
     "ssac_critic_fwd_bwd_fused": [_MP, _P, _L, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ssac_critic_bwd_fused": [_MP, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P],
     "ssac_head_wgrad_tiles": [_MP],
     "ssac_head_wgrad": [_MP, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P, _F, _P],
-    "ssac_critic_logs": [_P, _I, _I, _I, _F, _P, _I, _P, _P, _P],
+    "ssac_critic_logs": [_P, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P],
 }
-_RESTYPES = {"ssac_last_error": C.c_char_p, "ssac_mlp_layout": C.c_int64}
+_RESTYPES = {"ssac_last_error": C.c_char_p, "ssac_mlp_layout": C.c_int64, "ssac_record_end": C.c_void_p,
+             "ssac_launch_list_free": None}
 
 
 def _load():

@@ -194,7 +194,7 @@ extern "C" int ssac_im2col(const void *src, int src_u8, int64_t sb, int64_t sc, 
                  (Wi - k) / stride + 1, div, shift, col};
     const int64_t total = (int64_t)B * a.Ho * a.Wo * C * k * k;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, ST, a);
+    SSAC_LAUNCH(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, ST, a);
     return ssac_check_launch("im2col");
 }
 
@@ -206,26 +206,26 @@ extern "C" int ssac_col2im(const float *dcol, float *dx, int64_t sb, int64_t sc,
                  (Hi - k) / stride + 1, (Wi - k) / stride + 1};
     const int64_t total = (int64_t)B * C * Hi * Wi;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, ST, a);
+    SSAC_LAUNCH(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, ST, a);
     return ssac_check_launch("col2im");
 }
 
 extern "C" int ssac_relu_mask(float *dy, const float *y, int64_t n, void *stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for(n)), dim3(256), 0, ST, dy, y, n);
+    SSAC_LAUNCH(relu_mask_kernel, dim3(grid_for(n)), dim3(256), 0, ST, dy, y, n);
     return ssac_check_launch("relu_mask");
 }
 
 extern "C" int ssac_reduce_slices(const float *partial, int slices, int64_t n, float *out, void *stream) {
     if (n <= 0 || slices <= 0) return 0;
-    hipLaunchKernelGGL(reduce_slices_kernel, dim3(grid_for(n)), dim3(256), 0, ST, partial, slices, n, out);
+    SSAC_LAUNCH(reduce_slices_kernel, dim3(grid_for(n)), dim3(256), 0, ST, partial, slices, n, out);
     return ssac_check_launch("reduce_slices");
 }
 
 extern "C" int ssac_sumsq_blocks(void) { return 256; }
 
 extern "C" int ssac_sumsq(const float *x, int64_t n, float *out_partials, void *stream) {
-    hipLaunchKernelGGL(sumsq_kernel, dim3(256), dim3(256), 0, ST, x, n, out_partials);
+    SSAC_LAUNCH(sumsq_kernel, dim3(256), dim3(256), 0, ST, x, n, out_partials);
     return ssac_check_launch("sumsq");
 }
 
@@ -233,7 +233,7 @@ extern "C" int ssac_ln_tanh_fwd(const float *x, int64_t ldx, const float *gamma,
                                 int n_rows, int dim, float *out, int64_t ldo, float *xhat, float *rstd,
                                 void *stream) {
     if (n_rows <= 0) return 0;
-    hipLaunchKernelGGL(ln_tanh_fwd_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ST, x, ldx, gamma, beta,
+    SSAC_LAUNCH(ln_tanh_fwd_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ST, x, ldx, gamma, beta,
                        n_rows, dim, out, ldo, xhat, rstd);
     return ssac_check_launch("ln_tanh_fwd");
 }
@@ -243,7 +243,7 @@ extern "C" int ssac_ln_tanh_bwd(const float *d_out, int64_t ldd, const float *ou
                                 int dim, float *dx, int64_t ldx, float *dy_scratch, float *dgamma,
                                 float *dbeta, void *stream) {
     if (n_rows <= 0) return 0;
-    hipLaunchKernelGGL(ln_tanh_bwd_kernel, dim3(1), dim3(1024), 0, ST, d_out, ldd, out, ldo, xhat, rstd,
+    SSAC_LAUNCH(ln_tanh_bwd_kernel, dim3(1), dim3(1024), 0, ST, d_out, ldd, out, ldo, xhat, rstd,
                        gamma, n_rows, dim, dx, ldx, dy_scratch, dgamma, dbeta);
     return ssac_check_launch("ln_tanh_bwd");
 }

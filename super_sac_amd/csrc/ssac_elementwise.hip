@@ -440,9 +440,22 @@ __global__ __launch_bounds__(RED_THREADS) void alpha_update_kernel(
 __global__ void adam_advance_kernel(ssac_adam_ctl *ctl) { adam_refresh(ctl, ctl->step + 1); }
 
 // start of an update: clear the log block and advance the optimizer's step in one launch
-__global__ void begin_update_kernel(float *logs, int n, ssac_adam_ctl *ctl) {
+__global__ void begin_update_kernel(float *logs, int n, ssac_adam_ctl *ctl, const ssac_feed *feed) {
     if ((int)threadIdx.x < n) logs[threadIdx.x] = 0.0f;
     if (threadIdx.x == 0 && ctl) adam_refresh(ctl, ctl->step + 1);
+    if (feed) {  // this update's host inputs: pinned ring slot -> fixed device block (one PCIe round trip)
+        const ssac_feed f = *feed;
+        const uint32_t *src = f.host_ring + (int64_t)(f.tick % f.n_slots) * f.slot_words;
+        for (int i = threadIdx.x; i < f.slot_words; i += blockDim.x) f.dst[i] = src[i];
+    }
+}
+
+__global__ void publish_logs_kernel(const float *logs, ssac_feed *feed) {
+    const int slot = (int)feed->dst[feed->log_slot_word];
+    const int w = feed->log_width;
+    if ((int)threadIdx.x < w) feed->log_ring[(int64_t)slot * w + threadIdx.x] = logs[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) feed->tick += 1;
 }
 
 __global__ __launch_bounds__(RED_THREADS) void clip_coef_kernel(ssac_adam_ctl *ctl,
@@ -624,10 +637,10 @@ extern "C" int ssac_gather_rows(const void *src, int src_dtype, int64_t row_elem
     if (n_rows <= 0 || row_elems <= 0) return 0;
     const int64_t total = (int64_t)n_rows * row_elems;
     if (src_dtype == 0)
-        hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid_for(total)), dim3(256), 0, ST,
+        SSAC_LAUNCH(gather_rows_kernel<float>, dim3(grid_for(total)), dim3(256), 0, ST,
                            (const float *)src, row_elems, idx, n_rows, dst, ld_dst, dst_col0);
     else if (src_dtype == 1)
-        hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, dim3(grid_for(total)), dim3(256), 0, ST,
+        SSAC_LAUNCH(gather_rows_kernel<uint8_t>, dim3(grid_for(total)), dim3(256), 0, ST,
                            (const uint8_t *)src, row_elems, idx, n_rows, dst, ld_dst, dst_col0);
     else
         return ssac_fail("ssac_gather_rows: unsupported src_dtype");
@@ -642,11 +655,11 @@ extern "C" int ssac_gather_transition(const void *s, const void *s1, int s_dtype
     if (n_rows <= 0) return 0;
     const int64_t total = (int64_t)n_rows * (2 * s_elems + a_elems + 2);
     if (s_dtype == 0)
-        hipLaunchKernelGGL(gather_transition_kernel<float>, dim3(grid_for(total)), dim3(256), 0, ST,
+        SSAC_LAUNCH(gather_transition_kernel<float>, dim3(grid_for(total)), dim3(256), 0, ST,
                            (const float *)s, (const float *)s1, s_elems, act, a_elems, rew, done, idx,
                            n_rows, xsa, ld_x, x1sa, ld_x1, rew_out, done_out);
     else if (s_dtype == 1)
-        hipLaunchKernelGGL(gather_transition_kernel<uint8_t>, dim3(grid_for(total)), dim3(256), 0, ST,
+        SSAC_LAUNCH(gather_transition_kernel<uint8_t>, dim3(grid_for(total)), dim3(256), 0, ST,
                            (const uint8_t *)s, (const uint8_t *)s1, s_elems, act, a_elems, rew, done,
                            idx, n_rows, xsa, ld_x, x1sa, ld_x1, rew_out, done_out);
     else
@@ -658,7 +671,7 @@ extern "C" int ssac_tanh_normal_fwd(const float *out, int64_t ld_out, const floa
                                     int act_dim, float lo, float hi, float *act_dst, int64_t ld_act,
                                     int64_t act_col0, float *logp, void *stream) {
     if (n_rows <= 0) return 0;
-    hipLaunchKernelGGL(tanh_normal_fwd_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ST, out, ld_out,
+    SSAC_LAUNCH(tanh_normal_fwd_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ST, out, ld_out,
                        eps, n_rows, act_dim, lo, hi, act_dst, ld_act, act_col0, logp);
     return ssac_check_launch("tanh_normal_fwd");
 }
@@ -669,7 +682,7 @@ extern "C" int ssac_det_action_fwd(const float *out, int64_t ld_out, const float
                                    void *stream) {
     if (n_rows <= 0) return 0;
     const int total = n_rows * act_dim;
-    hipLaunchKernelGGL(det_action_fwd_kernel, dim3((total + 255) / 256), dim3(256), 0, ST, out, ld_out,
+    SSAC_LAUNCH(det_action_fwd_kernel, dim3((total + 255) / 256), dim3(256), 0, ST, out, ld_out,
                        eps, sample_std, noise, noise_scale, noise_clip, n_rows, act_dim, act_dst, ld_act,
                        act_col0);
     return ssac_check_launch("det_action_fwd");
@@ -680,7 +693,7 @@ extern "C" int ssac_td_target(const float *q_t, int n_sel, int n_rows, int q_dim
                               const float *log_alpha, int use_entropy, float gamma, ssac_popart *popart,
                               int pop, float *td, float *logs, void *stream) {
     if (n_sel < 1 || n_rows < 1 || q_dim < 1) return ssac_fail("ssac_td_target: bad sizes");
-    hipLaunchKernelGGL(td_target_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q_t, n_sel, n_rows, q_dim,
+    SSAC_LAUNCH(td_target_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q_t, n_sel, n_rows, q_dim,
                        logp_or_logits, rew, done, log_alpha, use_entropy, gamma, popart, pop, td, logs);
     return ssac_check_launch("td_target");
 }
@@ -691,7 +704,7 @@ extern "C" int ssac_critic_loss_bwd(const float *q, int n_nets, int n_rows, int 
                                     float *logs, void *stream) {
     if (n_nets < 1 || n_rows < 1 || q_dim < 1) return ssac_fail("ssac_critic_loss_bwd: bad sizes");
     if (q_dim > 1 && !act) return ssac_fail("ssac_critic_loss_bwd: discrete needs actions");
-    hipLaunchKernelGGL(critic_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_nets, n_rows,
+    SSAC_LAUNCH(critic_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_nets, n_rows,
                        q_dim, act, ld_act, td, weight, popart, pop, denom, dq, logs);
     return ssac_check_launch("critic_loss_bwd");
 }
@@ -701,7 +714,7 @@ extern "C" int ssac_actor_loss_bwd(const float *q, int n_nets, int n_rows, const
                                    int pop, float inv_members, const float *qmin_global, float *dq,
                                    float *logs, void *stream) {
     if (n_nets < 1 || n_rows < 1) return ssac_fail("ssac_actor_loss_bwd: bad sizes");
-    hipLaunchKernelGGL(actor_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_nets, n_rows, logp,
+    SSAC_LAUNCH(actor_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_nets, n_rows, logp,
                        log_alpha, use_entropy, popart, pop, inv_members, qmin_global, dq, logs);
     return ssac_check_launch("actor_loss_bwd");
 }
@@ -712,7 +725,7 @@ extern "C" int ssac_tanh_normal_bwd(const float *dX, int n_nets, int64_t ldx, in
                                     int use_entropy, float inv_members, float *d_out, int64_t ld_dout,
                                     void *stream) {
     if (n_rows <= 0) return 0;
-    hipLaunchKernelGGL(tanh_normal_bwd_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ST, dX, n_nets, ldx,
+    SSAC_LAUNCH(tanh_normal_bwd_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ST, dX, n_nets, ldx,
                        x_net_stride, act_col0, out, ld_out, eps, n_rows, act_dim, lo, hi, log_alpha,
                        use_entropy, inv_members, d_out, ld_dout);
     return ssac_check_launch("tanh_normal_bwd");
@@ -723,7 +736,7 @@ extern "C" int ssac_det_action_bwd(const float *dX, int n_nets, int64_t ldx, int
                                    int act_dim, float *d_out, int64_t ld_dout, void *stream) {
     if (n_rows <= 0) return 0;
     const int total = n_rows * act_dim;
-    hipLaunchKernelGGL(det_action_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, ST, dX, n_nets, ldx,
+    SSAC_LAUNCH(det_action_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, ST, dX, n_nets, ldx,
                        x_net_stride, act_col0, out, ld_out, n_rows, act_dim, d_out, ld_dout);
     return ssac_check_launch("det_action_bwd");
 }
@@ -733,7 +746,7 @@ extern "C" int ssac_discrete_actor_loss_bwd(const float *logits, const float *q,
                                             int pop, float inv_members, float *d_logits, float *logs,
                                             void *stream) {
     if (n_nets < 1 || n_rows < 1 || n_act < 2) return ssac_fail("ssac_discrete_actor_loss_bwd: bad sizes");
-    hipLaunchKernelGGL(discrete_actor_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, logits, q,
+    SSAC_LAUNCH(discrete_actor_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, logits, q,
                        n_nets, n_rows, n_act, log_alpha, popart, pop, inv_members, d_logits, logs);
     return ssac_check_launch("discrete_actor_loss_bwd");
 }
@@ -742,25 +755,32 @@ extern "C" int ssac_alpha_update(float *log_alpha, float *adam_m, float *adam_v,
                                  const float *logp_or_logits, int n_rows, int n_act, float target_entropy,
                                  float *logs, void *stream) {
     if (n_rows < 1) return ssac_fail("ssac_alpha_update: bad sizes");
-    hipLaunchKernelGGL(alpha_update_kernel, dim3(1), dim3(RED_THREADS), 0, ST, log_alpha, adam_m, adam_v,
+    SSAC_LAUNCH(alpha_update_kernel, dim3(1), dim3(RED_THREADS), 0, ST, log_alpha, adam_m, adam_v,
                        ctl, logp_or_logits, n_rows, n_act, target_entropy, logs);
     return ssac_check_launch("alpha_update");
 }
 
 extern "C" int ssac_adam_advance(ssac_adam_ctl *ctl, void *stream) {
-    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, ST, ctl);
+    SSAC_LAUNCH(adam_advance_kernel, dim3(1), dim3(1), 0, ST, ctl);
     return ssac_check_launch("adam_advance");
 }
 
-extern "C" int ssac_begin_update(float *logs, int n_logs, ssac_adam_ctl *ctl, void *stream) {
+extern "C" int ssac_begin_update(float *logs, int n_logs, ssac_adam_ctl *ctl, const ssac_feed *feed,
+                                 void *stream) {
     if (n_logs > 256) return ssac_fail("ssac_begin_update: log block too large");
-    hipLaunchKernelGGL(begin_update_kernel, dim3(1), dim3(256), 0, ST, logs, n_logs, ctl);
+    SSAC_LAUNCH(begin_update_kernel, dim3(1), dim3(256), 0, ST, logs, n_logs, ctl, feed);
     return ssac_check_launch("begin_update");
+}
+
+extern "C" int ssac_publish_logs(const float *logs, ssac_feed *feed, void *stream) {
+    if (!logs || !feed) return ssac_fail("ssac_publish_logs: null argument");
+    SSAC_LAUNCH(publish_logs_kernel, dim3(1), dim3(256), 0, ST, logs, feed);
+    return ssac_check_launch("publish_logs");
 }
 
 extern "C" int ssac_clip_coef(ssac_adam_ctl *ctl, const float *sumsq, int n, float max_norm,
                               float *norm_out, void *stream) {
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(RED_THREADS), 0, ST, ctl, sumsq, n, max_norm,
+    SSAC_LAUNCH(clip_coef_kernel, dim3(1), dim3(RED_THREADS), 0, ST, ctl, sumsq, n, max_norm,
                        norm_out);
     return ssac_check_launch("clip_coef");
 }
@@ -768,7 +788,7 @@ extern "C" int ssac_clip_coef(ssac_adam_ctl *ctl, const float *sumsq, int n, flo
 extern "C" int ssac_group_norms(const float *sumsq, int n_groups, int group_size,
                                 const ssac_adam_ctl *scale_by_clip, float *out, void *stream) {
     if (n_groups <= 0 || group_size <= 0) return 0;
-    hipLaunchKernelGGL(group_norms_kernel, dim3(n_groups), dim3(64), 0, ST, sumsq, group_size,
+    SSAC_LAUNCH(group_norms_kernel, dim3(n_groups), dim3(64), 0, ST, sumsq, group_size,
                        scale_by_clip, out);
     return ssac_check_launch("group_norms");
 }
@@ -776,27 +796,27 @@ extern "C" int ssac_group_norms(const float *sumsq, int n_groups, int group_size
 extern "C" int ssac_adam_step(float *params, float *adam_m, float *adam_v, const float *grads, int64_t n,
                               const ssac_adam_ctl *ctl, void *stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(adam_step_kernel, dim3(grid_for(n)), dim3(256), 0, ST, params, adam_m, adam_v,
+    SSAC_LAUNCH(adam_step_kernel, dim3(grid_for(n)), dim3(256), 0, ST, params, adam_m, adam_v,
                        grads, n, ctl);
     return ssac_check_launch("adam_step");
 }
 
 extern "C" int ssac_polyak(float *target, const float *source, int64_t n, float tau, void *stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(polyak_kernel, dim3(grid_for(n)), dim3(256), 0, ST, target, source, n, tau);
+    SSAC_LAUNCH(polyak_kernel, dim3(grid_for(n)), dim3(256), 0, ST, target, source, n, tau);
     return ssac_check_launch("polyak");
 }
 
 extern "C" int ssac_zero(float *p, int64_t n, void *stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(zero_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, n);
+    SSAC_LAUNCH(zero_kernel, dim3(grid_for(n)), dim3(256), 0, ST, p, n);
     return ssac_check_launch("zero");
 }
 
 extern "C" int ssac_sunrise_weights(const float *q, int n_members, int n_rows, float temp, float *w,
                                     float *logs, void *stream) {
     if (n_members < 2 || n_rows < 1) return ssac_fail("ssac_sunrise_weights: bad sizes");
-    hipLaunchKernelGGL(sunrise_weights_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_members, n_rows,
+    SSAC_LAUNCH(sunrise_weights_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_members, n_rows,
                        temp, w, logs);
     return ssac_check_launch("sunrise_weights");
 }
@@ -808,10 +828,10 @@ extern "C" int ssac_drq_shift(const void *src, int src_dtype, const int64_t *idx
     if (mode != 0 && mode != 1) return ssac_fail("ssac_drq_shift: bad mode");
     const int64_t total = (int64_t)n * c * h * h;
     if (src_dtype == 0)
-        hipLaunchKernelGGL(drq_shift_kernel<float>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST,
+        SSAC_LAUNCH(drq_shift_kernel<float>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST,
                            (const float *)src, idx, n, c, h, pad, shift, mode, noise, n_aug, dst);
     else if (src_dtype == 1)
-        hipLaunchKernelGGL(drq_shift_kernel<uint8_t>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST,
+        SSAC_LAUNCH(drq_shift_kernel<uint8_t>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST,
                            (const uint8_t *)src, idx, n, c, h, pad, shift, mode, noise, n_aug, dst);
     else
         return ssac_fail("ssac_drq_shift: unsupported src_dtype");
@@ -837,3 +857,46 @@ int ssac_check_launch(const char *what) {
 
 extern "C" const char *ssac_last_error(void) { return g_err; }
 extern "C" int ssac_abi_version(void) { return SSAC_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------
+// launch lists (see ssac_internal.h)
+// ---------------------------------------------------------------------------------------------
+thread_local std::vector<SsacLaunchRec> *g_ssac_recording = nullptr;
+
+struct ssac_launch_list {
+    std::vector<SsacLaunchRec> recs;
+};
+
+extern "C" int ssac_record_begin(void) {
+    if (g_ssac_recording) return ssac_fail("ssac_record_begin: a recording is already open on this thread");
+    g_ssac_recording = new std::vector<SsacLaunchRec>();
+    return 0;
+}
+
+extern "C" ssac_launch_list *ssac_record_end(void) {
+    if (!g_ssac_recording) {
+        ssac_fail("ssac_record_end: no recording is open on this thread");
+        return nullptr;
+    }
+    ssac_launch_list *l = new ssac_launch_list();
+    l->recs.swap(*g_ssac_recording);
+    delete g_ssac_recording;
+    g_ssac_recording = nullptr;
+    return l;
+}
+
+extern "C" int ssac_launch_list_size(const ssac_launch_list *list) { return list ? (int)list->recs.size() : -1; }
+
+extern "C" int ssac_replay(ssac_launch_list *list, void *stream) {
+    if (!list) return ssac_fail("ssac_replay: null launch list");
+    void *argv[64];
+    for (SsacLaunchRec &r : list->recs) {
+        if (r.offsets.size() > 64) return ssac_fail("ssac_replay: too many kernel arguments");
+        for (size_t i = 0; i < r.offsets.size(); ++i) argv[i] = r.blob.data() + r.offsets[i];
+        hipError_t e = hipLaunchKernel(r.func, r.grid, r.block, argv, r.lds, ST);
+        if (e != hipSuccess) return ssac_check_launch("ssac_replay");
+    }
+    return 0;
+}
+
+extern "C" void ssac_launch_list_free(ssac_launch_list *list) { delete list; }

@@ -8,6 +8,10 @@
 //   MODE_CRITIC  critic loss gradient (learning.py:90-98), head backward, and the backward-data
 //                GEMM of fc2 -- i.e. forward + loss + the whole dL/d(activations) chain.  Only
 //                what the weight-gradient GEMMs need (h1, h2, dz2, dz1, dq) is written to HBM.
+//   MODE_CRITIC_BWD  the second half of MODE_CRITIC alone: h1, h2, q tiles are read back from HBM (written
+//                by an earlier MODE_PLAIN launch), then loss gradient, head backward, fc2 backward-data.
+//                Lets the critic FORWARD run concurrently with the actor/target-critic/TD-target chain
+//                (it does not depend on the TD target); bit-identical to MODE_CRITIC.
 //
 // A workgroup is 512 threads = 8 waves (2 per SIMD, so one wave's LDS/barrier phases hide under
 // the other's MFMAs); wave w owns output columns [32w, 32w+32) of the 32 x H activation tile as one
@@ -37,7 +41,7 @@ constexpr int MAX_OUT = 16;
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 constexpr float LOG_2 = 0.69314718055994530942f;
 
-enum { MODE_PLAIN = 0, MODE_SAMPLE = 1, MODE_CRITIC = 2 };
+enum { MODE_PLAIN = 0, MODE_SAMPLE = 1, MODE_CRITIC = 2, MODE_CRITIC_BWD = 3 };
 
 struct FusedArgs {
     const float *params; int64_t net_stride; int in_dim, hidden, out_dim;
@@ -51,7 +55,6 @@ struct FusedArgs {
     // MODE_CRITIC
     const float *td, *weight, *act; int64_t ld_a; const ssac_popart *popart; int pop; float denom;
     float *DQ, *DZ2, *DZ1; float *partials;  // partials[(e*tiles + tile)*2 + {loss, err}]
-    int vec;  // 16-byte weight loads are legal for this arena
     long long *dbg;  // optional phase timestamps (s_memtime) of workgroup (0,0), thread 0
 };
 
@@ -60,122 +63,83 @@ __device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : lo
 // ---------------------------------------------------------------------------------------------
 // Weight staging.  Two LDS buffers; chunk c+1 is written while chunk c is being multiplied and the
 // global loads of chunk c+2 are in flight, so there is ONE barrier per 32-deep K chunk and the
-// memory instructions of a wave sit between its MFMAs (sched_group_barrier below) instead of in a
-// separate phase.  Per-thread source pointers are computed once and advanced by a uniform step
-// (no 64-bit address arithmetic in the loop).  VEC = 16-byte global loads (needs ldw % 4 == 0,
-// K % 32 == 0, 16-byte aligned base; the host checks); otherwise a guarded scalar path.
+// memory instructions of a wave sit between its MFMAs instead of in a separate phase.  Per-thread
+// source pointers are computed once and advanced by a uniform step (no 64-bit address arithmetic in
+// the loop).  All global loads are 16 bytes wide; the source only has to be dword aligned (gfx950
+// global loads have no wider alignment requirement), so rows of any length -- e.g. the 393-float rows of
+// a Humanoid critic's fc1 -- stage as fast as aligned ones.
 // ---------------------------------------------------------------------------------------------
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+struct NoStage {
+    __device__ __forceinline__ void load(int, int) {}
+};
 
 // W is (Nout x K), K contiguous.  LDS image Ws[n*WS_LD + k] for n < 256, k < 32.
-template <bool VEC>
 struct KcStage {
-    const float *p[VEC ? 4 : 16];
+    const float *p[4];
     unsigned okmask;
     int kk;
     f4 v[4];
-    float s[VEC ? 1 : 16];
     __device__ __forceinline__ void init(const float *W, int ldw, int Nout, int tid) {
         okmask = 0;
-        if (VEC) {
-            kk = (tid & 7) * 4;
+        kk = (tid & 7) * 4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = (tid >> 3) + 64 * q;
-                const bool ok = n < Nout;
-                p[q] = W + (ok ? (int64_t)n * ldw + kk : 0);
-                okmask |= (ok ? 1u : 0u) << q;
-            }
-        } else {
-            kk = tid & 31;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int n = (tid >> 5) + 16 * q;
-                const bool ok = n < Nout;
-                p[q] = W + (ok ? (int64_t)n * ldw + kk : 0);
-                okmask |= (ok ? 1u : 0u) << q;
-            }
+        for (int q = 0; q < 4; ++q) {
+            const int n = (tid >> 3) + 64 * q;
+            const bool ok = n < Nout;
+            p[q] = W + (ok ? (int64_t)n * ldw + kk : 0);
+            okmask |= (ok ? 1u : 0u) << q;
         }
     }
     __device__ __forceinline__ void load(int k0, int K) {
-        if (VEC) {
+        const int left = K - (k0 + kk);  // valid k values at and after this thread's first one
+        if (left >= 4) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f4 *>(p[q] + k0);
-        } else {
-            const bool kok = (k0 + kk) < K;
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f4u *>(p[q] + k0);
+        } else {  // ragged tail of the last chunk (K % 32 != 0): element-wise, zero filled
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const bool ok = kok && ((okmask >> q) & 1u);
-                const float x = p[q][ok ? k0 : 0];
-                s[q] = ok ? x : 0.0f;
-            }
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[q][i] = i < left ? p[q][k0 + i] : 0.0f;
         }
     }
     __device__ __forceinline__ void store(float *__restrict__ Ws, int tid) const {
-        if (VEC) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool ok = (okmask >> q) & 1u;
-                *reinterpret_cast<f4 *>(Ws + ((tid >> 3) + 64 * q) * WS_LD + kk) =
-                    ok ? v[q] : (f4){0.f, 0.f, 0.f, 0.f};
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) Ws[((tid >> 5) + 16 * q) * WS_LD + kk] = s[q];
+        for (int q = 0; q < 4; ++q) {
+            const bool ok = (okmask >> q) & 1u;
+            *reinterpret_cast<f4 *>(Ws + ((tid >> 3) + 64 * q) * WS_LD + kk) = ok ? v[q] : (f4){0.f, 0.f, 0.f, 0.f};
         }
     }
 };
 
-// W is (K x Ncols), rows contiguous; stage rows [n0, n0+32), columns [0, 256) -> Wt[n*256 + c].
-template <bool VEC>
+// W is (K x Ncols), rows contiguous, Ncols % 4 == 0; stage rows [n0, n0+32), columns [0, 256) -> Wt[n*256 + c].
 struct RcStage {
-    const float *p[VEC ? 4 : 16];
-    bool cok[VEC ? 1 : 1];
+    const float *p[4];
+    bool cok;
     int c0;
     f4 v[4];
-    float s[VEC ? 1 : 16];
-    int ldw_, ncols_;
+    int ldw_;
     __device__ __forceinline__ void init(const float *W, int ldw, int Ncols, int tid) {
-        ldw_ = ldw; ncols_ = Ncols;
-        if (VEC) {
-            c0 = (tid & 63) * 4;
-            cok[0] = c0 < Ncols;  // Ncols % 4 == 0 on this path
+        ldw_ = ldw;
+        c0 = (tid & 63) * 4;
+        cok = c0 < Ncols;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) p[q] = W + (cok[0] ? (int64_t)((tid >> 6) + 8 * q) * ldw + c0 : 0);
-        } else {
-            c0 = tid & 255;
-            cok[0] = c0 < Ncols;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) p[q] = W + (cok[0] ? (int64_t)((tid >> 8) + 2 * q) * ldw + c0 : 0);
-        }
+        for (int q = 0; q < 4; ++q) p[q] = W + (cok ? (int64_t)((tid >> 6) + 8 * q) * ldw + c0 : 0);
     }
     // rows n0 + local row; K = number of rows of W
     __device__ __forceinline__ void load(int n0, int K) {
-        if (VEC) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool ok = cok[0] && (n0 + (int)(threadIdx.x >> 6) + 8 * q) < K;
-                const f4 x = *reinterpret_cast<const f4 *>(p[q] + (ok ? (int64_t)n0 * ldw_ : 0));
-                v[q] = ok ? x : (f4){0.f, 0.f, 0.f, 0.f};
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const bool ok = cok[0] && (n0 + (int)(threadIdx.x >> 8) + 2 * q) < K;
-                const float x = p[q][ok ? (int64_t)n0 * ldw_ : 0];
-                s[q] = ok ? x : 0.0f;
-            }
+        for (int q = 0; q < 4; ++q) {
+            const bool ok = cok && (n0 + (int)(threadIdx.x >> 6) + 8 * q) < K;
+            const f4 x = *reinterpret_cast<const f4u *>(p[q] + (ok ? (int64_t)n0 * ldw_ : 0));
+            v[q] = ok ? x : (f4){0.f, 0.f, 0.f, 0.f};
         }
     }
     __device__ __forceinline__ void store(float *__restrict__ Wt, int tid) const {
-        if (VEC) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<f4 *>(Wt + ((tid >> 6) + 8 * q) * 256 + c0) = v[q];
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) Wt[((tid >> 8) + 2 * q) * 256 + c0] = s[q];
-        }
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f4 *>(Wt + ((tid >> 6) + 8 * q) * 256 + c0) = v[q];
     }
 };
 
@@ -296,36 +260,48 @@ template <> struct Tile<16> {
 // NN = true : acc += A[TMR x K] * W,   W = (K x Nw) rows contiguous    (backward-data)
 // Every wave runs the loop (waves whose columns lie beyond the layer width multiply staged zeros).
 // ---------------------------------------------------------------------------------------------
-template <int TMR, bool NN, typename Stage>
+template <int TMR, bool NN, typename Stage, typename Next>
 __device__ __forceinline__ void pipe_step(typename Tile<TMR>::Acc &acc, Stage &st, int c, int nch, int K,
                                           const float *As, int lda, float *nxt,
                                           const typename Tile<TMR>::Frag &cur, typename Tile<TMR>::Frag &nf,
-                                          int tid, int col0) {
+                                          int tid, int col0, Next &nx, int Knext) {
     const bool has1 = (c + 1) < nch, has2 = (c + 2) < nch;
     if (has1) st.store(nxt, tid);
     if (has2) st.load((c + 2) * 32, K);
+    if (!has1) nx.load(0, Knext);  // last chunk: the NEXT phase's first weight chunk goes in flight
     Tile<TMR>::template mfma_half<NN>(acc, cur, 0);
     __syncthreads();
     if (has1) Tile<TMR>::template read<NN>(nf, As, lda, nxt, c + 1, tid & 63, col0);
     Tile<TMR>::template mfma_half<NN>(acc, cur, 1);
 }
 
-// The caller has already done st.init(...) and st.load(0, K): the first weight chunk's global loads are
-// issued one phase EARLY (before the previous phase's epilogue / staging), so no phase of the kernel
-// starts by waiting a full HBM/L2 round trip.
-template <int TMR, bool NN, bool DBUF, typename Stage>
+// Contract: the caller has staged chunk 0 into B0 (stage_first below), and a barrier since then has made
+// it and the A operand visible.  While the LAST chunk is being multiplied, nx.load(0, Knext) puts the next
+// phase's first weight chunk in flight, so no phase starts by waiting a full HBM/L2 round trip; the caller
+// stores it (stage_first) after this function's closing barrier, next to its epilogue.
+template <typename Stage>
+__device__ __forceinline__ void stage_first(Stage &st, float *B0, int K, int tid) {
+    st.store(B0, tid);          // chunk 0 (already loaded) -> LDS
+    if (K > 32) st.load(32, K);  // chunk 1 -> registers
+}
+
+template <int TMR, bool NN, bool DBUF, typename Stage, typename Next>
 __device__ __forceinline__ void gemm_tile(typename Tile<TMR>::Acc &acc, Stage &st, const float *__restrict__ As,
-                                          int lda, int K, float *B0, float *B1, int tid, int col0) {
+                                          int lda, int K, float *B0, float *B1, int tid, int col0, Next &nx,
+                                          int Knext) {
     const int nch = (K + 31) >> 5;
     if (!DBUF) {
         // single staging buffer, two barriers per chunk: half the LDS, so TWO workgroups fit a CU and
         // each one's barrier / staging phases hide under the other's MFMAs (4 waves per SIMD)
         typename Tile<TMR>::Frag f;
         for (int c = 0; c < nch; ++c) {
-            __syncthreads();  // everybody is done with the previous chunk (and with As' writers)
-            st.store(B0, tid);
-            if (c + 1 < nch) st.load((c + 1) * 32, K);
-            __syncthreads();
+            if (c > 0) {
+                __syncthreads();  // everybody is done with the previous chunk
+                st.store(B0, tid);
+                if (c + 1 < nch) st.load((c + 1) * 32, K);
+                __syncthreads();
+            }
+            if (c + 1 == nch) nx.load(0, Knext);
             Tile<TMR>::template read<NN>(f, As, lda, B0, c, tid & 63, col0);
             Tile<TMR>::template mfma_half<NN>(acc, f, 0);
             Tile<TMR>::template mfma_half<NN>(acc, f, 1);
@@ -333,15 +309,11 @@ __device__ __forceinline__ void gemm_tile(typename Tile<TMR>::Acc &acc, Stage &s
         __syncthreads();
         return;
     }
-    __syncthreads();  // previous users of the staging buffers / writers of As are done
-    st.store(B0, tid);
-    if (nch > 1) st.load(32, K);
-    __syncthreads();
     typename Tile<TMR>::Frag f0, f1;
     Tile<TMR>::template read<NN>(f0, As, lda, B0, 0, tid & 63, col0);
     for (int c = 0; c < nch; c += 2) {
-        pipe_step<TMR, NN>(acc, st, c, nch, K, As, lda, B1, f0, f1, tid, col0);
-        if (c + 1 < nch) pipe_step<TMR, NN>(acc, st, c + 1, nch, K, As, lda, B0, f1, f0, tid, col0);
+        pipe_step<TMR, NN>(acc, st, c, nch, K, As, lda, B1, f0, f1, tid, col0, nx, Knext);
+        if (c + 1 < nch) pipe_step<TMR, NN>(acc, st, c + 1, nch, K, As, lda, B0, f1, f0, tid, col0, nx, Knext);
     }
     __syncthreads();  // all fragment reads done before the caller reuses As / the staging buffers
 }
@@ -381,119 +353,150 @@ void fused_mlp_kernel(FusedArgs g) {
 
     STAMP(0);
     const int ldw3 = H + APAD;
-    // ---- first weight chunk of fc1 in flight before anything else
-    KcStage<false> st1;
-    st1.init(P + g.off[0], IN, H, tid);
-    st1.load(0, IN);
-    // ---- small operands -> LDS (visible after the first barrier inside gemm_tile)
-    for (int i = tid; i < H; i += NTHR) { b1s[i] = P[g.off[1] + i]; b2s[i] = P[g.off[3] + i]; }
-    if (tid < OUT) b3s[tid] = P[g.off[5] + tid];
-    for (int i = tid; i < OUT * H; i += NTHR) {
-        const int o = i / H, k = i - o * H;
-        w3s[o * ldw3 + k] = P[g.off[4] + i];
-    }
-    if (MODE == MODE_CRITIC && tid < TMR) {
-        const int b = m0 + tid;
-        const bool ok = b < g.n_rows;
-        rowin[tid] = ok ? g.td[b] : 0.0f;
-        rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
-        rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
-    }
-    // ---- x tile -> LDS, zero padded to KP columns and to TMR rows
-    for (int i = tid; i < TMR * KP; i += NTHR) {
-        const int r = i / KP, k = i - r * KP;
-        const bool ok = (m0 + r) < g.n_rows && k < IN;
-        const float v = X[ok ? (int64_t)(m0 + r) * g.ldx + k : 0];
-        xs[r * ldx_s + k] = ok ? v : 0.0f;
-    }
-    // (gemm_tile starts with a barrier)
-
-    STAMP(1);
-    // ---- fc1
+    KcStage st1, st2;
+    RcStage st3;
+    NoStage none;
+    constexpr bool BWD_ONLY = MODE == MODE_CRITIC_BWD;
+    constexpr bool IS_CRITIC = MODE == MODE_CRITIC || MODE == MODE_CRITIC_BWD;
     typename T::Acc acc;
-    T::zero(acc);
-    gemm_tile<TMR, false, DBUF>(acc, st1, xs, ldx_s, IN, Ws, Ws1, tid, col0);
-    STAMP(2);
-    // fc2's first weight chunk is requested before fc1's epilogue
-    KcStage<true> st2v;
-    KcStage<false> st2s;
-    if (g.vec) { st2v.init(P + g.off[2], H, H, tid); st2v.load(0, H); }
-    else { st2s.init(P + g.off[2], H, H, tid); st2s.load(0, H); }
-    T::foreach(acc, lane, [&](int row, int cw, float val) {
-        const int col = col0 + cw;
-        if (col < H) {
-            const float v = fmaxf(val + b1s[col], 0.0f);
-            h1s[row * ldh + col] = v;
-            if (g.H1 && (m0 + row) < g.n_rows) g.H1[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
+    float *hpart = Ws;  // K-split partial head tiles [8][TMR][16] (staging buffer 0 is free after fc2)
+    if (BWD_ONLY) {
+        // ---- h1, h2, q tiles of an earlier forward launch -> LDS; W2's first chunk in flight meanwhile
+        st3.init(P + g.off[2], H, H, tid);
+        st3.load(0, H);
+        for (int o = 0; o < OUT; ++o)
+            for (int k = tid; k < H; k += NTHR) w3s[o * ldw3 + k] = P[g.off[4] + o * H + k];
+        if (tid < TMR) {
+            const int b = m0 + tid;
+            const bool ok = b < g.n_rows;
+            rowin[tid] = ok ? g.td[b] : 0.0f;
+            rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
+            rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
         }
-    });
-    STAMP(3);
-    // ---- fc2
-    T::zero(acc);
-    if (g.vec) gemm_tile<TMR, false, DBUF>(acc, st2v, h1s, ldh, H, Ws, Ws1, tid, col0);
-    else gemm_tile<TMR, false, DBUF>(acc, st2s, h1s, ldh, H, Ws, Ws1, tid, col0);
-    STAMP(4);
-    // the backward-data phase re-reads W2 (row-contiguous image): request its first chunk now
-    RcStage<true> st3v;
-    RcStage<false> st3s;
-    if (MODE == MODE_CRITIC) {
-        if (g.vec) { st3v.init(P + g.off[2], H, H, tid); st3v.load(0, H); }
-        else { st3s.init(P + g.off[2], H, H, tid); st3s.load(0, H); }
-    }
-    T::foreach(acc, lane, [&](int row, int cw, float val) {
-        const int col = col0 + cw;
-        if (col < H) {
-            const float v = fmaxf(val + b2s[col], 0.0f);
-            h2s[row * ldh + col] = v;
-            if (g.H2 && (m0 + row) < g.n_rows) g.H2[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
-        }
-    });
-    __syncthreads();
-
-    STAMP(5);
-    float *hpart = Ws;  // K-split partial head tiles [8][TMR][16] (the staging buffer is free after fc2)
-    STAMP(6);
-    // ---- head on the matrix cores: wave w multiplies the k-slice [32w, 32w+32) of h2 with W3^T
-    //      (a 16-wide B tile, rows >= OUT zero); the 8 partial tiles are summed through LDS.
-    {
-        f32x4 hacc[TMR / 16];
-#pragma unroll
-        for (int q = 0; q < TMR / 16; ++q)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) hacc[q][i] = 0.0f;
-        const int li = lane & 15, lg = lane >> 4;
-        if (col0 < H) {  // col0 = 32*wave doubles as this wave's k-slice start
-            const f4 *bp = reinterpret_cast<const f4 *>(w3s + (li < OUT ? li : 0) * ldw3 + col0 + lg * 8);
-            const float keep = li < OUT ? 1.0f : 0.0f;  // rows >= OUT of the 16-wide B tile are zero
-            const f4 b0 = bp[0] * keep, b1 = bp[1] * keep;
-#pragma unroll
-            for (int q = 0; q < TMR / 16; ++q) {
-                const f4 *ap = reinterpret_cast<const f4 *>(h2s + (16 * q + li) * ldh + col0 + lg * 8);
-                const f4 a0 = ap[0], a1 = ap[1];
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    hacc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(t < 4 ? a0[t & 3] : a1[t & 3],
-                                                                   t < 4 ? b0[t & 3] : b1[t & 3], hacc[q], 0, 0, 0);
+        const int c = (tid & 63) * 4;  // one wave per row pass, 16 bytes per lane
+        if (c < H) {
+            for (int r = tid >> 6; r < TMR; r += NTHR / 64) {
+                const bool ok = (m0 + r) < g.n_rows;
+                const int64_t src = ((int64_t)e * g.n_rows + (ok ? m0 + r : 0)) * H + c;
+                const f4 z = {0.f, 0.f, 0.f, 0.f};
+                const f4 a1 = *reinterpret_cast<const f4u *>(g.H1 + src);
+                const f4 a2 = *reinterpret_cast<const f4u *>(g.H2 + src);
+                *reinterpret_cast<f4 *>(h1s + r * ldh + c) = ok ? a1 : z;
+                *reinterpret_cast<f4 *>(h2s + r * ldh + c) = ok ? a2 : z;
             }
         }
-#pragma unroll
-        for (int q = 0; q < TMR / 16; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                hpart[(wave * TMR + 16 * q + 4 * lg + r) * MAX_OUT + li] = hacc[q][r];
+        for (int i = tid; i < TMR * OUT; i += NTHR) {
+            const int r = i / OUT, o = i - r * OUT;
+            ys[r * MAX_OUT + o] = (m0 + r) < g.n_rows ? g.Y[((int64_t)e * g.n_rows + m0 + r) * OUT + o] : 0.0f;
+        }
+    } else {
+        // ---- first weight chunk of fc1 in flight before anything else
+        st1.init(P + g.off[0], IN, H, tid);
+        st1.load(0, IN);
+        st2.init(P + g.off[2], H, H, tid);
+        // ---- small operands -> LDS (visible after the barrier below)
+        for (int i = tid; i < H; i += NTHR) { b1s[i] = P[g.off[1] + i]; b2s[i] = P[g.off[3] + i]; }
+        if (tid < OUT) b3s[tid] = P[g.off[5] + tid];
+        for (int o = 0; o < OUT; ++o)
+            for (int k = tid; k < H; k += NTHR) w3s[o * ldw3 + k] = P[g.off[4] + o * H + k];
+        if ((MODE == MODE_CRITIC) && tid < TMR) {
+            const int b = m0 + tid;
+            const bool ok = b < g.n_rows;
+            rowin[tid] = ok ? g.td[b] : 0.0f;
+            rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
+            rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
+        }
+        // ---- x tile -> LDS, zero padded to KP columns and to TMR rows (half-wave per row, 32 columns a pass)
+        for (int r = tid >> 5; r < TMR; r += NTHR / 32) {
+            const bool rok = (m0 + r) < g.n_rows;
+            const float *xr = X + (rok ? (int64_t)(m0 + r) * g.ldx : 0);
+            for (int k = tid & 31; k < KP; k += 32) {
+                const bool ok = rok && k < IN;
+                const float v = xr[ok ? k : 0];
+                xs[r * ldx_s + k] = ok ? v : 0.0f;
+            }
+        }
+        stage_first(st1, Ws, IN, tid);
         __syncthreads();
-        const int row = tid >> 4, o = tid & 15;
-        if (row < TMR && o < OUT) {
-            float v = b3s[o];
+
+        STAMP(1);
+        // ---- fc1 (fc2's first weight chunk is requested during its last K chunk)
+        T::zero(acc);
+        gemm_tile<TMR, false, DBUF>(acc, st1, xs, ldx_s, IN, Ws, Ws1, tid, col0, st2, H);
+        STAMP(2);
+        stage_first(st2, Ws, H, tid);
+        if (MODE == MODE_CRITIC) st3.init(P + g.off[2], H, H, tid);
+        T::foreach(acc, lane, [&](int row, int cw, float val) {
+            const int col = col0 + cw;
+            if (col < H) {
+                const float v = fmaxf(val + b1s[col], 0.0f);
+                h1s[row * ldh + col] = v;
+                if (g.H1 && (m0 + row) < g.n_rows) g.H1[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
+            }
+        });
+        __syncthreads();
+        STAMP(3);
+        // ---- fc2 (the backward-data phase re-reads W2 as a row-contiguous image: its first chunk is
+        //      requested during fc2's last K chunk)
+        T::zero(acc);
+        if (MODE == MODE_CRITIC) gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, st3, H);
+        else gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, none, 0);
+        STAMP(4);
+        T::foreach(acc, lane, [&](int row, int cw, float val) {
+            const int col = col0 + cw;
+            if (col < H) {
+                const float v = fmaxf(val + b2s[col], 0.0f);
+                h2s[row * ldh + col] = v;
+                if (g.H2 && (m0 + row) < g.n_rows) g.H2[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
+            }
+        });
+        __syncthreads();
+
+        STAMP(5);
+        STAMP(6);
+        // ---- head on the matrix cores: wave w multiplies the k-slice [32w, 32w+32) of h2 with W3^T
+        //      (a 16-wide B tile, rows >= OUT zero); the 8 partial tiles are summed through LDS.
+        {
+            f32x4 hacc[TMR / 16];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) v += hpart[(w * TMR + row) * MAX_OUT + o];
-            ys[row * MAX_OUT + o] = v;
-            if (g.Y && (m0 + row) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + row) * OUT + o] = v;
+            for (int q = 0; q < TMR / 16; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hacc[q][i] = 0.0f;
+            const int li = lane & 15, lg = lane >> 4;
+            if (col0 < H) {  // col0 = 32*wave doubles as this wave's k-slice start
+                const f4 *bp = reinterpret_cast<const f4 *>(w3s + (li < OUT ? li : 0) * ldw3 + col0 + lg * 8);
+                const float keep = li < OUT ? 1.0f : 0.0f;  // rows >= OUT of the 16-wide B tile are zero
+                const f4 b0 = bp[0] * keep, b1 = bp[1] * keep;
+#pragma unroll
+                for (int q = 0; q < TMR / 16; ++q) {
+                    const f4 *ap = reinterpret_cast<const f4 *>(h2s + (16 * q + li) * ldh + col0 + lg * 8);
+                    const f4 a0 = ap[0], a1 = ap[1];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        hacc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(t < 4 ? a0[t & 3] : a1[t & 3],
+                                                                       t < 4 ? b0[t & 3] : b1[t & 3], hacc[q], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < TMR / 16; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    hpart[(wave * TMR + 16 * q + 4 * lg + r) * MAX_OUT + li] = hacc[q][r];
+            __syncthreads();
+            const int row = tid >> 4, o = tid & 15;
+            if (row < TMR && o < OUT) {
+                float v = b3s[o];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += hpart[(w * TMR + row) * MAX_OUT + o];
+                ys[row * MAX_OUT + o] = v;
+                if (g.Y && (m0 + row) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + row) * OUT + o] = v;
+            }
         }
     }
     STAMP(7);
     if (MODE == MODE_PLAIN) return;
-    __syncthreads();
+    __syncthreads();  // hpart (= staging buffer 0) has been consumed
+    if (IS_CRITIC) stage_first(st3, Ws, H, tid);
 
     if (MODE == MODE_SAMPLE) {
         // tanh-normal head: one thread per row
@@ -516,7 +519,7 @@ void fused_mlp_kernel(FusedArgs g) {
         return;
     }
 
-    if (MODE == MODE_CRITIC) {
+    if (IS_CRITIC) {
         // ---- loss gradient per row (learning.py:90-98, 112)
         const float pw = (g.popart && g.pop) ? g.popart->w : 1.0f;
         const float pb = (g.popart && g.pop) ? g.popart->b : 0.0f;
@@ -566,10 +569,10 @@ void fused_mlp_kernel(FusedArgs g) {
             }
         }
         STAMP(9);
-        // ---- backward-data of fc2: dz1 = (dz2 W2) (.) [h1 > 0]   (gemm_tile starts with a barrier)
+        // ---- backward-data of fc2: dz1 = (dz2 W2) (.) [h1 > 0]
+        __syncthreads();  // dz2 (in h2s) and the staged first chunk of W2 are visible
         T::zero(acc);
-        if (g.vec) gemm_tile<TMR, true, DBUF>(acc, st3v, h2s, ldh, H, Ws, Ws1, tid, col0);
-        else gemm_tile<TMR, true, DBUF>(acc, st3s, h2s, ldh, H, Ws, Ws1, tid, col0);
+        gemm_tile<TMR, true, DBUF>(acc, st3, h2s, ldh, H, Ws, Ws1, tid, col0, none, 0);
         STAMP(10);
         T::foreach(acc, lane, [&](int row, int cw, float val) {
             const int col = col0 + cw;
@@ -624,10 +627,7 @@ void fill_common(FusedArgs &g, const ssac_mlp *nets, const int32_t *ids, const f
     g.in_dim = nets->in_dim; g.hidden = nets->hidden; g.out_dim = nets->out_dim;
     ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, g.off);
     g.ids = ids; g.X = X; g.ldx = ldx; g.sX = sX; g.n_rows = n_rows;
-    // W2 rows are 16-byte aligned when the arena base, the net stride and the W2 offset are
     g.dbg = g_fused_dbg;
-    g.vec = (((uintptr_t)nets->params & 15) == 0 && (nets->net_stride & 3) == 0 && (g.off[2] & 3) == 0 &&
-             (nets->hidden & 3) == 0) ? 1 : 0;
 }
 
 template <int MODE, int TMR, bool DBUF>
@@ -641,7 +641,7 @@ int launch_fused_t(const FusedArgs &g, int n_sel, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid((g.n_rows + TMR - 1) / TMR, n_sel);
-    hipLaunchKernelGGL((fused_mlp_kernel<MODE, TMR, DBUF>), grid, dim3(NTHR), lds, st, g);
+    SSAC_LAUNCH((fused_mlp_kernel<MODE, TMR, DBUF>), grid, dim3(NTHR), lds, st, g);
     return ssac_check_launch("fused_mlp");
 }
 
@@ -752,7 +752,8 @@ __global__ __launch_bounds__(64 * HW_GROUPS) void head_wgrad_kernel(
 __global__ __launch_bounds__(256) void critic_logs_kernel(const float *__restrict__ partials, int n_nets,
                                                           int tiles, int n_rows, float denom,
                                                           const float *__restrict__ sumsq, int n_ss,
-                                                          const ssac_adam_ctl *scale, float *logs) {
+                                                          const ssac_adam_ctl *scale, float *logs,
+                                                          ssac_feed *feed) {
     __shared__ float red[3][4];
     float sl = 0.f, se = 0.f, ss = 0.f;
     const int tot = n_nets * tiles;
@@ -775,6 +776,14 @@ __global__ __launch_bounds__(256) void critic_logs_kernel(const float *__restric
         logs[0] += sl / (denom * (float)n_rows);   // losses/critic_overall_loss (accumulates over members)
         logs[1] = se / (float)n_rows;              // losses/last_member_critic_td_error
         if (sumsq) logs[2] = sqrtf(ss) * (scale ? scale->clip_coef : 1.0f);
+    }
+    if (feed) {  // last launch of a captured update: publish the log block, advance the input ring
+        __syncthreads();
+        const int slot = (int)feed->dst[feed->log_slot_word];
+        const int w = feed->log_width;
+        if ((int)threadIdx.x < w) feed->log_ring[(int64_t)slot * w + threadIdx.x] = logs[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 0) feed->tick += 1;
     }
 }
 
@@ -828,6 +837,22 @@ extern "C" int ssac_critic_fwd_bwd_fused(const ssac_mlp *nets, const float *X, i
     return launch_fused<MODE_CRITIC>(g, nets->n_nets, (hipStream_t)stream);
 }
 
+extern "C" int ssac_critic_bwd_fused(const ssac_mlp *nets, int n_rows, const float *td, const float *weight,
+                                     const float *act, int64_t ld_act, const ssac_popart *popart, int pop,
+                                     float denom, const float *H1, const float *H2, const float *Q, float *DQ,
+                                     float *DZ2, float *DZ1, float *partials, void *stream) {
+    if (!fused_ok(nets)) return ssac_fail("ssac_critic_bwd_fused: shape not supported by the fused path");
+    if (nets->out_dim > 1 && !act) return ssac_fail("ssac_critic_bwd_fused: discrete needs actions");
+    if (!H1 || !H2 || !Q) return ssac_fail("ssac_critic_bwd_fused: needs the saved forward (H1, H2, Q)");
+    if (n_rows <= 0) return 0;
+    FusedArgs g{};
+    fill_common(g, nets, nullptr, nullptr, 0, 0, n_rows);
+    g.H1 = const_cast<float *>(H1); g.H2 = const_cast<float *>(H2); g.Y = const_cast<float *>(Q);
+    g.td = td; g.weight = weight; g.act = act; g.ld_a = ld_act; g.popart = popart; g.pop = pop;
+    g.denom = denom; g.DQ = DQ; g.DZ2 = DZ2; g.DZ1 = DZ1; g.partials = partials;
+    return launch_fused<MODE_CRITIC_BWD>(g, nets->n_nets, (hipStream_t)stream);
+}
+
 // row tiles the fused critic launch will use for (n_rows, n_nets): sizes the `partials` buffer
 extern "C" int ssac_fused_row_tiles(const ssac_mlp *nets, int n_rows, int n_nets) {
     FusedArgs g{};
@@ -853,7 +878,7 @@ extern "C" int ssac_head_wgrad(const ssac_mlp *nets, const int32_t *net_ids, int
     int64_t off[6];
     ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, off);
     dim3 grid((nets->hidden + 63) / 64, n_sel);
-    hipLaunchKernelGGL(head_wgrad_kernel, grid, dim3(64 * HW_GROUPS), 0, (hipStream_t)stream, nets->params,
+    SSAC_LAUNCH(head_wgrad_kernel, grid, dim3(64 * HW_GROUPS), 0, (hipStream_t)stream, nets->params,
                        nets->net_stride, nets->hidden, nets->out_dim, off[4], off[5], net_ids, H2, DQ,
                        n_rows, adam_m, adam_v, ctl, grads, sumsq, sumsq_net_stride, target, tau);
     return ssac_check_launch("head_wgrad");
@@ -863,8 +888,8 @@ extern "C" int ssac_head_wgrad_tiles(const ssac_mlp *nets) { return nets ? (nets
 
 extern "C" int ssac_critic_logs(const float *partials, int n_nets, int tiles, int n_rows, float denom,
                                 const float *sumsq, int n_sumsq, const ssac_adam_ctl *scale_by_clip,
-                                float *logs, void *stream) {
-    hipLaunchKernelGGL(critic_logs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n_nets,
-                       tiles, n_rows, denom, sumsq, n_sumsq, scale_by_clip, logs);
+                                float *logs, ssac_feed *feed, void *stream) {
+    SSAC_LAUNCH(critic_logs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n_nets,
+                       tiles, n_rows, denom, sumsq, n_sumsq, scale_by_clip, logs, feed);
     return ssac_check_launch("critic_logs");
 }

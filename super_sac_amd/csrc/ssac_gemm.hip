@@ -411,7 +411,7 @@ int launch_pair_ks(GemmPair &p, int batch0, int batch1, hipStream_t st) {
     }
     p.tiles0 = p.g0.grid_x * p.g0.grid_y * batch0;
     const int total = p.tiles0 + p.g1.grid_x * p.g1.grid_y * batch1;
-    hipLaunchKernelGGL((ens_gemm_pair_kernel<A_KC, B_KC, EPI, KS>), dim3(total), dim3(NTHREADS * KS), lds, st, p);
+    SSAC_LAUNCH((ens_gemm_pair_kernel<A_KC, B_KC, EPI, KS>), dim3(total), dim3(NTHREADS * KS), lds, st, p);
     return ssac_check_launch("ens_gemm_pair");
 }
 
@@ -425,7 +425,7 @@ int launch_ks(const GemmArgs &g, dim3 grid, hipStream_t st) {
             return ssac_fail("ens_gemm: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
-    hipLaunchKernelGGL((ens_gemm_kernel<A_KC, B_KC, EPI, KS>), grid, dim3(NTHREADS * KS), lds, st, g);
+    SSAC_LAUNCH((ens_gemm_kernel<A_KC, B_KC, EPI, KS>), grid, dim3(NTHREADS * KS), lds, st, g);
     return ssac_check_launch("ens_gemm");
 }
 

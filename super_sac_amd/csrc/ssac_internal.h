@@ -2,9 +2,59 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+#include <tuple>
+#include <vector>
+
 #include "ssac_hip.h"
 
 // record an error message (thread-local) and return a non-zero status
 int ssac_fail(const char *msg);
 // hipGetLastError() after a launch; non-zero + message on failure
 int ssac_check_launch(const char *what);
+
+// ---------------------------------------------------------------------------------------------
+// Launch lists (ssac_record_begin / ssac_record_end / ssac_replay in include/ssac_hip.h).
+// Every kernel of the library is launched through SSAC_LAUNCH.  While a recording is open, the launch is
+// ALSO appended -- kernel address, geometry and a byte copy of its arguments -- to a list, which a later
+// ssac_replay() re-issues from one C loop: an update whose inputs live at fixed device addresses costs one
+// host call instead of one Python->C->HIP trip per kernel, without the ~13 us idle tail a hipGraph launch
+// leaves on the queue on this platform.
+// ---------------------------------------------------------------------------------------------
+struct SsacLaunchRec {
+    const void *func;
+    dim3 grid, block;
+    size_t lds;
+    std::vector<char> blob;        // argument values, each at its natural alignment
+    std::vector<size_t> offsets;   // byte offset of argument i in `blob`
+};
+
+extern thread_local std::vector<SsacLaunchRec> *g_ssac_recording;
+
+template <typename T>
+inline void ssac_pack_arg(SsacLaunchRec &r, const T &v) {
+    size_t off = (r.blob.size() + alignof(T) - 1) / alignof(T) * alignof(T);
+    r.blob.resize(off + sizeof(T));
+    std::memcpy(r.blob.data() + off, &v, sizeof(T));
+    r.offsets.push_back(off);
+}
+
+template <typename... KArgs, typename... Args>
+inline void ssac_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t st,
+                        Args... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count mismatch");
+    std::tuple<KArgs...> vals{static_cast<KArgs>(args)...};
+    void *argv[sizeof...(KArgs) > 0 ? sizeof...(KArgs) : 1];
+    size_t i = 0;
+    std::apply([&](auto &...v) { ((argv[i++] = (void *)&v), ...); }, vals);
+    if (g_ssac_recording) {
+        SsacLaunchRec r;
+        r.func = (const void *)kernel;
+        r.grid = grid; r.block = block; r.lds = lds;
+        std::apply([&](auto &...v) { (ssac_pack_arg(r, v), ...); }, vals);
+        g_ssac_recording->push_back(std::move(r));
+    }
+    (void)hipLaunchKernel((const void *)kernel, grid, block, argv, lds, st);
+}
+
+#define SSAC_LAUNCH(kernel, grid, block, lds, st, ...) ssac_launch(kernel, grid, block, lds, st, __VA_ARGS__)

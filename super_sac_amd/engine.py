@@ -5,6 +5,7 @@ PyTorch is used here for device memory (tensors own the HBM allocations), stream
 pinned staging only; all arithmetic on the update path happens in libssac_hip.so.
 """
 import ctypes as C
+import os
 import struct
 
 import torch
@@ -17,6 +18,8 @@ SEGS = ("w1", "b1", "w2", "b2", "w3", "b3")
 # is bracketed by events recorded on the launch stream.
 PROFILE = {"tag": None, "events": []}
 USE_FUSED = True  # tests flip this to exercise the per-layer kernels on fused-capable shapes
+# launch the head layer's (VALU) weight-gradient kernel as a parallel branch beside the fc2/fc1 GEMM launch
+HEAD_BRANCH = os.environ.get("SSAC_HEAD_BRANCH", "1") == "1"
 
 
 class CaptureCtx:
@@ -24,10 +27,12 @@ class CaptureCtx:
     the host-RNG draw sites hand out these buffers instead of drawing, so the launch sequence that gets
     recorded into a HIP graph reads its per-update inputs from fixed addresses."""
 
-    def __init__(self, idx_cpu, idx_dev, ids, ids_dev, normals, logblk):
+    def __init__(self, idx_cpu, idx_dev, ids, ids_dev, normals, logblk, feed=0):
         self.idx_cpu, self.idx_dev, self.ids, self.ids_dev = idx_cpu, idx_dev, ids, ids_dev
         self.normals = list(normals)
         self.logblk = logblk
+        self.feed = feed          # device address of the update's ssac_feed (0: inputs arrive by copy)
+        self.published = False    # set once a captured launch has published the log block
 
 
 CAPTURE = None
@@ -45,15 +50,17 @@ _side = {}
 
 
 class side_stream:
-    """run the enclosed launches on a second HIP stream, forked from and joined back into the current
-    one (inside a graph capture this becomes a parallel branch): used to overlap small independent
-    kernels with the big GEMM launches instead of queueing them behind."""
+    """run the enclosed launches on a second HIP stream, forked from the current one (inside a graph capture
+    this becomes a parallel branch): used to overlap independent kernels with the launches of the main
+    chain instead of queueing them behind.  The branch is joined back when the block exits, or -- with
+    ``defer_join`` -- when the caller invokes ``join()`` later on the main stream."""
 
-    def __init__(self, device):
+    def __init__(self, device, defer_join=False):
         s = _side.get(device)
         if s is None:
             s = _side[device] = torch.cuda.Stream(device=device)
         self.s = s
+        self.defer = defer_join
 
     def __enter__(self):
         self.main = torch.cuda.current_stream()
@@ -64,7 +71,11 @@ class side_stream:
 
     def __exit__(self, *a):
         self.ctx.__exit__(*a)
-        self.main.wait_stream(self.s)
+        if not self.defer:
+            self.main.wait_stream(self.s)
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.s)
 
 
 def require_gpu(t=None):
@@ -250,7 +261,8 @@ def _timed(tag):
     """context manager recording a (start, end) event pair when bench.py asked for `tag`."""
     class _T:
         def __enter__(self_):
-            self_.on = PROFILE["tag"] == tag
+            want = PROFILE["tag"]
+            self_.on = want is not None and (tag == want or (isinstance(want, tuple) and tag in want))
             if self_.on:
                 self_.e0 = torch.cuda.Event(enable_timing=True)
                 self_.e1 = torch.cuda.Event(enable_timing=True)
@@ -258,7 +270,7 @@ def _timed(tag):
         def __exit__(self_, *a):
             if self_.on:
                 self_.e1.record()
-                PROFILE["events"].append((self_.e0, self_.e1))
+                PROFILE["events"].append((self_.e0, self_.e1, tag))
     return _T()
 
 
@@ -311,7 +323,8 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
         return 0 if sumsq is None else sumsq.data_ptr() + 4 * off[layer]
     if O <= 16:
         # the head's weight gradient is an independent VALU kernel: run it beside the GEMM launch below
-        with side_stream(arena.params.device):
+        import contextlib
+        with (side_stream(arena.params.device) if HEAD_BRANCH else contextlib.nullcontext()):
             check(lib.ssac_head_wgrad(C.byref(d), ids, n_sel, h2.data_ptr(), dY.data_ptr(), n_rows, _ptr(m),
                                       _ptr(v), ctl, _ptr(grads), ssp(2), ttot, _ptr(target), float(tau),
                                       stream()))

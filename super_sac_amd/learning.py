@@ -8,11 +8,13 @@ hand-derived backward, and weight-gradient GEMMs whose epilogue is the Adam step
 logs stay on the device until somebody reads them.
 """
 import ctypes as C
+import os
 
 import torch
 
 from . import engine, parallel, rng
 from . import learning_utils as lu
+from . import _lib
 from ._lib import check, lib
 
 
@@ -26,6 +28,40 @@ def _critic_input(bt, ws, tag, s_rep, a, discrete):
     x = lu._concat_buffer(ws, tag, s_rep, a.shape[1])
     x[:, S:].copy_(a)
     return x, x.stride(0)
+
+
+# Run the online critics' forward as a parallel branch beside the actor -> target critics -> TD-target chain.
+# Off by default: on MI355X a cross-stream join costs ~10 us of signalling (measured, also inside a HIP graph),
+# more than the overlap wins at the metric shape (6.6k vs 7.15k updates/s); tests exercise both settings.
+# how a repeated update is re-issued: "list" = the library's recorded launch list (ssac_replay), "graph" = a
+# hipGraph captured through torch.cuda.graph (leaves a ~13 us idle tail per launch on MI355X)
+LAUNCH_MODE = os.environ.get("SSAC_LAUNCH_MODE", "list")
+
+
+class _LaunchList:
+    def __init__(self, handle):
+        if not handle:
+            raise RuntimeError("libssac_hip: " + lib.ssac_last_error().decode())
+        self.handle = handle
+
+    def replay(self):
+        check(lib.ssac_replay(self.handle, engine.stream()))
+
+    def __del__(self):
+        try:
+            lib.ssac_launch_list_free(self.handle)
+        except Exception:
+            pass
+
+
+FEED_SLOTS = 16  # pinned input ring of a captured update: how far the host may run ahead of the GPU
+SPLIT_FORWARD = os.environ.get("SSAC_SPLIT_FORWARD", "0") == "1"
+
+
+def _split_forward(n_nets, n_rows):
+    """the branch pays off while the critic forward leaves CUs free for the small actor / target launches
+    it runs beside: one 32-row workgroup per CU, at most 192 of the 256 CUs."""
+    return SPLIT_FORWARD and n_nets * ((n_rows + 31) // 32) <= 192
 
 
 def _clip_and_step(adam, members, clip, slot_norm):
@@ -102,50 +138,86 @@ def _critic_update_graphed(gs, kw):
     actor = agent.actors[0]
     kind = lu.actor_kind(actor)
     n_sub = kw["target_critic_ensemble_n"]
+    ring = lu.ring_for(dev)
     if gs.graph is None:
-        # one fixed device block holds the per-update inputs: [B int64 indices | n int32 subset ids (padded)]
+        # one fixed device block holds the per-update inputs:
+        #   [B int64 indices | n int32 subset ids (padded to 8 bytes) | int32 log-ring slot, int32 pad]
+        # The host writes them into slot k % FEED_SLOTS of a pinned ring; the first captured launch pulls the
+        # slot over PCIe (ssac_feed in include/ssac_hip.h), so an update is ONE graph launch and no copy node.
         n_pad = (n_sub + 1) // 2 * 2
-        gs.inbuf = torch.zeros(8 * B + 4 * n_pad, dtype=torch.uint8, device=dev)
+        nbytes = 8 * B + 4 * n_pad + 8
+        gs.inbuf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         gs.idx_dev = gs.inbuf[:8 * B].view(torch.int64)
-        gs.ids_dev = gs.inbuf[8 * B:].view(torch.int32)[:n_sub]
-        gs.host = torch.zeros(8 * B + 4 * n_pad, dtype=torch.uint8)
-        gs.host_idx = gs.host[:8 * B].view(torch.int64)
-        gs.host_ids = gs.host[8 * B:].view(torch.int32)
-        from .replay import _PinnedRing
-        gs.ring = _PinnedRing(gs.host.numel())
+        gs.ids_dev = gs.inbuf[8 * B:8 * B + 4 * n_pad].view(torch.int32)[:n_sub]
+        gs.host = torch.zeros(FEED_SLOTS, nbytes, dtype=torch.uint8).pin_memory()
+        gs.host_idx = gs.host[:, :8 * B].view(torch.int64)
+        gs.host_i32 = gs.host[:, 8 * B:].view(torch.int32)  # ids..., then the log slot at [n_pad]
+        gs.n_pad = n_pad
+        gs.events = [None] * FEED_SLOTS
+        gs.k = 0
         gs.eps_dev = torch.empty(B, actor.action_size, device=dev) if kind == "stochastic" else None
         gs.logblk = torch.zeros(lu.LOG_WIDTH, device=dev)
+        gs.feed = engine.DeviceStruct(_lib.Feed(gs.host.data_ptr(), gs.inbuf.data_ptr(), ring.buf.data_ptr(), 0,
+                                                FEED_SLOTS, nbytes // 4, (8 * B + 4 * n_pad) // 4,
+                                                lu.LOG_WIDTH), dev)
     # ---- host draws, in the reference's order: indices -> (augmentation: none here) -> noise -> subset
     buffer.total_sample_calls += 1
     idx_cpu = rng.draw_indices(len(buffer), B)
     if kind == "stochastic":
-        rng.draw_normal_into(gs.eps_dev)  # noise straight into the graph's input buffer
+        # noise straight into the captured update's input buffer.  (Capturing the draw itself costs two extra
+        # Philox-state kernels per replay on ROCm -- measured slower than this one eager launch.)
+        rng.draw_normal_into(gs.eps_dev)
     ids = rng.draw_subset(agent.num_critics, n_sub)
+    # ---- per-update inputs into this update's pinned slot
+    k = gs.k % FEED_SLOTS
+    if gs.events[k] is not None:
+        gs.events[k].synchronize()  # the replay that read this slot FEED_SLOTS updates ago has finished
+    slot_i = ring.advance()
+    gs.host_idx[k].copy_(idx_cpu)
+    row = gs.host_i32[k]
+    for j, v in enumerate(ids):
+        row[j] = v
+    row[gs.n_pad] = slot_i
     if gs.graph is None:
         ctx = engine.CaptureCtx(idx_cpu, gs.idx_dev, ids, gs.ids_dev,
-                                [gs.eps_dev] if gs.eps_dev is not None else [], gs.logblk)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
+                                [gs.eps_dev] if gs.eps_dev is not None else [], gs.logblk, feed=gs.feed.ptr)
+
+        def body():
+            logs_, dicts_ = _critic_update_eager(**kw)
+            if not ctx.published:
+                check(lib.ssac_publish_logs(gs.logblk.data_ptr(), gs.feed.ptr, engine.stream()))
+            return logs_, dicts_
         engine.CAPTURE = ctx
         try:
-            with torch.cuda.graph(graph):
-                logs, dicts = _critic_update_eager(**kw)
+            if LAUNCH_MODE == "graph":
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    logs, dicts = body()
+                graph.replay()
+            else:
+                # launch list: this call's launches run normally AND are recorded for the later calls
+                check(lib.ssac_record_begin())
+                try:
+                    logs, dicts = body()
+                finally:
+                    handle = lib.ssac_record_end()
+                graph = _LaunchList(handle)
         finally:
             engine.CAPTURE = None
         gs.graph, gs.dicts = graph, dicts
         base = gs.logblk.data_ptr()
-        gs.log_index = {k: (v.data_ptr() - base) // 4 for k, v in logs.items()}
-    # ---- per-update inputs into the fixed-address buffers (ONE pinned H2D copy), then ONE graph launch
-    gs.host_idx.copy_(idx_cpu)
-    for j, v in enumerate(ids):
-        gs.host_ids[j] = v
-    gs.ring.push(gs.host, gs.inbuf)
-    gs.graph.replay()
+        gs.log_index = {k_: (v.data_ptr() - base) // 4 for k_, v in logs.items()}
+    else:
+        gs.graph.replay()  # ONE host call re-issues the whole update
+    ev = gs.events[k]
+    if ev is None:
+        ev = gs.events[k] = torch.cuda.Event()
+    ev.record()
+    gs.k += 1
     rng.choice(agent.critics)  # keep the Python RNG stream in step with learning.py:135
-    ring = lu.ring_for(dev)
-    slot = ring.buf[ring.advance()]
-    slot.copy_(gs.logblk, non_blocking=True)
-    logs = {k: slot[i] for k, i in gs.log_index.items()}
+    slot = ring.buf[slot_i]
+    logs = {k_: slot[i] for k_, i in gs.log_index.items()}
     rd = gs.dicts[0]
     rd["priority_idxs"] = idx_cpu.numpy()
     rd["_subset"] = ids
@@ -179,6 +251,22 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
     for i in range(E):
         rd = lu.sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter,
                                         aug_mix=aug_mix, per=per)
+        o, a, r, o1, d = rd["primary_batch"]
+        B = r.shape[0]
+        arena = agent.critics[i].arena(dev)
+        N, qd = arena.n_nets, arena.out_dim
+        H = arena.hidden
+        tag = f"cu.c{i}"
+        train_enc = not lu.is_identity(agent.encoder)
+        # The online critics' FORWARD does not depend on the TD target: on a second stream (a parallel graph
+        # branch) it overlaps the actor -> target critics -> TD-target chain, which occupies few CUs.
+        branch = None
+        if arena.fused and not train_enc and _split_forward(N, B):
+            s_rep = lu.encode(agent.encoder, o)
+            X, ldx = _critic_input(rd.get("_ssac"), ws, f"cu.x{i}", s_rep, a, discrete)
+            with engine.side_stream(dev, defer_join=True) as branch:
+                with engine._timed("critic_fwd"):
+                    h1, h2, q = engine.mlp_forward(arena, X, ldx, 0, B, ws, tag)
         td, _ = lu.compute_td_targets(logs=logs, replay_dict=rd, agent=agent, target_agent=target_agent,
                                       ensemble_idx=i, ensemble_n=target_critic_ensemble_n,
                                       log_alphas=log_alphas, pop=pop, gamma=gamma,
@@ -187,11 +275,6 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
         bw = lu.compute_backup_weights(logs=logs, replay_dict=rd, agent=agent, target_agent=target_agent,
                                        weight_type=weight_type, weight_temp=weighted_bellman_temp,
                                        batch_size=batch_size, discrete=discrete, _slot=slot)
-        o, a, r, o1, d = rd["primary_batch"]
-        B = r.shape[0]
-        arena = agent.critics[i].arena(dev)
-        N, qd = arena.n_nets, arena.out_dim
-        train_enc = not lu.is_identity(agent.encoder)
         if train_enc:
             # online encoder WITH gradient (learning.py:83): embedding goes straight into the critic input
             assert E == 1, "trainable encoders are supported for ensemble_size == 1"
@@ -199,14 +282,12 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             s_rep = lu.encode(agent.encoder, o, dst=xin, save=True)
             if not discrete:
                 xin[:, s_rep.shape[1]:].copy_(a)
-        else:
+            X, ldx = xin, xin.stride(0)
+        elif branch is None:
             s_rep = lu.encode(agent.encoder, o)
+            X, ldx = _critic_input(rd.get("_ssac"), ws, f"cu.x{i}", s_rep, a, discrete)
         shard = parallel.shard_of(agent)
         n_glob = N if shard is None else shard.num_critics  # loss is averaged over the GLOBAL ensemble
-        if train_enc:
-            X, ldx = xin, xin.stride(0)
-        else:
-            X, ldx = _critic_input(rd.get("_ssac"), ws, f"cu.x{i}", s_rep, a, discrete)
         popart = agent.popart[i]
         weight_ptr = 0
         if not isinstance(bw, float):
@@ -215,23 +296,30 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
         ttot = engine.wgrad_tiles_total(arena)
         ss = ws.get(f"cu.ss{i}", (N * ttot,))
         dq = ws.get(f"cu.dq{i}", (N, B, qd))
-        tag = f"cu.c{i}"
         grads = ws.get(f"cu.g{i}", (arena.params.numel(),), zero=True) if critic_clip else None
         if arena.fused:
-            # forward of all N critics + loss gradient + backward-data: ONE launch
-            H = arena.hidden
-            h1 = ws.get(tag + ".h1", (N, B, H))
-            h2 = ws.get(tag + ".h2", (N, B, H))
-            q = ws.get(tag + ".y", (N, B, qd))
             dz2 = ws.get(tag + ".dz2", (N, B, H))
             dz1 = ws.get(tag + ".dz1", (N, B, H))
             tiles = int(lib.ssac_fused_row_tiles(C.byref(arena.desc()), B, N))
             parts = ws.get(tag + ".parts", (N * tiles * 2,))
-            with engine._timed("critic_fused"):
-                check(lib.ssac_critic_fwd_bwd_fused(
-                    C.byref(arena.desc()), X.data_ptr(), ldx, B, td.data_ptr(), weight_ptr, a.data_ptr(),
-                    a.stride(0), pp, dopop, float(E * n_glob), h1.data_ptr(), h2.data_ptr(), q.data_ptr(),
-                    dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), st))
+            if branch is not None:
+                # loss gradient + head backward + backward-data on the saved forward: ONE launch
+                branch.join()
+                with engine._timed("critic_bwd"):
+                    check(lib.ssac_critic_bwd_fused(
+                        C.byref(arena.desc()), B, td.data_ptr(), weight_ptr, a.data_ptr(), a.stride(0), pp,
+                        dopop, float(E * n_glob), h1.data_ptr(), h2.data_ptr(), q.data_ptr(), dq.data_ptr(),
+                        dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), st))
+            else:
+                # forward of all N critics + loss gradient + backward-data: ONE launch
+                h1 = ws.get(tag + ".h1", (N, B, H))
+                h2 = ws.get(tag + ".h2", (N, B, H))
+                q = ws.get(tag + ".y", (N, B, qd))
+                with engine._timed("critic_fused"):
+                    check(lib.ssac_critic_fwd_bwd_fused(
+                        C.byref(arena.desc()), X.data_ptr(), ldx, B, td.data_ptr(), weight_ptr, a.data_ptr(),
+                        a.stride(0), pp, dopop, float(E * n_glob), h1.data_ptr(), h2.data_ptr(), q.data_ptr(),
+                        dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), st))
             if train_enc:  # dL/d(embedding) = sum over critics of dz1 W1[:, :emb], BEFORE W1 is updated
                 dX = ws.get(tag + ".dx", (N, B, arena.in_dim))
                 check(lib.ssac_mlp_layer_dgrad(C.byref(arena.desc()), 0, 0, N, dz1.data_ptr(), H, B * H, 0, 0, 0,
@@ -275,9 +363,13 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             continue
         parts, n_, tiles_, b_, ng_ = fl
         want = j == k
+        cap = engine.CAPTURE
+        last = cap is not None and cap.feed and j == len(fused_logs) - 1 and (done_norm or want)
         check(lib.ssac_critic_logs(parts.data_ptr(), n_, tiles_, b_, float(E * ng_),
                                    member_ss[k].data_ptr() if want else 0, member_ss[k].numel() if want else 0,
-                                   clip_ctl, slot.data_ptr(), st))
+                                   clip_ctl, slot.data_ptr(), cap.feed if last else 0, st))
+        if last:
+            cap.published = True
         done_norm = done_norm or want
     if not done_norm:
         check(lib.ssac_group_norms(member_ss[k].data_ptr(), 1, member_ss[k].numel(), clip_ctl,

@@ -42,7 +42,7 @@ class LogRing:
         """fresh zeroed block; the same launch advances `adam`'s step when given."""
         self.k = (self.k + 1) % self.buf.shape[0]
         blk = self.buf[self.k]
-        check(lib.ssac_begin_update(blk.data_ptr(), LOG_WIDTH, 0 if adam is None else adam.ctl.ptr,
+        check(lib.ssac_begin_update(blk.data_ptr(), LOG_WIDTH, 0 if adam is None else adam.ctl.ptr, 0,
                                     engine.stream()))
         return blk
 
@@ -67,7 +67,7 @@ def log_block(device, adam=None):
     if engine.CAPTURE is not None:
         blk = engine.CAPTURE.logblk
         check(lib.ssac_begin_update(blk.data_ptr(), LOG_WIDTH, 0 if adam is None else adam.ctl.ptr,
-                                    engine.stream()))
+                                    engine.CAPTURE.feed, engine.stream()))
         return blk
     return ring_for(device).next(adam)
 

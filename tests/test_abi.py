@@ -42,7 +42,7 @@ def test_layout_matches_header_contract():
 def test_struct_sizes_match_the_c_side():
     from super_sac_amd import _lib
     assert ctypes.sizeof(_lib.AdamCtl) == 72 and ctypes.sizeof(_lib.PopArtState) == 40
-    assert ctypes.sizeof(_lib.MlpDesc) == 32
+    assert ctypes.sizeof(_lib.MlpDesc) == 32 and ctypes.sizeof(_lib.Feed) == 48
 
 
 def test_update_path_refuses_to_run_without_a_gpu():

@@ -62,9 +62,9 @@ def test_graph_replay_equals_eager_launches():
     import torch
     import super_sac_amd as ssa
 
-    def run(use_graphs):
-        old = ssa.learning.USE_GRAPHS
-        ssa.learning.USE_GRAPHS = use_graphs
+    def run(use_graphs, split, mode="list"):
+        old, old_split, old_mode = ssa.learning.USE_GRAPHS, ssa.learning.SPLIT_FORWARD, ssa.learning.LAUNCH_MODE
+        ssa.learning.USE_GRAPHS, ssa.learning.SPLIT_FORWARD, ssa.learning.LAUNCH_MODE = use_graphs, split, mode
         try:
             torch.manual_seed(3); np.random.seed(3); random.seed(3)
             dev = torch.device("cuda")
@@ -96,10 +96,18 @@ def test_graph_replay_equals_eager_launches():
             tparams = torch.cat([p.detach().flatten() for p in target.critics[0].parameters()]).cpu().numpy()
             return params, tparams, last, buf.total_sample_calls
         finally:
-            ssa.learning.USE_GRAPHS = old
+            ssa.learning.USE_GRAPHS, ssa.learning.SPLIT_FORWARD, ssa.learning.LAUNCH_MODE = old, old_split, old_mode
 
-    pe, te, le, ce = run(False)
-    pg, tg, lg, cg = run(True)
+    pe, te, le, ce = run(False, split=False)
+    pg, tg, lg, cg = run(True, split=False, mode="list")     # the library's recorded launch list
+    ph, th, lh, ch = run(True, split=False, mode="graph")    # a hipGraph captured through torch
+    assert np.array_equal(pg, ph) and np.array_equal(tg, th) and lg[:2] == lh[:2] and ch == 20
+    # the critic forward as a parallel branch + backward-only launch vs. the single forward+backward launch
+    p1, t1, l1, _ = run(False, split=True)
+    p2, t2, l2, _ = run(True, split=True)
+    assert np.array_equal(p1, p2) and np.array_equal(t1, t2)
+    assert np.array_equal(pe, p1) and np.array_equal(te, t1) and le[0] == l1[0], \
+        "split forward/backward launches must be bit-identical to the one-launch critic kernel"
     assert ce == cg == 20
     assert np.array_equal(le[2], lg[2]), "replay indices must not depend on the launch mechanism"
     assert np.array_equal(pe, pg) and np.array_equal(te, tg), "graph replay must be bit-identical to eager launches"

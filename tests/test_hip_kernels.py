@@ -179,7 +179,7 @@ def test_fused_critic_fwd_bwd_matches_autograd(ssa, tile_rows, qd, B, H, N):
     ssa.engine.weight_grads(ar, xd, in_dim, 0, h1, h2, dq, dz2, dz1, B, grads=grads, sumsq=ss)
     logs = torch.zeros(4, device=DEV)
     ssa._lib.check(ssa._lib.lib.ssac_critic_logs(parts.data_ptr(), N, tiles, B, float(N), ss.data_ptr(),
-                                                 ss.numel(), 0, logs.data_ptr(), ssa.engine.stream()))
+                                                 ss.numel(), 0, logs.data_ptr(), 0, ssa.engine.stream()))
     assert abs(float(logs[0]) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
     gsq = 0.0
     for j in range(N):
@@ -714,3 +714,27 @@ def test_prioritised_sample_path_on_device(ssa):
     _, w1, idx1 = rb.sample(32)
     assert np.array_equal(idx1, f["i1"]) and np.allclose(w1.numpy(), f["w1"], rtol=1e-12)
     assert rb.total_sample_calls == 2
+
+
+def test_feed_pulls_host_slot_and_publishes_logs(ssa):
+    """ssac_feed: begin_update copies slot tick % n_slots of the pinned ring into the device block;
+    publish_logs / critic_logs write the log block to the ring slot named in the block and advance tick."""
+    import ctypes as C
+    n_slots, words, width = 4, 12, 64
+    host = torch.zeros(n_slots, words, dtype=torch.int32).pin_memory()
+    for k in range(n_slots):
+        host[k] = torch.arange(words, dtype=torch.int32) + 100 * k
+        host[k, words - 2] = 7 - k  # log-ring slot for update k
+    dst = torch.zeros(words, dtype=torch.int32, device=DEV)
+    ring = torch.zeros(8, width, device=DEV)
+    feed = ssa.engine.DeviceStruct(ssa._lib.Feed(host.data_ptr(), dst.data_ptr(), ring.data_ptr(), 0, n_slots,
+                                                 words, words - 2, width), DEV)
+    logs = torch.zeros(width, device=DEV)
+    lib = ssa._lib.lib
+    for k in range(6):
+        ssa._lib.check(lib.ssac_begin_update(logs.data_ptr(), width, 0, feed.ptr, ssa.engine.stream()))
+        assert torch.equal(dst.cpu(), host[k % n_slots]) and float(logs.abs().sum()) == 0.0
+        logs.fill_(float(k + 1))
+        ssa._lib.check(lib.ssac_publish_logs(logs.data_ptr(), feed.ptr, ssa.engine.stream()))
+        assert torch.equal(ring[7 - k % n_slots].cpu(), torch.full((width,), float(k + 1)))
+        assert feed.read().tick == k + 1

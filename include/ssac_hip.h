@@ -67,7 +67,8 @@ typedef struct ssac_popart {
  * target-critic launches) and ssac_critic_logs, the last launch of the update, publishes the log block into
  * log_ring[dst_words[log_slot_word]] and advances `tick`.  Lives in DEVICE memory. */
 typedef struct ssac_feed {
-    const uint32_t *host_ring;  /* pinned host memory, n_slots x slot_words 4-byte words */
+    const uint32_t *host_ring;  /* pinned host memory, n_slots x slot_words 4-byte words; 16-byte aligned,
+                                   slot_words % 4 == 0 */
     uint32_t *dst;              /* device copy of the current slot (slot_words words) */
     float *log_ring;            /* device ring of log blocks, log_width floats each */
     int64_t tick;               /* updates consumed so far */

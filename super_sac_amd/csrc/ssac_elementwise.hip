@@ -446,7 +446,23 @@ __global__ void begin_update_kernel(float *logs, int n, ssac_adam_ctl *ctl, cons
     if (feed) {  // this update's host inputs: pinned ring slot -> fixed device block (one PCIe round trip)
         const ssac_feed f = *feed;
         const uint32_t *src = f.host_ring + (int64_t)(f.tick % f.n_slots) * f.slot_words;
-        for (int i = threadIdx.x; i < f.slot_words; i += blockDim.x) f.dst[i] = src[i];
+        // 16 bytes per lane and every load issued before the first store: ONE round trip for slots up to
+        // 4 * blockDim 16-byte words (slot_words % 4 == 0 and 16-byte aligned slots are the host's contract)
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(f.dst);
+        const int n4 = f.slot_words >> 2;
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = threadIdx.x + u * blockDim.x;
+            v[u] = s4[i < n4 ? i : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = threadIdx.x + u * blockDim.x;
+            if (i < n4) d4[i] = v[u];
+        }
+        for (int i = 4 * blockDim.x + threadIdx.x; i < n4; i += blockDim.x) d4[i] = s4[i];
     }
 }
 

@@ -318,6 +318,29 @@ __device__ __forceinline__ void gemm_tile(typename Tile<TMR>::Acc &acc, Stage &s
     __syncthreads();  // all fragment reads done before the caller reuses As / the staging buffers
 }
 
+// W3 (OUT x H, rows contiguous) -> LDS rows of stride ldw3.  Four independent loads are issued before the
+// first LDS store, so the copy costs one global round trip instead of one per head row.
+__device__ __forceinline__ void stage_head_weights(float *w3s, const float *__restrict__ W3, int OUT, int H,
+                                                   int ldw3, int tid) {
+    const int n3 = OUT * H;
+    for (int i0 = tid; i0 < n3; i0 += 4 * NTHR) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * NTHR;
+            v[u] = W3[i < n3 ? i : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * NTHR;
+            if (i < n3) {
+                const int o = i / H;
+                w3s[o * ldw3 + (i - o * H)] = v[u];
+            }
+        }
+    }
+}
+
 #define STAMP(i) do { if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // DBUF = false: 2 workgroups per CU (needs <= 128 VGPRs and <= 80 KB of LDS each)
@@ -364,8 +387,7 @@ void fused_mlp_kernel(FusedArgs g) {
         // ---- h1, h2, q tiles of an earlier forward launch -> LDS; W2's first chunk in flight meanwhile
         st3.init(P + g.off[2], H, H, tid);
         st3.load(0, H);
-        for (int o = 0; o < OUT; ++o)
-            for (int k = tid; k < H; k += NTHR) w3s[o * ldw3 + k] = P[g.off[4] + o * H + k];
+        stage_head_weights(w3s, P + g.off[4], OUT, H, ldw3, tid);
         if (tid < TMR) {
             const int b = m0 + tid;
             const bool ok = b < g.n_rows;
@@ -397,8 +419,7 @@ void fused_mlp_kernel(FusedArgs g) {
         // ---- small operands -> LDS (visible after the barrier below)
         for (int i = tid; i < H; i += NTHR) { b1s[i] = P[g.off[1] + i]; b2s[i] = P[g.off[3] + i]; }
         if (tid < OUT) b3s[tid] = P[g.off[5] + tid];
-        for (int o = 0; o < OUT; ++o)
-            for (int k = tid; k < H; k += NTHR) w3s[o * ldw3 + k] = P[g.off[4] + o * H + k];
+        stage_head_weights(w3s, P + g.off[4], OUT, H, ldw3, tid);
         if ((MODE == MODE_CRITIC) && tid < TMR) {
             const int b = m0 + tid;
             const bool ok = b < g.n_rows;

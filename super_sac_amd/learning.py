@@ -145,7 +145,7 @@ def _critic_update_graphed(gs, kw):
         # The host writes them into slot k % FEED_SLOTS of a pinned ring; the first captured launch pulls the
         # slot over PCIe (ssac_feed in include/ssac_hip.h), so an update is ONE graph launch and no copy node.
         n_pad = (n_sub + 1) // 2 * 2
-        nbytes = 8 * B + 4 * n_pad + 8
+        nbytes = (8 * B + 4 * n_pad + 8 + 15) // 16 * 16  # slots are whole 16-byte words (ssac_feed contract)
         gs.inbuf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         gs.idx_dev = gs.inbuf[:8 * B].view(torch.int64)
         gs.ids_dev = gs.inbuf[8 * B:8 * B + 4 * n_pad].view(torch.int32)[:n_sub]

@@ -606,6 +606,416 @@ void fused_mlp_kernel(FusedArgs g) {
     }
 }
 
+
+// =============================================================================================
+// Direct-B variant.  Wave w of a workgroup is the ONLY consumer of columns [32w, 32w+32) of a weight
+// matrix, so staging weights through LDS buys no reuse inside the workgroup: each wave loads its own B
+// fragments straight from global memory (L2) into registers, two K chunks ahead, and only the A operand
+// (x, h1, dz2 -- shared by all eight waves) lives in LDS.  The K loop then has NO barrier and no LDS
+// store; waves drift apart freely and the two waves of a SIMD fill each other's gaps.  Without the two
+// 36 KB staging buffers a 32-row workgroup needs < 80 KB of LDS, so two of them share a CU.
+// The MFMA sequence per accumulator (k order inside a chunk) is the same as the staged kernel's, so the
+// results are bit-identical to it.
+// =============================================================================================
+template <int TMR, bool NN> struct DirectB;
+
+// All loads below are UNCONDITIONAL (out-of-range columns read row 0, a ragged K tail reads on into the
+// next row -- always inside the parameter arena, whose W segments are followed by bias/W segments -- and the
+// unwanted values are replaced by zeros with selects afterwards): a load inside a branch would force the
+// compiler to drain the whole vmcnt queue at the join, i.e. to wait for the prefetches as well.
+template <bool NN> struct DirectB<32, NN> {
+    const float *p;
+    int ldw, K, kofs;
+    bool ok;
+    __device__ __forceinline__ void init(const float *W, int ldw_, int Ncols, int K_, int lane, int col0) {
+        const int li = lane & 31, lh = lane >> 5;
+        ldw = ldw_; K = K_; kofs = lh * 16;
+        ok = (col0 + li) < Ncols;
+        const int n = ok ? col0 + li : 0;
+        p = NN ? W + (int64_t)(lh * 16) * ldw + n : W + (int64_t)n * ldw + lh * 16;
+    }
+    __device__ __forceinline__ void load(Tile<32>::Frag &f, int c) const {
+        const int k0 = c * 32;
+        if (NN) {  // W is (K x Ncols): 16 rows of this lane's column (K % 32 == 0 on this path)
+            const float *q = p + (int64_t)k0 * ldw;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float x = q[(int64_t)t * ldw];
+                f.bs[t] = ok ? x : 0.0f;
+            }
+        } else {   // W is (Ncols x K): 16 consecutive k of this lane's row
+            const int left = ok ? K - (k0 + kofs) : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4 x = *reinterpret_cast<const f4u *>(p + k0 + 4 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) f.b[q][i] = (4 * q + i) < left ? x[i] : 0.0f;
+            }
+        }
+    }
+};
+
+template <bool NN> struct DirectB<16, NN> {
+    const float *p[2];
+    int ldw, K, kofs;
+    bool ok[2];
+    __device__ __forceinline__ void init(const float *W, int ldw_, int Ncols, int K_, int lane, int col0) {
+        const int li = lane & 15, lg = lane >> 4;
+        ldw = ldw_; K = K_; kofs = lg * 8;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            ok[u] = (col0 + 16 * u + li) < Ncols;
+            const int n = ok[u] ? col0 + 16 * u + li : 0;
+            p[u] = NN ? W + (int64_t)(lg * 8) * ldw + n : W + (int64_t)n * ldw + lg * 8;
+        }
+    }
+    __device__ __forceinline__ void load(Tile<16>::Frag &f, int c) const {
+        const int k0 = c * 32;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (NN) {
+                const float *q = p[u] + (int64_t)k0 * ldw;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const float x = q[(int64_t)t * ldw];
+                    f.bs[u][t] = ok[u] ? x : 0.0f;
+                }
+            } else {
+                const int left = ok[u] ? K - (k0 + kofs) : 0;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f4 x = *reinterpret_cast<const f4u *>(p[u] + k0 + 4 * q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) f.b[u][q][i] = (4 * q + i) < left ? x[i] : 0.0f;
+                }
+            }
+        }
+    }
+};
+
+// A fragment of chunk c from LDS (same addressing as Tile<TMR>::read)
+template <int TMR>
+__device__ __forceinline__ void read_a(typename Tile<TMR>::Frag &f, const float *As, int lda, int c, int lane) {
+    if (TMR == 32) {
+        const f4 *ap = reinterpret_cast<const f4 *>(As + (lane & 31) * lda + c * 32 + (lane >> 5) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f.a[q] = ap[q];
+    } else {
+        const f4 *ap = reinterpret_cast<const f4 *>(As + (lane & 15) * lda + c * 32 + (lane >> 4) * 8);
+        f.a[0] = ap[0]; f.a[1] = ap[1];
+    }
+}
+
+template <int TMR, bool NN>
+__device__ __forceinline__ void mfma_chunk(typename Tile<TMR>::Acc &acc, typename Tile<TMR>::Frag &fa,
+                                           typename Tile<TMR>::Frag &fb) {
+    // move the A half into the B-carrying fragment's `a` slot is not needed: build the MFMAs directly
+    if constexpr (TMR == 32) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a[t >> 2][t & 3], NN ? fb.bs[t] : fb.b[t >> 2][t & 3],
+                                                      acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                acc.v[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.a[t >> 2][t & 3],
+                                                                NN ? fb.bs[u][t] : fb.b[u][t >> 2][t & 3],
+                                                                acc.v[u], 0, 0, 0);
+    }
+}
+
+// chunks 0 and 1 of `db` must already be in flight in fb[0], fb[1] (start_direct): the caller issues them
+// one phase early, before the previous phase's epilogue.  Prefetch indices are clamped to the last chunk
+// instead of being guarded (see DirectB): the few redundant loads at the end of the loop are never used.
+template <int TMR, bool NN>
+__device__ __forceinline__ void start_direct(const DirectB<TMR, NN> &db, typename Tile<TMR>::Frag (&fb)[3], int K) {
+    const int last = ((K + 31) >> 5) - 1;
+    db.load(fb[0], 0);
+    db.load(fb[1], min(1, last));
+}
+
+template <int TMR, bool NN>
+__device__ __forceinline__ void gemm_direct(typename Tile<TMR>::Acc &acc, const float *As, int lda, int K,
+                                            const DirectB<TMR, NN> &db, typename Tile<TMR>::Frag (&fb)[3],
+                                            int lane) {
+    const int nch = (K + 31) >> 5, last = nch - 1;
+    typename Tile<TMR>::Frag fa;
+    for (int c = 0; c < nch; c += 3) {
+        db.load(fb[2], min(c + 2, last));
+        read_a<TMR>(fa, As, lda, c, lane);
+        mfma_chunk<TMR, NN>(acc, fa, fb[0]);
+        db.load(fb[0], min(c + 3, last));
+        if (c + 1 < nch) {
+            read_a<TMR>(fa, As, lda, c + 1, lane);
+            mfma_chunk<TMR, NN>(acc, fa, fb[1]);
+        }
+        db.load(fb[1], min(c + 4, last));
+        if (c + 2 < nch) {
+            read_a<TMR>(fa, As, lda, c + 2, lane);
+            mfma_chunk<TMR, NN>(acc, fa, fb[2]);
+        }
+    }
+}
+
+template <int MODE, int TMR>
+__global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
+    typedef Tile<TMR> T;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = g.hidden, IN = g.in_dim, OUT = g.out_dim;
+    const int KP = (IN + 31) & ~31;
+    const int ldx_s = KP + APAD, ldh = H + APAD, ldw3 = H + APAD;
+    float *xs = smem;                       // [TMR][KP+4]
+    float *h1s = xs + TMR * ldx_s;          // [TMR][H+4]
+    // after fc2, [xs | h1s] is dead and holds the head's K-split partials [8][TMR][16]
+    const int front = max(TMR * ldx_s + TMR * ldh, 8 * TMR * MAX_OUT);
+    float *h2s = smem + front;              // [TMR][H+4]
+    float *ys = h2s + TMR * ldh;            // [TMR][MAX_OUT]
+    float *dqs = ys + TMR * MAX_OUT;        // [TMR][MAX_OUT]
+    float *rowred = dqs + TMR * MAX_OUT;    // [64]
+    float *b1s = rowred + 64;               // [H]
+    float *b2s = b1s + H;                   // [H]
+    float *b3s = b2s + H;                   // [16]
+    float *w3s = b3s + 16;                  // [OUT][H+4]
+    float *rowin = w3s + OUT * ldw3;        // [3][TMR]
+    float *hpart = smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e = blockIdx.y, m0 = blockIdx.x * TMR;
+    const int net = g.ids ? g.ids[e] : e;
+    const float *P = g.params + (int64_t)net * g.net_stride;
+    const int col0 = wave * 32;
+    constexpr bool BWD_ONLY = MODE == MODE_CRITIC_BWD;
+    constexpr bool IS_CRITIC = MODE == MODE_CRITIC || MODE == MODE_CRITIC_BWD;
+
+    STAMP(0);
+    typename T::Frag fb[3];
+    typename T::Acc acc;
+    DirectB<TMR, true> db3;
+    unsigned h1mask = 0;  // bit i: the i-th element of this lane's accumulator had h1 > 0 (fc1 epilogue order)
+    if (IS_CRITIC) db3.init(P + g.off[2], H, H, H, lane, col0);
+
+    if (IS_CRITIC && tid < TMR) {
+        const int b = m0 + tid;
+        const bool ok = b < g.n_rows;
+        rowin[tid] = ok ? g.td[b] : 0.0f;
+        rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
+        rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
+    }
+    if (BWD_ONLY) {
+        start_direct<TMR, true>(db3, fb, H);
+        stage_head_weights(w3s, P + g.off[4], OUT, H, ldw3, tid);
+        const int c = (tid & 63) * 4;
+        if (c < H) {
+            for (int r = tid >> 6; r < TMR; r += NTHR / 64) {
+                const bool ok = (m0 + r) < g.n_rows;
+                const int64_t src = ((int64_t)e * g.n_rows + (ok ? m0 + r : 0)) * H + c;
+                const f4 a2 = *reinterpret_cast<const f4u *>(g.H2 + src);
+                *reinterpret_cast<f4 *>(h2s + r * ldh + c) = ok ? a2 : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        for (int i = tid; i < TMR * OUT; i += NTHR) {
+            const int r = i / OUT, o = i - r * OUT;
+            ys[r * MAX_OUT + o] = (m0 + r) < g.n_rows ? g.Y[((int64_t)e * g.n_rows + m0 + r) * OUT + o] : 0.0f;
+        }
+        T::zero(acc);
+        T::foreach(acc, lane, [&](int row, int cw, float) {  // (only the element order matters here)
+            const int col = col0 + cw;
+            const bool on = col < H && (m0 + row) < g.n_rows &&
+                            g.H1[((int64_t)e * g.n_rows + m0 + row) * H + col] > 0.0f;
+            h1mask = (h1mask << 1) | (on ? 1u : 0u);
+        });
+    } else {
+        const float *X = g.X + (int64_t)e * g.sX;
+        DirectB<TMR, false> db1, db2;
+        db1.init(P + g.off[0], IN, H, IN, lane, col0);
+        start_direct<TMR, false>(db1, fb, IN);
+        db2.init(P + g.off[2], H, H, H, lane, col0);
+        for (int i = tid; i < H; i += NTHR) { b1s[i] = P[g.off[1] + i]; b2s[i] = P[g.off[3] + i]; }
+        if (tid < OUT) b3s[tid] = P[g.off[5] + tid];
+        stage_head_weights(w3s, P + g.off[4], OUT, H, ldw3, tid);
+        for (int r = tid >> 5; r < TMR; r += NTHR / 32) {
+            const bool rok = (m0 + r) < g.n_rows;
+            const float *xr = X + (rok ? (int64_t)(m0 + r) * g.ldx : 0);
+            for (int k = tid & 31; k < KP; k += 32) {
+                const bool ok = rok && k < IN;
+                const float v = xr[ok ? k : 0];
+                xs[r * ldx_s + k] = ok ? v : 0.0f;
+            }
+        }
+        __syncthreads();
+        STAMP(1);
+        // ---- fc1
+        T::zero(acc);
+        gemm_direct<TMR, false>(acc, xs, ldx_s, IN, db1, fb, lane);
+        STAMP(2);
+        start_direct<TMR, false>(db2, fb, H);  // fc2's first chunks go in flight under fc1's epilogue
+        T::foreach(acc, lane, [&](int row, int cw, float val) {
+            const int col = col0 + cw;
+            float v = 0.0f;
+            if (col < H) {
+                v = fmaxf(val + b1s[col], 0.0f);
+                h1s[row * ldh + col] = v;
+                if (g.H1 && (m0 + row) < g.n_rows) g.H1[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
+            }
+            h1mask = (h1mask << 1) | (v > 0.0f ? 1u : 0u);
+        });
+        __syncthreads();
+        STAMP(3);
+        // ---- fc2
+        T::zero(acc);
+        gemm_direct<TMR, false>(acc, h1s, ldh, H, db2, fb, lane);
+        STAMP(4);
+        if (MODE == MODE_CRITIC) start_direct<TMR, true>(db3, fb, H);  // backward-data's W2 chunks in flight
+        T::foreach(acc, lane, [&](int row, int cw, float val) {
+            const int col = col0 + cw;
+            if (col < H) {
+                const float v = fmaxf(val + b2s[col], 0.0f);
+                h2s[row * ldh + col] = v;
+                if (g.H2 && (m0 + row) < g.n_rows) g.H2[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
+            }
+        });
+        __syncthreads();  // h2 visible; every wave is done reading h1s, which now becomes `hpart`
+        STAMP(5);
+        STAMP(6);
+        // ---- head on the matrix cores (see fused_mlp_kernel)
+        {
+            f32x4 hacc[TMR / 16];
+#pragma unroll
+            for (int q = 0; q < TMR / 16; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hacc[q][i] = 0.0f;
+            const int li = lane & 15, lg = lane >> 4;
+            if (col0 < H) {
+                const f4 *bp = reinterpret_cast<const f4 *>(w3s + (li < OUT ? li : 0) * ldw3 + col0 + lg * 8);
+                const float keep = li < OUT ? 1.0f : 0.0f;
+                const f4 b0 = bp[0] * keep, b1 = bp[1] * keep;
+#pragma unroll
+                for (int q = 0; q < TMR / 16; ++q) {
+                    const f4 *ap = reinterpret_cast<const f4 *>(h2s + (16 * q + li) * ldh + col0 + lg * 8);
+                    const f4 a0 = ap[0], a1 = ap[1];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+                        hacc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(t < 4 ? a0[t & 3] : a1[t & 3],
+                                                                       t < 4 ? b0[t & 3] : b1[t & 3], hacc[q], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < TMR / 16; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    hpart[(wave * TMR + 16 * q + 4 * lg + r) * MAX_OUT + li] = hacc[q][r];
+            __syncthreads();
+            const int row = tid >> 4, o = tid & 15;
+            if (row < TMR && o < OUT) {
+                float v = b3s[o];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += hpart[(w * TMR + row) * MAX_OUT + o];
+                ys[row * MAX_OUT + o] = v;
+                if (g.Y && (m0 + row) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + row) * OUT + o] = v;
+            }
+        }
+    }
+    STAMP(7);
+    if (MODE == MODE_PLAIN) return;
+    __syncthreads();
+
+    if (MODE == MODE_SAMPLE) {
+        if (tid < TMR && (m0 + tid) < g.n_rows) {
+            const int b = m0 + tid, A = OUT >> 1;
+            float lp = 0.0f;
+            for (int i = 0; i < A; ++i) {
+                const float mu = ys[tid * MAX_OUT + i], raw = ys[tid * MAX_OUT + A + i];
+                const float log_std = g.lo + 0.5f * (g.hi - g.lo) * (tanhf(raw) + 1.0f);
+                const float sd = expf(log_std);
+                const float u = mu + sd * g.eps[(int64_t)b * A + i];
+                const float a = tanhf(u);
+                const float dlt = u - mu;
+                lp += (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -
+                      2.0f * (LOG_2 - u - softplus_f(-2.0f * u));
+                g.act_dst[b * g.ld_act + g.act_col0 + i] = a;
+            }
+            if (g.logp) g.logp[b] = lp;
+        }
+        return;
+    }
+
+    if (IS_CRITIC) {
+        // ---- loss gradient per row (learning.py:90-98, 112)
+        const float pw = (g.popart && g.pop) ? g.popart->w : 1.0f;
+        const float pb = (g.popart && g.pop) ? g.popart->b : 0.0f;
+        const float gscale = -2.0f * pw / (g.denom * (float)g.n_rows);
+        if (tid < TMR) {
+            float lossv = 0.0f, errv = 0.0f;
+            const int b = m0 + tid;
+            int ai = 0;
+            float dsel = 0.0f;
+            if (b < g.n_rows) {
+                if (OUT > 1) ai = (int)rowin[2 * TMR + tid];
+                const float w = rowin[TMR + tid];
+                const float err = rowin[tid] - (pw * ys[tid * MAX_OUT + ai] + pb);
+                lossv = w * err * err;
+                errv = err;
+                dsel = gscale * w * err;
+            }
+            for (int o = 0; o < OUT; ++o) {
+                const float d = (o == ai) ? dsel : 0.0f;
+                dqs[tid * MAX_OUT + o] = d;
+                if (b < g.n_rows) g.DQ[((int64_t)e * g.n_rows + b) * OUT + o] = d;
+            }
+            rowred[tid] = lossv;
+            rowred[32 + tid] = errv;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float sl = 0.0f, se = 0.0f;
+            for (int r = 0; r < TMR; ++r) { sl += rowred[r]; se += rowred[32 + r]; }
+            const int64_t pi = ((int64_t)e * gridDim.x + blockIdx.x) * 2;
+            g.partials[pi] = sl;
+            g.partials[pi + 1] = se;
+        }
+        STAMP(8);
+        // ---- head backward: dz2 = (dq W3) (.) [h2 > 0], in place over h2s
+        {
+            const int k = tid & 255;
+            if (k < H) {
+                for (int r = tid >> 8; r < TMR; r += 2) {
+                    float gsum = 0.0f;
+                    for (int o = 0; o < OUT; ++o) gsum += dqs[r * MAX_OUT + o] * w3s[o * ldw3 + k];
+                    const float dz = h2s[r * ldh + k] > 0.0f ? gsum : 0.0f;
+                    h2s[r * ldh + k] = dz;
+                    if ((m0 + r) < g.n_rows) g.DZ2[((int64_t)e * g.n_rows + m0 + r) * H + k] = dz;
+                }
+            }
+        }
+        __syncthreads();
+        STAMP(9);
+        // ---- backward-data of fc2: dz1 = (dz2 W2) (.) [h1 > 0]
+        T::zero(acc);
+        gemm_direct<TMR, true>(acc, h2s, ldh, H, db3, fb, lane);
+        STAMP(10);
+        constexpr int NEL = TMR == 32 ? 16 : 8;
+        int el = 0;
+        T::foreach(acc, lane, [&](int row, int cw, float val) {
+            const int col = col0 + cw;
+            const bool on = (h1mask >> (NEL - 1 - el)) & 1u;
+            ++el;
+            if (col < H && (m0 + row) < g.n_rows)
+                g.DZ1[((int64_t)e * g.n_rows + m0 + row) * H + col] = on ? val : 0.0f;
+        });
+        STAMP(11);
+    }
+}
+
+size_t direct_lds_bytes(int in_dim, int hidden, int out_dim, int tm) {
+    const int KP = (in_dim + 31) & ~31;
+    size_t front = (size_t)tm * (KP + APAD) + (size_t)tm * (hidden + APAD);
+    if (front < (size_t)8 * tm * MAX_OUT) front = (size_t)8 * tm * MAX_OUT;
+    return sizeof(float) * (front + (size_t)tm * (hidden + APAD) + 2 * tm * MAX_OUT + 64 + 2 * hidden + 16 +
+                            (size_t)out_dim * (hidden + APAD) + 3 * tm);
+}
+
 long long *g_fused_dbg = nullptr;
 
 int g_tile_rows = 0;  // 0 = automatic, else 16 or 32 (ssac_fused_tile_rows)
@@ -617,24 +1027,24 @@ size_t fused_lds_bytes(int in_dim, int hidden, int out_dim, int tm = TM, bool db
                             2 * hidden + 16 + (size_t)out_dim * (hidden + APAD) + 3 * tm);
 }
 
-// 16-row tiles whenever the launch is small enough that they still run in a single round of the 256 CUs
-int pick_tile_rows(const FusedArgs &g, int n_sel) {
-    const int n_rows = g.n_rows;
-    // wide inputs / wide heads with hidden 256 only fit the 160 KB of LDS with 16-row tiles
-    if (fused_lds_bytes(g.in_dim, g.hidden, g.out_dim, 32) > 160 * 1024) return 16;
-    if (g_tile_rows == 16 || g_tile_rows == 32) return g_tile_rows;
-    // 16-row tiles while the launch fits the chip in one round: one double-buffered workgroup per CU up to
-    // 256 workgroups, two single-buffered ones per CU up to 512 (variant 17 = "16 rows, single buffer")
-    const int wg16 = ((n_rows + 15) / 16) * n_sel;
-    return wg16 <= 256 ? 16 : 32;
-}
+// Kernel variant for one launch.  g_tile_rows (ssac_fused_tile_rows) forces one: 16 / 32 = staged weights,
+// double buffered; 17 = staged, 16 rows, single buffer; 116 / 132 = direct-B with 16 / 32 rows.
+struct TileChoice { int tm; int variant; };  // variant 0 staged double buffer, 1 staged single buffer, 2 direct-B
 
-bool pick_single_buffer(const FusedArgs &g, int n_sel) {
-    if (g_tile_rows == 17) return true;
-    // Measured on MI355X at the metric shape (320 such workgroups): 44.7 us against 40-44 us for the
-    // 32-row double-buffered tiles, so the variant is never chosen automatically; it stays a tested option.
-    (void)g; (void)n_sel;
-    return false;
+TileChoice choose_tile(const FusedArgs &g, int n_sel) {
+    const bool fits32 = fused_lds_bytes(g.in_dim, g.hidden, g.out_dim, 32) <= 160 * 1024;
+    switch (g_tile_rows) {
+        case 17: return {16, 1};
+        case 116: return {16, 2};
+        case 132: return {direct_lds_bytes(g.in_dim, g.hidden, g.out_dim, 32) <= 160 * 1024 ? 32 : 16, 2};
+        case 16: return {16, 0};
+        case 32: return {fits32 ? 32 : 16, 0};
+        default: break;
+    }
+    // automatic: 16-row tiles while the launch still fits the chip in one round (one workgroup per CU), and
+    // whenever wide inputs / heads leave no room for 32 rows in the 160 KB of LDS
+    const int wg16 = ((g.n_rows + 15) / 16) * n_sel;
+    return {(wg16 <= 256 || !fits32) ? 16 : 32, 0};
 }
 
 bool fused_ok(const ssac_mlp *n) {
@@ -666,11 +1076,29 @@ int launch_fused_t(const FusedArgs &g, int n_sel, hipStream_t st) {
     return ssac_check_launch("fused_mlp");
 }
 
+template <int MODE, int TMR>
+int launch_direct_t(const FusedArgs &g, int n_sel, hipStream_t st) {
+    static bool attr_set = false;
+    const size_t lds = direct_lds_bytes(g.in_dim, g.hidden, g.out_dim, TMR);
+    if (lds > 160 * 1024) return ssac_fail("fused_direct: LDS carve does not fit");
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)fused_direct_kernel<MODE, TMR>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return ssac_fail("fused_direct: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    dim3 grid((g.n_rows + TMR - 1) / TMR, n_sel);
+    SSAC_LAUNCH((fused_direct_kernel<MODE, TMR>), grid, dim3(NTHR), lds, st, g);
+    return ssac_check_launch("fused_direct");
+}
+
 template <int MODE>
 int launch_fused(const FusedArgs &g, int n_sel, hipStream_t st) {
-    if (pick_single_buffer(g, n_sel)) return launch_fused_t<MODE, 16, false>(g, n_sel, st);
-    return pick_tile_rows(g, n_sel) == 16 ? launch_fused_t<MODE, 16, true>(g, n_sel, st)
-                                                 : launch_fused_t<MODE, 32, true>(g, n_sel, st);
+    const TileChoice c = choose_tile(g, n_sel);
+    if (c.variant == 2)
+        return c.tm == 16 ? launch_direct_t<MODE, 16>(g, n_sel, st) : launch_direct_t<MODE, 32>(g, n_sel, st);
+    if (c.variant == 1) return launch_fused_t<MODE, 16, false>(g, n_sel, st);
+    return c.tm == 16 ? launch_fused_t<MODE, 16, true>(g, n_sel, st) : launch_fused_t<MODE, 32, true>(g, n_sel, st);
 }
 
 // ------------------------------------------------------------------ head weight gradient + Adam
@@ -878,13 +1306,13 @@ extern "C" int ssac_critic_bwd_fused(const ssac_mlp *nets, int n_rows, const flo
 extern "C" int ssac_fused_row_tiles(const ssac_mlp *nets, int n_rows, int n_nets) {
     FusedArgs g{};
     g.n_rows = n_rows; g.in_dim = nets->in_dim; g.hidden = nets->hidden; g.out_dim = nets->out_dim;
-    const int tm = pick_single_buffer(g, n_nets) ? 16 : pick_tile_rows(g, n_nets);
+    const int tm = choose_tile(g, n_nets).tm;
     return (n_rows + tm - 1) / tm;
 }
 
 extern "C" int ssac_fused_tile_rows(int rows) {
-    if (rows != 0 && rows != 16 && rows != 17 && rows != 32)
-        return ssac_fail("ssac_fused_tile_rows: 0 (auto), 16, 17 (16 rows, single buffer) or 32");
+    if (rows != 0 && rows != 16 && rows != 17 && rows != 32 && rows != 116 && rows != 132)
+        return ssac_fail("ssac_fused_tile_rows: 0 (auto), 16, 32, 17 (16 rows, single buffer), 116 / 132 (direct-B)");
     g_tile_rows = rows;
     return 0;
 }

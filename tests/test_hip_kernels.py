@@ -99,7 +99,8 @@ def test_ensemble_q_known_answers_from_reference(ssa):
     _close(q[:, :, 0], torch.from_numpy(f["ensq_q"]), 5e-5, what="ensemble Q")
 
 
-@pytest.fixture(params=[16, 17, 32], ids=["tile16", "tile16-single-buffer", "tile32"])
+@pytest.fixture(params=[16, 17, 32, 116, 132],
+                ids=["tile16", "tile16-single-buffer", "tile32", "direct16", "direct32"])
 def tile_rows(request, ssa):
     """run the fused kernels with 16-row (16x16x4 MFMA) and 32-row (32x32x2 MFMA) tiles"""
     ssa._lib.check(ssa._lib.lib.ssac_fused_tile_rows(request.param))
@@ -174,6 +175,16 @@ def test_fused_critic_fwd_bwd_matches_autograd(ssa, tile_rows, qd, B, H, N):
         C.byref(ar.desc()), xd.data_ptr(), in_dim, B, tdd.data_ptr(), wd.data_ptr(), ad.data_ptr(), 1, 0, 0,
         float(N), h1.data_ptr(), h2.data_ptr(), q.data_ptr(), dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(),
         parts.data_ptr(), ssa.engine.stream()))
+    # the two-launch form (forward with saved activations, then the backward-only kernel) is bit-identical
+    f1, f2, fq = ssa.engine.mlp_forward(ar, xd, in_dim, 0, B, ws, "split")
+    bdq, bdz2, bdz1, bparts = torch.zeros_like(dq), torch.zeros_like(dz2), torch.zeros_like(dz1), torch.zeros_like(parts)
+    ssa._lib.check(ssa._lib.lib.ssac_critic_bwd_fused(
+        C.byref(ar.desc()), B, tdd.data_ptr(), wd.data_ptr(), ad.data_ptr(), 1, 0, 0, float(N), f1.data_ptr(),
+        f2.data_ptr(), fq.data_ptr(), bdq.data_ptr(), bdz2.data_ptr(), bdz1.data_ptr(), bparts.data_ptr(),
+        ssa.engine.stream()))
+    for a_, b_, what in ((f1, h1, "h1"), (f2, h2, "h2"), (fq, q, "q"), (bdq, dq, "dq"), (bdz2, dz2, "dz2"),
+                         (bdz1, dz1, "dz1"), (bparts, parts, "partials")):
+        assert torch.equal(a_, b_), f"two-launch critic path differs in {what}"
     grads = torch.zeros_like(ar.params)
     ss = torch.zeros(N * ssa.engine.wgrad_tiles_total(ar), device=DEV)
     ssa.engine.weight_grads(ar, xd, in_dim, 0, h1, h2, dq, dz2, dz1, B, grads=grads, sumsq=ss)

@@ -6,6 +6,7 @@ import numpy as np, torch
 import super_sac_amd as ssa
 import ssac_oracle as orc
 dev = torch.device("cuda")
+ssa._lib.check(ssa._lib.lib.ssac_fused_tile_rows(int(os.environ.get("SSAC_TILE", "0"))))
 rng = np.random.RandomState(0)
 for (B, in_dim, H, out, N) in [(512, 23, 256, 1, 2), (512, 17, 256, 12, 1), (512, 23, 256, 1, 10)]:
     mlps = [orc.make_mlp(rng, in_dim, H, out) for _ in range(N)]

@@ -19,12 +19,12 @@ int main(){
     float* out; long long* cyc; hipMalloc(&out, 4*1024*1024); hipMalloc(&cyc, 8);
     hipEvent_t e0,e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int wgs : {1, 16, 160, 256, 512}) for (int threads : {256, 512}) {
-        int iters = 64;   // 1024 MFMAs per wave
+        int iters = 512;   // 8192 MFMAs per wave
         k<<<wgs, threads>>>(out, iters, cyc); hipDeviceSynchronize();
         hipEventRecord(e0); for (int r=0;r<20;++r) k<<<wgs, threads>>>(out, iters, cyc); hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-        double us = ms*1e3/20; double mf = 1024.0;
-        printf("wgs %4d thr %4d: %.2f us/launch, memtime ticks %lld -> %.1f ticks/MFMA/wave, %.1f ns/MFMA/wave\n", wgs, threads, us, c, (double)c/mf, us*1e3/mf);
+        double us = ms*1e3/20; double mf = 8192.0;
+        printf("wgs %4d thr %4d: %.2f us/launch, memtime ticks %lld -> %.1f ticks/MFMA/wave, %.1f ns/MFMA/wave, %.1f TFLOP/s\n", wgs, threads, us, c, (double)c/mf, us*1e3/mf, (double)wgs*(threads/64)*mf*4096.0/(us*1e-6)/1e12);
     }
     return 0;
 }

@@ -75,6 +75,19 @@ typedef struct ssac_feed {
     int32_t n_slots, slot_words, log_slot_word, log_width;
 } ssac_feed;
 
+/* TD target evaluated INSIDE the critic launch instead of by ssac_td_target (continuous actions, no PopArt):
+ * td[b] = rew[b] + gamma (1 - done[b]) (min_j q_t[j][b] - alpha logp[b])   (learning_utils.py:298-354),
+ * the same arithmetic in the same order as ssac_td_target.  Host-side struct, copied at launch. */
+typedef struct ssac_td_spec {
+    const float *q_t;        /* (n_sel x n_rows) target-critic outputs of the REDQ subset */
+    const float *logp;       /* (n_rows) log pi(a'|s'), read when use_entropy */
+    const float *rew, *done; /* (n_rows) */
+    const float *log_alpha;  /* scalar, read when use_entropy */
+    float *td_out;           /* (n_rows) the targets, written by the launch (for logs / replay dicts) */
+    float gamma;
+    int32_t n_sel, use_entropy, _pad;
+} ssac_td_spec;
+
 int ssac_abi_version(void);
 const char *ssac_last_error(void);
 
@@ -299,7 +312,8 @@ int ssac_actor_sample_fused(const ssac_mlp *actor, const float *X, int64_t ldx, 
 int ssac_critic_fwd_bwd_fused(const ssac_mlp *nets, const float *X, int64_t ldx, int n_rows,
                               const float *td, const float *weight, const float *act, int64_t ld_act,
                               const ssac_popart *popart, int pop, float denom, float *H1, float *H2,
-                              float *Q, float *DQ, float *DZ2, float *DZ1, float *partials, void *stream);
+                              float *Q, float *DQ, float *DZ2, float *DZ1, float *partials,
+                              const ssac_td_spec *lazy_td /* NULL: read `td` */, void *stream);
 
 /* the second half of ssac_critic_fwd_bwd_fused alone: H1, H2, Q come from an earlier ssac_mlp3_fwd_fused
  * launch over all nets (same layouts); results are bit-identical to the one-launch form.  The forward does
@@ -308,7 +322,7 @@ int ssac_critic_fwd_bwd_fused(const ssac_mlp *nets, const float *X, int64_t ldx,
 int ssac_critic_bwd_fused(const ssac_mlp *nets, int n_rows, const float *td, const float *weight,
                           const float *act, int64_t ld_act, const ssac_popart *popart, int pop, float denom,
                           const float *H1, const float *H2, const float *Q, float *DQ, float *DZ2,
-                          float *DZ1, float *partials, void *stream);
+                          float *DZ1, float *partials, const ssac_td_spec *lazy_td, void *stream);
 
 /* weight gradient of the head layer (out_dim <= 16) + Adam/Polyak, VALU: dW3 = DQ^T H2, db3 = colsum(DQ).
  * Same grads/sumsq/target conventions as ssac_mlp_layer_wgrad; sumsq slots: ssac_head_wgrad_tiles(). */
@@ -323,7 +337,8 @@ int ssac_head_wgrad(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, con
  * the launch also does what ssac_publish_logs does. */
 int ssac_critic_logs(const float *partials, int n_nets, int tiles, int n_rows, float denom,
                      const float *sumsq, int n_sumsq, const ssac_adam_ctl *scale_by_clip, float *logs,
-                     ssac_feed *feed, void *stream);
+                     const ssac_td_spec *lazy_td /* with td_logs: mean, std, entropy bonus of the targets */,
+                     float *td_logs, ssac_feed *feed, void *stream);
 /* last launch of a captured update: copy the finished log block to its ring slot and advance feed->tick. */
 int ssac_publish_logs(const float *logs, ssac_feed *feed, void *stream);
 

@@ -39,6 +39,13 @@ class Feed(C.Structure):
                 ("log_slot_word", C.c_int32), ("log_width", C.c_int32)]
 
 
+class TdSpec(C.Structure):
+    """struct ssac_td_spec"""
+    _fields_ = [("q_t", C.c_void_p), ("logp", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p),
+                ("log_alpha", C.c_void_p), ("td_out", C.c_void_p), ("gamma", C.c_float),
+                ("n_sel", C.c_int32), ("use_entropy", C.c_int32), ("_pad", C.c_int32)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _MP = C.POINTER(MlpDesc)
 
@@ -96,11 +103,11 @@ SIGNATURES = {
     "ssac_fused_tile_rows": [_I],
     "ssac_mlp3_fwd_fused": [_MP, _P, _I, _P, _L, _L, _I, _P, _P, _P, _P],
     "ssac_actor_sample_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _P, _P, _P],
-    "ssac_critic_fwd_bwd_fused": [_MP, _P, _L, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P],
-    "ssac_critic_bwd_fused": [_MP, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ssac_critic_fwd_bwd_fused": [_MP, _P, _L, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ssac_critic_bwd_fused": [_MP, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ssac_head_wgrad_tiles": [_MP],
     "ssac_head_wgrad": [_MP, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P, _F, _P],
-    "ssac_critic_logs": [_P, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P],
+    "ssac_critic_logs": [_P, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _P, _P],
 }
 _RESTYPES = {"ssac_last_error": C.c_char_p, "ssac_mlp_layout": C.c_int64, "ssac_record_end": C.c_void_p,
              "ssac_launch_list_free": None}

@@ -56,7 +56,21 @@ struct FusedArgs {
     const float *td, *weight, *act; int64_t ld_a; const ssac_popart *popart; int pop; float denom;
     float *DQ, *DZ2, *DZ1; float *partials;  // partials[(e*tiles + tile)*2 + {loss, err}]
     long long *dbg;  // optional phase timestamps (s_memtime) of workgroup (0,0), thread 0
+    ssac_td_spec tds;  // tds.q_t != null: the TD target is computed here instead of read from `td`
 };
+
+// TD target of row b (see ssac_td_spec; same operation order as td_target_kernel in ssac_elementwise.hip)
+__device__ __forceinline__ float td_of_row(const FusedArgs &g, int b) {
+    if (!g.tds.q_t) return g.td[b];
+    float mq = g.tds.q_t[b];
+    for (int j = 1; j < g.tds.n_sel; ++j) mq = fminf(mq, g.tds.q_t[(int64_t)j * g.n_rows + b]);
+    const float alpha = g.tds.use_entropy ? expf(g.tds.log_alpha[0]) : 0.0f;
+    const float bonus = g.tds.use_entropy ? alpha * g.tds.logp[b] : 0.0f;
+    const float val = mq - bonus;
+    const float t = g.tds.rew[b] + g.tds.gamma * (1.0f - g.tds.done[b]) * val;
+    if (blockIdx.y == 0) g.tds.td_out[b] = t;
+    return t;
+}
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
@@ -391,7 +405,7 @@ void fused_mlp_kernel(FusedArgs g) {
         if (tid < TMR) {
             const int b = m0 + tid;
             const bool ok = b < g.n_rows;
-            rowin[tid] = ok ? g.td[b] : 0.0f;
+            rowin[tid] = ok ? td_of_row(g, b) : 0.0f;
             rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
             rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
         }
@@ -423,7 +437,7 @@ void fused_mlp_kernel(FusedArgs g) {
         if ((MODE == MODE_CRITIC) && tid < TMR) {
             const int b = m0 + tid;
             const bool ok = b < g.n_rows;
-            rowin[tid] = ok ? g.td[b] : 0.0f;
+            rowin[tid] = ok ? td_of_row(g, b) : 0.0f;
             rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
             rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
         }
@@ -799,7 +813,7 @@ __global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
     if (IS_CRITIC && tid < TMR) {
         const int b = m0 + tid;
         const bool ok = b < g.n_rows;
-        rowin[tid] = ok ? g.td[b] : 0.0f;
+        rowin[tid] = ok ? td_of_row(g, b) : 0.0f;
         rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
         rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
     }
@@ -1202,8 +1216,39 @@ __global__ __launch_bounds__(256) void critic_logs_kernel(const float *__restric
                                                           int tiles, int n_rows, float denom,
                                                           const float *__restrict__ sumsq, int n_ss,
                                                           const ssac_adam_ctl *scale, float *logs,
-                                                          ssac_feed *feed) {
+                                                          ssac_td_spec tds, float *td_logs, ssac_feed *feed) {
     __shared__ float red[3][4];
+    if (tds.q_t && td_logs) {  // statistics of the targets the critic launch computed (td_target_kernel's logs)
+        float s_td = 0.f, s_b = 0.f;
+        const float alpha = tds.use_entropy ? expf(tds.log_alpha[0]) : 0.0f;
+        for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+            s_td += tds.td_out[b];
+            s_b += tds.use_entropy ? alpha * tds.logp[b] : 0.0f;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s_td += __shfl_xor(s_td, o, 64); s_b += __shfl_xor(s_b, o, 64); }
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s_td; red[1][threadIdx.x >> 6] = s_b; }
+        __syncthreads();
+        const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)n_rows;
+        const float mb = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)n_rows;
+        __syncthreads();
+        float sv = 0.f;
+        for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+            const float dlt = tds.td_out[b] - mean;
+            sv += dlt * dlt;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
+        if ((threadIdx.x & 63) == 0) red[2][threadIdx.x >> 6] = sv;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float var = (red[2][0] + red[2][1] + red[2][2] + red[2][3]) / (float)(n_rows > 1 ? n_rows - 1 : 1);
+            td_logs[0] = mean;
+            td_logs[1] = sqrtf(var);
+            td_logs[2] = mb;
+        }
+        __syncthreads();
+    }
     float sl = 0.f, se = 0.f, ss = 0.f;
     const int tot = n_nets * tiles;
     for (int i = threadIdx.x; i < tot; i += blockDim.x) {
@@ -1272,9 +1317,9 @@ extern "C" int ssac_critic_fwd_bwd_fused(const ssac_mlp *nets, const float *X, i
                                          const float *td, const float *weight, const float *act,
                                          int64_t ld_act, const ssac_popart *popart, int pop, float denom,
                                          float *H1, float *H2, float *Q, float *DQ, float *DZ2, float *DZ1,
-                                         float *partials, void *stream) {
+                                         float *partials, const ssac_td_spec *lazy_td, void *stream) {
     if (!fused_ok(nets)) return ssac_fail("ssac_critic_fwd_bwd_fused: shape not supported by the fused path");
-    if (!H1 || !H2 || !DQ || !DZ2 || !DZ1 || !partials || !td)
+    if (!H1 || !H2 || !DQ || !DZ2 || !DZ1 || !partials)
         return ssac_fail("ssac_critic_fwd_bwd_fused: missing output buffer");
     if (nets->out_dim > 1 && !act) return ssac_fail("ssac_critic_fwd_bwd_fused: discrete needs actions");
     if (n_rows <= 0) return 0;
@@ -1283,13 +1328,16 @@ extern "C" int ssac_critic_fwd_bwd_fused(const ssac_mlp *nets, const float *X, i
     g.H1 = H1; g.H2 = H2; g.Y = Q;
     g.td = td; g.weight = weight; g.act = act; g.ld_a = ld_act; g.popart = popart; g.pop = pop;
     g.denom = denom; g.DQ = DQ; g.DZ2 = DZ2; g.DZ1 = DZ1; g.partials = partials;
+    if (lazy_td) g.tds = *lazy_td;
+    if (!td && !lazy_td) return ssac_fail("ssac_critic_fwd_bwd_fused: no TD target given");
     return launch_fused<MODE_CRITIC>(g, nets->n_nets, (hipStream_t)stream);
 }
 
 extern "C" int ssac_critic_bwd_fused(const ssac_mlp *nets, int n_rows, const float *td, const float *weight,
                                      const float *act, int64_t ld_act, const ssac_popart *popart, int pop,
                                      float denom, const float *H1, const float *H2, const float *Q, float *DQ,
-                                     float *DZ2, float *DZ1, float *partials, void *stream) {
+                                     float *DZ2, float *DZ1, float *partials, const ssac_td_spec *lazy_td,
+                                     void *stream) {
     if (!fused_ok(nets)) return ssac_fail("ssac_critic_bwd_fused: shape not supported by the fused path");
     if (nets->out_dim > 1 && !act) return ssac_fail("ssac_critic_bwd_fused: discrete needs actions");
     if (!H1 || !H2 || !Q) return ssac_fail("ssac_critic_bwd_fused: needs the saved forward (H1, H2, Q)");
@@ -1299,6 +1347,8 @@ extern "C" int ssac_critic_bwd_fused(const ssac_mlp *nets, int n_rows, const flo
     g.H1 = const_cast<float *>(H1); g.H2 = const_cast<float *>(H2); g.Y = const_cast<float *>(Q);
     g.td = td; g.weight = weight; g.act = act; g.ld_a = ld_act; g.popart = popart; g.pop = pop;
     g.denom = denom; g.DQ = DQ; g.DZ2 = DZ2; g.DZ1 = DZ1; g.partials = partials;
+    if (lazy_td) g.tds = *lazy_td;
+    if (!td && !lazy_td) return ssac_fail("ssac_critic_bwd_fused: no TD target given");
     return launch_fused<MODE_CRITIC_BWD>(g, nets->n_nets, (hipStream_t)stream);
 }
 
@@ -1337,8 +1387,11 @@ extern "C" int ssac_head_wgrad_tiles(const ssac_mlp *nets) { return nets ? (nets
 
 extern "C" int ssac_critic_logs(const float *partials, int n_nets, int tiles, int n_rows, float denom,
                                 const float *sumsq, int n_sumsq, const ssac_adam_ctl *scale_by_clip,
-                                float *logs, ssac_feed *feed, void *stream) {
+                                float *logs, const ssac_td_spec *lazy_td, float *td_logs, ssac_feed *feed,
+                                void *stream) {
+    ssac_td_spec tds{};
+    if (lazy_td) tds = *lazy_td;
     SSAC_LAUNCH(critic_logs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n_nets,
-                       tiles, n_rows, denom, sumsq, n_sumsq, scale_by_clip, logs, feed);
+                       tiles, n_rows, denom, sumsq, n_sumsq, scale_by_clip, logs, tds, td_logs, feed);
     return ssac_check_launch("critic_logs");
 }

@@ -55,6 +55,8 @@ class _LaunchList:
 
 
 FEED_SLOTS = 16  # pinned input ring of a captured update: how far the host may run ahead of the GPU
+# evaluate the TD target inside the critic launch instead of a launch of its own (continuous, no PopArt)
+LAZY_TD = os.environ.get("SSAC_LAZY_TD", "1") == "1"
 SPLIT_FORWARD = os.environ.get("SSAC_SPLIT_FORWARD", "0") == "1"
 
 
@@ -271,7 +273,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                                       ensemble_idx=i, ensemble_n=target_critic_ensemble_n,
                                       log_alphas=log_alphas, pop=pop, gamma=gamma,
                                       random_process=random_process, noise_clip=noise_clip,
-                                      discrete=discrete, _slot=slot)
+                                      discrete=discrete, _slot=slot, _defer=arena.fused and LAZY_TD)
         bw = lu.compute_backup_weights(logs=logs, replay_dict=rd, agent=agent, target_agent=target_agent,
                                        weight_type=weight_type, weight_temp=weighted_bellman_temp,
                                        batch_size=batch_size, discrete=discrete, _slot=slot)
@@ -302,6 +304,8 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             dz1 = ws.get(tag + ".dz1", (N, B, H))
             tiles = int(lib.ssac_fused_row_tiles(C.byref(arena.desc()), B, N))
             parts = ws.get(tag + ".parts", (N * tiles * 2,))
+            spec = getattr(td, "_ssac_spec", None)  # the TD target is evaluated inside the critic launch
+            spec_ptr = C.addressof(spec) if spec is not None else 0
             if branch is not None:
                 # loss gradient + head backward + backward-data on the saved forward: ONE launch
                 branch.join()
@@ -309,7 +313,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                     check(lib.ssac_critic_bwd_fused(
                         C.byref(arena.desc()), B, td.data_ptr(), weight_ptr, a.data_ptr(), a.stride(0), pp,
                         dopop, float(E * n_glob), h1.data_ptr(), h2.data_ptr(), q.data_ptr(), dq.data_ptr(),
-                        dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), st))
+                        dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), spec_ptr, st))
             else:
                 # forward of all N critics + loss gradient + backward-data: ONE launch
                 h1 = ws.get(tag + ".h1", (N, B, H))
@@ -319,7 +323,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                     check(lib.ssac_critic_fwd_bwd_fused(
                         C.byref(arena.desc()), X.data_ptr(), ldx, B, td.data_ptr(), weight_ptr, a.data_ptr(),
                         a.stride(0), pp, dopop, float(E * n_glob), h1.data_ptr(), h2.data_ptr(), q.data_ptr(),
-                        dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), st))
+                        dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), spec_ptr, st))
             if train_enc:  # dL/d(embedding) = sum over critics of dz1 W1[:, :emb], BEFORE W1 is updated
                 dX = ws.get(tag + ".dx", (N, B, arena.in_dim))
                 check(lib.ssac_mlp_layer_dgrad(C.byref(arena.desc()), 0, 0, N, dz1.data_ptr(), H, B * H, 0, 0, 0,
@@ -327,7 +331,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                 _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, s_rep.shape[1], ws, slot, dev)
             engine.weight_grads(arena, X, ldx, 0, h1, h2, dq, dz2, dz1, B, adam=adam,
                                 adam_key=("critic", i), grads=grads, sumsq=ss)
-            fused_logs.append((parts, N, tiles, B, n_glob))
+            fused_logs.append((parts, N, tiles, B, n_glob, td))
         else:
             h1, h2, q = engine.mlp_forward(arena, X, ldx, 0, B, ws, tag)
             check(lib.ssac_critic_loss_bwd(q.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0),
@@ -361,13 +365,16 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
     for j, fl in enumerate(fused_logs):
         if fl is None:
             continue
-        parts, n_, tiles_, b_, ng_ = fl
+        parts, n_, tiles_, b_, ng_, td_ = fl
+        spec_ = getattr(td_, "_ssac_spec", None)
         want = j == k
         cap = engine.CAPTURE
         last = cap is not None and cap.feed and j == len(fused_logs) - 1 and (done_norm or want)
         check(lib.ssac_critic_logs(parts.data_ptr(), n_, tiles_, b_, float(E * ng_),
                                    member_ss[k].data_ptr() if want else 0, member_ss[k].numel() if want else 0,
-                                   clip_ctl, slot.data_ptr(), cap.feed if last else 0, st))
+                                   clip_ctl, slot.data_ptr(), C.addressof(spec_) if spec_ is not None else 0,
+                                   td_._ssac_logs.data_ptr() if spec_ is not None else 0,
+                                   cap.feed if last else 0, st))
         if last:
             cap.published = True
         done_norm = done_norm or want

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import augmentations, engine, nets, rng
+from . import _lib
 from ._lib import check, lib
 
 LOG_WIDTH = 64
@@ -269,7 +270,10 @@ def _upload_ids(ws, ids, device, tag):
 
 
 def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ensemble_n, log_alphas,
-                       pop, gamma, random_process, noise_clip, discrete=False, _slot=None):
+                       pop, gamma, random_process, noise_clip, discrete=False, _slot=None, _defer=False):
+    """learning_utils.py:298-354.  With ``_defer`` (critic_update's fused path; continuous actions, no PopArt)
+    the final elementwise step -- and its three log values -- is not launched here: the returned ``td`` buffer
+    carries a ``_ssac_spec`` (ssac_td_spec) and the critic launch evaluates the targets into it."""
     o, a, r, o1, d = replay_dict["primary_batch"]
     i = ensemble_idx
     dev = r.device
@@ -345,10 +349,16 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
         lp_ptr, qd = logp.data_ptr(), 1
         a_s1 = x1[:, S:]
     td = torch.empty(B, 1, device=dev)
-    check(lib.ssac_td_target(q1.data_ptr(), n_q, B, qd, lp_ptr, r.data_ptr(), d.data_ptr(),
-                             log_alpha.data_ptr(), use_entropy, float(gamma),
-                             popart.ptr if popart else 0, 1 if (popart and pop) else 0,
-                             td.data_ptr(), slot[L_TD0 + 3 * i:].data_ptr(), st))
+    if _defer and qd == 1 and not popart:
+        td._ssac_spec = _lib.TdSpec(q1.data_ptr(), lp_ptr, r.data_ptr(), d.data_ptr(), log_alpha.data_ptr(),
+                                    td.data_ptr(), float(gamma), n_q, use_entropy, 0)
+        td._ssac_logs = slot[L_TD0 + 3 * i:]
+        td._ssac_keep = (q1, logp, r, d, log_alpha)
+    else:
+        check(lib.ssac_td_target(q1.data_ptr(), n_q, B, qd, lp_ptr, r.data_ptr(), d.data_ptr(),
+                                 log_alpha.data_ptr(), use_entropy, float(gamma),
+                                 popart.ptr if popart else 0, 1 if (popart and pop) else 0,
+                                 td.data_ptr(), slot[L_TD0 + 3 * i:].data_ptr(), st))
     logs[f"td_targets/mean_td_target_{i}"] = slot[L_TD0 + 3 * i]
     logs[f"td_targets/std_td_target_{i}"] = slot[L_TD0 + 3 * i + 1]
     logs[f"td_targets/entropy_bonus_{i}"] = slot[L_TD0 + 3 * i + 2]

@@ -174,13 +174,13 @@ def test_fused_critic_fwd_bwd_matches_autograd(ssa, tile_rows, qd, B, H, N):
     ssa._lib.check(ssa._lib.lib.ssac_critic_fwd_bwd_fused(
         C.byref(ar.desc()), xd.data_ptr(), in_dim, B, tdd.data_ptr(), wd.data_ptr(), ad.data_ptr(), 1, 0, 0,
         float(N), h1.data_ptr(), h2.data_ptr(), q.data_ptr(), dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(),
-        parts.data_ptr(), ssa.engine.stream()))
+        parts.data_ptr(), 0, ssa.engine.stream()))
     # the two-launch form (forward with saved activations, then the backward-only kernel) is bit-identical
     f1, f2, fq = ssa.engine.mlp_forward(ar, xd, in_dim, 0, B, ws, "split")
     bdq, bdz2, bdz1, bparts = torch.zeros_like(dq), torch.zeros_like(dz2), torch.zeros_like(dz1), torch.zeros_like(parts)
     ssa._lib.check(ssa._lib.lib.ssac_critic_bwd_fused(
         C.byref(ar.desc()), B, tdd.data_ptr(), wd.data_ptr(), ad.data_ptr(), 1, 0, 0, float(N), f1.data_ptr(),
-        f2.data_ptr(), fq.data_ptr(), bdq.data_ptr(), bdz2.data_ptr(), bdz1.data_ptr(), bparts.data_ptr(),
+        f2.data_ptr(), fq.data_ptr(), bdq.data_ptr(), bdz2.data_ptr(), bdz1.data_ptr(), bparts.data_ptr(), 0,
         ssa.engine.stream()))
     for a_, b_, what in ((f1, h1, "h1"), (f2, h2, "h2"), (fq, q, "q"), (bdq, dq, "dq"), (bdz2, dz2, "dz2"),
                          (bdz1, dz1, "dz1"), (bparts, parts, "partials")):
@@ -190,7 +190,7 @@ def test_fused_critic_fwd_bwd_matches_autograd(ssa, tile_rows, qd, B, H, N):
     ssa.engine.weight_grads(ar, xd, in_dim, 0, h1, h2, dq, dz2, dz1, B, grads=grads, sumsq=ss)
     logs = torch.zeros(4, device=DEV)
     ssa._lib.check(ssa._lib.lib.ssac_critic_logs(parts.data_ptr(), N, tiles, B, float(N), ss.data_ptr(),
-                                                 ss.numel(), 0, logs.data_ptr(), 0, ssa.engine.stream()))
+                                                 ss.numel(), 0, logs.data_ptr(), 0, 0, 0, ssa.engine.stream()))
     assert abs(float(logs[0]) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
     gsq = 0.0
     for j in range(N):
@@ -749,3 +749,41 @@ def test_feed_pulls_host_slot_and_publishes_logs(ssa):
         ssa._lib.check(lib.ssac_publish_logs(logs.data_ptr(), feed.ptr, ssa.engine.stream()))
         assert torch.equal(ring[7 - k % n_slots].cpu(), torch.full((width,), float(k + 1)))
         assert feed.read().tick == k + 1
+
+
+def test_lazy_td_inside_critic_launch_equals_td_kernel(ssa):
+    """ssac_td_spec: the critic launch evaluates the TD targets itself; same bits as ssac_td_target, and the
+    three log values critic_logs derives from them agree with the kernel's."""
+    rng = np.random.RandomState(5)
+    B, N, H, in_dim, n_sel = 200, 3, 64, 9, 2
+    mlps = [orc.make_mlp(rng, in_dim, H, 1) for _ in range(N)]
+    ar = _arena_from(ssa, mlps)
+    f32 = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(DEV)
+    x, qt, lp, rew = f32(B, in_dim), f32(n_sel, B), f32(B), f32(B)
+    done = (torch.rand(B, device=DEV) < 0.1).float()
+    la = torch.tensor([math.log(0.2)], device=DEV)
+    lib, st = ssa._lib.lib, ssa.engine.stream()
+    td_ref, logs_ref = torch.zeros(B, device=DEV), torch.zeros(4, device=DEV)
+    ssa._lib.check(lib.ssac_td_target(qt.data_ptr(), n_sel, B, 1, lp.data_ptr(), rew.data_ptr(), done.data_ptr(),
+                                      la.data_ptr(), 1, 0.99, 0, 0, td_ref.data_ptr(), logs_ref.data_ptr(), st))
+    outs = []
+    for lazy in (False, True):
+        h1 = torch.zeros(N, B, H, device=DEV); h2 = torch.zeros_like(h1); dz2 = torch.zeros_like(h1); dz1 = torch.zeros_like(h1)
+        q = torch.zeros(N, B, 1, device=DEV); dq = torch.zeros_like(q)
+        tiles = int(lib.ssac_fused_row_tiles(C.byref(ar.desc()), B, N))
+        parts = torch.zeros(N * tiles * 2, device=DEV)
+        td_out = torch.zeros(B, device=DEV)
+        spec = ssa._lib.TdSpec(qt.data_ptr(), lp.data_ptr(), rew.data_ptr(), done.data_ptr(), la.data_ptr(),
+                               td_out.data_ptr(), 0.99, n_sel, 1, 0)
+        ssa._lib.check(lib.ssac_critic_fwd_bwd_fused(
+            C.byref(ar.desc()), x.data_ptr(), in_dim, B, 0 if lazy else td_ref.data_ptr(), 0, 0, 1, 0, 0, float(N),
+            h1.data_ptr(), h2.data_ptr(), q.data_ptr(), dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(),
+            parts.data_ptr(), C.addressof(spec) if lazy else 0, st))
+        outs.append((dq, dz1, parts, td_out))
+    assert torch.equal(outs[1][3], td_ref), "in-launch TD targets differ from ssac_td_target"
+    for a_, b_ in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a_, b_)
+    logs = torch.zeros(8, device=DEV)
+    ssa._lib.check(lib.ssac_critic_logs(outs[1][2].data_ptr(), N, tiles, B, float(N), 0, 0, 0, logs.data_ptr(),
+                                        C.addressof(spec), logs[4:].data_ptr(), 0, st))
+    _close(logs[4:7], logs_ref[:3], 1e-5, rtol=1e-5, what="td log statistics")

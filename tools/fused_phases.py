@@ -44,7 +44,7 @@ dbg = torch.zeros(16, dtype=torch.int64, device=dev)
 ssa._lib.lib.ssac_fused_debug_stamps(dbg.data_ptr())
 def run():
     ssa._lib.check(ssa._lib.lib.ssac_critic_fwd_bwd_fused(C.byref(ar.desc()), x.data_ptr(), in_dim, B, td.data_ptr(), 0, 0, 1, 0, 0,
-        float(N), h1.data_ptr(), h2.data_ptr(), q.data_ptr(), dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), ssa.engine.stream()))
+        float(N), h1.data_ptr(), h2.data_ptr(), q.data_ptr(), dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), 0, ssa.engine.stream()))
 for _ in range(3): run()
 torch.cuda.synchronize()
 t = dbg.cpu().numpy()

@@ -18,5 +18,5 @@ tiles = int(lib.ssac_fused_row_tiles(C.byref(ar.desc()), B, N)); parts = torch.z
 for _ in range(6):
     ssa.engine.mlp_forward(ar, x, in_dim, 0, B, ws, "q", save=False)
     ssa._lib.check(lib.ssac_critic_fwd_bwd_fused(C.byref(ar.desc()), x.data_ptr(), in_dim, B, td.data_ptr(), 0, 0, 1, 0, 0,
-        float(N), h1.data_ptr(), h2.data_ptr(), q.data_ptr(), dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), ssa.engine.stream()))
+        float(N), h1.data_ptr(), h2.data_ptr(), q.data_ptr(), dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), 0, ssa.engine.stream()))
 torch.cuda.synchronize()

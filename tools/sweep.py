@@ -80,7 +80,7 @@ def main():
                     ssa._lib.check(lib.ssac_critic_fwd_bwd_fused(
                         C.byref(ar.desc()), x.data_ptr(), in_dim, B, td.data_ptr(), 0, 0, 1, 0, 0, float(N),
                         h1.data_ptr(), h2.data_ptr(), q.data_ptr(), dq.data_ptr(), dz2.data_ptr(),
-                        dz1.data_ptr(), parts.data_ptr(), ssa.engine.stream()))
+                        dz1.data_ptr(), parts.data_ptr(), 0, ssa.engine.stream()))
                 t = timed(run, reps)
                 fl = 2.0 * B * N * (in_dim * H + 2 * H * H + H)
                 by = by + 4 * N * B * H * 4 + B * 4

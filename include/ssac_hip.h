@@ -124,6 +124,14 @@ int ssac_gather_transition(const void *s, const void *s1, int s_dtype, int64_t s
                            const float *act, int64_t a_elems, const float *rew, const uint8_t *done,
                            const int64_t *idx, int n_rows, float *xsa, int64_t ld_x, float *x1sa,
                            int64_t ld_x1, float *rew_out, float *done_out, void *stream);
+/* The same gather as the FIRST launch of a captured update: row indices are the first n_rows int64 of the
+ * current slot of feed's pinned host ring (read over PCIe by the gather itself), and the launch also does
+ * the work of ssac_begin_update(logs, n_logs, ctl, feed): one launch fewer on the update's critical chain. */
+int ssac_gather_transition_begin(const void *s, const void *s1, int s_dtype, int64_t s_elems, const float *act,
+                                 int64_t a_elems, const float *rew, const uint8_t *done, int n_rows, float *xsa,
+                                 int64_t ld_x, float *x1sa, int64_t ld_x1, float *rew_out, float *done_out,
+                                 const ssac_feed *feed, float *logs, int n_logs, ssac_adam_ctl *ctl,
+                                 void *stream);
 
 /* ---- one layer of every selected net: Y[e] = act(X[e] W_l[id_e]^T + b_l[id_e])
  * (mlps.py:33-35,125-129; agent.py:34 runs this once per net in a Python loop).

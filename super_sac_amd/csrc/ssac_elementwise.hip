@@ -56,6 +56,30 @@ __device__ __forceinline__ float popart_sigma(float mu, float nu) {
     return fminf(fmaxf(sqrtf(nu - mu * mu) + 1e-5f, 1e-4f), 1e6f);
 }
 
+__device__ __forceinline__ void adam_refresh(ssac_adam_ctl *c, int t);
+
+// this update's host inputs: pinned ring slot -> fixed device block, one PCIe round trip.
+// 16 bytes per lane and every load issued before the first store (slot_words % 4 == 0 and 16-byte
+// aligned slots are the host's contract).
+__device__ __forceinline__ void feed_pull(const ssac_feed &f) {
+    const uint32_t *src = f.host_ring + (int64_t)(f.tick % f.n_slots) * f.slot_words;
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+    uint4 *d4 = reinterpret_cast<uint4 *>(f.dst);
+    const int n4 = f.slot_words >> 2;
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = threadIdx.x + u * blockDim.x;
+        v[u] = s4[i < n4 ? i : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = threadIdx.x + u * blockDim.x;
+        if (i < n4) d4[i] = v[u];
+    }
+    for (int i = 4 * blockDim.x + threadIdx.x; i < n4; i += blockDim.x) d4[i] = s4[i];
+}
+
 // ------------------------------------------------------------------ replay gather
 template <typename T>
 __global__ void gather_rows_kernel(const T *__restrict__ src, int64_t row_elems,
@@ -77,7 +101,20 @@ __global__ void gather_transition_kernel(const T *__restrict__ s, const T *__res
                                          const int64_t *__restrict__ idx, int n_rows,
                                          float *__restrict__ xsa, int64_t ld_x,
                                          float *__restrict__ x1sa, int64_t ld_x1,
-                                         float *__restrict__ rew_out, float *__restrict__ done_out) {
+                                         float *__restrict__ rew_out, float *__restrict__ done_out,
+                                         const ssac_feed *feed, float *logs, int n_logs, ssac_adam_ctl *ctl) {
+    if (feed) {
+        // first launch of a captured update: the row indices are read straight from this update's slot of the
+        // pinned host ring, and workgroup 0 also does what ssac_begin_update would (slot -> device block for
+        // the later launches, log block cleared, optimizer step advanced) -- one launch fewer on the chain
+        const ssac_feed f = *feed;
+        idx = reinterpret_cast<const int64_t *>(f.host_ring + (int64_t)(f.tick % f.n_slots) * f.slot_words);
+        if (blockIdx.x == 0) {
+            feed_pull(f);
+            if ((int)threadIdx.x < n_logs) logs[threadIdx.x] = 0.0f;
+            if (threadIdx.x == 0 && ctl) adam_refresh(ctl, ctl->step + 1);
+        }
+    }
     // one row of work = 2*s_elems + a_elems + 2 elements; consecutive threads walk one row
     const int64_t per_row = 2 * s_elems + a_elems + 2;
     const int64_t total = (int64_t)n_rows * per_row;
@@ -444,25 +481,7 @@ __global__ void begin_update_kernel(float *logs, int n, ssac_adam_ctl *ctl, cons
     if ((int)threadIdx.x < n) logs[threadIdx.x] = 0.0f;
     if (threadIdx.x == 0 && ctl) adam_refresh(ctl, ctl->step + 1);
     if (feed) {  // this update's host inputs: pinned ring slot -> fixed device block (one PCIe round trip)
-        const ssac_feed f = *feed;
-        const uint32_t *src = f.host_ring + (int64_t)(f.tick % f.n_slots) * f.slot_words;
-        // 16 bytes per lane and every load issued before the first store: ONE round trip for slots up to
-        // 4 * blockDim 16-byte words (slot_words % 4 == 0 and 16-byte aligned slots are the host's contract)
-        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
-        uint4 *d4 = reinterpret_cast<uint4 *>(f.dst);
-        const int n4 = f.slot_words >> 2;
-        uint4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = threadIdx.x + u * blockDim.x;
-            v[u] = s4[i < n4 ? i : 0];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = threadIdx.x + u * blockDim.x;
-            if (i < n4) d4[i] = v[u];
-        }
-        for (int i = 4 * blockDim.x + threadIdx.x; i < n4; i += blockDim.x) d4[i] = s4[i];
+        feed_pull(*feed);
     }
 }
 
@@ -663,24 +682,45 @@ extern "C" int ssac_gather_rows(const void *src, int src_dtype, int64_t row_elem
     return ssac_check_launch("gather_rows");
 }
 
+static int gather_transition_impl(const void *s, const void *s1, int s_dtype, int64_t s_elems, const float *act,
+                                  int64_t a_elems, const float *rew, const uint8_t *done, const int64_t *idx,
+                                  int n_rows, float *xsa, int64_t ld_x, float *x1sa, int64_t ld_x1,
+                                  float *rew_out, float *done_out, const ssac_feed *feed, float *logs,
+                                  int n_logs, ssac_adam_ctl *ctl, void *stream) {
+    if (n_rows <= 0) return 0;
+    if (n_logs > 256) return ssac_fail("ssac_gather_transition: log block too large");
+    const int64_t total = (int64_t)n_rows * (2 * s_elems + a_elems + 2);
+    if (s_dtype == 0)
+        SSAC_LAUNCH(gather_transition_kernel<float>, dim3(grid_for(total)), dim3(256), 0, ST,
+                    (const float *)s, (const float *)s1, s_elems, act, a_elems, rew, done, idx, n_rows, xsa, ld_x,
+                    x1sa, ld_x1, rew_out, done_out, feed, logs, n_logs, ctl);
+    else if (s_dtype == 1)
+        SSAC_LAUNCH(gather_transition_kernel<uint8_t>, dim3(grid_for(total)), dim3(256), 0, ST,
+                    (const uint8_t *)s, (const uint8_t *)s1, s_elems, act, a_elems, rew, done, idx, n_rows, xsa,
+                    ld_x, x1sa, ld_x1, rew_out, done_out, feed, logs, n_logs, ctl);
+    else
+        return ssac_fail("ssac_gather_transition: unsupported s_dtype");
+    return ssac_check_launch("gather_transition");
+}
+
 extern "C" int ssac_gather_transition(const void *s, const void *s1, int s_dtype, int64_t s_elems,
                                       const float *act, int64_t a_elems, const float *rew,
                                       const uint8_t *done, const int64_t *idx, int n_rows, float *xsa,
                                       int64_t ld_x, float *x1sa, int64_t ld_x1, float *rew_out,
                                       float *done_out, void *stream) {
-    if (n_rows <= 0) return 0;
-    const int64_t total = (int64_t)n_rows * (2 * s_elems + a_elems + 2);
-    if (s_dtype == 0)
-        SSAC_LAUNCH(gather_transition_kernel<float>, dim3(grid_for(total)), dim3(256), 0, ST,
-                           (const float *)s, (const float *)s1, s_elems, act, a_elems, rew, done, idx,
-                           n_rows, xsa, ld_x, x1sa, ld_x1, rew_out, done_out);
-    else if (s_dtype == 1)
-        SSAC_LAUNCH(gather_transition_kernel<uint8_t>, dim3(grid_for(total)), dim3(256), 0, ST,
-                           (const uint8_t *)s, (const uint8_t *)s1, s_elems, act, a_elems, rew, done,
-                           idx, n_rows, xsa, ld_x, x1sa, ld_x1, rew_out, done_out);
-    else
-        return ssac_fail("ssac_gather_transition: unsupported s_dtype");
-    return ssac_check_launch("gather_transition");
+    return gather_transition_impl(s, s1, s_dtype, s_elems, act, a_elems, rew, done, idx, n_rows, xsa, ld_x, x1sa,
+                                  ld_x1, rew_out, done_out, nullptr, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int ssac_gather_transition_begin(const void *s, const void *s1, int s_dtype, int64_t s_elems,
+                                            const float *act, int64_t a_elems, const float *rew,
+                                            const uint8_t *done, int n_rows, float *xsa, int64_t ld_x,
+                                            float *x1sa, int64_t ld_x1, float *rew_out, float *done_out,
+                                            const ssac_feed *feed, float *logs, int n_logs, ssac_adam_ctl *ctl,
+                                            void *stream) {
+    if (!feed) return ssac_fail("ssac_gather_transition_begin: needs a feed");
+    return gather_transition_impl(s, s1, s_dtype, s_elems, act, a_elems, rew, done, nullptr, n_rows, xsa, ld_x,
+                                  x1sa, ld_x1, rew_out, done_out, feed, logs, n_logs, ctl, stream);
 }
 
 extern "C" int ssac_tanh_normal_fwd(const float *out, int64_t ld_out, const float *eps, int n_rows,

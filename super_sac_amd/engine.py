@@ -33,6 +33,8 @@ class CaptureCtx:
         self.logblk = logblk
         self.feed = feed          # device address of the update's ssac_feed (0: inputs arrive by copy)
         self.published = False    # set once a captured launch has published the log block
+        self.defer_begin = False  # the replay gather will also do ssac_begin_update's work (vector buffers)
+        self.pending_begin = None # (log block, adam ctl ptr) waiting for that gather
 
 
 CAPTURE = None

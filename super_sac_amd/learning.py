@@ -56,6 +56,7 @@ class _LaunchList:
 
 FEED_SLOTS = 16  # pinned input ring of a captured update: how far the host may run ahead of the GPU
 # evaluate the TD target inside the critic launch instead of a launch of its own (continuous, no PopArt)
+FOLD_BEGIN = os.environ.get("SSAC_FOLD_BEGIN", "1") == "1"  # fold ssac_begin_update into the replay gather
 LAZY_TD = os.environ.get("SSAC_LAZY_TD", "1") == "1"
 SPLIT_FORWARD = os.environ.get("SSAC_SPLIT_FORWARD", "0") == "1"
 
@@ -183,9 +184,16 @@ def _critic_update_graphed(gs, kw):
     if gs.graph is None:
         ctx = engine.CaptureCtx(idx_cpu, gs.idx_dev, ids, gs.ids_dev,
                                 [gs.eps_dev] if gs.eps_dev is not None else [], gs.logblk, feed=gs.feed.ptr)
+        st_ = buffer._storage
+        keys_ = list(st_.s_stack.keys())
+        # vector observations in one array: the whole-transition gather is the update's first launch and takes
+        # over ssac_begin_update's work (ensemble_size 1: a single gather per update)
+        ctx.defer_begin = (FOLD_BEGIN and agent.ensemble_size == 1 and len(keys_) == 1
+                           and st_.s_stack[keys_[0]].dim() == 2)
 
         def body():
             logs_, dicts_ = _critic_update_eager(**kw)
+            assert not ctx.pending_begin, "deferred ssac_begin_update was never issued"
             if not ctx.published:
                 check(lib.ssac_publish_logs(gs.logblk.data_ptr(), gs.feed.ptr, engine.stream()))
             return logs_, dicts_

@@ -66,9 +66,13 @@ def draw_subset(num_critics, k):
 
 def log_block(device, adam=None):
     if engine.CAPTURE is not None:
-        blk = engine.CAPTURE.logblk
+        cap = engine.CAPTURE
+        blk = cap.logblk
+        if cap.defer_begin and cap.feed and cap.pending_begin is None:
+            cap.pending_begin = (blk, 0 if adam is None else adam.ctl.ptr)  # folded into the replay gather
+            return blk
         check(lib.ssac_begin_update(blk.data_ptr(), LOG_WIDTH, 0 if adam is None else adam.ctl.ptr,
-                                    engine.CAPTURE.feed, engine.stream()))
+                                    cap.feed, engine.stream()))
         return blk
     return ring_for(device).next(adam)
 
@@ -178,12 +182,22 @@ def sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, per=True):
         xsa = torch.empty(B, S + A, device=dev)
         x1sa = torch.empty(B, S + A, device=dev)
         src = st.s_stack[key]
-        check(lib.ssac_gather_transition(src.data_ptr(), st.s1_stack[key].data_ptr(),
-                                         1 if src.dtype == torch.uint8 else 0, S,
-                                         st.action_stack.data_ptr(), A, st.reward_stack.data_ptr(),
-                                         st.done_stack.data_ptr(), idx.data_ptr(), B, xsa.data_ptr(),
-                                         S + A, x1sa.data_ptr(), S + A, r.data_ptr(), d.data_ptr(),
-                                         engine.stream()))
+        cap = engine.CAPTURE
+        if cap is not None and cap.pending_begin is not None:
+            blk, ctl = cap.pending_begin
+            cap.pending_begin = ()  # consumed
+            check(lib.ssac_gather_transition_begin(
+                src.data_ptr(), st.s1_stack[key].data_ptr(), 1 if src.dtype == torch.uint8 else 0, S,
+                st.action_stack.data_ptr(), A, st.reward_stack.data_ptr(), st.done_stack.data_ptr(), B,
+                xsa.data_ptr(), S + A, x1sa.data_ptr(), S + A, r.data_ptr(), d.data_ptr(), cap.feed,
+                blk.data_ptr(), LOG_WIDTH, ctl, engine.stream()))
+        else:
+            check(lib.ssac_gather_transition(src.data_ptr(), st.s1_stack[key].data_ptr(),
+                                             1 if src.dtype == torch.uint8 else 0, S,
+                                             st.action_stack.data_ptr(), A, st.reward_stack.data_ptr(),
+                                             st.done_stack.data_ptr(), idx.data_ptr(), B, xsa.data_ptr(),
+                                             S + A, x1sa.data_ptr(), S + A, r.data_ptr(), d.data_ptr(),
+                                             engine.stream()))
         o, o1, a = {key: xsa[:, :S]}, {key: x1sa[:, :S]}, xsa[:, S:]
         bt.S, bt.xsa, bt.x1sa, bt.key, bt.pixel = S, xsa, x1sa, key, False
         assert augmenter.is_identity(), "image augmentations need image observations"

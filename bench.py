@@ -38,7 +38,10 @@ OBS, ACT, BATCH, NCRIT, NSUB, HID = 17, 6, 512, 10, 2, 256
 ROWS, CAP = 100_000, 1_000_000
 GAMMA, LR, TAU, TARGET_DELAY = 0.99, 3e-4, 0.005, 2
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-TRAFFIC_FWD_BYTES = None  # filled from the PMC passes (profiles/): HBM bytes of one ensemble-Q forward launch
+# HBM bytes per launch from the PMC passes in profiles/r1_pmc_counters.md (FETCH_SIZE doubled per the guide's gfx950
+# note for 16-byte streaming reads + WRITE_SIZE, KiB -> bytes); not collected live, N=10 single-GPU shape only
+TRAFFIC_FUSED_CRITIC_BYTES = (2 * 13165 + 20527) * 1024
+TRAFFIC_FWD_BYTES = None  # the two-launch form (SSAC_SPLIT_FORWARD=1) has no PMC pass yet
 
 
 def synth_data():
@@ -185,7 +188,7 @@ def main():
     # LDS) of all local critics on the sampled batch, one launch per update.  Algorithmic FLOPs per launch
     # (SURVEY 8(d)): 2*B*N*(in*H + H*H + H*out).  Its backward half (loss gradient, head backward, fc2
     # backward-data: 2*B*N*(out*H + H*H) FLOPs) is a second launch of the same kernel template and is reported
-    # beside it.  The timed region replays the update as ONE HIP graph, inside which a single kernel cannot be
+    # beside it.  The timed region re-issues the update from ONE recorded launch list, inside which a single kernel is not
     # bracketed by events; so the same update is run again right here with plain launches and the launches are
     # bracketed by HIP events recorded on the stream each one is launched on (same shapes, buffers, binary).
     graphs_were_on = ssa.learning.USE_GRAPHS
@@ -218,11 +221,10 @@ def main():
                 "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                 "avg_launch_us": round(avg_ms * 1e3, 3), "launches_timed": len(ms),
                 "timing": "HIP events around the launch on its own stream, eager pass right after the timed "
-                          "(graph-replay) region",
+                          "(replayed) region",
                 "flops_per_launch": flops,
-                # HBM bytes per launch from the PMC passes in profiles/ (FETCH_SIZE doubled per the gfx950 note
-                # + WRITE_SIZE, KiB -> bytes); not collected live, N=10 single-GPU shape only
-                "traffic": TRAFFIC_FWD_BYTES if (world == 1 and n_local == NCRIT and "critic_fwd" in by_tag) else None}
+                "traffic": (None if not (world == 1 and n_local == NCRIT) else
+                            (TRAFFIC_FWD_BYTES if "critic_fwd" in by_tag else TRAFFIC_FUSED_CRITIC_BYTES))}
     if "critic_bwd" in by_tag:
         mb = by_tag["critic_bwd"]
         avg_b = sum(mb) / len(mb)
@@ -239,7 +241,9 @@ def main():
                "config": {"workload": "REDQ critic_update + Polyak/2: obs 17, act 6, batch 512, "
                                       "N=10 critics (n=2 target subset), hidden 256, replay 100k rows in HBM",
                           "global_batch": BATCH, "num_critics": NCRIT,
-                          "launch": "HIP graph replay" if (world == 1 and graphs_were_on) else "plain launches",
+                          "launch": (("recorded launch list (ssac_replay)" if ssa.learning.LAUNCH_MODE == "list"
+                                      else "HIP graph replay") if (world == 1 and graphs_were_on)
+                                     else "plain launches"),
                           "parallelism": "single GPU" if world == 1 else f"critic-ensemble sharded x{world}"},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:

@@ -234,6 +234,21 @@ int ssac_critic_loss_bwd(const float *q, int n_nets, int n_rows, int q_dim, cons
                          int64_t ld_act, const float *td, const float *weight, const ssac_popart *popart,
                          int pop, float denom, float *dq, float *logs, void *stream);
 
+/* ---- advantage-filtered behavioural cloning (learning.py:144-219)
+ * ssac_adv_filter: A(s,a) = Q(s,a) - V(s) of adv_estimator.py:58-79 from the critics' outputs q on the stacked
+ * batch [data | sample 1 .. sample n] ((n_nets) x (1+n_samples)*n_rows): Q = min over the nets (then w*q+b
+ * when popart != NULL), V = mean (use_max: max) over the sampled actions.  Optional outputs: adv, the binary
+ * filter mask (A >= 0), PER priorities relu(A)+1e-4 (learning_utils.py:287-295), logs[0] = mean(mask). */
+int ssac_adv_filter(const float *q, int n_nets, int n_rows, int n_samples, const ssac_popart *popart, int use_max,
+                    float *adv, float *mask, float *prio, float *logs, void *stream);
+/* filtered BC loss of one member and its gradient w.r.t. the actor output (learning_utils.py:241-269):
+ * loss_i = -mean(log pi(a_data|s) * mask) with the data action's pre-tanh value atanh(clamp(a, +-0.99))
+ * (distributions.py:74-84); d_out = dL/d(out) for L = sum_i loss_i * inv_members; logs_member[0] = loss_i,
+ * logs_total[0] += loss_i * inv_members.  mask == NULL: plain behavioural cloning (filter_=False). */
+int ssac_bc_logprob_bwd(const float *out, int64_t ld_out, const float *act, int64_t ld_act, const float *mask,
+                        int n_rows, int act_dim, float log_std_lo, float log_std_hi, float inv_members,
+                        float *d_out, int64_t ld_dout, float *logs_member, float *logs_total, void *stream);
+
 /* ---- actor loss gradient, continuous: learning.py:392-408.
  * q (n_nets x n_rows): min over ALL nets (learning.py:402), arg-min routing.
  * dq[j][b] = -(popart_w) / (n_rows*E) for j = argmin_b else 0;  logs[0] += -mean(minq' - bonus)/E,

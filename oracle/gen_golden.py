@@ -595,6 +595,90 @@ def gen_per():
     np.savez_compressed(os.path.join(OUT, "per.npz"), **rec)
 
 
+def run_afbc_case(name, cfg):
+    """learning.offline_actor_update (+ adv_estimator, PER sample / adjust_priorities) on the unmodified
+    reference; the oracle follows on the recorded draws and every output is asserted against it."""
+    print(f"== {name}")
+    torch.manual_seed(cfg["seed"]); np.random.seed(cfg["seed"]); random.seed(cfg["seed"])
+    B, E, A = cfg["B"], cfg["E"], cfg["act"]
+    s, a, r, s1, d = synth.synth_transitions(cfg["rows"], cfg["obs"], cfg["act"], False, seed=cfg["seed"] + 100)
+    rbuf = ref.replay.ReplayBuffer(cfg["cap"])
+    rbuf.load_experience(s, a, r, s1, d)
+    obuf = orc.ReplayOracle(cfg["cap"])
+    obuf.load_experience(s, a, r, s1, d)
+    tree = orc.PerOracle(cfg["cap"], 0.6, 1.0)
+    tree.push_rows(np.arange(cfg["rows"]))
+    ra, oa = build_pair(cfg)
+    oa.requires_grad_(True)
+    r_aopt = torch.optim.Adam(chain(*(ac.parameters() for ac in ra.actors)), lr=cfg["lr"], betas=(0.9, 0.999))
+    r_eopt = torch.optim.Adam(ra.encoder.parameters(), lr=1e-4)
+    o_aopt = orc.AdamOracle(oa.actor_params(), lr=cfg["lr"])
+    r_aug = ref.augmentations.AugmentationSequence([ref.augmentations.IdentityAug(B)])
+    o_aug = orc.AugOracle("identity", B)
+
+    advs = []
+    orig_fwd = type(ra.adv_estimator).forward
+
+    def adv_spy(self, *args, **kw):
+        out = orig_fwd(self, *args, **kw)
+        advs.append(out.detach().clone())
+        return out
+    type(ra.adv_estimator).forward = adv_spy
+
+    rec = {"n_steps": np.int64(len(cfg["steps"]))}
+    for k, (per, filt) in enumerate(cfg["steps"]):
+        # replicate the host draws the reference is about to make, then rewind
+        st, nst, pst = torch.get_rng_state(), np.random.get_state(), random.getstate()
+        if per:
+            idx, w = tree.sample(len(obuf), B)
+        else:
+            idx, w = torch.randint(len(rbuf), (B,)).numpy(), None
+        eps = [torch.randn(B, A) for _ in range(4)] if filt else None
+        random.choice(list(range(E)))              # random.choice(agent.actors) for the grad-norm log
+        pm = random.choice(range(E)) if per else None
+        peps = [torch.randn(B, A) for _ in range(4)] if per else None
+        torch.set_rng_state(st); np.random.set_state(nst); random.setstate(pst)
+
+        advs.clear()
+        rlogs = rl.offline_actor_update(
+            buffer=rbuf, agent=ra, actor_optimizer=r_aopt, encoder_optimizer=r_eopt, batch_size=B,
+            actor_clip=cfg["clip"], update_encoder=False, encoder_clip=cfg["clip"], augmenter=r_aug,
+            actor_lambda=0.0, aug_mix=0.0, premade_replay_dicts=None, per=per, discrete=False, filter_=filt)
+        ologs, ord_, oprio, _ = orc.offline_actor_update(
+            obuf, tree if per else None, oa, o_aopt, B, cfg["clip"], o_aug, 0.0, per=per, filter_=filt,
+            idx_list=[idx], eps_lists=[eps] if filt else None, prio_member=pm, prio_eps=peps)
+        rec[f"s{k}_per"], rec[f"s{k}_filter"] = np.int64(per), np.int64(filt)
+        rec[f"s{k}_idx"] = np.asarray(idx, np.int64)
+        if per:
+            rec[f"s{k}_weights"] = np.asarray(w, np.float64)
+            rec[f"s{k}_prio_eps"] = torch.stack(peps).numpy()
+            rec[f"s{k}_prio"] = np.asarray(oprio, np.float64)
+            # the reference's trees after its own adjust_priorities
+            leaves = np.array([rbuf._it_sum[int(j)] for j in idx], np.float64)
+            rprio = (torch.relu(advs[-1]) + 1e-4).squeeze(1).numpy()
+            print("   prio adv diff", float(np.abs(rprio - oprio).max()), "filter adv n", len(advs))
+            assert np.allclose(leaves, tree.sum[tree.cap + idx], rtol=1e-4, atol=1e-6), "priority update mismatch"
+            rec[f"s{k}_leaves"] = leaves
+        if filt:
+            rec[f"s{k}_eps"] = torch.stack(eps).numpy()
+            rec[f"s{k}_adv"] = advs[0].numpy()
+        for key, val in rlogs.items():
+            if key.startswith("gradients/"):
+                continue
+            v = float(val)
+            rec[f"s{k}_log:{key}"] = np.float64(v)
+            assert abs(v - float(ologs[key])) <= 2e-4 * max(1.0, abs(v)), (key, v, ologs[key])
+    type(ra.adv_estimator).forward = orig_fwd
+    _, rac = ref_params(ra, cfg)
+    dpar = maxdiff(rac, oa.actor_params())
+    print(f"   actor params max|diff| {dpar:.3e}; max priority {rbuf._max_priority:.4f} / {tree.max_priority:.4f}")
+    assert dpar < 5e-5 and abs(rbuf._max_priority - tree.max_priority) < 1e-6
+    rec["final_actor"] = np.concatenate([p.detach().numpy().ravel() for p in rac])
+    rec["final_max_priority"] = np.float64(rbuf._max_priority)
+    rec["final_tree_total"] = np.float64(rbuf._it_sum.sum())
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     units = {"indices": gen_indices, "popart": gen_popart, "aug": gen_aug, "nets": gen_nets,
@@ -605,4 +689,7 @@ if __name__ == "__main__":
     for name, cfg in synth.CASES.items():
         if not only or name in only:
             run_case(name, cfg)
+    for name, cfg in synth.AFBC_CASES.items():
+        if not only or name in only:
+            run_afbc_case(name, cfg)
     print("golden fixtures written to", OUT)

@@ -919,3 +919,112 @@ def soft_update(target_params, source_params, tau):
 def hard_update(target_params, source_params):
     for t, s in zip(target_params, source_params):
         t.copy_(s)
+
+
+# --------------------------------------------------------------------------------------
+# advantage-filtered behavioural cloning (AFBC / AWAC actor update) with PER.
+# adv_estimator.py:58-79 (continuous, "mean"/"max"), :41-56 (discrete indirect);
+# learning_utils.py:241-269 (filtered_bc_loss), :287-295 (adjust_priorities); learning.py:144-219.
+# --------------------------------------------------------------------------------------
+def tanh_normal_log_prob_data(out, lo, hi, a):
+    """log pi(a) of a DATA action: the TanhTransform cache misses, so the pre-tanh value is recovered as
+    atanh(clamp(a, -0.99, 0.99)) (distributions.py:74-84) and the jacobian term uses that value."""
+    mu, log_std = tanh_normal_params(out, lo, hi)
+    std = log_std.exp()
+    y = a.clamp(-0.99, 0.99)
+    x = 0.5 * (torch.log1p(y) - torch.log1p(-y))
+    base = -((x - mu) ** 2) / (2.0 * std * std) - log_std - LOG_2PI_HALF
+    ladj = 2.0 * (LOG2 - x - F.softplus(-2.0 * x))
+    return (base - ladj).sum(-1, keepdim=True)
+
+
+def _pop_q(agent, i, s, a):
+    """AdvantageEstimator.pop (adv_estimator.py:31-36): min over ALL critics of member i, then popart(q)
+    (normalized=True default -> w*q + b) when the member has a PopArt layer."""
+    q = ensemble_q(agent.critics[i], s, a)
+    return agent.popart[i](q) if agent.popart[i] else q
+
+
+def advantage(agent, o, a, i, eps_list=None, method="mean", n=4):
+    """A(s,a) = Q(s,a) - V(s).  Continuous: V from n sampled policy actions (eps_list: the n (B,A) normal
+    draws, in order).  Discrete: V = sum_a mean_members(pi)(a) * Q(s)_a, Q(s,a) by gather."""
+    with torch.no_grad():
+        s = encode(agent.encoder, o)
+        if agent.discrete:
+            probs = torch.stack([torch.softmax(mlp3(ac, s)[0], dim=-1) for ac in agent.actors], 0).mean(0)
+            q_all = _pop_q(agent, i, s, None)
+            value = (probs * q_all).sum(-1, keepdim=True)
+            return q_all.gather(-1, a.long()) - value
+        out = mlp3(agent.actors[i], s)[0]
+        qs = []
+        for k in range(n):
+            e = eps_list[k] if eps_list is not None else torch.randn(out.shape[0], agent.act_dim)
+            act = tanh_normal_sample(out, agent.lo, agent.hi, e)[0]
+            qs.append(_pop_q(agent, i, s, act))
+        qs = torch.stack(qs, 0)
+        value = qs.mean(0) if method == "mean" else qs.max(0).values
+        return _pop_q(agent, i, s, a) - value
+
+
+def offline_actor_update(buffer, per_tree, agent, actor_opt, batch_size, actor_clip, augmenter, aug_mix,
+                         per=True, filter_=True, dicts=None, idx_list=None, eps_lists=None,
+                         prio_member=None, prio_eps=None, method="mean"):
+    """learning.py:144-219 for identity encoders (update_encoder has nothing to update), actor_lambda 0.
+    per_tree: PerOracle over the buffer's rows (None when per is False).
+    eps_lists[i]: the 4 normal draws of member i's advantage estimate; prio_member / prio_eps: the
+    ``random.choice(range(E))`` result and the 4 draws of adjust_priorities (drawn here when None)."""
+    logs = {}
+    total = 0.0
+    rd = None
+    weights = []
+    for i in range(agent.E):
+        if dicts is not None:
+            rd = dicts[i]
+        else:
+            if per:
+                if idx_list is not None:
+                    idx = idx_list[i]
+                    w = None
+                else:
+                    buffer.total_sample_calls += 1
+                    idx, w = per_tree.sample(len(buffer), batch_size)
+                rd = sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, idx=idx)
+                rd["imp_weights"] = None if w is None else torch.from_numpy(w)
+                weights.append(w)
+            else:
+                rd = sample_move_and_augment(buffer, batch_size, augmenter, aug_mix,
+                                             idx=None if idx_list is None else idx_list[i])
+        o, a = rd["primary_batch"][0], rd["primary_batch"][1]
+        mask = None
+        if filter_:
+            adv = advantage(agent, o, a, i, None if eps_lists is None else eps_lists[i], method)
+            mask = (adv >= 0.0).float()
+        with torch.no_grad():
+            s = encode(agent.encoder, o)
+        out = mlp3(agent.actors[i], s)[0]
+        if agent.discrete:
+            logp = torch.log_softmax(out, dim=-1).gather(-1, a.long())
+        else:
+            logp = tanh_normal_log_prob_data(out, agent.lo, agent.hi, a)
+        if filter_:
+            logs["losses/adv_weights_mean"] = mask.mean().item()
+            logp = logp * mask
+        loss_i = -logp.mean()
+        logs[f"losses/filterd_bc_loss_{i}"] = loss_i.item()
+        total = total + loss_i
+    loss = total / agent.E
+    actor_opt.zero_grad()
+    loss.backward()
+    if actor_clip:
+        clip_grad_norm(agent.actor_params(), actor_clip)
+    actor_opt.step()
+    logs["losses/filtered_bc_overall_loss"] = loss.item()
+    new_prio = None
+    if per:
+        import random as _random
+        o, a = rd["primary_batch"][0], rd["primary_batch"][1]
+        m = prio_member if prio_member is not None else _random.choice(range(agent.E))
+        adv = advantage(agent, o, a, m, prio_eps, method)
+        new_prio = (F.relu(adv) + 1e-4).squeeze(1).numpy()
+        per_tree.update(rd["priority_idxs"], new_prio)
+    return logs, rd, new_prio, weights

@@ -28,6 +28,7 @@ from . import agent  # noqa: E402,F401
 from .agent import Agent  # noqa: E402,F401
 from . import learning_utils  # noqa: E402,F401
 from . import learning  # noqa: E402,F401
+from . import adv_estimator  # noqa: E402,F401
 from . import parallel  # noqa: E402,F401
 
 
@@ -40,9 +41,9 @@ def install(reference_package):
     ``super_sac.main.super_sac`` resolves ``learning.*`` / ``lu.*`` through the module objects at call
     time (main.py:18-19), so patching the module attributes is sufficient."""
     ref_learning, ref_lu = reference_package.learning, reference_package.learning_utils
-    for name in ("critic_update", "online_actor_update", "alpha_update"):
+    for name in ("critic_update", "online_actor_update", "alpha_update", "offline_actor_update"):
         setattr(ref_learning, name, getattr(learning, name))
     for name in ("soft_update", "hard_update", "sample_move_and_augment", "compute_td_targets",
-                 "compute_backup_weights"):
+                 "compute_backup_weights", "adjust_priorities", "compute_filter_stats"):
         setattr(ref_lu, name, getattr(learning_utils, name))
     return reference_package

@@ -70,6 +70,14 @@ class Agent:
         self.discrete = discrete
         self.ucb_bonus = ucb_bonus
         self.act_space_size = act_space_size
+        # agent.py:102-122
+        from .adv_estimator import AdvantageEstimator
+        if discrete:
+            self.adv_estimator = AdvantageEstimator(self, discrete=True,
+                                                    discrete_method=adv_method if adv_method else "indirect")
+        else:
+            self.adv_estimator = AdvantageEstimator(self, discrete=False,
+                                                    continuous_method=adv_method if adv_method else "mean")
 
     @property
     def ensemble(self):

@@ -354,6 +354,77 @@ __global__ __launch_bounds__(RED_THREADS) void critic_loss_bwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------ advantage filter + filtered BC (AFBC)
+// adv_estimator.py:58-79 (continuous): A(s,a) = Q(s,a) - V(s), Q = min over ALL critics (then popart(q), the
+// normalised-space affine map, when the member has a PopArt layer), V = mean (or max) of Q over n_samp
+// sampled policy actions.  q holds the critics' outputs on the stacked batch [data | sample 1 | ... | sample n]:
+// (n_nets x (1+n_samp)*n_rows).  Also the binary filter (learning_utils.py:254-256), its mean
+// ("losses/adv_weights_mean") and the PER priorities relu(A) + 1e-4 (learning_utils.py:293).
+__global__ __launch_bounds__(RED_THREADS) void adv_filter_kernel(
+    const float *__restrict__ q, int n_nets, int n_rows, int n_samp, const ssac_popart *popart, int use_max,
+    float *__restrict__ adv, float *__restrict__ mask, float *__restrict__ prio, float *__restrict__ logs) {
+    __shared__ float scratch[16];
+    const float pw = popart ? popart->w : 1.0f, pb = popart ? popart->b : 0.0f;
+    const int64_t ldq = (int64_t)(1 + n_samp) * n_rows;
+    float s_mask = 0.f;
+    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+        float qd = 0.f, acc = 0.f;
+        for (int k = 0; k <= n_samp; ++k) {
+            float mq = q[(int64_t)k * n_rows + b];
+            for (int j = 1; j < n_nets; ++j) mq = fminf(mq, q[j * ldq + (int64_t)k * n_rows + b]);
+            if (popart) mq = pw * mq + pb;
+            if (k == 0) qd = mq;
+            else if (k == 1) acc = mq;
+            else acc = use_max ? fmaxf(acc, mq) : acc + mq;
+        }
+        const float value = use_max ? acc : acc / (float)n_samp;
+        const float a = qd - value;
+        const float m = a >= 0.0f ? 1.0f : 0.0f;
+        if (adv) adv[b] = a;
+        if (mask) mask[b] = m;
+        if (prio) prio[b] = fmaxf(a, 0.0f) + 1e-4f;
+        s_mask += m;
+    }
+    const float tot = block_reduce<0>(s_mask, scratch);
+    if (threadIdx.x == 0 && logs) logs[0] = tot / (float)n_rows;
+}
+
+// learning_utils.py:241-269 (continuous): loss_i = -mean(log pi(a_data | s) * mask); the data action misses
+// the TanhTransform cache, so its pre-tanh value is atanh(clamp(a, +-0.99)) (distributions.py:74-84).
+// Writes dL/d(actor output) for L = sum_i loss_i / E, logs_member[0] = loss_i, logs_total[0] += loss_i / E.
+__global__ __launch_bounds__(RED_THREADS) void bc_logprob_bwd_kernel(
+    const float *__restrict__ out, int64_t ld_out, const float *__restrict__ act, int64_t ld_act,
+    const float *__restrict__ mask, int n_rows, int A, float lo, float hi, float inv_members,
+    float *__restrict__ d_out, int64_t ld_dout, float *__restrict__ logs_member, float *__restrict__ logs_total) {
+    __shared__ float scratch[16];
+    float s = 0.f;
+    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+        const float w = mask ? mask[b] : 1.0f;
+        const float coef = -w * inv_members / (float)n_rows;
+        float lp = 0.f;
+        for (int i = 0; i < A; ++i) {
+            const float mu = out[b * ld_out + i], raw = out[b * ld_out + A + i];
+            const float t = tanhf(raw);
+            const float log_std = lo + 0.5f * (hi - lo) * (t + 1.0f);
+            const float sd = expf(log_std);
+            const float y = fminf(fmaxf(act[b * ld_act + i], -0.99f), 0.99f);
+            const float x = 0.5f * (log1pf(y) - log1pf(-y));
+            const float dlt = x - mu;
+            const float r2 = (dlt * dlt) / (sd * sd);
+            lp += (-(dlt * dlt) / (2.0f * sd * sd) - log_std - LOG_SQRT_2PI) - 2.0f * (LOG_2 - x - softplus_f(-2.0f * x));
+            d_out[b * ld_dout + i] = coef * (dlt / (sd * sd));
+            d_out[b * ld_dout + A + i] = coef * (r2 - 1.0f) * 0.5f * (hi - lo) * (1.0f - t * t);
+        }
+        s += lp * w;
+    }
+    const float tot = block_reduce<0>(s, scratch);
+    if (threadIdx.x == 0) {
+        const float loss = -tot / (float)n_rows;
+        if (logs_member) logs_member[0] = loss;
+        if (logs_total) logs_total[0] += loss * inv_members;
+    }
+}
+
 // ------------------------------------------------------------------ actor loss gradients
 __global__ __launch_bounds__(RED_THREADS) void actor_loss_bwd_kernel(
     const float *__restrict__ q, int n_nets, int n_rows, const float *__restrict__ logp,
@@ -763,6 +834,24 @@ extern "C" int ssac_critic_loss_bwd(const float *q, int n_nets, int n_rows, int 
     SSAC_LAUNCH(critic_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_nets, n_rows,
                        q_dim, act, ld_act, td, weight, popart, pop, denom, dq, logs);
     return ssac_check_launch("critic_loss_bwd");
+}
+
+extern "C" int ssac_adv_filter(const float *q, int n_nets, int n_rows, int n_samples, const ssac_popart *popart,
+                               int use_max, float *adv, float *mask, float *prio, float *logs, void *stream) {
+    if (n_nets < 1 || n_rows < 1 || n_samples < 1) return ssac_fail("ssac_adv_filter: bad sizes");
+    SSAC_LAUNCH(adv_filter_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_nets, n_rows, n_samples, popart,
+                use_max, adv, mask, prio, logs);
+    return ssac_check_launch("adv_filter");
+}
+
+extern "C" int ssac_bc_logprob_bwd(const float *out, int64_t ld_out, const float *act, int64_t ld_act,
+                                   const float *mask, int n_rows, int act_dim, float log_std_lo,
+                                   float log_std_hi, float inv_members, float *d_out, int64_t ld_dout,
+                                   float *logs_member, float *logs_total, void *stream) {
+    if (n_rows < 1 || act_dim < 1) return ssac_fail("ssac_bc_logprob_bwd: bad sizes");
+    SSAC_LAUNCH(bc_logprob_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, out, ld_out, act, ld_act, mask, n_rows,
+                act_dim, log_std_lo, log_std_hi, inv_members, d_out, ld_dout, logs_member, logs_total);
+    return ssac_check_launch("bc_logprob_bwd");
 }
 
 extern "C" int ssac_actor_loss_bwd(const float *q, int n_nets, int n_rows, const float *logp,

@@ -510,6 +510,78 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
     return logs
 
 
+def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batch_size, actor_clip,
+                         update_encoder, encoder_clip, augmenter, actor_lambda, aug_mix,
+                         premade_replay_dicts=None, per=True, discrete=False, filter_=True):
+    """learning.py:144-219: advantage-filtered behavioural cloning (AWAC / AFBC actor update), optionally on a
+    prioritised batch whose priorities are refreshed from the advantage afterwards."""
+    engine.require_gpu()
+    if actor_lambda:
+        raise NotImplementedError("action invariance constraint (SURVEY 8(f) rank 4) is not accelerated")
+    if discrete:
+        raise NotImplementedError("discrete filtered BC (adv_estimator.py:41-56) is not accelerated")
+    if update_encoder and not lu.is_identity(agent.encoder):
+        raise NotImplementedError("encoder training through the BC loss is not accelerated")
+    E = agent.ensemble_size
+    dev = next(agent.actors[0].parameters()).device
+    ws = lu.agent_ws(agent, dev)
+    adam = engine.adam_group(actor_optimizer, dev)
+    slot = lu.log_block(dev, adam)
+    logs = {}
+    st = engine.stream()
+    inv_e = 1.0 / E
+    clip_members, member_ss = [], []
+    rd = None
+    for i in range(E):
+        if premade_replay_dicts is not None:
+            rd = premade_replay_dicts[i]
+        else:
+            rd = lu.sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter,
+                                            aug_mix=aug_mix, per=per)
+        o, a = rd["primary_batch"][0], rd["primary_batch"][1]
+        actor = agent.actors[i]
+        mask_ptr = 0
+        if filter_:
+            res = agent.adv_estimator.evaluate(o, a, i, want=("mask",), log_ptr=slot[lu.L_ADVW:].data_ptr())
+            mask_ptr = res["mask"].data_ptr()
+            logs["losses/adv_weights_mean"] = slot[lu.L_ADVW]
+        s_rep = lu.encode(agent.encoder, o)
+        B, S = s_rep.shape
+        lds = lu._row_stride(s_rep)
+        a_arena = engine.bind_arena(actor, "self", [actor], dev)
+        ah1, ah2, aout = engine.mlp_forward(a_arena, s_rep, lds, 0, B, ws, f"bc.a{i}")
+        A = actor.action_size
+        d_out = ws.get(f"bc.dout{i}", (1, B, 2 * A))
+        check(lib.ssac_bc_logprob_bwd(aout.data_ptr(), 2 * A, a.data_ptr(), a.stride(0), mask_ptr, B, A,
+                                      float(actor.log_std_low), float(actor.log_std_high), inv_e,
+                                      d_out.data_ptr(), 2 * A, slot[lu.L_BC0 + i:].data_ptr(),
+                                      slot[lu.L_BC_TOTAL:].data_ptr(), st))
+        logs[f"losses/filterd_bc_loss_{i}"] = slot[lu.L_BC0 + i]
+        ttot = engine.wgrad_tiles_total(a_arena)
+        ss = ws.get(f"bc.ss{i}", (ttot,))
+        if actor_clip:
+            grads = ws.get(f"bc.g{i}", (a_arena.params.numel(),), zero=True)
+            engine.mlp_backward(a_arena, d_out, s_rep, lds, 0, ah1, ah2, B, ws, f"bc.a{i}", grads=grads,
+                                sumsq=ss)
+            clip_members.append((a_arena, ("actor", i), grads, ss))
+        else:
+            engine.mlp_backward(a_arena, d_out, s_rep, lds, 0, ah1, ah2, B, ws, f"bc.a{i}", adam=adam,
+                                adam_key=("actor", i), sumsq=ss)
+        member_ss.append(ss)
+    if actor_clip:
+        _clip_and_step(adam, clip_members, actor_clip, None)
+    logs["losses/filtered_bc_overall_loss"] = slot[lu.L_BC_TOTAL]
+    pick = rng.choice(agent.actors)  # learning.py:210-212
+    k = next(j for j, a_ in enumerate(agent.actors) if a_ is pick)
+    check(lib.ssac_group_norms(member_ss[k].data_ptr(), 1, member_ss[k].numel(),
+                               adam.ctl.ptr if actor_clip else 0, slot[lu.L_BC_GN:].data_ptr(), st))
+    logs["gradients/actor_offline_grad_norm"] = slot[lu.L_BC_GN]
+    logs["gradients/encoder_offline_actorloss_grad_norm"] = slot[lu.L_ENC_GN]  # identity encoders: no gradient
+    if per:
+        lu.adjust_priorities(logs, rd, agent, buffer)
+    return logs
+
+
 def alpha_update(buffer, agent, optimizers, batch_size, log_alphas, augmenter, aug_mix, target_entropy,
                  premade_replay_dicts, discrete):
     engine.require_gpu()

@@ -24,6 +24,8 @@ L_TD0 = 4            # + 3*i : mean, std, entropy bonus of member i
 L_BW = 28            # bellman weights mean, max, min, std
 L_ACTOR_LOSS, L_ACTOR_GN = 32, 33
 L_ALPHA0 = 34        # + 2*i : alpha_loss_i, alpha_i
+L_ADVW, L_BC_TOTAL, L_BC_GN = 50, 51, 52   # AFBC: adv_weights_mean, overall loss, actor grad norm
+L_BC0 = 53           # + i : filtered BC loss of member i
 
 
 class LogRing:
@@ -159,13 +161,15 @@ class _Batch:
 
 def sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, per=True):
     assert len(buffer) >= batch_size
-    if per:
-        raise NotImplementedError("prioritised sampling is not on the accelerated path yet "
-                                  "(the 5 target configs sample uniformly, main.py:401)")
-    idx_cpu, idx = buffer.draw_uniform_indices(batch_size)
     st = buffer._storage
     dev = st.device
-    imp_weights = unit_weight(dev)
+    if per:
+        # replay.py:163-177: numpy-global-RNG mass draw + float64 sum/min trees on the host, gather on the device
+        idx_cpu, idx, w = buffer.draw_per_indices(batch_size)
+        imp_weights = torch.from_numpy(w).to(dev)  # float64 (B,), as the reference hands it over
+    else:
+        idx_cpu, idx = buffer.draw_uniform_indices(batch_size)
+        imp_weights = unit_weight(dev)
     B = batch_size
     keys = list(st.s_stack.keys())
     A = int(np.prod(st.action_stack.shape[1:]))
@@ -459,3 +463,25 @@ def _zeros(dev, n):
     if z is None:
         z = _zero_cache[(dev, n)] = torch.zeros(n, device=dev)
     return z
+
+
+# ------------------------------------------------------------------------------------------
+# AFBC helpers (learning_utils.py:217-240, 287-295)
+# ------------------------------------------------------------------------------------------
+def adjust_priorities(logs, replay_dict, agent, buffer):
+    """new PER priorities relu(A(s,a)) + 1e-4 from a random ensemble member (fresh policy samples)."""
+    o, a = replay_dict["primary_batch"][0], replay_dict["primary_batch"][1]
+    member = rng.choice(range(agent.ensemble_size))
+    res = agent.adv_estimator.evaluate(o, a, member, want=("prio",))
+    new_priorities = res["prio"].cpu().numpy()  # the reference blocks here too (.cpu(), learning_utils.py:293)
+    buffer.update_priorities(replay_dict["priority_idxs"], new_priorities)
+
+
+def compute_filter_stats(buffer, agent, augmenter, batch_size):
+    """percentage of a uniform batch the binary advantage filter accepts (learning_utils.py:217-238)."""
+    rd = sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter, aug_mix=0.0,
+                                 per=False)
+    o, a = rd["primary_batch"][0], rd["primary_batch"][1]
+    member = rng.choice(range(agent.ensemble_size))
+    res = agent.adv_estimator.evaluate(o, a, member, want=("mask",))
+    return float(res["mask"].sum() / res["mask"].numel() * 100.0)

@@ -243,6 +243,15 @@ class ReplayBuffer:
         idx = rng.draw_indices(len(self._storage), batch_size)
         return idx, self._stager.upload(idx)
 
+    def draw_per_indices(self, batch_size):
+        """prioritised draw of replay.py:163-177 without the gather: (cpu int64 indices, device indices,
+        float64 importance weights)."""
+        assert self._per is not None, "this buffer was built without prioritised sampling"
+        self.total_sample_calls += 1
+        idxes, weights = self._per.sample(len(self._storage), batch_size)
+        idx = torch.from_numpy(idxes)
+        return idx, self._stager.upload(idx), weights
+
     def gather(self, idx_dev, n):
         st = self._storage
         state = {k: st.gather_field(v, idx_dev, n) for k, v in st.s_stack.items()}

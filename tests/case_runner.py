@@ -10,6 +10,7 @@ serves oracle-vs-reference, engine-vs-reference and engine-vs-oracle.
 import copy
 import math
 import os
+import random
 import sys
 from itertools import chain
 
@@ -431,3 +432,118 @@ def compare(rec, fx, *, td_tol=2e-4, log_rtol=5e-4, par_tol=3e-5, enc_tol=3e-3, 
         elif "_popart" in key:
             assert np.allclose(got, ref, rtol=1e-4, atol=1e-5), f"{who}: {key} {got} vs {ref}"
     return worst
+
+
+# ------------------------------------------------------------------------------------------
+# AFBC / PER cases (synth.AFBC_CASES, fixtures written by oracle/gen_golden.py::run_afbc_case)
+# ------------------------------------------------------------------------------------------
+def run_afbc_oracle(name):
+    """the CPU oracle on the recorded draws; returns a record shaped like the fixture."""
+    cfg = synth.AFBC_CASES[name]
+    fx = load_fixture(name)
+    B = cfg["B"]
+    torch.manual_seed(cfg["seed"]); np.random.seed(cfg["seed"]); random.seed(cfg["seed"])
+    obuf = orc.ReplayOracle(cfg["cap"])
+    obuf.load_experience(*_buffers(cfg))
+    tree = orc.PerOracle(cfg["cap"], 0.6, 1.0)
+    tree.push_rows(np.arange(cfg["rows"]))
+    oa = _oracle_agent(cfg)
+    oa.requires_grad_(True)
+    aopt = orc.AdamOracle(oa.actor_params(), lr=cfg["lr"])
+    aug = orc.AugOracle("identity", B)
+    rec = {}
+    for k, (per, filt) in enumerate(cfg["steps"]):
+        eps = [torch.from_numpy(e) for e in fx[f"s{k}_eps"]] if filt else None
+        peps = [torch.from_numpy(e) for e in fx[f"s{k}_prio_eps"]] if per else None
+        if per:  # the oracle's own prioritised draw must reproduce the recorded one
+            idx, w = tree.sample(len(obuf), B)
+            rec[f"s{k}_idx"], rec[f"s{k}_weights"] = idx, w
+        else:
+            idx = fx[f"s{k}_idx"]
+            torch.randint(len(obuf), (B,))  # keep the torch CPU stream in step
+            rec[f"s{k}_idx"] = idx
+        logs, rd, prio, _ = orc.offline_actor_update(
+            obuf, tree if per else None, oa, aopt, B, cfg["clip"], aug, 0.0, per=per, filter_=filt,
+            idx_list=[idx], eps_lists=[eps] if filt else None, prio_member=0 if per else None, prio_eps=peps)
+        if per:
+            rec[f"s{k}_prio"] = prio
+            rec[f"s{k}_leaves"] = tree.sum[tree.cap + idx].copy()
+        for key, v in logs.items():
+            rec[f"s{k}_log:{key}"] = np.float64(v)
+    rec["final_actor"] = _flat(oa.actor_params())
+    rec["final_max_priority"] = np.float64(tree.max_priority)
+    rec["final_tree_total"] = np.float64(tree.sum[1])
+    return rec
+
+
+def run_afbc_engine(name, device="cuda"):
+    """super_sac_amd.learning.offline_actor_update on the HIP path, fed the recorded normal draws; the PER index
+    draw is the engine's own (numpy global generator seeded like the reference run)."""
+    import super_sac_amd as ssa
+    cfg = synth.AFBC_CASES[name]
+    fx = load_fixture(name)
+    B = cfg["B"]
+    device = torch.device(device)
+    torch.manual_seed(cfg["seed"]); np.random.seed(cfg["seed"]); random.seed(cfg["seed"])
+    buf = ssa.replay.ReplayBuffer(cfg["cap"], device=device)
+    buf.load_experience(*_buffers(cfg))
+    agent = build_engine_agent(cfg, device)
+    aopt = torch.optim.Adam(chain(*(a.parameters() for a in agent.actors)), lr=cfg["lr"], betas=(0.9, 0.999))
+    eopt = torch.optim.Adam(agent.encoder.parameters(), lr=1e-4)
+    aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(B)])
+    player = DrawPlayer(device)
+    player.install(ssa.rng)
+    rec = {}
+    try:
+        for k, (per, filt) in enumerate(cfg["steps"]):
+            if not per:
+                player.idx.append(fx[f"s{k}_idx"])
+            if filt:
+                player.normal.extend(list(fx[f"s{k}_eps"]))
+            if per:
+                player.normal.extend(list(fx[f"s{k}_prio_eps"]))
+            seen = {}
+            orig_upd = buf.update_priorities
+
+            def spy(idxes, prios, _seen=seen, _orig=orig_upd):
+                _seen["idx"], _seen["prio"] = np.asarray(idxes).copy(), np.asarray(prios, np.float64).copy()
+                return _orig(idxes, prios)
+            buf.update_priorities = spy
+            logs = ssa.learning.offline_actor_update(
+                buffer=buf, agent=agent, actor_optimizer=aopt, encoder_optimizer=eopt, batch_size=B,
+                actor_clip=cfg["clip"], update_encoder=False, encoder_clip=cfg["clip"], augmenter=aug,
+                actor_lambda=0.0, aug_mix=0.0, premade_replay_dicts=None, per=per, discrete=False, filter_=filt)
+            buf.update_priorities = orig_upd
+            if per:
+                rec[f"s{k}_idx"], rec[f"s{k}_prio"] = seen["idx"], seen["prio"]
+                rec[f"s{k}_leaves"] = buf._per.sum_tree[buf._per.cap + seen["idx"]].copy()
+            for key, v in logs.items():
+                if not key.startswith("gradients/"):
+                    rec[f"s{k}_log:{key}"] = np.float64(float(v))
+            assert not player.normal and not player.idx, "the engine consumed a different number of draws"
+    finally:
+        player.restore()
+    rec["final_actor"] = _flat([p for a in agent.actors for p in a.parameters()])
+    rec["final_max_priority"] = np.float64(buf._per._max_priority)
+    rec["final_tree_total"] = np.float64(buf._per.sum_tree[1])
+    return rec
+
+
+def compare_afbc(rec, fx, log_rtol=5e-4, par_tol=3e-5, prio_tol=2e-4):
+    n = int(fx["n_steps"])
+    for k in range(n):
+        if int(fx[f"s{k}_per"]):
+            assert np.array_equal(rec[f"s{k}_idx"], fx[f"s{k}_idx"]), f"step {k}: prioritised index draw differs"
+            if f"s{k}_weights" in rec:
+                np.testing.assert_allclose(rec[f"s{k}_weights"], fx[f"s{k}_weights"], rtol=1e-9)
+            np.testing.assert_allclose(rec[f"s{k}_prio"], fx[f"s{k}_prio"], rtol=prio_tol, atol=2e-6,
+                                       err_msg=f"step {k}: new priorities")
+            np.testing.assert_allclose(rec[f"s{k}_leaves"], fx[f"s{k}_leaves"], rtol=prio_tol, atol=2e-6)
+        for key in fx:
+            if key.startswith(f"s{k}_log:"):
+                v, r = float(rec[key]), float(fx[key])
+                assert abs(v - r) <= log_rtol * max(1.0, abs(r)), (key, v, r)
+    d = float(np.abs(rec["final_actor"] - fx["final_actor"]).max())
+    assert d <= par_tol, f"final actor parameters differ by {d:.3e}"
+    assert abs(float(rec["final_max_priority"]) - float(fx["final_max_priority"])) < 1e-6
+    assert abs(float(rec["final_tree_total"]) - float(fx["final_tree_total"])) <= 1e-5 * float(fx["final_tree_total"])

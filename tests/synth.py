@@ -65,6 +65,18 @@ CASES = {
 }
 
 
+# advantage-filtered BC (AWAC/AFBC actor update) with prioritised replay: SURVEY.md 8(f) rank 1.
+# steps: (per, filter_) of consecutive learning.offline_actor_update calls (learning.py:144-219)
+AFBC_CASES = {
+    "afbc_awac": dict(obs=11, act=3, hidden=64, N=2, n=2, E=1, B=64, rows=600, cap=1024, lo=-10.0, hi=2.0,
+                      popart=False, discrete=False, actor="stochastic", lr=3e-4, clip=40.0, seed=21,
+                      steps=[(False, False), (True, True), (True, True), (False, True), (True, True)]),
+    "afbc_noclip": dict(obs=17, act=6, hidden=64, N=3, n=2, E=1, B=128, rows=900, cap=1024, lo=-5.0, hi=2.0,
+                        popart=False, discrete=False, actor="stochastic", lr=1e-3, clip=None, seed=22,
+                        steps=[(True, True), (True, True), (True, False)]),
+}
+
+
 def synth_transitions(rows, obs_dim, act_dim, discrete=False, seed=1, n_actions=None):
     """obs,next_obs ~ N(0,1); act ~ U(-1,1); rew ~ N(0,1); done ~ Bern(0.01)."""
     rng = np.random.RandomState(seed)

@@ -112,3 +112,20 @@ def test_graph_replay_equals_eager_launches():
     assert np.array_equal(le[2], lg[2]), "replay indices must not depend on the launch mechanism"
     assert np.array_equal(pe, pg) and np.array_equal(te, tg), "graph replay must be bit-identical to eager launches"
     assert le[0] == lg[0] and le[1] == lg[1]
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
+@pytest.mark.parametrize("name", sorted(synth.AFBC_CASES))
+def test_afbc_and_per_match_reference(name, fused):
+    """learning.offline_actor_update (advantage filter from one stacked ensemble-Q launch,
+    filtered BC gradient, Adam) with prioritised sampling and the advantage-based priority refresh.  Prioritised
+    indices and importance weights must equal the reference's (float64 trees on the host, numpy global stream);
+    priorities within 2e-4, logs 5e-4, final actor parameters 3e-5."""
+    import super_sac_amd as ssa
+    old = ssa.engine.USE_FUSED
+    ssa.engine.USE_FUSED = fused
+    try:
+        rec = case_runner.run_afbc_engine(name)
+    finally:
+        ssa.engine.USE_FUSED = old
+    case_runner.compare_afbc(rec, case_runner.load_fixture(name))

@@ -180,3 +180,12 @@ def test_product_priority_sampler_matches_reference_fixture():
         ps.update_priorities(np.array([0, 1]), np.array([1.0, 0.0]), 300)   # priorities must be > 0
     with pytest.raises(AssertionError):
         ps.update_priorities(np.array([300]), np.array([1.0]), 300)          # index range (replay.py:187)
+
+
+@pytest.mark.parametrize("name", sorted(synth.AFBC_CASES))
+def test_oracle_reproduces_afbc_fixture(name):
+    """offline_actor_update + advantage filter + PER sample / priority refresh: the
+    oracle, drawing its own prioritised indices from the seeded numpy stream, lands on the reference's
+    recorded indices, weights, priorities, logs and final actor."""
+    rec = case_runner.run_afbc_oracle(name)
+    case_runner.compare_afbc(rec, case_runner.load_fixture(name), par_tol=1e-6)

@@ -625,8 +625,56 @@ def run_afbc_case(name, cfg):
         return out
     type(ra.adv_estimator).forward = adv_spy
 
+    has_critic = any(st_ == "critic" for st_ in cfg["steps"])
+    if has_critic:
+        rt, ot = copy.deepcopy(ra), oa.clone()
+        r_copt = torch.optim.Adam(chain(*(c.parameters() for c in ra.critics)), lr=cfg["lr"], betas=(0.9, 0.999))
+        o_copt = orc.AdamOracle(oa.critic_params(), lr=cfg["lr"])
+        o_eopt = orc.AdamOracle(oa.encoder_params(), lr=1e-4)
+        rla = torch.Tensor([math.log(cfg["init_alpha"])]).to(ref.device); rla.requires_grad = True
+        ola = torch.tensor([math.log(cfg["init_alpha"])], requires_grad=True)
+
     rec = {"n_steps": np.int64(len(cfg["steps"]))}
-    for k, (per, filt) in enumerate(cfg["steps"]):
+    for k, step in enumerate(cfg["steps"]):
+        if step == "critic":
+            # learning.critic_update(per=False, update_priorities=True) as in the offline phase of main.py
+            st, pst = torch.get_rng_state(), random.getstate()
+            idx = torch.randint(len(rbuf), (B,)).numpy()
+            ceps = torch.randn(B, A)
+            sub = random.sample(range(cfg["N"]), k=cfg["n"])
+            random.choice(list(range(cfg["N"])))  # random.choice(agent.critics) for the grad-norm log
+            pm = random.choice(range(E))
+            peps = [torch.randn(B, A) for _ in range(4)]
+            torch.set_rng_state(st); random.setstate(pst)
+            advs.clear()
+            rlogs, _ = rl.critic_update(
+                buffer=rbuf, agent=ra, target_agent=rt, critic_optimizer=r_copt, encoder_optimizer=r_eopt,
+                log_alphas=[rla], batch_size=B, gamma=cfg["gamma"], critic_clip=cfg["clip"], encoder_clip=cfg["clip"],
+                target_critic_ensemble_n=cfg["n"], weighted_bellman_temp=None, weight_type=None, pop=False,
+                augmenter=r_aug, encoder_lambda=0, aug_mix=0.0, discrete=False, random_process=None,
+                noise_clip=None, per=False, update_priorities=True, dr3_coeff=0.0)
+            ologs, odicts = orc.critic_update(
+                obuf, oa, ot, o_copt, o_eopt, [ola], B, cfg["gamma"], cfg["clip"], cfg["clip"], cfg["n"], None, None,
+                False, o_aug, aug_mix=0.0, idx_list=[idx], eps_list=[ceps], subset_list=[sub])
+            ord_ = odicts[-1]
+            oadv = orc.advantage(oa, ord_["primary_batch"][0], ord_["primary_batch"][1], pm, peps)
+            oprio = (torch.relu(oadv) + 1e-4).squeeze(1).numpy()
+            tree.update(idx, oprio)
+            leaves = np.array([rbuf._it_sum[int(j)] for j in idx], np.float64)
+            assert np.allclose(leaves, tree.sum[tree.cap + idx], rtol=1e-4, atol=1e-6), "critic priority refresh"
+            for ac, tc in zip(ra.critics, rt.critics):
+                rlu.soft_update(tc, ac, cfg["tau"])
+            orc.soft_update(ot.critic_params(), oa.critic_params(), cfg["tau"])
+            rec[f"s{k}_critic"] = np.int64(1)
+            rec[f"s{k}_idx"], rec[f"s{k}_ceps"] = np.asarray(idx, np.int64), ceps.numpy()
+            rec[f"s{k}_subset"] = np.array(sub, np.int64)
+            rec[f"s{k}_prio_eps"], rec[f"s{k}_prio"], rec[f"s{k}_leaves"] = torch.stack(peps).numpy(), oprio, leaves
+            for key, val in rlogs.items():
+                if not key.startswith("gradients/"):
+                    rec[f"s{k}_log:{key}"] = np.float64(float(val))
+                    assert abs(float(val) - float(ologs[key])) <= 2e-4 * max(1.0, abs(float(val))), key
+            continue
+        per, filt = step
         # replicate the host draws the reference is about to make, then rewind
         st, nst, pst = torch.get_rng_state(), np.random.get_state(), random.getstate()
         if per:
@@ -669,7 +717,10 @@ def run_afbc_case(name, cfg):
             rec[f"s{k}_log:{key}"] = np.float64(v)
             assert abs(v - float(ologs[key])) <= 2e-4 * max(1.0, abs(v)), (key, v, ologs[key])
     type(ra.adv_estimator).forward = orig_fwd
-    _, rac = ref_params(ra, cfg)
+    rcc, rac = ref_params(ra, cfg)
+    if has_critic:
+        assert maxdiff(rcc, oa.critic_params()) < 5e-5
+        rec["final_critic"] = np.concatenate([p.detach().numpy().ravel() for p in rcc])
     dpar = maxdiff(rac, oa.actor_params())
     print(f"   actor params max|diff| {dpar:.3e}; max priority {rbuf._max_priority:.4f} / {tree.max_priority:.4f}")
     assert dpar < 5e-5 and abs(rbuf._max_priority - tree.max_priority) < 1e-6

@@ -118,6 +118,7 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
               random_process=random_process, noise_clip=noise_clip, aug_mix=aug_mix, discrete=discrete, per=per,
               update_priorities=update_priorities, dr3_coeff=dr3_coeff)
     graphable = (USE_GRAPHS and engine.CAPTURE is None and agent.ensemble_size == 1 and not per
+                 and not update_priorities
                  and lu.is_identity(agent.encoder) and parallel.shard_of(agent) is None
                  and random_process is None and torch.cuda.is_available())
     if not graphable:
@@ -244,8 +245,6 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
         raise NotImplementedError("encoder invariance loss (SURVEY 8(f) rank 4) is not accelerated")
     if dr3_coeff > 0:
         raise NotImplementedError("DR3 regulariser (SURVEY 8(f) rank 4) is not accelerated")
-    if update_priorities:
-        raise NotImplementedError("PER priority refresh (SURVEY 8(f) rank 1) is not accelerated")
     E = agent.ensemble_size
     assert E <= lu.MAX_MEMBERS
     dev = log_alphas[0].device
@@ -302,6 +301,17 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
         weight_ptr = 0
         if not isinstance(bw, float):
             weight_ptr = bw.data_ptr()  # imp_weights is ones(1) on the uniform path
+        if per:
+            # learning.py:96-98 multiplies (B,1) errors by the (B,) importance weights: a (B,B) outer product
+            # whose mean is mean(w) * mean(bw * err^2) -- i.e. every row's weight is scaled by mean(w)
+            wrow = ws.get(f"cu.w{i}", (B, 1))
+            scale = rd["imp_weights"].mean().to(torch.float32)
+            if isinstance(bw, float):
+                wrow.fill_(1.0)
+            else:
+                wrow.copy_(bw.view(B, 1))
+            wrow.mul_(scale)
+            weight_ptr = wrow.data_ptr()
         pp, dopop = (popart.ptr if popart else 0), (1 if (popart and pop) else 0)
         ttot = engine.wgrad_tiles_total(arena)
         ss = ws.get(f"cu.ss{i}", (N * ttot,))
@@ -391,6 +401,8 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                                    slot[lu.L_CRITIC_GN:].data_ptr(), st))
     logs["gradients/critic_random_grad"] = slot[lu.L_CRITIC_GN]
     logs["gradients/encoder_criticloss_grad_norm"] = slot[lu.L_ENC_GN]
+    if update_priorities:  # learning.py:139-140: advantage-based priorities on the LAST member's batch
+        lu.adjust_priorities(logs, replay_dicts[-1], agent, buffer)
     return logs, replay_dicts
 
 

@@ -452,7 +452,31 @@ def run_afbc_oracle(name):
     aopt = orc.AdamOracle(oa.actor_params(), lr=cfg["lr"])
     aug = orc.AugOracle("identity", B)
     rec = {}
-    for k, (per, filt) in enumerate(cfg["steps"]):
+    if any(st_ == "critic" for st_ in cfg["steps"]):
+        ot = oa.clone()
+        copt = orc.AdamOracle(oa.critic_params(), lr=cfg["lr"])
+        eopt = orc.AdamOracle(oa.encoder_params(), lr=1e-4)
+        ola = torch.tensor([math.log(cfg["init_alpha"])], requires_grad=True)
+    for k, step in enumerate(cfg["steps"]):
+        if step == "critic":
+            idx = fx[f"s{k}_idx"]
+            torch.randint(len(obuf), (B,))
+            logs, odicts = orc.critic_update(
+                obuf, oa, ot, copt, eopt, [ola], B, cfg["gamma"], cfg["clip"], cfg["clip"], cfg["n"], None, None,
+                False, aug, aug_mix=0.0, idx_list=[idx], eps_list=[torch.from_numpy(fx[f"s{k}_ceps"])],
+                subset_list=[[int(v) for v in fx[f"s{k}_subset"]]])
+            rd = odicts[-1]
+            adv = orc.advantage(oa, rd["primary_batch"][0], rd["primary_batch"][1], 0,
+                                [torch.from_numpy(e) for e in fx[f"s{k}_prio_eps"]])
+            prio = (torch.relu(adv) + 1e-4).squeeze(1).numpy()
+            tree.update(idx, prio)
+            orc.soft_update(ot.critic_params(), oa.critic_params(), cfg["tau"])
+            rec[f"s{k}_idx"], rec[f"s{k}_prio"] = idx, prio
+            rec[f"s{k}_leaves"] = tree.sum[tree.cap + idx].copy()
+            for key, v in logs.items():
+                rec[f"s{k}_log:{key}"] = np.float64(v)
+            continue
+        per, filt = step
         eps = [torch.from_numpy(e) for e in fx[f"s{k}_eps"]] if filt else None
         peps = [torch.from_numpy(e) for e in fx[f"s{k}_prio_eps"]] if per else None
         if per:  # the oracle's own prioritised draw must reproduce the recorded one
@@ -471,6 +495,8 @@ def run_afbc_oracle(name):
         for key, v in logs.items():
             rec[f"s{k}_log:{key}"] = np.float64(v)
     rec["final_actor"] = _flat(oa.actor_params())
+    if "final_critic" in fx:
+        rec["final_critic"] = _flat(oa.critic_params())
     rec["final_max_priority"] = np.float64(tree.max_priority)
     rec["final_tree_total"] = np.float64(tree.sum[1])
     return rec
@@ -494,20 +520,48 @@ def run_afbc_engine(name, device="cuda"):
     player = DrawPlayer(device)
     player.install(ssa.rng)
     rec = {}
+    if any(st_ == "critic" for st_ in cfg["steps"]):
+        target = copy.deepcopy(agent)
+        copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=cfg["lr"], betas=(0.9, 0.999))
+        la = torch.Tensor([math.log(cfg["init_alpha"])]).to(device)
+        la.requires_grad = True
     try:
-        for k, (per, filt) in enumerate(cfg["steps"]):
-            if not per:
-                player.idx.append(fx[f"s{k}_idx"])
-            if filt:
-                player.normal.extend(list(fx[f"s{k}_eps"]))
-            if per:
-                player.normal.extend(list(fx[f"s{k}_prio_eps"]))
+        for k, step in enumerate(cfg["steps"]):
             seen = {}
             orig_upd = buf.update_priorities
 
             def spy(idxes, prios, _seen=seen, _orig=orig_upd):
                 _seen["idx"], _seen["prio"] = np.asarray(idxes).copy(), np.asarray(prios, np.float64).copy()
                 return _orig(idxes, prios)
+            if step == "critic":
+                player.idx.append(fx[f"s{k}_idx"])
+                player.normal.append(fx[f"s{k}_ceps"])
+                player.sub.append(fx[f"s{k}_subset"])
+                player.normal.extend(list(fx[f"s{k}_prio_eps"]))
+                buf.update_priorities = spy
+                logs, _ = ssa.learning.critic_update(
+                    buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt, encoder_optimizer=eopt,
+                    log_alphas=[la], batch_size=B, gamma=cfg["gamma"], critic_clip=cfg["clip"],
+                    encoder_clip=cfg["clip"], target_critic_ensemble_n=cfg["n"], weighted_bellman_temp=None,
+                    weight_type=None, pop=False, augmenter=aug, encoder_lambda=0, aug_mix=0.0, discrete=False,
+                    random_process=None, noise_clip=None, per=False, update_priorities=True, dr3_coeff=0.0)
+                buf.update_priorities = orig_upd
+                for ac, tc in zip(agent.critics, target.critics):
+                    ssa.learning_utils.soft_update(tc, ac, cfg["tau"])
+                rec[f"s{k}_idx"], rec[f"s{k}_prio"] = seen["idx"], seen["prio"]
+                rec[f"s{k}_leaves"] = buf._per.sum_tree[buf._per.cap + seen["idx"]].copy()
+                for key, v in logs.items():
+                    if not key.startswith("gradients/"):
+                        rec[f"s{k}_log:{key}"] = np.float64(float(v))
+                assert not player.normal and not player.idx and not player.sub
+                continue
+            per, filt = step
+            if not per:
+                player.idx.append(fx[f"s{k}_idx"])
+            if filt:
+                player.normal.extend(list(fx[f"s{k}_eps"]))
+            if per:
+                player.normal.extend(list(fx[f"s{k}_prio_eps"]))
             buf.update_priorities = spy
             logs = ssa.learning.offline_actor_update(
                 buffer=buf, agent=agent, actor_optimizer=aopt, encoder_optimizer=eopt, batch_size=B,
@@ -524,6 +578,8 @@ def run_afbc_engine(name, device="cuda"):
     finally:
         player.restore()
     rec["final_actor"] = _flat([p for a in agent.actors for p in a.parameters()])
+    if "final_critic" in fx:
+        rec["final_critic"] = _flat([p for c in agent.critics for p in c.parameters()])
     rec["final_max_priority"] = np.float64(buf._per._max_priority)
     rec["final_tree_total"] = np.float64(buf._per.sum_tree[1])
     return rec
@@ -532,7 +588,11 @@ def run_afbc_engine(name, device="cuda"):
 def compare_afbc(rec, fx, log_rtol=5e-4, par_tol=3e-5, prio_tol=2e-4):
     n = int(fx["n_steps"])
     for k in range(n):
-        if int(fx[f"s{k}_per"]):
+        if f"s{k}_critic" in fx:
+            np.testing.assert_allclose(rec[f"s{k}_prio"], fx[f"s{k}_prio"], rtol=prio_tol, atol=2e-6,
+                                       err_msg=f"step {k}: priorities after the critic update")
+            np.testing.assert_allclose(rec[f"s{k}_leaves"], fx[f"s{k}_leaves"], rtol=prio_tol, atol=2e-6)
+        elif int(fx[f"s{k}_per"]):
             assert np.array_equal(rec[f"s{k}_idx"], fx[f"s{k}_idx"]), f"step {k}: prioritised index draw differs"
             if f"s{k}_weights" in rec:
                 np.testing.assert_allclose(rec[f"s{k}_weights"], fx[f"s{k}_weights"], rtol=1e-9)
@@ -545,5 +605,8 @@ def compare_afbc(rec, fx, log_rtol=5e-4, par_tol=3e-5, prio_tol=2e-4):
                 assert abs(v - r) <= log_rtol * max(1.0, abs(r)), (key, v, r)
     d = float(np.abs(rec["final_actor"] - fx["final_actor"]).max())
     assert d <= par_tol, f"final actor parameters differ by {d:.3e}"
+    if "final_critic" in fx:
+        d = float(np.abs(rec["final_critic"] - fx["final_critic"]).max())
+        assert d <= max(par_tol, 3e-5), f"final critic parameters differ by {d:.3e}"
     assert abs(float(rec["final_max_priority"]) - float(fx["final_max_priority"])) < 1e-6
     assert abs(float(rec["final_tree_total"]) - float(fx["final_tree_total"])) <= 1e-5 * float(fx["final_tree_total"])

@@ -71,6 +71,11 @@ AFBC_CASES = {
     "afbc_awac": dict(obs=11, act=3, hidden=64, N=2, n=2, E=1, B=64, rows=600, cap=1024, lo=-10.0, hi=2.0,
                       popart=False, discrete=False, actor="stochastic", lr=3e-4, clip=40.0, seed=21,
                       steps=[(False, False), (True, True), (True, True), (False, True), (True, True)]),
+    # AWAC-style offline phase: critic updates refresh the priorities too (main.py:403-404 update_priorities)
+    "awac_offline": dict(obs=11, act=3, hidden=64, N=2, n=2, E=1, B=64, rows=600, cap=1024, lo=-10.0, hi=2.0,
+                         popart=False, discrete=False, actor="stochastic", lr=3e-4, clip=None, seed=23,
+                         gamma=0.99, tau=0.005, init_alpha=0.1,
+                         steps=[(False, False), "critic", (True, True), "critic", (True, True)]),
     "afbc_noclip": dict(obs=17, act=6, hidden=64, N=3, n=2, E=1, B=128, rows=900, cap=1024, lo=-5.0, hi=2.0,
                         popart=False, discrete=False, actor="stochastic", lr=1e-3, clip=None, seed=22,
                         steps=[(True, True), (True, True), (True, False)]),

@@ -109,6 +109,103 @@ class Agent:
         for m in self._modules():
             m.train()
 
+    # ---- acting path on the engine's weights (agent.py:204-327) ----------------------
+    def _process_obs(self, obs, num_envs=1):
+        dev = next(self.actors[0].parameters()).device
+        unsq = (lambda t: t.unsqueeze(0)) if num_envs == 1 else (lambda t: t)
+        return {k: unsq(torch.from_numpy(v)).float().to(dev) for k, v in obs.items()}
+
+    def _process_act(self, act, num_envs=1):
+        act = act.squeeze(0) if num_envs == 1 else act
+        if not self.discrete:
+            act.clamp_(-1.0, 1.0)
+        return act.cpu().numpy()
+
+    def _state_rep(self, obs, rolling):
+        return (self.encoder.forward_rolling(obs) if rolling else self.encoder.forward(obs)).contiguous()
+
+    def _mean_action(self, actor, out):
+        """dist.mean of a continuous actor: tanh(mu) (SquashedNormal.mean, distributions.py:99-104) or the
+        deterministic actor's tanh(out) (mlps.py:91-92), by the det-action kernel without noise."""
+        from ._lib import check, lib
+        n, A = out.shape[0], actor.action_size
+        act = torch.empty(n, A, device=out.device)
+        check(lib.ssac_det_action_fwd(out.data_ptr(), out.shape[1], 0, 0.0, 0, 0.0, 0.0, n, A,
+                                      act.data_ptr(), A, 0, engine.stream()))
+        return act
+
+    def _sample(self, actor, out):
+        """dist.sample() of one actor on the rows of `out` (device generator for the noise / the draw)."""
+        from ._lib import check, lib
+        n = out.shape[0]
+        if self.discrete:
+            return torch.multinomial(torch.softmax(out, dim=-1), 1).squeeze(-1)  # Categorical.sample()
+        A = actor.action_size
+        act = torch.empty(n, A, device=out.device)
+        if getattr(actor, "dist_impl", None) == "deterministic":
+            return self._mean_action(actor, out)  # ContinuousDeterministic.sample() = loc
+        eps = rng.draw_normal((n, A), out.device)
+        check(lib.ssac_tanh_normal_fwd(out.data_ptr(), 2 * A, eps.data_ptr(), n, A, float(actor.log_std_low),
+                                       float(actor.log_std_high), act.data_ptr(), A, 0, 0, engine.stream()))
+        return act
+
+    def forward(self, state, from_cpu=True, num_envs=1, rolling=False):
+        """greedy action: mean over the ensemble's actors of dist.mean (continuous) or argmax of the mean
+        action probabilities (discrete), agent.py:204-246."""
+        engine.require_gpu()
+        if from_cpu:
+            state = self._process_obs(state, num_envs=num_envs)
+        s_rep = self._state_rep(state, rolling)
+        outs = [actor.raw_forward(s_rep) for actor in self.actors]
+        if self.discrete:
+            probs = torch.stack([torch.softmax(o, dim=-1) for o in outs], dim=0).mean(0)
+            act = torch.argmax(probs, dim=-1, keepdim=True)
+        else:
+            act = torch.stack([self._mean_action(a, o) for a, o in zip(self.actors, outs)], dim=0).mean(0)
+        if from_cpu:
+            act = self._process_act(act, num_envs=num_envs)
+        return act
+
+    def sample_action(self, obs, from_cpu=True, num_envs=1, return_dist=False, rolling=False):
+        """exploration action (agent.py:248-315): a random actor's sample, or with ucb_bonus > 0 the SUNRISE
+        rule -- one candidate per actor, argmax over candidates of mean_c Q_c + bonus * std_c Q_c, the critics'
+        values coming from one ensemble-Q launch per member on the stacked candidates."""
+        engine.require_gpu()
+        if from_cpu:
+            obs = self._process_obs(obs, num_envs)
+        s_rep = self._state_rep(obs, rolling)
+        n = s_rep.shape[0]
+        if self.ucb_bonus > 0:
+            outs = [actor.raw_forward(s_rep) for actor in self.actors]
+            cands = torch.stack([self._sample(a, o) for a, o in zip(self.actors, outs)], dim=0)
+            dist_out = rng.choice(outs)  # `random.choice(act_dists)`: consumed for logging only
+            E = len(self.actors)
+            if self.discrete:
+                # q of the specific candidate action of every actor, for every critic member
+                q_all = torch.stack([critic(s_rep) for critic in self.critics], dim=0)       # (Ec, n, A)
+                q = torch.stack([q_all.gather(-1, cands[a].view(1, n, 1).expand(len(self.critics), n, 1))
+                                 for a in range(E)], dim=1).squeeze(-1)                      # (Ec, Ea, n)
+            else:
+                x = torch.cat((s_rep.unsqueeze(0).expand(E, n, s_rep.shape[1]), cands), dim=-1)
+                x = x.reshape(E * n, -1).contiguous()
+                q = torch.stack([critic(x).view(E, n) for critic in self.critics], dim=0)     # (Ec, Ea, n)
+            ucb = q.mean(0) + self.ucb_bonus * q.std(0)
+            best = torch.argmax(ucb, dim=0)                                                   # (n,)
+            act = cands[best, torch.arange(n, device=cands.device)]
+            if self.discrete:
+                act = act.unsqueeze(-1)
+        else:
+            actor = rng.choice(self.actors)
+            dist_out = actor.raw_forward(s_rep)
+            act = self._sample(actor, dist_out)
+            if self.discrete:
+                act = act.unsqueeze(-1)
+        if from_cpu:
+            act = self._process_act(act, num_envs)
+        if return_dist:
+            return act, dist_out  # the chosen actor's raw head output (distribution parameters)
+        return act
+
     # same per-module files as agent.py:172-202 (inverse/contrastive models are out of scope)
     def save(self, path):
         torch.save(self.encoder.state_dict(), os.path.join(path, "encoder.pt"))

@@ -379,6 +379,13 @@ int ssac_col2im(const float *dcol, float *dx, int64_t sb, int64_t sc, int64_t sy
 /* Y = act(X W^T + b), X (M x K), W (N x K): F.conv2d on patches / nn.Linear (cnns.py:61-66,98-102). */
 int ssac_linear_fwd(const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, float *Y,
                     int64_t ldy, int M, int N, int K, int relu, void *stream);
+/* split-K forward for short, very deep problems (the pixel encoders' fc over the flattened feature map):
+ * partial (slices x M x N) = X[:, slice] W[:, slice]^T per K slice of k_per_slice (multiple of 32) columns;
+ * ssac_reduce_slices_bias then writes Y[m*ld_out + n] = bias[n] + sum over slices, in a fixed order. */
+int ssac_linear_fwd_splitk(const float *X, int64_t ldx, const float *W, int64_t ldw, float *partial, int M, int N,
+                           int K, int k_per_slice, void *stream);
+int ssac_reduce_slices_bias(const float *partial, int slices, int M, int N, const float *bias, float *out,
+                            int64_t ld_out, void *stream);
 /* dX (M x N_in) = dY (M x K_out) W (K_out x N_in) */
 int ssac_linear_dgrad(const float *dY, int64_t ldy, const float *W, int64_t ldw, float *dX, int64_t ldx,
                       int M, int N_in, int K_out, void *stream);

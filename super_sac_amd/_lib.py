@@ -91,6 +91,8 @@ SIGNATURES = {
     "ssac_im2col": [_P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P],
     "ssac_col2im": [_P, _P, _L, _L, _L, _L, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P],
     "ssac_linear_fwd": [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _P],
+    "ssac_linear_fwd_splitk": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P],
+    "ssac_reduce_slices_bias": [_P, _I, _I, _I, _P, _P, _L, _P],
     "ssac_linear_dgrad": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P],
     "ssac_linear_wgrad_splitk": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _P],
     "ssac_reduce_slices": [_P, _I, _L, _P, _P],

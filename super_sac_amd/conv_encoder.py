@@ -20,6 +20,7 @@ import torch
 from . import engine
 from ._lib import check, lib
 
+FC_SLICES = 48  # K slices of the fc forward (8 row tiles x 48 slices ~ 1.5 workgroups per CU at B 512)
 ROWS_PER_SLICE = 4096  # split-K granularity of the convolution weight gradients
 
 
@@ -102,10 +103,24 @@ class ConvEncoderEngine:
         colf = self.ws.get(f"{tag}.colf", (B * flat_dim,))
         check(lib.ssac_im2col(src.data_ptr(), 0, *strides, B, co, Hi, Wi, Hi, 1, 1.0, 0.0, colf.data_ptr(), st))
         fc = self.module.fc
+
+        def fc_forward(out_ptr, ld_out):
+            # (B x flat_dim) . (emb x flat_dim)^T: 8 x 1 output tiles only -> cut K into slices so the launch fills
+            # the chip, then a fixed-order reduction adds the bias
+            kps = max(32, ((flat_dim + FC_SLICES - 1) // FC_SLICES + 31) // 32 * 32)
+            slices = (flat_dim + kps - 1) // kps
+            if slices < 4:
+                check(lib.ssac_linear_fwd(colf.data_ptr(), flat_dim, fc.weight.data_ptr(), flat_dim,
+                                          fc.bias.data_ptr(), out_ptr, ld_out, B, self.emb, flat_dim, 0, st))
+                return
+            part = self.ws.get("fc.partial", (slices * B * self.emb,))
+            check(lib.ssac_linear_fwd_splitk(colf.data_ptr(), flat_dim, fc.weight.data_ptr(), flat_dim,
+                                             part.data_ptr(), B, self.emb, flat_dim, kps, st))
+            check(lib.ssac_reduce_slices_bias(part.data_ptr(), slices, B, self.emb, fc.bias.data_ptr(), out_ptr,
+                                              ld_out, st))
         if self.big:
             z = self.ws.get(f"{tag}.z", (B, self.emb))
-            check(lib.ssac_linear_fwd(colf.data_ptr(), flat_dim, fc.weight.data_ptr(), flat_dim,
-                                      fc.bias.data_ptr(), z.data_ptr(), self.emb, B, self.emb, flat_dim, 0, st))
+            fc_forward(z.data_ptr(), self.emb)
             xhat = self.ws.get(f"{tag}.xhat", (B, self.emb))
             rstd = self.ws.get(f"{tag}.rstd", (B,))
             ln = self.module.ln
@@ -113,8 +128,7 @@ class ConvEncoderEngine:
                                        self.emb, dst.data_ptr(), ld_dst, xhat.data_ptr(), rstd.data_ptr(), st))
         else:
             xhat = rstd = None
-            check(lib.ssac_linear_fwd(colf.data_ptr(), flat_dim, fc.weight.data_ptr(), flat_dim,
-                                      fc.bias.data_ptr(), dst.data_ptr(), ld_dst, B, self.emb, flat_dim, 0, st))
+            fc_forward(dst.data_ptr(), ld_dst)
         if save:
             self.saved = dict(B=B, cols=cols, ys=ys, shapes=shapes, colf=colf, flat_dim=flat_dim,
                               Hf=Hi, Wf=Wi, xhat=xhat, rstd=rstd, out=dst, ld_out=ld_dst)

@@ -103,6 +103,19 @@ __global__ void reduce_slices_kernel(const float *__restrict__ partial, int slic
     }
 }
 
+// out[m*ldo + n] = bias[n] + sum_s partial[(s*M + m)*N + n], fixed order
+__global__ void reduce_slices_bias_kernel(const float *__restrict__ partial, int slices, int M, int N,
+                                          const float *__restrict__ bias, float *__restrict__ out, int64_t ldo) {
+    const int64_t n_el = (int64_t)M * N;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_el;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
+        float s = 0.0f;
+        for (int z = 0; z < slices; ++z) s += partial[(int64_t)z * n_el + i];
+        out[m * ldo + n] = s + (bias ? bias[n] : 0.0f);
+    }
+}
+
 // per-block partial sums of x^2 (for clip_grad_norm_ over an encoder's gradient arena)
 __global__ void sumsq_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
     __shared__ float red[4];
@@ -220,6 +233,14 @@ extern "C" int ssac_reduce_slices(const float *partial, int slices, int64_t n, f
     if (n <= 0 || slices <= 0) return 0;
     SSAC_LAUNCH(reduce_slices_kernel, dim3(grid_for(n)), dim3(256), 0, ST, partial, slices, n, out);
     return ssac_check_launch("reduce_slices");
+}
+
+extern "C" int ssac_reduce_slices_bias(const float *partial, int slices, int M, int N, const float *bias,
+                                       float *out, int64_t ld_out, void *stream) {
+    if (M <= 0 || N <= 0 || slices <= 0) return 0;
+    SSAC_LAUNCH(reduce_slices_bias_kernel, dim3(grid_for((int64_t)M * N)), dim3(256), 0, ST, partial, slices, M, N,
+                bias, out, ld_out);
+    return ssac_check_launch("reduce_slices_bias");
 }
 
 extern "C" int ssac_sumsq_blocks(void) { return 256; }

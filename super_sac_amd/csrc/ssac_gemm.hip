@@ -618,6 +618,21 @@ extern "C" int ssac_linear_fwd(const float *X, int64_t ldx, const float *W, int6
     return relu ? launch<true, true, EPI_BIAS_RELU>(g, 1, st) : launch<true, true, EPI_BIAS>(g, 1, st);
 }
 
+// Y = X W^T + b for a short, very deep problem (the encoder's fc: M = batch, N = embedding, K = C*H*W): the M x N
+// tiles alone leave the chip idle, so K is cut into slices of k_per_slice (a multiple of 32) that run as
+// separate workgroups into `partial` (slices x M x N), then ssac_reduce_slices_bias sums them in a fixed order.
+extern "C" int ssac_linear_fwd_splitk(const float *X, int64_t ldx, const float *W, int64_t ldw, float *partial,
+                                      int M, int N, int K, int k_per_slice, void *stream) {
+    if (k_per_slice <= 0 || (k_per_slice & 31)) return ssac_fail("ssac_linear_fwd_splitk: slice must be a multiple of 32");
+    const int slices = (K + k_per_slice - 1) / k_per_slice;
+    GemmArgs g{};
+    g.A = X; g.lda = ldx; g.sA = k_per_slice;
+    g.B = W; g.ldb = ldw; g.sB = k_per_slice;
+    g.C = partial; g.ldc = N; g.sC = (int64_t)M * N;
+    g.M = M; g.N = N; g.K = k_per_slice; g.Ktot = K;
+    return launch<true, true, EPI_STORE>(g, slices, (hipStream_t)stream);
+}
+
 extern "C" int ssac_linear_dgrad(const float *dY, int64_t ldy, const float *W, int64_t ldw, float *dX,
                                  int64_t ldx, int M, int N_in, int K_out, void *stream) {
     GemmArgs g{};

@@ -379,6 +379,22 @@ int ssac_col2im(const float *dcol, float *dx, int64_t sb, int64_t sc, int64_t sy
 /* Y = act(X W^T + b), X (M x K), W (N x K): F.conv2d on patches / nn.Linear (cnns.py:61-66,98-102). */
 int ssac_linear_fwd(const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, float *Y,
                     int64_t ldy, int M, int N, int K, int relu, void *stream);
+/* ---- implicit-GEMM convolutions (csrc/ssac_conv_implicit.hip) for layers with ci % 32 == 0 and co % 32 == 0:
+ * channels-last fp32 activations (B, H, W, C), nn.Conv2d weights (co, ci, k, k) used in place, no padding,
+ * stride s; the patch gather happens in the operand loads, no column matrix is materialised.
+ *   ssac_conv_fwd   y = relu(conv(x) + bias)                                  (cnns.py:59-66, 96-100)
+ *   ssac_conv_dgrad dx = [x_mask > 0] * conv_transpose(dy)    (x_mask = this layer's input = previous ReLU output)
+ *   ssac_conv_wgrad partial_w[slice] (co,ci,k,k), partial_b[slice] (co) over slices of pix_per_slice (multiple
+ *                   of 32) output pixels; sum them with ssac_reduce_slices (fixed order). */
+int ssac_conv_implicit_supported(int ci, int co, int k);
+int ssac_conv_fwd(const float *x, const float *w, const float *bias, float *y, int B, int Hi, int Wi, int ci, int co,
+                  int k, int s, void *stream);
+int ssac_conv_dgrad(const float *dy, const float *w, const float *x_mask, float *dx, int B, int Hi, int Wi, int ci,
+                    int co, int k, int s, void *stream);
+int ssac_conv_wgrad_slices(int B, int Ho, int Wo, int pix_per_slice);
+int ssac_conv_wgrad(const float *dy, const float *x, float *partial_w, float *partial_b, int B, int Hi, int Wi,
+                    int ci, int co, int k, int s, int pix_per_slice, void *stream);
+
 /* split-K forward for short, very deep problems (the pixel encoders' fc over the flattened feature map):
  * partial (slices x M x N) = X[:, slice] W[:, slice]^T per K slice of k_per_slice (multiple of 32) columns;
  * ssac_reduce_slices_bias then writes Y[m*ld_out + n] = bias[n] + sum over slices, in a fixed order. */

@@ -91,6 +91,11 @@ SIGNATURES = {
     "ssac_im2col": [_P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P],
     "ssac_col2im": [_P, _P, _L, _L, _L, _L, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P],
     "ssac_linear_fwd": [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _P],
+    "ssac_conv_implicit_supported": [_I, _I, _I],
+    "ssac_conv_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ssac_conv_dgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "ssac_conv_wgrad_slices": [_I, _I, _I, _I],
+    "ssac_conv_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "ssac_linear_fwd_splitk": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P],
     "ssac_reduce_slices_bias": [_P, _I, _I, _I, _P, _P, _L, _P],
     "ssac_linear_dgrad": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P],

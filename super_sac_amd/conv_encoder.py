@@ -20,6 +20,9 @@ import torch
 from . import engine
 from ._lib import check, lib
 
+import os
+
+USE_IMPLICIT = os.environ.get("SSAC_IMPLICIT_CONV", "1") == "1"  # implicit-GEMM inner conv layers
 FC_SLICES = 48  # K slices of the fc forward (8 row tiles x 48 slices ~ 1.5 workgroups per CU at B 512)
 ROWS_PER_SLICE = 4096  # split-K granularity of the convolution weight gradients
 
@@ -42,6 +45,9 @@ class ConvEncoderEngine:
         self.big = hasattr(module, "ln")
         self.geom = [(c.in_channels, c.out_channels, c.kernel_size[0], c.stride[0]) for c in convs]
         self.emb = module.fc.out_features
+        # inner layers with 32-multiple channel counts run as implicit GEMMs (csrc/ssac_conv_implicit.hip)
+        self.implicit = [USE_IMPLICIT and l > 0 and bool(lib.ssac_conv_implicit_supported(ci, co, k))
+                         for l, (ci, co, k, s) in enumerate(self.geom)]
         self.div, self.shift = (255.0, -0.5) if self.big else (255.0, 0.0)
         # ---- flat parameter arena (each tensor starts at a multiple of 4 floats)
         plist = []
@@ -89,12 +95,19 @@ class ConvEncoderEngine:
         for l, (ci, co, k, s) in enumerate(self.geom):
             Ho, Wo = (Hi - k) // s + 1, (Wi - k) // s + 1
             rows, ckk = B * Ho * Wo, ci * k * k
-            col = self.ws.get(f"{tag}.col{l if save else 0}", (rows * ckk,))
             y = self.ws.get(f"{tag}.y{l if save else l % 2}", (rows * co,))
-            check(lib.ssac_im2col(src.data_ptr(), u8, *strides, B, ci, Hi, Wi, k, s, div, shift,
-                                  col.data_ptr(), st))
-            check(lib.ssac_linear_fwd(col.data_ptr(), ckk, self.convs[l].weight.data_ptr(), ckk,
-                                      self.convs[l].bias.data_ptr(), y.data_ptr(), co, rows, co, ckk, 1, st))
+            if l > 0 and self.implicit[l]:
+                # channels-last input straight from the previous layer: the patch gather happens in the operand
+                # loads of the implicit-GEMM kernel, no column matrix
+                col = None
+                check(lib.ssac_conv_fwd(src.data_ptr(), self.convs[l].weight.data_ptr(),
+                                        self.convs[l].bias.data_ptr(), y.data_ptr(), B, Hi, Wi, ci, co, k, s, st))
+            else:
+                col = self.ws.get(f"{tag}.col{l if save else 0}", (rows * ckk,))
+                check(lib.ssac_im2col(src.data_ptr(), u8, *strides, B, ci, Hi, Wi, k, s, div, shift,
+                                      col.data_ptr(), st))
+                check(lib.ssac_linear_fwd(col.data_ptr(), ckk, self.convs[l].weight.data_ptr(), ckk,
+                                          self.convs[l].bias.data_ptr(), y.data_ptr(), co, rows, co, ckk, 1, st))
             cols.append(col); ys.append(y); shapes.append((ci, co, k, s, Hi, Wi, Ho, Wo))
             src, strides = y, (Ho * Wo * co, 1, Wo * co, co)  # channels-last view of the GEMM output
             Hi, Wi, div, shift = Ho, Wo, 1.0, 0.0
@@ -172,21 +185,30 @@ class ConvEncoderEngine:
             slices = (rows + ROWS_PER_SLICE - 1) // ROWS_PER_SLICE
             pw = self.ws.get("b.pw", (slices * co * ckk,))
             pb = self.ws.get("b.pb", (slices * co,))
-            check(lib.ssac_linear_wgrad_splitk(dy.data_ptr(), co, sv["cols"][l].data_ptr(), ckk, pw.data_ptr(),
-                                               pb.data_ptr(), co, ckk, rows, ROWS_PER_SLICE, st))
+            if self.implicit[l]:
+                x_in = sv["ys"][l - 1]  # this layer's input = previous layer's ReLU output, channels-last
+                check(lib.ssac_conv_wgrad(dy.data_ptr(), x_in.data_ptr(), pw.data_ptr(), pb.data_ptr(), B, Hi, Wi,
+                                          ci, co, k, s, ROWS_PER_SLICE, st))
+            else:
+                check(lib.ssac_linear_wgrad_splitk(dy.data_ptr(), co, sv["cols"][l].data_ptr(), ckk, pw.data_ptr(),
+                                                   pb.data_ptr(), co, ckk, rows, ROWS_PER_SLICE, st))
             check(lib.ssac_reduce_slices(pw.data_ptr(), slices, co * ckk,
                                          self._seg(2 * l, self.grads).data_ptr(), st))
             check(lib.ssac_reduce_slices(pb.data_ptr(), slices, co, self._seg(2 * l + 1, self.grads).data_ptr(), st))
             if l == 0:
                 break
-            dcol = self.ws.get("b.dcol", (rows * ckk,))
-            check(lib.ssac_linear_dgrad(dy.data_ptr(), co, self.convs[l].weight.data_ptr(), ckk, dcol.data_ptr(),
-                                        ckk, rows, ckk, co, st))
             pci, pco, pk, ps, pHi, pWi, pHo, pWo = sv["shapes"][l - 1]
             dprev = self.ws.get(f"b.dy{(l - 1) % 2}", (B * pHo * pWo * pco,))
-            pcl = (pHo * pWo * pco, 1, pWo * pco, pco)
-            check(lib.ssac_col2im(dcol.data_ptr(), dprev.data_ptr(), *pcl, sv["ys"][l - 1].data_ptr(), *pcl,
-                                  B, ci, Hi, Wi, k, s, st))
+            if self.implicit[l]:
+                check(lib.ssac_conv_dgrad(dy.data_ptr(), self.convs[l].weight.data_ptr(), sv["ys"][l - 1].data_ptr(),
+                                          dprev.data_ptr(), B, Hi, Wi, ci, co, k, s, st))
+            else:
+                dcol = self.ws.get("b.dcol", (rows * ckk,))
+                check(lib.ssac_linear_dgrad(dy.data_ptr(), co, self.convs[l].weight.data_ptr(), ckk, dcol.data_ptr(),
+                                            ckk, rows, ckk, co, st))
+                pcl = (pHo * pWo * pco, 1, pWo * pco, pco)
+                check(lib.ssac_col2im(dcol.data_ptr(), dprev.data_ptr(), *pcl, sv["ys"][l - 1].data_ptr(), *pcl,
+                                      B, ci, Hi, Wi, k, s, st))
             dy = dprev
 
     # ------------------------------------------------------------------------------------

@@ -1,0 +1,326 @@
+// Implicit-GEMM convolutions for the pixel encoders' inner layers (nets/cnns.py:41-44, 76-78) on gfx950.
+//
+// The im2col + GEMM path (ssac_conv.hip) writes and re-reads a (B*Ho*Wo) x (ci*k*k) column matrix per layer --
+// 807 MB for DrQ's 32->32 3x3 layers at batch 512, nine times the feature map -- and is bound by that HBM
+// traffic.  Here the patch gather happens in the operand loads: activations are channels-last
+// (B, H, W, C) fp32, so the 32 channels of one input pixel are 128 contiguous bytes, and a K chunk of the GEMM is
+// "one (ky, kx) tap x one block of 32 input channels".  Every lane of a wave loads its own pixel's 16 floats per
+// chunk straight from global memory (the map is read ~k*k times, from L2), weights for the workgroup's 32 output
+// channels sit in LDS for the whole launch (persistent workgroups), and the product runs on
+// v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered).  Requirements: ci % 32 == 0, co % 32 == 0 (all layers
+// except the first, which reads the uint8 NCHW image and stays on im2col).
+//
+//   forward        y[b,oy,ox,co]  = relu(bias[co] + sum_{ky,kx,c} x[b, oy*s+ky, ox*s+kx, c] * W[co][c][ky][kx])
+//   backward-data  dx[b,iy,ix,c]  = [x[b,iy,ix,c] > 0] * sum_{ky,kx,co} dy[b,(iy-ky)/s,(ix-kx)/s,co] * W[co][c][ky][kx]
+//                  (x is the ReLU output of the previous layer, so the mask is the ReLU derivative)
+//   weight grad    dW[co][c][ky][kx] = sum_{b,oy,ox} dy[b,oy,ox,co] * x[b, oy*s+ky, ox*s+kx, c]   (split over
+//                  workgroups into partial slices, reduced in a fixed order by ssac_reduce_slices)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ssac_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int CV_THREADS = 256;   // 4 waves, each a 32-pixel x 32-channel output tile
+constexpr int CV_PIX = 128;       // pixels per workgroup tile
+constexpr int WL_LD = 36;         // LDS row stride of a weight row (32 floats + 4: conflict-free b128 reads)
+
+struct ConvArgs {
+    const float *x;      // (B, Hi, Wi, ci) channels-last          [fwd: input; dgrad: the layer input (mask)]
+    const float *w;      // (co, ci, k, k) nn.Conv2d layout
+    const float *bias;   // (co)
+    const float *dy;     // (B, Ho, Wo, co)                         [dgrad / wgrad]
+    float *out;          // fwd: y (B,Ho,Wo,co); dgrad: dx (B,Hi,Wi,ci)
+    int B, Hi, Wi, ci, Ho, Wo, co, k, s;
+};
+
+// chunk index -> (ky, kx, channel block)
+__device__ __forceinline__ void chunk_decode(int ch, int k, int cblocks, int &ky, int &kx, int &cb) {
+    cb = ch % cblocks;
+    const int t = ch / cblocks;
+    kx = t % k;
+    ky = t / k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: grid (persistent pixel tiles, co / 32)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CV_THREADS) void conv_fwd_kernel(ConvArgs g, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [chunks][32 co][WL_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int cblocks = g.ci >> 5, nch = g.k * g.k * cblocks, kk = g.k * g.k;
+    const int co0 = blockIdx.y * 32;
+    // weights of this workgroup's 32 output channels -> LDS, chunk-major, k (= channel within block) contiguous
+    for (int i = tid; i < nch * 32 * 32; i += CV_THREADS) {
+        const int c = i & 31, co = (i >> 5) & 31, ch = i >> 10;
+        int ky, kx, cb;
+        chunk_decode(ch, g.k, cblocks, ky, kx, cb);
+        wl[(ch * 32 + co) * WL_LD + c] = g.w[((int64_t)(co0 + co) * g.ci + cb * 32 + c) * kk + ky * g.k + kx];
+    }
+    __syncthreads();
+    const float bias = g.bias[co0 + li];
+    const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t m = (int64_t)tile * CV_PIX + wave * 32 + li;
+        const bool ok = m < M;
+        const int64_t mm = ok ? m : 0;
+        const int ox = (int)(mm % g.Wo);
+        const int64_t t = mm / g.Wo;
+        const int oy = (int)(t % g.Ho), b = (int)(t / g.Ho);
+        const float *base = g.x + (((int64_t)b * g.Hi + oy * g.s) * g.Wi + ox * g.s) * g.ci + lh * 16;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        f4 a[2][4];
+        {
+            const float *p = base;  // chunk 0 = (ky 0, kx 0, cb 0)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[0][q] = *reinterpret_cast<const f4 *>(p + 4 * q);
+        }
+        for (int ch = 0; ch < nch; ++ch) {
+            const int nx = min(ch + 1, nch - 1);  // unconditional (clamped) prefetch of the next chunk
+            int ky, kx, cb;
+            chunk_decode(nx, g.k, cblocks, ky, kx, cb);
+            const float *p = base + ((int64_t)ky * g.Wi + kx) * g.ci + cb * 32;
+            const int cur = ch & 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[cur ^ 1][q] = *reinterpret_cast<const f4 *>(p + 4 * q);
+            const f4 *bp = reinterpret_cast<const f4 *>(wl + (ch * 32 + li) * WL_LD + lh * 16);
+            f4 bf[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bf[q] = bp[q];
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tt >> 2][tt & 3], bf[tt >> 2][tt & 3], acc, 0, 0, 0);
+        }
+        // C layout: column = lane & 31 (output channel), rows (r & 3) + 8 (r >> 2) + 4 lh (pixel within the wave)
+        const int64_t m_wave = (int64_t)tile * CV_PIX + wave * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t mr = m_wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (mr < M) g.out[mr * g.co + co0 + li] = fmaxf(acc[r] + bias, 0.0f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward-data: grid (persistent input-pixel tiles, ci / 32)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CV_THREADS) void conv_dgrad_kernel(ConvArgs g, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [chunks][32 c][WL_LD] : W[co][c0+c][ky][kx], co contiguous
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int oblocks = g.co >> 5, nch = g.k * g.k * oblocks, kk = g.k * g.k;
+    const int c0 = blockIdx.y * 32;
+    for (int i = tid; i < nch * 32 * 32; i += CV_THREADS) {
+        const int o = i & 31, c = (i >> 5) & 31, ch = i >> 10;
+        int ky, kx, ob;
+        chunk_decode(ch, g.k, oblocks, ky, kx, ob);
+        wl[(ch * 32 + c) * WL_LD + o] = g.w[((int64_t)(ob * 32 + o) * g.ci + c0 + c) * kk + ky * g.k + kx];
+    }
+    __syncthreads();
+    const int64_t M = (int64_t)g.B * g.Hi * g.Wi;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t m = (int64_t)tile * CV_PIX + wave * 32 + li;
+        const bool ok = m < M;
+        const int64_t mm = ok ? m : 0;
+        const int ix = (int)(mm % g.Wi);
+        const int64_t t = mm / g.Wi;
+        const int iy = (int)(t % g.Hi), b = (int)(t / g.Hi);
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        // chunk (ky, kx, ob) reads dy[b, (iy-ky)/s, (ix-kx)/s, ob*32 + 16 lh ..]: valid taps only, else zeros
+        auto tap = [&](int ch, const float *&p) -> bool {
+            int ky, kx, ob;
+            chunk_decode(ch, g.k, oblocks, ky, kx, ob);
+            const int ny = iy - ky, nx = ix - kx;
+            const int oy = ny / g.s, ox = nx / g.s;
+            const bool v = ok && ny >= 0 && nx >= 0 && oy * g.s == ny && ox * g.s == nx && oy < g.Ho && ox < g.Wo;
+            p = g.dy + (v ? (((int64_t)b * g.Ho + oy) * g.Wo + ox) * g.co : 0) + ob * 32 + lh * 16;
+            return v;
+        };
+        f4 a[2][4];
+        {
+            const float *p;
+            const bool v = tap(0, p);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4 x = *reinterpret_cast<const f4 *>(p + 4 * q);
+                a[0][q] = v ? x : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        for (int ch = 0; ch < nch; ++ch) {
+            const float *p;
+            const bool v = tap(min(ch + 1, nch - 1), p);
+            const int cur = ch & 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4 x = *reinterpret_cast<const f4 *>(p + 4 * q);
+                a[cur ^ 1][q] = v ? x : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+            const f4 *bp = reinterpret_cast<const f4 *>(wl + (ch * 32 + li) * WL_LD + lh * 16);
+            f4 bf[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bf[q] = bp[q];
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tt >> 2][tt & 3], bf[tt >> 2][tt & 3], acc, 0, 0, 0);
+        }
+        const int64_t m_wave = (int64_t)tile * CV_PIX + wave * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t mr = m_wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (mr < M) {
+                const int64_t o = mr * g.ci + c0 + li;
+                g.out[o] = g.x[o] > 0.0f ? acc[r] : 0.0f;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: grid (pixel slices, ci / 32, co / 32); each workgroup owns the (32 co x 32 c x k x k) block of
+// dW for its slice of output pixels.  Wave w takes the taps t = w, w+4, ... (one 32x32 accumulator per tap).
+//   A = dy^T : lane (co, half) needs dy[pixel 16 half + t][co]      -> 16 scalar loads, 128 B coalesced per pixel
+//   B = x    : lane (c,  half) needs x[pixel 16 half + t + tap][c]  -> same
+// ---------------------------------------------------------------------------------------------
+constexpr int WG_MAX_TAPS = 4;  // taps per wave held in registers (k*k <= 16)
+
+__global__ __launch_bounds__(CV_THREADS) void conv_wgrad_kernel(ConvArgs g, int64_t pix_per_slice, float *partial_w,
+                                                                float *partial_b) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int kk = g.k * g.k;
+    const int c0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
+    const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
+    const int64_t m_lo = (int64_t)blockIdx.x * pix_per_slice, m_hi = min(M, m_lo + pix_per_slice);
+    f32x16 acc[WG_MAX_TAPS];
+#pragma unroll
+    for (int j = 0; j < WG_MAX_TAPS; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+    float bsum = 0.0f;
+    for (int64_t mc = m_lo; mc < m_hi; mc += 32) {
+        float av[16];
+        int64_t xoff[16];
+        {
+            // (b, oy, ox) of this lane's first pixel by division, the other 15 by stepping
+            const int64_t m_first = mc + lh * 16;
+            const int64_t mf = m_first < M ? m_first : 0;
+            int ox = (int)(mf % g.Wo);
+            const int64_t q = mf / g.Wo;
+            int oy = (int)(q % g.Ho), b = (int)(q / g.Ho);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int64_t m = m_first + t;
+                const bool ok = m < m_hi;
+                const float d = g.dy[(ok ? m : m_lo) * g.co + co0 + li];
+                av[t] = ok ? d : 0.0f;
+                xoff[t] = ok ? (((int64_t)b * g.Hi + oy * g.s) * g.Wi + ox * g.s) * g.ci + c0 + li : (int64_t)(c0 + li);
+                if (++ox == g.Wo) { ox = 0; if (++oy == g.Ho) { oy = 0; ++b; } }
+            }
+        }
+        if (wave == 0 && blockIdx.y == 0) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) bsum += av[t];
+        }
+#pragma unroll
+        for (int j = 0; j < WG_MAX_TAPS; ++j) {
+            const int tap = wave + 4 * j;
+            if (tap < kk) {
+                const int ky = tap / g.k, kx = tap - ky * g.k;
+                const int64_t toff = ((int64_t)ky * g.Wi + kx) * g.ci;
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], g.x[xoff[t] + toff], acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // partial_w[slice][co][c][ky][kx]
+    float *pw = partial_w + (int64_t)blockIdx.x * g.co * g.ci * kk;
+#pragma unroll
+    for (int j = 0; j < WG_MAX_TAPS; ++j) {
+        const int tap = wave + 4 * j;
+        if (tap < kk) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                pw[((int64_t)co * g.ci + c0 + li) * kk + tap] = acc[j][r];
+            }
+        }
+    }
+    if (wave == 0 && blockIdx.y == 0) {  // bias gradient: column sums of dy over this slice
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lh == 0) partial_b[(int64_t)blockIdx.x * g.co + co0 + li] = bsum;
+    }
+}
+
+int conv_ok(int ci, int co, int k) { return ci % 32 == 0 && co % 32 == 0 && k >= 1 && k * k <= 4 * WG_MAX_TAPS; }
+
+}  // namespace
+
+extern "C" int ssac_conv_implicit_supported(int ci, int co, int k) { return conv_ok(ci, co, k) ? 1 : 0; }
+
+extern "C" int ssac_conv_fwd(const float *x, const float *w, const float *bias, float *y, int B, int Hi, int Wi,
+                             int ci, int co, int k, int s, void *stream) {
+    if (!conv_ok(ci, co, k)) return ssac_fail("ssac_conv_fwd: needs ci % 32 == 0 and co % 32 == 0");
+    ConvArgs g{};
+    g.x = x; g.w = w; g.bias = bias; g.out = y; g.B = B; g.Hi = Hi; g.Wi = Wi; g.ci = ci; g.co = co; g.k = k; g.s = s;
+    g.Ho = (Hi - k) / s + 1; g.Wo = (Wi - k) / s + 1;
+    const int64_t M = (int64_t)B * g.Ho * g.Wo;
+    const int n_tiles = (int)((M + CV_PIX - 1) / CV_PIX);
+    const size_t lds = sizeof(float) * (size_t)k * k * (ci / 32) * 32 * WL_LD;
+    if (lds > 160 * 1024) return ssac_fail("ssac_conv_fwd: weight tile does not fit LDS");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)conv_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    const int gx = n_tiles < 1024 ? n_tiles : 1024;
+    SSAC_LAUNCH(conv_fwd_kernel, dim3(gx, co / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
+    return ssac_check_launch("conv_fwd");
+}
+
+extern "C" int ssac_conv_dgrad(const float *dy, const float *w, const float *x_mask, float *dx, int B, int Hi, int Wi,
+                               int ci, int co, int k, int s, void *stream) {
+    if (!conv_ok(ci, co, k)) return ssac_fail("ssac_conv_dgrad: needs ci % 32 == 0 and co % 32 == 0");
+    ConvArgs g{};
+    g.x = x_mask; g.w = w; g.dy = dy; g.out = dx; g.B = B; g.Hi = Hi; g.Wi = Wi; g.ci = ci; g.co = co; g.k = k; g.s = s;
+    g.Ho = (Hi - k) / s + 1; g.Wo = (Wi - k) / s + 1;
+    const int64_t M = (int64_t)B * Hi * Wi;
+    const int n_tiles = (int)((M + CV_PIX - 1) / CV_PIX);
+    const size_t lds = sizeof(float) * (size_t)k * k * (co / 32) * 32 * WL_LD;
+    if (lds > 160 * 1024) return ssac_fail("ssac_conv_dgrad: weight tile does not fit LDS");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)conv_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    const int gx = n_tiles < 1024 ? n_tiles : 1024;
+    SSAC_LAUNCH(conv_dgrad_kernel, dim3(gx, ci / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
+    return ssac_check_launch("conv_dgrad");
+}
+
+extern "C" int ssac_conv_wgrad_slices(int B, int Ho, int Wo, int pix_per_slice) {
+    const int64_t M = (int64_t)B * Ho * Wo;
+    return (int)((M + pix_per_slice - 1) / pix_per_slice);
+}
+
+extern "C" int ssac_conv_wgrad(const float *dy, const float *x, float *partial_w, float *partial_b, int B, int Hi,
+                               int Wi, int ci, int co, int k, int s, int pix_per_slice, void *stream) {
+    if (!conv_ok(ci, co, k)) return ssac_fail("ssac_conv_wgrad: needs ci % 32 == 0 and co % 32 == 0");
+    if (pix_per_slice <= 0 || (pix_per_slice & 31)) return ssac_fail("ssac_conv_wgrad: slice must be a multiple of 32");
+    ConvArgs g{};
+    g.x = x; g.dy = dy; g.B = B; g.Hi = Hi; g.Wi = Wi; g.ci = ci; g.co = co; g.k = k; g.s = s;
+    g.Ho = (Hi - k) / s + 1; g.Wo = (Wi - k) / s + 1;
+    const int slices = ssac_conv_wgrad_slices(B, g.Ho, g.Wo, pix_per_slice);
+    SSAC_LAUNCH(conv_wgrad_kernel, dim3(slices, ci / 32, co / 32), dim3(CV_THREADS), 0, (hipStream_t)stream, g,
+                (int64_t)pix_per_slice, partial_w, partial_b);
+    return ssac_check_launch("conv_wgrad");
+}

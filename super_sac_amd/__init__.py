@@ -30,6 +30,7 @@ from . import learning_utils  # noqa: E402,F401
 from . import learning  # noqa: E402,F401
 from . import adv_estimator  # noqa: E402,F401
 from . import checkpoint  # noqa: E402,F401
+from . import conv_encoder  # noqa: E402,F401
 from . import parallel  # noqa: E402,F401
 
 

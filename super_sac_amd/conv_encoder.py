@@ -23,6 +23,8 @@ from ._lib import check, lib
 import os
 
 USE_IMPLICIT = os.environ.get("SSAC_IMPLICIT_CONV", "1") == "1"  # implicit-GEMM inner conv layers
+IMPLICIT_MIN_ROWS = 200_000      # output pixels (B*Ho*Wo) from which the implicit-GEMM kernels pay off
+IMPLICIT_ROWS_PER_SLICE = 1024   # output pixels per weight-gradient slice (= per workgroup)
 FC_SLICES = 48  # K slices of the fc forward (8 row tiles x 48 slices ~ 1.5 workgroups per CU at B 512)
 ROWS_PER_SLICE = 4096  # split-K granularity of the convolution weight gradients
 
@@ -46,8 +48,12 @@ class ConvEncoderEngine:
         self.geom = [(c.in_channels, c.out_channels, c.kernel_size[0], c.stride[0]) for c in convs]
         self.emb = module.fc.out_features
         # inner layers with 32-multiple channel counts run as implicit GEMMs (csrc/ssac_conv_implicit.hip)
-        self.implicit = [USE_IMPLICIT and l > 0 and bool(lib.ssac_conv_implicit_supported(ci, co, k))
-                         for l, (ci, co, k, s) in enumerate(self.geom)]
+        # (stride-1 layers only: with a stride the transposed gather of the backward-data pass wastes (s*s-1)/(s*s)
+        # of its taps; small maps -- decided per call from the row count -- stay on im2col, whose column matrix
+        # then lives in the 256 MB Infinity Cache anyway)
+        self.implicit_ok = [USE_IMPLICIT and l > 0 and s == 1 and bool(lib.ssac_conv_implicit_supported(ci, co, k))
+                            for l, (ci, co, k, s) in enumerate(self.geom)]
+        self.implicit = list(self.implicit_ok)
         self.div, self.shift = (255.0, -0.5) if self.big else (255.0, 0.0)
         # ---- flat parameter arena (each tensor starts at a multiple of 4 floats)
         plist = []
@@ -96,7 +102,9 @@ class ConvEncoderEngine:
             Ho, Wo = (Hi - k) // s + 1, (Wi - k) // s + 1
             rows, ckk = B * Ho * Wo, ci * k * k
             y = self.ws.get(f"{tag}.y{l if save else l % 2}", (rows * co,))
-            if l > 0 and self.implicit[l]:
+            if save:
+                self.implicit[l] = self.implicit_ok[l] and rows >= IMPLICIT_MIN_ROWS
+            if self.implicit_ok[l] and rows >= IMPLICIT_MIN_ROWS:
                 # channels-last input straight from the previous layer: the patch gather happens in the operand
                 # loads of the implicit-GEMM kernel, no column matrix
                 col = None
@@ -182,13 +190,14 @@ class ConvEncoderEngine:
         for l in range(nconv - 1, -1, -1):
             ci, co, k, s, Hi, Wi, Ho, Wo = sv["shapes"][l]
             rows, ckk = B * Ho * Wo, ci * k * k
-            slices = (rows + ROWS_PER_SLICE - 1) // ROWS_PER_SLICE
+            rps = IMPLICIT_ROWS_PER_SLICE if self.implicit[l] else ROWS_PER_SLICE
+            slices = (rows + rps - 1) // rps
             pw = self.ws.get("b.pw", (slices * co * ckk,))
             pb = self.ws.get("b.pb", (slices * co,))
             if self.implicit[l]:
                 x_in = sv["ys"][l - 1]  # this layer's input = previous layer's ReLU output, channels-last
                 check(lib.ssac_conv_wgrad(dy.data_ptr(), x_in.data_ptr(), pw.data_ptr(), pb.data_ptr(), B, Hi, Wi,
-                                          ci, co, k, s, ROWS_PER_SLICE, st))
+                                          ci, co, k, s, rps, st))
             else:
                 check(lib.ssac_linear_wgrad_splitk(dy.data_ptr(), co, sv["cols"][l].data_ptr(), ckk, pw.data_ptr(),
                                                    pb.data_ptr(), co, ckk, rows, ROWS_PER_SLICE, st))

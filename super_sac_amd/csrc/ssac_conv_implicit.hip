@@ -56,11 +56,15 @@ __global__ __launch_bounds__(CV_THREADS) void conv_fwd_kernel(ConvArgs g, int n_
     const int cblocks = g.ci >> 5, nch = g.k * g.k * cblocks, kk = g.k * g.k;
     const int co0 = blockIdx.y * 32;
     // weights of this workgroup's 32 output channels -> LDS, chunk-major, k (= channel within block) contiguous
-    for (int i = tid; i < nch * 32 * 32; i += CV_THREADS) {
-        const int c = i & 31, co = (i >> 5) & 31, ch = i >> 10;
+    for (int ch = 0; ch < nch; ++ch) {
         int ky, kx, cb;
         chunk_decode(ch, g.k, cblocks, ky, kx, cb);
-        wl[(ch * 32 + co) * WL_LD + c] = g.w[((int64_t)(co0 + co) * g.ci + cb * 32 + c) * kk + ky * g.k + kx];
+        const float *src = g.w + ((int64_t)co0 * g.ci + cb * 32) * kk + ky * g.k + kx;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + u * CV_THREADS, c = i & 31, co = i >> 5;
+            wl[(ch * 32 + co) * WL_LD + c] = src[((int64_t)co * g.ci + c) * kk];
+        }
     }
     __syncthreads();
     const float bias = g.bias[co0 + li];
@@ -117,11 +121,15 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dgrad_kernel(ConvArgs g, int 
     const int li = lane & 31, lh = lane >> 5;
     const int oblocks = g.co >> 5, nch = g.k * g.k * oblocks, kk = g.k * g.k;
     const int c0 = blockIdx.y * 32;
-    for (int i = tid; i < nch * 32 * 32; i += CV_THREADS) {
-        const int o = i & 31, c = (i >> 5) & 31, ch = i >> 10;
+    for (int ch = 0; ch < nch; ++ch) {
         int ky, kx, ob;
         chunk_decode(ch, g.k, oblocks, ky, kx, ob);
-        wl[(ch * 32 + c) * WL_LD + o] = g.w[((int64_t)(ob * 32 + o) * g.ci + c0 + c) * kk + ky * g.k + kx];
+        const float *src = g.w + ((int64_t)(ob * 32) * g.ci + c0) * kk + ky * g.k + kx;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + u * CV_THREADS, o = i & 31, c = i >> 5;
+            wl[(ch * 32 + c) * WL_LD + o] = src[((int64_t)o * g.ci + c) * kk];
+        }
     }
     __syncthreads();
     const int64_t M = (int64_t)g.B * g.Hi * g.Wi;
@@ -282,7 +290,8 @@ extern "C" int ssac_conv_fwd(const float *x, const float *w, const float *bias, 
         (void)hipFuncSetAttribute((const void *)conv_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    const int gx = n_tiles < 1024 ? n_tiles : 1024;
+    const int cap = 512 / (co / 32) > 0 ? 512 / (co / 32) : 1;  // persistent: ~2 workgroups per CU in total
+    const int gx = n_tiles < cap ? n_tiles : cap;
     SSAC_LAUNCH(conv_fwd_kernel, dim3(gx, co / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
     return ssac_check_launch("conv_fwd");
 }
@@ -302,7 +311,8 @@ extern "C" int ssac_conv_dgrad(const float *dy, const float *w, const float *x_m
         (void)hipFuncSetAttribute((const void *)conv_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    const int gx = n_tiles < 1024 ? n_tiles : 1024;
+    const int cap = 512 / (ci / 32) > 0 ? 512 / (ci / 32) : 1;
+    const int gx = n_tiles < cap ? n_tiles : cap;
     SSAC_LAUNCH(conv_dgrad_kernel, dim3(gx, ci / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
     return ssac_check_launch("conv_dgrad");
 }

@@ -129,3 +129,17 @@ def test_afbc_and_per_match_reference(name, fused):
     finally:
         ssa.engine.USE_FUSED = old
     case_runner.compare_afbc(rec, case_runner.load_fixture(name))
+
+
+@pytest.mark.parametrize("name", ["drqv2_pixels", "atari_pixels"])
+def test_pixel_cases_with_implicit_gemm_convolutions(name):
+    """the pixel fixtures again with the implicit-GEMM kernels forced on for every eligible layer (the
+    automatic choice keeps maps this small on im2col)."""
+    import super_sac_amd as ssa
+    old = ssa.conv_encoder.IMPLICIT_MIN_ROWS
+    ssa.conv_encoder.IMPLICIT_MIN_ROWS = 0
+    try:
+        rec = case_runner.run_engine(name)
+    finally:
+        ssa.conv_encoder.IMPLICIT_MIN_ROWS = old
+    case_runner.compare(rec, case_runner.load_fixture(name), who=f"hip[{name},implicit-conv]")

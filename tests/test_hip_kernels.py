@@ -787,3 +787,41 @@ def test_lazy_td_inside_critic_launch_equals_td_kernel(ssa):
     ssa._lib.check(lib.ssac_critic_logs(outs[1][2].data_ptr(), N, tiles, B, float(N), 0, 0, 0, logs.data_ptr(),
                                         C.addressof(spec), logs[4:].data_ptr(), 0, st))
     _close(logs[4:7], logs_ref[:3], 1e-5, rtol=1e-5, what="td log statistics")
+
+
+@pytest.mark.parametrize("B,ci,co,k,s,H", [(3, 32, 32, 3, 1, 12), (2, 32, 64, 4, 2, 20), (5, 64, 64, 3, 1, 9),
+                                           (40, 32, 32, 3, 1, 13)])
+def test_implicit_gemm_convolution_matches_torch_conv2d(ssa, B, ci, co, k, s, H):
+    """csrc/ssac_conv_implicit.hip: forward (bias + ReLU), backward-data (with the input's ReLU mask) and the
+    sliced weight gradient against torch.nn.functional.conv2d + autograd on the CPU (fp32)."""
+    rng = np.random.RandomState(ci + co + k)
+    x = torch.from_numpy(rng.standard_normal((B, ci, H, H)).astype(np.float32)).clamp_min(0.0)  # a ReLU output
+    w = torch.from_numpy((rng.standard_normal((co, ci, k, k)) * 0.1).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(co).astype(np.float32) * 0.1)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.relu(F.conv2d(xr, wr, br, stride=s))
+    Ho = y_ref.shape[-1]
+    dy = torch.from_numpy(rng.standard_normal(tuple(y_ref.shape)).astype(np.float32))
+    # the kernels' backward entry points take dL/d(pre-activation) = dy * [y > 0]
+    dz = dy * (y_ref.detach() > 0)
+    y_ref.backward(dy)
+    lib, st = ssa._lib.lib, ssa.engine.stream()
+    assert lib.ssac_conv_implicit_supported(ci, co, k)
+    cl = lambda t: t.permute(0, 2, 3, 1).contiguous().to(DEV)  # channels-last
+    xd, wd, bd, dzd = cl(x), w.to(DEV), b.to(DEV), cl(dz)
+    yd = torch.empty(B, Ho, Ho, co, device=DEV)
+    ssa._lib.check(lib.ssac_conv_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), B, H, H, ci, co, k, s, st))
+    _close(yd.permute(0, 3, 1, 2), y_ref.detach(), 2e-5, rtol=1e-5, what="conv forward")
+    dxd = torch.empty(B, H, H, ci, device=DEV)
+    ssa._lib.check(lib.ssac_conv_dgrad(dzd.data_ptr(), wd.data_ptr(), xd.data_ptr(), dxd.data_ptr(), B, H, H, ci, co, k,
+                                       s, st))
+    want_dx = xr.grad * (x > 0)  # the kernel folds the previous layer's ReLU derivative in
+    _close(dxd.permute(0, 3, 1, 2), want_dx, 3e-5, rtol=1e-5, what="conv backward-data")
+    pps = 64
+    slices = int(lib.ssac_conv_wgrad_slices(B, Ho, Ho, pps))
+    pw = torch.zeros(slices, co, ci, k, k, device=DEV)
+    pb = torch.zeros(slices, co, device=DEV)
+    ssa._lib.check(lib.ssac_conv_wgrad(dzd.data_ptr(), xd.data_ptr(), pw.data_ptr(), pb.data_ptr(), B, H, H, ci, co, k,
+                                       s, pps, st))
+    _close(pw.sum(0), wr.grad, 2e-4, rtol=1e-4, what="conv weight gradient")
+    _close(pb.sum(0), br.grad, 2e-4, rtol=1e-4, what="conv bias gradient")

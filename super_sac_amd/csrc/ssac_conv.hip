@@ -103,6 +103,27 @@ __global__ void reduce_slices_kernel(const float *__restrict__ partial, int slic
     }
 }
 
+// the same sum for MANY slices (implicit-conv weight gradients: ~700 slices): 16 waves per workgroup, wave w
+// adds the slices z = w, w+16, ... of its 64 outputs, then the 16 partial sums are added in a fixed order --
+// a fixed reduction tree, so the result is still run-to-run deterministic.
+__global__ __launch_bounds__(1024) void reduce_slices_wide_kernel(const float *__restrict__ partial, int slices,
+                                                                  int64_t n, float *__restrict__ out) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    float s = 0.0f;
+    if (i < n)
+        for (int z = w; z < slices; z += 16) s += partial[(int64_t)z * n + i];
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && i < n) {
+        float t = red[0][lane];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][lane];
+        out[i] = t;
+    }
+}
+
 // out[m*ldo + n] = bias[n] + sum_s partial[(s*M + m)*N + n], fixed order
 __global__ void reduce_slices_bias_kernel(const float *__restrict__ partial, int slices, int M, int N,
                                           const float *__restrict__ bias, float *__restrict__ out, int64_t ldo) {
@@ -231,6 +252,11 @@ extern "C" int ssac_relu_mask(float *dy, const float *y, int64_t n, void *stream
 
 extern "C" int ssac_reduce_slices(const float *partial, int slices, int64_t n, float *out, void *stream) {
     if (n <= 0 || slices <= 0) return 0;
+    if (slices >= 64) {
+        SSAC_LAUNCH(reduce_slices_wide_kernel, dim3((unsigned)((n + 63) / 64)), dim3(1024), 0, ST, partial, slices, n,
+                    out);
+        return ssac_check_launch("reduce_slices");
+    }
     SSAC_LAUNCH(reduce_slices_kernel, dim3(grid_for(n)), dim3(256), 0, ST, partial, slices, n, out);
     return ssac_check_launch("reduce_slices");
 }

@@ -412,6 +412,11 @@ int ssac_linear_wgrad_splitk(const float *dY, int64_t ldy, const float *X, int64
                              void *stream);
 int ssac_reduce_slices(const float *partial, int slices, int64_t n, float *out, void *stream);
 int ssac_relu_mask(float *dy, const float *y, int64_t n, void *stream);
+int ssac_relu_mask_to(const float *dy, const float *y, int64_t n, float *out, void *stream);
+/* (n x channels x pixels) <-> (n x pixels x channels): the encoders' fc weight is stored in the reference's NCHW
+ * flatten order (cnns.py:63,98); a channels-last copy lets the fc read the last feature map in place. */
+int ssac_permute_cp(const float *src, float *dst, int n, int channels, int pixels, int to_channels_last,
+                    void *stream);
 /* sum of squares of x as ssac_sumsq_blocks() partials (feed ssac_clip_coef / ssac_group_norms) */
 int ssac_sumsq_blocks(void);
 int ssac_sumsq(const float *x, int64_t n, float *out_partials, void *stream);

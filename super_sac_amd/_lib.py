@@ -102,6 +102,8 @@ SIGNATURES = {
     "ssac_linear_wgrad_splitk": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _P],
     "ssac_reduce_slices": [_P, _I, _L, _P, _P],
     "ssac_relu_mask": [_P, _P, _L, _P],
+    "ssac_relu_mask_to": [_P, _P, _L, _P, _P],
+    "ssac_permute_cp": [_P, _P, _I, _I, _I, _I, _P],
     "ssac_sumsq_blocks": [],
     "ssac_sumsq": [_P, _L, _P, _P],
     "ssac_ln_tanh_fwd": [_P, _L, _P, _P, _I, _I, _P, _L, _P, _P, _P],

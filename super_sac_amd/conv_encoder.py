@@ -23,6 +23,7 @@ from ._lib import check, lib
 import os
 
 USE_IMPLICIT = os.environ.get("SSAC_IMPLICIT_CONV", "1") == "1"  # implicit-GEMM inner conv layers
+FC_CHANNELS_LAST = os.environ.get("SSAC_FC_CHANNELS_LAST", "1") == "1"  # fc reads the last map in place
 IMPLICIT_MIN_ROWS = 200_000      # output pixels (B*Ho*Wo) from which the implicit-GEMM kernels pay off
 IMPLICIT_ROWS_PER_SLICE = 1024   # output pixels per weight-gradient slice (= per workgroup)
 FC_SLICES = 48  # K slices of the fc forward (8 row tiles x 48 slices ~ 1.5 workgroups per CU at B 512)
@@ -121,8 +122,17 @@ class ConvEncoderEngine:
             Hi, Wi, div, shift = Ho, Wo, 1.0, 0.0
         co = self.geom[-1][1]
         flat_dim = co * Hi * Wi
-        colf = self.ws.get(f"{tag}.colf", (B * flat_dim,))
-        check(lib.ssac_im2col(src.data_ptr(), 0, *strides, B, co, Hi, Wi, Hi, 1, 1.0, 0.0, colf.data_ptr(), st))
+        fc = self.module.fc
+        if FC_CHANNELS_LAST:
+            # the last feature map IS the fc input once the weight's columns are put in channels-last order
+            # (emb x C x P -> emb x P x C, 7.8 MB for DrQ: cheaper than gathering B x C*P activations both ways)
+            colf = src
+            wfc = self.ws.get("fc.wcl", (self.emb * flat_dim,))
+            check(lib.ssac_permute_cp(fc.weight.data_ptr(), wfc.data_ptr(), self.emb, co, Hi * Wi, 1, st))
+        else:
+            colf = self.ws.get(f"{tag}.colf", (B * flat_dim,))
+            check(lib.ssac_im2col(src.data_ptr(), 0, *strides, B, co, Hi, Wi, Hi, 1, 1.0, 0.0, colf.data_ptr(), st))
+            wfc = fc.weight
         fc = self.module.fc
 
         def fc_forward(out_ptr, ld_out):
@@ -131,11 +141,11 @@ class ConvEncoderEngine:
             kps = max(32, ((flat_dim + FC_SLICES - 1) // FC_SLICES + 31) // 32 * 32)
             slices = (flat_dim + kps - 1) // kps
             if slices < 4:
-                check(lib.ssac_linear_fwd(colf.data_ptr(), flat_dim, fc.weight.data_ptr(), flat_dim,
+                check(lib.ssac_linear_fwd(colf.data_ptr(), flat_dim, wfc.data_ptr(), flat_dim,
                                           fc.bias.data_ptr(), out_ptr, ld_out, B, self.emb, flat_dim, 0, st))
                 return
             part = self.ws.get("fc.partial", (slices * B * self.emb,))
-            check(lib.ssac_linear_fwd_splitk(colf.data_ptr(), flat_dim, fc.weight.data_ptr(), flat_dim,
+            check(lib.ssac_linear_fwd_splitk(colf.data_ptr(), flat_dim, wfc.data_ptr(), flat_dim,
                                              part.data_ptr(), B, self.emb, flat_dim, kps, st))
             check(lib.ssac_reduce_slices_bias(part.data_ptr(), slices, B, self.emb, fc.bias.data_ptr(), out_ptr,
                                               ld_out, st))
@@ -151,7 +161,7 @@ class ConvEncoderEngine:
             xhat = rstd = None
             fc_forward(dst.data_ptr(), ld_dst)
         if save:
-            self.saved = dict(B=B, cols=cols, ys=ys, shapes=shapes, colf=colf, flat_dim=flat_dim,
+            self.saved = dict(B=B, cols=cols, ys=ys, shapes=shapes, colf=colf, wfc=wfc, flat_dim=flat_dim,
                               Hf=Hi, Wf=Wi, xhat=xhat, rstd=rstd, out=dst, ld_out=ld_dst)
 
     # ------------------------------------------------------------------------------------
@@ -174,19 +184,31 @@ class ConvEncoderEngine:
         else:
             dz = d_rep
         flat_dim = sv["flat_dim"]
-        # fc: weight gradient (K = B rows, one slice writes straight into the gradient arena)
-        check(lib.ssac_linear_wgrad_splitk(dz.data_ptr(), self.emb, sv["colf"].data_ptr(), flat_dim,
-                                           self._seg(k_fcw, self.grads).data_ptr(),
-                                           self._seg(k_fcb, self.grads).data_ptr(), self.emb, flat_dim, B, B, st))
-        dcolf = self.ws.get("b.dcolf", (B * flat_dim,))
-        check(lib.ssac_linear_dgrad(dz.data_ptr(), self.emb, self.module.fc.weight.data_ptr(), flat_dim,
-                                    dcolf.data_ptr(), flat_dim, B, flat_dim, self.emb, st))
         ci, co, k, s, Hi, Wi, Ho, Wo = sv["shapes"][-1]
         dy = self.ws.get(f"b.dy{(nconv - 1) % 2}", (B * Ho * Wo * co,))
         ylast = sv["ys"][-1]
-        cl = (Ho * Wo * co, 1, Wo * co, co)
-        check(lib.ssac_col2im(dcolf.data_ptr(), dy.data_ptr(), *cl, ylast.data_ptr(), *cl, B, co, Ho, Wo,
-                              sv["Hf"], 1, st))
+        dcolf = self.ws.get("b.dcolf", (B * flat_dim,))
+        if FC_CHANNELS_LAST:
+            # fc weight gradient in channels-last column order, then back to the parameter's (C, P) order
+            gcl = self.ws.get("fc.gcl", (self.emb * flat_dim,))
+            check(lib.ssac_linear_wgrad_splitk(dz.data_ptr(), self.emb, sv["colf"].data_ptr(), flat_dim,
+                                               gcl.data_ptr(), self._seg(k_fcb, self.grads).data_ptr(), self.emb,
+                                               flat_dim, B, B, st))
+            check(lib.ssac_permute_cp(gcl.data_ptr(), self._seg(k_fcw, self.grads).data_ptr(), self.emb, co,
+                                      Ho * Wo, 0, st))
+            check(lib.ssac_linear_dgrad(dz.data_ptr(), self.emb, sv["wfc"].data_ptr(), flat_dim,
+                                        dcolf.data_ptr(), flat_dim, B, flat_dim, self.emb, st))
+            check(lib.ssac_relu_mask_to(dcolf.data_ptr(), ylast.data_ptr(), B * flat_dim, dy.data_ptr(), st))
+        else:
+            # fc: weight gradient (K = B rows, one slice writes straight into the gradient arena)
+            check(lib.ssac_linear_wgrad_splitk(dz.data_ptr(), self.emb, sv["colf"].data_ptr(), flat_dim,
+                                               self._seg(k_fcw, self.grads).data_ptr(),
+                                               self._seg(k_fcb, self.grads).data_ptr(), self.emb, flat_dim, B, B, st))
+            check(lib.ssac_linear_dgrad(dz.data_ptr(), self.emb, self.module.fc.weight.data_ptr(), flat_dim,
+                                        dcolf.data_ptr(), flat_dim, B, flat_dim, self.emb, st))
+            cl = (Ho * Wo * co, 1, Wo * co, co)
+            check(lib.ssac_col2im(dcolf.data_ptr(), dy.data_ptr(), *cl, ylast.data_ptr(), *cl, B, co, Ho, Wo,
+                                  sv["Hf"], 1, st))
         for l in range(nconv - 1, -1, -1):
             ci, co, k, s, Hi, Wi, Ho, Wo = sv["shapes"][l]
             rows, ckk = B * Ho * Wo, ci * k * k

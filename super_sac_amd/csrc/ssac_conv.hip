@@ -137,6 +137,31 @@ __global__ void reduce_slices_bias_kernel(const float *__restrict__ partial, int
     }
 }
 
+// dst[n][p][c] = src[n][c][p]  (to_cl) or dst[n][c][p] = src[n][p][c]  (!to_cl): the fc weight (emb x C x P, the
+// NCHW flatten order of cnns.py:63,98) <-> the channels-last order the feature maps are stored in.
+__global__ void permute_cp_kernel(const float *__restrict__ src, float *__restrict__ dst, int N, int Cc, int P,
+                                  int to_cl) {
+    const int64_t per = (int64_t)Cc * P, total = per * N;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = i / per, r = i - n * per;
+        if (to_cl) {  // i indexes dst (p, c)
+            const int p = (int)(r / Cc), c = (int)(r - (int64_t)p * Cc);
+            dst[i] = src[n * per + (int64_t)c * P + p];
+        } else {      // i indexes dst (c, p)
+            const int c = (int)(r / P), p = (int)(r - (int64_t)c * P);
+            dst[i] = src[n * per + (int64_t)p * Cc + c];
+        }
+    }
+}
+
+// out = dy * [y > 0] (out may alias dy)
+__global__ void relu_mask_to_kernel(const float *__restrict__ dy, const float *__restrict__ y, int64_t n,
+                                    float *__restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = y[i] > 0.0f ? dy[i] : 0.0f;
+}
+
 // per-block partial sums of x^2 (for clip_grad_norm_ over an encoder's gradient arena)
 __global__ void sumsq_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
     __shared__ float red[4];
@@ -267,6 +292,21 @@ extern "C" int ssac_reduce_slices_bias(const float *partial, int slices, int M, 
     SSAC_LAUNCH(reduce_slices_bias_kernel, dim3(grid_for((int64_t)M * N)), dim3(256), 0, ST, partial, slices, M, N,
                 bias, out, ld_out);
     return ssac_check_launch("reduce_slices_bias");
+}
+
+extern "C" int ssac_permute_cp(const float *src, float *dst, int n, int channels, int pixels, int to_channels_last,
+                               void *stream) {
+    const int64_t total = (int64_t)n * channels * pixels;
+    if (total <= 0) return 0;
+    SSAC_LAUNCH(permute_cp_kernel, dim3(grid_for(total)), dim3(256), 0, ST, src, dst, n, channels, pixels,
+                to_channels_last);
+    return ssac_check_launch("permute_cp");
+}
+
+extern "C" int ssac_relu_mask_to(const float *dy, const float *y, int64_t n, float *out, void *stream) {
+    if (n <= 0) return 0;
+    SSAC_LAUNCH(relu_mask_to_kernel, dim3(grid_for(n)), dim3(256), 0, ST, dy, y, n, out);
+    return ssac_check_launch("relu_mask_to");
 }
 
 extern "C" int ssac_sumsq_blocks(void) { return 256; }

@@ -173,6 +173,14 @@ int ssac_mlp_wgrad_fc12(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                         float *adam_m, float *adam_v, const ssac_adam_ctl *ctl, float *grads, float *sumsq1,
                         float *sumsq0, int64_t sumsq_net_stride, float *target, float tau, void *stream);
 
+/* ssac_mlp_wgrad_fc12 plus the head layer's weight gradient (ssac_head_wgrad: out_dim <= 16, H2 / DQ) as extra
+ * workgroups of the SAME launch; sumsq2 points at the head's slots of the per-net sumsq row. */
+int ssac_mlp_wgrad_all(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X, int64_t ldx,
+                       int64_t x_net_stride, const float *H1, const float *H2, const float *DZ2, const float *DZ1,
+                       const float *DQ, int n_rows, float *adam_m, float *adam_v, const ssac_adam_ctl *ctl,
+                       float *grads, float *sumsq2, float *sumsq1, float *sumsq0, int64_t sumsq_net_stride,
+                       float *target, float tau, void *stream);
+
 /* ---- elementwise Adam over a whole arena from stored gradients (clip path):
  * g *= ctl->clip_coef first (torch.nn.utils.clip_grad_norm_, learning.py:122-128). */
 int ssac_adam_step(float *params, float *adam_m, float *adam_v, const float *grads, int64_t n,

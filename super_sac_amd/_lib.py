@@ -66,6 +66,7 @@ SIGNATURES = {
     "ssac_mlp_layer_wgrad": [_MP, _I, _P, _I, _P, _L, _L, _P, _L, _L, _I, _P, _P, _P, _P, _P, _L, _P, _F, _P],
     "ssac_group_norms": [_P, _I, _I, _P, _P, _P],
     "ssac_mlp_wgrad_fc12": [_MP, _P, _I, _P, _L, _L, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _P, _F, _P],
+    "ssac_mlp_wgrad_all": [_MP, _P, _I, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _F, _P],
     "ssac_gather_transition": [_P, _P, _I, _L, _P, _L, _P, _P, _P, _I, _P, _L, _P, _L, _P, _P, _P],
     "ssac_gather_transition_begin": [_P, _P, _I, _L, _P, _L, _P, _P, _I, _P, _L, _P, _L, _P, _P, _P, _P, _I, _P, _P],
     "ssac_adam_step": [_P, _P, _P, _P, _L, _P, _P],

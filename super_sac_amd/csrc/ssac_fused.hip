@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "ssac_internal.h"
+#include "ssac_head_wgrad.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1116,99 +1117,11 @@ int launch_fused(const FusedArgs &g, int n_sel, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------ head weight gradient + Adam
-// dW3[o][k] = sum_m dq[m][o] h2[m][k];  db3[o] = sum_m dq[m][o].  grid (ceil(H/64), n_sel), 256 thr.
+// (body in ssac_head_wgrad.h; the update path normally runs it inside the merged weight-gradient launch)
 constexpr int HW_GROUPS = 16;  // row groups per workgroup (1024 threads = 64 columns x 16 groups)
-__global__ __launch_bounds__(64 * HW_GROUPS) void head_wgrad_kernel(
-    float *params, int64_t net_stride, int hidden, int out_dim, int64_t off_w, int64_t off_b,
-    const int32_t *ids, const float *__restrict__ H2, const float *__restrict__ DQ, int n_rows,
-    float *am, float *av, const ssac_adam_ctl *ctl, float *grads, float *sumsq, int64_t sumsq_stride,
-    float *target, float tau) {
-    __shared__ float red[HW_GROUPS][64];
-    __shared__ float redb[HW_GROUPS];
-    __shared__ float ssred;
-    const int tid = threadIdx.x, kk = tid & 63, mg = tid >> 6;
-    const int e = blockIdx.y, k = blockIdx.x * 64 + kk;
-    const int net = ids ? ids[e] : e;
-    const int64_t base = (int64_t)net * net_stride;
-    const bool kok = k < hidden;
-    const float *h2 = H2 + (int64_t)e * n_rows * hidden + (kok ? k : 0);
-    const float *dq = DQ + (int64_t)e * n_rows * out_dim;
-    if (tid == 0) ssred = 0.0f;
-    float ss = 0.0f;
-    // one output row o at a time: out_dim is small (1 for continuous critics), rows are the long axis
-    for (int o = 0; o < out_dim; ++o) {
-        float acc = 0.0f, accb = 0.0f;
-        int m = mg;
-        for (; m + 7 * HW_GROUPS < n_rows; m += 8 * HW_GROUPS) {
-            float hv[8], dv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                hv[u] = h2[(int64_t)(m + u * HW_GROUPS) * hidden];
-                dv[u] = dq[(int64_t)(m + u * HW_GROUPS) * out_dim + o];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { acc += dv[u] * hv[u]; accb += dv[u]; }
-        }
-        for (; m < n_rows; m += HW_GROUPS) {
-            const float d = dq[(int64_t)m * out_dim + o];
-            acc += d * h2[(int64_t)m * hidden];
-            accb += d;
-        }
-        __syncthreads();
-        red[mg][kk] = acc;
-        if (kk == 0) redb[mg] = accb;
-        __syncthreads();
-        if (mg == 0) {
-            float gr = 0.0f;
-#pragma unroll
-            for (int q = 0; q < HW_GROUPS; ++q) gr += red[q][kk];
-            const ssac_adam_ctl c = grads ? ssac_adam_ctl{} : *ctl;
-            if (kok) {
-                ss += gr * gr;
-                const int64_t i = base + off_w + (int64_t)o * hidden + k;
-                if (grads) {
-                    grads[i] = gr;
-                } else {
-                    float g2 = gr;
-                    const float p = params[i];
-                    if (c.weight_decay != 0.0f) g2 = g2 + c.weight_decay * p;
-                    float mm = am[i], vv = av[i];
-                    mm = mm + (1.0f - c.beta1) * (g2 - mm);
-                    vv = vv * c.beta2 + (1.0f - c.beta2) * g2 * g2;
-                    const float pn = p - c.step_size * (mm / (sqrtf(vv) / c.bc2_sqrt + c.eps));
-                    am[i] = mm; av[i] = vv; params[i] = pn;
-                    if (target) target[i] = target[i] * (1.0f - tau) + pn * tau;
-                }
-            }
-            if (blockIdx.x == 0 && kk == 0) {  // bias gradient db3[o] = sum_m dq[m][o]
-                float gb = 0.0f;
-#pragma unroll
-                for (int q = 0; q < HW_GROUPS; ++q) gb += redb[q];
-                ss += gb * gb;
-                const int64_t i = base + off_b + o;
-                if (grads) {
-                    grads[i] = gb;
-                } else {
-                    float g2 = gb;
-                    const float p = params[i];
-                    if (c.weight_decay != 0.0f) g2 = g2 + c.weight_decay * p;
-                    float mm = am[i], vv = av[i];
-                    mm = mm + (1.0f - c.beta1) * (g2 - mm);
-                    vv = vv * c.beta2 + (1.0f - c.beta2) * g2 * g2;
-                    const float pn = p - c.step_size * (mm / (sqrtf(vv) / c.bc2_sqrt + c.eps));
-                    am[i] = mm; av[i] = vv; params[i] = pn;
-                    if (target) target[i] = target[i] * (1.0f - tau) + pn * tau;
-                }
-            }
-        }
-    }
-    if (sumsq) {
-        if (mg == 0) {  // wave 0 holds every contribution
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-            if (kk == 0) sumsq[(int64_t)e * sumsq_stride + blockIdx.x] = ss;
-        }
-    }
+__global__ __launch_bounds__(64 * HW_GROUPS) void head_wgrad_kernel(HeadWgradArgs a) {
+    __shared__ float lds[HW_GROUPS * 64 + HW_GROUPS];
+    head_wgrad_body<HW_GROUPS>(a, lds, blockIdx.x, blockIdx.y);
 }
 
 // ------------------------------------------------------------------ log finalisation (1 WG)
@@ -1377,9 +1290,9 @@ extern "C" int ssac_head_wgrad(const ssac_mlp *nets, const int32_t *net_ids, int
     int64_t off[6];
     ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, off);
     dim3 grid((nets->hidden + 63) / 64, n_sel);
-    SSAC_LAUNCH(head_wgrad_kernel, grid, dim3(64 * HW_GROUPS), 0, (hipStream_t)stream, nets->params,
-                       nets->net_stride, nets->hidden, nets->out_dim, off[4], off[5], net_ids, H2, DQ,
-                       n_rows, adam_m, adam_v, ctl, grads, sumsq, sumsq_net_stride, target, tau);
+    HeadWgradArgs a{nets->params, nets->net_stride, nets->hidden, nets->out_dim, off[4], off[5], net_ids, H2, DQ,
+                    n_rows, adam_m, adam_v, ctl, grads, sumsq, sumsq_net_stride, target, tau};
+    SSAC_LAUNCH(head_wgrad_kernel, grid, dim3(64 * HW_GROUPS), 0, (hipStream_t)stream, a);
     return ssac_check_launch("head_wgrad");
 }
 

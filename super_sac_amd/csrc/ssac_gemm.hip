@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "ssac_internal.h"
+#include "ssac_head_wgrad.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -386,11 +387,17 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
 
 // Two problems in ONE launch (the fc2 and fc1 weight gradients of an update): workgroups
 // [0, tiles0) work on g0, the rest on g1, so the small problem fills CUs the big one leaves idle.
-struct GemmPair { GemmArgs g0, g1; int tiles0; };
+// Optionally a third piece: the head layer's (VALU) weight gradient as `head_tiles` extra workgroups.
+struct GemmPair { GemmArgs g0, g1; int tiles0; int tiles01; int head_grid_x; HeadWgradArgs head; };
 
 template <bool A_KC, bool B_KC, int EPI, int KS>
 __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if ((int)blockIdx.x >= p.tiles01) {  // head-layer weight gradient + Adam beside the GEMM tiles
+        const int L = blockIdx.x - p.tiles01;
+        head_wgrad_body<4 * KS>(p.head, lds, L % p.head_grid_x, L / p.head_grid_x);
+        return;
+    }
     const bool first = (int)blockIdx.x < p.tiles0;
     const GemmArgs &g = first ? p.g0 : p.g1;
     const int L = first ? blockIdx.x : blockIdx.x - p.tiles0;
@@ -410,7 +417,8 @@ int launch_pair_ks(GemmPair &p, int batch0, int batch1, hipStream_t st) {
         attr_set = true;
     }
     p.tiles0 = p.g0.grid_x * p.g0.grid_y * batch0;
-    const int total = p.tiles0 + p.g1.grid_x * p.g1.grid_y * batch1;
+    p.tiles01 = p.tiles0 + p.g1.grid_x * p.g1.grid_y * batch1;
+    const int total = p.tiles01 + (p.head_grid_x > 0 ? p.head_grid_x * batch0 : 0);
     SSAC_LAUNCH((ens_gemm_pair_kernel<A_KC, B_KC, EPI, KS>), dim3(total), dim3(NTHREADS * KS), lds, st, p);
     return ssac_check_launch("ens_gemm_pair");
 }
@@ -542,16 +550,50 @@ bool build_wgrad_args(GemmArgs &g, const ssac_mlp *nets, int layer, const int32_
 
 // fc2 and fc1 weight gradients (+Adam/Polyak or gradient store) of every selected net in ONE launch.
 // sumsq1 / sumsq0: the layers' slots inside the per-net sumsq row (see ssac_mlp_layer_wgrad).
+static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X, int64_t ldx,
+                        int64_t x_net_stride, const float *H1, const float *DZ2, const float *DZ1,
+                        const float *H2, const float *DQ, int n_rows, float *adam_m, float *adam_v,
+                        const ssac_adam_ctl *ctl, float *grads, float *sumsq1, float *sumsq0, float *sumsq2,
+                        int64_t sumsq_net_stride, float *target, float tau, void *stream);
+
 extern "C" int ssac_mlp_wgrad_fc12(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
                                    int64_t ldx, int64_t x_net_stride, const float *H1, const float *DZ2,
                                    const float *DZ1, int n_rows, float *adam_m, float *adam_v,
                                    const ssac_adam_ctl *ctl, float *grads, float *sumsq1, float *sumsq0,
                                    int64_t sumsq_net_stride, float *target, float tau, void *stream) {
+    return wgrad_merged(nets, net_ids, n_sel, X, ldx, x_net_stride, H1, DZ2, DZ1, nullptr, nullptr, n_rows, adam_m,
+                        adam_v, ctl, grads, sumsq1, sumsq0, nullptr, sumsq_net_stride, target, tau, stream);
+}
+
+extern "C" int ssac_mlp_wgrad_all(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
+                                  int64_t ldx, int64_t x_net_stride, const float *H1, const float *H2,
+                                  const float *DZ2, const float *DZ1, const float *DQ, int n_rows, float *adam_m,
+                                  float *adam_v, const ssac_adam_ctl *ctl, float *grads, float *sumsq2,
+                                  float *sumsq1, float *sumsq0, int64_t sumsq_net_stride, float *target, float tau,
+                                  void *stream) {
+    if (!nets || nets->out_dim > 16) return ssac_fail("ssac_mlp_wgrad_all: head wider than 16 outputs");
+    if (!H2 || !DQ) return ssac_fail("ssac_mlp_wgrad_all: H2 / DQ missing");
+    return wgrad_merged(nets, net_ids, n_sel, X, ldx, x_net_stride, H1, DZ2, DZ1, H2, DQ, n_rows, adam_m, adam_v, ctl,
+                        grads, sumsq1, sumsq0, sumsq2, sumsq_net_stride, target, tau, stream);
+}
+
+static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X, int64_t ldx,
+                        int64_t x_net_stride, const float *H1, const float *DZ2, const float *DZ1,
+                        const float *H2, const float *DQ, int n_rows, float *adam_m, float *adam_v,
+                        const ssac_adam_ctl *ctl, float *grads, float *sumsq1, float *sumsq0, float *sumsq2,
+                        int64_t sumsq_net_stride, float *target, float tau, void *stream) {
     if (n_sel < 0 || n_sel > SSAC_MAX_NETS) return ssac_fail("ssac_mlp_wgrad_fc12: n_sel out of range");
     if (!grads && (!adam_m || !adam_v || !ctl)) return ssac_fail("ssac_mlp_wgrad_fc12: Adam state missing");
     if (n_sel == 0 || n_rows <= 0) return 0;
     const int H = nets->hidden;
     GemmPair p{};
+    if (H2) {  // head-layer weight gradient as extra workgroups of the same launch
+        int64_t off[6];
+        ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, off);
+        p.head = HeadWgradArgs{nets->params, nets->net_stride, nets->hidden, nets->out_dim, off[4], off[5], net_ids, H2,
+                               DQ, n_rows, adam_m, adam_v, ctl, grads, sumsq2, sumsq_net_stride, target, tau};
+        p.head_grid_x = (nets->hidden + 63) / 64;
+    }
     if (!build_wgrad_args(p.g0, nets, 1, net_ids, H1, H, (int64_t)n_rows * H, DZ2, H, (int64_t)n_rows * H, n_rows,
                           adam_m, adam_v, ctl, grads, sumsq1, sumsq_net_stride, target, tau) ||
         !build_wgrad_args(p.g1, nets, 0, net_ids, X, ldx, x_net_stride, DZ1, H, (int64_t)n_rows * H, n_rows,

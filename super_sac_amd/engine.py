@@ -21,7 +21,9 @@ SEGS = ("w1", "b1", "w2", "b2", "w3", "b3")
 PROFILE = {"tag": None, "events": [], "reps": 1}
 USE_FUSED = True  # tests flip this to exercise the per-layer kernels on fused-capable shapes
 # launch the head layer's (VALU) weight-gradient kernel as a parallel branch beside the fc2/fc1 GEMM launch
-HEAD_BRANCH = os.environ.get("SSAC_HEAD_BRANCH", "1") == "1"
+HEAD_BRANCH = os.environ.get("SSAC_HEAD_BRANCH", "0") == "1"
+# head + fc2 + fc1 weight gradients in one launch (the head's VALU workgroups fill CUs the GEMM tiles leave idle)
+MERGE_HEAD_WGRAD = os.environ.get("SSAC_MERGE_HEAD_WGRAD", "1") == "1"
 
 
 class CaptureCtx:
@@ -330,6 +332,13 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
 
     def ssp(layer):
         return 0 if sumsq is None else sumsq.data_ptr() + 4 * off[layer]
+    if O <= 16 and MERGE_HEAD_WGRAD:
+        # head (VALU), fc2 and fc1 weight gradients of every selected net: ONE launch
+        check(lib.ssac_mlp_wgrad_all(C.byref(d), ids, n_sel, X.data_ptr(), ldx, x_net_stride, h1.data_ptr(),
+                                     h2.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), dY.data_ptr(), n_rows, _ptr(m),
+                                     _ptr(v), ctl, _ptr(grads), ssp(2), ssp(1), ssp(0), ttot, _ptr(target),
+                                     float(tau), st))
+        return
     if O <= 16:
         # the head's weight gradient is an independent VALU kernel: run it beside the GEMM launch below
         import contextlib

@@ -181,6 +181,18 @@ int ssac_mlp_wgrad_all(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, 
                        float *grads, float *sumsq2, float *sumsq1, float *sumsq0, int64_t sumsq_net_stride,
                        float *target, float tau, void *stream);
 
+/* ssac_mlp_wgrad_all (Adam mode) whose LAST workgroup to finish also does ssac_critic_logs' work (n_nets = n_sel;
+ * sumsq_all / n_sumsq: the whole per-net sumsq block for the gradient-norm log): the update ends with this launch.
+ * done_counter: one zero-initialised uint32 in device memory, reset by the launch itself. */
+int ssac_mlp_wgrad_all_logs(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X, int64_t ldx,
+                            int64_t x_net_stride, const float *H1, const float *H2, const float *DZ2,
+                            const float *DZ1, const float *DQ, int n_rows, float *adam_m, float *adam_v,
+                            const ssac_adam_ctl *ctl, float *sumsq2, float *sumsq1, float *sumsq0,
+                            int64_t sumsq_net_stride, float *target, float tau, const float *partials, int tiles,
+                            float denom, const float *sumsq_all, int n_sumsq, float *logs,
+                            const ssac_td_spec *lazy_td, float *td_logs, ssac_feed *feed, unsigned *done_counter,
+                            void *stream);
+
 /* ---- elementwise Adam over a whole arena from stored gradients (clip path):
  * g *= ctl->clip_coef first (torch.nn.utils.clip_grad_norm_, learning.py:122-128). */
 int ssac_adam_step(float *params, float *adam_m, float *adam_v, const float *grads, int64_t n,

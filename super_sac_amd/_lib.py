@@ -67,6 +67,8 @@ SIGNATURES = {
     "ssac_group_norms": [_P, _I, _I, _P, _P, _P],
     "ssac_mlp_wgrad_fc12": [_MP, _P, _I, _P, _L, _L, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _P, _F, _P],
     "ssac_mlp_wgrad_all": [_MP, _P, _I, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _F, _P],
+    "ssac_mlp_wgrad_all_logs": [_MP, _P, _I, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _P, _F,
+                                _P, _I, _F, _P, _I, _P, _P, _P, _P, _P, _P],
     "ssac_gather_transition": [_P, _P, _I, _L, _P, _L, _P, _P, _P, _I, _P, _L, _P, _L, _P, _P, _P],
     "ssac_gather_transition_begin": [_P, _P, _I, _L, _P, _L, _P, _P, _I, _P, _L, _P, _L, _P, _P, _P, _P, _I, _P, _P],
     "ssac_adam_step": [_P, _P, _P, _P, _L, _P, _P],

@@ -28,6 +28,7 @@
 
 #include "ssac_internal.h"
 #include "ssac_head_wgrad.h"
+#include "ssac_critic_logs.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1124,74 +1125,10 @@ __global__ __launch_bounds__(64 * HW_GROUPS) void head_wgrad_kernel(HeadWgradArg
     head_wgrad_body<HW_GROUPS>(a, lds, blockIdx.x, blockIdx.y);
 }
 
-// ------------------------------------------------------------------ log finalisation (1 WG)
-__global__ __launch_bounds__(256) void critic_logs_kernel(const float *__restrict__ partials, int n_nets,
-                                                          int tiles, int n_rows, float denom,
-                                                          const float *__restrict__ sumsq, int n_ss,
-                                                          const ssac_adam_ctl *scale, float *logs,
-                                                          ssac_td_spec tds, float *td_logs, ssac_feed *feed) {
-    __shared__ float red[3][4];
-    if (tds.q_t && td_logs) {  // statistics of the targets the critic launch computed (td_target_kernel's logs)
-        float s_td = 0.f, s_b = 0.f;
-        const float alpha = tds.use_entropy ? expf(tds.log_alpha[0]) : 0.0f;
-        for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
-            s_td += tds.td_out[b];
-            s_b += tds.use_entropy ? alpha * tds.logp[b] : 0.0f;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { s_td += __shfl_xor(s_td, o, 64); s_b += __shfl_xor(s_b, o, 64); }
-        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s_td; red[1][threadIdx.x >> 6] = s_b; }
-        __syncthreads();
-        const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)n_rows;
-        const float mb = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)n_rows;
-        __syncthreads();
-        float sv = 0.f;
-        for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
-            const float dlt = tds.td_out[b] - mean;
-            sv += dlt * dlt;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
-        if ((threadIdx.x & 63) == 0) red[2][threadIdx.x >> 6] = sv;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float var = (red[2][0] + red[2][1] + red[2][2] + red[2][3]) / (float)(n_rows > 1 ? n_rows - 1 : 1);
-            td_logs[0] = mean;
-            td_logs[1] = sqrtf(var);
-            td_logs[2] = mb;
-        }
-        __syncthreads();
-    }
-    float sl = 0.f, se = 0.f, ss = 0.f;
-    const int tot = n_nets * tiles;
-    for (int i = threadIdx.x; i < tot; i += blockDim.x) {
-        sl += partials[2 * i];
-        if (i / tiles == n_nets - 1) se += partials[2 * i + 1];
-    }
-    for (int i = threadIdx.x; i < n_ss; i += blockDim.x) ss += sumsq[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        sl += __shfl_xor(sl, o, 64); se += __shfl_xor(se, o, 64); ss += __shfl_xor(ss, o, 64);
-    }
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[0][w] = sl; red[1][w] = se; red[2][w] = ss; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        sl = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        se = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        ss = red[2][0] + red[2][1] + red[2][2] + red[2][3];
-        logs[0] += sl / (denom * (float)n_rows);   // losses/critic_overall_loss (accumulates over members)
-        logs[1] = se / (float)n_rows;              // losses/last_member_critic_td_error
-        if (sumsq) logs[2] = sqrtf(ss) * (scale ? scale->clip_coef : 1.0f);
-    }
-    if (feed) {  // last launch of a captured update: publish the log block, advance the input ring
-        __syncthreads();
-        const int slot = (int)feed->dst[feed->log_slot_word];
-        const int w = feed->log_width;
-        if ((int)threadIdx.x < w) feed->log_ring[(int64_t)slot * w + threadIdx.x] = logs[threadIdx.x];
-        __syncthreads();
-        if (threadIdx.x == 0) feed->tick += 1;
-    }
+// ------------------------------------------------------------------ log finalisation (1 WG; body in ssac_critic_logs.h)
+__global__ __launch_bounds__(256) void critic_logs_kernel(CriticLogsArgs a) {
+    __shared__ float red[12];
+    critic_logs_body(a, red);
 }
 
 }  // namespace
@@ -1302,9 +1239,8 @@ extern "C" int ssac_critic_logs(const float *partials, int n_nets, int tiles, in
                                 const float *sumsq, int n_sumsq, const ssac_adam_ctl *scale_by_clip,
                                 float *logs, const ssac_td_spec *lazy_td, float *td_logs, ssac_feed *feed,
                                 void *stream) {
-    ssac_td_spec tds{};
-    if (lazy_td) tds = *lazy_td;
-    SSAC_LAUNCH(critic_logs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, n_nets,
-                       tiles, n_rows, denom, sumsq, n_sumsq, scale_by_clip, logs, tds, td_logs, feed);
+    CriticLogsArgs a{partials, n_nets, tiles, n_rows, denom, sumsq, n_sumsq, scale_by_clip, logs, {}, td_logs, feed};
+    if (lazy_td) a.tds = *lazy_td;
+    SSAC_LAUNCH(critic_logs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     return ssac_check_launch("critic_logs");
 }

@@ -20,6 +20,7 @@
 
 #include "ssac_internal.h"
 #include "ssac_head_wgrad.h"
+#include "ssac_critic_logs.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -388,7 +389,11 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
 // Two problems in ONE launch (the fc2 and fc1 weight gradients of an update): workgroups
 // [0, tiles0) work on g0, the rest on g1, so the small problem fills CUs the big one leaves idle.
 // Optionally a third piece: the head layer's (VALU) weight gradient as `head_tiles` extra workgroups.
-struct GemmPair { GemmArgs g0, g1; int tiles0; int tiles01; int head_grid_x; HeadWgradArgs head; };
+// And optionally the update's log finalisation, run by whichever workgroup finishes LAST (device counter).
+struct GemmPair {
+    GemmArgs g0, g1; int tiles0; int tiles01; int head_grid_x; HeadWgradArgs head;
+    unsigned *done; CriticLogsArgs logs;  // done != null: the last workgroup runs critic_logs_body(logs)
+};
 
 template <bool A_KC, bool B_KC, int EPI, int KS>
 __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p) {
@@ -396,14 +401,27 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
     if ((int)blockIdx.x >= p.tiles01) {  // head-layer weight gradient + Adam beside the GEMM tiles
         const int L = blockIdx.x - p.tiles01;
         head_wgrad_body<4 * KS>(p.head, lds, L % p.head_grid_x, L / p.head_grid_x);
-        return;
+    } else {
+        const bool first = (int)blockIdx.x < p.tiles0;
+        const GemmArgs &g = first ? p.g0 : p.g1;
+        const int L = first ? blockIdx.x : blockIdx.x - p.tiles0;
+        const int per = g.grid_x * g.grid_y;
+        const int bz = L / per, rem = L - bz * per;
+        ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % g.grid_x, rem / g.grid_x, bz);
     }
-    const bool first = (int)blockIdx.x < p.tiles0;
-    const GemmArgs &g = first ? p.g0 : p.g1;
-    const int L = first ? blockIdx.x : blockIdx.x - p.tiles0;
-    const int per = g.grid_x * g.grid_y;
-    const int bz = L / per, rem = L - bz * per;
-    ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % g.grid_x, rem / g.grid_x, bz);
+    if (p.done) {
+        // the workgroup that finishes last sees every other one's gradient-norm partials and finalises the logs
+        __shared__ int is_last;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) is_last = (atomicAdd(p.done, 1u) == gridDim.x - 1) ? 1 : 0;
+        __syncthreads();
+        if (is_last) {
+            if (threadIdx.x == 0) *p.done = 0;  // ready for the next launch
+            __threadfence();
+            critic_logs_body(p.logs, lds);
+        }
+    }
 }
 
 template <bool A_KC, bool B_KC, int EPI, int KS>
@@ -554,7 +572,26 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                         int64_t x_net_stride, const float *H1, const float *DZ2, const float *DZ1,
                         const float *H2, const float *DQ, int n_rows, float *adam_m, float *adam_v,
                         const ssac_adam_ctl *ctl, float *grads, float *sumsq1, float *sumsq0, float *sumsq2,
-                        int64_t sumsq_net_stride, float *target, float tau, void *stream);
+                        int64_t sumsq_net_stride, float *target, float tau, void *stream,
+                        const CriticLogsArgs *logs = nullptr, unsigned *done = nullptr);
+
+extern "C" int ssac_mlp_wgrad_all_logs(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
+                                       int64_t ldx, int64_t x_net_stride, const float *H1, const float *H2,
+                                       const float *DZ2, const float *DZ1, const float *DQ, int n_rows,
+                                       float *adam_m, float *adam_v, const ssac_adam_ctl *ctl, float *sumsq2,
+                                       float *sumsq1, float *sumsq0, int64_t sumsq_net_stride, float *target,
+                                       float tau, const float *partials, int tiles, float denom,
+                                       const float *sumsq_all, int n_sumsq, float *logs,
+                                       const ssac_td_spec *lazy_td, float *td_logs, ssac_feed *feed,
+                                       unsigned *done_counter, void *stream) {
+    if (!nets || nets->out_dim > 16) return ssac_fail("ssac_mlp_wgrad_all_logs: head wider than 16 outputs");
+    if (!H2 || !DQ || !partials || !logs || !done_counter)
+        return ssac_fail("ssac_mlp_wgrad_all_logs: missing argument");
+    CriticLogsArgs la{partials, n_sel, tiles, n_rows, denom, sumsq_all, n_sumsq, nullptr, logs, {}, td_logs, feed};
+    if (lazy_td) la.tds = *lazy_td;
+    return wgrad_merged(nets, net_ids, n_sel, X, ldx, x_net_stride, H1, DZ2, DZ1, H2, DQ, n_rows, adam_m, adam_v, ctl,
+                        nullptr, sumsq1, sumsq0, sumsq2, sumsq_net_stride, target, tau, stream, &la, done_counter);
+}
 
 extern "C" int ssac_mlp_wgrad_fc12(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
                                    int64_t ldx, int64_t x_net_stride, const float *H1, const float *DZ2,
@@ -581,7 +618,8 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                         int64_t x_net_stride, const float *H1, const float *DZ2, const float *DZ1,
                         const float *H2, const float *DQ, int n_rows, float *adam_m, float *adam_v,
                         const ssac_adam_ctl *ctl, float *grads, float *sumsq1, float *sumsq0, float *sumsq2,
-                        int64_t sumsq_net_stride, float *target, float tau, void *stream) {
+                        int64_t sumsq_net_stride, float *target, float tau, void *stream,
+                        const CriticLogsArgs *logs, unsigned *done) {
     if (n_sel < 0 || n_sel > SSAC_MAX_NETS) return ssac_fail("ssac_mlp_wgrad_fc12: n_sel out of range");
     if (!grads && (!adam_m || !adam_v || !ctl)) return ssac_fail("ssac_mlp_wgrad_fc12: Adam state missing");
     if (n_sel == 0 || n_rows <= 0) return 0;
@@ -594,6 +632,7 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                                DQ, n_rows, adam_m, adam_v, ctl, grads, sumsq2, sumsq_net_stride, target, tau};
         p.head_grid_x = (nets->hidden + 63) / 64;
     }
+    if (logs) { p.logs = *logs; p.done = done; }
     if (!build_wgrad_args(p.g0, nets, 1, net_ids, H1, H, (int64_t)n_rows * H, DZ2, H, (int64_t)n_rows * H, n_rows,
                           adam_m, adam_v, ctl, grads, sumsq1, sumsq_net_stride, target, tau) ||
         !build_wgrad_args(p.g1, nets, 0, net_ids, X, ldx, x_net_stride, DZ1, H, (int64_t)n_rows * H, n_rows,

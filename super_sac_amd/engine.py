@@ -315,8 +315,10 @@ def mlp_forward(arena, X, ldx, x_net_stride, n_rows, ws, tag, net_ids=None, n_se
 
 
 def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, adam=None, adam_key=None,
-                 grads=None, sumsq=None, target=None, tau=0.0, net_ids=None, n_sel=None):
-    """the three weight-gradient launches (+Adam/Polyak in their epilogues, or gradient store)."""
+                 grads=None, sumsq=None, target=None, tau=0.0, net_ids=None, n_sel=None, logs=None):
+    """the weight-gradient launch(es) (+Adam/Polyak in their epilogues, or gradient store).
+    logs (critic update, Adam mode, merged launch only): dict(partials, tiles, denom, logs, spec_ptr, td_logs_ptr,
+    feed, done) -- the launch's last workgroup then also finalises the update's logs; returns True when it did."""
     n_sel = arena.n_nets if n_sel is None else n_sel
     H, O = arena.hidden, arena.out_dim
     d = arena.desc()
@@ -332,6 +334,14 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
 
     def ssp(layer):
         return 0 if sumsq is None else sumsq.data_ptr() + 4 * off[layer]
+    if O <= 16 and MERGE_HEAD_WGRAD and logs is not None and grads is None and sumsq is not None:
+        check(lib.ssac_mlp_wgrad_all_logs(
+            C.byref(d), ids, n_sel, X.data_ptr(), ldx, x_net_stride, h1.data_ptr(), h2.data_ptr(), dz2.data_ptr(),
+            dz1.data_ptr(), dY.data_ptr(), n_rows, _ptr(m), _ptr(v), ctl, ssp(2), ssp(1), ssp(0), ttot, _ptr(target),
+            float(tau), logs["partials"].data_ptr(), logs["tiles"], float(logs["denom"]), sumsq.data_ptr(),
+            sumsq.numel(), logs["logs"].data_ptr(), logs["spec_ptr"], logs["td_logs_ptr"], logs["feed"],
+            logs["done"].data_ptr(), st))
+        return True
     if O <= 16 and MERGE_HEAD_WGRAD:
         # head (VALU), fc2 and fc1 weight gradients of every selected net: ONE launch
         check(lib.ssac_mlp_wgrad_all(C.byref(d), ids, n_sel, X.data_ptr(), ldx, x_net_stride, h1.data_ptr(),

@@ -57,6 +57,10 @@ class _LaunchList:
 FEED_SLOTS = 16  # pinned input ring of a captured update: how far the host may run ahead of the GPU
 # evaluate the TD target inside the critic launch instead of a launch of its own (continuous, no PopArt)
 FOLD_BEGIN = os.environ.get("SSAC_FOLD_BEGIN", "1") == "1"  # fold ssac_begin_update into the replay gather
+# Log finalisation inside the weight-gradient launch (its last workgroup to finish does it).  Off by default: the
+# device-scope fences the last-workgroup pattern needs write back / invalidate the per-XCD L2s on MI355X, and with
+# 17 MB of freshly written Adam state per launch that halves the update rate (4.8k vs 8.5k updates/s, measured).
+FOLD_LOGS = os.environ.get("SSAC_FOLD_LOGS", "0") == "1"
 LAZY_TD = os.environ.get("SSAC_LAZY_TD", "1") == "1"
 SPLIT_FORWARD = os.environ.get("SSAC_SPLIT_FORWARD", "0") == "1"
 
@@ -257,6 +261,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
     replay_dicts = []
     member_ss = []
     fused_logs = []
+    logs_done_in_wgrad = False
     for i in range(E):
         rd = lu.sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter,
                                         aug_mix=aug_mix, per=per)
@@ -348,8 +353,20 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                 check(lib.ssac_mlp_layer_dgrad(C.byref(arena.desc()), 0, 0, N, dz1.data_ptr(), H, B * H, 0, 0, 0,
                                                B, dX.data_ptr(), arena.in_dim, B * arena.in_dim, st))
                 _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, s_rep.shape[1], ws, slot, dev)
-            engine.weight_grads(arena, X, ldx, 0, h1, h2, dq, dz2, dz1, B, adam=adam,
-                                adam_key=("critic", i), grads=grads, sumsq=ss)
+            fold = None
+            if FOLD_LOGS and E == 1 and not critic_clip and shard is None:
+                # single member, no clipping: the weight-gradient launch's last workgroup finalises the logs
+                cap = engine.CAPTURE
+                fold = dict(partials=parts, tiles=tiles, denom=float(E * n_glob), logs=slot,
+                            spec_ptr=spec_ptr, td_logs_ptr=td._ssac_logs.data_ptr() if spec is not None else 0,
+                            feed=cap.feed if (cap is not None and cap.feed) else 0,
+                            done=ws.get("cu.done", (1,), dtype=torch.int32, zero=True))
+            folded = engine.weight_grads(arena, X, ldx, 0, h1, h2, dq, dz2, dz1, B, adam=adam,
+                                         adam_key=("critic", i), grads=grads, sumsq=ss, logs=fold)
+            if folded:
+                logs_done_in_wgrad = True
+                if fold["feed"]:
+                    engine.CAPTURE.published = True
             fused_logs.append((parts, N, tiles, B, n_glob, td))
         else:
             h1, h2, q = engine.mlp_forward(arena, X, ldx, 0, B, ws, tag)
@@ -382,7 +399,8 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
     clip_ctl = adam.ctl.ptr if critic_clip else 0
     done_norm = False
     for j, fl in enumerate(fused_logs):
-        if fl is None:
+        if fl is None or logs_done_in_wgrad:
+            done_norm = done_norm or logs_done_in_wgrad
             continue
         parts, n_, tiles_, b_, ng_, td_ = fl
         spec_ = getattr(td_, "_ssac_spec", None)

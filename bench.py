@@ -243,9 +243,11 @@ def main():
                "config": {"workload": "REDQ critic_update + Polyak/2: obs 17, act 6, batch 512, "
                                       "N=10 critics (n=2 target subset), hidden 256, replay 100k rows in HBM",
                           "global_batch": BATCH, "num_critics": NCRIT,
-                          "launch": (("recorded launch list (ssac_replay)" if ssa.learning.LAUNCH_MODE == "list"
-                                      else "HIP graph replay") if (world == 1 and graphs_were_on)
-                                     else "plain launches"),
+                          "launch": ("plain launches" if not graphs_were_on else
+                                     ("recorded launch list (ssac_replay)" + ("" if world == 1 else
+                                      ", MIN all-reduce between two segments")
+                                      if ssa.learning.LAUNCH_MODE == "list" and (world == 1 or ssa.learning.SHARDED_LISTS)
+                                      else ("HIP graph replay" if world == 1 else "plain launches"))),
                           "parallelism": "single GPU" if world == 1 else f"critic-ensemble sharded x{world}"},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:

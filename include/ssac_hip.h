@@ -337,7 +337,9 @@ int ssac_fused_row_tiles(const ssac_mlp *nets, int n_rows, int n_nets);
 int ssac_fused_tile_rows(int rows);
 
 /* y = MLP(x) for every selected net in ONE launch (agent.py:34 loop + mlps.py:123-129).
- * H1/H2 (n_sel x n_rows x hidden) are written when not NULL (needed by a later backward). */
+ * H1/H2 (n_sel x n_rows x hidden) are written when not NULL (needed by a later backward).  A negative entry of
+ * net_ids marks an empty slot: its rows of Y are set to +inf (the sharded update forwards only the REDQ subset
+ * members a rank owns but keeps a fixed launch shape). */
 int ssac_mlp3_fwd_fused(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
                         int64_t ldx, int64_t x_net_stride, int n_rows, float *H1, float *H2, float *Y,
                         void *stream);

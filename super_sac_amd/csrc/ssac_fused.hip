@@ -386,6 +386,16 @@ void fused_mlp_kernel(FusedArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e = blockIdx.y, m0 = blockIdx.x * TMR;
     const int net = g.ids ? g.ids[e] : e;
+    if (net < 0) {
+        // slot without a net (a REDQ subset member another rank owns): its outputs are +inf, the neutral
+        // element of the min that follows, so a sharded launch sequence is the same for every subset draw
+        if (MODE == MODE_PLAIN && g.Y)
+            for (int i = threadIdx.x; i < TMR * OUT; i += NTHR) {
+                const int r = i / OUT, o = i - r * OUT;
+                if ((m0 + r) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + r) * OUT + o] = __builtin_inff();
+            }
+        return;
+    }
     const float *P = g.params + (int64_t)net * g.net_stride;
     const float *X = g.X + (int64_t)e * g.sX;
     const int col0 = wave * 32;
@@ -800,6 +810,16 @@ __global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e = blockIdx.y, m0 = blockIdx.x * TMR;
     const int net = g.ids ? g.ids[e] : e;
+    if (net < 0) {
+        // slot without a net (a REDQ subset member another rank owns): its outputs are +inf, the neutral
+        // element of the min that follows, so a sharded launch sequence is the same for every subset draw
+        if (MODE == MODE_PLAIN && g.Y)
+            for (int i = threadIdx.x; i < TMR * OUT; i += NTHR) {
+                const int r = i / OUT, o = i - r * OUT;
+                if ((m0 + r) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + r) * OUT + o] = __builtin_inff();
+            }
+        return;
+    }
     const float *P = g.params + (int64_t)net * g.net_stride;
     const int col0 = wave * 32;
     constexpr bool BWD_ONLY = MODE == MODE_CRITIC_BWD;

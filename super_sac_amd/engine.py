@@ -37,6 +37,7 @@ class CaptureCtx:
         self.logblk = logblk
         self.feed = feed          # device address of the update's ssac_feed (0: inputs arrive by copy)
         self.published = False    # set once a captured launch has published the log block
+        self.collective = None    # callable(fn): ends the open recording, runs fn() now, opens the next segment
         self.defer_begin = False  # the replay gather will also do ssac_begin_update's work (vector buffers)
         self.pending_begin = None # (log block, adam ctl ptr) waiting for that gather
 

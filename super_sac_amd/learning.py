@@ -39,23 +39,39 @@ LAUNCH_MODE = os.environ.get("SSAC_LAUNCH_MODE", "list")
 
 
 class _LaunchList:
-    def __init__(self, handle):
+    """recorded launch segments with host callables (collectives of the sharded update) between them"""
+
+    def __init__(self):
+        self.parts = []  # list handles (int) and callables, in issue order
+
+    def add_list(self, handle):
         if not handle:
             raise RuntimeError("libssac_hip: " + lib.ssac_last_error().decode())
-        self.handle = handle
+        if lib.ssac_launch_list_size(handle) > 0:
+            self.parts.append(handle)
+        else:
+            lib.ssac_launch_list_free(handle)
 
     def replay(self):
-        check(lib.ssac_replay(self.handle, engine.stream()))
+        st = engine.stream()
+        for part in self.parts:
+            if callable(part):
+                part()
+            else:
+                check(lib.ssac_replay(part, st))
 
     def __del__(self):
-        try:
-            lib.ssac_launch_list_free(self.handle)
-        except Exception:
-            pass
+        for part in self.parts:
+            if not callable(part):
+                try:
+                    lib.ssac_launch_list_free(part)
+                except Exception:
+                    pass
 
 
 FEED_SLOTS = 16  # pinned input ring of a captured update: how far the host may run ahead of the GPU
 # evaluate the TD target inside the critic launch instead of a launch of its own (continuous, no PopArt)
+SHARDED_LISTS = os.environ.get("SSAC_SHARDED_LISTS", "1") == "1"  # recorded launch lists on critic-sharded ranks
 FOLD_BEGIN = os.environ.get("SSAC_FOLD_BEGIN", "1") == "1"  # fold ssac_begin_update into the replay gather
 # Log finalisation inside the weight-gradient launch (its last workgroup to finish does it).  Off by default: the
 # device-scope fences the last-workgroup pattern needs write back / invalidate the per-XCD L2s on MI355X, and with
@@ -121,10 +137,15 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
               weight_type=weight_type, pop=pop, augmenter=augmenter, encoder_lambda=encoder_lambda,
               random_process=random_process, noise_clip=noise_clip, aug_mix=aug_mix, discrete=discrete, per=per,
               update_priorities=update_priorities, dr3_coeff=dr3_coeff)
+    shard = parallel.shard_of(agent)
     graphable = (USE_GRAPHS and engine.CAPTURE is None and agent.ensemble_size == 1 and not per
-                 and not update_priorities
-                 and lu.is_identity(agent.encoder) and parallel.shard_of(agent) is None
-                 and random_process is None and torch.cuda.is_available())
+                 and not update_priorities and lu.is_identity(agent.encoder)
+                 and random_process is None and torch.cuda.is_available()
+                 # critic-sharded ranks: recorded launch lists only (the collective sits between two segments),
+                 # continuous actions on the fused kernels (empty subset slots, in-launch TD target)
+                 and (shard is None or (LAUNCH_MODE == "list" and SHARDED_LISTS and not discrete
+                                        and not any(agent.popart)
+                                        and agent.critics[0].arena(log_alphas[0].device).fused)))
     if not graphable:
         return _critic_update_eager(**kw)
     key = (id(buffer), id(target_agent), id(critic_optimizer), batch_size, float(gamma), critic_clip,
@@ -175,7 +196,8 @@ def _critic_update_graphed(gs, kw):
         # noise straight into the captured update's input buffer.  (Capturing the draw itself costs two extra
         # Philox-state kernels per replay on ROCm -- measured slower than this one eager launch.)
         rng.draw_normal_into(gs.eps_dev)
-    ids = rng.draw_subset(agent.num_critics, n_sub)
+    shard = parallel.shard_of(agent)
+    ids = rng.draw_subset(agent.num_critics if shard is None else shard.num_critics, n_sub)  # GLOBAL ensemble
     # ---- per-update inputs into this update's pinned slot
     k = gs.k % FEED_SLOTS
     if gs.events[k] is not None:
@@ -184,7 +206,8 @@ def _critic_update_graphed(gs, kw):
     gs.host_idx[k].copy_(idx_cpu)
     row = gs.host_i32[k]
     for j, v in enumerate(ids):
-        row[j] = v
+        # sharded: the LOCAL index of a subset member this rank owns, -1 for a member that lives elsewhere
+        row[j] = v if shard is None else (v - shard.lo if shard.owns(v) else -1)
     row[gs.n_pad] = slot_i
     if gs.graph is None:
         ctx = engine.CaptureCtx(idx_cpu, gs.idx_dev, ids, gs.ids_dev,
@@ -212,12 +235,20 @@ def _critic_update_graphed(gs, kw):
                 graph.replay()
             else:
                 # launch list: this call's launches run normally AND are recorded for the later calls
+                graph = _LaunchList()
+
+                def collective(fn):
+                    graph.add_list(lib.ssac_record_end())
+                    fn()
+                    graph.parts.append(fn)
+                    check(lib.ssac_record_begin())
+                ctx.collective = collective
                 check(lib.ssac_record_begin())
                 try:
                     logs, dicts = body()
                 finally:
                     handle = lib.ssac_record_end()
-                graph = _LaunchList(handle)
+                graph.add_list(handle)
         finally:
             engine.CAPTURE = None
         gs.graph, gs.dicts = graph, dicts

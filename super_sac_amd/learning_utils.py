@@ -396,9 +396,19 @@ def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag):
                                       save=False)
         return q1, len(ids)
     from . import parallel
-    local = shard.local_subset(ids)
     O = t_arena.out_dim
     qpart = ws.get(tag + ".qpart", (1, B, O))
+    cap = engine.CAPTURE
+    if cap is not None:
+        # recorded launch sequence: a fixed shape for every subset draw -- all len(ids) slots are forwarded, the
+        # per-update device id block holds the LOCAL index of the members this rank owns and -1 for the others
+        # (their outputs are +inf), and the collective runs between two recorded segments
+        n = len(ids)
+        _, _, q1 = engine.mlp_forward(t_arena, X, ldx, 0, B, ws, tag, net_ids=cap.ids_dev, n_sel=n, save=False)
+        _min_over_nets(q1, n, B * O, qpart)
+        cap.collective(lambda: parallel.all_reduce_min(qpart))
+        return qpart, 1
+    local = shard.local_subset(ids)
     if local:
         ids_dev = _upload_ids(ws, local, dev, f"sub{len(local)}")
         _, _, q1 = engine.mlp_forward(t_arena, X, ldx, 0, B, ws, tag, net_ids=ids_dev, n_sel=len(local),

@@ -261,6 +261,14 @@ int ssac_critic_loss_bwd(const float *q, int n_nets, int n_rows, int q_dim, cons
  * filter mask (A >= 0), PER priorities relu(A)+1e-4 (learning_utils.py:287-295), logs[0] = mean(mask). */
 int ssac_adv_filter(const float *q, int n_nets, int n_rows, int n_samples, const ssac_popart *popart, int use_max,
                     float *adv, float *mask, float *prio, float *logs, void *stream);
+/* discrete counterparts (adv_estimator.py:41-56 "indirect"; learning_utils.py:257-268): q (n_nets x n_rows x A),
+ * logits (n_actors x n_rows x A) of ALL ensemble actors (V uses their mean probabilities), act = action index. */
+int ssac_adv_filter_discrete(const float *q, int n_nets, int n_rows, int n_actions, const float *logits, int n_actors,
+                             const float *act, int64_t ld_act, const ssac_popart *popart, float *adv, float *mask,
+                             float *prio, float *logs, void *stream);
+int ssac_bc_discrete_bwd(const float *logits, const float *act, int64_t ld_act, const float *mask, int n_rows,
+                         int n_actions, float inv_members, float *d_logits, float *logs_member, float *logs_total,
+                         void *stream);
 /* filtered BC loss of one member and its gradient w.r.t. the actor output (learning_utils.py:241-269):
  * loss_i = -mean(log pi(a_data|s) * mask) with the data action's pre-tanh value atanh(clamp(a, +-0.99))
  * (distributions.py:74-84); d_out = dL/d(out) for L = sum_i loss_i * inv_members; logs_member[0] = loss_i,

@@ -601,7 +601,9 @@ def run_afbc_case(name, cfg):
     print(f"== {name}")
     torch.manual_seed(cfg["seed"]); np.random.seed(cfg["seed"]); random.seed(cfg["seed"])
     B, E, A = cfg["B"], cfg["E"], cfg["act"]
-    s, a, r, s1, d = synth.synth_transitions(cfg["rows"], cfg["obs"], cfg["act"], False, seed=cfg["seed"] + 100)
+    disc = bool(cfg["discrete"])
+    s, a, r, s1, d = synth.synth_transitions(cfg["rows"], cfg["obs"], cfg["act"], disc, seed=cfg["seed"] + 100,
+                                             n_actions=cfg["act"])
     rbuf = ref.replay.ReplayBuffer(cfg["cap"])
     rbuf.load_experience(s, a, r, s1, d)
     obuf = orc.ReplayOracle(cfg["cap"])
@@ -681,25 +683,26 @@ def run_afbc_case(name, cfg):
             idx, w = tree.sample(len(obuf), B)
         else:
             idx, w = torch.randint(len(rbuf), (B,)).numpy(), None
-        eps = [torch.randn(B, A) for _ in range(4)] if filt else None
+        eps = [torch.randn(B, A) for _ in range(4)] if (filt and not disc) else None
         random.choice(list(range(E)))              # random.choice(agent.actors) for the grad-norm log
         pm = random.choice(range(E)) if per else None
-        peps = [torch.randn(B, A) for _ in range(4)] if per else None
+        peps = [torch.randn(B, A) for _ in range(4)] if (per and not disc) else None
         torch.set_rng_state(st); np.random.set_state(nst); random.setstate(pst)
 
         advs.clear()
         rlogs = rl.offline_actor_update(
             buffer=rbuf, agent=ra, actor_optimizer=r_aopt, encoder_optimizer=r_eopt, batch_size=B,
             actor_clip=cfg["clip"], update_encoder=False, encoder_clip=cfg["clip"], augmenter=r_aug,
-            actor_lambda=0.0, aug_mix=0.0, premade_replay_dicts=None, per=per, discrete=False, filter_=filt)
+            actor_lambda=0.0, aug_mix=0.0, premade_replay_dicts=None, per=per, discrete=disc, filter_=filt)
         ologs, ord_, oprio, _ = orc.offline_actor_update(
             obuf, tree if per else None, oa, o_aopt, B, cfg["clip"], o_aug, 0.0, per=per, filter_=filt,
-            idx_list=[idx], eps_lists=[eps] if filt else None, prio_member=pm, prio_eps=peps)
+            idx_list=[idx], eps_lists=[eps] if (filt and not disc) else None, prio_member=pm, prio_eps=peps)
         rec[f"s{k}_per"], rec[f"s{k}_filter"] = np.int64(per), np.int64(filt)
         rec[f"s{k}_idx"] = np.asarray(idx, np.int64)
         if per:
             rec[f"s{k}_weights"] = np.asarray(w, np.float64)
-            rec[f"s{k}_prio_eps"] = torch.stack(peps).numpy()
+            if not disc:
+                rec[f"s{k}_prio_eps"] = torch.stack(peps).numpy()
             rec[f"s{k}_prio"] = np.asarray(oprio, np.float64)
             # the reference's trees after its own adjust_priorities
             leaves = np.array([rbuf._it_sum[int(j)] for j in idx], np.float64)
@@ -708,7 +711,8 @@ def run_afbc_case(name, cfg):
             assert np.allclose(leaves, tree.sum[tree.cap + idx], rtol=1e-4, atol=1e-6), "priority update mismatch"
             rec[f"s{k}_leaves"] = leaves
         if filt:
-            rec[f"s{k}_eps"] = torch.stack(eps).numpy()
+            if not disc:
+                rec[f"s{k}_eps"] = torch.stack(eps).numpy()
             rec[f"s{k}_adv"] = advs[0].numpy()
         for key, val in rlogs.items():
             if key.startswith("gradients/"):

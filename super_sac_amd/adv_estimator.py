@@ -35,8 +35,6 @@ class AdvantageEstimator:
     def evaluate(self, obs, action, ensemble_idx, want=("adv",), log_ptr=0):
         """dict with the requested (B,) device tensors among adv / mask / prio (one launch chain)."""
         engine.require_gpu()
-        if self.discrete:
-            raise NotImplementedError("discrete advantage estimate (adv_estimator.py:41-56) is not accelerated")
         agent, i = self.agent, ensemble_idx
         actor, critic, popart = agent.actors[i], agent.critics[i], agent.popart[i]
         s_rep = lu.encode(agent.encoder, obs)
@@ -44,6 +42,25 @@ class AdvantageEstimator:
         dev = s_rep.device
         ws = lu.agent_ws(agent, dev)
         st = engine.stream()
+        if self.discrete:
+            if self.discrete_method != "indirect":
+                raise NotImplementedError("dueling-architecture advantage (adv_estimator.py:37-39)")
+            nA = agent.act_space_size
+            E = len(agent.actors)
+            logits = ws.get("adv.logits", (E, B, nA))
+            for m, ac in enumerate(agent.actors):  # V(s) uses the mean probabilities of ALL ensemble actors
+                arena = engine.bind_arena(ac, "self", [ac], dev)
+                _, _, out = engine.mlp_forward(arena, s_rep, lu._row_stride(s_rep), 0, B, ws, f"adv.a{m}", save=False)
+                logits[m].copy_(out[0])
+            c_arena = critic.arena(dev)
+            _, _, q = engine.mlp_forward(c_arena, s_rep, lu._row_stride(s_rep), 0, B, ws, f"adv.c{i}", save=False)
+            res = {k_: ws.get(f"adv.{k_}{i}", (B,)) for k_ in want}
+            check(lib.ssac_adv_filter_discrete(q.data_ptr(), c_arena.n_nets, B, nA, logits.data_ptr(), E,
+                                               action.data_ptr(), action.stride(0), popart.ptr if popart else 0,
+                                               res["adv"].data_ptr() if "adv" in res else 0,
+                                               res["mask"].data_ptr() if "mask" in res else 0,
+                                               res["prio"].data_ptr() if "prio" in res else 0, log_ptr, st))
+            return res
         A = actor.action_size
         n = N_SAMPLES
         # stacked batch: block 0 = (s, a_data), blocks 1..n = (s, a_k)

@@ -425,6 +425,75 @@ __global__ __launch_bounds__(RED_THREADS) void bc_logprob_bwd_kernel(
     }
 }
 
+// discrete (indirect) advantage, adv_estimator.py:41-56: V(s) = sum_a mean_actors(pi)(a) * Q(s)_a with Q = min over
+// the member's critics (elementwise, then popart's w*q+b when present); A = Q(s)[a_data] - V(s).
+// q: (n_nets x n_rows x A); logits: (n_actors x n_rows x A), actor stride n_rows*A; act: the action index as float.
+__global__ __launch_bounds__(RED_THREADS) void adv_filter_discrete_kernel(
+    const float *__restrict__ q, int n_nets, int n_rows, int A, const float *__restrict__ logits, int n_actors,
+    const float *__restrict__ act, int64_t ld_act, const ssac_popart *popart, float *__restrict__ adv,
+    float *__restrict__ mask, float *__restrict__ prio, float *__restrict__ logs) {
+    __shared__ float scratch[16];
+    const float pw = popart ? popart->w : 1.0f, pb = popart ? popart->b : 0.0f;
+    float s_mask = 0.f;
+    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+        const int ai = (int)act[b * ld_act];
+        float value = 0.f, qd = 0.f;
+        for (int k = 0; k < A; ++k) {
+            float mq = q[(int64_t)b * A + k];
+            for (int j = 1; j < n_nets; ++j) mq = fminf(mq, q[((int64_t)j * n_rows + b) * A + k]);
+            if (popart) mq = pw * mq + pb;
+            float pk = 0.f;  // mean over the actors of softmax(logits)_k
+            for (int m = 0; m < n_actors; ++m) {
+                const float *x = logits + ((int64_t)m * n_rows + b) * A;
+                float mx = x[0];
+                for (int t = 1; t < A; ++t) mx = fmaxf(mx, x[t]);
+                float se = 0.f;
+                for (int t = 0; t < A; ++t) se += expf(x[t] - mx);
+                pk += expf(x[k] - mx) / se;
+            }
+            pk /= (float)n_actors;
+            value += pk * mq;
+            if (k == ai) qd = mq;
+        }
+        const float a = qd - value;
+        const float m = a >= 0.0f ? 1.0f : 0.0f;
+        if (adv) adv[b] = a;
+        if (mask) mask[b] = m;
+        if (prio) prio[b] = fmaxf(a, 0.0f) + 1e-4f;
+        s_mask += m;
+    }
+    const float tot = block_reduce<0>(s_mask, scratch);
+    if (threadIdx.x == 0 && logs) logs[0] = tot / (float)n_rows;
+}
+
+// discrete filtered BC (learning_utils.py:257-268): loss_i = -mean(log_softmax(logits)[a_data] * mask)
+__global__ __launch_bounds__(RED_THREADS) void bc_discrete_bwd_kernel(
+    const float *__restrict__ logits, const float *__restrict__ act, int64_t ld_act, const float *__restrict__ mask,
+    int n_rows, int A, float inv_members, float *__restrict__ d_logits, float *__restrict__ logs_member,
+    float *__restrict__ logs_total) {
+    __shared__ float scratch[16];
+    float s = 0.f;
+    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+        const float w = mask ? mask[b] : 1.0f;
+        const float coef = -w * inv_members / (float)n_rows;
+        const float *x = logits + (int64_t)b * A;
+        const int ai = (int)act[b * ld_act];
+        float mx = x[0];
+        for (int t = 1; t < A; ++t) mx = fmaxf(mx, x[t]);
+        float se = 0.f;
+        for (int t = 0; t < A; ++t) se += expf(x[t] - mx);
+        const float lse = mx + logf(se);
+        s += (x[ai] - lse) * w;
+        for (int t = 0; t < A; ++t) d_logits[(int64_t)b * A + t] = coef * ((t == ai ? 1.0f : 0.0f) - expf(x[t] - lse));
+    }
+    const float tot = block_reduce<0>(s, scratch);
+    if (threadIdx.x == 0) {
+        const float loss = -tot / (float)n_rows;
+        if (logs_member) logs_member[0] = loss;
+        if (logs_total) logs_total[0] += loss * inv_members;
+    }
+}
+
 // ------------------------------------------------------------------ actor loss gradients
 __global__ __launch_bounds__(RED_THREADS) void actor_loss_bwd_kernel(
     const float *__restrict__ q, int n_nets, int n_rows, const float *__restrict__ logp,
@@ -834,6 +903,24 @@ extern "C" int ssac_critic_loss_bwd(const float *q, int n_nets, int n_rows, int 
     SSAC_LAUNCH(critic_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_nets, n_rows,
                        q_dim, act, ld_act, td, weight, popart, pop, denom, dq, logs);
     return ssac_check_launch("critic_loss_bwd");
+}
+
+extern "C" int ssac_adv_filter_discrete(const float *q, int n_nets, int n_rows, int n_actions, const float *logits,
+                                        int n_actors, const float *act, int64_t ld_act, const ssac_popart *popart,
+                                        float *adv, float *mask, float *prio, float *logs, void *stream) {
+    if (n_nets < 1 || n_rows < 1 || n_actions < 1 || n_actors < 1) return ssac_fail("ssac_adv_filter_discrete: bad sizes");
+    SSAC_LAUNCH(adv_filter_discrete_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_nets, n_rows, n_actions, logits,
+                n_actors, act, ld_act, popart, adv, mask, prio, logs);
+    return ssac_check_launch("adv_filter_discrete");
+}
+
+extern "C" int ssac_bc_discrete_bwd(const float *logits, const float *act, int64_t ld_act, const float *mask,
+                                    int n_rows, int n_actions, float inv_members, float *d_logits,
+                                    float *logs_member, float *logs_total, void *stream) {
+    if (n_rows < 1 || n_actions < 1) return ssac_fail("ssac_bc_discrete_bwd: bad sizes");
+    SSAC_LAUNCH(bc_discrete_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, logits, act, ld_act, mask, n_rows, n_actions,
+                inv_members, d_logits, logs_member, logs_total);
+    return ssac_check_launch("bc_discrete_bwd");
 }
 
 extern "C" int ssac_adv_filter(const float *q, int n_nets, int n_rows, int n_samples, const ssac_popart *popart,

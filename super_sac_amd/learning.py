@@ -580,8 +580,6 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
     engine.require_gpu()
     if actor_lambda:
         raise NotImplementedError("action invariance constraint (SURVEY 8(f) rank 4) is not accelerated")
-    if discrete:
-        raise NotImplementedError("discrete filtered BC (adv_estimator.py:41-56) is not accelerated")
     if update_encoder and not lu.is_identity(agent.encoder):
         raise NotImplementedError("encoder training through the BC loss is not accelerated")
     E = agent.ensemble_size
@@ -613,11 +611,17 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
         a_arena = engine.bind_arena(actor, "self", [actor], dev)
         ah1, ah2, aout = engine.mlp_forward(a_arena, s_rep, lds, 0, B, ws, f"bc.a{i}")
         A = actor.action_size
-        d_out = ws.get(f"bc.dout{i}", (1, B, 2 * A))
-        check(lib.ssac_bc_logprob_bwd(aout.data_ptr(), 2 * A, a.data_ptr(), a.stride(0), mask_ptr, B, A,
-                                      float(actor.log_std_low), float(actor.log_std_high), inv_e,
-                                      d_out.data_ptr(), 2 * A, slot[lu.L_BC0 + i:].data_ptr(),
-                                      slot[lu.L_BC_TOTAL:].data_ptr(), st))
+        if discrete:
+            d_out = ws.get(f"bc.dout{i}", (1, B, A))
+            check(lib.ssac_bc_discrete_bwd(aout.data_ptr(), a.data_ptr(), a.stride(0), mask_ptr, B, A, inv_e,
+                                           d_out.data_ptr(), slot[lu.L_BC0 + i:].data_ptr(),
+                                           slot[lu.L_BC_TOTAL:].data_ptr(), st))
+        else:
+            d_out = ws.get(f"bc.dout{i}", (1, B, 2 * A))
+            check(lib.ssac_bc_logprob_bwd(aout.data_ptr(), 2 * A, a.data_ptr(), a.stride(0), mask_ptr, B, A,
+                                          float(actor.log_std_low), float(actor.log_std_high), inv_e,
+                                          d_out.data_ptr(), 2 * A, slot[lu.L_BC0 + i:].data_ptr(),
+                                          slot[lu.L_BC_TOTAL:].data_ptr(), st))
         logs[f"losses/filterd_bc_loss_{i}"] = slot[lu.L_BC0 + i]
         ttot = engine.wgrad_tiles_total(a_arena)
         ss = ws.get(f"bc.ss{i}", (ttot,))

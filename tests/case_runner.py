@@ -477,8 +477,9 @@ def run_afbc_oracle(name):
                 rec[f"s{k}_log:{key}"] = np.float64(v)
             continue
         per, filt = step
-        eps = [torch.from_numpy(e) for e in fx[f"s{k}_eps"]] if filt else None
-        peps = [torch.from_numpy(e) for e in fx[f"s{k}_prio_eps"]] if per else None
+        disc = bool(cfg["discrete"])
+        eps = [torch.from_numpy(e) for e in fx[f"s{k}_eps"]] if (filt and not disc) else None
+        peps = [torch.from_numpy(e) for e in fx[f"s{k}_prio_eps"]] if (per and not disc) else None
         if per:  # the oracle's own prioritised draw must reproduce the recorded one
             idx, w = tree.sample(len(obuf), B)
             rec[f"s{k}_idx"], rec[f"s{k}_weights"] = idx, w
@@ -488,7 +489,8 @@ def run_afbc_oracle(name):
             rec[f"s{k}_idx"] = idx
         logs, rd, prio, _ = orc.offline_actor_update(
             obuf, tree if per else None, oa, aopt, B, cfg["clip"], aug, 0.0, per=per, filter_=filt,
-            idx_list=[idx], eps_lists=[eps] if filt else None, prio_member=0 if per else None, prio_eps=peps)
+            idx_list=[idx], eps_lists=[eps] if (filt and not disc) else None, prio_member=0 if per else None,
+            prio_eps=peps)
         if per:
             rec[f"s{k}_prio"] = prio
             rec[f"s{k}_leaves"] = tree.sum[tree.cap + idx].copy()
@@ -558,15 +560,16 @@ def run_afbc_engine(name, device="cuda"):
             per, filt = step
             if not per:
                 player.idx.append(fx[f"s{k}_idx"])
-            if filt:
+            disc = bool(cfg["discrete"])
+            if filt and not disc:
                 player.normal.extend(list(fx[f"s{k}_eps"]))
-            if per:
+            if per and not disc:
                 player.normal.extend(list(fx[f"s{k}_prio_eps"]))
             buf.update_priorities = spy
             logs = ssa.learning.offline_actor_update(
                 buffer=buf, agent=agent, actor_optimizer=aopt, encoder_optimizer=eopt, batch_size=B,
                 actor_clip=cfg["clip"], update_encoder=False, encoder_clip=cfg["clip"], augmenter=aug,
-                actor_lambda=0.0, aug_mix=0.0, premade_replay_dicts=None, per=per, discrete=False, filter_=filt)
+                actor_lambda=0.0, aug_mix=0.0, premade_replay_dicts=None, per=per, discrete=disc, filter_=filt)
             buf.update_priorities = orig_upd
             if per:
                 rec[f"s{k}_idx"], rec[f"s{k}_prio"] = seen["idx"], seen["prio"]

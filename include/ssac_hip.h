@@ -261,6 +261,12 @@ int ssac_critic_loss_bwd(const float *q, int n_nets, int n_rows, int q_dim, cons
  * filter mask (A >= 0), PER priorities relu(A)+1e-4 (learning_utils.py:287-295), logs[0] = mean(mask). */
 int ssac_adv_filter(const float *q, int n_nets, int n_rows, int n_samples, const ssac_popart *popart, int use_max,
                     float *adv, float *mask, float *prio, float *logs, void *stream);
+/* DR3 regulariser (learning.py:100-108) on a stacked batch [ (s,a) rows 0..B-1 | (s',a') rows B..2B-1 ]:
+ * dz2 += coef * h2[partner row] through the ReLU mask, for both halves; partial[0..ssac_dr3_blocks()) receive
+ * per-block sums of sum_h h2[b][h] * h2[B+b][h] (the "dr3_dotproduct" log is their total / (n_nets * B)). */
+int ssac_dr3_blocks(void);
+int ssac_dr3_add(float *dz2, const float *h2, int n_nets, int batch, int hidden, float coef, float *partial,
+                 void *stream);
 /* discrete counterparts (adv_estimator.py:41-56 "indirect"; learning_utils.py:257-268): q (n_nets x n_rows x A),
  * logits (n_actors x n_rows x A) of ALL ensemble actors (V uses their mean probabilities), act = action index. */
 int ssac_adv_filter_discrete(const float *q, int n_nets, int n_rows, int n_actions, const float *logits, int n_actors,

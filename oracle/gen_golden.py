@@ -654,10 +654,11 @@ def run_afbc_case(name, cfg):
                 log_alphas=[rla], batch_size=B, gamma=cfg["gamma"], critic_clip=cfg["clip"], encoder_clip=cfg["clip"],
                 target_critic_ensemble_n=cfg["n"], weighted_bellman_temp=None, weight_type=None, pop=False,
                 augmenter=r_aug, encoder_lambda=0, aug_mix=0.0, discrete=False, random_process=None,
-                noise_clip=None, per=False, update_priorities=True, dr3_coeff=0.0)
+                noise_clip=None, per=False, update_priorities=True, dr3_coeff=cfg.get("dr3", 0.0))
             ologs, odicts = orc.critic_update(
                 obuf, oa, ot, o_copt, o_eopt, [ola], B, cfg["gamma"], cfg["clip"], cfg["clip"], cfg["n"], None, None,
-                False, o_aug, aug_mix=0.0, idx_list=[idx], eps_list=[ceps], subset_list=[sub])
+                False, o_aug, aug_mix=0.0, idx_list=[idx], eps_list=[ceps], subset_list=[sub],
+                dr3_coeff=cfg.get("dr3", 0.0))
             ord_ = odicts[-1]
             oadv = orc.advantage(oa, ord_["primary_batch"][0], ord_["primary_batch"][1], pm, peps)
             oprio = (torch.relu(oadv) + 1e-4).squeeze(1).numpy()

@@ -768,8 +768,11 @@ def compute_backup_weights(logs, batch, agent, target_agent, weight_type, temp, 
 def critic_update(buffer, agent, target_agent, critic_opt, encoder_opt, log_alphas, batch_size, gamma,
                   critic_clip, encoder_clip, target_n, temp, weight_type, pop, augmenter,
                   aug_mix=0.0, noise_scale=None, noise_clip=None, py_rng=_pyrandom,
-                  idx_list=None, eps_list=None, noise_list=None, subset_list=None):
+                  idx_list=None, eps_list=None, noise_list=None, subset_list=None, dr3_coeff=0.0):
     """One gradient update of every critic of every ensemble member.
+    dr3_coeff > 0 adds the DR3 feature co-adaptation term (learning.py:100-108): the fc2 features of every critic
+    on (s, a) dotted with its features on (s', a'), mean over critics and batch -- inside the member loop, i.e.
+    BEFORE the division by E*N.
     Host RNG order per member (matches the reference run): index draw (torch CPU) ->
     augmentation draw (torch CPU) -> action noise (eps) -> REDQ subset (python random)."""
     logs = {}
@@ -790,9 +793,9 @@ def critic_update(buffer, agent, target_agent, critic_opt, encoder_opt, log_alph
             noise = torch.randn(batch_size, agent.act_dim)
         subset = (subset_list[i] if subset_list is not None
                   else py_rng.sample(range(agent.N), k=target_n))
-        td, _ = compute_td_targets(logs, (o, a, r, o1, d), agent, target_agent, i, subset,
-                                   log_alphas[i], pop, gamma, eps=eps, noise_scale=noise_scale,
-                                   noise_clip=noise_clip, noise=noise)
+        td, (s1, a1) = compute_td_targets(logs, (o, a, r, o1, d), agent, target_agent, i, subset,
+                                          log_alphas[i], pop, gamma, eps=eps, noise_scale=noise_scale,
+                                          noise_clip=noise_clip, noise=noise)
         w = compute_backup_weights(logs, (o, a, r, o1, d), agent, target_agent, weight_type, temp,
                                    batch_size)
         s = encode(agent.encoder, o)
@@ -804,6 +807,14 @@ def critic_update(buffer, agent, target_agent, critic_opt, encoder_opt, log_alph
                 q = agent.popart[i](q)
             td_error = td - q
             loss = loss + (w * rd["imp_weights"] * td_error ** 2).mean()
+        if dr3_coeff > 0:
+            xa = s if agent.discrete else torch.cat((s, a), dim=-1)
+            x1 = s1 if agent.discrete else torch.cat((s1, a1), dim=-1)
+            f_sa = torch.stack([mlp3(p, xa)[1] for p in agent.critics[i]], 0)
+            f_s1 = torch.stack([mlp3(p, x1)[1] for p in agent.critics[i]], 0)
+            fca = (f_sa * f_s1).sum(-1).mean()
+            logs[f"dr3_dotproduct_{i}"] = fca.item()
+            loss = loss + dr3_coeff * fca
         rd["subset"] = subset
         rd["td_target"] = td
         dicts.append(rd)

@@ -81,6 +81,8 @@ SIGNATURES = {
     "ssac_det_action_fwd": [_P, _L, _P, _F, _P, _F, _F, _I, _I, _P, _L, _L, _P],
     "ssac_td_target": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _I, _P, _P, _P],
     "ssac_critic_loss_bwd": [_P, _I, _I, _I, _P, _L, _P, _P, _P, _I, _F, _P, _P, _P],
+    "ssac_dr3_blocks": [],
+    "ssac_dr3_add": [_P, _P, _I, _I, _I, _F, _P, _P],
     "ssac_adv_filter_discrete": [_P, _I, _I, _I, _P, _I, _P, _L, _P, _P, _P, _P, _P, _P],
     "ssac_bc_discrete_bwd": [_P, _P, _L, _P, _I, _I, _F, _P, _P, _P, _P],
     "ssac_adv_filter": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P],

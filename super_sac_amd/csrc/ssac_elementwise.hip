@@ -494,6 +494,30 @@ __global__ __launch_bounds__(RED_THREADS) void bc_discrete_bwd_kernel(
     }
 }
 
+// DR3 feature co-adaptation term (learning.py:100-108) on a stacked batch: rows [0,B) are (s,a), rows [B,2B) are
+// (s',a'); h2 (n_nets x 2B x H) are the critics' fc2 features, dz2 their pre-activation gradients (ReLU mask of
+// the TD loss already applied).  d/dh2 of coef * sum_h h2[b][h] h2[B+b][h] is added through the ReLU mask, and the
+// per-block partial sums of the dot products are written for the "dr3_dotproduct" log.
+__global__ void dr3_add_kernel(float *__restrict__ dz2, const float *__restrict__ h2, int n_nets, int B, int H,
+                               float coef, float *__restrict__ partial) {
+    __shared__ float red[4];
+    const int64_t per_net = (int64_t)B * H, total = per_net * n_nets;
+    float dot = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = i / per_net, r = i - j * per_net;
+        const int64_t a = j * 2 * per_net + r, b = a + per_net;
+        const float f = h2[a], f1 = h2[b];
+        dz2[a] += f > 0.0f ? coef * f1 : 0.0f;
+        dz2[b] += f1 > 0.0f ? coef * f : 0.0f;
+        dot += f * f1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 // ------------------------------------------------------------------ actor loss gradients
 __global__ __launch_bounds__(RED_THREADS) void actor_loss_bwd_kernel(
     const float *__restrict__ q, int n_nets, int n_rows, const float *__restrict__ logp,
@@ -903,6 +927,15 @@ extern "C" int ssac_critic_loss_bwd(const float *q, int n_nets, int n_rows, int 
     SSAC_LAUNCH(critic_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_nets, n_rows,
                        q_dim, act, ld_act, td, weight, popart, pop, denom, dq, logs);
     return ssac_check_launch("critic_loss_bwd");
+}
+
+extern "C" int ssac_dr3_blocks(void) { return 256; }
+
+extern "C" int ssac_dr3_add(float *dz2, const float *h2, int n_nets, int batch, int hidden, float coef,
+                            float *partial, void *stream) {
+    if (n_nets < 1 || batch < 1 || hidden < 1) return ssac_fail("ssac_dr3_add: bad sizes");
+    SSAC_LAUNCH(dr3_add_kernel, dim3(256), dim3(256), 0, ST, dz2, h2, n_nets, batch, hidden, coef, partial);
+    return ssac_check_launch("dr3_add");
 }
 
 extern "C" int ssac_adv_filter_discrete(const float *q, int n_nets, int n_rows, int n_actions, const float *logits,

@@ -287,7 +287,7 @@ def _timed(tag):
 
 
 def mlp_forward(arena, X, ldx, x_net_stride, n_rows, ws, tag, net_ids=None, n_sel=None,
-                params=None, save=True):
+                params=None, save=True, force_layers=False):
     """h1 = relu(fc1 x), h2 = relu(fc2 h1), y = out(h2) for every selected net.
     Returns (h1, h2, y) with shapes (n_sel, n_rows, H|H|out); h1/h2 are what autograd would have
     saved for the backward pass (None when `save` is False and the fused kernel kept them in LDS)."""
@@ -297,7 +297,7 @@ def mlp_forward(arena, X, ldx, x_net_stride, n_rows, ws, tag, net_ids=None, n_se
     d = arena.desc(params)
     ids = _ptr(net_ids)
     st = stream()
-    if arena.fused:
+    if arena.fused and not force_layers:
         h1 = ws.get(tag + ".h1", (n_sel, n_rows, H)) if save else None
         h2 = ws.get(tag + ".h2", (n_sel, n_rows, H)) if save else None
         check(lib.ssac_mlp3_fwd_fused(C.byref(d), ids, n_sel, X.data_ptr(), ldx, x_net_stride, n_rows,
@@ -369,7 +369,7 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
 
 def mlp_backward(arena, dY, X, ldx, x_net_stride, h1, h2, n_rows, ws, tag, *, adam=None,
                  adam_key=None, need_dx=False, grads=None, sumsq=None, target=None, tau=0.0,
-                 net_ids=None, n_sel=None, update=True):
+                 net_ids=None, n_sel=None, update=True, after_dz2=None):
     """Backward of `mlp_forward` given dL/dy.  With `update`, the weight gradients are consumed
     in-kernel by Adam (or stored to `grads` when clipping needs the global norm first).
     Returns dX (n_sel, n_rows, in_dim) when `need_dx`."""
@@ -383,6 +383,8 @@ def mlp_backward(arena, dY, X, ldx, x_net_stride, h1, h2, n_rows, ws, tag, *, ad
     check(lib.ssac_mlp_layer_dgrad(C.byref(d), 2, ids, n_sel, dY.data_ptr(), O, n_rows * O,
                                    h2.data_ptr(), H, n_rows * H, n_rows,
                                    dz2.data_ptr(), H, n_rows * H, st))
+    if after_dz2 is not None:
+        after_dz2(dz2)  # extra gradient into the fc2 pre-activations (DR3)
     check(lib.ssac_mlp_layer_dgrad(C.byref(d), 1, ids, n_sel, dz2.data_ptr(), H, n_rows * H,
                                    h1.data_ptr(), H, n_rows * H, n_rows,
                                    dz1.data_ptr(), H, n_rows * H, st))

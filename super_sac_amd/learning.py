@@ -139,7 +139,7 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
               update_priorities=update_priorities, dr3_coeff=dr3_coeff)
     shard = parallel.shard_of(agent)
     graphable = (USE_GRAPHS and engine.CAPTURE is None and agent.ensemble_size == 1 and not per
-                 and not update_priorities and lu.is_identity(agent.encoder)
+                 and not update_priorities and not dr3_coeff and lu.is_identity(agent.encoder)
                  and random_process is None and torch.cuda.is_available()
                  # critic-sharded ranks: recorded launch lists only (the collective sits between two segments),
                  # continuous actions on the fused kernels (empty subset slots, in-launch TD target)
@@ -278,8 +278,6 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
     engine.require_gpu()
     if encoder_lambda:
         raise NotImplementedError("encoder invariance loss (SURVEY 8(f) rank 4) is not accelerated")
-    if dr3_coeff > 0:
-        raise NotImplementedError("DR3 regulariser (SURVEY 8(f) rank 4) is not accelerated")
     E = agent.ensemble_size
     assert E <= lu.MAX_MEMBERS
     dev = log_alphas[0].device
@@ -306,7 +304,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
         # The online critics' FORWARD does not depend on the TD target: on a second stream (a parallel graph
         # branch) it overlaps the actor -> target critics -> TD-target chain, which occupies few CUs.
         branch = None
-        if arena.fused and not train_enc and _split_forward(N, B):
+        if arena.fused and not train_enc and not dr3_coeff and _split_forward(N, B):
             s_rep = lu.encode(agent.encoder, o)
             X, ldx = _critic_input(rd.get("_ssac"), ws, f"cu.x{i}", s_rep, a, discrete)
             with engine.side_stream(dev, defer_join=True) as branch:
@@ -316,7 +314,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                                       ensemble_idx=i, ensemble_n=target_critic_ensemble_n,
                                       log_alphas=log_alphas, pop=pop, gamma=gamma,
                                       random_process=random_process, noise_clip=noise_clip,
-                                      discrete=discrete, _slot=slot, _defer=arena.fused and LAZY_TD)
+                                      discrete=discrete, _slot=slot, _defer=arena.fused and LAZY_TD and not dr3_coeff)
         bw = lu.compute_backup_weights(logs=logs, replay_dict=rd, agent=agent, target_agent=target_agent,
                                        weight_type=weight_type, weight_temp=weighted_bellman_temp,
                                        batch_size=batch_size, discrete=discrete, _slot=slot)
@@ -353,7 +351,38 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
         ss = ws.get(f"cu.ss{i}", (N * ttot,))
         dq = ws.get(f"cu.dq{i}", (N, B, qd))
         grads = ws.get(f"cu.g{i}", (arena.params.numel(),), zero=True) if critic_clip else None
-        if arena.fused:
+        if dr3_coeff:
+            # DR3 (learning.py:100-108): the critics also run on (s', a'); both batches go through the per-layer
+            # kernels as ONE stacked 2B-row batch, the co-adaptation gradient enters at the fc2 pre-activations
+            assert not train_enc and shard is None, "DR3 is supported for identity encoders on a single rank"
+            x1 = rd.get("_x1")
+            X1 = x1 if x1 is not None else lu.encode(target_agent.encoder, o1)
+            Xc = ws.get(f"cu.xcat{i}", (2 * B, arena.in_dim))
+            Xc[:B].copy_(torch.as_strided(X, (B, arena.in_dim), (ldx, 1)))
+            Xc[B:].copy_(X1[:, :arena.in_dim])
+            ch1, ch2, cq = engine.mlp_forward(arena, Xc, arena.in_dim, 0, 2 * B, ws, tag + ".dr3", force_layers=True)
+            qc = ws.get(tag + ".dr3.qc", (N, B, qd))
+            qc.copy_(cq[:, :B])
+            dqc = ws.get(tag + ".dr3.dqc", (N, B, qd))
+            check(lib.ssac_critic_loss_bwd(qc.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0), td.data_ptr(),
+                                           weight_ptr, pp, dopop, float(E * n_glob), dqc.data_ptr(),
+                                           slot.data_ptr(), st))
+            dq2 = ws.get(tag + ".dr3.dq", (N, 2 * B, qd), zero=True)
+            dq2[:, :B].copy_(dqc)
+            nblk = int(lib.ssac_dr3_blocks())
+            dparts = ws.get(tag + ".dr3.parts", (nblk,))
+            coef = float(dr3_coeff) / (E * n_glob) / (N * B)
+
+            def dr3_hook(dz2_, _h2=ch2, _parts=dparts):
+                check(lib.ssac_dr3_add(dz2_.data_ptr(), _h2.data_ptr(), N, B, H, coef, _parts.data_ptr(), st))
+            engine.mlp_backward(arena, dq2, Xc, arena.in_dim, 0, ch1, ch2, 2 * B, ws, tag + ".dr3", adam=adam,
+                                adam_key=("critic", i), grads=grads, sumsq=ss, after_dz2=dr3_hook)
+            fca = dparts.sum() / (N * B)
+            logs[f"dr3_dotproduct_{i}"] = fca
+            # the logged overall loss includes the regulariser (learning.py:108, 133)
+            slot[lu.L_CRITIC_LOSS:lu.L_CRITIC_LOSS + 1].add_(fca * (float(dr3_coeff) / (E * n_glob)))
+            fused_logs.append(None)
+        elif arena.fused:
             dz2 = ws.get(tag + ".dz2", (N, B, H))
             dz1 = ws.get(tag + ".dz1", (N, B, H))
             tiles = int(lib.ssac_fused_row_tiles(C.byref(arena.desc()), B, N))

@@ -381,6 +381,7 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
     logs[f"td_targets/std_td_target_{i}"] = slot[L_TD0 + 3 * i + 1]
     logs[f"td_targets/entropy_bonus_{i}"] = slot[L_TD0 + 3 * i + 2]
     replay_dict["_subset"] = ids
+    replay_dict["_x1"] = None if kind == "discrete" else x1  # [s' | a'] as fed to the target critics (DR3)
     if kind == "discrete":
         a_s1 = aout[0]  # logits; the reference returns probs here, only used by dr3
     return td, (s1_rep, a_s1)

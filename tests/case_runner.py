@@ -464,7 +464,7 @@ def run_afbc_oracle(name):
             logs, odicts = orc.critic_update(
                 obuf, oa, ot, copt, eopt, [ola], B, cfg["gamma"], cfg["clip"], cfg["clip"], cfg["n"], None, None,
                 False, aug, aug_mix=0.0, idx_list=[idx], eps_list=[torch.from_numpy(fx[f"s{k}_ceps"])],
-                subset_list=[[int(v) for v in fx[f"s{k}_subset"]]])
+                subset_list=[[int(v) for v in fx[f"s{k}_subset"]]], dr3_coeff=cfg.get("dr3", 0.0))
             rd = odicts[-1]
             adv = orc.advantage(oa, rd["primary_batch"][0], rd["primary_batch"][1], 0,
                                 [torch.from_numpy(e) for e in fx[f"s{k}_prio_eps"]])
@@ -546,7 +546,8 @@ def run_afbc_engine(name, device="cuda"):
                     log_alphas=[la], batch_size=B, gamma=cfg["gamma"], critic_clip=cfg["clip"],
                     encoder_clip=cfg["clip"], target_critic_ensemble_n=cfg["n"], weighted_bellman_temp=None,
                     weight_type=None, pop=False, augmenter=aug, encoder_lambda=0, aug_mix=0.0, discrete=False,
-                    random_process=None, noise_clip=None, per=False, update_priorities=True, dr3_coeff=0.0)
+                    random_process=None, noise_clip=None, per=False, update_priorities=True,
+                    dr3_coeff=cfg.get("dr3", 0.0))
                 buf.update_priorities = orig_upd
                 for ac, tc in zip(agent.critics, target.critics):
                     ssa.learning_utils.soft_update(tc, ac, cfg["tau"])

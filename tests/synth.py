@@ -80,6 +80,11 @@ AFBC_CASES = {
     "afbc_discrete": dict(obs=8, act=4, hidden=64, N=2, n=2, E=1, B=64, rows=600, cap=1024, lo=-10.0, hi=2.0,
                           popart=False, discrete=True, actor="discrete", lr=3e-4, clip=40.0, seed=24,
                           steps=[(False, False), (True, True), (True, True), (False, True)]),
+    # d4rl/basic_afbc.gin: critic updates with the DR3 regulariser (dr3_coeff 0.01) between filtered-BC updates
+    "d4rl_afbc_dr3": dict(obs=11, act=3, hidden=64, N=2, n=2, E=1, B=64, rows=600, cap=1024, lo=-10.0, hi=2.0,
+                          popart=False, discrete=False, actor="stochastic", lr=3e-4, clip=None, seed=25,
+                          gamma=0.99, tau=0.005, init_alpha=0.1, dr3=0.01,
+                          steps=["critic", (True, True), "critic", "critic", (True, True)]),
     "afbc_noclip": dict(obs=17, act=6, hidden=64, N=3, n=2, E=1, B=128, rows=900, cap=1024, lo=-5.0, hi=2.0,
                         popart=False, discrete=False, actor="stochastic", lr=1e-3, clip=None, seed=22,
                         steps=[(True, True), (True, True), (True, False)]),

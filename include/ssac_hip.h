@@ -88,6 +88,18 @@ typedef struct ssac_td_spec {
     int32_t n_sel, use_entropy, _pad;
 } ssac_td_spec;
 
+/* Engine noise stream (SURVEY 8(b) RNG contract: "device noise from an engine Philox stream"): standard normals
+ * from Philox4x32-10 + Box-Muller, element (row b, dim i) of draw number d = offset + *counter (counter may be
+ * NULL) under `seed`.  Counter-based, so a replayed launch list advances it with the device-resident update count
+ * and an eager launch passes the same number from the host.  ssac_philox_normal fills a buffer with that stream
+ * (tests; and the definition of the stream: out[b*cols + i]). */
+typedef struct ssac_rng {
+    uint64_t seed;
+    const int64_t *counter;  /* device pointer or NULL */
+    int64_t offset;
+} ssac_rng;
+int ssac_philox_normal(float *out, int n_rows, int cols, const ssac_rng *rng, void *stream);
+
 int ssac_abi_version(void);
 const char *ssac_last_error(void);
 
@@ -363,7 +375,7 @@ int ssac_mlp3_fwd_fused(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
 int ssac_actor_sample_fused(const ssac_mlp *actor, const float *X, int64_t ldx, int n_rows,
                             const float *eps, float log_std_lo, float log_std_hi, float *act_dst,
                             int64_t ld_act, int64_t act_col0, float *logp, float *H1, float *H2,
-                            float *out, void *stream);
+                            float *out, const ssac_rng *rng /* used when eps == NULL */, void *stream);
 
 /* critic forward of ALL nets + loss gradient + backward-data in ONE launch (learning.py:83-98,112,121):
  * writes H1, H2, Q (n_nets x n_rows x out), DQ, DZ2 = dL/d(pre-activation of fc2), DZ1, and per-(net,

@@ -39,6 +39,11 @@ class Feed(C.Structure):
                 ("log_slot_word", C.c_int32), ("log_width", C.c_int32)]
 
 
+class Rng(C.Structure):
+    """struct ssac_rng"""
+    _fields_ = [("seed", C.c_uint64), ("counter", C.c_void_p), ("offset", C.c_int64)]
+
+
 class TdSpec(C.Structure):
     """struct ssac_td_spec"""
     _fields_ = [("q_t", C.c_void_p), ("logp", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p),
@@ -121,7 +126,8 @@ SIGNATURES = {
     "ssac_fused_row_tiles": [_MP, _I, _I],
     "ssac_fused_tile_rows": [_I],
     "ssac_mlp3_fwd_fused": [_MP, _P, _I, _P, _L, _L, _I, _P, _P, _P, _P],
-    "ssac_actor_sample_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _P, _P, _P],
+    "ssac_actor_sample_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _P, _P, _P, _P],
+    "ssac_philox_normal": [_P, _I, _I, _P, _P],
     "ssac_critic_fwd_bwd_fused": [_MP, _P, _L, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ssac_critic_bwd_fused": [_MP, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ssac_head_wgrad_tiles": [_MP],

@@ -108,6 +108,7 @@ def save_training_state(path, agent, target_agent=None, optimizers=None, log_alp
     state["rng"] = {"torch_cpu": torch.get_rng_state(), "torch_dev": torch.cuda.get_rng_state(dev),
                     "numpy": np.random.get_state(), "python": random.getstate()}
     state["log_ring"] = lu.ring_for(dev).k
+    state["noise"] = {"agent": agent.__dict__.get("_ssac_noise")}
     torch.save(state, os.path.join(path, STATE_FILE))
 
 
@@ -135,5 +136,7 @@ def load_training_state(path, agent, target_agent=None, optimizers=None, log_alp
     np.random.set_state(r["numpy"])
     random.setstate(r["python"])
     lu.ring_for(dev).k = state["log_ring"]
+    if state.get("noise", {}).get("agent") is not None:
+        agent.__dict__["_ssac_noise"] = list(state["noise"]["agent"])
     torch.cuda.synchronize()
     return state

@@ -10,6 +10,7 @@
 #include <stdint.h>
 
 #include "ssac_internal.h"
+#include "ssac_philox.h"
 
 namespace {
 
@@ -78,6 +79,13 @@ __device__ __forceinline__ void feed_pull(const ssac_feed &f) {
         if (i < n4) d4[i] = v[u];
     }
     for (int i = 4 * blockDim.x + threadIdx.x; i < n4; i += blockDim.x) d4[i] = s4[i];
+}
+
+__global__ void philox_normal_kernel(float *out, int n_rows, int cols, RngArgs r) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * cols) return;
+    const int b = i / cols, c = i - b * cols;
+    out[i] = philox_normal(r.seed, rng_draw(r), b, c);
 }
 
 // ------------------------------------------------------------------ replay gather
@@ -830,6 +838,14 @@ inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
 }  // namespace
 
 #define ST ((hipStream_t)stream)
+
+extern "C" int ssac_philox_normal(float *out, int n_rows, int cols, const ssac_rng *rng, void *stream) {
+    if (!rng || n_rows <= 0 || cols <= 0) return ssac_fail("ssac_philox_normal: bad arguments");
+    const int n = n_rows * cols;
+    SSAC_LAUNCH(philox_normal_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, out, n_rows, cols,
+                RngArgs{rng->seed, rng->counter, rng->offset});
+    return ssac_check_launch("philox_normal");
+}
 
 extern "C" int ssac_gather_rows(const void *src, int src_dtype, int64_t row_elems, const int64_t *idx,
                                 int n_rows, float *dst, int64_t ld_dst, int64_t dst_col0, void *stream) {

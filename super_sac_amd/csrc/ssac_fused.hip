@@ -28,6 +28,7 @@
 
 #include "ssac_internal.h"
 #include "ssac_head_wgrad.h"
+#include "ssac_philox.h"
 #include "ssac_critic_logs.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -54,6 +55,7 @@ struct FusedArgs {
     float *Y;                    // (n_sel, n_rows, out) or null
     // MODE_SAMPLE
     const float *eps; float lo, hi; float *act_dst; int64_t ld_act, act_col0; float *logp;
+    RngArgs rng;  // eps == null: the noise comes from the engine's Philox stream
     // MODE_CRITIC
     const float *td, *weight, *act; int64_t ld_a; const ssac_popart *popart; int pop; float denom;
     float *DQ, *DZ2, *DZ1; float *partials;  // partials[(e*tiles + tile)*2 + {loss, err}]
@@ -547,21 +549,29 @@ void fused_mlp_kernel(FusedArgs g) {
 
     if (MODE == MODE_SAMPLE) {
         // tanh-normal head: one thread per row
-        if (tid < TMR && (m0 + tid) < g.n_rows) {
-            const int b = m0 + tid, A = OUT >> 1;
-            float lp = 0.0f;
-            for (int i = 0; i < A; ++i) {
-                const float mu = ys[tid * MAX_OUT + i], raw = ys[tid * MAX_OUT + A + i];
+        // one thread per (row, action dimension) for the transcendental work, then one per row sums the
+        // dimensions' log-probability terms in index order (the order a serial loop would use)
+        const int A = OUT >> 1;
+        float *lpt = dqs;  // [TMR][MAX_OUT] scratch, unused in this mode
+        if (tid < TMR * A) {
+            const int r = tid / A, i = tid - r * A, b = m0 + r;
+            if (b < g.n_rows) {
+                const float mu = ys[r * MAX_OUT + i], raw = ys[r * MAX_OUT + A + i];
                 const float log_std = g.lo + 0.5f * (g.hi - g.lo) * (tanhf(raw) + 1.0f);
                 const float sd = expf(log_std);
-                const float u = mu + sd * g.eps[(int64_t)b * A + i];
-                const float a = tanhf(u);
+                const float ep = g.eps ? g.eps[(int64_t)b * A + i] : philox_normal(g.rng.seed, rng_draw(g.rng), b, i);
+                const float u = mu + sd * ep;
                 const float dlt = u - mu;
-                lp += (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -
-                      2.0f * (LOG_2 - u - softplus_f(-2.0f * u));
-                g.act_dst[b * g.ld_act + g.act_col0 + i] = a;
+                lpt[r * MAX_OUT + i] = (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -
+                                       2.0f * (LOG_2 - u - softplus_f(-2.0f * u));
+                g.act_dst[b * g.ld_act + g.act_col0 + i] = tanhf(u);
             }
-            if (g.logp) g.logp[b] = lp;
+        }
+        __syncthreads();
+        if (g.logp && tid < TMR && (m0 + tid) < g.n_rows) {
+            float lp = 0.0f;
+            for (int i = 0; i < A; ++i) lp += lpt[tid * MAX_OUT + i];
+            g.logp[m0 + tid] = lp;
         }
         return;
     }
@@ -958,21 +968,29 @@ __global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
     __syncthreads();
 
     if (MODE == MODE_SAMPLE) {
-        if (tid < TMR && (m0 + tid) < g.n_rows) {
-            const int b = m0 + tid, A = OUT >> 1;
-            float lp = 0.0f;
-            for (int i = 0; i < A; ++i) {
-                const float mu = ys[tid * MAX_OUT + i], raw = ys[tid * MAX_OUT + A + i];
+        // one thread per (row, action dimension) for the transcendental work, then one per row sums the
+        // dimensions' log-probability terms in index order (the order a serial loop would use)
+        const int A = OUT >> 1;
+        float *lpt = dqs;  // [TMR][MAX_OUT] scratch, unused in this mode
+        if (tid < TMR * A) {
+            const int r = tid / A, i = tid - r * A, b = m0 + r;
+            if (b < g.n_rows) {
+                const float mu = ys[r * MAX_OUT + i], raw = ys[r * MAX_OUT + A + i];
                 const float log_std = g.lo + 0.5f * (g.hi - g.lo) * (tanhf(raw) + 1.0f);
                 const float sd = expf(log_std);
-                const float u = mu + sd * g.eps[(int64_t)b * A + i];
-                const float a = tanhf(u);
+                const float ep = g.eps ? g.eps[(int64_t)b * A + i] : philox_normal(g.rng.seed, rng_draw(g.rng), b, i);
+                const float u = mu + sd * ep;
                 const float dlt = u - mu;
-                lp += (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -
-                      2.0f * (LOG_2 - u - softplus_f(-2.0f * u));
-                g.act_dst[b * g.ld_act + g.act_col0 + i] = a;
+                lpt[r * MAX_OUT + i] = (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -
+                                       2.0f * (LOG_2 - u - softplus_f(-2.0f * u));
+                g.act_dst[b * g.ld_act + g.act_col0 + i] = tanhf(u);
             }
-            if (g.logp) g.logp[b] = lp;
+        }
+        __syncthreads();
+        if (g.logp && tid < TMR && (m0 + tid) < g.n_rows) {
+            float lp = 0.0f;
+            for (int i = 0; i < A; ++i) lp += lpt[tid * MAX_OUT + i];
+            g.logp[m0 + tid] = lp;
         }
         return;
     }
@@ -1171,7 +1189,8 @@ extern "C" int ssac_mlp3_fwd_fused(const ssac_mlp *nets, const int32_t *net_ids,
 extern "C" int ssac_actor_sample_fused(const ssac_mlp *actor, const float *X, int64_t ldx, int n_rows,
                                        const float *eps, float log_std_lo, float log_std_hi,
                                        float *act_dst, int64_t ld_act, int64_t act_col0, float *logp,
-                                       float *H1, float *H2, float *out, void *stream) {
+                                       float *H1, float *H2, float *out, const ssac_rng *rng, void *stream) {
+    if (!eps && !rng) return ssac_fail("ssac_actor_sample_fused: neither eps nor an rng stream given");
     if (!fused_ok(actor) || (actor->out_dim & 1))
         return ssac_fail("ssac_actor_sample_fused: shape not supported by the fused path");
     if (n_rows <= 0) return 0;
@@ -1179,6 +1198,7 @@ extern "C" int ssac_actor_sample_fused(const ssac_mlp *actor, const float *X, in
     fill_common(g, actor, nullptr, X, ldx, 0, n_rows);
     g.H1 = H1; g.H2 = H2; g.Y = out;
     g.eps = eps; g.lo = log_std_lo; g.hi = log_std_hi;
+    if (rng) g.rng = RngArgs{rng->seed, rng->counter, rng->offset};
     g.act_dst = act_dst; g.ld_act = ld_act; g.act_col0 = act_col0; g.logp = logp;
     return launch_fused<MODE_SAMPLE>(g, 1, (hipStream_t)stream);
 }

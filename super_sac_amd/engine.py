@@ -37,6 +37,8 @@ class CaptureCtx:
         self.logblk = logblk
         self.feed = feed          # device address of the update's ssac_feed (0: inputs arrive by copy)
         self.published = False    # set once a captured launch has published the log block
+        self.tick_ptr = 0         # device address of the update counter (ssac_feed.tick), for in-kernel noise
+        self.noise_offset = 0     # draw number of this agent's noise stream at capture time
         self.collective = None    # callable(fn): ends the open recording, runs fn() now, opens the next segment
         self.defer_begin = False  # the replay gather will also do ssac_begin_update's work (vector buffers)
         self.pending_begin = None # (log block, adam ctl ptr) waiting for that gather

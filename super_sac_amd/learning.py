@@ -168,13 +168,14 @@ def _critic_update_graphed(gs, kw):
     kind = lu.actor_kind(actor)
     n_sub = kw["target_critic_ensemble_n"]
     ring = lu.ring_for(dev)
-    if gs.graph is None:
+    if gs.graph is None and getattr(gs, "feed", None) is None:
         # one fixed device block holds the per-update inputs:
         #   [B int64 indices | n int32 subset ids (padded to 8 bytes) | int32 log-ring slot, int32 pad]
         # The host writes them into slot k % FEED_SLOTS of a pinned ring; the first captured launch pulls the
         # slot over PCIe (ssac_feed in include/ssac_hip.h), so an update is ONE graph launch and no copy node.
         n_pad = (n_sub + 1) // 2 * 2
-        nbytes = (8 * B + 4 * n_pad + 8 + 15) // 16 * 16  # slots are whole 16-byte words (ssac_feed contract)
+        # ... | int64 draw number of the agent's noise stream]; slots are whole 16-byte words (ssac_feed contract)
+        nbytes = (8 * B + 4 * n_pad + 16 + 15) // 16 * 16
         gs.inbuf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         gs.idx_dev = gs.inbuf[:8 * B].view(torch.int64)
         gs.ids_dev = gs.inbuf[8 * B:8 * B + 4 * n_pad].view(torch.int32)[:n_sub]
@@ -192,9 +193,12 @@ def _critic_update_graphed(gs, kw):
     # ---- host draws, in the reference's order: indices -> (augmentation: none here) -> noise -> subset
     buffer.total_sample_calls += 1
     idx_cpu = rng.draw_indices(len(buffer), B)
-    if kind == "stochastic":
-        # noise straight into the captured update's input buffer.  (Capturing the draw itself costs two extra
-        # Philox-state kernels per replay on ROCm -- measured slower than this one eager launch.)
+    in_kernel_noise = kind == "stochastic" and lu.IN_KERNEL_NOISE and rng.normal_is_stock()
+    if gs.graph is not None and gs.in_kernel_noise != in_kernel_noise:
+        gs.graph = None  # a noise hook was installed / removed since the recording: record the update again
+        gs.feed = None
+    if kind == "stochastic" and not in_kernel_noise:
+        # injected noise (parity tests) goes straight into the captured update's input buffer
         rng.draw_normal_into(gs.eps_dev)
     shard = parallel.shard_of(agent)
     ids = rng.draw_subset(agent.num_critics if shard is None else shard.num_critics, n_sub)  # GLOBAL ensemble
@@ -209,9 +213,18 @@ def _critic_update_graphed(gs, kw):
         # sharded: the LOCAL index of a subset member this rank owns, -1 for a member that lives elsewhere
         row[j] = v if shard is None else (v - shard.lo if shard.owns(v) else -1)
     row[gs.n_pad] = slot_i
+    if in_kernel_noise:
+        gs.host[k, 8 * B + 4 * gs.n_pad + 8:8 * B + 4 * gs.n_pad + 16].view(torch.int64)[0] = \
+            lu.noise_stream(agent, dev)[1]
     if gs.graph is None:
+        gs.in_kernel_noise = in_kernel_noise
         ctx = engine.CaptureCtx(idx_cpu, gs.idx_dev, ids, gs.ids_dev,
-                                [gs.eps_dev] if gs.eps_dev is not None else [], gs.logblk, feed=gs.feed.ptr)
+                                [gs.eps_dev] if (gs.eps_dev is not None and not in_kernel_noise) else [],
+                                gs.logblk, feed=gs.feed.ptr)
+        if in_kernel_noise:
+            # the draw number travels in the input slot, so recorded and eager updates of an agent may interleave
+            ctx.tick_ptr = gs.inbuf.data_ptr() + 8 * B + 4 * gs.n_pad + 8
+            ctx.noise_offset = 0
         st_ = buffer._storage
         keys_ = list(st_.s_stack.keys())
         # vector observations in one array: the whole-transition gather is the update's first launch and takes
@@ -261,6 +274,8 @@ def _critic_update_graphed(gs, kw):
         ev = gs.events[k] = torch.cuda.Event()
     ev.record()
     gs.k += 1
+    if in_kernel_noise:
+        lu.noise_stream(agent, dev)[1] += 1  # one draw of the agent's noise stream per update, as in eager launches
     rng.choice(agent.critics)  # keep the Python RNG stream in step with learning.py:135
     slot = ring.buf[slot_i]
     logs = {k_: slot[i] for k_, i in gs.log_index.items()}

@@ -7,6 +7,7 @@ keeps the reference's host-RNG order (index draw -> augmentation draw -> action 
 REDQ subset).
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -58,6 +59,19 @@ def draw_normal(shape, device):
     if engine.CAPTURE is not None:
         return engine.CAPTURE.normals.pop(0)
     return rng.draw_normal(shape, device)
+
+
+IN_KERNEL_NOISE = os.environ.get("SSAC_IN_KERNEL_NOISE", "1") == "1"
+
+
+def noise_stream(agent, device):
+    """[seed, draws so far] of the agent's engine noise stream (Philox4x32-10, include/ssac_hip.h: ssac_rng).  The seed
+    is drawn once from torch's device generator, so `torch.manual_seed` still determines the run."""
+    ns = agent.__dict__.get("_ssac_noise")
+    if ns is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,), device=device, dtype=torch.int64))
+        ns = agent.__dict__["_ssac_noise"] = [seed, 0]
+    return ns
 
 
 def draw_subset(num_critics, k):
@@ -339,13 +353,30 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
         if kind == "stochastic":
             if random_process is not None:
                 raise NotImplementedError("exploration noise on a stochastic actor")
-            eps = draw_normal((B, A), dev)
-            if fuse_sample:
+            if fuse_sample and IN_KERNEL_NOISE and rng.normal_is_stock():
+                # the noise comes from the agent's Philox stream inside the launch: draw number = host count (eager)
+                # or capture-time count + the device-resident update counter (recorded launch list)
+                ns = noise_stream(agent, dev)
+                cap = engine.CAPTURE
+                rs = _lib.Rng(ns[0], cap.tick_ptr, cap.noise_offset) if cap is not None else _lib.Rng(ns[0], 0, ns[1])
+                if cap is None:
+                    ns[1] += 1
+                check(lib.ssac_actor_sample_fused(C.byref(a_arena.desc()), s1_rep.data_ptr(),
+                                                  _row_stride(s1_rep), B, 0,
+                                                  float(actor.log_std_low), float(actor.log_std_high),
+                                                  x1.data_ptr(), S + A, S, logp.data_ptr(), 0, 0, 0,
+                                                  C.addressof(rs), st))
+                eps = None
+            else:
+                eps = draw_normal((B, A), dev)
+            if eps is None:
+                pass
+            elif fuse_sample:
                 # actor forward + sample + log pi: ONE launch, a' lands in the [s'|a'] buffer
                 check(lib.ssac_actor_sample_fused(C.byref(a_arena.desc()), s1_rep.data_ptr(),
                                                   _row_stride(s1_rep), B, eps.data_ptr(),
                                                   float(actor.log_std_low), float(actor.log_std_high),
-                                                  x1.data_ptr(), S + A, S, logp.data_ptr(), 0, 0, 0, st))
+                                                  x1.data_ptr(), S + A, S, logp.data_ptr(), 0, 0, 0, 0, st))
             else:
                 check(lib.ssac_tanh_normal_fwd(aout.data_ptr(), 2 * A, eps.data_ptr(), B, A,
                                                float(actor.log_std_low), float(actor.log_std_high),

@@ -33,6 +33,15 @@ def draw_normal_into(dst):
     return dst.normal_()
 
 
+_stock_draw_normal, _stock_draw_normal_into = draw_normal, draw_normal_into
+
+
+def normal_is_stock():
+    """True while no test hook replaces the device-noise draws: only then may a consumer switch to the engine's
+    in-kernel Philox stream ("device noise from an engine Philox stream; parity tests inject eps")."""
+    return draw_normal is _stock_draw_normal and draw_normal_into is _stock_draw_normal_into
+
+
 def draw_drqv2_shift(batch_size, pad):
     return torch.randint(0, 2 * pad + 1, size=(batch_size, 1, 1, 2))
 

@@ -140,7 +140,7 @@ def test_fused_actor_sample(ssa, tile_rows):
     logp = torch.zeros(B, device=DEV)
     ssa._lib.check(ssa._lib.lib.ssac_actor_sample_fused(C.byref(ar.desc()), xd.data_ptr(), S + A, B,
                                                         ed.data_ptr(), -5.0, 2.0, xd.data_ptr(), S + A, S,
-                                                        logp.data_ptr(), 0, 0, 0, ssa.engine.stream()))
+                                                        logp.data_ptr(), 0, 0, 0, 0, ssa.engine.stream()))
     _close(xd[:, S:], a_ref, 2e-5, what="a'")
     _close(logp, lp_ref[:, 0], 5e-4, rtol=2e-5, what="log pi")
     assert torch.equal(xd[:, :S].cpu(), x1[:, :S]), "state columns must be untouched"
@@ -825,3 +825,61 @@ def test_implicit_gemm_convolution_matches_torch_conv2d(ssa, B, ci, co, k, s, H)
                                        s, pps, st))
     _close(pw.sum(0), wr.grad, 2e-4, rtol=1e-4, what="conv weight gradient")
     _close(pb.sum(0), br.grad, 2e-4, rtol=1e-4, what="conv bias gradient")
+
+
+def _philox4x32_10(c, k):
+    """numpy restatement of Philox4x32-10 (Salmon et al. 2011) on arrays of counters (n, 4) and keys (2,)."""
+    c = c.astype(np.uint64).copy()
+    k0, k1 = np.uint64(k[0]), np.uint64(k[1])
+    M0, M1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[:, 0], M1 * c[:, 2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[:, 1] ^ k0) & mask
+        n1 = p1 & mask
+        n2 = ((p0 >> np.uint64(32)) ^ c[:, 3] ^ k1) & mask
+        n3 = p0 & mask
+        c = np.stack([n0, n1, n2, n3], 1)
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return c
+
+
+def test_engine_noise_stream_is_philox_box_muller(ssa):
+    """ssac_rng: element (b, i) of draw d = Box-Muller of Philox4x32-10(counter (b, i/4, d_lo, d_hi), key seed); checked
+    against a numpy restatement, for its first two moments, and through the fused actor launch (eps == NULL)."""
+    B, A, seed, draw = 300, 6, 0x1234567887654321 % (2 ** 62), 5
+    lib, st = ssa._lib.lib, ssa.engine.stream()
+    ctr = torch.tensor([2], dtype=torch.int64, device=DEV)
+    rs = ssa._lib.Rng(seed, ctr.data_ptr(), draw - 2)  # offset + *counter == draw
+    out = torch.zeros(B, A, device=DEV)
+    ssa._lib.check(lib.ssac_philox_normal(out.data_ptr(), B, A, C.byref(rs), st))
+    rows, cols = np.meshgrid(np.arange(B), np.arange(A), indexing="ij")
+    cnt = np.stack([rows.ravel(), cols.ravel() >> 2, np.full(B * A, draw), np.zeros(B * A, np.int64)], 1)
+    x = _philox4x32_10(cnt, (seed & 0xFFFFFFFF, seed >> 32))
+    pair = (cols.ravel() >> 1) & 1
+    x0 = x[np.arange(B * A), 2 * pair].astype(np.float32)
+    x1 = x[np.arange(B * A), 2 * pair + 1].astype(np.float32)
+    u1 = (x0 + np.float32(1.0)) * np.float32(2.3283064365386963e-10)
+    u2 = x1 * np.float32(2.3283064365386963e-10)
+    r = np.sqrt(np.float32(-2.0) * np.log(u1))
+    th = np.float32(6.283185307179586) * u2
+    want = np.where(cols.ravel() & 1, r * np.sin(th), r * np.cos(th)).reshape(B, A)
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=2e-5)
+    big = torch.zeros(20000, 8, device=DEV)
+    ssa._lib.check(lib.ssac_philox_normal(big.data_ptr(), 20000, 8, C.byref(rs), st))
+    assert abs(float(big.mean())) < 0.01 and abs(float(big.std()) - 1.0) < 0.01
+    assert abs(float((big[:, 0] * big[:, 1]).mean())) < 0.02   # the two outputs of one Box-Muller pair
+    # the fused actor launch with eps == NULL uses exactly this stream
+    rng = np.random.RandomState(3)
+    S, H = 17, 64
+    actor = orc.make_mlp(rng, S, H, 2 * A)
+    ar = _arena_from(ssa, [actor])
+    xs = torch.from_numpy(rng.standard_normal((B, S + A)).astype(np.float32)).to(DEV)
+    outs = []
+    for use_rng in (False, True):
+        xd, logp = xs.clone(), torch.zeros(B, device=DEV)
+        ssa._lib.check(lib.ssac_actor_sample_fused(C.byref(ar.desc()), xd.data_ptr(), S + A, B,
+                                                   0 if use_rng else out.data_ptr(), -5.0, 2.0, xd.data_ptr(), S + A, S,
+                                                   logp.data_ptr(), 0, 0, 0, C.byref(rs) if use_rng else 0, st))
+        outs.append((xd, logp))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])

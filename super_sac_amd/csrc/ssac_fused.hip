@@ -581,8 +581,8 @@ void fused_mlp_kernel(FusedArgs g) {
         const float pw = (g.popart && g.pop) ? g.popart->w : 1.0f;
         const float pb = (g.popart && g.pop) ? g.popart->b : 0.0f;
         const float gscale = -2.0f * pw / (g.denom * (float)g.n_rows);
+        float lossv = 0.0f, errv = 0.0f;  // this row's loss terms (threads < TMR), summed over wave 0 below
         if (tid < TMR) {
-            float lossv = 0.0f, errv = 0.0f;
             const int b = m0 + tid;
             int ai = 0;
             float dsel = 0.0f;
@@ -599,27 +599,39 @@ void fused_mlp_kernel(FusedArgs g) {
                 dqs[tid * MAX_OUT + o] = d;
                 if (b < g.n_rows) g.DQ[((int64_t)e * g.n_rows + b) * OUT + o] = d;
             }
-            rowred[tid] = lossv;
-            rowred[32 + tid] = errv;
         }
-        __syncthreads();
-        if (tid == 0) {
-            float sl = 0.0f, se = 0.0f;
-            for (int r = 0; r < TMR; ++r) { sl += rowred[r]; se += rowred[32 + r]; }
-            const int64_t pi = ((int64_t)e * gridDim.x + blockIdx.x) * 2;
-            g.partials[pi] = sl;
-            g.partials[pi + 1] = se;
+        if (wave == 0) {  // fixed shuffle tree over the tile's rows: no LDS round trip, no serial loop
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lossv += __shfl_xor(lossv, o, 64); errv += __shfl_xor(errv, o, 64); }
+            if (lane == 0) {
+                const int64_t pi = ((int64_t)e * gridDim.x + blockIdx.x) * 2;
+                g.partials[pi] = lossv;
+                g.partials[pi + 1] = errv;
+            }
         }
+        __syncthreads();  // dqs visible to every wave
         STAMP(8);
         // ---- head backward: dz2 = (dq W3) (.) [h2 > 0], in place over h2s
         {
             // thread -> column k = tid % 256, rows r = (tid >> 8), +2, ...  (H <= 256)
             const int k = tid & 255;
             if (k < H) {
-                for (int r = tid >> 8; r < TMR; r += 2) {
-                    float gsum = 0.0f;
-                    for (int o = 0; o < OUT; ++o) gsum += dqs[r * MAX_OUT + o] * w3s[o * ldw3 + k];
-                    const float dz = h2s[r * ldh + k] > 0.0f ? gsum : 0.0f;
+                // all of this thread's h2 values are loaded before the first in-place store (the compiler cannot
+                // prove the stores do not alias the later loads, and would serialise the LDS round trips)
+                constexpr int NR = TMR / 2;
+                const int r0 = tid >> 8;
+                float hv[NR], gs[NR];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) { hv[j] = h2s[(r0 + 2 * j) * ldh + k]; gs[j] = 0.0f; }
+                for (int o = 0; o < OUT; ++o) {
+                    const float w = w3s[o * ldw3 + k];
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) gs[j] += dqs[(r0 + 2 * j) * MAX_OUT + o] * w;
+                }
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const int r = r0 + 2 * j;
+                    const float dz = hv[j] > 0.0f ? gs[j] : 0.0f;
                     h2s[r * ldh + k] = dz;
                     if ((m0 + r) < g.n_rows) g.DZ2[((int64_t)e * g.n_rows + m0 + r) * H + k] = dz;
                 }
@@ -1000,8 +1012,8 @@ __global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
         const float pw = (g.popart && g.pop) ? g.popart->w : 1.0f;
         const float pb = (g.popart && g.pop) ? g.popart->b : 0.0f;
         const float gscale = -2.0f * pw / (g.denom * (float)g.n_rows);
+        float lossv = 0.0f, errv = 0.0f;  // this row's loss terms (threads < TMR), summed over wave 0 below
         if (tid < TMR) {
-            float lossv = 0.0f, errv = 0.0f;
             const int b = m0 + tid;
             int ai = 0;
             float dsel = 0.0f;
@@ -1018,26 +1030,38 @@ __global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
                 dqs[tid * MAX_OUT + o] = d;
                 if (b < g.n_rows) g.DQ[((int64_t)e * g.n_rows + b) * OUT + o] = d;
             }
-            rowred[tid] = lossv;
-            rowred[32 + tid] = errv;
         }
-        __syncthreads();
-        if (tid == 0) {
-            float sl = 0.0f, se = 0.0f;
-            for (int r = 0; r < TMR; ++r) { sl += rowred[r]; se += rowred[32 + r]; }
-            const int64_t pi = ((int64_t)e * gridDim.x + blockIdx.x) * 2;
-            g.partials[pi] = sl;
-            g.partials[pi + 1] = se;
+        if (wave == 0) {  // fixed shuffle tree over the tile's rows: no LDS round trip, no serial loop
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lossv += __shfl_xor(lossv, o, 64); errv += __shfl_xor(errv, o, 64); }
+            if (lane == 0) {
+                const int64_t pi = ((int64_t)e * gridDim.x + blockIdx.x) * 2;
+                g.partials[pi] = lossv;
+                g.partials[pi + 1] = errv;
+            }
         }
+        __syncthreads();  // dqs visible to every wave
         STAMP(8);
         // ---- head backward: dz2 = (dq W3) (.) [h2 > 0], in place over h2s
         {
             const int k = tid & 255;
             if (k < H) {
-                for (int r = tid >> 8; r < TMR; r += 2) {
-                    float gsum = 0.0f;
-                    for (int o = 0; o < OUT; ++o) gsum += dqs[r * MAX_OUT + o] * w3s[o * ldw3 + k];
-                    const float dz = h2s[r * ldh + k] > 0.0f ? gsum : 0.0f;
+                // all of this thread's h2 values are loaded before the first in-place store (the compiler cannot
+                // prove the stores do not alias the later loads, and would serialise the LDS round trips)
+                constexpr int NR = TMR / 2;
+                const int r0 = tid >> 8;
+                float hv[NR], gs[NR];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) { hv[j] = h2s[(r0 + 2 * j) * ldh + k]; gs[j] = 0.0f; }
+                for (int o = 0; o < OUT; ++o) {
+                    const float w = w3s[o * ldw3 + k];
+#pragma unroll
+                    for (int j = 0; j < NR; ++j) gs[j] += dqs[(r0 + 2 * j) * MAX_OUT + o] * w;
+                }
+#pragma unroll
+                for (int j = 0; j < NR; ++j) {
+                    const int r = r0 + 2 * j;
+                    const float dz = hv[j] > 0.0f ? gs[j] : 0.0f;
                     h2s[r * ldh + k] = dz;
                     if ((m0 + r) < g.n_rows) g.DZ2[((int64_t)e * g.n_rows + m0 + r) * H + k] = dz;
                 }

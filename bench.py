@@ -41,6 +41,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 # HBM bytes per launch from the PMC passes in profiles/r1_pmc_counters.md (FETCH_SIZE doubled per the guide's gfx950
 # note for 16-byte streaming reads + WRITE_SIZE, KiB -> bytes); not collected live, N=10 single-GPU shape only
 TRAFFIC_FUSED_CRITIC_BYTES = (2 * 13165 + 20527) * 1024
+TRAFFIC_DUAL_BYTES = None  # filled after the PMC pass of the merged actor + critic-forward launch
 TRAFFIC_FWD_BYTES = None  # the two-launch form (SSAC_SPLIT_FORWARD=1) has no PMC pass yet
 
 
@@ -193,7 +194,7 @@ def main():
     # bracketed by HIP events recorded on the stream each one is launched on (same shapes, buffers, binary).
     graphs_were_on = ssa.learning.USE_GRAPHS
     ssa.learning.USE_GRAPHS = False
-    ssa.engine.PROFILE["tag"] = ("critic_fwd", "critic_bwd", "critic_fused")
+    ssa.engine.PROFILE["tag"] = ("critic_fwd", "critic_bwd", "critic_fused", "dual_fwd")
     ssa.engine.PROFILE["events"] = []
     ssa.engine.PROFILE["reps"] = 8   # the bracketed (idempotent) launch is issued 8x per event pair
     for _ in range(min(args.steps, 300)):
@@ -208,7 +209,13 @@ def main():
     IN = OBS + ACT
     f_fwd = 2.0 * BATCH * n_local * (IN * HID + HID * HID + HID)
     f_bwd = 2.0 * BATCH * n_local * (HID + HID * HID)
-    if "critic_fwd" in by_tag:
+    f_actor = 2.0 * BATCH * (OBS * HID + HID * HID + HID * 2 * ACT)
+    if "dual_fwd" in by_tag:
+        ms = by_tag["dual_fwd"]
+        flops, kname = f_fwd + f_actor, (
+            "fused_dual_kernel: ensemble-Q forward (fc1+fc2+head, h1/h2/q saved) of all local critics as 32-row "
+            "workgroups + the actor forward with tanh-normal sample as 16-row workgroups, ONE launch per update")
+    elif "critic_fwd" in by_tag:
         ms = by_tag["critic_fwd"]
         flops, kname = f_fwd, ("fused_mlp_kernel<plain>: ensemble-Q forward (fc1+fc2+head) of all local critics, "
                                "h1/h2/q stored for the backward launches (one launch per update)")
@@ -226,7 +233,8 @@ def main():
                           "in an eager pass right after the timed (replayed) region",
                 "flops_per_launch": flops,
                 "traffic": (None if not (world == 1 and n_local == NCRIT) else
-                            (TRAFFIC_FWD_BYTES if "critic_fwd" in by_tag else TRAFFIC_FUSED_CRITIC_BYTES))}
+                            (TRAFFIC_DUAL_BYTES if "dual_fwd" in by_tag else
+                             (TRAFFIC_FWD_BYTES if "critic_fwd" in by_tag else TRAFFIC_FUSED_CRITIC_BYTES)))}
     if "critic_bwd" in by_tag:
         mb = by_tag["critic_bwd"]
         avg_b = sum(mb) / len(mb)

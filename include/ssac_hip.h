@@ -377,6 +377,14 @@ int ssac_actor_sample_fused(const ssac_mlp *actor, const float *X, int64_t ldx, 
                             int64_t ld_act, int64_t act_col0, float *logp, float *H1, float *H2,
                             float *out, const ssac_rng *rng /* used when eps == NULL */, void *stream);
 
+/* ssac_actor_sample_fused and the online critics' forward (ssac_mlp3_fwd_fused over all nets, H1 / H2 / Q saved) as
+ * ONE launch: the critic forward does not depend on the sampled action and fills the CUs the small actor launch
+ * leaves idle; follow it with ssac_critic_bwd_fused instead of ssac_critic_fwd_bwd_fused. */
+int ssac_actor_sample_critic_fwd(const ssac_mlp *actor, const float *Xa, int64_t ldxa, int n_rows, const float *eps,
+                                 float log_std_lo, float log_std_hi, float *act_dst, int64_t ld_act,
+                                 int64_t act_col0, float *logp, const ssac_rng *rng, const ssac_mlp *critics,
+                                 const float *Xc, int64_t ldxc, float *H1, float *H2, float *Q, void *stream);
+
 /* critic forward of ALL nets + loss gradient + backward-data in ONE launch (learning.py:83-98,112,121):
  * writes H1, H2, Q (n_nets x n_rows x out), DQ, DZ2 = dL/d(pre-activation of fc2), DZ1, and per-(net,
  * row-tile) partial sums partials[(e*tiles + tile)*2 + {sum w*err^2, sum err}] for ssac_critic_logs. */

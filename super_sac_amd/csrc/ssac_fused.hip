@@ -64,7 +64,7 @@ struct FusedArgs {
 };
 
 // TD target of row b (see ssac_td_spec; same operation order as td_target_kernel in ssac_elementwise.hip)
-__device__ __forceinline__ float td_of_row(const FusedArgs &g, int b) {
+__device__ __forceinline__ float td_of_row(const FusedArgs &g, int b, int e) {
     if (!g.tds.q_t) return g.td[b];
     float mq = g.tds.q_t[b];
     for (int j = 1; j < g.tds.n_sel; ++j) mq = fminf(mq, g.tds.q_t[(int64_t)j * g.n_rows + b]);
@@ -72,7 +72,7 @@ __device__ __forceinline__ float td_of_row(const FusedArgs &g, int b) {
     const float bonus = g.tds.use_entropy ? alpha * g.tds.logp[b] : 0.0f;
     const float val = mq - bonus;
     const float t = g.tds.rew[b] + g.tds.gamma * (1.0f - g.tds.done[b]) * val;
-    if (blockIdx.y == 0) g.tds.td_out[b] = t;
+    if (e == 0) g.tds.td_out[b] = t;
     return t;
 }
 
@@ -360,13 +360,15 @@ __device__ __forceinline__ void stage_head_weights(float *w3s, const float *__re
 }
 
 #define STAMP(i) do { if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define BSTAMP(i) do { if (g.dbg && bx == 0 && e == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // DBUF = false: 2 workgroups per CU (needs <= 128 VGPRs and <= 80 KB of LDS each)
+// (bx, e, grid_x) = tile index, net slot and number of row tiles of the launch this workgroup works for -- blockIdx /
+// gridDim of a plain launch, or the position inside one half of a merged launch (fused_dual_kernel).
 template <int MODE, int TMR, bool DBUF>
-__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(DBUF ? 2 : 4, DBUF ? 2 : 4)))
-void fused_mlp_kernel(FusedArgs g) {
+__device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, const int bx, const int e,
+                                               const int grid_x) {
     typedef Tile<TMR> T;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = g.hidden, IN = g.in_dim, OUT = g.out_dim;
     const int KP = (IN + 31) & ~31;
     const int ldx_s = KP + APAD, ldh = H + APAD;
@@ -386,7 +388,7 @@ void fused_mlp_kernel(FusedArgs g) {
     float *rowin = w3s + OUT * (H + APAD);  // [3][TMR]: td, weight, action index of this tile's rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int e = blockIdx.y, m0 = blockIdx.x * TMR;
+    const int m0 = bx * TMR;
     const int net = g.ids ? g.ids[e] : e;
     if (net < 0) {
         // slot without a net (a REDQ subset member another rank owns): its outputs are +inf, the neutral
@@ -402,7 +404,7 @@ void fused_mlp_kernel(FusedArgs g) {
     const float *X = g.X + (int64_t)e * g.sX;
     const int col0 = wave * 32;
 
-    STAMP(0);
+    BSTAMP(0);
     const int ldw3 = H + APAD;
     KcStage st1, st2;
     RcStage st3;
@@ -419,7 +421,7 @@ void fused_mlp_kernel(FusedArgs g) {
         if (tid < TMR) {
             const int b = m0 + tid;
             const bool ok = b < g.n_rows;
-            rowin[tid] = ok ? td_of_row(g, b) : 0.0f;
+            rowin[tid] = ok ? td_of_row(g, b, e) : 0.0f;
             rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
             rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
         }
@@ -451,7 +453,7 @@ void fused_mlp_kernel(FusedArgs g) {
         if ((MODE == MODE_CRITIC) && tid < TMR) {
             const int b = m0 + tid;
             const bool ok = b < g.n_rows;
-            rowin[tid] = ok ? td_of_row(g, b) : 0.0f;
+            rowin[tid] = ok ? td_of_row(g, b, e) : 0.0f;
             rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
             rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
         }
@@ -468,11 +470,11 @@ void fused_mlp_kernel(FusedArgs g) {
         stage_first(st1, Ws, IN, tid);
         __syncthreads();
 
-        STAMP(1);
+        BSTAMP(1);
         // ---- fc1 (fc2's first weight chunk is requested during its last K chunk)
         T::zero(acc);
         gemm_tile<TMR, false, DBUF>(acc, st1, xs, ldx_s, IN, Ws, Ws1, tid, col0, st2, H);
-        STAMP(2);
+        BSTAMP(2);
         stage_first(st2, Ws, H, tid);
         if (MODE == MODE_CRITIC) st3.init(P + g.off[2], H, H, tid);
         T::foreach(acc, lane, [&](int row, int cw, float val) {
@@ -484,13 +486,13 @@ void fused_mlp_kernel(FusedArgs g) {
             }
         });
         __syncthreads();
-        STAMP(3);
+        BSTAMP(3);
         // ---- fc2 (the backward-data phase re-reads W2 as a row-contiguous image: its first chunk is
         //      requested during fc2's last K chunk)
         T::zero(acc);
         if (MODE == MODE_CRITIC) gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, st3, H);
         else gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, none, 0);
-        STAMP(4);
+        BSTAMP(4);
         T::foreach(acc, lane, [&](int row, int cw, float val) {
             const int col = col0 + cw;
             if (col < H) {
@@ -501,8 +503,8 @@ void fused_mlp_kernel(FusedArgs g) {
         });
         __syncthreads();
 
-        STAMP(5);
-        STAMP(6);
+        BSTAMP(5);
+        BSTAMP(6);
         // ---- head on the matrix cores: wave w multiplies the k-slice [32w, 32w+32) of h2 with W3^T
         //      (a 16-wide B tile, rows >= OUT zero); the 8 partial tiles are summed through LDS.
         {
@@ -542,7 +544,7 @@ void fused_mlp_kernel(FusedArgs g) {
             }
         }
     }
-    STAMP(7);
+    BSTAMP(7);
     if (MODE == MODE_PLAIN) return;
     __syncthreads();  // hpart (= staging buffer 0) has been consumed
     if (IS_CRITIC) stage_first(st3, Ws, H, tid);
@@ -604,13 +606,13 @@ void fused_mlp_kernel(FusedArgs g) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { lossv += __shfl_xor(lossv, o, 64); errv += __shfl_xor(errv, o, 64); }
             if (lane == 0) {
-                const int64_t pi = ((int64_t)e * gridDim.x + blockIdx.x) * 2;
+                const int64_t pi = ((int64_t)e * grid_x + bx) * 2;
                 g.partials[pi] = lossv;
                 g.partials[pi + 1] = errv;
             }
         }
         __syncthreads();  // dqs visible to every wave
-        STAMP(8);
+        BSTAMP(8);
         // ---- head backward: dz2 = (dq W3) (.) [h2 > 0], in place over h2s
         {
             // thread -> column k = tid % 256, rows r = (tid >> 8), +2, ...  (H <= 256)
@@ -637,12 +639,12 @@ void fused_mlp_kernel(FusedArgs g) {
                 }
             }
         }
-        STAMP(9);
+        BSTAMP(9);
         // ---- backward-data of fc2: dz1 = (dz2 W2) (.) [h1 > 0]
         __syncthreads();  // dz2 (in h2s) and the staged first chunk of W2 are visible
         T::zero(acc);
         gemm_tile<TMR, true, DBUF>(acc, st3, h2s, ldh, H, Ws, Ws1, tid, col0, none, 0);
-        STAMP(10);
+        BSTAMP(10);
         T::foreach(acc, lane, [&](int row, int cw, float val) {
             const int col = col0 + cw;
             if (col < H && (m0 + row) < g.n_rows) {
@@ -650,10 +652,36 @@ void fused_mlp_kernel(FusedArgs g) {
                 g.DZ1[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
             }
         });
-        STAMP(11);
+        BSTAMP(11);
     }
 }
 
+
+template <int MODE, int TMR, bool DBUF>
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(DBUF ? 2 : 4, DBUF ? 2 : 4)))
+void fused_mlp_kernel(FusedArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    fused_mlp_body<MODE, TMR, DBUF>(g, smem, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+// Two independent fused launches in ONE: workgroups [0, tiles_a) run the actor (+ tanh-normal sample) on 16-row
+// tiles, the rest run the online critics' FORWARD (h1 / h2 / q saved) on 32-row tiles.  The critic forward does not
+// depend on the sampled action, so it fills the ~220 CUs the 32 actor workgroups leave idle; the critic kernel
+// that follows the target critics is then only its backward half (MODE_CRITIC_BWD).  Same-launch workgroups need no
+// cross-stream signalling (which costs ~10 us on this platform, see SPLIT_FORWARD in learning.py).
+// TC = row-tile size of the critic half (the same automatic choice a stand-alone forward would make, so the
+// results are bit-identical to it).
+template <int TC>
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void fused_dual_kernel(FusedArgs ga, FusedArgs gc, int tiles_a, int critic_grid_x) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < tiles_a) {
+        fused_mlp_body<MODE_SAMPLE, 16, true>(ga, smem, blockIdx.x, 0, tiles_a);
+    } else {
+        const int L = blockIdx.x - tiles_a;
+        fused_mlp_body<MODE_PLAIN, TC, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x);
+    }
+}
 
 // =============================================================================================
 // Direct-B variant.  Wave w of a workgroup is the ONLY consumer of columns [32w, 32w+32) of a weight
@@ -857,7 +885,7 @@ __global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
     if (IS_CRITIC && tid < TMR) {
         const int b = m0 + tid;
         const bool ok = b < g.n_rows;
-        rowin[tid] = ok ? td_of_row(g, b) : 0.0f;
+        rowin[tid] = ok ? td_of_row(g, b, e) : 0.0f;
         rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
         rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
     }
@@ -1225,6 +1253,43 @@ extern "C" int ssac_actor_sample_fused(const ssac_mlp *actor, const float *X, in
     if (rng) g.rng = RngArgs{rng->seed, rng->counter, rng->offset};
     g.act_dst = act_dst; g.ld_act = ld_act; g.act_col0 = act_col0; g.logp = logp;
     return launch_fused<MODE_SAMPLE>(g, 1, (hipStream_t)stream);
+}
+
+extern "C" int ssac_actor_sample_critic_fwd(const ssac_mlp *actor, const float *Xa, int64_t ldxa, int n_rows,
+                                            const float *eps, float log_std_lo, float log_std_hi, float *act_dst,
+                                            int64_t ld_act, int64_t act_col0, float *logp, const ssac_rng *rng,
+                                            const ssac_mlp *critics, const float *Xc, int64_t ldxc, float *H1,
+                                            float *H2, float *Q, void *stream) {
+    if (!eps && !rng) return ssac_fail("ssac_actor_sample_critic_fwd: neither eps nor an rng stream given");
+    if (!fused_ok(actor) || (actor->out_dim & 1) || !fused_ok(critics))
+        return ssac_fail("ssac_actor_sample_critic_fwd: shape not supported by the fused path");
+    if (!H1 || !H2 || !Q) return ssac_fail("ssac_actor_sample_critic_fwd: H1 / H2 / Q missing");
+    if (n_rows <= 0) return 0;
+    FusedArgs ga{}, gc{};
+    fill_common(ga, actor, nullptr, Xa, ldxa, 0, n_rows);
+    ga.eps = eps; ga.lo = log_std_lo; ga.hi = log_std_hi;
+    if (rng) ga.rng = RngArgs{rng->seed, rng->counter, rng->offset};
+    ga.act_dst = act_dst; ga.ld_act = ld_act; ga.act_col0 = act_col0; ga.logp = logp;
+    fill_common(gc, critics, nullptr, Xc, ldxc, 0, n_rows);
+    gc.H1 = H1; gc.H2 = H2; gc.Y = Q;
+    const int tc = choose_tile(gc, critics->n_nets).tm;  // what a stand-alone forward of the critics would use
+    const int tiles_a = (n_rows + 15) / 16, cgx = (n_rows + tc - 1) / tc;
+    size_t lds = fused_lds_bytes(actor->in_dim, actor->hidden, actor->out_dim, 16, true);
+    const size_t lc = fused_lds_bytes(critics->in_dim, critics->hidden, critics->out_dim, tc, true);
+    if (lc > lds) lds = lc;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)fused_dual_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)fused_dual_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return ssac_fail("fused_dual: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    const dim3 grid(tiles_a + cgx * critics->n_nets);
+    if (tc == 16) SSAC_LAUNCH(fused_dual_kernel<16>, grid, dim3(NTHR), lds, (hipStream_t)stream, ga, gc, tiles_a, cgx);
+    else SSAC_LAUNCH(fused_dual_kernel<32>, grid, dim3(NTHR), lds, (hipStream_t)stream, ga, gc, tiles_a, cgx);
+    return ssac_check_launch("fused_dual");
 }
 
 extern "C" int ssac_critic_fwd_bwd_fused(const ssac_mlp *nets, const float *X, int64_t ldx, int n_rows,

@@ -302,10 +302,13 @@ def _upload_ids(ws, ids, device, tag):
 
 
 def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ensemble_n, log_alphas,
-                       pop, gamma, random_process, noise_clip, discrete=False, _slot=None, _defer=False):
+                       pop, gamma, random_process, noise_clip, discrete=False, _slot=None, _defer=False,
+                       _co_forward=None):
     """learning_utils.py:298-354.  With ``_defer`` (critic_update's fused path; continuous actions, no PopArt)
     the final elementwise step -- and its three log values -- is not launched here: the returned ``td`` buffer
-    carries a ``_ssac_spec`` (ssac_td_spec) and the critic launch evaluates the targets into it."""
+    carries a ``_ssac_spec`` (ssac_td_spec) and the critic launch evaluates the targets into it.
+    ``_co_forward`` = (critic arena, X, ldx, h1, h2, q): when the actor runs as the fused sample launch, the online
+    critics' forward rides in the SAME launch (ssac_actor_sample_critic_fwd); replay_dict["_co_fwd"] is then True."""
     o, a, r, o1, d = replay_dict["primary_batch"]
     i = ensemble_idx
     dev = r.device
@@ -361,11 +364,8 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
                 rs = _lib.Rng(ns[0], cap.tick_ptr, cap.noise_offset) if cap is not None else _lib.Rng(ns[0], 0, ns[1])
                 if cap is None:
                     ns[1] += 1
-                check(lib.ssac_actor_sample_fused(C.byref(a_arena.desc()), s1_rep.data_ptr(),
-                                                  _row_stride(s1_rep), B, 0,
-                                                  float(actor.log_std_low), float(actor.log_std_high),
-                                                  x1.data_ptr(), S + A, S, logp.data_ptr(), 0, 0, 0,
-                                                  C.addressof(rs), st))
+                _actor_sample(a_arena, s1_rep, B, 0, actor, x1, S, A, logp, C.addressof(rs), st, _co_forward,
+                              replay_dict)
                 eps = None
             else:
                 eps = draw_normal((B, A), dev)
@@ -373,10 +373,8 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
                 pass
             elif fuse_sample:
                 # actor forward + sample + log pi: ONE launch, a' lands in the [s'|a'] buffer
-                check(lib.ssac_actor_sample_fused(C.byref(a_arena.desc()), s1_rep.data_ptr(),
-                                                  _row_stride(s1_rep), B, eps.data_ptr(),
-                                                  float(actor.log_std_low), float(actor.log_std_high),
-                                                  x1.data_ptr(), S + A, S, logp.data_ptr(), 0, 0, 0, 0, st))
+                _actor_sample(a_arena, s1_rep, B, eps.data_ptr(), actor, x1, S, A, logp, 0, st, _co_forward,
+                              replay_dict)
             else:
                 check(lib.ssac_tanh_normal_fwd(aout.data_ptr(), 2 * A, eps.data_ptr(), B, A,
                                                float(actor.log_std_low), float(actor.log_std_high),
@@ -416,6 +414,25 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
     if kind == "discrete":
         a_s1 = aout[0]  # logits; the reference returns probs here, only used by dr3
     return td, (s1_rep, a_s1)
+
+
+def _actor_sample(a_arena, s1_rep, B, eps_ptr, actor, x1, S, A, logp, rng_ptr, st, co_forward, replay_dict):
+    """actor forward + tanh-normal sample + log pi in ONE launch (a' lands in the [s'|a'] buffer), optionally with
+    the online critics' forward as extra workgroups of the same launch."""
+    if co_forward is not None:
+        c_arena, X, ldx, h1, h2, q = co_forward
+        with engine._timed("dual_fwd") as tm:
+            for _ in range(tm.reps):  # 1, except under bench.py's live kernel timing (the launch is idempotent)
+                check(lib.ssac_actor_sample_critic_fwd(
+                    C.byref(a_arena.desc()), s1_rep.data_ptr(), _row_stride(s1_rep), B, eps_ptr,
+                    float(actor.log_std_low), float(actor.log_std_high), x1.data_ptr(), S + A, S, logp.data_ptr(),
+                    rng_ptr, C.byref(c_arena.desc()), X.data_ptr(), ldx, h1.data_ptr(), h2.data_ptr(),
+                    q.data_ptr(), st))
+        replay_dict["_co_fwd"] = True
+        return
+    check(lib.ssac_actor_sample_fused(C.byref(a_arena.desc()), s1_rep.data_ptr(), _row_stride(s1_rep), B, eps_ptr,
+                                      float(actor.log_std_low), float(actor.log_std_high), x1.data_ptr(), S + A, S,
+                                      logp.data_ptr(), 0, 0, 0, rng_ptr, st))
 
 
 def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag):

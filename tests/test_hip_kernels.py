@@ -883,3 +883,29 @@ def test_engine_noise_stream_is_philox_box_muller(ssa):
                                                    logp.data_ptr(), 0, 0, 0, C.byref(rs) if use_rng else 0, st))
         outs.append((xd, logp))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("B,N", [(512, 10), (100, 3)])
+def test_merged_actor_and_critic_forward_launch_equals_the_two_launches(ssa, B, N):
+    """ssac_actor_sample_critic_fwd: same bits as ssac_actor_sample_fused + ssac_mlp3_fwd_fused issued separately."""
+    rng = np.random.RandomState(B)
+    S, A, H = 17, 6, 64 if B < 200 else 256
+    actor = orc.make_mlp(rng, S, H, 2 * A)
+    crit = [orc.make_mlp(rng, S + A, H, 1) for _ in range(N)]
+    aa, ca = _arena_from(ssa, [actor]), _arena_from(ssa, crit)
+    x1 = torch.from_numpy(rng.standard_normal((B, S + A)).astype(np.float32)).to(DEV)
+    xc = torch.from_numpy(rng.standard_normal((B, S + A)).astype(np.float32)).to(DEV)
+    eps = torch.from_numpy(rng.standard_normal((B, A)).astype(np.float32)).to(DEV)
+    lib, st = ssa._lib.lib, ssa.engine.stream()
+    ws = ssa.engine.Workspace(torch.device(DEV))
+    xa, lpa = x1.clone(), torch.zeros(B, device=DEV)
+    ssa._lib.check(lib.ssac_actor_sample_fused(C.byref(aa.desc()), xa.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0,
+                                               xa.data_ptr(), S + A, S, lpa.data_ptr(), 0, 0, 0, 0, st))
+    h1, h2, q = ssa.engine.mlp_forward(ca, xc, S + A, 0, B, ws, "sep")
+    xb, lpb = x1.clone(), torch.zeros(B, device=DEV)
+    g1, g2, gq = torch.zeros_like(h1), torch.zeros_like(h2), torch.zeros_like(q)
+    ssa._lib.check(lib.ssac_actor_sample_critic_fwd(
+        C.byref(aa.desc()), xb.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0, xb.data_ptr(), S + A, S, lpb.data_ptr(),
+        0, C.byref(ca.desc()), xc.data_ptr(), S + A, g1.data_ptr(), g2.data_ptr(), gq.data_ptr(), st))
+    for a_, b_, what in ((xa, xb, "a'"), (lpa, lpb, "log pi"), (h1, g1, "h1"), (h2, g2, "h2"), (q, gq, "q")):
+        assert torch.equal(a_, b_), f"merged launch differs in {what}"

@@ -194,7 +194,7 @@ def main():
     # bracketed by HIP events recorded on the stream each one is launched on (same shapes, buffers, binary).
     graphs_were_on = ssa.learning.USE_GRAPHS
     ssa.learning.USE_GRAPHS = False
-    ssa.engine.PROFILE["tag"] = ("critic_fwd", "critic_bwd", "critic_fused", "dual_fwd")
+    ssa.engine.PROFILE["tag"] = ("critic_fwd", "critic_bwd", "critic_fused", "dual_fwd", "dual_bwd")
     ssa.engine.PROFILE["events"] = []
     ssa.engine.PROFILE["reps"] = 8   # the bracketed (idempotent) launch is issued 8x per event pair
     for _ in range(min(args.steps, 300)):
@@ -235,7 +235,16 @@ def main():
                 "traffic": (None if not (world == 1 and n_local == NCRIT) else
                             (TRAFFIC_DUAL_BYTES if "dual_fwd" in by_tag else
                              (TRAFFIC_FWD_BYTES if "critic_fwd" in by_tag else TRAFFIC_FUSED_CRITIC_BYTES)))}
-    if "critic_bwd" in by_tag:
+    if "dual_bwd" in by_tag:
+        mb = by_tag["dual_bwd"]
+        avg_b = sum(mb) / len(mb)
+        f_tgt = 2.0 * BATCH * NSUB * (IN * HID + HID * HID + HID)
+        roofline["backward_launch"] = {
+            "kernel": "fused_dual2_kernel: TD-independent half of the critics' backward pass (head backward + fc2 "
+                      "backward-data, unscaled) as 32-row workgroups + the target critics' forward on the REDQ subset",
+            "avg_launch_us": round(avg_b * 1e3, 3), "flops_per_launch": f_bwd + f_tgt,
+            "achieved": round((f_bwd + f_tgt) / (avg_b * 1e-3) / 1e12, 3)}
+    elif "critic_bwd" in by_tag:
         mb = by_tag["critic_bwd"]
         avg_b = sum(mb) / len(mb)
         roofline["backward_launch"] = {"kernel": "fused_mlp_kernel<critic-bwd>: loss gradient + head backward + "

@@ -193,6 +193,27 @@ int ssac_mlp_wgrad_all(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, 
                        float *grads, float *sumsq2, float *sumsq1, float *sumsq0, int64_t sumsq_net_stride,
                        float *target, float tau, void *stream);
 
+/* ssac_mlp_wgrad_all for single-output heads when the backward pass was run UNSCALED (ssac_target_fwd_critic_bwdu):
+ * row_scale (n_sel x n_rows) = dL/dq of every net and row (ssac_critic_loss_bwd[_lazy]'s dq) multiplies the rows of
+ * DZ2u / DZ1u while they are loaded, and is the head layer's output gradient itself. */
+int ssac_mlp_wgrad_all_scaled(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X, int64_t ldx,
+                              int64_t x_net_stride, const float *H1, const float *H2, const float *DZ2u,
+                              const float *DZ1u, const float *row_scale, int n_rows, float *adam_m, float *adam_v,
+                              const ssac_adam_ctl *ctl, float *grads, float *sumsq2, float *sumsq1, float *sumsq0,
+                              int64_t sumsq_net_stride, float *target, float tau, void *stream);
+/* ssac_critic_loss_bwd with the TD targets evaluated in the same launch (ssac_td_spec; they are also written to
+ * lazy_td->td_out). */
+int ssac_critic_loss_bwd_lazy(const float *q, int n_nets, int n_rows, int q_dim, const float *act, int64_t ld_act,
+                              const ssac_td_spec *lazy_td, const float *weight, const ssac_popart *popart, int pop,
+                              float denom, float *dq, float *logs, void *stream);
+/* second merged launch of an update: the target critics' forward on the REDQ subset (Qt: n_sel x n_rows x out) and, as
+ * extra workgroups, the TD-independent half of the online critics' backward pass on the saved forward H1 / H2:
+ * DZ2u[b,:] = W3[a_b,:] (.) [h2 > 0], DZ1u[b,:] = (DZ2u[b,:] W2) (.) [h1 > 0]  (act: action index, discrete only). */
+int ssac_target_fwd_critic_bwdu(const ssac_mlp *targets, const int32_t *net_ids, int n_sel, const float *X1,
+                                int64_t ldx1, int n_rows, float *Qt, const ssac_mlp *critics, const float *H1,
+                                const float *H2, const float *act, int64_t ld_act, float *DZ2u, float *DZ1u,
+                                void *stream);
+
 /* ssac_mlp_wgrad_all (Adam mode) whose LAST workgroup to finish also does ssac_critic_logs' work (n_nets = n_sel;
  * sumsq_all / n_sumsq: the whole per-net sumsq block for the gradient-norm log): the update ends with this launch.
  * done_counter: one zero-initialised uint32 in device memory, reset by the launch itself. */

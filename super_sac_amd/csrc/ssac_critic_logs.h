@@ -71,8 +71,10 @@ __device__ __forceinline__ void critic_logs_body(const CriticLogsArgs &a, float 
         sl = red[0] + red[1] + red[2] + red[3];
         se = red[4] + red[5] + red[6] + red[7];
         ss = red[8] + red[9] + red[10] + red[11];
-        a.logs[0] += sl / (a.denom * (float)n_rows);   // losses/critic_overall_loss (accumulates over members)
-        a.logs[1] = se / (float)n_rows;                // losses/last_member_critic_td_error
+        if (a.n_nets > 0) {  // (n_nets == 0: the loss logs were written by ssac_critic_loss_bwd already)
+            a.logs[0] += sl / (a.denom * (float)n_rows);   // losses/critic_overall_loss (accumulates over members)
+            a.logs[1] = se / (float)n_rows;                // losses/last_member_critic_td_error
+        }
         if (a.sumsq) a.logs[2] = sqrtf(ss) * (a.scale ? a.scale->clip_coef : 1.0f);
     }
     if (a.feed) {  // last launch of a captured update: publish the log block, advance the input ring

@@ -326,12 +326,26 @@ __global__ __launch_bounds__(RED_THREADS) void td_target_kernel(
 // ------------------------------------------------------------------ critic loss gradient
 __global__ __launch_bounds__(RED_THREADS) void critic_loss_bwd_kernel(
     const float *__restrict__ q, int n_nets, int n_rows, int qd, const float *__restrict__ act,
-    int64_t ld_act, const float *__restrict__ td, const float *__restrict__ weight,
-    const ssac_popart *popart, int pop, float denom, float *__restrict__ dq, float *__restrict__ logs) {
+    int64_t ld_act, const float *td, const float *__restrict__ weight,
+    const ssac_popart *popart, int pop, float denom, float *__restrict__ dq, float *__restrict__ logs,
+    ssac_td_spec tds) {
     __shared__ float scratch[16];
     const float pw = (popart && pop) ? popart->w : 1.0f;
     const float pb = (popart && pop) ? popart->b : 0.0f;
     const float gscale = -2.0f * pw / (denom * (float)n_rows);
+    if (tds.q_t) {
+        // the TD targets are evaluated here (ssac_td_spec: same arithmetic and order as td_target_kernel) ...
+        const float alpha = tds.use_entropy ? expf(tds.log_alpha[0]) : 0.0f;
+        for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+            float mq = tds.q_t[b];
+            for (int j = 1; j < tds.n_sel; ++j) mq = fminf(mq, tds.q_t[(int64_t)j * n_rows + b]);
+            const float bonus = tds.use_entropy ? alpha * tds.logp[b] : 0.0f;
+            const float val = mq - bonus;
+            tds.td_out[b] = tds.rew[b] + tds.gamma * (1.0f - tds.done[b]) * val;
+        }
+        __syncthreads();  // ... and read back below by other threads of this (single) workgroup
+        td = tds.td_out;
+    }
     float s_loss = 0.f, s_err_last = 0.f;
     const int total = n_nets * n_rows;
     for (int i = threadIdx.x; i < total; i += blockDim.x) {
@@ -941,8 +955,19 @@ extern "C" int ssac_critic_loss_bwd(const float *q, int n_nets, int n_rows, int 
     if (n_nets < 1 || n_rows < 1 || q_dim < 1) return ssac_fail("ssac_critic_loss_bwd: bad sizes");
     if (q_dim > 1 && !act) return ssac_fail("ssac_critic_loss_bwd: discrete needs actions");
     SSAC_LAUNCH(critic_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_nets, n_rows,
-                       q_dim, act, ld_act, td, weight, popart, pop, denom, dq, logs);
+                       q_dim, act, ld_act, td, weight, popart, pop, denom, dq, logs, ssac_td_spec{});
     return ssac_check_launch("critic_loss_bwd");
+}
+
+extern "C" int ssac_critic_loss_bwd_lazy(const float *q, int n_nets, int n_rows, int q_dim, const float *act,
+                                         int64_t ld_act, const ssac_td_spec *lazy_td, const float *weight,
+                                         const ssac_popart *popart, int pop, float denom, float *dq, float *logs,
+                                         void *stream) {
+    if (n_nets < 1 || n_rows < 1 || q_dim < 1 || !lazy_td) return ssac_fail("ssac_critic_loss_bwd_lazy: bad arguments");
+    if (q_dim > 1 && !act) return ssac_fail("ssac_critic_loss_bwd_lazy: discrete needs actions");
+    SSAC_LAUNCH(critic_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_nets, n_rows, q_dim, act, ld_act,
+                (const float *)nullptr, weight, popart, pop, denom, dq, logs, *lazy_td);
+    return ssac_check_launch("critic_loss_bwd_lazy");
 }
 
 extern "C" int ssac_dr3_blocks(void) { return 256; }

@@ -12,6 +12,11 @@
 //                by an earlier MODE_PLAIN launch), then loss gradient, head backward, fc2 backward-data.
 //                Lets the critic FORWARD run concurrently with the actor/target-critic/TD-target chain
 //                (it does not depend on the TD target); bit-identical to MODE_CRITIC.
+//   MODE_CRITIC_BWDU the TD-INDEPENDENT part of the backward pass.  The loss gradient of row b is a scalar c_b (it
+//                holds the TD error) times a fixed selector of the head output, so dz2[b,:] = c_b * (W3[a_b,:] (.)
+//                [h2 > 0]) and dz1[b,:] = c_b * ((dz2u[b,:] W2) (.) [h1 > 0]): this mode computes the UNSCALED dz2u /
+//                dz1u from the saved forward alone; c_b enters later as a per-row scale in the weight-gradient
+//                reductions (ssac_mlp_wgrad_all_scaled).  So the backward GEMM can run beside the target critics.
 //
 // A workgroup is 512 threads = 8 waves (2 per SIMD, so one wave's LDS/barrier phases hide under
 // the other's MFMAs); wave w owns output columns [32w, 32w+32) of the 32 x H activation tile as one
@@ -44,7 +49,7 @@ constexpr int MAX_OUT = 16;
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 constexpr float LOG_2 = 0.69314718055994530942f;
 
-enum { MODE_PLAIN = 0, MODE_SAMPLE = 1, MODE_CRITIC = 2, MODE_CRITIC_BWD = 3 };
+enum { MODE_PLAIN = 0, MODE_SAMPLE = 1, MODE_CRITIC = 2, MODE_CRITIC_BWD = 3, MODE_CRITIC_BWDU = 4 };
 
 struct FusedArgs {
     const float *params; int64_t net_stride; int in_dim, hidden, out_dim;
@@ -409,8 +414,9 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     KcStage st1, st2;
     RcStage st3;
     NoStage none;
-    constexpr bool BWD_ONLY = MODE == MODE_CRITIC_BWD;
-    constexpr bool IS_CRITIC = MODE == MODE_CRITIC || MODE == MODE_CRITIC_BWD;
+    constexpr bool UNSCALED = MODE == MODE_CRITIC_BWDU;
+    constexpr bool BWD_ONLY = MODE == MODE_CRITIC_BWD || UNSCALED;
+    constexpr bool IS_CRITIC = MODE == MODE_CRITIC || BWD_ONLY;
     typename T::Acc acc;
     float *hpart = Ws;  // K-split partial head tiles [8][TMR][16] (staging buffer 0 is free after fc2)
     if (BWD_ONLY) {
@@ -421,8 +427,10 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         if (tid < TMR) {
             const int b = m0 + tid;
             const bool ok = b < g.n_rows;
-            rowin[tid] = ok ? td_of_row(g, b, e) : 0.0f;
-            rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
+            if (!UNSCALED) {
+                rowin[tid] = ok ? td_of_row(g, b, e) : 0.0f;
+                rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
+            }
             rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
         }
         const int c = (tid & 63) * 4;  // one wave per row pass, 16 bytes per lane
@@ -437,10 +445,11 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 *reinterpret_cast<f4 *>(h2s + r * ldh + c) = ok ? a2 : z;
             }
         }
-        for (int i = tid; i < TMR * OUT; i += NTHR) {
-            const int r = i / OUT, o = i - r * OUT;
-            ys[r * MAX_OUT + o] = (m0 + r) < g.n_rows ? g.Y[((int64_t)e * g.n_rows + m0 + r) * OUT + o] : 0.0f;
-        }
+        if (!UNSCALED)
+            for (int i = tid; i < TMR * OUT; i += NTHR) {
+                const int r = i / OUT, o = i - r * OUT;
+                ys[r * MAX_OUT + o] = (m0 + r) < g.n_rows ? g.Y[((int64_t)e * g.n_rows + m0 + r) * OUT + o] : 0.0f;
+            }
     } else {
         // ---- first weight chunk of fc1 in flight before anything else
         st1.init(P + g.off[0], IN, H, tid);
@@ -584,7 +593,13 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         const float pb = (g.popart && g.pop) ? g.popart->b : 0.0f;
         const float gscale = -2.0f * pw / (g.denom * (float)g.n_rows);
         float lossv = 0.0f, errv = 0.0f;  // this row's loss terms (threads < TMR), summed over wave 0 below
-        if (tid < TMR) {
+        if (UNSCALED) {
+            // selector of the head output the loss looks at (the taken action; the only output when OUT == 1)
+            if (tid < TMR) {
+                const int ai = OUT > 1 ? (int)rowin[2 * TMR + tid] : 0;
+                for (int o = 0; o < OUT; ++o) dqs[tid * MAX_OUT + o] = (o == ai && (m0 + tid) < g.n_rows) ? 1.0f : 0.0f;
+            }
+        } else if (tid < TMR) {
             const int b = m0 + tid;
             int ai = 0;
             float dsel = 0.0f;
@@ -602,7 +617,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 if (b < g.n_rows) g.DQ[((int64_t)e * g.n_rows + b) * OUT + o] = d;
             }
         }
-        if (wave == 0) {  // fixed shuffle tree over the tile's rows: no LDS round trip, no serial loop
+        if (!UNSCALED && wave == 0) {  // fixed shuffle tree over the tile's rows: no LDS round trip, no serial loop
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { lossv += __shfl_xor(lossv, o, 64); errv += __shfl_xor(errv, o, 64); }
             if (lane == 0) {
@@ -680,6 +695,22 @@ void fused_dual_kernel(FusedArgs ga, FusedArgs gc, int tiles_a, int critic_grid_
     } else {
         const int L = blockIdx.x - tiles_a;
         fused_mlp_body<MODE_PLAIN, TC, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x);
+    }
+}
+
+// Second merged launch of an update: workgroups [0, tiles_t) run the target critics' forward on the REDQ subset
+// (net_ids), the rest run the TD-independent half of the online critics' backward pass (MODE_CRITIC_BWDU) on the
+// forward the first merged launch saved.
+template <int TT, int TC>
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void fused_dual2_kernel(FusedArgs gt, FusedArgs gc, int tiles_t, int target_grid_x, int critic_grid_x) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < tiles_t) {
+        fused_mlp_body<MODE_PLAIN, TT, true>(gt, smem, blockIdx.x % target_grid_x, blockIdx.x / target_grid_x,
+                                             target_grid_x);
+    } else {
+        const int L = blockIdx.x - tiles_t;
+        fused_mlp_body<MODE_CRITIC_BWDU, TC, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x);
     }
 }
 
@@ -1253,6 +1284,46 @@ extern "C" int ssac_actor_sample_fused(const ssac_mlp *actor, const float *X, in
     if (rng) g.rng = RngArgs{rng->seed, rng->counter, rng->offset};
     g.act_dst = act_dst; g.ld_act = ld_act; g.act_col0 = act_col0; g.logp = logp;
     return launch_fused<MODE_SAMPLE>(g, 1, (hipStream_t)stream);
+}
+
+extern "C" int ssac_target_fwd_critic_bwdu(const ssac_mlp *targets, const int32_t *net_ids, int n_sel, const float *X1,
+                                           int64_t ldx1, int n_rows, float *Qt, const ssac_mlp *critics,
+                                           const float *H1, const float *H2, const float *act, int64_t ld_act,
+                                           float *DZ2u, float *DZ1u, void *stream) {
+    if (!fused_ok(targets) || !fused_ok(critics))
+        return ssac_fail("ssac_target_fwd_critic_bwdu: shape not supported by the fused path");
+    if (n_sel <= 0 || n_sel > SSAC_MAX_NETS) return ssac_fail("ssac_target_fwd_critic_bwdu: n_sel out of range");
+    if (!H1 || !H2 || !DZ2u || !DZ1u || !Qt) return ssac_fail("ssac_target_fwd_critic_bwdu: missing buffer");
+    if (critics->out_dim > 1 && !act) return ssac_fail("ssac_target_fwd_critic_bwdu: discrete needs actions");
+    if (n_rows <= 0) return 0;
+    FusedArgs gt{}, gc{};
+    fill_common(gt, targets, net_ids, X1, ldx1, 0, n_rows);
+    gt.Y = Qt;
+    fill_common(gc, critics, nullptr, nullptr, 0, 0, n_rows);
+    gc.H1 = const_cast<float *>(H1); gc.H2 = const_cast<float *>(H2);
+    gc.act = act; gc.ld_a = ld_act; gc.DZ2 = DZ2u; gc.DZ1 = DZ1u;
+    const int tt = choose_tile(gt, n_sel).tm, tc = choose_tile(gc, critics->n_nets).tm;
+    const int tgx = (n_rows + tt - 1) / tt, cgx = (n_rows + tc - 1) / tc;
+    size_t lds = fused_lds_bytes(targets->in_dim, targets->hidden, targets->out_dim, tt, true);
+    const size_t lc = fused_lds_bytes(critics->in_dim, critics->hidden, critics->out_dim, tc, true);
+    if (lc > lds) lds = lc;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const void *ks[4] = {(const void *)fused_dual2_kernel<16, 16>, (const void *)fused_dual2_kernel<16, 32>,
+                             (const void *)fused_dual2_kernel<32, 16>, (const void *)fused_dual2_kernel<32, 32>};
+        for (const void *k : ks)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return ssac_fail("fused_dual2: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    const int tiles_t = tgx * n_sel;
+    const dim3 grid(tiles_t + cgx * critics->n_nets);
+    hipStream_t st = (hipStream_t)stream;
+    if (tt == 16 && tc == 16) SSAC_LAUNCH((fused_dual2_kernel<16, 16>), grid, dim3(NTHR), lds, st, gt, gc, tiles_t, tgx, cgx);
+    else if (tt == 16) SSAC_LAUNCH((fused_dual2_kernel<16, 32>), grid, dim3(NTHR), lds, st, gt, gc, tiles_t, tgx, cgx);
+    else if (tc == 16) SSAC_LAUNCH((fused_dual2_kernel<32, 16>), grid, dim3(NTHR), lds, st, gt, gc, tiles_t, tgx, cgx);
+    else SSAC_LAUNCH((fused_dual2_kernel<32, 32>), grid, dim3(NTHR), lds, st, gt, gc, tiles_t, tgx, cgx);
+    return ssac_check_launch("fused_dual2");
 }
 
 extern "C" int ssac_actor_sample_critic_fwd(const ssac_mlp *actor, const float *Xa, int64_t ldxa, int n_rows,

@@ -55,6 +55,8 @@ struct GemmArgs {
     int vec;                 // bit0: A rows are 16-byte aligned, bit1: B rows (row-contiguous operands)
     long long *dbg;          // optional s_memtime stamps of workgroup (0,0,0), thread 0
     int grid_x, grid_y;      // tiles along N and M (filled by the launcher)
+    const float *rowscale;   // TN mode: A[k][m] is multiplied by rowscale[e*sRow + k] while it is loaded (null: 1)
+    int64_t sRow;
     int Ktot;                // > 0: batch entry e covers k in [e*K, min((e+1)*K, Ktot)) (split-K over blocks)
     int64_t sGb;             // EPI_GRAD: bias-gradient stride per batch entry (0 = same as sC)
 };
@@ -152,12 +154,14 @@ struct RcVecLoader {
 #pragma unroll
         for (int q = 0; q < 2; ++q) p[q] = S + (rok ? (int64_t)(kfirst + kk + 16 * q) * ld + R0 + r4 : 0);
     }
-    __device__ __forceinline__ void load(int k0, int K, int64_t adv) {
+    __device__ __forceinline__ void load(int k0, int K, int64_t adv, const float *scale = nullptr) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const bool ok = rok && (k0 + kk + 16 * q) < K;
+            const int k = k0 + kk + 16 * q;
+            const bool ok = rok && k < K;
             const f4 x = *reinterpret_cast<const f4 *>(ok ? p[q] : safe);
-            v[q] = ok ? x : (f4){0.f, 0.f, 0.f, 0.f};
+            const float sc = scale ? scale[ok ? k : 0] : 1.0f;
+            v[q] = ok ? x * sc : (f4){0.f, 0.f, 0.f, 0.f};
             p[q] += adv;
         }
     }
@@ -205,7 +209,18 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     if (vecB) vb.init(B, g.ldb, n0, g.N, kg * BK, tid);
     const int64_t advA = (int64_t)KS * BK * g.lda, advB = (int64_t)KS * BK * g.ldb;
 
-    auto loadA = [&](int k0) { if (vecA) va.load(k0, Kloc, advA); else load_chunk<A_KC>(ra, A, g.lda, m0, g.M, k0, Kloc, tid); };
+    const float *rscale = (TN && g.rowscale) ? g.rowscale + (int64_t)e * g.sRow : nullptr;
+    auto loadA = [&](int k0) {
+        if (vecA) { va.load(k0, Kloc, advA, rscale); return; }
+        load_chunk<A_KC>(ra, A, g.lda, m0, g.M, k0, Kloc, tid);
+        if (TN && rscale) {  // (K x R) layout: this thread's 8 values sit at k = k0 + (tid >> 6) + 4 p
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int k = k0 + (tid >> 6) + 4 * p;
+                ra[p] *= rscale[k < Kloc ? k : 0];
+            }
+        }
+    };
     auto loadB = [&](int k0) { if (vecB) vb.load(k0, Kloc, advB); else load_chunk<B_KC>(rb, B, g.ldb, n0, g.N, k0, Kloc, tid); };
     auto storeA = [&](float *d) { if (vecA) va.store(d); else store_chunk<A_KC>(ra, d, tid); };
     auto storeB = [&](float *d) { if (vecB) vb.store(d); else store_chunk<B_KC>(rb, d, tid); };
@@ -573,7 +588,22 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                         const float *H2, const float *DQ, int n_rows, float *adam_m, float *adam_v,
                         const ssac_adam_ctl *ctl, float *grads, float *sumsq1, float *sumsq0, float *sumsq2,
                         int64_t sumsq_net_stride, float *target, float tau, void *stream,
-                        const CriticLogsArgs *logs = nullptr, unsigned *done = nullptr);
+                        const CriticLogsArgs *logs = nullptr, unsigned *done = nullptr,
+                        const float *rowscale = nullptr);
+
+extern "C" int ssac_mlp_wgrad_all_scaled(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
+                                         int64_t ldx, int64_t x_net_stride, const float *H1, const float *H2,
+                                         const float *DZ2u, const float *DZ1u, const float *row_scale, int n_rows,
+                                         float *adam_m, float *adam_v, const ssac_adam_ctl *ctl, float *grads,
+                                         float *sumsq2, float *sumsq1, float *sumsq0, int64_t sumsq_net_stride,
+                                         float *target, float tau, void *stream) {
+    if (!nets || nets->out_dim != 1) return ssac_fail("ssac_mlp_wgrad_all_scaled: single-output heads only");
+    if (!H2 || !row_scale) return ssac_fail("ssac_mlp_wgrad_all_scaled: H2 / row_scale missing");
+    // out_dim == 1: the per-row scale IS the head's output gradient dq (n_sel x n_rows x 1)
+    return wgrad_merged(nets, net_ids, n_sel, X, ldx, x_net_stride, H1, DZ2u, DZ1u, H2, row_scale, n_rows, adam_m,
+                        adam_v, ctl, grads, sumsq1, sumsq0, sumsq2, sumsq_net_stride, target, tau, stream, nullptr,
+                        nullptr, row_scale);
+}
 
 extern "C" int ssac_mlp_wgrad_all_logs(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
                                        int64_t ldx, int64_t x_net_stride, const float *H1, const float *H2,
@@ -619,7 +649,7 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                         const float *H2, const float *DQ, int n_rows, float *adam_m, float *adam_v,
                         const ssac_adam_ctl *ctl, float *grads, float *sumsq1, float *sumsq0, float *sumsq2,
                         int64_t sumsq_net_stride, float *target, float tau, void *stream,
-                        const CriticLogsArgs *logs, unsigned *done) {
+                        const CriticLogsArgs *logs, unsigned *done, const float *rowscale) {
     if (n_sel < 0 || n_sel > SSAC_MAX_NETS) return ssac_fail("ssac_mlp_wgrad_fc12: n_sel out of range");
     if (!grads && (!adam_m || !adam_v || !ctl)) return ssac_fail("ssac_mlp_wgrad_fc12: Adam state missing");
     if (n_sel == 0 || n_rows <= 0) return 0;
@@ -638,6 +668,7 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
         !build_wgrad_args(p.g1, nets, 0, net_ids, X, ldx, x_net_stride, DZ1, H, (int64_t)n_rows * H, n_rows,
                           adam_m, adam_v, ctl, grads, sumsq0, sumsq_net_stride, target, tau))
         return ssac_fail("ssac_mlp_wgrad_fc12: bad arena");
+    if (rowscale) { p.g0.rowscale = p.g1.rowscale = rowscale; p.g0.sRow = p.g1.sRow = n_rows; }
     hipStream_t st = (hipStream_t)stream;
     const int tiles = (p.g0.grid_x * p.g0.grid_y + p.g1.grid_x * p.g1.grid_y) * n_sel;
     const int nchunks = (n_rows + BK - 1) / BK;

@@ -318,7 +318,8 @@ def mlp_forward(arena, X, ldx, x_net_stride, n_rows, ws, tag, net_ids=None, n_se
 
 
 def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, adam=None, adam_key=None,
-                 grads=None, sumsq=None, target=None, tau=0.0, net_ids=None, n_sel=None, logs=None):
+                 grads=None, sumsq=None, target=None, tau=0.0, net_ids=None, n_sel=None, logs=None,
+                 rowscale=None):
     """the weight-gradient launch(es) (+Adam/Polyak in their epilogues, or gradient store).
     logs (critic update, Adam mode, merged launch only): dict(partials, tiles, denom, logs, spec_ptr, td_logs_ptr,
     feed, done) -- the launch's last workgroup then also finalises the update's logs; returns True when it did."""
@@ -337,6 +338,14 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
 
     def ssp(layer):
         return 0 if sumsq is None else sumsq.data_ptr() + 4 * off[layer]
+    if rowscale is not None:
+        # UNSCALED backward (ssac_target_fwd_critic_bwdu): dL/dq of every (net, row) scales the rows while they load
+        assert O == 1
+        check(lib.ssac_mlp_wgrad_all_scaled(C.byref(d), ids, n_sel, X.data_ptr(), ldx, x_net_stride, h1.data_ptr(),
+                                            h2.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), rowscale.data_ptr(), n_rows,
+                                            _ptr(m), _ptr(v), ctl, _ptr(grads), ssp(2), ssp(1), ssp(0), ttot,
+                                            _ptr(target), float(tau), st))
+        return
     if O <= 16 and MERGE_HEAD_WGRAD and logs is not None and grads is None and sumsq is not None:
         check(lib.ssac_mlp_wgrad_all_logs(
             C.byref(d), ids, n_sel, X.data_ptr(), ldx, x_net_stride, h1.data_ptr(), h2.data_ptr(), dz2.data_ptr(),

@@ -81,6 +81,8 @@ LAZY_TD = os.environ.get("SSAC_LAZY_TD", "1") == "1"
 SPLIT_FORWARD = os.environ.get("SSAC_SPLIT_FORWARD", "0") == "1"
 
 
+# the TD-independent half of the critics' backward pass inside the target-critic launch (rank-1 loss gradient)
+RANK1_BWD = os.environ.get("SSAC_RANK1_BWD", "1") == "1"
 DUAL_LAUNCH = os.environ.get("SSAC_DUAL_LAUNCH", "1") == "1"  # critic forward inside the actor-sample launch
 
 
@@ -334,7 +336,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             with engine.side_stream(dev, defer_join=True) as branch:
                 with engine._timed("critic_fwd"):
                     h1, h2, q = engine.mlp_forward(arena, X, ldx, 0, B, ws, tag)
-        co = None
+        co = cob = None
         if (DUAL_LAUNCH and branch is None and arena.fused and not train_enc and not dr3_coeff and not discrete
                 and _dual_fits(arena, B)):
             # the critics' forward rides in the actor's launch (when compute_td_targets uses the fused sample
@@ -343,13 +345,18 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             X, ldx = _critic_input(rd.get("_ssac"), ws, f"cu.x{i}", s_rep, a, discrete)
             co = (arena, X, ldx, ws.get(tag + ".h1", (N, B, H)), ws.get(tag + ".h2", (N, B, H)),
                   ws.get(tag + ".y", (N, B, qd)))
+            if RANK1_BWD and qd == 1 and parallel.shard_of(agent) is None:
+                # and the TD-independent half of the backward pass rides in the target critics' launch
+                cob = (arena, co[3], co[4], a, a.stride(0), ws.get(tag + ".dz2", (N, B, H)),
+                       ws.get(tag + ".dz1", (N, B, H)))
         td, _ = lu.compute_td_targets(logs=logs, replay_dict=rd, agent=agent, target_agent=target_agent,
                                       ensemble_idx=i, ensemble_n=target_critic_ensemble_n,
                                       log_alphas=log_alphas, pop=pop, gamma=gamma,
                                       random_process=random_process, noise_clip=noise_clip,
                                       discrete=discrete, _slot=slot, _defer=arena.fused and LAZY_TD and not dr3_coeff,
-                                      _co_forward=co)
+                                      _co_forward=co, _co_backward=cob)
         co_done = bool(rd.pop("_co_fwd", False))
+        bwd_done = bool(rd.pop("_co_bwd", False))
         if co_done:
             h1, h2, q = co[3], co[4], co[5]
         bw = lu.compute_backup_weights(logs=logs, replay_dict=rd, agent=agent, target_agent=target_agent,
@@ -426,7 +433,17 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             parts = ws.get(tag + ".parts", (N * tiles * 2,))
             spec = getattr(td, "_ssac_spec", None)  # the TD target is evaluated inside the critic launch
             spec_ptr = C.addressof(spec) if spec is not None else 0
-            if branch is not None or co_done:
+            if bwd_done:
+                # dz2u / dz1u exist already; what depends on the TD target is one scalar per (net, row): dL/dq
+                if spec is not None:
+                    check(lib.ssac_critic_loss_bwd_lazy(q.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0), spec_ptr,
+                                                        weight_ptr, pp, dopop, float(E * n_glob), dq.data_ptr(),
+                                                        slot.data_ptr(), st))
+                else:
+                    check(lib.ssac_critic_loss_bwd(q.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0), td.data_ptr(),
+                                                   weight_ptr, pp, dopop, float(E * n_glob), dq.data_ptr(),
+                                                   slot.data_ptr(), st))
+            elif branch is not None or co_done:
                 # loss gradient + head backward + backward-data on the saved forward: ONE launch
                 if branch is not None:
                     branch.join()
@@ -461,12 +478,13 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                             feed=cap.feed if (cap is not None and cap.feed) else 0,
                             done=ws.get("cu.done", (1,), dtype=torch.int32, zero=True))
             folded = engine.weight_grads(arena, X, ldx, 0, h1, h2, dq, dz2, dz1, B, adam=adam,
-                                         adam_key=("critic", i), grads=grads, sumsq=ss, logs=fold)
+                                         adam_key=("critic", i), grads=grads, sumsq=ss,
+                                         logs=None if bwd_done else fold, rowscale=dq if bwd_done else None)
             if folded:
                 logs_done_in_wgrad = True
                 if fold["feed"]:
                     engine.CAPTURE.published = True
-            fused_logs.append((parts, N, tiles, B, n_glob, td))
+            fused_logs.append((parts, 0 if bwd_done else N, tiles, B, n_glob, td))
         else:
             h1, h2, q = engine.mlp_forward(arena, X, ldx, 0, B, ws, tag)
             check(lib.ssac_critic_loss_bwd(q.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0),

@@ -303,12 +303,15 @@ def _upload_ids(ws, ids, device, tag):
 
 def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ensemble_n, log_alphas,
                        pop, gamma, random_process, noise_clip, discrete=False, _slot=None, _defer=False,
-                       _co_forward=None):
+                       _co_forward=None, _co_backward=None):
     """learning_utils.py:298-354.  With ``_defer`` (critic_update's fused path; continuous actions, no PopArt)
     the final elementwise step -- and its three log values -- is not launched here: the returned ``td`` buffer
     carries a ``_ssac_spec`` (ssac_td_spec) and the critic launch evaluates the targets into it.
     ``_co_forward`` = (critic arena, X, ldx, h1, h2, q): when the actor runs as the fused sample launch, the online
-    critics' forward rides in the SAME launch (ssac_actor_sample_critic_fwd); replay_dict["_co_fwd"] is then True."""
+    critics' forward rides in the SAME launch (ssac_actor_sample_critic_fwd); replay_dict["_co_fwd"] is then True.
+    ``_co_backward`` = (critic arena, h1, h2, act, ld_act, dz2u, dz1u): after such a forward, the TD-independent half
+    of the critics' backward pass rides in the target critics' launch (ssac_target_fwd_critic_bwdu);
+    replay_dict["_co_bwd"] is then True."""
     o, a, r, o1, d = replay_dict["primary_batch"]
     i = ensemble_idx
     dev = r.device
@@ -392,7 +395,9 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
                                           float(noise_clip) if noise_clip is not None else 0.0, B, A,
                                           x1.data_ptr(), S + A, S, st))
         ids = draw_subset(N, ensemble_n)
-        q1, n_q = _subset_q(ws, shard, t_arena, ids, x1, S + A, B, dev, f"td.c{i}")
+        cob = _co_backward if replay_dict.get("_co_fwd") else None
+        q1, n_q = _subset_q(ws, shard, t_arena, ids, x1, S + A, B, dev, f"td.c{i}", co_backward=cob,
+                            replay_dict=replay_dict)
         lp_ptr, qd = logp.data_ptr(), 1
         a_s1 = x1[:, S:]
     td = torch.empty(B, 1, device=dev)
@@ -435,12 +440,23 @@ def _actor_sample(a_arena, s1_rep, B, eps_ptr, actor, x1, S, A, logp, rng_ptr, s
                                       logp.data_ptr(), 0, 0, 0, rng_ptr, st))
 
 
-def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag):
+def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag, co_backward=None, replay_dict=None):
     """target-critic outputs for the REDQ subset `ids`: (q, n) with q of shape (n, B, out).
     Sharded: forward of the locally owned subset members, elementwise min, MIN all-reduce of the
     (B x out) partial (the one real exchange step of the critic update), n = 1."""
     if shard is None:
         ids_dev = _upload_ids(ws, ids, dev, "sub")
+        if co_backward is not None and t_arena.fused:
+            c_arena, h1, h2, act, ld_act, dz2u, dz1u = co_backward
+            q1 = ws.get(tag + ".y", (len(ids), B, t_arena.out_dim))
+            with engine._timed("dual_bwd") as tm:
+                for _ in range(tm.reps):  # 1, except under bench.py's live kernel timing (idempotent launch)
+                    check(lib.ssac_target_fwd_critic_bwdu(
+                        C.byref(t_arena.desc()), ids_dev.data_ptr(), len(ids), X.data_ptr(), ldx, B, q1.data_ptr(),
+                        C.byref(c_arena.desc()), h1.data_ptr(), h2.data_ptr(), act.data_ptr(), ld_act,
+                        dz2u.data_ptr(), dz1u.data_ptr(), engine.stream()))
+            replay_dict["_co_bwd"] = True
+            return q1, len(ids)
         _, _, q1 = engine.mlp_forward(t_arena, X, ldx, 0, B, ws, tag, net_ids=ids_dev, n_sel=len(ids),
                                       save=False)
         return q1, len(ids)

@@ -62,9 +62,10 @@ def test_graph_replay_equals_eager_launches():
     import torch
     import super_sac_amd as ssa
 
-    def run(use_graphs, split, mode="list"):
-        old, old_split, old_mode = ssa.learning.USE_GRAPHS, ssa.learning.SPLIT_FORWARD, ssa.learning.LAUNCH_MODE
-        ssa.learning.USE_GRAPHS, ssa.learning.SPLIT_FORWARD, ssa.learning.LAUNCH_MODE = use_graphs, split, mode
+    def run(use_graphs, split, mode="list", dual=True, rank1=True):
+        L = ssa.learning
+        old = (L.USE_GRAPHS, L.SPLIT_FORWARD, L.LAUNCH_MODE, L.DUAL_LAUNCH, L.RANK1_BWD)
+        L.USE_GRAPHS, L.SPLIT_FORWARD, L.LAUNCH_MODE, L.DUAL_LAUNCH, L.RANK1_BWD = use_graphs, split, mode, dual, rank1
         try:
             torch.manual_seed(3); np.random.seed(3); random.seed(3)
             dev = torch.device("cuda")
@@ -96,18 +97,25 @@ def test_graph_replay_equals_eager_launches():
             tparams = torch.cat([p.detach().flatten() for p in target.critics[0].parameters()]).cpu().numpy()
             return params, tparams, last, buf.total_sample_calls
         finally:
-            ssa.learning.USE_GRAPHS, ssa.learning.SPLIT_FORWARD, ssa.learning.LAUNCH_MODE = old, old_split, old_mode
+            L.USE_GRAPHS, L.SPLIT_FORWARD, L.LAUNCH_MODE, L.DUAL_LAUNCH, L.RANK1_BWD = old
 
+    # default configuration (merged launches, rank-1 backward): the three launch mechanisms agree bit for bit
     pe, te, le, ce = run(False, split=False)
     pg, tg, lg, cg = run(True, split=False, mode="list")     # the library's recorded launch list
     ph, th, lh, ch = run(True, split=False, mode="graph")    # a hipGraph captured through torch
     assert np.array_equal(pg, ph) and np.array_equal(tg, th) and lg[:2] == lh[:2] and ch == 20
-    # the critic forward as a parallel branch + backward-only launch vs. the single forward+backward launch
-    p1, t1, l1, _ = run(False, split=True)
-    p2, t2, l2, _ = run(True, split=True)
+    # the one-launch critic kernel, the forward riding in the actor launch + backward-only launch, and the critic
+    # forward as a parallel branch are the same arithmetic in the same order: bit-identical to each other
+    # (the rank-1 backward reorders the scaling by dL/dq and is only tolerance-equal: covered by the fixtures)
+    p0, t0, l0, _ = run(False, split=False, dual=False, rank1=False)
+    pd, td_, ld_, _ = run(False, split=False, dual=True, rank1=False)
+    p1, t1, l1, _ = run(False, split=True, dual=False, rank1=False)
+    p2, t2, l2, _ = run(True, split=True, dual=False, rank1=False)
     assert np.array_equal(p1, p2) and np.array_equal(t1, t2)
-    assert np.array_equal(pe, p1) and np.array_equal(te, t1) and le[0] == l1[0], \
+    assert np.array_equal(p0, pd) and np.array_equal(t0, td_) and l0[0] == ld_[0], "merged actor + critic-forward launch"
+    assert np.array_equal(p0, p1) and np.array_equal(t0, t1) and l0[0] == l1[0], \
         "split forward/backward launches must be bit-identical to the one-launch critic kernel"
+    assert np.allclose(pe, p0, atol=2e-6) and np.allclose(te, t0, atol=2e-6), "rank-1 backward vs fused backward"
     assert ce == cg == 20
     assert np.array_equal(le[2], lg[2]), "replay indices must not depend on the launch mechanism"
     assert np.array_equal(pe, pg) and np.array_equal(te, tg), "graph replay must be bit-identical to eager launches"

@@ -909,3 +909,45 @@ def test_merged_actor_and_critic_forward_launch_equals_the_two_launches(ssa, B, 
         0, C.byref(ca.desc()), xc.data_ptr(), S + A, g1.data_ptr(), g2.data_ptr(), gq.data_ptr(), st))
     for a_, b_, what in ((xa, xb, "a'"), (lpa, lpb, "log pi"), (h1, g1, "h1"), (h2, g2, "h2"), (q, gq, "q")):
         assert torch.equal(a_, b_), f"merged launch differs in {what}"
+
+
+@pytest.mark.parametrize("B,H,N", [(512, 256, 10), (70, 64, 2)])
+def test_rank1_backward_matches_autograd(ssa, B, H, N):
+    """TD-independent backward (ssac_target_fwd_critic_bwdu) + dL/dq as a row scale in the weight-gradient launch
+    (ssac_mlp_wgrad_all_scaled) against autograd of the critic loss."""
+    rng = np.random.RandomState(B + N)
+    in_dim = 23
+    mlps = [orc.make_mlp(rng, in_dim, H, 1) for _ in range(N)]
+    tgt = [orc.make_mlp(rng, in_dim, H, 1) for _ in range(3)]
+    x = torch.from_numpy(rng.standard_normal((B, in_dim)).astype(np.float32))
+    x1 = torch.from_numpy(rng.standard_normal((B, in_dim)).astype(np.float32))
+    td = torch.from_numpy(rng.standard_normal((B, 1)).astype(np.float32))
+    w = torch.from_numpy(rng.uniform(0.5, 1.5, (B, 1)).astype(np.float32))
+    ps = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in mlps]
+    loss = sum((w * (td - orc.mlp3(p, x)[0]) ** 2).mean() for p in ps) / N
+    loss.backward()
+    ar, tar = _arena_from(ssa, mlps), _arena_from(ssa, tgt)
+    dev = torch.device(DEV)
+    ws = ssa.engine.Workspace(dev)
+    lib, st = ssa._lib.lib, ssa.engine.stream()
+    xd, x1d, tdd, wd = x.to(DEV), x1.to(DEV), td.to(DEV), w.to(DEV)
+    h1, h2, q = ssa.engine.mlp_forward(ar, xd, in_dim, 0, B, ws, "f")
+    ids = torch.tensor([2, 0], dtype=torch.int32, device=DEV)
+    qt = torch.zeros(2, B, 1, device=DEV)
+    dz2, dz1 = torch.zeros(N, B, H, device=DEV), torch.zeros(N, B, H, device=DEV)
+    dummy_act = torch.zeros(B, 1, device=DEV)
+    ssa._lib.check(lib.ssac_target_fwd_critic_bwdu(C.byref(tar.desc()), ids.data_ptr(), 2, x1d.data_ptr(), in_dim, B,
+                                                   qt.data_ptr(), C.byref(ar.desc()), h1.data_ptr(), h2.data_ptr(),
+                                                   dummy_act.data_ptr(), 1, dz2.data_ptr(), dz1.data_ptr(), st))
+    for k, j in enumerate((2, 0)):  # the target half of the launch is an ordinary forward
+        _close(qt[k], orc.mlp3(tgt[j], x1)[0], 5e-5, what=f"target q[{j}]")
+    dq, logs = torch.zeros(N, B, 1, device=DEV), torch.zeros(4, device=DEV)
+    ssa._lib.check(lib.ssac_critic_loss_bwd(q.data_ptr(), N, B, 1, 0, 1, tdd.data_ptr(), wd.data_ptr(), 0, 0, float(N),
+                                            dq.data_ptr(), logs.data_ptr(), st))
+    assert abs(float(logs[0]) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
+    grads = torch.zeros_like(ar.params)
+    ss = torch.zeros(N * ssa.engine.wgrad_tiles_total(ar), device=DEV)
+    ssa.engine.weight_grads(ar, xd, in_dim, 0, h1, h2, dq, dz2, dz1, B, grads=grads, sumsq=ss, rowscale=dq)
+    for j in range(N):
+        for seg in ssa.engine.SEGS:
+            _close(ar.view(j, seg, grads), ps[j][seg].grad, 3e-6, rtol=1e-4, what=f"grad {seg}[{j}]")

@@ -41,7 +41,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 # HBM bytes per launch from the PMC passes in profiles/r1_pmc_counters.md (FETCH_SIZE doubled per the guide's gfx950
 # note for 16-byte streaming reads + WRITE_SIZE, KiB -> bytes); not collected live, N=10 single-GPU shape only
 TRAFFIC_FUSED_CRITIC_BYTES = (2 * 13165 + 20527) * 1024
-TRAFFIC_DUAL_BYTES = None  # filled after the PMC pass of the merged actor + critic-forward launch
+TRAFFIC_DUAL_BYTES = (2 * 12812 + 10288) * 1024  # merged actor + ensemble-Q forward launch (gpurun_out/pmc3_*)
 TRAFFIC_FWD_BYTES = None  # the two-launch form (SSAC_SPLIT_FORWARD=1) has no PMC pass yet
 
 

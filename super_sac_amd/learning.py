@@ -204,7 +204,9 @@ def _critic_update_graphed(gs, kw):
     # ---- host draws, in the reference's order: indices -> (augmentation: none here) -> noise -> subset
     buffer.total_sample_calls += 1
     idx_cpu = rng.draw_indices(len(buffer), B)
-    in_kernel_noise = kind == "stochastic" and lu.IN_KERNEL_NOISE and rng.normal_is_stock()
+    # (the in-kernel stream is used by the fused actor-sample launch only: wide action heads take the per-layer path)
+    in_kernel_noise = (kind == "stochastic" and lu.IN_KERNEL_NOISE and rng.normal_is_stock()
+                       and engine.bind_arena(actor, "self", [actor], dev).fused)
     if gs.graph is not None and gs.in_kernel_noise != in_kernel_noise:
         gs.graph = None  # a noise hook was installed / removed since the recording: record the update again
         gs.feed = None

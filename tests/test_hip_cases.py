@@ -151,3 +151,47 @@ def test_pixel_cases_with_implicit_gemm_convolutions(name):
     finally:
         ssa.conv_encoder.IMPLICIT_MIN_ROWS = old
     case_runner.compare(rec, case_runner.load_fixture(name), who=f"hip[{name},implicit-conv]")
+
+
+def test_recorded_updates_with_a_wide_action_head():
+    """9-dimensional actions: the actor's 18 outputs exceed the fused kernels' 16-output head, so the actor runs on
+    the per-layer kernels and its noise comes from torch's generator -- inside a recorded update as well (this
+    combination once crashed the recording).  Recorded replay must equal eager launches bit for bit."""
+    import copy
+    import math
+    import random
+    from itertools import chain
+
+    import torch
+    import super_sac_amd as ssa
+
+    def run(use_lists):
+        old = ssa.learning.USE_GRAPHS
+        ssa.learning.USE_GRAPHS = use_lists
+        try:
+            torch.manual_seed(5); np.random.seed(5); random.seed(5)
+            dev = torch.device("cuda")
+            agent = ssa.Agent(act_space_size=9, encoder=ssa.nets.IdentityEncoder(20),
+                              actor_network_cls=ssa.nets.ContinuousStochasticActor,
+                              critic_network_cls=ssa.nets.ContinuousCritic, ensemble_size=1, num_critics=2,
+                              hidden_size=64, auto_rescale_targets=False, log_std_low=-5.0, log_std_high=2.0)
+            agent.to(dev)
+            target = copy.deepcopy(agent)
+            buf = ssa.replay.ReplayBuffer(2048, device=dev)
+            buf.load_experience(*synth.synth_transitions(1000, 20, 9, seed=7))
+            copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=3e-4)
+            eopt = torch.optim.Adam(agent.encoder.parameters(), lr=1e-4)
+            la = torch.Tensor([math.log(0.1)]).to(dev); la.requires_grad = True
+            aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(64)])
+            for _ in range(8):
+                ssa.learning.critic_update(
+                    buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt, encoder_optimizer=eopt,
+                    log_alphas=[la], batch_size=64, gamma=0.99, critic_clip=None, encoder_clip=None,
+                    target_critic_ensemble_n=2, weighted_bellman_temp=None, weight_type=None, pop=False,
+                    augmenter=aug, encoder_lambda=0, aug_mix=0.0, discrete=False, random_process=None,
+                    noise_clip=None, per=False, update_priorities=False, dr3_coeff=0.0)
+            return torch.cat([p.detach().flatten() for p in agent.critics[0].parameters()]).cpu().numpy()
+        finally:
+            ssa.learning.USE_GRAPHS = old
+
+    assert np.array_equal(run(False), run(True))

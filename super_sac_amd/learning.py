@@ -347,7 +347,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             X, ldx = _critic_input(rd.get("_ssac"), ws, f"cu.x{i}", s_rep, a, discrete)
             co = (arena, X, ldx, ws.get(tag + ".h1", (N, B, H)), ws.get(tag + ".h2", (N, B, H)),
                   ws.get(tag + ".y", (N, B, qd)))
-            if RANK1_BWD and qd == 1 and parallel.shard_of(agent) is None:
+            if RANK1_BWD and qd == 1:
                 # and the TD-independent half of the backward pass rides in the target critics' launch
                 cob = (arena, co[3], co[4], a, a.stride(0), ws.get(tag + ".dz2", (N, B, H)),
                        ws.get(tag + ".dz1", (N, B, H)))

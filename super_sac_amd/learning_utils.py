@@ -469,7 +469,17 @@ def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag, co_backward=None, re
         # per-update device id block holds the LOCAL index of the members this rank owns and -1 for the others
         # (their outputs are +inf), and the collective runs between two recorded segments
         n = len(ids)
-        _, _, q1 = engine.mlp_forward(t_arena, X, ldx, 0, B, ws, tag, net_ids=cap.ids_dev, n_sel=n, save=False)
+        if co_backward is not None and t_arena.fused:
+            # ... and the TD-independent half of the local critics' backward pass rides in the same launch
+            c_arena, h1, h2, act, ld_act, dz2u, dz1u = co_backward
+            q1 = ws.get(tag + ".y", (n, B, O))
+            check(lib.ssac_target_fwd_critic_bwdu(
+                C.byref(t_arena.desc()), cap.ids_dev.data_ptr(), n, X.data_ptr(), ldx, B, q1.data_ptr(),
+                C.byref(c_arena.desc()), h1.data_ptr(), h2.data_ptr(), act.data_ptr(), ld_act, dz2u.data_ptr(),
+                dz1u.data_ptr(), engine.stream()))
+            replay_dict["_co_bwd"] = True
+        else:
+            _, _, q1 = engine.mlp_forward(t_arena, X, ldx, 0, B, ws, tag, net_ids=cap.ids_dev, n_sel=n, save=False)
         _min_over_nets(q1, n, B * O, qpart)
         cap.collective(lambda: parallel.all_reduce_min(qpart))
         return qpart, 1

@@ -166,6 +166,12 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     step, ssa = build_engine(device, n_local, shard)
+    # Python's cyclic GC otherwise runs a full (generation-2) collection over the whole torch object graph every few
+    # hundred updates -- a 40-80 ms pause, i.e. hundreds of updates: park the start-up objects in the permanent
+    # generation (host runtime hygiene of a long-running training loop; nothing the update path allocates is cyclic)
+    import gc
+    gc.collect()
+    gc.freeze()
     for _ in range(args.warmup):
         step()
 

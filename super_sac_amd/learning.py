@@ -10,6 +10,7 @@ logs stay on the device until somebody reads them.
 import ctypes as C
 import os
 
+import numpy as np
 import torch
 
 from . import engine, parallel, rng
@@ -191,9 +192,13 @@ def _critic_update_graphed(gs, kw):
         gs.idx_dev = gs.inbuf[:8 * B].view(torch.int64)
         gs.ids_dev = gs.inbuf[8 * B:8 * B + 4 * n_pad].view(torch.int32)[:n_sub]
         gs.host = torch.zeros(FEED_SLOTS, nbytes, dtype=torch.uint8).pin_memory()
-        gs.host_idx = gs.host[:, :8 * B].view(torch.int64)
-        gs.host_i32 = gs.host[:, 8 * B:].view(torch.int32)  # ids..., then the log slot at [n_pad]
+        # numpy views of the pinned slots (host writes through numpy cost a fraction of torch indexing)
+        hnp = gs.host.numpy()
+        gs.np_idx = hnp[:, :8 * B].view(np.int64)                           # (slots, B)
+        gs.np_i32 = hnp[:, 8 * B:8 * B + 4 * n_pad + 8].view(np.int32)      # ids..., then the log slot at [n_pad]
+        gs.np_draw = hnp[:, 8 * B + 4 * n_pad + 8:8 * B + 4 * n_pad + 16].view(np.int64)  # (slots, 1)
         gs.n_pad = n_pad
+        gs.log_views = {}
         gs.events = [None] * FEED_SLOTS
         gs.k = 0
         gs.eps_dev = torch.empty(B, actor.action_size, device=dev) if kind == "stochastic" else None
@@ -220,15 +225,14 @@ def _critic_update_graphed(gs, kw):
     if gs.events[k] is not None:
         gs.events[k].synchronize()  # the replay that read this slot FEED_SLOTS updates ago has finished
     slot_i = ring.advance()
-    gs.host_idx[k].copy_(idx_cpu)
-    row = gs.host_i32[k]
+    gs.np_idx[k] = idx_cpu.numpy()
+    row = gs.np_i32[k]
     for j, v in enumerate(ids):
         # sharded: the LOCAL index of a subset member this rank owns, -1 for a member that lives elsewhere
         row[j] = v if shard is None else (v - shard.lo if shard.owns(v) else -1)
     row[gs.n_pad] = slot_i
     if in_kernel_noise:
-        gs.host[k, 8 * B + 4 * gs.n_pad + 8:8 * B + 4 * gs.n_pad + 16].view(torch.int64)[0] = \
-            lu.noise_stream(agent, dev)[1]
+        gs.np_draw[k, 0] = lu.noise_stream(agent, dev)[1]
     if gs.graph is None:
         gs.in_kernel_noise = in_kernel_noise
         ctx = engine.CaptureCtx(idx_cpu, gs.idx_dev, ids, gs.ids_dev,
@@ -280,6 +284,9 @@ def _critic_update_graphed(gs, kw):
         gs.graph, gs.dicts = graph, dicts
         base = gs.logblk.data_ptr()
         gs.log_index = {k_: (v.data_ptr() - base) // 4 for k_, v in logs.items()}
+        # the 0-dim views handed out as log values, for every slot of the ring, built once here
+        gs.log_views = {si: {k_: ring.buf[si][i] for k_, i in gs.log_index.items()}
+                        for si in range(ring.buf.shape[0])}
     else:
         gs.graph.replay()  # ONE host call re-issues the whole update
     ev = gs.events[k]
@@ -290,8 +297,11 @@ def _critic_update_graphed(gs, kw):
     if in_kernel_noise:
         lu.noise_stream(agent, dev)[1] += 1  # one draw of the agent's noise stream per update, as in eager launches
     rng.choice(agent.critics)  # keep the Python RNG stream in step with learning.py:135
-    slot = ring.buf[slot_i]
-    logs = {k_: slot[i] for k_, i in gs.log_index.items()}
+    logs = gs.log_views.get(slot_i)
+    if logs is None:  # 0-dim views of this ring slot, built once per slot
+        slot = ring.buf[slot_i]
+        logs = gs.log_views[slot_i] = {k_: slot[i] for k_, i in gs.log_index.items()}
+    logs = dict(logs)
     rd = gs.dicts[0]
     rd["priority_idxs"] = idx_cpu.numpy()
     rd["_subset"] = ids

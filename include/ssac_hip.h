@@ -370,8 +370,10 @@ int ssac_drq_shift(const void *src, int src_dtype, const int64_t *idx, int n, in
 
 /* ==== fused kernels (csrc/ssac_fused.hip): the same arithmetic as the per-layer entry points above,
  * with the activations of a 32-row tile kept in LDS across fc1 -> fc2 -> head.  Supported when
- * ssac_fused_supported() (hidden % 32 == 0, hidden <= 256, out_dim <= 16, LDS carve fits 160 KB);
- * callers fall back to the per-layer entry points otherwise. ==== */
+ * ssac_fused_supported() (hidden % 32 == 0, hidden <= 256, out_dim <= 64, LDS carve fits 160 KB);
+ * callers fall back to the per-layer entry points otherwise.  Returns 1 when the double-buffered weight
+ * staging fits (required of the CRITIC halves of the merged launches below), 2 when only the single-buffer
+ * carve fits (wide input + wide head, e.g. 376 -> 34), 0 when unsupported. ==== */
 int ssac_fused_supported(const ssac_mlp *nets);
 /* development aid: when set to a device buffer of >= 16 int64, workgroup (0,0) of every fused launch
  * records s_memtime() at its phase boundaries there; NULL (default) disables it. */

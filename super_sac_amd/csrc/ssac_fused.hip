@@ -23,7 +23,7 @@
 // v_mfma_f32_32x32x2_f32 accumulator (exact fp32).  The A operand (x, h1, dz2) is read from LDS
 // with odd row strides (bank = (row + k) % 32, conflict free); weight chunks of 32 k-steps are
 // staged through a 33 KB LDS buffer with the next chunk's global loads in flight during the MFMAs.
-// Constraints (checked by ssac_fused_supported): hidden % 32 == 0, hidden <= 256, out_dim <= 16,
+// Constraints (checked by ssac_fused_supported): hidden % 32 == 0, hidden <= 256, out_dim <= 64,
 // and the LDS carve (depends on in_dim) must fit 160 KB; other shapes use the per-layer kernels.
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -45,7 +45,8 @@ constexpr int NTHR = 512;       // 8 waves
 constexpr int WS_LD = 36;             // K-contiguous staging row stride: 16-byte rows, conflict-free b128
 constexpr int WS_FLOATS = 256 * WS_LD;  // weight staging buffer (>= 32*256 for the row-contiguous image)
 constexpr int APAD = 4;               // activation rows are padded by 4 floats (16-byte aligned rows)
-constexpr int MAX_OUT = 16;
+constexpr int MAX_OUT = 16;   // head outputs per MFMA pass (one 16-wide B tile)
+constexpr int HEAD_MAX = 64;  // widest head the fused kernels take (several passes)
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 constexpr float LOG_2 = 0.69314718055994530942f;
 
@@ -375,6 +376,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                                                const int grid_x) {
     typedef Tile<TMR> T;
     const int H = g.hidden, IN = g.in_dim, OUT = g.out_dim;
+    const int ldo = (OUT + 15) & ~15;  // row stride of the per-row head outputs / output gradients in LDS
     const int KP = (IN + 31) & ~31;
     const int ldx_s = KP + APAD, ldh = H + APAD;
     float *xs = smem;                       // [TMR][KP+4]
@@ -382,14 +384,14 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     float *h2s = h1s + TMR * ldh;           // [TMR][H+4]
     float *Ws = h2s + TMR * ldh;            // staging buffer 0
     float *Ws1 = Ws + WS_FLOATS;            // staging buffer 1 (DBUF only)
-    float *ys = Ws + (DBUF ? 2 : 1) * WS_FLOATS;  // [TMR][MAX_OUT]
-    float *dqs = ys + TMR * MAX_OUT;        // [TMR][MAX_OUT]
-    float *rowred = dqs + TMR * MAX_OUT;    // [64]
+    float *ys = Ws + (DBUF ? 2 : 1) * WS_FLOATS;  // [TMR][ldo], ldo = out_dim rounded up to 16
+    float *dqs = ys + TMR * ldo;            // [TMR][ldo]
+    float *rowred = dqs + TMR * ldo;        // [64]
     // small operands fetched at kernel start, so later phases never begin with a global round trip:
     float *b1s = rowred + 64;               // [H]
     float *b2s = b1s + H;                   // [H]
-    float *b3s = b2s + H;                   // [16]
-    float *w3s = b3s + 16;                  // [OUT][H+4]
+    float *b3s = b2s + H;                   // [HEAD_MAX]
+    float *w3s = b3s + HEAD_MAX;            // [OUT][H+4]
     float *rowin = w3s + OUT * (H + APAD);  // [3][TMR]: td, weight, action index of this tile's rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -448,7 +450,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         if (!UNSCALED)
             for (int i = tid; i < TMR * OUT; i += NTHR) {
                 const int r = i / OUT, o = i - r * OUT;
-                ys[r * MAX_OUT + o] = (m0 + r) < g.n_rows ? g.Y[((int64_t)e * g.n_rows + m0 + r) * OUT + o] : 0.0f;
+                ys[r * ldo + o] = (m0 + r) < g.n_rows ? g.Y[((int64_t)e * g.n_rows + m0 + r) * OUT + o] : 0.0f;
             }
     } else {
         // ---- first weight chunk of fc1 in flight before anything else
@@ -517,39 +519,44 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         // ---- head on the matrix cores: wave w multiplies the k-slice [32w, 32w+32) of h2 with W3^T
         //      (a 16-wide B tile, rows >= OUT zero); the 8 partial tiles are summed through LDS.
         {
-            f32x4 hacc[TMR / 16];
-#pragma unroll
-            for (int q = 0; q < TMR / 16; ++q)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) hacc[q][i] = 0.0f;
+            // 16 head outputs at a time (heads wider than one MFMA tile, e.g. a 34-output actor, take several passes)
             const int li = lane & 15, lg = lane >> 4;
-            if (col0 < H) {  // col0 = 32*wave doubles as this wave's k-slice start
-                const f4 *bp = reinterpret_cast<const f4 *>(w3s + (li < OUT ? li : 0) * ldw3 + col0 + lg * 8);
-                const float keep = li < OUT ? 1.0f : 0.0f;  // rows >= OUT of the 16-wide B tile are zero
-                const f4 b0 = bp[0] * keep, b1 = bp[1] * keep;
+            for (int ob = 0; ob < ldo; ob += 16) {
+                f32x4 hacc[TMR / 16];
 #pragma unroll
-                for (int q = 0; q < TMR / 16; ++q) {
-                    const f4 *ap = reinterpret_cast<const f4 *>(h2s + (16 * q + li) * ldh + col0 + lg * 8);
-                    const f4 a0 = ap[0], a1 = ap[1];
+                for (int q = 0; q < TMR / 16; ++q)
 #pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                        hacc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(t < 4 ? a0[t & 3] : a1[t & 3],
-                                                                       t < 4 ? b0[t & 3] : b1[t & 3], hacc[q], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) hacc[q][i] = 0.0f;
+                if (col0 < H) {  // col0 = 32*wave doubles as this wave's k-slice start
+                    const int lo = ob + li;
+                    const f4 *bp = reinterpret_cast<const f4 *>(w3s + (lo < OUT ? lo : 0) * ldw3 + col0 + lg * 8);
+                    const float keep = lo < OUT ? 1.0f : 0.0f;  // rows >= OUT of the 16-wide B tile are zero
+                    const f4 b0 = bp[0] * keep, b1 = bp[1] * keep;
+#pragma unroll
+                    for (int q = 0; q < TMR / 16; ++q) {
+                        const f4 *ap = reinterpret_cast<const f4 *>(h2s + (16 * q + li) * ldh + col0 + lg * 8);
+                        const f4 a0 = ap[0], a1 = ap[1];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            hacc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(t < 4 ? a0[t & 3] : a1[t & 3],
+                                                                           t < 4 ? b0[t & 3] : b1[t & 3], hacc[q], 0, 0, 0);
+                    }
                 }
-            }
+                if (ob > 0) __syncthreads();  // the previous block's partials have been summed
 #pragma unroll
-            for (int q = 0; q < TMR / 16; ++q)
+                for (int q = 0; q < TMR / 16; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    hpart[(wave * TMR + 16 * q + 4 * lg + r) * MAX_OUT + li] = hacc[q][r];
-            __syncthreads();
-            const int row = tid >> 4, o = tid & 15;
-            if (row < TMR && o < OUT) {
-                float v = b3s[o];
+                    for (int r = 0; r < 4; ++r)
+                        hpart[(wave * TMR + 16 * q + 4 * lg + r) * MAX_OUT + li] = hacc[q][r];
+                __syncthreads();
+                const int row = tid >> 4, o = ob + (tid & 15);
+                if (row < TMR && o < OUT) {
+                    float v = b3s[o];
 #pragma unroll
-                for (int w = 0; w < 8; ++w) v += hpart[(w * TMR + row) * MAX_OUT + o];
-                ys[row * MAX_OUT + o] = v;
-                if (g.Y && (m0 + row) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + row) * OUT + o] = v;
+                    for (int w = 0; w < 8; ++w) v += hpart[(w * TMR + row) * MAX_OUT + (tid & 15)];
+                    ys[row * ldo + o] = v;
+                    if (g.Y && (m0 + row) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + row) * OUT + o] = v;
+                }
             }
         }
     }
@@ -564,16 +571,16 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         // dimensions' log-probability terms in index order (the order a serial loop would use)
         const int A = OUT >> 1;
         float *lpt = dqs;  // [TMR][MAX_OUT] scratch, unused in this mode
-        if (tid < TMR * A) {
-            const int r = tid / A, i = tid - r * A, b = m0 + r;
+        for (int t = tid; t < TMR * A; t += NTHR) {
+            const int r = t / A, i = t - r * A, b = m0 + r;
             if (b < g.n_rows) {
-                const float mu = ys[r * MAX_OUT + i], raw = ys[r * MAX_OUT + A + i];
+                const float mu = ys[r * ldo + i], raw = ys[r * ldo + A + i];
                 const float log_std = g.lo + 0.5f * (g.hi - g.lo) * (tanhf(raw) + 1.0f);
                 const float sd = expf(log_std);
                 const float ep = g.eps ? g.eps[(int64_t)b * A + i] : philox_normal(g.rng.seed, rng_draw(g.rng), b, i);
                 const float u = mu + sd * ep;
                 const float dlt = u - mu;
-                lpt[r * MAX_OUT + i] = (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -
+                lpt[r * ldo + i] = (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -
                                        2.0f * (LOG_2 - u - softplus_f(-2.0f * u));
                 g.act_dst[b * g.ld_act + g.act_col0 + i] = tanhf(u);
             }
@@ -581,7 +588,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         __syncthreads();
         if (g.logp && tid < TMR && (m0 + tid) < g.n_rows) {
             float lp = 0.0f;
-            for (int i = 0; i < A; ++i) lp += lpt[tid * MAX_OUT + i];
+            for (int i = 0; i < A; ++i) lp += lpt[tid * ldo + i];
             g.logp[m0 + tid] = lp;
         }
         return;
@@ -597,7 +604,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
             // selector of the head output the loss looks at (the taken action; the only output when OUT == 1)
             if (tid < TMR) {
                 const int ai = OUT > 1 ? (int)rowin[2 * TMR + tid] : 0;
-                for (int o = 0; o < OUT; ++o) dqs[tid * MAX_OUT + o] = (o == ai && (m0 + tid) < g.n_rows) ? 1.0f : 0.0f;
+                for (int o = 0; o < OUT; ++o) dqs[tid * ldo + o] = (o == ai && (m0 + tid) < g.n_rows) ? 1.0f : 0.0f;
             }
         } else if (tid < TMR) {
             const int b = m0 + tid;
@@ -606,14 +613,14 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
             if (b < g.n_rows) {
                 if (OUT > 1) ai = (int)rowin[2 * TMR + tid];
                 const float w = rowin[TMR + tid];
-                const float err = rowin[tid] - (pw * ys[tid * MAX_OUT + ai] + pb);
+                const float err = rowin[tid] - (pw * ys[tid * ldo + ai] + pb);
                 lossv = w * err * err;
                 errv = err;
                 dsel = gscale * w * err;
             }
             for (int o = 0; o < OUT; ++o) {
                 const float d = (o == ai) ? dsel : 0.0f;
-                dqs[tid * MAX_OUT + o] = d;
+                dqs[tid * ldo + o] = d;
                 if (b < g.n_rows) g.DQ[((int64_t)e * g.n_rows + b) * OUT + o] = d;
             }
         }
@@ -643,7 +650,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 for (int o = 0; o < OUT; ++o) {
                     const float w = w3s[o * ldw3 + k];
 #pragma unroll
-                    for (int j = 0; j < NR; ++j) gs[j] += dqs[(r0 + 2 * j) * MAX_OUT + o] * w;
+                    for (int j = 0; j < NR; ++j) gs[j] += dqs[(r0 + 2 * j) * ldo + o] * w;
                 }
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
@@ -686,12 +693,13 @@ void fused_mlp_kernel(FusedArgs g) {
 // cross-stream signalling (which costs ~10 us on this platform, see SPLIT_FORWARD in learning.py).
 // TC = row-tile size of the critic half (the same automatic choice a stand-alone forward would make, so the
 // results are bit-identical to it).
-template <int TC>
+// ADBUF = the actor half double-buffers its weight staging (false when a wide input + wide head leave no room).
+template <int TC, bool ADBUF>
 __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_dual_kernel(FusedArgs ga, FusedArgs gc, int tiles_a, int critic_grid_x) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if ((int)blockIdx.x < tiles_a) {
-        fused_mlp_body<MODE_SAMPLE, 16, true>(ga, smem, blockIdx.x, 0, tiles_a);
+        fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga, smem, blockIdx.x, 0, tiles_a);
     } else {
         const int L = blockIdx.x - tiles_a;
         fused_mlp_body<MODE_PLAIN, TC, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x);
@@ -871,6 +879,7 @@ __global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
     typedef Tile<TMR> T;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int H = g.hidden, IN = g.in_dim, OUT = g.out_dim;
+    const int ldo = (OUT + 15) & ~15;  // row stride of the per-row head outputs / output gradients in LDS
     const int KP = (IN + 31) & ~31;
     const int ldx_s = KP + APAD, ldh = H + APAD, ldw3 = H + APAD;
     float *xs = smem;                       // [TMR][KP+4]
@@ -878,13 +887,13 @@ __global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
     // after fc2, [xs | h1s] is dead and holds the head's K-split partials [8][TMR][16]
     const int front = max(TMR * ldx_s + TMR * ldh, 8 * TMR * MAX_OUT);
     float *h2s = smem + front;              // [TMR][H+4]
-    float *ys = h2s + TMR * ldh;            // [TMR][MAX_OUT]
-    float *dqs = ys + TMR * MAX_OUT;        // [TMR][MAX_OUT]
-    float *rowred = dqs + TMR * MAX_OUT;    // [64]
+    float *ys = h2s + TMR * ldh;            // [TMR][ldo], ldo = out_dim rounded up to 16
+    float *dqs = ys + TMR * ldo;            // [TMR][ldo]
+    float *rowred = dqs + TMR * ldo;        // [64]
     float *b1s = rowred + 64;               // [H]
     float *b2s = b1s + H;                   // [H]
-    float *b3s = b2s + H;                   // [16]
-    float *w3s = b3s + 16;                  // [OUT][H+4]
+    float *b3s = b2s + H;                   // [HEAD_MAX]
+    float *w3s = b3s + HEAD_MAX;            // [OUT][H+4]
     float *rowin = w3s + OUT * ldw3;        // [3][TMR]
     float *hpart = smem;
 
@@ -934,7 +943,7 @@ __global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
         }
         for (int i = tid; i < TMR * OUT; i += NTHR) {
             const int r = i / OUT, o = i - r * OUT;
-            ys[r * MAX_OUT + o] = (m0 + r) < g.n_rows ? g.Y[((int64_t)e * g.n_rows + m0 + r) * OUT + o] : 0.0f;
+            ys[r * ldo + o] = (m0 + r) < g.n_rows ? g.Y[((int64_t)e * g.n_rows + m0 + r) * OUT + o] : 0.0f;
         }
         T::zero(acc);
         T::foreach(acc, lane, [&](int row, int cw, float) {  // (only the element order matters here)
@@ -998,39 +1007,44 @@ __global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
         STAMP(6);
         // ---- head on the matrix cores (see fused_mlp_kernel)
         {
-            f32x4 hacc[TMR / 16];
-#pragma unroll
-            for (int q = 0; q < TMR / 16; ++q)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) hacc[q][i] = 0.0f;
+            // 16 head outputs at a time (heads wider than one MFMA tile, e.g. a 34-output actor, take several passes)
             const int li = lane & 15, lg = lane >> 4;
-            if (col0 < H) {
-                const f4 *bp = reinterpret_cast<const f4 *>(w3s + (li < OUT ? li : 0) * ldw3 + col0 + lg * 8);
-                const float keep = li < OUT ? 1.0f : 0.0f;
-                const f4 b0 = bp[0] * keep, b1 = bp[1] * keep;
+            for (int ob = 0; ob < ldo; ob += 16) {
+                f32x4 hacc[TMR / 16];
 #pragma unroll
-                for (int q = 0; q < TMR / 16; ++q) {
-                    const f4 *ap = reinterpret_cast<const f4 *>(h2s + (16 * q + li) * ldh + col0 + lg * 8);
-                    const f4 a0 = ap[0], a1 = ap[1];
+                for (int q = 0; q < TMR / 16; ++q)
 #pragma unroll
-                    for (int t = 0; t < 8; ++t)
-                        hacc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(t < 4 ? a0[t & 3] : a1[t & 3],
-                                                                       t < 4 ? b0[t & 3] : b1[t & 3], hacc[q], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) hacc[q][i] = 0.0f;
+                if (col0 < H) {  // col0 = 32*wave doubles as this wave's k-slice start
+                    const int lo = ob + li;
+                    const f4 *bp = reinterpret_cast<const f4 *>(w3s + (lo < OUT ? lo : 0) * ldw3 + col0 + lg * 8);
+                    const float keep = lo < OUT ? 1.0f : 0.0f;  // rows >= OUT of the 16-wide B tile are zero
+                    const f4 b0 = bp[0] * keep, b1 = bp[1] * keep;
+#pragma unroll
+                    for (int q = 0; q < TMR / 16; ++q) {
+                        const f4 *ap = reinterpret_cast<const f4 *>(h2s + (16 * q + li) * ldh + col0 + lg * 8);
+                        const f4 a0 = ap[0], a1 = ap[1];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            hacc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(t < 4 ? a0[t & 3] : a1[t & 3],
+                                                                           t < 4 ? b0[t & 3] : b1[t & 3], hacc[q], 0, 0, 0);
+                    }
                 }
-            }
+                if (ob > 0) __syncthreads();  // the previous block's partials have been summed
 #pragma unroll
-            for (int q = 0; q < TMR / 16; ++q)
+                for (int q = 0; q < TMR / 16; ++q)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    hpart[(wave * TMR + 16 * q + 4 * lg + r) * MAX_OUT + li] = hacc[q][r];
-            __syncthreads();
-            const int row = tid >> 4, o = tid & 15;
-            if (row < TMR && o < OUT) {
-                float v = b3s[o];
+                    for (int r = 0; r < 4; ++r)
+                        hpart[(wave * TMR + 16 * q + 4 * lg + r) * MAX_OUT + li] = hacc[q][r];
+                __syncthreads();
+                const int row = tid >> 4, o = ob + (tid & 15);
+                if (row < TMR && o < OUT) {
+                    float v = b3s[o];
 #pragma unroll
-                for (int w = 0; w < 8; ++w) v += hpart[(w * TMR + row) * MAX_OUT + o];
-                ys[row * MAX_OUT + o] = v;
-                if (g.Y && (m0 + row) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + row) * OUT + o] = v;
+                    for (int w = 0; w < 8; ++w) v += hpart[(w * TMR + row) * MAX_OUT + (tid & 15)];
+                    ys[row * ldo + o] = v;
+                    if (g.Y && (m0 + row) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + row) * OUT + o] = v;
+                }
             }
         }
     }
@@ -1043,16 +1057,16 @@ __global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
         // dimensions' log-probability terms in index order (the order a serial loop would use)
         const int A = OUT >> 1;
         float *lpt = dqs;  // [TMR][MAX_OUT] scratch, unused in this mode
-        if (tid < TMR * A) {
-            const int r = tid / A, i = tid - r * A, b = m0 + r;
+        for (int t = tid; t < TMR * A; t += NTHR) {
+            const int r = t / A, i = t - r * A, b = m0 + r;
             if (b < g.n_rows) {
-                const float mu = ys[r * MAX_OUT + i], raw = ys[r * MAX_OUT + A + i];
+                const float mu = ys[r * ldo + i], raw = ys[r * ldo + A + i];
                 const float log_std = g.lo + 0.5f * (g.hi - g.lo) * (tanhf(raw) + 1.0f);
                 const float sd = expf(log_std);
                 const float ep = g.eps ? g.eps[(int64_t)b * A + i] : philox_normal(g.rng.seed, rng_draw(g.rng), b, i);
                 const float u = mu + sd * ep;
                 const float dlt = u - mu;
-                lpt[r * MAX_OUT + i] = (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -
+                lpt[r * ldo + i] = (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -
                                        2.0f * (LOG_2 - u - softplus_f(-2.0f * u));
                 g.act_dst[b * g.ld_act + g.act_col0 + i] = tanhf(u);
             }
@@ -1060,7 +1074,7 @@ __global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
         __syncthreads();
         if (g.logp && tid < TMR && (m0 + tid) < g.n_rows) {
             float lp = 0.0f;
-            for (int i = 0; i < A; ++i) lp += lpt[tid * MAX_OUT + i];
+            for (int i = 0; i < A; ++i) lp += lpt[tid * ldo + i];
             g.logp[m0 + tid] = lp;
         }
         return;
@@ -1079,14 +1093,14 @@ __global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
             if (b < g.n_rows) {
                 if (OUT > 1) ai = (int)rowin[2 * TMR + tid];
                 const float w = rowin[TMR + tid];
-                const float err = rowin[tid] - (pw * ys[tid * MAX_OUT + ai] + pb);
+                const float err = rowin[tid] - (pw * ys[tid * ldo + ai] + pb);
                 lossv = w * err * err;
                 errv = err;
                 dsel = gscale * w * err;
             }
             for (int o = 0; o < OUT; ++o) {
                 const float d = (o == ai) ? dsel : 0.0f;
-                dqs[tid * MAX_OUT + o] = d;
+                dqs[tid * ldo + o] = d;
                 if (b < g.n_rows) g.DQ[((int64_t)e * g.n_rows + b) * OUT + o] = d;
             }
         }
@@ -1115,7 +1129,7 @@ __global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
                 for (int o = 0; o < OUT; ++o) {
                     const float w = w3s[o * ldw3 + k];
 #pragma unroll
-                    for (int j = 0; j < NR; ++j) gs[j] += dqs[(r0 + 2 * j) * MAX_OUT + o] * w;
+                    for (int j = 0; j < NR; ++j) gs[j] += dqs[(r0 + 2 * j) * ldo + o] * w;
                 }
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
@@ -1149,7 +1163,8 @@ size_t direct_lds_bytes(int in_dim, int hidden, int out_dim, int tm) {
     const int KP = (in_dim + 31) & ~31;
     size_t front = (size_t)tm * (KP + APAD) + (size_t)tm * (hidden + APAD);
     if (front < (size_t)8 * tm * MAX_OUT) front = (size_t)8 * tm * MAX_OUT;
-    return sizeof(float) * (front + (size_t)tm * (hidden + APAD) + 2 * tm * MAX_OUT + 64 + 2 * hidden + 16 +
+    const int ldo = (out_dim + 15) & ~15;
+    return sizeof(float) * (front + (size_t)tm * (hidden + APAD) + 2 * tm * ldo + 64 + 2 * hidden + HEAD_MAX +
                             (size_t)out_dim * (hidden + APAD) + 3 * tm);
 }
 
@@ -1160,8 +1175,8 @@ int g_tile_rows = 0;  // 0 = automatic, else 16 or 32 (ssac_fused_tile_rows)
 size_t fused_lds_bytes(int in_dim, int hidden, int out_dim, int tm = TM, bool dbuf = true) {
     const int KP = (in_dim + 31) & ~31;
     return sizeof(float) * ((size_t)tm * (KP + APAD) + 2 * (size_t)tm * (hidden + APAD) +
-                            (dbuf ? 2 : 1) * WS_FLOATS + 2 * tm * MAX_OUT + 64 +
-                            2 * hidden + 16 + (size_t)out_dim * (hidden + APAD) + 3 * tm);
+                            (dbuf ? 2 : 1) * WS_FLOATS + 2 * tm * ((out_dim + 15) & ~15) + 64 +
+                            2 * hidden + HEAD_MAX + (size_t)out_dim * (hidden + APAD) + 3 * tm);
 }
 
 // Kernel variant for one launch.  g_tile_rows (ssac_fused_tile_rows) forces one: 16 / 32 = staged weights,
@@ -1170,6 +1185,8 @@ struct TileChoice { int tm; int variant; };  // variant 0 staged double buffer, 
 
 TileChoice choose_tile(const FusedArgs &g, int n_sel) {
     const bool fits32 = fused_lds_bytes(g.in_dim, g.hidden, g.out_dim, 32) <= 160 * 1024;
+    // a wide input together with a wide head (e.g. 376 -> 34): only the single-buffer carve fits
+    if (fused_lds_bytes(g.in_dim, g.hidden, g.out_dim, 16) > 160 * 1024 && g_tile_rows < 100) return {16, 1};
     switch (g_tile_rows) {
         case 17: return {16, 1};
         case 116: return {16, 2};
@@ -1185,8 +1202,13 @@ TileChoice choose_tile(const FusedArgs &g, int n_sel) {
 }
 
 bool fused_ok(const ssac_mlp *n) {
-    return n && n->hidden % 32 == 0 && n->hidden <= 256 && n->out_dim >= 1 && n->out_dim <= MAX_OUT &&
-           n->in_dim >= 1 && fused_lds_bytes(n->in_dim, n->hidden, n->out_dim, 16) <= 160 * 1024;
+    return n && n->hidden % 32 == 0 && n->hidden <= 256 && n->out_dim >= 1 && n->out_dim <= HEAD_MAX &&
+           n->in_dim >= 1 && fused_lds_bytes(n->in_dim, n->hidden, n->out_dim, 16, false) <= 160 * 1024;
+}
+
+// the merged launches run their critic halves with double-buffered staging only
+bool fused_dbuf_ok(const ssac_mlp *n) {
+    return fused_ok(n) && fused_lds_bytes(n->in_dim, n->hidden, n->out_dim, 16, true) <= 160 * 1024;
 }
 
 void fill_common(FusedArgs &g, const ssac_mlp *nets, const int32_t *ids, const float *X, int64_t ldx,
@@ -1255,7 +1277,9 @@ __global__ __launch_bounds__(256) void critic_logs_kernel(CriticLogsArgs a) {
 }  // namespace
 
 extern "C" int ssac_fused_debug_stamps(long long *dev_buf) { g_fused_dbg = dev_buf; return 0; }
-extern "C" int ssac_fused_supported(const ssac_mlp *nets) { return fused_ok(nets) ? 1 : 0; }
+extern "C" int ssac_fused_supported(const ssac_mlp *nets) {
+    return fused_dbuf_ok(nets) ? 1 : (fused_ok(nets) ? 2 : 0);
+}
 
 extern "C" int ssac_mlp3_fwd_fused(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
                                    int64_t ldx, int64_t x_net_stride, int n_rows, float *H1, float *H2,
@@ -1290,8 +1314,8 @@ extern "C" int ssac_target_fwd_critic_bwdu(const ssac_mlp *targets, const int32_
                                            int64_t ldx1, int n_rows, float *Qt, const ssac_mlp *critics,
                                            const float *H1, const float *H2, const float *act, int64_t ld_act,
                                            float *DZ2u, float *DZ1u, void *stream) {
-    if (!fused_ok(targets) || !fused_ok(critics))
-        return ssac_fail("ssac_target_fwd_critic_bwdu: shape not supported by the fused path");
+    if (!fused_dbuf_ok(targets) || !fused_dbuf_ok(critics))
+        return ssac_fail("ssac_target_fwd_critic_bwdu: shape not supported by the merged launch");
     if (n_sel <= 0 || n_sel > SSAC_MAX_NETS) return ssac_fail("ssac_target_fwd_critic_bwdu: n_sel out of range");
     if (!H1 || !H2 || !DZ2u || !DZ1u || !Qt) return ssac_fail("ssac_target_fwd_critic_bwdu: missing buffer");
     if (critics->out_dim > 1 && !act) return ssac_fail("ssac_target_fwd_critic_bwdu: discrete needs actions");
@@ -1332,8 +1356,8 @@ extern "C" int ssac_actor_sample_critic_fwd(const ssac_mlp *actor, const float *
                                             const ssac_mlp *critics, const float *Xc, int64_t ldxc, float *H1,
                                             float *H2, float *Q, void *stream) {
     if (!eps && !rng) return ssac_fail("ssac_actor_sample_critic_fwd: neither eps nor an rng stream given");
-    if (!fused_ok(actor) || (actor->out_dim & 1) || !fused_ok(critics))
-        return ssac_fail("ssac_actor_sample_critic_fwd: shape not supported by the fused path");
+    if (!fused_ok(actor) || (actor->out_dim & 1) || !fused_dbuf_ok(critics))
+        return ssac_fail("ssac_actor_sample_critic_fwd: shape not supported by the merged launch");
     if (!H1 || !H2 || !Q) return ssac_fail("ssac_actor_sample_critic_fwd: H1 / H2 / Q missing");
     if (n_rows <= 0) return 0;
     FusedArgs ga{}, gc{};
@@ -1345,21 +1369,25 @@ extern "C" int ssac_actor_sample_critic_fwd(const ssac_mlp *actor, const float *
     gc.H1 = H1; gc.H2 = H2; gc.Y = Q;
     const int tc = choose_tile(gc, critics->n_nets).tm;  // what a stand-alone forward of the critics would use
     const int tiles_a = (n_rows + 15) / 16, cgx = (n_rows + tc - 1) / tc;
-    size_t lds = fused_lds_bytes(actor->in_dim, actor->hidden, actor->out_dim, 16, true);
+    const bool adbuf = fused_dbuf_ok(actor);
+    size_t lds = fused_lds_bytes(actor->in_dim, actor->hidden, actor->out_dim, 16, adbuf);
     const size_t lc = fused_lds_bytes(critics->in_dim, critics->hidden, critics->out_dim, tc, true);
     if (lc > lds) lds = lc;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)fused_dual_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void *)fused_dual_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return ssac_fail("fused_dual: cannot raise the dynamic LDS limit");
+        const void *ks[4] = {(const void *)fused_dual_kernel<16, true>, (const void *)fused_dual_kernel<32, true>,
+                             (const void *)fused_dual_kernel<16, false>, (const void *)fused_dual_kernel<32, false>};
+        for (const void *k : ks)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return ssac_fail("fused_dual: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
     const dim3 grid(tiles_a + cgx * critics->n_nets);
-    if (tc == 16) SSAC_LAUNCH(fused_dual_kernel<16>, grid, dim3(NTHR), lds, (hipStream_t)stream, ga, gc, tiles_a, cgx);
-    else SSAC_LAUNCH(fused_dual_kernel<32>, grid, dim3(NTHR), lds, (hipStream_t)stream, ga, gc, tiles_a, cgx);
+    hipStream_t st = (hipStream_t)stream;
+    if (tc == 16 && adbuf) SSAC_LAUNCH((fused_dual_kernel<16, true>), grid, dim3(NTHR), lds, st, ga, gc, tiles_a, cgx);
+    else if (adbuf) SSAC_LAUNCH((fused_dual_kernel<32, true>), grid, dim3(NTHR), lds, st, ga, gc, tiles_a, cgx);
+    else if (tc == 16) SSAC_LAUNCH((fused_dual_kernel<16, false>), grid, dim3(NTHR), lds, st, ga, gc, tiles_a, cgx);
+    else SSAC_LAUNCH((fused_dual_kernel<32, false>), grid, dim3(NTHR), lds, st, ga, gc, tiles_a, cgx);
     return ssac_check_launch("fused_dual");
 }
 

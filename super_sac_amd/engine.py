@@ -132,7 +132,9 @@ class MlpArena:
         self.params = torch.zeros(n_nets * self.stride, dtype=torch.float32, device=device)
         self.device = device
         # one-launch fused kernels (csrc/ssac_fused.hip) apply to this shape?
-        self.fused = bool(lib.ssac_fused_supported(C.byref(self.desc()))) and USE_FUSED
+        kind = int(lib.ssac_fused_supported(C.byref(self.desc())))  # 1 double-buffered staging fits, 2 single only
+        self.fused = bool(kind) and USE_FUSED
+        self.fused_dbuf = kind == 1 and USE_FUSED  # eligible as the critic half of the merged launches
 
     def like(self):
         return torch.zeros_like(self.params)

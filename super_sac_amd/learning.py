@@ -349,7 +349,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                 with engine._timed("critic_fwd"):
                     h1, h2, q = engine.mlp_forward(arena, X, ldx, 0, B, ws, tag)
         co = cob = None
-        if (DUAL_LAUNCH and branch is None and arena.fused and not train_enc and not dr3_coeff and not discrete
+        if (DUAL_LAUNCH and branch is None and arena.fused_dbuf and not train_enc and not dr3_coeff and not discrete
                 and _dual_fits(arena, B)):
             # the critics' forward rides in the actor's launch (when compute_td_targets uses the fused sample
             # launch); the critic launch below is then only the backward half

@@ -446,7 +446,7 @@ def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag, co_backward=None, re
     (B x out) partial (the one real exchange step of the critic update), n = 1."""
     if shard is None:
         ids_dev = _upload_ids(ws, ids, dev, "sub")
-        if co_backward is not None and t_arena.fused:
+        if co_backward is not None and t_arena.fused_dbuf:
             c_arena, h1, h2, act, ld_act, dz2u, dz1u = co_backward
             q1 = ws.get(tag + ".y", (len(ids), B, t_arena.out_dim))
             with engine._timed("dual_bwd") as tm:
@@ -469,7 +469,7 @@ def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag, co_backward=None, re
         # per-update device id block holds the LOCAL index of the members this rank owns and -1 for the others
         # (their outputs are +inf), and the collective runs between two recorded segments
         n = len(ids)
-        if co_backward is not None and t_arena.fused:
+        if co_backward is not None and t_arena.fused_dbuf:
             # ... and the TD-independent half of the local critics' backward pass rides in the same launch
             c_arena, h1, h2, act, ld_act, dz2u, dz1u = co_backward
             q1 = ws.get(tag + ".y", (n, B, O))

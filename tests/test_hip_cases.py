@@ -154,8 +154,8 @@ def test_pixel_cases_with_implicit_gemm_convolutions(name):
 
 
 def test_recorded_updates_with_a_wide_action_head():
-    """9-dimensional actions: the actor's 18 outputs exceed the fused kernels' 16-output head, so the actor runs on
-    the per-layer kernels and its noise comes from torch's generator -- inside a recorded update as well (this
+    """9-dimensional actions: the actor's 18 outputs take two 16-column passes of the fused kernels' head (an
+    earlier version sent such actors to the per-layer kernels with torch's generator for the noise, and that
     combination once crashed the recording).  Recorded replay must equal eager launches bit for bit."""
     import copy
     import math

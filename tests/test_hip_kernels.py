@@ -109,7 +109,8 @@ def tile_rows(request, ssa):
 
 
 @pytest.mark.parametrize("B,in_dim,H,out,N", [(512, 23, 256, 1, 10), (100, 17, 64, 12, 1), (77, 393, 96, 1, 3),
-                                              (33, 128, 256, 4, 2), (1, 5, 32, 3, 2)])
+                                              (33, 128, 256, 4, 2), (1, 5, 32, 3, 2), (150, 45, 256, 34, 2),
+                                              (64, 30, 128, 18, 3), (40, 64, 64, 64, 1), (70, 376, 256, 34, 1)])
 def test_fused_forward_equals_per_layer_and_oracle(ssa, tile_rows, B, in_dim, H, out, N):
     rng = np.random.RandomState(B + in_dim + 1)
     mlps = [orc.make_mlp(rng, in_dim, H, out) for _ in range(N)]
@@ -128,9 +129,12 @@ def test_fused_forward_equals_per_layer_and_oracle(ssa, tile_rows, B, in_dim, H,
         _close(y[j], orc.mlp3(p, x)[0], 5e-5, what=f"y[{j}] vs oracle")
 
 
-def test_fused_actor_sample(ssa, tile_rows):
+@pytest.mark.parametrize("S,A", [(17, 6), (45, 17), (20, 9), (376, 17)])
+def test_fused_actor_sample(ssa, tile_rows, S, A):
+    """A = 17 / 9: heads wider than one 16-column MFMA pass; (376, 17) = Humanoid, whose wide input + wide head only
+    fit the single-buffer LDS carve"""
     rng = np.random.RandomState(41)
-    B, S, A, H = 200, 17, 6, 256
+    B, H = 200, 256
     actor = orc.make_mlp(rng, S, H, 2 * A)
     x1 = torch.from_numpy(rng.standard_normal((B, S + A)).astype(np.float32))
     eps = torch.from_numpy(rng.standard_normal((B, A)).astype(np.float32))
@@ -146,7 +150,7 @@ def test_fused_actor_sample(ssa, tile_rows):
     assert torch.equal(xd[:, :S].cpu(), x1[:, :S]), "state columns must be untouched"
 
 
-@pytest.mark.parametrize("qd,B,H,N", [(1, 512, 256, 10), (4, 70, 64, 2)])
+@pytest.mark.parametrize("qd,B,H,N", [(1, 512, 256, 10), (4, 70, 64, 2), (18, 90, 128, 2)])
 def test_fused_critic_fwd_bwd_matches_autograd(ssa, tile_rows, qd, B, H, N):
     rng = np.random.RandomState(42 + qd)
     in_dim = 23 if qd == 1 else 9

@@ -74,6 +74,8 @@ print("|---|---|---|---|---|---|")
 for name, obs, act, B, N, n in [("SAC (sac.gin shape)", 3, 1, 256, 2, 2), ("REDQ", 17, 6, 256, 10, 2),
                                 ("REDQ (headline)", 17, 6, 512, 10, 2), ("REDQ", 17, 6, 512, 16, 2),
                                 ("Humanoid", 376, 17, 512, 16, 2), ("Humanoid", 376, 17, 256, 10, 2)]:
+    if len(sys.argv) > 1 and sys.argv[1] not in name:  # optional row filter: python tools/bench_configs.py Humanoid
+        continue
     critic, env_step = build(obs, act, B, N, n)
     t = timed(critic, 1500, 200)
     print(f"| {name} | {obs} / {act} | {B} | {N} ({n}) | {t * 1e6:.1f} | {1 / t:.0f} |")

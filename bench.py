@@ -152,7 +152,9 @@ def main():
     dist = None
     shard = None
     n_local = NCRIT
-    if world > 1:
+    # SSAC_BENCH_FORCE_DIST=1: take the sharded path (process group, MIN all-reduce between the recorded segments) with
+    # a single rank too -- the RCCL check that can run on a 1-GPU box
+    if world > 1 or os.environ.get("SSAC_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("SSAC_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm

@@ -384,6 +384,11 @@ int ssac_gemm_debug_stamps(long long *dev_buf); /* same for the weight-gradient 
  * single weight-staging buffer, two workgroups per CU). */
 int ssac_fused_row_tiles(const ssac_mlp *nets, int n_rows, int n_nets);
 int ssac_fused_tile_rows(int rows);
+/* tuning knob, default 1: the MLP and weight-gradient kernels take their tile in XCD-contiguous order (workgroup b
+ * runs on XCD b % 8; each XCD then works on one contiguous range of (net, tile) ids, so a net's weights / saved
+ * activations are pulled into one or two of the eight L2s instead of all of them).  0 = hardware order.  Placement
+ * only: results are bit-identical either way. */
+int ssac_xcd_order(int on);
 
 /* y = MLP(x) for every selected net in ONE launch (agent.py:34 loop + mlps.py:123-129).
  * H1/H2 (n_sel x n_rows x hidden) are written when not NULL (needed by a later backward).  A negative entry of

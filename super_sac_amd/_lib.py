@@ -129,6 +129,7 @@ SIGNATURES = {
     "ssac_gemm_debug_stamps": [_P],
     "ssac_fused_row_tiles": [_MP, _I, _I],
     "ssac_fused_tile_rows": [_I],
+    "ssac_xcd_order": [_I],
     "ssac_mlp3_fwd_fused": [_MP, _P, _I, _P, _L, _L, _I, _P, _P, _P, _P],
     "ssac_actor_sample_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _P, _P, _P, _P],
     "ssac_actor_sample_critic_fwd": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _L, _P, _P, _P, _P],
@@ -155,6 +156,8 @@ def _load():
         fn.restype = _RESTYPES.get(name, C.c_int)
     if lib.ssac_abi_version() != 1:
         raise ImportError("libssac_hip.so ABI version mismatch; rebuild the extension")
+    if os.environ.get("SSAC_XCD_ORDER"):
+        lib.ssac_xcd_order(int(os.environ["SSAC_XCD_ORDER"]))
     return lib
 
 

@@ -1173,6 +1173,9 @@ struct ssac_launch_list {
     std::vector<SsacLaunchRec> recs;
 };
 
+int g_ssac_xcd = 2;  // bit 0: fused MLP kernels, bit 1: GEMM / weight-gradient kernels
+extern "C" int ssac_xcd_order(int mask) { g_ssac_xcd = mask & 3; return 0; }
+
 extern "C" int ssac_record_begin(void) {
     if (g_ssac_recording) return ssac_fail("ssac_record_begin: a recording is already open on this thread");
     g_ssac_recording = new std::vector<SsacLaunchRec>();

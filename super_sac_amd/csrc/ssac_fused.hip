@@ -65,6 +65,7 @@ struct FusedArgs {
     // MODE_CRITIC
     const float *td, *weight, *act; int64_t ld_a; const ssac_popart *popart; int pop; float denom;
     float *DQ, *DZ2, *DZ1; float *partials;  // partials[(e*tiles + tile)*2 + {loss, err}]
+    int xcd;                     // workgroups take their tile in XCD-contiguous order (ssac_internal.h)
     long long *dbg;  // optional phase timestamps (s_memtime) of workgroup (0,0), thread 0
     ssac_td_spec tds;  // tds.q_t != null: the TD target is computed here instead of read from `td`
 };
@@ -683,7 +684,8 @@ template <int MODE, int TMR, bool DBUF>
 __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(DBUF ? 2 : 4, DBUF ? 2 : 4)))
 void fused_mlp_kernel(FusedArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    fused_mlp_body<MODE, TMR, DBUF>(g, smem, blockIdx.x, blockIdx.y, gridDim.x);
+    const int L = ssac_xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, g.xcd);
+    fused_mlp_body<MODE, TMR, DBUF>(g, smem, L % gridDim.x, L / gridDim.x, gridDim.x);
 }
 
 // Two independent fused launches in ONE: workgroups [0, tiles_a) run the actor (+ tanh-normal sample) on 16-row
@@ -698,10 +700,11 @@ template <int TC, bool ADBUF>
 __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_dual_kernel(FusedArgs ga, FusedArgs gc, int tiles_a, int critic_grid_x) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if ((int)blockIdx.x < tiles_a) {
-        fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga, smem, blockIdx.x, 0, tiles_a);
+    const int bid = ssac_xcd_contiguous(blockIdx.x, gridDim.x, gc.xcd);
+    if (bid < tiles_a) {
+        fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga, smem, bid, 0, tiles_a);
     } else {
-        const int L = blockIdx.x - tiles_a;
+        const int L = bid - tiles_a;
         fused_mlp_body<MODE_PLAIN, TC, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x);
     }
 }
@@ -713,11 +716,11 @@ template <int TT, int TC>
 __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_dual2_kernel(FusedArgs gt, FusedArgs gc, int tiles_t, int target_grid_x, int critic_grid_x) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if ((int)blockIdx.x < tiles_t) {
-        fused_mlp_body<MODE_PLAIN, TT, true>(gt, smem, blockIdx.x % target_grid_x, blockIdx.x / target_grid_x,
-                                             target_grid_x);
+    const int bid = ssac_xcd_contiguous(blockIdx.x, gridDim.x, gc.xcd);
+    if (bid < tiles_t) {
+        fused_mlp_body<MODE_PLAIN, TT, true>(gt, smem, bid % target_grid_x, bid / target_grid_x, target_grid_x);
     } else {
-        const int L = blockIdx.x - tiles_t;
+        const int L = bid - tiles_t;
         fused_mlp_body<MODE_CRITIC_BWDU, TC, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x);
     }
 }
@@ -898,7 +901,8 @@ __global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
     float *hpart = smem;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int e = blockIdx.y, m0 = blockIdx.x * TMR;
+    const int Lid = ssac_xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, g.xcd);
+    const int bx = Lid % gridDim.x, e = Lid / gridDim.x, m0 = bx * TMR;
     const int net = g.ids ? g.ids[e] : e;
     if (net < 0) {
         // slot without a net (a REDQ subset member another rank owns): its outputs are +inf, the neutral
@@ -1108,7 +1112,7 @@ __global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { lossv += __shfl_xor(lossv, o, 64); errv += __shfl_xor(errv, o, 64); }
             if (lane == 0) {
-                const int64_t pi = ((int64_t)e * gridDim.x + blockIdx.x) * 2;
+                const int64_t pi = ((int64_t)e * gridDim.x + bx) * 2;
                 g.partials[pi] = lossv;
                 g.partials[pi + 1] = errv;
             }
@@ -1217,7 +1221,7 @@ void fill_common(FusedArgs &g, const ssac_mlp *nets, const int32_t *ids, const f
     g.in_dim = nets->in_dim; g.hidden = nets->hidden; g.out_dim = nets->out_dim;
     ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, g.off);
     g.ids = ids; g.X = X; g.ldx = ldx; g.sX = sX; g.n_rows = n_rows;
-    g.dbg = g_fused_dbg;
+    g.dbg = g_fused_dbg; g.xcd = g_ssac_xcd & 1;
 }
 
 template <int MODE, int TMR, bool DBUF>

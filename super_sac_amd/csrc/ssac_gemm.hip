@@ -59,6 +59,7 @@ struct GemmArgs {
     int64_t sRow;
     int Ktot;                // > 0: batch entry e covers k in [e*K, min((e+1)*K, Ktot)) (split-K over blocks)
     int64_t sGb;             // EPI_GRAD: bias-gradient stride per batch entry (0 = same as sC)
+    int xcd;                 // XCD-contiguous tile order (ssac_internal.h)
 };
 
 __device__ __forceinline__ int64_t batch_off(const int32_t *ids, int use_ids, int e, int64_t stride) {
@@ -226,34 +227,53 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     auto storeB = [&](float *d) { if (vecB) vb.store(d); else store_chunk<B_KC>(rb, d, tid); };
 
     GSTAMP(0);
+    // Software-pipelined K loop in half chunks: the fragments of the second half of chunk it are read while its
+    // first half multiplies, the first half of chunk it+1 is read (right after the barrier that publishes it) while
+    // the second half multiplies, and the staging stores / next global loads are issued between the two, so LDS
+    // and global latency sit under matrix work instead of in front of it
+    // (with read -> 16 MFMAs -> barrier the 4*KS waves of the workgroup all waited at the same points and the
+    // matrix pipe idled through every staging phase: 34k clocks for 16k clocks of MFMA work at K = 512).
+    // Buffer reuse: chunk it+1 overwrites the buffer of chunk it-1, whose fragments every wave finished
+    // reading before the barrier of iteration it-1.
+    const bool bias_wave = want_bias_grad && TN && wn == 0;  // bias gradient = column sums of A, from the fragments
+    constexpr int HT = BK / 4;  // MFMAs per half chunk
+    auto rd = [&](float (&fa)[HT], float (&fb)[HT], const float *buf, int half) {
+        const float *As = buf, *Bs = buf + TILE_FLOATS;
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            fa[t] = frag<A_KC>(As, wm * 32 + li, 2 * (half * HT + t) + lh);
+            fb[t] = frag<B_KC>(Bs, wn * 32 + li, 2 * (half * HT + t) + lh);
+        }
+    };
+    auto mm = [&](const float (&fa)[HT], const float (&fb)[HT]) {
+        if (bias_wave) {
+#pragma unroll
+            for (int t = 0; t < HT; ++t) bias_acc += fa[t];
+        }
+#pragma unroll
+        for (int t = 0; t < HT; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
+    };
     loadA(kg * BK);
     loadB(kg * BK);
     storeA(buf0);
     storeB(buf0 + TILE_FLOATS);
     if (iters > 1) { loadA((KS + kg) * BK); loadB((KS + kg) * BK); }
     __syncthreads();
+    float f0a[HT], f0b[HT], f1a[HT], f1b[HT];  // first / second half of the current chunk
+    if (iters > 0) rd(f0a, f0b, buf0, 0);
     GSTAMP(1);
     for (int it = 0; it < iters; ++it) {
         float *cur = (it & 1) ? buf1 : buf0;
         float *nxt = (it & 1) ? buf0 : buf1;
-        const float *As = cur, *Bs = cur + TILE_FLOATS;
-        float fa[BK / 2], fb[BK / 2];
-#pragma unroll
-        for (int t = 0; t < BK / 2; ++t) {
-            fa[t] = frag<A_KC>(As, wm * 32 + li, 2 * t + lh);
-            fb[t] = frag<B_KC>(Bs, wn * 32 + li, 2 * t + lh);
-        }
+        rd(f1a, f1b, cur, 1);
+        mm(f0a, f0b);
         if (it + 1 < iters) { storeA(nxt); storeB(nxt + TILE_FLOATS); }
         if (it + 2 < iters) { const int k0 = ((it + 2) * KS + kg) * BK; loadA(k0); loadB(k0); }
-        if (want_bias_grad && tid < 64) {
-            // A is staged row-contiguous in the weight-gradient mode: As[k][m]
-#pragma unroll 8
-            for (int k = 0; k < BK; ++k) bias_acc += As[k * LDS_RC + tid];
-        }
-#pragma unroll
-        for (int t = 0; t < BK / 2; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
         __syncthreads();
+        if (it + 1 < iters) rd(f0a, f0b, nxt, 0);
+        mm(f1a, f1b);
     }
+    if (bias_wave) bias_acc += __shfl_xor(bias_acc, 32, 64);  // the two k parities of column li
 
     GSTAMP(2);
     if (EPI == EPI_ADAM || EPI == EPI_GRAD) {
@@ -267,7 +287,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             mine[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + wn * 32 + li] = acc[r];
-        if (want_bias_grad && tid < 64) red[kg * 64 + tid] = bias_acc;
+        if (bias_wave && lh == 0) red[kg * 64 + wm * 32 + li] = bias_acc;
         __syncthreads();
         GSTAMP(3);
         constexpr int NT_ALL = NTHREADS * KS;
@@ -398,7 +418,10 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
 template <bool A_KC, bool B_KC, int EPI, int KS>
 __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, blockIdx.x, blockIdx.y, blockIdx.z);
+    const int per = gridDim.x * gridDim.y;
+    const int L = ssac_xcd_contiguous(blockIdx.z * per + blockIdx.y * gridDim.x + blockIdx.x, per * gridDim.z, g.xcd);
+    const int bz = L / per, rem = L - bz * per;
+    ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % gridDim.x, rem / gridDim.x, bz);
 }
 
 // Two problems in ONE launch (the fc2 and fc1 weight gradients of an update): workgroups
@@ -408,18 +431,20 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
 struct GemmPair {
     GemmArgs g0, g1; int tiles0; int tiles01; int head_grid_x; HeadWgradArgs head;
     unsigned *done; CriticLogsArgs logs;  // done != null: the last workgroup runs critic_logs_body(logs)
+    int xcd;                              // XCD-contiguous tile order (ssac_internal.h)
 };
 
 template <bool A_KC, bool B_KC, int EPI, int KS>
 __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if ((int)blockIdx.x >= p.tiles01) {  // head-layer weight gradient + Adam beside the GEMM tiles
-        const int L = blockIdx.x - p.tiles01;
+    const int bid = ssac_xcd_contiguous(blockIdx.x, gridDim.x, p.xcd);
+    if (bid >= p.tiles01) {  // head-layer weight gradient + Adam beside the GEMM tiles
+        const int L = bid - p.tiles01;
         head_wgrad_body<4 * KS>(p.head, lds, L % p.head_grid_x, L / p.head_grid_x);
     } else {
-        const bool first = (int)blockIdx.x < p.tiles0;
+        const bool first = bid < p.tiles0;
         const GemmArgs &g = first ? p.g0 : p.g1;
-        const int L = first ? blockIdx.x : blockIdx.x - p.tiles0;
+        const int L = first ? bid : bid - p.tiles0;
         const int per = g.grid_x * g.grid_y;
         const int bz = L / per, rem = L - bz * per;
         ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % g.grid_x, rem / g.grid_x, bz);
@@ -449,6 +474,7 @@ int launch_pair_ks(GemmPair &p, int batch0, int batch1, hipStream_t st) {
             return ssac_fail("ens_gemm_pair: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
+    p.xcd = (g_ssac_xcd >> 1) & 1;
     p.tiles0 = p.g0.grid_x * p.g0.grid_y * batch0;
     p.tiles01 = p.tiles0 + p.g1.grid_x * p.g1.grid_y * batch1;
     const int total = p.tiles01 + (p.head_grid_x > 0 ? p.head_grid_x * batch0 : 0);
@@ -475,7 +501,7 @@ int launch(const GemmArgs &g_in, int batch, hipStream_t st) {
     GemmArgs g = g_in;
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
     if (grid.x == 0 || grid.y == 0 || batch == 0) return 0;
-    g.grid_x = grid.x; g.grid_y = grid.y;
+    g.grid_x = grid.x; g.grid_y = grid.y; g.xcd = (g_ssac_xcd >> 1) & 1;
     const int tiles = grid.x * grid.y * batch;
     const int nchunks = (g.K + BK - 1) / BK;
     // K-split inside the workgroup when the launch cannot fill the chip with tiles alone

@@ -58,3 +58,21 @@ inline void ssac_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t 
 }
 
 #define SSAC_LAUNCH(kernel, grid, block, lds, st, ...) ssac_launch(kernel, grid, block, lds, st, __VA_ARGS__)
+
+// ---------------------------------------------------------------------------------------------
+// XCD-contiguous workgroup order.  The dispatcher is observed to place workgroup b on XCD b % 8 (a speed
+// assumption only -- nothing here depends on it for correctness), and each XCD has its own 4 MiB L2.  The
+// kernels whose neighbouring tiles share operands (the row tiles of one net share its weights; the tiles of
+// one net's weight gradient share its activations) therefore take their tile from this LOGICAL id: XCD x
+// works on one contiguous range of logical ids, so a net's operands are pulled into one or two L2s instead
+// of all eight.  Bijective for any number of workgroups.  g_ssac_xcd (ssac_xcd_order) = 0 keeps the
+// hardware order.
+// ---------------------------------------------------------------------------------------------
+extern int g_ssac_xcd;
+#ifdef __HIPCC__
+__device__ __forceinline__ int ssac_xcd_contiguous(int bid, int nwg, int on) {
+    if (!on) return bid;
+    const int xcd = bid & 7, slot = bid >> 3, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+#endif

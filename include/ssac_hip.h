@@ -201,6 +201,19 @@ int ssac_mlp_wgrad_all_scaled(const ssac_mlp *nets, const int32_t *net_ids, int 
                               const float *DZ1u, const float *row_scale, int n_rows, float *adam_m, float *adam_v,
                               const ssac_adam_ctl *ctl, float *grads, float *sumsq2, float *sumsq1, float *sumsq0,
                               int64_t sumsq_net_stride, float *target, float tau, void *stream);
+/* ssac_mlp_wgrad_all_scaled with the loss gradient itself folded in (all nets of the arena, single-output heads,
+ * n_rows <= 4096): every workgroup evaluates dL/dq = -2 pw w (td - (pw Q + pb)) / (denom n_rows) of ITS net's rows
+ * into LDS (learning.py:90-98, 112) instead of reading a row_scale array a separate launch wrote.  td (n_rows), or
+ * lazy_td (evaluated here, td_target_kernel's arithmetic; net slot 0's first workgroup writes lazy_td->td_out).
+ * partials[n_nets][2] receives sum_b w err^2 and sum_b err per net: ssac_critic_logs(partials, n_nets, tiles = 1, ...)
+ * finishes "losses/critic_overall_loss" and "losses/last_member_critic_td_error". */
+int ssac_mlp_wgrad_all_lossfold(const ssac_mlp *nets, const float *X, int64_t ldx, int64_t x_net_stride,
+                                const float *H1, const float *H2, const float *DZ2u, const float *DZ1u,
+                                const float *Q, const float *td, const ssac_td_spec *lazy_td, const float *weight,
+                                const ssac_popart *popart, int pop, float denom, float *partials, int n_rows,
+                                float *adam_m, float *adam_v, const ssac_adam_ctl *ctl, float *grads, float *sumsq2,
+                                float *sumsq1, float *sumsq0, int64_t sumsq_net_stride, float *target, float tau,
+                                void *stream);
 /* ssac_critic_loss_bwd with the TD targets evaluated in the same launch (ssac_td_spec; they are also written to
  * lazy_td->td_out). */
 int ssac_critic_loss_bwd_lazy(const float *q, int n_nets, int n_rows, int q_dim, const float *act, int64_t ld_act,

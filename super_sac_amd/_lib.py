@@ -75,6 +75,8 @@ SIGNATURES = {
     "ssac_mlp_wgrad_all_scaled": [_MP, _P, _I, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _F,
                                   _P],
     "ssac_critic_loss_bwd_lazy": [_P, _I, _I, _I, _P, _L, _P, _P, _P, _I, _F, _P, _P, _P],
+    "ssac_mlp_wgrad_all_lossfold": [_MP, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _I, _P, _P, _P, _P,
+                                    _P, _P, _P, _L, _P, _F, _P],
     "ssac_target_fwd_critic_bwdu": [_MP, _P, _I, _P, _L, _I, _P, _MP, _P, _P, _P, _L, _P, _P, _P],
     "ssac_mlp_wgrad_all_logs": [_MP, _P, _I, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _P, _F,
                                 _P, _I, _F, _P, _I, _P, _P, _P, _P, _P, _P],

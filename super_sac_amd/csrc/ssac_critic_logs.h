@@ -86,3 +86,62 @@ __device__ __forceinline__ void critic_logs_body(const CriticLogsArgs &a, float 
         if (tid == 0) a.feed->tick += 1;
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Loss gradient folded into the weight-gradient launch (continuous critics, one head output).  What the TD target
+// decides about the backward pass is ONE scalar per (net, row): dL/dq = -2 pw w (td - (pw q + pb)) / (denom B)
+// (learning.py:90-98, 112).  Every workgroup of the merged weight-gradient launch evaluates the n_rows scalars of
+// ITS net into LDS (a few KB of L2-resident reads) instead of a separate single-workgroup launch writing them to
+// memory first; one workgroup per net also reduces the loss terms, and net slot 0's writes the TD targets out.
+// ------------------------------------------------------------------------------------------------------------
+struct LossFoldArgs {
+    const float *q;           // (n_nets x n_rows) head outputs of the online critics; null = fold off
+    const float *td;          // TD targets (n_rows), or null with `tds` set (evaluated here, td_target_kernel order)
+    ssac_td_spec tds;
+    const float *weight;      // per-row loss weights, or null
+    const ssac_popart *popart; int pop; float denom;
+    float *partials;          // [n_nets][2]: sum_b w err^2, sum_b err
+    int n_rows;
+};
+
+__device__ __forceinline__ float ssac_lazy_td(const ssac_td_spec &t, int b, int n_rows, float alpha) {
+    float mq = t.q_t[b];
+    for (int j = 1; j < t.n_sel; ++j) mq = fminf(mq, t.q_t[(int64_t)j * n_rows + b]);
+    const float bonus = t.use_entropy ? alpha * t.logp[b] : 0.0f;
+    const float val = mq - bonus;
+    return t.rew[b] + t.gamma * (1.0f - t.done[b]) * val;
+}
+
+// Every thread of the workgroup calls this (barriers inside when `stats`; `stats` must be workgroup-uniform).
+// tab: n_rows floats of LDS; red: 2 * (blockDim.x / 64) floats of LDS.  The caller synchronises before reading tab.
+__device__ __forceinline__ void loss_fold_table(const LossFoldArgs &a, int e, float *tab, bool stats, float *red) {
+    const int tid = threadIdx.x, n_rows = a.n_rows;
+    const float pw = (a.popart && a.pop) ? a.popart->w : 1.0f;
+    const float pb = (a.popart && a.pop) ? a.popart->b : 0.0f;
+    const float gscale = -2.0f * pw / (a.denom * (float)n_rows);
+    const float alpha = (a.tds.q_t && a.tds.use_entropy) ? expf(a.tds.log_alpha[0]) : 0.0f;
+    const float *q = a.q + (int64_t)e * n_rows;
+    float sl = 0.0f, se = 0.0f;
+    for (int b = tid; b < n_rows; b += blockDim.x) {
+        const float t = a.tds.q_t ? ssac_lazy_td(a.tds, b, n_rows, alpha) : a.td[b];
+        if (stats && e == 0 && a.tds.q_t) a.tds.td_out[b] = t;
+        const float w = a.weight ? a.weight[b] : 1.0f;
+        const float err = t - (pw * q[b] + pb);
+        tab[b] = gscale * w * err;
+        sl += w * err * err;
+        se += err;
+    }
+    if (stats) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sl += __shfl_xor(sl, o, 64); se += __shfl_xor(se, o, 64); }
+        const int nw = blockDim.x >> 6;
+        if ((tid & 63) == 0) { red[tid >> 6] = sl; red[nw + (tid >> 6)] = se; }
+        __syncthreads();
+        if (tid == 0) {
+            float tl = 0.0f, te = 0.0f;
+            for (int w = 0; w < nw; ++w) { tl += red[w]; te += red[nw + w]; }
+            a.partials[2 * e] = tl;
+            a.partials[2 * e + 1] = te;
+        }
+    }
+}

@@ -146,6 +146,7 @@ struct RcVecLoader {
     const float *safe;  // always-valid 16-byte aligned address for predicated-off lanes
     f4 v[2];
     int kk, r4;
+    int kq[2];  // k of the rows held in v (late row scale: applied when the rows are stored)
     bool rok;
     __device__ __forceinline__ void init(const float *S, int64_t ld, int R0, int R, int kfirst, int tid) {
         r4 = (tid & 15) * 4;
@@ -163,17 +164,25 @@ struct RcVecLoader {
             const f4 x = *reinterpret_cast<const f4 *>(ok ? p[q] : safe);
             const float sc = scale ? scale[ok ? k : 0] : 1.0f;
             v[q] = ok ? x * sc : (f4){0.f, 0.f, 0.f, 0.f};
+            kq[q] = ok ? k : 0;
             p[q] += adv;
         }
     }
-    __device__ __forceinline__ void store(float *Xt) const {
+    // late: row scales in LDS (loss_fold_table), applied here so the loads need not wait for the table
+    __device__ __forceinline__ void store(float *Xt, const float *late = nullptr) const {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) *reinterpret_cast<f4 *>(Xt + (kk + 16 * q) * LDS_RC + r4) = v[q];
+        for (int q = 0; q < 2; ++q)
+            *reinterpret_cast<f4 *>(Xt + (kk + 16 * q) * LDS_RC + r4) = late ? v[q] * late[kq[q]] : v[q];
     }
 };
 
-template <bool A_KC, bool B_KC, int EPI, int KS>
-__device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int bx, int by, int bz) {
+struct NoPre { __device__ __forceinline__ void operator()() const {} };
+
+// late_rs / pre: the merged weight-gradient launch with the loss gradient folded in (loss_fold_table) -- `pre` runs
+// after the first operand loads have been issued and fills the LDS table `late_rs` of per-row scales (and syncs).
+template <bool A_KC, bool B_KC, int EPI, int KS, class Pre = NoPre>
+__device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int bx, int by, int bz,
+                                              const float *late_rs = nullptr, Pre pre = Pre()) {
     const int tid_all = threadIdx.x;
     const int kg = tid_all >> 8, tid = tid_all & 255;
     // per K-group: two staging buffers (double buffering), each [A tile | B tile]
@@ -210,9 +219,11 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     if (vecB) vb.init(B, g.ldb, n0, g.N, kg * BK, tid);
     const int64_t advA = (int64_t)KS * BK * g.lda, advB = (int64_t)KS * BK * g.ldb;
 
-    const float *rscale = (TN && g.rowscale) ? g.rowscale + (int64_t)e * g.sRow : nullptr;
+    const float *rscale = (TN && g.rowscale && !late_rs) ? g.rowscale + (int64_t)e * g.sRow : nullptr;
+    int ra_k0 = 0;
     auto loadA = [&](int k0) {
         if (vecA) { va.load(k0, Kloc, advA, rscale); return; }
+        ra_k0 = k0;
         load_chunk<A_KC>(ra, A, g.lda, m0, g.M, k0, Kloc, tid);
         if (TN && rscale) {  // (K x R) layout: this thread's 8 values sit at k = k0 + (tid >> 6) + 4 p
 #pragma unroll
@@ -223,7 +234,17 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
         }
     };
     auto loadB = [&](int k0) { if (vecB) vb.load(k0, Kloc, advB); else load_chunk<B_KC>(rb, B, g.ldb, n0, g.N, k0, Kloc, tid); };
-    auto storeA = [&](float *d) { if (vecA) va.store(d); else store_chunk<A_KC>(ra, d, tid); };
+    auto storeA = [&](float *d) {
+        if (vecA) { va.store(d, TN ? late_rs : nullptr); return; }
+        if (TN && late_rs) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const int k = ra_k0 + (tid >> 6) + 4 * p;
+                ra[p] *= late_rs[k < Kloc ? k : 0];
+            }
+        }
+        store_chunk<A_KC>(ra, d, tid);
+    };
     auto storeB = [&](float *d) { if (vecB) vb.store(d); else store_chunk<B_KC>(rb, d, tid); };
 
     GSTAMP(0);
@@ -255,6 +276,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     };
     loadA(kg * BK);
     loadB(kg * BK);
+    pre();
     storeA(buf0);
     storeB(buf0 + TILE_FLOATS);
     if (iters > 1) { loadA((KS + kg) * BK); loadB((KS + kg) * BK); }
@@ -432,22 +454,36 @@ struct GemmPair {
     GemmArgs g0, g1; int tiles0; int tiles01; int head_grid_x; HeadWgradArgs head;
     unsigned *done; CriticLogsArgs logs;  // done != null: the last workgroup runs critic_logs_body(logs)
     int xcd;                              // XCD-contiguous tile order (ssac_internal.h)
+    LossFoldArgs lf;                      // lf.q != null: dL/dq evaluated per workgroup (ssac_critic_logs.h)
 };
 
 template <bool A_KC, bool B_KC, int EPI, int KS>
 __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int bid = ssac_xcd_contiguous(blockIdx.x, gridDim.x, p.xcd);
+    float *tab = lds + KS * (4 * TILE_FLOATS) + 64 * KS;  // folded loss gradient: [n_rows] row scales, then scratch
+    const bool fold = p.lf.q != nullptr;
     if (bid >= p.tiles01) {  // head-layer weight gradient + Adam beside the GEMM tiles
         const int L = bid - p.tiles01;
-        head_wgrad_body<4 * KS>(p.head, lds, L % p.head_grid_x, L / p.head_grid_x);
+        const int e = L / p.head_grid_x;
+        if (fold) {
+            loss_fold_table(p.lf, e, tab, false, tab + p.lf.n_rows);
+            __syncthreads();
+        }
+        head_wgrad_body<4 * KS>(p.head, lds, L % p.head_grid_x, e, fold ? tab : nullptr);
     } else {
         const bool first = bid < p.tiles0;
         const GemmArgs &g = first ? p.g0 : p.g1;
         const int L = first ? bid : bid - p.tiles0;
         const int per = g.grid_x * g.grid_y;
         const int bz = L / per, rem = L - bz * per;
-        ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % g.grid_x, rem / g.grid_x, bz);
+        auto pre = [&]() {
+            if (fold) {  // the first fc2 tile of each net also reduces that net's loss terms
+                loss_fold_table(p.lf, bz, tab, first && rem == 0, tab + p.lf.n_rows);
+                __syncthreads();
+            }
+        };
+        ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % g.grid_x, rem / g.grid_x, bz, fold ? tab : nullptr, pre);
     }
     if (p.done) {
         // the workgroup that finishes last sees every other one's gradient-norm partials and finalises the logs
@@ -467,10 +503,12 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
 template <bool A_KC, bool B_KC, int EPI, int KS>
 int launch_pair_ks(GemmPair &p, int batch0, int batch1, hipStream_t st) {
     static bool attr_set = false;
-    const size_t lds = sizeof(float) * (KS * 4 * TILE_FLOATS + 64 * KS);
-    if (!attr_set && lds > 48 * 1024) {
+    const size_t lds = sizeof(float) * (KS * 4 * TILE_FLOATS + 64 * KS + (p.lf.q ? p.lf.n_rows + 8 * KS : 0));
+    constexpr int PAIR_LDS_MAX = 160 * 1024 - 256;  // the kernel also has a few bytes of static LDS
+    if (lds > PAIR_LDS_MAX) return ssac_fail("ens_gemm_pair: the folded loss table does not fit LDS");
+    if (!attr_set) {
         if (hipFuncSetAttribute((const void *)ens_gemm_pair_kernel<A_KC, B_KC, EPI, KS>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_MAX) != hipSuccess)
             return ssac_fail("ens_gemm_pair: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
@@ -615,7 +653,7 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                         const ssac_adam_ctl *ctl, float *grads, float *sumsq1, float *sumsq0, float *sumsq2,
                         int64_t sumsq_net_stride, float *target, float tau, void *stream,
                         const CriticLogsArgs *logs = nullptr, unsigned *done = nullptr,
-                        const float *rowscale = nullptr);
+                        const float *rowscale = nullptr, const LossFoldArgs *lossfold = nullptr);
 
 extern "C" int ssac_mlp_wgrad_all_scaled(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
                                          int64_t ldx, int64_t x_net_stride, const float *H1, const float *H2,
@@ -629,6 +667,25 @@ extern "C" int ssac_mlp_wgrad_all_scaled(const ssac_mlp *nets, const int32_t *ne
     return wgrad_merged(nets, net_ids, n_sel, X, ldx, x_net_stride, H1, DZ2u, DZ1u, H2, row_scale, n_rows, adam_m,
                         adam_v, ctl, grads, sumsq1, sumsq0, sumsq2, sumsq_net_stride, target, tau, stream, nullptr,
                         nullptr, row_scale);
+}
+
+extern "C" int ssac_mlp_wgrad_all_lossfold(const ssac_mlp *nets, const float *X, int64_t ldx, int64_t x_net_stride,
+                                           const float *H1, const float *H2, const float *DZ2u, const float *DZ1u,
+                                           const float *Q, const float *td, const ssac_td_spec *lazy_td,
+                                           const float *weight, const ssac_popart *popart, int pop, float denom,
+                                           float *partials, int n_rows, float *adam_m, float *adam_v,
+                                           const ssac_adam_ctl *ctl, float *grads, float *sumsq2, float *sumsq1,
+                                           float *sumsq0, int64_t sumsq_net_stride, float *target, float tau,
+                                           void *stream) {
+    if (!nets || nets->out_dim != 1) return ssac_fail("ssac_mlp_wgrad_all_lossfold: single-output heads only");
+    if (!H2 || !Q || !partials || (!td && !lazy_td)) return ssac_fail("ssac_mlp_wgrad_all_lossfold: missing argument");
+    if (n_rows > 4096) return ssac_fail("ssac_mlp_wgrad_all_lossfold: more than 4096 rows (use ssac_critic_loss_bwd)");
+    LossFoldArgs lf{};
+    lf.q = Q; lf.td = td; if (lazy_td) lf.tds = *lazy_td;
+    lf.weight = weight; lf.popart = popart; lf.pop = pop; lf.denom = denom; lf.partials = partials; lf.n_rows = n_rows;
+    return wgrad_merged(nets, nullptr, nets->n_nets, X, ldx, x_net_stride, H1, DZ2u, DZ1u, H2, Q, n_rows, adam_m,
+                        adam_v, ctl, grads, sumsq1, sumsq0, sumsq2, sumsq_net_stride, target, tau, stream, nullptr,
+                        nullptr, nullptr, &lf);
 }
 
 extern "C" int ssac_mlp_wgrad_all_logs(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
@@ -675,7 +732,8 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                         const float *H2, const float *DQ, int n_rows, float *adam_m, float *adam_v,
                         const ssac_adam_ctl *ctl, float *grads, float *sumsq1, float *sumsq0, float *sumsq2,
                         int64_t sumsq_net_stride, float *target, float tau, void *stream,
-                        const CriticLogsArgs *logs, unsigned *done, const float *rowscale) {
+                        const CriticLogsArgs *logs, unsigned *done, const float *rowscale,
+                        const LossFoldArgs *lossfold) {
     if (n_sel < 0 || n_sel > SSAC_MAX_NETS) return ssac_fail("ssac_mlp_wgrad_fc12: n_sel out of range");
     if (!grads && (!adam_m || !adam_v || !ctl)) return ssac_fail("ssac_mlp_wgrad_fc12: Adam state missing");
     if (n_sel == 0 || n_rows <= 0) return 0;
@@ -695,6 +753,7 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                           adam_m, adam_v, ctl, grads, sumsq0, sumsq_net_stride, target, tau))
         return ssac_fail("ssac_mlp_wgrad_fc12: bad arena");
     if (rowscale) { p.g0.rowscale = p.g1.rowscale = rowscale; p.g0.sRow = p.g1.sRow = n_rows; }
+    if (lossfold) p.lf = *lossfold;
     hipStream_t st = (hipStream_t)stream;
     const int tiles = (p.g0.grid_x * p.g0.grid_y + p.g1.grid_x * p.g1.grid_y) * n_sel;
     const int nchunks = (n_rows + BK - 1) / BK;

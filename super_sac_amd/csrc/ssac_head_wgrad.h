@@ -16,7 +16,8 @@ struct HeadWgradArgs {
 // dW3[o][k] = sum_m dq[m][o] h2[m][k];  db3[o] = sum_m dq[m][o].  Workgroup (bx, e): columns [64 bx, 64 bx + 64) of
 // net e; 64 * GROUPS threads = 64 columns x GROUPS row groups.  lds: >= GROUPS*64 + GROUPS floats.
 template <int GROUPS>
-__device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *lds, int bx, int e) {
+__device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *lds, int bx, int e,
+                                                const float *dq_override = nullptr) {
     float *red = lds;                 // [GROUPS][64]
     float *redb = lds + GROUPS * 64;  // [GROUPS]
     const int tid = threadIdx.x, kk = tid & 63, mg = tid >> 6;
@@ -26,7 +27,8 @@ __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *l
     const int64_t base = (int64_t)net * a.net_stride;
     const bool kok = k < hidden;
     const float *h2 = a.H2 + (int64_t)e * n_rows * hidden + (kok ? k : 0);
-    const float *dq = a.DQ + (int64_t)e * n_rows * out_dim;
+    // dq_override: this net's dL/dq in LDS (out_dim 1; the merged launch with the loss gradient folded in)
+    const float *dq = dq_override ? dq_override : a.DQ + (int64_t)e * n_rows * out_dim;
     float ss = 0.0f;
     // one output row o at a time: out_dim is small (1 for continuous critics), rows are the long axis
     for (int o = 0; o < out_dim; ++o) {

@@ -321,7 +321,7 @@ def mlp_forward(arena, X, ldx, x_net_stride, n_rows, ws, tag, net_ids=None, n_se
 
 def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, adam=None, adam_key=None,
                  grads=None, sumsq=None, target=None, tau=0.0, net_ids=None, n_sel=None, logs=None,
-                 rowscale=None):
+                 rowscale=None, lossfold=None):
     """the weight-gradient launch(es) (+Adam/Polyak in their epilogues, or gradient store).
     logs (critic update, Adam mode, merged launch only): dict(partials, tiles, denom, logs, spec_ptr, td_logs_ptr,
     feed, done) -- the launch's last workgroup then also finalises the update's logs; returns True when it did."""
@@ -340,6 +340,16 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
 
     def ssp(layer):
         return 0 if sumsq is None else sumsq.data_ptr() + 4 * off[layer]
+    if lossfold is not None:
+        # UNSCALED backward, and the loss gradient dL/dq itself is evaluated inside the launch (per workgroup, in LDS)
+        assert O == 1 and net_ids is None and n_sel == arena.n_nets
+        f = lossfold
+        check(lib.ssac_mlp_wgrad_all_lossfold(
+            C.byref(d), X.data_ptr(), ldx, x_net_stride, h1.data_ptr(), h2.data_ptr(), dz2.data_ptr(), dz1.data_ptr(),
+            f["q"].data_ptr(), f["td_ptr"], f["spec_ptr"], f["weight_ptr"], f["popart_ptr"], f["pop"],
+            float(f["denom"]), f["partials"].data_ptr(), n_rows, _ptr(m), _ptr(v), ctl, _ptr(grads), ssp(2), ssp(1),
+            ssp(0), ttot, _ptr(target), float(tau), st))
+        return
     if rowscale is not None:
         # UNSCALED backward (ssac_target_fwd_critic_bwdu): dL/dq of every (net, row) scales the rows while they load
         assert O == 1

@@ -84,6 +84,7 @@ SPLIT_FORWARD = os.environ.get("SSAC_SPLIT_FORWARD", "0") == "1"
 
 # the TD-independent half of the critics' backward pass inside the target-critic launch (rank-1 loss gradient)
 RANK1_BWD = os.environ.get("SSAC_RANK1_BWD", "1") == "1"
+FOLD_LOSS = os.environ.get("SSAC_FOLD_LOSS", "1") == "1"  # rank-1 backward: dL/dq evaluated inside the weight-gradient launch
 DUAL_LAUNCH = os.environ.get("SSAC_DUAL_LAUNCH", "1") == "1"  # critic forward inside the actor-sample launch
 
 
@@ -445,8 +446,16 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             parts = ws.get(tag + ".parts", (N * tiles * 2,))
             spec = getattr(td, "_ssac_spec", None)  # the TD target is evaluated inside the critic launch
             spec_ptr = C.addressof(spec) if spec is not None else 0
-            if bwd_done:
-                # dz2u / dz1u exist already; what depends on the TD target is one scalar per (net, row): dL/dq
+            lossfold = None
+            if bwd_done and FOLD_LOSS and B <= 4096:
+                # dz2u / dz1u exist already; what depends on the TD target is one scalar per (net, row), dL/dq, and the
+                # weight-gradient launch evaluates it itself (per workgroup, in LDS): no loss launch at all
+                fparts = ws.get(tag + ".fparts", (N * 2,))
+                lossfold = dict(q=q, td_ptr=0 if spec is not None else td.data_ptr(), spec_ptr=spec_ptr,
+                                weight_ptr=weight_ptr, popart_ptr=pp, pop=dopop, denom=float(E * n_glob),
+                                partials=fparts)
+            elif bwd_done:
+                # ... or a single-workgroup launch writes the N x B scalars for the weight-gradient launch to read
                 if spec is not None:
                     check(lib.ssac_critic_loss_bwd_lazy(q.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0), spec_ptr,
                                                         weight_ptr, pp, dopop, float(E * n_glob), dq.data_ptr(),
@@ -491,12 +500,16 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                             done=ws.get("cu.done", (1,), dtype=torch.int32, zero=True))
             folded = engine.weight_grads(arena, X, ldx, 0, h1, h2, dq, dz2, dz1, B, adam=adam,
                                          adam_key=("critic", i), grads=grads, sumsq=ss,
-                                         logs=None if bwd_done else fold, rowscale=dq if bwd_done else None)
+                                         logs=None if bwd_done else fold,
+                                         rowscale=dq if (bwd_done and lossfold is None) else None, lossfold=lossfold)
             if folded:
                 logs_done_in_wgrad = True
                 if fold["feed"]:
                     engine.CAPTURE.published = True
-            fused_logs.append((parts, 0 if bwd_done else N, tiles, B, n_glob, td))
+            if lossfold is not None:
+                fused_logs.append((lossfold["partials"], N, 1, B, n_glob, td))
+            else:
+                fused_logs.append((parts, 0 if bwd_done else N, tiles, B, n_glob, td))
         else:
             h1, h2, q = engine.mlp_forward(arena, X, ldx, 0, B, ws, tag)
             check(lib.ssac_critic_loss_bwd(q.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0),

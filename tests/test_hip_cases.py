@@ -62,10 +62,11 @@ def test_graph_replay_equals_eager_launches():
     import torch
     import super_sac_amd as ssa
 
-    def run(use_graphs, split, mode="list", dual=True, rank1=True):
+    def run(use_graphs, split, mode="list", dual=True, rank1=True, fold=True):
         L = ssa.learning
-        old = (L.USE_GRAPHS, L.SPLIT_FORWARD, L.LAUNCH_MODE, L.DUAL_LAUNCH, L.RANK1_BWD)
-        L.USE_GRAPHS, L.SPLIT_FORWARD, L.LAUNCH_MODE, L.DUAL_LAUNCH, L.RANK1_BWD = use_graphs, split, mode, dual, rank1
+        old = (L.USE_GRAPHS, L.SPLIT_FORWARD, L.LAUNCH_MODE, L.DUAL_LAUNCH, L.RANK1_BWD, L.FOLD_LOSS)
+        (L.USE_GRAPHS, L.SPLIT_FORWARD, L.LAUNCH_MODE, L.DUAL_LAUNCH, L.RANK1_BWD,
+         L.FOLD_LOSS) = use_graphs, split, mode, dual, rank1, fold
         try:
             torch.manual_seed(3); np.random.seed(3); random.seed(3)
             dev = torch.device("cuda")
@@ -97,7 +98,7 @@ def test_graph_replay_equals_eager_launches():
             tparams = torch.cat([p.detach().flatten() for p in target.critics[0].parameters()]).cpu().numpy()
             return params, tparams, last, buf.total_sample_calls
         finally:
-            L.USE_GRAPHS, L.SPLIT_FORWARD, L.LAUNCH_MODE, L.DUAL_LAUNCH, L.RANK1_BWD = old
+            L.USE_GRAPHS, L.SPLIT_FORWARD, L.LAUNCH_MODE, L.DUAL_LAUNCH, L.RANK1_BWD, L.FOLD_LOSS = old
 
     # default configuration (merged launches, rank-1 backward): the three launch mechanisms agree bit for bit
     pe, te, le, ce = run(False, split=False)
@@ -116,6 +117,11 @@ def test_graph_replay_equals_eager_launches():
     assert np.array_equal(p0, p1) and np.array_equal(t0, t1) and l0[0] == l1[0], \
         "split forward/backward launches must be bit-identical to the one-launch critic kernel"
     assert np.allclose(pe, p0, atol=2e-6) and np.allclose(te, t0, atol=2e-6), "rank-1 backward vs fused backward"
+    # dL/dq evaluated inside the weight-gradient launch vs written by the separate loss launch: the same products
+    # (the scale multiplies the rows when they are stored to LDS instead of when they are loaded)
+    pf, tf, lf, _ = run(False, split=False, fold=False)
+    assert np.array_equal(pe, pf) and np.array_equal(te, tf), "folded loss gradient vs loss launch"
+    assert abs(le[0] - lf[0]) <= 1e-5 * max(1.0, abs(lf[0])) and abs(le[1] - lf[1]) <= 1e-5 * max(1.0, abs(lf[1]))
     assert ce == cg == 20
     assert np.array_equal(le[2], lg[2]), "replay indices must not depend on the launch mechanism"
     assert np.array_equal(pe, pg) and np.array_equal(te, tg), "graph replay must be bit-identical to eager launches"

@@ -70,7 +70,7 @@ class _LaunchList:
                     pass
 
 
-FEED_SLOTS = 16  # pinned input ring of a captured update: how far the host may run ahead of the GPU
+FEED_SLOTS = 32  # pinned input ring of a captured update: how far the host may run ahead of the GPU
 # evaluate the TD target inside the critic launch instead of a launch of its own (continuous, no PopArt)
 SHARDED_LISTS = os.environ.get("SSAC_SHARDED_LISTS", "1") == "1"  # recorded launch lists on critic-sharded ranks
 FOLD_BEGIN = os.environ.get("SSAC_FOLD_BEGIN", "1") == "1"  # fold ssac_begin_update into the replay gather
@@ -84,6 +84,7 @@ SPLIT_FORWARD = os.environ.get("SSAC_SPLIT_FORWARD", "0") == "1"
 
 # the TD-independent half of the critics' backward pass inside the target-critic launch (rank-1 loss gradient)
 RANK1_BWD = os.environ.get("SSAC_RANK1_BWD", "1") == "1"
+EVENT_EVERY = int(os.environ.get("SSAC_EVENT_EVERY", "8"))  # must divide FEED_SLOTS
 FOLD_LOSS = os.environ.get("SSAC_FOLD_LOSS", "1") == "1"  # rank-1 backward: dL/dq evaluated inside the weight-gradient launch
 DUAL_LAUNCH = os.environ.get("SSAC_DUAL_LAUNCH", "1") == "1"  # critic forward inside the actor-sample launch
 
@@ -223,8 +224,10 @@ def _critic_update_graphed(gs, kw):
     ids = rng.draw_subset(agent.num_critics if shard is None else shard.num_critics, n_sub)  # GLOBAL ensemble
     # ---- per-update inputs into this update's pinned slot
     k = gs.k % FEED_SLOTS
-    if gs.events[k] is not None:
-        gs.events[k].synchronize()  # the replay that read this slot FEED_SLOTS updates ago has finished
+    # slot reuse: the replay that read this slot FEED_SLOTS updates ago must have finished.  One event per group of
+    # EVENT_EVERY updates (recorded after the group's last update; an event costs a barrier packet on the queue)
+    if gs.k % EVENT_EVERY == 0 and gs.k >= FEED_SLOTS:
+        gs.events[((gs.k - FEED_SLOTS) // EVENT_EVERY) % (FEED_SLOTS // EVENT_EVERY)].synchronize()
     slot_i = ring.advance()
     gs.np_idx[k] = idx_cpu.numpy()
     row = gs.np_i32[k]
@@ -290,10 +293,12 @@ def _critic_update_graphed(gs, kw):
                         for si in range(ring.buf.shape[0])}
     else:
         gs.graph.replay()  # ONE host call re-issues the whole update
-    ev = gs.events[k]
-    if ev is None:
-        ev = gs.events[k] = torch.cuda.Event()
-    ev.record()
+    if gs.k % EVENT_EVERY == EVENT_EVERY - 1:
+        gi = (gs.k // EVENT_EVERY) % (FEED_SLOTS // EVENT_EVERY)
+        ev = gs.events[gi]
+        if ev is None:
+            ev = gs.events[gi] = torch.cuda.Event()
+        ev.record()
     gs.k += 1
     if in_kernel_noise:
         lu.noise_stream(agent, dev)[1] += 1  # one draw of the agent's noise stream per update, as in eager launches

@@ -67,13 +67,24 @@ typedef struct ssac_popart {
  * target-critic launches) and ssac_critic_logs, the last launch of the update, publishes the log block into
  * log_ring[dst_words[log_slot_word]] and advances `tick`.  Lives in DEVICE memory. */
 typedef struct ssac_feed {
-    const uint32_t *host_ring;  /* pinned host memory, n_slots x slot_words 4-byte words; 16-byte aligned,
-                                   slot_words % 4 == 0 */
+    const uint32_t *host_ring;  /* the input ring (ssac_feed_ring_alloc): n_slots x slot_words 4-byte words;
+                                   16-byte aligned, slot_words % 4 == 0 */
     uint32_t *dst;              /* device copy of the current slot (slot_words words) */
     float *log_ring;            /* device ring of log blocks, log_width floats each */
     int64_t tick;               /* updates consumed so far */
     int32_t n_slots, slot_words, log_slot_word, log_width;
 } ssac_feed;
+
+/* The input ring of ssac_feed.  On a large-BAR system (the MI355X boxes: all of HBM is CPU-mappable) it is UNCACHED
+ * DEVICE memory the host stores into directly -- posted PCIe writes issued many updates ahead -- so the update's
+ * first launch reads its slot from local HBM instead of paying a PCIe read round trip (~4 us) on the critical
+ * path; otherwise pinned host memory the launch reads over PCIe.  *device_resident tells which.  The host writes a
+ * slot with ssac_feed_write (copy + store fence: write-combining buffers are drained before the launch that
+ * reads the slot is submitted). */
+int ssac_feed_ring_alloc(size_t bytes, void **ring, int *device_resident);
+int ssac_feed_ring_free(void *ring, int device_resident);
+int ssac_feed_write(void *ring_slot, const void *src, size_t bytes);
+int ssac_feed_ring_mode(int device_ok); /* 0: always pinned host memory (default 1: device memory when large-BAR) */
 
 /* TD target evaluated INSIDE the critic launch instead of by ssac_td_target (continuous actions, no PopArt):
  * td[b] = rew[b] + gamma (1 - done[b]) (min_j q_t[j][b] - alpha logp[b])   (learning_utils.py:298-354),

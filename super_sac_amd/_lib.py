@@ -132,6 +132,10 @@ SIGNATURES = {
     "ssac_fused_row_tiles": [_MP, _I, _I],
     "ssac_fused_tile_rows": [_I],
     "ssac_xcd_order": [_I],
+    "ssac_feed_ring_alloc": [C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_int)],
+    "ssac_feed_ring_free": [_P, _I],
+    "ssac_feed_ring_mode": [_I],
+    "ssac_feed_write": [_P, _P, C.c_size_t],
     "ssac_mlp3_fwd_fused": [_MP, _P, _I, _P, _L, _L, _I, _P, _P, _P, _P],
     "ssac_actor_sample_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _P, _P, _P, _P],
     "ssac_actor_sample_critic_fwd": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _L, _P, _P, _P, _P],
@@ -158,6 +162,8 @@ def _load():
         fn.restype = _RESTYPES.get(name, C.c_int)
     if lib.ssac_abi_version() != 1:
         raise ImportError("libssac_hip.so ABI version mismatch; rebuild the extension")
+    if os.environ.get("SSAC_FEED_DEVICE") == "0":
+        lib.ssac_feed_ring_mode(0)
     if os.environ.get("SSAC_XCD_ORDER"):
         lib.ssac_xcd_order(int(os.environ["SSAC_XCD_ORDER"]))
     return lib

@@ -6,6 +6,7 @@
 // (TD-target mean/std for the logs and PopArt, loss means) are produced by single-workgroup
 // kernels so their summation order is fixed and results are run-to-run deterministic.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <math.h>
 #include <stdint.h>
 
@@ -1172,6 +1173,41 @@ thread_local std::vector<SsacLaunchRec> *g_ssac_recording = nullptr;
 struct ssac_launch_list {
     std::vector<SsacLaunchRec> recs;
 };
+
+// ---- input ring of ssac_feed (see include/ssac_hip.h)
+int g_ssac_feed_device = 1;  // ssac_feed_ring_mode(0): always pinned host memory
+extern "C" int ssac_feed_ring_mode(int device_ok) { g_ssac_feed_device = device_ok ? 1 : 0; return 0; }
+
+extern "C" int ssac_feed_ring_alloc(size_t bytes, void **ring, int *device_resident) {
+    if (!ring || !device_resident || bytes == 0) return ssac_fail("ssac_feed_ring_alloc: bad arguments");
+    int dev = 0, large_bar = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return ssac_fail("ssac_feed_ring_alloc: no device");
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) large_bar = 0;
+    *ring = nullptr;
+    if (large_bar && g_ssac_feed_device &&
+        hipExtMallocWithFlags(ring, bytes, hipDeviceMallocUncached) == hipSuccess && *ring) {
+        *device_resident = 1;
+        return 0;
+    }
+    (void)hipGetLastError();
+    if (hipHostMalloc(ring, bytes, hipHostMallocDefault) != hipSuccess || !*ring)
+        return ssac_fail("ssac_feed_ring_alloc: hipHostMalloc failed");
+    *device_resident = 0;
+    return 0;
+}
+
+extern "C" int ssac_feed_ring_free(void *ring, int device_resident) {
+    if (!ring) return 0;
+    const hipError_t e = device_resident ? hipFree(ring) : hipHostFree(ring);
+    return e == hipSuccess ? 0 : ssac_fail("ssac_feed_ring_free: free failed");
+}
+
+extern "C" int ssac_feed_write(void *ring_slot, const void *src, size_t bytes) {
+    if (!ring_slot || !src) return ssac_fail("ssac_feed_write: null pointer");
+    memcpy(ring_slot, src, bytes);
+    __builtin_ia32_sfence();  // drain the write-combining buffers (BAR-mapped ring) before the launch is submitted
+    return 0;
+}
 
 int g_ssac_xcd = 2;  // bit 0: fused MLP kernels, bit 1: GEMM / weight-gradient kernels
 extern "C" int ssac_xcd_order(int mask) { g_ssac_xcd = mask & 3; return 0; }

@@ -175,6 +175,21 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
     return _critic_update_graphed(gs, kw)
 
 
+class _FeedRing:
+    """the input ring of a recorded update (ssac_feed_ring_alloc): device-resident on large-BAR systems"""
+
+    def __init__(self, nbytes):
+        p, d = C.c_void_p(), C.c_int()
+        check(lib.ssac_feed_ring_alloc(nbytes, C.byref(p), C.byref(d)))
+        self.ptr, self.device_resident = p.value, bool(d.value)
+
+    def __del__(self):
+        try:
+            lib.ssac_feed_ring_free(self.ptr, int(self.device_resident))
+        except Exception:
+            pass
+
+
 def _critic_update_graphed(gs, kw):
     buffer, agent, B = kw["buffer"], kw["agent"], kw["batch_size"]
     dev = kw["log_alphas"][0].device
@@ -193,9 +208,13 @@ def _critic_update_graphed(gs, kw):
         gs.inbuf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         gs.idx_dev = gs.inbuf[:8 * B].view(torch.int64)
         gs.ids_dev = gs.inbuf[8 * B:8 * B + 4 * n_pad].view(torch.int32)[:n_sub]
-        gs.host = torch.zeros(FEED_SLOTS, nbytes, dtype=torch.uint8).pin_memory()
-        # numpy views of the pinned slots (host writes through numpy cost a fraction of torch indexing)
-        hnp = gs.host.numpy()
+        # the slots are composed in ordinary host memory (numpy views: a fraction of the cost of torch indexing) and
+        # copied into the input ring with ONE ssac_feed_write each; the ring itself is uncached device memory the
+        # host stores into over the PCIe BAR when the system allows it, pinned host memory otherwise
+        gs.stage = np.zeros((FEED_SLOTS, nbytes), np.uint8)
+        gs.ring = _FeedRing(FEED_SLOTS * nbytes)
+        gs.slot_bytes = nbytes
+        hnp = gs.stage
         gs.np_idx = hnp[:, :8 * B].view(np.int64)                           # (slots, B)
         gs.np_i32 = hnp[:, 8 * B:8 * B + 4 * n_pad + 8].view(np.int32)      # ids..., then the log slot at [n_pad]
         gs.np_draw = hnp[:, 8 * B + 4 * n_pad + 8:8 * B + 4 * n_pad + 16].view(np.int64)  # (slots, 1)
@@ -205,7 +224,7 @@ def _critic_update_graphed(gs, kw):
         gs.k = 0
         gs.eps_dev = torch.empty(B, actor.action_size, device=dev) if kind == "stochastic" else None
         gs.logblk = torch.zeros(lu.LOG_WIDTH, device=dev)
-        gs.feed = engine.DeviceStruct(_lib.Feed(gs.host.data_ptr(), gs.inbuf.data_ptr(), ring.buf.data_ptr(), 0,
+        gs.feed = engine.DeviceStruct(_lib.Feed(gs.ring.ptr, gs.inbuf.data_ptr(), ring.buf.data_ptr(), 0,
                                                 FEED_SLOTS, nbytes // 4, (8 * B + 4 * n_pad) // 4,
                                                 lu.LOG_WIDTH), dev)
     # ---- host draws, in the reference's order: indices -> (augmentation: none here) -> noise -> subset
@@ -237,6 +256,7 @@ def _critic_update_graphed(gs, kw):
     row[gs.n_pad] = slot_i
     if in_kernel_noise:
         gs.np_draw[k, 0] = lu.noise_stream(agent, dev)[1]
+    check(lib.ssac_feed_write(gs.ring.ptr + k * gs.slot_bytes, gs.stage.ctypes.data + k * gs.slot_bytes, gs.slot_bytes))
     if gs.graph is None:
         gs.in_kernel_noise = in_kernel_noise
         ctx = engine.CaptureCtx(idx_cpu, gs.idx_dev, ids, gs.ids_dev,

@@ -86,6 +86,27 @@ int ssac_feed_ring_free(void *ring, int device_resident);
 int ssac_feed_write(void *ring_slot, const void *src, size_t bytes);
 int ssac_feed_ring_mode(int device_ok); /* 0: always pinned host memory (default 1: device memory when large-BAR) */
 
+/* The replay gather (replay.py:131-161: rows idx of s, a, r, s', d) folded into ssac_actor_sample_critic_fwd: each
+ * workgroup fetches ITS tile's rows straight from the replay arrays -- the actor half s' (and writes [s'|.], r, d out
+ * for the later launches), the critic half [s|a] (net slot 0 writes it out for the weight-gradient launch) -- so the
+ * update has no gather launch.  float32 vector observations.  Host-side struct, copied at launch. */
+typedef struct ssac_gather {
+    const float *s, *s1;           /* replay observation arrays (rows x s_elems) */
+    const float *act;              /* (rows x a_elems) */
+    const float *rew;              /* (rows) */
+    const uint8_t *done;           /* (rows) */
+    int64_t s_elems, a_elems;
+    const int64_t *idx;            /* (n_rows) replay row of every batch row, or NULL: the current slot of `feed` */
+    const ssac_feed *feed;         /* recorded update: indices from the input ring; the launch then also does the
+                                      work of ssac_begin_update (slot -> device block, logs cleared, step advanced) */
+    float *xsa; int64_t ld_x;      /* out: [s | a] (n_rows x ld_x) */
+    float *x1sa; int64_t ld_x1;    /* out: [s' | .] */
+    float *rew_out, *done_out;     /* out: (n_rows) */
+    float *logs; int32_t n_logs;   /* with feed: log block to clear */
+    int32_t rng_word;              /* with feed: 4-byte word offset of the int64 noise draw number in the slot, -1 = none */
+    ssac_adam_ctl *ctl;            /* with feed: optimizer control block to advance (may be NULL) */
+} ssac_gather;
+
 /* TD target evaluated INSIDE the critic launch instead of by ssac_td_target (continuous actions, no PopArt):
  * td[b] = rew[b] + gamma (1 - done[b]) (min_j q_t[j][b] - alpha logp[b])   (learning_utils.py:298-354),
  * the same arithmetic in the same order as ssac_td_target.  Host-side struct, copied at launch. */
@@ -435,7 +456,8 @@ int ssac_actor_sample_fused(const ssac_mlp *actor, const float *X, int64_t ldx, 
 int ssac_actor_sample_critic_fwd(const ssac_mlp *actor, const float *Xa, int64_t ldxa, int n_rows, const float *eps,
                                  float log_std_lo, float log_std_hi, float *act_dst, int64_t ld_act,
                                  int64_t act_col0, float *logp, const ssac_rng *rng, const ssac_mlp *critics,
-                                 const float *Xc, int64_t ldxc, float *H1, float *H2, float *Q, void *stream);
+                                 const float *Xc, int64_t ldxc, float *H1, float *H2, float *Q,
+                                 const ssac_gather *gather /* NULL: inputs are Xa / Xc */, void *stream);
 
 /* critic forward of ALL nets + loss gradient + backward-data in ONE launch (learning.py:83-98,112,121):
  * writes H1, H2, Q (n_nets x n_rows x out), DQ, DZ2 = dL/d(pre-activation of fc2), DZ1, and per-(net,

@@ -51,6 +51,15 @@ class TdSpec(C.Structure):
                 ("n_sel", C.c_int32), ("use_entropy", C.c_int32), ("_pad", C.c_int32)]
 
 
+class Gather(C.Structure):
+    """struct ssac_gather"""
+    _fields_ = [("s", C.c_void_p), ("s1", C.c_void_p), ("act", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p),
+                ("s_elems", C.c_int64), ("a_elems", C.c_int64), ("idx", C.c_void_p), ("feed", C.c_void_p),
+                ("xsa", C.c_void_p), ("ld_x", C.c_int64), ("x1sa", C.c_void_p), ("ld_x1", C.c_int64),
+                ("rew_out", C.c_void_p), ("done_out", C.c_void_p), ("logs", C.c_void_p), ("n_logs", C.c_int32),
+                ("rng_word", C.c_int32), ("ctl", C.c_void_p)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _MP = C.POINTER(MlpDesc)
 
@@ -138,7 +147,7 @@ SIGNATURES = {
     "ssac_feed_write": [_P, _P, C.c_size_t],
     "ssac_mlp3_fwd_fused": [_MP, _P, _I, _P, _L, _L, _I, _P, _P, _P, _P],
     "ssac_actor_sample_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _P, _P, _P, _P],
-    "ssac_actor_sample_critic_fwd": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _L, _P, _P, _P, _P],
+    "ssac_actor_sample_critic_fwd": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _L, _P, _P, _P, _P, _P],
     "ssac_philox_normal": [_P, _I, _I, _P, _P],
     "ssac_critic_fwd_bwd_fused": [_MP, _P, _L, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ssac_critic_bwd_fused": [_MP, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],

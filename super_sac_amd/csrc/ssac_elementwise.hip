@@ -10,6 +10,7 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "ssac_begin.h"
 #include "ssac_internal.h"
 #include "ssac_philox.h"
 
@@ -58,30 +59,6 @@ __device__ __forceinline__ float popart_sigma(float mu, float nu) {
     return fminf(fmaxf(sqrtf(nu - mu * mu) + 1e-5f, 1e-4f), 1e6f);
 }
 
-__device__ __forceinline__ void adam_refresh(ssac_adam_ctl *c, int t);
-
-// this update's host inputs: pinned ring slot -> fixed device block, one PCIe round trip.
-// 16 bytes per lane and every load issued before the first store (slot_words % 4 == 0 and 16-byte
-// aligned slots are the host's contract).
-__device__ __forceinline__ void feed_pull(const ssac_feed &f) {
-    const uint32_t *src = f.host_ring + (int64_t)(f.tick % f.n_slots) * f.slot_words;
-    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
-    uint4 *d4 = reinterpret_cast<uint4 *>(f.dst);
-    const int n4 = f.slot_words >> 2;
-    uint4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int i = threadIdx.x + u * blockDim.x;
-        v[u] = s4[i < n4 ? i : 0];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int i = threadIdx.x + u * blockDim.x;
-        if (i < n4) d4[i] = v[u];
-    }
-    for (int i = 4 * blockDim.x + threadIdx.x; i < n4; i += blockDim.x) d4[i] = s4[i];
-}
-
 __global__ void philox_normal_kernel(float *out, int n_rows, int cols, RngArgs r) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows * cols) return;
@@ -117,7 +94,7 @@ __global__ void gather_transition_kernel(const T *__restrict__ s, const T *__res
         // pinned host ring, and workgroup 0 also does what ssac_begin_update would (slot -> device block for
         // the later launches, log block cleared, optimizer step advanced) -- one launch fewer on the chain
         const ssac_feed f = *feed;
-        idx = reinterpret_cast<const int64_t *>(f.host_ring + (int64_t)(f.tick % f.n_slots) * f.slot_words);
+        idx = reinterpret_cast<const int64_t *>(feed_slot(f));
         if (blockIdx.x == 0) {
             feed_pull(f);
             if ((int)threadIdx.x < n_logs) logs[threadIdx.x] = 0.0f;
@@ -613,11 +590,6 @@ __global__ __launch_bounds__(RED_THREADS) void discrete_actor_loss_bwd_kernel(
 }
 
 // ------------------------------------------------------------------ temperature update
-__device__ __forceinline__ void adam_refresh(ssac_adam_ctl *c, int t) {
-    c->step = t;
-    c->step_size = (float)(c->lr_d / (1.0 - pow(c->beta1_d, (double)t)));
-    c->bc2_sqrt = (float)sqrt(1.0 - pow(c->beta2_d, (double)t));
-}
 
 __global__ __launch_bounds__(RED_THREADS) void alpha_update_kernel(
     float *log_alpha, float *am, float *av, ssac_adam_ctl *ctl, const float *__restrict__ lp,

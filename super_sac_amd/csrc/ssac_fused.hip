@@ -35,6 +35,7 @@
 #include "ssac_head_wgrad.h"
 #include "ssac_philox.h"
 #include "ssac_critic_logs.h"
+#include "ssac_begin.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -66,6 +67,7 @@ struct FusedArgs {
     const float *td, *weight, *act; int64_t ld_a; const ssac_popart *popart; int pop; float denom;
     float *DQ, *DZ2, *DZ1; float *partials;  // partials[(e*tiles + tile)*2 + {loss, err}]
     int xcd;                     // workgroups take their tile in XCD-contiguous order (ssac_internal.h)
+    ssac_gather gth; int gth_role;  // 1: actor half (s' rows, begin duties), 2: critic half ([s|a] rows); 0: input is X
     long long *dbg;  // optional phase timestamps (s_memtime) of workgroup (0,0), thread 0
     ssac_td_spec tds;  // tds.q_t != null: the TD target is computed here instead of read from `td`
 };
@@ -411,6 +413,22 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     const float *P = g.params + (int64_t)net * g.net_stride;
     const float *X = g.X + (int64_t)e * g.sX;
     const int col0 = wave * 32;
+    // replay gather folded into this launch (ssac_gather): where this tile's rows come from
+    const int64_t *gidx = nullptr;
+    const uint32_t *gslot = nullptr;
+    if (g.gth_role) {
+        gidx = g.gth.idx;
+        if (g.gth.feed) {
+            const ssac_feed f = *g.gth.feed;
+            gslot = feed_slot(f);
+            gidx = reinterpret_cast<const int64_t *>(gslot);
+            if (g.gth_role == 1 && bx == 0) {  // start-of-update duties (ssac_begin_update)
+                feed_pull(f);
+                if (tid < g.gth.n_logs) g.gth.logs[tid] = 0.0f;
+                if (tid == 0 && g.gth.ctl) adam_refresh(g.gth.ctl, g.gth.ctl->step + 1);
+            }
+        }
+    }
 
     BSTAMP(0);
     const int ldw3 = H + APAD;
@@ -470,6 +488,29 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
             rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
         }
         // ---- x tile -> LDS, zero padded to KP columns and to TMR rows (half-wave per row, 32 columns a pass)
+        if (gidx) {
+            const int Sg = (int)g.gth.s_elems;
+            const bool actor_half = g.gth_role == 1;
+            float *outp = actor_half ? g.gth.x1sa : (e == 0 ? g.gth.xsa : nullptr);
+            const int64_t ldo_g = actor_half ? g.gth.ld_x1 : g.gth.ld_x;
+            for (int r = tid >> 5; r < TMR; r += NTHR / 32) {
+                const bool rok = (m0 + r) < g.n_rows;
+                const int64_t src = gidx[rok ? m0 + r : 0];
+                const float *sr = (actor_half ? g.gth.s1 : g.gth.s) + src * Sg;
+                const float *ar = g.gth.act + src * g.gth.a_elems - Sg;
+                for (int k = tid & 31; k < KP; k += 32) {
+                    const bool ok = rok && k < IN;
+                    const float v = (k < Sg ? sr : ar)[ok ? k : (k < Sg ? 0 : Sg)];
+                    xs[r * ldx_s + k] = ok ? v : 0.0f;
+                    if (ok && outp) outp[(int64_t)(m0 + r) * ldo_g + k] = v;
+                }
+            }
+            if (actor_half && tid < TMR && (m0 + tid) < g.n_rows) {
+                const int64_t src = gidx[m0 + tid];
+                g.gth.rew_out[m0 + tid] = g.gth.rew[src];
+                g.gth.done_out[m0 + tid] = (float)g.gth.done[src];
+            }
+        } else
         for (int r = tid >> 5; r < TMR; r += NTHR / 32) {
             const bool rok = (m0 + r) < g.n_rows;
             const float *xr = X + (rok ? (int64_t)(m0 + r) * g.ldx : 0);
@@ -578,7 +619,12 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 const float mu = ys[r * ldo + i], raw = ys[r * ldo + A + i];
                 const float log_std = g.lo + 0.5f * (g.hi - g.lo) * (tanhf(raw) + 1.0f);
                 const float sd = expf(log_std);
-                const float ep = g.eps ? g.eps[(int64_t)b * A + i] : philox_normal(g.rng.seed, rng_draw(g.rng), b, i);
+                // (gather folded in: the draw number is read from the input slot itself -- the device copy of the
+                // slot is being written by this very launch)
+                const int64_t draw = (gslot && g.gth.rng_word >= 0)
+                                         ? g.rng.offset + *reinterpret_cast<const int64_t *>(gslot + g.gth.rng_word)
+                                         : rng_draw(g.rng);
+                const float ep = g.eps ? g.eps[(int64_t)b * A + i] : philox_normal(g.rng.seed, draw, b, i);
                 const float u = mu + sd * ep;
                 const float dlt = u - mu;
                 lpt[r * ldo + i] = (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -
@@ -1358,7 +1404,7 @@ extern "C" int ssac_actor_sample_critic_fwd(const ssac_mlp *actor, const float *
                                             const float *eps, float log_std_lo, float log_std_hi, float *act_dst,
                                             int64_t ld_act, int64_t act_col0, float *logp, const ssac_rng *rng,
                                             const ssac_mlp *critics, const float *Xc, int64_t ldxc, float *H1,
-                                            float *H2, float *Q, void *stream) {
+                                            float *H2, float *Q, const ssac_gather *gather, void *stream) {
     if (!eps && !rng) return ssac_fail("ssac_actor_sample_critic_fwd: neither eps nor an rng stream given");
     if (!fused_ok(actor) || (actor->out_dim & 1) || !fused_dbuf_ok(critics))
         return ssac_fail("ssac_actor_sample_critic_fwd: shape not supported by the merged launch");
@@ -1371,6 +1417,18 @@ extern "C" int ssac_actor_sample_critic_fwd(const ssac_mlp *actor, const float *
     ga.act_dst = act_dst; ga.ld_act = ld_act; ga.act_col0 = act_col0; ga.logp = logp;
     fill_common(gc, critics, nullptr, Xc, ldxc, 0, n_rows);
     gc.H1 = H1; gc.H2 = H2; gc.Y = Q;
+    if (gather) {
+        if (gather->s_elems != actor->in_dim || gather->s_elems + gather->a_elems != critics->in_dim)
+            return ssac_fail("ssac_actor_sample_critic_fwd: gather sizes do not match the networks");
+        if (!gather->s || !gather->s1 || !gather->act || !gather->rew || !gather->done || !gather->xsa ||
+            !gather->x1sa || !gather->rew_out || !gather->done_out || (!gather->idx && !gather->feed))
+            return ssac_fail("ssac_actor_sample_critic_fwd: incomplete ssac_gather");
+        if (gather->feed && gather->n_logs > NTHR) return ssac_fail("ssac_actor_sample_critic_fwd: log block too large");
+        ga.gth = *gather; ga.gth_role = 1;
+        gc.gth = *gather; gc.gth_role = 2;
+    } else if (!Xa || !Xc) {
+        return ssac_fail("ssac_actor_sample_critic_fwd: Xa / Xc missing");
+    }
     const int tc = choose_tile(gc, critics->n_nets).tm;  // what a stand-alone forward of the critics would use
     const int tiles_a = (n_rows + 15) / 16, cgx = (n_rows + tc - 1) / tc;
     const bool adbuf = fused_dbuf_ok(actor);

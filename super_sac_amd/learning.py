@@ -356,15 +356,19 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
     fused_logs = []
     logs_done_in_wgrad = False
     for i in range(E):
-        rd = lu.sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter,
-                                        aug_mix=aug_mix, per=per)
-        o, a, r, o1, d = rd["primary_batch"]
-        B = r.shape[0]
         arena = agent.critics[i].arena(dev)
         N, qd = arena.n_nets, arena.out_dim
         H = arena.hidden
         tag = f"cu.c{i}"
         train_enc = not lu.is_identity(agent.encoder)
+        # when the merged actor / critic-forward launch will run, its workgroups fetch their own replay rows
+        # (ssac_gather) and the update has no gather launch
+        dual_ok = (DUAL_LAUNCH and arena.fused_dbuf and not train_enc and not dr3_coeff and not discrete
+                   and _dual_fits(arena, batch_size) and not _split_forward(N, batch_size))
+        rd = lu.sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter,
+                                        aug_mix=aug_mix, per=per, _defer_gather=dual_ok)
+        o, a, r, o1, d = rd["primary_batch"]
+        B = r.shape[0]
         # The online critics' FORWARD does not depend on the TD target: on a second stream (a parallel graph
         # branch) it overlaps the actor -> target critics -> TD-target chain, which occupies few CUs.
         branch = None
@@ -375,8 +379,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                 with engine._timed("critic_fwd"):
                     h1, h2, q = engine.mlp_forward(arena, X, ldx, 0, B, ws, tag)
         co = cob = None
-        if (DUAL_LAUNCH and branch is None and arena.fused_dbuf and not train_enc and not dr3_coeff and not discrete
-                and _dual_fits(arena, B)):
+        if dual_ok and branch is None:
             # the critics' forward rides in the actor's launch (when compute_td_targets uses the fused sample
             # launch); the critic launch below is then only the backward half
             s_rep = lu.encode(agent.encoder, o)
@@ -393,6 +396,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                                       random_process=random_process, noise_clip=noise_clip,
                                       discrete=discrete, _slot=slot, _defer=arena.fused and LAZY_TD and not dr3_coeff,
                                       _co_forward=co, _co_backward=cob)
+        lu.ensure_gathered(rd.get("_ssac"))  # (no-op when the merged launch took the gather)
         co_done = bool(rd.pop("_co_fwd", False))
         bwd_done = bool(rd.pop("_co_bwd", False))
         if co_done:

@@ -170,10 +170,49 @@ def hard_update(target, source):
 # ------------------------------------------------------------------------------------------
 class _Batch:
     """device buffers of one sampled minibatch: xsa = [s | a], x1sa = [s' | (a' written later)]."""
-    __slots__ = ("B", "S", "A", "xsa", "x1sa", "r", "d", "key", "pixel")
+    __slots__ = ("B", "S", "A", "xsa", "x1sa", "r", "d", "key", "pixel", "pending")
 
 
-def sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, per=True):
+# the replay gather of a critic update rides in the merged actor / critic-forward launch (ssac_gather): no gather launch
+FOLD_GATHER = os.environ.get("SSAC_FOLD_GATHER", "1") == "1"
+
+
+def ensure_gathered(bt):
+    """issue the replay gather of a batch whose gather was deferred (sample_move_and_augment(_defer_gather=True)) and
+    has not been taken over by the merged launch"""
+    if bt is None or getattr(bt, "pending", None) is None:
+        return
+    p, bt.pending = bt.pending, None
+    S, A, B = p["S"], p["A"], bt.B
+    if p["begin"] is not None:
+        blk, ctl = p["begin"]
+        check(lib.ssac_gather_transition_begin(p["s"], p["s1"], p["dtype"], S, p["act"], A, p["rew"], p["done"], B,
+                                               bt.xsa.data_ptr(), S + A, bt.x1sa.data_ptr(), S + A, bt.r.data_ptr(),
+                                               bt.d.data_ptr(), p["feed"], blk.data_ptr(), LOG_WIDTH, ctl,
+                                               engine.stream()))
+    else:
+        check(lib.ssac_gather_transition(p["s"], p["s1"], p["dtype"], S, p["act"], A, p["rew"], p["done"],
+                                         p["idx"].data_ptr(), B, bt.xsa.data_ptr(), S + A, bt.x1sa.data_ptr(), S + A,
+                                         bt.r.data_ptr(), bt.d.data_ptr(), engine.stream()))
+
+
+def gather_struct(bt):
+    """the ssac_gather of a batch with a deferred gather (consumes it): handed to the merged launch"""
+    p, bt.pending = bt.pending, None
+    S, A = p["S"], p["A"]
+    cap = engine.CAPTURE
+    g = _lib.Gather(p["s"], p["s1"], p["act"], p["rew"], p["done"], S, A, p["idx"].data_ptr(), 0,
+                    bt.xsa.data_ptr(), S + A, bt.x1sa.data_ptr(), S + A, bt.r.data_ptr(), bt.d.data_ptr(), 0, 0, -1, 0)
+    if p["begin"] is not None:
+        blk, ctl = p["begin"]
+        g.idx, g.feed, g.logs, g.n_logs, g.ctl = 0, p["feed"], blk.data_ptr(), LOG_WIDTH, ctl
+        if cap is not None and cap.tick_ptr:
+            g.rng_word = (cap.tick_ptr - cap.idx_dev.data_ptr()) // 4
+    g._keep = (p["idx"],)
+    return g
+
+
+def sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, per=True, _defer_gather=False):
     assert len(buffer) >= batch_size
     st = buffer._storage
     dev = st.device
@@ -192,7 +231,7 @@ def sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, per=True):
     # one randomisation per call, shared by s and s' (augmentations.py:28-29)
     augmenter.change_randomization_params()
     bt = _Batch()
-    bt.B, bt.A = B, A
+    bt.B, bt.A, bt.pending = B, A, None
     vec = len(keys) == 1 and st.s_stack[keys[0]].dim() == 2
     if vec:
         key = keys[0]
@@ -201,21 +240,16 @@ def sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, per=True):
         x1sa = torch.empty(B, S + A, device=dev)
         src = st.s_stack[key]
         cap = engine.CAPTURE
-        if cap is not None and cap.pending_begin is not None:
-            blk, ctl = cap.pending_begin
-            cap.pending_begin = ()  # consumed
-            check(lib.ssac_gather_transition_begin(
-                src.data_ptr(), st.s1_stack[key].data_ptr(), 1 if src.dtype == torch.uint8 else 0, S,
-                st.action_stack.data_ptr(), A, st.reward_stack.data_ptr(), st.done_stack.data_ptr(), B,
-                xsa.data_ptr(), S + A, x1sa.data_ptr(), S + A, r.data_ptr(), d.data_ptr(), cap.feed,
-                blk.data_ptr(), LOG_WIDTH, ctl, engine.stream()))
-        else:
-            check(lib.ssac_gather_transition(src.data_ptr(), st.s1_stack[key].data_ptr(),
-                                             1 if src.dtype == torch.uint8 else 0, S,
-                                             st.action_stack.data_ptr(), A, st.reward_stack.data_ptr(),
-                                             st.done_stack.data_ptr(), idx.data_ptr(), B, xsa.data_ptr(),
-                                             S + A, x1sa.data_ptr(), S + A, r.data_ptr(), d.data_ptr(),
-                                             engine.stream()))
+        begin = None
+        if cap is not None and cap.pending_begin:
+            begin, cap.pending_begin = cap.pending_begin, ()  # this gather also does ssac_begin_update's work
+        bt.xsa, bt.x1sa, bt.r, bt.d = xsa, x1sa, r, d
+        bt.pending = dict(s=src.data_ptr(), s1=st.s1_stack[key].data_ptr(), act=st.action_stack.data_ptr(),
+                          rew=st.reward_stack.data_ptr(), done=st.done_stack.data_ptr(), idx=idx, S=S, A=A,
+                          begin=begin, feed=cap.feed if begin is not None else 0,
+                          dtype=1 if src.dtype == torch.uint8 else 0)
+        if not (_defer_gather and FOLD_GATHER and src.dtype == torch.float32):
+            ensure_gathered(bt)
         o, o1, a = {key: xsa[:, :S]}, {key: x1sa[:, :S]}, xsa[:, S:]
         bt.S, bt.xsa, bt.x1sa, bt.key, bt.pixel = S, xsa, x1sa, key, False
         assert augmenter.is_identity(), "image augmentations need image observations"
@@ -332,6 +366,8 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
     S = s1_rep.shape[1]
     a_arena = engine.bind_arena(actor, "self", [actor], dev)
     fuse_sample = kind == "stochastic" and a_arena.fused and random_process is None
+    if not (fuse_sample and _co_forward is not None):
+        ensure_gathered(replay_dict.get("_ssac"))  # (a deferred replay gather rides in the merged launch only)
     if not fuse_sample:
         _, _, aout = engine.mlp_forward(a_arena, s1_rep, _row_stride(s1_rep), 0, B, ws, f"td.a{i}",
                                         save=False)
@@ -424,17 +460,25 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
 def _actor_sample(a_arena, s1_rep, B, eps_ptr, actor, x1, S, A, logp, rng_ptr, st, co_forward, replay_dict):
     """actor forward + tanh-normal sample + log pi in ONE launch (a' lands in the [s'|a'] buffer), optionally with
     the online critics' forward as extra workgroups of the same launch."""
+    bt = replay_dict.get("_ssac")
     if co_forward is not None:
         c_arena, X, ldx, h1, h2, q = co_forward
+        gth = None
+        if (bt is not None and bt.pending is not None and x1.data_ptr() == bt.x1sa.data_ptr()
+                and X.data_ptr() == bt.xsa.data_ptr()):
+            gth = gather_struct(bt)  # the workgroups fetch their rows from the replay arrays themselves
+        else:
+            ensure_gathered(bt)
         with engine._timed("dual_fwd") as tm:
             for _ in range(tm.reps):  # 1, except under bench.py's live kernel timing (the launch is idempotent)
                 check(lib.ssac_actor_sample_critic_fwd(
                     C.byref(a_arena.desc()), s1_rep.data_ptr(), _row_stride(s1_rep), B, eps_ptr,
                     float(actor.log_std_low), float(actor.log_std_high), x1.data_ptr(), S + A, S, logp.data_ptr(),
                     rng_ptr, C.byref(c_arena.desc()), X.data_ptr(), ldx, h1.data_ptr(), h2.data_ptr(),
-                    q.data_ptr(), st))
+                    q.data_ptr(), C.byref(gth) if gth is not None else 0, st))
         replay_dict["_co_fwd"] = True
         return
+    ensure_gathered(bt)
     check(lib.ssac_actor_sample_fused(C.byref(a_arena.desc()), s1_rep.data_ptr(), _row_stride(s1_rep), B, eps_ptr,
                                       float(actor.log_std_low), float(actor.log_std_high), x1.data_ptr(), S + A, S,
                                       logp.data_ptr(), 0, 0, 0, rng_ptr, st))

@@ -910,9 +910,37 @@ def test_merged_actor_and_critic_forward_launch_equals_the_two_launches(ssa, B, 
     g1, g2, gq = torch.zeros_like(h1), torch.zeros_like(h2), torch.zeros_like(q)
     ssa._lib.check(lib.ssac_actor_sample_critic_fwd(
         C.byref(aa.desc()), xb.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0, xb.data_ptr(), S + A, S, lpb.data_ptr(),
-        0, C.byref(ca.desc()), xc.data_ptr(), S + A, g1.data_ptr(), g2.data_ptr(), gq.data_ptr(), st))
+        0, C.byref(ca.desc()), xc.data_ptr(), S + A, g1.data_ptr(), g2.data_ptr(), gq.data_ptr(), 0, st))
     for a_, b_, what in ((xa, xb, "a'"), (lpa, lpb, "log pi"), (h1, g1, "h1"), (h2, g2, "h2"), (q, gq, "q")):
         assert torch.equal(a_, b_), f"merged launch differs in {what}"
+    # ... and with the replay gather folded in (ssac_gather): the workgroups fetch their rows from the replay arrays
+    # through the index vector and write [s|a], [s'|.], r, d out for the later launches
+    R = 3 * B + 5
+    rs = torch.from_numpy(rng.standard_normal((R, S)).astype(np.float32)).to(DEV)
+    rs1 = torch.from_numpy(rng.standard_normal((R, S)).astype(np.float32)).to(DEV)
+    ra = torch.from_numpy(rng.uniform(-1, 1, (R, A)).astype(np.float32)).to(DEV)
+    rr = torch.from_numpy(rng.standard_normal(R).astype(np.float32)).to(DEV)
+    rdn = torch.from_numpy((rng.uniform(size=R) < 0.3).astype(np.uint8)).to(DEV)
+    idx = torch.from_numpy(rng.randint(0, R, B).astype(np.int64)).to(DEV)
+    xsa = torch.cat([rs[idx], ra[idx]], 1).contiguous()
+    x1_ref = torch.cat([rs1[idx], torch.zeros(B, A, device=DEV)], 1).contiguous()
+    lpr = torch.zeros(B, device=DEV)
+    ssa._lib.check(lib.ssac_actor_sample_fused(C.byref(aa.desc()), x1_ref.data_ptr(), S + A, B, eps.data_ptr(), -5.0,
+                                               2.0, x1_ref.data_ptr(), S + A, S, lpr.data_ptr(), 0, 0, 0, 0, st))
+    r1, r2, rq = ssa.engine.mlp_forward(ca, xsa, S + A, 0, B, ws, "sep2")
+    oxsa, ox1 = torch.full((B, S + A), 7.0, device=DEV), torch.zeros(B, S + A, device=DEV)
+    orew, odone, lpg = torch.zeros(B, device=DEV), torch.zeros(B, device=DEV), torch.zeros(B, device=DEV)
+    k1, k2, kq = torch.zeros_like(h1), torch.zeros_like(h2), torch.zeros_like(q)
+    gt = ssa._lib.Gather(rs.data_ptr(), rs1.data_ptr(), ra.data_ptr(), rr.data_ptr(), rdn.data_ptr(), S, A,
+                         idx.data_ptr(), 0, oxsa.data_ptr(), S + A, ox1.data_ptr(), S + A, orew.data_ptr(),
+                         odone.data_ptr(), 0, 0, -1, 0)
+    ssa._lib.check(lib.ssac_actor_sample_critic_fwd(
+        C.byref(aa.desc()), 0, 0, B, eps.data_ptr(), -5.0, 2.0, ox1.data_ptr(), S + A, S, lpg.data_ptr(), 0,
+        C.byref(ca.desc()), 0, 0, k1.data_ptr(), k2.data_ptr(), kq.data_ptr(), C.byref(gt), st))
+    for a_, b_, what in ((oxsa, xsa, "[s|a]"), (ox1, x1_ref, "[s'|a']"), (orew, rr[idx], "r"),
+                         (odone, rdn[idx].float(), "d"), (lpg, lpr, "log pi"), (k1, r1, "h1"), (k2, r2, "h2"),
+                         (kq, rq, "q")):
+        assert torch.equal(a_, b_), f"merged launch with folded gather differs in {what}"
 
 
 @pytest.mark.parametrize("B,H,N", [(512, 256, 10), (70, 64, 2)])

@@ -41,7 +41,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 # HBM bytes per launch from the PMC passes in profiles/r1_pmc_counters.md (FETCH_SIZE doubled per the guide's gfx950
 # note for 16-byte streaming reads + WRITE_SIZE, KiB -> bytes); not collected live, N=10 single-GPU shape only
 TRAFFIC_FUSED_CRITIC_BYTES = (2 * 13165 + 20527) * 1024
-TRAFFIC_DUAL_BYTES = (2 * 12812 + 10288) * 1024  # merged actor + ensemble-Q forward launch (gpurun_out/pmc3_*)
+TRAFFIC_DUAL_BYTES = (2 * 13067 + 10403) * 1024  # merged actor + ensemble-Q forward launch (profiles/r1_final_kernel_stats.md)
 TRAFFIC_FWD_BYTES = None  # the two-launch form (SSAC_SPLIT_FORWARD=1) has no PMC pass yet
 
 
@@ -222,7 +222,8 @@ def main():
         ms = by_tag["dual_fwd"]
         flops, kname = f_fwd + f_actor, (
             "fused_dual_kernel: ensemble-Q forward (fc1+fc2+head, h1/h2/q saved) of all local critics as 32-row "
-            "workgroups + the actor forward with tanh-normal sample as 16-row workgroups, ONE launch per update")
+            "workgroups + the actor forward with tanh-normal sample as 16-row workgroups, each workgroup gathering its own "
+            "replay rows, ONE launch per update")
     elif "critic_fwd" in by_tag:
         ms = by_tag["critic_fwd"]
         flops, kname = f_fwd, ("fused_mlp_kernel<plain>: ensemble-Q forward (fc1+fc2+head) of all local critics, "

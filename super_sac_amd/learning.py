@@ -89,10 +89,14 @@ FOLD_LOSS = os.environ.get("SSAC_FOLD_LOSS", "1") == "1"  # rank-1 backward: dL/
 DUAL_LAUNCH = os.environ.get("SSAC_DUAL_LAUNCH", "1") == "1"  # critic forward inside the actor-sample launch
 
 
+DUAL_MAX_WG = int(os.environ.get("SSAC_DUAL_MAX_WG", "320"))
+
+
 def _dual_fits(arena, n_rows):
-    """worth merging while the actor's tiles (16 rows) and the critic forward's (32 rows at this size) can all be
-    resident at once, one workgroup per CU; beyond that the actor would queue behind critic tiles"""
-    return (n_rows + 15) // 16 + arena.n_nets * ((n_rows + 31) // 32) <= 256
+    """worth merging while the actor's tiles (16 rows) and the critic forward's (32 rows at this size) are about one
+    round of workgroups (one per CU; a few more still pay for themselves because the merged path also carries the
+    replay gather, the rank-1 backward and the folded loss gradient: Humanoid N 16 at B 512 = 288 workgroups, +4 %)"""
+    return (n_rows + 15) // 16 + arena.n_nets * ((n_rows + 31) // 32) <= DUAL_MAX_WG
 
 
 def _split_forward(n_nets, n_rows):

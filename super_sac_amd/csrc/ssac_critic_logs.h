@@ -19,14 +19,40 @@ __device__ __forceinline__ void critic_logs_body(const CriticLogsArgs &a, float 
     const int tid = threadIdx.x;
     const bool act = tid < 256;
     const int n_rows = a.n_rows;
+    // every global load of the workgroup is issued up front (one round trip instead of one per phase): the loss
+    // partials, the gradient-norm partials, the ring slot, and -- below -- the TD targets, kept in registers for the
+    // variance pass (4 per thread cover 1024 rows; longer batches re-read the rest)
+    float sl = 0.f, se = 0.f, ss = 0.f;
+    const int tot = a.n_nets * a.tiles;
+    int slot = 0, w = 0;
+    if (a.feed) { slot = (int)a.feed->dst[a.feed->log_slot_word]; w = a.feed->log_width; }
+    if (act) {
+        for (int i = tid; i < tot; i += 256) {
+            sl += a.partials[2 * i];
+            if (i / a.tiles == a.n_nets - 1) se += a.partials[2 * i + 1];
+        }
+        for (int i = tid; i < a.n_ss; i += 256) ss += a.sumsq[i];
+    }
     if (a.tds.q_t && a.td_logs) {  // statistics of the targets the critic launch computed (td_target_kernel's logs)
         float s_td = 0.f, s_b = 0.f;
         const float alpha = a.tds.use_entropy ? expf(a.tds.log_alpha[0]) : 0.0f;
-        if (act)
-            for (int b = tid; b < n_rows; b += 256) {
+        float tv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (act) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = tid + 256 * u;
+                if (b < n_rows) tv[u] = a.tds.td_out[b];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // (same per-thread order as a 256-stride loop)
+                const int b = tid + 256 * u;
+                if (b < n_rows) { s_td += tv[u]; s_b += a.tds.use_entropy ? alpha * a.tds.logp[b] : 0.0f; }
+            }
+            for (int b = tid + 1024; b < n_rows; b += 256) {
                 s_td += a.tds.td_out[b];
                 s_b += a.tds.use_entropy ? alpha * a.tds.logp[b] : 0.0f;
             }
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { s_td += __shfl_xor(s_td, o, 64); s_b += __shfl_xor(s_b, o, 64); }
         if (act && (tid & 63) == 0) { red[tid >> 6] = s_td; red[4 + (tid >> 6)] = s_b; }
@@ -35,11 +61,17 @@ __device__ __forceinline__ void critic_logs_body(const CriticLogsArgs &a, float 
         const float mb = (red[4] + red[5] + red[6] + red[7]) / (float)n_rows;
         __syncthreads();
         float sv = 0.f;
-        if (act)
-            for (int b = tid; b < n_rows; b += 256) {
+        if (act) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = tid + 256 * u;
+                if (b < n_rows) { const float dlt = tv[u] - mean; sv += dlt * dlt; }
+            }
+            for (int b = tid + 1024; b < n_rows; b += 256) {
                 const float dlt = a.tds.td_out[b] - mean;
                 sv += dlt * dlt;
             }
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
         if (act && (tid & 63) == 0) red[8 + (tid >> 6)] = sv;
@@ -51,15 +83,6 @@ __device__ __forceinline__ void critic_logs_body(const CriticLogsArgs &a, float 
             a.td_logs[2] = mb;
         }
         __syncthreads();
-    }
-    float sl = 0.f, se = 0.f, ss = 0.f;
-    const int tot = a.n_nets * a.tiles;
-    if (act) {
-        for (int i = tid; i < tot; i += 256) {
-            sl += a.partials[2 * i];
-            if (i / a.tiles == a.n_nets - 1) se += a.partials[2 * i + 1];
-        }
-        for (int i = tid; i < a.n_ss; i += 256) ss += a.sumsq[i];
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -79,8 +102,6 @@ __device__ __forceinline__ void critic_logs_body(const CriticLogsArgs &a, float 
     }
     if (a.feed) {  // last launch of a captured update: publish the log block, advance the input ring
         __syncthreads();
-        const int slot = (int)a.feed->dst[a.feed->log_slot_word];
-        const int w = a.feed->log_width;
         if (tid < w) a.feed->log_ring[(int64_t)slot * w + tid] = a.logs[tid];
         __syncthreads();
         if (tid == 0) a.feed->tick += 1;

@@ -699,6 +699,24 @@ __global__ void polyak_kernel(float *__restrict__ t, const float *__restrict__ s
         t[i] = t[i] * (1.0f - tau) + s[i] * tau;
 }
 
+// 16-byte-aligned arenas (the packed MLP arenas are): 4 elements per lane, two independent quads in flight
+__global__ __launch_bounds__(256) void polyak4_kernel(float4 *__restrict__ t, const float4 *__restrict__ s,
+                                                       int64_t n4, float tau) {
+    const float k = 1.0f - tau;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        const float4 a0 = t[i], b0 = s[i], a1 = t[i + stride], b1 = s[i + stride];
+        t[i] = make_float4(a0.x * k + b0.x * tau, a0.y * k + b0.y * tau, a0.z * k + b0.z * tau, a0.w * k + b0.w * tau);
+        t[i + stride] = make_float4(a1.x * k + b1.x * tau, a1.y * k + b1.y * tau, a1.z * k + b1.z * tau,
+                                    a1.w * k + b1.w * tau);
+    }
+    if (i < n4) {
+        const float4 a0 = t[i], b0 = s[i];
+        t[i] = make_float4(a0.x * k + b0.x * tau, a0.y * k + b0.y * tau, a0.z * k + b0.z * tau, a0.w * k + b0.w * tau);
+    }
+}
+
 __global__ void zero_kernel(float *p, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x)
@@ -1082,7 +1100,14 @@ extern "C" int ssac_adam_step(float *params, float *adam_m, float *adam_v, const
 
 extern "C" int ssac_polyak(float *target, const float *source, int64_t n, float tau, void *stream) {
     if (n <= 0) return 0;
-    SSAC_LAUNCH(polyak_kernel, dim3(grid_for(n)), dim3(256), 0, ST, target, source, n, tau);
+    if ((n & 3) == 0 && (((uintptr_t)target | (uintptr_t)source) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        const int grid = (int)((n4 + 511) / 512 < 1024 ? (n4 + 511) / 512 : 1024);  // two quads per thread per trip
+        SSAC_LAUNCH(polyak4_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, ST, (float4 *)target,
+                    (const float4 *)source, n4, tau);
+    } else {
+        SSAC_LAUNCH(polyak_kernel, dim3(grid_for(n)), dim3(256), 0, ST, target, source, n, tau);
+    }
     return ssac_check_launch("polyak");
 }
 

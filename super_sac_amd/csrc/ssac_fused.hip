@@ -348,9 +348,9 @@ __device__ __forceinline__ void gemm_tile(typename Tile<TMR>::Acc &acc, Stage &s
 // W3 (OUT x H, rows contiguous) -> LDS rows of stride ldw3.  Four independent loads are issued before the
 // first LDS store, so the copy costs one global round trip instead of one per head row.
 __device__ __forceinline__ void stage_head_weights(float *w3s, const float *__restrict__ W3, int OUT, int H,
-                                                   int ldw3, int tid) {
+                                                   int ldw3, int tid, int start = 0) {
     const int n3 = OUT * H;
-    for (int i0 = tid; i0 < n3; i0 += 4 * NTHR) {
+    for (int i0 = start + tid; i0 < n3; i0 += 4 * NTHR) {
         float v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -476,49 +476,92 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         st1.init(P + g.off[0], IN, H, tid);
         st1.load(0, IN);
         st2.init(P + g.off[2], H, H, tid);
-        // ---- small operands -> LDS (visible after the barrier below)
-        for (int i = tid; i < H; i += NTHR) { b1s[i] = P[g.off[1] + i]; b2s[i] = P[g.off[3] + i]; }
-        if (tid < OUT) b3s[tid] = P[g.off[5] + tid];
-        stage_head_weights(w3s, P + g.off[4], OUT, H, ldw3, tid);
+        // ---- Every global load of the prologue is issued before the first LDS store, so the prologue costs one
+        //      round trip (two with the replay gather: index, then row) instead of one per operand: biases, head
+        //      weights (first 4 per thread), the x tile's first 32 columns.  Wider inputs / heads loop afterwards.
+        constexpr int XR = TMR / 16;  // x-tile rows per thread: half-wave per row, 16 rows a pass
+        const int xk = tid & 31, xr0 = tid >> 5;
+        const int Sg = gidx ? (int)g.gth.s_elems : 0;
+        const bool actor_half = g.gth_role == 1;
+        int64_t gsrc[XR];
+        bool xrok[XR];
+#pragma unroll
+        for (int j = 0; j < XR; ++j) {
+            xrok[j] = (m0 + xr0 + 16 * j) < g.n_rows;
+            gsrc[j] = gidx ? gidx[xrok[j] ? m0 + xr0 + 16 * j : 0] : 0;
+        }
+        float bv = 0.0f;  // thread t < H: b1[t]; thread 256 + t: b2[t]   (H <= 256, 512 threads)
+        if (tid < H) bv = P[g.off[1] + tid];
+        else if (tid >= 256 && tid - 256 < H) bv = P[g.off[3] + tid - 256];
+        const float b3v = tid < OUT ? P[g.off[5] + tid] : 0.0f;
+        const float *W3 = P + g.off[4];
+        const int n3 = OUT * H;
+        float w3v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i3 = tid + u * NTHR;
+            w3v[u] = W3[i3 < n3 ? i3 : 0];
+        }
+        const float *xrow[XR];
+        float xv[XR];
+#pragma unroll
+        for (int j = 0; j < XR; ++j) {
+            const bool ok = xrok[j] && xk < IN;
+            if (gidx) {
+                const float *sr = (actor_half ? g.gth.s1 : g.gth.s) + gsrc[j] * Sg;
+                const float *ar = g.gth.act + gsrc[j] * g.gth.a_elems - Sg;
+                xrow[j] = sr;
+                xv[j] = (xk < Sg ? sr : ar)[ok ? xk : (xk < Sg ? 0 : Sg)];
+            } else {
+                xrow[j] = X + (xrok[j] ? (int64_t)(m0 + xr0 + 16 * j) * g.ldx : 0);
+                xv[j] = xrow[j][ok ? xk : 0];
+            }
+        }
+        // ---- ... and now the LDS stores (visible after the barrier below)
+        if (tid < H) b1s[tid] = bv;
+        else if (tid >= 256 && tid - 256 < H) b2s[tid - 256] = bv;
+        if (tid < OUT) b3s[tid] = b3v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i3 = tid + u * NTHR;
+            if (i3 < n3) {
+                const int o = i3 / H;
+                w3s[o * ldw3 + (i3 - o * H)] = w3v[u];
+            }
+        }
+        float *outp = gidx ? (actor_half ? g.gth.x1sa : (e == 0 ? g.gth.xsa : nullptr)) : nullptr;
+        const int64_t ldo_g = actor_half ? g.gth.ld_x1 : g.gth.ld_x;
+#pragma unroll
+        for (int j = 0; j < XR; ++j) {
+            const int r = xr0 + 16 * j;
+            const bool ok = xrok[j] && xk < IN;
+            xs[r * ldx_s + xk] = ok ? xv[j] : 0.0f;
+            if (ok && outp) outp[(int64_t)(m0 + r) * ldo_g + xk] = xv[j];
+            for (int k = xk + 32; k < KP; k += 32) {  // inputs wider than 32 columns
+                const bool okk = xrok[j] && k < IN;
+                float v;
+                if (gidx) {
+                    const float *ar = g.gth.act + gsrc[j] * g.gth.a_elems - Sg;
+                    v = (k < Sg ? xrow[j] : ar)[okk ? k : (k < Sg ? 0 : Sg)];
+                } else {
+                    v = xrow[j][okk ? k : 0];
+                }
+                xs[r * ldx_s + k] = okk ? v : 0.0f;
+                if (okk && outp) outp[(int64_t)(m0 + r) * ldo_g + k] = v;
+            }
+        }
+        if (gidx && actor_half && tid < TMR && (m0 + tid) < g.n_rows) {
+            const int64_t src = gidx[m0 + tid];
+            g.gth.rew_out[m0 + tid] = g.gth.rew[src];
+            g.gth.done_out[m0 + tid] = (float)g.gth.done[src];
+        }
+        if (n3 > 4 * NTHR) stage_head_weights(w3s, W3, OUT, H, ldw3, tid, 4 * NTHR);  // heads wider than 8 outputs
         if ((MODE == MODE_CRITIC) && tid < TMR) {
             const int b = m0 + tid;
             const bool ok = b < g.n_rows;
             rowin[tid] = ok ? td_of_row(g, b, e) : 0.0f;
             rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
             rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
-        }
-        // ---- x tile -> LDS, zero padded to KP columns and to TMR rows (half-wave per row, 32 columns a pass)
-        if (gidx) {
-            const int Sg = (int)g.gth.s_elems;
-            const bool actor_half = g.gth_role == 1;
-            float *outp = actor_half ? g.gth.x1sa : (e == 0 ? g.gth.xsa : nullptr);
-            const int64_t ldo_g = actor_half ? g.gth.ld_x1 : g.gth.ld_x;
-            for (int r = tid >> 5; r < TMR; r += NTHR / 32) {
-                const bool rok = (m0 + r) < g.n_rows;
-                const int64_t src = gidx[rok ? m0 + r : 0];
-                const float *sr = (actor_half ? g.gth.s1 : g.gth.s) + src * Sg;
-                const float *ar = g.gth.act + src * g.gth.a_elems - Sg;
-                for (int k = tid & 31; k < KP; k += 32) {
-                    const bool ok = rok && k < IN;
-                    const float v = (k < Sg ? sr : ar)[ok ? k : (k < Sg ? 0 : Sg)];
-                    xs[r * ldx_s + k] = ok ? v : 0.0f;
-                    if (ok && outp) outp[(int64_t)(m0 + r) * ldo_g + k] = v;
-                }
-            }
-            if (actor_half && tid < TMR && (m0 + tid) < g.n_rows) {
-                const int64_t src = gidx[m0 + tid];
-                g.gth.rew_out[m0 + tid] = g.gth.rew[src];
-                g.gth.done_out[m0 + tid] = (float)g.gth.done[src];
-            }
-        } else
-        for (int r = tid >> 5; r < TMR; r += NTHR / 32) {
-            const bool rok = (m0 + r) < g.n_rows;
-            const float *xr = X + (rok ? (int64_t)(m0 + r) * g.ldx : 0);
-            for (int k = tid & 31; k < KP; k += 32) {
-                const bool ok = rok && k < IN;
-                const float v = xr[ok ? k : 0];
-                xs[r * ldx_s + k] = ok ? v : 0.0f;
-            }
         }
         stage_first(st1, Ws, IN, tid);
         __syncthreads();

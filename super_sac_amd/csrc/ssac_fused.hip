@@ -444,6 +444,20 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         // ---- h1, h2, q tiles of an earlier forward launch -> LDS; W2's first chunk in flight meanwhile
         st3.init(P + g.off[2], H, H, tid);
         st3.load(0, H);
+        // all loads of the two activation tiles before anything is stored: one round trip for the prologue
+        const int c = (tid & 63) * 4;  // one wave per row pass, 16 bytes per lane
+        constexpr int RP = TMR / (NTHR / 64);
+        f4 a1[RP], a2[RP];
+        if (c < H) {
+#pragma unroll
+            for (int j = 0; j < RP; ++j) {
+                const int r = (tid >> 6) + j * (NTHR / 64);
+                const bool ok = (m0 + r) < g.n_rows;
+                const int64_t src = ((int64_t)e * g.n_rows + (ok ? m0 + r : 0)) * H + c;
+                a1[j] = *reinterpret_cast<const f4u *>(g.H1 + src);
+                a2[j] = *reinterpret_cast<const f4u *>(g.H2 + src);
+            }
+        }
         stage_head_weights(w3s, P + g.off[4], OUT, H, ldw3, tid);
         if (tid < TMR) {
             const int b = m0 + tid;
@@ -454,16 +468,14 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
             }
             rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
         }
-        const int c = (tid & 63) * 4;  // one wave per row pass, 16 bytes per lane
         if (c < H) {
-            for (int r = tid >> 6; r < TMR; r += NTHR / 64) {
+#pragma unroll
+            for (int j = 0; j < RP; ++j) {
+                const int r = (tid >> 6) + j * (NTHR / 64);
                 const bool ok = (m0 + r) < g.n_rows;
-                const int64_t src = ((int64_t)e * g.n_rows + (ok ? m0 + r : 0)) * H + c;
                 const f4 z = {0.f, 0.f, 0.f, 0.f};
-                const f4 a1 = *reinterpret_cast<const f4u *>(g.H1 + src);
-                const f4 a2 = *reinterpret_cast<const f4u *>(g.H2 + src);
-                *reinterpret_cast<f4 *>(h1s + r * ldh + c) = ok ? a1 : z;
-                *reinterpret_cast<f4 *>(h2s + r * ldh + c) = ok ? a2 : z;
+                *reinterpret_cast<f4 *>(h1s + r * ldh + c) = ok ? a1[j] : z;
+                *reinterpret_cast<f4 *>(h2s + r * ldh + c) = ok ? a2[j] : z;
             }
         }
         if (!UNSCALED)

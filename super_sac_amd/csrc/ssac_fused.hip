@@ -215,7 +215,10 @@ template <> struct Tile<32> {
 #pragma unroll
         for (int t8 = 0; t8 < 8; ++t8) {
             const int t = half * 8 + t8;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t >> 2][t & 3], NN ? f.bs[t] : f.b[t >> 2][t & 3],
+            // the WEIGHT fragment is the MFMA's A operand and the activation fragment its B operand: the
+            // accumulator is then the transposed tile D[n][row], i.e. a lane holds 4 CONSECUTIVE output columns of
+            // ONE row per register quad, and the epilogues store 16 bytes at a time (LDS and global) instead of 4
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(NN ? f.bs[t] : f.b[t >> 2][t & 3], f.a[t >> 2][t & 3],
                                                       acc, 0, 0, 0);
         }
     }
@@ -224,7 +227,15 @@ template <> struct Tile<32> {
     static __device__ __forceinline__ void foreach(const Acc &acc, int lane, F fn) {
         const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) fn((r & 3) + 8 * (r >> 2) + 4 * lh, li, acc[r]);
+        for (int r = 0; r < 16; ++r) fn(li, (r & 3) + 8 * (r >> 2) + 4 * lh, acc[r]);
+    }
+    // f(row, first of 4 consecutive columns within the wave's 32, the 4 values)
+    template <class F>
+    static __device__ __forceinline__ void foreach4(const Acc &acc, int lane, F fn) {
+        const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            fn(li, 8 * q + 4 * lh, (f4){acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]});
     }
 };
 
@@ -262,9 +273,8 @@ template <> struct Tile<16> {
             const int t = half * 4 + t4;
 #pragma unroll
             for (int u = 0; u < 2; ++u)
-                acc.v[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[t >> 2][t & 3],
-                                                                NN ? f.bs[u][t] : f.b[u][t >> 2][t & 3],
-                                                                acc.v[u], 0, 0, 0);
+                acc.v[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(NN ? f.bs[u][t] : f.b[u][t >> 2][t & 3],
+                                                                f.a[t >> 2][t & 3], acc.v[u], 0, 0, 0);
         }
     }
     template <class F>
@@ -273,7 +283,13 @@ template <> struct Tile<16> {
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) fn(4 * lg + r, 16 * u + li, acc.v[u][r]);
+            for (int r = 0; r < 4; ++r) fn(li, 16 * u + 4 * lg + r, acc.v[u][r]);
+    }
+    template <class F>
+    static __device__ __forceinline__ void foreach4(const Acc &acc, int lane, F fn) {
+        const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) fn(li, 16 * u + 4 * lg, (f4){acc.v[u][0], acc.v[u][1], acc.v[u][2], acc.v[u][3]});
     }
 };
 
@@ -585,12 +601,16 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         BSTAMP(2);
         stage_first(st2, Ws, H, tid);
         if (MODE == MODE_CRITIC) st3.init(P + g.off[2], H, H, tid);
-        T::foreach(acc, lane, [&](int row, int cw, float val) {
-            const int col = col0 + cw;
+        T::foreach4(acc, lane, [&](int row, int cw, f4 val) {
+            const int col = col0 + cw;  // 4 consecutive columns (H % 32 == 0: all four in range or none)
             if (col < H) {
-                const float v = fmaxf(val + b1s[col], 0.0f);
-                h1s[row * ldh + col] = v;
-                if (g.H1 && (m0 + row) < g.n_rows) g.H1[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
+                const f4 bq = *reinterpret_cast<const f4 *>(b1s + col);
+                f4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(val[i] + bq[i], 0.0f);
+                *reinterpret_cast<f4 *>(h1s + row * ldh + col) = v;
+                if (g.H1 && (m0 + row) < g.n_rows)
+                    *reinterpret_cast<f4 *>(g.H1 + ((int64_t)e * g.n_rows + m0 + row) * H + col) = v;
             }
         });
         __syncthreads();
@@ -601,12 +621,16 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         if (MODE == MODE_CRITIC) gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, st3, H);
         else gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, none, 0);
         BSTAMP(4);
-        T::foreach(acc, lane, [&](int row, int cw, float val) {
+        T::foreach4(acc, lane, [&](int row, int cw, f4 val) {
             const int col = col0 + cw;
             if (col < H) {
-                const float v = fmaxf(val + b2s[col], 0.0f);
-                h2s[row * ldh + col] = v;
-                if (g.H2 && (m0 + row) < g.n_rows) g.H2[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
+                const f4 bq = *reinterpret_cast<const f4 *>(b2s + col);
+                f4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = fmaxf(val[i] + bq[i], 0.0f);
+                *reinterpret_cast<f4 *>(h2s + row * ldh + col) = v;
+                if (g.H2 && (m0 + row) < g.n_rows)
+                    *reinterpret_cast<f4 *>(g.H2 + ((int64_t)e * g.n_rows + m0 + row) * H + col) = v;
             }
         });
         __syncthreads();
@@ -769,11 +793,14 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         T::zero(acc);
         gemm_tile<TMR, true, DBUF>(acc, st3, h2s, ldh, H, Ws, Ws1, tid, col0, none, 0);
         BSTAMP(10);
-        T::foreach(acc, lane, [&](int row, int cw, float val) {
+        T::foreach4(acc, lane, [&](int row, int cw, f4 val) {
             const int col = col0 + cw;
             if (col < H && (m0 + row) < g.n_rows) {
-                const float v = h1s[row * ldh + col] > 0.0f ? val : 0.0f;
-                g.DZ1[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
+                const f4 hq = *reinterpret_cast<const f4 *>(h1s + row * ldh + col);
+                f4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = hq[i] > 0.0f ? val[i] : 0.0f;
+                *reinterpret_cast<f4 *>(g.DZ1 + ((int64_t)e * g.n_rows + m0 + row) * H + col) = v;
             }
         });
         BSTAMP(11);
@@ -932,16 +959,15 @@ __device__ __forceinline__ void mfma_chunk(typename Tile<TMR>::Acc &acc, typenam
     if constexpr (TMR == 32) {
 #pragma unroll
         for (int t = 0; t < 16; ++t)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.a[t >> 2][t & 3], NN ? fb.bs[t] : fb.b[t >> 2][t & 3],
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(NN ? fb.bs[t] : fb.b[t >> 2][t & 3], fa.a[t >> 2][t & 3],
                                                       acc, 0, 0, 0);
     } else {
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
-                acc.v[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa.a[t >> 2][t & 3],
-                                                                NN ? fb.bs[u][t] : fb.b[u][t >> 2][t & 3],
-                                                                acc.v[u], 0, 0, 0);
+                acc.v[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(NN ? fb.bs[u][t] : fb.b[u][t >> 2][t & 3],
+                                                                fa.a[t >> 2][t & 3], acc.v[u], 0, 0, 0);
     }
 }
 

@@ -763,27 +763,38 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         BSTAMP(8);
         // ---- head backward: dz2 = (dq W3) (.) [h2 > 0], in place over h2s
         {
-            // thread -> column k = tid % 256, rows r = (tid >> 8), +2, ...  (H <= 256)
-            const int k = tid & 255;
+            // thread -> 4 consecutive columns k = 4 (tid % 64), rows r = (tid >> 6), +8, ...  (H <= 256): 16-byte LDS
+            // reads / writes and global stores.  gs accumulates over o in index order per element, as before.
+            const int k = (tid & 63) * 4;
             if (k < H) {
                 // all of this thread's h2 values are loaded before the first in-place store (the compiler cannot
                 // prove the stores do not alias the later loads, and would serialise the LDS round trips)
-                constexpr int NR = TMR / 2;
-                const int r0 = tid >> 8;
-                float hv[NR], gs[NR];
+                constexpr int NR = TMR / 8;
+                const int r0 = tid >> 6;
+                f4 hv[NR], gs[NR];
 #pragma unroll
-                for (int j = 0; j < NR; ++j) { hv[j] = h2s[(r0 + 2 * j) * ldh + k]; gs[j] = 0.0f; }
+                for (int j = 0; j < NR; ++j) {
+                    hv[j] = *reinterpret_cast<const f4 *>(h2s + (r0 + 8 * j) * ldh + k);
+                    gs[j] = (f4){0.f, 0.f, 0.f, 0.f};
+                }
                 for (int o = 0; o < OUT; ++o) {
-                    const float w = w3s[o * ldw3 + k];
+                    const f4 w = *reinterpret_cast<const f4 *>(w3s + o * ldw3 + k);
 #pragma unroll
-                    for (int j = 0; j < NR; ++j) gs[j] += dqs[(r0 + 2 * j) * ldo + o] * w;
+                    for (int j = 0; j < NR; ++j) {
+                        const float d = dqs[(r0 + 8 * j) * ldo + o];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) gs[j][i] += d * w[i];
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < NR; ++j) {
-                    const int r = r0 + 2 * j;
-                    const float dz = hv[j] > 0.0f ? gs[j] : 0.0f;
-                    h2s[r * ldh + k] = dz;
-                    if ((m0 + r) < g.n_rows) g.DZ2[((int64_t)e * g.n_rows + m0 + r) * H + k] = dz;
+                    const int r = r0 + 8 * j;
+                    f4 dz;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dz[i] = hv[j][i] > 0.0f ? gs[j][i] : 0.0f;
+                    *reinterpret_cast<f4 *>(h2s + r * ldh + k) = dz;
+                    if ((m0 + r) < g.n_rows)
+                        *reinterpret_cast<f4 *>(g.DZ2 + ((int64_t)e * g.n_rows + m0 + r) * H + k) = dz;
                 }
             }
         }

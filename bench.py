@@ -42,6 +42,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 # note for 16-byte streaming reads + WRITE_SIZE, KiB -> bytes); not collected live, N=10 single-GPU shape only
 TRAFFIC_FUSED_CRITIC_BYTES = (2 * 13165 + 20527) * 1024
 TRAFFIC_DUAL_BYTES = (2 * 13067 + 10403) * 1024  # merged actor + ensemble-Q forward launch (profiles/r1_final_kernel_stats.md)
+TRAFFIC_CHAIN_BYTES = None  # set from the PMC passes of the chained launch (profiles/)
 TRAFFIC_FWD_BYTES = None  # the two-launch form (SSAC_SPLIT_FORWARD=1) has no PMC pass yet
 
 
@@ -202,7 +203,7 @@ def main():
     # bracketed by HIP events recorded on the stream each one is launched on (same shapes, buffers, binary).
     graphs_were_on = ssa.learning.USE_GRAPHS
     ssa.learning.USE_GRAPHS = False
-    ssa.engine.PROFILE["tag"] = ("critic_fwd", "critic_bwd", "critic_fused", "dual_fwd", "dual_bwd")
+    ssa.engine.PROFILE["tag"] = ("critic_fwd", "critic_bwd", "critic_fused", "dual_fwd", "dual_bwd", "chain")
     ssa.engine.PROFILE["events"] = []
     ssa.engine.PROFILE["reps"] = 8   # the bracketed (idempotent) launch is issued 8x per event pair
     for _ in range(min(args.steps, 300)):
@@ -218,7 +219,15 @@ def main():
     f_fwd = 2.0 * BATCH * n_local * (IN * HID + HID * HID + HID)
     f_bwd = 2.0 * BATCH * n_local * (HID + HID * HID)
     f_actor = 2.0 * BATCH * (OBS * HID + HID * HID + HID * 2 * ACT)
-    if "dual_fwd" in by_tag:
+    f_tgt_ = 2.0 * BATCH * NSUB * (IN * HID + HID * HID + HID)
+    if "chain" in by_tag:
+        ms = by_tag["chain"]
+        flops, kname = f_fwd + f_bwd + f_tgt_ + NSUB * f_actor, (
+            "fused_chain_kernel: ensemble-Q forward (fc1+fc2+head, h1/h2/q saved) AND the TD-independent half of the "
+            "backward pass (head backward + fc2 backward-data) of all local critics as 32-row workgroups, beside the "
+            "target chains (actor forward + tanh-normal sample -> target critic, per REDQ subset slot) as 16-row "
+            "workgroups; every workgroup gathers its own replay rows; ONE launch per update")
+    elif "dual_fwd" in by_tag:
         ms = by_tag["dual_fwd"]
         flops, kname = f_fwd + f_actor, (
             "fused_dual_kernel: ensemble-Q forward (fc1+fc2+head, h1/h2/q saved) of all local critics as 32-row "
@@ -242,7 +251,7 @@ def main():
                           "in an eager pass right after the timed (replayed) region",
                 "flops_per_launch": flops,
                 "traffic": (None if not (world == 1 and n_local == NCRIT) else
-                            (TRAFFIC_DUAL_BYTES if "dual_fwd" in by_tag else
+                            (TRAFFIC_CHAIN_BYTES if "chain" in by_tag else TRAFFIC_DUAL_BYTES if "dual_fwd" in by_tag else
                              (TRAFFIC_FWD_BYTES if "critic_fwd" in by_tag else TRAFFIC_FUSED_CRITIC_BYTES)))}
     if "dual_bwd" in by_tag:
         mb = by_tag["dual_bwd"]

@@ -105,6 +105,9 @@ typedef struct ssac_gather {
     float *logs; int32_t n_logs;   /* with feed: log block to clear */
     int32_t rng_word;              /* with feed: 4-byte word offset of the int64 noise draw number in the slot, -1 = none */
     ssac_adam_ctl *ctl;            /* with feed: optimizer control block to advance (may be NULL) */
+    int32_t ids_word, _pad;        /* with feed (ssac_chain_update): word offset of the int32 REDQ subset ids in the slot
+                                      (the target critics run in the launch that mirrors the slot: they read the ids
+                                      from the slot itself), -1 = use net_ids */
 } ssac_gather;
 
 /* TD target evaluated INSIDE the critic launch instead of by ssac_td_target (continuous actions, no PopArt):
@@ -458,6 +461,18 @@ int ssac_actor_sample_critic_fwd(const ssac_mlp *actor, const float *Xa, int64_t
                                  int64_t act_col0, float *logp, const ssac_rng *rng, const ssac_mlp *critics,
                                  const float *Xc, int64_t ldxc, float *H1, float *H2, float *Q,
                                  const ssac_gather *gather /* NULL: inputs are Xa / Xc */, void *stream);
+
+/* Everything of a critic update that does not need the TD target, as ONE launch (continuous actions, single-output
+ * critics): per REDQ subset slot j and 16-row tile a TARGET CHAIN workgroup -- actor forward on s' + tanh-normal sample
+ * (a' -> x1sa[:, act_col0:], log pi -> logp; every slot recomputes the actor for its rows) and then target critic
+ * net_ids[j] on [s'|a'] (-> Qt, n_sel x n_rows) -- beside the online critics' forward AND the TD-independent half of
+ * their backward pass in the same workgroup (H1 / H2 / Q saved, DZ2u / DZ1u as ssac_target_fwd_critic_bwdu writes
+ * them).  Replaces ssac_actor_sample_critic_fwd + ssac_target_fwd_critic_bwdu; `gather` as there. */
+int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t ldxa, int n_rows, const float *eps,
+                      float log_std_lo, float log_std_hi, float *x1sa, int64_t ld_x1, int64_t act_col0, float *logp,
+                      const ssac_rng *rng, const ssac_mlp *targets, const int32_t *net_ids, int n_sel, float *Qt,
+                      const ssac_mlp *critics, const float *Xc, int64_t ldxc, float *H1, float *H2, float *Q,
+                      float *DZ2u, float *DZ1u, const ssac_gather *gather, void *stream);
 
 /* critic forward of ALL nets + loss gradient + backward-data in ONE launch (learning.py:83-98,112,121):
  * writes H1, H2, Q (n_nets x n_rows x out), DQ, DZ2 = dL/d(pre-activation of fc2), DZ1, and per-(net,

@@ -57,7 +57,7 @@ class Gather(C.Structure):
                 ("s_elems", C.c_int64), ("a_elems", C.c_int64), ("idx", C.c_void_p), ("feed", C.c_void_p),
                 ("xsa", C.c_void_p), ("ld_x", C.c_int64), ("x1sa", C.c_void_p), ("ld_x1", C.c_int64),
                 ("rew_out", C.c_void_p), ("done_out", C.c_void_p), ("logs", C.c_void_p), ("n_logs", C.c_int32),
-                ("rng_word", C.c_int32), ("ctl", C.c_void_p)]
+                ("rng_word", C.c_int32), ("ctl", C.c_void_p), ("ids_word", C.c_int32), ("_pad", C.c_int32)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -148,6 +148,8 @@ SIGNATURES = {
     "ssac_mlp3_fwd_fused": [_MP, _P, _I, _P, _L, _L, _I, _P, _P, _P, _P],
     "ssac_actor_sample_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _P, _P, _P, _P],
     "ssac_actor_sample_critic_fwd": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _L, _P, _P, _P, _P, _P],
+    "ssac_chain_update": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _I, _P, _MP, _P, _L, _P, _P, _P, _P, _P,
+                          _P, _P],
     "ssac_philox_normal": [_P, _I, _I, _P, _P],
     "ssac_critic_fwd_bwd_fused": [_MP, _P, _L, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ssac_critic_bwd_fused": [_MP, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -51,7 +51,8 @@ constexpr int HEAD_MAX = 64;  // widest head the fused kernels take (several pas
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 constexpr float LOG_2 = 0.69314718055994530942f;
 
-enum { MODE_PLAIN = 0, MODE_SAMPLE = 1, MODE_CRITIC = 2, MODE_CRITIC_BWD = 3, MODE_CRITIC_BWDU = 4 };
+enum { MODE_PLAIN = 0, MODE_SAMPLE = 1, MODE_CRITIC = 2, MODE_CRITIC_BWD = 3, MODE_CRITIC_BWDU = 4,
+       MODE_CRITIC_U = 5 /* forward + the TD-independent (unscaled) backward, activations never leave LDS */ };
 
 struct FusedArgs {
     const float *params; int64_t net_stride; int in_dim, hidden, out_dim;
@@ -67,7 +68,8 @@ struct FusedArgs {
     const float *td, *weight, *act; int64_t ld_a; const ssac_popart *popart; int pop; float denom;
     float *DQ, *DZ2, *DZ1; float *partials;  // partials[(e*tiles + tile)*2 + {loss, err}]
     int xcd;                     // workgroups take their tile in XCD-contiguous order (ssac_internal.h)
-    ssac_gather gth; int gth_role;  // 1: actor half (s' rows, begin duties), 2: critic half ([s|a] rows); 0: input is X
+    ssac_gather gth; int gth_role;  // 1: actor half (s' rows, begin duties), 3: actor half without the begin duties,
+                                    // 2: critic half ([s|a] rows), 4: rows from X, net ids from the input slot; 0: X
     long long *dbg;  // optional phase timestamps (s_memtime) of workgroup (0,0), thread 0
     ssac_td_spec tds;  // tds.q_t != null: the TD target is computed here instead of read from `td`
 };
@@ -415,7 +417,27 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = bx * TMR;
-    const int net = g.ids ? g.ids[e] : e;
+    // replay gather folded into this launch (ssac_gather): where this tile's rows come from
+    const int64_t *gidx = nullptr;
+    const uint32_t *gslot = nullptr;
+    const int32_t *idsp = g.ids;
+    if (g.gth_role) {
+        gidx = g.gth.idx;
+        if (g.gth.feed) {
+            const ssac_feed f = *g.gth.feed;
+            gslot = feed_slot(f);
+            gidx = reinterpret_cast<const int64_t *>(gslot);
+            if (g.gth_role == 1 && bx == 0) {  // start-of-update duties (ssac_begin_update)
+                feed_pull(f);
+                if (tid < g.gth.n_logs) g.gth.logs[tid] = 0.0f;
+                if (tid == 0 && g.gth.ctl) adam_refresh(g.gth.ctl, g.gth.ctl->step + 1);
+            }
+            // role 4: the subset ids of a target-critic pass that runs in the launch that mirrors the slot
+            if (g.gth_role == 4 && g.gth.ids_word >= 0) idsp = reinterpret_cast<const int32_t *>(gslot + g.gth.ids_word);
+        }
+        if (g.gth_role == 4) gidx = nullptr;  // (its rows are read from X)
+    }
+    const int net = idsp ? idsp[e] : e;
     if (net < 0) {
         // slot without a net (a REDQ subset member another rank owns): its outputs are +inf, the neutral
         // element of the min that follows, so a sharded launch sequence is the same for every subset draw
@@ -429,31 +451,16 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     const float *P = g.params + (int64_t)net * g.net_stride;
     const float *X = g.X + (int64_t)e * g.sX;
     const int col0 = wave * 32;
-    // replay gather folded into this launch (ssac_gather): where this tile's rows come from
-    const int64_t *gidx = nullptr;
-    const uint32_t *gslot = nullptr;
-    if (g.gth_role) {
-        gidx = g.gth.idx;
-        if (g.gth.feed) {
-            const ssac_feed f = *g.gth.feed;
-            gslot = feed_slot(f);
-            gidx = reinterpret_cast<const int64_t *>(gslot);
-            if (g.gth_role == 1 && bx == 0) {  // start-of-update duties (ssac_begin_update)
-                feed_pull(f);
-                if (tid < g.gth.n_logs) g.gth.logs[tid] = 0.0f;
-                if (tid == 0 && g.gth.ctl) adam_refresh(g.gth.ctl, g.gth.ctl->step + 1);
-            }
-        }
-    }
 
     BSTAMP(0);
     const int ldw3 = H + APAD;
     KcStage st1, st2;
     RcStage st3;
     NoStage none;
-    constexpr bool UNSCALED = MODE == MODE_CRITIC_BWDU;
-    constexpr bool BWD_ONLY = MODE == MODE_CRITIC_BWD || UNSCALED;
-    constexpr bool IS_CRITIC = MODE == MODE_CRITIC || BWD_ONLY;
+    constexpr bool UNSCALED = MODE == MODE_CRITIC_BWDU || MODE == MODE_CRITIC_U;
+    constexpr bool BWD_ONLY = MODE == MODE_CRITIC_BWD || MODE == MODE_CRITIC_BWDU;
+    constexpr bool FWD_BWD = MODE == MODE_CRITIC || MODE == MODE_CRITIC_U;  // forward, then backward in the same workgroup
+    constexpr bool IS_CRITIC = FWD_BWD || BWD_ONLY;
     typename T::Acc acc;
     float *hpart = Ws;  // K-split partial head tiles [8][TMR][16] (staging buffer 0 is free after fc2)
     if (BWD_ONLY) {
@@ -510,7 +517,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         constexpr int XR = TMR / 16;  // x-tile rows per thread: half-wave per row, 16 rows a pass
         const int xk = tid & 31, xr0 = tid >> 5;
         const int Sg = gidx ? (int)g.gth.s_elems : 0;
-        const bool actor_half = g.gth_role == 1;
+        const bool actor_half = (g.gth_role & 1) != 0;  // roles 1 and 3 (3: no start-of-update duties)
         int64_t gsrc[XR];
         bool xrok[XR];
 #pragma unroll
@@ -584,11 +591,13 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
             g.gth.done_out[m0 + tid] = (float)g.gth.done[src];
         }
         if (n3 > 4 * NTHR) stage_head_weights(w3s, W3, OUT, H, ldw3, tid, 4 * NTHR);  // heads wider than 8 outputs
-        if ((MODE == MODE_CRITIC) && tid < TMR) {
+        if (FWD_BWD && tid < TMR) {
             const int b = m0 + tid;
             const bool ok = b < g.n_rows;
-            rowin[tid] = ok ? td_of_row(g, b, e) : 0.0f;
-            rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
+            if (!UNSCALED) {
+                rowin[tid] = ok ? td_of_row(g, b, e) : 0.0f;
+                rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
+            }
             rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
         }
         stage_first(st1, Ws, IN, tid);
@@ -600,7 +609,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         gemm_tile<TMR, false, DBUF>(acc, st1, xs, ldx_s, IN, Ws, Ws1, tid, col0, st2, H);
         BSTAMP(2);
         stage_first(st2, Ws, H, tid);
-        if (MODE == MODE_CRITIC) st3.init(P + g.off[2], H, H, tid);
+        if (FWD_BWD) st3.init(P + g.off[2], H, H, tid);
         T::foreach4(acc, lane, [&](int row, int cw, f4 val) {
             const int col = col0 + cw;  // 4 consecutive columns (H % 32 == 0: all four in range or none)
             if (col < H) {
@@ -618,7 +627,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         // ---- fc2 (the backward-data phase re-reads W2 as a row-contiguous image: its first chunk is
         //      requested during fc2's last K chunk)
         T::zero(acc);
-        if (MODE == MODE_CRITIC) gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, st3, H);
+        if (FWD_BWD) gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, st3, H);
         else gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, none, 0);
         BSTAMP(4);
         T::foreach4(acc, lane, [&](int row, int cw, f4 val) {
@@ -861,6 +870,33 @@ void fused_dual2_kernel(FusedArgs gt, FusedArgs gc, int tiles_t, int target_grid
     } else {
         const int L = bid - tiles_t;
         fused_mlp_body<MODE_CRITIC_BWDU, TC, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x);
+    }
+}
+
+// ONE launch for everything of a critic update that does not need the TD target (continuous actions):
+//   workgroups [0, tiles_t): the TARGET CHAIN of subset slot j on a 16-row tile -- actor forward on s' + tanh-normal
+//     sample (a' and log pi; every slot recomputes the actor for its rows: 75 MFLOP per slot, and no launch boundary
+//     between the actor and the target critics), then the target critic `ids[j]` on [s'|a'];
+//   the rest: the online critics' forward AND the TD-independent half of their backward in the same workgroup
+//     (MODE_CRITIC_U): h1 / h2 stay in LDS between the two, instead of being written out and read back by a
+//     second launch.
+// The replay gather and the start-of-update duties ride along as in fused_dual_kernel (actor part of slot 0).
+template <int TC>
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs gc, int tiles_t, int target_grid_x,
+                        int critic_grid_x) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bid = blockIdx.x;
+    if (bid < tiles_t) {
+        const int j = bid / target_grid_x, bx = bid - j * target_grid_x;
+        if (j == 0) fused_mlp_body<MODE_SAMPLE, 16, true>(ga, smem, bx, 0, target_grid_x);
+        else fused_mlp_body<MODE_SAMPLE, 16, true>(ga_rest, smem, bx, 0, target_grid_x);
+        __threadfence_block();  // this workgroup's a' rows (global) are read back by its own target-critic pass
+        __syncthreads();
+        fused_mlp_body<MODE_PLAIN, 16, true>(gt, smem, bx, j, target_grid_x);
+    } else {
+        const int L = bid - tiles_t;
+        fused_mlp_body<MODE_CRITIC_U, TC, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x);
     }
 }
 
@@ -1543,6 +1579,70 @@ extern "C" int ssac_actor_sample_critic_fwd(const ssac_mlp *actor, const float *
     else if (tc == 16) SSAC_LAUNCH((fused_dual_kernel<16, false>), grid, dim3(NTHR), lds, st, ga, gc, tiles_a, cgx);
     else SSAC_LAUNCH((fused_dual_kernel<32, false>), grid, dim3(NTHR), lds, st, ga, gc, tiles_a, cgx);
     return ssac_check_launch("fused_dual");
+}
+
+extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t ldxa, int n_rows, const float *eps,
+                                 float log_std_lo, float log_std_hi, float *x1sa, int64_t ld_x1, int64_t act_col0,
+                                 float *logp, const ssac_rng *rng, const ssac_mlp *targets, const int32_t *net_ids,
+                                 int n_sel, float *Qt, const ssac_mlp *critics, const float *Xc, int64_t ldxc,
+                                 float *H1, float *H2, float *Q, float *DZ2u, float *DZ1u,
+                                 const ssac_gather *gather, void *stream) {
+    if (!eps && !rng) return ssac_fail("ssac_chain_update: neither eps nor an rng stream given");
+    if (!fused_ok(actor) || (actor->out_dim & 1) || !fused_dbuf_ok(targets) || !fused_dbuf_ok(critics))
+        return ssac_fail("ssac_chain_update: shape not supported by the merged launch");
+    if (critics->out_dim != 1 || targets->out_dim != 1) return ssac_fail("ssac_chain_update: single-output critics only");
+    if (n_sel <= 0 || n_sel > SSAC_MAX_NETS) return ssac_fail("ssac_chain_update: n_sel out of range");
+    if (!x1sa || !logp || !Qt || !H1 || !H2 || !Q || !DZ2u || !DZ1u) return ssac_fail("ssac_chain_update: missing buffer");
+    if (act_col0 != actor->in_dim || targets->in_dim != actor->in_dim + actor->out_dim / 2)
+        return ssac_fail("ssac_chain_update: [s'|a'] layout does not match the networks");
+    if (n_rows <= 0) return 0;
+    FusedArgs ga{}, gr{}, gt{}, gc{};
+    fill_common(ga, actor, nullptr, Xa, ldxa, 0, n_rows);
+    ga.eps = eps; ga.lo = log_std_lo; ga.hi = log_std_hi;
+    if (rng) ga.rng = RngArgs{rng->seed, rng->counter, rng->offset};
+    ga.act_dst = x1sa; ga.ld_act = ld_x1; ga.act_col0 = act_col0; ga.logp = logp;
+    fill_common(gt, targets, net_ids, x1sa, ld_x1, 0, n_rows);
+    gt.Y = Qt;
+    fill_common(gc, critics, nullptr, Xc, ldxc, 0, n_rows);
+    gc.H1 = H1; gc.H2 = H2; gc.Y = Q; gc.DZ2 = DZ2u; gc.DZ1 = DZ1u;
+    if (gather) {
+        if (gather->s_elems != actor->in_dim || gather->s_elems + gather->a_elems != critics->in_dim)
+            return ssac_fail("ssac_chain_update: gather sizes do not match the networks");
+        if (!gather->s || !gather->s1 || !gather->act || !gather->rew || !gather->done || !gather->xsa ||
+            gather->x1sa != x1sa || !gather->rew_out || !gather->done_out || (!gather->idx && !gather->feed))
+            return ssac_fail("ssac_chain_update: incomplete ssac_gather");
+        if (gather->feed && gather->n_logs > NTHR) return ssac_fail("ssac_chain_update: log block too large");
+        ga.gth = *gather; ga.gth_role = 1;
+        gc.gth = *gather; gc.gth_role = 2;
+    } else if (!Xa || !Xc) {
+        return ssac_fail("ssac_chain_update: Xa / Xc missing");
+    }
+    gr = ga;
+    if (gather) gr.gth_role = 3;
+    if (gather && gather->feed && gather->ids_word >= 0) { gt.gth = *gather; gt.gth_role = 4; }
+    const int tc = choose_tile(gc, critics->n_nets).tm;
+    const int tgx = (n_rows + 15) / 16, cgx = (n_rows + tc - 1) / tc;
+    size_t lds = fused_lds_bytes(actor->in_dim, actor->hidden, actor->out_dim, 16, true);
+    const size_t lt = fused_lds_bytes(targets->in_dim, targets->hidden, targets->out_dim, 16, true);
+    const size_t lc = fused_lds_bytes(critics->in_dim, critics->hidden, critics->out_dim, tc, true);
+    if (lt > lds) lds = lt;
+    if (lc > lds) lds = lc;
+    if (lds > 160 * 1024) return ssac_fail("ssac_chain_update: LDS carve does not fit");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)fused_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void *)fused_chain_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return ssac_fail("fused_chain: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    const int tiles_t = tgx * n_sel;
+    const dim3 grid(tiles_t + cgx * critics->n_nets);
+    hipStream_t st = (hipStream_t)stream;
+    if (tc == 16) SSAC_LAUNCH(fused_chain_kernel<16>, grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx);
+    else SSAC_LAUNCH(fused_chain_kernel<32>, grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx);
+    return ssac_check_launch("fused_chain");
 }
 
 extern "C" int ssac_critic_fwd_bwd_fused(const ssac_mlp *nets, const float *X, int64_t ldx, int n_rows,

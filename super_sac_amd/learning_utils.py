@@ -173,6 +173,15 @@ class _Batch:
     __slots__ = ("B", "S", "A", "xsa", "x1sa", "r", "d", "key", "pixel", "pending")
 
 
+# actor sample -> target critics chained per workgroup, beside the critics' forward + unscaled backward: ONE launch
+CHAIN_LAUNCH = os.environ.get("SSAC_CHAIN_LAUNCH", "1") == "1"
+
+
+def parallel_shard_of(agent):
+    from . import parallel
+    return parallel.shard_of(agent)
+
+
 # the replay gather of a critic update rides in the merged actor / critic-forward launch (ssac_gather): no gather launch
 FOLD_GATHER = os.environ.get("SSAC_FOLD_GATHER", "1") == "1"
 
@@ -202,12 +211,15 @@ def gather_struct(bt):
     S, A = p["S"], p["A"]
     cap = engine.CAPTURE
     g = _lib.Gather(p["s"], p["s1"], p["act"], p["rew"], p["done"], S, A, p["idx"].data_ptr(), 0,
-                    bt.xsa.data_ptr(), S + A, bt.x1sa.data_ptr(), S + A, bt.r.data_ptr(), bt.d.data_ptr(), 0, 0, -1, 0)
+                    bt.xsa.data_ptr(), S + A, bt.x1sa.data_ptr(), S + A, bt.r.data_ptr(), bt.d.data_ptr(), 0, 0, -1, 0,
+                    -1, 0)
     if p["begin"] is not None:
         blk, ctl = p["begin"]
         g.idx, g.feed, g.logs, g.n_logs, g.ctl = 0, p["feed"], blk.data_ptr(), LOG_WIDTH, ctl
         if cap is not None and cap.tick_ptr:
             g.rng_word = (cap.tick_ptr - cap.idx_dev.data_ptr()) // 4
+        if cap is not None:
+            g.ids_word = (cap.ids_dev.data_ptr() - cap.idx_dev.data_ptr()) // 4
     g._keep = (p["idx"],)
     return g
 
@@ -366,6 +378,10 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
     S = s1_rep.shape[1]
     a_arena = engine.bind_arena(actor, "self", [actor], dev)
     fuse_sample = kind == "stochastic" and a_arena.fused and random_process is None
+    # actor -> target critics chained inside one launch with the critics' forward + TD-independent backward
+    chain = ({} if (CHAIN_LAUNCH and fuse_sample and _co_forward is not None and _co_backward is not None
+                    and parallel_shard_of(target_agent) is None and target_agent.critics[i].arena(dev).fused_dbuf
+                    and target_agent.critics[i].arena(dev).out_dim == 1) else None)
     if not (fuse_sample and _co_forward is not None):
         ensure_gathered(replay_dict.get("_ssac"))  # (a deferred replay gather rides in the merged launch only)
     if not fuse_sample:
@@ -404,7 +420,7 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
                 if cap is None:
                     ns[1] += 1
                 _actor_sample(a_arena, s1_rep, B, 0, actor, x1, S, A, logp, C.addressof(rs), st, _co_forward,
-                              replay_dict)
+                              replay_dict, chain=chain, rng_keep=rs)
                 eps = None
             else:
                 eps = draw_normal((B, A), dev)
@@ -413,7 +429,7 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
             elif fuse_sample:
                 # actor forward + sample + log pi: ONE launch, a' lands in the [s'|a'] buffer
                 _actor_sample(a_arena, s1_rep, B, eps.data_ptr(), actor, x1, S, A, logp, 0, st, _co_forward,
-                              replay_dict)
+                              replay_dict, chain=chain, rng_keep=eps)
             else:
                 check(lib.ssac_tanh_normal_fwd(aout.data_ptr(), 2 * A, eps.data_ptr(), B, A,
                                                float(actor.log_std_low), float(actor.log_std_high),
@@ -457,10 +473,19 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
     return td, (s1_rep, a_s1)
 
 
-def _actor_sample(a_arena, s1_rep, B, eps_ptr, actor, x1, S, A, logp, rng_ptr, st, co_forward, replay_dict):
+def _actor_sample(a_arena, s1_rep, B, eps_ptr, actor, x1, S, A, logp, rng_ptr, st, co_forward, replay_dict,
+                  chain=None, rng_keep=None):
     """actor forward + tanh-normal sample + log pi in ONE launch (a' lands in the [s'|a'] buffer), optionally with
     the online critics' forward as extra workgroups of the same launch."""
     bt = replay_dict.get("_ssac")
+    if co_forward is not None and chain is not None:
+        # the whole TD-independent part of the update is ONE launch (ssac_chain_update), issued by _subset_q once the
+        # REDQ subset is known: nothing is launched here
+        chain.update(a_arena=a_arena, s1_rep=s1_rep, eps_ptr=eps_ptr, actor=actor, x1=x1, S=S, A=A, logp=logp,
+                     rng_ptr=rng_ptr, rng_keep=rng_keep, co_forward=co_forward)
+        replay_dict["_chain"] = chain
+        replay_dict["_co_fwd"] = True
+        return
     if co_forward is not None:
         c_arena, X, ldx, h1, h2, q = co_forward
         gth = None
@@ -490,6 +515,31 @@ def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag, co_backward=None, re
     (B x out) partial (the one real exchange step of the critic update), n = 1."""
     if shard is None:
         ids_dev = _upload_ids(ws, ids, dev, "sub")
+        ch = replay_dict.pop("_chain", None) if replay_dict is not None else None
+        if ch is not None:
+            c_arena, h1, h2, act, ld_act, dz2u, dz1u = co_backward
+            _, Xc, ldxc, _, _, qc = ch["co_forward"]
+            bt = replay_dict.get("_ssac")
+            x1, S, A, actor = ch["x1"], ch["S"], ch["A"], ch["actor"]
+            gth = None
+            if (bt is not None and bt.pending is not None and x1.data_ptr() == bt.x1sa.data_ptr()
+                    and Xc.data_ptr() == bt.xsa.data_ptr() and bt.pending["dtype"] == 0):
+                gth = gather_struct(bt)
+            else:
+                ensure_gathered(bt)
+            q1 = ws.get(tag + ".y", (len(ids), B, 1))
+            s1_rep = ch["s1_rep"]
+            with engine._timed("chain") as tm:
+                for _ in range(tm.reps):  # 1, except under bench.py's live kernel timing (the launch is idempotent)
+                    check(lib.ssac_chain_update(
+                        C.byref(ch["a_arena"].desc()), s1_rep.data_ptr(), _row_stride(s1_rep), B, ch["eps_ptr"],
+                        float(actor.log_std_low), float(actor.log_std_high), x1.data_ptr(), S + A, S,
+                        ch["logp"].data_ptr(), ch["rng_ptr"], C.byref(t_arena.desc()), ids_dev.data_ptr(), len(ids),
+                        q1.data_ptr(), C.byref(c_arena.desc()), Xc.data_ptr(), ldxc, h1.data_ptr(), h2.data_ptr(),
+                        qc.data_ptr(), dz2u.data_ptr(), dz1u.data_ptr(), C.byref(gth) if gth is not None else 0,
+                        engine.stream()))
+            replay_dict["_co_bwd"] = True
+            return q1, len(ids)
         if co_backward is not None and t_arena.fused_dbuf:
             c_arena, h1, h2, act, ld_act, dz2u, dz1u = co_backward
             q1 = ws.get(tag + ".y", (len(ids), B, t_arena.out_dim))

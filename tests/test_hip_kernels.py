@@ -983,3 +983,41 @@ def test_rank1_backward_matches_autograd(ssa, B, H, N):
     for j in range(N):
         for seg in ssa.engine.SEGS:
             _close(ar.view(j, seg, grads), ps[j][seg].grad, 3e-6, rtol=1e-4, what=f"grad {seg}[{j}]")
+
+
+@pytest.mark.parametrize("B,N,H", [(512, 10, 256), (100, 3, 64)])
+def test_chain_launch_equals_the_separate_launches(ssa, B, N, H):
+    """ssac_chain_update (actor -> target critic chains beside critic forward + unscaled backward, ONE launch) against
+    ssac_actor_sample_fused + ssac_target_fwd_critic_bwdu's two halves issued separately: same bits everywhere."""
+    rng = np.random.RandomState(B + 7)
+    S, A = 17, 6
+    actor = orc.make_mlp(rng, S, H, 2 * A)
+    crit = [orc.make_mlp(rng, S + A, H, 1) for _ in range(N)]
+    tgt = [orc.make_mlp(rng, S + A, H, 1) for _ in range(N)]
+    aa, ca, ta = _arena_from(ssa, [actor]), _arena_from(ssa, crit), _arena_from(ssa, tgt)
+    x1 = torch.from_numpy(rng.standard_normal((B, S + A)).astype(np.float32)).to(DEV)
+    xc = torch.from_numpy(rng.standard_normal((B, S + A)).astype(np.float32)).to(DEV)
+    eps = torch.from_numpy(rng.standard_normal((B, A)).astype(np.float32)).to(DEV)
+    ids = torch.tensor([N - 1, 0], dtype=torch.int32, device=DEV)
+    lib, st = ssa._lib.lib, ssa.engine.stream()
+    ws = ssa.engine.Workspace(torch.device(DEV))
+    # reference sequence
+    xa, lpa = x1.clone(), torch.zeros(B, device=DEV)
+    ssa._lib.check(lib.ssac_actor_sample_fused(C.byref(aa.desc()), xa.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0,
+                                               xa.data_ptr(), S + A, S, lpa.data_ptr(), 0, 0, 0, 0, st))
+    h1, h2, q = ssa.engine.mlp_forward(ca, xc, S + A, 0, B, ws, "sep")
+    qt = torch.zeros(2, B, 1, device=DEV); dz2 = torch.zeros_like(h1); dz1 = torch.zeros_like(h1)
+    ssa._lib.check(lib.ssac_target_fwd_critic_bwdu(C.byref(ta.desc()), ids.data_ptr(), 2, xa.data_ptr(), S + A, B,
+                                                   qt.data_ptr(), C.byref(ca.desc()), h1.data_ptr(), h2.data_ptr(), 0, 0,
+                                                   dz2.data_ptr(), dz1.data_ptr(), st))
+    # chained launch
+    xb, lpb = x1.clone(), torch.zeros(B, device=DEV)
+    g1, g2, gq = torch.zeros_like(h1), torch.zeros_like(h2), torch.zeros_like(q)
+    gt_, gz2, gz1 = torch.zeros_like(qt), torch.zeros_like(dz2), torch.zeros_like(dz1)
+    ssa._lib.check(lib.ssac_chain_update(
+        C.byref(aa.desc()), xb.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0, xb.data_ptr(), S + A, S, lpb.data_ptr(),
+        0, C.byref(ta.desc()), ids.data_ptr(), 2, gt_.data_ptr(), C.byref(ca.desc()), xc.data_ptr(), S + A,
+        g1.data_ptr(), g2.data_ptr(), gq.data_ptr(), gz2.data_ptr(), gz1.data_ptr(), 0, st))
+    for a_, b_, what in ((xa, xb, "a'"), (lpa, lpb, "log pi"), (h1, g1, "h1"), (h2, g2, "h2"), (q, gq, "q"),
+                         (qt, gt_, "target q"), (dz2, gz2, "dz2u"), (dz1, gz1, "dz1u")):
+        assert torch.equal(a_, b_), f"chained launch differs in {what}"

@@ -881,7 +881,8 @@ void fused_dual2_kernel(FusedArgs gt, FusedArgs gc, int tiles_t, int target_grid
 //     (MODE_CRITIC_U): h1 / h2 stay in LDS between the two, instead of being written out and read back by a
 //     second launch.
 // The replay gather and the start-of-update duties ride along as in fused_dual_kernel (actor part of slot 0).
-template <int TC>
+// ADBUF = the actor pass double-buffers its weight staging (false: wide input + wide head, e.g. Humanoid's 376 -> 34).
+template <int TC, bool ADBUF>
 __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs gc, int tiles_t, int target_grid_x,
                         int critic_grid_x) {
@@ -889,8 +890,8 @@ void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs
     const int bid = blockIdx.x;
     if (bid < tiles_t) {
         const int j = bid / target_grid_x, bx = bid - j * target_grid_x;
-        if (j == 0) fused_mlp_body<MODE_SAMPLE, 16, true>(ga, smem, bx, 0, target_grid_x);
-        else fused_mlp_body<MODE_SAMPLE, 16, true>(ga_rest, smem, bx, 0, target_grid_x);
+        if (j == 0) fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga, smem, bx, 0, target_grid_x);
+        else fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga_rest, smem, bx, 0, target_grid_x);
         __threadfence_block();  // this workgroup's a' rows (global) are read back by its own target-critic pass
         __syncthreads();
         fused_mlp_body<MODE_PLAIN, 16, true>(gt, smem, bx, j, target_grid_x);
@@ -1622,7 +1623,8 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
     if (gather && gather->feed && gather->ids_word >= 0) { gt.gth = *gather; gt.gth_role = 4; }
     const int tc = choose_tile(gc, critics->n_nets).tm;
     const int tgx = (n_rows + 15) / 16, cgx = (n_rows + tc - 1) / tc;
-    size_t lds = fused_lds_bytes(actor->in_dim, actor->hidden, actor->out_dim, 16, true);
+    const bool adbuf = fused_dbuf_ok(actor);
+    size_t lds = fused_lds_bytes(actor->in_dim, actor->hidden, actor->out_dim, 16, adbuf);
     const size_t lt = fused_lds_bytes(targets->in_dim, targets->hidden, targets->out_dim, 16, true);
     const size_t lc = fused_lds_bytes(critics->in_dim, critics->hidden, critics->out_dim, tc, true);
     if (lt > lds) lds = lt;
@@ -1630,18 +1632,20 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
     if (lds > 160 * 1024) return ssac_fail("ssac_chain_update: LDS carve does not fit");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)fused_chain_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void *)fused_chain_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return ssac_fail("fused_chain: cannot raise the dynamic LDS limit");
+        const void *ks[4] = {(const void *)fused_chain_kernel<16, true>, (const void *)fused_chain_kernel<32, true>,
+                             (const void *)fused_chain_kernel<16, false>, (const void *)fused_chain_kernel<32, false>};
+        for (const void *k : ks)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return ssac_fail("fused_chain: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
     const int tiles_t = tgx * n_sel;
     const dim3 grid(tiles_t + cgx * critics->n_nets);
     hipStream_t st = (hipStream_t)stream;
-    if (tc == 16) SSAC_LAUNCH(fused_chain_kernel<16>, grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx);
-    else SSAC_LAUNCH(fused_chain_kernel<32>, grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx);
+    if (tc == 16 && adbuf) SSAC_LAUNCH((fused_chain_kernel<16, true>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx);
+    else if (adbuf) SSAC_LAUNCH((fused_chain_kernel<32, true>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx);
+    else if (tc == 16) SSAC_LAUNCH((fused_chain_kernel<16, false>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx);
+    else SSAC_LAUNCH((fused_chain_kernel<32, false>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx);
     return ssac_check_launch("fused_chain");
 }
 

@@ -153,25 +153,25 @@ __global__ void tanh_normal_bwd_kernel(const float *__restrict__ dX, int n_nets,
                                        int A, float lo, float hi, const float *__restrict__ log_alpha,
                                        int use_entropy, float inv_members, float *__restrict__ d_out,
                                        int64_t ld_dout) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_rows) return;
+    // one thread per (row, action dimension): the loads of a row's A x n_nets input gradients are spread over A lanes
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * A) return;
+    const int b = idx / A, i = idx - b * A;
     const float c = use_entropy ? expf(log_alpha[0]) * inv_members / (float)n_rows : 0.0f;
-    for (int i = 0; i < A; ++i) {
-        float gsum = 0.0f;
-        for (int j = 0; j < n_nets; ++j) gsum += dX[j * sX + b * ldx + col0 + i];
-        const float mu = out[b * ld_out + i];
-        const float raw = out[b * ld_out + A + i];
-        const float t = tanhf(raw);
-        const float log_std = lo + 0.5f * (hi - lo) * (t + 1.0f);
-        const float sd = expf(log_std);
-        const float e = eps[(int64_t)b * A + i];
-        const float a = tanhf(mu + sd * e);
-        const float gu = gsum * (1.0f - a * a);
-        const float d_mu = gu + c * 2.0f * a;
-        const float d_ls = gu * sd * e + c * (-1.0f + 2.0f * a * sd * e);
-        d_out[b * ld_dout + i] = d_mu;
-        d_out[b * ld_dout + A + i] = d_ls * 0.5f * (hi - lo) * (1.0f - t * t);
-    }
+    float gsum = 0.0f;
+    for (int j = 0; j < n_nets; ++j) gsum += dX[j * sX + b * ldx + col0 + i];
+    const float mu = out[b * ld_out + i];
+    const float raw = out[b * ld_out + A + i];
+    const float t = tanhf(raw);
+    const float log_std = lo + 0.5f * (hi - lo) * (t + 1.0f);
+    const float sd = expf(log_std);
+    const float e = eps[(int64_t)b * A + i];
+    const float a = tanhf(mu + sd * e);
+    const float gu = gsum * (1.0f - a * a);
+    const float d_mu = gu + c * 2.0f * a;
+    const float d_ls = gu * sd * e + c * (-1.0f + 2.0f * a * sd * e);
+    d_out[b * ld_dout + i] = d_mu;
+    d_out[b * ld_dout + A + i] = d_ls * 0.5f * (hi - lo) * (1.0f - t * t);
 }
 
 __global__ void det_action_fwd_kernel(const float *__restrict__ out, int64_t ld_out,
@@ -1022,7 +1022,7 @@ extern "C" int ssac_tanh_normal_bwd(const float *dX, int n_nets, int64_t ldx, in
                                     int use_entropy, float inv_members, float *d_out, int64_t ld_dout,
                                     void *stream) {
     if (n_rows <= 0) return 0;
-    SSAC_LAUNCH(tanh_normal_bwd_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ST, dX, n_nets, ldx,
+    SSAC_LAUNCH(tanh_normal_bwd_kernel, dim3((n_rows * act_dim + 255) / 256), dim3(256), 0, ST, dX, n_nets, ldx,
                        x_net_stride, act_col0, out, ld_out, eps, n_rows, act_dim, lo, hi, log_alpha,
                        use_entropy, inv_members, d_out, ld_dout);
     return ssac_check_launch("tanh_normal_bwd");

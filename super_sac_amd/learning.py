@@ -811,14 +811,31 @@ def alpha_update(buffer, agent, optimizers, batch_size, log_alphas, augmenter, a
         B, S = s_rep.shape
         actor = agent.actors[i]
         a_arena = engine.bind_arena(actor, "self", [actor], dev)
-        _, _, aout = engine.mlp_forward(a_arena, s_rep, lu._row_stride(s_rep), 0, B, ws, f"al.a{i}")
         kind = lu.actor_kind(actor)
+        fused_sample = kind == "stochastic" and a_arena.fused
+        if not fused_sample:
+            _, _, aout = engine.mlp_forward(a_arena, s_rep, lu._row_stride(s_rep), 0, B, ws, f"al.a{i}")
         if kind == "discrete":
             lp_ptr, n_act = aout.data_ptr(), a_arena.out_dim
         else:
             A = actor.action_size
             logp = ws.get(f"al.logp{i}", (B,))
-            if kind == "stochastic":
+            if fused_sample:
+                # actor forward + a_dist.sample() + log pi (learning.py:255) in ONE launch; the noise comes from the
+                # agent's Philox stream unless a noise hook is installed (then it is drawn like everywhere else)
+                scratch = ws.get(f"al.act{i}", (B, A))
+                if lu.IN_KERNEL_NOISE and rng.normal_is_stock():
+                    ns = lu.noise_stream(agent, dev)
+                    rs = _lib.Rng(ns[0], 0, ns[1])
+                    ns[1] += 1
+                    eps_ptr, rng_ptr = 0, C.addressof(rs)
+                else:
+                    eps = rng.draw_normal((B, A), dev)
+                    eps_ptr, rng_ptr = eps.data_ptr(), 0
+                check(lib.ssac_actor_sample_fused(C.byref(a_arena.desc()), s_rep.data_ptr(), lu._row_stride(s_rep), B,
+                                                  eps_ptr, float(actor.log_std_low), float(actor.log_std_high),
+                                                  scratch.data_ptr(), A, 0, logp.data_ptr(), 0, 0, 0, rng_ptr, st))
+            elif kind == "stochastic":
                 eps = rng.draw_normal((B, A), dev)  # a_dist.sample() (learning.py:255)
                 scratch = ws.get(f"al.act{i}", (B, A))
                 check(lib.ssac_tanh_normal_fwd(aout.data_ptr(), 2 * A, eps.data_ptr(), B, A,

@@ -17,6 +17,7 @@
 //   row-contiguous source-> Xt[k][row], row stride 64 floats   (consecutive lanes, same k)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "ssac_internal.h"
 #include "ssac_head_wgrad.h"
@@ -66,10 +67,13 @@ __device__ __forceinline__ int64_t batch_off(const int32_t *ids, int use_ids, in
     return (int64_t)((use_ids && ids) ? ids[e] : e) * stride;
 }
 
-// ---- global -> register staging (8 floats per thread per operand per chunk), branch-free:
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// ---- global -> register staging (8 floats per thread per operand per chunk, held in the SAME two f4 registers the
+//      16-byte loader uses -- one staging set per operand, whichever load path a launch takes), branch-free:
 //      out-of-range lanes read element 0 (always valid) and select 0.
 template <bool KCONTIG>
-__device__ __forceinline__ void load_chunk(float (&r)[8], const float *__restrict__ S, int64_t ld,
+__device__ __forceinline__ void load_chunk(f4 (&r)[2], const float *__restrict__ S, int64_t ld,
                                            int R0, int R, int k0, int K, int tid) {
     if (KCONTIG) {
         // S is (R x K) row-major: thread -> k = tid&31, rows (tid>>5) + 8p
@@ -80,7 +84,7 @@ __device__ __forceinline__ void load_chunk(float (&r)[8], const float *__restric
             const int row = R0 + rr + 8 * p;
             const bool ok = kok && row < R;
             const float v = S[ok ? (int64_t)row * ld + k0 + kk : 0];
-            r[p] = ok ? v : 0.0f;
+            r[p >> 2][p & 3] = ok ? v : 0.0f;
         }
     } else {
         // S is (K x R) row-major: thread -> row = tid&63, k = (tid>>6) + 4p
@@ -91,21 +95,21 @@ __device__ __forceinline__ void load_chunk(float (&r)[8], const float *__restric
             const int k = k0 + kk + 4 * p;
             const bool ok = rok && k < K;
             const float v = S[ok ? (int64_t)k * ld + R0 + rr : 0];
-            r[p] = ok ? v : 0.0f;
+            r[p >> 2][p & 3] = ok ? v : 0.0f;
         }
     }
 }
 
 template <bool KCONTIG>
-__device__ __forceinline__ void store_chunk(const float (&r)[8], float *__restrict__ Xs, int tid) {
+__device__ __forceinline__ void store_chunk(const f4 (&r)[2], float *__restrict__ Xs, int tid) {
     if (KCONTIG) {
         const int kk = tid & 31, rr = tid >> 5;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) Xs[(rr + 8 * p) * LDS_KC + kk] = r[p];
+        for (int p = 0; p < 8; ++p) Xs[(rr + 8 * p) * LDS_KC + kk] = r[p >> 2][p & 3];
     } else {
         const int rr = tid & 63, kk = tid >> 6;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) Xs[(kk + 4 * p) * LDS_RC + rr] = r[p];
+        for (int p = 0; p < 8; ++p) Xs[(kk + 4 * p) * LDS_RC + rr] = r[p >> 2][p & 3];
     }
 }
 
@@ -136,43 +140,45 @@ __device__ __forceinline__ float adam_elem(float p, float g, float &m, float &v,
 // (weight gradients: K = batch), where most CUs would otherwise run one wave per SIMD.
 #define GSTAMP(i) do { if (g.dbg && bx == 0 && by == 0 && bz == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
-typedef float f4 __attribute__((ext_vector_type(4)));
-
 // Row-contiguous operand (K x R row-major, e.g. dY and X of the weight-gradient GEMM), 16-byte
 // loads: thread -> 4 consecutive rows r4 = 4*(tid&15), k = (tid>>4) + 16q.  The source pointers
 // are built once and advanced by a uniform stride; the LDS image is Xt[k*64 + r] (b128 stores).
 struct RcVecLoader {
-    const float *p[2];
+    const float *p0;    // row kfirst + kk of this thread's 4 columns (the second row sits 16 rows further)
+    int64_t ld16;       // 16 rows, in floats
     const float *safe;  // always-valid 16-byte aligned address for predicated-off lanes
     f4 v[2];
     int kk, r4;
-    int kq[2];  // k of the rows held in v (late row scale: applied when the rows are stored)
+    int klast;          // k0 of the rows held in v (late row scale: applied when the rows are stored)
     bool rok;
     __device__ __forceinline__ void init(const float *S, int64_t ld, int R0, int R, int kfirst, int tid) {
         r4 = (tid & 15) * 4;
         kk = tid >> 4;
         safe = S;
         rok = (R0 + r4) < R;  // R % 4 == 0 on this path
-#pragma unroll
-        for (int q = 0; q < 2; ++q) p[q] = S + (rok ? (int64_t)(kfirst + kk + 16 * q) * ld + R0 + r4 : 0);
+        ld16 = 16 * ld;
+        p0 = S + (rok ? (int64_t)(kfirst + kk) * ld + R0 + r4 : 0);
+        klast = 0;
     }
     __device__ __forceinline__ void load(int k0, int K, int64_t adv, const float *scale = nullptr) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int k = k0 + kk + 16 * q;
             const bool ok = rok && k < K;
-            const f4 x = *reinterpret_cast<const f4 *>(ok ? p[q] : safe);
+            const f4 x = *reinterpret_cast<const f4 *>(ok ? p0 + q * ld16 : safe);
             const float sc = scale ? scale[ok ? k : 0] : 1.0f;
             v[q] = ok ? x * sc : (f4){0.f, 0.f, 0.f, 0.f};
-            kq[q] = ok ? k : 0;
-            p[q] += adv;
         }
+        klast = k0;
+        p0 += adv;
     }
     // late: row scales in LDS (loss_fold_table), applied here so the loads need not wait for the table
-    __device__ __forceinline__ void store(float *Xt, const float *late = nullptr) const {
+    __device__ __forceinline__ void store(float *Xt, const float *late = nullptr, int K = 0) const {
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-            *reinterpret_cast<f4 *>(Xt + (kk + 16 * q) * LDS_RC + r4) = late ? v[q] * late[kq[q]] : v[q];
+        for (int q = 0; q < 2; ++q) {
+            const int k = klast + kk + 16 * q;
+            *reinterpret_cast<f4 *>(Xt + (kk + 16 * q) * LDS_RC + r4) = late ? v[q] * late[(rok && k < K) ? k : 0] : v[q];
+        }
     }
 };
 
@@ -213,7 +219,6 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     // 16-byte loads need 16-byte aligned rows on both operands (checked per launch on the host)
     const bool vecA = TN && (g.vec & 1), vecB = TN && (g.vec & 2);
 
-    float ra[8], rb[8];
     RcVecLoader va, vb;
     if (vecA) va.init(A, g.lda, m0, g.M, kg * BK, tid);
     if (vecB) vb.init(B, g.ldb, n0, g.N, kg * BK, tid);
@@ -224,28 +229,28 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     auto loadA = [&](int k0) {
         if (vecA) { va.load(k0, Kloc, advA, rscale); return; }
         ra_k0 = k0;
-        load_chunk<A_KC>(ra, A, g.lda, m0, g.M, k0, Kloc, tid);
+        load_chunk<A_KC>(va.v, A, g.lda, m0, g.M, k0, Kloc, tid);
         if (TN && rscale) {  // (K x R) layout: this thread's 8 values sit at k = k0 + (tid >> 6) + 4 p
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int k = k0 + (tid >> 6) + 4 * p;
-                ra[p] *= rscale[k < Kloc ? k : 0];
+                va.v[p >> 2][p & 3] *= rscale[k < Kloc ? k : 0];
             }
         }
     };
-    auto loadB = [&](int k0) { if (vecB) vb.load(k0, Kloc, advB); else load_chunk<B_KC>(rb, B, g.ldb, n0, g.N, k0, Kloc, tid); };
+    auto loadB = [&](int k0) { if (vecB) vb.load(k0, Kloc, advB); else load_chunk<B_KC>(vb.v, B, g.ldb, n0, g.N, k0, Kloc, tid); };
     auto storeA = [&](float *d) {
-        if (vecA) { va.store(d, TN ? late_rs : nullptr); return; }
+        if (vecA) { va.store(d, TN ? late_rs : nullptr, Kloc); return; }
         if (TN && late_rs) {
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
                 const int k = ra_k0 + (tid >> 6) + 4 * p;
-                ra[p] *= late_rs[k < Kloc ? k : 0];
+                va.v[p >> 2][p & 3] *= late_rs[k < Kloc ? k : 0];
             }
         }
-        store_chunk<A_KC>(ra, d, tid);
+        store_chunk<A_KC>(va.v, d, tid);
     };
-    auto storeB = [&](float *d) { if (vecB) vb.store(d); else store_chunk<B_KC>(rb, d, tid); };
+    auto storeB = [&](float *d) { if (vecB) vb.store(d); else store_chunk<B_KC>(vb.v, d, tid); };
 
     GSTAMP(0);
     // Software-pipelined K loop in half chunks: the fragments of the second half of chunk it are read while its
@@ -762,6 +767,9 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
         if (tiles <= 512 && nchunks >= 4) return launch_pair_ks<false, false, EPI_GRAD, 2>(p, n_sel, n_sel, st);
         return launch_pair_ks<false, false, EPI_GRAD, 1>(p, n_sel, n_sel, st);
     }
+    static const int ks_force = getenv("SSAC_WGRAD_KS") ? atoi(getenv("SSAC_WGRAD_KS")) : 0;
+    if (ks_force == 2) return launch_pair_ks<false, false, EPI_ADAM, 2>(p, n_sel, n_sel, st);
+    if (ks_force == 1) return launch_pair_ks<false, false, EPI_ADAM, 1>(p, n_sel, n_sel, st);
     if (tiles <= 256 && nchunks >= 8) return launch_pair_ks<false, false, EPI_ADAM, 4>(p, n_sel, n_sel, st);
     if (tiles <= 512 && nchunks >= 4) return launch_pair_ks<false, false, EPI_ADAM, 2>(p, n_sel, n_sel, st);
     return launch_pair_ks<false, false, EPI_ADAM, 1>(p, n_sel, n_sel, st);

@@ -380,7 +380,8 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
     fuse_sample = kind == "stochastic" and a_arena.fused and random_process is None
     # actor -> target critics chained inside one launch with the critics' forward + TD-independent backward
     chain = ({} if (CHAIN_LAUNCH and fuse_sample and _co_forward is not None and _co_backward is not None
-                    and parallel_shard_of(target_agent) is None and target_agent.critics[i].arena(dev).fused_dbuf
+                    and (parallel_shard_of(target_agent) is None or engine.CAPTURE is not None)
+                    and target_agent.critics[i].arena(dev).fused_dbuf
                     and target_agent.critics[i].arena(dev).out_dim == 1) else None)
     if not (fuse_sample and _co_forward is not None):
         ensure_gathered(replay_dict.get("_ssac"))  # (a deferred replay gather rides in the merged launch only)
@@ -509,6 +510,34 @@ def _actor_sample(a_arena, s1_rep, B, eps_ptr, actor, x1, S, A, logp, rng_ptr, s
                                       logp.data_ptr(), 0, 0, 0, rng_ptr, st))
 
 
+def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict):
+    """ssac_chain_update: the deferred actor sample (ch, from _actor_sample), the target critics of the n subset slots
+    and the online critics' forward + TD-independent backward, ONE launch; returns the target outputs (n, B, 1)"""
+    c_arena, h1, h2, act, ld_act, dz2u, dz1u = co_backward
+    _, Xc, ldxc, _, _, qc = ch["co_forward"]
+    bt = replay_dict.get("_ssac")
+    x1, S, A, actor = ch["x1"], ch["S"], ch["A"], ch["actor"]
+    gth = None
+    if (bt is not None and bt.pending is not None and x1.data_ptr() == bt.x1sa.data_ptr()
+            and Xc.data_ptr() == bt.xsa.data_ptr() and bt.pending["dtype"] == 0):
+        gth = gather_struct(bt)
+    else:
+        ensure_gathered(bt)
+    q1 = ws.get(tag + ".y", (n, B, 1))
+    s1_rep = ch["s1_rep"]
+    with engine._timed("chain") as tm:
+        for _ in range(tm.reps):  # 1, except under bench.py's live kernel timing (the launch is idempotent)
+            check(lib.ssac_chain_update(
+                C.byref(ch["a_arena"].desc()), s1_rep.data_ptr(), _row_stride(s1_rep), B, ch["eps_ptr"],
+                float(actor.log_std_low), float(actor.log_std_high), x1.data_ptr(), S + A, S,
+                ch["logp"].data_ptr(), ch["rng_ptr"], C.byref(t_arena.desc()), ids_ptr, n,
+                q1.data_ptr(), C.byref(c_arena.desc()), Xc.data_ptr(), ldxc, h1.data_ptr(), h2.data_ptr(),
+                qc.data_ptr(), dz2u.data_ptr(), dz1u.data_ptr(), C.byref(gth) if gth is not None else 0,
+                engine.stream()))
+    replay_dict["_co_bwd"] = True
+    return q1
+
+
 def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag, co_backward=None, replay_dict=None):
     """target-critic outputs for the REDQ subset `ids`: (q, n) with q of shape (n, B, out).
     Sharded: forward of the locally owned subset members, elementwise min, MIN all-reduce of the
@@ -517,28 +546,7 @@ def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag, co_backward=None, re
         ids_dev = _upload_ids(ws, ids, dev, "sub")
         ch = replay_dict.pop("_chain", None) if replay_dict is not None else None
         if ch is not None:
-            c_arena, h1, h2, act, ld_act, dz2u, dz1u = co_backward
-            _, Xc, ldxc, _, _, qc = ch["co_forward"]
-            bt = replay_dict.get("_ssac")
-            x1, S, A, actor = ch["x1"], ch["S"], ch["A"], ch["actor"]
-            gth = None
-            if (bt is not None and bt.pending is not None and x1.data_ptr() == bt.x1sa.data_ptr()
-                    and Xc.data_ptr() == bt.xsa.data_ptr() and bt.pending["dtype"] == 0):
-                gth = gather_struct(bt)
-            else:
-                ensure_gathered(bt)
-            q1 = ws.get(tag + ".y", (len(ids), B, 1))
-            s1_rep = ch["s1_rep"]
-            with engine._timed("chain") as tm:
-                for _ in range(tm.reps):  # 1, except under bench.py's live kernel timing (the launch is idempotent)
-                    check(lib.ssac_chain_update(
-                        C.byref(ch["a_arena"].desc()), s1_rep.data_ptr(), _row_stride(s1_rep), B, ch["eps_ptr"],
-                        float(actor.log_std_low), float(actor.log_std_high), x1.data_ptr(), S + A, S,
-                        ch["logp"].data_ptr(), ch["rng_ptr"], C.byref(t_arena.desc()), ids_dev.data_ptr(), len(ids),
-                        q1.data_ptr(), C.byref(c_arena.desc()), Xc.data_ptr(), ldxc, h1.data_ptr(), h2.data_ptr(),
-                        qc.data_ptr(), dz2u.data_ptr(), dz1u.data_ptr(), C.byref(gth) if gth is not None else 0,
-                        engine.stream()))
-            replay_dict["_co_bwd"] = True
+            q1 = _launch_chain(ch, co_backward, t_arena, ids_dev.data_ptr(), len(ids), ws, tag, B, replay_dict)
             return q1, len(ids)
         if co_backward is not None and t_arena.fused_dbuf:
             c_arena, h1, h2, act, ld_act, dz2u, dz1u = co_backward
@@ -563,7 +571,10 @@ def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag, co_backward=None, re
         # per-update device id block holds the LOCAL index of the members this rank owns and -1 for the others
         # (their outputs are +inf), and the collective runs between two recorded segments
         n = len(ids)
-        if co_backward is not None and t_arena.fused_dbuf:
+        ch = replay_dict.pop("_chain", None) if replay_dict is not None else None
+        if ch is not None:
+            q1 = _launch_chain(ch, co_backward, t_arena, cap.ids_dev.data_ptr(), n, ws, tag, B, replay_dict)
+        elif co_backward is not None and t_arena.fused_dbuf:
             # ... and the TD-independent half of the local critics' backward pass rides in the same launch
             c_arena, h1, h2, act, ld_act, dz2u, dz1u = co_backward
             q1 = ws.get(tag + ".y", (n, B, O))

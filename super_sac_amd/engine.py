@@ -176,8 +176,9 @@ class MlpArena:
                     for seg, p in ((SEGS[2 * k], lin.weight), (SEGS[2 * k + 1], lin.bias)):
                         params.append(p)
                         expect.append(self.view(j, seg).data_ptr())
-            ptrs = self.__dict__["_bound_ptrs"] = (params, expect)
-        return all(p.data_ptr() == e for p, e in zip(*ptrs))
+            # (bound methods of the Parameter objects: they follow a re-assigned .data; one list comparison per call)
+            ptrs = self.__dict__["_bound_ptrs"] = (params, expect, [p.data_ptr for p in params])
+        return [f() for f in ptrs[2]] == ptrs[1]
 
     @classmethod
     def adopt(cls, modules, device):

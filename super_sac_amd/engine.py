@@ -51,7 +51,15 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """raw handle of torch's current stream on the current device (asked on every launch site: the fast C accessors
+    cost ~0.3 us, torch.cuda.current_stream() ~8 us)"""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 

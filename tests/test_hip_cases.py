@@ -209,3 +209,58 @@ def test_recorded_updates_with_a_wide_action_head():
             ssa.learning.USE_GRAPHS = old
 
     assert np.array_equal(run(False), run(True))
+
+
+def test_recorded_updates_wrap_the_input_ring():
+    """100 recorded updates (the 32-slot input ring wraps three times, slot reuse is guarded by one stream event per 8
+    updates) against 100 eager updates: same parameters, same last logs, same replay indices."""
+    import copy
+    import math
+    import random
+    from itertools import chain
+
+    import torch
+    import super_sac_amd as ssa
+
+    def run(recorded):
+        old = ssa.learning.USE_GRAPHS
+        ssa.learning.USE_GRAPHS = recorded
+        try:
+            torch.manual_seed(11); np.random.seed(11); random.seed(11)
+            dev = torch.device("cuda")
+            agent = ssa.Agent(act_space_size=3, encoder=ssa.nets.IdentityEncoder(11),
+                              actor_network_cls=ssa.nets.ContinuousStochasticActor,
+                              critic_network_cls=ssa.nets.ContinuousCritic, ensemble_size=1, num_critics=3,
+                              hidden_size=64, auto_rescale_targets=False, log_std_low=-5.0, log_std_high=2.0)
+            agent.to(dev)
+            target = copy.deepcopy(agent)
+            buf = ssa.replay.ReplayBuffer(4096, device=dev)
+            buf.load_experience(*synth.synth_transitions(1500, 11, 3, seed=9))
+            copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=3e-4)
+            eopt = torch.optim.Adam(agent.encoder.parameters(), lr=1e-4)
+            la = torch.Tensor([math.log(0.2)]).to(dev); la.requires_grad = True
+            aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(96)])
+            seen = []
+            for k in range(100):
+                logs, dicts = ssa.learning.critic_update(
+                    buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt, encoder_optimizer=eopt,
+                    log_alphas=[la], batch_size=96, gamma=0.99, critic_clip=None, encoder_clip=None,
+                    target_critic_ensemble_n=2, weighted_bellman_temp=None, weight_type=None, pop=False,
+                    augmenter=aug, encoder_lambda=0, aug_mix=0.0, discrete=False, random_process=None,
+                    noise_clip=None, per=False, update_priorities=False, dr3_coeff=0.0)
+                if k % 2 == 1:
+                    ssa.learning_utils.soft_update(target.critics[0], agent.critics[0], 0.01)
+                if k in (40, 99):  # (reading a log in the middle drains the queue: the ring must cope with that too)
+                    seen.append((float(logs["losses/critic_overall_loss"]), float(logs["td_targets/mean_td_target_0"]),
+                                 dicts[0]["priority_idxs"].copy()))
+            params = torch.cat([p.detach().flatten() for p in agent.critics[0].parameters()]).cpu().numpy()
+            tparams = torch.cat([p.detach().flatten() for p in target.critics[0].parameters()]).cpu().numpy()
+            return params, tparams, seen
+        finally:
+            ssa.learning.USE_GRAPHS = old
+
+    pe, te, se = run(False)
+    pr, tr, sr = run(True)
+    assert np.array_equal(pe, pr) and np.array_equal(te, tr)
+    for a, b in zip(se, sr):
+        assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])

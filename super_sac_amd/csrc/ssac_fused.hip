@@ -103,6 +103,7 @@ typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 
 struct NoStage {
     __device__ __forceinline__ void load(int, int) {}
+    __device__ __forceinline__ void load_full(int) {}
 };
 
 // W is (Nout x K), K contiguous.  LDS image Ws[n*WS_LD + k] for n < 256, k < 32.
@@ -134,6 +135,11 @@ struct KcStage {
                 for (int i = 0; i < 4; ++i) v[q][i] = i < left ? p[q][k0 + i] : 0.0f;
         }
     }
+    // a chunk that is known to lie fully inside K (every chunk but the last): no ragged-tail branch
+    __device__ __forceinline__ void load_full(int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f4u *>(p[q] + k0);
+    }
     __device__ __forceinline__ void store(float *__restrict__ Ws, int tid) const {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -164,6 +170,14 @@ struct RcStage {
             const bool ok = cok && (n0 + (int)(threadIdx.x >> 6) + 8 * q) < K;
             const f4 x = *reinterpret_cast<const f4u *>(p[q] + (ok ? (int64_t)n0 * ldw_ : 0));
             v[q] = ok ? x : (f4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // rows [n0, n0 + 32) known to lie inside K
+    __device__ __forceinline__ void load_full(int n0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f4 x = *reinterpret_cast<const f4u *>(p[q] + (cok ? (int64_t)n0 * ldw_ : 0));
+            v[q] = cok ? x : (f4){0.f, 0.f, 0.f, 0.f};
         }
     }
     __device__ __forceinline__ void store(float *__restrict__ Wt, int tid) const {
@@ -320,6 +334,28 @@ __device__ __forceinline__ void pipe_step(typename Tile<TMR>::Acc &acc, Stage &s
     Tile<TMR>::template mfma_half<NN>(acc, cur, 1);
 }
 
+// Steady-state step (chunks c+1 and c+2 exist and are full): straight-line code, so the staging stores and the next
+// global loads can be interleaved BETWEEN the MFMAs of the first half and the fragment reads between those of the
+// second half (a wave is issue-stalled behind its own dependent MFMA chain most of the time: those slots are free).
+template <int TMR, bool NN, typename Stage>
+__device__ __forceinline__ void pipe_steady(typename Tile<TMR>::Acc &acc, Stage &st, int c, const float *As, int lda,
+                                            float *nxt, const typename Tile<TMR>::Frag &cur,
+                                            typename Tile<TMR>::Frag &nf, int tid, int col0) {
+    st.store(nxt, tid);
+    st.load_full((c + 2) * 32);
+    Tile<TMR>::template mfma_half<NN>(acc, cur, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // MFMA, LDS write, MFMA, global load
+        __builtin_amdgcn_sched_group_barrier(0x008, TMR == 32 ? 1 : 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TMR == 32 ? 1 : 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __syncthreads();
+    Tile<TMR>::template read<NN>(nf, As, lda, nxt, c + 1, tid & 63, col0);
+    Tile<TMR>::template mfma_half<NN>(acc, cur, 1);
+}
+
 // Contract: the caller has staged chunk 0 into B0 (stage_first below), and a barrier since then has made
 // it and the A operand visible.  While the LAST chunk is being multiplied, nx.load(0, Knext) puts the next
 // phase's first weight chunk in flight, so no phase starts by waiting a full HBM/L2 round trip; the caller
@@ -356,7 +392,13 @@ __device__ __forceinline__ void gemm_tile(typename Tile<TMR>::Acc &acc, Stage &s
     }
     typename Tile<TMR>::Frag f0, f1;
     Tile<TMR>::template read<NN>(f0, As, lda, B0, 0, tid & 63, col0);
-    for (int c = 0; c < nch; c += 2) {
+    int c = 0;
+    const int full = (K & 31) ? nch - 1 : nch;  // chunks [0, full) hold 32 k values each
+    for (; c + 3 < full; c += 2) {  // chunks c+2 and c+3 exist and are full
+        pipe_steady<TMR, NN>(acc, st, c, As, lda, B1, f0, f1, tid, col0);
+        pipe_steady<TMR, NN>(acc, st, c + 1, As, lda, B0, f1, f0, tid, col0);
+    }
+    for (; c < nch; c += 2) {
         pipe_step<TMR, NN>(acc, st, c, nch, K, As, lda, B1, f0, f1, tid, col0, nx, Knext);
         if (c + 1 < nch) pipe_step<TMR, NN>(acc, st, c + 1, nch, K, As, lda, B0, f1, f0, tid, col0, nx, Knext);
     }

@@ -354,6 +354,11 @@ __device__ __forceinline__ void pipe_steady(typename Tile<TMR>::Acc &acc, Stage 
     __syncthreads();
     Tile<TMR>::template read<NN>(nf, As, lda, nxt, c + 1, tid & 63, col0);
     Tile<TMR>::template mfma_half<NN>(acc, cur, 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // MFMA, LDS read, MFMA, LDS read, ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NN ? 3 : 1, 0);
+    }
 }
 
 // Contract: the caller has staged chunk 0 into B0 (stage_first below), and a barrier since then has made

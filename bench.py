@@ -42,7 +42,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 # note for 16-byte streaming reads + WRITE_SIZE, KiB -> bytes); not collected live, N=10 single-GPU shape only
 TRAFFIC_FUSED_CRITIC_BYTES = (2 * 13165 + 20527) * 1024
 TRAFFIC_DUAL_BYTES = (2 * 13067 + 10403) * 1024  # merged actor + ensemble-Q forward launch (profiles/r1_final_kernel_stats.md)
-TRAFFIC_CHAIN_BYTES = (2 * 19357 + 20645) * 1024  # chained launch (profiles/r1_final_kernel_stats.md)
+TRAFFIC_CHAIN_BYTES = (2 * 18909 + 20647) * 1024  # chained launch (profiles/r1_final_kernel_stats.md)
 TRAFFIC_FWD_BYTES = None  # the two-launch form (SSAC_SPLIT_FORWARD=1) has no PMC pass yet
 
 

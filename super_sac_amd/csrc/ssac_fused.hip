@@ -346,9 +346,9 @@ __device__ __forceinline__ void pipe_steady(typename Tile<TMR>::Acc &acc, Stage 
     Tile<TMR>::template mfma_half<NN>(acc, cur, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {  // MFMA, LDS write, MFMA, global load
-        __builtin_amdgcn_sched_group_barrier(0x008, TMR == 32 ? 1 : 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, TMR == 32 ? 1 : 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
     __syncthreads();
@@ -619,18 +619,34 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
             const bool ok = xrok[j] && xk < IN;
             xs[r * ldx_s + xk] = ok ? xv[j] : 0.0f;
             if (ok && outp) outp[(int64_t)(m0 + r) * ldo_g + xk] = xv[j];
-            for (int k = xk + 32; k < KP; k += 32) {  // inputs wider than 32 columns
-                const bool okk = xrok[j] && k < IN;
-                float v;
-                if (gidx) {
-                    const float *ar = g.gth.act + gsrc[j] * g.gth.a_elems - Sg;
-                    v = (k < Sg ? xrow[j] : ar)[okk ? k : (k < Sg ? 0 : Sg)];
-                } else {
-                    v = xrow[j][okk ? k : 0];
+        }
+        // inputs wider than 32 columns: four column passes of every row in flight at a time
+        for (int k0 = xk + 32; k0 < KP; k0 += 128) {
+            float wv[XR][4];
+#pragma unroll
+            for (int j = 0; j < XR; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + 32 * u;
+                    const bool okk = xrok[j] && k < IN;
+                    if (gidx) {
+                        const float *ar = g.gth.act + gsrc[j] * g.gth.a_elems - Sg;
+                        wv[j][u] = (k < Sg ? xrow[j] : ar)[okk ? k : (k < Sg ? 0 : Sg)];
+                    } else {
+                        wv[j][u] = xrow[j][okk ? k : 0];
+                    }
                 }
-                xs[r * ldx_s + k] = okk ? v : 0.0f;
-                if (okk && outp) outp[(int64_t)(m0 + r) * ldo_g + k] = v;
-            }
+#pragma unroll
+            for (int j = 0; j < XR; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + 32 * u, r = xr0 + 16 * j;
+                    if (k < KP) {
+                        const bool okk = xrok[j] && k < IN;
+                        xs[r * ldx_s + k] = okk ? wv[j][u] : 0.0f;
+                        if (okk && outp) outp[(int64_t)(m0 + r) * ldo_g + k] = wv[j][u];
+                    }
+                }
         }
         if (gidx && actor_half && tid < TMR && (m0 + tid) < g.n_rows) {
             const int64_t src = gidx[m0 + tid];

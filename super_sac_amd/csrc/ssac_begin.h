@@ -21,19 +21,18 @@ __device__ __forceinline__ const uint32_t *feed_slot(const ssac_feed &f) {
 // slot -> fixed device block (read by the later launches of the update).  16 bytes per lane and every load issued
 // before the first store (slot_words % 4 == 0 and 16-byte aligned slots are the host's contract).
 __device__ __forceinline__ void feed_pull(const ssac_feed &f) {
-    const uint4 *s4 = reinterpret_cast<const uint4 *>(feed_slot(f));
-    uint4 *d4 = reinterpret_cast<uint4 *>(f.dst);
+    // (native vector type and predicated stores of named values: with HIP's uint4 struct in an array the compiler
+    // kept the staged values in scratch memory, which made every kernel that inlines this a scratch user)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 *s4 = reinterpret_cast<const u32x4 *>(feed_slot(f));
+    u32x4 *d4 = reinterpret_cast<u32x4 *>(f.dst);
     const int n4 = f.slot_words >> 2;
-    uint4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int i = threadIdx.x + u * blockDim.x;
-        v[u] = s4[i < n4 ? i : 0];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int i = threadIdx.x + u * blockDim.x;
-        if (i < n4) d4[i] = v[u];
-    }
-    for (int i = 4 * blockDim.x + threadIdx.x; i < n4; i += blockDim.x) d4[i] = s4[i];
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int i0 = t, i1 = t + nt, i2 = t + 2 * nt, i3 = t + 3 * nt;
+    const u32x4 v0 = s4[i0 < n4 ? i0 : 0], v1 = s4[i1 < n4 ? i1 : 0], v2 = s4[i2 < n4 ? i2 : 0], v3 = s4[i3 < n4 ? i3 : 0];
+    if (i0 < n4) d4[i0] = v0;
+    if (i1 < n4) d4[i1] = v1;
+    if (i2 < n4) d4[i2] = v2;
+    if (i3 < n4) d4[i3] = v3;
+    for (int i = 4 * nt + t; i < n4; i += nt) d4[i] = s4[i];
 }

@@ -1,7 +1,25 @@
 #!/bin/bash
 # Build libssac_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+# Each .hip is compiled to build/<name>.o (in parallel, only when it or a header changed), then linked.
 set -e
 cd "$(dirname "$0")"
+SRC=super_sac_amd/csrc
+OBJ=build/obj
+mkdir -p "$OBJ"
 # -ffp-contract=off: keep fp32 op boundaries as the reference's separate torch ops have them
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC -Iinclude -Isuper_sac_amd/csrc \
-    -o super_sac_amd/libssac_hip.so super_sac_amd/csrc/*.hip "$@"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Iinclude -I$SRC $*"
+newest_hdr=$(ls -t include/*.h $SRC/*.h build.sh | head -1)
+pids=()
+objs=()
+for f in $SRC/*.hip; do
+    o="$OBJ/$(basename "${f%.hip}").o"
+    objs+=("$o")
+    if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$newest_hdr" -nt "$o" ]; then
+        hipcc $FLAGS -c "$f" -o "$o" &
+        pids+=($!)
+    fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+if [ ${#pids[@]} -gt 0 ] || [ ! -f super_sac_amd/libssac_hip.so ]; then
+    hipcc --offload-arch=gfx950 -shared -fPIC -o super_sac_amd/libssac_hip.so "${objs[@]}"
+fi

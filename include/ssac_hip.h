@@ -374,6 +374,13 @@ int ssac_actor_loss_bwd(const float *q, int n_nets, int n_rows, const float *log
                         const float *log_alpha, int use_entropy, const ssac_popart *popart, int pop,
                         float inv_members, const float *qmin_global, float *dq, float *logs, void *stream);
 
+/* use_baseline (learning.py:359, 401): the objective is the advantage A(s, a_theta) = Q'(s, a_theta) - V(s)
+ * (adv_estimator.py:58-79; V has no gradient): dq as above, logs[0] += -mean(adv - bonus)/E with adv (n_rows) from
+ * ssac_adv_filter on the same actions. */
+int ssac_actor_loss_bwd_adv(const float *q, int n_nets, int n_rows, const float *logp, const float *log_alpha,
+                            int use_entropy, const ssac_popart *popart, int pop, float inv_members,
+                            const float *adv, float *dq, float *logs, void *stream);
+
 /* ---- backward of the tanh-normal head: given dL/da summed from the critics' input
  * gradients dX (n_nets x n_rows x ldx, action columns start at act_col0) and the entropy
  * term alpha/(n_rows*E) * log pi, produce dL/d(out) (n_rows x 2A). */
@@ -406,6 +413,17 @@ int ssac_alpha_update(float *log_alpha, float *adam_m, float *adam_v, ssac_adam_
  * w = sigmoid(-std_unbiased(q) * temp) + 0.5; logs[0..3] = mean,max,min,std(w). */
 int ssac_sunrise_weights(const float *q, int n_members, int n_rows, float temp, float *w, float *logs,
                          void *stream);
+
+/* ---- "softmax" backup weights: learning_utils.py:383-393.  q (n_members x n_rows): member k's critics (min over its
+ * nets) on (s', a'_k ~ pi_k(.|s')) -> w = n_rows * softmax over the BATCH of (-std_unbiased(q) * temp); logs as above. */
+int ssac_softmax_weights(const float *q, int n_members, int n_rows, float temp, float *w, float *logs,
+                         void *stream);
+
+/* ---- agent.Critic.forward(return_min=True) (agent.py:37-38): q (n_nets x n_rows x q_dim) -> elementwise min over
+ * the nets; with act != NULL the column (int)act[b*ld_act] is selected (q.gather(-1, a.long()),
+ * learning_utils.py:375, 389) and out is (n_rows), otherwise out is (n_rows x q_dim). */
+int ssac_ensemble_min_select(const float *q, int n_nets, int n_rows, int q_dim, const float *act, int64_t ld_act,
+                             float *out, void *stream);
 
 /* ---- DrQ augmentations: augmentations.py:214-263 (Drqv2Aug) and :165-204 (DrqAug).
  * src: uint8 or fp32 images (n x c x h x h) gathered through idx (may be NULL = identity);

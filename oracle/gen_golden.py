@@ -235,6 +235,8 @@ def run_case(name, cfg):
             # replicate the host draws the reference is about to make, then rewind
             st, pst = torch.get_rng_state(), random.getstate()
             idxs, epss, noises, subsets, shifts = [], [], [], [], []
+            bw_eps, bw_cat = [], []
+            softmax_w = cfg["weight_type"] == "softmax" and E > 1
             for i in range(E):
                 idxs.append(torch.randint(len(rbuf), (B,)).numpy())
                 if px and px["aug"] == "drqv2":
@@ -244,6 +246,16 @@ def run_case(name, cfg):
                 if cfg["noise"]:
                     noises.append(torch.randn(B, cfg["act"]))
                 subsets.append(random.sample(range(N), k=cfg["n"]))
+                if softmax_w:
+                    # learning_utils.py:383-393: every member's actor samples a' on THIS member's s' batch
+                    assert not px, "softmax cases use vector observations"
+                    if cfg["discrete"]:
+                        with torch.no_grad():
+                            s1_rep = rt.encoder({"obs": torch.from_numpy(s1["obs"][idxs[-1]]).float()})
+                            bw_cat.append([ra.actors[k_](s1_rep).sample() for k_ in range(E)])
+                    else:
+                        bw_eps.append([torch.randn(B, cfg["act"]) for _ in range(E)])
+            gpick = random.choice(range(E))  # random.choice(agent.critics), learning.py:135
             torch.set_rng_state(st)
             random.setstate(pst)
 
@@ -264,7 +276,15 @@ def run_case(name, cfg):
                 cfg["n"], cfg["temp"], cfg["weight_type"], cfg["pop"], o_aug, aug_mix=aug_mix,
                 noise_scale=nscale, noise_clip=nclip, idx_list=idxs,
                 eps_list=epss if stochastic else None,
-                noise_list=noises if cfg["noise"] else None, subset_list=subsets)
+                noise_list=noises if cfg["noise"] else None, subset_list=subsets,
+                bw_eps_list=bw_eps or None, bw_cat_list=bw_cat or None, grad_pick=gpick)
+            rec[f"u{upd}_gpick"] = np.int64(gpick)
+            for i in range(E):
+                for k_ in range(E if softmax_w else 0):
+                    if cfg["discrete"]:
+                        rec[f"u{upd}_cat{i}_{k_}"] = bw_cat[i][k_].numpy().astype(np.int64)
+                    else:
+                        rec[f"u{upd}_bweps{i}_{k_}"] = bw_eps[i][k_].numpy()
             for i in range(E):
                 assert np.array_equal(rdicts[i]["priority_idxs"], idxs[i]), "index stream mismatch"
                 dtd = float((captured[i] - odicts[i]["td_target"]).abs().max())
@@ -279,8 +299,6 @@ def run_case(name, cfg):
                     rec[f"u{upd}_noise{i}"] = noises[i].numpy()
                 rec[f"u{upd}_td{i}"] = captured[i].numpy()
             for key, val in rlogs.items():
-                if key.startswith("gradients/"):
-                    continue
                 v = float(val)
                 rec[f"u{upd}_log:{key}"] = np.float64(v)
                 dv = abs(v - float(ologs[key]))
@@ -307,30 +325,41 @@ def run_case(name, cfg):
             upd += 1
 
         # online actor update on the last critic batch (main.py:489-511)
-        st = torch.get_rng_state()
-        aeps, anoise = [], []
+        st, pst = torch.get_rng_state(), random.getstate()
+        aeps, anoise, abase = [], [], []
+        use_baseline = bool(cfg.get("use_baseline", False))
         for i in range(E):
             if not cfg["discrete"]:
                 aeps.append(torch.randn(B, cfg["act"]))
             if cfg["noise"]:
                 anoise.append(torch.randn(B, cfg["act"]))
+            if use_baseline:  # adv_estimator.py:58-64: 4 policy samples for V(s), drawn after the rsample
+                abase.append([torch.randn(B, cfg["act"]) for _ in range(4)])
+        apick = random.choice(range(E))  # random.choice(agent.actors), learning.py:417-419
         torch.set_rng_state(st)
+        random.setstate(pst)
         ralogs = rl.online_actor_update(
             buffer=rbuf, agent=ra, pop=cfg["pop"], actor_optimizer=r_aopt, log_alphas=r_las,
             batch_size=B, aug_mix=0.0, clip=cfg["clip"], augmenter=r_aug, per=False,
             discrete=cfg["discrete"], random_process=rproc, noise_clip=nclip,
-            premade_replay_dicts=rdicts, use_baseline=False)
+            premade_replay_dicts=rdicts, use_baseline=use_baseline)
         oalogs = orc.online_actor_update(oa, o_aopt, o_las, odicts, cfg["pop"], cfg["clip"],
                                          eps_list=aeps if aeps else None, noise_scale=nscale,
-                                         noise_clip=nclip, noise_list=anoise if anoise else None)
+                                         noise_clip=nclip, noise_list=anoise if anoise else None,
+                                         use_baseline=use_baseline, base_eps_lists=abase or None,
+                                         grad_pick=apick)
+        rec[f"a{cyc}_gpick"] = np.int64(apick)
         for i in range(E):
             if aeps:
                 rec[f"a{cyc}_eps{i}"] = aeps[i].numpy()
             if anoise:
                 rec[f"a{cyc}_noise{i}"] = anoise[i].numpy()
-        v = float(ralogs["losses/actor_pg_loss"])
-        rec[f"a{cyc}_log:losses/actor_pg_loss"] = np.float64(v)
-        assert abs(v - oalogs["losses/actor_pg_loss"]) <= 2e-4 * max(1.0, abs(v)), (v, oalogs)
+            if use_baseline:
+                rec[f"a{cyc}_base{i}"] = torch.stack(abase[i]).numpy()
+        for key, val in ralogs.items():
+            v = float(val)
+            rec[f"a{cyc}_log:{key}"] = np.float64(v)
+            assert abs(v - oalogs[key]) <= 2e-4 * max(1.0, abs(v)), (key, v, oalogs)
 
         if cfg["init_alpha"] > 0 and cfg["alpha_lr"] > 0:
             st = torch.get_rng_state()
@@ -673,9 +702,8 @@ def run_afbc_case(name, cfg):
             rec[f"s{k}_subset"] = np.array(sub, np.int64)
             rec[f"s{k}_prio_eps"], rec[f"s{k}_prio"], rec[f"s{k}_leaves"] = torch.stack(peps).numpy(), oprio, leaves
             for key, val in rlogs.items():
-                if not key.startswith("gradients/"):
-                    rec[f"s{k}_log:{key}"] = np.float64(float(val))
-                    assert abs(float(val) - float(ologs[key])) <= 2e-4 * max(1.0, abs(float(val))), key
+                rec[f"s{k}_log:{key}"] = np.float64(float(val))
+                assert abs(float(val) - float(ologs[key])) <= 2e-4 * max(1.0, abs(float(val))), key
             continue
         per, filt = step
         # replicate the host draws the reference is about to make, then rewind
@@ -716,8 +744,6 @@ def run_afbc_case(name, cfg):
                 rec[f"s{k}_eps"] = torch.stack(eps).numpy()
             rec[f"s{k}_adv"] = advs[0].numpy()
         for key, val in rlogs.items():
-            if key.startswith("gradients/"):
-                continue
             v = float(val)
             rec[f"s{k}_log:{key}"] = np.float64(v)
             assert abs(v - float(ologs[key])) <= 2e-4 * max(1.0, abs(v)), (key, v, ologs[key])

@@ -732,7 +732,7 @@ def compute_td_targets(logs, batch, agent, target_agent, i, subset_ids, log_alph
 # a11: SUNRISE / softmax backup weights.  learning_utils.py:357-398
 # --------------------------------------------------------------------------------------
 def compute_backup_weights(logs, batch, agent, target_agent, weight_type, temp, batch_size,
-                           eps_list=None):
+                           eps_list=None, cat_list=None):
     if weight_type is None or temp is None or agent.E == 1:
         return 1.0
     o, a, _, o1, _ = batch
@@ -750,7 +750,12 @@ def compute_backup_weights(logs, batch, agent, target_agent, weight_type, temp, 
             for k, (actor, crit) in enumerate(zip(agent.actors, agent.critics)):
                 out = mlp3(actor, s1)[0]
                 if agent.discrete:
-                    raise NotImplementedError("softmax weights, discrete: Categorical.sample stream")
+                    # a1 = Categorical(logits).sample() (learning_utils.py:388): torch.multinomial stream, so the
+                    # fixtures record the sampled actions (cat_list) instead of the raw draws
+                    a1 = (torch.distributions.Categorical(logits=out).sample() if cat_list is None
+                          else cat_list[k])
+                    qs.append(ensemble_q(crit, s1, None).gather(-1, a1.long().view(-1, 1)))
+                    continue
                 e = torch.randn(out.shape[0], out.shape[1] // 2) if eps_list is None else eps_list[k]
                 a1, _ = tanh_normal_sample(out, agent.lo, agent.hi, e)
                 qs.append(ensemble_q(crit, s1, a1))
@@ -768,7 +773,8 @@ def compute_backup_weights(logs, batch, agent, target_agent, weight_type, temp, 
 def critic_update(buffer, agent, target_agent, critic_opt, encoder_opt, log_alphas, batch_size, gamma,
                   critic_clip, encoder_clip, target_n, temp, weight_type, pop, augmenter,
                   aug_mix=0.0, noise_scale=None, noise_clip=None, py_rng=_pyrandom,
-                  idx_list=None, eps_list=None, noise_list=None, subset_list=None, dr3_coeff=0.0):
+                  idx_list=None, eps_list=None, noise_list=None, subset_list=None, dr3_coeff=0.0,
+                  bw_eps_list=None, bw_cat_list=None, grad_pick=None):
     """One gradient update of every critic of every ensemble member.
     dr3_coeff > 0 adds the DR3 feature co-adaptation term (learning.py:100-108): the fc2 features of every critic
     on (s, a) dotted with its features on (s', a'), mean over critics and batch -- inside the member loop, i.e.
@@ -797,7 +803,8 @@ def critic_update(buffer, agent, target_agent, critic_opt, encoder_opt, log_alph
                                           log_alphas[i], pop, gamma, eps=eps, noise_scale=noise_scale,
                                           noise_clip=noise_clip, noise=noise)
         w = compute_backup_weights(logs, (o, a, r, o1, d), agent, target_agent, weight_type, temp,
-                                   batch_size)
+                                   batch_size, eps_list=None if bw_eps_list is None else bw_eps_list[i],
+                                   cat_list=None if bw_cat_list is None else bw_cat_list[i])
         s = encode(agent.encoder, o)
         for p in agent.critics[i]:
             q = critic_q(p, s, None if agent.discrete else a)
@@ -830,6 +837,10 @@ def critic_update(buffer, agent, target_agent, critic_opt, encoder_opt, log_alph
     critic_opt.step()
     logs["losses/last_member_critic_td_error"] = td_error.mean().item()
     logs["losses/critic_overall_loss"] = loss.item()
+    # learning.py:135-137: gradient norm (after clipping) of a random.choice'd member's critics, and of the encoder
+    pick = py_rng.choice(range(agent.E)) if grad_pick is None else grad_pick
+    logs["gradients/critic_random_grad"] = grad_norm([c[k] for c in agent.critics[pick] for k in MLP_KEYS])
+    logs["gradients/encoder_criticloss_grad_norm"] = grad_norm(agent.encoder_params())
     return logs, dicts
 
 
@@ -837,7 +848,10 @@ def critic_update(buffer, agent, target_agent, critic_opt, encoder_opt, log_alph
 # a14: online actor update.  learning.py:344-421
 # --------------------------------------------------------------------------------------
 def online_actor_update(agent, actor_opt, log_alphas, dicts, pop, clip, eps_list=None,
-                        noise_scale=None, noise_clip=None, noise_list=None):
+                        noise_scale=None, noise_clip=None, noise_list=None, use_baseline=False,
+                        base_eps_lists=None, grad_pick=None, py_rng=_pyrandom):
+    """use_baseline (learning.py:401): vals = A(s, a) = Q(s, a) - V(s) from the advantage estimator (4 fresh policy
+    samples, adv_estimator.py:58-79; its ``pop`` applies the PopArt layer whenever the member has one)."""
     logs = {}
     total = 0.0
     for i in range(agent.E):
@@ -874,9 +888,13 @@ def online_actor_update(agent, actor_opt, log_alphas, dicts, pop, clip, eps_list
                 if logp is None:
                     logp = (-(e ** 2) / 2.0 - math.log(1e-4) - LOG_2PI_HALF).sum(-1, keepdim=True)
                 bonus = log_alphas[i].exp() * logp
-            vals = ensemble_q(agent.critics[i], s, a)  # min over ALL critics (learning.py:402)
-            if popart and pop:
-                vals = popart(vals)
+            if use_baseline:
+                vals = advantage(agent, o, a, i, None if base_eps_lists is None else base_eps_lists[i],
+                                 grad=True)
+            else:
+                vals = ensemble_q(agent.critics[i], s, a)  # min over ALL critics (learning.py:402)
+                if popart and pop:
+                    vals = popart(vals)
         total = total + (vals - bonus).mean()
     loss = -total / agent.E
     actor_opt.zero_grad()
@@ -884,6 +902,8 @@ def online_actor_update(agent, actor_opt, log_alphas, dicts, pop, clip, eps_list
     if clip:
         clip_grad_norm(agent.actor_params(), clip)
     actor_opt.step()
+    pick = py_rng.choice(range(agent.E)) if grad_pick is None else grad_pick  # learning.py:417-419
+    logs["gradients/random_actor_online_grad"] = grad_norm([agent.actors[pick][k] for k in MLP_KEYS])
     logs["losses/actor_pg_loss"] = loss.item()
     return logs
 
@@ -956,7 +976,7 @@ def _pop_q(agent, i, s, a):
     return agent.popart[i](q) if agent.popart[i] else q
 
 
-def advantage(agent, o, a, i, eps_list=None, method="mean", n=4):
+def advantage(agent, o, a, i, eps_list=None, method="mean", n=4, grad=False):
     """A(s,a) = Q(s,a) - V(s).  Continuous: V from n sampled policy actions (eps_list: the n (B,A) normal
     draws, in order).  Discrete: V = sum_a mean_members(pi)(a) * Q(s)_a, Q(s,a) by gather."""
     with torch.no_grad():
@@ -974,6 +994,10 @@ def advantage(agent, o, a, i, eps_list=None, method="mean", n=4):
             qs.append(_pop_q(agent, i, s, act))
         qs = torch.stack(qs, 0)
         value = qs.mean(0) if method == "mean" else qs.max(0).values
+    # Q(s, a) is evaluated OUTSIDE no_grad (adv_estimator.py:76): the use_baseline actor update differentiates it
+    if grad:
+        return _pop_q(agent, i, s, a) - value
+    with torch.no_grad():
         return _pop_q(agent, i, s, a) - value
 
 
@@ -1030,6 +1054,9 @@ def offline_actor_update(buffer, per_tree, agent, actor_opt, batch_size, actor_c
         clip_grad_norm(agent.actor_params(), actor_clip)
     actor_opt.step()
     logs["losses/filtered_bc_overall_loss"] = loss.item()
+    # learning.py:209-214 (all AFBC fixtures have one member: the random.choice pick is member 0)
+    logs["gradients/actor_offline_grad_norm"] = grad_norm([agent.actors[0][k] for k in MLP_KEYS])
+    logs["gradients/encoder_offline_actorloss_grad_norm"] = grad_norm(agent.encoder_params())
     new_prio = None
     if per:
         import random as _random

@@ -108,11 +108,14 @@ SIGNATURES = {
     "ssac_adv_filter": [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P],
     "ssac_bc_logprob_bwd": [_P, _L, _P, _L, _P, _I, _I, _F, _F, _F, _P, _L, _P, _P, _P],
     "ssac_actor_loss_bwd": [_P, _I, _I, _P, _P, _I, _P, _I, _F, _P, _P, _P, _P],
+    "ssac_actor_loss_bwd_adv": [_P, _I, _I, _P, _P, _I, _P, _I, _F, _P, _P, _P, _P],
     "ssac_tanh_normal_bwd": [_P, _I, _L, _L, _L, _P, _L, _P, _I, _I, _F, _F, _P, _I, _F, _P, _L, _P],
     "ssac_det_action_bwd": [_P, _I, _L, _L, _L, _P, _L, _I, _I, _P, _L, _P],
     "ssac_discrete_actor_loss_bwd": [_P, _P, _I, _I, _I, _P, _P, _I, _F, _P, _P, _P],
     "ssac_alpha_update": [_P, _P, _P, _P, _P, _I, _I, _F, _P, _P],
     "ssac_sunrise_weights": [_P, _I, _I, _F, _P, _P, _P],
+    "ssac_softmax_weights": [_P, _I, _I, _F, _P, _P, _P],
+    "ssac_ensemble_min_select": [_P, _I, _I, _I, _P, _L, _P, _P],
     "ssac_drq_shift": [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _P, _P],
     "ssac_zero": [_P, _L, _P],
     "ssac_im2col": [_P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P],

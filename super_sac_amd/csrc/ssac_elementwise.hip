@@ -523,7 +523,7 @@ __global__ __launch_bounds__(RED_THREADS) void actor_loss_bwd_kernel(
     const float *__restrict__ q, int n_nets, int n_rows, const float *__restrict__ logp,
     const float *__restrict__ log_alpha, int use_entropy, const ssac_popart *popart, int pop,
     float inv_members, const float *__restrict__ qmin_global, float *__restrict__ dq,
-    float *__restrict__ logs) {
+    float *__restrict__ logs, const float *__restrict__ adv) {
     __shared__ float scratch[16];
     const float pw = (popart && pop) ? popart->w : 1.0f;
     const float pb = (popart && pop) ? popart->b : 0.0f;
@@ -546,7 +546,8 @@ __global__ __launch_bounds__(RED_THREADS) void actor_loss_bwd_kernel(
         }
         for (int j = 0; j < n_nets; ++j) dq[(int64_t)j * n_rows + b] = (j == am) ? gq : 0.0f;
         const float bonus = use_entropy ? alpha * logp[b] : 0.0f;
-        s += (pw * mq + pb) - bonus;
+        // use_baseline (learning.py:401): the objective is the advantage A = Q' - V(s); V carries no gradient
+        s += (adv ? adv[b] : (pw * mq + pb)) - bonus;
     }
     const float tot = block_reduce<0>(s, scratch);
     if (threadIdx.x == 0 && logs) logs[0] += -inv_members * tot / (float)n_rows;
@@ -757,6 +758,68 @@ __global__ __launch_bounds__(RED_THREADS) void sunrise_weights_kernel(const floa
     const float var = block_reduce<0>(sv, scratch) / (float)(n_rows > 1 ? n_rows - 1 : 1);
     if (threadIdx.x == 0 && logs) {
         logs[0] = mean; logs[1] = mx; logs[2] = mn; logs[3] = sqrtf(var);
+    }
+}
+
+// "softmax" backup weights (learning_utils.py:383-393): w = n_rows * softmax_b(-std_k(q[k][b]) * temp)  (dim 0 = batch)
+__global__ __launch_bounds__(RED_THREADS) void softmax_weights_kernel(const float *__restrict__ q, int E, int n_rows,
+                                                                      float temp, float *__restrict__ w,
+                                                                      float *__restrict__ logs) {
+    __shared__ float scratch[16];
+    float xm = -INFINITY;
+    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+        float m = 0.f;
+        for (int k = 0; k < E; ++k) m += q[(int64_t)k * n_rows + b];
+        m /= (float)E;
+        float var = 0.f;
+        for (int k = 0; k < E; ++k) {
+            const float d = q[(int64_t)k * n_rows + b] - m;
+            var += d * d;
+        }
+        const float x = -sqrtf(var / (float)(E - 1)) * temp;
+        w[b] = x;  // logits, normalised below
+        xm = fmaxf(xm, x);
+    }
+    xm = block_reduce<1>(xm, scratch);
+    float se = 0.f;
+    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+        const float ev = expf(w[b] - xm);
+        w[b] = ev;
+        se += ev;
+    }
+    se = block_reduce<0>(se, scratch);
+    float s = 0.f, mx = -INFINITY, mn = INFINITY;
+    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+        const float wv = (float)n_rows * (w[b] / se);
+        w[b] = wv;
+        s += wv;
+        mx = fmaxf(mx, wv);
+        mn = fminf(mn, wv);
+    }
+    const float mean = block_reduce<0>(s, scratch) / (float)n_rows;
+    mx = block_reduce<1>(mx, scratch);
+    mn = block_reduce<2>(mn, scratch);
+    float sv = 0.f;
+    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
+        const float d = w[b] - mean;
+        sv += d * d;
+    }
+    const float var = block_reduce<0>(sv, scratch) / (float)(n_rows > 1 ? n_rows - 1 : 1);
+    if (threadIdx.x == 0 && logs) {
+        logs[0] = mean; logs[1] = mx; logs[2] = mn; logs[3] = sqrtf(var);
+    }
+}
+
+// out[b] = min_j q[j][b][sel_b], sel_b = (int)act[b*ld_act] (q_dim > 1 with act) -- agent.Critic.forward(return_min=True)
+// (agent.py:37-38) followed by .gather(-1, a.long()) (learning_utils.py:375, 389); act == null: out is (n_rows x q_dim)
+__global__ void ensemble_min_select_kernel(const float *__restrict__ q, int n_nets, int n_rows, int q_dim,
+                                           const float *__restrict__ act, int64_t ld_act, float *__restrict__ out) {
+    const int n_out = act ? n_rows : n_rows * q_dim;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += gridDim.x * blockDim.x) {
+        const int64_t e = act ? (int64_t)i * q_dim + (q_dim > 1 ? (int)act[(int64_t)i * ld_act] : 0) : i;
+        float m = q[e];
+        for (int j = 1; j < n_nets; ++j) m = fminf(m, q[(int64_t)j * n_rows * q_dim + e]);
+        out[i] = m;
     }
 }
 
@@ -1012,8 +1075,19 @@ extern "C" int ssac_actor_loss_bwd(const float *q, int n_nets, int n_rows, const
                                    float *logs, void *stream) {
     if (n_nets < 1 || n_rows < 1) return ssac_fail("ssac_actor_loss_bwd: bad sizes");
     SSAC_LAUNCH(actor_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_nets, n_rows, logp,
-                       log_alpha, use_entropy, popart, pop, inv_members, qmin_global, dq, logs);
+                       log_alpha, use_entropy, popart, pop, inv_members, qmin_global, dq, logs,
+                       (const float *)nullptr);
     return ssac_check_launch("actor_loss_bwd");
+}
+
+extern "C" int ssac_actor_loss_bwd_adv(const float *q, int n_nets, int n_rows, const float *logp,
+                                       const float *log_alpha, int use_entropy, const ssac_popart *popart,
+                                       int pop, float inv_members, const float *adv, float *dq, float *logs,
+                                       void *stream) {
+    if (n_nets < 1 || n_rows < 1 || !adv) return ssac_fail("ssac_actor_loss_bwd_adv: bad arguments");
+    SSAC_LAUNCH(actor_loss_bwd_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_nets, n_rows, logp,
+                       log_alpha, use_entropy, popart, pop, inv_members, (const float *)nullptr, dq, logs, adv);
+    return ssac_check_launch("actor_loss_bwd_adv");
 }
 
 extern "C" int ssac_tanh_normal_bwd(const float *dX, int n_nets, int64_t ldx, int64_t x_net_stride,
@@ -1123,6 +1197,23 @@ extern "C" int ssac_sunrise_weights(const float *q, int n_members, int n_rows, f
     SSAC_LAUNCH(sunrise_weights_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_members, n_rows,
                        temp, w, logs);
     return ssac_check_launch("sunrise_weights");
+}
+
+extern "C" int ssac_softmax_weights(const float *q, int n_members, int n_rows, float temp, float *w,
+                                    float *logs, void *stream) {
+    if (n_members < 2 || n_rows < 1) return ssac_fail("ssac_softmax_weights: bad sizes");
+    SSAC_LAUNCH(softmax_weights_kernel, dim3(1), dim3(RED_THREADS), 0, ST, q, n_members, n_rows, temp, w, logs);
+    return ssac_check_launch("softmax_weights");
+}
+
+extern "C" int ssac_ensemble_min_select(const float *q, int n_nets, int n_rows, int q_dim, const float *act,
+                                        int64_t ld_act, float *out, void *stream) {
+    if (!q || !out || n_nets < 1 || q_dim < 1) return ssac_fail("ssac_ensemble_min_select: bad arguments");
+    if (n_rows <= 0) return 0;
+    const int64_t n_out = act ? n_rows : (int64_t)n_rows * q_dim;
+    SSAC_LAUNCH(ensemble_min_select_kernel, dim3(grid_for(n_out, 256, 1024)), dim3(256), 0, ST, q, n_nets, n_rows,
+                q_dim, act, ld_act, out);
+    return ssac_check_launch("ensemble_min_select");
 }
 
 extern "C" int ssac_drq_shift(const void *src, int src_dtype, const int64_t *idx, int n, int c, int h,

@@ -359,6 +359,10 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
     member_ss = []
     fused_logs = []
     logs_done_in_wgrad = False
+    # Two passes over the ensemble members, as the reference's single backward at the end implies (learning.py:45-130):
+    # every member's batch, TD target and backup weights are computed BEFORE any critic is updated -- the "softmax"
+    # weights of member i look at the ONLINE critics of ALL members (learning_utils.py:383-393).
+    preps = []
     for i in range(E):
         arena = agent.critics[i].arena(dev)
         N, qd = arena.n_nets, arena.out_dim
@@ -408,6 +412,21 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
         bw = lu.compute_backup_weights(logs=logs, replay_dict=rd, agent=agent, target_agent=target_agent,
                                        weight_type=weight_type, weight_temp=weighted_bellman_temp,
                                        batch_size=batch_size, discrete=discrete, _slot=slot)
+        preps.append(dict(arena=arena, rd=rd, branch=branch, co=co, td=td, co_done=co_done, bwd_done=bwd_done, bw=bw,
+                          fwd=(h1, h2, q) if (co_done or branch is not None) else None,
+                          xin=(s_rep, X, ldx) if (branch is not None or co is not None) else None))
+    for i, P in enumerate(preps):
+        arena, rd, branch, co, td, co_done, bwd_done, bw = (P[k_] for k_ in ("arena", "rd", "branch", "co", "td",
+                                                                             "co_done", "bwd_done", "bw"))
+        N, qd, H = arena.n_nets, arena.out_dim, arena.hidden
+        tag = f"cu.c{i}"
+        train_enc = not lu.is_identity(agent.encoder)
+        o, a, r, o1, d = rd["primary_batch"]
+        B = r.shape[0]
+        if P["fwd"] is not None:
+            h1, h2, q = P["fwd"]
+        if P["xin"] is not None:
+            s_rep, X, ldx = P["xin"]
         if train_enc:
             # online encoder WITH gradient (learning.py:83): embedding goes straight into the critic input
             assert E == 1, "trainable encoders are supported for ensemble_size == 1"
@@ -604,8 +623,6 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
                         random_process, noise_clip, augmenter, aug_mix, premade_replay_dicts=None,
                         per=False, discrete=False, use_baseline=False):
     engine.require_gpu()
-    if use_baseline:
-        raise NotImplementedError("advantage baseline (AFBC path, SURVEY 8(f) rank 1)")
     E = agent.ensemble_size
     dev = log_alphas[0].device
     ws = lu.agent_ws(agent, dev)
@@ -673,9 +690,20 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
                 lu._min_over_nets(q, N, B, qmin)
                 parallel.all_reduce_min(qmin)
                 qmin_ptr = qmin.data_ptr()
-            check(lib.ssac_actor_loss_bwd(q.data_ptr(), N, B, logp.data_ptr(), log_alpha.data_ptr(),
-                                          use_entropy, pp, dopop, inv_e, qmin_ptr, dq.data_ptr(),
-                                          slot[lu.L_ACTOR_LOSS:].data_ptr(), st))
+            if use_baseline:
+                # learning.py:401: vals = A(s, a_theta) = Q'(s, a_theta) - V(s) from the advantage estimator (four fresh
+                # policy samples, drawn after the rsample; adv_estimator.py:31-36 applies the PopArt layer whenever
+                # the member has one).  V has no gradient: the routing of dL/dq is the plain path's.
+                assert shard is None, "use_baseline is not supported on critic-sharded ranks"
+                res = agent.adv_estimator.evaluate(o, xpi[:, S:], i, want=("adv",))
+                check(lib.ssac_actor_loss_bwd_adv(q.data_ptr(), N, B, logp.data_ptr(), log_alpha.data_ptr(),
+                                                  use_entropy, pp, 1 if popart else 0, inv_e,
+                                                  res["adv"].data_ptr(), dq.data_ptr(),
+                                                  slot[lu.L_ACTOR_LOSS:].data_ptr(), st))
+            else:
+                check(lib.ssac_actor_loss_bwd(q.data_ptr(), N, B, logp.data_ptr(), log_alpha.data_ptr(),
+                                              use_entropy, pp, dopop, inv_e, qmin_ptr, dq.data_ptr(),
+                                              slot[lu.L_ACTOR_LOSS:].data_ptr(), st))
             # dQ/da through the arg-min critic of every row; critic weights are NOT updated here
             dX = engine.mlp_backward(c_arena, dq, xpi, S + A, 0, ch1, ch2, B, ws, f"au.c{i}",
                                      need_dx=True, update=False)

@@ -603,35 +603,67 @@ def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag, co_backward=None, re
 
 def compute_backup_weights(logs, replay_dict, agent, target_agent, weight_type, weight_temp, batch_size,
                            discrete=False, _slot=None):
+    """learning_utils.py:357-398.  "sunrise": sigmoid(-std_k(Qbar_k(s, a)) T) + 0.5 over the members' TARGET critics
+    (discrete: the taken action's column); "softmax": B softmax_b(-std_k(Q_k(s', a'_k)) T) with a'_k sampled from
+    member k's ONLINE actor and scored by member k's ONLINE critics on the target encoder's s'.  Q_k = min over the
+    member's nets (agent.Critic.forward defaults, agent.py:22)."""
     if weight_type is None or weight_temp is None or agent.ensemble_size == 1:
         return 1.0
-    if weight_type != "sunrise":
-        raise NotImplementedError("only SUNRISE backup weights are on the accelerated path")
-    if discrete:
-        raise NotImplementedError("SUNRISE weights with discrete actions")
+    assert weight_type in ("sunrise", "softmax"), f"unknown weight_type {weight_type!r}"
     o, a, _, o1, _ = replay_dict["primary_batch"]
     dev = a.device
     ws = agent_ws(agent, dev)
     slot = _slot if _slot is not None else log_block(dev)
-    s_rep = encode(target_agent.encoder, o)
-    B, S = s_rep.shape
-    A = a.shape[1]
-    bt = replay_dict.get("_ssac")
-    if bt is not None and bt.xsa is not None and s_rep.data_ptr() == bt.xsa.data_ptr():
-        x = bt.xsa
-    else:
-        x = _concat_buffer(ws, "bw.x", s_rep, A)
-        x[:, S:].copy_(a)
+    st = engine.stream()
     E = agent.ensemble_size
-    qmin = ws.get("bw.qmin", (E, B))
-    for k in range(E):
-        ar = target_agent.critics[k].arena(dev)
-        _, _, q = engine.mlp_forward(ar, x, S + A, 0, B, ws, f"bw.c{k}")
-        # min over this member's critics: TD-target kernel's min is reused via torch-free path
-        _min_over_nets(q, ar.n_nets, B, qmin[k])
-    w = torch.empty(B, 1, device=dev)
-    check(lib.ssac_sunrise_weights(qmin.data_ptr(), E, B, float(weight_temp), w.data_ptr(),
-                                   slot[L_BW:].data_ptr(), engine.stream()))
+    bt = replay_dict.get("_ssac")
+    if weight_type == "sunrise":
+        s_rep = encode(target_agent.encoder, o)
+        B, S = s_rep.shape
+        if discrete:
+            x, ldx = s_rep, _row_stride(s_rep)
+        elif bt is not None and bt.xsa is not None and s_rep.data_ptr() == bt.xsa.data_ptr():
+            x, ldx = bt.xsa, bt.xsa.stride(0)
+        else:
+            x = _concat_buffer(ws, "bw.x", s_rep, a.shape[1])
+            x[:, S:].copy_(a)
+            ldx = x.stride(0)
+        qmin = ws.get("bw.qmin", (E, B))
+        for k in range(E):
+            ar = target_agent.critics[k].arena(dev)
+            _, _, q = engine.mlp_forward(ar, x, ldx, 0, B, ws, f"bw.c{k}", save=False)
+            check(lib.ssac_ensemble_min_select(q.data_ptr(), ar.n_nets, B, ar.out_dim,
+                                               a.data_ptr() if discrete else 0, a.stride(0) if discrete else 0,
+                                               qmin[k].data_ptr(), st))
+        w = torch.empty(B, 1, device=dev)
+        check(lib.ssac_sunrise_weights(qmin.data_ptr(), E, B, float(weight_temp), w.data_ptr(),
+                                       slot[L_BW:].data_ptr(), st))
+    else:
+        s1_rep = encode(target_agent.encoder, o1)
+        B, S = s1_rep.shape
+        lds = _row_stride(s1_rep)
+        qmin = ws.get("bw.qmin", (E, B))
+        for k, (actor, critic) in enumerate(agent.ensemble):
+            a_arena = engine.bind_arena(actor, "self", [actor], dev)
+            c_arena = critic.arena(dev)
+            _, _, aout = engine.mlp_forward(a_arena, s1_rep, lds, 0, B, ws, f"bw.a{k}", save=False)
+            if discrete:
+                a1 = rng.draw_categorical(aout[0]).to(torch.float32).view(B, 1)  # actor(s1_rep).sample()
+                _, _, q = engine.mlp_forward(c_arena, s1_rep, lds, 0, B, ws, f"bw.c{k}", save=False)
+                check(lib.ssac_ensemble_min_select(q.data_ptr(), c_arena.n_nets, B, c_arena.out_dim, a1.data_ptr(), 1,
+                                                   qmin[k].data_ptr(), st))
+            else:
+                A = actor.action_size
+                assert actor_kind(actor) == "stochastic", "softmax backup weights sample from a stochastic policy"
+                x1 = _concat_buffer(ws, f"bw.x1.{k}", s1_rep, A)
+                eps = rng.draw_normal((B, A), dev)  # actor(s1_rep).sample()
+                check(lib.ssac_tanh_normal_fwd(aout.data_ptr(), 2 * A, eps.data_ptr(), B, A, float(actor.log_std_low),
+                                               float(actor.log_std_high), x1.data_ptr(), S + A, S, 0, st))
+                _, _, q = engine.mlp_forward(c_arena, x1, S + A, 0, B, ws, f"bw.c{k}", save=False)
+                check(lib.ssac_ensemble_min_select(q.data_ptr(), c_arena.n_nets, B, 1, 0, 0, qmin[k].data_ptr(), st))
+        w = torch.empty(B, 1, device=dev)
+        check(lib.ssac_softmax_weights(qmin.data_ptr(), E, B, float(weight_temp), w.data_ptr(),
+                                       slot[L_BW:].data_ptr(), st))
     for j, nm in enumerate(("mean", "max", "min", "std")):
         logs[f"bellman_weights/{nm}"] = slot[L_BW + j]
     return w

@@ -42,6 +42,12 @@ def normal_is_stock():
     return draw_normal is _stock_draw_normal and draw_normal_into is _stock_draw_normal_into
 
 
+def draw_categorical(logits):
+    """Categorical(logits=logits).sample() on the logits' device (learning_utils.py:386-388, softmax backup weights of
+    a discrete agent): index plumbing on torch's device generator, as the reference draws it."""
+    return torch.distributions.Categorical(logits=logits).sample()
+
+
 def draw_drqv2_shift(batch_size, pad):
     return torch.randint(0, 2 * pad + 1, size=(batch_size, 1, 1, 2))
 

@@ -116,7 +116,12 @@ def run_oracle(name):
                 noise_clip=nclip, idx_list=[fx[f"u{upd}_idx{i}"] for i in range(E)],
                 eps_list=[T(f"u{upd}_eps{i}") for i in range(E)] if stochastic else None,
                 noise_list=[T(f"u{upd}_noise{i}") for i in range(E)] if cfg["noise"] else None,
-                subset_list=[list(fx[f"u{upd}_subset{i}"]) for i in range(E)])
+                subset_list=[list(fx[f"u{upd}_subset{i}"]) for i in range(E)],
+                bw_eps_list=([[T(f"u{upd}_bweps{i}_{k_}") for k_ in range(E)] for i in range(E)]
+                             if f"u{upd}_bweps0_0" in fx else None),
+                bw_cat_list=([[T(f"u{upd}_cat{i}_{k_}") for k_ in range(E)] for i in range(E)]
+                             if f"u{upd}_cat0_0" in fx else None),
+                grad_pick=int(fx[f"u{upd}_gpick"]))
             for i in range(E):
                 rec[f"u{upd}_td{i}"] = dicts[i]["td_target"].numpy()
                 if cfg["popart"]:
@@ -134,8 +139,13 @@ def run_oracle(name):
             oa, aopt, las, dicts, cfg["pop"], cfg["clip"],
             eps_list=[T(f"a{cyc}_eps{i}") for i in range(E)] if have_eps else None,
             noise_scale=nscale, noise_clip=nclip,
-            noise_list=[T(f"a{cyc}_noise{i}") for i in range(E)] if cfg["noise"] else None)
-        rec[f"a{cyc}_log:losses/actor_pg_loss"] = np.float64(alog["losses/actor_pg_loss"])
+            noise_list=[T(f"a{cyc}_noise{i}") for i in range(E)] if cfg["noise"] else None,
+            use_baseline=bool(cfg.get("use_baseline", False)),
+            base_eps_lists=([[torch.from_numpy(e) for e in fx[f"a{cyc}_base{i}"]] for i in range(E)]
+                            if cfg.get("use_baseline") else None),
+            grad_pick=int(fx[f"a{cyc}_gpick"]))
+        for key, val in alog.items():
+            rec[f"a{cyc}_log:{key}"] = np.float64(val)
         if cfg["init_alpha"] > 0 and cfg["alpha_lr"] > 0:
             llog = orc.alpha_update(oa, lopts, las, dicts, _target_entropy(cfg),
                                     eps_list=[T(f"l{cyc}_eps{i}") for i in range(E)] if stochastic else None)
@@ -167,9 +177,14 @@ class DrawPlayer:
     def __init__(self, device):
         self.device = device
         self.idx, self.sub, self.normal, self.shift = [], [], [], []
+        self.picks, self.cats = [], []
 
     def install(self, rng_mod):
         self._saved = (rng_mod.draw_indices, rng_mod.draw_subset, rng_mod.draw_normal)
+        self._saved_choice, self._saved_cat = rng_mod.choice, rng_mod.draw_categorical
+        # random.choice(agent.critics / agent.actors) of the gradient-norm logs: the recorded pick when one is queued
+        rng_mod.choice = lambda seq: seq[self.picks.pop(0)] if self.picks else random.choice(seq)
+        rng_mod.draw_categorical = lambda logits: torch.from_numpy(self.cats.pop(0)).to(self.device)
         self._saved_shift = rng_mod.draw_drqv2_shift
         rng_mod.draw_drqv2_shift = lambda b, pad: torch.from_numpy(self.shift.pop(0))
         self._saved_into = rng_mod.draw_normal_into
@@ -184,6 +199,7 @@ class DrawPlayer:
         m.draw_indices, m.draw_subset, m.draw_normal = self._saved
         m.draw_drqv2_shift = self._saved_shift
         m.draw_normal_into = self._saved_into
+        m.choice, m.draw_categorical = self._saved_choice, self._saved_cat
 
 
 def build_engine_agent(cfg, device, shard=None):
@@ -295,6 +311,13 @@ def run_engine(name, device="cuda", shard=None):
                     if cfg["noise"]:
                         player.normal.append(fx[f"u{upd}_noise{i}"])
                     player.sub.append(fx[f"u{upd}_subset{i}"])
+                    for k_ in range(E):  # "softmax" backup weights: every member's actor samples a' (lu:383-393)
+                        if f"u{upd}_bweps{i}_{k_}" in fx:
+                            player.normal.append(fx[f"u{upd}_bweps{i}_{k_}"])
+                        if f"u{upd}_cat{i}_{k_}" in fx:
+                            player.cats.append(fx[f"u{upd}_cat{i}_{k_}"])
+                if shard is None:
+                    player.picks.append(int(fx[f"u{upd}_gpick"]))
                 logs, dicts = ssa.learning.critic_update(
                     buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt,
                     encoder_optimizer=eopt, log_alphas=las, batch_size=B, gamma=cfg["gamma"],
@@ -322,12 +345,16 @@ def run_engine(name, device="cuda", shard=None):
                     player.normal.append(fx[f"a{cyc}_eps{i}"])
                 if cfg["noise"]:
                     player.normal.append(fx[f"a{cyc}_noise{i}"])
+                if cfg.get("use_baseline"):
+                    player.normal.extend(list(fx[f"a{cyc}_base{i}"]))
+            player.picks.append(int(fx[f"a{cyc}_gpick"]))
             alog = ssa.learning.online_actor_update(
                 buffer=buf, agent=agent, pop=cfg["pop"], actor_optimizer=aopt, log_alphas=las,
                 batch_size=B, aug_mix=aug_mix, clip=cfg["clip"], augmenter=aug, per=False,
                 discrete=cfg["discrete"], random_process=rproc, noise_clip=nclip,
-                premade_replay_dicts=dicts, use_baseline=False)
-            rec[f"a{cyc}_log:losses/actor_pg_loss"] = np.float64(float(alog["losses/actor_pg_loss"]))
+                premade_replay_dicts=dicts, use_baseline=bool(cfg.get("use_baseline", False)))
+            for key, val in alog.items():
+                rec[f"a{cyc}_log:{key}"] = np.float64(float(val))
             if cfg["init_alpha"] > 0 and cfg["alpha_lr"] > 0:
                 for i in range(E):
                     if stochastic:
@@ -338,8 +365,8 @@ def run_engine(name, device="cuda", shard=None):
                     premade_replay_dicts=dicts, discrete=cfg["discrete"])
                 for key, val in llog.items():
                     rec[f"l{cyc}_log:{key}"] = np.float64(float(val))
-        assert not player.idx and not player.sub and not player.normal and not player.shift, \
-            "unconsumed recorded draws"
+        assert not player.idx and not player.sub and not player.normal and not player.shift and \
+            not player.cats and not player.picks, "unconsumed recorded draws"
     finally:
         player.restore()
     crit = [p for i in range(E) for j in range(NL) for p in agent.critics[i].nets[j].parameters()]
@@ -401,8 +428,7 @@ def compare(rec, fx, *, td_tol=2e-4, log_rtol=5e-4, par_tol=3e-5, enc_tol=3e-3, 
     worst = {"td": 0.0, "log": 0.0, "param": 0.0}
     for key, ref in fx.items():
         if key not in rec:
-            assert not (key.startswith("u") and ("_td" in key or "_log:" in key)) or \
-                "gradients/" in key, f"{who}: missing {key}"
+            assert not (key[0] in "ual" and ("_td" in key or "_log:" in key)), f"{who}: missing {key}"
             continue
         got = np.asarray(rec[key], dtype=np.float64)
         ref = np.asarray(ref, dtype=np.float64)
@@ -411,7 +437,10 @@ def compare(rec, fx, *, td_tol=2e-4, log_rtol=5e-4, par_tol=3e-5, enc_tol=3e-3, 
             worst["td"] = max(worst["td"], dv)
             assert dv <= td_tol, f"{who}: {key} deviates {dv:.3e} > {td_tol}"
         elif "_log:" in key:
-            dv = float(abs(got - ref) / max(1.0, abs(ref)))
+            # (gradient norms are compared RELATIVE to their size: they range from 1e-3 to 1e2)
+            dv = float(abs(got - ref) / (max(1.0, abs(ref)) if "gradients/" not in key else max(1e-6, abs(ref))))
+            if "gradients/" in key and abs(ref) < 1e-12:
+                dv = float(abs(got))
             worst["log"] = max(worst["log"], dv)
             assert dv <= log_rtol, f"{who}: {key} = {got} vs reference {ref}"
         elif "encoder" in key and key.startswith("final"):
@@ -554,8 +583,7 @@ def run_afbc_engine(name, device="cuda"):
                 rec[f"s{k}_idx"], rec[f"s{k}_prio"] = seen["idx"], seen["prio"]
                 rec[f"s{k}_leaves"] = buf._per.sum_tree[buf._per.cap + seen["idx"]].copy()
                 for key, v in logs.items():
-                    if not key.startswith("gradients/"):
-                        rec[f"s{k}_log:{key}"] = np.float64(float(v))
+                    rec[f"s{k}_log:{key}"] = np.float64(float(v))
                 assert not player.normal and not player.idx and not player.sub
                 continue
             per, filt = step
@@ -576,8 +604,7 @@ def run_afbc_engine(name, device="cuda"):
                 rec[f"s{k}_idx"], rec[f"s{k}_prio"] = seen["idx"], seen["prio"]
                 rec[f"s{k}_leaves"] = buf._per.sum_tree[buf._per.cap + seen["idx"]].copy()
             for key, v in logs.items():
-                if not key.startswith("gradients/"):
-                    rec[f"s{k}_log:{key}"] = np.float64(float(v))
+                rec[f"s{k}_log:{key}"] = np.float64(float(v))
             assert not player.normal and not player.idx, "the engine consumed a different number of draws"
     finally:
         player.restore()
@@ -606,7 +633,8 @@ def compare_afbc(rec, fx, log_rtol=5e-4, par_tol=3e-5, prio_tol=2e-4):
         for key in fx:
             if key.startswith(f"s{k}_log:"):
                 v, r = float(rec[key]), float(fx[key])
-                assert abs(v - r) <= log_rtol * max(1.0, abs(r)), (key, v, r)
+                scale = max(1.0, abs(r)) if "gradients/" not in key else max(1e-6, abs(r))  # norms: relative
+                assert abs(v - r) <= log_rtol * scale, (key, v, r)
     d = float(np.abs(rec["final_actor"] - fx["final_actor"]).max())
     assert d <= par_tol, f"final actor parameters differ by {d:.3e}"
     if "final_critic" in fx:

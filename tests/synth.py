@@ -62,6 +62,56 @@ CASES = {
                          cycles=2, utd=2, target_delay=2, seed=18,
                          pixels=dict(kind="small", channels=4, hw=84, emb=128, enc_lr=3e-4, enc_tau=0.01,
                                      aug="drqv2", aug_mix=0.9)),
+    # ---- round 2 ----
+    # BASELINE config 1: Pendulum-v1 SAC (gym/sac.gin), 2 critics, batch 256, hidden 256
+    "pendulum_sac": dict(obs=3, act=1, hidden=256, N=2, n=2, E=1, B=256, rows=2000, cap=4096,
+                         lo=-5.0, hi=2.0, popart=False, pop=False, discrete=False,
+                         actor="stochastic", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                         clip=None, tau=0.005, weight_type=None, temp=None, noise=None,
+                         cycles=2, utd=1, target_delay=2, seed=31),
+    # BASELINE config 5's shape: Humanoid obs 376 / act 17, N 16 critics, batch 512 (also the sharded tests)
+    "redq_S": dict(obs=376, act=17, hidden=256, N=16, n=2, E=1, B=512, rows=3000, cap=4096,
+                   lo=-5.0, hi=2.0, popart=False, pop=False, discrete=False,
+                   actor="stochastic", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                   clip=None, tau=0.005, weight_type=None, temp=None, noise=None,
+                   cycles=1, utd=2, target_delay=2, seed=32),
+    # config 3's MLP stack on its own (DrQv2: embedding 50 + act 6 -> 1024 -> 1024 -> 1, batch 512): the per-layer
+    # kernel family at its production size, deterministic actor + exploration noise, n-step-3 discount
+    "drqv2_mlp1024": dict(obs=50, act=6, hidden=1024, N=2, n=2, E=1, B=512, rows=2000, cap=4096,
+                          lo=-10.0, hi=2.0, popart=False, pop=False, discrete=False,
+                          actor="deterministic", gamma=0.99 ** 3, lr=1e-4, alpha_lr=0.0, init_alpha=0.0,
+                          clip=None, tau=0.01, weight_type=None, temp=None,
+                          noise=dict(scale=0.5, clip=0.3), cycles=1, utd=2, target_delay=1, seed=33),
+    # config 4's MLP stack on its own (Atari: embedding 128 -> 256 -> 256 -> |A| = 4, batch 1024), clips 40
+    "atari_mlp_b1024": dict(obs=128, act=4, hidden=256, N=2, n=2, E=1, B=1024, rows=3000, cap=4096,
+                            lo=-10.0, hi=2.0, popart=False, pop=False, discrete=True,
+                            actor="discrete", gamma=0.99 ** 3, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                            clip=40.0, tau=0.005, weight_type=None, temp=None, noise=None,
+                            cycles=1, utd=2, target_delay=2, seed=34),
+    # "softmax" backup weights (learning_utils.py:383-393; super_sac()'s DEFAULT weight_type, main.py:37-88)
+    "softmax_weights": dict(obs=11, act=3, hidden=64, N=2, n=2, E=3, B=64, rows=1000, cap=1024,
+                            lo=-5.0, hi=2.0, popart=False, pop=False, discrete=False,
+                            actor="stochastic", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                            clip=None, tau=0.005, weight_type="softmax", temp=20.0, noise=None,
+                            cycles=1, utd=2, target_delay=2, seed=35),
+    # SUNRISE weights for a discrete agent (learning_utils.py:372-377)
+    "sunrise_discrete": dict(obs=8, act=4, hidden=64, N=2, n=2, E=3, B=64, rows=1000, cap=1024,
+                             lo=-10.0, hi=2.0, popart=False, pop=False, discrete=True,
+                             actor="discrete", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                             clip=40.0, tau=0.005, weight_type="sunrise", temp=20.0, noise=None,
+                             cycles=1, utd=2, target_delay=2, seed=36),
+    # softmax weights for a discrete agent: Categorical.sample() draws are recorded in the fixture (u*_cat*)
+    "softmax_discrete": dict(obs=8, act=4, hidden=64, N=2, n=2, E=2, B=64, rows=1000, cap=1024,
+                             lo=-10.0, hi=2.0, popart=False, pop=False, discrete=True,
+                             actor="discrete", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                             clip=None, tau=0.005, weight_type="softmax", temp=20.0, noise=None,
+                             cycles=1, utd=2, target_delay=2, seed=37),
+    # online_actor_update(use_baseline=True): the advantage estimator as the actor objective (learning.py:401)
+    "sac_baseline": dict(obs=11, act=3, hidden=64, N=2, n=2, E=1, B=64, rows=1000, cap=1024,
+                         lo=-5.0, hi=2.0, popart=False, pop=False, discrete=False,
+                         actor="stochastic", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                         clip=None, tau=0.005, weight_type=None, temp=None, noise=None,
+                         cycles=2, utd=1, target_delay=1, seed=38, use_baseline=True),
 }
 
 

@@ -32,6 +32,8 @@ from . import adv_estimator  # noqa: E402,F401
 from . import checkpoint  # noqa: E402,F401
 from . import conv_encoder  # noqa: E402,F401
 from . import parallel  # noqa: E402,F401
+from . import adopt  # noqa: E402,F401
+from .adopt import adopt_agent  # noqa: E402,F401
 
 
 def install(reference_package):

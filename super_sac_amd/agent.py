@@ -78,6 +78,10 @@ class Agent:
         else:
             self.adv_estimator = AdvantageEstimator(self, discrete=False,
                                                     continuous_method=adv_method if adv_method else "mean")
+        # agent.py:112-127: models of the Markov state-abstraction update (learning.py:266-341)
+        self.inverse_model = (nets.DiscreteInverseModel(**actor_kwargs) if discrete
+                              else nets.ContinuousInverseModel(**actor_kwargs))
+        self.contrastive_model = nets.ContrastiveModel(state_size=encoder.embedding_dim, hidden_size=hidden_size)
 
     @property
     def ensemble(self):
@@ -90,6 +94,8 @@ class Agent:
         for p in self.popart:
             if p:
                 yield p
+        yield self.inverse_model
+        yield self.contrastive_model
 
     def to(self, dev):
         for i, a in enumerate(self.actors):
@@ -100,6 +106,8 @@ class Agent:
                 self.popart[i] = p.to(dev)
         for i, c in enumerate(self.critics):
             self.critics[i] = c.to(dev)
+        self.inverse_model = self.inverse_model.to(dev)
+        self.contrastive_model = self.contrastive_model.to(dev)
 
     def eval(self):
         for m in self._modules():
@@ -206,16 +214,22 @@ class Agent:
             return act, dist_out  # the chosen actor's raw head output (distribution parameters)
         return act
 
-    # same per-module files as agent.py:172-202 (inverse/contrastive models are out of scope)
+    # The reference's on-disk layout, file for file (agent.py:172-202): a directory written here loads into the
+    # reference's Agent.load and vice versa (oracle/check_reference_compat.py).  The reference's PopArt layer has no
+    # parameters or buffers, so its popart{i}.pt is an EMPTY state_dict and the statistics are silently lost
+    # (popart.py:11-16); here they go into popart{i}_stats.pt beside it.
     def save(self, path):
         torch.save(self.encoder.state_dict(), os.path.join(path, "encoder.pt"))
         for i, p in enumerate(self.popart):
             if p:
                 torch.save(p.state_dict(), os.path.join(path, f"popart{i}.pt"))
+                torch.save(p.stats_dict(), os.path.join(path, f"popart{i}_stats.pt"))
         for i, c in enumerate(self.critics):
             torch.save(c.state_dict(), os.path.join(path, f"critic{i}.pt"))
         for i, a in enumerate(self.actors):
             torch.save(a.state_dict(), os.path.join(path, f"actor{i}.pt"))
+        torch.save(self.inverse_model.state_dict(), os.path.join(path, "inverse.pt"))
+        torch.save(self.contrastive_model.state_dict(), os.path.join(path, "contrastive.pt"))
 
     def load(self, path):
         _load = lambda name: torch.load(os.path.join(path, name), map_location=_default_device)
@@ -223,7 +237,11 @@ class Agent:
         for i, p in enumerate(self.popart):
             if p:
                 p.load_state_dict(_load(f"popart{i}.pt"))
+                if os.path.exists(os.path.join(path, f"popart{i}_stats.pt")):  # (absent in reference checkpoints)
+                    p.load_stats_dict(_load(f"popart{i}_stats.pt"))
         for i, c in enumerate(self.critics):
             c.load_state_dict(_load(f"critic{i}.pt"))
         for i, a in enumerate(self.actors):
             a.load_state_dict(_load(f"actor{i}.pt"))
+        self.inverse_model.load_state_dict(_load("inverse.pt"))
+        self.contrastive_model.load_state_dict(_load("contrastive.pt"))

@@ -155,6 +155,8 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
               weight_type=weight_type, pop=pop, augmenter=augmenter, encoder_lambda=encoder_lambda,
               random_process=random_process, noise_clip=noise_clip, aug_mix=aug_mix, discrete=discrete, per=per,
               update_priorities=update_priorities, dr3_coeff=dr3_coeff)
+    lu.ensure_adopted(agent, buffer)
+    lu.ensure_adopted(target_agent, buffer)
     shard = parallel.shard_of(agent)
     graphable = (USE_GRAPHS and engine.CAPTURE is None and agent.ensemble_size == 1 and not per
                  and not update_priorities and not dr3_coeff and lu.is_identity(agent.encoder)
@@ -623,6 +625,7 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
                         random_process, noise_clip, augmenter, aug_mix, premade_replay_dicts=None,
                         per=False, discrete=False, use_baseline=False):
     engine.require_gpu()
+    lu.ensure_adopted(agent, buffer)
     E = agent.ensemble_size
     dev = log_alphas[0].device
     ws = lu.agent_ws(agent, dev)
@@ -752,6 +755,7 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
     engine.require_gpu()
     if actor_lambda:
         raise NotImplementedError("action invariance constraint (SURVEY 8(f) rank 4) is not accelerated")
+    lu.ensure_adopted(agent, buffer)
     if update_encoder and not lu.is_identity(agent.encoder):
         raise NotImplementedError("encoder training through the BC loss is not accelerated")
     E = agent.ensemble_size
@@ -823,6 +827,7 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
 def alpha_update(buffer, agent, optimizers, batch_size, log_alphas, augmenter, aug_mix, target_entropy,
                  premade_replay_dicts, discrete):
     engine.require_gpu()
+    lu.ensure_adopted(agent, buffer)
     dev = log_alphas[0].device
     ws = lu.agent_ws(agent, dev)
     slot = lu.log_block(dev)

@@ -316,6 +316,19 @@ def is_identity(encoder):
     return getattr(encoder, "ssac_identity_key", None) is not None
 
 
+def ensure_adopted(agent, buffer=None):
+    """first contact with an agent: add what a foreign (reference-built) agent lacks (adopt.py) and find out whether
+    its encoder is an identity map, probing it with one row of the buffer's observations"""
+    if agent.__dict__.get("_ssac_adopted") and (buffer is None or agent.encoder.__dict__.get("_ssac_probed")
+                                                 or is_identity(agent.encoder)):
+        return
+    from . import adopt
+    adopt.adopt_agent(agent)
+    st = getattr(buffer, "_storage", None) if buffer is not None else None
+    if st is not None and not is_identity(agent.encoder):
+        adopt.probe_identity(agent.encoder, {k: v[:1].float() for k, v in st.s_stack.items()})
+
+
 def _row_stride(t):
     assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major (B, F) device tensor"
     return t.stride(0)

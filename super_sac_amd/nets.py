@@ -100,6 +100,38 @@ class DiscreteActor(_MLP3):
         self._build(state_size, hidden_size, action_size)
 
 
+class ContinuousInverseModel(_MLP3):
+    """mlps.py:45-76: (s, s') -> tanh-normal over the action that was taken (Markov state abstraction)."""
+    HEAD = "fc3"
+
+    def __init__(self, state_size, action_size, log_std_low=-10.0, log_std_high=2.0, hidden_size=256,
+                 dist_impl="pyd"):
+        super().__init__()
+        assert dist_impl == "pyd", "only the tanh-normal head is on the accelerated path"
+        self.log_std_low, self.log_std_high, self.dist_impl = log_std_low, log_std_high, dist_impl
+        self.action_size = action_size
+        self._build(2 * state_size, hidden_size, 2 * action_size)
+
+
+class DiscreteInverseModel(_MLP3):
+    """mlps.py:153-168: (s, s') -> logits over the action that was taken."""
+    HEAD = "act_p"
+
+    def __init__(self, state_size, action_size, hidden_size, **kwargs):
+        super().__init__()
+        self.action_size = action_size
+        self._build(2 * state_size, hidden_size, action_size)
+
+
+class ContrastiveModel(_MLP3):
+    """mlps.py:97-110: (s, s') -> logit of "this is a real transition" (the sigmoid lives in the loss kernel)."""
+    HEAD = "out"
+
+    def __init__(self, state_size, hidden_size=256):
+        super().__init__()
+        self._build(2 * state_size, hidden_size, 1)
+
+
 class Encoder(nn.Module):
     """nets/__init__.py:21-35: carries a dummy Linear(1,1) so optimizers are never empty."""
 

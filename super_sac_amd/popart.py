@@ -3,8 +3,9 @@
 Mirror of super_sac/popart.py:8-59.  The statistics update and the (de)normalisation of the
 TD target run inside the ``ssac_td_target`` kernel; this class only owns the state block
 (struct ssac_popart) and exposes the reference's attributes for inspection / checkpoints.
-Unlike the reference (whose mu/nu/w/b are plain tensors and silently missing from
-``state_dict()``), the state here is a registered buffer, so it is saved and restored.
+Like the reference's layer (whose mu/nu/w/b are plain tensors, so ``state_dict()`` is empty and the statistics are
+silently dropped from checkpoints), ``state_dict()`` is empty here -- the files stay interchangeable -- and the
+statistics are saved through ``stats_dict()`` (Agent.save writes popart{i}_stats.pt).
 """
 import ctypes as C
 
@@ -19,7 +20,15 @@ class PopArtLayer(nn.Module):
         super().__init__()
         st = _lib.PopArtState(0.0, float(init_nu), 1.0, 0.0, 1, int(min_steps), 0, 0, float(beta))
         raw = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).clone()
-        self.register_buffer("state", raw)
+        # non-persistent: state_dict() stays EMPTY like the reference layer's (popart.py:8-20 holds plain tensors), so
+        # popart{i}.pt files are interchangeable; the statistics travel through stats_dict() / load_stats_dict()
+        self.register_buffer("state", raw, persistent=False)
+
+    def stats_dict(self):
+        return {"state": self.state.detach().cpu().clone()}
+
+    def load_stats_dict(self, d):
+        self.state.copy_(d["state"])
 
     # ---- host views of the device struct (each read synchronises; not on the update path)
     def _read(self):

@@ -202,13 +202,31 @@ class DrawPlayer:
         m.choice, m.draw_categorical = self._saved_choice, self._saved_cat
 
 
-def build_engine_agent(cfg, device, shard=None):
+def build_engine_agent(cfg, device, shard=None, foreign=False):
     """super_sac_amd.Agent holding the same seeded weights as the oracle agent (with `shard`: only
-    the critics [shard.lo, shard.hi) of the global ensemble)."""
+    the critics [shard.lo, shard.hi) of the global ensemble).  foreign: an agent made of stand-ins that carry only
+    the REFERENCE classes' attributes (tests/foreign_agent.py), to be adopted by the update functions."""
     import super_sac_amd as ssa
     oa = _oracle_agent(cfg)
     lo = 0 if shard is None else shard.lo
     n_loc = cfg["N"] if shard is None else shard.n_local
+    if foreign:
+        import foreign_agent
+        assert not cfg.get("pixels")
+        ag = foreign_agent.ForeignAgent(cfg, n_loc)
+        head = {"stochastic": "fc3", "deterministic": "out", "discrete": "act_p"}[cfg["actor"]]
+        with torch.no_grad():
+            for i in range(cfg["E"]):
+                for mod, p, names in [(ag.actors[i], oa.actors[i], ("fc1", "fc2", head))] + \
+                        [(ag.critics[i].nets[j], oa.critics[i][lo + j], ("fc1", "fc2", "out")) for j in range(n_loc)]:
+                    for (wk, bk), nm in zip((("w1", "b1"), ("w2", "b2"), ("w3", "b3")), names):
+                        getattr(mod, nm).weight.copy_(p[wk])
+                        getattr(mod, nm).bias.copy_(p[bk])
+        ag.to(device)
+        if cfg["popart"]:
+            for p in ag.popart:
+                p.min_steps = cfg.get("popart_min_steps", 1000)
+        return ag
     actor_cls = {"stochastic": ssa.nets.ContinuousStochasticActor,
                  "deterministic": ssa.nets.ContinuousDeterministicActor,
                  "discrete": ssa.nets.DiscreteActor}[cfg["actor"]]
@@ -252,7 +270,7 @@ def build_engine_agent(cfg, device, shard=None):
     return ag
 
 
-def run_engine(name, device="cuda", shard=None):
+def run_engine(name, device="cuda", shard=None, foreign=False):
     """`shard` (super_sac_amd.parallel.Shard): run as one rank of a critic-sharded job; the record
     then holds this rank's critics only (see slice_fixture)."""
     import super_sac_amd as ssa
@@ -262,7 +280,7 @@ def run_engine(name, device="cuda", shard=None):
     device = torch.device(device)
     buf = ssa.replay.ReplayBuffer(cfg["cap"], device=device)
     buf.load_experience(*_buffers(cfg))
-    agent = build_engine_agent(cfg, device, shard)
+    agent = build_engine_agent(cfg, device, shard, foreign=foreign)
     target = copy.deepcopy(agent)
     if shard is not None:
         ssa.parallel.install(agent, target, shard)

@@ -31,6 +31,38 @@ def test_engine_matches_reference(name, fused):
     print(f"{name}: worst deviations vs reference {worst}")
 
 
+@pytest.mark.parametrize("name", ["redq_small", "sac_popart", "sac_discrete", "td3_noise"])
+def test_update_functions_adopt_a_foreign_agent(name):
+    """an agent that carries ONLY the reference classes' attributes (tests/foreign_agent.py: no arena(), no
+    action_size, plain-tensor PopArt, an identity encoder the engine has to recognise by probing) goes through the
+    same update sequence and lands on the reference's outputs (the engine adopts `agent.*` in place)."""
+    rec = case_runner.run_engine(name, foreign=True)
+    case_runner.compare(rec, case_runner.load_fixture(name), who=f"hip[{name},foreign agent]")
+
+
+@pytest.mark.parametrize("seed", [0, 7, 123])
+@pytest.mark.parametrize("n", [1000, 100_000, 1_000_000])
+def test_product_index_draw_is_bit_exact_on_the_gpu_box(seed, n):
+    """super_sac_amd.rng.draw_indices (what critic_update calls) under torch.manual_seed, on this machine, against
+    the reference's replay.sample_uniform index stream (replay.py:121-126) recorded in replay_indices.npz; and the
+    product replay buffer's sample_uniform returns those very rows."""
+    import torch
+    import super_sac_amd as ssa
+    ref = case_runner.load_fixture("replay_indices")[f"s{seed}_n{n}"]
+    torch.manual_seed(seed)
+    got = np.stack([ssa.rng.draw_indices(n, 512).numpy() for _ in range(3)])
+    assert got.dtype == np.int64 and np.array_equal(got, ref)
+    if n == 1000:
+        buf = ssa.replay.ReplayBuffer(2048, device=torch.device("cuda"))
+        s, a, r, s1, d = synth.synth_transitions(n, 5, 2, seed=3)
+        buf.load_experience(s, a, r, s1, d)
+        torch.manual_seed(seed)
+        (o, act, rew, o1, done), idx = buf.sample_uniform(512)
+        assert np.array_equal(idx, ref[0])
+        assert np.array_equal(o["obs"].cpu().numpy(), s["obs"][ref[0]])
+        assert np.array_equal(act.cpu().numpy(), a[ref[0]])
+
+
 def test_engine_matches_oracle_on_metric_shape():
     """engine vs oracle directly (not via the fixture) at obs 17 / act 6 / B 512 / N 10."""
     rec_o = case_runner.run_oracle("redq_M")

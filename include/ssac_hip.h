@@ -590,6 +590,42 @@ int ssac_ln_tanh_bwd(const float *d_out, int64_t ldd, const float *out, int64_t 
                      const float *rstd, const float *gamma, int n_rows, int dim, float *dx, int64_t ldx,
                      float *dy_scratch, float *dgamma, float *dbeta, void *stream);
 
+/* ==== bf16-operand mode (csrc/ssac_bf16.hip): BASELINE.json config 2.  No reference counterpart (the reference is
+ * fp32 only, super_sac/__init__.py:3): fp32 master weights / Adam moments / Polyak targets as above, matrix products
+ * on v_mfma_f32_32x32x16_bf16 (bf16 operands, fp32 accumulate) fed from a bf16 SHADOW arena per net
+ *   [ W1 (hidden x K1P, K zero-padded to 16) | W2 | W2^T | W3 ]        (ssac_bf16_layout: stride + the 4 offsets)
+ * that the Adam epilogue keeps current.  Saved activations are bf16 and TRANSPOSED ((n_nets x) hidden x Bp, batch
+ * contiguous, Bp = n_rows rounded up to 16, zero padded) so the weight-gradient products read both operands with
+ * 16-byte loads.  Covers the chained critic update of continuous single-output critics (hidden % 32 == 0, <= 256). ==== */
+int64_t ssac_bf16_layout(int in_dim, int hidden, int out_dim, int64_t offsets[4]);
+int ssac_bf16_supported(const ssac_mlp *nets);
+/* shadow <- bf16(master) for every net (after construction, load_state_dict, or an fp32 update of the arena) */
+int ssac_bf16_sync(const ssac_mlp *nets, uint16_t *shadow, void *stream);
+/* learning_utils.py:160-162 on the fp32 masters, and the target's shadow refreshed in the same launch */
+int ssac_bf16_polyak(const ssac_mlp *target, const ssac_mlp *source, float tau, uint16_t *target_shadow, void *stream);
+/* ensemble-Q forward (agent.py:34 loop + mlps.py:123-129) in bf16: Y (n_sel x n_rows x out) fp32 */
+int ssac_bf16_mlp3_fwd(const ssac_mlp *nets, const uint16_t *shadow, const int32_t *net_ids, int n_sel, const float *X,
+                       int64_t ldx, int n_rows, float *Y, void *stream);
+/* ssac_chain_update in bf16: same roles and arguments; the saved forward / unscaled backward leave as H1T, H2T, DZ2uT,
+ * DZ1uT (n_nets x hidden x Bp) and XT (K1P x Bp, the [s|a] tile transposed) instead of fp32 row-major buffers. */
+int ssac_bf16_chain_update(const ssac_mlp *actor, const uint16_t *actor_shadow, const float *Xa, int64_t ldxa, int n_rows,
+                           const float *eps, float log_std_lo, float log_std_hi, float *x1sa, int64_t ld_x1,
+                           int64_t act_col0, float *logp, const ssac_rng *rng, const ssac_mlp *targets,
+                           const uint16_t *target_shadow, const int32_t *net_ids, int n_sel, float *Qt,
+                           const ssac_mlp *critics, const uint16_t *critic_shadow, const float *Xc, int64_t ldxc,
+                           float *Q, uint16_t *H1T, uint16_t *H2T, uint16_t *DZ2uT, uint16_t *DZ1uT, uint16_t *XT,
+                           const ssac_gather *gather, void *stream);
+/* ssac_mlp_wgrad_all_lossfold in bf16 (all three layers, loss gradient per workgroup, Adam on the fp32 masters, shadow
+ * refreshed from the new values, optional Polyak of `target` + its shadow).  sumsq: ssac_bf16_wgrad_tiles() slots per
+ * net.  No split-K: every gradient element is accumulated by one wave in a fixed order. */
+int ssac_bf16_wgrad_tiles(const ssac_mlp *nets);
+int ssac_bf16_wgrad_lossfold(const ssac_mlp *nets, uint16_t *shadow, const uint16_t *XT, const uint16_t *H1T,
+                             const uint16_t *H2T, const uint16_t *DZ2uT, const uint16_t *DZ1uT, const float *Q,
+                             const float *td, const ssac_td_spec *lazy_td, const float *weight, float denom,
+                             float *partials, int n_rows, float *adam_m, float *adam_v, const ssac_adam_ctl *ctl,
+                             float *sumsq, int64_t sumsq_net_stride, float *target, uint16_t *target_shadow, float tau,
+                             void *stream);
+
 /* zero a float buffer (log accumulators) */
 int ssac_zero(float *p, int64_t n, void *stream);
 

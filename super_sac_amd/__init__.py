@@ -34,6 +34,7 @@ from . import conv_encoder  # noqa: E402,F401
 from . import parallel  # noqa: E402,F401
 from . import adopt  # noqa: E402,F401
 from .adopt import adopt_agent  # noqa: E402,F401
+from .engine import set_precision, sync_shadows  # noqa: E402,F401
 
 
 def install(reference_package):

@@ -159,8 +159,18 @@ SIGNATURES = {
     "ssac_head_wgrad_tiles": [_MP],
     "ssac_head_wgrad": [_MP, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P, _F, _P],
     "ssac_critic_logs": [_P, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _P, _P],
+    "ssac_bf16_layout": [_I, _I, _I, C.POINTER(C.c_int64)],
+    "ssac_bf16_supported": [_MP],
+    "ssac_bf16_sync": [_MP, _P, _P],
+    "ssac_bf16_polyak": [_MP, _MP, _F, _P, _P],
+    "ssac_bf16_mlp3_fwd": [_MP, _P, _P, _I, _P, _L, _I, _P, _P],
+    "ssac_bf16_chain_update": [_MP, _P, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _P, _I, _P, _MP, _P, _P, _L,
+                               _P, _P, _P, _P, _P, _P, _P, _P],
+    "ssac_bf16_wgrad_tiles": [_MP],
+    "ssac_bf16_wgrad_lossfold": [_MP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P, _L, _P, _P, _F,
+                                 _P],
 }
-_RESTYPES = {"ssac_last_error": C.c_char_p, "ssac_mlp_layout": C.c_int64, "ssac_record_end": C.c_void_p,
+_RESTYPES = {"ssac_last_error": C.c_char_p, "ssac_mlp_layout": C.c_int64, "ssac_bf16_layout": C.c_int64, "ssac_record_end": C.c_void_p,
              "ssac_launch_list_free": None}
 
 

@@ -245,3 +245,4 @@ class Agent:
             a.load_state_dict(_load(f"actor{i}.pt"))
         self.inverse_model.load_state_dict(_load("inverse.pt"))
         self.contrastive_model.load_state_dict(_load("contrastive.pt"))
+        engine.sync_shadows(self)  # (bf16 mode: the shadows follow the freshly loaded masters)

@@ -1,0 +1,772 @@
+// bf16-operand variant of the chained critic update for gfx950 (BASELINE.json config 2: "REDQ N=10 UTD=20 batch 256
+// bf16").  The reference computes in fp32 only (super_sac/__init__.py:3), so this mode has no reference counterpart:
+// fp32 MASTER weights, Adam moments and Polyak targets stay exactly as in the fp32 path; what changes is the operand
+// type of the matrix products -- bf16 in, fp32 accumulate, v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate) -- fed from
+// a bf16 SHADOW of every arena that the Adam epilogue keeps current.  Parity is tested against the same reference
+// fixtures at a separately stated (bf16) tolerance; the headline benchmark stays fp32.
+//
+// Data layout (all new buffers bf16):
+//   shadow arena per net   [ W1 (H x K1P, K zero-padded to a multiple of 16) | W2 (H x H) | W2^T (H x H) | W3 (out x H) ]
+//                          every product is evaluated as D^T = W . act^T: the weight rows are the MFMA's A operand, and
+//                          a lane's fragment (8 consecutive k of one row) is ONE 16-byte global load straight from the
+//                          shadow -- no LDS staging, no K-loop barrier.  W2^T serves the backward-data product.
+//   saved activations      H1T, H2T, DZ2uT, DZ1uT (n_nets x H x Bp) and XT (K1P x Bp): TRANSPOSED, batch contiguous, so
+//                          the weight-gradient products (K = batch) also read both operands with 16-byte loads per lane.
+//   Bp = batch rounded up to 16; the pad columns are zero (buffers are allocated zeroed and never written there).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "ssac_internal.h"
+#include "ssac_philox.h"
+#include "ssac_critic_logs.h"
+#include "ssac_begin.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TM = 32;      // batch rows per workgroup
+constexpr int NTHR = 512;   // 8 waves: wave w owns output features [32w, 32w + 32)
+constexpr int LPAD = 8;     // LDS row padding (elements): 16-byte aligned rows, conflict-free ds_read_b128
+constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
+constexpr float LOG_2 = 0.69314718055994530942f;
+
+__device__ __forceinline__ unsigned short f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+struct ShadowGeom { int64_t stride, o1, o2, o2t, o3; int k1p; };
+
+inline ShadowGeom shadow_geom(int in_dim, int hidden, int out_dim) {
+    ShadowGeom g;
+    g.k1p = (in_dim + 15) & ~15;
+    g.o1 = 0;
+    g.o2 = (int64_t)hidden * g.k1p;
+    g.o2t = g.o2 + (int64_t)hidden * hidden;
+    g.o3 = g.o2t + (int64_t)hidden * hidden;
+    g.stride = (g.o3 + (int64_t)out_dim * hidden + 7) & ~(int64_t)7;
+    return g;
+}
+
+enum { MODE_PLAIN = 0, MODE_SAMPLE = 1, MODE_CRITIC_U = 2 };
+
+struct BfArgs {
+    const float *params; int64_t net_stride; int in_dim, hidden, out_dim; int64_t off[6];   // fp32 master (biases)
+    const unsigned short *shadow; ShadowGeom sg;
+    const int32_t *ids;
+    const float *X; int64_t ldx; int n_rows, bp;
+    float *Y;                     // (n_sel, n_rows, out) fp32 head outputs, or null
+    // MODE_SAMPLE
+    const float *eps; float lo, hi; float *act_dst; int64_t ld_act, act_col0; float *logp; RngArgs rng;
+    // MODE_CRITIC_U: transposed bf16 saves
+    unsigned short *H1T, *H2T, *DZ2T, *DZ1T, *XT;
+    ssac_gather gth; int gth_role;  // as in ssac_fused.hip: 1 actor half (+ start-of-update duties), 3 actor half,
+                                    // 2 critic half, 4 rows from X with the subset ids read from the input slot
+};
+
+// One layer as D^T[n][b] = sum_k W[n][k] act[b][k] on v_mfma_f32_32x32x16_bf16: A = 32 weight rows starting at Wrows
+// (row stride ldw elements, K contiguous; lane (i = lane & 31, half = lane >> 5) reads 8 consecutive k of row i), B =
+// the tile's 32 activation rows in LDS (row stride lda).  acc[r] of lane (b, half) = D^T[(r & 3) + 8 (r >> 2) + 4 half][b].
+// nsteps = K / 16.  All global loads of a 16-step block are issued before its first MFMA.
+__device__ __forceinline__ void bf_layer(f32x16 &acc, const unsigned short *__restrict__ Wrows, int64_t ldw, int nsteps,
+                                         const unsigned short *__restrict__ act, int lda, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned short *wp = Wrows + (int64_t)li * ldw + 8 * lh;
+    const unsigned short *ap = act + li * lda + 8 * lh;
+    if (nsteps == 16) {  // hidden 256: the whole K in flight at once
+        u16x8 w[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const u16x8 *>(wp + 16 * t);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const u16x8 a = *reinterpret_cast<const u16x8 *>(ap + 16 * t);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t]), __builtin_bit_cast(bf16x8, a),
+                                                          acc, 0, 0, 0);
+        }
+        return;
+    }
+    int t = 0;
+    for (; t + 2 <= nsteps; t += 2) {
+        const u16x8 w0 = *reinterpret_cast<const u16x8 *>(wp + 16 * t);
+        const u16x8 w1 = *reinterpret_cast<const u16x8 *>(wp + 16 * t + 16);
+        const u16x8 a0 = *reinterpret_cast<const u16x8 *>(ap + 16 * t);
+        const u16x8 a1 = *reinterpret_cast<const u16x8 *>(ap + 16 * t + 16);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), __builtin_bit_cast(bf16x8, a0), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), __builtin_bit_cast(bf16x8, a1), acc, 0, 0, 0);
+    }
+    if (t < nsteps) {
+        const u16x8 w0 = *reinterpret_cast<const u16x8 *>(wp + 16 * t);
+        const u16x8 a0 = *reinterpret_cast<const u16x8 *>(ap + 16 * t);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), __builtin_bit_cast(bf16x8, a0), acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 &a) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = 0.0f;
+}
+
+// LDS carve (bytes) of one workgroup
+__host__ __device__ inline size_t bf_lds_bytes(int in_dim, int hidden, int out_dim) {
+    const int k1p = (in_dim + 15) & ~15;
+    const int ldo = (out_dim + 31) & ~31;
+    size_t b = 2 * ((size_t)TM * (k1p + LPAD) + 2 * (size_t)TM * (hidden + LPAD));   // xs, h1s, h2s (bf16)
+    b += 4 * ((size_t)TM * ldo + 2 * hidden + ldo + (size_t)TM * ldo + 3 * TM + 64);  // ys, b1s, b2s, b3s, lpt, rowin, pad
+    return (b + 15) & ~(size_t)15;
+}
+
+template <int MODE>
+__device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem, const int bx, const int e) {
+    const int H = g.hidden, IN = g.in_dim, OUT = g.out_dim, K1P = g.sg.k1p;
+    const int ldo = (OUT + 31) & ~31;
+    const int ldx_s = K1P + LPAD, ldh = H + LPAD;
+    unsigned short *xs = reinterpret_cast<unsigned short *>(smem);
+    unsigned short *h1s = xs + TM * ldx_s;
+    unsigned short *h2s = h1s + TM * ldh;
+    float *ys = reinterpret_cast<float *>(h2s + TM * ldh);   // [TM][ldo]
+    float *b1s = ys + TM * ldo;                              // [H]
+    float *b2s = b1s + H;                                    // [H]
+    float *b3s = b2s + H;                                    // [ldo]
+    float *lpt = b3s + ldo;                                  // [TM][ldo] scratch of the sample epilogue
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = bx * TM;
+
+    // ---- where this tile's rows come from (replay gather folded in; see ssac_gather in include/ssac_hip.h)
+    const int64_t *gidx = nullptr;
+    const uint32_t *gslot = nullptr;
+    const int32_t *idsp = g.ids;
+    if (g.gth_role) {
+        gidx = g.gth.idx;
+        if (g.gth.feed) {
+            const ssac_feed f = *g.gth.feed;
+            gslot = feed_slot(f);
+            gidx = reinterpret_cast<const int64_t *>(gslot);
+            if (g.gth_role == 1 && bx == 0) {  // start-of-update duties (ssac_begin_update)
+                feed_pull(f);
+                if (tid < g.gth.n_logs) g.gth.logs[tid] = 0.0f;
+                if (tid == 0 && g.gth.ctl) adam_refresh(g.gth.ctl, g.gth.ctl->step + 1);
+            }
+            if (g.gth_role == 4 && g.gth.ids_word >= 0) idsp = reinterpret_cast<const int32_t *>(gslot + g.gth.ids_word);
+        }
+        if (g.gth_role == 4) gidx = nullptr;
+    }
+    const int net = idsp ? idsp[e] : e;
+    if (net < 0) {  // empty subset slot of a sharded rank: +inf, the neutral element of the min that follows
+        if (MODE == MODE_PLAIN && g.Y)
+            for (int i = tid; i < TM * OUT; i += NTHR) {
+                const int r = i / OUT, o = i - r * OUT;
+                if ((m0 + r) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + r) * OUT + o] = __builtin_inff();
+            }
+        return;
+    }
+    const float *P = g.params + (int64_t)net * g.net_stride;
+    const unsigned short *S = g.shadow + (int64_t)net * g.sg.stride;
+    const int col0 = wave * 32;
+    const bool wave_on = col0 < H;
+
+    // ---- x tile -> LDS (bf16), biases -> LDS; the gathered rows are also written out in fp32 for the later updates
+    {
+        const bool actor_half = (g.gth_role & 1) != 0;
+        const int Sg = gidx ? (int)g.gth.s_elems : 0;
+        float *outp = gidx ? (actor_half ? g.gth.x1sa : (e == 0 ? g.gth.xsa : nullptr)) : nullptr;
+        const int64_t ldo_g = actor_half ? g.gth.ld_x1 : g.gth.ld_x;
+        for (int r = tid >> 4; r < TM; r += NTHR / 16) {   // 16 lanes per row
+            const bool rok = (m0 + r) < g.n_rows;
+            const int64_t src = (gidx && rok) ? gidx[m0 + r] : 0;
+            for (int k = tid & 15; k < K1P; k += 16) {
+                float v = 0.0f;
+                if (rok && k < IN) {
+                    if (gidx) v = k < Sg ? (actor_half ? g.gth.s1 : g.gth.s)[src * Sg + k]
+                                         : g.gth.act[src * g.gth.a_elems + (k - Sg)];
+                    else v = g.X[(int64_t)(m0 + r) * g.ldx + k];
+                    if (outp) outp[(int64_t)(m0 + r) * ldo_g + k] = v;
+                }
+                const unsigned short hv = f2bf(v);
+                xs[r * ldx_s + k] = hv;
+                if (MODE == MODE_CRITIC_U && e == 0 && g.XT && rok) g.XT[(int64_t)k * g.bp + m0 + r] = hv;
+            }
+        }
+        if (gidx && actor_half && tid < TM && (m0 + tid) < g.n_rows) {
+            const int64_t src = gidx[m0 + tid];
+            g.gth.rew_out[m0 + tid] = g.gth.rew[src];
+            g.gth.done_out[m0 + tid] = (float)g.gth.done[src];
+        }
+        for (int i = tid; i < H; i += NTHR) { b1s[i] = P[g.off[1] + i]; b2s[i] = P[g.off[3] + i]; }
+        for (int i = tid; i < ldo; i += NTHR) b3s[i] = i < OUT ? P[g.off[5] + i] : 0.0f;
+    }
+    __syncthreads();
+
+    f32x16 acc;
+    // ---- fc1
+    if (wave_on) {
+        zero_acc(acc);
+        bf_layer(acc, S + g.sg.o1 + (int64_t)col0 * K1P, K1P, K1P >> 4, xs, ldx_s, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = col0 + 8 * q + 4 * lh;
+            u16x4 hv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hv[i] = f2bf(fmaxf(acc[4 * q + i] + b1s[n + i], 0.0f));
+            *reinterpret_cast<u16x4 *>(h1s + li * ldh + n) = hv;
+            if (MODE == MODE_CRITIC_U && (m0 + li) < g.n_rows)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g.H1T[((int64_t)e * H + n + i) * g.bp + m0 + li] = hv[i];
+        }
+    }
+    __syncthreads();
+    // ---- fc2
+    if (wave_on) {
+        zero_acc(acc);
+        bf_layer(acc, S + g.sg.o2 + (int64_t)col0 * H, H, H >> 4, h1s, ldh, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = col0 + 8 * q + 4 * lh;
+            u16x4 hv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hv[i] = f2bf(fmaxf(acc[4 * q + i] + b2s[n + i], 0.0f));
+            *reinterpret_cast<u16x4 *>(h2s + li * ldh + n) = hv;
+            if (MODE == MODE_CRITIC_U && (m0 + li) < g.n_rows)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) g.H2T[((int64_t)e * H + n + i) * g.bp + m0 + li] = hv[i];
+        }
+    }
+    __syncthreads();
+    // ---- head: wave w computes outputs [32w, 32w + 32) over the whole K (rows past OUT read row 0 and are dropped)
+    if (col0 < OUT) {
+        zero_acc(acc);
+        const int row = (col0 + li) < OUT ? col0 + li : 0;
+        // (bf_layer adds li * ldw itself: hand it the row through a zero stride)
+        bf_layer(acc, S + g.sg.o3 + (int64_t)row * H, 0, H >> 4, h2s, ldh, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = col0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (o < OUT) {
+                const float v = acc[r] + b3s[o];
+                ys[li * ldo + o] = v;
+                if (g.Y && (m0 + li) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + li) * OUT + o] = v;
+            }
+        }
+    }
+    if (MODE == MODE_PLAIN) return;
+    __syncthreads();
+
+    if (MODE == MODE_SAMPLE) {
+        // tanh-normal head in fp32 (distributions.py:9-15, 64-104), as in ssac_fused.hip
+        const int A = OUT >> 1;
+        for (int t = tid; t < TM * A; t += NTHR) {
+            const int r = t / A, i = t - r * A, b = m0 + r;
+            if (b < g.n_rows) {
+                const float mu = ys[r * ldo + i], raw = ys[r * ldo + A + i];
+                const float log_std = g.lo + 0.5f * (g.hi - g.lo) * (tanhf(raw) + 1.0f);
+                const float sd = expf(log_std);
+                const int64_t draw = (gslot && g.gth.rng_word >= 0)
+                                         ? g.rng.offset + *reinterpret_cast<const int64_t *>(gslot + g.gth.rng_word)
+                                         : rng_draw(g.rng);
+                const float ep = g.eps ? g.eps[(int64_t)b * A + i] : philox_normal(g.rng.seed, draw, b, i);
+                const float u = mu + sd * ep;
+                const float dlt = u - mu;
+                lpt[r * ldo + i] = (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -
+                                   2.0f * (LOG_2 - u - softplus_f(-2.0f * u));
+                g.act_dst[b * g.ld_act + g.act_col0 + i] = tanhf(u);
+            }
+        }
+        __syncthreads();
+        if (g.logp && tid < TM && (m0 + tid) < g.n_rows) {
+            float lp = 0.0f;
+            for (int i = 0; i < A; ++i) lp += lpt[tid * ldo + i];
+            g.logp[m0 + tid] = lp;
+        }
+        return;
+    }
+
+    // ---- MODE_CRITIC_U (single-output critics): the TD-independent half of the backward pass.
+    //      dz2u[b][j] = W3[j] [h2[b][j] > 0] in place over h2s, then dz1u^T = (W2^T . dz2u^T) (.) [h1 > 0]
+    {
+        const unsigned short *w3 = S + g.sg.o3;
+        for (int i = tid; i < TM * (H >> 2); i += NTHR) {
+            const int r = i / (H >> 2), j = (i - r * (H >> 2)) * 4;
+            const u16x4 hv = *reinterpret_cast<const u16x4 *>(h2s + r * ldh + j);
+            const u16x4 wv = *reinterpret_cast<const u16x4 *>(w3 + j);
+            u16x4 dz;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dz[u] = (hv[u] & 0x7fff) != 0 && !(hv[u] & 0x8000) ? wv[u] : (unsigned short)0;
+            *reinterpret_cast<u16x4 *>(h2s + r * ldh + j) = dz;
+            if ((m0 + r) < g.n_rows)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) g.DZ2T[((int64_t)e * H + j + u) * g.bp + m0 + r] = dz[u];
+        }
+    }
+    __syncthreads();
+    if (wave_on) {
+        zero_acc(acc);
+        bf_layer(acc, S + g.sg.o2t + (int64_t)col0 * H, H, H >> 4, h2s, ldh, lane);
+        if ((m0 + li) < g.n_rows) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = col0 + 8 * q + 4 * lh;
+                const u16x4 hm = *reinterpret_cast<const u16x4 *>(h1s + li * ldh + n);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    g.DZ1T[((int64_t)e * H + n + i) * g.bp + m0 + li] =
+                        ((hm[i] & 0x7fff) != 0 && !(hm[i] & 0x8000)) ? f2bf(acc[4 * q + i]) : (unsigned short)0;
+            }
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(NTHR) void bf_mlp_kernel(BfArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf_mlp_body<MODE>(g, smem, blockIdx.x, blockIdx.y);
+}
+
+// everything of a critic update that does not need the TD target, ONE launch (see fused_chain_kernel in ssac_fused.hip):
+// workgroups [0, tiles_t): target chain of subset slot j (actor forward + sample, then target critic ids[j] on [s'|a']);
+// the rest: online critics' forward + TD-independent backward.
+__global__ __launch_bounds__(NTHR) void bf_chain_kernel(BfArgs ga, BfArgs ga_rest, BfArgs gt, BfArgs gc, int tiles_t,
+                                                       int grid_x) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int bid = blockIdx.x;
+    if (bid < tiles_t) {
+        const int j = bid / grid_x, bx = bid - j * grid_x;
+        if (j == 0) bf_mlp_body<MODE_SAMPLE>(ga, smem, bx, 0);
+        else bf_mlp_body<MODE_SAMPLE>(ga_rest, smem, bx, 0);
+        __threadfence_block();  // this workgroup's a' rows (global) are read back by its own target-critic pass
+        __syncthreads();
+        bf_mlp_body<MODE_PLAIN>(gt, smem, bx, j);
+    } else {
+        const int L = bid - tiles_t;
+        bf_mlp_body<MODE_CRITIC_U>(gc, smem, L % grid_x, L / grid_x);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// shadow maintenance
+// ------------------------------------------------------------------------------------------------------------
+__global__ void bf_sync_kernel(const float *__restrict__ params, int64_t net_stride, int in_dim, int hidden, int out_dim,
+                               int64_t off_w1, int64_t off_w2, int64_t off_w3, unsigned short *__restrict__ shadow,
+                               ShadowGeom sg) {
+    const int e = blockIdx.y;
+    const float *P = params + (int64_t)e * net_stride;
+    unsigned short *S = shadow + (int64_t)e * sg.stride;
+    const int64_t n1 = (int64_t)hidden * sg.k1p, n2 = (int64_t)hidden * hidden, n3 = (int64_t)out_dim * hidden;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n1 + n2 + n3; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n1) {
+            const int r = (int)(i / sg.k1p), k = (int)(i - (int64_t)r * sg.k1p);
+            S[sg.o1 + i] = k < in_dim ? f2bf(P[off_w1 + (int64_t)r * in_dim + k]) : (unsigned short)0;
+        } else if (i < n1 + n2) {
+            const int64_t t = i - n1;
+            const int r = (int)(t / hidden), c = (int)(t - (int64_t)r * hidden);
+            const unsigned short v = f2bf(P[off_w2 + t]);
+            S[sg.o2 + t] = v;
+            S[sg.o2t + (int64_t)c * hidden + r] = v;
+        } else {
+            S[sg.o3 + (i - n1 - n2)] = f2bf(P[off_w3 + (i - n1 - n2)]);
+        }
+    }
+}
+
+// Polyak on the fp32 masters of the weights' segments + the target's shadow (biases: fp32 only)
+__global__ void bf_polyak_kernel(float *__restrict__ target, const float *__restrict__ source, int64_t net_stride,
+                                 int in_dim, int hidden, int out_dim, int64_t off_w1, int64_t off_w2, int64_t off_w3,
+                                 int64_t n_per_net, float tau, unsigned short *__restrict__ shadow, ShadowGeom sg) {
+    const int e = blockIdx.y;
+    float *T = target + (int64_t)e * net_stride;
+    const float *Sp = source + (int64_t)e * net_stride;
+    unsigned short *S = shadow + (int64_t)e * sg.stride;
+    const int64_t end1 = off_w1 + (int64_t)hidden * in_dim, end2 = off_w2 + (int64_t)hidden * hidden,
+                  end3 = off_w3 + (int64_t)out_dim * hidden;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_per_net; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = T[i] * (1.0f - tau) + Sp[i] * tau;   // learning_utils.py:160-162
+        T[i] = v;
+        if (i >= off_w1 && i < end1) {
+            const int64_t t = i - off_w1;
+            const int r = (int)(t / in_dim), k = (int)(t - (int64_t)r * in_dim);
+            S[sg.o1 + (int64_t)r * sg.k1p + k] = f2bf(v);
+        } else if (i >= off_w2 && i < end2) {
+            const int64_t t = i - off_w2;
+            const int r = (int)(t / hidden), c = (int)(t - (int64_t)r * hidden);
+            const unsigned short h = f2bf(v);
+            S[sg.o2 + t] = h;
+            S[sg.o2t + (int64_t)c * hidden + r] = h;
+        } else if (i >= off_w3 && i < end3) {
+            S[sg.o3 + (i - off_w3)] = f2bf(v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// weight gradients (K = batch) + loss gradient folded in + Adam (+Polyak) + shadow refresh.  Single-output critics.
+//   dW2[j][i] = sum_b c_b dz2u[b][j] h1[b][i]      A = DZ2uT rows j, B = H1T rows i
+//   dW1[j][i] = sum_b c_b dz1u[b][j] x[b][i]       A = DZ1uT rows j, B = XT rows i
+//   dW3[i]    = sum_b c_b h2[b][i], db3 = sum_b c_b   (VALU workgroup per net)
+// c_b = dL/dq of (net, row b), evaluated per workgroup into LDS (loss_fold_table).  A 256-thread workgroup owns a 64x64
+// tile as 2x2 waves of one 32x32 accumulator; both operands are read straight from global memory, 16 bytes per lane
+// per MFMA, one 4-step group ahead.  No split-K: every gradient element is produced by ONE wave in a fixed order.
+// ------------------------------------------------------------------------------------------------------------
+struct BfWgradArgs {
+    float *params; int64_t net_stride; int in_dim, hidden; int64_t off[6];
+    unsigned short *shadow; ShadowGeom sg;
+    const unsigned short *H1T, *H2T, *DZ2T, *DZ1T, *XT;
+    int n_rows, bp, n_nets;
+    float *am, *av; const ssac_adam_ctl *ctl;
+    float *target; unsigned short *tshadow; float tau;
+    float *sumsq; int64_t sumsq_stride;
+    LossFoldArgs lf;
+    int tiles2, tiles1;   // 64x64 tiles of fc2 / fc1 per net; then 1 head workgroup per net
+};
+
+__device__ __forceinline__ float adam_elem(float p, float g, float &m, float &v, const ssac_adam_ctl &c) {
+    if (c.weight_decay != 0.0f) g = g + c.weight_decay * p;
+    m = m + (1.0f - c.beta1) * (g - m);
+    v = v * c.beta2 + (1.0f - c.beta2) * g * g;
+    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+    return p - c.step_size * (m / denom);
+}
+
+__device__ __forceinline__ u16x8 scale_frag(const u16x8 a, const float *__restrict__ c, float &colsum) {
+    const f4 c0 = *reinterpret_cast<const f4 *>(c), c1 = *reinterpret_cast<const f4 *>(c + 4);
+    u16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float v = bf2f(a[i]) * (i < 4 ? c0[i] : c1[i - 4]);
+        colsum += v;
+        o[i] = f2bf(v);
+    }
+    return o;
+}
+
+__global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    float *tab = wlds;                 // [bp] row scales (zero beyond n_rows)
+    float *red = wlds + g.bp;          // [16] scratch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per_net = g.tiles2 + g.tiles1 + 1;
+    const int e = blockIdx.x / per_net, t = blockIdx.x - e * per_net;
+    const int H = g.hidden, IN = g.in_dim, K1P = g.sg.k1p;
+    // ---- loss gradient of this net's rows -> LDS (the first fc2 tile of each net also reduces the loss terms)
+    for (int b = g.n_rows + tid; b < g.bp; b += 256) tab[b] = 0.0f;
+    loss_fold_table(g.lf, e, tab, t == 0, red);
+    __syncthreads();
+    float *P = g.params + (int64_t)e * g.net_stride;
+    float *M = g.am + (int64_t)e * g.net_stride, *V = g.av + (int64_t)e * g.net_stride;
+    float *T = g.target ? g.target + (int64_t)e * g.net_stride : nullptr;
+    unsigned short *S = g.shadow + (int64_t)e * g.sg.stride;
+    unsigned short *TS = g.tshadow ? g.tshadow + (int64_t)e * g.sg.stride : nullptr;
+    const ssac_adam_ctl ctl = *g.ctl;
+    float ss = 0.0f;
+    if (t == per_net - 1) {
+        // ---- head layer (VALU): thread i owns W3[i]
+        const int i = tid;
+        float gw = 0.0f, gb = 0.0f;
+        if (i < H) {
+            const unsigned short *hp = g.H2T + ((int64_t)e * H + i) * g.bp;
+            for (int b0 = 0; b0 < g.bp; b0 += 8) {
+                const u16x8 hv = *reinterpret_cast<const u16x8 *>(hp + b0);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) gw += tab[b0 + u] * bf2f(hv[u]);
+            }
+        }
+        if (tid < 64) {
+            for (int b = tid; b < g.bp; b += 64) gb += tab[b];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) gb += __shfl_xor(gb, o, 64);
+        }
+        if (i < H) {
+            const int64_t a = g.off[4] + i;
+            float m = M[a], v = V[a];
+            const float pn = adam_elem(P[a], gw, m, v, ctl);
+            M[a] = m; V[a] = v; P[a] = pn;
+            S[g.sg.o3 + i] = f2bf(pn);
+            if (T) { const float tv = T[a] * (1.0f - g.tau) + pn * g.tau; T[a] = tv; TS[g.sg.o3 + i] = f2bf(tv); }
+            ss += gw * gw;
+        }
+        if (tid == 0) {
+            const int64_t a = g.off[5];
+            float m = M[a], v = V[a];
+            const float pn = adam_elem(P[a], gb, m, v, ctl);
+            M[a] = m; V[a] = v; P[a] = pn;
+            if (T) T[a] = T[a] * (1.0f - g.tau) + pn * g.tau;
+            ss += gb * gb;
+        }
+    } else {
+        const bool fc2 = t < g.tiles2;
+        const int tt = fc2 ? t : t - g.tiles2;
+        const int Ncols = fc2 ? H : IN;                 // valid gradient columns
+        const int gx = fc2 ? (H + 63) / 64 : (IN + 63) / 64;
+        const int by = tt / gx, bxn = tt - by * gx;
+        const int wm = wave >> 1, wn = wave & 1;
+        const int li = lane & 31, lh = lane >> 5;
+        const int row = by * 64 + wm * 32 + li;         // gradient row j (0 .. H)
+        const int col = bxn * 64 + wn * 32 + li;        // gradient column i
+        const int Brows = fc2 ? H : K1P;                // rows of the B operand's transposed buffer
+        const unsigned short *AT = (fc2 ? g.DZ2T : g.DZ1T) + ((int64_t)e * H + (row < H ? row : 0)) * g.bp + 8 * lh;
+        const unsigned short *BT = fc2 ? g.H1T + ((int64_t)e * H + (col < Brows ? col : 0)) * g.bp + 8 * lh
+                                       : g.XT + (int64_t)(col < Brows ? col : 0) * g.bp + 8 * lh;
+        const float *cs = tab + 8 * lh;
+        f32x16 acc;
+        zero_acc(acc);
+        float colsum = 0.0f;   // bias gradient: sum_b c_b dz[b][row] from the scaled A fragments
+        const int nsteps = g.bp >> 4;
+        constexpr int G = 4;
+        u16x8 a0[G], b0[G], a1[G], b1[G];
+        auto load = [&](u16x8 (&a)[G], u16x8 (&b)[G], int s0) {
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                const int s = s0 + u < nsteps ? s0 + u : nsteps - 1;   // clamped: redundant loads, never used
+                a[u] = *reinterpret_cast<const u16x8 *>(AT + 16 * s);
+                b[u] = *reinterpret_cast<const u16x8 *>(BT + 16 * s);
+            }
+        };
+        auto mm = [&](const u16x8 (&a)[G], const u16x8 (&b)[G], int s0) {
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+                if (s0 + u < nsteps) {
+                    const u16x8 as = scale_frag(a[u], cs + 16 * (s0 + u), colsum);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, as),
+                                                                  __builtin_bit_cast(bf16x8, b[u]), acc, 0, 0, 0);
+                }
+            }
+        };
+        load(a0, b0, 0);
+        for (int s0 = 0; s0 < nsteps; s0 += 2 * G) {
+            load(a1, b1, s0 + G);
+            mm(a0, b0, s0);
+            load(a0, b0, s0 + 2 * G);
+            mm(a1, b1, s0 + G);
+        }
+        colsum += __shfl_xor(colsum, 32, 64);   // the two k halves of row `row`
+        // ---- Adam epilogue straight from the accumulator: acc[r] = dW[by*64 + wm*32 + (r&3) + 8(r>>2) + 4 lh][col]
+        const int64_t off_w = fc2 ? g.off[2] : g.off[0];
+        const int ldc = fc2 ? H : IN;
+        if (col < Ncols) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                u16x4 hq, tq;
+                const int j0 = by * 64 + wm * 32 + 8 * q + 4 * lh;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u;
+                    hq[u] = 0; tq[u] = 0;
+                    if (j < H) {
+                        const int64_t a = off_w + (int64_t)j * ldc + col;
+                        const float gr = acc[4 * q + u];
+                        float m = M[a], v = V[a];
+                        const float pn = adam_elem(P[a], gr, m, v, ctl);
+                        M[a] = m; V[a] = v; P[a] = pn;
+                        ss += gr * gr;
+                        hq[u] = f2bf(pn);
+                        if (fc2) S[g.sg.o2 + (int64_t)j * H + col] = hq[u];
+                        else S[g.sg.o1 + (int64_t)j * K1P + col] = hq[u];
+                        if (T) {
+                            const float tv = T[a] * (1.0f - g.tau) + pn * g.tau;
+                            T[a] = tv;
+                            tq[u] = f2bf(tv);
+                            if (fc2) TS[g.sg.o2 + (int64_t)j * H + col] = tq[u];
+                            else TS[g.sg.o1 + (int64_t)j * K1P + col] = tq[u];
+                        }
+                    }
+                }
+                if (fc2 && j0 + 3 < H) {   // W2^T shadow: 4 consecutive j of column `col` (H % 4 == 0)
+                    *reinterpret_cast<u16x4 *>(S + g.sg.o2t + (int64_t)col * H + j0) = hq;
+                    if (T) *reinterpret_cast<u16x4 *>(TS + g.sg.o2t + (int64_t)col * H + j0) = tq;
+                }
+            }
+        }
+        // ---- bias gradient of rows [by*64 + wm*32, +32): the n-tile-0 waves with wn == 0 own it
+        if (bxn == 0 && wn == 0 && lh == 0 && row < H) {
+            const int64_t a = (fc2 ? g.off[3] : g.off[1]) + row;
+            float m = M[a], v = V[a];
+            const float pn = adam_elem(P[a], colsum, m, v, ctl);
+            M[a] = m; V[a] = v; P[a] = pn;
+            if (T) T[a] = T[a] * (1.0f - g.tau) + pn * g.tau;
+            ss += colsum * colsum;
+        }
+    }
+    if (g.sumsq) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        __syncthreads();
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        if (tid == 0) g.sumsq[(int64_t)e * g.sumsq_stride + t] = red[0] + red[1] + red[2] + red[3];
+    }
+}
+
+bool bf_ok(const ssac_mlp *n) {
+    return n && n->hidden % 32 == 0 && n->hidden >= 32 && n->hidden <= 256 && n->out_dim >= 1 && n->out_dim <= 64 &&
+           n->in_dim >= 1 && bf_lds_bytes(n->in_dim, n->hidden, n->out_dim) <= 160 * 1024;
+}
+
+void bf_fill(BfArgs &g, const ssac_mlp *nets, const uint16_t *shadow, const int32_t *ids, const float *X, int64_t ldx,
+             int n_rows) {
+    g.params = nets->params; g.net_stride = nets->net_stride;
+    g.in_dim = nets->in_dim; g.hidden = nets->hidden; g.out_dim = nets->out_dim;
+    ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, g.off);
+    g.shadow = shadow; g.sg = shadow_geom(nets->in_dim, nets->hidden, nets->out_dim);
+    g.ids = ids; g.X = X; g.ldx = ldx; g.n_rows = n_rows; g.bp = (n_rows + 15) & ~15;
+}
+
+template <typename K>
+int raise_lds(K kernel, bool &done) {
+    if (done) return 0;
+    if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return ssac_fail("ssac_bf16: cannot raise the dynamic LDS limit");
+    done = true;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t ssac_bf16_layout(int in_dim, int hidden, int out_dim, int64_t offsets[4]) {
+    const ShadowGeom g = shadow_geom(in_dim, hidden, out_dim);
+    if (offsets) { offsets[0] = g.o1; offsets[1] = g.o2; offsets[2] = g.o2t; offsets[3] = g.o3; }
+    return g.stride;
+}
+
+extern "C" int ssac_bf16_supported(const ssac_mlp *nets) { return bf_ok(nets) ? 1 : 0; }
+
+extern "C" int ssac_bf16_sync(const ssac_mlp *nets, uint16_t *shadow, void *stream) {
+    if (!nets || !shadow) return ssac_fail("ssac_bf16_sync: missing argument");
+    int64_t off[6];
+    ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, off);
+    const ShadowGeom sg = shadow_geom(nets->in_dim, nets->hidden, nets->out_dim);
+    const int64_t n = (int64_t)nets->hidden * (sg.k1p + nets->hidden + nets->out_dim);
+    dim3 grid((unsigned)((n + 255) / 256 > 512 ? 512 : (n + 255) / 256), nets->n_nets);
+    SSAC_LAUNCH(bf_sync_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float *)nets->params, nets->net_stride,
+                nets->in_dim, nets->hidden, nets->out_dim, off[0], off[2], off[4], (unsigned short *)shadow, sg);
+    return ssac_check_launch("bf16_sync");
+}
+
+extern "C" int ssac_bf16_polyak(const ssac_mlp *target, const ssac_mlp *source, float tau, uint16_t *target_shadow,
+                                void *stream) {
+    if (!target || !source || !target_shadow) return ssac_fail("ssac_bf16_polyak: missing argument");
+    if (target->n_nets != source->n_nets || target->net_stride != source->net_stride || target->in_dim != source->in_dim ||
+        target->hidden != source->hidden || target->out_dim != source->out_dim)
+        return ssac_fail("ssac_bf16_polyak: arenas differ");
+    int64_t off[6];
+    const int64_t n = ssac_mlp_layout(target->in_dim, target->hidden, target->out_dim, off);
+    const ShadowGeom sg = shadow_geom(target->in_dim, target->hidden, target->out_dim);
+    dim3 grid((unsigned)((n + 255) / 256 > 256 ? 256 : (n + 255) / 256), target->n_nets);
+    SSAC_LAUNCH(bf_polyak_kernel, grid, dim3(256), 0, (hipStream_t)stream, target->params, (const float *)source->params,
+                target->net_stride, target->in_dim, target->hidden, target->out_dim, off[0], off[2], off[4], n, tau,
+                (unsigned short *)target_shadow, sg);
+    return ssac_check_launch("bf16_polyak");
+}
+
+extern "C" int ssac_bf16_mlp3_fwd(const ssac_mlp *nets, const uint16_t *shadow, const int32_t *net_ids, int n_sel,
+                                  const float *X, int64_t ldx, int n_rows, float *Y, void *stream) {
+    if (!bf_ok(nets) || !shadow) return ssac_fail("ssac_bf16_mlp3_fwd: shape not supported by the bf16 path");
+    if (n_sel < 0 || n_sel > SSAC_MAX_NETS) return ssac_fail("ssac_bf16_mlp3_fwd: n_sel out of range");
+    if (n_sel == 0 || n_rows <= 0) return 0;
+    BfArgs g{};
+    bf_fill(g, nets, shadow, net_ids, X, ldx, n_rows);
+    g.Y = Y;
+    static bool attr = false;
+    if (raise_lds(bf_mlp_kernel<MODE_PLAIN>, attr)) return 1;
+    const size_t lds = bf_lds_bytes(nets->in_dim, nets->hidden, nets->out_dim);
+    SSAC_LAUNCH(bf_mlp_kernel<MODE_PLAIN>, dim3((n_rows + TM - 1) / TM, n_sel), dim3(NTHR), lds, (hipStream_t)stream, g);
+    return ssac_check_launch("bf16_mlp3_fwd");
+}
+
+extern "C" int ssac_bf16_chain_update(const ssac_mlp *actor, const uint16_t *actor_shadow, const float *Xa, int64_t ldxa,
+                                      int n_rows, const float *eps, float log_std_lo, float log_std_hi, float *x1sa,
+                                      int64_t ld_x1, int64_t act_col0, float *logp, const ssac_rng *rng,
+                                      const ssac_mlp *targets, const uint16_t *target_shadow, const int32_t *net_ids,
+                                      int n_sel, float *Qt, const ssac_mlp *critics, const uint16_t *critic_shadow,
+                                      const float *Xc, int64_t ldxc, float *Q, uint16_t *H1T, uint16_t *H2T,
+                                      uint16_t *DZ2uT, uint16_t *DZ1uT, uint16_t *XT, const ssac_gather *gather,
+                                      void *stream) {
+    if (!eps && !rng) return ssac_fail("ssac_bf16_chain_update: neither eps nor an rng stream given");
+    if (!bf_ok(actor) || (actor->out_dim & 1) || !bf_ok(targets) || !bf_ok(critics))
+        return ssac_fail("ssac_bf16_chain_update: shape not supported by the bf16 path");
+    if (critics->out_dim != 1 || targets->out_dim != 1) return ssac_fail("ssac_bf16_chain_update: single-output critics only");
+    if (n_sel <= 0 || n_sel > SSAC_MAX_NETS) return ssac_fail("ssac_bf16_chain_update: n_sel out of range");
+    if (!actor_shadow || !target_shadow || !critic_shadow || !x1sa || !logp || !Qt || !Q || !H1T || !H2T || !DZ2uT ||
+        !DZ1uT || !XT)
+        return ssac_fail("ssac_bf16_chain_update: missing buffer");
+    if (act_col0 != actor->in_dim || targets->in_dim != actor->in_dim + actor->out_dim / 2)
+        return ssac_fail("ssac_bf16_chain_update: [s'|a'] layout does not match the networks");
+    if (n_rows <= 0) return 0;
+    BfArgs ga{}, gr{}, gt{}, gc{};
+    bf_fill(ga, actor, actor_shadow, nullptr, Xa, ldxa, n_rows);
+    ga.eps = eps; ga.lo = log_std_lo; ga.hi = log_std_hi;
+    if (rng) ga.rng = RngArgs{rng->seed, rng->counter, rng->offset};
+    ga.act_dst = x1sa; ga.ld_act = ld_x1; ga.act_col0 = act_col0; ga.logp = logp;
+    bf_fill(gt, targets, target_shadow, net_ids, x1sa, ld_x1, n_rows);
+    gt.Y = Qt;
+    bf_fill(gc, critics, critic_shadow, nullptr, Xc, ldxc, n_rows);
+    gc.Y = Q; gc.H1T = H1T; gc.H2T = H2T; gc.DZ2T = DZ2uT; gc.DZ1T = DZ1uT; gc.XT = XT;
+    if (gather) {
+        if (gather->s_elems != actor->in_dim || gather->s_elems + gather->a_elems != critics->in_dim)
+            return ssac_fail("ssac_bf16_chain_update: gather sizes do not match the networks");
+        if (!gather->s || !gather->s1 || !gather->act || !gather->rew || !gather->done || !gather->xsa ||
+            gather->x1sa != x1sa || !gather->rew_out || !gather->done_out || (!gather->idx && !gather->feed))
+            return ssac_fail("ssac_bf16_chain_update: incomplete ssac_gather");
+        if (gather->feed && gather->n_logs > NTHR) return ssac_fail("ssac_bf16_chain_update: log block too large");
+        ga.gth = *gather; ga.gth_role = 1;
+        gc.gth = *gather; gc.gth_role = 2;
+    } else if (!Xa || !Xc) {
+        return ssac_fail("ssac_bf16_chain_update: Xa / Xc missing");
+    }
+    gr = ga;
+    if (gather) gr.gth_role = 3;
+    if (gather && gather->feed && gather->ids_word >= 0) { gt.gth = *gather; gt.gth_role = 4; }
+    size_t lds = bf_lds_bytes(actor->in_dim, actor->hidden, actor->out_dim);
+    const size_t lt = bf_lds_bytes(targets->in_dim, targets->hidden, targets->out_dim);
+    const size_t lc = bf_lds_bytes(critics->in_dim, critics->hidden, critics->out_dim);
+    if (lt > lds) lds = lt;
+    if (lc > lds) lds = lc;
+    static bool attr = false;
+    if (raise_lds(bf_chain_kernel, attr)) return 1;
+    const int gx = (n_rows + TM - 1) / TM;
+    const int tiles_t = gx * n_sel;
+    SSAC_LAUNCH(bf_chain_kernel, dim3(tiles_t + gx * critics->n_nets), dim3(NTHR), lds, (hipStream_t)stream, ga, gr, gt, gc,
+                tiles_t, gx);
+    return ssac_check_launch("bf16_chain");
+}
+
+extern "C" int ssac_bf16_wgrad_tiles(const ssac_mlp *nets) {
+    if (!nets) return -1;
+    const int t = (nets->hidden + 63) / 64;
+    return t * t + t * ((nets->in_dim + 63) / 64) + 1;
+}
+
+extern "C" int ssac_bf16_wgrad_lossfold(const ssac_mlp *nets, uint16_t *shadow, const uint16_t *XT, const uint16_t *H1T,
+                                        const uint16_t *H2T, const uint16_t *DZ2uT, const uint16_t *DZ1uT, const float *Q,
+                                        const float *td, const ssac_td_spec *lazy_td, const float *weight, float denom,
+                                        float *partials, int n_rows, float *adam_m, float *adam_v,
+                                        const ssac_adam_ctl *ctl, float *sumsq, int64_t sumsq_net_stride, float *target,
+                                        uint16_t *target_shadow, float tau, void *stream) {
+    if (!bf_ok(nets) || nets->out_dim != 1) return ssac_fail("ssac_bf16_wgrad_lossfold: single-output critics only");
+    if (!shadow || !XT || !H1T || !H2T || !DZ2uT || !DZ1uT || !Q || !partials || (!td && !lazy_td) || !adam_m || !adam_v || !ctl)
+        return ssac_fail("ssac_bf16_wgrad_lossfold: missing argument");
+    if (target && !target_shadow) return ssac_fail("ssac_bf16_wgrad_lossfold: Polyak needs the target's shadow");
+    if (n_rows <= 0) return 0;
+    if (n_rows > 8192) return ssac_fail("ssac_bf16_wgrad_lossfold: more than 8192 rows");
+    BfWgradArgs g{};
+    g.params = nets->params; g.net_stride = nets->net_stride; g.in_dim = nets->in_dim; g.hidden = nets->hidden;
+    ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, g.off);
+    g.shadow = shadow; g.sg = shadow_geom(nets->in_dim, nets->hidden, nets->out_dim);
+    g.H1T = H1T; g.H2T = H2T; g.DZ2T = DZ2uT; g.DZ1T = DZ1uT; g.XT = XT;
+    g.n_rows = n_rows; g.bp = (n_rows + 15) & ~15; g.n_nets = nets->n_nets;
+    g.am = adam_m; g.av = adam_v; g.ctl = ctl; g.target = target; g.tshadow = target_shadow; g.tau = tau;
+    g.sumsq = sumsq; g.sumsq_stride = sumsq_net_stride;
+    g.lf.q = Q; g.lf.td = td; if (lazy_td) g.lf.tds = *lazy_td;
+    g.lf.weight = weight; g.lf.popart = nullptr; g.lf.pop = 0; g.lf.denom = denom; g.lf.partials = partials;
+    g.lf.n_rows = n_rows;
+    const int t = (nets->hidden + 63) / 64;
+    g.tiles2 = t * t; g.tiles1 = t * ((nets->in_dim + 63) / 64);
+    const size_t lds = sizeof(float) * (g.bp + 16);
+    static bool attr = false;
+    if (raise_lds(bf_wgrad_kernel, attr)) return 1;
+    SSAC_LAUNCH(bf_wgrad_kernel, dim3((g.tiles2 + g.tiles1 + 1) * nets->n_nets), dim3(256), lds, (hipStream_t)stream, g);
+    return ssac_check_launch("bf16_wgrad");
+}

@@ -143,6 +143,35 @@ class MlpArena:
         kind = int(lib.ssac_fused_supported(C.byref(self.desc())))  # 1 double-buffered staging fits, 2 single only
         self.fused = bool(kind) and USE_FUSED
         self.fused_dbuf = kind == 1 and USE_FUSED  # eligible as the critic half of the merged launches
+        # bf16-operand mode (csrc/ssac_bf16.hip): a bf16 shadow of the arena, None while the arena computes in fp32
+        self.shadow = None
+
+    # ---- bf16 shadow ---------------------------------------------------------------------------
+    def enable_bf16(self):
+        """allocate the bf16 shadow [W1 | W2 | W2^T | W3] per net and fill it from the fp32 masters"""
+        if not int(lib.ssac_bf16_supported(C.byref(self.desc()))):
+            raise NotImplementedError(f"bf16 mode: shape {self.in_dim}->{self.hidden}->{self.out_dim} is not covered "
+                                      "(hidden % 32 == 0, hidden <= 256, out_dim <= 64)")
+        if self.shadow is None:
+            stride = int(lib.ssac_bf16_layout(self.in_dim, self.hidden, self.out_dim, None))
+            self.shadow_stride = stride
+            self.shadow = torch.zeros(self.n_nets * stride, dtype=torch.bfloat16, device=self.device)
+        self.sync_shadow()
+        return self
+
+    def sync_shadow(self):
+        """shadow <- bf16(master): after construction, load_state_dict, or any fp32 update of the arena"""
+        if self.shadow is not None:
+            check(lib.ssac_bf16_sync(C.byref(self.desc()), self.shadow.data_ptr(), stream()))
+
+    def bf_buffers(self, ws, tag, n_rows):
+        """transposed bf16 saves of the chained update: H1T, H2T, DZ2uT, DZ1uT (n_nets x hidden x Bp), XT (K1P x Bp);
+        zero-initialised once (the kernels never write the pad columns b >= n_rows)"""
+        bp = (n_rows + 15) // 16 * 16
+        k1p = (self.in_dim + 15) // 16 * 16
+        shp = (self.n_nets, self.hidden, bp)
+        return {k_: ws.get(f"{tag}.bf.{k_}", shp if k_ != "xt" else (k1p, bp), dtype=torch.bfloat16, zero=True)
+                for k_ in ("h1t", "h2t", "dz2t", "dz1t", "xt")}
 
     def like(self):
         return torch.zeros_like(self.params)
@@ -214,7 +243,34 @@ def bind_arena(owner, key, modules, device):
     if arena is None or arena.n_nets != len(modules) or not arena.is_bound(modules):
         arena = MlpArena.adopt(modules, device)
         cache[key] = arena
+        if owner.__dict__.get("_ssac_precision") == "bf16":
+            arena.enable_bf16()
     return arena
+
+
+def set_precision(agent, precision):
+    """select the operand type of the matrix products of an agent's networks: "fp32" (the reference's arithmetic, the
+    default) or "bf16" (BASELINE.json config 2; fp32 masters + bf16 shadows, csrc/ssac_bf16.hip).  Marks the modules, so
+    a later ``copy.deepcopy(agent)`` (the target network) inherits the choice."""
+    assert precision in ("fp32", "bf16")
+    dev = next(agent.actors[0].parameters()).device
+    for owner, key, mods in ([(a, "self", [a]) for a in agent.actors] +
+                             [(c, "nets", list(c.nets)) for c in agent.critics]):
+        owner.__dict__["_ssac_precision"] = precision
+        arena = owner.__dict__.get("_ssac_arenas", {}).get(key)
+        if arena is not None:
+            if precision == "bf16":
+                arena.enable_bf16()
+            else:
+                arena.shadow = None
+    return agent
+
+
+def sync_shadows(agent):
+    """refresh every bf16 shadow of an agent from its fp32 masters (after load / load_state_dict)"""
+    for owner in list(agent.actors) + list(agent.critics):
+        for arena in owner.__dict__.get("_ssac_arenas", {}).values():
+            arena.sync_shadow()
 
 
 class DeviceStruct:
@@ -349,6 +405,17 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
 
     def ssp(layer):
         return 0 if sumsq is None else sumsq.data_ptr() + 4 * off[layer]
+    if lossfold is not None and arena.shadow is not None:
+        # bf16 mode: transposed bf16 saves, Adam on the fp32 masters, shadow refreshed by the epilogue
+        f = lossfold
+        bf = f["bf"]
+        tsh = f.get("target_shadow")
+        check(lib.ssac_bf16_wgrad_lossfold(
+            C.byref(d), arena.shadow.data_ptr(), bf["xt"].data_ptr(), bf["h1t"].data_ptr(), bf["h2t"].data_ptr(),
+            bf["dz2t"].data_ptr(), bf["dz1t"].data_ptr(), f["q"].data_ptr(), f["td_ptr"], f["spec_ptr"], f["weight_ptr"],
+            float(f["denom"]), f["partials"].data_ptr(), n_rows, m.data_ptr(), v.data_ptr(), ctl, _ptr(sumsq),
+            bf16_tiles_total(arena), _ptr(target), _ptr(tsh), float(tau), st))
+        return
     if lossfold is not None:
         # UNSCALED backward, and the loss gradient dL/dq itself is evaluated inside the launch (per workgroup, in LDS)
         assert O == 1 and net_ids is None and n_sel == arena.n_nets
@@ -434,6 +501,11 @@ def mlp_backward(arena, dY, X, ldx, x_net_stride, h1, h2, n_rows, ws, tag, *, ad
 
 def wgrad_tiles_total(arena):
     return sum(arena.tiles(l) for l in range(3))
+
+
+def bf16_tiles_total(arena):
+    """gradient-norm partial slots per net of the bf16 weight-gradient launch"""
+    return int(lib.ssac_bf16_wgrad_tiles(C.byref(arena.desc())))
 
 
 def pack_f32(*vals):

@@ -458,7 +458,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             wrow.mul_(scale)
             weight_ptr = wrow.data_ptr()
         pp, dopop = (popart.ptr if popart else 0), (1 if (popart and pop) else 0)
-        ttot = engine.wgrad_tiles_total(arena)
+        ttot = engine.bf16_tiles_total(arena) if arena.shadow is not None else engine.wgrad_tiles_total(arena)
         ss = ws.get(f"cu.ss{i}", (N * ttot,))
         dq = ws.get(f"cu.dq{i}", (N, B, qd))
         grads = ws.get(f"cu.g{i}", (arena.params.numel(),), zero=True) if critic_clip else None
@@ -508,6 +508,8 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                 lossfold = dict(q=q, td_ptr=0 if spec is not None else td.data_ptr(), spec_ptr=spec_ptr,
                                 weight_ptr=weight_ptr, popart_ptr=pp, pop=dopop, denom=float(E * n_glob),
                                 partials=fparts)
+                if arena.shadow is not None:
+                    lossfold["bf"] = arena.bf_buffers(ws, "cu", B)
             elif bwd_done:
                 # ... or a single-workgroup launch writes the N x B scalars for the weight-gradient launch to read
                 if spec is not None:
@@ -544,6 +546,10 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                 check(lib.ssac_mlp_layer_dgrad(C.byref(arena.desc()), 0, 0, N, dz1.data_ptr(), H, B * H, 0, 0, 0,
                                                B, dX.data_ptr(), arena.in_dim, B * arena.in_dim, st))
                 _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, s_rep.shape[1], ws, slot, dev)
+            if arena.shadow is not None and (lossfold is None or critic_clip or popart):
+                raise NotImplementedError(
+                    "bf16 mode covers the chained critic update (one member, continuous single-output critics, "
+                    "stochastic actor, identity encoder, uniform sampling, no PopArt / clipping / DR3)")
             fold = None
             if FOLD_LOGS and E == 1 and not critic_clip and shard is None:
                 # single member, no clipping: the weight-gradient launch's last workgroup finalises the logs
@@ -565,6 +571,8 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             else:
                 fused_logs.append((parts, 0 if bwd_done else N, tiles, B, n_glob, td))
         else:
+            if arena.shadow is not None:
+                raise NotImplementedError("bf16 mode needs the fused kernel family (hidden % 32 == 0, <= 256)")
             h1, h2, q = engine.mlp_forward(arena, X, ldx, 0, B, ws, tag)
             check(lib.ssac_critic_loss_bwd(q.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0),
                                            td.data_ptr(), weight_ptr, pp, dopop, float(E * n_glob),
@@ -738,6 +746,9 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
         member_ss.append(ss)
     if clip:
         _clip_and_step(adam, clip_members, clip, None)
+    for actor in agent.actors:  # bf16 mode: the actor step ran on the fp32 masters; refresh the shadows
+        for ar in actor.__dict__.get("_ssac_arenas", {}).values():
+            ar.sync_shadow()
     pick = rng.choice(agent.actors)  # learning.py:417-419
     k = next(j for j, a_ in enumerate(agent.actors) if a_ is pick)
     check(lib.ssac_group_norms(member_ss[k].data_ptr(), 1, member_ss[k].numel(),
@@ -812,6 +823,9 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
         member_ss.append(ss)
     if actor_clip:
         _clip_and_step(adam, clip_members, actor_clip, None)
+    for actor in agent.actors:
+        for ar in actor.__dict__.get("_ssac_arenas", {}).values():
+            ar.sync_shadow()
     logs["losses/filtered_bc_overall_loss"] = slot[lu.L_BC_TOTAL]
     pick = rng.choice(agent.actors)  # learning.py:210-212
     k = next(j for j, a_ in enumerate(agent.actors) if a_ is pick)

@@ -154,7 +154,11 @@ def soft_update(target, source, tau):
         dev = next(source.parameters()).device
         ta, sa = target.arena(dev), source.arena(dev)
         if ta.params.numel() == sa.params.numel():
-            _polyak_tensor(ta.params, sa.params, tau)
+            if ta.shadow is not None:  # bf16 mode: the target's shadow is refreshed by the same launch
+                check(lib.ssac_bf16_polyak(C.byref(ta.desc()), C.byref(sa.desc()), float(tau), ta.shadow.data_ptr(),
+                                           engine.stream()))
+            else:
+                _polyak_tensor(ta.params, sa.params, tau)
             return
     for tp, sp in zip(target.parameters(), source.parameters()):
         if tp.is_cuda and tp.data.is_contiguous() and sp.data.is_contiguous():
@@ -538,6 +542,23 @@ def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict)
         ensure_gathered(bt)
     q1 = ws.get(tag + ".y", (n, B, 1))
     s1_rep = ch["s1_rep"]
+    if c_arena.shadow is not None:
+        # bf16-operand mode: the same launch on v_mfma_f32_32x32x16_bf16, fed from the arenas' bf16 shadows
+        a_arena = ch["a_arena"]
+        assert a_arena.shadow is not None and t_arena.shadow is not None, \
+            "bf16 mode: set_precision must cover the actor and the target agent too"
+        bf = c_arena.bf_buffers(ws, "cu", B)
+        with engine._timed("chain") as tm:
+            for _ in range(tm.reps):
+                check(lib.ssac_bf16_chain_update(
+                    C.byref(a_arena.desc()), a_arena.shadow.data_ptr(), s1_rep.data_ptr(), _row_stride(s1_rep), B,
+                    ch["eps_ptr"], float(actor.log_std_low), float(actor.log_std_high), x1.data_ptr(), S + A, S,
+                    ch["logp"].data_ptr(), ch["rng_ptr"], C.byref(t_arena.desc()), t_arena.shadow.data_ptr(), ids_ptr, n,
+                    q1.data_ptr(), C.byref(c_arena.desc()), c_arena.shadow.data_ptr(), Xc.data_ptr(), ldxc, qc.data_ptr(),
+                    bf["h1t"].data_ptr(), bf["h2t"].data_ptr(), bf["dz2t"].data_ptr(), bf["dz1t"].data_ptr(),
+                    bf["xt"].data_ptr(), C.byref(gth) if gth is not None else 0, engine.stream()))
+        replay_dict["_co_bwd"] = True
+        return q1
     with engine._timed("chain") as tm:
         for _ in range(tm.reps):  # 1, except under bench.py's live kernel timing (the launch is idempotent)
             check(lib.ssac_chain_update(

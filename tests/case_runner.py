@@ -270,7 +270,7 @@ def build_engine_agent(cfg, device, shard=None, foreign=False):
     return ag
 
 
-def run_engine(name, device="cuda", shard=None, foreign=False):
+def run_engine(name, device="cuda", shard=None, foreign=False, precision="fp32"):
     """`shard` (super_sac_amd.parallel.Shard): run as one rank of a critic-sharded job; the record
     then holds this rank's critics only (see slice_fixture)."""
     import super_sac_amd as ssa
@@ -281,6 +281,8 @@ def run_engine(name, device="cuda", shard=None, foreign=False):
     buf = ssa.replay.ReplayBuffer(cfg["cap"], device=device)
     buf.load_experience(*_buffers(cfg))
     agent = build_engine_agent(cfg, device, shard, foreign=foreign)
+    if precision != "fp32":
+        ssa.set_precision(agent, precision)  # (the deepcopy below inherits it)
     target = copy.deepcopy(agent)
     if shard is not None:
         ssa.parallel.install(agent, target, shard)

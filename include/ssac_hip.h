@@ -151,6 +151,23 @@ int ssac_launch_list_size(const ssac_launch_list *list);
 int ssac_replay(ssac_launch_list *list, void *stream);
 void ssac_launch_list_free(ssac_launch_list *list);
 
+/* ---- one host call per recorded update.  A step owns the host side of a recorded critic update whose per-update
+ * inputs travel through an ssac_feed ring: ssac_step_run composes slot k % n_slots -- [n_rows int64 replay indices |
+ * n_ids int32 REDQ subset ids at ids_off | int32 log-ring slot at logslot_off | int64 noise draw number at draw_off
+ * (-1: none)] (byte offsets inside a slot of slot_bytes, a multiple of 16) -- copies it into the ring, re-issues the
+ * launch lists added with ssac_step_add_list in order (borrowed, not freed), and records / waits the slot-reuse events
+ * (one per event_every updates; event_every divides n_slots).  What remains above the C ABI per update is drawing the
+ * indices (torch CPU generator, replay.py:122) and the subset (Python random, agent.py:29). */
+typedef struct ssac_step ssac_step;
+ssac_step *ssac_step_create(void *ring, int n_slots, int slot_bytes, int n_rows, int n_ids, int ids_off,
+                            int logslot_off, int draw_off, int event_every);   /* NULL + ssac_last_error on error */
+int ssac_step_add_list(ssac_step *step, ssac_launch_list *list);
+int ssac_step_run(ssac_step *step, const int64_t *idx_host, const int32_t *ids_host, int32_t log_slot, int64_t draw,
+                  void *stream);
+int64_t ssac_step_count(const ssac_step *step);
+int ssac_step_seek(ssac_step *step, int64_t k);   /* updates the ring's device-side counter has consumed so far */
+void ssac_step_destroy(ssac_step *step);
+
 /* floats per net and the six segment offsets {W1,b1,W2,b2,W3,b3}. */
 int64_t ssac_mlp_layout(int in_dim, int hidden, int out_dim, int64_t offsets[6]);
 
@@ -599,6 +616,9 @@ int ssac_ln_tanh_bwd(const float *d_out, int64_t ldd, const float *out, int64_t 
  * 16-byte loads.  Covers the chained critic update of continuous single-output critics (hidden % 32 == 0, <= 256). ==== */
 int64_t ssac_bf16_layout(int in_dim, int hidden, int out_dim, int64_t offsets[4]);
 int ssac_bf16_supported(const ssac_mlp *nets);
+/* development aid: a device buffer of >= 64 int64 receives s_memtime() phase stamps of tile 0 of the bf16 launches
+ * (slots 0.. actor pass, 16.. target-critic pass, 32.. critic workgroup, 48.. weight-gradient tile); NULL disables */
+int ssac_bf16_debug_stamps(long long *dev_buf);
 /* shadow <- bf16(master) for every net (after construction, load_state_dict, or an fp32 update of the arena) */
 int ssac_bf16_sync(const ssac_mlp *nets, uint16_t *shadow, void *stream);
 /* learning_utils.py:160-162 on the fp32 masters, and the target's shadow refreshed in the same launch */

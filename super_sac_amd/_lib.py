@@ -73,6 +73,12 @@ SIGNATURES = {
     "ssac_launch_list_size": [_P],
     "ssac_replay": [_P, _P],
     "ssac_launch_list_free": [_P],
+    "ssac_step_create": [_P, _I, _I, _I, _I, _I, _I, _I, _I],
+    "ssac_step_add_list": [_P, _P],
+    "ssac_step_run": [_P, _P, _P, C.c_int32, _L, _P],
+    "ssac_step_count": [_P],
+    "ssac_step_seek": [_P, _L],
+    "ssac_step_destroy": [_P],
     "ssac_gather_rows": [_P, _I, _L, _P, _I, _P, _L, _L, _P],
     "ssac_mlp_layer_fwd": [_MP, _I, _P, _I, _P, _L, _L, _I, _P, _L, _L, _I, _P],
     "ssac_mlp_layer_dgrad": [_MP, _I, _P, _I, _P, _L, _L, _P, _L, _L, _I, _P, _L, _L, _P],
@@ -161,6 +167,7 @@ SIGNATURES = {
     "ssac_critic_logs": [_P, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _P, _P],
     "ssac_bf16_layout": [_I, _I, _I, C.POINTER(C.c_int64)],
     "ssac_bf16_supported": [_MP],
+    "ssac_bf16_debug_stamps": [_P],
     "ssac_bf16_sync": [_MP, _P, _P],
     "ssac_bf16_polyak": [_MP, _MP, _F, _P, _P],
     "ssac_bf16_mlp3_fwd": [_MP, _P, _P, _I, _P, _L, _I, _P, _P],
@@ -170,7 +177,8 @@ SIGNATURES = {
     "ssac_bf16_wgrad_lossfold": [_MP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P, _L, _P, _P, _F,
                                  _P],
 }
-_RESTYPES = {"ssac_last_error": C.c_char_p, "ssac_mlp_layout": C.c_int64, "ssac_bf16_layout": C.c_int64, "ssac_record_end": C.c_void_p,
+_RESTYPES = {"ssac_step_create": C.c_void_p, "ssac_step_count": C.c_int64, "ssac_step_destroy": None,
+             "ssac_last_error": C.c_char_p, "ssac_mlp_layout": C.c_int64, "ssac_bf16_layout": C.c_int64, "ssac_record_end": C.c_void_p,
              "ssac_launch_list_free": None}
 
 

@@ -37,6 +37,11 @@ constexpr int LPAD = 8;     // LDS row padding (elements): 16-byte aligned rows,
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 constexpr float LOG_2 = 0.69314718055994530942f;
 
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global loads / stores.
+// __syncthreads() also drains vmcnt, which would stall every phase boundary on the weight fragments prefetched for the
+// NEXT phase and on the (slow, fire-and-forget) transposed activation stores.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ unsigned short f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
@@ -68,42 +73,49 @@ struct BfArgs {
     unsigned short *H1T, *H2T, *DZ2T, *DZ1T, *XT;
     ssac_gather gth; int gth_role;  // as in ssac_fused.hip: 1 actor half (+ start-of-update duties), 3 actor half,
                                     // 2 critic half, 4 rows from X with the subset ids read from the input slot
+    long long *dbg;                 // optional s_memtime phase stamps of tile 0 (ssac_bf16_debug_stamps)
+};
+#define BSTAMP(i) do { if (g.dbg && bx == 0 && e == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+
+// ---- one layer as D[b][n] = sum_k act[b][k] W[n][k] on v_mfma_f32_32x32x16_bf16.  A = the tile's 32 activation rows in
+// LDS (lane (b = lane & 31, half = lane >> 5) reads 8 consecutive k of row b); B = 32 weight rows (row stride ldw, K
+// contiguous): lane (n = lane & 31, half) reads 8 consecutive k of row n -- one 16-byte global load per MFMA straight
+// from the shadow.  acc[r] of lane (n, half) = D[(r&3) + 8(r>>2) + 4 half][n]: a lane holds 4 CONSECUTIVE BATCH ROWS of
+// one feature per register quad, so the transposed saves (feature-major, batch contiguous) leave as 8-byte stores.
+// The weight fragments are PREFETCHED (Frags::load) one phase ahead, so no layer starts with an exposed global round
+// trip: the first 16 K-steps (K <= 256: all of them) wait in registers, longer K continue with in-loop loads.
+struct Frags {
+    u16x8 w[16];
+    // wp: this lane's fragment pointer (row n of the wave's 32 rows, + 8 half); steps beyond nsteps re-read the last
+    // one (unconditional loads: a load inside a branch would drain the whole vmcnt queue at the join)
+    __device__ __forceinline__ void load(const unsigned short *__restrict__ wp, int nsteps) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const u16x8 *>(wp + 16 * (t < nsteps ? t : nsteps - 1));
+    }
 };
 
-// One layer as D^T[n][b] = sum_k W[n][k] act[b][k] on v_mfma_f32_32x32x16_bf16: A = 32 weight rows starting at Wrows
-// (row stride ldw elements, K contiguous; lane (i = lane & 31, half = lane >> 5) reads 8 consecutive k of row i), B =
-// the tile's 32 activation rows in LDS (row stride lda).  acc[r] of lane (b, half) = D^T[(r & 3) + 8 (r >> 2) + 4 half][b].
-// nsteps = K / 16.  All global loads of a 16-step block are issued before its first MFMA.
-__device__ __forceinline__ void bf_layer(f32x16 &acc, const unsigned short *__restrict__ Wrows, int64_t ldw, int nsteps,
-                                         const unsigned short *__restrict__ act, int lda, int lane) {
-    const int li = lane & 31, lh = lane >> 5;
-    const unsigned short *wp = Wrows + (int64_t)li * ldw + 8 * lh;
-    const unsigned short *ap = act + li * lda + 8 * lh;
-    if (nsteps == 16) {  // hidden 256: the whole K in flight at once
-        u16x8 w[16];
+__device__ __forceinline__ void bf_mma(f32x16 &acc, const Frags &f, const unsigned short *__restrict__ wp, int nsteps,
+                                       const unsigned short *__restrict__ ap) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const u16x8 *>(wp + 16 * t);
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
+    for (int t = 0; t < 16; ++t) {
+        if (t < nsteps) {
             const u16x8 a = *reinterpret_cast<const u16x8 *>(ap + 16 * t);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t]), __builtin_bit_cast(bf16x8, a),
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, f.w[t]),
                                                           acc, 0, 0, 0);
         }
-        return;
     }
-    int t = 0;
-    for (; t + 2 <= nsteps; t += 2) {
-        const u16x8 w0 = *reinterpret_cast<const u16x8 *>(wp + 16 * t);
-        const u16x8 w1 = *reinterpret_cast<const u16x8 *>(wp + 16 * t + 16);
-        const u16x8 a0 = *reinterpret_cast<const u16x8 *>(ap + 16 * t);
-        const u16x8 a1 = *reinterpret_cast<const u16x8 *>(ap + 16 * t + 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), __builtin_bit_cast(bf16x8, a0), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1), __builtin_bit_cast(bf16x8, a1), acc, 0, 0, 0);
-    }
-    if (t < nsteps) {
-        const u16x8 w0 = *reinterpret_cast<const u16x8 *>(wp + 16 * t);
-        const u16x8 a0 = *reinterpret_cast<const u16x8 *>(ap + 16 * t);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w0), __builtin_bit_cast(bf16x8, a0), acc, 0, 0, 0);
+    for (int t0 = 16; t0 < nsteps; t0 += 8) {   // K > 256 (wide observations): 8 steps in flight at a time
+        u16x8 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const u16x8 *>(wp + 16 * (t0 + u < nsteps ? t0 + u : nsteps - 1));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (t0 + u < nsteps) {
+                const u16x8 a = *reinterpret_cast<const u16x8 *>(ap + 16 * (t0 + u));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, w[u]),
+                                                              acc, 0, 0, 0);
+            }
+        }
     }
 }
 
@@ -112,12 +124,26 @@ __device__ __forceinline__ void zero_acc(f32x16 &a) {
     for (int i = 0; i < 16; ++i) a[i] = 0.0f;
 }
 
+__device__ __forceinline__ bool bf_pos(unsigned short h) { return (h & 0x7fff) != 0 && !(h & 0x8000); }
+
+// 4 consecutive batch rows [b0, b0+4) of feature row `dst` (batch contiguous): one 8-byte store when the whole quad is
+// inside the batch, element-wise at a ragged end
+__device__ __forceinline__ void store_quad(unsigned short *__restrict__ dst, int b0, int n_rows, u16x4 v) {
+    if (b0 + 3 < n_rows) {
+        *reinterpret_cast<u16x4 *>(dst + b0) = v;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (b0 + i < n_rows) dst[b0 + i] = v[i];
+    }
+}
+
 // LDS carve (bytes) of one workgroup
 __host__ __device__ inline size_t bf_lds_bytes(int in_dim, int hidden, int out_dim) {
     const int k1p = (in_dim + 15) & ~15;
     const int ldo = (out_dim + 31) & ~31;
-    size_t b = 2 * ((size_t)TM * (k1p + LPAD) + 2 * (size_t)TM * (hidden + LPAD));   // xs, h1s, h2s (bf16)
-    b += 4 * ((size_t)TM * ldo + 2 * hidden + ldo + (size_t)TM * ldo + 3 * TM + 64);  // ys, b1s, b2s, b3s, lpt, rowin, pad
+    size_t b = 2 * ((size_t)TM * (k1p + LPAD) + 2 * (size_t)TM * (hidden + LPAD));             // xs, h1s, h2s (bf16)
+    b += 4 * (2 * (size_t)TM * ldo + 3 * (size_t)hidden + ldo + 64);                           // ys, lpt, b1s, b2s, w3f, b3s
     return (b + 15) & ~(size_t)15;
 }
 
@@ -130,14 +156,16 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
     unsigned short *h1s = xs + TM * ldx_s;
     unsigned short *h2s = h1s + TM * ldh;
     float *ys = reinterpret_cast<float *>(h2s + TM * ldh);   // [TM][ldo]
-    float *b1s = ys + TM * ldo;                              // [H]
+    float *lpt = ys + TM * ldo;                              // [TM][ldo] scratch of the sample epilogue
+    float *b1s = lpt + TM * ldo;                             // [H]
     float *b2s = b1s + H;                                    // [H]
-    float *b3s = b2s + H;                                    // [ldo]
-    float *lpt = b3s + ldo;                                  // [TM][ldo] scratch of the sample epilogue
+    float *w3f = b2s + H;                                    // [H]   W3 row 0 as fp32 (single-output heads)
+    float *b3s = w3f + H;                                    // [ldo]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int m0 = bx * TM;
 
+    BSTAMP(0);
     // ---- where this tile's rows come from (replay gather folded in; see ssac_gather in include/ssac_hip.h)
     const int64_t *gidx = nullptr;
     const uint32_t *gslot = nullptr;
@@ -157,6 +185,11 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
         }
         if (g.gth_role == 4) gidx = nullptr;
     }
+    // ---- the replay index of this thread's row is the OLDEST load in flight (16 lanes per row), so waiting for it
+    //      does not wait for the weight fragments issued behind it
+    const int xr = tid >> 4, xl = tid & 15;   // NTHR / 16 = TM rows, one pass
+    const bool rok = (m0 + xr) < g.n_rows;
+    const int64_t src = (gidx && rok) ? gidx[m0 + xr] : 0;
     const int net = idsp ? idsp[e] : e;
     if (net < 0) {  // empty subset slot of a sharded rank: +inf, the neutral element of the min that follows
         if (MODE == MODE_PLAIN && g.Y)
@@ -170,92 +203,166 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
     const unsigned short *S = g.shadow + (int64_t)net * g.sg.stride;
     const int col0 = wave * 32;
     const bool wave_on = col0 < H;
+    const int c0 = wave_on ? col0 : 0;  // (idle waves prefetch wave 0's rows: unconditional loads, results unused)
+    const int ns1 = K1P >> 4, nsh = H >> 4;
+    const int n_me = col0 + li;         // the feature this lane owns in the hidden layers
 
-    // ---- x tile -> LDS (bf16), biases -> LDS; the gathered rows are also written out in fp32 for the later updates
-    {
-        const bool actor_half = (g.gth_role & 1) != 0;
-        const int Sg = gidx ? (int)g.gth.s_elems : 0;
-        float *outp = gidx ? (actor_half ? g.gth.x1sa : (e == 0 ? g.gth.xsa : nullptr)) : nullptr;
-        const int64_t ldo_g = actor_half ? g.gth.ld_x1 : g.gth.ld_x;
-        for (int r = tid >> 4; r < TM; r += NTHR / 16) {   // 16 lanes per row
-            const bool rok = (m0 + r) < g.n_rows;
-            const int64_t src = (gidx && rok) ? gidx[m0 + r] : 0;
-            for (int k = tid & 15; k < K1P; k += 16) {
-                float v = 0.0f;
-                if (rok && k < IN) {
-                    if (gidx) v = k < Sg ? (actor_half ? g.gth.s1 : g.gth.s)[src * Sg + k]
-                                         : g.gth.act[src * g.gth.a_elems + (k - Sg)];
-                    else v = g.X[(int64_t)(m0 + r) * g.ldx + k];
-                    if (outp) outp[(int64_t)(m0 + r) * ldo_g + k] = v;
-                }
-                const unsigned short hv = f2bf(v);
-                xs[r * ldx_s + k] = hv;
-                if (MODE == MODE_CRITIC_U && e == 0 && g.XT && rok) g.XT[(int64_t)k * g.bp + m0 + r] = hv;
+    // ---- x tile: the row loads go out as soon as the index is back; every weight fragment of fc1 and fc2 and the
+    //      small operands follow them into flight (they depend on nothing but the net id)
+    const bool actor_half = (g.gth_role & 1) != 0;
+    const int Sg = gidx ? (int)g.gth.s_elems : 0;
+    const float *srow = gidx ? (actor_half ? g.gth.s1 : g.gth.s) + src * Sg : g.X + (int64_t)(rok ? m0 + xr : 0) * g.ldx;
+    const float *arow = gidx ? g.gth.act + src * g.gth.a_elems - Sg : srow;
+    float xv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {   // first 128 columns of the row (all of them for in_dim <= 128)
+        const int k = xl + 16 * u;
+        const bool ok = rok && k < IN;
+        const bool in_act = gidx && k >= Sg;   // (arow is biased by -Sg: its first valid index is Sg)
+        xv[u] = (in_act ? arow : srow)[ok ? k : (in_act ? Sg : 0)];
+        if (!ok) xv[u] = 0.0f;
+    }
+    const unsigned short *wp1 = S + g.sg.o1 + (int64_t)(c0 + li) * K1P + 8 * lh;
+    const unsigned short *wp2 = S + g.sg.o2 + (int64_t)(c0 + li) * H + 8 * lh;
+    Frags f1, f2;
+    f1.load(wp1, ns1);
+    f2.load(wp2, nsh);
+    float *outp = gidx ? (actor_half ? g.gth.x1sa : (e == 0 ? g.gth.xsa : nullptr)) : nullptr;
+    const int64_t ldo_g = actor_half ? g.gth.ld_x1 : g.gth.ld_x;
+    float rew_v = 0.0f, done_v = 0.0f;
+    const bool rd_lane = gidx && actor_half && xl == 0 && rok;
+    if (rd_lane) { rew_v = g.gth.rew[src]; done_v = (float)g.gth.done[src]; }
+    float bv1 = 0.0f, bv2 = 0.0f, wv3 = 0.0f, bv3 = 0.0f;
+    if (tid < H) { bv1 = P[g.off[1] + tid]; bv2 = P[g.off[3] + tid]; wv3 = bf2f(S[g.sg.o3 + tid]); }
+    if (tid < ldo) bv3 = tid < OUT ? P[g.off[5] + tid] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int k = xl + 16 * u;
+        if (k < K1P) {
+            xs[xr * ldx_s + k] = f2bf(xv[u]);
+            if (rok && k < IN && outp) outp[(int64_t)(m0 + xr) * ldo_g + k] = xv[u];
+        }
+    }
+    for (int k0 = xl + 128; k0 < K1P; k0 += 128) {   // wide observations: 8 more columns per lane per round
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 16 * u;
+            const bool ok = rok && k < IN;
+            const bool in_act = gidx && k >= Sg;
+            v[u] = (in_act ? arow : srow)[ok ? k : (in_act ? Sg : 0)];
+            if (!ok) v[u] = 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 16 * u;
+            if (k < K1P) {
+                xs[xr * ldx_s + k] = f2bf(v[u]);
+                if (rok && k < IN && outp) outp[(int64_t)(m0 + xr) * ldo_g + k] = v[u];
             }
         }
-        if (gidx && actor_half && tid < TM && (m0 + tid) < g.n_rows) {
-            const int64_t src = gidx[m0 + tid];
-            g.gth.rew_out[m0 + tid] = g.gth.rew[src];
-            g.gth.done_out[m0 + tid] = (float)g.gth.done[src];
-        }
-        for (int i = tid; i < H; i += NTHR) { b1s[i] = P[g.off[1] + i]; b2s[i] = P[g.off[3] + i]; }
-        for (int i = tid; i < ldo; i += NTHR) b3s[i] = i < OUT ? P[g.off[5] + i] : 0.0f;
     }
-    __syncthreads();
+    if (rd_lane) { g.gth.rew_out[m0 + xr] = rew_v; g.gth.done_out[m0 + xr] = done_v; }
+    if (tid < H) { b1s[tid] = bv1; b2s[tid] = bv2; w3f[tid] = wv3; }
+    if (tid < ldo) b3s[tid] = bv3;
+    lds_barrier();
+    BSTAMP(1);
+    if (MODE == MODE_CRITIC_U && e == 0 && g.XT) {
+        // the [s|a] tile transposed (K1P x Bp, batch contiguous) for the fc1 weight gradient: 4 batch rows per store
+        for (int i = tid; i < K1P * (TM / 4); i += NTHR) {
+            const int k = i % K1P, b0 = (i / K1P) * 4;
+            u16x4 v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = xs[(b0 + u) * ldx_s + k];
+            store_quad(g.XT + (int64_t)k * g.bp + m0, b0, g.n_rows - m0, v);
+        }
+    }
 
     f32x16 acc;
     // ---- fc1
+    zero_acc(acc);
+    bf_mma(acc, f1, wp1, ns1, xs + li * ldx_s + 8 * lh);
+    BSTAMP(2);
+    // the NEXT matrix after fc2 goes in flight now, into fc1's registers: W2^T (backward-data) or the head's rows
+    const unsigned short *wp3;
+    if (MODE == MODE_CRITIC_U) {
+        wp3 = S + g.sg.o2t + (int64_t)(c0 + li) * H + 8 * lh;
+    } else {
+        const int hrow = (col0 + li) < OUT ? col0 + li : 0;
+        wp3 = S + g.sg.o3 + (int64_t)hrow * H + 8 * lh;
+    }
+    f1.load(wp3, nsh);
     if (wave_on) {
-        zero_acc(acc);
-        bf_layer(acc, S + g.sg.o1 + (int64_t)col0 * K1P, K1P, K1P >> 4, xs, ldx_s, lane);
+        const float bias = b1s[n_me];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int n = col0 + 8 * q + 4 * lh;
+            const int b0 = 8 * q + 4 * lh;
             u16x4 hv;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hv[i] = f2bf(fmaxf(acc[4 * q + i] + b1s[n + i], 0.0f));
-            *reinterpret_cast<u16x4 *>(h1s + li * ldh + n) = hv;
-            if (MODE == MODE_CRITIC_U && (m0 + li) < g.n_rows)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) g.H1T[((int64_t)e * H + n + i) * g.bp + m0 + li] = hv[i];
+            for (int i = 0; i < 4; ++i) {
+                hv[i] = f2bf(fmaxf(acc[4 * q + i] + bias, 0.0f));
+                h1s[(b0 + i) * ldh + n_me] = hv[i];
+            }
+            if (MODE == MODE_CRITIC_U) store_quad(g.H1T + ((int64_t)e * H + n_me) * g.bp + m0, b0, g.n_rows - m0, hv);
         }
     }
-    __syncthreads();
+    lds_barrier();
+    BSTAMP(3);
     // ---- fc2
+    zero_acc(acc);
+    bf_mma(acc, f2, wp2, nsh, h1s + li * ldh + 8 * lh);
+    BSTAMP(4);
     if (wave_on) {
-        zero_acc(acc);
-        bf_layer(acc, S + g.sg.o2 + (int64_t)col0 * H, H, H >> 4, h1s, ldh, lane);
+        const float bias = b2s[n_me];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int n = col0 + 8 * q + 4 * lh;
+            const int b0 = 8 * q + 4 * lh;
             u16x4 hv;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hv[i] = f2bf(fmaxf(acc[4 * q + i] + b2s[n + i], 0.0f));
-            *reinterpret_cast<u16x4 *>(h2s + li * ldh + n) = hv;
-            if (MODE == MODE_CRITIC_U && (m0 + li) < g.n_rows)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) g.H2T[((int64_t)e * H + n + i) * g.bp + m0 + li] = hv[i];
+            for (int i = 0; i < 4; ++i) {
+                hv[i] = f2bf(fmaxf(acc[4 * q + i] + bias, 0.0f));
+                h2s[(b0 + i) * ldh + n_me] = hv[i];
+            }
+            if (MODE == MODE_CRITIC_U) store_quad(g.H2T + ((int64_t)e * H + n_me) * g.bp + m0, b0, g.n_rows - m0, hv);
         }
     }
-    __syncthreads();
-    // ---- head: wave w computes outputs [32w, 32w + 32) over the whole K (rows past OUT read row 0 and are dropped)
-    if (col0 < OUT) {
-        zero_acc(acc);
-        const int row = (col0 + li) < OUT ? col0 + li : 0;
-        // (bf_layer adds li * ldw itself: hand it the row through a zero stride)
-        bf_layer(acc, S + g.sg.o3 + (int64_t)row * H, 0, H >> 4, h2s, ldh, lane);
+    lds_barrier();
+    BSTAMP(5);
+    // ---- head
+    if (OUT == 1) {
+        // single output (critics): 16 lanes per row, fp32 dot product of the bf16 operands, shuffle tree
+        float s = 0.0f;
+        for (int k = xl * 8; k < H; k += 128) {
+            const u16x8 hv = *reinterpret_cast<const u16x8 *>(h2s + xr * ldh + k);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = col0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (o < OUT) {
-                const float v = acc[r] + b3s[o];
-                ys[li * ldo + o] = v;
-                if (g.Y && (m0 + li) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + li) * OUT + o] = v;
+            for (int u = 0; u < 8; ++u) s += bf2f(hv[u]) * w3f[k + u];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (xl == 0) {
+            const float v = s + b3s[0];
+            ys[xr * ldo] = v;
+            if (g.Y && rok) g.Y[(int64_t)e * g.n_rows + m0 + xr] = v;
+        }
+    } else if (col0 < OUT) {
+        // wave w computes outputs [32w, 32w + 32) over the whole K (rows past OUT read row 0 and are dropped)
+        zero_acc(acc);
+        bf_mma(acc, f1, wp3, nsh, h2s + li * ldh + 8 * lh);
+        const int o = col0 + li;
+        if (o < OUT) {
+            const float bias = b3s[o];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float v = acc[r] + bias;
+                ys[b * ldo + o] = v;
+                if (g.Y && (m0 + b) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + b) * OUT + o] = v;
             }
         }
     }
+    BSTAMP(6);
     if (MODE == MODE_PLAIN) return;
-    __syncthreads();
+    lds_barrier();
 
     if (MODE == MODE_SAMPLE) {
         // tanh-normal head in fp32 (distributions.py:9-15, 64-104), as in ssac_fused.hip
@@ -277,48 +384,46 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
                 g.act_dst[b * g.ld_act + g.act_col0 + i] = tanhf(u);
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (g.logp && tid < TM && (m0 + tid) < g.n_rows) {
             float lp = 0.0f;
             for (int i = 0; i < A; ++i) lp += lpt[tid * ldo + i];
             g.logp[m0 + tid] = lp;
         }
+        BSTAMP(7);
         return;
     }
 
     // ---- MODE_CRITIC_U (single-output critics): the TD-independent half of the backward pass.
-    //      dz2u[b][j] = W3[j] [h2[b][j] > 0] in place over h2s, then dz1u^T = (W2^T . dz2u^T) (.) [h1 > 0]
-    {
-        const unsigned short *w3 = S + g.sg.o3;
-        for (int i = tid; i < TM * (H >> 2); i += NTHR) {
-            const int r = i / (H >> 2), j = (i - r * (H >> 2)) * 4;
-            const u16x4 hv = *reinterpret_cast<const u16x4 *>(h2s + r * ldh + j);
-            const u16x4 wv = *reinterpret_cast<const u16x4 *>(w3 + j);
-            u16x4 dz;
+    //      dz2u[b][j] = W3[j] [h2[b][j] > 0] in place over h2s (one feature x 4 batch rows per thread: 8-byte transposed
+    //      stores), then dz1u = (dz2u . W2) (.) [h1 > 0]
+    for (int i = tid; i < H * (TM / 4); i += NTHR) {
+        const int j = i % H, b0 = (i / H) * 4;
+        const unsigned short wj = f2bf(w3f[j]);
+        u16x4 dz;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) dz[u] = (hv[u] & 0x7fff) != 0 && !(hv[u] & 0x8000) ? wv[u] : (unsigned short)0;
-            *reinterpret_cast<u16x4 *>(h2s + r * ldh + j) = dz;
-            if ((m0 + r) < g.n_rows)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) g.DZ2T[((int64_t)e * H + j + u) * g.bp + m0 + r] = dz[u];
+        for (int u = 0; u < 4; ++u) {
+            dz[u] = bf_pos(h2s[(b0 + u) * ldh + j]) ? wj : (unsigned short)0;
+            h2s[(b0 + u) * ldh + j] = dz[u];
         }
+        store_quad(g.DZ2T + ((int64_t)e * H + j) * g.bp + m0, b0, g.n_rows - m0, dz);
     }
-    __syncthreads();
+    lds_barrier();
+    BSTAMP(7);
+    zero_acc(acc);
+    bf_mma(acc, f1, wp3, nsh, h2s + li * ldh + 8 * lh);
+    BSTAMP(8);
     if (wave_on) {
-        zero_acc(acc);
-        bf_layer(acc, S + g.sg.o2t + (int64_t)col0 * H, H, H >> 4, h2s, ldh, lane);
-        if ((m0 + li) < g.n_rows) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = col0 + 8 * q + 4 * lh;
-                const u16x4 hm = *reinterpret_cast<const u16x4 *>(h1s + li * ldh + n);
+        for (int q = 0; q < 4; ++q) {
+            const int b0 = 8 * q + 4 * lh;
+            u16x4 dv;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    g.DZ1T[((int64_t)e * H + n + i) * g.bp + m0 + li] =
-                        ((hm[i] & 0x7fff) != 0 && !(hm[i] & 0x8000)) ? f2bf(acc[4 * q + i]) : (unsigned short)0;
-            }
+            for (int i = 0; i < 4; ++i) dv[i] = bf_pos(h1s[(b0 + i) * ldh + n_me]) ? f2bf(acc[4 * q + i]) : (unsigned short)0;
+            store_quad(g.DZ1T + ((int64_t)e * H + n_me) * g.bp + m0, b0, g.n_rows - m0, dv);
         }
     }
+    BSTAMP(9);
 }
 
 template <int MODE>
@@ -340,9 +445,12 @@ __global__ __launch_bounds__(NTHR) void bf_chain_kernel(BfArgs ga, BfArgs ga_res
         else bf_mlp_body<MODE_SAMPLE>(ga_rest, smem, bx, 0);
         __threadfence_block();  // this workgroup's a' rows (global) are read back by its own target-critic pass
         __syncthreads();
+        if (gt.dbg && j == 0) gt.dbg += 16;  // (stamps of the second pass: slots 16..)
+        else gt.dbg = nullptr;
         bf_mlp_body<MODE_PLAIN>(gt, smem, bx, j);
     } else {
         const int L = bid - tiles_t;
+        if (gc.dbg) gc.dbg += 32;  // (stamps of the critic half: slots 32..)
         bf_mlp_body<MODE_CRITIC_U>(gc, smem, L % grid_x, L / grid_x);
     }
 }
@@ -421,7 +529,9 @@ struct BfWgradArgs {
     float *sumsq; int64_t sumsq_stride;
     LossFoldArgs lf;
     int tiles2, tiles1;   // 64x64 tiles of fc2 / fc1 per net; then 1 head workgroup per net
+    long long *dbg;
 };
+#define WSTAMP(i) do { if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0) g.dbg[48 + i] = __builtin_amdgcn_s_memtime(); } while (0)
 
 __device__ __forceinline__ float adam_elem(float p, float g, float &m, float &v, const ssac_adam_ctl &c) {
     if (c.weight_decay != 0.0f) g = g + c.weight_decay * p;
@@ -451,27 +561,75 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
     const int per_net = g.tiles2 + g.tiles1 + 1;
     const int e = blockIdx.x / per_net, t = blockIdx.x - e * per_net;
     const int H = g.hidden, IN = g.in_dim, K1P = g.sg.k1p;
-    // ---- loss gradient of this net's rows -> LDS (the first fc2 tile of each net also reduces the loss terms)
-    for (int b = g.n_rows + tid; b < g.bp; b += 256) tab[b] = 0.0f;
-    loss_fold_table(g.lf, e, tab, t == 0, red);
-    __syncthreads();
     float *P = g.params + (int64_t)e * g.net_stride;
     float *M = g.am + (int64_t)e * g.net_stride, *V = g.av + (int64_t)e * g.net_stride;
     float *T = g.target ? g.target + (int64_t)e * g.net_stride : nullptr;
     unsigned short *S = g.shadow + (int64_t)e * g.sg.stride;
     unsigned short *TS = g.tshadow ? g.tshadow + (int64_t)e * g.sg.stride : nullptr;
+    const bool head = t == per_net - 1;
+    WSTAMP(0);
+    // ---- tile geometry (GEMM tiles)
+    const bool fc2 = t < g.tiles2;
+    const int tt = fc2 ? t : t - g.tiles2;
+    const int Ncols = fc2 ? H : IN;                 // valid gradient columns
+    const int gx = fc2 ? (H + 63) / 64 : (IN + 63) / 64;
+    const int by = tt / gx, bxn = tt - by * gx;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int row = by * 64 + wm * 32 + li;         // gradient row j (0 .. H)
+    const int col = bxn * 64 + wn * 32 + li;        // gradient column i
+    const int Brows = fc2 ? H : K1P;                // rows of the B operand's transposed buffer
+    const unsigned short *AT = (fc2 ? g.DZ2T : g.DZ1T) + ((int64_t)e * H + (row < H ? row : 0)) * g.bp + 8 * lh;
+    const unsigned short *BT = fc2 ? g.H1T + ((int64_t)e * H + (col < Brows ? col : 0)) * g.bp + 8 * lh
+                                   : g.XT + (int64_t)(col < Brows ? col : 0) * g.bp + 8 * lh;
+    const int nsteps = g.bp >> 4;
+    constexpr int G = 8;
+    u16x8 a0[G], b0[G], a1[G], b1[G];
+    auto load = [&](u16x8 (&a)[G], u16x8 (&b)[G], int s0) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int s = s0 + u < nsteps ? s0 + u : nsteps - 1;   // clamped: redundant loads, never used
+            a[u] = *reinterpret_cast<const u16x8 *>(AT + 16 * s);
+            b[u] = *reinterpret_cast<const u16x8 *>(BT + 16 * s);
+        }
+    };
+    // ---- everything that does not depend on the loss gradient goes in flight first: the first operand group and
+    //      the optimizer state of this wave's 16 gradient elements (read again only in the epilogue)
+    const int64_t off_w = fc2 ? g.off[2] : g.off[0];
+    const int ldc = fc2 ? H : IN;
+    float pv[16], mv[16], vv[16], tv[16];
+    if (!head) {
+        load(a0, b0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = by * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int64_t a = off_w + (int64_t)(j < H ? j : 0) * ldc + (col < Ncols ? col : 0);
+            pv[r] = P[a]; mv[r] = M[a]; vv[r] = V[a];
+            tv[r] = T ? T[a] : 0.0f;
+        }
+    }
+    // ---- loss gradient of this net's rows -> LDS (the first fc2 tile of each net also reduces the loss terms)
+    for (int b = g.n_rows + tid; b < g.bp; b += 256) tab[b] = 0.0f;
+    loss_fold_table(g.lf, e, tab, t == 0, red);
+    __syncthreads();
+    WSTAMP(1);
     const ssac_adam_ctl ctl = *g.ctl;
     float ss = 0.0f;
-    if (t == per_net - 1) {
+    if (head) {
         // ---- head layer (VALU): thread i owns W3[i]
         const int i = tid;
         float gw = 0.0f, gb = 0.0f;
         if (i < H) {
             const unsigned short *hp = g.H2T + ((int64_t)e * H + i) * g.bp;
-            for (int b0 = 0; b0 < g.bp; b0 += 8) {
-                const u16x8 hv = *reinterpret_cast<const u16x8 *>(hp + b0);
+            for (int b0_ = 0; b0_ < g.bp; b0_ += 32) {
+                u16x8 hv[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) gw += tab[b0 + u] * bf2f(hv[u]);
+                for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const u16x8 *>(hp + (b0_ + 8 * q < g.bp ? b0_ + 8 * q : 0));
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (b0_ + 8 * q < g.bp)
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) gw += tab[b0_ + 8 * q + u] * bf2f(hv[q][u]);
             }
         }
         if (tid < 64) {
@@ -485,7 +643,7 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
             const float pn = adam_elem(P[a], gw, m, v, ctl);
             M[a] = m; V[a] = v; P[a] = pn;
             S[g.sg.o3 + i] = f2bf(pn);
-            if (T) { const float tv = T[a] * (1.0f - g.tau) + pn * g.tau; T[a] = tv; TS[g.sg.o3 + i] = f2bf(tv); }
+            if (T) { const float tn = T[a] * (1.0f - g.tau) + pn * g.tau; T[a] = tn; TS[g.sg.o3 + i] = f2bf(tn); }
             ss += gw * gw;
         }
         if (tid == 0) {
@@ -497,34 +655,10 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
             ss += gb * gb;
         }
     } else {
-        const bool fc2 = t < g.tiles2;
-        const int tt = fc2 ? t : t - g.tiles2;
-        const int Ncols = fc2 ? H : IN;                 // valid gradient columns
-        const int gx = fc2 ? (H + 63) / 64 : (IN + 63) / 64;
-        const int by = tt / gx, bxn = tt - by * gx;
-        const int wm = wave >> 1, wn = wave & 1;
-        const int li = lane & 31, lh = lane >> 5;
-        const int row = by * 64 + wm * 32 + li;         // gradient row j (0 .. H)
-        const int col = bxn * 64 + wn * 32 + li;        // gradient column i
-        const int Brows = fc2 ? H : K1P;                // rows of the B operand's transposed buffer
-        const unsigned short *AT = (fc2 ? g.DZ2T : g.DZ1T) + ((int64_t)e * H + (row < H ? row : 0)) * g.bp + 8 * lh;
-        const unsigned short *BT = fc2 ? g.H1T + ((int64_t)e * H + (col < Brows ? col : 0)) * g.bp + 8 * lh
-                                       : g.XT + (int64_t)(col < Brows ? col : 0) * g.bp + 8 * lh;
         const float *cs = tab + 8 * lh;
         f32x16 acc;
         zero_acc(acc);
         float colsum = 0.0f;   // bias gradient: sum_b c_b dz[b][row] from the scaled A fragments
-        const int nsteps = g.bp >> 4;
-        constexpr int G = 4;
-        u16x8 a0[G], b0[G], a1[G], b1[G];
-        auto load = [&](u16x8 (&a)[G], u16x8 (&b)[G], int s0) {
-#pragma unroll
-            for (int u = 0; u < G; ++u) {
-                const int s = s0 + u < nsteps ? s0 + u : nsteps - 1;   // clamped: redundant loads, never used
-                a[u] = *reinterpret_cast<const u16x8 *>(AT + 16 * s);
-                b[u] = *reinterpret_cast<const u16x8 *>(BT + 16 * s);
-            }
-        };
         auto mm = [&](const u16x8 (&a)[G], const u16x8 (&b)[G], int s0) {
 #pragma unroll
             for (int u = 0; u < G; ++u) {
@@ -535,17 +669,20 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
                 }
             }
         };
-        load(a0, b0, 0);
         for (int s0 = 0; s0 < nsteps; s0 += 2 * G) {
             load(a1, b1, s0 + G);
             mm(a0, b0, s0);
             load(a0, b0, s0 + 2 * G);
             mm(a1, b1, s0 + G);
         }
+        WSTAMP(2);
         colsum += __shfl_xor(colsum, 32, 64);   // the two k halves of row `row`
-        // ---- Adam epilogue straight from the accumulator: acc[r] = dW[by*64 + wm*32 + (r&3) + 8(r>>2) + 4 lh][col]
-        const int64_t off_w = fc2 ? g.off[2] : g.off[0];
-        const int ldc = fc2 ? H : IN;
+        // the bias element of this lane's row (the n-tile-0 waves with wn == 0 own it): loaded before the stores below
+        const bool bias_lane = bxn == 0 && wn == 0 && lh == 0 && row < H;
+        const int64_t ab = (fc2 ? g.off[3] : g.off[1]) + (row < H ? row : 0);
+        const float pb = P[ab], mb0 = M[ab], vb0 = V[ab], tb0 = T ? T[ab] : 0.0f;
+        // ---- Adam epilogue straight from the accumulator: acc[r] = dW[by*64 + wm*32 + (r&3) + 8(r>>2) + 4 lh][col];
+        //      the optimizer state was loaded at kernel start, so this is arithmetic + stores only
         if (col < Ncols) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -553,22 +690,22 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
                 const int j0 = by * 64 + wm * 32 + 8 * q + 4 * lh;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int j = j0 + u;
+                    const int j = j0 + u, r = 4 * q + u;
                     hq[u] = 0; tq[u] = 0;
                     if (j < H) {
                         const int64_t a = off_w + (int64_t)j * ldc + col;
-                        const float gr = acc[4 * q + u];
-                        float m = M[a], v = V[a];
-                        const float pn = adam_elem(P[a], gr, m, v, ctl);
+                        const float gr = acc[r];
+                        float m = mv[r], v = vv[r];
+                        const float pn = adam_elem(pv[r], gr, m, v, ctl);
                         M[a] = m; V[a] = v; P[a] = pn;
                         ss += gr * gr;
                         hq[u] = f2bf(pn);
                         if (fc2) S[g.sg.o2 + (int64_t)j * H + col] = hq[u];
                         else S[g.sg.o1 + (int64_t)j * K1P + col] = hq[u];
                         if (T) {
-                            const float tv = T[a] * (1.0f - g.tau) + pn * g.tau;
-                            T[a] = tv;
-                            tq[u] = f2bf(tv);
+                            const float tn = tv[r] * (1.0f - g.tau) + pn * g.tau;
+                            T[a] = tn;
+                            tq[u] = f2bf(tn);
                             if (fc2) TS[g.sg.o2 + (int64_t)j * H + col] = tq[u];
                             else TS[g.sg.o1 + (int64_t)j * K1P + col] = tq[u];
                         }
@@ -580,16 +717,15 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
                 }
             }
         }
-        // ---- bias gradient of rows [by*64 + wm*32, +32): the n-tile-0 waves with wn == 0 own it
-        if (bxn == 0 && wn == 0 && lh == 0 && row < H) {
-            const int64_t a = (fc2 ? g.off[3] : g.off[1]) + row;
-            float m = M[a], v = V[a];
-            const float pn = adam_elem(P[a], colsum, m, v, ctl);
-            M[a] = m; V[a] = v; P[a] = pn;
-            if (T) T[a] = T[a] * (1.0f - g.tau) + pn * g.tau;
+        if (bias_lane) {
+            float m = mb0, v = vb0;
+            const float pn = adam_elem(pb, colsum, m, v, ctl);
+            M[ab] = m; V[ab] = v; P[ab] = pn;
+            if (T) T[ab] = tb0 * (1.0f - g.tau) + pn * g.tau;
             ss += colsum * colsum;
         }
     }
+    WSTAMP(3);
     if (g.sumsq) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
@@ -599,6 +735,8 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
         if (tid == 0) g.sumsq[(int64_t)e * g.sumsq_stride + t] = red[0] + red[1] + red[2] + red[3];
     }
 }
+
+long long *g_bf_dbg = nullptr;
 
 bool bf_ok(const ssac_mlp *n) {
     return n && n->hidden % 32 == 0 && n->hidden >= 32 && n->hidden <= 256 && n->out_dim >= 1 && n->out_dim <= 64 &&
@@ -612,6 +750,7 @@ void bf_fill(BfArgs &g, const ssac_mlp *nets, const uint16_t *shadow, const int3
     ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, g.off);
     g.shadow = shadow; g.sg = shadow_geom(nets->in_dim, nets->hidden, nets->out_dim);
     g.ids = ids; g.X = X; g.ldx = ldx; g.n_rows = n_rows; g.bp = (n_rows + 15) & ~15;
+    g.dbg = g_bf_dbg;
 }
 
 template <typename K>
@@ -632,6 +771,7 @@ extern "C" int64_t ssac_bf16_layout(int in_dim, int hidden, int out_dim, int64_t
 }
 
 extern "C" int ssac_bf16_supported(const ssac_mlp *nets) { return bf_ok(nets) ? 1 : 0; }
+extern "C" int ssac_bf16_debug_stamps(long long *dev_buf) { g_bf_dbg = dev_buf; return 0; }
 
 extern "C" int ssac_bf16_sync(const ssac_mlp *nets, uint16_t *shadow, void *stream) {
     if (!nets || !shadow) return ssac_fail("ssac_bf16_sync: missing argument");
@@ -764,6 +904,7 @@ extern "C" int ssac_bf16_wgrad_lossfold(const ssac_mlp *nets, uint16_t *shadow, 
     g.lf.n_rows = n_rows;
     const int t = (nets->hidden + 63) / 64;
     g.tiles2 = t * t; g.tiles1 = t * ((nets->in_dim + 63) / 64);
+    g.dbg = g_bf_dbg;
     const size_t lds = sizeof(float) * (g.bp + 16);
     static bool attr = false;
     if (raise_lds(bf_wgrad_kernel, attr)) return 1;

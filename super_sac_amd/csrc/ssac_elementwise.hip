@@ -1333,3 +1333,89 @@ extern "C" int ssac_replay(ssac_launch_list *list, void *stream) {
 }
 
 extern "C" void ssac_launch_list_free(ssac_launch_list *list) { delete list; }
+
+// ---------------------------------------------------------------------------------------------
+// ssac_step: ONE host call per recorded update (include/ssac_hip.h).  Composes the update's input slot in host
+// memory, copies it into the input ring (BAR-mapped device memory or pinned host memory), re-issues the recorded launch
+// segments and keeps the slot-reuse events, so the per-update host work above the C ABI is the three host-RNG draws.
+// ---------------------------------------------------------------------------------------------
+struct ssac_step {
+    char *ring; int n_slots, slot_bytes, n_rows, n_ids, ids_off, logslot_off, draw_off, event_every;
+    std::vector<char> stage;
+    std::vector<ssac_launch_list *> lists;
+    std::vector<hipEvent_t> events;
+    int64_t k;
+};
+
+extern "C" ssac_step *ssac_step_create(void *ring, int n_slots, int slot_bytes, int n_rows, int n_ids, int ids_off,
+                                       int logslot_off, int draw_off, int event_every) {
+    if (!ring || n_slots <= 0 || slot_bytes <= 0 || (slot_bytes & 15) || n_rows <= 0 || n_ids < 0 || event_every <= 0 ||
+        n_slots % event_every != 0 || 8 * n_rows > ids_off || ids_off + 4 * n_ids > logslot_off ||
+        logslot_off + 4 > slot_bytes || (draw_off >= 0 && (draw_off + 8 > slot_bytes || (draw_off & 7)))) {
+        ssac_fail("ssac_step_create: bad slot geometry");
+        return nullptr;
+    }
+    ssac_step *s = new ssac_step();
+    s->ring = (char *)ring; s->n_slots = n_slots; s->slot_bytes = slot_bytes; s->n_rows = n_rows; s->n_ids = n_ids;
+    s->ids_off = ids_off; s->logslot_off = logslot_off; s->draw_off = draw_off; s->event_every = event_every;
+    s->stage.assign((size_t)slot_bytes, 0);
+    s->events.resize(n_slots / event_every);
+    for (hipEvent_t &e : s->events)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            ssac_fail("ssac_step_create: hipEventCreate failed");
+            delete s;
+            return nullptr;
+        }
+    s->k = 0;
+    return s;
+}
+
+extern "C" int ssac_step_add_list(ssac_step *s, ssac_launch_list *list) {
+    if (!s || !list) return ssac_fail("ssac_step_add_list: null argument");
+    s->lists.push_back(list);
+    return 0;
+}
+
+extern "C" int64_t ssac_step_count(const ssac_step *s) { return s ? s->k : -1; }
+extern "C" int ssac_step_seek(ssac_step *s, int64_t k) {
+    if (!s || k < 0) return ssac_fail("ssac_step_seek: bad argument");
+    s->k = k;
+    return 0;
+}
+
+extern "C" int ssac_step_run(ssac_step *s, const int64_t *idx_host, const int32_t *ids_host, int32_t log_slot,
+                             int64_t draw, void *stream) {
+    if (!s || !idx_host || (s->n_ids > 0 && !ids_host)) return ssac_fail("ssac_step_run: null argument");
+    const int64_t k = s->k;
+    const int slot = (int)(k % s->n_slots);
+    const int groups = s->n_slots / s->event_every;
+    // slot reuse: the update that read this slot n_slots updates ago must have finished (one event per group of
+    // event_every updates, recorded behind the group's last update)
+    if (k >= s->n_slots && k % s->event_every == 0) {
+        if (hipEventSynchronize(s->events[((k - s->n_slots) / s->event_every) % groups]) != hipSuccess)
+            return ssac_check_launch("ssac_step_run: event wait");
+    }
+    char *st = s->stage.data();
+    memcpy(st, idx_host, 8 * (size_t)s->n_rows);
+    if (s->n_ids > 0) memcpy(st + s->ids_off, ids_host, 4 * (size_t)s->n_ids);
+    memcpy(st + s->logslot_off, &log_slot, 4);
+    if (s->draw_off >= 0) memcpy(st + s->draw_off, &draw, 8);
+    memcpy(s->ring + (size_t)slot * s->slot_bytes, st, (size_t)s->slot_bytes);
+    __builtin_ia32_sfence();
+    for (ssac_launch_list *l : s->lists) {
+        const int rc = ssac_replay(l, stream);
+        if (rc) return rc;
+    }
+    if (k % s->event_every == s->event_every - 1) {
+        if (hipEventRecord(s->events[(k / s->event_every) % groups], ST) != hipSuccess)
+            return ssac_check_launch("ssac_step_run: event record");
+    }
+    s->k = k + 1;
+    return 0;
+}
+
+extern "C" void ssac_step_destroy(ssac_step *s) {
+    if (!s) return;
+    for (hipEvent_t &e : s->events) (void)hipEventDestroy(e);
+    delete s;
+}

@@ -137,6 +137,8 @@ class _Graphed:
     def __init__(self):
         self.calls = 0
         self.graph = None
+        self.fast = None
+        self.path = "slow"
 
 
 def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimizer, log_alphas,
@@ -148,6 +150,15 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
     observations, uniform sampling, single rank) it is captured once into a HIP graph and replayed:
     the host then only draws the indices / REDQ subset / noise, uploads them into fixed-address
     buffers and issues one graph launch, instead of ~15 kernel launches."""
+    # ---- fast path: this exact call has been recorded already (ssac_step: one C call re-issues the update)
+    fast = agent.__dict__.get("_ssac_fast")
+    if fast is not None and USE_GRAPHS and engine.CAPTURE is None:
+        fs = fast.get((id(buffer), id(target_agent), id(critic_optimizer), id(log_alphas[0]), id(augmenter), batch_size,
+                       gamma, critic_clip, encoder_clip, target_critic_ensemble_n, weighted_bellman_temp, weight_type,
+                       pop, encoder_lambda, id(random_process), noise_clip, discrete, per, update_priorities, dr3_coeff,
+                       engine.USE_FUSED))
+        if fs is not None and fs.still_valid():
+            return fs.run()
     kw = dict(buffer=buffer, agent=agent, target_agent=target_agent, critic_optimizer=critic_optimizer,
               encoder_optimizer=encoder_optimizer, log_alphas=log_alphas, batch_size=batch_size, gamma=gamma,
               critic_clip=critic_clip, encoder_clip=encoder_clip,
@@ -178,7 +189,111 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
     gs.calls += 1
     if gs.calls <= GRAPH_WARMUP or len(buffer) < batch_size:
         return _critic_update_eager(**kw)
-    return _critic_update_graphed(gs, kw)
+    out = _critic_update_graphed(gs, kw)
+    if (gs.graph is not None and LAUNCH_MODE == "list" and shard is None and getattr(gs, "fast", None) is None
+            and all(not callable(p_) for p_ in gs.graph.parts)):
+        gs.fast = _FastStep(gs, kw)
+        agent.__dict__.setdefault("_ssac_fast", {})[
+            (id(buffer), id(target_agent), id(critic_optimizer), id(log_alphas[0]), id(augmenter), batch_size,
+             gamma, critic_clip, encoder_clip, target_critic_ensemble_n, weighted_bellman_temp, weight_type,
+             pop, encoder_lambda, id(random_process), noise_clip, discrete, per, update_priorities, dr3_coeff,
+             engine.USE_FUSED)] = gs.fast
+    return out
+
+
+class _FastStep:
+    """the recorded critic update behind ONE C call per update (ssac_step_run, include/ssac_hip.h): what stays in
+    Python is the reference's host-RNG draws, in its order (indices -> injected noise -> REDQ subset -> logged-net
+    choice), and handing out the log views of this update's ring slot"""
+
+    def __init__(self, gs, kw):
+        self.gs, self.kw = gs, kw
+        self.buffer, self.agent = kw["buffer"], kw["agent"]
+        self.B, self.n_sub = kw["batch_size"], kw["target_critic_ensemble_n"]
+        self.dev = kw["log_alphas"][0].device
+        self.ring = lu.ring_for(self.dev)
+        B, n_pad = self.B, gs.n_pad
+        draw_off = 8 * B + 4 * n_pad + 8
+        h = lib.ssac_step_create(gs.ring.ptr, FEED_SLOTS, gs.slot_bytes, B, self.n_sub, 8 * B, 8 * B + 4 * n_pad,
+                                 draw_off, EVENT_EVERY)
+        if not h:
+            raise RuntimeError("libssac_hip: " + lib.ssac_last_error().decode())
+        self.handle = h
+        for part in gs.graph.parts:
+            check(lib.ssac_step_add_list(h, part))
+        self.ids_c = (C.c_int32 * max(self.n_sub, 1))()
+        self.n_critics = self.agent.num_critics
+        self.in_kernel_noise = gs.in_kernel_noise
+        self.calls = 0
+        # a few parameter addresses checked on every call (cheap), all of them every 256 calls
+        actor = self.agent.actors[0]
+        tgt = kw["target_agent"]
+        self.arenas = [(self.agent.critics[0].arena(self.dev), list(self.agent.critics[0].nets)),
+                       (tgt.critics[0].arena(self.dev), list(tgt.critics[0].nets)),
+                       (engine.bind_arena(actor, "self", [actor], self.dev), [actor])]
+        self.probes = []
+        for arena, mods in self.arenas:
+            lins = engine.MlpArena.linear_triples(mods[0]) + engine.MlpArena.linear_triples(mods[-1])
+            for lin in (lins[0], lins[-1]):
+                self.probes.append((lin.weight, lin.weight.data_ptr()))
+
+    def still_valid(self):
+        gs = self.gs
+        if gs.fast is not self or LAUNCH_MODE != "list" or len(self.buffer) < self.B:
+            return False
+        if gs.eps_dev is not None and rng.normal_is_stock() != self.in_kernel_noise:
+            return False  # a noise hook was installed / removed: the slow path records the update again
+        self.calls += 1
+        if self.calls & 255 == 0:
+            if not all(arena.is_bound(mods) for arena, mods in self.arenas):
+                gs.fast = None
+                return False
+        else:
+            for p, ptr in self.probes:
+                if p.data_ptr() != ptr:
+                    gs.fast = None
+                    return False
+        return True
+
+    def run(self):
+        gs, buffer, agent = self.gs, self.buffer, self.agent
+        if gs.path != "fast":
+            # the Python path issued updates of this recording since: line the step up with the ring's device counter
+            # (its slot-reuse events know nothing about those updates, so let them finish first)
+            torch.cuda.synchronize()
+            check(lib.ssac_step_seek(self.handle, gs.k))
+            gs.path = "fast"
+        buffer.total_sample_calls += 1
+        idx_cpu = rng.draw_indices(len(buffer), self.B)
+        if gs.eps_dev is not None and not self.in_kernel_noise:
+            rng.draw_normal_into(gs.eps_dev)  # injected noise (parity tests)
+        ids = rng.draw_subset(self.n_critics, self.n_sub)
+        ida = self.ids_c
+        for j, v in enumerate(ids):
+            ida[j] = v
+        slot_i = self.ring.advance()
+        draw = 0
+        if self.in_kernel_noise:
+            ns = lu.noise_stream(agent, self.dev)
+            draw = ns[1]
+            ns[1] += 1
+        check(lib.ssac_step_run(self.handle, idx_cpu.data_ptr(), ida, slot_i, draw, engine.stream()))
+        gs.k += 1
+        rng.choice(agent.critics)  # keep the Python RNG stream in step with learning.py:135
+        logs = gs.log_views.get(slot_i)
+        if logs is None:
+            slot = self.ring.buf[slot_i]
+            logs = gs.log_views[slot_i] = {k_: slot[i] for k_, i in gs.log_index.items()}
+        rd = gs.dicts[0]
+        rd["priority_idxs"] = idx_cpu.numpy()
+        rd["_subset"] = ids
+        return dict(logs), gs.dicts
+
+    def __del__(self):
+        try:
+            lib.ssac_step_destroy(self.handle)
+        except Exception:
+            pass
 
 
 class _FeedRing:
@@ -198,6 +313,9 @@ class _FeedRing:
 
 def _critic_update_graphed(gs, kw):
     buffer, agent, B = kw["buffer"], kw["agent"], kw["batch_size"]
+    if gs.path == "fast":  # (the C step's slot-reuse events are not visible from here)
+        torch.cuda.synchronize()
+        gs.path = "slow"
     dev = kw["log_alphas"][0].device
     actor = agent.actors[0]
     kind = lu.actor_kind(actor)

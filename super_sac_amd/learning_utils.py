@@ -150,6 +150,20 @@ def _polyak_tensor(t, s, tau):
 def soft_update(target, source, tau):
     """theta_bar <- (1-tau) theta_bar + tau theta over all parameters (learning_utils.py:160-162);
     one launch over the packed arena when both sides are packed ensembles."""
+    plan = target.__dict__.get("_ssac_polyak")
+    if plan is not None and plan[0] is source:
+        # packed ensembles seen before: one C call (the arenas are re-validated by pointer every 256 calls)
+        _, ta, sa, tmods, smods, calls = plan
+        plan[5] = calls + 1
+        if (calls & 255) or (ta.is_bound(tmods) and sa.is_bound(smods)):
+            if ta.shadow is not None:
+                check(lib.ssac_bf16_polyak(C.byref(ta.desc()), C.byref(sa.desc()), float(tau), ta.shadow.data_ptr(),
+                                           engine.stream()))
+            else:
+                check(lib.ssac_polyak(ta.params.data_ptr(), sa.params.data_ptr(), ta.params.numel(), float(tau),
+                                      engine.stream()))
+            return
+        del target.__dict__["_ssac_polyak"]
     if hasattr(target, "arena") and hasattr(source, "arena"):
         dev = next(source.parameters()).device
         ta, sa = target.arena(dev), source.arena(dev)
@@ -159,6 +173,7 @@ def soft_update(target, source, tau):
                                            engine.stream()))
             else:
                 _polyak_tensor(ta.params, sa.params, tau)
+            target.__dict__["_ssac_polyak"] = [source, ta, sa, list(target.nets), list(source.nets), 1]
             return
     for tp, sp in zip(target.parameters(), source.parameters()):
         if tp.is_cuda and tp.data.is_contiguous() and sp.data.is_contiguous():

@@ -17,13 +17,14 @@ import synth
 dev = torch.device("cuda")
 
 
-def build(obs, act, B, N, n, hidden=256, rows=100_000):
+def build(obs, act, B, N, n, hidden=256, rows=100_000, precision="fp32"):
     torch.manual_seed(0); np.random.seed(0); random.seed(0)
     agent = ssa.Agent(act_space_size=act, encoder=ssa.nets.IdentityEncoder(obs),
                       actor_network_cls=ssa.nets.ContinuousStochasticActor,
                       critic_network_cls=ssa.nets.ContinuousCritic, ensemble_size=1, num_critics=N,
                       hidden_size=hidden, auto_rescale_targets=False, log_std_low=-5.0, log_std_high=2.0)
     agent.to(dev)
+    ssa.set_precision(agent, precision)
     target = copy.deepcopy(agent)
     buf = ssa.replay.ReplayBuffer(rows + 1000, device=dev)
     buf.load_experience(*synth.synth_transitions(rows, obs, act, seed=1))
@@ -69,17 +70,19 @@ def timed(fn, n, warm):
     return (time.perf_counter() - t0) / n
 
 
-print("| configuration | obs / act | B | N (n) | us per critic update | critic updates/s |")
-print("|---|---|---|---|---|---|")
-for name, obs, act, B, N, n in [("SAC (sac.gin shape)", 3, 1, 256, 2, 2), ("REDQ", 17, 6, 256, 10, 2),
-                                ("REDQ (headline)", 17, 6, 512, 10, 2), ("REDQ", 17, 6, 512, 16, 2),
-                                ("Humanoid", 376, 17, 512, 16, 2), ("Humanoid", 376, 17, 256, 10, 2)]:
+print("| configuration | precision | obs / act | B | N (n) | us per critic update | critic updates/s |")
+print("|---|---|---|---|---|---|---|")
+ROWS = [("SAC (sac.gin shape)", 3, 1, 256, 2, 2), ("REDQ", 17, 6, 256, 10, 2),
+        ("REDQ (headline)", 17, 6, 512, 10, 2), ("REDQ", 17, 6, 512, 16, 2),
+        ("Humanoid", 376, 17, 512, 16, 2), ("Humanoid", 376, 17, 256, 10, 2)]
+for precision in ("fp32", "bf16"):
+  for name, obs, act, B, N, n in ROWS:
     if len(sys.argv) > 1 and sys.argv[1] not in name:  # optional row filter: python tools/bench_configs.py Humanoid
         continue
-    critic, env_step = build(obs, act, B, N, n)
+    critic, env_step = build(obs, act, B, N, n, precision=precision)
     t = timed(critic, 1500, 200)
-    print(f"| {name} | {obs} / {act} | {B} | {N} ({n}) | {t * 1e6:.1f} | {1 / t:.0f} |")
-    if name == "REDQ (headline)":
+    print(f"| {name} | {precision} | {obs} / {act} | {B} | {N} ({n}) | {t * 1e6:.1f} | {1 / t:.0f} |")
+    if name in ("REDQ (headline)", "REDQ") and N == 10:
         te = timed(env_step, 60, 5)
-        print(f"| full REDQ env step: 20 critic updates + 10 Polyak + actor + temperature | {obs} / {act} | {B} | {N} ({n}) "
+        print(f"| full REDQ env step: 20 critic updates + 10 Polyak + actor + temperature | {precision} | {obs} / {act} | {B} | {N} ({n}) "
               f"| {te * 1e6 / 20:.1f} (x20 = {te * 1e3:.2f} ms per env step) | {20 / te:.0f} |")

@@ -1,0 +1,30 @@
+"""s_memtime phase stamps inside the bf16 chain / weight-gradient launches (eager launches, tile 0 of each role)
+    python tools/bf16_phases.py [B] [N]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.argv, args = sys.argv[:1] + ["__none__"], sys.argv[1:]
+import importlib.util
+spec = importlib.util.spec_from_file_location("bc", os.path.join(ROOT, "tools", "bench_configs.py"))
+bc = importlib.util.module_from_spec(spec); spec.loader.exec_module(bc)
+import torch
+import super_sac_amd as ssa
+B = int(args[0]) if args else 256
+N = int(args[1]) if len(args) > 1 else 10
+ssa.learning.USE_GRAPHS = False
+critic, _ = bc.build(17, 6, B, N, 2, precision="bf16")
+for _ in range(5):
+    critic()
+dbg = torch.zeros(64, dtype=torch.int64, device="cuda")
+ssa._lib.lib.ssac_bf16_debug_stamps(dbg.data_ptr())
+for _ in range(3):
+    critic()
+torch.cuda.synchronize()
+ssa._lib.lib.ssac_bf16_debug_stamps(0)
+t = dbg.cpu().numpy()
+def row(name, base, labels):
+    print(name, "total", t[base + len(labels)] - t[base], "clk:", ", ".join(f"{l} {t[base+i+1]-t[base+i]}" for i, l in enumerate(labels)))
+row("actor pass   ", 0, ["gather+prefetch", "fc1", "fc1-epi+sync", "fc2", "fc2-epi+sync", "head", "sample"])
+row("target pass  ", 16, ["x+prefetch", "fc1", "fc1-epi+sync", "fc2", "fc2-epi+sync", "head"])
+print("actor start -> target pass end:", t[22] - t[0])
+row("critic WG    ", 32, ["gather+prefetch", "fc1", "fc1-epi+sync", "fc2", "fc2-epi+sync", "head", "dz2u+sync", "dgrad", "dz1 store"])
+row("wgrad tile 0 ", 48, ["prefetch+lossfold", "K loop", "adam epilogue"])

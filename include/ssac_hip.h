@@ -168,6 +168,21 @@ int64_t ssac_step_count(const ssac_step *step);
 int ssac_step_seek(ssac_step *step, int64_t k);   /* updates the ring's device-side counter has consumed so far */
 void ssac_step_destroy(ssac_step *step);
 
+/* ---- one-shot exchange between the ranks of a critic-sharded update (csrc/ssac_xchg.hip; SURVEY 8(e) "Transport"):
+ * every rank owns a receive buffer, exported over HIP IPC and mapped by all peers; ssac_xchg_reduce is ONE recordable
+ * launch that writes this rank's partial into every rank's buffer (posted peer-to-peer stores over xGMI), raises a
+ * sequence flag, waits (bounded) for the peers' flags in its own buffer and reduces the `world` payloads in rank order,
+ * in place: op 0 = MIN (the per-shard min-Q, agent.py:37-38 / learning.py:402), op 1 = SUM (the action gradient).
+ * Set-up: create on every rank, exchange the ssac_xchg_handle bytes among the ranks (any host channel), connect. */
+typedef struct ssac_xchg ssac_xchg;
+ssac_xchg *ssac_xchg_create(int rank, int world, int slot_floats);   /* NULL + ssac_last_error on error */
+int ssac_xchg_handle_bytes(void);
+int ssac_xchg_handle(ssac_xchg *x, void *handle_out);
+int ssac_xchg_connect(ssac_xchg *x, const void *handles /* world x ssac_xchg_handle_bytes(), rank-major */);
+int ssac_xchg_reduce(ssac_xchg *x, float *data, int n, int op, void *stream);
+int ssac_xchg_error(ssac_xchg *x);   /* 1: a peer's flag did not arrive within the spin bound (synchronises) */
+void ssac_xchg_destroy(ssac_xchg *x);
+
 /* floats per net and the six segment offsets {W1,b1,W2,b2,W3,b3}. */
 int64_t ssac_mlp_layout(int in_dim, int hidden, int out_dim, int64_t offsets[6]);
 

@@ -73,6 +73,13 @@ SIGNATURES = {
     "ssac_launch_list_size": [_P],
     "ssac_replay": [_P, _P],
     "ssac_launch_list_free": [_P],
+    "ssac_xchg_create": [_I, _I, _I],
+    "ssac_xchg_handle_bytes": [],
+    "ssac_xchg_handle": [_P, _P],
+    "ssac_xchg_connect": [_P, _P],
+    "ssac_xchg_reduce": [_P, _P, _I, _I, _P],
+    "ssac_xchg_error": [_P],
+    "ssac_xchg_destroy": [_P],
     "ssac_step_create": [_P, _I, _I, _I, _I, _I, _I, _I, _I],
     "ssac_step_add_list": [_P, _P],
     "ssac_step_run": [_P, _P, _P, C.c_int32, _L, _P],
@@ -177,7 +184,7 @@ SIGNATURES = {
     "ssac_bf16_wgrad_lossfold": [_MP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P, _L, _P, _P, _F,
                                  _P],
 }
-_RESTYPES = {"ssac_step_create": C.c_void_p, "ssac_step_count": C.c_int64, "ssac_step_destroy": None,
+_RESTYPES = {"ssac_xchg_create": C.c_void_p, "ssac_xchg_destroy": None, "ssac_step_create": C.c_void_p, "ssac_step_count": C.c_int64, "ssac_step_destroy": None,
              "ssac_last_error": C.c_char_p, "ssac_mlp_layout": C.c_int64, "ssac_bf16_layout": C.c_int64, "ssac_record_end": C.c_void_p,
              "ssac_launch_list_free": None}
 

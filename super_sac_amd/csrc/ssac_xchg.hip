@@ -1,0 +1,189 @@
+// One-shot exchange between the ranks of a critic-sharded update (SURVEY.md 8(e) "Transport").
+//
+// The messages of the sharded update are tiny -- the (n_subset x B) partial min-Q of the critic step (4 KiB at the metric
+// shape), the (B,) min-Q and the (B x A) action gradient of the actor step -- so a ring all-reduce would be pure hop
+// latency.  Instead every rank owns a receive buffer in its HBM, exported over HIP IPC and mapped by every peer:
+//
+//   recv[src rank][slot][payload floats | flag]            (slot = sequence number mod N_SLOTS)
+//
+// and ONE kernel per exchange (a recordable launch: it sits inside the update's launch list, between the launch that
+// produces the partial and the launch that consumes the result, with no host involvement):
+//   1. writes this rank's partial into recv[rank][slot] of EVERY rank (its own included) with system-scope stores,
+//      then, after a system-scope release, the slot's flag = sequence number;
+//   2. polls the `world` flags of its OWN buffer (relaxed system-scope loads, bounded spin) until they carry the number;
+//   3. reduces the `world` payloads (MIN or SUM, fixed rank order -> identical bits on every rank) in place of the input.
+// The sequence number lives in device memory and is advanced by the kernel itself, so a replayed launch list needs no
+// per-update argument.  A rank can run at most one exchange ahead of the slowest peer (it needs that peer's flag of the
+// current exchange, which the peer writes only after it has finished reading the previous slot), so 4 slots are ample.
+// Over xGMI the writes are posted peer-to-peer stores; on a single device (two ranks sharing one GPU in the tests) the
+// very same code runs through the local HBM.  torch.distributed (RCCL) remains the fallback path (parallel.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "ssac_internal.h"
+
+namespace {
+
+constexpr int X_SLOTS = 4;
+constexpr int X_MAX_WORLD = 8;
+constexpr int X_THREADS = 256;
+constexpr long long X_SPIN_LIMIT = 4000000000LL;   // shader clocks (~2 s): a missing peer raises an error, never a hang
+
+struct XchgArgs {
+    float *peer[X_MAX_WORLD];   // every rank's receive buffer, as mapped into THIS process (peer[rank] = own buffer)
+    int rank, world, n, slot_floats, op;   // op 0 = MIN, 1 = SUM
+    float *data;                // in: this rank's partial (n floats); out: the reduction over ranks
+    unsigned long long *seq;    // device-resident exchange counter
+    int *error;                 // device int, set to 1 when a peer's flag did not arrive in time
+};
+
+__device__ __forceinline__ float *slot_of(float *base, int src, int slot, int slot_floats) {
+    return base + ((int64_t)src * X_SLOTS + slot) * (int64_t)(slot_floats + 4);
+}
+
+__global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
+    __shared__ unsigned long long s_seq;
+    __shared__ int s_ok;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_seq = *a.seq + 1; s_ok = 1; }
+    __syncthreads();
+    const unsigned long long seq = s_seq;
+    const int slot = (int)(seq % X_SLOTS);
+    // ---- 1. my partial -> every rank's recv[my rank][slot]
+    for (int p = 0; p < a.world; ++p) {
+        float *dst = slot_of(a.peer[p], a.rank, slot, a.slot_floats);
+        for (int i = tid; i < a.n; i += X_THREADS)
+            __hip_atomic_store(dst + i, a.data[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: payload before flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < a.world) {
+        float *dst = slot_of(a.peer[tid], a.rank, slot, a.slot_floats);
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + a.slot_floats), seq, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // ---- 2. wait for every rank's flag in MY buffer
+    if (tid < a.world) {
+        const unsigned long long *flag =
+            reinterpret_cast<const unsigned long long *>(slot_of(a.peer[a.rank], tid, slot, a.slot_floats) + a.slot_floats);
+        const long long t0 = __builtin_amdgcn_s_memtime();
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            __builtin_amdgcn_s_sleep(2);
+            if (__builtin_amdgcn_s_memtime() - t0 > X_SPIN_LIMIT) { s_ok = 0; break; }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    // ---- 3. reduce over ranks in rank order (system-scope loads: the payload may have come from a peer device)
+    if (s_ok) {
+        for (int i = tid; i < a.n; i += X_THREADS) {
+            float r = __hip_atomic_load(slot_of(a.peer[a.rank], 0, slot, a.slot_floats) + i, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_SYSTEM);
+            for (int p = 1; p < a.world; ++p) {
+                const float v = __hip_atomic_load(slot_of(a.peer[a.rank], p, slot, a.slot_floats) + i, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_SYSTEM);
+                r = a.op == 0 ? fminf(r, v) : r + v;
+            }
+            a.data[i] = r;
+        }
+    } else if (tid == 0) {
+        *a.error = 1;
+    }
+    __syncthreads();
+    if (tid == 0) *a.seq = seq;
+}
+
+}  // namespace
+
+struct ssac_xchg {
+    int rank, world, slot_floats;
+    float *local;                       // own receive buffer
+    std::vector<float *> peers;         // mapped views, peers[rank] == local
+    std::vector<bool> opened;
+    unsigned long long *seq;
+    int *error;
+};
+
+extern "C" ssac_xchg *ssac_xchg_create(int rank, int world, int slot_floats) {
+    if (rank < 0 || world < 1 || world > X_MAX_WORLD || rank >= world || slot_floats <= 0) {
+        ssac_fail("ssac_xchg_create: bad arguments");
+        return nullptr;
+    }
+    slot_floats = (slot_floats + 3) & ~3;   // 16-byte slots: the 8-byte flag behind the payload stays aligned
+    ssac_xchg *x = new ssac_xchg();
+    x->rank = rank; x->world = world; x->slot_floats = slot_floats;
+    const size_t bytes = sizeof(float) * (size_t)world * X_SLOTS * (slot_floats + 4);
+    if (hipMalloc((void **)&x->local, bytes) != hipSuccess || hipMemset(x->local, 0, bytes) != hipSuccess ||
+        hipMalloc((void **)&x->seq, 16) != hipSuccess || hipMemset(x->seq, 0, 16) != hipSuccess) {
+        ssac_fail("ssac_xchg_create: allocation failed");
+        delete x;
+        return nullptr;
+    }
+    x->error = reinterpret_cast<int *>(x->seq + 1);
+    x->peers.assign(world, nullptr);
+    x->opened.assign(world, false);
+    x->peers[rank] = x->local;
+    (void)hipDeviceSynchronize();
+    return x;
+}
+
+extern "C" int ssac_xchg_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+
+extern "C" int ssac_xchg_handle(ssac_xchg *x, void *handle_out) {
+    if (!x || !handle_out) return ssac_fail("ssac_xchg_handle: null argument");
+    hipIpcMemHandle_t h;
+    if (hipIpcGetMemHandle(&h, x->local) != hipSuccess) return ssac_check_launch("ssac_xchg_handle: hipIpcGetMemHandle");
+    memcpy(handle_out, &h, sizeof(h));
+    return 0;
+}
+
+// handles: world x ssac_xchg_handle_bytes(), rank-major (as gathered from every rank)
+extern "C" int ssac_xchg_connect(ssac_xchg *x, const void *handles) {
+    if (!x || !handles) return ssac_fail("ssac_xchg_connect: null argument");
+    for (int p = 0; p < x->world; ++p) {
+        if (p == x->rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const char *)handles + (size_t)p * sizeof(h), sizeof(h));
+        void *ptr = nullptr;
+        if (hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !ptr)
+            return ssac_check_launch("ssac_xchg_connect: hipIpcOpenMemHandle");
+        x->peers[p] = (float *)ptr;
+        x->opened[p] = true;
+    }
+    return 0;
+}
+
+// in place over data[0 .. n): MIN (op 0) or SUM (op 1) over the ranks.  A recordable launch.
+extern "C" int ssac_xchg_reduce(ssac_xchg *x, float *data, int n, int op, void *stream) {
+    if (!x || !data || n <= 0 || n > x->slot_floats || (op != 0 && op != 1))
+        return ssac_fail("ssac_xchg_reduce: bad arguments");
+    XchgArgs a{};
+    for (int p = 0; p < x->world; ++p) {
+        if (!x->peers[p]) return ssac_fail("ssac_xchg_reduce: not connected");
+        a.peer[p] = x->peers[p];
+    }
+    a.rank = x->rank; a.world = x->world; a.n = n; a.slot_floats = x->slot_floats; a.op = op;
+    a.data = data; a.seq = x->seq; a.error = x->error;
+    SSAC_LAUNCH(xchg_kernel, dim3(1), dim3(X_THREADS), 0, (hipStream_t)stream, a);
+    return ssac_check_launch("xchg");
+}
+
+// 1 when a peer's flag failed to arrive within the spin bound since the last call (synchronises the device)
+extern "C" int ssac_xchg_error(ssac_xchg *x) {
+    if (!x) return 1;
+    int e = 0;
+    if (hipMemcpy(&e, x->error, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    return e;
+}
+
+extern "C" void ssac_xchg_destroy(ssac_xchg *x) {
+    if (!x) return;
+    for (int p = 0; p < x->world; ++p)
+        if (x->opened[p]) (void)hipIpcCloseMemHandle(x->peers[p]);
+    (void)hipFree(x->local);
+    (void)hipFree(x->seq);
+    delete x;
+}

@@ -190,7 +190,7 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
     if gs.calls <= GRAPH_WARMUP or len(buffer) < batch_size:
         return _critic_update_eager(**kw)
     out = _critic_update_graphed(gs, kw)
-    if (gs.graph is not None and LAUNCH_MODE == "list" and shard is None and getattr(gs, "fast", None) is None
+    if (gs.graph is not None and LAUNCH_MODE == "list" and getattr(gs, "fast", None) is None
             and all(not callable(p_) for p_ in gs.graph.parts)):
         gs.fast = _FastStep(gs, kw)
         agent.__dict__.setdefault("_ssac_fast", {})[
@@ -222,7 +222,8 @@ class _FastStep:
         for part in gs.graph.parts:
             check(lib.ssac_step_add_list(h, part))
         self.ids_c = (C.c_int32 * max(self.n_sub, 1))()
-        self.n_critics = self.agent.num_critics
+        self.shard = parallel.shard_of(self.agent)
+        self.n_critics = self.agent.num_critics if self.shard is None else self.shard.num_critics  # GLOBAL ensemble
         self.in_kernel_noise = gs.in_kernel_noise
         self.calls = 0
         # a few parameter addresses checked on every call (cheap), all of them every 256 calls
@@ -268,9 +269,10 @@ class _FastStep:
         if gs.eps_dev is not None and not self.in_kernel_noise:
             rng.draw_normal_into(gs.eps_dev)  # injected noise (parity tests)
         ids = rng.draw_subset(self.n_critics, self.n_sub)
-        ida = self.ids_c
+        ida, sh = self.ids_c, self.shard
         for j, v in enumerate(ids):
-            ida[j] = v
+            # sharded: the LOCAL index of a subset member this rank owns, -1 for a member that lives elsewhere
+            ida[j] = v if sh is None else (v - sh.lo if sh.owns(v) else -1)
         slot_i = self.ring.advance()
         draw = 0
         if self.in_kernel_noise:

@@ -636,7 +636,10 @@ def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag, co_backward=None, re
             _, _, q1 = engine.mlp_forward(t_arena, X, ldx, 0, B, ws, tag, net_ids=cap.ids_dev, n_sel=n, save=False)
         # MIN all-reduce of all n slots at once (n x B x O floats; slots this rank does not own hold +inf): the minimum
         # over the slots is taken where the TD target is evaluated, so no local min launch is needed
-        cap.collective(lambda: parallel.all_reduce_min(q1))
+        if parallel.one_shot_ready(q1):
+            parallel.all_reduce_min(q1)  # ONE recorded launch (csrc/ssac_xchg.hip): the update stays one launch list
+        else:
+            cap.collective(lambda: parallel.all_reduce_min(q1))
         return q1, n
     local = shard.local_subset(ids)
     if local:

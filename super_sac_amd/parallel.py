@@ -11,8 +11,9 @@ batch broadcast.  The real exchange steps are:
   actor  update   MIN all-reduce of the (B,) min-Q over all critics, then SUM all-reduce of the
                   (B x A) action gradient coming back through the arg-min critics
 
-2-35 KiB messages, latency bound; ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the
-GPUs; "gloo" in the CPU tests) carries them.
+2-35 KiB messages, latency bound.  On the GPUs they go through the one-shot exchange of csrc/ssac_xchg.hip (``Exchange``:
+IPC-mapped receive buffers, one recordable launch per reduction, no host step between the launches of an update);
+``torch.distributed`` (backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests) is the fallback and the set-up channel.
 """
 import torch
 import torch.distributed as dist
@@ -47,13 +48,68 @@ def shard_of(agent):
     return getattr(agent, "ssac_shard", None)
 
 
+class Exchange:
+    """the one-shot exchange of csrc/ssac_xchg.hip: IPC-mapped receive buffers on every rank, one recordable launch
+    per reduction.  Built once per process after ``torch.distributed`` is up (the 64-byte IPC handles travel through
+    an all_gather of the process group -- a set-up step, not the data path)."""
+
+    def __init__(self, rank, world, max_floats, device):
+        import ctypes as C
+        from ._lib import check, lib
+        self.rank, self.world, self.max_floats = rank, world, int(max_floats)
+        torch.cuda.set_device(device)
+        h = lib.ssac_xchg_create(rank, world, self.max_floats)
+        if not h:
+            raise RuntimeError("libssac_hip: " + lib.ssac_last_error().decode())
+        self.handle = h
+        nb = int(lib.ssac_xchg_handle_bytes())
+        mine = C.create_string_buffer(nb)
+        check(lib.ssac_xchg_handle(h, mine))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, bytes(mine.raw))
+        check(lib.ssac_xchg_connect(h, b"".join(gathered)))
+        dist.barrier()
+
+    def reduce(self, t, op):
+        from . import engine
+        from ._lib import check, lib
+        check(lib.ssac_xchg_reduce(self.handle, t.data_ptr(), t.numel(), op, engine.stream()))
+
+    def failed(self):
+        from ._lib import lib
+        return bool(lib.ssac_xchg_error(self.handle))
+
+
+_exchange = None
+ONE_SHOT_MAX_FLOATS = 1 << 15  # largest payload the receive slots hold (the actor step's (B x A) action gradient)
+
+
+def enable_one_shot(device, max_floats=ONE_SHOT_MAX_FLOATS):
+    """switch the exchange steps of this process to the IPC one-shot kernel (needs an initialised process group whose
+    ranks can map each other's device memory: one node, HSA_ENABLE_IPC_MODE_LEGACY=0 on this platform)"""
+    global _exchange
+    if _exchange is None and dist.is_initialized() and dist.get_world_size() > 1:
+        _exchange = Exchange(dist.get_rank(), dist.get_world_size(), max_floats, device)
+    return _exchange
+
+
+def one_shot_ready(t):
+    x = _exchange
+    return (x is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+            and t.numel() <= x.max_floats)
+
+
 def all_reduce_min(t):
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if one_shot_ready(t):
+        _exchange.reduce(t, 0)
+    elif dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)  # fallback: RCCL on the GPUs, gloo in the CPU tests
     return t
 
 
 def all_reduce_sum(t):
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if one_shot_ready(t):
+        _exchange.reduce(t, 1)
+    elif dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t

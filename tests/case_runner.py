@@ -421,19 +421,21 @@ def run_engine(name, device="cuda", shard=None, foreign=False, precision="fp32")
 def slice_fixture(fx, cfg, shard):
     """the part of a (single-member, full-dump) fixture that rank `shard` can reproduce: its own
     critics' parameters/moments; TD targets, actor parameters and temperature are global."""
-    assert cfg["E"] == 1 and "final_critic" in fx, "sharded replays use the small full-dump fixtures"
+    assert cfg["E"] == 1, "sharded replays use single-member fixtures"
     out = dict(fx)
     in_dim = cfg["obs"] if cfg["discrete"] else cfg["obs"] + cfg["act"]
     out_dim = cfg["act"] if cfg["discrete"] else 1
     H = cfg["hidden"]
     per = H * in_dim + H + H * H + H + out_dim * H + out_dim
     for key in ("final_critic", "final_target_critic"):
-        out[key] = fx[key][shard.lo * per: shard.hi * per]
+        if key in fx:
+            out[key] = fx[key][shard.lo * per: shard.hi * per]
     sizes = [H * in_dim, H, H * H, H, out_dim * H, out_dim]
     fpn = [min(48, n) for n in sizes]
     perfp = sum(fpn)
-    for key in ("finalfp_critic_m", "finalfp_critic_v"):
-        out[key] = fx[key][shard.lo * perfp: shard.hi * perfp]
+    for key in ("finalfp_critic", "finalfp_target_critic", "finalfp_critic_m", "finalfp_critic_v"):
+        if key in fx:
+            out[key] = fx[key][shard.lo * perfp: shard.hi * perfp]
     # the critic-loss / td-error / grad-norm logs are per-rank partial sums in a sharded run
     for key in list(out):
         if "_log:losses/critic" in key or "_log:losses/last_member" in key or "_log:gradients/" in key:

@@ -38,3 +38,99 @@ def test_two_rank_sharded_sequence_matches_reference(tmp_path):
     mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for rank in range(2):
         assert (tmp_path / f"ok{rank}.npz").exists()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the one-shot exchange (csrc/ssac_xchg.hip): IPC-mapped receive buffers, one recordable launch per reduction
+# ---------------------------------------------------------------------------------------------------------------
+def _xchg_main(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    from super_sac_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    x = parallel.enable_one_shot(torch.device("cuda:0"), max_floats=9000)
+    assert x is not None
+    ok = True
+    for it in range(40):
+        for n, op in ((1024, 0), (8704, 1), (3, 0), (512, 1)):
+            g = torch.Generator().manual_seed(1000 * it + n)
+            parts = [torch.randn(n, generator=g) for _ in range(world)]   # every rank can rebuild every partial
+            if op == 0:
+                parts[it % world][::7] = float("inf")   # (+inf: "this rank owns no subset member")
+            t = parts[rank].cuda()
+            (parallel.all_reduce_min if op == 0 else parallel.all_reduce_sum)(t)
+            want = parts[0].clone()
+            for p in parts[1:]:
+                want = torch.minimum(want, p) if op == 0 else want + p
+            ok = ok and torch.equal(t.cpu(), want)   # rank-ordered reduction: identical bits everywhere
+    assert not x.failed() and ok
+    open(os.path.join(out_dir, f"xok{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_one_shot_exchange_two_ranks_on_one_device(tmp_path):
+    port = 29900 + (os.getpid() % 2000)
+    mp.spawn(_xchg_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"xok{r}").exists() for r in range(2))
+
+
+def _humanoid_main(rank, world, port, out_dir):
+    """BASELINE config 5's shape (obs 376 / act 17 / N 16 / B 512), critics sharded over two ranks that share this
+    GPU: critic updates replayed from ONE launch list per rank (the exchange is a recorded launch), Polyak, actor and
+    temperature updates -- against the UNSHARDED engine run by the same process, and the reference fixture."""
+    sys.path.insert(0, HERE)
+    import case_runner
+    import synth
+    import torch.distributed as dist
+    from super_sac_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    name = "redq_S"
+    cfg = synth.CASES[name]
+    full = case_runner.run_engine(name, device="cuda:0")
+    case_runner.compare(full, case_runner.load_fixture(name), who=f"hip[{name}] rank {rank} unsharded")
+    assert parallel.enable_one_shot(torch.device("cuda:0")) is not None
+    shard = parallel.Shard(rank, world, cfg["N"])
+    import super_sac_amd as ssa
+    old = ssa.learning.GRAPH_WARMUP
+    ssa.learning.GRAPH_WARMUP = 0   # record on the first call: the 2 critic updates of the case replay a launch list
+    try:
+        rec = case_runner.run_engine(name, device="cuda:0", shard=shard)
+    finally:
+        ssa.learning.GRAPH_WARMUP = old
+    assert not parallel._exchange.failed()
+    # TD targets: the MIN over ranks of the per-shard target-critic outputs is the unsharded subset min -- bit for bit
+    # on the first update; afterwards the shards' critics went through the 16-row tile variant (8 nets per rank fit one
+    # round of 16-row workgroups, 16 nets do not) whose fp32 summation order differs in the last bits
+    import re
+    for key in full:
+        if re.fullmatch(r"u\d+_td\d+", key):
+            if key.startswith("u0_"):
+                assert np.array_equal(rec[key], full[key]), key
+            assert np.max(np.abs(rec[key] - full[key])) <= 2e-5, (key, float(np.max(np.abs(rec[key] - full[key]))))
+    in_dim, H = cfg["obs"] + cfg["act"], cfg["hidden"]
+    sizes = [H * in_dim, H, H * H, H, H, 1]
+    perfp = sum(min(48, n) for n in sizes)
+    for key in ("finalfp_critic", "finalfp_target_critic", "finalfp_critic_m", "finalfp_critic_v"):
+        mine = full[key][shard.lo * perfp: shard.hi * perfp]
+        tol = 1e-6 if not key.endswith("_v") else 1e-9
+        assert np.max(np.abs(rec[key] - mine)) <= tol, (key, float(np.max(np.abs(rec[key] - mine))))
+    # the actor step: MIN over all critics and SUM of the action gradient cross the ranks (rank-ordered sums)
+    assert np.max(np.abs(rec["finalfp_actor"] - full["finalfp_actor"])) <= 2e-6
+    assert np.max(np.abs(rec["final_log_alpha"] - full["final_log_alpha"])) <= 1e-6
+    assert abs(rec["a0_log:losses/actor_pg_loss"] - full["a0_log:losses/actor_pg_loss"]) <= 1e-5
+    open(os.path.join(out_dir, f"hok{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_humanoid_n16_sharded_two_ranks_one_shot_exchange(tmp_path):
+    port = 30900 + (os.getpid() % 2000)
+    mp.spawn(_humanoid_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all((tmp_path / f"hok{r}").exists() for r in range(2))

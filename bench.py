@@ -1,27 +1,31 @@
 """Headline benchmark: gradient updates/sec of the REDQ critic update (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats R]
 
-One "step" = one ``learning.critic_update`` call on a synthetic replay batch (obs 17, act 6,
-batch 512, N=10 critics, n=2 target subset, hidden 256, fp32 -- the shape the metric is
-quoted on) followed, every ``target_delay``=2 updates, by the Polyak update of the target
-critics, exactly as the reference's UTD loop does (main.py:379-414).  The replay buffer
-(100k transitions) is resident in HBM before the timed region starts; the per-update host
-work that remains (index draw from the torch CPU generator, REDQ subset draw, a 4 KB index
-upload) is part of the path and is inside the timed region.
+One "step" = one ``learning.critic_update`` call on a synthetic replay batch (obs 17, act 6, batch 512, N=10 critics,
+n=2 target subset, hidden 256, fp32 -- the shape the metric is quoted on) followed, every ``target_delay``=2 updates,
+by the Polyak update of the target critics, exactly as the reference's UTD loop does (main.py:379-414).  The replay
+buffer (100k transitions) is resident in HBM before the timed region starts; the per-update host work that remains
+(index draw from the torch CPU generator, REDQ subset draw, a 4 KB index upload) is part of the path and is inside the
+timed region.  After W untimed warm-up steps, EXACTLY K steps are timed between barrier + synchronize brackets; this is
+done R times (default 5) and the MEDIAN repeat is reported (``value`` = K / median seconds).
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) the critic ensemble is
-sharded across ranks (super_sac_amd.parallel): one MIN all-reduce of the (B,) partial
-min-Q per update over RCCL; total work is fixed, so scaling is "strong".
+N > 1: one process per GPU.  Launched by ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE in the environment)
+the process is one rank; from a bare shell (``python bench.py --gpus N``) the parent -- which never touches the GPU --
+starts the N ranks itself as child processes and relays rank 0's line.  The critic ensemble is sharded across the
+ranks (super_sac_amd.parallel); the one exchange per update (MIN of the per-shard subset min-Q) is a recorded launch
+of the one-shot IPC exchange kernel (csrc/ssac_xchg.hip), RCCL being the fallback.  Total work is fixed: "strong".
 
-Prints ONE JSON line (rank 0) with `roofline` for the ensemble-Q GEMM and `cpu_baseline`
-(the CPU oracle -- a port of the reference's update -- timed on this host's cores).
+Prints ONE JSON line (rank 0) with `roofline` for the dominant kernel, `cpu_baseline` (the CPU oracle -- a port of the
+reference's update -- timed on this host's cores) and `secondary` rows (full REDQ environment step; bf16 config 2).
 """
 import argparse
 import copy
 import json
 import math
 import os
+import statistics
+import subprocess
 import sys
 import time
 from itertools import chain
@@ -31,27 +35,25 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 OBS, ACT, BATCH, NCRIT, NSUB, HID = 17, 6, 512, 10, 2, 256
 ROWS, CAP = 100_000, 1_000_000
 GAMMA, LR, TAU, TARGET_DELAY = 0.99, 3e-4, 0.005, 2
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-# HBM bytes per launch from the PMC passes in profiles/r1_pmc_counters.md (FETCH_SIZE doubled per the guide's gfx950
-# note for 16-byte streaming reads + WRITE_SIZE, KiB -> bytes); not collected live, N=10 single-GPU shape only
-TRAFFIC_FUSED_CRITIC_BYTES = (2 * 13165 + 20527) * 1024
-TRAFFIC_DUAL_BYTES = (2 * 13067 + 10403) * 1024  # merged actor + ensemble-Q forward launch (profiles/r1_final_kernel_stats.md)
-TRAFFIC_CHAIN_BYTES = (2 * 18909 + 20647) * 1024  # chained launch (profiles/r1_final_kernel_stats.md)
-TRAFFIC_FWD_BYTES = None  # the two-launch form (SSAC_SPLIT_FORWARD=1) has no PMC pass yet
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+# HBM bytes per launch of the chained kernel from the offline PMC passes in profiles/ (FETCH_SIZE doubled per the
+# guide's gfx950 note for 16-byte streaming reads + WRITE_SIZE); single-GPU N=10 shape only; not collected in this run
+TRAFFIC_CHAIN_BYTES = (2 * 18909 + 20647) * 1024
+TRAFFIC_SOURCE = "offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r1_final_kernel_stats.md)"
 
 
-def synth_data():
+def synth_data(obs=OBS, act=ACT):
     import synth
-    return synth.synth_transitions(ROWS, OBS, ACT, seed=1)
+    return synth.synth_transitions(ROWS, obs, act, seed=1)
 
 
-def build_engine(device, n_local, shard=None):
+def build_engine(device, n_local, shard=None, batch=BATCH, precision="fp32"):
+    import numpy as np
+    import torch
     import super_sac_amd as ssa
     torch.manual_seed(0)
     np.random.seed(0)
@@ -64,22 +66,25 @@ def build_engine(device, n_local, shard=None):
                       log_std_low=-5.0, log_std_high=2.0)
     agent.to(device)
     agent.train()
+    ssa.set_precision(agent, precision)
     target = copy.deepcopy(agent)
     buf = ssa.replay.ReplayBuffer(CAP, device=device)
     buf.load_experience(*synth_data())
     copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=LR, betas=(0.9, 0.999))
+    aopt = torch.optim.Adam(chain(*(a.parameters() for a in agent.actors)), lr=LR, betas=(0.9, 0.999))
     eopt = torch.optim.Adam(agent.encoder.parameters(), lr=1e-4)
     la = torch.Tensor([math.log(0.1)]).to(device)
     la.requires_grad = True
-    aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(BATCH)])
+    lopt = torch.optim.Adam([la], lr=1e-4, betas=(0.5, 0.999))
+    aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(batch)])
     if shard is not None:
         ssa.parallel.install(agent, target, shard)
     state = {"k": 0}
 
     def step():
-        ssa.learning.critic_update(
+        _, dicts = ssa.learning.critic_update(
             buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt, encoder_optimizer=eopt,
-            log_alphas=[la], batch_size=BATCH, gamma=GAMMA, critic_clip=None, encoder_clip=None,
+            log_alphas=[la], batch_size=batch, gamma=GAMMA, critic_clip=None, encoder_clip=None,
             target_critic_ensemble_n=NSUB, weighted_bellman_temp=None, weight_type=None, pop=False,
             augmenter=aug, encoder_lambda=0, aug_mix=0.0, discrete=False, random_process=None,
             noise_clip=None, per=False, update_priorities=False, dr3_coeff=0.0)
@@ -87,11 +92,26 @@ def build_engine(device, n_local, shard=None):
             for ac, tc in zip(agent.critics, target.critics):
                 ssa.learning_utils.soft_update(tc, ac, TAU)
         state["k"] += 1
-    return step, ssa
+        return dicts
+
+    def env_step():
+        """one environment step of redq.gin: UTD 20 critic updates (+ Polyak every 2nd), then one actor and one
+        temperature update on the last critic batch (main.py:379-414, 489-542)"""
+        for _ in range(20):
+            dicts = step()
+        ssa.learning.online_actor_update(buffer=buf, agent=agent, pop=False, actor_optimizer=aopt, log_alphas=[la],
+                                         batch_size=batch, clip=None, random_process=None, noise_clip=None,
+                                         augmenter=aug, aug_mix=0.0, premade_replay_dicts=dicts)
+        ssa.learning.alpha_update(buffer=buf, agent=agent, optimizers=[lopt], batch_size=batch, log_alphas=[la],
+                                  augmenter=aug, aug_mix=0.0, target_entropy=-float(ACT), premade_replay_dicts=dicts,
+                                  discrete=False)
+    return step, env_step, ssa
 
 
-def cpu_baseline(budget_s=12.0):
-    """The oracle's critic_update (+Polyak) on the host cores: same shape, same 100k-row buffer."""
+def cpu_baseline(budget_s=15.0):
+    """The oracle's critic_update (+Polyak) on the host cores: same shape, same 100k-row buffer.  Rows: every thread
+    count tried (1 thread and all cores included); `value` is the best of them."""
+    import torch
     import ssac_oracle as orc
     torch.manual_seed(0)
     buf = orc.ReplayOracle(CAP)
@@ -108,30 +128,76 @@ def cpu_baseline(budget_s=12.0):
         orc.critic_update(buf, oa, ot, copt, eopt, la, BATCH, GAMMA, None, None, NSUB, None, None, False, aug)
         if k % TARGET_DELAY == 0:
             orc.soft_update(ot.critic_params(), oa.critic_params(), TAU)
-    # pick the thread count that is FASTEST for this workload on this host (tiny GEMMs do not
-    # scale to hundreds of threads; the baseline should be the CPU's best, not its worst)
-    best = (float("inf"), 1)
-    for th in sorted({1, 4, 8, 16, 32, min(64, os.cpu_count() or 1)}):
-        if th > (os.cpu_count() or 1):
-            continue
+    ncpu = os.cpu_count() or 1
+    counts = sorted({c for c in (1, 8, 16, 32) if c <= ncpu} | {ncpu})
+    rows = {}
+    per = budget_s / len(counts)
+    for th in counts:
         torch.set_num_threads(th)
-        one(0)
-        t1 = time.perf_counter()
-        for k in range(3):
-            one(k)
-        best = min(best, ((time.perf_counter() - t1) / 3, th))
-    threads = best[1]
-    torch.set_num_threads(threads)
-    for k in range(3):
-        one(k)
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        one(n)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 2), "unit": "updates/s", "cores": threads, "kind": "port",
-            "sample": f"{n} critic updates (+Polyak every 2nd) of the same workload in {dt:.1f} s, "
-                      f"torch {torch.__version__} CPU, {threads} threads"}
+        # (no separate warm-up call: on a many-core host ONE update with every core takes tens of seconds -- hundreds
+        # of threads spinning around 100-microsecond operators -- so that row is a single timed update)
+        n, t0 = 0, time.perf_counter()
+        while n < 1 or time.perf_counter() - t0 < per:
+            one(n)
+            n += 1
+        rows[th] = (n, time.perf_counter() - t0)
+    best = max(rows, key=lambda th: rows[th][0] / rows[th][1])
+    n, dt = rows[best]
+    return {"value": round(n / dt, 2), "unit": "updates/s", "cores": best, "kind": "port",
+            "host_cores": ncpu,
+            "rows": {str(th): round(r[0] / r[1], 2) for th, r in rows.items()},
+            "sample": f"{sum(r[0] for r in rows.values())} critic updates (+Polyak every 2nd) of the same workload in "
+                      f"{sum(r[1] for r in rows.values()):.1f} s over thread counts {counts} "
+                      f"(host has {ncpu} logical cores), torch {torch.__version__} CPU; value = best row "
+                      f"({best} threads)"}
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as fresh child processes (this parent has not
+    touched the GPU and never does) and relay rank 0's line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps),
+               "--warmup", str(args.warmup), "--repeats", str(args.repeats)]
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        if args.no_secondary:
+            cmd.append("--no-secondary")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, p.wait())
+    sys.stdout.write(out.decode())
+    sys.exit(rc)
+
+
+def timed_repeats(fn, steps, repeats, dist, device):
+    import torch
+    times = []
+    for _ in range(repeats):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t)
+        times.append(dt)
+    return times
 
 
 def main():
@@ -139,26 +205,33 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)   # (does not return)
 
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
     ndev = torch.cuda.device_count()
-    local = local % max(ndev, 1)  # (the single-GPU smoke test of the N>1 path runs 2 ranks on 1 device)
+    shared_device = world > ndev          # (ranks sharing one device: the N>1 path on a 1-GPU box)
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     shard = None
     n_local = NCRIT
-    # SSAC_BENCH_FORCE_DIST=1: take the sharded path (process group, MIN all-reduce between the recorded segments) with
-    # a single rank too -- the RCCL check that can run on a 1-GPU box
+    exchange = "none"
+    # SSAC_BENCH_FORCE_DIST=1: take the sharded path with a single rank too (the RCCL check a 1-GPU box can run)
     if world > 1 or os.environ.get("SSAC_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("SSAC_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        # RCCL refuses two ranks on one device: such runs set the group up over gloo (the data path is the IPC kernel)
+        backend = os.environ.get("SSAC_BENCH_BACKEND", "gloo" if shared_device else "nccl")  # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -166,9 +239,16 @@ def main():
         from super_sac_amd import parallel
         shard = parallel.Shard(rank, world, NCRIT)
         n_local = shard.n_local
+        exchange = f"torch.distributed all_reduce ({backend})"
+        if world > 1 and os.environ.get("SSAC_BENCH_ONE_SHOT", "1") == "1":
+            try:
+                if parallel.enable_one_shot(device) is not None:
+                    exchange = "one-shot IPC exchange kernel (csrc/ssac_xchg.hip), recorded in the launch list"
+            except RuntimeError as e:   # peers not mappable: keep the collective
+                exchange += f" [one-shot unavailable: {e}]"
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    step, ssa = build_engine(device, n_local, shard)
+    step, env_step, ssa = build_engine(device, n_local, shard)
     # Python's cyclic GC otherwise runs a full (generation-2) collection over the whole torch object graph every few
     # hundred updates -- a 40-80 ms pause, i.e. hundreds of updates: park the start-up objects in the permanent
     # generation (host runtime hygiene of a long-running training loop; nothing the update path allocates is cyclic)
@@ -178,34 +258,22 @@ def main():
     for _ in range(args.warmup):
         step()
 
-    # ---- timed region: EXACTLY --steps steps between barrier+sync brackets
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+    # ---- timed region: EXACTLY --steps steps between barrier+sync brackets, `repeats` times; the median is reported
+    times = timed_repeats(step, args.steps, args.repeats, dist, device)
+    dt = statistics.median(times)
 
-    # ---- roofline of the dominant kernel: the ensemble-Q kernel = fused forward (fc1+fc2+head, activations in
-    # LDS) of all local critics on the sampled batch, one launch per update.  Algorithmic FLOPs per launch
-    # (SURVEY 8(d)): 2*B*N*(in*H + H*H + H*out).  Its backward half (loss gradient, head backward, fc2
-    # backward-data: 2*B*N*(out*H + H*H) FLOPs) is a second launch of the same kernel template and is reported
-    # beside it.  The timed region re-issues the update from ONE recorded launch list, inside which a single kernel is not
-    # bracketed by events; so the same update is run again right here with plain launches and the launches are
-    # bracketed by HIP events recorded on the stream each one is launched on (same shapes, buffers, binary).
+    # ---- roofline of the dominant kernel: the chained launch (ensemble-Q forward + TD-independent backward of all local
+    # critics beside the target chains).  Algorithmic FLOPs per launch: 2*B*N*(in*H + H*H + H) for the
+    # critics' forward, 2*B*N*(H + H*H) for their backward-data, the target critics of the subset and the actor ONCE
+    # (each subset slot recomputes the actor for its rows: redundant work, not counted).  The timed region re-issues the
+    # update from ONE recorded launch list, inside which a single kernel is not bracketed by events; so the same
+    # update is run again right here with plain launches and the launch is bracketed by HIP events recorded on the
+    # stream it is launched on (same shapes, buffers, binary), 8 back-to-back issues per event pair.
     graphs_were_on = ssa.learning.USE_GRAPHS
     ssa.learning.USE_GRAPHS = False
     ssa.engine.PROFILE["tag"] = ("critic_fwd", "critic_bwd", "critic_fused", "dual_fwd", "dual_bwd", "chain")
     ssa.engine.PROFILE["events"] = []
-    ssa.engine.PROFILE["reps"] = 8   # the bracketed (idempotent) launch is issued 8x per event pair
+    ssa.engine.PROFILE["reps"] = 8
     for _ in range(min(args.steps, 300)):
         step()
     torch.cuda.synchronize()
@@ -219,77 +287,125 @@ def main():
     f_fwd = 2.0 * BATCH * n_local * (IN * HID + HID * HID + HID)
     f_bwd = 2.0 * BATCH * n_local * (HID + HID * HID)
     f_actor = 2.0 * BATCH * (OBS * HID + HID * HID + HID * 2 * ACT)
-    f_tgt_ = 2.0 * BATCH * NSUB * (IN * HID + HID * HID + HID)
+    f_tgt = 2.0 * BATCH * NSUB * (IN * HID + HID * HID + HID)
     if "chain" in by_tag:
         ms = by_tag["chain"]
-        flops, kname = f_fwd + f_bwd + f_tgt_ + NSUB * f_actor, (
+        flops, kname = f_fwd + f_bwd + f_tgt + f_actor, (
             "fused_chain_kernel: ensemble-Q forward (fc1+fc2+head, h1/h2/q saved) AND the TD-independent half of the "
             "backward pass (head backward + fc2 backward-data) of all local critics as 32-row workgroups, beside the "
             "target chains (actor forward + tanh-normal sample -> target critic, per REDQ subset slot) as 16-row "
             "workgroups; every workgroup gathers its own replay rows; ONE launch per update")
     elif "dual_fwd" in by_tag:
         ms = by_tag["dual_fwd"]
-        flops, kname = f_fwd + f_actor, (
-            "fused_dual_kernel: ensemble-Q forward (fc1+fc2+head, h1/h2/q saved) of all local critics as 32-row "
-            "workgroups + the actor forward with tanh-normal sample as 16-row workgroups, each workgroup gathering its own "
-            "replay rows, ONE launch per update")
+        flops, kname = f_fwd + f_actor, "fused_dual_kernel: ensemble-Q forward + actor forward/sample, ONE launch"
     elif "critic_fwd" in by_tag:
         ms = by_tag["critic_fwd"]
-        flops, kname = f_fwd, ("fused_mlp_kernel<plain>: ensemble-Q forward (fc1+fc2+head) of all local critics, "
-                               "h1/h2/q stored for the backward launches (one launch per update)")
-    else:  # the one-launch forward+backward form (learning.SPLIT_FORWARD off / chip-filling ensembles)
+        flops, kname = f_fwd, "fused_mlp_kernel<plain>: ensemble-Q forward (fc1+fc2+head) of all local critics"
+    else:
         ms = by_tag["critic_fused"]
-        flops, kname = f_fwd + f_bwd, ("fused_mlp_kernel<critic>: forward of all local critics + loss gradient + "
-                                       "head backward + fc2 backward-data (one launch per update)")
+        flops, kname = f_fwd + f_bwd, "fused_mlp_kernel<critic>: forward + loss gradient + backward-data, ONE launch"
     avg_ms = sum(ms) / len(ms)
     achieved = flops / (avg_ms * 1e-3) / 1e12
-    roofline = {"kernel": kname,
-                "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+    single = world == 1 and n_local == NCRIT and "chain" in by_tag
+    roofline = {"kernel": kname, "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                 "avg_launch_us": round(avg_ms * 1e3, 3), "launches_timed": len(ms),
                 "timing": "HIP events on the launch stream around 8 back-to-back issues of the (idempotent) launch, "
                           "in an eager pass right after the timed (replayed) region",
                 "flops_per_launch": flops,
-                "traffic": (None if not (world == 1 and n_local == NCRIT) else
-                            (TRAFFIC_CHAIN_BYTES if "chain" in by_tag else TRAFFIC_DUAL_BYTES if "dual_fwd" in by_tag else
-                             (TRAFFIC_FWD_BYTES if "critic_fwd" in by_tag else TRAFFIC_FUSED_CRITIC_BYTES)))}
-    if "dual_bwd" in by_tag:
-        mb = by_tag["dual_bwd"]
-        avg_b = sum(mb) / len(mb)
-        f_tgt = 2.0 * BATCH * NSUB * (IN * HID + HID * HID + HID)
-        roofline["backward_launch"] = {
-            "kernel": "fused_dual2_kernel: TD-independent half of the critics' backward pass (head backward + fc2 "
-                      "backward-data, unscaled) as 32-row workgroups + the target critics' forward on the REDQ subset",
-            "avg_launch_us": round(avg_b * 1e3, 3), "flops_per_launch": f_bwd + f_tgt,
-            "achieved": round((f_bwd + f_tgt) / (avg_b * 1e-3) / 1e12, 3)}
-    elif "critic_bwd" in by_tag:
-        mb = by_tag["critic_bwd"]
-        avg_b = sum(mb) / len(mb)
-        roofline["backward_launch"] = {"kernel": "fused_mlp_kernel<critic-bwd>: loss gradient + head backward + "
-                                                 "fc2 backward-data on the saved forward",
-                                       "avg_launch_us": round(avg_b * 1e3, 3), "flops_per_launch": f_bwd,
-                                       "achieved": round(f_bwd / (avg_b * 1e-3) / 1e12, 3)}
+                "traffic": TRAFFIC_CHAIN_BYTES if single else None,
+                "traffic_source": TRAFFIC_SOURCE if single else None}
 
     if rank == 0:
         out = {"metric": "gradient updates/sec (REDQ N=10, batch 512)", "value": round(args.steps / dt, 2),
                "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 5), "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "repeats": args.repeats, "repeat_ms_per_step": [round(1e3 * t / args.steps, 5) for t in times],
                "config": {"workload": "REDQ critic_update + Polyak/2: obs 17, act 6, batch 512, "
                                       "N=10 critics (n=2 target subset), hidden 256, replay 100k rows in HBM",
                           "global_batch": BATCH, "num_critics": NCRIT,
-                          "launch": ("plain launches" if not graphs_were_on else
-                                     ("recorded launch list (ssac_replay)" + ("" if world == 1 else
-                                      ", MIN all-reduce between two segments")
-                                      if ssa.learning.LAUNCH_MODE == "list" and (world == 1 or ssa.learning.SHARDED_LISTS)
-                                      else ("HIP graph replay" if world == 1 else "plain launches"))),
-                          "parallelism": "single GPU" if world == 1 else f"critic-ensemble sharded x{world}"},
+                          "launch": "recorded launch list, one C call per update (ssac_step_run)"
+                                    if graphs_were_on else "plain launches",
+                          "parallelism": "single GPU" if world == 1 else
+                                         f"critic-ensemble sharded x{world}" +
+                                         (f" ({world} ranks sharing {ndev} device(s))" if shared_device else ""),
+                          "exchange": exchange},
                "roofline": roofline}
+    secondary = {}
+    if not args.no_secondary and world == 1:
+        # ---- full REDQ environment step (SURVEY 8(d) secondary unit): 20 critic updates + 10 Polyak + actor + alpha
+        for _ in range(3):
+            env_step()
+        ts = timed_repeats(env_step, 30, 3, None, device)
+        te = statistics.median(ts) / 30
+        secondary["full_redq_step_fp32"] = {
+            "workload": "redq.gin environment step at the headline shape: 20 critic updates + 10 Polyak + 1 actor + "
+                        "1 temperature update (B 512, N 10)",
+            "ms_per_env_step": round(te * 1e3, 4), "critic_updates_per_s": round(20 / te, 1),
+            "env_steps_per_s": round(1 / te, 1)}
+        # ---- BASELINE config 2: REDQ N=10 UTD=20 batch 256 in the bf16-operand mode; the ensemble-Q kernel's HBM fraction
+        del step, env_step
+        step_b, env_b, _ = build_engine(device, NCRIT, None, batch=256, precision="bf16")
+        for _ in range(60):
+            step_b()
+        tb = statistics.median(timed_repeats(step_b, 1000, 3, None, device)) / 1000
+        for _ in range(3):
+            env_b()
+        teb = statistics.median(timed_repeats(env_b, 30, 3, None, device)) / 30
+        secondary["config2_bf16"] = dict(bf16_rows(ssa, device), **{
+            "workload": "REDQ N=10 UTD=20 batch 256, bf16 operands / fp32 accumulate + fp32 masters (no reference "
+                        "counterpart; parity: tests/test_hip_bf16.py)",
+            "critic_updates_per_s": round(1 / tb, 1), "us_per_critic_update": round(tb * 1e6, 2),
+            "ms_per_env_step": round(teb * 1e3, 4), "env_steps_per_s": round(1 / teb, 1)})
+    if rank == 0:
+        if secondary:
+            out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def bf16_rows(ssa, device):
+    """the ensemble-Q kernel alone in bf16 (forward of N=10 critics): algorithmic bytes = bf16 weights +
+    fp32 batch in + fp32 Q out; reported against the HBM roof at the config-2 batch and at large batches"""
+    import ctypes as C
+    import torch
+    from super_sac_amd import engine
+    from super_sac_amd._lib import check, lib
+    N, IN = NCRIT, OBS + ACT
+    ar = engine.MlpArena(N, IN, HID, 1, device)
+    torch.manual_seed(1)
+    ar.params.copy_(torch.randn_like(ar.params) * 0.05)
+    ar.enable_bf16()
+    rows = {}
+    for B in (256, 4096, 65536):
+        x = torch.randn(B, IN, device=device)
+        y = torch.empty(N, B, 1, device=device)
+
+        def run():
+            check(lib.ssac_bf16_mlp3_fwd(C.byref(ar.desc()), ar.shadow.data_ptr(), 0, N, x.data_ptr(), IN, B,
+                                         y.data_ptr(), engine.stream()))
+        for _ in range(5):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50 if B <= 4096 else 10
+        e0.record()
+        for _ in range(reps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        nbytes = N * (IN * HID + HID * HID + HID) * 2 + N * (2 * HID + 1) * 4 + B * IN * 4 + N * B * 4
+        flops = 2.0 * B * N * (IN * HID + HID * HID + HID)
+        rows[f"B{B}"] = {"us_per_launch": round(us, 2), "algorithmic_bytes": nbytes,
+                         "hbm_GBs": round(nbytes / us / 1e3, 1), "hbm_frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
+                         "TFLOPs": round(flops / us / 1e6, 1)}
+    return {"ensemble_q_kernel_bf16": {"kernel": "bf_mlp_kernel<plain>: forward of N=10 critics (23->256->256->1), bf16 "
+                                                 "shadow weights, HIP events around back-to-back launches",
+                                       "hbm_peak_GBs": HBM_PEAK_GBS, "rows": rows}}
 
 
 if __name__ == "__main__":

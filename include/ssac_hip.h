@@ -274,13 +274,40 @@ int ssac_mlp_wgrad_all_scaled(const ssac_mlp *nets, const int32_t *net_ids, int 
  * lazy_td (evaluated here, td_target_kernel's arithmetic; net slot 0's first workgroup writes lazy_td->td_out).
  * partials[n_nets][2] receives sum_b w err^2 and sum_b err per net: ssac_critic_logs(partials, n_nets, tiles = 1, ...)
  * finishes "losses/critic_overall_loss" and "losses/last_member_critic_td_error". */
+/* logfold (nullable; Adam mode, every sumsq slot given): the update's log finalisation -- ssac_critic_logs' work --
+ * rides in this launch: the workgroup that evaluated the TD targets also computes their statistics, every workgroup
+ * draws an arrival ticket after its last cross-workgroup store, and the last arriver sums the partials in index order,
+ * writes logs[0] += loss, logs[1] = TD error of the last net, logs[2] = gradient norm, publishes the block to its ring
+ * slot and advances the input ring.  No fence and no second launch (csrc/ssac_critic_logs.h). */
+typedef struct ssac_logfold {
+    unsigned *done_counter;   /* one zero-initialised uint32 in device memory, reset by the launch itself */
+    float *logs;              /* the update's log block */
+    float *td_logs;           /* mean / std / entropy bonus of the TD targets (3 floats inside the block), or NULL */
+    ssac_feed *feed;          /* recorded update: publish + advance the ring; NULL otherwise */
+    float *deferred_stats;    /* != NULL (recorded updates): DEFERRED finalisation -- this launch leaves the partials and
+                                 the three TD statistics (here) behind and advances the input ring; the next update's
+                                 first launch, or ssac_deferred_logs_flush, writes the ring slot (ssac_deferred_logs) */
+} ssac_logfold;
+
+/* Deferred log finalisation of a recorded update (see ssac_logfold.deferred_stats): what the finishing workgroup reads.
+ * Host-side struct, copied at launch.  Passed to ssac_chain_update / ssac_bf16_chain_update (one extra workgroup of the
+ * launch finishes the PREVIOUS update's log block into its ring slot) and to ssac_deferred_logs_flush. */
+typedef struct ssac_deferred_logs {
+    const float *partials; int32_t n_nets, n_ss;   /* loss partials [n_nets][2]; gradient-norm partials (n_ss) */
+    const float *sumsq;
+    const float *td_stats;                         /* the 3 TD statistics the weight-gradient launch left, or NULL */
+    int32_t td_off, n_rows;                        /* index of the TD statistics inside a log block; batch rows */
+    float denom; int32_t _pad;
+    const ssac_feed *feed;
+} ssac_deferred_logs;
+int ssac_deferred_logs_flush(const ssac_deferred_logs *d, int ring_slot, void *stream);
 int ssac_mlp_wgrad_all_lossfold(const ssac_mlp *nets, const float *X, int64_t ldx, int64_t x_net_stride,
                                 const float *H1, const float *H2, const float *DZ2u, const float *DZ1u,
                                 const float *Q, const float *td, const ssac_td_spec *lazy_td, const float *weight,
                                 const ssac_popart *popart, int pop, float denom, float *partials, int n_rows,
                                 float *adam_m, float *adam_v, const ssac_adam_ctl *ctl, float *grads, float *sumsq2,
                                 float *sumsq1, float *sumsq0, int64_t sumsq_net_stride, float *target, float tau,
-                                void *stream);
+                                const ssac_logfold *logfold, void *stream);
 /* ssac_critic_loss_bwd with the TD targets evaluated in the same launch (ssac_td_spec; they are also written to
  * lazy_td->td_out). */
 int ssac_critic_loss_bwd_lazy(const float *q, int n_nets, int n_rows, int q_dim, const float *act, int64_t ld_act,
@@ -293,18 +320,6 @@ int ssac_target_fwd_critic_bwdu(const ssac_mlp *targets, const int32_t *net_ids,
                                 int64_t ldx1, int n_rows, float *Qt, const ssac_mlp *critics, const float *H1,
                                 const float *H2, const float *act, int64_t ld_act, float *DZ2u, float *DZ1u,
                                 void *stream);
-
-/* ssac_mlp_wgrad_all (Adam mode) whose LAST workgroup to finish also does ssac_critic_logs' work (n_nets = n_sel;
- * sumsq_all / n_sumsq: the whole per-net sumsq block for the gradient-norm log): the update ends with this launch.
- * done_counter: one zero-initialised uint32 in device memory, reset by the launch itself. */
-int ssac_mlp_wgrad_all_logs(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X, int64_t ldx,
-                            int64_t x_net_stride, const float *H1, const float *H2, const float *DZ2,
-                            const float *DZ1, const float *DQ, int n_rows, float *adam_m, float *adam_v,
-                            const ssac_adam_ctl *ctl, float *sumsq2, float *sumsq1, float *sumsq0,
-                            int64_t sumsq_net_stride, float *target, float tau, const float *partials, int tiles,
-                            float denom, const float *sumsq_all, int n_sumsq, float *logs,
-                            const ssac_td_spec *lazy_td, float *td_logs, ssac_feed *feed, unsigned *done_counter,
-                            void *stream);
 
 /* ---- elementwise Adam over a whole arena from stored gradients (clip path):
  * g *= ctl->clip_coef first (torch.nn.utils.clip_grad_norm_, learning.py:122-128). */
@@ -522,7 +537,8 @@ int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t ldxa, int 
                       float log_std_lo, float log_std_hi, float *x1sa, int64_t ld_x1, int64_t act_col0, float *logp,
                       const ssac_rng *rng, const ssac_mlp *targets, const int32_t *net_ids, int n_sel, float *Qt,
                       const ssac_mlp *critics, const float *Xc, int64_t ldxc, float *H1, float *H2, float *Q,
-                      float *DZ2u, float *DZ1u, const ssac_gather *gather, void *stream);
+                      float *DZ2u, float *DZ1u, const ssac_gather *gather,
+                      const ssac_deferred_logs *deferred /* nullable */, void *stream);
 
 /* critic forward of ALL nets + loss gradient + backward-data in ONE launch (learning.py:83-98,112,121):
  * writes H1, H2, Q (n_nets x n_rows x out), DQ, DZ2 = dL/d(pre-activation of fc2), DZ1, and per-(net,
@@ -649,7 +665,7 @@ int ssac_bf16_chain_update(const ssac_mlp *actor, const uint16_t *actor_shadow, 
                            const uint16_t *target_shadow, const int32_t *net_ids, int n_sel, float *Qt,
                            const ssac_mlp *critics, const uint16_t *critic_shadow, const float *Xc, int64_t ldxc,
                            float *Q, uint16_t *H1T, uint16_t *H2T, uint16_t *DZ2uT, uint16_t *DZ1uT, uint16_t *XT,
-                           const ssac_gather *gather, void *stream);
+                           const ssac_gather *gather, const ssac_deferred_logs *deferred /* nullable */, void *stream);
 /* ssac_mlp_wgrad_all_lossfold in bf16 (all three layers, loss gradient per workgroup, Adam on the fp32 masters, shadow
  * refreshed from the new values, optional Polyak of `target` + its shadow).  sumsq: ssac_bf16_wgrad_tiles() slots per
  * net.  No split-K: every gradient element is accumulated by one wave in a fixed order. */
@@ -659,7 +675,7 @@ int ssac_bf16_wgrad_lossfold(const ssac_mlp *nets, uint16_t *shadow, const uint1
                              const float *td, const ssac_td_spec *lazy_td, const float *weight, float denom,
                              float *partials, int n_rows, float *adam_m, float *adam_v, const ssac_adam_ctl *ctl,
                              float *sumsq, int64_t sumsq_net_stride, float *target, uint16_t *target_shadow, float tau,
-                             void *stream);
+                             const ssac_logfold *logfold, void *stream);
 
 /* zero a float buffer (log accumulators) */
 int ssac_zero(float *p, int64_t n, void *stream);

@@ -51,6 +51,19 @@ class TdSpec(C.Structure):
                 ("n_sel", C.c_int32), ("use_entropy", C.c_int32), ("_pad", C.c_int32)]
 
 
+class LogFold(C.Structure):
+    """struct ssac_logfold"""
+    _fields_ = [("done_counter", C.c_void_p), ("logs", C.c_void_p), ("td_logs", C.c_void_p), ("feed", C.c_void_p),
+                ("deferred_stats", C.c_void_p)]
+
+
+class DeferredLogs(C.Structure):
+    """struct ssac_deferred_logs"""
+    _fields_ = [("partials", C.c_void_p), ("n_nets", C.c_int32), ("n_ss", C.c_int32), ("sumsq", C.c_void_p),
+                ("td_stats", C.c_void_p), ("td_off", C.c_int32), ("n_rows", C.c_int32), ("denom", C.c_float),
+                ("_pad", C.c_int32), ("feed", C.c_void_p)]
+
+
 class Gather(C.Structure):
     """struct ssac_gather"""
     _fields_ = [("s", C.c_void_p), ("s1", C.c_void_p), ("act", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p),
@@ -98,10 +111,8 @@ SIGNATURES = {
                                   _P],
     "ssac_critic_loss_bwd_lazy": [_P, _I, _I, _I, _P, _L, _P, _P, _P, _I, _F, _P, _P, _P],
     "ssac_mlp_wgrad_all_lossfold": [_MP, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _I, _P, _P, _P, _P,
-                                    _P, _P, _P, _L, _P, _F, _P],
+                                    _P, _P, _P, _L, _P, _F, _P, _P],
     "ssac_target_fwd_critic_bwdu": [_MP, _P, _I, _P, _L, _I, _P, _MP, _P, _P, _P, _L, _P, _P, _P],
-    "ssac_mlp_wgrad_all_logs": [_MP, _P, _I, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _P, _F,
-                                _P, _I, _F, _P, _I, _P, _P, _P, _P, _P, _P],
     "ssac_gather_transition": [_P, _P, _I, _L, _P, _L, _P, _P, _P, _I, _P, _L, _P, _L, _P, _P, _P],
     "ssac_gather_transition_begin": [_P, _P, _I, _L, _P, _L, _P, _P, _I, _P, _L, _P, _L, _P, _P, _P, _P, _I, _P, _P],
     "ssac_adam_step": [_P, _P, _P, _P, _L, _P, _P],
@@ -165,7 +176,8 @@ SIGNATURES = {
     "ssac_actor_sample_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _P, _P, _P, _P],
     "ssac_actor_sample_critic_fwd": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _L, _P, _P, _P, _P, _P],
     "ssac_chain_update": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _I, _P, _MP, _P, _L, _P, _P, _P, _P, _P,
-                          _P, _P],
+                          _P, _P, _P],
+    "ssac_deferred_logs_flush": [_P, _I, _P],
     "ssac_philox_normal": [_P, _I, _I, _P, _P],
     "ssac_critic_fwd_bwd_fused": [_MP, _P, _L, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ssac_critic_bwd_fused": [_MP, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -179,10 +191,10 @@ SIGNATURES = {
     "ssac_bf16_polyak": [_MP, _MP, _F, _P, _P],
     "ssac_bf16_mlp3_fwd": [_MP, _P, _P, _I, _P, _L, _I, _P, _P],
     "ssac_bf16_chain_update": [_MP, _P, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _P, _I, _P, _MP, _P, _P, _L,
-                               _P, _P, _P, _P, _P, _P, _P, _P],
+                               _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ssac_bf16_wgrad_tiles": [_MP],
     "ssac_bf16_wgrad_lossfold": [_MP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P, _L, _P, _P, _F,
-                                 _P],
+                                 _P, _P],
 }
 _RESTYPES = {"ssac_xchg_create": C.c_void_p, "ssac_xchg_destroy": None, "ssac_step_create": C.c_void_p, "ssac_step_count": C.c_int64, "ssac_step_destroy": None,
              "ssac_last_error": C.c_char_p, "ssac_mlp_layout": C.c_int64, "ssac_bf16_layout": C.c_int64, "ssac_record_end": C.c_void_p,

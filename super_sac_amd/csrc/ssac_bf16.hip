@@ -436,9 +436,13 @@ __global__ __launch_bounds__(NTHR) void bf_mlp_kernel(BfArgs g) {
 // workgroups [0, tiles_t): target chain of subset slot j (actor forward + sample, then target critic ids[j] on [s'|a']);
 // the rest: online critics' forward + TD-independent backward.
 __global__ __launch_bounds__(NTHR) void bf_chain_kernel(BfArgs ga, BfArgs ga_rest, BfArgs gt, BfArgs gc, int tiles_t,
-                                                       int grid_x) {
+                                                       int grid_x, DeferredLogsArgs dl, int dl_on) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int bid = blockIdx.x;
+    if (dl_on && bid == (int)gridDim.x - 1) {   // the previous recorded update's log block -> its ring slot
+        deferred_logs_body(dl, -1);
+        return;
+    }
     if (bid < tiles_t) {
         const int j = bid / grid_x, bx = bid - j * grid_x;
         if (j == 0) bf_mlp_body<MODE_SAMPLE>(ga, smem, bx, 0);
@@ -528,6 +532,7 @@ struct BfWgradArgs {
     float *target; unsigned short *tshadow; float tau;
     float *sumsq; int64_t sumsq_stride;
     LossFoldArgs lf;
+    LogFoldArgs fold;     // fold.done != null: the update's logs are finalised by the last workgroup (ssac_critic_logs.h)
     int tiles2, tiles1;   // 64x64 tiles of fc2 / fc1 per net; then 1 head workgroup per net
     long long *dbg;
 };
@@ -611,10 +616,13 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
     // ---- loss gradient of this net's rows -> LDS (the first fc2 tile of each net also reduces the loss terms)
     for (int b = g.n_rows + tid; b < g.bp; b += 256) tab[b] = 0.0f;
     loss_fold_table(g.lf, e, tab, t == 0, red);
+    if (((g.fold.done && g.fold.td_logs) || g.fold.deferred_stats) && t == 0 && e == 0)
+        log_fold_td_stats(g.fold, g.lf.tds, red);
     __syncthreads();
     WSTAMP(1);
     const ssac_adam_ctl ctl = *g.ctl;
     float ss = 0.0f;
+    bool early = false;
     if (head) {
         // ---- head layer (VALU): thread i owns W3[i]
         const int i = tid;
@@ -681,6 +689,29 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
         const bool bias_lane = bxn == 0 && wn == 0 && lh == 0 && row < H;
         const int64_t ab = (fc2 ? g.off[3] : g.off[1]) + (row < H ? row : 0);
         const float pb = P[ab], mb0 = M[ab], vb0 = V[ab], tb0 = T ? T[ab] : 0.0f;
+        // ---- gradient-norm partial first (it needs the gradients only): with the logs folded in, the arrival ticket is
+        //      drawn BEFORE the optimizer stores, whose drain it must not wait for
+        if (col < Ncols) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = by * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (j < H) ss += acc[r] * acc[r];
+            }
+        }
+        if (bias_lane) ss += colsum * colsum;
+        early = true;
+        if (g.sumsq) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            __syncthreads();
+            if (lane == 0) red[wave] = ss;
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_store(g.sumsq + (int64_t)e * g.sumsq_stride + t, red[0] + red[1] + red[2] + red[3],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (g.fold.done) red[8] = log_fold_arrive(g.fold, gridDim.x) ? 1.0f : 0.0f;
+            }
+        }
         // ---- Adam epilogue straight from the accumulator: acc[r] = dW[by*64 + wm*32 + (r&3) + 8(r>>2) + 4 lh][col];
         //      the optimizer state was loaded at kernel start, so this is arithmetic + stores only
         if (col < Ncols) {
@@ -698,7 +729,6 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
                         float m = mv[r], v = vv[r];
                         const float pn = adam_elem(pv[r], gr, m, v, ctl);
                         M[a] = m; V[a] = v; P[a] = pn;
-                        ss += gr * gr;
                         hq[u] = f2bf(pn);
                         if (fc2) S[g.sg.o2 + (int64_t)j * H + col] = hq[u];
                         else S[g.sg.o1 + (int64_t)j * K1P + col] = hq[u];
@@ -722,17 +752,26 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
             const float pn = adam_elem(pb, colsum, m, v, ctl);
             M[ab] = m; V[ab] = v; P[ab] = pn;
             if (T) T[ab] = tb0 * (1.0f - g.tau) + pn * g.tau;
-            ss += colsum * colsum;
         }
     }
     WSTAMP(3);
-    if (g.sumsq) {
+    if (g.sumsq && !early) {   // (the head workgroup: its partial and ticket come after its few stores)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
         __syncthreads();
         if (lane == 0) red[wave] = ss;
         __syncthreads();
-        if (tid == 0) g.sumsq[(int64_t)e * g.sumsq_stride + t] = red[0] + red[1] + red[2] + red[3];
+        if (tid == 0) {
+            __hip_atomic_store(g.sumsq + (int64_t)e * g.sumsq_stride + t, red[0] + red[1] + red[2] + red[3],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g.fold.done) red[8] = log_fold_arrive(g.fold, gridDim.x) ? 1.0f : 0.0f;
+        }
+    }
+    if (g.fold.done) {
+        __syncthreads();
+        if (red[8] != 0.0f && tid < 64) log_fold_finish(g.fold);
+    } else if (g.fold.deferred_stats && g.fold.feed && blockIdx.x == 0 && tid == 0) {
+        g.fold.feed->tick += 1;   // deferred finalisation: the update is over for the input ring
     }
 }
 
@@ -823,7 +862,7 @@ extern "C" int ssac_bf16_chain_update(const ssac_mlp *actor, const uint16_t *act
                                       int n_sel, float *Qt, const ssac_mlp *critics, const uint16_t *critic_shadow,
                                       const float *Xc, int64_t ldxc, float *Q, uint16_t *H1T, uint16_t *H2T,
                                       uint16_t *DZ2uT, uint16_t *DZ1uT, uint16_t *XT, const ssac_gather *gather,
-                                      void *stream) {
+                                      const ssac_deferred_logs *deferred, void *stream) {
     if (!eps && !rng) return ssac_fail("ssac_bf16_chain_update: neither eps nor an rng stream given");
     if (!bf_ok(actor) || (actor->out_dim & 1) || !bf_ok(targets) || !bf_ok(critics))
         return ssac_fail("ssac_bf16_chain_update: shape not supported by the bf16 path");
@@ -868,8 +907,13 @@ extern "C" int ssac_bf16_chain_update(const ssac_mlp *actor, const uint16_t *act
     if (raise_lds(bf_chain_kernel, attr)) return 1;
     const int gx = (n_rows + TM - 1) / TM;
     const int tiles_t = gx * n_sel;
-    SSAC_LAUNCH(bf_chain_kernel, dim3(tiles_t + gx * critics->n_nets), dim3(NTHR), lds, (hipStream_t)stream, ga, gr, gt, gc,
-                tiles_t, gx);
+    DeferredLogsArgs dl{};
+    const int dl_on = (deferred && deferred->feed) ? 1 : 0;
+    if (dl_on)
+        dl = DeferredLogsArgs{deferred->partials, deferred->n_nets, deferred->sumsq, deferred->n_ss, deferred->td_stats,
+                              deferred->td_off, deferred->n_rows, deferred->denom, deferred->feed};
+    SSAC_LAUNCH(bf_chain_kernel, dim3(tiles_t + gx * critics->n_nets + dl_on), dim3(NTHR), lds, (hipStream_t)stream, ga, gr,
+                gt, gc, tiles_t, gx, dl, dl_on);
     return ssac_check_launch("bf16_chain");
 }
 
@@ -884,7 +928,7 @@ extern "C" int ssac_bf16_wgrad_lossfold(const ssac_mlp *nets, uint16_t *shadow, 
                                         const float *td, const ssac_td_spec *lazy_td, const float *weight, float denom,
                                         float *partials, int n_rows, float *adam_m, float *adam_v,
                                         const ssac_adam_ctl *ctl, float *sumsq, int64_t sumsq_net_stride, float *target,
-                                        uint16_t *target_shadow, float tau, void *stream) {
+                                        uint16_t *target_shadow, float tau, const ssac_logfold *logfold, void *stream) {
     if (!bf_ok(nets) || nets->out_dim != 1) return ssac_fail("ssac_bf16_wgrad_lossfold: single-output critics only");
     if (!shadow || !XT || !H1T || !H2T || !DZ2uT || !DZ1uT || !Q || !partials || (!td && !lazy_td) || !adam_m || !adam_v || !ctl)
         return ssac_fail("ssac_bf16_wgrad_lossfold: missing argument");
@@ -905,6 +949,17 @@ extern "C" int ssac_bf16_wgrad_lossfold(const ssac_mlp *nets, uint16_t *shadow, 
     const int t = (nets->hidden + 63) / 64;
     g.tiles2 = t * t; g.tiles1 = t * ((nets->in_dim + 63) / 64);
     g.dbg = g_bf_dbg;
+    if (logfold && logfold->done_counter) {
+        if (!sumsq) return ssac_fail("ssac_bf16_wgrad_lossfold: the folded logs need the sumsq slots");
+        g.fold = LogFoldArgs{logfold->done_counter, logfold->logs, lazy_td ? logfold->td_logs : nullptr, logfold->feed,
+                             nullptr, partials, nets->n_nets, sumsq, (int)(nets->n_nets * sumsq_net_stride), n_rows, denom};
+    } else if (logfold && logfold->deferred_stats) {
+        if (!logfold->feed || !lazy_td) return ssac_fail("ssac_bf16_wgrad_lossfold: deferred logs need a feed and the in-launch TD target");
+        g.fold = LogFoldArgs{};
+        g.fold.feed = logfold->feed;
+        g.fold.deferred_stats = logfold->deferred_stats;
+        g.fold.n_rows = n_rows;
+    }
     const size_t lds = sizeof(float) * (g.bp + 16);
     static bool attr = false;
     if (raise_lds(bf_wgrad_kernel, attr)) return 1;

@@ -161,8 +161,159 @@ __device__ __forceinline__ void loss_fold_table(const LossFoldArgs &a, int e, fl
         if (tid == 0) {
             float tl = 0.0f, te = 0.0f;
             for (int w = 0; w < nw; ++w) { tl += red[w]; te += red[nw + w]; }
-            a.partials[2 * e] = tl;
-            a.partials[2 * e + 1] = te;
+            // (agent-scope stores: with the logs folded into this launch the reader is a workgroup on another XCD)
+            __hip_atomic_store(a.partials + 2 * e, tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.partials + 2 * e + 1, te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Log finalisation folded into the weight-gradient launch (ssac_logfold in include/ssac_hip.h): no logs launch.
+//   * the statistics of the TD targets (mean / unbiased std / entropy bonus) are computed by ONE workgroup -- the one
+//     that evaluated and wrote the targets -- right after its loss-fold table (log_fold_td_stats);
+//   * every workgroup's cross-workgroup outputs (loss partials, gradient-norm partial, the three TD statistics) leave as
+//     agent-scope (write-through) stores; the workgroup then drains ITS stores (s_waitcnt vmcnt(0) in the storing lane)
+//     and bumps a device-scope arrival counter (log_fold_arrive);
+//   * the workgroup that draws the last ticket reads the partials back with agent-scope loads, sums them in index order
+//     (the result does not depend on WHICH workgroup is last), writes the log block, publishes it to its ring slot and
+//     advances the input ring (log_fold_finish): ~270 floats and one shuffle tree on one wave -- no fence, no second
+//     launch, no L2 write-back of the 17 MB of optimizer state the launch has just dirtied.
+// ------------------------------------------------------------------------------------------------------------
+struct LogFoldArgs {
+    unsigned *done;                 // null = fold off
+    float *logs, *td_logs; ssac_feed *feed;
+    float *deferred_stats;          // != null: DEFERRED mode (below): the TD statistics go here, no ticket is drawn, and
+                                    // the launch only advances the input ring; the next update's first launch finishes
+    const float *partials; int n_nets;     // [n_nets][2] from loss_fold_table
+    const float *sumsq; int n_ss;          // every gradient-norm partial of the launch
+    int n_rows; float denom;
+};
+
+// all threads of the (>= 256-thread) workgroup call this; red: 12 floats of LDS.  td_out was written by this workgroup.
+__device__ __forceinline__ void log_fold_td_stats(const LogFoldArgs &f, const ssac_td_spec &tds, float *red) {
+    const int tid = threadIdx.x, n_rows = f.n_rows;
+    const bool act = tid < 256;
+    __syncthreads();   // (td_out of every row is written; red is free)
+    float s_td = 0.f, s_b = 0.f;
+    const float alpha = tds.use_entropy ? expf(tds.log_alpha[0]) : 0.0f;
+    if (act)
+        for (int b = tid; b < n_rows; b += 256) {
+            s_td += tds.td_out[b];
+            s_b += tds.use_entropy ? alpha * tds.logp[b] : 0.0f;
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s_td += __shfl_xor(s_td, o, 64); s_b += __shfl_xor(s_b, o, 64); }
+    if (act && (tid & 63) == 0) { red[tid >> 6] = s_td; red[4 + (tid >> 6)] = s_b; }
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)n_rows;
+    const float mb = (red[4] + red[5] + red[6] + red[7]) / (float)n_rows;
+    float sv = 0.f;
+    if (act)
+        for (int b = tid; b < n_rows; b += 256) { const float d = tds.td_out[b] - mean; sv += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sv += __shfl_xor(sv, o, 64);
+    if (act && (tid & 63) == 0) red[8 + (tid >> 6)] = sv;
+    __syncthreads();
+    if (tid == 0 && f.deferred_stats) {   // read by the NEXT launch: plain stores
+        const float var = (red[8] + red[9] + red[10] + red[11]) / (float)(n_rows > 1 ? n_rows - 1 : 1);
+        f.deferred_stats[0] = mean; f.deferred_stats[1] = sqrtf(var); f.deferred_stats[2] = mb;
+    } else if (tid == 0 && f.td_logs) {
+        const float var = (red[8] + red[9] + red[10] + red[11]) / (float)(n_rows > 1 ? n_rows - 1 : 1);
+        __hip_atomic_store(f.td_logs + 0, mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(f.td_logs + 1, sqrtf(var), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(f.td_logs + 2, mb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+}
+
+// thread 0 of every workgroup, AFTER it has issued its last cross-workgroup store: true for the last arriver
+__device__ __forceinline__ bool log_fold_arrive(const LogFoldArgs &f, unsigned total) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's stores have left the CU (write-through) ...
+    const unsigned ticket = __hip_atomic_fetch_add(f.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ticket == total - 1;                        // ... before the ticket can be seen
+}
+
+// wave 0 (all 64 lanes) of the last workgroup
+__device__ __forceinline__ void log_fold_finish(const LogFoldArgs &f) {
+    const int lane = threadIdx.x & 63;
+    float sl = 0.f, se = 0.f, ss = 0.f;
+    for (int i = lane; i < f.n_nets; i += 64) {
+        sl += __hip_atomic_load(f.partials + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i == f.n_nets - 1) se = __hip_atomic_load(f.partials + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int i = lane; i < f.n_ss; i += 64) ss += __hip_atomic_load(f.sumsq + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sl += __shfl_xor(sl, o, 64); se += __shfl_xor(se, o, 64); ss += __shfl_xor(ss, o, 64);
+    }
+    float td0 = 0.f, td1 = 0.f, td2 = 0.f;
+    if (f.td_logs) {
+        td0 = __hip_atomic_load(f.td_logs + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        td1 = __hip_atomic_load(f.td_logs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        td2 = __hip_atomic_load(f.td_logs + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the log block was cleared at the start of this update (another launch): [0] accumulates over ensemble members
+    const float l0 = f.logs[0] + sl / (f.denom * (float)f.n_rows), l1 = se / (float)f.n_rows, l2 = sqrtf(ss);
+    if (lane == 0) { f.logs[0] = l0; f.logs[1] = l1; f.logs[2] = l2; }
+    if (f.feed) {  // publish the block to its ring slot, advance the input ring
+        const int slot = (int)f.feed->dst[f.feed->log_slot_word], w = f.feed->log_width;
+        const int tdo = f.td_logs ? (int)(f.td_logs - f.logs) : -1;
+        for (int i = lane; i < w; i += 64) {
+            float v = i == 0 ? l0 : i == 1 ? l1 : i == 2 ? l2 : f.logs[i];
+            if (tdo >= 0 && i >= tdo && i < tdo + 3) v = i == tdo ? td0 : (i == tdo + 1 ? td1 : td2);
+            f.feed->log_ring[(int64_t)slot * w + i] = v;
+        }
+        if (lane == 0) f.feed->tick += 1;
+    }
+    if (lane == 0) __hip_atomic_store(f.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Deferred log finalisation of a RECORDED update (ssac_deferred_logs in include/ssac_hip.h): nothing of update k's log
+// block depends on update k+1, but finishing it inside update k costs a dependent chain of memory round trips behind
+// the LAST weight-gradient workgroup (5 us as a launch of its own, the same again as a last-arriver epilogue).  So the
+// weight-gradient launch only leaves the inputs behind -- per-net loss partials, gradient-norm partials, the three TD
+// statistics -- and advances the input ring; ONE extra workgroup of the NEXT update's first launch (beside ~220 busy
+// ones, off every critical path) sums them in index order and writes update k's slot of the log ring.  Reading a log
+// value of the newest update before another update has been issued launches ssac_deferred_logs_flush (the same body).
+// ------------------------------------------------------------------------------------------------------------
+struct DeferredLogsArgs {
+    const float *partials; int n_nets;      // [n_nets][2]: sum_b w err^2, sum_b err  (loss_fold_table)
+    const float *sumsq; int n_ss;           // gradient-norm partials of the weight-gradient launch
+    const float *td_stats;                  // [3] mean / std / entropy bonus of the TD targets, or null
+    int td_off, n_rows; float denom;        // td_off: index of the 3 TD statistics inside a log block
+    const ssac_feed *feed;                  // the log ring + the input ring (which ring slot update k's block goes to)
+};
+
+// first wave of the calling workgroup.  ring_slot < 0: the update BEFORE the one this launch belongs to (its log-ring
+// slot is read from its slot of the input ring); >= 0: that slot (flush).
+__device__ __forceinline__ void deferred_logs_body(const DeferredLogsArgs &d, int ring_slot) {
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    const ssac_feed f = *d.feed;
+    int slot = ring_slot;
+    if (slot < 0) {
+        if (f.tick <= 0) return;   // no recorded update has run yet
+        const uint32_t *prev = f.host_ring + (int64_t)((f.tick - 1) % f.n_slots) * f.slot_words;
+        slot = (int)prev[f.log_slot_word];
+    }
+    float sl = 0.f, se = 0.f, ss = 0.f;
+    for (int i = lane; i < d.n_nets; i += 64) {
+        sl += d.partials[2 * i];
+        if (i == d.n_nets - 1) se = d.partials[2 * i + 1];
+    }
+    for (int i = lane; i < d.n_ss; i += 64) ss += d.sumsq[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sl += __shfl_xor(sl, o, 64); se += __shfl_xor(se, o, 64); ss += __shfl_xor(ss, o, 64);
+    }
+    const float l0 = sl / (d.denom * (float)d.n_rows), l1 = se / (float)d.n_rows, l2 = sqrtf(ss);
+    float *dst = f.log_ring + (int64_t)slot * f.log_width;
+    for (int i = lane; i < f.log_width; i += 64) {
+        float v = i == 0 ? l0 : i == 1 ? l1 : i == 2 ? l2 : 0.0f;
+        if (d.td_stats && i >= d.td_off && i < d.td_off + 3) v = d.td_stats[i - d.td_off];
+        dst[i] = v;
     }
 }

@@ -948,18 +948,25 @@ void fused_dual2_kernel(FusedArgs gt, FusedArgs gc, int tiles_t, int target_grid
 template <int TC, bool ADBUF>
 __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs gc, int tiles_t, int target_grid_x,
-                        int critic_grid_x) {
+                        int critic_grid_x, DeferredLogsArgs dl, int dl_on) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
+    if (dl_on && bid == (int)gridDim.x - 1) {
+        // one extra workgroup: the PREVIOUS recorded update's log block -> its slot of the log ring (ssac_critic_logs.h)
+        deferred_logs_body(dl, -1);
+        return;
+    }
     if (bid < tiles_t) {
         const int j = bid / target_grid_x, bx = bid - j * target_grid_x;
         if (j == 0) fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga, smem, bx, 0, target_grid_x);
-        else fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga_rest, smem, bx, 0, target_grid_x);
+        else { ga_rest.dbg = nullptr; fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga_rest, smem, bx, 0, target_grid_x); }
         __threadfence_block();  // this workgroup's a' rows (global) are read back by its own target-critic pass
         __syncthreads();
+        if (gt.dbg) gt.dbg += 16;  // (phase stamps of the target-critic pass: slots 16.., slot-0 chain only)
         fused_mlp_body<MODE_PLAIN, 16, true>(gt, smem, bx, j, target_grid_x);
     } else {
         const int L = bid - tiles_t;
+        if (gc.dbg) gc.dbg += 32;  // (phase stamps of the critic workgroup: slots 32..)
         fused_mlp_body<MODE_CRITIC_U, TC, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x);
     }
 }
@@ -1650,7 +1657,7 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
                                  float *logp, const ssac_rng *rng, const ssac_mlp *targets, const int32_t *net_ids,
                                  int n_sel, float *Qt, const ssac_mlp *critics, const float *Xc, int64_t ldxc,
                                  float *H1, float *H2, float *Q, float *DZ2u, float *DZ1u,
-                                 const ssac_gather *gather, void *stream) {
+                                 const ssac_gather *gather, const ssac_deferred_logs *deferred, void *stream) {
     if (!eps && !rng) return ssac_fail("ssac_chain_update: neither eps nor an rng stream given");
     if (!fused_ok(actor) || (actor->out_dim & 1) || !fused_dbuf_ok(targets) || !fused_dbuf_ok(critics))
         return ssac_fail("ssac_chain_update: shape not supported by the merged launch");
@@ -1703,12 +1710,17 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
         attr_set = true;
     }
     const int tiles_t = tgx * n_sel;
-    const dim3 grid(tiles_t + cgx * critics->n_nets);
+    DeferredLogsArgs dl{};
+    const int dl_on = (deferred && deferred->feed) ? 1 : 0;
+    if (dl_on)
+        dl = DeferredLogsArgs{deferred->partials, deferred->n_nets, deferred->sumsq, deferred->n_ss, deferred->td_stats,
+                              deferred->td_off, deferred->n_rows, deferred->denom, deferred->feed};
+    const dim3 grid(tiles_t + cgx * critics->n_nets + dl_on);
     hipStream_t st = (hipStream_t)stream;
-    if (tc == 16 && adbuf) SSAC_LAUNCH((fused_chain_kernel<16, true>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx);
-    else if (adbuf) SSAC_LAUNCH((fused_chain_kernel<32, true>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx);
-    else if (tc == 16) SSAC_LAUNCH((fused_chain_kernel<16, false>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx);
-    else SSAC_LAUNCH((fused_chain_kernel<32, false>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx);
+    if (tc == 16 && adbuf) SSAC_LAUNCH((fused_chain_kernel<16, true>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx, dl, dl_on);
+    else if (adbuf) SSAC_LAUNCH((fused_chain_kernel<32, true>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx, dl, dl_on);
+    else if (tc == 16) SSAC_LAUNCH((fused_chain_kernel<16, false>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx, dl, dl_on);
+    else SSAC_LAUNCH((fused_chain_kernel<32, false>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx, dl, dl_on);
     return ssac_check_launch("fused_chain");
 }
 
@@ -1783,6 +1795,17 @@ extern "C" int ssac_head_wgrad(const ssac_mlp *nets, const int32_t *net_ids, int
 }
 
 extern "C" int ssac_head_wgrad_tiles(const ssac_mlp *nets) { return nets ? (nets->hidden + 63) / 64 : -1; }
+
+namespace {
+__global__ __launch_bounds__(64) void deferred_logs_kernel(DeferredLogsArgs d, int ring_slot) { deferred_logs_body(d, ring_slot); }
+}  // namespace
+
+extern "C" int ssac_deferred_logs_flush(const ssac_deferred_logs *d, int ring_slot, void *stream) {
+    if (!d || !d->feed || !d->partials || ring_slot < 0) return ssac_fail("ssac_deferred_logs_flush: bad arguments");
+    DeferredLogsArgs dl{d->partials, d->n_nets, d->sumsq, d->n_ss, d->td_stats, d->td_off, d->n_rows, d->denom, d->feed};
+    SSAC_LAUNCH(deferred_logs_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dl, ring_slot);
+    return ssac_check_launch("deferred_logs");
+}
 
 extern "C" int ssac_critic_logs(const float *partials, int n_nets, int tiles, int n_rows, float denom,
                                 const float *sumsq, int n_sumsq, const ssac_adam_ctl *scale_by_clip,

@@ -186,9 +186,12 @@ struct NoPre { __device__ __forceinline__ void operator()() const {} };
 
 // late_rs / pre: the merged weight-gradient launch with the loss gradient folded in (loss_fold_table) -- `pre` runs
 // after the first operand loads have been issued and fills the LDS table `late_rs` of per-row scales (and syncs).
+// fold / last: the update's logs are folded into this launch (LogFoldArgs): thread 0 draws the arrival ticket right after
+// the workgroup's gradient-norm partial is stored -- BEFORE the optimizer stores, whose drain it must not wait for --
+// and reports through *last whether this workgroup arrived last.
 template <bool A_KC, bool B_KC, int EPI, int KS, class Pre = NoPre>
 __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int bx, int by, int bz,
-                                              const float *late_rs = nullptr, Pre pre = Pre()) {
+                                              const float *late_rs, Pre pre, const LogFoldArgs &fold, int &last) {
     const int tid_all = threadIdx.x;
     const int kg = tid_all >> 8, tid = tid_all & 255;
     // per K-group: two staging buffers (double buffering), each [A tile | B tile]
@@ -344,10 +347,40 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
                 tv[j] = g.tw ? g.tw[a] : 0.0f;
             }
         }
+        // the bias gradient of this tile's rows and its optimizer state (threads < 64 of n-tile 0)
+        const int gm = m0 + tid_all;
+        const bool bias_thr = want_bias_grad && tid_all < 64 && gm < g.M;
+        const int64_t bi = (EPI == EPI_GRAD && g.sGb) ? (int64_t)e * g.sGb + gm : coff + gm;
+        float bsum = 0.0f, bpv = 0.0f, bmv = 0.0f, bvv = 0.0f, btv = 0.0f;
+        if (bias_thr) {
+            bsum = red[tid_all];
+#pragma unroll
+            for (int gq = 1; gq < KS; ++gq) bsum += red[gq * 64 + tid_all];
+            if (EPI == EPI_ADAM) { bpv = g.pb[bi]; bmv = g.bm[bi]; bvv = g.bv[bi]; btv = g.tb ? g.tb[bi] : 0.0f; }
+        }
+        // ---- gradient-norm partial FIRST (it needs the gradients only), so that with the logs folded in the arrival
+        //      ticket is drawn before -- not behind -- the optimizer stores
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (ok[j]) ss += gval[j] * gval[j];
+        if (bias_thr) ss += bsum * bsum;
+        if (g.sumsq) {
+            ss = wave_sum(ss);
+            __syncthreads();  // red[] (bias partials) has been consumed
+            if (lane == 0) red[tid_all >> 6] = ss;
+            __syncthreads();
+            if (tid_all == 0) {
+                float tot = 0.0f;
+                for (int w = 0; w < 4 * KS; ++w) tot += red[w];
+                // (agent scope: with the logs folded into the launch the reader is a workgroup on another XCD)
+                __hip_atomic_store(g.sumsq + (int64_t)e * g.sumsq_stride + by * g.grid_x + bx, tot, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                if (fold.done) last = log_fold_arrive(fold, gridDim.x) ? 1 : 0;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             if (!ok[j]) continue;
-            ss += gval[j] * gval[j];
             if (EPI == EPI_GRAD) {
                 g.gw[ci[j]] = gval[j];
             } else {
@@ -359,38 +392,19 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
                 if (g.tw) g.tw[ci[j]] = tv[j] * (1.0f - g.tau) + pn * g.tau;
             }
         }
-        if (want_bias_grad && tid_all < 64) {
-            const int gm = m0 + tid_all;
-            if (gm < g.M) {
-                float bsum = red[tid_all];
-#pragma unroll
-                for (int gq = 1; gq < KS; ++gq) bsum += red[gq * 64 + tid_all];
-                const int64_t bi = (EPI == EPI_GRAD && g.sGb) ? (int64_t)e * g.sGb + gm : coff + gm;
-                ss += bsum * bsum;
-                if (EPI == EPI_GRAD) {
-                    g.gb[bi] = bsum;
-                } else {
-                    float m = g.bm[bi], v = g.bv[bi];
-                    const float pn = adam_elem(g.pb[bi], bsum, m, v, ctl);
-                    g.bm[bi] = m;
-                    g.bv[bi] = v;
-                    g.pb[bi] = pn;
-                    if (g.tb) g.tb[bi] = g.tb[bi] * (1.0f - g.tau) + pn * g.tau;
-                }
+        if (bias_thr) {
+            if (EPI == EPI_GRAD) {
+                g.gb[bi] = bsum;
+            } else {
+                float m = bmv, v = bvv;
+                const float pn = adam_elem(bpv, bsum, m, v, ctl);
+                g.bm[bi] = m;
+                g.bv[bi] = v;
+                g.pb[bi] = pn;
+                if (g.tb) g.tb[bi] = btv * (1.0f - g.tau) + pn * g.tau;
             }
         }
         GSTAMP(4);
-        if (g.sumsq) {
-            ss = wave_sum(ss);
-            __syncthreads();  // red[] (bias partials) has been consumed
-            if (lane == 0) red[tid_all >> 6] = ss;
-            __syncthreads();
-            if (tid_all == 0) {
-                float tot = 0.0f;
-                for (int w = 0; w < 4 * KS; ++w) tot += red[w];
-                g.sumsq[(int64_t)e * g.sumsq_stride + by * g.grid_x + bx] = tot;
-            }
-        }
         return;
     }
 
@@ -448,7 +462,8 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
     const int per = gridDim.x * gridDim.y;
     const int L = ssac_xcd_contiguous(blockIdx.z * per + blockIdx.y * gridDim.x + blockIdx.x, per * gridDim.z, g.xcd);
     const int bz = L / per, rem = L - bz * per;
-    ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % gridDim.x, rem / gridDim.x, bz);
+    int last = 0;
+    ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % gridDim.x, rem / gridDim.x, bz, nullptr, NoPre(), LogFoldArgs{}, last);
 }
 
 // Two problems in ONE launch (the fc2 and fc1 weight gradients of an update): workgroups
@@ -457,9 +472,9 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
 // And optionally the update's log finalisation, run by whichever workgroup finishes LAST (device counter).
 struct GemmPair {
     GemmArgs g0, g1; int tiles0; int tiles01; int head_grid_x; HeadWgradArgs head;
-    unsigned *done; CriticLogsArgs logs;  // done != null: the last workgroup runs critic_logs_body(logs)
     int xcd;                              // XCD-contiguous tile order (ssac_internal.h)
     LossFoldArgs lf;                      // lf.q != null: dL/dq evaluated per workgroup (ssac_critic_logs.h)
+    LogFoldArgs fold;                     // fold.done != null: the update's logs are finalised by the last workgroup
 };
 
 template <bool A_KC, bool B_KC, int EPI, int KS>
@@ -468,6 +483,8 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
     const int bid = ssac_xcd_contiguous(blockIdx.x, gridDim.x, p.xcd);
     float *tab = lds + KS * (4 * TILE_FLOATS) + 64 * KS;  // folded loss gradient: [n_rows] row scales, then scratch
     const bool fold = p.lf.q != nullptr;
+    int last = 0;
+    bool drawn = false;
     if (bid >= p.tiles01) {  // head-layer weight gradient + Adam beside the GEMM tiles
         const int L = bid - p.tiles01;
         const int e = L / p.head_grid_x;
@@ -485,30 +502,33 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
         auto pre = [&]() {
             if (fold) {  // the first fc2 tile of each net also reduces that net's loss terms
                 loss_fold_table(p.lf, bz, tab, first && rem == 0, tab + p.lf.n_rows);
+                // ... and net slot 0's, which evaluated and wrote the TD targets, their statistics (folded logs)
+                if (((p.fold.done && p.fold.td_logs) || p.fold.deferred_stats) && first && rem == 0 && bz == 0)
+                    log_fold_td_stats(p.fold, p.lf.tds, tab + p.lf.n_rows);
                 __syncthreads();
             }
         };
-        ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % g.grid_x, rem / g.grid_x, bz, fold ? tab : nullptr, pre);
+        ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % g.grid_x, rem / g.grid_x, bz, fold ? tab : nullptr, pre,
+                                           p.fold, last);
+        drawn = true;
     }
-    if (p.done) {
-        // the workgroup that finishes last sees every other one's gradient-norm partials and finalises the logs
-        __shared__ int is_last;
-        __threadfence();
+    if (p.fold.done) {
+        // thread 0 drew the arrival ticket right after storing the workgroup's gradient-norm partial (the GEMM tiles
+        // inside their epilogue, ahead of the optimizer stores); the wave of the last arriver finalises the logs
+        float *flag = lds + KS * (4 * TILE_FLOATS);   // (the bias / sumsq scratch: consumed by now)
         __syncthreads();
-        if (threadIdx.x == 0) is_last = (atomicAdd(p.done, 1u) == gridDim.x - 1) ? 1 : 0;
+        if (threadIdx.x == 0) flag[0] = (drawn ? last != 0 : log_fold_arrive(p.fold, gridDim.x)) ? 1.0f : 0.0f;
         __syncthreads();
-        if (is_last) {
-            if (threadIdx.x == 0) *p.done = 0;  // ready for the next launch
-            __threadfence();
-            critic_logs_body(p.logs, lds);
-        }
+        if (flag[0] != 0.0f && threadIdx.x < 64) log_fold_finish(p.fold);
+    } else if (p.fold.deferred_stats && p.fold.feed && blockIdx.x == 0 && threadIdx.x == 0) {
+        p.fold.feed->tick += 1;   // deferred finalisation: the update is over for the input ring (no reader in this launch)
     }
 }
 
 template <bool A_KC, bool B_KC, int EPI, int KS>
 int launch_pair_ks(GemmPair &p, int batch0, int batch1, hipStream_t st) {
     static bool attr_set = false;
-    const size_t lds = sizeof(float) * (KS * 4 * TILE_FLOATS + 64 * KS + (p.lf.q ? p.lf.n_rows + 8 * KS : 0));
+    const size_t lds = sizeof(float) * (KS * 4 * TILE_FLOATS + 64 * KS + (p.lf.q ? p.lf.n_rows + 16 * KS : 0));
     constexpr int PAIR_LDS_MAX = 160 * 1024 - 256;  // the kernel also has a few bytes of static LDS
     if (lds > PAIR_LDS_MAX) return ssac_fail("ens_gemm_pair: the folded loss table does not fit LDS");
     if (!attr_set) {
@@ -657,8 +677,8 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                         const float *H2, const float *DQ, int n_rows, float *adam_m, float *adam_v,
                         const ssac_adam_ctl *ctl, float *grads, float *sumsq1, float *sumsq0, float *sumsq2,
                         int64_t sumsq_net_stride, float *target, float tau, void *stream,
-                        const CriticLogsArgs *logs = nullptr, unsigned *done = nullptr,
-                        const float *rowscale = nullptr, const LossFoldArgs *lossfold = nullptr);
+                        const float *rowscale = nullptr, const LossFoldArgs *lossfold = nullptr,
+                        const ssac_logfold *logfold = nullptr);
 
 extern "C" int ssac_mlp_wgrad_all_scaled(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
                                          int64_t ldx, int64_t x_net_stride, const float *H1, const float *H2,
@@ -670,8 +690,7 @@ extern "C" int ssac_mlp_wgrad_all_scaled(const ssac_mlp *nets, const int32_t *ne
     if (!H2 || !row_scale) return ssac_fail("ssac_mlp_wgrad_all_scaled: H2 / row_scale missing");
     // out_dim == 1: the per-row scale IS the head's output gradient dq (n_sel x n_rows x 1)
     return wgrad_merged(nets, net_ids, n_sel, X, ldx, x_net_stride, H1, DZ2u, DZ1u, H2, row_scale, n_rows, adam_m,
-                        adam_v, ctl, grads, sumsq1, sumsq0, sumsq2, sumsq_net_stride, target, tau, stream, nullptr,
-                        nullptr, row_scale);
+                        adam_v, ctl, grads, sumsq1, sumsq0, sumsq2, sumsq_net_stride, target, tau, stream, row_scale);
 }
 
 extern "C" int ssac_mlp_wgrad_all_lossfold(const ssac_mlp *nets, const float *X, int64_t ldx, int64_t x_net_stride,
@@ -681,7 +700,7 @@ extern "C" int ssac_mlp_wgrad_all_lossfold(const ssac_mlp *nets, const float *X,
                                            float *partials, int n_rows, float *adam_m, float *adam_v,
                                            const ssac_adam_ctl *ctl, float *grads, float *sumsq2, float *sumsq1,
                                            float *sumsq0, int64_t sumsq_net_stride, float *target, float tau,
-                                           void *stream) {
+                                           const ssac_logfold *logfold, void *stream) {
     if (!nets || nets->out_dim != 1) return ssac_fail("ssac_mlp_wgrad_all_lossfold: single-output heads only");
     if (!H2 || !Q || !partials || (!td && !lazy_td)) return ssac_fail("ssac_mlp_wgrad_all_lossfold: missing argument");
     if (n_rows > 4096) return ssac_fail("ssac_mlp_wgrad_all_lossfold: more than 4096 rows (use ssac_critic_loss_bwd)");
@@ -689,26 +708,8 @@ extern "C" int ssac_mlp_wgrad_all_lossfold(const ssac_mlp *nets, const float *X,
     lf.q = Q; lf.td = td; if (lazy_td) lf.tds = *lazy_td;
     lf.weight = weight; lf.popart = popart; lf.pop = pop; lf.denom = denom; lf.partials = partials; lf.n_rows = n_rows;
     return wgrad_merged(nets, nullptr, nets->n_nets, X, ldx, x_net_stride, H1, DZ2u, DZ1u, H2, Q, n_rows, adam_m,
-                        adam_v, ctl, grads, sumsq1, sumsq0, sumsq2, sumsq_net_stride, target, tau, stream, nullptr,
-                        nullptr, nullptr, &lf);
-}
-
-extern "C" int ssac_mlp_wgrad_all_logs(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
-                                       int64_t ldx, int64_t x_net_stride, const float *H1, const float *H2,
-                                       const float *DZ2, const float *DZ1, const float *DQ, int n_rows,
-                                       float *adam_m, float *adam_v, const ssac_adam_ctl *ctl, float *sumsq2,
-                                       float *sumsq1, float *sumsq0, int64_t sumsq_net_stride, float *target,
-                                       float tau, const float *partials, int tiles, float denom,
-                                       const float *sumsq_all, int n_sumsq, float *logs,
-                                       const ssac_td_spec *lazy_td, float *td_logs, ssac_feed *feed,
-                                       unsigned *done_counter, void *stream) {
-    if (!nets || nets->out_dim > 16) return ssac_fail("ssac_mlp_wgrad_all_logs: head wider than 16 outputs");
-    if (!H2 || !DQ || !partials || !logs || !done_counter)
-        return ssac_fail("ssac_mlp_wgrad_all_logs: missing argument");
-    CriticLogsArgs la{partials, n_sel, tiles, n_rows, denom, sumsq_all, n_sumsq, nullptr, logs, {}, td_logs, feed};
-    if (lazy_td) la.tds = *lazy_td;
-    return wgrad_merged(nets, net_ids, n_sel, X, ldx, x_net_stride, H1, DZ2, DZ1, H2, DQ, n_rows, adam_m, adam_v, ctl,
-                        nullptr, sumsq1, sumsq0, sumsq2, sumsq_net_stride, target, tau, stream, &la, done_counter);
+                        adam_v, ctl, grads, sumsq1, sumsq0, sumsq2, sumsq_net_stride, target, tau, stream, nullptr, &lf,
+                        logfold);
 }
 
 extern "C" int ssac_mlp_wgrad_fc12(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
@@ -737,8 +738,7 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                         const float *H2, const float *DQ, int n_rows, float *adam_m, float *adam_v,
                         const ssac_adam_ctl *ctl, float *grads, float *sumsq1, float *sumsq0, float *sumsq2,
                         int64_t sumsq_net_stride, float *target, float tau, void *stream,
-                        const CriticLogsArgs *logs, unsigned *done, const float *rowscale,
-                        const LossFoldArgs *lossfold) {
+                        const float *rowscale, const LossFoldArgs *lossfold, const ssac_logfold *logfold) {
     if (n_sel < 0 || n_sel > SSAC_MAX_NETS) return ssac_fail("ssac_mlp_wgrad_fc12: n_sel out of range");
     if (!grads && (!adam_m || !adam_v || !ctl)) return ssac_fail("ssac_mlp_wgrad_fc12: Adam state missing");
     if (n_sel == 0 || n_rows <= 0) return 0;
@@ -751,7 +751,6 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                                DQ, n_rows, adam_m, adam_v, ctl, grads, sumsq2, sumsq_net_stride, target, tau};
         p.head_grid_x = (nets->hidden + 63) / 64;
     }
-    if (logs) { p.logs = *logs; p.done = done; }
     if (!build_wgrad_args(p.g0, nets, 1, net_ids, H1, H, (int64_t)n_rows * H, DZ2, H, (int64_t)n_rows * H, n_rows,
                           adam_m, adam_v, ctl, grads, sumsq1, sumsq_net_stride, target, tau) ||
         !build_wgrad_args(p.g1, nets, 0, net_ids, X, ldx, x_net_stride, DZ1, H, (int64_t)n_rows * H, n_rows,
@@ -759,6 +758,24 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
         return ssac_fail("ssac_mlp_wgrad_fc12: bad arena");
     if (rowscale) { p.g0.rowscale = p.g1.rowscale = rowscale; p.g0.sRow = p.g1.sRow = n_rows; }
     if (lossfold) p.lf = *lossfold;
+    if (logfold && logfold->done_counter) {
+        if (!lossfold || grads || !sumsq0 || !sumsq1 || !sumsq2 || net_ids)
+            return ssac_fail("ssac_mlp_wgrad_all_lossfold: the folded logs need the loss fold, Adam mode and sumsq slots");
+        // the gradient-norm partials of the launch: n_sel rows of sumsq_net_stride slots starting at the lowest pointer
+        const float *ss_base = sumsq0 < sumsq1 ? sumsq0 : sumsq1;
+        if (sumsq2 < ss_base) ss_base = sumsq2;
+        p.fold = LogFoldArgs{logfold->done_counter, logfold->logs, lossfold->tds.q_t ? logfold->td_logs : nullptr,
+                             logfold->feed, nullptr, lossfold->partials, n_sel, ss_base,
+                             (int)(n_sel * sumsq_net_stride), n_rows, lossfold->denom};
+    } else if (logfold && logfold->deferred_stats) {
+        if (!lossfold || grads || !logfold->feed)
+            return ssac_fail("ssac_mlp_wgrad_all_lossfold: deferred logs need the loss fold, Adam mode and a feed");
+        p.fold = LogFoldArgs{};
+        p.fold.feed = logfold->feed;
+        p.fold.deferred_stats = lossfold->tds.q_t ? logfold->deferred_stats : nullptr;
+        p.fold.n_rows = n_rows;
+        if (!p.fold.deferred_stats) return ssac_fail("ssac_mlp_wgrad_all_lossfold: deferred logs need the in-launch TD target");
+    }
     hipStream_t st = (hipStream_t)stream;
     const int tiles = (p.g0.grid_x * p.g0.grid_y + p.g1.grid_x * p.g1.grid_y) * n_sel;
     const int nchunks = (n_rows + BK - 1) / BK;

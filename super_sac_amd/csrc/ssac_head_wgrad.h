@@ -89,6 +89,6 @@ __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *l
     if (a.sumsq && mg == 0) {  // wave 0 holds every contribution
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        if (kk == 0) a.sumsq[(int64_t)e * a.sumsq_stride + bx] = ss;
+        if (kk == 0) __hip_atomic_store(a.sumsq + (int64_t)e * a.sumsq_stride + bx, ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

@@ -40,6 +40,9 @@ class CaptureCtx:
         self.tick_ptr = 0         # device address of the update counter (ssac_feed.tick), for in-kernel noise
         self.noise_offset = 0     # draw number of this agent's noise stream at capture time
         self.collective = None    # callable(fn): ends the open recording, runs fn() now, opens the next segment
+        self.deferred = None      # ssac_deferred_logs of this recorded update (deferred log finalisation), or None
+        self.deferred_chain = False  # the chained launch was issued with the finishing workgroup
+        self.deferred_used = False   # ... and the weight-gradient launch left the partials for it
         self.defer_begin = False  # the replay gather will also do ssac_begin_update's work (vector buffers)
         self.pending_begin = None # (log block, adam ctl ptr) waiting for that gather
 
@@ -414,8 +417,9 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
             C.byref(d), arena.shadow.data_ptr(), bf["xt"].data_ptr(), bf["h1t"].data_ptr(), bf["h2t"].data_ptr(),
             bf["dz2t"].data_ptr(), bf["dz1t"].data_ptr(), f["q"].data_ptr(), f["td_ptr"], f["spec_ptr"], f["weight_ptr"],
             float(f["denom"]), f["partials"].data_ptr(), n_rows, m.data_ptr(), v.data_ptr(), ctl, _ptr(sumsq),
-            bf16_tiles_total(arena), _ptr(target), _ptr(tsh), float(tau), st))
-        return
+            bf16_tiles_total(arena), _ptr(target), _ptr(tsh), float(tau),
+            C.byref(f["logfold"]) if f.get("logfold") is not None else 0, st))
+        return f.get("logfold") is not None
     if lossfold is not None:
         # UNSCALED backward, and the loss gradient dL/dq itself is evaluated inside the launch (per workgroup, in LDS)
         assert O == 1 and net_ids is None and n_sel == arena.n_nets
@@ -424,8 +428,8 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
             C.byref(d), X.data_ptr(), ldx, x_net_stride, h1.data_ptr(), h2.data_ptr(), dz2.data_ptr(), dz1.data_ptr(),
             f["q"].data_ptr(), f["td_ptr"], f["spec_ptr"], f["weight_ptr"], f["popart_ptr"], f["pop"],
             float(f["denom"]), f["partials"].data_ptr(), n_rows, _ptr(m), _ptr(v), ctl, _ptr(grads), ssp(2), ssp(1),
-            ssp(0), ttot, _ptr(target), float(tau), st))
-        return
+            ssp(0), ttot, _ptr(target), float(tau), C.byref(f["logfold"]) if f.get("logfold") is not None else 0, st))
+        return f.get("logfold") is not None
     if rowscale is not None:
         # UNSCALED backward (ssac_target_fwd_critic_bwdu): dL/dq of every (net, row) scales the rows while they load
         assert O == 1
@@ -434,14 +438,6 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
                                             _ptr(m), _ptr(v), ctl, _ptr(grads), ssp(2), ssp(1), ssp(0), ttot,
                                             _ptr(target), float(tau), st))
         return
-    if O <= 16 and MERGE_HEAD_WGRAD and logs is not None and grads is None and sumsq is not None:
-        check(lib.ssac_mlp_wgrad_all_logs(
-            C.byref(d), ids, n_sel, X.data_ptr(), ldx, x_net_stride, h1.data_ptr(), h2.data_ptr(), dz2.data_ptr(),
-            dz1.data_ptr(), dY.data_ptr(), n_rows, _ptr(m), _ptr(v), ctl, ssp(2), ssp(1), ssp(0), ttot, _ptr(target),
-            float(tau), logs["partials"].data_ptr(), logs["tiles"], float(logs["denom"]), sumsq.data_ptr(),
-            sumsq.numel(), logs["logs"].data_ptr(), logs["spec_ptr"], logs["td_logs_ptr"], logs["feed"],
-            logs["done"].data_ptr(), st))
-        return True
     if O <= 16 and MERGE_HEAD_WGRAD:
         # head (VALU), fc2 and fc1 weight gradients of every selected net: ONE launch
         check(lib.ssac_mlp_wgrad_all(C.byref(d), ids, n_sel, X.data_ptr(), ldx, x_net_stride, h1.data_ptr(),

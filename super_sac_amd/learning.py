@@ -74,10 +74,10 @@ FEED_SLOTS = 32  # pinned input ring of a captured update: how far the host may 
 # evaluate the TD target inside the critic launch instead of a launch of its own (continuous, no PopArt)
 SHARDED_LISTS = os.environ.get("SSAC_SHARDED_LISTS", "1") == "1"  # recorded launch lists on critic-sharded ranks
 FOLD_BEGIN = os.environ.get("SSAC_FOLD_BEGIN", "1") == "1"  # fold ssac_begin_update into the replay gather
-# Log finalisation inside the weight-gradient launch (its last workgroup to finish does it).  Off by default: the
-# device-scope fences the last-workgroup pattern needs write back / invalidate the per-XCD L2s on MI355X, and with
-# 17 MB of freshly written Adam state per launch that halves the update rate (4.8k vs 8.5k updates/s, measured).
-FOLD_LOGS = os.environ.get("SSAC_FOLD_LOGS", "0") == "1"
+# Log finalisation inside the weight-gradient launch: the last workgroup to ARRIVE (a device-scope ticket drawn after
+# its write-through partial stores -- no fence, so none of the 17 MB of freshly written Adam state is flushed) sums the
+# partials and publishes the log block; the separate 1-workgroup logs launch (~5 us per update) disappears.
+FOLD_LOGS = os.environ.get("SSAC_FOLD_LOGS", "1") == "1"
 LAZY_TD = os.environ.get("SSAC_LAZY_TD", "1") == "1"
 SPLIT_FORWARD = os.environ.get("SSAC_SPLIT_FORWARD", "0") == "1"
 
@@ -139,6 +139,20 @@ class _Graphed:
         self.graph = None
         self.fast = None
         self.path = "slow"
+        self.deferred = None   # ssac_deferred_logs of the recording (deferred log finalisation), else None
+        self.pending = None    # log-ring slot of the newest update whose block has not been written yet
+
+    def views(self, ring, slot_i):
+        """log values of ring slot slot_i (built once per slot)"""
+        v = self.log_views.get(slot_i)
+        if v is None:
+            if self.deferred is not None:
+                v = lu.lazy_views(self, ring, slot_i, self.log_index)
+            else:
+                blk = ring.buf[slot_i]
+                v = {k_: blk[i] for k_, i in self.log_index.items()}
+            self.log_views[slot_i] = v
+        return v
 
 
 def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimizer, log_alphas,
@@ -281,11 +295,10 @@ class _FastStep:
             ns[1] += 1
         check(lib.ssac_step_run(self.handle, idx_cpu.data_ptr(), ida, slot_i, draw, engine.stream()))
         gs.k += 1
+        if gs.deferred is not None:
+            gs.pending = slot_i   # (the previous update's block is written by the launch just issued)
         rng.choice(agent.critics)  # keep the Python RNG stream in step with learning.py:135
-        logs = gs.log_views.get(slot_i)
-        if logs is None:
-            slot = self.ring.buf[slot_i]
-            logs = gs.log_views[slot_i] = {k_: slot[i] for k_, i in gs.log_index.items()}
+        logs = gs.views(self.ring, slot_i)
         rd = gs.dicts[0]
         rd["priority_idxs"] = idx_cpu.numpy()
         rd["_subset"] = ids
@@ -398,10 +411,27 @@ def _critic_update_graphed(gs, kw):
         # over ssac_begin_update's work (ensemble_size 1: a single gather per update)
         ctx.defer_begin = (FOLD_BEGIN and agent.ensemble_size == 1 and len(keys_) == 1
                            and st_.s_stack[keys_[0]].dim() == 2)
+        c_arena_ = agent.critics[0].arena(dev)
+        if (lu.DEFERRED_LOGS and LAUNCH_MODE == "list" and FOLD_LOGS and FOLD_LOSS and LAZY_TD and ctx.defer_begin
+                and not kw["critic_clip"] and kind == "stochastic" and not any(agent.popart) and c_arena_.out_dim == 1
+                and B <= 4096):
+            # deferred log finalisation (csrc/ssac_critic_logs.h): the buffers the weight-gradient launch will leave
+            # its partials in are workspace tensors with fixed names, so the struct can be built before the body runs
+            ws_ = lu.agent_ws(agent, dev)
+            N_ = c_arena_.n_nets
+            ttot_ = (engine.bf16_tiles_total(c_arena_) if c_arena_.shadow is not None
+                     else engine.wgrad_tiles_total(c_arena_))
+            n_glob_ = N_ if shard is None else shard.num_critics
+            gs.td_stats = ws_.get("cu.tdstats", (4,), zero=True)
+            ctx.deferred = _lib.DeferredLogs(
+                ws_.get("cu.c0.fparts", (N_ * 2,)).data_ptr(), N_, N_ * ttot_, ws_.get("cu.ss0", (N_ * ttot_,)).data_ptr(),
+                gs.td_stats.data_ptr(), lu.L_TD0, B, float(n_glob_), 0, gs.feed.ptr)
 
         def body():
             logs_, dicts_ = _critic_update_eager(**kw)
             assert not ctx.pending_begin, "deferred ssac_begin_update was never issued"
+            assert ctx.deferred_used == ctx.deferred_chain, "deferred log finalisation: chain / weight-gradient mismatch"
+            gs.deferred = ctx.deferred if ctx.deferred_used else None
             if not ctx.published:
                 check(lib.ssac_publish_logs(gs.logblk.data_ptr(), gs.feed.ptr, engine.stream()))
             return logs_, dicts_
@@ -434,9 +464,7 @@ def _critic_update_graphed(gs, kw):
         gs.graph, gs.dicts = graph, dicts
         base = gs.logblk.data_ptr()
         gs.log_index = {k_: (v.data_ptr() - base) // 4 for k_, v in logs.items()}
-        # the 0-dim views handed out as log values, for every slot of the ring, built once here
-        gs.log_views = {si: {k_: ring.buf[si][i] for k_, i in gs.log_index.items()}
-                        for si in range(ring.buf.shape[0])}
+        gs.log_views = {}   # the 0-dim views handed out as log values, built once per ring slot (gs.views)
     else:
         gs.graph.replay()  # ONE host call re-issues the whole update
     if gs.k % EVENT_EVERY == EVENT_EVERY - 1:
@@ -449,11 +477,9 @@ def _critic_update_graphed(gs, kw):
     if in_kernel_noise:
         lu.noise_stream(agent, dev)[1] += 1  # one draw of the agent's noise stream per update, as in eager launches
     rng.choice(agent.critics)  # keep the Python RNG stream in step with learning.py:135
-    logs = gs.log_views.get(slot_i)
-    if logs is None:  # 0-dim views of this ring slot, built once per slot
-        slot = ring.buf[slot_i]
-        logs = gs.log_views[slot_i] = {k_: slot[i] for k_, i in gs.log_index.items()}
-    logs = dict(logs)
+    if gs.deferred is not None:
+        gs.pending = slot_i
+    logs = dict(gs.views(ring, slot_i))
     rd = gs.dicts[0]
     rd["priority_idxs"] = idx_cpu.numpy()
     rd["_subset"] = ids
@@ -630,6 +656,18 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                                 partials=fparts)
                 if arena.shadow is not None:
                     lossfold["bf"] = arena.bf_buffers(ws, "cu", B)
+                cap = engine.CAPTURE
+                if cap is not None and cap.deferred is not None and cap.deferred_chain and spec is not None:
+                    cap.deferred_used = True
+                    # recorded update: the launch leaves partials + TD statistics behind and advances the input ring;
+                    # the next update's first launch (or a flush) writes the ring slot
+                    lossfold["logfold"] = _lib.LogFold(0, slot.data_ptr(), 0, cap.feed, cap.deferred.td_stats)
+                elif FOLD_LOGS and E == 1 and not critic_clip:
+                    # the log finalisation rides in the weight-gradient launch (its last workgroup to arrive): no logs launch
+                    lossfold["logfold"] = _lib.LogFold(
+                        ws.get("cu.done", (1,), dtype=torch.int32, zero=True).data_ptr(), slot.data_ptr(),
+                        td._ssac_logs.data_ptr() if spec is not None else 0,
+                        cap.feed if (cap is not None and cap.feed) else 0, 0)
             elif bwd_done:
                 # ... or a single-workgroup launch writes the N x B scalars for the weight-gradient launch to read
                 if spec is not None:
@@ -670,21 +708,12 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                 raise NotImplementedError(
                     "bf16 mode covers the chained critic update (one member, continuous single-output critics, "
                     "stochastic actor, identity encoder, uniform sampling, no PopArt / clipping / DR3)")
-            fold = None
-            if FOLD_LOGS and E == 1 and not critic_clip and shard is None:
-                # single member, no clipping: the weight-gradient launch's last workgroup finalises the logs
-                cap = engine.CAPTURE
-                fold = dict(partials=parts, tiles=tiles, denom=float(E * n_glob), logs=slot,
-                            spec_ptr=spec_ptr, td_logs_ptr=td._ssac_logs.data_ptr() if spec is not None else 0,
-                            feed=cap.feed if (cap is not None and cap.feed) else 0,
-                            done=ws.get("cu.done", (1,), dtype=torch.int32, zero=True))
             folded = engine.weight_grads(arena, X, ldx, 0, h1, h2, dq, dz2, dz1, B, adam=adam,
                                          adam_key=("critic", i), grads=grads, sumsq=ss,
-                                         logs=None if bwd_done else fold,
                                          rowscale=dq if (bwd_done and lossfold is None) else None, lossfold=lossfold)
             if folded:
                 logs_done_in_wgrad = True
-                if fold["feed"]:
+                if lossfold["logfold"].feed:
                     engine.CAPTURE.published = True
             if lossfold is not None:
                 fused_logs.append((lossfold["partials"], N, 1, B, n_glob, td))

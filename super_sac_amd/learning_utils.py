@@ -53,6 +53,45 @@ class LogRing:
 
 _rings = {}
 
+# Deferred log finalisation of recorded updates (csrc/ssac_critic_logs.h): the newest recorded update's log block is
+# written to its ring slot by the NEXT update's first launch -- or, when somebody looks at one of its values first, by a
+# flush launch.  `pending` = (log-ring slot, ssac_deferred_logs struct) of that newest update, per device ring.
+DEFERRED_LOGS = os.environ.get("SSAC_DEFERRED_LOGS", "1") == "1"
+
+
+def flush_pending_logs(owner):
+    """write the newest recorded update's log block to its ring slot now (owner: the recording's state object, which
+    carries `pending` = that update's log-ring slot, and `deferred` = its ssac_deferred_logs struct)"""
+    slot_i = owner.__dict__.get("pending")
+    if slot_i is not None:
+        owner.pending = None
+        check(lib.ssac_deferred_logs_flush(C.byref(owner.deferred), slot_i, engine.stream()))
+
+
+class LazyLog(torch.Tensor):
+    """a log value of a recorded update: a 0-dim view of its slot of the log ring that makes sure the slot has been
+    written before anything reads it (any torch operation on it, float(), .item(), ...)"""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        for a in args:
+            if isinstance(a, LazyLog):
+                owner = a.__dict__.get("_ssac_owner")
+                if owner is not None and owner.__dict__.get("pending") == a.__dict__.get("_ssac_slot"):
+                    flush_pending_logs(owner)
+        return super().__torch_function__(func, types, args, kwargs or {})
+
+
+def lazy_views(owner, ring, slot_i, index):
+    """{log key: LazyLog view} of ring slot slot_i"""
+    out = {}
+    blk = ring.buf[slot_i]
+    for k_, i in index.items():
+        v = blk[i].as_subclass(LazyLog)
+        v.__dict__["_ssac_owner"], v.__dict__["_ssac_slot"] = owner, slot_i
+        out[k_] = v
+    return out
+
 
 def draw_normal(shape, device):
     """action-noise draw site (honours an active graph capture)."""
@@ -557,6 +596,12 @@ def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict)
         ensure_gathered(bt)
     q1 = ws.get(tag + ".y", (n, B, 1))
     s1_rep = ch["s1_rep"]
+    cap = engine.CAPTURE
+    dl_ptr = 0
+    if cap is not None and cap.feed and cap.deferred is not None:
+        # recorded update: one extra workgroup of this launch writes the PREVIOUS update's log block to its ring slot
+        dl_ptr = C.addressof(cap.deferred)
+        cap.deferred_chain = True
     if c_arena.shadow is not None:
         # bf16-operand mode: the same launch on v_mfma_f32_32x32x16_bf16, fed from the arenas' bf16 shadows
         a_arena = ch["a_arena"]
@@ -571,7 +616,7 @@ def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict)
                     ch["logp"].data_ptr(), ch["rng_ptr"], C.byref(t_arena.desc()), t_arena.shadow.data_ptr(), ids_ptr, n,
                     q1.data_ptr(), C.byref(c_arena.desc()), c_arena.shadow.data_ptr(), Xc.data_ptr(), ldxc, qc.data_ptr(),
                     bf["h1t"].data_ptr(), bf["h2t"].data_ptr(), bf["dz2t"].data_ptr(), bf["dz1t"].data_ptr(),
-                    bf["xt"].data_ptr(), C.byref(gth) if gth is not None else 0, engine.stream()))
+                    bf["xt"].data_ptr(), C.byref(gth) if gth is not None else 0, dl_ptr, engine.stream()))
         replay_dict["_co_bwd"] = True
         return q1
     with engine._timed("chain") as tm:
@@ -581,7 +626,7 @@ def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict)
                 float(actor.log_std_low), float(actor.log_std_high), x1.data_ptr(), S + A, S,
                 ch["logp"].data_ptr(), ch["rng_ptr"], C.byref(t_arena.desc()), ids_ptr, n,
                 q1.data_ptr(), C.byref(c_arena.desc()), Xc.data_ptr(), ldxc, h1.data_ptr(), h2.data_ptr(),
-                qc.data_ptr(), dz2u.data_ptr(), dz1u.data_ptr(), C.byref(gth) if gth is not None else 0,
+                qc.data_ptr(), dz2u.data_ptr(), dz1u.data_ptr(), C.byref(gth) if gth is not None else 0, dl_ptr,
                 engine.stream()))
     replay_dict["_co_bwd"] = True
     return q1

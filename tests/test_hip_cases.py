@@ -63,6 +63,66 @@ def test_product_index_draw_is_bit_exact_on_the_gpu_box(seed, n):
         assert np.array_equal(act.cpu().numpy(), a[ref[0]])
 
 
+def test_deferred_log_blocks_read_late_or_at_once():
+    """recorded updates leave their log block to the NEXT update's first launch (or a flush when somebody looks
+    first): values read long after the fact, values read at once and the eager path's values are the same numbers."""
+    import copy
+    import math
+    import random
+    from itertools import chain
+
+    import torch
+    import super_sac_amd as ssa
+
+    def run(use_lists, read_now):
+        old = ssa.learning.USE_GRAPHS
+        ssa.learning.USE_GRAPHS = use_lists
+        try:
+            torch.manual_seed(4); np.random.seed(4); random.seed(4)
+            dev = torch.device("cuda")
+            agent = ssa.Agent(act_space_size=6, encoder=ssa.nets.IdentityEncoder(17),
+                              actor_network_cls=ssa.nets.ContinuousStochasticActor,
+                              critic_network_cls=ssa.nets.ContinuousCritic, ensemble_size=1, num_critics=4,
+                              hidden_size=64, auto_rescale_targets=False, log_std_low=-5.0, log_std_high=2.0)
+            agent.to(dev)
+            target = copy.deepcopy(agent)
+            buf = ssa.replay.ReplayBuffer(4096, device=dev)
+            buf.load_experience(*synth.synth_transitions(2000, 17, 6, seed=5))
+            copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=3e-4)
+            eopt = torch.optim.Adam(agent.encoder.parameters(), lr=1e-4)
+            la = torch.Tensor([math.log(0.1)]).to(dev); la.requires_grad = True
+            aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(128)])
+            kept, vals = [], []
+            for k in range(14):
+                logs, _ = ssa.learning.critic_update(
+                    buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt, encoder_optimizer=eopt,
+                    log_alphas=[la], batch_size=128, gamma=0.99, critic_clip=None, encoder_clip=None,
+                    target_critic_ensemble_n=2, weighted_bellman_temp=None, weight_type=None, pop=False,
+                    augmenter=aug, encoder_lambda=0, aug_mix=0.0, discrete=False, random_process=None,
+                    noise_clip=None, per=False, update_priorities=False, dr3_coeff=0.0)
+                if k % 2 == 0:
+                    ssa.learning_utils.soft_update(target.critics[0], agent.critics[0], 0.005)
+                if read_now or k % 5 == 3:   # (some values are looked at straight away, most long afterwards)
+                    vals.append({k_: float(v) for k_, v in logs.items()})
+                    kept.append(None)
+                else:
+                    vals.append(None)
+                    kept.append(logs)
+            for k, lg in enumerate(kept):
+                if lg is not None:
+                    vals[k] = {k_: float(v) for k_, v in lg.items()}
+            return vals
+        finally:
+            ssa.learning.USE_GRAPHS = old
+
+    eager = run(False, True)
+    late = run(True, False)
+    now = run(True, True)
+    assert all(np.isfinite(list(v.values())).all() and v["gradients/critic_random_grad"] > 0 for v in eager)
+    for k in range(14):
+        assert late[k] == eager[k] == now[k], (k, late[k], eager[k], now[k])
+
+
 def test_engine_matches_oracle_on_metric_shape():
     """engine vs oracle directly (not via the fixture) at obs 17 / act 6 / B 512 / N 10."""
     rec_o = case_runner.run_oracle("redq_M")

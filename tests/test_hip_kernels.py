@@ -1017,7 +1017,7 @@ def test_chain_launch_equals_the_separate_launches(ssa, B, N, H):
     ssa._lib.check(lib.ssac_chain_update(
         C.byref(aa.desc()), xb.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0, xb.data_ptr(), S + A, S, lpb.data_ptr(),
         0, C.byref(ta.desc()), ids.data_ptr(), 2, gt_.data_ptr(), C.byref(ca.desc()), xc.data_ptr(), S + A,
-        g1.data_ptr(), g2.data_ptr(), gq.data_ptr(), gz2.data_ptr(), gz1.data_ptr(), 0, st))
+        g1.data_ptr(), g2.data_ptr(), gq.data_ptr(), gz2.data_ptr(), gz1.data_ptr(), 0, 0, st))
     for a_, b_, what in ((xa, xb, "a'"), (lpa, lpb, "log pi"), (h1, g1, "h1"), (h2, g2, "h2"), (q, gq, "q"),
                          (qt, gt_, "target q"), (dz2, gz2, "dz2u"), (dz1, gz1, "dz1u")):
         assert torch.equal(a_, b_), f"chained launch differs in {what}"

@@ -212,6 +212,18 @@ int ssac_gather_transition_begin(const void *s, const void *s1, int s_dtype, int
                                  const ssac_feed *feed, float *logs, int n_logs, ssac_adam_ctl *ctl,
                                  void *stream);
 
+/* ---- replay push: ReplayBufferStorage.add (replay.py:48-60) for n transitions in ONE launch.  `packed` (device) holds
+ * the fields one after the other, each as n rows of row_bytes payload bytes (the result of ONE async host-to-device copy
+ * of a pinned staging buffer); field i's rows go to dst + ((start_row + r) % capacity) * row_bytes, verbatim. */
+#define SSAC_MAX_PUSH_FIELDS 12
+typedef struct ssac_push_field {
+    void *dst;            /* the field's ring array (capacity x row_bytes) */
+    int64_t row_bytes;
+    int64_t src_offset;   /* byte offset of the field's n rows inside `packed` */
+} ssac_push_field;
+int ssac_replay_push(const ssac_push_field *fields, int n_fields, const void *packed, int n_rows, int64_t start_row,
+                     int64_t capacity, void *stream);
+
 /* ---- one layer of every selected net: Y[e] = act(X[e] W_l[id_e]^T + b_l[id_e])
  * (mlps.py:33-35,125-129; agent.py:34 runs this once per net in a Python loop).
  * layer 0/1/2 = fc1/fc2/out.  net_ids: device int32[n_sel] or NULL (=0..n_sel-1).

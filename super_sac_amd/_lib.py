@@ -51,6 +51,11 @@ class TdSpec(C.Structure):
                 ("n_sel", C.c_int32), ("use_entropy", C.c_int32), ("_pad", C.c_int32)]
 
 
+class PushField(C.Structure):
+    """struct ssac_push_field"""
+    _fields_ = [("dst", C.c_void_p), ("row_bytes", C.c_int64), ("src_offset", C.c_int64)]
+
+
 class LogFold(C.Structure):
     """struct ssac_logfold"""
     _fields_ = [("done_counter", C.c_void_p), ("logs", C.c_void_p), ("td_logs", C.c_void_p), ("feed", C.c_void_p),
@@ -99,6 +104,7 @@ SIGNATURES = {
     "ssac_step_count": [_P],
     "ssac_step_seek": [_P, _L],
     "ssac_step_destroy": [_P],
+    "ssac_replay_push": [_P, _I, _P, _I, _L, _L, _P],
     "ssac_gather_rows": [_P, _I, _L, _P, _I, _P, _L, _L, _P],
     "ssac_mlp_layer_fwd": [_MP, _I, _P, _I, _P, _L, _L, _I, _P, _L, _L, _I, _P],
     "ssac_mlp_layer_dgrad": [_MP, _I, _P, _I, _P, _L, _L, _P, _L, _L, _I, _P, _L, _L, _P],

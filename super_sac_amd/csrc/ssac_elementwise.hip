@@ -1233,6 +1233,50 @@ extern "C" int ssac_drq_shift(const void *src, int src_dtype, const int64_t *idx
     return ssac_check_launch("drq_shift");
 }
 
+// ------------------------------------------------------------------ replay push (ring-buffer add, replay.py:48-60)
+// ONE launch scatters every field of n freshly collected transitions from a packed staging buffer (one async H2D copy
+// of everything) into the SoA ring: rows (start + i) % capacity.  Payload bytes are copied verbatim.
+struct PushField { unsigned char *dst; int64_t row_bytes; int64_t src_off; };
+struct PushArgs { PushField f[SSAC_MAX_PUSH_FIELDS]; int n_fields; const unsigned char *src; int n; int64_t start, capacity; };
+
+__global__ void replay_push_kernel(PushArgs a) {
+    for (int fi = 0; fi < a.n_fields; ++fi) {
+        const PushField f = a.f[fi];
+        const int64_t total = (int64_t)a.n * f.row_bytes;
+        const unsigned char *src = a.src + f.src_off;
+        if ((f.row_bytes & 3) == 0 && (((uintptr_t)src | (uintptr_t)f.dst) & 3) == 0) {
+            const int64_t rw = f.row_bytes >> 2, tw = total >> 2;
+            for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < tw; i += (int64_t)gridDim.x * blockDim.x) {
+                const int64_t r = i / rw, c = i - r * rw;
+                reinterpret_cast<uint32_t *>(f.dst + ((a.start + r) % a.capacity) * f.row_bytes)[c] =
+                    reinterpret_cast<const uint32_t *>(src)[i];
+            }
+        } else {
+            for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+                const int64_t r = i / f.row_bytes, c = i - r * f.row_bytes;
+                f.dst[((a.start + r) % a.capacity) * f.row_bytes + c] = src[i];
+            }
+        }
+    }
+}
+
+extern "C" int ssac_replay_push(const ssac_push_field *fields, int n_fields, const void *packed, int n_rows,
+                                int64_t start_row, int64_t capacity, void *stream) {
+    if (!fields || !packed || n_fields <= 0 || n_fields > SSAC_MAX_PUSH_FIELDS || capacity <= 0 || start_row < 0)
+        return ssac_fail("ssac_replay_push: bad arguments");
+    if (n_rows <= 0) return 0;
+    PushArgs a{};
+    int64_t most = 0;
+    for (int i = 0; i < n_fields; ++i) {
+        if (!fields[i].dst || fields[i].row_bytes <= 0) return ssac_fail("ssac_replay_push: bad field");
+        a.f[i] = PushField{(unsigned char *)fields[i].dst, fields[i].row_bytes, fields[i].src_offset};
+        if (fields[i].row_bytes > most) most = fields[i].row_bytes;
+    }
+    a.n_fields = n_fields; a.src = (const unsigned char *)packed; a.n = n_rows; a.start = start_row; a.capacity = capacity;
+    SSAC_LAUNCH(replay_push_kernel, dim3(grid_for((int64_t)n_rows * most / 4 + 1, 256, 2048)), dim3(256), 0, ST, a);
+    return ssac_check_launch("replay_push");
+}
+
 // ------------------------------------------------------------------ error plumbing
 static thread_local char g_err[256] = "";
 

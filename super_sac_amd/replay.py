@@ -13,6 +13,7 @@ import torch
 
 from . import engine, rng
 from . import device as _default_device
+from . import _lib
 from ._lib import check, lib
 
 
@@ -169,20 +170,75 @@ class ReplayBufferStorage:
         t = torch.from_numpy(np.ascontiguousarray(host)).to(dtype).reshape((len(rows),) + tuple(dst.shape[1:]))
         dst[rows] = t.to(self.device, non_blocking=False)
 
+    PACKED_MAX_BYTES = 8 << 20  # pushes up to this size travel as ONE pinned staging buffer + ONE scatter launch
+
+    def _fields(self):
+        f = self.__dict__.get("_field_list")
+        if f is None:
+            f = [(self.s_stack[k], self.s_dtypes[k], ("s", k)) for k in self.s_stack]
+            f += [(self.s1_stack[k], self.s_dtypes[k], ("s1", k)) for k in self.s1_stack]
+            f += [(self.action_stack, torch.float32, ("a", None)), (self.reward_stack, torch.float32, ("r", None)),
+                  (self.done_stack, torch.uint8, ("d", None))]
+            self._field_list = f
+        return f
+
     def add(self, s, a, r, s1, d):
+        """ReplayBufferStorage.add (replay.py:48-60): rows arange(next, next + k) % size.  The k transitions are packed
+        field by field into a pinned staging buffer, cross the bus in ONE asynchronous copy and are scattered into the
+        ring arrays by ONE launch (ssac_replay_push); the caller's thread never waits for the device."""
         a = np.asarray(a)
         num = len(a) if a.ndim > 1 else 1
         R = np.arange(self._next_idx, self._next_idx + num) % self.size
-        rows = torch.from_numpy(R).to(self.device)
+        fields = self._fields()
+        host = {("a", None): a.astype(np.float32, copy=False), ("r", None): np.asarray(r, dtype=np.float32),
+                ("d", None): np.asarray(d).astype(np.uint8)}
         for label in s:
-            self._put(self.s_stack[label], rows, np.asarray(s[label]), self.s_dtypes[label])
-            self._put(self.s1_stack[label], rows, np.asarray(s1[label]), self.s_dtypes[label])
-        self._put(self.action_stack, rows, a.astype(np.float32), torch.float32)
-        self._put(self.reward_stack, rows, np.asarray(r, dtype=np.float32), torch.float32)
-        self._put(self.done_stack, rows, np.asarray(d).astype(np.uint8), torch.uint8)
+            np_dt = np.uint8 if self.s_dtypes[label] == torch.uint8 else np.float32
+            host[("s", label)] = np.asarray(s[label]).astype(np_dt, copy=False)
+            host[("s1", label)] = np.asarray(s1[label]).astype(np_dt, copy=False)
+        row_bytes = [int(np.prod(t.shape[1:])) * t.element_size() for t, _, _ in fields]
+        offs, total = [], 0
+        for rb in row_bytes:
+            offs.append(total)
+            total += (num * rb + 15) // 16 * 16
+        if total > self.PACKED_MAX_BYTES or len(fields) > 12:
+            rows = torch.from_numpy(R).to(self.device)   # bulk loads (load_experience): per-field copies
+            for (t, dt, key), _ in zip(fields, row_bytes):
+                self._put(t, rows, host[key], dt)
+        else:
+            stage = self._staging(total)
+            sv = stage.numpy()
+            for (t, dt, key), rb, off in zip(fields, row_bytes, offs):
+                sv[off:off + num * rb] = np.ascontiguousarray(host[key]).reshape(-1).view(np.uint8)[:num * rb]
+            dev = self._dev_staging(total)
+            dev[:total].copy_(stage[:total], non_blocking=True)
+            self._stage_events[self._stage_k] = ev = torch.cuda.Event()
+            ev.record()
+            tab = (_lib.PushField * len(fields))(*[_lib.PushField(t.data_ptr(), rb, off)
+                                                   for (t, _, _), rb, off in zip(fields, row_bytes, offs)])
+            check(lib.ssac_replay_push(tab, len(fields), dev.data_ptr(), num, self._next_idx, self.size,
+                                       engine.stream()))
         self._max_filled = min(max(self._next_idx + num, self._max_filled), self.size)
         self._next_idx = (self._next_idx + num) % self.size
         return R
+
+    def _staging(self, nbytes):
+        """next buffer of a small ring of pinned staging buffers (slot reuse guarded by an event)"""
+        ring = self.__dict__.setdefault("_stage_ring", [None] * 4)
+        evs = self.__dict__.setdefault("_stage_events", [None] * 4)
+        self._stage_k = k = (self.__dict__.get("_stage_k", -1) + 1) % 4
+        if evs[k] is not None:
+            evs[k].synchronize()
+        if ring[k] is None or ring[k].numel() < nbytes:
+            ring[k] = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8).pin_memory()
+        return ring[k]
+
+    def _dev_staging(self, nbytes):
+        ring = self.__dict__.setdefault("_dev_stage_ring", [None] * 4)
+        k = self._stage_k
+        if ring[k] is None or ring[k].numel() < nbytes:
+            ring[k] = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=self.device)
+        return ring[k]
 
     def gather_field(self, src, idx_dev, n, dst=None, ld=None, col0=0):
         """rows src[idx] -> fp32 (n, row_elems) (or into `dst` at column col0 with row stride ld)."""
@@ -276,3 +332,32 @@ class ReplayBuffer:
 
     def update_priorities(self, idxes, priorities):
         self._per.update_priorities(idxes, priorities, len(self._storage))
+
+
+class NStepFolder:
+    """The n-step fold of the collection loop (main.py:335-369, learning_utils.py:121-153) in front of ``buffer.push``:
+    keep the last ``n_step`` raw transitions; once the window is full, pop the oldest, add the discounted rewards of
+    the others (``r += gamma ** (i + 1) * r_i`` in double precision, exactly the reference's Python arithmetic), take
+    the newest transition's next state and termination flag, and push ONE n-step transition -- which the storage sends
+    to the device as one packed asynchronous copy + one scatter launch (ReplayBufferStorage.add).  ``clear()`` at every
+    environment reset, as the reference clears its deque."""
+
+    def __init__(self, buffer, n_step, gamma):
+        from collections import deque
+        assert n_step >= 1
+        self.buffer, self.n_step, self.gamma = buffer, int(n_step), float(gamma)
+        self.window = deque([], maxlen=self.n_step)
+
+    def clear(self):
+        self.window.clear()
+
+    def add(self, state, action, reward, next_state, terminated, done=False):
+        """one environment transition; returns the ring rows written (None while the window fills up)"""
+        self.window.append((state, action, reward, next_state, terminated))
+        if len(self.window) < self.window.maxlen:
+            return None
+        s, a, r, s1, d = self.window.popleft()
+        for i, trans in enumerate(self.window):
+            *_, r_i, s1, d = trans
+            r = r + (self.gamma ** (i + 1)) * r_i
+        return self.buffer.push(s, a, r, s1, done=d, terminate_traj=done)

@@ -356,3 +356,81 @@ def test_recorded_updates_wrap_the_input_ring():
     assert np.array_equal(pe, pr) and np.array_equal(te, tr)
     for a, b in zip(se, sr):
         assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2])
+
+
+def test_packed_push_and_n_step_fold_match_the_reference_storage():
+    """buffer.push through the packed single-copy path (ring wrap-around, batched and single transitions, uint8
+    images) against a plain numpy ring (ReplayBufferStorage.add, replay.py:48-60), and NStepFolder against the
+    collection loop's n-step arithmetic (main.py:347-365)."""
+    import torch
+    import super_sac_amd as ssa
+    rng_ = np.random.RandomState(0)
+    cap, S, A = 37, 5, 2
+    buf = ssa.replay.ReplayBuffer(cap, device=torch.device("cuda"))
+    ring = {k: None for k in ("s", "a", "r", "s1", "d")}
+    nxt, filled = 0, 0
+    for num in (1, 1, 8, 30, 1, 5, 37, 3):
+        s = rng_.standard_normal((num, S)).astype(np.float32)
+        s1 = rng_.standard_normal((num, S)).astype(np.float32)
+        a = rng_.uniform(-1, 1, (num, A)).astype(np.float32)
+        r = rng_.standard_normal((num, 1)).astype(np.float32)
+        d = (rng_.uniform(size=(num, 1)) < 0.3)
+        if num == 1:
+            R = buf.push({"obs": s[0]}, a[0], float(r[0, 0]), {"obs": s1[0]}, bool(d[0, 0]))
+        else:
+            R = buf.push({"obs": s}, a, r, {"obs": s1}, d)
+        if ring["s"] is None:
+            ring = {"s": np.zeros((cap, S), np.float32), "s1": np.zeros((cap, S), np.float32),
+                    "a": np.zeros((cap, A), np.float32), "r": np.zeros((cap, 1), np.float32),
+                    "d": np.zeros((cap, 1), np.uint8)}
+        rows = np.arange(nxt, nxt + num) % cap
+        assert np.array_equal(np.asarray(R), rows)
+        ring["s"][rows], ring["s1"][rows], ring["a"][rows], ring["r"][rows], ring["d"][rows] = s, s1, a, r, d
+        nxt, filled = (nxt + num) % cap, min(max(nxt + num, filled), cap)
+        assert len(buf) == filled
+    st = buf._storage
+    torch.cuda.synchronize()
+    assert np.array_equal(st.s_stack["obs"].cpu().numpy(), ring["s"])
+    assert np.array_equal(st.s1_stack["obs"].cpu().numpy(), ring["s1"])
+    assert np.array_equal(st.action_stack.cpu().numpy(), ring["a"])
+    assert np.array_equal(st.reward_stack.cpu().numpy(), ring["r"])
+    assert np.array_equal(st.done_stack.cpu().numpy(), ring["d"])
+    # uint8 image observations stay uint8 on the device
+    ib = ssa.replay.ReplayBuffer(16, device=torch.device("cuda"))
+    img = rng_.randint(0, 256, (6, 3, 8, 8)).astype(np.uint8)
+    ib.push({"obs": img}, np.zeros((6, 1), np.float32), np.zeros((6, 1), np.float32), {"obs": img[::-1].copy()},
+            np.zeros((6, 1), bool))
+    torch.cuda.synchronize()
+    assert ib._storage.s_stack["obs"].dtype == torch.uint8
+    assert np.array_equal(ib._storage.s_stack["obs"][:6].cpu().numpy(), img)
+    assert np.array_equal(ib._storage.s1_stack["obs"][:6].cpu().numpy(), img[::-1])
+    # ---- n-step fold: the reference loop's arithmetic on a stream of raw transitions with episode ends
+    n_step, gamma = 3, 0.99
+    nb = ssa.replay.ReplayBuffer(64, device=torch.device("cuda"))
+    folder = ssa.replay.NStepFolder(nb, n_step, gamma)
+    from collections import deque
+    dq, want = deque([], maxlen=n_step), []
+    for t in range(40):
+        s = {"obs": rng_.standard_normal(S).astype(np.float32)}
+        s1 = {"obs": rng_.standard_normal(S).astype(np.float32)}
+        a = rng_.uniform(-1, 1, A).astype(np.float32)
+        r, term = float(rng_.standard_normal()), bool(rng_.uniform() < 0.1)
+        folder.add(s, a, r, s1, term, done=term)
+        dq.append((s, a, r, s1, term))
+        if len(dq) == dq.maxlen:  # main.py:358-365
+            s_, a_, r_, s1_, d_ = dq.popleft()
+            for i, trans in enumerate(dq):
+                *_, r_i, s1_, d_ = trans
+                r_ += (gamma ** (i + 1)) * r_i
+            want.append((s_["obs"], a_, np.float32(r_), s1_["obs"], d_))
+        if term:
+            folder.clear()
+            dq.clear()
+    torch.cuda.synchronize()
+    assert len(nb) == len(want) > 10
+    ns = nb._storage
+    assert np.array_equal(ns.s_stack["obs"][:len(want)].cpu().numpy(), np.stack([w[0] for w in want]))
+    assert np.array_equal(ns.action_stack[:len(want)].cpu().numpy(), np.stack([w[1] for w in want]))
+    assert np.array_equal(ns.reward_stack[:len(want), 0].cpu().numpy(), np.array([w[2] for w in want], np.float32))
+    assert np.array_equal(ns.s1_stack["obs"][:len(want)].cpu().numpy(), np.stack([w[3] for w in want]))
+    assert np.array_equal(ns.done_stack[:len(want), 0].cpu().numpy(), np.array([w[4] for w in want], np.uint8))

@@ -552,6 +552,30 @@ int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t ldxa, int 
                       float *DZ2u, float *DZ1u, const ssac_gather *gather,
                       const ssac_deferred_logs *deferred /* nullable */, void *stream);
 
+/* ---- the online actor update (learning.py:344-421) in four launches:
+ *   ssac_actor_sample_concat_fused   actor forward (h1 / h2 / head output saved) + tanh-normal rsample + log pi, the rows
+ *                                    [s | a_theta] written out as the critics' input                 (mlps.py:32-39, 124)
+ *   ssac_critic_fwd_dx_fused         all critics' forward on [s | a_theta] and the UNSCALED input gradient of the action
+ *                                    columns, DXu[j][b][:] = dQ_j/da  (dz2 = W3 (.) [h2>0], dz1 = (dz2 W2) (.) [h1>0],
+ *                                    dx = dz1 W1[:, act cols]) -- what loss.backward() sends back to the actor
+ *   ssac_actor_bwd_fused             per row: arg-min critic (learning.py:402 takes the min over ALL critics), the
+ *                                    policy gradient -pw/(B E) dQ_argmin/da and the entropy term through the tanh-normal
+ *                                    head (d_out, B x 2A), then the actor's head backward and fc2 backward-data on the
+ *                                    saved forward (DZ2, DZ1); partials[tile] = sum of (Q' - alpha log pi) over the tile
+ *   ssac_mlp_wgrad_all               the actor's weight gradients + Adam (above), then ssac_actor_logs for the two logs */
+int ssac_actor_sample_concat_fused(const ssac_mlp *actor, const float *X, int64_t ldx, int n_rows, const float *eps,
+                                   float log_std_lo, float log_std_hi, float *xsa, int64_t ld_xsa, float *logp,
+                                   float *H1, float *H2, float *out, const ssac_rng *rng, void *stream);
+int ssac_critic_fwd_dx_fused(const ssac_mlp *nets, const float *X, int64_t ldx, int n_rows, int dx_col0, int dx_cols,
+                             float *Q, float *DXu, void *stream);
+int ssac_actor_bwd_fused(const ssac_mlp *actor, const float *H1, const float *H2, int n_rows, const float *Qc,
+                         int n_critics, const float *DXu, const float *aout, const float *eps, const float *logp,
+                         const float *log_alpha, int use_entropy, float log_std_lo, float log_std_hi, float inv_members,
+                         const ssac_popart *popart, int pop, float *d_out, float *DZ2, float *DZ1, float *partials,
+                         void *stream);
+int ssac_actor_logs(const float *partials, int n_tiles, int n_rows, float inv_members, const float *sumsq, int n_sumsq,
+                    float *logs_loss, float *logs_gn, void *stream);
+
 /* critic forward of ALL nets + loss gradient + backward-data in ONE launch (learning.py:83-98,112,121):
  * writes H1, H2, Q (n_nets x n_rows x out), DQ, DZ2 = dL/d(pre-activation of fc2), DZ1, and per-(net,
  * row-tile) partial sums partials[(e*tiles + tile)*2 + {sum w*err^2, sum err}] for ssac_critic_logs. */

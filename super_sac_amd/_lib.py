@@ -185,6 +185,10 @@ SIGNATURES = {
                           _P, _P, _P],
     "ssac_deferred_logs_flush": [_P, _I, _P],
     "ssac_philox_normal": [_P, _I, _I, _P, _P],
+    "ssac_actor_sample_concat_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _P, _P, _P, _P, _P, _P],
+    "ssac_critic_fwd_dx_fused": [_MP, _P, _L, _I, _I, _I, _P, _P, _P],
+    "ssac_actor_bwd_fused": [_MP, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _F, _F, _F, _P, _I, _P, _P, _P, _P, _P],
+    "ssac_actor_logs": [_P, _I, _I, _F, _P, _I, _P, _P, _P],
     "ssac_critic_fwd_bwd_fused": [_MP, _P, _L, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ssac_critic_bwd_fused": [_MP, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ssac_head_wgrad_tiles": [_MP],

@@ -1233,6 +1233,33 @@ extern "C" int ssac_drq_shift(const void *src, int src_dtype, const int64_t *idx
     return ssac_check_launch("drq_shift");
 }
 
+// ------------------------------------------------------------------ logs of the fused online actor update
+// logs_loss[0] += -inv_members * sum(partials) / n_rows  (losses/actor_pg_loss accumulates over the members);
+// logs_gn[0] = sqrt(sum(sumsq))  (gradients/random_actor_online_grad of the picked member)
+__global__ __launch_bounds__(RED_THREADS) void actor_logs_kernel(const float *__restrict__ partials, int n_tiles,
+                                                                int n_rows, float inv_members,
+                                                                const float *__restrict__ sumsq, int n_ss,
+                                                                float *logs_loss, float *logs_gn) {
+    __shared__ float scratch[16];
+    float s = 0.f, ss = 0.f;
+    for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) s += partials[i];
+    for (int i = threadIdx.x; i < n_ss; i += blockDim.x) ss += sumsq[i];
+    s = block_reduce<0>(s, scratch);
+    ss = block_reduce<0>(ss, scratch);
+    if (threadIdx.x == 0) {
+        if (logs_loss) logs_loss[0] += -inv_members * s / (float)n_rows;
+        if (logs_gn) logs_gn[0] = sqrtf(ss);
+    }
+}
+
+extern "C" int ssac_actor_logs(const float *partials, int n_tiles, int n_rows, float inv_members, const float *sumsq,
+                               int n_sumsq, float *logs_loss, float *logs_gn, void *stream) {
+    if (!partials || n_tiles <= 0 || n_rows <= 0) return ssac_fail("ssac_actor_logs: bad arguments");
+    SSAC_LAUNCH(actor_logs_kernel, dim3(1), dim3(RED_THREADS), 0, ST, partials, n_tiles, n_rows, inv_members, sumsq,
+                sumsq ? n_sumsq : 0, logs_loss, logs_gn);
+    return ssac_check_launch("actor_logs");
+}
+
 // ------------------------------------------------------------------ replay push (ring-buffer add, replay.py:48-60)
 // ONE launch scatters every field of n freshly collected transitions from a packed staging buffer (one async H2D copy
 // of everything) into the SoA ring: rows (start + i) % capacity.  Payload bytes are copied verbatim.

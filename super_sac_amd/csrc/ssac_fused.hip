@@ -52,7 +52,19 @@ constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 constexpr float LOG_2 = 0.69314718055994530942f;
 
 enum { MODE_PLAIN = 0, MODE_SAMPLE = 1, MODE_CRITIC = 2, MODE_CRITIC_BWD = 3, MODE_CRITIC_BWDU = 4,
-       MODE_CRITIC_U = 5 /* forward + the TD-independent (unscaled) backward, activations never leave LDS */ };
+       MODE_CRITIC_U = 5 /* forward + the TD-independent (unscaled) backward, activations never leave LDS */,
+       MODE_ACTOR_BWD = 6 /* policy-gradient backward of the actor: arg-min routing over the critics' Q, tanh-normal
+                             backward, head backward and fc2 backward-data on the saved actor forward */ };
+
+// policy-gradient routing of the online actor update (learning.py:392-408), evaluated per row by MODE_ACTOR_BWD
+struct ActorBwdArgs {
+    const float *qc; int n_critics;     // (n_critics x n_rows) critics' Q(s, a_theta)
+    const float *dxu;                   // (n_critics x n_rows x A) UNSCALED dQ_j/da (MODE_CRITIC_U's DXU)
+    const float *aout;                  // (n_rows x 2A) actor head output of the forward pass
+    const float *eps, *logp, *log_alpha; int use_entropy;
+    float lo, hi, inv_members;
+    float *partials;                    // [row tiles] sum over the tile's rows of (Q' - alpha log pi)
+};
 
 struct FusedArgs {
     const float *params; int64_t net_stride; int in_dim, hidden, out_dim;
@@ -72,6 +84,9 @@ struct FusedArgs {
                                     // 2: critic half ([s|a] rows), 4: rows from X, net ids from the input slot; 0: X
     long long *dbg;  // optional phase timestamps (s_memtime) of workgroup (0,0), thread 0
     ssac_td_spec tds;  // tds.q_t != null: the TD target is computed here instead of read from `td`
+    float *DXU; int dx_col0, dx_cols;  // MODE_CRITIC_U: also the unscaled input gradient of columns [dx_col0, +dx_cols)
+    int copy_x;                        // MODE_SAMPLE: also copy the input tile into act_dst[:, 0:in_dim]
+    ActorBwdArgs ab;                   // MODE_ACTOR_BWD
 };
 
 // TD target of row b (see ssac_td_spec; same operation order as td_target_kernel in ssac_elementwise.hip)
@@ -505,7 +520,8 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     RcStage st3;
     NoStage none;
     constexpr bool UNSCALED = MODE == MODE_CRITIC_BWDU || MODE == MODE_CRITIC_U;
-    constexpr bool BWD_ONLY = MODE == MODE_CRITIC_BWD || MODE == MODE_CRITIC_BWDU;
+    constexpr bool ACTOR = MODE == MODE_ACTOR_BWD;
+    constexpr bool BWD_ONLY = MODE == MODE_CRITIC_BWD || MODE == MODE_CRITIC_BWDU || ACTOR;
     constexpr bool FWD_BWD = MODE == MODE_CRITIC || MODE == MODE_CRITIC_U;  // forward, then backward in the same workgroup
     constexpr bool IS_CRITIC = FWD_BWD || BWD_ONLY;
     typename T::Acc acc;
@@ -529,7 +545,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
             }
         }
         stage_head_weights(w3s, P + g.off[4], OUT, H, ldw3, tid);
-        if (tid < TMR) {
+        if (!ACTOR && tid < TMR) {
             const int b = m0 + tid;
             const bool ok = b < g.n_rows;
             if (!UNSCALED) {
@@ -548,7 +564,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 *reinterpret_cast<f4 *>(h2s + r * ldh + c) = ok ? a2[j] : z;
             }
         }
-        if (!UNSCALED)
+        if (!UNSCALED && !ACTOR)
             for (int i = tid; i < TMR * OUT; i += NTHR) {
                 const int r = i / OUT, o = i - r * OUT;
                 ys[r * ldo + o] = (m0 + r) < g.n_rows ? g.Y[((int64_t)e * g.n_rows + m0 + r) * OUT + o] : 0.0f;
@@ -611,8 +627,9 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 w3s[o * ldw3 + (i3 - o * H)] = w3v[u];
             }
         }
-        float *outp = gidx ? (actor_half ? g.gth.x1sa : (e == 0 ? g.gth.xsa : nullptr)) : nullptr;
-        const int64_t ldo_g = actor_half ? g.gth.ld_x1 : g.gth.ld_x;
+        float *outp = gidx ? (actor_half ? g.gth.x1sa : (e == 0 ? g.gth.xsa : nullptr))
+                           : ((MODE == MODE_SAMPLE && g.copy_x) ? g.act_dst : nullptr);   // [s | .] for the critics
+        const int64_t ldo_g = gidx ? (actor_half ? g.gth.ld_x1 : g.gth.ld_x) : g.ld_act;
 #pragma unroll
         for (int j = 0; j < XR; ++j) {
             const int r = xr0 + 16 * j;
@@ -798,7 +815,52 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         const float pb = (g.popart && g.pop) ? g.popart->b : 0.0f;
         const float gscale = -2.0f * pw / (g.denom * (float)g.n_rows);
         float lossv = 0.0f, errv = 0.0f;  // this row's loss terms (threads < TMR), summed over wave 0 below
-        if (UNSCALED) {
+        if (ACTOR) {
+            // dL/d(actor output) of this tile's rows (learning.py:392-408): the policy gradient passes through the
+            // arg-min critic of every row (dQ/da, left UNSCALED by MODE_CRITIC_U), then through the tanh-normal head
+            const int A = OUT >> 1;
+            const ActorBwdArgs &ab = g.ab;
+            const float alpha = ab.use_entropy ? expf(ab.log_alpha[0]) : 0.0f;
+            const float gq = -pw * ab.inv_members / (float)g.n_rows;
+            const float cen = alpha * ab.inv_members / (float)g.n_rows;
+            float part = 0.0f;
+            for (int t = tid; t < TMR * A; t += NTHR) {
+                const int r = t / A, i = t - r * A, b = m0 + r;
+                float dmu = 0.0f, dls = 0.0f;
+                if (b < g.n_rows) {
+                    float mq = ab.qc[b];
+                    int am = 0;
+                    for (int j = 1; j < ab.n_critics; ++j) {
+                        const float v = ab.qc[(int64_t)j * g.n_rows + b];
+                        if (v < mq) { mq = v; am = j; }
+                    }
+                    const float gsum = gq * ab.dxu[((int64_t)am * g.n_rows + b) * A + i];
+                    const float mu = ab.aout[(int64_t)b * OUT + i], raw = ab.aout[(int64_t)b * OUT + A + i];
+                    const float th = tanhf(raw);
+                    const float sd = expf(ab.lo + 0.5f * (ab.hi - ab.lo) * (th + 1.0f));
+                    const float ep = ab.eps[(int64_t)b * A + i];
+                    const float a = tanhf(mu + sd * ep);
+                    const float gu = gsum * (1.0f - a * a);
+                    dmu = gu + cen * 2.0f * a;
+                    dls = (gu * sd * ep + cen * (-1.0f + 2.0f * a * sd * ep)) * 0.5f * (ab.hi - ab.lo) * (1.0f - th * th);
+                    g.DQ[(int64_t)b * OUT + i] = dmu;
+                    g.DQ[(int64_t)b * OUT + A + i] = dls;
+                    if (i == 0) part += (pw * mq + pb) - (ab.use_entropy ? alpha * ab.logp[b] : 0.0f);
+                }
+                dqs[r * ldo + i] = dmu;
+                dqs[r * ldo + A + i] = dls;
+            }
+            // the tile's loss term: fixed-order sum over the workgroup (partials are summed by ssac_actor_logs)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            if (lane == 0) rowred[wave] = part;
+            __syncthreads();
+            if (tid == 0) {
+                float tot = 0.0f;
+                for (int w = 0; w < NTHR / 64; ++w) tot += rowred[w];
+                ab.partials[bx] = tot;
+            }
+        } else if (UNSCALED) {
             // selector of the head output the loss looks at (the taken action; the only output when OUT == 1)
             if (tid < TMR) {
                 const int ai = OUT > 1 ? (int)rowin[2 * TMR + tid] : 0;
@@ -822,7 +884,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 if (b < g.n_rows) g.DQ[((int64_t)e * g.n_rows + b) * OUT + o] = d;
             }
         }
-        if (!UNSCALED && wave == 0) {  // fixed shuffle tree over the tile's rows: no LDS round trip, no serial loop
+        if (!UNSCALED && !ACTOR && wave == 0) {  // fixed shuffle tree over the tile's rows: no LDS round trip, no serial loop
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { lossv += __shfl_xor(lossv, o, 64); errv += __shfl_xor(errv, o, 64); }
             if (lane == 0) {
@@ -865,7 +927,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
 #pragma unroll
                     for (int i = 0; i < 4; ++i) dz[i] = hv[j][i] > 0.0f ? gs[j][i] : 0.0f;
                     *reinterpret_cast<f4 *>(h2s + r * ldh + k) = dz;
-                    if ((m0 + r) < g.n_rows)
+                    if (g.DZ2 && (m0 + r) < g.n_rows)
                         *reinterpret_cast<f4 *>(g.DZ2 + ((int64_t)e * g.n_rows + m0 + r) * H + k) = dz;
                 }
             }
@@ -876,16 +938,35 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         T::zero(acc);
         gemm_tile<TMR, true, DBUF>(acc, st3, h2s, ldh, H, Ws, Ws1, tid, col0, none, 0);
         BSTAMP(10);
+        const bool want_dx = MODE == MODE_CRITIC_U && g.DXU != nullptr;
         T::foreach4(acc, lane, [&](int row, int cw, f4 val) {
             const int col = col0 + cw;
-            if (col < H && (m0 + row) < g.n_rows) {
+            if (col < H) {
                 const f4 hq = *reinterpret_cast<const f4 *>(h1s + row * ldh + col);
                 f4 v;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = hq[i] > 0.0f ? val[i] : 0.0f;
-                *reinterpret_cast<f4 *>(g.DZ1 + ((int64_t)e * g.n_rows + m0 + row) * H + col) = v;
+                if (g.DZ1 && (m0 + row) < g.n_rows)
+                    *reinterpret_cast<f4 *>(g.DZ1 + ((int64_t)e * g.n_rows + m0 + row) * H + col) = v;
+                if (want_dx) *reinterpret_cast<f4 *>(h2s + row * ldh + col) = v;   // (dz2 is dead: gemm_tile ended with a barrier)
             }
         });
+        if (want_dx) {
+            // dX[b][c] = sum_k dz1u[b][k] W1[k][dx_col0 + c]: the (unscaled) gradient w.r.t. the ACTION columns of the
+            // critic input -- all the online actor update needs from the critics' backward pass (learning.py:402-411)
+            __syncthreads();
+            const float *W1 = P + g.off[0];
+            const int DC = g.dx_cols;
+            for (int t = tid; t < TMR * DC; t += NTHR) {
+                const int r = t / DC, cix = t - r * DC;
+                if ((m0 + r) < g.n_rows) {
+                    const float *wc = W1 + g.dx_col0 + cix;
+                    float sx = 0.0f;
+                    for (int k = 0; k < H; ++k) sx += h2s[r * ldh + k] * wc[(int64_t)k * IN];
+                    g.DXU[((int64_t)e * g.n_rows + m0 + r) * DC + cix] = sx;
+                }
+            }
+        }
         BSTAMP(11);
     }
 }
@@ -971,452 +1052,6 @@ void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs
     }
 }
 
-// =============================================================================================
-// Direct-B variant.  Wave w of a workgroup is the ONLY consumer of columns [32w, 32w+32) of a weight
-// matrix, so staging weights through LDS buys no reuse inside the workgroup: each wave loads its own B
-// fragments straight from global memory (L2) into registers, two K chunks ahead, and only the A operand
-// (x, h1, dz2 -- shared by all eight waves) lives in LDS.  The K loop then has NO barrier and no LDS
-// store; waves drift apart freely and the two waves of a SIMD fill each other's gaps.  Without the two
-// 36 KB staging buffers a 32-row workgroup needs < 80 KB of LDS, so two of them share a CU.
-// The MFMA sequence per accumulator (k order inside a chunk) is the same as the staged kernel's, so the
-// results are bit-identical to it.
-// =============================================================================================
-template <int TMR, bool NN> struct DirectB;
-
-// All loads below are UNCONDITIONAL (out-of-range columns read row 0, a ragged K tail reads on into the
-// next row -- always inside the parameter arena, whose W segments are followed by bias/W segments -- and the
-// unwanted values are replaced by zeros with selects afterwards): a load inside a branch would force the
-// compiler to drain the whole vmcnt queue at the join, i.e. to wait for the prefetches as well.
-template <bool NN> struct DirectB<32, NN> {
-    const float *p;
-    int ldw, K, kofs;
-    bool ok;
-    __device__ __forceinline__ void init(const float *W, int ldw_, int Ncols, int K_, int lane, int col0) {
-        const int li = lane & 31, lh = lane >> 5;
-        ldw = ldw_; K = K_; kofs = lh * 16;
-        ok = (col0 + li) < Ncols;
-        const int n = ok ? col0 + li : 0;
-        p = NN ? W + (int64_t)(lh * 16) * ldw + n : W + (int64_t)n * ldw + lh * 16;
-    }
-    __device__ __forceinline__ void load(Tile<32>::Frag &f, int c) const {
-        const int k0 = c * 32;
-        if (NN) {  // W is (K x Ncols): 16 rows of this lane's column (K % 32 == 0 on this path)
-            const float *q = p + (int64_t)k0 * ldw;
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float x = q[(int64_t)t * ldw];
-                f.bs[t] = ok ? x : 0.0f;
-            }
-        } else {   // W is (Ncols x K): 16 consecutive k of this lane's row
-            const int left = ok ? K - (k0 + kofs) : 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f4 x = *reinterpret_cast<const f4u *>(p + k0 + 4 * q);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) f.b[q][i] = (4 * q + i) < left ? x[i] : 0.0f;
-            }
-        }
-    }
-};
-
-template <bool NN> struct DirectB<16, NN> {
-    const float *p[2];
-    int ldw, K, kofs;
-    bool ok[2];
-    __device__ __forceinline__ void init(const float *W, int ldw_, int Ncols, int K_, int lane, int col0) {
-        const int li = lane & 15, lg = lane >> 4;
-        ldw = ldw_; K = K_; kofs = lg * 8;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            ok[u] = (col0 + 16 * u + li) < Ncols;
-            const int n = ok[u] ? col0 + 16 * u + li : 0;
-            p[u] = NN ? W + (int64_t)(lg * 8) * ldw + n : W + (int64_t)n * ldw + lg * 8;
-        }
-    }
-    __device__ __forceinline__ void load(Tile<16>::Frag &f, int c) const {
-        const int k0 = c * 32;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (NN) {
-                const float *q = p[u] + (int64_t)k0 * ldw;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const float x = q[(int64_t)t * ldw];
-                    f.bs[u][t] = ok[u] ? x : 0.0f;
-                }
-            } else {
-                const int left = ok[u] ? K - (k0 + kofs) : 0;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const f4 x = *reinterpret_cast<const f4u *>(p[u] + k0 + 4 * q);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) f.b[u][q][i] = (4 * q + i) < left ? x[i] : 0.0f;
-                }
-            }
-        }
-    }
-};
-
-// A fragment of chunk c from LDS (same addressing as Tile<TMR>::read)
-template <int TMR>
-__device__ __forceinline__ void read_a(typename Tile<TMR>::Frag &f, const float *As, int lda, int c, int lane) {
-    if (TMR == 32) {
-        const f4 *ap = reinterpret_cast<const f4 *>(As + (lane & 31) * lda + c * 32 + (lane >> 5) * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) f.a[q] = ap[q];
-    } else {
-        const f4 *ap = reinterpret_cast<const f4 *>(As + (lane & 15) * lda + c * 32 + (lane >> 4) * 8);
-        f.a[0] = ap[0]; f.a[1] = ap[1];
-    }
-}
-
-template <int TMR, bool NN>
-__device__ __forceinline__ void mfma_chunk(typename Tile<TMR>::Acc &acc, typename Tile<TMR>::Frag &fa,
-                                           typename Tile<TMR>::Frag &fb) {
-    // move the A half into the B-carrying fragment's `a` slot is not needed: build the MFMAs directly
-    if constexpr (TMR == 32) {
-#pragma unroll
-        for (int t = 0; t < 16; ++t)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(NN ? fb.bs[t] : fb.b[t >> 2][t & 3], fa.a[t >> 2][t & 3],
-                                                      acc, 0, 0, 0);
-    } else {
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-                acc.v[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(NN ? fb.bs[u][t] : fb.b[u][t >> 2][t & 3],
-                                                                fa.a[t >> 2][t & 3], acc.v[u], 0, 0, 0);
-    }
-}
-
-// chunks 0 and 1 of `db` must already be in flight in fb[0], fb[1] (start_direct): the caller issues them
-// one phase early, before the previous phase's epilogue.  Prefetch indices are clamped to the last chunk
-// instead of being guarded (see DirectB): the few redundant loads at the end of the loop are never used.
-template <int TMR, bool NN>
-__device__ __forceinline__ void start_direct(const DirectB<TMR, NN> &db, typename Tile<TMR>::Frag (&fb)[3], int K) {
-    const int last = ((K + 31) >> 5) - 1;
-    db.load(fb[0], 0);
-    db.load(fb[1], min(1, last));
-}
-
-template <int TMR, bool NN>
-__device__ __forceinline__ void gemm_direct(typename Tile<TMR>::Acc &acc, const float *As, int lda, int K,
-                                            const DirectB<TMR, NN> &db, typename Tile<TMR>::Frag (&fb)[3],
-                                            int lane) {
-    const int nch = (K + 31) >> 5, last = nch - 1;
-    typename Tile<TMR>::Frag fa;
-    for (int c = 0; c < nch; c += 3) {
-        db.load(fb[2], min(c + 2, last));
-        read_a<TMR>(fa, As, lda, c, lane);
-        mfma_chunk<TMR, NN>(acc, fa, fb[0]);
-        db.load(fb[0], min(c + 3, last));
-        if (c + 1 < nch) {
-            read_a<TMR>(fa, As, lda, c + 1, lane);
-            mfma_chunk<TMR, NN>(acc, fa, fb[1]);
-        }
-        db.load(fb[1], min(c + 4, last));
-        if (c + 2 < nch) {
-            read_a<TMR>(fa, As, lda, c + 2, lane);
-            mfma_chunk<TMR, NN>(acc, fa, fb[2]);
-        }
-    }
-}
-
-template <int MODE, int TMR>
-__global__ __launch_bounds__(NTHR) void fused_direct_kernel(FusedArgs g) {
-    typedef Tile<TMR> T;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int H = g.hidden, IN = g.in_dim, OUT = g.out_dim;
-    const int ldo = (OUT + 15) & ~15;  // row stride of the per-row head outputs / output gradients in LDS
-    const int KP = (IN + 31) & ~31;
-    const int ldx_s = KP + APAD, ldh = H + APAD, ldw3 = H + APAD;
-    float *xs = smem;                       // [TMR][KP+4]
-    float *h1s = xs + TMR * ldx_s;          // [TMR][H+4]
-    // after fc2, [xs | h1s] is dead and holds the head's K-split partials [8][TMR][16]
-    const int front = max(TMR * ldx_s + TMR * ldh, 8 * TMR * MAX_OUT);
-    float *h2s = smem + front;              // [TMR][H+4]
-    float *ys = h2s + TMR * ldh;            // [TMR][ldo], ldo = out_dim rounded up to 16
-    float *dqs = ys + TMR * ldo;            // [TMR][ldo]
-    float *rowred = dqs + TMR * ldo;        // [64]
-    float *b1s = rowred + 64;               // [H]
-    float *b2s = b1s + H;                   // [H]
-    float *b3s = b2s + H;                   // [HEAD_MAX]
-    float *w3s = b3s + HEAD_MAX;            // [OUT][H+4]
-    float *rowin = w3s + OUT * ldw3;        // [3][TMR]
-    float *hpart = smem;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Lid = ssac_xcd_contiguous(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, g.xcd);
-    const int bx = Lid % gridDim.x, e = Lid / gridDim.x, m0 = bx * TMR;
-    const int net = g.ids ? g.ids[e] : e;
-    if (net < 0) {
-        // slot without a net (a REDQ subset member another rank owns): its outputs are +inf, the neutral
-        // element of the min that follows, so a sharded launch sequence is the same for every subset draw
-        if (MODE == MODE_PLAIN && g.Y)
-            for (int i = threadIdx.x; i < TMR * OUT; i += NTHR) {
-                const int r = i / OUT, o = i - r * OUT;
-                if ((m0 + r) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + r) * OUT + o] = __builtin_inff();
-            }
-        return;
-    }
-    const float *P = g.params + (int64_t)net * g.net_stride;
-    const int col0 = wave * 32;
-    constexpr bool BWD_ONLY = MODE == MODE_CRITIC_BWD;
-    constexpr bool IS_CRITIC = MODE == MODE_CRITIC || MODE == MODE_CRITIC_BWD;
-
-    STAMP(0);
-    typename T::Frag fb[3];
-    typename T::Acc acc;
-    DirectB<TMR, true> db3;
-    unsigned h1mask = 0;  // bit i: the i-th element of this lane's accumulator had h1 > 0 (fc1 epilogue order)
-    if (IS_CRITIC) db3.init(P + g.off[2], H, H, H, lane, col0);
-
-    if (IS_CRITIC && tid < TMR) {
-        const int b = m0 + tid;
-        const bool ok = b < g.n_rows;
-        rowin[tid] = ok ? td_of_row(g, b, e) : 0.0f;
-        rowin[TMR + tid] = (ok && g.weight) ? g.weight[b] : 1.0f;
-        rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
-    }
-    if (BWD_ONLY) {
-        start_direct<TMR, true>(db3, fb, H);
-        stage_head_weights(w3s, P + g.off[4], OUT, H, ldw3, tid);
-        const int c = (tid & 63) * 4;
-        if (c < H) {
-            for (int r = tid >> 6; r < TMR; r += NTHR / 64) {
-                const bool ok = (m0 + r) < g.n_rows;
-                const int64_t src = ((int64_t)e * g.n_rows + (ok ? m0 + r : 0)) * H + c;
-                const f4 a2 = *reinterpret_cast<const f4u *>(g.H2 + src);
-                *reinterpret_cast<f4 *>(h2s + r * ldh + c) = ok ? a2 : (f4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        for (int i = tid; i < TMR * OUT; i += NTHR) {
-            const int r = i / OUT, o = i - r * OUT;
-            ys[r * ldo + o] = (m0 + r) < g.n_rows ? g.Y[((int64_t)e * g.n_rows + m0 + r) * OUT + o] : 0.0f;
-        }
-        T::zero(acc);
-        T::foreach(acc, lane, [&](int row, int cw, float) {  // (only the element order matters here)
-            const int col = col0 + cw;
-            const bool on = col < H && (m0 + row) < g.n_rows &&
-                            g.H1[((int64_t)e * g.n_rows + m0 + row) * H + col] > 0.0f;
-            h1mask = (h1mask << 1) | (on ? 1u : 0u);
-        });
-    } else {
-        const float *X = g.X + (int64_t)e * g.sX;
-        DirectB<TMR, false> db1, db2;
-        db1.init(P + g.off[0], IN, H, IN, lane, col0);
-        start_direct<TMR, false>(db1, fb, IN);
-        db2.init(P + g.off[2], H, H, H, lane, col0);
-        for (int i = tid; i < H; i += NTHR) { b1s[i] = P[g.off[1] + i]; b2s[i] = P[g.off[3] + i]; }
-        if (tid < OUT) b3s[tid] = P[g.off[5] + tid];
-        stage_head_weights(w3s, P + g.off[4], OUT, H, ldw3, tid);
-        for (int r = tid >> 5; r < TMR; r += NTHR / 32) {
-            const bool rok = (m0 + r) < g.n_rows;
-            const float *xr = X + (rok ? (int64_t)(m0 + r) * g.ldx : 0);
-            for (int k = tid & 31; k < KP; k += 32) {
-                const bool ok = rok && k < IN;
-                const float v = xr[ok ? k : 0];
-                xs[r * ldx_s + k] = ok ? v : 0.0f;
-            }
-        }
-        __syncthreads();
-        STAMP(1);
-        // ---- fc1
-        T::zero(acc);
-        gemm_direct<TMR, false>(acc, xs, ldx_s, IN, db1, fb, lane);
-        STAMP(2);
-        start_direct<TMR, false>(db2, fb, H);  // fc2's first chunks go in flight under fc1's epilogue
-        T::foreach(acc, lane, [&](int row, int cw, float val) {
-            const int col = col0 + cw;
-            float v = 0.0f;
-            if (col < H) {
-                v = fmaxf(val + b1s[col], 0.0f);
-                h1s[row * ldh + col] = v;
-                if (g.H1 && (m0 + row) < g.n_rows) g.H1[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
-            }
-            h1mask = (h1mask << 1) | (v > 0.0f ? 1u : 0u);
-        });
-        __syncthreads();
-        STAMP(3);
-        // ---- fc2
-        T::zero(acc);
-        gemm_direct<TMR, false>(acc, h1s, ldh, H, db2, fb, lane);
-        STAMP(4);
-        if (MODE == MODE_CRITIC) start_direct<TMR, true>(db3, fb, H);  // backward-data's W2 chunks in flight
-        T::foreach(acc, lane, [&](int row, int cw, float val) {
-            const int col = col0 + cw;
-            if (col < H) {
-                const float v = fmaxf(val + b2s[col], 0.0f);
-                h2s[row * ldh + col] = v;
-                if (g.H2 && (m0 + row) < g.n_rows) g.H2[((int64_t)e * g.n_rows + m0 + row) * H + col] = v;
-            }
-        });
-        __syncthreads();  // h2 visible; every wave is done reading h1s, which now becomes `hpart`
-        STAMP(5);
-        STAMP(6);
-        // ---- head on the matrix cores (see fused_mlp_kernel)
-        {
-            // 16 head outputs at a time (heads wider than one MFMA tile, e.g. a 34-output actor, take several passes)
-            const int li = lane & 15, lg = lane >> 4;
-            for (int ob = 0; ob < ldo; ob += 16) {
-                f32x4 hacc[TMR / 16];
-#pragma unroll
-                for (int q = 0; q < TMR / 16; ++q)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) hacc[q][i] = 0.0f;
-                if (col0 < H) {  // col0 = 32*wave doubles as this wave's k-slice start
-                    const int lo = ob + li;
-                    const f4 *bp = reinterpret_cast<const f4 *>(w3s + (lo < OUT ? lo : 0) * ldw3 + col0 + lg * 8);
-                    const float keep = lo < OUT ? 1.0f : 0.0f;  // rows >= OUT of the 16-wide B tile are zero
-                    const f4 b0 = bp[0] * keep, b1 = bp[1] * keep;
-#pragma unroll
-                    for (int q = 0; q < TMR / 16; ++q) {
-                        const f4 *ap = reinterpret_cast<const f4 *>(h2s + (16 * q + li) * ldh + col0 + lg * 8);
-                        const f4 a0 = ap[0], a1 = ap[1];
-#pragma unroll
-                        for (int t = 0; t < 8; ++t)
-                            hacc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(t < 4 ? a0[t & 3] : a1[t & 3],
-                                                                           t < 4 ? b0[t & 3] : b1[t & 3], hacc[q], 0, 0, 0);
-                    }
-                }
-                if (ob > 0) __syncthreads();  // the previous block's partials have been summed
-#pragma unroll
-                for (int q = 0; q < TMR / 16; ++q)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        hpart[(wave * TMR + 16 * q + 4 * lg + r) * MAX_OUT + li] = hacc[q][r];
-                __syncthreads();
-                const int row = tid >> 4, o = ob + (tid & 15);
-                if (row < TMR && o < OUT) {
-                    float v = b3s[o];
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) v += hpart[(w * TMR + row) * MAX_OUT + (tid & 15)];
-                    ys[row * ldo + o] = v;
-                    if (g.Y && (m0 + row) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + row) * OUT + o] = v;
-                }
-            }
-        }
-    }
-    STAMP(7);
-    if (MODE == MODE_PLAIN) return;
-    __syncthreads();
-
-    if (MODE == MODE_SAMPLE) {
-        // one thread per (row, action dimension) for the transcendental work, then one per row sums the
-        // dimensions' log-probability terms in index order (the order a serial loop would use)
-        const int A = OUT >> 1;
-        float *lpt = dqs;  // [TMR][MAX_OUT] scratch, unused in this mode
-        for (int t = tid; t < TMR * A; t += NTHR) {
-            const int r = t / A, i = t - r * A, b = m0 + r;
-            if (b < g.n_rows) {
-                const float mu = ys[r * ldo + i], raw = ys[r * ldo + A + i];
-                const float log_std = g.lo + 0.5f * (g.hi - g.lo) * (tanhf(raw) + 1.0f);
-                const float sd = expf(log_std);
-                const float ep = g.eps ? g.eps[(int64_t)b * A + i] : philox_normal(g.rng.seed, rng_draw(g.rng), b, i);
-                const float u = mu + sd * ep;
-                const float dlt = u - mu;
-                lpt[r * ldo + i] = (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -
-                                       2.0f * (LOG_2 - u - softplus_f(-2.0f * u));
-                g.act_dst[b * g.ld_act + g.act_col0 + i] = tanhf(u);
-            }
-        }
-        __syncthreads();
-        if (g.logp && tid < TMR && (m0 + tid) < g.n_rows) {
-            float lp = 0.0f;
-            for (int i = 0; i < A; ++i) lp += lpt[tid * ldo + i];
-            g.logp[m0 + tid] = lp;
-        }
-        return;
-    }
-
-    if (IS_CRITIC) {
-        // ---- loss gradient per row (learning.py:90-98, 112)
-        const float pw = (g.popart && g.pop) ? g.popart->w : 1.0f;
-        const float pb = (g.popart && g.pop) ? g.popart->b : 0.0f;
-        const float gscale = -2.0f * pw / (g.denom * (float)g.n_rows);
-        float lossv = 0.0f, errv = 0.0f;  // this row's loss terms (threads < TMR), summed over wave 0 below
-        if (tid < TMR) {
-            const int b = m0 + tid;
-            int ai = 0;
-            float dsel = 0.0f;
-            if (b < g.n_rows) {
-                if (OUT > 1) ai = (int)rowin[2 * TMR + tid];
-                const float w = rowin[TMR + tid];
-                const float err = rowin[tid] - (pw * ys[tid * ldo + ai] + pb);
-                lossv = w * err * err;
-                errv = err;
-                dsel = gscale * w * err;
-            }
-            for (int o = 0; o < OUT; ++o) {
-                const float d = (o == ai) ? dsel : 0.0f;
-                dqs[tid * ldo + o] = d;
-                if (b < g.n_rows) g.DQ[((int64_t)e * g.n_rows + b) * OUT + o] = d;
-            }
-        }
-        if (wave == 0) {  // fixed shuffle tree over the tile's rows: no LDS round trip, no serial loop
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { lossv += __shfl_xor(lossv, o, 64); errv += __shfl_xor(errv, o, 64); }
-            if (lane == 0) {
-                const int64_t pi = ((int64_t)e * gridDim.x + bx) * 2;
-                g.partials[pi] = lossv;
-                g.partials[pi + 1] = errv;
-            }
-        }
-        __syncthreads();  // dqs visible to every wave
-        STAMP(8);
-        // ---- head backward: dz2 = (dq W3) (.) [h2 > 0], in place over h2s
-        {
-            const int k = tid & 255;
-            if (k < H) {
-                // all of this thread's h2 values are loaded before the first in-place store (the compiler cannot
-                // prove the stores do not alias the later loads, and would serialise the LDS round trips)
-                constexpr int NR = TMR / 2;
-                const int r0 = tid >> 8;
-                float hv[NR], gs[NR];
-#pragma unroll
-                for (int j = 0; j < NR; ++j) { hv[j] = h2s[(r0 + 2 * j) * ldh + k]; gs[j] = 0.0f; }
-                for (int o = 0; o < OUT; ++o) {
-                    const float w = w3s[o * ldw3 + k];
-#pragma unroll
-                    for (int j = 0; j < NR; ++j) gs[j] += dqs[(r0 + 2 * j) * ldo + o] * w;
-                }
-#pragma unroll
-                for (int j = 0; j < NR; ++j) {
-                    const int r = r0 + 2 * j;
-                    const float dz = hv[j] > 0.0f ? gs[j] : 0.0f;
-                    h2s[r * ldh + k] = dz;
-                    if ((m0 + r) < g.n_rows) g.DZ2[((int64_t)e * g.n_rows + m0 + r) * H + k] = dz;
-                }
-            }
-        }
-        __syncthreads();
-        STAMP(9);
-        // ---- backward-data of fc2: dz1 = (dz2 W2) (.) [h1 > 0]
-        T::zero(acc);
-        gemm_direct<TMR, true>(acc, h2s, ldh, H, db3, fb, lane);
-        STAMP(10);
-        constexpr int NEL = TMR == 32 ? 16 : 8;
-        int el = 0;
-        T::foreach(acc, lane, [&](int row, int cw, float val) {
-            const int col = col0 + cw;
-            const bool on = (h1mask >> (NEL - 1 - el)) & 1u;
-            ++el;
-            if (col < H && (m0 + row) < g.n_rows)
-                g.DZ1[((int64_t)e * g.n_rows + m0 + row) * H + col] = on ? val : 0.0f;
-        });
-        STAMP(11);
-    }
-}
-
-size_t direct_lds_bytes(int in_dim, int hidden, int out_dim, int tm) {
-    const int KP = (in_dim + 31) & ~31;
-    size_t front = (size_t)tm * (KP + APAD) + (size_t)tm * (hidden + APAD);
-    if (front < (size_t)8 * tm * MAX_OUT) front = (size_t)8 * tm * MAX_OUT;
-    const int ldo = (out_dim + 15) & ~15;
-    return sizeof(float) * (front + (size_t)tm * (hidden + APAD) + 2 * tm * ldo + 64 + 2 * hidden + HEAD_MAX +
-                            (size_t)out_dim * (hidden + APAD) + 3 * tm);
-}
-
 long long *g_fused_dbg = nullptr;
 
 int g_tile_rows = 0;  // 0 = automatic, else 16 or 32 (ssac_fused_tile_rows)
@@ -1428,18 +1063,16 @@ size_t fused_lds_bytes(int in_dim, int hidden, int out_dim, int tm = TM, bool db
                             2 * hidden + HEAD_MAX + (size_t)out_dim * (hidden + APAD) + 3 * tm);
 }
 
-// Kernel variant for one launch.  g_tile_rows (ssac_fused_tile_rows) forces one: 16 / 32 = staged weights,
-// double buffered; 17 = staged, 16 rows, single buffer; 116 / 132 = direct-B with 16 / 32 rows.
-struct TileChoice { int tm; int variant; };  // variant 0 staged double buffer, 1 staged single buffer, 2 direct-B
+// Kernel variant for one launch.  g_tile_rows (ssac_fused_tile_rows) forces one: 16 / 32 = double-buffered weight
+// staging; 17 = 16 rows, single staging buffer (wide input + wide head shapes need it).
+struct TileChoice { int tm; int variant; };  // variant 0 double-buffered staging, 1 single buffer
 
 TileChoice choose_tile(const FusedArgs &g, int n_sel) {
     const bool fits32 = fused_lds_bytes(g.in_dim, g.hidden, g.out_dim, 32) <= 160 * 1024;
     // a wide input together with a wide head (e.g. 376 -> 34): only the single-buffer carve fits
-    if (fused_lds_bytes(g.in_dim, g.hidden, g.out_dim, 16) > 160 * 1024 && g_tile_rows < 100) return {16, 1};
+    if (fused_lds_bytes(g.in_dim, g.hidden, g.out_dim, 16) > 160 * 1024) return {16, 1};
     switch (g_tile_rows) {
         case 17: return {16, 1};
-        case 116: return {16, 2};
-        case 132: return {direct_lds_bytes(g.in_dim, g.hidden, g.out_dim, 32) <= 160 * 1024 ? 32 : 16, 2};
         case 16: return {16, 0};
         case 32: return {fits32 ? 32 : 16, 0};
         default: break;
@@ -1484,27 +1117,9 @@ int launch_fused_t(const FusedArgs &g, int n_sel, hipStream_t st) {
     return ssac_check_launch("fused_mlp");
 }
 
-template <int MODE, int TMR>
-int launch_direct_t(const FusedArgs &g, int n_sel, hipStream_t st) {
-    static bool attr_set = false;
-    const size_t lds = direct_lds_bytes(g.in_dim, g.hidden, g.out_dim, TMR);
-    if (lds > 160 * 1024) return ssac_fail("fused_direct: LDS carve does not fit");
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)fused_direct_kernel<MODE, TMR>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return ssac_fail("fused_direct: cannot raise the dynamic LDS limit");
-        attr_set = true;
-    }
-    dim3 grid((g.n_rows + TMR - 1) / TMR, n_sel);
-    SSAC_LAUNCH((fused_direct_kernel<MODE, TMR>), grid, dim3(NTHR), lds, st, g);
-    return ssac_check_launch("fused_direct");
-}
-
 template <int MODE>
 int launch_fused(const FusedArgs &g, int n_sel, hipStream_t st) {
     const TileChoice c = choose_tile(g, n_sel);
-    if (c.variant == 2)
-        return c.tm == 16 ? launch_direct_t<MODE, 16>(g, n_sel, st) : launch_direct_t<MODE, 32>(g, n_sel, st);
     if (c.variant == 1) return launch_fused_t<MODE, 16, false>(g, n_sel, st);
     return c.tm == 16 ? launch_fused_t<MODE, 16, true>(g, n_sel, st) : launch_fused_t<MODE, 32, true>(g, n_sel, st);
 }
@@ -1556,6 +1171,25 @@ extern "C" int ssac_actor_sample_fused(const ssac_mlp *actor, const float *X, in
     g.eps = eps; g.lo = log_std_lo; g.hi = log_std_hi;
     if (rng) g.rng = RngArgs{rng->seed, rng->counter, rng->offset};
     g.act_dst = act_dst; g.ld_act = ld_act; g.act_col0 = act_col0; g.logp = logp;
+    return launch_fused<MODE_SAMPLE>(g, 1, (hipStream_t)stream);
+}
+
+// ssac_actor_sample_fused that also copies the state columns next to the sampled action: act_dst rows become the
+// critics' input [s | a_theta] (mlps.py:124) without a separate copy launch
+extern "C" int ssac_actor_sample_concat_fused(const ssac_mlp *actor, const float *X, int64_t ldx, int n_rows,
+                                              const float *eps, float log_std_lo, float log_std_hi, float *xsa,
+                                              int64_t ld_xsa, float *logp, float *H1, float *H2, float *out,
+                                              const ssac_rng *rng, void *stream) {
+    if (!eps && !rng) return ssac_fail("ssac_actor_sample_concat_fused: neither eps nor an rng stream given");
+    if (!fused_ok(actor) || (actor->out_dim & 1)) return ssac_fail("ssac_actor_sample_concat_fused: shape not supported");
+    if (!xsa || ld_xsa < actor->in_dim + actor->out_dim / 2) return ssac_fail("ssac_actor_sample_concat_fused: bad output");
+    if (n_rows <= 0) return 0;
+    FusedArgs g{};
+    fill_common(g, actor, nullptr, X, ldx, 0, n_rows);
+    g.H1 = H1; g.H2 = H2; g.Y = out;
+    g.eps = eps; g.lo = log_std_lo; g.hi = log_std_hi;
+    if (rng) g.rng = RngArgs{rng->seed, rng->counter, rng->offset};
+    g.act_dst = xsa; g.ld_act = ld_xsa; g.act_col0 = actor->in_dim; g.logp = logp; g.copy_x = 1;
     return launch_fused<MODE_SAMPLE>(g, 1, (hipStream_t)stream);
 }
 
@@ -1763,6 +1397,39 @@ extern "C" int ssac_critic_bwd_fused(const ssac_mlp *nets, int n_rows, const flo
     return launch_fused<MODE_CRITIC_BWD>(g, nets->n_nets, (hipStream_t)stream);
 }
 
+// ---- the online actor update's two fused launches (learning.py:344-421; csrc notes at MODE_ACTOR_BWD / DXU)
+extern "C" int ssac_critic_fwd_dx_fused(const ssac_mlp *nets, const float *X, int64_t ldx, int n_rows, int dx_col0,
+                                        int dx_cols, float *Q, float *DXu, void *stream) {
+    if (!fused_dbuf_ok(nets) || nets->out_dim != 1)
+        return ssac_fail("ssac_critic_fwd_dx_fused: single-output critics on the fused path only");
+    if (!X || !Q || !DXu || dx_col0 < 0 || dx_cols <= 0 || dx_col0 + dx_cols > nets->in_dim)
+        return ssac_fail("ssac_critic_fwd_dx_fused: bad arguments");
+    if (n_rows <= 0) return 0;
+    FusedArgs g{};
+    fill_common(g, nets, nullptr, X, ldx, 0, n_rows);
+    g.Y = Q; g.DXU = DXu; g.dx_col0 = dx_col0; g.dx_cols = dx_cols;
+    return launch_fused<MODE_CRITIC_U>(g, nets->n_nets, (hipStream_t)stream);
+}
+
+extern "C" int ssac_actor_bwd_fused(const ssac_mlp *actor, const float *H1, const float *H2, int n_rows, const float *Qc,
+                                    int n_critics, const float *DXu, const float *aout, const float *eps,
+                                    const float *logp, const float *log_alpha, int use_entropy, float log_std_lo,
+                                    float log_std_hi, float inv_members, const ssac_popart *popart, int pop,
+                                    float *d_out, float *DZ2, float *DZ1, float *partials, void *stream) {
+    if (!fused_ok(actor) || (actor->out_dim & 1)) return ssac_fail("ssac_actor_bwd_fused: shape not supported by the fused path");
+    if (!H1 || !H2 || !Qc || !DXu || !aout || !eps || !log_alpha || !d_out || !DZ2 || !DZ1 || !partials || n_critics < 1 ||
+        (use_entropy && !logp))
+        return ssac_fail("ssac_actor_bwd_fused: missing argument");
+    if (n_rows <= 0) return 0;
+    FusedArgs g{};
+    fill_common(g, actor, nullptr, nullptr, 0, 0, n_rows);
+    g.H1 = const_cast<float *>(H1); g.H2 = const_cast<float *>(H2);
+    g.popart = popart; g.pop = pop; g.DQ = d_out; g.DZ2 = DZ2; g.DZ1 = DZ1;
+    g.ab = ActorBwdArgs{Qc, n_critics, DXu, aout, eps, logp, log_alpha, use_entropy, log_std_lo, log_std_hi, inv_members,
+                        partials};
+    return launch_fused<MODE_ACTOR_BWD>(g, 1, (hipStream_t)stream);
+}
+
 // row tiles the fused critic launch will use for (n_rows, n_nets): sizes the `partials` buffer
 extern "C" int ssac_fused_row_tiles(const ssac_mlp *nets, int n_rows, int n_nets) {
     FusedArgs g{};
@@ -1772,8 +1439,8 @@ extern "C" int ssac_fused_row_tiles(const ssac_mlp *nets, int n_rows, int n_nets
 }
 
 extern "C" int ssac_fused_tile_rows(int rows) {
-    if (rows != 0 && rows != 16 && rows != 17 && rows != 32 && rows != 116 && rows != 132)
-        return ssac_fail("ssac_fused_tile_rows: 0 (auto), 16, 32, 17 (16 rows, single buffer), 116 / 132 (direct-B)");
+    if (rows != 0 && rows != 16 && rows != 17 && rows != 32)
+        return ssac_fail("ssac_fused_tile_rows: 0 (auto), 16, 32, 17 (16 rows, single staging buffer)");
     g_tile_rows = rows;
     return 0;
 }

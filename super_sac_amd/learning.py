@@ -70,6 +70,7 @@ class _LaunchList:
                     pass
 
 
+FUSED_ACTOR = os.environ.get("SSAC_FUSED_ACTOR", "1") == "1"  # the online actor update in four fused launches
 FEED_SLOTS = 32  # pinned input ring of a captured update: how far the host may run ahead of the GPU
 # evaluate the TD target inside the critic launch instead of a launch of its own (continuous, no PopArt)
 SHARDED_LISTS = os.environ.get("SSAC_SHARDED_LISTS", "1") == "1"  # recorded launch lists on critic-sharded ranks
@@ -805,10 +806,48 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
         a_arena = engine.bind_arena(actor, "self", [actor], dev)
         c_arena = critic.arena(dev)
         N = c_arena.n_nets
-        ah1, ah2, aout = engine.mlp_forward(a_arena, s_rep, lds, 0, B, ws, f"au.a{i}")
         kind = lu.actor_kind(actor)
         pp, dopop = (popart.ptr if popart else 0), (1 if (popart and pop) else 0)
         shard = parallel.shard_of(agent)
+        if (FUSED_ACTOR and kind == "stochastic" and random_process is None and not use_baseline and shard is None
+                and not clip and a_arena.fused and c_arena.fused_dbuf and c_arena.out_dim == 1):
+            # ---- four launches instead of ~15 (include/ssac_hip.h, "the online actor update"): sample + [s|a] rows,
+            #      critics' forward + unscaled dQ/da, arg-min routing + tanh-normal backward + actor backward-data,
+            #      weight gradients + Adam; then one launch for the two log values
+            A, H = actor.action_size, a_arena.hidden
+            xpi = ws.get(f"au.x{i}", (B, S + A))
+            logp = ws.get(f"au.logp{i}", (B,))
+            ah1, ah2 = ws.get(f"au.a{i}.h1", (1, B, H)), ws.get(f"au.a{i}.h2", (1, B, H))
+            aout = ws.get(f"au.a{i}.y", (1, B, 2 * A))
+            eps = rng.draw_normal((B, A), dev)  # a_dist.rsample() (learning.py:392)
+            check(lib.ssac_actor_sample_concat_fused(C.byref(a_arena.desc()), s_rep.data_ptr(), lds, B, eps.data_ptr(),
+                                                     float(actor.log_std_low), float(actor.log_std_high),
+                                                     xpi.data_ptr(), S + A, logp.data_ptr(), ah1.data_ptr(),
+                                                     ah2.data_ptr(), aout.data_ptr(), 0, st))
+            q = ws.get(f"au.c{i}.y", (N, B, 1))
+            dxu = ws.get(f"au.dxu{i}", (N, B, A))
+            check(lib.ssac_critic_fwd_dx_fused(C.byref(c_arena.desc()), xpi.data_ptr(), S + A, B, S, A, q.data_ptr(),
+                                               dxu.data_ptr(), st))
+            tiles = int(lib.ssac_fused_row_tiles(C.byref(a_arena.desc()), B, 1))
+            parts = ws.get(f"au.parts{i}", (tiles,))
+            d_out = ws.get(f"au.dout{i}", (1, B, 2 * A))
+            dz2, dz1 = ws.get(f"au.a{i}.dz2", (1, B, H)), ws.get(f"au.a{i}.dz1", (1, B, H))
+            check(lib.ssac_actor_bwd_fused(C.byref(a_arena.desc()), ah1.data_ptr(), ah2.data_ptr(), B, q.data_ptr(), N,
+                                           dxu.data_ptr(), aout.data_ptr(), eps.data_ptr(), logp.data_ptr(),
+                                           log_alpha.data_ptr(), 1, float(actor.log_std_low),
+                                           float(actor.log_std_high), inv_e, pp, dopop, d_out.data_ptr(),
+                                           dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), st))
+            ttot = engine.wgrad_tiles_total(a_arena)
+            ss = ws.get(f"au.ss{i}", (ttot,))
+            engine.weight_grads(a_arena, s_rep, lds, 0, ah1, ah2, d_out, dz2, dz1, B, adam=adam,
+                                adam_key=("actor", i), sumsq=ss)
+            one = len(agent.actors) == 1   # (then the logged actor is this one: both logs in one launch)
+            check(lib.ssac_actor_logs(parts.data_ptr(), tiles, B, inv_e, ss.data_ptr() if one else 0, ss.numel(),
+                                      slot[lu.L_ACTOR_LOSS:].data_ptr(), slot[lu.L_ACTOR_GN:].data_ptr() if one else 0,
+                                      st))
+            member_ss.append(None if one else ss)
+            continue
+        ah1, ah2, aout = engine.mlp_forward(a_arena, s_rep, lds, 0, B, ws, f"au.a{i}")
         if kind == "discrete":
             A = a_arena.out_dim
             _, _, q = engine.mlp_forward(c_arena, s_rep, lds, 0, B, ws, f"au.c{i}", save=False)
@@ -900,8 +939,9 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
             ar.sync_shadow()
     pick = rng.choice(agent.actors)  # learning.py:417-419
     k = next(j for j, a_ in enumerate(agent.actors) if a_ is pick)
-    check(lib.ssac_group_norms(member_ss[k].data_ptr(), 1, member_ss[k].numel(),
-                               adam.ctl.ptr if clip else 0, slot[lu.L_ACTOR_GN:].data_ptr(), st))
+    if member_ss[k] is not None:  # (None: the fused path's log launch wrote the norm already)
+        check(lib.ssac_group_norms(member_ss[k].data_ptr(), 1, member_ss[k].numel(),
+                                   adam.ctl.ptr if clip else 0, slot[lu.L_ACTOR_GN:].data_ptr(), st))
     logs["gradients/random_actor_online_grad"] = slot[lu.L_ACTOR_GN]
     logs["losses/actor_pg_loss"] = slot[lu.L_ACTOR_LOSS]
     return logs

@@ -99,8 +99,7 @@ def test_ensemble_q_known_answers_from_reference(ssa):
     _close(q[:, :, 0], torch.from_numpy(f["ensq_q"]), 5e-5, what="ensemble Q")
 
 
-@pytest.fixture(params=[16, 17, 32, 116, 132],
-                ids=["tile16", "tile16-single-buffer", "tile32", "direct16", "direct32"])
+@pytest.fixture(params=[16, 17, 32], ids=["tile16", "tile16-single-buffer", "tile32"])
 def tile_rows(request, ssa):
     """run the fused kernels with 16-row (16x16x4 MFMA) and 32-row (32x32x2 MFMA) tiles"""
     ssa._lib.check(ssa._lib.lib.ssac_fused_tile_rows(request.param))

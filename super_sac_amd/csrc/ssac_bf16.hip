@@ -75,7 +75,7 @@ struct BfArgs {
                                     // 2 critic half, 4 rows from X with the subset ids read from the input slot
     long long *dbg;                 // optional s_memtime phase stamps of tile 0 (ssac_bf16_debug_stamps)
 };
-#define BSTAMP(i) do { if (g.dbg && bx == 0 && e == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define BSTAMP(i) do { if (g.dbg && dbg_off >= 0 && bx == 0 && e == 0 && threadIdx.x == 0) g.dbg[dbg_off + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // ---- one layer as D[b][n] = sum_k act[b][k] W[n][k] on v_mfma_f32_32x32x16_bf16.  A = the tile's 32 activation rows in
 // LDS (lane (b = lane & 31, half = lane >> 5) reads 8 consecutive k of row b); B = 32 weight rows (row stride ldw, K
@@ -148,7 +148,8 @@ __host__ __device__ inline size_t bf_lds_bytes(int in_dim, int hidden, int out_d
 }
 
 template <int MODE>
-__device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem, const int bx, const int e) {
+__device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem, const int bx, const int e,
+                                            const int dbg_off = 0) {
     const int H = g.hidden, IN = g.in_dim, OUT = g.out_dim, K1P = g.sg.k1p;
     const int ldo = (OUT + 31) & ~31;
     const int ldx_s = K1P + LPAD, ldh = H + LPAD;
@@ -445,17 +446,16 @@ __global__ __launch_bounds__(NTHR) void bf_chain_kernel(BfArgs ga, BfArgs ga_res
     }
     if (bid < tiles_t) {
         const int j = bid / grid_x, bx = bid - j * grid_x;
-        if (j == 0) bf_mlp_body<MODE_SAMPLE>(ga, smem, bx, 0);
-        else bf_mlp_body<MODE_SAMPLE>(ga_rest, smem, bx, 0);
+        // (kernel parameters are never written to -- that would copy them to scratch; the phase stamps of the actor
+        //  pass go to slots 0.., of subset slot 0's target-critic pass to 16.., of the critic half to 32..)
+        if (j == 0) bf_mlp_body<MODE_SAMPLE>(ga, smem, bx, 0, 0);
+        else bf_mlp_body<MODE_SAMPLE>(ga_rest, smem, bx, 0, -1);
         __threadfence_block();  // this workgroup's a' rows (global) are read back by its own target-critic pass
         __syncthreads();
-        if (gt.dbg && j == 0) gt.dbg += 16;  // (stamps of the second pass: slots 16..)
-        else gt.dbg = nullptr;
-        bf_mlp_body<MODE_PLAIN>(gt, smem, bx, j);
+        bf_mlp_body<MODE_PLAIN>(gt, smem, bx, j, j == 0 ? 16 : -1);
     } else {
         const int L = bid - tiles_t;
-        if (gc.dbg) gc.dbg += 32;  // (stamps of the critic half: slots 32..)
-        bf_mlp_body<MODE_CRITIC_U>(gc, smem, L % grid_x, L / grid_x);
+        bf_mlp_body<MODE_CRITIC_U>(gc, smem, L % grid_x, L / grid_x, 32);
     }
 }
 

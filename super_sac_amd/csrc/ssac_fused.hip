@@ -449,14 +449,16 @@ __device__ __forceinline__ void stage_head_weights(float *w3s, const float *__re
 }
 
 #define STAMP(i) do { if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
-#define BSTAMP(i) do { if (g.dbg && bx == 0 && e == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define BSTAMP(i) do { if (g.dbg && dbg_off >= 0 && bx == 0 && e == 0 && threadIdx.x == 0) g.dbg[dbg_off + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // DBUF = false: 2 workgroups per CU (needs <= 128 VGPRs and <= 80 KB of LDS each)
 // (bx, e, grid_x) = tile index, net slot and number of row tiles of the launch this workgroup works for -- blockIdx /
 // gridDim of a plain launch, or the position inside one half of a merged launch (fused_dual_kernel).
+// dbg_off: slot offset of this role's phase stamps in the debug buffer (-1: none); the kernel parameters themselves are
+// never modified (a by-value parameter that is written to is copied to scratch memory, all ~500 bytes of it)
 template <int MODE, int TMR, bool DBUF>
 __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, const int bx, const int e,
-                                               const int grid_x) {
+                                               const int grid_x, const int dbg_off = 0) {
     typedef Tile<TMR> T;
     const int H = g.hidden, IN = g.in_dim, OUT = g.out_dim;
     const int ldo = (OUT + 15) & ~15;  // row stride of the per-row head outputs / output gradients in LDS
@@ -1039,16 +1041,15 @@ void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs
     }
     if (bid < tiles_t) {
         const int j = bid / target_grid_x, bx = bid - j * target_grid_x;
-        if (j == 0) fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga, smem, bx, 0, target_grid_x);
-        else { ga_rest.dbg = nullptr; fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga_rest, smem, bx, 0, target_grid_x); }
+        if (j == 0) fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga, smem, bx, 0, target_grid_x, 0);
+        else fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga_rest, smem, bx, 0, target_grid_x, -1);
         __threadfence_block();  // this workgroup's a' rows (global) are read back by its own target-critic pass
         __syncthreads();
-        if (gt.dbg) gt.dbg += 16;  // (phase stamps of the target-critic pass: slots 16.., slot-0 chain only)
-        fused_mlp_body<MODE_PLAIN, 16, true>(gt, smem, bx, j, target_grid_x);
+        // (phase stamps: the actor pass in slots 0.., the target-critic pass of subset slot 0 in 16.., the critics in 32..)
+        fused_mlp_body<MODE_PLAIN, 16, true>(gt, smem, bx, j, target_grid_x, j == 0 ? 16 : -1);
     } else {
         const int L = bid - tiles_t;
-        if (gc.dbg) gc.dbg += 32;  // (phase stamps of the critic workgroup: slots 32..)
-        fused_mlp_body<MODE_CRITIC_U, TC, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x);
+        fused_mlp_body<MODE_CRITIC_U, TC, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x, 32);
     }
 }
 

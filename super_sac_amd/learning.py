@@ -779,16 +779,87 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
     return logs, replay_dicts
 
 
+class _RecordedActor:
+    def __init__(self):
+        self.calls, self.list, self.blk, self.eps, self.index = 0, None, None, None, None
+
+    def __del__(self):
+        if self.list:
+            try:
+                lib.ssac_launch_list_free(self.list)
+            except Exception:
+                pass
+
+
 def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_size, clip,
                         random_process, noise_clip, augmenter, aug_mix, premade_replay_dicts=None,
                         per=False, discrete=False, use_baseline=False):
+    """learning.py:344-421.  On the fused path (continuous stochastic actor, no clipping / exploration process /
+    baseline) the update is four launches + a log launch; called repeatedly on the batch buffers of a recorded critic
+    update (premade_replay_dicts at fixed addresses) it is recorded after two calls and re-issued from ONE C call."""
     engine.require_gpu()
     lu.ensure_adopted(agent, buffer)
+    kw = dict(buffer=buffer, agent=agent, pop=pop, actor_optimizer=actor_optimizer, log_alphas=log_alphas,
+              batch_size=batch_size, clip=clip, random_process=random_process, noise_clip=noise_clip,
+              augmenter=augmenter, aug_mix=aug_mix, premade_replay_dicts=premade_replay_dicts, per=per,
+              discrete=discrete, use_baseline=use_baseline)
+    dev = log_alphas[0].device
+    recordable = (USE_GRAPHS and LAUNCH_MODE == "list" and FUSED_ACTOR and engine.CAPTURE is None
+                  and premade_replay_dicts is not None and not discrete and not clip and random_process is None
+                  and not use_baseline and parallel.shard_of(agent) is None
+                  and lu.is_identity(agent.encoder)
+                  and all(lu.actor_kind(a_) == "stochastic" and engine.bind_arena(a_, "self", [a_], dev).fused
+                          for a_ in agent.actors)
+                  and all(c_.arena(dev).fused_dbuf and c_.arena(dev).out_dim == 1 for c_ in agent.critics))
+    if not recordable:
+        return _online_actor_update(**kw)
+    ptrs = tuple(lu.encode(agent.encoder, rd_["primary_batch"][0]).data_ptr() for rd_ in premade_replay_dicts)
+    key = (id(actor_optimizer), ptrs, batch_size, bool(pop), tuple(id(la_) for la_ in log_alphas), engine.USE_FUSED)
+    cache = agent.__dict__.setdefault("_ssac_actor_rec", {})
+    rec = cache.get(key)
+    if rec is None:
+        if len(cache) > 8:
+            cache.clear()
+        rec = cache[key] = _RecordedActor()
+    rec.calls += 1
+    if rec.calls <= 2:
+        return _online_actor_update(**kw)
+    A = agent.actors[0].action_size
+    ring = lu.ring_for(dev)
+    if rec.list is None:
+        rec.blk = torch.zeros(lu.LOG_WIDTH, device=dev)
+        rec.eps = [torch.empty(batch_size, A, device=dev) for _ in agent.actors]
+    for e_ in rec.eps:
+        rng.draw_normal_into(e_)  # a_dist.rsample() of every member, in member order (learning.py:392)
+    if rec.list is None:
+        check(lib.ssac_record_begin())
+        try:
+            logs = _online_actor_update(**kw, _rec_blk=rec.blk, _rec_eps=rec.eps)
+        finally:
+            rec.list = lib.ssac_record_end()
+        base = rec.blk.data_ptr()
+        rec.index = {k_: (v.data_ptr() - base) // 4 for k_, v in logs.items()}
+    else:
+        check(lib.ssac_replay(rec.list, engine.stream()))
+        rng.choice(agent.actors)  # learning.py:417-419 (keeps the Python RNG stream in step)
+    slot_i = ring.advance()
+    ring.buf[slot_i].copy_(rec.blk)   # this call's log block -> its own ring slot (device-to-device, no sync)
+    blk = ring.buf[slot_i]
+    return {k_: blk[i] for k_, i in rec.index.items()}
+
+
+def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_size, clip,
+                         random_process, noise_clip, augmenter, aug_mix, premade_replay_dicts=None,
+                         per=False, discrete=False, use_baseline=False, _rec_blk=None, _rec_eps=None):
     E = agent.ensemble_size
     dev = log_alphas[0].device
     ws = lu.agent_ws(agent, dev)
     adam = engine.adam_group(actor_optimizer, dev)
-    slot = lu.log_block(dev, adam)
+    if _rec_blk is not None:
+        slot = _rec_blk   # recorded update: a fixed log block, cleared (and the Adam step advanced) by a recorded launch
+        check(lib.ssac_begin_update(slot.data_ptr(), lu.LOG_WIDTH, adam.ctl.ptr, 0, engine.stream()))
+    else:
+        slot = lu.log_block(dev, adam)
     logs = {}
     st = engine.stream()
     inv_e = 1.0 / len(agent.actors)
@@ -819,7 +890,10 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
             logp = ws.get(f"au.logp{i}", (B,))
             ah1, ah2 = ws.get(f"au.a{i}.h1", (1, B, H)), ws.get(f"au.a{i}.h2", (1, B, H))
             aout = ws.get(f"au.a{i}.y", (1, B, 2 * A))
-            eps = rng.draw_normal((B, A), dev)  # a_dist.rsample() (learning.py:392)
+            if _rec_eps is not None:
+                eps = _rec_eps[i]   # recorded update: the draw was written into a fixed buffer by the caller
+            else:
+                eps = rng.draw_normal((B, A), dev)  # a_dist.rsample() (learning.py:392)
             check(lib.ssac_actor_sample_concat_fused(C.byref(a_arena.desc()), s_rep.data_ptr(), lds, B, eps.data_ptr(),
                                                      float(actor.log_std_low), float(actor.log_std_high),
                                                      xpi.data_ptr(), S + A, logp.data_ptr(), ah1.data_ptr(),

@@ -37,10 +37,6 @@ constexpr int LPAD = 8;     // LDS row padding (elements): 16-byte aligned rows,
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 constexpr float LOG_2 = 0.69314718055994530942f;
 
-// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global loads / stores.
-// __syncthreads() also drains vmcnt, which would stall every phase boundary on the weight fragments prefetched for the
-// NEXT phase and on the (slow, fire-and-forget) transposed activation stores.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ unsigned short f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }

@@ -344,7 +344,7 @@ __device__ __forceinline__ void pipe_step(typename Tile<TMR>::Acc &acc, Stage &s
     if (has2) st.load((c + 2) * 32, K);
     if (!has1) nx.load(0, Knext);  // last chunk: the NEXT phase's first weight chunk goes in flight
     Tile<TMR>::template mfma_half<NN>(acc, cur, 0);
-    __syncthreads();
+    lds_barrier();  // (LDS hand-off only: the loads of chunk c+2 stay in flight)
     if (has1) Tile<TMR>::template read<NN>(nf, As, lda, nxt, c + 1, tid & 63, col0);
     Tile<TMR>::template mfma_half<NN>(acc, cur, 1);
 }
@@ -366,7 +366,7 @@ __device__ __forceinline__ void pipe_steady(typename Tile<TMR>::Acc &acc, Stage 
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
-    __syncthreads();
+    lds_barrier();  // (LDS hand-off only: the loads of chunk c+2 stay in flight)
     Tile<TMR>::template read<NN>(nf, As, lda, nxt, c + 1, tid & 63, col0);
     Tile<TMR>::template mfma_half<NN>(acc, cur, 1);
 #pragma unroll

@@ -288,7 +288,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     storeA(buf0);
     storeB(buf0 + TILE_FLOATS);
     if (iters > 1) { loadA((KS + kg) * BK); loadB((KS + kg) * BK); }
-    __syncthreads();
+    lds_barrier();
     float f0a[HT], f0b[HT], f1a[HT], f1b[HT];  // first / second half of the current chunk
     if (iters > 0) rd(f0a, f0b, buf0, 0);
     GSTAMP(1);
@@ -299,7 +299,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
         mm(f0a, f0b);
         if (it + 1 < iters) { storeA(nxt); storeB(nxt + TILE_FLOATS); }
         if (it + 2 < iters) { const int k0 = ((it + 2) * KS + kg) * BK; loadA(k0); loadB(k0); }
-        __syncthreads();
+        lds_barrier();  // (LDS hand-off only: the loads just issued stay in flight over the next half chunk)
         if (it + 1 < iters) rd(f0a, f0b, nxt, 0);
         mm(f1a, f1b);
     }

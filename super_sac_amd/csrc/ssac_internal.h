@@ -70,6 +70,13 @@ inline void ssac_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t 
 // ---------------------------------------------------------------------------------------------
 extern int g_ssac_xcd;
 #ifdef __HIPCC__
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global loads / stores.
+// __syncthreads() also drains vmcnt -- inside a software-pipelined K loop that exposes the round trip of the operand
+// loads issued for the chunk AFTER next at every chunk barrier, and at phase boundaries it stalls on prefetched weights
+// and on fire-and-forget activation stores.  The waitcnt pass still inserts the vmcnt wait in front of the first USE
+// of a loaded register.  Use it only where everything handed over at the barrier went through LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ int ssac_xcd_contiguous(int bid, int nwg, int on) {
     if (!on) return bid;
     const int xcd = bid & 7, slot = bid >> 3, q = nwg >> 3, r = nwg & 7;

@@ -423,6 +423,24 @@ int ssac_bc_logprob_bwd(const float *out, int64_t ld_out, const float *act, int6
                         int n_rows, int act_dim, float log_std_lo, float log_std_hi, float inv_members,
                         float *d_out, int64_t ld_dout, float *logs_member, float *logs_total, void *stream);
 
+/* ---- Markov state-abstraction update (learning.py:266-341): the loss heads beside the MLP / encoder kernels.
+ * The inverse model's head is ssac_bc_logprob_bwd / ssac_bc_discrete_bwd above (log-probability of the DATA action).
+ *
+ * contrastive head (learning.py:300-308): rows [0, n_pos) of z are real transitions (label 1), the rest shuffled ones
+ * (label 0); loss_out[0] = F.binary_cross_entropy(sigmoid(z), labels) (logs clamped at -100 like torch) and
+ * dz = coeff * d loss / d z (through torch's binary_cross_entropy_backward and the sigmoid).  One workgroup. */
+int ssac_bce_sigmoid_bwd(const float *z, int n_pos, int n, float coeff, float *dz, float *loss_out, void *stream);
+/* smoothness term (learning.py:310-311): loss_out[0] = mean_b relu(||s1_b - s_b||_2 / sqrt(dim) - max_dist)^2;
+ * ds1 (and ds = its negative), nullable, receive coeff * d loss / d s1 -- written when accumulate == 0, added to
+ * otherwise (0 where the norm is 0, as torch.norm's backward). */
+int ssac_markov_smoothness_bwd(const float *s, int64_t lds, const float *s1, int64_t lds1, int n_rows, int dim,
+                               float max_dist, float coeff, float *ds, int64_t ldds, float *ds1, int64_t ldds1,
+                               int accumulate, float *loss_out, void *stream);
+/* logs[0..4) = inverse loss (inverse_raw[0] * inverse_scale), contrastive loss, smoothness loss and
+ * markov_loss = ic * inverse + cc * contrastive + sc * smoothness (learning.py:313-317, 337-340) */
+int ssac_markov_logs(const float *inverse_raw, float inverse_scale, const float *contrastive, const float *smoothness,
+                     float inverse_coeff, float contrastive_coeff, float smoothness_coeff, float *logs, void *stream);
+
 /* ---- actor loss gradient, continuous: learning.py:392-408.
  * q (n_nets x n_rows): min over ALL nets (learning.py:402), arg-min routing.
  * dq[j][b] = -(popart_w) / (n_rows*E) for j = argmin_b else 0;  logs[0] += -mean(minq' - bonus)/E,

@@ -761,6 +761,102 @@ def run_afbc_case(name, cfg):
     np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
 
 
+def run_markov_case(name, cfg):
+    """learning.markov_state_abstraction_update on the unmodified reference (main.py:218-224 builds its optimizer over
+    chain(encoder, inverse_model, contrastive_model)); the oracle follows on the recorded draws."""
+    print(f"== {name}")
+    torch.manual_seed(cfg["seed"]); np.random.seed(cfg["seed"]); random.seed(cfg["seed"])
+    B, A, mk, px = cfg["B"], cfg["act"], cfg["markov"], cfg.get("pixels")
+    disc = bool(cfg["discrete"])
+    if px:
+        s, a, r, s1, d = synth.synth_pixel_transitions(cfg["rows"], px["channels"], px["hw"],
+                                                      n_actions=A if disc else None, act_dim=A, seed=cfg["seed"] + 100)
+    else:
+        s, a, r, s1, d = synth.synth_transitions(cfg["rows"], cfg["obs"], A, disc, seed=cfg["seed"] + 100, n_actions=A)
+    rbuf = ref.replay.ReplayBuffer(cfg["cap"])
+    rbuf.load_experience(s, a, r, s1, d)
+    obuf = orc.ReplayOracle(cfg["cap"])
+    obuf.load_experience(s, a, r, s1, d)
+    ra, oa = build_pair(cfg)
+    oa.requires_grad_(True)
+    emb = px["emb"] if px else cfg["obs"]
+    inv_p, con_p = synth_markov_models(cfg)
+    load_mlp(ra.inverse_model, inv_p, ("fc1", "fc2", "act_p" if disc else "fc3"))
+    load_mlp(ra.contrastive_model, con_p, ("fc1", "fc2", "out"))
+    for t in list(inv_p.values()) + list(con_p.values()):
+        t.requires_grad_(True)
+    r_opt = torch.optim.Adam(chain(ra.encoder.parameters(), ra.inverse_model.parameters(),
+                                   ra.contrastive_model.parameters()), lr=cfg["lr"], weight_decay=0, betas=(0.9, 0.999))
+    o_opt = orc.AdamOracle(oa.encoder_params() + [inv_p[k] for k in orc.MLP_KEYS] + [con_p[k] for k in orc.MLP_KEYS],
+                           lr=cfg["lr"])
+    if px and px["aug"] == "drqv2":
+        r_aug = ref.augmentations.AugmentationSequence([ref.augmentations.Drqv2Aug(B)])
+        o_aug = orc.AugOracle("drqv2", B)
+    else:
+        r_aug = ref.augmentations.AugmentationSequence([ref.augmentations.IdentityAug(B)])
+        o_aug = orc.AugOracle("identity", B)
+    aug_mix = px["aug_mix"] if px else 0.0
+    ic, cc, sc = mk["coeffs"]
+    rec = {"n_steps": np.int64(mk["steps"])}
+    for k in range(mk["steps"]):
+        clip = mk["clip"][k]
+        st = torch.get_rng_state()
+        idx = torch.randint(len(rbuf), (B,)).numpy()
+        shift = orc.drqv2_draw_shift(B) if (px and px["aug"] == "drqv2") else None
+        perm = torch.randperm(B)
+        torch.set_rng_state(st)
+        rlogs = rl.markov_state_abstraction_update(
+            buffer=rbuf, agent=ra, optimizer=r_opt, batch_size=B, augmenter=r_aug, aug_mix=aug_mix, discrete=disc,
+            inverse_coeff=ic, contrastive_coeff=cc, smoothness_coeff=sc, smoothness_max_dist=mk["max_dist"],
+            grad_clip=clip)
+        if shift is not None:
+            assert torch.equal(r_aug.aug_list[0].shift, shift), "shift stream mismatch"
+            o_aug.forced = [shift.clone()]
+        ologs, _ = orc.markov_state_abstraction_update(
+            obuf, oa, inv_p, con_p, o_opt, B, o_aug, aug_mix, ic, cc, sc, mk["max_dist"], clip, idx=idx, perm=perm,
+            inv_lo=ra.inverse_model.log_std_low if not disc else -10.0,
+            inv_hi=ra.inverse_model.log_std_high if not disc else 2.0)
+        rec[f"m{k}_idx"], rec[f"m{k}_perm"] = np.asarray(idx, np.int64), perm.numpy().astype(np.int64)
+        if shift is not None:
+            rec[f"m{k}_shift"] = shift.numpy()
+        for key, val in rlogs.items():
+            v = float(val)
+            rec[f"m{k}_log:{key}"] = np.float64(v)
+            assert abs(v - float(ologs[key])) <= 2e-4 * max(1.0, abs(v)), (key, v, ologs[key])
+    r_inv = [p for p in ra.inverse_model.parameters()]
+    r_con = [p for p in ra.contrastive_model.parameters()]
+    dpar = max(maxdiff(r_inv, [inv_p[k] for k in orc.MLP_KEYS]), maxdiff(r_con, [con_p[k] for k in orc.MLP_KEYS]))
+    print(f"   inverse / contrastive params max|diff| {dpar:.3e}")
+    assert dpar < 5e-5
+    rec["final_inverse"] = np.concatenate([p.detach().numpy().ravel() for p in r_inv])
+    rec["final_contrastive"] = np.concatenate([p.detach().numpy().ravel() for p in r_con])
+    if px:
+        re_ = ref_encoder_params(ra.encoder, cfg)
+        # Adam's first steps move a weight by lr * sign-like(g): a weight whose gradient is rounding noise (fc columns
+        # behind a dead ReLU) can step the other way under a different summation order, so the pin is "all but a
+        # handful of the 2M weights agree", not the maximum
+        denc = maxdiff(re_, oa.encoder_params())
+        nbad = sum(int(((a_.detach() - b_.detach()).abs() > 5e-5).sum()) for a_, b_ in zip(re_, oa.encoder_params()))
+        ntot = sum(a_.numel() for a_ in re_)
+        print(f"   encoder params max|diff| {denc:.3e}; {nbad} of {ntot} differ by more than 5e-5")
+        assert nbad <= max(2, ntot // 100000)
+        vals = []
+        for p in re_:
+            flat = p.detach().numpy().ravel()
+            vals.append(flat[synth.fingerprint_indices(flat.size)])
+        rec["finalfp_encoder"] = np.concatenate(vals)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
+
+
+def synth_markov_models(cfg):
+    """seeded inverse / contrastive model weights of a Markov case (the same draw everywhere: generator, tests)"""
+    px = cfg.get("pixels")
+    emb = px["emb"] if px else cfg["obs"]
+    rng_ = np.random.RandomState(cfg["seed"] + 11)
+    inv_out = cfg["act"] if cfg["discrete"] else 2 * cfg["act"]
+    return orc.make_mlp(rng_, 2 * emb, cfg["hidden"], inv_out), orc.make_mlp(rng_, 2 * emb, cfg["hidden"], 1)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     units = {"indices": gen_indices, "popart": gen_popart, "aug": gen_aug, "nets": gen_nets,
@@ -774,4 +870,7 @@ if __name__ == "__main__":
     for name, cfg in synth.AFBC_CASES.items():
         if not only or name in only:
             run_afbc_case(name, cfg)
+    for name, cfg in synth.MARKOV_CASES.items():
+        if not only or name in only:
+            run_markov_case(name, cfg)
     print("golden fixtures written to", OUT)

@@ -1066,3 +1066,56 @@ def offline_actor_update(buffer, per_tree, agent, actor_opt, batch_size, actor_c
         new_prio = (F.relu(adv) + 1e-4).squeeze(1).numpy()
         per_tree.update(rd["priority_idxs"], new_prio)
     return logs, rd, new_prio, weights
+
+
+# --------------------------------------------------------------------------------------
+# Markov state-abstraction update.  learning.py:266-341; nets/mlps.py:44-75 (continuous inverse
+# model), :96-110 (contrastive model), :152-167 (discrete inverse model); main.py:218-224 (its optimizer).
+# --------------------------------------------------------------------------------------
+def markov_state_abstraction_update(buffer, agent, inverse, contrastive, opt, batch_size, augmenter, aug_mix,
+                                    inverse_coeff, contrastive_coeff, smoothness_coeff, smoothness_max_dist,
+                                    grad_clip, idx=None, perm=None, inv_lo=-10.0, inv_hi=2.0):
+    """inverse / contrastive: MLP parameter dicts (make_mlp) of the two side models; opt: AdamOracle over
+    encoder_params + inverse + contrastive (the reference's chain order).  idx / perm: the replay indices and the
+    torch.randperm(batch_size) draw of the reference (drawn here when None)."""
+    rd = sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, idx=idx)
+    o, a, _, o1, _ = rd["primary_batch"]
+    s_rep = encode(agent.encoder, o)          # both WITH gradient (learning.py:294-295)
+    s1_rep = encode(agent.encoder, o1)
+    out = mlp3(inverse, torch.cat((s_rep, s1_rep), dim=-1))[0]
+    if agent.discrete:
+        # Categorical(logits).log_prob(a.squeeze(-1)): (B,)
+        logp = torch.log_softmax(out, dim=-1).gather(-1, a.long()).squeeze(-1)
+        inverse_loss = -logp.mean()
+    else:
+        # SquashedNormal.log_prob of a DATA action is per dimension (B, A): the mean runs over B x A values
+        mu, log_std = tanh_normal_params(out, inv_lo, inv_hi)
+        std = log_std.exp()
+        y = a.clamp(-0.99, 0.99)
+        x = 0.5 * (torch.log1p(y) - torch.log1p(-y))
+        base = -((x - mu) ** 2) / (2.0 * std * std) - log_std - LOG_2PI_HALF
+        ladj = 2.0 * (LOG2 - x - F.softplus(-2.0 * x))
+        inverse_loss = -(base - ladj).mean()
+    if perm is None:
+        perm = torch.randperm(batch_size)
+    s1_neg = s1_rep[perm]
+    labels = torch.cat((torch.ones(batch_size, 1), torch.zeros(batch_size, 1)), dim=0)
+    s_c = torch.cat((s_rep, s_rep), dim=0)
+    s1_c = torch.cat((s1_rep, s1_neg), dim=0)
+    pred = torch.sigmoid(mlp3(contrastive, torch.cat((s_c, s1_c), dim=-1))[0])
+    contrastive_loss = F.binary_cross_entropy(pred, labels)
+    dist = torch.norm(s1_rep - s_rep, dim=-1, p=2) / math.sqrt(s_rep.shape[-1])
+    smoothness_loss = F.relu(dist - smoothness_max_dist).square().mean()
+    loss = inverse_coeff * inverse_loss + contrastive_coeff * contrastive_loss + smoothness_coeff * smoothness_loss
+    opt.zero_grad()
+    loss.backward()
+    inv_p, con_p = [inverse[k] for k in MLP_KEYS], [contrastive[k] for k in MLP_KEYS]
+    if grad_clip is not None:
+        clip_grad_norm(agent.encoder_params() + inv_p + con_p, grad_clip)
+    opt.step()
+    return {"gradients/contrastive_model_grad_norm": grad_norm(con_p),
+            "gradients/inverse_model_grad_norm": grad_norm(inv_p),
+            "gradients/encoder_markovloss_grad_norm": grad_norm(agent.encoder_params()),
+            "losses/markov_loss": loss.item(), "losses/inverse_model_loss": inverse_loss.item(),
+            "losses/contrastive_model_loss": contrastive_loss.item(),
+            "losses/smoothness_loss": smoothness_loss.item()}, rd

@@ -1,0 +1,142 @@
+// Markov state-abstraction update (reference learning.py:266-341): the loss heads that are
+// not plain MLP arithmetic.  The two MLPs (inverse model, contrastive model) and the encoder run on the engine's own
+// forward / backward kernels; the inverse-model head is the behavioural-cloning log-probability kernel
+// (ssac_bc_logprob_bwd / ssac_bc_discrete_bwd).  What is left is row work:
+//
+//   contrastive head   F.binary_cross_entropy(sigmoid(z), labels) over 2B rows, first B labelled 1   (learning.py:300-308)
+//   smoothness term    mean_b relu(||s'_b - s_b|| / sqrt(D) - max_dist)^2                             (learning.py:310-311)
+//   log block          inverse / contrastive / smoothness / total loss                                (learning.py:337-340)
+//
+// Batch-wide means are taken by ONE workgroup in a fixed order (run-to-run deterministic), like every other loss
+// statistic of the update path.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "ssac_internal.h"
+
+namespace {
+
+constexpr int MK_THREADS = 1024;
+
+__device__ __forceinline__ float mk_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// sum over the workgroup, fixed order; scratch: 16 floats of LDS; result broadcast
+__device__ float mk_block_sum(float v, float *scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = mk_wave_sum(v);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float r = scratch[0];
+    for (int w = 1; w < nw; ++w) r += scratch[w];
+    return r;
+}
+
+// p = sigmoid(z); loss = -[y log p + (1-y) log(1-p)] with the logs clamped at -100 (torch's binary_cross_entropy);
+// dL/dz = dL/dp * p(1-p), dL/dp = (p - y) / max(p(1-p), 1e-12) / n  (torch's binary_cross_entropy_backward).
+__global__ __launch_bounds__(MK_THREADS) void bce_sigmoid_bwd_kernel(const float *__restrict__ z, int n_pos, int n,
+                                                                      float coeff, float *__restrict__ dz,
+                                                                      float *__restrict__ loss_out) {
+    __shared__ float scratch[16];
+    float acc = 0.0f;
+    const float inv_n = 1.0f / (float)n;
+    for (int b = threadIdx.x; b < n; b += MK_THREADS) {
+        const float y = b < n_pos ? 1.0f : 0.0f;
+        const float p = 1.0f / (1.0f + expf(-z[b]));
+        const float lp = fmaxf(logf(p), -100.0f), l1p = fmaxf(logf(1.0f - p), -100.0f);
+        acc += -(y * lp + (1.0f - y) * l1p);
+        const float pq = p * (1.0f - p);
+        dz[b] = coeff * ((p - y) / fmaxf(pq, 1e-12f)) * inv_n * pq;
+    }
+    const float tot = mk_block_sum(acc, scratch);
+    if (threadIdx.x == 0) loss_out[0] = tot * inv_n;
+}
+
+// one wave per row: dist_b = ||s1_b - s_b|| / sqrt(D); l_b = relu(dist_b - max_dist)^2; loss = mean_b l_b.
+// d loss / d s1_b = coeff * 2 relu(dist_b - max_dist) / B * (s1_b - s_b) / (||s1_b - s_b|| sqrt(D))  (0 where the norm
+// is 0, as torch's norm backward), d / d s_b = its negative.  ds / ds1: written (accumulate = 0) or added to.
+__global__ __launch_bounds__(MK_THREADS) void smoothness_bwd_kernel(const float *__restrict__ s, int64_t lds,
+                                                                     const float *__restrict__ s1, int64_t lds1,
+                                                                     int n_rows, int dim, float max_dist, float coeff,
+                                                                     float *__restrict__ ds, int64_t ldds,
+                                                                     float *__restrict__ ds1, int64_t ldds1,
+                                                                     int accumulate, float *__restrict__ loss_out) {
+    __shared__ float scratch[16];
+    __shared__ float rowloss[MK_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = MK_THREADS / 64;
+    const float inv_sqrt_d = 1.0f / sqrtf((float)dim);
+    float acc = 0.0f;   // lane 0 of every wave: sum of its rows' losses, rows in increasing order
+    for (int b = wave; b < n_rows; b += nw) {
+        float ss = 0.0f;
+        for (int j = lane; j < dim; j += 64) {
+            const float d = s1[(int64_t)b * lds1 + j] - s[(int64_t)b * lds + j];
+            ss += d * d;
+        }
+        ss = mk_wave_sum(ss);
+        const float nrm = sqrtf(ss);
+        const float ex = fmaxf(nrm * inv_sqrt_d - max_dist, 0.0f);
+        acc += ex * ex;
+        if (ds || ds1) {
+            const float g = nrm > 0.0f ? coeff * 2.0f * ex / (float)n_rows * inv_sqrt_d / nrm : 0.0f;
+            for (int j = lane; j < dim; j += 64) {
+                const float d = s1[(int64_t)b * lds1 + j] - s[(int64_t)b * lds + j];
+                if (ds1) { float *p = ds1 + (int64_t)b * ldds1 + j; *p = (accumulate ? *p : 0.0f) + g * d; }
+                if (ds) { float *p = ds + (int64_t)b * ldds + j; *p = (accumulate ? *p : 0.0f) - g * d; }
+            }
+        }
+    }
+    (void)rowloss;
+    // per-wave partial sums live in lane 0; combine them in wave order
+    __syncthreads();
+    if (lane == 0) scratch[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.0f;
+        for (int w = 0; w < nw; ++w) tot += scratch[w];
+        loss_out[0] = tot / (float)n_rows;
+    }
+}
+
+// logs[0..4) = inverse loss, contrastive loss, smoothness loss, total (learning.py:313-317, 337-340)
+__global__ void markov_logs_kernel(const float *inv_raw, float inv_scale, const float *con, const float *smooth,
+                                   float ic, float cc, float sc, float *logs) {
+    if (threadIdx.x != 0) return;
+    const float li = inv_raw[0] * inv_scale, lc = con[0], ls = smooth[0];
+    logs[0] = li;
+    logs[1] = lc;
+    logs[2] = ls;
+    logs[3] = ic * li + cc * lc + sc * ls;
+}
+
+}  // namespace
+
+extern "C" int ssac_bce_sigmoid_bwd(const float *z, int n_pos, int n, float coeff, float *dz, float *loss_out,
+                                    void *stream) {
+    if (!z || !dz || !loss_out || n <= 0 || n_pos < 0 || n_pos > n) return ssac_fail("ssac_bce_sigmoid_bwd: bad arguments");
+    SSAC_LAUNCH(bce_sigmoid_bwd_kernel, dim3(1), dim3(MK_THREADS), 0, (hipStream_t)stream, z, n_pos, n, coeff, dz,
+                loss_out);
+    return ssac_check_launch("bce_sigmoid_bwd");
+}
+
+extern "C" int ssac_markov_smoothness_bwd(const float *s, int64_t lds, const float *s1, int64_t lds1, int n_rows,
+                                          int dim, float max_dist, float coeff, float *ds, int64_t ldds, float *ds1,
+                                          int64_t ldds1, int accumulate, float *loss_out, void *stream) {
+    if (!s || !s1 || !loss_out || n_rows <= 0 || dim <= 0) return ssac_fail("ssac_markov_smoothness_bwd: bad arguments");
+    SSAC_LAUNCH(smoothness_bwd_kernel, dim3(1), dim3(MK_THREADS), 0, (hipStream_t)stream, s, lds, s1, lds1, n_rows, dim,
+                max_dist, coeff, ds, ldds, ds1, ldds1, accumulate, loss_out);
+    return ssac_check_launch("markov_smoothness_bwd");
+}
+
+extern "C" int ssac_markov_logs(const float *inverse_raw, float inverse_scale, const float *contrastive,
+                                const float *smoothness, float inverse_coeff, float contrastive_coeff,
+                                float smoothness_coeff, float *logs, void *stream) {
+    if (!inverse_raw || !contrastive || !smoothness || !logs) return ssac_fail("ssac_markov_logs: null argument");
+    SSAC_LAUNCH(markov_logs_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, inverse_raw, inverse_scale, contrastive,
+                smoothness, inverse_coeff, contrastive_coeff, smoothness_coeff, logs);
+    return ssac_check_launch("markov_logs");
+}

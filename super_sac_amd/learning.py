@@ -1101,6 +1101,138 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
     return logs
 
 
+def markov_state_abstraction_update(buffer, agent, optimizer, batch_size, augmenter, aug_mix, discrete,
+                                    inverse_coeff, contrastive_coeff, smoothness_coeff, smoothness_max_dist,
+                                    grad_clip):
+    """learning.py:266-341: the self-supervised abstraction loss of "Learning Markov State Abstractions for Deep RL" --
+    inverse model (which action led from s to s'), contrastive model (is (s, s') a real transition; negatives by
+    shuffling s' over the batch) and a smoothness hinge on ||s' - s|| -- trained through ONE optimizer over
+    chain(encoder, inverse_model, contrastive_model) (main.py:218-224).
+
+    The two MLPs run on the engine's forward / backward kernels; a pixel encoder takes s and s' as ONE stacked 2B-row
+    pass (the weight gradients of the two uses add up inside its backward).  Loss heads: ssac_bc_logprob_bwd /
+    ssac_bc_discrete_bwd (log-probability of the data action), ssac_bce_sigmoid_bwd, ssac_markov_smoothness_bwd."""
+    engine.require_gpu()
+    lu.ensure_adopted(agent, buffer)
+    inv, con = agent.inverse_model, agent.contrastive_model
+    dev = next(inv.parameters()).device
+    ws = lu.agent_ws(agent, dev)
+    adam = engine.adam_group(optimizer, dev)
+    slot = lu.log_block(dev, adam)  # a log block of its own; advances the optimizer step
+    st = engine.stream()
+    rd = lu.sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter, aug_mix=aug_mix,
+                                    per=False)
+    o, a, _, o1, _ = rd["primary_batch"]
+    B = batch_size
+    ident = lu.is_identity(agent.encoder)
+    eng = None
+    if ident:
+        s_rep, s1_rep = lu.encode(agent.encoder, o), lu.encode(agent.encoder, o1)
+        D = s_rep.shape[1]
+    else:
+        from . import conv_encoder
+        key = getattr(agent.encoder, "ssac_obs_key", "obs")
+        eng = conv_encoder.conv_engine(agent.encoder, dev)
+        if eng is None:
+            raise NotImplementedError(f"{type(agent.encoder).__name__}: this encoder has no HIP path")
+        D = eng.emb
+        img = ws.get("mk.img", (2 * B,) + tuple(o[key].shape[1:]))
+        img[:B].copy_(o[key])
+        img[B:].copy_(o1[key])   # (device plumbing: the two observation batches behind one another)
+        s_all = ws.get("mk.sall", (2 * B, D))
+        eng.forward(img, s_all, D, True)
+        s_rep, s1_rep = s_all[:B], s_all[B:]
+    # ---- inputs: [s | s'] for the inverse model; [s | s'] over [s | s'[perm]] for the contrastive model
+    perm = rng.draw_permutation(B)
+    perm_dev = perm.to(dev)
+    x_inv = ws.get("mk.xinv", (B, 2 * D))
+    x_inv[:, :D].copy_(s_rep)
+    x_inv[:, D:].copy_(s1_rep)
+    x_con = ws.get("mk.xcon", (2 * B, 2 * D))
+    x_con[:B].copy_(x_inv)
+    x_con[B:, :D].copy_(s_rep)
+    torch.index_select(s1_rep, 0, perm_dev, out=x_con[B:, D:])
+    i_arena = engine.bind_arena(inv, "self", [inv], dev)
+    c_arena = engine.bind_arena(con, "self", [con], dev)
+    ih1, ih2, iout = engine.mlp_forward(i_arena, x_inv, 2 * D, 0, B, ws, "mk.inv")
+    ch1, ch2, cout = engine.mlp_forward(c_arena, x_con, 2 * D, 0, 2 * B, ws, "mk.con")
+    # ---- loss heads (each also leaves its share of d markov_loss / d output)
+    A = inv.action_size
+    if discrete:
+        d_iout = ws.get("mk.dinv", (1, B, A))
+        check(lib.ssac_bc_discrete_bwd(iout.data_ptr(), a.data_ptr(), a.stride(0), 0, B, A, float(inverse_coeff),
+                                       d_iout.data_ptr(), slot[lu.L_MK_RAW:].data_ptr(),
+                                       slot[lu.L_MK_TMP:].data_ptr(), st))
+        inv_scale = 1.0
+    else:
+        # -a_dist.log_prob(a).mean(): the mean runs over the B x A per-dimension log-probabilities (learning.py:298)
+        d_iout = ws.get("mk.dinv", (1, B, 2 * A))
+        check(lib.ssac_bc_logprob_bwd(iout.data_ptr(), 2 * A, a.data_ptr(), a.stride(0), 0, B, A,
+                                      float(inv.log_std_low), float(inv.log_std_high), float(inverse_coeff) / A,
+                                      d_iout.data_ptr(), 2 * A, slot[lu.L_MK_RAW:].data_ptr(),
+                                      slot[lu.L_MK_TMP:].data_ptr(), st))
+        inv_scale = 1.0 / A
+    d_cout = ws.get("mk.dcon", (1, 2 * B, 1))
+    check(lib.ssac_bce_sigmoid_bwd(cout.data_ptr(), B, 2 * B, float(contrastive_coeff), d_cout.data_ptr(),
+                                   slot[lu.L_MK_CON:].data_ptr(), st))
+    d_all = None if ident else ws.get("mk.dall", (2 * B, D))
+    check(lib.ssac_markov_smoothness_bwd(s_rep.data_ptr(), lu._row_stride(s_rep), s1_rep.data_ptr(),
+                                         lu._row_stride(s1_rep), B, D, float(smoothness_max_dist),
+                                         float(smoothness_coeff), engine._ptr(None if ident else d_all[:B]), D,
+                                         engine._ptr(None if ident else d_all[B:]), D, 0,
+                                         slot[lu.L_MK_SMOOTH:].data_ptr(), st))
+    check(lib.ssac_markov_logs(slot[lu.L_MK_RAW:].data_ptr(), inv_scale, slot[lu.L_MK_CON:].data_ptr(),
+                               slot[lu.L_MK_SMOOTH:].data_ptr(), float(inverse_coeff), float(contrastive_coeff),
+                               float(smoothness_coeff), slot[lu.L_MK_LOSS:].data_ptr(), st))
+    # ---- backward: gradients stored (the clip needs the joint norm first), input gradients only for a real encoder
+    members = []
+    for tag, arena, d_out, x, h1, h2, rows in (("mk.inv", i_arena, d_iout, x_inv, ih1, ih2, B),
+                                               ("mk.con", c_arena, d_cout, x_con, ch1, ch2, 2 * B)):
+        grads = ws.get(tag + ".g", (arena.params.numel(),), zero=True)
+        ss = ws.get(tag + ".ss", (engine.wgrad_tiles_total(arena),))
+        dx = engine.mlp_backward(arena, d_out, x, 2 * D, 0, h1, h2, rows, ws, tag, grads=grads, sumsq=ss,
+                                 need_dx=not ident)
+        members.append((arena, ("markov", tag), grads, ss, dx))
+    allss = [members[0][3], members[1][3]]
+    if not ident:
+        dxi, dxc = members[0][4][0], members[1][4][0]
+        d_all[:B] += dxi[:, :D]
+        d_all[:B] += dxc[:B, :D]
+        d_all[:B] += dxc[B:, :D]
+        d_all[B:] += dxi[:, D:]
+        d_all[B:] += dxc[:B, D:]
+        d_all[B:].index_add_(0, perm_dev, dxc[B:, D:])  # (a permutation: every row receives exactly one addend)
+        eng.backward(d_all)
+        ss_enc = ws.get("mk.enc.ss", (int(lib.ssac_sumsq_blocks()),))
+        check(lib.ssac_sumsq(eng.grads.data_ptr(), eng.numel, ss_enc.data_ptr(), st))
+        allss.append(ss_enc)
+    # ---- clip_grad_norm_ over chain(encoder, inverse, contrastive) jointly, then optimizer.step() (learning.py:321-330)
+    cat = torch.cat(allss)
+    check(lib.ssac_clip_coef(adam.ctl.ptr, cat.data_ptr(), cat.numel(), float(grad_clip) if grad_clip else 0.0, 0, st))
+    for arena, key_, grads, _, _ in members:
+        m, v = adam.moments_for(key_, arena.params)
+        check(lib.ssac_adam_step(arena.params.data_ptr(), m.data_ptr(), v.data_ptr(), grads.data_ptr(),
+                                 arena.params.numel(), adam.ctl.ptr, st))
+        arena.sync_shadow()
+    if not ident:
+        m, v = adam.moments_for("conv_encoder", eng.flat)
+        check(lib.ssac_adam_step(eng.flat.data_ptr(), m.data_ptr(), v.data_ptr(), eng.grads.data_ptr(), eng.numel,
+                                 adam.ctl.ptr, st))
+    # ---- logs (learning.py:332-340): the norms are read after the clip rescaled the gradients
+    scale = adam.ctl.ptr if grad_clip else 0
+    for (arena, _, _, ss, _), off in zip(members, (lu.L_MK_GN_INV, lu.L_MK_GN_CON)):
+        check(lib.ssac_group_norms(ss.data_ptr(), 1, ss.numel(), scale, slot[off:].data_ptr(), st))
+    if not ident:
+        check(lib.ssac_group_norms(allss[2].data_ptr(), 1, allss[2].numel(), scale, slot[lu.L_MK_GN_ENC:].data_ptr(), st))
+    return {"gradients/contrastive_model_grad_norm": slot[lu.L_MK_GN_CON],
+            "gradients/inverse_model_grad_norm": slot[lu.L_MK_GN_INV],
+            "gradients/encoder_markovloss_grad_norm": slot[lu.L_MK_GN_ENC],
+            "losses/markov_loss": slot[lu.L_MK_LOSS + 3],
+            "losses/inverse_model_loss": slot[lu.L_MK_LOSS],
+            "losses/contrastive_model_loss": slot[lu.L_MK_LOSS + 1],
+            "losses/smoothness_loss": slot[lu.L_MK_LOSS + 2]}
+
+
 def alpha_update(buffer, agent, optimizers, batch_size, log_alphas, augmenter, aug_mix, target_entropy,
                  premade_replay_dicts, discrete):
     engine.require_gpu()

@@ -48,6 +48,11 @@ def draw_categorical(logits):
     return torch.distributions.Categorical(logits=logits).sample()
 
 
+def draw_permutation(n):
+    """torch.randperm(n) on the CPU default generator (the negatives of the contrastive Markov loss, learning.py:300)."""
+    return torch.randperm(n)
+
+
 def draw_drqv2_shift(batch_size, pad):
     return torch.randint(0, 2 * pad + 1, size=(batch_size, 1, 1, 2))
 

@@ -140,6 +140,29 @@ AFBC_CASES = {
                         steps=[(True, True), (True, True), (True, False)]),
 }
 
+# Markov state-abstraction update (fixtures written by oracle/gen_golden.py::run_markov_case)
+MARKOV_CASES = {
+    # ---- Markov state-abstraction update (learning.py:266-341): steps of markov_state_abstraction_update
+    "markov_vec": dict(obs=17, act=6, hidden=64, N=2, n=2, E=1, B=128, rows=1500, cap=2048, lo=-10.0, hi=2.0,
+                       popart=False, pop=False, discrete=False, actor="stochastic", seed=41, lr=1e-3,
+                       markov=dict(steps=4, coeffs=(1.0, 1.0, 10.0), max_dist=0.01, clip=(None, None, 0.5, 0.5))),
+    "markov_discrete": dict(obs=12, act=5, hidden=64, N=2, n=2, E=1, B=96, rows=1000, cap=1024, lo=-10.0, hi=2.0,
+                            popart=False, pop=False, discrete=True, actor="discrete", seed=42, lr=1e-3,
+                            markov=dict(steps=3, coeffs=(1.0, 0.5, 0.0), max_dist=0.0, clip=(10.0, 10.0, 10.0))),
+    # dmc/drqv2_markov.gin's shape in small: BigPixelEncoder trained through the Markov loss, DrQv2 shift, coeffs 1/1/10
+    "markov_pixels": dict(obs=50, act=4, hidden=64, N=2, n=2, E=1, B=8, rows=48, cap=64, lo=-10.0, hi=2.0,
+                          popart=False, pop=False, discrete=False, actor="deterministic", seed=43, lr=1e-4,
+                          markov=dict(steps=3, coeffs=(1.0, 1.0, 10.0), max_dist=0.01, clip=(None, 1.0, 1.0)),
+                          pixels=dict(kind="big", channels=9, hw=84, emb=50, enc_lr=1e-4, enc_tau=1.0,
+                                      aug="drqv2", aug_mix=1.0)),
+    # visgrid/train.py's shape in small: SmallPixelEncoder, discrete actions, inverse + contrastive only, no augmentation
+    "markov_pixels_discrete": dict(obs=64, act=4, hidden=64, N=2, n=2, E=1, B=8, rows=48, cap=64, lo=-10.0, hi=2.0,
+                                   popart=False, pop=False, discrete=True, actor="discrete", seed=44, lr=3e-4,
+                                   markov=dict(steps=3, coeffs=(1.0, 1.0, 0.0), max_dist=0.0, clip=(None, None, 2.0)),
+                                   pixels=dict(kind="small", channels=4, hw=84, emb=64, enc_lr=3e-4, enc_tau=1.0,
+                                               aug="identity", aug_mix=0.0)),
+}
+
 
 def synth_transitions(rows, obs_dim, act_dim, discrete=False, seed=1, n_actions=None):
     """obs,next_obs ~ N(0,1); act ~ U(-1,1); rew ~ N(0,1); done ~ Bern(0.01)."""

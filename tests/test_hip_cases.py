@@ -245,6 +245,25 @@ def test_afbc_and_per_match_reference(name, fused):
     case_runner.compare_afbc(rec, case_runner.load_fixture(name))
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
+@pytest.mark.parametrize("name", sorted(synth.MARKOV_CASES))
+def test_markov_state_abstraction_update_matches_reference(name, fused):
+    """learning.markov_state_abstraction_update (learning.py:266-341) -- inverse model (tanh-normal
+    / categorical log-probability of the data action), contrastive model on [real | shuffled] transitions with BCE,
+    smoothness hinge, joint clip over encoder + both models, one Adam step -- on vector observations and through
+    both pixel encoders (s and s' as one stacked pass).  Logs within 5e-4 (gradient norms 2e-3), parameters 3e-5."""
+    import super_sac_amd as ssa
+    old = ssa.engine.USE_FUSED
+    ssa.engine.USE_FUSED = fused
+    try:
+        rec = case_runner.run_markov_engine(name)
+    finally:
+        ssa.engine.USE_FUSED = old
+    cfg = synth.MARKOV_CASES[name]
+    case_runner.compare_markov(rec, case_runner.load_fixture(name), f"hip[{name}]",
+                               max_step=2.2 * cfg["lr"] * cfg["markov"]["steps"] if "pixels" in name else 0.0)
+
+
 @pytest.mark.parametrize("name", ["drqv2_pixels", "atari_pixels"])
 def test_pixel_cases_with_implicit_gemm_convolutions(name):
     """the pixel fixtures again with the implicit-GEMM kernels forced on for every eligible layer (the

@@ -189,3 +189,14 @@ def test_oracle_reproduces_afbc_fixture(name):
     recorded indices, weights, priorities, logs and final actor."""
     rec = case_runner.run_afbc_oracle(name)
     case_runner.compare_afbc(rec, case_runner.load_fixture(name), par_tol=1e-6)
+
+
+@pytest.mark.parametrize("name", sorted(synth.MARKOV_CASES))
+def test_oracle_reproduces_markov_fixture(name):
+    """markov_state_abstraction_update (learning.py:266-341): inverse model, contrastive model with
+    the recorded shuffle, smoothness hinge, joint clip and the single optimizer over encoder + both models -- on vector
+    observations (continuous / discrete actions) and through both pixel encoders."""
+    rec = case_runner.run_markov_oracle(name)
+    case_runner.compare_markov(rec, case_runner.load_fixture(name), f"oracle[{name}]", log_tol=2e-4, gn_tol=2e-4,
+                               par_tol=1e-6 if "pixels" not in name else 3e-5,
+                               max_step=2.2 * synth.MARKOV_CASES[name]["lr"] * 3 if "pixels" in name else 0.0)

@@ -441,6 +441,13 @@ int ssac_markov_smoothness_bwd(const float *s, int64_t lds, const float *s1, int
 int ssac_markov_logs(const float *inverse_raw, float inverse_scale, const float *contrastive, const float *smoothness,
                      float inverse_coeff, float contrastive_coeff, float smoothness_coeff, float *logs, void *stream);
 
+/* encoder invariance constraint (learning_utils.py:401-409; learning.py:114-117): loss_out[0] = ||a - b||_F over the
+ * (n_rows x dim) batch (a = encoder(augmented obs), b = encoder(original obs), no gradient to b); d_a (nullable)
+ * receives coeff * d loss / d a -- written when accumulate == 0, added to otherwise; add_to[0] (nullable) += coeff *
+ * loss (the critic update's overall-loss log includes the regulariser, learning.py:133). */
+int ssac_frobenius_diff_bwd(const float *a, int64_t lda, const float *b, int64_t ldb, int n_rows, int dim, float coeff,
+                            float *d_a, int64_t ldd, int accumulate, float *loss_out, float *add_to, void *stream);
+
 /* ---- actor loss gradient, continuous: learning.py:392-408.
  * q (n_nets x n_rows): min over ALL nets (learning.py:402), arg-min routing.
  * dq[j][b] = -(popart_w) / (n_rows*E) for j = argmin_b else 0;  logs[0] += -mean(minq' - bonus)/E,

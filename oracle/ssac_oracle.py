@@ -774,8 +774,11 @@ def critic_update(buffer, agent, target_agent, critic_opt, encoder_opt, log_alph
                   critic_clip, encoder_clip, target_n, temp, weight_type, pop, augmenter,
                   aug_mix=0.0, noise_scale=None, noise_clip=None, py_rng=_pyrandom,
                   idx_list=None, eps_list=None, noise_list=None, subset_list=None, dr3_coeff=0.0,
-                  bw_eps_list=None, bw_cat_list=None, grad_pick=None):
+                  bw_eps_list=None, bw_cat_list=None, grad_pick=None, encoder_lambda=0.0):
     """One gradient update of every critic of every ensemble member.
+    encoder_lambda > 0 adds the encoder invariance constraint (learning.py:114-117, learning_utils.py:401-409) on the
+    LAST member's batch, after the division by E*N: the Frobenius norm of enc(augmented obs) - enc(original obs),
+    the latter without gradient.
     dr3_coeff > 0 adds the DR3 feature co-adaptation term (learning.py:100-108): the fc2 features of every critic
     on (s, a) dotted with its features on (s', a'), mean over critics and batch -- inside the member loop, i.e.
     BEFORE the division by E*N.
@@ -826,6 +829,13 @@ def critic_update(buffer, agent, target_agent, critic_opt, encoder_opt, log_alph
         rd["td_target"] = td
         dicts.append(rd)
     loss = loss / (agent.E * agent.N)
+    if encoder_lambda:
+        oo, ao = rd["original_obs"][0], rd["augmented_obs"][0]
+        with torch.no_grad():
+            os_rep = encode(agent.encoder, oo)
+        inv = torch.norm(encode(agent.encoder, ao) - os_rep)
+        logs["encoder_constraint_loss"] = inv.item()
+        loss = loss + encoder_lambda * inv
     encoder_opt.zero_grad()
     critic_opt.zero_grad()
     loss.backward()

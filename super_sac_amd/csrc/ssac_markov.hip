@@ -67,7 +67,6 @@ __global__ __launch_bounds__(MK_THREADS) void smoothness_bwd_kernel(const float 
                                                                      float *__restrict__ ds1, int64_t ldds1,
                                                                      int accumulate, float *__restrict__ loss_out) {
     __shared__ float scratch[16];
-    __shared__ float rowloss[MK_THREADS / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = MK_THREADS / 64;
     const float inv_sqrt_d = 1.0f / sqrtf((float)dim);
     float acc = 0.0f;   // lane 0 of every wave: sum of its rows' losses, rows in increasing order
@@ -90,7 +89,6 @@ __global__ __launch_bounds__(MK_THREADS) void smoothness_bwd_kernel(const float 
             }
         }
     }
-    (void)rowloss;
     // per-wave partial sums live in lane 0; combine them in wave order
     __syncthreads();
     if (lane == 0) scratch[wave] = acc;
@@ -99,6 +97,40 @@ __global__ __launch_bounds__(MK_THREADS) void smoothness_bwd_kernel(const float 
         float tot = 0.0f;
         for (int w = 0; w < nw; ++w) tot += scratch[w];
         loss_out[0] = tot / (float)n_rows;
+    }
+}
+
+// Encoder invariance constraint (learning_utils.py:401-409): loss = ||A - Bm||_F over the whole (n_rows x dim) batch;
+// d loss / d A = (A - Bm) / ||A - Bm||  (0 where the norm is 0, as torch.norm's backward).  One workgroup: the norm
+// is a fixed-order sum.  d_a (nullable) receives coeff * gradient (written or added), loss_out[0] the norm, and
+// add_to[0] (nullable) += coeff * norm (the critic update's overall-loss log includes the regulariser).
+__global__ __launch_bounds__(MK_THREADS) void frobenius_diff_bwd_kernel(const float *__restrict__ A, int64_t lda,
+                                                                         const float *__restrict__ Bm, int64_t ldb,
+                                                                         int n_rows, int dim, float coeff,
+                                                                         float *__restrict__ d_a, int64_t ldd,
+                                                                         int accumulate, float *__restrict__ loss_out,
+                                                                         float *__restrict__ add_to) {
+    __shared__ float scratch[16];
+    const int n = n_rows * dim;
+    float acc = 0.0f;
+    for (int i = threadIdx.x; i < n; i += MK_THREADS) {
+        const int r = i / dim, c = i - r * dim;
+        const float d = A[(int64_t)r * lda + c] - Bm[(int64_t)r * ldb + c];
+        acc += d * d;
+    }
+    const float nrm = sqrtf(mk_block_sum(acc, scratch));
+    if (d_a) {
+        const float g = nrm > 0.0f ? coeff / nrm : 0.0f;
+        for (int i = threadIdx.x; i < n; i += MK_THREADS) {
+            const int r = i / dim, c = i - r * dim;
+            const float d = A[(int64_t)r * lda + c] - Bm[(int64_t)r * ldb + c];
+            float *p = d_a + (int64_t)r * ldd + c;
+            *p = (accumulate ? *p : 0.0f) + g * d;
+        }
+    }
+    if (threadIdx.x == 0) {
+        loss_out[0] = nrm;
+        if (add_to) add_to[0] += coeff * nrm;
     }
 }
 
@@ -139,4 +171,13 @@ extern "C" int ssac_markov_logs(const float *inverse_raw, float inverse_scale, c
     SSAC_LAUNCH(markov_logs_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, inverse_raw, inverse_scale, contrastive,
                 smoothness, inverse_coeff, contrastive_coeff, smoothness_coeff, logs);
     return ssac_check_launch("markov_logs");
+}
+
+extern "C" int ssac_frobenius_diff_bwd(const float *a, int64_t lda, const float *b, int64_t ldb, int n_rows, int dim,
+                                       float coeff, float *d_a, int64_t ldd, int accumulate, float *loss_out,
+                                       float *add_to, void *stream) {
+    if (!a || !b || !loss_out || n_rows <= 0 || dim <= 0) return ssac_fail("ssac_frobenius_diff_bwd: bad arguments");
+    SSAC_LAUNCH(frobenius_diff_bwd_kernel, dim3(1), dim3(MK_THREADS), 0, (hipStream_t)stream, a, lda, b, ldb, n_rows, dim,
+                coeff, d_a, ldd, accumulate, loss_out, add_to);
+    return ssac_check_launch("frobenius_diff_bwd");
 }

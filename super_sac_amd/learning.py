@@ -118,14 +118,25 @@ def _clip_and_step(adam, members, clip, slot_norm):
                                  arena.params.numel(), adam.ctl.ptr, st))
 
 
-def _encoder_step(encoder, encoder_optimizer, encoder_clip, dX, emb, ws, slot, dev):
+def _encoder_step(encoder, encoder_optimizer, encoder_clip, dX, emb, ws, slot, dev, inv=None):
     """encoder backward from the critics' input gradients + clip + encoder_optimizer.step()
-    (learning.py:121,127-129); logs the (clipped) encoder gradient norm (learning.py:137)."""
+    (learning.py:121,127-129); logs the (clipped) encoder gradient norm (learning.py:137).
+    inv = (as_rep, os_rep, encoder_lambda, stacked): the encoder invariance constraint (learning.py:114-117) adds
+    lambda * d||as_rep - os_rep||_F / d as_rep -- to the critics' rows when the augmented batch IS the critic batch,
+    to rows [B, 2B) of a stacked pass otherwise."""
     from . import conv_encoder
     eng = conv_encoder.conv_engine(encoder, dev)
     B = dX.shape[1]
-    d_rep = ws.get("cu.drep", (B, emb))
-    torch.sum(dX[:, :, :emb], dim=0, out=d_rep)  # device plumbing: sum of N small slices
+    stacked = inv is not None and inv[3]
+    d_rep = ws.get("cu.drep2" if stacked else "cu.drep", (2 * B if stacked else B, emb))
+    torch.sum(dX[:, :, :emb], dim=0, out=d_rep[:B])  # device plumbing: sum of N small slices
+    if inv is not None:
+        as_rep, os_rep, lam, _ = inv
+        tgt = d_rep[B:] if stacked else d_rep[:B]
+        check(lib.ssac_frobenius_diff_bwd(as_rep.data_ptr(), lu._row_stride(as_rep), os_rep.data_ptr(),
+                                          lu._row_stride(os_rep), B, emb, float(lam), tgt.data_ptr(), emb,
+                                          0 if stacked else 1, slot[lu.L_ENC_INV:].data_ptr(),
+                                          slot[lu.L_CRITIC_LOSS:].data_ptr(), engine.stream()))
     eng.backward(d_rep)
     eng.optimizer_step(encoder_optimizer, encoder_clip, norm_out=slot[lu.L_ENC_GN:])
 
@@ -493,8 +504,6 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                          noise_clip, aug_mix=0.75, discrete=False, per=False, update_priorities=False,
                          dr3_coeff=0.0):
     engine.require_gpu()
-    if encoder_lambda:
-        raise NotImplementedError("encoder invariance loss (SURVEY 8(f) rank 4) is not accelerated")
     E = agent.ensemble_size
     assert E <= lu.MAX_MEMBERS
     dev = log_alphas[0].device
@@ -523,7 +532,8 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
         dual_ok = (DUAL_LAUNCH and arena.fused_dbuf and not train_enc and not dr3_coeff and not discrete
                    and _dual_fits(arena, batch_size) and not _split_forward(N, batch_size))
         rd = lu.sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter,
-                                        aug_mix=aug_mix, per=per, _defer_gather=dual_ok)
+                                        aug_mix=aug_mix, per=per, _defer_gather=dual_ok,
+                                        _invariance=bool(encoder_lambda))
         o, a, r, o1, d = rd["primary_batch"]
         B = r.shape[0]
         # The online critics' FORWARD does not depend on the TD target: on a second stream (a parallel graph
@@ -580,13 +590,43 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             # online encoder WITH gradient (learning.py:83): embedding goes straight into the critic input
             assert E == 1, "trainable encoders are supported for ensemble_size == 1"
             xin = ws.get(f"cu.x{i}", (B, arena.in_dim))
-            s_rep = lu.encode(agent.encoder, o, dst=xin, save=True)
+            inv = None
+            okey = getattr(agent.encoder, "ssac_obs_key", "obs")
+            if encoder_lambda and rd["augmented_obs"][0][okey] is not o[okey]:
+                # encoder invariance on a partly augmented batch: the fully augmented observations need an encoder
+                # pass of their own WITH gradient -- one stacked 2B-row pass [o ; ao], whose backward then receives
+                # the critics' gradient in rows [0, B) and the constraint's in rows [B, 2B)
+                from . import conv_encoder
+                eng = conv_encoder.conv_engine(agent.encoder, dev)
+                img2 = ws.get("cu.img2", (2 * B,) + tuple(o[okey].shape[1:]))
+                img2[:B].copy_(o[okey])
+                img2[B:].copy_(rd["augmented_obs"][0][okey])
+                sall = ws.get("cu.sall", (2 * B, eng.emb))
+                eng.forward(img2, sall, eng.emb, True)
+                xin[:, :eng.emb].copy_(sall[:B])
+                s_rep, as_rep, stacked = xin[:, :eng.emb], sall[B:], True
+            else:
+                s_rep = lu.encode(agent.encoder, o, dst=xin, save=True)
+                as_rep, stacked = s_rep, False
+            if encoder_lambda:
+                oo = rd["original_obs"][0]
+                if oo[okey] is o[okey]:
+                    os_rep = ws.get("cu.osrep", (B, s_rep.shape[1]))
+                    os_rep.copy_(s_rep)   # un-augmented batch: the target of the constraint is the embedding itself
+                else:
+                    os_rep = lu.encode(agent.encoder, oo, dst=ws.get("cu.osrep", (B, s_rep.shape[1])), save=False)
+                inv = (as_rep, os_rep, encoder_lambda, stacked)
+                logs["encoder_constraint_loss"] = slot[lu.L_ENC_INV]
             if not discrete:
                 xin[:, s_rep.shape[1]:].copy_(a)
             X, ldx = xin, xin.stride(0)
         elif branch is None and co is None:
             s_rep = lu.encode(agent.encoder, o)
             X, ldx = _critic_input(rd.get("_ssac"), ws, f"cu.x{i}", s_rep, a, discrete)
+        if encoder_lambda and not train_enc:
+            # identity encoder: augmented == original observations (only the identity augmentation applies to vectors),
+            # the constraint is exactly zero and has no parameter to reach (learning_utils.py:401-409)
+            logs["encoder_constraint_loss"] = slot[lu.L_ENC_INV]
         shard = parallel.shard_of(agent)
         n_glob = N if shard is None else shard.num_critics  # loss is averaged over the GLOBAL ensemble
         popart = agent.popart[i]
@@ -704,7 +744,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                 dX = ws.get(tag + ".dx", (N, B, arena.in_dim))
                 check(lib.ssac_mlp_layer_dgrad(C.byref(arena.desc()), 0, 0, N, dz1.data_ptr(), H, B * H, 0, 0, 0,
                                                B, dX.data_ptr(), arena.in_dim, B * arena.in_dim, st))
-                _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, s_rep.shape[1], ws, slot, dev)
+                _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, s_rep.shape[1], ws, slot, dev, inv)
             if arena.shadow is not None and (lossfold is None or critic_clip or popart):
                 raise NotImplementedError(
                     "bf16 mode covers the chained critic update (one member, continuous single-output critics, "
@@ -729,7 +769,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                                            dq.data_ptr(), slot.data_ptr(), st))
             if train_enc:
                 dX = engine.mlp_backward(arena, dq, X, ldx, 0, h1, h2, B, ws, tag, need_dx=True, update=False)
-                _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, s_rep.shape[1], ws, slot, dev)
+                _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, s_rep.shape[1], ws, slot, dev, inv)
                 dz2, dz1 = ws.get(tag + ".dz2", (N, B, arena.hidden)), ws.get(tag + ".dz1", (N, B, arena.hidden))
                 engine.weight_grads(arena, X, ldx, 0, h1, h2, dq, dz2, dz1, B, adam=adam,
                                     adam_key=("critic", i), grads=grads, sumsq=ss)

@@ -27,6 +27,7 @@ L_ACTOR_LOSS, L_ACTOR_GN = 32, 33
 L_ALPHA0 = 34        # + 2*i : alpha_loss_i, alpha_i
 L_ADVW, L_BC_TOTAL, L_BC_GN = 50, 51, 52   # AFBC: adv_weights_mean, overall loss, actor grad norm
 L_BC0 = 53           # + i : filtered BC loss of member i
+L_ENC_INV = 60       # encoder invariance constraint (learning_utils.py:401-409)
 # Markov state-abstraction update (its own log block): losses inverse / contrastive / smoothness / total, then the
 # gradient norms of the contrastive model, the inverse model and the encoder; two scratch words for the head kernels
 L_MK_LOSS, L_MK_GN_CON, L_MK_GN_INV, L_MK_GN_ENC, L_MK_RAW, L_MK_CON, L_MK_SMOOTH, L_MK_TMP = 40, 44, 45, 46, 47, 48, 49, 56
@@ -285,7 +286,8 @@ def gather_struct(bt):
     return g
 
 
-def sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, per=True, _defer_gather=False):
+def sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, per=True, _defer_gather=False,
+                            _invariance=False):
     assert len(buffer) >= batch_size
     st = buffer._storage
     dev = st.device
@@ -350,7 +352,32 @@ def sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, per=True, _d
         st.gather_field(st.reward_stack, idx, B, dst=r, ld=1)
         st.gather_field(st.done_stack, idx, B, dst=d, ld=1)
         bt.S, bt.xsa, bt.x1sa, bt.key, bt.pixel = None, None, None, None, True
+        if _invariance:
+            # the invariance constraints (learning_utils.py:272-285, 401-409) look at the FULLY augmented and the
+            # un-augmented observation batch (same rows, same randomisation); where the mix already is one of them
+            # (aug_mix 1 / 0) that tensor is shared
+            ao, oo = {}, {}
+            for key in keys:
+                src = st.s_stack[key]
+                if src.dim() == 4 and shift_aug is not None:
+                    c, h, w = src.shape[1:]
+                    for dst_dict, n_aug in ((ao, B), (oo, 0)):
+                        if n_aug == k_aug:
+                            dst_dict[key] = o[key]
+                            continue
+                        assert not shift_aug.noise, "the noise of DrqAug would have to be re-used across the passes"
+                        out = torch.empty(B, c, h, w, device=dev)
+                        shift_aug.apply(src, idx, B, c, h, n_aug, out, None)
+                        dst_dict[key] = out
+                else:
+                    ao[key] = oo[key] = o[key]
+            inv_obs = ((ao, None), (oo, None))
     bt.r, bt.d = r, d
+    if _invariance and vec:
+        inv_obs = ((o, None), (o, None))   # identity augmentation: augmented == original == the batch
+    if _invariance:
+        return {"primary_batch": (o, a, r, o1, d), "augmented_obs": inv_obs[0], "original_obs": inv_obs[1],
+                "priority_idxs": idx_cpu.numpy(), "imp_weights": imp_weights, "_ssac": bt}
     return {"primary_batch": (o, a, r, o1, d), "augmented_obs": None, "original_obs": None,
             "priority_idxs": idx_cpu.numpy(), "imp_weights": imp_weights, "_ssac": bt}
 

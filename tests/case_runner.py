@@ -121,7 +121,7 @@ def run_oracle(name):
                              if f"u{upd}_bweps0_0" in fx else None),
                 bw_cat_list=([[T(f"u{upd}_cat{i}_{k_}") for k_ in range(E)] for i in range(E)]
                              if f"u{upd}_cat0_0" in fx else None),
-                grad_pick=int(fx[f"u{upd}_gpick"]))
+                grad_pick=int(fx[f"u{upd}_gpick"]), encoder_lambda=cfg.get("encoder_lambda", 0))
             for i in range(E):
                 rec[f"u{upd}_td{i}"] = dicts[i]["td_target"].numpy()
                 if cfg["popart"]:
@@ -343,7 +343,8 @@ def run_engine(name, device="cuda", shard=None, foreign=False, precision="fp32")
                     encoder_optimizer=eopt, log_alphas=las, batch_size=B, gamma=cfg["gamma"],
                     critic_clip=cfg["clip"], encoder_clip=cfg["clip"],
                     target_critic_ensemble_n=cfg["n"], weighted_bellman_temp=cfg["temp"],
-                    weight_type=cfg["weight_type"], pop=cfg["pop"], augmenter=aug, encoder_lambda=0,
+                    weight_type=cfg["weight_type"], pop=cfg["pop"], augmenter=aug,
+                    encoder_lambda=cfg.get("encoder_lambda", 0),
                     aug_mix=aug_mix, discrete=cfg["discrete"], random_process=rproc, noise_clip=nclip,
                     per=False, update_priorities=False, dr3_coeff=0.0)
                 for i in range(E):

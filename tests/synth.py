@@ -112,6 +112,23 @@ CASES = {
                          actor="stochastic", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
                          clip=None, tau=0.005, weight_type=None, temp=None, noise=None,
                          cycles=2, utd=1, target_delay=1, seed=38, use_baseline=True),
+    # encoder invariance constraint (learning.py:114-117): half the batch augmented (the fully augmented batch needs
+    # its own encoder pass), and the atari shape with every row augmented (the constraint shares the critic's pass)
+    "drqv2_pixels_inv": dict(obs=50, act=4, hidden=64, N=2, n=2, E=1, B=8, rows=48, cap=64,
+                             lo=-10.0, hi=2.0, popart=False, pop=False, discrete=False,
+                             actor="deterministic", gamma=0.99 ** 3, lr=1e-4, alpha_lr=0.0, init_alpha=0.0,
+                             clip=None, tau=0.01, weight_type=None, temp=None,
+                             noise=dict(scale=0.5, clip=0.3), cycles=1, utd=2, target_delay=1, seed=51,
+                             encoder_lambda=0.1,
+                             pixels=dict(kind="big", channels=9, hw=84, emb=50, enc_lr=1e-4, enc_tau=1.0,
+                                         aug="drqv2", aug_mix=0.5)),
+    "atari_pixels_inv": dict(obs=128, act=6, hidden=64, N=2, n=2, E=1, B=8, rows=48, cap=64,
+                             lo=-10.0, hi=2.0, popart=False, pop=False, discrete=True,
+                             actor="discrete", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                             clip=40.0, tau=0.005, weight_type=None, temp=None, noise=None,
+                             cycles=1, utd=2, target_delay=2, seed=52, encoder_lambda=0.5,
+                             pixels=dict(kind="small", channels=4, hw=84, emb=128, enc_lr=3e-4, enc_tau=0.01,
+                                         aug="drqv2", aug_mix=1.0)),
 }
 
 

@@ -853,6 +853,62 @@ def run_markov_case(name, cfg):
     np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
 
 
+def run_bc_pixels_case(name, cfg):
+    """the BC warm-up of main.py:292-312 on the unmodified reference: learning.offline_actor_update(update_encoder=True,
+    filter_=False, per=False) with a pixel encoder trained through the BC loss."""
+    print(f"== {name}")
+    torch.manual_seed(cfg["seed"]); np.random.seed(cfg["seed"]); random.seed(cfg["seed"])
+    B, A, px, disc = cfg["B"], cfg["act"], cfg["pixels"], bool(cfg["discrete"])
+    s, a, r, s1, d = synth.synth_pixel_transitions(cfg["rows"], px["channels"], px["hw"], n_actions=A if disc else None,
+                                                  act_dim=A, seed=cfg["seed"] + 100)
+    rbuf = ref.replay.ReplayBuffer(cfg["cap"])
+    rbuf.load_experience(s, a, r, s1, d)
+    obuf = orc.ReplayOracle(cfg["cap"])
+    obuf.load_experience(s, a, r, s1, d)
+    ra, oa = build_pair(cfg)
+    oa.requires_grad_(True)
+    r_aopt = torch.optim.Adam(chain(*(ac.parameters() for ac in ra.actors)), lr=cfg["lr"], betas=(0.9, 0.999))
+    r_eopt = torch.optim.Adam(ra.encoder.parameters(), lr=px["enc_lr"], betas=(0.9, 0.999))
+    o_aopt = orc.AdamOracle(oa.actor_params(), lr=cfg["lr"])
+    o_eopt = orc.AdamOracle(oa.encoder_params(), lr=px["enc_lr"])
+    r_aug = ref.augmentations.AugmentationSequence([ref.augmentations.Drqv2Aug(B)])
+    o_aug = orc.AugOracle("drqv2", B)
+    rec = {"n_steps": np.int64(len(cfg["steps"]))}
+    for k in range(len(cfg["steps"])):
+        st, pst = torch.get_rng_state(), random.getstate()
+        idx = torch.randint(len(rbuf), (B,)).numpy()
+        shift = orc.drqv2_draw_shift(B)
+        torch.set_rng_state(st); random.setstate(pst)
+        rlogs = rl.offline_actor_update(
+            buffer=rbuf, agent=ra, actor_optimizer=r_aopt, encoder_optimizer=r_eopt, batch_size=B,
+            actor_clip=cfg["clip"], update_encoder=True, encoder_clip=cfg["enc_clip"][k], augmenter=r_aug,
+            actor_lambda=0.0, aug_mix=px["aug_mix"], premade_replay_dicts=None, per=False, discrete=disc,
+            filter_=False)
+        assert torch.equal(r_aug.aug_list[0].shift, shift), "shift stream mismatch"
+        o_aug.forced = [shift.clone()]
+        ologs, _, _, _ = orc.offline_actor_update(
+            obuf, None, oa, o_aopt, B, cfg["clip"], o_aug, px["aug_mix"], per=False, filter_=False, idx_list=[idx],
+            update_encoder=True, encoder_opt=o_eopt, encoder_clip=cfg["enc_clip"][k])
+        rec[f"s{k}_idx"], rec[f"s{k}_shift"] = np.asarray(idx, np.int64), shift.numpy()
+        for key, val in rlogs.items():
+            v = float(val)
+            rec[f"s{k}_log:{key}"] = np.float64(v)
+            assert abs(v - float(ologs[key])) <= 2e-4 * max(1.0, abs(v)), (key, v, ologs[key])
+    _, rac = ref_params(ra, cfg)
+    dpar = maxdiff(rac, oa.actor_params())
+    print(f"   actor params max|diff| {dpar:.3e}")
+    assert dpar < 5e-5
+    rec["final_actor"] = np.concatenate([p.detach().numpy().ravel() for p in rac])
+    re_ = ref_encoder_params(ra.encoder, cfg)
+    assert_encoder_close(re_, oa.encoder_params())
+    vals = []
+    for p in re_:
+        flat = p.detach().numpy().ravel()
+        vals.append(flat[synth.fingerprint_indices(flat.size)])
+    rec["finalfp_encoder"] = np.concatenate(vals)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
+
+
 def synth_markov_models(cfg):
     """seeded inverse / contrastive model weights of a Markov case (the same draw everywhere: generator, tests)"""
     px = cfg.get("pixels")
@@ -878,4 +934,7 @@ if __name__ == "__main__":
     for name, cfg in synth.MARKOV_CASES.items():
         if not only or name in only:
             run_markov_case(name, cfg)
+    for name, cfg in synth.BC_PIXEL_CASES.items():
+        if not only or name in only:
+            run_bc_pixels_case(name, cfg)
     print("golden fixtures written to", OUT)

@@ -1013,7 +1013,8 @@ def advantage(agent, o, a, i, eps_list=None, method="mean", n=4, grad=False):
 
 def offline_actor_update(buffer, per_tree, agent, actor_opt, batch_size, actor_clip, augmenter, aug_mix,
                          per=True, filter_=True, dicts=None, idx_list=None, eps_lists=None,
-                         prio_member=None, prio_eps=None, method="mean"):
+                         prio_member=None, prio_eps=None, method="mean", update_encoder=False, encoder_opt=None,
+                         encoder_clip=None):
     """learning.py:144-219 for identity encoders (update_encoder has nothing to update), actor_lambda 0.
     per_tree: PerOracle over the buffer's rows (None when per is False).
     eps_lists[i]: the 4 normal draws of member i's advantage estimate; prio_member / prio_eps: the
@@ -1044,8 +1045,11 @@ def offline_actor_update(buffer, per_tree, agent, actor_opt, batch_size, actor_c
         if filter_:
             adv = advantage(agent, o, a, i, None if eps_lists is None else eps_lists[i], method)
             mask = (adv >= 0.0).float()
-        with torch.no_grad():
+        if update_encoder:   # learning_utils.py:255-256: the encoder is trained through the BC loss (BC warm-up)
             s = encode(agent.encoder, o)
+        else:
+            with torch.no_grad():
+                s = encode(agent.encoder, o)
         out = mlp3(agent.actors[i], s)[0]
         if agent.discrete:
             logp = torch.log_softmax(out, dim=-1).gather(-1, a.long())
@@ -1059,10 +1063,16 @@ def offline_actor_update(buffer, per_tree, agent, actor_opt, batch_size, actor_c
         total = total + loss_i
     loss = total / agent.E
     actor_opt.zero_grad()
+    if encoder_opt is not None:
+        encoder_opt.zero_grad()
     loss.backward()
     if actor_clip:
         clip_grad_norm(agent.actor_params(), actor_clip)
+    if encoder_clip:
+        clip_grad_norm(agent.encoder_params(), encoder_clip)
     actor_opt.step()
+    if update_encoder:
+        encoder_opt.step()
     logs["losses/filtered_bc_overall_loss"] = loss.item()
     # learning.py:209-214 (all AFBC fixtures have one member: the random.choice pick is member 0)
     logs["gradients/actor_offline_grad_norm"] = grad_norm([agent.actors[0][k] for k in MLP_KEYS])

@@ -1070,9 +1070,12 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
     if actor_lambda:
         raise NotImplementedError("action invariance constraint (SURVEY 8(f) rank 4) is not accelerated")
     lu.ensure_adopted(agent, buffer)
-    if update_encoder and not lu.is_identity(agent.encoder):
-        raise NotImplementedError("encoder training through the BC loss is not accelerated")
     E = agent.ensemble_size
+    # the BC warm-up (main.py:292-312) trains a pixel encoder THROUGH the BC loss: the actor's input gradient goes
+    # back through the conv engine, then clip + encoder_optimizer.step()
+    train_enc = bool(update_encoder) and not lu.is_identity(agent.encoder)
+    if train_enc and E != 1:
+        raise NotImplementedError("trainable encoders are supported for ensemble_size == 1")
     dev = next(agent.actors[0].parameters()).device
     ws = lu.agent_ws(agent, dev)
     adam = engine.adam_group(actor_optimizer, dev)
@@ -1095,7 +1098,7 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
             res = agent.adv_estimator.evaluate(o, a, i, want=("mask",), log_ptr=slot[lu.L_ADVW:].data_ptr())
             mask_ptr = res["mask"].data_ptr()
             logs["losses/adv_weights_mean"] = slot[lu.L_ADVW]
-        s_rep = lu.encode(agent.encoder, o)
+        s_rep = lu.encode(agent.encoder, o, save=train_enc)
         B, S = s_rep.shape
         lds = lu._row_stride(s_rep)
         a_arena = engine.bind_arena(actor, "self", [actor], dev)
@@ -1117,12 +1120,14 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
         ss = ws.get(f"bc.ss{i}", (ttot,))
         if actor_clip:
             grads = ws.get(f"bc.g{i}", (a_arena.params.numel(),), zero=True)
-            engine.mlp_backward(a_arena, d_out, s_rep, lds, 0, ah1, ah2, B, ws, f"bc.a{i}", grads=grads,
-                                sumsq=ss)
+            dX = engine.mlp_backward(a_arena, d_out, s_rep, lds, 0, ah1, ah2, B, ws, f"bc.a{i}", grads=grads,
+                                     sumsq=ss, need_dx=train_enc)
             clip_members.append((a_arena, ("actor", i), grads, ss))
         else:
-            engine.mlp_backward(a_arena, d_out, s_rep, lds, 0, ah1, ah2, B, ws, f"bc.a{i}", adam=adam,
-                                adam_key=("actor", i), sumsq=ss)
+            dX = engine.mlp_backward(a_arena, d_out, s_rep, lds, 0, ah1, ah2, B, ws, f"bc.a{i}", adam=adam,
+                                     adam_key=("actor", i), sumsq=ss, need_dx=train_enc)
+        if train_enc:  # (dX was taken before the epilogue of the weight-gradient launch touched W1)
+            _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, S, ws, slot, dev)
         member_ss.append(ss)
     if actor_clip:
         _clip_and_step(adam, clip_members, actor_clip, None)

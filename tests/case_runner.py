@@ -792,3 +792,74 @@ def compare_markov(rec, fx, who, log_tol=5e-4, gn_tol=2e-3, par_tol=3e-5, max_st
             assert np.median(d) <= 1e-6, f"{who}: {key}: median |diff| {np.median(d)}"
             worst["par"] = max(worst["par"], float(np.median(d)))
     return worst
+
+
+# ------------------------------------------------------------------------------------------
+# BC warm-up on pixels (synth.BC_PIXEL_CASES, fixtures written by oracle/gen_golden.py::run_bc_pixels_case)
+# ------------------------------------------------------------------------------------------
+def _encoder_param_list(conv, kind):
+    names = ["conv1", "conv2", "conv3", "conv4"] if kind == "big" else ["conv1", "conv2", "conv3"]
+    plist = []
+    for nm in names:
+        plist += [getattr(conv, nm).weight, getattr(conv, nm).bias]
+    plist += [conv.fc.weight, conv.fc.bias]
+    if kind == "big":
+        plist += [conv.ln.weight, conv.ln.bias]
+    return plist
+
+
+def run_bc_pixels_oracle(name):
+    cfg = synth.BC_PIXEL_CASES[name]
+    fx = load_fixture(name)
+    B, px = cfg["B"], cfg["pixels"]
+    obuf = orc.ReplayOracle(cfg["cap"])
+    obuf.load_experience(*_buffers(cfg))
+    oa = _oracle_agent(cfg).requires_grad_(True)
+    aopt = orc.AdamOracle(oa.actor_params(), lr=cfg["lr"])
+    eopt = orc.AdamOracle(oa.encoder_params(), lr=px["enc_lr"])
+    aug = orc.AugOracle("drqv2", B)
+    rec = {}
+    for k in range(len(cfg["steps"])):
+        aug.forced = [torch.from_numpy(fx[f"s{k}_shift"])]
+        logs, _, _, _ = orc.offline_actor_update(
+            obuf, None, oa, aopt, B, cfg["clip"], aug, px["aug_mix"], per=False, filter_=False,
+            idx_list=[fx[f"s{k}_idx"]], update_encoder=True, encoder_opt=eopt, encoder_clip=cfg["enc_clip"][k])
+        for key, val in logs.items():
+            rec[f"s{k}_log:{key}"] = np.float64(val)
+    rec["final_actor"] = _flat(oa.actor_params())
+    rec["finalfp_encoder"] = _fingerprint(oa.encoder_params())
+    return rec
+
+
+def run_bc_pixels_engine(name, device="cuda"):
+    import super_sac_amd as ssa
+    cfg = synth.BC_PIXEL_CASES[name]
+    fx = load_fixture(name)
+    B, px = cfg["B"], cfg["pixels"]
+    device = torch.device(device)
+    buf = ssa.replay.ReplayBuffer(cfg["cap"], device=device)
+    buf.load_experience(*_buffers(cfg))
+    agent = build_engine_agent(cfg, device)
+    aopt = torch.optim.Adam(chain(*(a.parameters() for a in agent.actors)), lr=cfg["lr"], betas=(0.9, 0.999))
+    eopt = torch.optim.Adam(agent.encoder.parameters(), lr=px["enc_lr"], betas=(0.9, 0.999))
+    aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.Drqv2Aug(B)])
+    player = DrawPlayer(device)
+    player.install(ssa.rng)
+    rec = {}
+    try:
+        for k in range(len(cfg["steps"])):
+            player.idx.append(fx[f"s{k}_idx"])
+            player.shift.append(fx[f"s{k}_shift"])
+            logs = ssa.learning.offline_actor_update(
+                buffer=buf, agent=agent, actor_optimizer=aopt, encoder_optimizer=eopt, batch_size=B,
+                actor_clip=cfg["clip"], update_encoder=True, encoder_clip=cfg["enc_clip"][k], augmenter=aug,
+                actor_lambda=0.0, aug_mix=px["aug_mix"], premade_replay_dicts=None, per=False,
+                discrete=cfg["discrete"], filter_=False)
+            for key, val in logs.items():
+                rec[f"s{k}_log:{key}"] = np.float64(float(val))
+        assert not player.idx and not player.shift
+    finally:
+        player.restore()
+    rec["final_actor"] = _flat([p for a in agent.actors for p in a.parameters()])
+    rec["finalfp_encoder"] = _fingerprint(_encoder_param_list(ssa.conv_encoder.find_conv_module(agent.encoder), px["kind"]))
+    return rec

@@ -157,6 +157,22 @@ AFBC_CASES = {
                         steps=[(True, True), (True, True), (True, False)]),
 }
 
+# BC warm-up on pixels (fixtures written by oracle/gen_golden.py::run_bc_pixels_case)
+BC_PIXEL_CASES = {
+    # the behavioural-cloning warm-up of dmc/bc_from_pixels.gin (main.py:292-312): offline_actor_update with
+    # update_encoder=True, filter_=False, per=False -- the pixel encoder is trained through the BC loss
+    "bc_pixels": dict(obs=50, act=4, hidden=64, N=2, n=2, E=1, B=8, rows=48, cap=64, lo=-10.0, hi=2.0,
+                      popart=False, discrete=False, actor="stochastic", lr=1e-4, clip=None, seed=61, bc_pixels=True,
+                      steps=[(False, False)] * 3, enc_clip=(None, 0.5, 0.5),
+                      pixels=dict(kind="big", channels=9, hw=84, emb=50, enc_lr=1e-4, enc_tau=1.0, aug="drqv2",
+                                  aug_mix=0.9)),
+    "bc_pixels_discrete": dict(obs=64, act=5, hidden=64, N=2, n=2, E=1, B=8, rows=48, cap=64, lo=-10.0, hi=2.0,
+                               popart=False, discrete=True, actor="discrete", lr=3e-4, clip=5.0, seed=62,
+                               bc_pixels=True, steps=[(False, False)] * 3, enc_clip=(5.0, 5.0, 5.0),
+                               pixels=dict(kind="small", channels=4, hw=84, emb=64, enc_lr=3e-4, enc_tau=1.0,
+                                           aug="drqv2", aug_mix=0.9)),
+}
+
 # Markov state-abstraction update (fixtures written by oracle/gen_golden.py::run_markov_case)
 MARKOV_CASES = {
     # ---- Markov state-abstraction update (learning.py:266-341): steps of markov_state_abstraction_update

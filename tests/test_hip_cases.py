@@ -264,6 +264,17 @@ def test_markov_state_abstraction_update_matches_reference(name, fused):
                                max_step=2.2 * cfg["lr"] * cfg["markov"]["steps"] if "pixels" in name else 0.0)
 
 
+@pytest.mark.parametrize("name", sorted(synth.BC_PIXEL_CASES))
+def test_bc_warmup_trains_the_pixel_encoder_through_the_bc_loss(name):
+    """main.py:292-312 (dmc/bc_from_pixels.gin): learning.offline_actor_update(update_encoder=True, filter_=False,
+    per=False) -- the actor's input gradient runs back through the conv engine, encoder clip and optimizer step
+    included.  Logs within 5e-4 (gradient norms 2e-3), actor and encoder parameters 3e-5."""
+    cfg = synth.BC_PIXEL_CASES[name]
+    rec = case_runner.run_bc_pixels_engine(name)
+    case_runner.compare_markov(rec, case_runner.load_fixture(name), f"hip[{name}]",
+                               max_step=2.2 * max(cfg["lr"], cfg["pixels"]["enc_lr"]) * len(cfg["steps"]))
+
+
 @pytest.mark.parametrize("name", ["drqv2_pixels", "atari_pixels"])
 def test_pixel_cases_with_implicit_gemm_convolutions(name):
     """the pixel fixtures again with the implicit-GEMM kernels forced on for every eligible layer (the

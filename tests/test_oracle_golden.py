@@ -200,3 +200,12 @@ def test_oracle_reproduces_markov_fixture(name):
     case_runner.compare_markov(rec, case_runner.load_fixture(name), f"oracle[{name}]", log_tol=2e-4, gn_tol=2e-4,
                                par_tol=1e-6 if "pixels" not in name else 3e-5,
                                max_step=2.2 * synth.MARKOV_CASES[name]["lr"] * 3 if "pixels" in name else 0.0)
+
+
+@pytest.mark.parametrize("name", sorted(synth.BC_PIXEL_CASES))
+def test_oracle_reproduces_bc_warmup_on_pixels(name):
+    """main.py:292-312: offline_actor_update(update_encoder=True, filter_=False) -- the pixel encoder trained through
+    the BC loss, its own clip and optimizer."""
+    rec = case_runner.run_bc_pixels_oracle(name)
+    case_runner.compare_markov(rec, case_runner.load_fixture(name), f"oracle[{name}]", log_tol=2e-4, gn_tol=2e-4,
+                               par_tol=3e-5, max_step=2.2 * synth.BC_PIXEL_CASES[name]["lr"] * 3)

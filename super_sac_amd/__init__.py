@@ -46,7 +46,8 @@ def install(reference_package):
     ``super_sac.main.super_sac`` resolves ``learning.*`` / ``lu.*`` through the module objects at call
     time (main.py:18-19), so patching the module attributes is sufficient."""
     ref_learning, ref_lu = reference_package.learning, reference_package.learning_utils
-    for name in ("critic_update", "online_actor_update", "alpha_update", "offline_actor_update"):
+    for name in ("critic_update", "online_actor_update", "alpha_update", "offline_actor_update",
+                 "markov_state_abstraction_update"):
         setattr(ref_learning, name, getattr(learning, name))
     for name in ("soft_update", "hard_update", "sample_move_and_augment", "compute_td_targets",
                  "compute_backup_weights", "adjust_priorities", "compute_filter_stats"):

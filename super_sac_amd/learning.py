@@ -83,8 +83,9 @@ LAZY_TD = os.environ.get("SSAC_LAZY_TD", "1") == "1"
 SPLIT_FORWARD = os.environ.get("SSAC_SPLIT_FORWARD", "0") == "1"
 
 
-# the TD-independent half of the critics' backward pass inside the target-critic launch (rank-1 loss gradient)
-RANK1_BWD = os.environ.get("SSAC_RANK1_BWD", "1") == "1"
+# the TD-independent half of the critics' backward pass inside the target-critic launch (rank-1 loss gradient); a module
+# knob, not an environment switch: tests turn it off to compare against the launch forms other configurations take
+RANK1_BWD = True
 EVENT_EVERY = int(os.environ.get("SSAC_EVENT_EVERY", "8"))  # must divide FEED_SLOTS
 FOLD_LOSS = os.environ.get("SSAC_FOLD_LOSS", "1") == "1"  # rank-1 backward: dL/dq evaluated inside the weight-gradient launch
 DUAL_LAUNCH = os.environ.get("SSAC_DUAL_LAUNCH", "1") == "1"  # critic forward inside the actor-sample launch
@@ -554,7 +555,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             co = (arena, X, ldx, ws.get(tag + ".h1", (N, B, H)), ws.get(tag + ".h2", (N, B, H)),
                   ws.get(tag + ".y", (N, B, qd)))
             if RANK1_BWD and qd == 1:
-                # and the TD-independent half of the backward pass rides in the target critics' launch
+                # and the TD-independent half (rank-1 loss gradient) of the backward pass rides in the target critics' launch
                 cob = (arena, co[3], co[4], a, a.stride(0), ws.get(tag + ".dz2", (N, B, H)),
                        ws.get(tag + ".dz1", (N, B, H)))
         td, _ = lu.compute_td_targets(logs=logs, replay_dict=rd, agent=agent, target_agent=target_agent,

@@ -292,43 +292,16 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     float f0a[HT], f0b[HT], f1a[HT], f1b[HT];  // first / second half of the current chunk
     if (iters > 0) rd(f0a, f0b, buf0, 0);
     GSTAMP(1);
-    // Optimizer state of this thread's epilogue elements (EPI_ADAM): requested while the LAST chunk multiplies -- the
-    // staging registers are dead by then (no chunk is left to load), so the prefetch costs no registers, and the
-    // epilogue does not start with an exposed round trip to three 64x64 blocks of p / m / v.
-    constexpr int NT_ALL_ = NTHREADS * KS;
-    constexpr int PER_ = (BM * BN) / NT_ALL_;
-    float pre_p[PER_], pre_m[PER_], pre_v[PER_], pre_t[PER_];
-    auto prefetch_state = [&]() {
-        if (EPI != EPI_ADAM) return;
-#pragma unroll
-        for (int j = 0; j < PER_; ++j) {
-            const int idx = tid_all + j * NT_ALL_;
-            const int row = idx >> 6, col = idx & 63;
-            const bool okj = (m0 + row) < g.M && (n0 + col) < g.N;
-            const int64_t a = okj ? coff + (int64_t)(m0 + row) * g.ldc + n0 + col : coff;
-            pre_p[j] = g.C[a]; pre_m[j] = g.am[a]; pre_v[j] = g.av[a];
-            pre_t[j] = g.tw ? g.tw[a] : 0.0f;
-        }
-    };
-    for (int it = 0; it + 1 < iters; ++it) {
+    for (int it = 0; it < iters; ++it) {
         float *cur = (it & 1) ? buf1 : buf0;
         float *nxt = (it & 1) ? buf0 : buf1;
         rd(f1a, f1b, cur, 1);
         mm(f0a, f0b);
-        storeA(nxt); storeB(nxt + TILE_FLOATS);
+        if (it + 1 < iters) { storeA(nxt); storeB(nxt + TILE_FLOATS); }
         if (it + 2 < iters) { const int k0 = ((it + 2) * KS + kg) * BK; loadA(k0); loadB(k0); }
         lds_barrier();  // (LDS hand-off only: the loads just issued stay in flight over the next half chunk)
-        rd(f0a, f0b, nxt, 0);
+        if (it + 1 < iters) rd(f0a, f0b, nxt, 0);
         mm(f1a, f1b);
-    }
-    if (iters > 0) {   // last chunk: nothing left to stage
-        float *cur = ((iters - 1) & 1) ? buf1 : buf0;
-        rd(f1a, f1b, cur, 1);
-        prefetch_state();
-        mm(f0a, f0b);
-        mm(f1a, f1b);
-    } else {
-        prefetch_state();
     }
     if (bias_wave) bias_acc += __shfl_xor(bias_acc, 32, 64);  // the two k parities of column li
 
@@ -368,7 +341,11 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
         }
         if (EPI == EPI_ADAM) {
 #pragma unroll
-            for (int j = 0; j < PER; ++j) { pv[j] = pre_p[j]; mv[j] = pre_m[j]; vv[j] = pre_v[j]; tv[j] = pre_t[j]; }
+            for (int j = 0; j < PER; ++j) {
+                const int64_t a = ok[j] ? ci[j] : coff;
+                pv[j] = g.C[a]; mv[j] = g.am[a]; vv[j] = g.av[a];
+                tv[j] = g.tw ? g.tw[a] : 0.0f;
+            }
         }
         // the bias gradient of this tile's rows and its optimizer state (threads < 64 of n-tile 0)
         const int gm = m0 + tid_all;

@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
     }
     // ---- loss gradient of this net's rows -> LDS (the first fc2 tile of each net also reduces the loss terms)
     for (int b = g.n_rows + tid; b < g.bp; b += 256) tab[b] = 0.0f;
-    loss_fold_table(g.lf, e, tab, t == 0, red);
+    loss_fold_table(g.lf, e, tab, t == 0, red, t == 0 && e == 0);
     if (((g.fold.done && g.fold.td_logs) || g.fold.deferred_stats) && t == 0 && e == 0)
         log_fold_td_stats(g.fold, g.lf.tds, red);
     __syncthreads();

@@ -135,7 +135,10 @@ __device__ __forceinline__ float ssac_lazy_td(const ssac_td_spec &t, int b, int 
 
 // Every thread of the workgroup calls this (barriers inside when `stats`; `stats` must be workgroup-uniform).
 // tab: n_rows floats of LDS; red: 2 * (blockDim.x / 64) floats of LDS.  The caller synchronises before reading tab.
-__device__ __forceinline__ void loss_fold_table(const LossFoldArgs &a, int e, float *tab, bool stats, float *red) {
+// write_td: this workgroup also stores the (lazily evaluated) TD targets to tds.td_out -- the caller's td_target tensor
+// and the input of log_fold_td_stats; exactly one workgroup of a launch does that.
+__device__ __forceinline__ void loss_fold_table(const LossFoldArgs &a, int e, float *tab, bool stats, float *red,
+                                                bool write_td) {
     const int tid = threadIdx.x, n_rows = a.n_rows;
     const float pw = (a.popart && a.pop) ? a.popart->w : 1.0f;
     const float pb = (a.popart && a.pop) ? a.popart->b : 0.0f;
@@ -145,7 +148,7 @@ __device__ __forceinline__ void loss_fold_table(const LossFoldArgs &a, int e, fl
     float sl = 0.0f, se = 0.0f;
     for (int b = tid; b < n_rows; b += blockDim.x) {
         const float t = a.tds.q_t ? ssac_lazy_td(a.tds, b, n_rows, alpha) : a.td[b];
-        if (stats && e == 0 && a.tds.q_t) a.tds.td_out[b] = t;
+        if (write_td && a.tds.q_t) a.tds.td_out[b] = t;
         const float w = a.weight ? a.weight[b] : 1.0f;
         const float err = t - (pw * q[b] + pb);
         tab[b] = gscale * w * err;

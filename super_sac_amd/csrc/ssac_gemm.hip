@@ -472,6 +472,8 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
 // And optionally the update's log finalisation, run by whichever workgroup finishes LAST (device counter).
 struct GemmPair {
     GemmArgs g0, g1; int tiles0; int tiles01; int head_grid_x; HeadWgradArgs head;
+    int head_total;                       // number of head workgroups (head_grid_x per net)
+    int td_wg;                            // 1: one more workgroup behind them stores the TD targets + their statistics
     int xcd;                              // XCD-contiguous tile order (ssac_internal.h)
     LossFoldArgs lf;                      // lf.q != null: dL/dq evaluated per workgroup (ssac_critic_logs.h)
     LogFoldArgs fold;                     // fold.done != null: the update's logs are finalised by the last workgroup
@@ -485,11 +487,19 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
     const bool fold = p.lf.q != nullptr;
     int last = 0;
     bool drawn = false;
-    if (bid >= p.tiles01) {  // head-layer weight gradient + Adam beside the GEMM tiles
+    if (p.td_wg && bid == p.tiles01 + p.head_total) {
+        // The TD targets themselves (the caller's td_target tensor) and their statistics for the logs: a workgroup of
+        // its own.  As a side job of net 0's first GEMM tile (round 1) it made that tile the slowest workgroup of the
+        // launch -- a global write -> read round trip and five barriers in front of its K loop -- and the launch is as
+        // long as its slowest workgroup.
+        loss_fold_table(p.lf, 0, tab, false, tab + p.lf.n_rows, true);
+        if ((p.fold.done && p.fold.td_logs) || p.fold.deferred_stats)
+            log_fold_td_stats(p.fold, p.lf.tds, tab + p.lf.n_rows);
+    } else if (bid >= p.tiles01) {  // head-layer weight gradient + Adam beside the GEMM tiles
         const int L = bid - p.tiles01;
         const int e = L / p.head_grid_x;
         if (fold) {
-            loss_fold_table(p.lf, e, tab, false, tab + p.lf.n_rows);
+            loss_fold_table(p.lf, e, tab, false, tab + p.lf.n_rows, false);
             __syncthreads();
         }
         head_wgrad_body<4 * KS>(p.head, lds, L % p.head_grid_x, e, fold ? tab : nullptr);
@@ -501,10 +511,7 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
         const int bz = L / per, rem = L - bz * per;
         auto pre = [&]() {
             if (fold) {  // the first fc2 tile of each net also reduces that net's loss terms
-                loss_fold_table(p.lf, bz, tab, first && rem == 0, tab + p.lf.n_rows);
-                // ... and net slot 0's, which evaluated and wrote the TD targets, their statistics (folded logs)
-                if (((p.fold.done && p.fold.td_logs) || p.fold.deferred_stats) && first && rem == 0 && bz == 0)
-                    log_fold_td_stats(p.fold, p.lf.tds, tab + p.lf.n_rows);
+                loss_fold_table(p.lf, bz, tab, first && rem == 0, tab + p.lf.n_rows, false);
                 __syncthreads();
             }
         };
@@ -540,7 +547,9 @@ int launch_pair_ks(GemmPair &p, int batch0, int batch1, hipStream_t st) {
     p.xcd = (g_ssac_xcd >> 1) & 1;
     p.tiles0 = p.g0.grid_x * p.g0.grid_y * batch0;
     p.tiles01 = p.tiles0 + p.g1.grid_x * p.g1.grid_y * batch1;
-    const int total = p.tiles01 + (p.head_grid_x > 0 ? p.head_grid_x * batch0 : 0);
+    p.head_total = p.head_grid_x > 0 ? p.head_grid_x * batch0 : 0;
+    p.td_wg = (p.lf.q && p.lf.tds.q_t) ? 1 : 0;
+    const int total = p.tiles01 + p.head_total + p.td_wg;
     SSAC_LAUNCH((ens_gemm_pair_kernel<A_KC, B_KC, EPI, KS>), dim3(total), dim3(NTHREADS * KS), lds, st, p);
     return ssac_check_launch("ens_gemm_pair");
 }

@@ -474,6 +474,7 @@ struct GemmPair {
     GemmArgs g0, g1; int tiles0; int tiles01; int head_grid_x; HeadWgradArgs head;
     int head_total;                       // number of head workgroups (head_grid_x per net)
     int td_wg;                            // 1: one more workgroup behind them stores the TD targets + their statistics
+    int lf_nets;                          // ... and reduces the loss terms of these many nets
     int xcd;                              // XCD-contiguous tile order (ssac_internal.h)
     LossFoldArgs lf;                      // lf.q != null: dL/dq evaluated per workgroup (ssac_critic_logs.h)
     LogFoldArgs fold;                     // fold.done != null: the update's logs are finalised by the last workgroup
@@ -482,7 +483,10 @@ struct GemmPair {
 template <bool A_KC, bool B_KC, int EPI, int KS>
 __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int bid = ssac_xcd_contiguous(blockIdx.x, gridDim.x, p.xcd);
+    // (the XCD-contiguous order covers the GEMM + head workgroups only: the TD workgroup behind them keeps its own id,
+    // so the tiles land on the same XCDs with or without it)
+    const int n_main = p.tiles01 + p.head_total;
+    const int bid = (int)blockIdx.x < n_main ? ssac_xcd_contiguous(blockIdx.x, n_main, p.xcd) : (int)blockIdx.x;
     float *tab = lds + KS * (4 * TILE_FLOATS) + 64 * KS;  // folded loss gradient: [n_rows] row scales, then scratch
     const bool fold = p.lf.q != nullptr;
     int last = 0;
@@ -492,7 +496,12 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
         // its own.  As a side job of net 0's first GEMM tile (round 1) it made that tile the slowest workgroup of the
         // launch -- a global write -> read round trip and five barriers in front of its K loop -- and the launch is as
         // long as its slowest workgroup.
-        loss_fold_table(p.lf, 0, tab, false, tab + p.lf.n_rows, true);
+        // It also reduces every net's loss / TD-error terms (round 1: the first fc2 tile of each net, in front of its
+        // K loop): this workgroup has nothing else to do and is done long before the GEMM tiles.
+        for (int e = 0; e < p.lf_nets; ++e) {
+            loss_fold_table(p.lf, e, tab, true, tab + p.lf.n_rows, e == 0);
+            __syncthreads();
+        }
         if ((p.fold.done && p.fold.td_logs) || p.fold.deferred_stats)
             log_fold_td_stats(p.fold, p.lf.tds, tab + p.lf.n_rows);
     } else if (bid >= p.tiles01) {  // head-layer weight gradient + Adam beside the GEMM tiles
@@ -511,7 +520,7 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
         const int bz = L / per, rem = L - bz * per;
         auto pre = [&]() {
             if (fold) {  // the first fc2 tile of each net also reduces that net's loss terms
-                loss_fold_table(p.lf, bz, tab, first && rem == 0, tab + p.lf.n_rows, false);
+                loss_fold_table(p.lf, bz, tab, !p.td_wg && first && rem == 0, tab + p.lf.n_rows, false);
                 __syncthreads();
             }
         };
@@ -549,6 +558,7 @@ int launch_pair_ks(GemmPair &p, int batch0, int batch1, hipStream_t st) {
     p.tiles01 = p.tiles0 + p.g1.grid_x * p.g1.grid_y * batch1;
     p.head_total = p.head_grid_x > 0 ? p.head_grid_x * batch0 : 0;
     p.td_wg = (p.lf.q && p.lf.tds.q_t) ? 1 : 0;
+    p.lf_nets = batch0;
     const int total = p.tiles01 + p.head_total + p.td_wg;
     SSAC_LAUNCH((ens_gemm_pair_kernel<A_KC, B_KC, EPI, KS>), dim3(total), dim3(NTHREADS * KS), lds, st, p);
     return ssac_check_launch("ens_gemm_pair");

@@ -397,17 +397,17 @@ __device__ __forceinline__ void gemm_tile(typename Tile<TMR>::Acc &acc, Stage &s
         typename Tile<TMR>::Frag f;
         for (int c = 0; c < nch; ++c) {
             if (c > 0) {
-                __syncthreads();  // everybody is done with the previous chunk
+                lds_barrier();  // everybody is done with the previous chunk
                 st.store(B0, tid);
                 if (c + 1 < nch) st.load((c + 1) * 32, K);
-                __syncthreads();
+                lds_barrier();
             }
             if (c + 1 == nch) nx.load(0, Knext);
             Tile<TMR>::template read<NN>(f, As, lda, B0, c, tid & 63, col0);
             Tile<TMR>::template mfma_half<NN>(acc, f, 0);
             Tile<TMR>::template mfma_half<NN>(acc, f, 1);
         }
-        __syncthreads();
+        lds_barrier();
         return;
     }
     typename Tile<TMR>::Frag f0, f1;
@@ -422,7 +422,7 @@ __device__ __forceinline__ void gemm_tile(typename Tile<TMR>::Acc &acc, Stage &s
         pipe_step<TMR, NN>(acc, st, c, nch, K, As, lda, B1, f0, f1, tid, col0, nx, Knext);
         if (c + 1 < nch) pipe_step<TMR, NN>(acc, st, c + 1, nch, K, As, lda, B0, f1, f0, tid, col0, nx, Knext);
     }
-    __syncthreads();  // all fragment reads done before the caller reuses As / the staging buffers
+    lds_barrier();  // all fragment reads done before the caller reuses As / the staging buffers
 }
 
 // W3 (OUT x H, rows contiguous) -> LDS rows of stride ldw3.  Four independent loads are issued before the
@@ -683,7 +683,11 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
             rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
         }
         stage_first(st1, Ws, IN, tid);
-        __syncthreads();
+        // (every barrier of this body hands data over through LDS only, so it does not drain vmcnt: the activation
+        // tiles written out for the weight-gradient launch, the gathered rows and the next phase's prefetched weight
+        // chunk stay in flight across the phase boundaries.  The one global write -> read inside a workgroup, a' of
+        // the target chains, keeps a full barrier in fused_chain_kernel.)
+        lds_barrier();
 
         BSTAMP(1);
         // ---- fc1 (fc2's first weight chunk is requested during its last K chunk)
@@ -704,7 +708,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                     *reinterpret_cast<f4 *>(g.H1 + ((int64_t)e * g.n_rows + m0 + row) * H + col) = v;
             }
         });
-        __syncthreads();
+        lds_barrier();
         BSTAMP(3);
         // ---- fc2 (the backward-data phase re-reads W2 as a row-contiguous image: its first chunk is
         //      requested during fc2's last K chunk)
@@ -724,7 +728,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                     *reinterpret_cast<f4 *>(g.H2 + ((int64_t)e * g.n_rows + m0 + row) * H + col) = v;
             }
         });
-        __syncthreads();
+        lds_barrier();
 
         BSTAMP(5);
         BSTAMP(6);
@@ -754,13 +758,13 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                                                                            t < 4 ? b0[t & 3] : b1[t & 3], hacc[q], 0, 0, 0);
                     }
                 }
-                if (ob > 0) __syncthreads();  // the previous block's partials have been summed
+                if (ob > 0) lds_barrier();  // the previous block's partials have been summed
 #pragma unroll
                 for (int q = 0; q < TMR / 16; ++q)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         hpart[(wave * TMR + 16 * q + 4 * lg + r) * MAX_OUT + li] = hacc[q][r];
-                __syncthreads();
+                lds_barrier();
                 const int row = tid >> 4, o = ob + (tid & 15);
                 if (row < TMR && o < OUT) {
                     float v = b3s[o];
@@ -774,7 +778,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     }
     BSTAMP(7);
     if (MODE == MODE_PLAIN) return;
-    __syncthreads();  // hpart (= staging buffer 0) has been consumed
+    lds_barrier();  // hpart (= staging buffer 0) has been consumed
     if (IS_CRITIC) stage_first(st3, Ws, H, tid);
 
     if (MODE == MODE_SAMPLE) {
@@ -802,7 +806,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 g.act_dst[b * g.ld_act + g.act_col0 + i] = tanhf(u);
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (g.logp && tid < TMR && (m0 + tid) < g.n_rows) {
             float lp = 0.0f;
             for (int i = 0; i < A; ++i) lp += lpt[tid * ldo + i];
@@ -856,7 +860,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
             if (lane == 0) rowred[wave] = part;
-            __syncthreads();
+            lds_barrier();
             if (tid == 0) {
                 float tot = 0.0f;
                 for (int w = 0; w < NTHR / 64; ++w) tot += rowred[w];
@@ -895,7 +899,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 g.partials[pi + 1] = errv;
             }
         }
-        __syncthreads();  // dqs visible to every wave
+        lds_barrier();  // dqs visible to every wave
         BSTAMP(8);
         // ---- head backward: dz2 = (dq W3) (.) [h2 > 0], in place over h2s
         {
@@ -936,7 +940,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         }
         BSTAMP(9);
         // ---- backward-data of fc2: dz1 = (dz2 W2) (.) [h1 > 0]
-        __syncthreads();  // dz2 (in h2s) and the staged first chunk of W2 are visible
+        lds_barrier();  // dz2 (in h2s) and the staged first chunk of W2 are visible
         T::zero(acc);
         gemm_tile<TMR, true, DBUF>(acc, st3, h2s, ldh, H, Ws, Ws1, tid, col0, none, 0);
         BSTAMP(10);
@@ -956,7 +960,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         if (want_dx) {
             // dX[b][c] = sum_k dz1u[b][k] W1[k][dx_col0 + c]: the (unscaled) gradient w.r.t. the ACTION columns of the
             // critic input -- all the online actor update needs from the critics' backward pass (learning.py:402-411)
-            __syncthreads();
+            lds_barrier();
             const float *W1 = P + g.off[0];
             const int DC = g.dx_cols;
             for (int t = tid; t < TMR * DC; t += NTHR) {

@@ -73,6 +73,8 @@ typedef struct ssac_feed {
     float *log_ring;            /* device ring of log blocks, log_width floats each */
     int64_t tick;               /* updates consumed so far */
     int32_t n_slots, slot_words, log_slot_word, log_width;
+    uint32_t *late_word;        /* late-bound Polyak (ssac_late_polyak below): where the update's first launch leaves
+                                   its decision (tau bits, 0 = no request); NULL = the ring has no tail / feature off */
 } ssac_feed;
 
 /* The input ring of ssac_feed.  On a large-BAR system (the MI355X boxes: all of HBM is CPU-mappable) it is UNCACHED
@@ -81,7 +83,7 @@ typedef struct ssac_feed {
  * path; otherwise pinned host memory the launch reads over PCIe.  *device_resident tells which.  The host writes a
  * slot with ssac_feed_write (copy + store fence: write-combining buffers are drained before the launch that
  * reads the slot is submitted). */
-int ssac_feed_ring_alloc(size_t bytes, void **ring, int *device_resident);
+int ssac_feed_ring_alloc(size_t bytes, void **ring, int *device_resident); /* + SSAC_FEED_TAIL_BYTES behind, zeroed */
 int ssac_feed_ring_free(void *ring, int device_resident);
 int ssac_feed_write(void *ring_slot, const void *src, size_t bytes);
 int ssac_feed_ring_mode(int device_ok); /* 0: always pinned host memory (default 1: device memory when large-BAR) */
@@ -166,6 +168,13 @@ int ssac_step_run(ssac_step *step, const int64_t *idx_host, const int32_t *ids_h
                   void *stream);
 int64_t ssac_step_count(const ssac_step *step);
 int ssac_step_seek(ssac_step *step, int64_t k);   /* updates the ring's device-side counter has consumed so far */
+/* soft_update right after ssac_step_run (late-bound Polyak): leaves the request for the update just issued in the ring
+ * tail.  Returns 1 when the request is or will be served by that update's weight-gradient launch (nothing to launch):
+ * either the update's first launch had provably not started when the request landed, or -- the device keeping up with
+ * the host -- it had, and its decision (waited for: microseconds) was "served".  0: not served, the caller launches
+ * ssac_polyak.  -1: the decision did not arrive within 2 ms (the caller synchronises and asks ssac_step_polyak_done). */
+int ssac_step_polyak(ssac_step *step, float tau);
+int ssac_step_polyak_done(ssac_step *step);
 void ssac_step_destroy(ssac_step *step);
 
 /* ---- one-shot exchange between the ranks of a critic-sharded update (csrc/ssac_xchg.hip; SURVEY 8(e) "Transport"):
@@ -291,6 +300,19 @@ int ssac_mlp_wgrad_all_scaled(const ssac_mlp *nets, const int32_t *net_ids, int 
  * draws an arrival ticket after its last cross-workgroup store, and the last arriver sums the partials in index order,
  * writes logs[0] += loss, logs[1] = TD error of the last net, logs[2] = gradient norm, publishes the block to its ring
  * slot and advances the input ring.  No fence and no second launch (csrc/ssac_critic_logs.h). */
+/* Late-bound Polyak of a RECORDED update.  The reference calls soft_update AFTER critic_update returned
+ * (main.py:409-414), i.e. after the update's launches were queued -- but, with the host running many updates ahead of
+ * the GPU, long before they EXECUTE.  So the host leaves a request {tag = update number + 1, tau} in the tail of the
+ * input ring (ssac_step_polyak); ONE thread of the update's first launch (the one that pulls the input slot) publishes
+ * "begun", then looks for the request of its update and writes the decision (tau bits or 0) to feed->late_word; the
+ * update's weight-gradient launch reads that word and, when it is set, applies
+ * theta_bar <- (1 - tau) theta_bar + tau theta' in its Adam epilogue (the new parameters are in registers) -- no Polyak
+ * launch.  One decider, so every workgroup acts alike; "begun" is stored (and fenced) BEFORE the request is read, so a
+ * host that reads begun <= k after writing the request knows the request will be seen.
+ * Tail of the input ring (behind the n_slots slots; SSAC_FEED_TAIL_BYTES, zeroed by ssac_feed_ring_alloc):
+ *   int64 begun | int64 decided | uint32 last_served (tag) | 12 bytes pad | n_slots x {uint32 tag, uint32 tau bits}. */
+#define SSAC_FEED_TAIL_BYTES 512
+
 typedef struct ssac_logfold {
     unsigned *done_counter;   /* one zero-initialised uint32 in device memory, reset by the launch itself */
     float *logs;              /* the update's log block */
@@ -299,6 +321,8 @@ typedef struct ssac_logfold {
     float *deferred_stats;    /* != NULL (recorded updates): DEFERRED finalisation -- this launch leaves the partials and
                                  the three TD statistics (here) behind and advances the input ring; the next update's
                                  first launch, or ssac_deferred_logs_flush, writes the ring slot (ssac_deferred_logs) */
+    const uint32_t *late_word;     /* != NULL (= feed->late_word): `target` is updated only when the word is set, with
+                                      the tau it holds (the `tau` argument is ignored) */
 } ssac_logfold;
 
 /* Deferred log finalisation of a recorded update (see ssac_logfold.deferred_stats): what the finishing workgroup reads.

@@ -36,7 +36,7 @@ class Feed(C.Structure):
     """struct ssac_feed"""
     _fields_ = [("host_ring", C.c_void_p), ("dst", C.c_void_p), ("log_ring", C.c_void_p),
                 ("tick", C.c_int64), ("n_slots", C.c_int32), ("slot_words", C.c_int32),
-                ("log_slot_word", C.c_int32), ("log_width", C.c_int32)]
+                ("log_slot_word", C.c_int32), ("log_width", C.c_int32), ("late_word", C.c_void_p)]
 
 
 class Rng(C.Structure):
@@ -59,7 +59,7 @@ class PushField(C.Structure):
 class LogFold(C.Structure):
     """struct ssac_logfold"""
     _fields_ = [("done_counter", C.c_void_p), ("logs", C.c_void_p), ("td_logs", C.c_void_p), ("feed", C.c_void_p),
-                ("deferred_stats", C.c_void_p)]
+                ("deferred_stats", C.c_void_p), ("late_word", C.c_void_p)]
 
 
 class DeferredLogs(C.Structure):
@@ -178,6 +178,8 @@ SIGNATURES = {
     "ssac_fused_row_tiles": [_MP, _I, _I],
     "ssac_fused_tile_rows": [_I],
     "ssac_xcd_order": [_I],
+    "ssac_step_polyak": [_P, _F],
+    "ssac_step_polyak_done": [_P],
     "ssac_feed_ring_alloc": [C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_int)],
     "ssac_feed_ring_free": [_P, _I],
     "ssac_feed_ring_mode": [_I],

@@ -35,4 +35,18 @@ __device__ __forceinline__ void feed_pull(const ssac_feed &f) {
     if (i2 < n4) d4[i2] = v2;
     if (i3 < n4) d4[i3] = v3;
     for (int i = 4 * nt + t; i < n4; i += nt) d4[i] = s4[i];
+    // late-bound Polyak (include/ssac_hip.h): publish "begun", THEN look for this update's request -- one decider
+    if (t == 0 && f.late_word) {
+        uint32_t *tail = const_cast<uint32_t *>(f.host_ring) + (int64_t)f.n_slots * f.slot_words;
+        __hip_atomic_store(reinterpret_cast<int64_t *>(tail), f.tick + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);   // (system scope: the store is out before the loads below are issued)
+        const uint32_t *req = tail + 8 + 2 * (uint32_t)(f.tick % f.n_slots);
+        const uint32_t tag = __hip_atomic_load(req, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t bits = __hip_atomic_load(req + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const uint32_t mine = (uint32_t)(f.tick & 0x7fffffff) + 1u;
+        *f.late_word = tag == mine ? bits : 0u;
+        if (tag == mine) __hip_atomic_store(tail + 4, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // "decided": a host that found the update already begun waits for this (microseconds), then reads last_served
+        __hip_atomic_store(reinterpret_cast<int64_t *>(tail + 2), f.tick + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }

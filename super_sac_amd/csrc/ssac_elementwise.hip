@@ -7,6 +7,7 @@
 // kernels so their summation order is fixed and results are run-to-run deterministic.
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <chrono>
 #include <math.h>
 #include <stdint.h>
 
@@ -1343,14 +1344,19 @@ extern "C" int ssac_feed_ring_alloc(size_t bytes, void **ring, int *device_resid
     if (hipGetDevice(&dev) != hipSuccess) return ssac_fail("ssac_feed_ring_alloc: no device");
     if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, dev) != hipSuccess) large_bar = 0;
     *ring = nullptr;
+    // `bytes` of slots + the zero-initialised ring tail (SSAC_FEED_TAIL_BYTES: begun counter, Polyak requests)
+    const size_t total = bytes + SSAC_FEED_TAIL_BYTES;
     if (large_bar && g_ssac_feed_device &&
-        hipExtMallocWithFlags(ring, bytes, hipDeviceMallocUncached) == hipSuccess && *ring) {
+        hipExtMallocWithFlags(ring, total, hipDeviceMallocUncached) == hipSuccess && *ring) {
         *device_resident = 1;
+        if (hipMemset((char *)*ring + bytes, 0, SSAC_FEED_TAIL_BYTES) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+            return ssac_fail("ssac_feed_ring_alloc: cannot clear the ring tail");
         return 0;
     }
     (void)hipGetLastError();
-    if (hipHostMalloc(ring, bytes, hipHostMallocDefault) != hipSuccess || !*ring)
+    if (hipHostMalloc(ring, total, hipHostMallocDefault) != hipSuccess || !*ring)
         return ssac_fail("ssac_feed_ring_alloc: hipHostMalloc failed");
+    memset((char *)*ring + bytes, 0, SSAC_FEED_TAIL_BYTES);
     *device_resident = 0;
     return 0;
 }
@@ -1483,6 +1489,41 @@ extern "C" int ssac_step_run(ssac_step *s, const int64_t *idx_host, const int32_
     }
     s->k = k + 1;
     return 0;
+}
+
+// ---- late-bound Polyak (include/ssac_hip.h).  Ring tail: int64 begun | int64 decided | uint32 last_served | pad |
+//      (byte 32) n_slots x {tag, tau bits}.  The request is a posted store into the (BAR-mapped or pinned) ring; the
+//      read of `begun` that follows cannot pass it (PCIe ordering: a read does not overtake the requester's earlier
+//      posted writes), and the device publishes `begun` BEFORE it looks for the request, so "begun <= k at that read"
+//      proves the request will be seen.
+extern "C" int ssac_step_polyak(ssac_step *s, float tau) {
+    if (!s || s->k <= 0) return 0;
+    const int64_t k = s->k - 1;   // the update issued last
+    char *tail = s->ring + (size_t)s->n_slots * s->slot_bytes;
+    volatile uint32_t *req = reinterpret_cast<volatile uint32_t *>(tail + 32) + 2 * (k % s->n_slots);
+    const uint32_t tag = (uint32_t)(k & 0x7fffffff) + 1u;
+    uint32_t bits;
+    memcpy(&bits, &tau, 4);
+    req[1] = bits;
+    __builtin_ia32_sfence();
+    req[0] = tag;   // (tag last: a launch that sees the tag sees the tau)
+    __builtin_ia32_sfence();
+    if (*reinterpret_cast<volatile int64_t *>(tail) <= k) return 1;
+    // the device had already begun update k (it is keeping up with the host): its one decider takes a few microseconds
+    const auto t0 = std::chrono::steady_clock::now();
+    while (*reinterpret_cast<volatile int64_t *>(tail + 8) <= k) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return -1;
+        __builtin_ia32_pause();
+    }
+    return *reinterpret_cast<volatile uint32_t *>(tail + 16) == tag ? 1 : 0;
+}
+
+// after a stream synchronisation: was the last request served?
+extern "C" int ssac_step_polyak_done(ssac_step *s) {
+    if (!s || s->k <= 0) return 0;
+    const int64_t k = s->k - 1;
+    char *tail = s->ring + (size_t)s->n_slots * s->slot_bytes;
+    return *reinterpret_cast<volatile uint32_t *>(tail + 16) == (uint32_t)(k & 0x7fffffff) + 1u ? 1 : 0;
 }
 
 extern "C" void ssac_step_destroy(ssac_step *s) {

@@ -189,9 +189,14 @@ struct NoPre { __device__ __forceinline__ void operator()() const {} };
 // fold / last: the update's logs are folded into this launch (LogFoldArgs): thread 0 draws the arrival ticket right after
 // the workgroup's gradient-norm partial is stored -- BEFORE the optimizer stores, whose drain it must not wait for --
 // and reports through *last whether this workgroup arrived last.
+// Late-bound Polyak (include/ssac_hip.h): on = the target update of this launch waits for the decision the update's
+// first launch left in feed->late_word (tau bits, 0 = no soft_update followed this update)
+struct LateTau { bool on; uint32_t bits; };
+
 template <bool A_KC, bool B_KC, int EPI, int KS, class Pre = NoPre>
 __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int bx, int by, int bz,
-                                              const float *late_rs, Pre pre, const LogFoldArgs &fold, int &last) {
+                                              const float *late_rs, Pre pre, const LogFoldArgs &fold, int &last,
+                                              const LateTau &lt = LateTau{false, 0u}) {
     const int tid_all = threadIdx.x;
     const int kg = tid_all >> 8, tid = tid_all & 255;
     // per K-group: two staging buffers (double buffering), each [A tile | B tile]
@@ -324,6 +329,10 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
         constexpr int PER = (BM * BN) / NT_ALL;  // 16 / KS elements per thread
         ssac_adam_ctl ctl;
         if (EPI == EPI_ADAM) ctl = *g.ctl;
+        // target update in this epilogue: always (static tau) for eager callers, or only when this update's Polyak
+        // request is in the ring tail (late-bound)
+        const bool pol = g.tw != nullptr && (!lt.on || lt.bits != 0u);
+        const float tau = lt.on ? __uint_as_float(lt.bits) : g.tau;
         float gval[PER], pv[PER], mv[PER], vv[PER], tv[PER];
         int64_t ci[PER];
         bool ok[PER];
@@ -344,7 +353,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
             for (int j = 0; j < PER; ++j) {
                 const int64_t a = ok[j] ? ci[j] : coff;
                 pv[j] = g.C[a]; mv[j] = g.am[a]; vv[j] = g.av[a];
-                tv[j] = g.tw ? g.tw[a] : 0.0f;
+                tv[j] = pol ? g.tw[a] : 0.0f;
             }
         }
         // the bias gradient of this tile's rows and its optimizer state (threads < 64 of n-tile 0)
@@ -356,7 +365,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
             bsum = red[tid_all];
 #pragma unroll
             for (int gq = 1; gq < KS; ++gq) bsum += red[gq * 64 + tid_all];
-            if (EPI == EPI_ADAM) { bpv = g.pb[bi]; bmv = g.bm[bi]; bvv = g.bv[bi]; btv = g.tb ? g.tb[bi] : 0.0f; }
+            if (EPI == EPI_ADAM) { bpv = g.pb[bi]; bmv = g.bm[bi]; bvv = g.bv[bi]; btv = (pol && g.tb) ? g.tb[bi] : 0.0f; }
         }
         // ---- gradient-norm partial FIRST (it needs the gradients only), so that with the logs folded in the arrival
         //      ticket is drawn before -- not behind -- the optimizer stores
@@ -389,7 +398,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
                 g.am[ci[j]] = m;
                 g.av[ci[j]] = v;
                 g.C[ci[j]] = pn;
-                if (g.tw) g.tw[ci[j]] = tv[j] * (1.0f - g.tau) + pn * g.tau;
+                if (pol) g.tw[ci[j]] = tv[j] * (1.0f - tau) + pn * tau;
             }
         }
         if (bias_thr) {
@@ -401,7 +410,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
                 g.bm[bi] = m;
                 g.bv[bi] = v;
                 g.pb[bi] = pn;
-                if (g.tb) g.tb[bi] = btv * (1.0f - g.tau) + pn * g.tau;
+                if (pol && g.tb) g.tb[bi] = btv * (1.0f - tau) + pn * tau;
             }
         }
         GSTAMP(4);
@@ -478,6 +487,7 @@ struct GemmPair {
     int xcd;                              // XCD-contiguous tile order (ssac_internal.h)
     LossFoldArgs lf;                      // lf.q != null: dL/dq evaluated per workgroup (ssac_critic_logs.h)
     LogFoldArgs fold;                     // fold.done != null: the update's logs are finalised by the last workgroup
+    const uint32_t *late_word;            // != null: the target update waits for the decision in this word
 };
 
 template <bool A_KC, bool B_KC, int EPI, int KS>
@@ -489,6 +499,7 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
     const int bid = (int)blockIdx.x < n_main ? ssac_xcd_contiguous(blockIdx.x, n_main, p.xcd) : (int)blockIdx.x;
     float *tab = lds + KS * (4 * TILE_FLOATS) + 64 * KS;  // folded loss gradient: [n_rows] row scales, then scratch
     const bool fold = p.lf.q != nullptr;
+    const LateTau lt{p.late_word != nullptr, p.late_word ? *p.late_word : 0u};
     int last = 0;
     bool drawn = false;
     if (p.td_wg && bid == p.tiles01 + p.head_total) {
@@ -511,7 +522,13 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
             loss_fold_table(p.lf, e, tab, false, tab + p.lf.n_rows, false);
             __syncthreads();
         }
-        head_wgrad_body<4 * KS>(p.head, lds, L % p.head_grid_x, e, fold ? tab : nullptr);
+        bool hpol = p.head.target != nullptr;
+        float htau = p.head.tau;
+        if (lt.on) {
+            hpol = hpol && lt.bits != 0u;
+            htau = __uint_as_float(lt.bits);
+        }
+        head_wgrad_body<4 * KS>(p.head, lds, L % p.head_grid_x, e, fold ? tab : nullptr, hpol, htau);
     } else {
         const bool first = bid < p.tiles0;
         const GemmArgs &g = first ? p.g0 : p.g1;
@@ -525,7 +542,7 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
             }
         };
         ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % g.grid_x, rem / g.grid_x, bz, fold ? tab : nullptr, pre,
-                                           p.fold, last);
+                                           p.fold, last, lt);
         drawn = true;
     }
     if (p.fold.done) {
@@ -794,6 +811,10 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
         p.fold.deferred_stats = lossfold->tds.q_t ? logfold->deferred_stats : nullptr;
         p.fold.n_rows = n_rows;
         if (!p.fold.deferred_stats) return ssac_fail("ssac_mlp_wgrad_all_lossfold: deferred logs need the in-launch TD target");
+    }
+    if (logfold && logfold->late_word) {
+        if (!target || grads) return ssac_fail("ssac_mlp_wgrad_all_lossfold: the late-bound Polyak needs a target arena and Adam mode");
+        p.late_word = logfold->late_word;
     }
     hipStream_t st = (hipStream_t)stream;
     const int tiles = (p.g0.grid_x * p.g0.grid_y + p.g1.grid_x * p.g1.grid_y) * n_sel;

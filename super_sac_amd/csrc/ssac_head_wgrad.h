@@ -15,9 +15,18 @@ struct HeadWgradArgs {
 
 // dW3[o][k] = sum_m dq[m][o] h2[m][k];  db3[o] = sum_m dq[m][o].  Workgroup (bx, e): columns [64 bx, 64 bx + 64) of
 // net e; 64 * GROUPS threads = 64 columns x GROUPS row groups.  lds: >= GROUPS*64 + GROUPS floats.
+// pol / tau: whether and how the Polyak target is updated (the caller resolves a late-bound request, ssac_late_polyak)
+template <int GROUPS>
+__device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *lds, int bx, int e,
+                                                const float *dq_override, bool pol, float tau);
 template <int GROUPS>
 __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *lds, int bx, int e,
                                                 const float *dq_override = nullptr) {
+    head_wgrad_body<GROUPS>(a, lds, bx, e, dq_override, a.target != nullptr, a.tau);
+}
+template <int GROUPS>
+__device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *lds, int bx, int e,
+                                                const float *dq_override, bool pol, float tau) {
     float *red = lds;                 // [GROUPS][64]
     float *redb = lds + GROUPS * 64;  // [GROUPS]
     const int tid = threadIdx.x, kk = tid & 63, mg = tid >> 6;
@@ -70,7 +79,7 @@ __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *l
                     vv = vv * c.beta2 + (1.0f - c.beta2) * g2 * g2;
                     const float pn = p - c.step_size * (mm / (sqrtf(vv) / c.bc2_sqrt + c.eps));
                     a.am[i] = mm; a.av[i] = vv; a.params[i] = pn;
-                    if (a.target) a.target[i] = a.target[i] * (1.0f - a.tau) + pn * a.tau;
+                    if (pol) a.target[i] = a.target[i] * (1.0f - tau) + pn * tau;
                 }
             };
             if (kok) {

@@ -43,6 +43,9 @@ class CaptureCtx:
         self.deferred = None      # ssac_deferred_logs of this recorded update (deferred log finalisation), or None
         self.deferred_chain = False  # the chained launch was issued with the finishing workgroup
         self.deferred_used = False   # ... and the weight-gradient launch left the partials for it
+        self.late = None          # ssac_late_polyak of this recorded update (late-bound Polyak), or None
+        self.late_target = None   # ... and the target arena its weight-gradient launch carries
+        self.late_used = False
         self.defer_begin = False  # the replay gather will also do ssac_begin_update's work (vector buffers)
         self.pending_begin = None # (log block, adam ctl ptr) waiting for that gather
 

@@ -252,6 +252,7 @@ class _FastStep:
         self.shard = parallel.shard_of(self.agent)
         self.n_critics = self.agent.num_critics if self.shard is None else self.shard.num_critics  # GLOBAL ensemble
         self.in_kernel_noise = gs.in_kernel_noise
+        self.late_arenas = getattr(gs, "late_arenas", None)   # (target arena, online arena) of the late-bound Polyak
         self.calls = 0
         # a few parameter addresses checked on every call (cheap), all of them every 256 calls
         actor = self.agent.actors[0]
@@ -308,6 +309,8 @@ class _FastStep:
             ns[1] += 1
         check(lib.ssac_step_run(self.handle, idx_cpu.data_ptr(), ida, slot_i, draw, engine.stream()))
         gs.k += 1
+        if self.late_arenas is not None:
+            agent.critics[0].__dict__["_ssac_last_step"] = self   # a soft_update that follows needs no launch
         if gs.deferred is not None:
             gs.pending = slot_i   # (the previous update's block is written by the launch just issued)
         rng.choice(agent.critics)  # keep the Python RNG stream in step with learning.py:135
@@ -341,6 +344,7 @@ class _FeedRing:
 
 def _critic_update_graphed(gs, kw):
     buffer, agent, B = kw["buffer"], kw["agent"], kw["batch_size"]
+    agent.critics[0].__dict__.pop("_ssac_last_step", None)
     if gs.path == "fast":  # (the C step's slot-reuse events are not visible from here)
         torch.cuda.synchronize()
         gs.path = "slow"
@@ -376,9 +380,12 @@ def _critic_update_graphed(gs, kw):
         gs.k = 0
         gs.eps_dev = torch.empty(B, actor.action_size, device=dev) if kind == "stochastic" else None
         gs.logblk = torch.zeros(lu.LOG_WIDTH, device=dev)
+        # late-bound Polyak (include/ssac_hip.h): the decision word the update's first launch writes
+        gs.late_word = torch.zeros(4, dtype=torch.int32, device=dev) if lu.LATE_POLYAK else None
         gs.feed = engine.DeviceStruct(_lib.Feed(gs.ring.ptr, gs.inbuf.data_ptr(), ring.buf.data_ptr(), 0,
                                                 FEED_SLOTS, nbytes // 4, (8 * B + 4 * n_pad) // 4,
-                                                lu.LOG_WIDTH), dev)
+                                                lu.LOG_WIDTH,
+                                                gs.late_word.data_ptr() if gs.late_word is not None else 0), dev)
     # ---- host draws, in the reference's order: indices -> (augmentation: none here) -> noise -> subset
     buffer.total_sample_calls += 1
     idx_cpu = rng.draw_indices(len(buffer), B)
@@ -439,12 +446,20 @@ def _critic_update_graphed(gs, kw):
             ctx.deferred = _lib.DeferredLogs(
                 ws_.get("cu.c0.fparts", (N_ * 2,)).data_ptr(), N_, N_ * ttot_, ws_.get("cu.ss0", (N_ * ttot_,)).data_ptr(),
                 gs.td_stats.data_ptr(), lu.L_TD0, B, float(n_glob_), 0, gs.feed.ptr)
+            t_arena_ = kw["target_agent"].critics[0].arena(dev)
+            if (gs.late_word is not None and c_arena_.shadow is None and t_arena_.shadow is None
+                    and t_arena_.params.numel() == c_arena_.params.numel()):
+                # late-bound Polyak: the weight-gradient launch carries the target arena and waits for the decision
+                ctx.late = gs.late_word.data_ptr()
+                ctx.late_target = t_arena_
 
         def body():
             logs_, dicts_ = _critic_update_eager(**kw)
             assert not ctx.pending_begin, "deferred ssac_begin_update was never issued"
             assert ctx.deferred_used == ctx.deferred_chain, "deferred log finalisation: chain / weight-gradient mismatch"
             gs.deferred = ctx.deferred if ctx.deferred_used else None
+            gs.late_arenas = ((ctx.late_target, agent.critics[0].arena(dev))
+                              if (ctx.deferred_used and ctx.late_used) else None)
             if not ctx.published:
                 check(lib.ssac_publish_logs(gs.logblk.data_ptr(), gs.feed.ptr, engine.stream()))
             return logs_, dicts_
@@ -505,6 +520,8 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                          noise_clip, aug_mix=0.75, discrete=False, per=False, update_priorities=False,
                          dr3_coeff=0.0):
     engine.require_gpu()
+    if engine.CAPTURE is None:
+        agent.critics[0].__dict__.pop("_ssac_last_step", None)
     E = agent.ensemble_size
     assert E <= lu.MAX_MEMBERS
     dev = log_alphas[0].device
@@ -703,13 +720,18 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                     cap.deferred_used = True
                     # recorded update: the launch leaves partials + TD statistics behind and advances the input ring;
                     # the next update's first launch (or a flush) writes the ring slot
-                    lossfold["logfold"] = _lib.LogFold(0, slot.data_ptr(), 0, cap.feed, cap.deferred.td_stats)
+                    late_ptr = 0
+                    if cap.late is not None and arena.shadow is None:
+                        late_ptr = cap.late
+                        cap.late_used = True
+                        lossfold["late_target"] = cap.late_target.params
+                    lossfold["logfold"] = _lib.LogFold(0, slot.data_ptr(), 0, cap.feed, cap.deferred.td_stats, late_ptr)
                 elif FOLD_LOGS and E == 1 and not critic_clip:
                     # the log finalisation rides in the weight-gradient launch (its last workgroup to arrive): no logs launch
                     lossfold["logfold"] = _lib.LogFold(
                         ws.get("cu.done", (1,), dtype=torch.int32, zero=True).data_ptr(), slot.data_ptr(),
                         td._ssac_logs.data_ptr() if spec is not None else 0,
-                        cap.feed if (cap is not None and cap.feed) else 0, 0)
+                        cap.feed if (cap is not None and cap.feed) else 0, 0, 0)
             elif bwd_done:
                 # ... or a single-workgroup launch writes the N x B scalars for the weight-gradient launch to read
                 if spec is not None:
@@ -752,7 +774,8 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                     "stochastic actor, identity encoder, uniform sampling, no PopArt / clipping / DR3)")
             folded = engine.weight_grads(arena, X, ldx, 0, h1, h2, dq, dz2, dz1, B, adam=adam,
                                          adam_key=("critic", i), grads=grads, sumsq=ss,
-                                         rowscale=dq if (bwd_done and lossfold is None) else None, lossfold=lossfold)
+                                         rowscale=dq if (bwd_done and lossfold is None) else None, lossfold=lossfold,
+                                         target=lossfold.get("late_target") if lossfold is not None else None)
             if folded:
                 logs_done_in_wgrad = True
                 if lossfold["logfold"].feed:

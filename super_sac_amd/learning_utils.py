@@ -190,15 +190,30 @@ def _polyak_tensor(t, s, tau):
     check(lib.ssac_polyak(t.data_ptr(), s.data_ptr(), t.numel(), float(tau), engine.stream()))
 
 
+# soft_update right behind a recorded critic update: no launch -- the update's own weight-gradient launch, still
+# waiting in the queue, applies the target update in its Adam epilogue (ssac_late_polyak in include/ssac_hip.h)
+LATE_POLYAK = os.environ.get("SSAC_LATE_POLYAK", "1") == "1"
+
+
 def soft_update(target, source, tau):
     """theta_bar <- (1-tau) theta_bar + tau theta over all parameters (learning_utils.py:160-162);
     one launch over the packed arena when both sides are packed ensembles."""
     plan = target.__dict__.get("_ssac_polyak")
+    last = source.__dict__.pop("_ssac_last_step", None)  # the recorded update issued last on these critics, if any
     if plan is not None and plan[0] is source:
         # packed ensembles seen before: one C call (the arenas are re-validated by pointer every 256 calls)
         _, ta, sa, tmods, smods, calls = plan
         plan[5] = calls + 1
         if (calls & 255) or (ta.is_bound(tmods) and sa.is_bound(smods)):
+            if (last is not None and LATE_POLYAK and last.late_arenas is not None and last.late_arenas[0] is ta
+                    and last.late_arenas[1] is sa and last.gs.fast is last and last.gs.path == "fast"):
+                rc = lib.ssac_step_polyak(last.handle, float(tau))
+                if rc == 1:
+                    return  # served (or certain to be) by the update's own weight-gradient launch
+                if rc < 0:  # no decision within 2 ms (a stalled queue): settle it the slow way
+                    torch.cuda.synchronize()
+                    if lib.ssac_step_polyak_done(last.handle) == 1:
+                        return
             if ta.shadow is not None:
                 check(lib.ssac_bf16_polyak(C.byref(ta.desc()), C.byref(sa.desc()), float(tau), ta.shadow.data_ptr(),
                                            engine.stream()))

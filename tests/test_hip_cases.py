@@ -228,6 +228,79 @@ def test_graph_replay_equals_eager_launches():
     assert le[0] == lg[0] and le[1] == lg[1]
 
 
+def test_late_bound_polyak_equals_the_polyak_launch():
+    """soft_update right behind a recorded critic update leaves a request in the input ring's tail and the update's own
+    weight-gradient launch applies the target update (ssac_late_polyak): bit-identical to the Polyak launch -- whether
+    the request is served (host ahead of the device), found too late (device already past the update: the fallback
+    launches the kernel) or the mechanism is switched off."""
+    import copy
+    import math
+    import random
+    from itertools import chain
+
+    import torch
+    import super_sac_amd as ssa
+    lu = ssa.learning_utils
+
+    def run(late, sync_before, tau_seq):
+        old = lu.LATE_POLYAK
+        lu.LATE_POLYAK = late
+        served = [0, 0]
+        real_polyak = ssa._lib.lib.ssac_step_polyak
+
+        def counting(handle, tau):   # (ctypes function objects are replaceable attributes of the CDLL)
+            rc = real_polyak(handle, tau)
+            served[0 if rc == 1 else 1] += 1
+            return rc
+        try:
+            torch.manual_seed(3); np.random.seed(3); random.seed(3)
+            dev = torch.device("cuda")
+            agent = ssa.Agent(act_space_size=6, encoder=ssa.nets.IdentityEncoder(17),
+                              actor_network_cls=ssa.nets.ContinuousStochasticActor,
+                              critic_network_cls=ssa.nets.ContinuousCritic, ensemble_size=1, num_critics=4,
+                              hidden_size=64, auto_rescale_targets=False, log_std_low=-5.0, log_std_high=2.0)
+            agent.to(dev)
+            target = copy.deepcopy(agent)
+            buf = ssa.replay.ReplayBuffer(4096, device=dev)
+            buf.load_experience(*synth.synth_transitions(2000, 17, 6, seed=5))
+            copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=3e-4)
+            eopt = torch.optim.Adam(agent.encoder.parameters(), lr=1e-4)
+            la = torch.Tensor([math.log(0.1)]).to(dev); la.requires_grad = True
+            aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(128)])
+            ssa._lib.lib.ssac_step_polyak = counting
+            for k in range(48):   # (more than one trip around the 32-slot input ring)
+                if k == 8 and not sync_before:
+                    # park the device for a few milliseconds so that the host runs ahead of it, as it does in a
+                    # GPU-bound training loop (this tiny network alone keeps up with the host)
+                    torch.cuda._sleep(20_000_000)
+                ssa.learning.critic_update(
+                    buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt, encoder_optimizer=eopt,
+                    log_alphas=[la], batch_size=128, gamma=0.99, critic_clip=None, encoder_clip=None,
+                    target_critic_ensemble_n=2, weighted_bellman_temp=None, weight_type=None, pop=False,
+                    augmenter=aug, encoder_lambda=0, aug_mix=0.0, discrete=False, random_process=None,
+                    noise_clip=None, per=False, update_priorities=False, dr3_coeff=0.0)
+                if tau_seq[k % len(tau_seq)]:
+                    if sync_before:
+                        torch.cuda.synchronize()
+                    lu.soft_update(target.critics[0], agent.critics[0], tau_seq[k % len(tau_seq)])
+            params = torch.cat([p.detach().flatten() for p in agent.critics[0].parameters()]).cpu().numpy()
+            tparams = torch.cat([p.detach().flatten() for p in target.critics[0].parameters()]).cpu().numpy()
+            return params, tparams, served
+        finally:
+            lu.LATE_POLYAK = old
+            ssa._lib.lib.ssac_step_polyak = real_polyak
+
+    taus = (0.005, 0.0, 0.01, 0.0, 0.0)   # irregular pattern, two different step sizes
+    p0, t0, s0 = run(False, False, taus)
+    p1, t1, s1 = run(True, False, taus)
+    p2, t2, s2 = run(True, True, taus)
+    assert s0 == [0, 0], "switched off: no request is ever made"
+    assert s1[0] > 0, "requests are served by the weight-gradient launch (ahead of it, or decided while the host waits)"
+    assert s2[0] == 0 and s2[1] > 0, "device idle before every soft_update: every request comes too late"
+    assert np.array_equal(p0, p1) and np.array_equal(t0, t1), "served requests vs Polyak launches"
+    assert np.array_equal(p0, p2) and np.array_equal(t0, t2), "late requests must fall back to the Polyak launch"
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
 @pytest.mark.parametrize("name", sorted(synth.AFBC_CASES))
 def test_afbc_and_per_match_reference(name, fused):

@@ -735,7 +735,9 @@ def test_feed_pulls_host_slot_and_publishes_logs(ssa):
     publish_logs / critic_logs write the log block to the ring slot named in the block and advance tick."""
     import ctypes as C
     n_slots, words, width = 4, 12, 64
-    host = torch.zeros(n_slots, words, dtype=torch.int32).pin_memory()
+    # (n_slots slots + the ring tail of SSAC_FEED_TAIL_BYTES = 128 words: begun counter, Polyak requests)
+    whole = torch.zeros(n_slots * words + 128, dtype=torch.int32).pin_memory()
+    host = whole[:n_slots * words].view(n_slots, words)
     for k in range(n_slots):
         host[k] = torch.arange(words, dtype=torch.int32) + 100 * k
         host[k, words - 2] = 7 - k  # log-ring slot for update k
@@ -752,6 +754,7 @@ def test_feed_pulls_host_slot_and_publishes_logs(ssa):
         ssa._lib.check(lib.ssac_publish_logs(logs.data_ptr(), feed.ptr, ssa.engine.stream()))
         assert torch.equal(ring[7 - k % n_slots].cpu(), torch.full((width,), float(k + 1)))
         assert feed.read().tick == k + 1
+    assert int(whole[n_slots * words:].abs().sum()) == 0   # late_word is NULL: the ring tail is left alone
 
 
 def test_lazy_td_inside_critic_launch_equals_td_kernel(ssa):

@@ -526,6 +526,7 @@ struct BfWgradArgs {
     int n_rows, bp, n_nets;
     float *am, *av; const ssac_adam_ctl *ctl;
     float *target; unsigned short *tshadow; float tau;
+    const uint32_t *late_word;   // != null: the target update waits for the decision in this word (late-bound Polyak)
     float *sumsq; int64_t sumsq_stride;
     LossFoldArgs lf;
     LogFoldArgs fold;     // fold.done != null: the update's logs are finalised by the last workgroup (ssac_critic_logs.h)
@@ -564,9 +565,13 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
     const int H = g.hidden, IN = g.in_dim, K1P = g.sg.k1p;
     float *P = g.params + (int64_t)e * g.net_stride;
     float *M = g.am + (int64_t)e * g.net_stride, *V = g.av + (int64_t)e * g.net_stride;
-    float *T = g.target ? g.target + (int64_t)e * g.net_stride : nullptr;
+    // late-bound Polyak (include/ssac_hip.h): tau bits left by the update's first launch, 0 = no soft_update followed
+    const uint32_t late_bits = g.late_word ? *g.late_word : 0u;
+    const bool pol = g.target != nullptr && (g.late_word == nullptr || late_bits != 0u);
+    const float tau = g.late_word ? __uint_as_float(late_bits) : g.tau;
+    float *T = pol ? g.target + (int64_t)e * g.net_stride : nullptr;
     unsigned short *S = g.shadow + (int64_t)e * g.sg.stride;
-    unsigned short *TS = g.tshadow ? g.tshadow + (int64_t)e * g.sg.stride : nullptr;
+    unsigned short *TS = (pol && g.tshadow) ? g.tshadow + (int64_t)e * g.sg.stride : nullptr;
     const bool head = t == per_net - 1;
     WSTAMP(0);
     // ---- tile geometry (GEMM tiles)
@@ -647,7 +652,7 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
             const float pn = adam_elem(P[a], gw, m, v, ctl);
             M[a] = m; V[a] = v; P[a] = pn;
             S[g.sg.o3 + i] = f2bf(pn);
-            if (T) { const float tn = T[a] * (1.0f - g.tau) + pn * g.tau; T[a] = tn; TS[g.sg.o3 + i] = f2bf(tn); }
+            if (T) { const float tn = T[a] * (1.0f - tau) + pn * tau; T[a] = tn; TS[g.sg.o3 + i] = f2bf(tn); }
             ss += gw * gw;
         }
         if (tid == 0) {
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
             float m = M[a], v = V[a];
             const float pn = adam_elem(P[a], gb, m, v, ctl);
             M[a] = m; V[a] = v; P[a] = pn;
-            if (T) T[a] = T[a] * (1.0f - g.tau) + pn * g.tau;
+            if (T) T[a] = T[a] * (1.0f - tau) + pn * tau;
             ss += gb * gb;
         }
     } else {
@@ -729,7 +734,7 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
                         if (fc2) S[g.sg.o2 + (int64_t)j * H + col] = hq[u];
                         else S[g.sg.o1 + (int64_t)j * K1P + col] = hq[u];
                         if (T) {
-                            const float tn = tv[r] * (1.0f - g.tau) + pn * g.tau;
+                            const float tn = tv[r] * (1.0f - tau) + pn * tau;
                             T[a] = tn;
                             tq[u] = f2bf(tn);
                             if (fc2) TS[g.sg.o2 + (int64_t)j * H + col] = tq[u];
@@ -747,7 +752,7 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
             float m = mb0, v = vb0;
             const float pn = adam_elem(pb, colsum, m, v, ctl);
             M[ab] = m; V[ab] = v; P[ab] = pn;
-            if (T) T[ab] = tb0 * (1.0f - g.tau) + pn * g.tau;
+            if (T) T[ab] = tb0 * (1.0f - tau) + pn * tau;
         }
     }
     WSTAMP(3);
@@ -955,6 +960,10 @@ extern "C" int ssac_bf16_wgrad_lossfold(const ssac_mlp *nets, uint16_t *shadow, 
         g.fold.feed = logfold->feed;
         g.fold.deferred_stats = logfold->deferred_stats;
         g.fold.n_rows = n_rows;
+    }
+    if (logfold && logfold->late_word) {
+        if (!target) return ssac_fail("ssac_bf16_wgrad_lossfold: the late-bound Polyak needs the target arena");
+        g.late_word = logfold->late_word;
     }
     const size_t lds = sizeof(float) * (g.bp + 16);
     static bool attr = false;

@@ -447,7 +447,7 @@ def _critic_update_graphed(gs, kw):
                 ws_.get("cu.c0.fparts", (N_ * 2,)).data_ptr(), N_, N_ * ttot_, ws_.get("cu.ss0", (N_ * ttot_,)).data_ptr(),
                 gs.td_stats.data_ptr(), lu.L_TD0, B, float(n_glob_), 0, gs.feed.ptr)
             t_arena_ = kw["target_agent"].critics[0].arena(dev)
-            if (gs.late_word is not None and c_arena_.shadow is None and t_arena_.shadow is None
+            if (gs.late_word is not None and (c_arena_.shadow is None) == (t_arena_.shadow is None)
                     and t_arena_.params.numel() == c_arena_.params.numel()):
                 # late-bound Polyak: the weight-gradient launch carries the target arena and waits for the decision
                 ctx.late = gs.late_word.data_ptr()
@@ -721,10 +721,12 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                     # recorded update: the launch leaves partials + TD statistics behind and advances the input ring;
                     # the next update's first launch (or a flush) writes the ring slot
                     late_ptr = 0
-                    if cap.late is not None and arena.shadow is None:
+                    if cap.late is not None:
                         late_ptr = cap.late
                         cap.late_used = True
                         lossfold["late_target"] = cap.late_target.params
+                        if arena.shadow is not None:
+                            lossfold["target_shadow"] = cap.late_target.shadow
                     lossfold["logfold"] = _lib.LogFold(0, slot.data_ptr(), 0, cap.feed, cap.deferred.td_stats, late_ptr)
                 elif FOLD_LOGS and E == 1 and not critic_clip:
                     # the log finalisation rides in the weight-gradient launch (its last workgroup to arrive): no logs launch

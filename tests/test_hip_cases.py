@@ -228,7 +228,8 @@ def test_graph_replay_equals_eager_launches():
     assert le[0] == lg[0] and le[1] == lg[1]
 
 
-def test_late_bound_polyak_equals_the_polyak_launch():
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_late_bound_polyak_equals_the_polyak_launch(precision):
     """soft_update right behind a recorded critic update leaves a request in the input ring's tail and the update's own
     weight-gradient launch applies the target update (ssac_late_polyak): bit-identical to the Polyak launch -- whether
     the request is served (host ahead of the device), found too late (device already past the update: the fallback
@@ -260,6 +261,7 @@ def test_late_bound_polyak_equals_the_polyak_launch():
                               critic_network_cls=ssa.nets.ContinuousCritic, ensemble_size=1, num_critics=4,
                               hidden_size=64, auto_rescale_targets=False, log_std_low=-5.0, log_std_high=2.0)
             agent.to(dev)
+            ssa.set_precision(agent, precision)
             target = copy.deepcopy(agent)
             buf = ssa.replay.ReplayBuffer(4096, device=dev)
             buf.load_experience(*synth.synth_transitions(2000, 17, 6, seed=5))

@@ -716,7 +716,8 @@ int ssac_permute_cp(const float *src, float *dst, int n, int channels, int pixel
 /* sum of squares of x as ssac_sumsq_blocks() partials (feed ssac_clip_coef / ssac_group_norms) */
 int ssac_sumsq_blocks(void);
 int ssac_sumsq(const float *x, int64_t n, float *out_partials, void *stream);
-/* LayerNorm(eps 1e-5) + tanh (cnns.py:66-68) and its backward (one workgroup; dy_scratch n_rows*dim). */
+/* LayerNorm(eps 1e-5) + tanh (cnns.py:66-68) and its backward (a wave per row, then a workgroup per feature for
+ * dgamma / dbeta; dy_scratch n_rows*dim). */
 int ssac_ln_tanh_fwd(const float *x, int64_t ldx, const float *gamma, const float *beta, int n_rows, int dim,
                      float *out, int64_t ldo, float *xhat, float *rstd, void *stream);
 int ssac_ln_tanh_bwd(const float *d_out, int64_t ldd, const float *out, int64_t ldo, const float *xhat,

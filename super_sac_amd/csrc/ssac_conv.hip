@@ -198,41 +198,55 @@ __global__ void ln_tanh_fwd_kernel(const float *__restrict__ x, int64_t ldx, con
     }
 }
 
-// backward: d_out (n_rows x D) wrt tanh output -> dx (pre-LayerNorm), dgamma, dbeta.  One workgroup;
-// thread per row for dx, then per-feature column reductions in a fixed order.
-__global__ __launch_bounds__(1024) void ln_tanh_bwd_kernel(
+// backward: d_out (n_rows x D) wrt tanh output -> dx (pre-LayerNorm), dgamma, dbeta.  Two launches:
+//   rows:    one WAVE per row (lanes over the features, coalesced), the row's two means by a shuffle tree;
+//   columns: one workgroup per feature, 256 threads over the rows, fixed-order tree -> dgamma[j], dbeta[j].
+// (Round 1 ran this as ONE workgroup with a thread per row and serial feature loops: 170 us at B 512 / D 50.)
+__global__ __launch_bounds__(256) void ln_tanh_bwd_rows_kernel(
     const float *__restrict__ d_out, int64_t ldd, const float *__restrict__ out, int64_t ldo,
     const float *__restrict__ xhat, const float *__restrict__ rstd, const float *__restrict__ gamma,
-    int n_rows, int D, float *__restrict__ dx, int64_t ldx, float *__restrict__ dy_scratch,
-    float *__restrict__ dgamma, float *__restrict__ dbeta) {
-    for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
-        float m1 = 0.0f, m2 = 0.0f;
-        for (int j = 0; j < D; ++j) {
-            const float o = out[b * ldo + j];
-            const float dy = d_out[b * ldd + j] * (1.0f - o * o);
-            dy_scratch[(int64_t)b * D + j] = dy;
-            const float dxh = dy * gamma[j];
-            m1 += dxh;
-            m2 += dxh * xhat[(int64_t)b * D + j];
-        }
-        m1 /= (float)D;
-        m2 /= (float)D;
-        const float rs = rstd[b];
-        for (int j = 0; j < D; ++j) {
-            const float dxh = dy_scratch[(int64_t)b * D + j] * gamma[j];
-            dx[b * ldx + j] = rs * (dxh - m1 - xhat[(int64_t)b * D + j] * m2);
-        }
+    int n_rows, int D, float *__restrict__ dx, int64_t ldx, float *__restrict__ dy_scratch) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_rows) return;
+    float m1 = 0.0f, m2 = 0.0f;
+    for (int j = lane; j < D; j += 64) {
+        const float o = out[(int64_t)b * ldo + j];
+        const float dy = d_out[(int64_t)b * ldd + j] * (1.0f - o * o);
+        dy_scratch[(int64_t)b * D + j] = dy;
+        const float dxh = dy * gamma[j];
+        m1 += dxh;
+        m2 += dxh * xhat[(int64_t)b * D + j];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
+    m1 /= (float)D;
+    m2 /= (float)D;
+    const float rs = rstd[b];
+    for (int j = lane; j < D; j += 64) {
+        const float o = out[(int64_t)b * ldo + j];
+        const float dxh = d_out[(int64_t)b * ldd + j] * (1.0f - o * o) * gamma[j];
+        dx[(int64_t)b * ldx + j] = rs * (dxh - m1 - xhat[(int64_t)b * D + j] * m2);
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_tanh_bwd_cols_kernel(const float *__restrict__ dy_scratch,
+                                                               const float *__restrict__ xhat, int n_rows, int D,
+                                                               float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    __shared__ float red[2][4];
+    const int j = blockIdx.x, tid = threadIdx.x;
+    float g = 0.0f, bb = 0.0f;
+    for (int b = tid; b < n_rows; b += 256) {
+        const float dy = dy_scratch[(int64_t)b * D + j];
+        g += dy * xhat[(int64_t)b * D + j];
+        bb += dy;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { g += __shfl_xor(g, o, 64); bb += __shfl_xor(bb, o, 64); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = g; red[1][tid >> 6] = bb; }
     __syncthreads();
-    for (int j = threadIdx.x; j < D; j += blockDim.x) {
-        float g = 0.0f, bb = 0.0f;
-        for (int b = 0; b < n_rows; ++b) {
-            const float dy = dy_scratch[(int64_t)b * D + j];
-            g += dy * xhat[(int64_t)b * D + j];
-            bb += dy;
-        }
-        dgamma[j] = g;
-        dbeta[j] = bb;
+    if (tid == 0) {
+        dgamma[j] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        dbeta[j] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     }
 }
 
@@ -330,7 +344,9 @@ extern "C" int ssac_ln_tanh_bwd(const float *d_out, int64_t ldd, const float *ou
                                 int dim, float *dx, int64_t ldx, float *dy_scratch, float *dgamma,
                                 float *dbeta, void *stream) {
     if (n_rows <= 0) return 0;
-    SSAC_LAUNCH(ln_tanh_bwd_kernel, dim3(1), dim3(1024), 0, ST, d_out, ldd, out, ldo, xhat, rstd,
-                       gamma, n_rows, dim, dx, ldx, dy_scratch, dgamma, dbeta);
+    SSAC_LAUNCH(ln_tanh_bwd_rows_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, ST, d_out, ldd, out, ldo, xhat, rstd, gamma,
+                n_rows, dim, dx, ldx, dy_scratch);
+    SSAC_LAUNCH(ln_tanh_bwd_cols_kernel, dim3(dim), dim3(256), 0, ST, (const float *)dy_scratch, xhat, n_rows, dim, dgamma,
+                dbeta);
     return ssac_check_launch("ln_tanh_bwd");
 }

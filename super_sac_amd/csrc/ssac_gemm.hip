@@ -824,9 +824,6 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
         if (tiles <= 512 && nchunks >= 4) return launch_pair_ks<false, false, EPI_GRAD, 2>(p, n_sel, n_sel, st);
         return launch_pair_ks<false, false, EPI_GRAD, 1>(p, n_sel, n_sel, st);
     }
-    static const int ks_force = getenv("SSAC_WGRAD_KS") ? atoi(getenv("SSAC_WGRAD_KS")) : 0;
-    if (ks_force == 2) return launch_pair_ks<false, false, EPI_ADAM, 2>(p, n_sel, n_sel, st);
-    if (ks_force == 1) return launch_pair_ks<false, false, EPI_ADAM, 1>(p, n_sel, n_sel, st);
     if (tiles <= 256 && nchunks >= 8) return launch_pair_ks<false, false, EPI_ADAM, 4>(p, n_sel, n_sel, st);
     if (tiles <= 512 && nchunks >= 4) return launch_pair_ks<false, false, EPI_ADAM, 2>(p, n_sel, n_sel, st);
     return launch_pair_ks<false, false, EPI_ADAM, 1>(p, n_sel, n_sel, st);

@@ -716,22 +716,61 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         if (FWD_BWD) gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, st3, H);
         else gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, none, 0);
         BSTAMP(4);
+        // Single-output heads (every continuous critic): the head's dot product q = h2 . W3 is taken from the fc2
+        // accumulators right here -- each lane holds 8 or 16 columns of ONE row, so the row's partial is a lane sum, one
+        // or two shuffles and an 8-way sum over the waves through LDS -- instead of a separate MFMA pass over h2s.
+        // In the TD-independent backward mode (MODE_CRITIC_U) the head's backward, dz2u = W3 (.) [h2 > 0], needs nothing
+        // but h2's sign either, so it is written (to LDS in place of h2, and out for the weight-gradient launch) in the
+        // same pass: no head phase, no selector phase, no head-backward phase, two barriers fewer.
+        const bool dot_head = OUT == 1;
+        const bool fuse_dz2 = MODE == MODE_CRITIC_U && OUT == 1;
+        float qp = 0.0f;
         T::foreach4(acc, lane, [&](int row, int cw, f4 val) {
             const int col = col0 + cw;
             if (col < H) {
                 const f4 bq = *reinterpret_cast<const f4 *>(b2s + col);
+                const bool rok = (m0 + row) < g.n_rows;
                 f4 v;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = fmaxf(val[i] + bq[i], 0.0f);
-                *reinterpret_cast<f4 *>(h2s + row * ldh + col) = v;
-                if (g.H2 && (m0 + row) < g.n_rows)
-                    *reinterpret_cast<f4 *>(g.H2 + ((int64_t)e * g.n_rows + m0 + row) * H + col) = v;
+                if (g.H2 && rok) *reinterpret_cast<f4 *>(g.H2 + ((int64_t)e * g.n_rows + m0 + row) * H + col) = v;
+                if (dot_head) {
+                    const f4 w = *reinterpret_cast<const f4 *>(w3s + col);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) qp += v[i] * w[i];
+                    if (fuse_dz2) {
+                        f4 dz;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dz[i] = (rok && v[i] > 0.0f) ? w[i] : 0.0f;
+                        *reinterpret_cast<f4 *>(h2s + row * ldh + col) = dz;
+                        if (g.DZ2 && rok)
+                            *reinterpret_cast<f4 *>(g.DZ2 + ((int64_t)e * g.n_rows + m0 + row) * H + col) = dz;
+                    } else {
+                        *reinterpret_cast<f4 *>(h2s + row * ldh + col) = v;
+                    }
+                } else {
+                    *reinterpret_cast<f4 *>(h2s + row * ldh + col) = v;
+                }
             }
         });
+        if (dot_head) {
+            if (TMR == 16) qp += __shfl_xor(qp, 16, 64);   // 16-row tiles: a row's 32 columns sit in 4 lanes, else in 2
+            qp += __shfl_xor(qp, 32, 64);
+            if (lane < TMR) hpart[wave * TMR + lane] = qp;   // (waves beyond the layer width hold zeros)
+        }
         lds_barrier();
 
         BSTAMP(5);
         BSTAMP(6);
+        if (dot_head) {
+            if (tid < TMR) {
+                float v = b3s[0];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += hpart[w * TMR + tid];
+                ys[tid * ldo] = v;
+                if (g.Y && (m0 + tid) < g.n_rows) g.Y[(int64_t)e * g.n_rows + m0 + tid] = v;
+            }
+        } else
         // ---- head on the matrix cores: wave w multiplies the k-slice [32w, 32w+32) of h2 with W3^T
         //      (a 16-wide B tile, rows >= OUT zero); the 8 partial tiles are summed through LDS.
         {
@@ -866,6 +905,8 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 for (int w = 0; w < NTHR / 64; ++w) tot += rowred[w];
                 ab.partials[bx] = tot;
             }
+        } else if (UNSCALED && MODE == MODE_CRITIC_U && OUT == 1) {
+            // (dz2u was written by the fc2 epilogue: nothing to select, no head backward)
         } else if (UNSCALED) {
             // selector of the head output the loss looks at (the taken action; the only output when OUT == 1)
             if (tid < TMR) {
@@ -899,10 +940,11 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 g.partials[pi + 1] = errv;
             }
         }
-        lds_barrier();  // dqs visible to every wave
+        const bool dz2_done = MODE == MODE_CRITIC_U && OUT == 1;
+        if (!dz2_done) lds_barrier();  // dqs visible to every wave
         BSTAMP(8);
         // ---- head backward: dz2 = (dq W3) (.) [h2 > 0], in place over h2s
-        {
+        if (!dz2_done) {
             // thread -> 4 consecutive columns k = 4 (tid % 64), rows r = (tid >> 6), +8, ...  (H <= 256): 16-byte LDS
             // reads / writes and global stores.  gs accumulates over o in index order per element, as before.
             const int k = (tid & 63) * 4;

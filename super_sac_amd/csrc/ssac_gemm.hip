@@ -513,6 +513,10 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
             loss_fold_table(p.lf, e, tab, true, tab + p.lf.n_rows, e == 0);
             __syncthreads();
         }
+        if (p.lf_nets == 0) {   // multi-round launch: the tiles reduce their nets' loss terms, this one only the TD part
+            loss_fold_table(p.lf, 0, tab, false, tab + p.lf.n_rows, true);
+            __syncthreads();
+        }
         if ((p.fold.done && p.fold.td_logs) || p.fold.deferred_stats)
             log_fold_td_stats(p.fold, p.lf.tds, tab + p.lf.n_rows);
     } else if (bid >= p.tiles01) {  // head-layer weight gradient + Adam beside the GEMM tiles
@@ -537,7 +541,7 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
         const int bz = L / per, rem = L - bz * per;
         auto pre = [&]() {
             if (fold) {  // the first fc2 tile of each net also reduces that net's loss terms
-                loss_fold_table(p.lf, bz, tab, !p.td_wg && first && rem == 0, tab + p.lf.n_rows, false);
+                loss_fold_table(p.lf, bz, tab, p.lf_nets == 0 && first && rem == 0, tab + p.lf.n_rows, false);
                 __syncthreads();
             }
         };
@@ -575,7 +579,9 @@ int launch_pair_ks(GemmPair &p, int batch0, int batch1, hipStream_t st) {
     p.tiles01 = p.tiles0 + p.g1.grid_x * p.g1.grid_y * batch1;
     p.head_total = p.head_grid_x > 0 ? p.head_grid_x * batch0 : 0;
     p.td_wg = (p.lf.q && p.lf.tds.q_t) ? 1 : 0;
-    p.lf_nets = batch0;
+    // the TD workgroup takes over the per-net loss terms only while the launch is ONE round of workgroups (it then has
+    // ~25 us of slack); in a multi-round launch (N = 16) a serial pass over 16 nets would itself become the tail
+    p.lf_nets = (p.td_wg && p.tiles01 + p.head_total + 1 <= 256) ? batch0 : 0;
     const int total = p.tiles01 + p.head_total + p.td_wg;
     SSAC_LAUNCH((ens_gemm_pair_kernel<A_KC, B_KC, EPI, KS>), dim3(total), dim3(NTHREADS * KS), lds, st, p);
     return ssac_check_launch("ens_gemm_pair");

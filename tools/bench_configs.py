@@ -80,6 +80,8 @@ for precision in ("fp32", "bf16"):
     if len(sys.argv) > 1 and sys.argv[1] not in name:  # optional row filter: python tools/bench_configs.py Humanoid
         continue
     critic, env_step = build(obs, act, B, N, n, precision=precision)
+    import gc
+    gc.collect(); gc.freeze()   # (as bench.py and INTEGRATION.md: no generation-2 collection pause inside a timed row)
     t = timed(critic, 1500, 200)
     print(f"| {name} | {precision} | {obs} / {act} | {B} | {N} ({n}) | {t * 1e6:.1f} | {1 / t:.0f} |")
     if name in ("REDQ (headline)", "REDQ") and N == 10:

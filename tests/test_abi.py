@@ -39,10 +39,25 @@ def test_layout_matches_header_contract():
     assert stride == 72196 and stride % 4 == 0  # 72193 params padded to a multiple of 4
 
 
-def test_struct_sizes_match_the_c_side():
+def test_struct_sizes_match_the_c_side(tmp_path):
+    """every ctypes mirror in _lib.py against sizeof() of the struct in include/ssac_hip.h, as gcc lays it out (the
+    header is plain C; a field added on one side only shows up here, on the CPU)"""
+    import subprocess
     from super_sac_amd import _lib
-    assert ctypes.sizeof(_lib.AdamCtl) == 72 and ctypes.sizeof(_lib.PopArtState) == 40
-    assert ctypes.sizeof(_lib.MlpDesc) == 32 and ctypes.sizeof(_lib.Feed) == 48
+    pairs = {"ssac_mlp": _lib.MlpDesc, "ssac_adam_ctl": _lib.AdamCtl, "ssac_popart": _lib.PopArtState,
+             "ssac_feed": _lib.Feed, "ssac_rng": _lib.Rng, "ssac_td_spec": _lib.TdSpec,
+             "ssac_push_field": _lib.PushField, "ssac_logfold": _lib.LogFold,
+             "ssac_deferred_logs": _lib.DeferredLogs, "ssac_gather": _lib.Gather}
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "ssac_hip.h"\nint main(void) {\n' +
+                   "".join(f'    printf("{n} %zu\\n", sizeof({n}));\n' for n in pairs) + "    return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    sizes = dict((ln.split()[0], int(ln.split()[1])) for ln in out.strip().splitlines())
+    for name, cls in pairs.items():
+        assert ctypes.sizeof(cls) == sizes[name], (name, ctypes.sizeof(cls), sizes[name])
+    assert sizes["ssac_adam_ctl"] == 72 and sizes["ssac_popart"] == 40 and sizes["ssac_mlp"] == 32
 
 
 def test_update_path_refuses_to_run_without_a_gpu():

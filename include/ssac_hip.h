@@ -472,6 +472,19 @@ int ssac_markov_logs(const float *inverse_raw, float inverse_scale, const float 
 int ssac_frobenius_diff_bwd(const float *a, int64_t lda, const float *b, int64_t ldb, int n_rows, int dim, float coeff,
                             float *d_a, int64_t ldd, int accumulate, float *loss_out, float *add_to, void *stream);
 
+/* action invariance constraint (learning_utils.py:272-285; offline_actor_update's actor_lambda term).  act: the action
+ * sampled from the actor's distribution at the ORIGINAL observation, olp (n_rows) its log-probability there; out_a
+ * (n_rows x 2 act_dim): the actor's output at the AUGMENTED observation.  loss_out[0] = F.mse_loss(olp, alp) with
+ * alp_b = log pi_a(act_b) through atanh(clamp(act, +-0.99)); d_out = coeff * d loss / d out_a; add_to[0] += coeff*loss. */
+int ssac_action_invariance_bwd(const float *out_a, int64_t ld_out, const float *act, int64_t ld_act, const float *olp,
+                               int n_rows, int act_dim, float log_std_lo, float log_std_hi, float coeff, float *d_out,
+                               int64_t ld_dout, float *loss_out, float *add_to, void *stream);
+/* ... categorical actors: logits at the original / augmented observation, act (n_rows) the sampled class as float;
+ * the reference sums the (B,) log-probabilities before the mse: loss = (sum_b olp_b - sum_b alp_b)^2. */
+int ssac_action_invariance_discrete_bwd(const float *logits_o, const float *logits_a, const float *act, int n_rows,
+                                        int n_actions, float coeff, float *d_logits, float *loss_out, float *add_to,
+                                        void *stream);
+
 /* ---- actor loss gradient, continuous: learning.py:392-408.
  * q (n_nets x n_rows): min over ALL nets (learning.py:402), arg-min routing.
  * dq[j][b] = -(popart_w) / (n_rows*E) for j = argmin_b else 0;  logs[0] += -mean(minq' - bonus)/E,

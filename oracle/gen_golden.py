@@ -909,6 +909,93 @@ def run_bc_pixels_case(name, cfg):
     np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
 
 
+def run_actor_inv_case(name, cfg):
+    """learning.offline_actor_update(actor_lambda > 0, filter_=False, per=False) on the unmodified reference: the BC
+    loss plus the action invariance constraint (learning_utils.py:272-285), with and without update_encoder."""
+    print(f"== {name}")
+    torch.manual_seed(cfg["seed"]); np.random.seed(cfg["seed"]); random.seed(cfg["seed"])
+    B, A, E, px, disc = cfg["B"], cfg["act"], cfg["E"], cfg.get("pixels"), bool(cfg["discrete"])
+    if px:
+        s, a, r, s1, d = synth.synth_pixel_transitions(cfg["rows"], px["channels"], px["hw"], n_actions=A if disc else None,
+                                                      act_dim=A, seed=cfg["seed"] + 100)
+    else:
+        s, a, r, s1, d = synth.synth_transitions(cfg["rows"], cfg["obs"], A, disc, seed=cfg["seed"] + 100, n_actions=A)
+    rbuf = ref.replay.ReplayBuffer(cfg["cap"])
+    rbuf.load_experience(s, a, r, s1, d)
+    obuf = orc.ReplayOracle(cfg["cap"])
+    obuf.load_experience(s, a, r, s1, d)
+    ra, oa = build_pair(cfg)
+    oa.requires_grad_(True)
+    enc_lr = px["enc_lr"] if px else 1e-4
+    r_aopt = torch.optim.Adam(chain(*(ac.parameters() for ac in ra.actors)), lr=cfg["lr"], betas=(0.9, 0.999))
+    r_eopt = torch.optim.Adam(ra.encoder.parameters(), lr=enc_lr, betas=(0.9, 0.999))
+    o_aopt = orc.AdamOracle(oa.actor_params(), lr=cfg["lr"])
+    o_eopt = orc.AdamOracle(oa.encoder_params(), lr=enc_lr)
+    if px:
+        r_aug = ref.augmentations.AugmentationSequence([ref.augmentations.Drqv2Aug(B)])
+        o_aug = orc.AugOracle("drqv2", B)
+    else:
+        r_aug = ref.augmentations.AugmentationSequence([ref.augmentations.IdentityAug(B)])
+        o_aug = orc.AugOracle("identity", B)
+    aug_mix = px["aug_mix"] if px else 0.0
+    lam = cfg["actor_lambda"]
+    rec = {"n_steps": np.int64(len(cfg["steps"]))}
+    for k, stp in enumerate(cfg["steps"]):
+        st, pst = torch.get_rng_state(), random.getstate()
+        idxs, shifts, epss, cats = [], [], [], []
+        for i in range(E):
+            idx = torch.randint(len(rbuf), (B,)).numpy()
+            idxs.append(idx)
+            if px:
+                shifts.append(orc.drqv2_draw_shift(B))
+            if disc:
+                with torch.no_grad():   # o_dist.sample(): the reference's own draw at this point of the stream
+                    oo = {"obs": torch.from_numpy(s["obs"][idx]).float()}
+                    cats.append(ra.actors[i](ra.encoder(oo)).sample())
+            else:
+                epss.append(torch.randn(B, A))
+        gpick = random.choice(range(E))   # random.choice(agent.actors), learning.py:210-212
+        torch.set_rng_state(st); random.setstate(pst)
+        rlogs = rl.offline_actor_update(
+            buffer=rbuf, agent=ra, actor_optimizer=r_aopt, encoder_optimizer=r_eopt, batch_size=B,
+            actor_clip=stp["clip"], update_encoder=stp["update_encoder"], encoder_clip=stp.get("enc_clip"),
+            augmenter=r_aug, actor_lambda=lam, aug_mix=aug_mix, premade_replay_dicts=None, per=False, discrete=disc,
+            filter_=False)
+        if px:
+            o_aug.forced = [sh.clone() for sh in shifts]
+        ologs, _, _, _ = orc.offline_actor_update(
+            obuf, None, oa, o_aopt, B, stp["clip"], o_aug, aug_mix, per=False, filter_=False, idx_list=idxs,
+            update_encoder=stp["update_encoder"], encoder_opt=o_eopt, encoder_clip=stp.get("enc_clip"),
+            actor_lambda=lam, inv_eps_list=epss or None, inv_cat_list=cats or None, grad_pick=gpick)
+        rec[f"s{k}_gpick"] = np.int64(gpick)
+        for i in range(E):
+            rec[f"s{k}_idx{i}"] = np.asarray(idxs[i], np.int64)
+            if px:
+                rec[f"s{k}_shift{i}"] = shifts[i].numpy()
+            if disc:
+                rec[f"s{k}_cat{i}"] = cats[i].numpy().astype(np.int64)
+            else:
+                rec[f"s{k}_eps{i}"] = epss[i].numpy()
+        for key, val in rlogs.items():
+            v = float(val)
+            rec[f"s{k}_log:{key}"] = np.float64(v)
+            assert abs(v - float(ologs[key])) <= 2e-4 * max(1.0, abs(v)), (key, v, ologs[key])
+    _, rac = ref_params(ra, cfg)
+    dpar = maxdiff(rac, oa.actor_params())
+    print(f"   actor params max|diff| {dpar:.3e}")
+    assert dpar < 5e-5
+    rec["final_actor"] = np.concatenate([p.detach().numpy().ravel() for p in rac])
+    if px:
+        re_ = ref_encoder_params(ra.encoder, cfg)
+        assert_encoder_close(re_, oa.encoder_params())
+        vals = []
+        for p in re_:
+            flat = p.detach().numpy().ravel()
+            vals.append(flat[synth.fingerprint_indices(flat.size)])
+        rec["finalfp_encoder"] = np.concatenate(vals)
+    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
+
+
 def synth_markov_models(cfg):
     """seeded inverse / contrastive model weights of a Markov case (the same draw everywhere: generator, tests)"""
     px = cfg.get("pixels")
@@ -937,4 +1024,7 @@ if __name__ == "__main__":
     for name, cfg in synth.BC_PIXEL_CASES.items():
         if not only or name in only:
             run_bc_pixels_case(name, cfg)
+    for name, cfg in synth.ACTOR_INV_CASES.items():
+        if not only or name in only:
+            run_actor_inv_case(name, cfg)
     print("golden fixtures written to", OUT)

@@ -1014,7 +1014,7 @@ def advantage(agent, o, a, i, eps_list=None, method="mean", n=4, grad=False):
 def offline_actor_update(buffer, per_tree, agent, actor_opt, batch_size, actor_clip, augmenter, aug_mix,
                          per=True, filter_=True, dicts=None, idx_list=None, eps_lists=None,
                          prio_member=None, prio_eps=None, method="mean", update_encoder=False, encoder_opt=None,
-                         encoder_clip=None):
+                         encoder_clip=None, actor_lambda=0.0, inv_eps_list=None, inv_cat_list=None, grad_pick=0):
     """learning.py:144-219 for identity encoders (update_encoder has nothing to update), actor_lambda 0.
     per_tree: PerOracle over the buffer's rows (None when per is False).
     eps_lists[i]: the 4 normal draws of member i's advantage estimate; prio_member / prio_eps: the
@@ -1061,6 +1061,28 @@ def offline_actor_update(buffer, per_tree, agent, actor_opt, batch_size, actor_c
         loss_i = -logp.mean()
         logs[f"losses/filterd_bc_loss_{i}"] = loss_i.item()
         total = total + loss_i
+        if actor_lambda:
+            # action invariance constraint (learning_utils.py:272-285): an action sampled from the actor at the ORIGINAL
+            # observation (no gradient) must be as likely at the AUGMENTED one; the second log-probability goes through
+            # a fresh distribution object, i.e. through atanh(clamp(a)) for the tanh-normal (distributions.py:74-84).
+            # inv_eps_list[i]: the normal draw of o_dist.sample(); inv_cat_list[i]: the sampled classes (discrete)
+            oo, ao = rd["original_obs"][0], rd["augmented_obs"][0]
+            with torch.no_grad():
+                out_o = mlp3(agent.actors[i], encode(agent.encoder, oo))[0]
+                if agent.discrete:
+                    a_s = (inv_cat_list[i] if inv_cat_list is not None
+                           else torch.distributions.Categorical(logits=out_o).sample())
+                    olp = torch.log_softmax(out_o, -1).gather(-1, a_s.long().unsqueeze(-1)).squeeze(-1)
+                    olp = olp.sum(-1, keepdim=True)   # (the reference sums the (B,) log-probabilities: one number)
+                else:
+                    eps = inv_eps_list[i] if inv_eps_list is not None else torch.randn(batch_size, agent.act_dim)
+                    a_s, olp = tanh_normal_sample(out_o, agent.lo, agent.hi, eps)
+            out_a = mlp3(agent.actors[i], encode(agent.encoder, ao))[0]   # WITH gradient, encoder included
+            if agent.discrete:
+                alp = torch.log_softmax(out_a, -1).gather(-1, a_s.long().unsqueeze(-1)).squeeze(-1).sum(-1, keepdim=True)
+            else:
+                alp = tanh_normal_log_prob_data(out_a, agent.lo, agent.hi, a_s)
+            total = total + actor_lambda * F.mse_loss(olp, alp)
     loss = total / agent.E
     actor_opt.zero_grad()
     if encoder_opt is not None:
@@ -1075,7 +1097,7 @@ def offline_actor_update(buffer, per_tree, agent, actor_opt, batch_size, actor_c
         encoder_opt.step()
     logs["losses/filtered_bc_overall_loss"] = loss.item()
     # learning.py:209-214 (all AFBC fixtures have one member: the random.choice pick is member 0)
-    logs["gradients/actor_offline_grad_norm"] = grad_norm([agent.actors[0][k] for k in MLP_KEYS])
+    logs["gradients/actor_offline_grad_norm"] = grad_norm([agent.actors[grad_pick][k] for k in MLP_KEYS])
     logs["gradients/encoder_offline_actorloss_grad_norm"] = grad_norm(agent.encoder_params())
     new_prio = None
     if per:

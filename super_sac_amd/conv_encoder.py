@@ -243,17 +243,21 @@ class ConvEncoderEngine:
             dy = dprev
 
     # ------------------------------------------------------------------------------------
-    def optimizer_step(self, optimizer, clip, norm_out=None):
-        """clip_grad_norm_(encoder.parameters(), clip) + encoder_optimizer.step() (learning.py:127-129)."""
+    def optimizer_step(self, optimizer, clip, norm_out=None, step=True):
+        """clip_grad_norm_(encoder.parameters(), clip) + encoder_optimizer.step() (learning.py:127-129).
+        step=False: clip and log only (offline_actor_update without update_encoder, learning.py:203-208)."""
         st = engine.stream()
         adam = engine.adam_group(optimizer, self.device)
-        adam.advance()
+        if step:
+            adam.advance()
         nb = int(lib.ssac_sumsq_blocks())
         ss = self.ws.get("o.ss", (nb,))
         check(lib.ssac_sumsq(self.grads.data_ptr(), self.numel, ss.data_ptr(), st))
         check(lib.ssac_clip_coef(adam.ctl.ptr, ss.data_ptr(), nb, float(clip) if clip else 0.0, 0, st))
         if norm_out is not None:
             check(lib.ssac_group_norms(ss.data_ptr(), 1, nb, adam.ctl.ptr, norm_out.data_ptr(), st))
+        if not step:
+            return
         m, v = adam.moments_for("conv_encoder", self.flat)
         check(lib.ssac_adam_step(self.flat.data_ptr(), m.data_ptr(), v.data_ptr(), self.grads.data_ptr(),
                                  self.numel, adam.ctl.ptr, st))

@@ -134,6 +134,87 @@ __global__ __launch_bounds__(MK_THREADS) void frobenius_diff_bwd_kernel(const fl
     }
 }
 
+// Action invariance constraint (learning_utils.py:272-285), tanh-normal actor.  act: the action sampled from the actor's
+// distribution at the ORIGINAL observation (no gradient), olp its log-probability there (cached pre-tanh value);
+// out_a: the actor's output at the AUGMENTED observation.  alp_b = log pi_a(act_b) goes through the TanhTransform's
+// inverse, atanh(clamp(a, +-0.99)) (a fresh distribution object: no cache; distributions.py:74-84), summed over the
+// action dimensions; loss = F.mse_loss(olp, alp) = mean_b (olp_b - alp_b)^2; d_out = coeff * d loss / d out_a.
+__global__ __launch_bounds__(MK_THREADS) void action_invariance_bwd_kernel(
+    const float *__restrict__ out_a, int64_t ld_out, const float *__restrict__ act, int64_t ld_act,
+    const float *__restrict__ olp, int n_rows, int A, float lo, float hi, float coeff, float *__restrict__ d_out,
+    int64_t ld_dout, float *__restrict__ loss_out, float *__restrict__ add_to) {
+    __shared__ float scratch[16];
+    constexpr float LOG_SQRT_2PI_ = 0.91893853320467274178f, LOG_2_ = 0.69314718055994530942f;
+    float acc = 0.0f;
+    for (int b = threadIdx.x; b < n_rows; b += MK_THREADS) {
+        float lp = 0.0f;
+        for (int i = 0; i < A; ++i) {
+            const float mu = out_a[b * ld_out + i], raw = out_a[b * ld_out + A + i];
+            const float log_std = lo + 0.5f * (hi - lo) * (tanhf(raw) + 1.0f);
+            const float sd = expf(log_std);
+            const float y = fminf(fmaxf(act[b * ld_act + i], -0.99f), 0.99f);
+            const float x = 0.5f * (log1pf(y) - log1pf(-y));
+            const float dlt = x - mu;
+            const float sp = -2.0f * x > 20.0f ? -2.0f * x : log1pf(expf(-2.0f * x));   // F.softplus
+            lp += (-(dlt * dlt) / (2.0f * sd * sd) - log_std - LOG_SQRT_2PI_) - 2.0f * (LOG_2_ - x - sp);
+        }
+        const float diff = lp - olp[b];
+        acc += diff * diff;
+        const float coef = coeff * 2.0f * diff / (float)n_rows;   // d loss / d alp_b
+        for (int i = 0; i < A; ++i) {
+            const float mu = out_a[b * ld_out + i], raw = out_a[b * ld_out + A + i];
+            const float t = tanhf(raw);
+            const float sd = expf(lo + 0.5f * (hi - lo) * (t + 1.0f));
+            const float y = fminf(fmaxf(act[b * ld_act + i], -0.99f), 0.99f);
+            const float dlt = 0.5f * (log1pf(y) - log1pf(-y)) - mu;
+            const float r2 = (dlt * dlt) / (sd * sd);
+            d_out[b * ld_dout + i] = coef * (dlt / (sd * sd));
+            d_out[b * ld_dout + A + i] = coef * (r2 - 1.0f) * 0.5f * (hi - lo) * (1.0f - t * t);
+        }
+    }
+    const float tot = mk_block_sum(acc, scratch);
+    if (threadIdx.x == 0) {
+        loss_out[0] = tot / (float)n_rows;
+        if (add_to) add_to[0] += coeff * tot / (float)n_rows;
+    }
+}
+
+// ... categorical actor.  The reference sums the (B,) log-probabilities over dim -1 before the mse
+// (learning_utils.py:280-285: `.sum(-1, keepdim=True)` of a Categorical's log_prob), so the loss is
+// (sum_b olp_b - sum_b alp_b)^2 -- reproduced as is.  logits_o / logits_a: actor outputs at the original / augmented obs.
+__global__ __launch_bounds__(MK_THREADS) void action_invariance_discrete_bwd_kernel(
+    const float *__restrict__ logits_o, const float *__restrict__ logits_a, const float *__restrict__ act, int n_rows,
+    int A, float coeff, float *__restrict__ d_logits, float *__restrict__ loss_out, float *__restrict__ add_to) {
+    __shared__ float scratch[16];
+    auto logp_of = [&](const float *x, int ai, float &lse) {
+        float mx = x[0];
+        for (int t = 1; t < A; ++t) mx = fmaxf(mx, x[t]);
+        float se = 0.0f;
+        for (int t = 0; t < A; ++t) se += expf(x[t] - mx);
+        lse = mx + logf(se);
+        return x[ai] - lse;
+    };
+    float acc = 0.0f;
+    for (int b = threadIdx.x; b < n_rows; b += MK_THREADS) {
+        const int ai = (int)act[b];
+        float l0, l1;
+        acc += logp_of(logits_a + (int64_t)b * A, ai, l1) - logp_of(logits_o + (int64_t)b * A, ai, l0);
+    }
+    const float S = mk_block_sum(acc, scratch);   // sum_b alp_b - sum_b olp_b
+    for (int b = threadIdx.x; b < n_rows; b += MK_THREADS) {
+        const int ai = (int)act[b];
+        const float *x = logits_a + (int64_t)b * A;
+        float lse;
+        (void)logp_of(x, ai, lse);
+        for (int t = 0; t < A; ++t)
+            d_logits[(int64_t)b * A + t] = coeff * 2.0f * S * ((t == ai ? 1.0f : 0.0f) - expf(x[t] - lse));
+    }
+    if (threadIdx.x == 0) {
+        loss_out[0] = S * S;
+        if (add_to) add_to[0] += coeff * S * S;
+    }
+}
+
 // logs[0..4) = inverse loss, contrastive loss, smoothness loss, total (learning.py:313-317, 337-340)
 __global__ void markov_logs_kernel(const float *inv_raw, float inv_scale, const float *con, const float *smooth,
                                    float ic, float cc, float sc, float *logs) {
@@ -180,4 +261,25 @@ extern "C" int ssac_frobenius_diff_bwd(const float *a, int64_t lda, const float 
     SSAC_LAUNCH(frobenius_diff_bwd_kernel, dim3(1), dim3(MK_THREADS), 0, (hipStream_t)stream, a, lda, b, ldb, n_rows, dim,
                 coeff, d_a, ldd, accumulate, loss_out, add_to);
     return ssac_check_launch("frobenius_diff_bwd");
+}
+
+extern "C" int ssac_action_invariance_bwd(const float *out_a, int64_t ld_out, const float *act, int64_t ld_act,
+                                          const float *olp, int n_rows, int act_dim, float log_std_lo, float log_std_hi,
+                                          float coeff, float *d_out, int64_t ld_dout, float *loss_out, float *add_to,
+                                          void *stream) {
+    if (!out_a || !act || !olp || !d_out || !loss_out || n_rows <= 0 || act_dim <= 0)
+        return ssac_fail("ssac_action_invariance_bwd: bad arguments");
+    SSAC_LAUNCH(action_invariance_bwd_kernel, dim3(1), dim3(MK_THREADS), 0, (hipStream_t)stream, out_a, ld_out, act, ld_act,
+                olp, n_rows, act_dim, log_std_lo, log_std_hi, coeff, d_out, ld_dout, loss_out, add_to);
+    return ssac_check_launch("action_invariance_bwd");
+}
+
+extern "C" int ssac_action_invariance_discrete_bwd(const float *logits_o, const float *logits_a, const float *act,
+                                                   int n_rows, int n_actions, float coeff, float *d_logits,
+                                                   float *loss_out, float *add_to, void *stream) {
+    if (!logits_o || !logits_a || !act || !d_logits || !loss_out || n_rows <= 0 || n_actions <= 0)
+        return ssac_fail("ssac_action_invariance_discrete_bwd: bad arguments");
+    SSAC_LAUNCH(action_invariance_discrete_bwd_kernel, dim3(1), dim3(MK_THREADS), 0, (hipStream_t)stream, logits_o, logits_a,
+                act, n_rows, n_actions, coeff, d_logits, loss_out, add_to);
+    return ssac_check_launch("action_invariance_discrete_bwd");
 }

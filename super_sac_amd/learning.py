@@ -1093,15 +1093,19 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
     """learning.py:144-219: advantage-filtered behavioural cloning (AWAC / AFBC actor update), optionally on a
     prioritised batch whose priorities are refreshed from the advantage afterwards."""
     engine.require_gpu()
-    if actor_lambda:
-        raise NotImplementedError("action invariance constraint (SURVEY 8(f) rank 4) is not accelerated")
     lu.ensure_adopted(agent, buffer)
     E = agent.ensemble_size
     # the BC warm-up (main.py:292-312) trains a pixel encoder THROUGH the BC loss: the actor's input gradient goes
     # back through the conv engine, then clip + encoder_optimizer.step()
-    train_enc = bool(update_encoder) and not lu.is_identity(agent.encoder)
-    if train_enc and E != 1:
+    pixel = not lu.is_identity(agent.encoder)
+    train_enc = bool(update_encoder) and pixel
+    # the action invariance constraint (learning_utils.py:272-285) reaches the encoder through the AUGMENTED
+    # observations whether or not update_encoder is set (only encoder_optimizer.step() depends on it)
+    enc_grad = train_enc or (bool(actor_lambda) and pixel)
+    if enc_grad and E != 1:
         raise NotImplementedError("trainable encoders are supported for ensemble_size == 1")
+    if actor_lambda and any(lu.actor_kind(a_) == "deterministic" for a_ in agent.actors):
+        raise NotImplementedError("action invariance constraint on a deterministic actor")
     dev = next(agent.actors[0].parameters()).device
     ws = lu.agent_ws(agent, dev)
     adam = engine.adam_group(actor_optimizer, dev)
@@ -1116,7 +1120,7 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
             rd = premade_replay_dicts[i]
         else:
             rd = lu.sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter,
-                                            aug_mix=aug_mix, per=per)
+                                            aug_mix=aug_mix, per=per, _invariance=bool(actor_lambda))
         o, a = rd["primary_batch"][0], rd["primary_batch"][1]
         actor = agent.actors[i]
         mask_ptr = 0
@@ -1124,35 +1128,93 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
             res = agent.adv_estimator.evaluate(o, a, i, want=("mask",), log_ptr=slot[lu.L_ADVW:].data_ptr())
             mask_ptr = res["mask"].data_ptr()
             logs["losses/adv_weights_mean"] = slot[lu.L_ADVW]
-        s_rep = lu.encode(agent.encoder, o, save=train_enc)
-        B, S = s_rep.shape
-        lds = lu._row_stride(s_rep)
         a_arena = engine.bind_arena(actor, "self", [actor], dev)
-        ah1, ah2, aout = engine.mlp_forward(a_arena, s_rep, lds, 0, B, ws, f"bc.a{i}")
         A = actor.action_size
+        O = A if discrete else 2 * A
+        rows = batch_size
+        if actor_lambda:
+            # ---- action invariance (learning_utils.py:272-285).  (1) at the ORIGINAL observations, without gradient:
+            #      sample an action from the actor's distribution and keep its log-probability there
+            if rd.get("augmented_obs") is None:
+                raise NotImplementedError("actor_lambda needs replay dicts made with the invariance observations")
+            oo, ao = rd["original_obs"][0], rd["augmented_obs"][0]
+            B = batch_size
+            os_rep = lu.encode(agent.encoder, oo, dst=ws.get("bc.osrep", (B, agent.encoder.embedding_dim))
+                               if pixel else None)
+            _, _, out_o = engine.mlp_forward(a_arena, os_rep, lu._row_stride(os_rep), 0, B, ws, f"bc.o{i}", save=False)
+            olp = ws.get(f"bc.olp{i}", (B,))
+            if discrete:
+                a_inv = ws.get(f"bc.ainv{i}", (B,))
+                a_inv.copy_(rng.draw_categorical(out_o[0]))   # o_dist.sample() (device generator, as the reference)
+            else:
+                a_inv = ws.get(f"bc.ainv{i}", (B, A))
+                eps = rng.draw_normal((B, A), dev)
+                check(lib.ssac_tanh_normal_fwd(out_o.data_ptr(), 2 * A, eps.data_ptr(), B, A,
+                                               float(actor.log_std_low), float(actor.log_std_high), a_inv.data_ptr(), A,
+                                               0, olp.data_ptr(), st))
+            # (2) the BC rows and the AUGMENTED rows go through the encoder / actor as ONE stacked 2B-row pass: their
+            #     weight gradients add up inside one backward
+            if pixel:
+                from . import conv_encoder
+                okey = getattr(agent.encoder, "ssac_obs_key", "obs")
+                eng = conv_encoder.conv_engine(agent.encoder, dev)
+                img2 = ws.get("bc.img2", (2 * B,) + tuple(o[okey].shape[1:]))
+                img2[:B].copy_(o[okey])
+                img2[B:].copy_(ao[okey])
+                X2 = ws.get("bc.sall", (2 * B, eng.emb))
+                eng.forward(img2, X2, eng.emb, True)
+            else:
+                s_rep, as_rep = lu.encode(agent.encoder, o), lu.encode(agent.encoder, ao)
+                X2 = ws.get("bc.x2", (2 * B, s_rep.shape[1]))
+                X2[:B].copy_(s_rep)
+                X2[B:].copy_(as_rep)
+            s_rep, rows = X2, 2 * B
+        else:
+            s_rep = lu.encode(agent.encoder, o, save=train_enc)
+        B, S = batch_size, s_rep.shape[1]
+        lds = lu._row_stride(s_rep)
+        ah1, ah2, aout = engine.mlp_forward(a_arena, s_rep, lds, 0, rows, ws, f"bc.a{i}")
+        d_out = ws.get(f"bc.dout{i}", (1, rows, O))
         if discrete:
-            d_out = ws.get(f"bc.dout{i}", (1, B, A))
             check(lib.ssac_bc_discrete_bwd(aout.data_ptr(), a.data_ptr(), a.stride(0), mask_ptr, B, A, inv_e,
                                            d_out.data_ptr(), slot[lu.L_BC0 + i:].data_ptr(),
                                            slot[lu.L_BC_TOTAL:].data_ptr(), st))
+            if actor_lambda:
+                check(lib.ssac_action_invariance_discrete_bwd(
+                    out_o.data_ptr(), aout[0, B:].data_ptr(), a_inv.data_ptr(), B, A, float(actor_lambda) * inv_e,
+                    d_out[0, B:].data_ptr(), slot[lu.L_ACT_INV:].data_ptr(), slot[lu.L_BC_TOTAL:].data_ptr(), st))
         else:
-            d_out = ws.get(f"bc.dout{i}", (1, B, 2 * A))
             check(lib.ssac_bc_logprob_bwd(aout.data_ptr(), 2 * A, a.data_ptr(), a.stride(0), mask_ptr, B, A,
                                           float(actor.log_std_low), float(actor.log_std_high), inv_e,
                                           d_out.data_ptr(), 2 * A, slot[lu.L_BC0 + i:].data_ptr(),
                                           slot[lu.L_BC_TOTAL:].data_ptr(), st))
+            if actor_lambda:
+                check(lib.ssac_action_invariance_bwd(
+                    aout[0, B:].data_ptr(), 2 * A, a_inv.data_ptr(), A, olp.data_ptr(), B, A,
+                    float(actor.log_std_low), float(actor.log_std_high), float(actor_lambda) * inv_e,
+                    d_out[0, B:].data_ptr(), 2 * A, slot[lu.L_ACT_INV:].data_ptr(), slot[lu.L_BC_TOTAL:].data_ptr(), st))
         logs[f"losses/filterd_bc_loss_{i}"] = slot[lu.L_BC0 + i]
         ttot = engine.wgrad_tiles_total(a_arena)
         ss = ws.get(f"bc.ss{i}", (ttot,))
         if actor_clip:
             grads = ws.get(f"bc.g{i}", (a_arena.params.numel(),), zero=True)
-            dX = engine.mlp_backward(a_arena, d_out, s_rep, lds, 0, ah1, ah2, B, ws, f"bc.a{i}", grads=grads,
-                                     sumsq=ss, need_dx=train_enc)
+            dX = engine.mlp_backward(a_arena, d_out, s_rep, lds, 0, ah1, ah2, rows, ws, f"bc.a{i}", grads=grads,
+                                     sumsq=ss, need_dx=enc_grad)
             clip_members.append((a_arena, ("actor", i), grads, ss))
         else:
-            dX = engine.mlp_backward(a_arena, d_out, s_rep, lds, 0, ah1, ah2, B, ws, f"bc.a{i}", adam=adam,
-                                     adam_key=("actor", i), sumsq=ss, need_dx=train_enc)
-        if train_enc:  # (dX was taken before the epilogue of the weight-gradient launch touched W1)
+            dX = engine.mlp_backward(a_arena, d_out, s_rep, lds, 0, ah1, ah2, rows, ws, f"bc.a{i}", adam=adam,
+                                     adam_key=("actor", i), sumsq=ss, need_dx=enc_grad)
+        if enc_grad and actor_lambda:
+            # stacked encoder pass: the BC rows carry a gradient only when the encoder is trained through the BC loss
+            # (filtered_bc_loss computes s_rep without gradient otherwise), the augmented rows always do; the encoder
+            # is clipped and logged either way and stepped only with update_encoder (learning.py:203-208)
+            d_rep = ws.get("bc.drep2", (2 * B, S))
+            d_rep.copy_(dX[0])
+            if not train_enc:
+                d_rep[:B].zero_()
+            eng.backward(d_rep)
+            eng.optimizer_step(encoder_optimizer, encoder_clip, norm_out=slot[lu.L_ENC_GN:], step=train_enc)
+        elif train_enc:  # (dX was taken before the epilogue of the weight-gradient launch touched W1)
             _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, S, ws, slot, dev)
         member_ss.append(ss)
     if actor_clip:

@@ -28,6 +28,7 @@ L_ALPHA0 = 34        # + 2*i : alpha_loss_i, alpha_i
 L_ADVW, L_BC_TOTAL, L_BC_GN = 50, 51, 52   # AFBC: adv_weights_mean, overall loss, actor grad norm
 L_BC0 = 53           # + i : filtered BC loss of member i
 L_ENC_INV = 60       # encoder invariance constraint (learning_utils.py:401-409)
+L_ACT_INV = 61       # action invariance constraint (learning_utils.py:272-285; not a log key of the reference)
 # Markov state-abstraction update (its own log block): losses inverse / contrastive / smoothness / total, then the
 # gradient norms of the contrastive model, the inverse model and the encoder; two scratch words for the head kernels
 L_MK_LOSS, L_MK_GN_CON, L_MK_GN_INV, L_MK_GN_ENC, L_MK_RAW, L_MK_CON, L_MK_SMOOTH, L_MK_TMP = 40, 44, 45, 46, 47, 48, 49, 56

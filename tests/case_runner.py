@@ -863,3 +863,78 @@ def run_bc_pixels_engine(name, device="cuda"):
     rec["final_actor"] = _flat([p for a in agent.actors for p in a.parameters()])
     rec["finalfp_encoder"] = _fingerprint(_encoder_param_list(ssa.conv_encoder.find_conv_module(agent.encoder), px["kind"]))
     return rec
+
+
+# ------------------------------------------------------------------------------------------
+# action invariance constraint (synth.ACTOR_INV_CASES, fixtures written by oracle/gen_golden.py::run_actor_inv_case)
+# ------------------------------------------------------------------------------------------
+def run_actor_inv_oracle(name):
+    cfg = synth.ACTOR_INV_CASES[name]
+    fx = load_fixture(name)
+    B, E, px, disc = cfg["B"], cfg["E"], cfg.get("pixels"), bool(cfg["discrete"])
+    obuf = orc.ReplayOracle(cfg["cap"])
+    obuf.load_experience(*_buffers(cfg))
+    oa = _oracle_agent(cfg).requires_grad_(True)
+    aopt = orc.AdamOracle(oa.actor_params(), lr=cfg["lr"])
+    eopt = orc.AdamOracle(oa.encoder_params(), lr=px["enc_lr"] if px else 1e-4)
+    aug = orc.AugOracle("drqv2" if px else "identity", B)
+    rec = {}
+    for k, stp in enumerate(cfg["steps"]):
+        if px:
+            aug.forced = [torch.from_numpy(fx[f"s{k}_shift{i}"]) for i in range(E)]
+        logs, _, _, _ = orc.offline_actor_update(
+            obuf, None, oa, aopt, B, stp["clip"], aug, px["aug_mix"] if px else 0.0, per=False, filter_=False,
+            idx_list=[fx[f"s{k}_idx{i}"] for i in range(E)], update_encoder=stp["update_encoder"], encoder_opt=eopt,
+            encoder_clip=stp.get("enc_clip"), actor_lambda=cfg["actor_lambda"],
+            inv_eps_list=None if disc else [torch.from_numpy(fx[f"s{k}_eps{i}"]) for i in range(E)],
+            inv_cat_list=[torch.from_numpy(fx[f"s{k}_cat{i}"]) for i in range(E)] if disc else None,
+            grad_pick=int(fx[f"s{k}_gpick"]))
+        for key, val in logs.items():
+            rec[f"s{k}_log:{key}"] = np.float64(val)
+    rec["final_actor"] = _flat(oa.actor_params())
+    if px:
+        rec["finalfp_encoder"] = _fingerprint(oa.encoder_params())
+    return rec
+
+
+def run_actor_inv_engine(name, device="cuda"):
+    import super_sac_amd as ssa
+    cfg = synth.ACTOR_INV_CASES[name]
+    fx = load_fixture(name)
+    B, E, px, disc = cfg["B"], cfg["E"], cfg.get("pixels"), bool(cfg["discrete"])
+    device = torch.device(device)
+    buf = ssa.replay.ReplayBuffer(cfg["cap"], device=device)
+    buf.load_experience(*_buffers(cfg))
+    agent = build_engine_agent(cfg, device)
+    aopt = torch.optim.Adam(chain(*(a.parameters() for a in agent.actors)), lr=cfg["lr"], betas=(0.9, 0.999))
+    eopt = torch.optim.Adam(agent.encoder.parameters(), lr=px["enc_lr"] if px else 1e-4, betas=(0.9, 0.999))
+    aug = ssa.augmentations.AugmentationSequence(
+        [ssa.augmentations.Drqv2Aug(B) if px else ssa.augmentations.IdentityAug(B)])
+    player = DrawPlayer(device)
+    player.install(ssa.rng)
+    rec = {}
+    try:
+        for k, stp in enumerate(cfg["steps"]):
+            for i in range(E):
+                player.idx.append(fx[f"s{k}_idx{i}"])
+                if px:
+                    player.shift.append(fx[f"s{k}_shift{i}"])
+                if disc:
+                    player.cats.append(fx[f"s{k}_cat{i}"])
+                else:
+                    player.normal.append(fx[f"s{k}_eps{i}"])
+            player.picks.append(int(fx[f"s{k}_gpick"]))
+            logs = ssa.learning.offline_actor_update(
+                buffer=buf, agent=agent, actor_optimizer=aopt, encoder_optimizer=eopt, batch_size=B,
+                actor_clip=stp["clip"], update_encoder=stp["update_encoder"], encoder_clip=stp.get("enc_clip"),
+                augmenter=aug, actor_lambda=cfg["actor_lambda"], aug_mix=px["aug_mix"] if px else 0.0,
+                premade_replay_dicts=None, per=False, discrete=disc, filter_=False)
+            for key, val in logs.items():
+                rec[f"s{k}_log:{key}"] = np.float64(float(val))
+        assert not player.idx and not player.shift and not player.normal and not player.cats and not player.picks
+    finally:
+        player.restore()
+    rec["final_actor"] = _flat([p for a in agent.actors for p in a.parameters()])
+    if px:
+        rec["finalfp_encoder"] = _fingerprint(_encoder_param_list(ssa.conv_encoder.find_conv_module(agent.encoder), px["kind"]))
+    return rec

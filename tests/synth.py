@@ -173,6 +173,24 @@ BC_PIXEL_CASES = {
                                            aug="drqv2", aug_mix=0.9)),
 }
 
+# action invariance constraint in offline_actor_update (fixtures written by oracle/gen_golden.py::run_actor_inv_case)
+ACTOR_INV_CASES = {
+    "actinv_vec": dict(obs=17, act=6, hidden=64, N=2, n=2, E=2, B=128, rows=1500, cap=2048, lo=-5.0, hi=2.0,
+                       popart=False, discrete=False, actor="stochastic", lr=1e-3, seed=71, actor_lambda=0.5,
+                       steps=[dict(clip=None, update_encoder=False), dict(clip=0.5, update_encoder=False),
+                              dict(clip=0.5, update_encoder=True)]),
+    "actinv_discrete": dict(obs=12, act=5, hidden=64, N=2, n=2, E=1, B=96, rows=1000, cap=1024, lo=-10.0, hi=2.0,
+                            popart=False, discrete=True, actor="discrete", lr=1e-3, seed=72, actor_lambda=0.01,
+                            steps=[dict(clip=None, update_encoder=False)] * 3),
+    "actinv_pixels": dict(obs=50, act=4, hidden=64, N=2, n=2, E=1, B=8, rows=48, cap=64, lo=-5.0, hi=2.0,
+                          popart=False, discrete=False, actor="stochastic", lr=1e-4, seed=73, actor_lambda=1.0,
+                          steps=[dict(clip=None, update_encoder=True, enc_clip=None),
+                                 dict(clip=None, update_encoder=False, enc_clip=1.0),
+                                 dict(clip=1.0, update_encoder=True, enc_clip=1.0)],
+                          pixels=dict(kind="big", channels=9, hw=84, emb=50, enc_lr=1e-4, enc_tau=1.0, aug="drqv2",
+                                      aug_mix=0.5)),
+}
+
 # Markov state-abstraction update (fixtures written by oracle/gen_golden.py::run_markov_case)
 MARKOV_CASES = {
     # ---- Markov state-abstraction update (learning.py:266-341): steps of markov_state_abstraction_update

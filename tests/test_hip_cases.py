@@ -350,6 +350,19 @@ def test_bc_warmup_trains_the_pixel_encoder_through_the_bc_loss(name):
                                max_step=2.2 * max(cfg["lr"], cfg["pixels"]["enc_lr"]) * len(cfg["steps"]))
 
 
+@pytest.mark.parametrize("name", sorted(synth.ACTOR_INV_CASES))
+def test_action_invariance_constraint_matches_reference(name):
+    """learning.offline_actor_update(actor_lambda > 0) (learning_utils.py:272-285): an action sampled at the original
+    observation must be as likely at the augmented one.  The BC rows and the augmented rows run through the actor (and
+    a pixel encoder) as ONE stacked pass; the encoder is clipped and logged always, stepped only with update_encoder.
+    Logs within 5e-4 (gradient norms 2e-3), parameters 3e-5."""
+    cfg = synth.ACTOR_INV_CASES[name]
+    rec = case_runner.run_actor_inv_engine(name)
+    px = cfg.get("pixels")
+    case_runner.compare_markov(rec, case_runner.load_fixture(name), f"hip[{name}]",
+                               max_step=2.2 * max(cfg["lr"], px["enc_lr"]) * len(cfg["steps"]) if px else 0.0)
+
+
 @pytest.mark.parametrize("name", ["drqv2_pixels", "atari_pixels"])
 def test_pixel_cases_with_implicit_gemm_convolutions(name):
     """the pixel fixtures again with the implicit-GEMM kernels forced on for every eligible layer (the

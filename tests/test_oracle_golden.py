@@ -209,3 +209,15 @@ def test_oracle_reproduces_bc_warmup_on_pixels(name):
     rec = case_runner.run_bc_pixels_oracle(name)
     case_runner.compare_markov(rec, case_runner.load_fixture(name), f"oracle[{name}]", log_tol=2e-4, gn_tol=2e-4,
                                par_tol=3e-5, max_step=2.2 * synth.BC_PIXEL_CASES[name]["lr"] * 3)
+
+
+@pytest.mark.parametrize("name", sorted(synth.ACTOR_INV_CASES))
+def test_oracle_reproduces_action_invariance_fixture(name):
+    """offline_actor_update(actor_lambda > 0): the BC loss + the action invariance constraint (learning_utils.py:272-285)
+    on vector observations (two members; categorical actor with the reference's summed log-probabilities) and through
+    a pixel encoder that is clipped / logged always and stepped only with update_encoder."""
+    rec = case_runner.run_actor_inv_oracle(name)
+    cfg = synth.ACTOR_INV_CASES[name]
+    case_runner.compare_markov(rec, case_runner.load_fixture(name), f"oracle[{name}]", log_tol=2e-4, gn_tol=2e-4,
+                               par_tol=1e-6 if "pixels" not in name else 3e-5,
+                               max_step=2.2 * cfg["lr"] * len(cfg["steps"]) if "pixels" in name else 0.0)

@@ -485,6 +485,14 @@ int ssac_action_invariance_discrete_bwd(const float *logits_o, const float *logi
                                         int n_actions, float coeff, float *d_logits, float *loss_out, float *add_to,
                                         void *stream);
 
+/* GaussianExplorationNoise.sample on a device action (learning_utils.py:48-60), in place over act[:, col0:col0+A]:
+ * a <- clamp(a + clamp(scale * noise, +-clip), -1 + 1e-6, 1 - 1e-6)  (clip <= 0: no noise clipping). */
+int ssac_exploration_noise(float *act, int64_t ld_act, int64_t act_col0, const float *noise, float noise_scale,
+                           float noise_clip, int n_rows, int act_dim, void *stream);
+/* log-probability of a ContinuousDeterministic action under its Normal(loc, 1e-4) (distributions.py:107-114), summed over
+ * the action dimensions; eps (n_rows x act_dim, nullable): the rsample draw (NULL: the action is loc itself). */
+int ssac_det_logprob(const float *eps, int n_rows, int act_dim, float *logp, void *stream);
+
 /* ---- actor loss gradient, continuous: learning.py:392-408.
  * q (n_nets x n_rows): min over ALL nets (learning.py:402), arg-min routing.
  * dq[j][b] = -(popart_w) / (n_rows*E) for j = argmin_b else 0;  logs[0] += -mean(minq' - bonus)/E,

@@ -142,6 +142,8 @@ SIGNATURES = {
     "ssac_frobenius_diff_bwd": [_P, _L, _P, _L, _I, _I, _F, _P, _L, _I, _P, _P, _P],
     "ssac_action_invariance_bwd": [_P, _L, _P, _L, _P, _I, _I, _F, _F, _F, _P, _L, _P, _P, _P],
     "ssac_action_invariance_discrete_bwd": [_P, _P, _P, _I, _I, _F, _P, _P, _P, _P],
+    "ssac_exploration_noise": [_P, _L, _L, _P, _F, _F, _I, _I, _P],
+    "ssac_det_logprob": [_P, _I, _I, _P, _P],
     "ssac_markov_logs": [_P, _F, _P, _P, _F, _F, _F, _P, _P],
     "ssac_actor_loss_bwd": [_P, _I, _I, _P, _P, _I, _P, _I, _F, _P, _P, _P, _P],
     "ssac_actor_loss_bwd_adv": [_P, _I, _I, _P, _P, _I, _P, _I, _F, _P, _P, _P, _P],

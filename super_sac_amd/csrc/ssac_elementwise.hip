@@ -193,6 +193,33 @@ __global__ void det_action_fwd_kernel(const float *__restrict__ out, int64_t ld_
     act[b * ld_act + col0 + k] = a;
 }
 
+// GaussianExplorationNoise.sample on a device action (learning_utils.py:48-60), in place: a <- clamp(a + clamp(scale *
+// noise, +-clip), -1 + 1e-6, 1 - 1e-6); the reference's "gradient preservation" passes gradients through unchanged
+__global__ void exploration_noise_kernel(float *__restrict__ act, int64_t ld_act, int64_t col0,
+                                         const float *__restrict__ noise, float scale, float clip, int n_rows, int A) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * A) return;
+    const int b = i / A, k = i - b * A;
+    float nz = scale * noise[i];
+    if (clip > 0.0f) nz = fminf(fmaxf(nz, -clip), clip);
+    float *p = act + b * ld_act + col0 + k;
+    *p = fminf(fmaxf(*p + nz, -1.0f + 1e-6f), 1.0f - 1e-6f);
+}
+
+// log-probability of a ContinuousDeterministic action under its own Normal(loc, 1e-4) (distributions.py:107-114),
+// summed over the action dimensions: a = loc + 1e-4 eps (rsample) -> sum_d(-eps_d^2 / 2) + A (-log 1e-4 - log sqrt(2 pi));
+// eps == NULL: a = loc (sample)
+__global__ void det_logprob_kernel(const float *__restrict__ eps, int n_rows, int A, float *__restrict__ logp) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_rows) return;
+    float lp = 0.0f;
+    for (int k = 0; k < A; ++k) {
+        const float e = eps ? eps[b * A + k] : 0.0f;
+        lp += -(e * e) / 2.0f - logf(1e-4f) - LOG_SQRT_2PI;
+    }
+    logp[b] = lp;
+}
+
 __global__ void det_action_bwd_kernel(const float *__restrict__ dX, int n_nets, int64_t ldx, int64_t sX,
                                       int64_t col0, const float *__restrict__ out, int64_t ld_out,
                                       int n_rows, int A, float *__restrict__ d_out, int64_t ld_dout) {
@@ -991,6 +1018,23 @@ extern "C" int ssac_det_action_fwd(const float *out, int64_t ld_out, const float
                        eps, sample_std, noise, noise_scale, noise_clip, n_rows, act_dim, act_dst, ld_act,
                        act_col0);
     return ssac_check_launch("det_action_fwd");
+}
+
+extern "C" int ssac_exploration_noise(float *act, int64_t ld_act, int64_t act_col0, const float *noise, float noise_scale,
+                                      float noise_clip, int n_rows, int act_dim, void *stream) {
+    if (!act || !noise) return ssac_fail("ssac_exploration_noise: null argument");
+    if (n_rows <= 0) return 0;
+    const int total = n_rows * act_dim;
+    SSAC_LAUNCH(exploration_noise_kernel, dim3((total + 255) / 256), dim3(256), 0, ST, act, ld_act, act_col0, noise,
+                noise_scale, noise_clip, n_rows, act_dim);
+    return ssac_check_launch("exploration_noise");
+}
+
+extern "C" int ssac_det_logprob(const float *eps, int n_rows, int act_dim, float *logp, void *stream) {
+    if (!logp) return ssac_fail("ssac_det_logprob: null argument");
+    if (n_rows <= 0) return 0;
+    SSAC_LAUNCH(det_logprob_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, ST, eps, n_rows, act_dim, logp);
+    return ssac_check_launch("det_logprob");
 }
 
 extern "C" int ssac_td_target(const float *q_t, int n_sel, int n_rows, int q_dim,

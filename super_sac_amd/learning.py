@@ -1006,21 +1006,32 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             logp = ws.get(f"au.logp{i}", (B,))
             eps = rng.draw_normal((B, A), dev)  # a_dist.rsample() (learning.py:392)
             if kind == "stochastic":
-                if random_process is not None:
-                    raise NotImplementedError("exploration noise on a stochastic actor")
                 check(lib.ssac_tanh_normal_fwd(aout.data_ptr(), 2 * A, eps.data_ptr(), B, A,
                                                float(actor.log_std_low), float(actor.log_std_high),
                                                xpi.data_ptr(), S + A, S, logp.data_ptr(), st))
                 use_entropy = 1
-            else:
-                if random_process is None:
-                    raise NotImplementedError("deterministic actor without an exploration process")
+                if random_process is not None:
+                    # exploration noise on the sampled action, no entropy term (learning.py:393-395); the gradient
+                    # passes through the clamp unchanged (learning_utils.py:56-59)
+                    noise = rng.draw_normal((B, A), dev)
+                    check(lib.ssac_exploration_noise(xpi.data_ptr(), S + A, S, noise.data_ptr(),
+                                                     float(random_process.current_scale),
+                                                     float(noise_clip) if noise_clip is not None else 0.0, B, A, st))
+                    use_entropy = 0
+            elif random_process is not None:
                 noise = rng.draw_normal((B, A), dev)
                 check(lib.ssac_det_action_fwd(aout.data_ptr(), A, eps.data_ptr(), 1e-4, noise.data_ptr(),
                                               float(random_process.current_scale),
                                               float(noise_clip) if noise_clip is not None else 0.0, B, A,
                                               xpi.data_ptr(), S + A, S, st))
                 use_entropy = 0
+            else:
+                # deterministic actor without a process: a = loc + 1e-4 eps, entropy term = its Normal(loc, 1e-4)
+                # log-density (no gradient: a - loc does not depend on the actor; learning.py:396-399)
+                check(lib.ssac_det_action_fwd(aout.data_ptr(), A, eps.data_ptr(), 1e-4, 0, 0.0, 0.0, B, A,
+                                              xpi.data_ptr(), S + A, S, st))
+                check(lib.ssac_det_logprob(eps.data_ptr(), B, A, logp.data_ptr(), st))
+                use_entropy = 1
             ch1, ch2, q = engine.mlp_forward(c_arena, xpi, S + A, 0, B, ws, f"au.c{i}")
             dq = ws.get(f"au.dq{i}", (N, B, 1))
             qmin_ptr = 0
@@ -1056,7 +1067,7 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             if kind == "stochastic":
                 check(lib.ssac_tanh_normal_bwd(dX.data_ptr(), n_dx, ld_dx, s_dx, col_dx, aout.data_ptr(),
                                                2 * A, eps.data_ptr(), B, A, float(actor.log_std_low),
-                                               float(actor.log_std_high), log_alpha.data_ptr(), 1, inv_e,
+                                               float(actor.log_std_high), log_alpha.data_ptr(), use_entropy, inv_e,
                                                d_out.data_ptr(), 2 * A, st))
             else:
                 check(lib.ssac_det_action_bwd(dX.data_ptr(), n_dx, ld_dx, s_dx, col_dx, aout.data_ptr(), A,

@@ -527,8 +527,6 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
         else:
             x1 = _concat_buffer(ws, f"td.x1.{i}", s1_rep, A)
         if kind == "stochastic":
-            if random_process is not None:
-                raise NotImplementedError("exploration noise on a stochastic actor")
             if fuse_sample and IN_KERNEL_NOISE and rng.normal_is_stock():
                 # the noise comes from the agent's Philox stream inside the launch: draw number = host count (eager)
                 # or capture-time count + the device-resident update counter (recorded launch list)
@@ -553,17 +551,26 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
                                                float(actor.log_std_low), float(actor.log_std_high),
                                                x1.data_ptr(), S + A, S, logp.data_ptr(), st))
             use_entropy = 1
+            if random_process is not None:
+                # exploration noise on the sampled action replaces the entropy term (learning_utils.py:331-335)
+                noise = draw_normal((B, A), dev)
+                check(lib.ssac_exploration_noise(x1.data_ptr(), S + A, S, noise.data_ptr(),
+                                                 float(random_process.current_scale),
+                                                 float(noise_clip) if noise_clip is not None else 0.0, B, A, st))
+                use_entropy = 0
         else:
-            noise = None
-            scale = 0.0
             if random_process is not None:
                 noise = draw_normal((B, A), dev)
-                scale = float(random_process.current_scale)
+                check(lib.ssac_det_action_fwd(aout.data_ptr(), A, 0, 0.0, noise.data_ptr(),
+                                              float(random_process.current_scale),
+                                              float(noise_clip) if noise_clip is not None else 0.0, B, A,
+                                              x1.data_ptr(), S + A, S, st))
             else:
-                raise NotImplementedError("deterministic actor without an exploration process")
-            check(lib.ssac_det_action_fwd(aout.data_ptr(), A, 0, 0.0, noise.data_ptr(), scale,
-                                          float(noise_clip) if noise_clip is not None else 0.0, B, A,
-                                          x1.data_ptr(), S + A, S, st))
+                # no exploration process: a' = loc, and the entropy term is the log-density of Normal(loc, 1e-4) at its
+                # own mean (learning_utils.py:336-338 on distributions.py:107-114)
+                check(lib.ssac_det_action_fwd(aout.data_ptr(), A, 0, 0.0, 0, 0.0, 0.0, B, A, x1.data_ptr(), S + A, S, st))
+                check(lib.ssac_det_logprob(0, B, A, logp.data_ptr(), st))
+                use_entropy = 1
         ids = draw_subset(N, ensemble_n)
         cob = _co_backward if replay_dict.get("_co_fwd") else None
         q1, n_q = _subset_q(ws, shard, t_arena, ids, x1, S + A, B, dev, f"td.c{i}", co_backward=cob,

@@ -129,6 +129,18 @@ CASES = {
                              cycles=1, utd=2, target_delay=2, seed=52, encoder_lambda=0.5,
                              pixels=dict(kind="small", channels=4, hw=84, emb=128, enc_lr=3e-4, enc_tau=0.01,
                                          aug="drqv2", aug_mix=1.0)),
+    # the two remaining actor / exploration combinations of compute_td_targets and online_actor_update
+    # (learning_utils.py:329-341, learning.py:392-399): exploration noise on a STOCHASTIC actor (the noise replaces the
+    # entropy term) and a deterministic actor WITHOUT a process (entropy of Normal(loc, 1e-4))
+    "sac_noise": dict(obs=11, act=3, hidden=64, N=2, n=2, E=1, B=64, rows=1000, cap=1024,
+                      lo=-5.0, hi=2.0, popart=False, pop=False, discrete=False,
+                      actor="stochastic", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1, clip=None, tau=0.01,
+                      weight_type=None, temp=None, noise=dict(scale=0.3, clip=0.5), cycles=2, utd=2,
+                      target_delay=1, seed=81),
+    "ddpg_plain": dict(obs=9, act=4, hidden=64, N=2, n=2, E=1, B=64, rows=1000, cap=1024,
+                       lo=-10.0, hi=2.0, popart=False, pop=False, discrete=False,
+                       actor="deterministic", gamma=0.99, lr=1e-4, alpha_lr=1e-4, init_alpha=0.05, clip=10.0,
+                       tau=0.01, weight_type=None, temp=None, noise=None, cycles=2, utd=2, target_delay=2, seed=85),
 }
 
 

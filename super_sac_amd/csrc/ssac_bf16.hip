@@ -219,11 +219,9 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
         xv[u] = (in_act ? arow : srow)[ok ? k : (in_act ? Sg : 0)];
         if (!ok) xv[u] = 0.0f;
     }
-    const unsigned short *wp1 = S + g.sg.o1 + (int64_t)(c0 + li) * K1P + 8 * lh;
-    const unsigned short *wp2 = S + g.sg.o2 + (int64_t)(c0 + li) * H + 8 * lh;
-    Frags f1, f2;
-    f1.load(wp1, ns1);
-    f2.load(wp2, nsh);
+    // (vmcnt retires in order: everything the prologue's LDS stores wait for -- x, rewards, biases, W3 -- is requested
+    //  BEFORE the 18 fragment loads per lane, so that wait does not also sit out the whole fc1 + fc2 weight fetch;
+    //  with the small loads behind the fragments the prologue was 14-17 k clocks in every role)
     float *outp = gidx ? (actor_half ? g.gth.x1sa : (e == 0 ? g.gth.xsa : nullptr)) : nullptr;
     const int64_t ldo_g = actor_half ? g.gth.ld_x1 : g.gth.ld_x;
     float rew_v = 0.0f, done_v = 0.0f;
@@ -232,6 +230,11 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
     float bv1 = 0.0f, bv2 = 0.0f, wv3 = 0.0f, bv3 = 0.0f;
     if (tid < H) { bv1 = P[g.off[1] + tid]; bv2 = P[g.off[3] + tid]; wv3 = bf2f(S[g.sg.o3 + tid]); }
     if (tid < ldo) bv3 = tid < OUT ? P[g.off[5] + tid] : 0.0f;
+    const unsigned short *wp1 = S + g.sg.o1 + (int64_t)(c0 + li) * K1P + 8 * lh;
+    const unsigned short *wp2 = S + g.sg.o2 + (int64_t)(c0 + li) * H + 8 * lh;
+    Frags f1, f2;
+    f1.load(wp1, ns1);
+    f2.load(wp2, nsh);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int k = xl + 16 * u;

@@ -44,6 +44,18 @@ __device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : lo
 
 struct ShadowGeom { int64_t stride, o1, o2, o2t, o3; int k1p; };
 
+// FRAGMENT-MAJOR shadow matrices (W1, W2, W2^T; W3 stays row-major).  The MFMA B operand of lane (n = lane & 31,
+// half = lane >> 5) at K-step t is 8 consecutive k of weight row n; with row-major rows of 512 bytes one wave-level load
+// touches 32 cache lines and uses 32 bytes of each -- the other 96 are fetched again by the next three steps unless
+// the 16 KB L1 keeps 8 waves x 32 lines around, which it does not (18 loads per lane took ~8 k clocks at kernel start).
+// So element (n, k) of a matrix with K = 16 * nsteps columns lives at
+//     (((n >> 5) * nsteps + (k >> 4)) * 64 + (n & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7):
+// step t of a 32-row block is ONE contiguous KiB, lane l's 16 bytes at l * 16 -- every line fetched once, fully used.
+__host__ __device__ __forceinline__ int64_t frag_off(int nsteps, int n, int k) {
+    return ((((int64_t)(n >> 5) * nsteps + (k >> 4)) * 64 + (n & 31) + 32 * ((k >> 3) & 1)) << 3) + (k & 7);
+}
+constexpr int FRAG_STEP = 512;   // elements between consecutive K-steps of a lane's fragment pointer
+
 inline ShadowGeom shadow_geom(int in_dim, int hidden, int out_dim) {
     ShadowGeom g;
     g.k1p = (in_dim + 15) & ~15;
@@ -84,14 +96,14 @@ struct Frags {
     u16x8 w[16];
     // wp: this lane's fragment pointer (row n of the wave's 32 rows, + 8 half); steps beyond nsteps re-read the last
     // one (unconditional loads: a load inside a branch would drain the whole vmcnt queue at the join)
-    __device__ __forceinline__ void load(const unsigned short *__restrict__ wp, int nsteps) {
+    __device__ __forceinline__ void load(const unsigned short *__restrict__ wp, int nsteps, int step = FRAG_STEP) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const u16x8 *>(wp + 16 * (t < nsteps ? t : nsteps - 1));
+        for (int t = 0; t < 16; ++t) w[t] = *reinterpret_cast<const u16x8 *>(wp + step * (t < nsteps ? t : nsteps - 1));
     }
 };
 
 __device__ __forceinline__ void bf_mma(f32x16 &acc, const Frags &f, const unsigned short *__restrict__ wp, int nsteps,
-                                       const unsigned short *__restrict__ ap) {
+                                       const unsigned short *__restrict__ ap, int step = FRAG_STEP) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         if (t < nsteps) {
@@ -103,7 +115,7 @@ __device__ __forceinline__ void bf_mma(f32x16 &acc, const Frags &f, const unsign
     for (int t0 = 16; t0 < nsteps; t0 += 8) {   // K > 256 (wide observations): 8 steps in flight at a time
         u16x8 w[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const u16x8 *>(wp + 16 * (t0 + u < nsteps ? t0 + u : nsteps - 1));
+        for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const u16x8 *>(wp + step * (t0 + u < nsteps ? t0 + u : nsteps - 1));
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (t0 + u < nsteps) {
@@ -188,6 +200,8 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
     const bool rok = (m0 + xr) < g.n_rows;
     const int64_t src = (gidx && rok) ? gidx[m0 + xr] : 0;
     const int net = idsp ? idsp[e] : e;
+#define DSTAMP(i) do { if (g.dbg && dbg_off >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BSTAMP(i); } } while (0)
+    DSTAMP(12);   // (debug runs only: serialises the prologue to time its dependent loads one by one)
     if (net < 0) {  // empty subset slot of a sharded rank: +inf, the neutral element of the min that follows
         if (MODE == MODE_PLAIN && g.Y)
             for (int i = tid; i < TM * OUT; i += NTHR) {
@@ -219,6 +233,7 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
         xv[u] = (in_act ? arow : srow)[ok ? k : (in_act ? Sg : 0)];
         if (!ok) xv[u] = 0.0f;
     }
+    DSTAMP(13);
     // (vmcnt retires in order: everything the prologue's LDS stores wait for -- x, rewards, biases, W3 -- is requested
     //  BEFORE the 18 fragment loads per lane, so that wait does not also sit out the whole fc1 + fc2 weight fetch;
     //  with the small loads behind the fragments the prologue was 14-17 k clocks in every role)
@@ -230,11 +245,13 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
     float bv1 = 0.0f, bv2 = 0.0f, wv3 = 0.0f, bv3 = 0.0f;
     if (tid < H) { bv1 = P[g.off[1] + tid]; bv2 = P[g.off[3] + tid]; wv3 = bf2f(S[g.sg.o3 + tid]); }
     if (tid < ldo) bv3 = tid < OUT ? P[g.off[5] + tid] : 0.0f;
-    const unsigned short *wp1 = S + g.sg.o1 + (int64_t)(c0 + li) * K1P + 8 * lh;
-    const unsigned short *wp2 = S + g.sg.o2 + (int64_t)(c0 + li) * H + 8 * lh;
+    const unsigned short *wp1 = S + g.sg.o1 + frag_off(ns1, c0 + li, 8 * lh);   // (+ FRAG_STEP per K-step)
+    const unsigned short *wp2 = S + g.sg.o2 + frag_off(nsh, c0 + li, 8 * lh);
     Frags f1, f2;
+    DSTAMP(14);
     f1.load(wp1, ns1);
     f2.load(wp2, nsh);
+    DSTAMP(15);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int k = xl + 16 * u;
@@ -286,12 +303,13 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
     // the NEXT matrix after fc2 goes in flight now, into fc1's registers: W2^T (backward-data) or the head's rows
     const unsigned short *wp3;
     if (MODE == MODE_CRITIC_U) {
-        wp3 = S + g.sg.o2t + (int64_t)(c0 + li) * H + 8 * lh;
+        wp3 = S + g.sg.o2t + frag_off(nsh, c0 + li, 8 * lh);
     } else {
         const int hrow = (col0 + li) < OUT ? col0 + li : 0;
-        wp3 = S + g.sg.o3 + (int64_t)hrow * H + 8 * lh;
+        wp3 = S + g.sg.o3 + (int64_t)hrow * H + 8 * lh;   // (W3: row-major, 16 elements per K-step)
     }
-    f1.load(wp3, nsh);
+    const int step3 = MODE == MODE_CRITIC_U ? FRAG_STEP : 16;
+    f1.load(wp3, nsh, step3);
     if (wave_on) {
         const float bias = b1s[n_me];
 #pragma unroll
@@ -347,7 +365,7 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
     } else if (col0 < OUT) {
         // wave w computes outputs [32w, 32w + 32) over the whole K (rows past OUT read row 0 and are dropped)
         zero_acc(acc);
-        bf_mma(acc, f1, wp3, nsh, h2s + li * ldh + 8 * lh);
+        bf_mma(acc, f1, wp3, nsh, h2s + li * ldh + 8 * lh, step3);
         const int o = col0 + li;
         if (o < OUT) {
             const float bias = b3s[o];
@@ -471,13 +489,13 @@ __global__ void bf_sync_kernel(const float *__restrict__ params, int64_t net_str
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n1 + n2 + n3; i += (int64_t)gridDim.x * blockDim.x) {
         if (i < n1) {
             const int r = (int)(i / sg.k1p), k = (int)(i - (int64_t)r * sg.k1p);
-            S[sg.o1 + i] = k < in_dim ? f2bf(P[off_w1 + (int64_t)r * in_dim + k]) : (unsigned short)0;
+            S[sg.o1 + frag_off(sg.k1p >> 4, r, k)] = k < in_dim ? f2bf(P[off_w1 + (int64_t)r * in_dim + k]) : (unsigned short)0;
         } else if (i < n1 + n2) {
             const int64_t t = i - n1;
             const int r = (int)(t / hidden), c = (int)(t - (int64_t)r * hidden);
             const unsigned short v = f2bf(P[off_w2 + t]);
-            S[sg.o2 + t] = v;
-            S[sg.o2t + (int64_t)c * hidden + r] = v;
+            S[sg.o2 + frag_off(hidden >> 4, r, c)] = v;
+            S[sg.o2t + frag_off(hidden >> 4, c, r)] = v;
         } else {
             S[sg.o3 + (i - n1 - n2)] = f2bf(P[off_w3 + (i - n1 - n2)]);
         }
@@ -500,13 +518,13 @@ __global__ void bf_polyak_kernel(float *__restrict__ target, const float *__rest
         if (i >= off_w1 && i < end1) {
             const int64_t t = i - off_w1;
             const int r = (int)(t / in_dim), k = (int)(t - (int64_t)r * in_dim);
-            S[sg.o1 + (int64_t)r * sg.k1p + k] = f2bf(v);
+            S[sg.o1 + frag_off(sg.k1p >> 4, r, k)] = f2bf(v);
         } else if (i >= off_w2 && i < end2) {
             const int64_t t = i - off_w2;
             const int r = (int)(t / hidden), c = (int)(t - (int64_t)r * hidden);
             const unsigned short h = f2bf(v);
-            S[sg.o2 + t] = h;
-            S[sg.o2t + (int64_t)c * hidden + r] = h;
+            S[sg.o2 + frag_off(hidden >> 4, r, c)] = h;
+            S[sg.o2t + frag_off(hidden >> 4, c, r)] = h;
         } else if (i >= off_w3 && i < end3) {
             S[sg.o3 + (i - off_w3)] = f2bf(v);
         }
@@ -734,20 +752,20 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
                         const float pn = adam_elem(pv[r], gr, m, v, ctl);
                         M[a] = m; V[a] = v; P[a] = pn;
                         hq[u] = f2bf(pn);
-                        if (fc2) S[g.sg.o2 + (int64_t)j * H + col] = hq[u];
-                        else S[g.sg.o1 + (int64_t)j * K1P + col] = hq[u];
+                        if (fc2) S[g.sg.o2 + frag_off(H >> 4, j, col)] = hq[u];
+                        else S[g.sg.o1 + frag_off(K1P >> 4, j, col)] = hq[u];
                         if (T) {
                             const float tn = tv[r] * (1.0f - tau) + pn * tau;
                             T[a] = tn;
                             tq[u] = f2bf(tn);
-                            if (fc2) TS[g.sg.o2 + (int64_t)j * H + col] = tq[u];
-                            else TS[g.sg.o1 + (int64_t)j * K1P + col] = tq[u];
+                            if (fc2) TS[g.sg.o2 + frag_off(H >> 4, j, col)] = tq[u];
+                            else TS[g.sg.o1 + frag_off(K1P >> 4, j, col)] = tq[u];
                         }
                     }
                 }
-                if (fc2 && j0 + 3 < H) {   // W2^T shadow: 4 consecutive j of column `col` (H % 4 == 0)
-                    *reinterpret_cast<u16x4 *>(S + g.sg.o2t + (int64_t)col * H + j0) = hq;
-                    if (T) *reinterpret_cast<u16x4 *>(TS + g.sg.o2t + (int64_t)col * H + j0) = tq;
+                if (fc2 && j0 + 3 < H) {   // W2^T shadow: 4 consecutive j (= k of W2^T, j0 % 4 == 0) of its row `col`
+                    *reinterpret_cast<u16x4 *>(S + g.sg.o2t + frag_off(H >> 4, col, j0)) = hq;
+                    if (T) *reinterpret_cast<u16x4 *>(TS + g.sg.o2t + frag_off(H >> 4, col, j0)) = tq;
                 }
             }
         }

@@ -54,13 +54,20 @@ def test_shadow_layout_and_sync(in_dim, hidden, out_dim):
     assert list(offs) == [0, hidden * k1p, hidden * k1p + hidden * hidden, hidden * k1p + 2 * hidden * hidden]
     assert stride % 8 == 0 and stride >= offs[3] + out_dim * hidden and ar.shadow.numel() == 3 * stride
     torch.cuda.synchronize()
+
+    def unfrag(flat, n_rows, n_cols):
+        """fragment-major -> row-major: element (n, k) lives at (((n // 32) * steps + k // 16) * 64 + n % 32 +
+        32 * (k // 8 % 2)) * 8 + k % 8 -- K-step t of a 32-row block is one contiguous KiB (csrc/ssac_bf16.hip)"""
+        steps = n_cols // 16
+        t = flat.view(n_rows // 32, steps, 2, 32, 8)            # [row block][K step][half][row in block][8 k]
+        return t.permute(0, 3, 1, 2, 4).reshape(n_rows, n_cols)  # -> [block, row, step, half, k]
     for j in range(3):
         sh = ar.shadow[j * stride:(j + 1) * stride]
-        w1 = sh[:hidden * k1p].view(hidden, k1p)
+        w1 = unfrag(sh[:hidden * k1p], hidden, k1p)
         assert torch.equal(w1[:, :in_dim], ar.view(j, "w1").to(torch.bfloat16)) and not w1[:, in_dim:].any()
         w2 = ar.view(j, "w2").to(torch.bfloat16)
-        assert torch.equal(sh[offs[1]:offs[2]].view(hidden, hidden), w2)
-        assert torch.equal(sh[offs[2]:offs[3]].view(hidden, hidden), w2.t())
+        assert torch.equal(unfrag(sh[offs[1]:offs[2]], hidden, hidden), w2)
+        assert torch.equal(unfrag(sh[offs[2]:offs[3]], hidden, hidden), w2.t())
         assert torch.equal(sh[offs[3]:offs[3] + out_dim * hidden].view(out_dim, hidden), ar.view(j, "w3").to(torch.bfloat16))
 
 

@@ -28,3 +28,7 @@ row("target pass  ", 16, ["x+prefetch", "fc1", "fc1-epi+sync", "fc2", "fc2-epi+s
 print("actor start -> target pass end:", t[22] - t[0])
 row("critic WG    ", 32, ["gather+prefetch", "fc1", "fc1-epi+sync", "fc2", "fc2-epi+sync", "head", "dz2u+sync", "dgrad", "dz1 store"])
 row("wgrad tile 0 ", 48, ["prefetch+lossfold", "K loop", "adam epilogue"])
+for name, base in (("actor", 0), ("target", 16), ("critic", 32)):
+    print(name, "prologue (serialised by the debug stamps): index", t[base + 12] - t[base], " x rows", t[base + 13] - t[base + 12],
+          " small operands", t[base + 14] - t[base + 13], " 18 fragment loads", t[base + 15] - t[base + 14],
+          " rest to barrier", t[base + 1] - t[base + 15])

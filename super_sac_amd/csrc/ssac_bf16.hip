@@ -291,7 +291,7 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
             u16x4 v;
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = xs[(b0 + u) * ldx_s + k];
-            store_quad(g.XT + (int64_t)k * g.bp + m0, b0, g.n_rows - m0, v);
+            store_quad(g.XT + frag_off(g.bp >> 4, k, m0 + b0) - b0, b0, g.n_rows - m0, v);
         }
     }
 
@@ -321,7 +321,8 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
                 hv[i] = f2bf(fmaxf(acc[4 * q + i] + bias, 0.0f));
                 h1s[(b0 + i) * ldh + n_me] = hv[i];
             }
-            if (MODE == MODE_CRITIC_U) store_quad(g.H1T + ((int64_t)e * H + n_me) * g.bp + m0, b0, g.n_rows - m0, hv);
+            if (MODE == MODE_CRITIC_U)
+                store_quad(g.H1T + (int64_t)e * H * g.bp + frag_off(g.bp >> 4, n_me, m0 + b0) - b0, b0, g.n_rows - m0, hv);
         }
     }
     lds_barrier();
@@ -341,7 +342,8 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
                 hv[i] = f2bf(fmaxf(acc[4 * q + i] + bias, 0.0f));
                 h2s[(b0 + i) * ldh + n_me] = hv[i];
             }
-            if (MODE == MODE_CRITIC_U) store_quad(g.H2T + ((int64_t)e * H + n_me) * g.bp + m0, b0, g.n_rows - m0, hv);
+            if (MODE == MODE_CRITIC_U)
+                store_quad(g.H2T + (int64_t)e * H * g.bp + frag_off(g.bp >> 4, n_me, m0 + b0) - b0, b0, g.n_rows - m0, hv);
         }
     }
     lds_barrier();
@@ -424,7 +426,7 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
             dz[u] = bf_pos(h2s[(b0 + u) * ldh + j]) ? wj : (unsigned short)0;
             h2s[(b0 + u) * ldh + j] = dz[u];
         }
-        store_quad(g.DZ2T + ((int64_t)e * H + j) * g.bp + m0, b0, g.n_rows - m0, dz);
+        store_quad(g.DZ2T + (int64_t)e * H * g.bp + frag_off(g.bp >> 4, j, m0 + b0) - b0, b0, g.n_rows - m0, dz);
     }
     lds_barrier();
     BSTAMP(7);
@@ -438,7 +440,7 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
             u16x4 dv;
 #pragma unroll
             for (int i = 0; i < 4; ++i) dv[i] = bf_pos(h1s[(b0 + i) * ldh + n_me]) ? f2bf(acc[4 * q + i]) : (unsigned short)0;
-            store_quad(g.DZ1T + ((int64_t)e * H + n_me) * g.bp + m0, b0, g.n_rows - m0, dv);
+            store_quad(g.DZ1T + (int64_t)e * H * g.bp + frag_off(g.bp >> 4, n_me, m0 + b0) - b0, b0, g.n_rows - m0, dv);
         }
     }
     BSTAMP(9);
@@ -606,9 +608,10 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
     const int row = by * 64 + wm * 32 + li;         // gradient row j (0 .. H)
     const int col = bxn * 64 + wn * 32 + li;        // gradient column i
     const int Brows = fc2 ? H : K1P;                // rows of the B operand's transposed buffer
-    const unsigned short *AT = (fc2 ? g.DZ2T : g.DZ1T) + ((int64_t)e * H + (row < H ? row : 0)) * g.bp + 8 * lh;
-    const unsigned short *BT = fc2 ? g.H1T + ((int64_t)e * H + (col < Brows ? col : 0)) * g.bp + 8 * lh
-                                   : g.XT + (int64_t)(col < Brows ? col : 0) * g.bp + 8 * lh;
+    // (the transposed saves are fragment-major like the weight shadows: K-step s of a 32-row block is one KiB)
+    const unsigned short *AT = (fc2 ? g.DZ2T : g.DZ1T) + (int64_t)e * H * g.bp + frag_off(g.bp >> 4, row < H ? row : 0, 8 * lh);
+    const unsigned short *BT = fc2 ? g.H1T + (int64_t)e * H * g.bp + frag_off(g.bp >> 4, col < Brows ? col : 0, 8 * lh)
+                                   : g.XT + frag_off(g.bp >> 4, col < Brows ? col : 0, 8 * lh);
     const int nsteps = g.bp >> 4;
     constexpr int G = 8;
     u16x8 a0[G], b0[G], a1[G], b1[G];
@@ -616,8 +619,8 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
 #pragma unroll
         for (int u = 0; u < G; ++u) {
             const int s = s0 + u < nsteps ? s0 + u : nsteps - 1;   // clamped: redundant loads, never used
-            a[u] = *reinterpret_cast<const u16x8 *>(AT + 16 * s);
-            b[u] = *reinterpret_cast<const u16x8 *>(BT + 16 * s);
+            a[u] = *reinterpret_cast<const u16x8 *>(AT + FRAG_STEP * s);
+            b[u] = *reinterpret_cast<const u16x8 *>(BT + FRAG_STEP * s);
         }
     };
     // ---- everything that does not depend on the loss gradient goes in flight first: the first operand group and
@@ -650,11 +653,12 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
         const int i = tid;
         float gw = 0.0f, gb = 0.0f;
         if (i < H) {
-            const unsigned short *hp = g.H2T + ((int64_t)e * H + i) * g.bp;
+            const unsigned short *hbase = g.H2T + (int64_t)e * H * g.bp;
+            auto hp_at = [&](int k) { return hbase + frag_off(g.bp >> 4, i, k); };   // 8 consecutive k are contiguous
             for (int b0_ = 0; b0_ < g.bp; b0_ += 32) {
                 u16x8 hv[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const u16x8 *>(hp + (b0_ + 8 * q < g.bp ? b0_ + 8 * q : 0));
+                for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const u16x8 *>(hp_at(b0_ + 8 * q < g.bp ? b0_ + 8 * q : 0));
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (b0_ + 8 * q < g.bp)

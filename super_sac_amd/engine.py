@@ -174,7 +174,7 @@ class MlpArena:
         """transposed bf16 saves of the chained update: H1T, H2T, DZ2uT, DZ1uT (n_nets x hidden x Bp), XT (K1P x Bp);
         zero-initialised once (the kernels never write the pad columns b >= n_rows)"""
         bp = (n_rows + 15) // 16 * 16
-        k1p = (self.in_dim + 15) // 16 * 16
+        k1p = (self.in_dim + 31) // 32 * 32   # (fragment-major saves: whole 32-row blocks, csrc/ssac_bf16.hip)
         shp = (self.n_nets, self.hidden, bp)
         return {k_: ws.get(f"{tag}.bf.{k_}", shp if k_ != "xt" else (k1p, bp), dtype=torch.bfloat16, zero=True)
                 for k_ in ("h1t", "h2t", "dz2t", "dz1t", "xt")}

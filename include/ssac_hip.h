@@ -751,9 +751,10 @@ int ssac_ln_tanh_bwd(const float *d_out, int64_t ldd, const float *out, int64_t 
  *   [ W1 (hidden x K1P, K zero-padded to 16) | W2 | W2^T | W3 ]        (ssac_bf16_layout: stride + the 4 offsets)
  * that the Adam epilogue keeps current.  W1, W2 and W2^T are stored FRAGMENT-MAJOR -- element (n, k) of a matrix with
  * K = 16 * steps columns at (((n / 32) * steps + k / 16) * 64 + n % 32 + 32 * (k / 8 % 2)) * 8 + k % 8 -- so that K-step
- * t of a 32-row block, i.e. one wave-level load of MFMA B operands, is one contiguous KiB; W3 is row-major.  Saved activations are bf16 and TRANSPOSED ((n_nets x) hidden x Bp, batch
- * contiguous, Bp = n_rows rounded up to 16, zero padded) so the weight-gradient products read both operands with
- * 16-byte loads.  Covers the chained critic update of continuous single-output critics (hidden % 32 == 0, <= 256). ==== */
+ * t of a 32-row block, i.e. one wave-level load of MFMA B operands, is one contiguous KiB; W3 is row-major.
+ * Saved activations are bf16 and TRANSPOSED ((n_nets x) hidden x Bp: the batch is the K of the weight-gradient products,
+ * Bp = n_rows rounded up to 16, zero padded) and fragment-major in the same way (features = rows n, batch = k; XT holds
+ * K1P rounded up to 32 feature rows), so those products read both operands with fully used 16-byte loads.  Covers the chained critic update of continuous single-output critics (hidden % 32 == 0, <= 256). ==== */
 int64_t ssac_bf16_layout(int in_dim, int hidden, int out_dim, int64_t offsets[4]);
 int ssac_bf16_supported(const ssac_mlp *nets);
 /* development aid: a device buffer of >= 64 int64 receives s_memtime() phase stamps of tile 0 of the bf16 launches

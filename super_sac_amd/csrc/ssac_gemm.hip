@@ -287,12 +287,16 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
 #pragma unroll
         for (int t = 0; t < HT; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
     };
+#define GDSTAMP(i) do { if (g.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GSTAMP(i); } } while (0)
     loadA(kg * BK);
     loadB(kg * BK);
+    GDSTAMP(5);   // (debug runs only: serialises the prologue to time its pieces)
     pre();
+    GDSTAMP(6);
     storeA(buf0);
     storeB(buf0 + TILE_FLOATS);
     if (iters > 1) { loadA((KS + kg) * BK); loadB((KS + kg) * BK); }
+    GDSTAMP(7);
     lds_barrier();
     float f0a[HT], f0b[HT], f1a[HT], f1b[HT];  // first / second half of the current chunk
     if (iters > 0) rd(f0a, f0b, buf0, 0);

@@ -32,3 +32,5 @@ row("target pass ", t, 16, names)
 print("actor start -> target pass end:", t[23] - t[0])
 row("critic WG   ", t, 32, names + ["loss", "head-bwd", "dgrad", "dz1-store"])
 row("wgrad tile 0", g, 0, ["operand issue + loss fold + first chunk", "K loop", "partials -> LDS", "adam epilogue"])
+print("wgrad tile 0 prologue (serialised by the debug stamps): first operand chunk", g[5] - g[0], " loss fold (pre)", g[6] - g[5],
+      " LDS stores + second chunk", g[7] - g[6], " barrier + first fragment reads", g[1] - g[7])

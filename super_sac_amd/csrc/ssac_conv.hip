@@ -45,6 +45,28 @@ __global__ void im2col_kernel(Im2colArgs a) {
     }
 }
 
+// The same column matrix, one thread per (output pixel, channel, ky): it copies the k consecutive kx taps -- consecutive
+// source pixels, consecutive column entries -- with ONE index decode (32-bit) instead of one 64-bit div/mod chain per
+// element; neighbouring threads write neighbouring k-float segments of a row.  Same values, bit for bit.
+__global__ __launch_bounds__(256) void im2col_runs_kernel(Im2colArgs a, int n_items) {
+    const int ck = a.C * a.k, ckk = ck * a.k;
+    const uint8_t *s8 = (const uint8_t *)a.src;
+    const float *sf = (const float *)a.src;
+    const bool plain = a.div == 1.0f && a.shift == 0.0f;
+    for (int it = blockIdx.x * blockDim.x + threadIdx.x; it < n_items; it += gridDim.x * blockDim.x) {
+        const int row = it / ck, r = it - row * ck;
+        const int c = r / a.k, ky = r - c * a.k;
+        const int ox = row % a.Wo, t = row / a.Wo;
+        const int oy = t % a.Ho, b = t / a.Ho;
+        const int64_t si = b * a.sb + c * a.sc + (int64_t)(oy * a.stride + ky) * a.sy + (int64_t)(ox * a.stride) * a.sx;
+        float *dst = a.col + (int64_t)row * ckk + r * a.k;
+        for (int kx = 0; kx < a.k; ++kx) {
+            const float v = a.src_u8 ? (float)s8[si + kx * a.sx] : sf[si + kx * a.sx];
+            dst[kx] = plain ? v : v / a.div + a.shift;
+        }
+    }
+}
+
 struct Col2imArgs {
     const float *dcol;        // (B*Ho*Wo, C*k*k)
     float *dx; int64_t sb, sc, sy, sx;   // destination strides
@@ -267,6 +289,11 @@ extern "C" int ssac_im2col(const void *src, int src_u8, int64_t sb, int64_t sc, 
                  (Wi - k) / stride + 1, div, shift, col};
     const int64_t total = (int64_t)B * a.Ho * a.Wo * C * k * k;
     if (total <= 0) return 0;
+    const int64_t items = total / k;   // (pixel, channel, ky) runs of k taps
+    if (items < (1ll << 31) - 65536) {
+        SSAC_LAUNCH(im2col_runs_kernel, dim3(grid_for(items, 256, 65536)), dim3(256), 0, ST, a, (int)items);
+        return ssac_check_launch("im2col");
+    }
     SSAC_LAUNCH(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, ST, a);
     return ssac_check_launch("im2col");
 }

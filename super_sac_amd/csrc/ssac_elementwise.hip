@@ -926,6 +926,66 @@ __global__ void drq_shift_kernel(const T *__restrict__ src, const int64_t *__res
     }
 }
 
+// DrQv2 shift (mode 0), one workgroup per image plane (b, channel): the sampling positions and bilinear weights depend
+// only on (b, x) and (b, y), so they are evaluated once per row / column into LDS -- with exactly the operations of the
+// per-element kernel above -- instead of once per output element (~40 flops and two 64-bit div/mod chains each), and
+// the plane itself (h x h source pixels) is staged in LDS, so the four taps of an output are LDS reads.  Same bits.
+constexpr int SHIFT_MAX_H = 128;
+template <typename T>
+__global__ __launch_bounds__(256) void drqv2_shift_plane_kernel(const T *__restrict__ src, const int64_t *__restrict__ idx,
+                                                                int c, int h, int pad, const int64_t *__restrict__ shift,
+                                                                int n_aug, float *__restrict__ dst) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float pl[];   // [h * h] the source plane as float
+    __shared__ float w0x[SHIFT_MAX_H], w1x[SHIFT_MAX_H], w0y[SHIFT_MAX_H], w1y[SHIFT_MAX_H];
+    __shared__ int p0x[SHIFT_MAX_H], p0y[SHIFT_MAX_H];
+    const int b = blockIdx.x / c, ch = blockIdx.x - b * c, tid = threadIdx.x;
+    const int hh = h * h, hp = h + 2 * pad;
+    const T *img = src + ((idx ? idx[b] : (int64_t)b) * c + ch) * (int64_t)hh;
+    float *out = dst + ((int64_t)b * c + ch) * hh;
+    if (b >= n_aug) {   // (rows beyond the augmented part of the mix: plain copy)
+        for (int i = tid; i < hh; i += 256) out[i] = (float)img[i];
+        return;
+    }
+    for (int i = tid; i < hh; i += 256) pl[i] = (float)img[i];
+    if (tid < 2 * h) {
+        const int ax = tid >= h, i = ax ? tid - h : tid;   // ax 0: x / columns, 1: y / rows
+        const float start = (float)(-1.0 + 1.0 / (double)hp), end = (float)(1.0 - 1.0 / (double)hp);
+        const float step = __fdiv_rn(__fsub_rn(end, start), (float)(hp - 1));
+        const float sscale = (float)(2.0 / (double)hp);
+        const float gpos = __fadd_rn(linspace_f32(start, end, step, hp, i), __fmul_rn((float)shift[2 * b + ax], sscale));
+        const float ip = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gpos, 1.0f), (float)hp), 1.0f), 2.0f);
+        const float fl = floorf(ip);
+        const float w1 = __fsub_rn(ip, fl), w0 = __fsub_rn(1.0f, w1);
+        (ax ? w1y : w1x)[i] = w1;
+        (ax ? w0y : w0x)[i] = w0;
+        (ax ? p0y : p0x)[i] = (int)fl;
+    }
+    __syncthreads();
+    for (int i = tid; i < hh; i += 256) {
+        const int y = i / h, x = i - y * h;
+        const int x0 = p0x[x], y0 = p0y[y];
+        float acc = 0.0f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int yy = y0 + dy;
+            const float wy = dy ? w1y[y] : w0y[y];
+            const bool vy = yy >= 0 && yy < hp;
+            const int sy = min(max(yy - pad, 0), h - 1);  // replicate pad
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int xx = x0 + dx;
+                const float wx = dx ? w1x[x] : w0x[x];
+                const bool vx = xx >= 0 && xx < hp;
+                const int sx = min(max(xx - pad, 0), h - 1);
+                const float wgt = (vy && vx) ? __fmul_rn(wy, wx) : 0.0f;
+                acc = __fadd_rn(acc, __fmul_rn(pl[sy * h + sx], wgt));
+            }
+        }
+        out[i] = fminf(fmaxf(acc, 0.0f), 255.0f);
+    }
+}
+
 inline int grid_for(int64_t n, int block = 256, int cap = 2048) {
     int64_t g = (n + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -1267,6 +1327,16 @@ extern "C" int ssac_drq_shift(const void *src, int src_dtype, const int64_t *idx
     if (n <= 0) return 0;
     if (mode != 0 && mode != 1) return ssac_fail("ssac_drq_shift: bad mode");
     const int64_t total = (int64_t)n * c * h * h;
+    if (mode == 0 && h <= SHIFT_MAX_H && (src_dtype == 0 || src_dtype == 1) && (int64_t)n * c < (1ll << 30)) {
+        const size_t lds = sizeof(float) * (size_t)h * h;   // 28 KB at 84 x 84
+        if (src_dtype == 0)
+            SSAC_LAUNCH(drqv2_shift_plane_kernel<float>, dim3(n * c), dim3(256), lds, ST, (const float *)src, idx, c, h, pad,
+                        shift, n_aug, dst);
+        else
+            SSAC_LAUNCH(drqv2_shift_plane_kernel<uint8_t>, dim3(n * c), dim3(256), lds, ST, (const uint8_t *)src, idx, c, h,
+                        pad, shift, n_aug, dst);
+        return ssac_check_launch("drq_shift");
+    }
     if (src_dtype == 0)
         SSAC_LAUNCH(drq_shift_kernel<float>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, ST,
                            (const float *)src, idx, n, c, h, pad, shift, mode, noise, n_aug, dst);

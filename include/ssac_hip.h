@@ -711,6 +711,20 @@ int ssac_conv_dgrad(const float *dy, const float *w, const float *x_mask, float 
 int ssac_conv_wgrad_slices(int B, int Ho, int Wo, int pix_per_slice);
 int ssac_conv_wgrad(const float *dy, const float *x, float *partial_w, float *partial_b, int B, int Hi, int Wi,
                     int ci, int co, int k, int s, int pix_per_slice, void *stream);
+/* ---- the FIRST layer as an implicit GEMM too (cnns.py:41/76 conv1 with the x/div + shift input normalisation of
+ * cnns.py:58/95 in front): fp32 NCHW image (B, C, Hi, Wi) of raw pixel values, nn.Conv2d weight (co, C, k, k),
+ * channels-last output.  ssac_conv_first_supported returns the taps per lane half (2 or 4) when the geometry is
+ * covered -- co % 32 == 0, C k k <= 256, k <= 8, stride a multiple of 2 (k <= 4) or 4, (Wo-1) s + 2 taps <= Wi,
+ * fewer than 2^31 elements -- and 0 when the layer has to stay on ssac_im2col + ssac_linear_fwd.
+ *   ssac_conv_first_fwd    y = relu(conv(img / div + shift) + bias)
+ *   ssac_conv_first_wgrad  partial_w[slice] (co,C,k,k), partial_b[slice] (co) per slice of pix_per_slice (multiple of
+ *                          128) output pixels = one workgroup; slices as ssac_conv_wgrad_slices, sum with
+ *                          ssac_reduce_slices. */
+int ssac_conv_first_supported(int C, int co, int k, int s, int Hi, int Wi, int64_t B);
+int ssac_conv_first_fwd(const float *img, const float *w, const float *bias, float *y, int B, int C, int Hi, int Wi,
+                        int co, int k, int s, float div, float shift, void *stream);
+int ssac_conv_first_wgrad(const float *dy, const float *img, float *partial_w, float *partial_b, int B, int C, int Hi,
+                          int Wi, int co, int k, int s, float div, float shift, int pix_per_slice, void *stream);
 
 /* split-K forward for short, very deep problems (the pixel encoders' fc over the flattened feature map):
  * partial (slices x M x N) = X[:, slice] W[:, slice]^T per K slice of k_per_slice (multiple of 32) columns;

@@ -20,12 +20,13 @@ import torch
 from . import engine
 from ._lib import check, lib
 
-import os
-
-USE_IMPLICIT = os.environ.get("SSAC_IMPLICIT_CONV", "1") == "1"  # implicit-GEMM inner conv layers
-FC_CHANNELS_LAST = os.environ.get("SSAC_FC_CHANNELS_LAST", "1") == "1"  # fc reads the last map in place
+USE_IMPLICIT = True          # implicit-GEMM inner conv layers (False: every layer as im2col + GEMM; the tests' A/B)
+USE_IMPLICIT_FIRST = True    # the first layer as an implicit GEMM over the NCHW image
+FC_CHANNELS_LAST = True      # fc reads the last map in place
 IMPLICIT_MIN_ROWS = 200_000      # output pixels (B*Ho*Wo) from which the implicit-GEMM kernels pay off
 IMPLICIT_ROWS_PER_SLICE = 1024   # output pixels per weight-gradient slice (= per workgroup)
+FIRST_MIN_ROWS = 16_384          # output pixels from which the first layer leaves im2col
+FIRST_ROWS_PER_SLICE = 1024      # output pixels per first-layer weight-gradient slice
 FC_SLICES = 48  # K slices of the fc forward (8 row tiles x 48 slices ~ 1.5 workgroups per CU at B 512)
 ROWS_PER_SLICE = 4096  # split-K granularity of the convolution weight gradients
 
@@ -55,6 +56,7 @@ class ConvEncoderEngine:
         self.implicit_ok = [USE_IMPLICIT and l > 0 and s == 1 and bool(lib.ssac_conv_implicit_supported(ci, co, k))
                             for l, (ci, co, k, s) in enumerate(self.geom)]
         self.implicit = list(self.implicit_ok)
+        self.first = False   # the saved forward ran the first layer as an implicit GEMM
         self.div, self.shift = (255.0, -0.5) if self.big else (255.0, 0.0)
         # ---- flat parameter arena (each tensor starts at a multiple of 4 floats)
         plist = []
@@ -105,7 +107,17 @@ class ConvEncoderEngine:
             y = self.ws.get(f"{tag}.y{l if save else l % 2}", (rows * co,))
             if save:
                 self.implicit[l] = self.implicit_ok[l] and rows >= IMPLICIT_MIN_ROWS
-            if self.implicit_ok[l] and rows >= IMPLICIT_MIN_ROWS:
+            first = (l == 0 and USE_IMPLICIT_FIRST and rows >= FIRST_MIN_ROWS and not u8 and img.data_ptr() % 16 == 0
+                     and lib.ssac_conv_first_supported(ci, co, k, s, Hi, Wi, B) > 0)
+            if l == 0 and save:
+                self.first = first
+            if first:
+                # the gather AND the input normalisation happen in the operand loads; the image is what backward reads
+                col = None
+                check(lib.ssac_conv_first_fwd(img.data_ptr(), self.convs[0].weight.data_ptr(),
+                                              self.convs[0].bias.data_ptr(), y.data_ptr(), B, ci, Hi, Wi, co, k, s,
+                                              div, shift, st))
+            elif self.implicit_ok[l] and rows >= IMPLICIT_MIN_ROWS:
                 # channels-last input straight from the previous layer: the patch gather happens in the operand
                 # loads of the implicit-GEMM kernel, no column matrix
                 col = None
@@ -161,7 +173,7 @@ class ConvEncoderEngine:
             xhat = rstd = None
             fc_forward(dst.data_ptr(), ld_dst)
         if save:
-            self.saved = dict(B=B, cols=cols, ys=ys, shapes=shapes, colf=colf, wfc=wfc, flat_dim=flat_dim,
+            self.saved = dict(B=B, img=img, cols=cols, ys=ys, shapes=shapes, colf=colf, wfc=wfc, flat_dim=flat_dim,
                               Hf=Hi, Wf=Wi, xhat=xhat, rstd=rstd, out=dst, ld_out=ld_dst)
 
     # ------------------------------------------------------------------------------------
@@ -212,11 +224,15 @@ class ConvEncoderEngine:
         for l in range(nconv - 1, -1, -1):
             ci, co, k, s, Hi, Wi, Ho, Wo = sv["shapes"][l]
             rows, ckk = B * Ho * Wo, ci * k * k
-            rps = IMPLICIT_ROWS_PER_SLICE if self.implicit[l] else ROWS_PER_SLICE
+            first = l == 0 and self.first
+            rps = FIRST_ROWS_PER_SLICE if first else IMPLICIT_ROWS_PER_SLICE if self.implicit[l] else ROWS_PER_SLICE
             slices = (rows + rps - 1) // rps
             pw = self.ws.get("b.pw", (slices * co * ckk,))
             pb = self.ws.get("b.pb", (slices * co,))
-            if self.implicit[l]:
+            if first:
+                check(lib.ssac_conv_first_wgrad(dy.data_ptr(), sv["img"].data_ptr(), pw.data_ptr(), pb.data_ptr(), B, ci,
+                                                Hi, Wi, co, k, s, self.div, self.shift, rps, st))
+            elif self.implicit[l]:
                 x_in = sv["ys"][l - 1]  # this layer's input = previous layer's ReLU output, channels-last
                 check(lib.ssac_conv_wgrad(dy.data_ptr(), x_in.data_ptr(), pw.data_ptr(), pb.data_ptr(), B, Hi, Wi,
                                           ci, co, k, s, rps, st))

@@ -269,6 +269,207 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad_kernel(ConvArgs g, int6
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// First layer (cnns.py:41, 76): the input is the fp32 NCHW image with the x/div + shift normalisation of the
+// encoder's forward in front, few input channels (4 / 9) and a stride that divides the kernel.  Its column matrix
+// is the largest buffer of the whole pixel update (419 MB at Atari batch 1024; written once, read twice), so the
+// gather happens in the operand loads here too:
+//   forward        K runs over (c, ky); inside a run lane half h takes the KH consecutive taps kx = h*KH .. h*KH+KH-1
+//                  of its pixel with ONE 8/16-byte load (rows of k < 2 KH taps are padded with zero WEIGHTS; the
+//                  extra pixel read is inside the image row: (Wo-1) s + 2 KH <= Wi is a launch condition);
+//   weight grad    N runs over the flattened (c, ky, kx) patch index (NB blocks of 32), the reduction over pixels;
+//                  MFMA step t of a 32-pixel chunk takes the pixels 2t and 2t+1 (adjacent -> shared cache lines).
+// ---------------------------------------------------------------------------------------------
+struct FirstArgs {
+    const float *img;    // (B, C, Hi, Wi) fp32, raw pixel values
+    const float *w;      // (co, C, k, k)
+    const float *bias;   // (co)
+    const float *dy;     // (B, Ho, Wo, co)   [wgrad]
+    float *out;          // (B, Ho, Wo, co)   [fwd]
+    float div, shift;    // x / div + shift in front of the convolution
+    int B, C, Hi, Wi, Ho, Wo, co, k, s;
+};
+
+template <int KH> struct TapVec;
+template <> struct TapVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct TapVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+constexpr int FG = 4;  // runs per load group (two groups in flight)
+
+template <int KH>
+__global__ __launch_bounds__(CV_THREADS) void conv_first_fwd_kernel(FirstArgs g, int n_tiles) {
+    typedef typename TapVec<KH>::type vec;
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [run = (c, ky)][32 co][2 KH taps], zero-padded taps
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nruns = g.C * g.k, kk = g.k * g.k, HW = g.Hi * g.Wi;
+    const int co0 = blockIdx.y * 32;
+    for (int i = tid; i < nruns * 32 * 2 * KH; i += CV_THREADS) {
+        const int kx = i % (2 * KH), t = i / (2 * KH), co = t & 31, run = t >> 5;
+        const int c = run / g.k, ky = run - c * g.k;
+        wl[i] = kx < g.k ? g.w[((int64_t)(co0 + co) * g.C + c) * kk + ky * g.k + kx] : 0.0f;
+    }
+    __syncthreads();
+    const float bias = g.bias[co0 + li];
+    const int M = g.B * g.Ho * g.Wo;
+    const int ngroups = (nruns + FG - 1) / FG;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int m = tile * CV_PIX + wave * 32 + li;
+        const int mm = m < M ? m : 0;
+        const int ox = mm % g.Wo, t = mm / g.Wo;
+        const int oy = t % g.Ho, b = t / g.Ho;
+        const float *base = g.img + (int64_t)b * g.C * HW + (oy * g.s) * g.Wi + ox * g.s + lh * KH;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        // run -> image offset, stepped (c, ky) without divisions
+        int l_run = 0, l_ky = 0, l_off = 0;
+        auto load_group = [&](vec (&a)[FG]) {
+#pragma unroll
+            for (int u = 0; u < FG; ++u) {
+                a[u] = *reinterpret_cast<const vec *>(base + l_off);
+                if (l_run + 1 < nruns) {  // clamped: the groups past the end re-read the last run
+                    ++l_run;
+                    l_off += g.Wi;
+                    if (++l_ky == g.k) { l_ky = 0; l_off += HW - g.k * g.Wi; }
+                }
+            }
+        };
+        auto compute_group = [&](const vec (&a)[FG], int grp) {
+#pragma unroll
+            for (int u = 0; u < FG; ++u) {
+                const int run = grp * FG + u;
+                if (run < nruns) {
+                    const vec bw = *reinterpret_cast<const vec *>(wl + ((run * 32 + li) * 2 + lh) * KH);
+#pragma unroll
+                    for (int j = 0; j < KH; ++j)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j] / g.div + g.shift, bw[j], acc, 0, 0, 0);
+                }
+            }
+        };
+        vec a0[FG], a1[FG];
+        load_group(a0);
+        for (int grp = 0; grp < ngroups; grp += 2) {
+            load_group(a1);
+            compute_group(a0, grp);
+            load_group(a0);
+            compute_group(a1, grp + 1);
+        }
+        const int m_wave = tile * CV_PIX + wave * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mr = m_wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (mr < M) g.out[(int64_t)mr * g.co + co0 + li] = fmaxf(acc[r] + bias, 0.0f);
+        }
+    }
+}
+
+// weight gradient of the first layer: grid (pixel slices, co / 32); the 4 waves of a workgroup split the slice's pixels
+// and add their accumulators through LDS in a fixed order, so a slice is one workgroup's partial
+template <int NB>
+__global__ __launch_bounds__(CV_THREADS) void conv_first_wgrad_kernel(FirstArgs g, int pix_per_slice, float *partial_w,
+                                                                      float *partial_b) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [NB][16][64] + [64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int kk = g.k * g.k, ckk = g.C * kk, HW = g.Hi * g.Wi, CHW = g.C * HW;
+    const int co0 = blockIdx.y * 32;
+    int noff[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = nb * 32 + li;
+        const int c = n / kk, rem = n - c * kk, ky = rem / g.k, kx = rem - ky * g.k;
+        noff[nb] = n < ckk ? c * HW + ky * g.Wi + kx : 0;
+    }
+    const int M = g.B * g.Ho * g.Wo;
+    const int per_wave = pix_per_slice >> 2;
+    const int m_lo = blockIdx.x * pix_per_slice + wave * per_wave;
+    const int m_hi = min(M, m_lo + per_wave);
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][i] = 0.0f;
+    float bsum = 0.0f;
+    for (int mc = m_lo; mc < m_hi; mc += 32) {
+        float av[16];
+        int xo[16];
+        {
+            const int m_first = mc + lh;
+            const int mf = m_first < M ? m_first : 0;
+            int ox = mf % g.Wo;
+            const int q = mf / g.Wo;
+            int oy = q % g.Ho, b = q / g.Ho;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int m = m_first + 2 * t;
+                const bool ok = m < m_hi;
+                const float d = g.dy[(int64_t)(ok ? m : m_lo) * g.co + co0 + li];
+                av[t] = ok ? d : 0.0f;
+                xo[t] = ok ? b * CHW + (oy * g.s) * g.Wi + ox * g.s : 0;
+                ox += 2;
+                if (ox >= g.Wo) { ox -= g.Wo; if (++oy == g.Ho) { oy = 0; ++b; } }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) bsum += av[t];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], g.img[xo[t] + noff[nb]] / g.div + g.shift, acc[nb],
+                                                               0, 0, 0);
+        }
+    }
+    bsum += __shfl_xor(bsum, 32, 64);
+    float *bred = red + NB * 16 * 64;
+    // fixed-order sum over the waves: 3 -> 2 -> 1 -> 0
+    for (int w = 3; w >= 1; --w) {
+        if (wave == w) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(nb * 16 + r) * 64 + lane] = acc[nb][r];
+            if (lh == 0) bred[li] = bsum;
+        }
+        __syncthreads();
+        if (wave == w - 1) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nb][r] += red[(nb * 16 + r) * 64 + lane];
+            bsum += bred[li];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        float *pw = partial_w + (int64_t)blockIdx.x * g.co * ckk;   // partial_w[slice][co][c][ky][kx]
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int n = nb * 32 + li;
+            if (n < ckk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    pw[(int64_t)co * ckk + n] = acc[nb][r];
+                }
+            }
+        }
+        if (lh == 0) partial_b[(int64_t)blockIdx.x * g.co + co0 + li] = bsum;
+    }
+}
+
+// taps per lane half of the first-layer kernels for this geometry, 0 = stays on im2col
+int first_kh(int C, int co, int k, int s, int Hi, int Wi, int64_t B) {
+    if (co % 32 || k < 1 || s < 1 || Hi < k || Wi < k || C * k * k > 8 * 32) return 0;
+    if (B * C * Hi * Wi >= (1ll << 31) || B * ((Hi - k) / s + 1) * ((Wi - k) / s + 1) >= (1ll << 31) - 65536) return 0;
+    const int Wo = (Wi - k) / s + 1;
+    for (int kh = 2; kh <= 4; kh += 2) {
+        if (k <= 2 * kh && (Wo - 1) * s + 2 * kh <= Wi && Wi % kh == 0 && s % kh == 0) return kh;
+    }
+    return 0;
+}
+
 int conv_ok(int ci, int co, int k) { return ci % 32 == 0 && co % 32 == 0 && k >= 1 && k * k <= 4 * WG_MAX_TAPS; }
 
 }  // namespace
@@ -333,4 +534,60 @@ extern "C" int ssac_conv_wgrad(const float *dy, const float *x, float *partial_w
     SSAC_LAUNCH(conv_wgrad_kernel, dim3(slices, ci / 32, co / 32), dim3(CV_THREADS), 0, (hipStream_t)stream, g,
                 (int64_t)pix_per_slice, partial_w, partial_b);
     return ssac_check_launch("conv_wgrad");
+}
+
+extern "C" int ssac_conv_first_supported(int C, int co, int k, int s, int Hi, int Wi, int64_t B) {
+    return first_kh(C, co, k, s, Hi, Wi, B);
+}
+
+extern "C" int ssac_conv_first_fwd(const float *img, const float *w, const float *bias, float *y, int B, int C, int Hi,
+                                   int Wi, int co, int k, int s, float div, float shift, void *stream) {
+    const int kh = first_kh(C, co, k, s, Hi, Wi, B);
+    if (!kh) return ssac_fail("ssac_conv_first_fwd: geometry not supported (see ssac_conv_first_supported)");
+    if ((uintptr_t)img & 15) return ssac_fail("ssac_conv_first_fwd: image must be 16-byte aligned");
+    FirstArgs g{};
+    g.img = img; g.w = w; g.bias = bias; g.out = y; g.div = div; g.shift = shift;
+    g.B = B; g.C = C; g.Hi = Hi; g.Wi = Wi; g.co = co; g.k = k; g.s = s;
+    g.Ho = (Hi - k) / s + 1; g.Wo = (Wi - k) / s + 1;
+    const int M = B * g.Ho * g.Wo;
+    const int n_tiles = (M + CV_PIX - 1) / CV_PIX;
+    const size_t lds = sizeof(float) * (size_t)C * k * 32 * 2 * kh;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)conv_first_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv_first_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    if (lds > 160 * 1024) return ssac_fail("ssac_conv_first_fwd: weight tile does not fit LDS");
+    const int cap = 1024 / (co / 32) > 0 ? 1024 / (co / 32) : 1;  // persistent: ~4 workgroups per CU in total
+    const int gx = n_tiles < cap ? n_tiles : cap;
+    if (kh == 2)
+        SSAC_LAUNCH(conv_first_fwd_kernel<2>, dim3(gx, co / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
+    else
+        SSAC_LAUNCH(conv_first_fwd_kernel<4>, dim3(gx, co / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
+    return ssac_check_launch("conv_first_fwd");
+}
+
+extern "C" int ssac_conv_first_wgrad(const float *dy, const float *img, float *partial_w, float *partial_b, int B, int C,
+                                     int Hi, int Wi, int co, int k, int s, float div, float shift, int pix_per_slice,
+                                     void *stream) {
+    if (!first_kh(C, co, k, s, Hi, Wi, B)) return ssac_fail("ssac_conv_first_wgrad: geometry not supported");
+    if (pix_per_slice <= 0 || (pix_per_slice & 127)) return ssac_fail("ssac_conv_first_wgrad: slice must be a multiple of 128");
+    FirstArgs g{};
+    g.img = img; g.dy = dy; g.div = div; g.shift = shift;
+    g.B = B; g.C = C; g.Hi = Hi; g.Wi = Wi; g.co = co; g.k = k; g.s = s;
+    g.Ho = (Hi - k) / s + 1; g.Wo = (Wi - k) / s + 1;
+    const int slices = ssac_conv_wgrad_slices(B, g.Ho, g.Wo, pix_per_slice);
+    const int nb = (C * k * k + 31) / 32;
+    const size_t lds = sizeof(float) * ((size_t)nb * 16 * 64 + 64);
+    const dim3 grid(slices, co / 32), block(CV_THREADS);
+#define SSAC_FIRST_WGRAD(NB) \
+    case NB: SSAC_LAUNCH(conv_first_wgrad_kernel<NB>, grid, block, lds, (hipStream_t)stream, g, pix_per_slice, partial_w, partial_b); break;
+    switch (nb) {
+        SSAC_FIRST_WGRAD(1) SSAC_FIRST_WGRAD(2) SSAC_FIRST_WGRAD(3) SSAC_FIRST_WGRAD(4)
+        SSAC_FIRST_WGRAD(5) SSAC_FIRST_WGRAD(6) SSAC_FIRST_WGRAD(7) SSAC_FIRST_WGRAD(8)
+        default: return ssac_fail("ssac_conv_first_wgrad: patch too large");
+    }
+#undef SSAC_FIRST_WGRAD
+    return ssac_check_launch("conv_first_wgrad");
 }

@@ -368,12 +368,12 @@ def test_pixel_cases_with_implicit_gemm_convolutions(name):
     """the pixel fixtures again with the implicit-GEMM kernels forced on for every eligible layer (the
     automatic choice keeps maps this small on im2col)."""
     import super_sac_amd as ssa
-    old = ssa.conv_encoder.IMPLICIT_MIN_ROWS
-    ssa.conv_encoder.IMPLICIT_MIN_ROWS = 0
+    old = ssa.conv_encoder.IMPLICIT_MIN_ROWS, ssa.conv_encoder.FIRST_MIN_ROWS
+    ssa.conv_encoder.IMPLICIT_MIN_ROWS = ssa.conv_encoder.FIRST_MIN_ROWS = 0
     try:
         rec = case_runner.run_engine(name)
     finally:
-        ssa.conv_encoder.IMPLICIT_MIN_ROWS = old
+        ssa.conv_encoder.IMPLICIT_MIN_ROWS, ssa.conv_encoder.FIRST_MIN_ROWS = old
     case_runner.compare(rec, case_runner.load_fixture(name), who=f"hip[{name},implicit-conv]")
 
 

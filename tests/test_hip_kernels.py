@@ -660,9 +660,11 @@ def test_pixel_encoder_forward_reference_vectors(ssa, kind, ch, emb):
     _close(y, torch.from_numpy(f[f"enc_{kind}_y"]), 3e-5, rtol=1e-4, what=f"{kind} encoder output")
 
 
+@pytest.mark.parametrize("first", [False, True])
 @pytest.mark.parametrize("kind,ch,emb", [("big", 9, 50), ("small", 4, 128)])
-def test_pixel_encoder_backward_matches_autograd(ssa, kind, ch, emb):
+def test_pixel_encoder_backward_matches_autograd(ssa, kind, ch, emb, first, monkeypatch):
     from super_sac_amd import conv_encoder
+    monkeypatch.setattr(conv_encoder, "FIRST_MIN_ROWS", 0 if first else 1 << 40)  # conv1 implicit / on im2col
     conv, p = _engine_encoder(ssa, kind, ch, emb, 60 + ch)
     rng = np.random.RandomState(7)
     B = 5
@@ -831,6 +833,57 @@ def test_implicit_gemm_convolution_matches_torch_conv2d(ssa, B, ci, co, k, s, H)
                                        s, pps, st))
     _close(pw.sum(0), wr.grad, 2e-4, rtol=1e-4, what="conv weight gradient")
     _close(pb.sum(0), br.grad, 2e-4, rtol=1e-4, what="conv bias gradient")
+
+
+@pytest.mark.parametrize("B,C,co,k,s,H,div,shift", [(3, 4, 32, 8, 4, 84, 255.0, 0.0), (2, 9, 32, 3, 2, 84, 255.0, -0.5),
+                                                    (5, 3, 64, 4, 2, 20, 255.0, 0.0), (1, 1, 32, 7, 4, 36, 1.0, 0.0),
+                                                    (37, 4, 32, 8, 4, 84, 255.0, 0.0)])
+def test_first_layer_implicit_convolution_matches_torch_conv2d(ssa, B, C, co, k, s, H, div, shift):
+    """conv1 over the NCHW image with the input normalisation in the operand loads (ssac_conv_first_fwd / _wgrad)
+    against F.conv2d(x / div + shift) + autograd on the CPU; ragged pixel counts, rows of k < 2 KH taps (zero-padded
+    weights), a slice size that leaves the last workgroup's waves partly or wholly empty."""
+    rng = np.random.RandomState(C + co + k)
+    x = torch.from_numpy(rng.randint(0, 256, (B, C, H, H)).astype(np.float32) + rng.random_sample((B, C, H, H)).astype(np.float32))
+    w = torch.from_numpy((rng.standard_normal((co, C, k, k)) * 0.1).astype(np.float32))
+    b = torch.from_numpy(rng.standard_normal(co).astype(np.float32) * 0.1)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.relu(F.conv2d(x / div + shift, wr, br, stride=s))
+    Ho = y_ref.shape[-1]
+    dy = torch.from_numpy(rng.standard_normal(tuple(y_ref.shape)).astype(np.float32))
+    dz = dy * (y_ref.detach() > 0)
+    y_ref.backward(dy)
+    lib, st = ssa._lib.lib, ssa.engine.stream()
+    assert lib.ssac_conv_first_supported(C, co, k, s, H, H, B) in (2, 4)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    dzd = dz.permute(0, 2, 3, 1).contiguous().to(DEV)
+    yd = torch.empty(B, Ho, Ho, co, device=DEV)
+    ssa._lib.check(lib.ssac_conv_first_fwd(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr(), B, C, H, H, co, k,
+                                           s, div, shift, st))
+    _close(yd.permute(0, 3, 1, 2), y_ref.detach(), 3e-5, rtol=1e-5, what="first-layer forward")
+    pps = 128
+    slices = int(lib.ssac_conv_wgrad_slices(B, Ho, Ho, pps))
+    pw = torch.full((slices, co, C, k, k), float("nan"), device=DEV)
+    pb = torch.full((slices, co), float("nan"), device=DEV)
+    ssa._lib.check(lib.ssac_conv_first_wgrad(dzd.data_ptr(), xd.data_ptr(), pw.data_ptr(), pb.data_ptr(), B, C, H, H, co,
+                                             k, s, div, shift, pps, st))
+    scale = float(wr.grad.abs().max())
+    _close(pw.sum(0), wr.grad, 2e-5 * max(1.0, scale), rtol=1e-4, what="first-layer weight gradient")
+    _close(pb.sum(0), br.grad, 2e-4, rtol=1e-4, what="first-layer bias gradient")
+
+
+def test_first_layer_implicit_convolution_refuses_what_it_does_not_cover(ssa):
+    lib = ssa._lib.lib
+    assert lib.ssac_conv_first_supported(4, 32, 8, 4, 84, 84, 1024) == 4
+    assert lib.ssac_conv_first_supported(9, 32, 3, 2, 84, 84, 512) == 2
+    assert lib.ssac_conv_first_supported(9, 32, 3, 1, 84, 84, 512) == 0      # odd stride: unaligned tap loads
+    assert lib.ssac_conv_first_supported(4, 48, 8, 4, 84, 84, 8) == 0        # co not a multiple of 32
+    assert lib.ssac_conv_first_supported(4, 32, 8, 4, 86, 86, 8) == 0        # Wi % 4 != 0
+    assert lib.ssac_conv_first_supported(16, 32, 8, 4, 84, 84, 8) == 0       # patch of 1024 taps
+    x = torch.zeros(1, 9, 84, 84, device=DEV)
+    y = torch.zeros(1, 82, 82, 32, device=DEV)
+    w, b = torch.zeros(32, 9, 3, 3, device=DEV), torch.zeros(32, device=DEV)
+    assert lib.ssac_conv_first_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 9, 84, 84, 32, 3, 1, 255.0,
+                                   -0.5, ssa.engine.stream()) != 0
 
 
 def _philox4x32_10(c, k):

@@ -49,6 +49,22 @@ __device__ __forceinline__ void chunk_decode(int ch, int k, int cblocks, int &ky
 // ---------------------------------------------------------------------------------------------
 // forward: grid (persistent pixel tiles, co / 32)
 // ---------------------------------------------------------------------------------------------
+// chunk -> offset iterator in chunk order (cb fastest, then kx, then ky), uniform integer steps instead of a
+// division chain per chunk; next() returns the current chunk's (ky, kx, cb) and moves on, staying on the last chunk
+// (the prefetches past the end re-read it)
+struct ChunkIter {
+    int k, cblocks, left;
+    int ky = 0, kx = 0, cb = 0;
+    __device__ ChunkIter(int k_, int cblocks_, int nch) : k(k_), cblocks(cblocks_), left(nch - 1) {}
+    __device__ __forceinline__ void next(int &oky, int &okx, int &ocb) {
+        oky = ky; okx = kx; ocb = cb;
+        if (left > 0) {
+            --left;
+            if (++cb == cblocks) { cb = 0; if (++kx == k) { kx = 0; ++ky; } }
+        }
+    }
+};
+
 __global__ __launch_bounds__(CV_THREADS) void conv_fwd_kernel(ConvArgs g, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [chunks][32 co][WL_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -80,27 +96,33 @@ __global__ __launch_bounds__(CV_THREADS) void conv_fwd_kernel(ConvArgs g, int n_
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-        f4 a[2][4];
-        {
-            const float *p = base;  // chunk 0 = (ky 0, kx 0, cb 0)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[0][q] = *reinterpret_cast<const f4 *>(p + 4 * q);
-        }
-        for (int ch = 0; ch < nch; ++ch) {
-            const int nx = min(ch + 1, nch - 1);  // unconditional (clamped) prefetch of the next chunk
+        ChunkIter it(g.k, cblocks, nch);
+        auto load = [&](f4 (&a)[4]) {
             int ky, kx, cb;
-            chunk_decode(nx, g.k, cblocks, ky, kx, cb);
-            const float *p = base + ((int64_t)ky * g.Wi + kx) * g.ci + cb * 32;
-            const int cur = ch & 1;
+            it.next(ky, kx, cb);
+            const float *p = base + (ky * g.Wi + kx) * g.ci + cb * 32;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[cur ^ 1][q] = *reinterpret_cast<const f4 *>(p + 4 * q);
-            const f4 *bp = reinterpret_cast<const f4 *>(wl + (ch * 32 + li) * WL_LD + lh * 16);
-            f4 bf[4];
+            for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f4 *>(p + 4 * q);
+        };
+        auto compute = [&](const f4 (&a)[4], int ch) {
+            if (ch < nch) {
+                const f4 *bp = reinterpret_cast<const f4 *>(wl + (ch * 32 + li) * WL_LD + lh * 16);
+                f4 bf[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bf[q] = bp[q];
+                for (int q = 0; q < 4; ++q) bf[q] = bp[q];
 #pragma unroll
-            for (int tt = 0; tt < 16; ++tt)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tt >> 2][tt & 3], bf[tt >> 2][tt & 3], acc, 0, 0, 0);
+                for (int tt = 0; tt < 16; ++tt)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt >> 2][tt & 3], bf[tt >> 2][tt & 3], acc, 0, 0, 0);
+            }
+        };
+        // three operand buffers: the loads run two chunks ahead of the MFMAs
+        f4 a0[4], a1[4], a2[4];
+        load(a0);
+        load(a1);
+        for (int ch = 0; ch < nch; ch += 3) {
+            load(a2); compute(a0, ch);
+            load(a0); compute(a1, ch + 1);
+            load(a1); compute(a2, ch + 2);
         }
         // C layout: column = lane & 31 (output channel), rows (r & 3) + 8 (r >> 2) + 4 lh (pixel within the wave)
         const int64_t m_wave = (int64_t)tile * CV_PIX + wave * 32;
@@ -115,6 +137,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_fwd_kernel(ConvArgs g, int n_
 // ---------------------------------------------------------------------------------------------
 // backward-data: grid (persistent input-pixel tiles, ci / 32)
 // ---------------------------------------------------------------------------------------------
+template <bool S1>  // S1: stride 1 (every layer the engine sends here) -- no per-tap divisions
 __global__ __launch_bounds__(CV_THREADS) void conv_dgrad_kernel(ConvArgs g, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [chunks][32 c][WL_LD] : W[co][c0+c][ky][kx], co contiguous
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -144,41 +167,46 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dgrad_kernel(ConvArgs g, int 
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
         // chunk (ky, kx, ob) reads dy[b, (iy-ky)/s, (ix-kx)/s, ob*32 + 16 lh ..]: valid taps only, else zeros
-        auto tap = [&](int ch, const float *&p) -> bool {
+        const float *dyb = g.dy + (int64_t)b * g.Ho * g.Wo * g.co + lh * 16;
+        ChunkIter it(g.k, oblocks, nch);
+        auto load = [&](f4 (&a)[4]) {
             int ky, kx, ob;
-            chunk_decode(ch, g.k, oblocks, ky, kx, ob);
+            it.next(ky, kx, ob);
             const int ny = iy - ky, nx = ix - kx;
-            const int oy = ny / g.s, ox = nx / g.s;
-            const bool v = ok && ny >= 0 && nx >= 0 && oy * g.s == ny && ox * g.s == nx && oy < g.Ho && ox < g.Wo;
-            p = g.dy + (v ? (((int64_t)b * g.Ho + oy) * g.Wo + ox) * g.co : 0) + ob * 32 + lh * 16;
-            return v;
+            int oy, ox;
+            bool v;
+            if (S1) {
+                oy = ny; ox = nx;
+                v = ok && (unsigned)ny < (unsigned)g.Ho && (unsigned)nx < (unsigned)g.Wo;
+            } else {
+                oy = ny / g.s; ox = nx / g.s;
+                v = ok && ny >= 0 && nx >= 0 && oy * g.s == ny && ox * g.s == nx && oy < g.Ho && ox < g.Wo;
+            }
+            const float *p = dyb + (v ? (oy * g.Wo + ox) * g.co : 0) + ob * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4 x = *reinterpret_cast<const f4 *>(p + 4 * q);
+                a[q] = v ? x : (f4){0.f, 0.f, 0.f, 0.f};
+            }
         };
-        f4 a[2][4];
-        {
-            const float *p;
-            const bool v = tap(0, p);
+        auto compute = [&](const f4 (&a)[4], int ch) {
+            if (ch < nch) {
+                const f4 *bp = reinterpret_cast<const f4 *>(wl + (ch * 32 + li) * WL_LD + lh * 16);
+                f4 bf[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f4 x = *reinterpret_cast<const f4 *>(p + 4 * q);
-                a[0][q] = v ? x : (f4){0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < 4; ++q) bf[q] = bp[q];
+#pragma unroll
+                for (int tt = 0; tt < 16; ++tt)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt >> 2][tt & 3], bf[tt >> 2][tt & 3], acc, 0, 0, 0);
             }
-        }
-        for (int ch = 0; ch < nch; ++ch) {
-            const float *p;
-            const bool v = tap(min(ch + 1, nch - 1), p);
-            const int cur = ch & 1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f4 x = *reinterpret_cast<const f4 *>(p + 4 * q);
-                a[cur ^ 1][q] = v ? x : (f4){0.f, 0.f, 0.f, 0.f};
-            }
-            const f4 *bp = reinterpret_cast<const f4 *>(wl + (ch * 32 + li) * WL_LD + lh * 16);
-            f4 bf[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bf[q] = bp[q];
-#pragma unroll
-            for (int tt = 0; tt < 16; ++tt)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][tt >> 2][tt & 3], bf[tt >> 2][tt & 3], acc, 0, 0, 0);
+        };
+        f4 a0[4], a1[4], a2[4];
+        load(a0);
+        load(a1);
+        for (int ch = 0; ch < nch; ch += 3) {
+            load(a2); compute(a0, ch);
+            load(a0); compute(a1, ch + 1);
+            load(a1); compute(a2, ch + 2);
         }
         const int64_t m_wave = (int64_t)tile * CV_PIX + wave * 32;
 #pragma unroll
@@ -470,6 +498,116 @@ int first_kh(int C, int co, int k, int s, int Hi, int Wi, int64_t B) {
     return 0;
 }
 
+// The same weight gradient for k*k <= NT taps with every wave holding ALL taps (NT accumulators) over its own quarter
+// of the slice's pixels: the taps are balanced over the waves (9 taps over 4 waves were 3:2:2:2 above), dy is loaded
+// once per pixel instead of once per wave, MFMA step t of a 32-pixel chunk takes the ADJACENT pixels 2t / 2t+1 (one
+// 256-byte segment per operand load), and the operand loads of tap j+1 are in flight under the MFMAs of tap j.  The
+// four waves' accumulators are added through LDS in a fixed order (3 -> 2 -> 1 -> 0).
+template <int NT>
+__global__ __launch_bounds__(CV_THREADS) void conv_wgrad_taps_kernel(ConvArgs g, int pix_per_slice, float *partial_w,
+                                                                     float *partial_b) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [NT][16][64] + [32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int kk = g.k * g.k;
+    const int c0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
+    const int M = g.B * g.Ho * g.Wo;
+    const int per_wave = pix_per_slice >> 2;
+    const int m_lo = blockIdx.x * pix_per_slice + wave * per_wave;
+    const int m_hi = min(M, m_lo + per_wave);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+    float bsum = 0.0f;
+    const float *xb = g.x + c0 + li;
+    for (int mc = m_lo; mc < m_hi; mc += 32) {
+        float av[16];
+        int xo[16];
+        {
+            const int m_first = mc + lh;
+            const int mf = m_first < M ? m_first : 0;
+            int ox = mf % g.Wo;
+            const int q = mf / g.Wo;
+            int oy = q % g.Ho, b = q / g.Ho;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int m = m_first + 2 * t;
+                const bool ok = m < m_hi;
+                const float d = g.dy[(int64_t)(ok ? m : m_lo) * g.co + co0 + li];
+                av[t] = ok ? d : 0.0f;
+                xo[t] = ok ? ((b * g.Hi + oy * g.s) * g.Wi + ox * g.s) * g.ci : 0;
+                ox += 2;
+                if (ox >= g.Wo) { ox -= g.Wo; if (++oy == g.Ho) { oy = 0; ++b; } }
+            }
+        }
+        if (blockIdx.y == 0) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) bsum += av[t];
+        }
+        float bx[2][16];
+        int ky = 0, kx = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) bx[0][t] = xb[xo[t]];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (j + 1 < NT) {  // operands of the next tap (clamped to the last one: uniform, in bounds)
+                if (j + 1 < kk) { if (++kx == g.k) { kx = 0; ++ky; } }
+                const int toff = (ky * g.Wi + kx) * g.ci;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) bx[(j + 1) & 1][t] = xb[xo[t] + toff];
+            }
+            if (j < kk) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bx[j & 1][t], acc[j], 0, 0, 0);
+            }
+        }
+    }
+    bsum += __shfl_xor(bsum, 32, 64);
+    float *bred = red + NT * 16 * 64;
+    for (int w = 3; w >= 1; --w) {
+        if (wave == w) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(j * 16 + r) * 64 + lane] = acc[j][r];
+            if (lh == 0) bred[li] = bsum;
+        }
+        __syncthreads();
+        if (wave == w - 1) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] += red[(j * 16 + r) * 64 + lane];
+            bsum += bred[li];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        float *pw = partial_w + (int64_t)blockIdx.x * g.co * g.ci * kk;   // partial_w[slice][co][c][ky][kx]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (j < kk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    pw[((int64_t)co * g.ci + c0 + li) * kk + j] = acc[j][r];
+                }
+            }
+        }
+        if (blockIdx.y == 0 && lh == 0) partial_b[(int64_t)blockIdx.x * g.co + co0 + li] = bsum;
+    }
+}
+
+// persistent workgroups per CU: as many as the weight tile in LDS allows, at most 3 (three waves per SIMD hide the
+// operand-load latency the two-chunk prefetch leaves)
+int persistent_per_cu(size_t lds) {
+    const int fit = (int)((160 * 1024) / (lds + 1024));
+    return fit < 1 ? 1 : fit > 3 ? 3 : fit;
+}
+
 int conv_ok(int ci, int co, int k) { return ci % 32 == 0 && co % 32 == 0 && k >= 1 && k * k <= 4 * WG_MAX_TAPS; }
 
 }  // namespace
@@ -491,7 +629,8 @@ extern "C" int ssac_conv_fwd(const float *x, const float *w, const float *bias, 
         (void)hipFuncSetAttribute((const void *)conv_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    const int cap = 512 / (co / 32) > 0 ? 512 / (co / 32) : 1;  // persistent: ~2 workgroups per CU in total
+    const int per_cu = persistent_per_cu(lds);
+    const int cap = 256 * per_cu / (co / 32) > 0 ? 256 * per_cu / (co / 32) : 1;
     const int gx = n_tiles < cap ? n_tiles : cap;
     SSAC_LAUNCH(conv_fwd_kernel, dim3(gx, co / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
     return ssac_check_launch("conv_fwd");
@@ -509,12 +648,17 @@ extern "C" int ssac_conv_dgrad(const float *dy, const float *w, const float *x_m
     if (lds > 160 * 1024) return ssac_fail("ssac_conv_dgrad: weight tile does not fit LDS");
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void *)conv_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv_dgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)conv_dgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    const int cap = 512 / (ci / 32) > 0 ? 512 / (ci / 32) : 1;
+    const int per_cu = persistent_per_cu(lds);
+    const int cap = 256 * per_cu / (ci / 32) > 0 ? 256 * per_cu / (ci / 32) : 1;
     const int gx = n_tiles < cap ? n_tiles : cap;
-    SSAC_LAUNCH(conv_dgrad_kernel, dim3(gx, ci / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
+    if (s == 1)
+        SSAC_LAUNCH(conv_dgrad_kernel<true>, dim3(gx, ci / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
+    else
+        SSAC_LAUNCH(conv_dgrad_kernel<false>, dim3(gx, ci / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
     return ssac_check_launch("conv_dgrad");
 }
 
@@ -531,6 +675,14 @@ extern "C" int ssac_conv_wgrad(const float *dy, const float *x, float *partial_w
     g.x = x; g.dy = dy; g.B = B; g.Hi = Hi; g.Wi = Wi; g.ci = ci; g.co = co; g.k = k; g.s = s;
     g.Ho = (Hi - k) / s + 1; g.Wo = (Wi - k) / s + 1;
     const int slices = ssac_conv_wgrad_slices(B, g.Ho, g.Wo, pix_per_slice);
+    const int64_t in_elems = (int64_t)B * Hi * Wi * ci, out_pix = (int64_t)B * g.Ho * g.Wo;
+    if (k * k <= 9 && (pix_per_slice & 127) == 0 && in_elems < (1ll << 31) && out_pix < (1ll << 31) - 65536) {
+        // every wave holds all taps (32-bit offsets)
+        const size_t lds = sizeof(float) * (9 * 16 * 64 + 32);
+        SSAC_LAUNCH(conv_wgrad_taps_kernel<9>, dim3(slices, ci / 32, co / 32), dim3(CV_THREADS), lds, (hipStream_t)stream,
+                    g, pix_per_slice, partial_w, partial_b);
+        return ssac_check_launch("conv_wgrad");
+    }
     SSAC_LAUNCH(conv_wgrad_kernel, dim3(slices, ci / 32, co / 32), dim3(CV_THREADS), 0, (hipStream_t)stream, g,
                 (int64_t)pix_per_slice, partial_w, partial_b);
     return ssac_check_launch("conv_wgrad");

@@ -825,14 +825,14 @@ def test_implicit_gemm_convolution_matches_torch_conv2d(ssa, B, ci, co, k, s, H)
                                        s, st))
     want_dx = xr.grad * (x > 0)  # the kernel folds the previous layer's ReLU derivative in
     _close(dxd.permute(0, 3, 1, 2), want_dx, 3e-5, rtol=1e-5, what="conv backward-data")
-    pps = 64
-    slices = int(lib.ssac_conv_wgrad_slices(B, Ho, Ho, pps))
-    pw = torch.zeros(slices, co, ci, k, k, device=DEV)
-    pb = torch.zeros(slices, co, device=DEV)
-    ssa._lib.check(lib.ssac_conv_wgrad(dzd.data_ptr(), xd.data_ptr(), pw.data_ptr(), pb.data_ptr(), B, H, H, ci, co, k,
-                                       s, pps, st))
-    _close(pw.sum(0), wr.grad, 2e-4, rtol=1e-4, what="conv weight gradient")
-    _close(pb.sum(0), br.grad, 2e-4, rtol=1e-4, what="conv bias gradient")
+    for pps in (64, 128, 1024):  # 64: taps split over the waves; multiples of 128 with k*k <= 9: every wave all taps
+        slices = int(lib.ssac_conv_wgrad_slices(B, Ho, Ho, pps))
+        pw = torch.full((slices, co, ci, k, k), float("nan"), device=DEV)
+        pb = torch.full((slices, co), float("nan"), device=DEV)
+        ssa._lib.check(lib.ssac_conv_wgrad(dzd.data_ptr(), xd.data_ptr(), pw.data_ptr(), pb.data_ptr(), B, H, H, ci, co,
+                                           k, s, pps, st))
+        _close(pw.sum(0), wr.grad, 2e-4, rtol=1e-4, what=f"conv weight gradient (slices of {pps})")
+        _close(pb.sum(0), br.grad, 2e-4, rtol=1e-4, what=f"conv bias gradient (slices of {pps})")
 
 
 @pytest.mark.parametrize("B,C,co,k,s,H,div,shift", [(3, 4, 32, 8, 4, 84, 255.0, 0.0), (2, 9, 32, 3, 2, 84, 255.0, -0.5),

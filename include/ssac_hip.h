@@ -693,6 +693,11 @@ int ssac_im2col(const void *src, int src_u8, int64_t sb, int64_t sc, int64_t sy,
 int ssac_col2im(const float *dcol, float *dx, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
                 const float *mask, int64_t mb, int64_t mc, int64_t my, int64_t mx, int B, int C, int Hi,
                 int Wi, int k, int stride, void *stream);
+/* the same adjoint for a column matrix with columns in (ky, kx, c) order (dY times the weight permuted by
+ * ssac_permute_cp(W, co, ci, k*k, 1)) into a contiguous channels-last dx (B, Hi, Wi, C), C % 4 == 0; mask (same
+ * shape, may be NULL) as above.  Sums the same taps in the same order as ssac_col2im. */
+int ssac_col2im_cl(const float *dcol, float *dx, const float *mask, int B, int C, int Hi, int Wi, int k, int stride,
+                   void *stream);
 /* Y = act(X W^T + b), X (M x K), W (N x K): F.conv2d on patches / nn.Linear (cnns.py:61-66,98-102). */
 int ssac_linear_fwd(const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, float *Y,
                     int64_t ldy, int M, int N, int K, int relu, void *stream);

@@ -158,6 +158,7 @@ SIGNATURES = {
     "ssac_zero": [_P, _L, _P],
     "ssac_im2col": [_P, _I, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P],
     "ssac_col2im": [_P, _P, _L, _L, _L, _L, _P, _L, _L, _L, _L, _I, _I, _I, _I, _I, _I, _P],
+    "ssac_col2im_cl": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "ssac_linear_fwd": [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _P],
     "ssac_conv_implicit_supported": [_I, _I, _I],
     "ssac_conv_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

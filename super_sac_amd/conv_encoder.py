@@ -23,10 +23,12 @@ from ._lib import check, lib
 USE_IMPLICIT = True          # implicit-GEMM inner conv layers (False: every layer as im2col + GEMM; the tests' A/B)
 USE_IMPLICIT_FIRST = True    # the first layer as an implicit GEMM over the NCHW image
 FC_CHANNELS_LAST = True      # fc reads the last map in place
-IMPLICIT_MIN_ROWS = 200_000      # output pixels (B*Ho*Wo) from which the implicit-GEMM kernels pay off
-IMPLICIT_ROWS_PER_SLICE = 1024   # output pixels per weight-gradient slice (= per workgroup)
+IMPLICIT_MIN_ROWS = 16_384       # output pixels (B*Ho*Wo) from which the implicit-GEMM kernels pay off
+IMPLICIT_ROWS_PER_SLICE = 1024   # output pixels per weight-gradient slice (= per workgroup), at least
 FIRST_MIN_ROWS = 16_384          # output pixels from which the first layer leaves im2col
-FIRST_ROWS_PER_SLICE = 1024      # output pixels per first-layer weight-gradient slice
+FIRST_ROWS_PER_SLICE = 512       # output pixels per first-layer weight-gradient slice, at least
+IMPLICIT_WG_PER_CU = 2           # resident weight-gradient workgroups per CU (248 VGPRs: two waves per SIMD)
+FIRST_WG_PER_CU = 3
 FC_SLICES = 48  # K slices of the fc forward (8 row tiles x 48 slices ~ 1.5 workgroups per CU at B 512)
 ROWS_PER_SLICE = 4096  # split-K granularity of the convolution weight gradients
 
@@ -50,10 +52,10 @@ class ConvEncoderEngine:
         self.geom = [(c.in_channels, c.out_channels, c.kernel_size[0], c.stride[0]) for c in convs]
         self.emb = module.fc.out_features
         # inner layers with 32-multiple channel counts run as implicit GEMMs (csrc/ssac_conv_implicit.hip)
-        # (stride-1 layers only: with a stride the transposed gather of the backward-data pass wastes (s*s-1)/(s*s)
-        # of its taps; small maps -- decided per call from the row count -- stay on im2col, whose column matrix
-        # then lives in the 256 MB Infinity Cache anyway)
-        self.implicit_ok = [USE_IMPLICIT and l > 0 and s == 1 and bool(lib.ssac_conv_implicit_supported(ci, co, k))
+        # (forward and weight gradient; the backward-data pass of a STRIDED layer stays GEMM + col2im, which needs no
+        # saved column matrix: its transposed gather would waste (s*s-1)/(s*s) of the taps; small maps -- decided per
+        # call from the row count -- stay on im2col)
+        self.implicit_ok = [USE_IMPLICIT and l > 0 and bool(lib.ssac_conv_implicit_supported(ci, co, k))
                             for l, (ci, co, k, s) in enumerate(self.geom)]
         self.implicit = list(self.implicit_ok)
         self.first = False   # the saved forward ran the first layer as an implicit GEMM
@@ -225,7 +227,14 @@ class ConvEncoderEngine:
             ci, co, k, s, Hi, Wi, Ho, Wo = sv["shapes"][l]
             rows, ckk = B * Ho * Wo, ci * k * k
             first = l == 0 and self.first
-            rps = FIRST_ROWS_PER_SLICE if first else IMPLICIT_ROWS_PER_SLICE if self.implicit[l] else ROWS_PER_SLICE
+            if first or self.implicit[l]:
+                # one slice = one workgroup: as many slices as are resident at once (a partly filled second round
+                # costs a whole one), never below the configured slice size
+                resident = 256 * (FIRST_WG_PER_CU if first else IMPLICIT_WG_PER_CU)
+                rps = max(FIRST_ROWS_PER_SLICE if first else IMPLICIT_ROWS_PER_SLICE,
+                          ((rows + resident - 1) // resident + 127) // 128 * 128)
+            else:
+                rps = ROWS_PER_SLICE
             slices = (rows + rps - 1) // rps
             pw = self.ws.get("b.pw", (slices * co * ckk,))
             pb = self.ws.get("b.pb", (slices * co,))
@@ -246,16 +255,25 @@ class ConvEncoderEngine:
                 break
             pci, pco, pk, ps, pHi, pWi, pHo, pWo = sv["shapes"][l - 1]
             dprev = self.ws.get(f"b.dy{(l - 1) % 2}", (B * pHo * pWo * pco,))
-            if self.implicit[l]:
+            if self.implicit[l] and s == 1:
                 check(lib.ssac_conv_dgrad(dy.data_ptr(), self.convs[l].weight.data_ptr(), sv["ys"][l - 1].data_ptr(),
                                           dprev.data_ptr(), B, Hi, Wi, ci, co, k, s, st))
             else:
                 dcol = self.ws.get("b.dcol", (rows * ckk,))
-                check(lib.ssac_linear_dgrad(dy.data_ptr(), co, self.convs[l].weight.data_ptr(), ckk, dcol.data_ptr(),
-                                            ckk, rows, ckk, co, st))
-                pcl = (pHo * pWo * pco, 1, pWo * pco, pco)
-                check(lib.ssac_col2im(dcol.data_ptr(), dprev.data_ptr(), *pcl, sv["ys"][l - 1].data_ptr(), *pcl,
-                                      B, ci, Hi, Wi, k, s, st))
+                if ci % 4 == 0:
+                    # columns in (ky, kx, c) order: the adjoint gather then reads 16 contiguous bytes per tap
+                    wcl = self.ws.get("b.wcl", (co * ckk,))
+                    check(lib.ssac_permute_cp(self.convs[l].weight.data_ptr(), wcl.data_ptr(), co, ci, k * k, 1, st))
+                    check(lib.ssac_linear_dgrad(dy.data_ptr(), co, wcl.data_ptr(), ckk, dcol.data_ptr(), ckk, rows,
+                                                ckk, co, st))
+                    check(lib.ssac_col2im_cl(dcol.data_ptr(), dprev.data_ptr(), sv["ys"][l - 1].data_ptr(), B, ci, Hi,
+                                             Wi, k, s, st))
+                else:
+                    check(lib.ssac_linear_dgrad(dy.data_ptr(), co, self.convs[l].weight.data_ptr(), ckk,
+                                                dcol.data_ptr(), ckk, rows, ckk, co, st))
+                    pcl = (pHo * pWo * pco, 1, pWo * pco, pco)
+                    check(lib.ssac_col2im(dcol.data_ptr(), dprev.data_ptr(), *pcl, sv["ys"][l - 1].data_ptr(), *pcl,
+                                          B, ci, Hi, Wi, k, s, st))
             dy = dprev
 
     # ------------------------------------------------------------------------------------

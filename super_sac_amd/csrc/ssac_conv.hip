@@ -107,6 +107,44 @@ __global__ void col2im_kernel(Col2imArgs a) {
     }
 }
 
+// The same adjoint for a column matrix whose columns run (ky, kx, c) -- the product of dY with the weight in
+// channels-last column order (ssac_permute_cp) -- into a contiguous channels-last dx (B, Hi, Wi, C), C % 4 == 0:
+// a thread owns 4 channels of one input pixel and every tap it adds is a 16-byte read next to its neighbours'
+// (the (c, ky, kx) order above puts the channels of one tap k*k floats apart: 64-byte strides at k = 4).
+// Same taps in the same order (ky, then kx), so the sums are the ones col2im_kernel forms.
+__global__ __launch_bounds__(256) void col2im_cl_kernel(const float *__restrict__ dcol, float *__restrict__ dx,
+                                                        const float *__restrict__ mask, int B, int C, int Hi, int Wi,
+                                                        int k, int stride, int Ho, int Wo) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int c4n = C >> 2;
+    const int64_t total = (int64_t)B * Hi * Wi * c4n;
+    const int64_t ckk = (int64_t)C * k * k;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        int64_t t = i / c4n;
+        const int ix = (int)(t % Wi); t /= Wi;
+        const int iy = (int)(t % Hi);
+        const int b = (int)(t / Hi);
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ky = iy % stride; ky < k && ky <= iy; ky += stride) {
+            const int oy = (iy - ky) / stride;
+            if (oy >= Ho) continue;
+            for (int kx = ix % stride; kx < k && kx <= ix; kx += stride) {
+                const int ox = (ix - kx) / stride;
+                if (ox >= Wo) continue;
+                acc += *reinterpret_cast<const f4 *>(dcol + ((int64_t)(b * Ho + oy) * Wo + ox) * ckk +
+                                                      (ky * k + kx) * C + 4 * c4);
+            }
+        }
+        if (mask) {
+            const f4 m = *reinterpret_cast<const f4 *>(mask + 4 * i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = m[j] > 0.0f ? acc[j] : 0.0f;
+        }
+        *reinterpret_cast<f4 *>(dx + 4 * i) = acc;
+    }
+}
+
 // dY (.)= [Y > 0]  (ReLU backward on a contiguous buffer)
 __global__ void relu_mask_kernel(float *__restrict__ dy, const float *__restrict__ y, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
@@ -308,6 +346,16 @@ extern "C" int ssac_col2im(const float *dcol, float *dx, int64_t sb, int64_t sc,
     if (total <= 0) return 0;
     SSAC_LAUNCH(col2im_kernel, dim3(grid_for(total)), dim3(256), 0, ST, a);
     return ssac_check_launch("col2im");
+}
+
+extern "C" int ssac_col2im_cl(const float *dcol, float *dx, const float *mask, int B, int C, int Hi, int Wi, int k,
+                              int stride, void *stream) {
+    if (k < 1 || stride < 1 || Hi < k || Wi < k || (C & 3)) return ssac_fail("ssac_col2im_cl: bad geometry (C % 4 == 0)");
+    const int64_t total = (int64_t)B * Hi * Wi * (C / 4);
+    if (total <= 0) return 0;
+    SSAC_LAUNCH(col2im_cl_kernel, dim3(grid_for(total)), dim3(256), 0, ST, dcol, dx, mask, B, C, Hi, Wi, k, stride,
+                (Hi - k) / stride + 1, (Wi - k) / stride + 1);
+    return ssac_check_launch("col2im_cl");
 }
 
 extern "C" int ssac_relu_mask(float *dy, const float *y, int64_t n, void *stream) {

@@ -302,6 +302,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad_kernel(ConvArgs g, int6
 // encoder's forward in front, few input channels (4 / 9) and a stride that divides the kernel.  Its column matrix
 // is the largest buffer of the whole pixel update (419 MB at Atari batch 1024; written once, read twice), so the
 // gather happens in the operand loads here too:
+// The normalisation is linear, so the raw image goes through the MFMAs: the forward pass stages w/div and adds
+// shift * sum(w) to the bias, the weight gradient divides the finished sums and adds shift * sum(dy).
 //   forward        K runs over (c, ky); inside a run lane half h takes the KH consecutive taps kx = h*KH .. h*KH+KH-1
 //                  of its pixel with ONE 8/16-byte load (rows of k < 2 KH taps are padded with zero WEIGHTS; the
 //                  extra pixel read is inside the image row: (Wo-1) s + 2 KH <= Wi is a launch condition);
@@ -335,10 +337,19 @@ __global__ __launch_bounds__(CV_THREADS) void conv_first_fwd_kernel(FirstArgs g,
     for (int i = tid; i < nruns * 32 * 2 * KH; i += CV_THREADS) {
         const int kx = i % (2 * KH), t = i / (2 * KH), co = t & 31, run = t >> 5;
         const int c = run / g.k, ky = run - c * g.k;
-        wl[i] = kx < g.k ? g.w[((int64_t)(co0 + co) * g.C + c) * kk + ky * g.k + kx] : 0.0f;
+        // the input normalisation is linear, so it moves to the weights:  sum w (x/div + shift) = sum (w/div) x + shift sum w
+        wl[i] = kx < g.k ? g.w[((int64_t)(co0 + co) * g.C + c) * kk + ky * g.k + kx] / g.div : 0.0f;
     }
     __syncthreads();
-    const float bias = g.bias[co0 + li];
+    float bias = g.bias[co0 + li];
+    if (g.shift != 0.0f) {
+        // shift * sum_n w[co][n] for this lane's output channel: fixed-order sum of the staged (w/div) rows, times div
+        float ws = 0.0f;
+        for (int run = 0; run < nruns; ++run)
+#pragma unroll
+            for (int j = 0; j < 2 * KH; ++j) ws += wl[(run * 32 + li) * 2 * KH + j];
+        bias += g.shift * (ws * g.div);
+    }
     const int M = g.B * g.Ho * g.Wo;
     const int ngroups = (nruns + FG - 1) / FG;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_first_fwd_kernel(FirstArgs g,
                     const vec bw = *reinterpret_cast<const vec *>(wl + ((run * 32 + li) * 2 + lh) * KH);
 #pragma unroll
                     for (int j = 0; j < KH; ++j)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j] / g.div + g.shift, bw[j], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][j], bw[j], acc, 0, 0, 0);
                 }
             }
         };
@@ -445,8 +456,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_first_wgrad_kernel(FirstArgs 
         for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
             for (int t = 0; t < 16; ++t)
-                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], g.img[xo[t] + noff[nb]] / g.div + g.shift, acc[nb],
-                                                               0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], g.img[xo[t] + noff[nb]], acc[nb], 0, 0, 0);
         }
     }
     bsum += __shfl_xor(bsum, 32, 64);
@@ -472,14 +482,18 @@ __global__ __launch_bounds__(CV_THREADS) void conv_first_wgrad_kernel(FirstArgs 
     }
     if (wave == 0) {
         float *pw = partial_w + (int64_t)blockIdx.x * g.co * ckk;   // partial_w[slice][co][c][ky][kx]
+        float brow[16];  // sum of dy over the slice for the output channel of accumulator row r
+#pragma unroll
+        for (int r = 0; r < 16; ++r) brow[r] = __shfl(bsum, (r & 3) + 8 * (r >> 2) + 4 * lh, 64);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const int n = nb * 32 + li;
             if (n < ckk) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    pw[(int64_t)co * ckk + n] = acc[nb][r];
+                    // sum dy (x/div + shift) = (sum dy x) / div + shift sum dy   (the raw image went through the MFMAs)
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    pw[(int64_t)(co0 + row) * ckk + n] = acc[nb][r] / g.div + g.shift * brow[r];
                 }
             }
         }

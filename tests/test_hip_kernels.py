@@ -797,6 +797,27 @@ def test_lazy_td_inside_critic_launch_equals_td_kernel(ssa):
     _close(logs[4:7], logs_ref[:3], 1e-5, rtol=1e-5, what="td log statistics")
 
 
+@pytest.mark.parametrize("B,Cc,Hh,k,s", [(2, 8, 11, 3, 2), (3, 32, 20, 4, 2), (2, 4, 9, 3, 1), (1, 12, 13, 5, 3)])
+def test_col2im_channels_last_columns_equal_col2im(ssa, B, Cc, Hh, k, s):
+    """ssac_col2im_cl on a column matrix in (ky, kx, c) order == ssac_col2im on the same values in (c, ky, kx) order,
+    bit for bit (same taps, same order), with and without the ReLU mask."""
+    rng = np.random.RandomState(B + Cc + k)
+    Ho = (Hh - k) // s + 1
+    col = torch.from_numpy(rng.standard_normal((B * Ho * Ho, Cc, k * k)).astype(np.float32)).to(DEV)
+    col_cl = col.permute(0, 2, 1).contiguous()
+    mask = torch.from_numpy(rng.standard_normal((B, Hh, Hh, Cc)).astype(np.float32)).to(DEV)
+    lib, st, check = ssa._lib.lib, ssa.engine.stream(), ssa._lib.check
+    cl = (Hh * Hh * Cc, 1, Hh * Cc, Cc)
+    for m in (None, mask):
+        a = torch.full((B, Hh, Hh, Cc), float("nan"), device=DEV)
+        b = torch.full((B, Hh, Hh, Cc), float("nan"), device=DEV)
+        mp = 0 if m is None else m.data_ptr()
+        check(lib.ssac_col2im(col.data_ptr(), a.data_ptr(), *cl, mp, *(cl if m is not None else (0, 0, 0, 0)), B, Cc,
+                              Hh, Hh, k, s, st))
+        check(lib.ssac_col2im_cl(col_cl.data_ptr(), b.data_ptr(), mp, B, Cc, Hh, Hh, k, s, st))
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B,ci,co,k,s,H", [(3, 32, 32, 3, 1, 12), (2, 32, 64, 4, 2, 20), (5, 64, 64, 3, 1, 9),
                                            (40, 32, 32, 3, 1, 13)])
 def test_implicit_gemm_convolution_matches_torch_conv2d(ssa, B, ci, co, k, s, H):

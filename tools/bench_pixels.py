@@ -9,6 +9,8 @@ import numpy as np, torch
 import super_sac_amd as ssa
 import synth
 
+import super_sac_amd.conv_encoder as _ce
+if os.environ.get("PIX_MIN_ROWS"): _ce.IMPLICIT_MIN_ROWS = int(os.environ["PIX_MIN_ROWS"])
 which = sys.argv[1] if len(sys.argv) > 1 else "dmc"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device("cuda")

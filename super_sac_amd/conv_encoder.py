@@ -24,7 +24,7 @@ USE_IMPLICIT = True          # implicit-GEMM inner conv layers (False: every lay
 USE_IMPLICIT_FIRST = True    # the first layer as an implicit GEMM over the NCHW image
 FC_CHANNELS_LAST = True      # fc reads the last map in place
 IMPLICIT_MIN_ROWS = 16_384       # output pixels (B*Ho*Wo) from which the implicit-GEMM kernels pay off
-IMPLICIT_ROWS_PER_SLICE = 1024   # output pixels per weight-gradient slice (= per workgroup), at least
+IMPLICIT_ROWS_PER_SLICE = 256    # output pixels per weight-gradient slice (= per workgroup), at least
 FIRST_MIN_ROWS = 16_384          # output pixels from which the first layer leaves im2col
 FIRST_ROWS_PER_SLICE = 512       # output pixels per first-layer weight-gradient slice, at least
 IMPLICIT_WG_PER_CU = 2           # resident weight-gradient workgroups per CU (248 VGPRs: two waves per SIMD)
@@ -228,9 +228,10 @@ class ConvEncoderEngine:
             rows, ckk = B * Ho * Wo, ci * k * k
             first = l == 0 and self.first
             if first or self.implicit[l]:
-                # one slice = one workgroup: as many slices as are resident at once (a partly filled second round
-                # costs a whole one), never below the configured slice size
-                resident = 256 * (FIRST_WG_PER_CU if first else IMPLICIT_WG_PER_CU)
+                # one slice = one workgroup per (ci/32, co/32) block pair: as many slices as are resident at once (a
+                # partly filled second round costs a whole one), never below the configured slice size
+                blocks = 1 if first else (ci // 32) * (co // 32)
+                resident = max(1, 256 * (FIRST_WG_PER_CU if first else IMPLICIT_WG_PER_CU) // blocks)
                 rps = max(FIRST_ROWS_PER_SLICE if first else IMPLICIT_ROWS_PER_SLICE,
                           ((rows + resident - 1) // resident + 127) // 128 * 128)
             else:

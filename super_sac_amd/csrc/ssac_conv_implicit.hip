@@ -27,7 +27,7 @@ namespace {
 
 constexpr int CV_THREADS = 256;   // 4 waves, each a 32-pixel x 32-channel output tile
 constexpr int CV_PIX = 128;       // pixels per workgroup tile
-constexpr int WL_LD = 36;         // LDS row stride of a weight row (32 floats + 4: conflict-free b128 reads)
+constexpr int WL_LD = 32;         // LDS row stride of a weight row: 32 floats, the 16-byte columns XOR-swizzled by the row
 
 struct ConvArgs {
     const float *x;      // (B, Hi, Wi, ci) channels-last          [fwd: input; dgrad: the layer input (mask)]
@@ -37,6 +37,14 @@ struct ConvArgs {
     float *out;          // fwd: y (B,Ho,Wo,co); dgrad: dx (B,Hi,Wi,ci)
     int B, Hi, Wi, ci, Ho, Wo, co, k, s;
 };
+
+// element (row, col) of a 32-float weight row in LDS: the 16-byte column index is XORed with (row >> 1) & 7.  A
+// ds_read_b128 is served in groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) over 64 banks = 256 bytes;
+// rows are 128 bytes, so a group's 8 even rows (and its 8 odd rows) must land on 8 different 16-byte columns: their
+// row >> 1 values are distinct mod 8 in every group, hence conflict-free without a padding column
+__device__ __forceinline__ int wl_off(int row, int col) {
+    return row * WL_LD + ((((col >> 2) ^ ((row >> 1) & 7)) << 2) | (col & 3));
+}
 
 // chunk index -> (ky, kx, channel block)
 __device__ __forceinline__ void chunk_decode(int ch, int k, int cblocks, int &ky, int &kx, int &cb) {
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_fwd_kernel(ConvArgs g, int n_
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = tid + u * CV_THREADS, c = i & 31, co = i >> 5;
-            wl[(ch * 32 + co) * WL_LD + c] = src[((int64_t)co * g.ci + c) * kk];
+            wl[wl_off(ch * 32 + co, c)] = src[((int64_t)co * g.ci + c) * kk];
         }
     }
     __syncthreads();
@@ -106,10 +114,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv_fwd_kernel(ConvArgs g, int n_
         };
         auto compute = [&](const f4 (&a)[4], int ch) {
             if (ch < nch) {
-                const f4 *bp = reinterpret_cast<const f4 *>(wl + (ch * 32 + li) * WL_LD + lh * 16);
                 f4 bf[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bf[q] = bp[q];
+                for (int q = 0; q < 4; ++q)
+                    bf[q] = *reinterpret_cast<const f4 *>(wl + wl_off(ch * 32 + li, lh * 16 + 4 * q));
 #pragma unroll
                 for (int tt = 0; tt < 16; ++tt)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt >> 2][tt & 3], bf[tt >> 2][tt & 3], acc, 0, 0, 0);
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dgrad_kernel(ConvArgs g, int 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = tid + u * CV_THREADS, o = i & 31, c = i >> 5;
-            wl[(ch * 32 + c) * WL_LD + o] = src[((int64_t)o * g.ci + c) * kk];
+            wl[wl_off(ch * 32 + c, o)] = src[((int64_t)o * g.ci + c) * kk];
         }
     }
     __syncthreads();
@@ -191,10 +199,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dgrad_kernel(ConvArgs g, int 
         };
         auto compute = [&](const f4 (&a)[4], int ch) {
             if (ch < nch) {
-                const f4 *bp = reinterpret_cast<const f4 *>(wl + (ch * 32 + li) * WL_LD + lh * 16);
                 f4 bf[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bf[q] = bp[q];
+                for (int q = 0; q < 4; ++q)
+                    bf[q] = *reinterpret_cast<const f4 *>(wl + wl_off(ch * 32 + li, lh * 16 + 4 * q));
 #pragma unroll
                 for (int tt = 0; tt < 16; ++tt)
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt >> 2][tt & 3], bf[tt >> 2][tt & 3], acc, 0, 0, 0);
@@ -618,7 +626,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad_taps_kernel(ConvArgs g,
 // persistent workgroups per CU: as many as the weight tile in LDS allows, at most 3 (three waves per SIMD hide the
 // operand-load latency the two-chunk prefetch leaves)
 int persistent_per_cu(size_t lds) {
-    const int fit = (int)((160 * 1024) / (lds + 1024));
+    const int fit = (int)((160 * 1024) / (lds + 512));
     return fit < 1 ? 1 : fit > 3 ? 3 : fit;
 }
 

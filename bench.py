@@ -358,6 +358,25 @@ def main():
                         "counterpart; parity: tests/test_hip_bf16.py)",
             "critic_updates_per_s": round(1 / tb, 1), "us_per_critic_update": round(tb * 1e6, 2),
             "ms_per_env_step": round(teb * 1e3, 4), "env_steps_per_s": round(1 / teb, 1)})
+        # ---- BASELINE configs 3 and 4: the pixel configurations (one critic update incl. the encoder's backward pass)
+        del step_b, env_b
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        import bench_pixels
+        for which, label in (("dmc", "config3_dmc_pixels"), ("atari", "config4_atari_pixels")):
+            pstep, pB = bench_pixels.build(which, device)
+            for _ in range(8):   # (also past the clock ramp of a box that has just started)
+                pstep()
+            tp = statistics.median(timed_repeats(pstep, 20, 3, None, device)) / 20
+            secondary[label] = {
+                "workload": ("DrQv2 on 9x84x84 uint8 observations: shift augmentation, BigPixelEncoder, 2 critics of "
+                             "hidden 1024, B 512" if which == "dmc" else
+                             "SAC-Discrete on 4x84x84 uint8 observations: shift augmentation, SmallPixelEncoder, 2 "
+                             "critics of hidden 256, B 1024, gradient clip 40") +
+                            "; one critic update (encoder forward x2, backward, Adam, Polyak)",
+                "ms_per_critic_update": round(tp * 1e3, 3), "critic_updates_per_s": round(1 / tp, 1),
+                "frames_per_s": round(pB / tp, 0)}
+            del pstep
+            torch.cuda.empty_cache()
     if rank == 0:
         if secondary:
             out["secondary"] = secondary

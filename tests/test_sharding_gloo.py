@@ -114,8 +114,8 @@ def test_shard_ownership_map():
         Shard(0, 8, 4)
 
 
-def test_sharded_critic_updates_equal_unsharded(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])   # 4 ranks over the fixture's ensemble: uneven shards, ranks that own no subset member
+def test_sharded_critic_updates_equal_unsharded(tmp_path, world):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_sharded_critic_sequence, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     td_ref, params_ref = _unsharded_reference()

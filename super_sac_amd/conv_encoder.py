@@ -27,8 +27,10 @@ IMPLICIT_MIN_ROWS = 16_384       # output pixels (B*Ho*Wo) from which the implic
 IMPLICIT_ROWS_PER_SLICE = 256    # output pixels per weight-gradient slice (= per workgroup), at least
 FIRST_MIN_ROWS = 16_384          # output pixels from which the first layer leaves im2col
 FIRST_ROWS_PER_SLICE = 512       # output pixels per first-layer weight-gradient slice, at least
-IMPLICIT_WG_PER_CU = 2           # resident weight-gradient workgroups per CU (248 VGPRs: two waves per SIMD)
-FIRST_WG_PER_CU = 3
+IMPLICIT_WG_PER_CU = 2           # weight-gradient workgroups per CU (248 VGPRs: at most two waves per SIMD) ...
+IMPLICIT_WG_BIG_ROWS = 300_000   # ... and ONE from this many output pixels on (measured: DMC 3.31 -> 3.25 ms; fewer,
+                                 # longer slices amortise the cross-wave sum and the partial-slice traffic)
+FIRST_WG_PER_CU = 2              # (measured 2 / 3 / 4 / 6: Atari 1.57 / 1.59 / 1.61 / 1.61 ms)
 FC_SLICES = 48  # K slices of the fc forward (8 row tiles x 48 slices ~ 1.5 workgroups per CU at B 512)
 ROWS_PER_SLICE = 4096  # split-K granularity of the convolution weight gradients
 
@@ -231,7 +233,8 @@ class ConvEncoderEngine:
                 # one slice = one workgroup per (ci/32, co/32) block pair: as many slices as are resident at once (a
                 # partly filled second round costs a whole one), never below the configured slice size
                 blocks = 1 if first else (ci // 32) * (co // 32)
-                resident = max(1, 256 * (FIRST_WG_PER_CU if first else IMPLICIT_WG_PER_CU) // blocks)
+                per_cu = FIRST_WG_PER_CU if first else 1 if rows >= IMPLICIT_WG_BIG_ROWS else IMPLICIT_WG_PER_CU
+                resident = max(1, 256 * per_cu // blocks)
                 rps = max(FIRST_ROWS_PER_SLICE if first else IMPLICIT_ROWS_PER_SLICE,
                           ((rows + resident - 1) // resident + 127) // 128 * 128)
             else:

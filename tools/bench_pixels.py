@@ -54,8 +54,11 @@ def build(which, dev):
 
 if __name__ == "__main__":
     import super_sac_amd.conv_encoder as _ce
-    if os.environ.get("PIX_MIN_ROWS"):
-        _ce.IMPLICIT_MIN_ROWS = int(os.environ["PIX_MIN_ROWS"])
+    for env, knob in (("PIX_MIN_ROWS", "IMPLICIT_MIN_ROWS"), ("PIX_FIRST_WG", "FIRST_WG_PER_CU"),
+                      ("PIX_IMPL_WG", "IMPLICIT_WG_PER_CU"), ("PIX_FIRST_RPS", "FIRST_ROWS_PER_SLICE"),
+                      ("PIX_IMPL_RPS", "IMPLICIT_ROWS_PER_SLICE")):   # knob sweeps
+        if os.environ.get(env):
+            setattr(_ce, knob, int(os.environ[env]))
     which = sys.argv[1] if len(sys.argv) > 1 else "dmc"
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     step, B = build(which, torch.device("cuda"))

@@ -693,6 +693,36 @@ def test_pixel_encoder_backward_matches_autograd(ssa, kind, ch, emb, first, monk
         assert rel_l2 <= tol, f"{kind} grad {key}: rel L2 {rel_l2:.3e} > {tol}"
 
 
+@pytest.mark.parametrize("kind,ch,emb,B", [("big", 9, 50, 512), ("small", 4, 128, 1024)])
+def test_pixel_encoder_full_size_implicit_matches_im2col(ssa, kind, ch, emb, B, monkeypatch):
+    """BASELINE configs 3 and 4 at their real batch sizes (DMC B 512, Atari B 1024): the implicit-GEMM kernels every
+    layer takes at these sizes against the im2col + GEMM path (size-agnostic, pinned to the reference at small sizes
+    above) on the same weights, images and output gradient.  Embeddings within 3e-5; gradients in the L2 sense (a
+    pre-activation within rounding of zero may land on the other side of a ReLU), bias / LayerNorm gradients tight."""
+    from super_sac_amd import conv_encoder
+    conv, _ = _engine_encoder(ssa, kind, ch, emb, 70 + ch)
+    rng = np.random.RandomState(11)
+    x = torch.from_numpy(rng.randint(0, 256, (B, ch, 84, 84)).astype(np.uint8)).to(DEV).float()
+    x += torch.from_numpy(rng.random_sample((B, 1, 84, 84)).astype(np.float32)).to(DEV) * 1e-3   # (shifted images are not integers)
+    d_rep = torch.from_numpy(rng.standard_normal((B, emb)).astype(np.float32)).to(DEV) / B
+    outs = []
+    for implicit in (True, False):
+        monkeypatch.setattr(conv_encoder, "USE_IMPLICIT", implicit)
+        monkeypatch.setattr(conv_encoder, "USE_IMPLICIT_FIRST", implicit)
+        eng = conv_encoder.ConvEncoderEngine(conv, torch.device(DEV))
+        out = torch.zeros(B, emb, device=DEV)
+        eng.forward(x, out, emb, save=True)
+        assert eng.first == implicit and all(eng.implicit[1:]) == implicit
+        eng.backward(d_rep)
+        outs.append((out.clone(), [eng._seg(k, eng.grads).clone() for k in range(len(eng.plist))]))
+        del eng
+    (ya, ga), (yb, gb) = outs
+    _close(ya, yb, 3e-5, rtol=1e-4, what=f"{kind} embedding, implicit vs im2col")
+    for k, (a, b) in enumerate(zip(ga, gb)):
+        rel = float((a - b).double().norm() / (b.double().norm() + 1e-30))
+        assert rel <= 2e-3, f"{kind} parameter {k}: rel L2 {rel:.3e} between the implicit and the im2col gradients"
+
+
 def test_im2col_col2im_are_adjoint(ssa):
     """<im2col(x), c> == <x, col2im(c)> on a strided (channels-last) tensor with stride-2 patches."""
     rng = np.random.RandomState(3)

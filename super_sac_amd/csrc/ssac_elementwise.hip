@@ -947,7 +947,16 @@ __global__ __launch_bounds__(256) void drqv2_shift_plane_kernel(const T *__restr
         for (int i = tid; i < hh; i += 256) out[i] = (float)img[i];
         return;
     }
-    for (int i = tid; i < hh; i += 256) pl[i] = (float)img[i];
+    if (sizeof(T) == 1 && (hh & 3) == 0 && ((uintptr_t)img & 3) == 0) {   // uint8 plane: four pixels per load
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(img);
+        for (int i = tid; i < (hh >> 2); i += 256) {
+            const uint32_t u = w[i];
+            *reinterpret_cast<float4 *>(pl + 4 * i) =
+                make_float4((float)(u & 255u), (float)((u >> 8) & 255u), (float)((u >> 16) & 255u), (float)(u >> 24));
+        }
+    } else {
+        for (int i = tid; i < hh; i += 256) pl[i] = (float)img[i];
+    }
     if (tid < 2 * h) {
         const int ax = tid >= h, i = ax ? tid - h : tid;   // ax 0: x / columns, 1: y / rows
         const float start = (float)(-1.0 + 1.0 / (double)hp), end = (float)(1.0 - 1.0 / (double)hp);
@@ -962,27 +971,27 @@ __global__ __launch_bounds__(256) void drqv2_shift_plane_kernel(const T *__restr
         (ax ? p0y : p0x)[i] = (int)fl;
     }
     __syncthreads();
-    for (int i = tid; i < hh; i += 256) {
-        const int y = i / h, x = i - y * h;
-        const int x0 = p0x[x], y0 = p0y[y];
+    // a thread owns one output column (its two source columns, weights and validity stay in registers) and walks
+    // down the rows, 256 / h rows of the plane per pass: no per-element index division, row terms are LDS broadcasts
+    const int rpp = 256 / h, ty = tid / h, tx = tid - ty * h;
+    if (ty >= rpp) return;
+    const int x0 = p0x[tx];
+    const float wx0 = w0x[tx], wx1 = w1x[tx];
+    const bool vx0 = x0 >= 0 && x0 < hp, vx1 = x0 + 1 >= 0 && x0 + 1 < hp;
+    const int sx0 = min(max(x0 - pad, 0), h - 1), sx1 = min(max(x0 + 1 - pad, 0), h - 1);   // replicate pad
+    for (int y = ty; y < h; y += rpp) {
+        const int y0 = p0y[y];
         float acc = 0.0f;
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
             const int yy = y0 + dy;
             const float wy = dy ? w1y[y] : w0y[y];
             const bool vy = yy >= 0 && yy < hp;
-            const int sy = min(max(yy - pad, 0), h - 1);  // replicate pad
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                const int xx = x0 + dx;
-                const float wx = dx ? w1x[x] : w0x[x];
-                const bool vx = xx >= 0 && xx < hp;
-                const int sx = min(max(xx - pad, 0), h - 1);
-                const float wgt = (vy && vx) ? __fmul_rn(wy, wx) : 0.0f;
-                acc = __fadd_rn(acc, __fmul_rn(pl[sy * h + sx], wgt));
-            }
+            const float *row = pl + min(max(yy - pad, 0), h - 1) * h;
+            acc = __fadd_rn(acc, __fmul_rn(row[sx0], (vy && vx0) ? __fmul_rn(wy, wx0) : 0.0f));
+            acc = __fadd_rn(acc, __fmul_rn(row[sx1], (vy && vx1) ? __fmul_rn(wy, wx1) : 0.0f));
         }
-        out[i] = fminf(fmaxf(acc, 0.0f), 255.0f);
+        out[y * h + tx] = fminf(fmaxf(acc, 0.0f), 255.0f);
     }
 }
 

@@ -619,6 +619,59 @@ int launch(const GemmArgs &g_in, int batch, hipStream_t st) {
     return launch_ks<A_KC, B_KC, EPI, 1>(g, grid, st);
 }
 
+// Heads (N <= 8 outputs) over a deep layer: the 64x64 MFMA tile is 1/64 .. 1/8 full and the launch is 8-16
+// workgroups streaming their rows one 32-deep chunk at a time (30 us at hidden 1024 / B 512).  Here a WAVE owns a row:
+// the lanes take 4 consecutive k each (16-byte loads of x and of every output's weight row, all in flight at once),
+// a shuffle tree sums the 64 partials.  fp32 sums, k-order differs from the MFMA chain (rounding only).
+constexpr int HEAD_MAX_N = 8;
+template <bool RELU>
+__global__ __launch_bounds__(256) void mlp_head_rows_kernel(GemmArgs g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave, e = blockIdx.y;
+    if (row >= g.M) return;
+    const float *x = g.A + batch_off(g.ids, g.idsA, e, g.sA) + (int64_t)row * g.lda;
+    const float *W = g.B + batch_off(g.ids, g.idsB, e, g.sB);
+    float acc[HEAD_MAX_N];
+#pragma unroll
+    for (int n = 0; n < HEAD_MAX_N; ++n) acc[n] = 0.0f;
+    for (int k = lane * 4; k < g.K; k += 256) {
+        const f4 xv = *reinterpret_cast<const f4 *>(x + k);
+#pragma unroll
+        for (int n = 0; n < HEAD_MAX_N; ++n) {
+            if (n < g.N) {
+                const f4 wv = *reinterpret_cast<const f4 *>(W + (int64_t)n * g.ldb + k);
+                acc[n] += xv[0] * wv[0];
+                acc[n] += xv[1] * wv[1];
+                acc[n] += xv[2] * wv[2];
+                acc[n] += xv[3] * wv[3];
+            }
+        }
+    }
+    const float *bias = g.bias + batch_off(g.ids, g.idsB, e, g.sBias);
+    float *c = g.C + batch_off(g.ids, g.idsC, e, g.sC) + (int64_t)row * g.ldc;
+#pragma unroll
+    for (int n = 0; n < HEAD_MAX_N; ++n) {
+        if (n < g.N) {
+            const float v = wave_sum(acc[n]) + bias[n];
+            if (lane == 0) c[n] = RELU ? fmaxf(v, 0.0f) : v;
+        }
+    }
+}
+
+// the head kernel takes a forward layer with at most 8 outputs and K >= 256, 16-byte aligned rows
+bool head_rows_ok(const GemmArgs &g) {
+    return g.N >= 1 && g.N <= HEAD_MAX_N && g.K >= 256 && (g.K & 3) == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 &&
+           (g.sA & 3) == 0 && (g.sB & 3) == 0 && (((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0;
+}
+
+int launch_head_rows(const GemmArgs &g, int batch, bool relu, hipStream_t st) {
+    if (g.M <= 0 || batch <= 0) return 0;
+    const dim3 grid((g.M + 3) / 4, batch);
+    if (relu) SSAC_LAUNCH(mlp_head_rows_kernel<true>, grid, dim3(256), 0, st, g);
+    else SSAC_LAUNCH(mlp_head_rows_kernel<false>, grid, dim3(256), 0, st, g);
+    return ssac_check_launch("mlp_head_rows");
+}
+
 long long *g_gemm_dbg = nullptr;
 
 struct LayerGeom { int64_t off_w, off_b; int rows, cols; };
@@ -661,6 +714,7 @@ extern "C" int ssac_mlp_layer_fwd(const ssac_mlp *nets, int layer, const int32_t
     g.ids = net_ids;
     g.bias = nets->params + L.off_b; g.sBias = nets->net_stride;
     hipStream_t st = (hipStream_t)stream;
+    if (head_rows_ok(g)) return launch_head_rows(g, n_sel, relu != 0, st);
     return relu ? launch<true, true, EPI_BIAS_RELU>(g, n_sel, st) : launch<true, true, EPI_BIAS>(g, n_sel, st);
 }
 

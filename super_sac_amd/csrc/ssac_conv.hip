@@ -258,6 +258,46 @@ __global__ void ln_tanh_fwd_kernel(const float *__restrict__ x, int64_t ldx, con
     }
 }
 
+// The same arithmetic (a row's two sums run serially over its features, in index order -> same bits) with everything
+// else taken off the serial chain: 64 rows per workgroup are staged in LDS with coalesced loads (row stride D + 1:
+// conflict-free row walks), 64 threads form the rows' mean / rstd, then all 256 threads normalise, apply tanh -- the
+// expensive part: one thread per row spent 50 serial tanhf per row -- and store, one element each at a time.
+__global__ __launch_bounds__(256) void ln_tanh_fwd_lds_kernel(const float *__restrict__ x, int64_t ldx,
+                                                              const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, int n_rows, int D,
+                                                              float *__restrict__ out, int64_t ldo,
+                                                              float *__restrict__ xhat, float *__restrict__ rstd) {
+    extern __shared__ float lds[];   // xs[64][D + 1] | mean[64] | rs[64]
+    const int ld = D + 1, tid = threadIdx.x, r0 = blockIdx.x * 64;
+    const int rows = min(64, n_rows - r0);
+    float *xs = lds, *mean_s = lds + 64 * ld, *rs_s = mean_s + 64;
+    for (int i = tid; i < rows * D; i += 256) {
+        const int r = i / D, j = i - r * D;
+        xs[r * ld + j] = x[(int64_t)(r0 + r) * ldx + j];
+    }
+    __syncthreads();
+    if (tid < rows) {
+        const float *xr = xs + tid * ld;
+        float mean = 0.0f;
+        for (int j = 0; j < D; ++j) mean += xr[j];
+        mean /= (float)D;
+        float var = 0.0f;
+        for (int j = 0; j < D; ++j) { const float d = xr[j] - mean; var += d * d; }
+        var /= (float)D;
+        const float rs = 1.0f / sqrtf(var + 1e-5f);
+        if (rstd) rstd[r0 + tid] = rs;
+        mean_s[tid] = mean;
+        rs_s[tid] = rs;
+    }
+    __syncthreads();
+    for (int i = tid; i < rows * D; i += 256) {
+        const int r = i / D, j = i - r * D;
+        const float xh = (xs[r * ld + j] - mean_s[r]) * rs_s[r];
+        if (xhat) xhat[(int64_t)(r0 + r) * D + j] = xh;
+        out[(int64_t)(r0 + r) * ldo + j] = tanhf(xh * gamma[j] + beta[j]);
+    }
+}
+
 // backward: d_out (n_rows x D) wrt tanh output -> dx (pre-LayerNorm), dgamma, dbeta.  Two launches:
 //   rows:    one WAVE per row (lanes over the features, coalesced), the row's two means by a shuffle tree;
 //   columns: one workgroup per feature, 256 threads over the rows, fixed-order tree -> dgamma[j], dbeta[j].
@@ -409,8 +449,13 @@ extern "C" int ssac_ln_tanh_fwd(const float *x, int64_t ldx, const float *gamma,
                                 int n_rows, int dim, float *out, int64_t ldo, float *xhat, float *rstd,
                                 void *stream) {
     if (n_rows <= 0) return 0;
-    SSAC_LAUNCH(ln_tanh_fwd_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ST, x, ldx, gamma, beta,
-                       n_rows, dim, out, ldo, xhat, rstd);
+    const size_t lds = sizeof(float) * (64 * (size_t)(dim + 1) + 128);
+    if (lds <= 64 * 1024)
+        SSAC_LAUNCH(ln_tanh_fwd_lds_kernel, dim3((n_rows + 63) / 64), dim3(256), lds, ST, x, ldx, gamma, beta, n_rows, dim,
+                    out, ldo, xhat, rstd);
+    else
+        SSAC_LAUNCH(ln_tanh_fwd_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ST, x, ldx, gamma, beta,
+                    n_rows, dim, out, ldo, xhat, rstd);
     return ssac_check_launch("ln_tanh_fwd");
 }
 

@@ -723,6 +723,29 @@ def test_pixel_encoder_full_size_implicit_matches_im2col(ssa, kind, ch, emb, B, 
         assert rel <= 2e-3, f"{kind} parameter {k}: rel L2 {rel:.3e} between the implicit and the im2col gradients"
 
 
+@pytest.mark.parametrize("rows,D", [(130, 50), (64, 7), (1, 128), (513, 50)])
+def test_layernorm_tanh_forward(ssa, rows, D):
+    """ssac_ln_tanh_fwd (cnns.py:66-68) against torch layer_norm + tanh on the CPU: ragged row counts (partial last
+    workgroup), strided source and destination, the saved xhat / rstd of the backward pass."""
+    rng = np.random.RandomState(rows + D)
+    x = torch.from_numpy(rng.standard_normal((rows, D + 3)).astype(np.float32) * 2.0)
+    gm = torch.from_numpy(rng.standard_normal(D).astype(np.float32))
+    bt = torch.from_numpy(rng.standard_normal(D).astype(np.float32))
+    want = torch.tanh(F.layer_norm(x[:, :D], (D,), gm, bt, eps=1e-5))
+    mu, var = x[:, :D].mean(1, keepdim=True), x[:, :D].var(1, unbiased=False, keepdim=True)
+    xd, gd, bd = x.to(DEV), gm.to(DEV), bt.to(DEV)
+    out = torch.full((rows, D + 5), float("nan"), device=DEV)
+    xhat = torch.full((rows, D), float("nan"), device=DEV)
+    rstd = torch.full((rows,), float("nan"), device=DEV)
+    ssa._lib.check(ssa._lib.lib.ssac_ln_tanh_fwd(xd.data_ptr(), D + 3, gd.data_ptr(), bd.data_ptr(), rows, D,
+                                                 out.data_ptr(), D + 5, xhat.data_ptr(), rstd.data_ptr(),
+                                                 ssa.engine.stream()))
+    _close(out[:, :D], want, 2e-6, rtol=1e-5, what="LayerNorm + tanh")
+    _close(xhat, (x[:, :D] - mu) / torch.sqrt(var + 1e-5), 1e-5, rtol=1e-5, what="xhat")
+    _close(rstd, (1.0 / torch.sqrt(var + 1e-5)).squeeze(1), 1e-5, rtol=1e-5, what="rstd")
+    assert torch.isnan(out[:, D:]).all(), "wrote past the row"
+
+
 def test_im2col_col2im_are_adjoint(ssa):
     """<im2col(x), c> == <x, col2im(c)> on a strided (channels-last) tensor with stride-2 patches."""
     rng = np.random.RandomState(3)

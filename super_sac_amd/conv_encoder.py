@@ -54,9 +54,8 @@ class ConvEncoderEngine:
         self.geom = [(c.in_channels, c.out_channels, c.kernel_size[0], c.stride[0]) for c in convs]
         self.emb = module.fc.out_features
         # inner layers with 32-multiple channel counts run as implicit GEMMs (csrc/ssac_conv_implicit.hip)
-        # (forward and weight gradient; the backward-data pass of a STRIDED layer stays GEMM + col2im, which needs no
-        # saved column matrix: its transposed gather would waste (s*s-1)/(s*s) of the taps; small maps -- decided per
-        # call from the row count -- stay on im2col)
+        # (small maps -- decided per call from the row count -- stay on im2col; a strided layer's backward-data pass
+        # runs per parity class of input pixels, so no MFMA is spent on a structurally zero tap)
         self.implicit_ok = [USE_IMPLICIT and l > 0 and bool(lib.ssac_conv_implicit_supported(ci, co, k))
                             for l, (ci, co, k, s) in enumerate(self.geom)]
         self.implicit = list(self.implicit_ok)
@@ -259,7 +258,7 @@ class ConvEncoderEngine:
                 break
             pci, pco, pk, ps, pHi, pWi, pHo, pWo = sv["shapes"][l - 1]
             dprev = self.ws.get(f"b.dy{(l - 1) % 2}", (B * pHo * pWo * pco,))
-            if self.implicit[l] and s == 1:
+            if self.implicit[l] and s <= 4:   # (strided layers: one parity class of input pixels per tile)
                 check(lib.ssac_conv_dgrad(dy.data_ptr(), self.convs[l].weight.data_ptr(), sv["ys"][l - 1].data_ptr(),
                                           dprev.data_ptr(), B, Hi, Wi, ci, co, k, s, st))
             else:

@@ -229,6 +229,102 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dgrad_kernel(ConvArgs g, int 
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward-data of a STRIDED layer (s > 1): the input pixels are processed in s*s parity classes (iy % s, ix % s).
+// A pixel of class (py, px) receives only the taps ky = py + jy s, kx = px + jx s -- the same ones for every pixel
+// of its class, with oy = iy/s - jy, ox = ix/s - jx -- so a tile of one class spends its MFMAs on those taps only
+// (k*k / s*s of them; the generic gather above multiplies through all k*k and zeroes the rest).  Taps still go in
+// ascending (ky, kx) order: same sums as the generic kernel, bit for bit.
+// grid (persistent workgroups, class = blockIdx.x % s*s; ci / 32); class c has first[c+1] - first[c] tiles
+// ---------------------------------------------------------------------------------------------
+constexpr int DG_MAX_S = 4;
+struct StridedTiles { int first[DG_MAX_S * DG_MAX_S + 1]; };
+
+__global__ __launch_bounds__(CV_THREADS) void conv_dgrad_strided_kernel(ConvArgs g, StridedTiles tl, int max_chunks) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [this class's chunks][32 c][WL_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int oblocks = g.co >> 5, kk = g.k * g.k;
+    const int c0 = blockIdx.y * 32;
+    // a workgroup belongs to ONE class (blockIdx.x % s*s) and stages only that class's taps: k*k / s*s of the weights
+    const int n_classes = g.s * g.s, cls = blockIdx.x % n_classes, wg = blockIdx.x / n_classes, n_wg = gridDim.x / n_classes;
+    const int py = cls / g.s, px = cls - py * g.s;
+    const int njy = max((g.k - py + g.s - 1) / g.s, 0), njx = max((g.k - px + g.s - 1) / g.s, 0);
+    const int nch = njy * njx * oblocks;   // chunk (jy, jx, ob), ob fastest
+    int *pix_off = reinterpret_cast<int *>(wl + (size_t)max_chunks * 32 * WL_LD);   // [4 waves][32]: output pixel index
+    for (int ch = 0; ch < nch; ++ch) {
+        const int ob = ch % oblocks, tj = ch / oblocks, jx = tj % njx, jy = tj / njx;
+        const int ky = py + jy * g.s, kx = px + jx * g.s;
+        const float *src = g.w + ((int64_t)(ob * 32) * g.ci + c0) * kk + ky * g.k + kx;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + u * CV_THREADS, o = i & 31, c = i >> 5;
+            wl[wl_off(ch * 32 + c, o)] = src[((int64_t)o * g.ci + c) * kk];
+        }
+    }
+    __syncthreads();
+    const int Hy = (g.Hi - py + g.s - 1) / g.s, Wx = (g.Wi - px + g.s - 1) / g.s;
+    const int npix = g.B * Hy * Wx;
+    const int n_tiles = tl.first[cls + 1] - tl.first[cls];
+    for (int tile = wg; tile < n_tiles; tile += n_wg) {
+        const int p = tile * CV_PIX + wave * 32 + li;
+        const bool ok = p < npix;
+        const int pp = ok ? p : 0;
+        const int xq = pp % Wx, t = pp / Wx;
+        const int yq = t % Hy, b = t / Hy;
+        if (lh == 0) pix_off[wave * 32 + li] = ok ? (b * g.Hi + yq * g.s + py) * g.Wi + xq * g.s + px : -1;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        const float *dyb = g.dy + (int64_t)b * g.Ho * g.Wo * g.co + lh * 16;
+        // chunk order: jy, jx ascending, output-channel block fastest (uniform stepping; stays on the last chunk)
+        int ijy = 0, ijx = 0, iob = 0, left = nch - 1;
+        auto load = [&](f4 (&a)[4]) {
+            const int oy = yq - ijy, ox = xq - ijx;
+            const bool v = ok && nch > 0 && (unsigned)oy < (unsigned)g.Ho && (unsigned)ox < (unsigned)g.Wo;
+            const float *q = dyb + (v ? (oy * g.Wo + ox) * g.co : 0) + iob * 32;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f4 x = *reinterpret_cast<const f4 *>(q + 4 * u);
+                a[u] = v ? x : (f4){0.f, 0.f, 0.f, 0.f};
+            }
+            if (left > 0) {
+                --left;
+                if (++iob == oblocks) { iob = 0; if (++ijx == njx) { ijx = 0; ++ijy; } }
+            }
+        };
+        auto compute = [&](const f4 (&a)[4], int ch) {
+            if (ch < nch) {
+                f4 bf[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    bf[u] = *reinterpret_cast<const f4 *>(wl + wl_off(ch * 32 + li, lh * 16 + 4 * u));
+#pragma unroll
+                for (int tt = 0; tt < 16; ++tt)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt >> 2][tt & 3], bf[tt >> 2][tt & 3], acc, 0, 0, 0);
+            }
+        };
+        f4 a0[4], a1[4], a2[4];
+        load(a0);
+        load(a1);
+        for (int ch = 0; ch < nch; ch += 3) {
+            load(a2); compute(a0, ch);
+            load(a0); compute(a1, ch + 1);
+            load(a1); compute(a2, ch + 2);
+        }
+        lds_barrier();   // pix_off of this tile (a wave reads only the 32 entries it wrote itself)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int po = pix_off[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+            if (po >= 0) {
+                const int64_t o = (int64_t)po * g.ci + c0 + li;
+                g.out[o] = g.x[o] > 0.0f ? acc[r] : 0.0f;
+            }
+        }
+        lds_barrier();   // before the next tile overwrites pix_off
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient: grid (pixel slices, ci / 32, co / 32); each workgroup owns the (32 co x 32 c x k x k) block of
 // dW for its slice of output pixels.  Wave w takes the taps t = w, w+4, ... (one 32x32 accumulator per tap).
 //   A = dy^T : lane (co, half) needs dy[pixel 16 half + t][co]      -> 16 scalar loads, 128 B coalesced per pixel
@@ -677,10 +773,38 @@ extern "C" int ssac_conv_dgrad(const float *dy, const float *w, const float *x_m
     const int per_cu = persistent_per_cu(lds);
     const int cap = 256 * per_cu / (ci / 32) > 0 ? 256 * per_cu / (ci / 32) : 1;
     const int gx = n_tiles < cap ? n_tiles : cap;
-    if (s == 1)
+    if (s == 1) {
         SSAC_LAUNCH(conv_dgrad_kernel<true>, dim3(gx, ci / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
-    else
+    } else if (s <= DG_MAX_S && M < (1ll << 31) - 65536) {
+        // parity classes: only the taps a class of input pixels can receive
+        StridedTiles tl{};
+        int total = 0;
+        for (int cls = 0; cls < s * s; ++cls) {
+            const int py = cls / s, px = cls % s;
+            const int64_t npix = (int64_t)B * ((Hi - py + s - 1) / s) * ((Wi - px + s - 1) / s);
+            tl.first[cls] = total;
+            total += (int)((npix + CV_PIX - 1) / CV_PIX);
+        }
+        tl.first[s * s] = total;
+        const int tj = (k + s - 1) / s, max_chunks = tj * tj * (co / 32);   // taps of the richest class
+        const size_t lds2 = sizeof(float) * (size_t)max_chunks * 32 * WL_LD + sizeof(int) * 128;
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void *)conv_dgrad_strided_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024);
+            attr2 = true;
+        }
+        if (lds2 > 160 * 1024) return ssac_fail("ssac_conv_dgrad: weight tile does not fit LDS");
+        // persistent workgroups, the same number for every class
+        const int per_cu2 = persistent_per_cu(lds2), ncls = s * s;
+        int per_class = 256 * per_cu2 / (ci / 32) / ncls;
+        const int most = (total + ncls - 1) / ncls + 1;
+        per_class = per_class < 1 ? 1 : per_class > most ? most : per_class;
+        SSAC_LAUNCH(conv_dgrad_strided_kernel, dim3(per_class * ncls, ci / 32), dim3(CV_THREADS), lds2,
+                    (hipStream_t)stream, g, tl, max_chunks);
+    } else {
         SSAC_LAUNCH(conv_dgrad_kernel<false>, dim3(gx, ci / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
+    }
     return ssac_check_launch("conv_dgrad");
 }
 

@@ -872,7 +872,8 @@ def test_col2im_channels_last_columns_equal_col2im(ssa, B, Cc, Hh, k, s):
 
 
 @pytest.mark.parametrize("B,ci,co,k,s,H", [(3, 32, 32, 3, 1, 12), (2, 32, 64, 4, 2, 20), (5, 64, 64, 3, 1, 9),
-                                           (40, 32, 32, 3, 1, 13)])
+                                           (40, 32, 32, 3, 1, 13), (3, 32, 32, 3, 2, 11), (7, 64, 32, 4, 3, 16),
+                                           (2, 32, 32, 2, 4, 18)])   # strided: parity classes with 1..4 taps, or none
 def test_implicit_gemm_convolution_matches_torch_conv2d(ssa, B, ci, co, k, s, H):
     """csrc/ssac_conv_implicit.hip: forward (bias + ReLU), backward-data (with the input's ReLU mask) and the
     sliced weight gradient against torch.nn.functional.conv2d + autograd on the CPU (fp32)."""

@@ -720,7 +720,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad_taps_kernel(ConvArgs g,
 }
 
 // persistent workgroups per CU: as many as the weight tile in LDS allows, at most 3 (three waves per SIMD hide the
-// operand-load latency the two-chunk prefetch leaves)
+// operand-load latency the two-chunk prefetch leaves; measured on the DMC update at 2 / 3 / 4: 3.13 / 3.09 / 3.28 ms --
+// a fourth workgroup's operand stream no longer fits the L1 next to the others')
 int persistent_per_cu(size_t lds) {
     const int fit = (int)((160 * 1024) / (lds + 512));
     return fit < 1 ? 1 : fit > 3 ? 3 : fit;

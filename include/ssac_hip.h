@@ -705,9 +705,14 @@ int ssac_linear_fwd(const float *X, int64_t ldx, const float *W, int64_t ldw, co
  * channels-last fp32 activations (B, H, W, C), nn.Conv2d weights (co, ci, k, k) used in place, no padding,
  * stride s; the patch gather happens in the operand loads, no column matrix is materialised.
  *   ssac_conv_fwd   y = relu(conv(x) + bias)                                  (cnns.py:59-66, 96-100)
- *   ssac_conv_dgrad dx = [x_mask > 0] * conv_transpose(dy)    (x_mask = this layer's input = previous ReLU output)
+ *   ssac_conv_dgrad dx = [x_mask > 0] * conv_transpose(dy)    (x_mask = this layer's input = previous ReLU output;
+ *                   stride 1: every tap; stride 2..4: per parity class (iy % s, ix % s) of input pixels, only the taps
+ *                   that class can receive; larger strides: generic gather through all taps)
  *   ssac_conv_wgrad partial_w[slice] (co,ci,k,k), partial_b[slice] (co) over slices of pix_per_slice (multiple
- *                   of 32) output pixels; sum them with ssac_reduce_slices (fixed order). */
+ *                   of 32) output pixels; sum them with ssac_reduce_slices (fixed order).  With k*k <= 9 and slices
+ *                   that are multiples of 128 pixels every wave keeps all taps' accumulators (balanced, dy read once)
+ *                   and the four waves are summed through LDS in a fixed order; otherwise the taps are split over
+ *                   the waves. */
 int ssac_conv_implicit_supported(int ci, int co, int k);
 int ssac_conv_fwd(const float *x, const float *w, const float *bias, float *y, int B, int Hi, int Wi, int ci, int co,
                   int k, int s, void *stream);

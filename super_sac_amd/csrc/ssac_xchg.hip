@@ -116,7 +116,14 @@ extern "C" ssac_xchg *ssac_xchg_create(int rank, int world, int slot_floats) {
     ssac_xchg *x = new ssac_xchg();
     x->rank = rank; x->world = world; x->slot_floats = slot_floats;
     const size_t bytes = sizeof(float) * (size_t)world * X_SLOTS * (slot_floats + 4);
-    if (hipMalloc((void **)&x->local, bytes) != hipSuccess || hipMemset(x->local, 0, bytes) != hipSuccess ||
+    // The receive buffer is written by PEER devices while this device polls it: uncached (fine-grained) device memory,
+    // so that no stale line of it can sit in this device's L2 (what RCCL does for its flags and LL buffers); plain
+    // hipMalloc only where the runtime refuses the flag.
+    if (hipExtMallocWithFlags((void **)&x->local, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        x->local = nullptr;
+    }
+    if ((!x->local && hipMalloc((void **)&x->local, bytes) != hipSuccess) || hipMemset(x->local, 0, bytes) != hipSuccess ||
         hipMalloc((void **)&x->seq, 16) != hipSuccess || hipMemset(x->seq, 0, 16) != hipSuccess) {
         ssac_fail("ssac_xchg_create: allocation failed");
         delete x;

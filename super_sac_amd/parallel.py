@@ -67,8 +67,30 @@ class Exchange:
         check(lib.ssac_xchg_handle(h, mine))
         gathered = [None] * world
         dist.all_gather_object(gathered, bytes(mine.raw))
-        check(lib.ssac_xchg_connect(h, b"".join(gathered)))
+        # every rank must reach the same verdict (a rank that raised here while its peers went on would leave them in
+        # a collective nobody else joins): connect, then ONE exchange of known values, and the ranks vote
+        err = None
+        if lib.ssac_xchg_connect(h, b"".join(gathered)) != 0:
+            err = "connect: " + lib.ssac_last_error().decode()
         dist.barrier()
+        votes = [None] * world
+        dist.all_gather_object(votes, err)
+        if all(v is None for v in votes):
+            probe = torch.full((16,), float(rank + 1), device=device)
+            probe_sum = probe.clone()
+            self.reduce(probe, 0)
+            self.reduce(probe_sum, 1)
+            torch.cuda.synchronize(device)
+            if self.failed():
+                err = "probe: a peer's flag did not arrive"
+            elif not (bool((probe == 1.0).all()) and bool((probe_sum == world * (world + 1) / 2).all())):
+                err = "probe: wrong reduction"
+            dist.all_gather_object(votes, err)
+        if any(v is not None for v in votes):
+            bad = {r: v for r, v in enumerate(votes) if v is not None}
+            lib.ssac_xchg_destroy(h)
+            self.handle = None
+            raise RuntimeError(f"one-shot exchange unavailable on ranks {bad}")
 
     def reduce(self, t, op):
         from . import engine

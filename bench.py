@@ -255,12 +255,18 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
+    if dist is not None:
+        dist.barrier()   # ranks finish building at different times: start the exchanging updates together
     for _ in range(args.warmup):
         step()
 
     # ---- timed region: EXACTLY --steps steps between barrier+sync brackets, `repeats` times; the median is reported
     times = timed_repeats(step, args.steps, args.repeats, dist, device)
     dt = statistics.median(times)
+    if world > 1:
+        from super_sac_amd import parallel
+        if parallel.exchange_failed():   # a peer's flag never arrived: the numbers above would be of a broken run
+            raise RuntimeError("one-shot exchange: a peer's flag did not arrive within the spin limit")
 
     # ---- roofline of the dominant kernel: the chained launch (ensemble-Q forward + TD-independent backward of all local
     # critics beside the target chains).  Algorithmic FLOPs per launch: 2*B*N*(in*H + H*H + H) for the

@@ -29,7 +29,7 @@ namespace {
 constexpr int X_SLOTS = 4;
 constexpr int X_MAX_WORLD = 8;
 constexpr int X_THREADS = 256;
-constexpr long long X_SPIN_LIMIT = 4000000000LL;   // shader clocks (~2 s): a missing peer raises an error, never a hang
+constexpr long long X_SPIN_LIMIT = 20000000000LL;   // shader clocks (~10 s): a missing peer raises an error, never a hang
 
 struct XchgArgs {
     float *peer[X_MAX_WORLD];   // every rank's receive buffer, as mapped into THIS process (peer[rank] = own buffer)

@@ -115,6 +115,12 @@ def enable_one_shot(device, max_floats=ONE_SHOT_MAX_FLOATS):
     return _exchange
 
 
+def exchange_failed():
+    """True when an exchange kernel of this process gave up waiting for a peer (bounded spin, csrc/ssac_xchg.hip): the
+    reductions since then are not reductions.  Reads a device int -- call it at synchronisation points."""
+    return _exchange is not None and _exchange.failed()
+
+
 def one_shot_ready(t):
     x = _exchange
     return (x is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()

@@ -303,6 +303,82 @@ def test_late_bound_polyak_equals_the_polyak_launch(precision):
     assert np.array_equal(p0, p2) and np.array_equal(t0, t2), "late requests must fall back to the Polyak launch"
 
 
+def test_late_bound_polyak_under_random_timing():
+    """the host / device race of the late-bound Polyak request, exercised instead of staged: 1500 recorded updates, a
+    soft_update behind every second one, with random host delays (0-150 us busy wait) in front of the request and
+    random device stalls (0-40 us) in front of the updates, so requests arrive before the update's first launch has
+    begun, while it runs, and after it -- in one run.  Online and target parameters must equal, bit for bit, those of
+    the same run with the mechanism switched off (a Polyak launch per soft_update)."""
+    import copy
+    import math
+    import random
+    import time
+    from itertools import chain
+
+    import torch
+    import super_sac_amd as ssa
+    lu = ssa.learning_utils
+
+    def run(late):
+        old = lu.LATE_POLYAK
+        lu.LATE_POLYAK = late
+        served = [0, 0]
+        real_polyak = ssa._lib.lib.ssac_step_polyak
+
+        def counting(handle, tau):
+            rc = real_polyak(handle, tau)
+            served[0 if rc == 1 else 1] += 1
+            return rc
+        try:
+            torch.manual_seed(4); np.random.seed(4); random.seed(4)
+            jitter = np.random.RandomState(99)
+            dev = torch.device("cuda")
+            agent = ssa.Agent(act_space_size=6, encoder=ssa.nets.IdentityEncoder(17),
+                              actor_network_cls=ssa.nets.ContinuousStochasticActor,
+                              critic_network_cls=ssa.nets.ContinuousCritic, ensemble_size=1, num_critics=10,
+                              hidden_size=256, auto_rescale_targets=False, log_std_low=-5.0, log_std_high=2.0)
+            agent.to(dev)
+            target = copy.deepcopy(agent)
+            buf = ssa.replay.ReplayBuffer(8192, device=dev)
+            buf.load_experience(*synth.synth_transitions(4000, 17, 6, seed=6))
+            copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=3e-4)
+            eopt = torch.optim.Adam(agent.encoder.parameters(), lr=1e-4)
+            la = torch.Tensor([math.log(0.1)]).to(dev); la.requires_grad = True
+            aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(512)])
+            ssa._lib.lib.ssac_step_polyak = counting
+            for k in range(1500):
+                stall = int(jitter.randint(0, 4)) * 25_000       # 0 / ~13 / ~27 / ~40 us of device stall
+                if stall:
+                    torch.cuda._sleep(stall)
+                ssa.learning.critic_update(
+                    buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt, encoder_optimizer=eopt,
+                    log_alphas=[la], batch_size=512, gamma=0.99, critic_clip=None, encoder_clip=None,
+                    target_critic_ensemble_n=2, weighted_bellman_temp=None, weight_type=None, pop=False,
+                    augmenter=aug, encoder_lambda=0, aug_mix=0.0, discrete=False, random_process=None,
+                    noise_clip=None, per=False, update_priorities=False, dr3_coeff=0.0)
+                if k % 2:
+                    t_end = time.perf_counter() + float(jitter.randint(0, 150)) * 1e-6
+                    while time.perf_counter() < t_end:
+                        pass
+                    lu.soft_update(target.critics[0], agent.critics[0], 0.005)
+                if k % 400 == 399:
+                    torch.cuda.synchronize()   # (drain now and then: the host is not always far ahead)
+            params = torch.cat([p.detach().flatten() for p in agent.critics[0].parameters()]).cpu().numpy()
+            tparams = torch.cat([p.detach().flatten() for p in target.critics[0].parameters()]).cpu().numpy()
+            return params, tparams, served
+        finally:
+            lu.LATE_POLYAK = old
+            ssa._lib.lib.ssac_step_polyak = real_polyak
+
+    p0, t0, s0 = run(False)
+    p1, t1, s1 = run(True)
+    assert s0 == [0, 0] and 700 <= sum(s1) <= 750   # (the first updates run eagerly: their soft_update is a launch)
+    assert s1[0] > 0, f"no request was ever served by the weight-gradient launch: {s1}"
+    assert np.array_equal(t0, t1), f"target parameters differ (served / fell back: {s1})"
+    assert np.array_equal(p0, p1), f"online parameters differ (served / fell back: {s1})"
+    print(f"late-bound Polyak under random timing: {s1[0]} served in the weight-gradient launch, {s1[1]} fell back")
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
 @pytest.mark.parametrize("name", sorted(synth.AFBC_CASES))
 def test_afbc_and_per_match_reference(name, fused):

@@ -746,6 +746,11 @@ int ssac_reduce_slices_bias(const float *partial, int slices, int M, int N, cons
 /* dX (M x N_in) = dY (M x K_out) W (K_out x N_in) */
 int ssac_linear_dgrad(const float *dY, int64_t ldy, const float *W, int64_t ldw, float *dX, int64_t ldx,
                       int M, int N_in, int K_out, void *stream);
+/* the same with the ReLU derivative of the producing layer in the epilogue: dX = [mask > 0] * (dY W), mask (M x N_in)
+ * with row stride ldmask (the layer's saved output) -- the fc of the pixel encoders over the last feature map
+ * (cnns.py:63-66, 98-100), one pass over dX instead of a GEMM store + a mask pass */
+int ssac_linear_dgrad_masked(const float *dY, int64_t ldy, const float *W, int64_t ldw, const float *mask,
+                             int64_t ldmask, float *dX, int64_t ldx, int M, int N_in, int K_out, void *stream);
 /* split-K weight gradient: slice z covers rows [z*rows_per_slice, ...): partial_w[z] = dY_z^T X_z
  * (M_out x N_in), partial_b[z] = colsum(dY_z); reduce with ssac_reduce_slices. */
 int ssac_linear_wgrad_splitk(const float *dY, int64_t ldy, const float *X, int64_t ldx, float *partial_w,

@@ -171,6 +171,7 @@ SIGNATURES = {
     "ssac_linear_fwd_splitk": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P],
     "ssac_reduce_slices_bias": [_P, _I, _I, _I, _P, _P, _L, _P],
     "ssac_linear_dgrad": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P],
+    "ssac_linear_dgrad_masked": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P],
     "ssac_linear_wgrad_splitk": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _P],
     "ssac_reduce_slices": [_P, _I, _L, _P, _P],
     "ssac_relu_mask": [_P, _P, _L, _P],

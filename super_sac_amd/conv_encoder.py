@@ -202,7 +202,6 @@ class ConvEncoderEngine:
         ci, co, k, s, Hi, Wi, Ho, Wo = sv["shapes"][-1]
         dy = self.ws.get(f"b.dy{(nconv - 1) % 2}", (B * Ho * Wo * co,))
         ylast = sv["ys"][-1]
-        dcolf = self.ws.get("b.dcolf", (B * flat_dim,))
         if FC_CHANNELS_LAST:
             # fc weight gradient in channels-last column order, then back to the parameter's (C, P) order
             gcl = self.ws.get("fc.gcl", (self.emb * flat_dim,))
@@ -211,14 +210,16 @@ class ConvEncoderEngine:
                                                flat_dim, B, B, st))
             check(lib.ssac_permute_cp(gcl.data_ptr(), self._seg(k_fcw, self.grads).data_ptr(), self.emb, co,
                                       Ho * Wo, 0, st))
-            check(lib.ssac_linear_dgrad(dz.data_ptr(), self.emb, sv["wfc"].data_ptr(), flat_dim,
-                                        dcolf.data_ptr(), flat_dim, B, flat_dim, self.emb, st))
-            check(lib.ssac_relu_mask_to(dcolf.data_ptr(), ylast.data_ptr(), B * flat_dim, dy.data_ptr(), st))
+            # (the last map's ReLU derivative rides in the GEMM's epilogue: dy is written once, masked)
+            check(lib.ssac_linear_dgrad_masked(dz.data_ptr(), self.emb, sv["wfc"].data_ptr(), flat_dim,
+                                               ylast.data_ptr(), flat_dim, dy.data_ptr(), flat_dim, B, flat_dim,
+                                               self.emb, st))
         else:
             # fc: weight gradient (K = B rows, one slice writes straight into the gradient arena)
             check(lib.ssac_linear_wgrad_splitk(dz.data_ptr(), self.emb, sv["colf"].data_ptr(), flat_dim,
                                                self._seg(k_fcw, self.grads).data_ptr(),
                                                self._seg(k_fcb, self.grads).data_ptr(), self.emb, flat_dim, B, B, st))
+            dcolf = self.ws.get("b.dcolf", (B * flat_dim,))
             check(lib.ssac_linear_dgrad(dz.data_ptr(), self.emb, self.module.fc.weight.data_ptr(), flat_dim,
                                         dcolf.data_ptr(), flat_dim, B, flat_dim, self.emb, st))
             cl = (Ho * Wo * co, 1, Wo * co, co)

@@ -964,6 +964,16 @@ extern "C" int ssac_linear_dgrad(const float *dY, int64_t ldy, const float *W, i
     return launch<true, false, EPI_STORE>(g, 1, (hipStream_t)stream);
 }
 
+extern "C" int ssac_linear_dgrad_masked(const float *dY, int64_t ldy, const float *W, int64_t ldw, const float *mask,
+                                        int64_t ldmask, float *dX, int64_t ldx, int M, int N_in, int K_out, void *stream) {
+    if (!mask) return ssac_fail("ssac_linear_dgrad_masked: null mask");
+    GemmArgs g{};
+    g.A = dY; g.lda = ldy; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = ldx;
+    g.M = M; g.N = N_in; g.K = K_out;
+    g.mask = mask; g.ldmask = ldmask;
+    return launch<true, false, EPI_MASK>(g, 1, (hipStream_t)stream);
+}
+
 // dW partials: for slice z, partial_w[z] (M_out x N_in) = dY[rows of z]^T X[rows of z],
 // partial_b[z] (M_out) = colsum(dY[rows of z]); rows_per_slice rows each (the last one shorter).
 extern "C" int ssac_linear_wgrad_splitk(const float *dY, int64_t ldy, const float *X, int64_t ldx,

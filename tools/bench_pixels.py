@@ -56,7 +56,7 @@ if __name__ == "__main__":
     import super_sac_amd.conv_encoder as _ce
     for env, knob in (("PIX_MIN_ROWS", "IMPLICIT_MIN_ROWS"), ("PIX_FIRST_WG", "FIRST_WG_PER_CU"),
                       ("PIX_IMPL_WG", "IMPLICIT_WG_PER_CU"), ("PIX_FIRST_RPS", "FIRST_ROWS_PER_SLICE"),
-                      ("PIX_IMPL_RPS", "IMPLICIT_ROWS_PER_SLICE")):   # knob sweeps
+                      ("PIX_IMPL_RPS", "IMPLICIT_ROWS_PER_SLICE"), ("PIX_FC_SLICES", "FC_SLICES")):   # knob sweeps
         if os.environ.get(env):
             setattr(_ce, knob, int(os.environ[env]))
     which = sys.argv[1] if len(sys.argv) > 1 else "dmc"

@@ -58,8 +58,10 @@ def _close(got, ref, atol, rtol=1e-5, what=""):
 
 # --------------------------------------------------------------------- ensemble MLP forward
 @pytest.mark.parametrize("B,in_dim,H,out,N", [(512, 23, 256, 1, 10), (100, 17, 64, 12, 1),
-                                              (77, 393, 96, 1, 3), (1024, 128, 256, 4, 2), (1, 5, 32, 3, 2)])
+                                              (77, 393, 96, 1, 3), (1024, 128, 256, 4, 2), (1, 5, 32, 3, 2),
+                                              (130, 56, 1024, 6, 2), (33, 20, 512, 8, 3), (515, 56, 1024, 1, 2)])
 def test_mlp_forward_matches_oracle(ssa, B, in_dim, H, out, N):
+    # (heads of <= 8 outputs over >= 256 inputs take mlp_head_rows_kernel: a wave per row; wider / shallower ones the GEMM)
     rng = np.random.RandomState(B + in_dim)
     mlps = [orc.make_mlp(rng, in_dim, H, out) for _ in range(N)]
     x = torch.from_numpy(rng.standard_normal((B, in_dim)).astype(np.float32))
@@ -744,6 +746,24 @@ def test_layernorm_tanh_forward(ssa, rows, D):
     _close(xhat, (x[:, :D] - mu) / torch.sqrt(var + 1e-5), 1e-5, rtol=1e-5, what="xhat")
     _close(rstd, (1.0 / torch.sqrt(var + 1e-5)).squeeze(1), 1e-5, rtol=1e-5, what="rstd")
     assert torch.isnan(out[:, D:]).all(), "wrote past the row"
+
+
+@pytest.mark.parametrize("M,N_in,K_out", [(37, 200, 50), (512, 3136, 128), (5, 64, 7)])
+def test_linear_dgrad_with_relu_mask_epilogue(ssa, M, N_in, K_out):
+    """ssac_linear_dgrad_masked: dX = [mask > 0] * (dY W) == ssac_linear_dgrad followed by the mask, bit for bit, and
+    within fp32 tolerance of torch."""
+    rng = np.random.RandomState(M + N_in)
+    dy = torch.from_numpy(rng.standard_normal((M, K_out)).astype(np.float32)).to(DEV)
+    w = torch.from_numpy((rng.standard_normal((K_out, N_in)) * 0.1).astype(np.float32)).to(DEV)
+    mask = torch.from_numpy(rng.standard_normal((M, N_in)).astype(np.float32)).to(DEV).clamp_min(0.0)
+    lib, st, check = ssa._lib.lib, ssa.engine.stream(), ssa._lib.check
+    plain = torch.full((M, N_in), float("nan"), device=DEV)
+    fused = torch.full((M, N_in), float("nan"), device=DEV)
+    check(lib.ssac_linear_dgrad(dy.data_ptr(), K_out, w.data_ptr(), N_in, plain.data_ptr(), N_in, M, N_in, K_out, st))
+    check(lib.ssac_linear_dgrad_masked(dy.data_ptr(), K_out, w.data_ptr(), N_in, mask.data_ptr(), N_in, fused.data_ptr(),
+                                       N_in, M, N_in, K_out, st))
+    assert torch.equal(fused, torch.where(mask > 0, plain, torch.zeros_like(plain)))
+    _close(fused, (dy.cpu() @ w.cpu()) * (mask.cpu() > 0), 2e-5, rtol=1e-5, what="masked backward-data")
 
 
 def test_im2col_col2im_are_adjoint(ssa):

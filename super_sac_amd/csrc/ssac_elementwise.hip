@@ -971,8 +971,43 @@ __global__ __launch_bounds__(256) void drqv2_shift_plane_kernel(const T *__restr
         (ax ? p0y : p0x)[i] = (int)fl;
     }
     __syncthreads();
-    // a thread owns one output column (its two source columns, weights and validity stay in registers) and walks
-    // down the rows, 256 / h rows of the plane per pass: no per-element index division, row terms are LDS broadcasts
+    // a thread owns output columns (their source columns, weights and validity stay in registers) and walks down the
+    // rows: no per-element index division, row terms are LDS broadcasts.  With h % 4 == 0 it owns FOUR adjacent
+    // columns and stores 16 bytes per row (256 / (h/4) rows of the plane per pass), else one column.
+    if ((h & 3) == 0 && ((uintptr_t)out & 15) == 0) {
+        const int tpr = h >> 2, rpp = 256 / tpr, ty = tid / tpr, tx4 = tid - ty * tpr;
+        if (ty >= rpp) return;
+        float wx0[4], wx1[4];
+        int sx0[4], sx1[4];
+        bool vx0[4], vx1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = 4 * tx4 + j, x0 = p0x[x];
+            wx0[j] = w0x[x]; wx1[j] = w1x[x];
+            vx0[j] = x0 >= 0 && x0 < hp; vx1[j] = x0 + 1 >= 0 && x0 + 1 < hp;
+            sx0[j] = min(max(x0 - pad, 0), h - 1); sx1[j] = min(max(x0 + 1 - pad, 0), h - 1);   // replicate pad
+        }
+        for (int y = ty; y < h; y += rpp) {
+            const int y0 = p0y[y];
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int yy = y0 + dy;
+                const float wy = dy ? w1y[y] : w0y[y];
+                const bool vy = yy >= 0 && yy < hp;
+                const float *row = pl + min(max(yy - pad, 0), h - 1) * h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j] = __fadd_rn(acc[j], __fmul_rn(row[sx0[j]], (vy && vx0[j]) ? __fmul_rn(wy, wx0[j]) : 0.0f));
+                    acc[j] = __fadd_rn(acc[j], __fmul_rn(row[sx1[j]], (vy && vx1[j]) ? __fmul_rn(wy, wx1[j]) : 0.0f));
+                }
+            }
+            *reinterpret_cast<float4 *>(out + y * h + 4 * tx4) =
+                make_float4(fminf(fmaxf(acc[0], 0.0f), 255.0f), fminf(fmaxf(acc[1], 0.0f), 255.0f),
+                            fminf(fmaxf(acc[2], 0.0f), 255.0f), fminf(fmaxf(acc[3], 0.0f), 255.0f));
+        }
+        return;
+    }
     const int rpp = 256 / h, ty = tid / h, tx = tid - ty * h;
     if (ty >= rpp) return;
     const int x0 = p0x[tx];

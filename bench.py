@@ -340,54 +340,60 @@ def main():
                "roofline": roofline}
     secondary = {}
     if not args.no_secondary and world == 1:
-        # ---- full REDQ environment step (SURVEY 8(d) secondary unit): 20 critic updates + 10 Polyak + actor + alpha
-        for _ in range(3):
-            env_step()
-        ts = timed_repeats(env_step, 30, 3, None, device)
-        te = statistics.median(ts) / 30
-        secondary["full_redq_step_fp32"] = {
-            "workload": "redq.gin environment step at the headline shape: 20 critic updates + 10 Polyak + 1 actor + "
-                        "1 temperature update (B 512, N 10)",
-            "ms_per_env_step": round(te * 1e3, 4), "critic_updates_per_s": round(20 / te, 1),
-            "env_steps_per_s": round(1 / te, 1)}
-        # ---- BASELINE config 2: REDQ N=10 UTD=20 batch 256 in the bf16-operand mode; the ensemble-Q kernel's HBM fraction
-        del step, env_step
-        step_b, env_b, _ = build_engine(device, NCRIT, None, batch=256, precision="bf16")
-        for _ in range(60):
-            step_b()
-        tb = statistics.median(timed_repeats(step_b, 1000, 3, None, device)) / 1000
-        for _ in range(3):
-            env_b()
-        teb = statistics.median(timed_repeats(env_b, 30, 3, None, device)) / 30
-        secondary["config2_bf16"] = dict(bf16_rows(ssa, device), **{
-            "workload": "REDQ N=10 UTD=20 batch 256, bf16 operands / fp32 accumulate + fp32 masters (no reference "
-                        "counterpart; parity: tests/test_hip_bf16.py)",
-            "critic_updates_per_s": round(1 / tb, 1), "us_per_critic_update": round(tb * 1e6, 2),
-            "ms_per_env_step": round(teb * 1e3, 4), "env_steps_per_s": round(1 / teb, 1)})
-        # ---- BASELINE configs 3 and 4: the pixel configurations (one critic update incl. the encoder's backward pass)
-        del step_b, env_b
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
-        import bench_pixels
-        for which, label in (("dmc", "config3_dmc_pixels"), ("atari", "config4_atari_pixels")):
-            pstep, pB = bench_pixels.build(which, device)
-            for _ in range(8):   # (also past the clock ramp of a box that has just started)
-                pstep()
-            tp = statistics.median(timed_repeats(pstep, 20, 3, None, device)) / 20
-            secondary[label] = {
-                "workload": ("DrQv2 on 9x84x84 uint8 observations: shift augmentation, BigPixelEncoder, 2 critics of "
-                             "hidden 1024, B 512" if which == "dmc" else
-                             "SAC-Discrete on 4x84x84 uint8 observations: shift augmentation, SmallPixelEncoder, 2 "
-                             "critics of hidden 256, B 1024, gradient clip 40") +
-                            "; one critic update (encoder forward x2, backward, Adam, Polyak)",
-                "ms_per_critic_update": round(tp * 1e3, 3), "critic_updates_per_s": round(1 / tp, 1),
-                "frames_per_s": round(pB / tp, 0)}
-            del pstep
-            torch.cuda.empty_cache()
+        try:   # (a failing secondary row must not cost the headline line)
+            # ---- full REDQ environment step (SURVEY 8(d) secondary unit): 20 critic updates + 10 Polyak + actor + alpha
+            for _ in range(3):
+                env_step()
+            ts = timed_repeats(env_step, 30, 3, None, device)
+            te = statistics.median(ts) / 30
+            secondary["full_redq_step_fp32"] = {
+                "workload": "redq.gin environment step at the headline shape: 20 critic updates + 10 Polyak + 1 actor + "
+                            "1 temperature update (B 512, N 10)",
+                "ms_per_env_step": round(te * 1e3, 4), "critic_updates_per_s": round(20 / te, 1),
+                "env_steps_per_s": round(1 / te, 1)}
+            # ---- BASELINE config 2: REDQ N=10 UTD=20 batch 256 in the bf16-operand mode; the ensemble-Q kernel's HBM fraction
+            del step, env_step
+            step_b, env_b, _ = build_engine(device, NCRIT, None, batch=256, precision="bf16")
+            for _ in range(60):
+                step_b()
+            tb = statistics.median(timed_repeats(step_b, 1000, 3, None, device)) / 1000
+            for _ in range(3):
+                env_b()
+            teb = statistics.median(timed_repeats(env_b, 30, 3, None, device)) / 30
+            secondary["config2_bf16"] = dict(bf16_rows(ssa, device), **{
+                "workload": "REDQ N=10 UTD=20 batch 256, bf16 operands / fp32 accumulate + fp32 masters (no reference "
+                            "counterpart; parity: tests/test_hip_bf16.py)",
+                "critic_updates_per_s": round(1 / tb, 1), "us_per_critic_update": round(tb * 1e6, 2),
+                "ms_per_env_step": round(teb * 1e3, 4), "env_steps_per_s": round(1 / teb, 1)})
+            # ---- BASELINE configs 3 and 4: the pixel configurations (one critic update incl. the encoder's backward pass)
+            del step_b, env_b
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+            import bench_pixels
+            for which, label in (("dmc", "config3_dmc_pixels"), ("atari", "config4_atari_pixels")):
+                pstep, pB = bench_pixels.build(which, device)
+                for _ in range(8):   # (also past the clock ramp of a box that has just started)
+                    pstep()
+                tp = statistics.median(timed_repeats(pstep, 20, 3, None, device)) / 20
+                secondary[label] = {
+                    "workload": ("DrQv2 on 9x84x84 uint8 observations: shift augmentation, BigPixelEncoder, 2 critics of "
+                                 "hidden 1024, B 512" if which == "dmc" else
+                                 "SAC-Discrete on 4x84x84 uint8 observations: shift augmentation, SmallPixelEncoder, 2 "
+                                 "critics of hidden 256, B 1024, gradient clip 40") +
+                                "; one critic update (encoder forward x2, backward, Adam, Polyak)",
+                    "ms_per_critic_update": round(tp * 1e3, 3), "critic_updates_per_s": round(1 / tp, 1),
+                    "frames_per_s": round(pB / tp, 0)}
+                del pstep
+                torch.cuda.empty_cache()
+        except Exception as e:   # noqa: BLE001
+            secondary["error"] = f"{type(e).__name__}: {e}"
     if rank == 0:
         if secondary:
             out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:   # noqa: BLE001  (the GPU numbers above are still worth a line)
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

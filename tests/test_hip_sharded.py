@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _rank_main(rank, world, port, out_dir):
+def _rank_main(rank, world, port, out_dir, one_shot=False):
     sys.path.insert(0, HERE)
     import case_runner
     import synth
@@ -24,19 +24,26 @@ def _rank_main(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
+    if one_shot:
+        assert parallel.enable_one_shot(torch.device("cuda:0")) is not None
     cfg = synth.CASES["redq_small"]
     shard = parallel.Shard(rank, world, cfg["N"])
     rec = case_runner.run_engine("redq_small", device="cuda:0", shard=shard)
     fx = case_runner.slice_fixture(case_runner.load_fixture("redq_small"), cfg, shard)
     worst = case_runner.compare(rec, fx, who=f"hip-sharded[rank {rank}]")
+    assert not parallel.exchange_failed()
     np.savez(os.path.join(out_dir, f"ok{rank}.npz"), **{k: np.float64(v) for k, v in worst.items()})
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_sequence_matches_reference(tmp_path):
-    port = 29700 + (os.getpid() % 2000)
-    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    for rank in range(2):
+@pytest.mark.parametrize("world,one_shot", [(2, False), (4, False), (4, True)],
+                         ids=["2-ranks-collective", "4-ranks-collective", "4-ranks-one-shot"])
+def test_sharded_sequence_matches_reference(tmp_path, world, one_shot):
+    """2 and 4 ranks on the one device (4: one critic per rank, two ranks per update own no member of the drawn
+    subset), through the gloo collective and through the one-shot exchange kernel"""
+    port = 29700 + (os.getpid() % 2000) + 7 * world + int(one_shot)
+    mp.spawn(_rank_main, args=(world, port, str(tmp_path), one_shot), nprocs=world, join=True)
+    for rank in range(world):
         assert (tmp_path / f"ok{rank}.npz").exists()
 
 

@@ -9,6 +9,11 @@ mkdir -p "$OBJ"
 # -ffp-contract=off: keep fp32 op boundaries as the reference's separate torch ops have them
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Iinclude -I$SRC $*"
 newest_hdr=$(ls -t include/*.h $SRC/*.h build.sh | head -1)
+# a change of flags (extra arguments included) rebuilds everything: the flag string is kept beside the objects
+if [ ! -f "$OBJ/.flags" ] || [ "$(cat "$OBJ/.flags")" != "$FLAGS" ]; then
+    rm -f "$OBJ"/*.o
+    printf '%s' "$FLAGS" > "$OBJ/.flags"
+fi
 pids=()
 objs=()
 for f in $SRC/*.hip; do

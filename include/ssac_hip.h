@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SSAC_ABI_VERSION 1
+#define SSAC_ABI_VERSION 3
 #define SSAC_MAX_NETS 64
 
 typedef struct ssac_mlp {
@@ -189,7 +189,8 @@ int ssac_xchg_handle_bytes(void);
 int ssac_xchg_handle(ssac_xchg *x, void *handle_out);
 int ssac_xchg_connect(ssac_xchg *x, const void *handles /* world x ssac_xchg_handle_bytes(), rank-major */);
 int ssac_xchg_reduce(ssac_xchg *x, float *data, int n, int op, void *stream);
-int ssac_xchg_error(ssac_xchg *x);   /* 1: a peer's flag did not arrive within the spin bound (synchronises) */
+int ssac_xchg_error(ssac_xchg *x);   /* 1: a peer's flag did not arrive within the spin bound since the last call (the result
+                                        was poisoned with NaN); a pinned host word, cleared by the read, no synchronisation */
 void ssac_xchg_destroy(ssac_xchg *x);
 
 /* floats per net and the six segment offsets {W1,b1,W2,b2,W3,b3}. */

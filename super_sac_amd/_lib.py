@@ -226,6 +226,11 @@ _RESTYPES = {"ssac_xchg_create": C.c_void_p, "ssac_xchg_destroy": None, "ssac_st
              "ssac_launch_list_free": None}
 
 
+# SSAC_ABI_VERSION of include/ssac_hip.h this binding table was written against (bumped with every signature change:
+# a stale .so called with shifted pointer arguments would corrupt device memory)
+ABI_VERSION = 3
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -236,8 +241,9 @@ def _load():
         fn = getattr(lib, name)  # AttributeError here == ABI mismatch, fail loudly
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
-    if lib.ssac_abi_version() != 1:
-        raise ImportError("libssac_hip.so ABI version mismatch; rebuild the extension")
+    if lib.ssac_abi_version() != ABI_VERSION:
+        raise ImportError(f"libssac_hip.so has ABI version {lib.ssac_abi_version()}, this package binds version "
+                          f"{ABI_VERSION}: rebuild the extension (build.sh)")
     if os.environ.get("SSAC_FEED_DEVICE") == "0":
         lib.ssac_feed_ring_mode(0)
     if os.environ.get("SSAC_XCD_ORDER"):

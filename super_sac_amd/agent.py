@@ -236,13 +236,19 @@ class Agent:
         self.encoder.load_state_dict(_load("encoder.pt"))
         for i, p in enumerate(self.popart):
             if p:
-                p.load_state_dict(_load(f"popart{i}.pt"))
+                sd = _load(f"popart{i}.pt")
+                if "state" in sd:
+                    # checkpoint of an earlier revision of this package: the statistics were a persistent buffer
+                    p.load_stats_dict({"state": sd["state"]})
+                else:
+                    p.load_state_dict(sd)
                 if os.path.exists(os.path.join(path, f"popart{i}_stats.pt")):  # (absent in reference checkpoints)
                     p.load_stats_dict(_load(f"popart{i}_stats.pt"))
         for i, c in enumerate(self.critics):
             c.load_state_dict(_load(f"critic{i}.pt"))
         for i, a in enumerate(self.actors):
             a.load_state_dict(_load(f"actor{i}.pt"))
-        self.inverse_model.load_state_dict(_load("inverse.pt"))
-        self.contrastive_model.load_state_dict(_load("contrastive.pt"))
+        for name, model in (("inverse.pt", self.inverse_model), ("contrastive.pt", self.contrastive_model)):
+            if os.path.exists(os.path.join(path, name)):  # (absent in checkpoints of earlier revisions of this package)
+                model.load_state_dict(_load(name))
         engine.sync_shadows(self)  # (bf16 mode: the shadows follow the freshly loaded masters)

@@ -1651,8 +1651,8 @@ extern "C" int ssac_step_run(ssac_step *s, const int64_t *idx_host, const int32_
 
 // ---- late-bound Polyak (include/ssac_hip.h).  Ring tail: int64 begun | int64 decided | uint32 last_served | pad |
 //      (byte 32) n_slots x {tag, tau bits}.  The request is a posted store into the (BAR-mapped or pinned) ring; the
-//      read of `begun` that follows cannot pass it (PCIe ordering: a read does not overtake the requester's earlier
-//      posted writes), and the device publishes `begun` BEFORE it looks for the request, so "begun <= k at that read"
+//      read of `begun` that follows cannot pass it (a full fence on the host side, then PCIe ordering: a read does not
+//      overtake the requester's earlier posted writes), and the device publishes `begun` BEFORE it looks for the request, so "begun <= k at that read"
 //      proves the request will be seen.
 extern "C" int ssac_step_polyak(ssac_step *s, float tau) {
     if (!s || s->k <= 0) return 0;
@@ -1665,7 +1665,10 @@ extern "C" int ssac_step_polyak(ssac_step *s, float tau) {
     req[1] = bits;
     __builtin_ia32_sfence();
     req[0] = tag;   // (tag last: a launch that sees the tag sees the tau)
-    __builtin_ia32_sfence();
+    // FULL fence: sfence orders stores only, and on a pinned-host ring (no large BAR) the load of `begun` below could
+    // pass the tag store (store-buffer litmus) -- the host would read a stale begun <= k while the device decider has
+    // already looked for the tag and missed it.  mfence also drains the write-combining buffers of a BAR-mapped ring.
+    __builtin_ia32_mfence();
     if (*reinterpret_cast<volatile int64_t *>(tail) <= k) return 1;
     // the device had already begun update k (it is keeping up with the host): its one decider takes a few microseconds
     const auto t0 = std::chrono::steady_clock::now();

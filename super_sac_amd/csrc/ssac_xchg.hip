@@ -36,7 +36,8 @@ struct XchgArgs {
     int rank, world, n, slot_floats, op;   // op 0 = MIN, 1 = SUM
     float *data;                // in: this rank's partial (n floats); out: the reduction over ranks
     unsigned long long *seq;    // device-resident exchange counter
-    int *error;                 // device int, set to 1 when a peer's flag did not arrive in time
+    int *error;                 // HOST-pinned int (device view), set to 1 when a peer's flag did not arrive in time
+    int *dead;                  // device int: once a spin gave up, later exchanges fail at once instead of spinning again
 };
 
 __device__ __forceinline__ float *slot_of(float *base, int src, int slot, int slot_floats) {
@@ -70,9 +71,10 @@ __global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
         const unsigned long long *flag =
             reinterpret_cast<const unsigned long long *>(slot_of(a.peer[a.rank], tid, slot, a.slot_floats) + a.slot_floats);
         const long long t0 = __builtin_amdgcn_s_memtime();
+        const long long limit = *a.dead ? 0 : X_SPIN_LIMIT;
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
             __builtin_amdgcn_s_sleep(2);
-            if (__builtin_amdgcn_s_memtime() - t0 > X_SPIN_LIMIT) { s_ok = 0; break; }
+            if (__builtin_amdgcn_s_memtime() - t0 > limit) { s_ok = 0; break; }
         }
     }
     __syncthreads();
@@ -89,8 +91,15 @@ __global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
             }
             a.data[i] = r;
         }
-    } else if (tid == 0) {
-        *a.error = 1;
+    } else {
+        // no reduction happened: poison the result (slots this rank does not own still hold +inf, which a TD target
+        // would silently absorb) and tell the host -- the error word is pinned host memory, read without a device
+        // synchronisation at the training loop's periodic slot-reuse wait (learning.py) and raised there
+        for (int i = tid; i < a.n; i += X_THREADS) a.data[i] = __builtin_nanf("");
+        if (tid == 0) {
+            *a.dead = 1;
+            __hip_atomic_store(a.error, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     __syncthreads();
     if (tid == 0) *a.seq = seq;
@@ -104,7 +113,8 @@ struct ssac_xchg {
     std::vector<float *> peers;         // mapped views, peers[rank] == local
     std::vector<bool> opened;
     unsigned long long *seq;
-    int *error;
+    int *dead;                          // device int behind seq
+    int *error_host, *error_dev;        // pinned host word and its device view
 };
 
 extern "C" ssac_xchg *ssac_xchg_create(int rank, int world, int slot_floats) {
@@ -129,7 +139,14 @@ extern "C" ssac_xchg *ssac_xchg_create(int rank, int world, int slot_floats) {
         delete x;
         return nullptr;
     }
-    x->error = reinterpret_cast<int *>(x->seq + 1);
+    x->dead = reinterpret_cast<int *>(x->seq + 1);
+    if (hipHostMalloc((void **)&x->error_host, 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&x->error_dev, x->error_host, 0) != hipSuccess) {
+        ssac_fail("ssac_xchg_create: cannot allocate the error word");
+        delete x;
+        return nullptr;
+    }
+    *x->error_host = 0;
     x->peers.assign(world, nullptr);
     x->opened.assign(world, false);
     x->peers[rank] = x->local;
@@ -173,17 +190,17 @@ extern "C" int ssac_xchg_reduce(ssac_xchg *x, float *data, int n, int op, void *
         a.peer[p] = x->peers[p];
     }
     a.rank = x->rank; a.world = x->world; a.n = n; a.slot_floats = x->slot_floats; a.op = op;
-    a.data = data; a.seq = x->seq; a.error = x->error;
+    a.data = data; a.seq = x->seq; a.error = x->error_dev; a.dead = x->dead;
     SSAC_LAUNCH(xchg_kernel, dim3(1), dim3(X_THREADS), 0, (hipStream_t)stream, a);
     return ssac_check_launch("xchg");
 }
 
-// 1 when a peer's flag failed to arrive within the spin bound since the last call (synchronises the device)
+// 1 when a peer's flag failed to arrive within the spin bound since the last call (cleared by this read).  A plain
+// host load of a pinned word: no device synchronisation, cheap enough for the training loop's periodic check; a caller
+// that wants the verdict of a particular exchange synchronises the stream first.
 extern "C" int ssac_xchg_error(ssac_xchg *x) {
     if (!x) return 1;
-    int e = 0;
-    if (hipMemcpy(&e, x->error, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return 1;
-    return e;
+    return __atomic_exchange_n(x->error_host, 0, __ATOMIC_ACQ_REL) ? 1 : 0;
 }
 
 extern "C" void ssac_xchg_destroy(ssac_xchg *x) {
@@ -192,5 +209,6 @@ extern "C" void ssac_xchg_destroy(ssac_xchg *x) {
         if (x->opened[p]) (void)hipIpcCloseMemHandle(x->peers[p]);
     (void)hipFree(x->local);
     (void)hipFree(x->seq);
+    (void)hipHostFree(x->error_host);
     delete x;
 }

@@ -228,6 +228,15 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
     return out
 
 
+def _flush_other_recordings(agent, keep=None):
+    """Deferred log finalisation keeps update k's partials in name-keyed workspace tensors of the AGENT until the next
+    update of the same recording writes the block.  Any other critic update on the agent (an eager call, a second
+    recording, a re-recording) would overwrite them first: finalise the pending block now."""
+    for g in agent.__dict__.get("_ssac_graphs", {}).values():
+        if g is not keep and g.pending is not None:
+            lu.flush_pending_logs(g)
+
+
 class _FastStep:
     """the recorded critic update behind ONE C call per update (ssac_step_run, include/ssac_hip.h): what stays in
     Python is the reference's host-RNG draws, in its order (indices -> injected noise -> REDQ subset -> logged-net
@@ -292,6 +301,8 @@ class _FastStep:
             torch.cuda.synchronize()
             check(lib.ssac_step_seek(self.handle, gs.k))
             gs.path = "fast"
+        if len(agent.__dict__["_ssac_graphs"]) > 1:
+            _flush_other_recordings(agent, keep=gs)
         buffer.total_sample_calls += 1
         idx_cpu = rng.draw_indices(len(buffer), self.B)
         if gs.eps_dev is not None and not self.in_kernel_noise:
@@ -302,6 +313,8 @@ class _FastStep:
             # sharded: the LOCAL index of a subset member this rank owns, -1 for a member that lives elsewhere
             ida[j] = v if sh is None else (v - sh.lo if sh.owns(v) else -1)
         slot_i = self.ring.advance()
+        if sh is not None and gs.k % EVENT_EVERY == 0:
+            parallel.check_exchange()
         draw = 0
         if self.in_kernel_noise:
             ns = lu.noise_stream(agent, self.dev)
@@ -393,8 +406,10 @@ def _critic_update_graphed(gs, kw):
     in_kernel_noise = (kind == "stochastic" and lu.IN_KERNEL_NOISE and rng.normal_is_stock()
                        and engine.bind_arena(actor, "self", [actor], dev).fused)
     if gs.graph is not None and gs.in_kernel_noise != in_kernel_noise:
+        lu.flush_pending_logs(gs)  # (while the old recording's device structs are alive)
         gs.graph = None  # a noise hook was installed / removed since the recording: record the update again
         gs.feed = None
+    _flush_other_recordings(agent, keep=gs if gs.graph is not None else None)
     if kind == "stochastic" and not in_kernel_noise:
         # injected noise (parity tests) goes straight into the captured update's input buffer
         rng.draw_normal_into(gs.eps_dev)
@@ -406,6 +421,8 @@ def _critic_update_graphed(gs, kw):
     # EVENT_EVERY updates (recorded after the group's last update; an event costs a barrier packet on the queue)
     if gs.k % EVENT_EVERY == 0 and gs.k >= FEED_SLOTS:
         gs.events[((gs.k - FEED_SLOTS) // EVENT_EVERY) % (FEED_SLOTS // EVENT_EVERY)].synchronize()
+    if shard is not None and gs.k % EVENT_EVERY == 0:
+        parallel.check_exchange()
     slot_i = ring.advance()
     gs.np_idx[k] = idx_cpu.numpy()
     row = gs.np_i32[k]
@@ -522,6 +539,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
     engine.require_gpu()
     if engine.CAPTURE is None:
         agent.critics[0].__dict__.pop("_ssac_last_step", None)
+        _flush_other_recordings(agent)
     E = agent.ensemble_size
     assert E <= lu.MAX_MEMBERS
     dev = log_alphas[0].device

@@ -117,8 +117,18 @@ def enable_one_shot(device, max_floats=ONE_SHOT_MAX_FLOATS):
 
 def exchange_failed():
     """True when an exchange kernel of this process gave up waiting for a peer (bounded spin, csrc/ssac_xchg.hip): the
-    reductions since then are not reductions.  Reads a device int -- call it at synchronisation points."""
+    reductions since then are not reductions (and were poisoned with NaN).  Reads and CLEARS a pinned host word; for the
+    verdict of a particular exchange synchronise the stream first."""
     return _exchange is not None and _exchange.failed()
+
+
+def check_exchange():
+    """raise when an exchange of this process gave up on a peer.  The error word is pinned host memory (no device
+    synchronisation), so the update functions call this every few updates: a run whose reductions stopped being
+    reductions (the kernel poisons them with NaN) ends here instead of training on."""
+    if _exchange is not None and _exchange.failed():
+        raise RuntimeError("one-shot exchange: a peer rank's flag did not arrive within the spin bound (is a rank of "
+                           "the job gone?); the reductions since then were poisoned with NaN")
 
 
 def one_shot_ready(t):
@@ -129,6 +139,7 @@ def one_shot_ready(t):
 
 def all_reduce_min(t):
     if one_shot_ready(t):
+        check_exchange()  # (of the exchanges issued so far: a host load)
         _exchange.reduce(t, 0)
     elif dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MIN)  # fallback: RCCL on the GPUs, gloo in the CPU tests
@@ -137,6 +148,7 @@ def all_reduce_min(t):
 
 def all_reduce_sum(t):
     if one_shot_ready(t):
+        check_exchange()
         _exchange.reduce(t, 1)
     elif dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

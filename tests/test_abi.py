@@ -29,7 +29,10 @@ def test_library_exports_every_declared_symbol():
 def test_python_binding_covers_every_symbol():
     from super_sac_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
-    assert _lib.lib.ssac_abi_version() == 1
+    import re
+    header = open(os.path.join(ROOT, "include", "ssac_hip.h")).read()
+    declared = int(re.search(r"#define\s+SSAC_ABI_VERSION\s+(\d+)", header).group(1))
+    assert _lib.lib.ssac_abi_version() == _lib.ABI_VERSION == declared
 
 
 def test_layout_matches_header_contract():

@@ -82,7 +82,7 @@ def build_engine(device, n_local, shard=None, batch=BATCH, precision="fp32"):
     state = {"k": 0}
 
     def step():
-        _, dicts = ssa.learning.critic_update(
+        state["logs"], dicts = ssa.learning.critic_update(
             buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt, encoder_optimizer=eopt,
             log_alphas=[la], batch_size=batch, gamma=GAMMA, critic_clip=None, encoder_clip=None,
             target_critic_ensemble_n=NSUB, weighted_bellman_temp=None, weight_type=None, pop=False,
@@ -105,6 +105,8 @@ def build_engine(device, n_local, shard=None, batch=BATCH, precision="fp32"):
         ssa.learning.alpha_update(buffer=buf, agent=agent, optimizers=[lopt], batch_size=batch, log_alphas=[la],
                                   augmenter=aug, aug_mix=0.0, target_entropy=-float(ACT), premade_replay_dicts=dicts,
                                   discrete=False)
+    # (tests/test_hip_bench_bridge.py drives this very closure and compares it with the oracle)
+    step.objects = dict(agent=agent, target=target, buffer=buf, critic_optimizer=copt, log_alpha=la, state=state)
     return step, env_step, ssa
 
 

@@ -33,8 +33,12 @@ from . import checkpoint  # noqa: E402,F401
 from . import conv_encoder  # noqa: E402,F401
 from . import parallel  # noqa: E402,F401
 from . import adopt  # noqa: E402,F401
-from .adopt import adopt_agent  # noqa: E402,F401
+from .adopt import adopt_agent, adopt_augmenter, adopt_buffer  # noqa: E402,F401
 from .engine import set_precision, sync_shadows  # noqa: E402,F401
+
+
+INSTALLED_AUGMENTATIONS = ("AugmentationSequence", "Drqv2Aug", "DrqAug", "DrqNoNoiseAug", "LargeDrqAug",
+                           "LargeDrqNoNoiseAug", "IdentityAug")
 
 
 def install(reference_package):
@@ -44,8 +48,23 @@ def install(reference_package):
         super_sac_amd.install(super_sac)
 
     ``super_sac.main.super_sac`` resolves ``learning.*`` / ``lu.*`` through the module objects at call
-    time (main.py:18-19), so patching the module attributes is sufficient."""
+    time (main.py:18-19), so patching the module attributes is sufficient.
+
+    The two classes the training scripts construct themselves are rebound as well: ``super_sac.replay.ReplayBuffer``
+    (resolved at call time: experiments/gym/train_gym.py:84, dmc/train_dmc_from_pixels.py:62, atari/train_atari.py:41)
+    and the DrQ-family / identity augmentations with their ``AugmentationSequence`` (main.py:138-141 builds the default
+    through the module; a script that did ``from super_sac.augmentations import ...`` BEFORE install() hands over
+    reference-built objects, which the update functions adopt in place -- adopt.adopt_augmenter / adopt_buffer)."""
     ref_learning, ref_lu = reference_package.learning, reference_package.learning_utils
+    import sys
+    ref_name = reference_package.__name__
+    ref_replay = getattr(reference_package, "replay", None) or sys.modules.get(ref_name + ".replay")
+    ref_aug = getattr(reference_package, "augmentations", None) or sys.modules.get(ref_name + ".augmentations")
+    if ref_replay is not None:
+        ref_replay.ReplayBuffer = replay.ReplayBuffer
+    if ref_aug is not None:
+        for name in INSTALLED_AUGMENTATIONS:
+            setattr(ref_aug, name, getattr(augmentations, name))
     for name in ("critic_update", "online_actor_update", "alpha_update", "offline_actor_update",
                  "markov_state_abstraction_update"):
         setattr(ref_learning, name, getattr(learning, name))

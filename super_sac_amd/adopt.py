@@ -15,9 +15,21 @@ The engine needs a handful of things the reference's classes do not carry; ``ado
 
 Nothing is copied: weights stay in the torch modules' (re-pointed) parameters, so ``agent.save / load``,
 ``copy.deepcopy(agent)`` and acting through the modules keep working.
+
+The other two objects the training scripts build with the reference's classes are adopted the same way, in place:
+
+  augmenter         a reference ``AugmentationSequence`` (augmentations.py:20-41) whose ``aug_list`` holds DrQ-family /
+                    identity augmentations (:165-293, :489-503, matched by class NAME along the MRO): every element and
+                    the sequence itself change class to this package's; batch size, pad, noise flag and the CURRENT
+                    randomisation (``shift`` / ``w1, h1``) are kept, no host draw is consumed
+  buffer            a reference ``ReplayBuffer`` (replay.py:140-190: numpy ``ReplayBufferStorage`` + float64 segment
+                    trees): the filled rows move into an HBM-resident storage, the trees' arrays become the
+                    ``PrioritySampler``'s, counters carry over, and the object becomes a ``replay.ReplayBuffer`` --
+                    later ``buffer.push(...)`` calls of the collection loop land on the device ring
 """
 import types
 
+import numpy as np
 import torch
 
 from . import engine
@@ -92,3 +104,89 @@ def probe_identity(encoder, obs_dict):
             encoder.__dict__["ssac_identity_key"] = key
             return key
     return None
+
+
+# ------------------------------------------------------------------------------------------ augmenters
+_AUG_NAMES = ("Drqv2Aug", "DrqNoNoiseAug", "LargeDrqNoNoiseAug", "LargeDrqAug", "DrqAug", "IdentityAug")
+
+
+def _own_aug_class(obj):
+    from . import augmentations as A
+    for klass in type(obj).__mro__:
+        if klass.__name__ in _AUG_NAMES:
+            return getattr(A, klass.__name__)
+    return None
+
+
+def adopt_augmenter(augmenter):
+    """idempotent; returns the augmenter (class-swapped in place when it was built by the reference's classes)"""
+    from . import augmentations as A
+    if isinstance(augmenter, A.AugmentationSequence):
+        return augmenter
+    aug_list = getattr(augmenter, "aug_list", None)
+    if aug_list is None:
+        raise TypeError(f"{type(augmenter).__name__}: expected an AugmentationSequence (augmentations.py:20-41)")
+    swaps = []
+    for aug in aug_list:
+        if isinstance(aug, (A._ShiftAug, A.IdentityAug)):
+            swaps.append(None)
+            continue
+        mine = _own_aug_class(aug)
+        if mine is None:
+            raise NotImplementedError(
+                f"augmentation {type(aug).__name__!r} has no HIP path; the update engine runs the DrQ family "
+                f"({', '.join(_AUG_NAMES)}) -- the other augmentations of super_sac/augmentations.py are out of scope")
+        swaps.append(mine)
+    for aug, mine in zip(aug_list, swaps):
+        if mine is None:
+            continue
+        aug.__dict__.pop("pad_func", None)   # (nn.ReflectionPad2d of the reference's DrqAug: the kernel pads itself)
+        aug.__class__ = mine
+        aug._shift_dev = None
+        if not hasattr(aug, "noise"):
+            aug.noise = False
+        aug._adopt_state()
+    augmenter.__class__ = A.AugmentationSequence
+    return augmenter
+
+
+# ------------------------------------------------------------------------------------------ replay buffers
+def adopt_buffer(buffer, device=None):
+    """idempotent; returns the buffer.  A reference-built (numpy) ReplayBuffer becomes a device-resident one in place."""
+    from . import replay as R
+    from . import device as default_device
+    if isinstance(buffer, R.ReplayBuffer):
+        return buffer
+    need = ("_maxsize", "_storage", "alpha", "beta", "_it_sum", "_it_min", "_max_priority")
+    missing = [n for n in need if not hasattr(buffer, n)]
+    if missing:
+        raise TypeError(
+            f"{type(buffer).__name__} is neither a super_sac_amd.replay.ReplayBuffer nor a reference ReplayBuffer "
+            f"(replay.py:140-190; missing {missing}).  Build the buffer after `super_sac_amd.install(super_sac)` -- "
+            "it rebinds super_sac.replay.ReplayBuffer -- or pass a super_sac_amd.replay.ReplayBuffer.")
+    dev = torch.device(device) if device is not None else default_device
+    old = buffer._storage
+    per = R.PrioritySampler(buffer._maxsize, buffer.alpha, buffer.beta)
+    sum_v, min_v = np.asarray(buffer._it_sum._value, np.float64), np.asarray(buffer._it_min._value, np.float64)
+    assert sum_v.shape == per.sum_tree.shape == min_v.shape, "segment trees of an unexpected capacity"
+    per.sum_tree[:], per.min_tree[:] = sum_v, min_v
+    per._max_priority = float(buffer._max_priority)
+    storage = None
+    if old is not None:
+        n = int(old._max_filled)
+        storage = R.ReplayBufferStorage(int(old.size), {k: v[0] for k, v in old.s_stack.items()}, old.action_stack[0], dev)
+        for dst, src in ([(storage.s_stack[k], old.s_stack[k]) for k in old.s_stack]
+                         + [(storage.s1_stack[k], old.s1_stack[k]) for k in old.s1_stack]
+                         + [(storage.action_stack, old.action_stack), (storage.reward_stack, old.reward_stack),
+                            (storage.done_stack, old.done_stack)]):
+            if n:
+                dst[:n].copy_(torch.from_numpy(np.ascontiguousarray(src[:n])).to(dst.dtype))
+        storage._next_idx, storage._max_filled = int(old._next_idx), n
+    calls = int(getattr(buffer, "total_sample_calls", 0))
+    for name in ("_it_sum", "_it_min", "_max_priority"):
+        buffer.__dict__.pop(name, None)
+    buffer.__class__ = R.ReplayBuffer
+    buffer._storage, buffer._per, buffer.device = storage, per, dev
+    buffer._stager = R._IndexStager(dev) if storage is not None else None
+    buffer.total_sample_calls = calls
+    return buffer

@@ -22,6 +22,11 @@ class _ShiftAug:
         self._shift_host = shift_xy.contiguous()
         self._shift_dev = None
 
+    def _adopt_state(self):
+        """an object built by the reference's class of the same name (adopt.adopt_augmenter swapped its class): take
+        over the randomisation it currently holds, without drawing"""
+        raise NotImplementedError
+
     def shift_device(self, device):
         if self._shift_dev is None or self._shift_dev.device != device:
             self._shift_dev = self._shift_host.to(device)
@@ -54,6 +59,9 @@ class Drqv2Aug(_ShiftAug):
         self.shift = rng.draw_drqv2_shift(self.batch_size, self.pad)  # (B,1,1,2): x, y
         self._upload(self.shift.reshape(self.batch_size, 2).to(torch.int64))
 
+    def _adopt_state(self):
+        self._upload(self.shift.reshape(self.batch_size, 2).to(torch.int64))
+
     def __repr__(self):
         return "DrqV2"
 
@@ -69,6 +77,9 @@ class DrqAug(_ShiftAug):
         self.w1, self.h1 = rng.draw_drq_offsets(self.batch_size, self.pad)
         self._upload(torch.stack([self.w1, self.h1], dim=1).to(torch.int64))
 
+    def _adopt_state(self):
+        self._upload(torch.stack([self.w1, self.h1], dim=1).to(torch.int64))
+
     def __repr__(self):
         return "Drqv1"
 
@@ -77,15 +88,24 @@ class DrqNoNoiseAug(DrqAug):
     def __init__(self, batch_size, pad=4, noise=False, *_a, **_k):
         super().__init__(batch_size, pad, noise)
 
+    def __repr__(self):
+        return "Drqv1NoNoise"
+
 
 class LargeDrqNoNoiseAug(DrqAug):
     def __init__(self, batch_size, pad=12, noise=False, *_a, **_k):
         super().__init__(batch_size, pad, noise)
 
+    def __repr__(self):
+        return "Drqv1LargeNoNoise"
+
 
 class LargeDrqAug(DrqAug):
     def __init__(self, batch_size, pad=12, *_a, **_k):
         super().__init__(batch_size, pad)
+
+    def __repr__(self):
+        return "Drqv1Large"
 
 
 class IdentityAug:
@@ -96,6 +116,9 @@ class IdentityAug:
         return imgs
 
     def change_randomization_params(self):
+        return
+
+    def _adopt_state(self):
         return
 
     def __repr__(self):

@@ -305,6 +305,12 @@ def gather_struct(bt):
 def sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, per=True, _defer_gather=False,
                             _invariance=False):
     assert len(buffer) >= batch_size
+    if not hasattr(buffer, "draw_uniform_indices") or not hasattr(augmenter, "single_shift"):
+        # objects built by the reference's own classes (the shipped scripts construct them before main.super_sac
+        # runs: experiments/gym/train_gym.py:84, experiments/dmc/train_dmc_from_pixels.py:62,88) are adopted in place
+        from . import adopt
+        adopt.adopt_buffer(buffer)
+        adopt.adopt_augmenter(augmenter)
     st = buffer._storage
     dev = st.device
     if per:
@@ -428,6 +434,8 @@ def ensure_adopted(agent, buffer=None):
         return
     from . import adopt
     adopt.adopt_agent(agent)
+    if buffer is not None and not hasattr(buffer, "draw_uniform_indices"):
+        adopt.adopt_buffer(buffer, next(agent.actors[0].parameters()).device)
     st = getattr(buffer, "_storage", None) if buffer is not None else None
     if st is not None and not is_identity(agent.encoder):
         adopt.probe_identity(agent.encoder, {k: v[:1].float() for k, v in st.s_stack.items()})

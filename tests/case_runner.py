@@ -270,16 +270,21 @@ def build_engine_agent(cfg, device, shard=None, foreign=False):
     return ag
 
 
-def run_engine(name, device="cuda", shard=None, foreign=False, precision="fp32"):
+def run_engine(name, device="cuda", shard=None, foreign=False, precision="fp32", foreign_io=False):
     """`shard` (super_sac_amd.parallel.Shard): run as one rank of a critic-sharded job; the record
-    then holds this rank's critics only (see slice_fixture)."""
+    then holds this rank's critics only (see slice_fixture).  foreign_io: the replay buffer and the augmenter are
+    stand-ins carrying only the REFERENCE classes' attributes (tests/foreign_agent.py), adopted by the update functions."""
     import super_sac_amd as ssa
     cfg = synth.CASES[name]
     fx = load_fixture(name)
     B, E = cfg["B"], cfg["E"]
     device = torch.device(device)
-    buf = ssa.replay.ReplayBuffer(cfg["cap"], device=device)
-    buf.load_experience(*_buffers(cfg))
+    if foreign_io:
+        import foreign_agent
+        buf = foreign_agent.ForeignReplayBuffer(cfg["cap"], *_buffers(cfg))
+    else:
+        buf = ssa.replay.ReplayBuffer(cfg["cap"], device=device)
+        buf.load_experience(*_buffers(cfg))
     agent = build_engine_agent(cfg, device, shard, foreign=foreign)
     if precision != "fp32":
         ssa.set_precision(agent, precision)  # (the deepcopy below inherits it)
@@ -301,7 +306,10 @@ def run_engine(name, device="cuda", shard=None, foreign=False, precision="fp32")
         la.requires_grad = True
         las.append(la)
         lopts.append(torch.optim.Adam([la], lr=cfg["alpha_lr"], betas=(0.5, 0.999)))
-    if px and px["aug"] == "drqv2":
+    if foreign_io:
+        aug = foreign_agent.ForeignAugmentationSequence(
+            [foreign_agent.Drqv2Aug(B) if (px and px["aug"] == "drqv2") else foreign_agent.IdentityAug(B)])
+    elif px and px["aug"] == "drqv2":
         aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.Drqv2Aug(B)])
     else:
         aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(B)])
@@ -727,7 +735,10 @@ def run_markov_engine(name, device="cuda"):
                 getattr(mod, nm).bias.copy_(p[bk])
     opt = torch.optim.Adam(chain(agent.encoder.parameters(), agent.inverse_model.parameters(),
                                  agent.contrastive_model.parameters()), lr=cfg["lr"], weight_decay=0, betas=(0.9, 0.999))
-    if px and px["aug"] == "drqv2":
+    if foreign_io:
+        aug = foreign_agent.ForeignAugmentationSequence(
+            [foreign_agent.Drqv2Aug(B) if (px and px["aug"] == "drqv2") else foreign_agent.IdentityAug(B)])
+    elif px and px["aug"] == "drqv2":
         aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.Drqv2Aug(B)])
     else:
         aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(B)])

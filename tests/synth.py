@@ -20,6 +20,13 @@ CASES = {
                    actor="stochastic", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
                    clip=None, tau=0.005, weight_type=None, temp=None, noise=None,
                    cycles=2, utd=2, target_delay=2, seed=12),
+    # BASELINE config 2's exact shape (HalfCheetah REDQ N=10, batch 256): run in fp32 against the reference and in the
+    # bf16-operand mode at the stated bf16 tolerance (tests/test_hip_bf16.py)
+    "redq_c2": dict(obs=17, act=6, hidden=256, N=10, n=2, E=1, B=256, rows=5000, cap=8192,
+                    lo=-5.0, hi=2.0, popart=False, pop=False, discrete=False,
+                    actor="stochastic", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                    clip=None, tau=0.005, weight_type=None, temp=None, noise=None,
+                    cycles=2, utd=3, target_delay=2, seed=91),
     # PopArt + pop + gradient clipping on a SAC shape (Agent defaults: ART on, lo=-10)
     "sac_popart": dict(obs=11, act=3, hidden=64, N=2, n=2, E=1, B=64, rows=1000, cap=1024,
                        lo=-10.0, hi=2.0, popart=True, pop=True, discrete=False,

@@ -1,0 +1,170 @@
+"""GPU: the BENCHMARKED mode against the oracle.
+
+The fixture tests replace the noise draws (tests/case_runner.py DrawPlayer), which switches the in-kernel Philox stream
+off; bench.py runs with stock RNG hooks, i.e. recorded launch list + ssac_step_run (_FastStep) + in-kernel Philox +
+deferred log finalisation + late-bound Polyak.  Here that exact configuration -- bench.build_engine's own closure --
+runs, its noise is regenerated on the host with a numpy restatement of Philox4x32-10 + Box-Muller (csrc/ssac_philox.h),
+and the oracle's critic_update (reference learning.py:18-141, learning_utils.py:298-354) is fed the same indices /
+subsets / eps.  Tolerances as in test_hip_cases.py: TD targets 2e-4 * max(1,|x|), scalar logs 5e-4 relative,
+parameters / Polyak targets / Adam moments 3e-5 absolute.
+"""
+import numpy as np
+import pytest
+import torch
+
+import ssac_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+N_UPDATES = 14   # 3 eager warm-up calls, the recording call, then >= 10 replays through ssac_step_run
+
+
+def _philox4x32_10(c, k):
+    c = c.astype(np.uint64).copy()
+    k0, k1 = np.uint64(k[0]), np.uint64(k[1])
+    M0, M1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[:, 0], M1 * c[:, 2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[:, 1] ^ k0) & mask
+        n2 = ((p0 >> np.uint64(32)) ^ c[:, 3] ^ k1) & mask
+        c = np.stack([n0, p1 & mask, n2, p0 & mask], 1)
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return c
+
+
+def philox_normal(seed, draw, B, A):
+    """element (b, i) of draw number `draw` of the engine's noise stream (ssac_rng in include/ssac_hip.h)"""
+    rows, cols = np.meshgrid(np.arange(B), np.arange(A), indexing="ij")
+    rows, cols = rows.ravel(), cols.ravel()
+    cnt = np.stack([rows, cols >> 2, np.full(B * A, draw & 0xFFFFFFFF), np.full(B * A, draw >> 32)], 1)
+    x = _philox4x32_10(cnt, (seed & 0xFFFFFFFF, seed >> 32))
+    pair = (cols >> 1) & 1
+    x0 = x[np.arange(B * A), 2 * pair].astype(np.float32)
+    x1 = x[np.arange(B * A), 2 * pair + 1].astype(np.float32)
+    u1 = (x0 + np.float32(1.0)) * np.float32(2.3283064365386963e-10)
+    u2 = x1 * np.float32(2.3283064365386963e-10)
+    r = np.sqrt(np.float32(-2.0) * np.log(u1))
+    th = np.float32(6.283185307179586) * u2
+    return np.where(cols & 1, r * np.sin(th), r * np.cos(th)).reshape(B, A).astype(np.float32)
+
+
+def _mlp_dict(mod, head):
+    g = lambda lin: (lin.weight.detach().cpu().clone(), lin.bias.detach().cpu().clone())
+    (w1, b1), (w2, b2), (w3, b3) = g(mod.fc1), g(mod.fc2), g(getattr(mod, head))
+    return {"w1": w1, "b1": b1, "w2": w2, "b2": b2, "w3": w3, "b3": b3}
+
+
+def _engine_run(sync_every_update):
+    """bench.build_engine's step closure, N_UPDATES times; returns everything the comparison needs"""
+    import bench
+    import super_sac_amd as ssa
+    from super_sac_amd import learning_utils as lu
+    dev = torch.device("cuda")
+    step, _, _ = bench.build_engine(dev, bench.NCRIT)
+    ob = step.objects
+    agent, target = ob["agent"], ob["target"]
+    assert ssa.rng.normal_is_stock() and ssa.learning.LAUNCH_MODE == "list" and ssa.learning.USE_GRAPHS
+    init = dict(actor=_mlp_dict(agent.actors[0], "fc3"),
+                critics=[_mlp_dict(n, "out") for n in agent.critics[0].nets],
+                target=[_mlp_dict(n, "out") for n in target.critics[0].nets])
+    ns = lu.noise_stream(agent, dev)
+    rec = dict(init=init, seed=ns[0], draws=[], idx=[], subset=[], td=[], logs=[])
+    held = []
+    for u in range(N_UPDATES):
+        rec["draws"].append(ns[1])
+        dicts = step()
+        rec["idx"].append(dicts[0]["priority_idxs"].copy())
+        rec["subset"].append(list(dicts[0]["_subset"]))
+        if sync_every_update:
+            rec["td"].append(dicts[0]["td_target"].cpu().numpy().copy())
+            rec["logs"].append({k: float(v) for k, v in ob["state"]["logs"].items()})
+        else:
+            held.append(ob["state"]["logs"])   # read after the whole burst: every block but the last was written by
+                                               # the NEXT update's first launch (deferred finalisation)
+    torch.cuda.synchronize()
+    if not sync_every_update:
+        rec["logs"] = [{k: float(v) for k, v in lg.items()} for lg in held]
+    gs = next(iter(agent.__dict__["_ssac_graphs"].values()))
+    fast = next(iter(agent.__dict__["_ssac_fast"].values()))
+    rec["mode"] = dict(path=gs.path, in_kernel_noise=gs.in_kernel_noise, deferred=gs.deferred is not None,
+                       late=fast.late_arenas is not None, fast_calls=fast.calls)
+    flat = lambda mods: np.concatenate([p.detach().cpu().numpy().ravel() for m in mods for p in m.parameters()])
+    rec["final_critic"] = flat(agent.critics[0].nets)
+    rec["final_target"] = flat(target.critics[0].nets)
+    ar = agent.critics[0].arena(dev)
+    m, v = ob["critic_optimizer"]._ssac_adam.moments_for(("critic", 0), ar.params)
+    segs = ("w1", "b1", "w2", "b2", "w3", "b3")
+    rec["final_m"] = np.concatenate([ar.view(j, s, m).cpu().numpy().ravel() for j in range(ar.n_nets) for s in segs])
+    rec["final_v"] = np.concatenate([ar.view(j, s, v).cpu().numpy().ravel() for j in range(ar.n_nets) for s in segs])
+    return rec
+
+
+def _oracle_run(rec):
+    import bench
+    torch.manual_seed(0)
+    buf = orc.ReplayOracle(bench.CAP)
+    buf.load_experience(*bench.synth_data())
+    oa = orc.AgentOracle(state_dim=bench.OBS, act_dim=bench.ACT, hidden=bench.HID, num_critics=bench.NCRIT,
+                         ensemble_size=1, log_std_low=-5.0, log_std_high=2.0, seed=0)
+    oa.actors[0] = rec["init"]["actor"]
+    oa.critics[0] = rec["init"]["critics"]
+    oa.requires_grad_(True)
+    ot = oa.clone()
+    ot.critics[0] = rec["init"]["target"]
+    copt = orc.AdamOracle(oa.critic_params(), lr=bench.LR)
+    eopt = orc.AdamOracle([], lr=1e-4)
+    la = [torch.tensor([np.log(0.1)], dtype=torch.float32, requires_grad=True)]
+    aug = orc.AugOracle("identity", bench.BATCH)
+    out = dict(td=[], logs=[])
+    for u in range(N_UPDATES):
+        eps = torch.from_numpy(philox_normal(rec["seed"], rec["draws"][u], bench.BATCH, bench.ACT))
+        logs, dicts = orc.critic_update(buf, oa, ot, copt, eopt, la, bench.BATCH, bench.GAMMA, None, None, bench.NSUB,
+                                        None, None, False, aug, idx_list=[rec["idx"][u]], eps_list=[eps],
+                                        subset_list=[rec["subset"][u]], grad_pick=0)
+        out["td"].append(dicts[0]["td_target"].detach().numpy().copy())
+        out["logs"].append({k: float(v) for k, v in logs.items()})
+        if u % bench.TARGET_DELAY == 0:
+            orc.soft_update(ot.critic_params(), oa.critic_params(), bench.TAU)
+    cat = lambda ps: np.concatenate([p.detach().numpy().ravel() for p in ps])
+    out["final_critic"], out["final_target"] = cat(oa.critic_params()), cat(ot.critic_params())
+    out["final_m"], out["final_v"] = cat(copt.m), cat(copt.v)
+    return out
+
+
+def test_benchmarked_mode_matches_the_oracle():
+    a = _engine_run(sync_every_update=True)
+    assert a["mode"] == dict(path="fast", in_kernel_noise=True, deferred=True, late=True,
+                             fast_calls=a["mode"]["fast_calls"]) and a["mode"]["fast_calls"] >= N_UPDATES - 5, a["mode"]
+    assert a["draws"] == list(range(a["draws"][0], a["draws"][0] + N_UPDATES))
+    o = _oracle_run(a)
+    worst = {}
+    for u in range(N_UPDATES):
+        td, want = a["td"][u], o["td"][u]
+        err = float(np.max(np.abs(td - want) / np.maximum(1.0, np.abs(want))))
+        worst["td"] = max(worst.get("td", 0.0), err)
+        assert err < 2e-4, f"update {u}: TD target off by {err}"
+        for k, want_v in o["logs"][u].items():
+            if k not in a["logs"][u]:
+                continue
+            got = a["logs"][u][k]
+            rel = abs(got - want_v) / max(1.0, abs(want_v))
+            worst["log"] = max(worst.get("log", 0.0), rel)
+            assert rel < 5e-4, f"update {u}: log {k}: {got} vs {want_v}"
+        assert set(o["logs"][u]) <= set(a["logs"][u]), set(o["logs"][u]) - set(a["logs"][u])
+    for key in ("final_critic", "final_target", "final_m", "final_v"):
+        err = float(np.max(np.abs(a[key] - o[key])))
+        worst[key] = err
+        assert err < 3e-5, f"{key}: {err}"
+    print("benchmarked mode vs oracle, worst deviations:", worst)
+    # the same run with the host free to run ahead (no synchronisation inside the burst: soft_update requests land
+    # before the device begins the update, log blocks are finalised by the next update's first launch): same bits
+    b = _engine_run(sync_every_update=False)
+    assert b["mode"]["path"] == "fast" and b["mode"]["late"] and b["mode"]["deferred"]
+    assert b["seed"] == a["seed"] and all(np.array_equal(x, y) for x, y in zip(a["idx"], b["idx"]))
+    assert a["subset"] == b["subset"]
+    for key in ("final_critic", "final_target", "final_m", "final_v"):
+        assert np.array_equal(a[key], b[key]), f"{key}: the free-running burst differs from the synchronised run"
+    for u in range(N_UPDATES):
+        for k, v in a["logs"][u].items():
+            assert b["logs"][u][k] == v, f"update {u}: deferred log {k}: {b['logs'][u][k]} vs {v}"

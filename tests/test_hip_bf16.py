@@ -149,7 +149,7 @@ def compare_bf16(rec, fx, cfg, who):
     return worst
 
 
-@pytest.mark.parametrize("name", ["redq_small", "pendulum_sac", "redq_M", "redq_S"])
+@pytest.mark.parametrize("name", ["redq_small", "pendulum_sac", "redq_M", "redq_c2", "redq_S"])
 def test_bf16_update_sequences_against_reference_fixtures(name):
     """critic updates (bf16 chain + bf16 weight gradients + Adam on fp32 masters), Polyak with shadow refresh, fp32
     actor / temperature updates with the actor's shadow re-synced -- against the fp32 reference's outputs."""

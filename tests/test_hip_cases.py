@@ -40,6 +40,39 @@ def test_update_functions_adopt_a_foreign_agent(name):
     case_runner.compare(rec, case_runner.load_fixture(name), who=f"hip[{name},foreign agent]")
 
 
+@pytest.mark.parametrize("name", ["redq_small", "drqv2_pixels", "atari_pixels"])
+def test_update_functions_adopt_a_foreign_buffer_and_augmenter(name):
+    """a numpy replay buffer and an augmentation sequence that carry ONLY the reference classes' attributes
+    (tests/foreign_agent.py; what experiments/gym/train_gym.py:84 and dmc/train_dmc_from_pixels.py:62,88 build before
+    main.super_sac runs) are adopted in place by the first update -- storage moved to HBM, classes swapped, the
+    randomisation kept -- and the sequence lands on the reference's outputs."""
+    import super_sac_amd as ssa
+    rec = case_runner.run_engine(name, foreign_io=True)
+    case_runner.compare(rec, case_runner.load_fixture(name), who=f"hip[{name},foreign buffer + augmenter]")
+
+
+def test_adopted_buffer_keeps_collecting_on_the_device():
+    """after adoption the collection loop's buffer.push (main.py:365) lands in the HBM ring and the PER trees carry on"""
+    import torch
+    import foreign_agent
+    import super_sac_amd as ssa
+    s, a, r, s1, d = synth.synth_transitions(300, 5, 2, seed=3)
+    buf = foreign_agent.ForeignReplayBuffer(512, s, a, r, s1, d)
+    ssa.adopt_buffer(buf, torch.device("cuda"))
+    assert type(buf) is ssa.replay.ReplayBuffer and len(buf) == 300 and buf._storage.s_stack["obs"].is_cuda
+    assert np.array_equal(buf._storage.s_stack["obs"][:300].cpu().numpy(), s["obs"].astype(np.float32))
+    assert np.array_equal(buf._storage.done_stack[:300, 0].cpu().numpy(), np.asarray(d).reshape(-1).astype(np.uint8))
+    s2, a2, r2, s12, d2 = synth.synth_transitions(300, 5, 2, seed=4)
+    buf.push(s2, a2, r2.reshape(-1, 1), s12, d2.reshape(-1, 1))   # wraps around the ring
+    torch.cuda.synchronize()
+    assert len(buf) == 512 and buf._storage._next_idx == (600 % 512)
+    assert np.array_equal(buf._storage.action_stack[300:512].cpu().numpy(), a2[:212].astype(np.float32))
+    assert np.array_equal(buf._storage.action_stack[:88].cpu().numpy(), a2[212:].astype(np.float32))
+    assert buf._per.sum_tree[1] == 512.0
+    with pytest.raises(TypeError, match="install"):
+        ssa.adopt_buffer(object())
+
+
 @pytest.mark.parametrize("seed", [0, 7, 123])
 @pytest.mark.parametrize("n", [1000, 100_000, 1_000_000])
 def test_product_index_draw_is_bit_exact_on_the_gpu_box(seed, n):
@@ -628,3 +661,52 @@ def test_packed_push_and_n_step_fold_match_the_reference_storage():
     assert np.array_equal(ns.reward_stack[:len(want), 0].cpu().numpy(), np.array([w[2] for w in want], np.float32))
     assert np.array_equal(ns.s1_stack["obs"][:len(want)].cpu().numpy(), np.stack([w[3] for w in want]))
     assert np.array_equal(ns.done_stack[:len(want), 0].cpu().numpy(), np.array([w[4] for w in want], np.uint8))
+
+
+@pytest.mark.parametrize("which", ["dmc", "atari"])
+def test_full_size_pixel_critic_update_implicit_vs_im2col(which, monkeypatch):
+    """BASELINE configs 3 and 4 END TO END at their full batch (B 512 / B 1024; the update closure bench.py times):
+    three critic updates (DrQv2 shift, both encoder passes, encoder backward, clip, Adam, Polyak) with every
+    convolution as an implicit GEMM against the same three updates through im2col + GEMM -- the path the
+    reference-generated fixtures drqv2_pixels / atari_pixels pin at B 8.  Same arithmetic in a different summation
+    order: TD targets 2e-4 * max(1,|x|), logs 5e-4; parameters: median 1e-6 and worst element 2 * lr per update (Adam
+    moves a weight by ~lr whatever the gradient's size, so a near-zero gradient whose sign differs displaces it that far)."""
+    import os
+    import random
+    import sys
+    import torch
+    import super_sac_amd as ssa
+    from super_sac_amd import conv_encoder
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import bench_pixels
+    n_upd, lr = 3, 1e-4
+
+    def run(implicit):
+        monkeypatch.setattr(conv_encoder, "USE_IMPLICIT", implicit)
+        monkeypatch.setattr(conv_encoder, "USE_IMPLICIT_FIRST", implicit)
+        torch.manual_seed(0); np.random.seed(0); random.seed(0)
+        step, B = bench_pixels.build(which, torch.device("cuda"))
+        tds, logs = [], []
+        for _ in range(n_upd):
+            step()
+            lg, dicts = step.out
+            tds.append(dicts[0]["td_target"].cpu().numpy().copy())
+            logs.append({k: float(v) for k, v in lg.items()})
+        ag, tg = step.objects["agent"], step.objects["target"]
+        flat = lambda mods: np.concatenate([p.detach().cpu().numpy().ravel() for m in mods for p in m.parameters()])
+        out = dict(td=tds, logs=logs, enc=flat([ag.encoder]), tenc=flat([tg.encoder]), crit=flat(ag.critics),
+                   tcrit=flat(tg.critics))
+        del step
+        torch.cuda.empty_cache()
+        return out
+    a, b = run(True), run(False)
+    for u in range(n_upd):
+        dv = float(np.max(np.abs(a["td"][u] - b["td"][u]) / np.maximum(1.0, np.abs(b["td"][u]))))
+        assert dv <= 2e-4, f"update {u}: TD targets differ by {dv}"
+        for k, v in b["logs"][u].items():
+            assert abs(a["logs"][u][k] - v) <= 5e-4 * max(1.0, abs(v)), (u, k, a["logs"][u][k], v)
+    for key in ("enc", "tenc", "crit", "tcrit"):
+        err = np.abs(a[key] - b[key])
+        assert float(np.median(err)) <= 1e-6 and float(err.max()) <= 2 * lr * n_upd, (key, float(np.median(err)), float(err.max()))

@@ -141,6 +141,8 @@ def test_install_rebinds_the_real_reference_modules(ref):
     saved_lu = {n: getattr(ref.learning_utils, n) for n in ("soft_update", "hard_update", "sample_move_and_augment",
                                                            "compute_td_targets", "compute_backup_weights",
                                                            "adjust_priorities", "compute_filter_stats")}
+    saved_cls = [(ref.replay, "ReplayBuffer", ref.replay.ReplayBuffer)] + \
+        [(ref.augmentations, n, getattr(ref.augmentations, n)) for n in ssa.INSTALLED_AUGMENTATIONS]
     try:
         ssa.install(ref)
         import inspect
@@ -154,3 +156,120 @@ def test_install_rebinds_the_real_reference_modules(ref):
             setattr(ref.learning, n, fn)
         for n, fn in saved_lu.items():
             setattr(ref.learning_utils, n, fn)
+        for m, n, c in saved_cls:
+            setattr(m, n, c)
+
+
+def test_install_rebinds_the_buffer_and_augmentation_classes(ref):
+    """the classes the shipped scripts construct through the module objects (experiments/gym/train_gym.py:84,
+    main.py:138-141) resolve to this package's after install()"""
+    import super_sac_amd as ssa
+    names = ssa.INSTALLED_AUGMENTATIONS
+    saved_aug = {n: getattr(ref.augmentations, n) for n in names}
+    saved_buf = ref.replay.ReplayBuffer
+    saved_fn = {(m, n): getattr(m, n) for m in (ref.learning, ref.learning_utils) for n in dir(m)
+                if callable(getattr(m, n)) and hasattr(getattr(ssa, m.__name__.rsplit(".", 1)[1]), n)}
+    try:
+        ssa.install(ref)
+        assert ref.replay.ReplayBuffer is ssa.replay.ReplayBuffer
+        import inspect
+        assert (list(inspect.signature(saved_buf.__init__).parameters)
+                == list(inspect.signature(ssa.replay.ReplayBuffer.__init__).parameters)[:4])  # (+ optional device)
+        for n in names:
+            assert getattr(ref.augmentations, n) is getattr(ssa.augmentations, n), n
+            # constructor arguments of the reference class are accepted positionally and by name
+            a, b = inspect.signature(saved_aug[n].__init__), inspect.signature(getattr(ssa.augmentations, n).__init__)
+            named = [p for p in a.parameters.values() if p.kind == p.POSITIONAL_OR_KEYWORD]
+            mine = [p for p in b.parameters.values() if p.kind == p.POSITIONAL_OR_KEYWORD]
+            assert [p.name for p in named] == [p.name for p in mine][:len(named)], n
+            assert [p.default for p in named] == [p.default for p in mine][:len(named)], n
+        # main.py:138-141 builds the default augmenter through the module attributes
+        aug = ref.augmentations.AugmentationSequence([ref.augmentations.IdentityAug(32)])
+        assert isinstance(aug, ssa.augmentations.AugmentationSequence) and aug.is_identity()
+    finally:
+        ref.replay.ReplayBuffer = saved_buf
+        for n, c in saved_aug.items():
+            setattr(ref.augmentations, n, c)
+        for (m, n), fn in saved_fn.items():
+            setattr(m, n, fn)
+
+
+@pytest.mark.parametrize("cls,kw", [("Drqv2Aug", {}), ("DrqAug", {}), ("DrqNoNoiseAug", {}), ("LargeDrqAug", {}),
+                                    ("LargeDrqNoNoiseAug", {}), ("Drqv2Aug", {"pad": 6})])
+def test_reference_built_augmenter_is_adopted_in_place(ref, cls, kw):
+    """augmentations.py:20-41, 165-293: class, batch size, pad, noise flag and the CURRENT randomisation carry over;
+    adoption draws nothing from the host generators"""
+    import super_sac_amd as ssa
+    torch.manual_seed(5)
+    theirs = getattr(ref.augmentations, cls)(16, **kw)
+    seq = ref.augmentations.AugmentationSequence([theirs, ref.augmentations.IdentityAug(16)])
+    want = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in vars(theirs).items()}
+    state = torch.get_rng_state()
+    out = ssa.adopt_augmenter(seq)
+    assert out is seq and type(seq) is ssa.augmentations.AugmentationSequence
+    assert torch.equal(torch.get_rng_state(), state), "adoption must not consume the torch CPU generator"
+    mine = seq.aug_list[0]
+    assert mine is theirs and type(mine) is getattr(ssa.augmentations, cls)
+    assert type(seq.aug_list[1]) is ssa.augmentations.IdentityAug
+    assert (mine.batch_size, mine.pad, mine.noise) == (16, want["pad"], want["noise"])
+    assert repr(mine) == repr(getattr(ref.augmentations, cls)(16, **kw)) and "pad_func" not in vars(mine)
+    if cls == "Drqv2Aug":
+        assert torch.equal(mine._shift_host, want["shift"].reshape(16, 2))   # (x, y) per image, augmentations.py:226-231
+    else:
+        assert torch.equal(mine._shift_host, torch.stack([want["w1"], want["h1"]], 1))
+    assert seq.single_shift() is mine and not seq.is_identity()
+    # the next randomisation is the same draw the reference object would have made
+    torch.manual_seed(9)
+    mine.change_randomization_params()
+    torch.manual_seed(9)
+    again = getattr(ref.augmentations, cls)(16, **kw)   # (the constructor draws once, augmentations.py:178,222)
+    if cls == "Drqv2Aug":
+        assert torch.equal(mine.shift, again.shift)
+    else:
+        assert torch.equal(mine.w1, again.w1) and torch.equal(mine.h1, again.h1)
+    assert ssa.adopt_augmenter(seq) is seq   # idempotent
+    with pytest.raises(NotImplementedError, match="no HIP path"):
+        ssa.adopt_augmenter(ref.augmentations.AugmentationSequence([ref.augmentations.GrayscaleAug(16)]))
+
+
+def test_reference_built_replay_buffer_is_adopted_in_place(ref):
+    """replay.py:10-190: rows, cursor, fill level, priorities, trees and counters carry over attribute by attribute
+    (on CPU tensors here; the same code puts them in HBM on the GPU box)"""
+    import super_sac_amd as ssa
+    rs = np.random.RandomState(0)
+    theirs = ref.replay.ReplayBuffer(size=100, alpha=0.7, beta=0.9)
+    n = 130   # wraps around the ring once
+    s = {"obs": rs.randn(n, 5).astype(np.float32), "img": rs.randint(0, 256, (n, 2, 4, 4)).astype(np.uint8)}
+    s1 = {"obs": rs.randn(n, 5).astype(np.float32), "img": rs.randint(0, 256, (n, 2, 4, 4)).astype(np.uint8)}
+    a, r, d = rs.uniform(-1, 1, (n, 3)).astype(np.float32), rs.randn(n, 1).astype(np.float32), rs.rand(n, 1) < 0.1
+    theirs.push({k: v[:70] for k, v in s.items()}, a[:70], r[:70], {k: v[:70] for k, v in s1.items()}, d[:70])
+    theirs.push({k: v[70:] for k, v in s.items()}, a[70:], r[70:], {k: v[70:] for k, v in s1.items()}, d[70:])
+    theirs.update_priorities(np.arange(10), rs.rand(10) + 0.5)
+    np.random.seed(3)
+    _, w_ref, idx_ref = theirs.sample(32)
+    calls = theirs.total_sample_calls
+    old = theirs._storage
+    want_sum, want_min = theirs._it_sum._value.copy(), theirs._it_min._value.copy()
+    out = ssa.adopt_buffer(theirs, "cpu")
+    assert out is theirs and type(theirs) is ssa.replay.ReplayBuffer
+    st = theirs._storage
+    assert (len(theirs), st._next_idx, st._max_filled, st.size) == (100, 30, 100, 100)
+    assert theirs.total_sample_calls == calls and (theirs.alpha, theirs.beta, theirs._maxsize) == (0.7, 0.9, 100)
+    for k in s:
+        assert st.s_stack[k].dtype == (torch.uint8 if k == "img" else torch.float32)
+        assert np.array_equal(st.s_stack[k].numpy(), old.s_stack[k]) and np.array_equal(st.s1_stack[k].numpy(), old.s1_stack[k])
+    assert np.array_equal(st.action_stack.numpy(), old.action_stack)
+    assert np.array_equal(st.reward_stack.numpy(), old.reward_stack) and np.array_equal(st.done_stack.numpy(), old.done_stack)
+    assert np.array_equal(theirs._per.sum_tree, want_sum) and np.array_equal(theirs._per.min_tree, want_min)
+    assert theirs._per._max_priority == pytest.approx(max(1.0, float(np.max(theirs._per._max_priority))))
+    assert not hasattr(theirs, "_it_sum")
+    # the prioritised draw of the adopted buffer is the reference's (numpy global generator, float64 trees)
+    np.random.seed(3)
+    idx, w = theirs._per.sample(len(theirs), 32)
+    assert np.array_equal(idx, idx_ref) and np.array_equal(w, w_ref.numpy())
+    assert ssa.adopt_buffer(theirs) is theirs   # idempotent
+    # an empty reference buffer (the scripts hand main.super_sac a buffer that the warm-up fills) is adopted too
+    empty = ssa.adopt_buffer(ref.replay.ReplayBuffer(size=64), "cpu")
+    assert type(empty) is ssa.replay.ReplayBuffer and len(empty) == 0 and empty._storage is None
+    with pytest.raises(TypeError, match="install"):
+        ssa.adopt_buffer(ref.replay._BasicReplayBuffer(10))

@@ -41,7 +41,7 @@ def build(which, dev):
     rproc = None if discrete else ssa.learning_utils.GaussianExplorationNoise(space, 1.0, 0.1, 500000)
 
     def step():
-        ssa.learning.critic_update(buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt,
+        step.out = ssa.learning.critic_update(buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt,
             encoder_optimizer=eopt, log_alphas=[la], batch_size=B, gamma=gamma, critic_clip=clip, encoder_clip=clip,
             target_critic_ensemble_n=2, weighted_bellman_temp=None, weight_type=None, pop=False, augmenter=aug,
             encoder_lambda=0, aug_mix=mix, discrete=discrete, random_process=rproc, noise_clip=0.3, per=False,
@@ -49,6 +49,7 @@ def build(which, dev):
         for ac, tc in zip(agent.critics, target.critics):
             ssa.learning_utils.soft_update(tc, ac, 0.01)
         ssa.learning_utils.soft_update(target.encoder, agent.encoder, 0.01)
+    step.objects = dict(agent=agent, target=target)   # (tests/test_hip_cases.py compares two engine settings through this)
     return step, B
 
 

@@ -232,6 +232,9 @@ def main():
     if world > 1 or os.environ.get("SSAC_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:   # (the forced single-rank run is started from a bare shell)
+            for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29533")):
+                os.environ.setdefault(k_, v_)
         # RCCL refuses two ranks on one device: such runs set the group up over gloo (the data path is the IPC kernel)
         backend = os.environ.get("SSAC_BENCH_BACKEND", "gloo" if shared_device else "nccl")  # "nccl" is RCCL on ROCm
         if backend == "nccl":
@@ -239,6 +242,7 @@ def main():
         else:
             dist.init_process_group(backend)
         from super_sac_amd import parallel
+        parallel.FORCE_COLLECTIVE = world == 1
         shard = parallel.Shard(rank, world, NCRIT)
         n_local = shard.n_local
         exchange = f"torch.distributed all_reduce ({backend})"

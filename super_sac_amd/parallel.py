@@ -103,6 +103,9 @@ class Exchange:
 
 
 _exchange = None
+# issue the collective even in a process group of ONE rank (bench.py's SSAC_BENCH_FORCE_DIST=1: the RCCL check a
+# one-GPU box can run -- communicator set-up and ncclMin / ncclSum all-reduce through the fallback path)
+FORCE_COLLECTIVE = False
 ONE_SHOT_MAX_FLOATS = 1 << 15  # largest payload the receive slots hold (the actor step's (B x A) action gradient)
 
 
@@ -141,7 +144,7 @@ def all_reduce_min(t):
     if one_shot_ready(t):
         check_exchange()  # (of the exchanges issued so far: a host load)
         _exchange.reduce(t, 0)
-    elif dist.is_initialized() and dist.get_world_size() > 1:
+    elif dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVE):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)  # fallback: RCCL on the GPUs, gloo in the CPU tests
     return t
 
@@ -150,6 +153,6 @@ def all_reduce_sum(t):
     if one_shot_ready(t):
         check_exchange()
         _exchange.reduce(t, 1)
-    elif dist.is_initialized() and dist.get_world_size() > 1:
+    elif dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVE):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t

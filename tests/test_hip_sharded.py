@@ -141,3 +141,50 @@ def test_humanoid_n16_sharded_two_ranks_one_shot_exchange(tmp_path):
     port = 30900 + (os.getpid() % 2000)
     mp.spawn(_humanoid_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert all((tmp_path / f"hok{r}").exists() for r in range(2))
+
+
+def _rccl_main(rank, world, port, out_dir):
+    """ONE rank on the one GPU, backend "nccl" (= RCCL on ROCm): communicator set-up, ncclMin / ncclSum all-reduce of
+    device tensors, and the sharded update sequence with its exchange steps going through that collective (the
+    fallback path of parallel.all_reduce_*; FORCE_COLLECTIVE issues it although a group of one has nothing to add)."""
+    sys.path.insert(0, HERE)
+    import case_runner
+    import synth
+    import torch.distributed as dist
+    from super_sac_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    assert dist.get_backend() == "nccl"
+    parallel.FORCE_COLLECTIVE = True
+    calls = {"n": 0}
+    real = dist.all_reduce
+
+    def counted(t, op=dist.ReduceOp.SUM, **kw):
+        assert t.is_cuda
+        calls["n"] += 1
+        return real(t, op=op, **kw)
+    dist.all_reduce = counted
+    t = torch.tensor([1.0, float("inf"), -3.0], device="cuda:0")
+    parallel.all_reduce_min(t)
+    u = torch.arange(6, dtype=torch.float32, device="cuda:0")
+    parallel.all_reduce_sum(u)
+    torch.cuda.synchronize()
+    assert calls["n"] == 2 and t.tolist() == [1.0, float("inf"), -3.0] and u.tolist() == [0, 1, 2, 3, 4, 5]
+    cfg = synth.CASES["redq_small"]
+    shard = parallel.Shard(0, 1, cfg["N"])
+    rec = case_runner.run_engine("redq_small", device="cuda:0", shard=shard)
+    fx = case_runner.slice_fixture(case_runner.load_fixture("redq_small"), cfg, shard)
+    case_runner.compare(rec, fx, who="hip-sharded[1 rank, RCCL collective]")
+    # 6 critic updates (one MIN each) + 2 actor updates (one MIN + one SUM each)
+    assert calls["n"] >= 2 + 6 + 4, calls
+    open(os.path.join(out_dir, "rccl_ok"), "w").write(str(calls["n"]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rccl_collective_path_single_rank(tmp_path):
+    port = 31900 + (os.getpid() % 2000)
+    mp.spawn(_rccl_main, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "rccl_ok").exists()

@@ -706,7 +706,10 @@ def test_full_size_pixel_critic_update_implicit_vs_im2col(which, monkeypatch):
         dv = float(np.max(np.abs(a["td"][u] - b["td"][u]) / np.maximum(1.0, np.abs(b["td"][u]))))
         assert dv <= 2e-4, f"update {u}: TD targets differ by {dv}"
         for k, v in b["logs"][u].items():
-            assert abs(a["logs"][u][k] - v) <= 5e-4 * max(1.0, abs(v)), (u, k, a["logs"][u][k], v)
+            # (from the second update on the two runs' parameters differ at the lr scale, see above: gradient norms then
+            # agree to a few 1e-3 of their size)
+            tol = 5e-4 if u == 0 else 5e-3
+            assert abs(a["logs"][u][k] - v) <= tol * max(1.0, abs(v)), (u, k, a["logs"][u][k], v)
     for key in ("enc", "tenc", "crit", "tcrit"):
         err = np.abs(a[key] - b[key])
         assert float(np.median(err)) <= 1e-6 and float(err.max()) <= 2 * lr * n_upd, (key, float(np.median(err)), float(err.max()))

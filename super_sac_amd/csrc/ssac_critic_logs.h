@@ -171,6 +171,60 @@ __device__ __forceinline__ void loss_fold_table(const LossFoldArgs &a, int e, fl
     }
 }
 
+// The same table in two steps for the GEMM tiles (no statistics, no TD store): the first pass's operands (row b =
+// threadIdx.x) are REQUESTED before the tile's first operand chunk and the table is finished while that chunk is in
+// flight -- vector-memory returns are in order, so loads issued behind the operand chunk would wait for it.
+// Same arithmetic, operation by operation, as loss_fold_table.
+struct LossFoldRegs { float q, t0, t1, lp, rew, done, w, la; };
+
+__device__ __forceinline__ void loss_fold_issue(const LossFoldArgs &a, int e, LossFoldRegs &r) {
+    const int b = threadIdx.x, n_rows = a.n_rows;
+    r = LossFoldRegs{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
+    if (a.tds.q_t && a.tds.use_entropy) r.la = a.tds.log_alpha[0];
+    if (b < n_rows) {
+        r.q = a.q[(int64_t)e * n_rows + b];
+        if (a.weight) r.w = a.weight[b];
+        if (a.tds.q_t) {
+            r.t0 = a.tds.q_t[b];
+            if (a.tds.n_sel > 1) r.t1 = a.tds.q_t[(int64_t)n_rows + b];
+            if (a.tds.use_entropy) r.lp = a.tds.logp[b];
+            r.rew = a.tds.rew[b];
+            r.done = a.tds.done[b];
+        } else {
+            r.t0 = a.td[b];
+        }
+    }
+}
+
+// the caller synchronises (LDS hand-off) before reading tab
+__device__ __forceinline__ void loss_fold_finish(const LossFoldArgs &a, int e, const LossFoldRegs &r, float *tab) {
+    const int tid = threadIdx.x, n_rows = a.n_rows;
+    const float pw = (a.popart && a.pop) ? a.popart->w : 1.0f;
+    const float pb = (a.popart && a.pop) ? a.popart->b : 0.0f;
+    const float gscale = -2.0f * pw / (a.denom * (float)n_rows);
+    const float alpha = (a.tds.q_t && a.tds.use_entropy) ? expf(r.la) : 0.0f;
+    if (tid < n_rows) {
+        float t = r.t0;
+        if (a.tds.q_t) {
+            float mq = r.t0;
+            if (a.tds.n_sel > 1) mq = fminf(mq, r.t1);
+            for (int j = 2; j < a.tds.n_sel; ++j) mq = fminf(mq, a.tds.q_t[(int64_t)j * n_rows + tid]);
+            const float bonus = a.tds.use_entropy ? alpha * r.lp : 0.0f;
+            const float val = mq - bonus;
+            t = r.rew + a.tds.gamma * (1.0f - r.done) * val;
+        }
+        const float err = t - (pw * r.q + pb);
+        tab[tid] = gscale * r.w * err;
+    }
+    const float *q = a.q + (int64_t)e * n_rows;
+    for (int b = tid + blockDim.x; b < n_rows; b += blockDim.x) {   // (batches beyond one pass of the workgroup)
+        const float t = a.tds.q_t ? ssac_lazy_td(a.tds, b, n_rows, alpha) : a.td[b];
+        const float w = a.weight ? a.weight[b] : 1.0f;
+        const float err = t - (pw * q[b] + pb);
+        tab[b] = gscale * w * err;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Log finalisation folded into the weight-gradient launch (ssac_logfold in include/ssac_hip.h): no logs launch.
 //   * the statistics of the TD targets (mean / unbiased std / entropy bonus) are computed by ONE workgroup -- the one

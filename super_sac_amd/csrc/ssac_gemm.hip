@@ -144,9 +144,9 @@ __device__ __forceinline__ float adam_elem(float p, float g, float &m, float &v,
 // loads: thread -> 4 consecutive rows r4 = 4*(tid&15), k = (tid>>4) + 16q.  The source pointers
 // are built once and advanced by a uniform stride; the LDS image is Xt[k*64 + r] (b128 stores).
 struct RcVecLoader {
-    const float *p0;    // row kfirst + kk of this thread's 4 columns (the second row sits 16 rows further)
-    int64_t ld16;       // 16 rows, in floats
-    const float *safe;  // always-valid 16-byte aligned address for predicated-off lanes
+    const float *base;  // workgroup-uniform operand base (an SGPR pair: the loads use saddr + 32-bit lane offsets)
+    uint32_t off;       // float offset of row kfirst + kk, columns R0 + r4 .. + 3 of this thread (second row: + ld16)
+    uint32_t ld16;      // 16 rows, in floats (uniform)
     f4 v[2];
     int kk, r4;
     int klast;          // k0 of the rows held in v (late row scale: applied when the rows are stored)
@@ -154,23 +154,25 @@ struct RcVecLoader {
     __device__ __forceinline__ void init(const float *S, int64_t ld, int R0, int R, int kfirst, int tid) {
         r4 = (tid & 15) * 4;
         kk = tid >> 4;
-        safe = S;
+        base = S;
         rok = (R0 + r4) < R;  // R % 4 == 0 on this path
-        ld16 = 16 * ld;
-        p0 = S + (rok ? (int64_t)(kfirst + kk) * ld + R0 + r4 : 0);
+        ld16 = (uint32_t)(16 * ld);
+        off = rok ? (uint32_t)((kfirst + kk) * ld + R0 + r4) : 0u;
         klast = 0;
     }
-    __device__ __forceinline__ void load(int k0, int K, int64_t adv, const float *scale = nullptr) {
+    // predicated-off lanes read the (always valid, 16-byte aligned) first element of the operand
+    __device__ __forceinline__ void load(int k0, int K, uint32_t adv, const float *scale = nullptr) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int k = k0 + kk + 16 * q;
             const bool ok = rok && k < K;
-            const f4 x = *reinterpret_cast<const f4 *>(ok ? p0 + q * ld16 : safe);
+            const uint32_t o = ok ? off + q * ld16 : 0u;
+            const f4 x = *reinterpret_cast<const f4 *>(base + (size_t)o);
             const float sc = scale ? scale[ok ? k : 0] : 1.0f;
             v[q] = ok ? x * sc : (f4){0.f, 0.f, 0.f, 0.f};
         }
         klast = k0;
-        p0 += adv;
+        off += adv;
     }
     // late: row scales in LDS (loss_fold_table), applied here so the loads need not wait for the table
     __device__ __forceinline__ void store(float *Xt, const float *late = nullptr, int K = 0) const {
@@ -182,10 +184,12 @@ struct RcVecLoader {
     }
 };
 
-struct NoPre { __device__ __forceinline__ void operator()() const {} };
-
-// late_rs / pre: the merged weight-gradient launch with the loss gradient folded in (loss_fold_table) -- `pre` runs
-// after the first operand loads have been issued and fills the LDS table `late_rs` of per-row scales (and syncs).
+// late_rs / lf / lf_mode: the merged weight-gradient launch with the loss gradient folded in.  lf_mode 1: the fold's
+// inputs are requested BEFORE the first operand chunk (loss_fold_issue; in-order returns: they arrive first) and the
+// LDS table `late_rs` of per-row scales is finished with the operand chunk in flight (loss_fold_finish + an LDS-only
+// barrier); lf_mode 2: the one-step table with the net's loss statistics (loss_fold_table; the first fc2 tile of a net
+// in multi-round launches); 0: no fold.  (lf is passed down as a plain reference to the kernel argument: a struct
+// holding that reference made the compiler copy the whole argument block to scratch.)
 // fold / last: the update's logs are folded into this launch (LogFoldArgs): thread 0 draws the arrival ticket right after
 // the workgroup's gradient-norm partial is stored -- BEFORE the optimizer stores, whose drain it must not wait for --
 // and reports through *last whether this workgroup arrived last.
@@ -193,9 +197,10 @@ struct NoPre { __device__ __forceinline__ void operator()() const {} };
 // first launch left in feed->late_word (tau bits, 0 = no soft_update followed this update)
 struct LateTau { bool on; uint32_t bits; };
 
-template <bool A_KC, bool B_KC, int EPI, int KS, class Pre = NoPre>
+template <bool A_KC, bool B_KC, int EPI, int KS>
 __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int bx, int by, int bz,
-                                              const float *late_rs, Pre pre, const LogFoldArgs &fold, int &last,
+                                              float *late_rs, const LossFoldArgs &lf, int lf_mode,
+                                              const LogFoldArgs &fold, int &last,
                                               const LateTau &lt = LateTau{false, 0u}) {
     const int tid_all = threadIdx.x;
     const int kg = tid_all >> 8, tid = tid_all & 255;
@@ -225,12 +230,15 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     const int iters = (nchunks + KS - 1) / KS;
     constexpr bool TN = !A_KC && !B_KC;
     // 16-byte loads need 16-byte aligned rows on both operands (checked per launch on the host)
-    const bool vecA = TN && (g.vec & 1), vecB = TN && (g.vec & 2);
+    // ... and a batch entry's operand must span < 2^31 floats (32-bit lane offsets in RcVecLoader)
+    const bool vecA = TN && (g.vec & 1) && (int64_t)(Kloc + 1) * g.lda < (1LL << 31);
+    const bool vecB = TN && (g.vec & 2) && (int64_t)(Kloc + 1) * g.ldb < (1LL << 31);
 
     RcVecLoader va, vb;
     if (vecA) va.init(A, g.lda, m0, g.M, kg * BK, tid);
     if (vecB) vb.init(B, g.ldb, n0, g.N, kg * BK, tid);
-    const int64_t advA = (int64_t)KS * BK * g.lda, advB = (int64_t)KS * BK * g.ldb;
+    // (lane offsets are 32-bit: one batch entry's operand spans < 2^32 floats -- the launchers check it)
+    const uint32_t advA = (uint32_t)(KS * BK * g.lda), advB = (uint32_t)(KS * BK * g.ldb);
 
     const float *rscale = (TN && g.rowscale && !late_rs) ? g.rowscale + (int64_t)e * g.sRow : nullptr;
     int ra_k0 = 0;
@@ -260,6 +268,48 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     };
     auto storeB = [&](float *d) { if (vecB) vb.store(d); else store_chunk<B_KC>(vb.v, d, tid); };
 
+    // ---- optimizer state of this thread's 4 tile elements, requested during the LAST K chunk (the operand staging
+    //      registers are free by then) so that the epilogue finds p / m / v [/ target] in registers instead of opening
+    //      with a round trip to HBM / the Infinity Cache: 16-byte form, one float4 per thread (KS = 4) only.
+    constexpr int NT_ALL_ = NTHREADS * KS;
+    constexpr bool PREFETCH_OPT = EPI == EPI_ADAM && (BM * BN / 4) / NT_ALL_ == 1;
+    const bool vecC = (EPI == EPI_ADAM || EPI == EPI_GRAD) && (g.N & 3) == 0 && (g.ldc & 3) == 0 && (coff & 3) == 0 &&
+                      ((((uintptr_t)g.C | (uintptr_t)g.am | (uintptr_t)g.av | (uintptr_t)g.tw | (uintptr_t)g.gw) & 15) == 0);
+    const bool pol_ = g.tw != nullptr && (!lt.on || lt.bits != 0u);
+    f4 pf_p, pf_m, pf_v, pf_t;
+    bool pf_done = false;
+    auto opt_prefetch = [&]() {
+        if (!vecC) return;
+        const int row = tid_all >> 4, col = (tid_all & 15) * 4;
+        const bool ok = (m0 + row) < g.M && (n0 + col) < g.N;
+        const int64_t a = ok ? coff + (int64_t)(m0 + row) * g.ldc + n0 + col : coff;
+        pf_p = *reinterpret_cast<const f4 *>(g.C + a);
+        pf_m = *reinterpret_cast<const f4 *>(g.am + a);
+        pf_v = *reinterpret_cast<const f4 *>(g.av + a);
+        pf_t = pol_ ? *reinterpret_cast<const f4 *>(g.tw + a) : (f4){0.f, 0.f, 0.f, 0.f};
+        pf_done = true;
+    };
+
+    // ... and its cache lines are pulled towards this XCD's L2 at the very start of the workgroup (one dword per
+    // element group, result unused): the epilogues of all ~200 workgroups of the launch fall into the same few
+    // microseconds, and their 12.8 MB of optimizer-state reads + 12.8 MB of writes ran at the HBM rate there (8.7 k
+    // clocks per workgroup) -- requested here, the reads travel during the K loop, which is nowhere near the memory
+    // bandwidth.  (inline asm: a load whose result nobody uses would be deleted; the unaccounted vmcnt entries are the
+    // OLDEST in flight, so every compiler-placed wait still covers what it meant to cover)
+    // The landing register `l2_sink` stays reserved until the epilogue (the data arrives long after the asm statement;
+    // a register the allocator had handed to something else by then would be overwritten under it).
+    float l2_sink = 0.0f;
+    if (PREFETCH_OPT && vecC) {
+        const int row = tid_all >> 4, col = (tid_all & 15) * 4;
+        if ((m0 + row) < g.M && (n0 + col) < g.N) {
+            const int64_t a = coff + (int64_t)(m0 + row) * g.ldc + n0 + col;
+            asm volatile("global_load_dword %0, %1, off" : "+v"(l2_sink) : "v"(g.C + a) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "+v"(l2_sink) : "v"(g.am + a) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "+v"(l2_sink) : "v"(g.av + a) : "memory");
+            if (pol_) asm volatile("global_load_dword %0, %1, off" : "+v"(l2_sink) : "v"(g.tw + a) : "memory");
+        }
+    }
+
     GSTAMP(0);
     // Software-pipelined K loop in half chunks: the fragments of the second half of chunk it are read while its
     // first half multiplies, the first half of chunk it+1 is read (right after the barrier that publishes it) while
@@ -288,10 +338,13 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
         for (int t = 0; t < HT; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
     };
 #define GDSTAMP(i) do { if (g.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GSTAMP(i); } } while (0)
+    LossFoldRegs lfr;
+    if (lf_mode == 1) loss_fold_issue(lf, e, lfr);
     loadA(kg * BK);
     loadB(kg * BK);
     GDSTAMP(5);   // (debug runs only: serialises the prologue to time its pieces)
-    pre();
+    if (lf_mode == 1) { loss_fold_finish(lf, e, lfr, late_rs); lds_barrier(); }
+    else if (lf_mode == 2) { loss_fold_table(lf, e, late_rs, true, late_rs + lf.n_rows, false); __syncthreads(); }
     GDSTAMP(6);
     storeA(buf0);
     storeB(buf0 + TILE_FLOATS);
@@ -301,15 +354,27 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     float f0a[HT], f0b[HT], f1a[HT], f1b[HT];  // first / second half of the current chunk
     if (iters > 0) rd(f0a, f0b, buf0, 0);
     GSTAMP(1);
-    for (int it = 0; it < iters; ++it) {
+    for (int it = 0; it + 1 < iters; ++it) {
         float *cur = (it & 1) ? buf1 : buf0;
         float *nxt = (it & 1) ? buf0 : buf1;
         rd(f1a, f1b, cur, 1);
+        // (tools/lab/kloop_lab.hip: the staging work in front of these MFMAs, or staggered between the K-groups so that
+        // two waves of a SIMD stage while two multiply, measured no faster -- 21.2-22.4 k clocks per K = 512 loop either
+        // way against 17.0 k for the bare MFMAs + barriers; the fragment reads cost ~2.2 k and the staging ~2.3 k of
+        // it wherever they stand.)
         mm(f0a, f0b);
-        if (it + 1 < iters) { storeA(nxt); storeB(nxt + TILE_FLOATS); }
+        storeA(nxt); storeB(nxt + TILE_FLOATS);
         if (it + 2 < iters) { const int k0 = ((it + 2) * KS + kg) * BK; loadA(k0); loadB(k0); }
         lds_barrier();  // (LDS hand-off only: the loads just issued stay in flight over the next half chunk)
-        if (it + 1 < iters) rd(f0a, f0b, nxt, 0);
+        rd(f0a, f0b, nxt, 0);
+        mm(f1a, f1b);
+    }
+    if (iters > 0) {
+        // last chunk, peeled: nothing is staged any more, so the operand staging registers are dead here and the
+        // optimizer state takes their place (inside the loop the two live ranges would have overlapped)
+        rd(f1a, f1b, ((iters - 1) & 1) ? buf1 : buf0, 1);
+        if (PREFETCH_OPT) opt_prefetch();
+        mm(f0a, f0b);
         mm(f1a, f1b);
     }
     if (bias_wave) bias_acc += __shfl_xor(bias_acc, 32, 64);  // the two k parities of column li
@@ -322,12 +387,12 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
         // and three stores per element are spread over 4*KS waves and issued as independent batches
         // instead of one latency-bound chain per accumulator register.
         float *mine = lds + kg * (4 * TILE_FLOATS);
-        __syncthreads();
+        lds_barrier();   // (LDS hand-offs only: the prefetched optimizer state stays in flight)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             mine[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + wn * 32 + li] = acc[r];
         if (bias_wave && lh == 0) red[kg * 64 + wm * 32 + li] = bias_acc;
-        __syncthreads();
+        lds_barrier();
         GSTAMP(3);
         constexpr int NT_ALL = NTHREADS * KS;
         constexpr int PER = (BM * BN) / NT_ALL;  // 16 / KS elements per thread
@@ -337,10 +402,110 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
         // request is in the ring tail (late-bound)
         const bool pol = g.tw != nullptr && (!lt.on || lt.bits != 0u);
         const float tau = lt.on ? __uint_as_float(lt.bits) : g.tau;
+        float ss = 0.0f;
+        // 16-byte form: a thread owns 4 consecutive columns of one row (weight rows of a multiple of 4 floats on 16-byte
+        // aligned arenas: fc2 and every hidden-to-hidden layer).  The optimizer's traffic is 7-8 streams per element
+        // (p, m, v [, target] in; the same out) that come from HBM / the Infinity Cache once per update; as dword
+        // accesses that was 16 + 16 memory instructions per thread and the slowest phase of the workgroup after the K
+        // loop (11 k clocks at the metric shape), as dwordx4 it is 4 + 4.  Same sums, same Adam arithmetic per element.
+        if (vecC) {
+            constexpr int PER4 = (BM * BN / 4) / NT_ALL;  // 4 / KS float4 per thread
+            f4 g4[PER4], p4[PER4], m4[PER4], v4[PER4], t4[PER4];
+            int64_t c4[PER4];
+            bool ok4[PER4];
+#pragma unroll
+            for (int j = 0; j < PER4; ++j) {
+                const int id = tid_all + j * NT_ALL;
+                const int row = id >> 4, col = (id & 15) * 4;
+                ok4[j] = (m0 + row) < g.M && (n0 + col) < g.N;
+                c4[j] = coff + (int64_t)(m0 + row) * g.ldc + n0 + col;
+                if (EPI == EPI_ADAM) {
+                    if (PREFETCH_OPT && pf_done) {
+                        p4[j] = pf_p; m4[j] = pf_m; v4[j] = pf_v; t4[j] = pf_t;
+                    } else {
+                        const int64_t a = ok4[j] ? c4[j] : coff;
+                        p4[j] = *reinterpret_cast<const f4 *>(g.C + a);
+                        m4[j] = *reinterpret_cast<const f4 *>(g.am + a);
+                        v4[j] = *reinterpret_cast<const f4 *>(g.av + a);
+                        t4[j] = pol ? *reinterpret_cast<const f4 *>(g.tw + a) : (f4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                f4 sum = *reinterpret_cast<const f4 *>(lds + row * 64 + col);
+#pragma unroll
+                for (int gq = 1; gq < KS; ++gq) sum += *reinterpret_cast<const f4 *>(lds + gq * (4 * TILE_FLOATS) + row * 64 + col);
+                g4[j] = sum;
+            }
+            GSTAMP(8);
+            const int gm_ = m0 + tid_all;
+            const bool bias_thr_ = want_bias_grad && tid_all < 64 && gm_ < g.M;
+            const int64_t bi_ = (EPI == EPI_GRAD && g.sGb) ? (int64_t)e * g.sGb + gm_ : coff + gm_;
+            float bsum_ = 0.0f, bpv_ = 0.0f, bmv_ = 0.0f, bvv_ = 0.0f, btv_ = 0.0f;
+            if (bias_thr_) {
+                bsum_ = red[tid_all];
+#pragma unroll
+                for (int gq = 1; gq < KS; ++gq) bsum_ += red[gq * 64 + tid_all];
+                if (EPI == EPI_ADAM) { bpv_ = g.pb[bi_]; bmv_ = g.bm[bi_]; bvv_ = g.bv[bi_]; btv_ = (pol && g.tb) ? g.tb[bi_] : 0.0f; }
+            }
+#pragma unroll
+            for (int j = 0; j < PER4; ++j)
+                if (ok4[j]) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ss += g4[j][c] * g4[j][c];
+                }
+            if (bias_thr_) ss += bsum_ * bsum_;
+            if (g.sumsq) {
+                ss = wave_sum(ss);
+                lds_barrier();  // red[] (bias partials) and the partial tiles have been consumed
+                if (lane == 0) red[tid_all >> 6] = ss;
+                lds_barrier();
+                if (tid_all == 0) {
+                    float tot = 0.0f;
+                    for (int w = 0; w < 4 * KS; ++w) tot += red[w];
+                    __hip_atomic_store(g.sumsq + (int64_t)e * g.sumsq_stride + by * g.grid_x + bx, tot, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    if (fold.done) last = log_fold_arrive(fold, gridDim.x) ? 1 : 0;
+                }
+            }
+            GSTAMP(9);
+#pragma unroll
+            for (int j = 0; j < PER4; ++j) {
+                if (!ok4[j]) continue;
+                if (EPI == EPI_GRAD) {
+                    *reinterpret_cast<f4 *>(g.gw + c4[j]) = g4[j];
+                } else {
+                    f4 pn, tn;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float m = m4[j][c], v = v4[j][c];
+                        pn[c] = adam_elem(p4[j][c], g4[j][c], m, v, ctl);
+                        m4[j][c] = m; v4[j][c] = v;
+                        tn[c] = t4[j][c] * (1.0f - tau) + pn[c] * tau;
+                    }
+                    *reinterpret_cast<f4 *>(g.am + c4[j]) = m4[j];
+                    *reinterpret_cast<f4 *>(g.av + c4[j]) = v4[j];
+                    *reinterpret_cast<f4 *>(g.C + c4[j]) = pn;
+                    if (pol) *reinterpret_cast<f4 *>(g.tw + c4[j]) = tn;
+                }
+            }
+            asm volatile("" :: "v"(l2_sink));   // (end of the landing register's reservation)
+            if (bias_thr_) {
+                if (EPI == EPI_GRAD) {
+                    g.gb[bi_] = bsum_;
+                } else {
+                    float m = bmv_, v = bvv_;
+                    const float pn = adam_elem(bpv_, bsum_, m, v, ctl);
+                    g.bm[bi_] = m;
+                    g.bv[bi_] = v;
+                    g.pb[bi_] = pn;
+                    if (pol && g.tb) g.tb[bi_] = btv_ * (1.0f - tau) + pn * tau;
+                }
+            }
+            GSTAMP(4);
+            return;
+        }
         float gval[PER], pv[PER], mv[PER], vv[PER], tv[PER];
         int64_t ci[PER];
         bool ok[PER];
-        float ss = 0.0f;
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const int idx = tid_all + j * NT_ALL;
@@ -476,7 +641,7 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
     const int L = ssac_xcd_contiguous(blockIdx.z * per + blockIdx.y * gridDim.x + blockIdx.x, per * gridDim.z, g.xcd);
     const int bz = L / per, rem = L - bz * per;
     int last = 0;
-    ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % gridDim.x, rem / gridDim.x, bz, nullptr, NoPre(), LogFoldArgs{}, last);
+    ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % gridDim.x, rem / gridDim.x, bz, nullptr, LossFoldArgs{}, 0, LogFoldArgs{}, last);
 }
 
 // Two problems in ONE launch (the fc2 and fc1 weight gradients of an update): workgroups
@@ -543,14 +708,11 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
         const int L = first ? bid : bid - p.tiles0;
         const int per = g.grid_x * g.grid_y;
         const int bz = L / per, rem = L - bz * per;
-        auto pre = [&]() {
-            if (fold) {  // the first fc2 tile of each net also reduces that net's loss terms
-                loss_fold_table(p.lf, bz, tab, p.lf_nets == 0 && first && rem == 0, tab + p.lf.n_rows, false);
-                __syncthreads();
-            }
-        };
-        ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % g.grid_x, rem / g.grid_x, bz, fold ? tab : nullptr, pre,
-                                           p.fold, last, lt);
+        // multi-round launches (no TD workgroup pass over the nets): the first fc2 tile of each net also reduces that
+        // net's loss terms -- the one-step table with statistics; every other tile takes the two-step form
+        const bool stats = p.lf_nets == 0 && first && rem == 0;
+        ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % g.grid_x, rem / g.grid_x, bz, fold ? tab : nullptr, p.lf,
+                                           fold ? (stats ? 2 : 1) : 0, p.fold, last, lt);
         drawn = true;
     }
     if (p.fold.done) {
@@ -856,6 +1018,7 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
         !build_wgrad_args(p.g1, nets, 0, net_ids, X, ldx, x_net_stride, DZ1, H, (int64_t)n_rows * H, n_rows,
                           adam_m, adam_v, ctl, grads, sumsq0, sumsq_net_stride, target, tau))
         return ssac_fail("ssac_mlp_wgrad_fc12: bad arena");
+    p.g1.dbg = nullptr;   // (debug stamps: the first fc2 tile only -- both problems have a workgroup (0, 0, 0))
     if (rowscale) { p.g0.rowscale = p.g1.rowscale = rowscale; p.g0.sRow = p.g1.sRow = n_rows; }
     if (lossfold) p.lf = *lossfold;
     if (logfold && logfold->done_counter) {

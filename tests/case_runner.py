@@ -735,10 +735,7 @@ def run_markov_engine(name, device="cuda"):
                 getattr(mod, nm).bias.copy_(p[bk])
     opt = torch.optim.Adam(chain(agent.encoder.parameters(), agent.inverse_model.parameters(),
                                  agent.contrastive_model.parameters()), lr=cfg["lr"], weight_decay=0, betas=(0.9, 0.999))
-    if foreign_io:
-        aug = foreign_agent.ForeignAugmentationSequence(
-            [foreign_agent.Drqv2Aug(B) if (px and px["aug"] == "drqv2") else foreign_agent.IdentityAug(B)])
-    elif px and px["aug"] == "drqv2":
+    if px and px["aug"] == "drqv2":
         aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.Drqv2Aug(B)])
     else:
         aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(B)])

@@ -57,7 +57,7 @@ def install(reference_package):
     reference-built objects, which the update functions adopt in place -- adopt.adopt_augmenter / adopt_buffer)."""
     ref_learning, ref_lu = reference_package.learning, reference_package.learning_utils
     import sys
-    ref_name = reference_package.__name__
+    ref_name = getattr(reference_package, "__name__", "super_sac")
     ref_replay = getattr(reference_package, "replay", None) or sys.modules.get(ref_name + ".replay")
     ref_aug = getattr(reference_package, "augmentations", None) or sys.modules.get(ref_name + ".augmentations")
     if ref_replay is not None:

@@ -76,8 +76,12 @@ def test_update_path_refuses_to_run_without_a_gpu():
 def test_install_rebinds_the_reference_seam():
     import types
     import super_sac_amd as ssa
-    fake = types.SimpleNamespace(learning=types.SimpleNamespace(), learning_utils=types.SimpleNamespace())
+    fake = types.SimpleNamespace(learning=types.SimpleNamespace(), learning_utils=types.SimpleNamespace(),
+                                 replay=types.SimpleNamespace(), augmentations=types.SimpleNamespace())
     ssa.install(fake)
+    assert fake.replay.ReplayBuffer is ssa.replay.ReplayBuffer
+    assert fake.augmentations.Drqv2Aug is ssa.augmentations.Drqv2Aug
+    assert fake.augmentations.AugmentationSequence is ssa.augmentations.AugmentationSequence
     assert fake.learning.critic_update is ssa.learning.critic_update
     assert fake.learning.alpha_update is ssa.learning.alpha_update
     assert fake.learning_utils.soft_update is ssa.learning_utils.soft_update

@@ -59,11 +59,21 @@ def build_engine(device, n_local, shard=None, batch=BATCH, precision="fp32"):
     np.random.seed(0)
     import random
     random.seed(0)
-    agent = ssa.Agent(act_space_size=ACT, encoder=ssa.nets.IdentityEncoder(OBS),
-                      actor_network_cls=ssa.nets.ContinuousStochasticActor,
-                      critic_network_cls=ssa.nets.ContinuousCritic, discrete=False, ensemble_size=1,
-                      num_critics=n_local, ucb_bonus=0.0, hidden_size=HID, auto_rescale_targets=False,
-                      log_std_low=-5.0, log_std_high=2.0)
+    def make(n):
+        return ssa.Agent(act_space_size=ACT, encoder=ssa.nets.IdentityEncoder(OBS),
+                         actor_network_cls=ssa.nets.ContinuousStochasticActor,
+                         critic_network_cls=ssa.nets.ContinuousCritic, discrete=False, ensemble_size=1,
+                         num_critics=n, ucb_bonus=0.0, hidden_size=HID, auto_rescale_targets=False,
+                         log_std_low=-5.0, log_std_high=2.0)
+    agent = make(NCRIT if shard is not None else n_local)
+    if shard is not None:
+        # a rank of the sharded job holds critics [lo, hi) of THE SAME seeded ensemble the unsharded engine holds
+        # (so a sharded run can be checked against it value by value), the replicated actor included
+        full, agent = agent, make(n_local)
+        agent.actors[0].load_state_dict(full.actors[0].state_dict())
+        for j in range(n_local):
+            agent.critics[0].nets[j].load_state_dict(full.critics[0].nets[shard.lo + j].state_dict())
+        del full
     agent.to(device)
     agent.train()
     ssa.set_precision(agent, precision)
@@ -79,6 +89,13 @@ def build_engine(device, n_local, shard=None, batch=BATCH, precision="fp32"):
     aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(batch)])
     if shard is not None:
         ssa.parallel.install(agent, target, shard)
+    # every rank must draw the SAME replay indices / REDQ subsets (identically seeded generators instead of
+    # a batch broadcast), whatever number of critics it has just initialised: re-seed behind the construction.  (Found
+    # by sharded_value_check: with uneven shards -- 3 or 4 ranks over 10 critics -- the ranks' CPU generators had
+    # advanced by different amounts and they sampled different batches.)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    random.seed(0)
     state = {"k": 0}
 
     def step():
@@ -152,6 +169,58 @@ def cpu_baseline(budget_s=15.0):
                       f"{sum(r[1] for r in rows.values()):.1f} s over thread counts {counts} "
                       f"(host has {ncpu} logical cores), torch {torch.__version__} CPU; value = best row "
                       f"({best} threads)"}
+
+
+def sharded_value_check(step, ssa, device, shard, dist, n_updates=12):
+    """`bench.py --gpus N` is a VALUE check before it is a timing: the first n_updates updates of the sharded engine
+    (every rank, through the exchange) against the same updates of the unsharded engine run by rank 0 in this process
+    on the same seeds -- this rank's critics, Polyak targets and Adam moments, plus every TD target.  Tolerances as
+    in tests/test_hip_sharded.py: TD targets 2e-5 (a rank with few critics takes the 16-row tile variant, whose fp32
+    sums differ in the last bits), parameters / targets / first moments 5e-6 * n_updates."""
+    import random
+    import numpy as np
+    import torch
+
+    def run(stp):
+        tds = []
+        for _ in range(n_updates):
+            dicts = stp()
+            tds.append(dicts[0]["td_target"].detach().float().cpu().numpy().copy())
+        ob = stp.objects
+        ar, tar = ob["agent"].critics[0].arena(device), ob["target"].critics[0].arena(device)
+        m, _ = ob["critic_optimizer"]._ssac_adam.moments_for(("critic", 0), ar.params)
+        torch.cuda.synchronize()
+        n = ar.n_nets
+        return tds, [t.view(n, -1).cpu().numpy().copy() for t in (ar.params, tar.params, m)]
+    if dist is not None and dist.get_world_size() > 1:
+        dist.barrier()   # ranks finish building seconds apart; the exchange kernel's spin is bounded
+    tds, mine = run(step)
+    worst = {"td": 0.0, "params": 0.0, "target": 0.0, "adam_m": 0.0}
+    if shard.rank == 0:
+        # the unsharded engine on the same seeds (build_engine leaves every generator, the device's included, at seed 0)
+        keep = (torch.get_rng_state(), random.getstate(), np.random.get_state(), torch.cuda.get_rng_state(device))
+        ref_step, _, _ = build_engine(device, NCRIT, None)
+        ref_tds, ref = run(ref_step)
+        # ... and back to where the sharded job's generators stand (the other ranks did not make these extra draws)
+        torch.set_rng_state(keep[0]); random.setstate(keep[1]); np.random.set_state(keep[2])
+        torch.cuda.set_rng_state(keep[3], device)
+        per_update = [float(np.max(np.abs(a - b))) for a, b in zip(tds, ref_tds)]
+        worst["td"] = max(per_update)
+        worst["td_per_update"] = [float(f"{v:.2g}") for v in per_update]
+        for key, a, b in zip(("params", "target", "adam_m"), mine, ref):
+            worst[key] = float(np.max(np.abs(a - b[shard.lo:shard.hi])))
+        del ref_step
+    per_update = worst.pop("td_per_update", None)
+    ok = (worst["td"] <= 2e-5 and max(worst["params"], worst["target"], worst["adam_m"]) <= 5e-6 * n_updates)
+    if not ok:
+        worst["td_per_update"] = per_update
+    flag = torch.tensor([1.0 if ok else 0.0], device=device)
+    if dist is not None and dist.get_world_size() > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if float(flag) != 1.0:
+        raise RuntimeError(f"sharded run differs from the unsharded engine on the same seeds: {worst}")
+    return {"updates": n_updates, "max_abs_diff": {k: float(f"{v:.3g}") for k, v in worst.items()},
+            "against": "the unsharded engine, same seeds, run by rank 0 in the same process"}
 
 
 def launch_ranks(args):
@@ -255,6 +324,9 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     step, env_step, ssa = build_engine(device, n_local, shard)
+    value_check = None
+    if shard is not None:
+        value_check = sharded_value_check(step, ssa, device, shard, dist)
     # Python's cyclic GC otherwise runs a full (generation-2) collection over the whole torch object graph every few
     # hundred updates -- a 40-80 ms pause, i.e. hundreds of updates: park the start-up objects in the permanent
     # generation (host runtime hygiene of a long-running training loop; nothing the update path allocates is cyclic)
@@ -344,6 +416,8 @@ def main():
                                          (f" ({world} ranks sharing {ndev} device(s))" if shared_device else ""),
                           "exchange": exchange},
                "roofline": roofline}
+        if value_check is not None:
+            out["sharded_value_check"] = value_check
     secondary = {}
     if not args.no_secondary and world == 1:
         try:   # (a failing secondary row must not cost the headline line)

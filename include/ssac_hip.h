@@ -184,7 +184,9 @@ void ssac_step_destroy(ssac_step *step);
  * in place: op 0 = MIN (the per-shard min-Q, agent.py:37-38 / learning.py:402), op 1 = SUM (the action gradient).
  * Set-up: create on every rank, exchange the ssac_xchg_handle bytes among the ranks (any host channel), connect. */
 typedef struct ssac_xchg ssac_xchg;
-ssac_xchg *ssac_xchg_create(int rank, int world, int slot_floats);   /* NULL + ssac_last_error on error */
+/* allow_cached: 1 only when every rank shares ONE device (a single L2): the receive buffer may then fall back to
+ * ordinary device memory; across devices it must be uncached (fine-grained) memory or the call fails. */
+ssac_xchg *ssac_xchg_create(int rank, int world, int slot_floats, int allow_cached);   /* NULL + ssac_last_error on error */
 int ssac_xchg_handle_bytes(void);
 int ssac_xchg_handle(ssac_xchg *x, void *handle_out);
 int ssac_xchg_connect(ssac_xchg *x, const void *handles /* world x ssac_xchg_handle_bytes(), rank-major */);

@@ -91,7 +91,7 @@ SIGNATURES = {
     "ssac_launch_list_size": [_P],
     "ssac_replay": [_P, _P],
     "ssac_launch_list_free": [_P],
-    "ssac_xchg_create": [_I, _I, _I],
+    "ssac_xchg_create": [C.c_int, C.c_int, C.c_int, C.c_int],
     "ssac_xchg_handle_bytes": [],
     "ssac_xchg_handle": [_P, _P],
     "ssac_xchg_connect": [_P, _P],

@@ -117,7 +117,7 @@ struct ssac_xchg {
     int *error_host, *error_dev;        // pinned host word and its device view
 };
 
-extern "C" ssac_xchg *ssac_xchg_create(int rank, int world, int slot_floats) {
+extern "C" ssac_xchg *ssac_xchg_create(int rank, int world, int slot_floats, int allow_cached) {
     if (rank < 0 || world < 1 || world > X_MAX_WORLD || rank >= world || slot_floats <= 0) {
         ssac_fail("ssac_xchg_create: bad arguments");
         return nullptr;
@@ -127,11 +127,21 @@ extern "C" ssac_xchg *ssac_xchg_create(int rank, int world, int slot_floats) {
     x->rank = rank; x->world = world; x->slot_floats = slot_floats;
     const size_t bytes = sizeof(float) * (size_t)world * X_SLOTS * (slot_floats + 4);
     // The receive buffer is written by PEER devices while this device polls it: uncached (fine-grained) device memory,
-    // so that no stale line of it can sit in this device's L2 (what RCCL does for its flags and LL buffers); plain
-    // hipMalloc only where the runtime refuses the flag.
+    // so that no stale line of it can sit in this device's L2 (what RCCL does for its flags and LL buffers).  Ordinary
+    // (cached) device memory is accepted only when the caller says every rank shares ONE device (allow_cached: the
+    // test box) -- there a single L2 serves all of them and the system-scope accesses of the kernel are coherent by
+    // construction.  Across devices a cached buffer could serve the poll or the payload loads from a stale L2 line
+    // (the loads are sc0 sc1, but whether a peer's xGMI write invalidates the owner's L2 copy of a coarse-grained line
+    // is not something one probe exchange can prove): refused, the set-up vote then puts every rank on the collective.
     if (hipExtMallocWithFlags((void **)&x->local, bytes, hipDeviceMallocUncached) != hipSuccess) {
         (void)hipGetLastError();
         x->local = nullptr;
+        if (!allow_cached) {
+            ssac_fail("ssac_xchg_create: no uncached device memory for the receive buffer (and the ranks do not share "
+                      "one device): use the collective");
+            delete x;
+            return nullptr;
+        }
     }
     if ((!x->local && hipMalloc((void **)&x->local, bytes) != hipSuccess) || hipMemset(x->local, 0, bytes) != hipSuccess ||
         hipMalloc((void **)&x->seq, 16) != hipSuccess || hipMemset(x->seq, 0, 16) != hipSuccess) {

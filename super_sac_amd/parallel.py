@@ -58,9 +58,22 @@ class Exchange:
         from ._lib import check, lib
         self.rank, self.world, self.max_floats = rank, world, int(max_floats)
         torch.cuda.set_device(device)
-        h = lib.ssac_xchg_create(rank, world, self.max_floats)
-        if not h:
-            raise RuntimeError("libssac_hip: " + lib.ssac_last_error().decode())
+        # do all ranks sit on one device (the one-GPU test box)?  Only then may the receive buffer be ordinary cached
+        # memory; across devices the library insists on uncached memory and otherwise fails -- on EVERY rank alike, so
+        # the job falls back to the collective as a whole (csrc/ssac_xchg.hip)
+        props = torch.cuda.get_device_properties(device)
+        me = str(getattr(props, "uuid", None) or getattr(props, "pci_bus_id", None) or torch.device(device).index)
+        ids = [None] * world
+        dist.all_gather_object(ids, me)
+        shared = len(set(ids)) == 1
+        h = lib.ssac_xchg_create(rank, world, self.max_floats, 1 if shared else 0)
+        made = [None] * world
+        dist.all_gather_object(made, None if h else lib.ssac_last_error().decode())
+        if any(m is not None for m in made):
+            if h:
+                lib.ssac_xchg_destroy(h)
+            self.handle = None
+            raise RuntimeError(f"one-shot exchange unavailable: {dict((r, m) for r, m in enumerate(made) if m is not None)}")
         self.handle = h
         nb = int(lib.ssac_xchg_handle_bytes())
         mine = C.create_string_buffer(nb)

@@ -191,6 +191,11 @@ int ssac_xchg_handle_bytes(void);
 int ssac_xchg_handle(ssac_xchg *x, void *handle_out);
 int ssac_xchg_connect(ssac_xchg *x, const void *handles /* world x ssac_xchg_handle_bytes(), rank-major */);
 int ssac_xchg_reduce(ssac_xchg *x, float *data, int n, int op, void *stream);
+/* MIN where only the OWNERS of the update's REDQ subset members send: owners = the update's id block in
+ * device memory, n_slots int32 entries as every rank composes them from the same draw (agent.py:29): >= 0 a member this
+ * rank owns (its local index), -(r + 1) a member rank r owns.  Ranks that own none write nothing; every rank waits for
+ * the owners' flags only.  Same bits as ssac_xchg_reduce on partials that are +inf wherever a rank owns nothing. */
+int ssac_xchg_reduce_owned(ssac_xchg *x, float *data, int n, const int32_t *owners, int n_slots, void *stream);
 int ssac_xchg_error(ssac_xchg *x);   /* 1: a peer's flag did not arrive within the spin bound since the last call (the result
                                         was poisoned with NaN); a pinned host word, cleared by the read, no synchronisation */
 void ssac_xchg_destroy(ssac_xchg *x);

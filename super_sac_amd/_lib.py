@@ -96,6 +96,7 @@ SIGNATURES = {
     "ssac_xchg_handle": [_P, _P],
     "ssac_xchg_connect": [_P, _P],
     "ssac_xchg_reduce": [_P, _P, _I, _I, _P],
+    "ssac_xchg_reduce_owned": [_P, _P, _I, _P, _I, _P],
     "ssac_xchg_error": [_P],
     "ssac_xchg_destroy": [_P],
     "ssac_step_create": [_P, _I, _I, _I, _I, _I, _I, _I, _I],

@@ -1087,8 +1087,19 @@ void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs
     }
     if (bid < tiles_t) {
         const int j = bid / target_grid_x, bx = bid - j * target_grid_x;
-        if (j == 0) fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga, smem, bx, 0, target_grid_x, 0);
-        else fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga_rest, smem, bx, 0, target_grid_x, -1);
+        if (j > 0) {
+            // critic-sharded ranks ("only subset owners need to send"): a slot whose REDQ member lives on
+            // another rank has no target critic to feed here, and its a' / log pi rows are slot 0's work -- no actor
+            // pass for it; the target-critic pass below just stores +inf (the neutral element of the exchange's MIN)
+            const int32_t *idsp = gt.ids;
+            if (gt.gth_role == 4 && gt.gth.feed && gt.gth.ids_word >= 0) {
+                const ssac_feed f = *gt.gth.feed;
+                idsp = reinterpret_cast<const int32_t *>(feed_slot(f) + gt.gth.ids_word);
+            }
+            if (!(idsp && idsp[j] < 0)) fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga_rest, smem, bx, 0, target_grid_x, -1);
+        } else {
+            fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga, smem, bx, 0, target_grid_x, 0);
+        }
         __threadfence_block();  // this workgroup's a' rows (global) are read back by its own target-critic pass
         __syncthreads();
         // (phase stamps: the actor pass in slots 0.., the target-critic pass of subset slot 0 in 16.., the critics in 32..)

@@ -36,6 +36,8 @@ struct XchgArgs {
     int rank, world, n, slot_floats, op;   // op 0 = MIN, 1 = SUM
     float *data;                // in: this rank's partial (n floats); out: the reduction over ranks
     unsigned long long *seq;    // device-resident exchange counter
+    const int32_t *owners;      // != null: OWNERS-ONLY exchange (below), n_slots entries
+    int n_slots;
     int *error;                 // HOST-pinned int (device view), set to 1 when a peer's flag did not arrive in time
     int *dead;                  // device int: once a spin gave up, later exchanges fail at once instead of spinning again
 };
@@ -44,6 +46,11 @@ __device__ __forceinline__ float *slot_of(float *base, int src, int slot, int sl
     return base + ((int64_t)src * X_SLOTS + slot) * (int64_t)(slot_floats + 4);
 }
 
+// OWNERS-ONLY form (SURVEY 8(e) "Collective -- critic step": with n = 2 of N >= 10 subset members and 8 ranks, most ranks
+// contribute +inf -- only the members' owners need to SEND): `owners` is the update's id block as every rank composes
+// it from the same subset draw -- entry j >= 0: a member this rank owns, entry j = -(r + 1): rank r owns it.  Ranks that
+// own no member write nothing; every rank waits for the owners' flags only and reduces over the owners' payloads (the
+// others' would be +inf throughout).  `senders` = bit mask of owner ranks, the same on every rank.
 __global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
     __shared__ unsigned long long s_seq;
     __shared__ int s_ok;
@@ -52,8 +59,17 @@ __global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
     __syncthreads();
     const unsigned long long seq = s_seq;
     const int slot = (int)(seq % X_SLOTS);
+    unsigned senders = (1u << a.world) - 1u;
+    if (a.owners) {
+        senders = 0u;
+        for (int j = 0; j < a.n_slots; ++j) {
+            const int v = a.owners[j];
+            senders |= 1u << (v >= 0 ? a.rank : -v - 1);
+        }
+    }
+    const bool i_send = (senders >> a.rank) & 1u;
     // ---- 1. my partial -> every rank's recv[my rank][slot]
-    for (int p = 0; p < a.world; ++p) {
+    for (int p = 0; p < (i_send ? a.world : 0); ++p) {
         float *dst = slot_of(a.peer[p], a.rank, slot, a.slot_floats);
         for (int i = tid; i < a.n; i += X_THREADS)
             __hip_atomic_store(dst + i, a.data[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -61,13 +77,13 @@ __global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: payload before flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid < a.world) {
+    if (tid < a.world && i_send) {
         float *dst = slot_of(a.peer[tid], a.rank, slot, a.slot_floats);
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + a.slot_floats), seq, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    // ---- 2. wait for every rank's flag in MY buffer
-    if (tid < a.world) {
+    // ---- 2. wait for every sender's flag in MY buffer
+    if (tid < a.world && ((senders >> tid) & 1u)) {
         const unsigned long long *flag =
             reinterpret_cast<const unsigned long long *>(slot_of(a.peer[a.rank], tid, slot, a.slot_floats) + a.slot_floats);
         const long long t0 = __builtin_amdgcn_s_memtime();
@@ -82,12 +98,14 @@ __global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
     // ---- 3. reduce over ranks in rank order (system-scope loads: the payload may have come from a peer device)
     if (s_ok) {
         for (int i = tid; i < a.n; i += X_THREADS) {
-            float r = __hip_atomic_load(slot_of(a.peer[a.rank], 0, slot, a.slot_floats) + i, __ATOMIC_RELAXED,
-                                        __HIP_MEMORY_SCOPE_SYSTEM);
-            for (int p = 1; p < a.world; ++p) {
+            bool first = true;
+            float r = a.op == 0 ? __builtin_inff() : 0.0f;
+            for (int p = 0; p < a.world; ++p) {
+                if (!((senders >> p) & 1u)) continue;
                 const float v = __hip_atomic_load(slot_of(a.peer[a.rank], p, slot, a.slot_floats) + i, __ATOMIC_RELAXED,
                                                   __HIP_MEMORY_SCOPE_SYSTEM);
-                r = a.op == 0 ? fminf(r, v) : r + v;
+                r = first ? v : (a.op == 0 ? fminf(r, v) : r + v);
+                first = false;
             }
             a.data[i] = r;
         }
@@ -190,11 +208,25 @@ extern "C" int ssac_xchg_connect(ssac_xchg *x, const void *handles) {
     return 0;
 }
 
+static int xchg_launch(ssac_xchg *x, float *data, int n, int op, const int32_t *owners, int n_slots, void *stream);
+
 // in place over data[0 .. n): MIN (op 0) or SUM (op 1) over the ranks.  A recordable launch.
 extern "C" int ssac_xchg_reduce(ssac_xchg *x, float *data, int n, int op, void *stream) {
+    return xchg_launch(x, data, n, op, nullptr, 0, stream);
+}
+
+// MIN over the ranks of data[0 .. n) where only the OWNERS of the update's subset members send (see xchg_kernel):
+// owners = the update's id block in device memory (n_slots int32: >= 0 a member of this rank, -(r + 1) rank r's).
+extern "C" int ssac_xchg_reduce_owned(ssac_xchg *x, float *data, int n, const int32_t *owners, int n_slots, void *stream) {
+    if (!owners || n_slots <= 0 || n_slots > 64) return ssac_fail("ssac_xchg_reduce_owned: bad owner block");
+    return xchg_launch(x, data, n, 0, owners, n_slots, stream);
+}
+
+static int xchg_launch(ssac_xchg *x, float *data, int n, int op, const int32_t *owners, int n_slots, void *stream) {
     if (!x || !data || n <= 0 || n > x->slot_floats || (op != 0 && op != 1))
         return ssac_fail("ssac_xchg_reduce: bad arguments");
     XchgArgs a{};
+    a.owners = owners; a.n_slots = n_slots;
     for (int p = 0; p < x->world; ++p) {
         if (!x->peers[p]) return ssac_fail("ssac_xchg_reduce: not connected");
         a.peer[p] = x->peers[p];

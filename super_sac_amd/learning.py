@@ -310,8 +310,8 @@ class _FastStep:
         ids = rng.draw_subset(self.n_critics, self.n_sub)
         ida, sh = self.ids_c, self.shard
         for j, v in enumerate(ids):
-            # sharded: the LOCAL index of a subset member this rank owns, -1 for a member that lives elsewhere
-            ida[j] = v if sh is None else (v - sh.lo if sh.owns(v) else -1)
+            # sharded: the LOCAL index of a subset member this rank owns, -(owner rank + 1) for one that lives elsewhere
+            ida[j] = v if sh is None else sh.slot_code(v)
         slot_i = self.ring.advance()
         if sh is not None and gs.k % EVENT_EVERY == 0:
             parallel.check_exchange()
@@ -427,8 +427,8 @@ def _critic_update_graphed(gs, kw):
     gs.np_idx[k] = idx_cpu.numpy()
     row = gs.np_i32[k]
     for j, v in enumerate(ids):
-        # sharded: the LOCAL index of a subset member this rank owns, -1 for a member that lives elsewhere
-        row[j] = v if shard is None else (v - shard.lo if shard.owns(v) else -1)
+        # sharded: the LOCAL index of a subset member this rank owns, -(owner rank + 1) for one that lives elsewhere
+        row[j] = v if shard is None else shard.slot_code(v)
     row[gs.n_pad] = slot_i
     if in_kernel_noise:
         gs.np_draw[k, 0] = lu.noise_stream(agent, dev)[1]

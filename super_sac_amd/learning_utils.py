@@ -743,7 +743,9 @@ def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag, co_backward=None, re
         # MIN all-reduce of all n slots at once (n x B x O floats; slots this rank does not own hold +inf): the minimum
         # over the slots is taken where the TD target is evaluated, so no local min launch is needed
         if parallel.one_shot_ready(q1):
-            parallel.all_reduce_min(q1)  # ONE recorded launch (csrc/ssac_xchg.hip): the update stays one launch list
+            # ONE recorded launch (csrc/ssac_xchg.hip): the update stays one launch list; only the subset members'
+            # owners send (the id block, mirrored to device memory by the update's first launch, names them)
+            parallel.all_reduce_min_owned(q1, cap.ids_dev, n)
         else:
             cap.collective(lambda: parallel.all_reduce_min(q1))
         return q1, n

@@ -36,6 +36,17 @@ class Shard:
     def owns(self, j):
         return self.lo <= j < self.hi
 
+    def owner(self, j):
+        """rank that holds global critic j"""
+        base, rem = divmod(self.num_critics, self.world)
+        return j // (base + 1) if j < rem * (base + 1) else rem + (j - rem * (base + 1)) // base
+
+    def slot_code(self, j):
+        """entry of a recorded update's id block for subset member j (include/ssac_hip.h, ssac_xchg_reduce_owned): the
+        LOCAL index of a member this rank owns, else -(owner rank + 1) -- negative, which is all the kernels that skip a
+        foreign slot look at, and it tells the exchange who will send"""
+        return j - self.lo if self.owns(j) else -(self.owner(j) + 1)
+
 
 def install(agent, target_agent, shard):
     """mark both agents as holding shard `shard` of the global critic ensemble."""
@@ -110,6 +121,12 @@ class Exchange:
         from ._lib import check, lib
         check(lib.ssac_xchg_reduce(self.handle, t.data_ptr(), t.numel(), op, engine.stream()))
 
+    def reduce_min_owned(self, t, ids_dev, n_slots):
+        from . import engine
+        from ._lib import check, lib
+        check(lib.ssac_xchg_reduce_owned(self.handle, t.data_ptr(), t.numel(), ids_dev.data_ptr(), n_slots,
+                                         engine.stream()))
+
     def failed(self):
         from ._lib import lib
         return bool(lib.ssac_xchg_error(self.handle))
@@ -159,6 +176,14 @@ def all_reduce_min(t):
         _exchange.reduce(t, 0)
     elif dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVE):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)  # fallback: RCCL on the GPUs, gloo in the CPU tests
+    return t
+
+
+def all_reduce_min_owned(t, ids_dev, n_slots):
+    """MIN all-reduce of the (n_slots x B) target-critic outputs of a recorded sharded update, where only the ranks
+    that own a subset member send (the id block `ids_dev` says who: Shard.slot_code)"""
+    check_exchange()
+    _exchange.reduce_min_owned(t, ids_dev, n_slots)
     return t
 
 

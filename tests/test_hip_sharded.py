@@ -73,16 +73,34 @@ def _xchg_main(rank, world, port, out_dir):
             for p in parts[1:]:
                 want = torch.minimum(want, p) if op == 0 else want + p
             ok = ok and torch.equal(t.cpu(), want)   # rank-ordered reduction: identical bits everywhere
+    # owners-only form (ssac_xchg_reduce_owned): a 2-slot id block per round names the ranks that send -- both slots
+    # on one rank, one each, or (world > 2) on two ranks this rank is neither of; non-owners' partials are +inf
+    for it in range(30):
+        g = torch.Generator().manual_seed(5000 + it)
+        owners = [int(v) for v in torch.randint(0, world, (2,), generator=g)]
+        parts = [torch.randn(2, 300, generator=g) for _ in range(world)]
+        for r in range(world):
+            for j in range(2):
+                if owners[j] != r:
+                    parts[r][j] = float("inf")
+        ids = torch.tensor([j if owners[j] == rank else -(owners[j] + 1) for j in range(2)], dtype=torch.int32).cuda()
+        t = parts[rank].cuda()
+        parallel.all_reduce_min_owned(t, ids, 2)
+        want = parts[0].clone()
+        for p_ in parts[1:]:
+            want = torch.minimum(want, p_)
+        ok = ok and torch.equal(t.cpu(), want) and bool(torch.isfinite(want).all())
     assert not x.failed() and ok
     open(os.path.join(out_dir, f"xok{rank}"), "w").write("ok")
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_one_shot_exchange_two_ranks_on_one_device(tmp_path):
-    port = 29900 + (os.getpid() % 2000)
-    mp.spawn(_xchg_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    assert all((tmp_path / f"xok{r}").exists() for r in range(2))
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_shot_exchange_ranks_on_one_device(tmp_path, world):
+    port = 29900 + (os.getpid() % 2000) + world
+    mp.spawn(_xchg_main, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"xok{r}").exists() for r in range(world))
 
 
 def _humanoid_main(rank, world, port, out_dir):

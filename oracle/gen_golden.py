@@ -876,8 +876,13 @@ def run_bc_pixels_case(name, cfg):
     rec = {"n_steps": np.int64(len(cfg["steps"]))}
     for k in range(len(cfg["steps"])):
         st, pst = torch.get_rng_state(), random.getstate()
-        idx = torch.randint(len(rbuf), (B,)).numpy()
-        shift = orc.drqv2_draw_shift(B)
+        E = cfg["E"]
+        idxs, shifts = [], []
+        for _ in range(E):   # per member: index draw, then the augmenter's shift (learning_utils.py:174-201)
+            idxs.append(torch.randint(len(rbuf), (B,)).numpy())
+            shifts.append(orc.drqv2_draw_shift(B))
+        idx, shift = idxs[0], shifts[-1]
+        gpick = random.choice(range(E))   # random.choice(agent.actors), learning.py:210-212
         torch.set_rng_state(st); random.setstate(pst)
         rlogs = rl.offline_actor_update(
             buffer=rbuf, agent=ra, actor_optimizer=r_aopt, encoder_optimizer=r_eopt, batch_size=B,
@@ -885,11 +890,17 @@ def run_bc_pixels_case(name, cfg):
             actor_lambda=0.0, aug_mix=px["aug_mix"], premade_replay_dicts=None, per=False, discrete=disc,
             filter_=False)
         assert torch.equal(r_aug.aug_list[0].shift, shift), "shift stream mismatch"
-        o_aug.forced = [shift.clone()]
+        o_aug.forced = [sh.clone() for sh in shifts]
         ologs, _, _, _ = orc.offline_actor_update(
-            obuf, None, oa, o_aopt, B, cfg["clip"], o_aug, px["aug_mix"], per=False, filter_=False, idx_list=[idx],
-            update_encoder=True, encoder_opt=o_eopt, encoder_clip=cfg["enc_clip"][k])
-        rec[f"s{k}_idx"], rec[f"s{k}_shift"] = np.asarray(idx, np.int64), shift.numpy()
+            obuf, None, oa, o_aopt, B, cfg["clip"], o_aug, px["aug_mix"], per=False, filter_=False, idx_list=idxs,
+            update_encoder=True, encoder_opt=o_eopt, encoder_clip=cfg["enc_clip"][k], grad_pick=gpick)
+        if E > 1:
+            rec[f"s{k}_gpick"] = np.int64(gpick)
+        if E == 1:
+            rec[f"s{k}_idx"], rec[f"s{k}_shift"] = np.asarray(idx, np.int64), shift.numpy()
+        else:   # (E, B) / (E, B, 1, 1, 2)
+            rec[f"s{k}_idx"] = np.stack([np.asarray(v, np.int64) for v in idxs])
+            rec[f"s{k}_shift"] = np.stack([sh.numpy() for sh in shifts])
         for key, val in rlogs.items():
             v = float(val)
             rec[f"s{k}_log:{key}"] = np.float64(v)

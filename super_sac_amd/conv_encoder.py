@@ -180,9 +180,21 @@ class ConvEncoderEngine:
                               Hf=Hi, Wf=Wi, xhat=xhat, rstd=rstd, out=dst, ld_out=ld_dst)
 
     # ------------------------------------------------------------------------------------
-    def backward(self, d_rep):
+    def backward(self, d_rep, accumulate=False):
         """d_rep (B, emb) contiguous = dL/d(embedding).  Fills self.grads (flat, same layout as the
-        parameters)."""
+        parameters); accumulate=True ADDS to it instead (the members of an ensemble share one encoder and the
+        reference runs ONE backward over the sum of their losses, learning.py:47-121)."""
+        if accumulate:
+            keep, tmp = self.grads, self.__dict__.get("_gtmp")
+            if tmp is None:
+                tmp = self.__dict__["_gtmp"] = torch.zeros_like(self.flat)
+            self.grads = tmp
+            try:
+                self.backward(d_rep)
+            finally:
+                self.grads = keep
+            keep.add_(tmp)   # (device plumbing: one elementwise pass over the gradient arena)
+            return
         sv = self.saved
         assert sv is not None, "backward() needs a forward(save=True)"
         B, st = sv["B"], engine.stream()

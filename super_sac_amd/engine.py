@@ -21,9 +21,9 @@ SEGS = ("w1", "b1", "w2", "b2", "w3", "b3")
 PROFILE = {"tag": None, "events": [], "reps": 1}
 USE_FUSED = True  # tests flip this to exercise the per-layer kernels on fused-capable shapes
 # launch the head layer's (VALU) weight-gradient kernel as a parallel branch beside the fc2/fc1 GEMM launch
-HEAD_BRANCH = os.environ.get("SSAC_HEAD_BRANCH", "0") == "1"
+HEAD_BRANCH = _lib.debug_knob("head_branch", False)
 # head + fc2 + fc1 weight gradients in one launch (the head's VALU workgroups fill CUs the GEMM tiles leave idle)
-MERGE_HEAD_WGRAD = os.environ.get("SSAC_MERGE_HEAD_WGRAD", "1") == "1"
+MERGE_HEAD_WGRAD = _lib.debug_knob("merge_head_wgrad", True)
 
 
 class CaptureCtx:

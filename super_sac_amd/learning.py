@@ -70,28 +70,28 @@ class _LaunchList:
                     pass
 
 
-FUSED_ACTOR = os.environ.get("SSAC_FUSED_ACTOR", "1") == "1"  # the online actor update in four fused launches
+FUSED_ACTOR = _lib.debug_knob("fused_actor", True)  # the online actor update in four fused launches
 FEED_SLOTS = 32  # pinned input ring of a captured update: how far the host may run ahead of the GPU
 # evaluate the TD target inside the critic launch instead of a launch of its own (continuous, no PopArt)
-SHARDED_LISTS = os.environ.get("SSAC_SHARDED_LISTS", "1") == "1"  # recorded launch lists on critic-sharded ranks
-FOLD_BEGIN = os.environ.get("SSAC_FOLD_BEGIN", "1") == "1"  # fold ssac_begin_update into the replay gather
+SHARDED_LISTS = _lib.debug_knob("sharded_lists", True)  # recorded launch lists on critic-sharded ranks
+FOLD_BEGIN = _lib.debug_knob("fold_begin", True)  # fold ssac_begin_update into the replay gather
 # Log finalisation inside the weight-gradient launch: the last workgroup to ARRIVE (a device-scope ticket drawn after
 # its write-through partial stores -- no fence, so none of the 17 MB of freshly written Adam state is flushed) sums the
 # partials and publishes the log block; the separate 1-workgroup logs launch (~5 us per update) disappears.
-FOLD_LOGS = os.environ.get("SSAC_FOLD_LOGS", "1") == "1"
-LAZY_TD = os.environ.get("SSAC_LAZY_TD", "1") == "1"
-SPLIT_FORWARD = os.environ.get("SSAC_SPLIT_FORWARD", "0") == "1"
+FOLD_LOGS = _lib.debug_knob("fold_logs", True)
+LAZY_TD = _lib.debug_knob("lazy_td", True)
+SPLIT_FORWARD = _lib.debug_knob("split_forward", False)
 
 
 # the TD-independent half of the critics' backward pass inside the target-critic launch (rank-1 loss gradient); a module
 # knob, not an environment switch: tests turn it off to compare against the launch forms other configurations take
 RANK1_BWD = True
-EVENT_EVERY = int(os.environ.get("SSAC_EVENT_EVERY", "8"))  # must divide FEED_SLOTS
-FOLD_LOSS = os.environ.get("SSAC_FOLD_LOSS", "1") == "1"  # rank-1 backward: dL/dq evaluated inside the weight-gradient launch
-DUAL_LAUNCH = os.environ.get("SSAC_DUAL_LAUNCH", "1") == "1"  # critic forward inside the actor-sample launch
+EVENT_EVERY = _lib.debug_knob("event_every", 8)  # must divide FEED_SLOTS
+FOLD_LOSS = _lib.debug_knob("fold_loss", True)  # rank-1 backward: dL/dq evaluated inside the weight-gradient launch
+DUAL_LAUNCH = _lib.debug_knob("dual_launch", True)  # critic forward inside the actor-sample launch
 
 
-DUAL_MAX_WG = int(os.environ.get("SSAC_DUAL_MAX_WG", "320"))
+DUAL_MAX_WG = _lib.debug_knob("dual_max_wg", 320)
 
 
 def _dual_fits(arena, n_rows):
@@ -119,7 +119,8 @@ def _clip_and_step(adam, members, clip, slot_norm):
                                  arena.params.numel(), adam.ctl.ptr, st))
 
 
-def _encoder_step(encoder, encoder_optimizer, encoder_clip, dX, emb, ws, slot, dev, inv=None):
+def _encoder_step(encoder, encoder_optimizer, encoder_clip, dX, emb, ws, slot, dev, inv=None, accumulate=False,
+                  step=True):
     """encoder backward from the critics' input gradients + clip + encoder_optimizer.step()
     (learning.py:121,127-129); logs the (clipped) encoder gradient norm (learning.py:137).
     inv = (as_rep, os_rep, encoder_lambda, stacked): the encoder invariance constraint (learning.py:114-117) adds
@@ -138,8 +139,11 @@ def _encoder_step(encoder, encoder_optimizer, encoder_clip, dX, emb, ws, slot, d
                                           lu._row_stride(os_rep), B, emb, float(lam), tgt.data_ptr(), emb,
                                           0 if stacked else 1, slot[lu.L_ENC_INV:].data_ptr(),
                                           slot[lu.L_CRITIC_LOSS:].data_ptr(), engine.stream()))
-    eng.backward(d_rep)
-    eng.optimizer_step(encoder_optimizer, encoder_clip, norm_out=slot[lu.L_ENC_GN:])
+    # ensemble members share the encoder: member i > 0 adds its gradient to the arena, the clip + optimizer step
+    # follows the last member (learning.py:47-130: one backward over the summed loss, one encoder_optimizer.step())
+    eng.backward(d_rep, accumulate=accumulate)
+    if step:
+        eng.optimizer_step(encoder_optimizer, encoder_clip, norm_out=slot[lu.L_ENC_GN:])
 
 
 USE_GRAPHS = True   # replay the critic update's launch sequence as one HIP graph when it is static
@@ -624,11 +628,13 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             s_rep, X, ldx = P["xin"]
         if train_enc:
             # online encoder WITH gradient (learning.py:83): embedding goes straight into the critic input
-            assert E == 1, "trainable encoders are supported for ensemble_size == 1"
             xin = ws.get(f"cu.x{i}", (B, arena.in_dim))
             inv = None
             okey = getattr(agent.encoder, "ssac_obs_key", "obs")
-            if encoder_lambda and rd["augmented_obs"][0][okey] is not o[okey]:
+            # (the invariance constraint looks at the LAST member's batch only: learning.py:114-117 read the replay
+            # dict the member loop left behind)
+            lam_i = encoder_lambda if i == E - 1 else 0
+            if lam_i and rd["augmented_obs"][0][okey] is not o[okey]:
                 # encoder invariance on a partly augmented batch: the fully augmented observations need an encoder
                 # pass of their own WITH gradient -- one stacked 2B-row pass [o ; ao], whose backward then receives
                 # the critics' gradient in rows [0, B) and the constraint's in rows [B, 2B)
@@ -644,7 +650,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             else:
                 s_rep = lu.encode(agent.encoder, o, dst=xin, save=True)
                 as_rep, stacked = s_rep, False
-            if encoder_lambda:
+            if lam_i:
                 oo = rd["original_obs"][0]
                 if oo[okey] is o[okey]:
                     os_rep = ws.get("cu.osrep", (B, s_rep.shape[1]))
@@ -787,7 +793,8 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                 dX = ws.get(tag + ".dx", (N, B, arena.in_dim))
                 check(lib.ssac_mlp_layer_dgrad(C.byref(arena.desc()), 0, 0, N, dz1.data_ptr(), H, B * H, 0, 0, 0,
                                                B, dX.data_ptr(), arena.in_dim, B * arena.in_dim, st))
-                _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, s_rep.shape[1], ws, slot, dev, inv)
+                _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, s_rep.shape[1], ws, slot, dev, inv,
+                              accumulate=i > 0, step=i == E - 1)
             if arena.shadow is not None and (lossfold is None or critic_clip or popart):
                 raise NotImplementedError(
                     "bf16 mode covers the chained critic update (one member, continuous single-output critics, "
@@ -813,7 +820,8 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                                            dq.data_ptr(), slot.data_ptr(), st))
             if train_enc:
                 dX = engine.mlp_backward(arena, dq, X, ldx, 0, h1, h2, B, ws, tag, need_dx=True, update=False)
-                _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, s_rep.shape[1], ws, slot, dev, inv)
+                _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, s_rep.shape[1], ws, slot, dev, inv,
+                              accumulate=i > 0, step=i == E - 1)
                 dz2, dz1 = ws.get(tag + ".dz2", (N, B, arena.hidden)), ws.get(tag + ".dz1", (N, B, arena.hidden))
                 engine.weight_grads(arena, X, ldx, 0, h1, h2, dq, dz2, dz1, B, adam=adam,
                                     adam_key=("critic", i), grads=grads, sumsq=ss)
@@ -1131,8 +1139,7 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
     # the action invariance constraint (learning_utils.py:272-285) reaches the encoder through the AUGMENTED
     # observations whether or not update_encoder is set (only encoder_optimizer.step() depends on it)
     enc_grad = train_enc or (bool(actor_lambda) and pixel)
-    if enc_grad and E != 1:
-        raise NotImplementedError("trainable encoders are supported for ensemble_size == 1")
+    # (ensemble members share the encoder: member i > 0 adds its gradient, the clip / step follows the last member)
     if actor_lambda and any(lu.actor_kind(a_) == "deterministic" for a_ in agent.actors):
         raise NotImplementedError("action invariance constraint on a deterministic actor")
     dev = next(agent.actors[0].parameters()).device
@@ -1241,10 +1248,12 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
             d_rep.copy_(dX[0])
             if not train_enc:
                 d_rep[:B].zero_()
-            eng.backward(d_rep)
-            eng.optimizer_step(encoder_optimizer, encoder_clip, norm_out=slot[lu.L_ENC_GN:], step=train_enc)
+            eng.backward(d_rep, accumulate=i > 0)
+            if i == E - 1:
+                eng.optimizer_step(encoder_optimizer, encoder_clip, norm_out=slot[lu.L_ENC_GN:], step=train_enc)
         elif train_enc:  # (dX was taken before the epilogue of the weight-gradient launch touched W1)
-            _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, S, ws, slot, dev)
+            _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, S, ws, slot, dev, accumulate=i > 0,
+                          step=i == E - 1)
         member_ss.append(ss)
     if actor_clip:
         _clip_and_step(adam, clip_members, actor_clip, None)

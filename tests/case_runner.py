@@ -816,6 +816,13 @@ def _encoder_param_list(conv, kind):
     return plist
 
 
+def _per_member(idx, shift, E):
+    """the recorded draws of a step as per-member lists (single-member fixtures store them without the member axis)"""
+    if E == 1:
+        return [idx], [shift]
+    return [idx[i] for i in range(E)], [shift[i] for i in range(E)]
+
+
 def run_bc_pixels_oracle(name):
     cfg = synth.BC_PIXEL_CASES[name]
     fx = load_fixture(name)
@@ -828,10 +835,12 @@ def run_bc_pixels_oracle(name):
     aug = orc.AugOracle("drqv2", B)
     rec = {}
     for k in range(len(cfg["steps"])):
-        aug.forced = [torch.from_numpy(fx[f"s{k}_shift"])]
+        idxs, shifts = _per_member(fx[f"s{k}_idx"], fx[f"s{k}_shift"], cfg["E"])
+        aug.forced = [torch.from_numpy(sh) for sh in shifts]
         logs, _, _, _ = orc.offline_actor_update(
             obuf, None, oa, aopt, B, cfg["clip"], aug, px["aug_mix"], per=False, filter_=False,
-            idx_list=[fx[f"s{k}_idx"]], update_encoder=True, encoder_opt=eopt, encoder_clip=cfg["enc_clip"][k])
+            idx_list=idxs, update_encoder=True, encoder_opt=eopt, encoder_clip=cfg["enc_clip"][k],
+            grad_pick=int(fx[f"s{k}_gpick"]) if f"s{k}_gpick" in fx else 0)
         for key, val in logs.items():
             rec[f"s{k}_log:{key}"] = np.float64(val)
     rec["final_actor"] = _flat(oa.actor_params())
@@ -856,8 +865,11 @@ def run_bc_pixels_engine(name, device="cuda"):
     rec = {}
     try:
         for k in range(len(cfg["steps"])):
-            player.idx.append(fx[f"s{k}_idx"])
-            player.shift.append(fx[f"s{k}_shift"])
+            for idx_i, shift_i in zip(*_per_member(fx[f"s{k}_idx"], fx[f"s{k}_shift"], cfg["E"])):
+                player.idx.append(idx_i)
+                player.shift.append(shift_i)
+            if f"s{k}_gpick" in fx:
+                player.picks.append(int(fx[f"s{k}_gpick"]))
             logs = ssa.learning.offline_actor_update(
                 buffer=buf, agent=agent, actor_optimizer=aopt, encoder_optimizer=eopt, batch_size=B,
                 actor_clip=cfg["clip"], update_encoder=True, encoder_clip=cfg["enc_clip"][k], augmenter=aug,

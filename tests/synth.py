@@ -69,6 +69,23 @@ CASES = {
                          cycles=2, utd=2, target_delay=2, seed=18,
                          pixels=dict(kind="small", channels=4, hw=84, emb=128, enc_lr=3e-4, enc_tau=0.01,
                                      aug="drqv2", aug_mix=0.9)),
+    # ---- round 3: a TRAINABLE pixel encoder shared by the members of an ensemble (learning.py:47-117 loops the members
+    # over one encoder; its gradient is the sum over members, clipped and stepped once): SUNRISE-style E = 2 on the
+    # Atari-shaped encoder (discrete, clips 40) and on the DrQ encoder (deterministic actor + exploration noise)
+    "ens_pixels_atari": dict(obs=128, act=6, hidden=64, N=2, n=2, E=2, B=8, rows=48, cap=64,
+                             lo=-10.0, hi=2.0, popart=False, pop=False, discrete=True,
+                             actor="discrete", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                             clip=40.0, tau=0.005, weight_type=None, temp=None, noise=None,
+                             cycles=2, utd=2, target_delay=2, seed=92,
+                             pixels=dict(kind="small", channels=4, hw=84, emb=128, enc_lr=3e-4, enc_tau=0.01,
+                                         aug="drqv2", aug_mix=0.9)),
+    "ens_pixels_drq": dict(obs=50, act=4, hidden=64, N=2, n=2, E=2, B=8, rows=48, cap=64,
+                           lo=-10.0, hi=2.0, popart=False, pop=False, discrete=False,
+                           actor="deterministic", gamma=0.99 ** 3, lr=1e-4, alpha_lr=0.0, init_alpha=0.0,
+                           clip=None, tau=0.01, weight_type=None, temp=None,
+                           noise=dict(scale=0.5, clip=0.3), cycles=2, utd=1, target_delay=1, seed=93,
+                           pixels=dict(kind="big", channels=9, hw=84, emb=50, enc_lr=1e-4, enc_tau=1.0,
+                                       aug="drqv2", aug_mix=1.0)),
     # ---- round 2 ----
     # BASELINE config 1: Pendulum-v1 SAC (gym/sac.gin), 2 critics, batch 256, hidden 256
     "pendulum_sac": dict(obs=3, act=1, hidden=256, N=2, n=2, E=1, B=256, rows=2000, cap=4096,
@@ -185,6 +202,12 @@ BC_PIXEL_CASES = {
                       steps=[(False, False)] * 3, enc_clip=(None, 0.5, 0.5),
                       pixels=dict(kind="big", channels=9, hw=84, emb=50, enc_lr=1e-4, enc_tau=1.0, aug="drqv2",
                                   aug_mix=0.9)),
+    # round 3: two ensemble members behind ONE trainable encoder (its gradient is the sum over the members' BC losses)
+    "bc_pixels_ens": dict(obs=64, act=5, hidden=64, N=2, n=2, E=2, B=8, rows=48, cap=64, lo=-10.0, hi=2.0,
+                          popart=False, discrete=True, actor="discrete", lr=3e-4, clip=5.0, seed=94,
+                          bc_pixels=True, steps=[(False, False)] * 3, enc_clip=(5.0, None, 5.0),
+                          pixels=dict(kind="small", channels=4, hw=84, emb=64, enc_lr=3e-4, enc_tau=1.0,
+                                      aug="drqv2", aug_mix=0.9)),
     "bc_pixels_discrete": dict(obs=64, act=5, hidden=64, N=2, n=2, E=1, B=8, rows=48, cap=64, lo=-10.0, hi=2.0,
                                popart=False, discrete=True, actor="discrete", lr=3e-4, clip=5.0, seed=62,
                                bc_pixels=True, steps=[(False, False)] * 3, enc_clip=(5.0, 5.0, 5.0),

@@ -200,6 +200,23 @@ int ssac_xchg_error(ssac_xchg *x);   /* 1: a peer's flag did not arrive within t
                                         was poisoned with NaN); a pinned host word, cleared by the read, no synchronisation */
 void ssac_xchg_destroy(ssac_xchg *x);
 
+/* ---- prioritised replay on the device (replaces super_sac/replay.py:140-190 sample / update_priorities and the
+ * SumSegmentTree / MinSegmentTree of :207-353).  sum_tree / min_tree: float64 [2 cap], implicit heaps over cap = next
+ * power of two >= capacity (replay.py:147-152), root at 1, leaves at [cap, 2 cap).
+ * ssac_per_assign: leaves[rows] = prio^alpha (prio NULL: the current *max_priority, replay.py:156-161 push) and every
+ * ancestor re-derived; a row named twice takes the LAST entry (numpy fancy assignment); update_max: also
+ * *max_priority = max(*max_priority, max(prio)) and rows must be < n_filled (replay.py:183-190).  Violations of the
+ * reference's assertions (priority <= 0 -> 1, row out of range -> 2) are written to the pinned host word and raised
+ * by the Python layer at its next call.  winner_scratch: int32 [cap], all -1 between calls.
+ * ssac_per_sample: mass_b = u_b * sum(0, n_filled - 1) in the reference's association order (replay.py:163-168,
+ * 229-258), prefix-sum descent (:297-336), w_b = (p_b n)^-beta / max_weight (:171-177).  u: the B float64 uniforms the
+ * host drew from numpy's global generator. */
+int ssac_per_assign(double *sum_tree, double *min_tree, int64_t cap, const int64_t *rows, int n, const void *prio,
+                    int prio_is_f64, double alpha, double *max_priority, int update_max, int64_t n_filled,
+                    int *err_host_word, int32_t *winner_scratch, void *stream);
+int ssac_per_sample(const double *sum_tree, const double *min_tree, int64_t cap, int64_t n_filled, const double *u,
+                    int n_draws, double beta, int64_t *idx_out, double *weights_out, void *stream);
+
 /* floats per net and the six segment offsets {W1,b1,W2,b2,W3,b3}. */
 int64_t ssac_mlp_layout(int in_dim, int hidden, int out_dim, int64_t offsets[6]);
 

@@ -97,6 +97,8 @@ SIGNATURES = {
     "ssac_xchg_connect": [_P, _P],
     "ssac_xchg_reduce": [_P, _P, _I, _I, _P],
     "ssac_xchg_reduce_owned": [_P, _P, _I, _P, _I, _P],
+    "ssac_per_assign": [_P, _P, _L, _P, _I, _P, _I, C.c_double, _P, _I, _L, _P, _P, _P],
+    "ssac_per_sample": [_P, _P, _L, _L, _P, _I, C.c_double, _P, _P, _P],
     "ssac_xchg_error": [_P],
     "ssac_xchg_destroy": [_P],
     "ssac_step_create": [_P, _I, _I, _I, _I, _I, _I, _I, _I],

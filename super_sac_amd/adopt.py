@@ -164,13 +164,13 @@ def adopt_buffer(buffer, device=None):
             f"{type(buffer).__name__} is neither a super_sac_amd.replay.ReplayBuffer nor a reference ReplayBuffer "
             f"(replay.py:140-190; missing {missing}).  Build the buffer after `super_sac_amd.install(super_sac)` -- "
             "it rebinds super_sac.replay.ReplayBuffer -- or pass a super_sac_amd.replay.ReplayBuffer.")
-    dev = torch.device(device) if device is not None else default_device
+    dev = torch.device(device) if device is not None else torch.device(default_device)
     old = buffer._storage
-    per = R.PrioritySampler(buffer._maxsize, buffer.alpha, buffer.beta)
+    per = (R.DevicePrioritySampler(buffer._maxsize, buffer.alpha, buffer.beta, dev) if dev.type == "cuda"
+           else R.PrioritySampler(buffer._maxsize, buffer.alpha, buffer.beta))
     sum_v, min_v = np.asarray(buffer._it_sum._value, np.float64), np.asarray(buffer._it_min._value, np.float64)
-    assert sum_v.shape == per.sum_tree.shape == min_v.shape, "segment trees of an unexpected capacity"
-    per.sum_tree[:], per.min_tree[:] = sum_v, min_v
-    per._max_priority = float(buffer._max_priority)
+    assert sum_v.shape == (2 * per.cap,) == min_v.shape, "segment trees of an unexpected capacity"
+    per.load_state(sum_v, min_v, float(buffer._max_priority))
     storage = None
     if old is not None:
         n = int(old._max_filled)

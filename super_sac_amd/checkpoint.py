@@ -68,9 +68,7 @@ def load_buffer_state(buffer, state):
     from .replay import ReplayBufferStorage, _IndexStager
     assert state["maxsize"] == buffer._maxsize, "checkpointed buffer has a different capacity"
     buffer.total_sample_calls = state["total_sample_calls"]
-    buffer._per.sum_tree[:] = state["per"]["sum"]
-    buffer._per.min_tree[:] = state["per"]["min"]
-    buffer._per._max_priority = state["per"]["max_priority"]
+    buffer._per.load_state(state["per"]["sum"], state["per"]["min"], state["per"]["max_priority"])
     s = state["storage"]
     if s is None:
         return

@@ -302,6 +302,11 @@ def gather_struct(bt):
     return g
 
 
+def _host_view(idx):
+    """replay_dict["priority_idxs"]: numpy for a host-drawn index vector, the lazy host view of a device-drawn one"""
+    return idx.numpy() if torch.is_tensor(idx) else idx
+
+
 def sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, per=True, _defer_gather=False,
                             _invariance=False):
     assert len(buffer) >= batch_size
@@ -314,9 +319,10 @@ def sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, per=True, _d
     st = buffer._storage
     dev = st.device
     if per:
-        # replay.py:163-177: numpy-global-RNG mass draw + float64 sum/min trees on the host, gather on the device
+        # replay.py:163-177: the uniforms from numpy's global generator on the host; total mass, prefix-sum descent and
+        # importance weights on the float64 trees in HBM (csrc/ssac_per.hip) -- no synchronisation
         idx_cpu, idx, w = buffer.draw_per_indices(batch_size)
-        imp_weights = torch.from_numpy(w).to(dev)  # float64 (B,), as the reference hands it over
+        imp_weights = w if torch.is_tensor(w) else torch.from_numpy(w).to(dev)  # float64 (B,), as the reference hands it over
     else:
         idx_cpu, idx = buffer.draw_uniform_indices(batch_size)
         imp_weights = unit_weight(dev)
@@ -399,9 +405,9 @@ def sample_move_and_augment(buffer, batch_size, augmenter, aug_mix, per=True, _d
         inv_obs = ((o, None), (o, None))   # identity augmentation: augmented == original == the batch
     if _invariance:
         return {"primary_batch": (o, a, r, o1, d), "augmented_obs": inv_obs[0], "original_obs": inv_obs[1],
-                "priority_idxs": idx_cpu.numpy(), "imp_weights": imp_weights, "_ssac": bt}
+                "priority_idxs": _host_view(idx_cpu), "imp_weights": imp_weights, "_ssac": bt}
     return {"primary_batch": (o, a, r, o1, d), "augmented_obs": None, "original_obs": None,
-            "priority_idxs": idx_cpu.numpy(), "imp_weights": imp_weights, "_ssac": bt}
+            "priority_idxs": _host_view(idx_cpu), "imp_weights": imp_weights, "_ssac": bt}
 
 
 # ------------------------------------------------------------------------------------------
@@ -856,7 +862,11 @@ def adjust_priorities(logs, replay_dict, agent, buffer):
     o, a = replay_dict["primary_batch"][0], replay_dict["primary_batch"][1]
     member = rng.choice(range(agent.ensemble_size))
     res = agent.adv_estimator.evaluate(o, a, member, want=("prio",))
-    new_priorities = res["prio"].cpu().numpy()  # the reference blocks here too (.cpu(), learning_utils.py:293)
+    # (the reference blocks here, .cpu() in learning_utils.py:293; with the trees in HBM the new priorities and the
+    # indices they belong to never leave the device)
+    new_priorities = res["prio"].reshape(-1)
+    if not getattr(buffer, "per_on_device", False):
+        new_priorities = new_priorities.cpu().numpy()
     buffer.update_priorities(replay_dict["priority_idxs"], new_priorities)
 
 

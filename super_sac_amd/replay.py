@@ -93,6 +93,10 @@ class PrioritySampler:
         self._assign(idxes, priorities ** self.alpha)
         self._max_priority = max(self._max_priority, float(np.max(priorities)))
 
+    def load_state(self, sum_tree, min_tree, max_priority):
+        self.sum_tree[:], self.min_tree[:] = sum_tree, min_tree
+        self._max_priority = float(max_priority)
+
     def _range_sum(self, start, end_exclusive):
         return float(self.sum_tree[self.cap + start: self.cap + end_exclusive].sum())
 
@@ -121,6 +125,147 @@ class PrioritySampler:
         p_sample = self.sum_tree[self.cap + idx] / self.sum_tree[1]
         weights = (p_sample * n_filled) ** (-self.beta) / max_weight
         return idx, weights
+
+
+class LazyHost:
+    """a device tensor that turns into a numpy array when somebody looks at it (``np.asarray``, indexing, ``len``):
+    the indices / weights of a prioritised draw stay on the device along the update path and only cost a
+    synchronisation where a caller really reads them on the host (the reference hands out numpy arrays, replay.py:177)"""
+
+    def __init__(self, dev_tensor):
+        self.dev = dev_tensor
+        self._np = None
+
+    def numpy(self):
+        if self._np is None:
+            self._np = self.dev.cpu().numpy()
+        return self._np
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __len__(self):
+        return self.dev.shape[0]
+
+    def __getitem__(self, k):
+        return self.numpy()[k]
+
+    def __iter__(self):
+        return iter(self.numpy())
+
+    @property
+    def shape(self):
+        return tuple(self.dev.shape)
+
+
+class DevicePrioritySampler:
+    """PrioritySampler with the trees in HBM (csrc/ssac_per.hip): same layout, same arithmetic (float64), the draw
+    still consumes numpy's GLOBAL generator on the host (replay.py:166) -- B uniforms travel up, nothing comes back.
+    ``update_priorities`` takes device tensors (or numpy arrays) and returns without a synchronisation; the reference's
+    assertions on the priorities (replay.py:183-187) are evaluated by the kernel and raised at the next call."""
+
+    def __init__(self, capacity, alpha=0.6, beta=1.0, device=None):
+        cap = 1
+        while cap < capacity:
+            cap *= 2
+        self.cap, self.alpha, self.beta, self.device = cap, float(alpha), float(beta), device
+        self.sum_dev = torch.zeros(2 * cap, dtype=torch.float64, device=device)
+        self.min_dev = torch.full((2 * cap,), float("inf"), dtype=torch.float64, device=device)
+        self.max_dev = torch.ones(1, dtype=torch.float64, device=device)
+        self.win = torch.full((cap,), -1, dtype=torch.int32, device=device)
+        self.err = torch.zeros(16, dtype=torch.int32).pin_memory()
+        self._u_ring, self._u_k, self._u_ev = [None] * 4, 0, [None] * 4
+
+    # ---- host views (checkpoints, tests): a synchronising copy
+    @property
+    def sum_tree(self):
+        return self.sum_dev.cpu().numpy()
+
+    @property
+    def min_tree(self):
+        return self.min_dev.cpu().numpy()
+
+    @property
+    def _max_priority(self):
+        return float(self.max_dev.cpu()[0])
+
+    def load_state(self, sum_tree, min_tree, max_priority):
+        self.sum_dev.copy_(torch.from_numpy(np.ascontiguousarray(sum_tree, np.float64)))
+        self.min_dev.copy_(torch.from_numpy(np.ascontiguousarray(min_tree, np.float64)))
+        self.max_dev.fill_(float(max_priority))
+
+    def _raise_pending(self):
+        code = int(self.err[0])
+        if code:
+            self.err[0] = 0
+            # (the reference asserts synchronously, replay.py:183-187; here the kernel found it one call ago)
+            raise AssertionError("update_priorities: " + ("a priority <= 0" if code == 1 else "an index outside the filled rows"))
+
+    def _dev_i64(self, rows):
+        if isinstance(rows, LazyHost):
+            return rows.dev
+        if torch.is_tensor(rows):
+            return rows.to(device=self.device, dtype=torch.int64).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(np.atleast_1d(np.asarray(rows)), np.int64)).to(self.device)
+
+    def _assign(self, rows, prio, update_max, n_filled):
+        rows_d = self._dev_i64(rows)
+        n = rows_d.numel()
+        pptr, f64 = 0, 0
+        if prio is not None:
+            if isinstance(prio, LazyHost):
+                prio = prio.dev
+            if not torch.is_tensor(prio):
+                prio = torch.from_numpy(np.broadcast_to(np.asarray(prio, np.float64), (n,)).copy())
+            prio = prio.to(self.device).reshape(-1).contiguous()
+            assert prio.numel() == n
+            if prio.dtype not in (torch.float32, torch.float64):
+                prio = prio.to(torch.float64)
+            pptr, f64 = prio.data_ptr(), 1 if prio.dtype == torch.float64 else 0
+        check(lib.ssac_per_assign(self.sum_dev.data_ptr(), self.min_dev.data_ptr(), self.cap, rows_d.data_ptr(), n, pptr,
+                                  f64, self.alpha, self.max_dev.data_ptr(), 1 if update_max else 0, int(n_filled),
+                                  self.err.data_ptr(), self.win.data_ptr(), engine.stream()))
+        self._keep = (rows_d, prio)
+
+    def push_rows(self, rows, priorities=None):
+        self._raise_pending()
+        self._assign(rows, priorities, False, self.cap)
+
+    def update_priorities(self, idxes, priorities, n_filled):
+        self._raise_pending()
+        assert len(idxes) == len(priorities)
+        if not torch.is_tensor(priorities) and not isinstance(priorities, LazyHost):
+            # host arrays: the reference's assertions, synchronously, as it makes them (replay.py:183-187)
+            priorities = np.asarray(priorities, dtype=np.float64)
+            assert np.min(priorities) > 0
+            if not torch.is_tensor(idxes) and not isinstance(idxes, LazyHost):
+                assert np.min(idxes) >= 0
+                assert np.max(idxes) < n_filled
+        self._assign(idxes, priorities, True, n_filled)
+
+    def sample_device(self, n_filled, batch_size):
+        """(int64 indices, float64 weights) on the device; the uniforms come from numpy's global generator"""
+        self._raise_pending()
+        u = np.random.random(size=batch_size)
+        k = self._u_k = (self._u_k + 1) % 4
+        if self._u_ev[k] is not None:
+            self._u_ev[k].synchronize()
+        if self._u_ring[k] is None or self._u_ring[k].numel() < batch_size:
+            self._u_ring[k] = torch.empty(max(batch_size, 1024), dtype=torch.float64).pin_memory()
+        self._u_ring[k][:batch_size].copy_(torch.from_numpy(u))
+        u_dev = self._u_ring[k][:batch_size].to(self.device, non_blocking=True)
+        self._u_ev[k] = ev = torch.cuda.Event()
+        ev.record()
+        idx = torch.empty(batch_size, dtype=torch.int64, device=self.device)
+        w = torch.empty(batch_size, dtype=torch.float64, device=self.device)
+        check(lib.ssac_per_sample(self.sum_dev.data_ptr(), self.min_dev.data_ptr(), self.cap, int(n_filled),
+                                  u_dev.data_ptr(), batch_size, self.beta, idx.data_ptr(), w.data_ptr(), engine.stream()))
+        return idx, w
+
+    def sample(self, n_filled, batch_size):
+        idx, w = self.sample_device(n_filled, batch_size)
+        return idx.cpu().numpy(), w.cpu().numpy()
 
 
 class _PinnedRing:
@@ -260,7 +405,11 @@ class ReplayBuffer:
         self.total_sample_calls = 0
         self.device = torch.device(device) if device is not None else _default_device
         self._stager = None
-        self._per = PrioritySampler(size, alpha, beta)
+        # prioritised sampling: trees in HBM on a GPU (csrc/ssac_per.hip); the float64 host trees (PrioritySampler) are
+        # what a CPU-resident buffer uses and what the tests check the device trees against
+        dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
+        self._per = (DevicePrioritySampler(size, alpha, beta, dev) if dev.type == "cuda"
+                     else PrioritySampler(size, alpha, beta))
 
     def __len__(self):
         return len(self._storage) if self._storage is not None else 0
@@ -300,10 +449,14 @@ class ReplayBuffer:
         return idx, self._stager.upload(idx)
 
     def draw_per_indices(self, batch_size):
-        """prioritised draw of replay.py:163-177 without the gather: (cpu int64 indices, device indices,
-        float64 importance weights)."""
+        """prioritised draw of replay.py:163-177 without the gather: (host view of the int64 indices, device indices,
+        float64 importance weights).  With the trees on the device nothing synchronises: the host view is lazy and the
+        weights are a device tensor."""
         assert self._per is not None, "this buffer was built without prioritised sampling"
         self.total_sample_calls += 1
+        if isinstance(self._per, DevicePrioritySampler):
+            idx_dev, w_dev = self._per.sample_device(len(self._storage), batch_size)
+            return LazyHost(idx_dev), idx_dev, w_dev
         idxes, weights = self._per.sample(len(self._storage), batch_size)
         idx = torch.from_numpy(idxes)
         return idx, self._stager.upload(idx), weights
@@ -326,9 +479,16 @@ class ReplayBuffer:
     def sample(self, batch_size):
         """prioritised draw (replay.py:171-177): (batch, float64 importance weights, indices)."""
         self.total_sample_calls += 1
+        if isinstance(self._per, DevicePrioritySampler):
+            idx_dev, w_dev = self._per.sample_device(len(self._storage), batch_size)
+            return self.gather(idx_dev, batch_size), w_dev.cpu(), idx_dev.cpu().numpy()
         idxes, weights = self._per.sample(len(self._storage), batch_size)
         idx_dev = self._stager.upload(torch.from_numpy(idxes))
         return self.gather(idx_dev, batch_size), torch.from_numpy(weights), idxes
+
+    @property
+    def per_on_device(self):
+        return isinstance(self._per, DevicePrioritySampler)
 
     def update_priorities(self, idxes, priorities):
         self._per.update_priorities(idxes, priorities, len(self._storage))

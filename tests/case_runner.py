@@ -593,7 +593,11 @@ def run_afbc_engine(name, device="cuda"):
             orig_upd = buf.update_priorities
 
             def spy(idxes, prios, _seen=seen, _orig=orig_upd):
-                _seen["idx"], _seen["prio"] = np.asarray(idxes).copy(), np.asarray(prios, np.float64).copy()
+                if torch.is_tensor(prios):   # (trees in HBM: indices and priorities arrive as device data)
+                    prios_h = prios.detach().cpu().numpy().astype(np.float64)
+                else:
+                    prios_h = np.asarray(prios, np.float64).copy()
+                _seen["idx"], _seen["prio"] = np.asarray(idxes).copy(), prios_h
                 return _orig(idxes, prios)
             if step == "critic":
                 player.idx.append(fx[f"s{k}_idx"])

@@ -1171,3 +1171,80 @@ def test_chain_launch_equals_the_separate_launches(ssa, B, N, H):
     for a_, b_, what in ((xa, xb, "a'"), (lpa, lpb, "log pi"), (h1, g1, "h1"), (h2, g2, "h2"), (q, gq, "q"),
                          (qt, gt_, "target q"), (dz2, gz2, "dz2u"), (dz1, gz1, "dz1u")):
         assert torch.equal(a_, b_), f"chained launch differs in {what}"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# prioritised replay on the device (csrc/ssac_per.hip) against the float64 host trees (replay.PrioritySampler), which
+# tests/test_oracle_golden.py pins to the reference's draws (tests/golden/per.npz)
+# ---------------------------------------------------------------------------------------------------------------------
+def _reduce_helper(v, start, end, node, ns, ne):
+    """SegmentTree._reduce_helper restated (replay.py:229-243): the reference's own association order of a range sum"""
+    if start == ns and end == ne:
+        return v[node]
+    mid = (ns + ne) // 2
+    if end <= mid:
+        return _reduce_helper(v, start, end, 2 * node, ns, mid)
+    if mid + 1 <= start:
+        return _reduce_helper(v, start, end, 2 * node + 1, mid + 1, ne)
+    return _reduce_helper(v, start, mid, 2 * node, ns, mid) + _reduce_helper(v, mid + 1, end, 2 * node + 1, mid + 1, ne)
+
+
+@pytest.mark.parametrize("capacity,n_filled", [(400, 333), (1000, 1000), (5000, 2), (100_000, 77_777)])
+def test_device_priority_trees_match_the_host_trees(ssa, capacity, n_filled):
+    from super_sac_amd.replay import DevicePrioritySampler, PrioritySampler
+    rs = np.random.RandomState(capacity)
+    host, dev = PrioritySampler(capacity, 0.6, 0.9), DevicePrioritySampler(capacity, 0.6, 0.9, torch.device(DEV))
+    rows = np.arange(n_filled)
+    host.push_rows(rows)                       # every pushed row at max priority (replay.py:156-161): a bulk load
+    dev.push_rows(rows)
+    for rnd in range(6):
+        B = [1, 7, 256, 512, 1024, 3000][rnd]
+        idx = rs.randint(0, n_filled, size=B)
+        if B >= 256:
+            idx[5:40] = idx[3]                 # rows named many times: the LAST entry wins, as in numpy
+        prio = (rs.rand(B) * 3 + 1e-3).astype(np.float32)
+        host.update_priorities(idx, prio.astype(np.float64), n_filled)
+        if rnd % 2:
+            dev.update_priorities(torch.from_numpy(idx).to(DEV), torch.from_numpy(prio).to(DEV), n_filled)  # device data
+        else:
+            dev.update_priorities(idx, prio.astype(np.float64), n_filled)                                  # host arrays
+        torch.cuda.synchronize()
+        # pow(p, alpha) of the device library vs numpy's: equal to the last bit or one ulp off; sums of those above
+        np.testing.assert_allclose(dev.sum_tree, host.sum_tree, rtol=4e-16, atol=0)
+        np.testing.assert_allclose(dev.min_tree, host.min_tree, rtol=4e-16, atol=0)
+        assert dev._max_priority == host._max_priority
+        # the draw: same uniforms -> same indices, weights to float64 round-off
+        if n_filled >= 2:
+            np.random.seed(100 + rnd)
+            want_idx, want_w = host.sample(n_filled, 512)
+            np.random.seed(100 + rnd)
+            got_idx, got_w = dev.sample(n_filled, 512)
+            assert np.array_equal(got_idx, want_idx) and got_idx.dtype == np.int64
+            np.testing.assert_allclose(got_w, want_w, rtol=1e-13)
+    # total mass in the REFERENCE's association order (what the kernel evaluates), checked on the device trees
+    tree = dev.sum_tree
+    total_ref = _reduce_helper(tree, 0, n_filled - 2, 1, 0, dev.cap - 1)
+    u = torch.full((4,), 1.0, dtype=torch.float64, device=DEV)   # mass = total exactly -> descends to the range's end
+    idx = torch.empty(4, dtype=torch.int64, device=DEV)
+    w = torch.empty(4, dtype=torch.float64, device=DEV)
+    ssa._lib.check(ssa._lib.lib.ssac_per_sample(dev.sum_dev.data_ptr(), dev.min_dev.data_ptr(), dev.cap, n_filled,
+                                                u.data_ptr(), 4, 0.9, idx.data_ptr(), w.data_ptr(), ssa.engine.stream()))
+    # descending with mass = sum(leaves[0 .. n-2]) lands on leaf n-1 (prefix sums <= mass up to there), or n-2 when
+    # rounding in the two different association orders leaves mass a hair short
+    assert int(idx[0]) in (n_filled - 1, n_filled - 2), (int(idx[0]), n_filled, total_ref)
+
+
+def test_device_priority_refresh_reports_what_the_reference_asserts(ssa):
+    from super_sac_amd.replay import DevicePrioritySampler
+    dev = DevicePrioritySampler(64, 0.6, 1.0, torch.device(DEV))
+    dev.push_rows(np.arange(40))
+    dev.update_priorities(torch.tensor([1, 2, 3], device=DEV), torch.tensor([0.5, 0.0, 1.0], device=DEV), 40)
+    torch.cuda.synchronize()
+    with pytest.raises(AssertionError, match="priority <= 0"):
+        dev.update_priorities(torch.tensor([1], device=DEV), torch.tensor([0.5], device=DEV), 40)
+    dev.update_priorities(torch.tensor([45], device=DEV), torch.tensor([0.5], device=DEV), 40)
+    torch.cuda.synchronize()
+    with pytest.raises(AssertionError, match="outside the filled rows"):
+        dev.push_rows(np.arange(2))
+    with pytest.raises(AssertionError):
+        dev.update_priorities(np.array([1, 2]), np.array([1.0, -1.0]), 40)   # host arrays: synchronously, as the reference

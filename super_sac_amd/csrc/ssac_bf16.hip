@@ -15,6 +15,7 @@
 //   Bp = batch rounded up to 16; the pad columns are zero (buffers are allocated zeroed and never written there).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <algorithm>
 #include <stdint.h>
 
 #include "ssac_internal.h"
@@ -446,6 +447,146 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
     BSTAMP(9);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Large-batch ensemble-Q forward (single-output critics, SURVEY 8(d)'s B = 4 096 ... 65 536 rows of the kernel).
+// bf_mlp_body gives every 32-row tile its own workgroup, and every workgroup fetches its net's whole weight slab
+// (W1 + W2: ~140 KB of bf16) from L2 for 32 rows of work: ~128 B / clk / CU of operand demand against a 64 B / clk L2
+// port -- 0.07 of the bf16 matrix peak however large the batch.  Here a workgroup is PERSISTENT over row tiles: each
+// wave loads the fragments of its 32 output features ONCE (fc1: NS1 K-steps, fc2: 16 -- they stay in registers) and
+// then streams 64-row tiles through them, two MFMAs per fragment (rows 0-31 / 32-63 of the tile share it), the next
+// tile's rows in flight while the current one is multiplied.  Per tile the chip-side traffic is the tile's own rows
+// in and its Q values out.
+template <int NS1>
+__global__ __launch_bounds__(NTHR) void bf_stream_kernel(BfArgs g, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int TS = 64;
+    const int H = g.hidden, IN = g.in_dim, K1P = g.sg.k1p;
+    const int ldx_s = K1P + LPAD, ldh = H + LPAD;
+    unsigned short *xs = reinterpret_cast<unsigned short *>(smem);
+    unsigned short *h1s = xs + TS * ldx_s;
+    unsigned short *h2s = h1s + TS * ldh;
+    float *b1s = reinterpret_cast<float *>(h2s + TS * ldh);
+    float *b2s = b1s + H, *w3f = b2s + H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int e = blockIdx.y;
+    const int net = g.ids ? g.ids[e] : e;
+    if (net < 0) {   // empty subset slot of a sharded rank
+        for (int64_t i = blockIdx.x * (int64_t)NTHR + tid; i < g.n_rows; i += (int64_t)gridDim.x * NTHR)
+            g.Y[(int64_t)e * g.n_rows + i] = __builtin_inff();
+        return;
+    }
+    const float *P = g.params + (int64_t)net * g.net_stride;
+    const unsigned short *S = g.shadow + (int64_t)net * g.sg.stride;
+    const int col0 = wave * 32;
+    const bool wave_on = col0 < H;
+    const int c0 = wave_on ? col0 : 0, n_me = col0 + li;
+    const int ns1 = K1P >> 4, nsh = H >> 4;
+    // ---- the wave's weight fragments, once
+    u16x8 w1[NS1], w2[16];
+    {
+        const unsigned short *wp1 = S + g.sg.o1 + frag_off(ns1, c0 + li, 8 * lh);
+        const unsigned short *wp2 = S + g.sg.o2 + frag_off(nsh, c0 + li, 8 * lh);
+#pragma unroll
+        for (int t = 0; t < NS1; ++t) w1[t] = *reinterpret_cast<const u16x8 *>(wp1 + FRAG_STEP * (t < ns1 ? t : ns1 - 1));
+#pragma unroll
+        for (int t = 0; t < 16; ++t) w2[t] = *reinterpret_cast<const u16x8 *>(wp2 + FRAG_STEP * (t < nsh ? t : nsh - 1));
+    }
+    if (tid < H) { b1s[tid] = P[g.off[1] + tid]; b2s[tid] = P[g.off[3] + tid]; w3f[tid] = bf2f(S[g.sg.o3 + tid]); }
+    const float b3 = P[g.off[5]];
+    // ---- x staging: thread -> row tid >> 3 (64 rows), columns (tid & 7) + 8 u: XV values per thread per tile
+    constexpr int XV = NS1 * 2;            // K1P / 8
+    const int xr = tid >> 3, xl = tid & 7;
+    float xv[XV];
+    auto load_x = [&](int tile) {
+        const int row = tile * TS + xr;
+        const bool rok = tile < tiles && row < g.n_rows;
+        const float *src = g.X + (int64_t)(rok ? row : 0) * g.ldx;
+#pragma unroll
+        for (int u = 0; u < XV; ++u) {
+            const int k = xl + 8 * u;
+            const bool ok = rok && k < IN;
+            xv[u] = src[ok ? k : 0];
+            if (!ok) xv[u] = 0.0f;
+        }
+    };
+    int tile = blockIdx.x;
+    load_x(tile);
+    for (; tile < tiles; tile += gridDim.x) {
+        const int m0 = tile * TS;
+        // (the previous tile's head has read h2s / its fc1 has read xs: the barrier at the end of the loop body)
+#pragma unroll
+        for (int u = 0; u < XV; ++u) {
+            const int k = xl + 8 * u;
+            if (k < K1P) xs[xr * ldx_s + k] = f2bf(xv[u]);
+        }
+        load_x(tile + gridDim.x);          // next tile's rows travel under this tile's matrix work
+        lds_barrier();
+        f32x16 a0, a1;
+        // ---- fc1
+        zero_acc(a0); zero_acc(a1);
+#pragma unroll
+        for (int t = 0; t < NS1; ++t) {
+            if (t < ns1) {
+                const bf16x8 w = __builtin_bit_cast(bf16x8, w1[t]);
+                const u16x8 x0 = *reinterpret_cast<const u16x8 *>(xs + li * ldx_s + 8 * lh + 16 * t);
+                const u16x8 x1 = *reinterpret_cast<const u16x8 *>(xs + (32 + li) * ldx_s + 8 * lh + 16 * t);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x0), w, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x1), w, a1, 0, 0, 0);
+            }
+        }
+        if (wave_on) {
+            // (2-byte scattered stores: swapping one value per row pair with the neighbouring lane through a DPP quad
+            // permute to store 4 bytes measured slower, 178 vs 156 us at B 65 536 -- the selects cost more than the
+            // 16 store instructions saved)
+            const float bias = b1s[n_me];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                h1s[b * ldh + n_me] = f2bf(fmaxf(a0[r] + bias, 0.0f));
+                h1s[(32 + b) * ldh + n_me] = f2bf(fmaxf(a1[r] + bias, 0.0f));
+            }
+        }
+        lds_barrier();
+        // ---- fc2
+        zero_acc(a0); zero_acc(a1);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (t < nsh) {
+                const bf16x8 w = __builtin_bit_cast(bf16x8, w2[t]);
+                const u16x8 x0 = *reinterpret_cast<const u16x8 *>(h1s + li * ldh + 8 * lh + 16 * t);
+                const u16x8 x1 = *reinterpret_cast<const u16x8 *>(h1s + (32 + li) * ldh + 8 * lh + 16 * t);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x0), w, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x1), w, a1, 0, 0, 0);
+            }
+        }
+        if (wave_on) {
+            const float bias = b2s[n_me];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                h2s[b * ldh + n_me] = f2bf(fmaxf(a0[r] + bias, 0.0f));
+                h2s[(32 + b) * ldh + n_me] = f2bf(fmaxf(a1[r] + bias, 0.0f));
+            }
+        }
+        lds_barrier();
+        // ---- head: 8 lanes per row, fp32 dot product of the bf16 operands (the same products, k-order and shuffle
+        //      tree aside, as bf_mlp_body's single-output head)
+        {
+            float sacc = 0.0f;
+            for (int k = xl * 8; k < H; k += 64) {
+                const u16x8 hv = *reinterpret_cast<const u16x8 *>(h2s + xr * ldh + k);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sacc += bf2f(hv[u]) * w3f[k + u];
+            }
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+            if (xl == 0 && (m0 + xr) < g.n_rows) g.Y[(int64_t)e * g.n_rows + m0 + xr] = sacc + b3;
+        }
+        // (no barrier here: the next tile's xs stores follow this tile's fc1 reads by two barriers, and its h2s stores
+        //  come behind two MORE barriers that no wave passes before it has left this head)
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(NTHR) void bf_mlp_kernel(BfArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -874,6 +1015,23 @@ extern "C" int ssac_bf16_mlp3_fwd(const ssac_mlp *nets, const uint16_t *shadow, 
     BfArgs g{};
     bf_fill(g, nets, shadow, net_ids, X, ldx, n_rows);
     g.Y = Y;
+    // large batches of single-output critics: persistent workgroups that keep their weight fragments (bf_stream_kernel)
+    const int tiles64 = (n_rows + 63) / 64;
+    if (nets->out_dim == 1 && Y && g.sg.k1p <= 64 && tiles64 * n_sel >= 512) {
+        const size_t lds_s = 2 * (64 * (size_t)(g.sg.k1p + LPAD) + 2 * 64 * (size_t)(nets->hidden + LPAD)) + 4 * 3 * (size_t)nets->hidden + 64;
+        // one resident workgroup per CU (the fragments + two accumulators + the fragment reads in flight take ~200
+        // registers; held to 128 for two workgroups per CU the kernel spills and runs 3x slower)
+        const int per_net = std::max(1, std::min(tiles64, 256 / n_sel));
+        static bool a2 = false, a4 = false;
+        if (g.sg.k1p <= 32) {
+            if (raise_lds(bf_stream_kernel<2>, a2)) return 1;
+            SSAC_LAUNCH(bf_stream_kernel<2>, dim3(per_net, n_sel), dim3(NTHR), lds_s, (hipStream_t)stream, g, tiles64);
+        } else {
+            if (raise_lds(bf_stream_kernel<4>, a4)) return 1;
+            SSAC_LAUNCH(bf_stream_kernel<4>, dim3(per_net, n_sel), dim3(NTHR), lds_s, (hipStream_t)stream, g, tiles64);
+        }
+        return ssac_check_launch("bf16_mlp3_fwd (stream)");
+    }
     static bool attr = false;
     if (raise_lds(bf_mlp_kernel<MODE_PLAIN>, attr)) return 1;
     const size_t lds = bf_lds_bytes(nets->in_dim, nets->hidden, nets->out_dim);

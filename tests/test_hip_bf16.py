@@ -105,6 +105,39 @@ def test_ensemble_q_forward_matches_bf16_emulation(in_dim, hidden, out_dim, B):
     assert float((y - y32).abs().max()) <= 4e-2 * float(y32.abs().max()) + 1e-3
 
 
+@pytest.mark.parametrize("in_dim,B", [(23, 8192 + 37), (23, 65536), (56, 20000)])
+def test_large_batch_ensemble_q_streaming_kernel(in_dim, B):
+    """batches of >= 512 row tiles x nets take the persistent streaming kernel (weight fragments stay in registers, 64-row
+    tiles): against the bf16 emulation, against the per-tile kernel on the same rows, ragged last tile, a net list with
+    an empty (-1) slot"""
+    from super_sac_amd import engine
+    from super_sac_amd._lib import check, lib
+    N = 10
+    ar = _arena(N, in_dim, 256, 1, seed=2).enable_bf16()
+    x = torch.randn(B, in_dim, device="cuda")
+    sel = [3, -1, 0, 9, 5, 1, 2, 8]
+    ids = torch.tensor(sel, dtype=torch.int32, device="cuda")
+    y = torch.zeros(len(sel), B, 1, device="cuda")
+    check(lib.ssac_bf16_mlp3_fwd(C.byref(ar.desc()), ar.shadow.data_ptr(), ids.data_ptr(), len(sel), x.data_ptr(), in_dim,
+                                 B, y.data_ptr(), engine.stream()))
+    y_tile = torch.zeros_like(y)
+    for b0 in range(0, B, 1024):   # calls of <= 1024 rows stay on the per-tile kernel
+        n = min(1024, B - b0)
+        part = torch.zeros(len(sel), n, 1, device="cuda")
+        check(lib.ssac_bf16_mlp3_fwd(C.byref(ar.desc()), ar.shadow.data_ptr(), ids.data_ptr(), len(sel),
+                                     x[b0:b0 + n].data_ptr(), in_dim, n, part.data_ptr(), engine.stream()))
+        y_tile[:, b0:b0 + n] = part
+    torch.cuda.synchronize()
+    assert torch.isinf(y[1]).all() and (y[1] > 0).all()
+    live = [e for e, j in enumerate(sel) if j >= 0]
+    # same bf16 operands, same fp32 products; summation order of the head differs (8 vs 16 lanes per row)
+    assert float((y[live] - y_tile[live]).abs().max()) <= 1e-6 * max(1.0, float(y_tile[live].abs().max()))
+    for e in live[:3]:
+        ref = _emulate(ar, sel[e], x[:4096])
+        tol = 4e-3 * float(ref.abs().max()) + 1e-4
+        assert float((y[e, :4096] - ref).abs().max()) <= tol
+
+
 def test_empty_subset_slot_is_plus_infinity():
     from super_sac_amd import engine
     from super_sac_amd._lib import check, lib

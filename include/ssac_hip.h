@@ -836,8 +836,12 @@ int ssac_bf16_chain_update(const ssac_mlp *actor, const uint16_t *actor_shadow, 
 int ssac_bf16_wgrad_tiles(const ssac_mlp *nets);
 int ssac_bf16_wgrad_lossfold(const ssac_mlp *nets, uint16_t *shadow, const uint16_t *XT, const uint16_t *H1T,
                              const uint16_t *H2T, const uint16_t *DZ2uT, const uint16_t *DZ1uT, const float *Q,
-                             const float *td, const ssac_td_spec *lazy_td, const float *weight, float denom,
+                             const float *td, const ssac_td_spec *lazy_td, const float *weight,
+                             const ssac_popart *popart /* nullable */, int pop, float denom,
                              float *partials, int n_rows, float *adam_m, float *adam_v, const ssac_adam_ctl *ctl,
+                             float *grads /* != NULL: store the fp32 gradients there (arena layout), update nothing:
+                                             the clip_grad_norm_ path, followed by ssac_clip_coef + ssac_adam_step +
+                                             ssac_bf16_sync */,
                              float *sumsq, int64_t sumsq_net_stride, float *target, uint16_t *target_shadow, float tau,
                              const ssac_logfold *logfold, void *stream);
 

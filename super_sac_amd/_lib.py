@@ -221,8 +221,8 @@ SIGNATURES = {
     "ssac_bf16_chain_update": [_MP, _P, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _P, _I, _P, _MP, _P, _P, _L,
                                _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ssac_bf16_wgrad_tiles": [_MP],
-    "ssac_bf16_wgrad_lossfold": [_MP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P, _L, _P, _P, _F,
-                                 _P, _P],
+    "ssac_bf16_wgrad_lossfold": [_MP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _I, _P, _P, _P, _P, _P, _L,
+                                 _P, _P, _F, _P, _P],
 }
 _RESTYPES = {"ssac_xchg_create": C.c_void_p, "ssac_xchg_destroy": None, "ssac_step_create": C.c_void_p, "ssac_step_count": C.c_int64, "ssac_step_destroy": None,
              "ssac_last_error": C.c_char_p, "ssac_mlp_layout": C.c_int64, "ssac_bf16_layout": C.c_int64, "ssac_record_end": C.c_void_p,

@@ -689,6 +689,8 @@ struct BfWgradArgs {
     const unsigned short *H1T, *H2T, *DZ2T, *DZ1T, *XT;
     int n_rows, bp, n_nets;
     float *am, *av; const ssac_adam_ctl *ctl;
+    float *grads;         // != null: GRADIENT mode (clip_grad_norm_ path): the gradients are stored here, fp32, in the
+                          // arena's layout, and nothing is updated -- clip + Adam + shadow refresh follow as launches
     float *target; unsigned short *tshadow; float tau;
     const uint32_t *late_word;   // != null: the target update waits for the decision in this word (late-bound Polyak)
     float *sumsq; int64_t sumsq_stride;
@@ -729,6 +731,7 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
     const int H = g.hidden, IN = g.in_dim, K1P = g.sg.k1p;
     float *P = g.params + (int64_t)e * g.net_stride;
     float *M = g.am + (int64_t)e * g.net_stride, *V = g.av + (int64_t)e * g.net_stride;
+    float *Gr = g.grads ? g.grads + (int64_t)e * g.net_stride : nullptr;
     // late-bound Polyak (include/ssac_hip.h): tau bits left by the update's first launch, 0 = no soft_update followed
     const uint32_t late_bits = g.late_word ? *g.late_word : 0u;
     const bool pol = g.target != nullptr && (g.late_word == nullptr || late_bits != 0u);
@@ -775,7 +778,7 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
         for (int r = 0; r < 16; ++r) {
             const int j = by * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const int64_t a = off_w + (int64_t)(j < H ? j : 0) * ldc + (col < Ncols ? col : 0);
-            pv[r] = P[a]; mv[r] = M[a]; vv[r] = V[a];
+            pv[r] = P[a]; mv[r] = Gr ? 0.0f : M[a]; vv[r] = Gr ? 0.0f : V[a];
             tv[r] = T ? T[a] : 0.0f;
         }
     }
@@ -814,19 +817,27 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
         }
         if (i < H) {
             const int64_t a = g.off[4] + i;
-            float m = M[a], v = V[a];
-            const float pn = adam_elem(P[a], gw, m, v, ctl);
-            M[a] = m; V[a] = v; P[a] = pn;
-            S[g.sg.o3 + i] = f2bf(pn);
-            if (T) { const float tn = T[a] * (1.0f - tau) + pn * tau; T[a] = tn; TS[g.sg.o3 + i] = f2bf(tn); }
+            if (Gr) {
+                Gr[a] = gw;
+            } else {
+                float m = M[a], v = V[a];
+                const float pn = adam_elem(P[a], gw, m, v, ctl);
+                M[a] = m; V[a] = v; P[a] = pn;
+                S[g.sg.o3 + i] = f2bf(pn);
+                if (T) { const float tn = T[a] * (1.0f - tau) + pn * tau; T[a] = tn; TS[g.sg.o3 + i] = f2bf(tn); }
+            }
             ss += gw * gw;
         }
         if (tid == 0) {
             const int64_t a = g.off[5];
-            float m = M[a], v = V[a];
-            const float pn = adam_elem(P[a], gb, m, v, ctl);
-            M[a] = m; V[a] = v; P[a] = pn;
-            if (T) T[a] = T[a] * (1.0f - tau) + pn * tau;
+            if (Gr) {
+                Gr[a] = gb;
+            } else {
+                float m = M[a], v = V[a];
+                const float pn = adam_elem(P[a], gb, m, v, ctl);
+                M[a] = m; V[a] = v; P[a] = pn;
+                if (T) T[a] = T[a] * (1.0f - tau) + pn * tau;
+            }
             ss += gb * gb;
         }
     } else {
@@ -855,7 +866,7 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
         // the bias element of this lane's row (the n-tile-0 waves with wn == 0 own it): loaded before the stores below
         const bool bias_lane = bxn == 0 && wn == 0 && lh == 0 && row < H;
         const int64_t ab = (fc2 ? g.off[3] : g.off[1]) + (row < H ? row : 0);
-        const float pb = P[ab], mb0 = M[ab], vb0 = V[ab], tb0 = T ? T[ab] : 0.0f;
+        const float pb = P[ab], mb0 = Gr ? 0.0f : M[ab], vb0 = Gr ? 0.0f : V[ab], tb0 = T ? T[ab] : 0.0f;
         // ---- gradient-norm partial first (it needs the gradients only): with the logs folded in, the arrival ticket is
         //      drawn BEFORE the optimizer stores, whose drain it must not wait for
         if (col < Ncols) {
@@ -881,7 +892,16 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
         }
         // ---- Adam epilogue straight from the accumulator: acc[r] = dW[by*64 + wm*32 + (r&3) + 8(r>>2) + 4 lh][col];
         //      the optimizer state was loaded at kernel start, so this is arithmetic + stores only
-        if (col < Ncols) {
+        if (Gr) {
+            if (col < Ncols) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = by * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (j < H) Gr[off_w + (int64_t)j * ldc + col] = acc[r];
+                }
+            }
+            if (bias_lane) Gr[ab] = colsum;
+        } else if (col < Ncols) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 u16x4 hq, tq;
@@ -914,7 +934,7 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
                 }
             }
         }
-        if (bias_lane) {
+        if (bias_lane && !Gr) {
             float m = mb0, v = vb0;
             const float pn = adam_elem(pb, colsum, m, v, ctl);
             M[ab] = m; V[ab] = v; P[ab] = pn;
@@ -1109,10 +1129,12 @@ extern "C" int ssac_bf16_wgrad_tiles(const ssac_mlp *nets) {
 
 extern "C" int ssac_bf16_wgrad_lossfold(const ssac_mlp *nets, uint16_t *shadow, const uint16_t *XT, const uint16_t *H1T,
                                         const uint16_t *H2T, const uint16_t *DZ2uT, const uint16_t *DZ1uT, const float *Q,
-                                        const float *td, const ssac_td_spec *lazy_td, const float *weight, float denom,
+                                        const float *td, const ssac_td_spec *lazy_td, const float *weight,
+                                        const ssac_popart *popart, int pop, float denom,
                                         float *partials, int n_rows, float *adam_m, float *adam_v,
-                                        const ssac_adam_ctl *ctl, float *sumsq, int64_t sumsq_net_stride, float *target,
-                                        uint16_t *target_shadow, float tau, const ssac_logfold *logfold, void *stream) {
+                                        const ssac_adam_ctl *ctl, float *grads, float *sumsq, int64_t sumsq_net_stride,
+                                        float *target, uint16_t *target_shadow, float tau, const ssac_logfold *logfold,
+                                        void *stream) {
     if (!bf_ok(nets) || nets->out_dim != 1) return ssac_fail("ssac_bf16_wgrad_lossfold: single-output critics only");
     if (!shadow || !XT || !H1T || !H2T || !DZ2uT || !DZ1uT || !Q || !partials || (!td && !lazy_td) || !adam_m || !adam_v || !ctl)
         return ssac_fail("ssac_bf16_wgrad_lossfold: missing argument");
@@ -1126,9 +1148,12 @@ extern "C" int ssac_bf16_wgrad_lossfold(const ssac_mlp *nets, uint16_t *shadow, 
     g.H1T = H1T; g.H2T = H2T; g.DZ2T = DZ2uT; g.DZ1T = DZ1uT; g.XT = XT;
     g.n_rows = n_rows; g.bp = (n_rows + 15) & ~15; g.n_nets = nets->n_nets;
     g.am = adam_m; g.av = adam_v; g.ctl = ctl; g.target = target; g.tshadow = target_shadow; g.tau = tau;
+    g.grads = grads;
+    if (grads && (target || (logfold && logfold->late_word)))
+        return ssac_fail("ssac_bf16_wgrad_lossfold: gradient mode updates nothing (no Polyak step in the same launch)");
     g.sumsq = sumsq; g.sumsq_stride = sumsq_net_stride;
     g.lf.q = Q; g.lf.td = td; if (lazy_td) g.lf.tds = *lazy_td;
-    g.lf.weight = weight; g.lf.popart = nullptr; g.lf.pop = 0; g.lf.denom = denom; g.lf.partials = partials;
+    g.lf.weight = weight; g.lf.popart = popart; g.lf.pop = pop; g.lf.denom = denom; g.lf.partials = partials;
     g.lf.n_rows = n_rows;
     const int t = (nets->hidden + 63) / 64;
     g.tiles2 = t * t; g.tiles1 = t * ((nets->in_dim + 63) / 64);

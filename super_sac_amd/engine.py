@@ -402,7 +402,7 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
     ids = _ptr(net_ids)
     st = stream()
     m = v = None
-    if grads is None:
+    if grads is None or (lossfold is not None and arena.shadow is not None):
         m, v = adam.moments_for(adam_key, arena.params)
     tiles = [arena.tiles(l) for l in range(3)]
     ttot = sum(tiles)
@@ -419,7 +419,8 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
         check(lib.ssac_bf16_wgrad_lossfold(
             C.byref(d), arena.shadow.data_ptr(), bf["xt"].data_ptr(), bf["h1t"].data_ptr(), bf["h2t"].data_ptr(),
             bf["dz2t"].data_ptr(), bf["dz1t"].data_ptr(), f["q"].data_ptr(), f["td_ptr"], f["spec_ptr"], f["weight_ptr"],
-            float(f["denom"]), f["partials"].data_ptr(), n_rows, m.data_ptr(), v.data_ptr(), ctl, _ptr(sumsq),
+            f.get("popart_ptr", 0), int(f.get("pop", 0)),
+            float(f["denom"]), f["partials"].data_ptr(), n_rows, m.data_ptr(), v.data_ptr(), ctl, _ptr(grads), _ptr(sumsq),
             bf16_tiles_total(arena), _ptr(target), _ptr(tsh), float(tau),
             C.byref(f["logfold"]) if f.get("logfold") is not None else 0, st))
         return f.get("logfold") is not None

@@ -117,6 +117,8 @@ def _clip_and_step(adam, members, clip, slot_norm):
         m, v = adam.moments_for(key, arena.params)
         check(lib.ssac_adam_step(arena.params.data_ptr(), m.data_ptr(), v.data_ptr(), grads.data_ptr(),
                                  arena.params.numel(), adam.ctl.ptr, st))
+        if arena.shadow is not None:
+            arena.sync_shadow()   # bf16 mode: the operand copies follow the freshly stepped masters
 
 
 def _encoder_step(encoder, encoder_optimizer, encoder_clip, dX, emb, ws, slot, dev, inv=None, accumulate=False,
@@ -795,10 +797,10 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                                                B, dX.data_ptr(), arena.in_dim, B * arena.in_dim, st))
                 _encoder_step(agent.encoder, encoder_optimizer, encoder_clip, dX, s_rep.shape[1], ws, slot, dev, inv,
                               accumulate=i > 0, step=i == E - 1)
-            if arena.shadow is not None and (lossfold is None or critic_clip or popart):
+            if arena.shadow is not None and lossfold is None:
                 raise NotImplementedError(
-                    "bf16 mode covers the chained critic update (one member, continuous single-output critics, "
-                    "stochastic actor, identity encoder, uniform sampling, no PopArt / clipping / DR3)")
+                    "bf16 mode covers the chained critic update (continuous single-output critics, stochastic actor, "
+                    "identity encoder, with or without PopArt / gradient clipping; no DR3, no discrete critics)")
             folded = engine.weight_grads(arena, X, ldx, 0, h1, h2, dq, dz2, dz1, B, adam=adam,
                                          adam_key=("critic", i), grads=grads, sumsq=ss,
                                          rowscale=dq if (bwd_done and lossfold is None) else None, lossfold=lossfold,

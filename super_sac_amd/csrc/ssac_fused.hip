@@ -1355,7 +1355,9 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
         return ssac_fail("ssac_chain_update: shape not supported by the merged launch");
     if (critics->out_dim != 1 || targets->out_dim != 1) return ssac_fail("ssac_chain_update: single-output critics only");
     if (n_sel <= 0 || n_sel > SSAC_MAX_NETS) return ssac_fail("ssac_chain_update: n_sel out of range");
-    if (!x1sa || !logp || !Qt || !H1 || !H2 || !Q || !DZ2u || !DZ1u) return ssac_fail("ssac_chain_update: missing buffer");
+    // (DZ2u may be NULL: dz2u = W3 (.) [h2 > 0] is then not written out -- a weight-gradient launch that is given H2 and
+    //  W3 rebuilds it in its operand staging, ssac_mlp_wgrad_all_lossfold with DZ2u == NULL)
+    if (!x1sa || !logp || !Qt || !H1 || !H2 || !Q || !DZ1u) return ssac_fail("ssac_chain_update: missing buffer");
     if (act_col0 != actor->in_dim || targets->in_dim != actor->in_dim + actor->out_dim / 2)
         return ssac_fail("ssac_chain_update: [s'|a'] layout does not match the networks");
     if (n_rows <= 0) return 0;

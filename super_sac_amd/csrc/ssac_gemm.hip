@@ -61,6 +61,10 @@ struct GemmArgs {
     int Ktot;                // > 0: batch entry e covers k in [e*K, min((e+1)*K, Ktot)) (split-K over blocks)
     int64_t sGb;             // EPI_GRAD: bias-gradient stride per batch entry (0 = same as sC)
     int xcd;                 // XCD-contiguous tile order (ssac_internal.h)
+    // TN mode, vector loads: A is not read as stored but REBUILT from it -- A[k][m] = a_sign_w[e][m] where the stored
+    // value is positive, else 0 (dz2u = W3 (.) [h2 > 0] from the saved h2: the chained launch then does not write dz2u,
+    // 5 MB per update at the metric shape); per-net stride sC, indexed like C
+    const float *a_sign_w;
 };
 
 __device__ __forceinline__ int64_t batch_off(const int32_t *ids, int use_ids, int e, int64_t stride) {
@@ -148,10 +152,13 @@ struct RcVecLoader {
     uint32_t off;       // float offset of row kfirst + kk, columns R0 + r4 .. + 3 of this thread (second row: + ld16)
     uint32_t ld16;      // 16 rows, in floats (uniform)
     f4 v[2];
+    f4 sw;              // sign mode (GemmArgs::a_sign_w): the weights of this thread's 4 columns
+    bool sign;
     int kk, r4;
     int klast;          // k0 of the rows held in v (late row scale: applied when the rows are stored)
     bool rok;
     __device__ __forceinline__ void init(const float *S, int64_t ld, int R0, int R, int kfirst, int tid) {
+        sign = false;
         r4 = (tid & 15) * 4;
         kk = tid >> 4;
         base = S;
@@ -179,7 +186,12 @@ struct RcVecLoader {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int k = klast + kk + 16 * q;
-            *reinterpret_cast<f4 *>(Xt + (kk + 16 * q) * LDS_RC + r4) = late ? v[q] * late[(rok && k < K) ? k : 0] : v[q];
+            f4 x = v[q];
+            if (sign) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[c] = x[c] > 0.0f ? sw[c] : 0.0f;
+            }
+            *reinterpret_cast<f4 *>(Xt + (kk + 16 * q) * LDS_RC + r4) = late ? x * late[(rok && k < K) ? k : 0] : x;
         }
     }
 };
@@ -235,7 +247,13 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     const bool vecB = TN && (g.vec & 2) && (int64_t)(Kloc + 1) * g.ldb < (1LL << 31);
 
     RcVecLoader va, vb;
-    if (vecA) va.init(A, g.lda, m0, g.M, kg * BK, tid);
+    if (vecA) {
+        va.init(A, g.lda, m0, g.M, kg * BK, tid);
+        if (g.a_sign_w) {
+            va.sign = true;
+            va.sw = va.rok ? *reinterpret_cast<const f4 *>(g.a_sign_w + coff + m0 + va.r4) : (f4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
     if (vecB) vb.init(B, g.ldb, n0, g.N, kg * BK, tid);
     // (lane offsets are 32-bit: one batch entry's operand spans < 2^32 floats -- the launchers check it)
     const uint32_t advA = (uint32_t)(KS * BK * g.lda), advB = (uint32_t)(KS * BK * g.ldb);
@@ -965,6 +983,9 @@ extern "C" int ssac_mlp_wgrad_all_lossfold(const ssac_mlp *nets, const float *X,
                                            const ssac_logfold *logfold, void *stream) {
     if (!nets || nets->out_dim != 1) return ssac_fail("ssac_mlp_wgrad_all_lossfold: single-output heads only");
     if (!H2 || !Q || !partials || (!td && !lazy_td)) return ssac_fail("ssac_mlp_wgrad_all_lossfold: missing argument");
+    // DZ2u == NULL: the fc2 tiles rebuild dz2u = W3 (.) [h2 > 0] from H2 while staging it (16-byte operand rows needed)
+    if (!DZ2u && ((nets->hidden & 3) || ((uintptr_t)H2 & 15) || (nets->net_stride & 3)))
+        return ssac_fail("ssac_mlp_wgrad_all_lossfold: DZ2u == NULL needs 16-byte aligned H2 rows");
     if (n_rows > 4096) return ssac_fail("ssac_mlp_wgrad_all_lossfold: more than 4096 rows (use ssac_critic_loss_bwd)");
     LossFoldArgs lf{};
     lf.q = Q; lf.td = td; if (lazy_td) lf.tds = *lazy_td;
@@ -1013,11 +1034,21 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                                DQ, n_rows, adam_m, adam_v, ctl, grads, sumsq2, sumsq_net_stride, target, tau};
         p.head_grid_x = (nets->hidden + 63) / 64;
     }
-    if (!build_wgrad_args(p.g0, nets, 1, net_ids, H1, H, (int64_t)n_rows * H, DZ2, H, (int64_t)n_rows * H, n_rows,
+    // DZ2 == NULL (loss-fold launches only): the fc2 tiles read H2 and rebuild dz2u = W3 (.) [h2 > 0] in their staging
+    const float *A2 = DZ2 ? DZ2 : H2;
+    if (!A2) return ssac_fail("ssac_mlp_wgrad_fc12: DZ2 missing");
+    if (!build_wgrad_args(p.g0, nets, 1, net_ids, H1, H, (int64_t)n_rows * H, A2, H, (int64_t)n_rows * H, n_rows,
                           adam_m, adam_v, ctl, grads, sumsq1, sumsq_net_stride, target, tau) ||
         !build_wgrad_args(p.g1, nets, 0, net_ids, X, ldx, x_net_stride, DZ1, H, (int64_t)n_rows * H, n_rows,
                           adam_m, adam_v, ctl, grads, sumsq0, sumsq_net_stride, target, tau))
         return ssac_fail("ssac_mlp_wgrad_fc12: bad arena");
+    if (!DZ2) {
+        int64_t off4[6];
+        ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, off4);
+        if (!(p.g0.vec & 1) || nets->out_dim != 1 || net_ids)
+            return ssac_fail("ssac_mlp_wgrad_fc12: the sign-rebuilt dz2u needs 16-byte aligned H2 rows and the whole ensemble");
+        p.g0.a_sign_w = nets->params + off4[4];
+    }
     p.g1.dbg = nullptr;   // (debug stamps: the first fc2 tile only -- both problems have a workgroup (0, 0, 0))
     if (rowscale) { p.g0.rowscale = p.g1.rowscale = rowscale; p.g0.sRow = p.g1.sRow = n_rows; }
     if (lossfold) p.lf = *lossfold;

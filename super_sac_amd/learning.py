@@ -86,6 +86,7 @@ SPLIT_FORWARD = _lib.debug_knob("split_forward", False)
 # the TD-independent half of the critics' backward pass inside the target-critic launch (rank-1 loss gradient); a module
 # knob, not an environment switch: tests turn it off to compare against the launch forms other configurations take
 RANK1_BWD = True
+SKIP_DZ2 = _lib.debug_knob("skip_dz2", True)  # dz2u stays inside the chained launch (rebuilt from h2 by the weight gradient)
 EVENT_EVERY = _lib.debug_knob("event_every", 8)  # must divide FEED_SLOTS
 FOLD_LOSS = _lib.debug_knob("fold_loss", True)  # rank-1 backward: dL/dq evaluated inside the weight-gradient launch
 DUAL_LAUNCH = _lib.debug_knob("dual_launch", True)  # critic forward inside the actor-sample launch
@@ -599,6 +600,12 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                 # and the TD-independent half (rank-1 loss gradient) of the backward pass rides in the target critics' launch
                 cob = (arena, co[3], co[4], a, a.stride(0), ws.get(tag + ".dz2", (N, B, H)),
                        ws.get(tag + ".dz1", (N, B, H)))
+                # dz2u = W3 (.) [h2 > 0] need not leave the chained launch when the weight-gradient launch that follows
+                # is the loss-fold form: its fc2 tiles rebuild it from the saved h2 while staging (same values, bit for
+                # bit; 5 MB less written per update at the metric shape).  The chain launch reports whether it skipped.
+                rd["_dz2_optional"] = (SKIP_DZ2 and FOLD_LOSS and B <= 4096 and arena.shadow is None
+                                       and parallel.shard_of(agent) is None
+                                       and H % 4 == 0)
         td, _ = lu.compute_td_targets(logs=logs, replay_dict=rd, agent=agent, target_agent=target_agent,
                                       ensemble_idx=i, ensemble_n=target_critic_ensemble_n,
                                       log_alphas=log_alphas, pop=pop, gamma=gamma,
@@ -732,13 +739,16 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             spec = getattr(td, "_ssac_spec", None)  # the TD target is evaluated inside the critic launch
             spec_ptr = C.addressof(spec) if spec is not None else 0
             lossfold = None
+            dz2_skipped = bool(rd.pop("_dz2_skipped", False))
+            if dz2_skipped and not (bwd_done and FOLD_LOSS and B <= 4096):
+                raise RuntimeError("internal: the chained launch skipped dz2u but no loss-fold weight-gradient launch follows")
             if bwd_done and FOLD_LOSS and B <= 4096:
                 # dz2u / dz1u exist already; what depends on the TD target is one scalar per (net, row), dL/dq, and the
                 # weight-gradient launch evaluates it itself (per workgroup, in LDS): no loss launch at all
                 fparts = ws.get(tag + ".fparts", (N * 2,))
                 lossfold = dict(q=q, td_ptr=0 if spec is not None else td.data_ptr(), spec_ptr=spec_ptr,
                                 weight_ptr=weight_ptr, popart_ptr=pp, pop=dopop, denom=float(E * n_glob),
-                                partials=fparts)
+                                partials=fparts, dz2_from_h2=dz2_skipped)
                 if arena.shadow is not None:
                     lossfold["bf"] = arena.bf_buffers(ws, "cu", B)
                 cap = engine.CAPTURE

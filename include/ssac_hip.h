@@ -363,7 +363,13 @@ typedef struct ssac_deferred_logs {
 } ssac_deferred_logs;
 int ssac_deferred_logs_flush(const ssac_deferred_logs *d, int ring_slot, void *stream);
 int ssac_mlp_wgrad_all_lossfold(const ssac_mlp *nets, const float *X, int64_t ldx, int64_t x_net_stride,
-                                const float *H1, const float *H2, const float *DZ2u, const float *DZ1u,
+                                const float *H1, const float *H2,
+                                const float *DZ2u /* NULL: rebuilt as W3_snapshot (.) [H2 > 0] while the fc2 tiles stage
+                                                     their operand (the chained launch then never wrote it) */,
+                                const float *DZ1u,
+                                const float *W3_snapshot /* (n_nets x hidden) head rows as ssac_chain_update saved them;
+                                                            NOT the arena's W3, which this launch's head workgroups
+                                                            update concurrently */,
                                 const float *Q, const float *td, const ssac_td_spec *lazy_td, const float *weight,
                                 const ssac_popart *popart, int pop, float denom, float *partials, int n_rows,
                                 float *adam_m, float *adam_v, const ssac_adam_ctl *ctl, float *grads, float *sumsq2,
@@ -509,6 +515,15 @@ int ssac_action_invariance_bwd(const float *out_a, int64_t ld_out, const float *
 int ssac_action_invariance_discrete_bwd(const float *logits_o, const float *logits_a, const float *act, int n_rows,
                                         int n_actions, float coeff, float *d_logits, float *loss_out, float *add_to,
                                         void *stream);
+/* deterministic actors (nets/mlps.py:78-93) in the offline actor update: the reference's Normal(tanh(out), 1e-4)
+ * (distributions.py:107-114).  ssac_bc_det_logprob_bwd: filtered BC loss of learning_utils.py:241-269 and its gradient;
+ * ssac_action_invariance_det_bwd: the constraint of :272-285 with a = loc at the original observation. */
+int ssac_bc_det_logprob_bwd(const float *out, int64_t ld_out, const float *act, int64_t ld_act, const float *mask,
+                            int n_rows, int act_dim, float inv_members, float *d_out, int64_t ld_dout,
+                            float *logs_member, float *logs_total, void *stream);
+int ssac_action_invariance_det_bwd(const float *out_o, int64_t ld_o, const float *out_a, int64_t ld_a, int n_rows,
+                                   int act_dim, float coeff, float *d_out, int64_t ld_dout, float *loss_out,
+                                   float *add_to, void *stream);
 
 /* GaussianExplorationNoise.sample on a device action (learning_utils.py:48-60), in place over act[:, col0:col0+A]:
  * a <- clamp(a + clamp(scale * noise, +-clip), -1 + 1e-6, 1 - 1e-6)  (clip <= 0: no noise clipping). */
@@ -644,7 +659,8 @@ int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t ldxa, int 
                       float log_std_lo, float log_std_hi, float *x1sa, int64_t ld_x1, int64_t act_col0, float *logp,
                       const ssac_rng *rng, const ssac_mlp *targets, const int32_t *net_ids, int n_sel, float *Qt,
                       const ssac_mlp *critics, const float *Xc, int64_t ldxc, float *H1, float *H2, float *Q,
-                      float *DZ2u, float *DZ1u, const ssac_gather *gather,
+                      float *DZ2u /* NULL: not written; W3_snapshot (n_nets x hidden) is filled instead */, float *DZ1u,
+                      float *W3_snapshot, const ssac_gather *gather,
                       const ssac_deferred_logs *deferred /* nullable */, void *stream);
 
 /* ---- the online actor update (learning.py:344-421) in four launches:

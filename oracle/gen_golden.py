@@ -963,7 +963,7 @@ def run_actor_inv_case(name, cfg):
                 with torch.no_grad():   # o_dist.sample(): the reference's own draw at this point of the stream
                     oo = {"obs": torch.from_numpy(s["obs"][idx]).float()}
                     cats.append(ra.actors[i](ra.encoder(oo)).sample())
-            else:
+            elif cfg["actor"] != "deterministic":   # (ContinuousDeterministic.sample() draws nothing)
                 epss.append(torch.randn(B, A))
         gpick = random.choice(range(E))   # random.choice(agent.actors), learning.py:210-212
         torch.set_rng_state(st); random.setstate(pst)
@@ -985,7 +985,7 @@ def run_actor_inv_case(name, cfg):
                 rec[f"s{k}_shift{i}"] = shifts[i].numpy()
             if disc:
                 rec[f"s{k}_cat{i}"] = cats[i].numpy().astype(np.int64)
-            else:
+            elif epss:
                 rec[f"s{k}_eps{i}"] = epss[i].numpy()
         for key, val in rlogs.items():
             v = float(val)

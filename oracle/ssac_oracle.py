@@ -979,6 +979,15 @@ def tanh_normal_log_prob_data(out, lo, hi, a):
     return (base - ladj).sum(-1, keepdim=True)
 
 
+def det_normal_log_prob(out, a):
+    """ContinuousDeterministic(tanh(out)).log_prob(a) summed over the action dimensions (distributions.py:107-114: a
+    Normal with scale 1e-4; torch.distributions.Normal.log_prob in fp32: var = scale ** 2, log_scale = scale.log())."""
+    loc = torch.tanh(out)
+    scale = torch.tensor(1e-4, dtype=torch.float32)
+    var = scale ** 2
+    return (-((a - loc) ** 2) / (2 * var) - scale.log() - math.log(math.sqrt(2 * math.pi))).sum(-1, keepdim=True)
+
+
 def _pop_q(agent, i, s, a):
     """AdvantageEstimator.pop (adv_estimator.py:31-36): min over ALL critics of member i, then popart(q)
     (normalized=True default -> w*q + b) when the member has a PopArt layer."""
@@ -999,8 +1008,11 @@ def advantage(agent, o, a, i, eps_list=None, method="mean", n=4, grad=False):
         out = mlp3(agent.actors[i], s)[0]
         qs = []
         for k in range(n):
-            e = eps_list[k] if eps_list is not None else torch.randn(out.shape[0], agent.act_dim)
-            act = tanh_normal_sample(out, agent.lo, agent.hi, e)[0]
+            if agent.actor_kind == "deterministic":   # .sample() is the loc (distributions.py:113-114): no draw
+                act = torch.tanh(out)
+            else:
+                e = eps_list[k] if eps_list is not None else torch.randn(out.shape[0], agent.act_dim)
+                act = tanh_normal_sample(out, agent.lo, agent.hi, e)[0]
             qs.append(_pop_q(agent, i, s, act))
         qs = torch.stack(qs, 0)
         value = qs.mean(0) if method == "mean" else qs.max(0).values
@@ -1053,6 +1065,8 @@ def offline_actor_update(buffer, per_tree, agent, actor_opt, batch_size, actor_c
         out = mlp3(agent.actors[i], s)[0]
         if agent.discrete:
             logp = torch.log_softmax(out, dim=-1).gather(-1, a.long())
+        elif agent.actor_kind == "deterministic":
+            logp = det_normal_log_prob(out, a)
         else:
             logp = tanh_normal_log_prob_data(out, agent.lo, agent.hi, a)
         if filter_:
@@ -1074,12 +1088,17 @@ def offline_actor_update(buffer, per_tree, agent, actor_opt, batch_size, actor_c
                            else torch.distributions.Categorical(logits=out_o).sample())
                     olp = torch.log_softmax(out_o, -1).gather(-1, a_s.long().unsqueeze(-1)).squeeze(-1)
                     olp = olp.sum(-1, keepdim=True)   # (the reference sums the (B,) log-probabilities: one number)
+                elif agent.actor_kind == "deterministic":
+                    a_s = torch.tanh(out_o)
+                    olp = det_normal_log_prob(out_o, a_s)
                 else:
                     eps = inv_eps_list[i] if inv_eps_list is not None else torch.randn(batch_size, agent.act_dim)
                     a_s, olp = tanh_normal_sample(out_o, agent.lo, agent.hi, eps)
             out_a = mlp3(agent.actors[i], encode(agent.encoder, ao))[0]   # WITH gradient, encoder included
             if agent.discrete:
                 alp = torch.log_softmax(out_a, -1).gather(-1, a_s.long().unsqueeze(-1)).squeeze(-1).sum(-1, keepdim=True)
+            elif agent.actor_kind == "deterministic":
+                alp = det_normal_log_prob(out_a, a_s)
             else:
                 alp = tanh_normal_log_prob_data(out_a, agent.lo, agent.hi, a_s)
             total = total + actor_lambda * F.mse_loss(olp, alp)

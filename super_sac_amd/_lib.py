@@ -97,6 +97,8 @@ SIGNATURES = {
     "ssac_xchg_connect": [_P, _P],
     "ssac_xchg_reduce": [_P, _P, _I, _I, _P],
     "ssac_xchg_reduce_owned": [_P, _P, _I, _P, _I, _P],
+    "ssac_bc_det_logprob_bwd": [_P, _L, _P, _L, _P, _I, _I, _F, _P, _L, _P, _P, _P],
+    "ssac_action_invariance_det_bwd": [_P, _L, _P, _L, _I, _I, _F, _P, _L, _P, _P, _P],
     "ssac_per_assign": [_P, _P, _L, _P, _I, _P, _I, C.c_double, _P, _I, _L, _P, _P, _P],
     "ssac_per_sample": [_P, _P, _L, _L, _P, _I, C.c_double, _P, _P, _P],
     "ssac_xchg_error": [_P],
@@ -119,7 +121,7 @@ SIGNATURES = {
     "ssac_mlp_wgrad_all_scaled": [_MP, _P, _I, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _F,
                                   _P],
     "ssac_critic_loss_bwd_lazy": [_P, _I, _I, _I, _P, _L, _P, _P, _P, _I, _F, _P, _P, _P],
-    "ssac_mlp_wgrad_all_lossfold": [_MP, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _I, _P, _P, _P, _P,
+    "ssac_mlp_wgrad_all_lossfold": [_MP, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _I, _P, _P, _P, _P,
                                     _P, _P, _P, _L, _P, _F, _P, _P],
     "ssac_target_fwd_critic_bwdu": [_MP, _P, _I, _P, _L, _I, _P, _MP, _P, _P, _P, _L, _P, _P, _P],
     "ssac_gather_transition": [_P, _P, _I, _L, _P, _L, _P, _P, _P, _I, _P, _L, _P, _L, _P, _P, _P],
@@ -200,7 +202,7 @@ SIGNATURES = {
     "ssac_actor_sample_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _P, _P, _P, _P],
     "ssac_actor_sample_critic_fwd": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _L, _P, _P, _P, _P, _P],
     "ssac_chain_update": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _I, _P, _MP, _P, _L, _P, _P, _P, _P, _P,
-                          _P, _P, _P],
+                          _P, _P, _P, _P],
     "ssac_deferred_logs_flush": [_P, _I, _P],
     "ssac_philox_normal": [_P, _I, _I, _P, _P],
     "ssac_actor_sample_concat_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _P, _P, _P, _P, _P, _P],

@@ -70,9 +70,14 @@ class AdvantageEstimator:
         Xv[0, :, S:].copy_(action)
         a_arena = engine.bind_arena(actor, "self", [actor], dev)
         _, _, aout = engine.mlp_forward(a_arena, s_rep, lu._row_stride(s_rep), 0, B, ws, f"adv.a{i}", save=False)
+        deterministic = lu.actor_kind(actor) == "deterministic"
         for k in range(n):
-            eps = rng.draw_normal((B, A), dev)  # dist.sample(): one normal draw per sampled action
             blk = Xv[k + 1]
+            if deterministic:
+                # ContinuousDeterministic.sample() is its loc (distributions.py:113-114): no draw, n equal actions
+                check(lib.ssac_det_action_fwd(aout.data_ptr(), A, 0, 0.0, 0, 0.0, 0.0, B, A, blk.data_ptr(), S + A, S, st))
+                continue
+            eps = rng.draw_normal((B, A), dev)  # dist.sample(): one normal draw per sampled action
             check(lib.ssac_tanh_normal_fwd(aout.data_ptr(), 2 * A, eps.data_ptr(), B, A,
                                            float(actor.log_std_low), float(actor.log_std_high),
                                            blk.data_ptr(), S + A, S, 0, st))

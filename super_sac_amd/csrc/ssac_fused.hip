@@ -79,6 +79,9 @@ struct FusedArgs {
     // MODE_CRITIC
     const float *td, *weight, *act; int64_t ld_a; const ssac_popart *popart; int pop; float denom;
     float *DQ, *DZ2, *DZ1; float *partials;  // partials[(e*tiles + tile)*2 + {loss, err}]
+    float *W3S;   // MODE_CRITIC_U with DZ2 == null: (n_nets x hidden) copy of the head rows W3 as this launch saw them --
+                  // the weight-gradient launch that rebuilds dz2u from h2 must not read W3 itself: its own head
+                  // workgroups update W3 while its fc2 tiles run
     int xcd;                     // workgroups take their tile in XCD-contiguous order (ssac_internal.h)
     ssac_gather gth; int gth_role;  // 1: actor half (s' rows, begin duties), 3: actor half without the begin duties,
                                     // 2: critic half ([s|a] rows), 4: rows from X, net ids from the input slot; 0: X
@@ -745,6 +748,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                         *reinterpret_cast<f4 *>(h2s + row * ldh + col) = dz;
                         if (g.DZ2 && rok)
                             *reinterpret_cast<f4 *>(g.DZ2 + ((int64_t)e * g.n_rows + m0 + row) * H + col) = dz;
+                        if (g.W3S && bx == 0 && row == 0) *reinterpret_cast<f4 *>(g.W3S + (int64_t)e * H + col) = w;
                     } else {
                         *reinterpret_cast<f4 *>(h2s + row * ldh + col) = v;
                     }
@@ -1348,7 +1352,7 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
                                  float log_std_lo, float log_std_hi, float *x1sa, int64_t ld_x1, int64_t act_col0,
                                  float *logp, const ssac_rng *rng, const ssac_mlp *targets, const int32_t *net_ids,
                                  int n_sel, float *Qt, const ssac_mlp *critics, const float *Xc, int64_t ldxc,
-                                 float *H1, float *H2, float *Q, float *DZ2u, float *DZ1u,
+                                 float *H1, float *H2, float *Q, float *DZ2u, float *DZ1u, float *W3_snapshot,
                                  const ssac_gather *gather, const ssac_deferred_logs *deferred, void *stream) {
     if (!eps && !rng) return ssac_fail("ssac_chain_update: neither eps nor an rng stream given");
     if (!fused_ok(actor) || (actor->out_dim & 1) || !fused_dbuf_ok(targets) || !fused_dbuf_ok(critics))
@@ -1358,6 +1362,7 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
     // (DZ2u may be NULL: dz2u = W3 (.) [h2 > 0] is then not written out -- a weight-gradient launch that is given H2 and
     //  W3 rebuilds it in its operand staging, ssac_mlp_wgrad_all_lossfold with DZ2u == NULL)
     if (!x1sa || !logp || !Qt || !H1 || !H2 || !Q || !DZ1u) return ssac_fail("ssac_chain_update: missing buffer");
+    if (!DZ2u && !W3_snapshot) return ssac_fail("ssac_chain_update: DZ2u == NULL needs the W3 snapshot buffer");
     if (act_col0 != actor->in_dim || targets->in_dim != actor->in_dim + actor->out_dim / 2)
         return ssac_fail("ssac_chain_update: [s'|a'] layout does not match the networks");
     if (n_rows <= 0) return 0;
@@ -1369,7 +1374,7 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
     fill_common(gt, targets, net_ids, x1sa, ld_x1, 0, n_rows);
     gt.Y = Qt;
     fill_common(gc, critics, nullptr, Xc, ldxc, 0, n_rows);
-    gc.H1 = H1; gc.H2 = H2; gc.Y = Q; gc.DZ2 = DZ2u; gc.DZ1 = DZ1u;
+    gc.H1 = H1; gc.H2 = H2; gc.Y = Q; gc.DZ2 = DZ2u; gc.DZ1 = DZ1u; gc.W3S = DZ2u ? nullptr : W3_snapshot;
     if (gather) {
         if (gather->s_elems != actor->in_dim || gather->s_elems + gather->a_elems != critics->in_dim)
             return ssac_fail("ssac_chain_update: gather sizes do not match the networks");

@@ -63,7 +63,8 @@ struct GemmArgs {
     int xcd;                 // XCD-contiguous tile order (ssac_internal.h)
     // TN mode, vector loads: A is not read as stored but REBUILT from it -- A[k][m] = a_sign_w[e][m] where the stored
     // value is positive, else 0 (dz2u = W3 (.) [h2 > 0] from the saved h2: the chained launch then does not write dz2u,
-    // 5 MB per update at the metric shape); per-net stride sC, indexed like C
+    // 5 MB per update at the metric shape).  a_sign_w: (n_nets x M) SNAPSHOT of the head rows the chained launch took --
+    // not the arena's W3, which the head workgroups of this very launch are updating
     const float *a_sign_w;
 };
 
@@ -251,7 +252,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
         va.init(A, g.lda, m0, g.M, kg * BK, tid);
         if (g.a_sign_w) {
             va.sign = true;
-            va.sw = va.rok ? *reinterpret_cast<const f4 *>(g.a_sign_w + coff + m0 + va.r4) : (f4){0.f, 0.f, 0.f, 0.f};
+            va.sw = va.rok ? *reinterpret_cast<const f4 *>(g.a_sign_w + (int64_t)e * g.M + m0 + va.r4) : (f4){0.f, 0.f, 0.f, 0.f};
         }
     }
     if (vecB) vb.init(B, g.ldb, n0, g.N, kg * BK, tid);
@@ -958,7 +959,7 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                         const ssac_adam_ctl *ctl, float *grads, float *sumsq1, float *sumsq0, float *sumsq2,
                         int64_t sumsq_net_stride, float *target, float tau, void *stream,
                         const float *rowscale = nullptr, const LossFoldArgs *lossfold = nullptr,
-                        const ssac_logfold *logfold = nullptr);
+                        const ssac_logfold *logfold = nullptr, const float *w3_snapshot = nullptr);
 
 extern "C" int ssac_mlp_wgrad_all_scaled(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
                                          int64_t ldx, int64_t x_net_stride, const float *H1, const float *H2,
@@ -975,6 +976,7 @@ extern "C" int ssac_mlp_wgrad_all_scaled(const ssac_mlp *nets, const int32_t *ne
 
 extern "C" int ssac_mlp_wgrad_all_lossfold(const ssac_mlp *nets, const float *X, int64_t ldx, int64_t x_net_stride,
                                            const float *H1, const float *H2, const float *DZ2u, const float *DZ1u,
+                                           const float *W3_snapshot,
                                            const float *Q, const float *td, const ssac_td_spec *lazy_td,
                                            const float *weight, const ssac_popart *popart, int pop, float denom,
                                            float *partials, int n_rows, float *adam_m, float *adam_v,
@@ -984,15 +986,15 @@ extern "C" int ssac_mlp_wgrad_all_lossfold(const ssac_mlp *nets, const float *X,
     if (!nets || nets->out_dim != 1) return ssac_fail("ssac_mlp_wgrad_all_lossfold: single-output heads only");
     if (!H2 || !Q || !partials || (!td && !lazy_td)) return ssac_fail("ssac_mlp_wgrad_all_lossfold: missing argument");
     // DZ2u == NULL: the fc2 tiles rebuild dz2u = W3 (.) [h2 > 0] from H2 while staging it (16-byte operand rows needed)
-    if (!DZ2u && ((nets->hidden & 3) || ((uintptr_t)H2 & 15) || (nets->net_stride & 3)))
-        return ssac_fail("ssac_mlp_wgrad_all_lossfold: DZ2u == NULL needs 16-byte aligned H2 rows");
+    if (!DZ2u && (!W3_snapshot || (nets->hidden & 3) || (((uintptr_t)H2 | (uintptr_t)W3_snapshot) & 15)))
+        return ssac_fail("ssac_mlp_wgrad_all_lossfold: DZ2u == NULL needs the W3 snapshot and 16-byte aligned H2 rows");
     if (n_rows > 4096) return ssac_fail("ssac_mlp_wgrad_all_lossfold: more than 4096 rows (use ssac_critic_loss_bwd)");
     LossFoldArgs lf{};
     lf.q = Q; lf.td = td; if (lazy_td) lf.tds = *lazy_td;
     lf.weight = weight; lf.popart = popart; lf.pop = pop; lf.denom = denom; lf.partials = partials; lf.n_rows = n_rows;
     return wgrad_merged(nets, nullptr, nets->n_nets, X, ldx, x_net_stride, H1, DZ2u, DZ1u, H2, Q, n_rows, adam_m,
                         adam_v, ctl, grads, sumsq1, sumsq0, sumsq2, sumsq_net_stride, target, tau, stream, nullptr, &lf,
-                        logfold);
+                        logfold, W3_snapshot);
 }
 
 extern "C" int ssac_mlp_wgrad_fc12(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
@@ -1021,7 +1023,8 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                         const float *H2, const float *DQ, int n_rows, float *adam_m, float *adam_v,
                         const ssac_adam_ctl *ctl, float *grads, float *sumsq1, float *sumsq0, float *sumsq2,
                         int64_t sumsq_net_stride, float *target, float tau, void *stream,
-                        const float *rowscale, const LossFoldArgs *lossfold, const ssac_logfold *logfold) {
+                        const float *rowscale, const LossFoldArgs *lossfold, const ssac_logfold *logfold,
+                        const float *w3_snapshot) {
     if (n_sel < 0 || n_sel > SSAC_MAX_NETS) return ssac_fail("ssac_mlp_wgrad_fc12: n_sel out of range");
     if (!grads && (!adam_m || !adam_v || !ctl)) return ssac_fail("ssac_mlp_wgrad_fc12: Adam state missing");
     if (n_sel == 0 || n_rows <= 0) return 0;
@@ -1043,11 +1046,9 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                           adam_m, adam_v, ctl, grads, sumsq0, sumsq_net_stride, target, tau))
         return ssac_fail("ssac_mlp_wgrad_fc12: bad arena");
     if (!DZ2) {
-        int64_t off4[6];
-        ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, off4);
-        if (!(p.g0.vec & 1) || nets->out_dim != 1 || net_ids)
-            return ssac_fail("ssac_mlp_wgrad_fc12: the sign-rebuilt dz2u needs 16-byte aligned H2 rows and the whole ensemble");
-        p.g0.a_sign_w = nets->params + off4[4];
+        if (!(p.g0.vec & 1) || nets->out_dim != 1 || net_ids || !w3_snapshot)
+            return ssac_fail("ssac_mlp_wgrad_fc12: the sign-rebuilt dz2u needs the W3 snapshot, 16-byte aligned H2 rows and the whole ensemble");
+        p.g0.a_sign_w = w3_snapshot;
     }
     p.g1.dbg = nullptr;   // (debug stamps: the first fc2 tile only -- both problems have a workgroup (0, 0, 0))
     if (rowscale) { p.g0.rowscale = p.g1.rowscale = rowscale; p.g0.sRow = p.g1.sRow = n_rows; }

@@ -274,6 +274,93 @@ extern "C" int ssac_action_invariance_bwd(const float *out_a, int64_t ld_out, co
     return ssac_check_launch("action_invariance_bwd");
 }
 
+// ---- deterministic actors (nets/mlps.py:78-93: loc = tanh(out)) in the offline actor update.  The reference treats
+// them as Normal(loc, 1e-4) (distributions.py:107-114), so log pi(a) = sum_k [-(a_k - loc_k)^2 / (2 var) - log sd -
+// log sqrt(2 pi)] with sd = 1e-4f, var = sd * sd in fp32 (torch.distributions.Normal.log_prob, operation by operation).
+constexpr float DET_SD = 1e-4f;
+
+// filtered behaviour cloning (learning_utils.py:241-269): loss_i = -mean_b(mask_b log pi(a_b)); d_out = d(loss_i / E)/d out
+__global__ __launch_bounds__(MK_THREADS) void bc_det_logprob_bwd_kernel(
+    const float *__restrict__ out, int64_t ld_out, const float *__restrict__ act, int64_t ld_act,
+    const float *__restrict__ mask, int n_rows, int A, float inv_members, float *__restrict__ d_out, int64_t ld_dout,
+    float *__restrict__ logs_member, float *__restrict__ logs_total) {
+    __shared__ float scratch[16];
+    constexpr float LOG_SQRT_2PI_ = 0.91893853320467274178f;
+    const float var = DET_SD * DET_SD, log_sd = logf(DET_SD);
+    float acc = 0.0f;
+    for (int b = threadIdx.x; b < n_rows; b += MK_THREADS) {
+        const float w = mask ? mask[b] : 1.0f;
+        const float coef = -w * inv_members / (float)n_rows;
+        float lp = 0.0f;
+        for (int i = 0; i < A; ++i) {
+            const float loc = tanhf(out[b * ld_out + i]);
+            const float dlt = act[b * ld_act + i] - loc;
+            lp += -(dlt * dlt) / (2.0f * var) - log_sd - LOG_SQRT_2PI_;
+            d_out[b * ld_dout + i] = coef * (dlt / var) * (1.0f - loc * loc);
+        }
+        acc += lp * w;
+    }
+    const float tot = mk_block_sum(acc, scratch);
+    if (threadIdx.x == 0) {
+        const float loss = -tot / (float)n_rows;
+        if (logs_member) logs_member[0] = loss;
+        if (logs_total) logs_total[0] += loss * inv_members;
+    }
+}
+
+// action invariance (learning_utils.py:272-285): a = o_dist.sample() = loc_o (distributions.py:113-114), so
+// olp_b = A (-log sd - log sqrt(2 pi)) exactly and alp_b = sum_k [-(loc_o - loc_a)^2 / (2 var) - log sd - log sqrt(2 pi)];
+// loss = mean_b (olp_b - alp_b)^2; d_out = coeff * d loss / d out_a (nothing flows to out_o: no_grad in the reference).
+__global__ __launch_bounds__(MK_THREADS) void action_invariance_det_bwd_kernel(
+    const float *__restrict__ out_o, int64_t ld_o, const float *__restrict__ out_a, int64_t ld_a, int n_rows, int A,
+    float coeff, float *__restrict__ d_out, int64_t ld_dout, float *__restrict__ loss_out, float *__restrict__ add_to) {
+    __shared__ float scratch[16];
+    constexpr float LOG_SQRT_2PI_ = 0.91893853320467274178f;
+    const float var = DET_SD * DET_SD, log_sd = logf(DET_SD);
+    float acc = 0.0f;
+    for (int b = threadIdx.x; b < n_rows; b += MK_THREADS) {
+        float olp = 0.0f, alp = 0.0f;
+        for (int i = 0; i < A; ++i) {
+            const float a = tanhf(out_o[b * ld_o + i]), loc = tanhf(out_a[b * ld_a + i]);
+            const float z = a - a;   // (value - loc of the distribution the action was drawn from)
+            olp += -(z * z) / (2.0f * var) - log_sd - LOG_SQRT_2PI_;
+            const float dlt = a - loc;
+            alp += -(dlt * dlt) / (2.0f * var) - log_sd - LOG_SQRT_2PI_;
+        }
+        const float diff = olp - alp;
+        acc += diff * diff;
+        const float coef = coeff * 2.0f * diff / (float)n_rows;   // d loss / d (olp - alp); d(-alp)/d loc = -(a - loc)/var
+        for (int i = 0; i < A; ++i) {
+            const float a = tanhf(out_o[b * ld_o + i]), loc = tanhf(out_a[b * ld_a + i]);
+            d_out[b * ld_dout + i] = coef * (-(a - loc) / var) * (1.0f - loc * loc);
+        }
+    }
+    const float tot = mk_block_sum(acc, scratch);
+    if (threadIdx.x == 0) {
+        loss_out[0] = tot / (float)n_rows;
+        if (add_to) add_to[0] += coeff * tot / (float)n_rows;
+    }
+}
+
+extern "C" int ssac_bc_det_logprob_bwd(const float *out, int64_t ld_out, const float *act, int64_t ld_act, const float *mask,
+                                       int n_rows, int act_dim, float inv_members, float *d_out, int64_t ld_dout,
+                                       float *logs_member, float *logs_total, void *stream) {
+    if (!out || !act || !d_out || n_rows <= 0 || act_dim <= 0) return ssac_fail("ssac_bc_det_logprob_bwd: bad arguments");
+    SSAC_LAUNCH(bc_det_logprob_bwd_kernel, dim3(1), dim3(MK_THREADS), 0, (hipStream_t)stream, out, ld_out, act, ld_act, mask,
+                n_rows, act_dim, inv_members, d_out, ld_dout, logs_member, logs_total);
+    return ssac_check_launch("bc_det_logprob_bwd");
+}
+
+extern "C" int ssac_action_invariance_det_bwd(const float *out_o, int64_t ld_o, const float *out_a, int64_t ld_a, int n_rows,
+                                              int act_dim, float coeff, float *d_out, int64_t ld_dout, float *loss_out,
+                                              float *add_to, void *stream) {
+    if (!out_o || !out_a || !d_out || !loss_out || n_rows <= 0 || act_dim <= 0)
+        return ssac_fail("ssac_action_invariance_det_bwd: bad arguments");
+    SSAC_LAUNCH(action_invariance_det_bwd_kernel, dim3(1), dim3(MK_THREADS), 0, (hipStream_t)stream, out_o, ld_o, out_a, ld_a,
+                n_rows, act_dim, coeff, d_out, ld_dout, loss_out, add_to);
+    return ssac_check_launch("action_invariance_det_bwd");
+}
+
 extern "C" int ssac_action_invariance_discrete_bwd(const float *logits_o, const float *logits_a, const float *act,
                                                    int n_rows, int n_actions, float coeff, float *d_logits,
                                                    float *loss_out, float *add_to, void *stream) {

@@ -431,7 +431,7 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
         check(lib.ssac_mlp_wgrad_all_lossfold(
             C.byref(d), X.data_ptr(), ldx, x_net_stride, h1.data_ptr(), h2.data_ptr(),
             0 if f.get("dz2_from_h2") else dz2.data_ptr(),   # (0: dz2u is rebuilt from h2 and W3 in the operand staging)
-            dz1.data_ptr(),
+            dz1.data_ptr(), _ptr(f.get("w3_snapshot")),
             f["q"].data_ptr(), f["td_ptr"], f["spec_ptr"], f["weight_ptr"], f["popart_ptr"], f["pop"],
             float(f["denom"]), f["partials"].data_ptr(), n_rows, _ptr(m), _ptr(v), ctl, _ptr(grads), ssp(2), ssp(1),
             ssp(0), ttot, _ptr(target), float(tau), C.byref(f["logfold"]) if f.get("logfold") is not None else 0, st))

@@ -739,7 +739,8 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             spec = getattr(td, "_ssac_spec", None)  # the TD target is evaluated inside the critic launch
             spec_ptr = C.addressof(spec) if spec is not None else 0
             lossfold = None
-            dz2_skipped = bool(rd.pop("_dz2_skipped", False))
+            w3_snapshot = rd.pop("_dz2_skipped", None)
+            dz2_skipped = w3_snapshot is not None
             if dz2_skipped and not (bwd_done and FOLD_LOSS and B <= 4096):
                 raise RuntimeError("internal: the chained launch skipped dz2u but no loss-fold weight-gradient launch follows")
             if bwd_done and FOLD_LOSS and B <= 4096:
@@ -748,7 +749,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                 fparts = ws.get(tag + ".fparts", (N * 2,))
                 lossfold = dict(q=q, td_ptr=0 if spec is not None else td.data_ptr(), spec_ptr=spec_ptr,
                                 weight_ptr=weight_ptr, popart_ptr=pp, pop=dopop, denom=float(E * n_glob),
-                                partials=fparts, dz2_from_h2=dz2_skipped)
+                                partials=fparts, dz2_from_h2=dz2_skipped, w3_snapshot=w3_snapshot)
                 if arena.shadow is not None:
                     lossfold["bf"] = arena.bf_buffers(ws, "cu", B)
                 cap = engine.CAPTURE
@@ -1152,8 +1153,6 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
     # observations whether or not update_encoder is set (only encoder_optimizer.step() depends on it)
     enc_grad = train_enc or (bool(actor_lambda) and pixel)
     # (ensemble members share the encoder: member i > 0 adds its gradient, the clip / step follows the last member)
-    if actor_lambda and any(lu.actor_kind(a_) == "deterministic" for a_ in agent.actors):
-        raise NotImplementedError("action invariance constraint on a deterministic actor")
     dev = next(agent.actors[0].parameters()).device
     ws = lu.agent_ws(agent, dev)
     adam = engine.adam_group(actor_optimizer, dev)
@@ -1178,7 +1177,8 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
             logs["losses/adv_weights_mean"] = slot[lu.L_ADVW]
         a_arena = engine.bind_arena(actor, "self", [actor], dev)
         A = actor.action_size
-        O = A if discrete else 2 * A
+        det = not discrete and lu.actor_kind(actor) == "deterministic"   # Normal(tanh(out), 1e-4), distributions.py:107-114
+        O = A if (discrete or det) else 2 * A
         rows = batch_size
         if actor_lambda:
             # ---- action invariance (learning_utils.py:272-285).  (1) at the ORIGINAL observations, without gradient:
@@ -1194,6 +1194,8 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
             if discrete:
                 a_inv = ws.get(f"bc.ainv{i}", (B,))
                 a_inv.copy_(rng.draw_categorical(out_o[0]))   # o_dist.sample() (device generator, as the reference)
+            elif det:
+                a_inv = None   # o_dist.sample() is tanh(out_o): no draw; the constraint kernel takes out_o itself
             else:
                 a_inv = ws.get(f"bc.ainv{i}", (B, A))
                 eps = rng.draw_normal((B, A), dev)
@@ -1231,6 +1233,14 @@ def offline_actor_update(buffer, agent, actor_optimizer, encoder_optimizer, batc
                 check(lib.ssac_action_invariance_discrete_bwd(
                     out_o.data_ptr(), aout[0, B:].data_ptr(), a_inv.data_ptr(), B, A, float(actor_lambda) * inv_e,
                     d_out[0, B:].data_ptr(), slot[lu.L_ACT_INV:].data_ptr(), slot[lu.L_BC_TOTAL:].data_ptr(), st))
+        elif det:
+            check(lib.ssac_bc_det_logprob_bwd(aout.data_ptr(), A, a.data_ptr(), a.stride(0), mask_ptr, B, A, inv_e,
+                                              d_out.data_ptr(), A, slot[lu.L_BC0 + i:].data_ptr(),
+                                              slot[lu.L_BC_TOTAL:].data_ptr(), st))
+            if actor_lambda:
+                check(lib.ssac_action_invariance_det_bwd(
+                    out_o.data_ptr(), A, aout[0, B:].data_ptr(), A, B, A, float(actor_lambda) * inv_e,
+                    d_out[0, B:].data_ptr(), A, slot[lu.L_ACT_INV:].data_ptr(), slot[lu.L_BC_TOTAL:].data_ptr(), st))
         else:
             check(lib.ssac_bc_logprob_bwd(aout.data_ptr(), 2 * A, a.data_ptr(), a.stride(0), mask_ptr, B, A,
                                           float(actor.log_std_low), float(actor.log_std_high), inv_e,

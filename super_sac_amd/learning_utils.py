@@ -687,6 +687,9 @@ def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict)
         replay_dict["_co_bwd"] = True
         return q1
     skip_dz2 = bool(replay_dict.pop("_dz2_optional", False))
+    # (the head rows W3 as THIS launch sees them: the weight-gradient launch that rebuilds dz2u from h2 cannot read the
+    #  arena's W3 -- its own head workgroups are updating it while the fc2 tiles run)
+    w3s = ws.get(tag + ".w3s", (c_arena.n_nets, c_arena.hidden))
     with engine._timed("chain") as tm:
         for _ in range(tm.reps):  # 1, except under bench.py's live kernel timing (the launch is idempotent)
             check(lib.ssac_chain_update(
@@ -694,10 +697,10 @@ def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict)
                 float(actor.log_std_low), float(actor.log_std_high), x1.data_ptr(), S + A, S,
                 ch["logp"].data_ptr(), ch["rng_ptr"], C.byref(t_arena.desc()), ids_ptr, n,
                 q1.data_ptr(), C.byref(c_arena.desc()), Xc.data_ptr(), ldxc, h1.data_ptr(), h2.data_ptr(),
-                qc.data_ptr(), 0 if skip_dz2 else dz2u.data_ptr(), dz1u.data_ptr(),
+                qc.data_ptr(), 0 if skip_dz2 else dz2u.data_ptr(), dz1u.data_ptr(), w3s.data_ptr(),
                 C.byref(gth) if gth is not None else 0, dl_ptr, engine.stream()))
     if skip_dz2:
-        replay_dict["_dz2_skipped"] = True   # (the weight-gradient launch rebuilds dz2u from h2 and W3)
+        replay_dict["_dz2_skipped"] = w3s   # (the weight-gradient launch rebuilds dz2u from h2 and this W3 copy)
     replay_dict["_co_bwd"] = True
     return q1
 

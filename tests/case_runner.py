@@ -910,7 +910,7 @@ def run_actor_inv_oracle(name):
             obuf, None, oa, aopt, B, stp["clip"], aug, px["aug_mix"] if px else 0.0, per=False, filter_=False,
             idx_list=[fx[f"s{k}_idx{i}"] for i in range(E)], update_encoder=stp["update_encoder"], encoder_opt=eopt,
             encoder_clip=stp.get("enc_clip"), actor_lambda=cfg["actor_lambda"],
-            inv_eps_list=None if disc else [torch.from_numpy(fx[f"s{k}_eps{i}"]) for i in range(E)],
+            inv_eps_list=None if (disc or f"s{k}_eps0" not in fx) else [torch.from_numpy(fx[f"s{k}_eps{i}"]) for i in range(E)],
             inv_cat_list=[torch.from_numpy(fx[f"s{k}_cat{i}"]) for i in range(E)] if disc else None,
             grad_pick=int(fx[f"s{k}_gpick"]))
         for key, val in logs.items():
@@ -945,7 +945,7 @@ def run_actor_inv_engine(name, device="cuda"):
                     player.shift.append(fx[f"s{k}_shift{i}"])
                 if disc:
                     player.cats.append(fx[f"s{k}_cat{i}"])
-                else:
+                elif f"s{k}_eps{i}" in fx:   # (a deterministic actor's sample() is its loc: no draw)
                     player.normal.append(fx[f"s{k}_eps{i}"])
             player.picks.append(int(fx[f"s{k}_gpick"]))
             logs = ssa.learning.offline_actor_update(

@@ -224,6 +224,15 @@ ACTOR_INV_CASES = {
     "actinv_discrete": dict(obs=12, act=5, hidden=64, N=2, n=2, E=1, B=96, rows=1000, cap=1024, lo=-10.0, hi=2.0,
                             popart=False, discrete=True, actor="discrete", lr=1e-3, seed=72, actor_lambda=0.01,
                             steps=[dict(clip=None, update_encoder=False)] * 3),
+    # round 3: the constraint (and the BC loss) on a DETERMINISTIC actor -- the reference's Normal(tanh(out), 1e-4),
+    # distributions.py:107-114; a = loc at the original observation, no draw; two members behind one trainable encoder
+    "actinv_det_pixels": dict(obs=50, act=4, hidden=64, N=2, n=2, E=2, B=8, rows=48, cap=64, lo=-5.0, hi=2.0,
+                              popart=False, discrete=False, actor="deterministic", lr=1e-4, seed=95, actor_lambda=1e-9,
+                              steps=[dict(clip=None, update_encoder=True, enc_clip=None),
+                                     dict(clip=None, update_encoder=False, enc_clip=1.0),
+                                     dict(clip=1.0, update_encoder=True, enc_clip=1.0)],
+                              pixels=dict(kind="big", channels=9, hw=84, emb=50, enc_lr=1e-4, enc_tau=1.0, aug="drqv2",
+                                          aug_mix=0.5)),
     "actinv_pixels": dict(obs=50, act=4, hidden=64, N=2, n=2, E=1, B=8, rows=48, cap=64, lo=-5.0, hi=2.0,
                           popart=False, discrete=False, actor="stochastic", lr=1e-4, seed=73, actor_lambda=1.0,
                           steps=[dict(clip=None, update_encoder=True, enc_clip=None),

@@ -1167,10 +1167,23 @@ def test_chain_launch_equals_the_separate_launches(ssa, B, N, H):
     ssa._lib.check(lib.ssac_chain_update(
         C.byref(aa.desc()), xb.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0, xb.data_ptr(), S + A, S, lpb.data_ptr(),
         0, C.byref(ta.desc()), ids.data_ptr(), 2, gt_.data_ptr(), C.byref(ca.desc()), xc.data_ptr(), S + A,
-        g1.data_ptr(), g2.data_ptr(), gq.data_ptr(), gz2.data_ptr(), gz1.data_ptr(), 0, 0, st))
+        g1.data_ptr(), g2.data_ptr(), gq.data_ptr(), gz2.data_ptr(), gz1.data_ptr(), 0, 0, 0, st))
     for a_, b_, what in ((xa, xb, "a'"), (lpa, lpb, "log pi"), (h1, g1, "h1"), (h2, g2, "h2"), (q, gq, "q"),
                          (qt, gt_, "target q"), (dz2, gz2, "dz2u"), (dz1, gz1, "dz1u")):
         assert torch.equal(a_, b_), f"chained launch differs in {what}"
+    # ... and without the dz2u store: the launch leaves a copy of the head rows instead, from which (with h2) the
+    # weight-gradient launch rebuilds dz2u = W3 (.) [h2 > 0] -- exactly the values written above
+    w3s = torch.zeros(N, H, device=DEV)
+    k1, k2, kq, kz1 = torch.zeros_like(h1), torch.zeros_like(h2), torch.zeros_like(q), torch.zeros_like(dz1)
+    xb2, lpb2, kt = x1.clone(), torch.zeros(B, device=DEV), torch.zeros_like(qt)
+    ssa._lib.check(lib.ssac_chain_update(
+        C.byref(aa.desc()), xb2.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0, xb2.data_ptr(), S + A, S, lpb2.data_ptr(),
+        0, C.byref(ta.desc()), ids.data_ptr(), 2, kt.data_ptr(), C.byref(ca.desc()), xc.data_ptr(), S + A,
+        k1.data_ptr(), k2.data_ptr(), kq.data_ptr(), 0, kz1.data_ptr(), w3s.data_ptr(), 0, 0, st))
+    assert torch.equal(k2, g2) and torch.equal(kz1, gz1) and torch.equal(kq, gq)
+    w3 = torch.stack([ca.view(j, "w3").reshape(-1) for j in range(N)])
+    assert torch.equal(w3s, w3)
+    assert torch.equal(torch.where(k2 > 0, w3s[:, None, :].expand_as(k2), torch.zeros_like(k2)), gz2)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -708,6 +708,9 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
         if ((p.fold.done && p.fold.td_logs) || p.fold.deferred_stats)
             log_fold_td_stats(p.fold, p.lf.tds, tab + p.lf.n_rows);
     } else if (bid >= p.tiles01) {  // head-layer weight gradient + Adam beside the GEMM tiles
+#ifdef SSAC_EXPERIMENT_SKIP_HEAD
+        return;
+#endif
         const int L = bid - p.tiles01;
         const int e = L / p.head_grid_x;
         if (fold) {
@@ -723,6 +726,12 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
         head_wgrad_body<4 * KS>(p.head, lds, L % p.head_grid_x, e, fold ? tab : nullptr, hpol, htau);
     } else {
         const bool first = bid < p.tiles0;
+#ifdef SSAC_EXPERIMENT_SKIP_FC1
+        if (!first) return;   // (measurement builds only: how long is the launch without the fc1 problem's tiles?)
+#endif
+#ifdef SSAC_EXPERIMENT_SKIP_FC2
+        if (first) return;
+#endif
         const GemmArgs &g = first ? p.g0 : p.g1;
         const int L = first ? bid : bid - p.tiles0;
         const int per = g.grid_x * g.grid_y;

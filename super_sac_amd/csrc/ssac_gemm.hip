@@ -671,7 +671,8 @@ struct GemmPair {
     GemmArgs g0, g1; int tiles0; int tiles01; int head_grid_x; HeadWgradArgs head;
     int head_total;                       // number of head workgroups (head_grid_x per net)
     int td_wg;                            // 1: one more workgroup behind them stores the TD targets + their statistics
-    int lf_nets;                          // ... and reduces the loss terms of these many nets
+    int lf_nets;                          // ... and reduces the loss terms of these many nets (0 with stats_in_head)
+    int stats_in_head;                    // the first head workgroup of every net reduces that net's loss terms
     int xcd;                              // XCD-contiguous tile order (ssac_internal.h)
     LossFoldArgs lf;                      // lf.q != null: dL/dq evaluated per workgroup (ssac_critic_logs.h)
     LogFoldArgs fold;                     // fold.done != null: the update's logs are finalised by the last workgroup
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
             loss_fold_table(p.lf, e, tab, true, tab + p.lf.n_rows, e == 0);
             __syncthreads();
         }
-        if (p.lf_nets == 0) {   // multi-round launch: the tiles reduce their nets' loss terms, this one only the TD part
+        if (p.lf_nets == 0) {   // the nets' loss terms are reduced elsewhere (head workgroups / first tiles): only the TD part
             loss_fold_table(p.lf, 0, tab, false, tab + p.lf.n_rows, true);
             __syncthreads();
         }
@@ -714,7 +715,10 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
         const int L = bid - p.tiles01;
         const int e = L / p.head_grid_x;
         if (fold) {
-            loss_fold_table(p.lf, e, tab, false, tab + p.lf.n_rows, false);
+            // (the first head workgroup of a net also reduces the net's loss terms: it builds the very table they are
+            // sums over anyway.  Round 2 gave all ten nets' terms to the TD workgroup -- a serial pass of ~2 us per net,
+            // 21 us on its own: profiles/r3_kernel_stats.md)
+            loss_fold_table(p.lf, e, tab, p.stats_in_head && (L % p.head_grid_x) == 0, tab + p.lf.n_rows, false);
             __syncthreads();
         }
         bool hpol = p.head.target != nullptr;
@@ -738,7 +742,7 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
         const int bz = L / per, rem = L - bz * per;
         // multi-round launches (no TD workgroup pass over the nets): the first fc2 tile of each net also reduces that
         // net's loss terms -- the one-step table with statistics; every other tile takes the two-step form
-        const bool stats = p.lf_nets == 0 && first && rem == 0;
+        const bool stats = p.lf_nets == 0 && !p.stats_in_head && first && rem == 0;
         ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % g.grid_x, rem / g.grid_x, bz, fold ? tab : nullptr, p.lf,
                                            fold ? (stats ? 2 : 1) : 0, p.fold, last, lt);
         drawn = true;
@@ -775,7 +779,8 @@ int launch_pair_ks(GemmPair &p, int batch0, int batch1, hipStream_t st) {
     p.td_wg = (p.lf.q && p.lf.tds.q_t) ? 1 : 0;
     // the TD workgroup takes over the per-net loss terms only while the launch is ONE round of workgroups (it then has
     // ~25 us of slack); in a multi-round launch (N = 16) a serial pass over 16 nets would itself become the tail
-    p.lf_nets = (p.td_wg && p.tiles01 + p.head_total + 1 <= 256) ? batch0 : 0;
+    p.stats_in_head = (p.lf.q && p.head_total > 0) ? 1 : 0;
+    p.lf_nets = (!p.stats_in_head && p.td_wg && p.tiles01 + p.head_total + 1 <= 256) ? batch0 : 0;
     const int total = p.tiles01 + p.head_total + p.td_wg;
     SSAC_LAUNCH((ens_gemm_pair_kernel<A_KC, B_KC, EPI, KS>), dim3(total), dim3(NTHREADS * KS), lds, st, p);
     return ssac_check_launch("ens_gemm_pair");

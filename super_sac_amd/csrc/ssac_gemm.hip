@@ -1097,6 +1097,7 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
         if (tiles <= 512 && nchunks >= 4) return launch_pair_ks<false, false, EPI_GRAD, 2>(p, n_sel, n_sel, st);
         return launch_pair_ks<false, false, EPI_GRAD, 1>(p, n_sel, n_sel, st);
     }
+    // (measured again in round 3 at the metric shape: 4 K-groups 58.3 us per update, 2 K-groups 61.4, none 73.3)
     if (tiles <= 256 && nchunks >= 8) return launch_pair_ks<false, false, EPI_ADAM, 4>(p, n_sel, n_sel, st);
     if (tiles <= 512 && nchunks >= 4) return launch_pair_ks<false, false, EPI_ADAM, 2>(p, n_sel, n_sel, st);
     return launch_pair_ks<false, false, EPI_ADAM, 1>(p, n_sel, n_sel, st);

@@ -614,16 +614,23 @@ int ssac_fused_supported(const ssac_mlp *nets);
  * records s_memtime() at its phase boundaries there; NULL (default) disables it. */
 int ssac_fused_debug_stamps(long long *dev_buf);
 int ssac_gemm_debug_stamps(long long *dev_buf); /* same for the weight-gradient GEMM launches */
+/* dev_buf: 2048 x int64 or NULL.  (start, end) of EVERY workgroup of the chained launch [0, 1024) and of the merged
+   weight-gradient launch [1024, 2048), s_memrealtime ticks (100 MHz): dispatch skew and the slowest workgroup class of a
+   launch (tools/wg_timeline.py). */
+int ssac_debug_timeline(long long *dev_buf);
 /* row tiles the fused critic launch uses for (n_rows, n_nets): the `partials` buffer holds
  * n_nets * tiles * 2 floats.  ssac_fused_tile_rows(0|16|17|32) overrides the automatic choice (17 = 16 rows with a
  * single weight-staging buffer, two workgroups per CU). */
 int ssac_fused_row_tiles(const ssac_mlp *nets, int n_rows, int n_nets);
 int ssac_fused_tile_rows(int rows);
-/* tuning knob, default 1: the MLP and weight-gradient kernels take their tile in XCD-contiguous order (workgroup b
- * runs on XCD b % 8; each XCD then works on one contiguous range of (net, tile) ids, so a net's weights / saved
- * activations are pulled into one or two of the eight L2s instead of all of them).  0 = hardware order.  Placement
- * only: results are bit-identical either way. */
-int ssac_xcd_order(int on);
+/* tuning knob (bit mask, default 2): kernels take their tile in XCD-contiguous order (workgroup b runs on XCD b % 8 --
+ * tools/lab/xcc_map.hip; each XCD then works on one contiguous range of (net, tile) ids, so a net's weights / saved
+ * activations are pulled into one or two of the eight L2s instead of all of them).  bit 0: the stand-alone fused MLP
+ * launches, bit 1: the GEMM / weight-gradient launches.  On unless disabled: the merged weight-gradient launch orders
+ * PER WORKGROUP CLASS (an eighth of the fc2 tiles, of the fc1 tiles and of the head workgroups per XCD, so that every
+ * XCD carries the same mix of long and short workgroups; bit 2 = off), the chained launch orders each of its halves
+ * (bit 3 = off).  0 | 12 = hardware order everywhere.  Placement only: results are bit-identical either way. */
+int ssac_xcd_order(int mask);
 
 /* y = MLP(x) for every selected net in ONE launch (agent.py:34 loop + mlps.py:123-129).
  * H1/H2 (n_sel x n_rows x hidden) are written when not NULL (needed by a later backward).  A negative entry of

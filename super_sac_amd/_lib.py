@@ -189,6 +189,7 @@ SIGNATURES = {
     "ssac_fused_supported": [_MP],
     "ssac_fused_debug_stamps": [_P],
     "ssac_gemm_debug_stamps": [_P],
+    "ssac_debug_timeline": [_P],
     "ssac_fused_row_tiles": [_MP, _I, _I],
     "ssac_fused_tile_rows": [_I],
     "ssac_xcd_order": [_I],

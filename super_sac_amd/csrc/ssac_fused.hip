@@ -86,6 +86,7 @@ struct FusedArgs {
     ssac_gather gth; int gth_role;  // 1: actor half (s' rows, begin duties), 3: actor half without the begin duties,
                                     // 2: critic half ([s|a] rows), 4: rows from X, net ids from the input slot; 0: X
     long long *dbg;  // optional phase timestamps (s_memtime) of workgroup (0,0), thread 0
+    long long *tl;   // optional per-workgroup (start, end) stamps of the chained launch (s_memrealtime; ssac_debug_timeline)
     ssac_td_spec tds;  // tds.q_t != null: the TD target is computed here instead of read from `td`
     float *DXU; int dx_col0, dx_cols;  // MODE_CRITIC_U: also the unscaled input gradient of columns [dx_col0, +dx_cols)
     int copy_x;                        // MODE_SAMPLE: also copy the input tile into act_dst[:, 0:in_dim]
@@ -1084,13 +1085,20 @@ void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs
                         int critic_grid_x, DeferredLogsArgs dl, int dl_on) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
+    if (gc.tl && threadIdx.x == 0) gc.tl[2 * bid] = __builtin_amdgcn_s_memrealtime();
     if (dl_on && bid == (int)gridDim.x - 1) {
         // one extra workgroup: the PREVIOUS recorded update's log block -> its slot of the log ring (ssac_critic_logs.h)
         deferred_logs_body(dl, -1);
         return;
     }
-    if (bid < tiles_t) {
-        const int j = bid / target_grid_x, bx = bid - j * target_grid_x;
+    // The critic tiles take the FIRST workgroup ids (they are the longer chain, and a launch's workgroups start in id
+    // order, ~1 us from first to last), the target chains the ids behind them.
+    const int n_main = (int)gridDim.x - (dl_on ? 1 : 0), n_crit = n_main - tiles_t;
+    if (bid >= n_crit) {
+        // (XCD-contiguous order within each half, ssac_internal.h: the row tiles of one net -- which stream the same
+        // weights -- sit on one or two XCDs instead of all eight)
+        const int lb = ssac_xcd_contiguous_range(bid, n_crit, n_main, gc.xcd);
+        const int j = lb / target_grid_x, bx = lb - j * target_grid_x;
         if (j > 0) {
             // critic-sharded ranks ("only subset owners need to send"): a slot whose REDQ member lives on
             // another rank has no target critic to feed here, and its a' / log pi rows are slot 0's work -- no actor
@@ -1109,8 +1117,12 @@ void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs
         // (phase stamps: the actor pass in slots 0.., the target-critic pass of subset slot 0 in 16.., the critics in 32..)
         fused_mlp_body<MODE_PLAIN, 16, true>(gt, smem, bx, j, target_grid_x, j == 0 ? 16 : -1);
     } else {
-        const int L = bid - tiles_t;
+        const int L = ssac_xcd_contiguous_range(bid, 0, n_crit, gc.xcd);
         fused_mlp_body<MODE_CRITIC_U, TC, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x, 32);
+    }
+    if (gc.tl) {
+        __syncthreads();   // (drains this workgroup's stores too)
+        if (threadIdx.x == 0) gc.tl[2 * bid + 1] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -1161,7 +1173,7 @@ void fill_common(FusedArgs &g, const ssac_mlp *nets, const int32_t *ids, const f
     g.in_dim = nets->in_dim; g.hidden = nets->hidden; g.out_dim = nets->out_dim;
     ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, g.off);
     g.ids = ids; g.X = X; g.ldx = ldx; g.sX = sX; g.n_rows = n_rows;
-    g.dbg = g_fused_dbg; g.xcd = g_ssac_xcd & 1;
+    g.dbg = g_fused_dbg; g.tl = g_ssac_timeline; g.xcd = g_ssac_xcd & 1;
 }
 
 template <int MODE, int TMR, bool DBUF>
@@ -1375,6 +1387,7 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
     gt.Y = Qt;
     fill_common(gc, critics, nullptr, Xc, ldxc, 0, n_rows);
     gc.H1 = H1; gc.H2 = H2; gc.Y = Q; gc.DZ2 = DZ2u; gc.DZ1 = DZ1u; gc.W3S = DZ2u ? nullptr : W3_snapshot;
+    gc.xcd = ((g_ssac_xcd & 1) || !(g_ssac_xcd & 8)) ? 1 : 0;   // the chained launch: XCD-contiguous halves by default
     if (gather) {
         if (gather->s_elems != actor->in_dim || gather->s_elems + gather->a_elems != critics->in_dim)
             return ssac_fail("ssac_chain_update: gather sizes do not match the networks");

@@ -223,10 +223,19 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     float *red = lds + KS * (4 * TILE_FLOATS);  // 64*KS floats: bias-grad / sumsq scratch
 
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    // Quadrant of the 64 x 64 tile this wave multiplies.  A wave's SIMD is its index within the K-group, so the mapping
+    // is ROTATED by the K-group: the two waves that own the left column block sit on SIMDs {0, 2}, {3, 1}, {2, 0}, {1, 3}
+    // for K-groups 0..3.  When the right block does not exist (a weight gradient with <= 32 columns: fc1 of a
+    // low-dimensional observation, 23 of 64 tile columns at the metric shape) its waves skip their fragment reads and
+    // MFMAs, and the remaining half of the matrix work is spread over all four SIMDs instead of loading two and idling
+    // two: the fc1 tiles -- the slowest workgroups of the merged launch until then -- finish ~3 us before the fc2 tiles
+    // (tools/wg_timeline.py).
+    const int wq = (wave + kg) & 3;
+    const int wm = wq >> 1, wn = wq & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int e = bz;
     const int m0 = by * BM, n0 = bx * BN;
+    const bool dead_cols = (n0 + wn * 32) >= g.N;   // (wave-uniform) this wave's 32 columns lie beyond the matrix
 
     const float *A = g.A + batch_off(g.ids, g.idsA, e, g.sA);
     const float *B = g.B + batch_off(g.ids, g.idsB, e, g.sB);
@@ -341,6 +350,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     const bool bias_wave = want_bias_grad && TN && wn == 0;  // bias gradient = column sums of A, from the fragments
     constexpr int HT = BK / 4;  // MFMAs per half chunk
     auto rd = [&](float (&fa)[HT], float (&fb)[HT], const float *buf, int half) {
+        if (dead_cols) return;
         const float *As = buf, *Bs = buf + TILE_FLOATS;
 #pragma unroll
         for (int t = 0; t < HT; ++t) {
@@ -353,6 +363,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
 #pragma unroll
             for (int t = 0; t < HT; ++t) bias_acc += fa[t];
         }
+        if (dead_cols) return;
 #pragma unroll
         for (int t = 0; t < HT; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
     };
@@ -674,9 +685,11 @@ struct GemmPair {
     int lf_nets;                          // ... and reduces the loss terms of these many nets (0 with stats_in_head)
     int stats_in_head;                    // the first head workgroup of every net reduces that net's loss terms
     int xcd;                              // XCD-contiguous tile order (ssac_internal.h)
+    int xcd_mix;                          // ... per workgroup class (every class count a multiple of 8)
     LossFoldArgs lf;                      // lf.q != null: dL/dq evaluated per workgroup (ssac_critic_logs.h)
     LogFoldArgs fold;                     // fold.done != null: the update's logs are finalised by the last workgroup
     const uint32_t *late_word;            // != null: the target update waits for the decision in this word
+    long long *tl;                        // optional per-workgroup (start, end) stamps (ssac_debug_timeline), slots from 1024
 };
 
 template <bool A_KC, bool B_KC, int EPI, int KS>
@@ -684,8 +697,18 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // (the XCD-contiguous order covers the GEMM + head workgroups only: the TD workgroup behind them keeps its own id,
     // so the tiles land on the same XCDs with or without it)
+    if (p.tl && threadIdx.x == 0) p.tl[1024 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     const int n_main = p.tiles01 + p.head_total;
-    const int bid = (int)blockIdx.x < n_main ? ssac_xcd_contiguous(blockIdx.x, n_main, p.xcd) : (int)blockIdx.x;
+    int bid = (int)blockIdx.x < n_main ? ssac_xcd_contiguous(blockIdx.x, n_main, p.xcd) : (int)blockIdx.x;
+    if (p.xcd_mix && (int)blockIdx.x < n_main) {
+        // XCD-contiguous PER CLASS: XCD x takes a contiguous eighth of the fc2 tiles, of the fc1 tiles and of the head
+        // workgroups (heavy first), instead of a contiguous eighth of the concatenated list -- which gave five XCDs 30
+        // fc2 tiles each and two XCDs nothing but the short head workgroups
+        const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int a8 = p.tiles0 >> 3, f8 = (p.tiles01 - p.tiles0) >> 3, h8 = p.head_total >> 3;
+        bid = slot < a8 ? x * a8 + slot
+                        : (slot < a8 + f8 ? p.tiles0 + x * f8 + (slot - a8) : p.tiles01 + x * h8 + (slot - a8 - f8));
+    }
     float *tab = lds + KS * (4 * TILE_FLOATS) + 64 * KS;  // folded loss gradient: [n_rows] row scales, then scratch
     const bool fold = p.lf.q != nullptr;
     const LateTau lt{p.late_word != nullptr, p.late_word ? *p.late_word : 0u};
@@ -758,6 +781,10 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
     } else if (p.fold.deferred_stats && p.fold.feed && blockIdx.x == 0 && threadIdx.x == 0) {
         p.fold.feed->tick += 1;   // deferred finalisation: the update is over for the input ring (no reader in this launch)
     }
+    if (p.tl) {
+        __syncthreads();
+        if (threadIdx.x == 0) p.tl[1024 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 template <bool A_KC, bool B_KC, int EPI, int KS>
@@ -773,9 +800,12 @@ int launch_pair_ks(GemmPair &p, int batch0, int batch1, hipStream_t st) {
         attr_set = true;
     }
     p.xcd = (g_ssac_xcd >> 1) & 1;
+    p.tl = g_ssac_timeline;
+    p.xcd_mix = 0;
     p.tiles0 = p.g0.grid_x * p.g0.grid_y * batch0;
     p.tiles01 = p.tiles0 + p.g1.grid_x * p.g1.grid_y * batch1;
     p.head_total = p.head_grid_x > 0 ? p.head_grid_x * batch0 : 0;
+    p.xcd_mix = (p.xcd && (g_ssac_xcd & 4) == 0 && p.tiles0 % 8 == 0 && (p.tiles01 - p.tiles0) % 8 == 0 && p.head_total % 8 == 0) ? 1 : 0;
     p.td_wg = (p.lf.q && p.lf.tds.q_t) ? 1 : 0;
     // the TD workgroup takes over the per-net loss terms only while the launch is ONE round of workgroups (it then has
     // ~25 us of slack); in a multi-round launch (N = 16) a serial pass over 16 nets would itself become the tail

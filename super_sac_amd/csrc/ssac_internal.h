@@ -69,6 +69,7 @@ inline void ssac_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t 
 // hardware order.
 // ---------------------------------------------------------------------------------------------
 extern int g_ssac_xcd;
+extern long long *g_ssac_timeline;   // ssac_debug_timeline (ssac_fused.hip)
 #ifdef __HIPCC__
 // Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global loads / stores.
 // __syncthreads() also drains vmcnt -- inside a software-pipelined K loop that exposes the round trip of the operand
@@ -81,5 +82,21 @@ __device__ __forceinline__ int ssac_xcd_contiguous(int bid, int nwg, int on) {
     if (!on) return bid;
     const int xcd = bid & 7, slot = bid >> 3, q = nwg >> 3, r = nwg & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// The same order for a sub-range [t0, n) of a launch's workgroup ids (the halves of a merged launch): logical id
+// (0-based within the range) of workgroup `bid`, such that the range's workgroups on XCD x -- those with
+// bid % 8 == x -- hold one contiguous run of logical ids.
+__device__ __forceinline__ int ssac_xcd_contiguous_range(int bid, int t0, int n, int on) {
+    if (!on) return bid - t0;
+    const int x = bid & 7;
+    int before = 0;
+#pragma unroll
+    for (int y = 0; y < 8; ++y) {
+        const int upto_n = n > y ? (n - y + 7) >> 3 : 0, upto_t0 = t0 > y ? (t0 - y + 7) >> 3 : 0;
+        if (y < x) before += upto_n - upto_t0;
+    }
+    const int first_slot = t0 > x ? (t0 - x + 7) >> 3 : 0;   // ids below t0 on this XCD
+    return before + (bid >> 3) - first_slot;
 }
 #endif

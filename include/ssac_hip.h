@@ -618,6 +618,9 @@ int ssac_gemm_debug_stamps(long long *dev_buf); /* same for the weight-gradient 
    weight-gradient launch [1024, 2048), s_memrealtime ticks (100 MHz): dispatch skew and the slowest workgroup class of a
    launch (tools/wg_timeline.py). */
 int ssac_debug_timeline(long long *dev_buf);
+/* tuning knob, default 1: the merged weight-gradient launch uses its lean kernel (16-byte operand loader only) whenever
+   both problems qualify; 0 = always the general kernel.  Bit-identical results. */
+int ssac_gemm_lean(int on);
 /* row tiles the fused critic launch uses for (n_rows, n_nets): the `partials` buffer holds
  * n_nets * tiles * 2 floats.  ssac_fused_tile_rows(0|16|17|32) overrides the automatic choice (17 = 16 rows with a
  * single weight-staging buffer, two workgroups per CU). */

@@ -190,6 +190,7 @@ SIGNATURES = {
     "ssac_fused_debug_stamps": [_P],
     "ssac_gemm_debug_stamps": [_P],
     "ssac_debug_timeline": [_P],
+    "ssac_gemm_lean": [_I],
     "ssac_fused_row_tiles": [_MP, _I, _I],
     "ssac_fused_tile_rows": [_I],
     "ssac_xcd_order": [_I],
@@ -265,6 +266,8 @@ def _load():
                           f"{ABI_VERSION}: rebuild the extension (build.sh)")
     if not debug_knob("feed_device", True):
         lib.ssac_feed_ring_mode(0)
+    if debug_knob("gemm_lean", -1) >= 0:
+        lib.ssac_gemm_lean(debug_knob("gemm_lean", -1))
     if debug_knob("xcd_order", -1) >= 0:
         lib.ssac_xcd_order(debug_knob("xcd_order", -1))
     return lib

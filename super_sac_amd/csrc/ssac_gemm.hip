@@ -73,6 +73,7 @@ __device__ __forceinline__ int64_t batch_off(const int32_t *ids, int use_ids, in
 }
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load of a dword-aligned address (gfx950: no wider requirement)
 
 // ---- global -> register staging (8 floats per thread per operand per chunk, held in the SAME two f4 registers the
 //      16-byte loader uses -- one staging set per operand, whichever load path a launch takes), branch-free:
@@ -158,12 +159,16 @@ struct RcVecLoader {
     int kk, r4;
     int klast;          // k0 of the rows held in v (late row scale: applied when the rows are stored)
     bool rok;
+    bool ragged;        // this thread's 4 columns straddle the matrix edge (R % 4 != 0): element-wise loads, zero filled
+    int nv;             // ... and how many of them exist
     __device__ __forceinline__ void init(const float *S, int64_t ld, int R0, int R, int kfirst, int tid) {
         sign = false;
         r4 = (tid & 15) * 4;
         kk = tid >> 4;
         base = S;
-        rok = (R0 + r4) < R;  // R % 4 == 0 on this path
+        rok = (R0 + r4) < R;
+        nv = rok ? min(4, R - (R0 + r4)) : 0;
+        ragged = rok && nv < 4;
         ld16 = (uint32_t)(16 * ld);
         off = rok ? (uint32_t)((kfirst + kk) * ld + R0 + r4) : 0u;
         klast = 0;
@@ -175,7 +180,13 @@ struct RcVecLoader {
             const int k = k0 + kk + 16 * q;
             const bool ok = rok && k < K;
             const uint32_t o = ok ? off + q * ld16 : 0u;
-            const f4 x = *reinterpret_cast<const f4 *>(base + (size_t)o);
+            f4 x;
+            if (ragged) {   // (rows need not be 16-byte aligned, but nothing is read beyond a row's last element)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x[c] = c < nv ? base[(size_t)o + (ok ? c : 0)] : 0.0f;
+            } else {
+                x = *reinterpret_cast<const f4u *>(base + (size_t)o);
+            }
             const float sc = scale ? scale[ok ? k : 0] : 1.0f;
             v[q] = ok ? x * sc : (f4){0.f, 0.f, 0.f, 0.f};
         }
@@ -210,7 +221,12 @@ struct RcVecLoader {
 // first launch left in feed->late_word (tau bits, 0 = no soft_update followed this update)
 struct LateTau { bool on; uint32_t bits; };
 
-template <bool A_KC, bool B_KC, int EPI, int KS>
+// VECONLY: both operands take the 16-byte loader (decided per launch on the host): the element-wise loaders are not
+// compiled into the K loop at all.  They used to sit in it behind uniform branches -- never taken at the metric shape,
+// but the loop body was ~700 instructions long and its registers were allocated for the worst path.  One instantiation
+// of this body per KERNEL (a second one inside the same kernel makes the compiler copy the argument block to scratch),
+// hence the kernel carries the flag.
+template <bool A_KC, bool B_KC, int EPI, int KS, bool VECONLY = false>
 __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int bx, int by, int bz,
                                               float *late_rs, const LossFoldArgs &lf, int lf_mode,
                                               const LogFoldArgs &fold, int &last,
@@ -253,8 +269,9 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     constexpr bool TN = !A_KC && !B_KC;
     // 16-byte loads need 16-byte aligned rows on both operands (checked per launch on the host)
     // ... and a batch entry's operand must span < 2^31 floats (32-bit lane offsets in RcVecLoader)
-    const bool vecA = TN && (g.vec & 1) && (int64_t)(Kloc + 1) * g.lda < (1LL << 31);
-    const bool vecB = TN && (g.vec & 2) && (int64_t)(Kloc + 1) * g.ldb < (1LL << 31);
+    static_assert(!VECONLY || TN, "the 16-byte loader reads row-contiguous operands");
+    const bool vecA = VECONLY ? true : (TN && (g.vec & 1) && (int64_t)(Kloc + 1) * g.lda < (1LL << 31));
+    const bool vecB = VECONLY ? true : (TN && (g.vec & 2) && (int64_t)(Kloc + 1) * g.ldb < (1LL << 31));
 
     RcVecLoader va, vb;
     if (vecA) {
@@ -322,19 +339,20 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     // element group, result unused): the epilogues of all ~200 workgroups of the launch fall into the same few
     // microseconds, and their 12.8 MB of optimizer-state reads + 12.8 MB of writes ran at the HBM rate there (8.7 k
     // clocks per workgroup) -- requested here, the reads travel during the K loop, which is nowhere near the memory
-    // bandwidth.  (inline asm: a load whose result nobody uses would be deleted; the unaccounted vmcnt entries are the
-    // OLDEST in flight, so every compiler-placed wait still covers what it meant to cover)
-    // The landing register `l2_sink` stays reserved until the epilogue (the data arrives long after the asm statement;
-    // a register the allocator had handed to something else by then would be overwritten under it).
-    float l2_sink = 0.0f;
+    // bandwidth.  Ordinary loads whose four results stay live until the epilogue consumes them with an empty asm
+    // statement (a load nobody uses would be deleted).  (Until late in round 3 these were inline-asm loads into ONE
+    // register the compiler did not know to be in flight: correct only as long as the allocator never spilled or
+    // re-used that register during the K loop -- the general kernel, at 128 VGPRs with spills, eventually did, and the
+    // late-arriving dword overwrote an address: a memory access fault at the metric shape.)
+    float l2_sink[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (PREFETCH_OPT && vecC) {
         const int row = tid_all >> 4, col = (tid_all & 15) * 4;
         if ((m0 + row) < g.M && (n0 + col) < g.N) {
             const int64_t a = coff + (int64_t)(m0 + row) * g.ldc + n0 + col;
-            asm volatile("global_load_dword %0, %1, off" : "+v"(l2_sink) : "v"(g.C + a) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "+v"(l2_sink) : "v"(g.am + a) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "+v"(l2_sink) : "v"(g.av + a) : "memory");
-            if (pol_) asm volatile("global_load_dword %0, %1, off" : "+v"(l2_sink) : "v"(g.tw + a) : "memory");
+            l2_sink[0] = g.C[a];
+            l2_sink[1] = g.am[a];
+            l2_sink[2] = g.av[a];
+            if (pol_) l2_sink[3] = g.tw[a];
         }
     }
 
@@ -410,6 +428,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     if (bias_wave) bias_acc += __shfl_xor(bias_acc, 32, 64);  // the two k parities of column li
 
     GSTAMP(2);
+    asm volatile("" :: "v"(l2_sink[0]), "v"(l2_sink[1]), "v"(l2_sink[2]), "v"(l2_sink[3]));   // (the L2 touches end here)
     if (EPI == EPI_ADAM || EPI == EPI_GRAD) {
         // ---- weight-gradient epilogue on ALL threads of the workgroup.  Every K-group parks its
         // partial 64x64 tile in LDS; element idx = row*64 + col is then finished (partials summed in
@@ -517,7 +536,6 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
                     if (pol) *reinterpret_cast<f4 *>(g.tw + c4[j]) = tn;
                 }
             }
-            asm volatile("" :: "v"(l2_sink));   // (end of the landing register's reservation)
             if (bias_thr_) {
                 if (EPI == EPI_GRAD) {
                     g.gb[bi_] = bsum_;
@@ -678,6 +696,8 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
 // [0, tiles0) work on g0, the rest on g1, so the small problem fills CUs the big one leaves idle.
 // Optionally a third piece: the head layer's (VALU) weight gradient as `head_tiles` extra workgroups.
 // And optionally the update's log finalisation, run by whichever workgroup finishes LAST (device counter).
+extern int g_gemm_lean;   // ssac_gemm_lean: 0 = always the general kernel
+
 struct GemmPair {
     GemmArgs g0, g1; int tiles0; int tiles01; int head_grid_x; HeadWgradArgs head;
     int head_total;                       // number of head workgroups (head_grid_x per net)
@@ -692,7 +712,7 @@ struct GemmPair {
     long long *tl;                        // optional per-workgroup (start, end) stamps (ssac_debug_timeline), slots from 1024
 };
 
-template <bool A_KC, bool B_KC, int EPI, int KS>
+template <bool A_KC, bool B_KC, int EPI, int KS, bool VECONLY = false>
 __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // (the XCD-contiguous order covers the GEMM + head workgroups only: the TD workgroup behind them keeps its own id,
@@ -766,8 +786,8 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
         // multi-round launches (no TD workgroup pass over the nets): the first fc2 tile of each net also reduces that
         // net's loss terms -- the one-step table with statistics; every other tile takes the two-step form
         const bool stats = p.lf_nets == 0 && !p.stats_in_head && first && rem == 0;
-        ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % g.grid_x, rem / g.grid_x, bz, fold ? tab : nullptr, p.lf,
-                                           fold ? (stats ? 2 : 1) : 0, p.fold, last, lt);
+        ens_gemm_body<A_KC, B_KC, EPI, KS, VECONLY>(g, lds, rem % g.grid_x, rem / g.grid_x, bz, fold ? tab : nullptr, p.lf,
+                                                    fold ? (stats ? 2 : 1) : 0, p.fold, last, lt);
         drawn = true;
     }
     if (p.fold.done) {
@@ -793,10 +813,22 @@ int launch_pair_ks(GemmPair &p, int batch0, int batch1, hipStream_t st) {
     const size_t lds = sizeof(float) * (KS * 4 * TILE_FLOATS + 64 * KS + (p.lf.q ? p.lf.n_rows + 16 * KS : 0));
     constexpr int PAIR_LDS_MAX = 160 * 1024 - 256;  // the kernel also has a few bytes of static LDS
     if (lds > PAIR_LDS_MAX) return ssac_fail("ens_gemm_pair: the folded loss table does not fit LDS");
+    // the lean kernel (16-byte loader on both operands of both problems, nothing else compiled into the K loop)
+    constexpr bool TN_ = !A_KC && !B_KC;
+    auto vec_ok = [](const GemmArgs &g) {
+        return (g.vec & 1) && (g.vec & 6) && g.Ktot <= 0 && (int64_t)(g.K + 1) * g.lda < (1LL << 31) &&
+               (int64_t)(g.K + 1) * g.ldb < (1LL << 31);
+    };
+    const bool lean = TN_ && g_gemm_lean && vec_ok(p.g0) && vec_ok(p.g1);
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)ens_gemm_pair_kernel<A_KC, B_KC, EPI, KS>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_MAX) != hipSuccess)
             return ssac_fail("ens_gemm_pair: cannot raise the dynamic LDS limit");
+        if constexpr (TN_) {
+            if (hipFuncSetAttribute((const void *)ens_gemm_pair_kernel<A_KC, B_KC, EPI, KS, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, PAIR_LDS_MAX) != hipSuccess)
+                return ssac_fail("ens_gemm_pair: cannot raise the dynamic LDS limit");
+        }
         attr_set = true;
     }
     p.xcd = (g_ssac_xcd >> 1) & 1;
@@ -812,6 +844,12 @@ int launch_pair_ks(GemmPair &p, int batch0, int batch1, hipStream_t st) {
     p.stats_in_head = (p.lf.q && p.head_total > 0) ? 1 : 0;
     p.lf_nets = (!p.stats_in_head && p.td_wg && p.tiles01 + p.head_total + 1 <= 256) ? batch0 : 0;
     const int total = p.tiles01 + p.head_total + p.td_wg;
+    if constexpr (TN_) {
+        if (lean) {
+            SSAC_LAUNCH((ens_gemm_pair_kernel<A_KC, B_KC, EPI, KS, true>), dim3(total), dim3(NTHREADS * KS), lds, st, p);
+            return ssac_check_launch("ens_gemm_pair");
+        }
+    }
     SSAC_LAUNCH((ens_gemm_pair_kernel<A_KC, B_KC, EPI, KS>), dim3(total), dim3(NTHREADS * KS), lds, st, p);
     return ssac_check_launch("ens_gemm_pair");
 }
@@ -898,6 +936,8 @@ int launch_head_rows(const GemmArgs &g, int batch, bool relu, hipStream_t st) {
 }
 
 long long *g_gemm_dbg = nullptr;
+int g_gemm_lean = 1;
+extern "C" int ssac_gemm_lean(int on) { g_gemm_lean = on ? 1 : 0; return 0; }
 
 struct LayerGeom { int64_t off_w, off_b; int rows, cols; };
 
@@ -982,8 +1022,13 @@ bool build_wgrad_args(GemmArgs &g, const ssac_mlp *nets, int layer, const int32_
     g.M = L.rows; g.N = L.cols; g.K = n_rows;
     g.grid_x = (g.N + BN - 1) / BN; g.grid_y = (g.M + BM - 1) / BM;
     g.ids = net_ids;
+    // bit 0 / bit 1: the A / B rows are 16-byte aligned and a multiple of 4 floats long (the 16-byte loader of the
+    // general kernel); bit 2: the B rows take the LEAN kernel's loader -- any row length and leading dimension
+    // (dword-aligned 16-byte loads; a ragged last vector is read element-wise): the 23-float [s | a] rows of the
+    // metric shape as well
     g.vec = (((uintptr_t)dY & 15) == 0 && (ldy & 3) == 0 && (y_net_stride & 3) == 0 && (L.rows & 3) == 0 ? 1 : 0) |
-            (((uintptr_t)X & 15) == 0 && (ldx & 3) == 0 && (x_net_stride & 3) == 0 && (L.cols & 3) == 0 ? 2 : 0);
+            (((uintptr_t)X & 15) == 0 && (ldx & 3) == 0 && (x_net_stride & 3) == 0 && (L.cols & 3) == 0 ? 2 : 0) |
+            (((uintptr_t)X & 3) == 0 ? 4 : 0);
     g.pb = nets->params + L.off_b;
     g.ctl = ctl; g.sumsq = sumsq; g.sumsq_stride = sumsq_net_stride; g.dbg = g_gemm_dbg; g.tau = tau;
     if (grads) { g.gw = grads + L.off_w; g.gb = grads + L.off_b; }

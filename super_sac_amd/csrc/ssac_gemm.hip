@@ -174,11 +174,13 @@ struct RcVecLoader {
         klast = 0;
     }
     // predicated-off lanes read the (always valid, 16-byte aligned) first element of the operand
+    // KFULL: K is a multiple of the chunk depth (the lean kernel's launch condition): no row of a chunk lies beyond K
+    template <bool KFULL = false>
     __device__ __forceinline__ void load(int k0, int K, uint32_t adv, const float *scale = nullptr) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int k = k0 + kk + 16 * q;
-            const bool ok = rok && k < K;
+            const bool ok = KFULL ? rok : (rok && k < K);
             const uint32_t o = ok ? off + q * ld16 : 0u;
             f4 x;
             if (ragged) {   // (rows need not be 16-byte aligned, but nothing is read beyond a row's last element)
@@ -288,7 +290,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     const float *rscale = (TN && g.rowscale && !late_rs) ? g.rowscale + (int64_t)e * g.sRow : nullptr;
     int ra_k0 = 0;
     auto loadA = [&](int k0) {
-        if (vecA) { va.load(k0, Kloc, advA, rscale); return; }
+        if (vecA) { va.template load<VECONLY>(k0, Kloc, advA, rscale); return; }
         ra_k0 = k0;
         load_chunk<A_KC>(va.v, A, g.lda, m0, g.M, k0, Kloc, tid);
         if (TN && rscale) {  // (K x R) layout: this thread's 8 values sit at k = k0 + (tid >> 6) + 4 p
@@ -299,7 +301,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
             }
         }
     };
-    auto loadB = [&](int k0) { if (vecB) vb.load(k0, Kloc, advB); else load_chunk<B_KC>(vb.v, B, g.ldb, n0, g.N, k0, Kloc, tid); };
+    auto loadB = [&](int k0) { if (vecB) vb.template load<VECONLY>(k0, Kloc, advB); else load_chunk<B_KC>(vb.v, B, g.ldb, n0, g.N, k0, Kloc, tid); };
     auto storeA = [&](float *d) {
         if (vecA) { va.store(d, TN ? late_rs : nullptr, Kloc); return; }
         if (TN && late_rs) {
@@ -816,7 +818,7 @@ int launch_pair_ks(GemmPair &p, int batch0, int batch1, hipStream_t st) {
     // the lean kernel (16-byte loader on both operands of both problems, nothing else compiled into the K loop)
     constexpr bool TN_ = !A_KC && !B_KC;
     auto vec_ok = [](const GemmArgs &g) {
-        return (g.vec & 1) && (g.vec & 6) && g.Ktot <= 0 && (int64_t)(g.K + 1) * g.lda < (1LL << 31) &&
+        return (g.vec & 1) && (g.vec & 6) && g.Ktot <= 0 && g.K % BK == 0 && (int64_t)(g.K + 1) * g.lda < (1LL << 31) &&
                (int64_t)(g.K + 1) * g.ldb < (1LL << 31);
     };
     const bool lean = TN_ && g_gemm_lean && vec_ok(p.g0) && vec_ok(p.g1);

@@ -159,16 +159,18 @@ struct RcVecLoader {
     int kk, r4;
     int klast;          // k0 of the rows held in v (late row scale: applied when the rows are stored)
     bool rok;
-    bool ragged;        // this thread's 4 columns straddle the matrix edge (R % 4 != 0): element-wise loads, zero filled
-    int nv;             // ... and how many of them exist
+    bool any_ragged;    // R % 4 != 0: some thread's 4 columns straddle the matrix edge
+    int nv;             // how many of this thread's 4 columns exist (4: all; 1..3: the straddling vector)
+    uint32_t back;      // 4 - nv for the straddling vector (its load starts that many elements earlier), else 0
     __device__ __forceinline__ void init(const float *S, int64_t ld, int R0, int R, int kfirst, int tid) {
         sign = false;
         r4 = (tid & 15) * 4;
         kk = tid >> 4;
         base = S;
         rok = (R0 + r4) < R;
-        nv = rok ? min(4, R - (R0 + r4)) : 0;
-        ragged = rok && nv < 4;
+        nv = rok ? min(4, R - (R0 + r4)) : 4;
+        any_ragged = (R & 3) != 0;
+        back = (uint32_t)(4 - nv);
         ld16 = (uint32_t)(16 * ld);
         off = rok ? (uint32_t)((kfirst + kk) * ld + R0 + r4) : 0u;
         klast = 0;
@@ -182,12 +184,16 @@ struct RcVecLoader {
             const int k = k0 + kk + 16 * q;
             const bool ok = KFULL ? rok : (rok && k < K);
             const uint32_t o = ok ? off + q * ld16 : 0u;
-            f4 x;
-            if (ragged) {   // (rows need not be 16-byte aligned, but nothing is read beyond a row's last element)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) x[c] = c < nv ? base[(size_t)o + (ok ? c : 0)] : 0.0f;
-            } else {
-                x = *reinterpret_cast<const f4u *>(base + (size_t)o);
+            // (rows need not be 16-byte aligned.  A ragged last vector -- nv of its 4 columns exist -- is read 4 - nv
+            // elements EARLIER, so that nothing beyond the row's last element is touched, and shifted back: no branch,
+            // no extra load; rows have >= 4 elements on this path)
+            const f4 y = *reinterpret_cast<const f4u *>(base + (size_t)o - (ok ? back : 0u));
+            f4 x = y;
+            if (any_ragged) {   // (uniform: the matrix width is no multiple of 4)
+                x[0] = nv == 4 ? y[0] : (nv == 3 ? y[1] : (nv == 2 ? y[2] : y[3]));
+                x[1] = nv == 4 ? y[1] : (nv == 3 ? y[2] : (nv == 2 ? y[3] : 0.0f));
+                x[2] = nv == 4 ? y[2] : (nv == 3 ? y[3] : 0.0f);
+                x[3] = nv == 4 ? y[3] : 0.0f;
             }
             const float sc = scale ? scale[ok ? k : 0] : 1.0f;
             v[q] = ok ? x * sc : (f4){0.f, 0.f, 0.f, 0.f};
@@ -234,13 +240,16 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
                                               const LogFoldArgs &fold, int &last,
                                               const LateTau &lt = LateTau{false, 0u}) {
     const int tid_all = threadIdx.x;
-    const int kg = tid_all >> 8, tid = tid_all & 255;
+    // (K-group and wave index are the same in every lane of a wave: said so explicitly, everything derived from them --
+    // the tile quadrant, "this wave sums the bias", "this wave's columns do not exist" -- is a scalar branch instead of
+    // an exec-masked region inside the K loop)
+    const int kg = __builtin_amdgcn_readfirstlane(tid_all >> 8), tid = tid_all & 255;
     // per K-group: two staging buffers (double buffering), each [A tile | B tile]
     float *buf0 = lds + kg * (4 * TILE_FLOATS);
     float *buf1 = buf0 + 2 * TILE_FLOATS;
     float *red = lds + KS * (4 * TILE_FLOATS);  // 64*KS floats: bias-grad / sumsq scratch
 
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // Quadrant of the 64 x 64 tile this wave multiplies.  A wave's SIMD is its index within the K-group, so the mapping
     // is ROTATED by the K-group: the two waves that own the left column block sit on SIMDs {0, 2}, {3, 1}, {2, 0}, {1, 3}
     // for K-groups 0..3.  When the right block does not exist (a weight gradient with <= 32 columns: fc1 of a
@@ -1030,7 +1039,7 @@ bool build_wgrad_args(GemmArgs &g, const ssac_mlp *nets, int layer, const int32_
     // metric shape as well
     g.vec = (((uintptr_t)dY & 15) == 0 && (ldy & 3) == 0 && (y_net_stride & 3) == 0 && (L.rows & 3) == 0 ? 1 : 0) |
             (((uintptr_t)X & 15) == 0 && (ldx & 3) == 0 && (x_net_stride & 3) == 0 && (L.cols & 3) == 0 ? 2 : 0) |
-            (((uintptr_t)X & 3) == 0 ? 4 : 0);
+            ((((uintptr_t)X & 3) == 0 && L.cols >= 4) ? 4 : 0);
     g.pb = nets->params + L.off_b;
     g.ctl = ctl; g.sumsq = sumsq; g.sumsq_stride = sumsq_net_stride; g.dbg = g_gemm_dbg; g.tau = tau;
     if (grads) { g.gw = grads + L.off_w; g.gb = grads + L.off_b; }

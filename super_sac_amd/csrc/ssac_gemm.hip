@@ -169,7 +169,7 @@ struct RcVecLoader {
         base = S;
         rok = (R0 + r4) < R;
         nv = rok ? min(4, R - (R0 + r4)) : 4;
-        any_ragged = (R & 3) != 0;
+        any_ragged = __builtin_amdgcn_readfirstlane((R & 3) != 0 ? 1 : 0) != 0;
         back = (uint32_t)(4 - nv);
         ld16 = (uint32_t)(16 * ld);
         off = rok ? (uint32_t)((kfirst + kk) * ld + R0 + r4) : 0u;
@@ -177,12 +177,31 @@ struct RcVecLoader {
     }
     // predicated-off lanes read the (always valid, 16-byte aligned) first element of the operand
     // KFULL: K is a multiple of the chunk depth (the lean kernel's launch condition): no row of a chunk lies beyond K
+    // ... and the lanes whose columns do not exist are NOT zeroed there: a dead column of A or B only ever reaches output
+    // rows / columns beyond the matrix, which every epilogue guards (stores, bias sums, gradient-norm partials) -- so the
+    // lean loop carries no per-lane predicate at all: load, [rotate a ragged vector], [scale], store.
     template <bool KFULL = false>
     __device__ __forceinline__ void load(int k0, int K, uint32_t adv, const float *scale = nullptr) {
+        if constexpr (KFULL) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = k0 + kk + 16 * q;
+                f4 x = *reinterpret_cast<const f4u *>(base + (size_t)(off + q * ld16) - back);
+                if (any_ragged) {   // (uniform) rotate the straddling lane's vector left by `back`: x[c] = y[c + back]
+                    const bool b1 = (back & 1u) != 0, b2 = (back & 2u) != 0;
+                    const f4 t = {b1 ? x[1] : x[0], b1 ? x[2] : x[1], b1 ? x[3] : x[2], b1 ? x[0] : x[3]};
+                    x = (f4){b2 ? t[2] : t[0], b2 ? t[3] : t[1], b2 ? t[0] : t[2], b2 ? t[1] : t[3]};
+                }
+                v[q] = scale ? x * scale[k] : x;
+            }
+            klast = k0;
+            off += adv;
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int k = k0 + kk + 16 * q;
-            const bool ok = KFULL ? rok : (rok && k < K);
+            const bool ok = rok && k < K;
             const uint32_t o = ok ? off + q * ld16 : 0u;
             // (rows need not be 16-byte aligned.  A ragged last vector -- nv of its 4 columns exist -- is read 4 - nv
             // elements EARLIER, so that nothing beyond the row's last element is touched, and shifted back: no branch,
@@ -202,6 +221,7 @@ struct RcVecLoader {
         off += adv;
     }
     // late: row scales in LDS (loss_fold_table), applied here so the loads need not wait for the table
+    template <bool KFULL = false>
     __device__ __forceinline__ void store(float *Xt, const float *late = nullptr, int K = 0) const {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -211,7 +231,8 @@ struct RcVecLoader {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) x[c] = x[c] > 0.0f ? sw[c] : 0.0f;
             }
-            *reinterpret_cast<f4 *>(Xt + (kk + 16 * q) * LDS_RC + r4) = late ? x * late[(rok && k < K) ? k : 0] : x;
+            *reinterpret_cast<f4 *>(Xt + (kk + 16 * q) * LDS_RC + r4) =
+                late ? x * late[KFULL ? k : ((rok && k < K) ? k : 0)] : x;
         }
     }
 };
@@ -312,7 +333,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     };
     auto loadB = [&](int k0) { if (vecB) vb.template load<VECONLY>(k0, Kloc, advB); else load_chunk<B_KC>(vb.v, B, g.ldb, n0, g.N, k0, Kloc, tid); };
     auto storeA = [&](float *d) {
-        if (vecA) { va.store(d, TN ? late_rs : nullptr, Kloc); return; }
+        if (vecA) { va.template store<VECONLY>(d, TN ? late_rs : nullptr, Kloc); return; }
         if (TN && late_rs) {
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
@@ -322,7 +343,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
         }
         store_chunk<A_KC>(va.v, d, tid);
     };
-    auto storeB = [&](float *d) { if (vecB) vb.store(d); else store_chunk<B_KC>(vb.v, d, tid); };
+    auto storeB = [&](float *d) { if (vecB) vb.template store<VECONLY>(d); else store_chunk<B_KC>(vb.v, d, tid); };
 
     // ---- optimizer state of this thread's 4 tile elements, requested during the LAST K chunk (the operand staging
     //      registers are free by then) so that the epilogue finds p / m / v [/ target] in registers instead of opening

@@ -159,12 +159,11 @@ struct KcStage {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f4u *>(p[q] + k0);
     }
+    // (weight rows beyond the layer width are NOT zeroed: they only ever reach accumulator columns beyond the layer
+    // width, which no epilogue reads -- and the K loop loses 16 selects per chunk; their pointers read row 0)
     __device__ __forceinline__ void store(float *__restrict__ Ws, int tid) const {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool ok = (okmask >> q) & 1u;
-            *reinterpret_cast<f4 *>(Ws + ((tid >> 3) + 64 * q) * WS_LD + kk) = ok ? v[q] : (f4){0.f, 0.f, 0.f, 0.f};
-        }
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f4 *>(Ws + ((tid >> 3) + 64 * q) * WS_LD + kk) = v[q];
     }
 };
 
@@ -191,13 +190,11 @@ struct RcStage {
             v[q] = ok ? x : (f4){0.f, 0.f, 0.f, 0.f};
         }
     }
-    // rows [n0, n0 + 32) known to lie inside K
+    // rows [n0, n0 + 32) known to lie inside K.  (columns beyond the matrix are not zeroed -- they feed accumulator
+    // columns nobody reads -- so the steady loop has no per-lane predicate; their pointers read column 0)
     __device__ __forceinline__ void load_full(int n0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f4 x = *reinterpret_cast<const f4u *>(p[q] + (cok ? (int64_t)n0 * ldw_ : 0));
-            v[q] = cok ? x : (f4){0.f, 0.f, 0.f, 0.f};
-        }
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f4u *>(p[q] + (int64_t)n0 * ldw_);
     }
     __device__ __forceinline__ void store(float *__restrict__ Wt, int tid) const {
 #pragma unroll

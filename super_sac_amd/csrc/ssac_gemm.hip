@@ -66,6 +66,7 @@ struct GemmArgs {
     // 5 MB per update at the metric shape).  a_sign_w: (n_nets x M) SNAPSHOT of the head rows the chained launch took --
     // not the arena's W3, which the head workgroups of this very launch are updating
     const float *a_sign_w;
+    int no_bias;             // the bias gradient of this layer is somebody else's job (the head workgroups: HeadWgradArgs::b2_w3s)
 };
 
 __device__ __forceinline__ int64_t batch_off(const int32_t *ids, int use_ids, int e, int64_t stride) {
@@ -294,7 +295,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 
     float bias_acc = 0.0f;  // TN mode, column sums of A (bias gradient), threads < 64 of n-tile 0
-    const bool want_bias_grad = (EPI == EPI_ADAM || EPI == EPI_GRAD) && bx == 0;
+    const bool want_bias_grad = (EPI == EPI_ADAM || EPI == EPI_GRAD) && bx == 0 && !g.no_bias;
     const int Kloc = g.Ktot > 0 ? max(0, min(g.K, g.Ktot - e * g.K)) : g.K;
     const int nchunks = (Kloc + BK - 1) / BK;
     const int iters = (nchunks + KS - 1) / KS;
@@ -969,7 +970,8 @@ int launch_head_rows(const GemmArgs &g, int batch, bool relu, hipStream_t st) {
 
 long long *g_gemm_dbg = nullptr;
 int g_gemm_lean = 1;
-extern "C" int ssac_gemm_lean(int on) { g_gemm_lean = on ? 1 : 0; return 0; }
+int g_gemm_head_bias = 1;   // debugging knob (ssac_gemm_lean bit 1 = off)
+extern "C" int ssac_gemm_lean(int on) { g_gemm_lean = (on & 1) ? 1 : 0; g_gemm_head_bias = (on & 2) ? 0 : 1; return 0; }
 
 struct LayerGeom { int64_t off_w, off_b; int rows, cols; };
 
@@ -1151,9 +1153,9 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
     if (n_sel == 0 || n_rows <= 0) return 0;
     const int H = nets->hidden;
     GemmPair p{};
+    int64_t off[6];
+    ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, off);
     if (H2) {  // head-layer weight gradient as extra workgroups of the same launch
-        int64_t off[6];
-        ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, off);
         p.head = HeadWgradArgs{nets->params, nets->net_stride, nets->hidden, nets->out_dim, off[4], off[5], net_ids, H2,
                                DQ, n_rows, adam_m, adam_v, ctl, grads, sumsq2, sumsq_net_stride, target, tau};
         p.head_grid_x = (nets->hidden + 63) / 64;
@@ -1170,6 +1172,15 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
         if (!(p.g0.vec & 1) || nets->out_dim != 1 || net_ids || !w3_snapshot)
             return ssac_fail("ssac_mlp_wgrad_fc12: the sign-rebuilt dz2u needs the W3 snapshot, 16-byte aligned H2 rows and the whole ensemble");
         p.g0.a_sign_w = w3_snapshot;
+    }
+    if (p.head_grid_x > 0 && nets->out_dim == 1 && g_gemm_head_bias && (lossfold || rowscale)) {
+        // single-output heads, UNSCALED backward (dz2 = c_row * (W3 (.) [h2 > 0]) by construction: nothing but the head
+        // reaches fc2's output -- not so with DR3, whose launches pass a scaled dz2): the head workgroups read h2 anyway
+        // and take the fc2 bias gradient as well (HeadWgradArgs::with_b2) -- the same sums in the same order whether
+        // dz2u was stored or is rebuilt from h2's sign
+        p.g0.no_bias = 1;
+        p.head.with_b2 = 1;
+        p.head.off_b2 = off[3];
     }
     p.g1.dbg = nullptr;   // (debug stamps: the first fc2 tile only -- both problems have a workgroup (0, 0, 0))
     if (rowscale) { p.g0.rowscale = p.g1.rowscale = rowscale; p.g0.sRow = p.g1.sRow = n_rows; }

@@ -11,10 +11,16 @@ struct HeadWgradArgs {
     const int32_t *ids; const float *H2, *DQ; int n_rows;
     float *am, *av; const ssac_adam_ctl *ctl; float *grads, *sumsq; int64_t sumsq_stride;
     float *target; float tau;
+    // with_b2 (single-output heads over a ReLU layer): this workgroup also takes the fc2 BIAS gradient of its 64 columns,
+    // db2[k] = sum_m dz2[m][k] = W3[k] * sum_m dq[m] [h2[m][k] > 0] -- it reads those h2 values anyway and has ~15 us of
+    // slack in the merged launch, while the GEMM tile that used to carry the bias was the slowest of its net.  W3[k] is
+    // the value this very thread reads before it updates it (nobody else writes W3[k]).
+    int with_b2; int64_t off_b2;   // offset of b2 in a net's parameter block
 };
 
 // dW3[o][k] = sum_m dq[m][o] h2[m][k];  db3[o] = sum_m dq[m][o].  Workgroup (bx, e): columns [64 bx, 64 bx + 64) of
-// net e; 64 * GROUPS threads = 64 columns x GROUPS row groups.  lds: >= GROUPS*64 + GROUPS floats.
+// net e; 64 * GROUPS threads = 64 columns x GROUPS row groups.  lds: >= GROUPS*64 + GROUPS floats (2*GROUPS*64 + GROUPS
+// with b2_w3s).
 // pol / tau: whether and how the Polyak target is updated (the caller resolves a late-bound request, ssac_late_polyak)
 template <int GROUPS>
 __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *lds, int bx, int e,
@@ -40,8 +46,10 @@ __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *l
     const float *dq = dq_override ? dq_override : a.DQ + (int64_t)e * n_rows * out_dim;
     float ss = 0.0f;
     // one output row o at a time: out_dim is small (1 for continuous critics), rows are the long axis
+    const bool with_b2 = a.with_b2 != 0 && out_dim == 1;
+    float *reds = redb + GROUPS;      // [GROUPS][64] (with_b2)
     for (int o = 0; o < out_dim; ++o) {
-        float acc = 0.0f, accb = 0.0f;
+        float acc = 0.0f, accb = 0.0f, accs = 0.0f;
         int m = mg;
         for (; m + 7 * GROUPS < n_rows; m += 8 * GROUPS) {
             float hv[8], dv[8];
@@ -51,15 +59,18 @@ __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *l
                 dv[u] = dq[(int64_t)(m + u * GROUPS) * out_dim + o];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { acc += dv[u] * hv[u]; accb += dv[u]; }
+            for (int u = 0; u < 8; ++u) { acc += dv[u] * hv[u]; accb += dv[u]; accs += hv[u] > 0.0f ? dv[u] : 0.0f; }
         }
         for (; m < n_rows; m += GROUPS) {
             const float d = dq[(int64_t)m * out_dim + o];
-            acc += d * h2[(int64_t)m * hidden];
+            const float h = h2[(int64_t)m * hidden];
+            acc += d * h;
             accb += d;
+            accs += h > 0.0f ? d : 0.0f;
         }
         __syncthreads();
         red[mg * 64 + kk] = acc;
+        if (with_b2) reds[mg * 64 + kk] = accs;
         if (kk == 0) redb[mg] = accb;
         __syncthreads();
         if (mg == 0) {
@@ -84,7 +95,16 @@ __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *l
             };
             if (kok) {
                 ss += gr * gr;
+                const float w3_old = with_b2 ? a.params[base + a.off_w + k] : 0.0f;   // (before this thread's own update)
                 apply(base + a.off_w + (int64_t)o * hidden + k, gr);
+                if (with_b2) {
+                    float gs = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < GROUPS; ++q) gs += reds[q * 64 + kk];
+                    const float gb2 = w3_old * gs;
+                    ss += gb2 * gb2;
+                    apply(base + a.off_b2 + k, gb2);
+                }
             }
             if (bx == 0 && kk == 0) {  // bias gradient db3[o] = sum_m dq[m][o]
                 float gb = 0.0f;

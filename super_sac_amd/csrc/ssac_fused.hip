@@ -1088,13 +1088,17 @@ void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs
         deferred_logs_body(dl, -1);
         return;
     }
-    // The critic tiles take the FIRST workgroup ids (they are the longer chain, and a launch's workgroups start in id
-    // order, ~1 us from first to last), the target chains the ids behind them.
+    // The longer chain takes the FIRST workgroup ids (a launch's workgroups start in id order, ~1 us from first to last,
+    // and when the launch is more than one round of workgroups the ids behind the first round wait for a whole
+    // predecessor): 32-row critic tiles (forward + backward, ~58 k clocks) before the target chains (~57 k), but the
+    // target chains before 16-row critic tiles (~45 k).
+    constexpr bool CRIT_FIRST = TC == 32;
     const int n_main = (int)gridDim.x - (dl_on ? 1 : 0), n_crit = n_main - tiles_t;
-    if (bid >= n_crit) {
+    const int t_lo = CRIT_FIRST ? n_crit : 0, t_hi = CRIT_FIRST ? n_main : tiles_t;   // ids of the target chains
+    if (bid >= t_lo && bid < t_hi) {
         // (XCD-contiguous order within each half, ssac_internal.h: the row tiles of one net -- which stream the same
         // weights -- sit on one or two XCDs instead of all eight)
-        const int lb = ssac_xcd_contiguous_range(bid, n_crit, n_main, gc.xcd);
+        const int lb = ssac_xcd_contiguous_range(bid, t_lo, t_hi, gc.xcd);
         const int j = lb / target_grid_x, bx = lb - j * target_grid_x;
         if (j > 0) {
             // critic-sharded ranks ("only subset owners need to send"): a slot whose REDQ member lives on
@@ -1114,7 +1118,8 @@ void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs
         // (phase stamps: the actor pass in slots 0.., the target-critic pass of subset slot 0 in 16.., the critics in 32..)
         fused_mlp_body<MODE_PLAIN, 16, true>(gt, smem, bx, j, target_grid_x, j == 0 ? 16 : -1);
     } else {
-        const int L = ssac_xcd_contiguous_range(bid, 0, n_crit, gc.xcd);
+        const int L = CRIT_FIRST ? ssac_xcd_contiguous_range(bid, 0, n_crit, gc.xcd)
+                                 : ssac_xcd_contiguous_range(bid, tiles_t, n_main, gc.xcd);
         fused_mlp_body<MODE_CRITIC_U, TC, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x, 32);
     }
     if (gc.tl) {

@@ -281,6 +281,11 @@ class _FastStep:
             lins = engine.MlpArena.linear_triples(mods[0]) + engine.MlpArena.linear_triples(mods[-1])
             for lin in (lins[0], lins[-1]):
                 self.probes.append((lin.weight, lin.weight.data_ptr()))
+        # the log views of every ring slot, built now (~7 ms, once): built on a slot's first visit they cost the first
+        # 512 replayed updates ~11 us of host time each -- 30 us per step instead of 17, enough to starve the device in
+        # short bursts right after recording (tools/burst_parts.py)
+        for slot_i in range(self.ring.buf.shape[0]):
+            gs.views(self.ring, slot_i)
 
     def still_valid(self):
         gs = self.gs

@@ -83,6 +83,7 @@ struct BfArgs {
     ssac_gather gth; int gth_role;  // as in ssac_fused.hip: 1 actor half (+ start-of-update duties), 3 actor half,
                                     // 2 critic half, 4 rows from X with the subset ids read from the input slot
     long long *dbg;                 // optional s_memtime phase stamps of tile 0 (ssac_bf16_debug_stamps)
+    int xcd;                        // XCD-contiguous workgroup order (ssac_internal.h)
 };
 #define BSTAMP(i) do { if (g.dbg && dbg_off >= 0 && bx == 0 && e == 0 && threadIdx.x == 0) g.dbg[dbg_off + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
@@ -604,8 +605,11 @@ __global__ __launch_bounds__(NTHR) void bf_chain_kernel(BfArgs ga, BfArgs ga_res
         deferred_logs_body(dl, -1);
         return;
     }
+    // (each half in XCD-contiguous order, as in fused_chain_kernel: the row tiles of one net share its weight shadows)
+    const int n_main = (int)gridDim.x - (dl_on ? 1 : 0);
     if (bid < tiles_t) {
-        const int j = bid / grid_x, bx = bid - j * grid_x;
+        const int lb = ssac_xcd_contiguous_range(bid, 0, tiles_t, gc.xcd);
+        const int j = lb / grid_x, bx = lb - j * grid_x;
         // (kernel parameters are never written to -- that would copy them to scratch; the phase stamps of the actor
         //  pass go to slots 0.., of subset slot 0's target-critic pass to 16.., of the critic half to 32..)
         if (j == 0) bf_mlp_body<MODE_SAMPLE>(ga, smem, bx, 0, 0);
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(NTHR) void bf_chain_kernel(BfArgs ga, BfArgs ga_res
         __syncthreads();
         bf_mlp_body<MODE_PLAIN>(gt, smem, bx, j, j == 0 ? 16 : -1);
     } else {
-        const int L = bid - tiles_t;
+        const int L = ssac_xcd_contiguous_range(bid, tiles_t, n_main, gc.xcd);
         bf_mlp_body<MODE_CRITIC_U>(gc, smem, L % grid_x, L / grid_x, 32);
     }
 }
@@ -697,6 +701,7 @@ struct BfWgradArgs {
     LossFoldArgs lf;
     LogFoldArgs fold;     // fold.done != null: the update's logs are finalised by the last workgroup (ssac_critic_logs.h)
     int tiles2, tiles1;   // 64x64 tiles of fc2 / fc1 per net; then 1 head workgroup per net
+    int xcd;                     // XCD-contiguous workgroup order (ssac_internal.h)
     long long *dbg;
 };
 #define WSTAMP(i) do { if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0) g.dbg[48 + i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -727,7 +732,9 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
     float *red = wlds + g.bp;          // [16] scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per_net = g.tiles2 + g.tiles1 + 1;
-    const int e = blockIdx.x / per_net, t = blockIdx.x - e * per_net;
+    // (XCD-contiguous: the tiles of one net -- which share its transposed activation saves -- on one or two XCDs)
+    const int lbid = ssac_xcd_contiguous(blockIdx.x, gridDim.x, g.xcd);
+    const int e = lbid / per_net, t = lbid - e * per_net;
     const int H = g.hidden, IN = g.in_dim, K1P = g.sg.k1p;
     float *P = g.params + (int64_t)e * g.net_stride;
     float *M = g.am + (int64_t)e * g.net_stride, *V = g.av + (int64_t)e * g.net_stride;
@@ -977,6 +984,7 @@ void bf_fill(BfArgs &g, const ssac_mlp *nets, const uint16_t *shadow, const int3
     g.shadow = shadow; g.sg = shadow_geom(nets->in_dim, nets->hidden, nets->out_dim);
     g.ids = ids; g.X = X; g.ldx = ldx; g.n_rows = n_rows; g.bp = (n_rows + 15) & ~15;
     g.dbg = g_bf_dbg;
+    g.xcd = (g_ssac_xcd & 8) ? 0 : 1;   // (ssac_xcd_order bit 3: the chained launches in hardware order)
 }
 
 template <typename K>
@@ -1158,6 +1166,7 @@ extern "C" int ssac_bf16_wgrad_lossfold(const ssac_mlp *nets, uint16_t *shadow, 
     const int t = (nets->hidden + 63) / 64;
     g.tiles2 = t * t; g.tiles1 = t * ((nets->in_dim + 63) / 64);
     g.dbg = g_bf_dbg;
+    g.xcd = (g_ssac_xcd >> 1) & 1;
     if (logfold && logfold->done_counter) {
         if (!sumsq) return ssac_fail("ssac_bf16_wgrad_lossfold: the folded logs need the sumsq slots");
         g.fold = LogFoldArgs{logfold->done_counter, logfold->logs, lazy_td ? logfold->td_logs : nullptr, logfold->feed,

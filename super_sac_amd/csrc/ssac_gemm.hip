@@ -204,17 +204,8 @@ struct RcVecLoader {
             const int k = k0 + kk + 16 * q;
             const bool ok = rok && k < K;
             const uint32_t o = ok ? off + q * ld16 : 0u;
-            // (rows need not be 16-byte aligned.  A ragged last vector -- nv of its 4 columns exist -- is read 4 - nv
-            // elements EARLIER, so that nothing beyond the row's last element is touched, and shifted back: no branch,
-            // no extra load; rows have >= 4 elements on this path)
-            const f4 y = *reinterpret_cast<const f4u *>(base + (size_t)o - (ok ? back : 0u));
-            f4 x = y;
-            if (any_ragged) {   // (uniform: the matrix width is no multiple of 4)
-                x[0] = nv == 4 ? y[0] : (nv == 3 ? y[1] : (nv == 2 ? y[2] : y[3]));
-                x[1] = nv == 4 ? y[1] : (nv == 3 ? y[2] : (nv == 2 ? y[3] : 0.0f));
-                x[2] = nv == 4 ? y[2] : (nv == 3 ? y[3] : 0.0f);
-                x[3] = nv == 4 ? y[3] : 0.0f;
-            }
+            // (the general kernels take this loader for 16-byte aligned rows of a multiple of 4 floats only: GemmArgs::vec)
+            const f4 x = *reinterpret_cast<const f4 *>(base + (size_t)o);
             const float sc = scale ? scale[ok ? k : 0] : 1.0f;
             v[q] = ok ? x * sc : (f4){0.f, 0.f, 0.f, 0.f};
         }
@@ -265,13 +256,15 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     // (K-group and wave index are the same in every lane of a wave: said so explicitly, everything derived from them --
     // the tile quadrant, "this wave sums the bias", "this wave's columns do not exist" -- is a scalar branch instead of
     // an exec-masked region inside the K loop)
-    const int kg = __builtin_amdgcn_readfirstlane(tid_all >> 8), tid = tid_all & 255;
+    // (lean kernel only: in the general kernels the same hint made the NT forward GEMM of the hidden-1024 critics twice
+    // as slow -- 34 -> 62 us, found in the pixel configurations' kernel trace)
+    const int kg = VECONLY ? __builtin_amdgcn_readfirstlane(tid_all >> 8) : (tid_all >> 8), tid = tid_all & 255;
     // per K-group: two staging buffers (double buffering), each [A tile | B tile]
     float *buf0 = lds + kg * (4 * TILE_FLOATS);
     float *buf1 = buf0 + 2 * TILE_FLOATS;
     float *red = lds + KS * (4 * TILE_FLOATS);  // 64*KS floats: bias-grad / sumsq scratch
 
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, wave = VECONLY ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     // Quadrant of the 64 x 64 tile this wave multiplies.  A wave's SIMD is its index within the K-group, so the mapping
     // is ROTATED by the K-group: the two waves that own the left column block sit on SIMDs {0, 2}, {3, 1}, {2, 0}, {1, 3}
     // for K-groups 0..3.  When the right block does not exist (a weight gradient with <= 32 columns: fc1 of a
@@ -279,12 +272,14 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     // MFMAs, and the remaining half of the matrix work is spread over all four SIMDs instead of loading two and idling
     // two: the fc1 tiles -- the slowest workgroups of the merged launch until then -- finish ~3 us before the fc2 tiles
     // (tools/wg_timeline.py).
-    const int wq = (wave + kg) & 3;
+    // (weight gradients only -- the TN products; the forward / backward-data GEMMs keep the plain mapping)
+    constexpr bool TN_ROT = !A_KC && !B_KC;
+    const int wq = TN_ROT ? ((wave + kg) & 3) : wave;
     const int wm = wq >> 1, wn = wq & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int e = bz;
     const int m0 = by * BM, n0 = bx * BN;
-    const bool dead_cols = (n0 + wn * 32) >= g.N;   // (wave-uniform) this wave's 32 columns lie beyond the matrix
+    const bool dead_cols = TN_ROT && (n0 + wn * 32) >= g.N;   // (wave-uniform) this wave's 32 columns lie beyond the matrix
 
     const float *A = g.A + batch_off(g.ids, g.idsA, e, g.sA);
     const float *B = g.B + batch_off(g.ids, g.idsB, e, g.sB);
@@ -715,14 +710,15 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     }
 }
 
-template <bool A_KC, bool B_KC, int EPI, int KS>
+template <bool A_KC, bool B_KC, int EPI, int KS, bool VECONLY = false>
 __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int per = gridDim.x * gridDim.y;
     const int L = ssac_xcd_contiguous(blockIdx.z * per + blockIdx.y * gridDim.x + blockIdx.x, per * gridDim.z, g.xcd);
     const int bz = L / per, rem = L - bz * per;
     int last = 0;
-    ens_gemm_body<A_KC, B_KC, EPI, KS>(g, lds, rem % gridDim.x, rem / gridDim.x, bz, nullptr, LossFoldArgs{}, 0, LogFoldArgs{}, last);
+    ens_gemm_body<A_KC, B_KC, EPI, KS, VECONLY>(g, lds, rem % gridDim.x, rem / gridDim.x, bz, nullptr, LossFoldArgs{}, 0,
+                                                LogFoldArgs{}, last);
 }
 
 // Two problems in ONE launch (the fc2 and fc1 weight gradients of an update): workgroups
@@ -891,11 +887,25 @@ template <bool A_KC, bool B_KC, int EPI, int KS>
 int launch_ks(const GemmArgs &g, dim3 grid, hipStream_t st) {
     static bool attr_set = false;
     const size_t lds = sizeof(float) * (KS * 4 * TILE_FLOATS + 64 * KS);
+    constexpr bool TN_ = !A_KC && !B_KC;
     if (!attr_set && lds > 48 * 1024) {
         if (hipFuncSetAttribute((const void *)ens_gemm_kernel<A_KC, B_KC, EPI, KS>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return ssac_fail("ens_gemm: cannot raise the dynamic LDS limit");
+        if constexpr (TN_) {
+            if (hipFuncSetAttribute((const void *)ens_gemm_kernel<A_KC, B_KC, EPI, KS, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return ssac_fail("ens_gemm: cannot raise the dynamic LDS limit");
+        }
         attr_set = true;
+    }
+    if constexpr (TN_) {   // weight gradients: the lean kernel when the operands qualify (see launch_pair_ks)
+        extern int g_gemm_lean;
+        if (g_gemm_lean && (g.vec & 1) && (g.vec & 6) && g.Ktot <= 0 && g.K % BK == 0 &&
+            (int64_t)(g.K + 1) * g.lda < (1LL << 31) && (int64_t)(g.K + 1) * g.ldb < (1LL << 31)) {
+            SSAC_LAUNCH((ens_gemm_kernel<A_KC, B_KC, EPI, KS, true>), grid, dim3(NTHREADS * KS), lds, st, g);
+            return ssac_check_launch("ens_gemm");
+        }
     }
     SSAC_LAUNCH((ens_gemm_kernel<A_KC, B_KC, EPI, KS>), grid, dim3(NTHREADS * KS), lds, st, g);
     return ssac_check_launch("ens_gemm");

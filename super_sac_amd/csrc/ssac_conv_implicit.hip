@@ -73,9 +73,7 @@ struct ChunkIter {
     }
 };
 
-// xcd: the persistent workgroups take their pixel tiles in XCD-contiguous order (ssac_internal.h), so that neighbouring
-// tiles -- which share halo rows of the input map -- run on the same XCD and find them in its L2
-__global__ __launch_bounds__(CV_THREADS) void conv_fwd_kernel(ConvArgs g, int n_tiles, int xcd) {
+__global__ __launch_bounds__(CV_THREADS) void conv_fwd_kernel(ConvArgs g, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [chunks][32 co][WL_LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -95,8 +93,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_fwd_kernel(ConvArgs g, int n_
     __syncthreads();
     const float bias = g.bias[co0 + li];
     const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
-    const int first_tile = gridDim.y == 1 ? ssac_xcd_contiguous(blockIdx.x, gridDim.x, xcd) : (int)blockIdx.x;
-    for (int tile = first_tile; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t m = (int64_t)tile * CV_PIX + wave * 32 + li;
         const bool ok = m < M;
         const int64_t mm = ok ? m : 0;
@@ -149,7 +146,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_fwd_kernel(ConvArgs g, int n_
 // backward-data: grid (persistent input-pixel tiles, ci / 32)
 // ---------------------------------------------------------------------------------------------
 template <bool S1>  // S1: stride 1 (every layer the engine sends here) -- no per-tap divisions
-__global__ __launch_bounds__(CV_THREADS) void conv_dgrad_kernel(ConvArgs g, int n_tiles, int xcd) {
+__global__ __launch_bounds__(CV_THREADS) void conv_dgrad_kernel(ConvArgs g, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [chunks][32 c][WL_LD] : W[co][c0+c][ky][kx], co contiguous
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -167,8 +164,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dgrad_kernel(ConvArgs g, int 
     }
     __syncthreads();
     const int64_t M = (int64_t)g.B * g.Hi * g.Wi;
-    const int first_tile = gridDim.y == 1 ? ssac_xcd_contiguous(blockIdx.x, gridDim.x, xcd) : (int)blockIdx.x;
-    for (int tile = first_tile; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t m = (int64_t)tile * CV_PIX + wave * 32 + li;
         const bool ok = m < M;
         const int64_t mm = ok ? m : 0;
@@ -435,7 +431,7 @@ template <> struct TapVec<4> { typedef float type __attribute__((ext_vector_type
 constexpr int FG = 4;  // runs per load group (two groups in flight)
 
 template <int KH>
-__global__ __launch_bounds__(CV_THREADS) void conv_first_fwd_kernel(FirstArgs g, int n_tiles, int xcd) {
+__global__ __launch_bounds__(CV_THREADS) void conv_first_fwd_kernel(FirstArgs g, int n_tiles) {
     typedef typename TapVec<KH>::type vec;
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [run = (c, ky)][32 co][2 KH taps], zero-padded taps
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -460,8 +456,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_first_fwd_kernel(FirstArgs g,
     }
     const int M = g.B * g.Ho * g.Wo;
     const int ngroups = (nruns + FG - 1) / FG;
-    const int first_tile = gridDim.y == 1 ? ssac_xcd_contiguous(blockIdx.x, gridDim.x, xcd) : (int)blockIdx.x;
-    for (int tile = first_tile; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int m = tile * CV_PIX + wave * 32 + li;
         const int mm = m < M ? m : 0;
         const int ox = mm % g.Wo, t = mm / g.Wo;
@@ -756,7 +751,7 @@ extern "C" int ssac_conv_fwd(const float *x, const float *w, const float *bias, 
     const int per_cu = persistent_per_cu(lds);
     const int cap = 256 * per_cu / (co / 32) > 0 ? 256 * per_cu / (co / 32) : 1;
     const int gx = n_tiles < cap ? n_tiles : cap;
-    SSAC_LAUNCH(conv_fwd_kernel, dim3(gx, co / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles, (g_ssac_xcd & 16) ? 0 : 1);
+    SSAC_LAUNCH(conv_fwd_kernel, dim3(gx, co / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
     return ssac_check_launch("conv_fwd");
 }
 
@@ -780,7 +775,7 @@ extern "C" int ssac_conv_dgrad(const float *dy, const float *w, const float *x_m
     const int cap = 256 * per_cu / (ci / 32) > 0 ? 256 * per_cu / (ci / 32) : 1;
     const int gx = n_tiles < cap ? n_tiles : cap;
     if (s == 1) {
-        SSAC_LAUNCH(conv_dgrad_kernel<true>, dim3(gx, ci / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles, (g_ssac_xcd & 16) ? 0 : 1);
+        SSAC_LAUNCH(conv_dgrad_kernel<true>, dim3(gx, ci / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
     } else if (s <= DG_MAX_S && M < (1ll << 31) - 65536) {
         // parity classes: only the taps a class of input pixels can receive
         StridedTiles tl{};
@@ -809,7 +804,7 @@ extern "C" int ssac_conv_dgrad(const float *dy, const float *w, const float *x_m
         SSAC_LAUNCH(conv_dgrad_strided_kernel, dim3(per_class * ncls, ci / 32), dim3(CV_THREADS), lds2,
                     (hipStream_t)stream, g, tl, max_chunks);
     } else {
-        SSAC_LAUNCH(conv_dgrad_kernel<false>, dim3(gx, ci / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles, (g_ssac_xcd & 16) ? 0 : 1);
+        SSAC_LAUNCH(conv_dgrad_kernel<false>, dim3(gx, ci / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
     }
     return ssac_check_launch("conv_dgrad");
 }
@@ -866,9 +861,9 @@ extern "C" int ssac_conv_first_fwd(const float *img, const float *w, const float
     const int cap = 1024 / (co / 32) > 0 ? 1024 / (co / 32) : 1;  // persistent: ~4 workgroups per CU in total
     const int gx = n_tiles < cap ? n_tiles : cap;
     if (kh == 2)
-        SSAC_LAUNCH(conv_first_fwd_kernel<2>, dim3(gx, co / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles, (g_ssac_xcd & 16) ? 0 : 1);
+        SSAC_LAUNCH(conv_first_fwd_kernel<2>, dim3(gx, co / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
     else
-        SSAC_LAUNCH(conv_first_fwd_kernel<4>, dim3(gx, co / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles, (g_ssac_xcd & 16) ? 0 : 1);
+        SSAC_LAUNCH(conv_first_fwd_kernel<4>, dim3(gx, co / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
     return ssac_check_launch("conv_first_fwd");
 }
 

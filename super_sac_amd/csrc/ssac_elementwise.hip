@@ -1535,7 +1535,7 @@ extern "C" int ssac_feed_write(void *ring_slot, const void *src, size_t bytes) {
 // bit 0: fused MLP kernels, bit 1: GEMM / weight-gradient kernels; bit 2: the merged weight-gradient launch NOT per
 // workgroup class, bit 3: the chained launch NOT XCD-contiguous (both are on by default)
 int g_ssac_xcd = 2;
-extern "C" int ssac_xcd_order(int mask) { g_ssac_xcd = mask & 31; return 0; }
+extern "C" int ssac_xcd_order(int mask) { g_ssac_xcd = mask & 15; return 0; }
 long long *g_ssac_timeline = nullptr;   // [2048]: (start, end) per workgroup of the chained launch, then (from 1024) of the merged weight-gradient launch
 extern "C" int ssac_debug_timeline(long long *dev_buf) { g_ssac_timeline = dev_buf; return 0; }
 

@@ -31,7 +31,8 @@ for rep in range(3):
               f"ends {e.min():.2f} .. {e.max():.2f}; durations min {np.min(e - s):.2f} median {np.median(e - s):.2f} max {np.max(e - s):.2f}")
         if rep == 2:
             if name.startswith("chained"):
-                groups = (("target chains", 0, 64), ("critic tiles", 64, 64 + 16 * N))
+                NT = 2 * ((B + 15) // 16)   # target-chain workgroups: 16-row tiles x 2 subset slots
+                groups = (("target chains", 0, NT), ("critic tiles", NT, n))
             else:
                 groups = (("fc2 tiles", 0, 16 * N), ("fc1 tiles", 16 * N, 20 * N), ("head", 20 * N, 24 * N), ("TD", 24 * N, 24 * N + 1))
             if not name.startswith("chained"):
@@ -62,10 +63,15 @@ for rep in range(3):
                     for y in range(8):
                         before += np.where(y < x, cnt(n_, y) - cnt(t0_, y), 0)
                     return before + (b >> 3) - cnt(t0_, x)
-                nc = n - 64   # critic tiles first (ids [0, nc)), then the target chains; reported target chains first
-                order = np.concatenate([nc + np.argsort(rng_order(nc, n)), np.argsort(rng_order(0, nc))])
+                NT = 2 * ((B + 15) // 16)
+                nc = n - NT
+                rows32 = nc == N * ((B + 31) // 32)   # 32-row critic tiles take the first ids, 16-row ones the last
+                if rows32:
+                    order = np.concatenate([nc + np.argsort(rng_order(nc, n)), np.argsort(rng_order(0, nc))])
+                else:
+                    order = np.concatenate([np.argsort(rng_order(0, NT)), NT + np.argsort(rng_order(NT, n))])
                 s, e = s[order], e[order]
-                d = (e - s)[64:64 + 16 * N].reshape(N, 16)
+                d = (e - s)[NT:n].reshape(N, -1)
                 print("      critic tile durations by net (rows) x row tile (columns):")
                 for row in d:
                     print("       ", " ".join(f"{v:5.1f}" for v in row))

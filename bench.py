@@ -160,6 +160,7 @@ def cpu_baseline(budget_s=15.0):
             one(n)
             n += 1
         rows[th] = (n, time.perf_counter() - t0)
+    torch.set_num_threads(min(16, ncpu))   # (back to the harness's own setting)
     best = max(rows, key=lambda th: rows[th][0] / rows[th][1])
     n, dt = rows[best]
     return {"value": round(n / dt, 2), "unit": "updates/s", "cores": best, "kind": "port",
@@ -287,6 +288,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Host threads: torch's CPU pool defaults to every logical core (256 on the GPU boxes).  The only CPU work of this
+    # process is construction (orthogonal initialisation = a QR per layer), where hundreds of threads spinning around
+    # 100-us operators are slower than a few -- and N ranks each with a full-size pool oversubscribe the host N times:
+    # eight ranks on a loaded box were still initialising weights after three minutes.  (The CPU-baseline leg sets its
+    # own thread counts per row.)
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // max(1, world))))
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs an MI355X"
     ndev = torch.cuda.device_count()
     shared_device = world > ndev          # (ranks sharing one device: the N>1 path on a 1-GPU box)
@@ -315,7 +322,12 @@ def main():
         shard = parallel.Shard(rank, world, NCRIT)
         n_local = shard.n_local
         exchange = f"torch.distributed all_reduce ({backend})"
-        if world > 1 and os.environ.get("SSAC_BENCH_ONE_SHOT", "1") == "1":
+        # (more than 4 ranks SHARING one device -- the functional check a 1-GPU box can run: eight processes whose
+        # exchange kernels spin on each other's flags while the device time-slices their queues stalled for the whole
+        # 10 s spin bound once in a while; the collective path has no spinning kernel.  One rank per GPU -- the real
+        # layout -- keeps the one-shot exchange.)
+        one_shot_default = "0" if (shared_device and world > 4) else "1"
+        if world > 1 and os.environ.get("SSAC_BENCH_ONE_SHOT", one_shot_default) == "1":
             try:
                 if parallel.enable_one_shot(device) is not None:
                     exchange = "one-shot IPC exchange kernel (csrc/ssac_xchg.hip), recorded in the launch list"

@@ -172,7 +172,7 @@ def cpu_baseline(budget_s=15.0):
                       f"({best} threads)"}
 
 
-def sharded_value_check(step, ssa, device, shard, dist, n_updates=12):
+def sharded_value_check(step, ssa, device, shard, dist, n_updates=12, must_pass=True):
     """`bench.py --gpus N` is a VALUE check before it is a timing: the first n_updates updates of the sharded engine
     (every rank, through the exchange) against the same updates of the unsharded engine run by rank 0 in this process
     on the same seeds -- this rank's critics, Polyak targets and Adam moments, plus every TD target.  Tolerances as
@@ -195,9 +195,16 @@ def sharded_value_check(step, ssa, device, shard, dist, n_updates=12):
         return tds, [t.view(n, -1).cpu().numpy().copy() for t in (ar.params, tar.params, m)]
     if dist is not None and dist.get_world_size() > 1:
         dist.barrier()   # ranks finish building seconds apart; the exchange kernel's spin is bounded
-    tds, mine = run(step)
     worst = {"td": 0.0, "params": 0.0, "target": 0.0, "adam_m": 0.0}
-    if shard.rank == 0:
+    broke = None
+    try:
+        tds, mine = run(step)
+        torch.cuda.synchronize()
+        from super_sac_amd import parallel as _par
+        _par.check_exchange()
+    except RuntimeError as e:   # (an exchange that gave up on a peer: every rank still takes part in the verdict below)
+        broke = str(e)
+    if shard.rank == 0 and broke is None:
         # the unsharded engine on the same seeds (build_engine leaves every generator, the device's included, at seed 0)
         keep = (torch.get_rng_state(), random.getstate(), np.random.get_state(), torch.cuda.get_rng_state(device))
         ref_step, _, _ = build_engine(device, NCRIT, None)
@@ -212,14 +219,21 @@ def sharded_value_check(step, ssa, device, shard, dist, n_updates=12):
             worst[key] = float(np.max(np.abs(a - b[shard.lo:shard.hi])))
         del ref_step
     per_update = worst.pop("td_per_update", None)
-    ok = (worst["td"] <= 2e-5 and max(worst["params"], worst["target"], worst["adam_m"]) <= 5e-6 * n_updates)
+    ok = (broke is None and worst["td"] <= 2e-5 and np.isfinite(worst["td"])
+          and max(worst["params"], worst["target"], worst["adam_m"]) <= 5e-6 * n_updates)
+    if not must_pass and os.environ.get("SSAC_BENCH_TEST_FALLBACK") == "1":
+        ok = False   # (exercises the fall-back from the one-shot exchange to the collective on a box where it works)
     if not ok:
         worst["td_per_update"] = per_update
+        if broke:
+            worst["error"] = broke
     flag = torch.tensor([1.0 if ok else 0.0], device=device)
     if dist is not None and dist.get_world_size() > 1:
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # (the process group's collective, never the one-shot kernel)
     if float(flag) != 1.0:
-        raise RuntimeError(f"sharded run differs from the unsharded engine on the same seeds: {worst}")
+        if must_pass:
+            raise RuntimeError(f"sharded run differs from the unsharded engine on the same seeds: {worst}")
+        return None
     return {"updates": n_updates, "max_abs_diff": {k: float(f"{v:.3g}") for k, v in worst.items()},
             "against": "the unsharded engine, same seeds, run by rank 0 in the same process"}
 
@@ -338,7 +352,18 @@ def main():
     step, env_step, ssa = build_engine(device, n_local, shard)
     value_check = None
     if shard is not None:
-        value_check = sharded_value_check(step, ssa, device, shard, dist)
+        from super_sac_amd import parallel
+        one_shot_on = parallel._exchange is not None
+        value_check = sharded_value_check(step, ssa, device, shard, dist, must_pass=not one_shot_on)
+        if value_check is None:
+            # The one-shot exchange produced values that differ from the unsharded engine (or gave up on a peer) on
+            # this system -- peer-device mappings of the receive buffers have only ever run with the ranks on ONE device.
+            # Every rank saw the same verdict: all of them fall back to the collective, record again, check again.
+            parallel.disable_one_shot()
+            exchange = f"torch.distributed all_reduce ({backend}) [one-shot exchange failed its value check on this system]"
+            del step, env_step
+            step, env_step, ssa = build_engine(device, n_local, shard)
+            value_check = sharded_value_check(step, ssa, device, shard, dist)
     # Python's cyclic GC otherwise runs a full (generation-2) collection over the whole torch object graph every few
     # hundred updates -- a 40-80 ms pause, i.e. hundreds of updates: park the start-up objects in the permanent
     # generation (host runtime hygiene of a long-running training loop; nothing the update path allocates is cyclic)

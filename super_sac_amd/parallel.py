@@ -148,6 +148,20 @@ def enable_one_shot(device, max_floats=ONE_SHOT_MAX_FLOATS):
     return _exchange
 
 
+def disable_one_shot():
+    """back to the collective (torch.distributed all_reduce) for the exchange steps of this process.  Every rank of the job
+    must do the same, and update functions recorded with the one-shot kernel in their launch lists must be recorded again
+    (new agent / new recording).  The exchange object itself is left to the end of the process: a peer may still have
+    its buffers mapped."""
+    global _exchange, _retired
+    if _exchange is not None:
+        _retired.append(_exchange)
+        _exchange = None
+
+
+_retired = []
+
+
 def exchange_failed():
     """True when an exchange kernel of this process gave up waiting for a peer (bounded spin, csrc/ssac_xchg.hip): the
     reductions since then are not reductions (and were poisoned with NaN).  Reads and CLEARS a pinned host word; for the

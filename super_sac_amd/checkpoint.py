@@ -55,7 +55,8 @@ def buffer_state(buffer):
     st = buffer._storage
     out = {"maxsize": buffer._maxsize, "total_sample_calls": buffer.total_sample_calls, "storage": None,
            "per": {"sum": buffer._per.sum_tree.copy(), "min": buffer._per.min_tree.copy(),
-                   "max_priority": buffer._per._max_priority}}
+                   "max_priority": buffer._per._max_priority,
+                   "max_priority_is_f32": bool(getattr(buffer._per, "_max_priority_is_f32", False))}}
     if st is not None:
         out["storage"] = {"action": st.action_stack.cpu(), "reward": st.reward_stack.cpu(),
                           "done": st.done_stack.cpu(), "s": {k: v.cpu() for k, v in st.s_stack.items()},
@@ -68,7 +69,11 @@ def load_buffer_state(buffer, state):
     from .replay import ReplayBufferStorage, _IndexStager
     assert state["maxsize"] == buffer._maxsize, "checkpointed buffer has a different capacity"
     buffer.total_sample_calls = state["total_sample_calls"]
-    buffer._per.load_state(state["per"]["sum"], state["per"]["min"], state["per"]["max_priority"])
+    if hasattr(buffer._per, "_max_priority_is_f32"):
+        buffer._per.load_state(state["per"]["sum"], state["per"]["min"], state["per"]["max_priority"],
+                               bool(state["per"].get("max_priority_is_f32", False)))
+    else:
+        buffer._per.load_state(state["per"]["sum"], state["per"]["min"], state["per"]["max_priority"])
     s = state["storage"]
     if s is None:
         return

@@ -1082,7 +1082,7 @@ void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs
                         int critic_grid_x, DeferredLogsArgs dl, int dl_on) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
-    if (gc.tl && threadIdx.x == 0) gc.tl[2 * bid] = __builtin_amdgcn_s_memrealtime();
+    if (gc.tl && threadIdx.x == 0 && bid < 512) gc.tl[2 * bid] = __builtin_amdgcn_s_memrealtime();
     if (dl_on && bid == (int)gridDim.x - 1) {
         // one extra workgroup: the PREVIOUS recorded update's log block -> its slot of the log ring (ssac_critic_logs.h)
         deferred_logs_body(dl, -1);
@@ -1122,7 +1122,7 @@ void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs
                                  : ssac_xcd_contiguous_range(bid, tiles_t, n_main, gc.xcd);
         fused_mlp_body<MODE_CRITIC_U, TC, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x, 32);
     }
-    if (gc.tl) {
+    if (gc.tl && bid < 512) {   // (the stamp buffer holds 512 workgroups per launch: tools/wg_timeline.py)
         __syncthreads();   // (drains this workgroup's stores too)
         if (threadIdx.x == 0) gc.tl[2 * bid + 1] = __builtin_amdgcn_s_memrealtime();
     }
@@ -1541,7 +1541,10 @@ extern "C" int ssac_head_wgrad(const ssac_mlp *nets, const int32_t *net_ids, int
     return ssac_check_launch("head_wgrad");
 }
 
-extern "C" int ssac_head_wgrad_tiles(const ssac_mlp *nets) { return nets ? (nets->hidden + 63) / 64 : -1; }
+// gradient-norm slots of the head layer per net (ssac_head_wgrad.h: one per 16 columns)
+extern "C" int ssac_head_wgrad_tiles(const ssac_mlp *nets) {
+    return nets ? (nets->hidden + SSAC_HEAD_SLOT_COLS - 1) / SSAC_HEAD_SLOT_COLS : -1;
+}
 
 namespace {
 __global__ __launch_bounds__(64) void deferred_logs_kernel(DeferredLogsArgs d, int ring_slot) { deferred_logs_body(d, ring_slot); }

@@ -141,6 +141,21 @@ __device__ __forceinline__ float adam_elem(float p, float g, float &m, float &v,
     return p - c.step_size * (m / denom);
 }
 
+// Gradient-norm partial of one weight-gradient tile.  A layer owns ceil(M/32) x ceil(N/32) slots per net
+// (ssac_wgrad_tiles): the 32 x 32 tiles of the latency variant write one each (wgrad_small_body), a 64 x 64 tile writes
+// the first of the (up to) four it covers and zeroes the others -- the slots of a layer sum to the same value
+// whichever variant ran last.  (agent scope: with the logs folded into the launch the reader sits on another XCD)
+__device__ __forceinline__ void sumsq_store64(float *base, int M, int N, int bx, int by, float tot) {
+    const int gx = (N + 31) >> 5, gy = (M + 31) >> 5;
+    const int r = 2 * by, c = 2 * bx;
+    __hip_atomic_store(base + r * gx + c, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c + 1 < gx) __hip_atomic_store(base + r * gx + c + 1, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (r + 1 < gy) {
+        __hip_atomic_store(base + (r + 1) * gx + c, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c + 1 < gx) __hip_atomic_store(base + (r + 1) * gx + c + 1, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // KS = number of K-split groups of 4 waves inside the workgroup.  Group kg consumes chunks
 // kg, kg+KS, ... with its own LDS staging; the partial tiles are summed through LDS before the
 // epilogue.  It buys latency hiding (KS waves per SIMD) for launches with few tiles and a long K
@@ -538,8 +553,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
                 if (tid_all == 0) {
                     float tot = 0.0f;
                     for (int w = 0; w < 4 * KS; ++w) tot += red[w];
-                    __hip_atomic_store(g.sumsq + (int64_t)e * g.sumsq_stride + by * g.grid_x + bx, tot, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+                    sumsq_store64(g.sumsq + (int64_t)e * g.sumsq_stride, g.M, g.N, bx, by, tot);
                     if (fold.done) last = log_fold_arrive(fold, gridDim.x) ? 1 : 0;
                 }
             }
@@ -626,9 +640,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
             if (tid_all == 0) {
                 float tot = 0.0f;
                 for (int w = 0; w < 4 * KS; ++w) tot += red[w];
-                // (agent scope: with the logs folded into the launch the reader is a workgroup on another XCD)
-                __hip_atomic_store(g.sumsq + (int64_t)e * g.sumsq_stride + by * g.grid_x + bx, tot, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+                sumsq_store64(g.sumsq + (int64_t)e * g.sumsq_stride, g.M, g.N, bx, by, tot);
                 if (fold.done) last = log_fold_arrive(fold, gridDim.x) ? 1 : 0;
             }
         }
@@ -746,7 +758,7 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // (the XCD-contiguous order covers the GEMM + head workgroups only: the TD workgroup behind them keeps its own id,
     // so the tiles land on the same XCDs with or without it)
-    if (p.tl && threadIdx.x == 0) p.tl[1024 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (p.tl && threadIdx.x == 0 && blockIdx.x < 512) p.tl[1024 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     const int n_main = p.tiles01 + p.head_total;
     int bid = (int)blockIdx.x < n_main ? ssac_xcd_contiguous(blockIdx.x, n_main, p.xcd) : (int)blockIdx.x;
     if (p.xcd_mix && (int)blockIdx.x < n_main) {
@@ -834,6 +846,345 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
         __syncthreads();
         if (threadIdx.x == 0) p.tl[1024 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LATENCY VARIANT of the merged weight-gradient launch (round 4; VERDICT round 3 "under-filled launches").
+//
+// A launch of 64 x 64 tiles is as long as ONE tile's serial chain -- first operand chunk + loss fold, a K loop over the
+// whole batch, the partial-tile hand-off, the Adam epilogue: ~40 k clocks at the metric shape -- however few tiles it
+// has: with 2 critics (SAC; a rank holding 2 of 16) 32 + 8 + 8 workgroups keep 48 of 256 CUs busy for 20 us.  Here a
+// workgroup owns a 32 x 32 tile = ONE v_mfma_f32_32x32x2_f32 accumulator, and its 8 waves split K: wave w takes the
+// 32-deep chunks w, w + 8, ... (B 512: two chunks = 32 MFMAs per wave).  Both operands are row-contiguous over the
+// tile's 32 rows / columns (A[k][m], B[k][n]: the TN product of a weight gradient), so a lane's MFMA operand for step t
+// is ONE dword at k = k0 + 2 t + (lane >> 5), row / column (lane & 31): 128-byte coalesced loads straight into the
+// operand registers -- no LDS staging, no barrier in the K loop, every load of a chunk in flight at once.  The 8 partial
+// tiles meet in LDS (32 KB) and are summed in wave order (deterministic); each thread then finishes 2 elements (Adam
+// [+ Polyak] with the optimizer state requested at kernel start).  4x the workgroups of the 64 x 64 form, each ~5x
+// shorter: 128 + 16 + 32 + 1 workgroups for 2 critics at the metric shape.  The summation order over k differs from the
+// 64 x 64 kernel's (rounding only; the fixtures' fp32 tolerances hold for both: tests/test_hip_cases.py runs both).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int ST = 32;                  // tile edge
+constexpr int SW = 8;                   // waves per workgroup = K-split ways
+constexpr int STHREADS = 64 * SW;
+constexpr int S_HEAD_COLS = 16, S_HEAD_GROUPS = STHREADS / S_HEAD_COLS;
+constexpr int S_PART = SW * ST * ST;    // floats: the partial tiles
+constexpr int S_RED = SW * ST + 2 * SW; // bias partials [SW][32] + gradient-norm partials [SW] + scratch
+// head workgroups reuse the front of the LDS block: 2 * GROUPS * COLS + GROUPS floats (ssac_head_wgrad.h) <= S_PART
+static_assert(2 * S_HEAD_GROUPS * S_HEAD_COLS + S_HEAD_GROUPS <= S_PART, "head scratch must fit the partial-tile area");
+
+struct SmallFrag { float a[16], b[16]; };
+
+template <int EPI>
+__device__ __forceinline__ void wgrad_small_body(const GemmArgs &g, float *lds, int bx, int by, int bz, float *late_rs,
+                                                 const LossFoldArgs &lf, int lf_mode, const LogFoldArgs &fold, int &last,
+                                                 const LateTau &lt) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int e = bz, m0 = by * ST, n0 = bx * ST;
+    float *part = lds, *red = lds + S_PART;
+    const float *A = g.A + batch_off(g.ids, g.idsA, e, g.sA);
+    const float *B = g.B + batch_off(g.ids, g.idsB, e, g.sB);
+    const int64_t coff = batch_off(g.ids, g.idsC, e, g.sC);
+    const int K = g.K;
+    // rows / columns beyond the matrix read the tile's first row / column (always valid): they only reach accumulator
+    // rows / columns beyond the matrix, which the epilogue guards.  Uniform bases + 32-bit lane offsets (small_ok).
+    const bool mok = (m0 + li) < g.M, nok = (n0 + li) < g.N;
+    // Operand loads are BUFFER loads: one descriptor per operand in SGPRs (built from wave-uniform values only), the lane's
+    // byte offset in ONE VGPR, the row of MFMA step t as a scalar offset -- the 32 loads of a chunk need no address
+    // register each (as flat loads with 64-bit lane addresses the two register sets + 32 address pairs did not fit 128
+    // VGPRs, i.e. two workgroups per CU).
+    auto uniform_ptr = [](const float *p_) {
+        const uint64_t u = (uint64_t)(uintptr_t)p_;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+        return (void *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    };
+    const uint32_t lda = __builtin_amdgcn_readfirstlane((uint32_t)g.lda), ldb = __builtin_amdgcn_readfirstlane((uint32_t)g.ldb);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(A + m0), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(B + n0), 0, 0x7ffffffc, 0x00020000);
+    const int alane = 4 * (int)((mok ? (uint32_t)li : 0u) + (uint32_t)lh * lda), blane = 4 * (int)((nok ? (uint32_t)li : 0u) + (uint32_t)lh * ldb);
+    const bool sign = g.a_sign_w != nullptr;
+    const float sw = sign ? g.a_sign_w[(int64_t)e * g.M + (mok ? m0 + li : m0)] : 0.0f;
+    const bool ragged = (K & 31) != 0;   // (uniform; K is even: small_ok)
+    const float *rscale = (g.rowscale && !late_rs) ? g.rowscale + (int64_t)e * g.sRow : nullptr;
+    const bool want_bias = bx == 0 && !g.no_bias;
+    const int nchunks = (K + 31) >> 5;
+
+    // ---- this thread finishes 2 tile elements (idx = tid, tid + 512: row idx >> 5, column idx & 31)
+    const bool pol = g.tw != nullptr && (!lt.on || lt.bits != 0u);
+    const float tau = lt.on ? __uint_as_float(lt.bits) : g.tau;
+    auto elem = [&](int j, int64_t &c) {
+        const int idx = tid + j * STHREADS, row = idx >> 5, col = idx & 31;
+        c = coff + (int64_t)(m0 + row) * g.ldc + n0 + col;
+        return (m0 + row) < g.M && (n0 + col) < g.N;
+    };
+    int64_t ci0, ci1;
+    const bool ok0 = elem(0, ci0), ok1 = elem(1, ci1);
+    LossFoldRegs lfr;
+    if (lf_mode == 1) loss_fold_issue(lf, e, lfr);
+    auto load = [&](SmallFrag &f, int c) {
+        const int sa = (int)(4u * (uint32_t)(c * 32) * lda), sb = (int)(4u * (uint32_t)(c * 32) * ldb);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (!ragged || c * 32 + 2 * t < K) {   // (uniform: K is even, so both k parities of step t exist or neither)
+                f.a[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, alane, sa + (int)(8u * t * lda), 0));
+                f.b[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, blane, sb + (int)(8u * t * ldb), 0));
+            } else {
+                f.a[t] = 0.0f;
+                f.b[t] = 0.0f;
+            }
+        }
+    };
+    SmallFrag f0, f1;
+    if (wave < nchunks) load(f0, wave);
+    if (lf_mode == 1) { loss_fold_finish(lf, e, lfr, late_rs); lds_barrier(); }
+    else if (lf_mode == 2) { loss_fold_table(lf, e, late_rs, true, late_rs + lf.n_rows, false); __syncthreads(); }
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    float bias_acc = 0.0f;
+    // (the row scales are fetched per SOURCE -- LDS table, global vector, none -- in uniform branches of their own, the
+    // table through an LDS-qualified pointer: one `late_rs ? late_rs[k] : rscale[k]` per element turns into 16 generic-
+    // address loads, each followed by a wait for everything in flight, the operand loads included)
+    typedef __attribute__((address_space(3))) const float lds_cfloat;
+    lds_cfloat *tabl = (lds_cfloat *)late_rs;
+    auto consume = [&](SmallFrag &f, int c) {
+        const int k0 = c * 32 + lh;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // in halves of 8 steps: 8 scale registers live instead of 16
+            float sc[8];
+            if (late_rs) {
+                if (!ragged) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) sc[t] = tabl[k0 + 2 * (8 * h + t)];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) sc[t] = tabl[k0 + 2 * (8 * h + t) < K ? k0 + 2 * (8 * h + t) : 0];
+                }
+            } else if (rscale) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) sc[t] = rscale[(!ragged || k0 + 2 * (8 * h + t) < K) ? k0 + 2 * (8 * h + t) : 0];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) sc[t] = 1.0f;
+            }
+            if (sign) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) f.a[8 * h + t] = (f.a[8 * h + t] > 0.0f ? sw : 0.0f) * sc[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) f.a[8 * h + t] *= sc[t];   // (steps beyond a ragged K hold zeros already)
+            }
+            if (want_bias) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) bias_acc += f.a[8 * h + t];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[8 * h + t], f.b[8 * h + t], acc, 0, 0, 0);
+        }
+    };
+    int c = wave;
+    bool have1 = c + SW < nchunks;
+    if (have1) load(f1, c + SW);
+    // The optimizer state of the 2 elements is requested HERE: it has not been touched since the last update and comes
+    // from HBM (~2 us) -- behind the K loop that round trip was a phase of its own in every workgroup (10.4 us per fc2
+    // tile at B 512, of which the operands, the 32 MFMAs per wave and the exchange through LDS explain 6); in front of
+    // the operand loads it would hold THEM back (vector memory returns in order).  Behind the first two chunks' loads it
+    // travels while they multiply.
+    float pv0 = 0.f, mv0 = 0.f, vv0 = 0.f, tv0 = 0.f, pv1 = 0.f, mv1 = 0.f, vv1 = 0.f, tv1 = 0.f;
+    if (EPI == EPI_ADAM) {
+        const int64_t a0 = ok0 ? ci0 : coff, a1 = ok1 ? ci1 : coff;
+        pv0 = g.C[a0]; mv0 = g.am[a0]; vv0 = g.av[a0];
+        pv1 = g.C[a1]; mv1 = g.am[a1]; vv1 = g.av[a1];
+        if (pol) { tv0 = g.tw[a0]; tv1 = g.tw[a1]; }
+    }
+    for (; c + SW < nchunks; c += 2 * SW) {   // two register sets: chunk c + SW loads while chunk c multiplies
+        if (!have1) load(f1, c + SW);
+        have1 = false;
+        consume(f0, c);
+        if (c + 2 * SW < nchunks) load(f0, c + 2 * SW);
+        consume(f1, c + SW);
+    }
+    if (c < nchunks) consume(f0, c);   // (an odd number of chunks for this wave)
+
+    // ---- the 8 partial tiles meet in LDS; C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8 (r>>2) + 4 (lane>>5)
+    float *mine = part + wave * (ST * ST);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * lh) * ST + li] = acc[r];
+    if (want_bias) {
+        bias_acc += __shfl_xor(bias_acc, 32, 64);   // the two k parities of row li
+        if (lh == 0) red[wave * ST + li] = bias_acc;
+    }
+    lds_barrier();
+    float gval0 = part[tid], gval1 = part[tid + STHREADS];
+#pragma unroll
+    for (int w = 1; w < SW; ++w) {
+        gval0 += part[w * (ST * ST) + tid];
+        gval1 += part[w * (ST * ST) + tid + STHREADS];
+    }
+    const int gm = m0 + tid;
+    const bool bias_thr = want_bias && tid < ST && gm < g.M;
+    const int64_t bi = (EPI == EPI_GRAD && g.sGb) ? (int64_t)e * g.sGb + gm : coff + gm;
+    float bsum = 0.0f, bpv = 0.0f, bmv = 0.0f, bvv = 0.0f, btv = 0.0f;
+    if (bias_thr) {
+        bsum = red[tid];
+#pragma unroll
+        for (int w = 1; w < SW; ++w) bsum += red[w * ST + tid];
+        if (EPI == EPI_ADAM) { bpv = g.pb[bi]; bmv = g.bm[bi]; bvv = g.bv[bi]; btv = (pol && g.tb) ? g.tb[bi] : 0.0f; }
+    }
+    // ---- gradient-norm partial first (it needs the gradients only): with the logs folded in, the arrival ticket is
+    //      drawn before -- not behind -- the optimizer stores
+    if (g.sumsq) {
+        float ss = (ok0 ? gval0 * gval0 : 0.0f) + (ok1 ? gval1 * gval1 : 0.0f);
+        if (bias_thr) ss += bsum * bsum;
+        ss = wave_sum(ss);
+        float *red2 = red + SW * ST;
+        if (lane == 0) red2[wave] = ss;
+        lds_barrier();
+        if (tid == 0) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int w = 0; w < SW; ++w) tot += red2[w];
+            __hip_atomic_store(g.sumsq + (int64_t)e * g.sumsq_stride + by * ((g.N + ST - 1) / ST) + bx, tot, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            if (fold.done) last = log_fold_arrive(fold, gridDim.x) ? 1 : 0;
+        }
+    }
+    if (EPI == EPI_GRAD) {
+        if (ok0) g.gw[ci0] = gval0;
+        if (ok1) g.gw[ci1] = gval1;
+        if (bias_thr) g.gb[bi] = bsum;
+        return;
+    }
+    const ssac_adam_ctl ctl = *g.ctl;
+    if (ok0) {
+        const float pn = adam_elem(pv0, gval0, mv0, vv0, ctl);
+        g.am[ci0] = mv0; g.av[ci0] = vv0; g.C[ci0] = pn;
+        if (pol) g.tw[ci0] = tv0 * (1.0f - tau) + pn * tau;
+    }
+    if (ok1) {
+        const float pn = adam_elem(pv1, gval1, mv1, vv1, ctl);
+        g.am[ci1] = mv1; g.av[ci1] = vv1; g.C[ci1] = pn;
+        if (pol) g.tw[ci1] = tv1 * (1.0f - tau) + pn * tau;
+    }
+    if (bias_thr) {
+        const float pn = adam_elem(bpv, bsum, bmv, bvv, ctl);
+        g.bm[bi] = bmv; g.bv[bi] = bvv; g.pb[bi] = pn;
+        if (pol && g.tb) g.tb[bi] = btv * (1.0f - tau) + pn * tau;
+    }
+}
+
+// the merged launch in its latency form: [fc2 tiles | fc1 tiles | head workgroups (16 columns each) | TD workgroup]
+template <int EPI>
+__global__ __launch_bounds__(STHREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void wgrad_small_pair_kernel(GemmPair p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (p.tl && threadIdx.x == 0 && blockIdx.x < 512) p.tl[1024 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    const int n_main = p.tiles01 + p.head_total;
+    int bid = (int)blockIdx.x < n_main ? ssac_xcd_contiguous(blockIdx.x, n_main, p.xcd) : (int)blockIdx.x;
+    if (p.xcd_mix && (int)blockIdx.x < n_main) {   // XCD-contiguous PER CLASS (see ens_gemm_pair_kernel)
+        const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        const int a8 = p.tiles0 >> 3, f8 = (p.tiles01 - p.tiles0) >> 3, h8 = p.head_total >> 3;
+        bid = slot < a8 ? x * a8 + slot
+                        : (slot < a8 + f8 ? p.tiles0 + x * f8 + (slot - a8) : p.tiles01 + x * h8 + (slot - a8 - f8));
+    }
+    float *tab = lds + S_PART + S_RED;  // folded loss gradient: [n_rows] row scales, then scratch
+    const bool fold = p.lf.q != nullptr;
+    const LateTau lt{p.late_word != nullptr, p.late_word ? *p.late_word : 0u};
+    int last = 0;
+    bool drawn = false;
+    if (p.td_wg && bid == p.tiles01 + p.head_total) {
+        // the TD targets themselves + their statistics (and the nets' loss terms when no head workgroup takes them)
+        for (int e = 0; e < p.lf_nets; ++e) {
+            loss_fold_table(p.lf, e, tab, true, tab + p.lf.n_rows, e == 0);
+            __syncthreads();
+        }
+        if (p.lf_nets == 0) {
+            loss_fold_table(p.lf, 0, tab, false, tab + p.lf.n_rows, true);
+            __syncthreads();
+        }
+        if ((p.fold.done && p.fold.td_logs) || p.fold.deferred_stats)
+            log_fold_td_stats(p.fold, p.lf.tds, tab + p.lf.n_rows);
+    } else if (bid >= p.tiles01) {
+        const int L = bid - p.tiles01;
+        const int e = L / p.head_grid_x;
+        if (fold) {
+            loss_fold_table(p.lf, e, tab, p.stats_in_head && (L % p.head_grid_x) == 0, tab + p.lf.n_rows, false);
+            __syncthreads();
+        }
+        bool hpol = p.head.target != nullptr;
+        float htau = p.head.tau;
+        if (lt.on) {
+            hpol = hpol && lt.bits != 0u;
+            htau = __uint_as_float(lt.bits);
+        }
+        head_wgrad_body<S_HEAD_GROUPS, S_HEAD_COLS>(p.head, lds, L % p.head_grid_x, e, fold ? tab : nullptr, hpol, htau);
+    } else {
+        const bool first = bid < p.tiles0;
+        const GemmArgs &g = first ? p.g0 : p.g1;
+        const int L = first ? bid : bid - p.tiles0;
+        const int per = g.grid_x * g.grid_y;
+        const int bz = L / per, rem = L - bz * per;
+        const bool stats = p.lf_nets == 0 && !p.stats_in_head && first && rem == 0;
+        wgrad_small_body<EPI>(g, lds, rem % g.grid_x, rem / g.grid_x, bz, fold ? tab : nullptr, p.lf,
+                              fold ? (stats ? 2 : 1) : 0, p.fold, last, lt);
+        drawn = true;
+    }
+    if (p.fold.done) {
+        float *flag = lds + S_PART;   // (the bias / gradient-norm scratch: consumed by now)
+        __syncthreads();
+        if (threadIdx.x == 0) flag[0] = (drawn ? last != 0 : log_fold_arrive(p.fold, gridDim.x)) ? 1.0f : 0.0f;
+        __syncthreads();
+        if (flag[0] != 0.0f && threadIdx.x < 64) log_fold_finish(p.fold);
+    } else if (p.fold.deferred_stats && p.fold.feed && blockIdx.x == 0 && threadIdx.x == 0) {
+        p.fold.feed->tick += 1;   // deferred finalisation: the update is over for the input ring
+    }
+    if (p.tl && blockIdx.x < 512) {
+        __syncthreads();
+        if (threadIdx.x == 0) p.tl[1024 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// 0 = automatic (the latency form when the whole launch fits one resident round of its small workgroups and the 64 x 64
+// form would leave most of the chip idle), 1 = always 64 x 64 tiles, 2 = always 32 x 32 tiles (ssac_wgrad_variant)
+int g_wgrad_variant = 0;
+int g_wgrad_small_max = 512;   // automatic choice: the latency form up to this many workgroups (2 resident per CU)
+
+bool small_ok(const GemmArgs &g) {
+    return g.Ktot <= 0 && g.K >= 2 && (g.K & 1) == 0 && (int64_t)(g.K + 64) * g.lda < (1LL << 28) &&
+           (int64_t)(g.K + 64) * g.ldb < (1LL << 28);   // (byte offsets of the buffer loads stay below 2^31)
+}
+
+template <int EPI>
+int launch_pair_small(GemmPair &p, int batch, hipStream_t st) {
+    static bool attr_set = false;
+    const size_t lds = sizeof(float) * (S_PART + S_RED + (p.lf.q ? p.lf.n_rows + 2 * SW + 16 : 0));
+    if (lds > 150 * 1024) return ssac_fail("wgrad_small_pair: the folded loss table does not fit LDS");
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)wgrad_small_pair_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                150 * 1024) != hipSuccess)
+            return ssac_fail("wgrad_small_pair: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    for (GemmArgs *g : {&p.g0, &p.g1}) {
+        g->grid_x = (g->N + ST - 1) / ST;
+        g->grid_y = (g->M + ST - 1) / ST;
+    }
+    if (p.head_grid_x > 0) p.head_grid_x = (p.head.hidden + S_HEAD_COLS - 1) / S_HEAD_COLS;
+    p.xcd = (g_ssac_xcd >> 1) & 1;
+    p.tl = g_ssac_timeline;
+    p.tiles0 = p.g0.grid_x * p.g0.grid_y * batch;
+    p.tiles01 = p.tiles0 + p.g1.grid_x * p.g1.grid_y * batch;
+    p.head_total = p.head_grid_x > 0 ? p.head_grid_x * batch : 0;
+    p.xcd_mix = (p.xcd && (g_ssac_xcd & 4) == 0 && p.tiles0 % 8 == 0 && (p.tiles01 - p.tiles0) % 8 == 0 && p.head_total % 8 == 0) ? 1 : 0;
+    p.td_wg = (p.lf.q && p.lf.tds.q_t) ? 1 : 0;
+    p.stats_in_head = (p.lf.q && p.head_total > 0) ? 1 : 0;
+    p.lf_nets = (!p.stats_in_head && p.td_wg) ? batch : 0;
+    const int total = p.tiles01 + p.head_total + p.td_wg;
+    SSAC_LAUNCH((wgrad_small_pair_kernel<EPI>), dim3(total), dim3(STHREADS), lds, st, p);
+    return ssac_check_launch("wgrad_small_pair");
 }
 
 template <bool A_KC, bool B_KC, int EPI, int KS>
@@ -998,6 +1349,14 @@ bool layer_geom(const ssac_mlp *n, int layer, LayerGeom &L) {
 
 extern "C" int ssac_gemm_debug_stamps(long long *dev_buf) { g_gemm_dbg = dev_buf; return 0; }
 
+// Which form the merged weight-gradient launch takes: 0 = automatic, 1 = 64 x 64 tiles, 2 = 32 x 32 tiles (the latency
+// form) whenever the shapes allow.  Both are parity-tested on every fixture (tests/test_hip_cases.py).
+extern "C" int ssac_wgrad_variant(int variant) {
+    if (variant < 0 || variant > 2) return ssac_fail("ssac_wgrad_variant: 0 (automatic), 1 (64 x 64 tiles), 2 (32 x 32 tiles)");
+    g_wgrad_variant = variant;
+    return 0;
+}
+
 extern "C" int64_t ssac_mlp_layout(int in_dim, int hidden, int out_dim, int64_t off[6]) {
     int64_t o = 0;
     off[0] = o; o += (int64_t)hidden * in_dim;
@@ -1049,7 +1408,10 @@ extern "C" int ssac_mlp_layer_dgrad(const ssac_mlp *nets, int layer, const int32
 extern "C" int ssac_wgrad_tiles(const ssac_mlp *nets, int layer) {
     LayerGeom L;
     if (!nets || !layer_geom(nets, layer, L)) return -1;
-    return ((L.rows + BM - 1) / BM) * ((L.cols + BN - 1) / BN);
+    // gradient-norm slots of the layer per net: one per 32 x 32 tile (sumsq_store64); heads of <= 16 outputs go through
+    // the VALU head workgroups, which own one slot per 16 columns (ssac_head_wgrad.h)
+    if (layer == 2 && nets->out_dim <= 16) return (nets->hidden + SSAC_HEAD_SLOT_COLS - 1) / SSAC_HEAD_SLOT_COLS;
+    return ((L.rows + 31) / 32) * ((L.cols + 31) / 32);
 }
 
 namespace {
@@ -1220,6 +1582,15 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
     hipStream_t st = (hipStream_t)stream;
     const int tiles = (p.g0.grid_x * p.g0.grid_y + p.g1.grid_x * p.g1.grid_y) * n_sel;
     const int nchunks = (n_rows + BK - 1) / BK;
+    {
+        // latency form (32 x 32 tiles, wgrad_small_pair_kernel): when all of its workgroups are resident at once (two
+        // per CU) -- then the launch lasts one short workgroup instead of one long one
+        auto t32 = [](const GemmArgs &g) { return ((g.M + ST - 1) / ST) * ((g.N + ST - 1) / ST); };
+        const int small_wgs = (t32(p.g0) + t32(p.g1) + (p.head_grid_x > 0 ? (H + S_HEAD_COLS - 1) / S_HEAD_COLS : 0)) * n_sel + 1;
+        const bool can = small_ok(p.g0) && small_ok(p.g1) && nets->out_dim <= 16;
+        if (can && (g_wgrad_variant == 2 || (g_wgrad_variant == 0 && small_wgs <= g_wgrad_small_max)))
+            return grads ? launch_pair_small<EPI_GRAD>(p, n_sel, st) : launch_pair_small<EPI_ADAM>(p, n_sel, st);
+    }
     if (grads) {
         if (tiles <= 256 && nchunks >= 8) return launch_pair_ks<false, false, EPI_GRAD, 4>(p, n_sel, n_sel, st);
         if (tiles <= 512 && nchunks >= 4) return launch_pair_ks<false, false, EPI_GRAD, 2>(p, n_sel, n_sel, st);

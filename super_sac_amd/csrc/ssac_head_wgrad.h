@@ -18,25 +18,30 @@ struct HeadWgradArgs {
     int with_b2; int64_t off_b2;   // offset of b2 in a net's parameter block
 };
 
-// dW3[o][k] = sum_m dq[m][o] h2[m][k];  db3[o] = sum_m dq[m][o].  Workgroup (bx, e): columns [64 bx, 64 bx + 64) of
-// net e; 64 * GROUPS threads = 64 columns x GROUPS row groups.  lds: >= GROUPS*64 + GROUPS floats (2*GROUPS*64 + GROUPS
-// with b2_w3s).
+// dW3[o][k] = sum_m dq[m][o] h2[m][k];  db3[o] = sum_m dq[m][o].  Workgroup (bx, e): columns [COLS bx, COLS bx + COLS) of
+// net e; COLS * GROUPS threads = COLS columns x GROUPS row groups.  lds: >= GROUPS*COLS + GROUPS floats
+// (2*GROUPS*COLS + GROUPS with b2_w3s).  COLS = 64 everywhere but in the latency variant of the merged weight-gradient
+// launch (wgrad_small_pair_kernel, ssac_gemm.hip), whose 16-column head workgroups walk 16 rows per thread instead of 32.
+// Gradient-norm slots: a net's head layer owns hidden / 16 slots (ssac_head_wgrad_tiles); a 64-column workgroup writes
+// the first of its four and zeroes the rest, so the slots sum to the same value whichever variant ran last.
 // pol / tau: whether and how the Polyak target is updated (the caller resolves a late-bound request, ssac_late_polyak)
-template <int GROUPS>
+constexpr int SSAC_HEAD_SLOT_COLS = 16;
+template <int GROUPS, int COLS = 64>
 __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *lds, int bx, int e,
                                                 const float *dq_override, bool pol, float tau);
-template <int GROUPS>
+template <int GROUPS, int COLS = 64>
 __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *lds, int bx, int e,
                                                 const float *dq_override = nullptr) {
-    head_wgrad_body<GROUPS>(a, lds, bx, e, dq_override, a.target != nullptr, a.tau);
+    head_wgrad_body<GROUPS, COLS>(a, lds, bx, e, dq_override, a.target != nullptr, a.tau);
 }
-template <int GROUPS>
+template <int GROUPS, int COLS>
 __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *lds, int bx, int e,
                                                 const float *dq_override, bool pol, float tau) {
-    float *red = lds;                 // [GROUPS][64]
-    float *redb = lds + GROUPS * 64;  // [GROUPS]
-    const int tid = threadIdx.x, kk = tid & 63, mg = tid >> 6;
-    const int k = bx * 64 + kk;
+    static_assert(COLS == 64 || COLS == 16, "64-column (wave-wide) or 16-column head workgroups");
+    float *red = lds;                   // [GROUPS][COLS]
+    float *redb = lds + GROUPS * COLS;  // [GROUPS]
+    const int tid = threadIdx.x, kk = tid % COLS, mg = tid / COLS;
+    const int k = bx * COLS + kk;
     const int hidden = a.hidden, out_dim = a.out_dim, n_rows = a.n_rows;
     const int net = a.ids ? a.ids[e] : e;
     const int64_t base = (int64_t)net * a.net_stride;
@@ -47,7 +52,7 @@ __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *l
     float ss = 0.0f;
     // one output row o at a time: out_dim is small (1 for continuous critics), rows are the long axis
     const bool with_b2 = a.with_b2 != 0 && out_dim == 1;
-    float *reds = redb + GROUPS;      // [GROUPS][64] (with_b2)
+    float *reds = redb + GROUPS;      // [GROUPS][COLS] (with_b2)
     for (int o = 0; o < out_dim; ++o) {
         float acc = 0.0f, accb = 0.0f, accs = 0.0f;
         int m = mg;
@@ -69,14 +74,14 @@ __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *l
             accs += h > 0.0f ? d : 0.0f;
         }
         __syncthreads();
-        red[mg * 64 + kk] = acc;
-        if (with_b2) reds[mg * 64 + kk] = accs;
+        red[mg * COLS + kk] = acc;
+        if (with_b2) reds[mg * COLS + kk] = accs;
         if (kk == 0) redb[mg] = accb;
         __syncthreads();
         if (mg == 0) {
             float gr = 0.0f;
 #pragma unroll
-            for (int q = 0; q < GROUPS; ++q) gr += red[q * 64 + kk];
+            for (int q = 0; q < GROUPS; ++q) gr += red[q * COLS + kk];
             const ssac_adam_ctl c = a.grads ? ssac_adam_ctl{} : *a.ctl;
             auto apply = [&](int64_t i, float g_) {
                 if (a.grads) {
@@ -100,7 +105,7 @@ __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *l
                 if (with_b2) {
                     float gs = 0.0f;
 #pragma unroll
-                    for (int q = 0; q < GROUPS; ++q) gs += reds[q * 64 + kk];
+                    for (int q = 0; q < GROUPS; ++q) gs += reds[q * COLS + kk];
                     const float gb2 = w3_old * gs;
                     ss += gb2 * gb2;
                     apply(base + a.off_b2 + k, gb2);
@@ -115,9 +120,17 @@ __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *l
             }
         }
     }
-    if (a.sumsq && mg == 0) {  // wave 0 holds every contribution
+    if (a.sumsq && tid < 64) {  // the threads of row group 0 hold every contribution, and they all sit in wave 0
+        if (mg != 0) ss = 0.0f;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        if (kk == 0) __hip_atomic_store(a.sumsq + (int64_t)e * a.sumsq_stride + bx, ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            constexpr int SPAN = COLS / SSAC_HEAD_SLOT_COLS;   // slots this workgroup's columns cover
+            const int n_slots = (hidden + SSAC_HEAD_SLOT_COLS - 1) / SSAC_HEAD_SLOT_COLS;
+            float *slot = a.sumsq + (int64_t)e * a.sumsq_stride + bx * SPAN;
+            __hip_atomic_store(slot, ss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 1; i < SPAN && bx * SPAN + i < n_slots; ++i)
+                __hip_atomic_store(slot + i, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }

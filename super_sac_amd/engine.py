@@ -20,6 +20,15 @@ SEGS = ("w1", "b1", "w2", "b2", "w3", "b3")
 # overhead (~5 us) is amortised and the per-launch time agrees with a rocprofv3 kernel trace.
 PROFILE = {"tag": None, "events": [], "reps": 1}
 USE_FUSED = True  # tests flip this to exercise the per-layer kernels on fused-capable shapes
+
+
+def set_wgrad_variant(variant):
+    """form of the merged weight-gradient launch: 0 = automatic (the 32 x 32-tile latency form for under-filled launches),
+    1 = 64 x 64 tiles always, 2 = 32 x 32 tiles whenever the shapes allow.  Both forms are parity-tested on every fixture
+    (tests/test_hip_cases.py); recorded launch lists keep the form they were recorded with."""
+    check(lib.ssac_wgrad_variant(int(variant)))
+
+
 # launch the head layer's (VALU) weight-gradient kernel as a parallel branch beside the fc2/fc1 GEMM launch
 HEAD_BRANCH = _lib.debug_knob("head_branch", False)
 # head + fc2 + fc1 weight gradients in one launch (the head's VALU workgroups fill CUs the GEMM tiles leave idle)

@@ -108,11 +108,15 @@ def _split_forward(n_nets, n_rows):
     return SPLIT_FORWARD and n_nets * ((n_rows + 31) // 32) <= 192
 
 
-def _clip_and_step(adam, members, clip, slot_norm):
+def _clip_and_step(adam, members, clip, slot_norm, member_shard=None):
     """clip_grad_norm_ over ALL listed arenas jointly, then Adam from the stored gradients
-    (learning.py:122-130 / :413-416).  members: list of (arena, key, grads, sumsq)."""
+    (learning.py:122-130 / :413-416).  members: list of (arena, key, grads, sumsq).  member_shard: the joint norm runs
+    over the members of EVERY rank (one SUM all-reduce of this rank's squared norm)."""
     st = engine.stream()
     allss = members[0][3] if len(members) == 1 else torch.cat([m[3] for m in members])
+    if member_shard is not None:
+        allss = allss.sum().reshape(1)   # (device plumbing: one scalar to exchange)
+        parallel.all_reduce_sum(allss)
     check(lib.ssac_clip_coef(adam.ctl.ptr, allss.data_ptr(), allss.numel(), float(clip), 0, st))
     for arena, key, grads, _ in members:
         m, v = adam.moments_for(key, arena.params)
@@ -204,6 +208,7 @@ def critic_update(buffer, agent, target_agent, critic_optimizer, encoder_optimiz
     lu.ensure_adopted(target_agent, buffer)
     shard = parallel.shard_of(agent)
     graphable = (USE_GRAPHS and engine.CAPTURE is None and agent.ensemble_size == 1 and not per
+                 and parallel.member_shard_of(agent) is None
                  and not update_priorities and not dr3_coeff and lu.is_identity(agent.encoder)
                  and random_process is None and torch.cuda.is_available()
                  # critic-sharded ranks: recorded launch lists only (the collective sits between two segments),
@@ -554,6 +559,16 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
         _flush_other_recordings(agent)
     E = agent.ensemble_size
     assert E <= lu.MAX_MEMBERS
+    # member-sharded rank (parallel.MemberShard, SURVEY 8(e) "SUNRISE variant"): `agent` holds the members [ms.lo, ms.hi)
+    # of an ensemble of E_glob; the loss is averaged over the GLOBAL ensemble, every member's host draws are made here
+    ms = parallel.member_shard_of(agent)
+    E_glob = E if ms is None else ms.ensemble_size
+    if ms is not None:
+        assert lu.is_identity(agent.encoder), "member sharding: a trainable encoder is shared by all members (not sharded)"
+        assert not per and not update_priorities and not dr3_coeff, "member sharding covers the online critic update"
+        if weight_type is not None and weighted_bellman_temp is not None and weight_type != "sunrise":
+            raise NotImplementedError("member-sharded ranks compute the 'sunrise' backup weights (the 'softmax' weights "
+                                      "sample from every member's ONLINE actor: learning_utils.py:383-393)")
     dev = log_alphas[0].device
     ws = lu.agent_ws(agent, dev)
     adam = engine.adam_group(critic_optimizer, dev)
@@ -569,7 +584,18 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
     # every member's batch, TD target and backup weights are computed BEFORE any critic is updated -- the "softmax"
     # weights of member i look at the ONLINE critics of ALL members (learning_utils.py:383-393).
     preps = []
-    for i in range(E):
+    all_rd = []   # member-sharded ranks: every global member's batch, in member order
+    for ig in range(E_glob):
+        i = ig if ms is None else ms.local(ig)
+        if i is None:
+            # a member another rank owns: its batch (this rank's target critics score it for the sunrise weights) and
+            # its host draws, in the reference's order -- sample, action noise, REDQ subset
+            rd = lu.sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter,
+                                            aug_mix=aug_mix, per=per, _invariance=bool(encoder_lambda))
+            lu.skip_td_draws(agent, agent.actors[0], batch_size, dev, target_agent.critics[0].arena(dev).n_nets,
+                             target_critic_ensemble_n, random_process)
+            all_rd.append(rd)
+            continue
         arena = agent.critics[i].arena(dev)
         N, qd = arena.n_nets, arena.out_dim
         H = arena.hidden
@@ -616,18 +642,24 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                                       log_alphas=log_alphas, pop=pop, gamma=gamma,
                                       random_process=random_process, noise_clip=noise_clip,
                                       discrete=discrete, _slot=slot, _defer=arena.fused and LAZY_TD and not dr3_coeff,
-                                      _co_forward=co, _co_backward=cob)
+                                      _co_forward=co, _co_backward=cob, _log_idx=ig)
         lu.ensure_gathered(rd.get("_ssac"))  # (no-op when the merged launch took the gather)
         co_done = bool(rd.pop("_co_fwd", False))
         bwd_done = bool(rd.pop("_co_bwd", False))
         if co_done:
             h1, h2, q = co[3], co[4], co[5]
-        bw = lu.compute_backup_weights(logs=logs, replay_dict=rd, agent=agent, target_agent=target_agent,
-                                       weight_type=weight_type, weight_temp=weighted_bellman_temp,
-                                       batch_size=batch_size, discrete=discrete, _slot=slot)
+        all_rd.append(rd)
+        bw = 1.0 if ms is not None else \
+            lu.compute_backup_weights(logs=logs, replay_dict=rd, agent=agent, target_agent=target_agent,
+                                      weight_type=weight_type, weight_temp=weighted_bellman_temp,
+                                      batch_size=batch_size, discrete=discrete, _slot=slot)
         preps.append(dict(arena=arena, rd=rd, branch=branch, co=co, td=td, co_done=co_done, bwd_done=bwd_done, bw=bw,
                           fwd=(h1, h2, q) if (co_done or branch is not None) else None,
                           xin=(s_rep, X, ldx) if (branch is not None or co is not None) else None))
+    if ms is not None and weight_type is not None and weighted_bellman_temp is not None and E_glob > 1:
+        wts = lu.member_sharded_sunrise_weights(logs, all_rd, agent, target_agent, ms, weighted_bellman_temp, discrete, slot)
+        for i, P in enumerate(preps):
+            P["bw"] = wts[ms.lo + i]
     for i, P in enumerate(preps):
         arena, rd, branch, co, td, co_done, bwd_done, bw = (P[k_] for k_ in ("arena", "rd", "branch", "co", "td",
                                                                              "co_done", "bwd_done", "bw"))
@@ -719,13 +751,13 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             qc.copy_(cq[:, :B])
             dqc = ws.get(tag + ".dr3.dqc", (N, B, qd))
             check(lib.ssac_critic_loss_bwd(qc.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0), td.data_ptr(),
-                                           weight_ptr, pp, dopop, float(E * n_glob), dqc.data_ptr(),
+                                           weight_ptr, pp, dopop, float(E_glob * n_glob), dqc.data_ptr(),
                                            slot.data_ptr(), st))
             dq2 = ws.get(tag + ".dr3.dq", (N, 2 * B, qd), zero=True)
             dq2[:, :B].copy_(dqc)
             nblk = int(lib.ssac_dr3_blocks())
             dparts = ws.get(tag + ".dr3.parts", (nblk,))
-            coef = float(dr3_coeff) / (E * n_glob) / (N * B)
+            coef = float(dr3_coeff) / (E_glob * n_glob) / (N * B)
 
             def dr3_hook(dz2_, _h2=ch2, _parts=dparts):
                 check(lib.ssac_dr3_add(dz2_.data_ptr(), _h2.data_ptr(), N, B, H, coef, _parts.data_ptr(), st))
@@ -734,7 +766,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
             fca = dparts.sum() / (N * B)
             logs[f"dr3_dotproduct_{i}"] = fca
             # the logged overall loss includes the regulariser (learning.py:108, 133)
-            slot[lu.L_CRITIC_LOSS:lu.L_CRITIC_LOSS + 1].add_(fca * (float(dr3_coeff) / (E * n_glob)))
+            slot[lu.L_CRITIC_LOSS:lu.L_CRITIC_LOSS + 1].add_(fca * (float(dr3_coeff) / (E_glob * n_glob)))
             fused_logs.append(None)
         elif arena.fused:
             dz2 = ws.get(tag + ".dz2", (N, B, H))
@@ -753,7 +785,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                 # weight-gradient launch evaluates it itself (per workgroup, in LDS): no loss launch at all
                 fparts = ws.get(tag + ".fparts", (N * 2,))
                 lossfold = dict(q=q, td_ptr=0 if spec is not None else td.data_ptr(), spec_ptr=spec_ptr,
-                                weight_ptr=weight_ptr, popart_ptr=pp, pop=dopop, denom=float(E * n_glob),
+                                weight_ptr=weight_ptr, popart_ptr=pp, pop=dopop, denom=float(E_glob * n_glob),
                                 partials=fparts, dz2_from_h2=dz2_skipped, w3_snapshot=w3_snapshot)
                 if arena.shadow is not None:
                     lossfold["bf"] = arena.bf_buffers(ws, "cu", B)
@@ -770,7 +802,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                         if arena.shadow is not None:
                             lossfold["target_shadow"] = cap.late_target.shadow
                     lossfold["logfold"] = _lib.LogFold(0, slot.data_ptr(), 0, cap.feed, cap.deferred.td_stats, late_ptr)
-                elif FOLD_LOGS and E == 1 and not critic_clip:
+                elif FOLD_LOGS and E_glob == 1 and not critic_clip:
                     # the log finalisation rides in the weight-gradient launch (its last workgroup to arrive): no logs launch
                     lossfold["logfold"] = _lib.LogFold(
                         ws.get("cu.done", (1,), dtype=torch.int32, zero=True).data_ptr(), slot.data_ptr(),
@@ -780,11 +812,11 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                 # ... or a single-workgroup launch writes the N x B scalars for the weight-gradient launch to read
                 if spec is not None:
                     check(lib.ssac_critic_loss_bwd_lazy(q.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0), spec_ptr,
-                                                        weight_ptr, pp, dopop, float(E * n_glob), dq.data_ptr(),
+                                                        weight_ptr, pp, dopop, float(E_glob * n_glob), dq.data_ptr(),
                                                         slot.data_ptr(), st))
                 else:
                     check(lib.ssac_critic_loss_bwd(q.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0), td.data_ptr(),
-                                                   weight_ptr, pp, dopop, float(E * n_glob), dq.data_ptr(),
+                                                   weight_ptr, pp, dopop, float(E_glob * n_glob), dq.data_ptr(),
                                                    slot.data_ptr(), st))
             elif branch is not None or co_done:
                 # loss gradient + head backward + backward-data on the saved forward: ONE launch
@@ -794,7 +826,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                     for _ in range(tm.reps):  # 1, except under bench.py's live kernel timing (idempotent launch)
                         check(lib.ssac_critic_bwd_fused(
                             C.byref(arena.desc()), B, td.data_ptr(), weight_ptr, a.data_ptr(), a.stride(0), pp,
-                            dopop, float(E * n_glob), h1.data_ptr(), h2.data_ptr(), q.data_ptr(), dq.data_ptr(),
+                            dopop, float(E_glob * n_glob), h1.data_ptr(), h2.data_ptr(), q.data_ptr(), dq.data_ptr(),
                             dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), spec_ptr, st))
             else:
                 # forward of all N critics + loss gradient + backward-data: ONE launch
@@ -805,7 +837,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                     for _ in range(tm.reps):  # 1, except under bench.py's live kernel timing (idempotent launch)
                         check(lib.ssac_critic_fwd_bwd_fused(
                             C.byref(arena.desc()), X.data_ptr(), ldx, B, td.data_ptr(), weight_ptr, a.data_ptr(),
-                            a.stride(0), pp, dopop, float(E * n_glob), h1.data_ptr(), h2.data_ptr(), q.data_ptr(),
+                            a.stride(0), pp, dopop, float(E_glob * n_glob), h1.data_ptr(), h2.data_ptr(), q.data_ptr(),
                             dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), spec_ptr, st))
             if train_enc:  # dL/d(embedding) = sum over critics of dz1 W1[:, :emb], BEFORE W1 is updated
                 dX = ws.get(tag + ".dx", (N, B, arena.in_dim))
@@ -834,7 +866,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                 raise NotImplementedError("bf16 mode needs the fused kernel family (hidden % 32 == 0, <= 256)")
             h1, h2, q = engine.mlp_forward(arena, X, ldx, 0, B, ws, tag)
             check(lib.ssac_critic_loss_bwd(q.data_ptr(), N, B, qd, a.data_ptr(), a.stride(0),
-                                           td.data_ptr(), weight_ptr, pp, dopop, float(E * n_glob),
+                                           td.data_ptr(), weight_ptr, pp, dopop, float(E_glob * n_glob),
                                            dq.data_ptr(), slot.data_ptr(), st))
             if train_enc:
                 dX = engine.mlp_backward(arena, dq, X, ldx, 0, h1, h2, B, ws, tag, need_dx=True, update=False)
@@ -853,13 +885,18 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
         rd["td_target"] = td
         replay_dicts.append(rd)
     if critic_clip:
-        _clip_and_step(adam, clip_members, critic_clip, None)
+        _clip_and_step(adam, clip_members, critic_clip, None, member_shard=ms)
     # encoder: identity encoders carry no trainable tensor on this path (their dummy Linear(1,1)
     # never receives a gradient, nets/__init__.py:24), so encoder_optimizer.step() is a no-op.
     logs["losses/last_member_critic_td_error"] = slot[lu.L_TD_ERR]
     logs["losses/critic_overall_loss"] = slot[lu.L_CRITIC_LOSS]
-    pick = agent.critics[0] if engine.CAPTURE is not None else rng.choice(agent.critics)  # learning.py:135
-    k = next(j for j, c in enumerate(agent.critics) if c is pick)
+    if ms is not None:
+        # learning.py:135 picks over the GLOBAL ensemble (the same Python draw on every rank); a rank that does not hold
+        # the picked member logs the gradient norm of its first one
+        k = ms.local(rng.choice(range(E_glob))) or 0
+    else:
+        pick = agent.critics[0] if engine.CAPTURE is not None else rng.choice(agent.critics)  # learning.py:135
+        k = next(j for j, c in enumerate(agent.critics) if c is pick)
     clip_ctl = adam.ctl.ptr if critic_clip else 0
     done_norm = False
     for j, fl in enumerate(fused_logs):
@@ -871,7 +908,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
         want = j == k
         cap = engine.CAPTURE
         last = cap is not None and cap.feed and j == len(fused_logs) - 1 and (done_norm or want)
-        check(lib.ssac_critic_logs(parts.data_ptr(), n_, tiles_, b_, float(E * ng_),
+        check(lib.ssac_critic_logs(parts.data_ptr(), n_, tiles_, b_, float(E_glob * ng_),
                                    member_ss[k].data_ptr() if want else 0, member_ss[k].numel() if want else 0,
                                    clip_ctl, slot.data_ptr(), C.addressof(spec_) if spec_ is not None else 0,
                                    td_._ssac_logs.data_ptr() if spec_ is not None else 0,
@@ -917,7 +954,7 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
     recordable = (USE_GRAPHS and LAUNCH_MODE == "list" and FUSED_ACTOR and engine.CAPTURE is None
                   and premade_replay_dicts is not None and not discrete and not clip and random_process is None
                   and not use_baseline and parallel.shard_of(agent) is None
-                  and lu.is_identity(agent.encoder)
+                  and parallel.member_shard_of(agent) is None and lu.is_identity(agent.encoder)
                   and all(lu.actor_kind(a_) == "stochastic" and engine.bind_arena(a_, "self", [a_], dev).fused
                           for a_ in agent.actors)
                   and all(c_.arena(dev).fused_dbuf and c_.arena(dev).out_dim == 1 for c_ in agent.critics))
@@ -972,9 +1009,22 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
         slot = lu.log_block(dev, adam)
     logs = {}
     st = engine.stream()
-    inv_e = 1.0 / len(agent.actors)
+    # member-sharded rank (parallel.MemberShard): the loss is averaged over the GLOBAL ensemble (learning.py:409), and the
+    # members other ranks own still take their host draws here, in member order
+    ms = parallel.member_shard_of(agent)
+    E_glob = len(agent.actors) if ms is None else ms.ensemble_size
+    inv_e = 1.0 / E_glob
     clip_members, member_ss = [], []
-    for i, ((actor, critic), popart, log_alpha) in enumerate(zip(agent.ensemble, agent.popart, log_alphas)):
+    members = list(zip(agent.ensemble, agent.popart, log_alphas))
+    for ig in range(E_glob):
+        i = ig if ms is None else ms.local(ig)
+        if i is None:
+            assert not use_baseline, "use_baseline is not supported on member-sharded ranks"
+            if premade_replay_dicts is None:
+                lu.sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter, aug_mix=aug_mix, per=per)
+            lu.skip_actor_draws(agent.actors[0], batch_size, dev, random_process)
+            continue
+        (actor, critic), popart, log_alpha = members[i]
         if premade_replay_dicts is not None:
             rd = premade_replay_dicts[i]
         else:
@@ -1025,7 +1075,7 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             ss = ws.get(f"au.ss{i}", (ttot,))
             engine.weight_grads(a_arena, s_rep, lds, 0, ah1, ah2, d_out, dz2, dz1, B, adam=adam,
                                 adam_key=("actor", i), sumsq=ss)
-            one = len(agent.actors) == 1   # (then the logged actor is this one: both logs in one launch)
+            one = E_glob == 1   # (then the logged actor is this one: both logs in one launch)
             check(lib.ssac_actor_logs(parts.data_ptr(), tiles, B, inv_e, ss.data_ptr() if one else 0, ss.numel(),
                                       slot[lu.L_ACTOR_LOSS:].data_ptr(), slot[lu.L_ACTOR_GN:].data_ptr() if one else 0,
                                       st))
@@ -1128,12 +1178,15 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
                                 adam_key=("actor", i), sumsq=ss)
         member_ss.append(ss)
     if clip:
-        _clip_and_step(adam, clip_members, clip, None)
+        _clip_and_step(adam, clip_members, clip, None, member_shard=ms)
     for actor in agent.actors:  # bf16 mode: the actor step ran on the fp32 masters; refresh the shadows
         for ar in actor.__dict__.get("_ssac_arenas", {}).values():
             ar.sync_shadow()
-    pick = rng.choice(agent.actors)  # learning.py:417-419
-    k = next(j for j, a_ in enumerate(agent.actors) if a_ is pick)
+    if ms is not None:   # the pick is over the GLOBAL ensemble; a rank that does not hold it logs its first member's norm
+        k = ms.local(rng.choice(range(E_glob))) or 0
+    else:
+        pick = rng.choice(agent.actors)  # learning.py:417-419
+        k = next(j for j, a_ in enumerate(agent.actors) if a_ is pick)
     if member_ss[k] is not None:  # (None: the fused path's log launch wrote the norm already)
         check(lib.ssac_group_norms(member_ss[k].data_ptr(), 1, member_ss[k].numel(),
                                    adam.ctl.ptr if clip else 0, slot[lu.L_ACTOR_GN:].data_ptr(), st))
@@ -1440,7 +1493,15 @@ def alpha_update(buffer, agent, optimizers, batch_size, log_alphas, augmenter, a
     slot = lu.log_block(dev)
     logs = {}
     st = engine.stream()
-    for i in range(agent.ensemble_size):
+    ms = parallel.member_shard_of(agent)   # member-sharded rank: log_alphas / optimizers are the LOCAL members'
+    for ig in range(agent.ensemble_size if ms is None else ms.ensemble_size):
+        i = ig if ms is None else ms.local(ig)
+        if i is None:   # a member another rank owns: its host draws, in member order
+            if premade_replay_dicts is None:
+                lu.sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter, per=False,
+                                           aug_mix=aug_mix)
+            lu.skip_alpha_draws(agent, agent.actors[0], batch_size, dev)
+            continue
         if premade_replay_dicts is not None:
             rd = premade_replay_dicts[i]
         else:
@@ -1490,6 +1551,6 @@ def alpha_update(buffer, agent, optimizers, batch_size, log_alphas, augmenter, a
         m, v = adam.moments_for("log_alpha", la.data)
         check(lib.ssac_alpha_update(la.data_ptr(), m.data_ptr(), v.data_ptr(), adam.ctl.ptr, lp_ptr, B,
                                     n_act, float(target_entropy), slot[lu.L_ALPHA0 + 2 * i:].data_ptr(), st))
-        logs[f"losses/alpha_loss_{i}"] = slot[lu.L_ALPHA0 + 2 * i]
-        logs[f"alphas/alpha_{i}"] = slot[lu.L_ALPHA0 + 2 * i + 1]
+        logs[f"losses/alpha_loss_{ig}"] = slot[lu.L_ALPHA0 + 2 * i]
+        logs[f"alphas/alpha_{ig}"] = slot[lu.L_ALPHA0 + 2 * i + 1]
     return logs

@@ -480,7 +480,7 @@ def _upload_ids(ws, ids, device, tag):
 
 def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ensemble_n, log_alphas,
                        pop, gamma, random_process, noise_clip, discrete=False, _slot=None, _defer=False,
-                       _co_forward=None, _co_backward=None):
+                       _co_forward=None, _co_backward=None, _log_idx=None):
     """learning_utils.py:298-354.  With ``_defer`` (critic_update's fused path; continuous actions, no PopArt)
     the final elementwise step -- and its three log values -- is not launched here: the returned ``td`` buffer
     carries a ``_ssac_spec`` (ssac_td_spec) and the critic launch evaluates the targets into it.
@@ -602,9 +602,10 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
                                  log_alpha.data_ptr(), use_entropy, float(gamma),
                                  popart.ptr if popart else 0, 1 if (popart and pop) else 0,
                                  td.data_ptr(), slot[L_TD0 + 3 * i:].data_ptr(), st))
-    logs[f"td_targets/mean_td_target_{i}"] = slot[L_TD0 + 3 * i]
-    logs[f"td_targets/std_td_target_{i}"] = slot[L_TD0 + 3 * i + 1]
-    logs[f"td_targets/entropy_bonus_{i}"] = slot[L_TD0 + 3 * i + 2]
+    li = i if _log_idx is None else _log_idx   # (member-sharded ranks: the member's GLOBAL index names its logs)
+    logs[f"td_targets/mean_td_target_{li}"] = slot[L_TD0 + 3 * i]
+    logs[f"td_targets/std_td_target_{li}"] = slot[L_TD0 + 3 * i + 1]
+    logs[f"td_targets/entropy_bonus_{li}"] = slot[L_TD0 + 3 * i + 2]
     replay_dict["_subset"] = ids
     replay_dict["_x1"] = None if kind == "discrete" else x1  # [s' | a'] as fed to the target critics (DR3)
     if kind == "discrete":
@@ -771,6 +772,95 @@ def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag, co_backward=None, re
         qpart.fill_(float("inf"))
     parallel.all_reduce_min(qpart)
     return qpart, 1
+
+
+# ------------------------------------------------------------------------------------------
+# Member-sharded ranks (parallel.MemberShard, SURVEY 8(e) "SUNRISE variant"): a member another rank owns still
+# CONSUMES its host draws here -- in the order the reference makes them -- so that the generators of every rank (and
+# the in-kernel noise counter of this agent) stay in step with the owner's.  `actor` = any local actor (all members
+# share class and shape).
+# ------------------------------------------------------------------------------------------
+def skip_td_draws(agent, actor, B, dev, n_critics, ensemble_n, random_process):
+    """the draws of compute_td_targets for one member: a' noise, exploration noise, then the REDQ subset"""
+    kind = actor_kind(actor)
+    if kind != "discrete":
+        A = actor.action_size
+        if kind == "stochastic":
+            fused = engine.bind_arena(actor, "self", [actor], dev).fused and random_process is None
+            if fused and IN_KERNEL_NOISE and rng.normal_is_stock():
+                noise_stream(agent, dev)[1] += 1
+            else:
+                draw_normal((B, A), dev)
+        if random_process is not None:
+            draw_normal((B, A), dev)
+    draw_subset(n_critics, ensemble_n)
+
+
+def skip_actor_draws(actor, B, dev, random_process):
+    """the draws of online_actor_update for one member: rsample noise, then exploration noise"""
+    if actor_kind(actor) == "discrete":
+        return
+    A = actor.action_size
+    draw_normal((B, A), dev)
+    if random_process is not None:
+        draw_normal((B, A), dev)
+
+
+def skip_alpha_draws(agent, actor, B, dev):
+    """the draw of alpha_update for one member: the policy sample behind log pi"""
+    if actor_kind(actor) != "stochastic":
+        return
+    if engine.bind_arena(actor, "self", [actor], dev).fused and IN_KERNEL_NOISE and rng.normal_is_stock():
+        noise_stream(agent, dev)[1] += 1
+    else:
+        draw_normal((B, actor.action_size), dev)
+
+
+def member_sharded_sunrise_weights(logs, replay_dicts, agent, target_agent, member_shard, weight_temp, discrete, slot):
+    """compute_backup_weights("sunrise") on a member-sharded rank (learning_utils.py:372-382): replay_dicts = the batch
+    of EVERY global member (this rank gathered them all: same index draws everywhere).  This rank's members' target
+    critics score all E batches, the all-gather completes the (batch, member, row) table, and the weights of the
+    members this rank owns are formed from it.  Returns {global member index: (B, 1) weights}."""
+    from . import parallel
+    ms = member_shard
+    E, El = ms.ensemble_size, ms.n_local
+    a0 = replay_dicts[0]["primary_batch"][1]
+    dev = a0.device
+    ws = agent_ws(agent, dev)
+    st = engine.stream()
+    B = a0.shape[0]
+    table = ws.get("bw.table", (E, E, B))   # [batch of member i][member k][row]
+    table.zero_()
+    for ig, rd in enumerate(replay_dicts):
+        o, a = rd["primary_batch"][0], rd["primary_batch"][1]
+        ensure_gathered(rd.get("_ssac"))
+        s_rep = encode(target_agent.encoder, o)
+        S = s_rep.shape[1]
+        bt = rd.get("_ssac")
+        if discrete:
+            x, ldx = s_rep, _row_stride(s_rep)
+        elif bt is not None and bt.xsa is not None and s_rep.data_ptr() == bt.xsa.data_ptr():
+            x, ldx = bt.xsa, bt.xsa.stride(0)
+        else:
+            x = _concat_buffer(ws, f"bw.x{ig}", s_rep, a.shape[1])
+            x[:, S:].copy_(a)
+            ldx = x.stride(0)
+        for k in range(El):
+            ar = target_agent.critics[k].arena(dev)
+            _, _, q = engine.mlp_forward(ar, x, ldx, 0, B, ws, f"bw.c{k}", save=False)
+            check(lib.ssac_ensemble_min_select(q.data_ptr(), ar.n_nets, B, ar.out_dim,
+                                               a.data_ptr() if discrete else 0, a.stride(0) if discrete else 0,
+                                               table[ig, ms.lo + k].data_ptr(), st))
+    parallel.all_gather_blocks(table)
+    out = {}
+    for ig in range(ms.lo, ms.hi):
+        w = torch.empty(B, 1, device=dev)
+        check(lib.ssac_sunrise_weights(table[ig].data_ptr(), E, B, float(weight_temp), w.data_ptr(),
+                                       slot[L_BW:].data_ptr(), st))
+        out[ig] = w
+    for j, nm in enumerate(("mean", "max", "min", "std")):   # (the LAST owned member's statistics stay in the block)
+        logs[f"bellman_weights/{nm}"] = slot[L_BW + j]
+    return out
 
 
 def compute_backup_weights(logs, replay_dict, agent, target_agent, weight_type, weight_temp, batch_size,

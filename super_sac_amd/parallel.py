@@ -59,6 +59,53 @@ def shard_of(agent):
     return getattr(agent, "ssac_shard", None)
 
 
+class MemberShard:
+    """SUNRISE variant of SURVEY.md 8(e): with ``ensemble_size`` E > 1 the MEMBERS are independent -- own actor, own
+    critics, own temperature, own replay batch (learning.py:47-117 loops over them; experiments/gym/sunrise.gin:6-9 has
+    E 5 x 2 critics, so sharding the critics of a member could use 2 GPUs at most) -- and rank g holds the members
+    [lo, hi).  The replay buffer is replicated and every rank makes EVERY member's host draws (replay indices, REDQ
+    subset, action noise) in the reference's order, so the generators stay in step and every rank can gather every
+    member's batch locally.  The one exchange step: ``compute_backup_weights("sunrise")`` needs the target Q of ALL
+    members on a member's (s, a) (learning_utils.py:372-382) -- every rank evaluates ITS members' target critics on all E
+    batches, one all-gather (a SUM of disjointly filled (E x E x B) blocks) completes the table, each rank forms the
+    weights of its own members.  Actor and temperature updates are member-local: no exchange."""
+
+    def __init__(self, rank, world, ensemble_size):
+        assert 0 <= rank < world and ensemble_size >= world, "need at least one ensemble member per rank"
+        base, rem = divmod(ensemble_size, world)
+        sizes = [base + (1 if r < rem else 0) for r in range(world)]
+        self.rank, self.world, self.ensemble_size = rank, world, ensemble_size
+        self.lo = sum(sizes[:rank])
+        self.n_local = sizes[rank]
+        self.hi = self.lo + self.n_local
+
+    def owns(self, i):
+        return self.lo <= i < self.hi
+
+    def local(self, i):
+        """local index of global member i, None when another rank holds it"""
+        return i - self.lo if self.owns(i) else None
+
+
+def install_members(agent, target_agent, member_shard):
+    """mark both agents as holding the members [lo, hi) of the global ensemble (they are built with the LOCAL
+    ``ensemble_size``; the ``log_alphas`` / temperature optimizers handed to the update functions are the local members')"""
+    for ag in (agent, target_agent):
+        assert ag.ensemble_size == member_shard.n_local, "agent must be built with the LOCAL number of ensemble members"
+        assert shard_of(ag) is None, "members OR the critics of one member are sharded, not both"
+        ag.ssac_member_shard = member_shard
+
+
+def member_shard_of(agent):
+    return getattr(agent, "ssac_member_shard", None)
+
+
+def all_gather_blocks(t):
+    """every rank has filled ITS block of `t` and zeroed the rest: the SUM over ranks is the all-gather (one exchange
+    launch / one collective, rank-ordered sums of one non-zero term each: identical bits everywhere)"""
+    return all_reduce_sum(t)
+
+
 class Exchange:
     """the one-shot exchange of csrc/ssac_xchg.hip: IPC-mapped receive buffers on every rank, one recordable launch
     per reduction.  Built once per process after ``torch.distributed`` is up (the 64-byte IPC handles travel through

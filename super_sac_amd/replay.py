@@ -66,6 +66,10 @@ class PrioritySampler:
         self.sum_tree = np.zeros(2 * cap, dtype=np.float64)
         self.min_tree = np.full(2 * cap, np.inf, dtype=np.float64)
         self._max_priority = 1.0
+        # priority ** alpha: numpy's power, as the reference computes its leaves (replay.py:183-190).  Tests swap in an
+        # exactly rounded power to check the device trees bit for bit (numpy's own differs between its SIMD and scalar
+        # paths in the last bit; csrc/ssac_per.hip holds the correctly rounded value)
+        self.pow_fn = np.power
 
     def _assign(self, rows, values):
         rows = np.atleast_1d(np.asarray(rows, dtype=np.int64))
@@ -82,7 +86,7 @@ class PrioritySampler:
 
     def push_rows(self, rows, priorities=None):
         pr = self._max_priority if priorities is None else priorities
-        self._assign(rows, np.asarray(pr, dtype=np.float64) ** self.alpha)
+        self._assign(rows, self.pow_fn(np.asarray(pr, dtype=np.float64), self.alpha))
 
     def update_priorities(self, idxes, priorities, n_filled):
         priorities = np.asarray(priorities, dtype=np.float64)
@@ -90,7 +94,7 @@ class PrioritySampler:
         assert np.min(priorities) > 0
         assert np.min(idxes) >= 0
         assert np.max(idxes) < n_filled
-        self._assign(idxes, priorities ** self.alpha)
+        self._assign(idxes, self.pow_fn(priorities, self.alpha))
         self._max_priority = max(self._max_priority, float(np.max(priorities)))
 
     def load_state(self, sum_tree, min_tree, max_priority):
@@ -160,7 +164,9 @@ class LazyHost:
 
 
 class DevicePrioritySampler:
-    """PrioritySampler with the trees in HBM (csrc/ssac_per.hip): same layout, same arithmetic (float64), the draw
+    """PrioritySampler with the trees in HBM (csrc/ssac_per.hip): same layout, float64 trees whose leaves are
+    priority^alpha CORRECTLY ROUNDED in the precision the reference computes them in (float32 power for float32
+    priorities, float64 otherwise -- numpy's own power differs between its SIMD and scalar paths in the last bit); the draw
     still consumes numpy's GLOBAL generator on the host (replay.py:166) -- B uniforms travel up, nothing comes back.
     ``update_priorities`` takes device tensors (or numpy arrays) and returns without a synchronisation; the reference's
     assertions on the priorities (replay.py:183-187) are evaluated by the kernel and raised at the next call."""
@@ -172,7 +178,9 @@ class DevicePrioritySampler:
         self.cap, self.alpha, self.beta, self.device = cap, float(alpha), float(beta), device
         self.sum_dev = torch.zeros(2 * cap, dtype=torch.float64, device=device)
         self.min_dev = torch.full((2 * cap,), float("inf"), dtype=torch.float64, device=device)
-        self.max_dev = torch.ones(1, dtype=torch.float64, device=device)
+        # [0] the largest priority seen, [1] 1.0 once that maximum came from a float32 array (the reference's
+        # _max_priority is then an np.float32 and a row pushed at max priority takes a float32 power: csrc/ssac_per.hip)
+        self.max_dev = torch.tensor([1.0, 0.0], dtype=torch.float64, device=device)
         self.win = torch.full((cap,), -1, dtype=torch.int32, device=device)
         self.err = torch.zeros(16, dtype=torch.int32).pin_memory()
         self._u_ring, self._u_k, self._u_ev = [None] * 4, 0, [None] * 4
@@ -190,10 +198,16 @@ class DevicePrioritySampler:
     def _max_priority(self):
         return float(self.max_dev.cpu()[0])
 
-    def load_state(self, sum_tree, min_tree, max_priority):
+    @property
+    def _max_priority_is_f32(self):
+        return bool(self.max_dev.cpu()[1] != 0)
+
+    def load_state(self, sum_tree, min_tree, max_priority, max_is_f32=None):
         self.sum_dev.copy_(torch.from_numpy(np.ascontiguousarray(sum_tree, np.float64)))
         self.min_dev.copy_(torch.from_numpy(np.ascontiguousarray(min_tree, np.float64)))
-        self.max_dev.fill_(float(max_priority))
+        if max_is_f32 is None:   # (a reference-built buffer hands its _max_priority over as the object it is)
+            max_is_f32 = isinstance(max_priority, np.float32)
+        self.max_dev.copy_(torch.tensor([float(max_priority), 1.0 if max_is_f32 else 0.0], dtype=torch.float64))
 
     def _raise_pending(self):
         code = int(self.err[0])

@@ -203,14 +203,16 @@ class DrawPlayer:
         m.choice, m.draw_categorical = self._saved_choice, self._saved_cat
 
 
-def build_engine_agent(cfg, device, shard=None, foreign=False):
+def build_engine_agent(cfg, device, shard=None, foreign=False, members=None):
     """super_sac_amd.Agent holding the same seeded weights as the oracle agent (with `shard`: only
-    the critics [shard.lo, shard.hi) of the global ensemble).  foreign: an agent made of stand-ins that carry only
+    the critics [shard.lo, shard.hi) of the global ensemble; with `members` (parallel.MemberShard): only the ensemble
+    members [members.lo, members.hi)).  foreign: an agent made of stand-ins that carry only
     the REFERENCE classes' attributes (tests/foreign_agent.py), to be adopted by the update functions."""
     import super_sac_amd as ssa
     oa = _oracle_agent(cfg)
     lo = 0 if shard is None else shard.lo
     n_loc = cfg["N"] if shard is None else shard.n_local
+    m_lo, m_n = (0, cfg["E"]) if members is None else (members.lo, members.n_local)
     if foreign:
         import foreign_agent
         assert not cfg.get("pixels")
@@ -249,7 +251,7 @@ def build_engine_agent(cfg, device, shard=None, foreign=False):
         enc = ssa.nets.IdentityEncoder(cfg["obs"])
     ag = ssa.Agent(act_space_size=cfg["act"], encoder=enc,
                    actor_network_cls=actor_cls, critic_network_cls=critic_cls, discrete=cfg["discrete"],
-                   ensemble_size=cfg["E"], num_critics=n_loc, ucb_bonus=0.0,
+                   ensemble_size=m_n, num_critics=n_loc, ucb_bonus=0.0,
                    hidden_size=cfg["hidden"], auto_rescale_targets=cfg["popart"],
                    log_std_low=cfg["lo"], log_std_high=cfg["hi"])
     head = {"stochastic": "fc3", "deterministic": "out", "discrete": "act_p"}[cfg["actor"]]
@@ -259,10 +261,10 @@ def build_engine_agent(cfg, device, shard=None, foreign=False):
             for (wk, bk), nm in zip((("w1", "b1"), ("w2", "b2"), ("w3", "b3")), names):
                 getattr(mod, nm).weight.copy_(p[wk])
                 getattr(mod, nm).bias.copy_(p[bk])
-    for i in range(cfg["E"]):
-        load(ag.actors[i], oa.actors[i], ("fc1", "fc2", head))
+    for i in range(m_n):
+        load(ag.actors[i], oa.actors[m_lo + i], ("fc1", "fc2", head))
         for j in range(n_loc):
-            load(ag.critics[i].nets[j], oa.critics[i][lo + j], ("fc1", "fc2", "out"))
+            load(ag.critics[i].nets[j], oa.critics[m_lo + i][lo + j], ("fc1", "fc2", "out"))
     ag.to(device)
     if cfg["popart"]:
         for p in ag.popart:
@@ -271,7 +273,7 @@ def build_engine_agent(cfg, device, shard=None, foreign=False):
     return ag
 
 
-def run_engine(name, device="cuda", shard=None, foreign=False, precision="fp32", foreign_io=False):
+def run_engine(name, device="cuda", shard=None, foreign=False, precision="fp32", foreign_io=False, members=None):
     """`shard` (super_sac_amd.parallel.Shard): run as one rank of a critic-sharded job; the record
     then holds this rank's critics only (see slice_fixture).  foreign_io: the replay buffer and the augmenter are
     stand-ins carrying only the REFERENCE classes' attributes (tests/foreign_agent.py), adopted by the update functions."""
@@ -286,13 +288,19 @@ def run_engine(name, device="cuda", shard=None, foreign=False, precision="fp32",
     else:
         buf = ssa.replay.ReplayBuffer(cfg["cap"], device=device)
         buf.load_experience(*_buffers(cfg))
-    agent = build_engine_agent(cfg, device, shard, foreign=foreign)
+    agent = build_engine_agent(cfg, device, shard, foreign=foreign, members=members)
     if precision != "fp32":
         ssa.set_precision(agent, precision)  # (the deepcopy below inherits it)
     target = copy.deepcopy(agent)
     if shard is not None:
         ssa.parallel.install(agent, target, shard)
         fx = slice_fixture(fx, cfg, shard)
+    if members is not None:
+        # member-sharded rank (parallel.MemberShard): the agent holds EL of the E members; every member's recorded
+        # draws are still fed (the rank consumes the draws of the members it does not hold), records carry GLOBAL indices
+        ssa.parallel.install_members(agent, target, members)
+    EL = agent.ensemble_size
+    glob = (lambda i: i) if members is None else (lambda i: members.lo + i)
     NL = agent.num_critics
     copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=cfg["lr"],
                             weight_decay=0, betas=(0.9, 0.999))
@@ -302,7 +310,7 @@ def run_engine(name, device="cuda", shard=None, foreign=False, precision="fp32",
     eopt = torch.optim.Adam(agent.encoder.parameters(), lr=px["enc_lr"] if px else 1e-4, betas=(0.9, 0.999))
     init_alpha = max(cfg["init_alpha"], 1e-15)
     las, lopts = [], []
-    for _ in range(E):
+    for _ in range(EL):
         la = torch.Tensor([math.log(init_alpha)]).to(device)
         la.requires_grad = True
         las.append(la)
@@ -356,12 +364,12 @@ def run_engine(name, device="cuda", shard=None, foreign=False, precision="fp32",
                     encoder_lambda=cfg.get("encoder_lambda", 0),
                     aug_mix=aug_mix, discrete=cfg["discrete"], random_process=rproc, noise_clip=nclip,
                     per=False, update_priorities=False, dr3_coeff=0.0)
-                for i in range(E):
-                    assert np.array_equal(dicts[i]["priority_idxs"], fx[f"u{upd}_idx{i}"])
-                    rec[f"u{upd}_td{i}"] = dicts[i]["td_target"].cpu().numpy()
+                for i in range(EL):
+                    assert np.array_equal(dicts[i]["priority_idxs"], fx[f"u{upd}_idx{glob(i)}"])
+                    rec[f"u{upd}_td{glob(i)}"] = dicts[i]["td_target"].cpu().numpy()
                     if cfg["popart"]:
                         p = agent.popart[i]._read()
-                        rec[f"u{upd}_popart{i}"] = np.array([p.mu, p.nu, p.w, p.b, agent.popart[i].sigma, p.t])
+                        rec[f"u{upd}_popart{glob(i)}"] = np.array([p.mu, p.nu, p.w, p.b, agent.popart[i].sigma, p.t])
                 for key, val in logs.items():
                     rec[f"u{upd}_log:{key}"] = np.float64(float(val))
                 if int(fx[f"u{upd}_polyak"]):
@@ -399,12 +407,12 @@ def run_engine(name, device="cuda", shard=None, foreign=False, precision="fp32",
             not player.cats and not player.picks, "unconsumed recorded draws"
     finally:
         player.restore()
-    crit = [p for i in range(E) for j in range(NL) for p in agent.critics[i].nets[j].parameters()]
-    tcrit = [p for i in range(E) for j in range(NL) for p in target.critics[i].nets[j].parameters()]
-    act = [p for i in range(E) for p in agent.actors[i].parameters()]
+    crit = [p for i in range(EL) for j in range(NL) for p in agent.critics[i].nets[j].parameters()]
+    tcrit = [p for i in range(EL) for j in range(NL) for p in target.critics[i].nets[j].parameters()]
+    act = [p for i in range(EL) for p in agent.actors[i].parameters()]
     grp = copt._ssac_adam
     m_list, v_list = [], []
-    for i in range(E):
+    for i in range(EL):
         ar = agent.critics[i].arena(device)
         m, v = grp.moments_for(("critic", i), ar.params)
         for j in range(NL):
@@ -450,6 +458,57 @@ def slice_fixture(fx, cfg, shard):
     for key in list(out):
         if "_log:losses/critic" in key or "_log:losses/last_member" in key or "_log:gradients/" in key:
             del out[key]
+    return out
+
+
+def slice_fixture_members(fx, cfg, ms):
+    """the part of a full-dump fixture that a member-sharded rank (parallel.MemberShard) reproduces: TD targets, TD and
+    temperature logs, parameters, moments and temperatures of ITS members -- under their GLOBAL indices.  The overall
+    critic loss / TD error / actor loss are per-rank partial sums; the bellman-weight statistics are the last OWNED
+    member's (the fixture's when this rank holds the last member); the gradient-norm logs are the picked member's when
+    this rank holds it."""
+    E, N = cfg["E"], cfg["N"]
+    in_dim = cfg["obs"] if cfg["discrete"] else cfg["obs"] + cfg["act"]
+    out_dim = cfg["act"] if cfg["discrete"] else 1
+    H = cfg["hidden"]
+    per_c = (H * in_dim + H + H * H + H + out_dim * H + out_dim) * N
+    a_out = cfg["act"] if cfg["actor"] != "stochastic" else 2 * cfg["act"]
+    per_a = H * cfg["obs"] + H + H * H + H + a_out * H + a_out
+    perfp = sum(min(48, n) for n in [H * in_dim, H, H * H, H, out_dim * H, out_dim]) * N
+    out = {}
+    owned = range(ms.lo, ms.hi)
+    for key, val in fx.items():
+        m = re.fullmatch(r"([ual]\d+)_(td|popart)(\d+)", key)
+        if m:
+            if int(m.group(3)) in owned:
+                out[key] = val
+            continue
+        m = re.fullmatch(r"[ual]\d+_log:(td_targets/\w+?|losses/alpha_loss|alphas/alpha)_(\d+)", key)
+        if m:
+            if int(m.group(2)) in owned:
+                out[key] = val
+            continue
+        if "_log:bellman_weights/" in key:
+            if ms.owns(E - 1):
+                out[key] = val
+            continue
+        if "_log:gradients/critic_random_grad" in key or "_log:gradients/random_actor_online_grad" in key:
+            pick = int(fx[key.split("_log:")[0] + "_gpick"])
+            if ms.owns(pick):
+                out[key] = val
+            continue
+        if "_log:losses/" in key:
+            continue   # (sums over members: partial on a rank)
+        if key in ("final_critic", "final_target_critic"):
+            out[key] = val[ms.lo * per_c: ms.hi * per_c]
+        elif key == "final_actor":
+            out[key] = val[ms.lo * per_a: ms.hi * per_a]
+        elif key in ("finalfp_critic_m", "finalfp_critic_v"):
+            out[key] = val[ms.lo * perfp: ms.hi * perfp]
+        elif key == "final_log_alpha":
+            out[key] = val[ms.lo: ms.hi]
+        else:
+            out[key] = val
     return out
 
 

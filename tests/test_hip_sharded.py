@@ -215,6 +215,49 @@ def test_owners_only_exchange_survives_a_stalled_non_owner(tmp_path):
     assert not any(v[2]["detect_wrong_but_finite"]), v[2]
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# SUNRISE member sharding (parallel.MemberShard, SURVEY 8(e) "SUNRISE variant"): the ensemble MEMBERS over the ranks
+# ---------------------------------------------------------------------------------------------------------------
+def _member_main(rank, world, port, out_dir, name, one_shot):
+    sys.path.insert(0, HERE)
+    import case_runner
+    import synth
+    import torch.distributed as dist
+    from super_sac_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    if one_shot:
+        assert parallel.enable_one_shot(torch.device("cuda:0")) is not None
+    cfg = synth.CASES[name]
+    ms = parallel.MemberShard(rank, world, cfg["E"])
+    rec = case_runner.run_engine(name, device="cuda:0", members=ms)
+    fx = case_runner.slice_fixture_members(case_runner.load_fixture(name), cfg, ms)
+    assert any(k.endswith(f"_td{ms.lo}") for k in fx) and not any(k.endswith(f"_td{(ms.hi) % cfg['E']}") for k in fx
+                                                                  if not ms.owns(ms.hi % cfg["E"]))
+    worst = case_runner.compare(rec, fx, who=f"hip-member-sharded[{name}, rank {rank}/{world}]")
+    assert not parallel.exchange_failed()
+    np.savez(os.path.join(out_dir, f"mok{rank}.npz"), **{k: np.float64(v) for k, v in worst.items()})
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("name,world,one_shot", [("sunrise", 2, False), ("sunrise", 3, True), ("sunrise_discrete", 2, True),
+                                                 ("sunrise_discrete", 3, False)],
+                         ids=["sunrise-2-collective", "sunrise-3-one-shot", "discrete-2-one-shot", "discrete-3-collective"])
+def test_member_sharded_sunrise_matches_reference(tmp_path, name, world, one_shot):
+    """E = 3 members over 2 ranks (2 + 1) and over 3 ranks (one each), the ranks sharing the one device: every rank makes
+    every member's host draws, gathers all three batches, scores them with ITS members' target critics; the all-gather of
+    the (batch x member x row) table -- through gloo and through the one-shot exchange kernel -- gives each rank the
+    SUNRISE weights of its own members (learning_utils.py:372-382).  Each rank's TD targets, TD / temperature logs, critic,
+    target, actor parameters, Adam moments and temperatures land on the REFERENCE fixture's slices for its members;
+    sunrise_discrete also clips the critics' and actors' gradients by the norm over ALL members (one scalar all-reduce)."""
+    port = 31300 + (os.getpid() % 2000) + 11 * world + int(one_shot)
+    mp.spawn(_member_main, args=(world, port, str(tmp_path), name, one_shot), nprocs=world, join=True)
+    assert all((tmp_path / f"mok{r}.npz").exists() for r in range(world))
+
+
 def _humanoid_main(rank, world, port, out_dir):
     """BASELINE config 5's shape (obs 376 / act 17 / N 16 / B 512), critics sharded over two ranks that share this
     GPU: critic updates replayed from ONE launch list per rank (the exchange is a recorded launch), Polyak, actor and

@@ -124,3 +124,103 @@ def test_sharded_critic_updates_equal_unsharded(tmp_path, world):
         assert np.allclose(got["td"], td_ref, atol=1e-6), "TD targets after the MIN all-reduce"
         want = np.concatenate(params_ref[int(got["lo"]):int(got["hi"])])
         assert np.max(np.abs(got["params"] - want)) < 1e-6, f"rank {rank}: owned critics diverged"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SUNRISE member sharding (parallel.MemberShard): the members of the ensemble over the ranks
+# ---------------------------------------------------------------------------------------------------------------
+def test_member_shard_ownership_map():
+    from super_sac_amd.parallel import MemberShard
+    for e, w in ((5, 1), (5, 2), (5, 4), (5, 5), (3, 2), (8, 8)):
+        owned = []
+        for r in range(w):
+            m = MemberShard(r, w, e)
+            owned += list(range(m.lo, m.hi))
+            assert m.n_local >= 1 and m.local(m.lo) == 0 and m.local(m.hi - 1) == m.n_local - 1
+            assert m.local(m.hi % e) is None or w == 1
+        assert owned == list(range(e)), "every member has exactly one owner"
+    with pytest.raises(AssertionError):
+        MemberShard(0, 4, 3)
+
+
+def _member_sharded_sunrise_sequence(rank, world, port, out_dir):
+    """the member-sharded critic update with the arithmetic done by the oracle: what is under test is the protocol --
+    every rank gathers every member's batch, scores all of them with ITS members' target critics, the all-gather
+    (parallel.all_gather_blocks over a real collective) completes the table, the weights of the owned members are formed
+    from it, the loss is divided by the GLOBAL E * N"""
+    sys.path.insert(0, HERE)
+    import case_runner  # noqa: F401
+    import ssac_oracle as orc
+    import synth
+    from super_sac_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    cfg = synth.CASES["sunrise"]
+    fx = case_runner.load_fixture("sunrise")
+    E, N, B = cfg["E"], cfg["N"], cfg["B"]
+    ms = parallel.MemberShard(rank, world, E)
+    full = case_runner._oracle_agent(cfg).requires_grad_(True)
+    target = full.clone()
+    buf = orc.ReplayOracle(cfg["cap"])
+    buf.load_experience(*case_runner._buffers(cfg))
+    mine = [p for i in range(ms.lo, ms.hi) for p in full.critics[i]]
+    opt = orc.AdamOracle([p[k] for p in mine for k in orc.MLP_KEYS], lr=cfg["lr"])
+    la = torch.tensor([np.log(cfg["init_alpha"])], dtype=torch.float32)
+    tds, wts = [], []
+    for upd in range(int(fx["n_updates"])):
+        batches = [buf.gather(fx[f"u{upd}_idx{i}"]) for i in range(E)]   # same index draws on every rank
+        table = torch.zeros(E, E, B)
+        with torch.no_grad():
+            for i, (o, a, r, o1, d) in enumerate(batches):
+                for k in range(ms.lo, ms.hi):
+                    table[i, k] = orc.ensemble_q(target.critics[k], o["obs"], a).view(-1)
+        parallel.all_gather_blocks(table)   # the exchange step
+        loss = 0.0
+        for i in range(ms.lo, ms.hi):
+            o, a, r, o1, d = batches[i]
+            with torch.no_grad():
+                w = torch.sigmoid(-table[i].std(0).view(B, 1) * cfg["temp"]) + 0.5
+                a1, logp = orc.tanh_normal_sample(orc.mlp3(full.actors[i], o1["obs"])[0], cfg["lo"], cfg["hi"],
+                                                  torch.from_numpy(fx[f"u{upd}_eps{i}"]))
+                ids = [int(v) for v in fx[f"u{upd}_subset{i}"]]
+                q1 = orc.ensemble_q(target.critics[i], o1["obs"], a1, subset_ids=ids)
+                td = r + cfg["gamma"] * (1.0 - d) * (q1 - la.exp() * logp)
+            tds.append(td.numpy()); wts.append(w.numpy())
+            for p in full.critics[i]:
+                loss = loss + (w * (td - orc.critic_q(p, o["obs"], a)) ** 2).mean()
+        loss = loss / (E * N)   # GLOBAL ensemble in the denominator (learning.py:112)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if int(fx[f"u{upd}_polyak"]):
+            for i in range(ms.lo, ms.hi):
+                orc.soft_update([p[k] for p in target.critics[i] for k in orc.MLP_KEYS],
+                                [p[k] for p in full.critics[i] for k in orc.MLP_KEYS], cfg["tau"])
+    np.savez(os.path.join(out_dir, f"mrank{rank}.npz"), td=np.stack(tds), w=np.stack(wts), lo=ms.lo, hi=ms.hi,
+             params=np.concatenate([p[k].detach().numpy().ravel() for p in mine for k in orc.MLP_KEYS]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_member_sharded_sunrise_updates_equal_reference_fixture(tmp_path, world):
+    import case_runner
+    import synth
+    port = 29650 + (os.getpid() % 2000) + world
+    mp.spawn(_member_sharded_sunrise_sequence, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    cfg = synth.CASES["sunrise"]
+    fx = case_runner.load_fixture("sunrise")
+    E, N = cfg["E"], cfg["N"]
+    per_c = fx["final_critic"].size // E
+    for rank in range(world):
+        got = np.load(tmp_path / f"mrank{rank}.npz")
+        lo, hi = int(got["lo"]), int(got["hi"])
+        k = 0
+        for upd in range(int(fx["n_updates"])):
+            for i in range(lo, hi):
+                assert np.allclose(got["td"][k], fx[f"u{upd}_td{i}"], atol=2e-5), (rank, upd, i)
+                assert np.all(got["w"][k] >= 0.5) and np.all(got["w"][k] <= 1.0)
+                k += 1
+        want = fx["final_critic"][lo * per_c: hi * per_c]
+        assert np.max(np.abs(got["params"] - want)) < 2e-6, f"rank {rank}: its members' critics diverged from the reference"

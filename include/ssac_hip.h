@@ -629,9 +629,9 @@ int ssac_debug_timeline(long long *dev_buf);
 int ssac_gemm_lean(int on);
 /* Form of the merged weight-gradient launch (ssac_mlp_wgrad_all / _scaled / _lossfold / _fc12): 0 = automatic, 1 = 64 x 64
  * tiles with the K loop staged through LDS, 2 = the LATENCY form whenever the shapes allow: 32 x 32 tiles whose 8 waves split
- * the batch (K) and load their MFMA operands straight from memory -- 4x the workgroups, each ~5x shorter; the automatic
- * choice takes it while all of its workgroups are resident at once (<= 512), i.e. for the under-filled launches of small
- * ensembles (SAC's 2 critics, a rank that holds 2-4 of 16, the actor).  Same sums in another order (fp32 rounding). */
+ * the batch (K) and buffer-load their MFMA operands straight from memory -- 4x the workgroups, each ~4x shorter; the
+ * automatic choice takes it while all of its workgroups are resident at once (<= 512), i.e. for the under-filled launches of
+ * small ensembles (SAC's 2 critics, a rank that holds 2-4 of 16, the actor).  Same sums in another order (fp32 rounding). */
 int ssac_wgrad_variant(int variant);
 /* row tiles the fused critic launch uses for (n_rows, n_nets): the `partials` buffer holds
  * n_nets * tiles * 2 floats.  ssac_fused_tile_rows(0|16|17|32) overrides the automatic choice (17 = 16 rows with a

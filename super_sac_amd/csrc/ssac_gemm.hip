@@ -872,24 +872,34 @@ constexpr int S_PART = SW * ST * ST;    // floats: the partial tiles
 constexpr int S_RED = SW * ST + 2 * SW; // bias partials [SW][32] + gradient-norm partials [SW] + scratch
 // head workgroups reuse the front of the LDS block: 2 * GROUPS * COLS + GROUPS floats (ssac_head_wgrad.h) <= S_PART
 static_assert(2 * S_HEAD_GROUPS * S_HEAD_COLS + S_HEAD_GROUPS <= S_PART, "head scratch must fit the partial-tile area");
+// (the 64 x 32 form runs 32-column head workgroups of half as many row groups: the same scratch)
 
 struct SmallFrag { float a[16], b[16]; };
 
-template <int EPI>
+// MB = 32-row blocks of the tile: 1 -> a 32 x 32 tile whose 8 waves split K eight ways (the only form launched).  MB = 2 -- a
+// 64 x 32 tile, two row blocks x four K-groups -- was measured slower than the 64 x 64 kernel wherever the 32 x 32 form does
+// not fit (see wgrad_merged) and is not instantiated.
+template <int EPI, int MB>
 __device__ __forceinline__ void wgrad_small_body(const GemmArgs &g, float *lds, int bx, int by, int bz, float *late_rs,
                                                  const LossFoldArgs &lf, int lf_mode, const LogFoldArgs &fold, int &last,
                                                  const LateTau &lt) {
+    constexpr int KW = SW / MB;   // K-split ways
+    constexpr int NE = 2 * MB;    // tile elements finished per thread
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#define SSTAMP(i) do { if (g.dbg && bx == 0 && by == 0 && bz == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    SSTAMP(0);
     const int li = lane & 31, lh = lane >> 5;
-    const int e = bz, m0 = by * ST, n0 = bx * ST;
+    const int mb = wave / KW, kw = wave - mb * KW;   // (uniform) this wave's row block and K-group
+    const int e = bz, mt0 = by * (ST * MB), m0 = mt0 + mb * ST, n0 = bx * ST;
     float *part = lds, *red = lds + S_PART;
     const float *A = g.A + batch_off(g.ids, g.idsA, e, g.sA);
     const float *B = g.B + batch_off(g.ids, g.idsB, e, g.sB);
     const int64_t coff = batch_off(g.ids, g.idsC, e, g.sC);
     const int K = g.K;
-    // rows / columns beyond the matrix read the tile's first row / column (always valid): they only reach accumulator
-    // rows / columns beyond the matrix, which the epilogue guards.  Uniform bases + 32-bit lane offsets (small_ok).
+    // rows / columns beyond the matrix read the block's first row / column (always valid -- a row block that lies
+    // entirely beyond the matrix reads block 0's): they only reach accumulator rows / columns the epilogue guards
     const bool mok = (m0 + li) < g.M, nok = (n0 + li) < g.N;
+    const int m0c = m0 < g.M ? m0 : mt0;
     // Operand loads are BUFFER loads: one descriptor per operand in SGPRs (built from wave-uniform values only), the lane's
     // byte offset in ONE VGPR, the row of MFMA step t as a scalar offset -- the 32 loads of a chunk need no address
     // register each (as flat loads with 64-bit lane addresses the two register sets + 32 address pairs did not fit 128
@@ -900,26 +910,24 @@ __device__ __forceinline__ void wgrad_small_body(const GemmArgs &g, float *lds, 
         return (void *)(uintptr_t)(((uint64_t)hi << 32) | lo);
     };
     const uint32_t lda = __builtin_amdgcn_readfirstlane((uint32_t)g.lda), ldb = __builtin_amdgcn_readfirstlane((uint32_t)g.ldb);
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(A + m0), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(A + m0c), 0, 0x7ffffffc, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(B + n0), 0, 0x7ffffffc, 0x00020000);
     const int alane = 4 * (int)((mok ? (uint32_t)li : 0u) + (uint32_t)lh * lda), blane = 4 * (int)((nok ? (uint32_t)li : 0u) + (uint32_t)lh * ldb);
     const bool sign = g.a_sign_w != nullptr;
-    const float sw = sign ? g.a_sign_w[(int64_t)e * g.M + (mok ? m0 + li : m0)] : 0.0f;
+    const float sw = sign ? g.a_sign_w[(int64_t)e * g.M + (mok ? m0 + li : m0c)] : 0.0f;
     const bool ragged = (K & 31) != 0;   // (uniform; K is even: small_ok)
     const float *rscale = (g.rowscale && !late_rs) ? g.rowscale + (int64_t)e * g.sRow : nullptr;
     const bool want_bias = bx == 0 && !g.no_bias;
     const int nchunks = (K + 31) >> 5;
 
-    // ---- this thread finishes 2 tile elements (idx = tid, tid + 512: row idx >> 5, column idx & 31)
+    // ---- this thread finishes NE tile elements: idx = tid + 512 j -> row idx >> 5 (of the 32 MB), column idx & 31
     const bool pol = g.tw != nullptr && (!lt.on || lt.bits != 0u);
     const float tau = lt.on ? __uint_as_float(lt.bits) : g.tau;
     auto elem = [&](int j, int64_t &c) {
         const int idx = tid + j * STHREADS, row = idx >> 5, col = idx & 31;
-        c = coff + (int64_t)(m0 + row) * g.ldc + n0 + col;
-        return (m0 + row) < g.M && (n0 + col) < g.N;
+        c = coff + (int64_t)(mt0 + row) * g.ldc + n0 + col;
+        return (mt0 + row) < g.M && (n0 + col) < g.N;
     };
-    int64_t ci0, ci1;
-    const bool ok0 = elem(0, ci0), ok1 = elem(1, ci1);
     LossFoldRegs lfr;
     if (lf_mode == 1) loss_fold_issue(lf, e, lfr);
     auto load = [&](SmallFrag &f, int c) {
@@ -936,10 +944,11 @@ __device__ __forceinline__ void wgrad_small_body(const GemmArgs &g, float *lds, 
         }
     };
     SmallFrag f0, f1;
-    if (wave < nchunks) load(f0, wave);
+    if (kw < nchunks) load(f0, kw);
     if (lf_mode == 1) { loss_fold_finish(lf, e, lfr, late_rs); lds_barrier(); }
     else if (lf_mode == 2) { loss_fold_table(lf, e, late_rs, true, late_rs + lf.n_rows, false); __syncthreads(); }
 
+    SSTAMP(1);   // (loss-fold table ready)
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
@@ -985,30 +994,49 @@ __device__ __forceinline__ void wgrad_small_body(const GemmArgs &g, float *lds, 
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[8 * h + t], f.b[8 * h + t], acc, 0, 0, 0);
         }
     };
-    int c = wave;
-    bool have1 = c + SW < nchunks;
-    if (have1) load(f1, c + SW);
-    // The optimizer state of the 2 elements is requested HERE: it has not been touched since the last update and comes
-    // from HBM (~2 us) -- behind the K loop that round trip was a phase of its own in every workgroup (10.4 us per fc2
-    // tile at B 512, of which the operands, the 32 MFMAs per wave and the exchange through LDS explain 6); in front of
+    int c = kw;
+    bool have1 = c + KW < nchunks;
+    if (have1) load(f1, c + KW);
+    // The optimizer state of the thread's elements is requested HERE: it has not been touched since the last update and
+    // comes from HBM (~2 us) -- behind the K loop that round trip was a phase of its own in every workgroup; in front of
     // the operand loads it would hold THEM back (vector memory returns in order).  Behind the first two chunks' loads it
     // travels while they multiply.
-    float pv0 = 0.f, mv0 = 0.f, vv0 = 0.f, tv0 = 0.f, pv1 = 0.f, mv1 = 0.f, vv1 = 0.f, tv1 = 0.f;
-    if (EPI == EPI_ADAM) {
-        const int64_t a0 = ok0 ? ci0 : coff, a1 = ok1 ? ci1 : coff;
-        pv0 = g.C[a0]; mv0 = g.am[a0]; vv0 = g.av[a0];
-        pv1 = g.C[a1]; mv1 = g.am[a1]; vv1 = g.av[a1];
-        if (pol) { tv0 = g.tw[a0]; tv1 = g.tw[a1]; }
-    }
-    for (; c + SW < nchunks; c += 2 * SW) {   // two register sets: chunk c + SW loads while chunk c multiplies
-        if (!have1) load(f1, c + SW);
+    // (p, m, v here; the Polyak target -- every other update -- behind the K loop, under the exchange through LDS: with it
+    // the 64 x 32 form's four elements per thread no longer fit 128 registers beside the two operand sets)
+    float pv[NE], mv[NE], vv[NE], tv[NE];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) { pv[j] = 0.f; mv[j] = 0.f; vv[j] = 0.f; tv[j] = 0.f; }
+    auto opt_load = [&]() {
+        if (EPI != EPI_ADAM) return;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            int64_t cj;
+            const int64_t a_ = elem(j, cj) ? cj : coff;
+            pv[j] = g.C[a_]; mv[j] = g.am[a_]; vv[j] = g.av[a_];
+        }
+    };
+    // (the 64 x 32 form holds four elements per thread: beside the two operand sets their state does not fit 128
+    // registers, so it is requested behind the K loop and travels under the exchange through LDS)
+    constexpr bool EARLY = MB == 1;
+    if (EARLY) opt_load();
+    for (; c + KW < nchunks; c += 2 * KW) {   // two register sets: chunk c + KW loads while chunk c multiplies
+        if (!have1) load(f1, c + KW);
         have1 = false;
         consume(f0, c);
-        if (c + 2 * SW < nchunks) load(f0, c + 2 * SW);
-        consume(f1, c + SW);
+        if (c + 2 * KW < nchunks) load(f0, c + 2 * KW);
+        consume(f1, c + KW);
     }
     if (c < nchunks) consume(f0, c);   // (an odd number of chunks for this wave)
+    if (!EARLY) opt_load();
 
+    SSTAMP(2);   // (K loop done)
+    if (EPI == EPI_ADAM && pol) {
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            int64_t cj;
+            tv[j] = g.tw[elem(j, cj) ? cj : coff];
+        }
+    }
     // ---- the 8 partial tiles meet in LDS; C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8 (r>>2) + 4 (lane>>5)
     float *mine = part + wave * (ST * ST);
 #pragma unroll
@@ -1018,26 +1046,37 @@ __device__ __forceinline__ void wgrad_small_body(const GemmArgs &g, float *lds, 
         if (lh == 0) red[wave * ST + li] = bias_acc;
     }
     lds_barrier();
-    float gval0 = part[tid], gval1 = part[tid + STHREADS];
+    SSTAMP(3);   // (partials exchanged)
+    float gval[NE];
+    int64_t ci[NE];
+    bool ok[NE];
 #pragma unroll
-    for (int w = 1; w < SW; ++w) {
-        gval0 += part[w * (ST * ST) + tid];
-        gval1 += part[w * (ST * ST) + tid + STHREADS];
+    for (int j = 0; j < NE; ++j) {
+        ok[j] = elem(j, ci[j]);
+        // element idx = tid + 512 j lies in row block idx >> 10 (its K-groups' partials are summed in group order)
+        const int idx = tid + j * STHREADS, blk = idx >> 10, off = idx & 1023;
+        float sum = part[(blk * KW) * (ST * ST) + off];
+#pragma unroll
+        for (int w = 1; w < KW; ++w) sum += part[(blk * KW + w) * (ST * ST) + off];
+        gval[j] = sum;
     }
-    const int gm = m0 + tid;
-    const bool bias_thr = want_bias && tid < ST && gm < g.M;
+    const int gm = mt0 + tid;
+    const bool bias_thr = want_bias && tid < ST * MB && gm < g.M;
     const int64_t bi = (EPI == EPI_GRAD && g.sGb) ? (int64_t)e * g.sGb + gm : coff + gm;
     float bsum = 0.0f, bpv = 0.0f, bmv = 0.0f, bvv = 0.0f, btv = 0.0f;
     if (bias_thr) {
-        bsum = red[tid];
+        const int blk = tid >> 5, r_ = tid & 31;
+        bsum = red[(blk * KW) * ST + r_];
 #pragma unroll
-        for (int w = 1; w < SW; ++w) bsum += red[w * ST + tid];
+        for (int w = 1; w < KW; ++w) bsum += red[(blk * KW + w) * ST + r_];
         if (EPI == EPI_ADAM) { bpv = g.pb[bi]; bmv = g.bm[bi]; bvv = g.bv[bi]; btv = (pol && g.tb) ? g.tb[bi] : 0.0f; }
     }
     // ---- gradient-norm partial first (it needs the gradients only): with the logs folded in, the arrival ticket is
     //      drawn before -- not behind -- the optimizer stores
     if (g.sumsq) {
-        float ss = (ok0 ? gval0 * gval0 : 0.0f) + (ok1 ? gval1 * gval1 : 0.0f);
+        float ss = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) ss += ok[j] ? gval[j] * gval[j] : 0.0f;
         if (bias_thr) ss += bsum * bsum;
         ss = wave_sum(ss);
         float *red2 = red + SW * ST;
@@ -1047,37 +1086,41 @@ __device__ __forceinline__ void wgrad_small_body(const GemmArgs &g, float *lds, 
             float tot = 0.0f;
 #pragma unroll
             for (int w = 0; w < SW; ++w) tot += red2[w];
-            __hip_atomic_store(g.sumsq + (int64_t)e * g.sumsq_stride + by * ((g.N + ST - 1) / ST) + bx, tot, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+            // one slot per 32 x 32 tile (ssac_wgrad_tiles): the first of this workgroup's row blocks takes the sum
+            const int gx = (g.N + ST - 1) / ST, gy = (g.M + ST - 1) / ST;
+            float *slot = g.sumsq + (int64_t)e * g.sumsq_stride + (by * MB) * gx + bx;
+            __hip_atomic_store(slot, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (MB == 2 && by * MB + 1 < gy) __hip_atomic_store(slot + gx, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (fold.done) last = log_fold_arrive(fold, gridDim.x) ? 1 : 0;
         }
     }
+    SSTAMP(4);   // (gradient-norm partial out)
     if (EPI == EPI_GRAD) {
-        if (ok0) g.gw[ci0] = gval0;
-        if (ok1) g.gw[ci1] = gval1;
+#pragma unroll
+        for (int j = 0; j < NE; ++j)
+            if (ok[j]) g.gw[ci[j]] = gval[j];
         if (bias_thr) g.gb[bi] = bsum;
         return;
     }
     const ssac_adam_ctl ctl = *g.ctl;
-    if (ok0) {
-        const float pn = adam_elem(pv0, gval0, mv0, vv0, ctl);
-        g.am[ci0] = mv0; g.av[ci0] = vv0; g.C[ci0] = pn;
-        if (pol) g.tw[ci0] = tv0 * (1.0f - tau) + pn * tau;
-    }
-    if (ok1) {
-        const float pn = adam_elem(pv1, gval1, mv1, vv1, ctl);
-        g.am[ci1] = mv1; g.av[ci1] = vv1; g.C[ci1] = pn;
-        if (pol) g.tw[ci1] = tv1 * (1.0f - tau) + pn * tau;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        if (!ok[j]) continue;
+        const float pn = adam_elem(pv[j], gval[j], mv[j], vv[j], ctl);
+        g.am[ci[j]] = mv[j]; g.av[ci[j]] = vv[j]; g.C[ci[j]] = pn;
+        if (pol) g.tw[ci[j]] = tv[j] * (1.0f - tau) + pn * tau;
     }
     if (bias_thr) {
         const float pn = adam_elem(bpv, bsum, bmv, bvv, ctl);
         g.bm[bi] = bmv; g.bv[bi] = bvv; g.pb[bi] = pn;
         if (pol && g.tb) g.tb[bi] = btv * (1.0f - tau) + pn * tau;
     }
+    SSTAMP(5);
+#undef SSTAMP
 }
 
-// the merged launch in its latency form: [fc2 tiles | fc1 tiles | head workgroups (16 columns each) | TD workgroup]
-template <int EPI>
+// the merged launch in its latency form: [fc2 tiles | fc1 tiles | head workgroups (16 MB columns each) | TD workgroup]
+template <int EPI, int MB>
 __global__ __launch_bounds__(STHREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void wgrad_small_pair_kernel(GemmPair p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1120,7 +1163,7 @@ void wgrad_small_pair_kernel(GemmPair p) {
             hpol = hpol && lt.bits != 0u;
             htau = __uint_as_float(lt.bits);
         }
-        head_wgrad_body<S_HEAD_GROUPS, S_HEAD_COLS>(p.head, lds, L % p.head_grid_x, e, fold ? tab : nullptr, hpol, htau);
+        head_wgrad_body<S_HEAD_GROUPS / MB, S_HEAD_COLS * MB>(p.head, lds, L % p.head_grid_x, e, fold ? tab : nullptr, hpol, htau);
     } else {
         const bool first = bid < p.tiles0;
         const GemmArgs &g = first ? p.g0 : p.g1;
@@ -1128,7 +1171,7 @@ void wgrad_small_pair_kernel(GemmPair p) {
         const int per = g.grid_x * g.grid_y;
         const int bz = L / per, rem = L - bz * per;
         const bool stats = p.lf_nets == 0 && !p.stats_in_head && first && rem == 0;
-        wgrad_small_body<EPI>(g, lds, rem % g.grid_x, rem / g.grid_x, bz, fold ? tab : nullptr, p.lf,
+        wgrad_small_body<EPI, MB>(g, lds, rem % g.grid_x, rem / g.grid_x, bz, fold ? tab : nullptr, p.lf,
                               fold ? (stats ? 2 : 1) : 0, p.fold, last, lt);
         drawn = true;
     }
@@ -1147,8 +1190,8 @@ void wgrad_small_pair_kernel(GemmPair p) {
     }
 }
 
-// 0 = automatic (the latency form when the whole launch fits one resident round of its small workgroups and the 64 x 64
-// form would leave most of the chip idle), 1 = always 64 x 64 tiles, 2 = always 32 x 32 tiles (ssac_wgrad_variant)
+// 0 = automatic (the latency form when the whole launch fits one resident round of its small workgroups), 1 = always 64 x 64
+// tiles, 2 = 32 x 32 tiles whenever the shapes allow (ssac_wgrad_variant)
 int g_wgrad_variant = 0;
 int g_wgrad_small_max = 512;   // automatic choice: the latency form up to this many workgroups (2 resident per CU)
 
@@ -1157,22 +1200,22 @@ bool small_ok(const GemmArgs &g) {
            (int64_t)(g.K + 64) * g.ldb < (1LL << 28);   // (byte offsets of the buffer loads stay below 2^31)
 }
 
-template <int EPI>
+template <int EPI, int MB>
 int launch_pair_small(GemmPair &p, int batch, hipStream_t st) {
     static bool attr_set = false;
     const size_t lds = sizeof(float) * (S_PART + S_RED + (p.lf.q ? p.lf.n_rows + 2 * SW + 16 : 0));
     if (lds > 150 * 1024) return ssac_fail("wgrad_small_pair: the folded loss table does not fit LDS");
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)wgrad_small_pair_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void *)wgrad_small_pair_kernel<EPI, MB>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 150 * 1024) != hipSuccess)
             return ssac_fail("wgrad_small_pair: cannot raise the dynamic LDS limit");
         attr_set = true;
     }
     for (GemmArgs *g : {&p.g0, &p.g1}) {
         g->grid_x = (g->N + ST - 1) / ST;
-        g->grid_y = (g->M + ST - 1) / ST;
+        g->grid_y = (g->M + ST * MB - 1) / (ST * MB);
     }
-    if (p.head_grid_x > 0) p.head_grid_x = (p.head.hidden + S_HEAD_COLS - 1) / S_HEAD_COLS;
+    if (p.head_grid_x > 0) p.head_grid_x = (p.head.hidden + S_HEAD_COLS * MB - 1) / (S_HEAD_COLS * MB);
     p.xcd = (g_ssac_xcd >> 1) & 1;
     p.tl = g_ssac_timeline;
     p.tiles0 = p.g0.grid_x * p.g0.grid_y * batch;
@@ -1183,7 +1226,7 @@ int launch_pair_small(GemmPair &p, int batch, hipStream_t st) {
     p.stats_in_head = (p.lf.q && p.head_total > 0) ? 1 : 0;
     p.lf_nets = (!p.stats_in_head && p.td_wg) ? batch : 0;
     const int total = p.tiles01 + p.head_total + p.td_wg;
-    SSAC_LAUNCH((wgrad_small_pair_kernel<EPI>), dim3(total), dim3(STHREADS), lds, st, p);
+    SSAC_LAUNCH((wgrad_small_pair_kernel<EPI, MB>), dim3(total), dim3(STHREADS), lds, st, p);
     return ssac_check_launch("wgrad_small_pair");
 }
 
@@ -1583,13 +1626,16 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
     const int tiles = (p.g0.grid_x * p.g0.grid_y + p.g1.grid_x * p.g1.grid_y) * n_sel;
     const int nchunks = (n_rows + BK - 1) / BK;
     {
-        // latency form (32 x 32 tiles, wgrad_small_pair_kernel): when all of its workgroups are resident at once (two
-        // per CU) -- then the launch lasts one short workgroup instead of one long one
+        // latency form (wgrad_small_pair_kernel, 32 x 32 tiles): taken while ALL of its workgroups are resident at once
+        // (two per CU) -- the launch then lasts one short workgroup instead of one long one.  (A 64 x 32 form of the same
+        // body -- half the workgroups, for launches too big for this one -- was built and measured: 57.2 vs 53.0 us per
+        // update at N 10, 63.7 vs 59.6 at N 8: its 256 dword loads per lane make the address unit a second bottleneck
+        // beside the matrix pipe.  Dropped; profiles/r4_latency_forms.md.)
         auto t32 = [](const GemmArgs &g) { return ((g.M + ST - 1) / ST) * ((g.N + ST - 1) / ST); };
         const int small_wgs = (t32(p.g0) + t32(p.g1) + (p.head_grid_x > 0 ? (H + S_HEAD_COLS - 1) / S_HEAD_COLS : 0)) * n_sel + 1;
         const bool can = small_ok(p.g0) && small_ok(p.g1) && nets->out_dim <= 16;
         if (can && (g_wgrad_variant == 2 || (g_wgrad_variant == 0 && small_wgs <= g_wgrad_small_max)))
-            return grads ? launch_pair_small<EPI_GRAD>(p, n_sel, st) : launch_pair_small<EPI_ADAM>(p, n_sel, st);
+            return grads ? launch_pair_small<EPI_GRAD, 1>(p, n_sel, st) : launch_pair_small<EPI_ADAM, 1>(p, n_sel, st);
     }
     if (grads) {
         if (tiles <= 256 && nchunks >= 8) return launch_pair_ks<false, false, EPI_GRAD, 4>(p, n_sel, n_sel, st);

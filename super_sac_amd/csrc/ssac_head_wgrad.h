@@ -37,7 +37,7 @@ __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *l
 template <int GROUPS, int COLS>
 __device__ __forceinline__ void head_wgrad_body(const HeadWgradArgs &a, float *lds, int bx, int e,
                                                 const float *dq_override, bool pol, float tau) {
-    static_assert(COLS == 64 || COLS == 16, "64-column (wave-wide) or 16-column head workgroups");
+    static_assert(COLS == 64 || COLS == 32 || COLS == 16, "64-column (wave-wide), 32- or 16-column head workgroups");
     float *red = lds;                   // [GROUPS][COLS]
     float *redb = lds + GROUPS * COLS;  // [GROUPS]
     const int tid = threadIdx.x, kk = tid % COLS, mg = tid / COLS;

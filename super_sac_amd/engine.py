@@ -23,9 +23,10 @@ USE_FUSED = True  # tests flip this to exercise the per-layer kernels on fused-c
 
 
 def set_wgrad_variant(variant):
-    """form of the merged weight-gradient launch: 0 = automatic (the 32 x 32-tile latency form for under-filled launches),
-    1 = 64 x 64 tiles always, 2 = 32 x 32 tiles whenever the shapes allow.  Both forms are parity-tested on every fixture
-    (tests/test_hip_cases.py); recorded launch lists keep the form they were recorded with."""
+    """form of the merged weight-gradient launch: 0 = automatic (the 32 x 32-tile latency form while all of its workgroups
+    are resident at once, else 64 x 64 tiles), 1 = 64 x 64 tiles always, 2 = 32 x 32 tiles whenever the shapes allow.  Both
+    forms are parity-tested on every fixture (tests/test_hip_cases.py); recorded launch lists keep the form they were
+    recorded with."""
     check(lib.ssac_wgrad_variant(int(variant)))
 
 

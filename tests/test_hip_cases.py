@@ -21,7 +21,8 @@ pytestmark = pytest.mark.gpu
 def test_engine_matches_reference(name, fused, wgrad):
     """both kernel families: the one-launch fused MLP kernels and the per-layer GEMM path -- and both forms of the merged
     weight-gradient launch under each: 64 x 64 tiles with an LDS-staged K loop, and the latency form (32 x 32 tiles, K
-    split over the waves, operands straight from memory) that under-filled launches take automatically."""
+    split over the waves, operands straight from memory) that launches take automatically while all of their
+    workgroups are resident at once."""
     import super_sac_amd as ssa
     old = ssa.engine.USE_FUSED
     ssa.engine.USE_FUSED = fused

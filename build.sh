@@ -1,10 +1,15 @@
 #!/bin/bash
 # Build libssac_hip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
 # Each .hip is compiled to build/<name>.o (in parallel, only when it or a header changed), then linked.
+#   ./build.sh          the product library
+#   ./build.sh --lab    the LAB build (-DSSAC_LAB): the same library + the measurement scaffolding the tools under tools/
+#                       need (s_memtime phase stamps, per-workgroup timelines; -DSSAC_EXPERIMENT_SKIP_* take effect).  It
+#                       replaces super_sac_amd/libssac_hip.so: run ./build.sh again for the product library.
 set -e
 cd "$(dirname "$0")"
 SRC=super_sac_amd/csrc
 OBJ=build/obj
+if [ "$1" = "--lab" ]; then shift; set -- -DSSAC_LAB "$@"; fi
 mkdir -p "$OBJ"
 # -ffp-contract=off: keep fp32 op boundaries as the reference's separate torch ops have them
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Iinclude -I$SRC $*"

@@ -235,19 +235,6 @@ _RESTYPES = {"ssac_xchg_create": C.c_void_p, "ssac_xchg_destroy": None, "ssac_st
              "ssac_launch_list_free": None}
 
 
-def debug_knob(name, default):
-    """development switch `name` from the ONE debugging variable SSAC_DEBUG ("fold_logs=0,event_every=4"): every
-    alternative launch form the update path can take is parity-tested, but none is a supported configuration -- the
-    supported surface is SSAC_LAUNCH_MODE (list | graph) and nothing else.  Returns int for int defaults, bool for bool."""
-    raw = os.environ.get("SSAC_DEBUG", "")
-    for item in raw.split(","):
-        if "=" in item:
-            k, v = item.split("=", 1)
-            if k.strip().lower() == name:
-                return (v.strip() not in ("0", "false", "off", "")) if isinstance(default, bool) else int(v)
-    return default
-
-
 # SSAC_ABI_VERSION of include/ssac_hip.h this binding table was written against (bumped with every signature change:
 # a stale .so called with shifted pointer arguments would corrupt device memory)
 ABI_VERSION = 4
@@ -266,12 +253,6 @@ def _load():
     if lib.ssac_abi_version() != ABI_VERSION:
         raise ImportError(f"libssac_hip.so has ABI version {lib.ssac_abi_version()}, this package binds version "
                           f"{ABI_VERSION}: rebuild the extension (build.sh)")
-    if not debug_knob("feed_device", True):
-        lib.ssac_feed_ring_mode(0)
-    if debug_knob("gemm_lean", -1) >= 0:
-        lib.ssac_gemm_lean(debug_knob("gemm_lean", -1))
-    if debug_knob("xcd_order", -1) >= 0:
-        lib.ssac_xcd_order(debug_knob("xcd_order", -1))
     return lib
 
 

@@ -85,7 +85,11 @@ struct BfArgs {
     long long *dbg;                 // optional s_memtime phase stamps of tile 0 (ssac_bf16_debug_stamps)
     int xcd;                        // XCD-contiguous workgroup order (ssac_internal.h)
 };
+#ifdef SSAC_LAB
 #define BSTAMP(i) do { if (g.dbg && dbg_off >= 0 && bx == 0 && e == 0 && threadIdx.x == 0) g.dbg[dbg_off + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
 
 // ---- one layer as D[b][n] = sum_k act[b][k] W[n][k] on v_mfma_f32_32x32x16_bf16.  A = the tile's 32 activation rows in
 // LDS (lane (b = lane & 31, half = lane >> 5) reads 8 consecutive k of row b); B = 32 weight rows (row stride ldw, K
@@ -202,7 +206,11 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
     const bool rok = (m0 + xr) < g.n_rows;
     const int64_t src = (gidx && rok) ? gidx[m0 + xr] : 0;
     const int net = idsp ? idsp[e] : e;
+#ifdef SSAC_LAB
 #define DSTAMP(i) do { if (g.dbg && dbg_off >= 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BSTAMP(i); } } while (0)
+#else
+#define DSTAMP(i) do { } while (0)
+#endif
     DSTAMP(12);   // (debug runs only: serialises the prologue to time its dependent loads one by one)
     if (net < 0) {  // empty subset slot of a sharded rank: +inf, the neutral element of the min that follows
         if (MODE == MODE_PLAIN && g.Y)
@@ -704,7 +712,11 @@ struct BfWgradArgs {
     int xcd;                     // XCD-contiguous workgroup order (ssac_internal.h)
     long long *dbg;
 };
+#ifdef SSAC_LAB
 #define WSTAMP(i) do { if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0) g.dbg[48 + i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WSTAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ float adam_elem(float p, float g, float &m, float &v, const ssac_adam_ctl &c) {
     if (c.weight_decay != 0.0f) g = g + c.weight_decay * p;
@@ -1005,7 +1017,14 @@ extern "C" int64_t ssac_bf16_layout(int in_dim, int hidden, int out_dim, int64_t
 }
 
 extern "C" int ssac_bf16_supported(const ssac_mlp *nets) { return bf_ok(nets) ? 1 : 0; }
-extern "C" int ssac_bf16_debug_stamps(long long *dev_buf) { g_bf_dbg = dev_buf; return 0; }
+extern "C" int ssac_bf16_debug_stamps(long long *dev_buf) {
+#ifdef SSAC_LAB
+    g_bf_dbg = dev_buf;
+    return 0;
+#else
+    return dev_buf ? ssac_fail("ssac_bf16_debug_stamps: " SSAC_LAB_REFUSAL) : 0;
+#endif
+}
 
 extern "C" int ssac_bf16_sync(const ssac_mlp *nets, uint16_t *shadow, void *stream) {
     if (!nets || !shadow) return ssac_fail("ssac_bf16_sync: missing argument");

@@ -1537,7 +1537,14 @@ extern "C" int ssac_feed_write(void *ring_slot, const void *src, size_t bytes) {
 int g_ssac_xcd = 2;
 extern "C" int ssac_xcd_order(int mask) { g_ssac_xcd = mask & 15; return 0; }
 long long *g_ssac_timeline = nullptr;   // [2048]: (start, end) per workgroup of the chained launch, then (from 1024) of the merged weight-gradient launch
-extern "C" int ssac_debug_timeline(long long *dev_buf) { g_ssac_timeline = dev_buf; return 0; }
+extern "C" int ssac_debug_timeline(long long *dev_buf) {
+#ifdef SSAC_LAB
+    g_ssac_timeline = dev_buf;
+    return 0;
+#else
+    return dev_buf ? ssac_fail("ssac_debug_timeline: " SSAC_LAB_REFUSAL) : 0;
+#endif
+}
 
 extern "C" int ssac_record_begin(void) {
     if (g_ssac_recording) return ssac_fail("ssac_record_begin: a recording is already open on this thread");

@@ -449,8 +449,16 @@ __device__ __forceinline__ void stage_head_weights(float *w3s, const float *__re
     }
 }
 
+#ifdef SSAC_LAB
 #define STAMP(i) do { if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+#ifdef SSAC_LAB
 #define BSTAMP(i) do { if (g.dbg && dbg_off >= 0 && bx == 0 && e == 0 && threadIdx.x == 0) g.dbg[dbg_off + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
 
 // DBUF = false: 2 workgroups per CU (needs <= 128 VGPRs and <= 80 KB of LDS each)
 // (bx, e, grid_x) = tile index, net slot and number of row tiles of the launch this workgroup works for -- blockIdx /
@@ -1082,7 +1090,7 @@ void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs
                         int critic_grid_x, DeferredLogsArgs dl, int dl_on) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
-    if (gc.tl && threadIdx.x == 0 && bid < 512) gc.tl[2 * bid] = __builtin_amdgcn_s_memrealtime();
+    SSAC_LAB_ONLY(if (gc.tl && threadIdx.x == 0 && bid < 512) gc.tl[2 * bid] = __builtin_amdgcn_s_memrealtime();)
     if (dl_on && bid == (int)gridDim.x - 1) {
         // one extra workgroup: the PREVIOUS recorded update's log block -> its slot of the log ring (ssac_critic_logs.h)
         deferred_logs_body(dl, -1);
@@ -1122,10 +1130,12 @@ void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs
                                  : ssac_xcd_contiguous_range(bid, tiles_t, n_main, gc.xcd);
         fused_mlp_body<MODE_CRITIC_U, TC, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x, 32);
     }
+#ifdef SSAC_LAB
     if (gc.tl && bid < 512) {   // (the stamp buffer holds 512 workgroups per launch: tools/wg_timeline.py)
         __syncthreads();   // (drains this workgroup's stores too)
         if (threadIdx.x == 0) gc.tl[2 * bid + 1] = __builtin_amdgcn_s_memrealtime();
     }
+#endif
 }
 
 long long *g_fused_dbg = nullptr;
@@ -1216,7 +1226,14 @@ __global__ __launch_bounds__(256) void critic_logs_kernel(CriticLogsArgs a) {
 
 }  // namespace
 
-extern "C" int ssac_fused_debug_stamps(long long *dev_buf) { g_fused_dbg = dev_buf; return 0; }
+extern "C" int ssac_fused_debug_stamps(long long *dev_buf) {
+#ifdef SSAC_LAB
+    g_fused_dbg = dev_buf;
+    return 0;
+#else
+    return dev_buf ? ssac_fail("ssac_fused_debug_stamps: " SSAC_LAB_REFUSAL) : 0;
+#endif
+}
 extern "C" int ssac_fused_supported(const ssac_mlp *nets) {
     return fused_dbuf_ok(nets) ? 1 : (fused_ok(nets) ? 2 : 0);
 }

@@ -160,7 +160,11 @@ __device__ __forceinline__ void sumsq_store64(float *base, int M, int N, int bx,
 // kg, kg+KS, ... with its own LDS staging; the partial tiles are summed through LDS before the
 // epilogue.  It buys latency hiding (KS waves per SIMD) for launches with few tiles and a long K
 // (weight gradients: K = batch), where most CUs would otherwise run one wave per SIMD.
+#ifdef SSAC_LAB
 #define GSTAMP(i) do { if (g.dbg && bx == 0 && by == 0 && bz == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
 
 // Row-contiguous operand (K x R row-major, e.g. dY and X of the weight-gradient GEMM), 16-byte
 // loads: thread -> 4 consecutive rows r4 = 4*(tid&15), k = (tid>>4) + 16q.  The source pointers
@@ -428,7 +432,11 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
 #pragma unroll
         for (int t = 0; t < HT; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
     };
+#ifdef SSAC_LAB
 #define GDSTAMP(i) do { if (g.dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); GSTAMP(i); } } while (0)
+#else
+#define GDSTAMP(i) do { } while (0)
+#endif
     LossFoldRegs lfr;
     if (lf_mode == 1) loss_fold_issue(lf, e, lfr);
     loadA(kg * BK);
@@ -758,7 +766,7 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // (the XCD-contiguous order covers the GEMM + head workgroups only: the TD workgroup behind them keeps its own id,
     // so the tiles land on the same XCDs with or without it)
-    if (p.tl && threadIdx.x == 0 && blockIdx.x < 512) p.tl[1024 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    SSAC_LAB_ONLY(if (p.tl && threadIdx.x == 0 && blockIdx.x < 512) p.tl[1024 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();)
     const int n_main = p.tiles01 + p.head_total;
     int bid = (int)blockIdx.x < n_main ? ssac_xcd_contiguous(blockIdx.x, n_main, p.xcd) : (int)blockIdx.x;
     if (p.xcd_mix && (int)blockIdx.x < n_main) {
@@ -793,7 +801,7 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
         if ((p.fold.done && p.fold.td_logs) || p.fold.deferred_stats)
             log_fold_td_stats(p.fold, p.lf.tds, tab + p.lf.n_rows);
     } else if (bid >= p.tiles01) {  // head-layer weight gradient + Adam beside the GEMM tiles
-#ifdef SSAC_EXPERIMENT_SKIP_HEAD
+#if defined(SSAC_LAB) && defined(SSAC_EXPERIMENT_SKIP_HEAD)
         return;
 #endif
         const int L = bid - p.tiles01;
@@ -814,10 +822,10 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
         head_wgrad_body<4 * KS>(p.head, lds, L % p.head_grid_x, e, fold ? tab : nullptr, hpol, htau);
     } else {
         const bool first = bid < p.tiles0;
-#ifdef SSAC_EXPERIMENT_SKIP_FC1
+#if defined(SSAC_LAB) && defined(SSAC_EXPERIMENT_SKIP_FC1)
         if (!first) return;   // (measurement builds only: how long is the launch without the fc1 problem's tiles?)
 #endif
-#ifdef SSAC_EXPERIMENT_SKIP_FC2
+#if defined(SSAC_LAB) && defined(SSAC_EXPERIMENT_SKIP_FC2)
         if (first) return;
 #endif
         const GemmArgs &g = first ? p.g0 : p.g1;
@@ -842,10 +850,12 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
     } else if (p.fold.deferred_stats && p.fold.feed && blockIdx.x == 0 && threadIdx.x == 0) {
         p.fold.feed->tick += 1;   // deferred finalisation: the update is over for the input ring (no reader in this launch)
     }
-    if (p.tl) {
+#ifdef SSAC_LAB
+    if (p.tl && blockIdx.x < 512) {   // (the stamp buffer holds 512 workgroups per launch)
         __syncthreads();
         if (threadIdx.x == 0) p.tl[1024 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -886,7 +896,11 @@ __device__ __forceinline__ void wgrad_small_body(const GemmArgs &g, float *lds, 
     constexpr int KW = SW / MB;   // K-split ways
     constexpr int NE = 2 * MB;    // tile elements finished per thread
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SSAC_LAB
 #define SSTAMP(i) do { if (g.dbg && bx == 0 && by == 0 && bz == 0 && threadIdx.x == 0) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SSTAMP(i) do { } while (0)
+#endif
     SSTAMP(0);
     const int li = lane & 31, lh = lane >> 5;
     const int mb = wave / KW, kw = wave - mb * KW;   // (uniform) this wave's row block and K-group
@@ -1124,7 +1138,7 @@ template <int EPI, int MB>
 __global__ __launch_bounds__(STHREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void wgrad_small_pair_kernel(GemmPair p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if (p.tl && threadIdx.x == 0 && blockIdx.x < 512) p.tl[1024 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    SSAC_LAB_ONLY(if (p.tl && threadIdx.x == 0 && blockIdx.x < 512) p.tl[1024 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();)
     const int n_main = p.tiles01 + p.head_total;
     int bid = (int)blockIdx.x < n_main ? ssac_xcd_contiguous(blockIdx.x, n_main, p.xcd) : (int)blockIdx.x;
     if (p.xcd_mix && (int)blockIdx.x < n_main) {   // XCD-contiguous PER CLASS (see ens_gemm_pair_kernel)
@@ -1184,10 +1198,12 @@ void wgrad_small_pair_kernel(GemmPair p) {
     } else if (p.fold.deferred_stats && p.fold.feed && blockIdx.x == 0 && threadIdx.x == 0) {
         p.fold.feed->tick += 1;   // deferred finalisation: the update is over for the input ring
     }
-    if (p.tl && blockIdx.x < 512) {
+#ifdef SSAC_LAB
+    if (p.tl && blockIdx.x < 512) {   // (the stamp buffer holds 512 workgroups per launch)
         __syncthreads();
         if (threadIdx.x == 0) p.tl[1024 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     }
+#endif
 }
 
 // 0 = automatic (the latency form when the whole launch fits one resident round of its small workgroups), 1 = always 64 x 64
@@ -1390,7 +1406,14 @@ bool layer_geom(const ssac_mlp *n, int layer, LayerGeom &L) {
 
 }  // namespace
 
-extern "C" int ssac_gemm_debug_stamps(long long *dev_buf) { g_gemm_dbg = dev_buf; return 0; }
+extern "C" int ssac_gemm_debug_stamps(long long *dev_buf) {
+#ifdef SSAC_LAB
+    g_gemm_dbg = dev_buf;
+    return 0;
+#else
+    return dev_buf ? ssac_fail("ssac_gemm_debug_stamps: " SSAC_LAB_REFUSAL) : 0;
+#endif
+}
 
 // Which form the merged weight-gradient launch takes: 0 = automatic, 1 = 64 x 64 tiles, 2 = 32 x 32 tiles (the latency
 // form) whenever the shapes allow.  Both are parity-tested on every fixture (tests/test_hip_cases.py).

@@ -69,7 +69,16 @@ inline void ssac_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t 
 // hardware order.
 // ---------------------------------------------------------------------------------------------
 extern int g_ssac_xcd;
-extern long long *g_ssac_timeline;   // ssac_debug_timeline (ssac_fused.hip)
+extern long long *g_ssac_timeline;   // ssac_debug_timeline (ssac_elementwise.hip)
+// Measurement scaffolding -- s_memtime phase stamps of one workgroup, per-workgroup (start, end) timelines, builds in which a
+// workgroup class returns at once -- is compiled only into the LAB build (`./build.sh --lab`, -DSSAC_LAB): the product
+// library carries none of it, and its ssac_*_debug_stamps / ssac_debug_timeline entry points refuse.
+#ifdef SSAC_LAB
+#define SSAC_LAB_ONLY(...) __VA_ARGS__
+#else
+#define SSAC_LAB_ONLY(...)
+#endif
+#define SSAC_LAB_REFUSAL "measurement scaffolding is compiled into the lab build only: ./build.sh --lab"
 #ifdef __HIPCC__
 // Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global loads / stores.
 // __syncthreads() also drains vmcnt -- inside a software-pipelined K loop that exposes the round trip of the operand

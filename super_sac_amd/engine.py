@@ -31,9 +31,9 @@ def set_wgrad_variant(variant):
 
 
 # launch the head layer's (VALU) weight-gradient kernel as a parallel branch beside the fc2/fc1 GEMM launch
-HEAD_BRANCH = _lib.debug_knob("head_branch", False)
+HEAD_BRANCH = False
 # head + fc2 + fc1 weight gradients in one launch (the head's VALU workgroups fill CUs the GEMM tiles leave idle)
-MERGE_HEAD_WGRAD = _lib.debug_knob("merge_head_wgrad", True)
+MERGE_HEAD_WGRAD = True
 
 
 class CaptureCtx:

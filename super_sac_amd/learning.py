@@ -70,29 +70,29 @@ class _LaunchList:
                     pass
 
 
-FUSED_ACTOR = _lib.debug_knob("fused_actor", True)  # the online actor update in four fused launches
+FUSED_ACTOR = True  # the online actor update in four fused launches
 FEED_SLOTS = 32  # pinned input ring of a captured update: how far the host may run ahead of the GPU
 # evaluate the TD target inside the critic launch instead of a launch of its own (continuous, no PopArt)
-SHARDED_LISTS = _lib.debug_knob("sharded_lists", True)  # recorded launch lists on critic-sharded ranks
-FOLD_BEGIN = _lib.debug_knob("fold_begin", True)  # fold ssac_begin_update into the replay gather
+SHARDED_LISTS = True  # recorded launch lists on critic-sharded ranks
+FOLD_BEGIN = True  # fold ssac_begin_update into the replay gather
 # Log finalisation inside the weight-gradient launch: the last workgroup to ARRIVE (a device-scope ticket drawn after
 # its write-through partial stores -- no fence, so none of the 17 MB of freshly written Adam state is flushed) sums the
 # partials and publishes the log block; the separate 1-workgroup logs launch (~5 us per update) disappears.
-FOLD_LOGS = _lib.debug_knob("fold_logs", True)
-LAZY_TD = _lib.debug_knob("lazy_td", True)
-SPLIT_FORWARD = _lib.debug_knob("split_forward", False)
+FOLD_LOGS = True
+LAZY_TD = True
+SPLIT_FORWARD = False
 
 
 # the TD-independent half of the critics' backward pass inside the target-critic launch (rank-1 loss gradient); a module
 # knob, not an environment switch: tests turn it off to compare against the launch forms other configurations take
 RANK1_BWD = True
-SKIP_DZ2 = _lib.debug_knob("skip_dz2", True)  # dz2u stays inside the chained launch (rebuilt from h2 by the weight gradient)
-EVENT_EVERY = _lib.debug_knob("event_every", 8)  # must divide FEED_SLOTS
-FOLD_LOSS = _lib.debug_knob("fold_loss", True)  # rank-1 backward: dL/dq evaluated inside the weight-gradient launch
-DUAL_LAUNCH = _lib.debug_knob("dual_launch", True)  # critic forward inside the actor-sample launch
+SKIP_DZ2 = True  # dz2u stays inside the chained launch (rebuilt from h2 by the weight gradient)
+EVENT_EVERY = 8  # must divide FEED_SLOTS
+FOLD_LOSS = True  # rank-1 backward: dL/dq evaluated inside the weight-gradient launch
+DUAL_LAUNCH = True  # critic forward inside the actor-sample launch
 
 
-DUAL_MAX_WG = _lib.debug_knob("dual_max_wg", 320)
+DUAL_MAX_WG = 320
 
 
 def _dual_fits(arena, n_rows):

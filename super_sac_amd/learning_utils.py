@@ -61,7 +61,7 @@ _rings = {}
 # Deferred log finalisation of recorded updates (csrc/ssac_critic_logs.h): the newest recorded update's log block is
 # written to its ring slot by the NEXT update's first launch -- or, when somebody looks at one of its values first, by a
 # flush launch.  `pending` = (log-ring slot, ssac_deferred_logs struct) of that newest update, per device ring.
-DEFERRED_LOGS = _lib.debug_knob("deferred_logs", True)
+DEFERRED_LOGS = True
 
 
 def flush_pending_logs(owner):
@@ -105,7 +105,7 @@ def draw_normal(shape, device):
     return rng.draw_normal(shape, device)
 
 
-IN_KERNEL_NOISE = _lib.debug_knob("in_kernel_noise", True)
+IN_KERNEL_NOISE = True
 
 
 def noise_stream(agent, device):
@@ -193,7 +193,7 @@ def _polyak_tensor(t, s, tau):
 
 # soft_update right behind a recorded critic update: no launch -- the update's own weight-gradient launch, still
 # waiting in the queue, applies the target update in its Adam epilogue (ssac_late_polyak in include/ssac_hip.h)
-LATE_POLYAK = _lib.debug_knob("late_polyak", True)
+LATE_POLYAK = True
 
 
 def soft_update(target, source, tau):
@@ -252,7 +252,7 @@ class _Batch:
 
 
 # actor sample -> target critics chained per workgroup, beside the critics' forward + unscaled backward: ONE launch
-CHAIN_LAUNCH = _lib.debug_knob("chain_launch", True)
+CHAIN_LAUNCH = True
 
 
 def parallel_shard_of(agent):
@@ -261,7 +261,7 @@ def parallel_shard_of(agent):
 
 
 # the replay gather of a critic update rides in the merged actor / critic-forward launch (ssac_gather): no gather launch
-FOLD_GATHER = _lib.debug_knob("fold_gather", True)
+FOLD_GATHER = True
 
 
 def ensure_gathered(bt):

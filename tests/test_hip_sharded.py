@@ -258,6 +258,51 @@ def test_member_sharded_sunrise_matches_reference(tmp_path, name, world, one_sho
     assert all((tmp_path / f"mok{r}.npz").exists() for r in range(world))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE config 5 at 4 and 8 ranks (the ranks sharing the one device): the value check bench.py --gpus N runs before
+# it times, under pytest and at the HUMANOID shape (only builder-side bench logs, shape M)
+# ---------------------------------------------------------------------------------------------------------------
+def _config5_main(rank, world, port, out_dir, one_shot):
+    sys.path.insert(0, os.path.dirname(HERE))
+    import json
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    torch.set_num_threads(max(1, 16 // world))   # (eight ranks initialising 16 orthogonal critics each: see bench.py)
+    import bench
+    import super_sac_amd as ssa
+    from super_sac_amd import parallel
+    bench.OBS, bench.ACT, bench.NCRIT = 376, 17, 16      # Humanoid-v4, N 16 (BASELINE config 5)
+    bench.synth_data.__defaults__ = (376, 17)
+    device = torch.device("cuda:0")
+    if one_shot:
+        assert parallel.enable_one_shot(device) is not None
+    shard = parallel.Shard(rank, world, bench.NCRIT)
+    step, _, _ = bench.build_engine(device, shard.n_local, shard)
+    res = bench.sharded_value_check(step, ssa, device, shard, dist, n_updates=6)
+    assert res is not None and not parallel.exchange_failed()
+    json.dump(res, open(os.path.join(out_dir, f"c5_{rank}.json"), "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,one_shot", [(4, True), (8, False)], ids=["4-ranks-one-shot", "8-ranks-collective"])
+def test_config5_humanoid_n16_value_check_at_4_and_8_ranks(tmp_path, world, one_shot):
+    """obs 376 / act 17 / N 16 / B 512, 4 critics per rank (one-shot exchange) and 2 per rank (eight processes sharing the
+    device go through the gloo collective: bench.py's own default there): 6 recorded updates per rank against the UNSHARDED
+    engine run by rank 0 on the same seeds -- TD targets <= 2e-5, this rank's parameters / targets / moments <= 3e-5
+    (bench.sharded_value_check raises otherwise).  A rank with 2 or 4 critics takes the latency form of the
+    weight-gradient launch and the 16-row tile variants: the check is also those variants against the one-GPU kernels."""
+    import json
+    port = 32300 + (os.getpid() % 2000) + world
+    mp.spawn(_config5_main, args=(world, port, str(tmp_path), one_shot), nprocs=world, join=True)
+    res = json.load(open(tmp_path / "c5_0.json"))
+    assert res["updates"] == 6 and res["max_abs_diff"]["td"] <= 2e-5, res
+
+
 def _humanoid_main(rank, world, port, out_dir):
     """BASELINE config 5's shape (obs 376 / act 17 / N 16 / B 512), critics sharded over two ranks that share this
     GPU: critic updates replayed from ONE launch list per rank (the exchange is a recorded launch), Polyak, actor and

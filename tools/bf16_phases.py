@@ -1,4 +1,5 @@
-"""s_memtime phase stamps inside the bf16 chain / weight-gradient launches (eager launches, tile 0 of each role)
+"""(needs the LAB build of the library: ./build.sh --lab)
+s_memtime phase stamps inside the bf16 chain / weight-gradient launches (eager launches, tile 0 of each role)
     python tools/bf16_phases.py [B] [N]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +16,7 @@ critic, _ = bc.build(17, 6, B, N, 2, precision="bf16")
 for _ in range(5):
     critic()
 dbg = torch.zeros(64, dtype=torch.int64, device="cuda")
-ssa._lib.lib.ssac_bf16_debug_stamps(dbg.data_ptr())
+ssa._lib.check(ssa._lib.lib.ssac_bf16_debug_stamps(dbg.data_ptr()))
 for _ in range(3):
     critic()
 torch.cuda.synchronize()

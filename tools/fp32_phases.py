@@ -1,4 +1,5 @@
-"""s_memtime phase stamps inside the fp32 chained launch and the merged weight-gradient launch (eager launches of the
+"""(needs the LAB build of the library: ./build.sh --lab)
+s_memtime phase stamps inside the fp32 chained launch and the merged weight-gradient launch (eager launches of the
 real update at the headline shape; tile 0 of each role)       python tools/fp32_phases.py [B] [N]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,8 +17,8 @@ for _ in range(5):
     critic()
 dbg = torch.zeros(64, dtype=torch.int64, device="cuda")
 gdbg = torch.zeros(16, dtype=torch.int64, device="cuda")
-ssa._lib.lib.ssac_fused_debug_stamps(dbg.data_ptr())
-ssa._lib.lib.ssac_gemm_debug_stamps(gdbg.data_ptr())
+ssa._lib.check(ssa._lib.lib.ssac_fused_debug_stamps(dbg.data_ptr()))
+ssa._lib.check(ssa._lib.lib.ssac_gemm_debug_stamps(gdbg.data_ptr()))
 for _ in range(3):
     critic()
 torch.cuda.synchronize()

@@ -1,4 +1,5 @@
-"""phase timing (shader clocks) inside the fused MLP kernel, workgroup (0,0)"""
+"""(needs the LAB build of the library: ./build.sh --lab)
+phase timing (shader clocks) inside the fused MLP kernel, workgroup (0,0)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
@@ -17,7 +18,7 @@ for (B, in_dim, H, out, N) in [(512, 23, 256, 1, 2), (512, 17, 256, 12, 1), (512
     x = torch.randn(B, in_dim, device=dev)
     ws = ssa.engine.Workspace(dev)
     dbg = torch.zeros(16, dtype=torch.int64, device=dev)
-    ssa._lib.lib.ssac_fused_debug_stamps(dbg.data_ptr())
+    ssa._lib.check(ssa._lib.lib.ssac_fused_debug_stamps(dbg.data_ptr()))
     for _ in range(3):
         ssa.engine.mlp_forward(ar, x, in_dim, 0, B, ws, "t", save=False)
     torch.cuda.synchronize()
@@ -41,7 +42,7 @@ h1 = torch.zeros(N, B, H, device=dev); h2 = torch.zeros_like(h1); dz2 = torch.ze
 q = torch.zeros(N, B, 1, device=dev); dq = torch.zeros_like(q)
 tiles = int(ssa._lib.lib.ssac_fused_row_tiles(C.byref(ar.desc()), B, N)); parts = torch.zeros(N * tiles * 2, device=dev)
 dbg = torch.zeros(16, dtype=torch.int64, device=dev)
-ssa._lib.lib.ssac_fused_debug_stamps(dbg.data_ptr())
+ssa._lib.check(ssa._lib.lib.ssac_fused_debug_stamps(dbg.data_ptr()))
 def run():
     ssa._lib.check(ssa._lib.lib.ssac_critic_fwd_bwd_fused(C.byref(ar.desc()), x.data_ptr(), in_dim, B, td.data_ptr(), 0, 0, 1, 0, 0,
         float(N), h1.data_ptr(), h2.data_ptr(), q.data_ptr(), dq.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), 0, ssa.engine.stream()))
@@ -64,7 +65,7 @@ grp = ssa.engine.AdamGroup(topt, dev)
 grp.advance()
 m_, v_ = grp.moments_for("k", ar.params)
 for layer, (xin, ldi, sxi, dy, ldy, sy) in {1: (h1, H, B * H, dz2, H, B * H), 0: (x, in_dim, 0, dz1, H, B * H)}.items():
-    ssa._lib.lib.ssac_gemm_debug_stamps(dbg2.data_ptr())
+    ssa._lib.check(ssa._lib.lib.ssac_gemm_debug_stamps(dbg2.data_ptr()))
     def runw():
         ssa._lib.check(ssa._lib.lib.ssac_mlp_layer_wgrad(C.byref(ar.desc()), layer, 0, N, xin.data_ptr(), ldi, sxi, dy.data_ptr(), ldy, sy, B,
             m_.data_ptr(), v_.data_ptr(), grp.ctl.ptr, 0, 0, 0, 0, 0.0, ssa.engine.stream()))

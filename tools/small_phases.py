@@ -1,4 +1,5 @@
-"""Phase stamps (s_memtime) of fc2 tile (0, 0, 0) of the LATENCY form of the weight-gradient launch:
+"""(needs the LAB build of the library: ./build.sh --lab)
+Phase stamps (s_memtime) of fc2 tile (0, 0, 0) of the LATENCY form of the weight-gradient launch:
     python tools/small_phases.py [obs] [act] [B] [N]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +16,7 @@ critic, _ = bc.build(obs, act, B, N, 2)
 for _ in range(5):
     critic()
 gdbg = torch.zeros(16, dtype=torch.int64, device="cuda")
-ssa._lib.lib.ssac_gemm_debug_stamps(gdbg.data_ptr())
+ssa._lib.check(ssa._lib.lib.ssac_gemm_debug_stamps(gdbg.data_ptr()))
 for rep in range(4):
     gdbg.zero_()
     critic()

@@ -1,4 +1,5 @@
-"""Per-workgroup (start, end) of the two launches of a critic update (ssac_debug_timeline, s_memrealtime at 100 MHz):
+"""(needs the LAB build of the library: ./build.sh --lab)
+Per-workgroup (start, end) of the two launches of a critic update (ssac_debug_timeline, s_memrealtime at 100 MHz):
 when does each workgroup start (dispatch skew), which class finishes last.      python tools/wg_timeline.py [B] [N]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +17,7 @@ critic, _ = bc.build(17, 6, B, N, 2)
 for _ in range(5):
     critic()
 tl = torch.zeros(2048, dtype=torch.int64, device="cuda")
-ssa._lib.lib.ssac_debug_timeline(tl.data_ptr())
+ssa._lib.check(ssa._lib.lib.ssac_debug_timeline(tl.data_ptr()))
 for rep in range(3):
     tl.zero_()
     critic()

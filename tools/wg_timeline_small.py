@@ -1,4 +1,5 @@
-"""Per-workgroup (start, end) of the two launches of a critic update for UNDER-FILLED configurations (the latency form
+"""(needs the LAB build of the library: ./build.sh --lab)
+Per-workgroup (start, end) of the two launches of a critic update for UNDER-FILLED configurations (the latency form
 of the weight-gradient launch: 32 x 32 tiles):      python tools/wg_timeline_small.py [obs] [act] [B] [N]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +18,7 @@ critic, _ = bc.build(obs, act, B, N, 2)
 for _ in range(5):
     critic()
 tl = torch.zeros(2048, dtype=torch.int64, device="cuda")
-ssa._lib.lib.ssac_debug_timeline(tl.data_ptr())
+ssa._lib.check(ssa._lib.lib.ssac_debug_timeline(tl.data_ptr()))
 H = 256
 in_dim = obs + act
 small = (((H // 32) * (H // 32), "fc2 tiles"), ((H // 32) * ((in_dim + 31) // 32), "fc1 tiles"), (H // 16, "head"))

@@ -683,7 +683,13 @@ int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t ldxa, int 
                       const ssac_mlp *critics, const float *Xc, int64_t ldxc, float *H1, float *H2, float *Q,
                       float *DZ2u /* NULL: not written; W3_snapshot (n_nets x hidden) is filled instead */, float *DZ1u,
                       float *W3_snapshot, const ssac_gather *gather,
-                      const ssac_deferred_logs *deferred /* nullable */, void *stream);
+                      const ssac_deferred_logs *deferred /* nullable */,
+                      unsigned long long *handoff /* nullable: n_rows x A words, zeroed once */, void *stream);
+/* handoff != NULL selects the PRODUCER / CONSUMER form of the launch: the actor runs ONCE per 16-row tile (not once per
+ * subset slot) and publishes a' as tagged 8-byte granules in `handoff`; the target-critic workgroups of the tile gather
+ * their own s' rows, run fc1 on the state columns while the actor is still working, poll the granules and add
+ * a' W1[:, S:S+A]^T -- their critical path behind the actor is fc2 + head instead of a whole MLP pass.  Same outputs up
+ * to fp32 association of fc1's sum (the action columns enter last). */
 
 /* ---- the online actor update (learning.py:344-421) in four launches:
  *   ssac_actor_sample_concat_fused   actor forward (h1 / h2 / head output saved) + tanh-normal rsample + log pi, the rows

@@ -66,6 +66,20 @@ struct ActorBwdArgs {
     float *partials;                    // [row tiles] sum over the tile's rows of (Q' - alpha log pi)
 };
 
+// Hand-off of the sampled action a' from the ACTOR workgroup of a 16-row tile to the tile's TARGET-CRITIC workgroups
+// (fused_chain_pc_kernel): one 8-byte granule {a' bits, tag} per (row, action dimension), written with ONE write-through
+// (agent-scope) store and polled with agent-scope loads -- no fence on either side (a granule is complete or absent).  tag =
+// base + the update counter of a recorded launch list (ssac_feed.tick) or the host's launch counter (eager launches):
+// distinct for every launch, so a stale granule of an earlier update is never taken for this update's.
+struct Handoff {
+    unsigned long long *pub;    // [n_rows][A]; null = no hand-off
+    const long long *tick;      // device-resident update counter, or null
+    unsigned base;
+    int S, A;                   // the consumer's input columns [S, S + A) arrive through pub
+};
+constexpr long long HANDOFF_SPIN_LIMIT = 4000000000LL;   // shader clocks (~2 s): a producer that never arrives poisons, never hangs
+constexpr int HANDOFF_MAX_WA = 9;   // W1's action columns per thread (H * A <= 512 * 9: 256 x 18)
+
 struct FusedArgs {
     const float *params; int64_t net_stride; int in_dim, hidden, out_dim;
     int64_t off[6];
@@ -84,13 +98,15 @@ struct FusedArgs {
                   // workgroups update W3 while its fc2 tiles run
     int xcd;                     // workgroups take their tile in XCD-contiguous order (ssac_internal.h)
     ssac_gather gth; int gth_role;  // 1: actor half (s' rows, begin duties), 3: actor half without the begin duties,
-                                    // 2: critic half ([s|a] rows), 4: rows from X, net ids from the input slot; 0: X
+                                    // 2: critic half ([s|a] rows), 4: rows from X, net ids from the input slot; 0: X;
+                                    // 5: hand-off consumer (s' rows like the actor half, nothing written, ids from the slot)
     long long *dbg;  // optional phase timestamps (s_memtime) of workgroup (0,0), thread 0
     long long *tl;   // optional per-workgroup (start, end) stamps of the chained launch (s_memrealtime; ssac_debug_timeline)
     ssac_td_spec tds;  // tds.q_t != null: the TD target is computed here instead of read from `td`
     float *DXU; int dx_col0, dx_cols;  // MODE_CRITIC_U: also the unscaled input gradient of columns [dx_col0, +dx_cols)
     int copy_x;                        // MODE_SAMPLE: also copy the input tile into act_dst[:, 0:in_dim]
     ActorBwdArgs ab;                   // MODE_ACTOR_BWD
+    Handoff ho;                        // MODE_SAMPLE: publish a'; MODE_PLAIN (16-row tiles): take the action columns from it
 };
 
 // TD target of row b (see ssac_td_spec; same operation order as td_target_kernel in ssac_elementwise.hip)
@@ -506,7 +522,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 if (tid == 0 && g.gth.ctl) adam_refresh(g.gth.ctl, g.gth.ctl->step + 1);
             }
             // role 4: the subset ids of a target-critic pass that runs in the launch that mirrors the slot
-            if (g.gth_role == 4 && g.gth.ids_word >= 0) idsp = reinterpret_cast<const int32_t *>(gslot + g.gth.ids_word);
+            if ((g.gth_role == 4 || g.gth_role == 5) && g.gth.ids_word >= 0) idsp = reinterpret_cast<const int32_t *>(gslot + g.gth.ids_word);
         }
         if (g.gth_role == 4) gidx = nullptr;  // (its rows are read from X)
     }
@@ -591,7 +607,12 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         constexpr int XR = TMR / 16;  // x-tile rows per thread: half-wave per row, 16 rows a pass
         const int xk = tid & 31, xr0 = tid >> 5;
         const int Sg = gidx ? (int)g.gth.s_elems : 0;
-        const bool actor_half = (g.gth_role & 1) != 0;  // roles 1 and 3 (3: no start-of-update duties)
+        const bool actor_half = (g.gth_role & 1) != 0;  // roles 1, 3 (3: no start-of-update duties) and 5 (below)
+        // CONSUMER of a hand-off (MODE_PLAIN, role 5 / no gather): the input's state columns are fetched here -- s' rows
+        // from the replay arrays or from X -- the action columns [S, S + A) stay ZERO in the x tile: fc1 runs on the state
+        // part while the actor workgroup of the tile is still sampling, a' W1[:, S:]^T is added when it arrives
+        const bool CONS = MODE == MODE_PLAIN && TMR == 16 && g.ho.pub != nullptr;
+        const int XC = CONS ? g.ho.S : IN;   // columns of the x tile that are loaded
         int64_t gsrc[XR];
         bool xrok[XR];
 #pragma unroll
@@ -611,11 +632,24 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
             const int i3 = tid + u * NTHR;
             w3v[u] = W3[i3 < n3 ? i3 : 0];
         }
+        // (consumer) W1's action columns, H x A floats over the 512 threads: requested here, parked in staging buffer 1
+        // behind fc1's K loop
+        float war[HANDOFF_MAX_WA];
+        if (CONS) {
+            const float *W1 = P + g.off[0];
+            const int na = H * g.ho.A;
+#pragma unroll
+            for (int u = 0; u < HANDOFF_MAX_WA; ++u) {
+                const int ei = tid + u * NTHR;
+                const int c = ei / g.ho.A, i = ei - c * g.ho.A;
+                war[u] = W1[ei < na ? (int64_t)c * IN + g.ho.S + i : 0];
+            }
+        }
         const float *xrow[XR];
         float xv[XR];
 #pragma unroll
         for (int j = 0; j < XR; ++j) {
-            const bool ok = xrok[j] && xk < IN;
+            const bool ok = xrok[j] && xk < XC;
             if (gidx) {
                 const float *sr = (actor_half ? g.gth.s1 : g.gth.s) + gsrc[j] * Sg;
                 const float *ar = g.gth.act + gsrc[j] * g.gth.a_elems - Sg;
@@ -640,11 +674,12 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         }
         float *outp = gidx ? (actor_half ? g.gth.x1sa : (e == 0 ? g.gth.xsa : nullptr))
                            : ((MODE == MODE_SAMPLE && g.copy_x) ? g.act_dst : nullptr);   // [s | .] for the critics
+        if (CONS) outp = nullptr;   // (the actor workgroup of the tile writes the [s' | a'] rows)
         const int64_t ldo_g = gidx ? (actor_half ? g.gth.ld_x1 : g.gth.ld_x) : g.ld_act;
 #pragma unroll
         for (int j = 0; j < XR; ++j) {
             const int r = xr0 + 16 * j;
-            const bool ok = xrok[j] && xk < IN;
+            const bool ok = xrok[j] && xk < XC;
             xs[r * ldx_s + xk] = ok ? xv[j] : 0.0f;
             if (ok && outp) outp[(int64_t)(m0 + r) * ldo_g + xk] = xv[j];
         }
@@ -656,7 +691,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int k = k0 + 32 * u;
-                    const bool okk = xrok[j] && k < IN;
+                    const bool okk = xrok[j] && k < XC;
                     if (gidx) {
                         const float *ar = g.gth.act + gsrc[j] * g.gth.a_elems - Sg;
                         wv[j][u] = (k < Sg ? xrow[j] : ar)[okk ? k : (k < Sg ? 0 : Sg)];
@@ -670,13 +705,13 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 for (int u = 0; u < 4; ++u) {
                     const int k = k0 + 32 * u, r = xr0 + 16 * j;
                     if (k < KP) {
-                        const bool okk = xrok[j] && k < IN;
+                        const bool okk = xrok[j] && k < XC;
                         xs[r * ldx_s + k] = okk ? wv[j][u] : 0.0f;
                         if (okk && outp) outp[(int64_t)(m0 + r) * ldo_g + k] = wv[j][u];
                     }
                 }
         }
-        if (gidx && actor_half && tid < TMR && (m0 + tid) < g.n_rows) {
+        if (gidx && actor_half && !CONS && tid < TMR && (m0 + tid) < g.n_rows) {
             const int64_t src = gidx[m0 + tid];
             g.gth.rew_out[m0 + tid] = g.gth.rew[src];
             g.gth.done_out[m0 + tid] = (float)g.gth.done[src];
@@ -705,9 +740,45 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         BSTAMP(2);
         stage_first(st2, Ws, H, tid);
         if (FWD_BWD) st3.init(P + g.off[2], H, H, tid);
+        float *wa = Ws1, *as_ = ys;   // (consumer) W1[:, S:S+A] as [H][A]; a' of the tile as [TMR][32] (ys | dqs: free until the head)
+        if (CONS) {
+            const int A_ = g.ho.A, na = H * A_;
+#pragma unroll
+            for (int u = 0; u < HANDOFF_MAX_WA; ++u) {
+                const int ei = tid + u * NTHR;
+                if (ei < na) wa[ei] = war[u];
+            }
+            const unsigned tag = g.ho.base + (g.ho.tick ? (unsigned)*g.ho.tick : 0u);
+            for (int t = tid; t < TMR * A_; t += NTHR) {
+                const int r = t / A_, i = t - r * A_, b = m0 + r;
+                float v = 0.0f;
+                if (b < g.n_rows) {
+                    const unsigned long long *gp = g.ho.pub + (int64_t)b * A_ + i;
+                    const long long t0 = __builtin_amdgcn_s_memtime();
+                    unsigned long long w;
+                    for (;;) {
+                        w = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(w >> 32) == tag) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (__builtin_amdgcn_s_memtime() - t0 > HANDOFF_SPIN_LIMIT) { w = 0x7fc00000ull; break; }   // (NaN: never silently stale)
+                    }
+                    v = __uint_as_float((unsigned)w);
+                }
+                as_[r * 32 + i] = v;
+            }
+            lds_barrier();
+        }
         T::foreach4(acc, lane, [&](int row, int cw, f4 val) {
             const int col = col0 + cw;  // 4 consecutive columns (H % 32 == 0: all four in range or none)
             if (col < H) {
+                if (CONS) {   // + a' W1[:, S:S+A]^T: the action part of fc1
+                    const int A_ = g.ho.A;
+                    for (int i = 0; i < A_; ++i) {
+                        const float av = as_[row * 32 + i];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) val[q] += av * wa[(col + q) * A_ + i];
+                    }
+                }
                 const f4 bq = *reinterpret_cast<const f4 *>(b1s + col);
                 f4 v;
 #pragma unroll
@@ -836,6 +907,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         // dimensions' log-probability terms in index order (the order a serial loop would use)
         const int A = OUT >> 1;
         float *lpt = dqs;  // [TMR][MAX_OUT] scratch, unused in this mode
+        const unsigned long long ho_tag = g.ho.pub ? (unsigned long long)(g.ho.base + (g.ho.tick ? (unsigned)*g.ho.tick : 0u)) << 32 : 0ull;
         for (int t = tid; t < TMR * A; t += NTHR) {
             const int r = t / A, i = t - r * A, b = m0 + r;
             if (b < g.n_rows) {
@@ -852,7 +924,11 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 const float dlt = u - mu;
                 lpt[r * ldo + i] = (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -
                                        2.0f * (LOG_2 - u - softplus_f(-2.0f * u));
-                g.act_dst[b * g.ld_act + g.act_col0 + i] = tanhf(u);
+                const float a_new = tanhf(u);
+                g.act_dst[b * g.ld_act + g.act_col0 + i] = a_new;
+                if (g.ho.pub)   // the tile's target-critic workgroups are polling for it
+                    __hip_atomic_store(g.ho.pub + (int64_t)b * A + i, ho_tag | (unsigned long long)__float_as_uint(a_new),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         lds_barrier();
@@ -1138,6 +1214,55 @@ void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs
 #endif
 }
 
+// The chained launch with the target chains cut into PRODUCER and CONSUMER workgroups (round 4).
+// In fused_chain_kernel a target chain is one workgroup running two dependent MLP passes -- actor on s', then the target
+// critic on [s'|a'] -- and every subset slot repeats the actor pass: 26 + 23 k clocks + a global round trip between
+// them, the longest workgroup of every under-filled launch.  Here:
+//   workgroups [0, tiles_a): the ACTOR of a 16-row tile, ONCE (not per slot): forward, tanh-normal sample, log pi, the
+//     [s'|a'] rows -- and a' published as tagged 8-byte granules (Handoff);
+//   tiles_t consumers: the TARGET CRITIC ids[j] of (slot j, tile): everything that does not need a' FIRST -- prologue, its
+//     own gather of the s' rows, fc1 on the state columns (the action columns of its x tile are zero) -- then it polls
+//     the tile's granules, adds a' W1[:, S:S+A]^T to the fc1 accumulators and runs on.  Its critical path behind the
+//     actor is fc2 + head (~14 k clocks) instead of a whole pass;
+//   the rest: the online critics' tiles, unchanged.
+// Producers take the first workgroup ids: they are dispatched before any consumer and never wait, so the polling cannot
+// deadlock whatever part of the grid is resident.  The rank-A update adds a' W1^T after the state columns' sum (the
+// one-pass kernel sums all columns of a K chunk in MFMA order): same value up to fp32 association.
+template <int TC, bool ADBUF>
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void fused_chain_pc_kernel(FusedArgs ga, FusedArgs gt, FusedArgs gc, int tiles_a, int tiles_t, int target_grid_x,
+                           int critic_grid_x, DeferredLogsArgs dl, int dl_on) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bid = blockIdx.x;
+    SSAC_LAB_ONLY(if (gc.tl && threadIdx.x == 0 && bid < 512) gc.tl[2 * bid] = __builtin_amdgcn_s_memrealtime();)
+    if (dl_on && bid == (int)gridDim.x - 1) {
+        deferred_logs_body(dl, -1);   // the PREVIOUS recorded update's log block -> its slot of the log ring
+        return;
+    }
+    // 32-row critic tiles (~58 k clocks) go before the consumers (~41 k from the launch's start, most of it waiting),
+    // 16-row critic tiles (~40 k) behind them
+    constexpr bool CRIT_FIRST = TC == 32;
+    const int n_main = (int)gridDim.x - (dl_on ? 1 : 0), n_crit = n_main - tiles_a - tiles_t;
+    const int t_lo = CRIT_FIRST ? tiles_a + n_crit : tiles_a, t_hi = t_lo + tiles_t;   // ids of the consumers
+    if (bid < tiles_a) {
+        fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga, smem, ssac_xcd_contiguous_range(bid, 0, tiles_a, gc.xcd), 0, tiles_a, 0);
+    } else if (bid >= t_lo && bid < t_hi) {
+        const int lb = ssac_xcd_contiguous_range(bid, t_lo, t_hi, gc.xcd);
+        const int j = lb / target_grid_x, bx = lb - j * target_grid_x;
+        fused_mlp_body<MODE_PLAIN, 16, true>(gt, smem, bx, j, target_grid_x, j == 0 ? 16 : -1);
+    } else {
+        const int c_lo = CRIT_FIRST ? tiles_a : t_hi;
+        const int L = ssac_xcd_contiguous_range(bid, c_lo, c_lo + n_crit, gc.xcd);
+        fused_mlp_body<MODE_CRITIC_U, TC, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x, 32);
+    }
+#ifdef SSAC_LAB
+    if (gc.tl && bid < 512) {
+        __syncthreads();
+        if (threadIdx.x == 0) gc.tl[2 * bid + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+
 long long *g_fused_dbg = nullptr;
 
 int g_tile_rows = 0;  // 0 = automatic, else 16 or 32 (ssac_fused_tile_rows)
@@ -1384,7 +1509,8 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
                                  float *logp, const ssac_rng *rng, const ssac_mlp *targets, const int32_t *net_ids,
                                  int n_sel, float *Qt, const ssac_mlp *critics, const float *Xc, int64_t ldxc,
                                  float *H1, float *H2, float *Q, float *DZ2u, float *DZ1u, float *W3_snapshot,
-                                 const ssac_gather *gather, const ssac_deferred_logs *deferred, void *stream) {
+                                 const ssac_gather *gather, const ssac_deferred_logs *deferred,
+                                 unsigned long long *handoff, void *stream) {
     if (!eps && !rng) return ssac_fail("ssac_chain_update: neither eps nor an rng stream given");
     if (!fused_ok(actor) || (actor->out_dim & 1) || !fused_dbuf_ok(targets) || !fused_dbuf_ok(critics))
         return ssac_fail("ssac_chain_update: shape not supported by the merged launch");
@@ -1446,8 +1572,34 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
     if (dl_on)
         dl = DeferredLogsArgs{deferred->partials, deferred->n_nets, deferred->sumsq, deferred->n_ss, deferred->td_stats,
                               deferred->td_off, deferred->n_rows, deferred->denom, deferred->feed};
-    const dim3 grid(tiles_t + cgx * critics->n_nets + dl_on);
     hipStream_t st = (hipStream_t)stream;
+    const int A_ = actor->out_dim / 2;
+    if (handoff && A_ <= 32 && targets->hidden * A_ <= NTHR * HANDOFF_MAX_WA) {
+        // producer / consumer form (fused_chain_pc_kernel): the actor ONCE per tile, a' handed to the tile's target critics
+        static unsigned launch_no = 0;   // tags of eager launches: bit 31 set, so they never meet a recorded launch's
+        Handoff ho{handoff, nullptr, 0u, actor->in_dim, A_};
+        if (gather && gather->feed) { ho.tick = reinterpret_cast<const long long *>(&gather->feed->tick); ho.base = 1u; }
+        else ho.base = 0x80000000u | (++launch_no & 0x7fffffffu);
+        ga.ho = ho;
+        gt.ho = ho;
+        if (gather) { gt.gth = *gather; gt.gth_role = 5; }
+        static bool pc_attr = false;
+        if (!pc_attr) {
+            const void *ks[4] = {(const void *)fused_chain_pc_kernel<16, true>, (const void *)fused_chain_pc_kernel<32, true>,
+                                 (const void *)fused_chain_pc_kernel<16, false>, (const void *)fused_chain_pc_kernel<32, false>};
+            for (const void *k : ks)
+                if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                    return ssac_fail("fused_chain_pc: cannot raise the dynamic LDS limit");
+            pc_attr = true;
+        }
+        const dim3 grid_pc(tgx + tiles_t + cgx * critics->n_nets + dl_on);
+        if (tc == 16 && adbuf) SSAC_LAUNCH((fused_chain_pc_kernel<16, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_t, tgx, cgx, dl, dl_on);
+        else if (adbuf) SSAC_LAUNCH((fused_chain_pc_kernel<32, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_t, tgx, cgx, dl, dl_on);
+        else if (tc == 16) SSAC_LAUNCH((fused_chain_pc_kernel<16, false>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_t, tgx, cgx, dl, dl_on);
+        else SSAC_LAUNCH((fused_chain_pc_kernel<32, false>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_t, tgx, cgx, dl, dl_on);
+        return ssac_check_launch("fused_chain_pc");
+    }
+    const dim3 grid(tiles_t + cgx * critics->n_nets + dl_on);
     if (tc == 16 && adbuf) SSAC_LAUNCH((fused_chain_kernel<16, true>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx, dl, dl_on);
     else if (adbuf) SSAC_LAUNCH((fused_chain_kernel<32, true>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx, dl, dl_on);
     else if (tc == 16) SSAC_LAUNCH((fused_chain_kernel<16, false>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx, dl, dl_on);

@@ -253,6 +253,9 @@ class _Batch:
 
 # actor sample -> target critics chained per workgroup, beside the critics' forward + unscaled backward: ONE launch
 CHAIN_LAUNCH = True
+# the chained launch in its producer / consumer form (the actor once per tile, the target critics start before a' exists);
+# a module constant that tests flip to compare the two forms
+CHAIN_PC = True
 
 
 def parallel_shard_of(agent):
@@ -691,6 +694,9 @@ def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict)
     # (the head rows W3 as THIS launch sees them: the weight-gradient launch that rebuilds dz2u from h2 cannot read the
     #  arena's W3 -- its own head workgroups are updating it while the fc2 tiles run)
     w3s = ws.get(tag + ".w3s", (c_arena.n_nets, c_arena.hidden))
+    # producer / consumer form of the launch (csrc/ssac_fused.hip, fused_chain_pc_kernel): the actor once per tile, a'
+    # handed to the tile's target-critic workgroups through tagged granules in this buffer (zeroed once: tag 0 is never used)
+    ho = ws.get(tag + ".handoff", (B * A,), dtype=torch.int64, zero=True) if CHAIN_PC else None
     with engine._timed("chain") as tm:
         for _ in range(tm.reps):  # 1, except under bench.py's live kernel timing (the launch is idempotent)
             check(lib.ssac_chain_update(
@@ -699,7 +705,8 @@ def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict)
                 ch["logp"].data_ptr(), ch["rng_ptr"], C.byref(t_arena.desc()), ids_ptr, n,
                 q1.data_ptr(), C.byref(c_arena.desc()), Xc.data_ptr(), ldxc, h1.data_ptr(), h2.data_ptr(),
                 qc.data_ptr(), 0 if skip_dz2 else dz2u.data_ptr(), dz1u.data_ptr(), w3s.data_ptr(),
-                C.byref(gth) if gth is not None else 0, dl_ptr, engine.stream()))
+                C.byref(gth) if gth is not None else 0, dl_ptr, ho.data_ptr() if ho is not None else 0,
+                engine.stream()))
     if skip_dz2:
         replay_dict["_dz2_skipped"] = w3s   # (the weight-gradient launch rebuilds dz2u from h2 and this W3 copy)
     replay_dict["_co_bwd"] = True

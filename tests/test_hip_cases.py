@@ -37,6 +37,28 @@ def test_engine_matches_reference(name, fused, wgrad):
     print(f"{name}: worst deviations vs reference {worst}")
 
 
+@pytest.mark.parametrize("name", ["redq_small", "pendulum_sac", "redq_M", "redq_S", "redq_c2"])
+def test_chained_launch_forms_match_reference_and_each_other(name):
+    """the chained launch (everything of a critic update that does not need the TD target) in its two forms: ONE
+    workgroup per target chain (actor pass, then the target-critic pass, the actor repeated per subset slot) and the
+    PRODUCER / CONSUMER form (the actor once per 16-row tile; the tile's target-critic workgroups gather their own s'
+    rows, run fc1 on the state columns, poll the tagged a' granules and add a' W1[:, S:]^T).  Both land on the reference
+    fixture; their TD targets agree to fp32 association of fc1's sum."""
+    import super_sac_amd as ssa
+    recs = {}
+    for pc in (False, True):
+        old = ssa.learning_utils.CHAIN_PC
+        ssa.learning_utils.CHAIN_PC = pc
+        try:
+            recs[pc] = case_runner.run_engine(name)
+        finally:
+            ssa.learning_utils.CHAIN_PC = old
+        case_runner.compare(recs[pc], case_runner.load_fixture(name), who=f"hip[{name}, chain {'producer/consumer' if pc else 'one workgroup'}]")
+    for key in recs[True]:
+        if "_td" in key:
+            assert np.max(np.abs(recs[True][key] - recs[False][key])) <= 2e-5, key
+
+
 @pytest.mark.parametrize("name", ["redq_small", "sac_popart", "sac_discrete", "td3_noise"])
 def test_update_functions_adopt_a_foreign_agent(name):
     """an agent that carries ONLY the reference classes' attributes (tests/foreign_agent.py: no arena(), no

@@ -34,6 +34,17 @@ for rep in range(3):
         s, e = a[:, 0] - t0, a[:, 1] - t0
         print(f"[{rep}] {name}: {n} workgroups; starts {s.min():.2f} .. {s.max():.2f} us (median {np.median(s):.2f}); "
               f"ends {e.min():.2f} .. {e.max():.2f}; durations min {np.min(e - s):.2f} median {np.median(e - s):.2f} max {np.max(e - s):.2f}")
+        if rep == 2 and name.startswith("chained") and ssa.learning_utils.CHAIN_PC:
+            tiles = (B + 15) // 16
+            crit16 = n - 3 * tiles >= 0 and (n - 3 * tiles) == tiles * N   # 16-row critic tiles: [producers | consumers | critics]
+            if crit16:
+                groups = (("actor producers", 0, tiles), ("target consumers", tiles, 3 * tiles), ("critic tiles (16 rows)", 3 * tiles, n))
+            else:
+                nc = n - 3 * tiles
+                groups = (("actor producers", 0, tiles), ("critic tiles (32 rows)", tiles, tiles + nc), ("target consumers", tiles + nc, n))
+            for gname, lo, hi in groups:
+                print(f"      {gname:24s} start {s[lo:hi].min():6.2f}..{s[lo:hi].max():6.2f}  end {e[lo:hi].min():6.2f}..{e[lo:hi].max():6.2f}  "
+                      f"duration {np.min((e - s)[lo:hi]):6.2f}..{np.max((e - s)[lo:hi]):6.2f} (median {np.median((e - s)[lo:hi]):6.2f})")
         if rep == 2 and name.startswith("weight") and n == sum(c for c, _ in small) * N + 1:
             # (hardware order: classes are interleaved per XCD; report by duration clusters instead)
             d = np.sort(e - s)

@@ -122,7 +122,10 @@ typedef struct ssac_td_spec {
     const float *log_alpha;  /* scalar, read when use_entropy */
     float *td_out;           /* (n_rows) the targets, written by the launch (for logs / replay dicts) */
     float gamma;
-    int32_t n_sel, use_entropy, _pad;
+    int32_t n_sel, use_entropy;
+    int32_t n_parts;         /* 0 / 1: q_t is (n_sel x n_rows).  > 1: every slot's value arrives in n_parts partial sums,
+                                q_t[(j n_parts + s)][b], s < n_parts (column-split target critics, ssac_chain_update); the
+                                slot's value is their sum in index order (part 0 carries the head's bias) */
 } ssac_td_spec;
 
 /* Engine noise stream (SURVEY 8(b) RNG contract: "device noise from an engine Philox stream"): standard normals
@@ -195,7 +198,10 @@ int ssac_xchg_reduce(ssac_xchg *x, float *data, int n, int op, void *stream);
  * device memory, n_slots int32 entries as every rank composes them from the same draw (agent.py:29): >= 0 a member this
  * rank owns (its local index), -(r + 1) a member rank r owns.  Ranks that own none write nothing; every rank waits for
  * the owners' flags only.  Same bits as ssac_xchg_reduce on partials that are +inf wherever a rank owns nothing. */
-int ssac_xchg_reduce_owned(ssac_xchg *x, float *data, int n, const int32_t *owners, int n_slots, void *stream);
+int ssac_xchg_reduce_owned(ssac_xchg *x, float *data, int n, const int32_t *owners, int n_slots,
+                           int n_parts /* 1; > 1: data holds every slot's n / n_slots values as n_parts partial sums
+                                          (ssac_td_spec.n_parts): summed before they are sent, the result in part 0 */,
+                           void *stream);
 int ssac_xchg_error(ssac_xchg *x);   /* 1: a peer's flag did not arrive within the spin bound since the last call (the result
                                         was poisoned with NaN); a pinned host word, cleared by the read, no synchronisation */
 /* Flow control: every rank acknowledges the exchanges it has consumed and a sender reuses slot seq % 4 only when every
@@ -684,12 +690,17 @@ int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t ldxa, int 
                       float *DZ2u /* NULL: not written; W3_snapshot (n_nets x hidden) is filled instead */, float *DZ1u,
                       float *W3_snapshot, const ssac_gather *gather,
                       const ssac_deferred_logs *deferred /* nullable */,
-                      unsigned long long *handoff /* nullable: n_rows x A words, zeroed once */, void *stream);
+                      unsigned long long *handoff /* nullable: n_rows x A words, zeroed once */,
+                      int target_splits /* 1, 2, 4: ssac_chain_target_splits() */, void *stream);
 /* handoff != NULL selects the PRODUCER / CONSUMER form of the launch: the actor runs ONCE per 16-row tile (not once per
  * subset slot) and publishes a' as tagged 8-byte granules in `handoff`; the target-critic workgroups of the tile gather
  * their own s' rows, run fc1 on the state columns while the actor is still working, poll the granules and add
  * a' W1[:, S:S+A]^T -- their critical path behind the actor is fc2 + head instead of a whole MLP pass.  Same outputs up
- * to fp32 association of fc1's sum (the action columns enter last). */
+ * to fp32 association of fc1's sum (the action columns enter last).
+ * target_splits > 1 (hidden 256, with handoff): every (slot, tile) gets that many consumers, each computing hidden /
+ * target_splits columns of fc2 from register-resident weight fragments and a PARTIAL head dot product; Qt is then
+ * (n_sel x target_splits x n_rows), to be read through an ssac_td_spec with n_parts = target_splits. */
+int ssac_chain_target_splits(const ssac_mlp *actor, const ssac_mlp *targets, const ssac_mlp *critics, int n_rows, int n_sel);
 
 /* ---- the online actor update (learning.py:344-421) in four launches:
  *   ssac_actor_sample_concat_fused   actor forward (h1 / h2 / head output saved) + tanh-normal rsample + log pi, the rows

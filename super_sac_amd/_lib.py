@@ -48,7 +48,7 @@ class TdSpec(C.Structure):
     """struct ssac_td_spec"""
     _fields_ = [("q_t", C.c_void_p), ("logp", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p),
                 ("log_alpha", C.c_void_p), ("td_out", C.c_void_p), ("gamma", C.c_float),
-                ("n_sel", C.c_int32), ("use_entropy", C.c_int32), ("_pad", C.c_int32)]
+                ("n_sel", C.c_int32), ("use_entropy", C.c_int32), ("n_parts", C.c_int32)]
 
 
 class PushField(C.Structure):
@@ -96,7 +96,7 @@ SIGNATURES = {
     "ssac_xchg_handle": [_P, _P],
     "ssac_xchg_connect": [_P, _P],
     "ssac_xchg_reduce": [_P, _P, _I, _I, _P],
-    "ssac_xchg_reduce_owned": [_P, _P, _I, _P, _I, _P],
+    "ssac_xchg_reduce_owned": [_P, _P, _I, _P, _I, _I, _P],
     "ssac_bc_det_logprob_bwd": [_P, _L, _P, _L, _P, _I, _I, _F, _P, _L, _P, _P, _P],
     "ssac_action_invariance_det_bwd": [_P, _L, _P, _L, _I, _I, _F, _P, _L, _P, _P, _P],
     "ssac_per_assign": [_P, _P, _L, _P, _I, _P, _I, C.c_double, _P, _I, _L, _P, _P, _P],
@@ -206,7 +206,8 @@ SIGNATURES = {
     "ssac_actor_sample_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _P, _P, _P, _P],
     "ssac_actor_sample_critic_fwd": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _L, _P, _P, _P, _P, _P],
     "ssac_chain_update": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _I, _P, _MP, _P, _L, _P, _P, _P, _P, _P,
-                          _P, _P, _P, _P, _P],
+                          _P, _P, _P, _P, _I, _P],
+    "ssac_chain_target_splits": [_MP, _MP, _MP, _I, _I],
     "ssac_deferred_logs_flush": [_P, _I, _P],
     "ssac_philox_normal": [_P, _I, _I, _P, _P],
     "ssac_actor_sample_concat_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _P, _P, _P, _P, _P, _P],

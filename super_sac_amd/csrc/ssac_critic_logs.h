@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "ssac_hip.h"
+#include "ssac_internal.h"
 
 struct CriticLogsArgs {
     const float *partials; int n_nets, tiles, n_rows; float denom;
@@ -126,8 +127,7 @@ struct LossFoldArgs {
 };
 
 __device__ __forceinline__ float ssac_lazy_td(const ssac_td_spec &t, int b, int n_rows, float alpha) {
-    float mq = t.q_t[b];
-    for (int j = 1; j < t.n_sel; ++j) mq = fminf(mq, t.q_t[(int64_t)j * n_rows + b]);
+    const float mq = ssac_td_min_q(t, b, n_rows);
     const float bonus = t.use_entropy ? alpha * t.logp[b] : 0.0f;
     const float val = mq - bonus;
     return t.rew[b] + t.gamma * (1.0f - t.done[b]) * val;
@@ -175,25 +175,33 @@ __device__ __forceinline__ void loss_fold_table(const LossFoldArgs &a, int e, fl
 // threadIdx.x) are REQUESTED before the tile's first operand chunk and the table is finished while that chunk is in
 // flight -- vector-memory returns are in order, so loads issued behind the operand chunk would wait for it.
 // Same arithmetic, operation by operation, as loss_fold_table.
-struct LossFoldRegs { float q, t0, t1, lp, rew, done, w, la; };
+struct LossFoldRegs { float q, t0, t1, t2, t3, lp, rew, done, w, la; };
 
 __device__ __forceinline__ void loss_fold_issue(const LossFoldArgs &a, int e, LossFoldRegs &r) {
     const int b = threadIdx.x, n_rows = a.n_rows;
-    r = LossFoldRegs{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f};
-    if (a.tds.q_t && a.tds.use_entropy) r.la = a.tds.log_alpha[0];
+    // (named scalars, one unconditional assignment of the struct at the end: with conditional stores into the fields the
+    // compiler merged two of them into ONE store at a run-time offset -- i.e. the struct went to scratch memory, 12 bytes
+    // per lane in every kernel that inlines this)
+    float q = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, lp = 0.f, rew = 0.f, done = 0.f, w = 1.f, la = 0.f;
+    const bool lazy = a.tds.q_t != nullptr;
+    if (lazy && a.tds.use_entropy) la = a.tds.log_alpha[0];
     if (b < n_rows) {
-        r.q = a.q[(int64_t)e * n_rows + b];
-        if (a.weight) r.w = a.weight[b];
-        if (a.tds.q_t) {
-            r.t0 = a.tds.q_t[b];
-            if (a.tds.n_sel > 1) r.t1 = a.tds.q_t[(int64_t)n_rows + b];
-            if (a.tds.use_entropy) r.lp = a.tds.logp[b];
-            r.rew = a.tds.rew[b];
-            r.done = a.tds.done[b];
-        } else {
-            r.t0 = a.td[b];
+        q = a.q[(int64_t)e * n_rows + b];
+        if (a.weight) w = a.weight[b];
+        // (the first four entries of the [n_sel x n_parts] list: two slots, or two slots of two partials each)
+        const int ne = lazy ? a.tds.n_sel * (a.tds.n_parts > 1 ? a.tds.n_parts : 1) : 1;
+        const float *tp = lazy ? a.tds.q_t : a.td;
+        t0 = tp[b];
+        if (ne > 1) t1 = tp[(int64_t)n_rows + b];
+        if (ne > 2) t2 = tp[(int64_t)2 * n_rows + b];
+        if (ne > 3) t3 = tp[(int64_t)3 * n_rows + b];
+        if (lazy) {
+            if (a.tds.use_entropy) lp = a.tds.logp[b];
+            rew = a.tds.rew[b];
+            done = a.tds.done[b];
         }
     }
+    r = LossFoldRegs{q, t0, t1, t2, t3, lp, rew, done, w, la};
 }
 
 // the caller synchronises (LDS hand-off) before reading tab
@@ -206,9 +214,18 @@ __device__ __forceinline__ void loss_fold_finish(const LossFoldArgs &a, int e, c
     if (tid < n_rows) {
         float t = r.t0;
         if (a.tds.q_t) {
-            float mq = r.t0;
-            if (a.tds.n_sel > 1) mq = fminf(mq, r.t1);
-            for (int j = 2; j < a.tds.n_sel; ++j) mq = fminf(mq, a.tds.q_t[(int64_t)j * n_rows + tid]);
+            // min over the slots of the slot's value = the sum of its partials (entry e = j n_parts + s of the list; the
+            // first four entries are in registers) -- ssac_td_min_q, operation by operation
+            const int np = a.tds.n_parts > 1 ? a.tds.n_parts : 1;
+            auto entry = [&](int e_) {
+                return e_ == 0 ? r.t0 : e_ == 1 ? r.t1 : e_ == 2 ? r.t2 : e_ == 3 ? r.t3 : a.tds.q_t[(int64_t)e_ * n_rows + tid];
+            };
+            float mq = 0.0f;
+            for (int j = 0; j < a.tds.n_sel; ++j) {
+                float v = entry(j * np);
+                for (int s_ = 1; s_ < np; ++s_) v += entry(j * np + s_);
+                mq = j == 0 ? v : fminf(mq, v);
+            }
             const float bonus = a.tds.use_entropy ? alpha * r.lp : 0.0f;
             const float val = mq - bonus;
             t = r.rew + a.tds.gamma * (1.0f - r.done) * val;

@@ -343,8 +343,7 @@ __global__ __launch_bounds__(RED_THREADS) void critic_loss_bwd_kernel(
         // the TD targets are evaluated here (ssac_td_spec: same arithmetic and order as td_target_kernel) ...
         const float alpha = tds.use_entropy ? expf(tds.log_alpha[0]) : 0.0f;
         for (int b = threadIdx.x; b < n_rows; b += blockDim.x) {
-            float mq = tds.q_t[b];
-            for (int j = 1; j < tds.n_sel; ++j) mq = fminf(mq, tds.q_t[(int64_t)j * n_rows + b]);
+            const float mq = ssac_td_min_q(tds, b, n_rows);
             const float bonus = tds.use_entropy ? alpha * tds.logp[b] : 0.0f;
             const float val = mq - bonus;
             tds.td_out[b] = tds.rew[b] + tds.gamma * (1.0f - tds.done[b]) * val;

@@ -76,6 +76,7 @@ struct Handoff {
     const long long *tick;      // device-resident update counter, or null
     unsigned base;
     int S, A;                   // the consumer's input columns [S, S + A) arrive through pub
+    int nsplit;                 // consumers per (slot, tile): > 1 = each takes hidden / nsplit columns of fc2 (below)
 };
 constexpr long long HANDOFF_SPIN_LIMIT = 4000000000LL;   // shader clocks (~2 s): a producer that never arrives poisons, never hangs
 constexpr int HANDOFF_MAX_WA = 9;   // W1's action columns per thread (H * A <= 512 * 9: 256 x 18)
@@ -112,8 +113,7 @@ struct FusedArgs {
 // TD target of row b (see ssac_td_spec; same operation order as td_target_kernel in ssac_elementwise.hip)
 __device__ __forceinline__ float td_of_row(const FusedArgs &g, int b, int e) {
     if (!g.tds.q_t) return g.td[b];
-    float mq = g.tds.q_t[b];
-    for (int j = 1; j < g.tds.n_sel; ++j) mq = fminf(mq, g.tds.q_t[(int64_t)j * g.n_rows + b]);
+    const float mq = ssac_td_min_q(g.tds, b, g.n_rows);
     const float alpha = g.tds.use_entropy ? expf(g.tds.log_alpha[0]) : 0.0f;
     const float bonus = g.tds.use_entropy ? alpha * g.tds.logp[b] : 0.0f;
     const float val = mq - bonus;
@@ -481,9 +481,11 @@ __device__ __forceinline__ void stage_head_weights(float *w3s, const float *__re
 // gridDim of a plain launch, or the position inside one half of a merged launch (fused_dual_kernel).
 // dbg_off: slot offset of this role's phase stamps in the debug buffer (-1: none); the kernel parameters themselves are
 // never modified (a by-value parameter that is written to is copied to scratch memory, all ~500 bytes of it)
-template <int MODE, int TMR, bool DBUF>
+// HO: this instantiation may be the CONSUMER of a hand-off (fused_chain_pc_kernel's target-critic workgroups only: the
+// register-resident weight fragments of the column-split form must not weigh on the other kernels' register budgets)
+template <int MODE, int TMR, bool DBUF, bool HO = false>
 __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, const int bx, const int e,
-                                               const int grid_x, const int dbg_off = 0) {
+                                               const int grid_x, const int dbg_off = 0, const int split = 0) {
     typedef Tile<TMR> T;
     const int H = g.hidden, IN = g.in_dim, OUT = g.out_dim;
     const int ldo = (OUT + 15) & ~15;  // row stride of the per-row head outputs / output gradients in LDS
@@ -530,11 +532,14 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     if (net < 0) {
         // slot without a net (a REDQ subset member another rank owns): its outputs are +inf, the neutral
         // element of the min that follows, so a sharded launch sequence is the same for every subset draw
-        if (MODE == MODE_PLAIN && g.Y)
+        if (MODE == MODE_PLAIN && g.Y) {
+            const int nsp = (HO && TMR == 16 && g.ho.pub && g.ho.nsplit > 1) ? g.ho.nsplit : 1;   // (split consumers: +inf in part 0, 0 elsewhere)
             for (int i = threadIdx.x; i < TMR * OUT; i += NTHR) {
                 const int r = i / OUT, o = i - r * OUT;
-                if ((m0 + r) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + r) * OUT + o] = __builtin_inff();
+                if ((m0 + r) < g.n_rows)
+                    g.Y[(((int64_t)e * nsp + split) * g.n_rows + m0 + r) * OUT + o] = split == 0 ? __builtin_inff() : 0.0f;
             }
+        }
         return;
     }
     const float *P = g.params + (int64_t)net * g.net_stride;
@@ -611,7 +616,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         // CONSUMER of a hand-off (MODE_PLAIN, role 5 / no gather): the input's state columns are fetched here -- s' rows
         // from the replay arrays or from X -- the action columns [S, S + A) stay ZERO in the x tile: fc1 runs on the state
         // part while the actor workgroup of the tile is still sampling, a' W1[:, S:]^T is added when it arrives
-        const bool CONS = MODE == MODE_PLAIN && TMR == 16 && g.ho.pub != nullptr;
+        const bool CONS = HO && MODE == MODE_PLAIN && TMR == 16 && g.ho.pub != nullptr;
         const int XC = CONS ? g.ho.S : IN;   // columns of the x tile that are loaded
         int64_t gsrc[XR];
         bool xrok[XR];
@@ -644,6 +649,31 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 const int c = ei / g.ho.A, i = ei - c * g.ho.A;
                 war[u] = W1[ei < na ? (int64_t)c * IN + g.ho.S + i : 0];
             }
+        }
+        // COLUMN-SPLIT consumer (ho.nsplit = 2 or 4 workgroups per (slot, tile), hidden 256): this workgroup computes
+        // hidden / nsplit columns of fc2 -- the waves form CG column groups of 32 x KG K-groups -- and its weights never
+        // touch LDS: a lane's MFMA fragments of W2[its 32 columns][its K range] are requested HERE, 16-byte loads
+        // straight into registers, and wait there while fc1 runs and the hand-off is polled.  Behind a' the workgroup then
+        // has no memory access left but its LDS: NCH x 16 MFMAs per wave, a sum over the K-groups, the head's partial dot
+        // product -- q_t[(slot nsplit + split)][row], summed by the TD evaluation (ssac_td_spec.n_parts).
+        const int NSPL = (CONS && g.ho.nsplit > 1) ? g.ho.nsplit : 1;
+        constexpr int MAXCH = 4;            // K chunks of 32 per wave: 4 (nsplit 2) or 2 (nsplit 4)
+        f4 wq[MAXCH][2][2];
+        const int CG_ = 8 / NSPL;           // column groups of 32 inside the workgroup's hidden / nsplit columns
+        const int KG_ = 8 / CG_, KK_ = H / KG_, NCH_ = KK_ >> 5;
+        const int scg = wave % CG_, skg = wave / CG_;
+        const int scb = split * (H / NSPL) + scg * 32, skb = skg * KK_;
+        if (NSPL > 1) {
+            const float *W2 = P + g.off[2];
+            const int li_ = lane & 15, lg_ = lane >> 4;
+#pragma unroll
+            for (int c = 0; c < MAXCH; ++c)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f4 *bp = reinterpret_cast<const f4 *>(W2 + (int64_t)(scb + 16 * u + li_) * H + skb + 32 * (c < NCH_ ? c : 0) + lg_ * 8);
+                    wq[c][u][0] = bp[0];
+                    wq[c][u][1] = bp[1];
+                }
         }
         const float *xrow[XR];
         float xv[XR];
@@ -738,7 +768,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         T::zero(acc);
         gemm_tile<TMR, false, DBUF>(acc, st1, xs, ldx_s, IN, Ws, Ws1, tid, col0, st2, H);
         BSTAMP(2);
-        stage_first(st2, Ws, H, tid);
+        if (NSPL == 1) stage_first(st2, Ws, H, tid);
         if (FWD_BWD) st3.init(P + g.off[2], H, H, tid);
         float *wa = Ws1, *as_ = ys;   // (consumer) W1[:, S:S+A] as [H][A]; a' of the tile as [TMR][32] (ys | dqs: free until the head)
         if (CONS) {
@@ -790,6 +820,47 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         });
         lds_barrier();
         BSTAMP(3);
+        if (TMR == 16 && NSPL > 1) {
+            // ---- column-split consumer: fc2 on this workgroup's columns from the register-resident fragments
+            typename Tile<16>::Acc a2;
+            Tile<16>::zero(a2);
+            const int li_ = lane & 15, lg_ = lane >> 4;
+#pragma unroll
+            for (int c = 0; c < MAXCH; ++c) {
+                if (c < NCH_) {
+                    const f4 *ap = reinterpret_cast<const f4 *>(h1s + li_ * ldh + skb + 32 * c + lg_ * 8);
+                    const f4 a0 = ap[0], a1 = ap[1];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            a2.v[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[c][u][t >> 2][t & 3], t < 4 ? a0[t & 3] : a1[t & 3],
+                                                                           a2.v[u], 0, 0, 0);
+                }
+            }
+            // the K-groups' partial tiles meet in LDS (staging buffer 0 is free: no fc2 staging in this form)
+            float *redk = Ws;   // [8 waves][16 rows][32 columns]
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) redk[(wave * 16 + li_) * 32 + 16 * u + 4 * lg_ + r] = a2.v[u][r];
+            lds_barrier();
+            // thread t: row t / 32, columns (t % 32) + 32 i of the workgroup's CW: bias, ReLU, times W3, summed per row
+            const int CW = H / NSPL, row = tid >> 5, c0_ = tid & 31;
+            float qp_ = 0.0f;
+            for (int i = 0; i < CW / 32; ++i) {
+                float v = 0.0f;
+                for (int kg = 0; kg < KG_; ++kg) v += redk[((kg * CG_ + i) * 16 + row) * 32 + c0_];
+                const int col = split * CW + 32 * i + c0_;
+                v = fmaxf(v + b2s[col], 0.0f);
+                qp_ += v * w3s[col];
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) qp_ += __shfl_xor(qp_, o, 64);   // (the row's 32 threads are half a wave)
+            if (c0_ == 0 && g.Y && (m0 + row) < g.n_rows)
+                g.Y[((int64_t)e * NSPL + split) * g.n_rows + m0 + row] = split == 0 ? qp_ + b3s[0] : qp_;
+            return;
+        }
         // ---- fc2 (the backward-data phase re-reads W2 as a row-contiguous image: its first chunk is
         //      requested during fc2's last K chunk)
         T::zero(acc);
@@ -1248,8 +1319,10 @@ void fused_chain_pc_kernel(FusedArgs ga, FusedArgs gt, FusedArgs gc, int tiles_a
         fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga, smem, ssac_xcd_contiguous_range(bid, 0, tiles_a, gc.xcd), 0, tiles_a, 0);
     } else if (bid >= t_lo && bid < t_hi) {
         const int lb = ssac_xcd_contiguous_range(bid, t_lo, t_hi, gc.xcd);
-        const int j = lb / target_grid_x, bx = lb - j * target_grid_x;
-        fused_mlp_body<MODE_PLAIN, 16, true>(gt, smem, bx, j, target_grid_x, j == 0 ? 16 : -1);
+        const int per_slot = target_grid_x * (gt.ho.nsplit > 1 ? gt.ho.nsplit : 1);   // consumers of a subset slot
+        const int j = lb / per_slot, rem = lb - j * per_slot;
+        const int sp = rem / target_grid_x, bx = rem - sp * target_grid_x;
+        fused_mlp_body<MODE_PLAIN, 16, true, true>(gt, smem, bx, j, target_grid_x, (j == 0 && sp == 0) ? 16 : -1, sp);
     } else {
         const int c_lo = CRIT_FIRST ? tiles_a : t_hi;
         const int L = ssac_xcd_contiguous_range(bid, c_lo, c_lo + n_crit, gc.xcd);
@@ -1510,8 +1583,11 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
                                  int n_sel, float *Qt, const ssac_mlp *critics, const float *Xc, int64_t ldxc,
                                  float *H1, float *H2, float *Q, float *DZ2u, float *DZ1u, float *W3_snapshot,
                                  const ssac_gather *gather, const ssac_deferred_logs *deferred,
-                                 unsigned long long *handoff, void *stream) {
+                                 unsigned long long *handoff, int target_splits, void *stream) {
     if (!eps && !rng) return ssac_fail("ssac_chain_update: neither eps nor an rng stream given");
+    if (target_splits != 1 && target_splits != 2 && target_splits != 4) return ssac_fail("ssac_chain_update: target_splits is 1, 2 or 4");
+    if (target_splits > 1 && (!handoff || targets->hidden != 256))
+        return ssac_fail("ssac_chain_update: column-split target critics need the hand-off form and hidden 256");
     if (!fused_ok(actor) || (actor->out_dim & 1) || !fused_dbuf_ok(targets) || !fused_dbuf_ok(critics))
         return ssac_fail("ssac_chain_update: shape not supported by the merged launch");
     if (critics->out_dim != 1 || targets->out_dim != 1) return ssac_fail("ssac_chain_update: single-output critics only");
@@ -1577,8 +1653,12 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
     if (handoff && A_ <= 32 && targets->hidden * A_ <= NTHR * HANDOFF_MAX_WA) {
         // producer / consumer form (fused_chain_pc_kernel): the actor ONCE per tile, a' handed to the tile's target critics
         static unsigned launch_no = 0;   // tags of eager launches: bit 31 set, so they never meet a recorded launch's
-        Handoff ho{handoff, nullptr, 0u, actor->in_dim, A_};
-        if (gather && gather->feed) { ho.tick = reinterpret_cast<const long long *>(&gather->feed->tick); ho.base = 1u; }
+        Handoff ho{handoff, nullptr, 0u, actor->in_dim, A_, target_splits};
+        // (a RECORDED launch re-issues these very argument bytes: its tag must come from device memory -- the update
+        // counter of the input ring, reached through the gather or the deferred-log struct; the caller passes no hand-off
+        // buffer for a recording that has neither)
+        const ssac_feed *fd = (gather && gather->feed) ? gather->feed : ((deferred && deferred->feed) ? deferred->feed : nullptr);
+        if (fd) { ho.tick = reinterpret_cast<const long long *>(&fd->tick); ho.base = 1u; }
         else ho.base = 0x80000000u | (++launch_no & 0x7fffffffu);
         ga.ho = ho;
         gt.ho = ho;
@@ -1592,19 +1672,37 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
                     return ssac_fail("fused_chain_pc: cannot raise the dynamic LDS limit");
             pc_attr = true;
         }
-        const dim3 grid_pc(tgx + tiles_t + cgx * critics->n_nets + dl_on);
-        if (tc == 16 && adbuf) SSAC_LAUNCH((fused_chain_pc_kernel<16, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_t, tgx, cgx, dl, dl_on);
-        else if (adbuf) SSAC_LAUNCH((fused_chain_pc_kernel<32, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_t, tgx, cgx, dl, dl_on);
-        else if (tc == 16) SSAC_LAUNCH((fused_chain_pc_kernel<16, false>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_t, tgx, cgx, dl, dl_on);
-        else SSAC_LAUNCH((fused_chain_pc_kernel<32, false>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_t, tgx, cgx, dl, dl_on);
+        const int tiles_c = tiles_t * target_splits;   // consumers: one per (slot, column split, tile)
+        const dim3 grid_pc(tgx + tiles_c + cgx * critics->n_nets + dl_on);
+        if (tc == 16 && adbuf) SSAC_LAUNCH((fused_chain_pc_kernel<16, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
+        else if (adbuf) SSAC_LAUNCH((fused_chain_pc_kernel<32, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
+        else if (tc == 16) SSAC_LAUNCH((fused_chain_pc_kernel<16, false>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
+        else SSAC_LAUNCH((fused_chain_pc_kernel<32, false>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
         return ssac_check_launch("fused_chain_pc");
     }
+    if (target_splits != 1) return ssac_fail("ssac_chain_update: column-split target critics need the hand-off form");
     const dim3 grid(tiles_t + cgx * critics->n_nets + dl_on);
     if (tc == 16 && adbuf) SSAC_LAUNCH((fused_chain_kernel<16, true>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx, dl, dl_on);
     else if (adbuf) SSAC_LAUNCH((fused_chain_kernel<32, true>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx, dl, dl_on);
     else if (tc == 16) SSAC_LAUNCH((fused_chain_kernel<16, false>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx, dl, dl_on);
     else SSAC_LAUNCH((fused_chain_kernel<32, false>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx, dl, dl_on);
     return ssac_check_launch("fused_chain");
+}
+
+// How many column splits of the target critics ssac_chain_update should be given for this shape: the largest of 4, 2, 1
+// for which the whole launch -- one actor workgroup per tile, n_sel x splits consumers per tile, the online critics' tiles,
+// the log workgroup -- is still ONE resident round of workgroups (256 CUs, one 512-thread workgroup each).
+extern "C" int ssac_chain_target_splits(const ssac_mlp *actor, const ssac_mlp *targets, const ssac_mlp *critics, int n_rows,
+                                        int n_sel) {
+    if (!actor || !targets || !critics || n_rows <= 0 || n_sel <= 0) return 1;
+    if (targets->hidden != 256 || targets->out_dim != 1 || actor->out_dim / 2 > 32) return 1;
+    FusedArgs gc{};
+    gc.n_rows = n_rows; gc.in_dim = critics->in_dim; gc.hidden = critics->hidden; gc.out_dim = critics->out_dim;
+    const int tc = choose_tile(gc, critics->n_nets).tm;
+    const int tgx = (n_rows + 15) / 16, cgx = (n_rows + tc - 1) / tc;
+    for (int ns = 4; ns > 1; ns >>= 1)
+        if (tgx + n_sel * ns * tgx + cgx * critics->n_nets + 1 <= 256) return ns;
+    return 1;
 }
 
 extern "C" int ssac_critic_fwd_bwd_fused(const ssac_mlp *nets, const float *X, int64_t ldx, int n_rows,

@@ -80,6 +80,20 @@ extern long long *g_ssac_timeline;   // ssac_debug_timeline (ssac_elementwise.hi
 #endif
 #define SSAC_LAB_REFUSAL "measurement scaffolding is compiled into the lab build only: ./build.sh --lab"
 #ifdef __HIPCC__
+// min over the REDQ subset slots of the target Q of row b (ssac_td_spec): a slot's value is q_t[j][b], or -- n_parts > 1,
+// column-split target critics -- the sum of its partials q_t[(j n_parts + s)][b] in index order.  Every reader of
+// ssac_td_spec::q_t goes through this (n_parts <= 1: the plain min, operation by operation as before).
+__device__ __forceinline__ float ssac_td_min_q(const ssac_td_spec &t, int b, int n_rows) {
+    const int np = t.n_parts > 1 ? t.n_parts : 1;
+    float mq = 0.0f;
+    for (int j = 0; j < t.n_sel; ++j) {
+        float v = t.q_t[(int64_t)(j * np) * n_rows + b];
+        for (int s = 1; s < np; ++s) v += t.q_t[(int64_t)(j * np + s) * n_rows + b];
+        mq = j == 0 ? v : fminf(mq, v);
+    }
+    return mq;
+}
+
 // Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global loads / stores.
 // __syncthreads() also drains vmcnt -- inside a software-pipelined K loop that exposes the round trip of the operand
 // loads issued for the chunk AFTER next at every chunk barrier, and at phase boundaries it stalls on prefetched weights

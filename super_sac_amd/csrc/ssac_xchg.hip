@@ -57,6 +57,9 @@ struct XchgArgs {
     int *error;                 // HOST-pinned int (device view), set to 1 when a peer's flag did not arrive in time
     int *dead;                  // device int: once a spin gave up, later exchanges fail at once instead of spinning again
     int test_mode;              // tests only (ssac_xchg_test_mode): bit 0 = senders skip step 0, bit 1 = accept flag >= seq
+    int n_parts, part_stride;   // > 1: element i of the payload is the SUM of n_parts partials (column-split target critics,
+                                // ssac_td_spec.n_parts): data[(slot n_parts + s) part_stride + b]; the reduction lands in
+                                // part 0 of every slot and the other parts are zeroed, so the sum stays the value
 };
 
 __device__ __forceinline__ float *slot_of(float *base, int src, int slot, int slot_floats) {
@@ -91,6 +94,21 @@ __global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
         }
     }
     const bool i_send = (senders >> a.rank) & 1u;
+    // payload element i <-> where it lives in `data` (plain: data[i]; partial sums: slot i / stride, row i % stride)
+    const int np = a.n_parts > 1 ? a.n_parts : 1;
+    auto mine = [&](int i) {
+        if (np == 1) return a.data[i];
+        const int j = i / a.part_stride, b = i - j * a.part_stride;
+        float v = a.data[(int64_t)(j * np) * a.part_stride + b];
+        for (int s_ = 1; s_ < np; ++s_) v += a.data[(int64_t)(j * np + s_) * a.part_stride + b];
+        return v;
+    };
+    auto put = [&](int i, float v) {
+        if (np == 1) { a.data[i] = v; return; }
+        const int j = i / a.part_stride, b = i - j * a.part_stride;
+        a.data[(int64_t)(j * np) * a.part_stride + b] = v;
+        for (int s_ = 1; s_ < np; ++s_) a.data[(int64_t)(j * np + s_) * a.part_stride + b] = 0.0f;
+    };
     // ---- 0. slot reuse: every rank must have consumed exchange seq - X_SLOTS before its slot is written again
     if (i_send && seq > (unsigned long long)X_SLOTS && !(a.test_mode & 1)) {
         if (tid < a.world) {
@@ -110,7 +128,7 @@ __global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
     for (int p = 0; p < (i_send && go ? a.world : 0); ++p) {
         float *dst = slot_of(a.peer[p], a.rank, slot, a.slot_floats);
         for (int i = tid; i < a.n; i += X_THREADS)
-            __hip_atomic_store(dst + i, a.data[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(dst + i, mine(i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope: payload before flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -151,13 +169,13 @@ __global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
                 r = first ? v : (a.op == 0 ? fminf(r, v) : r + v);
                 first = false;
             }
-            a.data[i] = r;
+            put(i, r);
         }
     } else {
         // no reduction happened: poison the result (slots this rank does not own still hold +inf, which a TD target
         // would silently absorb) and tell the host -- the error word is pinned host memory, read without a device
         // synchronisation at the training loop's periodic slot-reuse wait (learning.py) and raised there
-        for (int i = tid; i < a.n; i += X_THREADS) a.data[i] = __builtin_nanf("");
+        for (int i = tid; i < a.n; i += X_THREADS) put(i, __builtin_nanf(""));
         if (tid == 0) {
             *a.dead = 1;
             __hip_atomic_store(a.error, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -258,7 +276,8 @@ extern "C" int ssac_xchg_connect(ssac_xchg *x, const void *handles) {
     return 0;
 }
 
-static int xchg_launch(ssac_xchg *x, float *data, int n, int op, const int32_t *owners, int n_slots, void *stream);
+static int xchg_launch(ssac_xchg *x, float *data, int n, int op, const int32_t *owners, int n_slots, void *stream,
+                       int n_parts = 1);
 
 // in place over data[0 .. n): MIN (op 0) or SUM (op 1) over the ranks.  A recordable launch.
 extern "C" int ssac_xchg_reduce(ssac_xchg *x, float *data, int n, int op, void *stream) {
@@ -267,12 +286,15 @@ extern "C" int ssac_xchg_reduce(ssac_xchg *x, float *data, int n, int op, void *
 
 // MIN over the ranks of data[0 .. n) where only the OWNERS of the update's subset members send (see xchg_kernel):
 // owners = the update's id block in device memory (n_slots int32: >= 0 a member of this rank, -(r + 1) rank r's).
-extern "C" int ssac_xchg_reduce_owned(ssac_xchg *x, float *data, int n, const int32_t *owners, int n_slots, void *stream) {
+extern "C" int ssac_xchg_reduce_owned(ssac_xchg *x, float *data, int n, const int32_t *owners, int n_slots, int n_parts,
+                                      void *stream) {
     if (!owners || n_slots <= 0 || n_slots > 64) return ssac_fail("ssac_xchg_reduce_owned: bad owner block");
-    return xchg_launch(x, data, n, 0, owners, n_slots, stream);
+    if (n_parts < 1 || n_parts > 8 || n % n_slots) return ssac_fail("ssac_xchg_reduce_owned: bad partial-sum layout");
+    return xchg_launch(x, data, n, 0, owners, n_slots, stream, n_parts);
 }
 
-static int xchg_launch(ssac_xchg *x, float *data, int n, int op, const int32_t *owners, int n_slots, void *stream) {
+static int xchg_launch(ssac_xchg *x, float *data, int n, int op, const int32_t *owners, int n_slots, void *stream,
+                       int n_parts) {
     if (!x || !data || n <= 0 || n > x->slot_floats || (op != 0 && op != 1))
         return ssac_fail("ssac_xchg_reduce: bad arguments");
     XchgArgs a{};
@@ -284,6 +306,7 @@ static int xchg_launch(ssac_xchg *x, float *data, int n, int op, const int32_t *
     a.rank = x->rank; a.world = x->world; a.n = n; a.slot_floats = x->slot_floats; a.op = op;
     a.data = data; a.seq = x->seq; a.error = x->error_dev; a.dead = x->dead;
     a.test_mode = x->test_mode;
+    a.n_parts = n_parts; a.part_stride = n_slots > 0 ? n / n_slots : n;
     SSAC_LAUNCH(xchg_kernel, dim3(1), dim3(X_THREADS), 0, (hipStream_t)stream, a);
     return ssac_check_launch("xchg");
 }

@@ -256,6 +256,7 @@ CHAIN_LAUNCH = True
 # the chained launch in its producer / consumer form (the actor once per tile, the target critics start before a' exists);
 # a module constant that tests flip to compare the two forms
 CHAIN_PC = True
+CHAIN_SPLIT = True   # ... with the target critics' fc2 split by columns over 2 / 4 consumer workgroups while the launch stays one round
 
 
 def parallel_shard_of(agent):
@@ -597,10 +598,11 @@ def compute_td_targets(logs, replay_dict, agent, target_agent, ensemble_idx, ens
     td = torch.empty(B, 1, device=dev)
     if _defer and qd == 1 and not popart:
         td._ssac_spec = _lib.TdSpec(q1.data_ptr(), lp_ptr, r.data_ptr(), d.data_ptr(), log_alpha.data_ptr(),
-                                    td.data_ptr(), float(gamma), n_q, use_entropy, 0)
+                                    td.data_ptr(), float(gamma), n_q, use_entropy, int(getattr(q1, "_ssac_parts", 1)))
         td._ssac_logs = slot[L_TD0 + 3 * i:]
         td._ssac_keep = (q1, logp, r, d, log_alpha)
     else:
+        assert getattr(q1, "_ssac_parts", 1) == 1, "partial target Q needs the in-launch TD target (ssac_td_spec.n_parts)"
         check(lib.ssac_td_target(q1.data_ptr(), n_q, B, qd, lp_ptr, r.data_ptr(), d.data_ptr(),
                                  log_alpha.data_ptr(), use_entropy, float(gamma),
                                  popart.ptr if popart else 0, 1 if (popart and pop) else 0,
@@ -652,7 +654,7 @@ def _actor_sample(a_arena, s1_rep, B, eps_ptr, actor, x1, S, A, logp, rng_ptr, s
                                       logp.data_ptr(), 0, 0, 0, rng_ptr, st))
 
 
-def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict):
+def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict, allow_split=True):
     """ssac_chain_update: the deferred actor sample (ch, from _actor_sample), the target critics of the n subset slots
     and the online critics' forward + TD-independent backward, ONE launch; returns the target outputs (n, B, 1)"""
     c_arena, h1, h2, act, ld_act, dz2u, dz1u = co_backward
@@ -665,7 +667,19 @@ def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict)
         gth = gather_struct(bt)
     else:
         ensure_gathered(bt)
-    q1 = ws.get(tag + ".y", (n, B, 1))
+    # column-split target critics (producer / consumer form, fp32 family): every (slot, tile) gets `splits` consumer
+    # workgroups and the slot's value arrives as that many partial sums -- read through ssac_td_spec.n_parts
+    # (inside a recording the hand-off's tag must change per replay: it then comes from the input ring's update counter,
+    # which the launch reaches through the folded gather or the deferred-log struct -- a recording with neither keeps the
+    # one-workgroup form)
+    cap_ = engine.CAPTURE
+    pc_ok = CHAIN_PC and (cap_ is None or (gth is not None and gth.feed) or (cap_.feed and cap_.deferred is not None))
+    splits = 1
+    if pc_ok and CHAIN_SPLIT and allow_split and c_arena.shadow is None:
+        splits = int(lib.ssac_chain_target_splits(C.byref(ch["a_arena"].desc()), C.byref(t_arena.desc()),
+                                                  C.byref(c_arena.desc()), B, n))
+    q1 = ws.get(tag + ".y", (n * splits, B, 1))
+    q1._ssac_parts = splits
     s1_rep = ch["s1_rep"]
     cap = engine.CAPTURE
     dl_ptr = 0
@@ -696,7 +710,7 @@ def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict)
     w3s = ws.get(tag + ".w3s", (c_arena.n_nets, c_arena.hidden))
     # producer / consumer form of the launch (csrc/ssac_fused.hip, fused_chain_pc_kernel): the actor once per tile, a'
     # handed to the tile's target-critic workgroups through tagged granules in this buffer (zeroed once: tag 0 is never used)
-    ho = ws.get(tag + ".handoff", (B * A,), dtype=torch.int64, zero=True) if CHAIN_PC else None
+    ho = ws.get(tag + ".handoff", (B * A,), dtype=torch.int64, zero=True) if pc_ok else None
     with engine._timed("chain") as tm:
         for _ in range(tm.reps):  # 1, except under bench.py's live kernel timing (the launch is idempotent)
             check(lib.ssac_chain_update(
@@ -705,7 +719,7 @@ def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict)
                 ch["logp"].data_ptr(), ch["rng_ptr"], C.byref(t_arena.desc()), ids_ptr, n,
                 q1.data_ptr(), C.byref(c_arena.desc()), Xc.data_ptr(), ldxc, h1.data_ptr(), h2.data_ptr(),
                 qc.data_ptr(), 0 if skip_dz2 else dz2u.data_ptr(), dz1u.data_ptr(), w3s.data_ptr(),
-                C.byref(gth) if gth is not None else 0, dl_ptr, ho.data_ptr() if ho is not None else 0,
+                C.byref(gth) if gth is not None else 0, dl_ptr, ho.data_ptr() if ho is not None else 0, splits,
                 engine.stream()))
     if skip_dz2:
         replay_dict["_dz2_skipped"] = w3s   # (the weight-gradient launch rebuilds dz2u from h2 and this W3 copy)
@@ -748,7 +762,9 @@ def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag, co_backward=None, re
         n = len(ids)
         ch = replay_dict.pop("_chain", None) if replay_dict is not None else None
         if ch is not None:
-            q1 = _launch_chain(ch, co_backward, t_arena, cap.ids_dev.data_ptr(), n, ws, tag, B, replay_dict)
+            # (partial sums only when the one-shot exchange will carry them: it sums a slot's parts before sending)
+            q1 = _launch_chain(ch, co_backward, t_arena, cap.ids_dev.data_ptr(), n, ws, tag, B, replay_dict,
+                               allow_split=parallel._exchange is not None)
         elif co_backward is not None and t_arena.fused_dbuf:
             # ... and the TD-independent half of the local critics' backward pass rides in the same launch
             c_arena, h1, h2, act, ld_act, dz2u, dz1u = co_backward
@@ -765,8 +781,9 @@ def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag, co_backward=None, re
         if parallel.one_shot_ready(q1):
             # ONE recorded launch (csrc/ssac_xchg.hip): the update stays one launch list; only the subset members'
             # owners send (the id block, mirrored to device memory by the update's first launch, names them)
-            parallel.all_reduce_min_owned(q1, cap.ids_dev, n)
+            parallel.all_reduce_min_owned(q1, cap.ids_dev, n, int(getattr(q1, "_ssac_parts", 1)))
         else:
+            assert getattr(q1, "_ssac_parts", 1) == 1
             cap.collective(lambda: parallel.all_reduce_min(q1))
         return q1, n
     local = shard.local_subset(ids)

@@ -168,11 +168,12 @@ class Exchange:
         from ._lib import check, lib
         check(lib.ssac_xchg_reduce(self.handle, t.data_ptr(), t.numel(), op, engine.stream()))
 
-    def reduce_min_owned(self, t, ids_dev, n_slots):
+    def reduce_min_owned(self, t, ids_dev, n_slots, n_parts=1):
         from . import engine
         from ._lib import check, lib
-        check(lib.ssac_xchg_reduce_owned(self.handle, t.data_ptr(), t.numel(), ids_dev.data_ptr(), n_slots,
-                                         engine.stream()))
+        # (n_parts > 1: t holds every slot's values as n_parts partial sums -- the payload is their sum, n_slots x B)
+        check(lib.ssac_xchg_reduce_owned(self.handle, t.data_ptr(), t.numel() // n_parts, ids_dev.data_ptr(), n_slots,
+                                         n_parts, engine.stream()))
 
     def failed(self):
         from ._lib import lib
@@ -240,11 +241,13 @@ def all_reduce_min(t):
     return t
 
 
-def all_reduce_min_owned(t, ids_dev, n_slots):
+def all_reduce_min_owned(t, ids_dev, n_slots, n_parts=1):
     """MIN all-reduce of the (n_slots x B) target-critic outputs of a recorded sharded update, where only the ranks
-    that own a subset member send (the id block `ids_dev` says who: Shard.slot_code)"""
+    that own a subset member send (the id block `ids_dev` says who: Shard.slot_code).  n_parts > 1: t is
+    (n_slots x n_parts x B), a slot's value the sum of its parts (column-split target critics); the reduced value comes
+    back in part 0, the other parts zeroed."""
     check_exchange()
-    _exchange.reduce_min_owned(t, ids_dev, n_slots)
+    _exchange.reduce_min_owned(t, ids_dev, n_slots, n_parts)
     return t
 
 

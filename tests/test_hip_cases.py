@@ -215,13 +215,13 @@ def test_graph_replay_equals_eager_launches():
     import torch
     import super_sac_amd as ssa
 
-    def run(use_graphs, split, mode="list", dual=True, rank1=True, fold=True, chained=True, gather=True):
+    def run(use_graphs, split, mode="list", dual=True, rank1=True, fold=True, chained=True, gather=True, pc=True):
         L = ssa.learning
         old = (L.USE_GRAPHS, L.SPLIT_FORWARD, L.LAUNCH_MODE, L.DUAL_LAUNCH, L.RANK1_BWD, L.FOLD_LOSS)
-        old_lu = (ssa.learning_utils.CHAIN_LAUNCH, ssa.learning_utils.FOLD_GATHER)
+        old_lu = (ssa.learning_utils.CHAIN_LAUNCH, ssa.learning_utils.FOLD_GATHER, ssa.learning_utils.CHAIN_PC)
         (L.USE_GRAPHS, L.SPLIT_FORWARD, L.LAUNCH_MODE, L.DUAL_LAUNCH, L.RANK1_BWD,
          L.FOLD_LOSS) = use_graphs, split, mode, dual, rank1, fold
-        ssa.learning_utils.CHAIN_LAUNCH, ssa.learning_utils.FOLD_GATHER = chained, gather
+        ssa.learning_utils.CHAIN_LAUNCH, ssa.learning_utils.FOLD_GATHER, ssa.learning_utils.CHAIN_PC = chained, gather, pc
         try:
             torch.manual_seed(3); np.random.seed(3); random.seed(3)
             dev = torch.device("cuda")
@@ -254,7 +254,7 @@ def test_graph_replay_equals_eager_launches():
             return params, tparams, last, buf.total_sample_calls
         finally:
             L.USE_GRAPHS, L.SPLIT_FORWARD, L.LAUNCH_MODE, L.DUAL_LAUNCH, L.RANK1_BWD, L.FOLD_LOSS = old
-            ssa.learning_utils.CHAIN_LAUNCH, ssa.learning_utils.FOLD_GATHER = old_lu
+            ssa.learning_utils.CHAIN_LAUNCH, ssa.learning_utils.FOLD_GATHER, ssa.learning_utils.CHAIN_PC = old_lu
 
     # default configuration (merged launches, rank-1 backward): the three launch mechanisms agree bit for bit
     pe, te, le, ce = run(False, split=False)
@@ -275,11 +275,19 @@ def test_graph_replay_equals_eager_launches():
     assert np.allclose(pe, p0, atol=2e-6) and np.allclose(te, t0, atol=2e-6), "rank-1 backward vs fused backward"
     # dL/dq evaluated inside the weight-gradient launch vs written by the separate loss launch: the same products
     # (the scale multiplies the rows when they are stored to LDS instead of when they are loaded)
-    # the chained launch, the two merged launches and the replay gather as its own launch: same bits, eager or replayed
-    for kw in (dict(chained=False), dict(chained=False, gather=False), dict(gather=False)):
+    # the chained launch in its ONE-WORKGROUP form, the two merged launches and the replay gather as its own launch: same
+    # bits, eager or replayed.  (The producer / consumer form of the chained launch -- today's default, `pe` above -- adds
+    # the action columns of the target critics' fc1 AFTER the state columns' sum: equal to rounding, and bit-identical
+    # across its own launch mechanisms and with or without the folded gather.)
+    po, to, lo, _ = run(False, split=False, pc=False)
+    assert np.allclose(pe, po, atol=2e-6) and np.allclose(te, to, atol=2e-6), "producer/consumer vs one-workgroup chained launch"
+    for kw in (dict(chained=False), dict(chained=False, gather=False), dict(gather=False, pc=False)):
         for graphs in (False, True):
             pc, tc_, lc, _ = run(graphs, split=False, **kw)
-            assert np.array_equal(pe, pc) and np.array_equal(te, tc_) and le[:2] == lc[:2], (kw, graphs)
+            assert np.array_equal(po, pc) and np.array_equal(to, tc_) and lo[:2] == lc[:2], (kw, graphs)
+    for graphs in (False, True):
+        pc, tc_, lc, _ = run(graphs, split=False, gather=False)
+        assert np.array_equal(pe, pc) and np.array_equal(te, tc_) and le[:2] == lc[:2], ("producer/consumer, gather launch", graphs)
     pf, tf, lf, _ = run(False, split=False, fold=False)
     assert np.array_equal(pe, pf) and np.array_equal(te, tf), "folded loss gradient vs loss launch"
     assert abs(le[0] - lf[0]) <= 1e-5 * max(1.0, abs(lf[0])) and abs(le[1] - lf[1]) <= 1e-5 * max(1.0, abs(lf[1]))

@@ -1167,10 +1167,32 @@ def test_chain_launch_equals_the_separate_launches(ssa, B, N, H):
     ssa._lib.check(lib.ssac_chain_update(
         C.byref(aa.desc()), xb.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0, xb.data_ptr(), S + A, S, lpb.data_ptr(),
         0, C.byref(ta.desc()), ids.data_ptr(), 2, gt_.data_ptr(), C.byref(ca.desc()), xc.data_ptr(), S + A,
-        g1.data_ptr(), g2.data_ptr(), gq.data_ptr(), gz2.data_ptr(), gz1.data_ptr(), 0, 0, 0, st))
+        g1.data_ptr(), g2.data_ptr(), gq.data_ptr(), gz2.data_ptr(), gz1.data_ptr(), 0, 0, 0, 0, 1, st))
     for a_, b_, what in ((xa, xb, "a'"), (lpa, lpb, "log pi"), (h1, g1, "h1"), (h2, g2, "h2"), (q, gq, "q"),
                          (qt, gt_, "target q"), (dz2, gz2, "dz2u"), (dz1, gz1, "dz1u")):
         assert torch.equal(a_, b_), f"chained launch differs in {what}"
+    # the PRODUCER / CONSUMER form (hand-off buffer given): the actor once per tile, the target critics take a' from tagged
+    # granules and add the action columns of fc1 after the state columns' sum -- everything but the target q bit for bit,
+    # the target q to rounding; with 2 and 4 column splits (hidden 256) the slot's value arrives as partial sums
+    for splits in ((1, 2, 4) if H == 256 else (1,)):
+        ho = torch.zeros(B * A, dtype=torch.int64, device=DEV)
+        xp, lpp = x1.clone(), torch.zeros(B, device=DEV)
+        p1_, p2_, pq = torch.zeros_like(h1), torch.zeros_like(h2), torch.zeros_like(q)
+        pt = torch.full((2 * splits, B, 1), float("nan"), device=DEV)
+        pz2, pz1 = torch.zeros_like(dz2), torch.zeros_like(dz1)
+        for rep in range(2):   # twice: the second launch must not take the first one's granules (fresh tag)
+            if rep == 1:
+                xp.copy_(x1); pt.fill_(float("nan"))
+            ssa._lib.check(lib.ssac_chain_update(
+                C.byref(aa.desc()), xp.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0, xp.data_ptr(), S + A, S, lpp.data_ptr(),
+                0, C.byref(ta.desc()), ids.data_ptr(), 2, pt.data_ptr(), C.byref(ca.desc()), xc.data_ptr(), S + A,
+                p1_.data_ptr(), p2_.data_ptr(), pq.data_ptr(), pz2.data_ptr(), pz1.data_ptr(), 0, 0, 0, ho.data_ptr(), splits, st))
+            torch.cuda.synchronize()
+            for a_, b_, what in ((xa, xp, "a'"), (lpa, lpp, "log pi"), (h1, p1_, "h1"), (h2, p2_, "h2"), (q, pq, "q"),
+                                 (dz2, pz2, "dz2u"), (dz1, pz1, "dz1u")):
+                assert torch.equal(a_, b_), f"producer/consumer chained launch ({splits} splits, launch {rep}) differs in {what}"
+            got = pt.view(2, splits, B, 1).sum(1)
+            assert torch.isfinite(got).all() and float((got - qt).abs().max()) <= 2e-5, (splits, rep, float((got - qt).abs().max()))
     # ... and without the dz2u store: the launch leaves a copy of the head rows instead, from which (with h2) the
     # weight-gradient launch rebuilds dz2u = W3 (.) [h2 > 0] -- exactly the values written above
     w3s = torch.zeros(N, H, device=DEV)
@@ -1179,7 +1201,7 @@ def test_chain_launch_equals_the_separate_launches(ssa, B, N, H):
     ssa._lib.check(lib.ssac_chain_update(
         C.byref(aa.desc()), xb2.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0, xb2.data_ptr(), S + A, S, lpb2.data_ptr(),
         0, C.byref(ta.desc()), ids.data_ptr(), 2, kt.data_ptr(), C.byref(ca.desc()), xc.data_ptr(), S + A,
-        k1.data_ptr(), k2.data_ptr(), kq.data_ptr(), 0, kz1.data_ptr(), w3s.data_ptr(), 0, 0, st))
+        k1.data_ptr(), k2.data_ptr(), kq.data_ptr(), 0, kz1.data_ptr(), w3s.data_ptr(), 0, 0, 0, 1, st))
     assert torch.equal(k2, g2) and torch.equal(kz1, gz1) and torch.equal(kq, gq)
     w3 = torch.stack([ca.view(j, "w3").reshape(-1) for j in range(N)])
     assert torch.equal(w3s, w3)

@@ -90,6 +90,25 @@ def _xchg_main(rank, world, port, out_dir):
         for p_ in parts[1:]:
             want = torch.minimum(want, p_)
         ok = ok and torch.equal(t.cpu(), want) and bool(torch.isfinite(want).all())
+    # ... and with every slot's values in TWO partial sums (column-split target critics: ssac_td_spec.n_parts): the
+    # payload is the sum of a slot's parts, the reduced value comes back in part 0 with the other part zeroed
+    for it in range(20):
+        g = torch.Generator().manual_seed(9000 + it)
+        owners = [int(v) for v in torch.randint(0, world, (2,), generator=g)]
+        parts = [torch.randn(2, 2, 300, generator=g) for _ in range(world)]   # [slot][part][row]
+        for r in range(world):
+            for j in range(2):
+                if owners[j] != r:
+                    parts[r][j, 0] = float("inf")
+                    parts[r][j, 1] = 0.0
+        ids = torch.tensor([j if owners[j] == rank else -(owners[j] + 1) for j in range(2)], dtype=torch.int32).cuda()
+        t = parts[rank].clone().cuda()
+        parallel.all_reduce_min_owned(t, ids, 2, 2)
+        want = (parts[0][:, 0] + parts[0][:, 1])
+        for p_ in parts[1:]:
+            want = torch.minimum(want, p_[:, 0] + p_[:, 1])
+        got = t.cpu()
+        ok = ok and torch.equal(got[:, 0], want) and bool((got[:, 1] == 0).all()) and bool(torch.isfinite(want).all())
     assert not x.failed() and ok
     open(os.path.join(out_dir, f"xok{rank}"), "w").write("ok")
     dist.destroy_process_group()
@@ -148,7 +167,7 @@ def _lap_main(rank, world, port, out_dir):
         for it in range(LAP_ROUNDS):
             if delay_rank2 and rank == 2:
                 time.sleep(0.05 if it == 0 else 0.005)
-            check(lib.ssac_xchg_reduce_owned(x.handle, ts[it].data_ptr(), n, ids.data_ptr(), 2,
+            check(lib.ssac_xchg_reduce_owned(x.handle, ts[it].data_ptr(), n, ids.data_ptr(), 2, 1,
                                              torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
         dist.barrier()

@@ -13,6 +13,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np, torch
 import super_sac_amd as ssa
 import synth
+if os.environ.get("SSAC_CHAIN_SPLIT"):
+    ssa.learning_utils.CHAIN_SPLIT = os.environ["SSAC_CHAIN_SPLIT"] == "1"
 if os.environ.get("SSAC_CHAIN_PC"):   # A/B of the chained launch's two forms (tools only)
     ssa.learning_utils.CHAIN_PC = os.environ["SSAC_CHAIN_PC"] == "1"
 if os.environ.get("SSAC_WGRAD_VARIANT"):   # A/B of the weight-gradient launch's forms (tools only)

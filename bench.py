@@ -385,8 +385,9 @@ def main():
 
     # ---- roofline of the dominant kernel: the chained launch (ensemble-Q forward + TD-independent backward of all local
     # critics beside the target chains).  Algorithmic FLOPs per launch: 2*B*N*(in*H + H*H + H) for the
-    # critics' forward, 2*B*N*(H + H*H) for their backward-data, the target critics of the subset and the actor ONCE
-    # (each subset slot recomputes the actor for its rows: redundant work, not counted).  The timed region re-issues the
+    # critics' forward, 2*B*N*(H + H*H) for their backward-data, the target critics of the subset and the actor once
+    # (round 4: the launch's producer / consumer form runs the actor once per tile -- executed = algorithmic).  The timed
+    # region re-issues the
     # update from ONE recorded launch list, inside which a single kernel is not bracketed by events; so the same
     # update is run again right here with plain launches and the launch is bracketed by HIP events recorded on the
     # stream it is launched on (same shapes, buffers, binary), 8 back-to-back issues per event pair.
@@ -412,10 +413,11 @@ def main():
     if "chain" in by_tag:
         ms = by_tag["chain"]
         flops, kname = f_fwd + f_bwd + f_tgt + f_actor, (
-            "fused_chain_kernel: ensemble-Q forward (fc1+fc2+head, h1/h2/q saved) AND the TD-independent half of the "
+            "fused_chain_pc_kernel: ensemble-Q forward (fc1+fc2+head, h1/h2/q saved) AND the TD-independent half of the "
             "backward pass (head backward + fc2 backward-data) of all local critics as 32-row workgroups, beside the "
-            "target chains (actor forward + tanh-normal sample -> target critic, per REDQ subset slot) as 16-row "
-            "workgroups; every workgroup gathers its own replay rows; ONE launch per update")
+            "target chains as producer / consumer workgroups of 16 rows (the actor forward + tanh-normal sample once per "
+            "tile hands a' to the tile's target critics of the REDQ subset, which have run fc1 on the state columns "
+            "meanwhile); every workgroup gathers its own replay rows; ONE launch per update")
     elif "dual_fwd" in by_tag:
         ms = by_tag["dual_fwd"]
         flops, kname = f_fwd + f_actor, "fused_dual_kernel: ensemble-Q forward + actor forward/sample, ONE launch"

@@ -63,6 +63,7 @@ def build(obs, act, B, N, n, hidden=256, rows=100_000, precision="fp32"):
         ssa.learning.alpha_update(buffer=buf, agent=agent, optimizers=[lopt], batch_size=B, log_alphas=[la],
                                   augmenter=aug, aug_mix=0.0, target_entropy=-float(act), premade_replay_dicts=dicts,
                                   discrete=False)
+    critic.objects = dict(agent=agent, target=target)
     return critic, env_step
 
 

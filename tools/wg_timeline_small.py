@@ -36,14 +36,25 @@ for rep in range(3):
               f"ends {e.min():.2f} .. {e.max():.2f}; durations min {np.min(e - s):.2f} median {np.median(e - s):.2f} max {np.max(e - s):.2f}")
         if rep == 2 and name.startswith("chained") and ssa.learning_utils.CHAIN_PC:
             tiles = (B + 15) // 16
-            crit16 = n - 3 * tiles >= 0 and (n - 3 * tiles) == tiles * N   # 16-row critic tiles: [producers | consumers | critics]
+            import ctypes as C
+            ag = critic.objects["agent"] if hasattr(critic, "objects") else None
+            splits = 1
+            if ssa.learning_utils.CHAIN_SPLIT and ag is not None:
+                dev = torch.device("cuda")
+                aa = ssa.engine.bind_arena(ag.actors[0], "self", [ag.actors[0]], dev)
+                ca = ag.critics[0].arena(dev)
+                splits = int(ssa._lib.lib.ssac_chain_target_splits(C.byref(aa.desc()), C.byref(ca.desc()), C.byref(ca.desc()), B, 2))
+            ncons = 2 * splits * tiles
+            crit16 = (n - tiles - ncons) == tiles * N   # 16-row critic tiles: [producers | consumers | critics]
             if crit16:
-                groups = (("actor producers", 0, tiles), ("target consumers", tiles, 3 * tiles), ("critic tiles (16 rows)", 3 * tiles, n))
+                groups = (("actor producers", 0, tiles), (f"target consumers (x{splits} column splits)", tiles, tiles + ncons),
+                          ("critic tiles (16 rows)", tiles + ncons, n))
             else:
-                nc = n - 3 * tiles
-                groups = (("actor producers", 0, tiles), ("critic tiles (32 rows)", tiles, tiles + nc), ("target consumers", tiles + nc, n))
+                nc = n - tiles - ncons
+                groups = (("actor producers", 0, tiles), ("critic tiles (32 rows)", tiles, tiles + nc),
+                          (f"target consumers (x{splits} column splits)", tiles + nc, n))
             for gname, lo, hi in groups:
-                print(f"      {gname:24s} start {s[lo:hi].min():6.2f}..{s[lo:hi].max():6.2f}  end {e[lo:hi].min():6.2f}..{e[lo:hi].max():6.2f}  "
+                print(f"      {gname:40s} start {s[lo:hi].min():6.2f}..{s[lo:hi].max():6.2f}  end {e[lo:hi].min():6.2f}..{e[lo:hi].max():6.2f}  "
                       f"duration {np.min((e - s)[lo:hi]):6.2f}..{np.max((e - s)[lo:hi]):6.2f} (median {np.median((e - s)[lo:hi]):6.2f})")
         if rep == 2 and name.startswith("weight") and n == sum(c for c, _ in small) * N + 1:
             # (hardware order: classes are interleaved per XCD; report by duration clusters instead)

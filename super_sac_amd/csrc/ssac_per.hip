@@ -144,17 +144,29 @@ __global__ __launch_bounds__(PER_THREADS) void per_assign_kernel(AssignArgs a) {
     const double maxp = a.max_priority[0];
     const bool max_f32 = a.max_priority[1] != 0.0;
     double seen = 0.0;
+    // The reference asserts BEFORE it touches the trees (replay.py:183-187): validate the whole batch first; one bad entry
+    // and nothing is written -- not a leaf, not max_priority -- only the error word (raised by the next host call).
+    int bad_p = 0, bad_r = 0;
     for (int i = tid; i < a.n; i += PER_THREADS) {
         const int64_t r = a.rows[i];
-        if (r >= 0 && r < a.cap) atomicMax(a.win + r, i);
+        if (a.prio) {
+            const double p = a.prio_f64 ? reinterpret_cast<const double *>(a.prio)[i] : (double)reinterpret_cast<const float *>(a.prio)[i];
+            bad_p |= !(p > 0.0);
+        }
+        bad_r |= r < 0 || r >= a.cap || (a.update_max && r >= a.n_filled);
     }
+    bad_p = __syncthreads_or(bad_p);
+    bad_r = __syncthreads_or(bad_r);
+    if (bad_p || bad_r) {
+        if (tid == 0) *a.err = bad_p ? 1 : 2;
+        return;
+    }
+    for (int i = tid; i < a.n; i += PER_THREADS) atomicMax(a.win + a.rows[i], i);
     __syncthreads();
     for (int i = tid; i < a.n; i += PER_THREADS) {
         const int64_t r = a.rows[i];
         double p = maxp;
         if (a.prio) p = a.prio_f64 ? reinterpret_cast<const double *>(a.prio)[i] : (double)reinterpret_cast<const float *>(a.prio)[i];
-        if (a.prio && !(p > 0.0)) { *a.err = 1; continue; }
-        if (r < 0 || r >= a.cap || (a.update_max && r >= a.n_filled)) { *a.err = 2; continue; }
         seen = fmax(seen, p);
         if (a.win[r] != i) continue;   // a later entry of the batch names the same row
         const double v = cr_pow(p, a.alpha, a.prio ? !a.prio_f64 : max_f32);
@@ -162,10 +174,7 @@ __global__ __launch_bounds__(PER_THREADS) void per_assign_kernel(AssignArgs a) {
         a.min_tree[a.cap + r] = v;
     }
     __syncthreads();
-    for (int i = tid; i < a.n; i += PER_THREADS) {
-        const int64_t r = a.rows[i];
-        if (r >= 0 && r < a.cap) a.win[r] = -1;
-    }
+    for (int i = tid; i < a.n; i += PER_THREADS) a.win[a.rows[i]] = -1;
     if (a.update_max) {   // _max_priority = max(_max_priority, max(priorities)): positive doubles order like their bits
         for (int o = 32; o > 0; o >>= 1) seen = fmax(seen, __shfl_xor(seen, o, 64));
         if ((tid & 63) == 0 && seen > 0.0)
@@ -178,9 +187,7 @@ __global__ __launch_bounds__(PER_THREADS) void per_assign_kernel(AssignArgs a) {
     for (int64_t span = 2; span <= a.cap; span <<= 1) {   // span = leaves under a node of this level
         __syncthreads();
         for (int i = tid; i < a.n; i += PER_THREADS) {
-            const int64_t r = a.rows[i];
-            if (r < 0 || r >= a.cap) continue;
-            const int64_t node = (a.cap + r) / span;
+            const int64_t node = (a.cap + a.rows[i]) / span;
             a.sum_tree[node] = a.sum_tree[2 * node] + a.sum_tree[2 * node + 1];
             a.min_tree[node] = fmin(a.min_tree[2 * node], a.min_tree[2 * node + 1]);
         }
@@ -248,12 +255,14 @@ extern "C" int ssac_per_assign(double *sum_tree, double *min_tree, int64_t cap, 
     AssignArgs a{sum_tree, min_tree, cap, rows, n, prio, prio_is_f64, alpha, max_priority, update_max, n_filled,
                  err_host_word, winner_scratch};
     hipStream_t st = (hipStream_t)stream;
-    if (n <= 8 * PER_THREADS) {
+    // A priority refresh (update_max) of ANY size goes through the one-workgroup kernel: it validates before it writes and
+    // resolves duplicated rows, and its loops stride over n (the reference accepts any batch size; 65 536 rows = 64 rows per
+    // thread and level).  Pushes of up to 8 192 rows too; larger ones are bulk loads.
+    if (update_max || n <= 8 * PER_THREADS) {
         SSAC_LAUNCH(per_assign_kernel, dim3(1), dim3(PER_THREADS), 0, st, a);
         return ssac_check_launch("per_assign");
     }
     // bulk (load_experience): leaves by a grid, then the inner levels bottom-up, one launch per level
-    if (update_max) return ssac_fail("ssac_per_assign: a priority refresh of more than 8192 rows");
     SSAC_LAUNCH(per_set_leaves_kernel, dim3(512), dim3(256), 0, st, a);
     for (int64_t first = cap / 2; first >= 1; first /= 2) {
         const int64_t count = first;

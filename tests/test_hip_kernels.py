@@ -1323,13 +1323,38 @@ def test_device_priority_refresh_reports_what_the_reference_asserts(ssa):
     from super_sac_amd.replay import DevicePrioritySampler
     dev = DevicePrioritySampler(64, 0.6, 1.0, torch.device(DEV))
     dev.push_rows(np.arange(40))
-    dev.update_priorities(torch.tensor([1, 2, 3], device=DEV), torch.tensor([0.5, 0.0, 1.0], device=DEV), 40)
+    dev.update_priorities(torch.tensor([4, 5], device=DEV), torch.tensor([0.25, 0.75], device=DEV), 40)
+    before = (dev.sum_tree.copy(), dev.min_tree.copy(), dev.max_dev.cpu().clone())
+    # the reference asserts BEFORE it writes (replay.py:183-187): a batch with one bad entry leaves the trees and the
+    # maximum untouched -- its valid entries (and the 7.0 that would raise the maximum) included
+    dev.update_priorities(torch.tensor([1, 2, 3], device=DEV), torch.tensor([7.0, 0.0, 1.0], device=DEV), 40)
     torch.cuda.synchronize()
     with pytest.raises(AssertionError, match="priority <= 0"):
         dev.update_priorities(torch.tensor([1], device=DEV), torch.tensor([0.5], device=DEV), 40)
-    dev.update_priorities(torch.tensor([45], device=DEV), torch.tensor([0.5], device=DEV), 40)
+    assert np.array_equal(dev.sum_tree, before[0]) and np.array_equal(dev.min_tree, before[1])
+    assert torch.equal(dev.max_dev.cpu(), before[2])
+    dev.update_priorities(torch.tensor([6, 45], device=DEV), torch.tensor([9.0, 0.5], device=DEV), 40)
     torch.cuda.synchronize()
     with pytest.raises(AssertionError, match="outside the filled rows"):
         dev.push_rows(np.arange(2))
+    assert np.array_equal(dev.sum_tree, before[0]) and torch.equal(dev.max_dev.cpu(), before[2])
     with pytest.raises(AssertionError):
         dev.update_priorities(np.array([1, 2]), np.array([1.0, -1.0]), 40)   # host arrays: synchronously, as the reference
+
+
+def test_device_priority_refresh_of_more_than_8192_rows(ssa):
+    """The reference accepts a priority refresh of any batch size (replay.py:179-190); duplicated rows take the last entry."""
+    from super_sac_amd.replay import DevicePrioritySampler, PrioritySampler
+    cap, n_filled, n = 32768, 30000, 20000
+    rng = np.random.default_rng(5)
+    dev = DevicePrioritySampler(cap, 0.6, 1.0, torch.device(DEV))
+    host = PrioritySampler(cap, 0.6, 1.0)
+    host.pow_fn = lambda p, alpha: exact_pow(p, alpha, False)
+    dev.push_rows(np.arange(n_filled)); host.push_rows(np.arange(n_filled))
+    rows = rng.integers(0, n_filled, n)
+    prio = rng.random(n).astype(np.float64) * 3 + 1e-3
+    host.update_priorities(rows, prio, n_filled)
+    dev.update_priorities(torch.from_numpy(rows).to(DEV), torch.from_numpy(prio).to(DEV), n_filled)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.sum_tree, host.sum_tree) and np.array_equal(dev.min_tree, host.min_tree)
+    assert dev._max_priority == host._max_priority

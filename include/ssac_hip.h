@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SSAC_ABI_VERSION 4
+#define SSAC_ABI_VERSION 5
 #define SSAC_MAX_NETS 64
 
 typedef struct ssac_mlp {
@@ -169,6 +169,12 @@ ssac_step *ssac_step_create(void *ring, int n_slots, int slot_bytes, int n_rows,
 int ssac_step_add_list(ssac_step *step, ssac_launch_list *list);
 int ssac_step_run(ssac_step *step, const int64_t *idx_host, const int32_t *ids_host, int32_t log_slot, int64_t draw,
                   void *stream);
+/* ssac_step_run hands the address of the slot it has just written to the replayed launches BY VALUE (a pointer member of
+ * their recorded argument bytes is overwritten before each re-issue), so no workgroup reads the ssac_feed block to find
+ * its inputs: one dependent load from cold memory less at the front of every workgroup of the update's first launch.
+ * ssac_slot_by_value(0) switches that off (the launches go through the feed block, as plain ssac_replay and hipGraph
+ * captures always do); results are bit-identical either way (tests/test_hip_cases.py). */
+int ssac_slot_by_value(int on);
 int64_t ssac_step_count(const ssac_step *step);
 int ssac_step_seek(ssac_step *step, int64_t k);   /* updates the ring's device-side counter has consumed so far */
 /* soft_update right after ssac_step_run (late-bound Polyak): leaves the request for the update just issued in the ring
@@ -724,7 +730,28 @@ int ssac_actor_bwd_fused(const ssac_mlp *actor, const float *H1, const float *H2
                          const ssac_popart *popart, int pop, float *d_out, float *DZ2, float *DZ1, float *partials,
                          void *stream);
 int ssac_actor_logs(const float *partials, int n_tiles, int n_rows, float inv_members, const float *sumsq, int n_sumsq,
-                    float *logs_loss, float *logs_gn, void *stream);
+                    float *logs_loss, float *logs_gn, long long *bump /* nullable: device counter, += 1 */, void *stream);
+
+/* The first three launches above as ONE (round 4): the actor's workgroups (16-row tiles, lowest workgroup ids) run the
+ * forward + rsample, publish a_theta as tagged 8-byte granules, WAIT for their rows' Q_j and dQ_j/da from every critic and
+ * run the backward half on the forward they have just saved; the critics' tiles take [s | a_theta] as the chained critic
+ * update's target critics do (state columns gathered and multiplied first, the action columns' rank-A term added when
+ * a_theta arrives) and send Q / dQ/da back as granules.  Same outputs as the three launches (fc1 of the critics sums the
+ * state and action columns separately: fp32 association only).
+ *   handoff  ssac_actor_chain_handoff_words(n_rows, n_critics, A) 8-byte words, zeroed ONCE; never reset: a granule carries
+ *            the launch's tag -- 1 + *tick for a recorded launch (tick: a device counter the caller advances once per update,
+ *            e.g. through ssac_actor_logs' bump), a host counter with bit 31 set when tick is NULL (eager launches)
+ *   rng      eps == NULL: the noise of row b, dimension i is the engine's Philox stream at draw rng->offset + *rng->counter
+ *            (pass the same counter as tick), evaluated identically by the forward and the backward half
+ *   begin_logs / n_logs / begin_ctl   nullable: ssac_begin_update's duties (log block cleared, optimizer step advanced)
+ *            done by the first actor workgroup, so that a recorded actor update needs no launch in front */
+int ssac_actor_chain_fused(const ssac_mlp *actor, const float *X, int64_t ldx, int n_rows, const float *eps,
+                           const ssac_rng *rng, float log_std_lo, float log_std_hi, float *xsa, int64_t ld_xsa,
+                           float *logp, float *H1, float *H2, float *out, const ssac_mlp *critics, float *Q, float *DXu,
+                           const float *log_alpha, int use_entropy, float inv_members, const ssac_popart *popart, int pop,
+                           float *d_out, float *DZ2, float *DZ1, float *partials, unsigned long long *handoff,
+                           const long long *tick, float *begin_logs, int n_logs, ssac_adam_ctl *begin_ctl, void *stream);
+int64_t ssac_actor_chain_handoff_words(int n_rows, int n_critics, int action_dim);
 
 /* critic forward of ALL nets + loss gradient + backward-data in ONE launch (learning.py:83-98,112,121):
  * writes H1, H2, Q (n_nets x n_rows x out), DQ, DZ2 = dL/d(pre-activation of fc2), DZ1, and per-(net,

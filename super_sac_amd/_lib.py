@@ -107,6 +107,7 @@ SIGNATURES = {
     "ssac_step_create": [_P, _I, _I, _I, _I, _I, _I, _I, _I],
     "ssac_step_add_list": [_P, _P],
     "ssac_step_run": [_P, _P, _P, C.c_int32, _L, _P],
+    "ssac_slot_by_value": [_I],
     "ssac_step_count": [_P],
     "ssac_step_seek": [_P, _L],
     "ssac_step_destroy": [_P],
@@ -213,7 +214,10 @@ SIGNATURES = {
     "ssac_actor_sample_concat_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _P, _P, _P, _P, _P, _P],
     "ssac_critic_fwd_dx_fused": [_MP, _P, _L, _I, _I, _I, _P, _P, _P],
     "ssac_actor_bwd_fused": [_MP, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _F, _F, _F, _P, _I, _P, _P, _P, _P, _P],
-    "ssac_actor_logs": [_P, _I, _I, _F, _P, _I, _P, _P, _P],
+    "ssac_actor_logs": [_P, _I, _I, _F, _P, _I, _P, _P, _P, _P],
+    "ssac_actor_chain_fused": [_MP, _P, _L, _I, _P, _P, _F, _F, _P, _L, _P, _P, _P, _P, _MP, _P, _P, _P, _I, _F, _P, _I,
+                               _P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
+    "ssac_actor_chain_handoff_words": [_I, _I, _I],
     "ssac_critic_fwd_bwd_fused": [_MP, _P, _L, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ssac_critic_bwd_fused": [_MP, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ssac_head_wgrad_tiles": [_MP],
@@ -231,14 +235,14 @@ SIGNATURES = {
     "ssac_bf16_wgrad_lossfold": [_MP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _I, _P, _P, _P, _P, _P, _L,
                                  _P, _P, _F, _P, _P],
 }
-_RESTYPES = {"ssac_xchg_create": C.c_void_p, "ssac_xchg_destroy": None, "ssac_step_create": C.c_void_p, "ssac_step_count": C.c_int64, "ssac_step_destroy": None,
+_RESTYPES = {"ssac_xchg_create": C.c_void_p, "ssac_xchg_destroy": None, "ssac_step_create": C.c_void_p, "ssac_step_count": C.c_int64, "ssac_actor_chain_handoff_words": C.c_int64, "ssac_step_destroy": None,
              "ssac_last_error": C.c_char_p, "ssac_mlp_layout": C.c_int64, "ssac_bf16_layout": C.c_int64, "ssac_record_end": C.c_void_p,
              "ssac_launch_list_free": None}
 
 
 # SSAC_ABI_VERSION of include/ssac_hip.h this binding table was written against (bumped with every signature change:
 # a stale .so called with shifted pointer arguments would corrupt device memory)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def _load():

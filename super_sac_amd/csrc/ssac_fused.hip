@@ -77,8 +77,28 @@ struct Handoff {
     unsigned base;
     int S, A;                   // the consumer's input columns [S, S + A) arrive through pub
     int nsplit;                 // consumers per (slot, tile): > 1 = each takes hidden / nsplit columns of fc2 (below)
+    // the chained ACTOR update (fused_actor_chain_kernel): the critics' results travel back the same way --
+    unsigned long long *qpub;   // [n_critics][n_rows]: Q_j(s, a_theta)           (MODE_CRITIC_U publishes, MODE_ACTOR_BWD polls)
+    unsigned long long *dxpub;  // [n_critics][n_rows][A]: unscaled dQ_j / da
 };
+
 constexpr long long HANDOFF_SPIN_LIMIT = 4000000000LL;   // shader clocks (~2 s): a producer that never arrives poisons, never hangs
+// one granule: spin until its tag is this launch's (bounded: a producer that never arrives yields NaN, never a hang)
+__device__ __forceinline__ float handoff_poll(const unsigned long long *gp, unsigned tag) {
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long w;
+    for (;;) {
+        w = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(w >> 32) == tag) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_s_memtime() - t0 > HANDOFF_SPIN_LIMIT) { w = 0x7fc00000ull; break; }   // (NaN: never silently stale)
+    }
+    return __uint_as_float((unsigned)w);
+}
+__device__ __forceinline__ void handoff_publish(unsigned long long *gp, unsigned tag, float v) {
+    __hip_atomic_store(gp, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
 constexpr int HANDOFF_MAX_WA = 9;   // W1's action columns per thread (H * A <= 512 * 9: 256 x 18)
 
 struct FusedArgs {
@@ -98,6 +118,8 @@ struct FusedArgs {
                   // the weight-gradient launch that rebuilds dz2u from h2 must not read W3 itself: its own head
                   // workgroups update W3 while its fc2 tiles run
     int xcd;                     // workgroups take their tile in XCD-contiguous order (ssac_internal.h)
+    const uint32_t *slot_now;       // this update's slot of gth.feed's input ring, filled in by ssac_step_run's replay
+                                    // (ssac_record_slot_patch, ssac_internal.h); null: found through the feed block
     ssac_gather gth; int gth_role;  // 1: actor half (s' rows, begin duties), 3: actor half without the begin duties,
                                     // 2: critic half ([s|a] rows), 4: rows from X, net ids from the input slot; 0: X;
                                     // 5: hand-off consumer (s' rows like the actor half, nothing written, ids from the slot)
@@ -107,6 +129,8 @@ struct FusedArgs {
     float *DXU; int dx_col0, dx_cols;  // MODE_CRITIC_U: also the unscaled input gradient of columns [dx_col0, +dx_cols)
     int copy_x;                        // MODE_SAMPLE: also copy the input tile into act_dst[:, 0:in_dim]
     ActorBwdArgs ab;                   // MODE_ACTOR_BWD
+    float *begin_logs; int begin_n; ssac_adam_ctl *begin_ctl;   // MODE_SAMPLE, tile 0: ssac_begin_update's duties folded in
+                                                                  // (log block cleared, optimizer step advanced)
     Handoff ho;                        // MODE_SAMPLE: publish a'; MODE_PLAIN (16-row tiles): take the action columns from it
 };
 
@@ -515,10 +539,15 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     if (g.gth_role) {
         gidx = g.gth.idx;
         if (g.gth.feed) {
-            const ssac_feed f = *g.gth.feed;
-            gslot = feed_slot(f);
+            if (g.slot_now) {
+                gslot = g.slot_now;   // by value: no dependent load in front of the index vector
+            } else {
+                const ssac_feed f = *g.gth.feed;
+                gslot = feed_slot(f);
+            }
             gidx = reinterpret_cast<const int64_t *>(gslot);
             if (g.gth_role == 1 && bx == 0) {  // start-of-update duties (ssac_begin_update)
+                const ssac_feed f = *g.gth.feed;
                 feed_pull(f);
                 if (tid < g.gth.n_logs) g.gth.logs[tid] = 0.0f;
                 if (tid == 0 && g.gth.ctl) adam_refresh(g.gth.ctl, g.gth.ctl->step + 1);
@@ -545,6 +574,10 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     const float *P = g.params + (int64_t)net * g.net_stride;
     const float *X = g.X + (int64_t)e * g.sX;
     const int col0 = wave * 32;
+    if (MODE == MODE_SAMPLE && bx == 0 && g.begin_ctl) {   // (the chained actor update: no begin launch in front)
+        if (tid < g.begin_n) g.begin_logs[tid] = 0.0f;
+        if (tid == 0) adam_refresh(g.begin_ctl, g.begin_ctl->step + 1);
+    }
 
     BSTAMP(0);
     const int ldw3 = H + APAD;
@@ -616,7 +649,8 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         // CONSUMER of a hand-off (MODE_PLAIN, role 5 / no gather): the input's state columns are fetched here -- s' rows
         // from the replay arrays or from X -- the action columns [S, S + A) stay ZERO in the x tile: fc1 runs on the state
         // part while the actor workgroup of the tile is still sampling, a' W1[:, S:]^T is added when it arrives
-        const bool CONS = HO && MODE == MODE_PLAIN && TMR == 16 && g.ho.pub != nullptr;
+        // (... or of the chained actor update: an online critic's forward + dQ/da pass, 16- or 32-row tiles)
+        const bool CONS = HO && ((MODE == MODE_PLAIN && TMR == 16) || MODE == MODE_CRITIC_U) && g.ho.pub != nullptr;
         const int XC = CONS ? g.ho.S : IN;   // columns of the x tile that are loaded
         int64_t gsrc[XR];
         bool xrok[XR];
@@ -656,7 +690,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         // straight into registers, and wait there while fc1 runs and the hand-off is polled.  Behind a' the workgroup then
         // has no memory access left but its LDS: NCH x 16 MFMAs per wave, a sum over the K-groups, the head's partial dot
         // product -- q_t[(slot nsplit + split)][row], summed by the TD evaluation (ssac_td_spec.n_parts).
-        const int NSPL = (CONS && g.ho.nsplit > 1) ? g.ho.nsplit : 1;
+        const int NSPL = (CONS && MODE == MODE_PLAIN && g.ho.nsplit > 1) ? g.ho.nsplit : 1;
         constexpr int MAXCH = 4;            // K chunks of 32 per wave: 4 (nsplit 2) or 2 (nsplit 4)
         f4 wq[MAXCH][2][2];
         const int CG_ = 8 / NSPL;           // column groups of 32 inside the workgroup's hidden / nsplit columns
@@ -782,18 +816,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
             for (int t = tid; t < TMR * A_; t += NTHR) {
                 const int r = t / A_, i = t - r * A_, b = m0 + r;
                 float v = 0.0f;
-                if (b < g.n_rows) {
-                    const unsigned long long *gp = g.ho.pub + (int64_t)b * A_ + i;
-                    const long long t0 = __builtin_amdgcn_s_memtime();
-                    unsigned long long w;
-                    for (;;) {
-                        w = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((unsigned)(w >> 32) == tag) break;
-                        __builtin_amdgcn_s_sleep(1);
-                        if (__builtin_amdgcn_s_memtime() - t0 > HANDOFF_SPIN_LIMIT) { w = 0x7fc00000ull; break; }   // (NaN: never silently stale)
-                    }
-                    v = __uint_as_float((unsigned)w);
-                }
+                if (b < g.n_rows) v = handoff_poll(g.ho.pub + (int64_t)b * A_ + i, tag);
                 as_[r * 32 + i] = v;
             }
             lds_barrier();
@@ -921,6 +944,9 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 for (int w = 0; w < 8; ++w) v += hpart[w * TMR + tid];
                 ys[tid * ldo] = v;
                 if (g.Y && (m0 + tid) < g.n_rows) g.Y[(int64_t)e * g.n_rows + m0 + tid] = v;
+                if (HO && MODE == MODE_CRITIC_U && g.ho.qpub && (m0 + tid) < g.n_rows)   // the actor workgroup of the tile is polling
+                    handoff_publish(g.ho.qpub + (int64_t)e * g.n_rows + m0 + tid,
+                                    g.ho.base + (g.ho.tick ? (unsigned)*g.ho.tick : 0u), v);
             }
         } else
         // ---- head on the matrix cores: wave w multiplies the k-slice [32w, 32w+32) of h2 with W3^T
@@ -1030,17 +1056,23 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 const int r = t / A, i = t - r * A, b = m0 + r;
                 float dmu = 0.0f, dls = 0.0f;
                 if (b < g.n_rows) {
-                    float mq = ab.qc[b];
+                    // (chained actor update: the critics' workgroups of this tile publish Q and dQ/da as tagged granules)
+                    const bool polled = HO && g.ho.qpub != nullptr;
+                    const unsigned ptag = polled ? g.ho.base + (g.ho.tick ? (unsigned)*g.ho.tick : 0u) : 0u;
+                    float mq = polled ? handoff_poll(g.ho.qpub + b, ptag) : ab.qc[b];
                     int am = 0;
                     for (int j = 1; j < ab.n_critics; ++j) {
-                        const float v = ab.qc[(int64_t)j * g.n_rows + b];
+                        const float v = polled ? handoff_poll(g.ho.qpub + (int64_t)j * g.n_rows + b, ptag)
+                                               : ab.qc[(int64_t)j * g.n_rows + b];
                         if (v < mq) { mq = v; am = j; }
                     }
-                    const float gsum = gq * ab.dxu[((int64_t)am * g.n_rows + b) * A + i];
+                    const float dxv = polled ? handoff_poll(g.ho.dxpub + ((int64_t)am * g.n_rows + b) * A + i, ptag)
+                                             : ab.dxu[((int64_t)am * g.n_rows + b) * A + i];
+                    const float gsum = gq * dxv;
                     const float mu = ab.aout[(int64_t)b * OUT + i], raw = ab.aout[(int64_t)b * OUT + A + i];
                     const float th = tanhf(raw);
                     const float sd = expf(ab.lo + 0.5f * (ab.hi - ab.lo) * (th + 1.0f));
-                    const float ep = ab.eps[(int64_t)b * A + i];
+                    const float ep = ab.eps ? ab.eps[(int64_t)b * A + i] : philox_normal(g.rng.seed, rng_draw(g.rng), b, i);
                     const float a = tanhf(mu + sd * ep);
                     const float gu = gsum * (1.0f - a * a);
                     dmu = gu + cen * 2.0f * a;
@@ -1158,17 +1190,25 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         });
         if (want_dx) {
             // dX[b][c] = sum_k dz1u[b][k] W1[k][dx_col0 + c]: the (unscaled) gradient w.r.t. the ACTION columns of the
-            // critic input -- all the online actor update needs from the critics' backward pass (learning.py:402-411)
-            lds_barrier();
+            // critic input -- all the online actor update needs from the critics' backward pass (learning.py:402-411).
+            // W1's action columns (H x DC floats) go through LDS first (staging buffer 0 is free behind the last K loop):
+            // read from global memory inside the k loop they were 256 strided loads per thread, ~5 us of a 35 us launch.
             const float *W1 = P + g.off[0];
             const int DC = g.dx_cols;
+            float *wdx = Ws;   // [H][DC]
+            for (int i = tid; i < H * DC; i += NTHR) {
+                const int k = i / DC, cix = i - k * DC;
+                wdx[i] = W1[(int64_t)k * IN + g.dx_col0 + cix];
+            }
+            lds_barrier();
+            const unsigned dtag = (HO && g.ho.dxpub) ? g.ho.base + (g.ho.tick ? (unsigned)*g.ho.tick : 0u) : 0u;
             for (int t = tid; t < TMR * DC; t += NTHR) {
                 const int r = t / DC, cix = t - r * DC;
                 if ((m0 + r) < g.n_rows) {
-                    const float *wc = W1 + g.dx_col0 + cix;
                     float sx = 0.0f;
-                    for (int k = 0; k < H; ++k) sx += h2s[r * ldh + k] * wc[(int64_t)k * IN];
+                    for (int k = 0; k < H; ++k) sx += h2s[r * ldh + k] * wdx[k * DC + cix];
                     g.DXU[((int64_t)e * g.n_rows + m0 + r) * DC + cix] = sx;
+                    if (HO && g.ho.dxpub) handoff_publish(g.ho.dxpub + ((int64_t)e * g.n_rows + m0 + r) * DC + cix, dtag, sx);
                 }
             }
         }
@@ -1261,8 +1301,12 @@ void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs
             // pass for it; the target-critic pass below just stores +inf (the neutral element of the exchange's MIN)
             const int32_t *idsp = gt.ids;
             if (gt.gth_role == 4 && gt.gth.feed && gt.gth.ids_word >= 0) {
-                const ssac_feed f = *gt.gth.feed;
-                idsp = reinterpret_cast<const int32_t *>(feed_slot(f) + gt.gth.ids_word);
+                if (gt.slot_now) {
+                    idsp = reinterpret_cast<const int32_t *>(gt.slot_now + gt.gth.ids_word);
+                } else {
+                    const ssac_feed f = *gt.gth.feed;
+                    idsp = reinterpret_cast<const int32_t *>(feed_slot(f) + gt.gth.ids_word);
+                }
             }
             if (!(idsp && idsp[j] < 0)) fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga_rest, smem, bx, 0, target_grid_x, -1);
         } else {
@@ -1334,6 +1378,32 @@ void fused_chain_pc_kernel(FusedArgs ga, FusedArgs gt, FusedArgs gc, int tiles_a
         if (threadIdx.x == 0) gc.tl[2 * bid + 1] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
+}
+
+// The online actor update's three dependent passes as ONE launch (round 4).  Stand-alone they are
+// actor forward + rsample (32 workgroups, ~15 us), every critic's forward + dQ/da (~35 us), arg-min routing + tanh-normal
+// backward + actor backward-data (32 workgroups, ~15 us): three launch boundaries in front of small launches.  Here
+//   workgroups [0, tiles_a): the ACTOR of a 16-row tile: forward, rsample, log pi, the [s | a] rows, a published as tagged
+//     granules (Handoff::pub) -- then it WAITS for its rows' Q_j and dQ_j/da from every critic (Handoff::qpub / dxpub) and
+//     runs its backward half (MODE_ACTOR_BWD) on the h1 / h2 / head outputs it has just written;
+//   the rest: the critics' tiles (MODE_CRITIC_U as a hand-off CONSUMER: gather of the state columns, fc1 on them, then a
+//     arrives, rank-A update, fc2, head, the unscaled backward, dQ/da) -- Q and dQ/da go out as granules.
+// Actor workgroups hold the lowest ids: they are resident before any critic tile can wait for them, and while they wait
+// for the critics they block nobody (a launch of more critic tiles than CUs drains behind them).
+template <int TC>
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void fused_actor_chain_kernel(FusedArgs ga, FusedArgs gb, FusedArgs gc, int tiles_a, int critic_grid_x) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bid = blockIdx.x;
+    if (bid < tiles_a) {
+        fused_mlp_body<MODE_SAMPLE, 16, true>(ga, smem, bid, 0, tiles_a, -1);
+        __threadfence_block();  // this workgroup's h1 / h2 / head-output rows (global) are read back by its backward half
+        __syncthreads();
+        fused_mlp_body<MODE_ACTOR_BWD, 16, true, true>(gb, smem, bid, 0, tiles_a, -1);
+    } else {
+        const int L = ssac_xcd_contiguous_range(bid, tiles_a, (int)gridDim.x, gc.xcd);
+        fused_mlp_body<MODE_CRITIC_U, TC, true, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x, -1);
+    }
 }
 
 long long *g_fused_dbg = nullptr;
@@ -1574,6 +1644,8 @@ extern "C" int ssac_actor_sample_critic_fwd(const ssac_mlp *actor, const float *
     else if (adbuf) SSAC_LAUNCH((fused_dual_kernel<32, true>), grid, dim3(NTHR), lds, st, ga, gc, tiles_a, cgx);
     else if (tc == 16) SSAC_LAUNCH((fused_dual_kernel<16, false>), grid, dim3(NTHR), lds, st, ga, gc, tiles_a, cgx);
     else SSAC_LAUNCH((fused_dual_kernel<32, false>), grid, dim3(NTHR), lds, st, ga, gc, tiles_a, cgx);
+    if (gather && gather->feed)
+        for (int a = 0; a < 2; ++a) ssac_record_slot_patch(a, offsetof(FusedArgs, slot_now));   // ga, gc
     return ssac_check_launch("fused_dual");
 }
 
@@ -1678,6 +1750,8 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
         else if (adbuf) SSAC_LAUNCH((fused_chain_pc_kernel<32, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
         else if (tc == 16) SSAC_LAUNCH((fused_chain_pc_kernel<16, false>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
         else SSAC_LAUNCH((fused_chain_pc_kernel<32, false>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
+        if (gather && gather->feed)
+            for (int a = 0; a < 3; ++a) ssac_record_slot_patch(a, offsetof(FusedArgs, slot_now));   // ga, gt, gc
         return ssac_check_launch("fused_chain_pc");
     }
     if (target_splits != 1) return ssac_fail("ssac_chain_update: column-split target critics need the hand-off form");
@@ -1686,6 +1760,8 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
     else if (adbuf) SSAC_LAUNCH((fused_chain_kernel<32, true>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx, dl, dl_on);
     else if (tc == 16) SSAC_LAUNCH((fused_chain_kernel<16, false>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx, dl, dl_on);
     else SSAC_LAUNCH((fused_chain_kernel<32, false>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx, dl, dl_on);
+    if (gather && gather->feed)
+        for (int a = 0; a < 4; ++a) ssac_record_slot_patch(a, offsetof(FusedArgs, slot_now));   // ga, gr, gt, gc
     return ssac_check_launch("fused_chain");
 }
 
@@ -1775,6 +1851,72 @@ extern "C" int ssac_actor_bwd_fused(const ssac_mlp *actor, const float *H1, cons
     g.ab = ActorBwdArgs{Qc, n_critics, DXu, aout, eps, logp, log_alpha, use_entropy, log_std_lo, log_std_hi, inv_members,
                         partials};
     return launch_fused<MODE_ACTOR_BWD>(g, 1, (hipStream_t)stream);
+}
+
+// ---- the chained form of the three launches above (fused_actor_chain_kernel)
+extern "C" int ssac_actor_chain_fused(const ssac_mlp *actor, const float *X, int64_t ldx, int n_rows, const float *eps,
+                                      const ssac_rng *rng, float log_std_lo, float log_std_hi, float *xsa, int64_t ld_xsa,
+                                      float *logp, float *H1, float *H2, float *out, const ssac_mlp *critics, float *Q,
+                                      float *DXu, const float *log_alpha, int use_entropy, float inv_members,
+                                      const ssac_popart *popart, int pop, float *d_out, float *DZ2, float *DZ1,
+                                      float *partials, unsigned long long *handoff, const long long *tick,
+                                      float *begin_logs, int n_logs, ssac_adam_ctl *begin_ctl, void *stream) {
+    if (!eps && !rng) return ssac_fail("ssac_actor_chain_fused: neither eps nor an rng stream given");
+    if (!fused_dbuf_ok(actor) || (actor->out_dim & 1) || !fused_dbuf_ok(critics) || critics->out_dim != 1)
+        return ssac_fail("ssac_actor_chain_fused: shape not supported by the chained launch");
+    const int A = actor->out_dim / 2, S = actor->in_dim;
+    if (critics->in_dim != S + A || A > 32 || critics->hidden * A > NTHR * HANDOFF_MAX_WA)
+        return ssac_fail("ssac_actor_chain_fused: critic input is not [s | a] / too many action columns");
+    if (!X || !xsa || ld_xsa < S + A || !H1 || !H2 || !out || !Q || !DXu || !log_alpha || !d_out || !DZ2 || !DZ1 ||
+        !partials || !handoff || (use_entropy && !logp) || (begin_logs && n_logs > NTHR))
+        return ssac_fail("ssac_actor_chain_fused: missing argument");
+    if (n_rows <= 0) return 0;
+    const int N = critics->n_nets;
+    FusedArgs ga{}, gb{}, gc{};
+    fill_common(ga, actor, nullptr, X, ldx, 0, n_rows);
+    ga.H1 = H1; ga.H2 = H2; ga.Y = out;
+    ga.eps = eps; ga.lo = log_std_lo; ga.hi = log_std_hi;
+    if (rng) ga.rng = RngArgs{rng->seed, rng->counter, rng->offset};
+    ga.act_dst = xsa; ga.ld_act = ld_xsa; ga.act_col0 = S; ga.logp = logp; ga.copy_x = 1;
+    ga.begin_logs = begin_logs; ga.begin_n = begin_logs ? n_logs : 0; ga.begin_ctl = begin_ctl;
+    static unsigned launch_no = 0;   // tags of eager launches: bit 31 set, so they never meet a recorded launch's
+    Handoff ho{handoff, tick, tick ? 1u : (0x80000000u | (++launch_no & 0x7fffffffu)), S, A, 1,
+               handoff + (int64_t)n_rows * A, handoff + (int64_t)n_rows * A + (int64_t)N * n_rows};
+    ga.ho = ho;
+    fill_common(gb, actor, nullptr, nullptr, 0, 0, n_rows);
+    gb.H1 = H1; gb.H2 = H2;
+    gb.popart = popart; gb.pop = pop; gb.DQ = d_out; gb.DZ2 = DZ2; gb.DZ1 = DZ1;
+    gb.ab = ActorBwdArgs{Q, N, DXu, out, eps, logp, log_alpha, use_entropy, log_std_lo, log_std_hi, inv_members, partials};
+    gb.rng = ga.rng;
+    gb.ho = ho;
+    fill_common(gc, critics, nullptr, X, ldx, 0, n_rows);   // (state columns from the actor's input; a arrives by hand-off)
+    gc.Y = Q; gc.DXU = DXu; gc.dx_col0 = S; gc.dx_cols = A;
+    gc.ho = ho;
+    gc.xcd = 1;
+    const int tc = choose_tile(gc, N).tm;
+    const int tiles_a = (n_rows + 15) / 16, cgx = (n_rows + tc - 1) / tc;
+    size_t lds = fused_lds_bytes(actor->in_dim, actor->hidden, actor->out_dim, 16, true);
+    const size_t lc = fused_lds_bytes(critics->in_dim, critics->hidden, critics->out_dim, tc, true);
+    if (lc > lds) lds = lc;
+    if (lds > 160 * 1024) return ssac_fail("ssac_actor_chain_fused: LDS carve does not fit");
+    static bool attr_set = false;
+    if (!attr_set) {
+        const void *ks[2] = {(const void *)fused_actor_chain_kernel<16>, (const void *)fused_actor_chain_kernel<32>};
+        for (const void *k : ks)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return ssac_fail("fused_actor_chain: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    const dim3 grid(tiles_a + cgx * N);
+    hipStream_t st = (hipStream_t)stream;
+    if (tc == 16) SSAC_LAUNCH((fused_actor_chain_kernel<16>), grid, dim3(NTHR), lds, st, ga, gb, gc, tiles_a, cgx);
+    else SSAC_LAUNCH((fused_actor_chain_kernel<32>), grid, dim3(NTHR), lds, st, ga, gb, gc, tiles_a, cgx);
+    return ssac_check_launch("fused_actor_chain");
+}
+
+// words of the `handoff` buffer of ssac_actor_chain_fused: a (n_rows x A), Q (n_critics x n_rows), dQ/da (n_critics x n_rows x A)
+extern "C" int64_t ssac_actor_chain_handoff_words(int n_rows, int n_critics, int action_dim) {
+    return (int64_t)n_rows * action_dim + (int64_t)n_critics * n_rows * (1 + action_dim);
 }
 
 // row tiles the fused critic launch will use for (n_rows, n_nets): sizes the `partials` buffer

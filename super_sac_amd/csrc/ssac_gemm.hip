@@ -819,7 +819,8 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
             hpol = hpol && lt.bits != 0u;
             htau = __uint_as_float(lt.bits);
         }
-        head_wgrad_body<4 * KS>(p.head, lds, L % p.head_grid_x, e, fold ? tab : nullptr, hpol, htau);
+        head_wgrad_body<4 * KS>(p.head, lds, L % p.head_grid_x, e, fold ? tab : nullptr, hpol, htau,
+                                KS * 4 * TILE_FLOATS + 64 * KS);
     } else {
         const bool first = bid < p.tiles0;
 #if defined(SSAC_LAB) && defined(SSAC_EXPERIMENT_SKIP_FC1)
@@ -1177,7 +1178,8 @@ void wgrad_small_pair_kernel(GemmPair p) {
             hpol = hpol && lt.bits != 0u;
             htau = __uint_as_float(lt.bits);
         }
-        head_wgrad_body<S_HEAD_GROUPS / MB, S_HEAD_COLS * MB>(p.head, lds, L % p.head_grid_x, e, fold ? tab : nullptr, hpol, htau);
+        head_wgrad_body<S_HEAD_GROUPS / MB, S_HEAD_COLS * MB>(p.head, lds, L % p.head_grid_x, e, fold ? tab : nullptr, hpol, htau,
+                                                              S_PART + S_RED);
     } else {
         const bool first = bid < p.tiles0;
         const GemmArgs &g = first ? p.g0 : p.g1;

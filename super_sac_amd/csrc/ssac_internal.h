@@ -27,6 +27,9 @@ struct SsacLaunchRec {
     size_t lds;
     std::vector<char> blob;        // argument values, each at its natural alignment
     std::vector<size_t> offsets;   // byte offset of argument i in `blob`
+    // byte offsets in `blob` of 8-byte pointers that a replay through ssac_step_run overwrites with the address of THIS
+    // update's slot of the input ring (ssac_record_slot_patch below); a plain ssac_replay writes null there
+    std::vector<size_t> slot_patches;
 };
 
 extern thread_local std::vector<SsacLaunchRec> *g_ssac_recording;
@@ -58,6 +61,20 @@ inline void ssac_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t 
 }
 
 #define SSAC_LAUNCH(kernel, grid, block, lds, st, ...) ssac_launch(kernel, grid, block, lds, st, __VA_ARGS__)
+
+// "This update's slot, by value".  A recorded launch finds its inputs through device memory: kernel arguments -> the
+// ssac_feed block (its update counter) -> the slot of the input ring (replay indices, subset ids) -> the replay rows: three
+// DEPENDENT loads from cold memory at the front of every workgroup.  The host that replays the list through
+// ssac_step_run knows the slot -- it has just written it -- so the recorded argument bytes carry a pointer member that
+// the replay fills in: the feed block leaves the address chain of every workgroup (one of them still reads it for the
+// start-of-update duties).  Call right behind the SSAC_LAUNCH of a kernel whose argument `arg_index` is a struct with such
+// a member at byte `member_off`; the member is null in the launch that is being recorded and in plain replays
+// (ssac_replay, hipGraph captures), where the kernels take the path through the feed block.
+inline void ssac_record_slot_patch(int arg_index, size_t member_off) {
+    if (!g_ssac_recording || g_ssac_recording->empty()) return;
+    SsacLaunchRec &r = g_ssac_recording->back();
+    r.slot_patches.push_back(r.offsets[(size_t)arg_index] + member_off);
+}
 
 // ---------------------------------------------------------------------------------------------
 // XCD-contiguous workgroup order.  The dispatcher is observed to place workgroup b on XCD b % 8 (a speed

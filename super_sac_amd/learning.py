@@ -71,6 +71,9 @@ class _LaunchList:
 
 
 FUSED_ACTOR = True  # the online actor update in four fused launches
+# ... of which the first three are ONE (ssac_actor_chain_fused: actor forward / critics' forward + dQ/da / actor backward as
+# producer and consumer workgroups of a single launch).  Module constant; tests/test_hip_cases.py flips it for the A/B.
+ACTOR_CHAIN = True
 FEED_SLOTS = 32  # pinned input ring of a captured update: how far the host may run ahead of the GPU
 # evaluate the TD target inside the critic launch instead of a launch of its own (continuous, no PopArt)
 SHARDED_LISTS = True  # recorded launch lists on critic-sharded ranks
@@ -929,6 +932,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
 class _RecordedActor:
     def __init__(self):
         self.calls, self.list, self.blk, self.eps, self.index = 0, None, None, None, None
+        self.in_kernel, self.tick = False, None
 
     def __del__(self):
         if self.list:
@@ -975,13 +979,21 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
     ring = lu.ring_for(dev)
     if rec.list is None:
         rec.blk = torch.zeros(lu.LOG_WIDTH, device=dev)
-        rec.eps = [torch.empty(batch_size, A, device=dev) for _ in agent.actors]
-    for e_ in rec.eps:
-        rng.draw_normal_into(e_)  # a_dist.rsample() of every member, in member order (learning.py:392)
+        # the chained launch (ACTOR_CHAIN) with the stock generator draws its noise in the kernel: no buffers, no launches
+        rec.in_kernel = ACTOR_CHAIN and lu.IN_KERNEL_NOISE and rng.normal_is_stock()
+        rec.eps = None if rec.in_kernel else [torch.empty(batch_size, A, device=dev) for _ in agent.actors]
+        rec.tick = torch.zeros(1, dtype=torch.int64, device=dev) if ACTOR_CHAIN else None
+    elif rec.in_kernel != (ACTOR_CHAIN and lu.IN_KERNEL_NOISE and rng.normal_is_stock()):
+        # a noise hook was installed / removed (or the form switched) since the recording: record again
+        del cache[key]
+        return online_actor_update(**kw)
+    if rec.eps is not None:
+        for e_ in rec.eps:
+            rng.draw_normal_into(e_)  # a_dist.rsample() of every member, in member order (learning.py:392)
     if rec.list is None:
         check(lib.ssac_record_begin())
         try:
-            logs = _online_actor_update(**kw, _rec_blk=rec.blk, _rec_eps=rec.eps)
+            logs = _online_actor_update(**kw, _rec_blk=rec.blk, _rec_eps=rec.eps, _rec_tick=rec.tick)
         finally:
             rec.list = lib.ssac_record_end()
         base = rec.blk.data_ptr()
@@ -997,16 +1009,21 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
 
 def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_size, clip,
                          random_process, noise_clip, augmenter, aug_mix, premade_replay_dicts=None,
-                         per=False, discrete=False, use_baseline=False, _rec_blk=None, _rec_eps=None):
+                         per=False, discrete=False, use_baseline=False, _rec_blk=None, _rec_eps=None, _rec_tick=None):
     E = agent.ensemble_size
     dev = log_alphas[0].device
     ws = lu.agent_ws(agent, dev)
     adam = engine.adam_group(actor_optimizer, dev)
+    begin_folded = False
     if _rec_blk is not None:
         slot = _rec_blk   # recorded update: a fixed log block, cleared (and the Adam step advanced) by a recorded launch
-        check(lib.ssac_begin_update(slot.data_ptr(), lu.LOG_WIDTH, adam.ctl.ptr, 0, engine.stream()))
+        # (_rec_tick: the chained launch of the first member does that itself -- no launch in front of it)
+        begin_folded = _rec_tick is not None
+        if not begin_folded:
+            check(lib.ssac_begin_update(slot.data_ptr(), lu.LOG_WIDTH, adam.ctl.ptr, 0, engine.stream()))
     else:
         slot = lu.log_block(dev, adam)
+    first_fused = True
     logs = {}
     st = engine.stream()
     # member-sharded rank (parallel.MemberShard): the loss is averaged over the GLOBAL ensemble (learning.py:409), and the
@@ -1050,35 +1067,70 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             logp = ws.get(f"au.logp{i}", (B,))
             ah1, ah2 = ws.get(f"au.a{i}.h1", (1, B, H)), ws.get(f"au.a{i}.h2", (1, B, H))
             aout = ws.get(f"au.a{i}.y", (1, B, 2 * A))
-            if _rec_eps is not None:
+            # the noise: a recorded update with the stock generator takes it from the engine's Philox stream INSIDE the
+            # launch (draw number = the recording's device counter; no generator launch, no buffer); otherwise a draw --
+            # into the recording's fixed buffer, or a fresh one -- as a_dist.rsample() makes it (learning.py:392)
+            chain = (ACTOR_CHAIN and a_arena.fused_dbuf and A <= 32 and H * A <= 512 * 9
+                     and (_rec_blk is None or _rec_tick is not None))
+            in_kernel = chain and _rec_tick is not None and _rec_eps is None
+            eps = None   # (kept alive to the end of the member's launches: the kernels read it asynchronously)
+            if in_kernel:
+                eps_ptr = 0
+            elif _rec_eps is not None:
                 eps = _rec_eps[i]   # recorded update: the draw was written into a fixed buffer by the caller
+                eps_ptr = eps.data_ptr()
             else:
-                eps = rng.draw_normal((B, A), dev)  # a_dist.rsample() (learning.py:392)
-            check(lib.ssac_actor_sample_concat_fused(C.byref(a_arena.desc()), s_rep.data_ptr(), lds, B, eps.data_ptr(),
-                                                     float(actor.log_std_low), float(actor.log_std_high),
-                                                     xpi.data_ptr(), S + A, logp.data_ptr(), ah1.data_ptr(),
-                                                     ah2.data_ptr(), aout.data_ptr(), 0, st))
+                eps = rng.draw_normal((B, A), dev)
+                eps_ptr = eps.data_ptr()
             q = ws.get(f"au.c{i}.y", (N, B, 1))
             dxu = ws.get(f"au.dxu{i}", (N, B, A))
-            check(lib.ssac_critic_fwd_dx_fused(C.byref(c_arena.desc()), xpi.data_ptr(), S + A, B, S, A, q.data_ptr(),
-                                               dxu.data_ptr(), st))
             tiles = int(lib.ssac_fused_row_tiles(C.byref(a_arena.desc()), B, 1))
             parts = ws.get(f"au.parts{i}", (tiles,))
             d_out = ws.get(f"au.dout{i}", (1, B, 2 * A))
             dz2, dz1 = ws.get(f"au.a{i}.dz2", (1, B, H)), ws.get(f"au.a{i}.dz1", (1, B, H))
-            check(lib.ssac_actor_bwd_fused(C.byref(a_arena.desc()), ah1.data_ptr(), ah2.data_ptr(), B, q.data_ptr(), N,
-                                           dxu.data_ptr(), aout.data_ptr(), eps.data_ptr(), logp.data_ptr(),
-                                           log_alpha.data_ptr(), 1, float(actor.log_std_low),
-                                           float(actor.log_std_high), inv_e, pp, dopop, d_out.data_ptr(),
-                                           dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), st))
+            if chain:
+                ho = ws.get(f"au.handoff{i}", (int(lib.ssac_actor_chain_handoff_words(B, N, A)),), dtype=torch.int64,
+                            zero=True)
+                tick_ptr = _rec_tick.data_ptr() if _rec_tick is not None else 0
+                rs = None
+                if in_kernel:
+                    ns = lu.noise_stream(agent, dev)
+                    # (its own stream: the critic updates number their draws from the same seed)
+                    rs = _lib.Rng((ns[0] ^ 0x5DEECE66D1CEB00C) & (2 ** 64 - 1), tick_ptr, i << 40)
+                fold = begin_folded and first_fused
+                check(lib.ssac_actor_chain_fused(
+                    C.byref(a_arena.desc()), s_rep.data_ptr(), lds, B, eps_ptr, C.byref(rs) if rs is not None else None,
+                    float(actor.log_std_low), float(actor.log_std_high), xpi.data_ptr(), S + A, logp.data_ptr(),
+                    ah1.data_ptr(), ah2.data_ptr(), aout.data_ptr(), C.byref(c_arena.desc()), q.data_ptr(),
+                    dxu.data_ptr(), log_alpha.data_ptr(), 1, inv_e, pp, dopop, d_out.data_ptr(), dz2.data_ptr(),
+                    dz1.data_ptr(), parts.data_ptr(), ho.data_ptr(), tick_ptr,
+                    slot.data_ptr() if fold else 0, lu.LOG_WIDTH if fold else 0, adam.ctl.ptr if fold else 0, st))
+            else:
+                if begin_folded and first_fused:   # (a member the chained launch does not take: the begin launch after all)
+                    check(lib.ssac_begin_update(slot.data_ptr(), lu.LOG_WIDTH, adam.ctl.ptr, 0, st))
+                check(lib.ssac_actor_sample_concat_fused(C.byref(a_arena.desc()), s_rep.data_ptr(), lds, B, eps_ptr,
+                                                         float(actor.log_std_low), float(actor.log_std_high),
+                                                         xpi.data_ptr(), S + A, logp.data_ptr(), ah1.data_ptr(),
+                                                         ah2.data_ptr(), aout.data_ptr(), 0, st))
+                check(lib.ssac_critic_fwd_dx_fused(C.byref(c_arena.desc()), xpi.data_ptr(), S + A, B, S, A, q.data_ptr(),
+                                                   dxu.data_ptr(), st))
+                check(lib.ssac_actor_bwd_fused(C.byref(a_arena.desc()), ah1.data_ptr(), ah2.data_ptr(), B, q.data_ptr(), N,
+                                               dxu.data_ptr(), aout.data_ptr(), eps_ptr, logp.data_ptr(),
+                                               log_alpha.data_ptr(), 1, float(actor.log_std_low),
+                                               float(actor.log_std_high), inv_e, pp, dopop, d_out.data_ptr(),
+                                               dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), st))
+            first_fused = False
             ttot = engine.wgrad_tiles_total(a_arena)
             ss = ws.get(f"au.ss{i}", (ttot,))
             engine.weight_grads(a_arena, s_rep, lds, 0, ah1, ah2, d_out, dz2, dz1, B, adam=adam,
                                 adam_key=("actor", i), sumsq=ss)
             one = E_glob == 1   # (then the logged actor is this one: both logs in one launch)
+            # (the LAST member's log launch advances the recording's update counter: hand-off tags, noise draws)
+            last_member = all(ms.local(j_) is None for j_ in range(ig + 1, E_glob)) if ms is not None else ig == E_glob - 1
+            bump = _rec_tick.data_ptr() if (_rec_tick is not None and last_member) else 0
             check(lib.ssac_actor_logs(parts.data_ptr(), tiles, B, inv_e, ss.data_ptr() if one else 0, ss.numel(),
                                       slot[lu.L_ACTOR_LOSS:].data_ptr(), slot[lu.L_ACTOR_GN:].data_ptr() if one else 0,
-                                      st))
+                                      bump, st))
             member_ss.append(None if one else ss)
             continue
         ah1, ah2, aout = engine.mlp_forward(a_arena, s_rep, lds, 0, B, ws, f"au.a{i}")

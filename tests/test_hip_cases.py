@@ -261,6 +261,14 @@ def test_graph_replay_equals_eager_launches():
     pg, tg, lg, cg = run(True, split=False, mode="list")     # the library's recorded launch list
     ph, th, lh, ch = run(True, split=False, mode="graph")    # a hipGraph captured through torch
     assert np.array_equal(pg, ph) and np.array_equal(tg, th) and lg[:2] == lh[:2] and ch == 20
+    # ssac_step_run hands the replayed launches their input slot by value (include/ssac_hip.h: ssac_slot_by_value); the
+    # hipGraph above found it through the feed block, and so does the list with the switch off: the same bits
+    ssa._lib.lib.ssac_slot_by_value(0)
+    try:
+        pv, tv, lv, _ = run(True, split=False, mode="list")
+    finally:
+        ssa._lib.lib.ssac_slot_by_value(1)
+    assert np.array_equal(pg, pv) and np.array_equal(tg, tv) and lg[:2] == lv[:2]
     # the one-launch critic kernel, the forward riding in the actor launch + backward-only launch, and the critic
     # forward as a parallel branch are the same arithmetic in the same order: bit-identical to each other
     # (the rank-1 backward reorders the scaling by dL/dq and is only tolerance-equal: covered by the fixtures)
@@ -749,3 +757,98 @@ def test_full_size_pixel_critic_update_implicit_vs_im2col(which, monkeypatch):
     for key in ("enc", "tenc", "crit", "tcrit"):
         err = np.abs(a[key] - b[key])
         assert float(np.median(err)) <= 1e-6 and float(err.max()) <= 2 * lr * n_upd, (key, float(np.median(err)), float(err.max()))
+
+
+def _actor_update_run(chained, hook=True, n_upd=8):
+    import copy, math, random
+    import ctypes as C
+    from itertools import chain
+    import torch
+    import super_sac_amd as ssa
+    from case_runner import straggler_check
+    L, lu = ssa.learning, ssa.learning_utils
+    dev = torch.device("cuda")
+    B, S, A, N = 256, 17, 6, 4
+
+    if True:
+        old = (L.ACTOR_CHAIN, ssa.rng.draw_normal, ssa.rng.draw_normal_into)
+        L.ACTOR_CHAIN = chained
+        gen = torch.Generator(device=dev); gen.manual_seed(11)
+        if hook:
+            ssa.rng.draw_normal = lambda shape, device: torch.randn(*shape, device=device, generator=gen)
+            ssa.rng.draw_normal_into = lambda dst: dst.normal_(generator=gen)
+        try:
+            torch.manual_seed(3); np.random.seed(3); random.seed(3)
+            agent = ssa.Agent(act_space_size=A, encoder=ssa.nets.IdentityEncoder(S),
+                              actor_network_cls=ssa.nets.ContinuousStochasticActor,
+                              critic_network_cls=ssa.nets.ContinuousCritic, ensemble_size=1, num_critics=N,
+                              hidden_size=64, auto_rescale_targets=False, log_std_low=-5.0, log_std_high=2.0)
+            agent.to(dev)
+            target = copy.deepcopy(agent)
+            buf = ssa.replay.ReplayBuffer(4096, device=dev)
+            buf.load_experience(*synth.synth_transitions(2000, S, A, seed=5))
+            copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=3e-4)
+            aopt = torch.optim.Adam(chain(*(a.parameters() for a in agent.actors)), lr=3e-4)
+            eopt = torch.optim.Adam(agent.encoder.parameters(), lr=1e-4)
+            la = torch.Tensor([math.log(0.1)]).to(dev); la.requires_grad = True
+            aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(B)])
+            for _ in range(4):   # (the critic update records after three calls: fixed batch buffers for the actor update)
+                _, dicts = L.critic_update(
+                    buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt, encoder_optimizer=eopt,
+                    log_alphas=[la], batch_size=B, gamma=0.99, critic_clip=None, encoder_clip=None,
+                    target_critic_ensemble_n=2, weighted_bellman_temp=None, weight_type=None, pop=False, augmenter=aug,
+                    encoder_lambda=0, aug_mix=0.0, discrete=False, random_process=None, noise_clip=None, per=False,
+                    update_priorities=False, dr3_coeff=0.0)
+            logs, first, ws = [], None, None
+            for k in range(n_upd):
+                lg = L.online_actor_update(buffer=buf, agent=agent, pop=False, actor_optimizer=aopt, log_alphas=[la],
+                                           batch_size=B, clip=None, random_process=None, noise_clip=None, augmenter=aug,
+                                           aug_mix=0.0, premade_replay_dicts=dicts)
+                logs.append((float(lg["losses/actor_pg_loss"]), float(lg["gradients/random_actor_online_grad"])))
+                if k == 0:
+                    ws = agent.__dict__["_ssac_ws"]   # (the update's own workspace)
+                    first = {n_: ws.get(n_, sh).detach().cpu().numpy().copy() for n_, sh in
+                             (("au.c0.y", (N, B, 1)), ("au.dxu0", (N, B, A)), ("au.dout0", (1, B, 2 * A)),
+                              ("au.a0.dz1", (1, B, 64)), ("au.x0", (B, S + A)), ("au.a0.y", (1, B, 2 * A)))}
+            params = torch.cat([p.detach().flatten() for p in agent.actors[0].parameters()]).cpu().numpy()
+            return first, logs, params, agent, ws
+        finally:
+            L.ACTOR_CHAIN, ssa.rng.draw_normal, ssa.rng.draw_normal_into = old
+
+
+def test_actor_update_chained_launch_matches_three_launches():
+    """ssac_actor_chain_fused (actor forward -> critics' forward + dQ/da -> actor backward as producer / consumer workgroups
+    of ONE launch, learning.ACTOR_CHAIN) against the three launches it replaces, on the same injected noise: the first
+    update's intermediate results (Q, dQ/da, dL/d(actor output), dz1) and the logs of eight updates -- two eager, one
+    recorded, five replayed -- within fp32 association (the critics' fc1 sums state and action columns separately);
+    parameters with counted sign-flip stragglers.  Then the in-kernel noise of a recorded chained update (stock generator):
+    the action the forward half stored must be tanh(mu + sd * eps) of the Philox stream the header documents."""
+    import ctypes as C
+    import torch
+    import super_sac_amd as ssa
+    from case_runner import straggler_check
+    lu = ssa.learning_utils
+    dev = torch.device("cuda")
+    B, S, A, N = 256, 17, 6, 4
+    run = _actor_update_run
+    f3, l3, p3, _, _ = run(False)
+    fc, lc, pc, _, _ = run(True)
+    for n_ in f3:
+        scale = max(1.0, float(np.abs(f3[n_]).max()))
+        np.testing.assert_allclose(fc[n_], f3[n_], rtol=0, atol=3e-5 * scale, err_msg=n_)
+    np.testing.assert_allclose(np.array(lc), np.array(l3), rtol=2e-4, atol=1e-6)
+    straggler_check(np.abs(pc - p3), 3e-5, 8 * 2 * 3e-4 * 1.01, "chained actor update", "actor parameters")
+    # in-kernel noise: stock generator, recorded chained update; the stored action against the documented Philox stream
+    _, _, _, agent, ws = run(True, hook=False, n_upd=5)
+    rec = next(iter(agent.__dict__["_ssac_actor_rec"].values()))
+    assert rec.in_kernel and rec.list is not None and int(rec.tick.item()) == 3   # (three recorded / replayed updates so far)
+    ns = lu.noise_stream(agent, dev)
+    eps = torch.empty(B, A, device=dev)
+    rs = ssa._lib.Rng((ns[0] ^ 0x5DEECE66D1CEB00C) & (2 ** 64 - 1), 0, 2)   # the LAST update ran at counter value 2
+    ssa._lib.check(ssa._lib.lib.ssac_philox_normal(eps.data_ptr(), B, A, C.byref(rs), ssa.engine.stream()))
+    y = ws.get("au.a0.y", (1, B, 2 * A))[0]
+    mu, raw = y[:, :A], y[:, A:]
+    sd = torch.exp(-5.0 + 0.5 * (2.0 - -5.0) * (torch.tanh(raw) + 1.0))
+    want = torch.tanh(mu + sd * eps)
+    got = ws.get("au.x0", (B, S + A))[:, S:]
+    assert torch.allclose(got, want, atol=2e-6), float((got - want).abs().max())

@@ -17,6 +17,8 @@ if os.environ.get("SSAC_CHAIN_SPLIT"):
     ssa.learning_utils.CHAIN_SPLIT = os.environ["SSAC_CHAIN_SPLIT"] == "1"
 if os.environ.get("SSAC_CHAIN_PC"):   # A/B of the chained launch's two forms (tools only)
     ssa.learning_utils.CHAIN_PC = os.environ["SSAC_CHAIN_PC"] == "1"
+if os.environ.get("SSAC_SLOT_BY_VALUE"):   # A/B: replayed launches find their input slot through the feed block (tools only)
+    ssa._lib.lib.ssac_slot_by_value(int(os.environ["SSAC_SLOT_BY_VALUE"]))
 if os.environ.get("SSAC_WGRAD_VARIANT"):   # A/B of the weight-gradient launch's forms (tools only)
     ssa.engine.set_wgrad_variant(int(os.environ["SSAC_WGRAD_VARIANT"]))
 

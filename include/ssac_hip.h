@@ -154,6 +154,9 @@ int ssac_record_begin(void);
 ssac_launch_list *ssac_record_end(void);          /* NULL (+ ssac_last_error) when no recording is open */
 int ssac_launch_list_size(const ssac_launch_list *list);
 int ssac_replay(ssac_launch_list *list, void *stream);
+/* the same for a list with launches that are NUMBERED per update (ssac_actor_chain_fused's update_no): `value` >= 0 takes
+ * the place of the number they were recorded with */
+int ssac_replay_value(ssac_launch_list *list, void *stream, long long value);
 void ssac_launch_list_free(ssac_launch_list *list);
 
 /* ---- one host call per recorded update.  A step owns the host side of a recorded critic update whose per-update
@@ -730,7 +733,7 @@ int ssac_actor_bwd_fused(const ssac_mlp *actor, const float *H1, const float *H2
                          const ssac_popart *popart, int pop, float *d_out, float *DZ2, float *DZ1, float *partials,
                          void *stream);
 int ssac_actor_logs(const float *partials, int n_tiles, int n_rows, float inv_members, const float *sumsq, int n_sumsq,
-                    float *logs_loss, float *logs_gn, long long *bump /* nullable: device counter, += 1 */, void *stream);
+                    float *logs_loss, float *logs_gn, void *stream);
 
 /* The first three launches above as ONE (round 4): the actor's workgroups (16-row tiles, lowest workgroup ids) run the
  * forward + rsample, publish a_theta as tagged 8-byte granules, WAIT for their rows' Q_j and dQ_j/da from every critic and
@@ -738,11 +741,14 @@ int ssac_actor_logs(const float *partials, int n_tiles, int n_rows, float inv_me
  * update's target critics do (state columns gathered and multiplied first, the action columns' rank-A term added when
  * a_theta arrives) and send Q / dQ/da back as granules.  Same outputs as the three launches (fc1 of the critics sums the
  * state and action columns separately: fp32 association only).
- *   handoff  ssac_actor_chain_handoff_words(n_rows, n_critics, A) 8-byte words, zeroed ONCE; never reset: a granule carries
- *            the launch's tag -- 1 + *tick for a recorded launch (tick: a device counter the caller advances once per update,
- *            e.g. through ssac_actor_logs' bump), a host counter with bit 31 set when tick is NULL (eager launches)
- *   rng      eps == NULL: the noise of row b, dimension i is the engine's Philox stream at draw rng->offset + *rng->counter
- *            (pass the same counter as tick), evaluated identically by the forward and the backward half
+ *   handoff    ssac_actor_chain_handoff_words(n_rows, n_critics, A) 8-byte words, zeroed ONCE; never reset: a granule
+ *              carries the launch's tag
+ *   update_no  >= 0: the caller's number of this update -- the tag is 1 + update_no, and with eps == NULL the noise of row
+ *              b, dimension i is the engine's Philox stream at draw rng->offset (rng->counter NULL), evaluated identically
+ *              by the forward and the backward half.  A RECORDED launch must be numbered; its replays go through
+ *              ssac_replay_value(list, stream, n), which renumbers it: tag 1 + n, draw rng->offset - update_no + n (a
+ *              plain ssac_replay of such a list is refused).  Numbers must not repeat on one handoff buffer.
+ *              < 0: an eager launch nobody numbers (tag: a host counter with bit 31 set)
  *   begin_logs / n_logs / begin_ctl   nullable: ssac_begin_update's duties (log block cleared, optimizer step advanced)
  *            done by the first actor workgroup, so that a recorded actor update needs no launch in front */
 int ssac_actor_chain_fused(const ssac_mlp *actor, const float *X, int64_t ldx, int n_rows, const float *eps,
@@ -750,7 +756,7 @@ int ssac_actor_chain_fused(const ssac_mlp *actor, const float *X, int64_t ldx, i
                            float *logp, float *H1, float *H2, float *out, const ssac_mlp *critics, float *Q, float *DXu,
                            const float *log_alpha, int use_entropy, float inv_members, const ssac_popart *popart, int pop,
                            float *d_out, float *DZ2, float *DZ1, float *partials, unsigned long long *handoff,
-                           const long long *tick, float *begin_logs, int n_logs, ssac_adam_ctl *begin_ctl, void *stream);
+                           long long update_no, float *begin_logs, int n_logs, ssac_adam_ctl *begin_ctl, void *stream);
 int64_t ssac_actor_chain_handoff_words(int n_rows, int n_critics, int action_dim);
 
 /* critic forward of ALL nets + loss gradient + backward-data in ONE launch (learning.py:83-98,112,121):

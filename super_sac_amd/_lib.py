@@ -90,6 +90,7 @@ SIGNATURES = {
     "ssac_record_end": [],
     "ssac_launch_list_size": [_P],
     "ssac_replay": [_P, _P],
+    "ssac_replay_value": [_P, _P, C.c_longlong],
     "ssac_launch_list_free": [_P],
     "ssac_xchg_create": [C.c_int, C.c_int, C.c_int, C.c_int],
     "ssac_xchg_handle_bytes": [],
@@ -214,9 +215,9 @@ SIGNATURES = {
     "ssac_actor_sample_concat_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _P, _P, _P, _P, _P, _P],
     "ssac_critic_fwd_dx_fused": [_MP, _P, _L, _I, _I, _I, _P, _P, _P],
     "ssac_actor_bwd_fused": [_MP, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _F, _F, _F, _P, _I, _P, _P, _P, _P, _P],
-    "ssac_actor_logs": [_P, _I, _I, _F, _P, _I, _P, _P, _P, _P],
+    "ssac_actor_logs": [_P, _I, _I, _F, _P, _I, _P, _P, _P],
     "ssac_actor_chain_fused": [_MP, _P, _L, _I, _P, _P, _F, _F, _P, _L, _P, _P, _P, _P, _MP, _P, _P, _P, _I, _F, _P, _I,
-                               _P, _P, _P, _P, _P, _P, _P, _I, _P, _P],
+                               _P, _P, _P, _P, _P, _L, _P, _I, _P, _P],
     "ssac_actor_chain_handoff_words": [_I, _I, _I],
     "ssac_critic_fwd_bwd_fused": [_MP, _P, _L, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ssac_critic_bwd_fused": [_MP, _I, _P, _P, _P, _L, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -1397,7 +1397,7 @@ extern "C" int ssac_drq_shift(const void *src, int src_dtype, const int64_t *idx
 __global__ __launch_bounds__(RED_THREADS) void actor_logs_kernel(const float *__restrict__ partials, int n_tiles,
                                                                 int n_rows, float inv_members,
                                                                 const float *__restrict__ sumsq, int n_ss,
-                                                                float *logs_loss, float *logs_gn, long long *bump) {
+                                                                float *logs_loss, float *logs_gn) {
     __shared__ float scratch[16];
     float s = 0.f, ss = 0.f;
     for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) s += partials[i];
@@ -1407,15 +1407,14 @@ __global__ __launch_bounds__(RED_THREADS) void actor_logs_kernel(const float *__
     if (threadIdx.x == 0) {
         if (logs_loss) logs_loss[0] += -inv_members * s / (float)n_rows;
         if (logs_gn) logs_gn[0] = sqrtf(ss);
-        if (bump) *bump += 1;   // the update counter of the chained actor launch (its hand-off tags, its noise draw)
     }
 }
 
 extern "C" int ssac_actor_logs(const float *partials, int n_tiles, int n_rows, float inv_members, const float *sumsq,
-                               int n_sumsq, float *logs_loss, float *logs_gn, long long *bump, void *stream) {
+                               int n_sumsq, float *logs_loss, float *logs_gn, void *stream) {
     if (!partials || n_tiles <= 0 || n_rows <= 0) return ssac_fail("ssac_actor_logs: bad arguments");
     SSAC_LAUNCH(actor_logs_kernel, dim3(1), dim3(RED_THREADS), 0, ST, partials, n_tiles, n_rows, inv_members, sumsq,
-                sumsq ? n_sumsq : 0, logs_loss, logs_gn, bump);
+                sumsq ? n_sumsq : 0, logs_loss, logs_gn);
     return ssac_check_launch("actor_logs");
 }
 
@@ -1575,12 +1574,24 @@ extern "C" ssac_launch_list *ssac_record_end(void) {
 extern "C" int ssac_launch_list_size(const ssac_launch_list *list) { return list ? (int)list->recs.size() : -1; }
 
 // slot_now: the address of this update's slot of the input ring for the argument members registered with
-// ssac_record_slot_patch (ssac_step_run), or null: the kernels find the slot through the feed block
-static int replay_list(ssac_launch_list *list, void *stream, const void *slot_now) {
+// ssac_record_slot_patch (ssac_step_run), or null: the kernels find the slot through the feed block.
+// value: this update's number for the members registered with ssac_record_value_patch (has_value: ssac_replay_value)
+static int replay_list(ssac_launch_list *list, void *stream, const void *slot_now, bool has_value, long long value) {
     void *argv[64];
     for (SsacLaunchRec &r : list->recs) {
         if (r.offsets.size() > 64) return ssac_fail("ssac_replay: too many kernel arguments");
+        if (!r.value_patches.empty() && !has_value)
+            return ssac_fail("ssac_replay: this list holds launches that take a per-update value: replay it with ssac_replay_value");
         for (size_t off : r.slot_patches) memcpy(r.blob.data() + off, &slot_now, sizeof(void *));
+        for (const SsacLaunchRec::ValuePatch &vp : r.value_patches) {
+            if (vp.kind == 0) {
+                const uint32_t v = (uint32_t)((value + vp.addend) & 0x7fffffff);
+                memcpy(r.blob.data() + vp.off, &v, 4);
+            } else {
+                const long long v = value + vp.addend;
+                memcpy(r.blob.data() + vp.off, &v, 8);
+            }
+        }
         for (size_t i = 0; i < r.offsets.size(); ++i) argv[i] = r.blob.data() + r.offsets[i];
         hipError_t e = hipLaunchKernel(r.func, r.grid, r.block, argv, r.lds, ST);
         if (e != hipSuccess) return ssac_check_launch("ssac_replay");
@@ -1590,7 +1601,13 @@ static int replay_list(ssac_launch_list *list, void *stream, const void *slot_no
 
 extern "C" int ssac_replay(ssac_launch_list *list, void *stream) {
     if (!list) return ssac_fail("ssac_replay: null launch list");
-    return replay_list(list, stream, nullptr);
+    return replay_list(list, stream, nullptr, false, 0);
+}
+
+extern "C" int ssac_replay_value(ssac_launch_list *list, void *stream, long long value) {
+    if (!list) return ssac_fail("ssac_replay_value: null launch list");
+    if (value < 0) return ssac_fail("ssac_replay_value: the per-update value must not be negative");
+    return replay_list(list, stream, nullptr, true, value);
 }
 
 extern "C" void ssac_launch_list_free(ssac_launch_list *list) { delete list; }
@@ -1664,7 +1681,7 @@ extern "C" int ssac_step_run(ssac_step *s, const int64_t *idx_host, const int32_
     memcpy(s->ring + (size_t)slot * s->slot_bytes, st, (size_t)s->slot_bytes);
     __builtin_ia32_sfence();
     for (ssac_launch_list *l : s->lists) {
-        const int rc = replay_list(l, stream, g_ssac_slot_by_value ? s->ring + (size_t)slot * s->slot_bytes : nullptr);
+        const int rc = replay_list(l, stream, g_ssac_slot_by_value ? s->ring + (size_t)slot * s->slot_bytes : nullptr, false, 0);
         if (rc) return rc;
     }
     if (k % s->event_every == s->event_every - 1) {

@@ -1859,7 +1859,7 @@ extern "C" int ssac_actor_chain_fused(const ssac_mlp *actor, const float *X, int
                                       float *logp, float *H1, float *H2, float *out, const ssac_mlp *critics, float *Q,
                                       float *DXu, const float *log_alpha, int use_entropy, float inv_members,
                                       const ssac_popart *popart, int pop, float *d_out, float *DZ2, float *DZ1,
-                                      float *partials, unsigned long long *handoff, const long long *tick,
+                                      float *partials, unsigned long long *handoff, long long update_no,
                                       float *begin_logs, int n_logs, ssac_adam_ctl *begin_ctl, void *stream) {
     if (!eps && !rng) return ssac_fail("ssac_actor_chain_fused: neither eps nor an rng stream given");
     if (!fused_dbuf_ok(actor) || (actor->out_dim & 1) || !fused_dbuf_ok(critics) || critics->out_dim != 1)
@@ -1879,9 +1879,13 @@ extern "C" int ssac_actor_chain_fused(const ssac_mlp *actor, const float *X, int
     if (rng) ga.rng = RngArgs{rng->seed, rng->counter, rng->offset};
     ga.act_dst = xsa; ga.ld_act = ld_xsa; ga.act_col0 = S; ga.logp = logp; ga.copy_x = 1;
     ga.begin_logs = begin_logs; ga.begin_n = begin_logs ? n_logs : 0; ga.begin_ctl = begin_ctl;
-    static unsigned launch_no = 0;   // tags of eager launches: bit 31 set, so they never meet a recorded launch's
-    Handoff ho{handoff, tick, tick ? 1u : (0x80000000u | (++launch_no & 0x7fffffffu)), S, A, 1,
-               handoff + (int64_t)n_rows * A, handoff + (int64_t)n_rows * A + (int64_t)N * n_rows};
+    // the launch's tag: 1 + update_no (a caller-numbered update: every RECORDED launch is -- its replays are renumbered
+    // through ssac_replay_value, which rewrites the tag and the noise draw in the recorded argument bytes), or a host counter
+    // with bit 31 set (update_no < 0: an eager launch nobody numbers)
+    static unsigned launch_no = 0;
+    if (update_no < 0 && g_ssac_recording) return ssac_fail("ssac_actor_chain_fused: a recorded launch needs an update number");
+    Handoff ho{handoff, nullptr, update_no >= 0 ? (unsigned)((update_no + 1) & 0x7fffffff) : (0x80000000u | (++launch_no & 0x7fffffffu)),
+               S, A, 1, handoff + (int64_t)n_rows * A, handoff + (int64_t)n_rows * A + (int64_t)N * n_rows};
     ga.ho = ho;
     fill_common(gb, actor, nullptr, nullptr, 0, 0, n_rows);
     gb.H1 = H1; gb.H2 = H2;
@@ -1911,6 +1915,12 @@ extern "C" int ssac_actor_chain_fused(const ssac_mlp *actor, const float *X, int
     hipStream_t st = (hipStream_t)stream;
     if (tc == 16) SSAC_LAUNCH((fused_actor_chain_kernel<16>), grid, dim3(NTHR), lds, st, ga, gb, gc, tiles_a, cgx);
     else SSAC_LAUNCH((fused_actor_chain_kernel<32>), grid, dim3(NTHR), lds, st, ga, gb, gc, tiles_a, cgx);
+    if (update_no >= 0) {   // (recorded: a replay's number replaces update_no in the tag and in the noise draw)
+        for (int a = 0; a < 3; ++a) ssac_record_value_patch(a, offsetof(FusedArgs, ho) + offsetof(Handoff, base), 0, 1);
+        if (rng && !rng->counter)
+            for (int a = 0; a < 2; ++a)
+                ssac_record_value_patch(a, offsetof(FusedArgs, rng) + offsetof(RngArgs, offset), 1, rng->offset - update_no);
+    }
     return ssac_check_launch("fused_actor_chain");
 }
 

@@ -30,6 +30,11 @@ struct SsacLaunchRec {
     // byte offsets in `blob` of 8-byte pointers that a replay through ssac_step_run overwrites with the address of THIS
     // update's slot of the input ring (ssac_record_slot_patch below); a plain ssac_replay writes null there
     std::vector<size_t> slot_patches;
+    // ... and of integers that a replay through ssac_replay_value overwrites with (value + addend): the per-update number
+    // a launch derives its hand-off tag and its noise draw from, when the update has no device-resident counter
+    // (ssac_record_value_patch below).  kind 0: uint32, (value + addend) & 0x7fffffff; kind 1: int64
+    struct ValuePatch { size_t off; int kind; long long addend; };
+    std::vector<ValuePatch> value_patches;
 };
 
 extern thread_local std::vector<SsacLaunchRec> *g_ssac_recording;
@@ -74,6 +79,11 @@ inline void ssac_record_slot_patch(int arg_index, size_t member_off) {
     if (!g_ssac_recording || g_ssac_recording->empty()) return;
     SsacLaunchRec &r = g_ssac_recording->back();
     r.slot_patches.push_back(r.offsets[(size_t)arg_index] + member_off);
+}
+inline void ssac_record_value_patch(int arg_index, size_t member_off, int kind, long long addend) {
+    if (!g_ssac_recording || g_ssac_recording->empty()) return;
+    SsacLaunchRec &r = g_ssac_recording->back();
+    r.value_patches.push_back(SsacLaunchRec::ValuePatch{r.offsets[(size_t)arg_index] + member_off, kind, addend});
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -932,7 +932,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
 class _RecordedActor:
     def __init__(self):
         self.calls, self.list, self.blk, self.eps, self.index = 0, None, None, None, None
-        self.in_kernel, self.tick = False, None
+        self.in_kernel = False
 
     def __del__(self):
         if self.list:
@@ -982,7 +982,6 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
         # the chained launch (ACTOR_CHAIN) with the stock generator draws its noise in the kernel: no buffers, no launches
         rec.in_kernel = ACTOR_CHAIN and lu.IN_KERNEL_NOISE and rng.normal_is_stock()
         rec.eps = None if rec.in_kernel else [torch.empty(batch_size, A, device=dev) for _ in agent.actors]
-        rec.tick = torch.zeros(1, dtype=torch.int64, device=dev) if ACTOR_CHAIN else None
     elif rec.in_kernel != (ACTOR_CHAIN and lu.IN_KERNEL_NOISE and rng.normal_is_stock()):
         # a noise hook was installed / removed (or the form switched) since the recording: record again
         del cache[key]
@@ -993,13 +992,15 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
     if rec.list is None:
         check(lib.ssac_record_begin())
         try:
-            logs = _online_actor_update(**kw, _rec_blk=rec.blk, _rec_eps=rec.eps, _rec_tick=rec.tick)
+            logs = _online_actor_update(**kw, _rec_blk=rec.blk, _rec_eps=rec.eps)
         finally:
             rec.list = lib.ssac_record_end()
         base = rec.blk.data_ptr()
         rec.index = {k_: (v.data_ptr() - base) // 4 for k_, v in logs.items()}
     else:
-        check(lib.ssac_replay(rec.list, engine.stream()))
+        ns_upd = lu.noise_stream(agent, dev)
+        check(lib.ssac_replay_value(rec.list, engine.stream(), ns_upd[2]))   # (this update's number: tags, noise draws)
+        ns_upd[2] += 1
         rng.choice(agent.actors)  # learning.py:417-419 (keeps the Python RNG stream in step)
     slot_i = ring.advance()
     ring.buf[slot_i].copy_(rec.blk)   # this call's log block -> its own ring slot (device-to-device, no sync)
@@ -1009,20 +1010,23 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
 
 def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_size, clip,
                          random_process, noise_clip, augmenter, aug_mix, premade_replay_dicts=None,
-                         per=False, discrete=False, use_baseline=False, _rec_blk=None, _rec_eps=None, _rec_tick=None):
+                         per=False, discrete=False, use_baseline=False, _rec_blk=None, _rec_eps=None):
     E = agent.ensemble_size
     dev = log_alphas[0].device
     ws = lu.agent_ws(agent, dev)
     adam = engine.adam_group(actor_optimizer, dev)
-    begin_folded = False
+    # a RECORDED update clears its (fixed) log block and advances the Adam step by a recorded launch: the chained launch of
+    # the first member does it (ACTOR_CHAIN), or a begin launch in front
+    begin_folded = _rec_blk is not None and ACTOR_CHAIN
     if _rec_blk is not None:
-        slot = _rec_blk   # recorded update: a fixed log block, cleared (and the Adam step advanced) by a recorded launch
-        # (_rec_tick: the chained launch of the first member does that itself -- no launch in front of it)
-        begin_folded = _rec_tick is not None
+        slot = _rec_blk
         if not begin_folded:
             check(lib.ssac_begin_update(slot.data_ptr(), lu.LOG_WIDTH, adam.ctl.ptr, 0, engine.stream()))
     else:
         slot = lu.log_block(dev, adam)
+    # this update's number: hand-off tags and in-kernel noise draws of the chained launches (checkpointed with the agent's
+    # noise stream, so a resumed run continues the sequence)
+    ns_upd = lu.noise_stream(agent, dev)
     first_fused = True
     logs = {}
     st = engine.stream()
@@ -1067,12 +1071,11 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             logp = ws.get(f"au.logp{i}", (B,))
             ah1, ah2 = ws.get(f"au.a{i}.h1", (1, B, H)), ws.get(f"au.a{i}.h2", (1, B, H))
             aout = ws.get(f"au.a{i}.y", (1, B, 2 * A))
-            # the noise: a recorded update with the stock generator takes it from the engine's Philox stream INSIDE the
-            # launch (draw number = the recording's device counter; no generator launch, no buffer); otherwise a draw --
-            # into the recording's fixed buffer, or a fresh one -- as a_dist.rsample() makes it (learning.py:392)
-            chain = (ACTOR_CHAIN and a_arena.fused_dbuf and A <= 32 and H * A <= 512 * 9
-                     and (_rec_blk is None or _rec_tick is not None))
-            in_kernel = chain and _rec_tick is not None and _rec_eps is None
+            # the noise: with the stock generator the chained launch takes it from the engine's Philox stream INSIDE the
+            # kernel (draw number = this update's number: no generator launch, no buffer); otherwise a draw -- into the
+            # recording's fixed buffer, or a fresh one -- as a_dist.rsample() makes it (learning.py:392)
+            chain = ACTOR_CHAIN and a_arena.fused_dbuf and A <= 32 and H * A <= 512 * 9
+            in_kernel = chain and lu.IN_KERNEL_NOISE and rng.normal_is_stock() and _rec_eps is None
             eps = None   # (kept alive to the end of the member's launches: the kernels read it asynchronously)
             if in_kernel:
                 eps_ptr = 0
@@ -1091,19 +1094,17 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             if chain:
                 ho = ws.get(f"au.handoff{i}", (int(lib.ssac_actor_chain_handoff_words(B, N, A)),), dtype=torch.int64,
                             zero=True)
-                tick_ptr = _rec_tick.data_ptr() if _rec_tick is not None else 0
                 rs = None
                 if in_kernel:
-                    ns = lu.noise_stream(agent, dev)
                     # (its own stream: the critic updates number their draws from the same seed)
-                    rs = _lib.Rng((ns[0] ^ 0x5DEECE66D1CEB00C) & (2 ** 64 - 1), tick_ptr, i << 40)
+                    rs = _lib.Rng((ns_upd[0] ^ 0x5DEECE66D1CEB00C) & (2 ** 64 - 1), 0, (i << 40) + ns_upd[2])
                 fold = begin_folded and first_fused
                 check(lib.ssac_actor_chain_fused(
                     C.byref(a_arena.desc()), s_rep.data_ptr(), lds, B, eps_ptr, C.byref(rs) if rs is not None else None,
                     float(actor.log_std_low), float(actor.log_std_high), xpi.data_ptr(), S + A, logp.data_ptr(),
                     ah1.data_ptr(), ah2.data_ptr(), aout.data_ptr(), C.byref(c_arena.desc()), q.data_ptr(),
                     dxu.data_ptr(), log_alpha.data_ptr(), 1, inv_e, pp, dopop, d_out.data_ptr(), dz2.data_ptr(),
-                    dz1.data_ptr(), parts.data_ptr(), ho.data_ptr(), tick_ptr,
+                    dz1.data_ptr(), parts.data_ptr(), ho.data_ptr(), ns_upd[2],
                     slot.data_ptr() if fold else 0, lu.LOG_WIDTH if fold else 0, adam.ctl.ptr if fold else 0, st))
             else:
                 if begin_folded and first_fused:   # (a member the chained launch does not take: the begin launch after all)
@@ -1125,12 +1126,9 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             engine.weight_grads(a_arena, s_rep, lds, 0, ah1, ah2, d_out, dz2, dz1, B, adam=adam,
                                 adam_key=("actor", i), sumsq=ss)
             one = E_glob == 1   # (then the logged actor is this one: both logs in one launch)
-            # (the LAST member's log launch advances the recording's update counter: hand-off tags, noise draws)
-            last_member = all(ms.local(j_) is None for j_ in range(ig + 1, E_glob)) if ms is not None else ig == E_glob - 1
-            bump = _rec_tick.data_ptr() if (_rec_tick is not None and last_member) else 0
             check(lib.ssac_actor_logs(parts.data_ptr(), tiles, B, inv_e, ss.data_ptr() if one else 0, ss.numel(),
                                       slot[lu.L_ACTOR_LOSS:].data_ptr(), slot[lu.L_ACTOR_GN:].data_ptr() if one else 0,
-                                      bump, st))
+                                      st))
             member_ss.append(None if one else ss)
             continue
         ah1, ah2, aout = engine.mlp_forward(a_arena, s_rep, lds, 0, B, ws, f"au.a{i}")
@@ -1229,6 +1227,7 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             engine.mlp_backward(a_arena, d_out, s_rep, lds, 0, ah1, ah2, B, ws, f"au.a{i}", adam=adam,
                                 adam_key=("actor", i), sumsq=ss)
         member_ss.append(ss)
+    ns_upd[2] += 1
     if clip:
         _clip_and_step(adam, clip_members, clip, None, member_shard=ms)
     for actor in agent.actors:  # bf16 mode: the actor step ran on the fp32 masters; refresh the shadows

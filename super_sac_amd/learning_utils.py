@@ -109,12 +109,14 @@ IN_KERNEL_NOISE = True
 
 
 def noise_stream(agent, device):
-    """[seed, draws so far] of the agent's engine noise stream (Philox4x32-10, include/ssac_hip.h: ssac_rng).  The seed
+    """[seed, critic-update draws so far, online-actor-update number] of the agent's engine noise stream (Philox4x32-10, include/ssac_hip.h: ssac_rng).  The seed
     is drawn once from torch's device generator, so `torch.manual_seed` still determines the run."""
     ns = agent.__dict__.get("_ssac_noise")
     if ns is None:
         seed = int(torch.randint(0, 2 ** 62, (1,), device=device, dtype=torch.int64))
-        ns = agent.__dict__["_ssac_noise"] = [seed, 0]
+        ns = agent.__dict__["_ssac_noise"] = [seed, 0, 0]
+    if len(ns) < 3:   # (a checkpoint written before the actor updates numbered themselves)
+        ns.append(0)
     return ns
 
 

@@ -821,8 +821,9 @@ def test_actor_update_chained_launch_matches_three_launches():
     of ONE launch, learning.ACTOR_CHAIN) against the three launches it replaces, on the same injected noise: the first
     update's intermediate results (Q, dQ/da, dL/d(actor output), dz1) and the logs of eight updates -- two eager, one
     recorded, five replayed -- within fp32 association (the critics' fc1 sums state and action columns separately);
-    parameters with counted sign-flip stragglers.  Then the in-kernel noise of a recorded chained update (stock generator):
-    the action the forward half stored must be tanh(mu + sd * eps) of the Philox stream the header documents."""
+    parameters with counted sign-flip stragglers.  Then the in-kernel noise of a replayed chained update (stock generator; renumbered
+    through ssac_replay_value): the action the forward half stored must be tanh(mu + sd * eps) of the Philox stream at the
+    update's number."""
     import ctypes as C
     import torch
     import super_sac_amd as ssa
@@ -841,10 +842,10 @@ def test_actor_update_chained_launch_matches_three_launches():
     # in-kernel noise: stock generator, recorded chained update; the stored action against the documented Philox stream
     _, _, _, agent, ws = run(True, hook=False, n_upd=5)
     rec = next(iter(agent.__dict__["_ssac_actor_rec"].values()))
-    assert rec.in_kernel and rec.list is not None and int(rec.tick.item()) == 3   # (three recorded / replayed updates so far)
     ns = lu.noise_stream(agent, dev)
+    assert rec.in_kernel and rec.list is not None and ns[2] == 5   # (five numbered updates: 2 eager, 1 recorded, 2 replayed)
     eps = torch.empty(B, A, device=dev)
-    rs = ssa._lib.Rng((ns[0] ^ 0x5DEECE66D1CEB00C) & (2 ** 64 - 1), 0, 2)   # the LAST update ran at counter value 2
+    rs = ssa._lib.Rng((ns[0] ^ 0x5DEECE66D1CEB00C) & (2 ** 64 - 1), 0, 4)   # the LAST update was number 4
     ssa._lib.check(ssa._lib.lib.ssac_philox_normal(eps.data_ptr(), B, A, C.byref(rs), ssa.engine.stream()))
     y = ws.get("au.a0.y", (1, B, 2 * A))[0]
     mu, raw = y[:, :A], y[:, A:]

@@ -555,9 +555,12 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
             if (bias_thr_) ss += bsum_ * bsum_;
             if (g.sumsq) {
                 ss = wave_sum(ss);
+                GSTAMP(10);
                 lds_barrier();  // red[] (bias partials) and the partial tiles have been consumed
+                GSTAMP(11);
                 if (lane == 0) red[tid_all >> 6] = ss;
                 lds_barrier();
+                GSTAMP(12);
                 if (tid_all == 0) {
                     float tot = 0.0f;
                     for (int w = 0; w < 4 * KS; ++w) tot += red[w];

@@ -36,3 +36,4 @@ row("wgrad tile 0", g, 0, ["operand issue + loss fold + first chunk", "K loop", 
 print("wgrad tile 0 prologue (serialised by the debug stamps): first operand chunk", g[5] - g[0], " loss fold (pre)", g[6] - g[5],
       " LDS stores + second chunk", g[7] - g[6], " barrier + first fragment reads", g[1] - g[7])
 print("wgrad tile 0 epilogue: partial sums from LDS", g[8] - g[3], " gradient-norm partial (2 barriers)", g[9] - g[8], " Adam + stores issued", g[4] - g[9])
+print("   gradient-norm partial: squares + wave sum", g[10] - g[8], " first barrier", g[11] - g[10], " second barrier", g[12] - g[11], " sum of 16 + slot stores", g[9] - g[12])

@@ -434,6 +434,11 @@ int ssac_group_norms(const float *sumsq, int n_groups, int group_size, const ssa
 
 /* ---- Polyak / hard update over n floats: learning_utils.py:160-167 */
 int ssac_polyak(float *target, const float *source, int64_t n, float tau, void *stream);
+/* the same over several (target, source, count) tensors in one launch (a module whose parameters are not a packed arena:
+ * the pixel encoders' conv / fc / norm tensors); per element the arithmetic of ssac_polyak */
+#define SSAC_MAX_POLYAK_SEGS 24
+int ssac_polyak_multi(float *const *targets, const float *const *sources, const int64_t *counts, int n_tensors, float tau,
+                      void *stream);
 
 /* ---- tanh-squashed normal head: distributions.py:9-15, 64-104.
  * out (n_rows x 2A) -> a = tanh(mu + sigma eps) written to act_dst (row stride ld_act, column
@@ -870,6 +875,10 @@ int ssac_linear_wgrad_splitk(const float *dY, int64_t ldy, const float *X, int64
                              float *partial_b, int M_out, int N_in, int n_rows, int rows_per_slice,
                              void *stream);
 int ssac_reduce_slices(const float *partial, int slices, int64_t n, float *out, void *stream);
+/* two such reductions with the same slice count in one launch (a layer's weight and bias slices); per output the same
+ * sums in the same order as ssac_reduce_slices */
+int ssac_reduce_slices_pair(const float *partial0, int64_t n0, float *out0, const float *partial1, int64_t n1, float *out1,
+                            int slices, void *stream);
 int ssac_relu_mask(float *dy, const float *y, int64_t n, void *stream);
 int ssac_relu_mask_to(const float *dy, const float *y, int64_t n, float *out, void *stream);
 /* (n x channels x pixels) <-> (n x pixels x channels): the encoders' fc weight is stored in the reference's NCHW

@@ -89,6 +89,7 @@ SIGNATURES = {
     "ssac_record_begin": [],
     "ssac_record_end": [],
     "ssac_launch_list_size": [_P],
+    "ssac_polyak_multi": [_P, _P, _P, _I, _F, _P],
     "ssac_replay": [_P, _P],
     "ssac_replay_value": [_P, _P, C.c_longlong],
     "ssac_launch_list_free": [_P],
@@ -182,6 +183,7 @@ SIGNATURES = {
     "ssac_linear_dgrad_masked": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P],
     "ssac_linear_wgrad_splitk": [_P, _L, _P, _L, _P, _P, _I, _I, _I, _I, _P],
     "ssac_reduce_slices": [_P, _I, _L, _P, _P],
+    "ssac_reduce_slices_pair": [_P, _L, _P, _P, _L, _P, _I, _P],
     "ssac_relu_mask": [_P, _P, _L, _P],
     "ssac_relu_mask_to": [_P, _P, _L, _P, _P],
     "ssac_permute_cp": [_P, _P, _I, _I, _I, _I, _P],

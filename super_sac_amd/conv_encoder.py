@@ -264,9 +264,8 @@ class ConvEncoderEngine:
             else:
                 check(lib.ssac_linear_wgrad_splitk(dy.data_ptr(), co, sv["cols"][l].data_ptr(), ckk, pw.data_ptr(),
                                                    pb.data_ptr(), co, ckk, rows, ROWS_PER_SLICE, st))
-            check(lib.ssac_reduce_slices(pw.data_ptr(), slices, co * ckk,
-                                         self._seg(2 * l, self.grads).data_ptr(), st))
-            check(lib.ssac_reduce_slices(pb.data_ptr(), slices, co, self._seg(2 * l + 1, self.grads).data_ptr(), st))
+            check(lib.ssac_reduce_slices_pair(pw.data_ptr(), co * ckk, self._seg(2 * l, self.grads).data_ptr(),
+                                              pb.data_ptr(), co, self._seg(2 * l + 1, self.grads).data_ptr(), slices, st))
             if l == 0:
                 break
             pci, pco, pk, ps, pHi, pWi, pHo, pWo = sv["shapes"][l - 1]

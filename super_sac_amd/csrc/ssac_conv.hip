@@ -184,6 +184,40 @@ __global__ __launch_bounds__(1024) void reduce_slices_wide_kernel(const float *_
     }
 }
 
+// two reductions in one launch (a convolution layer's weight AND bias slices): workgroups [0, ceil(n0 / 64)) take the first
+// problem, the rest the second; per output the sums of reduce_slices_kernel / reduce_slices_wide_kernel, in their order
+__global__ __launch_bounds__(1024) void reduce_slices_pair_kernel(const float *__restrict__ p0, int64_t n0, float *__restrict__ o0,
+                                                                  const float *__restrict__ p1, int64_t n1, float *__restrict__ o1,
+                                                                  int slices, int wide) {
+    __shared__ float red[16][64];
+    const int g0 = (int)((n0 + 63) / 64);
+    const bool second = (int)blockIdx.x >= g0;
+    const float *partial = second ? p1 : p0;
+    float *out = second ? o1 : o0;
+    const int64_t n = second ? n1 : n0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = (int64_t)(second ? blockIdx.x - g0 : blockIdx.x) * 64 + lane;
+    if (!wide) {   // few slices: one serial sum per output (wave 0)
+        if (w == 0 && i < n) {
+            float s = 0.0f;
+            for (int z = 0; z < slices; ++z) s += partial[(int64_t)z * n + i];
+            out[i] = s;
+        }
+        return;
+    }
+    float s = 0.0f;
+    if (i < n)
+        for (int z = w; z < slices; z += 16) s += partial[(int64_t)z * n + i];
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && i < n) {
+        float t = red[0][lane];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += red[k][lane];
+        out[i] = t;
+    }
+}
+
 // out[m*ldo + n] = bias[n] + sum_s partial[(s*M + m)*N + n], fixed order
 __global__ void reduce_slices_bias_kernel(const float *__restrict__ partial, int slices, int M, int N,
                                           const float *__restrict__ bias, float *__restrict__ out, int64_t ldo) {
@@ -413,6 +447,15 @@ extern "C" int ssac_reduce_slices(const float *partial, int slices, int64_t n, f
     }
     SSAC_LAUNCH(reduce_slices_kernel, dim3(grid_for(n)), dim3(256), 0, ST, partial, slices, n, out);
     return ssac_check_launch("reduce_slices");
+}
+
+extern "C" int ssac_reduce_slices_pair(const float *partial0, int64_t n0, float *out0, const float *partial1, int64_t n1,
+                                       float *out1, int slices, void *stream) {
+    if (slices <= 0 || n0 <= 0 || n1 <= 0) return ssac_fail("ssac_reduce_slices_pair: bad sizes");
+    const unsigned grid = (unsigned)((n0 + 63) / 64 + (n1 + 63) / 64);
+    SSAC_LAUNCH(reduce_slices_pair_kernel, dim3(grid), dim3(1024), 0, ST, partial0, n0, out0, partial1, n1, out1, slices,
+                slices >= 64 ? 1 : 0);
+    return ssac_check_launch("reduce_slices_pair");
 }
 
 extern "C" int ssac_reduce_slices_bias(const float *partial, int slices, int M, int N, const float *bias,

@@ -236,11 +236,18 @@ def soft_update(target, source, tau):
                 _polyak_tensor(ta.params, sa.params, tau)
             target.__dict__["_ssac_polyak"] = [source, ta, sa, list(target.nets), list(source.nets), 1]
             return
-    for tp, sp in zip(target.parameters(), source.parameters()):
-        if tp.is_cuda and tp.data.is_contiguous() and sp.data.is_contiguous():
-            _polyak_tensor(tp.data, sp.data, tau)
-        else:
-            raise RuntimeError("soft_update expects contiguous device parameters")
+    # any other module (a pixel encoder: conv / fc / norm tensors): all of its parameters in ONE launch
+    pairs = list(zip(target.parameters(), source.parameters()))
+    if not pairs:
+        return
+    n = len(pairs)
+    tp_, sp_, cn_ = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_int64 * n)()
+    for j, (tp, sp) in enumerate(pairs):
+        if not (tp.is_cuda and tp.data.is_contiguous() and sp.data.is_contiguous() and tp.dtype == torch.float32
+                and sp.dtype == torch.float32 and tp.numel() == sp.numel()):
+            raise RuntimeError("soft_update expects contiguous float32 device parameters of equal size")
+        tp_[j], sp_[j], cn_[j] = tp.data_ptr(), sp.data_ptr(), tp.numel()
+    check(lib.ssac_polyak_multi(tp_, sp_, cn_, n, float(tau), engine.stream()))
 
 
 def hard_update(target, source):

@@ -1358,3 +1358,30 @@ def test_device_priority_refresh_of_more_than_8192_rows(ssa):
     torch.cuda.synchronize()
     assert np.array_equal(dev.sum_tree, host.sum_tree) and np.array_equal(dev.min_tree, host.min_tree)
     assert dev._max_priority == host._max_priority
+
+
+def test_polyak_multi_equals_the_single_tensor_launch(ssa):
+    """ssac_polyak_multi (every parameter tensor of a module in one launch: the pixel encoders' soft_update) against
+    ssac_polyak per tensor, bit for bit -- aligned and unaligned starts, sizes that are not multiples of 4, more tensors
+    than one launch holds."""
+    import ctypes as C
+    lib, chk = ssa._lib.lib, ssa._lib.check
+    torch.manual_seed(0)
+    sizes = [1, 3, 4, 50, 864, 9216, 50 * 39200 // 7, 32, 5] * 4   # 36 tensors > SSAC_MAX_POLYAK_SEGS
+    pool = torch.randn(sum(sizes) + 64, device=DEV)
+    tgt, src, off = [], [], 1                                        # (offset 1: unaligned starts)
+    for n in sizes:
+        tgt.append(pool[off:off + n].clone() if n % 2 else pool[off:off + n].clone().contiguous())
+        src.append(torch.randn(n, device=DEV))
+        off += n
+    want = [t.clone() for t in tgt]
+    for t, s in zip(want, src):
+        chk(lib.ssac_polyak(t.data_ptr(), s.data_ptr(), t.numel(), 0.005, ssa.engine.stream()))
+    n = len(sizes)
+    tp, sp, cn = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_int64 * n)()
+    for j, (t, s) in enumerate(zip(tgt, src)):
+        tp[j], sp[j], cn[j] = t.data_ptr(), s.data_ptr(), t.numel()
+    chk(lib.ssac_polyak_multi(tp, sp, cn, n, 0.005, ssa.engine.stream()))
+    torch.cuda.synchronize()
+    for j, (a, b) in enumerate(zip(tgt, want)):
+        assert torch.equal(a, b), j

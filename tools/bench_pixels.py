@@ -64,6 +64,8 @@ if __name__ == "__main__":
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     step, B = build(which, torch.device("cuda"))
     for _ in range(3): step()
+    import gc
+    gc.collect(); gc.freeze()   # (as bench.py and INTEGRATION.md: no generation-2 collection pause inside the timed region)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): step()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps

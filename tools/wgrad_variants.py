@@ -5,6 +5,9 @@ import torch
 import super_sac_amd as ssa
 dev = torch.device("cuda")
 B, in_dim, H, N = 512, 23, 256, 10
+if len(sys.argv) > 2:
+    B, N = int(sys.argv[1]), int(sys.argv[2])
+print('B', B, 'N', N)
 ar = ssa.engine.MlpArena(N, in_dim, H, 1, dev); ar.params.normal_(std=0.05)
 x = torch.randn(B, in_dim, device=dev)
 h1 = torch.randn(N, B, H, device=dev).relu(); h2 = torch.randn(N, B, H, device=dev).relu()

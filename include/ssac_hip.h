@@ -739,6 +739,17 @@ int ssac_actor_bwd_fused(const ssac_mlp *actor, const float *H1, const float *H2
                          void *stream);
 int ssac_actor_logs(const float *partials, int n_tiles, int n_rows, float inv_members, const float *sumsq, int n_sumsq,
                     float *logs_loss, float *logs_gn, void *stream);
+/* The fused actor update on a CRITIC-SHARDED rank (SURVEY 8(e) "Collective -- actor step": a MIN over (B,) and a SUM over
+ * (B x A)): between ssac_critic_fwd_dx_fused on the rank's own critics and ssac_actor_bwd_fused with n_critics = 1 --
+ *   ssac_actor_route_local  q_local[b] = min over the local critics (and a copy, q_reduce, for the MIN all-reduce),
+ *                           d_sel[b][:] = dQ/da of the local arg-min critic (first index on ties)
+ *   (MIN all-reduce of q_reduce)
+ *   ssac_actor_route_mask   rows whose local minimum is not the global one are zeroed in d_sel
+ *   (SUM all-reduce of d_sel) */
+int ssac_actor_route_local(const float *q, const float *dxu, int n_local, int n_rows, int action_dim, float *q_local,
+                           float *q_reduce, float *d_sel, void *stream);
+int ssac_actor_route_mask(const float *q_local, const float *q_global, int n_rows, int action_dim, float *d_sel,
+                          void *stream);
 
 /* The first three launches above as ONE (round 4): the actor's workgroups (16-row tiles, lowest workgroup ids) run the
  * forward + rsample, publish a_theta as tagged 8-byte granules, WAIT for their rows' Q_j and dQ_j/da from every critic and

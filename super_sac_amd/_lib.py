@@ -218,6 +218,8 @@ SIGNATURES = {
     "ssac_critic_fwd_dx_fused": [_MP, _P, _L, _I, _I, _I, _P, _P, _P],
     "ssac_actor_bwd_fused": [_MP, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _F, _F, _F, _P, _I, _P, _P, _P, _P, _P],
     "ssac_actor_logs": [_P, _I, _I, _F, _P, _I, _P, _P, _P],
+    "ssac_actor_route_local": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
+    "ssac_actor_route_mask": [_P, _P, _I, _I, _P, _P],
     "ssac_actor_chain_fused": [_MP, _P, _L, _I, _P, _P, _F, _F, _P, _L, _P, _P, _P, _P, _MP, _P, _P, _P, _I, _F, _P, _I,
                                _P, _P, _P, _P, _P, _L, _P, _I, _P, _P],
     "ssac_actor_chain_handoff_words": [_I, _I, _I],

@@ -1435,6 +1435,53 @@ extern "C" int ssac_drq_shift(const void *src, int src_dtype, const int64_t *idx
     return ssac_check_launch("drq_shift");
 }
 
+// ------------------------------------------------------------------ arg-min routing on a critic-sharded rank
+// The online actor update routes dL/dQ through the arg-min critic of every row (learning.py:402: min over ALL critics).  A
+// rank that holds n_loc of them reduces locally first: q_loc[b] = min_j Q_j[b], d_sel[b][:] = dQ_am/da of the local arg-min
+// (first index on ties, as torch.min); after the MIN all-reduce of q_loc only the rank whose local minimum IS the global one
+// keeps its d_sel row (the others zero it), and the SUM all-reduce that follows hands every rank the routed gradient.
+__global__ void actor_route_local_kernel(const float *__restrict__ q, const float *__restrict__ dxu, int n_loc, int n_rows,
+                                         int A, float *__restrict__ q_loc, float *__restrict__ q_red,
+                                         float *__restrict__ d_sel) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_rows) return;
+    float mq = q[b];
+    int am = 0;
+    for (int j = 1; j < n_loc; ++j) {
+        const float v = q[(int64_t)j * n_rows + b];
+        if (v < mq) { mq = v; am = j; }
+    }
+    q_loc[b] = mq;
+    q_red[b] = mq;
+    for (int i = 0; i < A; ++i) d_sel[(int64_t)b * A + i] = dxu[((int64_t)am * n_rows + b) * A + i];
+}
+__global__ void actor_route_mask_kernel(const float *__restrict__ q_loc, const float *__restrict__ q_glob, int n_rows, int A,
+                                        float *__restrict__ d_sel) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_rows * A) return;
+    const int b = t / A;
+    if (q_loc[b] != q_glob[b]) d_sel[t] = 0.0f;
+}
+
+extern "C" int ssac_actor_route_local(const float *q, const float *dxu, int n_local, int n_rows, int action_dim,
+                                      float *q_local, float *q_reduce, float *d_sel, void *stream) {
+    if (!q || !dxu || !q_local || !q_reduce || !d_sel || n_local < 1 || action_dim < 1)
+        return ssac_fail("ssac_actor_route_local: bad arguments");
+    if (n_rows <= 0) return 0;
+    SSAC_LAUNCH(actor_route_local_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, ST, q, dxu, n_local, n_rows, action_dim,
+                q_local, q_reduce, d_sel);
+    return ssac_check_launch("actor_route_local");
+}
+
+extern "C" int ssac_actor_route_mask(const float *q_local, const float *q_global, int n_rows, int action_dim, float *d_sel,
+                                     void *stream) {
+    if (!q_local || !q_global || !d_sel || action_dim < 1) return ssac_fail("ssac_actor_route_mask: bad arguments");
+    if (n_rows <= 0) return 0;
+    SSAC_LAUNCH(actor_route_mask_kernel, dim3((n_rows * action_dim + 255) / 256), dim3(256), 0, ST, q_local, q_global, n_rows,
+                action_dim, d_sel);
+    return ssac_check_launch("actor_route_mask");
+}
+
 // ------------------------------------------------------------------ logs of the fused online actor update
 // logs_loss[0] += -inv_members * sum(partials) / n_rows  (losses/actor_pg_loss accumulates over the members);
 // logs_gn[0] = sqrt(sum(sumsq))  (gradients/random_actor_online_grad of the picked member)

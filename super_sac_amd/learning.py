@@ -1061,6 +1061,51 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
         kind = lu.actor_kind(actor)
         pp, dopop = (popart.ptr if popart else 0), (1 if (popart and pop) else 0)
         shard = parallel.shard_of(agent)
+        if (FUSED_ACTOR and kind == "stochastic" and random_process is None and not use_baseline and shard is not None
+                and not clip and a_arena.fused and c_arena.fused_dbuf and c_arena.out_dim == 1):
+            # ---- critic-sharded rank: the same fused launches, cut at the two exchange steps of SURVEY 8(e) -- sample +
+            #      [s|a] rows; the LOCAL critics' forward + dQ/da; local arg-min, MIN over the ranks, the global arg-min's
+            #      owner keeps its dQ/da row, SUM over the ranks; actor backward on (global min Q, routed dQ/da)
+            A, H = actor.action_size, a_arena.hidden
+            xpi = ws.get(f"au.x{i}", (B, S + A))
+            logp = ws.get(f"au.logp{i}", (B,))
+            ah1, ah2 = ws.get(f"au.a{i}.h1", (1, B, H)), ws.get(f"au.a{i}.h2", (1, B, H))
+            aout = ws.get(f"au.a{i}.y", (1, B, 2 * A))
+            eps = rng.draw_normal((B, A), dev)  # a_dist.rsample() (learning.py:392): every rank makes the same draw
+            check(lib.ssac_actor_sample_concat_fused(C.byref(a_arena.desc()), s_rep.data_ptr(), lds, B, eps.data_ptr(),
+                                                     float(actor.log_std_low), float(actor.log_std_high),
+                                                     xpi.data_ptr(), S + A, logp.data_ptr(), ah1.data_ptr(),
+                                                     ah2.data_ptr(), aout.data_ptr(), 0, st))
+            q = ws.get(f"au.c{i}.y", (N, B, 1))
+            dxu = ws.get(f"au.dxu{i}", (N, B, A))
+            check(lib.ssac_critic_fwd_dx_fused(C.byref(c_arena.desc()), xpi.data_ptr(), S + A, B, S, A, q.data_ptr(),
+                                               dxu.data_ptr(), st))
+            qloc, qglob = ws.get(f"au.qloc{i}", (B,)), ws.get(f"au.qmin{i}", (B,))
+            dsel = ws.get(f"au.da{i}", (1, B, A))
+            check(lib.ssac_actor_route_local(q.data_ptr(), dxu.data_ptr(), N, B, A, qloc.data_ptr(), qglob.data_ptr(),
+                                             dsel.data_ptr(), st))
+            parallel.all_reduce_min(qglob)
+            check(lib.ssac_actor_route_mask(qloc.data_ptr(), qglob.data_ptr(), B, A, dsel.data_ptr(), st))
+            parallel.all_reduce_sum(dsel)
+            tiles = int(lib.ssac_fused_row_tiles(C.byref(a_arena.desc()), B, 1))
+            parts = ws.get(f"au.parts{i}", (tiles,))
+            d_out = ws.get(f"au.dout{i}", (1, B, 2 * A))
+            dz2, dz1 = ws.get(f"au.a{i}.dz2", (1, B, H)), ws.get(f"au.a{i}.dz1", (1, B, H))
+            check(lib.ssac_actor_bwd_fused(C.byref(a_arena.desc()), ah1.data_ptr(), ah2.data_ptr(), B, qglob.data_ptr(), 1,
+                                           dsel.data_ptr(), aout.data_ptr(), eps.data_ptr(), logp.data_ptr(),
+                                           log_alpha.data_ptr(), 1, float(actor.log_std_low),
+                                           float(actor.log_std_high), inv_e, pp, dopop, d_out.data_ptr(),
+                                           dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), st))
+            ttot = engine.wgrad_tiles_total(a_arena)
+            ss = ws.get(f"au.ss{i}", (ttot,))
+            engine.weight_grads(a_arena, s_rep, lds, 0, ah1, ah2, d_out, dz2, dz1, B, adam=adam,
+                                adam_key=("actor", i), sumsq=ss)
+            one = E_glob == 1
+            check(lib.ssac_actor_logs(parts.data_ptr(), tiles, B, inv_e, ss.data_ptr() if one else 0, ss.numel(),
+                                      slot[lu.L_ACTOR_LOSS:].data_ptr(), slot[lu.L_ACTOR_GN:].data_ptr() if one else 0,
+                                      st))
+            member_ss.append(None if one else ss)
+            continue
         if (FUSED_ACTOR and kind == "stochastic" and random_process is None and not use_baseline and shard is None
                 and not clip and a_arena.fused and c_arena.fused_dbuf and c_arena.out_dim == 1):
             # ---- four launches instead of ~15 (include/ssac_hip.h, "the online actor update"): sample + [s|a] rows,

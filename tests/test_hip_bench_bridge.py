@@ -11,6 +11,8 @@ parameters / Polyak targets / Adam moments: the fixtures' 3e-5 absolute is state
 assertion), and the MEDIAN element within 2e-7.
 """
 import numpy as np
+
+import case_runner
 import pytest
 import torch
 
@@ -158,10 +160,13 @@ def test_benchmarked_mode_matches_the_oracle():
         diff = np.abs(a[key] - o[key])
         err, med, q = float(diff.max()), float(np.median(diff)), float(np.quantile(diff, 0.9999))
         worst[key] = (err, q, med)
-        # all but 1 in 10^4 elements inside the per-update tolerance; the stragglers are weights whose gradient is
-        # rounding noise around zero in some update -- Adam turns a sign difference there into a full lr-sized step
-        # (torch-CPU against the kernels' summation order; bounded by 2 lr per update, seen: a few 1e-4)
-        assert q < 5e-6 * N_UPDATES and med < 2e-7 and err < 2 * 3e-4 * N_UPDATES, f"{key}: max {err} q99.99 {q} median {med}"
+        # every element inside the per-update tolerance except COUNTED sign-flip stragglers (case_runner.straggler_check: at
+        # most 1 element in 10^4): weights whose gradient is rounding noise around zero in some update -- Adam turns a sign
+        # difference there into a full lr-sized step (torch-CPU against the kernels' summation order), so a straggler is
+        # bounded by the distance opposite steps can open, 2 lr per update; the Polyak targets and the moments follow the
+        # parameters
+        assert med < 2e-7, f"{key}: median {med}"
+        worst[key] += (case_runner.straggler_check(diff, 5e-6 * N_UPDATES, 2 * 3e-4 * N_UPDATES, "benchmarked mode vs oracle", key),)
     print("benchmarked mode vs oracle, worst deviations:", worst)
     # the same run with the host free to run ahead (no synchronisation inside the burst: soft_update requests land
     # before the device begins the update, log blocks are finalised by the next update's first launch): same bits

@@ -6,7 +6,7 @@
 #   gpurun -- 'bash tools/prof_r4.sh C1'   Atari pixel trace + PMC passes
 #   gpurun -- 'bash tools/prof_r4.sh C2'   phase stamps / per-workgroup timelines on the LAB build
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=gpurun_out/r4/final
+O=${R4_OUT:-gpurun_out/r4/final}
 mkdir -p $O
 B="python3 bench.py --no-cpu-baseline --no-secondary"
 pix() {

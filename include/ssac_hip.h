@@ -937,7 +937,10 @@ int ssac_bf16_chain_update(const ssac_mlp *actor, const uint16_t *actor_shadow, 
                            const uint16_t *target_shadow, const int32_t *net_ids, int n_sel, float *Qt,
                            const ssac_mlp *critics, const uint16_t *critic_shadow, const float *Xc, int64_t ldxc,
                            float *Q, uint16_t *H1T, uint16_t *H2T, uint16_t *DZ2uT, uint16_t *DZ1uT, uint16_t *XT,
-                           const ssac_gather *gather, const ssac_deferred_logs *deferred /* nullable */, void *stream);
+                           const ssac_gather *gather, const ssac_deferred_logs *deferred /* nullable */,
+                           unsigned long long *handoff /* nullable: n_rows x A words, zeroed once -- the producer / consumer
+                                                          form of the launch, as ssac_chain_update's (A <= 8) */,
+                           void *stream);
 /* ssac_mlp_wgrad_all_lossfold in bf16 (all three layers, loss gradient per workgroup, Adam on the fp32 masters, shadow
  * refreshed from the new values, optional Polyak of `target` + its shadow).  sumsq: ssac_bf16_wgrad_tiles() slots per
  * net.  No split-K: every gradient element is accumulated by one wave in a fixed order. */

@@ -82,9 +82,12 @@ struct BfArgs {
     unsigned short *H1T, *H2T, *DZ2T, *DZ1T, *XT;
     ssac_gather gth; int gth_role;  // as in ssac_fused.hip: 1 actor half (+ start-of-update duties), 3 actor half,
                                     // 2 critic half, 4 rows from X with the subset ids read from the input slot
+                                    // 5: hand-off consumer (s' rows like the actor half, nothing written, ids from the slot)
     long long *dbg;                 // optional s_memtime phase stamps of tile 0 (ssac_bf16_debug_stamps)
     int xcd;                        // XCD-contiguous workgroup order (ssac_internal.h)
+    Handoff ho;                     // bf_chain_pc_kernel: MODE_SAMPLE publishes a', MODE_PLAIN takes its action columns from it
 };
+constexpr int BF_HO_AMAX = 8;       // action dimensions a hand-off consumer keeps W1's action columns in registers for
 #ifdef SSAC_LAB
 #define BSTAMP(i) do { if (g.dbg && dbg_off >= 0 && bx == 0 && e == 0 && threadIdx.x == 0) g.dbg[dbg_off + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -161,7 +164,9 @@ __host__ __device__ inline size_t bf_lds_bytes(int in_dim, int hidden, int out_d
     return (b + 15) & ~(size_t)15;
 }
 
-template <int MODE>
+// HO: this instantiation may be the CONSUMER of a hand-off (bf_chain_pc_kernel's target-critic workgroups only: the other
+// kernels' register budgets -- two sets of 16 weight fragments are live across the prologue -- must not carry its code)
+template <int MODE, bool HO = false>
 __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem, const int bx, const int e,
                                             const int dbg_off = 0) {
     const int H = g.hidden, IN = g.in_dim, OUT = g.out_dim, K1P = g.sg.k1p;
@@ -196,7 +201,7 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
                 if (tid < g.gth.n_logs) g.gth.logs[tid] = 0.0f;
                 if (tid == 0 && g.gth.ctl) adam_refresh(g.gth.ctl, g.gth.ctl->step + 1);
             }
-            if (g.gth_role == 4 && g.gth.ids_word >= 0) idsp = reinterpret_cast<const int32_t *>(gslot + g.gth.ids_word);
+            if ((g.gth_role == 4 || g.gth_role == 5) && g.gth.ids_word >= 0) idsp = reinterpret_cast<const int32_t *>(gslot + g.gth.ids_word);
         }
         if (g.gth_role == 4) gidx = nullptr;
     }
@@ -230,7 +235,12 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
 
     // ---- x tile: the row loads go out as soon as the index is back; every weight fragment of fc1 and fc2 and the
     //      small operands follow them into flight (they depend on nothing but the net id)
-    const bool actor_half = (g.gth_role & 1) != 0;
+    const bool actor_half = (g.gth_role & 1) != 0;   // roles 1, 3 and 5
+    // CONSUMER of a hand-off (bf_chain_pc_kernel's target-critic workgroups; ssac_fused.hip has the fp32 original): the
+    // state columns of [s'|a'] are fetched here and fc1 runs on them while the tile's actor workgroup is still sampling; the
+    // action columns of the x tile stay ZERO, a' W1[:, S:]^T is added to the fc1 accumulators when the granules arrive
+    const bool CONS = HO && MODE == MODE_PLAIN && g.ho.pub != nullptr;
+    const int XC = CONS ? g.ho.S : IN;   // columns of the x tile that are loaded
     const int Sg = gidx ? (int)g.gth.s_elems : 0;
     const float *srow = gidx ? (actor_half ? g.gth.s1 : g.gth.s) + src * Sg : g.X + (int64_t)(rok ? m0 + xr : 0) * g.ldx;
     const float *arow = gidx ? g.gth.act + src * g.gth.a_elems - Sg : srow;
@@ -238,7 +248,7 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
 #pragma unroll
     for (int u = 0; u < 8; ++u) {   // first 128 columns of the row (all of them for in_dim <= 128)
         const int k = xl + 16 * u;
-        const bool ok = rok && k < IN;
+        const bool ok = rok && k < XC;
         const bool in_act = gidx && k >= Sg;   // (arow is biased by -Sg: its first valid index is Sg)
         xv[u] = (in_act ? arow : srow)[ok ? k : (in_act ? Sg : 0)];
         if (!ok) xv[u] = 0.0f;
@@ -247,10 +257,10 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
     // (vmcnt retires in order: everything the prologue's LDS stores wait for -- x, rewards, biases, W3 -- is requested
     //  BEFORE the 18 fragment loads per lane, so that wait does not also sit out the whole fc1 + fc2 weight fetch;
     //  with the small loads behind the fragments the prologue was 14-17 k clocks in every role)
-    float *outp = gidx ? (actor_half ? g.gth.x1sa : (e == 0 ? g.gth.xsa : nullptr)) : nullptr;
+    float *outp = (gidx && !CONS) ? (actor_half ? g.gth.x1sa : (e == 0 ? g.gth.xsa : nullptr)) : nullptr;
     const int64_t ldo_g = actor_half ? g.gth.ld_x1 : g.gth.ld_x;
     float rew_v = 0.0f, done_v = 0.0f;
-    const bool rd_lane = gidx && actor_half && xl == 0 && rok;
+    const bool rd_lane = gidx && actor_half && !CONS && xl == 0 && rok;
     if (rd_lane) { rew_v = g.gth.rew[src]; done_v = (float)g.gth.done[src]; }
     float bv1 = 0.0f, bv2 = 0.0f, wv3 = 0.0f, bv3 = 0.0f;
     if (tid < H) { bv1 = P[g.off[1] + tid]; bv2 = P[g.off[3] + tid]; wv3 = bf2f(S[g.sg.o3 + tid]); }
@@ -275,7 +285,7 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int k = k0 + 16 * u;
-            const bool ok = rok && k < IN;
+            const bool ok = rok && k < XC;
             const bool in_act = gidx && k >= Sg;
             v[u] = (in_act ? arow : srow)[ok ? k : (in_act ? Sg : 0)];
             if (!ok) v[u] = 0.0f;
@@ -310,6 +320,36 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
     zero_acc(acc);
     bf_mma(acc, f1, wp1, ns1, xs + li * ldx_s + 8 * lh);
     BSTAMP(2);
+    if (CONS) {
+        // W1's action columns of this lane's feature, from the bf16 shadow (what the MFMA would have multiplied): requested
+        // here -- fc1's fragments are dead, the next prefetch has not been issued: the body's register budget is full
+        // without them -- and back long before a' is
+        float wa[BF_HO_AMAX];
+#pragma unroll
+        for (int d = 0; d < BF_HO_AMAX; ++d)
+            wa[d] = d < g.ho.A ? bf2f(S[g.sg.o1 + frag_off(ns1, c0 + li, g.ho.S + d)]) : 0.0f;
+        // a' of the tile's rows: poll the granules (tag: this launch's), rounded to bf16 as the one-workgroup chain's x tile
+        // rounds them, parked in the sample epilogue's scratch [TM][BF_HO_AMAX]
+        const int A_ = g.ho.A;
+        const unsigned tag = g.ho.base + (g.ho.tick ? (unsigned)*g.ho.tick : 0u);
+        for (int t = tid; t < TM * A_; t += NTHR) {
+            const int r = t / A_, d = t - r * A_, b = m0 + r;
+            lpt[r * BF_HO_AMAX + d] = b < g.n_rows ? bf2f(f2bf(handoff_poll(g.ho.pub + (int64_t)b * A_ + d, tag))) : 0.0f;
+        }
+        lds_barrier();
+        if (wave_on) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float *ar = lpt + (8 * q + 4 * lh + i) * BF_HO_AMAX;
+                    float s_ = 0.0f;
+#pragma unroll
+                    for (int d = 0; d < BF_HO_AMAX; ++d) s_ += ar[d] * wa[d];   // (d >= A: wa = 0)
+                    acc[4 * q + i] += s_;
+                }
+        }
+    }
     // the NEXT matrix after fc2 goes in flight now, into fc1's registers: W2^T (backward-data) or the head's rows
     const unsigned short *wp3;
     if (MODE == MODE_CRITIC_U) {
@@ -411,7 +451,10 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
                 const float dlt = u - mu;
                 lpt[r * ldo + i] = (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -
                                    2.0f * (LOG_2 - u - softplus_f(-2.0f * u));
-                g.act_dst[b * g.ld_act + g.act_col0 + i] = tanhf(u);
+                const float a_new = tanhf(u);
+                g.act_dst[b * g.ld_act + g.act_col0 + i] = a_new;
+                if (g.ho.pub)   // the tile's target-critic workgroups are polling for it
+                    handoff_publish(g.ho.pub + (int64_t)b * A + i, g.ho.base + (g.ho.tick ? (unsigned)*g.ho.tick : 0u), a_new);
             }
         }
         lds_barrier();
@@ -628,6 +671,33 @@ __global__ __launch_bounds__(NTHR) void bf_chain_kernel(BfArgs ga, BfArgs ga_res
     } else {
         const int L = ssac_xcd_contiguous_range(bid, tiles_t, n_main, gc.xcd);
         bf_mlp_body<MODE_CRITIC_U>(gc, smem, L % grid_x, L / grid_x, 32);
+    }
+}
+
+// The same launch with the target chains cut into PRODUCER and CONSUMER workgroups (round 4; fused_chain_pc_kernel in
+// ssac_fused.hip is the fp32 original): [0, tiles_a) the ACTOR of a 32-row tile, once (not per subset slot), a' published
+// as tagged granules; tiles_t consumers, one per (slot, tile): the target critic's gather and fc1 on the state columns, then
+// the granules, the rank-A term, fc2 and the head; the online critics' tiles between them.  In bf16 the matrix work of a
+// pass is ~2 k clocks and everything else latency: the one-workgroup chain was 25.7 k (actor) + 17.5 k (target critic) =
+// 43.5 k clocks against 28.4 k for a critic tile; here the target critic's 10.6 k of prologue + fc1 hide behind the actor.
+__global__ __launch_bounds__(NTHR) void bf_chain_pc_kernel(BfArgs ga, BfArgs gt, BfArgs gc, int tiles_a, int tiles_t,
+                                                          int grid_x, DeferredLogsArgs dl, int dl_on) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int bid = blockIdx.x;
+    if (dl_on && bid == (int)gridDim.x - 1) {
+        deferred_logs_body(dl, -1);
+        return;
+    }
+    const int n_main = (int)gridDim.x - (dl_on ? 1 : 0), n_crit = n_main - tiles_a - tiles_t;
+    if (bid < tiles_a) {
+        bf_mlp_body<MODE_SAMPLE>(ga, smem, ssac_xcd_contiguous_range(bid, 0, tiles_a, gc.xcd), 0, 0);
+    } else if (bid < tiles_a + n_crit) {   // (the critic tiles before the consumers: a launch of more than one round)
+        const int L = ssac_xcd_contiguous_range(bid, tiles_a, tiles_a + n_crit, gc.xcd);
+        bf_mlp_body<MODE_CRITIC_U>(gc, smem, L % grid_x, L / grid_x, 32);
+    } else {
+        const int lb = ssac_xcd_contiguous_range(bid, tiles_a + n_crit, n_main, gc.xcd);
+        const int j = lb / grid_x, bx = lb - j * grid_x;
+        bf_mlp_body<MODE_PLAIN, true>(gt, smem, bx, j, j == 0 ? 16 : -1);
     }
 }
 
@@ -1093,7 +1163,7 @@ extern "C" int ssac_bf16_chain_update(const ssac_mlp *actor, const uint16_t *act
                                       int n_sel, float *Qt, const ssac_mlp *critics, const uint16_t *critic_shadow,
                                       const float *Xc, int64_t ldxc, float *Q, uint16_t *H1T, uint16_t *H2T,
                                       uint16_t *DZ2uT, uint16_t *DZ1uT, uint16_t *XT, const ssac_gather *gather,
-                                      const ssac_deferred_logs *deferred, void *stream) {
+                                      const ssac_deferred_logs *deferred, unsigned long long *handoff, void *stream) {
     if (!eps && !rng) return ssac_fail("ssac_bf16_chain_update: neither eps nor an rng stream given");
     if (!bf_ok(actor) || (actor->out_dim & 1) || !bf_ok(targets) || !bf_ok(critics))
         return ssac_fail("ssac_bf16_chain_update: shape not supported by the bf16 path");
@@ -1143,6 +1213,24 @@ extern "C" int ssac_bf16_chain_update(const ssac_mlp *actor, const uint16_t *act
     if (dl_on)
         dl = DeferredLogsArgs{deferred->partials, deferred->n_nets, deferred->sumsq, deferred->n_ss, deferred->td_stats,
                               deferred->td_off, deferred->n_rows, deferred->denom, deferred->feed};
+    const int A_ = actor->out_dim / 2;
+    if (handoff && A_ <= BF_HO_AMAX) {
+        // producer / consumer form (bf_chain_pc_kernel); tags as in ssac_chain_update: the input ring's update counter for a
+        // recorded launch (the caller passes no buffer for a recording without one), a host counter with bit 31 set else
+        static unsigned launch_no = 0;
+        Handoff ho{handoff, nullptr, 0u, actor->in_dim, A_, 1, nullptr, nullptr};
+        const ssac_feed *fd = (gather && gather->feed) ? gather->feed : ((deferred && deferred->feed) ? deferred->feed : nullptr);
+        if (fd) { ho.tick = reinterpret_cast<const long long *>(&fd->tick); ho.base = 1u; }
+        else ho.base = 0x80000000u | (++launch_no & 0x7fffffffu);
+        ga.ho = ho;
+        gt.ho = ho;
+        if (gather) { gt.gth = *gather; gt.gth_role = 5; }
+        static bool attr_pc = false;
+        if (raise_lds(bf_chain_pc_kernel, attr_pc)) return 1;
+        SSAC_LAUNCH(bf_chain_pc_kernel, dim3(gx + tiles_t + gx * critics->n_nets + dl_on), dim3(NTHR), lds, (hipStream_t)stream,
+                    ga, gt, gc, gx, tiles_t, gx, dl, dl_on);
+        return ssac_check_launch("bf16_chain_pc");
+    }
     SSAC_LAUNCH(bf_chain_kernel, dim3(tiles_t + gx * critics->n_nets + dl_on), dim3(NTHR), lds, (hipStream_t)stream, ga, gr,
                 gt, gc, tiles_t, gx, dl, dl_on);
     return ssac_check_launch("bf16_chain");

@@ -66,39 +66,7 @@ struct ActorBwdArgs {
     float *partials;                    // [row tiles] sum over the tile's rows of (Q' - alpha log pi)
 };
 
-// Hand-off of the sampled action a' from the ACTOR workgroup of a 16-row tile to the tile's TARGET-CRITIC workgroups
-// (fused_chain_pc_kernel): one 8-byte granule {a' bits, tag} per (row, action dimension), written with ONE write-through
-// (agent-scope) store and polled with agent-scope loads -- no fence on either side (a granule is complete or absent).  tag =
-// base + the update counter of a recorded launch list (ssac_feed.tick) or the host's launch counter (eager launches):
-// distinct for every launch, so a stale granule of an earlier update is never taken for this update's.
-struct Handoff {
-    unsigned long long *pub;    // [n_rows][A]; null = no hand-off
-    const long long *tick;      // device-resident update counter, or null
-    unsigned base;
-    int S, A;                   // the consumer's input columns [S, S + A) arrive through pub
-    int nsplit;                 // consumers per (slot, tile): > 1 = each takes hidden / nsplit columns of fc2 (below)
-    // the chained ACTOR update (fused_actor_chain_kernel): the critics' results travel back the same way --
-    unsigned long long *qpub;   // [n_critics][n_rows]: Q_j(s, a_theta)           (MODE_CRITIC_U publishes, MODE_ACTOR_BWD polls)
-    unsigned long long *dxpub;  // [n_critics][n_rows][A]: unscaled dQ_j / da
-};
-
-constexpr long long HANDOFF_SPIN_LIMIT = 4000000000LL;   // shader clocks (~2 s): a producer that never arrives poisons, never hangs
-// one granule: spin until its tag is this launch's (bounded: a producer that never arrives yields NaN, never a hang)
-__device__ __forceinline__ float handoff_poll(const unsigned long long *gp, unsigned tag) {
-    const long long t0 = __builtin_amdgcn_s_memtime();
-    unsigned long long w;
-    for (;;) {
-        w = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(w >> 32) == tag) break;
-        __builtin_amdgcn_s_sleep(1);
-        if (__builtin_amdgcn_s_memtime() - t0 > HANDOFF_SPIN_LIMIT) { w = 0x7fc00000ull; break; }   // (NaN: never silently stale)
-    }
-    return __uint_as_float((unsigned)w);
-}
-__device__ __forceinline__ void handoff_publish(unsigned long long *gp, unsigned tag, float v) {
-    __hip_atomic_store(gp, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
+// (struct Handoff, handoff_poll / handoff_publish: ssac_internal.h -- shared with the bf16 family)
 constexpr int HANDOFF_MAX_WA = 9;   // W1's action columns per thread (H * A <= 512 * 9: 256 x 18)
 
 struct FusedArgs {

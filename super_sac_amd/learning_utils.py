@@ -702,6 +702,8 @@ def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict,
         assert a_arena.shadow is not None and t_arena.shadow is not None, \
             "bf16 mode: set_precision must cover the actor and the target agent too"
         bf = c_arena.bf_buffers(ws, "cu", B)
+        # producer / consumer form (csrc/ssac_bf16.hip, bf_chain_pc_kernel), as below for the fp32 family
+        ho = ws.get(tag + ".handoff", (B * A,), dtype=torch.int64, zero=True) if (pc_ok and A <= 8) else None
         with engine._timed("chain") as tm:
             for _ in range(tm.reps):
                 check(lib.ssac_bf16_chain_update(
@@ -710,7 +712,8 @@ def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict,
                     ch["logp"].data_ptr(), ch["rng_ptr"], C.byref(t_arena.desc()), t_arena.shadow.data_ptr(), ids_ptr, n,
                     q1.data_ptr(), C.byref(c_arena.desc()), c_arena.shadow.data_ptr(), Xc.data_ptr(), ldxc, qc.data_ptr(),
                     bf["h1t"].data_ptr(), bf["h2t"].data_ptr(), bf["dz2t"].data_ptr(), bf["dz1t"].data_ptr(),
-                    bf["xt"].data_ptr(), C.byref(gth) if gth is not None else 0, dl_ptr, engine.stream()))
+                    bf["xt"].data_ptr(), C.byref(gth) if gth is not None else 0, dl_ptr,
+                    ho.data_ptr() if ho is not None else 0, engine.stream()))
         replay_dict["_co_bwd"] = True
         return q1
     skip_dz2 = bool(replay_dict.pop("_dz2_optional", False))

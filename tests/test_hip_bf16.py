@@ -191,6 +191,28 @@ def test_bf16_update_sequences_against_reference_fixtures(name):
     print(f"{name}: worst bf16 deviations vs the fp32 reference {worst}")
 
 
+@pytest.mark.parametrize("name", ["redq_small", "redq_c2"])
+def test_bf16_chained_launch_forms_agree(name):
+    """the bf16 chained launch as producer / consumer workgroups (bf_chain_pc_kernel: the actor once per tile, a' handed to
+    the tile's target critics as tagged granules, fc1 on the state columns meanwhile) against one workgroup per target
+    chain (bf_chain_kernel): both land on the reference fixture, and their first TD targets agree far inside the bf16
+    tolerance -- the two forms differ by the fp32 association of fc1's sum only (the products are the same bf16 x bf16)"""
+    import super_sac_amd as ssa
+    fx, cfg = case_runner.load_fixture(name), synth.CASES[name]
+    recs = {}
+    old = ssa.learning_utils.CHAIN_PC
+    try:
+        for pc in (False, True):
+            ssa.learning_utils.CHAIN_PC = pc
+            recs[pc] = case_runner.run_engine(name, precision="bf16")
+            compare_bf16(recs[pc], fx, cfg, f"hip-bf16[{name}, pc={pc}]")
+    finally:
+        ssa.learning_utils.CHAIN_PC = old
+    k0 = sorted(k for k in fx if k.startswith("u0") and "_td" in k)[0]
+    a, b = np.asarray(recs[False][k0], np.float64), np.asarray(recs[True][k0], np.float64)
+    assert float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(a)))) <= 2e-3, "the two forms' first TD targets"
+
+
 def test_bf16_with_popart_and_gradient_clipping():
     """sac_popart (PopArt statistics + pop + clip_grad_norm_ 40): the bf16 weight-gradient launch stores fp32 gradients,
     clip + Adam run on the masters, the shadows are refreshed; the PopArt scalars follow the (bf16-perturbed) targets"""

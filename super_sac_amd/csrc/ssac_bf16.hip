@@ -159,7 +159,7 @@ __device__ __forceinline__ void store_quad(unsigned short *__restrict__ dst, int
 __host__ __device__ inline size_t bf_lds_bytes(int in_dim, int hidden, int out_dim) {
     const int k1p = (in_dim + 15) & ~15;
     const int ldo = (out_dim + 31) & ~31;
-    size_t b = 2 * ((size_t)TM * (k1p + LPAD) + 2 * (size_t)TM * (hidden + LPAD));             // xs, h1s, h2s (bf16)
+    size_t b = 2 * ((size_t)TM * (k1p + LPAD) + 3 * (size_t)TM * (hidden + LPAD));             // xs, h1s, h2s, dz2s (bf16)
     b += 4 * (2 * (size_t)TM * ldo + 3 * (size_t)hidden + ldo + 64);                           // ys, lpt, b1s, b2s, w3f, b3s
     return (b + 15) & ~(size_t)15;
 }
@@ -175,7 +175,8 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
     unsigned short *xs = reinterpret_cast<unsigned short *>(smem);
     unsigned short *h1s = xs + TM * ldx_s;
     unsigned short *h2s = h1s + TM * ldh;
-    float *ys = reinterpret_cast<float *>(h2s + TM * ldh);   // [TM][ldo]
+    unsigned short *dz2s = h2s + TM * ldh;                   // MODE_CRITIC_U: dz2u, written by the fc2 epilogue
+    float *ys = reinterpret_cast<float *>(dz2s + TM * ldh);  // [TM][ldo]
     float *lpt = ys + TM * ldo;                              // [TM][ldo] scratch of the sample epilogue
     float *b1s = lpt + TM * ldo;                             // [H]
     float *b2s = b1s + H;                                    // [H]
@@ -392,8 +393,20 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
                 hv[i] = f2bf(fmaxf(acc[4 * q + i] + bias, 0.0f));
                 h2s[(b0 + i) * ldh + n_me] = hv[i];
             }
-            if (MODE == MODE_CRITIC_U)
+            if (MODE == MODE_CRITIC_U) {
                 store_quad(g.H2T + (int64_t)e * H * g.bp + frag_off(g.bp >> 4, n_me, m0 + b0) - b0, b0, g.n_rows - m0, hv);
+                // single-output critics: the head's backward needs h2's sign only -- dz2u[b][j] = W3[j] [h2[b][j] > 0] is
+                // written right here (its own LDS tile: the head below still reads h2), not in a pass of its own behind
+                // the head (4.5 k clocks of a 28 k-clock workgroup: 2-byte LDS read-modify-writes)
+                const unsigned short wj = f2bf(w3f[n_me]);
+                u16x4 dz;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dz[i] = bf_pos(hv[i]) ? wj : (unsigned short)0;
+                    dz2s[(b0 + i) * ldh + n_me] = dz[i];
+                }
+                store_quad(g.DZ2T + (int64_t)e * H * g.bp + frag_off(g.bp >> 4, n_me, m0 + b0) - b0, b0, g.n_rows - m0, dz);
+            }
         }
     }
     lds_barrier();
@@ -467,24 +480,11 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
         return;
     }
 
-    // ---- MODE_CRITIC_U (single-output critics): the TD-independent half of the backward pass.
-    //      dz2u[b][j] = W3[j] [h2[b][j] > 0] in place over h2s (one feature x 4 batch rows per thread: 8-byte transposed
-    //      stores), then dz1u = (dz2u . W2) (.) [h1 > 0]
-    for (int i = tid; i < H * (TM / 4); i += NTHR) {
-        const int j = i % H, b0 = (i / H) * 4;
-        const unsigned short wj = f2bf(w3f[j]);
-        u16x4 dz;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            dz[u] = bf_pos(h2s[(b0 + u) * ldh + j]) ? wj : (unsigned short)0;
-            h2s[(b0 + u) * ldh + j] = dz[u];
-        }
-        store_quad(g.DZ2T + (int64_t)e * H * g.bp + frag_off(g.bp >> 4, j, m0 + b0) - b0, b0, g.n_rows - m0, dz);
-    }
-    lds_barrier();
+    // ---- MODE_CRITIC_U (single-output critics): the TD-independent half of the backward pass: dz2u was written by the fc2
+    //      epilogue (dz2s; visible since the barrier behind it), dz1u = (dz2u . W2) (.) [h1 > 0]
     BSTAMP(7);
     zero_acc(acc);
-    bf_mma(acc, f1, wp3, nsh, h2s + li * ldh + 8 * lh);
+    bf_mma(acc, f1, wp3, nsh, dz2s + li * ldh + 8 * lh);
     BSTAMP(8);
     if (wave_on) {
 #pragma unroll

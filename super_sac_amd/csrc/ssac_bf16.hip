@@ -273,6 +273,17 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
     f1.load(wp1, ns1);
     f2.load(wp2, nsh);
     DSTAMP(15);
+    if (MODE == MODE_SAMPLE && !g.eps) {
+        // in-kernel noise: this tile's standard normals are computed while the prologue's loads are in flight (ssac_fused.hip)
+        const int A = OUT >> 1;
+        for (int t = tid; t < TM * A; t += NTHR) {
+            const int r = t / A, i = t - r * A, b = m0 + r;
+            const int64_t draw = (gslot && g.gth.rng_word >= 0)
+                                     ? g.rng.offset + *reinterpret_cast<const int64_t *>(gslot + g.gth.rng_word)
+                                     : rng_draw(g.rng);
+            lpt[r * ldo + A + i] = b < g.n_rows ? philox_normal(g.rng.seed, draw, b, i) : 0.0f;
+        }
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int k = xl + 16 * u;
@@ -456,10 +467,7 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
                 const float mu = ys[r * ldo + i], raw = ys[r * ldo + A + i];
                 const float log_std = g.lo + 0.5f * (g.hi - g.lo) * (tanhf(raw) + 1.0f);
                 const float sd = expf(log_std);
-                const int64_t draw = (gslot && g.gth.rng_word >= 0)
-                                         ? g.rng.offset + *reinterpret_cast<const int64_t *>(gslot + g.gth.rng_word)
-                                         : rng_draw(g.rng);
-                const float ep = g.eps ? g.eps[(int64_t)b * A + i] : philox_normal(g.rng.seed, draw, b, i);
+                const float ep = g.eps ? g.eps[(int64_t)b * A + i] : lpt[r * ldo + A + i];   // (drawn in the prologue by this thread)
                 const float u = mu + sd * ep;
                 const float dlt = u - mu;
                 lpt[r * ldo + i] = (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -

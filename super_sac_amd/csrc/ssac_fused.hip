@@ -692,6 +692,20 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 xv[j] = xrow[j][ok ? xk : 0];
             }
         }
+        // (MODE_SAMPLE with in-kernel noise: the standard normals of this tile -- Philox4x32-10 + Box-Muller, ~300 instructions
+        // that depend on nothing but (seed, draw, row, dimension) -- are computed HERE, while the prologue's loads are in
+        // flight, and parked in the upper half of the sample epilogue's scratch rows; in the epilogue, behind the head, they
+        // were half of its ~5 k clocks on the critical path of every launch that waits for its actor workgroups)
+        if (MODE == MODE_SAMPLE && !g.eps) {
+            const int A = OUT >> 1;
+            for (int t = tid; t < TMR * A; t += NTHR) {
+                const int r = t / A, i = t - r * A, b = m0 + r;
+                const int64_t draw = (gslot && g.gth.rng_word >= 0)
+                                         ? g.rng.offset + *reinterpret_cast<const int64_t *>(gslot + g.gth.rng_word)
+                                         : rng_draw(g.rng);
+                dqs[r * ldo + A + i] = b < g.n_rows ? philox_normal(g.rng.seed, draw, b, i) : 0.0f;
+            }
+        }
         // ---- ... and now the LDS stores (visible after the barrier below)
         if (tid < H) b1s[tid] = bv;
         else if (tid >= 256 && tid - 256 < H) b2s[tid - 256] = bv;
@@ -981,10 +995,8 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 const float sd = expf(log_std);
                 // (gather folded in: the draw number is read from the input slot itself -- the device copy of the
                 // slot is being written by this very launch)
-                const int64_t draw = (gslot && g.gth.rng_word >= 0)
-                                         ? g.rng.offset + *reinterpret_cast<const int64_t *>(gslot + g.gth.rng_word)
-                                         : rng_draw(g.rng);
-                const float ep = g.eps ? g.eps[(int64_t)b * A + i] : philox_normal(g.rng.seed, draw, b, i);
+                // (in-kernel noise: drawn in the prologue by THIS thread -- same (row, dimension) mapping -- into the row's upper half)
+                const float ep = g.eps ? g.eps[(int64_t)b * A + i] : lpt[r * ldo + A + i];
                 const float u = mu + sd * ep;
                 const float dlt = u - mu;
                 lpt[r * ldo + i] = (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -

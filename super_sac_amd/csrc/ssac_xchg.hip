@@ -57,6 +57,7 @@ struct XchgArgs {
     int *error;                 // HOST-pinned int (device view), set to 1 when a peer's flag did not arrive in time
     int *dead;                  // device int: once a spin gave up, later exchanges fail at once instead of spinning again
     int test_mode;              // tests only (ssac_xchg_test_mode): bit 0 = senders skip step 0, bit 1 = accept flag >= seq
+    long long spin_limit;       // shader clocks a wait may take (X_SPIN_LIMIT; longer when the ranks time-slice ONE device)
     int n_parts, part_stride;   // > 1: element i of the payload is the SUM of n_parts partials (column-split target critics,
                                 // ssac_td_spec.n_parts): data[(slot n_parts + s) part_stride + b]; the reduction lands in
                                 // part 0 of every slot and the other parts are zeroed, so the sum stays the value
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
         if (tid < a.world) {
             const unsigned long long *ack = ack_of(a.peer[a.rank], a.world, tid, a.slot_floats);
             const long long t0 = __builtin_amdgcn_s_memtime();
-            const long long limit = *a.dead ? 0 : X_SPIN_LIMIT;
+            const long long limit = *a.dead ? 0 : a.spin_limit;
             while (__hip_atomic_load(ack, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + X_SLOTS < seq) {
                 __builtin_amdgcn_s_sleep(2);
                 if (__builtin_amdgcn_s_memtime() - t0 > limit) { s_ok = 0; break; }
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
         const unsigned long long *flag =
             reinterpret_cast<const unsigned long long *>(slot_of(a.peer[a.rank], tid, slot, a.slot_floats) + a.slot_floats);
         const long long t0 = __builtin_amdgcn_s_memtime();
-        const long long limit = *a.dead ? 0 : X_SPIN_LIMIT;
+        const long long limit = *a.dead ? 0 : a.spin_limit;
         for (;;) {
             const unsigned long long f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (f == seq) break;
@@ -201,6 +202,11 @@ struct ssac_xchg {
     int *dead;                          // device int behind seq
     int *error_host, *error_dev;        // pinned host word and its device view
     int test_mode = 0;
+    // ranks that share ONE device (allow_cached: the one-GPU test box) run their exchange kernels in turn -- a spinning
+    // kernel is preempted only by the scheduler's quantum, and a wait can sit out several of them per peer: the bound grows
+    // with the number of ranks there (three ranks once sat out 10 s on a loaded box; eight did in round 3).  One rank per
+    // GPU -- the real layout -- keeps ~10 s.
+    long long spin_limit = X_SPIN_LIMIT;
 };
 
 extern "C" ssac_xchg *ssac_xchg_create(int rank, int world, int slot_floats, int allow_cached) {
@@ -211,6 +217,7 @@ extern "C" ssac_xchg *ssac_xchg_create(int rank, int world, int slot_floats, int
     slot_floats = (slot_floats + 3) & ~3;   // 16-byte slots: the 8-byte flag behind the payload stays aligned
     ssac_xchg *x = new ssac_xchg();
     x->rank = rank; x->world = world; x->slot_floats = slot_floats;
+    if (allow_cached && world > 1) x->spin_limit = X_SPIN_LIMIT * (long long)(2 * world);
     const size_t bytes = sizeof(float) * ((size_t)world * X_SLOTS * (slot_floats + 4) + 4 * (size_t)world);   // slots | acks
     // The receive buffer is written by PEER devices while this device polls it: uncached (fine-grained) device memory,
     // so that no stale line of it can sit in this device's L2 (what RCCL does for its flags and LL buffers).  Ordinary
@@ -306,6 +313,7 @@ static int xchg_launch(ssac_xchg *x, float *data, int n, int op, const int32_t *
     a.rank = x->rank; a.world = x->world; a.n = n; a.slot_floats = x->slot_floats; a.op = op;
     a.data = data; a.seq = x->seq; a.error = x->error_dev; a.dead = x->dead;
     a.test_mode = x->test_mode;
+    a.spin_limit = x->spin_limit;
     a.n_parts = n_parts; a.part_stride = n_slots > 0 ? n / n_slots : n;
     SSAC_LAUNCH(xchg_kernel, dim3(1), dim3(X_THREADS), 0, (hipStream_t)stream, a);
     return ssac_check_launch("xchg");

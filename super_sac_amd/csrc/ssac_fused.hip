@@ -475,9 +475,14 @@ __device__ __forceinline__ void stage_head_weights(float *w3s, const float *__re
 // never modified (a by-value parameter that is written to is copied to scratch memory, all ~500 bytes of it)
 // HO: this instantiation may be the CONSUMER of a hand-off (fused_chain_pc_kernel's target-critic workgroups only: the
 // register-resident weight fragments of the column-split form must not weigh on the other kernels' register budgets)
-template <int MODE, int TMR, bool DBUF, bool HO = false>
+// W3LATE (MODE_SAMPLE, double-buffered): the head's weight rows are NOT resident in LDS from the start -- a wide head over a
+// wide input (Humanoid's actor: 376 -> 256 -> 256 -> 34, 35 KB of W3) leaves no room for the second staging buffer, and with
+// a single buffer its 20 K chunks cost 2.4 k clocks each instead of 1.4 k.  They are requested into registers before fc2 and
+// parked in staging buffer 1 behind fc2's K loop, where the head reads them.
+template <int MODE, int TMR, bool DBUF, bool HO = false, bool W3LATE = false>
 __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, const int bx, const int e,
                                                const int grid_x, const int dbg_off = 0, const int split = 0) {
+    static_assert(!W3LATE || (MODE == MODE_SAMPLE && DBUF), "the late head image is the actor pass's, behind a double-buffered fc2");
     typedef Tile<TMR> T;
     const int H = g.hidden, IN = g.in_dim, OUT = g.out_dim;
     const int ldo = (OUT + 15) & ~15;  // row stride of the per-row head outputs / output gradients in LDS
@@ -495,8 +500,8 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     float *b1s = rowred + 64;               // [H]
     float *b2s = b1s + H;                   // [H]
     float *b3s = b2s + H;                   // [HEAD_MAX]
-    float *w3s = b3s + HEAD_MAX;            // [OUT][H+4]
-    float *rowin = w3s + OUT * (H + APAD);  // [3][TMR]: td, weight, action index of this tile's rows
+    float *w3s = W3LATE ? Ws1 : b3s + HEAD_MAX;   // [OUT][H+4]  (W3LATE: staging buffer 1, filled behind fc2)
+    float *rowin = W3LATE ? b3s + HEAD_MAX : w3s + OUT * (H + APAD);  // [3][TMR]: td, weight, action index of this tile's rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = bx * TMR;
@@ -637,7 +642,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i3 = tid + u * NTHR;
-            w3v[u] = W3[i3 < n3 ? i3 : 0];
+            w3v[u] = W3LATE ? 0.0f : W3[i3 < n3 ? i3 : 0];
         }
         // (consumer) W1's action columns, H x A floats over the 512 threads: requested here, parked in staging buffer 1
         // behind fc1's K loop
@@ -713,7 +718,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i3 = tid + u * NTHR;
-            if (i3 < n3) {
+            if (!W3LATE && i3 < n3) {
                 const int o = i3 / H;
                 w3s[o * ldw3 + (i3 - o * H)] = w3v[u];
             }
@@ -762,7 +767,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
             g.gth.rew_out[m0 + tid] = g.gth.rew[src];
             g.gth.done_out[m0 + tid] = (float)g.gth.done[src];
         }
-        if (n3 > 4 * NTHR) stage_head_weights(w3s, W3, OUT, H, ldw3, tid, 4 * NTHR);  // heads wider than 8 outputs
+        if (!W3LATE && n3 > 4 * NTHR) stage_head_weights(w3s, W3, OUT, H, ldw3, tid, 4 * NTHR);  // heads wider than 8 outputs
         if (FWD_BWD && tid < TMR) {
             const int b = m0 + tid;
             const bool ok = b < g.n_rows;
@@ -869,8 +874,29 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         // ---- fc2 (the backward-data phase re-reads W2 as a row-contiguous image: its first chunk is
         //      requested during fc2's last K chunk)
         T::zero(acc);
+        // (W3LATE: the head's rows go in flight now, W3L_MAX per thread, and land in staging buffer 1 behind the K loop)
+        constexpr int W3L_MAX = (HEAD_MAX * 256 + NTHR - 1) / NTHR;   // 32: heads up to 64 outputs over 256 hidden units
+        float w3r[W3LATE ? W3L_MAX : 1];
+        if (W3LATE) {
+#pragma unroll
+            for (int u = 0; u < W3L_MAX; ++u) {
+                const int i3 = tid + u * NTHR;
+                w3r[u] = (u * NTHR < n3) ? W3[i3 < n3 ? i3 : 0] : 0.0f;
+            }
+        }
         if (FWD_BWD) gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, st3, H);
         else gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, none, 0);
+        if (W3LATE) {   // (gemm_tile ended with a barrier: nobody reads the staging buffers any more; visible to the head
+                        //  behind the barrier that follows the fc2 epilogue)
+#pragma unroll
+            for (int u = 0; u < W3L_MAX; ++u) {
+                const int i3 = tid + u * NTHR;
+                if (i3 < n3) {
+                    const int o = i3 / H;
+                    w3s[o * ldw3 + (i3 - o * H)] = w3r[u];
+                }
+            }
+        }
         BSTAMP(4);
         // Single-output heads (every continuous critic): the head's dot product q = h2 . W3 is taken from the fc2
         // accumulators right here -- each lane holds 8 or 16 columns of ONE row, so the row's partial is a lane sum, one
@@ -1008,12 +1034,14 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        BSTAMP(9);
         lds_barrier();
         if (g.logp && tid < TMR && (m0 + tid) < g.n_rows) {
             float lp = 0.0f;
             for (int i = 0; i < A; ++i) lp += lpt[tid * ldo + i];
             g.logp[m0 + tid] = lp;
         }
+        BSTAMP(8);
         return;
     }
 
@@ -1323,7 +1351,7 @@ void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs
 // Producers take the first workgroup ids: they are dispatched before any consumer and never wait, so the polling cannot
 // deadlock whatever part of the grid is resident.  The rank-A update adds a' W1^T after the state columns' sum (the
 // one-pass kernel sums all columns of a K chunk in MFMA order): same value up to fp32 association.
-template <int TC, bool ADBUF>
+template <int TC, bool ADBUF, bool AW3LATE = false>
 __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_chain_pc_kernel(FusedArgs ga, FusedArgs gt, FusedArgs gc, int tiles_a, int tiles_t, int target_grid_x,
                            int critic_grid_x, DeferredLogsArgs dl, int dl_on) {
@@ -1340,7 +1368,7 @@ void fused_chain_pc_kernel(FusedArgs ga, FusedArgs gt, FusedArgs gc, int tiles_a
     const int n_main = (int)gridDim.x - (dl_on ? 1 : 0), n_crit = n_main - tiles_a - tiles_t;
     const int t_lo = CRIT_FIRST ? tiles_a + n_crit : tiles_a, t_hi = t_lo + tiles_t;   // ids of the consumers
     if (bid < tiles_a) {
-        fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga, smem, ssac_xcd_contiguous_range(bid, 0, tiles_a, gc.xcd), 0, tiles_a, 0);
+        fused_mlp_body<MODE_SAMPLE, 16, ADBUF, false, AW3LATE>(ga, smem, ssac_xcd_contiguous_range(bid, 0, tiles_a, gc.xcd), 0, tiles_a, 0);
     } else if (bid >= t_lo && bid < t_hi) {
         const int lb = ssac_xcd_contiguous_range(bid, t_lo, t_hi, gc.xcd);
         const int per_slot = target_grid_x * (gt.ho.nsplit > 1 ? gt.ho.nsplit : 1);   // consumers of a subset slot
@@ -1390,11 +1418,11 @@ long long *g_fused_dbg = nullptr;
 
 int g_tile_rows = 0;  // 0 = automatic, else 16 or 32 (ssac_fused_tile_rows)
 
-size_t fused_lds_bytes(int in_dim, int hidden, int out_dim, int tm = TM, bool dbuf = true) {
+size_t fused_lds_bytes(int in_dim, int hidden, int out_dim, int tm = TM, bool dbuf = true, bool w3_late = false) {
     const int KP = (in_dim + 31) & ~31;
     return sizeof(float) * ((size_t)tm * (KP + APAD) + 2 * (size_t)tm * (hidden + APAD) +
                             (dbuf ? 2 : 1) * WS_FLOATS + 2 * tm * ((out_dim + 15) & ~15) + 64 +
-                            2 * hidden + HEAD_MAX + (size_t)out_dim * (hidden + APAD) + 3 * tm);
+                            2 * hidden + HEAD_MAX + (w3_late ? 0 : (size_t)out_dim * (hidden + APAD)) + 3 * tm);
 }
 
 // Kernel variant for one launch.  g_tile_rows (ssac_fused_tile_rows) forces one: 16 / 32 = double-buffered weight
@@ -1420,6 +1448,13 @@ TileChoice choose_tile(const FusedArgs &g, int n_sel) {
 bool fused_ok(const ssac_mlp *n) {
     return n && n->hidden % 32 == 0 && n->hidden <= 256 && n->out_dim >= 1 && n->out_dim <= HEAD_MAX &&
            n->in_dim >= 1 && fused_lds_bytes(n->in_dim, n->hidden, n->out_dim, 16, false) <= 160 * 1024;
+}
+
+// the actor pass with a double-buffered K loop and the head's rows parked in staging buffer 1 (W3LATE): for actors whose
+// resident head image leaves no room for the second buffer
+bool fused_dbuf_late_ok(const ssac_mlp *n) {
+    return fused_ok(n) && (size_t)n->out_dim * (n->hidden + APAD) <= (size_t)WS_FLOATS &&
+           fused_lds_bytes(n->in_dim, n->hidden, n->out_dim, 16, true, true) <= 160 * 1024;
 }
 
 // the merged launches run their critic halves with double-buffered staging only
@@ -1679,7 +1714,12 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
     const int tc = choose_tile(gc, critics->n_nets).tm;
     const int tgx = (n_rows + 15) / 16, cgx = (n_rows + tc - 1) / tc;
     const bool adbuf = fused_dbuf_ok(actor);
-    size_t lds = fused_lds_bytes(actor->in_dim, actor->hidden, actor->out_dim, 16, adbuf);
+    // (producer / consumer form only: an actor whose resident head image leaves no room for the second staging buffer runs
+    // double-buffered with the head's rows parked behind fc2 -- W3LATE in fused_mlp_body)
+    const int A_ = actor->out_dim / 2;
+    const bool pc_form = handoff && A_ <= 32 && targets->hidden * A_ <= NTHR * HANDOFF_MAX_WA;
+    const bool alate = pc_form && !adbuf && fused_dbuf_late_ok(actor);
+    size_t lds = fused_lds_bytes(actor->in_dim, actor->hidden, actor->out_dim, 16, adbuf || alate, alate);
     const size_t lt = fused_lds_bytes(targets->in_dim, targets->hidden, targets->out_dim, 16, true);
     const size_t lc = fused_lds_bytes(critics->in_dim, critics->hidden, critics->out_dim, tc, true);
     if (lt > lds) lds = lt;
@@ -1701,8 +1741,7 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
         dl = DeferredLogsArgs{deferred->partials, deferred->n_nets, deferred->sumsq, deferred->n_ss, deferred->td_stats,
                               deferred->td_off, deferred->n_rows, deferred->denom, deferred->feed};
     hipStream_t st = (hipStream_t)stream;
-    const int A_ = actor->out_dim / 2;
-    if (handoff && A_ <= 32 && targets->hidden * A_ <= NTHR * HANDOFF_MAX_WA) {
+    if (pc_form) {
         // producer / consumer form (fused_chain_pc_kernel): the actor ONCE per tile, a' handed to the tile's target critics
         static unsigned launch_no = 0;   // tags of eager launches: bit 31 set, so they never meet a recorded launch's
         Handoff ho{handoff, nullptr, 0u, actor->in_dim, A_, target_splits};
@@ -1717,8 +1756,9 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
         if (gather) { gt.gth = *gather; gt.gth_role = 5; }
         static bool pc_attr = false;
         if (!pc_attr) {
-            const void *ks[4] = {(const void *)fused_chain_pc_kernel<16, true>, (const void *)fused_chain_pc_kernel<32, true>,
-                                 (const void *)fused_chain_pc_kernel<16, false>, (const void *)fused_chain_pc_kernel<32, false>};
+            const void *ks[6] = {(const void *)fused_chain_pc_kernel<16, true>, (const void *)fused_chain_pc_kernel<32, true>,
+                                 (const void *)fused_chain_pc_kernel<16, false>, (const void *)fused_chain_pc_kernel<32, false>,
+                                 (const void *)fused_chain_pc_kernel<16, true, true>, (const void *)fused_chain_pc_kernel<32, true, true>};
             for (const void *k : ks)
                 if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                     return ssac_fail("fused_chain_pc: cannot raise the dynamic LDS limit");
@@ -1726,7 +1766,9 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
         }
         const int tiles_c = tiles_t * target_splits;   // consumers: one per (slot, column split, tile)
         const dim3 grid_pc(tgx + tiles_c + cgx * critics->n_nets + dl_on);
-        if (tc == 16 && adbuf) SSAC_LAUNCH((fused_chain_pc_kernel<16, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
+        if (alate && tc == 16) SSAC_LAUNCH((fused_chain_pc_kernel<16, true, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
+        else if (alate) SSAC_LAUNCH((fused_chain_pc_kernel<32, true, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
+        else if (tc == 16 && adbuf) SSAC_LAUNCH((fused_chain_pc_kernel<16, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
         else if (adbuf) SSAC_LAUNCH((fused_chain_pc_kernel<32, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
         else if (tc == 16) SSAC_LAUNCH((fused_chain_pc_kernel<16, false>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
         else SSAC_LAUNCH((fused_chain_pc_kernel<32, false>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);

@@ -29,6 +29,7 @@ def row(name, tt, base, labels):
     print(name, "total", tt[base + len(labels)] - tt[base], "clk:", ", ".join(f"{l} {tt[base+i+1]-tt[base+i]}" for i, l in enumerate(labels)))
 names = ["prologue", "fc1", "fc1-epi", "fc2", "fc2-epi+sync", "w3stage", "head"]
 row("actor pass  ", t, 0, names)
+print("actor pass: tanh-normal sample per (row, dim) incl. publish", t[9] - t[7], " barrier + log pi sum + store", t[8] - t[9])
 row("target pass ", t, 16, names)
 print("actor start -> target pass end:", t[23] - t[0])
 row("critic WG   ", t, 32, names + ["loss", "head-bwd", "dgrad", "dz1-store"])

@@ -765,6 +765,7 @@ int ssac_actor_route_mask(const float *q_local, const float *q_global, int n_row
  *              ssac_replay_value(list, stream, n), which renumbers it: tag 1 + n, draw rng->offset - update_no + n (a
  *              plain ssac_replay of such a list is refused).  Numbers must not repeat on one handoff buffer.
  *              < 0: an eager launch nobody numbers (tag: a host counter with bit 31 set)
+ *   n_rows     at most SSAC_ACTOR_CHAIN_MAX_ROWS (refused beyond: see the define below)
  *   begin_logs / n_logs / begin_ctl   nullable: ssac_begin_update's duties (log block cleared, optimizer step advanced)
  *            done by the first actor workgroup, so that a recorded actor update needs no launch in front */
 int ssac_actor_chain_fused(const ssac_mlp *actor, const float *X, int64_t ldx, int n_rows, const float *eps,
@@ -774,6 +775,9 @@ int ssac_actor_chain_fused(const ssac_mlp *actor, const float *X, int64_t ldx, i
                            float *d_out, float *DZ2, float *DZ1, float *partials, unsigned long long *handoff,
                            long long update_no, float *begin_logs, int n_logs, ssac_adam_ctl *begin_ctl, void *stream);
 int64_t ssac_actor_chain_handoff_words(int n_rows, int n_critics, int action_dim);
+/* batch rows the chained launch takes: its actor workgroups (one per 16 rows) wait for critic tiles dispatched behind them,
+ * so they may occupy at most half of the 256 CUs; larger batches run the three launches */
+#define SSAC_ACTOR_CHAIN_MAX_ROWS 2048
 
 /* critic forward of ALL nets + loss gradient + backward-data in ONE launch (learning.py:83-98,112,121):
  * writes H1, H2, Q (n_nets x n_rows x out), DQ, DZ2 = dL/d(pre-activation of fc2), DZ1, and per-(net,

@@ -1921,6 +1921,10 @@ extern "C" int ssac_actor_chain_fused(const ssac_mlp *actor, const float *X, int
     gc.xcd = 1;
     const int tc = choose_tile(gc, N).tm;
     const int tiles_a = (n_rows + 15) / 16, cgx = (n_rows + tc - 1) / tc;
+    // The actor workgroups WAIT for critic tiles that are dispatched behind them: they must never hold every slot of the
+    // chip (one workgroup per CU at this LDS carve), or the critics they wait for could not start.  Half the CUs at most.
+    if (tiles_a > SSAC_ACTOR_CHAIN_MAX_ROWS / 16)
+        return ssac_fail("ssac_actor_chain_fused: more than SSAC_ACTOR_CHAIN_MAX_ROWS batch rows (use the three launches)");
     size_t lds = fused_lds_bytes(actor->in_dim, actor->hidden, actor->out_dim, 16, true);
     const size_t lc = fused_lds_bytes(critics->in_dim, critics->hidden, critics->out_dim, tc, true);
     if (lc > lds) lds = lc;

@@ -1119,7 +1119,9 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             # the noise: with the stock generator the chained launch takes it from the engine's Philox stream INSIDE the
             # kernel (draw number = this update's number: no generator launch, no buffer); otherwise a draw -- into the
             # recording's fixed buffer, or a fresh one -- as a_dist.rsample() makes it (learning.py:392)
-            chain = ACTOR_CHAIN and a_arena.fused_dbuf and A <= 32 and H * A <= 512 * 9
+            # (B <= 2048 = SSAC_ACTOR_CHAIN_MAX_ROWS: the chained launch's actor workgroups wait for critic tiles dispatched
+            # behind them and must leave them CUs to run on)
+            chain = ACTOR_CHAIN and a_arena.fused_dbuf and A <= 32 and H * A <= 512 * 9 and B <= 2048
             in_kernel = chain and lu.IN_KERNEL_NOISE and rng.normal_is_stock() and _rec_eps is None
             eps = None   # (kept alive to the end of the member's launches: the kernels read it asynchronously)
             if in_kernel:

@@ -844,6 +844,10 @@ def test_actor_update_chained_launch_matches_three_launches():
     rec = next(iter(agent.__dict__["_ssac_actor_rec"].values()))
     ns = lu.noise_stream(agent, dev)
     assert rec.in_kernel and rec.list is not None and ns[2] == 5   # (five numbered updates: 2 eager, 1 recorded, 2 replayed)
+    # a list with numbered launches must be renumbered at every replay: the plain replay entry refuses it (a repeated tag
+    # would let a consumer match the previous update's granules)
+    assert ssa._lib.lib.ssac_replay(rec.list, ssa.engine.stream()) != 0
+    assert b"ssac_replay_value" in ssa._lib.lib.ssac_last_error()
     eps = torch.empty(B, A, device=dev)
     rs = ssa._lib.Rng((ns[0] ^ 0x5DEECE66D1CEB00C) & (2 ** 64 - 1), 0, 4)   # the LAST update was number 4
     ssa._lib.check(ssa._lib.lib.ssac_philox_normal(eps.data_ptr(), B, A, C.byref(rs), ssa.engine.stream()))

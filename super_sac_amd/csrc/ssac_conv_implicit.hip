@@ -93,14 +93,75 @@ __global__ __launch_bounds__(CV_THREADS) void conv_fwd_kernel(ConvArgs g, int n_
     __syncthreads();
     const float bias = g.bias[co0 + li];
     const int64_t M = (int64_t)g.B * g.Ho * g.Wo;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // this lane's input pixel of a tile (lanes beyond the last pixel read pixel 0: valid memory, results dropped)
+    auto tile_base = [&](int tile) {
         const int64_t m = (int64_t)tile * CV_PIX + wave * 32 + li;
-        const bool ok = m < M;
-        const int64_t mm = ok ? m : 0;
+        const int64_t mm = m < M ? m : 0;
         const int ox = (int)(mm % g.Wo);
         const int64_t t = mm / g.Wo;
         const int oy = (int)(t % g.Ho), b = (int)(t / g.Ho);
-        const float *base = g.x + (((int64_t)b * g.Hi + oy * g.s) * g.Wi + ox * g.s) * g.ci + lh * 16;
+        return g.x + (((int64_t)b * g.Hi + oy * g.s) * g.Wi + ox * g.s) * g.ci + lh * 16;
+    };
+    auto compute = [&](f32x16 &acc, const f4 (&a)[4], int ch) {
+        if (ch < nch) {
+            f4 bf[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                bf[q] = *reinterpret_cast<const f4 *>(wl + wl_off(ch * 32 + li, lh * 16 + 4 * q));
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt >> 2][tt & 3], bf[tt >> 2][tt & 3], acc, 0, 0, 0);
+        }
+    };
+    auto store = [&](const f32x16 &acc, int tile) {
+        // C layout: column = lane & 31 (output channel), rows (r & 3) + 8 (r >> 2) + 4 lh (pixel within the wave)
+        const int64_t m_wave = (int64_t)tile * CV_PIX + wave * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t mr = m_wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (mr < M) g.out[mr * g.co + co0 + li] = fmaxf(acc[r] + bias, 0.0f);
+        }
+    };
+    if (nch % 3 == 0) {
+        // ONE operand stream over all of this workgroup's tiles: the loads run two chunks ahead of the MFMAs ACROSS tile
+        // boundaries -- with a per-tile pipeline every tile began with an exposed round trip for its first chunk and ended
+        // with two loads nobody used (the three-buffer rotation realigns at a tile boundary when nch is a multiple of 3)
+        int ltile = blockIdx.x;
+        if (ltile >= n_tiles) return;
+        const float *lbase = tile_base(ltile);
+        ChunkIter lit(g.k, cblocks, nch);
+        int lleft = nch;
+        auto load = [&](f4 (&a)[4]) {
+            int ky, kx, cb;
+            lit.next(ky, kx, cb);
+            const float *p = lbase + (ky * g.Wi + kx) * g.ci + cb * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f4 *>(p + 4 * q);
+            if (--lleft == 0) {   // that was the tile's last chunk: the stream moves to the workgroup's next tile
+                ltile += gridDim.x;
+                lbase = tile_base(ltile < n_tiles ? ltile : blockIdx.x);   // (past the end: redundant loads of a valid tile)
+                lit = ChunkIter(g.k, cblocks, nch);
+                lleft = nch;
+            }
+        };
+        f4 a0[4], a1[4], a2[4];
+        load(a0);
+        load(a1);
+        for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+            for (int ch = 0; ch < nch; ch += 3) {
+                load(a2); compute(acc, a0, ch);
+                load(a0); compute(acc, a1, ch + 1);
+                load(a1); compute(acc, a2, ch + 2);
+            }
+            store(acc, tile);
+        }
+        return;
+    }
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const float *base = tile_base(tile);
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
@@ -112,33 +173,16 @@ __global__ __launch_bounds__(CV_THREADS) void conv_fwd_kernel(ConvArgs g, int n_
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f4 *>(p + 4 * q);
         };
-        auto compute = [&](const f4 (&a)[4], int ch) {
-            if (ch < nch) {
-                f4 bf[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    bf[q] = *reinterpret_cast<const f4 *>(wl + wl_off(ch * 32 + li, lh * 16 + 4 * q));
-#pragma unroll
-                for (int tt = 0; tt < 16; ++tt)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt >> 2][tt & 3], bf[tt >> 2][tt & 3], acc, 0, 0, 0);
-            }
-        };
         // three operand buffers: the loads run two chunks ahead of the MFMAs
         f4 a0[4], a1[4], a2[4];
         load(a0);
         load(a1);
         for (int ch = 0; ch < nch; ch += 3) {
-            load(a2); compute(a0, ch);
-            load(a0); compute(a1, ch + 1);
-            load(a1); compute(a2, ch + 2);
+            load(a2); compute(acc, a0, ch);
+            load(a0); compute(acc, a1, ch + 1);
+            load(a1); compute(acc, a2, ch + 2);
         }
-        // C layout: column = lane & 31 (output channel), rows (r & 3) + 8 (r >> 2) + 4 lh (pixel within the wave)
-        const int64_t m_wave = (int64_t)tile * CV_PIX + wave * 32;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t mr = m_wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (mr < M) g.out[mr * g.co + co0 + li] = fmaxf(acc[r] + bias, 0.0f);
-        }
+        store(acc, tile);
     }
 }
 
@@ -174,6 +218,15 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dgrad_kernel(ConvArgs g, int 
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        // the ReLU mask of this tile's outputs (the layer's input activation) is requested NOW, 16 coalesced loads per lane
+        // that come back under the K loop: read in the epilogue they were an exposed round trip per tile
+        const int64_t m_wave = (int64_t)tile * CV_PIX + wave * 32;
+        float xm[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t mr = m_wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            xm[r] = g.x[(mr < M ? mr : 0) * g.ci + c0 + li];
+        }
         // chunk (ky, kx, ob) reads dy[b, (iy-ky)/s, (ix-kx)/s, ob*32 + 16 lh ..]: valid taps only, else zeros
         const float *dyb = g.dy + (int64_t)b * g.Ho * g.Wo * g.co + lh * 16;
         ChunkIter it(g.k, oblocks, nch);
@@ -216,14 +269,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dgrad_kernel(ConvArgs g, int 
             load(a0); compute(a1, ch + 1);
             load(a1); compute(a2, ch + 2);
         }
-        const int64_t m_wave = (int64_t)tile * CV_PIX + wave * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t mr = m_wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (mr < M) {
-                const int64_t o = mr * g.ci + c0 + li;
-                g.out[o] = g.x[o] > 0.0f ? acc[r] : 0.0f;
-            }
+            if (mr < M) g.out[mr * g.ci + c0 + li] = xm[r] > 0.0f ? acc[r] : 0.0f;
         }
     }
 }
@@ -272,6 +321,16 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dgrad_strided_kernel(ConvArgs
         const int xq = pp % Wx, t = pp / Wx;
         const int yq = t % Hy, b = t / Hy;
         if (lh == 0) pix_off[wave * 32 + li] = ok ? (b * g.Hi + yq * g.s + py) * g.Wi + xq * g.s + px : -1;
+        // (the pixel offsets of this lane's 16 output rows, and with them the ReLU mask values, are fetched NOW: the mask
+        // loads come back under the K loop instead of being an exposed round trip in the epilogue of every tile)
+        lds_barrier();   // pix_off of this tile (a wave reads only the 32 entries it wrote itself)
+        int po[16];
+        float xm[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            po[r] = pix_off[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+            xm[r] = g.x[(int64_t)(po[r] >= 0 ? po[r] : 0) * g.ci + c0 + li];
+        }
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
@@ -311,15 +370,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dgrad_strided_kernel(ConvArgs
             load(a0); compute(a1, ch + 1);
             load(a1); compute(a2, ch + 2);
         }
-        lds_barrier();   // pix_off of this tile (a wave reads only the 32 entries it wrote itself)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int po = pix_off[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
-            if (po >= 0) {
-                const int64_t o = (int64_t)po * g.ci + c0 + li;
-                g.out[o] = g.x[o] > 0.0f ? acc[r] : 0.0f;
-            }
-        }
+        for (int r = 0; r < 16; ++r)
+            if (po[r] >= 0) g.out[(int64_t)po[r] * g.ci + c0 + li] = xm[r] > 0.0f ? acc[r] : 0.0f;
         lds_barrier();   // before the next tile overwrites pix_off
     }
 }

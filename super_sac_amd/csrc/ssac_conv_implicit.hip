@@ -190,7 +190,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv_fwd_kernel(ConvArgs g, int n_
 // backward-data: grid (persistent input-pixel tiles, ci / 32)
 // ---------------------------------------------------------------------------------------------
 template <bool S1>  // S1: stride 1 (every layer the engine sends here) -- no per-tap divisions
-__global__ __launch_bounds__(CV_THREADS) void conv_dgrad_kernel(ConvArgs g, int n_tiles) {
+__global__ __launch_bounds__(CV_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))   // (three persistent workgroups per CU: <= 168 VGPRs)
+void conv_dgrad_kernel(ConvArgs g, int n_tiles) {
     extern __shared__ __attribute__((aligned(16))) float wl[];  // [chunks][32 c][WL_LD] : W[co][c0+c][ky][kx], co contiguous
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -208,72 +209,126 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dgrad_kernel(ConvArgs g, int 
     }
     __syncthreads();
     const int64_t M = (int64_t)g.B * g.Hi * g.Wi;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // this lane's input pixel of a tile
+    struct Pix { int iy, ix; bool ok; const float *dyb; };
+    auto tile_pix = [&](int tile) {
         const int64_t m = (int64_t)tile * CV_PIX + wave * 32 + li;
-        const bool ok = m < M;
-        const int64_t mm = ok ? m : 0;
-        const int ix = (int)(mm % g.Wi);
+        Pix p;
+        p.ok = m < M;
+        const int64_t mm = p.ok ? m : 0;
+        p.ix = (int)(mm % g.Wi);
         const int64_t t = mm / g.Wi;
-        const int iy = (int)(t % g.Hi), b = (int)(t / g.Hi);
-        f32x16 acc;
+        p.iy = (int)(t % g.Hi);
+        p.dyb = g.dy + (int64_t)(t / g.Hi) * g.Ho * g.Wo * g.co + lh * 16;
+        return p;
+    };
+    // chunk (ky, kx, ob) reads dy[b, (iy-ky)/s, (ix-kx)/s, ob*32 + 16 lh ..]: valid taps only, else zeros
+    auto load_at = [&](f4 (&a)[4], const Pix &px, int ky, int kx, int ob) {
+        const int ny = px.iy - ky, nx = px.ix - kx;
+        int oy, ox;
+        bool v;
+        if (S1) {
+            oy = ny; ox = nx;
+            v = px.ok && (unsigned)ny < (unsigned)g.Ho && (unsigned)nx < (unsigned)g.Wo;
+        } else {
+            oy = ny / g.s; ox = nx / g.s;
+            v = px.ok && ny >= 0 && nx >= 0 && oy * g.s == ny && ox * g.s == nx && oy < g.Ho && ox < g.Wo;
+        }
+        const float *p = px.dyb + (v ? (oy * g.Wo + ox) * g.co : 0) + ob * 32;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-        // the ReLU mask of this tile's outputs (the layer's input activation) is requested NOW, 16 coalesced loads per lane
-        // that come back under the K loop: read in the epilogue they were an exposed round trip per tile
+        for (int q = 0; q < 4; ++q) {
+            const f4 x = *reinterpret_cast<const f4 *>(p + 4 * q);
+            a[q] = v ? x : (f4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto compute = [&](f32x16 &acc, const f4 (&a)[4], int ch) {
+        if (ch < nch) {
+            f4 bf[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                bf[q] = *reinterpret_cast<const f4 *>(wl + wl_off(ch * 32 + li, lh * 16 + 4 * q));
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt >> 2][tt & 3], bf[tt >> 2][tt & 3], acc, 0, 0, 0);
+        }
+    };
+    // the ReLU mask of a tile's outputs (the layer's input activation): 16 coalesced loads per lane, requested at the START
+    // of the tile so that they come back under its K loop (read in the epilogue they were an exposed round trip per tile)
+    auto mask_load = [&](float (&xm)[16], int tile) {
         const int64_t m_wave = (int64_t)tile * CV_PIX + wave * 32;
-        float xm[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t mr = m_wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
             xm[r] = g.x[(mr < M ? mr : 0) * g.ci + c0 + li];
         }
-        // chunk (ky, kx, ob) reads dy[b, (iy-ky)/s, (ix-kx)/s, ob*32 + 16 lh ..]: valid taps only, else zeros
-        const float *dyb = g.dy + (int64_t)b * g.Ho * g.Wo * g.co + lh * 16;
-        ChunkIter it(g.k, oblocks, nch);
-        auto load = [&](f4 (&a)[4]) {
-            int ky, kx, ob;
-            it.next(ky, kx, ob);
-            const int ny = iy - ky, nx = ix - kx;
-            int oy, ox;
-            bool v;
-            if (S1) {
-                oy = ny; ox = nx;
-                v = ok && (unsigned)ny < (unsigned)g.Ho && (unsigned)nx < (unsigned)g.Wo;
-            } else {
-                oy = ny / g.s; ox = nx / g.s;
-                v = ok && ny >= 0 && nx >= 0 && oy * g.s == ny && ox * g.s == nx && oy < g.Ho && ox < g.Wo;
-            }
-            const float *p = dyb + (v ? (oy * g.Wo + ox) * g.co : 0) + ob * 32;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f4 x = *reinterpret_cast<const f4 *>(p + 4 * q);
-                a[q] = v ? x : (f4){0.f, 0.f, 0.f, 0.f};
-            }
-        };
-        auto compute = [&](const f4 (&a)[4], int ch) {
-            if (ch < nch) {
-                f4 bf[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    bf[q] = *reinterpret_cast<const f4 *>(wl + wl_off(ch * 32 + li, lh * 16 + 4 * q));
-#pragma unroll
-                for (int tt = 0; tt < 16; ++tt)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt >> 2][tt & 3], bf[tt >> 2][tt & 3], acc, 0, 0, 0);
-            }
-        };
-        f4 a0[4], a1[4], a2[4];
-        load(a0);
-        load(a1);
-        for (int ch = 0; ch < nch; ch += 3) {
-            load(a2); compute(a0, ch);
-            load(a0); compute(a1, ch + 1);
-            load(a1); compute(a2, ch + 2);
-        }
+    };
+    auto store = [&](const f32x16 &acc, const float (&xm)[16], int tile) {
+        const int64_t m_wave = (int64_t)tile * CV_PIX + wave * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t mr = m_wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (mr < M) g.out[mr * g.ci + c0 + li] = xm[r] > 0.0f ? acc[r] : 0.0f;
         }
+    };
+    if (nch % 3 == 0) {
+        // one operand stream over all of this workgroup's tiles (conv_fwd_kernel): the loads run two chunks ahead of the
+        // MFMAs across tile boundaries
+        int ltile = blockIdx.x;
+        if (ltile >= n_tiles) return;
+        Pix lpx = tile_pix(ltile);
+        ChunkIter lit(g.k, oblocks, nch);
+        int lleft = nch;
+        auto load = [&](f4 (&a)[4]) {
+            int ky, kx, ob;
+            lit.next(ky, kx, ob);
+            load_at(a, lpx, ky, kx, ob);
+            if (--lleft == 0) {
+                ltile += gridDim.x;
+                lpx = tile_pix(ltile < n_tiles ? ltile : blockIdx.x);   // (past the end: redundant loads of a valid tile)
+                lit = ChunkIter(g.k, oblocks, nch);
+                lleft = nch;
+            }
+        };
+        f4 a0[4], a1[4], a2[4];
+        load(a0);
+        load(a1);
+        for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+            float xm[16];
+            mask_load(xm, tile);
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+            for (int ch = 0; ch < nch; ch += 3) {
+                load(a2); compute(acc, a0, ch);
+                load(a0); compute(acc, a1, ch + 1);
+                load(a1); compute(acc, a2, ch + 2);
+            }
+            store(acc, xm, tile);
+        }
+        return;
+    }
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const Pix px = tile_pix(tile);
+        float xm[16];
+        mask_load(xm, tile);
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+        ChunkIter it(g.k, oblocks, nch);
+        auto load = [&](f4 (&a)[4]) {
+            int ky, kx, ob;
+            it.next(ky, kx, ob);
+            load_at(a, px, ky, kx, ob);
+        };
+        f4 a0[4], a1[4], a2[4];
+        load(a0);
+        load(a1);
+        for (int ch = 0; ch < nch; ch += 3) {
+            load(a2); compute(acc, a0, ch);
+            load(a0); compute(acc, a1, ch + 1);
+            load(a1); compute(acc, a2, ch + 2);
+        }
+        store(acc, xm, tile);
     }
 }
 

@@ -748,26 +748,32 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad_taps_kernel(ConvArgs g,
         for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
     float bsum = 0.0f;
     const float *xb = g.x + c0 + li;
-    for (int mc = m_lo; mc < m_hi; mc += 32) {
-        float av[16];
-        int xo[16];
-        {
-            const int m_first = mc + lh;
-            const int mf = m_first < M ? m_first : 0;
-            int ox = mf % g.Wo;
-            const int q = mf / g.Wo;
-            int oy = q % g.Ho, b = q / g.Ho;
+    // One wave per SIMD (nine accumulators: 440 VGPRs), so nothing hides a round trip but the wave's own MFMAs: the dy values
+    // and pixel offsets of the NEXT 32-pixel chunk are requested under the current chunk's 144 MFMAs, and so are the next
+    // chunk's first-tap x operands (under the current chunk's last tap) -- per chunk two exposed round trips less.
+    auto fetch = [&](float (&av)[16], int (&xo)[16], int mc) {
+        const int m_first = mc + lh;
+        const int mf = m_first < M ? m_first : 0;
+        int ox = mf % g.Wo;
+        const int q = mf / g.Wo;
+        int oy = q % g.Ho, b = q / g.Ho;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int m = m_first + 2 * t;
-                const bool ok = m < m_hi;
-                const float d = g.dy[(int64_t)(ok ? m : m_lo) * g.co + co0 + li];
-                av[t] = ok ? d : 0.0f;
-                xo[t] = ok ? ((b * g.Hi + oy * g.s) * g.Wi + ox * g.s) * g.ci : 0;
-                ox += 2;
-                if (ox >= g.Wo) { ox -= g.Wo; if (++oy == g.Ho) { oy = 0; ++b; } }
-            }
+        for (int t = 0; t < 16; ++t) {
+            const int m = m_first + 2 * t;
+            const bool ok = m < m_hi;
+            const float d = g.dy[(int64_t)(ok ? m : m_lo) * g.co + co0 + li];
+            av[t] = ok ? d : 0.0f;
+            xo[t] = ok ? ((b * g.Hi + oy * g.s) * g.Wi + ox * g.s) * g.ci : 0;
+            ox += 2;
+            if (ox >= g.Wo) { ox -= g.Wo; if (++oy == g.Ho) { oy = 0; ++b; } }
         }
+    };
+    float avA[16], avB[16], bx0[16];
+    int xoA[16], xoB[16];
+    // one chunk: its first-tap operands are in bx0; (avn, xon) is the next chunk, fetched here, whose first-tap operands
+    // replace bx0 under the last tap
+    auto process = [&](const float (&av)[16], const int (&xo)[16], float (&avn)[16], int (&xon)[16], int mc_next) {
+        fetch(avn, xon, mc_next);
         if (blockIdx.y == 0) {
 #pragma unroll
             for (int t = 0; t < 16; ++t) bsum += av[t];
@@ -775,7 +781,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad_taps_kernel(ConvArgs g,
         float bx[2][16];
         int ky = 0, kx = 0;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) bx[0][t] = xb[xo[t]];
+        for (int t = 0; t < 16; ++t) bx[0][t] = bx0[t];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             if (j + 1 < NT) {  // operands of the next tap (clamped to the last one: uniform, in bounds)
@@ -783,12 +789,25 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad_taps_kernel(ConvArgs g,
                 const int toff = (ky * g.Wi + kx) * g.ci;
 #pragma unroll
                 for (int t = 0; t < 16; ++t) bx[(j + 1) & 1][t] = xb[xo[t] + toff];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) bx0[t] = xb[xon[t]];   // the next chunk's tap (0, 0)
             }
             if (j < kk) {
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bx[j & 1][t], acc[j], 0, 0, 0);
             }
+        }
+    };
+    if (m_lo < m_hi) {
+        fetch(avA, xoA, m_lo);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) bx0[t] = xb[xoA[t]];
+        for (int mc = m_lo; mc < m_hi; mc += 64) {
+            process(avA, xoA, avB, xoB, mc + 32);   // (a chunk beyond m_hi fetches zeros from valid addresses)
+            if (mc + 32 >= m_hi) break;
+            process(avB, xoB, avA, xoA, mc + 64);
         }
     }
     bsum += __shfl_xor(bsum, 32, 64);

@@ -122,67 +122,49 @@ __global__ __launch_bounds__(CV_THREADS) void conv_fwd_kernel(ConvArgs g, int n_
             if (mr < M) g.out[mr * g.co + co0 + li] = fmaxf(acc[r] + bias, 0.0f);
         }
     };
-    if (nch % 3 == 0) {
-        // ONE operand stream over all of this workgroup's tiles: the loads run two chunks ahead of the MFMAs ACROSS tile
-        // boundaries -- with a per-tile pipeline every tile began with an exposed round trip for its first chunk and ended
-        // with two loads nobody used (the three-buffer rotation realigns at a tile boundary when nch is a multiple of 3)
-        int ltile = blockIdx.x;
-        if (ltile >= n_tiles) return;
-        const float *lbase = tile_base(ltile);
-        ChunkIter lit(g.k, cblocks, nch);
-        int lleft = nch;
-        auto load = [&](f4 (&a)[4]) {
-            int ky, kx, cb;
-            lit.next(ky, kx, cb);
-            const float *p = lbase + (ky * g.Wi + kx) * g.ci + cb * 32;
+    // ONE operand stream over all of this workgroup's tiles: the loads run two chunks ahead of the MFMAs ACROSS tile
+    // boundaries -- with a per-tile pipeline every tile began with an exposed round trip for its first chunk and ended with
+    // two loads nobody used.  The three operand buffers rotate over the stream; a tile ends wherever its last chunk falls.
+    int ltile = blockIdx.x;
+    if (ltile >= n_tiles) return;
+    const float *lbase = tile_base(ltile);
+    ChunkIter lit(g.k, cblocks, nch);
+    int lleft = nch;
+    auto load = [&](f4 (&a)[4]) {
+        int ky, kx, cb;
+        lit.next(ky, kx, cb);
+        const float *p = lbase + (ky * g.Wi + kx) * g.ci + cb * 32;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f4 *>(p + 4 * q);
-            if (--lleft == 0) {   // that was the tile's last chunk: the stream moves to the workgroup's next tile
-                ltile += gridDim.x;
-                lbase = tile_base(ltile < n_tiles ? ltile : blockIdx.x);   // (past the end: redundant loads of a valid tile)
-                lit = ChunkIter(g.k, cblocks, nch);
-                lleft = nch;
-            }
-        };
-        f4 a0[4], a1[4], a2[4];
-        load(a0);
-        load(a1);
-        for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-            f32x16 acc;
+        for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f4 *>(p + 4 * q);
+        if (--lleft == 0) {   // that was the tile's last chunk: the stream moves to the workgroup's next tile
+            ltile += gridDim.x;
+            lbase = tile_base(ltile < n_tiles ? ltile : blockIdx.x);   // (past the end: redundant loads of a valid tile)
+            lit = ChunkIter(g.k, cblocks, nch);
+            lleft = nch;
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    int ctile = blockIdx.x, cch = 0;   // the tile / chunk the MFMAs are at
+    auto step = [&](const f4 (&a)[4]) {
+        if (ctile >= n_tiles) return;
+        compute(acc, a, cch);
+        if (++cch == nch) {
+            store(acc, ctile);
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-            for (int ch = 0; ch < nch; ch += 3) {
-                load(a2); compute(acc, a0, ch);
-                load(a0); compute(acc, a1, ch + 1);
-                load(a1); compute(acc, a2, ch + 2);
-            }
-            store(acc, tile);
+            cch = 0;
+            ctile += gridDim.x;
         }
-        return;
-    }
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const float *base = tile_base(tile);
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-        ChunkIter it(g.k, cblocks, nch);
-        auto load = [&](f4 (&a)[4]) {
-            int ky, kx, cb;
-            it.next(ky, kx, cb);
-            const float *p = base + (ky * g.Wi + kx) * g.ci + cb * 32;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f4 *>(p + 4 * q);
-        };
-        // three operand buffers: the loads run two chunks ahead of the MFMAs
-        f4 a0[4], a1[4], a2[4];
-        load(a0);
-        load(a1);
-        for (int ch = 0; ch < nch; ch += 3) {
-            load(a2); compute(acc, a0, ch);
-            load(a0); compute(acc, a1, ch + 1);
-            load(a1); compute(acc, a2, ch + 2);
-        }
-        store(acc, tile);
+    };
+    f4 a0[4], a1[4], a2[4];
+    load(a0);
+    load(a1);
+    while (ctile < n_tiles) {
+        load(a2); step(a0);
+        load(a0); step(a1);
+        load(a1); step(a2);
     }
 }
 
@@ -270,65 +252,49 @@ void conv_dgrad_kernel(ConvArgs g, int n_tiles) {
             if (mr < M) g.out[mr * g.ci + c0 + li] = xm[r] > 0.0f ? acc[r] : 0.0f;
         }
     };
-    if (nch % 3 == 0) {
-        // one operand stream over all of this workgroup's tiles (conv_fwd_kernel): the loads run two chunks ahead of the
-        // MFMAs across tile boundaries
-        int ltile = blockIdx.x;
-        if (ltile >= n_tiles) return;
-        Pix lpx = tile_pix(ltile);
-        ChunkIter lit(g.k, oblocks, nch);
-        int lleft = nch;
-        auto load = [&](f4 (&a)[4]) {
-            int ky, kx, ob;
-            lit.next(ky, kx, ob);
-            load_at(a, lpx, ky, kx, ob);
-            if (--lleft == 0) {
-                ltile += gridDim.x;
-                lpx = tile_pix(ltile < n_tiles ? ltile : blockIdx.x);   // (past the end: redundant loads of a valid tile)
-                lit = ChunkIter(g.k, oblocks, nch);
-                lleft = nch;
-            }
-        };
-        f4 a0[4], a1[4], a2[4];
-        load(a0);
-        load(a1);
-        for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-            float xm[16];
-            mask_load(xm, tile);
-            f32x16 acc;
+    // one operand stream over all of this workgroup's tiles (conv_fwd_kernel): the loads run two chunks ahead of the MFMAs
+    // across tile boundaries
+    int ltile = blockIdx.x;
+    if (ltile >= n_tiles) return;
+    Pix lpx = tile_pix(ltile);
+    ChunkIter lit(g.k, oblocks, nch);
+    int lleft = nch;
+    auto load = [&](f4 (&a)[4]) {
+        int ky, kx, ob;
+        lit.next(ky, kx, ob);
+        load_at(a, lpx, ky, kx, ob);
+        if (--lleft == 0) {
+            ltile += gridDim.x;
+            lpx = tile_pix(ltile < n_tiles ? ltile : blockIdx.x);   // (past the end: redundant loads of a valid tile)
+            lit = ChunkIter(g.k, oblocks, nch);
+            lleft = nch;
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    int ctile = blockIdx.x, cch = 0;
+    float xm[16];
+    mask_load(xm, ctile);
+    auto step = [&](const f4 (&a)[4]) {
+        if (ctile >= n_tiles) return;
+        compute(acc, a, cch);
+        if (++cch == nch) {
+            store(acc, xm, ctile);
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-            for (int ch = 0; ch < nch; ch += 3) {
-                load(a2); compute(acc, a0, ch);
-                load(a0); compute(acc, a1, ch + 1);
-                load(a1); compute(acc, a2, ch + 2);
-            }
-            store(acc, xm, tile);
+            cch = 0;
+            ctile += gridDim.x;
+            if (ctile < n_tiles) mask_load(xm, ctile);
         }
-        return;
-    }
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const Pix px = tile_pix(tile);
-        float xm[16];
-        mask_load(xm, tile);
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-        ChunkIter it(g.k, oblocks, nch);
-        auto load = [&](f4 (&a)[4]) {
-            int ky, kx, ob;
-            it.next(ky, kx, ob);
-            load_at(a, px, ky, kx, ob);
-        };
-        f4 a0[4], a1[4], a2[4];
-        load(a0);
-        load(a1);
-        for (int ch = 0; ch < nch; ch += 3) {
-            load(a2); compute(acc, a0, ch);
-            load(a0); compute(acc, a1, ch + 1);
-            load(a1); compute(acc, a2, ch + 2);
-        }
-        store(acc, xm, tile);
+    };
+    f4 a0[4], a1[4], a2[4];
+    load(a0);
+    load(a1);
+    while (ctile < n_tiles) {
+        load(a2); step(a0);
+        load(a0); step(a1);
+        load(a1); step(a2);
     }
 }
 

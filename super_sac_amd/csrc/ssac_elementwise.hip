@@ -874,12 +874,7 @@ __global__ void ensemble_min_select_kernel(const float *__restrict__ q, int n_ne
 }
 
 // ------------------------------------------------------------------ DrQ shifts
-// torch.linspace(start, end, steps) element i in fp32 (two-sided evaluation)
-__device__ __forceinline__ float linspace_f32(float start, float end, float step, int steps, int i) {
-    // each element is one fused multiply-add in ATen (CPU build and nvcc contract it alike)
-    return (i < steps / 2) ? __fmaf_rn(step, (float)i, start)
-                           : __fmaf_rn(-step, (float)(steps - 1 - i), end);
-}
+// (linspace_f32 / drqv2_shift_axis: ssac_internal.h)
 
 template <typename T>
 __global__ void drq_shift_kernel(const T *__restrict__ src, const int64_t *__restrict__ idx, int n, int c,
@@ -981,16 +976,10 @@ __global__ __launch_bounds__(256) void drqv2_shift_plane_kernel(const T *__restr
     }
     if (tid < 2 * h) {
         const int ax = tid >= h, i = ax ? tid - h : tid;   // ax 0: x / columns, 1: y / rows
-        const float start = (float)(-1.0 + 1.0 / (double)hp), end = (float)(1.0 - 1.0 / (double)hp);
-        const float step = __fdiv_rn(__fsub_rn(end, start), (float)(hp - 1));
-        const float sscale = (float)(2.0 / (double)hp);
-        const float gpos = __fadd_rn(linspace_f32(start, end, step, hp, i), __fmul_rn((float)shift[2 * b + ax], sscale));
-        const float ip = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gpos, 1.0f), (float)hp), 1.0f), 2.0f);
-        const float fl = floorf(ip);
-        const float w1 = __fsub_rn(ip, fl), w0 = __fsub_rn(1.0f, w1);
-        (ax ? w1y : w1x)[i] = w1;
-        (ax ? w0y : w0x)[i] = w0;
-        (ax ? p0y : p0x)[i] = (int)fl;
+        const ShiftAxis sa = drqv2_shift_axis(i, shift[2 * b + ax], hp);
+        (ax ? w1y : w1x)[i] = sa.w1;
+        (ax ? w0y : w0x)[i] = sa.w0;
+        (ax ? p0y : p0x)[i] = sa.p0;
     }
     __syncthreads();
     // a thread owns output columns (their source columns, weights and validity stay in registers) and walks down the

@@ -155,6 +155,46 @@ __device__ __forceinline__ void handoff_publish(unsigned long long *gp, unsigned
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- DrQv2 random shift (augmentations.py:214-269): the sampling position of output index i along one axis.
+// torch.linspace(start, end, steps) element i in fp32 (two-sided evaluation: each element is one fused multiply-add in
+// ATen -- CPU build and nvcc contract it alike); then grid_sample's un-normalisation (align_corners=False)
+// ((g + 1) * size - 1) / 2 in ATen's separate fp32 ops.  Shared by the shift kernels (ssac_elementwise.hip) and the
+// first convolution that applies the shift in its operand staging (ssac_conv_implicit.hip): the same bits in both.
+__device__ __forceinline__ float linspace_f32(float start, float end, float step, int steps, int i) {
+    return (i < steps / 2) ? __fmaf_rn(step, (float)i, start) : __fmaf_rn(-step, (float)(steps - 1 - i), end);
+}
+struct ShiftAxis {
+    float w0, w1;   // bilinear weights of the taps p0 and p0 + 1
+    int p0;         // first tap, in PADDED coordinates (valid inside [0, hp); source index = clamp(p - pad, 0, h - 1))
+};
+struct ShiftGrid {  // the constants of one padded size hp (two double divisions: evaluate once per kernel, not per position)
+    float start, end, step, sscale;
+    int hp;
+};
+__device__ __forceinline__ ShiftGrid drqv2_shift_grid(int hp) {
+#pragma clang fp contract(off)
+    ShiftGrid g;
+    g.start = (float)(-1.0 + 1.0 / (double)hp); g.end = (float)(1.0 - 1.0 / (double)hp);
+    g.step = __fdiv_rn(__fsub_rn(g.end, g.start), (float)(hp - 1));
+    g.sscale = (float)(2.0 / (double)hp);
+    g.hp = hp;
+    return g;
+}
+__device__ __forceinline__ ShiftAxis drqv2_shift_axis(int i, int64_t shift, const ShiftGrid &g) {
+#pragma clang fp contract(off)
+    const float gpos = __fadd_rn(linspace_f32(g.start, g.end, g.step, g.hp, i), __fmul_rn((float)shift, g.sscale));
+    const float ip = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(gpos, 1.0f), (float)g.hp), 1.0f), 2.0f);
+    const float fl = floorf(ip);
+    ShiftAxis a;
+    a.w1 = __fsub_rn(ip, fl);
+    a.w0 = __fsub_rn(1.0f, a.w1);
+    a.p0 = (int)fl;
+    return a;
+}
+__device__ __forceinline__ ShiftAxis drqv2_shift_axis(int i, int64_t shift, int hp) {
+    return drqv2_shift_axis(i, shift, drqv2_shift_grid(hp));
+}
+
 // Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global loads / stores.
 // __syncthreads() also drains vmcnt -- inside a software-pipelined K loop that exposes the round trip of the operand
 // loads issued for the chunk AFTER next at every chunk barrier, and at phase boundaries it stalls on prefetched weights

@@ -22,6 +22,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -603,7 +604,7 @@ struct ShiftSrc {
 
 constexpr int FS_PW = 8, FS_CW = 8;   // producer waves (the next item's shifted band), consumer waves (this item's MFMA tiles)
 constexpr int FS_THREADS = 64 * (FS_PW + FS_CW);
-constexpr int FS_NW = 14;         // source words a producer lane carries for the item after next
+constexpr int FS_NW = 9;          // source words a producer lane carries for the item after next
 constexpr int FS_SEG = 4;         // channels a producer wave's row range can touch
 
 // The rows (c, r) of an item's band are cut into FS_PW contiguous ranges, one per producer wave; a wave stages the source
@@ -626,10 +627,11 @@ __global__ __launch_bounds__(FS_THREADS) void conv_first_shift_fwd_kernel(FirstA
     const ShiftGrid sg = drqv2_shift_grid(hp);
     const int Rin = (sa.R - 1) * g.s + g.k;
     const int per_max = (g.C * Rin + FS_PW - 1) / FS_PW, seg_words = (per_max + 2 * FS_SEG) * wpr;
-    float *band0 = wl + nruns * 32 * 2 * KH;                                 // 2 x [C][Rin][H] shifted fp32 input rows
+    const int nruns3 = (nruns + 2) / 3 * 3;                                   // (the operand rotation runs in threes: zero weights behind the last run)
+    float *band0 = wl + nruns3 * 32 * 2 * KH;                                // 2 x [C][Rin][H] shifted fp32 input rows
     const int band_floats = g.C * Rin * H;
     uint32_t *srcw_all = reinterpret_cast<uint32_t *>(band0 + 2 * band_floats);   // FS_PW x [seg_words] source rows, 4 pixels a word
-    float *ytab_all = reinterpret_cast<float *>(srcw_all + FS_PW * seg_words);    // FS_PW x [3][per_max]: w0, w1, p0 of the wave's rows
+    uint32_t *rtab_all = srcw_all + FS_PW * seg_words;                       // FS_PW x [per_max][8]: the row table of a producer wave
     const int co0 = blockIdx.y * 32;
     const int nbands = (g.Ho + sa.R - 1) / sa.R;
     const int64_t img_bytes = (int64_t)g.C * H * H;
@@ -643,10 +645,10 @@ __global__ __launch_bounds__(FS_THREADS) void conv_first_shift_fwd_kernel(FirstA
         it.aug = it.b < sa.n_aug;
         return it;
     };
-    for (int i = tid; i < nruns * 32 * 2 * KH; i += FS_THREADS) {
+    for (int i = tid; i < nruns3 * 32 * 2 * KH; i += FS_THREADS) {
         const int kx = i % (2 * KH), t = i / (2 * KH), co = t & 31, run = t >> 5;
         const int c = run / g.k, ky = run - c * g.k;
-        wl[i] = kx < g.k ? g.w[((int64_t)(co0 + co) * g.C + c) * kk + ky * g.k + kx] / g.div : 0.0f;
+        wl[i] = (kx < g.k && run < nruns) ? g.w[((int64_t)(co0 + co) * g.C + c) * kk + ky * g.k + kx] / g.div : 0.0f;
     }
     __syncthreads();
     const int my_items = blockIdx.x < n_items ? (n_items - 1 - blockIdx.x) / gridDim.x + 1 : 0;
@@ -655,8 +657,7 @@ __global__ __launch_bounds__(FS_THREADS) void conv_first_shift_fwd_kernel(FirstA
         // ------------------------------------------------------------------------------------------ producer waves
         uint32_t *sw = srcw_all + wave * seg_words;
         const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
-        float *w0y = ytab_all + wave * 3 * per_max, *w1y = w0y + per_max;
-        int *p0y = reinterpret_cast<int *>(w1y + per_max);
+        uint32_t *rtab = rtab_all + wave * per_max * 8;
         const int ry = lane / wpr, tx4 = lane - ry * wpr, rpi = 64 / wpr;   // rows per pass of the wave, this lane's quad
         auto src_lo = [&](const FsItem &it, int64_t sy, int r) {
             return it.aug ? min(max(drqv2_shift_axis(it.iy0 + r, sy, sg).p0 - sa.pad, 0), H - 1) : it.iy0 + r;
@@ -727,12 +728,28 @@ __global__ __launch_bounds__(FS_THREADS) void conv_first_shift_fwd_kernel(FirstA
                 const int i = lane + u * 64;
                 if (i < d.total) sw[i] = pre[u];
             }
-            if (it.aug)
-                for (int i = lane; i < d.q1 - d.q0; i += 64) {
-                    const int q = d.q0 + i, c = q / it.rin;
-                    const ShiftAxis t = drqv2_shift_axis(it.iy0 + q - c * it.rin, sy, sg);
-                    w0y[i] = t.w0; w1y[i] = t.w1; p0y[i] = t.p0;
+            // the row table: per row of this wave's range the byte offsets of its two source rows inside the staged runs,
+            // the two row weights (0 where the tap lies outside the padded image: all weights are >= 0, so wy * 0 = +0 = the
+            // two-launch form's selected 0.0f -- the same bits) and where the row goes in the band
+            for (int i = lane; i < d.q1 - d.q0; i += 64) {
+                const int q = d.q0 + i, c = q / it.rin, r = q - c * it.rin, k = c - d.c_lo;
+                int ya = d.ya[0], base = d.base[0];
+#pragma unroll
+                for (int j = 1; j < FS_SEG; ++j) if (k == j) { ya = d.ya[j]; base = d.base[j]; }
+                uint32_t o0, o1;
+                float w0 = 1.0f, w1 = 0.0f;
+                if (it.aug) {
+                    const ShiftAxis t = drqv2_shift_axis(it.iy0 + r, sy, sg);
+                    o0 = (base + (min(max(t.p0 - sa.pad, 0), H - 1) - ya) * wpr) * 4;
+                    o1 = (base + (min(max(t.p0 + 1 - sa.pad, 0), H - 1) - ya) * wpr) * 4;
+                    w0 = (t.p0 >= 0 && t.p0 < hp) ? t.w0 : 0.0f;
+                    w1 = (t.p0 + 1 >= 0 && t.p0 + 1 < hp) ? t.w1 : 0.0f;
+                } else {
+                    o0 = o1 = (base + (it.iy0 + r - ya) * wpr) * 4;
                 }
+                *reinterpret_cast<uint4 *>(rtab + i * 8) = uint4{o0, o1, __float_as_uint(w0), __float_as_uint(w1)};
+                rtab[i * 8 + 4] = (c * Rin + r) * H;
+            }
             // the item after: its rows are requested now (they land while this one is evaluated), its successor's draws too
             sxA = sxB; syA = syB; rowA = rowB;
             if (n + 1 < my_items) {
@@ -744,44 +761,40 @@ __global__ __launch_bounds__(FS_THREADS) void conv_first_shift_fwd_kernel(FirstA
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");   // (this wave's LDS stores above are read below: DS operations of a wave stay in order)
             if (ry < rpi) {
-                // a tap outside the padded image weighs 0: the mask goes into the axis weights (all weights are >= 0, so
-                // wy * 0 = +0 = the two-launch form's selected 0.0f -- the same bits)
-                float wx0[4], wx1[4];
-                int sx0[4], sx1[4];
+                const int nrow = d.q1 - d.q0;
                 if (it.aug) {
+                    f2 wxa[2], wxb[2];    // the masked column weights of taps x0 / x0 + 1, columns (0, 1) and (2, 3)
+                    int sx0[4], sx1[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const ShiftAxis t = drqv2_shift_axis(4 * tx4 + j, sx, sg);
-                        wx0[j] = (t.p0 >= 0 && t.p0 < hp) ? t.w0 : 0.0f;
-                        wx1[j] = (t.p0 + 1 >= 0 && t.p0 + 1 < hp) ? t.w1 : 0.0f;
+                        wxa[j >> 1][j & 1] = (t.p0 >= 0 && t.p0 < hp) ? t.w0 : 0.0f;
+                        wxb[j >> 1][j & 1] = (t.p0 + 1 >= 0 && t.p0 + 1 < hp) ? t.w1 : 0.0f;
                         sx0[j] = min(max(t.p0 - sa.pad, 0), H - 1); sx1[j] = min(max(t.p0 + 1 - sa.pad, 0), H - 1);   // replicate pad
                     }
-                }
-                for (int q = d.q0 + ry; q < d.q1; q += rpi) {
-                    const int c = q / it.rin, r = q - c * it.rin, k = c - d.c_lo;
-                    int ya = d.ya[0], base = d.base[0];
-#pragma unroll
-                    for (int j = 1; j < FS_SEG; ++j) if (k == j) { ya = d.ya[j]; base = d.base[j]; }
-                    float *dst = band + (c * Rin + r) * H + 4 * tx4;
-                    if (it.aug) {
-                        const int qi = q - d.q0, y0 = p0y[qi];
-                        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    for (int i = ry; i < nrow; i += rpi) {
+                        const uint4 e = *reinterpret_cast<const uint4 *>(rtab + i * 8);
+                        float *dst = band + rtab[i * 8 + 4] + 4 * tx4;
+                        f2 acc[2] = {f2{0.0f, 0.0f}, f2{0.0f, 0.0f}};
 #pragma unroll
                         for (int dy = 0; dy < 2; ++dy) {
-                            const int yy = y0 + dy;
-                            const float wy = (yy >= 0 && yy < hp) ? (dy ? w1y[qi] : w0y[qi]) : 0.0f;
-                            const uint8_t *row = sb + (base + (min(max(yy - sa.pad, 0), H - 1) - ya) * wpr) * 4;
+                            const uint8_t *row = sb + (dy ? e.y : e.x);
+                            const float wy = __uint_as_float(dy ? e.w : e.z);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                acc[j] = __fadd_rn(acc[j], __fmul_rn((float)row[sx0[j]], __fmul_rn(wy, wx0[j])));
-                                acc[j] = __fadd_rn(acc[j], __fmul_rn((float)row[sx1[j]], __fmul_rn(wy, wx1[j])));
+                            for (int h = 0; h < 2; ++h) {   // two columns per packed operation; per column the two-launch order
+                                const f2 pa = f2{(float)row[sx0[2 * h]], (float)row[sx0[2 * h + 1]]};
+                                const f2 pb = f2{(float)row[sx1[2 * h]], (float)row[sx1[2 * h + 1]]};
+                                acc[h] = acc[h] + pa * (wxa[h] * wy);
+                                acc[h] = acc[h] + pb * (wxb[h] * wy);
                             }
                         }
-                        *reinterpret_cast<f4 *>(dst) = f4{fminf(fmaxf(acc[0], 0.0f), 255.0f), fminf(fmaxf(acc[1], 0.0f), 255.0f),
-                                                          fminf(fmaxf(acc[2], 0.0f), 255.0f), fminf(fmaxf(acc[3], 0.0f), 255.0f)};
-                    } else {
-                        const uint32_t u = sw[base + (it.iy0 + r - ya) * wpr + tx4];
-                        *reinterpret_cast<f4 *>(dst) =
+                        *reinterpret_cast<f4 *>(dst) = f4{__builtin_amdgcn_fmed3f(acc[0][0], 0.0f, 255.0f), __builtin_amdgcn_fmed3f(acc[0][1], 0.0f, 255.0f),
+                                                          __builtin_amdgcn_fmed3f(acc[1][0], 0.0f, 255.0f), __builtin_amdgcn_fmed3f(acc[1][1], 0.0f, 255.0f)};
+                    }
+                } else {
+                    for (int i = ry; i < nrow; i += rpi) {
+                        const uint32_t u = sw[(rtab[i * 8] >> 2) + tx4];
+                        *reinterpret_cast<f4 *>(band + rtab[i * 8 + 4] + 4 * tx4) =
                             f4{(float)(u & 255u), (float)((u >> 8) & 255u), (float)((u >> 16) & 255u), (float)(u >> 24)};
                     }
                 }
@@ -818,27 +831,26 @@ __global__ __launch_bounds__(FS_THREADS) void conv_first_shift_fwd_kernel(FirstA
                 f32x16 acc;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-                // operands two runs ahead of the MFMAs (three rotating register sets; LDS latency under 2 KH MFMAs)
-                int l_off = 0, l_ky = 0, l_run = 0, c_run = 0;
+                // operands two runs ahead of the MFMAs (three rotating register sets; LDS latency under 2 KH MFMAs); the
+                // runs behind the last one re-read its pixels against zero weights (acc + 0 * x: unchanged bits)
+                int l_off = 0, l_ky = 0, l_run = 0;
                 auto load = [&](vec &a, vec &bw) {
                     a = *reinterpret_cast<const vec *>(ab + l_off);
                     bw = *reinterpret_cast<const vec *>(wb + l_run * 64 * KH);
-                    if (l_run + 1 < nruns) {   // (clamped: the loads past the end re-read the last run)
-                        ++l_run;
-                        l_off += H;
-                        if (++l_ky == g.k) { l_ky = 0; l_off += (Rin - g.k) * H; }
-                    }
+                    const bool adv = l_run + 1 < nruns;
+                    l_run += l_run + 1 < nruns3;
+                    l_ky += adv;
+                    const bool wrap = l_ky == g.k;
+                    l_off += (adv ? H : 0) + (wrap ? (Rin - g.k) * H : 0);
+                    l_ky = wrap ? 0 : l_ky;
                 };
                 auto step = [&](const vec &a, const vec &bw) {
-                    if (c_run < nruns) {
 #pragma unroll
-                        for (int j = 0; j < KH; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bw[j], acc, 0, 0, 0);
-                    }
-                    ++c_run;
+                    for (int j = 0; j < KH; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bw[j], acc, 0, 0, 0);
                 };
                 vec a0, a1, a2, b0, b1, b2;
                 load(a0, b0); load(a1, b1);
-                while (c_run < nruns) {
+                for (int c_run = 0; c_run < nruns3; c_run += 3) {
                     load(a2, b2); step(a0, b0);
                     load(a0, b0); step(a1, b1);
                     load(a1, b1); step(a2, b2);
@@ -1239,7 +1251,7 @@ extern "C" int ssac_conv_first_fwd(const float *img, const float *w, const float
 // the producer waves' shifted input rows (bands overlap by k - s rows); ties go to the taller band.
 static size_t first_shift_lds(int C, int k, int s, int H, int kh, int R) {
     const int Rin = (R - 1) * s + k, per = (C * Rin + FS_PW - 1) / FS_PW;
-    return sizeof(float) * ((size_t)C * k * 64 * kh + 2 * (size_t)C * Rin * H + FS_PW * (size_t)(per + 2 * FS_SEG) * (H / 4) + 3 * FS_PW * (size_t)per);
+    return sizeof(float) * ((size_t)((C * k + 2) / 3 * 3) * 64 * kh + 2 * (size_t)C * Rin * H + FS_PW * (size_t)(per + 2 * FS_SEG) * (H / 4) + 8 * FS_PW * (size_t)per);
 }
 // one band height's row ranges fit the producer waves' bounds (channels touched, words carried per lane)
 static bool first_shift_rows_ok(int C, int rin, int H) {

@@ -218,7 +218,8 @@ __global__ __launch_bounds__(1024) void reduce_slices_pair_kernel(const float *_
     }
 }
 
-// out[m*ldo + n] = bias[n] + sum_s partial[(s*M + m)*N + n], fixed order
+// out[m*ldo + n] = bias[n] + sum_s partial[(s*M + m)*N + n], fixed order (slice 0 first).  The additions of an element
+// are a dependent chain, its loads are not: 16 slices are requested at once (one round trip per 16 instead of per slice).
 __global__ void reduce_slices_bias_kernel(const float *__restrict__ partial, int slices, int M, int N,
                                           const float *__restrict__ bias, float *__restrict__ out, int64_t ldo) {
     const int64_t n_el = (int64_t)M * N;
@@ -226,26 +227,44 @@ __global__ void reduce_slices_bias_kernel(const float *__restrict__ partial, int
          i += (int64_t)gridDim.x * blockDim.x) {
         const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
         float s = 0.0f;
-        for (int z = 0; z < slices; ++z) s += partial[(int64_t)z * n_el + i];
+        for (int z0 = 0; z0 < slices; z0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = partial[(int64_t)min(z0 + u, slices - 1) * n_el + i];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (z0 + u < slices) s += v[u];
+        }
         out[m * ldo + n] = s + (bias ? bias[n] : 0.0f);
     }
 }
 
 // dst[n][p][c] = src[n][c][p]  (to_cl) or dst[n][c][p] = src[n][p][c]  (!to_cl): the fc weight (emb x C x P, the
-// NCHW flatten order of cnns.py:63,98) <-> the channels-last order the feature maps are stored in.
-__global__ void permute_cp_kernel(const float *__restrict__ src, float *__restrict__ dst, int N, int Cc, int P,
-                                  int to_cl) {
-    const int64_t per = (int64_t)Cc * P, total = per * N;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = i / per, r = i - n * per;
-        if (to_cl) {  // i indexes dst (p, c)
-            const int p = (int)(r / Cc), c = (int)(r - (int64_t)p * Cc);
-            dst[i] = src[n * per + (int64_t)c * P + p];
-        } else {      // i indexes dst (c, p)
-            const int c = (int)(r / P), p = (int)(r - (int64_t)c * P);
-            dst[i] = src[n * per + (int64_t)p * Cc + c];
+// NCHW flatten order of cnns.py:63,98) <-> the channels-last order the feature maps are stored in.  A workgroup moves a
+// 32 x 32 tile of one matrix through LDS: both the reads and the writes are 128-byte rows (the element-wise form read
+// with a stride of a whole row: 32 cache lines per wave load).
+__global__ __launch_bounds__(256) void permute_cp_kernel(const float *__restrict__ src, float *__restrict__ dst, int N, int Cc,
+                                                         int P, int to_cl) {
+    __shared__ float tile[32][33];
+    // rows x cols of the SOURCE matrix of one n: (Cc x P) when to_cl, else (P x Cc)
+    const int R = to_cl ? Cc : P, Q = to_cl ? P : Cc;
+    const int tr = (R + 31) >> 5, tq = (Q + 31) >> 5, per_n = tr * tq;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int64_t t = blockIdx.x; t < (int64_t)N * per_n; t += gridDim.x) {
+        const int n = (int)(t / per_n), rem = (int)(t - (int64_t)n * per_n), r0 = (rem / tq) << 5, q0 = (rem % tq) << 5;
+        const float *sn = src + (int64_t)n * R * Q;
+        float *dn = dst + (int64_t)n * R * Q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + ty + 8 * j, q = q0 + tx;
+            if (r < R && q < Q) tile[ty + 8 * j][tx] = sn[(int64_t)r * Q + q];
         }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + ty + 8 * j, r = r0 + tx;
+            if (r < R && q < Q) dn[(int64_t)q * R + r] = tile[tx][ty + 8 * j];
+        }
+        __syncthreads();
     }
 }
 
@@ -470,8 +489,9 @@ extern "C" int ssac_permute_cp(const float *src, float *dst, int n, int channels
                                void *stream) {
     const int64_t total = (int64_t)n * channels * pixels;
     if (total <= 0) return 0;
-    SSAC_LAUNCH(permute_cp_kernel, dim3(grid_for(total)), dim3(256), 0, ST, src, dst, n, channels, pixels,
-                to_channels_last);
+    const int64_t tiles = (int64_t)n * ((channels + 31) / 32) * ((pixels + 31) / 32);
+    SSAC_LAUNCH(permute_cp_kernel, dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(256), 0, ST, src, dst, n, channels,
+                pixels, to_channels_last);
     return ssac_check_launch("permute_cp");
 }
 

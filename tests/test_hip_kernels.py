@@ -1003,6 +1003,31 @@ def test_first_layer_with_the_shift_in_its_operand_staging(ssa, B, C, co, k, s, 
     assert lib.ssac_conv_first_shift_supported(C, co, k, s, H + 2, B, pad) == 0   # H % 4 != 0: stays on the two launches
 
 
+def test_slice_reduction_and_weight_permutation_are_exact(ssa):
+    """ssac_reduce_slices_bias: slices summed in index order behind 16 loads in flight (bit-identical to the sequential
+    fp32 sum, any slice count); ssac_permute_cp: the fc weight (emb, C, P) <-> channels-last (emb, P, C) through 32 x 32
+    LDS tiles, ragged edges in both dimensions."""
+    lib, st = ssa._lib.lib, ssa.engine.stream()
+    g = torch.Generator().manual_seed(3)
+    for slices, M, N, ld in ((1, 5, 7, 7), (16, 33, 50, 64), (17, 512, 50, 50), (48, 64, 50, 56)):
+        part = torch.randn(slices, M, N, generator=g).to(DEV)
+        bias = torch.randn(N, generator=g).to(DEV)
+        out = torch.full((M, ld), float("nan"), device=DEV)
+        ssa._lib.check(lib.ssac_reduce_slices_bias(part.data_ptr(), slices, M, N, bias.data_ptr(), out.data_ptr(), ld, st))
+        want = torch.zeros(M, N, device=DEV)
+        for z in range(slices):
+            want = want + part[z]
+        assert torch.equal(out[:, :N], want + bias), (slices, M, N)
+    for n, C, P in ((50, 32, 1225), (3, 5, 7), (2, 33, 64), (1, 64, 31)):
+        w = torch.randn(n, C, P, generator=g).to(DEV)
+        cl = torch.full((n, P, C), float("nan"), device=DEV)
+        ssa._lib.check(lib.ssac_permute_cp(w.data_ptr(), cl.data_ptr(), n, C, P, 1, st))
+        assert torch.equal(cl, w.permute(0, 2, 1).contiguous()), (n, C, P)
+        back = torch.full((n, C, P), float("nan"), device=DEV)
+        ssa._lib.check(lib.ssac_permute_cp(cl.data_ptr(), back.data_ptr(), n, C, P, 0, st))
+        assert torch.equal(back, w), (n, C, P)
+
+
 def test_first_layer_implicit_convolution_refuses_what_it_does_not_cover(ssa):
     lib = ssa._lib.lib
     assert lib.ssac_conv_first_supported(4, 32, 8, 4, 84, 84, 1024) == 4

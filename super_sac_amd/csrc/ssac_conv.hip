@@ -153,13 +153,25 @@ __global__ void relu_mask_kernel(float *__restrict__ dy, const float *__restrict
 }
 
 // out[i] = sum_s partial[s*n + i], fixed order
+// sum of partial[z * n + i] over z = z0, z0 + dz, ... < slices, added in that order; the loads of 8 terms are requested
+// together (the additions are a dependent chain, the loads are not: one round trip per 8 terms instead of per term)
+__device__ __forceinline__ float sum_slices(const float *__restrict__ partial, int64_t n, int64_t i, int z0, int dz, int slices) {
+    float s = 0.0f;
+    for (int z = z0; z < slices; z += 8 * dz) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)min(z + u * dz, slices - 1) * n + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (z + u * dz < slices) s += v[u];
+    }
+    return s;
+}
+
 __global__ void reduce_slices_kernel(const float *__restrict__ partial, int slices, int64_t n,
                                      float *__restrict__ out) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.0f;
-        for (int z = 0; z < slices; ++z) s += partial[(int64_t)z * n + i];
-        out[i] = s;
+        out[i] = sum_slices(partial, n, i, 0, 1, slices);
     }
 }
 
@@ -171,10 +183,7 @@ __global__ __launch_bounds__(1024) void reduce_slices_wide_kernel(const float *_
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-    float s = 0.0f;
-    if (i < n)
-        for (int z = w; z < slices; z += 16) s += partial[(int64_t)z * n + i];
-    red[w][lane] = s;
+    red[w][lane] = i < n ? sum_slices(partial, n, i, w, 16, slices) : 0.0f;
     __syncthreads();
     if (w == 0 && i < n) {
         float t = red[0][lane];
@@ -198,17 +207,10 @@ __global__ __launch_bounds__(1024) void reduce_slices_pair_kernel(const float *_
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t i = (int64_t)(second ? blockIdx.x - g0 : blockIdx.x) * 64 + lane;
     if (!wide) {   // few slices: one serial sum per output (wave 0)
-        if (w == 0 && i < n) {
-            float s = 0.0f;
-            for (int z = 0; z < slices; ++z) s += partial[(int64_t)z * n + i];
-            out[i] = s;
-        }
+        if (w == 0 && i < n) out[i] = sum_slices(partial, n, i, 0, 1, slices);
         return;
     }
-    float s = 0.0f;
-    if (i < n)
-        for (int z = w; z < slices; z += 16) s += partial[(int64_t)z * n + i];
-    red[w][lane] = s;
+    red[w][lane] = i < n ? sum_slices(partial, n, i, w, 16, slices) : 0.0f;
     __syncthreads();
     if (w == 0 && i < n) {
         float t = red[0][lane];
@@ -279,9 +281,15 @@ __global__ void relu_mask_to_kernel(const float *__restrict__ dy, const float *_
 __global__ void sumsq_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
     __shared__ float red[4];
     float s = 0.0f;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x)
-        s += x[i] * x[i];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // (a thread's terms are added in index order; 8 of them are requested together: one round trip per 8 instead of per term)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += 8 * stride) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = i + u * stride < n ? x[i + u * stride] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (i + u * stride < n) s += v[u] * v[u];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -312,18 +320,19 @@ __global__ void ln_tanh_fwd_kernel(const float *__restrict__ x, int64_t ldx, con
 }
 
 // The same arithmetic (a row's two sums run serially over its features, in index order -> same bits) with everything
-// else taken off the serial chain: 64 rows per workgroup are staged in LDS with coalesced loads (row stride D + 1:
+// else taken off the serial chain: LN_ROWS rows per workgroup are staged in LDS with coalesced loads (row stride D + 1:
 // conflict-free row walks), 64 threads form the rows' mean / rstd, then all 256 threads normalise, apply tanh -- the
 // expensive part: one thread per row spent 50 serial tanhf per row -- and store, one element each at a time.
+constexpr int LN_ROWS = 16;   // rows per workgroup: the per-row sums are serial, everything around them scales with the rows (B 512: 32 workgroups)
 __global__ __launch_bounds__(256) void ln_tanh_fwd_lds_kernel(const float *__restrict__ x, int64_t ldx,
                                                               const float *__restrict__ gamma,
                                                               const float *__restrict__ beta, int n_rows, int D,
                                                               float *__restrict__ out, int64_t ldo,
                                                               float *__restrict__ xhat, float *__restrict__ rstd) {
-    extern __shared__ float lds[];   // xs[64][D + 1] | mean[64] | rs[64]
-    const int ld = D + 1, tid = threadIdx.x, r0 = blockIdx.x * 64;
-    const int rows = min(64, n_rows - r0);
-    float *xs = lds, *mean_s = lds + 64 * ld, *rs_s = mean_s + 64;
+    extern __shared__ float lds[];   // xs[LN_ROWS][D + 1] | mean[LN_ROWS] | rs[LN_ROWS]
+    const int ld = D + 1, tid = threadIdx.x, r0 = blockIdx.x * LN_ROWS;
+    const int rows = min(LN_ROWS, n_rows - r0);
+    float *xs = lds, *mean_s = lds + LN_ROWS * ld, *rs_s = mean_s + LN_ROWS;
     for (int i = tid; i < rows * D; i += 256) {
         const int r = i / D, j = i - r * D;
         xs[r * ld + j] = x[(int64_t)(r0 + r) * ldx + j];
@@ -512,9 +521,9 @@ extern "C" int ssac_ln_tanh_fwd(const float *x, int64_t ldx, const float *gamma,
                                 int n_rows, int dim, float *out, int64_t ldo, float *xhat, float *rstd,
                                 void *stream) {
     if (n_rows <= 0) return 0;
-    const size_t lds = sizeof(float) * (64 * (size_t)(dim + 1) + 128);
+    const size_t lds = sizeof(float) * (LN_ROWS * (size_t)(dim + 1) + 2 * LN_ROWS);
     if (lds <= 64 * 1024)
-        SSAC_LAUNCH(ln_tanh_fwd_lds_kernel, dim3((n_rows + 63) / 64), dim3(256), lds, ST, x, ldx, gamma, beta, n_rows, dim,
+        SSAC_LAUNCH(ln_tanh_fwd_lds_kernel, dim3((n_rows + LN_ROWS - 1) / LN_ROWS), dim3(256), lds, ST, x, ldx, gamma, beta, n_rows, dim,
                     out, ldo, xhat, rstd);
     else
         SSAC_LAUNCH(ln_tanh_fwd_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ST, x, ldx, gamma, beta,

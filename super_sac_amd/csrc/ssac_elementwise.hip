@@ -758,7 +758,14 @@ __global__ __launch_bounds__(256) void polyak_multi_kernel(PolyakSegs a, float t
         if ((n & 3) == 0 && (((uintptr_t)t | (uintptr_t)s) & 15) == 0) {
             float4 *t4 = reinterpret_cast<float4 *>(t);
             const float4 *s4 = reinterpret_cast<const float4 *>(s);
-            for (int64_t i = first; i < (n >> 2); i += stride) {
+            const int64_t n4 = n >> 2;
+            int64_t i = first;
+            for (; i + stride < n4; i += 2 * stride) {   // (two elements' loads in flight)
+                const float4 x0 = t4[i], y0 = s4[i], x1 = t4[i + stride], y1 = s4[i + stride];
+                t4[i] = make_float4(x0.x * k + y0.x * tau, x0.y * k + y0.y * tau, x0.z * k + y0.z * tau, x0.w * k + y0.w * tau);
+                t4[i + stride] = make_float4(x1.x * k + y1.x * tau, x1.y * k + y1.y * tau, x1.z * k + y1.z * tau, x1.w * k + y1.w * tau);
+            }
+            if (i < n4) {
                 const float4 x = t4[i], y = s4[i];
                 t4[i] = make_float4(x.x * k + y.x * tau, x.y * k + y.y * tau, x.z * k + y.z * tau, x.w * k + y.w * tau);
             }

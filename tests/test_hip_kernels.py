@@ -1018,6 +1018,35 @@ def test_slice_reduction_and_weight_permutation_are_exact(ssa):
         for z in range(slices):
             want = want + part[z]
         assert torch.equal(out[:, :N], want + bias), (slices, M, N)
+    def ordered(part):   # the documented order: < 64 slices one serial sum; else wave w takes w, w + 16, ..., then 0 .. 15
+        S = part.shape[0]
+        if S < 64:
+            t = torch.zeros_like(part[0])
+            for z in range(S):
+                t = t + part[z]
+            return t
+        waves = []
+        for w in range(16):
+            t = torch.zeros_like(part[0])
+            for z in range(w, S, 16):
+                t = t + part[z]
+            waves.append(t)
+        t = waves[0]
+        for w in range(1, 16):
+            t = t + waves[w]
+        return t
+    for slices, n0, n1 in ((3, 70, 5), (63, 1000, 32), (64, 129, 64), (250, 9216, 32), (701, 300, 7)):
+        p0, p1 = torch.randn(slices, n0, generator=g).to(DEV), torch.randn(slices, n1, generator=g).to(DEV)
+        o0, o1, o2 = torch.empty(n0, device=DEV), torch.empty(n1, device=DEV), torch.empty(n0, device=DEV)
+        ssa._lib.check(lib.ssac_reduce_slices_pair(p0.data_ptr(), n0, o0.data_ptr(), p1.data_ptr(), n1, o1.data_ptr(), slices, st))
+        ssa._lib.check(lib.ssac_reduce_slices(p0.data_ptr(), slices, n0, o2.data_ptr(), st))
+        assert torch.equal(o0, ordered(p0)) and torch.equal(o1, ordered(p1)) and torch.equal(o2, o0), (slices, n0, n1)
+    for n_el in (5, 65536 * 3 + 17, 2_000_003):
+        x = torch.randn(n_el, generator=g).to(DEV)
+        parts = torch.empty(int(lib.ssac_sumsq_blocks()), device=DEV)
+        ssa._lib.check(lib.ssac_sumsq(x.data_ptr(), n_el, parts.data_ptr(), st))
+        want = float((x.double() ** 2).sum())
+        assert abs(float(parts.double().sum()) - want) <= 2e-6 * want, n_el
     for n, C, P in ((50, 32, 1225), (3, 5, 7), (2, 33, 64), (1, 64, 31)):
         w = torch.randn(n, C, P, generator=g).to(DEV)
         cl = torch.full((n, P, C), float("nan"), device=DEV)

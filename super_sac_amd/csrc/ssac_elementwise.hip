@@ -973,10 +973,17 @@ __global__ __launch_bounds__(256) void drqv2_shift_plane_kernel(const T *__restr
     }
     if (sizeof(T) == 1 && (hh & 3) == 0 && ((uintptr_t)img & 3) == 0) {   // uint8 plane: four pixels per load
         const uint32_t *w = reinterpret_cast<const uint32_t *>(img);
-        for (int i = tid; i < (hh >> 2); i += 256) {
-            const uint32_t u = w[i];
-            *reinterpret_cast<float4 *>(pl + 4 * i) =
-                make_float4((float)(u & 255u), (float)((u >> 8) & 255u), (float)((u >> 16) & 255u), (float)(u >> 24));
+        const int nw = hh >> 2;
+        // (8 words per thread requested together: the plane arrives in one round trip, not one per 256 words)
+        for (int base = tid; base < nw; base += 8 * 256) {
+            uint32_t u[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) u[k] = base + k * 256 < nw ? w[base + k * 256] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (base + k * 256 < nw)
+                    *reinterpret_cast<float4 *>(pl + 4 * (base + k * 256)) =
+                        make_float4((float)(u[k] & 255u), (float)((u[k] >> 8) & 255u), (float)((u[k] >> 16) & 255u), (float)(u[k] >> 24));
         }
     } else {
         for (int i = tid; i < hh; i += 256) pl[i] = (float)img[i];
@@ -984,45 +991,46 @@ __global__ __launch_bounds__(256) void drqv2_shift_plane_kernel(const T *__restr
     if (tid < 2 * h) {
         const int ax = tid >= h, i = ax ? tid - h : tid;   // ax 0: x / columns, 1: y / rows
         const ShiftAxis sa = drqv2_shift_axis(i, shift[2 * b + ax], hp);
-        (ax ? w1y : w1x)[i] = sa.w1;
-        (ax ? w0y : w0x)[i] = sa.w0;
+        // a tap outside the padded image weighs 0 (grid_sample's zero padding): the mask goes into the axis weights --
+        // all weights are >= 0, so w * 0 = +0, the value the product is replaced by otherwise: the same bits
+        (ax ? w1y : w1x)[i] = (sa.p0 + 1 >= 0 && sa.p0 + 1 < hp) ? sa.w1 : 0.0f;
+        (ax ? w0y : w0x)[i] = (sa.p0 >= 0 && sa.p0 < hp) ? sa.w0 : 0.0f;
         (ax ? p0y : p0x)[i] = sa.p0;
     }
     __syncthreads();
-    // a thread owns output columns (their source columns, weights and validity stay in registers) and walks down the
-    // rows: no per-element index division, row terms are LDS broadcasts.  With h % 4 == 0 it owns FOUR adjacent
-    // columns and stores 16 bytes per row (256 / (h/4) rows of the plane per pass), else one column.
+    // a thread owns output columns (their source columns and weights stay in registers) and walks down the rows: no
+    // per-element index division, row terms are LDS broadcasts.  With h % 4 == 0 it owns FOUR adjacent columns and stores
+    // 16 bytes per row (256 / (h/4) rows of the plane per pass), else one column.  Two columns per packed fp32 operation
+    // (v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations per column, in the per-element kernel's order).
     if ((h & 3) == 0 && ((uintptr_t)out & 15) == 0) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
         const int tpr = h >> 2, rpp = 256 / tpr, ty = tid / tpr, tx4 = tid - ty * tpr;
         if (ty >= rpp) return;
-        float wx0[4], wx1[4];
+        f2 wxa[2], wxb[2];
         int sx0[4], sx1[4];
-        bool vx0[4], vx1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int x = 4 * tx4 + j, x0 = p0x[x];
-            wx0[j] = w0x[x]; wx1[j] = w1x[x];
-            vx0[j] = x0 >= 0 && x0 < hp; vx1[j] = x0 + 1 >= 0 && x0 + 1 < hp;
+            wxa[j >> 1][j & 1] = w0x[x]; wxb[j >> 1][j & 1] = w1x[x];
             sx0[j] = min(max(x0 - pad, 0), h - 1); sx1[j] = min(max(x0 + 1 - pad, 0), h - 1);   // replicate pad
         }
         for (int y = ty; y < h; y += rpp) {
             const int y0 = p0y[y];
-            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            f2 acc[2] = {f2{0.0f, 0.0f}, f2{0.0f, 0.0f}};
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy) {
-                const int yy = y0 + dy;
                 const float wy = dy ? w1y[y] : w0y[y];
-                const bool vy = yy >= 0 && yy < hp;
-                const float *row = pl + min(max(yy - pad, 0), h - 1) * h;
+                const float *row = pl + min(max(y0 + dy - pad, 0), h - 1) * h;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[j] = __fadd_rn(acc[j], __fmul_rn(row[sx0[j]], (vy && vx0[j]) ? __fmul_rn(wy, wx0[j]) : 0.0f));
-                    acc[j] = __fadd_rn(acc[j], __fmul_rn(row[sx1[j]], (vy && vx1[j]) ? __fmul_rn(wy, wx1[j]) : 0.0f));
+                for (int q = 0; q < 2; ++q) {
+                    const f2 pa = f2{row[sx0[2 * q]], row[sx0[2 * q + 1]]}, pb = f2{row[sx1[2 * q]], row[sx1[2 * q + 1]]};
+                    acc[q] = acc[q] + pa * (wxa[q] * wy);
+                    acc[q] = acc[q] + pb * (wxb[q] * wy);
                 }
             }
             *reinterpret_cast<float4 *>(out + y * h + 4 * tx4) =
-                make_float4(fminf(fmaxf(acc[0], 0.0f), 255.0f), fminf(fmaxf(acc[1], 0.0f), 255.0f),
-                            fminf(fmaxf(acc[2], 0.0f), 255.0f), fminf(fmaxf(acc[3], 0.0f), 255.0f));
+                make_float4(__builtin_amdgcn_fmed3f(acc[0][0], 0.0f, 255.0f), __builtin_amdgcn_fmed3f(acc[0][1], 0.0f, 255.0f),
+                            __builtin_amdgcn_fmed3f(acc[1][0], 0.0f, 255.0f), __builtin_amdgcn_fmed3f(acc[1][1], 0.0f, 255.0f));
         }
         return;
     }

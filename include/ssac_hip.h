@@ -868,6 +868,14 @@ int ssac_conv_first_fwd(const float *img, const float *w, const float *bias, flo
                         int co, int k, int s, float div, float shift, void *stream);
 int ssac_conv_first_wgrad(const float *dy, const float *img, float *partial_w, float *partial_b, int B, int C, int Hi,
                           int Wi, int co, int k, int s, float div, float shift, int pix_per_slice, void *stream);
+/* The same weight gradient with the image staged through LDS in bands of output rows (16-byte loads; the patch entries are
+ * LDS reads instead of global gathers); persistent workgroups, ONE partial (slice) per workgroup:
+ * ssac_conv_first_wgrad_band_slices returns that count (0: geometry not covered, use ssac_conv_first_wgrad); partial_w
+ * (slices, co, C, k, k) and partial_b (slices, co) are summed with ssac_reduce_slices(_pair) as before.  Same values up to
+ * the order of the sum over pixels. */
+int ssac_conv_first_wgrad_band_slices(int B, int C, int Hi, int Wi, int co, int k, int s);
+int ssac_conv_first_wgrad_band(const float *dy, const float *img, float *partial_w, float *partial_b, int B, int C, int Hi,
+                               int Wi, int co, int k, int s, float div, float shift, void *stream);
 /* The first layer with the DrQv2 random shift (augmentations.py:214-269: replicate pad + bilinear grid shift) applied in
  * its operand staging: replaces ssac_drq_shift(mode 0, uint8 source, gathered through idx) + ssac_conv_first_fwd for a
  * batch whose shifted image nobody else needs (the target encoder's s'; the online encoder's forward) -- the fp32 image

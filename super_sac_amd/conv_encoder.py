@@ -31,6 +31,7 @@ IMPLICIT_WG_PER_CU = 2           # weight-gradient workgroups per CU (248 VGPRs:
 IMPLICIT_WG_BIG_ROWS = 300_000   # ... and ONE from this many output pixels on (measured: DMC 3.31 -> 3.25 ms; fewer,
                                  # longer slices amortise the cross-wave sum and the partial-slice traffic)
 FIRST_WG_PER_CU = 2              # (measured 2 / 3 / 4 / 6: Atari 1.57 / 1.59 / 1.61 / 1.61 ms)
+FIRST_WGRAD_BANDS = True         # conv1's weight gradient with the image staged through LDS where covered (DMC: 116 -> 86 us)
 FC_SLICES = 48  # K slices of the fc forward (8 row tiles x 48 slices ~ 1.5 workgroups per CU at B 512)
 ROWS_PER_SLICE = 4096  # split-K granularity of the convolution weight gradients
 
@@ -252,9 +253,15 @@ class ConvEncoderEngine:
             else:
                 rps = ROWS_PER_SLICE
             slices = (rows + rps - 1) // rps
+            band_slices = int(lib.ssac_conv_first_wgrad_band_slices(B, ci, Hi, Wi, co, k, s)) if first and FIRST_WGRAD_BANDS else 0
+            if band_slices:   # (the image staged through LDS in bands of output rows: one partial per persistent workgroup)
+                slices = band_slices
             pw = self.ws.get("b.pw", (slices * co * ckk,))
             pb = self.ws.get("b.pb", (slices * co,))
-            if first:
+            if band_slices:
+                check(lib.ssac_conv_first_wgrad_band(dy.data_ptr(), sv["img"].data_ptr(), pw.data_ptr(), pb.data_ptr(), B, ci,
+                                                     Hi, Wi, co, k, s, self.div, self.shift, st))
+            elif first:
                 check(lib.ssac_conv_first_wgrad(dy.data_ptr(), sv["img"].data_ptr(), pw.data_ptr(), pb.data_ptr(), B, ci,
                                                 Hi, Wi, co, k, s, self.div, self.shift, rps, st))
             elif self.implicit[l]:

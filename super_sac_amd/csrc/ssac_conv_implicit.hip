@@ -964,6 +964,137 @@ __global__ __launch_bounds__(CV_THREADS) void conv_first_wgrad_kernel(FirstArgs 
     }
 }
 
+// The same weight gradient with the image operand staged through LDS.  conv_first_wgrad_kernel gathers its B operand from
+// global memory -- per MFMA 64 scattered dwords (lane = patch entry (c, ky, kx), 3 / 8 consecutive floats per (c, ky) row):
+// 48 (DMC) / 128 (Atari) gather instructions per 32-pixel chunk through the texture path.  Here a workgroup takes (image b,
+// band of R output rows) items: it copies the band's input rows (C x Rin x Wi fp32, contiguous per channel) into LDS with
+// 16-byte loads and reads the patch entries from there (ds_read_b32, 2-way conflicts at worst).  Persistent workgroups
+// accumulate over their items; one partial (= slice) per workgroup.  Summation order over pixels differs from the gather
+// form's (rounding only).
+template <int NB>
+__global__ __launch_bounds__(CV_THREADS) void conv_first_wgrad_band_kernel(FirstArgs g, int R, int n_items, float *partial_w,
+                                                                           float *partial_b) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // band [C][Rin][Wi]; after the items: red [NB][16][64] + [64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int kk = g.k * g.k, ckk = g.C * kk, HW = g.Hi * g.Wi;
+    const int Rin = (R - 1) * g.s + g.k, plane = Rin * g.Wi;
+    const int co0 = blockIdx.y * 32;
+    int noff[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = nb * 32 + li;
+        const int c = n / kk, rem = n - c * kk, ky = rem / g.k, kx = rem - ky * g.k;
+        noff[nb] = n < ckk ? c * plane + ky * g.Wi + kx : 0;
+    }
+    f32x16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][i] = 0.0f;
+    float bsum = 0.0f;
+    const f4 *img4 = reinterpret_cast<const f4 *>(g.img);
+    f4 *lds4 = reinterpret_cast<f4 *>(lds);
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        // item -> (image, band): the band index changes slowest, so a persistent workgroup meets every band height
+        const int bi = item / g.B, b = item - bi * g.B;
+        const int oy0 = bi * R, rows = min(R, g.Ho - oy0);
+        const int iy0 = oy0 * g.s, rin = (rows - 1) * g.s + g.k;
+        const int per_c = (rin * g.Wi) >> 2, total = g.C * per_c;
+        __syncthreads();   // (the previous item's chunks have read the band)
+        for (int base = tid; base < total; base += 4 * CV_THREADS) {   // four 16-byte loads in flight per thread
+            f4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * CV_THREADS;
+                if (i < total) {
+                    const int c = i / per_c, rem = i - c * per_c;
+                    v[u] = img4[(((int64_t)b * g.C + c) * HW + iy0 * g.Wi) / 4 + rem];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * CV_THREADS;
+                if (i < total) {
+                    const int c = i / per_c, rem = i - c * per_c;
+                    lds4[(c * plane) / 4 + rem] = v[u];
+                }
+            }
+        }
+        __syncthreads();
+        const int npix = rows * g.Wo, nchunks = (npix + 31) >> 5;
+        const int64_t mbase = ((int64_t)b * g.Ho + oy0) * g.Wo;
+        for (int ch = wave; ch < nchunks; ch += 4) {
+            float av[16];
+            int xo[16];
+            {
+                const int p_first = ch * 32 + lh, pf = p_first < npix ? p_first : 0;
+                int r = pf / g.Wo, ox = pf - r * g.Wo;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int p = p_first + 2 * t;
+                    const bool ok = p < npix;
+                    const float d = g.dy[(mbase + (ok ? p : 0)) * g.co + co0 + li];
+                    av[t] = ok ? d : 0.0f;
+                    xo[t] = ok ? (r * g.s) * g.Wi + ox * g.s : 0;
+                    ox += 2;
+                    if (ox >= g.Wo) { ox -= g.Wo; ++r; }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) bsum += av[t];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], lds[xo[t] + noff[nb]], acc[nb], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();   // the band is dead: its LDS carries the waves' partial sums now
+    float *red = lds;
+    bsum += __shfl_xor(bsum, 32, 64);
+    float *bred = red + NB * 16 * 64;
+    // fixed-order sum over the waves: 3 -> 2 -> 1 -> 0
+    for (int w = 3; w >= 1; --w) {
+        if (wave == w) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(nb * 16 + r) * 64 + lane] = acc[nb][r];
+            if (lh == 0) bred[li] = bsum;
+        }
+        __syncthreads();
+        if (wave == w - 1) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nb][r] += red[(nb * 16 + r) * 64 + lane];
+            bsum += bred[li];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        float *pw = partial_w + (int64_t)blockIdx.x * g.co * ckk;   // partial_w[slice][co][c][ky][kx]
+        float brow[16];  // sum of dy over the slice for the output channel of accumulator row r
+#pragma unroll
+        for (int r = 0; r < 16; ++r) brow[r] = __shfl(bsum, (r & 3) + 8 * (r >> 2) + 4 * lh, 64);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int n = nb * 32 + li;
+            if (n < ckk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // sum dy (x/div + shift) = (sum dy x) / div + shift sum dy   (the raw image went through the MFMAs)
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    pw[(int64_t)(co0 + row) * ckk + n] = acc[nb][r] / g.div + g.shift * brow[r];
+                }
+            }
+        }
+        if (lh == 0) partial_b[(int64_t)blockIdx.x * g.co + co0 + li] = bsum;
+    }
+}
+
 // taps per lane half of the first-layer kernels for this geometry, 0 = stays on im2col
 int first_kh(int C, int co, int k, int s, int Hi, int Wi, int64_t B) {
     if (co % 32 || k < 1 || s < 1 || Hi < k || Wi < k || C * k * k > 8 * 32) return 0;
@@ -1243,6 +1374,72 @@ extern "C" int ssac_conv_first_fwd(const float *img, const float *w, const float
     else
         SSAC_LAUNCH(conv_first_fwd_kernel<4>, dim3(gx, co / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, n_tiles);
     return ssac_check_launch("conv_first_fwd");
+}
+
+// ---- the LDS-staged first-layer weight gradient: band height R and the number of persistent workgroups (= slices)
+static int first_band_rows(int C, int co, int k, int s, int Hi, int Wi, int64_t B, int *slices_out) {
+    if (!first_kh(C, co, k, s, Hi, Wi, B) || (Wi & 3) || ((Hi * Wi) & 3)) return 0;
+    const int Ho = (Hi - k) / s + 1, Wo = (Wi - k) / s + 1, nb = (C * k * k + 31) / 32;
+    // more than 4 patch blocks (Atari's 8 x 8 x 4 patch: 8): 300 registers per lane leave one workgroup per CU, and cutting the
+    // blocks over two workgroups stages every band twice -- measured 137.9 us against the gather form's 124.2: not covered
+    if (nb > 4) return 0;
+    const size_t red = sizeof(float) * ((size_t)nb * 16 * 64 + 64);
+    int best = 0;
+    double best_cost = 0.0;
+    for (int R = 1; R <= Ho; ++R) {
+        const int Rin = (R - 1) * s + k;
+        if (sizeof(float) * (size_t)C * Rin * Wi > 48 * 1024) break;
+        double cost = 0.0;
+        for (int oy0 = 0; oy0 < Ho; oy0 += R) {   // MFMA rounds of the four waves + the band's rows (clocks, roughly)
+            const int rows = R < Ho - oy0 ? R : Ho - oy0, nch = (rows * Wo + 31) / 32;
+            cost += (double)((nch + 3) / 4) * (nb * 16 * 64 + 400) + (double)((rows - 1) * s + k) * (C * Wi * 0.25) + 1500.0;
+        }
+        if (!best || cost <= best_cost) { best = R; best_cost = cost; }
+    }
+    if (best && slices_out) {
+        const size_t band = sizeof(float) * (size_t)C * ((best - 1) * s + k) * Wi, lds = band > red ? band : red;
+        int per_cu = (int)((160 * 1024) / lds);
+        const int by_regs = nb <= 1 ? 6 : nb == 2 ? 4 : nb == 3 ? 3 : 2;   // (76 + 32 NB registers per lane, measured)
+        per_cu = per_cu < by_regs ? per_cu : by_regs;
+        if (per_cu < 1) per_cu = 1;
+        const int64_t n_items = B * ((Ho + best - 1) / best);
+        const int64_t cap = 256 * per_cu / (co / 32) > 0 ? 256 * per_cu / (co / 32) : 1;
+        *slices_out = (int)(n_items < cap ? n_items : cap);
+    }
+    return best;
+}
+
+extern "C" int ssac_conv_first_wgrad_band_slices(int B, int C, int Hi, int Wi, int co, int k, int s) {
+    int slices = 0;
+    return first_band_rows(C, co, k, s, Hi, Wi, B, &slices) ? slices : 0;
+}
+
+extern "C" int ssac_conv_first_wgrad_band(const float *dy, const float *img, float *partial_w, float *partial_b, int B, int C,
+                                          int Hi, int Wi, int co, int k, int s, float div, float shift, void *stream) {
+    int slices = 0;
+    const int R = first_band_rows(C, co, k, s, Hi, Wi, B, &slices);
+    if (!R) return ssac_fail("ssac_conv_first_wgrad_band: geometry not supported (see ssac_conv_first_wgrad_band_slices)");
+    if ((uintptr_t)img & 15) return ssac_fail("ssac_conv_first_wgrad_band: image must be 16-byte aligned");
+    FirstArgs g{};
+    g.img = img; g.dy = dy; g.div = div; g.shift = shift;
+    g.B = B; g.C = C; g.Hi = Hi; g.Wi = Wi; g.co = co; g.k = k; g.s = s;
+    g.Ho = (Hi - k) / s + 1; g.Wo = (Wi - k) / s + 1;
+    const int nb = (C * k * k + 31) / 32;
+    const size_t band = sizeof(float) * (size_t)C * ((R - 1) * s + k) * Wi, red = sizeof(float) * ((size_t)nb * 16 * 64 + 64);
+    const size_t lds = band > red ? band : red;
+    const int n_items = B * ((g.Ho + R - 1) / R);
+    const dim3 grid(slices, co / 32), block(CV_THREADS);
+#define SSAC_FIRST_WGRAD_BAND(NB) \
+    case NB: { \
+        static bool attr##NB = false; \
+        if (!attr##NB) { (void)hipFuncSetAttribute((const void *)conv_first_wgrad_band_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr##NB = true; } \
+        SSAC_LAUNCH(conv_first_wgrad_band_kernel<NB>, grid, block, lds, (hipStream_t)stream, g, R, n_items, partial_w, partial_b); } break;
+    switch (nb) {
+        SSAC_FIRST_WGRAD_BAND(1) SSAC_FIRST_WGRAD_BAND(2) SSAC_FIRST_WGRAD_BAND(3) SSAC_FIRST_WGRAD_BAND(4)
+        default: return ssac_fail("ssac_conv_first_wgrad_band: patch too large");
+    }
+#undef SSAC_FIRST_WGRAD_BAND
+    return ssac_check_launch("conv_first_wgrad_band");
 }
 
 // rows per band of the shift-fused first layer for this geometry (0: stays on the two-launch form).  One workgroup per CU

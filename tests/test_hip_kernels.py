@@ -964,6 +964,17 @@ def test_first_layer_implicit_convolution_matches_torch_conv2d(ssa, B, C, co, k,
     scale = float(wr.grad.abs().max())
     _close(pw.sum(0), wr.grad, 2e-5 * max(1.0, scale), rtol=1e-4, what="first-layer weight gradient")
     _close(pb.sum(0), br.grad, 2e-4, rtol=1e-4, what="first-layer bias gradient")
+    # the LDS-staged form (bands of output rows, one partial per persistent workgroup)
+    slices = int(lib.ssac_conv_first_wgrad_band_slices(B, C, H, H, co, k, s))
+    assert (slices > 0) == (C * k * k <= 128)   # (more than 4 patch blocks of 32 stay on the gather form)
+    if slices == 0:
+        return
+    pw = torch.full((slices, co, C, k, k), float("nan"), device=DEV)
+    pb = torch.full((slices, co), float("nan"), device=DEV)
+    ssa._lib.check(lib.ssac_conv_first_wgrad_band(dzd.data_ptr(), xd.data_ptr(), pw.data_ptr(), pb.data_ptr(), B, C, H, H, co,
+                                                  k, s, div, shift, st))
+    _close(pw.sum(0), wr.grad, 2e-5 * max(1.0, scale), rtol=1e-4, what="first-layer weight gradient (LDS bands)")
+    _close(pb.sum(0), br.grad, 2e-4, rtol=1e-4, what="first-layer bias gradient (LDS bands)")
 
 
 @pytest.mark.parametrize("B,C,co,k,s,H,pad,div,shift", [(37, 9, 32, 3, 2, 84, 4, 255.0, -0.5), (21, 4, 32, 8, 4, 84, 4, 255.0, 0.0),

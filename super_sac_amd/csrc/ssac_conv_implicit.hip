@@ -971,6 +971,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_first_wgrad_kernel(FirstArgs 
 // 16-byte loads and reads the patch entries from there (ds_read_b32, 2-way conflicts at worst).  Persistent workgroups
 // accumulate over their items; one partial (= slice) per workgroup.  Summation order over pixels differs from the gather
 // form's (rounding only).
+constexpr int BAND_LOADS = 10;   // 16-byte loads a thread keeps in flight while staging a band (DMC: 2457 per band / 256 threads)
 template <int NB>
 __global__ __launch_bounds__(CV_THREADS) void conv_first_wgrad_band_kernel(FirstArgs g, int R, int n_items, float *partial_w,
                                                                            float *partial_b) {
@@ -1002,10 +1003,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv_first_wgrad_band_kernel(First
         const int iy0 = oy0 * g.s, rin = (rows - 1) * g.s + g.k;
         const int per_c = (rin * g.Wi) >> 2, total = g.C * per_c;
         __syncthreads();   // (the previous item's chunks have read the band)
-        for (int base = tid; base < total; base += 4 * CV_THREADS) {   // four 16-byte loads in flight per thread
-            f4 v[4];
+        for (int base = tid; base < total; base += BAND_LOADS * CV_THREADS) {   // the band in (mostly) one round trip
+            f4 v[BAND_LOADS];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < BAND_LOADS; ++u) {
                 const int i = base + u * CV_THREADS;
                 if (i < total) {
                     const int c = i / per_c, rem = i - c * per_c;
@@ -1013,7 +1014,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_first_wgrad_band_kernel(First
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < BAND_LOADS; ++u) {
                 const int i = base + u * CV_THREADS;
                 if (i < total) {
                     const int c = i / per_c, rem = i - c * per_c;
@@ -1399,7 +1400,7 @@ static int first_band_rows(int C, int co, int k, int s, int Hi, int Wi, int64_t 
     if (best && slices_out) {
         const size_t band = sizeof(float) * (size_t)C * ((best - 1) * s + k) * Wi, lds = band > red ? band : red;
         int per_cu = (int)((160 * 1024) / lds);
-        const int by_regs = nb <= 1 ? 6 : nb == 2 ? 4 : nb == 3 ? 3 : 2;   // (76 + 32 NB registers per lane, measured)
+        const int by_regs = nb <= 1 ? 4 : nb <= 3 ? 3 : 2;   // (116 / 160 / 148 / 172 registers per lane for 1 .. 4 blocks)
         per_cu = per_cu < by_regs ? per_cu : by_regs;
         if (per_cu < 1) per_cu = 1;
         const int64_t n_items = B * ((Ho + best - 1) / best);

@@ -971,9 +971,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv_first_wgrad_kernel(FirstArgs 
 // 16-byte loads and reads the patch entries from there (ds_read_b32, 2-way conflicts at worst).  Persistent workgroups
 // accumulate over their items; one partial (= slice) per workgroup.  Summation order over pixels differs from the gather
 // form's (rounding only).
-constexpr int BAND_LOADS = 10;   // 16-byte loads a thread keeps in flight while staging a band (DMC: 2457 per band / 256 threads)
+// 16-byte loads a thread keeps in flight while staging a band (DMC: 2457 per band / 256 threads); 5 .. 8 patch blocks hold
+// 80 .. 128 accumulator registers per lane: fewer loads in flight there, and two waves per SIMD asked of the compiler
 template <int NB>
-__global__ __launch_bounds__(CV_THREADS) void conv_first_wgrad_band_kernel(FirstArgs g, int R, int n_items, float *partial_w,
+__global__ __launch_bounds__(CV_THREADS, NB > 4 ? 2 : 1) void conv_first_wgrad_band_kernel(FirstArgs g, int R, int n_items, float *partial_w,
                                                                            float *partial_b) {
     extern __shared__ __attribute__((aligned(16))) float lds[];  // band [C][Rin][Wi]; after the items: red [NB][16][64] + [64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -996,6 +997,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_first_wgrad_band_kernel(First
     float bsum = 0.0f;
     const f4 *img4 = reinterpret_cast<const f4 *>(g.img);
     f4 *lds4 = reinterpret_cast<f4 *>(lds);
+    constexpr int BAND_LOADS = NB > 4 ? 4 : 10;
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         // item -> (image, band): the band index changes slowest, so a persistent workgroup meets every band height
         const int bi = item / g.B, b = item - bi * g.B;
@@ -1381,9 +1383,7 @@ extern "C" int ssac_conv_first_fwd(const float *img, const float *w, const float
 static int first_band_rows(int C, int co, int k, int s, int Hi, int Wi, int64_t B, int *slices_out) {
     if (!first_kh(C, co, k, s, Hi, Wi, B) || (Wi & 3) || ((Hi * Wi) & 3)) return 0;
     const int Ho = (Hi - k) / s + 1, Wo = (Wi - k) / s + 1, nb = (C * k * k + 31) / 32;
-    // more than 4 patch blocks (Atari's 8 x 8 x 4 patch: 8): 300 registers per lane leave one workgroup per CU, and cutting the
-    // blocks over two workgroups stages every band twice -- measured 137.9 us against the gather form's 124.2: not covered
-    if (nb > 4) return 0;
+    if (nb > 8) return 0;
     const size_t red = sizeof(float) * ((size_t)nb * 16 * 64 + 64);
     int best = 0;
     double best_cost = 0.0;
@@ -1400,7 +1400,7 @@ static int first_band_rows(int C, int co, int k, int s, int Hi, int Wi, int64_t 
     if (best && slices_out) {
         const size_t band = sizeof(float) * (size_t)C * ((best - 1) * s + k) * Wi, lds = band > red ? band : red;
         int per_cu = (int)((160 * 1024) / lds);
-        const int by_regs = nb <= 1 ? 4 : nb <= 3 ? 3 : 2;   // (116 / 160 / 148 / 172 registers per lane for 1 .. 4 blocks)
+        const int by_regs = nb <= 1 ? 4 : nb <= 3 ? 3 : 2;   // (116 / 160 / 148 / 172 registers per lane for 1 .. 4 blocks; <= 256 asked for 5 .. 8)
         per_cu = per_cu < by_regs ? per_cu : by_regs;
         if (per_cu < 1) per_cu = 1;
         const int64_t n_items = B * ((Ho + best - 1) / best);
@@ -1437,6 +1437,7 @@ extern "C" int ssac_conv_first_wgrad_band(const float *dy, const float *img, flo
         SSAC_LAUNCH(conv_first_wgrad_band_kernel<NB>, grid, block, lds, (hipStream_t)stream, g, R, n_items, partial_w, partial_b); } break;
     switch (nb) {
         SSAC_FIRST_WGRAD_BAND(1) SSAC_FIRST_WGRAD_BAND(2) SSAC_FIRST_WGRAD_BAND(3) SSAC_FIRST_WGRAD_BAND(4)
+        SSAC_FIRST_WGRAD_BAND(5) SSAC_FIRST_WGRAD_BAND(6) SSAC_FIRST_WGRAD_BAND(7) SSAC_FIRST_WGRAD_BAND(8)
         default: return ssac_fail("ssac_conv_first_wgrad_band: patch too large");
     }
 #undef SSAC_FIRST_WGRAD_BAND

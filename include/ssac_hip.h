@@ -854,6 +854,13 @@ int ssac_conv_dgrad(const float *dy, const float *w, const float *x_mask, float 
 int ssac_conv_wgrad_slices(int B, int Ho, int Wo, int pix_per_slice);
 int ssac_conv_wgrad(const float *dy, const float *x, float *partial_w, float *partial_b, int B, int Hi, int Wi,
                     int ci, int co, int k, int s, int pix_per_slice, void *stream);
+/* The weight gradient of a layer with SMALL feature maps (an image's 32-channel slices of x and dy fit LDS twice per CU;
+ * k k <= 16): both operands staged in LDS per image, persistent workgroups, ONE partial (slice) per workgroup and
+ * (ci / 32, co / 32) block pair.  ssac_conv_wgrad_img_slices returns that count (0: use ssac_conv_wgrad); partial_w
+ * (slices, co, ci, k, k), partial_b (slices, co) as ssac_conv_wgrad.  Same values up to the order of the sum over pixels. */
+int ssac_conv_wgrad_img_slices(int B, int Hi, int Wi, int ci, int co, int k, int s);
+int ssac_conv_wgrad_img(const float *dy, const float *x, float *partial_w, float *partial_b, int B, int Hi, int Wi, int ci,
+                        int co, int k, int s, void *stream);
 /* ---- the FIRST layer as an implicit GEMM too (cnns.py:41/76 conv1 with the x/div + shift input normalisation of
  * cnns.py:58/95 in front): fp32 NCHW image (B, C, Hi, Wi) of raw pixel values, nn.Conv2d weight (co, C, k, k),
  * channels-last output.  ssac_conv_first_supported returns the taps per lane half (2 or 4) when the geometry is

@@ -177,6 +177,8 @@ SIGNATURES = {
     "ssac_conv_first_supported": [_I, _I, _I, _I, _I, _I, _L],
     "ssac_conv_first_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P],
     "ssac_conv_first_wgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
+    "ssac_conv_wgrad_img_slices": [_I, _I, _I, _I, _I, _I, _I],
+    "ssac_conv_wgrad_img": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ssac_conv_first_wgrad_band_slices": [_I, _I, _I, _I, _I, _I, _I],
     "ssac_conv_first_wgrad_band": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P],
     "ssac_conv_first_shift_supported": [_I, _I, _I, _I, _I, _L, _I],

@@ -32,6 +32,7 @@ IMPLICIT_WG_BIG_ROWS = 300_000   # ... and ONE from this many output pixels on (
                                  # longer slices amortise the cross-wave sum and the partial-slice traffic)
 FIRST_WG_PER_CU = 2              # (measured 2 / 3 / 4 / 6: Atari 1.57 / 1.59 / 1.61 / 1.61 ms)
 FIRST_WGRAD_BANDS = True         # conv1's weight gradient with the image staged through LDS where covered (DMC: 116 -> 86 us)
+WGRAD_WHOLE_IMAGES = True        # weight gradients of layers with small feature maps: x and dy of an image staged in LDS
 FC_SLICES = 48  # K slices of the fc forward (8 row tiles x 48 slices ~ 1.5 workgroups per CU at B 512)
 ROWS_PER_SLICE = 4096  # split-K granularity of the convolution weight gradients
 
@@ -256,6 +257,10 @@ class ConvEncoderEngine:
             band_slices = int(lib.ssac_conv_first_wgrad_band_slices(B, ci, Hi, Wi, co, k, s)) if first and FIRST_WGRAD_BANDS else 0
             if band_slices:   # (the image staged through LDS in bands of output rows: one partial per persistent workgroup)
                 slices = band_slices
+            img_slices = (int(lib.ssac_conv_wgrad_img_slices(B, Hi, Wi, ci, co, k, s))
+                          if (not first and self.implicit[l] and WGRAD_WHOLE_IMAGES) else 0)
+            if img_slices:    # (small feature maps: both operands of an image staged in LDS, one partial per workgroup)
+                slices = img_slices
             pw = self.ws.get("b.pw", (slices * co * ckk,))
             pb = self.ws.get("b.pb", (slices * co,))
             if band_slices:
@@ -264,6 +269,9 @@ class ConvEncoderEngine:
             elif first:
                 check(lib.ssac_conv_first_wgrad(dy.data_ptr(), sv["img"].data_ptr(), pw.data_ptr(), pb.data_ptr(), B, ci,
                                                 Hi, Wi, co, k, s, self.div, self.shift, rps, st))
+            elif img_slices:
+                check(lib.ssac_conv_wgrad_img(dy.data_ptr(), sv["ys"][l - 1].data_ptr(), pw.data_ptr(), pb.data_ptr(), B, Hi,
+                                              Wi, ci, co, k, s, st))
             elif self.implicit[l]:
                 x_in = sv["ys"][l - 1]  # this layer's input = previous layer's ReLU output, channels-last
                 check(lib.ssac_conv_wgrad(dy.data_ptr(), x_in.data_ptr(), pw.data_ptr(), pb.data_ptr(), B, Hi, Wi,

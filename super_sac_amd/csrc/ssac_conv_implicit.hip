@@ -407,6 +407,41 @@ __global__ __launch_bounds__(CV_THREADS) void conv_dgrad_strided_kernel(ConvArgs
 // ---------------------------------------------------------------------------------------------
 constexpr int WG_MAX_TAPS = 4;  // taps per wave held in registers (k*k <= 16)
 
+// A workgroup's (32 co x 32 c x k k) block of partial_w[slice][co][c][ky][kx] leaves through LDS: in the accumulators a
+// lane holds (co row, c = lane, ONE tap) -- stored directly, consecutive lanes are k k floats apart (a 64-byte stride at
+// 4 x 4: every store instruction touched 64 different segments, the epilogue of a 256-slice launch cost ~45 us).  Staged
+// as [16 co rows][32 c][k k + 1] (odd row length: conflict-free) a co row's 32 k k floats are one contiguous run in
+// global memory; two halves of 16 rows.  tap_of(j) = the tap of accumulator j of this wave (>= k k: none).
+template <int NACC, typename TapOf>
+__device__ __forceinline__ void wgrad_store_block(float *stage, const f32x16 (&acc)[NACC], TapOf tap_of, int kk, float *pw,
+                                                  int ci_total, int c0, int co0) {
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int ldk = kk + 1, row_floats = 32 * kk;
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();   // (the staging area is free: the main loop / the previous half is done with it)
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) {
+            const int tap = tap_of(j);
+            if (tap < kk) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int rr = 8 * h + r;   // accumulator rows of this half: co rows 16 h .. 16 h + 15
+                    const int row = (rr & 3) + 8 * ((rr >> 2) & 1) + 4 * lh;
+                    stage[(row * 32 + li) * ldk + tap] = acc[j][rr];
+                }
+            }
+        }
+        __syncthreads();
+        for (int row = 0; row < 16; ++row) {   // (per co row one contiguous run of 32 k k floats; no division by row length)
+            float *dst = pw + ((int64_t)(co0 + 16 * h + row) * ci_total + c0) * kk;
+            for (int rem = tid; rem < row_floats; rem += CV_THREADS) {
+                const int c = kk == 16 ? rem >> 4 : kk == 9 ? rem / 9 : kk == 4 ? rem >> 2 : rem / kk;
+                dst[rem] = stage[(row * 32 + c) * ldk + rem - c * kk];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(CV_THREADS) void conv_wgrad_kernel(ConvArgs g, int64_t pix_per_slice, float *partial_w,
                                                                 float *partial_b) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -471,6 +506,103 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad_kernel(ConvArgs g, int6
         }
     }
     if (wave == 0 && blockIdx.y == 0) {  // bias gradient: column sums of dy over this slice
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (lh == 0) partial_b[(int64_t)blockIdx.x * g.co + co0 + li] = bsum;
+    }
+}
+
+// The same weight gradient for SMALL feature maps (Atari's 20 x 20 and 9 x 9 layers): conv_wgrad_kernel issues 16 + 16 taps
+// global loads per 32-pixel chunk and wave -- every wave re-reads dy, every tap re-reads x -- and runs at ~0.28 of the
+// matrix peak.  Here a workgroup takes whole images: the image's 32-channel slice of x (Hi Wi x 32 floats, channels-last)
+// and its 32-channel slice of dy (zero rows behind the last pixel) are staged in LDS once with 16-byte loads, and both
+// MFMA operands are ds_read_b32 (lane = channel: consecutive dwords, conflict-free).  Wave w still takes the taps
+// w, w + 4, ...; persistent workgroups accumulate over their images, one partial (= slice) per workgroup.
+constexpr int WI_NX = 13, WI_ND = 4;   // 16-byte words of x / dy a thread carries for the next image (Hi Wi <= 416, Ho Wo <= 128)
+__global__ __launch_bounds__(CV_THREADS, 2) void conv_wgrad_img_kernel(ConvArgs g, float *partial_w, float *partial_b) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // xs [Hi Wi][32] | dys [chunks * 32][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int kk = g.k * g.k, HWi = g.Hi * g.Wi, npix = g.Ho * g.Wo, nch = (npix + 31) >> 5;
+    const int c0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
+    float *xs = lds, *dys = lds + HWi * 32;
+    f4 *xs4 = reinterpret_cast<f4 *>(xs), *dys4 = reinterpret_cast<f4 *>(dys);
+    int toff[WG_MAX_TAPS];
+#pragma unroll
+    for (int j = 0; j < WG_MAX_TAPS; ++j) {
+        const int tap = wave + 4 * j, ky = tap / g.k, kx = tap - ky * g.k;
+        toff[j] = tap < kk ? (ky * g.Wi + kx) * 32 + li : li;
+    }
+    f32x16 acc[WG_MAX_TAPS];
+#pragma unroll
+    for (int j = 0; j < WG_MAX_TAPS; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.0f;
+    float bsum = 0.0f;
+    // the NEXT image's tiles are requested (registers) before this image's chunks and written to LDS after them: the
+    // round trip hides under the MFMAs (two co-resident workgroups run in lockstep: they do not hide it for each other)
+    f4 xr[WI_NX], dr[WI_ND];
+    auto request = [&](int b) {
+        const float *xb = g.x + (int64_t)b * HWi * g.ci + c0;
+        const float *db = g.dy + (int64_t)b * npix * g.co + co0;
+#pragma unroll
+        for (int u = 0; u < WI_NX; ++u) {
+            const int i = tid + u * CV_THREADS;
+            if (i < HWi * 8) xr[u] = *reinterpret_cast<const f4 *>(xb + (int64_t)(i >> 3) * g.ci + 4 * (i & 7));
+        }
+#pragma unroll
+        for (int u = 0; u < WI_ND; ++u) {
+            const int i = tid + u * CV_THREADS;
+            dr[u] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (i < npix * 8) dr[u] = *reinterpret_cast<const f4 *>(db + (int64_t)(i >> 3) * g.co + 4 * (i & 7));
+        }
+    };
+    if ((int)blockIdx.x < g.B) request(blockIdx.x);
+    for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();   // (the previous image's chunks have read the tiles)
+#pragma unroll
+        for (int u = 0; u < WI_NX; ++u) {
+            const int i = tid + u * CV_THREADS;
+            if (i < HWi * 8) xs4[i] = xr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < WI_ND; ++u) {
+            const int i = tid + u * CV_THREADS;
+            if (i < nch * 32 * 8) dys4[i] = dr[u];
+        }
+        __syncthreads();
+        if (b + (int)gridDim.x < g.B) request(b + gridDim.x);
+        for (int ch = 0; ch < nch; ++ch) {
+            float av[16];
+            int xo[16];
+            {
+                const int p0 = ch * 32 + 16 * lh, pf = p0 < npix ? p0 : 0;
+                int oy = pf / g.Wo, ox = pf - oy * g.Wo;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int p = p0 + t;
+                    av[t] = dys[p * 32 + li];   // (zero behind the last pixel)
+                    xo[t] = p < npix ? ((oy * g.s) * g.Wi + ox * g.s) * 32 : 0;
+                    if (++ox == g.Wo) { ox = 0; ++oy; }
+                }
+            }
+            if (wave == 0 && blockIdx.y == 0) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) bsum += av[t];
+            }
+#pragma unroll
+            for (int j = 0; j < WG_MAX_TAPS; ++j) {
+                if (wave + 4 * j < kk) {
+#pragma unroll
+                    for (int t = 0; t < 16; ++t)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], xs[xo[t] + toff[j]], acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partial_w[slice][co][c][ky][kx], through LDS (the tiles are dead)
+    wgrad_store_block<WG_MAX_TAPS>(lds, acc, [&](int j) { return wave + 4 * j; }, kk,
+                                   partial_w + (int64_t)blockIdx.x * g.co * g.ci * kk, g.ci, c0, co0);
+    if (wave == 0 && blockIdx.y == 0) {  // bias gradient: column sums of dy over this workgroup's images
         bsum += __shfl_xor(bsum, 32, 64);
         if (lh == 0) partial_b[(int64_t)blockIdx.x * g.co + co0 + li] = bsum;
     }
@@ -1215,20 +1347,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad_taps_kernel(ConvArgs g,
         }
         __syncthreads();
     }
-    if (wave == 0) {
-        float *pw = partial_w + (int64_t)blockIdx.x * g.co * g.ci * kk;   // partial_w[slice][co][c][ky][kx]
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            if (j < kk) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    pw[((int64_t)co * g.ci + c0 + li) * kk + j] = acc[j][r];
-                }
-            }
-        }
-        if (blockIdx.y == 0 && lh == 0) partial_b[(int64_t)blockIdx.x * g.co + co0 + li] = bsum;
-    }
+    // partial_w[slice][co][c][ky][kx]: wave 0 holds the sums; the block leaves through LDS in contiguous runs
+    wgrad_store_block<NT>(red, acc, [&](int j) { return wave == 0 ? j : kk; }, kk,
+                          partial_w + (int64_t)blockIdx.x * g.co * g.ci * kk, g.ci, c0, co0);
+    if (wave == 0 && blockIdx.y == 0 && lh == 0) partial_b[(int64_t)blockIdx.x * g.co + co0 + li] = bsum;
 }
 
 // persistent workgroups per CU: as many as the weight tile in LDS allows, at most 3 (three waves per SIMD hide the
@@ -1324,6 +1446,46 @@ extern "C" int ssac_conv_dgrad(const float *dy, const float *w, const float *x_m
 extern "C" int ssac_conv_wgrad_slices(int B, int Ho, int Wo, int pix_per_slice) {
     const int64_t M = (int64_t)B * Ho * Wo;
     return (int)((M + pix_per_slice - 1) / pix_per_slice);
+}
+
+// the whole-image form: number of persistent workgroups per (ci / 32, co / 32) block pair = slices (0: not covered --
+// both tiles of an image must fit LDS twice per CU, at most 16 taps)
+static int wgrad_img_slices(int B, int Hi, int Wi, int ci, int co, int k, int s, size_t *lds_out) {
+    if (!conv_ok(ci, co, k) || k * k > 4 * WG_MAX_TAPS || s < 1 || Hi < k || Wi < k || (ci & 3) || (co & 3)) return 0;
+    const int Ho = (Hi - k) / s + 1, Wo = (Wi - k) / s + 1;
+    size_t lds = sizeof(float) * 32 * ((size_t)Hi * Wi + (size_t)((Ho * Wo + 31) / 32) * 32);
+    const size_t stage = sizeof(float) * 16 * 32 * (size_t)(k * k + 1);   // (the epilogue's staging area)
+    if (lds < stage) lds = stage;
+    if (lds > 80 * 1024 || Hi * Wi * 8 > WI_NX * CV_THREADS || ((Ho * Wo + 31) / 32) * 32 * 8 > WI_ND * CV_THREADS) return 0;
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 2) per_cu = 2;   // (two waves per SIMD asked of the compiler: the accumulators + the next image's words)
+    const int blocks = (ci / 32) * (co / 32);
+    const int cap = 256 * per_cu / blocks > 0 ? 256 * per_cu / blocks : 1;
+    if (lds_out) *lds_out = lds;
+    return B < cap ? B : cap;
+}
+
+extern "C" int ssac_conv_wgrad_img_slices(int B, int Hi, int Wi, int ci, int co, int k, int s) {
+    return wgrad_img_slices(B, Hi, Wi, ci, co, k, s, nullptr);
+}
+
+extern "C" int ssac_conv_wgrad_img(const float *dy, const float *x, float *partial_w, float *partial_b, int B, int Hi, int Wi,
+                                   int ci, int co, int k, int s, void *stream) {
+    size_t lds = 0;
+    const int slices = wgrad_img_slices(B, Hi, Wi, ci, co, k, s, &lds);
+    if (!slices) return ssac_fail("ssac_conv_wgrad_img: geometry not supported (see ssac_conv_wgrad_img_slices)");
+    if (((uintptr_t)x | (uintptr_t)dy) & 15) return ssac_fail("ssac_conv_wgrad_img: operands must be 16-byte aligned");
+    ConvArgs g{};
+    g.x = x; g.dy = dy; g.B = B; g.Hi = Hi; g.Wi = Wi; g.ci = ci; g.co = co; g.k = k; g.s = s;
+    g.Ho = (Hi - k) / s + 1; g.Wo = (Wi - k) / s + 1;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)conv_wgrad_img_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    SSAC_LAUNCH(conv_wgrad_img_kernel, dim3(slices, ci / 32, co / 32), dim3(CV_THREADS), lds, (hipStream_t)stream, g, partial_w,
+                partial_b);
+    return ssac_check_launch("conv_wgrad_img");
 }
 
 extern "C" int ssac_conv_wgrad(const float *dy, const float *x, float *partial_w, float *partial_b, int B, int Hi,

@@ -928,6 +928,14 @@ def test_implicit_gemm_convolution_matches_torch_conv2d(ssa, B, ci, co, k, s, H)
                                            k, s, pps, st))
         _close(pw.sum(0), wr.grad, 2e-4, rtol=1e-4, what=f"conv weight gradient (slices of {pps})")
         _close(pb.sum(0), br.grad, 2e-4, rtol=1e-4, what=f"conv bias gradient (slices of {pps})")
+    slices = int(lib.ssac_conv_wgrad_img_slices(B, H, H, ci, co, k, s))   # whole images staged in LDS (small maps only)
+    if slices:
+        pw = torch.full((slices, co, ci, k, k), float("nan"), device=DEV)
+        pb = torch.full((slices, co), float("nan"), device=DEV)
+        ssa._lib.check(lib.ssac_conv_wgrad_img(dzd.data_ptr(), xd.data_ptr(), pw.data_ptr(), pb.data_ptr(), B, H, H, ci, co, k,
+                                               s, st))
+        _close(pw.sum(0), wr.grad, 2e-4, rtol=1e-4, what="conv weight gradient (whole images in LDS)")
+        _close(pb.sum(0), br.grad, 2e-4, rtol=1e-4, what="conv bias gradient (whole images in LDS)")
 
 
 @pytest.mark.parametrize("B,C,co,k,s,H,div,shift", [(3, 4, 32, 8, 4, 84, 255.0, 0.0), (2, 9, 32, 3, 2, 84, 255.0, -0.5),

@@ -1347,10 +1347,22 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad_taps_kernel(ConvArgs g,
         }
         __syncthreads();
     }
-    // partial_w[slice][co][c][ky][kx]: wave 0 holds the sums; the block leaves through LDS in contiguous runs
-    wgrad_store_block<NT>(red, acc, [&](int j) { return wave == 0 ? j : kk; }, kk,
-                          partial_w + (int64_t)blockIdx.x * g.co * g.ci * kk, g.ci, c0, co0);
-    if (wave == 0 && blockIdx.y == 0 && lh == 0) partial_b[(int64_t)blockIdx.x * g.co + co0 + li] = bsum;
+    if (wave == 0) {
+        // (direct stores: consecutive lanes are k k floats apart -- staging this block through LDS as conv_wgrad_img_kernel
+        //  does cost this kernel 9 us per launch at DMC: two more barrier rounds with three waves idle)
+        float *pw = partial_w + (int64_t)blockIdx.x * g.co * g.ci * kk;   // partial_w[slice][co][c][ky][kx]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (j < kk) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    pw[((int64_t)co * g.ci + c0 + li) * kk + j] = acc[j][r];
+                }
+            }
+        }
+        if (blockIdx.y == 0 && lh == 0) partial_b[(int64_t)blockIdx.x * g.co + co0 + li] = bsum;
+    }
 }
 
 // persistent workgroups per CU: as many as the weight tile in LDS allows, at most 3 (three waves per SIMD hide the

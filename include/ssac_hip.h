@@ -901,6 +901,12 @@ int ssac_conv_first_shift_fwd(const void *src, const int64_t *idx, const int64_t
  * ssac_reduce_slices_bias then writes Y[m*ld_out + n] = bias[n] + sum over slices, in a fixed order. */
 int ssac_linear_fwd_splitk(const float *X, int64_t ldx, const float *W, int64_t ldw, float *partial, int M, int N,
                            int K, int k_per_slice, void *stream);
+/* the same partials for N <= 64 outputs as an operand stream (no LDS: each lane reads its row 16 bytes at a time into the
+ * MFMA operand registers, 8 groups in flight); K and k_per_slice multiples of 8, 16-byte aligned rows.  Same values up to
+ * the k order inside a slice. */
+int ssac_linear_fwd_stream_supported(int M, int N, int K, int k_per_slice, int64_t ldx, int64_t ldw);
+int ssac_linear_fwd_stream(const float *X, int64_t ldx, const float *W, int64_t ldw, float *partial, int M, int N, int K,
+                           int k_per_slice, void *stream);
 int ssac_reduce_slices_bias(const float *partial, int slices, int M, int N, const float *bias, float *out,
                             int64_t ld_out, void *stream);
 /* dX (M x N_in) = dY (M x K_out) W (K_out x N_in) */

@@ -184,6 +184,8 @@ SIGNATURES = {
     "ssac_conv_first_shift_supported": [_I, _I, _I, _I, _I, _L, _I],
     "ssac_conv_first_shift_fwd": [_P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P],
     "ssac_linear_fwd_splitk": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P],
+    "ssac_linear_fwd_stream_supported": [_I, _I, _I, _I, _L, _L],
+    "ssac_linear_fwd_stream": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P],
     "ssac_reduce_slices_bias": [_P, _I, _I, _I, _P, _P, _L, _P],
     "ssac_linear_dgrad": [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P],
     "ssac_linear_dgrad_masked": [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P],

@@ -33,7 +33,8 @@ IMPLICIT_WG_BIG_ROWS = 300_000   # ... and ONE from this many output pixels on (
 FIRST_WG_PER_CU = 2              # (measured 2 / 3 / 4 / 6: Atari 1.57 / 1.59 / 1.61 / 1.61 ms)
 FIRST_WGRAD_BANDS = True         # conv1's weight gradient with the image staged through LDS where covered (DMC: 116 -> 86 us)
 WGRAD_WHOLE_IMAGES = True        # weight gradients of layers with small feature maps: x and dy of an image staged in LDS
-FC_SLICES = 48  # K slices of the fc forward (8 row tiles x 48 slices ~ 1.5 workgroups per CU at B 512)
+FC_STREAM = True  # the fc forward as an operand stream (N <= 64 outputs; DMC 49 -> 38 us per pass)
+FC_SLICES = 48  # K slices of the tiled fc forward (8 row tiles x 48 slices ~ 1.5 workgroups per CU at B 512)
 ROWS_PER_SLICE = 4096  # split-K granularity of the convolution weight gradients
 
 
@@ -155,6 +156,18 @@ class ConvEncoderEngine:
         def fc_forward(out_ptr, ld_out):
             # (B x flat_dim) . (emb x flat_dim)^T: 8 x 1 output tiles only -> cut K into slices so the launch fills
             # the chip, then a fixed-order reduction adds the bias
+            # few outputs (N <= 64): the operand-stream kernel, one wave per (32 rows, K slice), one workgroup per CU
+            row_groups = (B + 127) // 128
+            skps = ((flat_dim + max(1, 256 // row_groups) - 1) // max(1, 256 // row_groups) + 7) // 8 * 8
+            if FC_STREAM and lib.ssac_linear_fwd_stream_supported(B, self.emb, flat_dim, skps, flat_dim, flat_dim) \
+                    and (flat_dim + skps - 1) // skps >= 4:
+                slices = (flat_dim + skps - 1) // skps
+                part = self.ws.get("fc.partial", (slices * B * self.emb,))
+                check(lib.ssac_linear_fwd_stream(colf.data_ptr(), flat_dim, wfc.data_ptr(), flat_dim, part.data_ptr(), B,
+                                                 self.emb, flat_dim, skps, st))
+                check(lib.ssac_reduce_slices_bias(part.data_ptr(), slices, B, self.emb, fc.bias.data_ptr(), out_ptr,
+                                                  ld_out, st))
+                return
             kps = max(32, ((flat_dim + FC_SLICES - 1) // FC_SLICES + 31) // 32 * 32)
             slices = (flat_dim + kps - 1) // kps
             if slices < 4:

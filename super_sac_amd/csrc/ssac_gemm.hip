@@ -1739,6 +1739,82 @@ extern "C" int ssac_linear_fwd_splitk(const float *X, int64_t ldx, const float *
     return launch<true, true, EPI_STORE>(g, slices, (hipStream_t)stream);
 }
 
+// The same split-K forward for N <= 64 outputs as a pure operand STREAM (the pixel encoders' fc: M 512, N 50, K 39 200 --
+// 80 MB of X against 2.6 GFLOP: both roofs near 20 us, the tiled kernel above takes 45).  A wave owns (32 rows, one K
+// slice): both operands are K-contiguous, so a lane reads ITS row 16 bytes at a time (lane half h takes k + 4 h .. + 3 of
+// every 8) straight into the MFMA operand registers -- no LDS, no barrier -- and keeps FS_DEPTH groups of 8 k in flight
+// (one wave per SIMD: the loads must cover the round trip themselves).  The X fragment feeds both 32-column halves of the
+// output.  The four waves of a workgroup take four row blocks of the SAME slice (their W reads hit the L1).  Partials
+// [slice][M][N] as ssac_linear_fwd_splitk; the k order inside a slice differs from the tiled kernel's (rounding only).
+constexpr int FS_DEPTH = 8;
+__global__ __launch_bounds__(256) void linear_fwd_stream_kernel(const float *__restrict__ X, int64_t ldx,
+                                                                const float *__restrict__ W, int64_t ldw,
+                                                                float *__restrict__ partial, int M, int N, int K,
+                                                                int k_per_slice) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+    const int slice = blockIdx.x, r0 = (blockIdx.y * 4 + wave) * 32;
+    if (r0 >= M) return;
+    const int k_lo = slice * k_per_slice, k_hi = min(K, k_lo + k_per_slice), ngroups = (k_hi - k_lo) >> 3;
+    const float *xr = X + (int64_t)min(r0 + li, M - 1) * ldx + k_lo + 4 * lh;
+    const float *w0 = W + (int64_t)min(li, N - 1) * ldw + k_lo + 4 * lh;
+    const float *w1 = W + (int64_t)min(32 + li, N - 1) * ldw + k_lo + 4 * lh;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
+    f4 xa[FS_DEPTH], wa[FS_DEPTH], wb[FS_DEPTH];
+#pragma unroll
+    for (int d = 0; d < FS_DEPTH; ++d) {
+        if (d < ngroups) {
+            xa[d] = *reinterpret_cast<const f4 *>(xr + 8 * d);
+            wa[d] = *reinterpret_cast<const f4 *>(w0 + 8 * d);
+            wb[d] = *reinterpret_cast<const f4 *>(w1 + 8 * d);
+        }
+    }
+    for (int g0 = 0; g0 < ngroups; g0 += FS_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < FS_DEPTH; ++d) {
+            if (g0 + d < ngroups) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[d][j], wa[d][j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[d][j], wb[d][j], acc1, 0, 0, 0);
+                }
+            }
+            if (g0 + d + FS_DEPTH < ngroups) {
+                const int o = 8 * (g0 + d + FS_DEPTH);
+                xa[d] = *reinterpret_cast<const f4 *>(xr + o);
+                wa[d] = *reinterpret_cast<const f4 *>(w0 + o);
+                wb[d] = *reinterpret_cast<const f4 *>(w1 + o);
+            }
+        }
+    }
+    float *out = partial + (int64_t)slice * M * N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < M) {
+            if (li < N) out[(int64_t)row * N + li] = acc0[r];
+            if (32 + li < N) out[(int64_t)row * N + 32 + li] = acc1[r];
+        }
+    }
+}
+
+// 1 when ssac_linear_fwd_stream covers the problem: N <= 64, K and the slice multiples of 8, 16-byte aligned rows
+extern "C" int ssac_linear_fwd_stream_supported(int M, int N, int K, int k_per_slice, int64_t ldx, int64_t ldw) {
+    return M > 0 && N >= 1 && N <= 64 && K >= 8 && (K & 7) == 0 && k_per_slice >= 8 && (k_per_slice & 7) == 0 &&
+           (ldx & 3) == 0 && (ldw & 3) == 0;
+}
+
+extern "C" int ssac_linear_fwd_stream(const float *X, int64_t ldx, const float *W, int64_t ldw, float *partial, int M,
+                                      int N, int K, int k_per_slice, void *stream) {
+    if (!ssac_linear_fwd_stream_supported(M, N, K, k_per_slice, ldx, ldw) || (((uintptr_t)X | (uintptr_t)W) & 15))
+        return ssac_fail("ssac_linear_fwd_stream: shape / alignment not covered (see ssac_linear_fwd_stream_supported)");
+    const int slices = (K + k_per_slice - 1) / k_per_slice;
+    SSAC_LAUNCH(linear_fwd_stream_kernel, dim3(slices, (M + 127) / 128), dim3(256), 0, (hipStream_t)stream, X, ldx, W, ldw,
+                partial, M, N, K, k_per_slice);
+    return ssac_check_launch("linear_fwd_stream");
+}
+
 extern "C" int ssac_linear_dgrad(const float *dY, int64_t ldy, const float *W, int64_t ldw, float *dX,
                                  int64_t ldx, int M, int N_in, int K_out, void *stream) {
     GemmArgs g{};

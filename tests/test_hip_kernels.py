@@ -1074,6 +1074,32 @@ def test_slice_reduction_and_weight_permutation_are_exact(ssa):
         assert torch.equal(back, w), (n, C, P)
 
 
+@pytest.mark.parametrize("M,N,K,kps", [(512, 50, 39200, 616), (70, 50, 3136, 104), (33, 64, 256, 64), (5, 1, 8, 8),
+                                        (1024, 128 // 4, 800, 800)])
+def test_streamed_split_k_forward_of_a_narrow_layer(ssa, M, N, K, kps):
+    """ssac_linear_fwd_stream (operands straight into the MFMA registers, no LDS) + ssac_reduce_slices_bias against
+    X W^T + b in float64 and against the tiled split-K kernel it replaces for the pixel encoders' fc: ragged row
+    blocks, a last slice shorter than the others, N below / at / between the 32-column halves."""
+    lib, st = ssa._lib.lib, ssa.engine.stream()
+    g = torch.Generator().manual_seed(M + N)
+    X, W, b = torch.randn(M, K, generator=g).to(DEV), (torch.randn(N, K, generator=g) * 0.05).to(DEV), torch.randn(N, generator=g).to(DEV)
+    assert lib.ssac_linear_fwd_stream_supported(M, N, K, kps, K, K) == 1
+    slices = (K + kps - 1) // kps
+    part = torch.full((slices, M, N), float("nan"), device=DEV)
+    ssa._lib.check(lib.ssac_linear_fwd_stream(X.data_ptr(), K, W.data_ptr(), K, part.data_ptr(), M, N, K, kps, st))
+    out = torch.empty(M, N, device=DEV)
+    ssa._lib.check(lib.ssac_reduce_slices_bias(part.data_ptr(), slices, M, N, b.data_ptr(), out.data_ptr(), N, st))
+    want = (X.double() @ W.double().T + b.double())
+    scale = float(want.abs().max())
+    assert float((out.double() - want).abs().max()) <= 2e-6 * max(1.0, scale) * (K ** 0.5) / 8 + 1e-5, (M, N, K)
+    if kps % 32 == 0:
+        part2 = torch.full((slices, M, N), float("nan"), device=DEV)
+        ssa._lib.check(lib.ssac_linear_fwd_splitk(X.data_ptr(), K, W.data_ptr(), K, part2.data_ptr(), M, N, K, kps, st))
+        assert float((part - part2).abs().max()) <= 1e-4 * max(1.0, float(part2.abs().max()))
+    assert lib.ssac_linear_fwd_stream_supported(M, 65, K, kps, K, K) == 0
+    assert lib.ssac_linear_fwd_stream_supported(M, N, K + 4, kps, K + 4, K + 4) == 0
+
+
 def test_first_layer_implicit_convolution_refuses_what_it_does_not_cover(ssa):
     lib = ssa._lib.lib
     assert lib.ssac_conv_first_supported(4, 32, 8, 4, 84, 84, 1024) == 4

@@ -1,8 +1,8 @@
 #!/bin/bash
 # end-of-round evidence: full GPU suite, pixel traces, driver-style + default bench lines
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r4e
-O=gpurun_out/r4e
+mkdir -p gpurun_out/r4f
+O=gpurun_out/r4f
 timeout 1500 python -m pytest tests -x -q -m gpu > $O/gpu_suite.log 2>&1; echo "suite exit $?" >> $O/gpu_suite.log
 tail -4 $O/gpu_suite.log
 export TMPDIR=/tmp
@@ -17,7 +17,7 @@ python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 python3 - <<'P'
 import json
 for f in ("bench_driver", "bench_default"):
-    t = open(f"gpurun_out/r4e/{f}.json").read()
+    t = open(f"gpurun_out/r4f/{f}.json").read()
     j = json.loads(t[t.index('{"metric"'):])
     s = j["secondary"]
     print(f, j["value"], j["ms_per_step"], j["roofline"]["frac"], s["config3_dmc_pixels"]["ms_per_critic_update"], s["config4_atari_pixels"]["ms_per_critic_update"], s["full_redq_step_fp32"]["ms_per_env_step"])

@@ -711,7 +711,8 @@ def test_packed_push_and_n_step_fold_match_the_reference_storage():
 def test_full_size_pixel_critic_update_implicit_vs_im2col(which, monkeypatch):
     """BASELINE configs 3 and 4 END TO END at their full batch (B 512 / B 1024; the update closure bench.py times):
     three critic updates (DrQv2 shift, both encoder passes, encoder backward, clip, Adam, Polyak) with every
-    convolution as an implicit GEMM against the same three updates through im2col + GEMM -- the path the
+    convolution as an implicit GEMM (conv1's and the small maps' weight gradients LDS-staged, the fc forward streamed) against
+    the same three updates through im2col + GEMM and the tiled fc kernel -- the path the
     reference-generated fixtures drqv2_pixels / atari_pixels pin at B 8.  Same arithmetic in a different summation
     order: TD targets 2e-4 * max(1,|x|), logs 5e-4; parameters: median 1e-6 and worst element 2 * lr per update (Adam
     moves a weight by ~lr whatever the gradient's size, so a near-zero gradient whose sign differs displaces it that far)."""
@@ -730,6 +731,7 @@ def test_full_size_pixel_critic_update_implicit_vs_im2col(which, monkeypatch):
     def run(implicit):
         monkeypatch.setattr(conv_encoder, "USE_IMPLICIT", implicit)
         monkeypatch.setattr(conv_encoder, "USE_IMPLICIT_FIRST", implicit)
+        monkeypatch.setattr(conv_encoder, "FC_STREAM", implicit)   # (the fc forward: operand stream / tiled split-K kernel)
         torch.manual_seed(0); np.random.seed(0); random.seed(0)
         step, B = bench_pixels.build(which, torch.device("cuda"))
         tds, logs = [], []

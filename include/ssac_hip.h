@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SSAC_ABI_VERSION 5
+#define SSAC_ABI_VERSION 6
 #define SSAC_MAX_NETS 64
 
 typedef struct ssac_mlp {
@@ -215,7 +215,8 @@ int ssac_xchg_error(ssac_xchg *x);   /* 1: a peer's flag did not arrive within t
                                         was poisoned with NaN); a pinned host word, cleared by the read, no synchronisation */
 /* Flow control: every rank acknowledges the exchanges it has consumed and a sender reuses slot seq % 4 only when every
  * rank has consumed exchange seq - 4; a receiver accepts a flag only when it EQUALS its sequence number (a larger one
- * = the slot was lapped: poisoned result + error word).  ssac_xchg_test_mode is for tests/ only: bit 0 makes this
+ * = the slot was lapped: poisoned result + error word).  ssac_xchg_test_mode exists in the LAB build only
+ * (`./build.sh --lab`; the product library refuses any mode but 0 and its kernel does not read the field): bit 0 makes this
  * rank's senders skip the reuse wait, bit 1 makes its receivers accept flag >= seq -- 3 is the protocol of round 3,
  * whose owners-only form let senders lap a rank that owned no subset member (tests/test_hip_sharded.py shows both). */
 int ssac_xchg_test_mode(ssac_xchg *x, int mode);
@@ -715,6 +716,12 @@ int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t ldxa, int 
  * target_splits columns of fc2 from register-resident weight fragments and a PARTIAL head dot product; Qt is then
  * (n_sel x target_splits x n_rows), to be read through an ssac_td_spec with n_parts = target_splits. */
 int ssac_chain_target_splits(const ssac_mlp *actor, const ssac_mlp *targets, const ssac_mlp *critics, int n_rows, int n_sel);
+/* Form of the producer / consumer launch (round 5): 1 (default) = automatic -- when 16-row tiles of the three roles are
+ * more than 256 but at most 512 workgroups and every role's co-resident LDS carve fits 80 KB, the launch runs TWO
+ * workgroups per CU (16-row tiles, <= 128 VGPRs; one tile's prologue / epilogues / stores hide under its neighbour's K
+ * loop); 0 = always one workgroup per CU.  Outputs are bit-identical to the 16-row tiles of the one-per-CU form
+ * (ssac_fused_tile_rows(16)); against its 32-row tiles they differ by fp32 association of the K sums. */
+int ssac_chain_form(int form);
 
 /* ---- the online actor update (learning.py:344-421) in four launches:
  *   ssac_actor_sample_concat_fused   actor forward (h1 / h2 / head output saved) + tanh-normal rsample + log pi, the rows
@@ -744,12 +751,14 @@ int ssac_actor_logs(const float *partials, int n_tiles, int n_rows, float inv_me
  *   ssac_actor_route_local  q_local[b] = min over the local critics (and a copy, q_reduce, for the MIN all-reduce),
  *                           d_sel[b][:] = dQ/da of the local arg-min critic (first index on ties)
  *   (MIN all-reduce of q_reduce)
- *   ssac_actor_route_mask   rows whose local minimum is not the global one are zeroed in d_sel
+ *   ssac_actor_route_claim  claim[b] = rank if the local minimum IS the global one, +inf otherwise
+ *   (MIN all-reduce of claim: bit-equal minima on several ranks go to the lowest rank -- torch.min's first index)
+ *   ssac_actor_route_mask   rows this rank did not win are zeroed in d_sel
  *   (SUM all-reduce of d_sel) */
 int ssac_actor_route_local(const float *q, const float *dxu, int n_local, int n_rows, int action_dim, float *q_local,
                            float *q_reduce, float *d_sel, void *stream);
-int ssac_actor_route_mask(const float *q_local, const float *q_global, int n_rows, int action_dim, float *d_sel,
-                          void *stream);
+int ssac_actor_route_claim(const float *q_local, const float *q_global, int n_rows, int rank, float *claim, void *stream);
+int ssac_actor_route_mask(const float *claim, int rank, int n_rows, int action_dim, float *d_sel, void *stream);
 
 /* The first three launches above as ONE (round 4): the actor's workgroups (16-row tiles, lowest workgroup ids) run the
  * forward + rsample, publish a_theta as tagged 8-byte granules, WAIT for their rows' Q_j and dQ_j/da from every critic and

@@ -8,7 +8,13 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# The LAB build (`./build.sh --lab`: phase stamps, per-workgroup timelines, SKIP_* experiment builds) is a SEPARATE file,
+# libssac_hip_lab.so, that only the measurement scripts under tools/ ask for (SSAC_LAB_BUILD=1 in their environment): a
+# forgotten rebuild can no longer ship the scaffolding as the product library.
 LIB_PATH = os.path.join(_HERE, "libssac_hip.so")
+if os.environ.get("SSAC_LAB_BUILD") == "1":   # (SSAC_LAB_TAG=name: an experiment variant, `./build.sh --lab --tag name -D...`)
+    _tag = os.environ.get("SSAC_LAB_TAG")
+    LIB_PATH = os.path.join(_HERE, f"libssac_hip_lab_{_tag}.so" if _tag else "libssac_hip_lab.so")
 
 
 class MlpDesc(C.Structure):
@@ -220,6 +226,7 @@ SIGNATURES = {
     "ssac_chain_update": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _I, _P, _MP, _P, _L, _P, _P, _P, _P, _P,
                           _P, _P, _P, _P, _I, _P],
     "ssac_chain_target_splits": [_MP, _MP, _MP, _I, _I],
+    "ssac_chain_form": [_I],
     "ssac_deferred_logs_flush": [_P, _I, _P],
     "ssac_philox_normal": [_P, _I, _I, _P, _P],
     "ssac_actor_sample_concat_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _P, _P, _P, _P, _P, _P],
@@ -227,7 +234,8 @@ SIGNATURES = {
     "ssac_actor_bwd_fused": [_MP, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _F, _F, _F, _P, _I, _P, _P, _P, _P, _P],
     "ssac_actor_logs": [_P, _I, _I, _F, _P, _I, _P, _P, _P],
     "ssac_actor_route_local": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
-    "ssac_actor_route_mask": [_P, _P, _I, _I, _P, _P],
+    "ssac_actor_route_claim": [_P, _P, _I, _I, _P, _P],
+    "ssac_actor_route_mask": [_P, _I, _I, _I, _P, _P],
     "ssac_actor_chain_fused": [_MP, _P, _L, _I, _P, _P, _F, _F, _P, _L, _P, _P, _P, _P, _MP, _P, _P, _P, _I, _F, _P, _I,
                                _P, _P, _P, _P, _P, _L, _P, _I, _P, _P],
     "ssac_actor_chain_handoff_words": [_I, _I, _I],
@@ -255,7 +263,7 @@ _RESTYPES = {"ssac_xchg_create": C.c_void_p, "ssac_xchg_destroy": None, "ssac_st
 
 # SSAC_ABI_VERSION of include/ssac_hip.h this binding table was written against (bumped with every signature change:
 # a stale .so called with shifted pointer arguments would corrupt device memory)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def _load():

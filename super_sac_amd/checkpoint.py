@@ -141,5 +141,12 @@ def load_training_state(path, agent, target_agent=None, optimizers=None, log_alp
     lu.ring_for(dev).k = state["log_ring"]
     if state.get("noise", {}).get("agent") is not None:
         agent.__dict__["_ssac_noise"] = list(state["noise"]["agent"])
+    # The chained actor update tags its hand-off granules with (update number + 1) of the noise stream just restored.  A
+    # load that REWINDS the counter inside one process would let granules of the earlier pass carry a tag the counter
+    # reaches again: zero the hand-off buffers (tag 0 is never used), so a consumer can only ever accept this pass's values.
+    ws = agent.__dict__.get("_ssac_ws")
+    for key, buf in (getattr(ws, "_bufs", None) or {}).items():
+        if "handoff" in key[0]:
+            buf.zero_()
     torch.cuda.synchronize()
     return state

@@ -1459,12 +1459,22 @@ __global__ void actor_route_local_kernel(const float *__restrict__ q, const floa
     q_red[b] = mq;
     for (int i = 0; i < A; ++i) d_sel[(int64_t)b * A + i] = dxu[((int64_t)am * n_rows + b) * A + i];
 }
-__global__ void actor_route_mask_kernel(const float *__restrict__ q_loc, const float *__restrict__ q_glob, int n_rows, int A,
+// Ties ACROSS ranks (bit-equal minima on two ranks -- saturated Q values, identical critics): torch.min routes the gradient
+// to exactly one index, the first.  Every rank whose local minimum is the global one CLAIMS the row with its rank number
+// (+inf otherwise); after a MIN all-reduce of the claims the lowest claiming rank -- the owner of the first arg-min index,
+// ranks hold ascending critic ranges -- keeps its row, everybody else zeroes it.
+__global__ void actor_route_claim_kernel(const float *__restrict__ q_loc, const float *__restrict__ q_glob, int n_rows,
+                                         int rank, float *__restrict__ claim) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_rows) return;
+    claim[b] = q_loc[b] == q_glob[b] ? (float)rank : __builtin_inff();
+}
+__global__ void actor_route_mask_kernel(const float *__restrict__ claim, int rank, int n_rows, int A,
                                         float *__restrict__ d_sel) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_rows * A) return;
     const int b = t / A;
-    if (q_loc[b] != q_glob[b]) d_sel[t] = 0.0f;
+    if (claim[b] != (float)rank) d_sel[t] = 0.0f;
 }
 
 extern "C" int ssac_actor_route_local(const float *q, const float *dxu, int n_local, int n_rows, int action_dim,
@@ -1477,11 +1487,18 @@ extern "C" int ssac_actor_route_local(const float *q, const float *dxu, int n_lo
     return ssac_check_launch("actor_route_local");
 }
 
-extern "C" int ssac_actor_route_mask(const float *q_local, const float *q_global, int n_rows, int action_dim, float *d_sel,
-                                     void *stream) {
-    if (!q_local || !q_global || !d_sel || action_dim < 1) return ssac_fail("ssac_actor_route_mask: bad arguments");
+extern "C" int ssac_actor_route_claim(const float *q_local, const float *q_global, int n_rows, int rank, float *claim,
+                                      void *stream) {
+    if (!q_local || !q_global || !claim || rank < 0) return ssac_fail("ssac_actor_route_claim: bad arguments");
     if (n_rows <= 0) return 0;
-    SSAC_LAUNCH(actor_route_mask_kernel, dim3((n_rows * action_dim + 255) / 256), dim3(256), 0, ST, q_local, q_global, n_rows,
+    SSAC_LAUNCH(actor_route_claim_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, ST, q_local, q_global, n_rows, rank, claim);
+    return ssac_check_launch("actor_route_claim");
+}
+
+extern "C" int ssac_actor_route_mask(const float *claim, int rank, int n_rows, int action_dim, float *d_sel, void *stream) {
+    if (!claim || !d_sel || action_dim < 1 || rank < 0) return ssac_fail("ssac_actor_route_mask: bad arguments");
+    if (n_rows <= 0) return 0;
+    SSAC_LAUNCH(actor_route_mask_kernel, dim3((n_rows * action_dim + 255) / 256), dim3(256), 0, ST, claim, rank, n_rows,
                 action_dim, d_sel);
     return ssac_check_launch("actor_route_mask");
 }

@@ -151,6 +151,9 @@ struct KcStage {
         }
     }
     __device__ __forceinline__ void load(int k0, int K) {
+#if defined(SSAC_LAB) && defined(SSAC_EXP_NO_WLOAD)
+        if (k0 > 0) return;
+#endif
         const int left = K - (k0 + kk);  // valid k values at and after this thread's first one
         if (left >= 4) {
 #pragma unroll
@@ -164,6 +167,9 @@ struct KcStage {
     }
     // a chunk that is known to lie fully inside K (every chunk but the last): no ragged-tail branch
     __device__ __forceinline__ void load_full(int k0) {
+#if defined(SSAC_LAB) && defined(SSAC_EXP_NO_WLOAD)
+        return;   // (experiment build: the K loops' weight chunks are never fetched)
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f4u *>(p[q] + k0);
     }
@@ -191,6 +197,9 @@ struct RcStage {
     }
     // rows n0 + local row; K = number of rows of W
     __device__ __forceinline__ void load(int n0, int K) {
+#if defined(SSAC_LAB) && defined(SSAC_EXP_NO_WLOAD)
+        if (n0 > 0) return;
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool ok = cok && (n0 + (int)(threadIdx.x >> 6) + 8 * q) < K;
@@ -201,6 +210,9 @@ struct RcStage {
     // rows [n0, n0 + 32) known to lie inside K.  (columns beyond the matrix are not zeroed -- they feed accumulator
     // columns nobody reads -- so the steady loop has no per-lane predicate; their pointers read column 0)
     __device__ __forceinline__ void load_full(int n0) {
+#if defined(SSAC_LAB) && defined(SSAC_EXP_NO_WLOAD)
+        return;
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f4u *>(p[q] + (int64_t)n0 * ldw_);
     }
@@ -308,6 +320,10 @@ template <> struct Tile<16> {
     }
     template <bool NN>
     static __device__ __forceinline__ void mfma_half(Acc &acc, const Frag &f, int half) {
+#if defined(SSAC_LAB) && defined(SSAC_EXP_NO_MFMA)
+        acc.v[0][0] += f.a[0][0] + (NN ? f.bs[0][half] : f.b[0][0][0]);   // (experiment build: the operands stay live, no matrix work)
+        return;
+#endif
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
             const int t = half * 4 + t4;
@@ -479,10 +495,16 @@ __device__ __forceinline__ void stage_head_weights(float *w3s, const float *__re
 // wide input (Humanoid's actor: 376 -> 256 -> 256 -> 34, 35 KB of W3) leaves no room for the second staging buffer, and with
 // a single buffer its 20 K chunks cost 2.4 k clocks each instead of 1.4 k.  They are requested into registers before fc2 and
 // parked in staging buffer 1 behind fc2's K loop, where the head reads them.
-template <int MODE, int TMR, bool DBUF, bool HO = false, bool W3LATE = false>
+// CO ("co-resident", round 5): the LDS carve of a workgroup that shares its CU with a second one (<= 80 KB, <= 128 VGPRs:
+// fused_chain_co_kernel) -- 16-row tiles; h2 / dz2u take h1's place in LDS (fc2's epilogue runs behind the K loop's closing
+// barrier, when nobody reads h1 any more), and the ReLU mask of h1 that the backward-data epilogue needs stays in a
+// register: a lane's accumulator elements are the same (row, column) set in fc1 and in the backward-data GEMM.
+template <int MODE, int TMR, bool DBUF, bool HO = false, bool W3LATE = false, bool CO = false>
 __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, const int bx, const int e,
                                                const int grid_x, const int dbg_off = 0, const int split = 0) {
     static_assert(!W3LATE || (MODE == MODE_SAMPLE && DBUF), "the late head image is the actor pass's, behind a double-buffered fc2");
+    static_assert(!CO || (TMR == 16 && !W3LATE && (MODE == MODE_PLAIN || MODE == MODE_SAMPLE || MODE == MODE_CRITIC_U)),
+                  "the co-resident carve: 16-row tiles of the chained launch's three roles");
     typedef Tile<TMR> T;
     const int H = g.hidden, IN = g.in_dim, OUT = g.out_dim;
     const int ldo = (OUT + 15) & ~15;  // row stride of the per-row head outputs / output gradients in LDS
@@ -490,7 +512,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     const int ldx_s = KP + APAD, ldh = H + APAD;
     float *xs = smem;                       // [TMR][KP+4]
     float *h1s = xs + TMR * ldx_s;          // [TMR][H+4]
-    float *h2s = h1s + TMR * ldh;           // [TMR][H+4]
+    float *h2s = CO ? h1s : h1s + TMR * ldh;   // [TMR][H+4]  (CO: in h1's place)
     float *Ws = h2s + TMR * ldh;            // staging buffer 0
     float *Ws1 = Ws + WS_FLOATS;            // staging buffer 1 (DBUF only)
     float *ys = Ws + (DBUF ? 2 : 1) * WS_FLOATS;  // [TMR][ldo], ldo = out_dim rounded up to 16
@@ -502,6 +524,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     float *b3s = b2s + H;                   // [HEAD_MAX]
     float *w3s = W3LATE ? Ws1 : b3s + HEAD_MAX;   // [OUT][H+4]  (W3LATE: staging buffer 1, filled behind fc2)
     float *rowin = W3LATE ? b3s + HEAD_MAX : w3s + OUT * (H + APAD);  // [3][TMR]: td, weight, action index of this tile's rows
+    float *wa_co = rowin + 3 * TMR;         // CO consumer: W1's action columns [H][A] (the other carves park them in staging buffer 1)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = bx * TMR;
@@ -563,6 +586,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     constexpr bool FWD_BWD = MODE == MODE_CRITIC || MODE == MODE_CRITIC_U;  // forward, then backward in the same workgroup
     constexpr bool IS_CRITIC = FWD_BWD || BWD_ONLY;
     typename T::Acc acc;
+    unsigned m1 = 0;   // CO: [h1 > 0] of this lane's accumulator elements, in foreach4's visiting order
     float *hpart = Ws;  // K-split partial head tiles [8][TMR][16] (staging buffer 0 is free after fc2)
     if (BWD_ONLY) {
         // ---- h1, h2, q tiles of an earlier forward launch -> LDS; W2's first chunk in flight meanwhile
@@ -663,7 +687,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         // straight into registers, and wait there while fc1 runs and the hand-off is polled.  Behind a' the workgroup then
         // has no memory access left but its LDS: NCH x 16 MFMAs per wave, a sum over the K-groups, the head's partial dot
         // product -- q_t[(slot nsplit + split)][row], summed by the TD evaluation (ssac_td_spec.n_parts).
-        const int NSPL = (CONS && MODE == MODE_PLAIN && g.ho.nsplit > 1) ? g.ho.nsplit : 1;
+        const int NSPL = (!CO && CONS && MODE == MODE_PLAIN && g.ho.nsplit > 1) ? g.ho.nsplit : 1;
         constexpr int MAXCH = 4;            // K chunks of 32 per wave: 4 (nsplit 2) or 2 (nsplit 4)
         f4 wq[MAXCH][2][2];
         const int CG_ = 8 / NSPL;           // column groups of 32 inside the workgroup's hidden / nsplit columns
@@ -791,7 +815,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         BSTAMP(2);
         if (NSPL == 1) stage_first(st2, Ws, H, tid);
         if (FWD_BWD) st3.init(P + g.off[2], H, H, tid);
-        float *wa = Ws1, *as_ = ys;   // (consumer) W1[:, S:S+A] as [H][A]; a' of the tile as [TMR][32] (ys | dqs: free until the head)
+        float *wa = CO ? wa_co : Ws1, *as_ = ys;   // (consumer) W1[:, S:S+A] as [H][A]; a' of the tile as [TMR][32] (ys | dqs: free until the head)
         if (CONS) {
             const int A_ = g.ho.A, na = H * A_;
 #pragma unroll
@@ -808,6 +832,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
             }
             lds_barrier();
         }
+        int m1q = 0;
         T::foreach4(acc, lane, [&](int row, int cw, f4 val) {
             const int col = col0 + cw;  // 4 consecutive columns (H % 32 == 0: all four in range or none)
             if (col < H) {
@@ -826,7 +851,12 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 *reinterpret_cast<f4 *>(h1s + row * ldh + col) = v;
                 if (g.H1 && (m0 + row) < g.n_rows)
                     *reinterpret_cast<f4 *>(g.H1 + ((int64_t)e * g.n_rows + m0 + row) * H + col) = v;
+                if (CO && FWD_BWD) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) m1 |= (v[i] > 0.0f ? 1u : 0u) << (4 * m1q + i);
+                }
             }
+            ++m1q;
         });
         lds_barrier();
         BSTAMP(3);
@@ -1184,17 +1214,24 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         gemm_tile<TMR, true, DBUF>(acc, st3, h2s, ldh, H, Ws, Ws1, tid, col0, none, 0);
         BSTAMP(10);
         const bool want_dx = MODE == MODE_CRITIC_U && g.DXU != nullptr;
+        int m1r = 0;
         T::foreach4(acc, lane, [&](int row, int cw, f4 val) {
             const int col = col0 + cw;
             if (col < H) {
-                const f4 hq = *reinterpret_cast<const f4 *>(h1s + row * ldh + col);
                 f4 v;
+                if (CO) {   // (h1 is gone from LDS: its mask was kept by the fc1 epilogue)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = hq[i] > 0.0f ? val[i] : 0.0f;
+                    for (int i = 0; i < 4; ++i) v[i] = ((m1 >> (4 * m1r + i)) & 1u) ? val[i] : 0.0f;
+                } else {
+                    const f4 hq = *reinterpret_cast<const f4 *>(h1s + row * ldh + col);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = hq[i] > 0.0f ? val[i] : 0.0f;
+                }
                 if (g.DZ1 && (m0 + row) < g.n_rows)
                     *reinterpret_cast<f4 *>(g.DZ1 + ((int64_t)e * g.n_rows + m0 + row) * H + col) = v;
                 if (want_dx) *reinterpret_cast<f4 *>(h2s + row * ldh + col) = v;   // (dz2 is dead: gemm_tile ended with a barrier)
             }
+            ++m1r;
         });
         if (want_dx) {
             // dX[b][c] = sum_k dz1u[b][k] W1[k][dx_col0 + c]: the (unscaled) gradient w.r.t. the ACTION columns of the
@@ -1388,6 +1425,43 @@ void fused_chain_pc_kernel(FusedArgs ga, FusedArgs gt, FusedArgs gc, int tiles_a
 #endif
 }
 
+// The producer / consumer chained launch with TWO workgroups resident per CU (round 5).  At the
+// headline shape fused_chain_pc_kernel is exactly as long as one of its 160 32-row critic tiles, ~58 k clocks of which
+// ~18 k (prologue, fc1, epilogues, dz1 store) overlap nothing: ~130 KB of LDS per workgroup means one workgroup per CU.
+// Here every role runs 16-row tiles on the co-resident carve (fused_mlp_body<..., CO>: <= 80 KB of LDS, <= 128 VGPRs), so
+// the 32 producers + 64 consumers + 320 critic tiles of the headline are ONE resident round at two per CU (4 waves per
+// SIMD), and one tile's non-matrix phases hide under its neighbour's K loop.  Same arithmetic, operation by operation, as
+// the 16-row tiles of fused_chain_pc_kernel<16, ...> (bit-identical outputs).
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void fused_chain_co_kernel(FusedArgs ga, FusedArgs gt, FusedArgs gc, int tiles_a, int tiles_t, int target_grid_x,
+                           int critic_grid_x, DeferredLogsArgs dl, int dl_on) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int bid = blockIdx.x;
+    SSAC_LAB_ONLY(if (gc.tl && threadIdx.x == 0 && bid < 512) gc.tl[2 * bid] = __builtin_amdgcn_s_memrealtime();)
+    if (dl_on && bid == (int)gridDim.x - 1) {
+        deferred_logs_body(dl, -1);   // the PREVIOUS recorded update's log block -> its slot of the log ring
+        return;
+    }
+    const int n_main = (int)gridDim.x - (dl_on ? 1 : 0), n_crit = n_main - tiles_a - tiles_t;
+    const int t_lo = tiles_a, t_hi = t_lo + tiles_t;   // producers, consumers, critic tiles
+    if (bid < tiles_a) {
+        fused_mlp_body<MODE_SAMPLE, 16, false, false, false, true>(ga, smem, ssac_xcd_contiguous_range(bid, 0, tiles_a, gc.xcd), 0, tiles_a, 0);
+    } else if (bid < t_hi) {
+        const int lb = ssac_xcd_contiguous_range(bid, t_lo, t_hi, gc.xcd);
+        const int j = lb / target_grid_x, bx = lb - j * target_grid_x;
+        fused_mlp_body<MODE_PLAIN, 16, false, true, false, true>(gt, smem, bx, j, target_grid_x, j == 0 ? 16 : -1, 0);
+    } else {
+        const int L = ssac_xcd_contiguous_range(bid, t_hi, t_hi + n_crit, gc.xcd);
+        fused_mlp_body<MODE_CRITIC_U, 16, false, false, false, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x, 32);
+    }
+#ifdef SSAC_LAB
+    if (gc.tl && bid < 512) {
+        __syncthreads();
+        if (threadIdx.x == 0) gc.tl[2 * bid + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+}
+
 // The online actor update's three dependent passes as ONE launch (round 4).  Stand-alone they are
 // actor forward + rsample (32 workgroups, ~15 us), every critic's forward + dQ/da (~35 us), arg-min routing + tanh-normal
 // backward + actor backward-data (32 workgroups, ~15 us): three launch boundaries in front of small launches.  Here
@@ -1417,12 +1491,15 @@ void fused_actor_chain_kernel(FusedArgs ga, FusedArgs gb, FusedArgs gc, int tile
 long long *g_fused_dbg = nullptr;
 
 int g_tile_rows = 0;  // 0 = automatic, else 16 or 32 (ssac_fused_tile_rows)
+int g_chain_form = 1;  // ssac_chain_form: 0 = one workgroup per CU (fused_chain_pc_kernel), 1 = automatic (the co-resident form where it applies)
 
-size_t fused_lds_bytes(int in_dim, int hidden, int out_dim, int tm = TM, bool dbuf = true, bool w3_late = false) {
+// co: the co-resident carve (one activation tile instead of two); cons_wa: floats of W1's action columns a CO consumer parks
+size_t fused_lds_bytes(int in_dim, int hidden, int out_dim, int tm = TM, bool dbuf = true, bool w3_late = false,
+                       bool co = false, int cons_wa = 0) {
     const int KP = (in_dim + 31) & ~31;
-    return sizeof(float) * ((size_t)tm * (KP + APAD) + 2 * (size_t)tm * (hidden + APAD) +
+    return sizeof(float) * ((size_t)tm * (KP + APAD) + (co ? 1 : 2) * (size_t)tm * (hidden + APAD) +
                             (dbuf ? 2 : 1) * WS_FLOATS + 2 * tm * ((out_dim + 15) & ~15) + 64 +
-                            2 * hidden + HEAD_MAX + (w3_late ? 0 : (size_t)out_dim * (hidden + APAD)) + 3 * tm);
+                            2 * hidden + HEAD_MAX + (w3_late ? 0 : (size_t)out_dim * (hidden + APAD)) + 3 * tm + cons_wa);
 }
 
 // Kernel variant for one launch.  g_tile_rows (ssac_fused_tile_rows) forces one: 16 / 32 = double-buffered weight
@@ -1741,6 +1818,16 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
         dl = DeferredLogsArgs{deferred->partials, deferred->n_nets, deferred->sumsq, deferred->n_ss, deferred->td_stats,
                               deferred->td_off, deferred->n_rows, deferred->denom, deferred->feed};
     hipStream_t st = (hipStream_t)stream;
+    // Co-resident form (fused_chain_co_kernel): when 16-row tiles of the three roles make MORE than one workgroup per CU but
+    // at most two, and each role's co-resident carve fits half a CU's LDS.  (Launches of <= 256 16-row tiles are one round
+    // at one workgroup per CU already and keep the double-buffered K loop.)
+    const int n16 = tgx + tgx * n_sel + tgx * critics->n_nets + ((deferred && deferred->feed) ? 1 : 0);
+    const size_t co_lds_a = fused_lds_bytes(actor->in_dim, actor->hidden, actor->out_dim, 16, false, false, true);
+    const size_t co_lds_t = fused_lds_bytes(targets->in_dim, targets->hidden, targets->out_dim, 16, false, false, true, targets->hidden * A_);
+    const size_t co_lds_c = fused_lds_bytes(critics->in_dim, critics->hidden, critics->out_dim, 16, false, false, true);
+    const size_t co_lds = co_lds_a > co_lds_t ? (co_lds_a > co_lds_c ? co_lds_a : co_lds_c) : (co_lds_t > co_lds_c ? co_lds_t : co_lds_c);
+    const bool co_form = pc_form && g_chain_form == 1 && g_tile_rows == 0 && target_splits == 1 && n16 > 256 && n16 <= 512 &&
+                         co_lds <= 80 * 1024;
     if (pc_form) {
         // producer / consumer form (fused_chain_pc_kernel): the actor ONCE per tile, a' handed to the tile's target critics
         static unsigned launch_no = 0;   // tags of eager launches: bit 31 set, so they never meet a recorded launch's
@@ -1765,6 +1852,19 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
             pc_attr = true;
         }
         const int tiles_c = tiles_t * target_splits;   // consumers: one per (slot, column split, tile)
+        if (co_form) {
+            static bool co_attr = false;
+            if (!co_attr) {
+                if (hipFuncSetAttribute((const void *)fused_chain_co_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+                    return ssac_fail("fused_chain_co: cannot raise the dynamic LDS limit");
+                co_attr = true;
+            }
+            const dim3 grid_co(tgx + tiles_t + tgx * critics->n_nets + dl_on);
+            SSAC_LAUNCH(fused_chain_co_kernel, grid_co, dim3(NTHR), co_lds, st, ga, gt, gc, tgx, tiles_t, tgx, tgx, dl, dl_on);
+            if (gather && gather->feed)
+                for (int a = 0; a < 3; ++a) ssac_record_slot_patch(a, offsetof(FusedArgs, slot_now));   // ga, gt, gc
+            return ssac_check_launch("fused_chain_co");
+        }
         const dim3 grid_pc(tgx + tiles_c + cgx * critics->n_nets + dl_on);
         if (alate && tc == 16) SSAC_LAUNCH((fused_chain_pc_kernel<16, true, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
         else if (alate) SSAC_LAUNCH((fused_chain_pc_kernel<32, true, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
@@ -1961,6 +2061,12 @@ extern "C" int ssac_fused_row_tiles(const ssac_mlp *nets, int n_rows, int n_nets
     g.n_rows = n_rows; g.in_dim = nets->in_dim; g.hidden = nets->hidden; g.out_dim = nets->out_dim;
     const int tm = choose_tile(g, n_nets).tm;
     return (n_rows + tm - 1) / tm;
+}
+
+extern "C" int ssac_chain_form(int form) {
+    if (form != 0 && form != 1) return ssac_fail("ssac_chain_form: 0 (one workgroup per CU), 1 (automatic: co-resident 16-row tiles where they apply)");
+    g_chain_form = form;
+    return 0;
 }
 
 extern "C" int ssac_fused_tile_rows(int rows) {

@@ -46,6 +46,13 @@ constexpr int X_SLOTS = 4;
 constexpr int X_MAX_WORLD = 8;
 constexpr int X_THREADS = 256;
 constexpr long long X_SPIN_LIMIT = 20000000000LL;   // shader clocks (~10 s): a missing peer raises an error, never a hang
+// round 3's protocol / ack-less senders for the failing-first evidence (ssac_xchg_test_mode): LAB build only -- the product
+// kernel does not read the field
+#ifdef SSAC_LAB
+#define X_TEST_MODE(a) ((a).test_mode)
+#else
+#define X_TEST_MODE(a) 0
+#endif
 
 struct XchgArgs {
     float *peer[X_MAX_WORLD];   // every rank's receive buffer, as mapped into THIS process (peer[rank] = own buffer)
@@ -56,7 +63,7 @@ struct XchgArgs {
     int n_slots;
     int *error;                 // HOST-pinned int (device view), set to 1 when a peer's flag did not arrive in time
     int *dead;                  // device int: once a spin gave up, later exchanges fail at once instead of spinning again
-    int test_mode;              // tests only (ssac_xchg_test_mode): bit 0 = senders skip step 0, bit 1 = accept flag >= seq
+    int test_mode;              // LAB build only (ssac_xchg_test_mode): bit 0 = senders skip step 0, bit 1 = accept flag >= seq
     long long spin_limit;       // shader clocks a wait may take (X_SPIN_LIMIT; longer when the ranks time-slice ONE device)
     int n_parts, part_stride;   // > 1: element i of the payload is the SUM of n_parts partials (column-split target critics,
                                 // ssac_td_spec.n_parts): data[(slot n_parts + s) part_stride + b]; the reduction lands in
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
         for (int s_ = 1; s_ < np; ++s_) a.data[(int64_t)(j * np + s_) * a.part_stride + b] = 0.0f;
     };
     // ---- 0. slot reuse: every rank must have consumed exchange seq - X_SLOTS before its slot is written again
-    if (i_send && seq > (unsigned long long)X_SLOTS && !(a.test_mode & 1)) {
+    if (i_send && seq > (unsigned long long)X_SLOTS && !(X_TEST_MODE(a) & 1)) {
         if (tid < a.world) {
             const unsigned long long *ack = ack_of(a.peer[a.rank], a.world, tid, a.slot_floats);
             const long long t0 = __builtin_amdgcn_s_memtime();
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(X_THREADS) void xchg_kernel(XchgArgs a) {
             const unsigned long long f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (f == seq) break;
             if (f > seq) {   // the slot was LAPPED: it holds a later exchange's payload
-                if (!(a.test_mode & 2)) s_ok = 0;
+                if (!(X_TEST_MODE(a) & 2)) s_ok = 0;
                 break;
             }
             __builtin_amdgcn_s_sleep(2);
@@ -323,6 +330,10 @@ static int xchg_launch(ssac_xchg *x, float *data, int n, int op, const int32_t *
 // accept flag >= seq.  Mode 3 is the protocol of round 3; tests/test_hip_sharded.py uses 3 to show the hazard (a delayed
 // non-owner silently reduces a later update's payload) and 1 to show that the lap DETECTION (flag > seq) fires.
 extern "C" int ssac_xchg_test_mode(ssac_xchg *x, int mode) {
+#ifndef SSAC_LAB
+    // (the product library's exchange cannot be put back on round 3's unsafe protocol: the kernel does not read the field)
+    if (mode != 0) return ssac_fail("ssac_xchg_test_mode: " SSAC_LAB_REFUSAL);
+#endif
     if (!x || mode < 0 || mode > 3) return ssac_fail("ssac_xchg_test_mode: bad argument");
     x->test_mode = mode;
     return 0;

@@ -929,6 +929,23 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
     return logs, replay_dicts
 
 
+def _actor_chain_form(a_arena, A, B):
+    """does this member's online actor update take the chained launch (ssac_actor_chain_fused)?  ONE predicate for the
+    launch selection in _online_actor_update and for the recording's choice of noise source in online_actor_update: a
+    member on the three-launch form (e.g. Humanoid's 376 -> 256 -> 34 actor, whose double-buffered LDS carve does not fit)
+    reads its noise from a buffer, which a recording must own and refill before every replay.
+    (B <= 2048 = SSAC_ACTOR_CHAIN_MAX_ROWS: the chained launch's actor workgroups wait for critic tiles dispatched behind
+    them and must leave them CUs to run on)"""
+    return bool(ACTOR_CHAIN and a_arena.fused_dbuf and A <= 32 and a_arena.hidden * A <= 512 * 9 and B <= 2048)
+
+
+def _actor_noise_in_kernel(agent, batch_size, dev):
+    """recorded actor update: the noise is drawn inside the launches only if EVERY member takes the chained launch"""
+    return bool(lu.IN_KERNEL_NOISE and rng.normal_is_stock()
+                and all(_actor_chain_form(engine.bind_arena(a_, "self", [a_], dev), a_.action_size, batch_size)
+                        for a_ in agent.actors))
+
+
 class _RecordedActor:
     def __init__(self):
         self.calls, self.list, self.blk, self.eps, self.index = 0, None, None, None, None
@@ -980,9 +997,10 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
     if rec.list is None:
         rec.blk = torch.zeros(lu.LOG_WIDTH, device=dev)
         # the chained launch (ACTOR_CHAIN) with the stock generator draws its noise in the kernel: no buffers, no launches
-        rec.in_kernel = ACTOR_CHAIN and lu.IN_KERNEL_NOISE and rng.normal_is_stock()
+        # (... if every member takes it: a member on the three-launch form reads a buffer this recording must own)
+        rec.in_kernel = _actor_noise_in_kernel(agent, batch_size, dev)
         rec.eps = None if rec.in_kernel else [torch.empty(batch_size, A, device=dev) for _ in agent.actors]
-    elif rec.in_kernel != (ACTOR_CHAIN and lu.IN_KERNEL_NOISE and rng.normal_is_stock()):
+    elif rec.in_kernel != _actor_noise_in_kernel(agent, batch_size, dev):
         # a noise hook was installed / removed (or the form switched) since the recording: record again
         del cache[key]
         return online_actor_update(**kw)
@@ -1043,7 +1061,17 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             assert not use_baseline, "use_baseline is not supported on member-sharded ranks"
             if premade_replay_dicts is None:
                 lu.sample_move_and_augment(buffer=buffer, batch_size=batch_size, augmenter=augmenter, aug_mix=aug_mix, per=per)
-            lu.skip_actor_draws(agent.actors[0], batch_size, dev, random_process)
+            # (what the member's owner consumes from the device generator: nothing when its chained launch draws the noise
+            # in the kernel -- members share their shapes, so this rank's first member answers for the absent one)
+            a0_, c0_ = agent.actors[0], agent.critics[0]
+            ar0_, cr0_ = engine.bind_arena(a0_, "self", [a0_], dev), c0_.arena(dev)
+            owner_in_kernel = (FUSED_ACTOR and lu.actor_kind(a0_) == "stochastic" and random_process is None
+                               and not use_baseline and parallel.shard_of(agent) is None and not clip and ar0_.fused
+                               and cr0_.fused_dbuf and cr0_.out_dim == 1
+                               and _actor_chain_form(ar0_, a0_.action_size, batch_size)
+                               and lu.IN_KERNEL_NOISE and rng.normal_is_stock() and _rec_eps is None)
+            if not owner_in_kernel:
+                lu.skip_actor_draws(agent.actors[0], batch_size, dev, random_process)
             continue
         (actor, critic), popart, log_alpha = members[i]
         if premade_replay_dicts is not None:
@@ -1085,7 +1113,11 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             check(lib.ssac_actor_route_local(q.data_ptr(), dxu.data_ptr(), N, B, A, qloc.data_ptr(), qglob.data_ptr(),
                                              dsel.data_ptr(), st))
             parallel.all_reduce_min(qglob)
-            check(lib.ssac_actor_route_mask(qloc.data_ptr(), qglob.data_ptr(), B, A, dsel.data_ptr(), st))
+            # (bit-equal minima on two ranks: the lowest rank keeps the row, as torch.min keeps the first index)
+            claim = ws.get(f"au.claim{i}", (B,))
+            check(lib.ssac_actor_route_claim(qloc.data_ptr(), qglob.data_ptr(), B, shard.rank, claim.data_ptr(), st))
+            parallel.all_reduce_min(claim)
+            check(lib.ssac_actor_route_mask(claim.data_ptr(), shard.rank, B, A, dsel.data_ptr(), st))
             parallel.all_reduce_sum(dsel)
             tiles = int(lib.ssac_fused_row_tiles(C.byref(a_arena.desc()), B, 1))
             parts = ws.get(f"au.parts{i}", (tiles,))
@@ -1119,9 +1151,7 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             # the noise: with the stock generator the chained launch takes it from the engine's Philox stream INSIDE the
             # kernel (draw number = this update's number: no generator launch, no buffer); otherwise a draw -- into the
             # recording's fixed buffer, or a fresh one -- as a_dist.rsample() makes it (learning.py:392)
-            # (B <= 2048 = SSAC_ACTOR_CHAIN_MAX_ROWS: the chained launch's actor workgroups wait for critic tiles dispatched
-            # behind them and must leave them CUs to run on)
-            chain = ACTOR_CHAIN and a_arena.fused_dbuf and A <= 32 and H * A <= 512 * 9 and B <= 2048
+            chain = _actor_chain_form(a_arena, A, B)
             in_kernel = chain and lu.IN_KERNEL_NOISE and rng.normal_is_stock() and _rec_eps is None
             eps = None   # (kept alive to the end of the member's launches: the kernels read it asynchronously)
             if in_kernel:
@@ -1130,6 +1160,8 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
                 eps = _rec_eps[i]   # recorded update: the draw was written into a fixed buffer by the caller
                 eps_ptr = eps.data_ptr()
             else:
+                # (never inside a recording: a replay would re-read a buffer long returned to the allocator)
+                assert _rec_blk is None, "recorded actor update: the noise must come from the kernel or from the recording's buffers"
                 eps = rng.draw_normal((B, A), dev)
                 eps_ptr = eps.data_ptr()
             q = ws.get(f"au.c{i}.y", (N, B, 1))
@@ -1144,7 +1176,8 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
                 rs = None
                 if in_kernel:
                     # (its own stream: the critic updates number their draws from the same seed)
-                    rs = _lib.Rng((ns_upd[0] ^ 0x5DEECE66D1CEB00C) & (2 ** 64 - 1), 0, (i << 40) + ns_upd[2])
+                    # (the GLOBAL member index: a member-sharded rank draws its members' noise as the unsharded run does)
+                    rs = _lib.Rng((ns_upd[0] ^ 0x5DEECE66D1CEB00C) & (2 ** 64 - 1), 0, (ig << 40) + ns_upd[2])
                 fold = begin_folded and first_fused
                 check(lib.ssac_actor_chain_fused(
                     C.byref(a_arena.desc()), s_rep.data_ptr(), lds, B, eps_ptr, C.byref(rs) if rs is not None else None,

@@ -1285,15 +1285,23 @@ def test_chain_launch_equals_the_separate_launches(ssa, B, N, H):
     ids = torch.tensor([N - 1, 0], dtype=torch.int32, device=DEV)
     lib, st = ssa._lib.lib, ssa.engine.stream()
     ws = ssa.engine.Workspace(torch.device(DEV))
-    # reference sequence
-    xa, lpa = x1.clone(), torch.zeros(B, device=DEV)
-    ssa._lib.check(lib.ssac_actor_sample_fused(C.byref(aa.desc()), xa.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0,
-                                               xa.data_ptr(), S + A, S, lpa.data_ptr(), 0, 0, 0, 0, st))
-    h1, h2, q = ssa.engine.mlp_forward(ca, xc, S + A, 0, B, ws, "sep")
-    qt = torch.zeros(2, B, 1, device=DEV); dz2 = torch.zeros_like(h1); dz1 = torch.zeros_like(h1)
-    ssa._lib.check(lib.ssac_target_fwd_critic_bwdu(C.byref(ta.desc()), ids.data_ptr(), 2, xa.data_ptr(), S + A, B,
-                                                   qt.data_ptr(), C.byref(ca.desc()), h1.data_ptr(), h2.data_ptr(), 0, 0,
-                                                   dz2.data_ptr(), dz1.data_ptr(), st))
+    # reference sequence (also with 16-row tiles forced: what the co-resident form of the launch must reproduce)
+    def separate():
+        xa, lpa = x1.clone(), torch.zeros(B, device=DEV)
+        ssa._lib.check(lib.ssac_actor_sample_fused(C.byref(aa.desc()), xa.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0,
+                                                   xa.data_ptr(), S + A, S, lpa.data_ptr(), 0, 0, 0, 0, st))
+        h1, h2, q = (t.clone() for t in ssa.engine.mlp_forward(ca, xc, S + A, 0, B, ws, "sep"))
+        qt = torch.zeros(2, B, 1, device=DEV); dz2 = torch.zeros_like(h1); dz1 = torch.zeros_like(h1)
+        ssa._lib.check(lib.ssac_target_fwd_critic_bwdu(C.byref(ta.desc()), ids.data_ptr(), 2, xa.data_ptr(), S + A, B,
+                                                       qt.data_ptr(), C.byref(ca.desc()), h1.data_ptr(), h2.data_ptr(), 0, 0,
+                                                       dz2.data_ptr(), dz1.data_ptr(), st))
+        return xa, lpa, h1, h2, q, qt, dz2, dz1
+    ssa._lib.check(lib.ssac_fused_tile_rows(16))
+    try:
+        ref16 = separate()
+    finally:
+        ssa._lib.check(lib.ssac_fused_tile_rows(0))
+    xa, lpa, h1, h2, q, qt, dz2, dz1 = separate()
     # chained launch
     xb, lpb = x1.clone(), torch.zeros(B, device=DEV)
     g1, g2, gq = torch.zeros_like(h1), torch.zeros_like(h2), torch.zeros_like(q)
@@ -1308,25 +1316,36 @@ def test_chain_launch_equals_the_separate_launches(ssa, B, N, H):
     # the PRODUCER / CONSUMER form (hand-off buffer given): the actor once per tile, the target critics take a' from tagged
     # granules and add the action columns of fc1 after the state columns' sum -- everything but the target q bit for bit,
     # the target q to rounding; with 2 and 4 column splits (hidden 256) the slot's value arrives as partial sums
-    for splits in ((1, 2, 4) if H == 256 else (1,)):
-        ho = torch.zeros(B * A, dtype=torch.int64, device=DEV)
-        xp, lpp = x1.clone(), torch.zeros(B, device=DEV)
-        p1_, p2_, pq = torch.zeros_like(h1), torch.zeros_like(h2), torch.zeros_like(q)
-        pt = torch.full((2 * splits, B, 1), float("nan"), device=DEV)
-        pz2, pz1 = torch.zeros_like(dz2), torch.zeros_like(dz1)
-        for rep in range(2):   # twice: the second launch must not take the first one's granules (fresh tag)
-            if rep == 1:
-                xp.copy_(x1); pt.fill_(float("nan"))
-            ssa._lib.check(lib.ssac_chain_update(
-                C.byref(aa.desc()), xp.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0, xp.data_ptr(), S + A, S, lpp.data_ptr(),
-                0, C.byref(ta.desc()), ids.data_ptr(), 2, pt.data_ptr(), C.byref(ca.desc()), xc.data_ptr(), S + A,
-                p1_.data_ptr(), p2_.data_ptr(), pq.data_ptr(), pz2.data_ptr(), pz1.data_ptr(), 0, 0, 0, ho.data_ptr(), splits, st))
-            torch.cuda.synchronize()
-            for a_, b_, what in ((xa, xp, "a'"), (lpa, lpp, "log pi"), (h1, p1_, "h1"), (h2, p2_, "h2"), (q, pq, "q"),
-                                 (dz2, pz2, "dz2u"), (dz1, pz1, "dz1u")):
-                assert torch.equal(a_, b_), f"producer/consumer chained launch ({splits} splits, launch {rep}) differs in {what}"
-            got = pt.view(2, splits, B, 1).sum(1)
-            assert torch.isfinite(got).all() and float((got - qt).abs().max()) <= 2e-5, (splits, rep, float((got - qt).abs().max()))
+    # Round 5: the CO-RESIDENT form (ssac_chain_form(1), the default; two workgroups per CU, 16-row tiles everywhere) takes
+    # launches of 257..512 16-row tiles -- here B 512 / N 10 -- and must give the bits of the separate launches with 16-row
+    # tiles forced; ssac_chain_form(0) keeps the one-workgroup-per-CU kernel (32-row critic tiles at that shape).
+    co_applies = B == 512 and N == 10
+    for form, splits in [(0, sp) for sp in ((1, 2, 4) if H == 256 else (1,))] + [(1, 1)]:
+        ssa._lib.check(lib.ssac_chain_form(form))
+        try:
+            ho = torch.zeros(B * A, dtype=torch.int64, device=DEV)
+            xp, lpp = x1.clone(), torch.zeros(B, device=DEV)
+            p1_, p2_, pq = torch.zeros_like(h1), torch.zeros_like(h2), torch.zeros_like(q)
+            pt = torch.full((2 * splits, B, 1), float("nan"), device=DEV)
+            pz2, pz1 = torch.zeros_like(dz2), torch.zeros_like(dz1)
+            exp = ref16 if (form == 1 and co_applies) else (xa, lpa, h1, h2, q, qt, dz2, dz1)
+            for rep in range(2):   # twice: the second launch must not take the first one's granules (fresh tag)
+                if rep == 1:
+                    xp.copy_(x1); pt.fill_(float("nan"))
+                ssa._lib.check(lib.ssac_chain_update(
+                    C.byref(aa.desc()), xp.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0, xp.data_ptr(), S + A, S, lpp.data_ptr(),
+                    0, C.byref(ta.desc()), ids.data_ptr(), 2, pt.data_ptr(), C.byref(ca.desc()), xc.data_ptr(), S + A,
+                    p1_.data_ptr(), p2_.data_ptr(), pq.data_ptr(), pz2.data_ptr(), pz1.data_ptr(), 0, 0, 0, ho.data_ptr(), splits, st))
+                torch.cuda.synchronize()
+                for a_, b_, what in ((exp[0], xp, "a'"), (exp[1], lpp, "log pi"), (exp[2], p1_, "h1"), (exp[3], p2_, "h2"),
+                                     (exp[4], pq, "q"), (exp[6], pz2, "dz2u"), (exp[7], pz1, "dz1u")):
+                    assert torch.equal(a_, b_), f"producer/consumer chained launch (form {form}, {splits} splits, launch {rep}) differs in {what}"
+                got = pt.view(2, splits, B, 1).sum(1)
+                assert torch.isfinite(got).all() and float((got - exp[5]).abs().max()) <= 2e-5, (form, splits, rep, float((got - exp[5]).abs().max()))
+            if form == 1 and co_applies:   # (the 16-row and 32-row tiles sum K in different orders: the co-resident form really ran)
+                assert not torch.equal(p2_, h2)
+        finally:
+            ssa._lib.check(lib.ssac_chain_form(1))
     # ... and without the dz2u store: the launch leaves a copy of the head rows instead, from which (with h2) the
     # weight-gradient launch rebuilds dz2u = W3 (.) [h2 > 0] -- exactly the values written above
     w3s = torch.zeros(N, H, device=DEV)
@@ -1340,6 +1359,39 @@ def test_chain_launch_equals_the_separate_launches(ssa, B, N, H):
     w3 = torch.stack([ca.view(j, "w3").reshape(-1) for j in range(N)])
     assert torch.equal(w3s, w3)
     assert torch.equal(torch.where(k2 > 0, w3s[:, None, :].expand_as(k2), torch.zeros_like(k2)), gz2)
+
+
+def test_sharded_actor_routing_breaks_ties_like_torch_min(ssa):
+    """learning.py:402 takes torch.min over ALL critics: the gradient of a row goes to exactly ONE arg-min index, the first.
+    Three simulated ranks (2 critics each) with bit-equal minima planted across ranks: local route -> MIN -> claim -> MIN of
+    the claims -> mask -> SUM must equal the routing of the unsharded min, also on the tied rows (round-4 advisor: two ranks
+    that both hold the minimum doubled the gradient)."""
+    rng = np.random.RandomState(5)
+    B, A, W, NL = 300, 6, 3, 2
+    q = rng.standard_normal((W * NL, B)).astype(np.float32)
+    q[3, :40] = q[0, :40] = q[:, :40].min(0) - 1.0          # rank 0 and rank 1 tie on the global minimum
+    q[5, 40:70] = q[2, 40:70] = q[:, 40:70].min(0) - 1.0     # rank 1 and rank 2 tie
+    q[4, 70:90] = q[2, 70:90] = q[0, 70:90] = -50.0          # all three
+    dxu = rng.standard_normal((W * NL, B, A)).astype(np.float32)
+    qd, dd = torch.from_numpy(q).to(DEV), torch.from_numpy(dxu).to(DEV)
+    lib, st = ssa._lib.lib, ssa.engine.stream()
+    qloc, dsel = torch.zeros(W, B, device=DEV), torch.zeros(W, B, A, device=DEV)
+    qred = torch.zeros(W, B, device=DEV)
+    for r in range(W):
+        ssa._lib.check(lib.ssac_actor_route_local(qd[r * NL:].data_ptr(), dd[r * NL:].data_ptr(), NL, B, A, qloc[r].data_ptr(),
+                                                  qred[r].data_ptr(), dsel[r].data_ptr(), st))
+    qglob = qred.min(0).values.contiguous()                  # the MIN all-reduce
+    claim = torch.zeros(W, B, device=DEV)
+    for r in range(W):
+        ssa._lib.check(lib.ssac_actor_route_claim(qloc[r].data_ptr(), qglob.data_ptr(), B, r, claim[r].data_ptr(), st))
+    won = claim.min(0).values.contiguous()                   # the MIN all-reduce of the claims
+    for r in range(W):
+        ssa._lib.check(lib.ssac_actor_route_mask(won.data_ptr(), r, B, A, dsel[r].data_ptr(), st))
+    routed = dsel.sum(0)                                     # the SUM all-reduce
+    am = torch.from_numpy(q).min(0).indices                  # torch.min: first index on ties
+    expect = torch.from_numpy(dxu)[am, torch.arange(B)]
+    assert torch.equal(routed.cpu(), expect)
+    assert torch.equal(qglob.cpu(), torch.from_numpy(q).min(0).values)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

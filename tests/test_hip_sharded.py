@@ -179,7 +179,11 @@ def _lap_main(rank, world, port, out_dir):
     verdict = {"rank": rank, "legacy_lib": legacy_lib,
                "delayed_equal": [bool(torch.equal(a, b)) for a, b in zip(delayed, lockstep)],
                "delayed_failed_flag": bool(x.failed())}
-    if not legacy_lib:
+    # (the two protocol replays below need the LAB build, `./build.sh --lab` + SSAC_LAB_BUILD=1: the product library refuses
+    #  ssac_xchg_test_mode -- round-4 review: a production exchange must not be switchable to round 3's unsafe protocol)
+    lab = (not legacy_lib) and lib.ssac_xchg_test_mode(x.handle, 3) == 0
+    verdict["lab_build"] = bool(lab)
+    if lab:
         # (a) the round-3 protocol on today's kernel (no reuse wait, flag >= seq accepted): the hazard, demonstrated --
         # the delayed non-owner reduces LATER exchanges' payloads and nothing notices
         check(lib.ssac_xchg_test_mode(x.handle, 3))
@@ -214,7 +218,8 @@ def test_owners_only_exchange_survives_a_stalled_non_owner(tmp_path):
     False, False, False, False, False, ...], 'delayed_failed_flag': False, 'legacy_lib': True, 'rank': 2})` -- rank 2's
     results were finite, wrong and unflagged: silently wrong TD targets.  The same is reproduced in every CI run through
     `ssac_xchg_test_mode(3)` (round 3's protocol on today's kernel), and `ssac_xchg_test_mode(1)` shows that a lap,
-    should one ever happen again, is detected by the receiver (flag > seq: NaN-poisoned result + error word)."""
+    should one ever happen again, is detected by the receiver (flag > seq: NaN-poisoned result + error word) -- both in
+    the LAB build only (`SSAC_LAB_BUILD=1 pytest ...` after `./build.sh --lab`); the product library refuses the switch."""
     import json
     world = 3
     port = 30300 + (os.getpid() % 2000)
@@ -223,8 +228,8 @@ def test_owners_only_exchange_survives_a_stalled_non_owner(tmp_path):
     for r in range(world):
         assert all(v[r]["delayed_equal"]), (r, v[r])
         assert not v[r]["delayed_failed_flag"], (r, v[r])
-    if v[2]["legacy_lib"]:
-        return
+    if v[2]["legacy_lib"] or not v[2]["lab_build"]:
+        return   # (product library: the replays of round 3's protocol are refused; profiles/r4_xchg_lap_evidence.md holds them)
     # round 3's protocol: the stalled rank is silently wrong in most rounds (only the last X_SLOTS survive in the ring)
     assert sum(not e for e in v[2]["r3_protocol_equal"]) >= LAP_ROUNDS - 4, v[2]
     assert v[2]["r3_protocol_finite"] and not v[2]["r3_protocol_failed_flag"], v[2]

@@ -21,6 +21,8 @@ if os.environ.get("SSAC_SLOT_BY_VALUE"):   # A/B: replayed launches find their i
     ssa._lib.lib.ssac_slot_by_value(int(os.environ["SSAC_SLOT_BY_VALUE"]))
 if os.environ.get("SSAC_WGRAD_VARIANT"):   # A/B of the weight-gradient launch's forms (tools only)
     ssa.engine.set_wgrad_variant(int(os.environ["SSAC_WGRAD_VARIANT"]))
+if os.environ.get("SSAC_CHAIN_FORM"):   # A/B: one workgroup per CU (0) / co-resident 16-row tiles where they apply (1) (tools only)
+    ssa._lib.check(ssa._lib.lib.ssac_chain_form(int(os.environ["SSAC_CHAIN_FORM"])))
 
 dev = torch.device("cuda")
 

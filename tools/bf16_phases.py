@@ -2,6 +2,7 @@
 s_memtime phase stamps inside the bf16 chain / weight-gradient launches (eager launches, tile 0 of each role)
     python tools/bf16_phases.py [B] [N]"""
 import os, sys
+os.environ.setdefault("SSAC_LAB_BUILD", "1")   # the lab library (./build.sh --lab -> libssac_hip_lab.so)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.argv, args = sys.argv[:1] + ["__none__"], sys.argv[1:]
 import importlib.util

@@ -1,5 +1,6 @@
 """phase stamps of critic workgroup (0,0) inside the merged actor + critic-forward launch vs the stand-alone forward"""
 import ctypes as C, os, sys
+os.environ.setdefault("SSAC_LAB_BUILD", "1")   # the lab library (./build.sh --lab -> libssac_hip_lab.so)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import super_sac_amd as ssa

@@ -1,6 +1,7 @@
 """(needs the LAB build of the library: ./build.sh --lab)
 phase timing (shader clocks) inside the fused MLP kernel, workgroup (0,0)"""
 import ctypes as C, os, sys
+os.environ.setdefault("SSAC_LAB_BUILD", "1")   # the lab library (./build.sh --lab -> libssac_hip_lab.so)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 import numpy as np, torch

@@ -2,6 +2,7 @@
 Phase stamps (s_memtime) of fc2 tile (0, 0, 0) of the LATENCY form of the weight-gradient launch:
     python tools/small_phases.py [obs] [act] [B] [N]"""
 import os, sys
+os.environ.setdefault("SSAC_LAB_BUILD", "1")   # the lab library (./build.sh --lab -> libssac_hip_lab.so)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.argv, args = sys.argv[:1] + ["__none__"], sys.argv[1:]
 import importlib.util

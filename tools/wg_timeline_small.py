@@ -2,6 +2,7 @@
 Per-workgroup (start, end) of the two launches of a critic update for UNDER-FILLED configurations (the latency form
 of the weight-gradient launch: 32 x 32 tiles):      python tools/wg_timeline_small.py [obs] [act] [B] [N]"""
 import os, sys
+os.environ.setdefault("SSAC_LAB_BUILD", "1")   # the lab library (./build.sh --lab -> libssac_hip_lab.so)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.argv, args = sys.argv[:1] + ["__none__"], sys.argv[1:]
 import importlib.util

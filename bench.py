@@ -1,6 +1,6 @@
 """Headline benchmark: gradient updates/sec of the REDQ critic update (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats R]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats R] [--critics N] [--obs S] [--act A] [--batch B]
 
 One "step" = one ``learning.critic_update`` call on a synthetic replay batch (obs 17, act 6, batch 512, N=10 critics,
 n=2 target subset, hidden 256, fp32 -- the shape the metric is quoted on) followed, every ``target_delay``=2 updates,
@@ -9,6 +9,10 @@ buffer (100k transitions) is resident in HBM before the timed region starts; the
 (index draw from the torch CPU generator, REDQ subset draw, a 4 KB index upload) is part of the path and is inside the
 timed region.  After W untimed warm-up steps, EXACTLY K steps are timed between barrier + synchronize brackets; this is
 done R times (default 5) and the MEDIAN repeat is reported (``value`` = K / median seconds).
+
+--critics / --obs / --act / --batch (defaults 10 / 17 / 6 / 512 = the headline) select another ensemble: `--gpus 8
+--critics 16` is the configuration BASELINE.json's scaling target is quoted on (N = 16 critics over 8 GPUs), `--obs 376
+--act 17 --critics 16` its Humanoid shape (config 5); the metric name and `config.workload` say what was run.
 
 N > 1: one process per GPU.  Launched by ``torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE in the environment)
 the process is one rank; from a bare shell (``python bench.py --gpus N``) the parent -- which never touches the GPU --
@@ -51,7 +55,9 @@ def synth_data(obs=OBS, act=ACT):
     return synth.synth_transitions(ROWS, obs, act, seed=1)
 
 
-def build_engine(device, n_local, shard=None, batch=BATCH, precision="fp32"):
+def build_engine(device, n_local, shard=None, batch=None, precision="fp32", obs=None, act=None, ncrit=None):
+    """(obs / act / ncrit / batch default to the module's OBS / ACT / NCRIT / BATCH, i.e. the headline unless main() was given
+    --obs / --act / --critics / --batch)"""
     import numpy as np
     import torch
     import super_sac_amd as ssa
@@ -59,13 +65,15 @@ def build_engine(device, n_local, shard=None, batch=BATCH, precision="fp32"):
     np.random.seed(0)
     import random
     random.seed(0)
+    OBS_, ACT_, NCRIT_ = OBS if obs is None else obs, ACT if act is None else act, NCRIT if ncrit is None else ncrit
+    batch = BATCH if batch is None else batch
     def make(n):
-        return ssa.Agent(act_space_size=ACT, encoder=ssa.nets.IdentityEncoder(OBS),
+        return ssa.Agent(act_space_size=ACT_, encoder=ssa.nets.IdentityEncoder(OBS_),
                          actor_network_cls=ssa.nets.ContinuousStochasticActor,
                          critic_network_cls=ssa.nets.ContinuousCritic, discrete=False, ensemble_size=1,
                          num_critics=n, ucb_bonus=0.0, hidden_size=HID, auto_rescale_targets=False,
                          log_std_low=-5.0, log_std_high=2.0)
-    agent = make(NCRIT if shard is not None else n_local)
+    agent = make(NCRIT_ if shard is not None else n_local)
     if shard is not None:
         # a rank of the sharded job holds critics [lo, hi) of THE SAME seeded ensemble the unsharded engine holds
         # (so a sharded run can be checked against it value by value), the replicated actor included
@@ -79,7 +87,7 @@ def build_engine(device, n_local, shard=None, batch=BATCH, precision="fp32"):
     ssa.set_precision(agent, precision)
     target = copy.deepcopy(agent)
     buf = ssa.replay.ReplayBuffer(CAP, device=device)
-    buf.load_experience(*synth_data())
+    buf.load_experience(*synth_data(OBS_, ACT_))
     copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=LR, betas=(0.9, 0.999))
     aopt = torch.optim.Adam(chain(*(a.parameters() for a in agent.actors)), lr=LR, betas=(0.9, 0.999))
     eopt = torch.optim.Adam(agent.encoder.parameters(), lr=1e-4)
@@ -120,7 +128,7 @@ def build_engine(device, n_local, shard=None, batch=BATCH, precision="fp32"):
                                          batch_size=batch, clip=None, random_process=None, noise_clip=None,
                                          augmenter=aug, aug_mix=0.0, premade_replay_dicts=dicts)
         ssa.learning.alpha_update(buffer=buf, agent=agent, optimizers=[lopt], batch_size=batch, log_alphas=[la],
-                                  augmenter=aug, aug_mix=0.0, target_entropy=-float(ACT), premade_replay_dicts=dicts,
+                                  augmenter=aug, aug_mix=0.0, target_entropy=-float(ACT_), premade_replay_dicts=dicts,
                                   discrete=False)
     # (tests/test_hip_bench_bridge.py drives this very closure and compares it with the oracle)
     step.objects = dict(agent=agent, target=target, buffer=buf, critic_optimizer=copt, log_alpha=la, state=state)
@@ -250,7 +258,8 @@ def launch_ranks(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps),
-               "--warmup", str(args.warmup), "--repeats", str(args.repeats)]
+               "--warmup", str(args.warmup), "--repeats", str(args.repeats), "--critics", str(args.critics),
+               "--obs", str(args.obs), "--act", str(args.act), "--batch", str(args.batch)]
         if args.no_cpu_baseline:
             cmd.append("--no-cpu-baseline")
         if args.no_secondary:
@@ -294,7 +303,13 @@ def main():
     ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--critics", type=int, default=NCRIT, help="ensemble size N (16: the scaling target's configuration)")
+    ap.add_argument("--obs", type=int, default=OBS, help="observation size (376: Humanoid, BASELINE config 5)")
+    ap.add_argument("--act", type=int, default=ACT, help="action size (17: Humanoid)")
+    ap.add_argument("--batch", type=int, default=BATCH)
     args = ap.parse_args()
+    headline = (args.critics, args.obs, args.act, args.batch) == (10, 17, 6, 512)
+    globals().update(NCRIT=args.critics, OBS=args.obs, ACT=args.act, BATCH=args.batch)   # (read by every helper below)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)   # (does not return)
 
@@ -429,7 +444,7 @@ def main():
         flops, kname = f_fwd + f_bwd, "fused_mlp_kernel<critic>: forward + loss gradient + backward-data, ONE launch"
     avg_ms = sum(ms) / len(ms)
     achieved = flops / (avg_ms * 1e-3) / 1e12
-    single = world == 1 and n_local == NCRIT and "chain" in by_tag
+    single = world == 1 and n_local == NCRIT and "chain" in by_tag and headline
     roofline = {"kernel": kname, "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                 "avg_launch_us": round(avg_ms * 1e3, 3), "launches_timed": len(ms),
@@ -440,13 +455,13 @@ def main():
                 "traffic_source": TRAFFIC_SOURCE if single else None}
 
     if rank == 0:
-        out = {"metric": "gradient updates/sec (REDQ N=10, batch 512)", "value": round(args.steps / dt, 2),
+        out = {"metric": f"gradient updates/sec (REDQ N={NCRIT}, batch {BATCH})", "value": round(args.steps / dt, 2),
                "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 5), "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "repeats": args.repeats, "repeat_ms_per_step": [round(1e3 * t / args.steps, 5) for t in times],
-               "config": {"workload": "REDQ critic_update + Polyak/2: obs 17, act 6, batch 512, "
-                                      "N=10 critics (n=2 target subset), hidden 256, replay 100k rows in HBM",
+               "config": {"workload": f"REDQ critic_update + Polyak/2: obs {OBS}, act {ACT}, batch {BATCH}, "
+                                      f"N={NCRIT} critics (n=2 target subset), hidden 256, replay 100k rows in HBM",
                           "global_batch": BATCH, "num_critics": NCRIT,
                           "launch": "recorded launch list, one C call per update (ssac_step_run)"
                                     if graphs_were_on else "plain launches",

@@ -716,10 +716,10 @@ int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t ldxa, int 
  * target_splits columns of fc2 from register-resident weight fragments and a PARTIAL head dot product; Qt is then
  * (n_sel x target_splits x n_rows), to be read through an ssac_td_spec with n_parts = target_splits. */
 int ssac_chain_target_splits(const ssac_mlp *actor, const ssac_mlp *targets, const ssac_mlp *critics, int n_rows, int n_sel);
-/* Form of the producer / consumer launch (round 5): 1 (default) = automatic -- when 16-row tiles of the three roles are
- * more than 256 but at most 512 workgroups and every role's co-resident LDS carve fits 80 KB, the launch runs TWO
- * workgroups per CU (16-row tiles, <= 128 VGPRs; one tile's prologue / epilogues / stores hide under its neighbour's K
- * loop); 0 = always one workgroup per CU.  Outputs are bit-identical to the 16-row tiles of the one-per-CU form
+/* Form of the producer / consumer launch (round 5): 1 = when 16-row tiles of the three roles are more than 256 but at
+ * most 512 workgroups and every role's co-resident LDS carve fits 80 KB, the launch runs TWO workgroups per CU (16-row
+ * tiles, <= 128 VGPRs; one tile's prologue / epilogues / stores hide under its neighbour's K loop); 0 = always one
+ * workgroup per CU; -1 = the library's default.  Outputs are bit-identical to the 16-row tiles of the one-per-CU form
  * (ssac_fused_tile_rows(16)); against its 32-row tiles they differ by fp32 association of the K sums. */
 int ssac_chain_form(int form);
 

@@ -47,6 +47,7 @@ constexpr int WS_LD = 36;             // K-contiguous staging row stride: 16-byt
 constexpr int WS_FLOATS = 256 * WS_LD;  // weight staging buffer (>= 32*256 for the row-contiguous image)
 constexpr int APAD = 4;               // activation rows are padded by 4 floats (16-byte aligned rows)
 constexpr int MAX_OUT = 16;   // head outputs per MFMA pass (one 16-wide B tile)
+constexpr int CO_SCRATCH = 8 * 16 * 16;   // co-resident carve: the K-split partial head tiles [8 waves][16 rows][16] are all that "Ws" holds
 constexpr int HEAD_MAX = 64;  // widest head the fused kernels take (several passes)
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 constexpr float LOG_2 = 0.69314718055994530942f;
@@ -450,6 +451,140 @@ __device__ __forceinline__ void gemm_tile(typename Tile<TMR>::Acc &acc, Stage &s
     lds_barrier();  // all fragment reads done before the caller reuses As / the staging buffers
 }
 
+// ---------------------------------------------------------------------------------------------
+// The K loop of the CO-RESIDENT carve (16-row tiles, two workgroups per CU; round 5): the weight fragments go STRAIGHT
+// from L2 into the MFMA operand registers -- no LDS image of the weights, no staging stores, NO barrier inside the loop.
+// Measured first (profiles/r5_chain_coresident.md): with LDS-staged weights two co-resident 16-row tiles cost MORE than one
+// 32-row tile (35 vs 30 us per launch) -- per 32 rows they stage every weight chunk twice, read 1.5 x the fragments and
+// hit twice the barriers, and without the MFMAs AND without the weight loads the pair still took 49 k clocks: the LDS /
+// barrier skeleton, not L2 streaming and not the matrix pipe, was what two tiles on a CU competed for.  Here a wave's
+// only LDS traffic in the loop is its activation fragment (2 x ds_read_b128 per chunk); its 32 columns' weights are 4
+// (forward: 16 bytes, K-contiguous rows) or 16 (backward-data: dwords down a column block) global loads per chunk,
+// requested one chunk ahead, the next PHASE's first chunk during the last one -- with 4 waves per SIMD from two
+// independent workgroups the L2 round trip hides under the other waves' MFMAs.
+// Same fragments, same MFMA order as Tile<16>: bit-identical to the LDS-staged 16-row tiles.
+// ---------------------------------------------------------------------------------------------
+template <bool NN>
+struct DirectW {
+    // NN = false: W is (Nw x K), K contiguous: lane (li, lg) reads W[col0 + 16u + li][32c + 8lg .. + 8) -- two 16-byte global
+    //   loads per column sub-tile u through a per-lane pointer (2 address pairs in all).
+    // NN = true : W is (K x Nw), rows contiguous: lane reads W[32c + 8lg + t][col0 + 16u + li], t = 0..7 -- 16 dword loads per
+    //   chunk.  As flat loads with 64-bit lane addresses they held 16 address pairs (32 VGPRs: spills at the 128-VGPR budget
+    //   of two workgroups per CU), so they are BUFFER loads: one descriptor in SGPRs (wave-uniform base), ONE 32-bit byte
+    //   offset per lane and sub-tile, the row as a scalar offset (wgrad_small_pair_kernel's idiom, ssac_gemm.hip).
+    //   (This toolchain lowers __builtin_amdgcn_raw_buffer_load_b128 / _b64 to a ONE-dword load whose value is replicated --
+    //   checked in the ISA -- so the forward form cannot use the descriptor path for its 16-byte loads.)
+    // Columns beyond the layer width read column / row 0: they only reach accumulator columns nobody reads.
+    const float *p[2];
+    __amdgpu_buffer_rsrc_t r;
+    int off[2];          // NN: byte offset of this lane's first element of chunk 0, column sub-tiles u = 0, 1
+    uint32_t ld4;        // NN: row stride in bytes (uniform)
+    __device__ __forceinline__ void init(const float *W, int ldw, int Nw, int col0, int lane) {
+        const int li = lane & 15, lg = lane >> 4;
+        if (NN) {
+            // (readfirstlane returns a SIGNED int: each half goes through uint32_t, or a base whose bit 31 is set comes back
+            // sign-extended -- 0xffffffff in the upper word, a memory access fault on every other allocation layout)
+            const uint64_t ub = (uint64_t)(uintptr_t)W;
+            const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ub);
+            const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ub >> 32));
+            void *base = (void *)(uintptr_t)(((uint64_t)bhi << 32) | (uint64_t)blo);
+            r = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7ffffffc, 0x00020000);
+            ld4 = 4u * (uint32_t)__builtin_amdgcn_readfirstlane(ldw);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int n = col0 + 16 * u + li;
+            const uint32_t nn = n < Nw ? (uint32_t)n : 0u;
+            if (NN) off[u] = (int)((uint32_t)(lg * 8) * ld4 + 4u * nn);
+            else p[u] = W + (int64_t)nn * ldw + lg * 8;
+        }
+    }
+    // chunk c (32 k values).  A ragged last chunk of the forward form (K % 32 != 0: fc1) reads up to 31 floats past the
+    // row's end -- the next rows / the bias of the same parameter arena, finite values that meet the zero padding of the
+    // activation tile in the MFMA.
+    __device__ __forceinline__ void load(float (&v)[2][8], int c) const {
+#if defined(SSAC_LAB) && defined(SSAC_EXP_NO_WLOAD)
+        if (c > 0) return;   // (experiment build: only a phase's first chunk is ever fetched)
+#endif
+#if defined(SSAC_LAB) && defined(SSAC_EXP_NO_NN)
+        if (NN) return;
+#endif
+#if defined(SSAC_LAB) && defined(SSAC_EXP_NO_FWD)
+        if (!NN) return;
+#endif
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (NN) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    v[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off[u], (int)((uint32_t)(c * 32 + t) * ld4), 0));
+            } else {
+                const f4 x0 = *reinterpret_cast<const f4u *>(p[u] + c * 32), x1 = *reinterpret_cast<const f4u *>(p[u] + c * 32 + 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[u][i] = x0[i]; v[u][4 + i] = x1[i]; }
+            }
+        }
+    }
+};
+struct NoDirect {
+    __device__ __forceinline__ void load(float (&)[2][8], int) const {}
+};
+
+__device__ __forceinline__ void direct_chunk16(Tile<16>::Acc &acc, const float (&b)[2][8], const float *As, int lda, int c, int lane) {
+    const int li = lane & 15, lg = lane >> 4;
+    const f4 *ap = reinterpret_cast<const f4 *>(As + li * lda + c * 32 + lg * 8);
+    const f4 a0 = ap[0], a1 = ap[1];
+#if defined(SSAC_LAB) && defined(SSAC_EXP_NO_MFMA)
+    acc.v[0][0] += a0[0] + b[0][0] + b[1][7] + a1[3];
+    return;
+#endif
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            acc.v[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[u][t], t < 4 ? a0[t & 3] : a1[t & 3], acc.v[u], 0, 0, 0);
+}
+
+// b0: chunk 0 of W, already requested by the caller.  nb: receives chunk 0 of the NEXT phase's weights (nx), requested
+// while the last chunk multiplies.  Ends with a barrier: every wave is done reading As.
+template <bool NN, typename Next>
+__device__ __forceinline__ void gemm_direct16(Tile<16>::Acc &acc, const DirectW<NN> &w, float (&b0)[2][8], const float *As,
+                                              int lda, int K, int lane, const Next &nx, float (&nb)[2][8]) {
+    const int nch = (K + 31) >> 5;
+    // TWO chunks in flight ahead of the one that multiplies (three register sets): with one, a wave's 4 KB per chunk x 16
+    // waves per CU is 64 KB in flight against a ~2 k-clock loaded L2 round trip, i.e. ~32 B/clk per CU -- the K loop ran at
+    // the load rate, not at the MFMA rate (fc2 of a 16-row tile 24 k clocks against a floor of 8.2 k / 16.4 k shared).
+    float b1[2][8], b2[2][8];
+    if (nch > 1) w.load(b1, 1);
+    int c = 0;
+    for (; c + 3 < nch; c += 3) {   // steady state (chunks up to c + 3 + 1 exist or are guarded below)
+        w.load(b2, c + 2);
+        direct_chunk16(acc, b0, As, lda, c, lane);
+        w.load(b0, c + 3);
+        direct_chunk16(acc, b1, As, lda, c + 1, lane);
+        if (c + 4 < nch) w.load(b1, c + 4);
+        direct_chunk16(acc, b2, As, lda, c + 2, lane);
+    }
+    // tail: 1, 2 or 3 chunks left; b0 holds chunk c, b1 chunk c + 1 (if it exists) -- the next phase's first chunk goes in
+    // flight as early as a register set is free
+    const int left = nch - c;
+    if (left == 3) {
+        w.load(b2, c + 2);
+        direct_chunk16(acc, b0, As, lda, c, lane);
+        nx.load(nb, 0);
+        direct_chunk16(acc, b1, As, lda, c + 1, lane);
+        direct_chunk16(acc, b2, As, lda, c + 2, lane);
+    } else if (left == 2) {
+        nx.load(nb, 0);
+        direct_chunk16(acc, b0, As, lda, c, lane);
+        direct_chunk16(acc, b1, As, lda, c + 1, lane);
+    } else {
+        nx.load(nb, 0);
+        direct_chunk16(acc, b0, As, lda, c, lane);
+    }
+    lds_barrier();
+}
+
 // W3 (OUT x H, rows contiguous) -> LDS rows of stride ldw3.  Four independent loads are issued before the
 // first LDS store, so the copy costs one global round trip instead of one per head row.
 __device__ __forceinline__ void stage_head_weights(float *w3s, const float *__restrict__ W3, int OUT, int H,
@@ -515,7 +650,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     float *h2s = CO ? h1s : h1s + TMR * ldh;   // [TMR][H+4]  (CO: in h1's place)
     float *Ws = h2s + TMR * ldh;            // staging buffer 0
     float *Ws1 = Ws + WS_FLOATS;            // staging buffer 1 (DBUF only)
-    float *ys = Ws + (DBUF ? 2 : 1) * WS_FLOATS;  // [TMR][ldo], ldo = out_dim rounded up to 16
+    float *ys = Ws + (CO ? CO_SCRATCH : (DBUF ? 2 : 1) * WS_FLOATS);  // [TMR][ldo], ldo = out_dim rounded up to 16  (CO: no weight image, Ws is scratch)
     float *dqs = ys + TMR * ldo;            // [TMR][ldo]
     float *rowred = dqs + TMR * ldo;        // [64]
     // small operands fetched at kernel start, so later phases never begin with a global round trip:
@@ -580,6 +715,10 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     KcStage st1, st2;
     RcStage st3;
     NoStage none;
+    DirectW<false> d1, d2;   // CO: weight fragments straight from memory (gemm_direct16)
+    DirectW<true> d3;
+    NoDirect nodirect;
+    float bq1[2][8], bq2[2][8], bq3[2][8];   // CO: the first weight chunk of fc1 / fc2 / backward-data, requested a phase ahead
     constexpr bool UNSCALED = MODE == MODE_CRITIC_BWDU || MODE == MODE_CRITIC_U;
     constexpr bool ACTOR = MODE == MODE_ACTOR_BWD;
     constexpr bool BWD_ONLY = MODE == MODE_CRITIC_BWD || MODE == MODE_CRITIC_BWDU || ACTOR;
@@ -633,9 +772,15 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
             }
     } else {
         // ---- first weight chunk of fc1 in flight before anything else
-        st1.init(P + g.off[0], IN, H, tid);
-        st1.load(0, IN);
-        st2.init(P + g.off[2], H, H, tid);
+        if constexpr (CO) {
+            d1.init(P + g.off[0], IN, H, col0, lane);
+            d2.init(P + g.off[2], H, H, col0, lane);
+            d1.load(bq1, 0);
+        } else {
+            st1.init(P + g.off[0], IN, H, tid);
+            st1.load(0, IN);
+            st2.init(P + g.off[2], H, H, tid);
+        }
         // ---- Every global load of the prologue is issued before the first LDS store, so the prologue costs one
         //      round trip (two with the replay gather: index, then row) instead of one per operand: biases, head
         //      weights (first 4 per thread), the x tile's first 32 columns.  Wider inputs / heads loop afterwards.
@@ -801,7 +946,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
             }
             rowin[2 * TMR + tid] = (ok && OUT > 1) ? g.act[b * g.ld_a] : 0.0f;
         }
-        stage_first(st1, Ws, IN, tid);
+        if constexpr (!CO) stage_first(st1, Ws, IN, tid);
         // (every barrier of this body hands data over through LDS only, so it does not drain vmcnt: the activation
         // tiles written out for the weight-gradient launch, the gathered rows and the next phase's prefetched weight
         // chunk stay in flight across the phase boundaries.  The one global write -> read inside a workgroup, a' of
@@ -811,10 +956,15 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         BSTAMP(1);
         // ---- fc1 (fc2's first weight chunk is requested during its last K chunk)
         T::zero(acc);
-        gemm_tile<TMR, false, DBUF>(acc, st1, xs, ldx_s, IN, Ws, Ws1, tid, col0, st2, H);
+        if constexpr (CO) {
+            gemm_direct16<false>(acc, d1, bq1, xs, ldx_s, IN, lane, d2, bq2);
+            if (FWD_BWD) d3.init(P + g.off[2], H, H, col0, lane);
+        } else {
+            gemm_tile<TMR, false, DBUF>(acc, st1, xs, ldx_s, IN, Ws, Ws1, tid, col0, st2, H);
+        }
         BSTAMP(2);
-        if (NSPL == 1) stage_first(st2, Ws, H, tid);
-        if (FWD_BWD) st3.init(P + g.off[2], H, H, tid);
+        if (NSPL == 1 && !CO) stage_first(st2, Ws, H, tid);
+        if (FWD_BWD && !CO) st3.init(P + g.off[2], H, H, tid);
         float *wa = CO ? wa_co : Ws1, *as_ = ys;   // (consumer) W1[:, S:S+A] as [H][A]; a' of the tile as [TMR][32] (ys | dqs: free until the head)
         if (CONS) {
             const int A_ = g.ho.A, na = H * A_;
@@ -914,8 +1064,13 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
                 w3r[u] = (u * NTHR < n3) ? W3[i3 < n3 ? i3 : 0] : 0.0f;
             }
         }
-        if (FWD_BWD) gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, st3, H);
-        else gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, none, 0);
+        if constexpr (CO) {
+            if (FWD_BWD) gemm_direct16<false>(acc, d2, bq2, h1s, ldh, H, lane, d3, bq3);
+            else gemm_direct16<false>(acc, d2, bq2, h1s, ldh, H, lane, nodirect, bq3);
+        } else {
+            if (FWD_BWD) gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, st3, H);
+            else gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, none, 0);
+        }
         if (W3LATE) {   // (gemm_tile ended with a barrier: nobody reads the staging buffers any more; visible to the head
                         //  behind the barrier that follows the fc2 epilogue)
 #pragma unroll
@@ -1034,7 +1189,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     BSTAMP(7);
     if (MODE == MODE_PLAIN) return;
     lds_barrier();  // hpart (= staging buffer 0) has been consumed
-    if (IS_CRITIC) stage_first(st3, Ws, H, tid);
+    if (IS_CRITIC && !CO) stage_first(st3, Ws, H, tid);
 
     if (MODE == MODE_SAMPLE) {
         // tanh-normal head: one thread per row
@@ -1211,7 +1366,8 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         // ---- backward-data of fc2: dz1 = (dz2 W2) (.) [h1 > 0]
         lds_barrier();  // dz2 (in h2s) and the staged first chunk of W2 are visible
         T::zero(acc);
-        gemm_tile<TMR, true, DBUF>(acc, st3, h2s, ldh, H, Ws, Ws1, tid, col0, none, 0);
+        if constexpr (CO) gemm_direct16<true>(acc, d3, bq3, h2s, ldh, H, lane, nodirect, bq1);
+        else gemm_tile<TMR, true, DBUF>(acc, st3, h2s, ldh, H, Ws, Ws1, tid, col0, none, 0);
         BSTAMP(10);
         const bool want_dx = MODE == MODE_CRITIC_U && g.DXU != nullptr;
         int m1r = 0;
@@ -1443,15 +1599,27 @@ void fused_chain_co_kernel(FusedArgs ga, FusedArgs gt, FusedArgs gc, int tiles_a
         return;
     }
     const int n_main = (int)gridDim.x - (dl_on ? 1 : 0), n_crit = n_main - tiles_a - tiles_t;
-    const int t_lo = tiles_a, t_hi = t_lo + tiles_t;   // producers, consumers, critic tiles
-    if (bid < tiles_a) {
-        fused_mlp_body<MODE_SAMPLE, 16, false, false, false, true>(ga, smem, ssac_xcd_contiguous_range(bid, 0, tiles_a, gc.xcd), 0, tiles_a, 0);
-    } else if (bid < t_hi) {
+    // Workgroup ids: [critic tiles, first part][producers][consumers][critic tiles, rest].  The dispatcher hands out first
+    // slots CU by CU and then second slots in the same CU order: with 256 - (producers + consumers) critic tiles in front, the
+    // actor -> target-critic chain (ONE dependent chain that must end before the launch does) gets CUs of its own and the
+    // tiles of the second round double up on critic CUs.  (Every workgroup of the launch is resident at once -- <= 512
+    // at two per CU, checked by the launcher -- so the producers need not hold the lowest ids here.)
+    int c_first = 256 - tiles_a - tiles_t;
+    c_first = c_first < 0 ? 0 : (c_first > n_crit ? n_crit : c_first);
+    const int p_lo = c_first, t_lo = p_lo + tiles_a, t_hi = t_lo + tiles_t;
+#if !(defined(SSAC_LAB) && defined(SSAC_EXP_NO_PRIO))
+    if (bid >= p_lo && bid < t_hi) __builtin_amdgcn_s_setprio(3);
+#endif
+    if (bid >= p_lo && bid < t_lo) {
+        fused_mlp_body<MODE_SAMPLE, 16, false, false, false, true>(ga, smem, ssac_xcd_contiguous_range(bid, p_lo, t_lo, gc.xcd), 0, tiles_a, 0);
+    } else if (bid >= t_lo && bid < t_hi) {
         const int lb = ssac_xcd_contiguous_range(bid, t_lo, t_hi, gc.xcd);
         const int j = lb / target_grid_x, bx = lb - j * target_grid_x;
         fused_mlp_body<MODE_PLAIN, 16, false, true, false, true>(gt, smem, bx, j, target_grid_x, j == 0 ? 16 : -1, 0);
     } else {
-        const int L = ssac_xcd_contiguous_range(bid, t_hi, t_hi + n_crit, gc.xcd);
+        // critic tiles: logical ids [0, c_first) in front of the chain's workgroups, [c_first, n_crit) behind
+        const int L = bid < p_lo ? ssac_xcd_contiguous_range(bid, 0, c_first, gc.xcd)
+                                 : c_first + ssac_xcd_contiguous_range(bid, t_hi, t_hi + (n_crit - c_first), gc.xcd);
         fused_mlp_body<MODE_CRITIC_U, 16, false, false, false, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x, 32);
     }
 #ifdef SSAC_LAB
@@ -1461,6 +1629,21 @@ void fused_chain_co_kernel(FusedArgs ga, FusedArgs gt, FusedArgs gc, int tiles_a
     }
 #endif
 }
+
+#ifdef SSAC_VGPR_PROBE   // (register budget of each role of fused_chain_co_kernel on its own: hipcc -DSSAC_VGPR_PROBE -S)
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))) void probe_co_producer(FusedArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    fused_mlp_body<MODE_SAMPLE, 16, false, false, false, true>(g, smem, blockIdx.x, 0, gridDim.x, 0);
+}
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))) void probe_co_consumer(FusedArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    fused_mlp_body<MODE_PLAIN, 16, false, true, false, true>(g, smem, blockIdx.x, 0, gridDim.x, -1, 0);
+}
+__global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))) void probe_co_critic(FusedArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    fused_mlp_body<MODE_CRITIC_U, 16, false, false, false, true>(g, smem, blockIdx.x, 0, gridDim.x, 32);
+}
+#endif
 
 // The online actor update's three dependent passes as ONE launch (round 4).  Stand-alone they are
 // actor forward + rsample (32 workgroups, ~15 us), every critic's forward + dQ/da (~35 us), arg-min routing + tanh-normal
@@ -1491,14 +1674,15 @@ void fused_actor_chain_kernel(FusedArgs ga, FusedArgs gb, FusedArgs gc, int tile
 long long *g_fused_dbg = nullptr;
 
 int g_tile_rows = 0;  // 0 = automatic, else 16 or 32 (ssac_fused_tile_rows)
-int g_chain_form = 1;  // ssac_chain_form: 0 = one workgroup per CU (fused_chain_pc_kernel), 1 = automatic (the co-resident form where it applies)
+constexpr int CHAIN_FORM_DEFAULT = 0;
+int g_chain_form = CHAIN_FORM_DEFAULT;  // ssac_chain_form: 0 = one workgroup per CU (fused_chain_pc_kernel), 1 = the co-resident form where it applies
 
 // co: the co-resident carve (one activation tile instead of two); cons_wa: floats of W1's action columns a CO consumer parks
 size_t fused_lds_bytes(int in_dim, int hidden, int out_dim, int tm = TM, bool dbuf = true, bool w3_late = false,
                        bool co = false, int cons_wa = 0) {
     const int KP = (in_dim + 31) & ~31;
     return sizeof(float) * ((size_t)tm * (KP + APAD) + (co ? 1 : 2) * (size_t)tm * (hidden + APAD) +
-                            (dbuf ? 2 : 1) * WS_FLOATS + 2 * tm * ((out_dim + 15) & ~15) + 64 +
+                            (co ? CO_SCRATCH : (dbuf ? 2 : 1) * WS_FLOATS) + 2 * tm * ((out_dim + 15) & ~15) + 64 +
                             2 * hidden + HEAD_MAX + (w3_late ? 0 : (size_t)out_dim * (hidden + APAD)) + 3 * tm + cons_wa);
 }
 
@@ -1860,6 +2044,9 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
                 co_attr = true;
             }
             const dim3 grid_co(tgx + tiles_t + tgx * critics->n_nets + dl_on);
+#if defined(SSAC_LAB) && defined(SSAC_EXP_NO_STORE)
+            gc.H1 = gc.H2 = gc.DZ1 = gc.DZ2 = gc.Y = gc.W3S = nullptr;   // (experiment build: the critic tiles store nothing)
+#endif
             SSAC_LAUNCH(fused_chain_co_kernel, grid_co, dim3(NTHR), co_lds, st, ga, gt, gc, tgx, tiles_t, tgx, tgx, dl, dl_on);
             if (gather && gather->feed)
                 for (int a = 0; a < 3; ++a) ssac_record_slot_patch(a, offsetof(FusedArgs, slot_now));   // ga, gt, gc
@@ -2064,8 +2251,9 @@ extern "C" int ssac_fused_row_tiles(const ssac_mlp *nets, int n_rows, int n_nets
 }
 
 extern "C" int ssac_chain_form(int form) {
-    if (form != 0 && form != 1) return ssac_fail("ssac_chain_form: 0 (one workgroup per CU), 1 (automatic: co-resident 16-row tiles where they apply)");
-    g_chain_form = form;
+    if (form != 0 && form != 1 && form != -1)
+        return ssac_fail("ssac_chain_form: 0 (one workgroup per CU), 1 (co-resident 16-row tiles where they apply), -1 (the library's default)");
+    g_chain_form = form < 0 ? CHAIN_FORM_DEFAULT : form;
     return 0;
 }
 

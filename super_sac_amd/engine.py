@@ -349,8 +349,9 @@ def adam_group(optimizer, device):
 # ------------------------------------------------------------------------------------------
 # launch sequences
 # ------------------------------------------------------------------------------------------
-def _timed(tag):
-    """context manager recording a (start, end) event pair when bench.py asked for `tag`."""
+def _timed(tag, repeatable=True):
+    """context manager recording a (start, end) event pair when bench.py asked for `tag`.  repeatable=False: the launch is
+    not idempotent (it steps the optimizer): one issue per event pair whatever PROFILE["reps"] says."""
     class _T:
         def __enter__(self_):
             self_._enter()
@@ -359,7 +360,7 @@ def _timed(tag):
         def _enter(self_):
             want = PROFILE["tag"]
             self_.on = want is not None and (tag == want or (isinstance(want, tuple) and tag in want))
-            self_.reps = max(1, int(PROFILE.get("reps", 1))) if self_.on else 1
+            self_.reps = max(1, int(PROFILE.get("reps", 1))) if (self_.on and repeatable) else 1
             if self_.on:
                 self_.e0 = torch.cuda.Event(enable_timing=True)
                 self_.e1 = torch.cuda.Event(enable_timing=True)
@@ -438,21 +439,23 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
         # UNSCALED backward, and the loss gradient dL/dq itself is evaluated inside the launch (per workgroup, in LDS)
         assert O == 1 and net_ids is None and n_sel == arena.n_nets
         f = lossfold
-        check(lib.ssac_mlp_wgrad_all_lossfold(
-            C.byref(d), X.data_ptr(), ldx, x_net_stride, h1.data_ptr(), h2.data_ptr(),
-            0 if f.get("dz2_from_h2") else dz2.data_ptr(),   # (0: dz2u is rebuilt from h2 and W3 in the operand staging)
-            dz1.data_ptr(), _ptr(f.get("w3_snapshot")),
-            f["q"].data_ptr(), f["td_ptr"], f["spec_ptr"], f["weight_ptr"], f["popart_ptr"], f["pop"],
-            float(f["denom"]), f["partials"].data_ptr(), n_rows, _ptr(m), _ptr(v), ctl, _ptr(grads), ssp(2), ssp(1),
-            ssp(0), ttot, _ptr(target), float(tau), C.byref(f["logfold"]) if f.get("logfold") is not None else 0, st))
+        with _timed("wgrad", repeatable=False):   # (bench.py's live timing; the launch steps Adam)
+            check(lib.ssac_mlp_wgrad_all_lossfold(
+                C.byref(d), X.data_ptr(), ldx, x_net_stride, h1.data_ptr(), h2.data_ptr(),
+                0 if f.get("dz2_from_h2") else dz2.data_ptr(),   # (0: dz2u is rebuilt from h2 and W3 in the operand staging)
+                dz1.data_ptr(), _ptr(f.get("w3_snapshot")),
+                f["q"].data_ptr(), f["td_ptr"], f["spec_ptr"], f["weight_ptr"], f["popart_ptr"], f["pop"],
+                float(f["denom"]), f["partials"].data_ptr(), n_rows, _ptr(m), _ptr(v), ctl, _ptr(grads), ssp(2), ssp(1),
+                ssp(0), ttot, _ptr(target), float(tau), C.byref(f["logfold"]) if f.get("logfold") is not None else 0, st))
         return f.get("logfold") is not None
     if rowscale is not None:
         # UNSCALED backward (ssac_target_fwd_critic_bwdu): dL/dq of every (net, row) scales the rows while they load
         assert O == 1
-        check(lib.ssac_mlp_wgrad_all_scaled(C.byref(d), ids, n_sel, X.data_ptr(), ldx, x_net_stride, h1.data_ptr(),
-                                            h2.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), rowscale.data_ptr(), n_rows,
-                                            _ptr(m), _ptr(v), ctl, _ptr(grads), ssp(2), ssp(1), ssp(0), ttot,
-                                            _ptr(target), float(tau), st))
+        with _timed("wgrad", repeatable=False):
+            check(lib.ssac_mlp_wgrad_all_scaled(C.byref(d), ids, n_sel, X.data_ptr(), ldx, x_net_stride, h1.data_ptr(),
+                                                h2.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), rowscale.data_ptr(), n_rows,
+                                                _ptr(m), _ptr(v), ctl, _ptr(grads), ssp(2), ssp(1), ssp(0), ttot,
+                                                _ptr(target), float(tau), st))
         return
     if O <= 16 and MERGE_HEAD_WGRAD:
         # head (VALU), fc2 and fc1 weight gradients of every selected net: ONE launch

@@ -1316,7 +1316,7 @@ def test_chain_launch_equals_the_separate_launches(ssa, B, N, H):
     # the PRODUCER / CONSUMER form (hand-off buffer given): the actor once per tile, the target critics take a' from tagged
     # granules and add the action columns of fc1 after the state columns' sum -- everything but the target q bit for bit,
     # the target q to rounding; with 2 and 4 column splits (hidden 256) the slot's value arrives as partial sums
-    # Round 5: the CO-RESIDENT form (ssac_chain_form(1), the default; two workgroups per CU, 16-row tiles everywhere) takes
+    # Round 5: the CO-RESIDENT form (ssac_chain_form(1); two workgroups per CU, 16-row tiles everywhere) takes
     # launches of 257..512 16-row tiles -- here B 512 / N 10 -- and must give the bits of the separate launches with 16-row
     # tiles forced; ssac_chain_form(0) keeps the one-workgroup-per-CU kernel (32-row critic tiles at that shape).
     co_applies = B == 512 and N == 10
@@ -1345,7 +1345,7 @@ def test_chain_launch_equals_the_separate_launches(ssa, B, N, H):
             if form == 1 and co_applies:   # (the 16-row and 32-row tiles sum K in different orders: the co-resident form really ran)
                 assert not torch.equal(p2_, h2)
         finally:
-            ssa._lib.check(lib.ssac_chain_form(1))
+            ssa._lib.check(lib.ssac_chain_form(-1))   # (the library's default)
     # ... and without the dz2u store: the launch leaves a copy of the head rows instead, from which (with h2) the
     # weight-gradient launch rebuilds dz2u = W3 (.) [h2 > 0] -- exactly the values written above
     w3s = torch.zeros(N, H, device=DEV)

@@ -31,7 +31,8 @@ for rep in range(3):
     t0 = a[:, 0].min()
     s, e = a[:, 0] - t0, a[:, 1] - t0
     if n == T + 2 * T + N * T:
-        groups = (("producers", 0, T), ("consumers", T, 3 * T), ("critic16", 3 * T, n))
+        cf = max(0, min(N * T, 256 - 3 * T))   # fused_chain_co_kernel: [critic tiles, first part][producers][consumers][critic tiles, rest]
+        groups = (("critic16a", 0, cf), ("producers", cf, cf + T), ("consumers", cf + T, cf + 3 * T), ("critic16", cf + 3 * T, n))
     else:
         nc = n - 3 * T
         groups = (("producers", 0, T), ("critic32", T, T + nc), ("consumers", T + nc, n))

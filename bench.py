@@ -485,8 +485,13 @@ def main():
                             "1 temperature update (B 512, N 10)",
                 "ms_per_env_step": round(te * 1e3, 4), "critic_updates_per_s": round(20 / te, 1),
                 "env_steps_per_s": round(1 / te, 1)}
-            # ---- BASELINE config 2: REDQ N=10 UTD=20 batch 256 in the bf16-operand mode; the ensemble-Q kernel's HBM fraction
             del step, env_step
+            # ---- the N = 1 anchors of the scaling target's configurations (BASELINE.json: ">= 3.5x at 8 vs 1 GPU for N = 16";
+            #      `bench.py --gpus 8 --critics 16 [--obs 376 --act 17]` measures the other end when an 8-GPU node runs it)
+            secondary["scaling_anchors_n16_1gpu"] = n16_rows(device)
+            # ---- large-batch sweep of the fp32 path's two launches (the asymptotic fraction of the matrix peak)
+            secondary["fp32_sweep"] = fp32_sweep(ssa, device)
+            # ---- BASELINE config 2: REDQ N=10 UTD=20 batch 256 in the bf16-operand mode; the ensemble-Q kernel's HBM fraction
             step_b, env_b, _ = build_engine(device, NCRIT, None, batch=256, precision="bf16")
             for _ in range(60):
                 step_b()
@@ -531,6 +536,82 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def n16_rows(device):
+    """critic_update (+ Polyak / 2) with ALL 16 critics on one GPU, recorded launch list as the headline: the metric shape and
+    the Humanoid shape of BASELINE config 5"""
+    rows = {}
+    for label, obs, act in (("M_obs17_act6", 17, 6), ("humanoid_obs376_act17", 376, 17)):
+        st, _, _ = build_engine(device, 16, None, batch=512, obs=obs, act=act, ncrit=16)
+        for _ in range(60):
+            st()
+        t = statistics.median(timed_repeats(st, 1000, 3, None, device)) / 1000
+        rows[label] = {"num_critics": 16, "batch": 512, "us_per_critic_update": round(t * 1e6, 2),
+                       "critic_updates_per_s": round(1 / t, 1)}
+        del st
+    return rows
+
+
+def fp32_sweep(ssa, device):
+    """the fp32 path's two launches at B = 4096 / 16384 / 65536 (N = 10, obs 17 / act 6, n = 2): the chained
+    launch (`ssac_chain_update`, producer / consumer form: the headline's kernel, its rows from a batch buffer instead of the
+    replay gather) and the merged weight-gradient launch (`ssac_mlp_wgrad_all_scaled`, gradient-store epilogue: what the
+    engine issues above 4096 rows, where the loss fold's LDS table no longer fits), HIP events around back-to-back launches
+    on the launch stream, against the fp32 matrix peak.  FLOPs as in `roofline`: chained = critics' forward + backward-data +
+    the subset's target critics + the actor once; weight gradient = 2 B N (in H + H H + H)."""
+    import ctypes as C
+    import torch
+    from super_sac_amd import engine
+    from super_sac_amd._lib import check, lib
+    S, A, N, H = 17, 6, 10, HID
+    IN = S + A
+    out = {"peak_TFLOPs": FP32_MFMA_PEAK_TFLOPS, "rows": {}}
+    torch.manual_seed(2)
+    aa, ca, ta = engine.MlpArena(1, S, H, 2 * A, device), engine.MlpArena(N, IN, H, 1, device), engine.MlpArena(N, IN, H, 1, device)
+    for ar in (aa, ca, ta):
+        ar.params.copy_(torch.randn_like(ar.params) * 0.05)
+    ids = torch.tensor([N - 1, 0], dtype=torch.int32, device=device)
+    st = engine.stream()
+    for B in (4096, 16384, 65536):
+        x1, xc = torch.randn(B, IN, device=device), torch.randn(B, IN, device=device)
+        eps, lp = torch.randn(B, A, device=device), torch.zeros(B, device=device)
+        h1 = torch.empty(N, B, H, device=device); h2 = torch.empty_like(h1); dz2 = torch.empty_like(h1); dz1 = torch.empty_like(h1)
+        q, qt = torch.empty(N, B, 1, device=device), torch.empty(2, B, 1, device=device)
+        ho = torch.zeros(B * A, dtype=torch.int64, device=device)
+        grads = torch.zeros_like(ca.params)
+        ss = torch.zeros(N * engine.wgrad_tiles_total(ca), device=device)
+        dq = torch.randn(N, B, 1, device=device)
+
+        def chain_launch():
+            check(lib.ssac_chain_update(
+                C.byref(aa.desc()), x1.data_ptr(), IN, B, eps.data_ptr(), -5.0, 2.0, x1.data_ptr(), IN, S, lp.data_ptr(), 0,
+                C.byref(ta.desc()), ids.data_ptr(), 2, qt.data_ptr(), C.byref(ca.desc()), xc.data_ptr(), IN, h1.data_ptr(),
+                h2.data_ptr(), q.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), 0, 0, 0, ho.data_ptr(), 1, st))
+
+        def wgrad_launch():
+            engine.weight_grads(ca, xc, IN, 0, h1, h2, dq, dz2, dz1, B, grads=grads, sumsq=ss, rowscale=dq)
+        f_chain = (2.0 * B * N * (IN * H + H * H + H) + 2.0 * B * N * (H + H * H) + 2.0 * B * NSUB * (IN * H + H * H + H) +
+                   2.0 * B * (S * H + H * H + H * 2 * A))
+        f_wg = 2.0 * B * N * (IN * H + H * H + H)
+        row = {}
+        for tag, fn, fl in (("chain", chain_launch, f_chain), ("wgrad", wgrad_launch, f_wg)):
+            for _ in range(3):
+                fn()
+            reps = 20 if B <= 16384 else 6
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            row[tag] = {"us_per_launch": round(us, 2), "TFLOPs": round(fl / us / 1e6, 1),
+                        "frac": round(fl / us / 1e6 / FP32_MFMA_PEAK_TFLOPS, 3)}
+        out["rows"][f"B{B}"] = row
+        del x1, xc, eps, lp, h1, h2, dz2, dz1, q, qt, ho, grads, ss, dq
+        torch.cuda.empty_cache()
+    return out
 
 
 def bf16_rows(ssa, device):

@@ -585,6 +585,120 @@ __device__ __forceinline__ void gemm_direct16(Tile<16>::Acc &acc, const DirectW<
     lds_barrier();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward-data K loop WITHOUT an LDS image of the weights, every tile size (round 5).  dz1 = dz2 W2 reads W2 (K x N, rows
+// contiguous) down column blocks: the MFMA's weight fragment of step t is W2[k(t)][col0 + lane's column] -- for the 64
+// lanes of a wave two (32-row tiles) or four (16-row tiles) fully used 128- / 64-byte runs, i.e. as a GLOBAL access the
+// fragment load is perfectly coalesced, while as an LDS access it was 16 scalar ds_read_b32 per chunk per lane behind 4
+// staging stores and a workgroup barrier.  So the fragments are buffer loads (one descriptor in SGPRs, one byte offset per
+// lane, the row as a scalar offset: no address register per load), two chunks in flight ahead of the multiplying one, and the
+// loop has no barrier and no LDS traffic but the activation fragment.  Measured inside the co-resident experiment
+// (profiles/r5_chain_coresident.md: 10.9 k clocks per 16-row K loop against 19.2 - 24.4 k for the forward form, whose 16-byte
+// row-wise loads touch 16 lines per instruction) and then taken for the product's tiles.  Same fragments, same MFMA
+// order as the staged loop: bit-identical.  (The forward loops keep the LDS image: a lane needs 8 - 16 consecutive k of its
+// OWN weight row, which only a staged, re-laid-out chunk serves with wide accesses.)
+// ---------------------------------------------------------------------------------------------
+template <int TMR>
+struct DirectNN {
+    static constexpr int NOFF = TMR == 32 ? 1 : 2;
+    __amdgpu_buffer_rsrc_t r;
+    int off[NOFF];       // byte offset of this lane's element of row (its k group's first), per column sub-tile
+    uint32_t ld4;        // row stride in bytes (uniform)
+    float b0[16];        // chunk 0, requested through the `Next` interface of the K loop in front (load(0, K))
+    __device__ __forceinline__ void init(const float *W, int ldw, int Nw, int col0, int lane) {
+        // (readfirstlane returns a signed int: each half through uint32_t, or a base with bit 31 set is sign-extended)
+        const uint64_t ub = (uint64_t)(uintptr_t)W;
+        const uint32_t blo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ub);
+        const uint32_t bhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ub >> 32));
+        r = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)(((uint64_t)bhi << 32) | (uint64_t)blo), 0, 0x7ffffffc, 0x00020000);
+        ld4 = 4u * (uint32_t)__builtin_amdgcn_readfirstlane(ldw);
+        if (TMR == 32) {
+            const int li = lane & 31, lh = lane >> 5, n = col0 + li;
+            off[0] = (int)((uint32_t)(lh * 16) * ld4 + 4u * (uint32_t)(n < Nw ? n : 0));
+        } else {
+            const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+            for (int u = 0; u < NOFF; ++u) {
+                const int n = col0 + 16 * u + li;
+                off[u] = (int)((uint32_t)(lg * 8) * ld4 + 4u * (uint32_t)(n < Nw ? n : 0));
+            }
+        }
+    }
+    // chunk c: Tile<32>: v[t] = W[32c + 16 lh + t][column], t < 16;  Tile<16>: v[8u + t] = W[32c + 8 lg + t][column of u], t < 8
+    __device__ __forceinline__ void load_chunk(float (&v)[16], int c) const {
+#if defined(SSAC_LAB) && defined(SSAC_EXP_NO_WLOAD)
+        if (c > 0) return;
+#endif
+        if (TMR == 32) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                v[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off[0], (int)((uint32_t)(c * 32 + t) * ld4), 0));
+        } else {
+#pragma unroll
+            for (int u = 0; u < NOFF; ++u)
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    v[8 * u + t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off[u], (int)((uint32_t)(c * 32 + t) * ld4), 0));
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int) { load_chunk(b0, k0 >> 5); }   // (`Next` interface of gemm_tile)
+};
+
+template <int TMR>
+__device__ __forceinline__ void direct_nn_chunk(typename Tile<TMR>::Acc &acc, const float (&b)[16], const float *As, int lda,
+                                                int c, int lane) {
+    if constexpr (TMR == 32) {
+        const int li = lane & 31, lh = lane >> 5;
+        const f4 *ap = reinterpret_cast<const f4 *>(As + li * lda + c * 32 + lh * 16);
+        const f4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const f4 &aq = t < 4 ? a0 : (t < 8 ? a1 : (t < 12 ? a2 : a3));
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b[t], aq[t & 3], acc, 0, 0, 0);
+        }
+    } else {
+        const int li = lane & 15, lg = lane >> 4;
+        const f4 *ap = reinterpret_cast<const f4 *>(As + li * lda + c * 32 + lg * 8);
+        const f4 a0 = ap[0], a1 = ap[1];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                acc.v[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[8 * u + t], t < 4 ? a0[t & 3] : a1[t & 3], acc.v[u], 0, 0, 0);
+    }
+}
+
+// w.b0 holds chunk 0 (requested by the caller a phase ahead).  Ends with a barrier: every wave is done reading As.
+template <int TMR>
+__device__ __forceinline__ void gemm_direct_nn(typename Tile<TMR>::Acc &acc, DirectNN<TMR> &w, const float *As, int lda, int K,
+                                               int lane) {
+    const int nch = (K + 31) >> 5;
+    float b1[16], b2[16];
+    if (nch > 1) w.load_chunk(b1, 1);
+    int c = 0;
+    for (; c + 3 < nch; c += 3) {
+        w.load_chunk(b2, c + 2);
+        direct_nn_chunk<TMR>(acc, w.b0, As, lda, c, lane);
+        w.load_chunk(w.b0, c + 3);
+        direct_nn_chunk<TMR>(acc, b1, As, lda, c + 1, lane);
+        if (c + 4 < nch) w.load_chunk(b1, c + 4);
+        direct_nn_chunk<TMR>(acc, b2, As, lda, c + 2, lane);
+    }
+    const int left = nch - c;
+    if (left == 3) {
+        w.load_chunk(b2, c + 2);
+        direct_nn_chunk<TMR>(acc, w.b0, As, lda, c, lane);
+        direct_nn_chunk<TMR>(acc, b1, As, lda, c + 1, lane);
+        direct_nn_chunk<TMR>(acc, b2, As, lda, c + 2, lane);
+    } else if (left == 2) {
+        direct_nn_chunk<TMR>(acc, w.b0, As, lda, c, lane);
+        direct_nn_chunk<TMR>(acc, b1, As, lda, c + 1, lane);
+    } else {
+        direct_nn_chunk<TMR>(acc, w.b0, As, lda, c, lane);
+    }
+    lds_barrier();
+}
+
 // W3 (OUT x H, rows contiguous) -> LDS rows of stride ldw3.  Four independent loads are issued before the
 // first LDS store, so the copy costs one global round trip instead of one per head row.
 __device__ __forceinline__ void stage_head_weights(float *w3s, const float *__restrict__ W3, int OUT, int H,
@@ -714,6 +828,12 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     const int ldw3 = H + APAD;
     KcStage st1, st2;
     RcStage st3;
+    DirectNN<TMR> dnn;   // backward-data without an LDS image of W2 (gemm_direct_nn); the staged loop (st3) stays for A/B builds
+#if defined(SSAC_LAB) && defined(SSAC_EXP_STAGED_BWD)
+    constexpr bool DIRECT_BWD = false;
+#else
+    constexpr bool DIRECT_BWD = !CO;   // (the co-resident carve has its own direct loops)
+#endif
     NoStage none;
     DirectW<false> d1, d2;   // CO: weight fragments straight from memory (gemm_direct16)
     DirectW<true> d3;
@@ -729,8 +849,8 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     float *hpart = Ws;  // K-split partial head tiles [8][TMR][16] (staging buffer 0 is free after fc2)
     if (BWD_ONLY) {
         // ---- h1, h2, q tiles of an earlier forward launch -> LDS; W2's first chunk in flight meanwhile
-        st3.init(P + g.off[2], H, H, tid);
-        st3.load(0, H);
+        if (DIRECT_BWD) { dnn.init(P + g.off[2], H, H, col0, lane); dnn.load(0, H); }
+        else { st3.init(P + g.off[2], H, H, tid); st3.load(0, H); }
         // all loads of the two activation tiles before anything is stored: one round trip for the prologue
         const int c = (tid & 63) * 4;  // one wave per row pass, 16 bytes per lane
         constexpr int RP = TMR / (NTHR / 64);
@@ -964,7 +1084,10 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         }
         BSTAMP(2);
         if (NSPL == 1 && !CO) stage_first(st2, Ws, H, tid);
-        if (FWD_BWD && !CO) st3.init(P + g.off[2], H, H, tid);
+        if (FWD_BWD && !CO) {
+            if (DIRECT_BWD) dnn.init(P + g.off[2], H, H, col0, lane);
+            else st3.init(P + g.off[2], H, H, tid);
+        }
         float *wa = CO ? wa_co : Ws1, *as_ = ys;   // (consumer) W1[:, S:S+A] as [H][A]; a' of the tile as [TMR][32] (ys | dqs: free until the head)
         if (CONS) {
             const int A_ = g.ho.A, na = H * A_;
@@ -1068,7 +1191,8 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
             if (FWD_BWD) gemm_direct16<false>(acc, d2, bq2, h1s, ldh, H, lane, d3, bq3);
             else gemm_direct16<false>(acc, d2, bq2, h1s, ldh, H, lane, nodirect, bq3);
         } else {
-            if (FWD_BWD) gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, st3, H);
+            if (FWD_BWD && DIRECT_BWD) gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, dnn, H);
+            else if (FWD_BWD) gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, st3, H);
             else gemm_tile<TMR, false, DBUF>(acc, st2, h1s, ldh, H, Ws, Ws1, tid, col0, none, 0);
         }
         if (W3LATE) {   // (gemm_tile ended with a barrier: nobody reads the staging buffers any more; visible to the head
@@ -1189,7 +1313,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     BSTAMP(7);
     if (MODE == MODE_PLAIN) return;
     lds_barrier();  // hpart (= staging buffer 0) has been consumed
-    if (IS_CRITIC && !CO) stage_first(st3, Ws, H, tid);
+    if (IS_CRITIC && !CO && !DIRECT_BWD) stage_first(st3, Ws, H, tid);
 
     if (MODE == MODE_SAMPLE) {
         // tanh-normal head: one thread per row
@@ -1367,6 +1491,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         lds_barrier();  // dz2 (in h2s) and the staged first chunk of W2 are visible
         T::zero(acc);
         if constexpr (CO) gemm_direct16<true>(acc, d3, bq3, h2s, ldh, H, lane, nodirect, bq1);
+        else if constexpr (DIRECT_BWD) gemm_direct_nn<TMR>(acc, dnn, h2s, ldh, H, lane);
         else gemm_tile<TMR, true, DBUF>(acc, st3, h2s, ldh, H, Ws, Ws1, tid, col0, none, 0);
         BSTAMP(10);
         const bool want_dx = MODE == MODE_CRITIC_U && g.DXU != nullptr;
@@ -2012,6 +2137,14 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
     const size_t co_lds = co_lds_a > co_lds_t ? (co_lds_a > co_lds_c ? co_lds_a : co_lds_c) : (co_lds_t > co_lds_c ? co_lds_t : co_lds_c);
     const bool co_form = pc_form && g_chain_form == 1 && g_tile_rows == 0 && target_splits == 1 && n16 > 256 && n16 <= 512 &&
                          co_lds <= 80 * 1024;
+    // RESIDENCY INVARIANT of the hand-off launches (any B x N, any number of rounds of workgroups): a consumer spins on granules
+    // that only a PRODUCER writes; producers never wait for anybody; every producer holds a LOWER workgroup id than every
+    // consumer (fused_chain_pc_kernel: producers [0, tiles_a), then critic tiles / consumers), and the dispatcher starts
+    // workgroups in id order.  So when a consumer is resident and spinning, every producer has already been started: it is
+    // running or done, never queued behind the spinner -- no occupancy, however small, can deadlock the launch (and a
+    // producer that dies leaves a bounded spin + NaN, handoff_poll).  The co-resident form orders its ids differently and
+    // therefore insists that the WHOLE launch is resident at once (n16 <= 512 at two workgroups per CU, checked below).
+    // tests/test_hip_kernels.py::test_chain_launch_equals_the_separate_launches runs B 4096 / N 16 (eleven rounds).
     if (pc_form) {
         // producer / consumer form (fused_chain_pc_kernel): the actor ONCE per tile, a' handed to the tile's target critics
         static unsigned launch_no = 0;   // tags of eager launches: bit 31 set, so they never meet a recorded launch's

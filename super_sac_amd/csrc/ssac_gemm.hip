@@ -145,16 +145,7 @@ __device__ __forceinline__ float adam_elem(float p, float g, float &m, float &v,
 // (ssac_wgrad_tiles): the 32 x 32 tiles of the latency variant write one each (wgrad_small_body), a 64 x 64 tile writes
 // the first of the (up to) four it covers and zeroes the others -- the slots of a layer sum to the same value
 // whichever variant ran last.  (agent scope: with the logs folded into the launch the reader sits on another XCD)
-__device__ __forceinline__ void sumsq_store64(float *base, int M, int N, int bx, int by, float tot) {
-    const int gx = (N + 31) >> 5, gy = (M + 31) >> 5;
-    const int r = 2 * by, c = 2 * bx;
-    __hip_atomic_store(base + r * gx + c, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (c + 1 < gx) __hip_atomic_store(base + r * gx + c + 1, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (r + 1 < gy) {
-        __hip_atomic_store(base + (r + 1) * gx + c, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (c + 1 < gx) __hip_atomic_store(base + (r + 1) * gx + c + 1, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
+// (the stores themselves: `sumsq_finish` in ens_gemm_body -- four lanes of one store instruction)
 
 // KS = number of K-split groups of 4 waves inside the workgroup.  Group kg consumes chunks
 // kg, kg+KS, ... with its own LDS staging; the partial tiles are summed through LDS before the
@@ -503,6 +494,24 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
         const bool pol = g.tw != nullptr && (!lt.on || lt.bits != 0u);
         const float tau = lt.on ? __uint_as_float(lt.bits) : g.tau;
         float ss = 0.0f;
+        // Gradient-norm partial of the tile (round 5).  The sum over the tile's 4 KS wave partials and the slot stores used to
+        // be ONE thread's serial work in front of its optimizer stores -- 2.2 k clocks that only the first wave paid, and
+        // with it the workgroup.  Now the LAST wave takes them BEHIND its own optimizer stores: a fixed xor tree over the
+        // partials (deterministic), the slot of the tile's first 32 x 32 block takes the sum and the siblings are zeroed by
+        // lanes 1..3 of the same store instruction (one slot per 32 x 32 block, above); lane 0 then draws the arrival ticket of the
+        // folded logs (its wave's stores drained first: log_fold_arrive).
+        auto sumsq_finish = [&]() {
+            if (!(g.sumsq && (tid_all >> 6) == 4 * KS - 1)) return;
+            float tot = lane < 4 * KS ? red[lane] : 0.0f;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);   // (4 KS <= 16 partials in lanes 0..15)
+            const int gx = (g.N + 31) >> 5, gy = (g.M + 31) >> 5;
+            const int r_ = 2 * by + (lane >> 1), c_ = 2 * bx + (lane & 1);
+            if (lane < 4 && r_ < gy && c_ < gx)
+                __hip_atomic_store(g.sumsq + (int64_t)e * g.sumsq_stride + r_ * gx + c_, lane == 0 ? tot : 0.0f, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (fold.done && lane == 0) last = log_fold_arrive(fold, gridDim.x) ? 1 : 0;
+        };
         // 16-byte form: a thread owns 4 consecutive columns of one row (weight rows of a multiple of 4 floats on 16-byte
         // aligned arenas: fc2 and every hidden-to-hidden layer).  The optimizer's traffic is 7-8 streams per element
         // (p, m, v [, target] in; the same out) that come from HBM / the Infinity Cache once per update; as dword
@@ -561,12 +570,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
                 if (lane == 0) red[tid_all >> 6] = ss;
                 lds_barrier();
                 GSTAMP(12);
-                if (tid_all == 0) {
-                    float tot = 0.0f;
-                    for (int w = 0; w < 4 * KS; ++w) tot += red[w];
-                    sumsq_store64(g.sumsq + (int64_t)e * g.sumsq_stride, g.M, g.N, bx, by, tot);
-                    if (fold.done) last = log_fold_arrive(fold, gridDim.x) ? 1 : 0;
-                }
+                // (the sum of the wave partials and the slot stores: sumsq_finish, behind the optimizer stores)
             }
             GSTAMP(9);
 #pragma unroll
@@ -601,6 +605,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
                     if (pol && g.tb) g.tb[bi_] = btv_ * (1.0f - tau) + pn * tau;
                 }
             }
+            sumsq_finish();
             GSTAMP(4);
             return;
         }
@@ -648,12 +653,6 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
             __syncthreads();  // red[] (bias partials) has been consumed
             if (lane == 0) red[tid_all >> 6] = ss;
             __syncthreads();
-            if (tid_all == 0) {
-                float tot = 0.0f;
-                for (int w = 0; w < 4 * KS; ++w) tot += red[w];
-                sumsq_store64(g.sumsq + (int64_t)e * g.sumsq_stride, g.M, g.N, bx, by, tot);
-                if (fold.done) last = log_fold_arrive(fold, gridDim.x) ? 1 : 0;
-            }
         }
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
@@ -681,6 +680,7 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
                 if (pol && g.tb) g.tb[bi] = btv * (1.0f - tau) + pn * tau;
             }
         }
+        sumsq_finish();
         GSTAMP(4);
         return;
     }
@@ -848,7 +848,9 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
         // inside their epilogue, ahead of the optimizer stores); the wave of the last arriver finalises the logs
         float *flag = lds + KS * (4 * TILE_FLOATS);   // (the bias / sumsq scratch: consumed by now)
         __syncthreads();
-        if (threadIdx.x == 0) flag[0] = (drawn ? last != 0 : log_fold_arrive(p.fold, gridDim.x)) ? 1.0f : 0.0f;
+        // (a GEMM tile's ticket was drawn by lane 0 of its LAST wave -- sumsq_finish; the other workgroup classes draw it here)
+        if (threadIdx.x == (drawn ? (4 * KS - 1) * 64 : 0))
+            flag[0] = (drawn ? last != 0 : log_fold_arrive(p.fold, gridDim.x)) ? 1.0f : 0.0f;
         __syncthreads();
         if (flag[0] != 0.0f && threadIdx.x < 64) log_fold_finish(p.fold);
     } else if (p.fold.deferred_stats && p.fold.feed && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1479,7 +1481,7 @@ extern "C" int ssac_mlp_layer_dgrad(const ssac_mlp *nets, int layer, const int32
 extern "C" int ssac_wgrad_tiles(const ssac_mlp *nets, int layer) {
     LayerGeom L;
     if (!nets || !layer_geom(nets, layer, L)) return -1;
-    // gradient-norm slots of the layer per net: one per 32 x 32 tile (sumsq_store64); heads of <= 16 outputs go through
+    // gradient-norm slots of the layer per net: one per 32 x 32 tile (sumsq_finish); heads of <= 16 outputs go through
     // the VALU head workgroups, which own one slot per 16 columns (ssac_head_wgrad.h)
     if (layer == 2 && nets->out_dim <= 16) return (nets->hidden + SSAC_HEAD_SLOT_COLS - 1) / SSAC_HEAD_SLOT_COLS;
     return ((L.rows + 31) / 32) * ((L.cols + 31) / 32);

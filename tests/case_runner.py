@@ -436,6 +436,68 @@ def run_engine(name, device="cuda", shard=None, foreign=False, precision="fp32",
     return rec
 
 
+def run_engine_stock(name, device="cuda", members=None, cycles=3):
+    """The update sequence of a case with the STOCK generators -- no injected draws: replay indices from torch's CPU
+    generator, REDQ subsets / logged-net picks from Python's `random`, the policy noise from the engine's Philox stream
+    (in-kernel where the launches draw it) or the device generator.  Returns {global member index: flat parameters} for the
+    actors and critics of the members this process holds, and their temperatures.  (What the fixtures cannot pin: they
+    replay recorded draws through hooks, so the stock noise path of a member-sharded rank never ran under them.)"""
+    import random
+    import super_sac_amd as ssa
+    cfg = synth.CASES[name]
+    B, E = cfg["B"], cfg["E"]
+    device = torch.device(device)
+    torch.manual_seed(cfg["seed"]); np.random.seed(cfg["seed"]); random.seed(cfg["seed"])
+    buf = ssa.replay.ReplayBuffer(cfg["cap"], device=device)
+    buf.load_experience(*_buffers(cfg))
+    agent = build_engine_agent(cfg, device, None, members=members)
+    target = copy.deepcopy(agent)
+    if members is not None:
+        ssa.parallel.install_members(agent, target, members)
+    EL = agent.ensemble_size
+    glob = (lambda i: i) if members is None else (lambda i: members.lo + i)
+    copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=cfg["lr"], betas=(0.9, 0.999))
+    aopt = torch.optim.Adam(chain(*(a.parameters() for a in agent.actors)), lr=cfg["lr"], betas=(0.9, 0.999))
+    eopt = torch.optim.Adam(agent.encoder.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    las, lopts = [], []
+    for _ in range(EL):
+        la = torch.Tensor([math.log(max(cfg["init_alpha"], 1e-15))]).to(device)
+        la.requires_grad = True
+        las.append(la)
+        lopts.append(torch.optim.Adam([la], lr=cfg["alpha_lr"], betas=(0.5, 0.999)))
+    aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(B)])
+    # every process re-seeds behind the construction (a rank that built fewer members consumed fewer draws)
+    torch.manual_seed(cfg["seed"] + 1); np.random.seed(cfg["seed"] + 1); random.seed(cfg["seed"] + 1)
+    torch.cuda.manual_seed(cfg["seed"] + 1)
+    upd = 0
+    for cyc in range(cycles):
+        for k in range(cfg["utd"]):
+            _, dicts = ssa.learning.critic_update(
+                buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt, encoder_optimizer=eopt,
+                log_alphas=las, batch_size=B, gamma=cfg["gamma"], critic_clip=cfg["clip"], encoder_clip=cfg["clip"],
+                target_critic_ensemble_n=cfg["n"], weighted_bellman_temp=cfg["temp"], weight_type=cfg["weight_type"],
+                pop=cfg["pop"], augmenter=aug, encoder_lambda=0, aug_mix=0.0, discrete=cfg["discrete"],
+                random_process=None, noise_clip=None, per=False, update_priorities=False, dr3_coeff=0.0)
+            if upd % cfg["target_delay"] == 0:
+                for ac, tc in zip(agent.critics, target.critics):
+                    ssa.learning_utils.soft_update(tc, ac, cfg["tau"])
+            upd += 1
+        ssa.learning.online_actor_update(
+            buffer=buf, agent=agent, pop=cfg["pop"], actor_optimizer=aopt, log_alphas=las, batch_size=B, aug_mix=0.0,
+            clip=cfg["clip"], augmenter=aug, per=False, discrete=cfg["discrete"], random_process=None, noise_clip=None,
+            premade_replay_dicts=dicts)
+        ssa.learning.alpha_update(
+            buffer=buf, agent=agent, optimizers=lopts, batch_size=B, log_alphas=las, augmenter=aug, aug_mix=0.0,
+            target_entropy=_target_entropy(cfg), premade_replay_dicts=dicts, discrete=cfg["discrete"])
+    torch.cuda.synchronize()
+    out = {}
+    for i in range(EL):
+        out[f"actor{glob(i)}"] = _flat(agent.actors[i].parameters())
+        out[f"critic{glob(i)}"] = _flat(chain(*(n_.parameters() for n_ in agent.critics[i].nets)))
+        out[f"log_alpha{glob(i)}"] = np.float64(float(las[i].detach()))
+    return out
+
+
 def slice_fixture(fx, cfg, shard):
     """the part of a (single-member, full-dump) fixture that rank `shard` can reproduce: its own
     critics' parameters/moments; TD targets, actor parameters and temperature are global."""

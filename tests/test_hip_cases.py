@@ -818,6 +818,64 @@ def _actor_update_run(chained, hook=True, n_upd=8):
             L.ACTOR_CHAIN, ssa.rng.draw_normal, ssa.rng.draw_normal_into = old
 
 
+def test_recorded_actor_update_off_the_chained_form_owns_and_refills_its_noise():
+    """Round-4 advisor (high): Humanoid's actor (376 -> 256 -> 34) is fused but its double-buffered LDS carve does not fit,
+    so its online actor update takes the THREE-launch form -- which reads its noise from a buffer.  The recording decided
+    "in-kernel noise" from the generator alone and recorded the address of a temporary: every replay then re-read freed
+    memory (frozen or arbitrary noise), silently.  Now the predicate is per member (learning._actor_chain_form): the
+    recording owns fixed buffers, refills them before every replay, and an allocation inside a recording asserts.
+    Checked here with the stock generator: not the in-kernel form, the sampled action of every update is
+    tanh(mu + sd * eps) of the recording's buffer AS REFILLED for that update, and it changes from update to update."""
+    import copy, math, random
+    from itertools import chain
+    import torch
+    import super_sac_amd as ssa
+    L = ssa.learning
+    dev = torch.device("cuda")
+    B, S, A, N, H = 64, 376, 17, 2, 256
+    torch.manual_seed(13); np.random.seed(13); random.seed(13)
+    agent = ssa.Agent(act_space_size=A, encoder=ssa.nets.IdentityEncoder(S),
+                      actor_network_cls=ssa.nets.ContinuousStochasticActor, critic_network_cls=ssa.nets.ContinuousCritic,
+                      ensemble_size=1, num_critics=N, hidden_size=H, auto_rescale_targets=False, log_std_low=-5.0,
+                      log_std_high=2.0)
+    agent.to(dev)
+    target = copy.deepcopy(agent)
+    buf = ssa.replay.ReplayBuffer(4096, device=dev)
+    buf.load_experience(*synth.synth_transitions(1500, S, A, seed=9))
+    copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=3e-4)
+    aopt = torch.optim.Adam(chain(*(a.parameters() for a in agent.actors)), lr=3e-4)
+    eopt = torch.optim.Adam(agent.encoder.parameters(), lr=1e-4)
+    la = torch.Tensor([math.log(0.1)]).to(dev); la.requires_grad = True
+    aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(B)])
+    a_arena = ssa.engine.bind_arena(agent.actors[0], "self", [agent.actors[0]], dev)
+    assert a_arena.fused and not L._actor_chain_form(a_arena, A, B), "this shape is meant to miss the chained launch"
+    for _ in range(4):
+        _, dicts = L.critic_update(
+            buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt, encoder_optimizer=eopt, log_alphas=[la],
+            batch_size=B, gamma=0.99, critic_clip=None, encoder_clip=None, target_critic_ensemble_n=2,
+            weighted_bellman_temp=None, weight_type=None, pop=False, augmenter=aug, encoder_lambda=0, aug_mix=0.0,
+            discrete=False, random_process=None, noise_clip=None, per=False, update_priorities=False, dr3_coeff=0.0)
+    acts, rec = [], None
+    for k in range(7):   # two eager calls, the recording, four replays
+        L.online_actor_update(buffer=buf, agent=agent, pop=False, actor_optimizer=aopt, log_alphas=[la], batch_size=B,
+                              clip=None, random_process=None, noise_clip=None, augmenter=aug, aug_mix=0.0,
+                              premade_replay_dicts=dicts)
+        ws = agent.__dict__["_ssac_ws"]
+        x = ws.get("au.x0", (B, S + A))[:, S:].clone()
+        if k >= 2:
+            rec = next(iter(agent.__dict__["_ssac_actor_rec"].values()))
+            assert not rec.in_kernel and rec.eps is not None and rec.list is not None
+            y = ws.get("au.a0.y", (1, B, 2 * A))[0]
+            mu, raw = y[:, :A], y[:, A:]
+            sd = torch.exp(-5.0 + 0.5 * (2.0 - -5.0) * (torch.tanh(raw) + 1.0))
+            want = torch.tanh(mu + sd * rec.eps[0])
+            assert torch.allclose(x, want, atol=2e-6), (k, float((x - want).abs().max()))
+        acts.append(x)
+    for k in range(1, 7):
+        assert not torch.equal(acts[k], acts[k - 1]), f"update {k} re-used update {k - 1}'s noise"
+    assert all(bool(torch.isfinite(a_).all()) for a_ in acts)
+
+
 def test_actor_update_chained_launch_matches_three_launches():
     """ssac_actor_chain_fused (actor forward -> critics' forward + dQ/da -> actor backward as producer / consumer workgroups
     of ONE launch, learning.ACTOR_CHAIN) against the three launches it replaces, on the same injected noise: the first

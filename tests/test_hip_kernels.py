@@ -1269,10 +1269,13 @@ def test_rank1_backward_matches_autograd(ssa, B, H, N):
             _close(ar.view(j, seg, grads), ps[j][seg].grad, 3e-6, rtol=1e-4, what=f"grad {seg}[{j}]")
 
 
-@pytest.mark.parametrize("B,N,H", [(512, 10, 256), (100, 3, 64)])
+@pytest.mark.parametrize("B,N,H", [(512, 10, 256), (100, 3, 64), (4096, 16, 256)])
 def test_chain_launch_equals_the_separate_launches(ssa, B, N, H):
     """ssac_chain_update (actor -> target critic chains beside critic forward + unscaled backward, ONE launch) against
-    ssac_actor_sample_fused + ssac_target_fwd_critic_bwdu's two halves issued separately: same bits everywhere."""
+    ssac_actor_sample_fused + ssac_target_fwd_critic_bwdu's two halves issued separately: same bits everywhere.
+    (B 4096 / N 16: 256 producers + 512 consumers + 2048 critic tiles = eleven rounds of workgroups -- the residency
+    invariant of the hand-off written down in ssac_chain_update: consumers spin only on producers that hold LOWER workgroup
+    ids, which the dispatcher starts first, so a waiting consumer can never keep its producer off the chip.)"""
     rng = np.random.RandomState(B + 7)
     S, A = 17, 6
     actor = orc.make_mlp(rng, S, H, 2 * A)
@@ -1312,6 +1315,11 @@ def test_chain_launch_equals_the_separate_launches(ssa, B, N, H):
         g1.data_ptr(), g2.data_ptr(), gq.data_ptr(), gz2.data_ptr(), gz1.data_ptr(), 0, 0, 0, 0, 1, st))
     for a_, b_, what in ((xa, xb, "a'"), (lpa, lpb, "log pi"), (h1, g1, "h1"), (h2, g2, "h2"), (q, gq, "q"),
                          (qt, gt_, "target q"), (dz2, gz2, "dz2u"), (dz1, gz1, "dz1u")):
+        if what == "target q" and 2 * ((B + 15) // 16) > 256:
+            # (the stand-alone target forward takes 32-row tiles from 257 16-row workgroups on, the chained launch's target
+            # chains are always 16 rows: the K sums associate differently)
+            assert float((a_ - b_).abs().max()) <= 2e-5, f"chained launch differs in {what}"
+            continue
         assert torch.equal(a_, b_), f"chained launch differs in {what}"
     # the PRODUCER / CONSUMER form (hand-off buffer given): the actor once per tile, the target critics take a' from tagged
     # granules and add the action columns of fc1 after the state columns' sum -- everything but the target q bit for bit,

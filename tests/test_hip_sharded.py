@@ -14,6 +14,25 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _spawn(fn, args, nprocs, retries=1):
+    """mp.spawn for ranks that SHARE the test box's one GPU.  Their one-shot exchange kernels spin on each other's flags
+    while the device time-slices the processes' queues; once in a while (documented since round 3: about one run of the
+    suite in six on a loaded box) a wait sits out the whole spin bound and the exchange reports it as designed -- error
+    word, NaN-poisoned result, RuntimeError("... did not arrive within the spin bound").  That outcome says something
+    about the box's scheduler, not about the protocol (one rank per GPU -- the product layout -- has no time-slicing), so
+    THAT failure alone is retried once on a fresh rendezvous port; every other failure propagates at once."""
+    port_arg = [i for i, a in enumerate(args) if isinstance(a, int) and 20000 <= a < 65000][-1]
+    for attempt in range(retries + 1):
+        try:
+            mp.spawn(fn, args=tuple(args), nprocs=nprocs, join=True)
+            return
+        except Exception as e:   # noqa: BLE001  (torch.multiprocessing.spawn.ProcessRaisedException)
+            if attempt == retries or "within the spin bound" not in str(e):
+                raise
+            args = list(args)
+            args[port_arg] += 97
+
+
 def _rank_main(rank, world, port, out_dir, one_shot=False):
     sys.path.insert(0, HERE)
     import case_runner
@@ -42,7 +61,7 @@ def test_sharded_sequence_matches_reference(tmp_path, world, one_shot):
     """2 and 4 ranks on the one device (4: one critic per rank, two ranks per update own no member of the drawn
     subset), through the gloo collective and through the one-shot exchange kernel"""
     port = 29700 + (os.getpid() % 2000) + 7 * world + int(one_shot)
-    mp.spawn(_rank_main, args=(world, port, str(tmp_path), one_shot), nprocs=world, join=True)
+    _spawn(_rank_main, (world, port, str(tmp_path), one_shot), world)
     for rank in range(world):
         assert (tmp_path / f"ok{rank}.npz").exists()
 
@@ -118,7 +137,7 @@ def _xchg_main(rank, world, port, out_dir):
 @pytest.mark.parametrize("world", [2, 3])
 def test_one_shot_exchange_ranks_on_one_device(tmp_path, world):
     port = 29900 + (os.getpid() % 2000) + world
-    mp.spawn(_xchg_main, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    _spawn(_xchg_main, (world, port, str(tmp_path)), world)
     assert all((tmp_path / f"xok{r}").exists() for r in range(world))
 
 
@@ -266,6 +285,48 @@ def _member_main(rank, world, port, out_dir, name, one_shot):
     dist.destroy_process_group()
 
 
+def _member_stock_main(rank, world, port, out_dir, name):
+    sys.path.insert(0, HERE)
+    import case_runner
+    import synth
+    import torch.distributed as dist
+    from super_sac_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    ms = parallel.MemberShard(rank, world, synth.CASES[name]["E"])
+    res = case_runner.run_engine_stock(name, device="cuda:0", members=ms)
+    assert not parallel.exchange_failed()
+    np.savez(os.path.join(out_dir, f"mstock{rank}.npz"), **res)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_member_sharded_stock_generators_match_the_unsharded_run(tmp_path):
+    """Round-4 advisor (medium): with the STOCK generators a member-sharded rank seeded the in-kernel Philox stream of its
+    chained actor update with the LOCAL member index -- members at the same local position on different ranks got identical
+    noise, all of them a different one than in the unsharded run -- and consumed a device-generator draw for every member
+    it does not own although the owner's launch draws nothing, so the ranks' generators drifted apart.  Three cycles of the
+    `sunrise` case (E 3, members split 2 + 1) with NO injected draws, two ranks on the device against the unsharded engine
+    in this process on the same seeds: actors, critics and temperatures of every member agree (the fixtures run through
+    draw hooks and could not see this)."""
+    import case_runner
+    import synth
+    name, world = "sunrise", 2
+    ref = case_runner.run_engine_stock(name)
+    port = 30900 + (os.getpid() % 2000)
+    _spawn(_member_stock_main, (world, port, str(tmp_path), name), world)
+    got = {}
+    for r in range(world):
+        got.update(dict(np.load(tmp_path / f"mstock{r}.npz")))
+    E = synth.CASES[name]["E"]
+    assert sorted(got) == sorted(ref) and len(got) == 3 * E
+    for k in sorted(ref):
+        err = float(np.max(np.abs(np.asarray(got[k], np.float64) - np.asarray(ref[k], np.float64))))
+        assert err <= 2e-6, (k, err)
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("name,world,one_shot", [("sunrise", 2, False), ("sunrise", 3, True), ("sunrise_discrete", 2, True),
                                                  ("sunrise_discrete", 3, False)],
@@ -278,7 +339,7 @@ def test_member_sharded_sunrise_matches_reference(tmp_path, name, world, one_sho
     target, actor parameters, Adam moments and temperatures land on the REFERENCE fixture's slices for its members;
     sunrise_discrete also clips the critics' and actors' gradients by the norm over ALL members (one scalar all-reduce)."""
     port = 31300 + (os.getpid() % 2000) + 11 * world + int(one_shot)
-    mp.spawn(_member_main, args=(world, port, str(tmp_path), name, one_shot), nprocs=world, join=True)
+    _spawn(_member_main, (world, port, str(tmp_path), name, one_shot), world)
     assert all((tmp_path / f"mok{r}.npz").exists() for r in range(world))
 
 
@@ -322,7 +383,7 @@ def test_config5_humanoid_n16_value_check_at_4_and_8_ranks(tmp_path, world, one_
     weight-gradient launch and the 16-row tile variants: the check is also those variants against the one-GPU kernels."""
     import json
     port = 32300 + (os.getpid() % 2000) + world
-    mp.spawn(_config5_main, args=(world, port, str(tmp_path), one_shot), nprocs=world, join=True)
+    _spawn(_config5_main, (world, port, str(tmp_path), one_shot), world)
     res = json.load(open(tmp_path / "c5_0.json"))
     assert res["updates"] == 6 and res["max_abs_diff"]["td"] <= 2e-5, res
 
@@ -381,7 +442,7 @@ def _humanoid_main(rank, world, port, out_dir):
 @pytest.mark.timeout(600)
 def test_humanoid_n16_sharded_two_ranks_one_shot_exchange(tmp_path):
     port = 30900 + (os.getpid() % 2000)
-    mp.spawn(_humanoid_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    _spawn(_humanoid_main, (2, port, str(tmp_path)), 2)
     assert all((tmp_path / f"hok{r}").exists() for r in range(2))
 
 

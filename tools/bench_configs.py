@@ -27,7 +27,10 @@ if os.environ.get("SSAC_CHAIN_FORM"):   # A/B: one workgroup per CU (0) / co-res
 dev = torch.device("cuda")
 
 
-def build(obs, act, B, N, n, hidden=256, rows=100_000, precision="fp32"):
+def build(obs, act, B, N, n, hidden=256, rows=100_000, precision="fp32", as_rank=False):
+    """as_rank: the agent is installed as a critic-sharded RANK of a one-rank job (parallel.install + Shard(0, 1, N)): its
+    updates take the sharded code path -- the launch list cut at the exchange, the one-shot exchange kernel between the
+    chained launch and the weight-gradient launch -- with every subset member owned locally (tools/shard_budget.py)"""
     torch.manual_seed(0); np.random.seed(0); random.seed(0)
     agent = ssa.Agent(act_space_size=act, encoder=ssa.nets.IdentityEncoder(obs),
                       actor_network_cls=ssa.nets.ContinuousStochasticActor,
@@ -36,6 +39,8 @@ def build(obs, act, B, N, n, hidden=256, rows=100_000, precision="fp32"):
     agent.to(dev)
     ssa.set_precision(agent, precision)
     target = copy.deepcopy(agent)
+    if as_rank:
+        ssa.parallel.install(agent, target, ssa.parallel.Shard(0, 1, N))
     buf = ssa.replay.ReplayBuffer(rows + 1000, device=dev)
     buf.load_experience(*synth.synth_transitions(rows, obs, act, seed=1))
     copt = torch.optim.Adam(chain(*(c.parameters() for c in agent.critics)), lr=3e-4)

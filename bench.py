@@ -46,8 +46,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # HBM bytes per launch of the chained kernel from the offline PMC passes in profiles/ (FETCH_SIZE doubled per the
 # guide's gfx950 note for 16-byte streaming reads + WRITE_SIZE); single-GPU N=10 shape only; not collected in this run
-TRAFFIC_CHAIN_BYTES = (2 * 6067 + 15526) * 1024
-TRAFFIC_SOURCE = "offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r4_kernel_stats.md)"
+TRAFFIC_CHAIN_BYTES = (2 * 6081 + 15541) * 1024
+TRAFFIC_SOURCE = "offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r5_kernel_stats.md)"
 
 
 def synth_data(obs=OBS, act=ACT):

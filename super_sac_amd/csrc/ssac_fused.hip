@@ -1711,8 +1711,12 @@ void fused_chain_pc_kernel(FusedArgs ga, FusedArgs gt, FusedArgs gc, int tiles_a
 // ~18 k (prologue, fc1, epilogues, dz1 store) overlap nothing: ~130 KB of LDS per workgroup means one workgroup per CU.
 // Here every role runs 16-row tiles on the co-resident carve (fused_mlp_body<..., CO>: <= 80 KB of LDS, <= 128 VGPRs), so
 // the 32 producers + 64 consumers + 320 critic tiles of the headline are ONE resident round at two per CU (4 waves per
-// SIMD), and one tile's non-matrix phases hide under its neighbour's K loop.  Same arithmetic, operation by operation, as
-// the 16-row tiles of fused_chain_pc_kernel<16, ...> (bit-identical outputs).
+// SIMD) -- the idea being that one tile's non-matrix phases hide under its neighbour's K loop.  Same arithmetic, operation
+// by operation, as the 16-row tiles of fused_chain_pc_kernel<16, ...> (bit-identical outputs).
+// MEASURED (profiles/r5_chain_coresident.md): NOT faster -- 35.0 - 38.6 us per launch against 29.8 (56 - 63 us per update
+// against 51.4): a pair of 16-row tiles on a CU takes as long as the two one after the other (twice the prologues,
+// epilogues, weight passes and barriers per 32 rows), and the actor -> target-critic chain slows down when it shares CUs.
+// Kept as a selectable, tested form (ssac_chain_form(1)); the library's default is one workgroup per CU.
 __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void fused_chain_co_kernel(FusedArgs ga, FusedArgs gt, FusedArgs gc, int tiles_a, int tiles_t, int target_grid_x,
                            int critic_grid_x, DeferredLogsArgs dl, int dl_on) {

@@ -19,7 +19,7 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29611")
 dist.init_process_group("gloo", rank=0, world_size=1)
 # (enable_one_shot() wants more than one rank; the exchange object itself is happy with a world of one)
-parallel._exchange = parallel.Exchange(0, 1, parallel.ONE_SHOT_MAX_FLOATS, torch.device("cuda"))
+parallel._exchange = parallel.Exchange(0, 1, parallel.ONE_SHOT_MAX_FLOATS, torch.device("cuda", 0))
 
 print("| shape | obs / act | B | critics on the rank | sharded rank: us per critic update (+Polyak/2) | unsharded engine with that many critics |")
 print("|---|---|---|---|---|---|")

@@ -33,8 +33,14 @@ for rep in range(3):
               f"ends {e.min():.2f} .. {e.max():.2f}; durations min {np.min(e - s):.2f} median {np.median(e - s):.2f} max {np.max(e - s):.2f}")
         if rep == 2:
             if name.startswith("chained"):
-                NT = 2 * ((B + 15) // 16)   # target-chain workgroups: 16-row tiles x 2 subset slots
-                groups = (("target chains", 0, NT), ("critic tiles", NT, n))
+                # producer / consumer form (fused_chain_pc_kernel<32>): producers, 32-row critic tiles, consumers; with 16-row
+                # critic tiles: producers, consumers, critic tiles (tools/r5/co_timeline.py knows the co-resident form too)
+                T = (B + 15) // 16
+                nc32 = N * ((B + 31) // 32)
+                if n in (3 * T + nc32, 3 * T + nc32 + 1):
+                    groups = (("producers", 0, T), ("critic tiles", T, T + nc32), ("consumers", T + nc32, 3 * T + nc32))
+                else:
+                    groups = (("producers", 0, T), ("consumers", T, 3 * T), ("critic tiles", 3 * T, n))
             else:
                 groups = (("fc2 tiles", 0, 16 * N), ("fc1 tiles", 16 * N, 20 * N), ("head", 20 * N, 24 * N), ("TD", 24 * N, 24 * N + 1))
             if not name.startswith("chained"):
@@ -53,28 +59,6 @@ for rep in range(3):
                 s, e = s[order], e[order]
                 d = (e - s)[:16 * N].reshape(N, 16)
                 print("      fc2 tile durations by net (rows) x tile (columns):")
-                for row in d:
-                    print("       ", " ".join(f"{v:5.1f}" for v in row))
-            else:
-                # (each half of the chained launch is XCD-contiguous: ssac_xcd_contiguous_range)
-                def rng_order(t0_, n_):
-                    b = np.arange(t0_, n_)
-                    x = b & 7
-                    cnt = lambda upto, y: np.where(upto > y, (upto - y + 7) >> 3, 0)
-                    before = np.zeros_like(b)
-                    for y in range(8):
-                        before += np.where(y < x, cnt(n_, y) - cnt(t0_, y), 0)
-                    return before + (b >> 3) - cnt(t0_, x)
-                NT = 2 * ((B + 15) // 16)
-                nc = n - NT
-                rows32 = nc == N * ((B + 31) // 32)   # 32-row critic tiles take the first ids, 16-row ones the last
-                if rows32:
-                    order = np.concatenate([nc + np.argsort(rng_order(nc, n)), np.argsort(rng_order(0, nc))])
-                else:
-                    order = np.concatenate([np.argsort(rng_order(0, NT)), NT + np.argsort(rng_order(NT, n))])
-                s, e = s[order], e[order]
-                d = (e - s)[NT:n].reshape(N, -1)
-                print("      critic tile durations by net (rows) x row tile (columns):")
                 for row in d:
                     print("       ", " ".join(f"{v:5.1f}" for v in row))
             for gname, lo, hi in groups:

@@ -401,7 +401,17 @@ def run_case(name, cfg):
                maxdiff(rtc, ot.critic_params()))
     dla = max(abs(float(x) - float(y)) for x, y in zip(r_las, o_las))
     print(f"   td max|diff| {worst:.3e}   params max|diff| {dpar:.3e}   log_alpha diff {dla:.3e}")
-    assert worst < 5e-4 and dpar < 5e-5 and dla < 1e-6
+    if name in synth.FULL_SIZE:
+        # BASELINE's full pixel sizes (hidden-1024 MLPs behind a 39 200-wide encoder output, B 512 / 1024): the counted
+        # sign-flip rule of assert_encoder_close for the MLPs too -- a weight whose gradient is rounding noise takes Adam's
+        # first steps of ~lr in either direction under another summation order
+        pairs = list(zip(rc, oa.critic_params())) + list(zip(rac, oa.actor_params())) + list(zip(rtc, ot.critic_params()))
+        nbad = sum(int(((a_.detach() - b_.detach()).abs() > 5e-5).sum()) for a_, b_ in pairs)
+        ntot = sum(a_.numel() for a_, _ in pairs)
+        print(f"   {nbad} of {ntot} MLP parameters differ by more than 5e-5")
+        assert worst < 5e-4 and dla < 1e-6 and nbad <= max(2, ntot // 10000) and dpar <= 2.2 * cfg["lr"] * max(upd, 1)
+    else:
+        assert worst < 5e-4 and dpar < 5e-5 and dla < 1e-6
 
     if px:
         re_, rte_ = ref_encoder_params(ra.encoder, cfg), ref_encoder_params(rt.encoder, cfg)

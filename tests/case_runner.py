@@ -595,7 +595,7 @@ def straggler_check(err, tol, max_step, who, key):
     return int(bad.sum())
 
 
-def compare(rec, fx, *, td_tol=2e-4, log_rtol=5e-4, par_tol=3e-5, enc_max_step=3e-3, who="backend"):
+def compare(rec, fx, *, td_tol=2e-4, log_rtol=5e-4, par_tol=3e-5, enc_max_step=3e-3, who="backend", mlp_max_step=0.0):
     """Assert rec (a backend's record) matches the reference fixture within the stated
     fp32 tolerances.  Returns the worst deviations for reporting.  EVERY output key of the fixture must be in the
     record: a dropped key fails (round 3 skipped silently anything that was not a TD / log key)."""
@@ -621,6 +621,12 @@ def compare(rec, fx, *, td_tol=2e-4, log_rtol=5e-4, par_tol=3e-5, enc_max_step=3
             err = np.abs(got - ref)
             worst["stragglers"] += straggler_check(err, par_tol, enc_max_step, who, key)
             assert float(np.median(err)) <= 1e-6, f"{who}: {key} median {np.median(err):.3e}"
+        elif key.startswith("final") and key != "final_log_alpha" and mlp_max_step > 0.0 and not key.endswith("_v") \
+                and not key.endswith("_m"):
+            # (full-size pixel cases, synth.FULL_SIZE: counted sign-flip stragglers in the MLP parameters as well, bounded
+            # by the distance opposite Adam steps can open)
+            err = np.abs(got - ref)
+            worst["stragglers"] += straggler_check(err, par_tol, mlp_max_step, who, key)
         elif key.startswith("final") and key != "final_log_alpha":
             scale = 1.0 if not key.endswith("_v") else max(1e-12, float(np.max(np.abs(ref))))
             dv = float(np.max(np.abs(got - ref)) / scale)
@@ -633,6 +639,51 @@ def compare(rec, fx, *, td_tol=2e-4, log_rtol=5e-4, par_tol=3e-5, enc_max_step=3
             assert np.allclose(got, ref, rtol=1e-4, atol=1e-5), f"{who}: {key} {got} vs {ref}"
         else:
             raise AssertionError(f"{who}: fixture key {key} is neither a declared input nor an output compare() knows")
+    return worst
+
+
+def compare_full_size(rec, fx, cfg, who):
+    """The pixel configurations at BASELINE.json's full sizes (synth.FULL_SIZE) against the reference's fixture.
+    * Update 0 -- everything that does not sit behind an optimizer step: TD targets 2e-4, logs 5e-4 (measured on the GPU:
+      TD 7.5e-7, losses exact, gradient norms <= 3.5e-4 relative): the full-size forward, loss and backward.
+    * Parameters / Polyak targets after the sequence: median error <= 2e-6, at least 99 % of the elements within 3e-5, EVERY
+      element within the distance opposite Adam steps can open (2.2 lr per step).  Adam's first steps move a weight by
+      ~lr * sign(g) whatever |g| is; at these sizes a fraction of a percent of the weights (fc columns behind mostly-dead
+      features, 860 k-term convolution sums) have gradients at rounding level, which another summation order sends the
+      other way -- the reference's own CPU arithmetic against the oracle's flips 6 of 499 220 MLP weights, the GPU's
+      implicit-GEMM order ~0.5 % of the sampled encoder weights.  Counted and bounded, not waved through.
+    * Quantities BEHIND an optimizer step (update >= 1, the actor / temperature step) inherit that: TD targets 3e-3, logs 1e-2
+      (measured: <= 8.6e-4 / 5.3e-3)."""
+    lr_max = max(cfg["lr"], (cfg.get("pixels") or {}).get("enc_lr", 0.0))
+    max_step = 2.2 * lr_max * cfg["cycles"] * cfg["utd"]
+    worst = {"td0": 0.0, "log0": 0.0, "td": 0.0, "log": 0.0, "param_max": 0.0, "param_bad_frac": 0.0}
+    for key, ref in fx.items():
+        if _INPUT_KEY.fullmatch(key):
+            continue
+        assert key in rec, f"{who}: the record lacks the fixture's output {key}"
+        got, ref = np.asarray(rec[key], np.float64), np.asarray(ref, np.float64)
+        first = key.startswith("u0_")
+        if "_td" in key:
+            dv = float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))))
+            worst["td0" if first else "td"] = max(worst["td0" if first else "td"], dv)
+            assert dv <= (2e-4 if first else 3e-3), f"{who}: {key} deviates {dv:.3e}"
+        elif "_log:" in key:
+            dv = float(abs(got - ref) / (max(1.0, abs(ref)) if "gradients/" not in key else max(1e-6, abs(ref))))
+            worst["log0" if first else "log"] = max(worst["log0" if first else "log"], dv)
+            assert dv <= (5e-4 if first else 1e-2), f"{who}: {key} = {got} vs reference {ref}"
+        elif key == "final_log_alpha":
+            assert np.max(np.abs(got - ref)) <= 1e-6, f"{who}: log_alpha {got} vs {ref}"
+        elif key.endswith("_v") or key.endswith("_m"):
+            scale = max(1e-12, float(np.max(np.abs(ref))))
+            assert float(np.max(np.abs(got - ref))) / scale <= (1e-3 if key.endswith("_v") else 2e-2), f"{who}: {key}"
+        elif key.startswith("final"):
+            err = np.abs(got - ref)
+            frac = float((err > 3e-5).mean())
+            worst["param_max"], worst["param_bad_frac"] = max(worst["param_max"], float(err.max())), max(worst["param_bad_frac"], frac)
+            assert float(np.median(err)) <= 2e-6 and frac <= 0.01 and float(err.max()) <= max_step, \
+                f"{who}: {key}: median {np.median(err):.3e}, {frac:.2%} over 3e-5, max {err.max():.3e} (bound {max_step:.2e})"
+        else:
+            raise AssertionError(f"{who}: fixture key {key} is neither a declared input nor an output compare_full_size knows")
     return worst
 
 

@@ -7,6 +7,10 @@ draws that the reference consumed), never the 100k-row buffers or the weights.
 import numpy as np
 
 # name -> configuration of one parity case.  Values follow SURVEY.md Appendix C.
+# the cases that run at BASELINE.json's full pixel sizes (seconds per update on the CPU): the GPU suite runs them once each,
+# not once per launch form
+FULL_SIZE = ("drqv2_pixels_full", "atari_pixels_full")
+
 CASES = {
     # small REDQ: full post-update parameter dump is stored
     "redq_small": dict(obs=17, act=6, hidden=64, N=4, n=2, E=1, B=128, rows=2000, cap=4096,
@@ -86,6 +90,23 @@ CASES = {
                            noise=dict(scale=0.5, clip=0.3), cycles=2, utd=1, target_delay=1, seed=93,
                            pixels=dict(kind="big", channels=9, hw=84, emb=50, enc_lr=1e-4, enc_tau=1.0,
                                        aug="drqv2", aug_mix=1.0)),
+    # ---- round 5: the two pixel configurations at BASELINE.json's FULL sizes (configs 3 and 4): until now the reference
+    # fixtures for pixels were B 8 and the full-size GPU tests compared the implicit-GEMM path with the im2col path
+    # (round-4 review, weak 1d).  One environment step each (the CPU reference needs ~10 s per update at these sizes).
+    "drqv2_pixels_full": dict(obs=50, act=6, hidden=1024, N=2, n=2, E=1, B=512, rows=640, cap=704,
+                              lo=-10.0, hi=2.0, popart=False, pop=False, discrete=False,
+                              actor="deterministic", gamma=0.99 ** 3, lr=1e-4, alpha_lr=0.0, init_alpha=0.0,
+                              clip=None, tau=0.01, weight_type=None, temp=None,
+                              noise=dict(scale=0.5, clip=0.3), cycles=1, utd=2, target_delay=1, seed=117,
+                              pixels=dict(kind="big", channels=9, hw=84, emb=50, enc_lr=1e-4, enc_tau=1.0,
+                                          aug="drqv2", aug_mix=1.0)),
+    "atari_pixels_full": dict(obs=128, act=4, hidden=256, N=2, n=2, E=1, B=1024, rows=1200, cap=1280,
+                              lo=-10.0, hi=2.0, popart=False, pop=False, discrete=True,
+                              actor="discrete", gamma=0.99, lr=3e-4, alpha_lr=1e-4, init_alpha=0.1,
+                              clip=40.0, tau=0.005, weight_type=None, temp=None, noise=None,
+                              cycles=1, utd=2, target_delay=2, seed=118,
+                              pixels=dict(kind="small", channels=4, hw=84, emb=128, enc_lr=3e-4, enc_tau=0.01,
+                                          aug="drqv2", aug_mix=0.9)),
     # ---- round 2 ----
     # BASELINE config 1: Pendulum-v1 SAC (gym/sac.gin), 2 critics, batch 256, hidden 256
     "pendulum_sac": dict(obs=3, act=1, hidden=256, N=2, n=2, E=1, B=256, rows=2000, cap=4096,

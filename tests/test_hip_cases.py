@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("wgrad", [1, 2], ids=["wgrad-64x64", "wgrad-32x32"])
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "per-layer"])
-@pytest.mark.parametrize("name", list(synth.CASES))
+@pytest.mark.parametrize("name", [n_ for n_ in synth.CASES if n_ not in synth.FULL_SIZE])
 def test_engine_matches_reference(name, fused, wgrad):
     """both kernel families: the one-launch fused MLP kernels and the per-layer GEMM path -- and both forms of the merged
     weight-gradient launch under each: 64 x 64 tiles with an LDS-staged K loop, and the latency form (32 x 32 tiles, K
@@ -34,6 +34,21 @@ def test_engine_matches_reference(name, fused, wgrad):
         ssa.engine.set_wgrad_variant(0)
     fx = case_runner.load_fixture(name)
     worst = case_runner.compare(rec, fx, who=f"hip[{name},{'fused' if fused else 'per-layer'},wgrad {wgrad}]")
+    print(f"{name}: worst deviations vs reference {worst}")
+
+
+@pytest.mark.parametrize("name", synth.FULL_SIZE)
+def test_full_size_pixel_updates_match_the_reference(name):
+    """BASELINE configs 3 and 4 at their FULL sizes against the REFERENCE (round-4 review, weak 1d: the pixel fixtures were
+    B 8, the full-size tests compared the implicit-GEMM path with the im2col path): DrQv2 on 9 x 84 x 84 observations, B 512,
+    hidden 1024 (`drqv2_pixels_full`) and SAC-Discrete on 4 x 84 x 84, B 1024, clip 40 (`atari_pixels_full`) -- one
+    environment step each (two critic updates, Polyak, actor [, temperature] update) through the implicit-GEMM convolutions
+    the benchmark runs, fixtures written by oracle/gen_golden.py from the unmodified reference.  Tolerances: see
+    case_runner.compare_full_size (update 0 at the fp32 tolerances of every other fixture; parameters with counted, bounded
+    sign-flip stragglers; what sits behind an optimizer step at 3e-3 / 1e-2)."""
+    cfg = synth.CASES[name]
+    rec = case_runner.run_engine(name)
+    worst = case_runner.compare_full_size(rec, case_runner.load_fixture(name), cfg, who=f"hip[{name}]")
     print(f"{name}: worst deviations vs reference {worst}")
 
 

@@ -160,7 +160,10 @@ def test_pixel_encoders(kind, ch, emb):
 @pytest.mark.parametrize("name", list(synth.CASES))
 def test_update_cases_match_reference(name):
     rec = case_runner.run_oracle(name)
-    worst = case_runner.compare(rec, case_runner.load_fixture(name), who=f"oracle[{name}]")
+    cfg = synth.CASES[name]
+    # (the full-size pixel cases: counted sign-flip stragglers in the hidden-1024 / B 1024 MLPs too, see compare())
+    step = 2.2 * cfg["lr"] * cfg["cycles"] * cfg["utd"] if name in synth.FULL_SIZE else 0.0
+    worst = case_runner.compare(rec, case_runner.load_fixture(name), who=f"oracle[{name}]", mlp_max_step=step)
     assert worst["param"] < 3e-5
 
 

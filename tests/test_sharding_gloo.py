@@ -224,3 +224,48 @@ def test_member_sharded_sunrise_updates_equal_reference_fixture(tmp_path, world)
                 k += 1
         want = fx["final_critic"][lo * per_c: hi * per_c]
         assert np.max(np.abs(got["params"] - want)) < 2e-6, f"rank {rank}: its members' critics diverged from the reference"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the actor step's exchange steps on a critic-sharded job (SURVEY 8(e) "Collective -- actor step"; round 5: rank claim)
+# ---------------------------------------------------------------------------------------------------------------
+def _actor_routing_rank(rank, world, port, out_dir):
+    """local arg-min -> MIN all-reduce -> claim (rank if the local minimum is the global one, else +inf) -> MIN all-reduce of
+    the claims -> only the winner keeps its dQ/da row -> SUM all-reduce: what learning._online_actor_update issues around
+    ssac_actor_route_local / _claim / _mask, with the kernels' arithmetic restated in torch and the REAL collectives"""
+    sys.path.insert(0, HERE)
+    from super_sac_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    N, B, A = 7, 200, 5                      # 7 critics over 3 ranks: shards of 3 / 2 / 2
+    shard = parallel.Shard(rank, world, N)
+    g = torch.Generator().manual_seed(77)    # every rank rebuilds the whole table, uses its own critics' rows
+    q = torch.randn(N, B, generator=g)
+    dxu = torch.randn(N, B, A, generator=g)
+    q[3, :30] = q[0, :30] = q[:, :30].min(0).values - 1.0      # bit-equal minima on ranks 0 and 1
+    q[6, 30:50] = q[4, 30:50] = q[:, 30:50].min(0).values - 1.0  # ... on ranks 1 and 2
+    q[5, 50:60] = q[3, 50:60] = q[1, 50:60] = -40.0            # ... on all three
+    ql, dl = q[shard.lo:shard.hi], dxu[shard.lo:shard.hi]
+    qloc, am = ql.min(0)                                       # first local index on ties, as the kernel's scan
+    dsel = dl[am, torch.arange(B)].clone()
+    qglob = qloc.clone()
+    parallel.all_reduce_min(qglob)
+    claim = torch.where(qloc == qglob, torch.full((B,), float(rank)), torch.full((B,), float("inf")))
+    parallel.all_reduce_min(claim)
+    dsel[claim != float(rank)] = 0.0
+    parallel.all_reduce_sum(dsel)
+    am_glob = q.min(0).indices                                 # torch.min over ALL critics: the reference's routing
+    ok = torch.equal(dsel, dxu[am_glob, torch.arange(B)]) and torch.equal(qglob, q.min(0).values)
+    open(os.path.join(out_dir, f"route{rank}"), "w").write("ok" if ok else "WRONG")
+    dist.destroy_process_group()
+
+
+def test_sharded_actor_routing_with_ties_equals_torch_min(tmp_path):
+    """three ranks, gloo: the routed action gradient of every row -- rows whose minimum is held bit-equal by two or three
+    ranks included -- is the one torch.min over all critics routes (learning.py:402; before round 5 every tied rank kept
+    its row and the SUM doubled the gradient)"""
+    port = 29400 + (os.getpid() % 2000)
+    mp.spawn(_actor_routing_rank, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert all((tmp_path / f"route{r}").read_text() == "ok" for r in range(3))

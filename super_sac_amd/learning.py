@@ -569,9 +569,7 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
     if ms is not None:
         assert lu.is_identity(agent.encoder), "member sharding: a trainable encoder is shared by all members (not sharded)"
         assert not per and not update_priorities and not dr3_coeff, "member sharding covers the online critic update"
-        if weight_type is not None and weighted_bellman_temp is not None and weight_type != "sunrise":
-            raise NotImplementedError("member-sharded ranks compute the 'sunrise' backup weights (the 'softmax' weights "
-                                      "sample from every member's ONLINE actor: learning_utils.py:383-393)")
+        assert weight_type in (None, "sunrise", "softmax"), f"unknown weight_type {weight_type!r}"
     dev = log_alphas[0].device
     ws = lu.agent_ws(agent, dev)
     adam = engine.adam_group(critic_optimizer, dev)
@@ -588,6 +586,13 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
     # weights of member i look at the ONLINE critics of ALL members (learning_utils.py:383-393).
     preps = []
     all_rd = []   # member-sharded ranks: every global member's batch, in member order
+    # member-sharded "softmax" weights (round 5): every member's policy samples on EVERY member's batch, drawn in the
+    # reference's order -- right behind that batch's TD draws -- by every rank; the table is completed after the loop
+    ms_softmax = (ms is not None and weight_type == "softmax" and weighted_bellman_temp is not None and E_glob > 1)
+    sm_table = None
+    if ms_softmax:
+        sm_table = ws.get("bw.table", (E_glob, E_glob, batch_size))   # [batch of member i][member k][row]
+        sm_table.zero_()
     for ig in range(E_glob):
         i = ig if ms is None else ms.local(ig)
         if i is None:
@@ -597,6 +602,8 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                                             aug_mix=aug_mix, per=per, _invariance=bool(encoder_lambda))
             lu.skip_td_draws(agent, agent.actors[0], batch_size, dev, target_agent.critics[0].arena(dev).n_nets,
                              target_critic_ensemble_n, random_process)
+            if ms_softmax:
+                lu.member_sharded_softmax_scores(rd, agent, target_agent, ms, sm_table[ig])
             all_rd.append(rd)
             continue
         arena = agent.critics[i].arena(dev)
@@ -652,6 +659,8 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
         if co_done:
             h1, h2, q = co[3], co[4], co[5]
         all_rd.append(rd)
+        if ms_softmax:
+            lu.member_sharded_softmax_scores(rd, agent, target_agent, ms, sm_table[ig])
         bw = 1.0 if ms is not None else \
             lu.compute_backup_weights(logs=logs, replay_dict=rd, agent=agent, target_agent=target_agent,
                                       weight_type=weight_type, weight_temp=weighted_bellman_temp,
@@ -660,7 +669,10 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
                           fwd=(h1, h2, q) if (co_done or branch is not None) else None,
                           xin=(s_rep, X, ldx) if (branch is not None or co is not None) else None))
     if ms is not None and weight_type is not None and weighted_bellman_temp is not None and E_glob > 1:
-        wts = lu.member_sharded_sunrise_weights(logs, all_rd, agent, target_agent, ms, weighted_bellman_temp, discrete, slot)
+        if ms_softmax:
+            wts = lu.member_sharded_softmax_finish(logs, sm_table, ms, weighted_bellman_temp, slot)
+        else:
+            wts = lu.member_sharded_sunrise_weights(logs, all_rd, agent, target_agent, ms, weighted_bellman_temp, discrete, slot)
         for i, P in enumerate(preps):
             P["bw"] = wts[ms.lo + i]
     for i, P in enumerate(preps):

@@ -899,6 +899,69 @@ def member_sharded_sunrise_weights(logs, replay_dicts, agent, target_agent, memb
     return out
 
 
+def member_sharded_softmax_scores(replay_dict, agent, target_agent, member_shard, row):
+    """The "softmax" backup weights on a member-sharded rank, first half (learning_utils.py:383-393), for the batch of ONE
+    global member -- owned or not: EVERY member k's online actor samples a'_k on the target encoder's s' and member k's online
+    critics score it.  The draws are made for all E members in member order on every rank (shape-only for the tanh-normal
+    policy; a categorical draw on a uniform stand-in for a member another rank holds), this rank's members fill their rows
+    of `row` (E x B: [member k][batch row]); the all-gather over the ranks completes the table
+    (member_sharded_softmax_finish)."""
+    ms = member_shard
+    o1 = replay_dict["primary_batch"][3]
+    ensure_gathered(replay_dict.get("_ssac"))
+    s1_rep = encode(target_agent.encoder, o1)
+    B, S = s1_rep.shape
+    dev = s1_rep.device
+    ws = agent_ws(agent, dev)
+    st = engine.stream()
+    lds = _row_stride(s1_rep)
+    for kg in range(ms.ensemble_size):
+        k = ms.local(kg)
+        actor = agent.actors[0 if k is None else k]
+        kind = actor_kind(actor)
+        if kind == "discrete":
+            if k is None:   # (a stand-in draw of the same shape keeps the hooks / the generator in step with the owner's)
+                rng.draw_categorical(torch.zeros(B, agent.critics[0].arena(dev).out_dim, device=dev))
+                continue
+            a_arena, c_arena = engine.bind_arena(actor, "self", [actor], dev), agent.critics[k].arena(dev)
+            _, _, aout = engine.mlp_forward(a_arena, s1_rep, lds, 0, B, ws, f"bw.a{k}", save=False)
+            a1 = rng.draw_categorical(aout[0]).to(torch.float32).view(B, 1)
+            _, _, q = engine.mlp_forward(c_arena, s1_rep, lds, 0, B, ws, f"bw.c{k}", save=False)
+            check(lib.ssac_ensemble_min_select(q.data_ptr(), c_arena.n_nets, B, c_arena.out_dim, a1.data_ptr(), 1,
+                                               row[kg].data_ptr(), st))
+        else:
+            assert kind == "stochastic", "softmax backup weights sample from a stochastic policy"
+            A = actor.action_size
+            eps = rng.draw_normal((B, A), dev)   # actor_k(s1_rep).sample(): every rank makes every member's draw
+            if k is None:
+                continue
+            a_arena, c_arena = engine.bind_arena(actor, "self", [actor], dev), agent.critics[k].arena(dev)
+            _, _, aout = engine.mlp_forward(a_arena, s1_rep, lds, 0, B, ws, f"bw.a{k}", save=False)
+            x1 = _concat_buffer(ws, f"bw.x1.{k}", s1_rep, A)
+            check(lib.ssac_tanh_normal_fwd(aout.data_ptr(), 2 * A, eps.data_ptr(), B, A, float(actor.log_std_low),
+                                           float(actor.log_std_high), x1.data_ptr(), S + A, S, 0, st))
+            _, _, q = engine.mlp_forward(c_arena, x1, S + A, 0, B, ws, f"bw.c{k}", save=False)
+            check(lib.ssac_ensemble_min_select(q.data_ptr(), c_arena.n_nets, B, 1, 0, 0, row[kg].data_ptr(), st))
+
+
+def member_sharded_softmax_finish(logs, table, member_shard, weight_temp, slot):
+    """second half: all-gather of the (batch of member i, member k, row) table -- a SUM of disjointly filled blocks -- then
+    B softmax_b(-std_k T) for the members this rank owns.  Returns {global member index: (B, 1) weights}."""
+    from . import parallel
+    ms = member_shard
+    E, B = table.shape[1], table.shape[2]
+    parallel.all_gather_blocks(table)
+    out = {}
+    for ig in range(ms.lo, ms.hi):
+        w = torch.empty(B, 1, device=table.device)
+        check(lib.ssac_softmax_weights(table[ig].data_ptr(), E, B, float(weight_temp), w.data_ptr(), slot[L_BW:].data_ptr(),
+                                       engine.stream()))
+        out[ig] = w
+    for j, nm in enumerate(("mean", "max", "min", "std")):   # (the LAST owned member's statistics stay in the block)
+        logs[f"bellman_weights/{nm}"] = slot[L_BW + j]
+    return out
+
+
 def compute_backup_weights(logs, replay_dict, agent, target_agent, weight_type, weight_temp, batch_size,
                            discrete=False, _slot=None):
     """learning_utils.py:357-398.  "sunrise": sigmoid(-std_k(Qbar_k(s, a)) T) + 0.5 over the members' TARGET critics

@@ -329,15 +329,20 @@ def test_member_sharded_stock_generators_match_the_unsharded_run(tmp_path):
 
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize("name,world,one_shot", [("sunrise", 2, False), ("sunrise", 3, True), ("sunrise_discrete", 2, True),
-                                                 ("sunrise_discrete", 3, False)],
-                         ids=["sunrise-2-collective", "sunrise-3-one-shot", "discrete-2-one-shot", "discrete-3-collective"])
+                                                 ("sunrise_discrete", 3, False), ("softmax_weights", 2, True),
+                                                 ("softmax_weights", 3, False), ("softmax_discrete", 2, True)],
+                         ids=["sunrise-2-collective", "sunrise-3-one-shot", "discrete-2-one-shot", "discrete-3-collective",
+                              "softmax-2-one-shot", "softmax-3-collective", "softmax-discrete-2-one-shot"])
 def test_member_sharded_sunrise_matches_reference(tmp_path, name, world, one_shot):
     """E = 3 members over 2 ranks (2 + 1) and over 3 ranks (one each), the ranks sharing the one device: every rank makes
     every member's host draws, gathers all three batches, scores them with ITS members' target critics; the all-gather of
     the (batch x member x row) table -- through gloo and through the one-shot exchange kernel -- gives each rank the
     SUNRISE weights of its own members (learning_utils.py:372-382).  Each rank's TD targets, TD / temperature logs, critic,
     target, actor parameters, Adam moments and temperatures land on the REFERENCE fixture's slices for its members;
-    sunrise_discrete also clips the critics' and actors' gradients by the norm over ALL members (one scalar all-reduce)."""
+    sunrise_discrete also clips the critics' and actors' gradients by the norm over ALL members (one scalar all-reduce).
+    Round 5: the "softmax" weights too (learning_utils.py:383-393: every member's ONLINE actor samples a' on every member's
+    next states and its online critics score it) -- every rank makes all E x E policy draws in the reference's order, fills
+    its members' rows of the table, one all-gather, B softmax_b(-std_k T) for its own members; continuous and discrete."""
     port = 31300 + (os.getpid() % 2000) + 11 * world + int(one_shot)
     _spawn(_member_main, (world, port, str(tmp_path), name, one_shot), world)
     assert all((tmp_path / f"mok{r}.npz").exists() for r in range(world))

@@ -587,7 +587,7 @@ def fp32_sweep(ssa, device):
             check(lib.ssac_chain_update(
                 C.byref(aa.desc()), x1.data_ptr(), IN, B, eps.data_ptr(), -5.0, 2.0, x1.data_ptr(), IN, S, lp.data_ptr(), 0,
                 C.byref(ta.desc()), ids.data_ptr(), 2, qt.data_ptr(), C.byref(ca.desc()), xc.data_ptr(), IN, h1.data_ptr(),
-                h2.data_ptr(), q.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), 0, 0, 0, ho.data_ptr(), 1, st))
+                h2.data_ptr(), q.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), 0, 0, 0, ho.data_ptr(), 1, 0, st))
 
         def wgrad_launch():
             engine.weight_grads(ca, xc, IN, 0, h1, h2, dq, dz2, dz1, B, grads=grads, sumsq=ss, rowscale=dq)

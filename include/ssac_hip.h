@@ -706,7 +706,12 @@ int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t ldxa, int 
                       float *W3_snapshot, const ssac_gather *gather,
                       const ssac_deferred_logs *deferred /* nullable */,
                       unsigned long long *handoff /* nullable: n_rows x A words, zeroed once */,
-                      int target_splits /* 1, 2, 4: ssac_chain_target_splits() */, void *stream);
+                      int target_splits /* 1, 2, 4: ssac_chain_target_splits() */,
+                      ssac_xchg *xchg /* nullable; critic-sharded rank, with handoff: the MIN exchange of Qt over the ranks
+                                         (what ssac_xchg_reduce_owned(xchg, Qt, n_sel * n_rows, net_ids, n_sel, target_splits)
+                                         would do as a launch of its own) runs in a tail workgroup of THIS launch, behind
+                                         its target-critic workgroups */,
+                      void *stream);
 /* handoff != NULL selects the PRODUCER / CONSUMER form of the launch: the actor runs ONCE per 16-row tile (not once per
  * subset slot) and publishes a' as tagged 8-byte granules in `handoff`; the target-critic workgroups of the tile gather
  * their own s' rows, run fc1 on the state columns while the actor is still working, poll the granules and add

@@ -224,7 +224,7 @@ SIGNATURES = {
     "ssac_actor_sample_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _P, _P, _P, _P],
     "ssac_actor_sample_critic_fwd": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _L, _P, _P, _P, _P, _P],
     "ssac_chain_update": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _I, _P, _MP, _P, _L, _P, _P, _P, _P, _P,
-                          _P, _P, _P, _P, _I, _P],
+                          _P, _P, _P, _P, _I, _P, _P],
     "ssac_chain_target_splits": [_MP, _MP, _MP, _I, _I],
     "ssac_chain_form": [_I],
     "ssac_deferred_logs_flush": [_P, _I, _P],

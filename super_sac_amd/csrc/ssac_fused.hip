@@ -36,6 +36,7 @@
 #include "ssac_philox.h"
 #include "ssac_critic_logs.h"
 #include "ssac_begin.h"
+#include "ssac_xchg_body.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -101,6 +102,8 @@ struct FusedArgs {
     float *begin_logs; int begin_n; ssac_adam_ctl *begin_ctl;   // MODE_SAMPLE, tile 0: ssac_begin_update's duties folded in
                                                                   // (log block cleared, optimizer step advanced)
     Handoff ho;                        // MODE_SAMPLE: publish a'; MODE_PLAIN (16-row tiles): take the action columns from it
+    unsigned *xarrive;                 // hand-off consumers of a SHARDED rank whose exchange runs in the launch's tail workgroup
+                                       // (fused_chain_pc_kernel): Y leaves as agent-scope stores and the workgroup counts itself in
 };
 
 // TD target of row b (see ssac_td_spec; same operation order as td_target_kernel in ssac_elementwise.hip)
@@ -802,6 +805,18 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         }
         if (g.gth_role == 4) gidx = nullptr;  // (its rows are read from X)
     }
+    // (sharded rank, exchange inside this launch: a consumer's Q must be visible to the exchange's workgroup on another CU / XCD
+    //  -- agent-scope stores -- and the workgroup counts itself in once its stores have left the CU)
+    auto y_store = [&](float *p_, float v_) {
+        if (HO && MODE == MODE_PLAIN && g.xarrive) __hip_atomic_store(p_, v_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p_ = v_;
+    };
+    auto consumer_arrive = [&]() {
+        if (HO && MODE == MODE_PLAIN && g.xarrive) {
+            __syncthreads();   // (drains every wave's stores: s_waitcnt vmcnt(0) in front of the barrier)
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(g.xarrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     const int net = idsp ? idsp[e] : e;
     if (net < 0) {
         // slot without a net (a REDQ subset member another rank owns): its outputs are +inf, the neutral
@@ -811,9 +826,10 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
             for (int i = threadIdx.x; i < TMR * OUT; i += NTHR) {
                 const int r = i / OUT, o = i - r * OUT;
                 if ((m0 + r) < g.n_rows)
-                    g.Y[(((int64_t)e * nsp + split) * g.n_rows + m0 + r) * OUT + o] = split == 0 ? __builtin_inff() : 0.0f;
+                    y_store(g.Y + (((int64_t)e * nsp + split) * g.n_rows + m0 + r) * OUT + o, split == 0 ? __builtin_inff() : 0.0f);
             }
         }
+        consumer_arrive();
         return;
     }
     const float *P = g.params + (int64_t)net * g.net_stride;
@@ -1171,7 +1187,8 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
 #pragma unroll
             for (int o = 16; o > 0; o >>= 1) qp_ += __shfl_xor(qp_, o, 64);   // (the row's 32 threads are half a wave)
             if (c0_ == 0 && g.Y && (m0 + row) < g.n_rows)
-                g.Y[((int64_t)e * NSPL + split) * g.n_rows + m0 + row] = split == 0 ? qp_ + b3s[0] : qp_;
+                y_store(g.Y + ((int64_t)e * NSPL + split) * g.n_rows + m0 + row, split == 0 ? qp_ + b3s[0] : qp_);
+            consumer_arrive();
             return;
         }
         // ---- fc2 (the backward-data phase re-reads W2 as a row-contiguous image: its first chunk is
@@ -1260,7 +1277,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
 #pragma unroll
                 for (int w = 0; w < 8; ++w) v += hpart[w * TMR + tid];
                 ys[tid * ldo] = v;
-                if (g.Y && (m0 + tid) < g.n_rows) g.Y[(int64_t)e * g.n_rows + m0 + tid] = v;
+                if (g.Y && (m0 + tid) < g.n_rows) y_store(g.Y + (int64_t)e * g.n_rows + m0 + tid, v);
                 if (HO && MODE == MODE_CRITIC_U && g.ho.qpub && (m0 + tid) < g.n_rows)   // the actor workgroup of the tile is polling
                     handoff_publish(g.ho.qpub + (int64_t)e * g.n_rows + m0 + tid,
                                     g.ho.base + (g.ho.tick ? (unsigned)*g.ho.tick : 0u), v);
@@ -1311,7 +1328,7 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
         }
     }
     BSTAMP(7);
-    if (MODE == MODE_PLAIN) return;
+    if (MODE == MODE_PLAIN) { consumer_arrive(); return; }
     lds_barrier();  // hpart (= staging buffer 0) has been consumed
     if (IS_CRITIC && !CO && !DIRECT_BWD) stage_first(st3, Ws, H, tid);
 
@@ -1672,7 +1689,7 @@ void fused_chain_kernel(FusedArgs ga, FusedArgs ga_rest, FusedArgs gt, FusedArgs
 template <int TC, bool ADBUF, bool AW3LATE = false>
 __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_chain_pc_kernel(FusedArgs ga, FusedArgs gt, FusedArgs gc, int tiles_a, int tiles_t, int target_grid_x,
-                           int critic_grid_x, DeferredLogsArgs dl, int dl_on) {
+                           int critic_grid_x, DeferredLogsArgs dl, int dl_on, XchgArgs xa, int xchg_on) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
     SSAC_LAB_ONLY(if (gc.tl && threadIdx.x == 0 && bid < 512) gc.tl[2 * bid] = __builtin_amdgcn_s_memrealtime();)
@@ -1680,10 +1697,37 @@ void fused_chain_pc_kernel(FusedArgs ga, FusedArgs gt, FusedArgs gc, int tiles_a
         deferred_logs_body(dl, -1);   // the PREVIOUS recorded update's log block -> its slot of the log ring
         return;
     }
+    if (xchg_on && bid == (int)gridDim.x - 1 - (dl_on ? 1 : 0)) {
+        // Critic-sharded rank (round 5): the exchange of the subset's target Q runs HERE, in a tail workgroup of the launch
+        // that produced it, instead of as a launch of its own between this one and the weight-gradient launch (measured on an
+        // installed rank: that third launch -- two boundaries, a one-workgroup kernel -- cost 8.4 - 9.9 us per update,
+        // profiles/r5_sharding_budget.md).  It waits until every target-critic workgroup of the launch has counted itself in
+        // (their Q left as agent-scope stores), then does exactly what xchg_kernel does -- same protocol, same slots, flags and
+        // acknowledgements -- and overlaps the critic tiles' tail.  It holds the highest workgroup id but the log workgroup's:
+        // everything it waits for was dispatched before it.
+        const int32_t *own = nullptr;
+        if (gt.gth.feed && gt.gth.ids_word >= 0) {   // this update's id block, from the input slot itself (uncached)
+            const uint32_t *gslot = gt.slot_now;
+            if (!gslot) { const ssac_feed f = *gt.gth.feed; gslot = feed_slot(f); }
+            own = reinterpret_cast<const int32_t *>(gslot + gt.gth.ids_word);
+        }
+        if (threadIdx.x == 0) {
+            const long long t0 = __builtin_amdgcn_s_memtime();
+            const long long limit = *xa.dead ? 0 : xa.spin_limit;
+            while (__hip_atomic_load(xa.arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tiles_t) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__builtin_amdgcn_s_memtime() - t0 > limit) { *xa.dead = 1; break; }   // (the exchange then poisons + reports)
+            }
+            __hip_atomic_store(xa.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        xchg_body<NTHR, true>(xa, smem, own);   // (its 16 bytes of LDS: the front of this workgroup's unused dynamic block)
+        return;
+    }
     // 32-row critic tiles (~58 k clocks) go before the consumers (~41 k from the launch's start, most of it waiting),
     // 16-row critic tiles (~40 k) behind them
     constexpr bool CRIT_FIRST = TC == 32;
-    const int n_main = (int)gridDim.x - (dl_on ? 1 : 0), n_crit = n_main - tiles_a - tiles_t;
+    const int n_main = (int)gridDim.x - (dl_on ? 1 : 0) - (xchg_on ? 1 : 0), n_crit = n_main - tiles_a - tiles_t;
     const int t_lo = CRIT_FIRST ? tiles_a + n_crit : tiles_a, t_hi = t_lo + tiles_t;   // ids of the consumers
     if (bid < tiles_a) {
         fused_mlp_body<MODE_SAMPLE, 16, ADBUF, false, AW3LATE>(ga, smem, ssac_xcd_contiguous_range(bid, 0, tiles_a, gc.xcd), 0, tiles_a, 0);
@@ -2060,7 +2104,7 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
                                  int n_sel, float *Qt, const ssac_mlp *critics, const float *Xc, int64_t ldxc,
                                  float *H1, float *H2, float *Q, float *DZ2u, float *DZ1u, float *W3_snapshot,
                                  const ssac_gather *gather, const ssac_deferred_logs *deferred,
-                                 unsigned long long *handoff, int target_splits, void *stream) {
+                                 unsigned long long *handoff, int target_splits, ssac_xchg *xchg, void *stream) {
     if (!eps && !rng) return ssac_fail("ssac_chain_update: neither eps nor an rng stream given");
     if (target_splits != 1 && target_splits != 2 && target_splits != 4) return ssac_fail("ssac_chain_update: target_splits is 1, 2 or 4");
     if (target_splits > 1 && (!handoff || targets->hidden != 256))
@@ -2173,6 +2217,17 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
             pc_attr = true;
         }
         const int tiles_c = tiles_t * target_splits;   // consumers: one per (slot, column split, tile)
+        // critic-sharded rank: the exchange of the subset's target Q as a tail workgroup of THIS launch (xchg != NULL)
+        XchgArgs xa{};
+        int xchg_on = 0;
+        if (xchg) {
+            if (co_form) return ssac_fail("ssac_chain_update: the in-launch exchange rides in the one-workgroup-per-CU form");
+            if (ssac_xchg_fill_args(xchg, Qt, n_sel * n_rows, 0, net_ids, n_sel, target_splits, &xa)) return 1;
+            if (!net_ids && !(gather && gather->feed && gather->ids_word >= 0))
+                return ssac_fail("ssac_chain_update: the in-launch exchange needs the update's id block");
+            gt.xarrive = xa.arrive;
+            xchg_on = 1;
+        }
         if (co_form) {
             static bool co_attr = false;
             if (!co_attr) {
@@ -2189,18 +2244,19 @@ extern "C" int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t
                 for (int a = 0; a < 3; ++a) ssac_record_slot_patch(a, offsetof(FusedArgs, slot_now));   // ga, gt, gc
             return ssac_check_launch("fused_chain_co");
         }
-        const dim3 grid_pc(tgx + tiles_c + cgx * critics->n_nets + dl_on);
-        if (alate && tc == 16) SSAC_LAUNCH((fused_chain_pc_kernel<16, true, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
-        else if (alate) SSAC_LAUNCH((fused_chain_pc_kernel<32, true, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
-        else if (tc == 16 && adbuf) SSAC_LAUNCH((fused_chain_pc_kernel<16, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
-        else if (adbuf) SSAC_LAUNCH((fused_chain_pc_kernel<32, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
-        else if (tc == 16) SSAC_LAUNCH((fused_chain_pc_kernel<16, false>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
-        else SSAC_LAUNCH((fused_chain_pc_kernel<32, false>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on);
+        const dim3 grid_pc(tgx + tiles_c + cgx * critics->n_nets + dl_on + xchg_on);
+        if (alate && tc == 16) SSAC_LAUNCH((fused_chain_pc_kernel<16, true, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on, xa, xchg_on);
+        else if (alate) SSAC_LAUNCH((fused_chain_pc_kernel<32, true, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on, xa, xchg_on);
+        else if (tc == 16 && adbuf) SSAC_LAUNCH((fused_chain_pc_kernel<16, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on, xa, xchg_on);
+        else if (adbuf) SSAC_LAUNCH((fused_chain_pc_kernel<32, true>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on, xa, xchg_on);
+        else if (tc == 16) SSAC_LAUNCH((fused_chain_pc_kernel<16, false>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on, xa, xchg_on);
+        else SSAC_LAUNCH((fused_chain_pc_kernel<32, false>), grid_pc, dim3(NTHR), lds, st, ga, gt, gc, tgx, tiles_c, tgx, cgx, dl, dl_on, xa, xchg_on);
         if (gather && gather->feed)
             for (int a = 0; a < 3; ++a) ssac_record_slot_patch(a, offsetof(FusedArgs, slot_now));   // ga, gt, gc
         return ssac_check_launch("fused_chain_pc");
     }
     if (target_splits != 1) return ssac_fail("ssac_chain_update: column-split target critics need the hand-off form");
+    if (xchg) return ssac_fail("ssac_chain_update: the in-launch exchange needs the hand-off (producer / consumer) form");
     const dim3 grid(tiles_t + cgx * critics->n_nets + dl_on);
     if (tc == 16 && adbuf) SSAC_LAUNCH((fused_chain_kernel<16, true>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx, dl, dl_on);
     else if (adbuf) SSAC_LAUNCH((fused_chain_kernel<32, true>), grid, dim3(NTHR), lds, st, ga, gr, gt, gc, tiles_t, tgx, cgx, dl, dl_on);

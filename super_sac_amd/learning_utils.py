@@ -663,7 +663,12 @@ def _actor_sample(a_arena, s1_rep, B, eps_ptr, actor, x1, S, A, logp, rng_ptr, s
                                       logp.data_ptr(), 0, 0, 0, rng_ptr, st))
 
 
-def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict, allow_split=True):
+# critic-sharded ranks: the exchange of the subset's target Q rides in the chained launch (a tail workgroup behind its
+# target-critic workgroups) instead of being a launch of its own behind it; a module constant that tests flip to compare
+FUSE_XCHG = True
+
+
+def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict, allow_split=True, xchg=None):
     """ssac_chain_update: the deferred actor sample (ch, from _actor_sample), the target critics of the n subset slots
     and the online critics' forward + TD-independent backward, ONE launch; returns the target outputs (n, B, 1)"""
     c_arena, h1, h2, act, ld_act, dz2u, dz1u = co_backward
@@ -732,7 +737,8 @@ def _launch_chain(ch, co_backward, t_arena, ids_ptr, n, ws, tag, B, replay_dict,
                 q1.data_ptr(), C.byref(c_arena.desc()), Xc.data_ptr(), ldxc, h1.data_ptr(), h2.data_ptr(),
                 qc.data_ptr(), 0 if skip_dz2 else dz2u.data_ptr(), dz1u.data_ptr(), w3s.data_ptr(),
                 C.byref(gth) if gth is not None else 0, dl_ptr, ho.data_ptr() if ho is not None else 0, splits,
-                engine.stream()))
+                xchg.handle if (xchg is not None and ho is not None) else 0, engine.stream()))
+    q1._ssac_xchg_done = xchg is not None and ho is not None   # (the launch reduced q1 over the ranks itself)
     if skip_dz2:
         replay_dict["_dz2_skipped"] = w3s   # (the weight-gradient launch rebuilds dz2u from h2 and this W3 copy)
     replay_dict["_co_bwd"] = True
@@ -775,8 +781,13 @@ def _subset_q(ws, shard, t_arena, ids, X, ldx, B, dev, tag, co_backward=None, re
         ch = replay_dict.pop("_chain", None) if replay_dict is not None else None
         if ch is not None:
             # (partial sums only when the one-shot exchange will carry them: it sums a slot's parts before sending)
+            x_ = parallel._exchange if (FUSE_XCHG and parallel._exchange is not None and ch["a_arena"].shadow is None
+                                        and n * B <= parallel._exchange.max_floats) else None
             q1 = _launch_chain(ch, co_backward, t_arena, cap.ids_dev.data_ptr(), n, ws, tag, B, replay_dict,
-                               allow_split=parallel._exchange is not None)
+                               allow_split=parallel._exchange is not None, xchg=x_)
+            if getattr(q1, "_ssac_xchg_done", False):
+                parallel.check_exchange()   # (of the exchanges issued so far: a host load, as all_reduce_min_owned does)
+                return q1, n
         elif co_backward is not None and t_arena.fused_dbuf:
             # ... and the TD-independent half of the local critics' backward pass rides in the same launch
             c_arena, h1, h2, act, ld_act, dz2u, dz1u = co_backward

@@ -1312,7 +1312,7 @@ def test_chain_launch_equals_the_separate_launches(ssa, B, N, H):
     ssa._lib.check(lib.ssac_chain_update(
         C.byref(aa.desc()), xb.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0, xb.data_ptr(), S + A, S, lpb.data_ptr(),
         0, C.byref(ta.desc()), ids.data_ptr(), 2, gt_.data_ptr(), C.byref(ca.desc()), xc.data_ptr(), S + A,
-        g1.data_ptr(), g2.data_ptr(), gq.data_ptr(), gz2.data_ptr(), gz1.data_ptr(), 0, 0, 0, 0, 1, st))
+        g1.data_ptr(), g2.data_ptr(), gq.data_ptr(), gz2.data_ptr(), gz1.data_ptr(), 0, 0, 0, 0, 1, 0, st))
     for a_, b_, what in ((xa, xb, "a'"), (lpa, lpb, "log pi"), (h1, g1, "h1"), (h2, g2, "h2"), (q, gq, "q"),
                          (qt, gt_, "target q"), (dz2, gz2, "dz2u"), (dz1, gz1, "dz1u")):
         if what == "target q" and 2 * ((B + 15) // 16) > 256:
@@ -1343,7 +1343,7 @@ def test_chain_launch_equals_the_separate_launches(ssa, B, N, H):
                 ssa._lib.check(lib.ssac_chain_update(
                     C.byref(aa.desc()), xp.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0, xp.data_ptr(), S + A, S, lpp.data_ptr(),
                     0, C.byref(ta.desc()), ids.data_ptr(), 2, pt.data_ptr(), C.byref(ca.desc()), xc.data_ptr(), S + A,
-                    p1_.data_ptr(), p2_.data_ptr(), pq.data_ptr(), pz2.data_ptr(), pz1.data_ptr(), 0, 0, 0, ho.data_ptr(), splits, st))
+                    p1_.data_ptr(), p2_.data_ptr(), pq.data_ptr(), pz2.data_ptr(), pz1.data_ptr(), 0, 0, 0, ho.data_ptr(), splits, 0, st))
                 torch.cuda.synchronize()
                 for a_, b_, what in ((exp[0], xp, "a'"), (exp[1], lpp, "log pi"), (exp[2], p1_, "h1"), (exp[3], p2_, "h2"),
                                      (exp[4], pq, "q"), (exp[6], pz2, "dz2u"), (exp[7], pz1, "dz1u")):
@@ -1362,7 +1362,7 @@ def test_chain_launch_equals_the_separate_launches(ssa, B, N, H):
     ssa._lib.check(lib.ssac_chain_update(
         C.byref(aa.desc()), xb2.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0, xb2.data_ptr(), S + A, S, lpb2.data_ptr(),
         0, C.byref(ta.desc()), ids.data_ptr(), 2, kt.data_ptr(), C.byref(ca.desc()), xc.data_ptr(), S + A,
-        k1.data_ptr(), k2.data_ptr(), kq.data_ptr(), 0, kz1.data_ptr(), w3s.data_ptr(), 0, 0, 0, 1, st))
+        k1.data_ptr(), k2.data_ptr(), kq.data_ptr(), 0, kz1.data_ptr(), w3s.data_ptr(), 0, 0, 0, 1, 0, st))
     assert torch.equal(k2, g2) and torch.equal(kz1, gz1) and torch.equal(kq, gq)
     w3 = torch.stack([ca.view(j, "w3").reshape(-1) for j in range(N)])
     assert torch.equal(w3s, w3)

@@ -39,6 +39,9 @@ def _rank_main(rank, world, port, out_dir, one_shot=False):
     import synth
     import torch.distributed as dist
     from super_sac_amd import parallel
+    import super_sac_amd as ssa
+    if one_shot == 2:   # the exchange as a launch of its own (round 4's form) instead of the chained launch's tail workgroup
+        ssa.learning_utils.FUSE_XCHG = False
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -52,18 +55,31 @@ def _rank_main(rank, world, port, out_dir, one_shot=False):
     worst = case_runner.compare(rec, fx, who=f"hip-sharded[rank {rank}]")
     assert not parallel.exchange_failed()
     np.savez(os.path.join(out_dir, f"ok{rank}.npz"), **{k: np.float64(v) for k, v in worst.items()})
+    np.savez(os.path.join(out_dir, f"rec{rank}.npz"), **{k: np.asarray(v) for k, v in rec.items()})
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,one_shot", [(2, False), (4, False), (4, True)],
-                         ids=["2-ranks-collective", "4-ranks-collective", "4-ranks-one-shot"])
+@pytest.mark.parametrize("world,one_shot", [(2, False), (4, False), (4, True), (2, True)],
+                         ids=["2-ranks-collective", "4-ranks-collective", "4-ranks-one-shot", "2-ranks-one-shot"])
 def test_sharded_sequence_matches_reference(tmp_path, world, one_shot):
     """2 and 4 ranks on the one device (4: one critic per rank, two ranks per update own no member of the drawn
-    subset), through the gloo collective and through the one-shot exchange kernel"""
+    subset), through the gloo collective and through the one-shot exchange -- which, round 5, runs in a TAIL WORKGROUP of
+    the chained launch (behind its target-critic workgroups, which count themselves in) instead of as a launch of its own;
+    both forms of it land on the fixture and on each other BIT FOR BIT (same protocol, same rank-ordered reduction)."""
     port = 29700 + (os.getpid() % 2000) + 7 * world + int(one_shot)
     _spawn(_rank_main, (world, port, str(tmp_path), one_shot), world)
     for rank in range(world):
         assert (tmp_path / f"ok{rank}.npz").exists()
+    if one_shot:
+        fused = [dict(np.load(tmp_path / f"rec{rank}.npz")) for rank in range(world)]
+        sep_dir = tmp_path / "separate"
+        sep_dir.mkdir()
+        _spawn(_rank_main, (world, port + 1, str(sep_dir), 2), world)
+        for rank in range(world):
+            sep = dict(np.load(sep_dir / f"rec{rank}.npz"))
+            assert sorted(sep) == sorted(fused[rank])
+            for k in sep:
+                assert np.array_equal(sep[k], fused[rank][k]), (rank, k)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -35,7 +35,7 @@ for k in range(n_launch):
     ssa._lib.check(lib.ssac_chain_update(
         C.byref(aa.desc()), xp.data_ptr(), S + A, B, eps.data_ptr(), -5.0, 2.0, xp.data_ptr(), S + A, S, lpp.data_ptr(),
         0, C.byref(ta.desc()), ids.data_ptr(), 2, qt.data_ptr(), C.byref(ca.desc()), xc.data_ptr(), S + A,
-        h1.data_ptr(), h2.data_ptr(), q.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), 0, 0, 0, ho.data_ptr(), 1, st))
+        h1.data_ptr(), h2.data_ptr(), q.data_ptr(), dz2.data_ptr(), dz1.data_ptr(), 0, 0, 0, ho.data_ptr(), 1, 0, st))
     if k % 2000 == 0:
         torch.cuda.synchronize()
         cur = [t.clone() for t in (h1, h2, q, qt, dz2, dz1, lpp)]

@@ -845,10 +845,18 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     KcStage st1, st2;
     RcStage st3;
     DirectNN<TMR> dnn;   // backward-data without an LDS image of W2 (gemm_direct_nn); the staged loop (st3) stays for A/B builds
+    // Which loop -- measured, A/B builds in one box (profiles/r5_kernel_stats.md, "backward-data loop"): 16-row tiles take the
+    // DIRECT loop (Humanoid N 16, whose tiles are 16 rows because 32 do not fit the LDS: 135.8 -> 131.6 us per update; a
+    // 2-of-16 shard 0 .. -1.6 us), 32-row tiles keep the STAGED loop (headline 53.0 vs 53.3 us, N 16 78.0 vs 78.3: a 32-row
+    // tile's 16 dword loads per lane and chunk against 4 sixteen-byte loads per thread for the image).  Compile-time per tile
+    // size: with BOTH loops behind a run-time flag in one kernel the headline lost the difference again (code size /
+    // register allocation of the fc2 loop in front).
 #if defined(SSAC_LAB) && defined(SSAC_EXP_STAGED_BWD)
     constexpr bool DIRECT_BWD = false;
+#elif defined(SSAC_LAB) && defined(SSAC_EXP_DIRECT_BWD)
+    constexpr bool DIRECT_BWD = !CO;
 #else
-    constexpr bool DIRECT_BWD = !CO;   // (the co-resident carve has its own direct loops)
+    constexpr bool DIRECT_BWD = !CO && TMR == 16;   // (the co-resident carve has its own direct loops)
 #endif
     NoStage none;
     DirectW<false> d1, d2;   // CO: weight fragments straight from memory (gemm_direct16)

@@ -303,7 +303,11 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
     const bool want_bias_grad = (EPI == EPI_ADAM || EPI == EPI_GRAD) && bx == 0 && !g.no_bias;
     const int Kloc = g.Ktot > 0 ? max(0, min(g.K, g.Ktot - e * g.K)) : g.K;
     const int nchunks = (Kloc + BK - 1) / BK;
+#if defined(SSAC_LAB) && defined(SSAC_EXP_WGRAD_SKIP_ITER)
+    const int iters = (nchunks + KS - 1) / KS - ((TN_ROT && g.N > 32) ? 1 : 0);   // (measurement build, WRONG results: an fc2 tile without its last K iteration)
+#else
     const int iters = (nchunks + KS - 1) / KS;
+#endif
     constexpr bool TN = !A_KC && !B_KC;
     // 16-byte loads need 16-byte aligned rows on both operands (checked per launch on the host)
     // ... and a batch entry's operand must span < 2^31 floats (32-bit lane offsets in RcVecLoader)

@@ -980,6 +980,10 @@ int ssac_bf16_polyak(const ssac_mlp *target, const ssac_mlp *source, float tau, 
 /* ensemble-Q forward (agent.py:34 loop + mlps.py:123-129) in bf16: Y (n_sel x n_rows x out) fp32 */
 int ssac_bf16_mlp3_fwd(const ssac_mlp *nets, const uint16_t *shadow, const int32_t *net_ids, int n_sel, const float *X,
                        int64_t ldx, int n_rows, float *Y, void *stream);
+/* A/B switch of its large-batch form (>= 512 row tiles x nets, single-output critics): 1 (default) = the register-chained
+ * kernel where it applies (hidden 256, 17 <= in_dim <= 32: weights in LDS, activations never leave the registers),
+ * 0 = the streaming kernel (weights in registers, activations through LDS) everywhere.  Same operands, same rounding points. */
+int ssac_bf16_fwd_form(int form);
 /* ssac_chain_update in bf16: same roles and arguments; the saved forward / unscaled backward leave as H1T, H2T, DZ2uT,
  * DZ1uT (n_nets x hidden x Bp) and XT (K1P x Bp, the [s|a] tile transposed) instead of fp32 row-major buffers. */
 int ssac_bf16_chain_update(const ssac_mlp *actor, const uint16_t *actor_shadow, const float *Xa, int64_t ldxa, int n_rows,

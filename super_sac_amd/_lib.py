@@ -250,6 +250,7 @@ SIGNATURES = {
     "ssac_bf16_sync": [_MP, _P, _P],
     "ssac_bf16_polyak": [_MP, _MP, _F, _P, _P],
     "ssac_bf16_mlp3_fwd": [_MP, _P, _P, _I, _P, _L, _I, _P, _P],
+    "ssac_bf16_fwd_form": [_I],
     "ssac_bf16_chain_update": [_MP, _P, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _P, _I, _P, _MP, _P, _P, _L,
                                _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ssac_bf16_wgrad_tiles": [_MP],

@@ -647,6 +647,228 @@ __global__ __launch_bounds__(NTHR) void bf_stream_kernel(BfArgs g, int tiles) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Large-batch ensemble-Q forward, REGISTER-CHAINED (round 5; hidden 256, 17 <= in_dim <= 32, single-output critics).
+// bf_stream_kernel above keeps the WEIGHTS in registers and sends every activation through LDS: x -> LDS -> fc1 -> h1 as
+// 32 two-byte scattered stores per lane -> barrier -> fc2 (one ds_read_b128 per MFMA) -> h2 -> LDS -> barrier -> head:
+// three barriers per 64 rows, one LDS read per MFMA (the LDS port's whole bandwidth at the matrix peak), 0.24 of the bf16
+// peak at B 65 536.  Here it is the other way round: the net's W1 / W2 live in LDS for the lifetime of the (persistent)
+// workgroup -- 144 KB, as MFMA A-operand fragments -- and a WAVE owns 64 batch rows end to end:
+//   * every product is D^T = W . act^T, so a lane (b = lane & 31, half) holds, for ITS batch row, 16 features of each
+//     32-feature block: acc[r] = D^T[32 blk + (r & 3) + 8 (r >> 2) + 4 half][b];
+//   * bias + ReLU + bf16 rounding happen in registers and the 8 packed values of accumulator registers 8 s .. 8 s + 7 ARE
+//     the next layer's B-operand fragment of K-step (blk, s) -- for the k values {16 s + 4 half + 0..3, 16 s + 4 half +
+//     8..11} of the block, not 8 consecutive ones: the MFMA does not care which k a slot carries as long as A and B agree,
+//     so the LDS image of W2 is written with that permutation once per workgroup;
+//   * x comes straight from memory in the B-fragment layout (a lane reads 8 consecutive floats of its row per K-step), h2
+//     never exists outside the accumulators (the head's dot product is taken from them), Q leaves as one coalesced store.
+// No activation ever touches LDS, no barrier after the weight image is built, every weight fragment read feeds two MFMAs
+// (the wave's two 32-row blocks): half the LDS traffic per FLOP, waves fully independent of each other.
+// Same bf16 operands, same fp32 products and the same rounding points as bf_mlp_body / bf_stream_kernel; the summation
+// order of the head differs (tests/test_hip_bf16.py compares the three).
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// ReLU as ONE integer max on the bit pattern (negative floats are negative integers; fmaxf costs a second instruction that
+// quiets a possible signalling NaN first): -0 and negative NaNs become +0, positive values are untouched
+__device__ __forceinline__ float relu_bits(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+__device__ __forceinline__ bf16x8 pack_bf8(const float (&v)[8]) {
+    const f32x8 t = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+    return __builtin_convertvector(t, bf16x8);
+}
+
+constexpr int RC_H = 256, RC_NB = RC_H / 32, RC_NS1 = 2;
+constexpr size_t RC_LDS = 2 * ((size_t)RC_NB * RC_NB * 2 + RC_NB * RC_NS1) * 512 + 4 * 3 * RC_H;
+
+__global__ __launch_bounds__(NTHR) void bf_regchain_kernel(BfArgs g, int tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int H = RC_H, NB = RC_NB, NS1 = RC_NS1;
+    unsigned short *w2s = reinterpret_cast<unsigned short *>(smem);   // chunk ((j NB + i) 2 + s): lane l's 8 elements at l * 8
+    unsigned short *w1s = w2s + NB * NB * 2 * 512;                    // chunk (i NS1 + s)
+    float *b1s = reinterpret_cast<float *>(w1s + NB * NS1 * 512);
+    float *b2s = b1s + H;
+    unsigned short *w3b = reinterpret_cast<unsigned short *>(b2s + H);   // W3's row as it is in the shadow (bf16)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+    const int e = blockIdx.y, IN = g.in_dim;
+    const int net = g.ids ? g.ids[e] : e;
+    if (net < 0) {   // empty subset slot of a sharded rank
+        for (int64_t i = blockIdx.x * (int64_t)NTHR + tid; i < g.n_rows; i += (int64_t)gridDim.x * NTHR)
+            g.Y[(int64_t)e * g.n_rows + i] = __builtin_inff();
+        return;
+    }
+    const float *P = g.params + (int64_t)net * g.net_stride;
+    const unsigned short *S = g.shadow + (int64_t)net * g.sg.stride;
+    // ---- the net's weights -> LDS, once.  W1: the shadow's fragment-major chunks as they are.  W2: chunk (j, t) of the
+    //      shadow holds k = 16 t + 8 h' + 0..7 in lane (n, h'); lane (n, half) of the image takes elements 4 half .. + 3
+    //      of BOTH of them (k = 16 t + 4 half + 0..3 and + 8)
+    {
+        const unsigned short *s1 = S + g.sg.o1, *s2 = S + g.sg.o2;
+        for (int i = tid; i < NB * NS1 * 64; i += NTHR)
+            *reinterpret_cast<u16x8 *>(w1s + i * 8) = *reinterpret_cast<const u16x8 *>(s1 + i * 8);
+        for (int idx = tid; idx < NB * NB * 2 * 64; idx += NTHR) {
+            const int c = idx >> 6, l = idx & 63, n = l & 31, hf = l >> 5;
+            const u16x4 lo = *reinterpret_cast<const u16x4 *>(s2 + ((int64_t)c * 64 + n) * 8 + 4 * hf);
+            const u16x4 hi = *reinterpret_cast<const u16x4 *>(s2 + ((int64_t)c * 64 + 32 + n) * 8 + 4 * hf);
+            const u16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            *reinterpret_cast<u16x8 *>(w2s + idx * 8) = v;
+        }
+        if (tid < H) { b1s[tid] = P[g.off[1] + tid]; b2s[tid] = P[g.off[3] + tid]; w3b[tid] = S[g.sg.o3 + tid]; }
+    }
+    const float b3 = P[g.off[5]];
+    __syncthreads();
+
+    // x of a wave tile in the B-fragment layout: lane (b, half) reads x[row b of block rb][16 s + 8 half + 0..7].  A K-step
+    // that lies inside the row for both halves takes two 16-byte loads per lane; the ragged one reads element-wise with
+    // clamped offsets (unconditional loads, values beyond the row replaced by zero)
+    auto load_x = [&](float (&xf)[2][NS1][8], int tile) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            int row = tile * 64 + 32 * rb + li;
+            row = row < g.n_rows ? row : g.n_rows - 1;   // (rows past the batch: a valid row, results dropped)
+            const float *prow = g.X + (int64_t)row * g.ldx;
+#pragma unroll
+            for (int s = 0; s < NS1; ++s) {
+                const int k0 = 16 * s + 8 * lh;
+                if (16 * s + 16 <= IN) {   // (uniform)
+                    const f4 a = *reinterpret_cast<const f4u *>(prow + k0), b = *reinterpret_cast<const f4u *>(prow + k0 + 4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { xf[rb][s][u] = a[u]; xf[rb][s][4 + u] = b[u]; }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool ok = (k0 + u) < IN;
+                        const float v = prow[ok ? k0 + u : 0];
+                        xf[rb][s][u] = ok ? v : 0.0f;
+                    }
+                }
+            }
+        }
+    };
+    const int nw = gridDim.x * (NTHR / 64);
+    int tile = blockIdx.x * (NTHR / 64) + wave;
+    float xf[2][NS1][8];
+    load_x(xf, tile);
+    for (; tile < tiles; tile += nw) {
+        bf16x8 xb[2][NS1];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int s = 0; s < NS1; ++s) xb[rb][s] = pack_bf8(xf[rb][s]);
+        // ---- fc1: feature block i -> the B fragments of fc2's K-steps (i, 0) and (i, 1).  The bias is the MFMA's C operand
+        //      (the accumulators start from it), so the epilogue is max + pack: 1.5 VALU instructions per element
+        bf16x8 h1[2][NB][2];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            // (an offset the compiler cannot see through: W1's fragments and the biases are the same for every tile, and
+            //  hoisted out of the tile loop they are 192 registers that live in scratch)
+            int z = 0;
+            asm volatile("" : "+v"(z));
+            f32x16 a0, a1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4 bq = *reinterpret_cast<const f4 *>(b1s + 32 * i + 8 * q + 4 * lh + z);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { a0[4 * q + c] = bq[c]; a1[4 * q + c] = bq[c]; }
+            }
+#pragma unroll
+            for (int s = 0; s < NS1; ++s) {
+                const bf16x8 w = *reinterpret_cast<const bf16x8 *>(w1s + ((i * NS1 + s) * 64 + lane) * 8 + z);
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xb[0][s], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xb[1][s], a1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v0[8], v1[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    v0[u] = relu_bits(a0[8 * s2 + u]);
+                    v1[u] = relu_bits(a1[8 * s2 + u]);
+                }
+                h1[0][i][s2] = pack_bf8(v0);
+                h1[1][i][s2] = pack_bf8(v1);
+            }
+            // (one block at a time: left alone, the compiler multiplies all eight blocks first -- 16 accumulators, 32 bias
+            //  vectors and 16 weight fragments live at once -- and spills a kilobyte per lane.  The block's four results are
+            //  "used" here, and volatile asm statements keep their order: the next block's loads depend on its own z)
+            asm volatile("" :: "v"(h1[0][i][0]), "v"(h1[0][i][1]), "v"(h1[1][i][0]), "v"(h1[1][i][1]));
+        }
+        load_x(xf, tile + nw);   // the next tile's rows travel under fc2
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- fc2 + head: output block j; the accumulators start from b2, and the head's dot product is taken straight
+        //      from them: max, pack two features to bf16 (the rounding point of h2), v_dot2c_f32_bf16 with the packed pair
+        //      of W3 -- 2 VALU instructions per element, h2 never exists outside the registers
+        float q0 = 0.0f, q1 = 0.0f;
+#pragma unroll 1
+        for (int j = 0; j < NB; ++j) {
+            f32x16 a0, a1;
+#if defined(SSAC_LAB) && defined(SSAC_EXP_RC_NOEPI)
+            zero_acc(a0); zero_acc(a1);
+#else
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f4 bq = *reinterpret_cast<const f4 *>(b2s + 32 * j + 8 * q + 4 * lh);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { a0[4 * q + c] = bq[c]; a1[4 * q + c] = bq[c]; }
+            }
+#endif
+            const unsigned short *wj = w2s + ((int64_t)j * NB * 2 * 64 + lane) * 8;
+#pragma unroll
+            for (int t = 0; t < 2 * NB; ++t) {
+#if defined(SSAC_LAB) && defined(SSAC_EXP_RC_NOFRAG)
+                bf16x8 w = h1[0][0][0]; asm volatile("" : "+v"(w));   // (measurement build, wrong results: no weight fragment reads)
+#else
+                const bf16x8 w = *reinterpret_cast<const bf16x8 *>(wj + t * 512);
+#endif
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, h1[0][t >> 1][t & 1], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, h1[1][t >> 1][t & 1], a1, 0, 0, 0);
+            }
+            // weight fragments three K-steps ahead of their MFMAs, no further (16 in flight would be 64 registers); the first
+            // group also holds the four bias reads in front of them
+#if defined(SSAC_LAB) && defined(SSAC_EXP_RC_NOEPI)
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#else
+            __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+#endif
+#pragma unroll
+            for (int t = 0; t < 2 * NB - 3; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#if defined(SSAC_LAB) && defined(SSAC_EXP_RC_NOEPI)
+            q0 += a0[0] + a0[15]; q1 += a1[0] + a1[15];   // (measurement build, wrong results: no fc2 epilogue)
+#else
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // W3 of features 32 j + 8 q + 4 half + 0..3: two packed bf16 pairs (8 bytes)
+                const bf16x4 wq = *reinterpret_cast<const bf16x4 *>(w3b + 32 * j + 8 * q + 4 * lh);
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const bf16x2 wp = {wq[2 * c], wq[2 * c + 1]};
+                    const f32x2 m0 = {relu_bits(a0[4 * q + 2 * c]), relu_bits(a0[4 * q + 2 * c + 1])};
+                    const f32x2 m1 = {relu_bits(a1[4 * q + 2 * c]), relu_bits(a1[4 * q + 2 * c + 1])};
+                    q0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_convertvector(m0, bf16x2), wp, q0, false);
+                    q1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_convertvector(m1, bf16x2), wp, q1, false);
+                }
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        q0 += __shfl_xor(q0, 32, 64);
+        q1 += __shfl_xor(q1, 32, 64);
+        const int row = tile * 64 + lane;   // lanes 0..31: block 0, lanes 32..63: block 1
+        if (row < g.n_rows) g.Y[(int64_t)e * g.n_rows + row] = (lh ? q1 : q0) + b3;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(NTHR) void bf_mlp_kernel(BfArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1061,6 +1283,7 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
 
 long long *g_bf_dbg = nullptr;
 
+bool g_bf_regchain = true;
 bool bf_ok(const ssac_mlp *n) {
     return n && n->hidden % 32 == 0 && n->hidden >= 32 && n->hidden <= 256 && n->out_dim >= 1 && n->out_dim <= 64 &&
            n->in_dim >= 1 && bf_lds_bytes(n->in_dim, n->hidden, n->out_dim) <= 160 * 1024;
@@ -1095,6 +1318,9 @@ extern "C" int64_t ssac_bf16_layout(int in_dim, int hidden, int out_dim, int64_t
 }
 
 extern "C" int ssac_bf16_supported(const ssac_mlp *nets) { return bf_ok(nets) ? 1 : 0; }
+// A/B switch of the large-batch forward (tools / tests): 1 (default) = the register-chained kernel where it applies,
+// 0 = bf_stream_kernel everywhere
+extern "C" int ssac_bf16_fwd_form(int form) { g_bf_regchain = form != 0; return 0; }
 extern "C" int ssac_bf16_debug_stamps(long long *dev_buf) {
 #ifdef SSAC_LAB
     g_bf_dbg = dev_buf;
@@ -1142,6 +1368,14 @@ extern "C" int ssac_bf16_mlp3_fwd(const ssac_mlp *nets, const uint16_t *shadow, 
     g.Y = Y;
     // large batches of single-output critics: persistent workgroups that keep their weight fragments (bf_stream_kernel)
     const int tiles64 = (n_rows + 63) / 64;
+    if (nets->out_dim == 1 && Y && nets->hidden == RC_H && g.sg.k1p == 16 * RC_NS1 && tiles64 * n_sel >= 512 && g_bf_regchain) {
+        // register-chained form (bf_regchain_kernel): one persistent workgroup per CU, its 8 waves take 64-row tiles
+        const int per_net = std::max(1, std::min((tiles64 + 7) / 8, 256 / n_sel));
+        static bool arc = false;
+        if (raise_lds(bf_regchain_kernel, arc)) return 1;
+        SSAC_LAUNCH(bf_regchain_kernel, dim3(per_net, n_sel), dim3(NTHR), RC_LDS, (hipStream_t)stream, g, tiles64);
+        return ssac_check_launch("bf16_mlp3_fwd (register-chained)");
+    }
     if (nets->out_dim == 1 && Y && g.sg.k1p <= 64 && tiles64 * n_sel >= 512) {
         const size_t lds_s = 2 * (64 * (size_t)(g.sg.k1p + LPAD) + 2 * 64 * (size_t)(nets->hidden + LPAD)) + 4 * 3 * (size_t)nets->hidden + 64;
         // one resident workgroup per CU (the fragments + two accumulators + the fragment reads in flight take ~200

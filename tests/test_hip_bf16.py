@@ -105,11 +105,23 @@ def test_ensemble_q_forward_matches_bf16_emulation(in_dim, hidden, out_dim, B):
     assert float((y - y32).abs().max()) <= 4e-2 * float(y32.abs().max()) + 1e-3
 
 
-@pytest.mark.parametrize("in_dim,B", [(23, 8192 + 37), (23, 65536), (56, 20000)])
-def test_large_batch_ensemble_q_streaming_kernel(in_dim, B):
-    """batches of >= 512 row tiles x nets take the persistent streaming kernel (weight fragments stay in registers, 64-row
-    tiles): against the bf16 emulation, against the per-tile kernel on the same rows, ragged last tile, a net list with
-    an empty (-1) slot"""
+@pytest.mark.parametrize("in_dim,B,form", [(23, 8192 + 37, 1), (23, 65536, 1), (17, 40000, 1), (32, 12345, 1),
+                                             (23, 8192 + 37, 0), (56, 20000, 1)])
+def test_large_batch_ensemble_q_streaming_kernel(in_dim, B, form):
+    """batches of >= 512 row tiles x nets take a persistent kernel -- form 1: register-chained (hidden 256, 17 <= in_dim <=
+    32: weights in LDS, a wave owns 64 rows end to end, no activation leaves the registers), else / form 0: streaming
+    (weight fragments in registers, 64-row tiles through LDS): against the bf16 emulation, against the per-tile kernel on
+    the same rows, ragged last tile, a net list with an empty (-1) slot"""
+    from super_sac_amd import engine
+    from super_sac_amd._lib import check, lib
+    check(lib.ssac_bf16_fwd_form(form))
+    try:
+        _large_batch_case(in_dim, B, form)
+    finally:
+        check(lib.ssac_bf16_fwd_form(1))
+
+
+def _large_batch_case(in_dim, B, form):
     from super_sac_amd import engine
     from super_sac_amd._lib import check, lib
     N = 10
@@ -131,7 +143,12 @@ def test_large_batch_ensemble_q_streaming_kernel(in_dim, B):
     assert torch.isinf(y[1]).all() and (y[1] > 0).all()
     live = [e for e, j in enumerate(sel) if j >= 0]
     # same bf16 operands, same fp32 products; summation order of the head differs (8 vs 16 lanes per row)
-    assert float((y[live] - y_tile[live]).abs().max()) <= 1e-6 * max(1.0, float(y_tile[live].abs().max()))
+    if form == 1 and 17 <= in_dim <= 32:
+        # register-chained kernel: fc2's K-steps carry a permutation of the k values, so the fp32 sums differ in their last
+        # bits and a hidden activation on a bf16 tie may round the other way (one bf16 ulp of one term)
+        assert float((y[live] - y_tile[live]).abs().max()) <= 1.5e-3 * float(y_tile[live].abs().max()) + 1e-5
+    else:
+        assert float((y[live] - y_tile[live]).abs().max()) <= 1e-6 * max(1.0, float(y_tile[live].abs().max()))
     for e in live[:3]:
         ref = _emulate(ar, sel[e], x[:4096])
         tol = 4e-3 * float(ref.abs().max()) + 1e-4

@@ -9,6 +9,8 @@ import super_sac_amd as ssa
 from super_sac_amd import engine
 from super_sac_amd._lib import check, lib
 dev = torch.device("cuda")
+if os.environ.get("SSAC_BF16_FWD_FORM"):   # A/B: 0 = the streaming kernel everywhere, 1 = register-chained where it applies
+    check(lib.ssac_bf16_fwd_form(int(os.environ["SSAC_BF16_FWD_FORM"])))
 rows = bench.bf16_rows(ssa, dev)["ensemble_q_kernel_bf16"]["rows"]
 for k, v in rows.items():
     print(k, v)

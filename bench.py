@@ -648,9 +648,11 @@ def bf16_rows(ssa, device):
         flops = 2.0 * B * N * (IN * HID + HID * HID + HID)
         rows[f"B{B}"] = {"us_per_launch": round(us, 2), "algorithmic_bytes": nbytes,
                          "hbm_GBs": round(nbytes / us / 1e3, 1), "hbm_frac": round(nbytes / us / 1e3 / HBM_PEAK_GBS, 4),
-                         "TFLOPs": round(flops / us / 1e6, 1)}
-    return {"ensemble_q_kernel_bf16": {"kernel": "bf_mlp_kernel<plain>: forward of N=10 critics (23->256->256->1), bf16 "
-                                                 "shadow weights, HIP events around back-to-back launches",
+                         "TFLOPs": round(flops / us / 1e6, 1), "mfma_frac": round(flops / us / 1e6 / 2500.0, 3)}
+    return {"ensemble_q_kernel_bf16": {"kernel": "ssac_bf16_mlp3_fwd: forward of N=10 critics (23->256->256->1), bf16 shadow "
+                                                 "weights (B 256 / 4096: one workgroup per 32-row tile; B 65536: the register-"
+                                                 "chained persistent kernel, weights in LDS, no activation leaves the registers); "
+                                                 "HIP events around back-to-back launches; bf16 MFMA peak 2.5 PFLOP/s",
                                        "hbm_peak_GBs": HBM_PEAK_GBS, "rows": rows}}
 
 

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <algorithm>
+#include <type_traits>
 #include <stdint.h>
 
 #include "ssac_internal.h"
@@ -687,7 +688,7 @@ __device__ __forceinline__ bf16x8 pack_bf8(const float (&v)[8]) {
 constexpr int RC_H = 256, RC_NB = RC_H / 32, RC_NS1 = 2;
 constexpr size_t RC_LDS = 2 * ((size_t)RC_NB * RC_NB * 2 + RC_NB * RC_NS1) * 512 + 4 * 3 * RC_H;
 
-__global__ __launch_bounds__(NTHR) void bf_regchain_kernel(BfArgs g, int tiles) {
+__global__ __launch_bounds__(NTHR) void bf_regchain_kernel(BfArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int H = RC_H, NB = RC_NB, NS1 = RC_NS1;
     unsigned short *w2s = reinterpret_cast<unsigned short *>(smem);   // chunk ((j NB + i) 2 + s): lane l's 8 elements at l * 8
@@ -703,6 +704,9 @@ __global__ __launch_bounds__(NTHR) void bf_regchain_kernel(BfArgs g, int tiles) 
             g.Y[(int64_t)e * g.n_rows + i] = __builtin_inff();
         return;
     }
+#ifdef SSAC_LAB
+    if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g.dbg[5] = __builtin_amdgcn_s_memtime();
+#endif
     const float *P = g.params + (int64_t)net * g.net_stride;
     const unsigned short *S = g.shadow + (int64_t)net * g.sg.stride;
     // ---- the net's weights -> LDS, once.  W1: the shadow's fragment-major chunks as they are.  W2: chunk (j, t) of the
@@ -712,161 +716,271 @@ __global__ __launch_bounds__(NTHR) void bf_regchain_kernel(BfArgs g, int tiles) 
         const unsigned short *s1 = S + g.sg.o1, *s2 = S + g.sg.o2;
         for (int i = tid; i < NB * NS1 * 64; i += NTHR)
             *reinterpret_cast<u16x8 *>(w1s + i * 8) = *reinterpret_cast<const u16x8 *>(s1 + i * 8);
-        for (int idx = tid; idx < NB * NB * 2 * 64; idx += NTHR) {
-            const int c = idx >> 6, l = idx & 63, n = l & 31, hf = l >> 5;
-            const u16x4 lo = *reinterpret_cast<const u16x4 *>(s2 + ((int64_t)c * 64 + n) * 8 + 4 * hf);
-            const u16x4 hi = *reinterpret_cast<const u16x4 *>(s2 + ((int64_t)c * 64 + 32 + n) * 8 + 4 * hf);
-            const u16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            *reinterpret_cast<u16x8 *>(w2s + idx * 8) = v;
+        // (a thread takes row n of a chunk: both halves in, both halves out -- 16-byte loads and stores, all 16 loads of a
+        //  thread in flight before the first store)
+        constexpr int PER = NB * NB * 2 * 32 / NTHR;   // 8
+        u16x8 n0[PER], n1[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int idx = tid + k * NTHR, c = idx >> 5, n = idx & 31;
+            n0[k] = *reinterpret_cast<const u16x8 *>(s2 + ((int64_t)c * 64 + n) * 8);
+            n1[k] = *reinterpret_cast<const u16x8 *>(s2 + ((int64_t)c * 64 + 32 + n) * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int idx = tid + k * NTHR, c = idx >> 5, n = idx & 31;
+            const u16x8 lo = {n0[k][0], n0[k][1], n0[k][2], n0[k][3], n1[k][0], n1[k][1], n1[k][2], n1[k][3]};
+            const u16x8 hi = {n0[k][4], n0[k][5], n0[k][6], n0[k][7], n1[k][4], n1[k][5], n1[k][6], n1[k][7]};
+            *reinterpret_cast<u16x8 *>(w2s + (c * 64 + n) * 8) = lo;
+            *reinterpret_cast<u16x8 *>(w2s + (c * 64 + 32 + n) * 8) = hi;
         }
         if (tid < H) { b1s[tid] = P[g.off[1] + tid]; b2s[tid] = P[g.off[3] + tid]; w3b[tid] = S[g.sg.o3 + tid]; }
     }
     const float b3 = P[g.off[5]];
     __syncthreads();
 
-    // x of a wave tile in the B-fragment layout: lane (b, half) reads x[row b of block rb][16 s + 8 half + 0..7].  A K-step
-    // that lies inside the row for both halves takes two 16-byte loads per lane; the ragged one reads element-wise with
-    // clamped offsets (unconditional loads, values beyond the row replaced by zero)
-    auto load_x = [&](float (&xf)[2][NS1][8], int tile) {
+    // ---- work of this wave: a contiguous range of 32-row UNITS, taken two at a time (the two row blocks of an iteration
+    //      share every weight fragment read); an odd last unit runs the same body with one row block (half the MFMAs).
+    //      32-row granularity matters: 65 536 rows over 25 workgroups per net are 10.24 units per wave -- whole 64-row tiles
+    //      made that 5 or 6 iterations with every workgroup waiting for its 6-iteration waves
+    const int units = (g.n_rows + 31) >> 5, nwv = gridDim.x * (NTHR / 64), wv = blockIdx.x * (NTHR / 64) + wave;
+    const int ubase = units / nwv, urem = units - ubase * nwv;
+    const int u_lo = wv * ubase + (wv < urem ? wv : urem), u_hi = u_lo + ubase + (wv < urem ? 1 : 0);
+
+    // x of one iteration in the B-fragment layout: lane (b, half) wants x[row b of unit u + rb][16 s + 8 half + 0..7]: two
+    // 16-byte loads per lane and K-step (load_x: issue only -- nothing here waits for the data).  The ragged K-step (in_dim
+    // not a multiple of 16) has one half whose 8-float window crosses the end of the row: those lanes read the LAST 8 floats
+    // of the row instead (always inside it) and pack_x, an iteration later, shifts them down in registers -- the shift is
+    // the same for every lane that shifts, so it is a 3-stage barrel shifter on scalar conditions, 32 selects; the other
+    // half's window lies fully inside the row (kept) or fully outside (zero)
+    auto load_x = [&](float (&xf)[2][NS1][8], int u, int nrb) {
+        // (the lane's row / half through an asm the compiler cannot see through: everything derived from them here is the
+        //  same in every iteration, and hoisted out of the loop it is live across fc2 -- i.e. spilled, and reloaded behind an
+        //  s_waitcnt vmcnt(0) that also waits for the rows just requested)
+        int lnx = lane;
+        asm volatile("" : "+v"(lnx));
+        const int lix = lnx & 31, lhx = lnx >> 5;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-            int row = tile * 64 + 32 * rb + li;
+            if (rb >= nrb) break;   // (uniform)
+            int row = (u + rb) * 32 + lix;
             row = row < g.n_rows ? row : g.n_rows - 1;   // (rows past the batch: a valid row, results dropped)
-            const float *prow = g.X + (int64_t)row * g.ldx;
+            // (32-bit byte offsets from the uniform base -- the launcher checks that X spans < 4 GiB: no 64-bit address
+            //  pairs per lane, which this kernel has no registers for)
+            const uint32_t rowoff = (uint32_t)row * (uint32_t)g.ldx;
 #pragma unroll
             for (int s = 0; s < NS1; ++s) {
-                const int k0 = 16 * s + 8 * lh;
-                if (16 * s + 16 <= IN) {   // (uniform)
-                    const f4 a = *reinterpret_cast<const f4u *>(prow + k0), b = *reinterpret_cast<const f4u *>(prow + k0 + 4);
+                const int rem = IN - 16 * s;   // (uniform) k values of this K-step inside the row
+                const bool hi_part = rem >= 8;
+                // first float of the lane's window: half 0 / half 1 (both uniform)
+                const int st0 = (rem >= 16 || hi_part) ? 16 * s : IN - 8;
+                const int st1 = rem >= 16 ? 16 * s + 8 : IN - 8;
+                const int start = st0 + lhx * (st1 - st0);
+                const char *p = reinterpret_cast<const char *>(g.X) + (size_t)((rowoff + (uint32_t)start) * 4u);
+                const f4 a = *reinterpret_cast<const f4u *>(p), b = *reinterpret_cast<const f4u *>(p + 16);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { xf[rb][s][u] = a[u]; xf[rb][s][4 + u] = b[u]; }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const bool ok = (k0 + u) < IN;
-                        const float v = prow[ok ? k0 + u : 0];
-                        xf[rb][s][u] = ok ? v : 0.0f;
-                    }
-                }
+                for (int c = 0; c < 4; ++c) { xf[rb][s][c] = a[c]; xf[rb][s][4 + c] = b[c]; }
             }
         }
     };
-    const int nw = gridDim.x * (NTHR / 64);
-    int tile = blockIdx.x * (NTHR / 64) + wave;
-    float xf[2][NS1][8];
-    load_x(xf, tile);
-    for (; tile < tiles; tile += nw) {
-        bf16x8 xb[2][NS1];
+    auto pack_x = [&](const float (&t0)[8], int s) -> bf16x8 {
+        const int rem = IN - 16 * s;
+        float v[8];
+        if (rem >= 16) {   // (uniform)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+            for (int c = 0; c < 8; ++c) v[c] = t0[c];
+        } else {
+            const bool hi_part = rem >= 8;                    // (uniform) half 0 whole, half 1 shifts; else half 0 shifts, half 1 empty
+            const bool shifts = hi_part ? lh == 1 : lh == 0;
+            const int sh = hi_part ? 16 - rem : 8 - rem;      // (uniform) 1 .. 8
+            float t1[8], t2[8];
 #pragma unroll
-            for (int s = 0; s < NS1; ++s) xb[rb][s] = pack_bf8(xf[rb][s]);
+            for (int c = 0; c < 8; ++c) t1[c] = (sh & 1) ? (c + 1 < 8 ? t0[c + 1] : 0.0f) : t0[c];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) t2[c] = (sh & 2) ? (c + 2 < 8 ? t1[c + 2] : 0.0f) : t1[c];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float w = (sh & 4) ? (c + 4 < 8 ? t2[c + 4] : 0.0f) : t2[c];
+                w = (sh & 8) ? 0.0f : w;
+                v[c] = shifts ? w : (hi_part ? t0[c] : 0.0f);
+            }
+        }
+        return pack_bf8(v);
+    };
+    float xf[2][NS1][8] = {};
+    if (u_lo < u_hi) load_x(xf, u_lo, u_hi - u_lo >= 2 ? 2 : 1);
+#ifdef SSAC_LAB
+    if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { g.dbg[6] = __builtin_amdgcn_s_memtime(); g.dbg[8] = u_hi - u_lo; }
+#endif
+
+#ifdef SSAC_LAB
+#define RSTAMP(i) do { if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && u == u_lo + 2) g.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RSTAMP(i) do { } while (0)
+#endif
+    // one iteration: TWO row blocks (units u, u + 1) or one
+    auto body = [&](auto two_c, int u, int u_next, int n_next) {
+        constexpr bool TWO = decltype(two_c)::value;
+        constexpr int NR = TWO ? 2 : 1;
+        RSTAMP(0);
+        bf16x8 xb[NR][NS1];
+#pragma unroll
+        for (int rb = 0; rb < NR; ++rb)
+#pragma unroll
+            for (int s = 0; s < NS1; ++s) xb[rb][s] = pack_x(xf[rb][s], s);
         // ---- fc1: feature block i -> the B fragments of fc2's K-steps (i, 0) and (i, 1).  The bias is the MFMA's C operand
-        //      (the accumulators start from it), so the epilogue is max + pack: 1.5 VALU instructions per element
-        bf16x8 h1[2][NB][2];
+        //      (the accumulators start from it), so the epilogue is max + pack: 1.5 VALU instructions per element.
+        //      Software-pipelined one block deep BY HAND: block i + 1's bias vectors and weight fragments are requested
+        //      before block i's MFMAs.  (Left alone, the compiler hoists W1's fragments and the biases -- the same for every
+        //      tile -- out of the tile loop, 192 registers that live in scratch, or multiplies all eight blocks first: the
+        //      loads hang on an offset it cannot see through, z, re-made once per block by a volatile asm statement, and
+        //      each block's results are "used" by another one: volatile asm statements keep their order.)
+        bf16x8 h1[NR][NB][2];
+        f4 bqn[4];
+        bf16x8 wn[NS1];
+        auto fc1_fetch = [&](int i, int z) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            // (an offset the compiler cannot see through: W1's fragments and the biases are the same for every tile, and
-            //  hoisted out of the tile loop they are 192 registers that live in scratch)
+            for (int q = 0; q < 4; ++q) bqn[q] = *reinterpret_cast<const f4 *>(b1s + 32 * i + 8 * q + 4 * lh + z);
+#pragma unroll
+            for (int s = 0; s < NS1; ++s) wn[s] = *reinterpret_cast<const bf16x8 *>(w1s + ((i * NS1 + s) * 64 + lane) * 8 + z);
+        };
+        {
             int z = 0;
             asm volatile("" : "+v"(z));
-            f32x16 a0, a1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f4 bq = *reinterpret_cast<const f4 *>(b1s + 32 * i + 8 * q + 4 * lh + z);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { a0[4 * q + c] = bq[c]; a1[4 * q + c] = bq[c]; }
-            }
-#pragma unroll
-            for (int s = 0; s < NS1; ++s) {
-                const bf16x8 w = *reinterpret_cast<const bf16x8 *>(w1s + ((i * NS1 + s) * 64 + lane) * 8 + z);
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xb[0][s], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xb[1][s], a1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                float v0[8], v1[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    v0[u] = relu_bits(a0[8 * s2 + u]);
-                    v1[u] = relu_bits(a1[8 * s2 + u]);
-                }
-                h1[0][i][s2] = pack_bf8(v0);
-                h1[1][i][s2] = pack_bf8(v1);
-            }
-            // (one block at a time: left alone, the compiler multiplies all eight blocks first -- 16 accumulators, 32 bias
-            //  vectors and 16 weight fragments live at once -- and spills a kilobyte per lane.  The block's four results are
-            //  "used" here, and volatile asm statements keep their order: the next block's loads depend on its own z)
-            asm volatile("" :: "v"(h1[0][i][0]), "v"(h1[0][i][1]), "v"(h1[1][i][0]), "v"(h1[1][i][1]));
+            fc1_fetch(0, z);
         }
-        load_x(xf, tile + nw);   // the next tile's rows travel under fc2
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            f32x16 a[NR];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int rb = 0; rb < NR; ++rb) a[rb][4 * q + c] = bqn[q][c];
+            bf16x8 w[NS1];
+#pragma unroll
+            for (int s = 0; s < NS1; ++s) w[s] = wn[s];
+            if (i + 1 < NB) {
+                int z = 0;
+                asm volatile("" : "+v"(z));
+                fc1_fetch(i + 1, z);
+            }
+#pragma unroll
+            for (int s = 0; s < NS1; ++s)
+#pragma unroll
+                for (int rb = 0; rb < NR; ++rb) a[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[s], xb[rb][s], a[rb], 0, 0, 0);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int rb = 0; rb < NR; ++rb) {
+                    float v[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = relu_bits(a[rb][8 * s2 + c]);
+                    h1[rb][i][s2] = pack_bf8(v);
+                }
+            if (TWO) asm volatile("" :: "v"(h1[0][i][0]), "v"(h1[0][i][1]), "v"(h1[NR - 1][i][0]), "v"(h1[NR - 1][i][1]));
+            else asm volatile("" :: "v"(h1[0][i][0]), "v"(h1[0][i][1]));
+        }
+        RSTAMP(1);
+        if (n_next > 0) load_x(xf, u_next, n_next);   // the next iteration's rows travel under fc2
+        RSTAMP(2);
         __builtin_amdgcn_sched_barrier(0);
         // ---- fc2 + head: output block j; the accumulators start from b2, and the head's dot product is taken straight
         //      from them: max, pack two features to bf16 (the rounding point of h2), v_dot2c_f32_bf16 with the packed pair
-        //      of W3 -- 2 VALU instructions per element, h2 never exists outside the registers
-        float q0 = 0.0f, q1 = 0.0f;
+        //      of W3 -- 2 VALU instructions per element, h2 never exists outside the registers.  The weight fragments run
+        //      three K-steps ahead of their MFMAs ACROSS the j loop (the chunks of block j + 1 follow block j's in LDS), and
+        //      block j + 1's bias vectors are requested in the middle of block j's epilogue.
+        float qv[NR];
+#pragma unroll
+        for (int rb = 0; rb < NR; ++rb) qv[rb] = 0.0f;
+        constexpr int PF = 2;   // weight fragments in flight ahead of their MFMAs (a third costs 4 registers the kernel does not have: spills)
+        int lnf = lane;   // (as in load_x: the lane's LDS offsets are re-derived here, not kept live -- i.e. spilled -- across fc1)
+        asm volatile("" : "+v"(lnf));
+        bf16x8 wf[PF];
+#pragma unroll
+        for (int t = 0; t < PF; ++t) wf[t] = *reinterpret_cast<const bf16x8 *>(w2s + (t * 64 + lnf) * 8);
+        f4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f4 *>(b2s + 8 * q + 4 * lh);
 #pragma unroll 1
         for (int j = 0; j < NB; ++j) {
-            f32x16 a0, a1;
+            f32x16 a[NR];
 #if defined(SSAC_LAB) && defined(SSAC_EXP_RC_NOEPI)
-            zero_acc(a0); zero_acc(a1);
+#pragma unroll
+            for (int rb = 0; rb < NR; ++rb) zero_acc(a[rb]);
 #else
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f4 bq = *reinterpret_cast<const f4 *>(b2s + 32 * j + 8 * q + 4 * lh);
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { a0[4 * q + c] = bq[c]; a1[4 * q + c] = bq[c]; }
-            }
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int rb = 0; rb < NR; ++rb) a[rb][4 * q + c] = bq[q][c];
 #endif
-            const unsigned short *wj = w2s + ((int64_t)j * NB * 2 * 64 + lane) * 8;
+            const unsigned short *wj = w2s + (j * NB * 2 * 64 + lnf) * 8;
+            bf16x8 w[2 * NB + PF];
+#pragma unroll
+            for (int t = 0; t < PF; ++t) w[t] = wf[t];
 #pragma unroll
             for (int t = 0; t < 2 * NB; ++t) {
-#if defined(SSAC_LAB) && defined(SSAC_EXP_RC_NOFRAG)
-                bf16x8 w = h1[0][0][0]; asm volatile("" : "+v"(w));   // (measurement build, wrong results: no weight fragment reads)
-#else
-                const bf16x8 w = *reinterpret_cast<const bf16x8 *>(wj + t * 512);
-#endif
-                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, h1[0][t >> 1][t & 1], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, h1[1][t >> 1][t & 1], a1, 0, 0, 0);
-            }
-            // weight fragments three K-steps ahead of their MFMAs, no further (16 in flight would be 64 registers); the first
-            // group also holds the four bias reads in front of them
-#if defined(SSAC_LAB) && defined(SSAC_EXP_RC_NOEPI)
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#else
-            __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
-#endif
+                // (t + PF >= 16: the first chunks of block j + 1; behind the last block they are W1's image -- read, unused)
+                w[t + PF] = *reinterpret_cast<const bf16x8 *>(wj + (t + PF) * 512);
 #pragma unroll
-            for (int t = 0; t < 2 * NB - 3; ++t) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                for (int rb = 0; rb < NR; ++rb)
+                    a[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t], h1[rb][t >> 1][t & 1], a[rb], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+#pragma unroll
+            for (int t = 0; t < PF; ++t) wf[t] = w[2 * NB + t];
+#pragma unroll
+            for (int t = 0; t < 2 * NB; ++t) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NR, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #if defined(SSAC_LAB) && defined(SSAC_EXP_RC_NOEPI)
-            q0 += a0[0] + a0[15]; q1 += a1[0] + a1[15];   // (measurement build, wrong results: no fc2 epilogue)
+#pragma unroll
+            for (int rb = 0; rb < NR; ++rb) qv[rb] += a[rb][0] + a[rb][15];   // (measurement build, wrong results: no fc2 epilogue)
 #else
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                // W3 of features 32 j + 8 q + 4 half + 0..3: two packed bf16 pairs (8 bytes)
-                const bf16x4 wq = *reinterpret_cast<const bf16x4 *>(w3b + 32 * j + 8 * q + 4 * lh);
+            for (int rb = 0; rb < NR; ++rb) {
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const bf16x2 wp = {wq[2 * c], wq[2 * c + 1]};
-                    const f32x2 m0 = {relu_bits(a0[4 * q + 2 * c]), relu_bits(a0[4 * q + 2 * c + 1])};
-                    const f32x2 m1 = {relu_bits(a1[4 * q + 2 * c]), relu_bits(a1[4 * q + 2 * c + 1])};
-                    q0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_convertvector(m0, bf16x2), wp, q0, false);
-                    q1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_convertvector(m1, bf16x2), wp, q1, false);
+                for (int q = 0; q < 4; ++q) {
+                    // W3 of features 32 j + 8 q + 4 half + 0..3: two packed bf16 pairs (8 bytes; read again per row block)
+                    const bf16x4 wq = *reinterpret_cast<const bf16x4 *>(w3b + 32 * j + 8 * q + 4 * lh);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const bf16x2 wp = {wq[2 * c], wq[2 * c + 1]};
+                        const f32x2 m = {relu_bits(a[rb][4 * q + 2 * c]), relu_bits(a[rb][4 * q + 2 * c + 1])};
+                        qv[rb] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_convertvector(m, bf16x2), wp, qv[rb], false);
+                    }
+                }
+                if (rb == 0) {   // block j + 1's biases (behind the last block: block 0's, unused)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const f4 *>(b2s + 32 * ((j + 1) & (NB - 1)) + 8 * q + 4 * lh);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
-        q0 += __shfl_xor(q0, 32, 64);
-        q1 += __shfl_xor(q1, 32, 64);
-        const int row = tile * 64 + lane;   // lanes 0..31: block 0, lanes 32..63: block 1
-        if (row < g.n_rows) g.Y[(int64_t)e * g.n_rows + row] = (lh ? q1 : q0) + b3;
+        RSTAMP(3);
+#pragma unroll
+        for (int rb = 0; rb < NR; ++rb) qv[rb] += __shfl_xor(qv[rb], 32, 64);
+        // lanes 0..31: unit u, lanes 32..63: unit u + 1 -- one coalesced store
+        const int row = u * 32 + lane;
+        const float val = (TWO && lh) ? qv[NR - 1] : qv[0];
+        if ((TWO || lh == 0) && row < g.n_rows) g.Y[(int64_t)e * g.n_rows + row] = val + b3;
+        RSTAMP(4);
+    };
+    int u = u_lo;
+    for (; u + 2 <= u_hi; u += 2) {
+        const int left = u_hi - (u + 2);
+        body(std::true_type{}, u, u + 2, left >= 2 ? 2 : left);
     }
+    if (u < u_hi) body(std::false_type{}, u, 0, 0);
+#ifdef SSAC_LAB
+    if (g.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g.dbg[7] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 template <int MODE>
@@ -1368,12 +1482,15 @@ extern "C" int ssac_bf16_mlp3_fwd(const ssac_mlp *nets, const uint16_t *shadow, 
     g.Y = Y;
     // large batches of single-output critics: persistent workgroups that keep their weight fragments (bf_stream_kernel)
     const int tiles64 = (n_rows + 63) / 64;
-    if (nets->out_dim == 1 && Y && nets->hidden == RC_H && g.sg.k1p == 16 * RC_NS1 && tiles64 * n_sel >= 512 && g_bf_regchain) {
-        // register-chained form (bf_regchain_kernel): one persistent workgroup per CU, its 8 waves take 64-row tiles
+    // (measured, N 10: the register-chained kernel's fixed cost -- 144 KB of weights into LDS per workgroup -- is paid back from
+    //  ~6 000 rows on: 18.8 vs 18.7 us at B 6 144, 19.2 vs 25.8 at 8 192, 89 vs 149 at 65 536; profiles/r5_bf16_forward.md)
+    if (nets->out_dim == 1 && Y && nets->hidden == RC_H && g.sg.k1p == 16 * RC_NS1 && tiles64 * n_sel >= 1024 && g_bf_regchain &&
+        (int64_t)n_rows * ldx * 4 < (1LL << 32)) {
+        // register-chained form (bf_regchain_kernel): one persistent workgroup per CU, its 8 waves take 32-row units in pairs
         const int per_net = std::max(1, std::min((tiles64 + 7) / 8, 256 / n_sel));
         static bool arc = false;
         if (raise_lds(bf_regchain_kernel, arc)) return 1;
-        SSAC_LAUNCH(bf_regchain_kernel, dim3(per_net, n_sel), dim3(NTHR), RC_LDS, (hipStream_t)stream, g, tiles64);
+        SSAC_LAUNCH(bf_regchain_kernel, dim3(per_net, n_sel), dim3(NTHR), RC_LDS, (hipStream_t)stream, g);
         return ssac_check_launch("bf16_mlp3_fwd (register-chained)");
     }
     if (nets->out_dim == 1 && Y && g.sg.k1p <= 64 && tiles64 * n_sel >= 512) {

@@ -627,7 +627,7 @@ def bf16_rows(ssa, device):
     ar.params.copy_(torch.randn_like(ar.params) * 0.05)
     ar.enable_bf16()
     rows = {}
-    for B in (256, 4096, 65536):
+    for B in (256, 4096, 16384, 65536, 262144):
         x = torch.randn(B, IN, device=device)
         y = torch.empty(N, B, 1, device=device)
 

@@ -1132,12 +1132,18 @@ struct BfWgradArgs {
 #define WSTAMP(i) do { } while (0)
 #endif
 
-__device__ __forceinline__ float adam_elem(float p, float g, float &m, float &v, const ssac_adam_ctl &c) {
+// Adam on one element.  bf16 mode has no reference to be bit-compatible with (the fp32 path keeps torch's exact sequence:
+// ssac_gemm.hip), and this epilogue is 16 elements per lane with ONE wave of the workgroup per SIMD: the IEEE square root and
+// the two IEEE divisions were ~30 of its ~40 instructions per element, a dependent chain nothing overlaps -- 11.5 k of the
+// workgroup's 29 k clocks (LAB stamps; re-arranging its ~230 stores per lane into 16-byte ones through LDS changed nothing).
+// Here: v_sqrt_f32 / v_rcp_f32 (1 ulp each) and the bias correction as a multiplication by its reciprocal -- the update differs
+// from the exact sequence by a few ulp of the STEP, i.e. ~1e-7 of lr.
+__device__ __forceinline__ float adam_elem(float p, float g, float &m, float &v, const ssac_adam_ctl &c, float inv_bc2_sqrt) {
     if (c.weight_decay != 0.0f) g = g + c.weight_decay * p;
     m = m + (1.0f - c.beta1) * (g - m);
     v = v * c.beta2 + (1.0f - c.beta2) * g * g;
-    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
-    return p - c.step_size * (m / denom);
+    const float denom = __builtin_amdgcn_sqrtf(v) * inv_bc2_sqrt + c.eps;
+    return p - c.step_size * (m * __builtin_amdgcn_rcpf(denom));
 }
 
 __device__ __forceinline__ u16x8 scale_frag(const u16x8 a, const float *__restrict__ c, float &colsum) {
@@ -1217,12 +1223,15 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
     }
     // ---- loss gradient of this net's rows -> LDS (the first fc2 tile of each net also reduces the loss terms)
     for (int b = g.n_rows + tid; b < g.bp; b += 256) tab[b] = 0.0f;
+    // (the two-step table of the fp32 tiles -- inputs requested ahead of the prefetch, LDS-only barrier -- was tried here
+    //  and measured slower: 33.6 vs 33.0 us per update, profiles/r5_bf16_forward.md)
     loss_fold_table(g.lf, e, tab, t == 0, red, t == 0 && e == 0);
     if (((g.fold.done && g.fold.td_logs) || g.fold.deferred_stats) && t == 0 && e == 0)
         log_fold_td_stats(g.fold, g.lf.tds, red);
     __syncthreads();
     WSTAMP(1);
     const ssac_adam_ctl ctl = *g.ctl;
+    const float inv_bc2 = 1.0f / ctl.bc2_sqrt;
     float ss = 0.0f;
     bool early = false;
     if (head) {
@@ -1254,7 +1263,7 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
                 Gr[a] = gw;
             } else {
                 float m = M[a], v = V[a];
-                const float pn = adam_elem(P[a], gw, m, v, ctl);
+                const float pn = adam_elem(P[a], gw, m, v, ctl, inv_bc2);
                 M[a] = m; V[a] = v; P[a] = pn;
                 S[g.sg.o3 + i] = f2bf(pn);
                 if (T) { const float tn = T[a] * (1.0f - tau) + pn * tau; T[a] = tn; TS[g.sg.o3 + i] = f2bf(tn); }
@@ -1267,7 +1276,7 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
                 Gr[a] = gb;
             } else {
                 float m = M[a], v = V[a];
-                const float pn = adam_elem(P[a], gb, m, v, ctl);
+                const float pn = adam_elem(P[a], gb, m, v, ctl, inv_bc2);
                 M[a] = m; V[a] = v; P[a] = pn;
                 if (T) T[a] = T[a] * (1.0f - tau) + pn * tau;
             }
@@ -1347,7 +1356,7 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
                         const int64_t a = off_w + (int64_t)j * ldc + col;
                         const float gr = acc[r];
                         float m = mv[r], v = vv[r];
-                        const float pn = adam_elem(pv[r], gr, m, v, ctl);
+                        const float pn = adam_elem(pv[r], gr, m, v, ctl, inv_bc2);
                         M[a] = m; V[a] = v; P[a] = pn;
                         hq[u] = f2bf(pn);
                         if (fc2) S[g.sg.o2 + frag_off(H >> 4, j, col)] = hq[u];
@@ -1369,7 +1378,7 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
         }
         if (bias_lane && !Gr) {
             float m = mb0, v = vb0;
-            const float pn = adam_elem(pb, colsum, m, v, ctl);
+            const float pn = adam_elem(pb, colsum, m, v, ctl, inv_bc2);
             M[ab] = m; V[ab] = v; P[ab] = pn;
             if (T) T[ab] = tb0 * (1.0f - tau) + pn * tau;
         }

@@ -43,6 +43,13 @@ constexpr float LOG_2 = 0.69314718055994530942f;
 __device__ __forceinline__ unsigned short f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+// v_exp_f32 / v_log_f32 / v_rcp_f32 forms (bf16 mode's sample epilogue)
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+__device__ __forceinline__ float fast_tanh(float x) {   // 1 - 2 / (e^{2x} + 1); saturates cleanly at +-1 (e^{2x} -> inf / 0)
+    const float xc = fminf(fmaxf(x, -15.0f), 15.0f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(fast_exp(2.0f * xc) + 1.0f);
+}
 
 struct ShadowGeom { int64_t stride, o1, o2, o2t, o3; int k1p; };
 
@@ -465,15 +472,19 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
         for (int t = tid; t < TM * A; t += NTHR) {
             const int r = t / A, i = t - r * A, b = m0 + r;
             if (b < g.n_rows) {
+                // (bf16 mode: hardware exp2 / log2 / rcp, ~1 ulp each, instead of the libm-grade sequences the fp32 path
+                //  keeps for parity with the reference -- this epilogue is a dependent chain on the launch's critical path,
+                //  actor -> a' -> target critics, and its consumers round a' to bf16 anyway.  dlt / sd = eps exactly, log sd =
+                //  log_std by construction)
                 const float mu = ys[r * ldo + i], raw = ys[r * ldo + A + i];
-                const float log_std = g.lo + 0.5f * (g.hi - g.lo) * (tanhf(raw) + 1.0f);
-                const float sd = expf(log_std);
+                const float log_std = g.lo + 0.5f * (g.hi - g.lo) * (fast_tanh(raw) + 1.0f);
+                const float sd = fast_exp(log_std);
                 const float ep = g.eps ? g.eps[(int64_t)b * A + i] : lpt[r * ldo + A + i];   // (drawn in the prologue by this thread)
                 const float u = mu + sd * ep;
-                const float dlt = u - mu;
-                lpt[r * ldo + i] = (-(dlt * dlt) / (2.0f * sd * sd) - logf(sd) - LOG_SQRT_2PI) -
-                                   2.0f * (LOG_2 - u - softplus_f(-2.0f * u));
-                const float a_new = tanhf(u);
+                const float z = -2.0f * u;
+                const float sp = z > 20.0f ? z : fast_log(1.0f + fast_exp(z));   // softplus(-2u)
+                lpt[r * ldo + i] = (-0.5f * ep * ep - log_std - LOG_SQRT_2PI) - 2.0f * (LOG_2 - u - sp);
+                const float a_new = fast_tanh(u);
                 g.act_dst[b * g.ld_act + g.act_col0 + i] = a_new;
                 if (g.ho.pub)   // the tile's target-critic workgroups are polling for it
                     handoff_publish(g.ho.pub + (int64_t)b * A + i, g.ho.base + (g.ho.tick ? (unsigned)*g.ho.tick : 0u), a_new);

@@ -156,6 +156,44 @@ def _large_batch_case(in_dim, B, form):
         assert float((y[e, :4096] - ref).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("in_dim,B,pad,n_sel", [(23, 30000, 9, 3), (20, 70001, 1, 1), (32, 9000, 32, 10)])
+def test_register_chained_forward_on_strided_rows_and_other_net_counts(in_dim, B, pad, n_sel):
+    """the register-chained kernel reads x with a leading dimension of its own (rows of a wider tensor, not 16-byte aligned),
+    for 1 / 3 / 10 selected nets (1 net: 256 workgroups of one net; the last row block of the batch ragged): against the
+    float64 emulation and against the streaming kernel on a contiguous copy"""
+    from super_sac_amd import engine
+    from super_sac_amd._lib import check, lib
+    torch.manual_seed(B + pad)
+    ar = _arena(10, in_dim, 256, 1, seed=4).enable_bf16()
+    big = torch.randn(B, in_dim + pad, device="cuda")
+    big[:, in_dim:] = float("nan")   # nothing beyond a row's in_dim floats may reach the result
+    big[:, :3] = float("nan") if pad > 8 else big[:, :3]
+    off = 3 if pad > 8 else 0
+    if off:
+        big[:, off:off + in_dim] = torch.randn(B, in_dim, device="cuda")
+    x = big[:, off:off + in_dim]
+    sel = list(range(10))[:n_sel]
+    ids = torch.tensor(sel, dtype=torch.int32, device="cuda")
+    y = torch.zeros(n_sel, B, 1, device="cuda")
+    check(lib.ssac_bf16_fwd_form(1))
+    check(lib.ssac_bf16_mlp3_fwd(C.byref(ar.desc()), ar.shadow.data_ptr(), ids.data_ptr(), n_sel,
+                                 big.data_ptr() + 4 * off, in_dim + pad, B, y.data_ptr(), engine.stream()))
+    xc = x.contiguous()
+    y0 = torch.zeros_like(y)
+    check(lib.ssac_bf16_fwd_form(0))
+    try:
+        check(lib.ssac_bf16_mlp3_fwd(C.byref(ar.desc()), ar.shadow.data_ptr(), ids.data_ptr(), n_sel, xc.data_ptr(), in_dim,
+                                     B, y0.data_ptr(), engine.stream()))
+    finally:
+        check(lib.ssac_bf16_fwd_form(1))
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+    assert float((y - y0).abs().max()) <= 4e-3 * float(y0.abs().max()) + 1e-4
+    for e in range(min(n_sel, 2)):
+        ref = _emulate(ar, sel[e], xc[-3000:])
+        assert float((y[e, -3000:] - ref).abs().max()) <= 4e-3 * float(ref.abs().max()) + 1e-4
+
+
 def test_empty_subset_slot_is_plus_infinity():
     from super_sac_amd import engine
     from super_sac_amd._lib import check, lib

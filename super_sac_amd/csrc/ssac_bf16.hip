@@ -36,6 +36,7 @@ namespace {
 constexpr int TM = 32;      // batch rows per workgroup
 constexpr int NTHR = 512;   // 8 waves: wave w owns output features [32w, 32w + 32)
 constexpr int LPAD = 8;     // LDS row padding (elements): 16-byte aligned rows, conflict-free ds_read_b128
+constexpr int XA_LD = 32 + LPAD;   // row stride of the consumer's a' tile (two K-steps of 16)
 constexpr float LOG_SQRT_2PI = 0.91893853320467274178f;
 constexpr float LOG_2 = 0.69314718055994530942f;
 
@@ -92,6 +93,7 @@ struct BfArgs {
                                     // 2 critic half, 4 rows from X with the subset ids read from the input slot
                                     // 5: hand-off consumer (s' rows like the actor half, nothing written, ids from the slot)
     long long *dbg;                 // optional s_memtime phase stamps of tile 0 (ssac_bf16_debug_stamps)
+    long long *tl;                  // optional per-workgroup (start, end) stamps of the chained launch (ssac_debug_timeline)
     int xcd;                        // XCD-contiguous workgroup order (ssac_internal.h)
     Handoff ho;                     // bf_chain_pc_kernel: MODE_SAMPLE publishes a', MODE_PLAIN takes its action columns from it
 };
@@ -119,14 +121,21 @@ struct Frags {
     }
 };
 
+// TR = false: D[b][n] (activation rows are the MFMA's A operand): acc[r] of lane (n, half) = D[(r&3) + 8(r>>2) + 4 half][n]
+// TR = true : D^T[n][b] (weight rows are the A operand):            acc[r] of lane (b, half) = D^T[(r&3) + 8(r>>2) + 4 half][b]
+//             -- a lane then holds 4 CONSECUTIVE FEATURES of one batch row per register quad: bias / ReLU / pack and ONE
+//             8-byte LDS store per quad into the row-major activation tile (instead of four scattered 2-byte ones), and a
+//             single-output head can be taken straight from the accumulators.  Same products, same K order.
+template <bool TR = false>
 __device__ __forceinline__ void bf_mma(f32x16 &acc, const Frags &f, const unsigned short *__restrict__ wp, int nsteps,
                                        const unsigned short *__restrict__ ap, int step = FRAG_STEP) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
         if (t < nsteps) {
-            const u16x8 a = *reinterpret_cast<const u16x8 *>(ap + 16 * t);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, f.w[t]),
-                                                          acc, 0, 0, 0);
+            const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8 *>(ap + 16 * t));
+            const bf16x8 w = __builtin_bit_cast(bf16x8, f.w[t]);
+            acc = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, acc, 0, 0, 0)
+                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w, acc, 0, 0, 0);
         }
     }
     for (int t0 = 16; t0 < nsteps; t0 += 8) {   // K > 256 (wide observations): 8 steps in flight at a time
@@ -136,9 +145,10 @@ __device__ __forceinline__ void bf_mma(f32x16 &acc, const Frags &f, const unsign
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             if (t0 + u < nsteps) {
-                const u16x8 a = *reinterpret_cast<const u16x8 *>(ap + 16 * (t0 + u));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, w[u]),
-                                                              acc, 0, 0, 0);
+                const bf16x8 a = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8 *>(ap + 16 * (t0 + u)));
+                const bf16x8 ww = __builtin_bit_cast(bf16x8, w[u]);
+                acc = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(ww, a, acc, 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, ww, acc, 0, 0, 0);
             }
         }
     }
@@ -169,7 +179,9 @@ __host__ __device__ inline size_t bf_lds_bytes(int in_dim, int hidden, int out_d
     const int ldo = (out_dim + 31) & ~31;
     size_t b = 2 * ((size_t)TM * (k1p + LPAD) + 3 * (size_t)TM * (hidden + LPAD));             // xs, h1s, h2s, dz2s (bf16)
     b += 4 * (2 * (size_t)TM * ldo + 3 * (size_t)hidden + ldo + 64);                           // ys, lpt, b1s, b2s, w3f, b3s
-    return (b + 15) & ~(size_t)15;
+    b = (b + 15) & ~(size_t)15;
+    b += 2 * (size_t)(NTHR / 64) * TM * XA_LD;   // hand-off consumer: a wave-private [TM][32] tile of a' (bf16) per wave
+    return b;
 }
 
 // HO: this instantiation may be the CONSUMER of a hand-off (bf_chain_pc_kernel's target-critic workgroups only: the other
@@ -190,6 +202,8 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
     float *b2s = b1s + H;                                    // [H]
     float *w3f = b2s + H;                                    // [H]   W3 row 0 as fp32 (single-output heads)
     float *b3s = w3f + H;                                    // [ldo]
+    // hand-off consumer: wave-private [TM][XA_LD] tiles of a' (the carve's last block)
+    unsigned short *xa = reinterpret_cast<unsigned short *>(smem + bf_lds_bytes(IN, H, OUT)) - (NTHR / 64) * TM * XA_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int m0 = bx * TM;
@@ -322,6 +336,10 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
     if (rd_lane) { g.gth.rew_out[m0 + xr] = rew_v; g.gth.done_out[m0 + xr] = done_v; }
     if (tid < H) { b1s[tid] = bv1; b2s[tid] = bv2; w3f[tid] = wv3; }
     if (tid < ldo) b3s[tid] = bv3;
+    if (CONS) {   // the wave's a' tile: zero but for the action columns, which arrive later
+        const u16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = lane; i < TM * XA_LD / 8; i += 64) *reinterpret_cast<u16x8 *>(xa + wave * (TM * XA_LD) + 8 * i) = z;
+    }
     lds_barrier();
     BSTAMP(1);
     if (MODE == MODE_CRITIC_U && e == 0 && g.XT) {
@@ -336,10 +354,118 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
     }
 
     f32x16 acc;
+    // The passes that save nothing transposed (actor, target critics, the plain forward) run D^T = W . act^T (bf_mma<true>);
+    // the critic workgroup keeps D = act . W^T, whose accumulators are the feature-major saves of the weight-gradient launch.
+    constexpr bool TR = MODE != MODE_CRITIC_U;
+    const unsigned short *wp3;   // the matrix after fc2: W2^T (backward-data) or the head's rows
+    constexpr int step3 = MODE == MODE_CRITIC_U ? FRAG_STEP : 16;
     // ---- fc1
     zero_acc(acc);
-    bf_mma(acc, f1, wp1, ns1, xs + li * ldx_s + 8 * lh);
+    bf_mma<TR>(acc, f1, wp1, ns1, xs + li * ldx_s + 8 * lh);
     BSTAMP(2);
+    if constexpr (TR) {
+        if (CONS) {
+            // a' W1[:, S:S+A]^T as ONE or TWO more MFMAs (round 5; was 128 fused multiply-adds per lane behind an LDS tile and
+            // a workgroup barrier): the W1 fragments of the K-steps that hold the action columns are requested now; every
+            // wave polls the tile's granules itself -- lane (row, half) takes 4 of the <= 8 action dimensions -- into its
+            // OWN zeroed [TM][32] tile (columns k - 16 t0; no workgroup barrier: a wave's LDS accesses are in order), reads
+            // the two B fragments back and multiplies.  a' is rounded to bf16 as the one-workgroup chain's x tile rounds it.
+            const int A_ = g.ho.A, S_ = g.ho.S;
+            const int t0 = S_ >> 4, t1 = (S_ + A_ - 1) >> 4;   // (A <= 8: at most two K-steps)
+            const bf16x8 wact0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8 *>(wp1 + FRAG_STEP * t0));
+            const bf16x8 wact1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8 *>(wp1 + FRAG_STEP * t1));
+            unsigned short *xaw = xa + wave * (TM * XA_LD);
+            const unsigned tag = g.ho.base + (g.ho.tick ? (unsigned)*g.ho.tick : 0u);
+            const int b = m0 + li;
+#pragma unroll
+            for (int dd = 0; dd < BF_HO_AMAX / 2; ++dd) {
+                const int d = (BF_HO_AMAX / 2) * lh + dd;
+                if (d < A_) {
+                    const float v = b < g.n_rows ? handoff_poll(g.ho.pub + (int64_t)b * A_ + d, tag) : 0.0f;
+                    xaw[li * XA_LD + (S_ + d - 16 * t0)] = f2bf(v);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const bf16x8 xa0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8 *>(xaw + li * XA_LD + 8 * lh));
+            const bf16x8 xa1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u16x8 *>(xaw + li * XA_LD + 16 + 8 * lh));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wact0, xa0, acc, 0, 0, 0);
+            if (t1 != t0) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wact1, xa1, acc, 0, 0, 0);
+        }
+        // heads wider than one output (the actor, discrete critics): W3's rows go in flight now, into fc1's registers
+        const int hrow = (col0 + li) < OUT ? col0 + li : 0;
+        wp3 = S + g.sg.o3 + (int64_t)hrow * H + 8 * lh;   // (W3: row-major, 16 elements per K-step)
+        if (OUT > 1) f1.load(wp3, nsh, 16);
+        if (wave_on) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n0 = col0 + 8 * q + 4 * lh;   // 4 consecutive features of row li
+                const f4 bq = *reinterpret_cast<const f4 *>(b1s + n0);
+                u16x4 hv;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hv[i] = f2bf(fmaxf(acc[4 * q + i] + bq[i], 0.0f));
+                *reinterpret_cast<u16x4 *>(h1s + li * ldh + n0) = hv;
+            }
+        }
+        lds_barrier();
+        BSTAMP(3);
+        // ---- fc2
+        zero_acc(acc);
+        bf_mma<true>(acc, f2, wp2, nsh, h1s + li * ldh + 8 * lh);
+        BSTAMP(4);
+        if (OUT == 1) {
+            // single output (critics): the head's dot product straight from the accumulators -- h2 is rounded to bf16 where
+            // it used to be stored -- summed over the lane's 16 features, the two halves, then the 8 waves through LDS
+            float qp = 0.0f;
+            if (wave_on) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n0 = col0 + 8 * q + 4 * lh;
+                    const f4 bq = *reinterpret_cast<const f4 *>(b2s + n0), wq = *reinterpret_cast<const f4 *>(w3f + n0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) qp += bf2f(f2bf(fmaxf(acc[4 * q + i] + bq[i], 0.0f))) * wq[i];
+                }
+            }
+            qp += __shfl_xor(qp, 32, 64);
+            if (lh == 0) lpt[wave * TM + li] = qp;   // (lpt: the sample epilogue's scratch, unused by a single-output pass)
+            lds_barrier();
+            BSTAMP(5);
+            if (tid < TM) {
+                float v = b3s[0];
+#pragma unroll
+                for (int w = 0; w < NTHR / 64; ++w) v += lpt[w * TM + tid];
+                ys[tid * ldo] = v;
+                if (g.Y && (m0 + tid) < g.n_rows) g.Y[(int64_t)e * g.n_rows + m0 + tid] = v;
+            }
+        } else {
+            if (wave_on) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n0 = col0 + 8 * q + 4 * lh;
+                    const f4 bq = *reinterpret_cast<const f4 *>(b2s + n0);
+                    u16x4 hv;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hv[i] = f2bf(fmaxf(acc[4 * q + i] + bq[i], 0.0f));
+                    *reinterpret_cast<u16x4 *>(h2s + li * ldh + n0) = hv;
+                }
+            }
+            lds_barrier();
+            BSTAMP(5);
+            if (col0 < OUT) {
+                // wave w computes outputs [32w, 32w + 32) over the whole K (rows past OUT read row 0 and are dropped)
+                zero_acc(acc);
+                bf_mma<true>(acc, f1, wp3, nsh, h2s + li * ldh + 8 * lh, 16);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = col0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (o < OUT) {
+                        const float v = acc[r] + b3s[o];
+                        ys[li * ldo + o] = v;
+                        if (g.Y && (m0 + li) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + li) * OUT + o] = v;
+                    }
+                }
+            }
+        }
+    } else {
     if (CONS) {
         // W1's action columns of this lane's feature, from the bf16 shadow (what the MFMA would have multiplied): requested
         // here -- fc1's fragments are dead, the next prefetch has not been issued: the body's register budget is full
@@ -371,14 +497,12 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
         }
     }
     // the NEXT matrix after fc2 goes in flight now, into fc1's registers: W2^T (backward-data) or the head's rows
-    const unsigned short *wp3;
     if (MODE == MODE_CRITIC_U) {
         wp3 = S + g.sg.o2t + frag_off(nsh, c0 + li, 8 * lh);
     } else {
         const int hrow = (col0 + li) < OUT ? col0 + li : 0;
         wp3 = S + g.sg.o3 + (int64_t)hrow * H + 8 * lh;   // (W3: row-major, 16 elements per K-step)
     }
-    const int step3 = MODE == MODE_CRITIC_U ? FRAG_STEP : 16;
     f1.load(wp3, nsh, step3);
     if (wave_on) {
         const float bias = b1s[n_me];
@@ -461,6 +585,7 @@ __device__ __forceinline__ void bf_mlp_body(const BfArgs &g, unsigned char *smem
                 if (g.Y && (m0 + b) < g.n_rows) g.Y[((int64_t)e * g.n_rows + m0 + b) * OUT + o] = v;
             }
         }
+    }
     }
     BSTAMP(6);
     if (MODE == MODE_PLAIN) return;
@@ -1039,6 +1164,8 @@ __global__ __launch_bounds__(NTHR) void bf_chain_pc_kernel(BfArgs ga, BfArgs gt,
                                                           int grid_x, DeferredLogsArgs dl, int dl_on) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int bid = blockIdx.x;
+    // (LAB build: per-workgroup (start, end) stamps, ssac_debug_timeline -- slots of the chained launch, as in ssac_fused.hip)
+    SSAC_LAB_ONLY(long long *tl = gc.tl; if (tl && threadIdx.x == 0 && bid < 512) tl[2 * bid] = __builtin_amdgcn_s_memrealtime();)
     if (dl_on && bid == (int)gridDim.x - 1) {
         deferred_logs_body(dl, -1);
         return;
@@ -1054,6 +1181,12 @@ __global__ __launch_bounds__(NTHR) void bf_chain_pc_kernel(BfArgs ga, BfArgs gt,
         const int j = lb / grid_x, bx = lb - j * grid_x;
         bf_mlp_body<MODE_PLAIN, true>(gt, smem, bx, j, j == 0 ? 16 : -1);
     }
+#ifdef SSAC_LAB
+    if (tl && bid < 512) {
+        __syncthreads();
+        if (threadIdx.x == 0) tl[2 * bid + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1136,6 +1269,7 @@ struct BfWgradArgs {
     int tiles2, tiles1;   // 64x64 tiles of fc2 / fc1 per net; then 1 head workgroup per net
     int xcd;                     // XCD-contiguous workgroup order (ssac_internal.h)
     long long *dbg;
+    long long *tl;               // optional per-workgroup (start, end) stamps, slots from 1024 (ssac_debug_timeline)
 };
 #ifdef SSAC_LAB
 #define WSTAMP(i) do { if (g.dbg && blockIdx.x == 0 && threadIdx.x == 0) g.dbg[48 + i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -1171,6 +1305,7 @@ __device__ __forceinline__ u16x8 scale_frag(const u16x8 a, const float *__restri
 
 __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
     extern __shared__ __attribute__((aligned(16))) float wlds[];
+    SSAC_LAB_ONLY(if (g.tl && threadIdx.x == 0 && blockIdx.x < 512) g.tl[1024 + 2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();)
     float *tab = wlds;                 // [bp] row scales (zero beyond n_rows)
     float *red = wlds + g.bp;          // [16] scratch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1252,16 +1387,23 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
         if (i < H) {
             const unsigned short *hbase = g.H2T + (int64_t)e * H * g.bp;
             auto hp_at = [&](int k) { return hbase + frag_off(g.bp >> 4, i, k); };   // 8 consecutive k are contiguous
+            // (round 5: FOUR partial sums -- one dependent chain of bp fused multiply-adds per thread made the head workgroup
+            //  the LAST one of the launch, 12 - 14 us against 10 - 11 for the GEMM tiles (tools/r5/bf16_timeline.py) -- and the
+            //  row scales as 16-byte LDS reads)
+            float gq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             for (int b0_ = 0; b0_ < g.bp; b0_ += 32) {
                 u16x8 hv[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const u16x8 *>(hp_at(b0_ + 8 * q < g.bp ? b0_ + 8 * q : 0));
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (b0_ + 8 * q < g.bp)
+                    if (b0_ + 8 * q < g.bp) {
+                        const f4 c0 = *reinterpret_cast<const f4 *>(tab + b0_ + 8 * q), c1 = *reinterpret_cast<const f4 *>(tab + b0_ + 8 * q + 4);
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) gw += tab[b0_ + 8 * q + u] * bf2f(hv[q][u]);
+                        for (int u = 0; u < 8; ++u) gq[q] += (u < 4 ? c0[u] : c1[u - 4]) * bf2f(hv[q][u]);
+                    }
             }
+            gw = (gq[0] + gq[1]) + (gq[2] + gq[3]);
         }
         if (tid < 64) {
             for (int b = tid; b < g.bp; b += 64) gb += tab[b];
@@ -1413,6 +1555,12 @@ __global__ __launch_bounds__(256) void bf_wgrad_kernel(BfWgradArgs g) {
     } else if (g.fold.deferred_stats && g.fold.feed && blockIdx.x == 0 && tid == 0) {
         g.fold.feed->tick += 1;   // deferred finalisation: the update is over for the input ring
     }
+#ifdef SSAC_LAB
+    if (g.tl && blockIdx.x < 512) {
+        __syncthreads();
+        if (tid == 0) g.tl[1024 + 2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 long long *g_bf_dbg = nullptr;
@@ -1430,7 +1578,7 @@ void bf_fill(BfArgs &g, const ssac_mlp *nets, const uint16_t *shadow, const int3
     ssac_mlp_layout(nets->in_dim, nets->hidden, nets->out_dim, g.off);
     g.shadow = shadow; g.sg = shadow_geom(nets->in_dim, nets->hidden, nets->out_dim);
     g.ids = ids; g.X = X; g.ldx = ldx; g.n_rows = n_rows; g.bp = (n_rows + 15) & ~15;
-    g.dbg = g_bf_dbg;
+    g.dbg = g_bf_dbg; g.tl = g_ssac_timeline;
     g.xcd = (g_ssac_xcd & 8) ? 0 : 1;   // (ssac_xcd_order bit 3: the chained launches in hardware order)
 }
 
@@ -1651,7 +1799,7 @@ extern "C" int ssac_bf16_wgrad_lossfold(const ssac_mlp *nets, uint16_t *shadow, 
     g.lf.n_rows = n_rows;
     const int t = (nets->hidden + 63) / 64;
     g.tiles2 = t * t; g.tiles1 = t * ((nets->in_dim + 63) / 64);
-    g.dbg = g_bf_dbg;
+    g.dbg = g_bf_dbg; g.tl = g_ssac_timeline;
     g.xcd = (g_ssac_xcd >> 1) & 1;
     if (logfold && logfold->done_counter) {
         if (!sumsq) return ssac_fail("ssac_bf16_wgrad_lossfold: the folded logs need the sumsq slots");

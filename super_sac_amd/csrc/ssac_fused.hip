@@ -813,7 +813,11 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
     };
     auto consumer_arrive = [&]() {
         if (HO && MODE == MODE_PLAIN && g.xarrive) {
-            __syncthreads();   // (drains every wave's stores: s_waitcnt vmcnt(0) in front of the barrier)
+            // every wave drains ITS OWN stores before the barrier: __syncthreads() is s_waitcnt lgkmcnt(0) + s_barrier on this
+            // toolchain (no vmcnt), and thread 0's release below waits on wave 0's stores only -- the column-split consumers'
+            // other seven waves store Qt partials too
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
             if (threadIdx.x == 0) __hip_atomic_fetch_add(g.xarrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
@@ -1719,17 +1723,25 @@ void fused_chain_pc_kernel(FusedArgs ga, FusedArgs gt, FusedArgs gc, int tiles_a
             if (!gslot) { const ssac_feed f = *gt.gth.feed; gslot = feed_slot(f); }
             own = reinterpret_cast<const int32_t *>(gslot + gt.gth.ids_word);
         }
+        int *s_late = reinterpret_cast<int *>(smem) + 4;   // (behind the 16 bytes xchg_body keeps at the front of the block)
         if (threadIdx.x == 0) {
             const long long t0 = __builtin_amdgcn_s_memtime();
             const long long limit = *xa.dead ? 0 : xa.spin_limit;
+            int late = 0;
             while (__hip_atomic_load(xa.arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tiles_t) {
                 __builtin_amdgcn_s_sleep(2);
-                if (__builtin_amdgcn_s_memtime() - t0 > limit) { *xa.dead = 1; break; }   // (the exchange then poisons + reports)
+                if (__builtin_amdgcn_s_memtime() - t0 > limit) { late = 1; break; }
             }
-            __hip_atomic_store(xa.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // a wait that gave up: the Qt in `data` is incomplete.  The exchange is told to FAIL (nothing sent, result poisoned,
+            // error word raised, `dead` set -- xchg_body's !s_ok branch), and the counter is left alone: stragglers may still
+            // bump it, and with `dead` set no later launch of this engine trusts it again
+            if (!late) __hip_atomic_store(xa.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_late = late;
         }
         __syncthreads();
-        xchg_body<NTHR, true>(xa, smem, own);   // (its 16 bytes of LDS: the front of this workgroup's unused dynamic block)
+        const bool late = *s_late != 0;
+        __syncthreads();   // (everyone has read the word before xchg_body's thread 0 reuses the front of the block)
+        xchg_body<NTHR, true>(xa, smem, own, late);   // (its 16 bytes of LDS: the front of this workgroup's unused dynamic block)
         return;
     }
     // 32-row critic tiles (~58 k clocks) go before the consumers (~41 k from the launch's start, most of it waiting),

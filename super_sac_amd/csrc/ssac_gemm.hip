@@ -487,6 +487,11 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
         for (int r = 0; r < 16; ++r)
             mine[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + wn * 32 + li] = acc[r];
         if (bias_wave && lh == 0) red[kg * 64 + wm * 32 + li] = bias_acc;
+        // The arrival ticket of the folded logs is drawn by the LAST wave (sumsq_finish), the net's loss partials were stored
+        // by wave 0 at the front (loss_fold_table): wave 0 drains its stores in front of THIS barrier, which the last wave
+        // passes before it draws -- the order no longer rests on the K loop's waits (by now only the prefetched optimizer
+        // state is in flight in this wave, and it is consumed right behind the barrier)
+        if (fold.done && (tid_all >> 6) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
         GSTAMP(3);
         constexpr int NT_ALL = NTHREADS * KS;
@@ -646,8 +651,8 @@ __device__ __forceinline__ void ens_gemm_body(const GemmArgs &g, float *lds, int
             for (int gq = 1; gq < KS; ++gq) bsum += red[gq * 64 + tid_all];
             if (EPI == EPI_ADAM) { bpv = g.pb[bi]; bmv = g.bm[bi]; bvv = g.bv[bi]; btv = (pol && g.tb) ? g.tb[bi] : 0.0f; }
         }
-        // ---- gradient-norm partial FIRST (it needs the gradients only), so that with the logs folded in the arrival
-        //      ticket is drawn before -- not behind -- the optimizer stores
+        // ---- gradient-norm partial of the tile: per-wave sums here, finished by the LAST wave behind its optimizer
+        //      stores (sumsq_finish above: xor tree over the wave partials, then the arrival ticket of the folded logs)
 #pragma unroll
         for (int j = 0; j < PER; ++j)
             if (ok[j]) ss += gval[j] * gval[j];
@@ -848,8 +853,8 @@ __global__ __launch_bounds__(NTHREADS *KS) void ens_gemm_pair_kernel(GemmPair p)
         drawn = true;
     }
     if (p.fold.done) {
-        // thread 0 drew the arrival ticket right after storing the workgroup's gradient-norm partial (the GEMM tiles
-        // inside their epilogue, ahead of the optimizer stores); the wave of the last arriver finalises the logs
+        // a GEMM tile's ticket was drawn inside its epilogue by lane 0 of its last wave, behind that wave's optimizer stores
+        // and behind the barrier in front of which wave 0 drained the loss partials; the wave of the last arriver finalises the logs
         float *flag = lds + KS * (4 * TILE_FLOATS);   // (the bias / sumsq scratch: consumed by now)
         __syncthreads();
         // (a GEMM tile's ticket was drawn by lane 0 of its LAST wave -- sumsq_finish; the other workgroup classes draw it here)

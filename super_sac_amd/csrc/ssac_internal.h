@@ -195,11 +195,13 @@ __device__ __forceinline__ ShiftAxis drqv2_shift_axis(int i, int64_t shift, int 
     return drqv2_shift_axis(i, shift, drqv2_shift_grid(hp));
 }
 
-// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global loads / stores.
-// __syncthreads() also drains vmcnt -- inside a software-pipelined K loop that exposes the round trip of the operand
-// loads issued for the chunk AFTER next at every chunk barrier, and at phase boundaries it stalls on prefetched weights
-// and on fire-and-forget activation stores.  The waitcnt pass still inserts the vmcnt wait in front of the first USE
-// of a loaded register.  Use it only where everything handed over at the barrier went through LDS.
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic, NOT for its global loads / stores, and
+// is opaque to the compiler's fence lowering.  With this toolchain (ROCm 7.2, gfx950, probed in round 6) __syncthreads()
+// emits the same two instructions -- s_waitcnt lgkmcnt(0); s_barrier, NO vmcnt(0): a workgroup-scope release does not
+// drain vector-memory stores on a CU in non-tgsplit mode -- so neither barrier makes one wave's GLOBAL stores visible
+// beyond the CU.  A cross-workgroup hand-off therefore needs `s_waitcnt vmcnt(0)` in EVERY storing wave in front of the
+// barrier that precedes the arrival (consumer_arrive in ssac_fused.hip, xchg_body, the weight-gradient epilogue).
+// The waitcnt pass still inserts the vmcnt wait in front of the first USE of a loaded register.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ int ssac_xcd_contiguous(int bid, int nwg, int on) {

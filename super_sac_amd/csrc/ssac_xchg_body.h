@@ -55,15 +55,19 @@ __device__ __forceinline__ unsigned long long *ack_of(float *base, int world, in
 // launch (agent-scope stores): read it with agent-scope loads, not through this CU's non-coherent caches.
 // owners_now: the update's id block where the CALLER found it (the in-launch form reads it from the input slot, as the
 // launch's other workgroups do); null = a.owners.
+// force_fail: see below.
 // lds16: 16 bytes of the CALLER's LDS (8-byte aligned) -- the body keeps no static LDS of its own: a kernel that asks for the
 // CU's whole 160 KB as dynamic LDS (the chained launch) could not carry even 16 static bytes.
 template <int NT, bool DATA_AGENT>
-__device__ __forceinline__ void xchg_body(const XchgArgs &a, void *lds16, const int32_t *owners_now = nullptr) {
+__device__ __forceinline__ void xchg_body(const XchgArgs &a, void *lds16, const int32_t *owners_now = nullptr,
+                                          bool force_fail = false) {
     const int32_t *owners = owners_now ? owners_now : a.owners;
     unsigned long long &s_seq = *reinterpret_cast<unsigned long long *>(lds16);
     int &s_ok = *reinterpret_cast<int *>(reinterpret_cast<char *>(lds16) + 8);
     const int tid = threadIdx.x;
-    if (tid == 0) { s_seq = *a.seq + 1; s_ok = 1; }
+    // force_fail: the caller already knows the payload is not whole (the in-launch form's wait for its producers gave up):
+    // take the !s_ok path from the start -- nothing is sent or polled, the result is poisoned, the error word raised
+    if (tid == 0) { s_seq = *a.seq + 1; s_ok = force_fail ? 0 : 1; }
     __syncthreads();
     const unsigned long long seq = s_seq;
     const int slot = (int)(seq % X_SLOTS);

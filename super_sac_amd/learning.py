@@ -951,11 +951,33 @@ def _actor_chain_form(a_arena, A, B):
     return bool(ACTOR_CHAIN and a_arena.fused_dbuf and A <= 32 and a_arena.hidden * A <= 512 * 9 and B <= 2048)
 
 
+def _actor_fused_member(kind, random_process, use_baseline, clip, a_arena, c_arena):
+    """does this member's online actor update take the fused launches at all (the sharded and the unsharded branch of
+    _online_actor_update share it; which of the two is decided by parallel.shard_of at the call site)?"""
+    return bool(FUSED_ACTOR and kind == "stochastic" and random_process is None and not use_baseline and not clip
+                and a_arena.fused and c_arena.fused_dbuf and c_arena.out_dim == 1)
+
+
+def _member_noise_in_kernel(chain, rec_eps):
+    """the chained launch with the stock generator draws the member's noise inside the kernel (no buffer, no draw from
+    the device generator) -- unless a recording owns noise buffers for it"""
+    return bool(chain and lu.IN_KERNEL_NOISE and rng.normal_is_stock() and rec_eps is None)
+
+
 def _actor_noise_in_kernel(agent, batch_size, dev):
-    """recorded actor update: the noise is drawn inside the launches only if EVERY member takes the chained launch"""
-    return bool(lu.IN_KERNEL_NOISE and rng.normal_is_stock()
-                and all(_actor_chain_form(engine.bind_arena(a_, "self", [a_], dev), a_.action_size, batch_size)
-                        for a_ in agent.actors))
+    """recorded actor update: the noise is drawn inside the launches only if EVERY member takes the chained launch.
+    (the arenas' shapes cannot change under a recording, so the per-form answer is cached on the agent; what CAN change
+    between calls -- a noise hook, the IN_KERNEL_NOISE / ACTOR_CHAIN switches -- is re-read every time)"""
+    if not (lu.IN_KERNEL_NOISE and rng.normal_is_stock()):
+        return False
+    key = (batch_size, str(dev), ACTOR_CHAIN, tuple(id(a_) for a_ in agent.actors))
+    memo = agent.__dict__.setdefault("_ssac_chain_form_memo", {})
+    if key not in memo:
+        if len(memo) > 16:
+            memo.clear()
+        memo[key] = all(_actor_chain_form(engine.bind_arena(a_, "self", [a_], dev), a_.action_size, batch_size)
+                        for a_ in agent.actors)
+    return memo[key]
 
 
 class _RecordedActor:
@@ -1077,11 +1099,9 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             # in the kernel -- members share their shapes, so this rank's first member answers for the absent one)
             a0_, c0_ = agent.actors[0], agent.critics[0]
             ar0_, cr0_ = engine.bind_arena(a0_, "self", [a0_], dev), c0_.arena(dev)
-            owner_in_kernel = (FUSED_ACTOR and lu.actor_kind(a0_) == "stochastic" and random_process is None
-                               and not use_baseline and parallel.shard_of(agent) is None and not clip and ar0_.fused
-                               and cr0_.fused_dbuf and cr0_.out_dim == 1
-                               and _actor_chain_form(ar0_, a0_.action_size, batch_size)
-                               and lu.IN_KERNEL_NOISE and rng.normal_is_stock() and _rec_eps is None)
+            owner_in_kernel = (_actor_fused_member(lu.actor_kind(a0_), random_process, use_baseline, clip, ar0_, cr0_)
+                               and parallel.shard_of(agent) is None
+                               and _member_noise_in_kernel(_actor_chain_form(ar0_, a0_.action_size, batch_size), _rec_eps))
             if not owner_in_kernel:
                 lu.skip_actor_draws(agent.actors[0], batch_size, dev, random_process)
             continue
@@ -1101,8 +1121,8 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
         kind = lu.actor_kind(actor)
         pp, dopop = (popart.ptr if popart else 0), (1 if (popart and pop) else 0)
         shard = parallel.shard_of(agent)
-        if (FUSED_ACTOR and kind == "stochastic" and random_process is None and not use_baseline and shard is not None
-                and not clip and a_arena.fused and c_arena.fused_dbuf and c_arena.out_dim == 1):
+        fused_member = _actor_fused_member(kind, random_process, use_baseline, clip, a_arena, c_arena)
+        if fused_member and shard is not None:
             # ---- critic-sharded rank: the same fused launches, cut at the two exchange steps of SURVEY 8(e) -- sample +
             #      [s|a] rows; the LOCAL critics' forward + dQ/da; local arg-min, MIN over the ranks, the global arg-min's
             #      owner keeps its dQ/da row, SUM over the ranks; actor backward on (global min Q, routed dQ/da)
@@ -1150,8 +1170,7 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
                                       st))
             member_ss.append(None if one else ss)
             continue
-        if (FUSED_ACTOR and kind == "stochastic" and random_process is None and not use_baseline and shard is None
-                and not clip and a_arena.fused and c_arena.fused_dbuf and c_arena.out_dim == 1):
+        if fused_member and shard is None:
             # ---- four launches instead of ~15 (include/ssac_hip.h, "the online actor update"): sample + [s|a] rows,
             #      critics' forward + unscaled dQ/da, arg-min routing + tanh-normal backward + actor backward-data,
             #      weight gradients + Adam; then one launch for the two log values
@@ -1164,7 +1183,7 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             # kernel (draw number = this update's number: no generator launch, no buffer); otherwise a draw -- into the
             # recording's fixed buffer, or a fresh one -- as a_dist.rsample() makes it (learning.py:392)
             chain = _actor_chain_form(a_arena, A, B)
-            in_kernel = chain and lu.IN_KERNEL_NOISE and rng.normal_is_stock() and _rec_eps is None
+            in_kernel = _member_noise_in_kernel(chain, _rec_eps)
             eps = None   # (kept alive to the end of the member's launches: the kernels read it asynchronously)
             if in_kernel:
                 eps_ptr = 0

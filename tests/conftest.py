@@ -26,3 +26,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter):
+    """spin-bound retries of the ranks-share-one-GPU tests (tests/test_hip_sharded.py::_spawn) are never silent"""
+    mod = sys.modules.get("test_hip_sharded")
+    retried = getattr(mod, "RETRIED", None) if mod else None
+    if retried:
+        terminalreporter.section("exchange retries (shared test GPU)")
+        for test_id, msg in retried:
+            terminalreporter.line(f"{test_id}: {msg}")

@@ -14,14 +14,23 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+RETRIED = []   # (test id, message) of every spin-bound retry of this session: reported at the end of the run (conftest)
+
+
 def _spawn(fn, args, nprocs, retries=1):
     """mp.spawn for ranks that SHARE the test box's one GPU.  Their one-shot exchange kernels spin on each other's flags
     while the device time-slices the processes' queues; once in a while (documented since round 3: about one run of the
     suite in six on a loaded box) a wait sits out the whole spin bound and the exchange reports it as designed -- error
     word, NaN-poisoned result, RuntimeError("... did not arrive within the spin bound").  That outcome says something
     about the box's scheduler, not about the protocol (one rank per GPU -- the product layout -- has no time-slicing), so
-    THAT failure alone is retried once on a fresh rendezvous port; every other failure propagates at once."""
+    THAT failure alone is retried once on a fresh rendezvous port; every other failure propagates at once.
+    A retry is never silent and never sees the failed attempt's files: it is recorded in RETRIED + a warning (pytest's
+    summary shows it), and the attempt's output directory (the str argument that is an existing directory) is emptied
+    first, so ok*/rec* files of the failed attempt cannot satisfy the caller's assertions."""
+    import shutil
+    import warnings
     port_arg = [i for i, a in enumerate(args) if isinstance(a, int) and 20000 <= a < 65000][-1]
+    dir_args = [a for a in args if isinstance(a, str) and os.path.isdir(a)]
     for attempt in range(retries + 1):
         try:
             mp.spawn(fn, args=tuple(args), nprocs=nprocs, join=True)
@@ -29,6 +38,13 @@ def _spawn(fn, args, nprocs, retries=1):
         except Exception as e:   # noqa: BLE001  (torch.multiprocessing.spawn.ProcessRaisedException)
             if attempt == retries or "within the spin bound" not in str(e):
                 raise
+            msg = f"{fn.__name__}: exchange wait sat out the spin bound on the shared test GPU; retried once"
+            RETRIED.append((os.environ.get("PYTEST_CURRENT_TEST", "?"), msg))
+            warnings.warn(msg)
+            for d in dir_args:
+                for f in os.listdir(d):
+                    fp = os.path.join(d, f)
+                    shutil.rmtree(fp) if os.path.isdir(fp) else os.remove(fp)
             args = list(args)
             args[port_arg] += 97
 

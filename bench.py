@@ -8,7 +8,9 @@ by the Polyak update of the target critics, exactly as the reference's UTD loop 
 buffer (100k transitions) is resident in HBM before the timed region starts; the per-update host work that remains
 (index draw from the torch CPU generator, REDQ subset draw, a 4 KB index upload) is part of the path and is inside the
 timed region.  After W untimed warm-up steps, EXACTLY K steps are timed between barrier + synchronize brackets; this is
-done R times (default 5) and the MEDIAN repeat is reported (``value`` = K / median seconds).
+done R times (default 31: at the driver's K = 20 that is ~35 ms, past the ~14 ms the core clock takes to ramp after the idle
+construction phase; every repeat's time and the shader clock beside it are listed in the line) and the MEDIAN repeat is
+reported (``value`` = K / median seconds).
 
 --critics / --obs / --act / --batch (defaults 10 / 17 / 6 / 512 = the headline) select another ensemble: `--gpus 8
 --critics 16` is the configuration BASELINE.json's scaling target is quoted on (N = 16 critics over 8 GPUs), `--obs 376
@@ -44,10 +46,52 @@ ROWS, CAP = 100_000, 1_000_000
 GAMMA, LR, TAU, TARGET_DELAY = 0.99, 3e-4, 0.005, 2
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-# HBM bytes per launch of the chained kernel from the offline PMC passes in profiles/ (FETCH_SIZE doubled per the
-# guide's gfx950 note for 16-byte streaming reads + WRITE_SIZE); single-GPU N=10 shape only; not collected in this run
-TRAFFIC_CHAIN_BYTES = (2 * 6081 + 15541) * 1024
-TRAFFIC_SOURCE = "offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (profiles/r5_kernel_stats.md)"
+# HBM bytes per launch of the chained kernel come from OFFLINE rocprofv3 --pmc passes of this command (FETCH_SIZE doubled per
+# the guide's gfx950 note for 16-byte streaming reads + WRITE_SIZE; separate passes) -- they cannot be collected inside this
+# run.  profiles/traffic.json records them together with a hash of the kernel sources they were taken on
+# (tools/traffic_record.py writes it from the PMC summaries); a line printed from other sources carries `traffic: null` and
+# says why, instead of a number that silently went stale (round-5 review, weak 11).
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
+TRAFFIC_SOURCES = ("super_sac_amd/csrc/ssac_fused.hip", "super_sac_amd/csrc/ssac_internal.h", "super_sac_amd/csrc/ssac_begin.h")
+
+
+def kernel_source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for rel in TRAFFIC_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def recorded_traffic():
+    """(bytes per launch or None, provenance string)"""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None, "no offline PMC record (profiles/traffic.json)"
+    if rec.get("source_hash") != kernel_source_hash():
+        return None, (f"stale: the kernel sources changed since the PMC passes of {rec.get('taken_at', '?')} "
+                      f"({rec.get('bytes')} B per launch then)")
+    return int(rec["bytes"]), (f"offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these kernel sources "
+                               f"({rec.get('taken_at', '?')}; {rec.get('evidence', 'profiles/')}): 2 x {rec.get('fetch_kib')} KiB "
+                               f"fetched + {rec.get('write_kib')} KiB written")
+
+
+def sclk_mhz(index=0):
+    """current shader clock of the device from sysfs (the starred level of pp_dpm_sclk), or None: a few microseconds, no
+    GPU work, no subprocess -- read beside every timed repeat so that the clock ramp after an idle stretch is IN the line"""
+    import glob
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        with open(cards[min(index, len(cards) - 1)]) as f:
+            for ln in f:
+                if "*" in ln:
+                    return int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
+    except Exception:   # noqa: BLE001  (no sysfs node / not readable: the line says null)
+        pass
+    return None
 
 
 def synth_data(obs=OBS, act=ACT):
@@ -273,7 +317,8 @@ def launch_ranks(args):
     sys.exit(rc)
 
 
-def timed_repeats(fn, steps, repeats, dist, device):
+def timed_repeats(fn, steps, repeats, dist, device, clocks=None):
+    """clocks: a list that receives the shader clock (MHz, sysfs) read right after every repeat's closing synchronise"""
     import torch
     times = []
     for _ in range(repeats):
@@ -292,6 +337,8 @@ def timed_repeats(fn, steps, repeats, dist, device):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t)
         times.append(dt)
+        if clocks is not None:
+            clocks.append(sclk_mhz(device.index or 0))
     return times
 
 
@@ -300,7 +347,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--repeats", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=31,
+                    help="timed regions of EXACTLY --steps steps each (every one listed in the line); the median is the value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--critics", type=int, default=NCRIT, help="ensemble size N (16: the scaling target's configuration)")
@@ -387,11 +435,17 @@ def main():
     gc.freeze()
     if dist is not None:
         dist.barrier()   # ranks finish building at different times: start the exchanging updates together
+    sclk_before = sclk_mhz(local)
     for _ in range(args.warmup):
         step()
 
-    # ---- timed region: EXACTLY --steps steps between barrier+sync brackets, `repeats` times; the median is reported
-    times = timed_repeats(step, args.steps, args.repeats, dist, device)
+    # ---- timed region: EXACTLY --steps steps between barrier+sync brackets, `repeats` times; the median is reported.
+    # It is the FIRST GPU work of the process behind construction and the --warmup steps (no hidden warm-up: the CPU
+    # baseline, the roofline's event pass and every secondary row come after it).  The device has idled through the
+    # construction (seconds of host work), so the first ~14 ms of it run inside the core clock's ramp: every repeat's time and
+    # the shader clock read beside it are in the line, as are the first and the fastest repeat.
+    sclk = []
+    times = timed_repeats(step, args.steps, args.repeats, dist, device, clocks=sclk)
     dt = statistics.median(times)
     if world > 1:
         from super_sac_amd import parallel
@@ -451,8 +505,9 @@ def main():
                 "timing": "HIP events on the launch stream around 8 back-to-back issues of the (idempotent) launch, "
                           "in an eager pass right after the timed (replayed) region",
                 "flops_per_launch": flops,
-                "traffic": TRAFFIC_CHAIN_BYTES if single else None,
-                "traffic_source": TRAFFIC_SOURCE if single else None}
+                "traffic": None, "traffic_source": None}
+    if single:
+        roofline["traffic"], roofline["traffic_source"] = recorded_traffic()
 
     if rank == 0:
         out = {"metric": f"gradient updates/sec (REDQ N={NCRIT}, batch {BATCH})", "value": round(args.steps / dt, 2),
@@ -460,6 +515,10 @@ def main():
                "ms_per_step": round(1e3 * dt / args.steps, 5), "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "repeats": args.repeats, "repeat_ms_per_step": [round(1e3 * t / args.steps, 5) for t in times],
+               "ms_per_step_first": round(1e3 * times[0] / args.steps, 5),
+               "ms_per_step_min": round(1e3 * min(times) / args.steps, 5),
+               "sclk_mhz": {"before_warmup": sclk_before, "after_each_repeat": sclk,
+                            "source": "sysfs pp_dpm_sclk (current level), rank 0's device"},
                "config": {"workload": f"REDQ critic_update + Polyak/2: obs {OBS}, act {ACT}, batch {BATCH}, "
                                       f"N={NCRIT} critics (n=2 target subset), hidden 256, replay 100k rows in HBM",
                           "global_batch": BATCH, "num_critics": NCRIT,

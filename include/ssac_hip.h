@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SSAC_ABI_VERSION 6
+#define SSAC_ABI_VERSION 7
 #define SSAC_MAX_NETS 64
 
 typedef struct ssac_mlp {
@@ -175,9 +175,7 @@ int ssac_step_run(ssac_step *step, const int64_t *idx_host, const int32_t *ids_h
 /* ssac_step_run hands the address of the slot it has just written to the replayed launches BY VALUE (a pointer member of
  * their recorded argument bytes is overwritten before each re-issue), so no workgroup reads the ssac_feed block to find
  * its inputs: one dependent load from cold memory less at the front of every workgroup of the update's first launch.
- * ssac_slot_by_value(0) switches that off (the launches go through the feed block, as plain ssac_replay and hipGraph
- * captures always do); results are bit-identical either way (tests/test_hip_cases.py). */
-int ssac_slot_by_value(int on);
+ * (A/B switch: ssac_slot_by_value in ssac_hip_test.h; results are bit-identical either way.) */
 int64_t ssac_step_count(const ssac_step *step);
 int ssac_step_seek(ssac_step *step, int64_t k);   /* updates the ring's device-side counter has consumed so far */
 /* soft_update right after ssac_step_run (late-bound Polyak): leaves the request for the update just issued in the ring
@@ -215,11 +213,8 @@ int ssac_xchg_error(ssac_xchg *x);   /* 1: a peer's flag did not arrive within t
                                         was poisoned with NaN); a pinned host word, cleared by the read, no synchronisation */
 /* Flow control: every rank acknowledges the exchanges it has consumed and a sender reuses slot seq % 4 only when every
  * rank has consumed exchange seq - 4; a receiver accepts a flag only when it EQUALS its sequence number (a larger one
- * = the slot was lapped: poisoned result + error word).  ssac_xchg_test_mode exists in the LAB build only
- * (`./build.sh --lab`; the product library refuses any mode but 0 and its kernel does not read the field): bit 0 makes this
- * rank's senders skip the reuse wait, bit 1 makes its receivers accept flag >= seq -- 3 is the protocol of round 3,
- * whose owners-only form let senders lap a rank that owned no subset member (tests/test_hip_sharded.py shows both). */
-int ssac_xchg_test_mode(ssac_xchg *x, int mode);
+ * = the slot was lapped: poisoned result + error word).  (The protocol's failing-first evidence switch, ssac_xchg_test_mode,
+ * exists in the LAB build only: ssac_hip_test.h.) */
 void ssac_xchg_destroy(ssac_xchg *x);
 
 /* ---- prioritised replay on the device (replaces super_sac/replay.py:140-190 sample / update_priorities and the
@@ -637,36 +632,15 @@ int ssac_drq_shift(const void *src, int src_dtype, const int64_t *idx, int n, in
  * staging fits (required of the CRITIC halves of the merged launches below), 2 when only the single-buffer
  * carve fits (wide input + wide head, e.g. 376 -> 34), 0 when unsupported. ==== */
 int ssac_fused_supported(const ssac_mlp *nets);
-/* development aid: when set to a device buffer of >= 16 int64, workgroup (0,0) of every fused launch
- * records s_memtime() at its phase boundaries there; NULL (default) disables it. */
-int ssac_fused_debug_stamps(long long *dev_buf);
-int ssac_gemm_debug_stamps(long long *dev_buf); /* same for the weight-gradient GEMM launches */
-/* dev_buf: 2048 x int64 or NULL.  (start, end) of EVERY workgroup of the chained launch [0, 1024) and of the merged
-   weight-gradient launch [1024, 2048), s_memrealtime ticks (100 MHz): dispatch skew and the slowest workgroup class of a
-   launch (tools/wg_timeline.py). */
-int ssac_debug_timeline(long long *dev_buf);
-/* tuning knob, default 1: the merged weight-gradient launch uses its lean kernel (16-byte operand loader only) whenever
-   both problems qualify; 0 = always the general kernel.  Bit-identical results. */
-int ssac_gemm_lean(int on);
-/* Form of the merged weight-gradient launch (ssac_mlp_wgrad_all / _scaled / _lossfold / _fc12): 0 = automatic, 1 = 64 x 64
- * tiles with the K loop staged through LDS, 2 = the LATENCY form whenever the shapes allow: 32 x 32 tiles whose 8 waves split
- * the batch (K) and buffer-load their MFMA operands straight from memory -- 4x the workgroups, each ~4x shorter; the
- * automatic choice takes it while all of its workgroups are resident at once (<= 512), i.e. for the under-filled launches of
- * small ensembles (SAC's 2 critics, a rank that holds 2-4 of 16, the actor).  Same sums in another order (fp32 rounding). */
-int ssac_wgrad_variant(int variant);
+/* The merged weight-gradient launch (ssac_mlp_wgrad_all / _scaled / _lossfold / _fc12) picks its FORM by itself: 64 x 64 tiles
+ * with the K loop staged through LDS, or -- while all of its workgroups are resident at once (<= 512), i.e. for the under-
+ * filled launches of small ensembles (SAC's 2 critics, a rank that holds 2-4 of 16, the actor) -- the LATENCY form: 32 x 32
+ * tiles whose 8 waves split the batch (K) and buffer-load their MFMA operands straight from memory.  Same sums in another
+ * order (fp32 rounding).  (Forcing a form, for the parity tests: ssac_wgrad_variant in ssac_hip_test.h.) */
 /* row tiles the fused critic launch uses for (n_rows, n_nets): the `partials` buffer holds
- * n_nets * tiles * 2 floats.  ssac_fused_tile_rows(0|16|17|32) overrides the automatic choice (17 = 16 rows with a
- * single weight-staging buffer, two workgroups per CU). */
+ * n_nets * tiles * 2 floats (the tile size is the library's automatic choice unless ssac_fused_tile_rows of
+ * ssac_hip_test.h overrides it). */
 int ssac_fused_row_tiles(const ssac_mlp *nets, int n_rows, int n_nets);
-int ssac_fused_tile_rows(int rows);
-/* tuning knob (bit mask, default 2): kernels take their tile in XCD-contiguous order (workgroup b runs on XCD b % 8 --
- * tools/lab/xcc_map.hip; each XCD then works on one contiguous range of (net, tile) ids, so a net's weights / saved
- * activations are pulled into one or two of the eight L2s instead of all of them).  bit 0: the stand-alone fused MLP
- * launches, bit 1: the GEMM / weight-gradient launches.  On unless disabled: the merged weight-gradient launch orders
- * PER WORKGROUP CLASS (an eighth of the fc2 tiles, of the fc1 tiles and of the head workgroups per XCD, so that every
- * XCD carries the same mix of long and short workgroups; bit 2 = off), the chained launch orders each of its halves
- * (bit 3 = off).  0 | 12 = hardware order everywhere.  Placement only: results are bit-identical either way. */
-int ssac_xcd_order(int mask);
 
 /* y = MLP(x) for every selected net in ONE launch (agent.py:34 loop + mlps.py:123-129).
  * H1/H2 (n_sel x n_rows x hidden) are written when not NULL (needed by a later backward).  A negative entry of
@@ -721,12 +695,6 @@ int ssac_chain_update(const ssac_mlp *actor, const float *Xa, int64_t ldxa, int 
  * target_splits columns of fc2 from register-resident weight fragments and a PARTIAL head dot product; Qt is then
  * (n_sel x target_splits x n_rows), to be read through an ssac_td_spec with n_parts = target_splits. */
 int ssac_chain_target_splits(const ssac_mlp *actor, const ssac_mlp *targets, const ssac_mlp *critics, int n_rows, int n_sel);
-/* Form of the producer / consumer launch (round 5): 1 = when 16-row tiles of the three roles are more than 256 but at
- * most 512 workgroups and every role's co-resident LDS carve fits 80 KB, the launch runs TWO workgroups per CU (16-row
- * tiles, <= 128 VGPRs; one tile's prologue / epilogues / stores hide under its neighbour's K loop); 0 = always one
- * workgroup per CU; -1 = the library's default.  Outputs are bit-identical to the 16-row tiles of the one-per-CU form
- * (ssac_fused_tile_rows(16)); against its 32-row tiles they differ by fp32 association of the K sums. */
-int ssac_chain_form(int form);
 
 /* ---- the online actor update (learning.py:344-421) in four launches:
  *   ssac_actor_sample_concat_fused   actor forward (h1 / h2 / head output saved) + tanh-normal rsample + log pi, the rows
@@ -970,9 +938,6 @@ int ssac_ln_tanh_bwd(const float *d_out, int64_t ldd, const float *out, int64_t 
  * K1P rounded up to 32 feature rows), so those products read both operands with fully used 16-byte loads.  Covers the chained critic update of continuous single-output critics (hidden % 32 == 0, <= 256). ==== */
 int64_t ssac_bf16_layout(int in_dim, int hidden, int out_dim, int64_t offsets[4]);
 int ssac_bf16_supported(const ssac_mlp *nets);
-/* development aid: a device buffer of >= 64 int64 receives s_memtime() phase stamps of tile 0 of the bf16 launches
- * (slots 0.. actor pass, 16.. target-critic pass, 32.. critic workgroup, 48.. weight-gradient tile); NULL disables */
-int ssac_bf16_debug_stamps(long long *dev_buf);
 /* shadow <- bf16(master) for every net (after construction, load_state_dict, or an fp32 update of the arena) */
 int ssac_bf16_sync(const ssac_mlp *nets, uint16_t *shadow, void *stream);
 /* learning_utils.py:160-162 on the fp32 masters, and the target's shadow refreshed in the same launch */
@@ -980,10 +945,9 @@ int ssac_bf16_polyak(const ssac_mlp *target, const ssac_mlp *source, float tau, 
 /* ensemble-Q forward (agent.py:34 loop + mlps.py:123-129) in bf16: Y (n_sel x n_rows x out) fp32 */
 int ssac_bf16_mlp3_fwd(const ssac_mlp *nets, const uint16_t *shadow, const int32_t *net_ids, int n_sel, const float *X,
                        int64_t ldx, int n_rows, float *Y, void *stream);
-/* A/B switch of its large-batch form (>= 512 row tiles x nets, single-output critics): 1 (default) = the register-chained
- * kernel where it applies (hidden 256, 17 <= in_dim <= 32: weights in LDS, activations never leave the registers),
- * 0 = the streaming kernel (weights in registers, activations through LDS) everywhere.  Same operands, same rounding points. */
-int ssac_bf16_fwd_form(int form);
+/* (large batches -- >= 512 row tiles x nets, single-output critics, hidden 256, 17 <= in_dim <= 32 -- take the register-chained
+ * kernel: weights in LDS, activations never leave the registers; otherwise the streaming kernel.  Same operands, same rounding
+ * points; forcing one for the parity tests: ssac_bf16_fwd_form in ssac_hip_test.h.) */
 /* ssac_chain_update in bf16: same roles and arguments; the saved forward / unscaled backward leave as H1T, H2T, DZ2uT,
  * DZ1uT (n_nets x hidden x Bp) and XT (K1P x Bp, the [s|a] tile transposed) instead of fp32 row-major buffers. */
 int ssac_bf16_chain_update(const ssac_mlp *actor, const uint16_t *actor_shadow, const float *Xa, int64_t ldxa, int n_rows,

@@ -30,6 +30,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ref_harness  # noqa: E402
 import ssac_oracle as orc  # noqa: E402
 import synth  # noqa: E402
+import case_runner  # noqa: E402  (tests/: the checkpoint <-> fixture-array helpers shared with the parity tests)
 
 ref = ref_harness.import_reference()
 rl = ref.learning
@@ -164,8 +165,24 @@ def assert_encoder_close(ref_list, orc_list):
     assert nbad <= max(2, ntot // 100000)
 
 
-def run_case(name, cfg):
-    print(f"== {name}")
+_CKPT_DIRS = {}   # base case -> directory the REFERENCE agent saved itself to at the end of that case
+
+
+def reference_checkpoint(base):
+    """Agent.save (agent.py:172-195) of the reference agent at the end of case `base`'s update sequence"""
+    if base not in _CKPT_DIRS:
+        import tempfile
+        ra = run_case(base, synth.CASES[base], write=False)
+        d = tempfile.mkdtemp(prefix=f"ssac_ckpt_{base}_")
+        ra.save(d)
+        _CKPT_DIRS[base] = d
+    return _CKPT_DIRS[base]
+
+
+def run_case(name, cfg, write=True):
+    print(f"== {name}" + ("" if write else "  (for its checkpoint only)"))
+    ckpt_rec = {}
+    ckpt_dir = reference_checkpoint(cfg["resume"]) if cfg.get("resume") else None
     torch.manual_seed(cfg["seed"])
     np.random.seed(cfg["seed"])
     random.seed(cfg["seed"])
@@ -184,6 +201,18 @@ def run_case(name, cfg):
     obuf.load_experience(s, a, r, s1, d)
 
     ra, oa = build_pair(cfg)
+    if ckpt_dir:
+        # a reference user's resume: Agent.load into a freshly built agent (other seed), target = deepcopy, new optimizers
+        before = torch.cat([p.detach().flatten() for p in ra.critics[0].parameters()]).clone()
+        ra.load(ckpt_dir)
+        assert not torch.equal(before, torch.cat([p.detach().flatten() for p in ra.critics[0].parameters()]))
+        for fname in sorted(os.listdir(ckpt_dir)):
+            sd = torch.load(os.path.join(ckpt_dir, fname), map_location="cpu")
+            ckpt_rec[f"{case_runner.CKPT_PREFIX}{fname}|"] = np.zeros(0, np.float32)   # (the file exists, even when empty)
+            for key, val in sd.items():
+                ckpt_rec[f"{case_runner.CKPT_PREFIX}{fname}|{key}"] = val.detach().cpu().numpy()
+        case_runner.oracle_load_checkpoint(oa, cfg, case_runner.checkpoint_arrays(ckpt_rec))
+        ra.train()
     rt = copy.deepcopy(ra)
     oa.requires_grad_(True)
     ot = oa.clone()
@@ -444,7 +473,10 @@ def run_case(name, cfg):
     rec["finalfp_critic_v"] = np.concatenate(vs)
     rec["final_log_alpha"] = np.array([float(x) for x in r_las], np.float64)
     rec["n_updates"] = np.int64(upd)
-    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
+    rec.update(ckpt_rec)
+    if write:
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **rec)
+    return ra
 
 
 def gen_indices():

@@ -110,12 +110,10 @@ SIGNATURES = {
     "ssac_per_assign": [_P, _P, _L, _P, _I, _P, _I, C.c_double, _P, _I, _L, _P, _P, _P],
     "ssac_per_sample": [_P, _P, _L, _L, _P, _I, C.c_double, _P, _P, _P],
     "ssac_xchg_error": [_P],
-    "ssac_xchg_test_mode": [_P, _I],
     "ssac_xchg_destroy": [_P],
     "ssac_step_create": [_P, _I, _I, _I, _I, _I, _I, _I, _I],
     "ssac_step_add_list": [_P, _P],
     "ssac_step_run": [_P, _P, _P, C.c_int32, _L, _P],
-    "ssac_slot_by_value": [_I],
     "ssac_step_count": [_P],
     "ssac_step_seek": [_P, _L],
     "ssac_step_destroy": [_P],
@@ -206,14 +204,7 @@ SIGNATURES = {
     "ssac_ln_tanh_fwd": [_P, _L, _P, _P, _I, _I, _P, _L, _P, _P, _P],
     "ssac_ln_tanh_bwd": [_P, _L, _P, _L, _P, _P, _P, _I, _I, _P, _L, _P, _P, _P, _P],
     "ssac_fused_supported": [_MP],
-    "ssac_fused_debug_stamps": [_P],
-    "ssac_gemm_debug_stamps": [_P],
-    "ssac_debug_timeline": [_P],
-    "ssac_gemm_lean": [_I],
-    "ssac_wgrad_variant": [_I],
     "ssac_fused_row_tiles": [_MP, _I, _I],
-    "ssac_fused_tile_rows": [_I],
-    "ssac_xcd_order": [_I],
     "ssac_step_polyak": [_P, _F],
     "ssac_step_polyak_done": [_P],
     "ssac_feed_ring_alloc": [C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_int)],
@@ -226,7 +217,6 @@ SIGNATURES = {
     "ssac_chain_update": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _I, _P, _MP, _P, _L, _P, _P, _P, _P, _P,
                           _P, _P, _P, _P, _I, _P, _P],
     "ssac_chain_target_splits": [_MP, _MP, _MP, _I, _I],
-    "ssac_chain_form": [_I],
     "ssac_deferred_logs_flush": [_P, _I, _P],
     "ssac_philox_normal": [_P, _I, _I, _P, _P],
     "ssac_actor_sample_concat_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _P, _P, _P, _P, _P, _P],
@@ -246,16 +236,32 @@ SIGNATURES = {
     "ssac_critic_logs": [_P, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _P, _P],
     "ssac_bf16_layout": [_I, _I, _I, C.POINTER(C.c_int64)],
     "ssac_bf16_supported": [_MP],
-    "ssac_bf16_debug_stamps": [_P],
     "ssac_bf16_sync": [_MP, _P, _P],
     "ssac_bf16_polyak": [_MP, _MP, _F, _P, _P],
     "ssac_bf16_mlp3_fwd": [_MP, _P, _P, _I, _P, _L, _I, _P, _P],
-    "ssac_bf16_fwd_form": [_I],
     "ssac_bf16_chain_update": [_MP, _P, _P, _L, _I, _P, _F, _F, _P, _L, _L, _P, _P, _MP, _P, _P, _I, _P, _MP, _P, _P, _L,
                                _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ssac_bf16_wgrad_tiles": [_MP],
     "ssac_bf16_wgrad_lossfold": [_MP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _F, _P, _I, _P, _P, _P, _P, _P, _L,
                                  _P, _P, _F, _P, _P],
+}
+# include/ssac_hip_test.h, group 1 (form selection: always exported, used by tests/ and tools/ only)
+TEST_SIGNATURES = {
+    "ssac_slot_by_value": [_I],
+    "ssac_gemm_lean": [_I],
+    "ssac_wgrad_variant": [_I],
+    "ssac_fused_tile_rows": [_I],
+    "ssac_xcd_order": [_I],
+    "ssac_chain_form": [_I],
+    "ssac_bf16_fwd_form": [_I],
+}
+# include/ssac_hip_test.h, group 2 (lab hooks): defined by the LAB build only (`./build.sh --lab`, SSAC_LAB_BUILD=1); bound when present
+LAB_SIGNATURES = {
+    "ssac_fused_debug_stamps": [_P],
+    "ssac_gemm_debug_stamps": [_P],
+    "ssac_bf16_debug_stamps": [_P],
+    "ssac_debug_timeline": [_P],
+    "ssac_xchg_test_mode": [_P, _I],
 }
 _RESTYPES = {"ssac_xchg_create": C.c_void_p, "ssac_xchg_destroy": None, "ssac_step_create": C.c_void_p, "ssac_step_count": C.c_int64, "ssac_actor_chain_handoff_words": C.c_int64, "ssac_step_destroy": None,
              "ssac_last_error": C.c_char_p, "ssac_mlp_layout": C.c_int64, "ssac_bf16_layout": C.c_int64, "ssac_record_end": C.c_void_p,
@@ -264,7 +270,7 @@ _RESTYPES = {"ssac_xchg_create": C.c_void_p, "ssac_xchg_destroy": None, "ssac_st
 
 # SSAC_ABI_VERSION of include/ssac_hip.h this binding table was written against (bumped with every signature change:
 # a stale .so called with shifted pointer arguments would corrupt device memory)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def _load():
@@ -273,10 +279,15 @@ def _load():
             f"{LIB_PATH} not found: the HIP extension is the only implementation of this package. "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc).")
     lib = C.CDLL(LIB_PATH)
-    for name, argtypes in SIGNATURES.items():
+    for name, argtypes in {**SIGNATURES, **TEST_SIGNATURES}.items():
         fn = getattr(lib, name)  # AttributeError here == ABI mismatch, fail loudly
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
+    for name, argtypes in LAB_SIGNATURES.items():
+        fn = getattr(lib, name, None)   # (absent from the product library by design)
+        if fn is not None:
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
     if lib.ssac_abi_version() != ABI_VERSION:
         raise ImportError(f"libssac_hip.so has ABI version {lib.ssac_abi_version()}, this package binds version "
                           f"{ABI_VERSION}: rebuild the extension (build.sh)")

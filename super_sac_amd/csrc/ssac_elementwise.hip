@@ -1648,14 +1648,12 @@ extern "C" int ssac_feed_write(void *ring_slot, const void *src, size_t bytes) {
 int g_ssac_xcd = 2;
 extern "C" int ssac_xcd_order(int mask) { g_ssac_xcd = mask & 15; return 0; }
 long long *g_ssac_timeline = nullptr;   // [2048]: (start, end) per workgroup of the chained launch, then (from 1024) of the merged weight-gradient launch
+#ifdef SSAC_LAB   // (ssac_hip_test.h, lab hooks: the product library does not define the symbol)
 extern "C" int ssac_debug_timeline(long long *dev_buf) {
-#ifdef SSAC_LAB
     g_ssac_timeline = dev_buf;
     return 0;
-#else
-    return dev_buf ? ssac_fail("ssac_debug_timeline: " SSAC_LAB_REFUSAL) : 0;
-#endif
 }
+#endif
 
 // ssac_slot_by_value(0): ssac_step_run replays without the slot pointer (the kernels go through the feed block) -- the A/B
 // switch of tests/test_hip_cases.py::test_graph_replay_equals_eager_launches and tools/one_config.py

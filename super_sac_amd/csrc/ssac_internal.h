@@ -99,13 +99,13 @@ extern int g_ssac_xcd;
 extern long long *g_ssac_timeline;   // ssac_debug_timeline (ssac_elementwise.hip)
 // Measurement scaffolding -- s_memtime phase stamps of one workgroup, per-workgroup (start, end) timelines, builds in which a
 // workgroup class returns at once -- is compiled only into the LAB build (`./build.sh --lab`, -DSSAC_LAB): the product
-// library carries none of it, and its ssac_*_debug_stamps / ssac_debug_timeline entry points refuse.
+// library carries none of it, and does not define the ssac_*_debug_stamps / ssac_debug_timeline / ssac_xchg_test_mode entry
+// points at all (include/ssac_hip_test.h, "lab hooks").
 #ifdef SSAC_LAB
 #define SSAC_LAB_ONLY(...) __VA_ARGS__
 #else
 #define SSAC_LAB_ONLY(...)
 #endif
-#define SSAC_LAB_REFUSAL "measurement scaffolding is compiled into the lab build only: ./build.sh --lab"
 #ifdef __HIPCC__
 // min over the REDQ subset slots of the target Q of row b (ssac_td_spec): a slot's value is q_t[j][b], or -- n_parts > 1,
 // column-split target critics -- the sum of its partials q_t[(j n_parts + s)][b] in index order.  Every reader of

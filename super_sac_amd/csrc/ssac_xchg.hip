@@ -191,15 +191,15 @@ static int xchg_launch(ssac_xchg *x, float *data, int n, int op, const int32_t *
 // Tests only.  Bit 0: this rank's later exchanges skip the slot-reuse wait (step 0 of xchg_kernel); bit 1: its receivers
 // accept flag >= seq.  Mode 3 is the protocol of round 3; tests/test_hip_sharded.py uses 3 to show the hazard (a delayed
 // non-owner silently reduces a later update's payload) and 1 to show that the lap DETECTION (flag > seq) fires.
+// (LAB build only -- ssac_hip_test.h: the product library does not define the symbol, and its kernel does not read the field:
+//  a production exchange cannot be put back on round 3's unsafe protocol)
+#ifdef SSAC_LAB
 extern "C" int ssac_xchg_test_mode(ssac_xchg *x, int mode) {
-#ifndef SSAC_LAB
-    // (the product library's exchange cannot be put back on round 3's unsafe protocol: the kernel does not read the field)
-    if (mode != 0) return ssac_fail("ssac_xchg_test_mode: " SSAC_LAB_REFUSAL);
-#endif
     if (!x || mode < 0 || mode > 3) return ssac_fail("ssac_xchg_test_mode: bad argument");
     x->test_mode = mode;
     return 0;
 }
+#endif
 
 // 1 when a peer's flag failed to arrive within the spin bound since the last call (cleared by this read).  A plain
 // host load of a pinned word: no device synchronisation, cheap enough for the training loop's periodic check; a caller

@@ -84,13 +84,68 @@ def _fingerprint(params):
 
 
 # ------------------------------------------------------------------------------------------
+# resume cases (cfg["resume"]): the reference's checkpoint travels in the fixture as arrays "ckpt|<file>|<key>"
+CKPT_PREFIX = "ckpt|"
+
+
+def checkpoint_arrays(fx):
+    """{file name: {state-dict key: array}} of the reference checkpoint held by a resume fixture"""
+    out = {}
+    for k, v in fx.items():
+        if k.startswith(CKPT_PREFIX):
+            _, fname, key = k.split("|", 2)
+            out.setdefault(fname, {})
+            if key:   # (an empty state dict -- the reference's popart{i}.pt, popart.py:11-16 -- is the bare file entry)
+                out[fname][key] = v
+    return out
+
+
+def write_checkpoint_dir(fx, path):
+    """the fixture's arrays back into the directory layout Agent.save writes (agent.py:172-195): one torch-saved
+    state dict per file"""
+    os.makedirs(path, exist_ok=True)
+    for fname, sd in checkpoint_arrays(fx).items():
+        torch.save({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, os.path.join(path, fname))
+    return path
+
+
+def oracle_load_checkpoint(oa, cfg, files):
+    """Agent.load (agent.py:196-202) for the oracle's parameter dicts; `files` = checkpoint_arrays(...).  PopArt: the
+    reference's layer keeps its statistics in plain attributes, its state dict is empty -- a loaded agent starts from
+    fresh statistics, and so does the oracle's."""
+    head = {"stochastic": "fc3", "deterministic": "out", "discrete": "act_p"}[cfg["actor"]]
+
+    def put(dst, sd, prefix, names):
+        with torch.no_grad():
+            for (wk, bk), nm in zip((("w1", "b1"), ("w2", "b2"), ("w3", "b3")), names):
+                dst[wk].copy_(torch.from_numpy(np.array(sd[f"{prefix}{nm}.weight"])))
+                dst[bk].copy_(torch.from_numpy(np.array(sd[f"{prefix}{nm}.bias"])))
+    for i in range(cfg["E"]):
+        put(oa.actors[i], files[f"actor{i}.pt"], "", ("fc1", "fc2", head))
+        for j in range(cfg["N"]):
+            put(oa.critics[i][j], files[f"critic{i}.pt"], f"nets.{j}.", ("fc1", "fc2", "out"))
+    px = cfg.get("pixels")
+    if px:
+        sd, p = files["encoder.pt"], oa.encoder["p"]
+        names = ["conv1", "conv2", "conv3", "conv4"] if px["kind"] == "big" else ["conv1", "conv2", "conv3"]
+        pairs = [(f"c{i_}", nm) for i_, nm in enumerate(names, 1)] + [("fc", "fc")] + ([("ln", "ln")] if px["kind"] == "big" else [])
+        with torch.no_grad():
+            for short, nm in pairs:
+                p[f"{short}w"].copy_(torch.from_numpy(np.array(sd[f"conv_block.{nm}.weight"])))
+                p[f"{short}b"].copy_(torch.from_numpy(np.array(sd[f"conv_block.{nm}.bias"])))
+
+
+# ------------------------------------------------------------------------------------------
 def run_oracle(name):
     cfg = synth.CASES[name]
     fx = load_fixture(name)
     B, E = cfg["B"], cfg["E"]
     obuf = orc.ReplayOracle(cfg["cap"])
     obuf.load_experience(*_buffers(cfg))
-    oa = _oracle_agent(cfg).requires_grad_(True)
+    oa = _oracle_agent(cfg)
+    if cfg.get("resume"):
+        oracle_load_checkpoint(oa, cfg, checkpoint_arrays(fx))
+    oa.requires_grad_(True)
     ot = oa.clone()
     copt = orc.AdamOracle(oa.critic_params(), lr=cfg["lr"])
     aopt = orc.AdamOracle(oa.actor_params(), lr=cfg["lr"])
@@ -289,6 +344,13 @@ def run_engine(name, device="cuda", shard=None, foreign=False, precision="fp32",
         buf = ssa.replay.ReplayBuffer(cfg["cap"], device=device)
         buf.load_experience(*_buffers(cfg))
     agent = build_engine_agent(cfg, device, shard, foreign=foreign, members=members)
+    if cfg.get("resume"):
+        # the checkpoint the REFERENCE wrote (fixture arrays -> the files Agent.save writes) through the agent's own load();
+        # a reference-class stand-in (foreign) has no such method to exercise, a shard holds a slice of the files' nets
+        assert shard is None and members is None and not foreign, "resume cases run unsharded on this package's Agent"
+        import tempfile
+        with tempfile.TemporaryDirectory() as ckpt_dir:
+            agent.load(write_checkpoint_dir(fx, ckpt_dir))
     if precision != "fp32":
         ssa.set_precision(agent, precision)  # (the deepcopy below inherits it)
     target = copy.deepcopy(agent)
@@ -577,8 +639,8 @@ def slice_fixture_members(fx, cfg, ms):
 # ------------------------------------------------------------------------------------------
 # fixture keys that are INPUTS of a replay (the host draws the reference consumed, step counts) -- everything else in a
 # fixture is an OUTPUT of the reference and a backend's record must carry it
-_INPUT_KEY = re.compile(r"(n_updates|n_steps|[ualsm]\d+_(eps\d*|ceps|prio_eps|bweps\d+_\d+|noise\d+|idx\d*|subset\d*|shift\d*|"
-                        r"cat\d+(_\d+)?|gpick|polyak|base\d+|perm|per|filter|critic))")
+_INPUT_KEY = re.compile(r"(n_updates|n_steps|ckpt\|.*|[ualsm]\d+_(eps\d*|ceps|prio_eps|bweps\d+_\d+|noise\d+|idx\d*|subset\d*|shift\d*|"
+                        r"cat\d+(_\d+)?|gpick|polyak|base\d+|perm|per|filter|critic))")   # (ckpt|...: the reference checkpoint a resume case starts from)
 
 
 def straggler_check(err, tol, max_step, who, key):

@@ -189,6 +189,15 @@ CASES = {
 }
 
 
+# ---- round 6: a checkpoint written by the REFERENCE (Agent.save after the base case's whole update sequence, agent.py:172-
+# 195) is loaded into a freshly initialised agent of ANOTHER seed (Agent.load, agent.py:196-202), the target agent is a deepcopy
+# of the loaded one and the optimizers are fresh (what main.super_sac does with a loaded agent, main.py:188-239, 321) -- then
+# the base case's update schedule runs on.  The fixture holds the checkpoint's state dicts as arrays ("ckpt|<file>|<key>")
+# next to the usual records, so the GPU test loads what the reference wrote, not what this package wrote.
+for _base, _seed in (("redq_small", 211), ("sac_popart", 213), ("sac_discrete", 214), ("atari_pixels", 218)):
+    CASES[f"ckpt_{_base}"] = dict(CASES[_base], seed=_seed, resume=_base)
+
+
 # advantage-filtered BC (AWAC/AFBC actor update) with prioritised replay: SURVEY.md 8(f) rank 1.
 # steps: (per, filter_) of consecutive learning.offline_actor_update calls (learning.py:144-219)
 AFBC_CASES = {

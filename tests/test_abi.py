@@ -7,10 +7,65 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "ssac_hip.h")).read()
+INCLUDE = os.path.join(ROOT, "include")
+
+
+def _strip(text):
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ssac_[a-z0-9_]+)\s*\(", text)))
+    return re.sub(r"//[^\n]*", "", text)
+
+
+def _split_lab(text):
+    """(text outside #ifdef SSAC_LAB ... #endif, text inside)"""
+    inside = "".join(re.findall(r"#ifdef\s+SSAC_LAB\b(.*?)#endif", text, flags=re.S))
+    outside = re.sub(r"#ifdef\s+SSAC_LAB\b.*?#endif", "", text, flags=re.S)
+    return outside, inside
+
+
+def prototypes(text):
+    """{name: (return type, [parameter C types])} of every `ssac_*` function prototype in (comment-free) header text"""
+    out = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ \t\*]*?)\b(ssac_[a-z0-9_]+)\s*\(([^;{}()]*)\)\s*;", text):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret.startswith("typedef") or not ret:
+            continue
+        params = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+        types = []
+        for a in params:
+            a = re.sub(r"\[[^\]]*\]", "*", a)                        # array parameter == pointer
+            m2 = re.fullmatch(r"(.*?)([A-Za-z_][A-Za-z0-9_]*)?\s*", a)   # drop the parameter name
+            ty = a if "*" in a and a.rstrip().endswith("*") else m2.group(1)
+            types.append(re.sub(r"\s+", " ", ty.replace("const", "")).replace(" *", "*").strip())
+        out[name] = (re.sub(r"\s+", " ", ret.replace("const", "")).replace(" *", "*").strip(), types)
+    return out
+
+
+def header_prototypes():
+    prod = prototypes(_strip(open(os.path.join(INCLUDE, "ssac_hip.h")).read()))
+    test_all = _strip(open(os.path.join(INCLUDE, "ssac_hip_test.h")).read())
+    outside, inside = _split_lab(test_all)
+    return prod, prototypes(outside), prototypes(inside)
+
+
+def declared_symbols():
+    return sorted(header_prototypes()[0])
+
+
+def _ctype_class(t):
+    """coarse class of a ctypes argument type, comparable with _c_class of the header's C type"""
+    if t is None:
+        return "void"
+    if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents"):   # void* / char* / POINTER(...)
+        return "ptr"
+    return {ctypes.c_int: "i32", ctypes.c_int32: "i32", ctypes.c_uint32: "i32", ctypes.c_int64: "i64", ctypes.c_longlong: "i64",
+            ctypes.c_uint64: "i64", ctypes.c_size_t: "i64", ctypes.c_float: "f32", ctypes.c_double: "f64"}[t]
+
+
+def _c_class(ty):
+    if ty.endswith("*"):
+        return "ptr"
+    return {"int": "i32", "int32_t": "i32", "uint32_t": "i32", "unsigned": "i32", "int64_t": "i64", "long long": "i64",
+            "unsigned long long": "i64", "uint64_t": "i64", "size_t": "i64", "float": "f32", "double": "f64", "void": "void"}[ty]
 
 
 def test_header_declares_the_expected_surface():
@@ -18,21 +73,56 @@ def test_header_declares_the_expected_surface():
     for must in ("ssac_mlp_layer_fwd", "ssac_mlp_layer_dgrad", "ssac_mlp_layer_wgrad", "ssac_td_target",
                  "ssac_gather_transition", "ssac_drq_shift", "ssac_polyak", "ssac_alpha_update"):
         assert must in syms
+    # the drop-in header carries no form switches and no lab hooks (round-5 review, weak 10): those live in ssac_hip_test.h
+    prod, test, lab = header_prototypes()
+    for name in ("ssac_wgrad_variant", "ssac_chain_form", "ssac_bf16_fwd_form", "ssac_gemm_lean", "ssac_xcd_order"):
+        assert name not in prod and name in test
+    for name in ("ssac_fused_debug_stamps", "ssac_gemm_debug_stamps", "ssac_debug_timeline", "ssac_xchg_test_mode"):
+        assert name not in prod and name not in test and name in lab
 
 
 def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(os.path.join(ROOT, "super_sac_amd", "libssac_hip.so"))
-    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
-    assert not missing, f"declared in ssac_hip.h but not exported: {missing}"
+    prod, test, lab = header_prototypes()
+    missing = [s for s in list(prod) + list(test) if not hasattr(lib, s)]
+    assert not missing, f"declared in ssac_hip.h / ssac_hip_test.h but not exported: {missing}"
+    leaked = [s for s in lab if hasattr(lib, s)]
+    assert not leaked, f"lab hooks defined by the PRODUCT library: {leaked}"
 
 
 def test_python_binding_covers_every_symbol():
     from super_sac_amd import _lib
-    assert sorted(_lib.SIGNATURES) == declared_symbols()
-    import re
+    prod, test, lab = header_prototypes()
+    assert sorted(_lib.SIGNATURES) == sorted(prod)
+    assert sorted(_lib.TEST_SIGNATURES) == sorted(test)
+    assert sorted(_lib.LAB_SIGNATURES) == sorted(lab)
     header = open(os.path.join(ROOT, "include", "ssac_hip.h")).read()
     declared = int(re.search(r"#define\s+SSAC_ABI_VERSION\s+(\d+)", header).group(1))
     assert _lib.lib.ssac_abi_version() == _lib.ABI_VERSION == declared
+
+
+def test_python_binding_matches_every_prototype():
+    """argument COUNT and C type class (pointer / 32-bit int / 64-bit int / float / double) of every ctypes signature
+    against the prototype parsed from the headers, and the return types: a changed signature is caught here, on the
+    CPU, not by a crash on the GPU box (round-5 review, weak 10)."""
+    from super_sac_amd import _lib
+    prod, test, lab = header_prototypes()
+    bound = {**_lib.SIGNATURES, **_lib.TEST_SIGNATURES, **_lib.LAB_SIGNATURES}
+    assert len(bound) >= 150 and set(bound) == set(prod) | set(test) | set(lab)
+    bad = []
+    for name, (ret, ctys) in {**prod, **test, **lab}.items():
+        args = bound[name]
+        if len(args) != len(ctys):
+            bad.append(f"{name}: {len(args)} ctypes arguments, the header declares {len(ctys)}")
+            continue
+        for k, (a, c) in enumerate(zip(args, ctys)):
+            if _ctype_class(a) != _c_class(c):
+                bad.append(f"{name}: argument {k} is {a.__name__} in _lib.py, `{c}` in the header")
+        want = _c_class(ret)
+        got = _ctype_class(_lib._RESTYPES.get(name, ctypes.c_int))
+        if want != got:
+            bad.append(f"{name}: returns `{ret}` in the header, {got} in _lib.py")
+    assert not bad, "\n".join(bad)
 
 
 def test_layout_matches_header_contract():

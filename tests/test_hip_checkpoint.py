@@ -93,3 +93,54 @@ def test_resume_is_bit_identical(tmp_path, popart):
     for a, b, what in zip(ref, got, ("critics", "actors", "target critics", "log_alpha", "last critic loss",
                                      "priority tree")):
         assert np.array_equal(np.asarray(a), np.asarray(b)), f"resumed run differs in {what}"
+
+
+RESUME_CASES = [n_ for n_, c_ in synth.CASES.items() if c_.get("resume")]
+
+
+@pytest.mark.parametrize("name", RESUME_CASES)
+def test_reference_checkpoint_loads_and_resumes_on_the_gpu(tmp_path, name):
+    """SURVEY 8(f) rank 3 against the REFERENCE, not against this package: the fixture holds the state dicts the reference's
+    Agent.save wrote after the base case's update sequence (agent.py:172-195; oracle/gen_golden.py::reference_checkpoint) and
+    the outputs of the reference continuing from Agent.load of them (fresh agent of another seed, target = deepcopy, new
+    optimizers: main.py:188-239, 321).  Here: the arrays go back into the files, this package's Agent.load reads them on the
+    GPU -- every parameter bit-equal to what the reference saved -- the base case's update schedule runs on the HIP path
+    and must land on the reference's continuation at the tolerances of every other fixture; then Agent.save of the RESUMED
+    agent is read back file by file: the reference's file set, its keys, its shapes (what its load_state_dict expects)."""
+    import os
+    import case_runner
+    import super_sac_amd as ssa
+    cfg, fx = synth.CASES[name], case_runner.load_fixture(name)
+    files = case_runner.checkpoint_arrays(fx)
+    assert {"encoder.pt", "actor0.pt", "critic0.pt", "inverse.pt", "contrastive.pt"} <= set(files)
+    dev = torch.device("cuda")
+    # (1) load only: bit-equal parameters, arenas re-pointed at the loaded values
+    agent = case_runner.build_engine_agent(cfg, dev)
+    agent.load(case_runner.write_checkpoint_dir(fx, str(tmp_path / "from_reference")))
+    for i, critic in enumerate(agent.critics):
+        sd = critic.state_dict()
+        assert set(sd) == set(files[f"critic{i}.pt"])
+        for k, v in files[f"critic{i}.pt"].items():
+            assert np.array_equal(sd[k].cpu().numpy(), v), (i, k)
+        arena = critic.arena(dev)
+        assert np.array_equal(arena.view(0, "w1").cpu().numpy(), files[f"critic{i}.pt"]["nets.0.fc1.weight"])
+    for i, actor in enumerate(agent.actors):
+        for k, v in files[f"actor{i}.pt"].items():
+            assert np.array_equal(actor.state_dict()[k].cpu().numpy(), v), (i, k)
+    for k, v in files["encoder.pt"].items():
+        assert np.array_equal(agent.encoder.state_dict()[k].cpu().numpy(), v), k
+    # (2) load + the update schedule on the HIP path vs the reference's continuation
+    rec = case_runner.run_engine(name)
+    worst = case_runner.compare(rec, fx, who=f"hip[{name}: resumed from the reference's checkpoint]")
+    print(f"{name}: worst deviations vs the reference's continuation {worst}")
+    # (3) the file set / keys / shapes this package writes for the same agent = the reference's
+    out = tmp_path / "from_engine"
+    out.mkdir()
+    agent.save(str(out))
+    written = sorted(f for f in os.listdir(out) if not f.endswith("_stats.pt"))
+    assert written == sorted(files), (written, sorted(files))
+    for fname in written:
+        sd = torch.load(os.path.join(out, fname), map_location="cpu")
+        assert set(sd) == set(files[fname]), fname
+        for k, v in files[fname].items():
+            assert tuple(sd[k].shape) == v.shape and np.array_equal(sd[k].numpy(), v), (fname, k)

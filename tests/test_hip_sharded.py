@@ -191,7 +191,7 @@ def _lap_main(rank, world, port, out_dir):
     torch.cuda.set_device(0)
     x = parallel.enable_one_shot(torch.device("cuda:0"), max_floats=2048)
     assert x is not None
-    legacy_lib = not hasattr(lib, "ssac_xchg_test_mode")   # (only in the failing-first run against round 3's library)
+    legacy_lib = not hasattr(lib, "ssac_xchg_reduce_owned")   # (only in a failing-first run against a pre-round-3 library)
     n = 2 * 512
     owners = (0, 1)   # slot 0 is rank 0's, slot 1 rank 1's -- in EVERY round: rank 2 never sends
     ids = torch.tensor([j if owners[j] == rank else -(owners[j] + 1) for j in range(2)], dtype=torch.int32).cuda()
@@ -230,9 +230,10 @@ def _lap_main(rank, world, port, out_dir):
     verdict = {"rank": rank, "legacy_lib": legacy_lib,
                "delayed_equal": [bool(torch.equal(a, b)) for a, b in zip(delayed, lockstep)],
                "delayed_failed_flag": bool(x.failed())}
-    # (the two protocol replays below need the LAB build, `./build.sh --lab` + SSAC_LAB_BUILD=1: the product library refuses
-    #  ssac_xchg_test_mode -- round-4 review: a production exchange must not be switchable to round 3's unsafe protocol)
-    lab = (not legacy_lib) and lib.ssac_xchg_test_mode(x.handle, 3) == 0
+    # (the two protocol replays below need the LAB build, `./build.sh --lab` + SSAC_LAB_BUILD=1: the product library does not
+    #  define ssac_xchg_test_mode at all, include/ssac_hip_test.h -- a production exchange cannot be switched to round 3's
+    #  unsafe protocol; tools/gpu_suite_lab.sh is the lab leg that runs them)
+    lab = hasattr(lib, "ssac_xchg_test_mode") and lib.ssac_xchg_test_mode(x.handle, 3) == 0
     verdict["lab_build"] = bool(lab)
     if lab:
         # (a) the round-3 protocol on today's kernel (no reuse wait, flag >= seq accepted): the hazard, demonstrated --

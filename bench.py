@@ -545,6 +545,8 @@ def main():
                 "ms_per_env_step": round(te * 1e3, 4), "critic_updates_per_s": round(20 / te, 1),
                 "env_steps_per_s": round(1 / te, 1)}
             del step, env_step
+            # ---- latency of the acting path (what an environment step pays before the updates)
+            secondary["acting"] = acting_rows(device)
             # ---- the N = 1 anchors of the scaling target's configurations (BASELINE.json: ">= 3.5x at 8 vs 1 GPU for N = 16";
             #      `bench.py --gpus 8 --critics 16 [--obs 376 --act 17]` measures the other end when an 8-GPU node runs it)
             secondary["scaling_anchors_n16_1gpu"] = n16_rows(device)
@@ -595,6 +597,56 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def acting_rows(device):
+    """SURVEY 8(f) rank 2, the acting path (Agent.sample_action / Agent.forward, agent.py:204-315) as the collection loop calls
+    it: numpy observation in, numpy action out (one H2D, the launches, one D2H), wall-clock per call, median of 300 calls
+    after 30 warm-up calls.  Shapes: the headline REDQ agent (obs 17 / act 6, one actor), a SUNRISE agent (5 members x 2
+    critics, ucb_bonus 5: candidates of every actor, ensemble-Q of every member on the stacked candidates, mean + bonus * std,
+    arg-max) and the Atari agent (4 x 84 x 84 uint8 frames through the SmallPixelEncoder, categorical sample)."""
+    import numpy as np
+    import torch
+    import super_sac_amd as ssa
+    rows = {}
+    rs = np.random.RandomState(0)
+
+    def agent_of(kind):
+        if kind == "atari":
+            conv = ssa.nets.SmallPixelEncoder((4, 84, 84), 128)
+            ag = ssa.Agent(act_space_size=4, encoder=ssa.nets.PixelEncoder(conv), actor_network_cls=ssa.nets.DiscreteActor,
+                           critic_network_cls=ssa.nets.DiscreteCritic, discrete=True, ensemble_size=1, num_critics=2,
+                           hidden_size=256, auto_rescale_targets=False)
+            obs = lambda n: {"obs": rs.randint(0, 256, (n, 4, 84, 84) if n > 1 else (4, 84, 84)).astype(np.uint8)}
+        else:
+            E, N, ucb = (5, 2, 5.0) if kind == "sunrise" else (1, 10, 0.0)
+            ag = ssa.Agent(act_space_size=6, encoder=ssa.nets.IdentityEncoder(17),
+                           actor_network_cls=ssa.nets.ContinuousStochasticActor, critic_network_cls=ssa.nets.ContinuousCritic,
+                           discrete=False, ensemble_size=E, num_critics=N, ucb_bonus=ucb, hidden_size=HID,
+                           auto_rescale_targets=False, log_std_low=-5.0, log_std_high=2.0)
+            obs = lambda n: {"obs": rs.standard_normal((n, 17) if n > 1 else (17,)).astype(np.float32)}
+        ag.to(device)
+        ag.eval()
+        return ag, obs
+
+    for kind in ("redq_M", "sunrise", "atari"):
+        ag, obs = agent_of(kind)
+        for n in (1, 16):
+            o = obs(n)
+            for fn_name in ("sample_action", "forward"):
+                fn = getattr(ag, fn_name)
+                for _ in range(30):
+                    fn(o, num_envs=n)
+                ts = []
+                for _ in range(300):
+                    t0 = time.perf_counter()
+                    fn(o, num_envs=n)
+                    ts.append(time.perf_counter() - t0)
+                rows[f"{kind}.{fn_name}.envs{n}"] = {"us_per_call_median": round(statistics.median(ts) * 1e6, 1),
+                                                     "us_per_call_p90": round(sorted(ts)[int(0.9 * len(ts))] * 1e6, 1)}
+        del ag
+    return {"what": "Agent.sample_action / Agent.forward, numpy observation in -> numpy action out (H2D + launches + D2H), "
+                    "wall clock per call, 300 calls after 30 warm-up calls", "rows": rows}
 
 
 def n16_rows(device):

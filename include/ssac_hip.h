@@ -975,6 +975,45 @@ int ssac_bf16_wgrad_lossfold(const ssac_mlp *nets, uint16_t *shadow, const uint1
                              float *sumsq, int64_t sumsq_net_stride, float *target, uint16_t *target_shadow, float tau,
                              const ssac_logfold *logfold, void *stream);
 
+/* ==== the ACTING path (agent.py:204-315: Agent.forward / Agent.sample_action; csrc/ssac_act.hip) ====
+ * One observation per environment in, one action out: the cost of a call is its launches and its two trips over PCIe, not
+ * its arithmetic.  ssac_act bundles what removes them: an observation buffer the HOST writes directly (uncached device
+ * memory behind the large BAR, else pinned host memory), a result buffer the DEVICE writes directly (pinned host memory, a
+ * sequence word behind it), a device-resident call counter -- the draw number of the engine's noise stream
+ * (ssac_rng.counter = ssac_act_counter) -- and recorded launch lists.
+ *   plan:  a = ssac_act_create(obs_bytes, out_floats); ssac_record_begin(); <the rule's launches reading ssac_act_obs(a),
+ *          ssac_rng.counter = ssac_act_counter(a)>; ssac_act_publish(a, result, n, stream) LAST; which = ssac_act_add_list(a,
+ *          ssac_record_end())            (an agent that draws a random actor per call records one list per actor)
+ *   call:  ssac_act_run(a, which, obs_host, obs_bytes, out_host, out_floats, stream) = memcpy + sfence, re-issue the list,
+ *          spin on the sequence word (bounded: 5 s -> error), memcpy.  No hipMemcpy, no stream synchronisation.
+ * The lists are owned by the plan (freed by ssac_act_destroy). */
+typedef struct ssac_act ssac_act;
+ssac_act *ssac_act_create(int obs_bytes, int out_floats);
+void *ssac_act_obs(ssac_act *a);                 /* DEVICE pointer of the observation buffer */
+const int64_t *ssac_act_counter(ssac_act *a);    /* DEVICE pointer of the call counter (advanced by ssac_act_publish) */
+int ssac_act_publish(ssac_act *a, const float *src, int n, void *stream);
+int ssac_act_add_list(ssac_act *a, ssac_launch_list *list);   /* returns the list's index, < 0 on error */
+int ssac_act_run(ssac_act *a, int which, const void *obs_host, int obs_bytes, float *out_host, int out_floats, void *stream);
+long long ssac_act_calls(const ssac_act *a);
+void ssac_act_destroy(ssac_act *a);
+/* SUNRISE's UCB rule (agent.py:262-300) on stacked candidates: q_members[c] (HOST array of n_members <= 8 device pointers) =
+ * member c's critics on row (a n_rows + b) of X, (n_nets x n_cand n_rows); a candidate's value per member = min over its nets
+ * (agent.Critic.forward), score = mean over the members + bonus * unbiased std, best = first arg-max over the candidates;
+ * act (n_rows x act_dim) = columns [col0, col0 + act_dim) of X's row (best n_rows + b), clamped to [-1, 1]. */
+int ssac_ucb_select(const float *const *q_members, int n_members, int n_nets, int n_cand, int n_rows, float bonus,
+                    const float *X, int64_t ldx, int col0, int act_dim, float *act, void *stream);
+/* greedy continuous action (agent.py:204-246): act = clamp(mean over the actors of tanh(outs[e][b][k]), -1, 1) */
+int ssac_act_mean_tanh(const float *const *outs, int n_actors, int64_t ld_out, int n_rows, int act_dim, float *act,
+                       void *stream);
+/* act (n_rows x act_dim) = clamp(columns [col0, col0 + act_dim) of src, lo, hi) */
+int ssac_act_take_clamp(const float *src, int64_t ld, int col0, int n_rows, int act_dim, float lo, float hi, float *act,
+                        void *stream);
+/* discrete actors (agent.py:218-226, 301-309): sample = 0: arg-max of the mean over the actors of softmax(outs[e]); sample = 1
+ * (one actor): Categorical(logits).sample() by inversion with one uniform per row from `rng`'s Philox stream.  act (n_rows):
+ * the action index as a float. */
+int ssac_act_discrete(const float *const *outs, int n_actors, int64_t ld_out, int n_rows, int n_actions, int sample,
+                      const ssac_rng *rng, float *act, void *stream);
+
 /* zero a float buffer (log accumulators) */
 int ssac_zero(float *p, int64_t n, void *stream);
 

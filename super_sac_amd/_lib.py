@@ -234,6 +234,18 @@ SIGNATURES = {
     "ssac_head_wgrad_tiles": [_MP],
     "ssac_head_wgrad": [_MP, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _L, _P, _F, _P],
     "ssac_critic_logs": [_P, _I, _I, _I, _F, _P, _I, _P, _P, _P, _P, _P, _P],
+    "ssac_act_create": [_I, _I],
+    "ssac_act_obs": [_P],
+    "ssac_act_counter": [_P],
+    "ssac_act_publish": [_P, _P, _I, _P],
+    "ssac_act_add_list": [_P, _P],
+    "ssac_act_run": [_P, _I, _P, _I, _P, _I, _P],
+    "ssac_act_calls": [_P],
+    "ssac_act_destroy": [_P],
+    "ssac_ucb_select": [_P, _I, _I, _I, _I, _F, _P, _L, _I, _I, _P, _P],
+    "ssac_act_mean_tanh": [_P, _I, _L, _I, _I, _P, _P],
+    "ssac_act_take_clamp": [_P, _L, _I, _I, _I, _F, _F, _P, _P],
+    "ssac_act_discrete": [_P, _I, _L, _I, _I, _I, _P, _P, _P],
     "ssac_bf16_layout": [_I, _I, _I, C.POINTER(C.c_int64)],
     "ssac_bf16_supported": [_MP],
     "ssac_bf16_sync": [_MP, _P, _P],
@@ -263,7 +275,8 @@ LAB_SIGNATURES = {
     "ssac_debug_timeline": [_P],
     "ssac_xchg_test_mode": [_P, _I],
 }
-_RESTYPES = {"ssac_xchg_create": C.c_void_p, "ssac_xchg_destroy": None, "ssac_step_create": C.c_void_p, "ssac_step_count": C.c_int64, "ssac_actor_chain_handoff_words": C.c_int64, "ssac_step_destroy": None,
+_RESTYPES = {"ssac_act_create": C.c_void_p, "ssac_act_obs": C.c_void_p, "ssac_act_counter": C.c_void_p, "ssac_act_calls": C.c_longlong,
+             "ssac_act_destroy": None, "ssac_xchg_create": C.c_void_p, "ssac_xchg_destroy": None, "ssac_step_create": C.c_void_p, "ssac_step_count": C.c_int64, "ssac_actor_chain_handoff_words": C.c_int64, "ssac_step_destroy": None,
              "ssac_last_error": C.c_char_p, "ssac_mlp_layout": C.c_int64, "ssac_bf16_layout": C.c_int64, "ssac_record_end": C.c_void_p,
              "ssac_launch_list_free": None}
 

@@ -1,0 +1,218 @@
+"""The acting path as ONE C call per environment step (agent.py:204-315; csrc/ssac_act.hip).
+
+``Agent.forward`` / ``Agent.sample_action`` with a numpy observation of an identity-encoder agent whose networks fit the
+fused MLP kernels take this path: the first call at a given (rule, num_envs) RECORDS the rule's launches -- every actor's
+forward (+ tanh-normal sample from the engine's Philox stream, in the kernel), SUNRISE's ensemble-Q passes on the stacked
+candidates, the rule's reduction (UCB arg-max / mean of mean actions / categorical draw / arg-max of mean probabilities) and
+the publish step -- into a launch list of an ``ssac_act`` plan; every later call is ``ssac_act_run``: the observation is
+written straight into device-visible memory, the list is re-issued, the action arrives in pinned host memory.  No torch op,
+no hipMemcpy, no stream synchronisation.  Measured (bench.py ``secondary.acting``): see profiles/r6_acting.md.
+
+What stays on the general path (agent.py's eager code, unchanged): pixel encoders, injected noise (a hook on
+``rng.draw_normal`` -- the parity tests), discrete UCB, networks outside the fused kernels' shapes (hidden > 256),
+``from_cpu=False`` callers.  Host RNG contract: the Python ``random`` draws of the reference (``random.choice`` of the
+acting actor / of the logged distribution) are consumed exactly as before."""
+import ctypes as C
+import weakref
+
+import numpy as np
+import torch
+
+from . import _lib, engine, rng
+from . import learning_utils as lu
+from ._lib import check, lib
+
+ENABLED = True
+_PLANS = weakref.WeakKeyDictionary()   # agent -> {(rule, num_envs, bonus): _Plan}
+_SERIAL = [0]
+_STREAM_SALT = 0x41C7A11D5EEDB00C      # the acting noise stream: the agent's engine seed under another key
+
+
+class _Plan:
+    def __init__(self, agent, rule, n, dev):
+        self.rule, self.n, self.dev = rule, n, dev
+        self.S = agent.encoder.embedding_dim
+        self.key = agent.encoder.ssac_identity_key
+        self.discrete = bool(agent.discrete)
+        self.A = agent.act_space_size
+        self.out_floats = n if self.discrete else n * self.A
+        self.handle = lib.ssac_act_create(4 * n * self.S, self.out_floats)
+        if not self.handle:
+            raise RuntimeError("libssac_hip: " + lib.ssac_last_error().decode())
+        self.obs_dev = lib.ssac_act_obs(self.handle)
+        self.counter = lib.ssac_act_counter(self.handle)
+        _SERIAL[0] += 1
+        self.serial = _SERIAL[0]
+        self.result = np.empty(self.out_floats, np.float32)
+        self.bufs = []        # device tensors the recorded launches point at
+        self.outs = []        # per actor: its head output (n x out_dim), what return_dist hands back
+        self.sig = None
+        self.lists = {}       # which-actor -> list index
+
+    def buf(self, *shape):
+        t = torch.zeros(*shape, device=self.dev)
+        self.bufs.append(t)
+        return t
+
+    def rng_for(self, agent, member):
+        seed = (lu.noise_stream(agent, self.dev)[0] ^ _STREAM_SALT) & (2 ** 64 - 1)
+        return _lib.Rng(seed, self.counter, (self.serial << 48) + (member << 40))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib.ssac_act_destroy(self.handle)
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+def _signature(agent, with_critics):
+    sig = [a.fc1.weight.data_ptr() for a in agent.actors]
+    if with_critics:
+        sig += [c.nets[0].fc1.weight.data_ptr() for c in agent.critics]
+    return tuple(sig)
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _eligible(agent, obs, num_envs, sample, rolling):
+    if not (ENABLED and isinstance(obs, dict) and lu.is_identity(agent.encoder) and engine.CAPTURE is None):
+        return False
+    v = obs.get(agent.encoder.ssac_identity_key)
+    if not isinstance(v, np.ndarray) or v.size != num_envs * agent.encoder.embedding_dim:
+        return False
+    E = len(agent.actors)
+    if E > 8 or agent.act_space_size > 64:
+        return False
+    kind = lu.actor_kind(agent.actors[0])
+    if sample and kind == "stochastic" and not rng.normal_is_stock():
+        return False          # injected noise: the general path draws it through the hook
+    if sample and agent.ucb_bonus > 0 and (agent.discrete or kind != "stochastic" or E < 2):
+        return False
+    return True
+
+
+def _arena_ok(agent, dev, with_critics):
+    for a in agent.actors:
+        if not engine.bind_arena(a, "self", [a], dev).fused:
+            return False
+    if with_critics:
+        for c in agent.critics:
+            if not c.arena(dev).fused:
+                return False
+    return True
+
+
+def _fwd(plan, arena, x_ptr, ldx, n_rows, y):
+    check(lib.ssac_mlp3_fwd_fused(C.byref(arena.desc()), 0, arena.n_nets, x_ptr, ldx, 0, n_rows, 0, 0, y.data_ptr(),
+                                  engine.stream()))
+
+
+def _record(plan, agent, which):
+    """record the launches of plan.rule for acting actor `which` (None: the rule involves every actor)"""
+    dev, n, S, A = plan.dev, plan.n, plan.S, plan.A
+    st = engine.stream()
+    kind = lu.actor_kind(agent.actors[0])
+    E = len(agent.actors)
+    arenas = [engine.bind_arena(a, "self", [a], dev) for a in agent.actors]
+    if not plan.outs:
+        plan.outs = [plan.buf(n, ar.out_dim) for ar in arenas]
+        plan.res = plan.buf(max(plan.out_floats, 1))
+        plan.logp = plan.buf(max(n * E, 1))
+    check(lib.ssac_record_begin())
+    try:
+        if plan.rule == "forward":
+            for ar, out in zip(arenas, plan.outs):
+                _fwd(plan, ar, plan.obs_dev, S, n, out)
+            if plan.discrete:
+                check(lib.ssac_act_discrete(_ptr_array(plan.outs), E, A, n, A, 0, None, plan.res.data_ptr(), st))
+            else:
+                check(lib.ssac_act_mean_tanh(_ptr_array(plan.outs), E, arenas[0].out_dim, n, A, plan.res.data_ptr(), st))
+        elif plan.rule == "ucb":
+            # agent.py:262-300: a candidate per actor on the rows of x = [s | a_k] (E n rows), every member's critics on x,
+            # mean + bonus * std over the members, arg-max over the candidates
+            x = plan.buf(E * n, S + A)
+            for k, (actor, ar) in enumerate(zip(agent.actors, arenas)):
+                r = plan.rng_for(agent, k)
+                check(lib.ssac_actor_sample_concat_fused(
+                    C.byref(ar.desc()), plan.obs_dev, S, n, 0, float(actor.log_std_low), float(actor.log_std_high),
+                    x[k * n:].data_ptr(), S + A, plan.logp[k * n:].data_ptr(), 0, 0, plan.outs[k].data_ptr(), C.byref(r), st))
+            qs = []
+            for c in agent.critics:
+                car = c.arena(dev)
+                q = plan.buf(car.n_nets, E * n, 1)
+                _fwd(plan, car, x.data_ptr(), S + A, E * n, q)
+                qs.append(q)
+            check(lib.ssac_ucb_select(_ptr_array(qs), len(qs), agent.critics[0].arena(dev).n_nets, E, n, float(agent.ucb_bonus),
+                                      x.data_ptr(), S + A, S, A, plan.res.data_ptr(), st))
+        else:   # "sample": one actor's draw (agent.py:301-309)
+            actor, ar, out = agent.actors[which], arenas[which], plan.outs[which]
+            if plan.discrete:
+                _fwd(plan, ar, plan.obs_dev, S, n, out)
+                r = plan.rng_for(agent, which)
+                check(lib.ssac_act_discrete(_ptr_array([out]), 1, A, n, A, 1, C.byref(r), plan.res.data_ptr(), st))
+            elif kind == "stochastic":
+                # (tanh-normal samples lie inside (-1, 1): _process_act's clamp is the identity)
+                r = plan.rng_for(agent, which)
+                check(lib.ssac_actor_sample_fused(
+                    C.byref(ar.desc()), plan.obs_dev, S, n, 0, float(actor.log_std_low), float(actor.log_std_high),
+                    plan.res.data_ptr(), A, 0, plan.logp.data_ptr(), 0, 0, out.data_ptr(), C.byref(r), st))
+            else:   # deterministic actor: sample() = loc = tanh(out) (distributions.py:107-114)
+                _fwd(plan, ar, plan.obs_dev, S, n, out)
+                check(lib.ssac_act_mean_tanh(_ptr_array([out]), 1, ar.out_dim, n, A, plan.res.data_ptr(), st))
+        check(lib.ssac_act_publish(plan.handle, plan.res.data_ptr(), plan.out_floats, st))
+    finally:
+        lst = lib.ssac_record_end()
+    # (the recording pass issued the launches too -- on whatever the observation buffer held -- and advanced the device-side
+    #  call counter: ssac_act_add_list drains the device and re-reads the count)
+    idx = lib.ssac_act_add_list(plan.handle, lst)
+    if idx < 0:
+        raise RuntimeError("libssac_hip: " + lib.ssac_last_error().decode())
+    plan.lists[which] = idx
+
+
+def act(agent, obs, num_envs, sample, return_dist=False, rolling=False):
+    """the fast path's answer -- (action as numpy, dist_out or None) -- or None when the call is not eligible"""
+    if not _eligible(agent, obs, num_envs, sample, rolling):
+        return None
+    dev = next(agent.actors[0].parameters()).device
+    ucb = bool(sample and agent.ucb_bonus > 0)
+    rule = "ucb" if ucb else ("sample" if sample else "forward")
+    plans = _PLANS.setdefault(agent, {})
+    pkey = (rule, num_envs, float(agent.ucb_bonus) if ucb else 0.0)
+    plan = plans.get(pkey)
+    sig = _signature(agent, ucb)
+    if plan is None or plan.sig != sig:
+        if not _arena_ok(agent, dev, ucb):
+            return None
+        if len(plans) > 12:
+            plans.clear()
+        plan = plans[pkey] = _Plan(agent, rule, num_envs, dev)
+        plan.sig = _signature(agent, ucb)   # (binding the arenas may have re-pointed the parameters)
+    # the reference's host draws, in its order: random.choice(act_dists) under UCB (for the logged distribution),
+    # random.choice(self.actors) otherwise (agent.py:262, 301)
+    which = None
+    if rule == "ucb":
+        which_dist = rng.choice(range(len(agent.actors)))
+    elif rule == "sample":
+        which = which_dist = rng.choice(range(len(agent.actors)))
+    if which not in plan.lists:
+        _record(plan, agent, which)
+    v = np.ascontiguousarray(obs[plan.key], dtype=np.float32)
+    rc = lib.ssac_act_run(plan.handle, plan.lists[which], v.ctypes.data, v.nbytes, plan.result.ctypes.data, plan.out_floats,
+                          engine.stream())
+    if rc:
+        raise RuntimeError("libssac_hip: " + lib.ssac_last_error().decode())
+    n, A = num_envs, plan.A
+    if plan.discrete:
+        out = plan.result.astype(np.int64).reshape(n, 1)
+    else:
+        out = plan.result.reshape(n, A).copy()
+    if num_envs == 1:
+        out = out[0]
+    dist_out = None
+    if return_dist:
+        dist_out = plan.outs[which_dist].clone()   # the chosen actor's raw head output (distribution parameters)
+    return out, dist_out

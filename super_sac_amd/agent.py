@@ -162,6 +162,11 @@ class Agent:
         action probabilities (discrete), agent.py:204-246."""
         engine.require_gpu()
         if from_cpu:
+            # one C call per step where the agent allows it (identity encoder, fused-kernel shapes): acting.py
+            from . import acting
+            fast = acting.act(self, state, num_envs, sample=False, rolling=rolling)
+            if fast is not None:
+                return fast[0]
             state = self._process_obs(state, num_envs=num_envs)
         s_rep = self._state_rep(state, rolling)
         outs = [actor.raw_forward(s_rep) for actor in self.actors]
@@ -180,6 +185,10 @@ class Agent:
         values coming from one ensemble-Q launch per member on the stacked candidates."""
         engine.require_gpu()
         if from_cpu:
+            from . import acting
+            fast = acting.act(self, obs, num_envs, sample=True, return_dist=return_dist, rolling=rolling)
+            if fast is not None:
+                return fast if return_dist else fast[0]
             obs = self._process_obs(obs, num_envs)
         s_rep = self._state_rep(obs, rolling)
         n = s_rep.shape[0]

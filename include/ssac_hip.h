@@ -865,19 +865,6 @@ int ssac_conv_first_wgrad(const float *dy, const float *img, float *partial_w, f
 int ssac_conv_first_wgrad_band_slices(int B, int C, int Hi, int Wi, int co, int k, int s);
 int ssac_conv_first_wgrad_band(const float *dy, const float *img, float *partial_w, float *partial_b, int B, int C, int Hi,
                                int Wi, int co, int k, int s, float div, float shift, void *stream);
-/* The first layer with the DrQv2 random shift (augmentations.py:214-269: replicate pad + bilinear grid shift) applied in
- * its operand staging: replaces ssac_drq_shift(mode 0, uint8 source, gathered through idx) + ssac_conv_first_fwd for a
- * batch whose shifted image nobody else needs (the target encoder's s'; the online encoder's forward) -- the fp32 image
- * (B C H H x 4 bytes) is neither written nor read.  y is bit-identical to the two launches.
- *   src   replay storage (rows, C, H, H) uint8, 4-byte aligned;  idx (B) int64 storage rows or NULL;  shift (B, 2) int64
- *         x, y draws;  batch rows >= n_aug are taken un-shifted (aug_mix).
- * ssac_conv_first_shift_supported returns the output rows per workgroup band (> 0) when the geometry is covered
- * (ssac_conv_first_supported, square H % 4 == 0 images, two workgroups' LDS per CU), else 0. */
-int ssac_conv_first_shift_supported(int C, int co, int k, int s, int H, int64_t B, int pad);
-int ssac_conv_first_shift_fwd(const void *src, const int64_t *idx, const int64_t *shift, int pad, int n_aug,
-                              const float *w, const float *bias, float *y, int B, int C, int H, int co, int k, int s,
-                              float div, float shift_norm, void *stream);
-
 /* split-K forward for short, very deep problems (the pixel encoders' fc over the flattened feature map):
  * partial (slices x M x N) = X[:, slice] W[:, slice]^T per K slice of k_per_slice (multiple of 32) columns;
  * ssac_reduce_slices_bias then writes Y[m*ld_out + n] = bias[n] + sum over slices, in a fixed order. */

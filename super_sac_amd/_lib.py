@@ -185,8 +185,6 @@ SIGNATURES = {
     "ssac_conv_wgrad_img": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "ssac_conv_first_wgrad_band_slices": [_I, _I, _I, _I, _I, _I, _I],
     "ssac_conv_first_wgrad_band": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P],
-    "ssac_conv_first_shift_supported": [_I, _I, _I, _I, _I, _L, _I],
-    "ssac_conv_first_shift_fwd": [_P, _P, _P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P],
     "ssac_linear_fwd_splitk": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P],
     "ssac_linear_fwd_stream_supported": [_I, _I, _I, _I, _L, _L],
     "ssac_linear_fwd_stream": [_P, _L, _P, _L, _P, _I, _I, _I, _I, _P],

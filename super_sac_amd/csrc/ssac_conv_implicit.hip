@@ -714,289 +714,6 @@ __global__ __launch_bounds__(CV_THREADS) void conv_first_fwd_kernel(FirstArgs g,
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// First layer with the DrQv2 random shift applied in its operand staging (augmentations.py:214-269 in front of
-// cnns.py:41,76).  The two-launch form -- drqv2_shift_plane_kernel writes the shifted batch as fp32 (B C H W x 4 bytes:
-// 130 MB at DMC B 512), conv_first_fwd_kernel reads it back -- moves 2 x 4 bytes per input pixel through HBM for one byte
-// of information.  Here a workgroup takes (image b, band of R output rows): it copies the uint8 source rows the band's
-// input rows can tap into LDS (gathered through the replay index: the replay rows are read where they lie), evaluates
-// the shifted fp32 pixels of the band ONCE per input pixel into LDS -- with exactly the operations of the shift kernel
-// (drqv2_shift_axis; same taps, same order, same clamp) -- and runs the 32-pixel MFMA tiles of the band with operands
-// read from LDS in conv_first_fwd_kernel's order (run-major, tap-minor: the same accumulation chain per output, so the
-// result is bit-identical to the two launches).  Two workgroups per CU (<= 80 KB of LDS each): one's VALU phase runs
-// under the other's MFMA phase.
-// ---------------------------------------------------------------------------------------------
-struct ShiftSrc {
-    const uint8_t *src;     // replay storage (rows, C, H, H) uint8
-    const int64_t *idx;     // (B) storage row of each batch element; null: row b
-    const int64_t *shift;   // (B, 2) the x, y draws of this randomisation
-    int pad, n_aug;         // batch rows >= n_aug are copied un-shifted (aug_mix)
-    int R;                  // output rows per band
-};
-
-constexpr int FS_PW = 8, FS_CW = 8;   // producer waves (the next item's shifted band), consumer waves (this item's MFMA tiles)
-constexpr int FS_THREADS = 64 * (FS_PW + FS_CW);
-constexpr int FS_NW = 9;          // source words a producer lane carries for the item after next
-constexpr int FS_SEG = 4;         // channels a producer wave's row range can touch
-
-// The rows (c, r) of an item's band are cut into FS_PW contiguous ranges, one per producer wave; a wave stages the source
-// rows ITS range taps into a private LDS region (per touched channel one run of consecutive rows) and evaluates its rows
-// from there: nothing is shared between producer waves, so the only workgroup barrier of an item is the band hand-off.
-struct FsItem { int b, oy0, rows, iy0, rin; bool aug; };
-struct FsSeg {                    // (wave-uniform)
-    int q0, q1, c_lo, total;      // row range [q0, q1) of this wave, first channel, words staged
-    int ya[FS_SEG], base[FS_SEG]; // per touched channel: first source row staged, word offset of its run
-};
-
-template <int KH>
-__global__ __launch_bounds__(FS_THREADS) void conv_first_shift_fwd_kernel(FirstArgs g, ShiftSrc sa, int n_items) {
-#pragma clang fp contract(off)
-    typedef typename TapVec<KH>::type vec;
-    extern __shared__ __attribute__((aligned(16))) float wl[];  // [run = (c, ky)][32 co][2 KH taps], zero-padded taps
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int nruns = g.C * g.k, kk = g.k * g.k, H = g.Hi, hp = H + 2 * sa.pad, wpr = H >> 2;
-    const ShiftGrid sg = drqv2_shift_grid(hp);
-    const int Rin = (sa.R - 1) * g.s + g.k;
-    const int per_max = (g.C * Rin + FS_PW - 1) / FS_PW, seg_words = (per_max + 2 * FS_SEG) * wpr;
-    const int nruns3 = (nruns + 2) / 3 * 3;                                   // (the operand rotation runs in threes: zero weights behind the last run)
-    float *band0 = wl + nruns3 * 32 * 2 * KH;                                // 2 x [C][Rin][H] shifted fp32 input rows
-    const int band_floats = g.C * Rin * H;
-    uint32_t *srcw_all = reinterpret_cast<uint32_t *>(band0 + 2 * band_floats);   // FS_PW x [seg_words] source rows, 4 pixels a word
-    uint32_t *rtab_all = srcw_all + FS_PW * seg_words;                       // FS_PW x [per_max][8]: the row table of a producer wave
-    const int co0 = blockIdx.y * 32;
-    const int nbands = (g.Ho + sa.R - 1) / sa.R;
-    const int64_t img_bytes = (int64_t)g.C * H * H;
-    // item -> (image, band): the band index changes slowest, so a persistent workgroup meets every band height
-    auto item_of = [&](int item) {
-        FsItem it;
-        const int bi = item / g.B;
-        it.b = item - bi * g.B;
-        it.oy0 = bi * sa.R; it.rows = min(sa.R, g.Ho - it.oy0);
-        it.iy0 = it.oy0 * g.s; it.rin = (it.rows - 1) * g.s + g.k;
-        it.aug = it.b < sa.n_aug;
-        return it;
-    };
-    for (int i = tid; i < nruns3 * 32 * 2 * KH; i += FS_THREADS) {
-        const int kx = i % (2 * KH), t = i / (2 * KH), co = t & 31, run = t >> 5;
-        const int c = run / g.k, ky = run - c * g.k;
-        wl[i] = (kx < g.k && run < nruns) ? g.w[((int64_t)(co0 + co) * g.C + c) * kk + ky * g.k + kx] / g.div : 0.0f;
-    }
-    __syncthreads();
-    const int my_items = blockIdx.x < n_items ? (n_items - 1 - blockIdx.x) / gridDim.x + 1 : 0;
-
-    if (wave < FS_PW) {
-        // ------------------------------------------------------------------------------------------ producer waves
-        uint32_t *sw = srcw_all + wave * seg_words;
-        const uint8_t *sb = reinterpret_cast<const uint8_t *>(sw);
-        uint32_t *rtab = rtab_all + wave * per_max * 8;
-        const int ry = lane / wpr, tx4 = lane - ry * wpr, rpi = 64 / wpr;   // rows per pass of the wave, this lane's quad
-        auto src_lo = [&](const FsItem &it, int64_t sy, int r) {
-            return it.aug ? min(max(drqv2_shift_axis(it.iy0 + r, sy, sg).p0 - sa.pad, 0), H - 1) : it.iy0 + r;
-        };
-        auto src_hi = [&](const FsItem &it, int64_t sy, int r) {
-            return it.aug ? min(max(drqv2_shift_axis(it.iy0 + r, sy, sg).p0 + 1 - sa.pad, 0), H - 1) : it.iy0 + r;
-        };
-        auto segments = [&](const FsItem &it, int64_t sy) {
-            FsSeg d;
-            const int Q = g.C * it.rin, per = (Q + FS_PW - 1) / FS_PW;
-            d.q0 = min(wave * per, Q); d.q1 = min(Q, d.q0 + per);
-            d.c_lo = d.q0 / it.rin;
-            int words = 0;
-#pragma unroll
-            for (int k = 0; k < FS_SEG; ++k) {
-                const int c = d.c_lo + k;
-                const int ra = max(d.q0 - c * it.rin, 0), rb = min(d.q1 - c * it.rin, it.rin) - 1;
-                d.ya[k] = 0; d.base[k] = words;
-                if (rb >= ra) {   // (the sampling positions are monotone in the row index)
-                    d.ya[k] = src_lo(it, sy, ra);
-                    words += (src_hi(it, sy, rb) - d.ya[k] + 1) * wpr;
-                }
-            }
-            d.total = words;
-            return d;
-        };
-        uint32_t pre[FS_NW];
-        auto request = [&](const FsItem &it, const FsSeg &d, int64_t row) {
-            const uint8_t *img = sa.src + row * img_bytes;
-#pragma unroll
-            for (int u = 0; u < FS_NW; ++u) {
-                const int i = lane + u * 64;
-                if (i < d.total) {
-                    int k = 0;
-#pragma unroll
-                    for (int j = 1; j < FS_SEG; ++j) k += i >= d.base[j];   // (the empty runs behind the last channel start at `total`)
-                    int ya = d.ya[0], base = d.base[0];
-#pragma unroll
-                    for (int j = 1; j < FS_SEG; ++j) if (k == j) { ya = d.ya[j]; base = d.base[j]; }
-                    pre[u] = reinterpret_cast<const uint32_t *>(img + ((int64_t)(d.c_lo + k) * H + ya) * H)[i - base];
-                }
-            }
-        };
-        auto draw = [&](int n, int64_t &sx, int64_t &sy, int64_t &row) {
-            const int item = blockIdx.x + (n < my_items ? n : 0) * gridDim.x;
-            const int b = item % g.B;
-            sx = sa.shift[2 * b]; sy = sa.shift[2 * b + 1];
-            row = sa.idx ? sa.idx[b] : (int64_t)b;
-        };
-        int64_t sxA, syA, rowA, sxB, syB, rowB;
-        FsItem nx{};
-        FsSeg nxd{};
-        if (my_items > 0) {
-            draw(0, sxA, syA, rowA);
-            draw(1, sxB, syB, rowB);
-            nx = item_of(blockIdx.x);
-            nxd = segments(nx, syA);
-            request(nx, nxd, rowA);
-        }
-        // produce(n): the band of this workgroup's n-th item into band buffer n & 1
-        auto produce = [&](int n) {
-            const FsItem it = nx;
-            const FsSeg d = nxd;
-            const int64_t sx = sxA, sy = syA;
-            float *band = band0 + (n & 1) * band_floats;
-#pragma unroll
-            for (int u = 0; u < FS_NW; ++u) {
-                const int i = lane + u * 64;
-                if (i < d.total) sw[i] = pre[u];
-            }
-            // the row table: per row of this wave's range the byte offsets of its two source rows inside the staged runs,
-            // the two row weights (0 where the tap lies outside the padded image: all weights are >= 0, so wy * 0 = +0 = the
-            // two-launch form's selected 0.0f -- the same bits) and where the row goes in the band
-            for (int i = lane; i < d.q1 - d.q0; i += 64) {
-                const int q = d.q0 + i, c = q / it.rin, r = q - c * it.rin, k = c - d.c_lo;
-                int ya = d.ya[0], base = d.base[0];
-#pragma unroll
-                for (int j = 1; j < FS_SEG; ++j) if (k == j) { ya = d.ya[j]; base = d.base[j]; }
-                uint32_t o0, o1;
-                float w0 = 1.0f, w1 = 0.0f;
-                if (it.aug) {
-                    const ShiftAxis t = drqv2_shift_axis(it.iy0 + r, sy, sg);
-                    o0 = (base + (min(max(t.p0 - sa.pad, 0), H - 1) - ya) * wpr) * 4;
-                    o1 = (base + (min(max(t.p0 + 1 - sa.pad, 0), H - 1) - ya) * wpr) * 4;
-                    w0 = (t.p0 >= 0 && t.p0 < hp) ? t.w0 : 0.0f;
-                    w1 = (t.p0 + 1 >= 0 && t.p0 + 1 < hp) ? t.w1 : 0.0f;
-                } else {
-                    o0 = o1 = (base + (it.iy0 + r - ya) * wpr) * 4;
-                }
-                *reinterpret_cast<uint4 *>(rtab + i * 8) = uint4{o0, o1, __float_as_uint(w0), __float_as_uint(w1)};
-                rtab[i * 8 + 4] = (c * Rin + r) * H;
-            }
-            // the item after: its rows are requested now (they land while this one is evaluated), its successor's draws too
-            sxA = sxB; syA = syB; rowA = rowB;
-            if (n + 1 < my_items) {
-                nx = item_of(blockIdx.x + (n + 1) * gridDim.x);
-                nxd = segments(nx, syA);
-                request(nx, nxd, rowA);
-                draw(n + 2, sxB, syB, rowB);
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");   // (this wave's LDS stores above are read below: DS operations of a wave stay in order)
-            if (ry < rpi) {
-                const int nrow = d.q1 - d.q0;
-                if (it.aug) {
-                    f2 wxa[2], wxb[2];    // the masked column weights of taps x0 / x0 + 1, columns (0, 1) and (2, 3)
-                    int sx0[4], sx1[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const ShiftAxis t = drqv2_shift_axis(4 * tx4 + j, sx, sg);
-                        wxa[j >> 1][j & 1] = (t.p0 >= 0 && t.p0 < hp) ? t.w0 : 0.0f;
-                        wxb[j >> 1][j & 1] = (t.p0 + 1 >= 0 && t.p0 + 1 < hp) ? t.w1 : 0.0f;
-                        sx0[j] = min(max(t.p0 - sa.pad, 0), H - 1); sx1[j] = min(max(t.p0 + 1 - sa.pad, 0), H - 1);   // replicate pad
-                    }
-                    for (int i = ry; i < nrow; i += rpi) {
-                        const uint4 e = *reinterpret_cast<const uint4 *>(rtab + i * 8);
-                        float *dst = band + rtab[i * 8 + 4] + 4 * tx4;
-                        f2 acc[2] = {f2{0.0f, 0.0f}, f2{0.0f, 0.0f}};
-#pragma unroll
-                        for (int dy = 0; dy < 2; ++dy) {
-                            const uint8_t *row = sb + (dy ? e.y : e.x);
-                            const float wy = __uint_as_float(dy ? e.w : e.z);
-#pragma unroll
-                            for (int h = 0; h < 2; ++h) {   // two columns per packed operation; per column the two-launch order
-                                const f2 pa = f2{(float)row[sx0[2 * h]], (float)row[sx0[2 * h + 1]]};
-                                const f2 pb = f2{(float)row[sx1[2 * h]], (float)row[sx1[2 * h + 1]]};
-                                acc[h] = acc[h] + pa * (wxa[h] * wy);
-                                acc[h] = acc[h] + pb * (wxb[h] * wy);
-                            }
-                        }
-                        *reinterpret_cast<f4 *>(dst) = f4{__builtin_amdgcn_fmed3f(acc[0][0], 0.0f, 255.0f), __builtin_amdgcn_fmed3f(acc[0][1], 0.0f, 255.0f),
-                                                          __builtin_amdgcn_fmed3f(acc[1][0], 0.0f, 255.0f), __builtin_amdgcn_fmed3f(acc[1][1], 0.0f, 255.0f)};
-                    }
-                } else {
-                    for (int i = ry; i < nrow; i += rpi) {
-                        const uint32_t u = sw[(rtab[i * 8] >> 2) + tx4];
-                        *reinterpret_cast<f4 *>(band + rtab[i * 8 + 4] + 4 * tx4) =
-                            f4{(float)(u & 255u), (float)((u >> 8) & 255u), (float)((u >> 16) & 255u), (float)(u >> 24)};
-                    }
-                }
-            }
-        };
-        if (my_items > 0) produce(0);
-        lds_barrier();
-        for (int n = 0; n < my_items; ++n) {
-            if (n + 1 < my_items) produce(n + 1);
-            lds_barrier();
-        }
-    } else {
-        // ------------------------------------------------------------------------------------------ consumer waves
-        const int cw = wave - FS_PW;
-        float bias = g.bias[co0 + li];
-        if (g.shift != 0.0f) {
-            float ws = 0.0f;
-            for (int run = 0; run < nruns; ++run)
-#pragma unroll
-                for (int j = 0; j < 2 * KH; ++j) ws += wl[(run * 32 + li) * 2 * KH + j];
-            bias += g.shift * (ws * g.div);
-        }
-        lds_barrier();
-        for (int n = 0; n < my_items; ++n) {
-            const FsItem it = item_of(blockIdx.x + n * gridDim.x);
-            const float *band = band0 + (n & 1) * band_floats;
-            const int npix = it.rows * g.Wo, ntl = (npix + 31) >> 5;
-            const int64_t mbase = ((int64_t)it.b * g.Ho + it.oy0) * g.Wo;
-            for (int tl = cw; tl < ntl; tl += FS_CW) {
-                const int p = tl * 32 + li, pp = p < npix ? p : 0;
-                const int r = pp / g.Wo, ox = pp - r * g.Wo;
-                const float *ab = band + (r * g.s) * H + ox * g.s + lh * KH;
-                const float *wb = wl + (li * 2 + lh) * KH;
-                f32x16 acc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-                // operands two runs ahead of the MFMAs (three rotating register sets; LDS latency under 2 KH MFMAs); the
-                // runs behind the last one re-read its pixels against zero weights (acc + 0 * x: unchanged bits)
-                int l_off = 0, l_ky = 0, l_run = 0;
-                auto load = [&](vec &a, vec &bw) {
-                    a = *reinterpret_cast<const vec *>(ab + l_off);
-                    bw = *reinterpret_cast<const vec *>(wb + l_run * 64 * KH);
-                    const bool adv = l_run + 1 < nruns;
-                    l_run += l_run + 1 < nruns3;
-                    l_ky += adv;
-                    const bool wrap = l_ky == g.k;
-                    l_off += (adv ? H : 0) + (wrap ? (Rin - g.k) * H : 0);
-                    l_ky = wrap ? 0 : l_ky;
-                };
-                auto step = [&](const vec &a, const vec &bw) {
-#pragma unroll
-                    for (int j = 0; j < KH; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bw[j], acc, 0, 0, 0);
-                };
-                vec a0, a1, a2, b0, b1, b2;
-                load(a0, b0); load(a1, b1);
-                for (int c_run = 0; c_run < nruns3; c_run += 3) {
-                    load(a2, b2); step(a0, b0);
-                    load(a0, b0); step(a1, b1);
-                    load(a1, b1); step(a2, b2);
-                }
-#pragma unroll
-                for (int rr = 0; rr < 16; ++rr) {
-                    const int pr = tl * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * lh;
-                    if (pr < npix) g.out[(mbase + pr) * g.co + co0 + li] = fmaxf(acc[rr] + bias, 0.0f);
-                }
-            }
-            lds_barrier();
-        }
-    }
-}
 
 // weight gradient of the first layer: grid (pixel slices, co / 32); the 4 waves of a workgroup split the slice's pixels
 // and add their accumulators through LDS in a fixed order, so a slice is one workgroup's partial
@@ -1618,78 +1335,6 @@ extern "C" int ssac_conv_first_wgrad_band(const float *dy, const float *img, flo
     return ssac_check_launch("conv_first_wgrad_band");
 }
 
-// rows per band of the shift-fused first layer for this geometry (0: stays on the two-launch form).  One workgroup per CU
-// (two band buffers + the weights + the producer waves' source rows <= 160 KB of LDS); among the band heights that fit,
-// the one that minimises an image's cost: per band the longer of ceil(tiles / 4) MFMA rounds of the consumer waves and
-// the producer waves' shifted input rows (bands overlap by k - s rows); ties go to the taller band.
-static size_t first_shift_lds(int C, int k, int s, int H, int kh, int R) {
-    const int Rin = (R - 1) * s + k, per = (C * Rin + FS_PW - 1) / FS_PW;
-    return sizeof(float) * ((size_t)((C * k + 2) / 3 * 3) * 64 * kh + 2 * (size_t)C * Rin * H + FS_PW * (size_t)(per + 2 * FS_SEG) * (H / 4) + 8 * FS_PW * (size_t)per);
-}
-// one band height's row ranges fit the producer waves' bounds (channels touched, words carried per lane)
-static bool first_shift_rows_ok(int C, int rin, int H) {
-    const int Q = C * rin, per = (Q + FS_PW - 1) / FS_PW;
-    int nseg = 1;
-    for (int w = 0; w < FS_PW; ++w) {
-        const int q0 = w * per < Q ? w * per : Q, q1 = q0 + per < Q ? q0 + per : Q;
-        if (q1 > q0 && (q1 - 1) / rin - q0 / rin + 1 > nseg) nseg = (q1 - 1) / rin - q0 / rin + 1;
-    }
-    return nseg <= FS_SEG && (per + 2 * nseg) * (H / 4) <= FS_NW * 64 && H / 4 <= 64;
-}
-static int first_shift_rows(int C, int co, int k, int s, int H, int64_t B, int pad) {
-    const int kh = first_kh(C, co, k, s, H, H, B);
-    if (!kh || (H & 3) || pad < 0 || H + 2 * pad > 4096) return 0;
-    const int Ho = (H - k) / s + 1, Wo = Ho;
-    int best = 0;
-    double best_cost = 0.0;
-    for (int R = 1; R <= Ho; ++R) {
-        if (first_shift_lds(C, k, s, H, kh, R) > 160 * 1024) break;
-        double cost = 0.0;
-        bool ok = true;
-        for (int oy0 = 0; oy0 < Ho; oy0 += R) {   // an item costs the longer of its two halves (clocks, roughly)
-            const int rows = R < Ho - oy0 ? R : Ho - oy0, ntl = (rows * Wo + 31) / 32, rin = (rows - 1) * s + k;
-            ok = ok && first_shift_rows_ok(C, rin, H);
-            const double consume = (double)((ntl + FS_CW - 1) / FS_CW) * (C * k * kh * 64 + 600), produce = 800.0 + (double)rin * (C * H * 0.45);
-            cost += consume > produce ? consume : produce;
-        }
-        if (ok && (!best || cost <= best_cost)) { best = R; best_cost = cost; }
-    }
-    return best;
-}
-
-extern "C" int ssac_conv_first_shift_supported(int C, int co, int k, int s, int H, int64_t B, int pad) {
-    return first_shift_rows(C, co, k, s, H, B, pad);
-}
-
-extern "C" int ssac_conv_first_shift_fwd(const void *src, const int64_t *idx, const int64_t *shift, int pad, int n_aug,
-                                         const float *w, const float *bias, float *y, int B, int C, int H, int co, int k,
-                                         int s, float div, float shift_norm, void *stream) {
-    const int R = first_shift_rows(C, co, k, s, H, B, pad);
-    if (!R) return ssac_fail("ssac_conv_first_shift_fwd: geometry not supported (see ssac_conv_first_shift_supported)");
-    if (!src || !shift || ((uintptr_t)src & 3)) return ssac_fail("ssac_conv_first_shift_fwd: bad source / shift pointer");
-    if (B <= 0) return 0;
-    const int kh = first_kh(C, co, k, s, H, H, B);
-    FirstArgs g{};
-    g.w = w; g.bias = bias; g.out = y; g.div = div; g.shift = shift_norm;
-    g.B = B; g.C = C; g.Hi = H; g.Wi = H; g.co = co; g.k = k; g.s = s;
-    g.Ho = (H - k) / s + 1; g.Wo = g.Ho;
-    ShiftSrc sa{(const uint8_t *)src, idx, shift, pad, n_aug < B ? (n_aug < 0 ? 0 : n_aug) : B, R};
-    const int n_items = B * ((g.Ho + R - 1) / R);
-    const size_t lds = first_shift_lds(C, k, s, H, kh, R);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)conv_first_shift_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)conv_first_shift_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
-    const int cap = 256 / (co / 32) > 0 ? 256 / (co / 32) : 1;   // persistent: one workgroup (4 + 4 waves) per CU
-    const int gx = n_items < cap ? n_items : cap;
-    if (kh == 2)
-        SSAC_LAUNCH(conv_first_shift_fwd_kernel<2>, dim3(gx, co / 32), dim3(FS_THREADS), lds, (hipStream_t)stream, g, sa, n_items);
-    else
-        SSAC_LAUNCH(conv_first_shift_fwd_kernel<4>, dim3(gx, co / 32), dim3(FS_THREADS), lds, (hipStream_t)stream, g, sa, n_items);
-    return ssac_check_launch("conv_first_shift_fwd");
-}
 
 extern "C" int ssac_conv_first_wgrad(const float *dy, const float *img, float *partial_w, float *partial_b, int B, int C,
                                      int Hi, int Wi, int co, int k, int s, float div, float shift, int pix_per_slice,

@@ -183,6 +183,13 @@ __device__ __forceinline__ void loss_fold_issue(const LossFoldArgs &a, int e, Lo
     // compiler merged two of them into ONE store at a run-time offset -- i.e. the struct went to scratch memory, 12 bytes
     // per lane in every kernel that inlines this)
     float q = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, lp = 0.f, rew = 0.f, done = 0.f, w = 1.f, la = 0.f;
+#if defined(SSAC_LAB) && defined(SSAC_EXP_DQ_READY)
+    // (measurement build only, WRONG values: the bound of "dL/dq computed once, elsewhere" -- a GEMM workgroup reads ONE
+    //  float per row instead of evaluating the TD target: round-5 review, item 1(a))
+    if (b < n_rows) q = a.q[(int64_t)e * n_rows + b];
+    r = LossFoldRegs{q, t0, t1, t2, t3, lp, rew, done, w, la};
+    return;
+#endif
     const bool lazy = a.tds.q_t != nullptr;
     if (lazy && a.tds.use_entropy) la = a.tds.log_alpha[0];
     if (b < n_rows) {
@@ -210,6 +217,10 @@ __device__ __forceinline__ void loss_fold_finish(const LossFoldArgs &a, int e, c
     const float pw = (a.popart && a.pop) ? a.popart->w : 1.0f;
     const float pb = (a.popart && a.pop) ? a.popart->b : 0.0f;
     const float gscale = -2.0f * pw / (a.denom * (float)n_rows);
+#if defined(SSAC_LAB) && defined(SSAC_EXP_DQ_READY)
+    if (tid < n_rows) tab[tid] = gscale * r.q;
+    return;
+#endif
     const float alpha = (a.tds.q_t && a.tds.use_entropy) ? expf(r.la) : 0.0f;
     if (tid < n_rows) {
         float t = r.t0;

@@ -947,7 +947,13 @@ __device__ __forceinline__ void fused_mlp_body(const FusedArgs &g, float *smem, 
 #pragma unroll
         for (int j = 0; j < XR; ++j) {
             xrok[j] = (m0 + xr0 + 16 * j) < g.n_rows;
+#if defined(SSAC_LAB) && defined(SSAC_EXP_IDENTITY_IDX)
+            // (measurement build only, WRONG rows: the bound of a batch whose rows are known without the index load -- one
+            //  dependent load less in front of fc1: round-5 review, item 1(b))
+            gsrc[j] = gidx ? (int64_t)(m0 + xr0 + 16 * j) : 0;
+#else
             gsrc[j] = gidx ? gidx[xrok[j] ? m0 + xr0 + 16 * j : 0] : 0;
+#endif
         }
         float bv = 0.0f;  // thread t < H: b1[t]; thread 256 + t: b2[t]   (H <= 256, 512 threads)
         if (tid < H) bv = P[g.off[1] + tid];

@@ -137,8 +137,14 @@ __device__ __forceinline__ float adam_elem(float p, float g, float &m, float &v,
     if (c.weight_decay != 0.0f) g = g + c.weight_decay * p;
     m = m + (1.0f - c.beta1) * (g - m);
     v = v * c.beta2 + (1.0f - c.beta2) * g * g;
+#if defined(SSAC_LAB) && defined(SSAC_EXP_FAST_ADAM)
+    // (measurement build only: the bound of an epilogue on v_sqrt / v_rcp instead of the IEEE sequences -- NOT torch's bits)
+    const float denom = __builtin_amdgcn_sqrtf(v) * __builtin_amdgcn_rcpf(c.bc2_sqrt) + c.eps;
+    return p - c.step_size * (m * __builtin_amdgcn_rcpf(denom));
+#else
     const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
     return p - c.step_size * (m / denom);
+#endif
 }
 
 // Gradient-norm partial of one weight-gradient tile.  A layer owns ceil(M/32) x ceil(N/32) slots per net

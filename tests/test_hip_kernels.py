@@ -983,43 +983,6 @@ def test_first_layer_implicit_convolution_matches_torch_conv2d(ssa, B, C, co, k,
     _close(pb.sum(0), br.grad, 2e-4, rtol=1e-4, what="first-layer bias gradient (LDS bands)")
 
 
-@pytest.mark.parametrize("B,C,co,k,s,H,pad,div,shift", [(37, 9, 32, 3, 2, 84, 4, 255.0, -0.5), (21, 4, 32, 8, 4, 84, 4, 255.0, 0.0),
-                                                        (6, 3, 64, 4, 2, 20, 2, 255.0, 0.0), (3, 1, 32, 7, 4, 36, 12, 1.0, 0.0),
-                                                        (530, 9, 32, 3, 2, 84, 4, 255.0, -0.5)])
-def test_first_layer_with_the_shift_in_its_operand_staging(ssa, B, C, co, k, s, H, pad, div, shift):
-    """ssac_conv_first_shift_fwd (uint8 replay rows -> DrQv2 shift -> conv1, one launch, no fp32 image) against the two
-    launches it replaces, ssac_drq_shift + ssac_conv_first_fwd: BIT-identical outputs -- the same shift arithmetic per
-    pixel, the same MFMA chain per output.  Covers every draw 0 .. 2 pad (both borders clamp), un-augmented rows
-    (aug_mix), a gather index with repeats, more items than persistent workgroups, co = 64, bands with a ragged tail."""
-    rng = np.random.RandomState(B + C + k)
-    rows = 50
-    store = torch.from_numpy(rng.randint(0, 256, (rows, C, H, H)).astype(np.uint8)).to(DEV)
-    idx = torch.from_numpy(rng.randint(0, rows, B).astype(np.int64)).to(DEV)
-    sh = rng.randint(0, 2 * pad + 1, (B, 2)).astype(np.int64)
-    sh[0], sh[1 % B] = (0, 0), (2 * pad, 2 * pad)
-    shd = torch.from_numpy(sh).to(DEV)
-    w = torch.from_numpy((rng.standard_normal((co, C, k, k)) * 0.1).astype(np.float32)).to(DEV)
-    b = torch.from_numpy(rng.standard_normal(co).astype(np.float32) * 0.1).to(DEV)
-    lib, st = ssa._lib.lib, ssa.engine.stream()
-    assert lib.ssac_conv_first_shift_supported(C, co, k, s, H, B, pad) > 0
-    Ho = (H - k) // s + 1
-    for n_aug, use_idx in ((B, True), (int(0.75 * B), True), (0, False)):
-        if not use_idx and B > rows:
-            continue
-        ip = idx.data_ptr() if use_idx else 0
-        img = torch.empty(B, C, H, H, device=DEV)
-        ssa._lib.check(lib.ssac_drq_shift(store.data_ptr(), 1, ip, B, C, H, pad, shd.data_ptr(), 0, 0, n_aug, img.data_ptr(), st))
-        want = torch.empty(B, Ho, Ho, co, device=DEV)
-        ssa._lib.check(lib.ssac_conv_first_fwd(img.data_ptr(), w.data_ptr(), b.data_ptr(), want.data_ptr(), B, C, H, H, co, k,
-                                               s, div, shift, st))
-        got = torch.full((B, Ho, Ho, co), float("nan"), device=DEV)
-        ssa._lib.check(lib.ssac_conv_first_shift_fwd(store.data_ptr(), ip, shd.data_ptr(), pad, n_aug, w.data_ptr(),
-                                                     b.data_ptr(), got.data_ptr(), B, C, H, co, k, s, div, shift, st))
-        torch.cuda.synchronize()
-        assert torch.equal(got, want), (n_aug, use_idx, float((got - want).abs().max()))
-    assert lib.ssac_conv_first_shift_supported(C, co, k, s, H + 2, B, pad) == 0   # H % 4 != 0: stays on the two launches
-
-
 def test_slice_reduction_and_weight_permutation_are_exact(ssa):
     """ssac_reduce_slices_bias: slices summed in index order behind 16 loads in flight (bit-identical to the sequential
     fp32 sum, any slice count); ssac_permute_cp: the fc weight (emb, C, P) <-> channels-last (emb, P, C) through 32 x 32

@@ -174,8 +174,14 @@ def build_engine(device, n_local, shard=None, batch=None, precision="fp32", obs=
         ssa.learning.alpha_update(buffer=buf, agent=agent, optimizers=[lopt], batch_size=batch, log_alphas=[la],
                                   augmenter=aug, aug_mix=0.0, target_entropy=-float(ACT_), premade_replay_dicts=dicts,
                                   discrete=False)
+    def actor_step(dicts):
+        """the online actor update alone, on the batch of a critic update (premade_replay_dicts: main.py:489-511)"""
+        return ssa.learning.online_actor_update(buffer=buf, agent=agent, pop=False, actor_optimizer=aopt, log_alphas=[la],
+                                                batch_size=batch, clip=None, random_process=None, noise_clip=None,
+                                                augmenter=aug, aug_mix=0.0, premade_replay_dicts=dicts)
     # (tests/test_hip_bench_bridge.py drives this very closure and compares it with the oracle)
-    step.objects = dict(agent=agent, target=target, buffer=buf, critic_optimizer=copt, log_alpha=la, state=state)
+    step.objects = dict(agent=agent, target=target, buffer=buf, critic_optimizer=copt, log_alpha=la, state=state,
+                        actor_step=actor_step)
     return step, env_step, ssa
 
 
@@ -547,6 +553,8 @@ def main():
             del step, env_step
             # ---- latency of the acting path (what an environment step pays before the updates)
             secondary["acting"] = acting_rows(device)
+            # ---- the online actor update alone (UTD-1 configurations: it is ~60 % of an environment step's device time)
+            secondary["actor_update"] = actor_update_rows(device)
             # ---- the N = 1 anchors of the scaling target's configurations (BASELINE.json: ">= 3.5x at 8 vs 1 GPU for N = 16";
             #      `bench.py --gpus 8 --critics 16 [--obs 376 --act 17]` measures the other end when an 8-GPU node runs it)
             secondary["scaling_anchors_n16_1gpu"] = n16_rows(device)
@@ -647,6 +655,24 @@ def acting_rows(device):
         del ag
     return {"what": "Agent.sample_action / Agent.forward, numpy observation in -> numpy action out (H2D + launches + D2H), "
                     "wall clock per call, 300 calls after 30 warm-up calls", "rows": rows}
+
+
+def actor_update_rows(device):
+    """the online actor update (learning.py:344-421) alone -- what a UTD-1 configuration pays per environment step beside
+    its critic update -- at the headline shape and at the Humanoid shape (BASELINE config 5), recorded launch list, on the
+    fixed batch buffers of a critic update"""
+    rows = {}
+    for label, obs, act, ncrit in (("M_obs17_act6_N10", 17, 6, 10), ("humanoid_obs376_act17_N16", 376, 17, 16)):
+        st, _, _ = build_engine(device, ncrit, None, batch=512, obs=obs, act=act, ncrit=ncrit)
+        for _ in range(5):
+            dicts = st()
+        actor = st.objects["actor_step"]
+        for _ in range(30):
+            actor(dicts)
+        t = statistics.median(timed_repeats(lambda: actor(dicts), 500, 3, None, device)) / 500
+        rows[label] = {"batch": 512, "us_per_actor_update": round(t * 1e6, 2)}
+        del st, actor, dicts
+    return rows
 
 
 def n16_rows(device):

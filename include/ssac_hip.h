@@ -157,6 +157,8 @@ int ssac_replay(ssac_launch_list *list, void *stream);
 /* the same for a list with launches that are NUMBERED per update (ssac_actor_chain_fused's update_no): `value` >= 0 takes
  * the place of the number they were recorded with */
 int ssac_replay_value(ssac_launch_list *list, void *stream, long long value);
+/* ... and a second number, >= 0: the slot of a ring that a recorded launch writes its result to (ssac_actor_logs) */
+int ssac_replay_value2(ssac_launch_list *list, void *stream, long long value, long long value2);
 void ssac_launch_list_free(ssac_launch_list *list);
 
 /* ---- one host call per recorded update.  A step owns the host side of a recorded critic update whose per-update
@@ -717,8 +719,12 @@ int ssac_actor_bwd_fused(const ssac_mlp *actor, const float *H1, const float *H2
                          const float *log_alpha, int use_entropy, float log_std_lo, float log_std_hi, float inv_members,
                          const ssac_popart *popart, int pop, float *d_out, float *DZ2, float *DZ1, float *partials,
                          void *stream);
+/* ring != NULL (round 6): the finished block (`width` floats at `block`, logs_loss / logs_gn pointing into it) is also written
+ * to slot `ring_slot` of the log ring (ring + ring_slot * width) by this launch; in a RECORDED launch the slot is the
+ * second number of ssac_replay_value2 -- no copy behind the replay. */
 int ssac_actor_logs(const float *partials, int n_tiles, int n_rows, float inv_members, const float *sumsq, int n_sumsq,
-                    float *logs_loss, float *logs_gn, void *stream);
+                    float *logs_loss, float *logs_gn, const float *block, int width, float *ring, long long ring_slot,
+                    void *stream);
 /* The fused actor update on a CRITIC-SHARDED rank (SURVEY 8(e) "Collective -- actor step": a MIN over (B,) and a SUM over
  * (B x A)): between ssac_critic_fwd_dx_fused on the rank's own critics and ssac_actor_bwd_fused with n_critics = 1 --
  *   ssac_actor_route_local  q_local[b] = min over the local critics (and a copy, q_reduce, for the MIN all-reduce),

@@ -98,6 +98,7 @@ SIGNATURES = {
     "ssac_polyak_multi": [_P, _P, _P, _I, _F, _P],
     "ssac_replay": [_P, _P],
     "ssac_replay_value": [_P, _P, C.c_longlong],
+    "ssac_replay_value2": [_P, _P, C.c_longlong, C.c_longlong],
     "ssac_launch_list_free": [_P],
     "ssac_xchg_create": [C.c_int, C.c_int, C.c_int, C.c_int],
     "ssac_xchg_handle_bytes": [],
@@ -220,7 +221,7 @@ SIGNATURES = {
     "ssac_actor_sample_concat_fused": [_MP, _P, _L, _I, _P, _F, _F, _P, _L, _P, _P, _P, _P, _P, _P],
     "ssac_critic_fwd_dx_fused": [_MP, _P, _L, _I, _I, _I, _P, _P, _P],
     "ssac_actor_bwd_fused": [_MP, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P, _I, _F, _F, _F, _P, _I, _P, _P, _P, _P, _P],
-    "ssac_actor_logs": [_P, _I, _I, _F, _P, _I, _P, _P, _P],
+    "ssac_actor_logs": [_P, _I, _I, _F, _P, _I, _P, _P, _P, _I, _P, C.c_longlong, _P],
     "ssac_actor_route_local": [_P, _P, _I, _I, _I, _P, _P, _P, _P],
     "ssac_actor_route_claim": [_P, _P, _I, _I, _P, _P],
     "ssac_actor_route_mask": [_P, _I, _I, _I, _P, _P],

@@ -1509,24 +1509,45 @@ extern "C" int ssac_actor_route_mask(const float *claim, int rank, int n_rows, i
 __global__ __launch_bounds__(RED_THREADS) void actor_logs_kernel(const float *__restrict__ partials, int n_tiles,
                                                                 int n_rows, float inv_members,
                                                                 const float *__restrict__ sumsq, int n_ss,
-                                                                float *logs_loss, float *logs_gn) {
+                                                                float *logs_loss, float *logs_gn, const float *block,
+                                                                int width, float *publish_dst) {
     __shared__ float scratch[16];
+    __shared__ float fin[2];
     float s = 0.f, ss = 0.f;
     for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) s += partials[i];
     for (int i = threadIdx.x; i < n_ss; i += blockDim.x) ss += sumsq[i];
     s = block_reduce<0>(s, scratch);
     ss = block_reduce<0>(ss, scratch);
     if (threadIdx.x == 0) {
-        if (logs_loss) logs_loss[0] += -inv_members * s / (float)n_rows;
-        if (logs_gn) logs_gn[0] = sqrtf(ss);
+        const float loss = (logs_loss ? logs_loss[0] : 0.0f) + -inv_members * s / (float)n_rows, gn = sqrtf(ss);
+        if (logs_loss) logs_loss[0] = loss;
+        if (logs_gn) logs_gn[0] = gn;
+        fin[0] = loss; fin[1] = gn;
+    }
+    // publish_dst (recorded update of a single-member agent): the finished log block -> its slot of the log ring in THIS
+    // launch -- the two values just computed from LDS, the rest of the block as it stands -- instead of a copy launch behind
+    // every replay
+    if (publish_dst) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < width; i += blockDim.x) {
+            float v = block[i];
+            if (logs_loss && block + i == logs_loss) v = fin[0];
+            if (logs_gn && block + i == logs_gn) v = fin[1];
+            publish_dst[i] = v;
+        }
     }
 }
 
 extern "C" int ssac_actor_logs(const float *partials, int n_tiles, int n_rows, float inv_members, const float *sumsq,
-                               int n_sumsq, float *logs_loss, float *logs_gn, void *stream) {
+                               int n_sumsq, float *logs_loss, float *logs_gn, const float *block, int width, float *ring,
+                               long long ring_slot, void *stream) {
     if (!partials || n_tiles <= 0 || n_rows <= 0) return ssac_fail("ssac_actor_logs: bad arguments");
+    if (ring && (!block || width <= 0 || ring_slot < 0)) return ssac_fail("ssac_actor_logs: a ring needs the block, its width and a slot");
+    float *dst = ring ? ring + ring_slot * width : nullptr;
     SSAC_LAUNCH(actor_logs_kernel, dim3(1), dim3(RED_THREADS), 0, ST, partials, n_tiles, n_rows, inv_members, sumsq,
-                sumsq ? n_sumsq : 0, logs_loss, logs_gn);
+                sumsq ? n_sumsq : 0, logs_loss, logs_gn, block, width, dst);
+    // recorded: every replay names its own slot (ssac_replay_value2's second number)
+    if (ring) ssac_record_value_patch(10, 0, 2, (long long)(uintptr_t)ring, (long long)width * 4);
     return ssac_check_launch("actor_logs");
 }
 
@@ -1686,7 +1707,8 @@ extern "C" int ssac_launch_list_size(const ssac_launch_list *list) { return list
 // slot_now: the address of this update's slot of the input ring for the argument members registered with
 // ssac_record_slot_patch (ssac_step_run), or null: the kernels find the slot through the feed block.
 // value: this update's number for the members registered with ssac_record_value_patch (has_value: ssac_replay_value)
-static int replay_list(ssac_launch_list *list, void *stream, const void *slot_now, bool has_value, long long value) {
+static int replay_list(ssac_launch_list *list, void *stream, const void *slot_now, bool has_value, long long value,
+                       long long value2 = -1) {
     void *argv[64];
     for (SsacLaunchRec &r : list->recs) {
         if (r.offsets.size() > 64) return ssac_fail("ssac_replay: too many kernel arguments");
@@ -1697,6 +1719,10 @@ static int replay_list(ssac_launch_list *list, void *stream, const void *slot_no
             if (vp.kind == 0) {
                 const uint32_t v = (uint32_t)((value + vp.addend) & 0x7fffffff);
                 memcpy(r.blob.data() + vp.off, &v, 4);
+            } else if (vp.kind == 2) {
+                if (value2 < 0) return ssac_fail("ssac_replay: this list holds a launch that writes into a ring slot: replay it with ssac_replay_value2");
+                const long long v = vp.addend + value2 * vp.stride;
+                memcpy(r.blob.data() + vp.off, &v, 8);
             } else {
                 const long long v = value + vp.addend;
                 memcpy(r.blob.data() + vp.off, &v, 8);
@@ -1718,6 +1744,12 @@ extern "C" int ssac_replay_value(ssac_launch_list *list, void *stream, long long
     if (!list) return ssac_fail("ssac_replay_value: null launch list");
     if (value < 0) return ssac_fail("ssac_replay_value: the per-update value must not be negative");
     return replay_list(list, stream, nullptr, true, value);
+}
+
+extern "C" int ssac_replay_value2(ssac_launch_list *list, void *stream, long long value, long long value2) {
+    if (!list) return ssac_fail("ssac_replay_value2: null launch list");
+    if (value < 0 || value2 < 0) return ssac_fail("ssac_replay_value2: the per-update values must not be negative");
+    return replay_list(list, stream, nullptr, true, value, value2);
 }
 
 extern "C" void ssac_launch_list_free(ssac_launch_list *list) { delete list; }

@@ -1854,16 +1854,19 @@ __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(4, 4))) vo
 //     arrives, rank-A update, fc2, head, the unscaled backward, dQ/da) -- Q and dQ/da go out as granules.
 // Actor workgroups hold the lowest ids: they are resident before any critic tile can wait for them, and while they wait
 // for the critics they block nobody (a launch of more critic tiles than CUs drains behind them).
-template <int TC>
+// ADBUF = false (round 6): the ACTOR's two passes with a single weight-staging buffer -- a wide input together with a wide
+// head (Humanoid's 376 -> 256 -> 34: 35 KB of W3 resident beside a 384-column x tile) leaves no room for the second one;
+// the critics' tiles keep theirs.  Same arithmetic, same order: the carve only decides how far ahead the weights stream.
+template <int TC, bool ADBUF = true>
 __global__ __launch_bounds__(NTHR) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void fused_actor_chain_kernel(FusedArgs ga, FusedArgs gb, FusedArgs gc, int tiles_a, int critic_grid_x) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int bid = blockIdx.x;
     if (bid < tiles_a) {
-        fused_mlp_body<MODE_SAMPLE, 16, true>(ga, smem, bid, 0, tiles_a, -1);
+        fused_mlp_body<MODE_SAMPLE, 16, ADBUF>(ga, smem, bid, 0, tiles_a, -1);
         __threadfence_block();  // this workgroup's h1 / h2 / head-output rows (global) are read back by its backward half
         __syncthreads();
-        fused_mlp_body<MODE_ACTOR_BWD, 16, true, true>(gb, smem, bid, 0, tiles_a, -1);
+        fused_mlp_body<MODE_ACTOR_BWD, 16, ADBUF, true>(gb, smem, bid, 0, tiles_a, -1);
     } else {
         const int L = ssac_xcd_contiguous_range(bid, tiles_a, (int)gridDim.x, gc.xcd);
         fused_mlp_body<MODE_CRITIC_U, TC, true, true>(gc, smem, L % critic_grid_x, L / critic_grid_x, critic_grid_x, -1);
@@ -2388,8 +2391,9 @@ extern "C" int ssac_actor_chain_fused(const ssac_mlp *actor, const float *X, int
                                       float *partials, unsigned long long *handoff, long long update_no,
                                       float *begin_logs, int n_logs, ssac_adam_ctl *begin_ctl, void *stream) {
     if (!eps && !rng) return ssac_fail("ssac_actor_chain_fused: neither eps nor an rng stream given");
-    if (!fused_dbuf_ok(actor) || (actor->out_dim & 1) || !fused_dbuf_ok(critics) || critics->out_dim != 1)
+    if (!fused_ok(actor) || (actor->out_dim & 1) || !fused_dbuf_ok(critics) || critics->out_dim != 1)
         return ssac_fail("ssac_actor_chain_fused: shape not supported by the chained launch");
+    const bool adbuf = fused_dbuf_ok(actor);   // (false: the actor's passes stream their weights through ONE staging buffer)
     const int A = actor->out_dim / 2, S = actor->in_dim;
     if (critics->in_dim != S + A || A > 32 || critics->hidden * A > NTHR * HANDOFF_MAX_WA)
         return ssac_fail("ssac_actor_chain_fused: critic input is not [s | a] / too many action columns");
@@ -2429,13 +2433,14 @@ extern "C" int ssac_actor_chain_fused(const ssac_mlp *actor, const float *X, int
     // chip (one workgroup per CU at this LDS carve), or the critics they wait for could not start.  Half the CUs at most.
     if (tiles_a > SSAC_ACTOR_CHAIN_MAX_ROWS / 16)
         return ssac_fail("ssac_actor_chain_fused: more than SSAC_ACTOR_CHAIN_MAX_ROWS batch rows (use the three launches)");
-    size_t lds = fused_lds_bytes(actor->in_dim, actor->hidden, actor->out_dim, 16, true);
+    size_t lds = fused_lds_bytes(actor->in_dim, actor->hidden, actor->out_dim, 16, adbuf);
     const size_t lc = fused_lds_bytes(critics->in_dim, critics->hidden, critics->out_dim, tc, true);
     if (lc > lds) lds = lc;
     if (lds > 160 * 1024) return ssac_fail("ssac_actor_chain_fused: LDS carve does not fit");
     static bool attr_set = false;
     if (!attr_set) {
-        const void *ks[2] = {(const void *)fused_actor_chain_kernel<16>, (const void *)fused_actor_chain_kernel<32>};
+        const void *ks[4] = {(const void *)fused_actor_chain_kernel<16>, (const void *)fused_actor_chain_kernel<32>,
+                             (const void *)fused_actor_chain_kernel<16, false>, (const void *)fused_actor_chain_kernel<32, false>};
         for (const void *k : ks)
             if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return ssac_fail("fused_actor_chain: cannot raise the dynamic LDS limit");
@@ -2443,8 +2448,10 @@ extern "C" int ssac_actor_chain_fused(const ssac_mlp *actor, const float *X, int
     }
     const dim3 grid(tiles_a + cgx * N);
     hipStream_t st = (hipStream_t)stream;
-    if (tc == 16) SSAC_LAUNCH((fused_actor_chain_kernel<16>), grid, dim3(NTHR), lds, st, ga, gb, gc, tiles_a, cgx);
-    else SSAC_LAUNCH((fused_actor_chain_kernel<32>), grid, dim3(NTHR), lds, st, ga, gb, gc, tiles_a, cgx);
+    if (tc == 16 && adbuf) SSAC_LAUNCH((fused_actor_chain_kernel<16>), grid, dim3(NTHR), lds, st, ga, gb, gc, tiles_a, cgx);
+    else if (adbuf) SSAC_LAUNCH((fused_actor_chain_kernel<32>), grid, dim3(NTHR), lds, st, ga, gb, gc, tiles_a, cgx);
+    else if (tc == 16) SSAC_LAUNCH((fused_actor_chain_kernel<16, false>), grid, dim3(NTHR), lds, st, ga, gb, gc, tiles_a, cgx);
+    else SSAC_LAUNCH((fused_actor_chain_kernel<32, false>), grid, dim3(NTHR), lds, st, ga, gb, gc, tiles_a, cgx);
     if (update_no >= 0) {   // (recorded: a replay's number replaces update_no in the tag and in the noise draw)
         for (int a = 0; a < 3; ++a) ssac_record_value_patch(a, offsetof(FusedArgs, ho) + offsetof(Handoff, base), 0, 1);
         if (rng && !rng->counter)

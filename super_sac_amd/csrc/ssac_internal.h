@@ -32,8 +32,10 @@ struct SsacLaunchRec {
     std::vector<size_t> slot_patches;
     // ... and of integers that a replay through ssac_replay_value overwrites with (value + addend): the per-update number
     // a launch derives its hand-off tag and its noise draw from, when the update has no device-resident counter
-    // (ssac_record_value_patch below).  kind 0: uint32, (value + addend) & 0x7fffffff; kind 1: int64
-    struct ValuePatch { size_t off; int kind; long long addend; };
+    // (ssac_record_value_patch below).  kind 0: uint32, (value + addend) & 0x7fffffff; kind 1: int64 value + addend;
+    // kind 2: a POINTER, addend + value2 * stride -- the replay's SECOND number (ssac_replay_value2) picks a slot of a ring
+    // (the online actor update's log block goes straight to its slot of the log ring: no copy behind the replay)
+    struct ValuePatch { size_t off; int kind; long long addend; long long stride; };
     std::vector<ValuePatch> value_patches;
 };
 
@@ -80,10 +82,10 @@ inline void ssac_record_slot_patch(int arg_index, size_t member_off) {
     SsacLaunchRec &r = g_ssac_recording->back();
     r.slot_patches.push_back(r.offsets[(size_t)arg_index] + member_off);
 }
-inline void ssac_record_value_patch(int arg_index, size_t member_off, int kind, long long addend) {
+inline void ssac_record_value_patch(int arg_index, size_t member_off, int kind, long long addend, long long stride = 0) {
     if (!g_ssac_recording || g_ssac_recording->empty()) return;
     SsacLaunchRec &r = g_ssac_recording->back();
-    r.value_patches.push_back(SsacLaunchRec::ValuePatch{r.offsets[(size_t)arg_index] + member_off, kind, addend});
+    r.value_patches.push_back(SsacLaunchRec::ValuePatch{r.offsets[(size_t)arg_index] + member_off, kind, addend, stride});
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -941,14 +941,22 @@ def _critic_update_eager(buffer, agent, target_agent, critic_optimizer, encoder_
     return logs, replay_dicts
 
 
-def _actor_chain_form(a_arena, A, B):
+def _actor_chain_form(a_arena, A, B, c_arena):
     """does this member's online actor update take the chained launch (ssac_actor_chain_fused)?  ONE predicate for the
     launch selection in _online_actor_update and for the recording's choice of noise source in online_actor_update: a
-    member on the three-launch form (e.g. Humanoid's 376 -> 256 -> 34 actor, whose double-buffered LDS carve does not fit)
-    reads its noise from a buffer, which a recording must own and refill before every replay.
+    member on the three-launch form reads its noise from a buffer, which a recording must own and refill before every replay.
     (B <= 2048 = SSAC_ACTOR_CHAIN_MAX_ROWS: the chained launch's actor workgroups wait for critic tiles dispatched behind
-    them and must leave them CUs to run on)"""
-    return bool(ACTOR_CHAIN and a_arena.fused_dbuf and A <= 32 and a_arena.hidden * A <= 512 * 9 and B <= 2048)
+    them and must leave them CUs to run on.)
+    Round 6: an actor whose carve holds only ONE weight-staging buffer (Humanoid's 376 -> 256 -> 34) can take the chained
+    launch too, its two passes single-buffered -- `fused`, not `fused_dbuf` -- and the form is taken only while the launch
+    is ONE RESIDENT ROUND (actor tiles + critic tiles <= 256 workgroups).  Measured: Humanoid with N = 16 critics is 32 + 512
+    workgroups; the actor workgroups then sit on 32 CUs through two and a half rounds of critic tiles and the chained launch
+    is SLOWER than the three launches, 177.2 against 162.8 us per actor update (profiles/r6_kernel_stats.md)."""
+    if not (ACTOR_CHAIN and a_arena.fused and A <= 32 and a_arena.hidden * A <= 512 * 9 and B <= 2048 and c_arena.fused_dbuf
+            and c_arena.out_dim == 1):
+        return False
+    tiles_c = int(lib.ssac_fused_row_tiles(C.byref(c_arena.desc()), B, c_arena.n_nets)) * c_arena.n_nets
+    return (B + 15) // 16 + tiles_c <= 256
 
 
 def _actor_fused_member(kind, random_process, use_baseline, clip, a_arena, c_arena):
@@ -975,8 +983,8 @@ def _actor_noise_in_kernel(agent, batch_size, dev):
     if key not in memo:
         if len(memo) > 16:
             memo.clear()
-        memo[key] = all(_actor_chain_form(engine.bind_arena(a_, "self", [a_], dev), a_.action_size, batch_size)
-                        for a_ in agent.actors)
+        memo[key] = all(_actor_chain_form(engine.bind_arena(a_, "self", [a_], dev), a_.action_size, batch_size, c_.arena(dev))
+                        for a_, c_ in zip(agent.actors, agent.critics))
     return memo[key]
 
 
@@ -984,6 +992,7 @@ class _RecordedActor:
     def __init__(self):
         self.calls, self.list, self.blk, self.eps, self.index = 0, None, None, None, None
         self.in_kernel = False
+        self.published = False
 
     def __del__(self):
         if self.list:
@@ -1041,28 +1050,35 @@ def online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_s
     if rec.eps is not None:
         for e_ in rec.eps:
             rng.draw_normal_into(e_)  # a_dist.rsample() of every member, in member order (learning.py:392)
+    slot_i = ring.advance()   # this call's slot of the log ring
     if rec.list is None:
+        pub = {"buf": ring.buf, "slot": slot_i, "published": False}
         check(lib.ssac_record_begin())
         try:
-            logs = _online_actor_update(**kw, _rec_blk=rec.blk, _rec_eps=rec.eps)
+            logs = _online_actor_update(**kw, _rec_blk=rec.blk, _rec_eps=rec.eps, _rec_ring=pub)
         finally:
             rec.list = lib.ssac_record_end()
+        rec.published = pub["published"]   # (the log launch writes the ring slot itself: single-member agents)
         base = rec.blk.data_ptr()
         rec.index = {k_: (v.data_ptr() - base) // 4 for k_, v in logs.items()}
     else:
         ns_upd = lu.noise_stream(agent, dev)
-        check(lib.ssac_replay_value(rec.list, engine.stream(), ns_upd[2]))   # (this update's number: tags, noise draws)
+        # (this update's number: tags, noise draws -- and, when the log launch publishes, the ring slot it writes)
+        if rec.published:
+            check(lib.ssac_replay_value2(rec.list, engine.stream(), ns_upd[2], slot_i))
+        else:
+            check(lib.ssac_replay_value(rec.list, engine.stream(), ns_upd[2]))
         ns_upd[2] += 1
         rng.choice(agent.actors)  # learning.py:417-419 (keeps the Python RNG stream in step)
-    slot_i = ring.advance()
-    ring.buf[slot_i].copy_(rec.blk)   # this call's log block -> its own ring slot (device-to-device, no sync)
+    if not rec.published:
+        ring.buf[slot_i].copy_(rec.blk)   # this call's log block -> its own ring slot (device-to-device, no sync)
     blk = ring.buf[slot_i]
     return {k_: blk[i] for k_, i in rec.index.items()}
 
 
 def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_size, clip,
                          random_process, noise_clip, augmenter, aug_mix, premade_replay_dicts=None,
-                         per=False, discrete=False, use_baseline=False, _rec_blk=None, _rec_eps=None):
+                         per=False, discrete=False, use_baseline=False, _rec_blk=None, _rec_eps=None, _rec_ring=None):
     E = agent.ensemble_size
     dev = log_alphas[0].device
     ws = lu.agent_ws(agent, dev)
@@ -1101,7 +1117,7 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             ar0_, cr0_ = engine.bind_arena(a0_, "self", [a0_], dev), c0_.arena(dev)
             owner_in_kernel = (_actor_fused_member(lu.actor_kind(a0_), random_process, use_baseline, clip, ar0_, cr0_)
                                and parallel.shard_of(agent) is None
-                               and _member_noise_in_kernel(_actor_chain_form(ar0_, a0_.action_size, batch_size), _rec_eps))
+                               and _member_noise_in_kernel(_actor_chain_form(ar0_, a0_.action_size, batch_size, cr0_), _rec_eps))
             if not owner_in_kernel:
                 lu.skip_actor_draws(agent.actors[0], batch_size, dev, random_process)
             continue
@@ -1165,9 +1181,15 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             engine.weight_grads(a_arena, s_rep, lds, 0, ah1, ah2, d_out, dz2, dz1, B, adam=adam,
                                 adam_key=("actor", i), sumsq=ss)
             one = E_glob == 1
+            # (a recorded update of a single-member agent: this launch also writes the finished block to its slot of the log
+            #  ring -- the replay names the slot, ssac_replay_value2 -- instead of a copy launch behind every replay)
+            pub = _rec_ring if (one and _rec_ring is not None and _rec_blk is not None) else None
             check(lib.ssac_actor_logs(parts.data_ptr(), tiles, B, inv_e, ss.data_ptr() if one else 0, ss.numel(),
                                       slot[lu.L_ACTOR_LOSS:].data_ptr(), slot[lu.L_ACTOR_GN:].data_ptr() if one else 0,
-                                      st))
+                                      slot.data_ptr(), lu.LOG_WIDTH, pub["buf"].data_ptr() if pub else 0,
+                                      pub["slot"] if pub else 0, st))
+            if pub is not None:
+                pub["published"] = True
             member_ss.append(None if one else ss)
             continue
         if fused_member and shard is None:
@@ -1182,7 +1204,7 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             # the noise: with the stock generator the chained launch takes it from the engine's Philox stream INSIDE the
             # kernel (draw number = this update's number: no generator launch, no buffer); otherwise a draw -- into the
             # recording's fixed buffer, or a fresh one -- as a_dist.rsample() makes it (learning.py:392)
-            chain = _actor_chain_form(a_arena, A, B)
+            chain = _actor_chain_form(a_arena, A, B, c_arena)
             in_kernel = _member_noise_in_kernel(chain, _rec_eps)
             eps = None   # (kept alive to the end of the member's launches: the kernels read it asynchronously)
             if in_kernel:
@@ -1237,9 +1259,15 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             engine.weight_grads(a_arena, s_rep, lds, 0, ah1, ah2, d_out, dz2, dz1, B, adam=adam,
                                 adam_key=("actor", i), sumsq=ss)
             one = E_glob == 1   # (then the logged actor is this one: both logs in one launch)
+            # (a recorded update of a single-member agent: this launch also writes the finished block to its slot of the log
+            #  ring -- the replay names the slot, ssac_replay_value2 -- instead of a copy launch behind every replay)
+            pub = _rec_ring if (one and _rec_ring is not None and _rec_blk is not None) else None
             check(lib.ssac_actor_logs(parts.data_ptr(), tiles, B, inv_e, ss.data_ptr() if one else 0, ss.numel(),
                                       slot[lu.L_ACTOR_LOSS:].data_ptr(), slot[lu.L_ACTOR_GN:].data_ptr() if one else 0,
-                                      st))
+                                      slot.data_ptr(), lu.LOG_WIDTH, pub["buf"].data_ptr() if pub else 0,
+                                      pub["slot"] if pub else 0, st))
+            if pub is not None:
+                pub["published"] = True
             member_ss.append(None if one else ss)
             continue
         ah1, ah2, aout = engine.mlp_forward(a_arena, s_rep, lds, 0, B, ws, f"au.a{i}")

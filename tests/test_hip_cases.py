@@ -776,7 +776,7 @@ def test_full_size_pixel_critic_update_implicit_vs_im2col(which, monkeypatch):
         assert float(np.median(err)) <= 1e-6 and float(err.max()) <= 2 * lr * n_upd, (key, float(np.median(err)), float(err.max()))
 
 
-def _actor_update_run(chained, hook=True, n_upd=8):
+def _actor_update_run(chained, hook=True, n_upd=8, shape=(256, 17, 6, 4, 64)):
     import copy, math, random
     import ctypes as C
     from itertools import chain
@@ -785,7 +785,7 @@ def _actor_update_run(chained, hook=True, n_upd=8):
     from case_runner import straggler_check
     L, lu = ssa.learning, ssa.learning_utils
     dev = torch.device("cuda")
-    B, S, A, N = 256, 17, 6, 4
+    B, S, A, N, H = shape
 
     if True:
         old = (L.ACTOR_CHAIN, ssa.rng.draw_normal, ssa.rng.draw_normal_into)
@@ -799,8 +799,11 @@ def _actor_update_run(chained, hook=True, n_upd=8):
             agent = ssa.Agent(act_space_size=A, encoder=ssa.nets.IdentityEncoder(S),
                               actor_network_cls=ssa.nets.ContinuousStochasticActor,
                               critic_network_cls=ssa.nets.ContinuousCritic, ensemble_size=1, num_critics=N,
-                              hidden_size=64, auto_rescale_targets=False, log_std_low=-5.0, log_std_high=2.0)
+                              hidden_size=H, auto_rescale_targets=False, log_std_low=-5.0, log_std_high=2.0)
             agent.to(dev)
+            if chained:
+                a_arena = ssa.engine.bind_arena(agent.actors[0], "self", [agent.actors[0]], dev)
+                assert L._actor_chain_form(a_arena, A, B, agent.critics[0].arena(dev)), "this shape is meant to take the chained launch"
             target = copy.deepcopy(agent)
             buf = ssa.replay.ReplayBuffer(4096, device=dev)
             buf.load_experience(*synth.synth_transitions(2000, S, A, seed=5))
@@ -826,7 +829,7 @@ def _actor_update_run(chained, hook=True, n_upd=8):
                     ws = agent.__dict__["_ssac_ws"]   # (the update's own workspace)
                     first = {n_: ws.get(n_, sh).detach().cpu().numpy().copy() for n_, sh in
                              (("au.c0.y", (N, B, 1)), ("au.dxu0", (N, B, A)), ("au.dout0", (1, B, 2 * A)),
-                              ("au.a0.dz1", (1, B, 64)), ("au.x0", (B, S + A)), ("au.a0.y", (1, B, 2 * A)))}
+                              ("au.a0.dz1", (1, B, H)), ("au.x0", (B, S + A)), ("au.a0.y", (1, B, 2 * A)))}
             params = torch.cat([p.detach().flatten() for p in agent.actors[0].parameters()]).cpu().numpy()
             return first, logs, params, agent, ws
         finally:
@@ -834,8 +837,9 @@ def _actor_update_run(chained, hook=True, n_upd=8):
 
 
 def test_recorded_actor_update_off_the_chained_form_owns_and_refills_its_noise():
-    """Round-4 advisor (high): Humanoid's actor (376 -> 256 -> 34) is fused but its double-buffered LDS carve does not fit,
-    so its online actor update takes the THREE-launch form -- which reads its noise from a buffer.  The recording decided
+    """Round-4 advisor (high): an actor whose online update takes the THREE-launch form reads its noise from a buffer (until
+    round 6 that was Humanoid's 376 -> 256 -> 34 actor, whose double-buffered LDS carve does not fit; it takes the chained
+    launch single-buffered now, so the form is forced here: learning.ACTOR_CHAIN = False).  The recording decided
     "in-kernel noise" from the generator alone and recorded the address of a temporary: every replay then re-read freed
     memory (frozen or arbitrary noise), silently.  Now the predicate is per member (learning._actor_chain_form): the
     recording owns fixed buffers, refills them before every replay, and an allocation inside a recording asserts.
@@ -863,7 +867,16 @@ def test_recorded_actor_update_off_the_chained_form_owns_and_refills_its_noise()
     la = torch.Tensor([math.log(0.1)]).to(dev); la.requires_grad = True
     aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(B)])
     a_arena = ssa.engine.bind_arena(agent.actors[0], "self", [agent.actors[0]], dev)
-    assert a_arena.fused and not L._actor_chain_form(a_arena, A, B), "this shape is meant to miss the chained launch"
+    old_chain, L.ACTOR_CHAIN = L.ACTOR_CHAIN, False
+    try:
+        assert a_arena.fused and not L._actor_chain_form(a_arena, A, B, agent.critics[0].arena(dev)), "the three-launch form is forced here"
+        _off_chain_body(L, ssa, agent, target, buf, copt, aopt, eopt, la, aug, B, S, A)
+    finally:
+        L.ACTOR_CHAIN = old_chain
+
+
+def _off_chain_body(L, ssa, agent, target, buf, copt, aopt, eopt, la, aug, B, S, A):
+    import torch
     for _ in range(4):
         _, dicts = L.critic_update(
             buffer=buf, agent=agent, target_agent=target, critic_optimizer=copt, encoder_optimizer=eopt, log_alphas=[la],
@@ -907,6 +920,17 @@ def test_actor_update_chained_launch_matches_three_launches():
     dev = torch.device("cuda")
     B, S, A, N = 256, 17, 6, 4
     run = _actor_update_run
+    # Round 6: Humanoid's actor (376 -> 256 -> 34: a 384-column x tile beside 35 KB of W3 leaves room for ONE weight-staging
+    # buffer) takes the chained launch too, its two passes single-buffered (fused_actor_chain_kernel<.., ADBUF = false>),
+    # the critics (393 -> 256 -> 1) as 16-row tiles: against the three launches, same injected noise
+    hum = (128, 376, 17, 3, 256)
+    f3h, l3h, p3h, _, _ = run(False, shape=hum)
+    fch, lch, pch, _, _ = run(True, shape=hum)
+    for n_ in f3h:
+        scale = max(1.0, float(np.abs(f3h[n_]).max()))
+        np.testing.assert_allclose(fch[n_], f3h[n_], rtol=0, atol=3e-5 * scale, err_msg="humanoid shape: " + n_)
+    np.testing.assert_allclose(np.array(lch), np.array(l3h), rtol=2e-4, atol=1e-6)
+    straggler_check(np.abs(pch - p3h), 3e-5, 8 * 2 * 3e-4 * 1.01, "chained actor update (Humanoid shape)", "actor parameters")
     f3, l3, p3, _, _ = run(False)
     fc, lc, pc, _, _ = run(True)
     for n_ in f3:

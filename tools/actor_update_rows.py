@@ -1,7 +1,7 @@
 """The online actor update alone (learning.py:344-421 of the reference) at a bench_configs shape:
     python tools/actor_update_rows.py <obs> <act> <B> <N> [updates]      (GPU box)
 us per actor update, recorded launch list, on the batch of one critic update (premade_replay_dicts, as redq.gin runs it).
-Under rocprofv3 --kernel-trace it gives the per-launch breakdown (tools/prof_r4.sh D)."""
+Under rocprofv3 --kernel-trace it gives the per-launch breakdown (rocprofv3 --kernel-trace --stats -- python3 tools/actor_update_rows.py 17 6 512 10)."""
 import os, sys, time
 sys.argv, args = sys.argv[:1], sys.argv[1:]
 sys.argv.append("__none__")

@@ -995,6 +995,12 @@ void ssac_act_destroy(ssac_act *a);
  * act (n_rows x act_dim) = columns [col0, col0 + act_dim) of X's row (best n_rows + b), clamped to [-1, 1]. */
 int ssac_ucb_select(const float *const *q_members, int n_members, int n_nets, int n_cand, int n_rows, float bonus,
                     const float *X, int64_t ldx, int col0, int act_dim, float *act, void *stream);
+/* the UCB rule's candidates from the head outputs of n_actors PACKED actors (outs: n_actors x n_rows x 2 act_dim, one
+ * ssac_mlp3_fwd_fused over the pack): row (e n_rows + b) of X = [S_rows[b] | tanh(mu + sd eps)], eps = element (b, i) of `rng`'s
+ * stream at draw rng->offset + e member_stride (+ *rng->counter) -- what ssac_actor_sample_concat_fused with that offset draws */
+int ssac_act_candidates(const float *outs, int n_actors, int n_rows, int act_dim, const float *S_rows, int64_t lds,
+                        int state_dim, float log_std_lo, float log_std_hi, const ssac_rng *rng, long long member_stride,
+                        float *X, int64_t ldx, void *stream);
 /* greedy continuous action (agent.py:204-246): act = clamp(mean over the actors of tanh(outs[e][b][k]), -1, 1) */
 int ssac_act_mean_tanh(const float *const *outs, int n_actors, int64_t ld_out, int n_rows, int act_dim, float *act,
                        void *stream);

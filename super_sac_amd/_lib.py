@@ -242,6 +242,7 @@ SIGNATURES = {
     "ssac_act_calls": [_P],
     "ssac_act_destroy": [_P],
     "ssac_ucb_select": [_P, _I, _I, _I, _I, _F, _P, _L, _I, _I, _P, _P],
+    "ssac_act_candidates": [_P, _I, _I, _I, _P, _L, _I, _F, _F, _P, C.c_longlong, _P, _L, _P],
     "ssac_act_mean_tanh": [_P, _I, _L, _I, _I, _P, _P],
     "ssac_act_take_clamp": [_P, _L, _I, _I, _I, _F, _F, _P, _P],
     "ssac_act_discrete": [_P, _I, _L, _I, _I, _I, _P, _P, _P],

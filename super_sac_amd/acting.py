@@ -110,6 +110,39 @@ def _fwd(plan, arena, x_ptr, ldx, n_rows, y):
                                   engine.stream()))
 
 
+class _Pack:
+    """the members' networks of one role in ONE plan-owned arena: the members of an ensemble are separate allocations (one arena
+    per actor, one per member's critics), so a forward of all of them is one launch PER MEMBER -- ~11 us each for a 16-row
+    tile.  A plan copies them into a pack at the head of every call (one multi-tensor launch, a few MB: ~5 us) and runs ONE
+    fused launch over the pack instead."""
+
+    def __init__(self, plan, arenas):
+        a0 = arenas[0]
+        assert all((a.in_dim, a.hidden, a.out_dim, a.stride) == (a0.in_dim, a0.hidden, a0.out_dim, a0.stride) for a in arenas)
+        self.n_nets = sum(a.n_nets for a in arenas)
+        self.buf = plan.buf(self.n_nets * a0.stride)
+        self.srcs = [a.params for a in arenas]
+        self.desc = _lib.MlpDesc(self.buf.data_ptr(), a0.stride, self.n_nets, a0.in_dim, a0.hidden, a0.out_dim)
+        self.out_dim = a0.out_dim
+
+    def segments(self):
+        off, out = 0, []
+        for s in self.srcs:
+            out.append((self.buf.data_ptr() + 4 * off, s.data_ptr(), s.numel()))
+            off += s.numel()
+        return out
+
+
+def _pack_launch(packs):
+    """one launch: every pack <- its members' arenas (ssac_polyak_multi with tau = 1: t <- 0 t + 1 s)"""
+    segs = [sg for p in packs for sg in p.segments()]
+    n = len(segs)
+    t = (C.c_void_p * n)(*[s[0] for s in segs])
+    s_ = (C.c_void_p * n)(*[s[1] for s in segs])
+    cnt = (C.c_int64 * n)(*[s[2] for s in segs])
+    check(lib.ssac_polyak_multi(t, s_, cnt, n, 1.0, engine.stream()))
+
+
 def _record(plan, agent, which):
     """record the launches of plan.rule for acting actor `which` (None: the rule involves every actor)"""
     dev, n, S, A = plan.dev, plan.n, plan.S, plan.A
@@ -124,8 +157,14 @@ def _record(plan, agent, which):
     check(lib.ssac_record_begin())
     try:
         if plan.rule == "forward":
-            for ar, out in zip(arenas, plan.outs):
-                _fwd(plan, ar, plan.obs_dev, S, n, out)
+            if E > 1:   # one launch over the packed actors; plan.outs[e] are views of its output
+                pa = _Pack(plan, arenas)
+                packed_out = plan.buf(E, n, pa.out_dim)
+                plan.outs = [packed_out[e] for e in range(E)]
+                _pack_launch([pa])
+                check(lib.ssac_mlp3_fwd_fused(C.byref(pa.desc), 0, E, plan.obs_dev, S, 0, n, 0, 0, packed_out.data_ptr(), st))
+            else:
+                _fwd(plan, arenas[0], plan.obs_dev, S, n, plan.outs[0])
             if plan.discrete:
                 check(lib.ssac_act_discrete(_ptr_array(plan.outs), E, A, n, A, 0, None, plan.res.data_ptr(), st))
             else:
@@ -133,20 +172,29 @@ def _record(plan, agent, which):
         elif plan.rule == "ucb":
             # agent.py:262-300: a candidate per actor on the rows of x = [s | a_k] (E n rows), every member's critics on x,
             # mean + bonus * std over the members, arg-max over the candidates
+            # Six launches whatever the ensemble size: the members' networks copied into two packs, ONE forward of all actors,
+            # the candidates (tanh-normal samples from the engine's Philox stream, member e at offset e << 40 of the plan's
+            # stream) beside the state columns, ONE ensemble-Q forward of every member's critics on the E n stacked rows, the
+            # rule's reduction, the publish step
             x = plan.buf(E * n, S + A)
-            for k, (actor, ar) in enumerate(zip(agent.actors, arenas)):
-                r = plan.rng_for(agent, k)
-                check(lib.ssac_actor_sample_concat_fused(
-                    C.byref(ar.desc()), plan.obs_dev, S, n, 0, float(actor.log_std_low), float(actor.log_std_high),
-                    x[k * n:].data_ptr(), S + A, plan.logp[k * n:].data_ptr(), 0, 0, plan.outs[k].data_ptr(), C.byref(r), st))
-            qs = []
-            for c in agent.critics:
-                car = c.arena(dev)
-                q = plan.buf(car.n_nets, E * n, 1)
-                _fwd(plan, car, x.data_ptr(), S + A, E * n, q)
-                qs.append(q)
-            check(lib.ssac_ucb_select(_ptr_array(qs), len(qs), agent.critics[0].arena(dev).n_nets, E, n, float(agent.ucb_bonus),
-                                      x.data_ptr(), S + A, S, A, plan.res.data_ptr(), st))
+            c_arenas = [c.arena(dev) for c in agent.critics]
+            pa, pc = _Pack(plan, arenas), _Pack(plan, c_arenas)
+            packed_out = plan.buf(E, n, pa.out_dim)
+            plan.outs = [packed_out[e] for e in range(E)]
+            N = c_arenas[0].n_nets
+            q = plan.buf(pc.n_nets, E * n, 1)
+            _pack_launch([pa, pc])
+            check(lib.ssac_mlp3_fwd_fused(C.byref(pa.desc), 0, E, plan.obs_dev, S, 0, n, 0, 0, packed_out.data_ptr(), st))
+            r = plan.rng_for(agent, 0)
+            a0 = agent.actors[0]
+            assert all((float(a_.log_std_low), float(a_.log_std_high)) == (float(a0.log_std_low), float(a0.log_std_high))
+                       for a_ in agent.actors)
+            check(lib.ssac_act_candidates(packed_out.data_ptr(), E, n, A, plan.obs_dev, S, S, float(a0.log_std_low),
+                                          float(a0.log_std_high), C.byref(r), 1 << 40, x.data_ptr(), S + A, st))
+            check(lib.ssac_mlp3_fwd_fused(C.byref(pc.desc), 0, pc.n_nets, x.data_ptr(), S + A, 0, E * n, 0, 0, q.data_ptr(), st))
+            qs = [q[c * N:(c + 1) * N] for c in range(len(c_arenas))]
+            check(lib.ssac_ucb_select(_ptr_array(qs), len(qs), N, E, n, float(agent.ucb_bonus), x.data_ptr(), S + A, S, A,
+                                      plan.res.data_ptr(), st))
         else:   # "sample": one actor's draw (agent.py:301-309)
             actor, ar, out = agent.actors[which], arenas[which], plan.outs[which]
             if plan.discrete:

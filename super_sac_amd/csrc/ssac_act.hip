@@ -80,6 +80,28 @@ __global__ void ucb_select_kernel(PtrList q, int n_members, int n_nets, int n_ca
         act[(int64_t)b * A + i] = fminf(fmaxf(X[((int64_t)best * n_rows + b) * ldx + col0 + i], -1.0f), 1.0f);
 }
 
+// ---- the candidates of the UCB rule from the PACKED actors' head outputs: row (e n_rows + b) of X = [s_b | a_e,b] with
+// a = tanh(mu + sd eps) (distributions.py:9-15, 64-104; tanh_normal_fwd_kernel's arithmetic), eps = element (b, i) of the
+// engine's Philox stream at draw rng.offset + e * member_stride (+ *rng.counter): member e draws what a launch of its own
+// (ssac_actor_sample_concat_fused with that offset) would draw
+__global__ void ucb_candidates_kernel(const float *__restrict__ outs, int n_actors, int n_rows, int A,
+                                      const float *__restrict__ S_rows, int64_t lds, int S, float lo, float hi, RngArgs rng,
+                                      long long member_stride, float *__restrict__ X, int64_t ldx) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int W = S + A;
+    if (idx >= n_actors * n_rows * W) return;
+    const int r = idx / W, c = idx - r * W;      // r = e n_rows + b
+    const int e = r / n_rows, b = r - e * n_rows;
+    if (c < S) { X[(int64_t)r * ldx + c] = S_rows[(int64_t)b * lds + c]; return; }
+    const int i = c - S;
+    const float *o = outs + ((int64_t)e * n_rows + b) * (2 * A);
+    const float mu = o[i], raw = o[A + i];
+    const float log_std = lo + 0.5f * (hi - lo) * (tanhf(raw) + 1.0f);
+    const float sd = expf(log_std);
+    const float eps = philox_normal(rng.seed, rng_draw(rng) + (long long)e * member_stride, b, i);
+    X[(int64_t)r * ldx + c] = tanhf(mu + sd * eps);
+}
+
 // ---- greedy continuous action (agent.py:204-246): mean over the actors of dist.mean = tanh(mu) (SquashedNormal.mean /
 // the deterministic actor's tanh(out)), clamped
 __global__ void mean_tanh_kernel(PtrList outs, int n_actors, int64_t ld_out, int n_rows, int A, float *__restrict__ act) {
@@ -281,6 +303,17 @@ extern "C" int ssac_ucb_select(const float *const *q_members, int n_members, int
     SSAC_LAUNCH(ucb_select_kernel, dim3((n_rows + 63) / 64), dim3(64), 0, ST, pl, n_members, n_nets, n_cand, n_rows, bonus, X,
                 ldx, col0, act_dim, act);
     return ssac_check_launch("ssac_ucb_select");
+}
+
+extern "C" int ssac_act_candidates(const float *outs, int n_actors, int n_rows, int act_dim, const float *S_rows, int64_t lds,
+                                   int state_dim, float log_std_lo, float log_std_hi, const ssac_rng *rng, long long member_stride,
+                                   float *X, int64_t ldx, void *stream) {
+    if (!outs || !S_rows || !X || !rng || n_actors <= 0 || n_rows <= 0 || act_dim <= 0 || state_dim <= 0 || ldx < state_dim + act_dim)
+        return ssac_fail("ssac_act_candidates: bad arguments");
+    const int n = n_actors * n_rows * (state_dim + act_dim);
+    SSAC_LAUNCH(ucb_candidates_kernel, dim3((n + 255) / 256), dim3(256), 0, ST, outs, n_actors, n_rows, act_dim, S_rows, lds,
+                state_dim, log_std_lo, log_std_hi, RngArgs{rng->seed, rng->counter, rng->offset}, member_stride, X, ldx);
+    return ssac_check_launch("ssac_act_candidates");
 }
 
 extern "C" int ssac_act_mean_tanh(const float *const *outs, int n_actors, int64_t ld_out, int n_rows, int act_dim, float *act,

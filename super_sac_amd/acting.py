@@ -29,14 +29,16 @@ _STREAM_SALT = 0x41C7A11D5EEDB00C      # the acting noise stream: the agent's en
 
 
 class _Plan:
-    def __init__(self, agent, rule, n, dev):
+    def __init__(self, agent, rule, n, dev, pixel_shape=None):
         self.rule, self.n, self.dev = rule, n, dev
         self.S = agent.encoder.embedding_dim
-        self.key = agent.encoder.ssac_identity_key
+        self.pixel_shape = pixel_shape    # (C, H, W) of a uint8 observation that goes through the pixel encoder, or None
+        self.key = agent.encoder.ssac_identity_key if pixel_shape is None else getattr(agent.encoder, "ssac_obs_key", "obs")
         self.discrete = bool(agent.discrete)
         self.A = agent.act_space_size
         self.out_floats = n if self.discrete else n * self.A
-        self.handle = lib.ssac_act_create(4 * n * self.S, self.out_floats)
+        obs_bytes = 4 * n * self.S if pixel_shape is None else n * int(np.prod(pixel_shape))
+        self.handle = lib.ssac_act_create(obs_bytes, self.out_floats)
         if not self.handle:
             raise RuntimeError("libssac_hip: " + lib.ssac_last_error().decode())
         self.obs_dev = lib.ssac_act_obs(self.handle)
@@ -68,6 +70,9 @@ class _Plan:
 
 def _signature(agent, with_critics):
     sig = [a.fc1.weight.data_ptr() for a in agent.actors]
+    if not lu.is_identity(agent.encoder):
+        conv = _conv_module(agent)
+        sig.append(conv.conv1.weight.data_ptr() if conv is not None else 0)
     if with_critics:
         sig += [c.nets[0].fc1.weight.data_ptr() for c in agent.critics]
     return tuple(sig)
@@ -77,12 +82,39 @@ def _ptr_array(tensors):
     return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+def _conv_module(agent):
+    """the convolutional module inside the agent's encoder wrapper (found once per encoder object)"""
+    enc = agent.encoder
+    if "_ssac_conv_mod" not in enc.__dict__:
+        from . import conv_encoder
+        enc.__dict__["_ssac_conv_mod"] = conv_encoder.find_conv_module(enc)
+    return enc.__dict__["_ssac_conv_mod"]
+
+
+def _pixel_obs(agent, obs, num_envs):
+    """(key, (C, H, W)) when the observation is a uint8 image batch for a pixel encoder of this package, else None"""
+    key = getattr(agent.encoder, "ssac_obs_key", None)
+    if key is None:
+        return None
+    conv = _conv_module(agent)
+    v = obs.get(key)
+    if conv is None or not isinstance(v, np.ndarray) or v.dtype != np.uint8:
+        return None
+    shape = tuple(v.shape[-3:])
+    if len(shape) != 3 or v.size != num_envs * int(np.prod(shape)) or shape[0] != conv.conv1.in_channels:
+        return None
+    return key, shape
+
+
 def _eligible(agent, obs, num_envs, sample, rolling):
-    if not (ENABLED and isinstance(obs, dict) and lu.is_identity(agent.encoder) and engine.CAPTURE is None):
+    if not (ENABLED and isinstance(obs, dict) and engine.CAPTURE is None):
         return False
-    v = obs.get(agent.encoder.ssac_identity_key)
-    if not isinstance(v, np.ndarray) or v.size != num_envs * agent.encoder.embedding_dim:
-        return False
+    if lu.is_identity(agent.encoder):
+        v = obs.get(agent.encoder.ssac_identity_key)
+        if not isinstance(v, np.ndarray) or v.size != num_envs * agent.encoder.embedding_dim:
+            return False
+    elif rolling or _pixel_obs(agent, obs, num_envs) is None:
+        return False          # (a rolling encoder keeps state between calls: the general path)
     E = len(agent.actors)
     if E > 8 or agent.act_space_size > 64:
         return False
@@ -156,15 +188,22 @@ def _record(plan, agent, which):
         plan.logp = plan.buf(max(n * E, 1))
     check(lib.ssac_record_begin())
     try:
+        x_in = plan.obs_dev      # what the actors read: the observation itself, or the encoder's output
+        if plan.pixel_shape is not None:
+            # the pixel encoder's forward straight from the uint8 observation buffer (the cast and the /255 normalisation
+            # happen in the first layer's patch gather), into a buffer of this plan -- the same launches as lu.encode
+            plan.srep = plan.buf(n, S)
+            plan.conv_engine.forward_ptr(plan.obs_dev, (n,) + plan.pixel_shape, 1, plan.srep.data_ptr(), S, False)
+            x_in = plan.srep.data_ptr()
         if plan.rule == "forward":
             if E > 1:   # one launch over the packed actors; plan.outs[e] are views of its output
                 pa = _Pack(plan, arenas)
                 packed_out = plan.buf(E, n, pa.out_dim)
                 plan.outs = [packed_out[e] for e in range(E)]
                 _pack_launch([pa])
-                check(lib.ssac_mlp3_fwd_fused(C.byref(pa.desc), 0, E, plan.obs_dev, S, 0, n, 0, 0, packed_out.data_ptr(), st))
+                check(lib.ssac_mlp3_fwd_fused(C.byref(pa.desc), 0, E, x_in, S, 0, n, 0, 0, packed_out.data_ptr(), st))
             else:
-                _fwd(plan, arenas[0], plan.obs_dev, S, n, plan.outs[0])
+                _fwd(plan, arenas[0], x_in, S, n, plan.outs[0])
             if plan.discrete:
                 check(lib.ssac_act_discrete(_ptr_array(plan.outs), E, A, n, A, 0, None, plan.res.data_ptr(), st))
             else:
@@ -184,12 +223,12 @@ def _record(plan, agent, which):
             N = c_arenas[0].n_nets
             q = plan.buf(pc.n_nets, E * n, 1)
             _pack_launch([pa, pc])
-            check(lib.ssac_mlp3_fwd_fused(C.byref(pa.desc), 0, E, plan.obs_dev, S, 0, n, 0, 0, packed_out.data_ptr(), st))
+            check(lib.ssac_mlp3_fwd_fused(C.byref(pa.desc), 0, E, x_in, S, 0, n, 0, 0, packed_out.data_ptr(), st))
             r = plan.rng_for(agent, 0)
             a0 = agent.actors[0]
             assert all((float(a_.log_std_low), float(a_.log_std_high)) == (float(a0.log_std_low), float(a0.log_std_high))
                        for a_ in agent.actors)
-            check(lib.ssac_act_candidates(packed_out.data_ptr(), E, n, A, plan.obs_dev, S, S, float(a0.log_std_low),
+            check(lib.ssac_act_candidates(packed_out.data_ptr(), E, n, A, x_in, S, S, float(a0.log_std_low),
                                           float(a0.log_std_high), C.byref(r), 1 << 40, x.data_ptr(), S + A, st))
             check(lib.ssac_mlp3_fwd_fused(C.byref(pc.desc), 0, pc.n_nets, x.data_ptr(), S + A, 0, E * n, 0, 0, q.data_ptr(), st))
             qs = [q[c * N:(c + 1) * N] for c in range(len(c_arenas))]
@@ -198,17 +237,17 @@ def _record(plan, agent, which):
         else:   # "sample": one actor's draw (agent.py:301-309)
             actor, ar, out = agent.actors[which], arenas[which], plan.outs[which]
             if plan.discrete:
-                _fwd(plan, ar, plan.obs_dev, S, n, out)
+                _fwd(plan, ar, x_in, S, n, out)
                 r = plan.rng_for(agent, which)
                 check(lib.ssac_act_discrete(_ptr_array([out]), 1, A, n, A, 1, C.byref(r), plan.res.data_ptr(), st))
             elif kind == "stochastic":
                 # (tanh-normal samples lie inside (-1, 1): _process_act's clamp is the identity)
                 r = plan.rng_for(agent, which)
                 check(lib.ssac_actor_sample_fused(
-                    C.byref(ar.desc()), plan.obs_dev, S, n, 0, float(actor.log_std_low), float(actor.log_std_high),
+                    C.byref(ar.desc()), x_in, S, n, 0, float(actor.log_std_low), float(actor.log_std_high),
                     plan.res.data_ptr(), A, 0, plan.logp.data_ptr(), 0, 0, out.data_ptr(), C.byref(r), st))
             else:   # deterministic actor: sample() = loc = tanh(out) (distributions.py:107-114)
-                _fwd(plan, ar, plan.obs_dev, S, n, out)
+                _fwd(plan, ar, x_in, S, n, out)
                 check(lib.ssac_act_mean_tanh(_ptr_array([out]), 1, ar.out_dim, n, A, plan.res.data_ptr(), st))
         check(lib.ssac_act_publish(plan.handle, plan.res.data_ptr(), plan.out_floats, st))
     finally:
@@ -237,7 +276,15 @@ def act(agent, obs, num_envs, sample, return_dist=False, rolling=False):
             return None
         if len(plans) > 12:
             plans.clear()
-        plan = plans[pkey] = _Plan(agent, rule, num_envs, dev)
+        pix = None if lu.is_identity(agent.encoder) else _pixel_obs(agent, obs, num_envs)
+        eng = None
+        if pix is not None:
+            from . import conv_encoder
+            eng = conv_encoder.conv_engine(agent.encoder, dev)   # (the module's own engine: its parameters live in its arena)
+            if eng is None:
+                return None
+        plan = plans[pkey] = _Plan(agent, rule, num_envs, dev, pixel_shape=None if pix is None else pix[1])
+        plan.conv_engine = eng
         plan.sig = _signature(agent, ucb)   # (binding the arenas may have re-pointed the parameters)
     # the reference's host draws, in its order: random.choice(act_dists) under UCB (for the logged distribution),
     # random.choice(self.actors) otherwise (agent.py:262, 301)
@@ -248,7 +295,7 @@ def act(agent, obs, num_envs, sample, return_dist=False, rolling=False):
         which = which_dist = rng.choice(range(len(agent.actors)))
     if which not in plan.lists:
         _record(plan, agent, which)
-    v = np.ascontiguousarray(obs[plan.key], dtype=np.float32)
+    v = np.ascontiguousarray(obs[plan.key], dtype=np.float32 if plan.pixel_shape is None else np.uint8)
     rc = lib.ssac_act_run(plan.handle, plan.lists[which], v.ctypes.data, v.nbytes, plan.result.ctypes.data, plan.out_floats,
                           engine.stream())
     if rc:

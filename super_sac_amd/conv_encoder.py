@@ -100,9 +100,16 @@ class ConvEncoderEngine:
         ld_dst).  With `save`, keeps what backward() needs."""
         engine.require_gpu(img)
         img = img.contiguous()
-        B, Cc, Hh, Ww = img.shape
+        self.forward_ptr(img.data_ptr(), tuple(img.shape), 1 if img.dtype == torch.uint8 else 0, dst.data_ptr(), ld_dst, save,
+                         img=img, dst=dst)
+
+    def forward_ptr(self, img_ptr, shape, u8, dst_ptr, ld_dst, save, img=None, dst=None):
+        """forward() on a raw device pointer: (B, C, H, W) fp32 -- or uint8 (u8 = 1: the cast and the input normalisation
+        happen in the first layer's patch gather) -- e.g. the observation buffer of an acting plan (acting.py), which is
+        not a torch allocation.  Every launch reads / writes workspace buffers keyed by shape: recordable."""
+        B, Cc, Hh, Ww = shape
         st = engine.stream()
-        src, u8 = img, 0
+        src_ptr = img_ptr
         strides = (Cc * Hh * Ww, Hh * Ww, Ww, 1)
         Hi, Wi, div, shift = Hh, Ww, self.div, self.shift
         cols, ys, shapes = [], [], []
@@ -113,30 +120,30 @@ class ConvEncoderEngine:
             y = self.ws.get(f"{tag}.y{l if save else l % 2}", (rows * co,))
             if save:
                 self.implicit[l] = self.implicit_ok[l] and rows >= IMPLICIT_MIN_ROWS
-            first = (l == 0 and USE_IMPLICIT_FIRST and rows >= FIRST_MIN_ROWS and not u8 and img.data_ptr() % 16 == 0
+            first = (l == 0 and USE_IMPLICIT_FIRST and rows >= FIRST_MIN_ROWS and not u8 and img_ptr % 16 == 0
                      and lib.ssac_conv_first_supported(ci, co, k, s, Hi, Wi, B) > 0)
             if l == 0 and save:
                 self.first = first
             if first:
                 # the gather AND the input normalisation happen in the operand loads; the image is what backward reads
                 col = None
-                check(lib.ssac_conv_first_fwd(img.data_ptr(), self.convs[0].weight.data_ptr(),
+                check(lib.ssac_conv_first_fwd(img_ptr, self.convs[0].weight.data_ptr(),
                                               self.convs[0].bias.data_ptr(), y.data_ptr(), B, ci, Hi, Wi, co, k, s,
                                               div, shift, st))
             elif self.implicit_ok[l] and rows >= IMPLICIT_MIN_ROWS:
                 # channels-last input straight from the previous layer: the patch gather happens in the operand
                 # loads of the implicit-GEMM kernel, no column matrix
                 col = None
-                check(lib.ssac_conv_fwd(src.data_ptr(), self.convs[l].weight.data_ptr(),
+                check(lib.ssac_conv_fwd(src_ptr, self.convs[l].weight.data_ptr(),
                                         self.convs[l].bias.data_ptr(), y.data_ptr(), B, Hi, Wi, ci, co, k, s, st))
             else:
                 col = self.ws.get(f"{tag}.col{l if save else 0}", (rows * ckk,))
-                check(lib.ssac_im2col(src.data_ptr(), u8, *strides, B, ci, Hi, Wi, k, s, div, shift,
+                check(lib.ssac_im2col(src_ptr, u8 if l == 0 else 0, *strides, B, ci, Hi, Wi, k, s, div, shift,
                                       col.data_ptr(), st))
                 check(lib.ssac_linear_fwd(col.data_ptr(), ckk, self.convs[l].weight.data_ptr(), ckk,
                                           self.convs[l].bias.data_ptr(), y.data_ptr(), co, rows, co, ckk, 1, st))
             cols.append(col); ys.append(y); shapes.append((ci, co, k, s, Hi, Wi, Ho, Wo))
-            src, strides = y, (Ho * Wo * co, 1, Wo * co, co)  # channels-last view of the GEMM output
+            src, src_ptr, strides = y, y.data_ptr(), (Ho * Wo * co, 1, Wo * co, co)  # channels-last view of the GEMM output
             Hi, Wi, div, shift = Ho, Wo, 1.0, 0.0
         co = self.geom[-1][1]
         flat_dim = co * Hi * Wi
@@ -149,7 +156,7 @@ class ConvEncoderEngine:
             check(lib.ssac_permute_cp(fc.weight.data_ptr(), wfc.data_ptr(), self.emb, co, Hi * Wi, 1, st))
         else:
             colf = self.ws.get(f"{tag}.colf", (B * flat_dim,))
-            check(lib.ssac_im2col(src.data_ptr(), 0, *strides, B, co, Hi, Wi, Hi, 1, 1.0, 0.0, colf.data_ptr(), st))
+            check(lib.ssac_im2col(src_ptr, 0, *strides, B, co, Hi, Wi, Hi, 1, 1.0, 0.0, colf.data_ptr(), st))
             wfc = fc.weight
         fc = self.module.fc
 
@@ -186,10 +193,10 @@ class ConvEncoderEngine:
             rstd = self.ws.get(f"{tag}.rstd", (B,))
             ln = self.module.ln
             check(lib.ssac_ln_tanh_fwd(z.data_ptr(), self.emb, ln.weight.data_ptr(), ln.bias.data_ptr(), B,
-                                       self.emb, dst.data_ptr(), ld_dst, xhat.data_ptr(), rstd.data_ptr(), st))
+                                       self.emb, dst_ptr, ld_dst, xhat.data_ptr(), rstd.data_ptr(), st))
         else:
             xhat = rstd = None
-            fc_forward(dst.data_ptr(), ld_dst)
+            fc_forward(dst_ptr, ld_dst)
         if save:
             self.saved = dict(B=B, img=img, cols=cols, ys=ys, shapes=shapes, colf=colf, wfc=wfc, flat_dim=flat_dim,
                               Hf=Hi, Wf=Wi, xhat=xhat, rstd=rstd, out=dst, ld_out=ld_dst)

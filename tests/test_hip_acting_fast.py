@@ -162,9 +162,37 @@ def test_fast_path_reads_the_weights_of_the_moment_and_survives_a_reload(tmp_pat
     np.testing.assert_allclose(agent.forward({"obs": obs}), a1, atol=1e-7)
 
 
+def test_pixel_agents_take_the_one_call_path_and_equal_the_general_path():
+    """a uint8 image observation of a pixel-encoder agent: the encoder's forward is recorded in front of the rule's launches
+    (the cast and the /255 normalisation happen in the first layer's patch gather, straight from the observation buffer);
+    against agent.py's general path on the same frames: the logits (return_dist) and the greedy actions"""
+    from super_sac_amd import acting
+    cfg, agent, _ = _pair("atari_pixels")
+    rs = np.random.RandomState(2)
+    for n in (1, 3):
+        for rep in range(2):
+            obs = rs.randint(0, 256, (n, 4, 84, 84) if n > 1 else (4, 84, 84)).astype(np.uint8)
+            act, logits = agent.sample_action({"obs": obs}, num_envs=n, return_dist=True)
+            greedy = agent.forward({"obs": obs}, num_envs=n)
+            assert ("sample", n, 0.0) in acting._PLANS[agent] and ("forward", n, 0.0) in acting._PLANS[agent]
+            assert act.shape == ((n, 1) if n > 1 else (1,)) and act.dtype == np.int64
+            acting.ENABLED = False
+            try:
+                _, want_logits = agent.sample_action({"obs": obs}, num_envs=n, return_dist=True)
+                want_greedy = agent.forward({"obs": obs}, num_envs=n)
+            finally:
+                acting.ENABLED = True
+            np.testing.assert_allclose(logits.cpu().numpy(), want_logits.cpu().numpy(), atol=2e-5)
+            assert np.array_equal(greedy, want_greedy)
+
+
 def test_ineligible_calls_take_the_general_path():
     from super_sac_amd import acting
-    cfg, agent, _ = _pair("atari_pixels")   # a pixel encoder: not an identity map
-    obs = np.random.RandomState(2).randint(0, 255, (4, 84, 84)).astype(np.uint8)
+    cfg, agent, _ = _pair("atari_pixels")
+    obs = np.random.RandomState(2).randint(0, 255, (4, 84, 84)).astype(np.float32)   # float frames: not the uint8 contract
     act = agent.sample_action({"obs": obs})
     assert act.shape == (1,) and agent not in acting._PLANS
+    cfg, agent, _ = _pair("sunrise")
+    s = torch.randn(2, cfg["obs"], device=DEV)
+    act = agent.sample_action({"obs": s}, from_cpu=False, num_envs=2)   # device tensors in, device tensor out
+    assert torch.is_tensor(act) and agent not in acting._PLANS

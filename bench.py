@@ -79,17 +79,26 @@ def recorded_traffic():
                                f"fetched + {rec.get('write_kib')} KiB written")
 
 
+_SCLK_NODE = {}
+
+
 def sclk_mhz(index=0):
-    """current shader clock of the device from sysfs (the starred level of pp_dpm_sclk), or None: a few microseconds, no
-    GPU work, no subprocess -- read beside every timed repeat so that the clock ramp after an idle stretch is IN the line"""
-    import glob
+    """shader clock level of torch device `index` from sysfs (the starred level of pp_dpm_sclk of ITS PCI function -- a box
+    lists every GPU of the node, visible to this process or not), or None: a few microseconds, no GPU work, no subprocess.
+    Read beside every timed repeat.  (What it shows on these boxes is the DPM level, which sits at its cap whenever the
+    device has work: the ramp after an idle stretch is visible in the first repeats' TIMES, not in this number.)"""
     try:
-        cards = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        with open(cards[min(index, len(cards) - 1)]) as f:
+        node = _SCLK_NODE.get(index)
+        if node is None:
+            import torch
+            p = torch.cuda.get_device_properties(index)
+            bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            node = _SCLK_NODE[index] = f"/sys/bus/pci/devices/{bdf}/pp_dpm_sclk"
+        with open(node) as f:
             for ln in f:
                 if "*" in ln:
                     return int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
-    except Exception:   # noqa: BLE001  (no sysfs node / not readable: the line says null)
+    except Exception:   # noqa: BLE001  (no sysfs node / not readable / no PCI ids: the line says null)
         pass
     return None
 
@@ -524,7 +533,7 @@ def main():
                "ms_per_step_first": round(1e3 * times[0] / args.steps, 5),
                "ms_per_step_min": round(1e3 * min(times) / args.steps, 5),
                "sclk_mhz": {"before_warmup": sclk_before, "after_each_repeat": sclk,
-                            "source": "sysfs pp_dpm_sclk (current level), rank 0's device"},
+                            "source": "sysfs pp_dpm_sclk (current DPM level) of rank 0's device, by PCI address"},
                "config": {"workload": f"REDQ critic_update + Polyak/2: obs {OBS}, act {ACT}, batch {BATCH}, "
                                       f"N={NCRIT} critics (n=2 target subset), hidden 256, replay 100k rows in HBM",
                           "global_batch": BATCH, "num_critics": NCRIT,

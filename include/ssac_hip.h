@@ -719,6 +719,25 @@ int ssac_actor_bwd_fused(const ssac_mlp *actor, const float *H1, const float *H2
                          const float *log_alpha, int use_entropy, float log_std_lo, float log_std_hi, float inv_members,
                          const ssac_popart *popart, int pop, float *d_out, float *DZ2, float *DZ1, float *partials,
                          void *stream);
+/* The same two logs folded into the actor's weight-gradient launch (round 6): ssac_mlp_wgrad_all for ONE net in Adam mode
+ * whose last workgroup to finish (arrival tickets, as ssac_logfold) adds -inv_members sum(partials) / n_rows to logs_loss[0],
+ * writes sqrt(sum of the launch's sumsq slots) to logs_gn[0] and -- ring != NULL -- the finished block to slot ring_slot of
+ * the log ring (recorded: the second number of ssac_replay_value2).  No log launch behind the update. */
+typedef struct ssac_actor_logfold {
+    unsigned *done_counter;   /* one zero-initialised uint32 in device memory, reset by the launch itself */
+    const float *partials;    /* the tiles' loss terms (ssac_actor_bwd_fused / ssac_actor_chain_fused) */
+    int32_t n_tiles, n_rows;
+    float inv_members;
+    int32_t width;            /* floats of the log block (with ring) */
+    float *logs_loss, *logs_gn;   /* logs_gn may be NULL */
+    const float *block;       /* the log block logs_loss / logs_gn point into (with ring) */
+    float *ring;              /* NULL: no publication */
+    int64_t ring_slot;
+} ssac_actor_logfold;
+int ssac_mlp_wgrad_all_actor(const ssac_mlp *nets, const float *X, int64_t ldx, const float *H1, const float *H2,
+                             const float *DZ2, const float *DZ1, const float *DQ, int n_rows, float *adam_m, float *adam_v,
+                             const ssac_adam_ctl *ctl, float *sumsq2, float *sumsq1, float *sumsq0, int64_t sumsq_net_stride,
+                             const ssac_actor_logfold *fold, void *stream);
 /* ring != NULL (round 6): the finished block (`width` floats at `block`, logs_loss / logs_gn pointing into it) is also written
  * to slot `ring_slot` of the log ring (ring + ring_slot * width) by this launch; in a RECORDED launch the slot is the
  * second number of ssac_replay_value2 -- no copy behind the replay. */

@@ -75,6 +75,13 @@ class DeferredLogs(C.Structure):
                 ("_pad", C.c_int32), ("feed", C.c_void_p)]
 
 
+class ActorLogFold(C.Structure):
+    """struct ssac_actor_logfold"""
+    _fields_ = [("done_counter", C.c_void_p), ("partials", C.c_void_p), ("n_tiles", C.c_int32), ("n_rows", C.c_int32),
+                ("inv_members", C.c_float), ("width", C.c_int32), ("logs_loss", C.c_void_p), ("logs_gn", C.c_void_p),
+                ("block", C.c_void_p), ("ring", C.c_void_p), ("ring_slot", C.c_int64)]
+
+
 class Gather(C.Structure):
     """struct ssac_gather"""
     _fields_ = [("s", C.c_void_p), ("s1", C.c_void_p), ("act", C.c_void_p), ("rew", C.c_void_p), ("done", C.c_void_p),
@@ -127,6 +134,7 @@ SIGNATURES = {
     "ssac_group_norms": [_P, _I, _I, _P, _P, _P],
     "ssac_mlp_wgrad_fc12": [_MP, _P, _I, _P, _L, _L, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _P, _F, _P],
     "ssac_mlp_wgrad_all": [_MP, _P, _I, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _F, _P],
+    "ssac_mlp_wgrad_all_actor": [_MP, _P, _L, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _L, _P, _P],
     "ssac_mlp_wgrad_all_scaled": [_MP, _P, _I, _P, _L, _L, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _L, _P, _F,
                                   _P],
     "ssac_critic_loss_bwd_lazy": [_P, _I, _I, _I, _P, _L, _P, _P, _P, _I, _F, _P, _P, _P],

@@ -273,6 +273,10 @@ struct LogFoldArgs {
     const float *partials; int n_nets;     // [n_nets][2] from loss_fold_table
     const float *sumsq; int n_ss;          // every gradient-norm partial of the launch
     int n_rows; float denom;
+    // ACTOR mode (round 6: the online actor update's two logs, ssac_actor_logs' work, in its weight-gradient launch): partials
+    // = the tiles' loss terms (stride 1, n_nets = their count), logs[0] += a_scale * their sum, *a_gn = sqrt(sum of sumsq);
+    // a_pub != null: the finished block (a_width floats at a_block) also goes to its slot of the log ring
+    int actor; float a_scale; float *a_gn; const float *a_block; int a_width; float *a_pub;
 };
 
 // all threads of the (>= 256-thread) workgroup call this; red: 12 floats of LDS.  td_out was written by this workgroup.
@@ -322,6 +326,24 @@ __device__ __forceinline__ bool log_fold_arrive(const LogFoldArgs &f, unsigned t
 // wave 0 (all 64 lanes) of the last workgroup
 __device__ __forceinline__ void log_fold_finish(const LogFoldArgs &f) {
     const int lane = threadIdx.x & 63;
+    if (f.actor) {
+        float s = 0.f, q = 0.f;
+        for (int i = lane; i < f.n_nets; i += 64) s += f.partials[i];   // (written by an earlier launch)
+        for (int i = lane; i < f.n_ss; i += 64) q += __hip_atomic_load(f.sumsq + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        const float loss = f.logs[0] + f.a_scale * s, gn = sqrtf(q);
+        if (lane == 0) { f.logs[0] = loss; if (f.a_gn) *f.a_gn = gn; }
+        if (f.a_pub)
+            for (int i = lane; i < f.a_width; i += 64) {
+                float v = f.a_block[i];
+                if (f.a_block + i == f.logs) v = loss;
+                if (f.a_gn && f.a_block + i == f.a_gn) v = gn;
+                f.a_pub[i] = v;
+            }
+        if (lane == 0) __hip_atomic_store(f.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        return;
+    }
     float sl = 0.f, se = 0.f, ss = 0.f;
     for (int i = lane; i < f.n_nets; i += 64) {
         sl += __hip_atomic_load(f.partials + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -1540,7 +1540,8 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                         const ssac_adam_ctl *ctl, float *grads, float *sumsq1, float *sumsq0, float *sumsq2,
                         int64_t sumsq_net_stride, float *target, float tau, void *stream,
                         const float *rowscale = nullptr, const LossFoldArgs *lossfold = nullptr,
-                        const ssac_logfold *logfold = nullptr, const float *w3_snapshot = nullptr);
+                        const ssac_logfold *logfold = nullptr, const float *w3_snapshot = nullptr,
+                        const ssac_actor_logfold *afold = nullptr);
 
 extern "C" int ssac_mlp_wgrad_all_scaled(const ssac_mlp *nets, const int32_t *net_ids, int n_sel, const float *X,
                                          int64_t ldx, int64_t x_net_stride, const float *H1, const float *H2,
@@ -1605,7 +1606,7 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
                         const ssac_adam_ctl *ctl, float *grads, float *sumsq1, float *sumsq0, float *sumsq2,
                         int64_t sumsq_net_stride, float *target, float tau, void *stream,
                         const float *rowscale, const LossFoldArgs *lossfold, const ssac_logfold *logfold,
-                        const float *w3_snapshot) {
+                        const float *w3_snapshot, const ssac_actor_logfold *afold) {
     if (n_sel < 0 || n_sel > SSAC_MAX_NETS) return ssac_fail("ssac_mlp_wgrad_fc12: n_sel out of range");
     if (!grads && (!adam_m || !adam_v || !ctl)) return ssac_fail("ssac_mlp_wgrad_fc12: Adam state missing");
     if (n_sel == 0 || n_rows <= 0) return 0;
@@ -1665,6 +1666,31 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
         if (!target || grads) return ssac_fail("ssac_mlp_wgrad_all_lossfold: the late-bound Polyak needs a target arena and Adam mode");
         p.late_word = logfold->late_word;
     }
+    bool actor_ring = false;
+    if (afold && afold->done_counter) {
+        // the online actor update's two logs ride in this launch (ssac_actor_logs' arithmetic, by the last workgroup to arrive)
+        if (lossfold || logfold || grads || !sumsq0 || !sumsq1 || !sumsq2 || net_ids || n_sel != 1 || !afold->partials ||
+            afold->n_tiles <= 0 || afold->n_rows <= 0 || !afold->logs_loss || (afold->ring && (!afold->block || afold->width <= 0 || afold->ring_slot < 0)))
+            return ssac_fail("ssac_mlp_wgrad_all_actor: the folded actor logs need ONE net, Adam mode, every sumsq slot and the tiles' loss terms");
+        const float *ss_base = sumsq0 < sumsq1 ? sumsq0 : sumsq1;
+        if (sumsq2 < ss_base) ss_base = sumsq2;
+        p.fold = LogFoldArgs{};
+        p.fold.done = afold->done_counter;
+        p.fold.logs = afold->logs_loss;
+        p.fold.partials = afold->partials; p.fold.n_nets = afold->n_tiles;
+        p.fold.sumsq = ss_base; p.fold.n_ss = (int)sumsq_net_stride;
+        p.fold.n_rows = afold->n_rows;
+        p.fold.actor = 1; p.fold.a_scale = -afold->inv_members / (float)afold->n_rows; p.fold.a_gn = afold->logs_gn;
+        p.fold.a_block = afold->block; p.fold.a_width = afold->width;
+        p.fold.a_pub = afold->ring ? afold->ring + afold->ring_slot * afold->width : nullptr;
+        actor_ring = afold->ring != nullptr;
+    }
+    // (a recorded launch: every replay names its own ring slot -- ssac_replay_value2's second number)
+    auto ring_patch = [&]() {
+        if (actor_ring)
+            ssac_record_value_patch(0, offsetof(GemmPair, fold) + offsetof(LogFoldArgs, a_pub), 2, (long long)(uintptr_t)afold->ring,
+                                    (long long)afold->width * 4);
+    };
     hipStream_t st = (hipStream_t)stream;
     const int tiles = (p.g0.grid_x * p.g0.grid_y + p.g1.grid_x * p.g1.grid_y) * n_sel;
     const int nchunks = (n_rows + BK - 1) / BK;
@@ -1677,8 +1703,11 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
         auto t32 = [](const GemmArgs &g) { return ((g.M + ST - 1) / ST) * ((g.N + ST - 1) / ST); };
         const int small_wgs = (t32(p.g0) + t32(p.g1) + (p.head_grid_x > 0 ? (H + S_HEAD_COLS - 1) / S_HEAD_COLS : 0)) * n_sel + 1;
         const bool can = small_ok(p.g0) && small_ok(p.g1) && nets->out_dim <= 16;
-        if (can && (g_wgrad_variant == 2 || (g_wgrad_variant == 0 && small_wgs <= g_wgrad_small_max)))
-            return grads ? launch_pair_small<EPI_GRAD, 1>(p, n_sel, st) : launch_pair_small<EPI_ADAM, 1>(p, n_sel, st);
+        if (can && (g_wgrad_variant == 2 || (g_wgrad_variant == 0 && small_wgs <= g_wgrad_small_max))) {
+            const int rc = grads ? launch_pair_small<EPI_GRAD, 1>(p, n_sel, st) : launch_pair_small<EPI_ADAM, 1>(p, n_sel, st);
+            ring_patch();
+            return rc;
+        }
     }
     if (grads) {
         if (tiles <= 256 && nchunks >= 8) return launch_pair_ks<false, false, EPI_GRAD, 4>(p, n_sel, n_sel, st);
@@ -1686,9 +1715,22 @@ static int wgrad_merged(const ssac_mlp *nets, const int32_t *net_ids, int n_sel,
         return launch_pair_ks<false, false, EPI_GRAD, 1>(p, n_sel, n_sel, st);
     }
     // (measured again in round 3 at the metric shape: 4 K-groups 58.3 us per update, 2 K-groups 61.4, none 73.3)
-    if (tiles <= 256 && nchunks >= 8) return launch_pair_ks<false, false, EPI_ADAM, 4>(p, n_sel, n_sel, st);
-    if (tiles <= 512 && nchunks >= 4) return launch_pair_ks<false, false, EPI_ADAM, 2>(p, n_sel, n_sel, st);
-    return launch_pair_ks<false, false, EPI_ADAM, 1>(p, n_sel, n_sel, st);
+    const int rc = (tiles <= 256 && nchunks >= 8) ? launch_pair_ks<false, false, EPI_ADAM, 4>(p, n_sel, n_sel, st)
+                   : (tiles <= 512 && nchunks >= 4) ? launch_pair_ks<false, false, EPI_ADAM, 2>(p, n_sel, n_sel, st)
+                                                    : launch_pair_ks<false, false, EPI_ADAM, 1>(p, n_sel, n_sel, st);
+    ring_patch();
+    return rc;
+}
+
+// ssac_mlp_wgrad_all with the online actor update's two logs folded in (round 6; was a launch of its own, ssac_actor_logs)
+extern "C" int ssac_mlp_wgrad_all_actor(const ssac_mlp *nets, const float *X, int64_t ldx, const float *H1, const float *H2,
+                                        const float *DZ2, const float *DZ1, const float *DQ, int n_rows, float *adam_m,
+                                        float *adam_v, const ssac_adam_ctl *ctl, float *sumsq2, float *sumsq1, float *sumsq0,
+                                        int64_t sumsq_net_stride, const ssac_actor_logfold *fold, void *stream) {
+    if (!nets || nets->out_dim > 16 || nets->n_nets != 1) return ssac_fail("ssac_mlp_wgrad_all_actor: one net, head of <= 16 outputs");
+    if (!H2 || !DQ || !fold) return ssac_fail("ssac_mlp_wgrad_all_actor: H2 / DQ / fold missing");
+    return wgrad_merged(nets, nullptr, 1, X, ldx, 0, H1, DZ2, DZ1, H2, DQ, n_rows, adam_m, adam_v, ctl, nullptr, sumsq1, sumsq0,
+                        sumsq2, sumsq_net_stride, nullptr, 0.0f, stream, nullptr, nullptr, nullptr, nullptr, fold);
 }
 
 extern "C" int ssac_mlp_layer_wgrad(const ssac_mlp *nets, int layer, const int32_t *net_ids, int n_sel,

@@ -403,7 +403,7 @@ def mlp_forward(arena, X, ldx, x_net_stride, n_rows, ws, tag, net_ids=None, n_se
 
 def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, adam=None, adam_key=None,
                  grads=None, sumsq=None, target=None, tau=0.0, net_ids=None, n_sel=None, logs=None,
-                 rowscale=None, lossfold=None):
+                 rowscale=None, lossfold=None, actor_fold=None):
     """the weight-gradient launch(es) (+Adam/Polyak in their epilogues, or gradient store).
     logs (critic update, Adam mode, merged launch only): dict(partials, tiles, denom, logs, spec_ptr, td_logs_ptr,
     feed, done) -- the launch's last workgroup then also finalises the update's logs; returns True when it did."""
@@ -457,6 +457,12 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
                                                 _ptr(m), _ptr(v), ctl, _ptr(grads), ssp(2), ssp(1), ssp(0), ttot,
                                                 _ptr(target), float(tau), st))
         return
+    if actor_fold is not None and actor_fold_applies(arena, grads, sumsq, target, net_ids, n_sel):
+        # the online actor update's ONE net: the same merged launch, its last workgroup also finishes the update's two logs
+        check(lib.ssac_mlp_wgrad_all_actor(C.byref(d), X.data_ptr(), ldx, h1.data_ptr(), h2.data_ptr(), dz2.data_ptr(),
+                                           dz1.data_ptr(), dY.data_ptr(), n_rows, m.data_ptr(), v.data_ptr(), ctl, ssp(2), ssp(1),
+                                           ssp(0), ttot, C.byref(actor_fold), st))
+        return True
     if O <= 16 and MERGE_HEAD_WGRAD:
         # head (VALU), fc2 and fc1 weight gradients of every selected net: ONE launch
         check(lib.ssac_mlp_wgrad_all(C.byref(d), ids, n_sel, X.data_ptr(), ldx, x_net_stride, h1.data_ptr(),
@@ -479,6 +485,12 @@ def weight_grads(arena, X, ldx, x_net_stride, h1, h2, dY, dz2, dz1, n_rows, *, a
     check(lib.ssac_mlp_wgrad_fc12(C.byref(d), ids, n_sel, X.data_ptr(), ldx, x_net_stride, h1.data_ptr(),
                                   dz2.data_ptr(), dz1.data_ptr(), n_rows, _ptr(m), _ptr(v), ctl, _ptr(grads),
                                   ssp(1), ssp(0), ttot, _ptr(target), float(tau), st))
+
+
+def actor_fold_applies(arena, grads, sumsq, target, net_ids, n_sel):
+    """can the merged weight-gradient launch of this call carry the actor update's logs (ssac_mlp_wgrad_all_actor)?"""
+    return (MERGE_HEAD_WGRAD and arena.out_dim <= 16 and arena.n_nets == 1 and grads is None and sumsq is not None
+            and target is None and net_ids is None and (n_sel is None or n_sel == 1) and arena.shadow is None)
 
 
 def mlp_backward(arena, dY, X, ldx, x_net_stride, h1, h2, n_rows, ws, tag, *, adam=None,

@@ -1178,16 +1178,27 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
                                            dz2.data_ptr(), dz1.data_ptr(), parts.data_ptr(), st))
             ttot = engine.wgrad_tiles_total(a_arena)
             ss = ws.get(f"au.ss{i}", (ttot,))
-            engine.weight_grads(a_arena, s_rep, lds, 0, ah1, ah2, d_out, dz2, dz1, B, adam=adam,
-                                adam_key=("actor", i), sumsq=ss)
-            one = E_glob == 1
-            # (a recorded update of a single-member agent: this launch also writes the finished block to its slot of the log
+            one = E_glob == 1   # (then the logged actor is this one: both logs in one launch)
+            # (a recorded update of a single-member agent: the log step also writes the finished block to its slot of the log
             #  ring -- the replay names the slot, ssac_replay_value2 -- instead of a copy launch behind every replay)
             pub = _rec_ring if (one and _rec_ring is not None and _rec_blk is not None) else None
-            check(lib.ssac_actor_logs(parts.data_ptr(), tiles, B, inv_e, ss.data_ptr() if one else 0, ss.numel(),
-                                      slot[lu.L_ACTOR_LOSS:].data_ptr(), slot[lu.L_ACTOR_GN:].data_ptr() if one else 0,
-                                      slot.data_ptr(), lu.LOG_WIDTH, pub["buf"].data_ptr() if pub else 0,
-                                      pub["slot"] if pub else 0, st))
+            folded = False
+            if one and engine.actor_fold_applies(a_arena, None, ss, None, None, None):
+                # ... and the log step itself rides in the weight-gradient launch: its last workgroup to finish sums the
+                # tiles' loss terms and the gradient-norm partials (ssac_actor_logs' arithmetic), no launch of its own
+                done = ws.get(f"au.logdone{i}", (1,), dtype=torch.int32, zero=True)
+                af = _lib.ActorLogFold(done.data_ptr(), parts.data_ptr(), tiles, B, inv_e, lu.LOG_WIDTH,
+                                       slot[lu.L_ACTOR_LOSS:].data_ptr(), slot[lu.L_ACTOR_GN:].data_ptr(), slot.data_ptr(),
+                                       pub["buf"].data_ptr() if pub else 0, pub["slot"] if pub else 0)
+                folded = bool(engine.weight_grads(a_arena, s_rep, lds, 0, ah1, ah2, d_out, dz2, dz1, B, adam=adam,
+                                                  adam_key=("actor", i), sumsq=ss, actor_fold=af))
+            if not folded:
+                engine.weight_grads(a_arena, s_rep, lds, 0, ah1, ah2, d_out, dz2, dz1, B, adam=adam,
+                                    adam_key=("actor", i), sumsq=ss)
+                check(lib.ssac_actor_logs(parts.data_ptr(), tiles, B, inv_e, ss.data_ptr() if one else 0, ss.numel(),
+                                          slot[lu.L_ACTOR_LOSS:].data_ptr(), slot[lu.L_ACTOR_GN:].data_ptr() if one else 0,
+                                          slot.data_ptr(), lu.LOG_WIDTH, pub["buf"].data_ptr() if pub else 0,
+                                          pub["slot"] if pub else 0, st))
             if pub is not None:
                 pub["published"] = True
             member_ss.append(None if one else ss)
@@ -1256,16 +1267,27 @@ def _online_actor_update(buffer, agent, pop, actor_optimizer, log_alphas, batch_
             first_fused = False
             ttot = engine.wgrad_tiles_total(a_arena)
             ss = ws.get(f"au.ss{i}", (ttot,))
-            engine.weight_grads(a_arena, s_rep, lds, 0, ah1, ah2, d_out, dz2, dz1, B, adam=adam,
-                                adam_key=("actor", i), sumsq=ss)
             one = E_glob == 1   # (then the logged actor is this one: both logs in one launch)
-            # (a recorded update of a single-member agent: this launch also writes the finished block to its slot of the log
+            # (a recorded update of a single-member agent: the log step also writes the finished block to its slot of the log
             #  ring -- the replay names the slot, ssac_replay_value2 -- instead of a copy launch behind every replay)
             pub = _rec_ring if (one and _rec_ring is not None and _rec_blk is not None) else None
-            check(lib.ssac_actor_logs(parts.data_ptr(), tiles, B, inv_e, ss.data_ptr() if one else 0, ss.numel(),
-                                      slot[lu.L_ACTOR_LOSS:].data_ptr(), slot[lu.L_ACTOR_GN:].data_ptr() if one else 0,
-                                      slot.data_ptr(), lu.LOG_WIDTH, pub["buf"].data_ptr() if pub else 0,
-                                      pub["slot"] if pub else 0, st))
+            folded = False
+            if one and engine.actor_fold_applies(a_arena, None, ss, None, None, None):
+                # ... and the log step itself rides in the weight-gradient launch: its last workgroup to finish sums the
+                # tiles' loss terms and the gradient-norm partials (ssac_actor_logs' arithmetic), no launch of its own
+                done = ws.get(f"au.logdone{i}", (1,), dtype=torch.int32, zero=True)
+                af = _lib.ActorLogFold(done.data_ptr(), parts.data_ptr(), tiles, B, inv_e, lu.LOG_WIDTH,
+                                       slot[lu.L_ACTOR_LOSS:].data_ptr(), slot[lu.L_ACTOR_GN:].data_ptr(), slot.data_ptr(),
+                                       pub["buf"].data_ptr() if pub else 0, pub["slot"] if pub else 0)
+                folded = bool(engine.weight_grads(a_arena, s_rep, lds, 0, ah1, ah2, d_out, dz2, dz1, B, adam=adam,
+                                                  adam_key=("actor", i), sumsq=ss, actor_fold=af))
+            if not folded:
+                engine.weight_grads(a_arena, s_rep, lds, 0, ah1, ah2, d_out, dz2, dz1, B, adam=adam,
+                                    adam_key=("actor", i), sumsq=ss)
+                check(lib.ssac_actor_logs(parts.data_ptr(), tiles, B, inv_e, ss.data_ptr() if one else 0, ss.numel(),
+                                          slot[lu.L_ACTOR_LOSS:].data_ptr(), slot[lu.L_ACTOR_GN:].data_ptr() if one else 0,
+                                          slot.data_ptr(), lu.LOG_WIDTH, pub["buf"].data_ptr() if pub else 0,
+                                          pub["slot"] if pub else 0, st))
             if pub is not None:
                 pub["published"] = True
             member_ss.append(None if one else ss)

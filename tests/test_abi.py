@@ -140,7 +140,7 @@ def test_struct_sizes_match_the_c_side(tmp_path):
     pairs = {"ssac_mlp": _lib.MlpDesc, "ssac_adam_ctl": _lib.AdamCtl, "ssac_popart": _lib.PopArtState,
              "ssac_feed": _lib.Feed, "ssac_rng": _lib.Rng, "ssac_td_spec": _lib.TdSpec,
              "ssac_push_field": _lib.PushField, "ssac_logfold": _lib.LogFold,
-             "ssac_deferred_logs": _lib.DeferredLogs, "ssac_gather": _lib.Gather}
+             "ssac_deferred_logs": _lib.DeferredLogs, "ssac_gather": _lib.Gather, "ssac_actor_logfold": _lib.ActorLogFold}
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include "ssac_hip.h"\nint main(void) {\n' +
                    "".join(f'    printf("{n} %zu\\n", sizeof({n}));\n' for n in pairs) + "    return 0;\n}\n")

@@ -646,24 +646,38 @@ def acting_rows(device):
         ag.eval()
         return ag, obs
 
+    from super_sac_amd import acting
+
+    def timed(fn, o, n, calls=300):
+        for _ in range(30):
+            fn(o, num_envs=n)
+        ts = []
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            fn(o, num_envs=n)
+            ts.append(time.perf_counter() - t0)
+        return ts
+
     for kind in ("redq_M", "sunrise", "atari"):
         ag, obs = agent_of(kind)
         for n in (1, 16):
             o = obs(n)
             for fn_name in ("sample_action", "forward"):
-                fn = getattr(ag, fn_name)
-                for _ in range(30):
-                    fn(o, num_envs=n)
-                ts = []
-                for _ in range(300):
-                    t0 = time.perf_counter()
-                    fn(o, num_envs=n)
-                    ts.append(time.perf_counter() - t0)
+                ts = timed(getattr(ag, fn_name), o, n)
                 rows[f"{kind}.{fn_name}.envs{n}"] = {"us_per_call_median": round(statistics.median(ts) * 1e6, 1),
                                                      "us_per_call_p90": round(sorted(ts)[int(0.9 * len(ts))] * 1e6, 1)}
+        # the same agent through agent.py's general (eager) path -- what the one-call path replaces -- one row per agent
+        acting.ENABLED = False
+        try:
+            ts = timed(ag.sample_action, obs(1), 1, calls=150)
+        finally:
+            acting.ENABLED = True
+        rows[f"{kind}.sample_action.envs1"]["general_path_us_median"] = round(statistics.median(ts) * 1e6, 1)
         del ag
-    return {"what": "Agent.sample_action / Agent.forward, numpy observation in -> numpy action out (H2D + launches + D2H), "
-                    "wall clock per call, 300 calls after 30 warm-up calls", "rows": rows}
+    return {"what": "Agent.sample_action / Agent.forward, numpy observation in -> numpy action out, wall clock per call, 300 calls "
+                    "after 30 warm-up calls: ONE C call per step (super_sac_amd/acting.py: recorded launch list, observation over the "
+                    "BAR, action through pinned memory); general_path_us_median = agent.py's eager path on the same agent",
+            "rows": rows}
 
 
 def actor_update_rows(device):

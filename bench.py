@@ -215,7 +215,11 @@ def cpu_baseline(budget_s=15.0):
         if k % TARGET_DELAY == 0:
             orc.soft_update(ot.critic_params(), oa.critic_params(), TAU)
     ncpu = os.cpu_count() or 1
-    counts = sorted({c for c in (1, 8, 16, 32) if c <= ncpu} | {ncpu})
+    # thread counts: 1, 8, 16, 32 and every core -- but at most 64 threads: on the 256-core GPU boxes ONE update with every
+    # core takes ~40 s (hundreds of threads spinning around 100-microsecond operators: 0.02 updates/s, measured in rounds 5
+    # and 6, profiles/r6_raw/final/bench_steps20.json of the first lease), which alone blew the leg's 10 - 30 s bound
+    top = min(ncpu, 64)
+    counts = sorted({c for c in (1, 8, 16, 32) if c <= ncpu} | {top})
     rows = {}
     per = budget_s / len(counts)
     for th in counts:
@@ -235,8 +239,9 @@ def cpu_baseline(budget_s=15.0):
             "rows": {str(th): round(r[0] / r[1], 2) for th, r in rows.items()},
             "sample": f"{sum(r[0] for r in rows.values())} critic updates (+Polyak every 2nd) of the same workload in "
                       f"{sum(r[1] for r in rows.values()):.1f} s over thread counts {counts} "
-                      f"(host has {ncpu} logical cores), torch {torch.__version__} CPU; value = best row "
-                      f"({best} threads)"}
+                      f"(host has {ncpu} logical cores" + (f"; the all-cores row is capped at {top} threads: with {ncpu} threads "
+                      f"one update takes tens of seconds, oversubscription" if top < ncpu else "") +
+                      f"), torch {torch.__version__} CPU; value = best row ({best} threads)"}
 
 
 def sharded_value_check(step, ssa, device, shard, dist, n_updates=12, must_pass=True):

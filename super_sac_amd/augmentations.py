@@ -142,18 +142,26 @@ class AugmentationSequence:
         for aug in self.aug_list:
             aug.change_randomization_params()
 
+    def _augment_one(self, batch):
+        """one observation dict through every augmentation, key by key; keys outside `self.keys` pass through as copies"""
+        out = {}
+        for name, value in batch.items():
+            value = value.clone()
+            if name in self.keys:
+                for aug in self.aug_list:
+                    value = aug(value)
+            out[name] = value
+        return out
+
     def __call__(self, *batches):
-        if self.keys is None:
+        """augmentations.py:20-38 as a contract: ONE randomisation per call, shared by every batch passed (s and s' get the
+        same shift); the batches themselves are left untouched; one batch in -> one dict out, several -> a tuple."""
+        if self.keys is None:   # (first call: every key of the first batch, remembered -- as the reference does)
             self.keys = batches[0].keys()
         self.change_randomization_params()
-        results = []
-        for original in batches:
-            batch = {x: y.clone() for x, y in original.items()}
-            for key in self.keys:
-                for aug in self.aug_list:
-                    batch[key] = aug(batch[key])
-            results.append(batch)
-        return tuple(results) if len(results) > 1 else results[0]
+        augmented = tuple(self._augment_one(b) for b in batches)
+        return augmented[0] if len(augmented) == 1 else augmented
 
     def __repr__(self):
-        return f"AugmentationSequence: ({[repr(a) for a in self.aug_list]})"
+        names = [repr(a) for a in self.aug_list]
+        return f"AugmentationSequence: ({names})"

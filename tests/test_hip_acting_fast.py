@@ -112,6 +112,7 @@ def test_fast_ucb_picks_the_argmax_candidate_and_equals_the_general_path():
 def test_fast_discrete_rules():
     """greedy = arg-max of the mean probabilities; sample = inversion of the cumulative distribution with the Philox uniform
     of (row, draw): recomputed here in numpy, index for index, and checked against the softmax frequencies"""
+    torch.manual_seed(1234)   # (the acting stream's seed is drawn from torch's device generator: a fixed run)
     cfg, agent, oa = _pair("sac_discrete")
     A, n = cfg["act"], 16
     rs = np.random.RandomState(5)
@@ -138,7 +139,9 @@ def test_fast_discrete_rules():
         mismatches += int(np.sum(want != a[:, 0]))
         counts[np.arange(n), a[:, 0]] += 1
     assert mismatches <= 3, f"{mismatches} of {calls * n} draws differ from the numpy restatement (rounding at a boundary only)"
-    assert np.max(np.abs(counts / calls - probs)) < 0.09   # (400 draws per row: 4 sigma of a p = 0.5 frequency is 0.1)
+    # (400 draws per row: sigma of a p = 0.5 frequency is 0.025; the index-for-index check above is the sharp one, this one
+    #  only says the draws are not degenerate -- 6 sigma, so that 64 cells never trip it by chance)
+    assert np.max(np.abs(counts / calls - probs)) < 0.15
 
 
 def test_fast_path_reads_the_weights_of_the_moment_and_survives_a_reload(tmp_path):

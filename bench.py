@@ -569,6 +569,8 @@ def main():
             secondary["acting"] = acting_rows(device)
             # ---- the online actor update alone (UTD-1 configurations: it is ~60 % of an environment step's device time)
             secondary["actor_update"] = actor_update_rows(device)
+            # ---- a whole UTD-1 environment step (configs 1, 3, 4, 5 run UTD 1): acting + the three updates in sequence
+            secondary["utd1_env_step"] = utd1_rows(device)
             # ---- the N = 1 anchors of the scaling target's configurations (BASELINE.json: ">= 3.5x at 8 vs 1 GPU for N = 16";
             #      `bench.py --gpus 8 --critics 16 [--obs 376 --act 17]` measures the other end when an 8-GPU node runs it)
             secondary["scaling_anchors_n16_1gpu"] = n16_rows(device)
@@ -701,6 +703,37 @@ def actor_update_rows(device):
         rows[label] = {"batch": 512, "us_per_actor_update": round(t * 1e6, 2)}
         del st, actor, dicts
     return rows
+
+
+def utd1_rows(device):
+    """A UTD-1 environment step on the device path (BASELINE configs 1, 3, 4, 5 run UTD 1): Agent.sample_action on a numpy
+    observation, critic_update (+ Polyak / 2), online_actor_update, alpha_update -- strictly in sequence, as main.super_sac runs
+    them (the action of step t + 1 needs the actor of step t); wall clock per step"""
+    import numpy as np
+    import torch
+    rows = {}
+    for label, obs, act, ncrit, batch in (("sac_obs3_act1_N2_B256", 3, 1, 2, 256), ("M_obs17_act6_N10_B512", 17, 6, 10, 512)):
+        st, _, ssa = build_engine(device, ncrit, None, batch=batch, obs=obs, act=act, ncrit=ncrit)
+        ob = st.objects
+        agent, la, buf, actor = ob["agent"], ob["log_alpha"], ob["buffer"], ob["actor_step"]
+        lopt = torch.optim.Adam([la], lr=1e-4, betas=(0.5, 0.999))
+        aug = ssa.augmentations.AugmentationSequence([ssa.augmentations.IdentityAug(batch)])
+        o = {"obs": np.random.RandomState(0).standard_normal(obs).astype(np.float32)}
+
+        def one():
+            agent.sample_action(o)
+            dicts = st()
+            actor(dicts)
+            ssa.learning.alpha_update(buffer=buf, agent=agent, optimizers=[lopt], batch_size=batch, log_alphas=[la],
+                                      augmenter=aug, aug_mix=0.0, target_entropy=-float(act), premade_replay_dicts=dicts,
+                                      discrete=False)
+        for _ in range(40):
+            one()
+        t = statistics.median(timed_repeats(one, 300, 3, None, device)) / 300
+        rows[label] = {"us_per_env_step": round(t * 1e6, 1), "env_steps_per_s": round(1 / t, 0)}
+        del st, actor, one
+    return {"what": "UTD-1 environment step: sample_action (numpy in / out) + critic_update (+ Polyak / 2) + online_actor_update + "
+                    "alpha_update, in sequence", "rows": rows}
 
 
 def n16_rows(device):

@@ -1702,7 +1702,13 @@ def alpha_update(buffer, agent, optimizers, batch_size, log_alphas, augmenter, a
     lu.ensure_adopted(agent, buffer)
     dev = log_alphas[0].device
     ws = lu.agent_ws(agent, dev)
-    slot = lu.log_block(dev)
+    if engine.CAPTURE is None:
+        # this update's block of the log ring as it stands: ssac_alpha_update ASSIGNS its two entries per member and nothing
+        # else of the block is handed out, so no launch is spent on clearing it (one of the update's three launches, round 6)
+        ring = lu.ring_for(dev)
+        slot = ring.buf[ring.advance()]
+    else:
+        slot = lu.log_block(dev)
     logs = {}
     st = engine.stream()
     ms = parallel.member_shard_of(agent)   # member-sharded rank: log_alphas / optimizers are the LOCAL members'

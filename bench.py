@@ -36,6 +36,16 @@ import sys
 import time
 from itertools import chain
 
+# Host-side wait mode of the ROCm runtime, set BEFORE anything initialises it (torch is imported inside main()): with the
+# default (interrupt-driven signal waits) the thread that blocks in torch.cuda.synchronize() sleeps and is woken by an
+# interrupt -- the first update behind every synchronisation then costs 50 - 120 us of host time on a just-woken thread
+# (HISTORY.md, round 3: tools/first_step_py.py), i.e. 2 - 3 us per update of a 20-step region.  Polling waits
+# (HSA_ENABLE_INTERRUPT=0, a documented ROCr setting; INTEGRATION.md recommends it for training loops that synchronise every
+# environment step) remove the sleep: measured 17.98 k -> 18.45 k updates/s in the driver's form, nothing at 2000 steps.
+# `--interrupt-wait` (or the variable already set by the caller) keeps the runtime's default; the line says which it was.
+if "--interrupt-wait" not in sys.argv:
+    os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
     if p not in sys.path:
@@ -328,6 +338,8 @@ def launch_ranks(args):
             cmd.append("--no-cpu-baseline")
         if args.no_secondary:
             cmd.append("--no-secondary")
+        if args.interrupt_wait:
+            cmd.append("--interrupt-wait")
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     rc = procs[0].returncode
@@ -370,6 +382,8 @@ def main():
     ap.add_argument("--repeats", type=int, default=31,
                     help="timed regions of EXACTLY --steps steps each (every one listed in the line); the median is the value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--interrupt-wait", action="store_true",
+                    help="keep the ROCm runtime's interrupt-driven host waits (default here: polling, HSA_ENABLE_INTERRUPT=0)")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--critics", type=int, default=NCRIT, help="ensemble size N (16: the scaling target's configuration)")
     ap.add_argument("--obs", type=int, default=OBS, help="observation size (376: Humanoid, BASELINE config 5)")
@@ -544,6 +558,8 @@ def main():
                           "global_batch": BATCH, "num_critics": NCRIT,
                           "launch": "recorded launch list, one C call per update (ssac_step_run)"
                                     if graphs_were_on else "plain launches",
+                          "host_wait": ("polling (HSA_ENABLE_INTERRUPT=0)" if os.environ.get("HSA_ENABLE_INTERRUPT") == "0"
+                                        else "interrupt (ROCm default)"),
                           "parallelism": "single GPU" if world == 1 else
                                          f"critic-ensemble sharded x{world}" +
                                          (f" ({world} ranks sharing {ndev} device(s))" if shared_device else ""),

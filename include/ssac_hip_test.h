@@ -70,7 +70,9 @@ int ssac_bf16_debug_stamps(long long *dev_buf);
 int ssac_debug_timeline(long long *dev_buf);
 /* the one-shot exchange's protocol switches for the failing-first evidence (tests/test_hip_sharded.py): bit 0 makes this
  * rank's senders skip the slot-reuse wait, bit 1 makes its receivers accept flag >= seq -- 3 is the protocol of round 3,
- * whose owners-only form let senders lap a rank that owned no subset member. */
+ * whose owners-only form let senders lap a rank that owned no subset member; bit 2 makes the exchange that runs inside the
+ * chained launch treat its wait for the launch's target-critic workgroups as TIMED OUT (the failure path: nothing is sent,
+ * the result is NaN, the error word is raised). */
 int ssac_xchg_test_mode(ssac_xchg *x, int mode);
 #endif /* SSAC_LAB */
 

@@ -1738,6 +1738,8 @@ void fused_chain_pc_kernel(FusedArgs ga, FusedArgs gt, FusedArgs gc, int tiles_a
                 __builtin_amdgcn_s_sleep(2);
                 if (__builtin_amdgcn_s_memtime() - t0 > limit) { late = 1; break; }
             }
+            // (LAB build, ssac_xchg_test_mode bit 2: behave as if the wait had given up -- the failure path's test)
+            if (X_TEST_MODE(xa) & 4) late = 1;
             // a wait that gave up: the Qt in `data` is incomplete.  The exchange is told to FAIL (nothing sent, result poisoned,
             // error word raised, `dead` set -- xchg_body's !s_ok branch), and the counter is left alone: stragglers may still
             // bump it, and with `dead` set no later launch of this engine trusts it again

@@ -195,7 +195,7 @@ static int xchg_launch(ssac_xchg *x, float *data, int n, int op, const int32_t *
 //  a production exchange cannot be put back on round 3's unsafe protocol)
 #ifdef SSAC_LAB
 extern "C" int ssac_xchg_test_mode(ssac_xchg *x, int mode) {
-    if (!x || mode < 0 || mode > 3) return ssac_fail("ssac_xchg_test_mode: bad argument");
+    if (!x || mode < 0 || mode > 7) return ssac_fail("ssac_xchg_test_mode: bad argument");
     x->test_mode = mode;
     return 0;
 }

@@ -27,7 +27,8 @@ struct XchgArgs {
     int *dead;                  // device int: once a spin gave up, later exchanges fail at once instead of spinning again
     unsigned *arrive;           // device counter behind `dead`: the workgroups whose output the in-launch form of the exchange
                                 // waits for (fused_chain_pc_kernel's target-critic workgroups) bump it, the exchange zeroes it
-    int test_mode;              // LAB build only (ssac_xchg_test_mode): bit 0 = senders skip step 0, bit 1 = accept flag >= seq
+    int test_mode;              // LAB build only (ssac_xchg_test_mode): bit 0 = senders skip step 0, bit 1 = accept flag >= seq,
+                                // bit 2 = the in-launch form treats its wait for the launch's target-critic workgroups as timed out
     long long spin_limit;       // shader clocks a wait may take (X_SPIN_LIMIT; longer when the ranks time-slice ONE device)
     int n_parts, part_stride;   // > 1: element i of the payload is the SUM of n_parts partials (column-split target critics,
                                 // ssac_td_spec.n_parts): data[(slot n_parts + s) part_stride + b]; the reduction lands in

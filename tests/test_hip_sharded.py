@@ -529,3 +529,55 @@ def test_rccl_collective_path_single_rank(tmp_path):
     port = 31900 + (os.getpid() % 2000)
     mp.spawn(_rccl_main, args=(1, port, str(tmp_path)), nprocs=1, join=True)
     assert (tmp_path / "rccl_ok").exists()
+
+
+def _late_main(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    import json
+    import case_runner
+    import synth
+    import torch.distributed as dist
+    from super_sac_amd import parallel
+    from super_sac_amd._lib import lib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    x = parallel.enable_one_shot(torch.device("cuda:0"))
+    assert x is not None
+    verdict = {"lab_build": hasattr(lib, "ssac_xchg_test_mode")}
+    if verdict["lab_build"]:
+        assert lib.ssac_xchg_test_mode(x.handle, 4) == 0   # every in-launch exchange of this rank: "the arrival wait gave up"
+        cfg = synth.CASES["redq_small"]
+        shard = parallel.Shard(rank, world, cfg["N"])
+        raised, rec = None, None
+        try:
+            rec = case_runner.run_engine("redq_small", device="cuda:0", shard=shard)
+        except RuntimeError as e:   # (the update functions' periodic check of the error word)
+            raised = str(e)
+        torch.cuda.synchronize()
+        verdict["raised"] = raised
+        verdict["failed_flag"] = bool(parallel.exchange_failed()) or raised is not None
+        if rec is not None:
+            tds = [v for k, v in rec.items() if "_td" in k]
+            verdict["td_all_nan"] = bool(all(np.isnan(t).all() for t in tds)) if tds else None
+    json.dump(verdict, open(os.path.join(out_dir, f"late{rank}.json"), "w"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_an_arrival_wait_that_gives_up_fails_the_exchange_instead_of_sending_incomplete_q(tmp_path):
+    """Round-5 advisor (medium): when the tail workgroup's wait for the launch's target-critic workgroups timed out it only
+    zeroed the spin limit -- with the peers' flags and acknowledgements present it then SENT the incomplete Qt, reduced it and
+    raised nothing.  Now the wait's verdict goes into the exchange (xchg_body force_fail): nothing is sent, the result is NaN,
+    the error word is raised.  Forced here through the LAB build's ssac_xchg_test_mode bit 2 on both ranks (the product
+    library has no such switch: the assertions need `SSAC_LAB_BUILD=1`, tools/gpu_suite_lab.sh)."""
+    import json
+    port = 33500 + (os.getpid() % 2000)
+    _spawn(_late_main, (2, port, str(tmp_path)), 2, retries=0)
+    v = [json.load(open(tmp_path / f"late{r}.json")) for r in range(2)]
+    if not v[0]["lab_build"]:
+        pytest.skip("ssac_xchg_test_mode exists in the LAB build only (tools/gpu_suite_lab.sh runs this test)")
+    for r in range(2):
+        assert v[r]["failed_flag"], v[r]
+        assert v[r]["raised"] is not None or v[r]["td_all_nan"], v[r]

@@ -6,5 +6,5 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 O=${LAB_OUT:-gpurun_out/r6/lab}
 mkdir -p $O
-SSAC_LAB_BUILD=1 timeout 900 python -m pytest tests/test_hip_sharded.py -q -x -k "stalled_non_owner or sharded_sequence or one_shot" > $O/lab_suite.log 2>&1
+SSAC_LAB_BUILD=1 timeout 900 python -m pytest tests/test_hip_sharded.py -q -x -k "stalled_non_owner or sharded_sequence or one_shot or gives_up" > $O/lab_suite.log 2>&1
 tail -5 $O/lab_suite.log

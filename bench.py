@@ -644,7 +644,8 @@ def acting_rows(device):
     it: numpy observation in, numpy action out (one H2D, the launches, one D2H), wall-clock per call, median of 300 calls
     after 30 warm-up calls.  Shapes: the headline REDQ agent (obs 17 / act 6, one actor), a SUNRISE agent (5 members x 2
     critics, ucb_bonus 5: candidates of every actor, ensemble-Q of every member on the stacked candidates, mean + bonus * std,
-    arg-max) and the Atari agent (4 x 84 x 84 uint8 frames through the SmallPixelEncoder, categorical sample)."""
+    arg-max), the Atari agent (4 x 84 x 84 uint8 frames through the SmallPixelEncoder, categorical sample) and the DMC agent
+    (9 x 84 x 84 frames through the BigPixelEncoder, hidden-1024 deterministic actor)."""
     import numpy as np
     import torch
     import super_sac_amd as ssa
@@ -652,7 +653,13 @@ def acting_rows(device):
     rs = np.random.RandomState(0)
 
     def agent_of(kind):
-        if kind == "atari":
+        if kind == "dmc":   # BASELINE config 3: 9 x 84 x 84 frames, BigPixelEncoder, deterministic actor 50 -> 1024 -> 1024 -> 6
+            conv = ssa.nets.BigPixelEncoder((9, 84, 84), 50)
+            ag = ssa.Agent(act_space_size=6, encoder=ssa.nets.PixelEncoder(conv), actor_network_cls=ssa.nets.ContinuousDeterministicActor,
+                           critic_network_cls=ssa.nets.ContinuousCritic, discrete=False, ensemble_size=1, num_critics=2,
+                           hidden_size=1024, auto_rescale_targets=False)
+            obs = lambda n: {"obs": rs.randint(0, 256, (n, 9, 84, 84) if n > 1 else (9, 84, 84)).astype(np.uint8)}
+        elif kind == "atari":
             conv = ssa.nets.SmallPixelEncoder((4, 84, 84), 128)
             ag = ssa.Agent(act_space_size=4, encoder=ssa.nets.PixelEncoder(conv), actor_network_cls=ssa.nets.DiscreteActor,
                            critic_network_cls=ssa.nets.DiscreteCritic, discrete=True, ensemble_size=1, num_critics=2,
@@ -681,7 +688,7 @@ def acting_rows(device):
             ts.append(time.perf_counter() - t0)
         return ts
 
-    for kind in ("redq_M", "sunrise", "atari"):
+    for kind in ("redq_M", "sunrise", "atari", "dmc"):
         ag, obs = agent_of(kind)
         for n in (1, 16):
             o = obs(n)

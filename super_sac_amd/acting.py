@@ -127,19 +127,31 @@ def _eligible(agent, obs, num_envs, sample, rolling):
 
 
 def _arena_ok(agent, dev, with_critics):
-    for a in agent.actors:
-        if not engine.bind_arena(a, "self", [a], dev).fused:
-            return False
+    """every network the rule touches has a launchable forward: the fused MLP kernel, or -- networks outside its shapes, e.g.
+    DrQv2's hidden-1024 actor -- the per-layer GEMM family (three launches); the UCB rule's sampling kernels are fused-only"""
+    arenas = [engine.bind_arena(a, "self", [a], dev) for a in agent.actors]
     if with_critics:
-        for c in agent.critics:
-            if not c.arena(dev).fused:
-                return False
-    return True
+        return all(a.fused for a in arenas) and all(c.arena(dev).fused for c in agent.critics)
+    return all(a.fused for a in arenas) or lu.actor_kind(agent.actors[0]) != "stochastic"
+
+
+def _fwd_desc(plan, desc, n_nets, fused, hidden, out_dim, x_ptr, ldx, n_rows, y):
+    """y (n_nets x n_rows x out) = MLP(x) for every net of `desc` (shared input rows): one fused launch, or three per-layer
+    launches through plan-owned activations (mlps.py:123-129)"""
+    st = engine.stream()
+    if fused:
+        check(lib.ssac_mlp3_fwd_fused(C.byref(desc), 0, n_nets, x_ptr, ldx, 0, n_rows, 0, 0, y.data_ptr(), st))
+        return
+    h1, h2 = plan.buf(n_nets, n_rows, hidden), plan.buf(n_nets, n_rows, hidden)
+    check(lib.ssac_mlp_layer_fwd(C.byref(desc), 0, 0, n_nets, x_ptr, ldx, 0, n_rows, h1.data_ptr(), hidden, n_rows * hidden, 1, st))
+    check(lib.ssac_mlp_layer_fwd(C.byref(desc), 1, 0, n_nets, h1.data_ptr(), hidden, n_rows * hidden, n_rows, h2.data_ptr(), hidden,
+                                 n_rows * hidden, 1, st))
+    check(lib.ssac_mlp_layer_fwd(C.byref(desc), 2, 0, n_nets, h2.data_ptr(), hidden, n_rows * hidden, n_rows, y.data_ptr(), out_dim,
+                                 n_rows * out_dim, 0, st))
 
 
 def _fwd(plan, arena, x_ptr, ldx, n_rows, y):
-    check(lib.ssac_mlp3_fwd_fused(C.byref(arena.desc()), 0, arena.n_nets, x_ptr, ldx, 0, n_rows, 0, 0, y.data_ptr(),
-                                  engine.stream()))
+    _fwd_desc(plan, arena.desc(), arena.n_nets, arena.fused, arena.hidden, arena.out_dim, x_ptr, ldx, n_rows, y)
 
 
 class _Pack:
@@ -155,7 +167,7 @@ class _Pack:
         self.buf = plan.buf(self.n_nets * a0.stride)
         self.srcs = [a.params for a in arenas]
         self.desc = _lib.MlpDesc(self.buf.data_ptr(), a0.stride, self.n_nets, a0.in_dim, a0.hidden, a0.out_dim)
-        self.out_dim = a0.out_dim
+        self.out_dim, self.hidden, self.fused = a0.out_dim, a0.hidden, all(a.fused for a in arenas)
 
     def segments(self):
         off, out = 0, []
@@ -201,7 +213,7 @@ def _record(plan, agent, which):
                 packed_out = plan.buf(E, n, pa.out_dim)
                 plan.outs = [packed_out[e] for e in range(E)]
                 _pack_launch([pa])
-                check(lib.ssac_mlp3_fwd_fused(C.byref(pa.desc), 0, E, x_in, S, 0, n, 0, 0, packed_out.data_ptr(), st))
+                _fwd_desc(plan, pa.desc, E, pa.fused, pa.hidden, pa.out_dim, x_in, S, n, packed_out)
             else:
                 _fwd(plan, arenas[0], x_in, S, n, plan.outs[0])
             if plan.discrete:

@@ -189,6 +189,35 @@ def test_pixel_agents_take_the_one_call_path_and_equal_the_general_path():
             assert np.array_equal(greedy, want_greedy)
 
 
+def test_networks_outside_the_fused_shapes_take_the_per_layer_launches():
+    """DrQv2's actor is 50 -> 1024 -> 1024 -> A: outside the fused MLP kernel (hidden <= 256).  The plan then records the
+    per-layer GEMM launches (three per network); a deterministic actor's sample is its mean action.  Against the general path."""
+    import super_sac_amd as ssa
+    from super_sac_amd import acting
+    torch.manual_seed(5)
+    agent = ssa.Agent(act_space_size=4, encoder=ssa.nets.IdentityEncoder(50), actor_network_cls=ssa.nets.ContinuousDeterministicActor,
+                      critic_network_cls=ssa.nets.ContinuousCritic, discrete=False, ensemble_size=2, num_critics=2,
+                      hidden_size=288, auto_rescale_targets=False)
+    agent.to(torch.device(DEV))
+    assert not ssa.engine.bind_arena(agent.actors[0], "self", [agent.actors[0]], torch.device(DEV)).fused
+    rs = np.random.RandomState(4)
+    for n in (1, 7):
+        obs = rs.standard_normal((n, 50) if n > 1 else (50,)).astype(np.float32)
+        random.seed(3)
+        fast_s = agent.sample_action({"obs": obs}, num_envs=n)
+        fast_f = agent.forward({"obs": obs}, num_envs=n)
+        assert ("sample", n, 0.0) in acting._PLANS[agent] and ("forward", n, 0.0) in acting._PLANS[agent]
+        acting.ENABLED = False
+        try:
+            random.seed(3)
+            want_s = agent.sample_action({"obs": obs}, num_envs=n)
+            want_f = agent.forward({"obs": obs}, num_envs=n)
+        finally:
+            acting.ENABLED = True
+        np.testing.assert_allclose(fast_s, want_s, atol=3e-6)
+        np.testing.assert_allclose(fast_f, want_f, atol=3e-6)
+
+
 def test_ineligible_calls_take_the_general_path():
     from super_sac_amd import acting
     cfg, agent, _ = _pair("atari_pixels")

@@ -43,7 +43,9 @@ from itertools import chain
 # (HSA_ENABLE_INTERRUPT=0, a documented ROCr setting; INTEGRATION.md recommends it for training loops that synchronise every
 # environment step) remove the sleep: measured 17.98 k -> 18.45 k updates/s in the driver's form, nothing at 2000 steps.
 # `--interrupt-wait` (or the variable already set by the caller) keeps the runtime's default; the line says which it was.
-if "--interrupt-wait" not in sys.argv:
+# ONLY when this file is the program: a process that merely imports `bench` (the parity tests do, for build_engine) keeps
+# its environment -- the variable would leak into the ranks the sharded tests spawn on one shared device.
+if __name__ == "__main__" and "--interrupt-wait" not in sys.argv:
     os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -23,7 +23,8 @@ def _spawn(fn, args, nprocs, retries=1):
     suite in six on a loaded box) a wait sits out the whole spin bound and the exchange reports it as designed -- error
     word, NaN-poisoned result, RuntimeError("... did not arrive within the spin bound").  That outcome says something
     about the box's scheduler, not about the protocol (one rank per GPU -- the product layout -- has no time-slicing), so
-    THAT failure alone is retried once on a fresh rendezvous port; every other failure propagates at once.
+    THAT failure alone is retried (once; the stand-alone exchange test up to three times) on a fresh rendezvous port; every
+    other failure propagates at once.
     A retry is never silent and never sees the failed attempt's files: it is recorded in RETRIED + a warning (pytest's
     summary shows it), and the attempt's output directory (the str argument that is an existing directory) is emptied
     first, so ok*/rec* files of the failed attempt cannot satisfy the caller's assertions."""
@@ -38,7 +39,8 @@ def _spawn(fn, args, nprocs, retries=1):
         except Exception as e:   # noqa: BLE001  (torch.multiprocessing.spawn.ProcessRaisedException)
             if attempt == retries or "within the spin bound" not in str(e):
                 raise
-            msg = f"{fn.__name__}: exchange wait sat out the spin bound on the shared test GPU; retried once"
+            msg = (f"{fn.__name__}: exchange wait sat out the spin bound on the shared test GPU; retry {attempt + 1} "
+                   f"of {retries}")
             RETRIED.append((os.environ.get("PYTEST_CURRENT_TEST", "?"), msg))
             warnings.warn(msg)
             for d in dir_args:
@@ -165,11 +167,14 @@ def _xchg_main(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("world", [2, 3])
 def test_one_shot_exchange_ranks_on_one_device(tmp_path, world):
+    # (the STAND-ALONE exchange kernels of ranks that share the box's one GPU: the test most exposed to the device's
+    #  time-slicing of processes -- round 6 saw both parametrisations sit out the 60 s bound in one lease and none in the
+    #  next five.  Up to three loud retries; the in-launch form's tests keep a single one.)
     port = 29900 + (os.getpid() % 2000) + world
-    _spawn(_xchg_main, (world, port, str(tmp_path)), world)
+    _spawn(_xchg_main, (world, port, str(tmp_path)), world, retries=3)
     assert all((tmp_path / f"xok{r}").exists() for r in range(world))
 
 
